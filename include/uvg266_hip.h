@@ -1,0 +1,121 @@
+/*
+ * uvg266_hip.h -- C ABI of libuvg266hip.so, the MI355X (gfx950) "hip"
+ * strategy backend for uvg266's per-CTU block-processing hot path.
+ *
+ * Two layers are exported:
+ *
+ *  (1) Drop-in registrars, one per strategy group, with the reference's
+ *      registrar signature (src/strategies/generic/picture-generic.c:1445,
+ *      src/strategyselector.h:99):
+ *          int uvg_strategy_register_<group>_hip(void *opaque, uint8_t bitdepth);
+ *      Each calls the host's uvg_strategyselector_register(opaque, type,
+ *      "hip", 50, fptr) for every function of the group this backend
+ *      implements (priority 50 > avx2's 40, src/strategyselector.c:283-348).
+ *      The registered function pointers have exactly the reference typedefs
+ *      (src/strategies/strategies-*.h) and take HOST buffers: one call = one
+ *      upload + launch + download.  This is the parity path, not the
+ *      throughput path (hard part 1).
+ *
+ *  (2) A batched ABI over planes that are already resident in HBM
+ *      (uvghip_* below).  Every pointer argument is a DEVICE pointer unless
+ *      its name ends in _host; `stream` is a hipStream_t passed as void*
+ *      (NULL = the default stream).  Calls enqueue work and return without
+ *      synchronising.  Return value: 0 on success, otherwise a hipError_t
+ *      value (uvghip_last_error() gives text).  `bitdepth` selects the pixel
+ *      type the reference fixes at compile time (src/uvg266.h:89-99):
+ *      8 -> uint8_t planes, 10 -> uint16_t planes.
+ *
+ * No type from PyTorch, HIP or the reference appears in any signature.
+ */
+#ifndef UVG266_HIP_H_
+#define UVG266_HIP_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* exported symbol marker (the library is built with -fvisibility=hidden) */
+#define UVGHIP_API __attribute__((visibility("default")))
+
+#define UVGHIP_STRATEGY_NAME     "hip"
+#define UVGHIP_STRATEGY_PRIORITY 50
+
+/* ------------------------------------------------------------------ core */
+
+/* Select the device and create the per-process context.  Returns 0 or a
+ * hipError_t.  Must succeed before any other call; there is NO CPU fallback:
+ * without a usable gfx950 device every entry point fails. */
+UVGHIP_API int uvghip_init(int device);
+/* Text for the last failing call on this thread ("" if none). */
+UVGHIP_API const char *uvghip_last_error(void);
+/* ABI version of this header (bumped on any signature change). */
+UVGHIP_API int uvghip_abi_version(void);
+
+/* ---------------------------------------------- (1) drop-in registrars -- */
+/* replaces: the line a maintainer adds after
+ *   src/strategies/strategies-picture.c:106-108 (avx2 registration), etc.
+ * The host's uvg_strategyselector_register symbol is resolved at load time;
+ * when the library is loaded stand-alone (tests), uvghip_set_register_fn()
+ * must supply it. */
+typedef int (*uvghip_register_fn)(void *opaque, const char *type, const char *strategy_name,
+                                  int priority, void *fptr);
+UVGHIP_API void uvghip_set_register_fn(uvghip_register_fn fn);
+
+UVGHIP_API int uvg_strategy_register_picture_hip(void *opaque, uint8_t bitdepth); /* strategies-picture.h:160-232 */
+
+/* -------------------------------------------- (2) batched ABI: picture -- */
+
+/* One block pair: top-left of the block in the current plane and in the
+ * reference plane (integer pel).  The reference position may lie partly or
+ * wholly outside the reference frame; samples are then edge-replicated,
+ * which is what uvg_image_calc_sad / uvg_image_calc_satd compute
+ * (src/image.c:310-428,438-473,482-557). */
+typedef struct uvghip_blk {
+  int32_t cur_x, cur_y;
+  int32_t ref_x, ref_y;
+} uvghip_blk_t;
+
+/* replaces: uvg_image_calc_sad -> uvg_reg_sad / uvg_hor_sad / uvg_ver_sad
+ * (src/image.c:438; src/strategies/generic/picture-generic.c:99,1266,1308).
+ * out[i] = SAD(block i) >> (bitdepth-8).  bw,bh: multiples of 4, 4..64 (any
+ * w,h >= 1 accepted).  ref_w/ref_h: visible size of the reference frame. */
+UVGHIP_API int uvghip_sad_batch(int bitdepth, const void *cur, int cur_stride, const void *ref, int ref_stride,
+                     int ref_w, int ref_h, int bw, int bh,
+                     const uvghip_blk_t *blks, int n, uint32_t *out, void *stream);
+
+/* replaces: uvg_image_calc_satd -> uvg_satd_any_size
+ * (src/image.c:482; src/strategies/strategies-picture.h:76-109).  Tiling
+ * rule: first 4 columns by 4x4 tiles if bw%8, first 4 rows by 4x4 if bh%8,
+ * the rest by 8x8; out[i] = sum >> (bitdepth-8). */
+UVGHIP_API int uvghip_satd_batch(int bitdepth, const void *cur, int cur_stride, const void *ref, int ref_stride,
+                      int ref_w, int ref_h, int bw, int bh,
+                      const uvghip_blk_t *blks, int n, uint32_t *out, void *stream);
+
+/* replaces: uvg_pixels_calc_ssd (picture-generic.c:1115); out[i] = SSD >> 2*(bitdepth-8).
+ * No clamping: both blocks must be inside their planes. */
+UVGHIP_API int uvghip_ssd_batch(int bitdepth, const void *a, int a_stride, const void *b, int b_stride,
+                     int bw, int bh, const uvghip_blk_t *blks, int n, uint32_t *out, void *stream);
+
+/* Full-search SAD surface for integer motion estimation: for every bw x bh
+ * block of the grid covering the frame (blocks_x = cur_w/bw, blocks_y =
+ * cur_h/bh, row-major) and every displacement (dx,dy) in [-range,range]^2,
+ *   out[(blk*(2r+1) + (dy+r))*(2r+1) + (dx+r)] = uvg_image_calc_sad(cur, ref,
+ *        bx, by, bx+dx, by+dy, bw, bh)
+ * i.e. the value check_mv_cost (src/search_inter.c:204) obtains per
+ * candidate, for all candidates at once.  The search window of each block is
+ * staged once in LDS. */
+UVGHIP_API int uvghip_sad_surface(int bitdepth, const void *cur, int cur_stride, const void *ref, int ref_stride,
+                       int w, int h, int bw, int bh, int range, uint32_t *out, void *stream);
+
+/* replaces: uvg_generate_residual (picture-generic.c:1360) over whole planes:
+ * res[y*res_stride+x] = (int16)(a - b). */
+UVGHIP_API int uvghip_residual_plane(int bitdepth, const void *a, int a_stride, const void *b, int b_stride,
+                          int16_t *res, int res_stride, int w, int h, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UVG266_HIP_H_ */

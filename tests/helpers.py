@@ -1,0 +1,161 @@
+"""Test-side helpers: oracle loader (ctypes), golden-file reader, KAT patterns."""
+import ctypes
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+_ORC = None
+
+c_int, c_uint, c_vp = ctypes.c_int, ctypes.c_uint, ctypes.c_void_p
+
+
+def px_dtype(depth):
+    return np.uint8 if depth == 8 else np.uint16
+
+
+def load_oracle():
+    """dlopen oracle/liborc.so (built by `make -C oracle`; rebuilt here if stale or absent)."""
+    global _ORC
+    if _ORC is None:
+        path = os.path.join(ROOT, "oracle", "liborc.so")
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+        _ORC = Oracle(ctypes.CDLL(path))
+    return _ORC
+
+
+def ptr(a):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_vp)
+
+
+class Oracle:
+    """Typed access to orc8_* / orc10_* (oracle/*.c)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def fn(self, depth, name, restype=c_int):
+        f = getattr(self.lib, f"orc{depth}_{name}")
+        f.restype = restype
+
+        def call(*args):
+            return f(*[int(a) if isinstance(a, np.integer) else a for a in args])
+        return call
+
+    # ---- picture ---------------------------------------------------------
+    def reg_sad(self, d, a, b, w, h, sa, sb):
+        return self.fn(d, "reg_sad", c_uint)(ptr(a), ptr(b), w, h, c_uint(sa), c_uint(sb))
+
+    def image_calc_sad(self, d, pic, ref, ref_w, ref_h, px, py, rx, ry, bw, bh):
+        return self.fn(d, "image_calc_sad", c_uint)(ptr(pic), pic.shape[1], ptr(ref), ref.shape[1],
+                                                     ref_w, ref_h, px, py, rx, ry, bw, bh)
+
+    def sad_nxn(self, d, a, b, n):
+        return self.fn(d, "sad_nxn", c_uint)(ptr(a), ptr(b), n)
+
+    def satd_nxn(self, d, a, b, n):
+        return self.fn(d, "satd_nxn", c_uint)(ptr(a), ptr(b), n)
+
+    def sad_nxn_dual(self, d, preds, orig, n):
+        out = np.zeros(2, np.uint32)
+        self.fn(d, "sad_nxn_dual", None)(ptr(preds), ptr(orig), n, ptr(out))
+        return out
+
+    def satd_nxn_dual(self, d, preds, orig, n):
+        out = np.zeros(2, np.uint32)
+        self.fn(d, "satd_nxn_dual", None)(ptr(preds), ptr(orig), n, ptr(out))
+        return out
+
+    def satd_any_size(self, d, w, h, a, sa, b, sb, a_off=0, b_off=0):
+        es = a.itemsize
+        return self.fn(d, "satd_any_size", c_uint)(w, h, c_vp(a.ctypes.data + int(a_off) * es), sa,
+                                                   c_vp(b.ctypes.data + int(b_off) * es), sb)
+
+    def satd_any_size_quad(self, d, w, h, base, offs, ps, orig, os_):
+        arr = (c_vp * 4)(*[c_vp(base.ctypes.data + int(o) * base.itemsize) for o in offs])
+        out = np.zeros(4, np.uint32)
+        self.fn(d, "satd_any_size_quad", None)(w, h, arr, ps, ptr(orig), os_, ptr(out))
+        return out
+
+    def pixels_calc_ssd(self, d, a, b, sa, sb, w, h):
+        return self.fn(d, "pixels_calc_ssd", c_uint)(ptr(a), ptr(b), sa, sb, w, h)
+
+    def generate_residual(self, d, a, b, w, h, sa, sb):
+        res = np.zeros(w * h, np.int16)
+        self.fn(d, "generate_residual", None)(ptr(a), ptr(b), ptr(res), w, h, sa, sb)
+        return res
+
+
+# ---- golden container (written by tools/refcheck/refcheck.c) ----------------
+_DT = {0: np.uint8, 1: np.uint16, 2: np.int16, 3: np.int32, 4: np.uint32, 5: np.int64, 6: np.float64}
+
+
+def read_golden(group, depth):
+    """-> list of (name, [arrays]) records of tests/golden/ref_<group>_<depth>.bin"""
+    path = os.path.join(GOLDEN, f"ref_{group}_{depth}.bin")
+    recs = []
+    with open(path, "rb") as f:
+        data = f.read()
+    pos = 0
+    while pos < len(data):
+        magic, nl = struct.unpack_from("<II", data, pos); pos += 8
+        assert magic == 0x52454631, "corrupt golden file"
+        name = data[pos:pos + nl].decode(); pos += nl
+        (na,) = struct.unpack_from("<I", data, pos); pos += 4
+        arrs = []
+        for _ in range(na):
+            code, n = struct.unpack_from("<II", data, pos); pos += 8
+            dt = np.dtype(_DT[code])
+            arrs.append(np.frombuffer(data, dt, n, pos).copy()); pos += n * dt.itemsize
+        recs.append((name, arrs))
+    return recs
+
+
+# ---- the reference's own KAT inputs (tests/satd_tests.c:60-106, tests/sad_tests.c:51-71) ----
+def satd_kat_buffers(test, log_w):
+    size = 1 << (2 * log_w)
+    i = np.arange(size)
+    if test == 0:      # black / white
+        return np.zeros(size, np.uint8), np.full(size, 255, np.uint8)
+    if test == 1:      # checkers: buf2 = (buf1 + 1) % 2
+        b1 = (255 * ((((i >> log_w) % 2) + (i % 2)) % 2)).astype(np.uint8)
+        b2 = ((b1.astype(np.int32) + 1) % 2).astype(np.uint8)
+        return b1, b2
+    col, row = i % (1 << log_w), i // (1 << log_w)
+    r = np.floor(np.sqrt((row * row + col * col).astype(np.float64))).astype(np.int64)
+    b1 = (255 // (r + 1)).astype(np.uint8)
+    return b1, (255 - 255 // (r + 1)).astype(np.uint8)
+
+
+SATD_KAT = {0: [510, 1020, 4080, 16320, 65280],       # tests/satd_tests.c:122
+            1: [1278, 2556, 10224, 40896, 163584],     # tests/satd_tests.c:140
+            2: [2728, 7158, 10775, 23399, 72780]}      # tests/satd_tests.c:159
+
+SAD_REF_8x8 = np.array([1, 2, 2, 2, 2, 2, 2, 3] + [4, 5, 5, 5, 5, 5, 5, 6] * 6 + [7, 8, 8, 8, 8, 8, 8, 9],
+                       np.uint8).reshape(8, 8) + 48     # tests/sad_tests.c:51-60,91-98
+SAD_PIC_8x8 = np.full((8, 8), 1 + 48, np.uint8)         # tests/sad_tests.c:62-71,84-89
+# (ref_x, ref_y) -> expected, tests/sad_tests.c:144-285
+SAD_BORDER_KAT = [
+    ((-3, -3), 1 * 16 + (2 + 4) * 16 + 5 * 16 - 64), ((0, -3), (1 + 3) * 4 + 2 * 24 + (4 + 6) * 4 + 5 * 24 - 64),
+    ((3, -3), 3 * 16 + (2 + 6) * 16 + 5 * 16 - 64), ((-3, 0), (1 + 7) * 4 + 4 * 24 + (2 + 8) * 4 + 5 * 24 - 64),
+    ((0, 0), (1 + 3 + 7 + 9) + (2 + 4 + 6 + 8) * 6 + 5 * 36 - 64), ((3, 0), (3 + 9) * 4 + 6 * 24 + (2 + 8) * 4 + 5 * 24 - 64),
+    ((-3, 3), 7 * 16 + (4 + 8) * 16 + 5 * 16 - 64), ((0, 3), (7 + 9) * 4 + 8 * 24 + (4 + 6) * 4 + 5 * 24 - 64),
+    ((3, 3), 9 * 16 + (6 + 8) * 16 + 5 * 16 - 64),
+    ((-10, -10), 1 * 64 - 64), ((0, -10), (1 + 3) * 8 + 2 * 48 - 64), ((10, -10), 3 * 64 - 64),
+    ((-10, 0), (1 + 7) * 8 + 4 * 48 - 64), ((10, 0), (3 + 9) * 8 + 6 * 48 - 64),
+    ((-10, 10), 7 * 64 - 64), ((0, 10), (7 + 9) * 8 + 8 * 48 - 64), ((10, 10), 9 * 64 - 64),
+]
+# tests/sad_tests.c:392-399
+SAD_DIMS = [(64, 64), (32, 32), (16, 16), (8, 8), (64, 32), (32, 64), (32, 16), (16, 32), (16, 8), (8, 16),
+            (8, 4), (4, 8), (48, 16), (16, 48), (24, 16), (16, 24), (12, 4), (4, 12)]
+
+
+def sad_big_planes():
+    """tests/sad_tests.c:100-118: 64x64 g_big_pic / g_big_ref"""
+    i = np.arange(64 * 64, dtype=np.int64)
+    return (((i * i // 32 + i) % 255).astype(np.uint8).reshape(64, 64),
+            ((i * i // 16 + i) % 255).astype(np.uint8).reshape(64, 64))

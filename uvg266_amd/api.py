@@ -1,0 +1,89 @@
+"""Thin torch-tensor front end over the batched C ABI (include/uvg266_hip.h).
+
+Every function takes CUDA(HIP) tensors that are already resident in HBM,
+enqueues the kernel on torch's current stream and returns device tensors.
+Planes are 2-D tensors (rows x stride) of dtype uint8 (8-bit) or uint16/int16
+(10-bit); `width` is the visible width when the stride is larger.
+"""
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+
+def _depth(t):
+    if t.dtype == torch.uint8:
+        return 8
+    if t.dtype in (torch.uint16, torch.int16):
+        return 10
+    raise TypeError(f"plane dtype {t.dtype} is not a uvg_pixel type")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t):
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return t.data_ptr()
+
+
+def make_blocks(cur_xy, ref_xy, device="cuda"):
+    """(n,2) cur positions and (n,2) ref positions -> device array of uvghip_blk_t."""
+    a = np.concatenate([np.asarray(cur_xy, np.int32).reshape(-1, 2),
+                        np.asarray(ref_xy, np.int32).reshape(-1, 2)], axis=1)
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def _batch(fn_name, cur, ref, bw, bh, blks, ref_w=None, ref_h=None):
+    L = _lib.init(cur.device.index or 0)
+    n = blks.shape[0]
+    out = torch.empty(n, dtype=torch.int32, device=cur.device)
+    ref_w = ref.shape[1] if ref_w is None else ref_w
+    ref_h = ref.shape[0] if ref_h is None else ref_h
+    rc = getattr(L, fn_name)(_depth(cur), _dev(cur), cur.stride(0), _dev(ref), ref.stride(0),
+                             ref_w, ref_h, bw, bh, _dev(blks), n, _dev(out), _stream())
+    _lib.check(rc, fn_name)
+    return out
+
+
+def sad_batch(cur, ref, bw, bh, blks, ref_w=None, ref_h=None):
+    """uvg_image_calc_sad for n same-size blocks (edge-replicated reference)."""
+    return _batch("uvghip_sad_batch", cur, ref, bw, bh, blks, ref_w, ref_h)
+
+
+def satd_batch(cur, ref, bw, bh, blks, ref_w=None, ref_h=None):
+    """uvg_image_calc_satd / uvg_satd_any_size for n same-size blocks."""
+    return _batch("uvghip_satd_batch", cur, ref, bw, bh, blks, ref_w, ref_h)
+
+
+def ssd_batch(a, b, bw, bh, blks):
+    L = _lib.init(a.device.index or 0)
+    n = blks.shape[0]
+    out = torch.empty(n, dtype=torch.int32, device=a.device)
+    rc = L.uvghip_ssd_batch(_depth(a), _dev(a), a.stride(0), _dev(b), b.stride(0), bw, bh,
+                            _dev(blks), n, _dev(out), _stream())
+    _lib.check(rc, "uvghip_ssd_batch")
+    return out
+
+
+def sad_surface(cur, ref, w, h, bw, bh, rng):
+    L = _lib.init(cur.device.index or 0)
+    nblk = (w // bw) * (h // bh)
+    side = 2 * rng + 1
+    out = torch.empty((nblk, side, side), dtype=torch.int32, device=cur.device)
+    rc = L.uvghip_sad_surface(_depth(cur), _dev(cur), cur.stride(0), _dev(ref), ref.stride(0),
+                              w, h, bw, bh, rng, _dev(out), _stream())
+    _lib.check(rc, "uvghip_sad_surface")
+    return out
+
+
+def residual_plane(a, b, w=None, h=None):
+    L = _lib.init(a.device.index or 0)
+    h = a.shape[0] if h is None else h
+    w = a.shape[1] if w is None else w
+    res = torch.empty((h, w), dtype=torch.int16, device=a.device)
+    rc = L.uvghip_residual_plane(_depth(a), _dev(a), a.stride(0), _dev(b), b.stride(0),
+                                 _dev(res), res.stride(0), w, h, _stream())
+    _lib.check(rc, "uvghip_residual_plane")
+    return res

@@ -1,0 +1,77 @@
+"""ctypes loader for libuvg266hip.so (built in-tree by uvg266_amd/csrc/Makefile)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuvg266hip.so")
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+class DeviceMissing(RuntimeError):
+    pass
+
+
+class Blk(ctypes.Structure):
+    """uvghip_blk_t (include/uvg266_hip.h)."""
+    _fields_ = [("cur_x", ctypes.c_int32), ("cur_y", ctypes.c_int32),
+                ("ref_x", ctypes.c_int32), ("ref_y", ctypes.c_int32)]
+
+
+_lib = None
+_inited_device = None
+
+c_int, c_vp, c_u32p = ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p
+
+# name -> (restype, argtypes).  Must list every symbol include/uvg266_hip.h declares
+# (tests/test_abi.py checks the header against this table and against the .so).
+SIGNATURES = {
+    "uvghip_init": (c_int, [c_int]),
+    "uvghip_last_error": (ctypes.c_char_p, []),
+    "uvghip_abi_version": (c_int, []),
+    "uvghip_set_register_fn": (None, [c_vp]),
+    "uvg_strategy_register_picture_hip": (c_int, [c_vp, ctypes.c_uint8]),
+    "uvghip_sad_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_satd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_ssd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_sad_surface": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "uvghip_residual_plane": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp]),
+}
+
+
+def load_library():
+    """dlopen the in-tree library and declare every signature.  No device needed."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback)")
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def init(device=0):
+    """uvghip_init on `device`; raises DeviceMissing when there is no gfx950 GPU."""
+    global _inited_device
+    lib = load_library()
+    if _inited_device == device:
+        return lib
+    rc = lib.uvghip_init(device)
+    if rc != 0:
+        raise DeviceMissing(f"uvghip_init({device}) failed: {lib.uvghip_last_error().decode()}")
+    _inited_device = device
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {load_library().uvghip_last_error().decode()}")
