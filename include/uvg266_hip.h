@@ -65,6 +65,7 @@ typedef int (*uvghip_register_fn)(void *opaque, const char *type, const char *st
 UVGHIP_API void uvghip_set_register_fn(uvghip_register_fn fn);
 
 UVGHIP_API int uvg_strategy_register_picture_hip(void *opaque, uint8_t bitdepth); /* strategies-picture.h:160-232 */
+UVGHIP_API int uvg_strategy_register_dct_hip(void *opaque, uint8_t bitdepth);     /* strategies-dct.h:77-110   */
 
 /* -------------------------------------------- (2) batched ABI: picture -- */
 
@@ -114,6 +115,32 @@ UVGHIP_API int uvghip_sad_surface(int bitdepth, const void *cur, int cur_stride,
  * res[y*res_stride+x] = (int16)(a - b). */
 UVGHIP_API int uvghip_residual_plane(int bitdepth, const void *a, int a_stride, const void *b, int b_stride,
                           int16_t *res, int res_stride, int w, int h, void *stream);
+
+/* ------------------------------------------ (2) batched ABI: transforms -- */
+
+/* transform kernel types, values of tr_type_t (src/uvg266.h:235-237) */
+#define UVGHIP_TR_DCT2 0
+#define UVGHIP_TR_DCT8 1
+#define UVGHIP_TR_DST7 2
+
+/* replaces: uvg_dct_NxN / uvg_idct_NxN / uvg_mts_dct / uvg_mts_idct
+ * (src/strategies/generic/dct-generic.c:720-750,2560-2678) for n blocks of
+ * one shape.  in/out: n contiguous blocks of width*height int16 (row-major,
+ * stride = width), exactly the coeff_t buffers the reference passes.
+ * width,height in {4,8,16,32}; type_*: UVGHIP_TR_*; skip_width/skip_height:
+ * the reference's zero-out counts (0 for plain DCT-2; use uvghip_mts_select).
+ * Forward truncates to int16, inverse clips, as the reference does. */
+UVGHIP_API int uvghip_transform_batch(int bitdepth, int inverse, int type_hor, int type_ver, int width, int height,
+                           int skip_width, int skip_height, const int16_t *in, int16_t *out, int n,
+                           void *stream);
+
+/* Host helper, no device work: uvg_get_tr_type (dct-generic.c:2501-2557) and
+ * the skip rules of mts_dct_generic (:2582-2600) on plain arguments.
+ * color: 0 luma / 1,2 chroma; cu_type: cu_type_t value (1 intra, 2 inter);
+ * mts_type: enum uvg_mts (src/uvg266.h:225-229). */
+UVGHIP_API int uvghip_mts_select(int width, int height, int color, int cu_type, int isp_mode, int lfnst_idx,
+                      int cr_lfnst_idx, int tr_idx, int mts_type, int *type_hor, int *type_ver,
+                      int *skip_width, int *skip_height);
 
 #ifdef __cplusplus
 }

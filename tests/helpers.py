@@ -90,6 +90,32 @@ class Oracle:
         return res
 
 
+    # ---- dct ---------------------------------------------------------------
+    def dct_nxn(self, d, bitdepth, n, block, inverse=False):
+        out = np.zeros(n * n, np.int16)
+        self.fn(d, "idct_nxn" if inverse else "dct_nxn", None)(bitdepth, n, ptr(block), ptr(out))
+        return out
+
+    def tr(self, d, bitdepth, inverse, hor, ver, w, h, sw, sh, block):
+        out = np.zeros(w * h, np.int16)
+        self.fn(d, "tr_inverse" if inverse else "tr_forward", None)(bitdepth, hor, ver, w, h, sw, sh, ptr(block), ptr(out))
+        return out
+
+    def mts_dct(self, d, bitdepth, color, cu_intra, cu_inter, isp, lfnst, cr_lfnst, tr_idx, w, h, block, mts_type, inverse):
+        out = np.zeros(w * h, np.int16)
+        self.fn(d, "mts_dct", None)(bitdepth, color, cu_intra, cu_inter, isp, lfnst, cr_lfnst, tr_idx, w, h,
+                                    ptr(block), ptr(out), mts_type, int(inverse))
+        return out
+
+    def mts_select(self, d, w, h, color, cu_intra, cu_inter, isp, lfnst, cr_lfnst, tr_idx, mts_type):
+        hor, ver, sw, sh = (ctypes.c_int() for _ in range(4))
+        self.fn(d, "get_tr_type", None)(w, h, color, cu_intra, cu_inter, isp, lfnst, cr_lfnst, tr_idx, mts_type,
+                                        ctypes.byref(hor), ctypes.byref(ver))
+        lf = (lfnst and color == 0) or (cr_lfnst and color != 0)
+        self.fn(d, "mts_skips", None)(w, h, hor.value, ver.value, int(bool(lf)), ctypes.byref(sw), ctypes.byref(sh))
+        return hor.value, ver.value, sw.value, sh.value
+
+
 # ---- golden container (written by tools/refcheck/refcheck.c) ----------------
 _DT = {0: np.uint8, 1: np.uint16, 2: np.int16, 3: np.int32, 4: np.uint32, 5: np.int64, 6: np.float64}
 
@@ -159,3 +185,11 @@ def sad_big_planes():
     i = np.arange(64 * 64, dtype=np.int64)
     return (((i * i // 32 + i) % 255).astype(np.uint8).reshape(64, 64),
             ((i * i // 16 + i) % 255).astype(np.uint8).reshape(64, 64))
+
+
+def dct_test_gradient(width=64):
+    """tests/dct_tests.c:68-78,88-91: init_gradient(width, width, width, 255/width, buf)"""
+    y, x = np.mgrid[0:width, 0:width]
+    slope = 255 // width
+    val = (slope * np.sqrt(((width - x) ** 2 + (width - y) ** 2).astype(np.float64)) + 0.5).astype(np.int64)
+    return np.clip(val, 0, 255).astype(np.int16)

@@ -87,3 +87,29 @@ def residual_plane(a, b, w=None, h=None):
                                  _dev(res), res.stride(0), w, h, _stream())
     _lib.check(rc, "uvghip_residual_plane")
     return res
+
+
+# ---- transforms ------------------------------------------------------------
+TR_DCT2, TR_DCT8, TR_DST7 = 0, 1, 2
+
+
+def mts_select(width, height, color=0, cu_type=1, isp_mode=0, lfnst_idx=0, cr_lfnst_idx=0, tr_idx=0, mts_type=0):
+    """-> (type_hor, type_ver, skip_width, skip_height) per uvg_get_tr_type + mts skip rules."""
+    import ctypes
+    L = _lib.load_library()
+    o = [ctypes.c_int() for _ in range(4)]
+    L.uvghip_mts_select(width, height, color, cu_type, isp_mode, lfnst_idx, cr_lfnst_idx, tr_idx, mts_type,
+                        *[ctypes.byref(v) for v in o])
+    return tuple(v.value for v in o)
+
+
+def transform_batch(blocks, bitdepth, inverse=False, type_hor=TR_DCT2, type_ver=TR_DCT2, skip_w=0, skip_h=0):
+    """blocks: (n, h, w) int16 device tensor -> (n, h, w) int16 coefficients / residuals."""
+    L = _lib.init(blocks.device.index or 0)
+    assert blocks.dtype == torch.int16
+    n, h, w = blocks.shape
+    out = torch.empty_like(blocks)
+    rc = L.uvghip_transform_batch(bitdepth, int(inverse), type_hor, type_ver, w, h, skip_w, skip_h,
+                                  _dev(blocks), _dev(out), n, _stream())
+    _lib.check(rc, "uvghip_transform_batch")
+    return out

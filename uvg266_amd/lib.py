@@ -33,6 +33,9 @@ SIGNATURES = {
     "uvghip_abi_version": (c_int, []),
     "uvghip_set_register_fn": (None, [c_vp]),
     "uvg_strategy_register_picture_hip": (c_int, [c_vp, ctypes.c_uint8]),
+    "uvg_strategy_register_dct_hip": (c_int, [c_vp, ctypes.c_uint8]),
+    "uvghip_transform_batch": (c_int, [c_int] * 8 + [c_vp, c_vp, c_int, c_vp]),
+    "uvghip_mts_select": (c_int, [c_int] * 9 + [c_vp] * 4),
     "uvghip_sad_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_satd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_ssd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
