@@ -66,6 +66,7 @@ UVGHIP_API void uvghip_set_register_fn(uvghip_register_fn fn);
 
 UVGHIP_API int uvg_strategy_register_picture_hip(void *opaque, uint8_t bitdepth); /* strategies-picture.h:160-232 */
 UVGHIP_API int uvg_strategy_register_dct_hip(void *opaque, uint8_t bitdepth);     /* strategies-dct.h:77-110   */
+UVGHIP_API int uvg_strategy_register_quant_hip(void *opaque, uint8_t bitdepth);   /* strategies-quant.h:93-111 (state-free functions only) */
 
 /* -------------------------------------------- (2) batched ABI: picture -- */
 
@@ -141,6 +142,46 @@ UVGHIP_API int uvghip_transform_batch(int bitdepth, int inverse, int type_hor, i
 UVGHIP_API int uvghip_mts_select(int width, int height, int color, int cu_type, int isp_mode, int lfnst_idx,
                       int cr_lfnst_idx, int tr_idx, int mts_type, int *type_hor, int *type_ver,
                       int *skip_width, int *skip_height);
+
+/* ------------------------------------- (2) batched ABI: quantisation / TU -- */
+
+/* replaces: uvg_quant (src/strategies/generic/quant-generic.c:51-121) with the
+ * values it reads from encoder_state_t passed explicitly:
+ *   qp_scaled      = uvg_get_scaled_qp(color, state->qp, (bitdepth-8)*6, qp_map[0])  (src/transform.c:150)
+ *   slice_is_intra = state->frame->slicetype == UVG_SLICE_I  (rounding offset 171 vs 85, :77)
+ * Scaling lists off, lfnst_idx 0, sign hiding off (signhide=0 in the presets of
+ * the target configs).  coef/q_coef: n contiguous blocks of width*height int16. */
+UVGHIP_API int uvghip_quant_batch(int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n,
+                       int qp_scaled, int transform_skip, int slice_is_intra, void *stream);
+
+/* replaces: uvg_dequant (quant-generic.c:618-669), no scaling list / dep-quant. */
+UVGHIP_API int uvghip_dequant_batch(int bitdepth, const int16_t *q_coef, int16_t *coef, int width, int height, int n,
+                         int qp_scaled, int transform_skip, void *stream);
+
+/* replaces: uvg_coeff_abs_sum (quant-generic.c:671): out[b] = sum |c| over `length` coefficients of block b. */
+UVGHIP_API int uvghip_coeff_abs_sum_batch(const int16_t *coeffs, int length, int n, uint32_t *out, void *stream);
+
+/* replaces: uvg_fast_coeff_cost (quant-generic.c:688): weights = four packed u16 for |c| = 0,1,2,>=3. */
+UVGHIP_API int uvghip_fast_coeff_cost_batch(const int16_t *coeffs, int width, int height, int n, uint64_t weights,
+                                 uint32_t *out, void *stream);
+
+/* top-left corner of a transform unit inside the planes */
+typedef struct uvghip_tu {
+  int32_t x, y;
+} uvghip_tu_t;
+
+/* replaces: uvg_quantize_residual (quant-generic.c:460-612) on its plain-quant
+ * branch (no RDOQ / dep-quant / transform skip / LFNST / LMCS chroma scaling),
+ * for n TUs of one shape lying at tus[i] in three co-located planes:
+ *   residual = orig - pred -> forward transform -> quant -> coeff_out[i]
+ *   -> dequant -> inverse transform -> rec = clip(pred + residual)
+ * has_coeffs[i] (may be NULL) = any level != 0.  rec may alias pred only if no
+ * two TUs overlap.  type_* / skip_* as for uvghip_transform_batch. */
+UVGHIP_API int uvghip_tu_roundtrip_batch(int bitdepth, int type_hor, int type_ver, int skip_width, int skip_height,
+                              int width, int height, int qp_scaled, int slice_is_intra,
+                              const void *orig, int orig_stride, const void *pred, int pred_stride,
+                              void *rec, int rec_stride, const uvghip_tu_t *tus, int n,
+                              int16_t *coeff_out, uint8_t *has_coeffs, void *stream);
 
 #ifdef __cplusplus
 }

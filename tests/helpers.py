@@ -116,6 +116,35 @@ class Oracle:
         return hor.value, ver.value, sw.value, sh.value
 
 
+    # ---- quant -------------------------------------------------------------
+    def quant(self, d, coef, w, h, bitdepth, qp_scaled, ts, intra):
+        out = np.zeros(w * h, np.int16)
+        self.fn(d, "quant", None)(ptr(coef), ptr(out), w, h, bitdepth, qp_scaled, ts, intra)
+        return out
+
+    def dequant(self, d, q, w, h, bitdepth, qp_scaled, ts):
+        out = np.zeros(w * h, np.int16)
+        self.fn(d, "dequant", None)(ptr(q), ptr(out), w, h, bitdepth, qp_scaled, ts)
+        return out
+
+    def coeff_abs_sum(self, d, c):
+        return self.fn(d, "coeff_abs_sum", ctypes.c_uint32)(ptr(c), ctypes.c_size_t(c.size))
+
+    def fast_coeff_cost(self, d, c, w, h, weights):
+        return self.fn(d, "fast_coeff_cost", ctypes.c_uint32)(ptr(c), w, h, ctypes.c_uint64(weights))
+
+    def tu_roundtrip(self, d, bitdepth, hor, ver, sw, sh, w, h, qp_scaled, intra, ref, pred, stride, x0=0, y0=0):
+        """-> (has_coeffs, coeff, rec plane copy)"""
+        rec = pred.copy()
+        coeff = np.zeros(w * h, np.int16)
+        es = ref.itemsize
+        off = (y0 * stride + x0) * es
+        has = self.fn(d, "tu_roundtrip")(bitdepth, hor, ver, sw, sh, w, h, qp_scaled, intra,
+                                         c_vp(ref.ctypes.data + off), c_vp(pred.ctypes.data + off), stride,
+                                         c_vp(rec.ctypes.data + off), stride, ptr(coeff))
+        return has, coeff, rec
+
+
 # ---- golden container (written by tools/refcheck/refcheck.c) ----------------
 _DT = {0: np.uint8, 1: np.uint16, 2: np.int16, 3: np.int32, 4: np.uint32, 5: np.int64, 6: np.float64}
 

@@ -113,3 +113,59 @@ def transform_batch(blocks, bitdepth, inverse=False, type_hor=TR_DCT2, type_ver=
                                   _dev(blocks), _dev(out), n, _stream())
     _lib.check(rc, "uvghip_transform_batch")
     return out
+
+
+# ---- quantisation / TU round trip ---------------------------------------------
+def quant_batch(coef, bitdepth, qp_scaled, transform_skip=False, slice_is_intra=True):
+    L = _lib.init(coef.device.index or 0)
+    n, h, w = coef.shape
+    out = torch.empty_like(coef)
+    _lib.check(L.uvghip_quant_batch(bitdepth, _dev(coef), _dev(out), w, h, n, qp_scaled, int(transform_skip),
+                                    int(slice_is_intra), _stream()), "uvghip_quant_batch")
+    return out
+
+
+def dequant_batch(q_coef, bitdepth, qp_scaled, transform_skip=False):
+    L = _lib.init(q_coef.device.index or 0)
+    n, h, w = q_coef.shape
+    out = torch.empty_like(q_coef)
+    _lib.check(L.uvghip_dequant_batch(bitdepth, _dev(q_coef), _dev(out), w, h, n, qp_scaled, int(transform_skip),
+                                      _stream()), "uvghip_dequant_batch")
+    return out
+
+
+def coeff_abs_sum_batch(coeffs):
+    L = _lib.init(coeffs.device.index or 0)
+    n = coeffs.shape[0]
+    length = coeffs[0].numel()
+    out = torch.empty(n, dtype=torch.int32, device=coeffs.device)
+    _lib.check(L.uvghip_coeff_abs_sum_batch(_dev(coeffs), length, n, _dev(out), _stream()), "uvghip_coeff_abs_sum_batch")
+    return out
+
+
+def fast_coeff_cost_batch(coeffs, weights):
+    L = _lib.init(coeffs.device.index or 0)
+    n, h, w = coeffs.shape
+    out = torch.empty(n, dtype=torch.int32, device=coeffs.device)
+    _lib.check(L.uvghip_fast_coeff_cost_batch(_dev(coeffs), w, h, n, weights, _dev(out), _stream()),
+               "uvghip_fast_coeff_cost_batch")
+    return out
+
+
+def make_tus(xy, device="cuda"):
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(xy, np.int32).reshape(-1, 2))).to(device)
+
+
+def tu_roundtrip_batch(orig, pred, rec, tus, w, h, qp_scaled, slice_is_intra=True,
+                       type_hor=TR_DCT2, type_ver=TR_DCT2, skip_w=0, skip_h=0):
+    """Fused residual->transform->quant->dequant->inverse->recon for n TUs.  Writes `rec` in place;
+    returns (coeff (n,h,w) int16, has_coeffs (n,) uint8)."""
+    L = _lib.init(orig.device.index or 0)
+    n = tus.shape[0]
+    coeff = torch.empty((n, h, w), dtype=torch.int16, device=orig.device)
+    has = torch.empty(n, dtype=torch.uint8, device=orig.device)
+    _lib.check(L.uvghip_tu_roundtrip_batch(_depth(orig), type_hor, type_ver, skip_w, skip_h, w, h, qp_scaled,
+                                           int(slice_is_intra), _dev(orig), orig.stride(0), _dev(pred), pred.stride(0),
+                                           _dev(rec), rec.stride(0), _dev(tus), n, _dev(coeff), _dev(has), _stream()),
+               "uvghip_tu_roundtrip_batch")
+    return coeff, has

@@ -15,73 +15,17 @@
 #include "uvghip_common.h"
 #include "percall.h"
 #include "ref_abi.h"
-#include "vvc_tables.h"
 
-typedef short v2s __attribute__((ext_vector_type(2)));
-
-enum { TR_DCT2 = 0, TR_DCT8 = 1, TR_DST7 = 2 };   // src/uvg266.h:235-237
-
-struct tr_pass {
-  int R, C, K;          // lines, outputs per line, taps
-  int rmax, cmax, kmax; // lines processed / outputs kept / taps summed (rest -> 0)
-  int shift;
-};
-struct tr_params {
-  int w, h, inverse;
-  int type_hor, type_ver;
-  tr_pass p1, p2;
-};
-
-__device__ __forceinline__ const int16_t *tr_matrix_dev(int type, int n)
-{
-  if (type == TR_DCT2) return n == 4 ? VVC_DCT2_4 : n == 8 ? VVC_DCT2_8 : n == 16 ? VVC_DCT2_16 : VVC_DCT2_32;
-  if (type == TR_DCT8) return n == 4 ? VVC_DCT8_4 : n == 8 ? VVC_DCT8_8 : n == 16 ? VVC_DCT8_16 : VVC_DCT8_32;
-  return n == 4 ? VVC_DST7_4 : n == 8 ? VVC_DST7_8 : n == 16 ? VVC_DST7_16 : VVC_DST7_32;
-}
-
-// LDS pitches: K+2 int16 per row keeps rows 4-byte aligned and walks the
-// banks (row stride = K/2+1 dwords, odd) so lanes reading different rows at
-// the same k do not collide.
-__device__ __forceinline__ int pitch_of(int k) { return k + 2; }
-
-// One 1-D pass over all blocks held by the workgroup.
-//   acc(r,c) = sum_{k<kmax} A[b][r][k] * B[c][k]
-// r_fast: consecutive lanes take consecutive r (B row broadcast) else consecutive c.
-// dst index = b*dst_blk + r*sr + c*sc.
-template <bool INVERSE, typename DST>
-__device__ __forceinline__ void run_pass(const tr_pass &p, const int16_t *A, int a_blk, const int16_t *B,
-                                         DST *dst, int dst_blk, int sr, int sc, bool r_fast, int nblk_here)
-{
-  const int pa = pitch_of(p.K), pb = pitch_of(p.K);
-  const int per_blk = p.R * p.C, total = per_blk * nblk_here;
-  const int add = p.shift > 0 ? 1 << (p.shift - 1) : 0;
-  for (int e = threadIdx.x; e < total; e += blockDim.x) {
-    const int b = e / per_blk, rem = e - b * per_blk;
-    int r, c;
-    if (r_fast) { c = rem / p.R; r = rem - c * p.R; } else { r = rem / p.C; c = rem - r * p.C; }
-    int v = 0;
-    if (r < p.rmax && c < p.cmax) {
-      const int *a2 = reinterpret_cast<const int *>(A + b * a_blk + r * pa);
-      const int *b2 = reinterpret_cast<const int *>(B + c * pb);
-      int acc = 0;
-#pragma unroll 4
-      for (int k = 0; k < p.kmax / 2; ++k)
-        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a2[k]), __builtin_bit_cast(v2s, b2[k]), acc, false);
-      v = (acc + add) >> p.shift;
-      if (INVERSE) v = clampi(v, -32768, 32767);   // inverse clips (dct-generic.c:438)
-    }
-    dst[b * dst_blk + r * sr + c * sc] = (DST)(int16_t)v;   // forward truncates (dct-generic.c:411)
-  }
-}
+#include "transform_dev.h"
 
 __global__ void __launch_bounds__(256)
-transform_kernel(tr_params P, const int16_t *__restrict__ in, int16_t *__restrict__ out, int n, int bpg)
+transform_kernel(tr_params P, int inverse, const int16_t *__restrict__ in, int16_t *__restrict__ out, int n, int bpg)
 {
   // A: input (K-contiguous per line), T: hand-off between the passes, M1/M2: kernel matrices
-  __shared__ __attribute__((aligned(16))) int16_t sA[1024 + 2 * 256 + 64];
-  __shared__ __attribute__((aligned(16))) int16_t sT[1024 + 2 * 256 + 64];
-  __shared__ __attribute__((aligned(16))) int16_t sM1[32 * 34];
-  __shared__ __attribute__((aligned(16))) int16_t sM2[32 * 34];
+  __shared__ __attribute__((aligned(16))) int16_t sA[TR_LINEBUF_ELEMS];
+  __shared__ __attribute__((aligned(16))) int16_t sT[TR_LINEBUF_ELEMS];
+  __shared__ __attribute__((aligned(16))) int16_t sM1[TR_MATRIX_ELEMS];
+  __shared__ __attribute__((aligned(16))) int16_t sM2[TR_MATRIX_ELEMS];
 
   const int w = P.w, h = P.h, wh = w * h;
   const int blk0 = blockIdx.x * bpg;
@@ -90,86 +34,59 @@ transform_kernel(tr_params P, const int16_t *__restrict__ in, int16_t *__restric
   const int16_t *gin = in + (size_t)blk0 * wh;
   int16_t *gout = out + (size_t)blk0 * wh;
 
-  const tr_pass &p1 = P.p1, &p2 = P.p2;
-  const int pa1 = pitch_of(p1.K), a1_blk = p1.R * pa1;
-  const int pa2 = pitch_of(p2.K), a2_blk = p2.R * pa2;
+  const tr_pass p1 = inverse ? P.i1 : P.f1, p2 = inverse ? P.i2 : P.f2;
+  const int pa1 = tr_pitch(p1.K), a1_blk = p1.R * pa1;
+  const int pa2 = tr_pitch(p2.K), a2_blk = p2.R * pa2;
 
   // ---- stage input and matrices ------------------------------------------
-  if (!P.inverse) {
+  if (!inverse) {
     // lines = rows of the block (R = h, K = w)
     for (int e = threadIdx.x; e < here * wh; e += blockDim.x) {
       const int b = e / wh, rem = e - b * wh, y = rem / w, x = rem - y * w;
       sA[b * a1_blk + y * pa1 + x] = gin[e];
     }
-    const int16_t *Th = tr_matrix_dev(P.type_hor, w), *Tv = tr_matrix_dev(P.type_ver, h);
-    for (int e = threadIdx.x; e < w * w; e += blockDim.x) sM1[(e / w) * pitch_of(w) + (e % w)] = Th[e];
-    for (int e = threadIdx.x; e < h * h; e += blockDim.x) sM2[(e / h) * pitch_of(h) + (e % h)] = Tv[e];
+    tr_stage_matrix(sM1, P.type_hor, w, false);
+    tr_stage_matrix(sM2, P.type_ver, h, false);
   } else {
     // first pass is vertical: lines = columns i of the block (R = w, K = h), A[i][k] = in[k*w + i]
     for (int e = threadIdx.x; e < here * wh; e += blockDim.x) {
       const int b = e / wh, rem = e - b * wh, k = rem / w, i = rem - k * w;
       sA[b * a1_blk + i * pa1 + k] = gin[e];
     }
-    const int16_t *Th = tr_matrix_dev(P.type_hor, w), *Tv = tr_matrix_dev(P.type_ver, h);
-    // B[c][k] = T[k][c]
-    for (int e = threadIdx.x; e < h * h; e += blockDim.x) sM1[(e % h) * pitch_of(h) + (e / h)] = Tv[e];
-    for (int e = threadIdx.x; e < w * w; e += blockDim.x) sM2[(e % w) * pitch_of(w) + (e / w)] = Th[e];
+    tr_stage_matrix(sM1, P.type_ver, h, true);
+    tr_stage_matrix(sM2, P.type_hor, w, true);
   }
   __syncthreads();
 
-  if (!P.inverse) {
-    // pass 1 (horizontal): r = row y, c = freq j -> T[j][y]  (lines of pass 2 = j, K = h)
-    run_pass<false>(p1, sA, a1_blk, sM1, sT, a2_blk, 1, pa2, true, here);
-    __syncthreads();
-    // pass 2 (vertical): r = hor freq i, c = ver freq j -> out[j*w + i]
-    run_pass<false>(p2, sT, a2_blk, sM2, gout, wh, 1, w, true, here);
-  } else {
-    // pass 1 (vertical): r = column i, c = spatial row j -> T[j][i]  (lines of pass 2 = j, K = w)
-    run_pass<true>(p1, sA, a1_blk, sM1, sT, a2_blk, 1, pa2, true, here);
-    __syncthreads();
-    // pass 2 (horizontal): r = spatial row, c = spatial column -> out[r*w + c]
-    run_pass<true>(p2, sT, a2_blk, sM2, gout, wh, w, 1, false, here);
-  }
-}
-
-// Which 1-D kernels honour skip_line2 in the reference (dct-generic.c):
-//   forward: DST7/DCT8 with n >= 8 zero rows >= cutoff (:1651,:1768,:2014,:2139,:2264,:2335);
-//            every DCT2 kernel and the 4-point DST7/DCT8 ignore it.
-//   inverse: only the 8-point DST7/DCT8 stop their sums at cutoff (:2280,:2351).
-static bool fwd_cut(int type, int n) { return type != TR_DCT2 && n >= 8; }
-static bool inv_cut(int type, int n) { return type != TR_DCT2 && n == 8; }
-static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
-
-static tr_params make_params(int bitdepth, int inverse, int th, int tv, int w, int h, int sw, int sh)
-{
-  tr_params P;
-  P.w = w; P.h = h; P.inverse = inverse; P.type_hor = th; P.type_ver = tv;
+  // pass 1 hands lines to pass 2 K-contiguously: T[b][c][r]
+  auto to_lds = [&](int b, int r, int c, int v) { sT[b * a2_blk + c * pa2 + r] = (int16_t)v; };
   if (!inverse) {
-    P.p1 = tr_pass{h, w, w, h, fwd_cut(th, w) ? w - sw : w, w, ilog2(w) - 1 + bitdepth - 8};
-    P.p2 = tr_pass{w, h, h, w - sw, fwd_cut(tv, h) ? h - sh : h, h, ilog2(h) + 6};
+    tr_run_pass<false>(p1, sA, a1_blk, sM1, true, here, to_lds);     // horizontal: r = row, c = hor freq
+    __syncthreads();
+    // vertical: r = hor freq i, c = ver freq j -> out[j*w + i]
+    tr_run_pass<false>(p2, sT, a2_blk, sM2, true, here, [&](int b, int r, int c, int v) { gout[b * wh + c * w + r] = (int16_t)v; });
   } else {
-    P.p1 = tr_pass{w, h, h, w - sw, h, inv_cut(tv, h) ? h - sh : h, 7};
-    P.p2 = tr_pass{h, w, w, h, w, inv_cut(th, w) ? w - sw : w, 20 - bitdepth};
+    tr_run_pass<true>(p1, sA, a1_blk, sM1, true, here, to_lds);      // vertical: r = column, c = spatial row
+    __syncthreads();
+    // horizontal: r = spatial row, c = spatial column -> out[r*w + c]
+    tr_run_pass<true>(p2, sT, a2_blk, sM2, false, here, [&](int b, int r, int c, int v) { gout[b * wh + r * w + c] = (int16_t)v; });
   }
-  return P;
 }
-
-static bool valid_dim(int v) { return v == 4 || v == 8 || v == 16 || v == 32; }
 
 extern "C" int uvghip_transform_batch(int bitdepth, int inverse, int type_hor, int type_ver, int width, int height,
                                       int skip_width, int skip_height, const int16_t *in, int16_t *out, int n,
                                       void *stream)
 {
   UVGHIP_REQUIRE_READY();
-  if (!valid_dim(width) || !valid_dim(height) || type_hor < 0 || type_hor > 2 || type_ver < 0 || type_ver > 2 ||
+  if (!tr_valid_dim(width) || !tr_valid_dim(height) || type_hor < 0 || type_hor > 2 || type_ver < 0 || type_ver > 2 ||
       skip_width < 0 || skip_width >= width || skip_height < 0 || skip_height >= height ||
       (skip_width & 3) || (skip_height & 3))
     return uvghip_set_error(hipErrorInvalidValue, __func__);
   if (n <= 0) return 0;
-  const tr_params P = make_params(bitdepth, inverse != 0, type_hor, type_ver, width, height, skip_width, skip_height);
+  const tr_params P = tr_make_params(bitdepth, type_hor, type_ver, width, height, skip_width, skip_height);
   const int bpg = 1024 / (width * height);
   const int grid = (n + bpg - 1) / bpg;
-  transform_kernel<<<grid, 256, 0, uvghip_stream(stream)>>>(P, in, out, n, bpg);
+  transform_kernel<<<grid, 256, 0, uvghip_stream(stream)>>>(P, inverse != 0, in, out, n, bpg);
   UVGHIP_CHECK_LAUNCH();
 }
 

@@ -1,0 +1,293 @@
+// "quant" strategy group on gfx950: quant / dequant / coeff_abs_sum /
+// fast_coeff_cost and the fused TU round trip (quantize_residual).
+// Bit-exact with src/strategies/generic/quant-generic.c:
+//   uvg_quant_generic    :51-121  (scaling list off, lfnst 0; sign hiding :123-233 not implemented --
+//                                  signhide=0 in every preset of the north-star configs)
+//   uvg_dequant_generic  :618-669 (no scaling list / dep-quant)
+//   uvg_quantize_residual_generic :460-612, plain-quant branch (:532-536)
+//   coeff_abs_sum :671, fast_coeff_cost :688
+// The reference reads qp, bit depth, slice type and flags from
+// encoder_state_t; here they are plain arguments (the host-side shim that
+// extracts them is shown in INTEGRATION.md).
+//
+// Fused TU kernel data flow (one workgroup = 1024 coefficients = 1..64 TUs):
+//   HBM: orig + pred pixels (read once) -> residual in LDS -> 2 forward
+//   passes (dot2) -> quant in registers -> levels to HBM (coeff_out) and
+//   dequantised straight into the inverse line buffer in LDS -> 2 inverse
+//   passes -> + pred, clip -> recon pixels to HBM.  Nothing intermediate
+//   touches HBM; algorithmic bytes per TU = w*h*(2*px + 2 + px).
+#include "uvghip_common.h"
+#include "percall.h"
+#include "transform_dev.h"
+
+struct quant_params {
+  int scale, add; int q_bits;      // level = (|c| * scale + add) >> q_bits   (int64 product)
+  int iscale, iadd, ishift;        // coef  = clip16((q * iscale + iadd) >> ishift)
+};
+
+static quant_params make_quant_params(int bitdepth, int width, int height, int qp_scaled, int transform_skip,
+                                      int slice_is_intra)
+{
+  static const int16_t qs[2][6] = {{26214, 23302, 20560, 18396, 16384, 14564}, {18396, 16384, 14564, 13107, 11651, 10280}};
+  static const int16_t iqs[2][6] = {{40, 45, 51, 57, 64, 72}, {57, 64, 72, 80, 90, 102}};
+  const int lw = tr_ilog2(width), lh = tr_ilog2(height);
+  if (transform_skip && qp_scaled < 4 + 6 * 2) qp_scaled = 4 + 6 * 2;     // MIN_QP_PRIME_TS (global.h:147)
+  const int sqrt2 = !transform_skip && ((lw + lh) & 1);
+  quant_params q;
+  const int tshift_q = 15 - bitdepth - ((lw + lh) >> 1) - sqrt2;         // quant-generic.c:74
+  q.q_bits = 14 + qp_scaled / 6 + (transform_skip ? 0 : tshift_q);
+  q.add = (slice_is_intra ? 171 : 85) << (q.q_bits - 9);
+  q.scale = qs[sqrt2][qp_scaled % 6];
+  const int tshift_d = 15 - bitdepth - ((lw + lh) >> 1);                  // quant-generic.c:629
+  q.ishift = 20 - 14 - (transform_skip ? 0 : tshift_d - sqrt2);
+  q.iscale = iqs[sqrt2][qp_scaled % 6] << (qp_scaled / 6);
+  q.iadd = 1 << (q.ishift - 1);
+  return q;
+}
+
+__device__ __forceinline__ int quant_one(int c, const quant_params &q)
+{
+  const long long a = c < 0 ? -(long long)c : (long long)c;
+  int level = (int)((a * q.scale + q.add) >> q.q_bits);
+  if (c < 0) level = -level;
+  return clampi(level, -32768, 32767);
+}
+__device__ __forceinline__ int dequant_one(int l, const quant_params &q)
+{
+  return clampi((l * q.iscale + q.iadd) >> q.ishift, -32768, 32767);
+}
+
+__global__ void __launch_bounds__(256)
+quant_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out, size_t total, quant_params q, int inverse)
+{
+  const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i0 >= total) return;
+  if (i0 + 4 <= total) {
+    const short4 v = *reinterpret_cast<const short4 *>(in + i0);
+    short4 r;
+    if (inverse) { r.x = dequant_one(v.x, q); r.y = dequant_one(v.y, q); r.z = dequant_one(v.z, q); r.w = dequant_one(v.w, q); }
+    else { r.x = quant_one(v.x, q); r.y = quant_one(v.y, q); r.z = quant_one(v.z, q); r.w = quant_one(v.w, q); }
+    *reinterpret_cast<short4 *>(out + i0) = r;
+  } else {
+    for (size_t i = i0; i < total; ++i) out[i] = inverse ? dequant_one(in[i], q) : quant_one(in[i], q);
+  }
+}
+
+static int check_qargs(int bitdepth, int width, int height, int qp_scaled)
+{
+  if ((bitdepth != 8 && bitdepth != 10) || width < 1 || height < 1 || width > 64 || height > 64 ||
+      (width & (width - 1)) || (height & (height - 1)) || qp_scaled < 0 || qp_scaled > 63 + 12)
+    return uvghip_set_error(hipErrorInvalidValue, "quant arguments");
+  return 0;
+}
+
+extern "C" int uvghip_quant_batch(int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n,
+                                  int qp_scaled, int transform_skip, int slice_is_intra, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (int rc = check_qargs(bitdepth, width, height, qp_scaled)) return rc;
+  if (n <= 0) return 0;
+  const quant_params q = make_quant_params(bitdepth, width, height, qp_scaled, transform_skip, slice_is_intra);
+  const size_t total = (size_t)n * width * height;
+  quant_kernel<<<(unsigned)((total / 4 + 255) / 256 + 1), 256, 0, uvghip_stream(stream)>>>(coef, q_coef, total, q, 0);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+extern "C" int uvghip_dequant_batch(int bitdepth, const int16_t *q_coef, int16_t *coef, int width, int height, int n,
+                                    int qp_scaled, int transform_skip, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (int rc = check_qargs(bitdepth, width, height, qp_scaled)) return rc;
+  if (n <= 0) return 0;
+  const quant_params q = make_quant_params(bitdepth, width, height, qp_scaled, transform_skip, 1);
+  const size_t total = (size_t)n * width * height;
+  quant_kernel<<<(unsigned)((total / 4 + 255) / 256 + 1), 256, 0, uvghip_stream(stream)>>>(q_coef, coef, total, q, 1);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// ---- per-block coefficient sums ------------------------------------------------
+// out[b] = sum |c| (mode 0, coeff_abs_sum) or (sum weights[min(|c|,3)] + 128) >> 8 (mode 1, fast_coeff_cost)
+__global__ void __launch_bounds__(256)
+coeff_cost_kernel(const int16_t *__restrict__ c, int len, int n, uint32_t *__restrict__ out, int lpb, int mode,
+                  unsigned long long weights)
+{
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int bpw = 64 / lpb;
+  const int blk = wave * bpw + lane / lpb;
+  const int l = lane & (lpb - 1);
+  const bool active = blk < n;
+  int acc = 0;
+  if (active) {
+    const int16_t *p = c + (size_t)blk * len;
+    for (int i = l; i < len; i += lpb) {
+      int a = abs((int)p[i]);
+      if (mode) { a = a > 3 ? 3 : a; acc += (int)((weights >> (16 * a)) & 0xffff); }
+      else acc += a;
+    }
+  }
+  acc = group_sum(acc, lpb);
+  if (active && l == 0) out[blk] = mode ? ((uint32_t)acc + 128u) >> 8 : (uint32_t)acc;
+}
+
+static int launch_coeff_cost(const int16_t *c, int len, int n, uint32_t *out, int mode, unsigned long long w, hipStream_t st)
+{
+  if (n <= 0) return 0;
+  int lpb = 1; while (lpb < len && lpb < 64) lpb <<= 1;
+  const int bpw = 64 / lpb, waves = (n + bpw - 1) / bpw;
+  coeff_cost_kernel<<<(waves + 3) / 4, 256, 0, st>>>(c, len, n, out, lpb, mode, w);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+extern "C" int uvghip_coeff_abs_sum_batch(const int16_t *coeffs, int length, int n, uint32_t *out, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  return launch_coeff_cost(coeffs, length, n, out, 0, 0, uvghip_stream(stream));
+}
+extern "C" int uvghip_fast_coeff_cost_batch(const int16_t *coeffs, int width, int height, int n, uint64_t weights,
+                                            uint32_t *out, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  return launch_coeff_cost(coeffs, width * height, n, out, 1, weights, uvghip_stream(stream));
+}
+
+// ---- fused TU round trip -----------------------------------------------------------
+
+template <typename PX>
+__global__ void __launch_bounds__(256)
+tu_roundtrip_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int orig_stride,
+                    const PX *__restrict__ pred, int pred_stride, PX *__restrict__ rec, int rec_stride,
+                    const uvghip_tu_t *__restrict__ tus, int n, int bpg, int16_t *__restrict__ coeff_out,
+                    uint8_t *__restrict__ has_coeffs)
+{
+  __shared__ __attribute__((aligned(16))) int16_t sA[TR_LINEBUF_ELEMS];
+  __shared__ __attribute__((aligned(16))) int16_t sT[TR_LINEBUF_ELEMS];
+  __shared__ __attribute__((aligned(16))) int16_t sMf1[TR_MATRIX_ELEMS], sMf2[TR_MATRIX_ELEMS];
+  __shared__ __attribute__((aligned(16))) int16_t sMi1[TR_MATRIX_ELEMS], sMi2[TR_MATRIX_ELEMS];
+  __shared__ int16_t sPred[1024];
+  __shared__ int sHas[64];
+  __shared__ int sX[64], sY[64];
+
+  const int w = P.w, h = P.h, wh = w * h;
+  const int blk0 = blockIdx.x * bpg;
+  const int here = min(bpg, n - blk0);
+  if (here <= 0) return;
+
+  for (int b = threadIdx.x; b < here; b += blockDim.x) { sX[b] = tus[blk0 + b].x; sY[b] = tus[blk0 + b].y; sHas[b] = 0; }
+  tr_stage_matrix(sMf1, P.type_hor, w, false);
+  tr_stage_matrix(sMf2, P.type_ver, h, false);
+  tr_stage_matrix(sMi1, P.type_ver, h, true);
+  tr_stage_matrix(sMi2, P.type_hor, w, true);
+  __syncthreads();
+
+  // residual = orig - pred (picture-generic.c:1360), forward line layout A[b][y][x]
+  const int paf1 = tr_pitch(P.f1.K), af1_blk = P.f1.R * paf1;
+  for (int e = threadIdx.x; e < here * wh; e += blockDim.x) {
+    const int b = e / wh, rem = e - b * wh, y = rem / w, x = rem - y * w;
+    const int o = orig[(size_t)(sY[b] + y) * orig_stride + sX[b] + x];
+    const int p = pred[(size_t)(sY[b] + y) * pred_stride + sX[b] + x];
+    sPred[e] = (int16_t)p;
+    sA[b * af1_blk + y * paf1 + x] = (int16_t)(o - p);
+  }
+  __syncthreads();
+
+  const int paf2 = tr_pitch(P.f2.K), af2_blk = P.f2.R * paf2;
+  tr_run_pass<false>(P.f1, sA, af1_blk, sMf1, true, here,
+                     [&](int b, int r, int c, int v) { sT[b * af2_blk + c * paf2 + r] = (int16_t)v; });
+  __syncthreads();
+
+  // vertical pass -> coefficient (j,i); quantise; store the level; dequantise into the
+  // inverse line buffer A'[b][i][j] (lines = columns, K = h)
+  const int pai1 = tr_pitch(P.i1.K), ai1_blk = P.i1.R * pai1;
+  int16_t *gco = coeff_out + (size_t)blk0 * wh;
+  tr_run_pass<false>(P.f2, sT, af2_blk, sMf2, true, here, [&](int b, int r, int c, int v) {
+    const int level = quant_one(v, Q);
+    gco[b * wh + c * w + r] = (int16_t)level;
+    if (level) sHas[b] = 1;                         // benign race: every writer stores 1
+    sA[b * ai1_blk + r * pai1 + c] = (int16_t)dequant_one(level, Q);
+  });
+  __syncthreads();
+
+  const int pai2 = tr_pitch(P.i2.K), ai2_blk = P.i2.R * pai2;
+  tr_run_pass<true>(P.i1, sA, ai1_blk, sMi1, true, here,
+                    [&](int b, int r, int c, int v) { sT[b * ai2_blk + c * pai2 + r] = (int16_t)v; });
+  __syncthreads();
+  tr_run_pass<true>(P.i2, sT, ai2_blk, sMi2, false, here, [&](int b, int r, int c, int v) {
+    // int16 wrap of (residual + pred) then clip, as quant-generic.c:594-595
+    const int s = (int)(int16_t)(v + sPred[b * wh + r * w + c]);
+    rec[(size_t)(sY[b] + r) * rec_stride + sX[b] + c] = (PX)clampi(s, 0, px_traits<PX>::maxv);
+  });
+  if (has_coeffs)
+    for (int b = threadIdx.x; b < here; b += blockDim.x) has_coeffs[blk0 + b] = (uint8_t)sHas[b];
+}
+
+extern "C" int uvghip_tu_roundtrip_batch(int bitdepth, int type_hor, int type_ver, int skip_width, int skip_height,
+                                         int width, int height, int qp_scaled, int slice_is_intra,
+                                         const void *orig, int orig_stride, const void *pred, int pred_stride,
+                                         void *rec, int rec_stride, const uvghip_tu_t *tus, int n,
+                                         int16_t *coeff_out, uint8_t *has_coeffs, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!tr_valid_dim(width) || !tr_valid_dim(height) || type_hor < 0 || type_hor > 2 || type_ver < 0 || type_ver > 2 ||
+      skip_width < 0 || skip_width >= width || skip_height < 0 || skip_height >= height)
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (int rc = check_qargs(bitdepth, width, height, qp_scaled)) return rc;
+  if (n <= 0) return 0;
+  const tr_params P = tr_make_params(bitdepth, type_hor, type_ver, width, height, skip_width, skip_height);
+  const quant_params Q = make_quant_params(bitdepth, width, height, qp_scaled, 0, slice_is_intra);
+  const int bpg = 1024 / (width * height);
+  const int grid = (n + bpg - 1) / bpg;
+  hipStream_t st = uvghip_stream(stream);
+  if (bitdepth == 8)
+    tu_roundtrip_kernel<uint8_t><<<grid, 256, 0, st>>>(P, Q, (const uint8_t *)orig, orig_stride, (const uint8_t *)pred, pred_stride,
+                                                       (uint8_t *)rec, rec_stride, tus, n, bpg, coeff_out, has_coeffs);
+  else
+    tu_roundtrip_kernel<uint16_t><<<grid, 256, 0, st>>>(P, Q, (const uint16_t *)orig, orig_stride, (const uint16_t *)pred, pred_stride,
+                                                        (uint16_t *)rec, rec_stride, tus, n, bpg, coeff_out, has_coeffs);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// =================================================== drop-in strategy layer ====
+namespace {
+
+// coeff_abs_sum_func (strategies-quant.h:87): (const coeff_t *coeffs, size_t length)
+uint32_t coeff_abs_sum_hip(const int16_t *coeffs, size_t length)
+{
+  percall_ctx *c = percall_get(length * 2 + 1024);
+  const size_t oi = c->take(length * 2), oo = c->take(4);
+  memcpy(c->hp<int16_t>(oi), coeffs, length * 2);
+  c->upload(oi, length * 2);
+  c->must(launch_coeff_cost(c->dp<int16_t>(oi), (int)length, 1, c->dp<uint32_t>(oo), 0, 0, c->stream), "coeff_abs_sum");
+  c->download(oo, 4);
+  c->sync();
+  return *c->hp<uint32_t>(oo);
+}
+// fast_coeff_cost_func (strategies-quant.h:88): (const coeff_t *coeff, int32_t width, int32_t height, uint64_t weights)
+uint32_t fast_coeff_cost_hip(const int16_t *coeff, int32_t width, int32_t height, uint64_t weights)
+{
+  const size_t length = (size_t)width * height;
+  percall_ctx *c = percall_get(length * 2 + 1024);
+  const size_t oi = c->take(length * 2), oo = c->take(4);
+  memcpy(c->hp<int16_t>(oi), coeff, length * 2);
+  c->upload(oi, length * 2);
+  c->must(launch_coeff_cost(c->dp<int16_t>(oi), (int)length, 1, c->dp<uint32_t>(oo), 1, weights, c->stream), "fast_coeff_cost");
+  c->download(oo, 4);
+  c->sync();
+  return *c->hp<uint32_t>(oo);
+}
+
+}  // namespace
+
+// quant / dequant / quantize_residual / quant_cbcr_residual take encoder_state_t*
+// (strategies-quant.h:48-86): they cannot be bound without the encoder's own
+// headers, so they are registered by the host-side shim of INTEGRATION.md,
+// which forwards to uvghip_quant_batch / uvghip_dequant_batch /
+// uvghip_tu_roundtrip_batch.  The two state-free functions register here.
+extern "C" int uvg_strategy_register_quant_hip(void *opaque, uint8_t bitdepth)
+{
+  if (!uvghip_ready() && uvghip_init(0) != 0) return 0;
+  int ok = 1;
+  ok &= uvghip_do_register(opaque, "coeff_abs_sum", (void *)&coeff_abs_sum_hip);
+  ok &= uvghip_do_register(opaque, "fast_coeff_cost", (void *)&fast_coeff_cost_hip);
+  return ok;
+}

@@ -36,6 +36,12 @@ SIGNATURES = {
     "uvg_strategy_register_dct_hip": (c_int, [c_vp, ctypes.c_uint8]),
     "uvghip_transform_batch": (c_int, [c_int] * 8 + [c_vp, c_vp, c_int, c_vp]),
     "uvghip_mts_select": (c_int, [c_int] * 9 + [c_vp] * 4),
+    "uvg_strategy_register_quant_hip": (c_int, [c_vp, ctypes.c_uint8]),
+    "uvghip_quant_batch": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "uvghip_dequant_batch": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "uvghip_coeff_abs_sum_batch": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
+    "uvghip_fast_coeff_cost_batch": (c_int, [c_vp, c_int, c_int, c_int, ctypes.c_uint64, c_vp, c_vp]),
+    "uvghip_tu_roundtrip_batch": (c_int, [c_int] * 9 + [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvghip_sad_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_satd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_ssd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
