@@ -66,6 +66,7 @@ UVGHIP_API void uvghip_set_register_fn(uvghip_register_fn fn);
 
 UVGHIP_API int uvg_strategy_register_picture_hip(void *opaque, uint8_t bitdepth); /* strategies-picture.h:160-232 */
 UVGHIP_API int uvg_strategy_register_dct_hip(void *opaque, uint8_t bitdepth);     /* strategies-dct.h:77-110   */
+UVGHIP_API int uvg_strategy_register_intra_hip(void *opaque, uint8_t bitdepth);   /* strategies-intra.h:81-103 */
 UVGHIP_API int uvg_strategy_register_quant_hip(void *opaque, uint8_t bitdepth);   /* strategies-quant.h:93-111 (state-free functions only) */
 
 /* -------------------------------------------- (2) batched ABI: picture -- */
@@ -182,6 +183,37 @@ UVGHIP_API int uvghip_tu_roundtrip_batch(int bitdepth, int type_hor, int type_ve
                               const void *orig, int orig_stride, const void *pred, int pred_stride,
                               void *rec, int rec_stride, const uvghip_tu_t *tus, int n,
                               int16_t *coeff_out, uint8_t *has_coeffs, void *stream);
+
+/* ------------------------------------------ (2) batched ABI: intra -------- */
+
+/* One intra block in a reconstructed plane.  avail_top / avail_left are the
+ * numbers of already reconstructed samples to the top(-right) and left(-below)
+ * of the block that may be used as references, i.e. px_available_top/left of
+ * uvg_intra_build_reference after all its limits (coded-neighbour count * 4,
+ * cu+pu size, picture size, WPP clamp; src/intra.c:850-852,1038-1039,1252-1318).
+ * The caller knows the coding order; the kernels never guess it. */
+typedef struct uvghip_intra_blk {
+  int32_t x, y;
+  int32_t avail_top, avail_left;
+} uvghip_intra_blk_t;
+
+/* replaces: uvg_intra_build_reference + uvg_intra_predict (src/intra.c:1344,1372:
+ * reference rows incl. [1 2 1]/4 smoothing, planar / DC / angular with wide
+ * angles, PDPC) for n blocks of one shape and a list of n_modes signalled modes
+ * (0 planar, 1 DC, 2..66).  MRL 0, no ISP/MIP/CCLM.
+ * preds_out: [n][n_modes][height*width] pixels. */
+UVGHIP_API int uvghip_intra_pred_batch(int bitdepth, const void *rec, int rec_stride, int is_chroma, int width, int height,
+                            const uvghip_intra_blk_t *blks, int n, const int8_t *modes, int n_modes,
+                            void *preds_out, void *stream);
+
+/* replaces: the rough mode search loop of search_intra_rough (src/search_intra.c:986-1110)
+ * = uvg_intra_predict + get_cost_dual (:133-158) per candidate, for n square luma
+ * blocks of `size` (4..32) and all n_modes candidates at once:
+ *   costs[i*n_modes + m] = min(SATD, 2*SAD)(pred of modes[m], orig block at (x,y)).
+ * Predictions stay in registers; only costs are written. */
+UVGHIP_API int uvghip_intra_search_batch(int bitdepth, const void *rec, int rec_stride, const void *orig, int orig_stride,
+                              int size, const uvghip_intra_blk_t *blks, int n, const int8_t *modes, int n_modes,
+                              uint32_t *costs, void *stream);
 
 #ifdef __cplusplus
 }

@@ -145,6 +145,38 @@ class Oracle:
         return has, coeff, rec
 
 
+    # ---- intra -------------------------------------------------------------
+    REF_LEN = 400
+
+    def intra_build_refs(self, d, rec, pic_w, pic_h, x, y, w, h, at, al):
+        top = np.zeros(self.REF_LEN, rec.dtype); left = np.zeros(self.REF_LEN, rec.dtype)
+        self.fn(d, "intra_build_refs", None)(ptr(rec), rec.shape[1], pic_w, pic_h, x, y, w, h, at, al, ptr(top), ptr(left))
+        return top, left
+
+    def intra_filter_refs(self, d, top, left, w, h):
+        ft = np.zeros_like(top); fl = np.zeros_like(left)
+        self.fn(d, "intra_filter_refs", None)(ptr(top), ptr(left), w, h, ptr(ft), ptr(fl))
+        return ft, fl
+
+    def intra_predict(self, d, mode, is_chroma, w, h, top, left, ftop, fleft):
+        dst = np.zeros(w * h, top.dtype)
+        self.fn(d, "intra_predict")(mode, int(is_chroma), w, h, ptr(top), ptr(left), ptr(ftop), ptr(fleft), ptr(dst))
+        return dst
+
+    def angular_pred(self, d, w, h, mode, is_chroma, above, left, mrl=0, isp=0):
+        dst = np.zeros(w * h, above.dtype)
+        self.fn(d, "angular_pred", None)(w, h, mode, int(is_chroma), ptr(above), ptr(left), ptr(dst), mrl, isp)
+        return dst
+
+    def intra_mode_costs(self, d, rec, pic_w, pic_h, x, y, n, at, al, orig, modes, want_preds=False):
+        modes = np.asarray(modes, np.int8)
+        costs = np.zeros(len(modes), np.uint32)
+        preds = np.zeros(len(modes) * n * n, rec.dtype) if want_preds else None
+        self.fn(d, "intra_mode_costs", None)(ptr(rec), rec.shape[1], pic_w, pic_h, x, y, n, at, al, ptr(orig),
+                                             ptr(modes), len(modes), ptr(costs), ptr(preds) if want_preds else None)
+        return (costs, preds) if want_preds else costs
+
+
 # ---- golden container (written by tools/refcheck/refcheck.c) ----------------
 _DT = {0: np.uint8, 1: np.uint16, 2: np.int16, 3: np.int32, 4: np.uint32, 5: np.int64, 6: np.float64}
 
@@ -222,3 +254,45 @@ def dct_test_gradient(width=64):
     slope = 255 // width
     val = (slope * np.sqrt(((width - x) ** 2 + (width - y) ** 2).astype(np.float64)) + 0.5).astype(np.int64)
     return np.clip(val, 0, 255).astype(np.int16)
+
+
+def intra_golden_blocks(depth):
+    """Yield (frame, x, y, n, at, al, orig, preds(67,n*n), costs(67)) from ref_intra_<depth>.bin,
+    with the dumped crop pasted into a zero frame (only the crop is ever read as reference)."""
+    for name, arrs in read_golden("intra", depth):
+        if name != "block":
+            continue
+        meta, crop, orig, preds, costs = arrs
+        FW, FH, x, y, n, at, al, cx0, cy0, cw, ch = [int(v) for v in meta[:11]]
+        frame = np.zeros((FH, FW), crop.dtype)
+        frame[cy0:cy0 + ch, cx0:cx0 + cw] = crop.reshape(ch, cw)
+        yield frame, x, y, n, at, al, orig, preds.reshape(67, n * n), costs
+
+
+def zorder_avail(x, y, n, pic_w, pic_h, ctu=64):
+    """Availability a z-order (quad-tree only) encoder would report for an n x n block at (x,y):
+    (avail_top, avail_left) in samples, with the reference's limits (2n, picture edge)."""
+    def z(sx, sy):
+        v = 0
+        for b in range(4):
+            v |= ((sx >> b) & 1) << (2 * b) | ((sy >> b) & 1) << (2 * b + 1)
+        return v
+    lx, ly = x % ctu, y % ctu
+    zc = z(lx // 4, ly // 4)
+
+    def coded(px, py):
+        if px < 0 or py < 0 or px >= pic_w or py >= pic_h:
+            return False
+        cx, cy = (px // ctu) * ctu, (py // ctu) * ctu
+        if cy < y - ly or (cy == y - ly and cx < x - lx):
+            return cx <= x - lx + ctu or cy < y - ly     # CTUs above (incl. above-right) and to the left
+        if cx == x - lx and cy == y - ly:
+            return z((px - cx) // 4, (py - cy) // 4) < zc
+        return False
+    at = 0
+    while at < 2 * n and coded(x + at, y - 1):
+        at += 4
+    al = 0
+    while al < 2 * n and coded(x - 1, y + al):
+        al += 4
+    return min(at, 2 * n, pic_w - x), min(al, 2 * n, pic_h - y)

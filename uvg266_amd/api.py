@@ -169,3 +169,34 @@ def tu_roundtrip_batch(orig, pred, rec, tus, w, h, qp_scaled, slice_is_intra=Tru
                                            _dev(rec), rec.stride(0), _dev(tus), n, _dev(coeff), _dev(has), _stream()),
                "uvghip_tu_roundtrip_batch")
     return coeff, has
+
+
+# ---- intra ---------------------------------------------------------------------
+def make_intra_blocks(xyaa, device="cuda"):
+    """(n,4) rows of (x, y, avail_top, avail_left) -> device array of uvghip_intra_blk_t."""
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(xyaa, np.int32).reshape(-1, 4))).to(device)
+
+
+def make_modes(modes, device="cuda"):
+    return torch.from_numpy(np.asarray(modes, np.int8)).to(device)
+
+
+def intra_pred_batch(rec, blks, w, h, modes, is_chroma=False):
+    """-> (n, n_modes, h, w) predictions (dtype of `rec`)."""
+    L = _lib.init(rec.device.index or 0)
+    n, nm = blks.shape[0], modes.shape[0]
+    out = torch.empty((n, nm, h, w), dtype=rec.dtype, device=rec.device)
+    _lib.check(L.uvghip_intra_pred_batch(_depth(rec), _dev(rec), rec.stride(0), int(is_chroma), w, h, _dev(blks), n,
+                                         _dev(modes), nm, _dev(out), _stream()), "uvghip_intra_pred_batch")
+    return out
+
+
+def intra_search_batch(rec, orig, blks, size, modes):
+    """-> (n, n_modes) int32 costs min(SATD, 2*SAD)."""
+    L = _lib.init(rec.device.index or 0)
+    n, nm = blks.shape[0], modes.shape[0]
+    out = torch.empty((n, nm), dtype=torch.int32, device=rec.device)
+    _lib.check(L.uvghip_intra_search_batch(_depth(rec), _dev(rec), rec.stride(0), _dev(orig), orig.stride(0), size,
+                                           _dev(blks), n, _dev(modes), nm, _dev(out), _stream()),
+               "uvghip_intra_search_batch")
+    return out

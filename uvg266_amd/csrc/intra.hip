@@ -1,0 +1,617 @@
+// Intra prediction on gfx950: reference construction + smoothing, planar, DC,
+// angular (incl. wide angles), PDPC -- and the fused rough mode search
+// (predict every candidate mode and cost it with min(SATD, 2*SAD) without the
+// predictions ever leaving the CU).
+//
+// Bit-exact with the reference path
+//   uvg_intra_build_reference   src/intra.c:756-1342   (frame-level semantics, MRL 0, no ISP)
+//   intra_filter_reference      src/intra.c:190-225
+//   intra_predict_regular       src/intra.c:660-753    (filtered/unfiltered choice, PDPC)
+//   intra_pred_dc               src/intra.c:236-273
+//   uvg_angular_pred_generic    src/strategies/generic/intra-generic.c:55-295
+//   uvg_intra_pred_planar_generic :306-361, uvg_pdpc_planar_dc_generic :414-437
+//   get_cost_dual               src/search_intra.c:133-158
+//
+// Data flow of the search kernel: per CU the 4N+1 reference samples and the
+// N*N original samples are read from HBM once and staged in LDS (raw +
+// smoothed reference rows, original block and its transpose).  Every
+// (mode, 8x8 tile) pair is one task for an 8-lane group: each lane predicts
+// one 8-pixel row in registers, the difference row goes straight into the
+// row-per-lane Hadamard (picture.hip), and only two integers per task reach
+// LDS.  Horizontal modes are evaluated in the reference's transposed "work"
+// domain against the transposed original: SAD and the Hadamard magnitude
+// multiset are transpose-invariant, so costs are identical.
+#include "uvghip_common.h"
+#include "percall.h"
+#include "ref_abi.h"
+
+// ---- constant tables (H.266 8.4.5.2.13: intraPredAngle, invAngle; table 25 fC) -------------
+__device__ static const int16_t kSampleDisp[32] = {0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 18, 20, 23, 26, 29, 32, 35, 39, 45, 51,
+                                                   57, 64, 73, 86, 102, 128, 171, 256, 341, 512, 1024};
+__device__ static const int16_t kInvDisp[32] = {0, 16384, 8192, 5461, 4096, 2731, 2048, 1638, 1365, 1170, 1024, 910, 819, 712,
+                                                630, 565, 512, 468, 420, 364, 321, 287, 256, 224, 191, 161, 128, 96, 64, 48, 32, 16};
+__device__ static const int8_t kPreScale[32] = {8, 7, 6, 5, 5, 4, 4, 4, 3, 3, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 0, 0, 0,
+                                                -1, -1, -2, -3};
+__device__ static const int8_t kDistThres[8] = {24, 24, 24, 14, 2, 0, 0, 0};
+__device__ static const int8_t kCubic[32][4] = {
+  {0, 64, 0, 0},    {-1, 63, 2, 0},   {-2, 62, 4, 0},   {-2, 60, 7, -1},  {-2, 58, 10, -2}, {-3, 57, 12, -2},
+  {-4, 56, 14, -2}, {-4, 55, 15, -2}, {-4, 54, 16, -2}, {-5, 53, 18, -2}, {-6, 52, 20, -2}, {-6, 49, 24, -3},
+  {-6, 46, 28, -4}, {-5, 44, 29, -4}, {-4, 42, 30, -4}, {-4, 39, 33, -4}, {-4, 36, 36, -4}, {-4, 33, 39, -4},
+  {-4, 30, 42, -4}, {-4, 29, 44, -5}, {-4, 28, 46, -6}, {-3, 24, 49, -6}, {-2, 20, 52, -6}, {-2, 18, 53, -5},
+  {-2, 16, 54, -4}, {-2, 15, 55, -4}, {-2, 14, 56, -4}, {-2, 12, 57, -3}, {-2, 10, 58, -2}, {-1, 7, 60, -2},
+  {0, 4, 62, -2},   {0, 2, 63, -1}};
+
+__device__ __forceinline__ int ilog2_dev(int v) { return 31 - __clz(v); }
+
+// Everything a lane needs to know about one candidate mode of a w x h block.
+struct mode_info {
+  int16_t mode;         // signalled mode (0 planar, 1 DC, 2..66 angular)
+  int16_t pred_mode;    // after wide-angle mapping (-14..80)
+  int8_t filtered;      // use the smoothed reference rows
+  int8_t vertical;      // pred_mode >= 34: work domain == block domain, else transposed
+  int16_t sample_disp;  // intraPredAngle
+  int16_t inv_disp;     // invAngle
+  int8_t scale;         // PDPC scale of the angular branch
+  int8_t use_cubic;
+  int8_t pdpc;
+  int8_t frac;          // (|sample_disp| & 31) != 0
+};
+
+// intra.c:637-658 + :690-726 + intra-generic.c:118-136,206-246
+__device__ inline mode_info make_mode_info(int mode, int w, int h, int is_chroma)
+{
+  const int lw = ilog2_dev(w), lh = ilog2_dev(h);
+  mode_info M;
+  M.mode = (int16_t)mode;
+  int pm = mode;
+  if (lw != lh && mode > 1 && mode <= 66) {
+    const int shift_tab[6] = {0, 6, 10, 12, 14, 15};
+    const int d = abs(lw - lh);
+    if (lw > lh && mode < 2 + shift_tab[d]) pm += 65;
+    else if (lh > lw && mode > 66 - shift_tab[d]) pm -= 65;
+  }
+  M.pred_mode = (int16_t)pm;
+  M.filtered = 0;
+  M.vertical = 1; M.sample_disp = 0; M.inv_disp = 0; M.scale = 0; M.use_cubic = 1; M.pdpc = 0; M.frac = 0;
+  if (mode >= 2) {
+    const int d50 = abs(pm - 50), d18 = abs(pm - 18);
+    const int dist = d50 < d18 ? d50 : d18;
+    const int thres = kDistThres[(lw + lh) >> 1];
+    const int vertical = pm >= 34;
+    const int mode_disp = vertical ? pm - 50 : 18 - pm;
+    const int amd = abs(mode_disp);
+    const int sd = (mode_disp < 0 ? -1 : 1) * kSampleDisp[amd];
+    if (!is_chroma && !(w == 4 && h == 4) && dist > thres) {
+      // int_fast8_t truncation of sample_disp in intra_predict_regular (intra.c:711)
+      const int sd8 = (int)(int8_t)sd;
+      if ((abs(sd8) & 31) == 0) M.filtered = 1;
+    }
+    M.vertical = (int8_t)vertical;
+    M.sample_disp = (int16_t)sd;
+    M.inv_disp = kInvDisp[amd];
+    const int side_log2 = vertical ? lh : lw;
+    int scale = side_log2 - kPreScale[amd];
+    if (scale > 2) scale = 2;
+    M.scale = (int8_t)scale;
+    M.frac = (abs(sd) & 31) != 0;
+    M.use_cubic = !(dist > thres && M.frac);
+    int pdpc = (w >= 4 && h >= 4);
+    if (sd != 0) {
+      if (pm > 1 && pm < 67) {
+        if (mode_disp < 0) pdpc = 0;
+        else if (mode_disp > 0) pdpc = pdpc && scale >= 0;
+      }
+    }
+    M.pdpc = (int8_t)pdpc;
+  } else if (mode == 0) {
+    M.filtered = !is_chroma && !(w == 4 && h == 4) && (w * h > 32);
+    M.pdpc = (w >= 4 && h >= 4);
+  } else {
+    M.pdpc = (w >= 4 && h >= 4);
+  }
+  return M;
+}
+
+// LDS image of one block's reference rows: [top | left | ftop | fleft], `refn` entries each.
+struct ref_rows {
+  const uint16_t *top, *left, *ftop, *fleft;
+};
+
+// Cooperative construction of the four reference rows of one block (threads tid0 + k*nthreads).
+template <typename PX>
+__device__ inline void build_ref_rows(const PX *__restrict__ rec, int stride, int x, int y, int w, int h,
+                                      int avail_top, int avail_left, uint16_t *top, uint16_t *left, int refn,
+                                      int tid, int nthreads)
+{
+  const int dc = 1 << (px_traits<PX>::depth - 1);
+  if (avail_left < 1) avail_left = 1;
+  if (avail_top < 1) avail_top = 1;
+  for (int i = tid; i < refn - 1; i += nthreads) {
+    int lv, tv;
+    if (x > 0) lv = rec[(size_t)(y + min(i, avail_left - 1)) * stride + x - 1];
+    else lv = y > 0 ? rec[(size_t)(y - 1) * stride + x] : dc;
+    if (y > 0) tv = rec[(size_t)(y - 1) * stride + x + min(i, avail_top - 1)];
+    else tv = x > 0 ? rec[(size_t)y * stride + x - 1] : dc;
+    left[1 + i] = (uint16_t)lv;
+    top[1 + i] = (uint16_t)tv;
+  }
+  if (tid == 0) {
+    int c;
+    if (x > 0 && y > 0) c = rec[(size_t)(y - 1) * stride + x - 1];
+    else if (x > 0) c = rec[(size_t)y * stride + x - 1];          // == left[1]
+    else c = y > 0 ? rec[(size_t)(y - 1) * stride + x] : dc;       // == left[1]
+    top[0] = left[0] = (uint16_t)c;
+  }
+}
+// intra.c:190-225 (needs the raw rows complete: call after a barrier)
+__device__ inline void filter_ref_rows(const uint16_t *top, const uint16_t *left, uint16_t *ftop, uint16_t *fleft,
+                                       int w, int h, int refn, int tid, int nthreads)
+{
+  for (int i = tid; i < refn; i += nthreads) {
+    int fl, ft;
+    if (i == 0) fl = ft = (left[1] + 2 * left[0] + top[1] + 2) >> 2;
+    else {
+      fl = i < 2 * h ? (left[i - 1] + 2 * left[i] + left[i + 1] + 2) >> 2 : left[i];
+      ft = i < 2 * w ? (top[i - 1] + 2 * top[i] + top[i + 1] + 2) >> 2 : top[i];
+    }
+    fleft[i] = (uint16_t)fl;
+    ftop[i] = (uint16_t)ft;
+  }
+}
+
+// intra.c:236-273
+__device__ inline int dc_value(const uint16_t *top, const uint16_t *left, int w, int h)
+{
+  int sum = 0;
+  if (w >= h) for (int i = 0; i < w; ++i) sum += top[1 + i];
+  if (w <= h) for (int j = 0; j < h; ++j) sum += left[1 + j];
+  const int denom = w == h ? w << 1 : max(w, h);
+  return (sum + (denom >> 1)) >> ilog2_dev(denom);
+}
+
+// NP consecutive predicted samples of one row of the WORK domain (for horizontal
+// modes the work domain is the transposed block): row yd, columns xd0..xd0+NP-1.
+// wd/hd: work-domain width/height.
+template <int NP>
+__device__ __forceinline__ void predict_row(const mode_info &M, const ref_rows &R, int dc, int is_chroma, int wd, int hd,
+                                            int yd, int xd0, int maxv, int (&out)[NP])
+{
+  const uint16_t *top = M.filtered ? R.ftop : R.top;
+  const uint16_t *left = M.filtered ? R.fleft : R.left;
+  if (M.mode < 2) {
+    const int lw = ilog2_dev(wd), lh = ilog2_dev(hd);
+    const int scale = (lw + lh - 2) >> 2;
+    const int sy = (yd << 1) >> scale, wt = 32 >> min(31, sy);
+    const int l = left[yd + 1];
+    if (M.mode == 0) {
+      const int tr = top[wd + 1], bl = left[hd + 1];
+      const int offset = 1 << (lw + lh), shift = 1 + lw + lh;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int x = xd0 + i, t = top[x + 1];
+        const int hor = (l << lw) + (x + 1) * (tr - l);
+        const int ver = (t << lh) + (yd + 1) * (bl - t);
+        out[i] = ((hor << lh) + (ver << lw) + offset) >> shift;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) out[i] = dc;
+    }
+    if (M.pdpc) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int x = xd0 + i, sx = (x << 1) >> scale, wl = 32 >> min(31, sx);
+        const int c = out[i];
+        out[i] = c + ((wl * (l - c) + wt * ((int)top[x + 1] - c) + 32) >> 6);
+      }
+    }
+    return;
+  }
+  // angular: main/side in the work domain
+  const uint16_t *mainr = M.vertical ? top : left;
+  const uint16_t *side = M.vertical ? left : top;
+  const int sd = M.sample_disp;
+  if (sd != 0) {
+    const int inv = M.inv_disp;
+    const int delta = sd * (yd + 1), di = delta >> 5, df = delta & 31;
+    auto ref = [&](int idx) -> int {
+      if (idx >= 0) return mainr[idx];
+      int s = (-idx * inv + 256) >> 9;      // projected side reference (intra-generic.c:156-159)
+      return side[min(s, hd)];
+    };
+    if (M.frac) {
+      if (!is_chroma) {
+        int f0, f1, f2, f3;
+        if (M.use_cubic) { f0 = kCubic[df][0]; f1 = kCubic[df][1]; f2 = kCubic[df][2]; f3 = kCubic[df][3]; }
+        else { f0 = 16 - (df >> 1); f1 = 32 - (df >> 1); f2 = 16 + (df >> 1); f3 = df >> 1; }
+        int p[NP + 3];
+#pragma unroll
+        for (int k = 0; k < NP + 3; ++k) p[k] = ref(di + xd0 + k);
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+          out[i] = clampi((f0 * p[i] + f1 * p[i + 1] + f2 * p[i + 2] + f3 * p[i + 3] + 32) >> 6, 0, maxv);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+          const int r1 = ref(xd0 + i + di + 1), r2 = ref(xd0 + i + di + 2);
+          out[i] = r1 + ((df * (r2 - r1) + 16) >> 5);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) out[i] = ref(xd0 + i + di + 1);
+    }
+    if (M.pdpc) {
+      const int scale = M.scale;
+      const int lim = min(3 << scale, wd);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int x = xd0 + i;
+        if (x < lim) {
+          const int inv_sum = 256 + (x + 1) * inv;
+          const int wl = 32 >> ((2 * x) >> scale);
+          const int l = side[yd + (inv_sum >> 9) + 1];
+          out[i] = out[i] + ((wl * (l - out[i]) + 32) >> 6);
+        }
+      }
+    }
+  } else {
+    const int lw = ilog2_dev(wd), lh = ilog2_dev(hd);
+    const int sc = (lw + lh - 2) >> 2;
+    const int tl = mainr[0], l = side[1 + yd];
+    const int lim = min(3 << sc, wd);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int x = xd0 + i;
+      int v = mainr[1 + x];
+      if (M.pdpc && x < lim) v = clampi(v + (((32 >> ((2 * x) >> sc)) * (l - tl) + 32) >> 6), 0, maxv);
+      out[i] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ prediction kernel ----
+// One workgroup per block; every (mode, work-domain row, 4-sample segment) is one thread task.
+template <typename PX>
+__global__ void __launch_bounds__(256)
+intra_pred_kernel(const PX *__restrict__ rec, int stride, int is_chroma, int w, int h,
+                  const uvghip_intra_blk_t *__restrict__ blks, const int8_t *__restrict__ modes, int n_modes,
+                  PX *__restrict__ out, int refn)
+{
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t *top = smem, *left = smem + refn, *ftop = smem + 2 * refn, *fleft = smem + 3 * refn;
+  mode_info *sM = reinterpret_cast<mode_info *>(smem + 4 * refn);
+  __shared__ int sDC;
+  const uvghip_intra_blk_t b = blks[blockIdx.x];
+  build_ref_rows<PX>(rec, stride, b.x, b.y, w, h, b.avail_top, b.avail_left, top, left, refn, threadIdx.x, blockDim.x);
+  for (int m = threadIdx.x; m < n_modes; m += blockDim.x) sM[m] = make_mode_info(modes[m], w, h, is_chroma);
+  __syncthreads();
+  filter_ref_rows(top, left, ftop, fleft, w, h, refn, threadIdx.x, blockDim.x);
+  if (threadIdx.x == 0) sDC = dc_value(top, left, w, h);
+  __syncthreads();
+  const ref_rows R{top, left, ftop, fleft};
+  const int maxv = px_traits<PX>::maxv;
+  const int wh = w * h, segs = wh / 4;
+  PX *o = out + (size_t)blockIdx.x * n_modes * wh;
+  for (int t = threadIdx.x; t < n_modes * segs; t += blockDim.x) {
+    const int m = t / segs, s = t - m * segs;
+    const mode_info M = sM[m];
+    const bool transposed = M.mode >= 2 && !M.vertical;
+    const int wd = transposed ? h : w, hd = transposed ? w : h;
+    const int yd = s / (wd / 4), xd0 = (s - yd * (wd / 4)) * 4;
+    int v[4];
+    predict_row<4>(M, R, sDC, is_chroma, wd, hd, yd, xd0, maxv, v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int px = transposed ? yd : xd0 + i, py = transposed ? xd0 + i : yd;
+      o[(size_t)m * wh + py * w + px] = (PX)v[i];
+    }
+  }
+}
+
+static int ref_len(int w, int h)
+{
+  // enough for every in-range read of angular_pred incl. wide angles (intra.c:855-858: 2*dim + (dim << s) + 2)
+  const int lw = 31 - __builtin_clz(w), lh = 31 - __builtin_clz(h);
+  const int st = lw > lh ? lw - lh : 0, sl = lh > lw ? lh - lw : 0;
+  int a = 2 * w + (w << st) + 4, b = 2 * h + (h << sl) + 4;
+  int r = a > b ? a : b;
+  r = (r + 7) & ~7;
+  return r > 352 ? 352 : r;   // uvg_intra_ref rows hold INTRA_REF_LENGTH = 358 samples (intra.h:46)
+}
+
+extern "C" int uvghip_intra_pred_batch(int bitdepth, const void *rec, int rec_stride, int is_chroma, int width, int height,
+                                       const uvghip_intra_blk_t *blks, int n, const int8_t *modes, int n_modes,
+                                       void *preds_out, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  auto ok = [](int v) { return v == 4 || v == 8 || v == 16 || v == 32; };
+  if (!ok(width) || !ok(height) || n_modes < 1 || n_modes > 128) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (n <= 0) return 0;
+  const int refn = ref_len(width, height);
+  const size_t lds = (size_t)4 * refn * 2 + (size_t)n_modes * sizeof(mode_info);
+  hipStream_t st = uvghip_stream(stream);
+  if (bitdepth == 8)
+    intra_pred_kernel<uint8_t><<<n, 256, lds, st>>>((const uint8_t *)rec, rec_stride, is_chroma, width, height, blks, modes, n_modes, (uint8_t *)preds_out, refn);
+  else
+    intra_pred_kernel<uint16_t><<<n, 256, lds, st>>>((const uint16_t *)rec, rec_stride, is_chroma, width, height, blks, modes, n_modes, (uint16_t *)preds_out, refn);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// ----------------------------------------------------------------------- search kernel ----
+template <int N>
+__device__ __forceinline__ void wht_rows_i(int (&v)[N], int r)
+{
+#pragma unroll
+  for (int half = N / 2; half >= 1; half >>= 1)
+#pragma unroll
+    for (int base = 0; base < N; base += 2 * half)
+#pragma unroll
+      for (int i = 0; i < half; ++i) {
+        const int p = v[base + i], q = v[base + i + half];
+        v[base + i] = p + q; v[base + i + half] = p - q;
+      }
+#pragma unroll
+  for (int m = N / 2; m >= 1; m >>= 1) {
+    const bool hi = (r & m) != 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int o = __shfl_xor(v[j], m, 64);
+      v[j] = hi ? (o - v[j]) : (v[j] + o);
+    }
+  }
+}
+
+// NP = 8: 8x8 tiles of an n x n block (n >= 8); NP = 4: the whole 4x4 block.
+template <typename PX, int NP>
+__global__ void __launch_bounds__(256)
+intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__restrict__ orig, int orig_stride,
+                    int n, const uvghip_intra_blk_t *__restrict__ blks, int n_blks, int bpg,
+                    const int8_t *__restrict__ modes, int n_modes, uint32_t *__restrict__ costs)
+{
+  constexpr int REFN = 104;   // 3*32 + 3 rounded up
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  // per block: 4 reference rows, orig, origT; then per block cost accumulators; then the mode table
+  const int nn = n * n;
+  const int per_blk_u16 = 4 * REFN + 2 * nn;
+  uint16_t *sBlk = smem;
+  int *sAcc = reinterpret_cast<int *>(smem + (size_t)bpg * per_blk_u16);      // [bpg][n_modes][2]
+  int *sDC = sAcc + (size_t)bpg * n_modes * 2;                                  // [bpg]
+  mode_info *sM = reinterpret_cast<mode_info *>(sDC + bpg);
+
+  const int blk0 = blockIdx.x * bpg;
+  const int here = min(bpg, n_blks - blk0);
+  if (here <= 0) return;
+
+  // ---- stage ----
+  const int tpb = blockDim.x / bpg;        // threads cooperating on one block
+  const int myb = threadIdx.x / tpb, mytid = threadIdx.x - myb * tpb;
+  if (myb < here) {
+    const uvghip_intra_blk_t b = blks[blk0 + myb];
+    uint16_t *base = sBlk + (size_t)myb * per_blk_u16;
+    build_ref_rows<PX>(rec, rec_stride, b.x, b.y, n, n, b.avail_top, b.avail_left, base, base + REFN, REFN, mytid, tpb);
+    uint16_t *so = base + 4 * REFN, *sot = so + nn;
+    for (int e = mytid; e < nn; e += tpb) {
+      const int yy = e / n, xx = e - yy * n;
+      const uint16_t v = orig[(size_t)(b.y + yy) * orig_stride + b.x + xx];
+      so[e] = v;
+      sot[xx * n + yy] = v;
+    }
+  }
+  for (int m = threadIdx.x; m < n_modes; m += blockDim.x) sM[m] = make_mode_info(modes[m], n, n, 0);
+  for (int e = threadIdx.x; e < here * n_modes * 2; e += blockDim.x) sAcc[e] = 0;
+  __syncthreads();
+  if (myb < here) {
+    uint16_t *base = sBlk + (size_t)myb * per_blk_u16;
+    filter_ref_rows(base, base + REFN, base + 2 * REFN, base + 3 * REFN, n, n, REFN, mytid, tpb);
+    if (mytid == 0) sDC[myb] = dc_value(base, base + REFN, n, n);
+  }
+  __syncthreads();
+
+  // ---- tasks: (block, mode, tile) per NP-lane group ----
+  const int maxv = px_traits<PX>::maxv;
+  const int tiles_x = n / NP, tiles = tiles_x * tiles_x;
+  const int ngroups = blockDim.x / NP;
+  const int g = threadIdx.x / NP, r = threadIdx.x & (NP - 1);
+  const int ntasks = here * n_modes * tiles;
+  const int rounds = (ntasks + ngroups - 1) / ngroups;
+  for (int it = 0; it < rounds; ++it) {
+    const int task = it * ngroups + g;
+    const bool on = task < ntasks;
+    int d[NP];
+    int b = 0, m = 0;
+    if (on) {
+      b = task / (n_modes * tiles);
+      const int rem = task - b * n_modes * tiles;
+      m = rem / tiles;
+      const int tile = rem - m * tiles, ty = tile / tiles_x, tx = tile - ty * tiles_x;
+      const mode_info M = sM[m];
+      const uint16_t *base = sBlk + (size_t)b * per_blk_u16;
+      const ref_rows R{base, base + REFN, base + 2 * REFN, base + 3 * REFN};
+      const bool transposed = M.mode >= 2 && !M.vertical;
+      const int yd = (transposed ? tx : ty) * NP + r, xd0 = (transposed ? ty : tx) * NP;
+      int p[NP];
+      predict_row<NP>(M, R, sDC[b], 0, n, n, yd, xd0, maxv, p);
+      const uint16_t *o = base + 4 * REFN + (transposed ? nn : 0) + yd * n + xd0;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) d[i] = (int)o[i] - p[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) d[i] = 0;
+    }
+    int sad = 0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) sad += abs(d[i]);
+    wht_rows_i<NP>(d, r);
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) s += abs(d[i]);
+    if (r == 0) s += (abs(d[0]) >> 2) - abs(d[0]);
+    for (int off = NP >> 1; off >= 1; off >>= 1) { s += __shfl_xor(s, off, 64); sad += __shfl_xor(sad, off, 64); }
+    const int satd = NP == 8 ? (s + 2) >> 2 : (s + 1) >> 1;   // picture-generic.c:345 / :197
+    if (on && r == 0) {
+      atomicAdd(&sAcc[(b * n_modes + m) * 2], satd);
+      atomicAdd(&sAcc[(b * n_modes + m) * 2 + 1], sad);
+    }
+  }
+  __syncthreads();
+  // search_intra.c:158: min(SATD, 2*SAD) with the NxN strategy functions' depth shifts
+  // (satd_4x4 is unshifted, picture-generic.c:170; everything else >> depth-8)
+  const int dshift = px_traits<PX>::depth - 8;
+  for (int e = threadIdx.x; e < here * n_modes; e += blockDim.x) {
+    const uint32_t satd = (uint32_t)sAcc[e * 2] >> (NP == 4 ? 0 : dshift);
+    const uint32_t sad = (uint32_t)sAcc[e * 2 + 1] >> dshift;
+    costs[(size_t)blk0 * n_modes + e] = min(satd, 2 * sad);
+  }
+}
+
+extern "C" int uvghip_intra_search_batch(int bitdepth, const void *rec, int rec_stride, const void *orig, int orig_stride,
+                                         int size, const uvghip_intra_blk_t *blks, int n, const int8_t *modes,
+                                         int n_modes, uint32_t *costs, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!(size == 4 || size == 8 || size == 16 || size == 32) || n_modes < 1 || n_modes > 128)
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (n <= 0) return 0;
+  const int bpg = size == 4 ? 8 : size == 8 ? 4 : 1;
+  const size_t lds = (size_t)bpg * (4 * 104 + 2 * size * size) * 2 + (size_t)bpg * n_modes * 2 * 4 +
+                     (size_t)n_modes * sizeof(mode_info) + (size_t)bpg * 4 + 16;
+  const int grid = (n + bpg - 1) / bpg;
+  hipStream_t st = uvghip_stream(stream);
+#define LAUNCH(PX, NP) intra_search_kernel<PX, NP><<<grid, 256, lds, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, blks, n, bpg, modes, n_modes, costs)
+  if (bitdepth == 8) { if (size == 4) LAUNCH(uint8_t, 4); else LAUNCH(uint8_t, 8); }
+  else { if (size == 4) LAUNCH(uint16_t, 4); else LAUNCH(uint16_t, 8); }
+#undef LAUNCH
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// =================================================== drop-in strategy layer ====
+// angular_pred_func / intra_pred_planar_func / pdpc_planar_dc_func
+// (src/strategies/strategies-intra.h:47-79).  The reference hands these
+// functions ready-made reference arrays, so the per-call path uploads the two
+// arrays, runs a one-block launch of a kernel that only predicts, and
+// downloads the block.
+namespace {
+
+template <typename PX>
+__global__ void __launch_bounds__(256)
+pred_from_rows_kernel(const PX *__restrict__ ref_top, const PX *__restrict__ ref_left, int refn, int kind, int mode,
+                      int is_chroma, int w, int h, int mrl, int isp, PX *__restrict__ dst)
+{
+  // kind 0: angular (mode = already wide-angle-corrected mode), 1: planar, 2: pdpc on dst (mode 0/1)
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  uint16_t *top = smem, *left = smem + refn;
+  for (int i = threadIdx.x; i < refn; i += blockDim.x) { top[i] = ref_top[i]; left[i] = ref_left[i]; }
+  __syncthreads();
+  const ref_rows R{top, left, top, left};
+  const int maxv = px_traits<PX>::maxv;
+  mode_info M;
+  if (kind == 0) {
+    // rebuild the angular parameters from the corrected mode (intra-generic.c:118-136,206-246)
+    const int lw = ilog2_dev(w), lh = ilog2_dev(h);
+    const int pm = mode, vertical = pm >= 34;
+    const int mode_disp = vertical ? pm - 50 : 18 - pm, amd = abs(mode_disp);
+    const int sd = (mode_disp < 0 ? -1 : 1) * kSampleDisp[amd];
+    const int d50 = abs(pm - 50), d18 = abs(pm - 18), dist = d50 < d18 ? d50 : d18;
+    M.mode = 2; M.pred_mode = (int16_t)pm; M.filtered = 0; M.vertical = (int8_t)vertical;
+    M.sample_disp = (int16_t)sd; M.inv_disp = kInvDisp[amd];
+    int scale = (vertical ? lh : lw) - kPreScale[amd]; if (scale > 2) scale = 2;
+    M.scale = (int8_t)scale; M.frac = (abs(sd) & 31) != 0;
+    M.use_cubic = !(dist > kDistThres[(lw + lh) >> 1] && M.frac);
+    int pdpc = (w >= 4 && h >= 4);
+    if (sd != 0 && pm > 1 && pm < 67) { if (mode_disp < 0) pdpc = 0; else if (mode_disp > 0) pdpc = pdpc && scale >= 0; }
+    M.pdpc = (int8_t)pdpc;
+  } else {
+    M = make_mode_info(kind == 1 ? 0 : mode, w, h, is_chroma);
+    M.filtered = 0;
+    if (kind == 1) M.pdpc = 0;      // uvg_intra_pred_planar alone does no PDPC
+  }
+  const bool transposed = kind == 0 && !M.vertical;
+  const int wd = transposed ? h : w, hd = transposed ? w : h;
+  const int segs = w * h / 4;
+  for (int s = threadIdx.x; s < segs; s += blockDim.x) {
+    const int yd = s / (wd / 4), xd0 = (s - yd * (wd / 4)) * 4;
+    int v[4];
+    if (kind == 2) {
+      // PDPC only: dst holds the un-combined prediction (intra-generic.c:429-435)
+      const int lw = ilog2_dev(w), lh = ilog2_dev(h), scale = (lw + lh - 2) >> 2;
+      const int wt = 32 >> min(31, (yd << 1) >> scale), l = left[yd + 1];
+      for (int i = 0; i < 4; ++i) {
+        const int x = xd0 + i, wl = 32 >> min(31, (x << 1) >> scale), c = dst[yd * w + x];
+        dst[yd * w + x] = (PX)(c + ((wl * (l - c) + wt * ((int)top[x + 1] - c) + 32) >> 6));
+      }
+      continue;
+    }
+    predict_row<4>(M, R, 0, is_chroma, wd, hd, yd, xd0, maxv, v);
+    for (int i = 0; i < 4; ++i) {
+      const int px = transposed ? yd : xd0 + i, py = transposed ? xd0 + i : yd;
+      dst[py * w + px] = (PX)v[i];
+    }
+  }
+}
+
+template <typename PX>
+void percall_rows(int kind, int mode, int is_chroma, int w, int h, const PX *ref_top, const PX *ref_left, PX *dst,
+                  int mrl, int isp)
+{
+  const int refn = ref_len(w, h);
+  const size_t rb = (size_t)refn * sizeof(PX), db = (size_t)w * h * sizeof(PX);
+  percall_ctx *c = percall_get(2 * rb + db + 1024);
+  const size_t ot = c->take(rb), ol = c->take(rb), od = c->take(db);
+  memcpy(c->hp<PX>(ot), ref_top, rb);
+  memcpy(c->hp<PX>(ol), ref_left, rb);
+  if (kind == 2) memcpy(c->hp<PX>(od), dst, db);
+  c->upload(0, c->used);
+  pred_from_rows_kernel<PX><<<1, 256, (size_t)2 * refn * 2, c->stream>>>(c->dp<PX>(ot), c->dp<PX>(ol), refn, kind, mode, is_chroma, w, h, mrl, isp, c->dp<PX>(od));
+  if (hipGetLastError() != hipSuccess) c->fail("intra launch");
+  c->download(od, db);
+  c->sync();
+  memcpy(dst, c->hp<PX>(od), db);
+}
+
+template <typename PX>
+void angular_pred_hip(const ref_cu_loc *cu_loc, const int_fast8_t intra_mode, const int_fast8_t channel_type,
+                      const PX *in_ref_above, const PX *in_ref_left, PX *dst, const uint8_t multi_ref_idx,
+                      const uint8_t isp_mode, const int cu_dim)
+{
+  const int w = channel_type == 0 ? cu_loc->width : cu_loc->chroma_width;
+  const int h = channel_type == 0 ? cu_loc->height : cu_loc->chroma_height;
+  if (multi_ref_idx || isp_mode || w < 4 || h < 4) {
+    fprintf(stderr, "uvg266hip: angular_pred with MRL/ISP/sub-4 blocks is not supported by the hip strategy; "
+                    "run with --no-mrl --no-isp or override UVG266_OVERRIDE_angular_pred=generic\n");
+    abort();
+  }
+  percall_rows<PX>(0, intra_mode, channel_type != 0, w, h, in_ref_above, in_ref_left, dst, 0, 0);
+}
+template <typename PX>
+void intra_pred_planar_hip(const ref_cu_loc *cu_loc, int color, const PX *ref_top, const PX *ref_left, PX *dst)
+{
+  const int w = color == 0 ? cu_loc->width : cu_loc->chroma_width, h = color == 0 ? cu_loc->height : cu_loc->chroma_height;
+  percall_rows<PX>(1, 0, color != 0, w, h, ref_top, ref_left, dst, 0, 0);
+}
+// uvg_intra_ref (intra.h:48-51): { uvg_pixel left[INTRA_REF_LENGTH]; uvg_pixel top[INTRA_REF_LENGTH]; }, INTRA_REF_LENGTH = 358
+template <typename PX>
+void pdpc_planar_dc_hip(const int mode, const ref_cu_loc *cu_loc, const int color, const PX *used_ref, PX *dst)
+{
+  const int w = color == 0 ? cu_loc->width : cu_loc->chroma_width, h = color == 0 ? cu_loc->height : cu_loc->chroma_height;
+  percall_rows<PX>(2, mode, color != 0, w, h, used_ref + 358, used_ref, dst, 0, 0);
+}
+
+}  // namespace
+
+// Not registered: intra_pred_filtered_dc (dead upstream), mip_predict (mip=0 in all target configs).
+extern "C" int uvg_strategy_register_intra_hip(void *opaque, uint8_t bitdepth)
+{
+  if (!uvghip_ready() && uvghip_init(0) != 0) return 0;
+  int ok = 1;
+  if (bitdepth == 8) {
+    ok &= uvghip_do_register(opaque, "angular_pred", (void *)&angular_pred_hip<uint8_t>);
+    ok &= uvghip_do_register(opaque, "intra_pred_planar", (void *)&intra_pred_planar_hip<uint8_t>);
+    ok &= uvghip_do_register(opaque, "pdpc_planar_dc", (void *)&pdpc_planar_dc_hip<uint8_t>);
+  } else {
+    ok &= uvghip_do_register(opaque, "angular_pred", (void *)&angular_pred_hip<uint16_t>);
+    ok &= uvghip_do_register(opaque, "intra_pred_planar", (void *)&intra_pred_planar_hip<uint16_t>);
+    ok &= uvghip_do_register(opaque, "pdpc_planar_dc", (void *)&pdpc_planar_dc_hip<uint16_t>);
+  }
+  return ok;
+}

@@ -42,6 +42,9 @@ SIGNATURES = {
     "uvghip_coeff_abs_sum_batch": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "uvghip_fast_coeff_cost_batch": (c_int, [c_vp, c_int, c_int, c_int, ctypes.c_uint64, c_vp, c_vp]),
     "uvghip_tu_roundtrip_batch": (c_int, [c_int] * 9 + [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "uvg_strategy_register_intra_hip": (c_int, [c_vp, ctypes.c_uint8]),
+    "uvghip_intra_pred_batch": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_intra_search_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_sad_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_satd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_ssd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
