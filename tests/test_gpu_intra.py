@@ -61,7 +61,7 @@ def test_pred_batch_vs_oracle_incl_wide_angles(hip, orc, depth, shape, chroma):
     Hh, W = 96, 160
     rec = rand_plane(rng, Hh, W, depth)
     rows = [[0, 0, 0, 0], [w, 0, 0, h], [0, h, w, 0], [w, h, 2 * w, 2 * h], [2 * w, h, w, h], [W - w, Hh - h, w, h], [3 * w, 2 * h, w + 4, h + 4]]
-    rows = [r for r in rows if r[0] + w <= W and r[1] + h <= Hh]
+    rows = [[x, y, min(at, W - x), min(al, Hh - y)] for x, y, at, al in rows if x + w <= W and y + h <= Hh]
     got = api.intra_pred_batch(dev(rec), api.make_intra_blocks(rows), w, h, api.make_modes(ALL_MODES), chroma).cpu().numpy()
     for i, (x, y, at, al) in enumerate(rows):
         top, left = orc.intra_build_refs(depth, rec, W, Hh, x, y, w, h, at, al)
