@@ -215,6 +215,19 @@ UVGHIP_API int uvghip_intra_search_batch(int bitdepth, const void *rec, int rec_
                               int size, const uvghip_intra_blk_t *blks, int n, const int8_t *modes, int n_modes,
                               uint32_t *costs, void *stream);
 
+/* As uvghip_intra_pred_batch for square luma blocks, but every block has its own decided mode
+ * (modes[i]) and the prediction is written into `pred_plane` at the block's position: the
+ * predict step of uvg_intra_recon_cu (src/intra.c:1537-1580). */
+UVGHIP_API int uvghip_intra_pred_plane_batch(int bitdepth, const void *rec, int rec_stride, int size,
+                                  const uvghip_intra_blk_t *blks, int n, const int8_t *modes,
+                                  void *pred_plane, int pred_stride, void *stream);
+
+/* Picks, per block, the candidate with the smallest cost; ties keep the earlier candidate, like
+ * the strict "<" scans of search_intra_rough (src/search_intra.c:1089-1101).
+ * best_mode[i] = modes[argmin_m costs[i*n_modes+m]], best_cost (may be NULL) the minimum. */
+UVGHIP_API int uvghip_intra_select_best(const uint32_t *costs, int n, const int8_t *modes, int n_modes,
+                             int8_t *best_mode, uint32_t *best_cost, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

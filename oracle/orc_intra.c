@@ -321,3 +321,38 @@ ORC_EXPORT void ORC_FN(intra_mode_costs)(const orc_px *rec, int stride, int pic_
     if (preds_out) memcpy(preds_out + (size_t)m * n * n, pred, (size_t)n * n * sizeof(orc_px));
   }
 }
+
+/*
+ * Frame-level driver used by bench.py's cpu_baseline leg and by tests: rough
+ * search costs of every n x n block of a plane (raster order), OpenMP over
+ * blocks.  blks: n_blks x 4 int32 (x, y, avail_top, avail_left).
+ */
+ORC_EXPORT void ORC_FN(intra_search_frame)(const orc_px *rec, int rec_stride, const orc_px *orig, int orig_stride,
+                                           int pic_w, int pic_h, int n, const int32_t *blks, int n_blks,
+                                           const int8_t *modes, int n_modes, uint32_t *costs)
+{
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int b = 0; b < n_blks; ++b) {
+    orc_px o[32 * 32];
+    const int x = blks[4 * b], y = blks[4 * b + 1];
+    for (int yy = 0; yy < n; ++yy) memcpy(o + yy * n, orig + (size_t)(y + yy) * orig_stride + x, (size_t)n * sizeof(orc_px));
+    ORC_FN(intra_mode_costs)(rec, rec_stride, pic_w, pic_h, x, y, n, blks[4 * b + 2], blks[4 * b + 3], o, modes, n_modes,
+                             costs + (size_t)b * n_modes, NULL);
+  }
+}
+
+/* Frame-level driver: predict every n x n block with its own mode into a plane (bench cpu_baseline). */
+ORC_EXPORT void ORC_FN(intra_pred_plane_frame)(const orc_px *rec, int rec_stride, int pic_w, int pic_h, int n,
+                                               const int32_t *blks, int n_blks, const int8_t *block_modes,
+                                               orc_px *pred, int pred_stride)
+{
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int b = 0; b < n_blks; ++b) {
+    orc_px top[REF_LEN], left[REF_LEN], ftop[REF_LEN], fleft[REF_LEN], p[32 * 32];
+    const int x = blks[4 * b], y = blks[4 * b + 1];
+    ORC_FN(intra_build_refs)(rec, rec_stride, pic_w, pic_h, x, y, n, n, blks[4 * b + 2], blks[4 * b + 3], top, left);
+    ORC_FN(intra_filter_refs)(top, left, n, n, ftop, fleft);
+    ORC_FN(intra_predict)(block_modes[b], 0, n, n, top, left, ftop, fleft, p);
+    for (int yy = 0; yy < n; ++yy) memcpy(pred + (size_t)(y + yy) * pred_stride + x, p + yy * n, (size_t)n * sizeof(orc_px));
+  }
+}

@@ -114,3 +114,16 @@ ORC_EXPORT int ORC_FN(tu_roundtrip)(int bitdepth, int hor, int ver, int skip_w, 
   }
   return has;
 }
+
+/* Frame-level driver (bench cpu_baseline / tests): TU round trip of n_tus w x h TUs, OpenMP over TUs. */
+ORC_EXPORT void ORC_FN(tu_roundtrip_frame)(int bitdepth, int width, int height, int qp_scaled, int slice_is_intra,
+                                           const orc_px *orig, const orc_px *pred, orc_px *rec, int stride,
+                                           const int32_t *tus, int n_tus, int16_t *coeff_out)
+{
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int i = 0; i < n_tus; ++i) {
+    const size_t off = (size_t)tus[2 * i + 1] * stride + tus[2 * i];
+    ORC_FN(tu_roundtrip)(bitdepth, 0, 0, 0, 0, width, height, qp_scaled, slice_is_intra, orig + off, pred + off, stride,
+                         rec + off, stride, coeff_out + (size_t)i * width * height);
+  }
+}

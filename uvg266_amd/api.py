@@ -200,3 +200,23 @@ def intra_search_batch(rec, orig, blks, size, modes):
                                            _dev(blks), n, _dev(modes), nm, _dev(out), _stream()),
                "uvghip_intra_search_batch")
     return out
+
+
+def intra_pred_plane_batch(rec, blks, size, block_modes, pred_plane):
+    """Predict every block with its own mode (block_modes: (n,) int8) into `pred_plane` (in place)."""
+    L = _lib.init(rec.device.index or 0)
+    _lib.check(L.uvghip_intra_pred_plane_batch(_depth(rec), _dev(rec), rec.stride(0), size, _dev(blks), blks.shape[0],
+                                               _dev(block_modes), _dev(pred_plane), pred_plane.stride(0), _stream()),
+               "uvghip_intra_pred_plane_batch")
+    return pred_plane
+
+
+def intra_select_best(costs, modes):
+    """-> (best_mode (n,) int8, best_cost (n,) int32); ties keep the earlier candidate."""
+    L = _lib.init(costs.device.index or 0)
+    n, nm = costs.shape
+    bm = torch.empty(n, dtype=torch.int8, device=costs.device)
+    bc = torch.empty(n, dtype=torch.int32, device=costs.device)
+    _lib.check(L.uvghip_intra_select_best(_dev(costs), n, _dev(modes), nm, _dev(bm), _dev(bc), _stream()),
+               "uvghip_intra_select_best")
+    return bm, bc

@@ -338,6 +338,94 @@ extern "C" int uvghip_intra_pred_batch(int bitdepth, const void *rec, int rec_st
   UVGHIP_CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------ per-block-mode plane kernel ----
+// Each block carries its own (already decided) mode; the prediction is written into a plane at
+// the block's position -- what uvg_intra_recon_cu's predict step leaves in lcu->rec (intra.c:1537).
+template <typename PX>
+__global__ void __launch_bounds__(256)
+intra_pred_plane_kernel(const PX *__restrict__ rec, int stride, int n, const uvghip_intra_blk_t *__restrict__ blks,
+                        int n_blks, int bpg, const int8_t *__restrict__ modes, PX *__restrict__ out, int out_stride)
+{
+  constexpr int REFN = 104;
+  __shared__ __attribute__((aligned(16))) uint16_t sRef[8 * 4 * REFN];
+  __shared__ mode_info sM[8];
+  __shared__ int sDC[8], sX[8], sY[8];
+  const int blk0 = blockIdx.x * bpg;
+  const int here = min(bpg, n_blks - blk0);
+  if (here <= 0) return;
+  const int tpb = blockDim.x / bpg;
+  const int myb = threadIdx.x / tpb, mytid = threadIdx.x - myb * tpb;
+  uint16_t *base = sRef + myb * 4 * REFN;
+  if (myb < here) {
+    const uvghip_intra_blk_t b = blks[blk0 + myb];
+    build_ref_rows<PX>(rec, stride, b.x, b.y, n, n, b.avail_top, b.avail_left, base, base + REFN, REFN, mytid, tpb);
+    if (mytid == 0) { sM[myb] = make_mode_info(modes[blk0 + myb], n, n, 0); sX[myb] = b.x; sY[myb] = b.y; }
+  }
+  __syncthreads();
+  if (myb < here) {
+    filter_ref_rows(base, base + REFN, base + 2 * REFN, base + 3 * REFN, n, n, REFN, mytid, tpb);
+    if (mytid == 0) sDC[myb] = dc_value(base, base + REFN, n, n);
+  }
+  __syncthreads();
+  if (myb >= here) return;
+  const ref_rows R{base, base + REFN, base + 2 * REFN, base + 3 * REFN};
+  const mode_info M = sM[myb];
+  const bool transposed = M.mode >= 2 && !M.vertical;
+  const int maxv = px_traits<PX>::maxv;
+  const int segs = n * n / 4;
+  for (int s = mytid; s < segs; s += tpb) {
+    const int yd = s / (n / 4), xd0 = (s - yd * (n / 4)) * 4;
+    int v[4];
+    predict_row<4>(M, R, sDC[myb], 0, n, n, yd, xd0, maxv, v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int px = transposed ? yd : xd0 + i, py = transposed ? xd0 + i : yd;
+      out[(size_t)(sY[myb] + py) * out_stride + sX[myb] + px] = (PX)v[i];
+    }
+  }
+}
+
+extern "C" int uvghip_intra_pred_plane_batch(int bitdepth, const void *rec, int rec_stride, int size,
+                                             const uvghip_intra_blk_t *blks, int n, const int8_t *modes,
+                                             void *pred_plane, int pred_stride, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!(size == 4 || size == 8 || size == 16 || size == 32)) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (n <= 0) return 0;
+  const int bpg = size == 4 ? 8 : size == 8 ? 4 : size == 16 ? 2 : 1;
+  const int grid = (n + bpg - 1) / bpg;
+  hipStream_t st = uvghip_stream(stream);
+  if (bitdepth == 8)
+    intra_pred_plane_kernel<uint8_t><<<grid, 256, 0, st>>>((const uint8_t *)rec, rec_stride, size, blks, n, bpg, modes, (uint8_t *)pred_plane, pred_stride);
+  else
+    intra_pred_plane_kernel<uint16_t><<<grid, 256, 0, st>>>((const uint16_t *)rec, rec_stride, size, blks, n, bpg, modes, (uint16_t *)pred_plane, pred_stride);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// costs[n][n_modes] -> best[n] = index (into the mode list) of the first minimum, the tie-break of
+// the reference's strict "<" scans (search_intra.c:1089-1101 keeps the earlier candidate on ties)
+__global__ void __launch_bounds__(256)
+argmin_rows_kernel(const uint32_t *__restrict__ costs, int n, int n_modes, const int8_t *__restrict__ modes,
+                   int8_t *__restrict__ best_mode, uint32_t *__restrict__ best_cost)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t *c = costs + (size_t)i * n_modes;
+  uint32_t bc = c[0]; int bi = 0;
+  for (int m = 1; m < n_modes; ++m) if (c[m] < bc) { bc = c[m]; bi = m; }
+  best_mode[i] = modes[bi];
+  if (best_cost) best_cost[i] = bc;
+}
+
+extern "C" int uvghip_intra_select_best(const uint32_t *costs, int n, const int8_t *modes, int n_modes,
+                                        int8_t *best_mode, uint32_t *best_cost, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (n <= 0) return 0;
+  argmin_rows_kernel<<<(n + 255) / 256, 256, 0, uvghip_stream(stream)>>>(costs, n, n_modes, modes, best_mode, best_cost);
+  UVGHIP_CHECK_LAUNCH();
+}
+
 // ----------------------------------------------------------------------- search kernel ----
 template <int N>
 __device__ __forceinline__ void wht_rows_i(int (&v)[N], int r)
