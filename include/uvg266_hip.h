@@ -228,6 +228,41 @@ UVGHIP_API int uvghip_intra_pred_plane_batch(int bitdepth, const void *rec, int 
 UVGHIP_API int uvghip_intra_select_best(const uint32_t *costs, int n, const int8_t *modes, int n_modes,
                              int8_t *best_mode, uint32_t *best_cost, void *stream);
 
+/* ------------------------------------ (2) batched ABI: interpolation ------- */
+
+/* One motion-compensated block: (x,y) = integer sample position of the block's
+ * top-left in the reference plane (block position + (mv >> 4), may lie outside
+ * the picture: edge replication as uvg_get_extended_block, ipol-generic.c:761),
+ * fx,fy = fractional phase (luma: mv & 15, chroma: mv & 31). */
+typedef struct uvghip_mc_blk {
+  int32_t x, y;
+  int32_t fx, fy;
+} uvghip_mc_blk_t;
+
+/* replaces: uvg_get_extended_block + uvg_sample_quarterpel_luma(_hi) /
+ * uvg_sample_octpel_chroma(_hi) (src/strategies/generic/ipol-generic.c:134-211,
+ * 681-758; callers src/inter.c:107-330).  dst: n contiguous blocks of
+ * width*height; pixels when hi == 0, int16 14-bit intermediates when hi != 0. */
+UVGHIP_API int uvghip_mc_batch(int bitdepth, const void *ref, int ref_stride, int pic_w, int pic_h, int is_chroma,
+                    int width, int height, const uvghip_mc_blk_t *blks, int n, int hi, void *dst, void *stream);
+
+/* replaces: one or more steps of search_frac (src/search_inter.c:1029-1216):
+ * uvg_filter_{hpel,qpel}_blocks_{hor_ver,diag}_luma + uvg_satd_any_size_quad.
+ * For block i (cur position / integer-MV reference position in blks[i]) and
+ * each of the n_cand displacements cand_mv[2c], cand_mv[2c+1] (1/16 sample
+ * units, |mv| <= 15, shared by all blocks):
+ *   costs[i*n_cand + c] = SATD(cur block, prediction at ref + mv)
+ * which is what the reference obtains from filtered[j] of the step that owns
+ * that displacement.  width,height: multiples of 4, <= 64. */
+UVGHIP_API int uvghip_frac_satd_batch(int bitdepth, const void *cur, int cur_stride, const void *ref, int ref_stride,
+                           int pic_w, int pic_h, int width, int height, const uvghip_blk_t *blks, int n,
+                           const int16_t *cand_mv, int n_cand, uint32_t *costs, void *stream);
+
+/* replaces: bipred_average_px_px / _im_im / _px_im (picture-generic.c:1132-1193)
+ * on flat arrays of `total` samples.  mode bit0: l0 is int16 14-bit, bit1: l1 is. */
+UVGHIP_API int uvghip_bipred_average_batch(int bitdepth, const void *l0, const void *l1, int mode, size_t total,
+                                void *dst, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -177,6 +177,26 @@ class Oracle:
         return (costs, preds) if want_preds else costs
 
 
+    # ---- ipol --------------------------------------------------------------
+    def ipol_sample(self, d, ref, pic_w, pic_h, x0, y0, w, h, fx, fy, chroma=False, hi=False):
+        out = np.zeros(w * h, np.int16 if hi else ref.dtype)
+        self.fn(d, "ipol_sample", None)(ptr(ref), ref.shape[1], pic_w, pic_h, x0, y0, w, h, fx, fy, int(chroma), int(hi), ptr(out), w)
+        return out
+
+    def frac_satd(self, d, cur, cx, cy, ref, pic_w, pic_h, rx, ry, w, h, cands):
+        cands = np.ascontiguousarray(np.asarray(cands, np.int16).reshape(-1, 2))
+        costs = np.zeros(len(cands), np.uint32)
+        self.fn(d, "frac_satd", None)(ptr(cur), cur.shape[1], cx, cy, ptr(ref), ref.shape[1], pic_w, pic_h, rx, ry, w, h,
+                                      ptr(cands), len(cands), ptr(costs))
+        return costs
+
+    def bipred_average(self, d, l0, l1, w, h):
+        out = np.zeros(w * h, px_dtype(d))
+        mode = (1 if l0.dtype == np.int16 else 0) | (2 if l1.dtype == np.int16 else 0)
+        self.fn(d, "bipred_average", None)(ptr(out), w, ptr(l0), ptr(l1), mode, w, h)
+        return out
+
+
 # ---- golden container (written by tools/refcheck/refcheck.c) ----------------
 _DT = {0: np.uint8, 1: np.uint16, 2: np.int16, 3: np.int32, 4: np.uint32, 5: np.int64, 6: np.float64}
 

@@ -1,0 +1,103 @@
+"""HIP interpolation (MC, fractional-ME SATD, bi-pred average) vs oracle / reference goldens."""
+import numpy as np
+import pytest
+
+import helpers as H
+from test_gpu_picture import dev, rand_plane
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_vs_reference_goldens(hip, depth):
+    from uvg266_amd import api
+    ns = nf = 0
+    for name, arrs in H.read_golden("ipol", depth):
+        if name == "sample":
+            (PW, PH, x0, y0, w, h, fx, fy, chroma, _), plane, px, hi = arrs
+            w, h = int(w), int(h)
+            d = dev(plane.reshape(PH, PW))
+            blk = api.make_mc_blocks([[x0, y0, fx, fy]])
+            assert np.array_equal(api.mc_batch(d, blk, w, h, is_chroma=bool(chroma)).cpu().numpy().ravel(), px)
+            assert np.array_equal(api.mc_batch(d, blk, w, h, is_chroma=bool(chroma), hi=True).cpu().numpy().ravel(), hi)
+            ns += 1
+        elif name == "fme":
+            (PW, PH, bx, by, w, h), plane, cur, cands, costs = arrs
+            got = api.frac_satd_batch(dev(cur.reshape(64, 64)), dev(plane.reshape(PH, PW)), api.make_blocks([[0, 0]], [[bx, by]]),
+                                      int(w), int(h), dev(cands.reshape(-1, 2))).cpu().numpy().ravel()
+            assert np.array_equal(got.astype(np.uint32), costs)
+            nf += 1
+    assert ns >= 30 and nf >= 15
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("shape", [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 32), (12, 16), (4, 8)])
+def test_mc_batch_vs_oracle(hip, orc, depth, shape):
+    from uvg266_amd import api
+    w, h = shape
+    rng = np.random.default_rng(w + h * 3 + depth)
+    PH, PW = 120, 168
+    ref = rand_plane(rng, PH, PW, depth)
+    n = 29
+    for chroma in (False, True):
+        if chroma and w > 32:
+            continue
+        rows = np.stack([rng.integers(-w - 4, PW + 4, n), rng.integers(-h - 4, PH + 4, n),
+                         rng.integers(0, 32 if chroma else 16, n), rng.integers(0, 32 if chroma else 16, n)], 1)
+        got = api.mc_batch(dev(ref), api.make_mc_blocks(rows), w, h, is_chroma=chroma).cpu().numpy()
+        goth = api.mc_batch(dev(ref), api.make_mc_blocks(rows), w, h, is_chroma=chroma, hi=True).cpu().numpy()
+        for i, (x0, y0, fx, fy) in enumerate(rows):
+            assert np.array_equal(got[i].ravel(), orc.ipol_sample(depth, ref, PW, PH, x0, y0, w, h, fx, fy, chroma, False))
+            assert np.array_equal(goth[i].ravel(), orc.ipol_sample(depth, ref, PW, PH, x0, y0, w, h, fx, fy, chroma, True))
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("shape", [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 16), (12, 12), (4, 4), (16, 4)])
+def test_frac_satd_batch_vs_oracle(hip, orc, depth, shape):
+    from uvg266_amd import api
+    w, h = shape
+    rng = np.random.default_rng(w * 5 + h + depth)
+    PH, PW = 136, 200
+    cur = rand_plane(rng, PH, PW, depth)
+    ref = np.roll(cur, (1, -2), (0, 1))
+    ref = np.clip(ref.astype(np.int32) + rng.integers(-3, 4, ref.shape), 0, (1 << depth) - 1).astype(cur.dtype)
+    n = 17
+    cxy = np.stack([rng.integers(0, PW - w + 1, n), rng.integers(0, PH - h + 1, n)], 1)
+    rxy = cxy + rng.integers(-6, 7, (n, 2))
+    rxy[:3] = [[-3, -2], [PW - w + 2, PH - h + 3], [0, PH - h + 1]]
+    cands = [(dx, dy) for dy in (-12, -8, -4, 0, 4, 8, 12) for dx in (-12, -8, -4, 0, 4, 8, 12)]   # the whole quarter-sample grid
+    got = api.frac_satd_batch(dev(cur), dev(ref), api.make_blocks(cxy, rxy), w, h, dev(np.array(cands, np.int16))).cpu().numpy()
+    for i in range(n):
+        want = orc.frac_satd(depth, cur, cxy[i, 0], cxy[i, 1], ref, PW, PH, rxy[i, 0], rxy[i, 1], w, h, cands)
+        assert np.array_equal(got[i].astype(np.uint32), want), i
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_bipred_average(hip, orc, depth):
+    from uvg266_amd import api
+    rng = np.random.default_rng(depth)
+    w, h = 16, 8
+    px0 = rng.integers(0, 1 << depth, w * h).astype(H.px_dtype(depth)); px1 = rng.integers(0, 1 << depth, w * h).astype(H.px_dtype(depth))
+    im0 = rng.integers(-2000, 18000, w * h).astype(np.int16); im1 = rng.integers(-2000, 18000, w * h).astype(np.int16)
+    for a, b in ((px0, px1), (im0, im1), (px0, im1), (im0, px1)):
+        if depth == 10 and (a.dtype == np.uint16 or b.dtype == np.uint16):
+            # 10-bit pixels are uint16 on the host; the api distinguishes operands by dtype (int16 = intermediate)
+            pass
+        got = api.bipred_average_batch(dev(a), dev(b), depth).cpu().numpy()
+        assert np.array_equal(got, orc.bipred_average(depth, a, b, w, h))
+
+
+def test_full_size_shift_property(hip):
+    """1080p: a reference that is the current picture shifted by a whole sample is found with zero SATD at
+    the matching integer candidate, and the half-sample candidates cost more (size-independent property)."""
+    import torch
+    from uvg266_amd import api
+    rng = np.random.default_rng(3)
+    Hh, W = 1080, 1920
+    cur = rand_plane(rng, Hh, W, 8)
+    ref = np.roll(cur, -1, 1)                     # ref(x) = cur(x+1)  -> best displacement is -1 sample = -16
+    xs, ys = np.meshgrid(np.arange(16, W - 32, 16), np.arange(16, Hh - 32, 16))
+    cxy = np.stack([xs.ravel(), ys.ravel()], 1)
+    cands = np.array([[0, 0], [-8, 0], [8, 0], [-12, 0], [-4, 0]], np.int16)
+    c = api.frac_satd_batch(dev(cur), dev(ref), api.make_blocks(cxy, cxy - [1, 0]), 16, 16, dev(cands))
+    assert int(c[:, 0].sum()) == 0 and int(c[:, 1:].min()) > 0

@@ -220,3 +220,44 @@ def intra_select_best(costs, modes):
     _lib.check(L.uvghip_intra_select_best(_dev(costs), n, _dev(modes), nm, _dev(bm), _dev(bc), _stream()),
                "uvghip_intra_select_best")
     return bm, bc
+
+
+# ---- interpolation ---------------------------------------------------------------
+def make_mc_blocks(xyff, device="cuda"):
+    """(n,4) rows (x, y, fx, fy) -> device array of uvghip_mc_blk_t."""
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(xyff, np.int32).reshape(-1, 4))).to(device)
+
+
+def mc_batch(ref, blks, w, h, pic_w=None, pic_h=None, is_chroma=False, hi=False):
+    """Motion-compensated blocks -> (n, h, w) pixels, or int16 14-bit intermediates when hi."""
+    L = _lib.init(ref.device.index or 0)
+    n = blks.shape[0]
+    pic_w = ref.shape[1] if pic_w is None else pic_w
+    pic_h = ref.shape[0] if pic_h is None else pic_h
+    out = torch.empty((n, h, w), dtype=torch.int16 if hi else ref.dtype, device=ref.device)
+    _lib.check(L.uvghip_mc_batch(_depth(ref), _dev(ref), ref.stride(0), pic_w, pic_h, int(is_chroma), w, h, _dev(blks), n,
+                                 int(hi), _dev(out), _stream()), "uvghip_mc_batch")
+    return out
+
+
+def frac_satd_batch(cur, ref, blks, w, h, cand_mv, pic_w=None, pic_h=None):
+    """-> (n, n_cand) SATD costs of the fractional-ME candidates cand_mv ((k,2) int16, 1/16 units)."""
+    L = _lib.init(ref.device.index or 0)
+    n, k = blks.shape[0], cand_mv.shape[0]
+    pic_w = ref.shape[1] if pic_w is None else pic_w
+    pic_h = ref.shape[0] if pic_h is None else pic_h
+    out = torch.empty((n, k), dtype=torch.int32, device=ref.device)
+    _lib.check(L.uvghip_frac_satd_batch(_depth(ref), _dev(cur), cur.stride(0), _dev(ref), ref.stride(0), pic_w, pic_h, w, h,
+                                        _dev(blks), n, _dev(cand_mv), k, _dev(out), _stream()), "uvghip_frac_satd_batch")
+    return out
+
+
+def bipred_average_batch(l0, l1, bitdepth):
+    """l0/l1: flat tensors, pixel dtype or int16 (14-bit) each -> pixels."""
+    L = _lib.init(l0.device.index or 0)
+    pxdt = torch.uint8 if bitdepth == 8 else torch.uint16
+    mode = (1 if l0.dtype == torch.int16 else 0) | (2 if l1.dtype == torch.int16 else 0)
+    out = torch.empty(l0.numel(), dtype=pxdt, device=l0.device)
+    _lib.check(L.uvghip_bipred_average_batch(bitdepth, _dev(l0), _dev(l1), mode, l0.numel(), _dev(out), _stream()),
+               "uvghip_bipred_average_batch")
+    return out

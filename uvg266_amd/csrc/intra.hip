@@ -24,6 +24,7 @@
 #include "uvghip_common.h"
 #include "percall.h"
 #include "ref_abi.h"
+#include "satd_dev.h"
 
 // ---- constant tables (H.266 8.4.5.2.13: intraPredAngle, invAngle; table 25 fC) -------------
 __device__ static const int16_t kSampleDisp[32] = {0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 18, 20, 23, 26, 29, 32, 35, 39, 45, 51,
@@ -427,29 +428,6 @@ extern "C" int uvghip_intra_select_best(const uint32_t *costs, int n, const int8
 }
 
 // ----------------------------------------------------------------------- search kernel ----
-template <int N>
-__device__ __forceinline__ void wht_rows_i(int (&v)[N], int r)
-{
-#pragma unroll
-  for (int half = N / 2; half >= 1; half >>= 1)
-#pragma unroll
-    for (int base = 0; base < N; base += 2 * half)
-#pragma unroll
-      for (int i = 0; i < half; ++i) {
-        const int p = v[base + i], q = v[base + i + half];
-        v[base + i] = p + q; v[base + i + half] = p - q;
-      }
-#pragma unroll
-  for (int m = N / 2; m >= 1; m >>= 1) {
-    const bool hi = (r & m) != 0;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const int o = __shfl_xor(v[j], m, 64);
-      v[j] = hi ? (o - v[j]) : (v[j] + o);
-    }
-  }
-}
-
 // NP = 8: 8x8 tiles of an n x n block (n >= 8); NP = 4: the whole 4x4 block.
 template <typename PX, int NP>
 __global__ void __launch_bounds__(256)
@@ -530,7 +508,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
     int sad = 0;
 #pragma unroll
     for (int i = 0; i < NP; ++i) sad += abs(d[i]);
-    wht_rows_i<NP>(d, r);
+    wht_rows<NP>(d, r);
     int s = 0;
 #pragma unroll
     for (int i = 0; i < NP; ++i) s += abs(d[i]);

@@ -1,0 +1,190 @@
+// "ipol" strategy group on gfx950: sub-sample interpolation for motion
+// compensation and fractional motion estimation.
+// Bit-exact with src/strategies/generic/ipol-generic.c:
+//   sample_quarterpel_luma(_hi) :134-211   8-tap, 1/16 phases (filter.c:62-80)
+//   sample_octpel_chroma(_hi)   :681-758   4-tap, 1/32 phases (filter.c:82-116)
+//   get_extended_block          :761-810   = edge-replicated reads, done here by coordinate clamping
+//   filter_hpel/qpel_blocks_*   :213-679   the four candidate blocks of each fractional-ME step are the
+//        predictions at +-1/2 and +-1/4 sample offsets (search_inter.c:1133-1216); uvghip_frac_satd_batch
+//        evaluates any list of such offsets and returns the SATD the search compares (:1172).
+//   bipred_average              picture-generic.c:1132-1247
+//
+// Data flow: per block the (w+7) x (h+7) reference window (+1 for fractional
+// ME) is read from HBM once into LDS with edge replication; the horizontal
+// pass writes int16 intermediates to LDS, the vertical pass reads them back
+// and either stores the block (MC) or feeds the row-per-lane Hadamard (ME).
+#include "uvghip_common.h"
+#include "percall.h"
+#include "satd_dev.h"
+#include "vvc_tables.h"
+
+// Stage ref[(y0+yy), (x0+xx)] for yy < wh, xx < ww into LDS (pitch wp), clamped to the picture.
+template <typename PX>
+__device__ __forceinline__ void stage_window(const PX *__restrict__ ref, int stride, int pic_w, int pic_h, int x0, int y0,
+                                             int ww, int wh, uint16_t *win, int wp)
+{
+  for (int i = threadIdx.x; i < ww * wh; i += blockDim.x) {
+    const int yy = i / ww, xx = i - yy * ww;
+    win[yy * wp + xx] = ref[(size_t)clampi(y0 + yy, 0, pic_h - 1) * stride + clampi(x0 + xx, 0, pic_w - 1)];
+  }
+}
+
+// Horizontal pass: tmp[y][x] = (sum_k f[k] * win[y][x + xo + k]) >> shift1 for y < rows, x < w.
+template <int TAPS>
+__device__ __forceinline__ void hor_pass(const uint16_t *win, int wp, int xo, int yo, int w, int rows, const int8_t *f,
+                                         int shift1, int16_t *tmp, int tp)
+{
+  for (int i = threadIdx.x; i < w * rows; i += blockDim.x) {
+    const int y = i / w, x = i - y * w;
+    const uint16_t *p = win + (y + yo) * wp + x + xo;
+    int acc = 0;
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) acc += f[k] * (int)p[k];
+    tmp[y * tp + x] = (int16_t)(acc >> shift1);
+  }
+}
+
+// ---------------------------------------------------------------- motion compensation ----
+template <typename PX, int TAPS>
+__global__ void __launch_bounds__(256)
+mc_kernel(const PX *__restrict__ ref, int stride, int pic_w, int pic_h, int w, int h,
+          const uvghip_mc_blk_t *__restrict__ blks, int hi, void *__restrict__ dst)
+{
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  constexpr int OFF = TAPS == 8 ? 3 : 1;
+  const int ww = w + TAPS - 1, wh = h + TAPS - 1, wp = ww + 1;
+  uint16_t *win = smem;
+  int16_t *tmp = reinterpret_cast<int16_t *>(smem + wp * wh);
+  const uvghip_mc_blk_t b = blks[blockIdx.x];
+  const int8_t *tab = TAPS == 8 ? VVC_LUMA_FILTER : VVC_CHROMA_FILTER;
+  const int8_t *fh = tab + TAPS * b.fx, *fv = tab + TAPS * b.fy;
+  stage_window<PX>(ref, stride, pic_w, pic_h, b.x - OFF, b.y - OFF, ww, wh, win, wp);
+  __syncthreads();
+  constexpr int depth = px_traits<PX>::depth;
+  hor_pass<TAPS>(win, wp, 0, 0, w, wh, fh, depth - 8, tmp, w);
+  __syncthreads();
+  const int wp_shift = 14 - depth, wp_off = 1 << (wp_shift - 1);
+  for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
+    const int y = i / w, x = i - y * w;
+    int acc = 0;
+#pragma unroll
+    for (int k = 0; k < TAPS; ++k) acc += fv[k] * (int)tmp[(y + k) * w + x];
+    acc >>= 6;
+    if (hi) reinterpret_cast<int16_t *>(dst)[(size_t)blockIdx.x * w * h + i] = (int16_t)acc;
+    else reinterpret_cast<PX *>(dst)[(size_t)blockIdx.x * w * h + i] = (PX)clampi((acc + wp_off) >> wp_shift, 0, px_traits<PX>::maxv);
+  }
+}
+
+extern "C" int uvghip_mc_batch(int bitdepth, const void *ref, int ref_stride, int pic_w, int pic_h, int is_chroma,
+                               int width, int height, const uvghip_mc_blk_t *blks, int n, int hi, void *dst, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (width < 1 || height < 1 || width > 64 || height > 64) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (n <= 0) return 0;
+  const int taps = is_chroma ? 4 : 8;
+  const size_t lds = ((size_t)(width + taps) * (height + taps - 1) + (size_t)width * (height + taps - 1)) * 2;
+  hipStream_t st = uvghip_stream(stream);
+#define MC(PX, T) mc_kernel<PX, T><<<n, 256, lds, st>>>((const PX *)ref, ref_stride, pic_w, pic_h, width, height, blks, hi, dst)
+  if (bitdepth == 8) { if (is_chroma) MC(uint8_t, 4); else MC(uint8_t, 8); }
+  else { if (is_chroma) MC(uint16_t, 4); else MC(uint16_t, 8); }
+#undef MC
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// --------------------------------------------------------- fractional ME: sample + SATD ----
+template <typename PX>
+__global__ void __launch_bounds__(256)
+frac_satd_kernel(const PX *__restrict__ cur, int cur_stride, const PX *__restrict__ ref, int ref_stride, int pic_w, int pic_h,
+                 int w, int h, const uvghip_blk_t *__restrict__ blks, const int16_t *__restrict__ cands, int n_cand,
+                 uint32_t *__restrict__ costs)
+{
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  // window covers integer offsets -1..0 around the block plus the 8-tap support
+  const int ww = w + 8, wh = h + 8, wp = ww + 1;
+  uint16_t *win = smem;
+  int16_t *tmp = reinterpret_cast<int16_t *>(smem + wp * wh);          // (h+7) x w
+  uint16_t *sCur = reinterpret_cast<uint16_t *>(tmp + (h + 7) * w);    // h x w
+  const uvghip_blk_t b = blks[blockIdx.x];
+  stage_window<PX>(ref, ref_stride, pic_w, pic_h, b.ref_x - 4, b.ref_y - 4, ww, wh, win, wp);
+  for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
+    const int y = i / w, x = i - y * w;
+    sCur[i] = cur[(size_t)(b.cur_y + y) * cur_stride + b.cur_x + x];
+  }
+  constexpr int depth = px_traits<PX>::depth;
+  const int wp_shift = 14 - depth, wp_off = 1 << (wp_shift - 1);
+  const satd_tiling T = make_tiling(w, h);
+  for (int c = 0; c < n_cand; ++c) {
+    const int mvx = cands[2 * c], mvy = cands[2 * c + 1];
+    const int ix = mvx >> 4, iy = mvy >> 4;                              // -1 or 0 (|mv| < 16)
+    const int8_t *fh = VVC_LUMA_FILTER + 8 * (mvx & 15), *fv = VVC_LUMA_FILTER + 8 * (mvy & 15);
+    __syncthreads();                                                     // window/cur staged; previous tmp consumed
+    hor_pass<8>(win, wp, 1 + ix, 1 + iy, w, h + 7, fh, depth - 8, tmp, w);
+    __syncthreads();
+    // vertical pass fused with the Hadamard: every lane produces one row segment of the prediction
+    auto diff = [&](int x, int y, auto &d) {
+      constexpr int N = sizeof(d) / sizeof(d[0]);
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += fv[k] * (int)tmp[(y + k) * w + x + i];
+        const int p = clampi(((acc >> 6) + wp_off) >> wp_shift, 0, px_traits<PX>::maxv);
+        d[i] = (int)sCur[y * w + x + i] - p;
+      }
+    };
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // each wave takes every 4th group-task; satd_block distributes over the 64 lanes of a wave,
+    // so give each wave a quarter of the rows by offsetting tiles: simplest is one wave per candidate pass
+    int total = 0;
+    if (wave == 0) total = satd_block<PX>(T, lane, 64, true, diff);
+    if (threadIdx.x == 0) costs[(size_t)blockIdx.x * n_cand + c] = (uint32_t)total >> (depth - 8);
+  }
+}
+
+extern "C" int uvghip_frac_satd_batch(int bitdepth, const void *cur, int cur_stride, const void *ref, int ref_stride,
+                                      int pic_w, int pic_h, int width, int height, const uvghip_blk_t *blks, int n,
+                                      const int16_t *cand_mv, int n_cand, uint32_t *costs, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (width < 4 || height < 4 || (width & 3) || (height & 3) || width > 64 || height > 64 || n_cand < 1)
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (n <= 0) return 0;
+  const size_t lds = ((size_t)(width + 9) * (height + 8) + (size_t)(height + 7) * width + (size_t)width * height) * 2;
+  hipStream_t st = uvghip_stream(stream);
+  if (bitdepth == 8)
+    frac_satd_kernel<uint8_t><<<n, 256, lds, st>>>((const uint8_t *)cur, cur_stride, (const uint8_t *)ref, ref_stride, pic_w, pic_h, width, height, blks, cand_mv, n_cand, costs);
+  else
+    frac_satd_kernel<uint16_t><<<n, 256, lds, st>>>((const uint16_t *)cur, cur_stride, (const uint16_t *)ref, ref_stride, pic_w, pic_h, width, height, blks, cand_mv, n_cand, costs);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------- bi-prediction average ----
+// mode bit0/bit1: operand L0/L1 is a 14-bit int16 intermediate instead of pixels (picture-generic.c:1132-1193)
+template <typename PX>
+__global__ void __launch_bounds__(256)
+bipred_kernel(const void *__restrict__ l0, const void *__restrict__ l1, int mode, size_t total, PX *__restrict__ dst)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  constexpr int depth = px_traits<PX>::depth;
+  const int shift = 15 - depth, off = 1 << (shift - 1);
+  const int s0 = (mode & 1) ? (int)reinterpret_cast<const int16_t *>(l0)[i] : (int)(int16_t)(reinterpret_cast<const PX *>(l0)[i] << (14 - depth));
+  const int s1 = (mode & 2) ? (int)reinterpret_cast<const int16_t *>(l1)[i] : (int)(int16_t)(reinterpret_cast<const PX *>(l1)[i] << (14 - depth));
+  dst[i] = (PX)clampi((s0 + s1 + off) >> shift, 0, px_traits<PX>::maxv);
+}
+
+extern "C" int uvghip_bipred_average_batch(int bitdepth, const void *l0, const void *l1, int mode, size_t total,
+                                           void *dst, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (total == 0) return 0;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  hipStream_t st = uvghip_stream(stream);
+  if (bitdepth == 8) bipred_kernel<uint8_t><<<grid, 256, 0, st>>>(l0, l1, mode, total, (uint8_t *)dst);
+  else bipred_kernel<uint16_t><<<grid, 256, 0, st>>>(l0, l1, mode, total, (uint16_t *)dst);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// The ipol strategy typedefs (strategies-ipol.h:62-114) all take encoder_control_t* plus
+// caller-side extended blocks and scratch arrays; like the quant group they are bound by the
+// host-side shim of INTEGRATION.md, which forwards to uvghip_mc_batch / uvghip_frac_satd_batch.

@@ -47,6 +47,9 @@ SIGNATURES = {
     "uvghip_intra_search_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_intra_pred_plane_batch": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
     "uvghip_intra_select_best": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "uvghip_mc_batch": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
+    "uvghip_frac_satd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_bipred_average_batch": (c_int, [c_int, c_vp, c_vp, c_int, ctypes.c_size_t, c_vp, c_vp]),
     "uvghip_sad_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_satd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_ssd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
