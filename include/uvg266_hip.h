@@ -67,6 +67,7 @@ UVGHIP_API void uvghip_set_register_fn(uvghip_register_fn fn);
 UVGHIP_API int uvg_strategy_register_picture_hip(void *opaque, uint8_t bitdepth); /* strategies-picture.h:160-232 */
 UVGHIP_API int uvg_strategy_register_dct_hip(void *opaque, uint8_t bitdepth);     /* strategies-dct.h:77-110   */
 UVGHIP_API int uvg_strategy_register_intra_hip(void *opaque, uint8_t bitdepth);   /* strategies-intra.h:81-103 */
+UVGHIP_API int uvg_strategy_register_sao_hip(void *opaque, uint8_t bitdepth);     /* strategies-sao.h:66-82    */
 UVGHIP_API int uvg_strategy_register_quant_hip(void *opaque, uint8_t bitdepth);   /* strategies-quant.h:93-111 (state-free functions only) */
 
 /* -------------------------------------------- (2) batched ABI: picture -- */
@@ -262,6 +263,40 @@ UVGHIP_API int uvghip_frac_satd_batch(int bitdepth, const void *cur, int cur_str
  * on flat arrays of `total` samples.  mode bit0: l0 is int16 14-bit, bit1: l1 is. */
 UVGHIP_API int uvghip_bipred_average_batch(int bitdepth, const void *l0, const void *l1, int mode, size_t total,
                                 void *dst, void *stream);
+
+/* ------------------------------------------ (2) batched ABI: SAO ----------- */
+
+/* A rectangle of a plane (one CTU, or the part of it the reference hands to SAO). */
+typedef struct uvghip_rect {
+  int32_t x, y, w, h;
+} uvghip_rect_t;
+
+/* replaces: uvg_calc_sao_edge_dir for all four classes + calc_sao_bands
+ * (src/strategies/generic/sao-generic.c:51-81, src/sao.c:268-285) for n rectangles:
+ *   edge_stats[r][class][0][cat] = sum(orig - rec), [1][cat] = count   (40 int32 per rectangle)
+ *   band_stats[r][0][band]       = sum(orig - rec), [1][band] = count  (64 int32 per rectangle)
+ * over the rectangle's interior (edge) / whole area (band); neighbours are taken inside the
+ * rectangle only, like the reference's packed CTU copies.  uvg_sao_edge_ddistortion and
+ * uvg_sao_band_ddistortion are exact functions of these statistics
+ * (sum_cat cnt*o^2 - 2*o*sum), so the offset/RD decision needs nothing else from the pixels. */
+UVGHIP_API int uvghip_sao_stats_batch(int bitdepth, const void *orig, int orig_stride, const void *rec, int rec_stride,
+                           const uvghip_rect_t *rects, int n, int32_t *edge_stats, int32_t *band_stats,
+                           void *stream);
+
+/* SAO parameters of one rectangle for ONE colour plane (the host picks the U or V
+ * half of sao_info_t.offsets / band_position; src/sao.h:55-63).  type: 0 none, 1 band, 2 edge.
+ * offsets[cat] for edge; offsets[1..4] = the four band offsets for band. */
+typedef struct uvghip_sao_param {
+  int32_t type, eo_class, band_position;
+  int32_t offsets[5];
+} uvghip_sao_param_t;
+
+/* replaces: uvg_sao_reconstruct -> uvg_sao_reconstruct_color (src/sao.c:302-361,
+ * sao-generic.c:84-124): out = SAO(rec) inside each rectangle with its parameters; edge classes
+ * leave the picture's outermost row/column untouched.  rec and out must be different planes. */
+UVGHIP_API int uvghip_sao_apply_batch(int bitdepth, const void *rec, int rec_stride, void *out, int out_stride,
+                           int pic_w, int pic_h, const uvghip_rect_t *rects,
+                           const uvghip_sao_param_t *params, int n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -197,6 +197,19 @@ class Oracle:
         return out
 
 
+    # ---- sao ---------------------------------------------------------------
+    def sao_stats_rects(self, d, orig, rec, rects):
+        rects = np.ascontiguousarray(np.asarray(rects, np.int32).reshape(-1, 4))
+        edge = np.zeros((len(rects), 4, 2, 5), np.int32); band = np.zeros((len(rects), 2, 32), np.int32)
+        self.fn(d, "sao_stats_rects", None)(ptr(orig), ptr(rec), rec.shape[1], ptr(rects), len(rects), ptr(edge), ptr(band))
+        return edge, band
+
+    def sao_reconstruct_rect(self, d, rec, out, pic_w, pic_h, fx, fy, w, h, typ, eo, band_position, offsets, is_v):
+        bp = np.asarray(band_position, np.int32); of = np.asarray(offsets, np.int32)
+        self.fn(d, "sao_reconstruct_rect", None)(ptr(rec), ptr(out), rec.shape[1], pic_w, pic_h, fx, fy, w, h, typ, eo,
+                                                 ptr(bp), ptr(of), int(is_v))
+
+
 # ---- golden container (written by tools/refcheck/refcheck.c) ----------------
 _DT = {0: np.uint8, 1: np.uint16, 2: np.int16, 3: np.int32, 4: np.uint32, 5: np.int64, 6: np.float64}
 

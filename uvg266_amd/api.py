@@ -261,3 +261,33 @@ def bipred_average_batch(l0, l1, bitdepth):
     _lib.check(L.uvghip_bipred_average_batch(bitdepth, _dev(l0), _dev(l1), mode, l0.numel(), _dev(out), _stream()),
                "uvghip_bipred_average_batch")
     return out
+
+
+# ---- SAO ---------------------------------------------------------------------------
+def make_rects(xywh, device="cuda"):
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(xywh, np.int32).reshape(-1, 4))).to(device)
+
+
+def make_sao_params(rows, device="cuda"):
+    """(n,8) rows (type, eo_class, band_position, o0..o4) -> device array of uvghip_sao_param_t."""
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(rows, np.int32).reshape(-1, 8))).to(device)
+
+
+def sao_stats_batch(orig, rec, rects):
+    """-> (edge (n,4,2,5) int32, band (n,2,32) int32)."""
+    L = _lib.init(rec.device.index or 0)
+    n = rects.shape[0]
+    edge = torch.empty((n, 4, 2, 5), dtype=torch.int32, device=rec.device)
+    band = torch.empty((n, 2, 32), dtype=torch.int32, device=rec.device)
+    _lib.check(L.uvghip_sao_stats_batch(_depth(rec), _dev(orig), orig.stride(0), _dev(rec), rec.stride(0), _dev(rects), n,
+                                        _dev(edge), _dev(band), _stream()), "uvghip_sao_stats_batch")
+    return edge, band
+
+
+def sao_apply_batch(rec, out, rects, params, pic_w=None, pic_h=None):
+    L = _lib.init(rec.device.index or 0)
+    pic_w = rec.shape[1] if pic_w is None else pic_w
+    pic_h = rec.shape[0] if pic_h is None else pic_h
+    _lib.check(L.uvghip_sao_apply_batch(_depth(rec), _dev(rec), rec.stride(0), _dev(out), out.stride(0), pic_w, pic_h,
+                                        _dev(rects), _dev(params), rects.shape[0], _stream()), "uvghip_sao_apply_batch")
+    return out

@@ -50,3 +50,12 @@ typedef struct ref_cu_loc {
   uint8_t local_x, local_y, width, height, chroma_width, chroma_height;
 } ref_cu_loc;
 static_assert(sizeof(ref_cu_loc) == 10, "cu_loc_t mirror");
+
+// sao_info_t : src/sao.h:55-63 (enums are ints)
+typedef struct ref_sao_info {
+  int type, eo_class;
+  int ddistortion, merge_left_flag, merge_up_flag;
+  int band_position[2];
+  int offsets[10];
+} ref_sao_info;
+static_assert(sizeof(ref_sao_info) == 68, "sao_info_t mirror");

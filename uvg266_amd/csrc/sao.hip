@@ -1,0 +1,274 @@
+// "sao" strategy group on gfx950: sample-adaptive-offset statistics and
+// reconstruction over rectangles (CTUs) of device-resident planes.
+// Bit-exact with
+//   calc_sao_edge_dir       src/strategies/generic/sao-generic.c:51-81
+//   sao_edge_ddistortion    src/strategies/generic/sao_shared_generics.h:53-88
+//   sao_band_ddistortion    src/strategies/generic/sao_shared_generics.h:90-127
+//   sao_reconstruct_color   src/strategies/generic/sao-generic.c:84-124
+//   calc_sao_bands / uvg_calc_sao_offset_array / uvg_sao_reconstruct   src/sao.c:180-201,268-285,302-361
+//
+// Statistics kernel: one workgroup per rectangle.  Each thread walks its
+// pixels once, classifying them for all four edge classes from a 3x3
+// neighbourhood, keeps the 4x5 (sum,count) pairs in registers (select-adds,
+// no indexed register file), reduces them across the wave and adds them to
+// LDS once per wave; band histograms go to per-wave LDS histograms.  HBM
+// traffic: orig + rec read once, 104 integers written per rectangle.
+#include "uvghip_common.h"
+#include "percall.h"
+#include "ref_abi.h"
+
+__device__ __forceinline__ int sgn3(int v) { return (v > 0) - (v < 0); }
+__device__ __forceinline__ int eo_cat(int a, int b, int c)
+{
+  // {1,2,0,3,4}[2 + sign(c-a) + sign(c-b)]  (sao_shared_generics.h:42-50)
+  const int idx = 2 + sgn3(c - a) + sgn3(c - b);
+  return (0x43021 >> (4 * idx)) & 7;
+}
+__device__ static const int8_t kEoOfs[4][4] = {{-1, 0, 1, 0}, {0, -1, 0, 1}, {-1, -1, 1, 1}, {1, -1, -1, 1}};  // ax,ay,bx,by (sao.h:71-76)
+
+template <typename PX>
+__global__ void __launch_bounds__(256)
+sao_stats_kernel(const PX *__restrict__ orig, int ostride, const PX *__restrict__ rec, int rstride,
+                 const uvghip_rect_t *__restrict__ rects, int32_t *__restrict__ edge_out, int32_t *__restrict__ band_out)
+{
+  __shared__ int sEdge[40];
+  __shared__ int sBand[4][64];
+  const uvghip_rect_t R = rects[blockIdx.x];
+  for (int i = threadIdx.x; i < 40; i += blockDim.x) sEdge[i] = 0;
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) (&sBand[0][0])[i] = 0;
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  constexpr int bshift = px_traits<PX>::depth - 5;
+  int acc[4][2][5];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { acc[c][0][k] = 0; acc[c][1][k] = 0; }
+  const int npx = R.w * R.h;
+  for (int i = threadIdx.x; i < npx; i += blockDim.x) {
+    const int y = i / R.w, x = i - y * R.w;
+    const PX *rp = rec + (size_t)(R.y + y) * rstride + R.x + x;
+    const int c = rp[0];
+    const int diff = (int)orig[(size_t)(R.y + y) * ostride + R.x + x] - c;
+    atomicAdd(&sBand[wave][c >> bshift], diff);
+    atomicAdd(&sBand[wave][32 + (c >> bshift)], 1);
+    if (x >= 1 && y >= 1 && x < R.w - 1 && y < R.h - 1) {   // interior only (sao-generic.c:67-68)
+      const int l = rp[-1], r = rp[1];
+      const int u = rp[-rstride], d = rp[rstride];
+      const int ul = rp[-rstride - 1], ur = rp[-rstride + 1], dl = rp[rstride - 1], dr = rp[rstride + 1];
+      const int cats[4] = {eo_cat(l, r, c), eo_cat(u, d, c), eo_cat(ul, dr, c), eo_cat(ur, dl, c)};
+#pragma unroll
+      for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const bool hit = cats[cl] == k;
+          acc[cl][0][k] += hit ? diff : 0;
+          acc[cl][1][k] += hit ? 1 : 0;
+        }
+    }
+  }
+#pragma unroll
+  for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int v = group_sum(acc[cl][s][k], 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&sEdge[cl * 10 + s * 5 + k], v);
+      }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 40; i += blockDim.x) edge_out[(size_t)blockIdx.x * 40 + i] = sEdge[i];
+  for (int i = threadIdx.x; i < 64; i += blockDim.x)
+    band_out[(size_t)blockIdx.x * 64 + i] = sBand[0][i] + sBand[1][i] + sBand[2][i] + sBand[3][i];
+}
+
+extern "C" int uvghip_sao_stats_batch(int bitdepth, const void *orig, int orig_stride, const void *rec, int rec_stride,
+                                      const uvghip_rect_t *rects, int n, int32_t *edge_stats, int32_t *band_stats,
+                                      void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (n <= 0) return 0;
+  hipStream_t st = uvghip_stream(stream);
+  if (bitdepth == 8) sao_stats_kernel<uint8_t><<<n, 256, 0, st>>>((const uint8_t *)orig, orig_stride, (const uint8_t *)rec, rec_stride, rects, edge_stats, band_stats);
+  else sao_stats_kernel<uint16_t><<<n, 256, 0, st>>>((const uint16_t *)orig, orig_stride, (const uint16_t *)rec, rec_stride, rects, edge_stats, band_stats);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// Apply one parameter set per rectangle.  Edge classes skip the picture's outermost
+// rows/columns (sao.c:321-348); band offsets are applied through the value test of
+// uvg_calc_sao_offset_array (sao.c:180-201) instead of a 2^depth LUT.
+template <typename PX>
+__global__ void __launch_bounds__(256)
+sao_apply_kernel(const PX *__restrict__ rec, int rstride, PX *__restrict__ out, int ostride, int pic_w, int pic_h,
+                 const uvghip_rect_t *__restrict__ rects, const uvghip_sao_param_t *__restrict__ params)
+{
+  const uvghip_rect_t R = rects[blockIdx.x];
+  const uvghip_sao_param_t P = params[blockIdx.x];
+  if (P.type == 0) return;
+  constexpr int maxv = px_traits<PX>::maxv;
+  constexpr int bshift = px_traits<PX>::depth - 5;
+  int x0 = R.x, y0 = R.y, w = R.w, h = R.h;
+  int ax = 0, ay = 0, bx = 0, by = 0;
+  if (P.type == 2) {
+    ax = kEoOfs[P.eo_class][0]; ay = kEoOfs[P.eo_class][1]; bx = kEoOfs[P.eo_class][2]; by = kEoOfs[P.eo_class][3];
+    if (x0 + w + ax > pic_w || x0 + w + bx > pic_w) w -= 1;
+    if (x0 + ax < 0 || x0 + bx < 0) { x0 += 1; w -= 1; }
+    if (y0 + h + ay > pic_h || y0 + h + by > pic_h) h -= 1;
+    if (y0 + ay < 0 || y0 + by < 0) { y0 += 1; h -= 1; }
+  }
+  for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
+    const int y = i / w, x = i - y * w;
+    const PX *rp = rec + (size_t)(y0 + y) * rstride + x0 + x;
+    const int c = rp[0];
+    int v;
+    if (P.type == 1) {
+      const int band = (c >> bshift) - P.band_position;
+      v = (band >= 0 && band <= 3) ? clampi(c + P.offsets[band + 1], 0, maxv) : c;
+    } else {
+      const int cat = eo_cat(rp[ay * rstride + ax], rp[by * rstride + bx], c);
+      v = clampi(c + P.offsets[cat], 0, maxv);
+    }
+    out[(size_t)(y0 + y) * ostride + x0 + x] = (PX)v;
+  }
+}
+
+extern "C" int uvghip_sao_apply_batch(int bitdepth, const void *rec, int rec_stride, void *out, int out_stride,
+                                      int pic_w, int pic_h, const uvghip_rect_t *rects,
+                                      const uvghip_sao_param_t *params, int n, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (n <= 0) return 0;
+  hipStream_t st = uvghip_stream(stream);
+  if (bitdepth == 8) sao_apply_kernel<uint8_t><<<n, 256, 0, st>>>((const uint8_t *)rec, rec_stride, (uint8_t *)out, out_stride, pic_w, pic_h, rects, params);
+  else sao_apply_kernel<uint16_t><<<n, 256, 0, st>>>((const uint16_t *)rec, rec_stride, (uint16_t *)out, out_stride, pic_w, pic_h, rects, params);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// =================================================== drop-in strategy layer ====
+// strategies-sao.h:49-66.  encoder_control_t* / encoder_state_t* arguments are
+// only read for the bit depth in the reference (sao.c:183, sao_shared_generics.h:100),
+// which the registrar fixes, so they are ignored here.
+namespace {
+
+template <typename PX>
+struct staged_pair { percall_ctx *c; size_t oo, orr, orect; };
+
+template <typename PX>
+staged_pair<PX> stage_packed(const PX *orig, const PX *rec, int bw, int bh, size_t extra)
+{
+  const size_t nb = (size_t)bw * bh * sizeof(PX);
+  percall_ctx *c = percall_get(2 * nb + extra + 2048);
+  staged_pair<PX> s{c, c->take(nb), c->take(nb), c->take(sizeof(uvghip_rect_t))};
+  memcpy(c->hp<PX>(s.oo), orig, nb);
+  memcpy(c->hp<PX>(s.orr), rec, nb);
+  *c->hp<uvghip_rect_t>(s.orect) = uvghip_rect_t{0, 0, bw, bh};
+  return s;
+}
+
+template <typename PX>
+void stats_packed(const PX *orig, const PX *rec, int bw, int bh, int32_t (&edge)[40], int32_t (&band)[64])
+{
+  staged_pair<PX> s = stage_packed<PX>(orig, rec, bw, bh, 512);
+  percall_ctx *c = s.c;
+  const size_t oe = c->take(160), ob = c->take(256);
+  c->upload(0, oe);
+  c->must(uvghip_sao_stats_batch(px_traits<PX>::depth, c->dp<PX>(s.oo), bw, c->dp<PX>(s.orr), bw, c->dp<uvghip_rect_t>(s.orect), 1,
+                                 c->dp<int32_t>(oe), c->dp<int32_t>(ob), c->stream), "sao stats");
+  c->download(oe, 160 + 256 + 96);
+  c->sync();
+  memcpy(edge, c->hp<int32_t>(oe), 160);
+  memcpy(band, c->hp<int32_t>(ob), 256);
+}
+
+template <typename PX>
+void calc_sao_edge_dir_hip(const PX *orig_data, const PX *rec_data, int eo_class, int block_width, int block_height,
+                           int cat_sum_cnt[2][5])
+{
+  int32_t edge[40], band[64];
+  stats_packed<PX>(orig_data, rec_data, block_width, block_height, edge, band);
+  for (int s = 0; s < 2; ++s)
+    for (int k = 0; k < 5; ++k) cat_sum_cnt[s][k] += edge[eo_class * 10 + s * 5 + k];   // accumulates, like the reference
+}
+
+// delta-distortion = sum_cat cnt*o^2 - 2*o*sum: an exact function of the statistics
+template <typename PX>
+int sao_edge_ddistortion_hip(const PX *orig_data, const PX *rec_data, int block_width, int block_height, int eo_class,
+                             int offsets[5])
+{
+  int32_t edge[40], band[64];
+  stats_packed<PX>(orig_data, rec_data, block_width, block_height, edge, band);
+  int sum = 0;
+  for (int k = 0; k < 5; ++k) sum += edge[eo_class * 10 + 5 + k] * offsets[k] * offsets[k] - 2 * offsets[k] * edge[eo_class * 10 + k];
+  return sum;
+}
+template <typename PX>
+int sao_band_ddistortion_hip(const void * /*state*/, const PX *orig_data, const PX *rec_data, int block_width,
+                             int block_height, int band_pos, const int sao_bands[4])
+{
+  int32_t edge[40], band[64];
+  stats_packed<PX>(orig_data, rec_data, block_width, block_height, edge, band);
+  int sum = 0;
+  for (int k = 0; k < 4; ++k) {
+    const int b = band_pos + k;
+    if (b < 0 || b > 31) continue;
+    sum += band[32 + b] * sao_bands[k] * sao_bands[k] - 2 * sao_bands[k] * band[b];
+  }
+  return sum;
+}
+
+// sao_reconstruct_color: rec_data may be read one sample outside the block for edge
+// classes (the caller's buffer has a 1-sample border, sao.c:302-361), so a bordered copy is staged.
+template <typename PX>
+void sao_reconstruct_color_hip(const void * /*encoder*/, const PX *rec_data, PX *new_rec_data, const ref_sao_info *sao,
+                               int stride, int new_stride, int block_width, int block_height, int color_i)
+{
+  if (sao->type == 0 || block_width <= 0 || block_height <= 0) return;
+  const int bw = block_width + 2, bh = block_height + 2;
+  const size_t nb = (size_t)bw * bh * sizeof(PX);
+  percall_ctx *c = percall_get(2 * nb + 2048);
+  const size_t oi = c->take(nb), orect = c->take(sizeof(uvghip_rect_t)), op = c->take(sizeof(uvghip_sao_param_t)), oo = c->take(nb);
+  PX *h = c->hp<PX>(oi);
+  const bool edge = sao->type == 2;
+  for (int y = 0; y < bh; ++y)
+    for (int x = 0; x < bw; ++x) {
+      const bool in_x = x >= 1 && x <= block_width, in_y = y >= 1 && y <= block_height;
+      // touch only the border samples the edge class really reads (class 0: left/right, 1: up/down, 2/3: corners too)
+      const bool need = (in_x && in_y) || (edge && ((in_y && sao->eo_class != 1) || (in_x && sao->eo_class != 0) ||
+                                                    (!in_x && !in_y && sao->eo_class >= 2)));
+      h[y * bw + x] = need ? rec_data[(ptrdiff_t)(y - 1) * stride + (x - 1)] : (PX)0;
+    }
+  *c->hp<uvghip_rect_t>(orect) = uvghip_rect_t{1, 1, block_width, block_height};
+  uvghip_sao_param_t P;
+  const int v = color_i == 2;
+  P.type = sao->type; P.eo_class = sao->eo_class; P.band_position = sao->band_position[v ? 1 : 0];
+  for (int k = 0; k < 5; ++k) P.offsets[k] = sao->offsets[k + (v ? 5 : 0)];
+  *c->hp<uvghip_sao_param_t>(op) = P;
+  c->upload(0, oo);
+  // picture size chosen so that no border row/column is dropped: the caller already did that (sao.c:321-348)
+  c->must(uvghip_sao_apply_batch(px_traits<PX>::depth, c->dp<PX>(oi), bw, c->dp<PX>(oo), bw, bw + 2, bh + 2,
+                                 c->dp<uvghip_rect_t>(orect), c->dp<uvghip_sao_param_t>(op), 1, c->stream), "sao apply");
+  c->download(oo, nb);
+  c->sync();
+  const PX *o = c->hp<PX>(oo);
+  for (int y = 0; y < block_height; ++y)
+    memcpy(new_rec_data + (size_t)y * new_stride, o + (size_t)(y + 1) * bw + 1, (size_t)block_width * sizeof(PX));
+}
+
+template <typename PX>
+int register_sao(void *opaque)
+{
+  int ok = 1;
+  ok &= uvghip_do_register(opaque, "calc_sao_edge_dir", (void *)&calc_sao_edge_dir_hip<PX>);
+  ok &= uvghip_do_register(opaque, "sao_edge_ddistortion", (void *)&sao_edge_ddistortion_hip<PX>);
+  ok &= uvghip_do_register(opaque, "sao_band_ddistortion", (void *)&sao_band_ddistortion_hip<PX>);
+  ok &= uvghip_do_register(opaque, "sao_reconstruct_color", (void *)&sao_reconstruct_color_hip<PX>);
+  return ok;
+}
+
+}  // namespace
+
+extern "C" int uvg_strategy_register_sao_hip(void *opaque, uint8_t bitdepth)
+{
+  if (!uvghip_ready() && uvghip_init(0) != 0) return 0;
+  return bitdepth == 8 ? register_sao<uint8_t>(opaque) : register_sao<uint16_t>(opaque);
+}

@@ -50,6 +50,9 @@ SIGNATURES = {
     "uvghip_mc_batch": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
     "uvghip_frac_satd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_bipred_average_batch": (c_int, [c_int, c_vp, c_vp, c_int, ctypes.c_size_t, c_vp, c_vp]),
+    "uvg_strategy_register_sao_hip": (c_int, [c_vp, ctypes.c_uint8]),
+    "uvghip_sao_stats_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "uvghip_sao_apply_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
     "uvghip_sad_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_satd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_ssd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
