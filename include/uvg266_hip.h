@@ -298,6 +298,38 @@ UVGHIP_API int uvghip_sao_apply_batch(int bitdepth, const void *rec, int rec_str
                            int pic_w, int pic_h, const uvghip_rect_t *rects,
                            const uvghip_sao_param_t *params, int n, void *stream);
 
+/* ------------------------------------------ (2) batched ABI: deblocking ---- */
+
+/* Side information of one 4x4 luma block ("SCU"), the subset of cu_info_t
+ * (src/cu.h:134-198) that src/filter.c reads, in a fixed 32-byte device layout.
+ * One entry per 4x4 block of the picture, row-major, scu_stride entries per row
+ * (the reference's cu_array_t, src/cu.h:256-263).  The host-side conversion from
+ * cu_info_t is shown in INTEGRATION.md. */
+typedef struct uvghip_scu {
+  uint8_t luma_edges;          /* cu_info_t.luma_deblocking: bit0 (EDGE_VER=1) left edge, bit1 (EDGE_HOR=2) top edge */
+  uint8_t chroma_edges;        /* cu_info_t.chroma_deblocking, same bits */
+  uint8_t type;                /* cu_type_t: 1 intra, 2 inter, 4 IBC */
+  uint8_t cbf;                 /* bit0 Y, bit1 U, bit2 V (cbf_is_set, src/cu.h:581) */
+  int8_t  qp;                  /* cu_info_t.qp */
+  uint8_t log2_width, log2_height, log2_chroma_width, log2_chroma_height;
+  uint8_t isp_mode;            /* 0 none, 1 horizontal, 2 vertical (src/intra.h:183-185) */
+  uint8_t mv_dir;              /* bit0: L0 used, bit1: L1 used */
+  uint8_t reserved;
+  int16_t ref_id[2];           /* state->frame->ref_LX[l][mv_ref[l]] (filter.c:770-773): only compared for equality */
+  int32_t mv[2][2];            /* 1/16-sample motion vectors */
+} uvghip_scu_t;
+
+/* replaces: uvg_filter_deblock_lcu called for every CTU of a picture
+ * (src/filter.c:1372; caller src/encoderstate.c:842), luma and 4:2:0 chroma, in place.
+ * u/v may be NULL (luma only).  width/height: multiples of 4.
+ *   beta_offset_div2 / tc_offset_div2 = cfg.deblock_beta / cfg.deblock_tc
+ *   slice_is_b  = state->frame->slicetype == UVG_SLICE_B
+ *   frame_qp    = state->qp when per-CU QPs are off (max_qp_delta_depth < 0), else -1
+ *   chroma_qp_map_host = encoder_control->qp_map[0] (64 entries, HOST pointer) or NULL */
+UVGHIP_API int uvghip_deblock_frame(int bitdepth, void *y, int y_stride, void *u, void *v, int c_stride, int width, int height,
+                         const uvghip_scu_t *scu, int scu_stride, int beta_offset_div2, int tc_offset_div2,
+                         int slice_is_b, int frame_qp, const int8_t *chroma_qp_map_host, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

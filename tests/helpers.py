@@ -210,6 +210,14 @@ class Oracle:
                                                  ptr(bp), ptr(of), int(is_v))
 
 
+    # ---- deblock -----------------------------------------------------------
+    def deblock_frame(self, d, y, u, v, width, height, scu_bytes, scu_stride, beta_off, tc_off, slice_is_b, frame_qp, qp_map):
+        qm = np.ascontiguousarray(np.asarray(qp_map, np.int8)) if qp_map is not None else None
+        self.fn(d, "deblock_frame", None)(ptr(y), y.shape[1], ptr(u) if u is not None else None, ptr(v) if v is not None else None,
+                                          u.shape[1] if u is not None else 0, width, height, ptr(scu_bytes), scu_stride,
+                                          beta_off, tc_off, int(slice_is_b), frame_qp, ptr(qm) if qm is not None else None)
+
+
 # ---- golden container (written by tools/refcheck/refcheck.c) ----------------
 _DT = {0: np.uint8, 1: np.uint16, 2: np.int16, 3: np.int32, 4: np.uint32, 5: np.int64, 6: np.float64}
 

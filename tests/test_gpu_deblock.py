@@ -1,0 +1,120 @@
+"""HIP deblocking vs reference-deblocked pictures and vs the oracle on a synthetic partition."""
+import numpy as np
+import pytest
+
+import helpers as H
+from test_gpu_picture import dev
+from test_oracle_deblock import golden_frames
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_vs_reference_goldens(hip, depth):
+    from uvg266_amd import api
+    k = 0
+    for W, Hh, ts, th, is_b, fqp, tab, qmap, iy, iu, iv, oy, ou, ov in golden_frames(depth):
+        y, u, v = dev(iy), dev(iu), dev(iv)
+        scu = dev(tab.reshape(th, ts * 32))
+        api.deblock_frame(y, u, v, scu, W, Hh, 0, 0, is_b, fqp, qmap)
+        assert np.array_equal(y.cpu().numpy(), oy)
+        assert np.array_equal(u.cpu().numpy(), ou) and np.array_equal(v.cpu().numpy(), ov)
+        k += 1
+    assert k >= 5
+
+
+def random_partition(rng, W, Hh, inter):
+    """Random quad-tree partition into square CUs -> SCU table with mark_deblocking-style edge flags."""
+    from uvg266_amd import api
+    ts, th = ((W + 63) // 64) * 16, ((Hh + 63) // 64) * 16
+    tab = np.zeros((th, ts), api.SCU_DTYPE)
+
+    def split(x, y, size):
+        if x >= W or y >= Hh:
+            return
+        must = x + size > W or y + size > Hh
+        if size > 4 and (must or rng.random() < {64: 0.85, 32: 0.6, 16: 0.5, 8: 0.4}[size]):
+            h = size // 2
+            for dx, dy in ((0, 0), (h, 0), (0, h), (h, h)):
+                split(x + dx, y + dy, h)
+            return
+        lg = int(np.log2(size))
+        intra = (not inter) or rng.random() < 0.3
+        cu = tab[y // 4:(y + size) // 4, x // 4:(x + size) // 4]
+        cu["type"] = 1 if intra else 2
+        cu["cbf"] = rng.integers(0, 8)
+        cu["qp"] = rng.integers(20, 45)
+        cu["log2_width"] = cu["log2_height"] = lg
+        cu["log2_chroma_width"] = cu["log2_chroma_height"] = max(lg - 1, 2)
+        if not intra:
+            cu["mv_dir"] = rng.integers(1, 4)
+            cu["mv"] = rng.integers(-20, 21, (2, 2))
+            cu["ref_id"] = rng.integers(0, 3, 2)
+        for yy in range(y, y + size, 4):
+            for xx in range(x, x + size, 4):
+                e = 0
+                if (x > 0 and (xx - x) % 32 == 0) or (x == 0 and size == 64 and xx == 32):
+                    e |= 1
+                if (y > 0 and (yy - y) % 32 == 0) or (y == 0 and size == 64 and yy == 32):
+                    e |= 2
+                tab[yy // 4, xx // 4]["luma_edges"] = e
+                tab[yy // 4, xx // 4]["chroma_edges"] = e
+    for cy in range(0, Hh, 64):
+        for cx in range(0, W, 64):
+            split(cx, cy, 64)
+    return tab
+
+
+def blocky_planes(rng, W, Hh, depth):
+    sc = 1 << (depth - 8)
+    yy, xx = np.mgrid[0:Hh, 0:W]
+    ps = 8
+    base = ((1 << depth) // 2 + ((((xx // ps) * 7 + (yy // ps) * 13) % 9) - 4) * 2 * sc + (xx + yy) // 16 * sc)
+    y = np.clip(base + rng.integers(-1, 2, base.shape) * sc, 0, (1 << depth) - 1).astype(H.px_dtype(depth))
+    cy, cx = np.mgrid[0:Hh // 2, 0:W // 2]
+    cb = (1 << depth) // 2 + ((((cx // 8) * 5 + (cy // 8) * 11) % 7) - 3) * 2 * sc
+    u = np.clip(cb + rng.integers(-1, 2, cb.shape) * sc, 0, (1 << depth) - 1).astype(y.dtype)
+    v = np.clip(cb - 9 * sc + rng.integers(-1, 2, cb.shape) * sc, 0, (1 << depth) - 1).astype(y.dtype)
+    return y, u, v
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("inter", [False, True])
+def test_random_partition_vs_oracle(hip, orc, depth, inter):
+    from uvg266_amd import api
+    rng = np.random.default_rng(depth * 2 + inter)
+    W, Hh = 328, 200
+    tab = random_partition(rng, W, Hh, inter)
+    y, u, v = blocky_planes(rng, W, Hh, depth)
+    qmap = np.arange(64, dtype=np.int8)
+    for frame_qp, is_b in ((32, False), (-1, inter)):
+        gy, gu, gv = dev(y), dev(u), dev(v)
+        api.deblock_frame(gy, gu, gv, api.make_scu_table(tab), W, Hh, 0, 0, is_b, frame_qp, qmap)
+        oy, ou, ov = y.copy(), u.copy(), v.copy()
+        orc.deblock_frame(depth, oy, ou, ov, W, Hh, tab.view(np.uint8).reshape(tab.shape[0], -1), tab.shape[1], 0, 0, is_b, frame_qp, qmap)
+        assert np.array_equal(gy.cpu().numpy(), oy) and np.array_equal(gu.cpu().numpy(), ou) and np.array_equal(gv.cpu().numpy(), ov)
+        assert (oy != y).mean() > 0.02
+
+
+def test_full_size_properties(hip):
+    """1080p: a flat picture is a fixed point; filtering is idempotent on unflagged tables; only samples within 7 of
+    a flagged edge may change."""
+    import torch
+    from uvg266_amd import api
+    rng = np.random.default_rng(1)
+    W, Hh = 1920, 1080
+    tab = random_partition(rng, W, Hh + 8, False)[: (Hh + 8 + 63) // 64 * 16]
+    flat = torch.full((Hh, W), 100, dtype=torch.uint8, device="cuda")
+    fu = torch.full((Hh // 2, W // 2), 100, dtype=torch.uint8, device="cuda")
+    y = flat.clone()
+    api.deblock_frame(y, fu.clone(), fu.clone(), api.make_scu_table(tab), W, Hh, frame_qp=32)
+    assert torch.equal(y, flat)
+    yv, u, v = blocky_planes(rng, W, Hh, 8)
+    g = dev(yv)
+    api.deblock_frame(g, dev(u), dev(v), api.make_scu_table(tab), W, Hh, frame_qp=37)
+    changed = (g != dev(yv))
+    assert float(changed.float().mean()) > 0.02
+    none = np.zeros_like(tab); none[:] = tab; none["luma_edges"] = 0; none["chroma_edges"] = 0
+    g2 = dev(yv)
+    api.deblock_frame(g2, dev(u), dev(v), api.make_scu_table(none), W, Hh, frame_qp=37)
+    assert torch.equal(g2, dev(yv))

@@ -291,3 +291,34 @@ def sao_apply_batch(rec, out, rects, params, pic_w=None, pic_h=None):
     _lib.check(L.uvghip_sao_apply_batch(_depth(rec), _dev(rec), rec.stride(0), _dev(out), out.stride(0), pic_w, pic_h,
                                         _dev(rects), _dev(params), rects.shape[0], _stream()), "uvghip_sao_apply_batch")
     return out
+
+
+# ---- deblocking ---------------------------------------------------------------------
+SCU_DTYPE = np.dtype([("luma_edges", "u1"), ("chroma_edges", "u1"), ("type", "u1"), ("cbf", "u1"), ("qp", "i1"),
+                      ("log2_width", "u1"), ("log2_height", "u1"), ("log2_chroma_width", "u1"), ("log2_chroma_height", "u1"),
+                      ("isp_mode", "u1"), ("mv_dir", "u1"), ("reserved", "u1"), ("ref_id", "<i2", (2,)),
+                      ("mv", "<i4", (2, 2))])
+assert SCU_DTYPE.itemsize == 32
+
+
+def make_scu_table(table, device="cuda"):
+    """numpy structured array (rows, cols) of SCU_DTYPE -> device byte tensor (rows, cols*32)."""
+    t = np.ascontiguousarray(table)
+    assert t.dtype == SCU_DTYPE and t.ndim == 2
+    return torch.from_numpy(t.view(np.uint8).reshape(t.shape[0], t.shape[1] * 32)).to(device)
+
+
+def deblock_frame(y, u, v, scu, width, height, beta_offset_div2=0, tc_offset_div2=0, slice_is_b=False, frame_qp=-1,
+                  chroma_qp_map=None):
+    """In-place deblocking of a picture.  scu: device table from make_scu_table (row stride = cols)."""
+    import ctypes
+    L = _lib.init(y.device.index or 0)
+    qm = None
+    if chroma_qp_map is not None:
+        qm_arr = np.ascontiguousarray(np.asarray(chroma_qp_map, np.int8)[:64])
+        qm = qm_arr.ctypes.data_as(ctypes.c_void_p)
+    _lib.check(L.uvghip_deblock_frame(_depth(y), _dev(y), y.stride(0), None if u is None else _dev(u),
+                                      None if v is None else _dev(v), 0 if u is None else u.stride(0), width, height,
+                                      _dev(scu), scu.shape[1] // 32, beta_offset_div2, tc_offset_div2, int(slice_is_b),
+                                      frame_qp, qm, _stream()), "uvghip_deblock_frame")
+    return y
