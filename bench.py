@@ -32,9 +32,11 @@ W, H, DEPTH, QP = 1920, 1080, 8, 22
 SIZES = (32, 16, 8, 4)            # --pu-depth-intra 1-4 (cfg.c:769-801)
 MODES = list(range(67))           # every luma mode; the reference's rough search visits a subset
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
-WORKLOAD = ("1920x1080 8-bit yuv420p luma, all-intra medium hot path per frame: for N in 32,16,8,4 "
+WORKLOAD = ("1920x1080 8-bit yuv420p, all-intra medium hot path per frame: luma, for N in 32,16,8,4 "
             "{intra rough search 67 modes min(SATD,2SAD) on all NxN blocks -> best mode -> intra predict "
-            "-> fused residual/DCT-2/quant/dequant/IDCT/recon}; open-loop references (source picture)")
+            "-> fused residual/DCT-2/quant/dequant/IDCT/recon}; then deblock (Y,U,V; seeded random quad-tree "
+            "partition) -> SAO statistics (4 edge classes + bands per CTU) -> SAO apply; open-loop references "
+            "(source picture); serial RDOQ/CABAC excluded (out of hot-path scope)")
 
 
 class Frame:
@@ -50,6 +52,15 @@ class Frame:
             blks = layout.intra_availability(layout.block_grid(W, H, n), n, W, H)
             self.tables[n] = (api.make_intra_blocks(blks, device), api.make_tus(blks[:, :2], device), len(blks))
         self.host_y = y
+        self.u = torch.from_numpy(u).to(device)
+        self.v = torch.from_numpy(v).to(device)
+        self.u_rec = torch.zeros_like(self.u)
+        self.v_rec = torch.zeros_like(self.v)
+        self.sao_out = torch.zeros_like(self.y)
+        self.scu = api.make_scu_table(layout.quadtree_scu_table(W, H, seed=t, qp=QP), device)
+        rects = layout.ctu_rects(W, H)
+        self.rects = api.make_rects(rects, device)
+        self.n_ctu = len(rects)
 
 
 class KernelClock:
@@ -83,6 +94,12 @@ def algorithmic_bytes(kernel, n, count):
         return count * n * n * (2 * b + 2 + b)
     if kernel == "select_best":
         return count * (4 * len(MODES) + 1 + 4)
+    if kernel == "deblock":           # 2 * 1.5*W*H*b (read+write) + 32 B side info per 4x4 (n = 0)
+        return int(2 * 1.5 * W * H * b + 32 * W * H / 16)
+    if kernel == "sao_stats":         # orig + rec luma read, 104 counters per CTU written
+        return W * H * 2 * b + count * 104 * 4
+    if kernel == "sao_apply":         # rec read, out written (+ 32 B parameters per CTU)
+        return W * H * 2 * b + count * 32
     raise KeyError(kernel)
 
 
@@ -93,6 +110,32 @@ def hot_path_step(fr, modes_dev, clock, timed):
         best, _ = clock.run(f"select_best_{n}", lambda: api.intra_select_best(costs, modes_dev), timed)
         clock.run(f"intra_pred_plane_{n}", lambda: api.intra_pred_plane_batch(fr.y, blks, n, best, fr.pred), timed)
         clock.run(f"tu_roundtrip_{n}", lambda: api.tu_roundtrip_batch(fr.y, fr.pred, fr.rec, tus, n, n, QP), timed)
+    # in-loop filters on the reconstruction left by the last (4x4) pass
+    fr.u_rec.copy_(fr.u)
+    fr.v_rec.copy_(fr.v)
+    clock.run("deblock_0", lambda: api.deblock_frame(fr.rec, fr.u_rec, fr.v_rec, fr.scu, W, H, 0, 0, False, QP, None), timed)
+    edge, band = clock.run("sao_stats_0", lambda: api.sao_stats_batch(fr.y, fr.rec, fr.rects), timed)
+    params = sao_decide(edge)
+    clock.run("sao_apply_0", lambda: api.sao_apply_batch(fr.rec, fr.sao_out, fr.rects, params), timed)
+
+
+def sao_decide(edge):
+    """Edge-offset choice per CTU from the statistics alone (distortion only; the reference adds CABAC rate,
+    sao.c:364-460, which stays on the host): offset = round(sum/cnt) clipped to +-7 with the category sign
+    constraint, class = argmin of sum_cat cnt*o^2 - 2*o*sum.  Runs on the device with torch (plumbing)."""
+    s, c = edge[:, :, 0].float(), edge[:, :, 1].float().clamp(min=1)
+    off = torch.round(s / c).clamp(-7, 7)
+    off[:, :, 0] = 0
+    off[:, :, 1:3] = off[:, :, 1:3].clamp(min=0)
+    off[:, :, 3:5] = off[:, :, 3:5].clamp(max=0)
+    dd = (edge[:, :, 1].float() * off * off - 2 * off * s).sum(-1)
+    best = dd.argmin(1)
+    o = off[torch.arange(off.shape[0], device=off.device), best].to(torch.int32)
+    p = torch.zeros((off.shape[0], 8), dtype=torch.int32, device=off.device)
+    p[:, 0] = 2
+    p[:, 1] = best.to(torch.int32)
+    p[:, 3:8] = o
+    return p
 
 
 def cpu_baseline(fr_host_y):
@@ -192,7 +235,7 @@ def main():
         per_kernel = {}
         for name, (ms, launches) in totals.items():
             kern, n = name.rsplit("_", 1)
-            cnt = frames[0].tables[int(n)][2]
+            cnt = frames[0].tables[int(n)][2] if int(n) else frames[0].n_ctu
             byts = algorithmic_bytes(kern, int(n), cnt)
             avg_ms = ms / launches
             per_kernel[name] = {"avg_ms": round(avg_ms, 4), "share": 0.0, "alg_bytes": byts,

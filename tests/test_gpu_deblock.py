@@ -24,45 +24,8 @@ def test_vs_reference_goldens(hip, depth):
 
 
 def random_partition(rng, W, Hh, inter):
-    """Random quad-tree partition into square CUs -> SCU table with mark_deblocking-style edge flags."""
-    from uvg266_amd import api
-    ts, th = ((W + 63) // 64) * 16, ((Hh + 63) // 64) * 16
-    tab = np.zeros((th, ts), api.SCU_DTYPE)
-
-    def split(x, y, size):
-        if x >= W or y >= Hh:
-            return
-        must = x + size > W or y + size > Hh
-        if size > 4 and (must or rng.random() < {64: 0.85, 32: 0.6, 16: 0.5, 8: 0.4}[size]):
-            h = size // 2
-            for dx, dy in ((0, 0), (h, 0), (0, h), (h, h)):
-                split(x + dx, y + dy, h)
-            return
-        lg = int(np.log2(size))
-        intra = (not inter) or rng.random() < 0.3
-        cu = tab[y // 4:(y + size) // 4, x // 4:(x + size) // 4]
-        cu["type"] = 1 if intra else 2
-        cu["cbf"] = rng.integers(0, 8)
-        cu["qp"] = rng.integers(20, 45)
-        cu["log2_width"] = cu["log2_height"] = lg
-        cu["log2_chroma_width"] = cu["log2_chroma_height"] = max(lg - 1, 2)
-        if not intra:
-            cu["mv_dir"] = rng.integers(1, 4)
-            cu["mv"] = rng.integers(-20, 21, (2, 2))
-            cu["ref_id"] = rng.integers(0, 3, 2)
-        for yy in range(y, y + size, 4):
-            for xx in range(x, x + size, 4):
-                e = 0
-                if (x > 0 and (xx - x) % 32 == 0) or (x == 0 and size == 64 and xx == 32):
-                    e |= 1
-                if (y > 0 and (yy - y) % 32 == 0) or (y == 0 and size == 64 and yy == 32):
-                    e |= 2
-                tab[yy // 4, xx // 4]["luma_edges"] = e
-                tab[yy // 4, xx // 4]["chroma_edges"] = e
-    for cy in range(0, Hh, 64):
-        for cx in range(0, W, 64):
-            split(cx, cy, 64)
-    return tab
+    from uvg266_amd import layout
+    return layout.quadtree_scu_table(W, Hh, seed=int(rng.integers(1 << 30)), inter=inter)
 
 
 def blocky_planes(rng, W, Hh, depth):

@@ -294,10 +294,7 @@ def sao_apply_batch(rec, out, rects, params, pic_w=None, pic_h=None):
 
 
 # ---- deblocking ---------------------------------------------------------------------
-SCU_DTYPE = np.dtype([("luma_edges", "u1"), ("chroma_edges", "u1"), ("type", "u1"), ("cbf", "u1"), ("qp", "i1"),
-                      ("log2_width", "u1"), ("log2_height", "u1"), ("log2_chroma_width", "u1"), ("log2_chroma_height", "u1"),
-                      ("isp_mode", "u1"), ("mv_dir", "u1"), ("reserved", "u1"), ("ref_id", "<i2", (2,)),
-                      ("mv", "<i4", (2, 2))])
+from .layout import SCU_DTYPE  # noqa: E402
 assert SCU_DTYPE.itemsize == 32
 
 

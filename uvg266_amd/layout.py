@@ -70,3 +70,60 @@ def synthetic_yuv420(w, h, t, depth=8, seed=1234):
     dt = np.uint8 if depth == 8 else np.uint16
     mx = (1 << depth) - 1
     return tuple(np.clip(np.rint(p), 0, mx).astype(dt) for p in (Y, U, V))
+
+
+SCU_DTYPE = np.dtype([("luma_edges", "u1"), ("chroma_edges", "u1"), ("type", "u1"), ("cbf", "u1"), ("qp", "i1"),
+                      ("log2_width", "u1"), ("log2_height", "u1"), ("log2_chroma_width", "u1"), ("log2_chroma_height", "u1"),
+                      ("isp_mode", "u1"), ("mv_dir", "u1"), ("reserved", "u1"), ("ref_id", "<i2", (2,)),
+                      ("mv", "<i4", (2, 2))])   # uvghip_scu_t, include/uvg266_hip.h
+
+
+def quadtree_scu_table(pic_w, pic_h, seed=0, inter=False, qp=None, split_prob=None):
+    """A seeded random quad-tree partition of every CTU into square CUs (4..64) written as the per-4x4
+    side-information table deblocking needs (uvghip_scu_t), with edge flags placed like the reference's
+    mark_deblocking (src/search.c:1075-1110: CU edges, plus the 32-sample TU split of 64-wide CUs)."""
+    rng = np.random.default_rng(seed)
+    ts, th = ((pic_w + CTU - 1) // CTU) * 16, ((pic_h + CTU - 1) // CTU) * 16
+    tab = np.zeros((th, ts), SCU_DTYPE)
+    prob = split_prob or {64: 0.85, 32: 0.6, 16: 0.5, 8: 0.4}
+
+    def split(x, y, size):
+        if x >= pic_w or y >= pic_h:
+            return
+        must = x + size > pic_w or y + size > pic_h
+        if size > 4 and (must or rng.random() < prob[size]):
+            h = size // 2
+            for dx, dy in ((0, 0), (h, 0), (0, h), (h, h)):
+                split(x + dx, y + dy, h)
+            return
+        lg = size.bit_length() - 1
+        intra = (not inter) or rng.random() < 0.3
+        cu = tab[y // 4:(y + size) // 4, x // 4:(x + size) // 4]
+        cu["type"] = 1 if intra else 2
+        cu["cbf"] = rng.integers(0, 8)
+        cu["qp"] = rng.integers(20, 45) if qp is None else qp
+        cu["log2_width"] = cu["log2_height"] = lg
+        cu["log2_chroma_width"] = cu["log2_chroma_height"] = max(lg - 1, 2)
+        if not intra:
+            cu["mv_dir"] = rng.integers(1, 4)
+            cu["mv"] = rng.integers(-20, 21, (2, 2))
+            cu["ref_id"] = rng.integers(0, 3, 2)
+        ex = np.zeros((size // 4, size // 4), np.uint8)
+        xs = np.arange(x, x + size, 4)
+        ys = np.arange(y, y + size, 4)
+        ver = ((xs - x) % 32 == 0) if x > 0 else ((xs == 32) & (size == 64))
+        hor = ((ys - y) % 32 == 0) if y > 0 else ((ys == 32) & (size == 64))
+        ex |= ver[None, :].astype(np.uint8)
+        ex |= (hor[:, None].astype(np.uint8) << 1)
+        cu["luma_edges"] = ex
+        cu["chroma_edges"] = ex
+    for cy in range(0, pic_h, CTU):
+        for cx in range(0, pic_w, CTU):
+            split(cx, cy, CTU)
+    return tab
+
+
+def ctu_rects(pic_w, pic_h, ctu=CTU):
+    """(n,4) int32 rows (x, y, w, h): the CTU grid clipped to the picture = uvghip_rect_t."""
+    return np.array([[x, y, min(ctu, pic_w - x), min(ctu, pic_h - y)]
+                     for y in range(0, pic_h, ctu) for x in range(0, pic_w, ctu)], np.int32)
