@@ -127,3 +127,9 @@ def ctu_rects(pic_w, pic_h, ctu=CTU):
     """(n,4) int32 rows (x, y, w, h): the CTU grid clipped to the picture = uvghip_rect_t."""
     return np.array([[x, y, min(ctu, pic_w - x), min(ctu, pic_h - y)]
                      for y in range(0, pic_h, ctu) for x in range(0, pic_w, ctu)], np.int32)
+
+
+def frames_of_rank(rank, world, n_frames):
+    """Frames a rank owns when a sequence is sharded over `world` ranks (all-intra: frames are
+    independent units): frame t belongs to rank t % world."""
+    return list(range(rank, n_frames, world))
