@@ -330,6 +330,35 @@ UVGHIP_API int uvghip_deblock_frame(int bitdepth, void *y, int y_stride, void *u
                          const uvghip_scu_t *scu, int scu_stride, int beta_offset_div2, int tc_offset_div2,
                          int slice_is_b, int frame_qp, const int8_t *chroma_qp_map_host, void *stream);
 
+/* ------------------------------------------ (2) batched ABI: ALF ----------- */
+
+/* replaces: alf_derive_classification -> uvg_alf_derive_classification_blk over the whole luma plane
+ * (src/alf.c:5138-5189, src/strategies/generic/alf-generic.c:49-288).  One byte per 4x4 block:
+ *   cls[(y/4)*cls_stride + x/4] = class_idx (0..24) | transpose_idx (0..3) << 5
+ * (the reference stores the same pair per pixel, alf.h:197-200).  shift = input_bitdepth + 4. */
+UVGHIP_API int uvghip_alf_classify_frame(int bitdepth, const void *rec, int rec_stride, int width, int height, int shift,
+                              uint8_t *cls, int cls_stride, void *stream);
+
+/* replaces: the CTU loop of alf_reconstruct -> uvg_alf_filter_7x7_blk / uvg_alf_filter_5x5_blk
+ * (src/alf.c:5075-5125, alf-generic.c:290-737).  For rectangle i (a CTU): set_idx[i] < 0 -> not filtered (dst
+ * untouched), else the filter set to use:
+ *   luma   (is_chroma 0): coef_sets/clip_sets = [n_sets][25 classes][13] int16, per-4x4 class/transpose from cls
+ *   chroma (is_chroma 1): coef_sets/clip_sets = [n_alternatives][7] int16, cls unused
+ * src and dst must be different planes (src = the pre-ALF copy alf_tmp_*). */
+UVGHIP_API int uvghip_alf_filter_batch(int bitdepth, const void *src, int src_stride, void *dst, int dst_stride, int pic_w,
+                            int pic_h, int is_chroma, const uvghip_rect_t *rects, const int32_t *set_idx, int n,
+                            const int16_t *coef_sets, const int16_t *clip_sets, const uint8_t *cls, int cls_stride,
+                            void *stream);
+
+/* replaces: alf_get_blk_stats per CTU (src/alf.c:4227-4330, alf-generic.c:742-999).  For rectangle r (width <= 64,
+ * x and width multiples of 4) and class c (luma: 25 classes from cls; chroma: c = 0):
+ *   ee[r][c][k][l][b0][b1] (int64, full symmetric 13x13x4x4), y[r][c][k][b] (int32), pix_acc[r][c] (int64; the
+ *   reference keeps this integer in a double) -- the fields of alf_covariance (alf.h:176-182).
+ * Clipping values are the reference's defaults for the bit depth (alf.c:5248-5260). */
+UVGHIP_API int uvghip_alf_stats_batch(int bitdepth, const void *org, int org_stride, const void *rec, int rec_stride, int pic_w,
+                           int pic_h, int is_chroma, const uvghip_rect_t *rects, int n, const uint8_t *cls,
+                           int cls_stride, int64_t *ee, int32_t *y, int64_t *pix_acc, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -218,6 +218,29 @@ class Oracle:
                                           beta_off, tc_off, int(slice_is_b), frame_qp, ptr(qm) if qm is not None else None)
 
 
+    # ---- alf ---------------------------------------------------------------
+    def alf_classify_frame(self, d, rec, w, h, shift, vbh=64, vb_pos=60):
+        cls = np.zeros((h // 4, w // 4), np.uint8)
+        self.fn(d, "alf_classify_frame", None)(ptr(rec), rec.shape[1], w, h, shift, vbh, vb_pos, ptr(cls), cls.shape[1])
+        return cls
+
+    def alf_filter_rect(self, d, src, dst, pic_w, pic_h, x0, y0, w, h, chroma, coef, clip, cls):
+        vbh, vbp = (32, 30) if chroma else (64, 60)
+        self.fn(d, "alf_filter_rect", None)(ptr(src), ptr(dst), src.shape[1], pic_w, pic_h, x0, y0, w, h, int(chroma),
+                                            ptr(coef), ptr(clip), ptr(cls) if cls is not None else None,
+                                            cls.shape[1] if cls is not None else 0, vbh, vbp)
+
+    def alf_stats_rect(self, d, org, rec, pic_w, pic_h, x0, y0, w, h, chroma, cls):
+        C = 1 if chroma else 25
+        vbh, vbp = (32, 30) if chroma else (64, 60)
+        ee = np.zeros((C, 13, 13, 4, 4), np.int64); yv = np.zeros((C, 13, 4), np.int32); pa = np.zeros(C, np.int64)
+        clip = np.array([1 << d] + [1 << (7 - 2 * i + d - 8) for i in (1, 2, 3)], np.int16)
+        self.fn(d, "alf_stats_rect", None)(ptr(org), org.shape[1], ptr(rec), rec.shape[1], pic_w, pic_h, x0, y0, w, h, int(chroma),
+                                           ptr(cls) if cls is not None else None, cls.shape[1] if cls is not None else 0,
+                                           vbh, vbp, ptr(clip), ptr(ee), ptr(yv), ptr(pa))
+        return ee, yv, pa
+
+
 # ---- golden container (written by tools/refcheck/refcheck.c) ----------------
 _DT = {0: np.uint8, 1: np.uint16, 2: np.int16, 3: np.int32, 4: np.uint32, 5: np.int64, 6: np.float64}
 

@@ -319,3 +319,41 @@ def deblock_frame(y, u, v, scu, width, height, beta_offset_div2=0, tc_offset_div
                                       _dev(scu), scu.shape[1] // 32, beta_offset_div2, tc_offset_div2, int(slice_is_b),
                                       frame_qp, qm, _stream()), "uvghip_deblock_frame")
     return y
+
+
+# ---- ALF ---------------------------------------------------------------------------
+def alf_classify_frame(rec, width, height, shift=None):
+    """-> (height/4, width/4) uint8: class_idx | transpose_idx << 5 per 4x4 luma block."""
+    L = _lib.init(rec.device.index or 0)
+    depth = _depth(rec)
+    cls = torch.empty((height // 4, width // 4), dtype=torch.uint8, device=rec.device)
+    _lib.check(L.uvghip_alf_classify_frame(depth, _dev(rec), rec.stride(0), width, height, depth + 4 if shift is None else shift,
+                                           _dev(cls), cls.stride(0), _stream()), "uvghip_alf_classify_frame")
+    return cls
+
+
+def alf_filter_batch(src, dst, rects, set_idx, coef_sets, clip_sets, cls=None, is_chroma=False, pic_w=None, pic_h=None):
+    L = _lib.init(src.device.index or 0)
+    pic_w = src.shape[1] if pic_w is None else pic_w
+    pic_h = src.shape[0] if pic_h is None else pic_h
+    _lib.check(L.uvghip_alf_filter_batch(_depth(src), _dev(src), src.stride(0), _dev(dst), dst.stride(0), pic_w, pic_h,
+                                         int(is_chroma), _dev(rects), _dev(set_idx), rects.shape[0], _dev(coef_sets),
+                                         _dev(clip_sets), None if cls is None else _dev(cls),
+                                         0 if cls is None else cls.stride(0), _stream()), "uvghip_alf_filter_batch")
+    return dst
+
+
+def alf_stats_batch(org, rec, rects, cls=None, is_chroma=False, pic_w=None, pic_h=None):
+    """-> (ee (n,C,13,13,4,4) int64, y (n,C,13,4) int32, pix_acc (n,C) int64), C = 25 (luma) or 1 (chroma)."""
+    L = _lib.init(rec.device.index or 0)
+    n, C = rects.shape[0], (1 if is_chroma else 25)
+    pic_w = rec.shape[1] if pic_w is None else pic_w
+    pic_h = rec.shape[0] if pic_h is None else pic_h
+    ee = torch.empty((n, C, 13, 13, 4, 4), dtype=torch.int64, device=rec.device)
+    yv = torch.empty((n, C, 13, 4), dtype=torch.int32, device=rec.device)
+    pa = torch.empty((n, C), dtype=torch.int64, device=rec.device)
+    _lib.check(L.uvghip_alf_stats_batch(_depth(rec), _dev(org), org.stride(0), _dev(rec), rec.stride(0), pic_w, pic_h,
+                                        int(is_chroma), _dev(rects), n, None if cls is None else _dev(cls),
+                                        0 if cls is None else cls.stride(0), _dev(ee), _dev(yv), _dev(pa), _stream()),
+               "uvghip_alf_stats_batch")
+    return ee, yv, pa
