@@ -429,20 +429,22 @@ extern "C" int uvghip_intra_select_best(const uint32_t *costs, int n, const int8
 
 // ----------------------------------------------------------------------- search kernel ----
 // NP = 8: 8x8 tiles of an n x n block (n >= 8); NP = 4: the whole 4x4 block.
+// Work unit of an NP-lane group = one (block, mode): the group walks the block's tiles, keeps the two
+// cost sums in registers and stores the final cost itself (no LDS atomics, no integer division:
+// the (block, mode) counters advance incrementally and the tile index splits by shifts).
 template <typename PX, int NP>
 __global__ void __launch_bounds__(256)
 intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__restrict__ orig, int orig_stride,
-                    int n, const uvghip_intra_blk_t *__restrict__ blks, int n_blks, int bpg,
+                    int n, int log2_tiles_x, const uvghip_intra_blk_t *__restrict__ blks, int n_blks, int bpg,
                     const int8_t *__restrict__ modes, int n_modes, uint32_t *__restrict__ costs)
 {
   constexpr int REFN = 104;   // 3*32 + 3 rounded up
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-  // per block: 4 reference rows, orig, origT; then per block cost accumulators; then the mode table
+  // per block: 4 reference rows, orig, origT; then DC values; then the mode table
   const int nn = n * n;
   const int per_blk_u16 = 4 * REFN + 2 * nn;
   uint16_t *sBlk = smem;
-  int *sAcc = reinterpret_cast<int *>(smem + (size_t)bpg * per_blk_u16);      // [bpg][n_modes][2]
-  int *sDC = sAcc + (size_t)bpg * n_modes * 2;                                  // [bpg]
+  int *sDC = reinterpret_cast<int *>(smem + (size_t)bpg * per_blk_u16);        // [bpg]
   mode_info *sM = reinterpret_cast<mode_info *>(sDC + bpg);
 
   const int blk0 = blockIdx.x * bpg;
@@ -457,15 +459,15 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
     uint16_t *base = sBlk + (size_t)myb * per_blk_u16;
     build_ref_rows<PX>(rec, rec_stride, b.x, b.y, n, n, b.avail_top, b.avail_left, base, base + REFN, REFN, mytid, tpb);
     uint16_t *so = base + 4 * REFN, *sot = so + nn;
+    const int lg = 31 - __clz(n);
     for (int e = mytid; e < nn; e += tpb) {
-      const int yy = e / n, xx = e - yy * n;
+      const int yy = e >> lg, xx = e & (n - 1);
       const uint16_t v = orig[(size_t)(b.y + yy) * orig_stride + b.x + xx];
       so[e] = v;
       sot[xx * n + yy] = v;
     }
   }
   for (int m = threadIdx.x; m < n_modes; m += blockDim.x) sM[m] = make_mode_info(modes[m], n, n, 0);
-  for (int e = threadIdx.x; e < here * n_modes * 2; e += blockDim.x) sAcc[e] = 0;
   __syncthreads();
   if (myb < here) {
     uint16_t *base = sBlk + (size_t)myb * per_blk_u16;
@@ -474,60 +476,57 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   }
   __syncthreads();
 
-  // ---- tasks: (block, mode, tile) per NP-lane group ----
+  // ---- units: (block, mode) per NP-lane group ----
   const int maxv = px_traits<PX>::maxv;
-  const int tiles_x = n / NP, tiles = tiles_x * tiles_x;
-  const int ngroups = blockDim.x / NP;
+  const int dshift = px_traits<PX>::depth - 8;
+  const int tiles = 1 << (2 * log2_tiles_x), tmask = (1 << log2_tiles_x) - 1;
+  constexpr int ngroups = 256 / NP;
   const int g = threadIdx.x / NP, r = threadIdx.x & (NP - 1);
-  const int ntasks = here * n_modes * tiles;
-  const int rounds = (ntasks + ngroups - 1) / ngroups;
+  const int units = here * n_modes;
+  // group g takes units g, g + ngroups, ...; (b, m) follow incrementally
+  int b = 0, m = g;
+  while (m >= n_modes) { m -= n_modes; ++b; }
+  const int rounds = (units + ngroups - 1) / ngroups;
   for (int it = 0; it < rounds; ++it) {
-    const int task = it * ngroups + g;
-    const bool on = task < ntasks;
-    int d[NP];
-    int b = 0, m = 0;
-    if (on) {
-      b = task / (n_modes * tiles);
-      const int rem = task - b * n_modes * tiles;
-      m = rem / tiles;
-      const int tile = rem - m * tiles, ty = tile / tiles_x, tx = tile - ty * tiles_x;
-      const mode_info M = sM[m];
-      const uint16_t *base = sBlk + (size_t)b * per_blk_u16;
-      const ref_rows R{base, base + REFN, base + 2 * REFN, base + 3 * REFN};
-      const bool transposed = M.mode >= 2 && !M.vertical;
+    const bool on = b < here;
+    const int bb = on ? b : 0, mm = on ? m : 0;
+    const mode_info M = sM[mm];
+    const uint16_t *base = sBlk + (size_t)bb * per_blk_u16;
+    const ref_rows R{base, base + REFN, base + 2 * REFN, base + 3 * REFN};
+    const bool transposed = M.mode >= 2 && !M.vertical;
+    const uint16_t *ob = base + 4 * REFN + (transposed ? nn : 0);
+    const int dc = sDC[bb];
+    int satd = 0, sad = 0;
+    for (int tile = 0; tile < tiles; ++tile) {
+      const int ty = tile >> log2_tiles_x, tx = tile & tmask;
       const int yd = (transposed ? tx : ty) * NP + r, xd0 = (transposed ? ty : tx) * NP;
-      int p[NP];
-      predict_row<NP>(M, R, sDC[b], 0, n, n, yd, xd0, maxv, p);
-      const uint16_t *o = base + 4 * REFN + (transposed ? nn : 0) + yd * n + xd0;
+      int p[NP], d[NP];
+      predict_row<NP>(M, R, dc, 0, n, n, yd, xd0, maxv, p);
+      const uint16_t *o = ob + yd * n + xd0;
 #pragma unroll
       for (int i = 0; i < NP; ++i) d[i] = (int)o[i] - p[i];
-    } else {
+      int sa = 0;
 #pragma unroll
-      for (int i = 0; i < NP; ++i) d[i] = 0;
+      for (int i = 0; i < NP; ++i) sa += abs(d[i]);
+      wht_rows<NP>(d, r);
+      int s = 0;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) s += abs(d[i]);
+      if (r == 0) s += (abs(d[0]) >> 2) - abs(d[0]);
+      s = dpp_group_sum<NP>(s);
+      sad += sa;                                                // reduced once per unit below
+      satd += NP == 8 ? (s + 2) >> 2 : (s + 1) >> 1;            // picture-generic.c:345 / :197
     }
-    int sad = 0;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) sad += abs(d[i]);
-    wht_rows<NP>(d, r);
-    int s = 0;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) s += abs(d[i]);
-    if (r == 0) s += (abs(d[0]) >> 2) - abs(d[0]);
-    for (int off = NP >> 1; off >= 1; off >>= 1) { s += __shfl_xor(s, off, 64); sad += __shfl_xor(sad, off, 64); }
-    const int satd = NP == 8 ? (s + 2) >> 2 : (s + 1) >> 1;   // picture-generic.c:345 / :197
+    sad = dpp_group_sum<NP>(sad);
     if (on && r == 0) {
-      atomicAdd(&sAcc[(b * n_modes + m) * 2], satd);
-      atomicAdd(&sAcc[(b * n_modes + m) * 2 + 1], sad);
+      // search_intra.c:158: min(SATD, 2*SAD) with the NxN strategy functions' depth shifts
+      // (satd_4x4 is unshifted, picture-generic.c:170; everything else >> depth-8)
+      const uint32_t c_satd = (uint32_t)satd >> (NP == 4 ? 0 : dshift);
+      const uint32_t c_sad = (uint32_t)sad >> dshift;
+      costs[(size_t)(blk0 + b) * n_modes + m] = min(c_satd, 2 * c_sad);
     }
-  }
-  __syncthreads();
-  // search_intra.c:158: min(SATD, 2*SAD) with the NxN strategy functions' depth shifts
-  // (satd_4x4 is unshifted, picture-generic.c:170; everything else >> depth-8)
-  const int dshift = px_traits<PX>::depth - 8;
-  for (int e = threadIdx.x; e < here * n_modes; e += blockDim.x) {
-    const uint32_t satd = (uint32_t)sAcc[e * 2] >> (NP == 4 ? 0 : dshift);
-    const uint32_t sad = (uint32_t)sAcc[e * 2 + 1] >> dshift;
-    costs[(size_t)blk0 * n_modes + e] = min(satd, 2 * sad);
+    m += ngroups;
+    while (m >= n_modes) { m -= n_modes; ++b; }
   }
 }
 
@@ -539,12 +538,13 @@ extern "C" int uvghip_intra_search_batch(int bitdepth, const void *rec, int rec_
   if (!(size == 4 || size == 8 || size == 16 || size == 32) || n_modes < 1 || n_modes > 128)
     return uvghip_set_error(hipErrorInvalidValue, __func__);
   if (n <= 0) return 0;
-  const int bpg = size == 4 ? 8 : size == 8 ? 4 : 1;
-  const size_t lds = (size_t)bpg * (4 * 104 + 2 * size * size) * 2 + (size_t)bpg * n_modes * 2 * 4 +
-                     (size_t)n_modes * sizeof(mode_info) + (size_t)bpg * 4 + 16;
+  // blocks per workgroup: enough (block, mode) units to keep the 32 (64 for 4x4) lane groups busy
+  const int bpg = size == 4 ? 16 : size == 8 ? 8 : 4;
+  const int log2_tiles_x = size == 4 ? 0 : (size == 8 ? 0 : size == 16 ? 1 : 2);
+  const size_t lds = (size_t)bpg * (4 * 104 + 2 * size * size) * 2 + (size_t)bpg * 4 + (size_t)n_modes * sizeof(mode_info) + 16;
   const int grid = (n + bpg - 1) / bpg;
   hipStream_t st = uvghip_stream(stream);
-#define LAUNCH(PX, NP) intra_search_kernel<PX, NP><<<grid, 256, lds, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, blks, n, bpg, modes, n_modes, costs)
+#define LAUNCH(PX, NP) intra_search_kernel<PX, NP><<<grid, 256, lds, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, log2_tiles_x, blks, n, bpg, modes, n_modes, costs)
   if (bitdepth == 8) { if (size == 4) LAUNCH(uint8_t, 4); else LAUNCH(uint8_t, 8); }
   else { if (size == 4) LAUNCH(uint16_t, 4); else LAUNCH(uint16_t, 8); }
 #undef LAUNCH

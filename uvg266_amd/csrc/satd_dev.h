@@ -4,11 +4,30 @@
 #pragma once
 #include "uvghip_common.h"
 
+// Lane exchanges inside a 4- or 8-lane group as single DPP moves (no LDS crossbar traffic):
+// xor 1 / xor 2 are quad permutes, "mirror8" maps lane i of every aligned 8-lane group to lane 7-i.
+__device__ __forceinline__ int dpp_xor1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true); }    // quad_perm [1,0,3,2]
+__device__ __forceinline__ int dpp_xor2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true); }    // quad_perm [2,3,0,1]
+__device__ __forceinline__ int dpp_mirror8(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true); } // row_half_mirror
+
+// Sum over an aligned group of 4 or 8 lanes; every lane of the group gets the total.
+template <int G> __device__ __forceinline__ int dpp_group_sum(int v)
+{
+  v += dpp_xor1(v);
+  v += dpp_xor2(v);
+  if constexpr (G == 8) v += dpp_mirror8(v);
+  return v;
+}
+
 // Row-per-lane Walsh-Hadamard.  `v` holds one row of N differences; the N
 // lanes r = 0..N-1 of an aligned lane group hold the N rows.  Horizontal pass
-// in registers, vertical pass by lane-xor butterflies.  The coefficient order
-// differs from the reference's butterfly network but the multiset of
-// magnitudes is identical and the DC term ends up in lane 0, v[0].
+// in registers, vertical pass by DPP butterflies.  For N = 8 the three vertical
+// stages pair lanes by xor 1, xor 2 and the 8-lane mirror (r <-> 7-r = r xor 7):
+// {001, 010, 111} is a basis of Z2^3, and with the roles (who keeps the sum, who
+// the difference) taken from the coordinates of r in that basis -- bit0^bit2,
+// bit1^bit2, bit2 -- the result is the full set of Walsh functions.  The
+// coefficient order differs from the reference's butterfly network but the
+// multiset of magnitudes is identical and the DC term ends up in lane 0, v[0].
 template <int N>
 __device__ __forceinline__ void wht_rows(int (&v)[N], int r)
 {
@@ -24,14 +43,15 @@ __device__ __forceinline__ void wht_rows(int (&v)[N], int r)
       }
     }
   }
+  const int b2 = N == 8 ? (r >> 2) & 1 : 0;
+  const bool hi1 = ((r & 1) ^ b2) != 0, hi2 = (((r >> 1) & 1) ^ b2) != 0, hi3 = b2 != 0;
 #pragma unroll
-  for (int m = N / 2; m >= 1; m >>= 1) {
-    const bool hi = (r & m) != 0;
+  for (int j = 0; j < N; ++j) { const int o = dpp_xor1(v[j]); v[j] = hi1 ? (o - v[j]) : (v[j] + o); }
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const int o = __shfl_xor(v[j], m, 64);
-      v[j] = hi ? (o - v[j]) : (v[j] + o);
-    }
+  for (int j = 0; j < N; ++j) { const int o = dpp_xor2(v[j]); v[j] = hi2 ? (o - v[j]) : (v[j] + o); }
+  if constexpr (N == 8) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) { const int o = dpp_mirror8(v[j]); v[j] = hi3 ? (o - v[j]) : (v[j] + o); }
   }
 }
 
@@ -44,7 +64,7 @@ __device__ __forceinline__ int satd8_cost(int (&d)[8], int r)
 #pragma unroll
   for (int j = 0; j < 8; ++j) s += abs(d[j]);
   if (r == 0) s += (abs(d[0]) >> 2) - abs(d[0]);          // DC term counted as |dc|>>2
-  s = group_sum(s, 8);
+  s = dpp_group_sum<8>(s);
   return (s + 2) >> 2;                                     // picture-generic.c:345
 }
 __device__ __forceinline__ int satd4_cost(int (&d)[4], int r)
@@ -54,7 +74,7 @@ __device__ __forceinline__ int satd4_cost(int (&d)[4], int r)
 #pragma unroll
   for (int j = 0; j < 4; ++j) s += abs(d[j]);
   if (r == 0) s += (abs(d[0]) >> 2) - abs(d[0]);
-  s = group_sum(s, 4);
+  s = dpp_group_sum<4>(s);
   return (s + 1) >> 1;                                     // picture-generic.c:197
 }
 
