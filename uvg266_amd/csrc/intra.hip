@@ -25,6 +25,7 @@
 #include "percall.h"
 #include "ref_abi.h"
 #include "satd_dev.h"
+#include "satd_tile_dev.h"
 
 // ---- constant tables (H.266 8.4.5.2.13: intraPredAngle, invAngle; table 25 fC) -------------
 __device__ static const int16_t kSampleDisp[32] = {0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 18, 20, 23, 26, 29, 32, 35, 39, 45, 51,
@@ -428,105 +429,281 @@ extern "C" int uvghip_intra_select_best(const uint32_t *costs, int n, const int8
 }
 
 // ----------------------------------------------------------------------- search kernel ----
-// NP = 8: 8x8 tiles of an n x n block (n >= 8); NP = 4: the whole 4x4 block.
-// Work unit of an NP-lane group = one (block, mode): the group walks the block's tiles, keeps the two
-// cost sums in registers and stores the final cost itself (no LDS atomics, no integer division:
-// the (block, mode) counters advance incrementally and the tile index splits by shifts).
-template <typename PX, int NP>
+// Tile-per-lane rough search.  A workgroup owns 64 tiles (T x T, T = 8, or 4 for 4x4 blocks) =
+// 64 / tiles_per_block blocks; lane l of every wave is tile l.  The four waves walk the candidate
+// list (wave w takes modes w, w+4, ...), so the mode -- and with it every branch of the predictor --
+// is uniform across the wave.  A lane predicts its whole tile row by row in registers, subtracts the
+// original (packed 16-bit pairs straight from LDS), accumulates SAD with v_sad_u16 and runs the
+// Hadamard in its own registers (satd_tile_dev.h).  Tile costs of one block are added across
+// 1/4/16 neighbouring lanes with DPP and one lane stores min(SATD, 2*SAD).
+//
+// LDS per block: four reference rows of RS = 2n+4 samples (raw top/left, smoothed top/left), the
+// original block and its transpose (horizontal modes are predicted in the reference's transposed
+// work domain and compared with the transposed original -- SAD and the Hadamard magnitudes are
+// transpose-invariant).  Block strides are odd multiples of a dword (rows) / of 4 dwords
+// (originals) so that the 64 lanes of a wave spread over all banks.
+// Negative angles read the projected side reference left of main[0]
+// (intra-generic.c:150-170); each wave builds that extended row for its current mode in a
+// private LDS strip so the tap loads are plain base+immediate ds_read_u16.
+struct search_mode {
+  int kind;        // 0 planar, 1 DC, 2 angular
+  int row_main;    // reference row (0 top, 1 left, 2 smoothed top, 3 smoothed left) that is "main"
+  int row_side;
+  int sd, inv;     // intraPredAngle, invAngle
+  int pdpc;        // 0 none, 1 planar/DC, 2 angular (projected side sample), 3 gradient (sd == 0)
+  int scale;       // PDPC scale
+  int coef;        // offset of the 32-entry tap table in sCoef (0 cubic, 32 smoothing)
+  int transposed;  // work domain is the transposed block
+};
+
+__device__ inline search_mode make_search_mode(int mode, int n)
+{
+  const mode_info M = make_mode_info(mode, n, n, 0);
+  const int lgn = ilog2_dev(n);
+  search_mode S;
+  S.kind = mode < 2 ? mode : 2;
+  const int f = M.filtered ? 2 : 0;
+  if (mode < 2 || M.vertical) { S.row_main = f; S.row_side = f + 1; }
+  else { S.row_main = f + 1; S.row_side = f; }
+  S.sd = M.sample_disp; S.inv = M.inv_disp;
+  S.pdpc = !M.pdpc ? 0 : (mode < 2 ? 1 : (M.sample_disp != 0 ? 2 : 3));
+  S.scale = (mode < 2 || M.sample_disp == 0) ? (2 * lgn - 2) >> 2 : M.scale;
+  S.coef = M.use_cubic ? 0 : 32;
+  S.transposed = mode >= 2 && !M.vertical;
+  return S;
+}
+
+// Predict rows yd0..yd0+T-1, columns xd0..xd0+T-1 of the work domain and leave
+// original - prediction in d (packed pairs), adding the tile's SAD to `sad`.
+template <int T>
+__device__ __forceinline__ void search_tile_diff(const search_mode &S, const uint16_t *ref, int RS, const uint16_t *ext,
+                                                 const uint32_t *sCoef, int dc, int n, int lgn, int xd0, int yd0,
+                                                 const uint16_t *otile, int maxv, uint32_t (&d)[T][T / 2], uint32_t &sad)
+{
+  const uint16_t *mainr = ref + S.row_main * RS, *side = ref + S.row_side * RS;
+#pragma unroll
+  for (int r = 0; r < T; ++r) {
+    const int yd = yd0 + r;
+    int out[T];
+    if (S.kind == 2) {
+      const uint16_t *rowp = S.sd < 0 ? ext : mainr;
+      const int delta = S.sd * (yd + 1), di = delta >> 5, df = delta & 31;
+      const uint32_t cf = sCoef[S.coef + df];
+      const int f0 = (int)(int8_t)(cf & 0xff), f1 = (int)(int8_t)((cf >> 8) & 0xff), f2 = (int)(int8_t)((cf >> 16) & 0xff),
+                f3 = (int)(int8_t)(cf >> 24);
+      const uint16_t *q = rowp + di + xd0;
+      int p[T + 3];
+#pragma unroll
+      for (int k = 0; k < T + 3; ++k) p[k] = q[k];
+#pragma unroll
+      for (int i = 0; i < T; ++i)
+        out[i] = clampi((f0 * p[i] + f1 * p[i + 1] + f2 * p[i + 2] + f3 * p[i + 3] + 32) >> 6, 0, maxv);
+      if (S.pdpc == 2) {
+        const int lim = min(3 << S.scale, n);
+        if (xd0 < lim) {
+#pragma unroll
+          for (int i = 0; i < T; ++i) {
+            const int x = xd0 + i;
+            if (x < lim) {
+              const int inv_sum = 256 + (x + 1) * S.inv;
+              const int wl = 32 >> ((2 * x) >> S.scale);
+              const int l = side[yd + (inv_sum >> 9) + 1];
+              out[i] = out[i] + ((wl * (l - out[i]) + 32) >> 6);
+            }
+          }
+        }
+      } else if (S.pdpc == 3) {
+        const int lim = min(3 << S.scale, n);
+        if (xd0 < lim) {
+          const int g = (int)side[1 + yd] - (int)mainr[0];
+#pragma unroll
+          for (int i = 0; i < T; ++i) {
+            const int x = xd0 + i;
+            if (x < lim) out[i] = clampi(out[i] + (((32 >> ((2 * x) >> S.scale)) * g + 32) >> 6), 0, maxv);
+          }
+        }
+      }
+    } else {
+      const int l = side[yd + 1];
+      if (S.kind == 0) {
+        const int tr = mainr[n + 1], bl = side[n + 1];
+        const int offset = 1 << (2 * lgn), shift = 1 + 2 * lgn;
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+          const int x = xd0 + i, t = mainr[x + 1];
+          const int hor = (l << lgn) + (x + 1) * (tr - l);
+          const int ver = (t << lgn) + (yd + 1) * (bl - t);
+          out[i] = ((hor << lgn) + (ver << lgn) + offset) >> shift;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i) out[i] = dc;
+      }
+      if (S.pdpc) {
+        const int wt = 32 >> min(31, (yd << 1) >> S.scale);
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+          const int x = xd0 + i, wl = 32 >> min(31, (x << 1) >> S.scale);
+          const int c = out[i];
+          out[i] = c + ((wl * (l - c) + wt * ((int)mainr[x + 1] - c) + 32) >> 6);
+        }
+      }
+    }
+    // original row (already transposed for horizontal modes), packed pairs
+    uint32_t o[T / 2];
+    if constexpr (T == 8) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(otile + r * n);
+      o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else {
+      const uint2 v = *reinterpret_cast<const uint2 *>(otile + r * n);
+      o[0] = v.x; o[1] = v.y;
+    }
+#pragma unroll
+    for (int c = 0; c < T / 2; ++c) {
+      const uint32_t pp = (uint32_t)out[2 * c] | ((uint32_t)out[2 * c + 1] << 16);
+      sad = __builtin_amdgcn_sad_u16(o[c], pp, sad);
+      d[r][c] = pk_sub(o[c], pp);
+    }
+  }
+}
+
+struct search_layout {
+  int RS, BRS, OS, PS;                        // u16 units
+  int off_orig, off_ref, off_priv, off_dc, off_coef, off_mode;   // bytes
+  size_t total;
+};
+__host__ __device__ inline search_layout make_search_layout(int n, int bpg, int n_modes)
+{
+  search_layout L;
+  L.RS = 2 * n + 4;
+  L.BRS = 4 * L.RS + 2;                       // 2*RS + 1 dwords: odd
+  L.OS = 2 * n * n + (n == 4 ? 4 : 8);        // orig + transpose, stride = 4 (2 for 4x4) dwords mod 32
+  L.PS = 2 * n + 6;                           // n + 3 dwords: odd
+  size_t o = 0;
+  L.off_orig = (int)o; o += (size_t)bpg * L.OS * 2; o = (o + 15) & ~(size_t)15;
+  L.off_ref = (int)o;  o += (size_t)bpg * L.BRS * 2; o = (o + 15) & ~(size_t)15;
+  L.off_priv = (int)o; o += (size_t)4 * bpg * L.PS * 2; o = (o + 15) & ~(size_t)15;
+  L.off_dc = (int)o;   o += (size_t)bpg * 4;
+  L.off_coef = (int)o; o += 64 * 4;
+  L.off_mode = (int)o; o += (size_t)n_modes * sizeof(search_mode);
+  L.total = o;
+  return L;
+}
+
+template <typename PX, int T>
 __global__ void __launch_bounds__(256)
 intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__restrict__ orig, int orig_stride,
-                    int n, int log2_tiles_x, const uvghip_intra_blk_t *__restrict__ blks, int n_blks, int bpg,
+                    int n, const uvghip_intra_blk_t *__restrict__ blks, int n_blks,
                     const int8_t *__restrict__ modes, int n_modes, uint32_t *__restrict__ costs)
 {
-  constexpr int REFN = 104;   // 3*32 + 3 rounded up
-  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-  // per block: 4 reference rows, orig, origT; then DC values; then the mode table
-  const int nn = n * n;
-  const int per_blk_u16 = 4 * REFN + 2 * nn;
-  uint16_t *sBlk = smem;
-  int *sDC = reinterpret_cast<int *>(smem + (size_t)bpg * per_blk_u16);        // [bpg]
-  mode_info *sM = reinterpret_cast<mode_info *>(sDC + bpg);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lgn = ilog2_dev(n);
+  const int lg_tx = lgn - (T == 8 ? 3 : 2);       // log2(tiles per block row)
+  const int lg_tiles = 2 * lg_tx, tiles = 1 << lg_tiles;
+  const int bpg = 64 >> lg_tiles;
+  const search_layout L = make_search_layout(n, bpg, n_modes);
+  uint16_t *sOrig = reinterpret_cast<uint16_t *>(smem_raw + L.off_orig);
+  uint16_t *sRef = reinterpret_cast<uint16_t *>(smem_raw + L.off_ref);
+  uint16_t *sPriv = reinterpret_cast<uint16_t *>(smem_raw + L.off_priv);
+  int *sDC = reinterpret_cast<int *>(smem_raw + L.off_dc);
+  uint32_t *sCoef = reinterpret_cast<uint32_t *>(smem_raw + L.off_coef);
+  search_mode *sMode = reinterpret_cast<search_mode *>(smem_raw + L.off_mode);
 
   const int blk0 = blockIdx.x * bpg;
   const int here = min(bpg, n_blks - blk0);
   if (here <= 0) return;
+  const int nn = n * n;
 
-  // ---- stage ----
-  const int tpb = blockDim.x / bpg;        // threads cooperating on one block
-  const int myb = threadIdx.x / tpb, mytid = threadIdx.x - myb * tpb;
-  if (myb < here) {
-    const uvghip_intra_blk_t b = blks[blk0 + myb];
-    uint16_t *base = sBlk + (size_t)myb * per_blk_u16;
-    build_ref_rows<PX>(rec, rec_stride, b.x, b.y, n, n, b.avail_top, b.avail_left, base, base + REFN, REFN, mytid, tpb);
-    uint16_t *so = base + 4 * REFN, *sot = so + nn;
-    const int lg = 31 - __clz(n);
-    for (int e = mytid; e < nn; e += tpb) {
-      const int yy = e >> lg, xx = e & (n - 1);
-      const uint16_t v = orig[(size_t)(b.y + yy) * orig_stride + b.x + xx];
-      so[e] = v;
-      sot[xx * n + yy] = v;
+  // ---- stage: tpb = 4 * tiles threads per block ----
+  {
+    const int tpb = 4 << lg_tiles;
+    const int myb = threadIdx.x >> (lg_tiles + 2), mytid = threadIdx.x & (tpb - 1);
+    const bool on = myb < here;
+    uvghip_intra_blk_t b;
+    uint16_t *base = sRef + (size_t)myb * L.BRS;
+    if (on) {
+      b = blks[blk0 + myb];
+      build_ref_rows<PX>(rec, rec_stride, b.x, b.y, n, n, b.avail_top, b.avail_left, base, base + L.RS, L.RS, mytid, tpb);
+      uint16_t *so = sOrig + (size_t)myb * L.OS, *sot = so + nn;
+      for (int e = mytid; e < nn; e += tpb) {
+        const int yy = e >> lgn, xx = e & (n - 1);
+        const uint16_t v = orig[(size_t)(b.y + yy) * orig_stride + b.x + xx];
+        so[e] = v;
+        sot[xx * n + yy] = v;
+      }
     }
+    for (int m = threadIdx.x; m < n_modes; m += 256) sMode[m] = make_search_mode(modes[m], n);
+    if (threadIdx.x < 64) {
+      const int df = threadIdx.x & 31;
+      int f0, f1, f2, f3;
+      if (threadIdx.x < 32) { f0 = kCubic[df][0]; f1 = kCubic[df][1]; f2 = kCubic[df][2]; f3 = kCubic[df][3]; }
+      else { f0 = 16 - (df >> 1); f1 = 32 - (df >> 1); f2 = 16 + (df >> 1); f3 = df >> 1; }   // intra-generic.c:206-214
+      sCoef[threadIdx.x] = (uint32_t)(f0 & 0xff) | ((uint32_t)(f1 & 0xff) << 8) | ((uint32_t)(f2 & 0xff) << 16) | ((uint32_t)(f3 & 0xff) << 24);
+    }
+    __syncthreads();
+    if (on) {
+      filter_ref_rows(base, base + L.RS, base + 2 * L.RS, base + 3 * L.RS, n, n, L.RS, mytid, tpb);
+      if (mytid == 0) sDC[myb] = dc_value(base, base + L.RS, n, n);
+    }
+    __syncthreads();
   }
-  for (int m = threadIdx.x; m < n_modes; m += blockDim.x) sM[m] = make_mode_info(modes[m], n, n, 0);
-  __syncthreads();
-  if (myb < here) {
-    uint16_t *base = sBlk + (size_t)myb * per_blk_u16;
-    filter_ref_rows(base, base + REFN, base + 2 * REFN, base + 3 * REFN, n, n, REFN, mytid, tpb);
-    if (mytid == 0) sDC[myb] = dc_value(base, base + REFN, n, n);
-  }
-  __syncthreads();
 
-  // ---- units: (block, mode) per NP-lane group ----
+  // ---- search: lane = tile, wave = mode ----
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int lb = lane >> lg_tiles, tile = lane & (tiles - 1);
+  const bool active = lb < here;
+  const int bb = active ? lb : 0;
+  const int xd0 = (tile & ((1 << lg_tx) - 1)) * T, yd0 = (tile >> lg_tx) * T;
+  const uint16_t *ref = sRef + (size_t)bb * L.BRS;
+  const uint16_t *ob = sOrig + (size_t)bb * L.OS + yd0 * n + xd0;
+  uint16_t *priv = sPriv + ((size_t)wave * bpg + bb) * L.PS;
+  const int dc = sDC[bb];
   const int maxv = px_traits<PX>::maxv;
   const int dshift = px_traits<PX>::depth - 8;
-  const int tiles = 1 << (2 * log2_tiles_x), tmask = (1 << log2_tiles_x) - 1;
-  constexpr int ngroups = 256 / NP;
-  const int g = threadIdx.x / NP, r = threadIdx.x & (NP - 1);
-  const int units = here * n_modes;
-  // group g takes units g, g + ngroups, ...; (b, m) follow incrementally
-  int b = 0, m = g;
-  while (m >= n_modes) { m -= n_modes; ++b; }
-  const int rounds = (units + ngroups - 1) / ngroups;
-  for (int it = 0; it < rounds; ++it) {
-    const bool on = b < here;
-    const int bb = on ? b : 0, mm = on ? m : 0;
-    const mode_info M = sM[mm];
-    const uint16_t *base = sBlk + (size_t)bb * per_blk_u16;
-    const ref_rows R{base, base + REFN, base + 2 * REFN, base + 3 * REFN};
-    const bool transposed = M.mode >= 2 && !M.vertical;
-    const uint16_t *ob = base + 4 * REFN + (transposed ? nn : 0);
-    const int dc = sDC[bb];
-    int satd = 0, sad = 0;
-    for (int tile = 0; tile < tiles; ++tile) {
-      const int ty = tile >> log2_tiles_x, tx = tile & tmask;
-      const int yd = (transposed ? tx : ty) * NP + r, xd0 = (transposed ? ty : tx) * NP;
-      int p[NP], d[NP];
-      predict_row<NP>(M, R, dc, 0, n, n, yd, xd0, maxv, p);
-      const uint16_t *o = ob + yd * n + xd0;
+
+  for (int m = wave; m < n_modes; m += 4) {
+    search_mode S;
+    {
+      const int *src = reinterpret_cast<const int *>(sMode + m);
+      int *dst = reinterpret_cast<int *>(&S);
 #pragma unroll
-      for (int i = 0; i < NP; ++i) d[i] = (int)o[i] - p[i];
-      int sa = 0;
-#pragma unroll
-      for (int i = 0; i < NP; ++i) sa += abs(d[i]);
-      wht_rows<NP>(d, r);
-      int s = 0;
-#pragma unroll
-      for (int i = 0; i < NP; ++i) s += abs(d[i]);
-      if (r == 0) s += (abs(d[0]) >> 2) - abs(d[0]);
-      s = dpp_group_sum<NP>(s);
-      sad += sa;                                                // reduced once per unit below
-      satd += NP == 8 ? (s + 2) >> 2 : (s + 1) >> 1;            // picture-generic.c:345 / :197
+      for (int k = 0; k < (int)(sizeof(search_mode) / 4); ++k) dst[k] = __builtin_amdgcn_readfirstlane(src[k]);
     }
-    sad = dpp_group_sum<NP>(sad);
-    if (on && r == 0) {
+    if (S.kind == 2 && S.sd < 0) {
+      // extended main row of this (block, mode): priv[n - j] = side[min((j*inv + 256) >> 9, n)], j = 1..n;
+      // priv[n + i] = main[i], i = 0..n+2.  The block's `tiles` lanes share the work.
+      const uint16_t *mainr = ref + S.row_main * L.RS, *side = ref + S.row_side * L.RS;
+      for (int e = tile; e < 2 * n + 3; e += tiles) {
+        uint16_t v;
+        if (e < n) { const int j = n - e; v = side[min((j * S.inv + 256) >> 9, n)]; }
+        else v = mainr[e - n];
+        priv[e] = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    uint32_t d[T][T / 2];
+    uint32_t sad = 0;
+    search_tile_diff<T>(S, ref, L.RS, priv + n, sCoef, dc, n, lgn, xd0, yd0, ob + (S.transposed ? nn : 0), maxv, d, sad);
+    uint32_t satd;
+    if constexpr (T == 8) satd = satd8_tile_lane(d); else satd = satd4_tile_lane(d);
+    if (lg_tiles >= 2) {
+      satd += dpp_xor1(satd); sad += dpp_xor1(sad);
+      satd += dpp_xor2(satd); sad += dpp_xor2(sad);
+      if (lg_tiles == 4) {
+        satd += dpp_mirror8(satd); sad += dpp_mirror8(sad);
+        satd += dpp_mirror16(satd); sad += dpp_mirror16(sad);
+      }
+    }
+    if (S.kind == 2 && S.sd < 0) __builtin_amdgcn_wave_barrier();   // strip is rewritten by the next negative mode
+    if (active && tile == 0) {
       // search_intra.c:158: min(SATD, 2*SAD) with the NxN strategy functions' depth shifts
       // (satd_4x4 is unshifted, picture-generic.c:170; everything else >> depth-8)
-      const uint32_t c_satd = (uint32_t)satd >> (NP == 4 ? 0 : dshift);
-      const uint32_t c_sad = (uint32_t)sad >> dshift;
-      costs[(size_t)(blk0 + b) * n_modes + m] = min(c_satd, 2 * c_sad);
+      const uint32_t c_satd = satd >> (T == 4 ? 0 : dshift);
+      const uint32_t c_sad = sad >> dshift;
+      costs[(size_t)(blk0 + lb) * n_modes + m] = min(c_satd, 2 * c_sad);
     }
-    m += ngroups;
-    while (m >= n_modes) { m -= n_modes; ++b; }
   }
 }
 
@@ -538,13 +715,12 @@ extern "C" int uvghip_intra_search_batch(int bitdepth, const void *rec, int rec_
   if (!(size == 4 || size == 8 || size == 16 || size == 32) || n_modes < 1 || n_modes > 128)
     return uvghip_set_error(hipErrorInvalidValue, __func__);
   if (n <= 0) return 0;
-  // blocks per workgroup: enough (block, mode) units to keep the 32 (64 for 4x4) lane groups busy
-  const int bpg = size == 4 ? 16 : size == 8 ? 8 : 4;
-  const int log2_tiles_x = size == 4 ? 0 : (size == 8 ? 0 : size == 16 ? 1 : 2);
-  const size_t lds = (size_t)bpg * (4 * 104 + 2 * size * size) * 2 + (size_t)bpg * 4 + (size_t)n_modes * sizeof(mode_info) + 16;
+  const int tiles = size == 4 ? 1 : (size / 8) * (size / 8);
+  const int bpg = 64 / tiles;
+  const search_layout L = make_search_layout(size, bpg, n_modes);
   const int grid = (n + bpg - 1) / bpg;
   hipStream_t st = uvghip_stream(stream);
-#define LAUNCH(PX, NP) intra_search_kernel<PX, NP><<<grid, 256, lds, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, log2_tiles_x, blks, n, bpg, modes, n_modes, costs)
+#define LAUNCH(PX, T) intra_search_kernel<PX, T><<<grid, 256, L.total, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, blks, n, modes, n_modes, costs)
   if (bitdepth == 8) { if (size == 4) LAUNCH(uint8_t, 4); else LAUNCH(uint8_t, 8); }
   else { if (size == 4) LAUNCH(uint16_t, 4); else LAUNCH(uint16_t, 8); }
 #undef LAUNCH

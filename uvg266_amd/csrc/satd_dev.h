@@ -10,6 +10,8 @@ __device__ __forceinline__ int dpp_xor1(int v) { return __builtin_amdgcn_update_
 __device__ __forceinline__ int dpp_xor2(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true); }    // quad_perm [2,3,0,1]
 __device__ __forceinline__ int dpp_mirror8(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true); } // row_half_mirror
 
+__device__ __forceinline__ int dpp_mirror16(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true); } // row_mirror
+
 // Sum over an aligned group of 4 or 8 lanes; every lane of the group gets the total.
 template <int G> __device__ __forceinline__ int dpp_group_sum(int v)
 {
