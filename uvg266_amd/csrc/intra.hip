@@ -473,97 +473,177 @@ __device__ inline search_mode make_search_mode(int mode, int n)
   return S;
 }
 
-// Predict rows yd0..yd0+T-1, columns xd0..xd0+T-1 of the work domain and leave
-// original - prediction in d (packed pairs), adding the tile's SAD to `sad`.
+// ---- tile predictors of the search kernel --------------------------------------------------
+// Each predicts rows yd0..yd0+T-1, columns xd0..xd0+T-1 of the work domain, leaves
+// original - prediction in d (packed pairs) and adds the tile's SAD to `sad`.  One function per
+// predictor family, every one straight-line over the T rows (column-dependent PDPC weights are
+// hoisted and set to zero where PDPC does not apply instead of branching), with the LDS loads
+// of row r+1 issued before the arithmetic of row r.
+
 template <int T>
-__device__ __forceinline__ void search_tile_diff(const search_mode &S, const uint16_t *ref, int RS, const uint16_t *ext,
-                                                 const uint32_t *sCoef, int dc, int n, int lgn, int xd0, int yd0,
-                                                 const uint16_t *otile, int maxv, uint32_t (&d)[T][T / 2], uint32_t &sad)
+__device__ __forceinline__ void load_orig_row(const uint16_t *otile, int n, int r, uint32_t (&o)[T / 2])
 {
-  const uint16_t *mainr = ref + S.row_main * RS, *side = ref + S.row_side * RS;
+  if constexpr (T == 8) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(otile + r * n);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  } else {
+    const uint2 v = *reinterpret_cast<const uint2 *>(otile + r * n);
+    o[0] = v.x; o[1] = v.y;
+  }
+}
+template <int T>
+__device__ __forceinline__ void finish_row(const int (&out)[T], const uint32_t (&o)[T / 2], uint32_t (&drow)[T / 2], uint32_t &sad)
+{
+#pragma unroll
+  for (int c = 0; c < T / 2; ++c) {
+    const uint32_t pp = (uint32_t)out[2 * c] | ((uint32_t)out[2 * c + 1] << 16);
+    sad = __builtin_amdgcn_sad_u16(o[c], pp, sad);
+    drow[c] = pk_sub(o[c], pp);
+  }
+}
+
+// PDPC column weights 32 >> ((2x) >> scale) for x < lim, else 0 (a zero weight leaves the sample as is)
+template <int T>
+__device__ __forceinline__ void pdpc_col_weights(int xd0, int scale, int lim, int (&wl)[T])
+{
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    const int x = xd0 + i;
+    wl[i] = x < lim ? 32 >> min(31, (2 * x) >> scale) : 0;
+  }
+}
+
+template <int T>
+__device__ __forceinline__ void ang_load(const search_mode &S, const uint16_t *rowp, const uint32_t *sCoef, int xd0, int yd,
+                                         int (&p)[T + 3], uint32_t &cf)
+{
+  const int delta = __mul24(S.sd, yd + 1), di = delta >> 5, df = delta & 31;
+  cf = sCoef[S.coef + df];
+  const uint16_t *q = rowp + di + xd0;
+#pragma unroll
+  for (int k = 0; k < T + 3; ++k) p[k] = q[k];
+}
+template <int T>
+__device__ __forceinline__ void ang_filter(const int (&p)[T + 3], uint32_t cf, int maxv, int (&out)[T])
+{
+  const int f0 = (int)(int8_t)(cf & 0xff), f1 = (int)(int8_t)((cf >> 8) & 0xff), f2 = (int)(int8_t)((cf >> 16) & 0xff),
+            f3 = (int)(int8_t)(cf >> 24);
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+    out[i] = clampi((__mul24(f0, p[i]) + __mul24(f1, p[i + 1]) + __mul24(f2, p[i + 2]) + __mul24(f3, p[i + 3]) + 32) >> 6, 0, maxv);
+}
+
+// PDPC: 0 none, 2 projected side sample (intra-generic.c:262-277), 3 gradient of the pure
+// horizontal/vertical modes (:279-293)
+template <int T, int PDPC>
+__device__ __forceinline__ void search_tile_angular(const search_mode &S, const uint16_t *mainr, const uint16_t *side,
+                                                    const uint16_t *rowp, const uint32_t *sCoef, int n, int RS, int xd0, int yd0,
+                                                    const uint16_t *otile, int maxv, uint32_t (&d)[T][T / 2], uint32_t &sad)
+{
+  int wl[T], so[T];
+  int tl = 0;
+  if constexpr (PDPC != 0) {
+    const int lim = min(3 << S.scale, n);
+    pdpc_col_weights<T>(xd0, S.scale, lim, wl);
+    if constexpr (PDPC == 2) {
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        // side[yd + (inv_sum >> 9) + 1]; columns without PDPC get a harmless in-range offset
+        const int x = xd0 + i;
+        so[i] = x < lim ? ((256 + __mul24(x + 1, S.inv)) >> 9) + 1 : 0;
+      }
+    } else tl = mainr[0];
+  }
+  int pA[T + 3], pB[T + 3];
+  uint32_t cA, cB = 0;
+  uint32_t oA[T / 2], oB[T / 2];
+  int lA[T], lB[T];
+  auto side_load = [&](int yd, int (&l)[T]) {
+    if constexpr (PDPC == 2) {
+#pragma unroll
+      for (int i = 0; i < T; ++i) l[i] = side[yd + so[i]];
+    } else if constexpr (PDPC == 3) l[0] = side[1 + yd];
+  };
+  ang_load<T>(S, rowp, sCoef, xd0, yd0, pA, cA);
+  load_orig_row<T>(otile, n, 0, oA);
+  side_load(yd0, lA);
+#pragma unroll
+  for (int r = 0; r < T; ++r) {
+    if (r + 1 < T) {
+      ang_load<T>(S, rowp, sCoef, xd0, yd0 + r + 1, pB, cB);
+      load_orig_row<T>(otile, n, r + 1, oB);
+      side_load(yd0 + r + 1, lB);
+    }
+    int out[T];
+    ang_filter<T>(pA, cA, maxv, out);
+    if constexpr (PDPC == 2) {
+#pragma unroll
+      for (int i = 0; i < T; ++i) out[i] = out[i] + ((__mul24(wl[i], lA[i] - out[i]) + 32) >> 6);
+    } else if constexpr (PDPC == 3) {
+      const int g = lA[0] - tl;
+#pragma unroll
+      for (int i = 0; i < T; ++i) out[i] = clampi(out[i] + ((__mul24(wl[i], g) + 32) >> 6), 0, maxv);
+    }
+    finish_row<T>(out, oA, d[r], sad);
+#pragma unroll
+    for (int k = 0; k < T + 3; ++k) pA[k] = pB[k];
+    cA = cB;
+#pragma unroll
+    for (int c = 0; c < T / 2; ++c) oA[c] = oB[c];
+#pragma unroll
+    for (int i = 0; i < T; ++i) lA[i] = lB[i];
+  }
+}
+
+// planar (intra-generic.c:306-361) or DC, both with the planar/DC PDPC (:414-437).
+// ((hor << lg) + (ver << lg) + (1 << 2lg)) >> (2lg + 1) == (hor + ver + n) >> (lg + 1); hor and ver are
+// linear in x and y, so they advance by one addition per sample.
+template <int T, bool PLANAR>
+__device__ __forceinline__ void search_tile_nonangular(const search_mode &S, const uint16_t *top, const uint16_t *left, int dc,
+                                                       int n, int lgn, int xd0, int yd0, const uint16_t *otile,
+                                                       uint32_t (&d)[T][T / 2], uint32_t &sad)
+{
+  int t[T], wl[T], ver[T], dv[T];
+#pragma unroll
+  for (int i = 0; i < T; ++i) t[i] = top[xd0 + i + 1];
+  pdpc_col_weights<T>(xd0, S.scale, S.pdpc ? n : 0, wl);
+  int tr = 0;
+  if constexpr (PLANAR) {
+    tr = top[n + 1];
+    const int bl = left[n + 1];
+#pragma unroll
+    for (int i = 0; i < T; ++i) { dv[i] = bl - t[i]; ver[i] = (t[i] << lgn) + __mul24(yd0, dv[i]); }   // + dv per row below
+  }
+  int lA = left[yd0 + 1], lB = 0;
+  uint32_t oA[T / 2], oB[T / 2];
+  load_orig_row<T>(otile, n, 0, oA);
 #pragma unroll
   for (int r = 0; r < T; ++r) {
     const int yd = yd0 + r;
+    if (r + 1 < T) { lB = left[yd + 2]; load_orig_row<T>(otile, n, r + 1, oB); }
     int out[T];
-    if (S.kind == 2) {
-      const uint16_t *rowp = S.sd < 0 ? ext : mainr;
-      const int delta = S.sd * (yd + 1), di = delta >> 5, df = delta & 31;
-      const uint32_t cf = sCoef[S.coef + df];
-      const int f0 = (int)(int8_t)(cf & 0xff), f1 = (int)(int8_t)((cf >> 8) & 0xff), f2 = (int)(int8_t)((cf >> 16) & 0xff),
-                f3 = (int)(int8_t)(cf >> 24);
-      const uint16_t *q = rowp + di + xd0;
-      int p[T + 3];
+    if constexpr (PLANAR) {
+      const int dh = tr - lA;
+      int hor = (lA << lgn) + __mul24(xd0, dh) + n;
 #pragma unroll
-      for (int k = 0; k < T + 3; ++k) p[k] = q[k];
-#pragma unroll
-      for (int i = 0; i < T; ++i)
-        out[i] = clampi((f0 * p[i] + f1 * p[i + 1] + f2 * p[i + 2] + f3 * p[i + 3] + 32) >> 6, 0, maxv);
-      if (S.pdpc == 2) {
-        const int lim = min(3 << S.scale, n);
-        if (xd0 < lim) {
-#pragma unroll
-          for (int i = 0; i < T; ++i) {
-            const int x = xd0 + i;
-            if (x < lim) {
-              const int inv_sum = 256 + (x + 1) * S.inv;
-              const int wl = 32 >> ((2 * x) >> S.scale);
-              const int l = side[yd + (inv_sum >> 9) + 1];
-              out[i] = out[i] + ((wl * (l - out[i]) + 32) >> 6);
-            }
-          }
-        }
-      } else if (S.pdpc == 3) {
-        const int lim = min(3 << S.scale, n);
-        if (xd0 < lim) {
-          const int g = (int)side[1 + yd] - (int)mainr[0];
-#pragma unroll
-          for (int i = 0; i < T; ++i) {
-            const int x = xd0 + i;
-            if (x < lim) out[i] = clampi(out[i] + (((32 >> ((2 * x) >> S.scale)) * g + 32) >> 6), 0, maxv);
-          }
-        }
+      for (int i = 0; i < T; ++i) {
+        hor += dh; ver[i] += dv[i];
+        out[i] = (hor + ver[i]) >> (lgn + 1);
       }
     } else {
-      const int l = side[yd + 1];
-      if (S.kind == 0) {
-        const int tr = mainr[n + 1], bl = side[n + 1];
-        const int offset = 1 << (2 * lgn), shift = 1 + 2 * lgn;
 #pragma unroll
-        for (int i = 0; i < T; ++i) {
-          const int x = xd0 + i, t = mainr[x + 1];
-          const int hor = (l << lgn) + (x + 1) * (tr - l);
-          const int ver = (t << lgn) + (yd + 1) * (bl - t);
-          out[i] = ((hor << lgn) + (ver << lgn) + offset) >> shift;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < T; ++i) out[i] = dc;
-      }
-      if (S.pdpc) {
-        const int wt = 32 >> min(31, (yd << 1) >> S.scale);
-#pragma unroll
-        for (int i = 0; i < T; ++i) {
-          const int x = xd0 + i, wl = 32 >> min(31, (x << 1) >> S.scale);
-          const int c = out[i];
-          out[i] = c + ((wl * (l - c) + wt * ((int)mainr[x + 1] - c) + 32) >> 6);
-        }
-      }
+      for (int i = 0; i < T; ++i) out[i] = dc;
     }
-    // original row (already transposed for horizontal modes), packed pairs
-    uint32_t o[T / 2];
-    if constexpr (T == 8) {
-      const uint4 v = *reinterpret_cast<const uint4 *>(otile + r * n);
-      o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-    } else {
-      const uint2 v = *reinterpret_cast<const uint2 *>(otile + r * n);
-      o[0] = v.x; o[1] = v.y;
-    }
+    const int wt = S.pdpc ? 32 >> min(31, (yd << 1) >> S.scale) : 0;
 #pragma unroll
-    for (int c = 0; c < T / 2; ++c) {
-      const uint32_t pp = (uint32_t)out[2 * c] | ((uint32_t)out[2 * c + 1] << 16);
-      sad = __builtin_amdgcn_sad_u16(o[c], pp, sad);
-      d[r][c] = pk_sub(o[c], pp);
+    for (int i = 0; i < T; ++i) {
+      const int c = out[i];
+      out[i] = c + ((__mul24(wl[i], lA - c) + __mul24(wt, t[i] - c) + 32) >> 6);
     }
+    finish_row<T>(out, oA, d[r], sad);
+    lA = lB;
+#pragma unroll
+    for (int c = 0; c < T / 2; ++c) oA[c] = oB[c];
   }
 }
 
@@ -685,7 +765,17 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
     }
     uint32_t d[T][T / 2];
     uint32_t sad = 0;
-    search_tile_diff<T>(S, ref, L.RS, priv + n, sCoef, dc, n, lgn, xd0, yd0, ob + (S.transposed ? nn : 0), maxv, d, sad);
+    {
+      const uint16_t *mainr = ref + S.row_main * L.RS, *side = ref + S.row_side * L.RS;
+      const uint16_t *ot = ob + (S.transposed ? nn : 0);
+      if (S.kind == 2) {
+        const uint16_t *rowp = S.sd < 0 ? priv + n : mainr;
+        if (S.pdpc == 0) search_tile_angular<T, 0>(S, mainr, side, rowp, sCoef, n, L.RS, xd0, yd0, ot, maxv, d, sad);
+        else if (S.pdpc == 2) search_tile_angular<T, 2>(S, mainr, side, rowp, sCoef, n, L.RS, xd0, yd0, ot, maxv, d, sad);
+        else search_tile_angular<T, 3>(S, mainr, side, rowp, sCoef, n, L.RS, xd0, yd0, ot, maxv, d, sad);
+      } else if (S.kind == 0) search_tile_nonangular<T, true>(S, mainr, side, dc, n, lgn, xd0, yd0, ot, d, sad);
+      else search_tile_nonangular<T, false>(S, mainr, side, dc, n, lgn, xd0, yd0, ot, d, sad);
+    }
     uint32_t satd;
     if constexpr (T == 8) satd = satd8_tile_lane(d); else satd = satd4_tile_lane(d);
     if (lg_tiles >= 2) {
