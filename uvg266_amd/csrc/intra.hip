@@ -480,26 +480,42 @@ __device__ inline search_mode make_search_mode(int mode, int n)
 // hoisted and set to zero where PDPC does not apply instead of branching), with the LDS loads
 // of row r+1 issued before the arithmetic of row r.
 
+struct __attribute__((packed, aligned(2))) lds_u32x4 { uint32_t v[4]; };
+struct __attribute__((packed, aligned(2))) lds_u32x2 { uint32_t v[2]; };
+
+// the lane's original tile, packed pairs, kept in registers across all modes of one domain
 template <int T>
-__device__ __forceinline__ void load_orig_row(const uint16_t *otile, int n, int r, uint32_t (&o)[T / 2])
+__device__ __forceinline__ void load_orig_tile(const uint16_t *otile, int n, uint32_t (&o)[T][T / 2])
 {
-  if constexpr (T == 8) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(otile + r * n);
-    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-  } else {
-    const uint2 v = *reinterpret_cast<const uint2 *>(otile + r * n);
-    o[0] = v.x; o[1] = v.y;
+#pragma unroll
+  for (int r = 0; r < T; ++r) {
+    if constexpr (T == 8) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(otile + r * n);
+      o[r][0] = v.x; o[r][1] = v.y; o[r][2] = v.z; o[r][3] = v.w;
+    } else {
+      const uint2 v = *reinterpret_cast<const uint2 *>(otile + r * n);
+      o[r][0] = v.x; o[r][1] = v.y;
+    }
   }
 }
+__device__ __forceinline__ uint32_t pack_lo16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
+
 template <int T>
-__device__ __forceinline__ void finish_row(const int (&out)[T], const uint32_t (&o)[T / 2], uint32_t (&drow)[T / 2], uint32_t &sad)
+__device__ __forceinline__ void finish_row(const uint32_t (&pp)[T / 2], const uint32_t (&o)[T / 2], uint32_t (&drow)[T / 2], uint32_t &sad)
 {
 #pragma unroll
   for (int c = 0; c < T / 2; ++c) {
-    const uint32_t pp = (uint32_t)out[2 * c] | ((uint32_t)out[2 * c + 1] << 16);
-    sad = __builtin_amdgcn_sad_u16(o[c], pp, sad);
-    drow[c] = pk_sub(o[c], pp);
+    sad = __builtin_amdgcn_sad_u16(o[c], pp[c], sad);
+    drow[c] = pk_sub(o[c], pp[c]);
   }
+}
+template <int T>
+__device__ __forceinline__ void finish_row_i32(const int (&out)[T], const uint32_t (&o)[T / 2], uint32_t (&drow)[T / 2], uint32_t &sad)
+{
+  uint32_t pp[T / 2];
+#pragma unroll
+  for (int c = 0; c < T / 2; ++c) pp[c] = (uint32_t)out[2 * c] | ((uint32_t)out[2 * c + 1] << 16);
+  finish_row<T>(pp, o, drow, sad);
 }
 
 // PDPC column weights 32 >> ((2x) >> scale) for x < lim, else 0 (a zero weight leaves the sample as is)
@@ -513,32 +529,49 @@ __device__ __forceinline__ void pdpc_col_weights(int xd0, int scale, int lim, in
   }
 }
 
+// One row of 4-tap inputs: the T+3 (+1 spare) reference samples as "even" pairs E[j] = (p[2j], p[2j+1])
+// -- two unaligned wide LDS reads -- and the two coefficient pairs (f0,f1), (f2,f3) of the row's phase.
+template <int T> struct ang_row { uint32_t E[T / 2 + 2]; uint32_t f01, f23; };
+
 template <int T>
-__device__ __forceinline__ void ang_load(const search_mode &S, const uint16_t *rowp, const uint32_t *sCoef, int xd0, int yd,
-                                         int (&p)[T + 3], uint32_t &cf)
+__device__ __forceinline__ void ang_load(const search_mode &S, const uint16_t *rowp, const uint2 *sCoef, int xd0, int yd, ang_row<T> &R)
 {
   const int delta = __mul24(S.sd, yd + 1), di = delta >> 5, df = delta & 31;
-  cf = sCoef[S.coef + df];
+  const uint2 cf = sCoef[S.coef + df];
+  R.f01 = cf.x; R.f23 = cf.y;
   const uint16_t *q = rowp + di + xd0;
-#pragma unroll
-  for (int k = 0; k < T + 3; ++k) p[k] = q[k];
+  const lds_u32x4 a = *reinterpret_cast<const lds_u32x4 *>(q);
+  R.E[0] = a.v[0]; R.E[1] = a.v[1]; R.E[2] = a.v[2]; R.E[3] = a.v[3];
+  if constexpr (T == 8) {
+    const lds_u32x2 b = *reinterpret_cast<const lds_u32x2 *>(q + 8);
+    R.E[4] = b.v[0]; R.E[5] = b.v[1];
+  }
 }
+// out[i] = (f0 p[i] + f1 p[i+1] + f2 p[i+2] + f3 p[i+3] + 32) >> 6, unclamped (intra-generic.c:216-222):
+// two v_dot2_i32_i16 per sample; the odd-phase pairs (p[2j+1], p[2j+2]) come from v_alignbit.
 template <int T>
-__device__ __forceinline__ void ang_filter(const int (&p)[T + 3], uint32_t cf, int maxv, int (&out)[T])
+__device__ __forceinline__ void ang_filter(const ang_row<T> &R, int (&out)[T])
 {
-  const int f0 = (int)(int8_t)(cf & 0xff), f1 = (int)(int8_t)((cf >> 8) & 0xff), f2 = (int)(int8_t)((cf >> 16) & 0xff),
-            f3 = (int)(int8_t)(cf >> 24);
+  const pk_s16 f01 = __builtin_bit_cast(pk_s16, R.f01), f23 = __builtin_bit_cast(pk_s16, R.f23);
+  uint32_t O[T / 2 + 1];
 #pragma unroll
-  for (int i = 0; i < T; ++i)
-    out[i] = clampi((__mul24(f0, p[i]) + __mul24(f1, p[i + 1]) + __mul24(f2, p[i + 2]) + __mul24(f3, p[i + 3]) + 32) >> 6, 0, maxv);
+  for (int j = 0; j < T / 2 + 1; ++j) O[j] = __builtin_amdgcn_alignbit(R.E[j + 1], R.E[j], 16);
+#pragma unroll
+  for (int j = 0; j < T / 2; ++j) {
+    int ev = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_s16, R.E[j]), f01, 32, false);
+    ev = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_s16, R.E[j + 1]), f23, ev, false);
+    int od = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_s16, O[j]), f01, 32, false);
+    od = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_s16, O[j + 1]), f23, od, false);
+    out[2 * j] = ev >> 6; out[2 * j + 1] = od >> 6;
+  }
 }
 
 // PDPC: 0 none, 2 projected side sample (intra-generic.c:262-277), 3 gradient of the pure
 // horizontal/vertical modes (:279-293)
 template <int T, int PDPC>
 __device__ __forceinline__ void search_tile_angular(const search_mode &S, const uint16_t *mainr, const uint16_t *side,
-                                                    const uint16_t *rowp, const uint32_t *sCoef, int n, int RS, int xd0, int yd0,
-                                                    const uint16_t *otile, int maxv, uint32_t (&d)[T][T / 2], uint32_t &sad)
+                                                    const uint16_t *rowp, const uint2 *sCoef, int n, int xd0, int yd0,
+                                                    const uint32_t (&o)[T][T / 2], int maxv, uint32_t (&d)[T][T / 2], uint32_t &sad)
 {
   int wl[T], so[T];
   int tl = 0;
@@ -554,9 +587,7 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
       }
     } else tl = mainr[0];
   }
-  int pA[T + 3], pB[T + 3];
-  uint32_t cA, cB = 0;
-  uint32_t oA[T / 2], oB[T / 2];
+  ang_row<T> A, B;
   int lA[T], lB[T];
   auto side_load = [&](int yd, int (&l)[T]) {
     if constexpr (PDPC == 2) {
@@ -564,32 +595,41 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
       for (int i = 0; i < T; ++i) l[i] = side[yd + so[i]];
     } else if constexpr (PDPC == 3) l[0] = side[1 + yd];
   };
-  ang_load<T>(S, rowp, sCoef, xd0, yd0, pA, cA);
-  load_orig_row<T>(otile, n, 0, oA);
+  const pk_s16 vmax = {(short)maxv, (short)maxv};
+  ang_load<T>(S, rowp, sCoef, xd0, yd0, A);
   side_load(yd0, lA);
 #pragma unroll
   for (int r = 0; r < T; ++r) {
     if (r + 1 < T) {
-      ang_load<T>(S, rowp, sCoef, xd0, yd0 + r + 1, pB, cB);
-      load_orig_row<T>(otile, n, r + 1, oB);
+      ang_load<T>(S, rowp, sCoef, xd0, yd0 + r + 1, B);
       side_load(yd0 + r + 1, lB);
     }
     int out[T];
-    ang_filter<T>(pA, cA, maxv, out);
-    if constexpr (PDPC == 2) {
+    ang_filter<T>(A, out);
+    if constexpr (PDPC == 0) {
+      uint32_t pp[T / 2];
 #pragma unroll
-      for (int i = 0; i < T; ++i) out[i] = out[i] + ((__mul24(wl[i], lA[i] - out[i]) + 32) >> 6);
-    } else if constexpr (PDPC == 3) {
-      const int g = lA[0] - tl;
+      for (int c = 0; c < T / 2; ++c) {
+        pk_s16 v = __builtin_bit_cast(pk_s16, pack_lo16(out[2 * c], out[2 * c + 1]));
+        v = __builtin_elementwise_min(__builtin_elementwise_max(v, (pk_s16){0, 0}), vmax);
+        pp[c] = __builtin_bit_cast(uint32_t, v);
+      }
+      finish_row<T>(pp, o[r], d[r], sad);
+    } else {
+      if constexpr (PDPC == 2) {
 #pragma unroll
-      for (int i = 0; i < T; ++i) out[i] = clampi(out[i] + ((__mul24(wl[i], g) + 32) >> 6), 0, maxv);
+        for (int i = 0; i < T; ++i) {
+          const int c = clampi(out[i], 0, maxv);
+          out[i] = c + ((__mul24(wl[i], lA[i] - c) + 32) >> 6);
+        }
+      } else {
+        const int g = lA[0] - tl;
+#pragma unroll
+        for (int i = 0; i < T; ++i) out[i] = clampi(clampi(out[i], 0, maxv) + ((__mul24(wl[i], g) + 32) >> 6), 0, maxv);
+      }
+      finish_row_i32<T>(out, o[r], d[r], sad);
     }
-    finish_row<T>(out, oA, d[r], sad);
-#pragma unroll
-    for (int k = 0; k < T + 3; ++k) pA[k] = pB[k];
-    cA = cB;
-#pragma unroll
-    for (int c = 0; c < T / 2; ++c) oA[c] = oB[c];
+    A = B;
 #pragma unroll
     for (int i = 0; i < T; ++i) lA[i] = lB[i];
   }
@@ -600,7 +640,7 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
 // linear in x and y, so they advance by one addition per sample.
 template <int T, bool PLANAR>
 __device__ __forceinline__ void search_tile_nonangular(const search_mode &S, const uint16_t *top, const uint16_t *left, int dc,
-                                                       int n, int lgn, int xd0, int yd0, const uint16_t *otile,
+                                                       int n, int lgn, int xd0, int yd0, const uint32_t (&o)[T][T / 2],
                                                        uint32_t (&d)[T][T / 2], uint32_t &sad)
 {
   int t[T], wl[T], ver[T], dv[T];
@@ -615,12 +655,10 @@ __device__ __forceinline__ void search_tile_nonangular(const search_mode &S, con
     for (int i = 0; i < T; ++i) { dv[i] = bl - t[i]; ver[i] = (t[i] << lgn) + __mul24(yd0, dv[i]); }   // + dv per row below
   }
   int lA = left[yd0 + 1], lB = 0;
-  uint32_t oA[T / 2], oB[T / 2];
-  load_orig_row<T>(otile, n, 0, oA);
 #pragma unroll
   for (int r = 0; r < T; ++r) {
     const int yd = yd0 + r;
-    if (r + 1 < T) { lB = left[yd + 2]; load_orig_row<T>(otile, n, r + 1, oB); }
+    if (r + 1 < T) lB = left[yd + 2];
     int out[T];
     if constexpr (PLANAR) {
       const int dh = tr - lA;
@@ -640,10 +678,8 @@ __device__ __forceinline__ void search_tile_nonangular(const search_mode &S, con
       const int c = out[i];
       out[i] = c + ((__mul24(wl[i], lA - c) + __mul24(wt, t[i] - c) + 32) >> 6);
     }
-    finish_row<T>(out, oA, d[r], sad);
+    finish_row_i32<T>(out, o[r], d[r], sad);
     lA = lB;
-#pragma unroll
-    for (int c = 0; c < T / 2; ++c) oA[c] = oB[c];
   }
 }
 
@@ -664,7 +700,8 @@ __host__ __device__ inline search_layout make_search_layout(int n, int bpg, int 
   L.off_ref = (int)o;  o += (size_t)bpg * L.BRS * 2; o = (o + 15) & ~(size_t)15;
   L.off_priv = (int)o; o += (size_t)4 * bpg * L.PS * 2; o = (o + 15) & ~(size_t)15;
   L.off_dc = (int)o;   o += (size_t)bpg * 4;
-  L.off_coef = (int)o; o += 64 * 4;
+  o = (o + 7) & ~(size_t)7;
+  L.off_coef = (int)o; o += 64 * 8;
   L.off_mode = (int)o; o += (size_t)n_modes * sizeof(search_mode);
   L.total = o;
   return L;
@@ -686,7 +723,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   uint16_t *sRef = reinterpret_cast<uint16_t *>(smem_raw + L.off_ref);
   uint16_t *sPriv = reinterpret_cast<uint16_t *>(smem_raw + L.off_priv);
   int *sDC = reinterpret_cast<int *>(smem_raw + L.off_dc);
-  uint32_t *sCoef = reinterpret_cast<uint32_t *>(smem_raw + L.off_coef);
+  uint2 *sCoef = reinterpret_cast<uint2 *>(smem_raw + L.off_coef);
   search_mode *sMode = reinterpret_cast<search_mode *>(smem_raw + L.off_mode);
 
   const int blk0 = blockIdx.x * bpg;
@@ -718,7 +755,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       int f0, f1, f2, f3;
       if (threadIdx.x < 32) { f0 = kCubic[df][0]; f1 = kCubic[df][1]; f2 = kCubic[df][2]; f3 = kCubic[df][3]; }
       else { f0 = 16 - (df >> 1); f1 = 32 - (df >> 1); f2 = 16 + (df >> 1); f3 = df >> 1; }   // intra-generic.c:206-214
-      sCoef[threadIdx.x] = (uint32_t)(f0 & 0xff) | ((uint32_t)(f1 & 0xff) << 8) | ((uint32_t)(f2 & 0xff) << 16) | ((uint32_t)(f3 & 0xff) << 24);
+      sCoef[threadIdx.x] = make_uint2((uint32_t)(f0 & 0xffff) | ((uint32_t)f1 << 16), (uint32_t)(f2 & 0xffff) | ((uint32_t)f3 << 16));
     }
     __syncthreads();
     if (on) {
@@ -741,58 +778,62 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   const int maxv = px_traits<PX>::maxv;
   const int dshift = px_traits<PX>::depth - 8;
 
-  for (int m = wave; m < n_modes; m += 4) {
-    search_mode S;
-    {
-      const int *src = reinterpret_cast<const int *>(sMode + m);
-      int *dst = reinterpret_cast<int *>(&S);
+  // two passes over the candidate list: modes predicted in the block domain, then those predicted in
+  // the transposed domain; the lane's original tile stays in registers for a whole pass
+  for (int phase = 0; phase < 2; ++phase) {
+    uint32_t o[T][T / 2];
+    load_orig_tile<T>(ob + (phase ? nn : 0), n, o);
+    for (int m = wave; m < n_modes; m += 4) {
+      search_mode S;
+      {
+        const int *src = reinterpret_cast<const int *>(sMode + m);
+        int *dst = reinterpret_cast<int *>(&S);
 #pragma unroll
-      for (int k = 0; k < (int)(sizeof(search_mode) / 4); ++k) dst[k] = __builtin_amdgcn_readfirstlane(src[k]);
-    }
-    if (S.kind == 2 && S.sd < 0) {
-      // extended main row of this (block, mode): priv[n - j] = side[min((j*inv + 256) >> 9, n)], j = 1..n;
-      // priv[n + i] = main[i], i = 0..n+2.  The block's `tiles` lanes share the work.
-      const uint16_t *mainr = ref + S.row_main * L.RS, *side = ref + S.row_side * L.RS;
-      for (int e = tile; e < 2 * n + 3; e += tiles) {
-        uint16_t v;
-        if (e < n) { const int j = n - e; v = side[min((j * S.inv + 256) >> 9, n)]; }
-        else v = mainr[e - n];
-        priv[e] = v;
+        for (int k = 0; k < (int)(sizeof(search_mode) / 4); ++k) dst[k] = __builtin_amdgcn_readfirstlane(src[k]);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    uint32_t d[T][T / 2];
-    uint32_t sad = 0;
-    {
+      if (S.transposed != phase) continue;
       const uint16_t *mainr = ref + S.row_main * L.RS, *side = ref + S.row_side * L.RS;
-      const uint16_t *ot = ob + (S.transposed ? nn : 0);
+      const bool neg = S.kind == 2 && S.sd < 0;
+      if (neg) {
+        // extended main row of this (block, mode): priv[n - j] = side[min((j*inv + 256) >> 9, n)], j = 1..n;
+        // priv[n + i] = main[i], i = 0..n+2.  The block's `tiles` lanes share the work.
+        for (int e = tile; e < 2 * n + 3; e += tiles) {
+          uint16_t v;
+          if (e < n) { const int j = n - e; v = side[min((__mul24(j, S.inv) + 256) >> 9, n)]; }
+          else v = mainr[e - n];
+          priv[e] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      uint32_t d[T][T / 2];
+      uint32_t sad = 0;
       if (S.kind == 2) {
-        const uint16_t *rowp = S.sd < 0 ? priv + n : mainr;
-        if (S.pdpc == 0) search_tile_angular<T, 0>(S, mainr, side, rowp, sCoef, n, L.RS, xd0, yd0, ot, maxv, d, sad);
-        else if (S.pdpc == 2) search_tile_angular<T, 2>(S, mainr, side, rowp, sCoef, n, L.RS, xd0, yd0, ot, maxv, d, sad);
-        else search_tile_angular<T, 3>(S, mainr, side, rowp, sCoef, n, L.RS, xd0, yd0, ot, maxv, d, sad);
-      } else if (S.kind == 0) search_tile_nonangular<T, true>(S, mainr, side, dc, n, lgn, xd0, yd0, ot, d, sad);
-      else search_tile_nonangular<T, false>(S, mainr, side, dc, n, lgn, xd0, yd0, ot, d, sad);
-    }
-    uint32_t satd;
-    if constexpr (T == 8) satd = satd8_tile_lane(d); else satd = satd4_tile_lane(d);
-    if (lg_tiles >= 2) {
-      satd += dpp_xor1(satd); sad += dpp_xor1(sad);
-      satd += dpp_xor2(satd); sad += dpp_xor2(sad);
-      if (lg_tiles == 4) {
-        satd += dpp_mirror8(satd); sad += dpp_mirror8(sad);
-        satd += dpp_mirror16(satd); sad += dpp_mirror16(sad);
+        const uint16_t *rowp = neg ? priv + n : mainr;
+        if (S.pdpc == 0) search_tile_angular<T, 0>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);
+        else if (S.pdpc == 2) search_tile_angular<T, 2>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);
+        else search_tile_angular<T, 3>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);
+      } else if (S.kind == 0) search_tile_nonangular<T, true>(S, mainr, side, dc, n, lgn, xd0, yd0, o, d, sad);
+      else search_tile_nonangular<T, false>(S, mainr, side, dc, n, lgn, xd0, yd0, o, d, sad);
+      uint32_t satd;
+      if constexpr (T == 8) satd = satd8_tile_lane(d); else satd = satd4_tile_lane(d);
+      if (lg_tiles >= 2) {
+        satd += dpp_xor1(satd); sad += dpp_xor1(sad);
+        satd += dpp_xor2(satd); sad += dpp_xor2(sad);
+        if (lg_tiles == 4) {
+          satd += dpp_mirror8(satd); sad += dpp_mirror8(sad);
+          satd += dpp_mirror16(satd); sad += dpp_mirror16(sad);
+        }
       }
-    }
-    if (S.kind == 2 && S.sd < 0) __builtin_amdgcn_wave_barrier();   // strip is rewritten by the next negative mode
-    if (active && tile == 0) {
-      // search_intra.c:158: min(SATD, 2*SAD) with the NxN strategy functions' depth shifts
-      // (satd_4x4 is unshifted, picture-generic.c:170; everything else >> depth-8)
-      const uint32_t c_satd = satd >> (T == 4 ? 0 : dshift);
-      const uint32_t c_sad = sad >> dshift;
-      costs[(size_t)(blk0 + lb) * n_modes + m] = min(c_satd, 2 * c_sad);
+      if (neg) __builtin_amdgcn_wave_barrier();   // strip is rewritten by the next negative mode
+      if (active && tile == 0) {
+        // search_intra.c:158: min(SATD, 2*SAD) with the NxN strategy functions' depth shifts
+        // (satd_4x4 is unshifted, picture-generic.c:170; everything else >> depth-8)
+        const uint32_t c_satd = satd >> (T == 4 ? 0 : dshift);
+        const uint32_t c_sad = sad >> dshift;
+        costs[(size_t)(blk0 + lb) * n_modes + m] = min(c_satd, 2 * c_sad);
+      }
     }
   }
 }
