@@ -145,6 +145,40 @@ __device__ inline void build_ref_rows(const PX *__restrict__ rec, int stride, in
     top[0] = left[0] = (uint16_t)c;
   }
 }
+// Same rows, but every thread first issues all of its (at most KR per row) global loads and only then
+// stores to LDS, so the round trips overlap instead of running one after the other.
+template <typename PX, int KR>
+__device__ __forceinline__ void build_ref_rows_batched(const PX *__restrict__ rec, int stride, int x, int y,
+                                                       int avail_top, int avail_left, uint16_t *top, uint16_t *left,
+                                                       int refn, int tid, int nthreads)
+{
+  const int dc = 1 << (px_traits<PX>::depth - 1);
+  if (avail_left < 1) avail_left = 1;
+  if (avail_top < 1) avail_top = 1;
+  int lv[KR], tv[KR], c = dc;
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    const int i = tid + k * nthreads;
+    lv[k] = tv[k] = dc;
+    if (i < refn - 1) {
+      if (x > 0) lv[k] = rec[(size_t)(y + min(i, avail_left - 1)) * stride + x - 1];
+      else if (y > 0) lv[k] = rec[(size_t)(y - 1) * stride + x];
+      if (y > 0) tv[k] = rec[(size_t)(y - 1) * stride + x + min(i, avail_top - 1)];
+      else if (x > 0) tv[k] = rec[(size_t)y * stride + x - 1];
+    }
+  }
+  if (tid == 0) {
+    if (x > 0 && y > 0) c = rec[(size_t)(y - 1) * stride + x - 1];
+    else if (x > 0) c = rec[(size_t)y * stride + x - 1];
+    else if (y > 0) c = rec[(size_t)(y - 1) * stride + x];
+  }
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    const int i = tid + k * nthreads;
+    if (i < refn - 1) { left[1 + i] = (uint16_t)lv[k]; top[1 + i] = (uint16_t)tv[k]; }
+  }
+  if (tid == 0) top[0] = left[0] = (uint16_t)c;
+}
 // intra.c:190-225 (needs the raw rows complete: call after a barrier)
 __device__ inline void filter_ref_rows(const uint16_t *top, const uint16_t *left, uint16_t *ftop, uint16_t *fleft,
                                        int w, int h, int refn, int tid, int nthreads)
@@ -688,7 +722,7 @@ struct search_layout {
   int off_orig, off_ref, off_priv, off_dc, off_coef, off_mode;   // bytes
   size_t total;
 };
-__host__ __device__ inline search_layout make_search_layout(int n, int bpg, int n_modes)
+__host__ __device__ inline search_layout make_search_layout(int n, int bpg, int n_modes, int waves)
 {
   search_layout L;
   L.RS = 2 * n + 4;
@@ -698,7 +732,7 @@ __host__ __device__ inline search_layout make_search_layout(int n, int bpg, int 
   size_t o = 0;
   L.off_orig = (int)o; o += (size_t)bpg * L.OS * 2; o = (o + 15) & ~(size_t)15;
   L.off_ref = (int)o;  o += (size_t)bpg * L.BRS * 2; o = (o + 15) & ~(size_t)15;
-  L.off_priv = (int)o; o += (size_t)4 * bpg * L.PS * 2; o = (o + 15) & ~(size_t)15;
+  L.off_priv = (int)o; o += (size_t)waves * bpg * L.PS * 2; o = (o + 15) & ~(size_t)15;
   L.off_dc = (int)o;   o += (size_t)bpg * 4;
   o = (o + 7) & ~(size_t)7;
   L.off_coef = (int)o; o += 64 * 8;
@@ -707,8 +741,11 @@ __host__ __device__ inline search_layout make_search_layout(int n, int bpg, int 
   return L;
 }
 
-template <typename PX, int T>
-__global__ void __launch_bounds__(256)
+#ifndef UVGHIP_SEARCH_WAVES
+#define UVGHIP_SEARCH_WAVES 8
+#endif
+template <typename PX, int T, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 1)
 intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__restrict__ orig, int orig_stride,
                     int n, const uvghip_intra_blk_t *__restrict__ blks, int n_blks,
                     const int8_t *__restrict__ modes, int n_modes, uint32_t *__restrict__ costs)
@@ -718,7 +755,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   const int lg_tx = lgn - (T == 8 ? 3 : 2);       // log2(tiles per block row)
   const int lg_tiles = 2 * lg_tx, tiles = 1 << lg_tiles;
   const int bpg = 64 >> lg_tiles;
-  const search_layout L = make_search_layout(n, bpg, n_modes);
+  const search_layout L = make_search_layout(n, bpg, n_modes, WAVES);
   uint16_t *sOrig = reinterpret_cast<uint16_t *>(smem_raw + L.off_orig);
   uint16_t *sRef = reinterpret_cast<uint16_t *>(smem_raw + L.off_ref);
   uint16_t *sPriv = reinterpret_cast<uint16_t *>(smem_raw + L.off_priv);
@@ -731,25 +768,40 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   if (here <= 0) return;
   const int nn = n * n;
 
-  // ---- stage: tpb = 4 * tiles threads per block ----
+  // ---- stage: tpb = WAVES * tiles threads per block; all global loads of a thread are in flight together ----
   {
-    const int tpb = 4 << lg_tiles;
-    const int myb = threadIdx.x >> (lg_tiles + 2), mytid = threadIdx.x & (tpb - 1);
+    constexpr int NT = WAVES * 64;
+    const int lg_tpb = lg_tiles + (WAVES == 8 ? 3 : 2), tpb = 1 << lg_tpb;
+    const int myb = threadIdx.x >> lg_tpb, mytid = threadIdx.x & (tpb - 1);
     const bool on = myb < here;
-    uvghip_intra_blk_t b;
     uint16_t *base = sRef + (size_t)myb * L.BRS;
     if (on) {
-      b = blks[blk0 + myb];
-      build_ref_rows<PX>(rec, rec_stride, b.x, b.y, n, n, b.avail_top, b.avail_left, base, base + L.RS, L.RS, mytid, tpb);
+      const uvghip_intra_blk_t b = blks[blk0 + myb];
+      build_ref_rows_batched<PX, 5>(rec, rec_stride, b.x, b.y, b.avail_top, b.avail_left, base, base + L.RS, L.RS, mytid, tpb);
+      // original block in 4-sample segments: segment sg = (row, 4 columns)
       uint16_t *so = sOrig + (size_t)myb * L.OS, *sot = so + nn;
-      for (int e = mytid; e < nn; e += tpb) {
-        const int yy = e >> lgn, xx = e & (n - 1);
-        const uint16_t v = orig[(size_t)(b.y + yy) * orig_stride + b.x + xx];
-        so[e] = v;
-        sot[xx * n + yy] = v;
+      const int nseg = nn >> 2, lg_spr = lgn - 2;     // segments, log2(segments per row)
+      int v[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int sg = mytid + k * tpb;
+        if (sg < nseg) {
+          const int yy = sg >> lg_spr, xx = (sg & ((1 << lg_spr) - 1)) * 4;
+          load4(orig + (size_t)(b.y + yy) * orig_stride + b.x + xx, v[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int sg = mytid + k * tpb;
+        if (sg < nseg) {
+          const int yy = sg >> lg_spr, xx = (sg & ((1 << lg_spr) - 1)) * 4;
+          *reinterpret_cast<uint2 *>(so + yy * n + xx) = make_uint2((uint32_t)v[k][0] | ((uint32_t)v[k][1] << 16), (uint32_t)v[k][2] | ((uint32_t)v[k][3] << 16));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sot[(xx + i) * n + yy] = (uint16_t)v[k][i];
+        }
       }
     }
-    for (int m = threadIdx.x; m < n_modes; m += 256) sMode[m] = make_search_mode(modes[m], n);
+    for (int m = threadIdx.x; m < n_modes; m += NT) sMode[m] = make_search_mode(modes[m], n);
     if (threadIdx.x < 64) {
       const int df = threadIdx.x & 31;
       int f0, f1, f2, f3;
@@ -783,7 +835,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   for (int phase = 0; phase < 2; ++phase) {
     uint32_t o[T][T / 2];
     load_orig_tile<T>(ob + (phase ? nn : 0), n, o);
-    for (int m = wave; m < n_modes; m += 4) {
+    for (int m = wave; m < n_modes; m += WAVES) {
       search_mode S;
       {
         const int *src = reinterpret_cast<const int *>(sMode + m);
@@ -797,7 +849,8 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       if (neg) {
         // extended main row of this (block, mode): priv[n - j] = side[min((j*inv + 256) >> 9, n)], j = 1..n;
         // priv[n + i] = main[i], i = 0..n+2.  The block's `tiles` lanes share the work.
-        for (int e = tile; e < 2 * n + 3; e += tiles) {
+        const int need = min(n, (__mul24(-S.sd, n) + 31) >> 5);   // deepest row reaches main[-need]
+        for (int e = n - need + tile; e < 2 * n + 3; e += tiles) {
           uint16_t v;
           if (e < n) { const int j = n - e; v = side[min((__mul24(j, S.inv) + 256) >> 9, n)]; }
           else v = mainr[e - n];
@@ -848,12 +901,13 @@ extern "C" int uvghip_intra_search_batch(int bitdepth, const void *rec, int rec_
   if (n <= 0) return 0;
   const int tiles = size == 4 ? 1 : (size / 8) * (size / 8);
   const int bpg = 64 / tiles;
-  const search_layout L = make_search_layout(size, bpg, n_modes);
   const int grid = (n + bpg - 1) / bpg;
   hipStream_t st = uvghip_stream(stream);
-#define LAUNCH(PX, T) intra_search_kernel<PX, T><<<grid, 256, L.total, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, blks, n, modes, n_modes, costs)
-  if (bitdepth == 8) { if (size == 4) LAUNCH(uint8_t, 4); else LAUNCH(uint8_t, 8); }
-  else { if (size == 4) LAUNCH(uint16_t, 4); else LAUNCH(uint16_t, 8); }
+  // 8x8 tiles: 8 waves per workgroup (two workgroups per CU = 4 waves per SIMD); 4x4: 4 waves, many workgroups
+#define LAUNCH(PX, T, W) do { const search_layout L = make_search_layout(size, bpg, n_modes, W); \
+    intra_search_kernel<PX, T, W><<<grid, W * 64, L.total, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, blks, n, modes, n_modes, costs); } while (0)
+  if (bitdepth == 8) { if (size == 4) LAUNCH(uint8_t, 4, 4); else LAUNCH(uint8_t, 8, UVGHIP_SEARCH_WAVES); }
+  else { if (size == 4) LAUNCH(uint16_t, 4, 4); else LAUNCH(uint16_t, 8, UVGHIP_SEARCH_WAVES); }
 #undef LAUNCH
   UVGHIP_CHECK_LAUNCH();
 }
