@@ -514,21 +514,36 @@ __device__ inline search_mode make_search_mode(int mode, int n)
 // hoisted and set to zero where PDPC does not apply instead of branching), with the LDS loads
 // of row r+1 issued before the arithmetic of row r.
 
-struct __attribute__((packed, aligned(2))) lds_u32x4 { uint32_t v[4]; };
-struct __attribute__((packed, aligned(2))) lds_u32x2 { uint32_t v[2]; };
+// Reference rows live in LDS as "pair rows": dword i of a row holds (sample i, sample i+1).  A 4-tap
+// window starting at any sample is then a run of aligned dwords that are directly the packed operands
+// of v_dot2_i32_i16 -- no sub-dword-aligned wide loads (those cost tens of LDS cycles on gfx950) and
+// no shuffling.  Single samples are the low halves.
+__device__ __forceinline__ int pr_sample(const uint32_t *row, int i) { return reinterpret_cast<const uint16_t *>(row)[2 * i]; }
 
 // the lane's original tile, packed pairs, kept in registers across all modes of one domain
-template <int T>
-__device__ __forceinline__ void load_orig_tile(const uint16_t *otile, int n, uint32_t (&o)[T][T / 2])
+template <typename PX, int T>
+__device__ __forceinline__ void load_orig_tile(const PX *otile, int n, uint32_t (&o)[T][T / 2])
 {
 #pragma unroll
   for (int r = 0; r < T; ++r) {
-    if constexpr (T == 8) {
-      const uint4 v = *reinterpret_cast<const uint4 *>(otile + r * n);
-      o[r][0] = v.x; o[r][1] = v.y; o[r][2] = v.z; o[r][3] = v.w;
+    if constexpr (sizeof(PX) == 2) {
+      if constexpr (T == 8) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(otile + r * n);
+        o[r][0] = v.x; o[r][1] = v.y; o[r][2] = v.z; o[r][3] = v.w;
+      } else {
+        const uint2 v = *reinterpret_cast<const uint2 *>(otile + r * n);
+        o[r][0] = v.x; o[r][1] = v.y;
+      }
     } else {
-      const uint2 v = *reinterpret_cast<const uint2 *>(otile + r * n);
-      o[r][0] = v.x; o[r][1] = v.y;
+      // bytes (b0 b1 b2 b3) -> (b0, b1 as 16-bit halves), (b2, b3)
+      if constexpr (T == 8) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(otile + r * n);
+        o[r][0] = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u); o[r][1] = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u);
+        o[r][2] = __builtin_amdgcn_perm(0u, v.y, 0x0c010c00u); o[r][3] = __builtin_amdgcn_perm(0u, v.y, 0x0c030c02u);
+      } else {
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(otile + r * n);
+        o[r][0] = __builtin_amdgcn_perm(0u, v, 0x0c010c00u); o[r][1] = __builtin_amdgcn_perm(0u, v, 0x0c030c02u);
+      }
     }
   }
 }
@@ -563,48 +578,39 @@ __device__ __forceinline__ void pdpc_col_weights(int xd0, int scale, int lim, in
   }
 }
 
-// One row of 4-tap inputs: the T+3 (+1 spare) reference samples as "even" pairs E[j] = (p[2j], p[2j+1])
-// -- two unaligned wide LDS reads -- and the two coefficient pairs (f0,f1), (f2,f3) of the row's phase.
-template <int T> struct ang_row { uint32_t E[T / 2 + 2]; uint32_t f01, f23; };
+// One row of 4-tap inputs: pairs P[k] = (p[k], p[k+1]), k = 0..T+1, and the two coefficient pairs
+// (f0,f1), (f2,f3) of the row's phase.
+template <int T> struct ang_row { uint32_t P[T + 2]; uint32_t f01, f23; };
 
 template <int T>
-__device__ __forceinline__ void ang_load(const search_mode &S, const uint16_t *rowp, const uint2 *sCoef, int xd0, int yd, ang_row<T> &R)
+__device__ __forceinline__ void ang_load(const search_mode &S, const uint32_t *rowp, const uint2 *sCoef, int xd0, int yd, ang_row<T> &R)
 {
   const int delta = __mul24(S.sd, yd + 1), di = delta >> 5, df = delta & 31;
   const uint2 cf = sCoef[S.coef + df];
   R.f01 = cf.x; R.f23 = cf.y;
-  const uint16_t *q = rowp + di + xd0;
-  const lds_u32x4 a = *reinterpret_cast<const lds_u32x4 *>(q);
-  R.E[0] = a.v[0]; R.E[1] = a.v[1]; R.E[2] = a.v[2]; R.E[3] = a.v[3];
-  if constexpr (T == 8) {
-    const lds_u32x2 b = *reinterpret_cast<const lds_u32x2 *>(q + 8);
-    R.E[4] = b.v[0]; R.E[5] = b.v[1];
-  }
+  const uint32_t *q = rowp + di + xd0;
+#pragma unroll
+  for (int k = 0; k < T + 2; ++k) R.P[k] = q[k];
 }
 // out[i] = (f0 p[i] + f1 p[i+1] + f2 p[i+2] + f3 p[i+3] + 32) >> 6, unclamped (intra-generic.c:216-222):
-// two v_dot2_i32_i16 per sample; the odd-phase pairs (p[2j+1], p[2j+2]) come from v_alignbit.
+// two v_dot2_i32_i16 per sample.
 template <int T>
 __device__ __forceinline__ void ang_filter(const ang_row<T> &R, int (&out)[T])
 {
   const pk_s16 f01 = __builtin_bit_cast(pk_s16, R.f01), f23 = __builtin_bit_cast(pk_s16, R.f23);
-  uint32_t O[T / 2 + 1];
 #pragma unroll
-  for (int j = 0; j < T / 2 + 1; ++j) O[j] = __builtin_amdgcn_alignbit(R.E[j + 1], R.E[j], 16);
-#pragma unroll
-  for (int j = 0; j < T / 2; ++j) {
-    int ev = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_s16, R.E[j]), f01, 32, false);
-    ev = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_s16, R.E[j + 1]), f23, ev, false);
-    int od = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_s16, O[j]), f01, 32, false);
-    od = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_s16, O[j + 1]), f23, od, false);
-    out[2 * j] = ev >> 6; out[2 * j + 1] = od >> 6;
+  for (int i = 0; i < T; ++i) {
+    int v = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_s16, R.P[i]), f01, 32, false);
+    v = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_s16, R.P[i + 2]), f23, v, false);
+    out[i] = v >> 6;
   }
 }
 
 // PDPC: 0 none, 2 projected side sample (intra-generic.c:262-277), 3 gradient of the pure
 // horizontal/vertical modes (:279-293)
 template <int T, int PDPC>
-__device__ __forceinline__ void search_tile_angular(const search_mode &S, const uint16_t *mainr, const uint16_t *side,
-                                                    const uint16_t *rowp, const uint2 *sCoef, int n, int xd0, int yd0,
+__device__ __forceinline__ void search_tile_angular(const search_mode &S, const uint32_t *mainr, const uint32_t *side,
+                                                    const uint32_t *rowp, const uint2 *sCoef, int n, int xd0, int yd0,
                                                     const uint32_t (&o)[T][T / 2], int maxv, uint32_t (&d)[T][T / 2], uint32_t &sad)
 {
   int wl[T], so[T];
@@ -619,15 +625,15 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
         const int x = xd0 + i;
         so[i] = x < lim ? ((256 + __mul24(x + 1, S.inv)) >> 9) + 1 : 0;
       }
-    } else tl = mainr[0];
+    } else tl = pr_sample(mainr, 0);
   }
   ang_row<T> A, B;
   int lA[T], lB[T];
   auto side_load = [&](int yd, int (&l)[T]) {
     if constexpr (PDPC == 2) {
 #pragma unroll
-      for (int i = 0; i < T; ++i) l[i] = side[yd + so[i]];
-    } else if constexpr (PDPC == 3) l[0] = side[1 + yd];
+      for (int i = 0; i < T; ++i) l[i] = pr_sample(side, yd + so[i]);
+    } else if constexpr (PDPC == 3) l[0] = pr_sample(side, 1 + yd);
   };
   const pk_s16 vmax = {(short)maxv, (short)maxv};
   ang_load<T>(S, rowp, sCoef, xd0, yd0, A);
@@ -673,26 +679,26 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
 // ((hor << lg) + (ver << lg) + (1 << 2lg)) >> (2lg + 1) == (hor + ver + n) >> (lg + 1); hor and ver are
 // linear in x and y, so they advance by one addition per sample.
 template <int T, bool PLANAR>
-__device__ __forceinline__ void search_tile_nonangular(const search_mode &S, const uint16_t *top, const uint16_t *left, int dc,
+__device__ __forceinline__ void search_tile_nonangular(const search_mode &S, const uint32_t *top, const uint32_t *left, int dc,
                                                        int n, int lgn, int xd0, int yd0, const uint32_t (&o)[T][T / 2],
                                                        uint32_t (&d)[T][T / 2], uint32_t &sad)
 {
   int t[T], wl[T], ver[T], dv[T];
 #pragma unroll
-  for (int i = 0; i < T; ++i) t[i] = top[xd0 + i + 1];
+  for (int i = 0; i < T; ++i) t[i] = pr_sample(top, xd0 + i + 1);
   pdpc_col_weights<T>(xd0, S.scale, S.pdpc ? n : 0, wl);
   int tr = 0;
   if constexpr (PLANAR) {
-    tr = top[n + 1];
-    const int bl = left[n + 1];
+    tr = pr_sample(top, n + 1);
+    const int bl = pr_sample(left, n + 1);
 #pragma unroll
     for (int i = 0; i < T; ++i) { dv[i] = bl - t[i]; ver[i] = (t[i] << lgn) + __mul24(yd0, dv[i]); }   // + dv per row below
   }
-  int lA = left[yd0 + 1], lB = 0;
+  int lA = pr_sample(left, yd0 + 1), lB = 0;
 #pragma unroll
   for (int r = 0; r < T; ++r) {
     const int yd = yd0 + r;
-    if (r + 1 < T) lB = left[yd + 2];
+    if (r + 1 < T) lB = pr_sample(left, yd + 2);
     int out[T];
     if constexpr (PLANAR) {
       const int dh = tr - lA;
@@ -718,21 +724,26 @@ __device__ __forceinline__ void search_tile_nonangular(const search_mode &S, con
 }
 
 struct search_layout {
-  int RS, BRS, OS, PS;                        // u16 units
+  int RS;        // samples per reference row (u16 scratch) = dwords per pair row
+  int BRS;       // dwords per block: four pair rows, odd so that the wave's lanes spread over the banks
+  int OS;        // PX elements per block: original + transpose + pad
+  int PS;        // dwords per private extended row (odd)
   int off_orig, off_ref, off_priv, off_dc, off_coef, off_mode;   // bytes
   size_t total;
 };
-__host__ __device__ inline search_layout make_search_layout(int n, int bpg, int n_modes, int waves)
+__host__ __device__ inline search_layout make_search_layout(int n, int bpg, int n_modes, int waves, int pxsz)
 {
   search_layout L;
   L.RS = 2 * n + 4;
-  L.BRS = 4 * L.RS + 2;                       // 2*RS + 1 dwords: odd
-  L.OS = 2 * n * n + (n == 4 ? 4 : 8);        // orig + transpose, stride = 4 (2 for 4x4) dwords mod 32
-  L.PS = 2 * n + 6;                           // n + 3 dwords: odd
+  L.BRS = 4 * L.RS + 1;
+  L.OS = 2 * n * n + 8;
+  L.PS = 2 * n + 1;
   size_t o = 0;
-  L.off_orig = (int)o; o += (size_t)bpg * L.OS * 2; o = (o + 15) & ~(size_t)15;
-  L.off_ref = (int)o;  o += (size_t)bpg * L.BRS * 2; o = (o + 15) & ~(size_t)15;
-  L.off_priv = (int)o; o += (size_t)waves * bpg * L.PS * 2; o = (o + 15) & ~(size_t)15;
+  L.off_orig = (int)o; o += (size_t)bpg * L.OS * pxsz; o = (o + 15) & ~(size_t)15;
+  L.off_ref = (int)o;  o += (size_t)bpg * L.BRS * 4; o = (o + 15) & ~(size_t)15;
+  // private strips; the same space holds the u16 staging image of the rows (4 * RS samples per block)
+  size_t pv = (size_t)waves * bpg * L.PS * 4, scratch = (size_t)bpg * 4 * L.RS * 2;
+  L.off_priv = (int)o; o += pv > scratch ? pv : scratch; o = (o + 15) & ~(size_t)15;
   L.off_dc = (int)o;   o += (size_t)bpg * 4;
   o = (o + 7) & ~(size_t)7;
   L.off_coef = (int)o; o += 64 * 8;
@@ -755,10 +766,11 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   const int lg_tx = lgn - (T == 8 ? 3 : 2);       // log2(tiles per block row)
   const int lg_tiles = 2 * lg_tx, tiles = 1 << lg_tiles;
   const int bpg = 64 >> lg_tiles;
-  const search_layout L = make_search_layout(n, bpg, n_modes, WAVES);
-  uint16_t *sOrig = reinterpret_cast<uint16_t *>(smem_raw + L.off_orig);
-  uint16_t *sRef = reinterpret_cast<uint16_t *>(smem_raw + L.off_ref);
-  uint16_t *sPriv = reinterpret_cast<uint16_t *>(smem_raw + L.off_priv);
+  const search_layout L = make_search_layout(n, bpg, n_modes, WAVES, (int)sizeof(PX));
+  PX *sOrig = reinterpret_cast<PX *>(smem_raw + L.off_orig);
+  uint32_t *sRef = reinterpret_cast<uint32_t *>(smem_raw + L.off_ref);
+  uint32_t *sPriv = reinterpret_cast<uint32_t *>(smem_raw + L.off_priv);
+  uint16_t *sScratch = reinterpret_cast<uint16_t *>(smem_raw + L.off_priv);
   int *sDC = reinterpret_cast<int *>(smem_raw + L.off_dc);
   uint2 *sCoef = reinterpret_cast<uint2 *>(smem_raw + L.off_coef);
   search_mode *sMode = reinterpret_cast<search_mode *>(smem_raw + L.off_mode);
@@ -774,12 +786,12 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
     const int lg_tpb = lg_tiles + (WAVES == 8 ? 3 : 2), tpb = 1 << lg_tpb;
     const int myb = threadIdx.x >> lg_tpb, mytid = threadIdx.x & (tpb - 1);
     const bool on = myb < here;
-    uint16_t *base = sRef + (size_t)myb * L.BRS;
+    uint16_t *base = sScratch + (size_t)myb * 4 * L.RS;     // u16 image: top | left | ftop | fleft
     if (on) {
       const uvghip_intra_blk_t b = blks[blk0 + myb];
       build_ref_rows_batched<PX, 5>(rec, rec_stride, b.x, b.y, b.avail_top, b.avail_left, base, base + L.RS, L.RS, mytid, tpb);
       // original block in 4-sample segments: segment sg = (row, 4 columns)
-      uint16_t *so = sOrig + (size_t)myb * L.OS, *sot = so + nn;
+      PX *so = sOrig + (size_t)myb * L.OS, *sot = so + nn;
       const int nseg = nn >> 2, lg_spr = lgn - 2;     // segments, log2(segments per row)
       int v[4][4];
 #pragma unroll
@@ -795,9 +807,12 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
         const int sg = mytid + k * tpb;
         if (sg < nseg) {
           const int yy = sg >> lg_spr, xx = (sg & ((1 << lg_spr) - 1)) * 4;
-          *reinterpret_cast<uint2 *>(so + yy * n + xx) = make_uint2((uint32_t)v[k][0] | ((uint32_t)v[k][1] << 16), (uint32_t)v[k][2] | ((uint32_t)v[k][3] << 16));
+          if constexpr (sizeof(PX) == 2)
+            *reinterpret_cast<uint2 *>(so + yy * n + xx) = make_uint2((uint32_t)v[k][0] | ((uint32_t)v[k][1] << 16), (uint32_t)v[k][2] | ((uint32_t)v[k][3] << 16));
+          else
+            *reinterpret_cast<uint32_t *>(so + yy * n + xx) = (uint32_t)v[k][0] | ((uint32_t)v[k][1] << 8) | ((uint32_t)v[k][2] << 16) | ((uint32_t)v[k][3] << 24);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) sot[(xx + i) * n + yy] = (uint16_t)v[k][i];
+          for (int i = 0; i < 4; ++i) sot[(xx + i) * n + yy] = (PX)v[k][i];
         }
       }
     }
@@ -815,6 +830,15 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       if (mytid == 0) sDC[myb] = dc_value(base, base + L.RS, n, n);
     }
     __syncthreads();
+    if (on) {
+      // u16 image -> pair rows
+      uint32_t *pr = sRef + (size_t)myb * L.BRS;
+      for (int e = mytid; e < 4 * L.RS; e += tpb) {
+        const int i = e % L.RS;
+        pr[e] = (uint32_t)base[e] | (i + 1 < L.RS ? (uint32_t)base[e + 1] << 16 : 0u);
+      }
+    }
+    __syncthreads();   // also: the scratch image is dead from here on, its space becomes the private strips
   }
 
   // ---- search: lane = tile, wave = mode ----
@@ -823,9 +847,9 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   const bool active = lb < here;
   const int bb = active ? lb : 0;
   const int xd0 = (tile & ((1 << lg_tx) - 1)) * T, yd0 = (tile >> lg_tx) * T;
-  const uint16_t *ref = sRef + (size_t)bb * L.BRS;
-  const uint16_t *ob = sOrig + (size_t)bb * L.OS + yd0 * n + xd0;
-  uint16_t *priv = sPriv + ((size_t)wave * bpg + bb) * L.PS;
+  const uint32_t *ref = sRef + (size_t)bb * L.BRS;
+  const PX *ob = sOrig + (size_t)bb * L.OS + yd0 * n + xd0;
+  uint32_t *priv = sPriv + ((size_t)wave * bpg + bb) * L.PS;
   const int dc = sDC[bb];
   const int maxv = px_traits<PX>::maxv;
   const int dshift = px_traits<PX>::depth - 8;
@@ -834,7 +858,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   // the transposed domain; the lane's original tile stays in registers for a whole pass
   for (int phase = 0; phase < 2; ++phase) {
     uint32_t o[T][T / 2];
-    load_orig_tile<T>(ob + (phase ? nn : 0), n, o);
+    load_orig_tile<PX, T>(ob + (phase ? nn : 0), n, o);
     for (int m = wave; m < n_modes; m += WAVES) {
       search_mode S;
       {
@@ -844,16 +868,22 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
         for (int k = 0; k < (int)(sizeof(search_mode) / 4); ++k) dst[k] = __builtin_amdgcn_readfirstlane(src[k]);
       }
       if (S.transposed != phase) continue;
-      const uint16_t *mainr = ref + S.row_main * L.RS, *side = ref + S.row_side * L.RS;
+      const uint32_t *mainr = ref + S.row_main * L.RS, *side = ref + S.row_side * L.RS;
       const bool neg = S.kind == 2 && S.sd < 0;
       if (neg) {
-        // extended main row of this (block, mode): priv[n - j] = side[min((j*inv + 256) >> 9, n)], j = 1..n;
-        // priv[n + i] = main[i], i = 0..n+2.  The block's `tiles` lanes share the work.
-        const int need = min(n, (__mul24(-S.sd, n) + 31) >> 5);   // deepest row reaches main[-need]
-        for (int e = n - need + tile; e < 2 * n + 3; e += tiles) {
-          uint16_t v;
-          if (e < n) { const int j = n - e; v = side[min((__mul24(j, S.inv) + 256) >> 9, n)]; }
-          else v = mainr[e - n];
+        // extended main pair row of this (block, mode), ext[-j] = side[min((j*inv + 256) >> 9, n)]
+        // (intra-generic.c:156-159; j = 0 gives the corner = main[0]):
+        //   priv[n - j] = (ext[-j], ext[-j+1]), j = 1..need;  priv[n + i] = main pair i, i = 0..n.
+        // The block's `tiles` lanes share the work.
+        const int need = min(n, (__mul24(-S.sd, n) + 31) >> 5);   // deepest row reaches ext[-need]
+        for (int e = n - need + tile; e < 2 * n + 1; e += tiles) {
+          uint32_t v;
+          if (e < n) {
+            const int j = n - e;
+            const int a0 = pr_sample(side, min((__mul24(j, S.inv) + 256) >> 9, n));
+            const int a1 = pr_sample(side, min((__mul24(j - 1, S.inv) + 256) >> 9, n));
+            v = (uint32_t)a0 | ((uint32_t)a1 << 16);
+          } else v = mainr[e - n];
           priv[e] = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -863,7 +893,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       uint32_t d[T][T / 2];
       uint32_t sad = 0;
       if (S.kind == 2) {
-        const uint16_t *rowp = neg ? priv + n : mainr;
+        const uint32_t *rowp = neg ? priv + n : mainr;
         if (S.pdpc == 0) search_tile_angular<T, 0>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);
         else if (S.pdpc == 2) search_tile_angular<T, 2>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);
         else search_tile_angular<T, 3>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);
@@ -904,7 +934,9 @@ extern "C" int uvghip_intra_search_batch(int bitdepth, const void *rec, int rec_
   const int grid = (n + bpg - 1) / bpg;
   hipStream_t st = uvghip_stream(stream);
   // 8x8 tiles: 8 waves per workgroup (two workgroups per CU = 4 waves per SIMD); 4x4: 4 waves, many workgroups
-#define LAUNCH(PX, T, W) do { const search_layout L = make_search_layout(size, bpg, n_modes, W); \
+#define LAUNCH(PX, T, W) do { const search_layout L = make_search_layout(size, bpg, n_modes, W, (int)sizeof(PX)); \
+    static bool big_lds = false; /* allow more than the default 64 KiB of dynamic LDS, once per instantiation */ \
+    if (!big_lds) { UVGHIP_TRY(hipFuncSetAttribute((const void *)intra_search_kernel<PX, T, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); big_lds = true; } \
     intra_search_kernel<PX, T, W><<<grid, W * 64, L.total, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, blks, n, modes, n_modes, costs); } while (0)
   if (bitdepth == 8) { if (size == 4) LAUNCH(uint8_t, 4, 4); else LAUNCH(uint8_t, 8, UVGHIP_SEARCH_WAVES); }
   else { if (size == 4) LAUNCH(uint16_t, 4, 4); else LAUNCH(uint16_t, 8, UVGHIP_SEARCH_WAVES); }
