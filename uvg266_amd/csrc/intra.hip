@@ -592,19 +592,25 @@ __device__ __forceinline__ void ang_load(const search_mode &S, const uint32_t *r
 #pragma unroll
   for (int k = 0; k < T + 2; ++k) R.P[k] = q[k];
 }
-// out[i] = (f0 p[i] + f1 p[i+1] + f2 p[i+2] + f3 p[i+3] + 32) >> 6, unclamped (intra-generic.c:216-222):
-// two v_dot2_i32_i16 per sample.
-template <int T>
-__device__ __forceinline__ void ang_filter(const ang_row<T> &R, int (&out)[T])
+// The tap table holds 4*f, so with the rounding term 4*32 the accumulator is 4*(sum + 32) and the
+// filtered sample (sum + 32) >> 6 (intra-generic.c:216-222, unclamped here) sits byte-aligned in bits 8..23:
+// two v_dot2_i32_i16 per sample, and one v_perm packs a pair of samples.
+__device__ __forceinline__ int dot2_round(uint32_t a, uint32_t b)
 {
-  const pk_s16 f01 = __builtin_bit_cast(pk_s16, R.f01), f23 = __builtin_bit_cast(pk_s16, R.f23);
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-    int v = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_s16, R.P[i]), f01, 32, false);
-    v = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_s16, R.P[i + 2]), f23, v, false);
-    out[i] = v >> 6;
-  }
+  int v;
+  asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(v) : "v"(a), "v"(b), "s"(128));   // VOP3P form: scalar accumulator, no v_mov
+  return v;
 }
+template <int T>
+__device__ __forceinline__ void ang_filter_x4(const ang_row<T> &R, int (&acc)[T])
+{
+  const pk_s16 f23 = __builtin_bit_cast(pk_s16, R.f23);
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+    acc[i] = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_s16, R.P[i + 2]), f23, dot2_round(R.P[i], R.f01), false);
+}
+// (lo >> 8, hi >> 8) as packed 16-bit halves
+__device__ __forceinline__ uint32_t pack_shr8(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x06050201u); }
 
 // PDPC: 0 none, 2 projected side sample (intra-generic.c:262-277), 3 gradient of the pure
 // horizontal/vertical modes (:279-293)
@@ -613,7 +619,8 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
                                                     const uint32_t *rowp, const uint2 *sCoef, int n, int xd0, int yd0,
                                                     const uint32_t (&o)[T][T / 2], int maxv, uint32_t (&d)[T][T / 2], uint32_t &sad)
 {
-  int wl[T], so[T];
+  int wl[T];
+  const uint16_t *sp[T];    // PDPC 2: address of the projected side sample of column i in row yd0 (dword stride per row)
   int tl = 0;
   if constexpr (PDPC != 0) {
     const int lim = min(3 << S.scale, n);
@@ -623,34 +630,38 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
       for (int i = 0; i < T; ++i) {
         // side[yd + (inv_sum >> 9) + 1]; columns without PDPC get a harmless in-range offset
         const int x = xd0 + i;
-        so[i] = x < lim ? ((256 + __mul24(x + 1, S.inv)) >> 9) + 1 : 0;
+        const int so = x < lim ? ((256 + __mul24(x + 1, S.inv)) >> 9) + 1 : 0;
+        sp[i] = reinterpret_cast<const uint16_t *>(side + yd0 + so);
       }
-    } else tl = pr_sample(mainr, 0);
+    } else {
+      tl = pr_sample(mainr, 0);
+      sp[0] = reinterpret_cast<const uint16_t *>(side + yd0 + 1);
+    }
   }
   ang_row<T> A, B;
   int lA[T], lB[T];
-  auto side_load = [&](int yd, int (&l)[T]) {
+  auto side_load = [&](int r, int (&l)[T]) {
     if constexpr (PDPC == 2) {
 #pragma unroll
-      for (int i = 0; i < T; ++i) l[i] = pr_sample(side, yd + so[i]);
-    } else if constexpr (PDPC == 3) l[0] = pr_sample(side, 1 + yd);
+      for (int i = 0; i < T; ++i) l[i] = sp[i][2 * r];
+    } else if constexpr (PDPC == 3) l[0] = sp[0][2 * r];
   };
   const pk_s16 vmax = {(short)maxv, (short)maxv};
   ang_load<T>(S, rowp, sCoef, xd0, yd0, A);
-  side_load(yd0, lA);
+  side_load(0, lA);
 #pragma unroll
   for (int r = 0; r < T; ++r) {
     if (r + 1 < T) {
       ang_load<T>(S, rowp, sCoef, xd0, yd0 + r + 1, B);
-      side_load(yd0 + r + 1, lB);
+      side_load(r + 1, lB);
     }
     int out[T];
-    ang_filter<T>(A, out);
+    ang_filter_x4<T>(A, out);
     if constexpr (PDPC == 0) {
       uint32_t pp[T / 2];
 #pragma unroll
       for (int c = 0; c < T / 2; ++c) {
-        pk_s16 v = __builtin_bit_cast(pk_s16, pack_lo16(out[2 * c], out[2 * c + 1]));
+        pk_s16 v = __builtin_bit_cast(pk_s16, pack_shr8(out[2 * c], out[2 * c + 1]));
         v = __builtin_elementwise_min(__builtin_elementwise_max(v, (pk_s16){0, 0}), vmax);
         pp[c] = __builtin_bit_cast(uint32_t, v);
       }
@@ -659,13 +670,13 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
       if constexpr (PDPC == 2) {
 #pragma unroll
         for (int i = 0; i < T; ++i) {
-          const int c = clampi(out[i], 0, maxv);
+          const int c = clampi(out[i] >> 8, 0, maxv);
           out[i] = c + ((__mul24(wl[i], lA[i] - c) + 32) >> 6);
         }
       } else {
         const int g = lA[0] - tl;
 #pragma unroll
-        for (int i = 0; i < T; ++i) out[i] = clampi(clampi(out[i], 0, maxv) + ((__mul24(wl[i], g) + 32) >> 6), 0, maxv);
+        for (int i = 0; i < T; ++i) out[i] = clampi(clampi(out[i] >> 8, 0, maxv) + ((__mul24(wl[i], g) + 32) >> 6), 0, maxv);
       }
       finish_row_i32<T>(out, o[r], d[r], sad);
     }
@@ -822,6 +833,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       int f0, f1, f2, f3;
       if (threadIdx.x < 32) { f0 = kCubic[df][0]; f1 = kCubic[df][1]; f2 = kCubic[df][2]; f3 = kCubic[df][3]; }
       else { f0 = 16 - (df >> 1); f1 = 32 - (df >> 1); f2 = 16 + (df >> 1); f3 = df >> 1; }   // intra-generic.c:206-214
+      f0 *= 4; f1 *= 4; f2 *= 4; f3 *= 4;        // see ang_filter_x4
       sCoef[threadIdx.x] = make_uint2((uint32_t)(f0 & 0xffff) | ((uint32_t)f1 << 16), (uint32_t)(f2 & 0xffff) | ((uint32_t)f3 << 16));
     }
     __syncthreads();
