@@ -32,6 +32,8 @@ W, H, DEPTH, QP = 1920, 1080, 8, 22
 SIZES = (32, 16, 8, 4)            # --pu-depth-intra 1-4 (cfg.c:769-801)
 MODES = list(range(67))           # every luma mode; the reference's rough search visits a subset
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+# HBM bytes per launch from the PMC passes under profiles/ (FETCH_SIZE doubled per the guide's gfx950 note + WRITE_SIZE)
+TRAFFIC = {}
 WORKLOAD = ("1920x1080 8-bit yuv420p, all-intra medium hot path per frame: luma, for N in 32,16,8,4 "
             "{intra rough search 67 modes min(SATD,2SAD) on all NxN blocks -> best mode -> intra predict "
             "-> fused residual/DCT-2/quant/dequant/IDCT/recon}; then deblock (Y,U,V; seeded random quad-tree "
@@ -64,13 +66,15 @@ class Frame:
 
 
 class KernelClock:
-    """Per-kernel HIP-event timing on the launch stream (torch's current stream)."""
+    """Per-kernel HIP-event timing on the launch stream (torch's current stream).  `only` restricts the
+    instrumentation to kernels whose family name is in the set (None = all)."""
 
     def __init__(self):
         self.spans = {}
+        self.only = None
 
     def run(self, name, fn, enabled):
-        if not enabled:
+        if not enabled or (self.only is not None and name.rsplit("_", 1)[0] not in self.only):
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -98,6 +102,8 @@ def algorithmic_bytes(kernel, n, count):
         return int(2 * 1.5 * W * H * b + 32 * W * H / 16)
     if kernel == "sao_stats":         # orig + rec luma read, 104 counters per CTU written
         return W * H * 2 * b + count * 104 * 4
+    if kernel == "sao_offsets":       # 40 counters read, 8 words written per CTU
+        return count * (40 + 8) * 4
     if kernel == "sao_apply":         # rec read, out written (+ 32 B parameters per CTU)
         return W * H * 2 * b + count * 32
     raise KeyError(kernel)
@@ -115,27 +121,8 @@ def hot_path_step(fr, modes_dev, clock, timed):
     fr.v_rec.copy_(fr.v)
     clock.run("deblock_0", lambda: api.deblock_frame(fr.rec, fr.u_rec, fr.v_rec, fr.scu, W, H, 0, 0, False, QP, None), timed)
     edge, band = clock.run("sao_stats_0", lambda: api.sao_stats_batch(fr.y, fr.rec, fr.rects), timed)
-    params = sao_decide(edge)
+    params = clock.run("sao_offsets_0", lambda: api.sao_edge_offsets_batch(edge), timed)
     clock.run("sao_apply_0", lambda: api.sao_apply_batch(fr.rec, fr.sao_out, fr.rects, params), timed)
-
-
-def sao_decide(edge):
-    """Edge-offset choice per CTU from the statistics alone (distortion only; the reference adds CABAC rate,
-    sao.c:364-460, which stays on the host): offset = round(sum/cnt) clipped to +-7 with the category sign
-    constraint, class = argmin of sum_cat cnt*o^2 - 2*o*sum.  Runs on the device with torch (plumbing)."""
-    s, c = edge[:, :, 0].float(), edge[:, :, 1].float().clamp(min=1)
-    off = torch.round(s / c).clamp(-7, 7)
-    off[:, :, 0] = 0
-    off[:, :, 1:3] = off[:, :, 1:3].clamp(min=0)
-    off[:, :, 3:5] = off[:, :, 3:5].clamp(max=0)
-    dd = (edge[:, :, 1].float() * off * off - 2 * off * s).sum(-1)
-    best = dd.argmin(1)
-    o = off[torch.arange(off.shape[0], device=off.device), best].to(torch.int32)
-    p = torch.zeros((off.shape[0], 8), dtype=torch.int32, device=off.device)
-    p[:, 0] = 2
-    p[:, 1] = best.to(torch.int32)
-    p[:, 3:8] = o
-    return p
 
 
 def cpu_baseline(fr_host_y):
@@ -189,6 +176,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=4, help="untimed, fully instrumented steps for the per-kernel table")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -214,6 +202,20 @@ def main():
     for s in range(args.warmup):
         hot_path_step(frames[s % n_resident], modes_dev, clock, False)
     torch.cuda.synchronize()
+
+    # untimed profile pass: every kernel bracketed by HIP events -> per-kernel breakdown and the dominant family
+    prof = KernelClock()
+    for s in range(args.profile_steps):
+        hot_path_step(frames[s % n_resident], modes_dev, prof, True)
+    torch.cuda.synchronize()
+    prof_tot = prof.totals()
+    fam_ms = {}
+    for name, (ms, launches) in prof_tot.items():
+        fam_ms[name.rsplit("_", 1)[0]] = fam_ms.get(name.rsplit("_", 1)[0], 0.0) + ms
+    dom_family = max(fam_ms, key=fam_ms.get)
+
+    # timed region: only the dominant family's launches carry events (live roofline timing), the rest run bare
+    clock.only = {dom_family}
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -231,19 +233,23 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        totals = clock.totals()
-        per_kernel = {}
-        for name, (ms, launches) in totals.items():
-            kern, n = name.rsplit("_", 1)
-            cnt = frames[0].tables[int(n)][2] if int(n) else frames[0].n_ctu
-            byts = algorithmic_bytes(kern, int(n), cnt)
-            avg_ms = ms / launches
-            per_kernel[name] = {"avg_ms": round(avg_ms, 4), "share": 0.0, "alg_bytes": byts,
-                                "gbs": round(byts / (avg_ms * 1e-3) / 1e9, 2)}
+        def table(totals):
+            t = {}
+            for name, (ms, launches) in totals.items():
+                kern, n = name.rsplit("_", 1)
+                cnt = frames[0].tables[int(n)][2] if int(n) else frames[0].n_ctu
+                byts = algorithmic_bytes(kern, int(n), cnt)
+                avg_ms = ms / launches
+                t[name] = {"avg_ms": round(avg_ms, 4), "share": 0.0, "alg_bytes": byts, "launches": launches,
+                           "gbs": round(byts / (avg_ms * 1e-3) / 1e9, 2)}
+            return t
+        per_kernel = table(prof_tot)                 # all kernels, untimed profile pass
         tot_ms = sum(v["avg_ms"] for v in per_kernel.values())
         for v in per_kernel.values():
             v["share"] = round(v["avg_ms"] / tot_ms, 3)
-        dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"])
+        live = table(clock.totals())                 # dominant family, inside the timed region
+        dom = max(live, key=lambda k: live[k]["avg_ms"])
+        per_kernel_live = live
         fps = args.steps * world / elapsed
         out = {
             "metric": "hot-path fps (1080p all-intra medium kernel path; Mpixels/s in config)",
@@ -252,9 +258,14 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": WORKLOAD, "mpixels_per_s": round(fps * W * H / 1e6, 1), "qp": QP,
                        "parallelism": f"frames sharded over {world} rank(s), no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["gbs"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(per_kernel[dom]["gbs"] / HBM_PEAK_GBS, 5), "traffic": None,
-                         "avg_launch_ms": per_kernel[dom]["avg_ms"], "alg_bytes_per_launch": per_kernel[dom]["alg_bytes"]},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": live[dom]["gbs"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(live[dom]["gbs"] / HBM_PEAK_GBS, 5), "traffic": TRAFFIC.get(dom),
+                         "avg_launch_ms": live[dom]["avg_ms"], "alg_bytes_per_launch": live[dom]["alg_bytes"],
+                         "launches_timed": live[dom]["launches"],
+                         "note": "HIP events around every launch of the dominant kernel family inside the timed region; "
+                                 "traffic = PMC bytes per launch from profiles/ (null if not collected)"},
+            "kernel_sum_ms": round(tot_ms, 4),
+            "kernels_timed_region": per_kernel_live,
             "kernels": per_kernel,
         }
         if world == 1 and not args.no_cpu_baseline:

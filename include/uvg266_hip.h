@@ -298,6 +298,17 @@ UVGHIP_API int uvghip_sao_apply_batch(int bitdepth, const void *rec, int rec_str
                            int pic_w, int pic_h, const uvghip_rect_t *rects,
                            const uvghip_sao_param_t *params, int n, void *stream);
 
+/* replaces: the arithmetic core of sao_search_edge_sao (src/sao.c:380-439): per rectangle and edge
+ * class the offsets  (sum + (cnt >> 1)) / cnt  clipped to +-7 with the sign constraint of the
+ * category (:400-411), the class's distortion change  sum_cat cnt*o^2 - 2*o*sum  (:421), and the
+ * class with the smallest one (strict "<", first wins).  The CABAC rate term mode_bits*lambda
+ * (:426-427) depends on the serial entropy-coder state and stays with the host: pass it per
+ * (rectangle, class) in rate_cost[n][4] (already (int)(bits*lambda + 0.5)), or NULL for 0.
+ * edge_stats as written by uvghip_sao_stats_batch; params_out[i] = {type 2, class, 0, offsets};
+ * ddist_out[i] (optional) = the winning sum_ddistortion. */
+UVGHIP_API int uvghip_sao_edge_offsets_batch(const int32_t *edge_stats, const int32_t *rate_cost, int n,
+                                  uvghip_sao_param_t *params_out, int32_t *ddist_out, void *stream);
+
 /* ------------------------------------------ (2) batched ABI: deblocking ---- */
 
 /* Side information of one 4x4 luma block ("SCU"), the subset of cu_info_t

@@ -153,3 +153,37 @@ ORC_EXPORT void ORC_FN(sao_stats_rects)(const orc_px *orig, const orc_px *rec, i
     free(po); free(pr);
   }
 }
+
+/* sao_search_edge_sao's arithmetic (sao.c:380-439) on the statistics; rate term supplied or zero.
+ * Depth-independent, exported once (8-bit build). */
+#if ORC_BIT_DEPTH == 8
+ORC_EXPORT void orc_sao_edge_offsets(const int32_t *edge_stats, const int32_t *rate_cost, int n,
+                                     int32_t *params /* [n][8] */, int32_t *ddist)
+{
+  for (int i = 0; i < n; ++i) {
+    const int32_t *st = edge_stats + (size_t)i * 40;
+    int best_dd = INT32_MAX, best_class = 0, best_off[5] = {0, 0, 0, 0, 0};
+    for (int c = 0; c < 4; ++c) {
+      int off[5] = {0, 0, 0, 0, 0}, dd = 0;
+      for (int cat = 1; cat <= 4; ++cat) {
+        const int sum = st[c * 10 + cat], cnt = st[c * 10 + 5 + cat];
+        int o = 0;
+        if (cnt != 0) {
+          o = (sum + (cnt >> 1)) / cnt;                    /* sao.c:401 */
+          o = o < -7 ? -7 : (o > 7 ? 7 : o);
+        }
+        if (cat <= 2 && o < 0) o = 0;                      /* sao.c:406-411 */
+        if (cat >= 3 && o > 0) o = 0;
+        off[cat] = o;
+        dd += cnt * o * o - 2 * o * sum;                   /* sao.c:421 */
+      }
+      if (rate_cost) dd += rate_cost[(size_t)i * 4 + c];
+      if (dd < best_dd) { best_dd = dd; best_class = c; for (int k = 0; k < 5; ++k) best_off[k] = off[k]; }
+    }
+    int32_t *P = params + (size_t)i * 8;
+    P[0] = 2; P[1] = best_class; P[2] = 0;
+    for (int k = 0; k < 5; ++k) P[3 + k] = best_off[k];
+    if (ddist) ddist[i] = best_dd;
+  }
+}
+#endif

@@ -121,3 +121,31 @@ def test_full_size_properties(hip):
     params = api.make_sao_params([[1, 0, 3, 0, 0, 0, 0, 0]] * len(rects))
     api.sao_apply_batch(rec, out, dr, params)
     assert torch.equal(out, rec)
+
+
+def _random_edge_stats(n, seed):
+    rng = np.random.default_rng(seed)
+    cnt = rng.integers(0, 4096, (n, 4, 1, 5)).astype(np.int32)
+    cnt[rng.random(cnt.shape) < 0.1] = 0
+    mean = rng.normal(0, 3, (n, 4, 1, 5))
+    s = np.rint(cnt * mean).astype(np.int32)
+    s[cnt == 0] = 0
+    return np.ascontiguousarray(np.concatenate([s, cnt], 2))
+
+
+@pytest.mark.parametrize("with_rate", [False, True])
+def test_edge_offsets_vs_oracle(hip, orc, with_rate):
+    """sao_search_edge_sao's offset derivation + class choice (sao.c:380-439), bit-exact with the oracle."""
+    from uvg266_amd import api
+    n = 777
+    edge = _random_edge_stats(n, 5)
+    rate = np.random.default_rng(6).integers(0, 200, (n, 4)).astype(np.int32) if with_rate else None
+    want_p, want_d = np.zeros((n, 8), np.int32), np.zeros(n, np.int32)
+    orc.lib.orc_sao_edge_offsets(H.ptr(edge), H.ptr(rate) if with_rate else None, n, H.ptr(want_p), H.ptr(want_d))
+    dd = dev(np.zeros(n, np.int32))
+    got = api.sao_edge_offsets_batch(dev(edge), dev(rate) if with_rate else None, None, dd)
+    assert np.array_equal(got.cpu().numpy(), want_p)
+    assert np.array_equal(dd.cpu().numpy(), want_d)
+    # sign constraints and range (sao.c:402-411)
+    o = want_p[:, 3:]
+    assert (o[:, 0] == 0).all() and (o[:, 1:3] >= 0).all() and (o[:, 3:5] <= 0).all() and (np.abs(o) <= 7).all()

@@ -284,6 +284,18 @@ def sao_stats_batch(orig, rec, rects):
     return edge, band
 
 
+def sao_edge_offsets_batch(edge, rate_cost=None, params=None, ddist=None):
+    """edge (n,4,2,5) statistics -> (n,8) int32 uvghip_sao_param_t rows (type 2, class, 0, offsets[5])."""
+    L = _lib.init(edge.device.index or 0)
+    n = edge.shape[0]
+    if params is None:
+        params = torch.empty((n, 8), dtype=torch.int32, device=edge.device)
+    _lib.check(L.uvghip_sao_edge_offsets_batch(_dev(edge), _dev(rate_cost) if rate_cost is not None else None, n, _dev(params),
+                                               _dev(ddist) if ddist is not None else None, _stream()),
+               "uvghip_sao_edge_offsets_batch")
+    return params
+
+
 def sao_apply_batch(rec, out, rects, params, pic_w=None, pic_h=None):
     L = _lib.init(rec.device.index or 0)
     pic_w = rec.shape[1] if pic_w is None else pic_w

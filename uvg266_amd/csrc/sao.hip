@@ -13,6 +13,7 @@
 // no indexed register file), reduces them across the wave and adds them to
 // LDS once per wave; band histograms go to per-wave LDS histograms.  HBM
 // traffic: orig + rec read once, 104 integers written per rectangle.
+#include <climits>
 #include "uvghip_common.h"
 #include "percall.h"
 #include "ref_abi.h"
@@ -141,6 +142,54 @@ extern "C" int uvghip_sao_apply_batch(int bitdepth, const void *rec, int rec_str
   hipStream_t st = uvghip_stream(stream);
   if (bitdepth == 8) sao_apply_kernel<uint8_t><<<n, 256, 0, st>>>((const uint8_t *)rec, rec_stride, (uint8_t *)out, out_stride, pic_w, pic_h, rects, params);
   else sao_apply_kernel<uint16_t><<<n, 256, 0, st>>>((const uint16_t *)rec, rec_stride, (uint16_t *)out, out_stride, pic_w, pic_h, rects, params);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------- edge offsets from statistics ----
+// sao.c:380-439 without the entropy-coder rate (passed in by the host, or zero).  One thread per rectangle.
+__global__ void __launch_bounds__(256)
+sao_edge_offsets_kernel(const int32_t *__restrict__ edge_stats, const int32_t *__restrict__ rate_cost, int n,
+                        uvghip_sao_param_t *__restrict__ params, int32_t *__restrict__ ddist)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t *st = edge_stats + (size_t)i * 40;          // [class][sum|cnt][cat]
+  int best_dd = INT_MAX, best_class = 0;
+  int best_off[5] = {0, 0, 0, 0, 0};
+  for (int c = 0; c < 4; ++c) {
+    int off[5] = {0, 0, 0, 0, 0};
+    int dd = 0;
+#pragma unroll
+    for (int cat = 1; cat <= 4; ++cat) {
+      const int sum = st[c * 10 + cat], cnt = st[c * 10 + 5 + cat];
+      int o = 0;
+      if (cnt != 0) o = clampi((sum + (cnt >> 1)) / cnt, -7, 7);   // C division: truncates toward zero
+      if (cat <= 2 && o < 0) o = 0;
+      if (cat >= 3 && o > 0) o = 0;
+      off[cat] = o;
+      dd += cnt * o * o - 2 * o * sum;
+    }
+    if (rate_cost) dd += rate_cost[(size_t)i * 4 + c];
+    if (dd < best_dd) {
+      best_dd = dd; best_class = c;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) best_off[k] = off[k];
+    }
+  }
+  uvghip_sao_param_t P;
+  P.type = 2; P.eo_class = best_class; P.band_position = 0;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) P.offsets[k] = best_off[k];
+  params[i] = P;
+  if (ddist) ddist[i] = best_dd;
+}
+
+extern "C" int uvghip_sao_edge_offsets_batch(const int32_t *edge_stats, const int32_t *rate_cost, int n,
+                                             uvghip_sao_param_t *params_out, int32_t *ddist_out, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (n <= 0) return 0;
+  sao_edge_offsets_kernel<<<(n + 255) / 256, 256, 0, uvghip_stream(stream)>>>(edge_stats, rate_cost, n, params_out, ddist_out);
   UVGHIP_CHECK_LAUNCH();
 }
 
