@@ -377,47 +377,53 @@ extern "C" int uvghip_intra_pred_batch(int bitdepth, const void *rec, int rec_st
 // ------------------------------------------------------ per-block-mode plane kernel ----
 // Each block carries its own (already decided) mode; the prediction is written into a plane at
 // the block's position -- what uvg_intra_recon_cu's predict step leaves in lcu->rec (intra.c:1537).
+// One thread per 4-sample segment: n*n/4 threads per block, 256/(n*n/4) blocks per workgroup
+// (64 4x4 blocks ... one 32x32 block); reference rows of 2n+4 samples per block in LDS.
 template <typename PX>
 __global__ void __launch_bounds__(256)
 intra_pred_plane_kernel(const PX *__restrict__ rec, int stride, int n, const uvghip_intra_blk_t *__restrict__ blks,
-                        int n_blks, int bpg, const int8_t *__restrict__ modes, PX *__restrict__ out, int out_stride)
+                        int n_blks, const int8_t *__restrict__ modes, PX *__restrict__ out, int out_stride)
 {
-  constexpr int REFN = 104;
-  __shared__ __attribute__((aligned(16))) uint16_t sRef[8 * 4 * REFN];
-  __shared__ mode_info sM[8];
-  __shared__ int sDC[8], sX[8], sY[8];
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  const int lgn = ilog2_dev(n);
+  const int lg_tpb = 2 * lgn - 2, tpb = 1 << lg_tpb, bpg = 256 >> lg_tpb;
+  const int RS = 2 * n + 4;
+  uint16_t *sRef = smem;                                                     // [bpg][4][RS]
+  int *sDC = reinterpret_cast<int *>(smem + (size_t)bpg * 4 * RS);            // [bpg], then x, y
+  int *sX = sDC + bpg, *sY = sX + bpg;
+  mode_info *sM = reinterpret_cast<mode_info *>(sY + bpg);                    // [bpg]
   const int blk0 = blockIdx.x * bpg;
   const int here = min(bpg, n_blks - blk0);
   if (here <= 0) return;
-  const int tpb = blockDim.x / bpg;
-  const int myb = threadIdx.x / tpb, mytid = threadIdx.x - myb * tpb;
-  uint16_t *base = sRef + myb * 4 * REFN;
+  const int myb = threadIdx.x >> lg_tpb, mytid = threadIdx.x & (tpb - 1);
+  uint16_t *base = sRef + (size_t)myb * 4 * RS;
   if (myb < here) {
     const uvghip_intra_blk_t b = blks[blk0 + myb];
-    build_ref_rows<PX>(rec, stride, b.x, b.y, n, n, b.avail_top, b.avail_left, base, base + REFN, REFN, mytid, tpb);
+    build_ref_rows_batched<PX, 3>(rec, stride, b.x, b.y, b.avail_top, b.avail_left, base, base + RS, RS, mytid, tpb);
     if (mytid == 0) { sM[myb] = make_mode_info(modes[blk0 + myb], n, n, 0); sX[myb] = b.x; sY[myb] = b.y; }
   }
   __syncthreads();
   if (myb < here) {
-    filter_ref_rows(base, base + REFN, base + 2 * REFN, base + 3 * REFN, n, n, REFN, mytid, tpb);
-    if (mytid == 0) sDC[myb] = dc_value(base, base + REFN, n, n);
+    filter_ref_rows(base, base + RS, base + 2 * RS, base + 3 * RS, n, n, RS, mytid, tpb);
+    if (mytid == 0) sDC[myb] = dc_value(base, base + RS, n, n);
   }
   __syncthreads();
   if (myb >= here) return;
-  const ref_rows R{base, base + REFN, base + 2 * REFN, base + 3 * REFN};
+  const ref_rows R{base, base + RS, base + 2 * RS, base + 3 * RS};
   const mode_info M = sM[myb];
   const bool transposed = M.mode >= 2 && !M.vertical;
   const int maxv = px_traits<PX>::maxv;
-  const int segs = n * n / 4;
-  for (int s = mytid; s < segs; s += tpb) {
-    const int yd = s / (n / 4), xd0 = (s - yd * (n / 4)) * 4;
-    int v[4];
-    predict_row<4>(M, R, sDC[myb], 0, n, n, yd, xd0, maxv, v);
+  const int yd = mytid >> (lgn - 2), xd0 = (mytid & ((n >> 2) - 1)) * 4;
+  int v[4];
+  predict_row<4>(M, R, sDC[myb], 0, n, n, yd, xd0, maxv, v);
+  PX *o = out + (size_t)sY[myb] * out_stride + sX[myb];
+  if (!transposed) {
+    PX *q = o + (size_t)yd * out_stride + xd0;
+    if constexpr (sizeof(PX) == 1) *reinterpret_cast<u32_unaligned *>(q) = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+    else { q[0] = (PX)v[0]; q[1] = (PX)v[1]; q[2] = (PX)v[2]; q[3] = (PX)v[3]; }
+  } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int px = transposed ? yd : xd0 + i, py = transposed ? xd0 + i : yd;
-      out[(size_t)(sY[myb] + py) * out_stride + sX[myb] + px] = (PX)v[i];
-    }
+    for (int i = 0; i < 4; ++i) o[(size_t)(xd0 + i) * out_stride + yd] = (PX)v[i];
   }
 }
 
@@ -428,29 +434,44 @@ extern "C" int uvghip_intra_pred_plane_batch(int bitdepth, const void *rec, int 
   UVGHIP_REQUIRE_READY();
   if (!(size == 4 || size == 8 || size == 16 || size == 32)) return uvghip_set_error(hipErrorInvalidValue, __func__);
   if (n <= 0) return 0;
-  const int bpg = size == 4 ? 8 : size == 8 ? 4 : size == 16 ? 2 : 1;
+  const int bpg = 256 / (size * size / 4);
   const int grid = (n + bpg - 1) / bpg;
+  const size_t lds = (size_t)bpg * 4 * (2 * size + 4) * 2 + (size_t)bpg * (sizeof(mode_info) + 12) + 16;
   hipStream_t st = uvghip_stream(stream);
   if (bitdepth == 8)
-    intra_pred_plane_kernel<uint8_t><<<grid, 256, 0, st>>>((const uint8_t *)rec, rec_stride, size, blks, n, bpg, modes, (uint8_t *)pred_plane, pred_stride);
+    intra_pred_plane_kernel<uint8_t><<<grid, 256, lds, st>>>((const uint8_t *)rec, rec_stride, size, blks, n, modes, (uint8_t *)pred_plane, pred_stride);
   else
-    intra_pred_plane_kernel<uint16_t><<<grid, 256, 0, st>>>((const uint16_t *)rec, rec_stride, size, blks, n, bpg, modes, (uint16_t *)pred_plane, pred_stride);
+    intra_pred_plane_kernel<uint16_t><<<grid, 256, lds, st>>>((const uint16_t *)rec, rec_stride, size, blks, n, modes, (uint16_t *)pred_plane, pred_stride);
   UVGHIP_CHECK_LAUNCH();
 }
 
 // costs[n][n_modes] -> best[n] = index (into the mode list) of the first minimum, the tie-break of
 // the reference's strict "<" scans (search_intra.c:1089-1101 keeps the earlier candidate on ties)
+// Eight lanes per row: lane j scans candidates j, j+8, ... (the group reads 32 contiguous bytes per step),
+// then the (cost, index) pairs are min-reduced as 64-bit keys cost:index, so ties keep the lower index.
 __global__ void __launch_bounds__(256)
 argmin_rows_kernel(const uint32_t *__restrict__ costs, int n, int n_modes, const int8_t *__restrict__ modes,
                    int8_t *__restrict__ best_mode, uint32_t *__restrict__ best_cost)
 {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t *c = costs + (size_t)i * n_modes;
-  uint32_t bc = c[0]; int bi = 0;
-  for (int m = 1; m < n_modes; ++m) if (c[m] < bc) { bc = c[m]; bi = m; }
-  best_mode[i] = modes[bi];
-  if (best_cost) best_cost[i] = bc;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 3, j = t & 7;
+  const bool on = i < n;
+  const uint32_t *c = costs + (size_t)(on ? i : 0) * n_modes;
+  uint64_t key = ~0ull;
+  for (int m = j; m < n_modes; m += 8) {
+    const uint64_t k = ((uint64_t)c[m] << 32) | (uint32_t)m;
+    key = k < key ? k : key;
+  }
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) {
+    const uint32_t lo = __shfl_xor((uint32_t)key, off, 64), hi = __shfl_xor((uint32_t)(key >> 32), off, 64);
+    const uint64_t k = ((uint64_t)hi << 32) | lo;
+    key = k < key ? k : key;
+  }
+  if (on && j == 0) {
+    best_mode[i] = modes[(uint32_t)key];
+    if (best_cost) best_cost[i] = (uint32_t)(key >> 32);
+  }
 }
 
 extern "C" int uvghip_intra_select_best(const uint32_t *costs, int n, const int8_t *modes, int n_modes,
@@ -458,7 +479,7 @@ extern "C" int uvghip_intra_select_best(const uint32_t *costs, int n, const int8
 {
   UVGHIP_REQUIRE_READY();
   if (n <= 0) return 0;
-  argmin_rows_kernel<<<(n + 255) / 256, 256, 0, uvghip_stream(stream)>>>(costs, n, n_modes, modes, best_mode, best_cost);
+  argmin_rows_kernel<<<(n * 8 + 255) / 256, 256, 0, uvghip_stream(stream)>>>(costs, n, n_modes, modes, best_mode, best_cost);
   UVGHIP_CHECK_LAUNCH();
 }
 
