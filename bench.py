@@ -34,6 +34,11 @@ MODES = list(range(67))           # every luma mode; the reference's rough searc
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 # HBM bytes per launch from the PMC passes under profiles/ (FETCH_SIZE doubled per the guide's gfx950 note + WRITE_SIZE)
 TRAFFIC = {}
+try:
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic_latest.json")) as _f:
+        TRAFFIC = json.load(_f)
+except OSError:
+    pass
 WORKLOAD = ("1920x1080 8-bit yuv420p, all-intra medium hot path per frame: luma, for N in 32,16,8,4 "
             "{intra rough search 67 modes min(SATD,2SAD) on all NxN blocks -> best mode -> intra predict "
             "-> fused residual/DCT-2/quant/dequant/IDCT/recon}; then deblock (Y,U,V; seeded random quad-tree "
