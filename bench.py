@@ -40,7 +40,7 @@ try:
 except OSError:
     pass
 WORKLOAD = ("1920x1080 8-bit yuv420p, all-intra medium hot path per frame: luma, for N in 32,16,8,4 "
-            "{intra rough search 67 modes min(SATD,2SAD) on all NxN blocks -> best mode -> intra predict "
+            "{intra rough search 67 modes min(SATD,2SAD) on all NxN blocks with fused arg-min -> intra predict "
             "-> fused residual/DCT-2/quant/dequant/IDCT/recon}; then deblock (Y,U,V; seeded random quad-tree "
             "partition) -> SAO statistics (4 edge classes + bands per CTU) -> SAO apply; open-loop references "
             "(source picture); serial RDOQ/CABAC excluded (out of hot-path scope)")
@@ -95,8 +95,8 @@ class KernelClock:
 def algorithmic_bytes(kernel, n, count):
     """SURVEY.md 8(d) per-unit figures x units per launch (b = 1 byte per 8-bit sample)."""
     b = 1
-    if kernel == "intra_search":      # refs (4N+1) + original NxN read, one 4-byte cost per mode written
-        return count * ((4 * n + 1) * b + n * n * b + 4 * len(MODES))
+    if kernel == "intra_search":      # refs (4N+1) + original NxN read, best mode + cost written (fused arg-min)
+        return count * ((4 * n + 1) * b + n * n * b + 5)
     if kernel == "intra_pred_plane":  # refs read, NxN written
         return count * ((4 * n + 1) * b + n * n * b)
     if kernel == "tu_roundtrip":      # orig + pred read, levels (int16) + recon written
@@ -117,8 +117,7 @@ def algorithmic_bytes(kernel, n, count):
 def hot_path_step(fr, modes_dev, clock, timed):
     for n in SIZES:
         blks, tus, cnt = fr.tables[n]
-        costs = clock.run(f"intra_search_{n}", lambda: api.intra_search_batch(fr.y, fr.y, blks, n, modes_dev), timed)
-        best, _ = clock.run(f"select_best_{n}", lambda: api.intra_select_best(costs, modes_dev), timed)
+        best, _ = clock.run(f"intra_search_{n}", lambda: api.intra_search_best_batch(fr.y, fr.y, blks, n, modes_dev), timed)
         clock.run(f"intra_pred_plane_{n}", lambda: api.intra_pred_plane_batch(fr.y, blks, n, best, fr.pred), timed)
         clock.run(f"tu_roundtrip_{n}", lambda: api.tu_roundtrip_batch(fr.y, fr.pred, fr.rec, tus, n, n, QP), timed)
     # in-loop filters on the reconstruction left by the last (4x4) pass

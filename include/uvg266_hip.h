@@ -216,6 +216,16 @@ UVGHIP_API int uvghip_intra_search_batch(int bitdepth, const void *rec, int rec_
                               int size, const uvghip_intra_blk_t *blks, int n, const int8_t *modes, int n_modes,
                               uint32_t *costs, void *stream);
 
+/* uvghip_intra_search_batch + uvghip_intra_select_best in one launch: the whole rough search of
+ * search_intra_rough (src/search_intra.c:986-1110) down to its winner.  best_mode[i] = the candidate
+ * with the smallest min(SATD, 2*SAD), ties to the earlier candidate (strict "<", :1089-1101);
+ * best_cost (may be NULL) its cost; costs (may be NULL) the full [n][n_modes] matrix as above.
+ * Without `costs` the kernel writes 5 bytes per block instead of 4*n_modes. */
+UVGHIP_API int uvghip_intra_search_best_batch(int bitdepth, const void *rec, int rec_stride, const void *orig, int orig_stride,
+                                   int size, const uvghip_intra_blk_t *blks, int n, const int8_t *modes,
+                                   int n_modes, int8_t *best_mode, uint32_t *best_cost, uint32_t *costs,
+                                   void *stream);
+
 /* As uvghip_intra_pred_batch for square luma blocks, but every block has its own decided mode
  * (modes[i]) and the prediction is written into `pred_plane` at the block's position: the
  * predict step of uvg_intra_recon_cu (src/intra.c:1537-1580). */

@@ -45,10 +45,18 @@ def test_search_batch_vs_oracle(hip, orc, depth, n):
     rows = [[x, y, *H.zorder_avail(int(x), int(y), n, W, Hh)] for x, y in xy]
     modes = ALL_MODES if n <= 8 else [0, 1] + list(range(2, 67, 3)) + [18, 34, 50, 66]
     got = api.intra_search_batch(dev(rec), dev(orig), api.make_intra_blocks(rows), n, api.make_modes(modes)).cpu().numpy()
+    best, bcost, full = api.intra_search_best_batch(dev(rec), dev(orig), api.make_intra_blocks(rows), n, api.make_modes(modes), True)
+    best2, bcost2 = api.intra_search_best_batch(dev(rec), dev(orig), api.make_intra_blocks(rows), n, api.make_modes(modes))
+    best, bcost, full = best.cpu().numpy(), bcost.cpu().numpy(), full.cpu().numpy()
     for i, (x, y, at, al) in enumerate(rows):
         o = np.ascontiguousarray(orig[y:y + n, x:x + n]).ravel()
         want = orc.intra_mode_costs(depth, rec, W, Hh, x, y, n, at, al, o, modes)
         assert np.array_equal(got[i].astype(np.uint32), want), (x, y, at, al)
+        # fused arg-min: first minimum of the candidate list (strict "<", search_intra.c:1089-1101)
+        j = int(np.argmin(want))
+        assert best[i] == modes[j] and bcost[i] == want[j], (x, y, best[i], modes[j])
+    assert np.array_equal(full, got)
+    assert np.array_equal(best2.cpu().numpy(), best) and np.array_equal(bcost2.cpu().numpy(), bcost)
 
 
 @pytest.mark.parametrize("depth", [8, 10])
@@ -124,6 +132,8 @@ def test_full_size_properties(hip):
     blks = api.make_intra_blocks(rows)
     flat = torch.full((Hh, W), 90, dtype=torch.uint8, device="cuda")
     c = api.intra_search_batch(flat, flat, blks, n, api.make_modes(ALL_MODES))
+    b, bc = api.intra_search_best_batch(flat, flat, blks, n, api.make_modes(ALL_MODES))
+    assert torch.equal(bc, c.min(1).values) and torch.equal(b.long(), c.argmin(1))      # ties -> first candidate (mode == index here)
     first_row_or_col = torch.tensor([(r[0] == 0 and r[1] == 0) for r in rows], device="cuda")
     assert int(c[~first_row_or_col].abs().sum()) == 0              # interior: flat refs predict the flat block exactly
     # vertical stripes: mode 50 (pure vertical) reproduces every block below the first row exactly

@@ -202,6 +202,20 @@ def intra_search_batch(rec, orig, blks, size, modes):
     return out
 
 
+def intra_search_best_batch(rec, orig, blks, size, modes, want_costs=False):
+    """Fused rough search + arg-min -> (best_mode (n,) int8, best_cost (n,) int32[, costs (n, n_modes)])."""
+    L = _lib.init(rec.device.index or 0)
+    n, nm = blks.shape[0], modes.shape[0]
+    best = torch.empty((n,), dtype=torch.int8, device=rec.device)
+    cost = torch.empty((n,), dtype=torch.int32, device=rec.device)
+    costs = torch.empty((n, nm), dtype=torch.int32, device=rec.device) if want_costs else None
+    _lib.check(L.uvghip_intra_search_best_batch(_depth(rec), _dev(rec), rec.stride(0), _dev(orig), orig.stride(0), size,
+                                                _dev(blks), n, _dev(modes), nm, _dev(best), _dev(cost),
+                                                _dev(costs) if want_costs else None, _stream()),
+               "uvghip_intra_search_best_batch")
+    return (best, cost, costs) if want_costs else (best, cost)
+
+
 def intra_pred_plane_batch(rec, blks, size, block_modes, pred_plane):
     """Predict every block with its own mode (block_modes: (n,) int8) into `pred_plane` (in place)."""
     L = _lib.init(rec.device.index or 0)

@@ -776,7 +776,7 @@ __host__ __device__ inline search_layout make_search_layout(int n, int bpg, int 
   // private strips; the same space holds the u16 staging image of the rows (4 * RS samples per block)
   size_t pv = (size_t)waves * bpg * L.PS * 4, scratch = (size_t)bpg * 4 * L.RS * 2;
   L.off_priv = (int)o; o += pv > scratch ? pv : scratch; o = (o + 15) & ~(size_t)15;
-  L.off_dc = (int)o;   o += (size_t)bpg * 4;
+  L.off_dc = (int)o;   o += (size_t)bpg * 8;      // DC values, then the per-block best keys
   o = (o + 7) & ~(size_t)7;
   L.off_coef = (int)o; o += 64 * 8;
   L.off_mode = (int)o; o += (size_t)n_modes * sizeof(search_mode);
@@ -791,7 +791,8 @@ template <typename PX, int T, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 1)
 intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__restrict__ orig, int orig_stride,
                     int n, const uvghip_intra_blk_t *__restrict__ blks, int n_blks,
-                    const int8_t *__restrict__ modes, int n_modes, uint32_t *__restrict__ costs)
+                    const int8_t *__restrict__ modes, int n_modes, uint32_t *__restrict__ costs,
+                    int8_t *__restrict__ best_mode, uint32_t *__restrict__ best_cost)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lgn = ilog2_dev(n);
@@ -804,6 +805,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   uint32_t *sPriv = reinterpret_cast<uint32_t *>(smem_raw + L.off_priv);
   uint16_t *sScratch = reinterpret_cast<uint16_t *>(smem_raw + L.off_priv);
   int *sDC = reinterpret_cast<int *>(smem_raw + L.off_dc);
+  uint32_t *sBest = reinterpret_cast<uint32_t *>(sDC + bpg);     // per block: min over modes of cost << 7 | candidate index
   uint2 *sCoef = reinterpret_cast<uint2 *>(smem_raw + L.off_coef);
   search_mode *sMode = reinterpret_cast<search_mode *>(smem_raw + L.off_mode);
 
@@ -849,6 +851,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       }
     }
     for (int m = threadIdx.x; m < n_modes; m += NT) sMode[m] = make_search_mode(modes[m], n);
+    if (threadIdx.x < bpg) sBest[threadIdx.x] = 0xffffffffu;
     if (threadIdx.x < 64) {
       const int df = threadIdx.x & 31;
       int f0, f1, f2, f3;
@@ -889,6 +892,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
 
   // two passes over the candidate list: modes predicted in the block domain, then those predicted in
   // the transposed domain; the lane's original tile stays in registers for a whole pass
+  uint32_t my_best = 0xffffffffu;
   for (int phase = 0; phase < 2; ++phase) {
     uint32_t o[T][T / 2];
     load_orig_tile<PX, T>(ob + (phase ? nn : 0), n, o);
@@ -948,19 +952,32 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
         // (satd_4x4 is unshifted, picture-generic.c:170; everything else >> depth-8)
         const uint32_t c_satd = satd >> (T == 4 ? 0 : dshift);
         const uint32_t c_sad = sad >> dshift;
-        costs[(size_t)(blk0 + lb) * n_modes + m] = min(c_satd, 2 * c_sad);
+        const uint32_t c = min(c_satd, 2 * c_sad);
+        if (costs) costs[(size_t)(blk0 + lb) * n_modes + m] = c;
+        my_best = min(my_best, (c << 7) | (uint32_t)m);       // c < 2^25: at most 2 * 1024 samples * 255 (after the depth shift)
       }
+    }
+  }
+  // fused arg-min (the strict "<" scan of search_intra.c:1089-1101: ties keep the earlier candidate):
+  // every wave contributes the best of its share of the candidates
+  if (best_mode) {
+    if (active && tile == 0) atomicMin(&sBest[lb], my_best);
+    __syncthreads();
+    if ((int)threadIdx.x < here) {
+      const uint32_t k = sBest[threadIdx.x];
+      best_mode[blk0 + threadIdx.x] = modes[k & 127];
+      if (best_cost) best_cost[blk0 + threadIdx.x] = k >> 7;
     }
   }
 }
 
-extern "C" int uvghip_intra_search_batch(int bitdepth, const void *rec, int rec_stride, const void *orig, int orig_stride,
-                                         int size, const uvghip_intra_blk_t *blks, int n, const int8_t *modes,
-                                         int n_modes, uint32_t *costs, void *stream)
+static int launch_intra_search(int bitdepth, const void *rec, int rec_stride, const void *orig, int orig_stride,
+                               int size, const uvghip_intra_blk_t *blks, int n, const int8_t *modes, int n_modes,
+                               uint32_t *costs, int8_t *best_mode, uint32_t *best_cost, void *stream, const char *who)
 {
   UVGHIP_REQUIRE_READY();
   if (!(size == 4 || size == 8 || size == 16 || size == 32) || n_modes < 1 || n_modes > 128)
-    return uvghip_set_error(hipErrorInvalidValue, __func__);
+    return uvghip_set_error(hipErrorInvalidValue, who);
   if (n <= 0) return 0;
   const int tiles = size == 4 ? 1 : (size / 8) * (size / 8);
   const int bpg = 64 / tiles;
@@ -970,11 +987,30 @@ extern "C" int uvghip_intra_search_batch(int bitdepth, const void *rec, int rec_
 #define LAUNCH(PX, T, W) do { const search_layout L = make_search_layout(size, bpg, n_modes, W, (int)sizeof(PX)); \
     static bool big_lds = false; /* allow more than the default 64 KiB of dynamic LDS, once per instantiation */ \
     if (!big_lds) { UVGHIP_TRY(hipFuncSetAttribute((const void *)intra_search_kernel<PX, T, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); big_lds = true; } \
-    intra_search_kernel<PX, T, W><<<grid, W * 64, L.total, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, blks, n, modes, n_modes, costs); } while (0)
+    intra_search_kernel<PX, T, W><<<grid, W * 64, L.total, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, blks, n, modes, n_modes, costs, best_mode, best_cost); } while (0)
   if (bitdepth == 8) { if (size == 4) LAUNCH(uint8_t, 4, 4); else LAUNCH(uint8_t, 8, UVGHIP_SEARCH_WAVES); }
   else { if (size == 4) LAUNCH(uint16_t, 4, 4); else LAUNCH(uint16_t, 8, UVGHIP_SEARCH_WAVES); }
 #undef LAUNCH
   UVGHIP_CHECK_LAUNCH();
+}
+
+extern "C" int uvghip_intra_search_batch(int bitdepth, const void *rec, int rec_stride, const void *orig, int orig_stride,
+                                         int size, const uvghip_intra_blk_t *blks, int n, const int8_t *modes,
+                                         int n_modes, uint32_t *costs, void *stream)
+{
+  if (!costs) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  return launch_intra_search(bitdepth, rec, rec_stride, orig, orig_stride, size, blks, n, modes, n_modes, costs, nullptr, nullptr,
+                             stream, __func__);
+}
+
+extern "C" int uvghip_intra_search_best_batch(int bitdepth, const void *rec, int rec_stride, const void *orig, int orig_stride,
+                                              int size, const uvghip_intra_blk_t *blks, int n, const int8_t *modes,
+                                              int n_modes, int8_t *best_mode, uint32_t *best_cost, uint32_t *costs,
+                                              void *stream)
+{
+  if (!best_mode) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  return launch_intra_search(bitdepth, rec, rec_stride, orig, orig_stride, size, blks, n, modes, n_modes, costs, best_mode,
+                             best_cost, stream, __func__);
 }
 
 // =================================================== drop-in strategy layer ====

@@ -45,6 +45,7 @@ SIGNATURES = {
     "uvg_strategy_register_intra_hip": (c_int, [c_vp, ctypes.c_uint8]),
     "uvghip_intra_pred_batch": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_intra_search_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_intra_search_best_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_intra_pred_plane_batch": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
     "uvghip_intra_select_best": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvghip_mc_batch": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
