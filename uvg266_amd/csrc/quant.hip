@@ -52,6 +52,15 @@ __device__ __forceinline__ int quant_one(int c, const quant_params &q)
   if (c < 0) level = -level;
   return clampi(level, -32768, 32767);
 }
+// Same value with 32-bit arithmetic, valid while |c| <= 32768 and q_bits <= 31 (every TU of at least 4x4):
+// |c| * scale <= 32768 * 26214 and add <= 171 << 22, so the sum stays below 2^32.
+__device__ __forceinline__ int quant_one32(int c, const quant_params &q)
+{
+  const uint32_t a = (uint32_t)abs(c);
+  int level = (int)((__umul24(a, (uint32_t)q.scale) + (uint32_t)q.add) >> q.q_bits);
+  if (c < 0) level = -level;
+  return clampi(level, -32768, 32767);
+}
 __device__ __forceinline__ int dequant_one(int l, const quant_params &q)
 {
   return clampi((l * q.iscale + q.iadd) >> q.ishift, -32768, 32767);
@@ -221,6 +230,126 @@ tu_roundtrip_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, in
     for (int b = threadIdx.x; b < here; b += blockDim.x) has_coeffs[blk0 + b] = (uint8_t)sHas[b];
 }
 
+// ---- fused TU round trip, small square TUs: one lane = one TU, everything in registers -----------
+// 4x4 and 8x8 TUs without zero-out.  The kernel matrices are read through uniform (scalar) loads, so
+// every multiply-accumulate is a v_dot2_i32_i16 with an SGPR coefficient pair; between passes the
+// int16 intermediates are re-packed along the next pass's tap dimension (a compile-time register
+// permutation).  Blocks in raster order make the row loads/stores of a wave contiguous.
+//   fwd1  t[y][c]  = int16((sum_k res[y][k] Th[c][k] + a1) >> s1)      dct-generic.c:411 (truncation)
+//   fwd2  co[j][c] = int16((sum_y t[y][c] Tv[j][y] + a2) >> s2)
+//   quant / dequant                                                   quant-generic.c:51-121, :618-669
+//   inv1  u[y][c]  = clip16((sum_j dq[j][c] Tv[j][y] + 64) >> 7)       dct-generic.c:438 (clip)
+//   inv2  r[y][x]  = clip16((sum_c u[y][c] Th[c][x] + a4) >> s4)
+template <int N, bool ROWPAIRS>
+__device__ __forceinline__ uint32_t tu_coef_pair(const int16_t *T, int o, int t)
+{
+  if constexpr (ROWPAIRS) return reinterpret_cast<const uint32_t *>(T)[(o * N + 2 * t) >> 1];        // (T[o][2t], T[o][2t+1])
+  else return (uint32_t)(uint16_t)T[(2 * t) * N + o] | ((uint32_t)(uint16_t)T[(2 * t + 1) * N + o] << 16);   // (T[2t][o], T[2t+1][o])
+}
+// out[l][o] = (sum_t in[l][t] . pair(o, t) + add) >> shift, optionally clipped to int16
+template <int N, bool ROWPAIRS, bool CLIP>
+__device__ __forceinline__ void tu_lane_pass(const uint32_t (&in)[N][N / 2], const int16_t *T, int shift, int (&out)[N][N])
+{
+  const int add = shift > 0 ? 1 << (shift - 1) : 0;
+#pragma unroll
+  for (int o = 0; o < N; ++o) {
+    uint32_t cp[N / 2];
+#pragma unroll
+    for (int t = 0; t < N / 2; ++t) cp[t] = tu_coef_pair<N, ROWPAIRS>(T, o, t);
+#pragma unroll
+    for (int l = 0; l < N; ++l) {
+      int acc = add;
+#pragma unroll
+      for (int t = 0; t < N / 2; ++t) acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, in[l][t]), __builtin_bit_cast(v2s, cp[t]), acc, false);
+      acc >>= shift;
+      out[l][o] = CLIP ? clampi(acc, -32768, 32767) : acc;      // forward passes: the int16 truncation happens when packing
+    }
+  }
+}
+// next[o][l/2] = (v[l][o], v[l+1][o]) low halves: lines become taps
+template <int N>
+__device__ __forceinline__ void tu_repack(const int (&v)[N][N], uint32_t (&next)[N][N / 2])
+{
+#pragma unroll
+  for (int o = 0; o < N; ++o)
+#pragma unroll
+    for (int l = 0; l < N; l += 2) next[o][l >> 1] = __builtin_amdgcn_perm((uint32_t)v[l + 1][o], (uint32_t)v[l][o], 0x05040100u);
+}
+
+template <typename PX, int N>
+__global__ void __launch_bounds__(256)
+tu_lane_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int orig_stride,
+               const PX *__restrict__ pred, int pred_stride, PX *__restrict__ rec, int rec_stride,
+               const uvghip_tu_t *__restrict__ tus, int n, int16_t *__restrict__ coeff_out, uint8_t *__restrict__ has_coeffs)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uvghip_tu_t tu = tus[i];
+  const int16_t *Th = tr_matrix_dev(P.type_hor, N), *Tv = tr_matrix_dev(P.type_ver, N);
+  int pr[N][N];
+  uint32_t a[N][N / 2];
+  int v[N][N];
+#pragma unroll
+  for (int y = 0; y < N; ++y) {
+    int o[N];
+    load_row<PX, N>(orig, orig_stride, tu.x, tu.y + y, o);
+    load_row<PX, N>(pred, pred_stride, tu.x, tu.y + y, pr[y]);
+#pragma unroll
+    for (int x = 0; x < N; x += 2)
+      a[y][x >> 1] = __builtin_amdgcn_perm((uint32_t)(o[x + 1] - pr[y][x + 1]), (uint32_t)(o[x] - pr[y][x]), 0x05040100u);
+  }
+  tu_lane_pass<N, true, false>(a, Th, P.f1.shift, v);            // v[y][c]
+  tu_repack<N>(v, a);                                             // a[c][y pairs]
+  tu_lane_pass<N, true, false>(a, Tv, P.f2.shift, v);            // v[c][j]
+  // quantise, store levels row-major [j][c], dequantise
+  int any = 0;
+  int16_t *co = coeff_out + (size_t)i * (N * N);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    int lv[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+      lv[c] = quant_one32((int)(int16_t)v[c][j], Q);
+      any |= lv[c];
+      v[c][j] = dequant_one(lv[c], Q);
+    }
+    if constexpr (N == 8) {
+      uint4 w;
+      w.x = (uint32_t)(uint16_t)lv[0] | ((uint32_t)lv[1] << 16); w.y = (uint32_t)(uint16_t)lv[2] | ((uint32_t)lv[3] << 16);
+      w.z = (uint32_t)(uint16_t)lv[4] | ((uint32_t)lv[5] << 16); w.w = (uint32_t)(uint16_t)lv[6] | ((uint32_t)lv[7] << 16);
+      *reinterpret_cast<uint4 *>(co + j * 8) = w;
+    } else {
+      uint2 w;
+      w.x = (uint32_t)(uint16_t)lv[0] | ((uint32_t)lv[1] << 16); w.y = (uint32_t)(uint16_t)lv[2] | ((uint32_t)lv[3] << 16);
+      *reinterpret_cast<uint2 *>(co + j * 4) = w;
+    }
+  }
+  if (has_coeffs) has_coeffs[i] = any != 0;
+  // v[c][j] = dequantised; taps of inv1 run over j: already the second index -> pack pairs along j
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int j = 0; j < N; j += 2) a[c][j >> 1] = __builtin_amdgcn_perm((uint32_t)v[c][j + 1], (uint32_t)v[c][j], 0x05040100u);
+  tu_lane_pass<N, false, true>(a, Tv, P.i1.shift, v);            // v[c][y] = sum_j dq[j][c] Tv[j][y]
+  tu_repack<N>(v, a);                                             // a[y][c pairs]
+  tu_lane_pass<N, false, true>(a, Th, P.i2.shift, v);            // v[y][x] = sum_c u[y][c] Th[c][x]
+#pragma unroll
+  for (int y = 0; y < N; ++y) {
+    PX *q = rec + (size_t)(tu.y + y) * rec_stride + tu.x;
+    int r[N];
+#pragma unroll
+    for (int x = 0; x < N; ++x) r[x] = clampi((int)(int16_t)(v[y][x] + pr[y][x]), 0, px_traits<PX>::maxv);   // quant-generic.c:594-595
+    if constexpr (sizeof(PX) == 1) {
+#pragma unroll
+      for (int x = 0; x < N; x += 4)
+        *reinterpret_cast<u32_unaligned *>(q + x) = (uint32_t)r[x] | ((uint32_t)r[x + 1] << 8) | ((uint32_t)r[x + 2] << 16) | ((uint32_t)r[x + 3] << 24);
+    } else {
+#pragma unroll
+      for (int x = 0; x < N; x += 2) *reinterpret_cast<u32_unaligned *>(q + x) = (uint32_t)r[x] | ((uint32_t)r[x + 1] << 16);
+    }
+  }
+}
+
 extern "C" int uvghip_tu_roundtrip_batch(int bitdepth, int type_hor, int type_ver, int skip_width, int skip_height,
                                          int width, int height, int qp_scaled, int slice_is_intra,
                                          const void *orig, int orig_stride, const void *pred, int pred_stride,
@@ -235,9 +364,17 @@ extern "C" int uvghip_tu_roundtrip_batch(int bitdepth, int type_hor, int type_ve
   if (n <= 0) return 0;
   const tr_params P = tr_make_params(bitdepth, type_hor, type_ver, width, height, skip_width, skip_height);
   const quant_params Q = make_quant_params(bitdepth, width, height, qp_scaled, 0, slice_is_intra);
+  hipStream_t st = uvghip_stream(stream);
+  if (width == height && width <= 8 && skip_width == 0 && skip_height == 0) {
+    const int g = (n + 255) / 256;
+#define TU_LANE(PX, N) tu_lane_kernel<PX, N><<<g, 256, 0, st>>>(P, Q, (const PX *)orig, orig_stride, (const PX *)pred, pred_stride, (PX *)rec, rec_stride, tus, n, coeff_out, has_coeffs)
+    if (bitdepth == 8) { if (width == 4) TU_LANE(uint8_t, 4); else TU_LANE(uint8_t, 8); }
+    else { if (width == 4) TU_LANE(uint16_t, 4); else TU_LANE(uint16_t, 8); }
+#undef TU_LANE
+    UVGHIP_CHECK_LAUNCH();
+  }
   const int bpg = 1024 / (width * height);
   const int grid = (n + bpg - 1) / bpg;
-  hipStream_t st = uvghip_stream(stream);
   if (bitdepth == 8)
     tu_roundtrip_kernel<uint8_t><<<grid, 256, 0, st>>>(P, Q, (const uint8_t *)orig, orig_stride, (const uint8_t *)pred, pred_stride,
                                                        (uint8_t *)rec, rec_stride, tus, n, bpg, coeff_out, has_coeffs);
