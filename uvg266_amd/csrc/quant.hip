@@ -350,6 +350,201 @@ tu_lane_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int ori
   }
 }
 
+// ---- fused TU round trip, 16x16 / 32x32 without zero-out: one wave = 1024 coefficients ----------
+// A wave owns one 32x32 TU (or four 16x16 TUs) and walks the four passes on its own two LDS line
+// buffers with no workgroup barrier after the matrices are staged.  Each lane computes a 4 lines x 4
+// outputs register tile per pass: per 8 taps it loads 4 + 4 b128 rows (input lines, matrix rows) and
+// issues 64 v_dot2 -- 8 LDS dwords per 64 MACs instead of 2 per MAC.  Pitches (32x32: 20 dwords per
+// row, matrix rows 16..31 skewed by 4 dwords; 16x16: 12 dwords per row, 196 per block) keep every b128
+// 16-byte aligned and put the lanes of each b128 service group on different 4-dword bank slots.  Results leave a pass already packed along the next pass's tap
+// dimension (two dwords per output = one ds_write_b64).
+template <int N> struct tuw {
+  static constexpr int PITCH = N == 32 ? 40 : 24;                 // int16 per line
+  // matrix row o starts at o * PITCH + skew(o): the 8 row groups a service group touches must differ in bank slot
+  __host__ __device__ static constexpr int mrow(int o) { return o * PITCH + (N == 32 && o >= 16 ? 8 : 0); }
+  static constexpr int BPW = 1024 / (N * N);                      // TUs per wave
+  static constexpr int BLK = N * PITCH + (N == 16 ? 8 : 0);       // int16 per TU in a line buffer
+  static constexpr int BUF = BPW * BLK;
+  static constexpr int MAT = N * PITCH;
+};
+
+// acc[i][j] = sum_k A[l0+i][k] * B[o0+j][k]
+template <int N>
+__device__ __forceinline__ void tuw_mma(const int16_t *A, const int16_t *B, int (&acc)[4][4])
+{
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+#pragma unroll
+  for (int kk = 0; kk < N / 8; ++kk) {
+    uint4 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const uint4 *>(A + i * tuw<N>::PITCH + kk * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const uint4 *>(B + j * tuw<N>::PITCH + kk * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int s = acc[i][j];
+        s = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a[i].x), __builtin_bit_cast(v2s, b[j].x), s, false);
+        s = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a[i].y), __builtin_bit_cast(v2s, b[j].y), s, false);
+        s = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a[i].z), __builtin_bit_cast(v2s, b[j].z), s, false);
+        s = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a[i].w), __builtin_bit_cast(v2s, b[j].w), s, false);
+        acc[i][j] = s;
+      }
+  }
+}
+__device__ __forceinline__ void tuw_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// v[i][j] (line l0+i, output o0+j) -> dst[o0+j][l0 .. l0+3] (lines become taps)
+template <int N>
+__device__ __forceinline__ void tuw_store_transposed(int16_t *dst, int l0, const int (&v)[4][4])
+{
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    *reinterpret_cast<uint2 *>(dst + j * tuw<N>::PITCH + l0) =
+        make_uint2(__builtin_amdgcn_perm((uint32_t)v[1][j], (uint32_t)v[0][j], 0x05040100u),
+                   __builtin_amdgcn_perm((uint32_t)v[3][j], (uint32_t)v[2][j], 0x05040100u));
+}
+
+template <typename PX, int N>
+__global__ void __launch_bounds__(256)
+tu_wave_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int orig_stride,
+               const PX *__restrict__ pred, int pred_stride, PX *__restrict__ rec, int rec_stride,
+               const uvghip_tu_t *__restrict__ tus, int n, int16_t *__restrict__ coeff_out, uint8_t *__restrict__ has_coeffs)
+{
+  using W = tuw<N>;
+  __shared__ __attribute__((aligned(16))) int16_t sM[4][W::MAT];       // Bf1, Bf2, Bi1, Bi2
+  __shared__ __attribute__((aligned(16))) int16_t sBuf[4][2][W::BUF];  // per wave: two line buffers
+  {
+    const int16_t *Th = tr_matrix_dev(P.type_hor, N), *Tv = tr_matrix_dev(P.type_ver, N);
+    for (int e = threadIdx.x; e < N * N; e += 256) {
+      const int r = e / N, c = e - r * N;                                // compile-time N: shifts
+      sM[0][W::mrow(r) + c] = Th[e];                                     // Bf1[c'][k]  = Th[c'][k]
+      sM[1][W::mrow(r) + c] = Tv[e];                                     // Bf2[j][y]   = Tv[j][y]
+      sM[2][W::mrow(c) + r] = Tv[e];                                     // Bi1[y][j]   = Tv[j][y]
+      sM[3][W::mrow(c) + r] = Th[e];                                     // Bi2[x][c']  = Th[c'][x]
+    }
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * 4 + wave;
+  const int tu0 = unit * W::BPW;
+  if (tu0 >= n) return;
+  int16_t *bufA = sBuf[wave][0], *bufB = sBuf[wave][1];
+  // lane -> (TU b, line group, output group)
+  const int b = N == 32 ? 0 : lane >> 4;
+  const int l0 = (N == 32 ? lane >> 3 : (lane >> 2) & 3) * 4;
+  const int o0 = (N == 32 ? lane & 7 : lane & 3) * 4;
+  const bool on = tu0 + b < n;
+  const uvghip_tu_t tu = tus[on ? tu0 + b : tu0];
+
+  // residual rows -> bufA[b][y][x]
+  {
+    const int row = N == 32 ? lane >> 1 : lane & 15, x0 = N == 32 ? (lane & 1) * 16 : 0;
+    const int lb = N == 32 ? 0 : lane >> 4;
+    const uvghip_tu_t t2 = tus[tu0 + lb < n ? tu0 + lb : tu0];
+    int o[16], p[16];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int o8[8], p8[8];
+      load_row<PX, 8>(orig, orig_stride, t2.x + x0 + q * 8, t2.y + row, o8);
+      load_row<PX, 8>(pred, pred_stride, t2.x + x0 + q * 8, t2.y + row, p8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { o[q * 8 + k] = o8[k]; p[q * 8 + k] = p8[k]; }
+    }
+    int16_t *dst = bufA + lb * W::BLK + row * W::PITCH + x0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<uint2 *>(dst + q * 4) =
+          make_uint2(__builtin_amdgcn_perm((uint32_t)(o[q * 4 + 1] - p[q * 4 + 1]), (uint32_t)(o[q * 4] - p[q * 4]), 0x05040100u),
+                     __builtin_amdgcn_perm((uint32_t)(o[q * 4 + 3] - p[q * 4 + 3]), (uint32_t)(o[q * 4 + 2] - p[q * 4 + 2]), 0x05040100u));
+  }
+  tuw_sync();
+
+  int acc[4][4];
+  // fwd1: lines y, outputs c -> bufB[c][y]
+  tuw_mma<N>(bufA + b * W::BLK + l0 * W::PITCH, sM[0] + W::mrow(o0), acc);
+  {
+    const int add = P.f1.shift > 0 ? 1 << (P.f1.shift - 1) : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (acc[i][j] + add) >> P.f1.shift;     // int16 truncation on packing
+    tuw_store_transposed<N>(bufB + b * W::BLK + o0 * W::PITCH, l0, acc);
+  }
+  tuw_sync();
+  // fwd2: lines c, outputs j -> quantise; levels to HBM [j][c]; dequantised -> bufA[c][j]
+  tuw_mma<N>(bufB + b * W::BLK + l0 * W::PITCH, sM[1] + W::mrow(o0), acc);
+  int any = 0;
+  {
+    const int add = 1 << (P.f2.shift - 1);
+    int lv[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lv[i][j] = quant_one32((int)(int16_t)((acc[i][j] + add) >> P.f2.shift), Q);
+        any |= lv[i][j];
+        acc[i][j] = dequant_one(lv[i][j], Q);
+      }
+    if (on) {
+      int16_t *co = coeff_out + (size_t)(tu0 + b) * (N * N);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)     // row j = o0 + j, columns c = l0 .. l0+3
+        *reinterpret_cast<uint2 *>(co + (o0 + j) * N + l0) =
+            make_uint2((uint32_t)(uint16_t)lv[0][j] | ((uint32_t)lv[1][j] << 16), (uint32_t)(uint16_t)lv[2][j] | ((uint32_t)lv[3][j] << 16));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)       // natural orientation: line c = l0 + i, taps j = o0 .. o0+3
+      *reinterpret_cast<uint2 *>(bufA + b * W::BLK + (l0 + i) * W::PITCH + o0) =
+          make_uint2(__builtin_amdgcn_perm((uint32_t)acc[i][1], (uint32_t)acc[i][0], 0x05040100u),
+                     __builtin_amdgcn_perm((uint32_t)acc[i][3], (uint32_t)acc[i][2], 0x05040100u));
+  }
+  if (has_coeffs) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(any != 0);
+    if (N == 32) { if (lane == 0) has_coeffs[tu0] = m != 0; }
+    else if ((lane & 15) == 0 && on) has_coeffs[tu0 + b] = ((m >> (lane & 48)) & 0xffffull) != 0;
+  }
+  tuw_sync();
+  // inv1: lines c, taps j, outputs y -> bufB[y][c]
+  tuw_mma<N>(bufA + b * W::BLK + l0 * W::PITCH, sM[2] + W::mrow(o0), acc);
+  {
+    const int add = 1 << (P.i1.shift - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = clampi((acc[i][j] + add) >> P.i1.shift, -32768, 32767);
+    tuw_store_transposed<N>(bufB + b * W::BLK + o0 * W::PITCH, l0, acc);
+  }
+  tuw_sync();
+  // inv2: lines y, taps c, outputs x -> + pred -> rec
+  tuw_mma<N>(bufB + b * W::BLK + l0 * W::PITCH, sM[3] + W::mrow(o0), acc);
+  if (on) {
+    const int add = 1 << (P.i2.shift - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int p4[4];
+      load_row<PX, 4>(pred, pred_stride, tu.x + o0, tu.y + l0 + i, p4);
+      int r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int v = clampi((acc[i][j] + add) >> P.i2.shift, -32768, 32767);
+        r[j] = clampi((int)(int16_t)(v + p4[j]), 0, px_traits<PX>::maxv);          // quant-generic.c:594-595
+      }
+      PX *q = rec + (size_t)(tu.y + l0 + i) * rec_stride + tu.x + o0;
+      if constexpr (sizeof(PX) == 1) *reinterpret_cast<u32_unaligned *>(q) = (uint32_t)r[0] | ((uint32_t)r[1] << 8) | ((uint32_t)r[2] << 16) | ((uint32_t)r[3] << 24);
+      else { *reinterpret_cast<u32_unaligned *>(q) = (uint32_t)r[0] | ((uint32_t)r[1] << 16); *reinterpret_cast<u32_unaligned *>(q + 2) = (uint32_t)r[2] | ((uint32_t)r[3] << 16); }
+    }
+  }
+}
+
 extern "C" int uvghip_tu_roundtrip_batch(int bitdepth, int type_hor, int type_ver, int skip_width, int skip_height,
                                          int width, int height, int qp_scaled, int slice_is_intra,
                                          const void *orig, int orig_stride, const void *pred, int pred_stride,
@@ -371,6 +566,14 @@ extern "C" int uvghip_tu_roundtrip_batch(int bitdepth, int type_hor, int type_ve
     if (bitdepth == 8) { if (width == 4) TU_LANE(uint8_t, 4); else TU_LANE(uint8_t, 8); }
     else { if (width == 4) TU_LANE(uint16_t, 4); else TU_LANE(uint16_t, 8); }
 #undef TU_LANE
+    UVGHIP_CHECK_LAUNCH();
+  }
+  if (width == height && width >= 16 && skip_width == 0 && skip_height == 0) {
+    const int units = width == 32 ? n : (n + 3) / 4, g = (units + 3) / 4;
+#define TU_WAVE(PX, N) tu_wave_kernel<PX, N><<<g, 256, 0, st>>>(P, Q, (const PX *)orig, orig_stride, (const PX *)pred, pred_stride, (PX *)rec, rec_stride, tus, n, coeff_out, has_coeffs)
+    if (bitdepth == 8) { if (width == 16) TU_WAVE(uint8_t, 16); else TU_WAVE(uint8_t, 32); }
+    else { if (width == 16) TU_WAVE(uint16_t, 16); else TU_WAVE(uint16_t, 32); }
+#undef TU_WAVE
     UVGHIP_CHECK_LAUNCH();
   }
   const int bpg = 1024 / (width * height);
