@@ -912,16 +912,28 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
         // (intra-generic.c:156-159; j = 0 gives the corner = main[0]):
         //   priv[n - j] = (ext[-j], ext[-j+1]), j = 1..need;  priv[n + i] = main pair i, i = 0..n.
         // The block's `tiles` lanes share the work.
-        const int need = min(n, (__mul24(-S.sd, n) + 31) >> 5);   // deepest row reaches ext[-need]
-        for (int e = n - need + tile; e < 2 * n + 1; e += tiles) {
-          uint32_t v;
-          if (e < n) {
-            const int j = n - e;
-            const int a0 = pr_sample(side, min((__mul24(j, S.inv) + 256) >> 9, n));
-            const int a1 = pr_sample(side, min((__mul24(j - 1, S.inv) + 256) >> 9, n));
-            v = (uint32_t)a0 | ((uint32_t)a1 << 16);
-          } else v = mainr[e - n];
-          priv[e] = v;
+        if (lg_tiles == 0) {
+          // one tile per block (n == T): the lane builds its own strip, fully unrolled.  j and inv are uniform,
+          // so the projected indices are scalar arithmetic and each sample costs one LDS read.
+          int sv[T + 1];
+#pragma unroll
+          for (int j = 0; j <= T; ++j) sv[j] = pr_sample(side, min((j * S.inv + 256) >> 9, T));
+#pragma unroll
+          for (int j = 1; j <= T; ++j) priv[T - j] = (uint32_t)sv[j] | ((uint32_t)sv[j - 1] << 16);
+#pragma unroll
+          for (int i = 0; i <= T; ++i) priv[T + i] = mainr[i];
+        } else {
+          const int need = min(n, (__mul24(-S.sd, n) + 31) >> 5);   // deepest row reaches ext[-need]
+          for (int e = n - need + tile; e < 2 * n + 1; e += tiles) {
+            uint32_t v;
+            if (e < n) {
+              const int j = n - e;
+              const int a0 = pr_sample(side, min((__mul24(j, S.inv) + 256) >> 9, n));
+              const int a1 = pr_sample(side, min((__mul24(j - 1, S.inv) + 256) >> 9, n));
+              v = (uint32_t)a0 | ((uint32_t)a1 << 16);
+            } else v = mainr[e - n];
+            priv[e] = v;
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
