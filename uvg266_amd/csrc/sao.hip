@@ -27,60 +27,100 @@ __device__ __forceinline__ int eo_cat(int a, int b, int c)
 }
 __device__ static const int8_t kEoOfs[4][4] = {{-1, 0, 1, 0}, {0, -1, 0, 1}, {-1, -1, 1, 1}, {1, -1, -1, 1}};  // ax,ay,bx,by (sao.h:71-76)
 
+// Statistics: one workgroup per rectangle, one thread per 4-sample segment at a time.  Every thread owns a
+// private column of an LDS table [52 entries][256 threads]: entries 0..19 = (edge class, category),
+// 20..51 = band; each holds (count << 16 | sum of (diff + BIAS)).  A sample is five conflict-free
+// ds_add_u32 on the thread's own column (bank = thread id) -- no select chains, no contended atomics.
+// The 16-bit fields hold a chunk of at most 8192 samples per workgroup (32 per thread; a 64x64 CTU is one
+// chunk); larger rectangles are walked in row chunks whose column sums accumulate in 32-bit registers.
 template <typename PX>
 __global__ void __launch_bounds__(256)
 sao_stats_kernel(const PX *__restrict__ orig, int ostride, const PX *__restrict__ rec, int rstride,
                  const uvghip_rect_t *__restrict__ rects, int32_t *__restrict__ edge_out, int32_t *__restrict__ band_out)
 {
-  __shared__ int sEdge[40];
-  __shared__ int sBand[4][64];
-  const uvghip_rect_t R = rects[blockIdx.x];
-  for (int i = threadIdx.x; i < 40; i += blockDim.x) sEdge[i] = 0;
-  for (int i = threadIdx.x; i < 256; i += blockDim.x) (&sBand[0][0])[i] = 0;
-  __syncthreads();
-  const int wave = threadIdx.x >> 6;
+  constexpr int BIAS = 1 << px_traits<PX>::depth;
   constexpr int bshift = px_traits<PX>::depth - 5;
-  int acc[4][2][5];
+  __shared__ uint32_t sT[52][256];
+  const uvghip_rect_t R = rects[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int segs_per_row = (R.w + 3) >> 2;
+  const int rows_chunk = max(1, 2048 / segs_per_row);          // <= 8192 samples per chunk
+  int tot_sum = 0, tot_cnt = 0;                                // running totals of entry tid / 4 (quarter tid & 3)
+  for (int row0 = 0; row0 < R.h; row0 += rows_chunk) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int e = 0; e < 52; ++e) sT[e][tid] = 0;
+  const int nseg = segs_per_row * min(rows_chunk, R.h - row0);
+  for (int sg = tid; sg < nseg; sg += 256) {
+    const int yc = sg / segs_per_row, x0 = (sg - yc * segs_per_row) * 4, y = row0 + yc;
+    const PX *rp = rec + (size_t)(R.y + y) * rstride + R.x + x0;
+    const PX *op = orig + (size_t)(R.y + y) * ostride + R.x + x0;
+    const int nx = min(4, R.w - x0);
+    const bool rows_in = y >= 1 && y < R.h - 1;                 // interior rows only (sao-generic.c:67-68)
+    int c[4], o[4], u[6], m[6], d[6];                           // m = this row at x0-1 .. x0+4
+    if (nx == 4) { load4(rp, c); load4(op, o); }
+    else {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) { acc[c][0][k] = 0; acc[c][1][k] = 0; }
-  const int npx = R.w * R.h;
-  for (int i = threadIdx.x; i < npx; i += blockDim.x) {
-    const int y = i / R.w, x = i - y * R.w;
-    const PX *rp = rec + (size_t)(R.y + y) * rstride + R.x + x;
-    const int c = rp[0];
-    const int diff = (int)orig[(size_t)(R.y + y) * ostride + R.x + x] - c;
-    atomicAdd(&sBand[wave][c >> bshift], diff);
-    atomicAdd(&sBand[wave][32 + (c >> bshift)], 1);
-    if (x >= 1 && y >= 1 && x < R.w - 1 && y < R.h - 1) {   // interior only (sao-generic.c:67-68)
-      const int l = rp[-1], r = rp[1];
-      const int u = rp[-rstride], d = rp[rstride];
-      const int ul = rp[-rstride - 1], ur = rp[-rstride + 1], dl = rp[rstride - 1], dr = rp[rstride + 1];
-      const int cats[4] = {eo_cat(l, r, c), eo_cat(u, d, c), eo_cat(ul, dr, c), eo_cat(ur, dl, c)};
+      for (int i = 0; i < 4; ++i) { c[i] = i < nx ? rp[i] : 0; o[i] = i < nx ? op[i] : 0; }
+    }
 #pragma unroll
-      for (int cl = 0; cl < 4; ++cl)
+    for (int i = 0; i < 4; ++i) m[1 + i] = c[i];
+    const bool has_l = x0 >= 1, has_r = x0 + 4 < R.w;           // the samples left/right of the segment, inside the rectangle
+    m[0] = has_l ? rp[-1] : 0; m[5] = has_r ? rp[4] : 0;
+    if (rows_in) {
+      if (nx == 4) { int t[4]; load4(rp - rstride, t); u[1] = t[0]; u[2] = t[1]; u[3] = t[2]; u[4] = t[3];
+                     load4(rp + rstride, t); d[1] = t[0]; d[2] = t[1]; d[3] = t[2]; d[4] = t[3]; }
+      else {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-          const bool hit = cats[cl] == k;
-          acc[cl][0][k] += hit ? diff : 0;
-          acc[cl][1][k] += hit ? 1 : 0;
+        for (int i = 0; i < 4; ++i) { u[1 + i] = i < nx ? rp[i - rstride] : 0; d[1 + i] = i < nx ? rp[i + rstride] : 0; }
+      }
+      u[0] = has_l ? rp[-rstride - 1] : 0; u[5] = has_r ? rp[-rstride + 4] : 0;
+      d[0] = has_l ? rp[rstride - 1] : 0;  d[5] = has_r ? rp[rstride + 4] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < nx) {
+        const int x = x0 + i;
+        const uint32_t add = (1u << 16) + (uint32_t)(o[i] - c[i] + BIAS);
+        atomicAdd(&sT[20 + (c[i] >> bshift)][tid], add);
+        if (rows_in && x >= 1 && x < R.w - 1) {
+          const int cc = c[i];
+          atomicAdd(&sT[0 + eo_cat(m[i], m[i + 2], cc)][tid], add);         // class 0: left / right
+          atomicAdd(&sT[5 + eo_cat(u[i + 1], d[i + 1], cc)][tid], add);     // class 1: up / down
+          atomicAdd(&sT[10 + eo_cat(u[i], d[i + 2], cc)][tid], add);        // class 2: up-left / down-right
+          atomicAdd(&sT[15 + eo_cat(u[i + 2], d[i], cc)][tid], add);        // class 3: up-right / down-left
         }
+      }
     }
   }
-#pragma unroll
-  for (int cl = 0; cl < 4; ++cl)
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        const int v = group_sum(acc[cl][s][k], 64);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&sEdge[cl * 10 + s * 5 + k], v);
-      }
   __syncthreads();
-  for (int i = threadIdx.x; i < 40; i += blockDim.x) edge_out[(size_t)blockIdx.x * 40 + i] = sEdge[i];
-  for (int i = threadIdx.x; i < 64; i += blockDim.x)
-    band_out[(size_t)blockIdx.x * 64 + i] = sBand[0][i] + sBand[1][i] + sBand[2][i] + sBand[3][i];
+  // column sums: 52 entries x 256 threads; thread t reduces entry t / 4 over a quarter of the columns
+  if (tid < 208) {
+    const int e = tid >> 2, q = tid & 3;
+    int sum = 0, cnt = 0;
+    for (int k = 0; k < 64; ++k) {
+      const uint32_t v = sT[e][q * 64 + ((k + tid) & 63)];     // staggered start: the wave's lanes hit different banks
+      sum += (int)(v & 0xffffu); cnt += (int)(v >> 16);
+    }
+    tot_sum += sum - cnt * BIAS; tot_cnt += cnt;
+  }
+  __syncthreads();
+  }   // chunks
+  {
+    const int e = tid >> 2, q = tid & 3;
+    int s = tot_sum, cnt = tot_cnt;                              // the four quarter partials meet through the wave
+    s += __shfl_xor(s, 1, 64); cnt += __shfl_xor(cnt, 1, 64);
+    s += __shfl_xor(s, 2, 64); cnt += __shfl_xor(cnt, 2, 64);
+    if (q == 0 && e < 52) {
+      if (e < 20) {
+        const int cl = e / 5, k = e - cl * 5;
+        edge_out[(size_t)blockIdx.x * 40 + cl * 10 + k] = s;
+        edge_out[(size_t)blockIdx.x * 40 + cl * 10 + 5 + k] = cnt;
+      } else {
+        band_out[(size_t)blockIdx.x * 64 + (e - 20)] = s;
+        band_out[(size_t)blockIdx.x * 64 + 32 + (e - 20)] = cnt;
+      }
+    }
+  }
 }
 
 extern "C" int uvghip_sao_stats_batch(int bitdepth, const void *orig, int orig_stride, const void *rec, int rec_stride,
@@ -98,14 +138,21 @@ extern "C" int uvghip_sao_stats_batch(int bitdepth, const void *orig, int orig_s
 // Apply one parameter set per rectangle.  Edge classes skip the picture's outermost
 // rows/columns (sao.c:321-348); band offsets are applied through the value test of
 // uvg_calc_sao_offset_array (sao.c:180-201) instead of a 2^depth LUT.
+// One thread per 4-sample segment: the segment and its two neighbour segments (class-dependent) are three
+// unaligned 4-sample loads; offsets come from a 5-entry LDS table.
 template <typename PX>
 __global__ void __launch_bounds__(256)
 sao_apply_kernel(const PX *__restrict__ rec, int rstride, PX *__restrict__ out, int ostride, int pic_w, int pic_h,
                  const uvghip_rect_t *__restrict__ rects, const uvghip_sao_param_t *__restrict__ params)
 {
+  __shared__ int sOff[8];
   const uvghip_rect_t R = rects[blockIdx.x];
   const uvghip_sao_param_t P = params[blockIdx.x];
   if (P.type == 0) return;
+  // straight from global memory: indexing the register copy P dynamically would make the compiler promote P to an
+  // LDS alloca whose addressing reads the AQL dispatch packet (host memory) -- measured +13 us per launch
+  if (threadIdx.x < 5) sOff[threadIdx.x] = params[blockIdx.x].offsets[threadIdx.x];
+  __syncthreads();
   constexpr int maxv = px_traits<PX>::maxv;
   constexpr int bshift = px_traits<PX>::depth - 5;
   int x0 = R.x, y0 = R.y, w = R.w, h = R.h;
@@ -117,19 +164,41 @@ sao_apply_kernel(const PX *__restrict__ rec, int rstride, PX *__restrict__ out, 
     if (y0 + h + ay > pic_h || y0 + h + by > pic_h) h -= 1;
     if (y0 + ay < 0 || y0 + by < 0) { y0 += 1; h -= 1; }
   }
-  for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
-    const int y = i / w, x = i - y * w;
+  if (w <= 0 || h <= 0) return;
+  const int segs_per_row = (w + 3) >> 2, nseg = segs_per_row * h;
+  const ptrdiff_t oa = (ptrdiff_t)ay * rstride + ax, ob = (ptrdiff_t)by * rstride + bx;
+  for (int sg = threadIdx.x; sg < nseg; sg += 256) {
+    const int y = sg / segs_per_row, x = (sg - y * segs_per_row) * 4;
     const PX *rp = rec + (size_t)(y0 + y) * rstride + x0 + x;
-    const int c = rp[0];
-    int v;
-    if (P.type == 1) {
-      const int band = (c >> bshift) - P.band_position;
-      v = (band >= 0 && band <= 3) ? clampi(c + P.offsets[band + 1], 0, maxv) : c;
+    PX *q = out + (size_t)(y0 + y) * ostride + x0 + x;
+    const int nx = min(4, w - x);
+    int c[4], a[4], b[4], v[4];
+    if (nx == 4) {
+      load4(rp, c);
+      if (P.type == 2) { load4(rp + oa, a); load4(rp + ob, b); }
     } else {
-      const int cat = eo_cat(rp[ay * rstride + ax], rp[by * rstride + bx], c);
-      v = clampi(c + P.offsets[cat], 0, maxv);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool in = i < nx;
+        c[i] = in ? rp[i] : 0;
+        a[i] = in && P.type == 2 ? rp[oa + i] : 0;
+        b[i] = in && P.type == 2 ? rp[ob + i] : 0;
+      }
     }
-    out[(size_t)(y0 + y) * ostride + x0 + x] = (PX)v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (P.type == 1) {
+        const int band = (c[i] >> bshift) - P.band_position;
+        v[i] = (band >= 0 && band <= 3) ? clampi(c[i] + sOff[band + 1], 0, maxv) : c[i];
+      } else v[i] = clampi(c[i] + sOff[eo_cat(a[i], b[i], c[i])], 0, maxv);
+    }
+    if (nx == 4) {
+      if constexpr (sizeof(PX) == 1) *reinterpret_cast<u32_unaligned *>(q) = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+      else { *reinterpret_cast<u32_unaligned *>(q) = (uint32_t)v[0] | ((uint32_t)v[1] << 16); *reinterpret_cast<u32_unaligned *>(q + 2) = (uint32_t)v[2] | ((uint32_t)v[3] << 16); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (i < nx) q[i] = (PX)v[i];
+    }
   }
 }
 
