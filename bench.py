@@ -47,49 +47,97 @@ WORKLOAD = ("1920x1080 8-bit yuv420p, all-intra medium hot path per frame: luma,
 
 
 class Frame:
-    """Device-resident planes + descriptor tables of one picture."""
+    """Device-resident planes, descriptor tables and every output buffer of one picture (nothing is allocated
+    inside the step), plus the prebuilt launch plan: (name, stream slot, C entry point, argument tuple)."""
 
-    def __init__(self, t, device):
+    def __init__(self, t, device, L, modes_dev):
         y, u, v = layout.synthetic_yuv420(W, H, t, DEPTH)
-        self.y = torch.from_numpy(y).to(device)
-        self.pred = torch.zeros_like(self.y)
-        self.rec = torch.zeros_like(self.y)
-        self.tables = {}
-        for n in SIZES:
-            blks = layout.intra_availability(layout.block_grid(W, H, n), n, W, H)
-            self.tables[n] = (api.make_intra_blocks(blks, device), api.make_tus(blks[:, :2], device), len(blks))
+        dev = lambda a: torch.from_numpy(a).to(device)
         self.host_y = y
-        self.u = torch.from_numpy(u).to(device)
-        self.v = torch.from_numpy(v).to(device)
-        self.u_rec = torch.zeros_like(self.u)
-        self.v_rec = torch.zeros_like(self.v)
+        self.y, self.u, self.v = dev(y), dev(u), dev(v)
+        self.u_rec, self.v_rec = torch.zeros_like(self.u), torch.zeros_like(self.v)
         self.sao_out = torch.zeros_like(self.y)
         self.scu = api.make_scu_table(layout.quadtree_scu_table(W, H, seed=t, qp=QP), device)
         rects = layout.ctu_rects(W, H)
         self.rects = api.make_rects(rects, device)
         self.n_ctu = len(rects)
+        self.edge = torch.zeros((self.n_ctu, 4, 2, 5), dtype=torch.int32, device=device)
+        self.band = torch.zeros((self.n_ctu, 2, 32), dtype=torch.int32, device=device)
+        self.params = torch.zeros((self.n_ctu, 8), dtype=torch.int32, device=device)
+        self.tables, self.bufs = {}, {}
+        P = lambda t_: t_.data_ptr()
+        ys = self.y.stride(0)
+        nm = modes_dev.shape[0]
+        self.chains = []          # one list of launches per block size (independent: own pred/rec planes)
+        for n in SIZES:
+            blks_np = layout.intra_availability(layout.block_grid(W, H, n), n, W, H)
+            blks, tus, cnt = api.make_intra_blocks(blks_np, device), api.make_tus(blks_np[:, :2], device), len(blks_np)
+            self.tables[n] = (blks, tus, cnt)
+            b = {"best": torch.zeros(cnt, dtype=torch.int8, device=device), "cost": torch.zeros(cnt, dtype=torch.int32, device=device),
+                 "pred": torch.zeros_like(self.y), "rec": torch.zeros_like(self.y),
+                 "coeff": torch.zeros((cnt, n, n), dtype=torch.int16, device=device), "has": torch.zeros(cnt, dtype=torch.uint8, device=device)}
+            self.bufs[n] = b
+            self.chains.append([
+                (f"intra_search_{n}", L.uvghip_intra_search_best_batch,
+                 [DEPTH, P(self.y), ys, P(self.y), ys, n, P(blks), cnt, P(modes_dev), nm, P(b["best"]), P(b["cost"]), None]),
+                (f"intra_pred_plane_{n}", L.uvghip_intra_pred_plane_batch,
+                 [DEPTH, P(self.y), ys, n, P(blks), cnt, P(b["best"]), P(b["pred"]), ys]),
+                (f"tu_roundtrip_{n}", L.uvghip_tu_roundtrip_batch,
+                 [DEPTH, 0, 0, 0, 0, n, n, QP, 1, P(self.y), ys, P(b["pred"]), ys, P(b["rec"]), ys, P(tus), cnt, P(b["coeff"]), P(b["has"])]),
+            ])
+        rec = self.bufs[SIZES[-1]]["rec"]       # in-loop filters run on the reconstruction of the last (4x4) pass
+        cs = self.u_rec.stride(0)
+        self.tail = [
+            ("deblock_0", L.uvghip_deblock_frame,
+             [DEPTH, P(rec), ys, P(self.u_rec), P(self.v_rec), cs, W, H, P(self.scu), self.scu.shape[1] // 32, 0, 0, 0, QP, None]),
+            ("sao_stats_0", L.uvghip_sao_stats_batch, [DEPTH, P(self.y), ys, P(rec), ys, P(self.rects), self.n_ctu, P(self.edge), P(self.band)]),
+            ("sao_offsets_0", L.uvghip_sao_edge_offsets_batch, [P(self.edge), None, self.n_ctu, P(self.params), None]),
+            ("sao_apply_0", L.uvghip_sao_apply_batch,
+             [DEPTH, P(rec), ys, P(self.sao_out), ys, W, H, P(self.rects), P(self.params), self.n_ctu]),
+        ]
+        self.ev_chain = [torch.cuda.Event() for _ in SIZES]
+        self.ev_done = torch.cuda.Event()
+        self.ev_done.record()
 
 
 class KernelClock:
-    """Per-kernel HIP-event timing on the launch stream (torch's current stream).  `only` restricts the
-    instrumentation to kernels whose family name is in the set (None = all)."""
+    """Per-kernel HIP-event timing on the stream the kernel is launched on.  `only` restricts the
+    instrumentation to kernels whose family name is in the set (None = all).  Event objects are recycled: spans
+    are harvested (elapsed_time read, events returned to the pool) once their frame is known to have retired --
+    a few hundred live timing events make every later HIP call slow on this runtime."""
 
     def __init__(self):
-        self.spans = {}
+        self.ms = {}          # name -> [total ms, launches]
+        self.pending = {}     # slot -> [(name, e0, e1)]
+        self.pool = []
         self.only = None
 
-    def run(self, name, fn, enabled):
-        if not enabled or (self.only is not None and name.rsplit("_", 1)[0] not in self.only):
-            return fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = fn()
-        e1.record()
-        self.spans.setdefault(name, []).append((e0, e1))
-        return out
+    def _event(self):
+        return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
+
+    def launch(self, name, fn, args, stream, enabled, slot=0):
+        timed = enabled and (self.only is None or name.rsplit("_", 1)[0] in self.only)
+        if timed:
+            e0, e1 = self._event(), self._event()
+            e0.record(stream)
+        rc = fn(*args, stream.cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"{name} failed ({rc}): {lib.load_library().uvghip_last_error().decode()}")
+        if timed:
+            e1.record(stream)
+            self.pending.setdefault(slot, []).append((name, e0, e1))
+
+    def harvest(self, slot=None):
+        """Fold the finished spans of `slot` (all slots if None; the caller guarantees they have completed)."""
+        for k in ([slot] if slot is not None else list(self.pending)):
+            for name, e0, e1 in self.pending.pop(k, []):
+                t = self.ms.setdefault(name, [0.0, 0])
+                t[0] += e0.elapsed_time(e1); t[1] += 1
+                self.pool += [e0, e1]
 
     def totals(self):
-        return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in self.spans.items()}
+        self.harvest()
+        return {k: (v[0], v[1]) for k, v in self.ms.items()}
 
 
 def algorithmic_bytes(kernel, n, count):
@@ -114,19 +162,30 @@ def algorithmic_bytes(kernel, n, count):
     raise KeyError(kernel)
 
 
-def hot_path_step(fr, modes_dev, clock, timed):
-    for n in SIZES:
-        blks, tus, cnt = fr.tables[n]
-        best, _ = clock.run(f"intra_search_{n}", lambda: api.intra_search_best_batch(fr.y, fr.y, blks, n, modes_dev), timed)
-        clock.run(f"intra_pred_plane_{n}", lambda: api.intra_pred_plane_batch(fr.y, blks, n, best, fr.pred), timed)
-        clock.run(f"tu_roundtrip_{n}", lambda: api.tu_roundtrip_batch(fr.y, fr.pred, fr.rec, tus, n, n, QP), timed)
-    # in-loop filters on the reconstruction left by the last (4x4) pass
-    fr.u_rec.copy_(fr.u)
+def hot_path_step(fr, clock, timed, main, side):
+    """One frame.  The four block sizes are independent chains (search -> predict -> TU round trip, own planes); with
+    `side` streams they run concurrently and overlap with the previous frame's in-loop filters on `main`;
+    side=None runs everything in order on `main` (profile pass)."""
+    # at most n_resident frames in flight: the host waits for this frame's previous use (queueing thousands of
+    # launches ahead of the GPU makes the HIP runtime itself slow)
+    fr.ev_done.synchronize()
+    clock.harvest(id(fr))
+    for k, chain in enumerate(fr.chains):
+        st = side[k] if side else main
+        if side:
+            st.wait_event(fr.ev_done)            # this frame's buffers: their previous use (4 steps ago) has retired
+        for name, fn, args in chain:
+            clock.launch(name, fn, args, st, timed, id(fr))
+        if side:
+            fr.ev_chain[k].record(st)
+    if side:
+        for ev in fr.ev_chain:
+            main.wait_event(ev)
+    fr.u_rec.copy_(fr.u)                         # torch copies run on the current (= main) stream
     fr.v_rec.copy_(fr.v)
-    clock.run("deblock_0", lambda: api.deblock_frame(fr.rec, fr.u_rec, fr.v_rec, fr.scu, W, H, 0, 0, False, QP, None), timed)
-    edge, band = clock.run("sao_stats_0", lambda: api.sao_stats_batch(fr.y, fr.rec, fr.rects), timed)
-    params = clock.run("sao_offsets_0", lambda: api.sao_edge_offsets_batch(edge), timed)
-    clock.run("sao_apply_0", lambda: api.sao_apply_batch(fr.rec, fr.sao_out, fr.rects, params), timed)
+    for name, fn, args in fr.tail:
+        clock.launch(name, fn, args, main, timed, id(fr))
+    fr.ev_done.record(main)
 
 
 def cpu_baseline(fr_host_y):
@@ -180,6 +239,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="one stream: no overlap between block sizes / frames")
     ap.add_argument("--profile-steps", type=int, default=4, help="untimed, fully instrumented steps for the per-kernel table")
     args = ap.parse_args()
 
@@ -199,18 +259,21 @@ def main():
 
     # every rank owns its own frames (frame t = rank + k*world): independent units, no exchange
     n_resident = 4
-    frames = [Frame(rank + k * world, device) for k in range(n_resident)]
     modes_dev = api.make_modes(MODES, device)
+    L = lib.load_library()
+    frames = [Frame(rank + k * world, device, L, modes_dev) for k in range(n_resident)]
     clock = KernelClock()
+    main_stream = torch.cuda.current_stream()
+    side = None if args.serial else [torch.cuda.Stream(device=device) for _ in SIZES]
 
     for s in range(args.warmup):
-        hot_path_step(frames[s % n_resident], modes_dev, clock, False)
+        hot_path_step(frames[s % n_resident], clock, False, main_stream, side)
     torch.cuda.synchronize()
 
     # untimed profile pass: every kernel bracketed by HIP events -> per-kernel breakdown and the dominant family
     prof = KernelClock()
     for s in range(args.profile_steps):
-        hot_path_step(frames[s % n_resident], modes_dev, prof, True)
+        hot_path_step(frames[s % n_resident], prof, True, main_stream, None)
     torch.cuda.synchronize()
     prof_tot = prof.totals()
     fam_ms = {}
@@ -225,7 +288,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        hot_path_step(frames[s % n_resident], modes_dev, clock, True)
+        hot_path_step(frames[s % n_resident], clock, True, main_stream, side)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -261,12 +324,16 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": WORKLOAD, "mpixels_per_s": round(fps * W * H / 1e6, 1), "qp": QP,
-                       "parallelism": f"frames sharded over {world} rank(s), no data-path collective"},
+                       "parallelism": f"frames sharded over {world} rank(s), no data-path collective",
+                       "streams": 1 if args.serial else 1 + len(SIZES)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": live[dom]["gbs"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(live[dom]["gbs"] / HBM_PEAK_GBS, 5), "traffic": TRAFFIC.get(dom),
                          "avg_launch_ms": live[dom]["avg_ms"], "alg_bytes_per_launch": live[dom]["alg_bytes"],
                          "launches_timed": live[dom]["launches"],
-                         "note": "HIP events around every launch of the dominant kernel family inside the timed region; "
+                         "serial_avg_launch_ms": per_kernel[dom]["avg_ms"],
+                         "note": "HIP events (on the launch stream) around every launch of the dominant kernel family inside the "
+                                 "timed region, where the four block sizes run on concurrent streams, so a launch shares the GPU; "
+                                 "serial_avg_launch_ms = the same launch alone (profile pass); "
                                  "traffic = PMC bytes per launch from profiles/ (null if not collected)"},
             "kernel_sum_ms": round(tot_ms, 4),
             "kernels_timed_region": per_kernel_live,

@@ -21,6 +21,8 @@
 // LDS.  Horizontal modes are evaluated in the reference's transposed "work"
 // domain against the transposed original: SAD and the Hadamard magnitude
 // multiset are transpose-invariant, so costs are identical.
+#include <cstdio>
+#include <cstdlib>
 #include "uvghip_common.h"
 #include "percall.h"
 #include "ref_abi.h"
@@ -676,6 +678,9 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
       ang_load<T>(S, rowp, sCoef, xd0, yd0 + r + 1, B);
       side_load(r + 1, lB);
     }
+    // keep the next row's LDS reads above this row's arithmetic (the scheduler otherwise sinks them to their uses and
+    // every row pays the full LDS latency)
+    __builtin_amdgcn_sched_barrier(0);
     int out[T];
     ang_filter_x4<T>(A, out);
     if constexpr (PDPC == 0) {
@@ -999,6 +1004,8 @@ static int launch_intra_search(int bitdepth, const void *rec, int rec_stride, co
 #define LAUNCH(PX, T, W) do { const search_layout L = make_search_layout(size, bpg, n_modes, W, (int)sizeof(PX)); \
     static bool big_lds = false; /* allow more than the default 64 KiB of dynamic LDS, once per instantiation */ \
     if (!big_lds) { UVGHIP_TRY(hipFuncSetAttribute((const void *)intra_search_kernel<PX, T, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); big_lds = true; } \
+    if (getenv("UVGHIP_DEBUG_OCC")) { int nb = -1; hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, intra_search_kernel<PX, T, W>, W * 64, L.total); \
+      fprintf(stderr, "intra_search<%d,%d,%d> size %d: lds %zu grid %d occupancy %d blocks/CU (err %d)\n", (int)sizeof(PX), T, W, size, (size_t)L.total, grid, nb, (int)oe); } \
     intra_search_kernel<PX, T, W><<<grid, W * 64, L.total, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, blks, n, modes, n_modes, costs, best_mode, best_cost); } while (0)
   if (bitdepth == 8) { if (size == 4) LAUNCH(uint8_t, 4, 4); else LAUNCH(uint8_t, 8, UVGHIP_SEARCH_WAVES); }
   else { if (size == 4) LAUNCH(uint16_t, 4, 4); else LAUNCH(uint16_t, 8, UVGHIP_SEARCH_WAVES); }
