@@ -511,6 +511,7 @@ struct search_mode {
   int scale;       // PDPC scale
   int coef;        // offset of the 32-entry tap table in sCoef (0 cubic, 32 smoothing)
   int transposed;  // work domain is the transposed block
+  int noclamp;     // the 4-tap result cannot leave the sample range (smoothing taps are a convex combination; so is an integer phase)
 };
 
 __device__ inline search_mode make_search_mode(int mode, int n)
@@ -527,6 +528,7 @@ __device__ inline search_mode make_search_mode(int mode, int n)
   S.scale = (mode < 2 || M.sample_disp == 0) ? (2 * lgn - 2) >> 2 : M.scale;
   S.coef = M.use_cubic ? 0 : 32;
   S.transposed = mode >= 2 && !M.vertical;
+  S.noclamp = mode >= 2 && (!M.use_cubic || !M.frac);
   return S;
 }
 
@@ -637,7 +639,7 @@ __device__ __forceinline__ uint32_t pack_shr8(int lo, int hi) { return __builtin
 
 // PDPC: 0 none, 2 projected side sample (intra-generic.c:262-277), 3 gradient of the pure
 // horizontal/vertical modes (:279-293)
-template <int T, int PDPC>
+template <int T, int PDPC, bool CLAMP>
 __device__ __forceinline__ void search_tile_angular(const search_mode &S, const uint32_t *mainr, const uint32_t *side,
                                                     const uint32_t *rowp, const uint2 *sCoef, int n, int xd0, int yd0,
                                                     const uint32_t (&o)[T][T / 2], int maxv, uint32_t (&d)[T][T / 2], uint32_t &sad)
@@ -678,9 +680,6 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
       ang_load<T>(S, rowp, sCoef, xd0, yd0 + r + 1, B);
       side_load(r + 1, lB);
     }
-    // keep the next row's LDS reads above this row's arithmetic (the scheduler otherwise sinks them to their uses and
-    // every row pays the full LDS latency)
-    __builtin_amdgcn_sched_barrier(0);
     int out[T];
     ang_filter_x4<T>(A, out);
     if constexpr (PDPC == 0) {
@@ -688,7 +687,7 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
 #pragma unroll
       for (int c = 0; c < T / 2; ++c) {
         pk_s16 v = __builtin_bit_cast(pk_s16, pack_shr8(out[2 * c], out[2 * c + 1]));
-        v = __builtin_elementwise_min(__builtin_elementwise_max(v, (pk_s16){0, 0}), vmax);
+        if constexpr (CLAMP) v = __builtin_elementwise_min(__builtin_elementwise_max(v, (pk_s16){0, 0}), vmax);
         pp[c] = __builtin_bit_cast(uint32_t, v);
       }
       finish_row<T>(pp, o[r], d[r], sad);
@@ -696,13 +695,13 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
       if constexpr (PDPC == 2) {
 #pragma unroll
         for (int i = 0; i < T; ++i) {
-          const int c = clampi(out[i] >> 8, 0, maxv);
+          const int c = CLAMP ? clampi(out[i] >> 8, 0, maxv) : out[i] >> 8;
           out[i] = c + ((__mul24(wl[i], lA[i] - c) + 32) >> 6);
         }
       } else {
         const int g = lA[0] - tl;
 #pragma unroll
-        for (int i = 0; i < T; ++i) out[i] = clampi(clampi(out[i] >> 8, 0, maxv) + ((__mul24(wl[i], g) + 32) >> 6), 0, maxv);
+        for (int i = 0; i < T; ++i) out[i] = clampi((CLAMP ? clampi(out[i] >> 8, 0, maxv) : out[i] >> 8) + ((__mul24(wl[i], g) + 32) >> 6), 0, maxv);
       }
       finish_row_i32<T>(out, o[r], d[r], sad);
     }
@@ -948,9 +947,13 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       uint32_t sad = 0;
       if (S.kind == 2) {
         const uint32_t *rowp = neg ? priv + n : mainr;
-        if (S.pdpc == 0) search_tile_angular<T, 0>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);
-        else if (S.pdpc == 2) search_tile_angular<T, 2>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);
-        else search_tile_angular<T, 3>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);
+        if (S.pdpc == 0) {
+          if (S.noclamp) search_tile_angular<T, 0, false>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);
+          else search_tile_angular<T, 0, true>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);
+        } else if (S.pdpc == 2) {
+          if (S.noclamp) search_tile_angular<T, 2, false>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);
+          else search_tile_angular<T, 2, true>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);
+        } else search_tile_angular<T, 3, false>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);   // pure H/V: integer phase
       } else if (S.kind == 0) search_tile_nonangular<T, true>(S, mainr, side, dc, n, lgn, xd0, yd0, o, d, sad);
       else search_tile_nonangular<T, false>(S, mainr, side, dc, n, lgn, xd0, yd0, o, d, sad);
       uint32_t satd;
