@@ -53,7 +53,7 @@ class Frame:
     def __init__(self, t, device, L, modes_dev):
         y, u, v = layout.synthetic_yuv420(W, H, t, DEPTH)
         dev = lambda a: torch.from_numpy(a).to(device)
-        self.host_y = y
+        self.host_y, self.host_u, self.host_v = y, u, v
         self.y, self.u, self.v = dev(y), dev(u), dev(v)
         self.u_rec, self.v_rec = torch.zeros_like(self.u), torch.zeros_like(self.v)
         self.sao_out = torch.zeros_like(self.y)
@@ -188,7 +188,7 @@ def hot_path_step(fr, clock, timed, main, side):
     fr.ev_done.record(main)
 
 
-def cpu_baseline(fr_host_y):
+def cpu_baseline(fr_host_y, fr_host_u, fr_host_v):
     """The oracle (C restatement, OpenMP over blocks) on the host cores, on a bounded sample:
     slabs of the top 256 luma rows of one frame (4 CTU rows = 23.7 % of a frame), repeated until
     about 10 s of wall time have passed; same kernels as the GPU step."""
@@ -200,6 +200,10 @@ def cpu_baseline(fr_host_y):
     y = np.ascontiguousarray(fr_host_y[:rows])
     modes = np.asarray(MODES, np.int8)
     tables = {n: layout.intra_availability(layout.block_grid(W, rows, n), n, W, rows) for n in SIZES}
+    u0, v0 = np.ascontiguousarray(fr_host_u[:rows // 2]), np.ascontiguousarray(fr_host_v[:rows // 2])
+    scu = layout.quadtree_scu_table(W, rows, seed=0, qp=QP)
+    scu_bytes = np.ascontiguousarray(scu.view(np.uint8).reshape(scu.shape[0], -1))
+    rects = np.ascontiguousarray(np.asarray(layout.ctu_rects(W, rows), np.int32).reshape(-1, 4))
 
     def one_slab():
         for n in SIZES:
@@ -216,6 +220,16 @@ def cpu_baseline(fr_host_y):
             tus = np.ascontiguousarray(blks[:, :2])
             orc.fn(DEPTH, "tu_roundtrip_frame", None)(DEPTH, n, n, QP, 1, Hh.ptr(y), Hh.ptr(pred), Hh.ptr(rec), W,
                                                       Hh.ptr(tus), len(tus), Hh.ptr(coeff))
+        # in-loop filters on the 4x4 pass's reconstruction (deblocking in the oracle is single-threaded)
+        ur, vr = u0.copy(), v0.copy()
+        orc.deblock_frame(DEPTH, rec, ur, vr, W, rows, scu_bytes, scu.shape[1], 0, 0, False, QP, None)
+        edge, band = orc.sao_stats_rects(DEPTH, y, rec, rects)
+        params, dd = np.zeros((len(rects), 8), np.int32), np.zeros(len(rects), np.int32)
+        orc.lib.orc_sao_edge_offsets(Hh.ptr(edge), None, len(rects), Hh.ptr(params), Hh.ptr(dd))
+        out = rec.copy()
+        for (fx, fy, w_, h_), p_ in zip(rects, params):
+            orc.sao_reconstruct_rect(DEPTH, rec, out, W, rows, int(fx), int(fy), int(w_), int(h_), int(p_[0]), int(p_[1]),
+                                     [0, 0], list(p_[3:]) + [0] * 5, False)
 
     slabs = 0
     t0 = time.perf_counter()
@@ -229,15 +243,16 @@ def cpu_baseline(fr_host_y):
     except AttributeError:
         cores = os.cpu_count()
     return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{slabs} x the top {rows} of {H} luma rows of a 1080p frame ({frames:.3f} frame), same kernels, "
-                      f"oracle C -O2 + OpenMP on {cores} threads ({dt:.1f} s)"}
+            "sample": f"{slabs} x the top {rows} of {H} luma rows of a 1080p frame ({frames:.3f} frame), the same kernel sequence "
+                      f"(search/predict/TU round trip for four block sizes, deblock, SAO statistics/offsets/apply), "
+                      f"oracle C -O2, OpenMP over blocks on {cores} threads except deblocking (serial) ({dt:.1f} s)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one stream: no overlap between block sizes / frames")
     ap.add_argument("--profile-steps", type=int, default=4, help="untimed, fully instrumented steps for the per-kernel table")
@@ -340,7 +355,7 @@ def main():
             "kernels": per_kernel,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames[0].host_y)
+            out["cpu_baseline"] = cpu_baseline(frames[0].host_y, frames[0].host_u, frames[0].host_v)
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()

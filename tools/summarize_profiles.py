@@ -4,15 +4,19 @@ statistics table as is, and per-kernel HBM bytes per launch from the FETCH_SIZE 
 FETCH_SIZE is doubled (MI355X_MICROARCH.md: on gfx950 it counts 64-byte units of 128-byte requests);
 both counters are in KiB-like units of 1024 B?  -- no: rocprofv3 reports FETCH_SIZE/WRITE_SIZE in
 kilobytes (derived metric), so bytes = value * 1024 (* 2 for FETCH_SIZE on gfx950)."""
-import collections, csv, glob, json, shutil, sys
+import collections, csv, glob, json, os, shutil, sys
+
+def newest(pattern):
+    return max(glob.glob(pattern, recursive=True), key=os.path.getmtime)
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-stats = glob.glob("gpurun_out/prof_stats/**/*kernel_stats.csv", recursive=True)[0]
+stats = newest("gpurun_out/prof_stats/**/*kernel_stats.csv")
 shutil.copy(stats, f"profiles/{tag}_bench_kernel_stats.csv")
+shutil.copy(newest("gpurun_out/prof_stats_serial/**/*kernel_stats.csv"), f"profiles/{tag}_bench_kernel_stats_serial.csv")
 shutil.copy("gpurun_out/prof_bench_line.json", f"profiles/{tag}_bench_line_profiled.json")
 
 def per_kernel(dirname, counter):
-    f = glob.glob(f"gpurun_out/{dirname}/**/*counter_collection.csv", recursive=True)[0]
+    f = newest(f"gpurun_out/{dirname}/**/*counter_collection.csv")
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:

@@ -545,31 +545,17 @@ __device__ inline search_mode make_search_mode(int mode, int n)
 // no shuffling.  Single samples are the low halves.
 __device__ __forceinline__ int pr_sample(const uint32_t *row, int i) { return reinterpret_cast<const uint16_t *>(row)[2 * i]; }
 
-// the lane's original tile, packed pairs, kept in registers across all modes of one domain
-template <typename PX, int T>
-__device__ __forceinline__ void load_orig_tile(const PX *otile, int n, uint32_t (&o)[T][T / 2])
+// one row of the lane's original tile: packed 16-bit pairs straight from LDS (the block and its transpose are
+// staged as uint16 for both bit depths, so the row is one aligned b128 / b64 read issued with the row's taps)
+template <int T>
+__device__ __forceinline__ void load_orig_row(const uint16_t *otile, int n, int r, uint32_t (&o)[T / 2])
 {
-#pragma unroll
-  for (int r = 0; r < T; ++r) {
-    if constexpr (sizeof(PX) == 2) {
-      if constexpr (T == 8) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(otile + r * n);
-        o[r][0] = v.x; o[r][1] = v.y; o[r][2] = v.z; o[r][3] = v.w;
-      } else {
-        const uint2 v = *reinterpret_cast<const uint2 *>(otile + r * n);
-        o[r][0] = v.x; o[r][1] = v.y;
-      }
-    } else {
-      // bytes (b0 b1 b2 b3) -> (b0, b1 as 16-bit halves), (b2, b3)
-      if constexpr (T == 8) {
-        const uint2 v = *reinterpret_cast<const uint2 *>(otile + r * n);
-        o[r][0] = __builtin_amdgcn_perm(0u, v.x, 0x0c010c00u); o[r][1] = __builtin_amdgcn_perm(0u, v.x, 0x0c030c02u);
-        o[r][2] = __builtin_amdgcn_perm(0u, v.y, 0x0c010c00u); o[r][3] = __builtin_amdgcn_perm(0u, v.y, 0x0c030c02u);
-      } else {
-        const uint32_t v = *reinterpret_cast<const uint32_t *>(otile + r * n);
-        o[r][0] = __builtin_amdgcn_perm(0u, v, 0x0c010c00u); o[r][1] = __builtin_amdgcn_perm(0u, v, 0x0c030c02u);
-      }
-    }
+  if constexpr (T == 8) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(otile + r * n);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  } else {
+    const uint2 v = *reinterpret_cast<const uint2 *>(otile + r * n);
+    o[0] = v.x; o[1] = v.y;
   }
 }
 __device__ __forceinline__ uint32_t pack_lo16(int lo, int hi) { return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u); }
@@ -605,11 +591,13 @@ __device__ __forceinline__ void pdpc_col_weights(int xd0, int scale, int lim, in
 
 // One row of 4-tap inputs: pairs P[k] = (p[k], p[k+1]), k = 0..T+1, and the two coefficient pairs
 // (f0,f1), (f2,f3) of the row's phase.
-template <int T> struct ang_row { uint32_t P[T + 2]; uint32_t f01, f23; };
+template <int T> struct ang_row { uint32_t P[T + 2]; uint32_t f01, f23; uint32_t o[T / 2]; };
 
 template <int T>
-__device__ __forceinline__ void ang_load(const search_mode &S, const uint32_t *rowp, const uint2 *sCoef, int xd0, int yd, ang_row<T> &R)
+__device__ __forceinline__ void ang_load(const search_mode &S, const uint32_t *rowp, const uint2 *sCoef, int xd0, int yd,
+                                         const uint16_t *otile, int n, int r, ang_row<T> &R)
 {
+  load_orig_row<T>(otile, n, r, R.o);
   const int delta = __mul24(S.sd, yd + 1), di = delta >> 5, df = delta & 31;
   const uint2 cf = sCoef[S.coef + df];
   R.f01 = cf.x; R.f23 = cf.y;
@@ -642,14 +630,18 @@ __device__ __forceinline__ uint32_t pack_shr8(int lo, int hi) { return __builtin
 template <int T, int PDPC, bool CLAMP>
 __device__ __forceinline__ void search_tile_angular(const search_mode &S, const uint32_t *mainr, const uint32_t *side,
                                                     const uint32_t *rowp, const uint2 *sCoef, int n, int xd0, int yd0,
-                                                    const uint32_t (&o)[T][T / 2], int maxv, uint32_t (&d)[T][T / 2], uint32_t &sad)
+                                                    const uint16_t *otile, int maxv, uint32_t (&d)[T][T / 2], uint32_t &sad)
 {
-  int wl[T];
+  uint32_t wlp[T / 4];       // PDPC column weights (<= 32), one byte each: they are only ever multiplied (SDWA byte operand)
   const uint16_t *sp[T];    // PDPC 2: address of the projected side sample of column i in row yd0 (dword stride per row)
   int tl = 0;
   if constexpr (PDPC != 0) {
     const int lim = min(3 << S.scale, n);
+    int wl[T];
     pdpc_col_weights<T>(xd0, S.scale, lim, wl);
+#pragma unroll
+    for (int q = 0; q < T / 4; ++q)
+      wlp[q] = (uint32_t)wl[4 * q] | ((uint32_t)wl[4 * q + 1] << 8) | ((uint32_t)wl[4 * q + 2] << 16) | ((uint32_t)wl[4 * q + 3] << 24);
     if constexpr (PDPC == 2) {
 #pragma unroll
       for (int i = 0; i < T; ++i) {
@@ -663,8 +655,9 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
       sp[0] = reinterpret_cast<const uint16_t *>(side + yd0 + 1);
     }
   }
+  auto wl_of = [&](int i) -> int { return (int)((wlp[i >> 2] >> (8 * (i & 3))) & 0xffu); };
   ang_row<T> A, B;
-  int lA[T], lB[T];
+  int lA[T];
   auto side_load = [&](int r, int (&l)[T]) {
     if constexpr (PDPC == 2) {
 #pragma unroll
@@ -672,14 +665,15 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
     } else if constexpr (PDPC == 3) l[0] = sp[0][2 * r];
   };
   const pk_s16 vmax = {(short)maxv, (short)maxv};
-  ang_load<T>(S, rowp, sCoef, xd0, yd0, A);
-  side_load(0, lA);
+  // PDPC 2 is the register-hungriest variant (eight side-sample pointers and values on top of the 32 difference
+  // registers): it loads each row when it needs it instead of one row ahead; with four waves per SIMD the wait is covered
+  constexpr bool PREFETCH = PDPC != 2;
+  if constexpr (PREFETCH) ang_load<T>(S, rowp, sCoef, xd0, yd0, otile, n, 0, A);
 #pragma unroll
   for (int r = 0; r < T; ++r) {
-    if (r + 1 < T) {
-      ang_load<T>(S, rowp, sCoef, xd0, yd0 + r + 1, B);
-      side_load(r + 1, lB);
-    }
+    if constexpr (PREFETCH) { if (r + 1 < T) ang_load<T>(S, rowp, sCoef, xd0, yd0 + r + 1, otile, n, r + 1, B); }
+    else ang_load<T>(S, rowp, sCoef, xd0, yd0 + r, otile, n, r, A);
+    side_load(r, lA);
     int out[T];
     ang_filter_x4<T>(A, out);
     if constexpr (PDPC == 0) {
@@ -690,24 +684,22 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
         if constexpr (CLAMP) v = __builtin_elementwise_min(__builtin_elementwise_max(v, (pk_s16){0, 0}), vmax);
         pp[c] = __builtin_bit_cast(uint32_t, v);
       }
-      finish_row<T>(pp, o[r], d[r], sad);
+      finish_row<T>(pp, A.o, d[r], sad);
     } else {
       if constexpr (PDPC == 2) {
 #pragma unroll
         for (int i = 0; i < T; ++i) {
           const int c = CLAMP ? clampi(out[i] >> 8, 0, maxv) : out[i] >> 8;
-          out[i] = c + ((__mul24(wl[i], lA[i] - c) + 32) >> 6);
+          out[i] = c + ((__mul24(wl_of(i), lA[i] - c) + 32) >> 6);
         }
       } else {
         const int g = lA[0] - tl;
 #pragma unroll
-        for (int i = 0; i < T; ++i) out[i] = clampi((CLAMP ? clampi(out[i] >> 8, 0, maxv) : out[i] >> 8) + ((__mul24(wl[i], g) + 32) >> 6), 0, maxv);
+        for (int i = 0; i < T; ++i) out[i] = clampi((CLAMP ? clampi(out[i] >> 8, 0, maxv) : out[i] >> 8) + ((__mul24(wl_of(i), g) + 32) >> 6), 0, maxv);
       }
-      finish_row_i32<T>(out, o[r], d[r], sad);
+      finish_row_i32<T>(out, A.o, d[r], sad);
     }
-    A = B;
-#pragma unroll
-    for (int i = 0; i < T; ++i) lA[i] = lB[i];
+    if constexpr (PREFETCH) A = B;
   }
 }
 
@@ -716,32 +708,43 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
 // linear in x and y, so they advance by one addition per sample.
 template <int T, bool PLANAR>
 __device__ __forceinline__ void search_tile_nonangular(const search_mode &S, const uint32_t *top, const uint32_t *left, int dc,
-                                                       int n, int lgn, int xd0, int yd0, const uint32_t (&o)[T][T / 2],
+                                                       int n, int lgn, int xd0, int yd0, const uint16_t *otile,
                                                        uint32_t (&d)[T][T / 2], uint32_t &sad)
 {
-  int t[T], wl[T], ver[T], dv[T];
+  int t[T], ver[T];
+  uint32_t wlp[T / 4];       // column weights as bytes (see search_tile_angular)
+  const uint32_t *topx = top + xd0;      // one base register; the columns are immediate offsets
 #pragma unroll
-  for (int i = 0; i < T; ++i) t[i] = pr_sample(top, xd0 + i + 1);
-  pdpc_col_weights<T>(xd0, S.scale, S.pdpc ? n : 0, wl);
-  int tr = 0;
+  for (int i = 0; i < T; ++i) t[i] = pr_sample(topx, i + 1);
+  {
+    int wl[T];
+    pdpc_col_weights<T>(xd0, S.scale, S.pdpc ? n : 0, wl);
+#pragma unroll
+    for (int q = 0; q < T / 4; ++q)
+      wlp[q] = (uint32_t)wl[4 * q] | ((uint32_t)wl[4 * q + 1] << 8) | ((uint32_t)wl[4 * q + 2] << 16) | ((uint32_t)wl[4 * q + 3] << 24);
+  }
+  auto wl_of = [&](int i) -> int { return (int)((wlp[i >> 2] >> (8 * (i & 3))) & 0xffu); };
+  int tr = 0, bl = 0;
   if constexpr (PLANAR) {
     tr = pr_sample(top, n + 1);
-    const int bl = pr_sample(left, n + 1);
+    bl = pr_sample(left, n + 1);
 #pragma unroll
-    for (int i = 0; i < T; ++i) { dv[i] = bl - t[i]; ver[i] = (t[i] << lgn) + __mul24(yd0, dv[i]); }   // + dv per row below
+    for (int i = 0; i < T; ++i) ver[i] = (t[i] << lgn) + __mul24(yd0, bl - t[i]);   // + (bl - t) per row below
   }
   int lA = pr_sample(left, yd0 + 1), lB = 0;
+  uint32_t oA[T / 2], oB[T / 2];
+  load_orig_row<T>(otile, n, 0, oA);
 #pragma unroll
   for (int r = 0; r < T; ++r) {
     const int yd = yd0 + r;
-    if (r + 1 < T) lB = pr_sample(left, yd + 2);
+    if (r + 1 < T) { lB = pr_sample(left, yd + 2); load_orig_row<T>(otile, n, r + 1, oB); }
     int out[T];
     if constexpr (PLANAR) {
       const int dh = tr - lA;
       int hor = (lA << lgn) + __mul24(xd0, dh) + n;
 #pragma unroll
       for (int i = 0; i < T; ++i) {
-        hor += dh; ver[i] += dv[i];
+        hor += dh; ver[i] += bl - t[i];
         out[i] = (hor + ver[i]) >> (lgn + 1);
       }
     } else {
@@ -752,17 +755,19 @@ __device__ __forceinline__ void search_tile_nonangular(const search_mode &S, con
 #pragma unroll
     for (int i = 0; i < T; ++i) {
       const int c = out[i];
-      out[i] = c + ((__mul24(wl[i], lA - c) + __mul24(wt, t[i] - c) + 32) >> 6);
+      out[i] = c + ((__mul24(wl_of(i), lA - c) + __mul24(wt, t[i] - c) + 32) >> 6);
     }
-    finish_row_i32<T>(out, o[r], d[r], sad);
+    finish_row_i32<T>(out, oA, d[r], sad);
     lA = lB;
+#pragma unroll
+    for (int c = 0; c < T / 2; ++c) oA[c] = oB[c];
   }
 }
 
 struct search_layout {
   int RS;        // samples per reference row (u16 scratch) = dwords per pair row
   int BRS;       // dwords per block: four pair rows, odd so that the wave's lanes spread over the banks
-  int OS;        // PX elements per block: original + transpose + pad
+  int OS;        // uint16 elements per block: original + transpose + pad
   int PS;        // dwords per private extended row (odd)
   int off_orig, off_ref, off_priv, off_dc, off_coef, off_mode;   // bytes
   size_t total;
@@ -775,7 +780,7 @@ __host__ __device__ inline search_layout make_search_layout(int n, int bpg, int 
   L.OS = 2 * n * n + 8;
   L.PS = 2 * n + 1;
   size_t o = 0;
-  L.off_orig = (int)o; o += (size_t)bpg * L.OS * pxsz; o = (o + 15) & ~(size_t)15;
+  L.off_orig = (int)o; o += (size_t)bpg * L.OS * 2; o = (o + 15) & ~(size_t)15;
   L.off_ref = (int)o;  o += (size_t)bpg * L.BRS * 4; o = (o + 15) & ~(size_t)15;
   // private strips; the same space holds the u16 staging image of the rows (4 * RS samples per block)
   size_t pv = (size_t)waves * bpg * L.PS * 4, scratch = (size_t)bpg * 4 * L.RS * 2;
@@ -792,7 +797,7 @@ __host__ __device__ inline search_layout make_search_layout(int n, int bpg, int 
 #define UVGHIP_SEARCH_WAVES 8
 #endif
 template <typename PX, int T, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : 1)
+__global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : (WAVES == 6 ? 3 : 1))
 intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__restrict__ orig, int orig_stride,
                     int n, const uvghip_intra_blk_t *__restrict__ blks, int n_blks,
                     const int8_t *__restrict__ modes, int n_modes, uint32_t *__restrict__ costs,
@@ -804,7 +809,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   const int lg_tiles = 2 * lg_tx, tiles = 1 << lg_tiles;
   const int bpg = 64 >> lg_tiles;
   const search_layout L = make_search_layout(n, bpg, n_modes, WAVES, (int)sizeof(PX));
-  PX *sOrig = reinterpret_cast<PX *>(smem_raw + L.off_orig);
+  uint16_t *sOrig = reinterpret_cast<uint16_t *>(smem_raw + L.off_orig);
   uint32_t *sRef = reinterpret_cast<uint32_t *>(smem_raw + L.off_ref);
   uint32_t *sPriv = reinterpret_cast<uint32_t *>(smem_raw + L.off_priv);
   uint16_t *sScratch = reinterpret_cast<uint16_t *>(smem_raw + L.off_priv);
@@ -821,15 +826,16 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   // ---- stage: tpb = WAVES * tiles threads per block; all global loads of a thread are in flight together ----
   {
     constexpr int NT = WAVES * 64;
+    // staging uses the largest power-of-two share of the workgroup (8 or 4 waves): tpb threads per block
     const int lg_tpb = lg_tiles + (WAVES == 8 ? 3 : 2), tpb = 1 << lg_tpb;
     const int myb = threadIdx.x >> lg_tpb, mytid = threadIdx.x & (tpb - 1);
-    const bool on = myb < here;
+    const bool on = myb < here;     // also false for the waves beyond the staging share (myb >= bpg)
     uint16_t *base = sScratch + (size_t)myb * 4 * L.RS;     // u16 image: top | left | ftop | fleft
     if (on) {
       const uvghip_intra_blk_t b = blks[blk0 + myb];
       build_ref_rows_batched<PX, 5>(rec, rec_stride, b.x, b.y, b.avail_top, b.avail_left, base, base + L.RS, L.RS, mytid, tpb);
       // original block in 4-sample segments: segment sg = (row, 4 columns)
-      PX *so = sOrig + (size_t)myb * L.OS, *sot = so + nn;
+      uint16_t *so = sOrig + (size_t)myb * L.OS, *sot = so + nn;
       const int nseg = nn >> 2, lg_spr = lgn - 2;     // segments, log2(segments per row)
       int v[4][4];
 #pragma unroll
@@ -845,12 +851,9 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
         const int sg = mytid + k * tpb;
         if (sg < nseg) {
           const int yy = sg >> lg_spr, xx = (sg & ((1 << lg_spr) - 1)) * 4;
-          if constexpr (sizeof(PX) == 2)
-            *reinterpret_cast<uint2 *>(so + yy * n + xx) = make_uint2((uint32_t)v[k][0] | ((uint32_t)v[k][1] << 16), (uint32_t)v[k][2] | ((uint32_t)v[k][3] << 16));
-          else
-            *reinterpret_cast<uint32_t *>(so + yy * n + xx) = (uint32_t)v[k][0] | ((uint32_t)v[k][1] << 8) | ((uint32_t)v[k][2] << 16) | ((uint32_t)v[k][3] << 24);
+          *reinterpret_cast<uint2 *>(so + yy * n + xx) = make_uint2((uint32_t)v[k][0] | ((uint32_t)v[k][1] << 16), (uint32_t)v[k][2] | ((uint32_t)v[k][3] << 16));
 #pragma unroll
-          for (int i = 0; i < 4; ++i) sot[(xx + i) * n + yy] = (PX)v[k][i];
+          for (int i = 0; i < 4; ++i) sot[(xx + i) * n + yy] = (uint16_t)v[k][i];
         }
       }
     }
@@ -885,21 +888,11 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int lb = lane >> lg_tiles, tile = lane & (tiles - 1);
   const bool active = lb < here;
-  const int bb = active ? lb : 0;
-  const int xd0 = (tile & ((1 << lg_tx) - 1)) * T, yd0 = (tile >> lg_tx) * T;
-  const uint32_t *ref = sRef + (size_t)bb * L.BRS;
-  const PX *ob = sOrig + (size_t)bb * L.OS + yd0 * n + xd0;
-  uint32_t *priv = sPriv + ((size_t)wave * bpg + bb) * L.PS;
-  const int dc = sDC[bb];
   const int maxv = px_traits<PX>::maxv;
   const int dshift = px_traits<PX>::depth - 8;
 
-  // two passes over the candidate list: modes predicted in the block domain, then those predicted in
-  // the transposed domain; the lane's original tile stays in registers for a whole pass
   uint32_t my_best = 0xffffffffu;
-  for (int phase = 0; phase < 2; ++phase) {
-    uint32_t o[T][T / 2];
-    load_orig_tile<PX, T>(ob + (phase ? nn : 0), n, o);
+  {
     for (int m = wave; m < n_modes; m += WAVES) {
       search_mode S;
       {
@@ -908,7 +901,17 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
 #pragma unroll
         for (int k = 0; k < (int)(sizeof(search_mode) / 4); ++k) dst[k] = __builtin_amdgcn_readfirstlane(src[k]);
       }
-      if (S.transposed != phase) continue;
+      // Everything per-lane is re-derived from one opaque copy of the lane's (block, tile) each iteration: left to itself
+      // LICM hoists these pointers and a dozen per-column values (xd0 | i, 2 * (xd0 | i), ...) out of the mode loop and the
+      // register allocator then spills them to scratch (measured: 18 MB of scratch writes per launch)
+      int lane_i = lane;
+      asm volatile("" : "+v"(lane_i));
+      const int lb_i = lane_i >> lg_tiles, tile_i = lane_i & (tiles - 1);
+      const int bb_i = lb_i < here ? lb_i : 0;
+      const int xd0 = (tile_i & ((1 << lg_tx) - 1)) * T, yd0 = (tile_i >> lg_tx) * T;
+      const uint32_t *ref = sRef + __mul24(bb_i, L.BRS);
+      const uint16_t *ob = sOrig + __mul24(bb_i, L.OS) + __mul24(yd0, n) + xd0;
+      uint32_t *priv = sPriv + __mul24(wave * bpg + bb_i, L.PS);
       const uint32_t *mainr = ref + S.row_main * L.RS, *side = ref + S.row_side * L.RS;
       const bool neg = S.kind == 2 && S.sd < 0;
       if (neg) {
@@ -945,17 +948,18 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       }
       uint32_t d[T][T / 2];
       uint32_t sad = 0;
+      const uint16_t *ot = ob + (S.transposed ? nn : 0);
       if (S.kind == 2) {
         const uint32_t *rowp = neg ? priv + n : mainr;
         if (S.pdpc == 0) {
-          if (S.noclamp) search_tile_angular<T, 0, false>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);
-          else search_tile_angular<T, 0, true>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);
+          if (S.noclamp) search_tile_angular<T, 0, false>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);
+          else search_tile_angular<T, 0, true>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);
         } else if (S.pdpc == 2) {
-          if (S.noclamp) search_tile_angular<T, 2, false>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);
-          else search_tile_angular<T, 2, true>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);
-        } else search_tile_angular<T, 3, false>(S, mainr, side, rowp, sCoef, n, xd0, yd0, o, maxv, d, sad);   // pure H/V: integer phase
-      } else if (S.kind == 0) search_tile_nonangular<T, true>(S, mainr, side, dc, n, lgn, xd0, yd0, o, d, sad);
-      else search_tile_nonangular<T, false>(S, mainr, side, dc, n, lgn, xd0, yd0, o, d, sad);
+          if (S.noclamp) search_tile_angular<T, 2, false>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);
+          else search_tile_angular<T, 2, true>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);
+        } else search_tile_angular<T, 3, false>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);   // pure H/V: integer phase
+      } else if (S.kind == 0) search_tile_nonangular<T, true>(S, mainr, side, 0, n, lgn, xd0, yd0, ot, d, sad);
+      else search_tile_nonangular<T, false>(S, mainr, side, sDC[bb_i], n, lgn, xd0, yd0, ot, d, sad);
       uint32_t satd;
       if constexpr (T == 8) satd = satd8_tile_lane(d); else satd = satd4_tile_lane(d);
       if (lg_tiles >= 2) {
