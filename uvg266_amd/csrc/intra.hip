@@ -514,6 +514,28 @@ struct search_mode {
   int noclamp;     // the 4-tap result cannot leave the sample range (smoothing taps are a convex combination; so is an integer phase)
 };
 
+// LDS form of a search_mode: two dwords, so a wave fetches its mode with one 8-byte read + two v_readfirstlane and
+// unpacks with scalar bit-field extracts.
+//   x: kind[1:0] row_main[3:2] row_side[5:4] pdpc[7:6] scale[10:8] (0..2, 0 without PDPC) coef>>5 [11] transposed[12] noclamp[13]
+//   y: sd (low 16, signed) | inv << 16 (inv < 2^15)
+__device__ inline uint2 pack_search_mode(const search_mode &S)
+{
+  uint2 p;
+  p.x = (uint32_t)S.kind | ((uint32_t)S.row_main << 2) | ((uint32_t)S.row_side << 4) | ((uint32_t)S.pdpc << 6) |
+        ((uint32_t)((S.pdpc ? S.scale : 0) & 7) << 8) | ((uint32_t)(S.coef >> 5) << 11) | ((uint32_t)S.transposed << 12) | ((uint32_t)S.noclamp << 13);
+  p.y = ((uint32_t)S.sd & 0xffffu) | ((uint32_t)S.inv << 16);
+  return p;
+}
+__device__ __forceinline__ search_mode unpack_search_mode(uint32_t x, uint32_t y)
+{
+  search_mode S;
+  S.kind = x & 3; S.row_main = (x >> 2) & 3; S.row_side = (x >> 4) & 3; S.pdpc = (x >> 6) & 3;
+  S.scale = (x >> 8) & 7;                         // only meaningful (and then 0..2) when pdpc != 0
+  S.coef = ((x >> 11) & 1) << 5; S.transposed = (x >> 12) & 1; S.noclamp = (x >> 13) & 1;
+  S.sd = (int)(int16_t)(y & 0xffffu); S.inv = (int)(y >> 16);
+  return S;
+}
+
 __device__ inline search_mode make_search_mode(int mode, int n)
 {
   const mode_info M = make_mode_info(mode, n, n, 0);
@@ -788,7 +810,8 @@ __host__ __device__ inline search_layout make_search_layout(int n, int bpg, int 
   L.off_dc = (int)o;   o += (size_t)bpg * 8;      // DC values, then the per-block best keys
   o = (o + 7) & ~(size_t)7;
   L.off_coef = (int)o; o += 64 * 8;
-  L.off_mode = (int)o; o += (size_t)n_modes * sizeof(search_mode);
+  o = (o + 7) & ~(size_t)7;
+  L.off_mode = (int)o; o += (size_t)n_modes * 8;
   L.total = o;
   return L;
 }
@@ -816,7 +839,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   int *sDC = reinterpret_cast<int *>(smem_raw + L.off_dc);
   uint32_t *sBest = reinterpret_cast<uint32_t *>(sDC + bpg);     // per block: min over modes of cost << 7 | candidate index
   uint2 *sCoef = reinterpret_cast<uint2 *>(smem_raw + L.off_coef);
-  search_mode *sMode = reinterpret_cast<search_mode *>(smem_raw + L.off_mode);
+  uint2 *sMode = reinterpret_cast<uint2 *>(smem_raw + L.off_mode);
 
   const int blk0 = blockIdx.x * bpg;
   const int here = min(bpg, n_blks - blk0);
@@ -857,7 +880,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
         }
       }
     }
-    for (int m = threadIdx.x; m < n_modes; m += NT) sMode[m] = make_search_mode(modes[m], n);
+    for (int m = threadIdx.x; m < n_modes; m += NT) sMode[m] = pack_search_mode(make_search_mode(modes[m], n));
     if (threadIdx.x < bpg) sBest[threadIdx.x] = 0xffffffffu;
     if (threadIdx.x < 64) {
       const int df = threadIdx.x & 31;
@@ -894,13 +917,8 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   uint32_t my_best = 0xffffffffu;
   {
     for (int m = wave; m < n_modes; m += WAVES) {
-      search_mode S;
-      {
-        const int *src = reinterpret_cast<const int *>(sMode + m);
-        int *dst = reinterpret_cast<int *>(&S);
-#pragma unroll
-        for (int k = 0; k < (int)(sizeof(search_mode) / 4); ++k) dst[k] = __builtin_amdgcn_readfirstlane(src[k]);
-      }
+      const uint2 pm = sMode[m];
+      const search_mode S = unpack_search_mode(__builtin_amdgcn_readfirstlane(pm.x), __builtin_amdgcn_readfirstlane(pm.y));
       // Everything per-lane is re-derived from one opaque copy of the lane's (block, tile) each iteration: left to itself
       // LICM hoists these pointers and a dozen per-column values (xd0 | i, 2 * (xd0 | i), ...) out of the mode loop and the
       // register allocator then spills them to scratch (measured: 18 MB of scratch writes per launch)
