@@ -39,6 +39,13 @@ try:
         TRAFFIC = json.load(_f)
 except OSError:
     pass
+VALU = {}
+try:
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "valu_latest.json")) as _f:
+        VALU = json.load(_f)
+except OSError:
+    pass
+N_SIMD, CLOCK_GHZ, CYC_PER_VALU = 1024, 2.4, 4     # MI355X: 256 CUs x 4 SIMDs; peak engine clock; wave64 op = 4 cycles on a 16-lane SIMD
 WORKLOAD = ("1920x1080 8-bit yuv420p, all-intra medium hot path per frame: luma, for N in 32,16,8,4 "
             "{intra rough search 67 modes min(SATD,2SAD) on all NxN blocks with fused arg-min -> intra predict "
             "-> fused residual/DCT-2/quant/dequant/IDCT/recon}; then deblock (Y,U,V; seeded random quad-tree "
@@ -351,6 +358,11 @@ def main():
                                  "serial_avg_launch_ms = the same launch alone (profile pass); "
                                  "traffic = PMC bytes per launch from profiles/ (null if not collected)"},
             "kernel_sum_ms": round(tot_ms, 4),
+            "valu": (lambda v: None if v is None else {
+                "kernel": dom, "insts_per_launch": v["valu_insts"],
+                "issue_util_alone": round(v["valu_insts"] * CYC_PER_VALU / (N_SIMD * per_kernel[dom]["avg_ms"] * 1e-3 * CLOCK_GHZ * 1e9), 3),
+                "note": "SQ_INSTS_VALU (PMC, --serial) x 4 cycles / (1024 SIMDs x launch duration alone x 2.4 GHz): the limiter of "
+                        "the dominant kernel is integer VALU issue, not HBM (the real clock under load is below 2.4 GHz, so this is a floor)"})(VALU.get(dom)),
             "kernels_timed_region": per_kernel_live,
             "kernels": per_kernel,
         }

@@ -5,13 +5,15 @@
 #                      duration includes the time it shares the GPU with the other chains)
 #   prof_stats_serial  the same with --serial (one stream): each launch alone on the GPU
 #   prof_fetch/_write  PMC passes (counters only), --serial so that the device-wide TCC counters belong to one kernel
+#   prof_valu          SQ instruction counts per launch (--serial)
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-rm -rf gpurun_out/prof_stats gpurun_out/prof_stats_serial gpurun_out/prof_fetch gpurun_out/prof_write
+rm -rf gpurun_out/prof_stats gpurun_out/prof_stats_serial gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_valu
 CMD="python bench.py --steps 40 --warmup 4 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- $CMD > gpurun_out/prof_stats.log 2>&1
 grep '^{' gpurun_out/prof_stats.log | tail -1 > gpurun_out/prof_bench_line.json
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats_serial -- $CMD --serial > gpurun_out/prof_stats_serial.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -- $CMD --serial > gpurun_out/prof_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -- $CMD --serial > gpurun_out/prof_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d gpurun_out/prof_valu -- $CMD --serial > gpurun_out/prof_valu.log 2>&1
 ls gpurun_out/prof_stats/*/ gpurun_out/prof_stats_serial/*/ gpurun_out/prof_fetch/*/ 2>/dev/null | head -30

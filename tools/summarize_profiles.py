@@ -43,6 +43,21 @@ for r in rows:
         r["bench_name"] = names[r["grid"]]
         by_bench[names[r["grid"]]] = r["hbm_bytes_per_launch"]
 json.dump(by_bench, open("profiles/hbm_traffic_latest.json", "w"), indent=1)
+try:
+    valu, _ = per_kernel("prof_valu", "SQ_INSTS_VALU")
+    lds, _ = per_kernel("prof_valu", "SQ_INSTS_LDS")
+    waves, _ = per_kernel("prof_valu", "SQ_WAVES")
+    vb = {}
+    for k, v in valu.items():
+        if "intra_search_kernel" in k[0] and k[1] in names:
+            vb[names[k[1]]] = {"valu_insts": round(v), "lds_insts": round(lds.get(k, 0)), "waves": round(waves.get(k, 0))}
+    json.dump(vb, open("profiles/valu_latest.json", "w"), indent=1)
+    json.dump({"note": "SQ_INSTS_VALU / SQ_INSTS_LDS / SQ_WAVES per launch (wave-level instruction counts), --serial bench",
+               "kernels": [{"kernel": k[0], "grid": k[1], "valu_insts": round(v), "lds_insts": round(lds.get(k, 0)), "waves": round(waves.get(k, 0))}
+                           for k, v in sorted(valu.items(), key=lambda kv: -kv[1])]},
+              open(f"profiles/{tag}_bench_sq_insts.json", "w"), indent=1)
+except (IndexError, ValueError):
+    pass
 json.dump({"note": "FETCH_SIZE x 1024 x 2 (gfx950 correction) + WRITE_SIZE x 1024, averaged per launch; separate --pmc passes",
            "kernels": rows}, open(f"profiles/{tag}_bench_hbm_traffic.json", "w"), indent=1)
 for r in rows[:24]:

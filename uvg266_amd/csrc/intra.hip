@@ -649,12 +649,13 @@ __device__ __forceinline__ uint32_t pack_shr8(int lo, int hi) { return __builtin
 
 // PDPC: 0 none, 2 projected side sample (intra-generic.c:262-277), 3 gradient of the pure
 // horizontal/vertical modes (:279-293)
-template <int T, int PDPC, bool CLAMP>
+template <int T, int PDPC, bool CLAMP, bool PK8>
 __device__ __forceinline__ void search_tile_angular(const search_mode &S, const uint32_t *mainr, const uint32_t *side,
                                                     const uint32_t *rowp, const uint2 *sCoef, int n, int xd0, int yd0,
                                                     const uint16_t *otile, int maxv, uint32_t (&d)[T][T / 2], uint32_t &sad)
 {
   uint32_t wlp[T / 4];       // PDPC column weights (<= 32), one byte each: they are only ever multiplied (SDWA byte operand)
+  uint32_t wpk[T / 2];       // ... or as 16-bit pairs for the packed 8-bit blend
   const uint16_t *sp[T];    // PDPC 2: address of the projected side sample of column i in row yd0 (dword stride per row)
   int tl = 0;
   if constexpr (PDPC != 0) {
@@ -664,6 +665,8 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
 #pragma unroll
     for (int q = 0; q < T / 4; ++q)
       wlp[q] = (uint32_t)wl[4 * q] | ((uint32_t)wl[4 * q + 1] << 8) | ((uint32_t)wl[4 * q + 2] << 16) | ((uint32_t)wl[4 * q + 3] << 24);
+#pragma unroll
+    for (int c = 0; c < T / 2; ++c) wpk[c] = (uint32_t)wl[2 * c] | ((uint32_t)wl[2 * c + 1] << 16);
     if constexpr (PDPC == 2) {
 #pragma unroll
       for (int i = 0; i < T; ++i) {
@@ -708,7 +711,22 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
       }
       finish_row<T>(pp, A.o, d[r], sad);
     } else {
-      if constexpr (PDPC == 2) {
+      if constexpr (PDPC == 2 && PK8) {
+        // 8-bit samples: the whole blend  c + ((wl * (l - c) + 32) >> 6)  stays inside int16 (|wl * (l - c)| <= 32 * 255),
+        // so it runs on packed pairs: pack, [clamp], sub, v_pk_mad_i16, v_pk_ashrrev_i16, add
+        uint32_t pp[T / 2];
+#pragma unroll
+        for (int c = 0; c < T / 2; ++c) {
+          pk_s16 v = __builtin_bit_cast(pk_s16, pack_shr8(out[2 * c], out[2 * c + 1]));
+          if constexpr (CLAMP) v = __builtin_elementwise_min(__builtin_elementwise_max(v, (pk_s16){0, 0}), vmax);
+          const pk_s16 l = __builtin_bit_cast(pk_s16, (uint32_t)lA[2 * c] | ((uint32_t)lA[2 * c + 1] << 16));
+          const pk_s16 w = __builtin_bit_cast(pk_s16, wpk[c]);
+          const pk_s16 t = ((l - v) * w + (pk_s16){32, 32}) >> (pk_s16){6, 6};
+          pp[c] = __builtin_bit_cast(uint32_t, v + t);
+        }
+        finish_row<T>(pp, A.o, d[r], sad);
+        continue;
+      } else if constexpr (PDPC == 2) {
 #pragma unroll
         for (int i = 0; i < T; ++i) {
           const int c = CLAMP ? clampi(out[i] >> 8, 0, maxv) : out[i] >> 8;
@@ -970,12 +988,12 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       if (S.kind == 2) {
         const uint32_t *rowp = neg ? priv + n : mainr;
         if (S.pdpc == 0) {
-          if (S.noclamp) search_tile_angular<T, 0, false>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);
-          else search_tile_angular<T, 0, true>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);
+          if (S.noclamp) search_tile_angular<T, 0, false, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);
+          else search_tile_angular<T, 0, true, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);
         } else if (S.pdpc == 2) {
-          if (S.noclamp) search_tile_angular<T, 2, false>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);
-          else search_tile_angular<T, 2, true>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);
-        } else search_tile_angular<T, 3, false>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);   // pure H/V: integer phase
+          if (S.noclamp) search_tile_angular<T, 2, false, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);
+          else search_tile_angular<T, 2, true, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);
+        } else search_tile_angular<T, 3, false, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);   // pure H/V: integer phase
       } else if (S.kind == 0) search_tile_nonangular<T, true>(S, mainr, side, 0, n, lgn, xd0, yd0, ot, d, sad);
       else search_tile_nonangular<T, false>(S, mainr, side, sDC[bb_i], n, lgn, xd0, yd0, ot, d, sad);
       uint32_t satd;
