@@ -351,6 +351,23 @@ UVGHIP_API int uvghip_deblock_frame(int bitdepth, void *y, int y_stride, void *u
                          const uvghip_scu_t *scu, int scu_stride, int beta_offset_div2, int tc_offset_div2,
                          int slice_is_b, int frame_qp, const int8_t *chroma_qp_map_host, void *stream);
 
+/* ------------------------------------------ (2) batched ABI: LFNST --------- */
+
+/* Per-TU parameters of the low-frequency non-separable transform.  intra_mode: the mode the reference
+ * resolves before the wide-angle correction (src/transform.c:978-1001: the luma mode; for chroma the
+ * chroma mode, the co-located luma mode for CCLM, planar for MIP).  lfnst_idx: 0 = leave the TU alone,
+ * 1..2 = kernel.  log2_cu_width/height: the dimensions uvg_wide_angle_correction is called with
+ * (:1004-1009: the CU's for luma, the TU's for chroma). */
+typedef struct uvghip_lfnst_tu {
+  int8_t intra_mode, lfnst_idx, log2_cu_width, log2_cu_height;
+} uvghip_lfnst_tu_t;
+
+/* replaces: uvg_fwd_lfnst (inverse = 0, src/transform.c:965-1077) / uvg_inv_lfnst (inverse = 1,
+ * :1104-1225) -- plain C in the reference, called between the primary transform and quantisation --
+ * for n TUs of one shape, in place on coeffs[n][height][width]. */
+UVGHIP_API int uvghip_lfnst_batch(int inverse, int16_t *coeffs, int width, int height, const uvghip_lfnst_tu_t *tus, int n,
+                       void *stream);
+
 /* ------------------------------------------ (2) batched ABI: ALF ----------- */
 
 /* replaces: alf_derive_classification -> uvg_alf_derive_classification_blk over the whole luma plane

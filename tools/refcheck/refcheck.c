@@ -55,6 +55,7 @@ void check_ipol(void);
 void check_sao(void);
 void check_alf(void);
 void check_deblock(void);
+void check_lfnst(void);
 
 int main(int argc, char **argv)
 {
@@ -82,6 +83,9 @@ int main(int argc, char **argv)
 #ifdef HAVE_DEBLOCK
   check_deblock();
 #endif
+#if defined(HAVE_LFNST) && UVG_BIT_DEPTH == 8   /* depth-independent: the oracle exports it once */
+  check_lfnst();
+#endif
   if (g_out) fclose(g_out);
   printf("refcheck %d-bit: %s (%d mismatches)\n", UVG_BIT_DEPTH, g_fail ? "FAIL" : "OK", g_fail);
   return g_fail ? 1 : 0;
@@ -108,4 +112,7 @@ int main(int argc, char **argv)
 #endif
 #ifdef HAVE_DEBLOCK
 #include "rc_deblock.inc"
+#endif
+#if defined(HAVE_LFNST) && UVG_BIT_DEPTH == 8
+#include "rc_lfnst.inc"
 #endif

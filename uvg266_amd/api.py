@@ -347,6 +347,20 @@ def deblock_frame(y, u, v, scu, width, height, beta_offset_div2=0, tc_offset_div
     return y
 
 
+# ---- LFNST -------------------------------------------------------------------------
+def make_lfnst_tus(rows, device="cuda"):
+    """(n,4) rows of (intra_mode, lfnst_idx, log2_cu_width, log2_cu_height) -> device array of uvghip_lfnst_tu_t."""
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(rows, np.int8).reshape(-1, 4))).to(device)
+
+
+def lfnst_batch(coeffs, tus, inverse=False):
+    """In place on coeffs (n, h, w) int16."""
+    L = _lib.init(coeffs.device.index or 0)
+    n, h, w = coeffs.shape
+    _lib.check(L.uvghip_lfnst_batch(int(inverse), _dev(coeffs), w, h, _dev(tus), n, _stream()), "uvghip_lfnst_batch")
+    return coeffs
+
+
 # ---- ALF ---------------------------------------------------------------------------
 def alf_classify_frame(rec, width, height, shift=None):
     """-> (height/4, width/4) uint8: class_idx | transpose_idx << 5 per 4x4 luma block."""

@@ -56,6 +56,7 @@ SIGNATURES = {
     "uvghip_sao_apply_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
     "uvghip_sao_edge_offsets_batch": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvghip_deblock_frame": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "uvghip_lfnst_batch": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "uvghip_alf_classify_frame": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "uvghip_alf_filter_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
     "uvghip_alf_stats_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
