@@ -269,6 +269,15 @@ UVGHIP_API int uvghip_frac_satd_batch(int bitdepth, const void *cur, int cur_str
                            int pic_w, int pic_h, int width, int height, const uvghip_blk_t *blks, int n,
                            const int16_t *cand_mv, int n_cand, uint32_t *costs, void *stream);
 
+/* replaces: crc32c_4x4 / crc32c_8x8 (picture-generic.c:1371-1443; the IBC hash): CRC-32C of the size x size block at
+ * blks[i] (bytes in raster order; 10-bit samples contribute low byte then high byte), init/final xor 0xFFFFFFFF. */
+UVGHIP_API int uvghip_crc32c_batch(int bitdepth, const void *plane, int stride, int size, const uvghip_tu_t *blks, int n,
+                        uint32_t *out, void *stream);
+
+/* replaces: pixel_var (picture-generic.c:1334-1357; VAQ): out[i] = variance (double) of the len samples
+ * arr[i*len ..].  Floating point: summation order differs from the reference, results agree to ~1e-13 relative. */
+UVGHIP_API int uvghip_pixel_var_batch(int bitdepth, const void *arr, uint32_t len, int n, double *out, void *stream);
+
 /* replaces: bipred_average_px_px / _im_im / _px_im (picture-generic.c:1132-1193)
  * on flat arrays of `total` samples.  mode bit0: l0 is int16 14-bit, bit1: l1 is. */
 UVGHIP_API int uvghip_bipred_average_batch(int bitdepth, const void *l0, const void *l1, int mode, size_t total,

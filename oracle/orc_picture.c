@@ -320,3 +320,33 @@ ORC_EXPORT void ORC_FN(bipred_average)(orc_px *dst, int dst_stride, const void *
     dst[(i / w) * dst_stride + (i % w)] = orc_clip_px(v);
   }
 }
+
+/* ------------------------------------------------- IBC hash, variance -- */
+/* picture-generic.c:1371-1443: byte-wise table-driven CRC-32C (reflected polynomial 0x82F63B78), rows in order,
+ * 10-bit samples as two bytes (low first: the reference walks the uvg_pixel buffer as uint8_t on a little-endian
+ * host). */
+ORC_EXPORT uint32_t ORC_FN(crc32c_nxn)(const orc_px *buf, uint32_t stride, int n)
+{
+  static uint32_t table[256];
+  static int have = 0;
+  if (!have) {
+    for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u))); table[i] = c; }
+    have = 1;
+  }
+  uint32_t crc = 0xFFFFFFFFu;
+  for (int y = 0; y < n; ++y) {
+    const uint8_t *b = (const uint8_t *)(buf + (size_t)y * stride);
+    for (int i = 0; i < n * (int)sizeof(orc_px); ++i) crc = (crc >> 8) ^ table[(crc ^ b[i]) & 0xFF];
+  }
+  return crc ^ 0xFFFFFFFFu;
+}
+
+/* picture-generic.c:1334-1357, same accumulation order */
+ORC_EXPORT double ORC_FN(pixel_var)(const orc_px *arr, uint32_t len)
+{
+  double sum = 0, var = 0;
+  for (uint32_t i = 0; i < len; ++i) sum += arr[i];
+  const double mean = sum / (double)len;
+  for (uint32_t i = 0; i < len; ++i) { const double t = (double)arr[i] - mean; var += t * t; }
+  return var / len;
+}

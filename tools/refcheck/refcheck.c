@@ -56,6 +56,7 @@ void check_sao(void);
 void check_alf(void);
 void check_deblock(void);
 void check_lfnst(void);
+void check_hashvar(void);
 
 int main(int argc, char **argv)
 {
@@ -86,6 +87,7 @@ int main(int argc, char **argv)
 #if defined(HAVE_LFNST) && UVG_BIT_DEPTH == 8   /* depth-independent: the oracle exports it once */
   check_lfnst();
 #endif
+  check_hashvar();
   if (g_out) fclose(g_out);
   printf("refcheck %d-bit: %s (%d mismatches)\n", UVG_BIT_DEPTH, g_fail ? "FAIL" : "OK", g_fail);
   return g_fail ? 1 : 0;
@@ -116,3 +118,4 @@ int main(int argc, char **argv)
 #if defined(HAVE_LFNST) && UVG_BIT_DEPTH == 8
 #include "rc_lfnst.inc"
 #endif
+#include "rc_hashvar.inc"

@@ -171,6 +171,25 @@ def tu_roundtrip_batch(orig, pred, rec, tus, w, h, qp_scaled, slice_is_intra=Tru
     return coeff, has
 
 
+def crc32c_batch(plane, blks_xy, size):
+    """CRC-32C (IBC hash) of size x size blocks at (x, y) rows of `blks_xy` (device uvghip_tu_t array) -> (n,) int32 bit patterns."""
+    L = _lib.init(plane.device.index or 0)
+    n = blks_xy.shape[0]
+    out = torch.empty(n, dtype=torch.int32, device=plane.device)
+    _lib.check(L.uvghip_crc32c_batch(_depth(plane), _dev(plane), plane.stride(0), size, _dev(blks_xy), n, _dev(out), _stream()),
+               "uvghip_crc32c_batch")
+    return out
+
+
+def pixel_var_batch(arr):
+    """arr (n, len) samples -> (n,) float64 variances."""
+    L = _lib.init(arr.device.index or 0)
+    n, ln = arr.shape
+    out = torch.empty(n, dtype=torch.float64, device=arr.device)
+    _lib.check(L.uvghip_pixel_var_batch(_depth(arr), _dev(arr), ln, n, _dev(out), _stream()), "uvghip_pixel_var_batch")
+    return out
+
+
 # ---- intra ---------------------------------------------------------------------
 def make_intra_blocks(xyaa, device="cuda"):
     """(n,4) rows of (x, y, avail_top, avail_left) -> device array of uvghip_intra_blk_t."""

@@ -162,8 +162,13 @@ void mts_hip(const int8_t bitdepth, const int /*color_t*/ color, const ref_cu_in
 
 }  // namespace
 
-// Not registered: fast_forward/inverse_dst_4x4 (dead upstream: their only
-// callers are commented out, strategies-dct.c:106-110,140-144).
+// fast_forward/inverse_dst_4x4 (dct-generic.c:359-393,752-770; dead upstream: their only callers are commented
+// out, strategies-dct.c:106-110,140-144) are the HEVC 4-point DST-VII, whose integer matrix and stage shifts are
+// exactly the VVC DST-7 4x4 transform pair -- registered for table completeness as that kernel.
+template <int INV> void dst_4x4_hip(int8_t bitdepth, const int16_t *input, int16_t *output)
+{
+  percall_transform(bitdepth, INV, TR_DST7, TR_DST7, 4, 4, 0, 0, input, output);
+}
 extern "C" int uvg_strategy_register_dct_hip(void *opaque, uint8_t bitdepth)
 {
   if (!uvghip_ready() && uvghip_init(0) != 0) return 0;
@@ -173,6 +178,8 @@ extern "C" int uvg_strategy_register_dct_hip(void *opaque, uint8_t bitdepth)
   REG("dct_16x16", (&dct_nxn_hip<16, 0>));  REG("dct_32x32", (&dct_nxn_hip<32, 0>));
   REG("idct_4x4", (&dct_nxn_hip<4, 1>));    REG("idct_8x8", (&dct_nxn_hip<8, 1>));
   REG("idct_16x16", (&dct_nxn_hip<16, 1>)); REG("idct_32x32", (&dct_nxn_hip<32, 1>));
+  REG("fast_forward_dst_4x4", (&dst_4x4_hip<0>));
+  REG("fast_inverse_dst_4x4", (&dst_4x4_hip<1>));
   REG("mts_dct", (&mts_hip<0>));
   REG("mts_idct", (&mts_hip<1>));
 #undef REG

@@ -335,6 +335,85 @@ extern "C" int uvghip_sad_surface(int bitdepth, const void *cur, int cur_stride,
   UVGHIP_CHECK_LAUNCH();
 }
 
+// ---- IBC hash and variance (rows a8: crc32c_4x4/8x8, pixel_var) -------------------------------
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) over the bytes of a 4x4 / 8x8 block, row by row, initial
+// value and final xor 0xFFFFFFFF (picture-generic.c:1371-1443; 10-bit blocks hash both bytes of every sample,
+// low byte first).  The table is computed, entry by entry, in LDS.
+__device__ __forceinline__ uint32_t crc32c_table_entry(uint32_t i)
+{
+  uint32_t c = i;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
+  return c;
+}
+template <typename PX>
+__global__ void __launch_bounds__(256)
+crc32c_kernel(const PX *__restrict__ plane, int stride, int size, const uvghip_tu_t *__restrict__ blks, int n, uint32_t *__restrict__ out)
+{
+  __shared__ uint32_t sT[256];
+  sT[threadIdx.x] = crc32c_table_entry(threadIdx.x);
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const PX *b = plane + (size_t)blks[i].y * stride + blks[i].x;
+  uint32_t crc = 0xFFFFFFFFu;
+  for (int y = 0; y < size; ++y)
+    for (int x = 0; x < size; ++x) {
+      const uint32_t v = b[(size_t)y * stride + x];
+      crc = (crc >> 8) ^ sT[(crc ^ v) & 0xFF];
+      if constexpr (sizeof(PX) == 2) crc = (crc >> 8) ^ sT[(crc ^ (v >> 8)) & 0xFF];
+    }
+  out[i] = crc ^ 0xFFFFFFFFu;
+}
+
+extern "C" int uvghip_crc32c_batch(int bitdepth, const void *plane, int stride, int size, const uvghip_tu_t *blks, int n,
+                                   uint32_t *out, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if ((bitdepth != 8 && bitdepth != 10) || (size != 4 && size != 8)) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (n <= 0) return 0;
+  hipStream_t st = uvghip_stream(stream);
+  if (bitdepth == 8) crc32c_kernel<uint8_t><<<(n + 255) / 256, 256, 0, st>>>((const uint8_t *)plane, stride, size, blks, n, out);
+  else crc32c_kernel<uint16_t><<<(n + 255) / 256, 256, 0, st>>>((const uint16_t *)plane, stride, size, blks, n, out);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// Variance of n arrays of `len` samples (picture-generic.c:1334-1357): mean = sum / len and the mean of squared
+// deviations, in double.  The reference accumulates the len squared deviations in index order; here each lane of a
+// wave accumulates a strided subset and the 64 partial sums are added in a fixed tree, so the result can differ
+// from the reference in the last bits (relative 1e-13 for realistic len): a floating-point row, compared with a
+// tolerance, not bit-exact.
+template <typename PX>
+__global__ void __launch_bounds__(256)
+pixel_var_kernel(const PX *__restrict__ arr, uint32_t len, int n, double *__restrict__ out)
+{
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= n) return;
+  const PX *a = arr + (size_t)wave * len;
+  unsigned long long s = 0;
+  for (uint32_t i = lane; i < len; i += 64) s += a[i];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += ((unsigned long long)__shfl_xor((uint32_t)(s >> 32), off, 64) << 32) | __shfl_xor((uint32_t)s, off, 64);
+  const double mean = (double)s / (double)len;
+  double v = 0;
+  for (uint32_t i = lane; i < len; i += 64) { const double t = (double)a[i] - mean; v += t * t; }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  if (lane == 0) out[wave] = v / len;
+}
+
+extern "C" int uvghip_pixel_var_batch(int bitdepth, const void *arr, uint32_t len, int n, double *out, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if ((bitdepth != 8 && bitdepth != 10) || len == 0) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (n <= 0) return 0;
+  hipStream_t st = uvghip_stream(stream);
+  const int grid = (n + 3) / 4;
+  if (bitdepth == 8) pixel_var_kernel<uint8_t><<<grid, 256, 0, st>>>((const uint8_t *)arr, len, n, out);
+  else pixel_var_kernel<uint16_t><<<grid, 256, 0, st>>>((const uint16_t *)arr, len, n, out);
+  UVGHIP_CHECK_LAUNCH();
+}
+
 // =================================================== drop-in strategy layer ====
 // Host-pointer functions with the reference typedefs
 // (src/strategies/strategies-picture.h:112-158).  The reference fixes
@@ -386,6 +465,32 @@ unsigned reg_sad_hip(const PX *data1, const PX *data2, const int width, const in
   c->download(oo, sizeof(uint32_t));
   c->sync();
   return *c->hp<uint32_t>(oo);
+}
+
+// crc32c_4x4_func / crc32c_8x8_func (strategies-picture.h:157-158): (const uvg_pixel *buf, uint32_t pic_stride)
+template <typename PX, int N> uint32_t crc32c_hip(const PX *buf, uint32_t pic_stride)
+{
+  percall_ctx *c = percall_get((size_t)N * N * sizeof(PX) + 1024);
+  const size_t oa = c->stage_block(buf, pic_stride, N, N, sizeof(PX));
+  const size_t od = c->take(sizeof(uvghip_tu_t)), oo = c->take(sizeof(uint32_t));
+  *c->hp<uvghip_tu_t>(od) = uvghip_tu_t{0, 0};
+  c->upload(0, c->used);
+  c->must(uvghip_crc32c_batch(px_traits<PX>::depth, c->dp<PX>(oa), N, N, c->dp<uvghip_tu_t>(od), 1, c->dp<uint32_t>(oo), c->stream), "crc32c");
+  c->download(oo, sizeof(uint32_t));
+  c->sync();
+  return *c->hp<uint32_t>(oo);
+}
+// pixel_var_func (strategies-picture.h:150): (const uvg_pixel *buf, const uint32_t len)
+template <typename PX> double pixel_var_hip(const PX *buf, const uint32_t len)
+{
+  percall_ctx *c = percall_get((size_t)len * sizeof(PX) + 1024);
+  const size_t oa = c->take((size_t)len * sizeof(PX)), oo = c->take(sizeof(double));
+  memcpy(c->hp<PX>(oa), buf, (size_t)len * sizeof(PX));
+  c->upload(0, c->used);
+  c->must(uvghip_pixel_var_batch(px_traits<PX>::depth, c->dp<PX>(oa), len, 1, c->dp<double>(oo), c->stream), "pixel_var");
+  c->download(oo, sizeof(double));
+  c->sync();
+  return *c->hp<double>(oo);
 }
 
 // cost_pixel_nxn_func: contiguous NxN
@@ -460,6 +565,9 @@ int register_picture(void *opaque)
   REG("satd_16x16_dual", (&satd_nxn_dual_hip<PX, 16>)); REG("satd_32x32_dual", (&satd_nxn_dual_hip<PX, 32>));
   REG("satd_any_size", (&satd_any_size_hip<PX>));
   REG("pixels_calc_ssd", (&pixels_calc_ssd_hip<PX>));
+  REG("crc32c_4x4", (&crc32c_hip<PX, 4>));
+  REG("crc32c_8x8", (&crc32c_hip<PX, 8>));
+  REG("pixel_var", (&pixel_var_hip<PX>));
   REG("generate_residual", (&generate_residual_hip<PX>));
 #undef REG
   return ok;
