@@ -207,6 +207,14 @@ UVGHIP_API int uvghip_intra_pred_batch(int bitdepth, const void *rec, int rec_st
                             const uvghip_intra_blk_t *blks, int n, const int8_t *modes, int n_modes,
                             void *preds_out, void *stream);
 
+/* replaces: uvg_mip_predict = mip_predict_generic (src/strategies/generic/intra-generic.c:579-727) with the
+ * reference rows built from the plane as in uvghip_intra_pred_batch (MRL 0): matrix-based intra prediction of n
+ * blocks of one shape (4..64 per side).  mode_transp[i] = mip_mode | transpose << 7 (modes 0..15 for 4x4, 0..7 for
+ * 4xN / Nx4 / 8x8, 0..5 otherwise).  preds_out: [n][height*width]. */
+UVGHIP_API int uvghip_mip_pred_batch(int bitdepth, const void *rec, int rec_stride, int width, int height,
+                          const uvghip_intra_blk_t *blks, int n, const uint8_t *mode_transp, void *preds_out,
+                          void *stream);
+
 /* replaces: the rough mode search loop of search_intra_rough (src/search_intra.c:986-1110)
  * = uvg_intra_predict + get_cost_dual (:133-158) per candidate, for n square luma
  * blocks of `size` (4..32) and all n_modes candidates at once:

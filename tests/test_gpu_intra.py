@@ -84,7 +84,7 @@ def test_strategy_pointers(hip, orc, depth):
     """angular_pred / intra_pred_planar / pdpc_planar_dc through the registered 'hip' pointers."""
     reg = Registry(hip)
     assert hip.uvg_strategy_register_intra_hip(None, depth) == 1
-    assert set(reg.table) == {"angular_pred", "intra_pred_planar", "pdpc_planar_dc"}
+    assert set(reg.table) == {"angular_pred", "intra_pred_planar", "pdpc_planar_dc", "mip_predict"}
     VP, I, I8, U8 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int8, ctypes.c_uint8
     ang = ctypes.CFUNCTYPE(None, VP, I8, I8, VP, VP, VP, U8, U8, I)(reg.table["angular_pred"])
     k = 0

@@ -57,6 +57,7 @@ void check_alf(void);
 void check_deblock(void);
 void check_lfnst(void);
 void check_hashvar(void);
+void check_mip(void);
 
 int main(int argc, char **argv)
 {
@@ -88,6 +89,9 @@ int main(int argc, char **argv)
   check_lfnst();
 #endif
   check_hashvar();
+#ifdef HAVE_INTRA
+  check_mip();
+#endif
   if (g_out) fclose(g_out);
   printf("refcheck %d-bit: %s (%d mismatches)\n", UVG_BIT_DEPTH, g_fail ? "FAIL" : "OK", g_fail);
   return g_fail ? 1 : 0;
@@ -119,3 +123,6 @@ int main(int argc, char **argv)
 #include "rc_lfnst.inc"
 #endif
 #include "rc_hashvar.inc"
+#ifdef HAVE_INTRA
+#include "rc_mip.inc"
+#endif

@@ -210,6 +210,16 @@ def intra_pred_batch(rec, blks, w, h, modes, is_chroma=False):
     return out
 
 
+def mip_pred_batch(rec, blks, w, h, mode_transp):
+    """Matrix-based intra prediction; mode_transp: (n,) uint8 = mip_mode | transpose << 7 -> (n, h, w) predictions."""
+    L = _lib.init(rec.device.index or 0)
+    n = blks.shape[0]
+    out = torch.empty((n, h, w), dtype=rec.dtype, device=rec.device)
+    _lib.check(L.uvghip_mip_pred_batch(_depth(rec), _dev(rec), rec.stride(0), w, h, _dev(blks), n, _dev(mode_transp), _dev(out),
+                                       _stream()), "uvghip_mip_pred_batch")
+    return out
+
+
 def intra_search_batch(rec, orig, blks, size, modes):
     """-> (n, n_modes) int32 costs min(SATD, 2*SAD)."""
     L = _lib.init(rec.device.index or 0)

@@ -1189,7 +1189,9 @@ void pdpc_planar_dc_hip(const int mode, const ref_cu_loc *cu_loc, const int colo
 
 }  // namespace
 
-// Not registered: intra_pred_filtered_dc (dead upstream), mip_predict (mip=0 in all target configs).
+int uvghip_register_mip(void *opaque, uint8_t bitdepth);   // mip.hip
+
+// Not registered: intra_pred_filtered_dc (dead upstream).
 extern "C" int uvg_strategy_register_intra_hip(void *opaque, uint8_t bitdepth)
 {
   if (!uvghip_ready() && uvghip_init(0) != 0) return 0;
@@ -1203,5 +1205,6 @@ extern "C" int uvg_strategy_register_intra_hip(void *opaque, uint8_t bitdepth)
     ok &= uvghip_do_register(opaque, "intra_pred_planar", (void *)&intra_pred_planar_hip<uint16_t>);
     ok &= uvghip_do_register(opaque, "pdpc_planar_dc", (void *)&pdpc_planar_dc_hip<uint16_t>);
   }
+  ok &= uvghip_register_mip(opaque, bitdepth);
   return ok;
 }

@@ -44,6 +44,7 @@ SIGNATURES = {
     "uvghip_tu_roundtrip_batch": (c_int, [c_int] * 9 + [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvg_strategy_register_intra_hip": (c_int, [c_vp, ctypes.c_uint8]),
     "uvghip_intra_pred_batch": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_mip_pred_batch": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvghip_intra_search_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_intra_search_best_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_intra_pred_plane_batch": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
