@@ -91,7 +91,7 @@ ORC_EXPORT void orc_lfnst_fwd(int16_t *coeffs, int width, int height, int intra_
                         : ORC_LFNST4 + ((size_t)lfnst_set_of_mode(m) * 2 + (lfnst_idx - 1)) * 16 * 16;
   for (int j = 0; j < zero_out; ++j) {
     int acc = 0;
-    for (int i = 0; i < tr_size; ++i) acc += in[i] * M[j * tr_size + i];
+    for (int i = 0; i < tr_size; ++i) acc += in[i] * M[i * 16 + j];        /* tables are input-major: [input][output] */
     out[j] = (int16_t)((acc + 64) >> 7);
   }
   for (int j = zero_out; j < tr_size; ++j) out[j] = 0;
@@ -116,7 +116,7 @@ ORC_EXPORT void orc_lfnst_inv(int16_t *coeffs, int width, int height, int intra_
                         : ORC_LFNST4 + ((size_t)lfnst_set_of_mode(m) * 2 + (lfnst_idx - 1)) * 16 * 16;
   for (int j = 0; j < tr_size; ++j) {
     int acc = 0;
-    for (int i = 0; i < zero_out; ++i) acc += in[i] * M[i * tr_size + j];
+    for (int i = 0; i < zero_out; ++i) acc += in[i] * M[j * 16 + i];        /* transposed kernel: spatial j from coefficient i */
     const int v = (acc + 64) >> 7;
     out[j] = (int16_t)v;    /* transform.c:1098 casts to coeff_t before CLIP(-2^15, 2^15-1): the clip never acts, the value wraps */
   }

@@ -68,7 +68,7 @@ ORC_EXPORT void ORC_FN(mip_predict)(const orc_px *top, const orc_px *left, int w
   int red[64], tmp[64];
   for (int k = 0; k < rp * rp; ++k) {
     int acc = 0;
-    for (int i = 0; i < in_size; ++i) acc += in[i] * M[k * in_size + i];
+    for (int i = 0; i < in_size; ++i) acc += in[i] * M[i * rp * rp + k];     /* tables are input-major: [input][output] */
     int v = ((acc + offset) >> 6) + in_off;
     tmp[k] = v < 0 ? 0 : (v > ORC_PX_MAX ? ORC_PX_MAX : v);
   }

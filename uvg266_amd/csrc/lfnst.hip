@@ -81,7 +81,7 @@ lfnst_kernel(int inverse, int16_t *__restrict__ coeffs, int width, int height, c
       int v = 0;
       if (lane < zero_out) {
         int acc = 0;
-        for (int i = 0; i < tr_size; ++i) acc += sIn[wave][i] * M[lane * tr_size + i];
+        for (int i = 0; i < tr_size; ++i) acc += sIn[wave][i] * M[i * 16 + lane];    // input-major table: [input][output]
         v = (int)(int16_t)((acc + 64) >> 7);
       }
       c[lfnst_scan_pos(lane, width)] = (int16_t)v;
@@ -91,7 +91,7 @@ lfnst_kernel(int inverse, int16_t *__restrict__ coeffs, int width, int height, c
     __syncthreads();
     if (act && lane < tr_size) {
       int acc = 0;
-      for (int i = 0; i < zero_out; ++i) acc += sIn[wave][i] * M[i * tr_size + lane];
+      for (int i = 0; i < zero_out; ++i) acc += sIn[wave][i] * M[lane * 16 + i];
       // transform.c:1098: the cast to coeff_t precedes the clip, so the value wraps to 16 bits
       c[lfnst_gather_pos(lane, width, big, transpose)] = (int16_t)((acc + 64) >> 7);
     }

@@ -51,7 +51,7 @@ __device__ __forceinline__ void mip_block(const uint16_t *top, const uint16_t *l
   if (lane < rp * rp) {
     int acc = 32 - 32 * sum;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) if (i < in_size) acc += in[i] * M[lane * in_size + i];
+    for (int i = 0; i < 8; ++i) if (i < in_size) acc += in[i] * M[i * rp * rp + lane];     // input-major table
     const int v = clampi((acc >> 6) + in_off, 0, px_traits<PX>::maxv);
     const int y = lane / rp, x = lane - y * rp;
     sRed[transpose ? x * rp + y : lane] = v;             // transposed: result (y, x) is output (x, y)
