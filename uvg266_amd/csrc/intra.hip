@@ -837,7 +837,12 @@ __host__ __device__ inline search_layout make_search_layout(int n, int bpg, int 
 #ifndef UVGHIP_SEARCH_WAVES
 #define UVGHIP_SEARCH_WAVES 8
 #endif
-template <typename PX, int T, int WAVES>
+#ifndef UVGHIP_SEARCH_BPL4
+#define UVGHIP_SEARCH_BPL4 1      // 4x4 blocks per lane (2 was measured slower: 109 vs 84 us per 1080p launch)
+#endif
+// BPL = blocks per lane (only with one tile per block): the lane evaluates BPL blocks per mode, which amortises the
+// per-mode overhead (descriptor fetch, branching, bookkeeping) that dominates for 4x4 blocks.
+template <typename PX, int T, int WAVES, int BPL>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : (WAVES == 6 ? 3 : 1))
 intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__restrict__ orig, int orig_stride,
                     int n, const uvghip_intra_blk_t *__restrict__ blks, int n_blks,
@@ -848,7 +853,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   const int lgn = ilog2_dev(n);
   const int lg_tx = lgn - (T == 8 ? 3 : 2);       // log2(tiles per block row)
   const int lg_tiles = 2 * lg_tx, tiles = 1 << lg_tiles;
-  const int bpg = 64 >> lg_tiles;
+  const int bpg = (64 * BPL) >> lg_tiles;
   const search_layout L = make_search_layout(n, bpg, n_modes, WAVES, (int)sizeof(PX));
   uint16_t *sOrig = reinterpret_cast<uint16_t *>(smem_raw + L.off_orig);
   uint32_t *sRef = reinterpret_cast<uint32_t *>(smem_raw + L.off_ref);
@@ -868,13 +873,13 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   {
     constexpr int NT = WAVES * 64;
     // staging uses the largest power-of-two share of the workgroup (8 or 4 waves): tpb threads per block
-    const int lg_tpb = lg_tiles + (WAVES == 8 ? 3 : 2), tpb = 1 << lg_tpb;
+    const int lg_tpb = lg_tiles + (WAVES == 8 ? 3 : 2) - (BPL == 2 ? 1 : 0), tpb = 1 << lg_tpb;
     const int myb = threadIdx.x >> lg_tpb, mytid = threadIdx.x & (tpb - 1);
     const bool on = myb < here;     // also false for the waves beyond the staging share (myb >= bpg)
     uint16_t *base = sScratch + (size_t)myb * 4 * L.RS;     // u16 image: top | left | ftop | fleft
     if (on) {
       const uvghip_intra_blk_t b = blks[blk0 + myb];
-      build_ref_rows_batched<PX, 5>(rec, rec_stride, b.x, b.y, b.avail_top, b.avail_left, base, base + L.RS, L.RS, mytid, tpb);
+      build_ref_rows_batched<PX, 6>(rec, rec_stride, b.x, b.y, b.avail_top, b.avail_left, base, base + L.RS, L.RS, mytid, tpb);
       // original block in 4-sample segments: segment sg = (row, 4 columns)
       uint16_t *so = sOrig + (size_t)myb * L.OS, *sot = so + nn;
       const int nseg = nn >> 2, lg_spr = lgn - 2;     // segments, log2(segments per row)
@@ -899,7 +904,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       }
     }
     for (int m = threadIdx.x; m < n_modes; m += NT) sMode[m] = pack_search_mode(make_search_mode(modes[m], n));
-    if (threadIdx.x < bpg) sBest[threadIdx.x] = 0xffffffffu;
+    for (int i = threadIdx.x; i < bpg; i += NT) sBest[i] = 0xffffffffu;
     if (threadIdx.x < 64) {
       const int df = threadIdx.x & 31;
       int f0, f1, f2, f3;
@@ -917,22 +922,26 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
     if (on) {
       // u16 image -> pair rows
       uint32_t *pr = sRef + (size_t)myb * L.BRS;
-      for (int e = mytid; e < 4 * L.RS; e += tpb) {
-        const int i = e % L.RS;
-        pr[e] = (uint32_t)base[e] | (i + 1 < L.RS ? (uint32_t)base[e + 1] << 16 : 0u);
-      }
+#pragma unroll
+      for (int row = 0; row < 4; ++row)
+        for (int i = mytid; i < L.RS; i += tpb) {
+          const int e = row * L.RS + i;
+          pr[e] = (uint32_t)base[e] | (i + 1 < L.RS ? (uint32_t)base[e + 1] << 16 : 0u);
+        }
     }
     __syncthreads();   // also: the scratch image is dead from here on, its space becomes the private strips
   }
 
   // ---- search: lane = tile, wave = mode ----
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int lb = lane >> lg_tiles, tile = lane & (tiles - 1);
-  const bool active = lb < here;
+  const int tile = lane & (tiles - 1);
+  constexpr int LB_STEP_NUM = 64;                       // block q of a lane is lb + q * (64 >> lg_tiles)
   const int maxv = px_traits<PX>::maxv;
   const int dshift = px_traits<PX>::depth - 8;
 
-  uint32_t my_best = 0xffffffffu;
+  uint32_t my_best[BPL];
+#pragma unroll
+  for (int q = 0; q < BPL; ++q) my_best[q] = 0xffffffffu;
   {
     for (int m = wave; m < n_modes; m += WAVES) {
       const uint2 pm = sMode[m];
@@ -940,9 +949,11 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       // Everything per-lane is re-derived from one opaque copy of the lane's (block, tile) each iteration: left to itself
       // LICM hoists these pointers and a dozen per-column values (xd0 | i, 2 * (xd0 | i), ...) out of the mode loop and the
       // register allocator then spills them to scratch (measured: 18 MB of scratch writes per launch)
+#pragma unroll
+      for (int q = 0; q < BPL; ++q) {
       int lane_i = lane;
       asm volatile("" : "+v"(lane_i));
-      const int lb_i = lane_i >> lg_tiles, tile_i = lane_i & (tiles - 1);
+      const int lb_i = (lane_i >> lg_tiles) + q * (LB_STEP_NUM >> lg_tiles), tile_i = lane_i & (tiles - 1);
       const int bb_i = lb_i < here ? lb_i : 0;
       const int xd0 = (tile_i & ((1 << lg_tx) - 1)) * T, yd0 = (tile_i >> lg_tx) * T;
       const uint32_t *ref = sRef + __mul24(bb_i, L.BRS);
@@ -1007,26 +1018,31 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
         }
       }
       if (neg) __builtin_amdgcn_wave_barrier();   // strip is rewritten by the next negative mode
-      if (active && tile == 0) {
+      if (lb_i < here && tile == 0) {
         // search_intra.c:158: min(SATD, 2*SAD) with the NxN strategy functions' depth shifts
         // (satd_4x4 is unshifted, picture-generic.c:170; everything else >> depth-8)
         const uint32_t c_satd = satd >> (T == 4 ? 0 : dshift);
         const uint32_t c_sad = sad >> dshift;
         const uint32_t c = min(c_satd, 2 * c_sad);
-        if (costs) costs[(size_t)(blk0 + lb) * n_modes + m] = c;
-        my_best = min(my_best, (c << 7) | (uint32_t)m);       // c < 2^25: at most 2 * 1024 samples * 255 (after the depth shift)
+        if (costs) costs[(size_t)(blk0 + lb_i) * n_modes + m] = c;
+        my_best[q] = min(my_best[q], (c << 7) | (uint32_t)m);       // c < 2^25: at most 2 * 1024 samples * 255 (after the depth shift)
       }
+      }   // q
     }
   }
   // fused arg-min (the strict "<" scan of search_intra.c:1089-1101: ties keep the earlier candidate):
   // every wave contributes the best of its share of the candidates
   if (best_mode) {
-    if (active && tile == 0) atomicMin(&sBest[lb], my_best);
+#pragma unroll
+    for (int q = 0; q < BPL; ++q) {
+      const int lb = (lane >> lg_tiles) + q * (LB_STEP_NUM >> lg_tiles);
+      if (lb < here && tile == 0) atomicMin(&sBest[lb], my_best[q]);
+    }
     __syncthreads();
-    if ((int)threadIdx.x < here) {
-      const uint32_t k = sBest[threadIdx.x];
-      best_mode[blk0 + threadIdx.x] = modes[k & 127];
-      if (best_cost) best_cost[blk0 + threadIdx.x] = k >> 7;
+    for (int i = threadIdx.x; i < here; i += WAVES * 64) {
+      const uint32_t k = sBest[i];
+      best_mode[blk0 + i] = modes[k & 127];
+      if (best_cost) best_cost[blk0 + i] = k >> 7;
     }
   }
 }
@@ -1040,18 +1056,19 @@ static int launch_intra_search(int bitdepth, const void *rec, int rec_stride, co
     return uvghip_set_error(hipErrorInvalidValue, who);
   if (n <= 0) return 0;
   const int tiles = size == 4 ? 1 : (size / 8) * (size / 8);
-  const int bpg = 64 / tiles;
+  const int bpl = size == 4 ? UVGHIP_SEARCH_BPL4 : 1;
+  const int bpg = 64 * bpl / tiles;
   const int grid = (n + bpg - 1) / bpg;
   hipStream_t st = uvghip_stream(stream);
   // 8x8 tiles: 8 waves per workgroup (two workgroups per CU = 4 waves per SIMD); 4x4: 4 waves, many workgroups
-#define LAUNCH(PX, T, W) do { const search_layout L = make_search_layout(size, bpg, n_modes, W, (int)sizeof(PX)); \
+#define LAUNCH(PX, T, W, B) do { const search_layout L = make_search_layout(size, bpg, n_modes, W, (int)sizeof(PX)); \
     static bool big_lds = false; /* allow more than the default 64 KiB of dynamic LDS, once per instantiation */ \
-    if (!big_lds) { UVGHIP_TRY(hipFuncSetAttribute((const void *)intra_search_kernel<PX, T, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); big_lds = true; } \
-    if (getenv("UVGHIP_DEBUG_OCC")) { int nb = -1; hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, intra_search_kernel<PX, T, W>, W * 64, L.total); \
+    if (!big_lds) { UVGHIP_TRY(hipFuncSetAttribute((const void *)intra_search_kernel<PX, T, W, B>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); big_lds = true; } \
+    if (getenv("UVGHIP_DEBUG_OCC")) { int nb = -1; hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, intra_search_kernel<PX, T, W, B>, W * 64, L.total); \
       fprintf(stderr, "intra_search<%d,%d,%d> size %d: lds %zu grid %d occupancy %d blocks/CU (err %d)\n", (int)sizeof(PX), T, W, size, (size_t)L.total, grid, nb, (int)oe); } \
-    intra_search_kernel<PX, T, W><<<grid, W * 64, L.total, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, blks, n, modes, n_modes, costs, best_mode, best_cost); } while (0)
-  if (bitdepth == 8) { if (size == 4) LAUNCH(uint8_t, 4, 4); else LAUNCH(uint8_t, 8, UVGHIP_SEARCH_WAVES); }
-  else { if (size == 4) LAUNCH(uint16_t, 4, 4); else LAUNCH(uint16_t, 8, UVGHIP_SEARCH_WAVES); }
+    intra_search_kernel<PX, T, W, B><<<grid, W * 64, L.total, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, blks, n, modes, n_modes, costs, best_mode, best_cost); } while (0)
+  if (bitdepth == 8) { if (size == 4) LAUNCH(uint8_t, 4, 4, UVGHIP_SEARCH_BPL4); else LAUNCH(uint8_t, 8, UVGHIP_SEARCH_WAVES, 1); }
+  else { if (size == 4) LAUNCH(uint16_t, 4, 4, UVGHIP_SEARCH_BPL4); else LAUNCH(uint16_t, 8, UVGHIP_SEARCH_WAVES, 1); }
 #undef LAUNCH
   UVGHIP_CHECK_LAUNCH();
 }
