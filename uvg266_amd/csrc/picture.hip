@@ -314,6 +314,70 @@ sad_surface_kernel(const PX *__restrict__ cur, int cs, const PX *__restrict__ re
   }
 }
 
+// 8-bit fast path: v_qsad_pk_u16_u8.  One QSAD takes 8 consecutive reference bytes and 4 current bytes and returns the
+// four SADs at byte offsets 0..3 -- four neighbouring candidates of a 4-sample segment per instruction -- accumulated
+// in four packed u16.  A lane owns (dy, group of four dx): per block row it reads bw/4 + 1 aligned reference dwords of
+// window row y + dy and bw/4 current dwords (the same address for every lane: a broadcast), and issues bw/4 QSADs.
+// 64 QSADs can add at most 64 * 4 * 255 = 65280 to a u16 lane, so the packed sums are folded into 32-bit totals every
+// 64 instructions.  All LDS reads are aligned dwords; candidates that differ by a sub-dword shift never cost an
+// unaligned access.
+template <int BW>
+__global__ void __launch_bounds__(128)
+sad_surface_qsad_kernel(const uint8_t *__restrict__ cur, int cs, const uint8_t *__restrict__ ref, int rs, int W, int H,
+                        int bh, int range, int blocks_x, uint32_t *__restrict__ out)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int SEG = BW / 4;
+  const int side = 2 * range + 1, groups = (side + 3) >> 2;
+  const int ww = BW + 2 * range, wh = bh + 2 * range;
+  const int pitch = ((ww + 3) >> 2) + 2;                 // dwords per window row (+ the dword a QSAD window may run into)
+  uint32_t *win = reinterpret_cast<uint32_t *>(smem_raw);
+  uint32_t *blk = win + (size_t)pitch * wh;              // bh rows of SEG dwords
+  const int bidx = blockIdx.x;
+  const int by = (bidx / blocks_x) * bh, bx = (bidx % blocks_x) * BW;
+  // stage the window with edge replication (= uvg_image_calc_sad's border handling), one dword per thread and step
+  for (int i = threadIdx.x; i < pitch * wh; i += blockDim.x) {
+    const int y = i / pitch, xd = i - y * pitch;
+    const uint8_t *row = ref + (size_t)clampi(by - range + y, 0, H - 1) * rs;
+    const int x = bx - range + 4 * xd;
+    uint32_t v;
+    if (x >= 0 && x + 3 < W) v = *reinterpret_cast<const u32_unaligned *>(row + x);
+    else v = (uint32_t)row[clampi(x, 0, W - 1)] | ((uint32_t)row[clampi(x + 1, 0, W - 1)] << 8) |
+             ((uint32_t)row[clampi(x + 2, 0, W - 1)] << 16) | ((uint32_t)row[clampi(x + 3, 0, W - 1)] << 24);
+    win[i] = v;
+  }
+  for (int i = threadIdx.x; i < SEG * bh; i += blockDim.x) {
+    const int y = i / SEG, s = i - y * SEG;
+    blk[i] = *reinterpret_cast<const u32_unaligned *>(cur + (size_t)(by + y) * cs + bx + 4 * s);
+  }
+  __syncthreads();
+  const int ntasks = side * groups;
+  for (int t = threadIdx.x; t < ntasks; t += blockDim.x) {
+    const int dy = t / groups, g = t - dy * groups;
+    uint32_t tot[4] = {0, 0, 0, 0};
+    unsigned long long acc = 0;
+    int since = 0;
+    for (int y = 0; y < bh; ++y) {
+      const uint32_t *wr = win + (size_t)(y + dy) * pitch + g;
+      uint32_t d[SEG + 1];
+#pragma unroll
+      for (int k = 0; k <= SEG; ++k) d[k] = wr[k];
+#pragma unroll
+      for (int sgm = 0; sgm < SEG; ++sgm)
+        acc = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)d[sgm + 1] << 32) | d[sgm], blk[y * SEG + sgm], acc);
+      since += SEG;
+      if (since + SEG > 64 || y == bh - 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tot[k] += (uint32_t)(acc >> (16 * k)) & 0xffffu;
+        acc = 0; since = 0;
+      }
+    }
+    uint32_t *o = out + ((size_t)bidx * side + dy) * side + 4 * g;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (4 * g + k < side) o[k] = tot[k];
+  }
+}
+
 extern "C" int uvghip_sad_surface(int bitdepth, const void *cur, int cur_stride, const void *ref, int ref_stride,
                                   int w, int h, int bw, int bh, int range, uint32_t *out, void *stream)
 {
@@ -325,6 +389,17 @@ extern "C" int uvghip_sad_surface(int bitdepth, const void *cur, int cur_stride,
   const size_t lds = ((size_t)(bw + 2 * range + 1) * (bh + 2 * range) + (size_t)bw * bh) * es;
   if (lds > 160 * 1024) return uvghip_set_error(hipErrorInvalidValue, "uvghip_sad_surface: window exceeds LDS");
   hipStream_t st = uvghip_stream(stream);
+  if (bitdepth == 8 && (bw == 8 || bw == 16 || bw == 32 || bw == 64)) {
+    const size_t pitch = (size_t)((bw + 2 * range + 3) / 4 + 2);
+    const size_t ql = (pitch * (bh + 2 * range) + (size_t)(bw / 4) * bh) * 4;
+    if (ql <= 64 * 1024) {
+      const int nb = blocks_x * blocks_y;
+#define QS(BWV) sad_surface_qsad_kernel<BWV><<<nb, 128, ql, st>>>((const uint8_t *)cur, cur_stride, (const uint8_t *)ref, ref_stride, w, h, bh, range, blocks_x, out)
+      if (bw == 8) QS(8); else if (bw == 16) QS(16); else if (bw == 32) QS(32); else QS(64);
+#undef QS
+      UVGHIP_CHECK_LAUNCH();
+    }
+  }
   if (bitdepth == 8) {
     if (lds > 64 * 1024) UVGHIP_TRY(hipFuncSetAttribute((const void *)sad_surface_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     sad_surface_kernel<uint8_t><<<blocks_x * blocks_y, 256, lds, st>>>((const uint8_t *)cur, cur_stride, (const uint8_t *)ref, ref_stride, w, h, bw, bh, range, blocks_x, out, 0);
