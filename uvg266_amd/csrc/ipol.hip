@@ -16,6 +16,7 @@
 #include "uvghip_common.h"
 #include "percall.h"
 #include "satd_dev.h"
+#include "satd_tile_dev.h"
 #include "vvc_tables.h"
 
 // Stage ref[(y0+yy), (x0+xx)] for yy < wh, xx < ww into LDS (pitch wp), clamped to the picture.
@@ -141,6 +142,112 @@ frac_satd_kernel(const PX *__restrict__ cur, int cur_stride, const PX *__restric
   }
 }
 
+// ---- fractional ME, tile per lane (blocks whose sides are multiples of 8) ----------------------------------------
+// A lane owns one (block, 8x8 tile, candidate): it filters its tile's 15 x 8 horizontal intermediates row by row
+// (window rows in LDS as dword pair rows, so the eight taps of an output are four aligned dwords feeding v_dot2),
+// scatters each finished pair of intermediate rows into the 64 vertical accumulators (again v_dot2 on row pairs),
+// rounds/clips the 64 predicted samples, subtracts the current tile and runs the Hadamard in its own registers
+// (satd_tile_dev.h).  Lanes of a wave work on different candidates and tiles: the filter phases are per-lane data
+// (coefficient pairs from an LDS table), not control flow, so there is no divergence and no barrier after staging.
+template <typename PX>
+__global__ void __launch_bounds__(256)
+frac_satd_tile_kernel(const PX *__restrict__ cur, int cur_stride, const PX *__restrict__ ref, int ref_stride, int pic_w, int pic_h,
+                      int w, int h, const uvghip_blk_t *__restrict__ blks, int n, int bpw, const int16_t *__restrict__ cands,
+                      int n_cand, uint32_t *__restrict__ costs)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem32[];
+  constexpr int depth = px_traits<PX>::depth;
+  const int ww = w + 8, wh = h + 8;                     // window samples per row / rows; dword i of a row = (s[i], s[i+1])
+  const int tiles_x = w >> 3, tiles = tiles_x * (h >> 3);
+  uint32_t *sWin = smem32;                               // [bpw][wh][ww]
+  uint32_t *sCur = sWin + (size_t)bpw * wh * ww;         // [bpw][h][w/2] packed pairs
+  uint32_t *sCoef = sCur + (size_t)bpw * h * (w >> 1);   // [16 phases][4 pairs]
+  uint32_t *sCost = sCoef + 64;                          // [bpw][n_cand]
+  const int blk0 = blockIdx.x * bpw;
+  const int here = min(bpw, n - blk0);
+  for (int i = threadIdx.x; i < here * wh * ww; i += 256) {
+    const int b = i / (wh * ww), r = i - b * (wh * ww), y = r / ww, x = r - y * ww;
+    const uvghip_blk_t B = blks[blk0 + b];
+    const PX *row = ref + (size_t)clampi(B.ref_y - 4 + y, 0, pic_h - 1) * ref_stride;
+    sWin[i] = (uint32_t)row[clampi(B.ref_x - 4 + x, 0, pic_w - 1)] | ((uint32_t)row[clampi(B.ref_x - 4 + x + 1, 0, pic_w - 1)] << 16);
+  }
+  for (int i = threadIdx.x; i < here * h * (w >> 1); i += 256) {
+    const int b = i / (h * (w >> 1)), r = i - b * (h * (w >> 1)), y = r / (w >> 1), x2 = r - y * (w >> 1);
+    const uvghip_blk_t B = blks[blk0 + b];
+    const PX *p = cur + (size_t)(B.cur_y + y) * cur_stride + B.cur_x + 2 * x2;
+    sCur[i] = (uint32_t)p[0] | ((uint32_t)p[1] << 16);
+  }
+  if (threadIdx.x < 64) {
+    const int ph = threadIdx.x >> 2, m = threadIdx.x & 3;
+    sCoef[threadIdx.x] = (uint32_t)(uint16_t)(int16_t)VVC_LUMA_FILTER[8 * ph + 2 * m] | ((uint32_t)(uint16_t)(int16_t)VVC_LUMA_FILTER[8 * ph + 2 * m + 1] << 16);
+  }
+  for (int i = threadIdx.x; i < bpw * n_cand; i += 256) sCost[i] = 0;
+  __syncthreads();
+
+  const int wp_shift = 14 - depth, wp_off = 1 << (wp_shift - 1);
+  const pk_s16 vmax = {(short)px_traits<PX>::maxv, (short)px_traits<PX>::maxv};
+  const int per_blk = tiles * n_cand, ntasks = here * per_blk;
+  for (int task = threadIdx.x; task < ntasks; task += 256) {
+    const int b = task / per_blk, r0 = task - b * per_blk, c = r0 / tiles, t = r0 - c * tiles;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int mvx = cands[2 * c], mvy = cands[2 * c + 1];
+    const int ix = mvx >> 4, iy = mvy >> 4;                                       // -1 or 0 (|mv| < 16)
+    uint32_t fh[4], fv[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { fh[m] = sCoef[(mvx & 15) * 4 + m]; fv[m] = sCoef[(mvy & 15) * 4 + m]; }
+    const uint32_t *wbase = sWin + ((size_t)b * wh + (ty * 8 + 1 + iy)) * ww + tx * 8 + 1 + ix;
+    int acc[8][8];
+#pragma unroll
+    for (int yy = 0; yy < 8; ++yy)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[yy][j] = 0;
+    int prev[8];
+#pragma unroll
+    for (int r = 0; r < 15; ++r) {
+      const uint32_t *wr = wbase + r * ww;
+      uint32_t P[14];
+#pragma unroll
+      for (int k = 0; k < 14; ++k) P[k] = wr[k];
+      int hcur[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int a = 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a = __builtin_amdgcn_sdot2(__builtin_bit_cast(pk_s16, P[j + 2 * m]), __builtin_bit_cast(pk_s16, fh[m]), a, false);
+        hcur[j] = (int)(int16_t)(a >> (depth - 8));                               // ipol-generic.c:170 (int16 intermediates)
+      }
+      if (r >= 1) {
+        // row pair (r-1, r) carries taps (2m, 2m+1) of output row yy = r - 1 - 2m
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const pk_s16 pr = __builtin_bit_cast(pk_s16, __builtin_amdgcn_perm((uint32_t)hcur[j], (uint32_t)prev[j], 0x05040100u));
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int yy = r - 1 - 2 * m;
+            if (yy >= 0 && yy < 8) acc[yy][j] = __builtin_amdgcn_sdot2(pr, __builtin_bit_cast(pk_s16, fv[m]), acc[yy][j], false);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) prev[j] = hcur[j];
+    }
+    uint32_t d[8][4];
+    const uint32_t *cb = sCur + ((size_t)b * h + ty * 8) * (w >> 1) + tx * 4;
+#pragma unroll
+    for (int yy = 0; yy < 8; ++yy)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int p0 = ((acc[yy][2 * q] >> 6) + wp_off) >> wp_shift, p1 = ((acc[yy][2 * q + 1] >> 6) + wp_off) >> wp_shift;
+        pk_s16 v = __builtin_bit_cast(pk_s16, __builtin_amdgcn_perm((uint32_t)p1, (uint32_t)p0, 0x05040100u));
+        v = __builtin_elementwise_min(__builtin_elementwise_max(v, (pk_s16){0, 0}), vmax);
+        d[yy][q] = pk_sub(cb[yy * (w >> 1) + q], __builtin_bit_cast(uint32_t, v));
+      }
+    atomicAdd(&sCost[b * n_cand + c], satd8_tile_lane(d));
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < here * n_cand; i += 256) costs[(size_t)blk0 * n_cand + i] = sCost[i] >> (depth - 8);
+}
+
 extern "C" int uvghip_frac_satd_batch(int bitdepth, const void *cur, int cur_stride, const void *ref, int ref_stride,
                                       int pic_w, int pic_h, int width, int height, const uvghip_blk_t *blks, int n,
                                       const int16_t *cand_mv, int n_cand, uint32_t *costs, void *stream)
@@ -149,8 +256,23 @@ extern "C" int uvghip_frac_satd_batch(int bitdepth, const void *cur, int cur_str
   if (width < 4 || height < 4 || (width & 3) || (height & 3) || width > 64 || height > 64 || n_cand < 1)
     return uvghip_set_error(hipErrorInvalidValue, __func__);
   if (n <= 0) return 0;
-  const size_t lds = ((size_t)(width + 9) * (height + 8) + (size_t)(height + 7) * width + (size_t)width * height) * 2;
   hipStream_t st = uvghip_stream(stream);
+  if ((width & 7) == 0 && (height & 7) == 0 && n_cand <= 64) {
+    const int tiles = (width / 8) * (height / 8);
+    int bpw = 256 / (tiles * n_cand); if (bpw < 1) bpw = 1; if (bpw > 16) bpw = 16;
+    const size_t per_blk = (size_t)(width + 8) * (height + 8) * 4 + (size_t)height * (width / 2) * 4 + (size_t)n_cand * 4;
+    while (bpw > 1 && bpw * per_blk + 256 > 60 * 1024) --bpw;
+    const size_t tl = bpw * per_blk + 256;
+    if (tl <= 64 * 1024) {
+      const int grid = (n + bpw - 1) / bpw;
+      if (bitdepth == 8)
+        frac_satd_tile_kernel<uint8_t><<<grid, 256, tl, st>>>((const uint8_t *)cur, cur_stride, (const uint8_t *)ref, ref_stride, pic_w, pic_h, width, height, blks, n, bpw, cand_mv, n_cand, costs);
+      else
+        frac_satd_tile_kernel<uint16_t><<<grid, 256, tl, st>>>((const uint16_t *)cur, cur_stride, (const uint16_t *)ref, ref_stride, pic_w, pic_h, width, height, blks, n, bpw, cand_mv, n_cand, costs);
+      UVGHIP_CHECK_LAUNCH();
+    }
+  }
+  const size_t lds = ((size_t)(width + 9) * (height + 8) + (size_t)(height + 7) * width + (size_t)width * height) * 2;
   if (bitdepth == 8)
     frac_satd_kernel<uint8_t><<<n, 256, lds, st>>>((const uint8_t *)cur, cur_stride, (const uint8_t *)ref, ref_stride, pic_w, pic_h, width, height, blks, cand_mv, n_cand, costs);
   else
