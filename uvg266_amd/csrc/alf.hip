@@ -224,6 +224,7 @@ __device__ inline void covariance_sample(int16_t *e /*[13][4]*/, const PX *rec, 
     for (int b = 0; b < 4; ++b) e[kk * 4 + b] = (int16_t)acc[kk][b];
 }
 
+#define ALF_SPLIT 4
 template <typename PX, bool CHROMA>
 __global__ void __launch_bounds__(128)
 alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__ rec, int rstride, int pic_w, int pic_h,
@@ -237,13 +238,13 @@ alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__
   __shared__ __attribute__((aligned(16))) int16_t sE[256 * 52];
   __shared__ int16_t sY[256];
   __shared__ uint8_t sCls[64];
-  const uvghip_rect_t R = rects[blockIdx.x];
-  long long *E = ee + (size_t)blockIdx.x * NCLS * 13 * 13 * 16;
-  int32_t *Y = yv + (size_t)blockIdx.x * NCLS * 13 * 4;
-  long long *PA = pix + (size_t)blockIdx.x * NCLS;
-  for (int i = threadIdx.x; i < NCLS * 13 * 13 * 16; i += blockDim.x) E[i] = 0;
-  for (int i = threadIdx.x; i < NCLS * 52; i += blockDim.x) Y[i] = 0;
-  for (int i = threadIdx.x; i < NCLS; i += blockDim.x) PA[i] = 0;
+  // ALF_SPLIT workgroups share one rectangle (each takes a contiguous run of the class-sorted blocks); the outputs are zeroed by the
+  // host wrapper and every flush is an atomic add
+  const int rect_i = blockIdx.x / ALF_SPLIT, part = blockIdx.x % ALF_SPLIT;
+  const uvghip_rect_t R = rects[rect_i];
+  long long *E = ee + (size_t)rect_i * NCLS * 13 * 13 * 16;
+  int32_t *Y = yv + (size_t)rect_i * NCLS * 13 * 4;
+  long long *PA = pix + (size_t)rect_i * NCLS;
   int clipv[4];
   clipv[0] = 1 << DEPTH;
 #pragma unroll
@@ -259,7 +260,7 @@ alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0;
   int cur_cls = -1;
-  __syncthreads();   // zero-fill visible before any flush (same thread owns the same entries, but keep it simple)
+  __syncthreads();
 
   auto flush = [&]() {
     if (cur_cls < 0) return;
@@ -270,62 +271,97 @@ alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__
       for (int b0 = 0; b0 < 4; ++b0)
 #pragma unroll
         for (int b1 = 0; b1 < 4; ++b1) {
-          e0[b0 * 4 + b1] += acc[b0 * 4 + b1];
-          if (pk != pl) e1[b1 * 4 + b0] += acc[b0 * 4 + b1];     // mirrored lower triangle (alf-generic.c:982-996)
+          if (acc[b0 * 4 + b1] == 0) continue;
+          atomicAdd(reinterpret_cast<unsigned long long *>(e0 + b0 * 4 + b1), (unsigned long long)acc[b0 * 4 + b1]);
+          if (pk != pl) atomicAdd(reinterpret_cast<unsigned long long *>(e1 + b1 * 4 + b0), (unsigned long long)acc[b0 * 4 + b1]);     // mirrored lower triangle (alf-generic.c:982-996)
         }
     } else if (is_y) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) Y[(cur_cls * 13 + yk) * 4 + b] += (int32_t)acc[b];
+      for (int b = 0; b < 4; ++b) if (acc[b]) atomicAdd(&Y[(cur_cls * 13 + yk) * 4 + b], (int32_t)acc[b]);
     } else if (is_pix) {
-      PA[cur_cls] += acc[0];
+      if (acc[0]) atomicAdd(reinterpret_cast<unsigned long long *>(&PA[cur_cls]), (unsigned long long)acc[0]);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0;
   };
 
-  const int bw = (R.w + 3) / 4;      // 4x4 blocks per strip
-  for (int sy = 0; sy < R.h; sy += 4) {
-    const int rows = min(4, R.h - sy);
-    // ---- phase A: tap sums of every sample of the strip ----
-    for (int i = t; i < rows * R.w; i += blockDim.x) {
-      const int yy = i / R.w, xx = i - yy * R.w;
-      const int x = R.x + xx, y = R.y + sy + yy;
-      int tr = 0;
-      if constexpr (!CHROMA) tr = cls[(y >> 2) * cls_stride + (x >> 2)] >> 5;
-      covariance_sample<PX, CHROMA>(sE + (size_t)(yy * R.w + xx) * 52, rec, rstride, pic_w, pic_h, x, y, tr, (y % vbh) - vb_pos, clipv);
-      sY[yy * R.w + xx] = (int16_t)((int)org[(size_t)y * ostride + x] - (int)rec[(size_t)y * rstride + x]);
+  // The rectangle's 4x4 blocks are walked in class order (counting sort in LDS): the per-thread accumulators then change
+  // class at most 25 times per rectangle instead of at nearly every block, and every change costs a read-modify-write
+  // of the thread's 2 x 16 covariance entries in global memory.  Sums are integers, so the order does not matter.
+  __shared__ uint8_t sBlkCls[256], sOrder[256];
+  __shared__ int sCnt[32], sPos[32];
+  const int bw = (R.w + 3) / 4, bhh = (R.h + 3) / 4, nblk = bw * bhh;      // <= 256 (rectangles are at most 64x64)
+  if (t < 32) sCnt[t] = 0;
+  __syncthreads();
+  for (int i = t; i < nblk; i += blockDim.x) {
+    const int by = i / bw, bx = i - by * bw;
+    const int c = CHROMA ? 0 : (cls[((R.y >> 2) + by) * cls_stride + (R.x >> 2) + bx] & 31);
+    sBlkCls[i] = (uint8_t)c;
+    atomicAdd(&sCnt[c], 1);
+  }
+  __syncthreads();
+  if (t == 0) { int run = 0; for (int c = 0; c < 32; ++c) { sPos[c] = run; run += sCnt[c]; } }
+  __syncthreads();
+  // stable placement (rank among the earlier blocks of the same class): every workgroup of the rectangle must derive
+  // the same order, an atomic cursor would not
+  for (int i = t; i < nblk; i += blockDim.x) {
+    const int c = sBlkCls[i];
+    int rank = 0;
+    for (int j = 0; j < i; ++j) rank += sBlkCls[j] == c;
+    sOrder[sPos[c] + rank] = (uint8_t)i;
+  }
+  __syncthreads();
+
+  // contiguous share of the class-sorted list: a workgroup meets only a few classes, so it flushes only a few times
+  const int nchunks = (nblk + 15) >> 4, per_part = (nchunks + ALF_SPLIT - 1) / ALF_SPLIT;
+  for (int c0 = part * per_part * 16; c0 < min(nblk, (part + 1) * per_part * 16); c0 += 16) {
+    const int nb = min(16, nblk - c0);
+    // ---- phase A: tap sums of every sample of the chunk's blocks (slot = block j of the chunk, sample p of the block) ----
+    for (int i = t; i < nb * 16; i += blockDim.x) {
+      const int j = i >> 4, p = i & 15, blk = sOrder[c0 + j];
+      const int by = blk / bw, bx = blk - by * bw;
+      const int xx = bx * 4 + (p & 3), yy = by * 4 + (p >> 2);
+      if (xx < R.w && yy < R.h) {
+        const int x = R.x + xx, y = R.y + yy;
+        int tr = 0;
+        if constexpr (!CHROMA) tr = cls[(y >> 2) * cls_stride + (x >> 2)] >> 5;
+        covariance_sample<PX, CHROMA>(sE + (size_t)i * 52, rec, rstride, pic_w, pic_h, x, y, tr, (y % vbh) - vb_pos, clipv);
+        sY[i] = (int16_t)((int)org[(size_t)y * ostride + x] - (int)rec[(size_t)y * rstride + x]);
+      } else {
+        // sample outside the rectangle: contributes nothing
+#pragma unroll
+        for (int q = 0; q < 52; ++q) sE[(size_t)i * 52 + q] = 0;
+        sY[i] = 0;
+      }
     }
-    if (t < bw) sCls[t] = CHROMA ? 0 : (cls[((R.y + sy) >> 2) * cls_stride + ((R.x >> 2) + t)] & 31);
+    if (t < nb) sCls[t] = sBlkCls[sOrder[c0 + t]];
     __syncthreads();
     // ---- phase B: outer products, block by block ----
     if (is_pair || is_y || is_pix) {
-      for (int b = 0; b < bw; ++b) {
-        const int c = sCls[b];
+      for (int j = 0; j < nb; ++j) {
+        const int c = sCls[j];
         if (c != cur_cls) { flush(); cur_cls = c; }
         int part[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) part[i] = 0;
-        const int x1 = min(4, R.w - b * 4);
-        for (int yy = 0; yy < rows; ++yy)
-          for (int xx = 0; xx < x1; ++xx) {
-            const int p = yy * R.w + b * 4 + xx;
-            const int16_t *e = sE + (size_t)p * 52;
-            if (is_pair) {
-              const short4 ek = *reinterpret_cast<const short4 *>(e + pk * 4), el = *reinterpret_cast<const short4 *>(e + pl * 4);
-              const int a[4] = {ek.x, ek.y, ek.z, ek.w}, bb[4] = {el.x, el.y, el.z, el.w};
+        for (int p = j * 16; p < j * 16 + 16; ++p) {
+          const int16_t *e = sE + (size_t)p * 52;
+          if (is_pair) {
+            const short4 ek = *reinterpret_cast<const short4 *>(e + pk * 4), el = *reinterpret_cast<const short4 *>(e + pl * 4);
+            const int a[4] = {ek.x, ek.y, ek.z, ek.w}, bb[4] = {el.x, el.y, el.z, el.w};
 #pragma unroll
-              for (int b0 = 0; b0 < 4; ++b0)
+            for (int b0 = 0; b0 < 4; ++b0)
 #pragma unroll
-                for (int b1 = 0; b1 < 4; ++b1) part[b0 * 4 + b1] += a[b0] * bb[b1];
-            } else if (is_y) {
-              const short4 ek = *reinterpret_cast<const short4 *>(e + yk * 4);
-              const int yl = sY[p];
-              part[0] += ek.x * yl; part[1] += ek.y * yl; part[2] += ek.z * yl; part[3] += ek.w * yl;
-            } else {
-              const int yl = sY[p];
-              part[0] += yl * yl;
-            }
+              for (int b1 = 0; b1 < 4; ++b1) part[b0 * 4 + b1] += a[b0] * bb[b1];
+          } else if (is_y) {
+            const short4 ek = *reinterpret_cast<const short4 *>(e + yk * 4);
+            const int yl = sY[p];
+            part[0] += ek.x * yl; part[1] += ek.y * yl; part[2] += ek.z * yl; part[3] += ek.w * yl;
+          } else {
+            const int yl = sY[p];
+            part[0] += yl * yl;
           }
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] += part[i];
       }
@@ -342,7 +378,11 @@ extern "C" int uvghip_alf_stats_batch(int bitdepth, const void *org, int org_str
   UVGHIP_REQUIRE_READY();
   if (n <= 0) return 0;
   hipStream_t st = uvghip_stream(stream);
-#define K(PX, C) alf_stats_kernel<PX, C><<<n, 128, 0, st>>>((const PX *)org, org_stride, (const PX *)rec, rec_stride, pic_w, pic_h, rects, cls, cls_stride, (long long *)ee, y, (long long *)pix_acc)
+  const int ncls = is_chroma ? 1 : 25;
+  UVGHIP_TRY(hipMemsetAsync(ee, 0, (size_t)n * ncls * 13 * 13 * 16 * 8, st));
+  UVGHIP_TRY(hipMemsetAsync(y, 0, (size_t)n * ncls * 13 * 4 * 4, st));
+  UVGHIP_TRY(hipMemsetAsync(pix_acc, 0, (size_t)n * ncls * 8, st));
+#define K(PX, C) alf_stats_kernel<PX, C><<<n * ALF_SPLIT, 128, 0, st>>>((const PX *)org, org_stride, (const PX *)rec, rec_stride, pic_w, pic_h, rects, cls, cls_stride, (long long *)ee, y, (long long *)pix_acc)
   if (bitdepth == 8) { if (is_chroma) K(uint8_t, true); else K(uint8_t, false); }
   else { if (is_chroma) K(uint16_t, true); else K(uint16_t, false); }
 #undef K
