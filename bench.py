@@ -262,6 +262,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one stream: no overlap between block sizes / frames")
+    ap.add_argument("--stream-sets", type=int, default=2, help="sets of per-block-size streams (frames alternate between them)")
     ap.add_argument("--profile-steps", type=int, default=4, help="untimed, fully instrumented steps for the per-kernel table")
     args = ap.parse_args()
 
@@ -286,10 +287,13 @@ def main():
     frames = [Frame(rank + k * world, device, L, modes_dev) for k in range(n_resident)]
     clock = KernelClock()
     main_stream = torch.cuda.current_stream()
-    side = None if args.serial else [torch.cuda.Stream(device=device) for _ in SIZES]
+    # two sets of side streams: consecutive frames use different sets, so the searches of frame f+1 can start while
+    # the chains of frame f are still draining
+    side_sets = None if args.serial else [[torch.cuda.Stream(device=device) for _ in SIZES] for _ in range(args.stream_sets)]
+    side = None if args.serial else side_sets[0]
 
     for s in range(args.warmup):
-        hot_path_step(frames[s % n_resident], clock, False, main_stream, side)
+        hot_path_step(frames[s % n_resident], clock, False, main_stream, side_sets[s % len(side_sets)] if side_sets else None)
     torch.cuda.synchronize()
 
     # untimed profile pass: every kernel bracketed by HIP events -> per-kernel breakdown and the dominant family
@@ -310,7 +314,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        hot_path_step(frames[s % n_resident], clock, True, main_stream, side)
+        hot_path_step(frames[s % n_resident], clock, True, main_stream, side_sets[s % len(side_sets)] if side_sets else None)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -347,7 +351,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": WORKLOAD, "mpixels_per_s": round(fps * W * H / 1e6, 1), "qp": QP,
                        "parallelism": f"frames sharded over {world} rank(s), no data-path collective",
-                       "streams": 1 if args.serial else 1 + len(SIZES)},
+                       "streams": 1 if args.serial else 1 + len(SIZES) * args.stream_sets},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": live[dom]["gbs"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(live[dom]["gbs"] / HBM_PEAK_GBS, 5), "traffic": TRAFFIC.get(dom),
                          "avg_launch_ms": live[dom]["avg_ms"], "alg_bytes_per_launch": live[dom]["alg_bytes"],
