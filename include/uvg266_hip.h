@@ -69,6 +69,7 @@ UVGHIP_API int uvg_strategy_register_dct_hip(void *opaque, uint8_t bitdepth);   
 UVGHIP_API int uvg_strategy_register_intra_hip(void *opaque, uint8_t bitdepth);   /* strategies-intra.h:81-103 */
 UVGHIP_API int uvg_strategy_register_sao_hip(void *opaque, uint8_t bitdepth);     /* strategies-sao.h:66-82    */
 UVGHIP_API int uvg_strategy_register_quant_hip(void *opaque, uint8_t bitdepth);   /* strategies-quant.h:93-111 (state-free functions only) */
+UVGHIP_API int uvg_strategy_register_ipol_hip(void *opaque, uint8_t bitdepth);    /* strategies-ipol.h:116-139 (all but get_extended_block*) */
 
 /* -------------------------------------------- (2) batched ABI: picture -- */
 

@@ -101,3 +101,81 @@ def test_full_size_shift_property(hip):
     cands = np.array([[0, 0], [-8, 0], [8, 0], [-12, 0], [-4, 0]], np.int16)
     c = api.frac_satd_batch(dev(cur), dev(ref), api.make_blocks(cxy, cxy - [1, 0]), 16, 16, dev(cands))
     assert int(c[:, 0].sum()) == 0 and int(c[:, 1:].min()) > 0
+
+
+def _ipol_registry(hip, depth):
+    from test_gpu_picture import Registry
+    reg = Registry(hip)
+    assert hip.uvg_strategy_register_ipol_hip(None, depth) == 1
+    assert set(reg.table) == {"filter_hpel_blocks_hor_ver_luma", "filter_hpel_blocks_diag_luma",
+                              "filter_qpel_blocks_hor_ver_luma", "filter_qpel_blocks_diag_luma",
+                              "sample_quarterpel_luma", "sample_octpel_chroma",
+                              "sample_quarterpel_luma_hi", "sample_octpel_chroma_hi"}
+    return reg
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_registered_sample_functions(hip, orc, depth):
+    """sample_quarterpel_luma / sample_octpel_chroma (+ _hi) through the registered 'hip' pointers
+    (typedefs strategies-ipol.h:95-114): src points into a caller-padded block, dst is strided."""
+    import ctypes
+    reg = _ipol_registry(hip, depth)
+    VP, I, I16, I8 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int16, ctypes.c_int8
+    sig = ctypes.CFUNCTYPE(None, VP, VP, I16, I, I, VP, I16, I8, I8, VP)
+    rng = np.random.default_rng(depth)
+    PH, PW = 90, 100
+    plane = rand_plane(rng, PH, PW, depth)
+    es = plane.itemsize
+    for name, chroma, hi in (("sample_quarterpel_luma", False, False), ("sample_octpel_chroma", True, False),
+                             ("sample_quarterpel_luma_hi", False, True), ("sample_octpel_chroma_hi", True, True)):
+        f = sig(reg.table[name])
+        for (w, h) in ((8, 8), (16, 4), (4, 16), (64, 64), (32, 16), (2, 2) if chroma else (12, 12)):
+            x0, y0 = int(rng.integers(4, PW - w - 5)), int(rng.integers(4, PH - h - 5))
+            mv = np.array(rng.integers(-200, 200, 2), np.int32)
+            ds = w + 5
+            dst = np.full((h, ds), -7 if hi else 3, np.int16 if hi else plane.dtype)
+            f(None, plane.ctypes.data + (y0 * PW + x0) * es, PW, w, h, H.ptr(dst), ds, 1, 1, H.ptr(mv))
+            mask = 31 if chroma else 15
+            want = orc.ipol_sample(depth, plane, PW, PH, x0, y0, w, h, int(mv[0]) & mask, int(mv[1]) & mask, chroma, hi)
+            assert np.array_equal(dst[:, :w].ravel(), want), (name, w, h)
+            assert np.all(dst[:, w:] == (-7 if hi else 3))          # nothing written beyond the block
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_registered_fme_blocks_vs_reference_costs(hip, orc, depth):
+    """filter_{hpel,qpel}_blocks_* through the registered pointers, called in search_frac's order
+    (search_inter.c:1142-1166) on the reference-dumped cases: the SATD of each returned candidate block must
+    equal the cost the reference got from its own generic functions; the blocks also equal the oracle's samples."""
+    import ctypes
+    reg = _ipol_registry(hip, depth)
+    VP, I, I16, I8 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int16, ctypes.c_int8
+    sig = ctypes.CFUNCTYPE(None, VP, VP, I16, I, I, VP, VP, I8, VP, I8, I8)
+    steps = [sig(reg.table[n]) for n in ("filter_hpel_blocks_hor_ver_luma", "filter_hpel_blocks_diag_luma",
+                                         "filter_qpel_blocks_hor_ver_luma", "filter_qpel_blocks_diag_luma")]
+    seen = 0
+    for name, arrs in H.read_golden("ipol", depth):
+        if name != "fme":
+            continue
+        (PW, PH, bx, by, w, h), plane, cur, cands, costs = arrs
+        PW, PH, bx, by, w, h = (int(v) for v in (PW, PH, bx, by, w, h))
+        plane = plane.reshape(PH, PW)
+        cands = cands.reshape(16, 2).astype(int)
+        # what uvg_get_extended_block hands to search_frac: block + 1-sample ME border + 3/4 filter pad, edges replicated
+        ys = np.clip(np.arange(by - 4, by + h + 4), 0, PH - 1)
+        xs = np.clip(np.arange(bx - 4, bx + w + 4), 0, PW - 1)
+        ext = np.ascontiguousarray(plane[np.ix_(ys, xs)])
+        es, S = ext.itemsize, ext.shape[1]
+        hx, hy = (cands[8][0] + 4) // 8, cands[8][1] // 8
+        filtered = np.zeros((4, 64 * 64), plane.dtype)
+        for step, f in enumerate(steps):
+            filtered[:] = 0
+            f(None, ext.ctypes.data + (3 * S + 3) * es, S, w, h, H.ptr(filtered), None, 4, None,
+              0 if step < 2 else hx, 0 if step < 2 else hy)
+            for j in range(4):
+                mvx, mvy = cands[step * 4 + j]
+                blk = filtered[j].reshape(64, 64)
+                want = orc.ipol_sample(depth, plane, PW, PH, bx + (mvx >> 4), by + (mvy >> 4), w, h, mvx & 15, mvy & 15, False, False)
+                assert np.array_equal(blk[:h, :w].ravel(), want), (step, j, w, h)
+                assert orc.satd_any_size(depth, w, h, cur, 64, np.ascontiguousarray(blk), 64) == costs[step * 4 + j]
+        seen += 1
+    assert seen >= 6

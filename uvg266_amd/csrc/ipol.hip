@@ -13,6 +13,7 @@
 // ME) is read from HBM once into LDS with edge replication; the horizontal
 // pass writes int16 intermediates to LDS, the vertical pass reads them back
 // and either stores the block (MC) or feeds the row-per-lane Hadamard (ME).
+#include <type_traits>
 #include "uvghip_common.h"
 #include "percall.h"
 #include "satd_dev.h"
@@ -307,6 +308,97 @@ extern "C" int uvghip_bipred_average_batch(int bitdepth, const void *l0, const v
   UVGHIP_CHECK_LAUNCH();
 }
 
-// The ipol strategy typedefs (strategies-ipol.h:62-114) all take encoder_control_t* plus
-// caller-side extended blocks and scratch arrays; like the quant group they are bound by the
-// host-side shim of INTEGRATION.md, which forwards to uvghip_mc_batch / uvghip_frac_satd_batch.
+// ------------------------------------------------ drop-in "ipol" strategy functions (host buffers) ----
+// The ipol typedefs (strategies-ipol.h:62-114) take `const encoder_control_t *` first, but the generic
+// implementations never read it (ipol-generic.c:134-758: bit depth is the compile-time UVG_BIT_DEPTH), so
+// the pointer is carried as an opaque `const void *` and the depth comes from the registrar's argument.
+// One call = stage the extended source block -> upload -> mc kernel -> download (percall.h).
+namespace {
+
+// sample_quarterpel_luma / sample_octpel_chroma and their 14-bit `_hi` forms.  `src` points at the block's
+// top-left inside a caller-padded extended block (TAPS/2-1 samples before, TAPS/2 after, ipol-generic.c:161-165).
+template <typename PX, int TAPS, bool HI>
+void sample_hip(const void *, PX *src, int16_t src_stride, int width, int height,
+                typename std::conditional<HI, int16_t, PX>::type *dst, int16_t dst_stride, int8_t, int8_t,
+                const int32_t mv[2])
+{
+  using OUT = typename std::conditional<HI, int16_t, PX>::type;
+  constexpr int OFF = TAPS / 2 - 1;
+  const int rw = width + TAPS - 1, rh = height + TAPS - 1;
+  percall_ctx *c = percall_get((size_t)rw * rh * sizeof(PX) + (size_t)width * height * sizeof(OUT) + 2048);
+  const size_t os = c->stage_block(src - (ptrdiff_t)OFF * src_stride - OFF, (size_t)src_stride, rw, rh, sizeof(PX));
+  const size_t ob = c->take(sizeof(uvghip_mc_blk_t));
+  const int mask = TAPS == 8 ? 15 : 31;
+  *c->hp<uvghip_mc_blk_t>(ob) = uvghip_mc_blk_t{OFF, OFF, mv[0] & mask, mv[1] & mask};
+  c->upload(0, c->used);
+  const size_t oo = c->take((size_t)width * height * sizeof(OUT));
+  c->must(uvghip_mc_batch(px_traits<PX>::depth, c->dp<PX>(os), rw, rw, rh, TAPS == 4, width, height,
+                          c->dp<uvghip_mc_blk_t>(ob), 1, HI, c->dp<OUT>(oo), c->stream), "mc launch");
+  c->download(oo, (size_t)width * height * sizeof(OUT));
+  c->sync();
+  for (int y = 0; y < height; ++y)
+    memcpy(dst + (ptrdiff_t)y * dst_stride, c->hp<OUT>(oo) + (size_t)y * width, (size_t)width * sizeof(OUT));
+}
+
+// filter_{hpel,qpel}_blocks_{hor_ver,diag}_luma (ipol-generic.c:213-679).  STEP 0..3 in the order search_frac
+// calls them (search_inter.c:1142-1166).  The four candidate blocks a step returns are the motion-compensated
+// predictions at square[1 + 4*(STEP&1) + j] half-samples (STEP < 2) or quarter-samples around the chosen
+// half-sample offset (STEP >= 2) -- identity proven against the reference by tools/refcheck/rc_ipol.inc -- so
+// every call is computed from `src` alone; the caller's `hor_intermediate` / `hor_first_cols` scratch (a private
+// hand-over between the four functions of one strategy) is left untouched.  `src` = block origin minus the 1-sample
+// ME border, inside an extended block with 3 samples before and 4 after (search_inter.c:1085-1120).
+constexpr int FME_STRIDE = 64;  // LCU_WIDTH: row stride of filtered[4][LCU_LUMA_SIZE]
+template <typename PX, int STEP>
+void fme_blocks_hip(const void *, PX *src, int16_t src_stride, int width, int height, PX (*filtered)[FME_STRIDE * FME_STRIDE],
+                    void * /*hor_intermediate*/, int8_t /*fme_level*/, void * /*hor_first_cols*/, int8_t hpel_off_x,
+                    int8_t hpel_off_y)
+{
+  static const int8_t square[9][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-1, -1}, {1, -1}, {-1, 1}, {1, 1}};
+  const int rw = width + 8, rh = height + 8;
+  const size_t out_bytes = (size_t)4 * width * height * sizeof(PX);
+  percall_ctx *c = percall_get((size_t)rw * rh * sizeof(PX) + out_bytes + 2048);
+  const size_t os = c->stage_block(src - (ptrdiff_t)3 * src_stride - 3, (size_t)src_stride, rw, rh, sizeof(PX));
+  const size_t ob = c->take(4 * sizeof(uvghip_mc_blk_t));
+  for (int j = 0; j < 4; ++j) {
+    const int8_t *d = square[1 + (STEP & 1) * 4 + j];
+    const int mvx = STEP < 2 ? d[0] * 8 : hpel_off_x * 8 + d[0] * 4;   // 1/16 sample units
+    const int mvy = STEP < 2 ? d[1] * 8 : hpel_off_y * 8 + d[1] * 4;
+    c->hp<uvghip_mc_blk_t>(ob)[j] = uvghip_mc_blk_t{4 + (mvx >> 4), 4 + (mvy >> 4), mvx & 15, mvy & 15};
+  }
+  c->upload(0, c->used);
+  const size_t oo = c->take(out_bytes);
+  c->must(uvghip_mc_batch(px_traits<PX>::depth, c->dp<PX>(os), rw, rw, rh, 0, width, height,
+                          c->dp<uvghip_mc_blk_t>(ob), 4, 0, c->dp<PX>(oo), c->stream), "fme launch");
+  c->download(oo, out_bytes);
+  c->sync();
+  for (int j = 0; j < 4; ++j)
+    for (int y = 0; y < height; ++y)
+      memcpy(filtered[j] + (size_t)y * FME_STRIDE, c->hp<PX>(oo) + ((size_t)j * height + y) * width, (size_t)width * sizeof(PX));
+}
+
+template <typename PX>
+int register_ipol(void *opaque)
+{
+  int ok = 1;
+#define REG(type, fn) ok &= uvghip_do_register(opaque, type, (void *)(fn))
+  REG("filter_hpel_blocks_hor_ver_luma", (&fme_blocks_hip<PX, 0>));
+  REG("filter_hpel_blocks_diag_luma", (&fme_blocks_hip<PX, 1>));
+  REG("filter_qpel_blocks_hor_ver_luma", (&fme_blocks_hip<PX, 2>));
+  REG("filter_qpel_blocks_diag_luma", (&fme_blocks_hip<PX, 3>));
+  REG("sample_quarterpel_luma", (&sample_hip<PX, 8, false>));
+  REG("sample_octpel_chroma", (&sample_hip<PX, 4, false>));
+  REG("sample_quarterpel_luma_hi", (&sample_hip<PX, 8, true>));
+  REG("sample_octpel_chroma_hi", (&sample_hip<PX, 4, true>));
+#undef REG
+  return ok;
+}
+
+}  // namespace
+
+// Not registered: get_extended_block(_wraparound) -- pure host pointer logic / edge-replicating copy with no
+// arithmetic (ipol-generic.c:761-883); the batched kernels clamp coordinates instead.
+extern "C" int uvg_strategy_register_ipol_hip(void *opaque, uint8_t bitdepth)
+{
+  if (!uvghip_ready() && uvghip_init(0) != 0) return 0;
+  return bitdepth == 8 ? register_ipol<uint8_t>(opaque) : register_ipol<uint16_t>(opaque);
+}

@@ -53,6 +53,7 @@ SIGNATURES = {
     "uvghip_frac_satd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_bipred_average_batch": (c_int, [c_int, c_vp, c_vp, c_int, ctypes.c_size_t, c_vp, c_vp]),
     "uvg_strategy_register_sao_hip": (c_int, [c_vp, ctypes.c_uint8]),
+    "uvg_strategy_register_ipol_hip": (c_int, [c_vp, ctypes.c_uint8]),
     "uvghip_sao_stats_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvghip_sao_apply_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
     "uvghip_sao_edge_offsets_batch": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
