@@ -188,3 +188,36 @@ def test_full_size_properties(hip):
     # residual: a - b reconstructs a
     res = api.residual_plane(dcur, dref).cpu().numpy()
     assert np.array_equal((res + ref.astype(np.int16)).astype(np.uint8), cur)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_border_sad_strategy_pointers(strategies, orc, depth):
+    """ver_sad / hor_sad / get_optimized_sad (strategies-picture.h:128-134) through the registered pointers,
+    against the oracle's restatement of picture-generic.c:1250-1332."""
+    t = strategies[depth]
+    rng = np.random.default_rng(40 + depth)
+    S = 80
+    pic, ref = rand_plane(rng, 70, S, depth), rand_plane(rng, 70, S, depth)
+    ver = ctypes.CFUNCTYPE(U, VP, VP, I, I, U)(t["ver_sad"])
+    hor = ctypes.CFUNCTYPE(U, VP, VP, I, I, U, U, U, U)(t["hor_sad"])
+    gos = ctypes.CFUNCTYPE(VP, I)(t["get_optimized_sad"])
+    over = orc.fn(depth, "ver_sad", ctypes.c_uint)
+    ohor = orc.fn(depth, "hor_sad", ctypes.c_uint)
+    oreg = orc.fn(depth, "reg_sad", ctypes.c_uint)
+    es = pic.itemsize
+    for (w, h) in [(4, 4), (8, 8), (16, 16), (64, 64), (32, 8), (12, 16), (24, 32), (6, 5), (8, 1)]:
+        p = pic.ctypes.data + (3 * S + 5) * es
+        r = ref.ctypes.data + (2 * S + 7) * es
+        assert ver(p, r, w, h, S) == over(ctypes.c_void_p(p), ctypes.c_void_p(r), w, h, S)
+        for left, right in [(0, 0), (1, 0), (w // 2, 0), (w - 1, 0), (0, 1), (0, w // 2), (0, w - 1), (2, 3)]:
+            if left >= w or right >= w:
+                continue
+            assert hor(p, r, w, h, S, S, left, right) == ohor(ctypes.c_void_p(p), ctypes.c_void_p(r), w, h, S, S, left, right), (w, h, left, right)
+    for w in range(0, 70):
+        fp = gos(w)
+        if w in (4, 8, 12, 16, 24, 32, 64):
+            f = ctypes.CFUNCTYPE(U, VP, VP, I, U, U)(fp)
+            for h in (4, 16, 64):
+                assert f(H.ptr(pic), H.ptr(ref), h, S, S) == oreg(H.ptr(pic), H.ptr(ref), w, h, S, S)
+        else:
+            assert not fp          # NULL: the caller falls back to reg_sad (image.c:259-265)

@@ -516,30 +516,77 @@ unsigned percall_block_cost(int kind, const PX *a, const PX *b, int w, int h, un
   return *c->hp<uint32_t>(oo);
 }
 
+// Raw (unshifted) SAD of a host w x h block against a host reference region of rw x rh samples whose sample
+// (rx, ry) lies under the block's top-left; positions outside the region are edge-replicated by the kernel's
+// coordinate clamp.  reg_sad itself does not shift by depth-8 (picture-generic.c:99), hence shift 0.
+template <typename PX>
+unsigned percall_sad(const PX *pic, unsigned pic_stride, int w, int h, const PX *ref, unsigned ref_stride, int rw, int rh,
+                     int rx, int ry)
+{
+  percall_ctx *c = percall_get(((size_t)w * h + (size_t)rw * rh) * sizeof(PX) + 1024);
+  const size_t oa = c->stage_block(pic, pic_stride, w, h, sizeof(PX));
+  const size_t ob = c->stage_block(ref, ref_stride, rw, rh, sizeof(PX));
+  const size_t od = c->take(sizeof(uvghip_blk_t)), oo = c->take(sizeof(uint32_t));
+  *c->hp<uvghip_blk_t>(od) = uvghip_blk_t{0, 0, rx, ry};
+  c->upload(0, c->used);
+  const int unit = (w % 8 == 0) ? 8 : (w % 4 == 0 ? 4 : 1);
+  int lpb = pow2ceil((w / unit) * h); if (lpb > 64) lpb = 64;
+  const PX *da = c->dp<PX>(oa), *db = c->dp<PX>(ob);
+  const uvghip_blk_t *dd = c->dp<uvghip_blk_t>(od); uint32_t *dout = c->dp<uint32_t>(oo);
+  if (unit == 8) sad_batch_kernel<PX, 8><<<1, 64, 0, c->stream>>>(da, w, db, rw, rw, rh, w, h, dd, 1, dout, lpb, 0, 1);
+  else if (unit == 4) sad_batch_kernel<PX, 4><<<1, 64, 0, c->stream>>>(da, w, db, rw, rw, rh, w, h, dd, 1, dout, lpb, 0, 1);
+  else sad_batch_kernel<PX, 1><<<1, 64, 0, c->stream>>>(da, w, db, rw, rw, rh, w, h, dd, 1, dout, lpb, 0, 1);
+  if (hipGetLastError() != hipSuccess) c->fail("sad launch");
+  c->download(oo, sizeof(uint32_t));
+  c->sync();
+  return *c->hp<uint32_t>(oo);
+}
+
 // reg_sad_func
 template <typename PX>
 unsigned reg_sad_hip(const PX *data1, const PX *data2, const int width, const int height,
                      const unsigned stride1, const unsigned stride2)
 {
-  // reg_sad itself does not shift by depth-8 (picture-generic.c:99); undo the batch kernel's shift by
-  // asking for the raw sum: launch_sad shifts by depth-8, so use the SAD kernel on 8-bit-style shift 0.
-  percall_ctx *c = percall_get((size_t)2 * width * height * sizeof(PX) + 1024);
-  const size_t oa = c->stage_block(data1, stride1, width, height, sizeof(PX));
-  const size_t ob = c->stage_block(data2, stride2, width, height, sizeof(PX));
-  const size_t od = c->take(sizeof(uvghip_blk_t)), oo = c->take(sizeof(uint32_t));
-  *c->hp<uvghip_blk_t>(od) = uvghip_blk_t{0, 0, 0, 0};
-  c->upload(0, c->used);
-  const int unit = (width % 8 == 0) ? 8 : (width % 4 == 0 ? 4 : 1);
-  int lpb = pow2ceil((width / unit) * height); if (lpb > 64) lpb = 64;
-  const PX *da = c->dp<PX>(oa), *db = c->dp<PX>(ob);
-  const uvghip_blk_t *dd = c->dp<uvghip_blk_t>(od); uint32_t *dout = c->dp<uint32_t>(oo);
-  if (unit == 8) sad_batch_kernel<PX, 8><<<1, 64, 0, c->stream>>>(da, width, db, width, width, height, width, height, dd, 1, dout, lpb, 0, 0);
-  else if (unit == 4) sad_batch_kernel<PX, 4><<<1, 64, 0, c->stream>>>(da, width, db, width, width, height, width, height, dd, 1, dout, lpb, 0, 0);
-  else sad_batch_kernel<PX, 1><<<1, 64, 0, c->stream>>>(da, width, db, width, width, height, width, height, dd, 1, dout, lpb, 0, 0);
-  if (hipGetLastError() != hipSuccess) c->fail("reg_sad launch");
-  c->download(oo, sizeof(uint32_t));
-  c->sync();
-  return *c->hp<uint32_t>(oo);
+  if (width <= 0 || height <= 0) return 0;
+  return percall_sad<PX>(data1, stride1, width, height, data2, stride2, width, height, 0, 0);
+}
+
+// ver_sad_func (picture-generic.c:1266): every block row against the one reference row -> a 1-row region.
+template <typename PX>
+uint32_t ver_sad_hip(const PX *pic_data, const PX *ref_data, int32_t block_width, int32_t block_height, uint32_t pic_stride)
+{
+  if (block_width <= 0 || block_height <= 0) return 0;
+  return percall_sad<PX>(pic_data, pic_stride, block_width, block_height, ref_data, (unsigned)block_width, block_width, 1, 0, 0);
+}
+
+// hor_sad_func (picture-generic.c:1308): `left` columns replicate reference column `left`, else `right` columns
+// replicate column width-right-1 (left wins when both are set, as in the reference's if/else-if).
+template <typename PX>
+uint32_t hor_sad_hip(const PX *pic_data, const PX *ref_data, int32_t width, int32_t height, uint32_t pic_stride,
+                     uint32_t ref_stride, uint32_t left, uint32_t right)
+{
+  if (width <= 0 || height <= 0) return 0;
+  if (left) return percall_sad<PX>(pic_data, pic_stride, width, height, ref_data + left, ref_stride, width - (int)left, height, -(int)left, 0);
+  if (right) return percall_sad<PX>(pic_data, pic_stride, width, height, ref_data, ref_stride, width - (int)right, height, 0, 0);
+  return percall_sad<PX>(pic_data, pic_stride, width, height, ref_data, ref_stride, width, height, 0, 0);
+}
+
+// get_optimized_sad_func (strategies-picture.h:128, optimized_sad_func_ptr_t.h:13): width-specialised SAD or NULL.
+template <typename PX, int W>
+uint32_t opt_sad_hip(const PX *const a, const PX *const b, const int32_t height, const uint32_t stride1, const uint32_t stride2)
+{
+  return height > 0 ? percall_sad<PX>(a, stride1, W, height, b, stride2, W, height, 0, 0) : 0;
+}
+template <typename PX>
+void *get_optimized_sad_hip(int32_t width)
+{
+  switch (width) {
+    case 4: return (void *)&opt_sad_hip<PX, 4>;    case 8: return (void *)&opt_sad_hip<PX, 8>;
+    case 12: return (void *)&opt_sad_hip<PX, 12>;  case 16: return (void *)&opt_sad_hip<PX, 16>;
+    case 24: return (void *)&opt_sad_hip<PX, 24>;  case 32: return (void *)&opt_sad_hip<PX, 32>;
+    case 64: return (void *)&opt_sad_hip<PX, 64>;
+    default: return nullptr;   // the caller then uses reg_sad (image.c:259-263)
+  }
 }
 
 // crc32c_4x4_func / crc32c_8x8_func (strategies-picture.h:157-158): (const uvg_pixel *buf, uint32_t pic_stride)
@@ -628,6 +675,8 @@ int register_picture(void *opaque)
   int ok = 1;
 #define REG(type, fn) ok &= uvghip_do_register(opaque, type, (void *)(fn))
   REG("reg_sad", (&reg_sad_hip<PX>));
+  REG("ver_sad", (&ver_sad_hip<PX>));  REG("hor_sad", (&hor_sad_hip<PX>));
+  REG("get_optimized_sad", (&get_optimized_sad_hip<PX>));
   REG("sad_4x4", (&sad_nxn_hip<PX, 4>));     REG("sad_8x8", (&sad_nxn_hip<PX, 8>));
   REG("sad_16x16", (&sad_nxn_hip<PX, 16>));  REG("sad_32x32", (&sad_nxn_hip<PX, 32>));
   REG("sad_64x64", (&sad_nxn_hip<PX, 64>));
@@ -652,9 +701,8 @@ int register_picture(void *opaque)
 
 // Not registered (left to generic/avx2 by priority): satd_any_size_quad (its
 // h%8==4 indexing quirk is reproduced only by the oracle), satd_any_size_vtm
-// (double sqrt), bipred_average (takes lcu_t), hor_sad/ver_sad/
-// get_optimized_sad (subsumed by the clamped batch kernels), crc32c_*,
-// pixel_var, sad/satd_64x64_dual (pred_buffer is 32x32).
+// (double sqrt), bipred_average (takes lcu_t), sad/satd_64x64_dual
+// (pred_buffer is 32x32).
 extern "C" int uvg_strategy_register_picture_hip(void *opaque, uint8_t bitdepth)
 {
   if (!uvghip_ready() && uvghip_init(0) != 0) return 0;
