@@ -125,6 +125,13 @@ def test_strategy_pointers_vs_reference_goldens(strategies, depth):
             got = np.zeros(w * h, np.int16)
             ctypes.CFUNCTYPE(None, VP, VP, VP, I, I, I, I)(t["generate_residual"])(H.ptr(a), H.ptr(b), H.ptr(got), w, h, S, S)
             assert np.array_equal(got, res)
+            # satd_any_size_quad incl. the reference's h % 8 == 4 tiling quirk (picture-generic.c:412-479)
+            qoff = int(qoff)
+            preds = (VP * 4)(*[qbase.ctypes.data + k * qoff * qbase.itemsize for k in range(4)])
+            q = np.zeros(4, np.uint32)
+            valid = np.ones(4, np.int8)
+            ctypes.CFUNCTYPE(None, I, I, VP, I, VP, I, U, VP, VP)(t["satd_any_size_quad"])(w, h, preds, 64, H.ptr(a), S, 4, H.ptr(q), H.ptr(valid))
+            assert list(q) == list(outs[3:7]), (w, h)
         elif name == "nxn":
             (n,), pr64, p0, p1, orig, outs = arrs
             n = int(n)

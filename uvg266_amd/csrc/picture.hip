@@ -631,6 +631,53 @@ unsigned satd_any_size_hip(int width, int height, const PX *b1, int s1, const PX
 {
   return percall_block_cost<PX>(1, b1, b2, width, height, (unsigned)s1, (unsigned)s2) >> (px_traits<PX>::depth - 8);
 }
+// cost_pixel_any_size_multi_func, 4 predictors (picture-generic.c:412-479, caller search_inter.c:1172).  The
+// reference's loop nest is not satd_any_size x 4: its 8x8 part starts at row (h - 4) % 8 taken *after* h -= 4 and
+// its first-row strip restarts at column 0, so for h % 8 == 4 rows 0..h-5 are covered again and the last four rows
+// only by nothing.  Bit-exactness means reproducing that: the cost is the sum of up to three rectangular regions
+// (first column 4 x h, first row w' x 4, 8x8 body w' x h' at column w % 8, row 0), each of which the batch kernel's
+// own any_size tiling covers with exactly the reference's tiles.  `num_modes` and `valid` are ignored as upstream.
+__global__ void quad_finish_kernel(const uint32_t *__restrict__ parts, int shift, uint32_t *__restrict__ out)
+{
+  const int k = threadIdx.x;
+  if (k < 4) out[k] = (parts[k] + parts[4 + k] + parts[8 + k]) >> shift;
+}
+template <typename PX>
+void satd_any_size_quad_hip(int width, int height, const PX **preds, const int stride, const PX *orig, const int orig_stride,
+                            unsigned /*num_modes*/, unsigned *costs_out, int8_t * /*valid*/)
+{
+  percall_ctx *c = percall_get((size_t)5 * width * height * sizeof(PX) + 4096);
+  if (width < 4 || height < 4 || (width & 3) || (height & 3) || width > 64 || height > 64) c->fail("satd_any_size_quad: unsupported size");
+  const size_t oo = c->stage_block(orig, (size_t)orig_stride, width, height, sizeof(PX));
+  const size_t op = c->take((size_t)4 * width * height * sizeof(PX));
+  for (int k = 0; k < 4; ++k)
+    for (int y = 0; y < height; ++y)
+      memcpy(c->hp<PX>(op) + ((size_t)k * height + y) * width, preds[k] + (size_t)y * stride, (size_t)width * sizeof(PX));
+  const size_t ob = c->take(12 * sizeof(uvghip_blk_t)), oparts = c->take(12 * sizeof(uint32_t));
+  memset(c->hp<uint32_t>(oparts), 0, 12 * sizeof(uint32_t));
+  const int wmod = width % 8, w2 = wmod ? width - 4 : width, h2 = (height % 8) ? height - 4 : height;
+  uvghip_blk_t *hb = c->hp<uvghip_blk_t>(ob);
+  for (int k = 0; k < 4; ++k) {
+    hb[k] = uvghip_blk_t{0, 0, 0, k * height};            // first column, first row: both planes from column 0
+    hb[4 + k] = hb[k];
+    hb[8 + k] = uvghip_blk_t{wmod, 0, wmod, k * height};  // 8x8 body
+  }
+  c->upload(0, c->used);
+  const size_t ores = c->take(4 * sizeof(uint32_t));
+  const PX *dorig = c->dp<PX>(oo), *dpred = c->dp<PX>(op);
+  const uvghip_blk_t *db = c->dp<uvghip_blk_t>(ob);
+  uint32_t *dparts = c->dp<uint32_t>(oparts);
+  int rc = 0;
+  if (wmod) rc |= launch_satd<PX>(dorig, width, dpred, width, width, 4 * height, 4, height, db, 4, dparts, 0, 0, c->stream);
+  if ((height % 8) && w2 > 0) rc |= launch_satd<PX>(dorig, width, dpred, width, width, 4 * height, w2, 4, db + 4, 4, dparts + 4, 0, 0, c->stream);
+  if (w2 > 0 && h2 > 0) rc |= launch_satd<PX>(dorig, width, dpred, width, width, 4 * height, w2, h2, db + 8, 4, dparts + 8, 0, 0, c->stream);
+  c->must(rc, "satd quad launch");
+  quad_finish_kernel<<<1, 64, 0, c->stream>>>(dparts, px_traits<PX>::depth - 8, c->dp<uint32_t>(ores));
+  if (hipGetLastError() != hipSuccess) c->fail("satd quad finish");
+  c->download(ores, 4 * sizeof(uint32_t));
+  c->sync();
+  for (int k = 0; k < 4; ++k) costs_out[k] = c->hp<uint32_t>(ores)[k];
+}
 // cost_pixel_nxn_multi_func (pred_buffer = PX (*)[32*32]); orig is the first Hadamard operand
 template <typename PX, int N>
 void sad_nxn_dual_hip(PX (*preds)[32 * 32], const PX *orig, unsigned num_modes, unsigned *costs_out)
@@ -688,6 +735,7 @@ int register_picture(void *opaque)
   REG("satd_4x4_dual", (&satd_nxn_dual_hip<PX, 4>)); REG("satd_8x8_dual", (&satd_nxn_dual_hip<PX, 8>));
   REG("satd_16x16_dual", (&satd_nxn_dual_hip<PX, 16>)); REG("satd_32x32_dual", (&satd_nxn_dual_hip<PX, 32>));
   REG("satd_any_size", (&satd_any_size_hip<PX>));
+  REG("satd_any_size_quad", (&satd_any_size_quad_hip<PX>));
   REG("pixels_calc_ssd", (&pixels_calc_ssd_hip<PX>));
   REG("crc32c_4x4", (&crc32c_hip<PX, 4>));
   REG("crc32c_8x8", (&crc32c_hip<PX, 8>));
@@ -699,8 +747,7 @@ int register_picture(void *opaque)
 
 }  // namespace
 
-// Not registered (left to generic/avx2 by priority): satd_any_size_quad (its
-// h%8==4 indexing quirk is reproduced only by the oracle), satd_any_size_vtm
+// Not registered (left to generic/avx2 by priority): satd_any_size_vtm
 // (double sqrt), bipred_average (takes lcu_t), sad/satd_64x64_dual
 // (pred_buffer is 32x32).
 extern "C" int uvg_strategy_register_picture_hip(void *opaque, uint8_t bitdepth)
