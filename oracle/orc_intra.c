@@ -237,6 +237,28 @@ ORC_EXPORT void ORC_FN(intra_pred_dc)(int width, int height, const orc_px *ref_t
   for (int i = 0; i < width * height; ++i) dst[i] = dc;
 }
 
+/*
+ * intra_pred_filtered_dc (intra-generic.c:371-402; HEVC-style DC with [1 2 1]/[1 3] boundary smoothing --
+ * registered upstream but without a caller).  Square 2^log2_width block; the DC sum honours the
+ * multi-reference-line offset, the boundary filter does not (as upstream).  dc is stored as a pixel.
+ */
+ORC_EXPORT void ORC_FN(intra_pred_filtered_dc)(int log2_width, const orc_px *ref_top, const orc_px *ref_left,
+                                               orc_px *dst, int multi_ref_idx)
+{
+  const int n = 1 << log2_width;
+  long total = 0;
+  for (int i = 0; i < n; ++i) total += ref_top[i + 1 + multi_ref_idx] + ref_left[i + 1 + multi_ref_idx];
+  const orc_px dc = (orc_px)((total + n) >> (log2_width + 1));
+  for (int y = 0; y < n; ++y)
+    for (int x = 0; x < n; ++x) {
+      int v = dc;
+      if (x == 0 && y == 0) v = (ref_left[1] + 2 * dc + ref_top[1] + 2) / 4;
+      else if (y == 0) v = (ref_top[x + 1] + 3 * dc + 2) / 4;
+      else if (x == 0) v = (ref_left[y + 1] + 3 * dc + 2) / 4;
+      dst[y * n + x] = (orc_px)v;
+    }
+}
+
 /* intra-generic.c:414-437 */
 ORC_EXPORT void ORC_FN(pdpc_planar_dc)(int width, int height, const orc_px *ref_top, const orc_px *ref_left,
                                        orc_px *dst)

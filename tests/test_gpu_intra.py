@@ -84,7 +84,7 @@ def test_strategy_pointers(hip, orc, depth):
     """angular_pred / intra_pred_planar / pdpc_planar_dc through the registered 'hip' pointers."""
     reg = Registry(hip)
     assert hip.uvg_strategy_register_intra_hip(None, depth) == 1
-    assert set(reg.table) == {"angular_pred", "intra_pred_planar", "pdpc_planar_dc", "mip_predict"}
+    assert set(reg.table) == {"angular_pred", "intra_pred_planar", "pdpc_planar_dc", "mip_predict", "intra_pred_filtered_dc"}
     VP, I, I8, U8 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int8, ctypes.c_uint8
     ang = ctypes.CFUNCTYPE(None, VP, I8, I8, VP, VP, VP, U8, U8, I)(reg.table["angular_pred"])
     k = 0
@@ -141,3 +141,20 @@ def test_full_size_properties(hip):
     c = api.intra_search_batch(stripes, stripes, blks, n, api.make_modes([50, 18]))
     not_top = torch.tensor([r[1] > 0 for r in rows], device="cuda")
     assert int(c[not_top, 0].sum()) == 0 and int(c[not_top, 1].sum()) > 0
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_filtered_dc_pointer_vs_reference_golden(hip, depth):
+    """intra_pred_filtered_dc (registered upstream, no caller): the 'hip' pointer against vectors dumped from the
+    reference's generic function (tools/refcheck/rc_dcfilt.inc)."""
+    reg = Registry(hip)
+    assert hip.uvg_strategy_register_intra_hip(None, depth) == 1
+    f = ctypes.CFUNCTYPE(None, ctypes.c_int8, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint8)(reg.table["intra_pred_filtered_dc"])
+    n = 0
+    for name, (meta, top, left, want) in H.read_golden("dcfilt", depth):
+        log2w, mrl = int(meta[0]), int(meta[1])
+        got = np.zeros(want.size, want.dtype)
+        f(log2w, H.ptr(top), H.ptr(left), H.ptr(got), mrl)
+        assert np.array_equal(got, want), (log2w, mrl)
+        n += 1
+    assert n >= 24

@@ -228,3 +228,17 @@ def test_border_sad_strategy_pointers(strategies, orc, depth):
                 assert f(H.ptr(pic), H.ptr(ref), h, S, S) == oreg(H.ptr(pic), H.ptr(ref), w, h, S, S)
         else:
             assert not fp          # NULL: the caller falls back to reg_sad (image.c:259-265)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_dual_64_strategy_pointers(strategies, orc, depth):
+    """sad/satd_64x64_dual (picture-generic.c:1087,1475,1481): preds[1] = preds[0] + 32*32 as upstream's pred_buffer."""
+    t = strategies[depth]
+    rng = np.random.default_rng(64 + depth)
+    preds = rand_plane(rng, 1, 1024 + 4096, depth).ravel()
+    orig = rand_plane(rng, 1, 4096, depth).ravel()
+    for name, want in (("sad_64x64_dual", orc.sad_nxn_dual(depth, preds, orig, 64)),
+                       ("satd_64x64_dual", orc.satd_nxn_dual(depth, preds, orig, 64))):
+        o = np.zeros(2, np.uint32)
+        ctypes.CFUNCTYPE(None, VP, VP, U, VP)(t[name])(H.ptr(preds), H.ptr(orig), 2, H.ptr(o))
+        assert list(o) == list(want), name

@@ -58,6 +58,7 @@ void check_deblock(void);
 void check_lfnst(void);
 void check_hashvar(void);
 void check_mip(void);
+void check_dcfilt(void);
 
 int main(int argc, char **argv)
 {
@@ -91,6 +92,7 @@ int main(int argc, char **argv)
   check_hashvar();
 #ifdef HAVE_INTRA
   check_mip();
+  check_dcfilt();
 #endif
   if (g_out) fclose(g_out);
   printf("refcheck %d-bit: %s (%d mismatches)\n", UVG_BIT_DEPTH, g_fail ? "FAIL" : "OK", g_fail);
@@ -125,4 +127,5 @@ int main(int argc, char **argv)
 #include "rc_hashvar.inc"
 #ifdef HAVE_INTRA
 #include "rc_mip.inc"
+#include "rc_dcfilt.inc"
 #endif

@@ -1204,11 +1204,50 @@ void pdpc_planar_dc_hip(const int mode, const ref_cu_loc *cu_loc, const int colo
   percall_rows<PX>(2, mode, color != 0, w, h, used_ref + 358, used_ref, dst, 0, 0);
 }
 
+
+// intra_pred_filtered_dc_func (strategies-intra.h; intra-generic.c:371-402): HEVC-style smoothed DC, registered
+// upstream without a caller -- bound for table completeness.  One wave: lanes sum the two reference sides (shuffle
+// reduction), then every lane writes samples; the DC sum honours multi_ref_idx, the boundary filter does not.
+template <typename PX>
+__global__ void __launch_bounds__(64)
+filtered_dc_kernel(const PX *__restrict__ top, const PX *__restrict__ left, int log2w, int mrl, PX *__restrict__ dst)
+{
+  const int n = 1 << log2w, l = threadIdx.x;
+  int part = l < n ? (int)top[l + 1 + mrl] + (int)left[l + 1 + mrl] : 0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+  const int dc = (int)(PX)((__builtin_amdgcn_readfirstlane(part) + n) >> (log2w + 1));
+  for (int i = l; i < n * n; i += 64) {
+    const int y = i >> log2w, x = i & (n - 1);
+    int v = dc;
+    if (i == 0) v = ((int)left[1] + 2 * dc + (int)top[1] + 2) >> 2;
+    else if (y == 0) v = ((int)top[x + 1] + 3 * dc + 2) >> 2;
+    else if (x == 0) v = ((int)left[y + 1] + 3 * dc + 2) >> 2;
+    dst[i] = (PX)v;
+  }
+}
+template <typename PX>
+void intra_pred_filtered_dc_hip(const int_fast8_t log2_width, const PX *ref_top, const PX *ref_left, PX *out_block,
+                                const uint8_t multi_ref_idx)
+{
+  const int n = 1 << log2_width, len = n + 1 + multi_ref_idx;
+  percall_ctx *c = percall_get((size_t)(2 * len + n * n) * sizeof(PX) + 1024);
+  if (log2_width < 2 || log2_width > 5) c->fail("intra_pred_filtered_dc: log2_width outside 2..5");
+  const size_t ot = c->stage_block(ref_top, (size_t)len, len, 1, sizeof(PX));
+  const size_t ol = c->stage_block(ref_left, (size_t)len, len, 1, sizeof(PX));
+  c->upload(0, c->used);
+  const size_t oo = c->take((size_t)n * n * sizeof(PX));
+  filtered_dc_kernel<PX><<<1, 64, 0, c->stream>>>(c->dp<PX>(ot), c->dp<PX>(ol), log2_width, multi_ref_idx, c->dp<PX>(oo));
+  if (hipGetLastError() != hipSuccess) c->fail("filtered dc launch");
+  c->download(oo, (size_t)n * n * sizeof(PX));
+  c->sync();
+  memcpy(out_block, c->hp<PX>(oo), (size_t)n * n * sizeof(PX));
+}
+
 }  // namespace
 
 int uvghip_register_mip(void *opaque, uint8_t bitdepth);   // mip.hip
 
-// Not registered: intra_pred_filtered_dc (dead upstream).
 extern "C" int uvg_strategy_register_intra_hip(void *opaque, uint8_t bitdepth)
 {
   if (!uvghip_ready() && uvghip_init(0) != 0) return 0;
@@ -1217,10 +1256,12 @@ extern "C" int uvg_strategy_register_intra_hip(void *opaque, uint8_t bitdepth)
     ok &= uvghip_do_register(opaque, "angular_pred", (void *)&angular_pred_hip<uint8_t>);
     ok &= uvghip_do_register(opaque, "intra_pred_planar", (void *)&intra_pred_planar_hip<uint8_t>);
     ok &= uvghip_do_register(opaque, "pdpc_planar_dc", (void *)&pdpc_planar_dc_hip<uint8_t>);
+    ok &= uvghip_do_register(opaque, "intra_pred_filtered_dc", (void *)&intra_pred_filtered_dc_hip<uint8_t>);
   } else {
     ok &= uvghip_do_register(opaque, "angular_pred", (void *)&angular_pred_hip<uint16_t>);
     ok &= uvghip_do_register(opaque, "intra_pred_planar", (void *)&intra_pred_planar_hip<uint16_t>);
     ok &= uvghip_do_register(opaque, "pdpc_planar_dc", (void *)&pdpc_planar_dc_hip<uint16_t>);
+    ok &= uvghip_do_register(opaque, "intra_pred_filtered_dc", (void *)&intra_pred_filtered_dc_hip<uint16_t>);
   }
   ok &= uvghip_register_mip(opaque, bitdepth);
   return ok;

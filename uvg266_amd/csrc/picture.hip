@@ -732,6 +732,8 @@ int register_picture(void *opaque)
   REG("satd_64x64", (&satd_nxn_hip<PX, 64>));
   REG("sad_4x4_dual", (&sad_nxn_dual_hip<PX, 4>));   REG("sad_8x8_dual", (&sad_nxn_dual_hip<PX, 8>));
   REG("sad_16x16_dual", (&sad_nxn_dual_hip<PX, 16>)); REG("sad_32x32_dual", (&sad_nxn_dual_hip<PX, 32>));
+  // 64x64: pred_buffer rows are 32*32 samples, so preds[1] = preds[0] + 1024 overlaps -- same reads as upstream
+  REG("sad_64x64_dual", (&sad_nxn_dual_hip<PX, 64>));  REG("satd_64x64_dual", (&satd_nxn_dual_hip<PX, 64>));
   REG("satd_4x4_dual", (&satd_nxn_dual_hip<PX, 4>)); REG("satd_8x8_dual", (&satd_nxn_dual_hip<PX, 8>));
   REG("satd_16x16_dual", (&satd_nxn_dual_hip<PX, 16>)); REG("satd_32x32_dual", (&satd_nxn_dual_hip<PX, 32>));
   REG("satd_any_size", (&satd_any_size_hip<PX>));
@@ -748,8 +750,7 @@ int register_picture(void *opaque)
 }  // namespace
 
 // Not registered (left to generic/avx2 by priority): satd_any_size_vtm
-// (double sqrt), bipred_average (takes lcu_t), sad/satd_64x64_dual
-// (pred_buffer is 32x32).
+// (double sqrt), bipred_average (takes lcu_t).
 extern "C" int uvg_strategy_register_picture_hip(void *opaque, uint8_t bitdepth)
 {
   if (!uvghip_ready() && uvghip_init(0) != 0) return 0;
