@@ -5,9 +5,14 @@
 //
 // Reference arithmetic: src/strategies/generic/picture-generic.c:118-200 (4x4), :256-348 (8x8).
 //
-// Range: differences are at most 10 bits + sign.  The last butterfly stage is never
-// materialised -- |a+b| + |a-b| = 2*max(|a|,|b|) -- so the widest stored value is
-// 32 * 1023 = 32736 for 8x8 (five stages) and fits int16 at both bit depths.
+// Range: differences are at most 10 bits + sign; five butterfly stages give |v| <= 32 * 1023 = 32736, which fits int16
+// at both bit depths.  The sixth stage is never materialised.  Its absolute sum |a+b| + |a-b| comes from v_sad_u16,
+// which needs unsigned operands: flipping bit 15 of ONE input (x ^ 0x8000 = x + 0x8000 mod 2^16) offsets every
+// butterfly output that contains that input by +-0x8000 = 0x8000 (mod 2^16), because each output is a +-1 combination
+// in which the input appears exactly once.  After five stages a value combines the rows of one parity and all columns,
+// so biasing d[0][0].lo and d[1][0].lo biases everything; then, per half,
+//   |a - b| = sad_u16(a', b'),   |a + b| = sad_u16(a', (0 - b')),      (0 - b') = -b + 0x8000 (mod 2^16)
+// three instructions per register pair including the 32-bit accumulation (was: max, min, neg, max, dot2).
 #pragma once
 #include "uvghip_common.h"
 
@@ -33,16 +38,11 @@ __device__ __forceinline__ void pk_bfly(uint32_t &a, uint32_t &b)
   const uint32_t s = pk_add(a, b), t = pk_sub(a, b);
   a = s; b = t;
 }
-// per half: max(|x|, |y|) = max(max(x,y), -min(x,y))
-__device__ __forceinline__ uint32_t pk_absmax(uint32_t x, uint32_t y)
+// acc + |a+b| + |a-b| over both halves of offset operands (see the header comment)
+__device__ __forceinline__ uint32_t pk_last_stage_acc(uint32_t a, uint32_t b, uint32_t acc)
 {
-  const pk_s16 a = __builtin_bit_cast(pk_s16, x), b = __builtin_bit_cast(pk_s16, y);
-  const pk_s16 mx = __builtin_elementwise_max(a, b), mn = __builtin_elementwise_min(a, b);
-  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(mx, (pk_s16){0, 0} - mn));
-}
-__device__ __forceinline__ uint32_t pk_hsum_acc(uint32_t x, uint32_t acc)
-{
-  return __builtin_amdgcn_udot2(__builtin_bit_cast(pk_u16, x), (pk_u16){1, 1}, acc, false);
+  acc = __builtin_amdgcn_sad_u16(a, b, acc);
+  return __builtin_amdgcn_sad_u16(a, pk_sub(0u, b), acc);
 }
 __device__ __forceinline__ int pk_lo_s16(uint32_t x) { return (int)(int16_t)(x & 0xffffu); }
 
@@ -51,6 +51,7 @@ __device__ __forceinline__ int pk_lo_s16(uint32_t x) { return (int)(int16_t)(x &
 // term counted as |DC| >> 2, then (sum + 2) >> 2.
 __device__ __forceinline__ uint32_t satd8_tile_lane(uint32_t (&d)[8][4])
 {
+  d[0][0] ^= 0x8000u; d[1][0] ^= 0x8000u;                            // unsigned offset, see the header comment
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
 #pragma unroll
@@ -65,21 +66,22 @@ __device__ __forceinline__ uint32_t satd8_tile_lane(uint32_t (&d)[8][4])
     pk_bfly(d[0][c], d[2][c]); pk_bfly(d[1][c], d[3][c]);            // rows r / r+2
     pk_bfly(d[4][c], d[6][c]); pk_bfly(d[5][c], d[7][c]);
   }
-  // DC = a + b of the (row 0, row 1) pair in column 0
-  const int dc = pk_lo_s16(d[0][0]) + pk_lo_s16(d[1][0]);
+  // DC = a + b of the (row 0, row 1) pair in column 0, both carrying the 0x8000 offset
+  const int dc = (int)(d[0][0] & 0xffffu) + (int)(d[1][0] & 0xffffu) - 0x10000;
   uint32_t acc = 0;
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int r = 0; r < 8; r += 2) acc = pk_hsum_acc(pk_absmax(d[r][c], d[r + 1][c]), acc);   // rows r / r+1
+    for (int r = 0; r < 8; r += 2) acc = pk_last_stage_acc(d[r][c], d[r + 1][c], acc);   // rows r / r+1
   const uint32_t adc = (uint32_t)abs(dc);
-  const uint32_t sum = 2 * acc - adc + (adc >> 2);
+  const uint32_t sum = acc - adc + (adc >> 2);
   return (sum + 2) >> 2;
 }
 
 // 4x4: d[r][c], c = 0..1.  (sum + 1) >> 1 (picture-generic.c:197).
 __device__ __forceinline__ uint32_t satd4_tile_lane(uint32_t (&d)[4][2])
 {
+  d[0][0] ^= 0x8000u; d[1][0] ^= 0x8000u;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     d[r][0] = pk_bfly_pair(d[r][0]); d[r][1] = pk_bfly_pair(d[r][1]);
@@ -87,14 +89,14 @@ __device__ __forceinline__ uint32_t satd4_tile_lane(uint32_t (&d)[4][2])
   }
 #pragma unroll
   for (int c = 0; c < 2; ++c) { pk_bfly(d[0][c], d[2][c]); pk_bfly(d[1][c], d[3][c]); }
-  const int dc = pk_lo_s16(d[0][0]) + pk_lo_s16(d[1][0]);
+  const int dc = (int)(d[0][0] & 0xffffu) + (int)(d[1][0] & 0xffffu) - 0x10000;
   uint32_t acc = 0;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    acc = pk_hsum_acc(pk_absmax(d[0][c], d[1][c]), acc);
-    acc = pk_hsum_acc(pk_absmax(d[2][c], d[3][c]), acc);
+    acc = pk_last_stage_acc(d[0][c], d[1][c], acc);
+    acc = pk_last_stage_acc(d[2][c], d[3][c], acc);
   }
   const uint32_t adc = (uint32_t)abs(dc);
-  const uint32_t sum = 2 * acc - adc + (adc >> 2);
+  const uint32_t sum = acc - adc + (adc >> 2);
   return (sum + 1) >> 1;
 }
