@@ -651,34 +651,42 @@ __device__ __forceinline__ uint32_t pack_shr8(int lo, int hi) { return __builtin
 // horizontal/vertical modes (:279-293)
 template <int T, int PDPC, bool CLAMP, bool PK8>
 __device__ __forceinline__ void search_tile_angular(const search_mode &S, const uint32_t *mainr, const uint32_t *side,
-                                                    const uint32_t *rowp, const uint2 *sCoef, int n, int xd0, int yd0,
+                                                    const uint32_t *rowp, const uint2 *sCoef, const uint16_t *wrow,
+                                                    const uint16_t *sorow, int n, int xd0, int yd0,
                                                     const uint16_t *otile, int maxv, uint32_t (&d)[T][T / 2], uint32_t &sad)
 {
-  uint32_t wlp[T / 4];       // PDPC column weights (<= 32), one byte each: they are only ever multiplied (SDWA byte operand)
-  uint32_t wpk[T / 2];       // ... or as 16-bit pairs for the packed 8-bit blend
+  uint32_t wpk[T / 2];       // PDPC column weights (<= 32) of the lane's columns as 16-bit pairs
   const uint16_t *sp[T];    // PDPC 2: address of the projected side sample of column i in row yd0 (dword stride per row)
   int tl = 0;
-  if constexpr (PDPC != 0) {
+  if constexpr (PDPC == 2) {
+    // weights and projected-sample offsets come from the tables built at staging: one wide read each
+    uint32_t so[T / 2];
+    if constexpr (T == 8) {
+      const uint4 w = *reinterpret_cast<const uint4 *>(wrow + xd0), o = *reinterpret_cast<const uint4 *>(sorow + xd0);
+      wpk[0] = w.x; wpk[1] = w.y; wpk[2] = w.z; wpk[3] = w.w;
+      so[0] = o.x; so[1] = o.y; so[2] = o.z; so[3] = o.w;
+    } else {
+      const uint2 w = *reinterpret_cast<const uint2 *>(wrow + xd0), o = *reinterpret_cast<const uint2 *>(sorow + xd0);
+      wpk[0] = w.x; wpk[1] = w.y;
+      so[0] = o.x; so[1] = o.y;
+    }
+    const char *sbase = reinterpret_cast<const char *>(side + yd0);
+#pragma unroll
+    for (int i = 0; i < T; ++i) sp[i] = reinterpret_cast<const uint16_t *>(sbase + ((so[i >> 1] >> (16 * (i & 1))) & 0xffffu));
+  } else if constexpr (PDPC == 3) {
     const int lim = min(3 << S.scale, n);
     int wl[T];
     pdpc_col_weights<T>(xd0, S.scale, lim, wl);
 #pragma unroll
-    for (int q = 0; q < T / 4; ++q)
-      wlp[q] = (uint32_t)wl[4 * q] | ((uint32_t)wl[4 * q + 1] << 8) | ((uint32_t)wl[4 * q + 2] << 16) | ((uint32_t)wl[4 * q + 3] << 24);
-#pragma unroll
     for (int c = 0; c < T / 2; ++c) wpk[c] = (uint32_t)wl[2 * c] | ((uint32_t)wl[2 * c + 1] << 16);
-    if constexpr (PDPC == 2) {
+    tl = pr_sample(mainr, 0);
+    sp[0] = reinterpret_cast<const uint16_t *>(side + yd0 + 1);
+  }
+  // the gradient blend of the pure horizontal / vertical modes only ever multiplies by a weight: bytes suffice
+  uint32_t wlp[T / 4];
+  if constexpr (PDPC == 3) {
 #pragma unroll
-      for (int i = 0; i < T; ++i) {
-        // side[yd + (inv_sum >> 9) + 1]; columns without PDPC get a harmless in-range offset
-        const int x = xd0 + i;
-        const int so = x < lim ? ((256 + __mul24(x + 1, S.inv)) >> 9) + 1 : 0;
-        sp[i] = reinterpret_cast<const uint16_t *>(side + yd0 + so);
-      }
-    } else {
-      tl = pr_sample(mainr, 0);
-      sp[0] = reinterpret_cast<const uint16_t *>(side + yd0 + 1);
-    }
+    for (int q = 0; q < T / 4; ++q) wlp[q] = __builtin_amdgcn_perm(wpk[2 * q + 1], wpk[2 * q], 0x06040200u);
   }
   auto wl_of = [&](int i) -> int { return (int)((wlp[i >> 2] >> (8 * (i & 3))) & 0xffu); };
   ang_row<T> A, B;
@@ -711,9 +719,10 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
       }
       finish_row<T>(pp, A.o, d[r], sad);
     } else {
-      if constexpr (PDPC == 2 && PK8) {
-        // 8-bit samples: the whole blend  c + ((wl * (l - c) + 32) >> 6)  stays inside int16 (|wl * (l - c)| <= 32 * 255),
-        // so it runs on packed pairs: pack, [clamp], sub, v_pk_mad_i16, v_pk_ashrrev_i16, add
+      if constexpr (PDPC == 2) {
+        // the whole blend  c + ((wl * (l - c) + 32) >> 6)  runs on packed pairs: |wl * (l - c)| <= 32 * 1023 fits int16.
+        // 8-bit: the rounding term fits too (v_pk_mad_i16, shift).  10-bit: 32736 + 32 would overflow, so the shift is
+        // split -- (P + 32) >> 6 == ((P >> 5) + 1) >> 1 for every integer P.
         uint32_t pp[T / 2];
 #pragma unroll
         for (int c = 0; c < T / 2; ++c) {
@@ -721,17 +730,13 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
           if constexpr (CLAMP) v = __builtin_elementwise_min(__builtin_elementwise_max(v, (pk_s16){0, 0}), vmax);
           const pk_s16 l = __builtin_bit_cast(pk_s16, (uint32_t)lA[2 * c] | ((uint32_t)lA[2 * c + 1] << 16));
           const pk_s16 w = __builtin_bit_cast(pk_s16, wpk[c]);
-          const pk_s16 t = ((l - v) * w + (pk_s16){32, 32}) >> (pk_s16){6, 6};
+          pk_s16 t;
+          if constexpr (PK8) t = ((l - v) * w + (pk_s16){32, 32}) >> (pk_s16){6, 6};
+          else t = ((((l - v) * w) >> (pk_s16){5, 5}) + (pk_s16){1, 1}) >> (pk_s16){1, 1};
           pp[c] = __builtin_bit_cast(uint32_t, v + t);
         }
         finish_row<T>(pp, A.o, d[r], sad);
         continue;
-      } else if constexpr (PDPC == 2) {
-#pragma unroll
-        for (int i = 0; i < T; ++i) {
-          const int c = CLAMP ? clampi(out[i] >> 8, 0, maxv) : out[i] >> 8;
-          out[i] = c + ((__mul24(wl_of(i), lA[i] - c) + 32) >> 6);
-        }
       } else {
         const int g = lA[0] - tl;
 #pragma unroll
@@ -809,7 +814,7 @@ struct search_layout {
   int BRS;       // dwords per block: four pair rows, odd so that the wave's lanes spread over the banks
   int OS;        // uint16 elements per block: original + transpose + pad
   int PS;        // dwords per private extended row (odd)
-  int off_orig, off_ref, off_priv, off_dc, off_coef, off_mode;   // bytes
+  int off_orig, off_ref, off_priv, off_dc, off_coef, off_mode, off_wtab, off_sotab;   // bytes
   size_t total;
 };
 __host__ __device__ inline search_layout make_search_layout(int n, int bpg, int n_modes, int waves, int pxsz)
@@ -830,6 +835,10 @@ __host__ __device__ inline search_layout make_search_layout(int n, int bpg, int 
   L.off_coef = (int)o; o += 64 * 8;
   o = (o + 7) & ~(size_t)7;
   L.off_mode = (int)o; o += (size_t)n_modes * 8;
+  o = (o + 15) & ~(size_t)15;
+  L.off_wtab = (int)o; o += (size_t)3 * n * 2;          // PDPC column weights, u16 [scale 0..2][x < n]
+  o = (o + 15) & ~(size_t)15;
+  L.off_sotab = (int)o; o += (size_t)n_modes * n * 2;   // PDPC projected-side-sample byte offsets, u16 [candidate][x < n]
   L.total = o;
   return L;
 }
@@ -863,6 +872,8 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   uint32_t *sBest = reinterpret_cast<uint32_t *>(sDC + bpg);     // per block: min over modes of cost << 7 | candidate index
   uint2 *sCoef = reinterpret_cast<uint2 *>(smem_raw + L.off_coef);
   uint2 *sMode = reinterpret_cast<uint2 *>(smem_raw + L.off_mode);
+  uint16_t *sWtab = reinterpret_cast<uint16_t *>(smem_raw + L.off_wtab);
+  uint16_t *sSoTab = reinterpret_cast<uint16_t *>(smem_raw + L.off_sotab);
 
   const int blk0 = blockIdx.x * bpg;
   const int here = min(bpg, n_blks - blk0);
@@ -904,6 +915,15 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       }
     }
     for (int m = threadIdx.x; m < n_modes; m += NT) sMode[m] = pack_search_mode(make_search_mode(modes[m], n));
+    // PDPC tables (intra-generic.c:262-277): what every lane used to derive per mode from (column, scale, invAngle)
+    //   wtab[s][x]  = 32 >> ((2x) >> s) for x < min(3 << s, n), else 0 (a zero weight leaves the sample as is)
+    //   sotab[m][x] = byte offset, inside the side pair row, of the projected side sample of column x in row 0
+    //                 (side[(inv_sum >> 9) + 1]); 0, a harmless in-range offset, where the column has no PDPC
+    //                 (filled after the barrier, from the packed modes)
+    for (int i = threadIdx.x; i < 3 * n; i += NT) {
+      const int sc = i / n, x = i - sc * n;
+      sWtab[i] = (uint16_t)(x < min(3 << sc, n) ? 32 >> min(31, (2 * x) >> sc) : 0);
+    }
     for (int i = threadIdx.x; i < bpg; i += NT) sBest[i] = 0xffffffffu;
     if (threadIdx.x < 64) {
       const int df = threadIdx.x & 31;
@@ -914,6 +934,13 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       sCoef[threadIdx.x] = make_uint2((uint32_t)(f0 & 0xffff) | ((uint32_t)f1 << 16), (uint32_t)(f2 & 0xffff) | ((uint32_t)f3 << 16));
     }
     __syncthreads();
+    for (int i = threadIdx.x; i < n_modes * n; i += NT) {
+      const int m = i >> lgn, x = i & (n - 1);
+      const uint2 pm = sMode[m];
+      const search_mode Sm = unpack_search_mode(pm.x, pm.y);
+      const bool on_col = Sm.pdpc == 2 && x < min(3 << Sm.scale, n);
+      sSoTab[i] = (uint16_t)(on_col ? 4 * (((256 + (x + 1) * Sm.inv) >> 9) + 1) : 0);
+    }
     if (on) {
       filter_ref_rows(base, base + L.RS, base + 2 * L.RS, base + 3 * L.RS, n, n, L.RS, mytid, tpb);
       if (mytid == 0) sDC[myb] = dc_value(base, base + L.RS, n, n);
@@ -952,7 +979,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
 #pragma unroll
       for (int q = 0; q < BPL; ++q) {
       int lane_i = lane;
-      asm volatile("" : "+v"(lane_i));
+      if constexpr (T == 8) asm volatile("" : "+v"(lane_i));     // the 4x4 kernel has registers to spare: let LICM hoist
       const int lb_i = (lane_i >> lg_tiles) + q * (LB_STEP_NUM >> lg_tiles), tile_i = lane_i & (tiles - 1);
       const int bb_i = lb_i < here ? lb_i : 0;
       const int xd0 = (tile_i & ((1 << lg_tx) - 1)) * T, yd0 = (tile_i >> lg_tx) * T;
@@ -998,13 +1025,14 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       const uint16_t *ot = ob + (S.transposed ? nn : 0);
       if (S.kind == 2) {
         const uint32_t *rowp = neg ? priv + n : mainr;
+        const uint16_t *wrow = sWtab + S.scale * n, *sorow = sSoTab + m * n;     // wave-uniform rows; the lane adds its xd0
         if (S.pdpc == 0) {
-          if (S.noclamp) search_tile_angular<T, 0, false, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);
-          else search_tile_angular<T, 0, true, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);
+          if (S.noclamp) search_tile_angular<T, 0, false, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, wrow, sorow, n, xd0, yd0, ot, maxv, d, sad);
+          else search_tile_angular<T, 0, true, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, wrow, sorow, n, xd0, yd0, ot, maxv, d, sad);
         } else if (S.pdpc == 2) {
-          if (S.noclamp) search_tile_angular<T, 2, false, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);
-          else search_tile_angular<T, 2, true, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);
-        } else search_tile_angular<T, 3, false, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, n, xd0, yd0, ot, maxv, d, sad);   // pure H/V: integer phase
+          if (S.noclamp) search_tile_angular<T, 2, false, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, wrow, sorow, n, xd0, yd0, ot, maxv, d, sad);
+          else search_tile_angular<T, 2, true, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, wrow, sorow, n, xd0, yd0, ot, maxv, d, sad);
+        } else search_tile_angular<T, 3, false, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, wrow, sorow, n, xd0, yd0, ot, maxv, d, sad);   // pure H/V: integer phase
       } else if (S.kind == 0) search_tile_nonangular<T, true>(S, mainr, side, 0, n, lgn, xd0, yd0, ot, d, sad);
       else search_tile_nonangular<T, false>(S, mainr, side, sDC[bb_i], n, lgn, xd0, yd0, ot, d, sad);
       uint32_t satd;
