@@ -9,7 +9,14 @@ def main():
     what = sys.argv[2] if len(sys.argv) > 2 else 'all67'
     count = int(sys.argv[3]) if len(sys.argv) > 3 else 64
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
-    modes = list(range(67)) if what == 'all67' else [int(what)] * count
+    if what == 'all67':
+        modes = list(range(67))
+    elif what == 'pos':                      # non-negative angles: windows read from the block's pair rows
+        modes = [m for m in range(2, 67) if m <= 18 or m >= 50]
+    elif what == 'neg':                      # negative angles: windows read from the per-wave strips
+        modes = list(range(19, 50))
+    else:
+        modes = [int(what)] * count
     dev = torch.device('cuda:0')
     y, _, _ = layout.synthetic_yuv420(1920, 1080, 0, 8)
     Y = torch.from_numpy(y).to(dev)

@@ -813,17 +813,48 @@ struct search_layout {
   int RS;        // samples per reference row (u16 scratch) = dwords per pair row
   int BRS;       // dwords per block: four pair rows, odd so that the wave's lanes spread over the banks
   int OS;        // uint16 elements per block: original + transpose + pad
+  int BAND;      // uint16 elements per band of T rows of the original (T * n + pad)
+  int OT;        // uint16 offset of the transposed copy inside the block's original area
   int PS;        // dwords per private extended row (odd)
   int off_orig, off_ref, off_priv, off_dc, off_coef, off_mode, off_wtab, off_sotab;   // bytes
   size_t total;
 };
+// measured on MI355X with tools/dev/sweep_lds_strides.sh (SQ_LDS_BANK_CONFLICT per launch)
+#ifndef UVGHIP_BRS16_PAD
+#define UVGHIP_BRS16_PAD 11
+#endif
+#ifndef UVGHIP_PS16
+#define UVGHIP_PS16 37
+#endif
+#ifndef UVGHIP_BRS32_PAD
+#define UVGHIP_BRS32_PAD 2
+#endif
+#ifndef UVGHIP_PS32
+#define UVGHIP_PS32 82
+#endif
 __host__ __device__ inline search_layout make_search_layout(int n, int bpg, int n_modes, int waves, int pxsz)
 {
   search_layout L;
   L.RS = 2 * n + 4;
-  L.BRS = 4 * L.RS + 1;
-  L.OS = 2 * n * n + 8;
-  L.PS = 2 * n + 1;
+  // Strides chosen against LDS bank conflicts (64 banks x 4 B; measured with SQ_LDS_BANK_CONFLICT: at 32x32 half of
+  // the LDS-active cycles were conflicts).  The 64 lanes of a wave are (block, tile column, tile row): window reads
+  // start at block * BRS + 8 * column + row-dependent phase, so BRS / PS are picked per size by a model of the reads
+  // of all 65 angular modes (tools/dev/lds_bank_model.py); original rows are read as b128 at band * BAND + row * n +
+  // 8 * column, where a band stride of 0 mod 64 dwords (32x32: 8 rows of 16 dwords) puts all four tile rows on the
+  // same banks -- the pad makes it 4 mod 16 quads, so (column, row) tile the 64 banks exactly.
+  L.BRS = 4 * L.RS + (n == 16 ? UVGHIP_BRS16_PAD : (n == 32 ? UVGHIP_BRS32_PAD : 1));
+  L.PS = n == 16 ? UVGHIP_PS16 : (n == 32 ? UVGHIP_PS32 : 2 * n + 1);
+  // Original rows are read as one b128 (4x4: b64) per lane, which the LDS serves 16 (32) lanes per cycle; the 16
+  // lanes of such a group must land on 16 different bank quads, q = block * OSq + band * BANDq + row * rowq + column:
+  //   32x32 (group = the 16 tiles of one block):        BANDq = 36 = 4 (mod 16)  -> 4 * band + column; the block stride
+  //          has to be 0 mod 64 dwords on top of that (tools/dev/lds_probe.hip sweep: 4.5 clk per b128 instead of 8.4)
+  //   16x16 (group = 4 blocks x 4 tiles):               BANDq = 18 = 2, OSq = 76 = 12 (mod 16) -> 12 * block + 2 * band + column
+  //   8x8   (group = 16 blocks):                        OSq = 17 = 1 (mod 16)
+  //   4x4   (b64, group = 32 blocks, dword pairs):      OS = 22 dwords = 2 * 11 (mod 64)
+  const int t = n >= 8 ? 8 : 4;
+  L.BAND = t * n + (n == 32 ? 32 : (n == 16 ? 16 : 0));
+  L.OT = (n / t) * L.BAND;
+  L.OS = 2 * L.OT + (n == 32 ? 0 : (n == 16 ? 32 : (n == 4 ? 12 : 8)));
   size_t o = 0;
   L.off_orig = (int)o; o += (size_t)bpg * L.OS * 2; o = (o + 15) & ~(size_t)15;
   L.off_ref = (int)o;  o += (size_t)bpg * L.BRS * 4; o = (o + 15) & ~(size_t)15;
@@ -892,7 +923,8 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       const uvghip_intra_blk_t b = blks[blk0 + myb];
       build_ref_rows_batched<PX, 6>(rec, rec_stride, b.x, b.y, b.avail_top, b.avail_left, base, base + L.RS, L.RS, mytid, tpb);
       // original block in 4-sample segments: segment sg = (row, 4 columns)
-      uint16_t *so = sOrig + (size_t)myb * L.OS, *sot = so + nn;
+      uint16_t *so = sOrig + (size_t)myb * L.OS, *sot = so + L.OT;
+      auto band_off = [&](int row) { return (row / T) * L.BAND + (row % T) * n; };   // element offset of a row of the block
       const int nseg = nn >> 2, lg_spr = lgn - 2;     // segments, log2(segments per row)
       int v[4][4];
 #pragma unroll
@@ -908,9 +940,9 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
         const int sg = mytid + k * tpb;
         if (sg < nseg) {
           const int yy = sg >> lg_spr, xx = (sg & ((1 << lg_spr) - 1)) * 4;
-          *reinterpret_cast<uint2 *>(so + yy * n + xx) = make_uint2((uint32_t)v[k][0] | ((uint32_t)v[k][1] << 16), (uint32_t)v[k][2] | ((uint32_t)v[k][3] << 16));
+          *reinterpret_cast<uint2 *>(so + band_off(yy) + xx) = make_uint2((uint32_t)v[k][0] | ((uint32_t)v[k][1] << 16), (uint32_t)v[k][2] | ((uint32_t)v[k][3] << 16));
 #pragma unroll
-          for (int i = 0; i < 4; ++i) sot[(xx + i) * n + yy] = (uint16_t)v[k][i];
+          for (int i = 0; i < 4; ++i) sot[band_off(xx + i) + yy] = (uint16_t)v[k][i];
         }
       }
     }
@@ -984,7 +1016,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       const int bb_i = lb_i < here ? lb_i : 0;
       const int xd0 = (tile_i & ((1 << lg_tx) - 1)) * T, yd0 = (tile_i >> lg_tx) * T;
       const uint32_t *ref = sRef + __mul24(bb_i, L.BRS);
-      const uint16_t *ob = sOrig + __mul24(bb_i, L.OS) + __mul24(yd0, n) + xd0;
+      const uint16_t *ob = sOrig + __mul24(bb_i, L.OS) + __mul24(yd0 / T, L.BAND) + xd0;     // yd0 is a multiple of T
       uint32_t *priv = sPriv + __mul24(wave * bpg + bb_i, L.PS);
       const uint32_t *mainr = ref + S.row_main * L.RS, *side = ref + S.row_side * L.RS;
       const bool neg = S.kind == 2 && S.sd < 0;
@@ -1022,7 +1054,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       }
       uint32_t d[T][T / 2];
       uint32_t sad = 0;
-      const uint16_t *ot = ob + (S.transposed ? nn : 0);
+      const uint16_t *ot = ob + (S.transposed ? L.OT : 0);
       if (S.kind == 2) {
         const uint32_t *rowp = neg ? priv + n : mainr;
         const uint16_t *wrow = sWtab + S.scale * n, *sorow = sSoTab + m * n;     // wave-uniform rows; the lane adds its xd0
