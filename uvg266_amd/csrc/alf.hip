@@ -224,151 +224,196 @@ __device__ inline void covariance_sample(int16_t *e /*[13][4]*/, const PX *rec, 
     for (int b = 0; b < 4; ++b) e[kk * 4 + b] = (int16_t)acc[kk][b];
 }
 
-#define ALF_SPLIT 4
+// The covariance is the one dense contraction of the path: per class, C = [E | d]^T [E | d] with E the
+// n_samples x 52 matrix of clipped tap sums and d = org - rec; ee[k][l][b0][b1] = C[4k+b0][4l+b1], y[k][b] = C[4k+b][52],
+// pix_acc = C[52][52].  It runs on the i8 matrix cores with exact integer arithmetic: every 12-bit signed entry is
+// split as v = 128 * h + l (l = v & 127 in 0..127, h = v >> 7 in -16..16), so
+//     C = 16384 * H^T H + 128 * (H^T L + (H^T L)^T) + L^T L
+// and the three products are v_mfma_i32_32x32x32_i8 accumulations (|sums| < 2^31 for the <= 4096 samples of a rectangle).
+// A and B fragments come from the same [entry][sample] byte layout with the same code, so the contraction does not depend
+// on how the hardware orders the 32 k values inside an instruction.  A workgroup owns a rectangle: its 4x4 blocks are
+// walked in class order (every class padded to an even number of blocks = whole K = 32 chunks), the int32 accumulators
+// are combined into the int64 outputs once per class, and every output entry of the rectangle is written exactly once
+// (zeros for absent classes) -- no atomics, no memset of the 540 KB per rectangle.
+typedef int alf_v4i __attribute__((ext_vector_type(4)));
+typedef int alf_v16i __attribute__((ext_vector_type(16)));
+constexpr int ALF_KP = 272;        // bytes per operand row: 256 samples + pad (68 dwords = 4 mod 64: b128 reads of 16 rows tile the banks)
+constexpr int ALF_SLOTS = 16;      // 4x4 blocks per phase-A chunk (256 samples, one per thread)
+
 template <typename PX, bool CHROMA>
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(256)
 alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__ rec, int rstride, int pic_w, int pic_h,
                  const uvghip_rect_t *__restrict__ rects, const uint8_t *__restrict__ cls, int cls_stride,
                  long long *__restrict__ ee, int32_t *__restrict__ yv, long long *__restrict__ pix)
 {
   constexpr int NC = CHROMA ? 7 : 13, NCLS = CHROMA ? 1 : 25;
-  constexpr int NPAIR = NC * (NC + 1) / 2;
+  constexpr int NE = NC * 4;                   // entries of e; index NE is d = org - rec
+  constexpr int NT = CHROMA ? 1 : 2;           // 32-row tiles of the (NE + 1)-square result
+  constexpr int NROW = 32 * NT;
   constexpr int vbh = CHROMA ? 32 : 64, vb_pos = CHROMA ? 30 : 60;
   constexpr int DEPTH = px_traits<PX>::depth;
-  __shared__ __attribute__((aligned(16))) int16_t sE[256 * 52];
-  __shared__ int16_t sY[256];
-  __shared__ uint8_t sCls[64];
-  // ALF_SPLIT workgroups share one rectangle (each takes a contiguous run of the class-sorted blocks); the outputs are zeroed by the
-  // host wrapper and every flush is an atomic add
-  const int rect_i = blockIdx.x / ALF_SPLIT, part = blockIdx.x % ALF_SPLIT;
-  const uvghip_rect_t R = rects[rect_i];
-  long long *E = ee + (size_t)rect_i * NCLS * 13 * 13 * 16;
-  int32_t *Y = yv + (size_t)rect_i * NCLS * 13 * 4;
-  long long *PA = pix + (size_t)rect_i * NCLS;
+  // tile jobs: hh and ll are symmetric (upper tile triangle), hl needs all tiles
+  constexpr int N_SYM = NT * (NT + 1) / 2, N_FULL = NT * NT, N_TILES = 2 * N_SYM + N_FULL;
+  __shared__ __attribute__((aligned(16))) int8_t sH[NROW * ALF_KP], sL[NROW * ALF_KP];
+  __shared__ int sAcc[N_TILES][32][33];
+  __shared__ uint8_t sBlkCls[256];
+  __shared__ uint16_t sSlot[256 + 32];         // class-ordered block list, 0xffff = padding slot
+  __shared__ uint8_t sSlotCls[256 + 32];
+  __shared__ int sCnt[32], sPos[32];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const uvghip_rect_t R = rects[blockIdx.x];
+  long long *E = ee + (size_t)blockIdx.x * NCLS * 13 * 13 * 16;
+  int32_t *Y = yv + (size_t)blockIdx.x * NCLS * 13 * 4;
+  long long *PA = pix + (size_t)blockIdx.x * NCLS;
   int clipv[4];
   clipv[0] = 1 << DEPTH;
 #pragma unroll
   for (int i = 1; i < 4; ++i) clipv[i] = 1 << (7 - 2 * i + DEPTH - 8);     // alf.c:5248-5260
 
-  // role of this thread in phase B
-  const int t = threadIdx.x;
-  int pk = 0, pl = 0;
-  if (t < NPAIR) { int rem = t; while (rem >= NC - pk) { rem -= NC - pk; ++pk; } pl = pk + rem; }
-  const bool is_pair = t < NPAIR, is_y = t >= NPAIR && t < NPAIR + NC, is_pix = t == NPAIR + NC;
-  const int yk = t - NPAIR;
-  long long acc[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0;
-  int cur_cls = -1;
-  __syncthreads();
-
-  auto flush = [&]() {
-    if (cur_cls < 0) return;
-    if (is_pair) {
-      long long *e0 = E + ((size_t)cur_cls * 13 * 13 + pk * 13 + pl) * 16;
-      long long *e1 = E + ((size_t)cur_cls * 13 * 13 + pl * 13 + pk) * 16;
-#pragma unroll
-      for (int b0 = 0; b0 < 4; ++b0)
-#pragma unroll
-        for (int b1 = 0; b1 < 4; ++b1) {
-          if (acc[b0 * 4 + b1] == 0) continue;
-          atomicAdd(reinterpret_cast<unsigned long long *>(e0 + b0 * 4 + b1), (unsigned long long)acc[b0 * 4 + b1]);
-          if (pk != pl) atomicAdd(reinterpret_cast<unsigned long long *>(e1 + b1 * 4 + b0), (unsigned long long)acc[b0 * 4 + b1]);     // mirrored lower triangle (alf-generic.c:982-996)
-        }
-    } else if (is_y) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) if (acc[b]) atomicAdd(&Y[(cur_cls * 13 + yk) * 4 + b], (int32_t)acc[b]);
-    } else if (is_pix) {
-      if (acc[0]) atomicAdd(reinterpret_cast<unsigned long long *>(&PA[cur_cls]), (unsigned long long)acc[0]);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0;
-  };
-
-  // The rectangle's 4x4 blocks are walked in class order (counting sort in LDS): the per-thread accumulators then change
-  // class at most 25 times per rectangle instead of at nearly every block, and every change costs a read-modify-write
-  // of the thread's 2 x 16 covariance entries in global memory.  Sums are integers, so the order does not matter.
-  __shared__ uint8_t sBlkCls[256], sOrder[256];
-  __shared__ int sCnt[32], sPos[32];
+  // ---- class-ordered slot list (stable counting sort; every class padded to an even number of blocks) ----
   const int bw = (R.w + 3) / 4, bhh = (R.h + 3) / 4, nblk = bw * bhh;      // <= 256 (rectangles are at most 64x64)
   if (t < 32) sCnt[t] = 0;
+  for (int i = t; i < NROW * ALF_KP; i += 256) { sH[i] = 0; sL[i] = 0; }   // rows NE+1.. stay zero for good
   __syncthreads();
-  for (int i = t; i < nblk; i += blockDim.x) {
+  for (int i = t; i < nblk; i += 256) {
     const int by = i / bw, bx = i - by * bw;
     const int c = CHROMA ? 0 : (cls[((R.y >> 2) + by) * cls_stride + (R.x >> 2) + bx] & 31);
     sBlkCls[i] = (uint8_t)c;
     atomicAdd(&sCnt[c], 1);
   }
   __syncthreads();
-  if (t == 0) { int run = 0; for (int c = 0; c < 32; ++c) { sPos[c] = run; run += sCnt[c]; } }
+  if (t == 0) { int run = 0; for (int c = 0; c < 32; ++c) { sPos[c] = run; run += (sCnt[c] + 1) & ~1; } }
   __syncthreads();
-  // stable placement (rank among the earlier blocks of the same class): every workgroup of the rectangle must derive
-  // the same order, an atomic cursor would not
-  for (int i = t; i < nblk; i += blockDim.x) {
+  const int nslot = sPos[31] + ((sCnt[31] + 1) & ~1);                      // even
+  for (int i = t; i < nblk; i += 256) {
     const int c = sBlkCls[i];
     int rank = 0;
     for (int j = 0; j < i; ++j) rank += sBlkCls[j] == c;
-    sOrder[sPos[c] + rank] = (uint8_t)i;
+    sSlot[sPos[c] + rank] = (uint16_t)i; sSlotCls[sPos[c] + rank] = (uint8_t)c;
   }
+  if (t < 32 && (sCnt[t] & 1)) { sSlot[sPos[t] + sCnt[t]] = 0xffffu; sSlotCls[sPos[t] + sCnt[t]] = (uint8_t)t; }
   __syncthreads();
 
-  // contiguous share of the class-sorted list: a workgroup meets only a few classes, so it flushes only a few times
-  const int nchunks = (nblk + 15) >> 4, per_part = (nchunks + ALF_SPLIT - 1) / ALF_SPLIT;
-  for (int c0 = part * per_part * 16; c0 < min(nblk, (part + 1) * per_part * 16); c0 += 16) {
-    const int nb = min(16, nblk - c0);
-    // ---- phase A: tap sums of every sample of the chunk's blocks (slot = block j of the chunk, sample p of the block) ----
-    for (int i = t; i < nb * 16; i += blockDim.x) {
-      const int j = i >> 4, p = i & 15, blk = sOrder[c0 + j];
-      const int by = blk / bw, bx = blk - by * bw;
-      const int xx = bx * 4 + (p & 3), yy = by * 4 + (p >> 2);
-      if (xx < R.w && yy < R.h) {
-        const int x = R.x + xx, y = R.y + yy;
-        int tr = 0;
-        if constexpr (!CHROMA) tr = cls[(y >> 2) * cls_stride + (x >> 2)] >> 5;
-        covariance_sample<PX, CHROMA>(sE + (size_t)i * 52, rec, rstride, pic_w, pic_h, x, y, tr, (y % vbh) - vb_pos, clipv);
-        sY[i] = (int16_t)((int)org[(size_t)y * ostride + x] - (int)rec[(size_t)y * rstride + x]);
-      } else {
-        // sample outside the rectangle: contributes nothing
+  // ---- which tiles this wave accumulates: hh on wave 0, ll on wave 1, hl split over waves 2 and 3 ----
+  alf_v16i acc[3];
 #pragma unroll
-        for (int q = 0; q < 52; ++q) sE[(size_t)i * 52 + q] = 0;
-        sY[i] = 0;
+  for (int j = 0; j < 3; ++j) acc[j] = alf_v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // wave 0: H^T H tiles (0,0) (0,1) (1,1) -> sAcc 0..N_SYM-1;  wave 1: L^T L likewise -> N_SYM..;  waves 2, 3: H^T L tile row
+  // (wave - 2): tiles (a, 0) (a, 1) -> 2 * N_SYM + a * NT + b.  Everything below branches on the (uniform) wave index
+  // explicitly: no run-time indexing into register arrays.
+  const int8_t *opA = wave == 1 ? sL : sH;     // A operand digit plane
+  const int8_t *opB = wave == 0 ? sH : sL;     // B operand digit plane
+  const int hl_row = wave >= 2 ? wave - 2 : 0;
+  const bool has_work = wave < 2 || hl_row < NT;
+
+  unsigned done_mask = 0;                       // classes already written
+  int cur_cls = -1;
+  // combine the int32 tile sums into the class's int64 outputs (all threads) and clear the accumulators
+  auto flush = [&]() {
+    if (cur_cls >= 0 && has_work) {
+      const int s0 = wave < 2 ? wave * N_SYM : 2 * N_SYM + hl_row * NT;
+      constexpr int NJ = NT == 1 ? 1 : 3;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (wave >= 2 && j >= NT) break;       // an hl tile row has NT tiles
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sAcc[s0 + j][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][lane & 31] = acc[j][r];
+        acc[j] = alf_v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       }
     }
-    if (t < nb) sCls[t] = sBlkCls[sOrder[c0 + t]];
     __syncthreads();
-    // ---- phase B: outer products, block by block ----
-    if (is_pair || is_y || is_pix) {
-      for (int j = 0; j < nb; ++j) {
-        const int c = sCls[j];
-        if (c != cur_cls) { flush(); cur_cls = c; }
-        int part[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) part[i] = 0;
-        for (int p = j * 16; p < j * 16 + 16; ++p) {
-          const int16_t *e = sE + (size_t)p * 52;
-          if (is_pair) {
-            const short4 ek = *reinterpret_cast<const short4 *>(e + pk * 4), el = *reinterpret_cast<const short4 *>(e + pl * 4);
-            const int a[4] = {ek.x, ek.y, ek.z, ek.w}, bb[4] = {el.x, el.y, el.z, el.w};
-#pragma unroll
-            for (int b0 = 0; b0 < 4; ++b0)
-#pragma unroll
-              for (int b1 = 0; b1 < 4; ++b1) part[b0 * 4 + b1] += a[b0] * bb[b1];
-          } else if (is_y) {
-            const short4 ek = *reinterpret_cast<const short4 *>(e + yk * 4);
-            const int yl = sY[p];
-            part[0] += ek.x * yl; part[1] += ek.y * yl; part[2] += ek.z * yl; part[3] += ek.w * yl;
-          } else {
-            const int yl = sY[p];
-            part[0] += yl * yl;
+    if (cur_cls >= 0) {
+      auto sym = [&](int base, int i, int j2) -> long long {      // symmetric product stored as its upper tile triangle
+        int ti = i >> 5, tj = j2 >> 5;
+        if (ti > tj) { const int x = i; i = j2; j2 = x; ti = i >> 5; tj = j2 >> 5; }
+        const int q = ti == 0 ? tj : NT + tj - 1;                  // (0,0) (0,1) (1,1) -> 0 1 2
+        return sAcc[base + q][i & 31][j2 & 31];
+      };
+      auto full = [&](int i, int j2) -> long long { return sAcc[2 * N_SYM + (i >> 5) * NT + (j2 >> 5)][i & 31][j2 & 31]; };
+      auto cval = [&](int i, int j2) -> long long {
+        return sym(0, i, j2) * 16384 + (full(i, j2) + full(j2, i)) * 128 + sym(N_SYM, i, j2);
+      };
+      long long *Ec = E + (size_t)cur_cls * 13 * 13 * 16;
+      for (int idx = t; idx < 13 * 13 * 16; idx += 256) {
+        const int b1 = idx & 3, b0 = (idx >> 2) & 3, kl = idx >> 4, k = kl / 13, l = kl - k * 13;
+        Ec[idx] = (k < NC && l < NC) ? cval(4 * k + b0, 4 * l + b1) : 0;
+      }
+      for (int idx = t; idx < 13 * 4; idx += 256) Y[cur_cls * 13 * 4 + idx] = (idx >> 2) < NC ? (int32_t)cval(idx, NE) : 0;
+      if (t == 0) PA[cur_cls] = cval(NE, NE);
+      done_mask |= 1u << cur_cls;
+    }
+    __syncthreads();
+  };
+
+  for (int c0 = 0; c0 < nslot; c0 += ALF_SLOTS) {
+    const int ns = min(ALF_SLOTS, nslot - c0);                    // even
+    // ---- phase A: one sample per thread: tap sums -> digit planes ----
+    {
+      const int j = t >> 4, p = t & 15;
+      int16_t ev[52];
+      int dval = 0;
+      bool live = false;
+      if (j < ns) {
+        const int blk = sSlot[c0 + j];
+        if (blk != 0xffff) {
+          const int by = blk / bw, bx = blk - by * bw;
+          const int xx = bx * 4 + (p & 3), yy = by * 4 + (p >> 2);
+          if (xx < R.w && yy < R.h) {
+            const int x = R.x + xx, y = R.y + yy;
+            int tr = 0;
+            if constexpr (!CHROMA) tr = cls[(y >> 2) * cls_stride + (x >> 2)] >> 5;
+            covariance_sample<PX, CHROMA>(ev, rec, rstride, pic_w, pic_h, x, y, tr, (y % vbh) - vb_pos, clipv);
+            dval = (int)org[(size_t)y * ostride + x] - (int)rec[(size_t)y * rstride + x];
+            live = true;
           }
         }
+      }
+      if (j < ns) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] += part[i];
+        for (int q = 0; q < NE; ++q) {
+          const int v = live ? (int)ev[q] : 0;
+          sH[q * ALF_KP + t] = (int8_t)(v >> 7); sL[q * ALF_KP + t] = (int8_t)(v & 127);
+        }
+        sH[NE * ALF_KP + t] = (int8_t)(dval >> 7); sL[NE * ALF_KP + t] = (int8_t)(dval & 127);
+      }
+    }
+    __syncthreads();
+    // ---- phase B: K = 32 samples (two slots of one class) per step ----
+    for (int q = 0; q < ns; q += 2) {
+      const int c = sSlotCls[c0 + q];
+      if (c != cur_cls) { flush(); cur_cls = c; }
+      const int koff = q * 16 + 16 * (lane >> 5);
+      auto frag = [&](const int8_t *plane, int tile) {
+        return *reinterpret_cast<const alf_v4i *>(plane + (tile * 32 + (lane & 31)) * ALF_KP + koff);
+      };
+      if (wave < 2) {                           // symmetric products: the B fragments are the A fragments
+        const alf_v4i f0 = frag(opA, 0);
+        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f0, f0, acc[0], 0, 0, 0);
+        if constexpr (NT == 2) {
+          const alf_v4i f1 = frag(opA, 1);
+          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f0, f1, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f1, f1, acc[2], 0, 0, 0);
+        }
+      } else if (has_work) {
+        const alf_v4i fa = frag(opA, hl_row), fb0 = frag(opB, 0);
+        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb0, acc[0], 0, 0, 0);
+        if constexpr (NT == 2) {
+          const alf_v4i fb1 = frag(opB, 1);
+          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb1, acc[1], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
   }
   flush();
+  cur_cls = -1;
+  // classes without a block in this rectangle: zeros
+  for (int c = 0; c < NCLS; ++c) {
+    if (done_mask >> c & 1) continue;
+    for (int idx = t; idx < 13 * 13 * 16; idx += 256) E[(size_t)c * 13 * 13 * 16 + idx] = 0;
+    if (t < 13 * 4) Y[c * 13 * 4 + t] = 0;
+    if (t == 0) PA[c] = 0;
+  }
 }
 
 extern "C" int uvghip_alf_stats_batch(int bitdepth, const void *org, int org_stride, const void *rec, int rec_stride, int pic_w,
@@ -378,11 +423,7 @@ extern "C" int uvghip_alf_stats_batch(int bitdepth, const void *org, int org_str
   UVGHIP_REQUIRE_READY();
   if (n <= 0) return 0;
   hipStream_t st = uvghip_stream(stream);
-  const int ncls = is_chroma ? 1 : 25;
-  UVGHIP_TRY(hipMemsetAsync(ee, 0, (size_t)n * ncls * 13 * 13 * 16 * 8, st));
-  UVGHIP_TRY(hipMemsetAsync(y, 0, (size_t)n * ncls * 13 * 4 * 4, st));
-  UVGHIP_TRY(hipMemsetAsync(pix_acc, 0, (size_t)n * ncls * 8, st));
-#define K(PX, C) alf_stats_kernel<PX, C><<<n * ALF_SPLIT, 128, 0, st>>>((const PX *)org, org_stride, (const PX *)rec, rec_stride, pic_w, pic_h, rects, cls, cls_stride, (long long *)ee, y, (long long *)pix_acc)
+#define K(PX, C) alf_stats_kernel<PX, C><<<n, 256, 0, st>>>((const PX *)org, org_stride, (const PX *)rec, rec_stride, pic_w, pic_h, rects, cls, cls_stride, (long long *)ee, y, (long long *)pix_acc)
   if (bitdepth == 8) { if (is_chroma) K(uint8_t, true); else K(uint8_t, false); }
   else { if (is_chroma) K(uint16_t, true); else K(uint16_t, false); }
 #undef K
