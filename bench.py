@@ -7,7 +7,7 @@
 One "step" = one pass of the hot path over one synthetic 1920x1080 8-bit
 yuv420p frame (BASELINE.json configs[1]: all-intra, --preset medium path:
 intra prediction + DCT/quant [+ in-loop filters as they land]), with the frame
-already resident in HBM.  See WORKLOAD below and DESIGN.md "Measurement" for
+already resident in HBM.  See workload_text() below and DESIGN.md "Measurement" for
 exactly which kernels run; serial RDOQ/CABAC are outside the hot-path scope
 (SURVEY.md section 8), so this is hot-path frames/s, not .266 frames/s.
 
@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 from uvg266_amd import api, layout, lib  # noqa: E402
 
 W, H, DEPTH, QP = 1920, 1080, 8, 22
+ALF = False                       # --workload 2160p10alf adds the ALF kernels of config C4 (--alf full)
 SIZES = (32, 16, 8, 4)            # --pu-depth-intra 1-4 (cfg.c:769-801)
 MODES = list(range(67))           # every luma mode; the reference's rough search visits a subset
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
@@ -46,10 +47,13 @@ try:
 except OSError:
     pass
 N_SIMD, CLOCK_GHZ, CYC_PER_VALU = 1024, 2.4, 4     # MI355X: 256 CUs x 4 SIMDs; peak engine clock; wave64 op = 4 cycles on a 16-lane SIMD
-WORKLOAD = ("1920x1080 8-bit yuv420p, all-intra medium hot path per frame: luma, for N in 32,16,8,4 "
+def workload_text():
+    alf = ("-> ALF classification (4x4 Laplacian classes) -> ALF covariance statistics per CTU and class (i8 MFMA) -> ALF "
+           "7x7 luma filter " if ALF else "")
+    return (f"{W}x{H} {DEPTH}-bit yuv420p, all-intra medium hot path per frame: luma, for N in 32,16,8,4 "
             "{intra rough search 67 modes min(SATD,2SAD) on all NxN blocks with fused arg-min -> intra predict "
             "-> fused residual/DCT-2/quant/dequant/IDCT/recon}; then deblock (Y,U,V; seeded random quad-tree "
-            "partition) -> SAO statistics (4 edge classes + bands per CTU) -> SAO apply; open-loop references "
+            f"partition) -> SAO statistics (4 edge classes + bands per CTU) -> SAO apply {alf}; open-loop references "
             "(source picture); serial RDOQ/CABAC excluded (out of hot-path scope)")
 
 
@@ -102,6 +106,30 @@ class Frame:
             ("sao_apply_0", L.uvghip_sao_apply_batch,
              [DEPTH, P(rec), ys, P(self.sao_out), ys, W, H, P(self.rects), P(self.params), self.n_ctu]),
         ]
+        if ALF:
+            # config C4 (--alf full): classify the SAO output, gather the per-CTU/class covariances against the source,
+            # filter with a fixed coefficient set (deriving the filters from the covariances is host-side, alf.c:792-835)
+            self.alf_cls = torch.zeros((H // 4, W // 4), dtype=torch.uint8, device=device)
+            self.alf_ee = torch.empty((self.n_ctu, 25, 13, 13, 4, 4), dtype=torch.int64, device=device)
+            self.alf_y = torch.empty((self.n_ctu, 25, 13, 4), dtype=torch.int32, device=device)
+            self.alf_pix = torch.empty((self.n_ctu, 25), dtype=torch.int64, device=device)
+            self.alf_out = torch.zeros_like(self.y)
+            g = torch.Generator().manual_seed(7)
+            coefs = torch.randint(-8, 9, (1, 25, 13), dtype=torch.int16, generator=g)
+            coefs[:, :, 12] = 0
+            self.alf_coefs = coefs.to(device)
+            self.alf_clips = torch.full((1, 25, 13), 1 << DEPTH, dtype=torch.int16, device=device)
+            self.alf_set = torch.zeros(self.n_ctu, dtype=torch.int32, device=device)
+            so = self.sao_out
+            self.tail += [
+                ("alf_classify_0", L.uvghip_alf_classify_frame, [DEPTH, P(so), ys, W, H, DEPTH + 4, P(self.alf_cls), self.alf_cls.stride(0)]),
+                ("alf_stats_0", L.uvghip_alf_stats_batch,
+                 [DEPTH, P(self.y), ys, P(so), ys, W, H, 0, P(self.rects), self.n_ctu, P(self.alf_cls), self.alf_cls.stride(0),
+                  P(self.alf_ee), P(self.alf_y), P(self.alf_pix)]),
+                ("alf_filter_0", L.uvghip_alf_filter_batch,
+                 [DEPTH, P(so), ys, P(self.alf_out), ys, W, H, 0, P(self.rects), P(self.alf_set), self.n_ctu, P(self.alf_coefs),
+                  P(self.alf_clips), P(self.alf_cls), self.alf_cls.stride(0)]),
+            ]
         self.ev_chain = [torch.cuda.Event() for _ in SIZES]
         self.ev_done = torch.cuda.Event()
         self.ev_done.record()
@@ -149,7 +177,7 @@ class KernelClock:
 
 def algorithmic_bytes(kernel, n, count):
     """SURVEY.md 8(d) per-unit figures x units per launch (b = 1 byte per 8-bit sample)."""
-    b = 1
+    b = DEPTH // 8 if DEPTH % 8 == 0 else 2
     if kernel == "intra_search":      # refs (4N+1) + original NxN read, best mode + cost written (fused arg-min)
         return count * ((4 * n + 1) * b + n * n * b + 5)
     if kernel == "intra_pred_plane":  # refs read, NxN written
@@ -166,6 +194,12 @@ def algorithmic_bytes(kernel, n, count):
         return count * (40 + 8) * 4
     if kernel == "sao_apply":         # rec read, out written (+ 32 B parameters per CTU)
         return W * H * 2 * b + count * 32
+    if kernel == "alf_classify":      # SAO output read, one class byte per 4x4 written
+        return W * H * b + W * H // 16
+    if kernel == "alf_stats":         # orig + rec read, 25 covariances (13x13x16 int64 + 13x4 int32 + int64) per CTU written
+        return W * H * 2 * b + count * 25 * (13 * 13 * 16 * 8 + 13 * 4 * 4 + 8)
+    if kernel == "alf_filter":        # read + write
+        return W * H * 2 * b
     raise KeyError(kernel)
 
 
@@ -264,7 +298,13 @@ def main():
     ap.add_argument("--serial", action="store_true", help="one stream: no overlap between block sizes / frames")
     ap.add_argument("--stream-sets", type=int, default=2, help="sets of per-block-size streams (frames alternate between them)")
     ap.add_argument("--profile-steps", type=int, default=4, help="untimed, fully instrumented steps for the per-kernel table")
+    ap.add_argument("--workload", choices=("1080p8", "2160p10alf"), default="1080p8",
+                    help="1080p8 = BASELINE.json configs[1] (the default, the judged line); 2160p10alf = configs[3]: 3840x2160 "
+                         "10-bit with the ALF kernels (extra line, no cpu_baseline)")
     args = ap.parse_args()
+    global W, H, DEPTH, ALF
+    if args.workload == "2160p10alf":
+        W, H, DEPTH, ALF = 3840, 2160, 10, True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -345,11 +385,11 @@ def main():
         per_kernel_live = live
         fps = args.steps * world / elapsed
         out = {
-            "metric": "hot-path fps (1080p all-intra medium kernel path; Mpixels/s in config)",
+            "metric": f"hot-path fps ({H}p all-intra medium kernel path; Mpixels/s in config)",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": WORKLOAD, "mpixels_per_s": round(fps * W * H / 1e6, 1), "qp": QP,
+            "vs_baseline": None, "dtype": "u8" if DEPTH == 8 else "u16", "data": "synthetic",
+            "config": {"workload": workload_text(), "mpixels_per_s": round(fps * W * H / 1e6, 1), "qp": QP,
                        "parallelism": f"frames sharded over {world} rank(s), no data-path collective",
                        "streams": 1 if args.serial else 1 + len(SIZES) * args.stream_sets},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": live[dom]["gbs"], "peak": HBM_PEAK_GBS,
@@ -370,7 +410,7 @@ def main():
             "kernels_timed_region": per_kernel_live,
             "kernels": per_kernel,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "1080p8":
             out["cpu_baseline"] = cpu_baseline(frames[0].host_y, frames[0].host_u, frames[0].host_v)
         print(json.dumps(out))
     if dist:
