@@ -305,6 +305,7 @@ def main():
     global W, H, DEPTH, ALF
     if args.workload == "2160p10alf":
         W, H, DEPTH, ALF = 3840, 2160, 10, True
+        TRAFFIC.clear(); VALU.clear()            # the PMC figures under profiles/ belong to the default workload
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -8,7 +8,7 @@
 #   prof_valu          SQ instruction counts per launch (--serial)
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-rm -rf gpurun_out/prof_stats gpurun_out/prof_stats_serial gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_valu
+rm -rf gpurun_out/prof_stats gpurun_out/prof_stats_serial gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_valu gpurun_out/prof_stats_4k
 CMD="python bench.py --steps 40 --warmup 4 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- $CMD > gpurun_out/prof_stats.log 2>&1
 grep '^{' gpurun_out/prof_stats.log | tail -1 > gpurun_out/prof_bench_line.json
@@ -16,4 +16,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats_se
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -- $CMD --serial > gpurun_out/prof_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -- $CMD --serial > gpurun_out/prof_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d gpurun_out/prof_valu -- $CMD --serial > gpurun_out/prof_valu.log 2>&1
+#   prof_stats_4k      kernel-trace statistics of the extra workload (3840x2160 10-bit + ALF), serial
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats_4k -- python bench.py --workload 2160p10alf --steps 12 --warmup 2 --serial > gpurun_out/prof_stats_4k.log 2>&1
 ls gpurun_out/prof_stats/*/ gpurun_out/prof_stats_serial/*/ gpurun_out/prof_fetch/*/ 2>/dev/null | head -30

@@ -14,6 +14,10 @@ stats = newest("gpurun_out/prof_stats/**/*kernel_stats.csv")
 shutil.copy(stats, f"profiles/{tag}_bench_kernel_stats.csv")
 shutil.copy(newest("gpurun_out/prof_stats_serial/**/*kernel_stats.csv"), f"profiles/{tag}_bench_kernel_stats_serial.csv")
 shutil.copy("gpurun_out/prof_bench_line.json", f"profiles/{tag}_bench_line_profiled.json")
+try:
+    shutil.copy(newest("gpurun_out/prof_stats_4k/**/*kernel_stats.csv"), f"profiles/{tag}_bench4k_kernel_stats_serial.csv")
+except ValueError:
+    pass
 
 def per_kernel(dirname, counter):
     f = newest(f"gpurun_out/{dirname}/**/*counter_collection.csv")
