@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 from uvg266_amd import api, layout, lib  # noqa: E402
 
 W, H, DEPTH, QP = 1920, 1080, 8, 22
+HOST_DEBUG = [0.0] if os.environ.get("UVGHIP_BENCH_DEBUG") else None   # seconds the host spent waiting for a frame slot
 ALF = False                       # --workload 2160p10alf adds the ALF kernels of config C4 (--alf full)
 SIZES = (32, 16, 8, 4)            # --pu-depth-intra 1-4 (cfg.c:769-801)
 MODES = list(range(67))           # every luma mode; the reference's rough search visits a subset
@@ -131,6 +132,7 @@ class Frame:
                   P(self.alf_clips), P(self.alf_cls), self.alf_cls.stride(0)]),
             ]
         self.ev_chain = [torch.cuda.Event() for _ in SIZES]
+        self.ev_small = torch.cuda.Event()
         self.ev_done = torch.cuda.Event()
         self.ev_done.record()
 
@@ -209,7 +211,11 @@ def hot_path_step(fr, clock, timed, main, side):
     side=None runs everything in order on `main` (profile pass)."""
     # at most n_resident frames in flight: the host waits for this frame's previous use (queueing thousands of
     # launches ahead of the GPU makes the HIP runtime itself slow)
+    if HOST_DEBUG is not None:
+        _t = time.perf_counter()
     fr.ev_done.synchronize()
+    if HOST_DEBUG is not None:
+        HOST_DEBUG[0] += time.perf_counter() - _t
     clock.harvest(id(fr))
     for k, chain in enumerate(fr.chains):
         st = side[k] if side else main
@@ -223,6 +229,36 @@ def hot_path_step(fr, clock, timed, main, side):
         for ev in fr.ev_chain:
             main.wait_event(ev)
     fr.u_rec.copy_(fr.u)                         # torch copies run on the current (= main) stream
+    fr.v_rec.copy_(fr.v)
+    for name, fn, args in fr.tail:
+        clock.launch(name, fn, args, main, timed, id(fr))
+    fr.ev_done.record(main)
+
+
+def hot_path_step_split(fr, clock, timed, main, sx, sy, sz):
+    """Same launches, other stream plan (--schedule split): the searches -- the only VALU-heavy kernels -- run back to back
+    on two streams (32/16 on sx, 8/4 on sy: two searches on the GPU at any time, never a window where all chains are in
+    their small latency-bound kernels at once), every predict / TU round trip on sz behind its search's event, the
+    in-loop filters on main.  Four streams = the runtime's four hardware queues, none shared."""
+    if HOST_DEBUG is not None:
+        _t = time.perf_counter()
+    fr.ev_done.synchronize()
+    if HOST_DEBUG is not None:
+        HOST_DEBUG[0] += time.perf_counter() - _t
+    clock.harvest(id(fr))
+    for st, ks in (((sx, (0, 1, 2, 3)),) if sy is None else ((sx, (0, 1)), (sy, (2, 3)))):
+        st.wait_event(fr.ev_done)                # this frame's buffers: their previous use has retired
+        for k in ks:
+            name, fn, args = fr.chains[k][0]
+            clock.launch(name, fn, args, st, timed, id(fr))
+            fr.ev_chain[k].record(st)
+    for k, chain in enumerate(fr.chains):
+        sz.wait_event(fr.ev_chain[k])
+        for name, fn, args in chain[1:]:
+            clock.launch(name, fn, args, sz, timed, id(fr))
+    fr.ev_small.record(sz)
+    main.wait_event(fr.ev_small)
+    fr.u_rec.copy_(fr.u)
     fr.v_rec.copy_(fr.v)
     for name, fn, args in fr.tail:
         clock.launch(name, fn, args, main, timed, id(fr))
@@ -298,6 +334,9 @@ def main():
     ap.add_argument("--serial", action="store_true", help="one stream: no overlap between block sizes / frames")
     ap.add_argument("--stream-sets", type=int, default=2, help="sets of per-block-size streams (frames alternate between them)")
     ap.add_argument("--profile-steps", type=int, default=4, help="untimed, fully instrumented steps for the per-kernel table")
+    ap.add_argument("--search-streams", type=int, default=2, choices=(1, 2), help="--schedule split: streams the searches alternate over")
+    ap.add_argument("--schedule", choices=("chains", "split"), default="split",
+                    help="chains: one stream per block size (x --stream-sets); split: searches on two streams, small kernels on a third")
     ap.add_argument("--workload", choices=("1080p8", "2160p10alf"), default="1080p8",
                     help="1080p8 = BASELINE.json configs[1] (the default, the judged line); 2160p10alf = configs[3]: 3840x2160 "
                          "10-bit with the ALF kernels (extra line, no cpu_baseline)")
@@ -332,9 +371,16 @@ def main():
     # the chains of frame f are still draining
     side_sets = None if args.serial else [[torch.cuda.Stream(device=device) for _ in SIZES] for _ in range(args.stream_sets)]
     side = None if args.serial else side_sets[0]
+    split = None if (args.serial or args.schedule != "split") else [torch.cuda.Stream(device=device) for _ in range(3)]
+
+    def step(fr, clk, timed, s_idx):
+        if split:
+            hot_path_step_split(fr, clk, timed, main_stream, split[0], split[1] if args.search_streams == 2 else None, split[2])
+        else:
+            hot_path_step(fr, clk, timed, main_stream, side_sets[s_idx % len(side_sets)] if side_sets else None)
 
     for s in range(args.warmup):
-        hot_path_step(frames[s % n_resident], clock, False, main_stream, side_sets[s % len(side_sets)] if side_sets else None)
+        step(frames[s % n_resident], clock, False, s)
     torch.cuda.synchronize()
 
     # untimed profile pass: every kernel bracketed by HIP events -> per-kernel breakdown and the dominant family
@@ -353,14 +399,23 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
+    if HOST_DEBUG is not None:
+        HOST_DEBUG[:] = [0.0, 0.0]
     t0 = time.perf_counter()
     for s in range(args.steps):
-        hot_path_step(frames[s % n_resident], clock, True, main_stream, side_sets[s % len(side_sets)] if side_sets else None)
+        step(frames[s % n_resident], clock, True, s)
+    if HOST_DEBUG is not None:
+        _t = time.perf_counter()
     torch.cuda.synchronize()
+    if HOST_DEBUG is not None:
+        HOST_DEBUG[1] = HOST_DEBUG[0] + time.perf_counter() - _t
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if HOST_DEBUG is not None and rank == 0:
+        print(f"[debug] timed region {elapsed * 1e3:.1f} ms, host blocked on frame slots {HOST_DEBUG[1] * 1e3:.1f} ms "
+              f"(issue time per step {(elapsed - HOST_DEBUG[1]) / args.steps * 1e6:.0f} us)", file=sys.stderr)
     if dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
