@@ -48,6 +48,10 @@ try:
 except OSError:
     pass
 N_SIMD, CLOCK_GHZ, CYC_PER_VALU = 1024, 2.4, 4     # MI355X: 256 CUs x 4 SIMDs; peak engine clock; wave64 op = 4 cycles on a 16-lane SIMD
+# what a SIMD actually sustains under load (tools/dev/valu_rate.hip, profiles/r01e_microbench.txt): one full-rate wave
+# instruction (v_add3 / v_perm / v_sad_u16 / v_pk_mad) per 4.85 cycles of the nominal 2.4 GHz clock, i.e. the clock under
+# sustained VALU load is ~2.0 GHz; v_dot2_i32_i16 / v_mad_i32_i24 take 6.2
+MEASURED_CYC_PER_VALU = 4.85
 def workload_text():
     alf = ("-> ALF classification (4x4 Laplacian classes) -> ALF covariance statistics per CTU and class (i8 MFMA) -> ALF "
            "7x7 luma filter " if ALF else "")
@@ -461,8 +465,12 @@ def main():
             "valu": (lambda v: None if v is None else {
                 "kernel": dom, "insts_per_launch": v["valu_insts"],
                 "issue_util_alone": round(v["valu_insts"] * CYC_PER_VALU / (N_SIMD * per_kernel[dom]["avg_ms"] * 1e-3 * CLOCK_GHZ * 1e9), 3),
-                "note": "SQ_INSTS_VALU (PMC, --serial) x 4 cycles / (1024 SIMDs x launch duration alone x 2.4 GHz): the limiter of "
-                        "the dominant kernel is integer VALU issue, not HBM (the real clock under load is below 2.4 GHz, so this is a floor)"})(VALU.get(dom)),
+                "issue_util_vs_measured_rate": round(v["valu_insts"] * MEASURED_CYC_PER_VALU / (N_SIMD * per_kernel[dom]["avg_ms"] * 1e-3 * CLOCK_GHZ * 1e9), 3),
+                "note": "SQ_INSTS_VALU (PMC, --serial) x 4 cycles / (1024 SIMDs x launch duration alone (with its event pair) x 2.4 GHz): "
+                        "the limiter of the dominant kernel is integer VALU issue, not HBM.  issue_util_vs_measured_rate prices an "
+                        "instruction at the 4.85 cycles a SIMD sustains for full-rate ops in tools/dev/valu_rate.hip "
+                        "(profiles/r01e_microbench.txt; a quarter of the kernel's ops are v_dot2 at 6.2), i.e. the fraction of the "
+                        "VALU issue rate the hardware really delivers"})(VALU.get(dom)),
             "kernels_timed_region": per_kernel_live,
             "kernels": per_kernel,
         }
