@@ -748,6 +748,63 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
   }
 }
 
+// Smoothing-filter modes on 8-bit samples, non-negative angles (the majority of the candidates of 16x16 and 32x32 blocks).
+// The 4-tap smoothing kernel is (16 - h, 32 - h, 16 + h, h), h = fraction >> 1 (intra-generic.c:206-214), so
+//     sum f_k p_k + 32 = A + h * B,   A = 16 (p0 + 2 p1 + p2) + 32,   B = p2 + p3 - p0 - p1,
+// exactly.  A and B do not depend on the mode: they are staged once per block as two more pair rows per reference side
+// (rowA, rowB: dword i = values i and i + 1), and a row of the tile is four aligned dword reads of each followed by one
+// v_pk_mad_i16 and one v_pk_ashrrev_i16 per sample pair -- 8 VALU and 8 window dwords per row instead of 20 and 10
+// (+ the tap fetch).  Ranges: A <= 16352, |h B| <= 15 * 510, so everything stays inside int16; the result is a convex
+// combination of samples (no clamp).  PDPC as in search_tile_angular (0 none, 2 projected side sample).
+template <int T, int PDPC>
+__device__ __forceinline__ void search_tile_angular_ab(const search_mode &S, const uint32_t *side, const uint32_t *rowA,
+                                                       const uint32_t *rowB, const uint16_t *wrow, const uint16_t *sorow,
+                                                       int n, int xd0, int yd0, const uint16_t *otile,
+                                                       uint32_t (&d)[T][T / 2], uint32_t &sad)
+{
+  static_assert(T == 8, "used for 16x16 / 32x32 blocks only");
+  uint32_t wpk[T / 2];
+  const uint16_t *sp[T];
+  if constexpr (PDPC == 2) {
+    const uint4 w = *reinterpret_cast<const uint4 *>(wrow + xd0), o = *reinterpret_cast<const uint4 *>(sorow + xd0);
+    wpk[0] = w.x; wpk[1] = w.y; wpk[2] = w.z; wpk[3] = w.w;
+    const uint32_t so[4] = {o.x, o.y, o.z, o.w};
+    const char *sbase = reinterpret_cast<const char *>(side + yd0);
+#pragma unroll
+    for (int i = 0; i < T; ++i) sp[i] = reinterpret_cast<const uint16_t *>(sbase + ((so[i >> 1] >> (16 * (i & 1))) & 0xffffu));
+  }
+  struct ab_row { uint32_t a[T / 2], b[T / 2], hh, o[T / 2]; };
+  auto load = [&](int r, ab_row &R) {
+    load_orig_row<T>(otile, n, r, R.o);
+    const int delta = __mul24(S.sd, yd0 + r + 1), k0 = (delta >> 5) + xd0, h = (delta & 31) >> 1;
+    R.hh = (uint32_t)h | ((uint32_t)h << 16);
+#pragma unroll
+    for (int c = 0; c < T / 2; ++c) { R.a[c] = rowA[k0 + 2 * c]; R.b[c] = rowB[k0 + 2 * c]; }
+  };
+  ab_row A, B;
+  constexpr bool PREFETCH = PDPC != 2;
+  if constexpr (PREFETCH) load(0, A);
+#pragma unroll
+  for (int r = 0; r < T; ++r) {
+    if constexpr (PREFETCH) { if (r + 1 < T) load(r + 1, B); }
+    else load(r, A);
+    uint32_t pp[T / 2];
+#pragma unroll
+    for (int c = 0; c < T / 2; ++c) {
+      const pk_s16 acc = __builtin_bit_cast(pk_s16, A.b[c]) * __builtin_bit_cast(pk_s16, A.hh) + __builtin_bit_cast(pk_s16, A.a[c]);
+      pk_s16 v = acc >> (pk_s16){6, 6};
+      if constexpr (PDPC == 2) {
+        const pk_s16 l = {(short)sp[2 * c][2 * r], (short)sp[2 * c + 1][2 * r]};
+        const pk_s16 w = __builtin_bit_cast(pk_s16, wpk[c]);
+        v = v + (((l - v) * w + (pk_s16){32, 32}) >> (pk_s16){6, 6});
+      }
+      pp[c] = __builtin_bit_cast(uint32_t, v);
+    }
+    finish_row<T>(pp, A.o, d[r], sad);
+    if constexpr (PREFETCH) A = B;
+  }
+}
+
 // planar (intra-generic.c:306-361) or DC, both with the planar/DC PDPC (:414-437).
 // ((hor << lg) + (ver << lg) + (1 << 2lg)) >> (2lg + 1) == (hor + ver + n) >> (lg + 1); hor and ver are
 // linear in x and y, so they advance by one addition per sample.
@@ -813,6 +870,7 @@ struct search_layout {
   int RS;        // samples per reference row (u16 scratch) = dwords per pair row
   int BRS;       // dwords per block: four pair rows, odd so that the wave's lanes spread over the banks
   int OS;        // uint16 elements per block: original + transpose + pad
+  int AB;        // 8-bit, n >= 16: four more pair rows per block (A and B of the smoothing filter for top and left)
   int BAND;      // uint16 elements per band of T rows of the original (T * n + pad)
   int OT;        // uint16 offset of the transposed copy inside the block's original area
   int PS;        // dwords per private extended row (odd)
@@ -842,7 +900,8 @@ __host__ __device__ inline search_layout make_search_layout(int n, int bpg, int 
   // of all 65 angular modes (tools/dev/lds_bank_model.py); original rows are read as b128 at band * BAND + row * n +
   // 8 * column, where a band stride of 0 mod 64 dwords (32x32: 8 rows of 16 dwords) puts all four tile rows on the
   // same banks -- the pad makes it 4 mod 16 quads, so (column, row) tile the 64 banks exactly.
-  L.BRS = 4 * L.RS + (n == 16 ? UVGHIP_BRS16_PAD : (n == 32 ? UVGHIP_BRS32_PAD : 1));
+  L.AB = pxsz == 1 && n >= 16;
+  L.BRS = (L.AB ? 8 : 4) * L.RS + (n == 16 ? UVGHIP_BRS16_PAD : (n == 32 ? UVGHIP_BRS32_PAD : 1));
   L.PS = n == 16 ? UVGHIP_PS16 : (n == 32 ? UVGHIP_PS32 : 2 * n + 1);
   // Original rows are read as one b128 (4x4: b64) per lane, which the LDS serves 16 (32) lanes per cycle; the 16
   // lanes of such a group must land on 16 different bank quads, q = block * OSq + band * BANDq + row * rowq + column:
@@ -987,6 +1046,18 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
           const int e = row * L.RS + i;
           pr[e] = (uint32_t)base[e] | (i + 1 < L.RS ? (uint32_t)base[e + 1] << 16 : 0u);
         }
+      if (L.AB) {
+        // rows 4..7: A(top), B(top), A(left), B(left) of the unfiltered references (see search_tile_angular_ab)
+        for (int e = mytid; e < 2 * L.RS; e += tpb) {
+          const int side_i = e >= L.RS, i = e - side_i * L.RS;
+          const uint16_t *b = base + side_i * L.RS;
+          auto at = [&](int j) { return j < L.RS ? (int)b[j] : 0; };
+          const int a0 = 16 * (at(i) + 2 * at(i + 1) + at(i + 2)) + 32, a1 = 16 * (at(i + 1) + 2 * at(i + 2) + at(i + 3)) + 32;
+          const int b0 = at(i + 2) + at(i + 3) - at(i) - at(i + 1), b1 = at(i + 3) + at(i + 4) - at(i + 1) - at(i + 2);
+          pr[(4 + 2 * side_i) * L.RS + i] = (uint32_t)(a0 & 0xffff) | ((uint32_t)a1 << 16);
+          pr[(5 + 2 * side_i) * L.RS + i] = (uint32_t)(b0 & 0xffff) | ((uint32_t)b1 << 16);
+        }
+      }
     }
     __syncthreads();   // also: the scratch image is dead from here on, its space becomes the private strips
   }
@@ -1058,7 +1129,14 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       if (S.kind == 2) {
         const uint32_t *rowp = neg ? priv + n : mainr;
         const uint16_t *wrow = sWtab + S.scale * n, *sorow = sSoTab + m * n;     // wave-uniform rows; the lane adds its xd0
-        if (S.pdpc == 0) {
+        if (T == 8 && sizeof(PX) == 1 && L.AB && S.coef == 32 && !neg) {
+          // smoothing taps, non-negative angle: A + h * B on the precomputed rows (S.row_main is an unfiltered row here)
+          if constexpr (T == 8 && sizeof(PX) == 1) {
+            const uint32_t *rowA = ref + (4 + 2 * S.row_main) * L.RS, *rowB = rowA + L.RS;
+            if (S.pdpc == 2) search_tile_angular_ab<T, 2>(S, side, rowA, rowB, wrow, sorow, n, xd0, yd0, ot, d, sad);
+            else search_tile_angular_ab<T, 0>(S, side, rowA, rowB, wrow, sorow, n, xd0, yd0, ot, d, sad);
+          }
+        } else if (S.pdpc == 0) {
           if (S.noclamp) search_tile_angular<T, 0, false, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, wrow, sorow, n, xd0, yd0, ot, maxv, d, sad);
           else search_tile_angular<T, 0, true, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, wrow, sorow, n, xd0, yd0, ot, maxv, d, sad);
         } else if (S.pdpc == 2) {
