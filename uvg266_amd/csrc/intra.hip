@@ -487,21 +487,22 @@ extern "C" int uvghip_intra_select_best(const uint32_t *costs, int n, const int8
 
 // ----------------------------------------------------------------------- search kernel ----
 // Tile-per-lane rough search.  A workgroup owns 64 tiles (T x T, T = 8, or 4 for 4x4 blocks) =
-// 64 / tiles_per_block blocks; lane l of every wave is tile l.  The four waves walk the candidate
-// list (wave w takes modes w, w+4, ...), so the mode -- and with it every branch of the predictor --
-// is uniform across the wave.  A lane predicts its whole tile row by row in registers, subtracts the
-// original (packed 16-bit pairs straight from LDS), accumulates SAD with v_sad_u16 and runs the
-// Hadamard in its own registers (satd_tile_dev.h).  Tile costs of one block are added across
-// 1/4/16 neighbouring lanes with DPP and one lane stores min(SATD, 2*SAD).
+// 64 / tiles_per_block blocks; lane l of every wave is tile l.  Its waves (8; 4 for 4x4 blocks) walk the
+// candidate list (wave w takes modes w, w + WAVES, ...), so the mode -- and with it every branch of the
+// predictor -- is uniform across the wave.  A lane predicts its whole tile row by row in registers,
+// subtracts the original (packed 16-bit pairs straight from LDS), accumulates SAD with v_sad_u16 and runs
+// the Hadamard in its own registers (satd_tile_dev.h).  Tile costs of one block are added across 1/4/16
+// neighbouring lanes with DPP; one lane keeps min(SATD, 2*SAD), writes it (if asked) and folds it into the
+// block's best (cost << 7 | candidate index) key, an LDS atomicMin across the waves at the end.
 //
-// LDS per block: four reference rows of RS = 2n+4 samples (raw top/left, smoothed top/left), the
-// original block and its transpose (horizontal modes are predicted in the reference's transposed
-// work domain and compared with the transposed original -- SAD and the Hadamard magnitudes are
-// transpose-invariant).  Block strides are odd multiples of a dword (rows) / of 4 dwords
-// (originals) so that the 64 lanes of a wave spread over all banks.
-// Negative angles read the projected side reference left of main[0]
-// (intra-generic.c:150-170); each wave builds that extended row for its current mode in a
-// private LDS strip so the tap loads are plain base+immediate ds_read_u16.
+// LDS per block: the reference rows as dword "pair rows" of RS = 2n+4 entries (raw top/left, smoothed
+// top/left; 8-bit 16x16/32x32 blocks also A and B of the smoothing filter, see search_tile_angular_ab), the
+// original block and its transpose in bands of T rows (horizontal modes are predicted in the reference's
+// transposed work domain and compared with the transposed original -- SAD and the Hadamard magnitudes are
+// transpose-invariant).  All strides are chosen against bank conflicts (make_search_layout).  Per
+// workgroup: the packed candidate descriptors, the tap tables, the PDPC weight / projected-offset tables.
+// Negative angles read the projected side reference left of main[0] (intra-generic.c:150-170); each wave
+// builds that extended pair row for its current mode in a private LDS strip.
 struct search_mode {
   int kind;        // 0 planar, 1 DC, 2 angular
   int row_main;    // reference row (0 top, 1 left, 2 smoothed top, 3 smoothed left) that is "main"
