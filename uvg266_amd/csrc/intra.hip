@@ -942,15 +942,18 @@ __host__ __device__ inline search_layout make_search_layout(int n, int bpg, int 
 #endif
 // BPL = blocks per lane (only with one tile per block): the lane evaluates BPL blocks per mode, which amortises the
 // per-mode overhead (descriptor fetch, branching, bookkeeping) that dominates for 4x4 blocks.
-template <typename PX, int T, int WAVES, int BPL>
+// NFIX: block size known at compile time (4x4 and 8x8: one tile per block, so the tile origin is (0, 0) and the per-row
+// angle arithmetic -- integer offset, fraction, tap pair -- becomes scalar), 0 = run-time size (16x16 / 32x32).
+template <typename PX, int T, int WAVES, int BPL, int NFIX>
 __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : (WAVES == 6 ? 3 : 1))
 intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__restrict__ orig, int orig_stride,
-                    int n, const uvghip_intra_blk_t *__restrict__ blks, int n_blks,
+                    int n_arg, const uvghip_intra_blk_t *__restrict__ blks, int n_blks,
                     const int8_t *__restrict__ modes, int n_modes, uint32_t *__restrict__ costs,
                     int8_t *__restrict__ best_mode, uint32_t *__restrict__ best_cost)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int lgn = ilog2_dev(n);
+  const int n = NFIX ? NFIX : n_arg;
+  const int lgn = NFIX ? (NFIX == 4 ? 2 : 3) : ilog2_dev(n);
   const int lg_tx = lgn - (T == 8 ? 3 : 2);       // log2(tiles per block row)
   const int lg_tiles = 2 * lg_tx, tiles = 1 << lg_tiles;
   const int bpg = (64 * BPL) >> lg_tiles;
@@ -1200,14 +1203,21 @@ static int launch_intra_search(int bitdepth, const void *rec, int rec_stride, co
   const int grid = (n + bpg - 1) / bpg;
   hipStream_t st = uvghip_stream(stream);
   // 8x8 tiles: 8 waves per workgroup (two workgroups per CU = 4 waves per SIMD); 4x4: 4 waves, many workgroups
-#define LAUNCH(PX, T, W, B) do { const search_layout L = make_search_layout(size, bpg, n_modes, W, (int)sizeof(PX)); \
+#define LAUNCH(PX, T, W, B, NF) do { const search_layout L = make_search_layout(size, bpg, n_modes, W, (int)sizeof(PX)); \
     static bool big_lds = false; /* allow more than the default 64 KiB of dynamic LDS, once per instantiation */ \
-    if (!big_lds) { UVGHIP_TRY(hipFuncSetAttribute((const void *)intra_search_kernel<PX, T, W, B>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); big_lds = true; } \
-    if (getenv("UVGHIP_DEBUG_OCC")) { int nb = -1; hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, intra_search_kernel<PX, T, W, B>, W * 64, L.total); \
+    if (!big_lds) { UVGHIP_TRY(hipFuncSetAttribute((const void *)intra_search_kernel<PX, T, W, B, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); big_lds = true; } \
+    if (getenv("UVGHIP_DEBUG_OCC")) { int nb = -1; hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, intra_search_kernel<PX, T, W, B, NF>, W * 64, L.total); \
       fprintf(stderr, "intra_search<%d,%d,%d> size %d: lds %zu grid %d occupancy %d blocks/CU (err %d)\n", (int)sizeof(PX), T, W, size, (size_t)L.total, grid, nb, (int)oe); } \
-    intra_search_kernel<PX, T, W, B><<<grid, W * 64, L.total, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, blks, n, modes, n_modes, costs, best_mode, best_cost); } while (0)
-  if (bitdepth == 8) { if (size == 4) LAUNCH(uint8_t, 4, 4, UVGHIP_SEARCH_BPL4); else LAUNCH(uint8_t, 8, UVGHIP_SEARCH_WAVES, 1); }
-  else { if (size == 4) LAUNCH(uint16_t, 4, 4, UVGHIP_SEARCH_BPL4); else LAUNCH(uint16_t, 8, UVGHIP_SEARCH_WAVES, 1); }
+    intra_search_kernel<PX, T, W, B, NF><<<grid, W * 64, L.total, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, blks, n, modes, n_modes, costs, best_mode, best_cost); } while (0)
+  if (bitdepth == 8) {
+    if (size == 4) LAUNCH(uint8_t, 4, 4, UVGHIP_SEARCH_BPL4, 4);
+    else if (size == 8) LAUNCH(uint8_t, 8, UVGHIP_SEARCH_WAVES, 1, 8);
+    else LAUNCH(uint8_t, 8, UVGHIP_SEARCH_WAVES, 1, 0);
+  } else {
+    if (size == 4) LAUNCH(uint16_t, 4, 4, UVGHIP_SEARCH_BPL4, 4);
+    else if (size == 8) LAUNCH(uint16_t, 8, UVGHIP_SEARCH_WAVES, 1, 8);
+    else LAUNCH(uint16_t, 8, UVGHIP_SEARCH_WAVES, 1, 0);
+  }
 #undef LAUNCH
   UVGHIP_CHECK_LAUNCH();
 }
