@@ -953,7 +953,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n = NFIX ? NFIX : n_arg;
-  const int lgn = NFIX ? (NFIX == 4 ? 2 : 3) : ilog2_dev(n);
+  const int lgn = NFIX ? (NFIX == 4 ? 2 : (NFIX == 8 ? 3 : (NFIX == 16 ? 4 : 5))) : ilog2_dev(n);
   const int lg_tx = lgn - (T == 8 ? 3 : 2);       // log2(tiles per block row)
   const int lg_tiles = 2 * lg_tx, tiles = 1 << lg_tiles;
   const int bpg = (64 * BPL) >> lg_tiles;
@@ -1212,11 +1212,13 @@ static int launch_intra_search(int bitdepth, const void *rec, int rec_stride, co
   if (bitdepth == 8) {
     if (size == 4) LAUNCH(uint8_t, 4, 4, UVGHIP_SEARCH_BPL4, 4);
     else if (size == 8) LAUNCH(uint8_t, 8, UVGHIP_SEARCH_WAVES, 1, 8);
-    else LAUNCH(uint8_t, 8, UVGHIP_SEARCH_WAVES, 1, 0);
+    else if (size == 16) LAUNCH(uint8_t, 8, UVGHIP_SEARCH_WAVES, 1, 16);
+    else LAUNCH(uint8_t, 8, UVGHIP_SEARCH_WAVES, 1, 32);
   } else {
     if (size == 4) LAUNCH(uint16_t, 4, 4, UVGHIP_SEARCH_BPL4, 4);
     else if (size == 8) LAUNCH(uint16_t, 8, UVGHIP_SEARCH_WAVES, 1, 8);
-    else LAUNCH(uint16_t, 8, UVGHIP_SEARCH_WAVES, 1, 0);
+    else if (size == 16) LAUNCH(uint16_t, 8, UVGHIP_SEARCH_WAVES, 1, 16);
+    else LAUNCH(uint16_t, 8, UVGHIP_SEARCH_WAVES, 1, 32);
   }
 #undef LAUNCH
   UVGHIP_CHECK_LAUNCH();
