@@ -693,10 +693,7 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
   ang_row<T> A, B;
   int lA[T];
   auto side_load = [&](int r, int (&l)[T]) {
-    if constexpr (PDPC == 2) {
-#pragma unroll
-      for (int i = 0; i < T; ++i) l[i] = sp[i][2 * r];
-    } else if constexpr (PDPC == 3) l[0] = sp[0][2 * r];
+    if constexpr (PDPC == 3) l[0] = sp[0][2 * r];      // PDPC 2 reads its side samples where it blends them
   };
   const pk_s16 vmax = {(short)maxv, (short)maxv};
   // PDPC 2 is the register-hungriest variant (eight side-sample pointers and values on top of the 32 difference
@@ -729,7 +726,7 @@ __device__ __forceinline__ void search_tile_angular(const search_mode &S, const 
         for (int c = 0; c < T / 2; ++c) {
           pk_s16 v = __builtin_bit_cast(pk_s16, pack_shr8(out[2 * c], out[2 * c + 1]));
           if constexpr (CLAMP) v = __builtin_elementwise_min(__builtin_elementwise_max(v, (pk_s16){0, 0}), vmax);
-          const pk_s16 l = __builtin_bit_cast(pk_s16, (uint32_t)lA[2 * c] | ((uint32_t)lA[2 * c + 1] << 16));
+          const pk_s16 l = {(short)sp[2 * c][2 * r], (short)sp[2 * c + 1][2 * r]};   // projected side samples of the pair
           const pk_s16 w = __builtin_bit_cast(pk_s16, wpk[c]);
           pk_s16 t;
           if constexpr (PK8) t = ((l - v) * w + (pk_s16){32, 32}) >> (pk_s16){6, 6};
@@ -1144,7 +1141,11 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
           if (S.noclamp) search_tile_angular<T, 0, false, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, wrow, sorow, n, xd0, yd0, ot, maxv, d, sad);
           else search_tile_angular<T, 0, true, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, wrow, sorow, n, xd0, yd0, ot, maxv, d, sad);
         } else if (S.pdpc == 2) {
-          if (S.noclamp) search_tile_angular<T, 2, false, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, wrow, sorow, n, xd0, yd0, ot, maxv, d, sad);
+          // 8-bit 16x16 / 32x32: the smoothing modes took the A + h * B path above, which leaves only the two integer-slope
+          // modes for the unclamped variant -- they go through the clamped one (same result, 64 ops more for two modes)
+          // and the register-hungriest variant is not instantiated at all (it was the one that spilled)
+          constexpr bool kNoclampVariant = !((sizeof(PX) == 1 && NFIX >= 16) || (sizeof(PX) == 2 && NFIX == 16));   // 10-bit 16x16: spilled too
+          if (kNoclampVariant && S.noclamp) search_tile_angular<T, 2, false, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, wrow, sorow, n, xd0, yd0, ot, maxv, d, sad);
           else search_tile_angular<T, 2, true, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, wrow, sorow, n, xd0, yd0, ot, maxv, d, sad);
         } else search_tile_angular<T, 3, false, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, wrow, sorow, n, xd0, yd0, ot, maxv, d, sad);   // pure H/V: integer phase
       } else if (S.kind == 0) search_tile_nonangular<T, true>(S, mainr, side, 0, n, lgn, xd0, yd0, ot, d, sad);
