@@ -64,3 +64,28 @@ def test_product_does_not_touch_oracle():
                 if re.search(r"liborc|orc_common|oracle/|orc8_|orc10_", txt):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_no_kernel_uses_scratch():
+    """The build leaves the compiler's per-kernel resource report in uvg266_amd/csrc/_build/*.usage.  No kernel may touch
+    scratch memory: a single spilled register makes the dispatch bind scratch and cost tens of microseconds per launch
+    (measured on the search kernel), and dynamic indexing into register arrays shows up here as well."""
+    import glob
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "uvg266_amd", "csrc", "_build")
+    files = sorted(glob.glob(os.path.join(root, "*.usage")))
+    assert len(files) >= 10, "build with `python __graft_entry__.py` first"
+    kernels = 0
+    for f in files:
+        name = None
+        for line in open(f):
+            line = line.strip()
+            if line.startswith("Function Name:"):
+                name = line.split(":", 1)[1].strip(); kernels += 1
+            m = re.match(r"(ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill): (\d+)", line)
+            if m and m.group(1) != "SGPRs Spill":
+                assert int(m.group(2)) == 0, f"{os.path.basename(f)}: {name}: {line}"
+            if line.startswith("Dynamic Stack:"):
+                assert line.endswith("False"), f"{os.path.basename(f)}: {name}: {line}"
+    assert kernels >= 60
