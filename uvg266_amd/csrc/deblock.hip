@@ -346,13 +346,14 @@ extern "C" int uvghip_deblock_frame(int bitdepth, void *y, int y_stride, void *u
   cfg.has_qp_map = chroma_qp_map_host != nullptr;
   for (int i = 0; i < 64; ++i) cfg.qp_map[i] = chroma_qp_map_host ? chroma_qp_map_host[i] : 0;
   const int ux = width / 4, uy = height / 4;
-  dim3 grid((ux + 255) / 256, uy);
+  constexpr int DBK_THREADS = 64;     // one wave per workgroup: 2160 workgroups at 1080p spread evenly over the 256 CUs (256-thread groups: 540)
+  dim3 grid((ux + DBK_THREADS - 1) / DBK_THREADS, uy);
   hipStream_t st = uvghip_stream(stream);
   for (int dir_hor = 0; dir_hor < 2; ++dir_hor) {
     if (bitdepth == 8)
-      deblock_pass_kernel<uint8_t><<<grid, 256, 0, st>>>((uint8_t *)y, y_stride, (uint8_t *)u, (uint8_t *)v, c_stride, width, height, scu, scu_stride, cfg, dir_hor);
+      deblock_pass_kernel<uint8_t><<<grid, DBK_THREADS, 0, st>>>((uint8_t *)y, y_stride, (uint8_t *)u, (uint8_t *)v, c_stride, width, height, scu, scu_stride, cfg, dir_hor);
     else
-      deblock_pass_kernel<uint16_t><<<grid, 256, 0, st>>>((uint16_t *)y, y_stride, (uint16_t *)u, (uint16_t *)v, c_stride, width, height, scu, scu_stride, cfg, dir_hor);
+      deblock_pass_kernel<uint16_t><<<grid, DBK_THREADS, 0, st>>>((uint16_t *)y, y_stride, (uint16_t *)u, (uint16_t *)v, c_stride, width, height, scu, scu_stride, cfg, dir_hor);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return uvghip_set_error(e, __func__);
   }
