@@ -381,13 +381,14 @@ extern "C" int uvghip_intra_pred_batch(int bitdepth, const void *rec, int rec_st
 // the block's position -- what uvg_intra_recon_cu's predict step leaves in lcu->rec (intra.c:1537).
 // One thread per 4-sample segment: n*n/4 threads per block, 256/(n*n/4) blocks per workgroup
 // (64 4x4 blocks ... one 32x32 block); reference rows of 2n+4 samples per block in LDS.
-template <typename PX>
+template <typename PX, int N>      // N: the block size, a compile-time constant (all the index arithmetic folds)
 __global__ void __launch_bounds__(256)
-intra_pred_plane_kernel(const PX *__restrict__ rec, int stride, int n, const uvghip_intra_blk_t *__restrict__ blks,
+intra_pred_plane_kernel(const PX *__restrict__ rec, int stride, const uvghip_intra_blk_t *__restrict__ blks,
                         int n_blks, const int8_t *__restrict__ modes, PX *__restrict__ out, int out_stride)
 {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-  const int lgn = ilog2_dev(n);
+  constexpr int n = N;
+  constexpr int lgn = N == 4 ? 2 : (N == 8 ? 3 : (N == 16 ? 4 : 5));
   const int lg_tpb = 2 * lgn - 2, tpb = 1 << lg_tpb, bpg = 256 >> lg_tpb;
   const int RS = 2 * n + 4;
   uint16_t *sRef = smem;                                                     // [bpg][4][RS]
@@ -440,10 +441,11 @@ extern "C" int uvghip_intra_pred_plane_batch(int bitdepth, const void *rec, int 
   const int grid = (n + bpg - 1) / bpg;
   const size_t lds = (size_t)bpg * 4 * (2 * size + 4) * 2 + (size_t)bpg * (sizeof(mode_info) + 12) + 16;
   hipStream_t st = uvghip_stream(stream);
-  if (bitdepth == 8)
-    intra_pred_plane_kernel<uint8_t><<<grid, 256, lds, st>>>((const uint8_t *)rec, rec_stride, size, blks, n, modes, (uint8_t *)pred_plane, pred_stride);
-  else
-    intra_pred_plane_kernel<uint16_t><<<grid, 256, lds, st>>>((const uint16_t *)rec, rec_stride, size, blks, n, modes, (uint16_t *)pred_plane, pred_stride);
+#define PP(PX, N) intra_pred_plane_kernel<PX, N><<<grid, 256, lds, st>>>((const PX *)rec, rec_stride, blks, n, modes, (PX *)pred_plane, pred_stride)
+#define PPS(PX) do { if (size == 4) PP(PX, 4); else if (size == 8) PP(PX, 8); else if (size == 16) PP(PX, 16); else PP(PX, 32); } while (0)
+  if (bitdepth == 8) PPS(uint8_t); else PPS(uint16_t);
+#undef PPS
+#undef PP
   UVGHIP_CHECK_LAUNCH();
 }
 
