@@ -332,8 +332,8 @@ def cpu_baseline(fr_host_y, fr_host_u, fr_host_v):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one stream: no overlap between block sizes / frames")
     ap.add_argument("--stream-sets", type=int, default=2, help="sets of per-block-size streams (frames alternate between them)")
