@@ -378,6 +378,69 @@ sad_surface_qsad_kernel(const uint8_t *__restrict__ cur, int cs, const uint8_t *
   }
 }
 
+// 10-bit fast path: v_sad_u16 on packed sample pairs.  The window lives in LDS as pair rows (dword k of a row = samples k and
+// k + 1, as in the intra search), so the pair a candidate needs at any horizontal offset is an aligned dword.  A lane owns
+// (dy, four neighbouring dx): per block row and chunk of CH columns it reads the run of pair dwords 4g .. 4g + CH + 3 with
+// aligned b128 reads (candidate dx = 4g + k uses dwords k, k + 2, ...), the chunk's CH/2 current pairs (same address in all
+// lanes: a broadcast) and issues 4 * CH/2 v_sad_u16, each accumulating two absolute differences into a 32-bit sum.
+template <int BW>
+__global__ void __launch_bounds__(128)
+sad_surface_pk16_kernel(const uint16_t *__restrict__ cur, int cs, const uint16_t *__restrict__ ref, int rs, int W, int H,
+                        int bh, int range, int blocks_x, uint32_t *__restrict__ out, int shift)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int CH = BW >= 16 ? 16 : 8;                  // columns per chunk
+  constexpr int NQ = (CH + 4 + 3) / 4;                   // b128 reads covering pair dwords 0 .. CH + 2 of a group
+  const int side = 2 * range + 1, groups = (side + 3) >> 2;
+  const int ww = BW + 2 * range, wh = bh + 2 * range;
+  const int pitch = ((ww + 3) & ~3) + 8;                 // dwords per pair row, a multiple of 4; the last group may read past ww
+  uint32_t *win = reinterpret_cast<uint32_t *>(smem_raw);
+  uint32_t *blk = win + (size_t)pitch * wh;              // bh rows of BW / 2 pair dwords
+  const int bidx = blockIdx.x;
+  const int by = (bidx / blocks_x) * bh, bx = (bidx % blocks_x) * BW;
+  for (int i = threadIdx.x; i < pitch * wh; i += blockDim.x) {
+    const int y = i / pitch, k = i - y * pitch;
+    const uint16_t *row = ref + (size_t)clampi(by - range + y, 0, H - 1) * rs;
+    const int x = bx - range + k;
+    win[i] = (uint32_t)row[clampi(x, 0, W - 1)] | ((uint32_t)row[clampi(x + 1, 0, W - 1)] << 16);
+  }
+  for (int i = threadIdx.x; i < (BW / 2) * bh; i += blockDim.x) {
+    const int y = i / (BW / 2), j = i - y * (BW / 2);
+    blk[i] = *reinterpret_cast<const u32_unaligned *>(cur + (size_t)(by + y) * cs + bx + 2 * j);
+  }
+  __syncthreads();
+  const int ntasks = side * groups;
+  for (int t = threadIdx.x; t < ntasks; t += blockDim.x) {
+    const int dy = t / groups, g = t - dy * groups;
+    uint32_t tot[4] = {0, 0, 0, 0};
+    for (int y = 0; y < bh; ++y) {
+      const uint32_t *wr = win + (size_t)(y + dy) * pitch + 4 * g;
+      const uint32_t *br = blk + y * (BW / 2);
+#pragma unroll
+      for (int c0 = 0; c0 < BW; c0 += CH) {
+        uint32_t d[4 * NQ], cpk[CH / 2];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const uint4 v = *reinterpret_cast<const uint4 *>(wr + c0 + 4 * q);
+          d[4 * q] = v.x; d[4 * q + 1] = v.y; d[4 * q + 2] = v.z; d[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int q = 0; q < CH / 8; ++q) {
+          const uint4 v = *reinterpret_cast<const uint4 *>(br + c0 / 2 + 4 * q);
+          cpk[4 * q] = v.x; cpk[4 * q + 1] = v.y; cpk[4 * q + 2] = v.z; cpk[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int j = 0; j < CH / 2; ++j) tot[k] = __builtin_amdgcn_sad_u16(d[k + 2 * j], cpk[j], tot[k]);
+      }
+    }
+    uint32_t *o = out + ((size_t)bidx * side + dy) * side + 4 * g;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (4 * g + k < side) o[k] = tot[k] >> shift;
+  }
+}
+
 extern "C" int uvghip_sad_surface(int bitdepth, const void *cur, int cur_stride, const void *ref, int ref_stride,
                                   int w, int h, int bw, int bh, int range, uint32_t *out, void *stream)
 {
@@ -397,6 +460,17 @@ extern "C" int uvghip_sad_surface(int bitdepth, const void *cur, int cur_stride,
 #define QS(BWV) sad_surface_qsad_kernel<BWV><<<nb, 128, ql, st>>>((const uint8_t *)cur, cur_stride, (const uint8_t *)ref, ref_stride, w, h, bh, range, blocks_x, out)
       if (bw == 8) QS(8); else if (bw == 16) QS(16); else if (bw == 32) QS(32); else QS(64);
 #undef QS
+      UVGHIP_CHECK_LAUNCH();
+    }
+  }
+  if (bitdepth != 8 && (bw == 8 || bw == 16 || bw == 32 || bw == 64)) {
+    const size_t pitch = (size_t)(((bw + 2 * range + 3) & ~3) + 8);
+    const size_t pl = (pitch * (bh + 2 * range) + (size_t)(bw / 2) * bh) * 4;
+    if (pl <= 64 * 1024) {
+      const int nb = blocks_x * blocks_y;
+#define PK(BWV) sad_surface_pk16_kernel<BWV><<<nb, 128, pl, st>>>((const uint16_t *)cur, cur_stride, (const uint16_t *)ref, ref_stride, w, h, bh, range, blocks_x, out, bitdepth - 8)
+      if (bw == 8) PK(8); else if (bw == 16) PK(16); else if (bw == 32) PK(32); else PK(64);
+#undef PK
       UVGHIP_CHECK_LAUNCH();
     }
   }
