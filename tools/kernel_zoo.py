@@ -7,8 +7,10 @@ import csv
 import json
 import sys
 
+import os
 W, H = 1920, 1080
 REPS = 5
+DEPTH = int(os.environ.get("ZOO_DEPTH", "8"))      # ZOO_DEPTH=10: the same workloads on 10-bit planes (uint16)
 
 
 def workloads():
@@ -17,8 +19,8 @@ def workloads():
     sys.path.insert(0, ".")
     from uvg266_amd import api, layout
     dev = torch.device("cuda:0")
-    y0, u0, v0 = layout.synthetic_yuv420(W, H, 0, 8)
-    y1, _, _ = layout.synthetic_yuv420(W, H, 1, 8)
+    y0, u0, v0 = layout.synthetic_yuv420(W, H, 0, DEPTH)
+    y1, _, _ = layout.synthetic_yuv420(W, H, 1, DEPTH)
     Y0, Y1 = torch.from_numpy(y0).to(dev), torch.from_numpy(y1).to(dev)
     U0, V0 = torch.from_numpy(u0).to(dev), torch.from_numpy(v0).to(dev)
     rng = np.random.default_rng(0)
@@ -46,8 +48,8 @@ def workloads():
     for nsz in (4, 8, 16, 32):
         nb = (W // nsz) * (H // nsz)
         blocks = torch.randint(-255, 256, (nb, nsz, nsz), dtype=torch.int16, device=dev)
-        add(f"transform fwd DCT2 {nsz}", lambda b=blocks: api.transform_batch(b, 8, False), nb * nsz * nsz * 4)
-        add(f"transform inv DST7 {nsz}", lambda b=blocks: api.transform_batch(b, 8, True, 2, 2), nb * nsz * nsz * 4)
+        add(f"transform fwd DCT2 {nsz}", lambda b=blocks: api.transform_batch(b, DEPTH, False), nb * nsz * nsz * 4)
+        add(f"transform inv DST7 {nsz}", lambda b=blocks: api.transform_batch(b, DEPTH, True, 2, 2), nb * nsz * nsz * 4)
     coef = torch.randint(-2000, 2001, ((W // 8) * (H // 8), 8, 8), dtype=torch.int16, device=dev)
     add("quant 8x8", lambda: api.quant_batch(coef, 8, 22), coef.numel() * 4)
     add("dequant 8x8", lambda: api.dequant_batch(coef, 8, 22), coef.numel() * 4)
@@ -69,8 +71,8 @@ def workloads():
     cand = torch.from_numpy(np.array([[0, 0], [8, 0], [-8, 0], [0, 8], [0, -8], [4, 4], [-4, 4], [4, -4], [-4, -4]], np.int16) ).to(dev)
     fb = api.make_blocks(xy, xy + mv)
     add("frac_satd 16x16 x9", lambda: api.frac_satd_batch(Y0, Y1, fb, 16, 16, cand), n * (23 * 23 + 256 + 36))
-    l0 = torch.randint(0, 256, (W * H,), dtype=torch.uint8, device=dev)
-    add("bipred_average px/px", lambda: api.bipred_average_batch(l0, l0, 8), W * H * 3)
+    l0 = (Y0.reshape(-1) if DEPTH == 8 else Y0.reshape(-1))
+    add("bipred_average px/px", lambda: api.bipred_average_batch(l0, l0, DEPTH), W * H * 3)
     # --- in-loop filters
     scu = api.make_scu_table(layout.quadtree_scu_table(W, H, seed=0, qp=22))
     rec = Y0.clone()
@@ -85,7 +87,7 @@ def workloads():
     cls = api.alf_classify_frame(Y1, W, H)
     add("alf_classify", lambda: api.alf_classify_frame(Y1, W, H), W * H + W * H // 16)
     coefs = torch.zeros((1, 25, 13), dtype=torch.int16, device=dev); coefs[:, :, 12] = 0
-    clips = torch.full((1, 25, 13), 255, dtype=torch.int16, device=dev)
+    clips = torch.full((1, 25, 13), (1 << DEPTH) - 1, dtype=torch.int16, device=dev)
     sidx = torch.zeros(len(rects_np), dtype=torch.int32, device=dev)
     add("alf_filter luma 7x7", lambda: api.alf_filter_batch(Y1, sout, rects, sidx, coefs, clips, cls), 2 * W * H)
     add("alf_stats luma", lambda: api.alf_stats_batch(Y0, Y1, rects, cls), 2 * W * H + len(rects_np) * 25 * (13 * 13 * 16 * 8 + 13 * 4 * 4 + 8))
@@ -121,7 +123,8 @@ def summarize(trace_csv, plan_json, tag):
         gbs = w["alg_bytes"] / (per_call_us * 1e-6) / 1e9
         table.append({"workload": w["name"], "kernel": seg[0]["Kernel_Name"].split("(")[0][:60], "us_per_call": round(per_call_us, 1),
                       "alg_MB": round(w["alg_bytes"] / 1e6, 2), "GBps": round(gbs, 1), "pct_of_8TBps": round(100 * gbs / 8000, 2)})
-    json.dump({"note": "rocprofv3 --kernel-trace durations of tools/kernel_zoo.py, 1080p 8-bit, one launch alone on the GPU; "
+    depth = 10 if "10bit" in tag else 8
+    json.dump({"note": f"rocprofv3 --kernel-trace durations of tools/kernel_zoo.py, 1080p {depth}-bit, one launch alone on the GPU; "
                        "algorithmic bytes as in DESIGN.md section 4", "kernels": table}, open(f"profiles/{tag}_kernel_zoo.json", "w"), indent=1)
     for t in table:
         print(f'{t["workload"]:32s} {t["kernel"][:44]:44s} {t["us_per_call"]:8.1f} us {t["alg_MB"]:8.2f} MB {t["GBps"]:8.1f} GB/s {t["pct_of_8TBps"]:6.2f} %')
