@@ -70,8 +70,10 @@ class Frame:
         y, u, v = layout.synthetic_yuv420(W, H, t, DEPTH)
         dev = lambda a: torch.from_numpy(a).to(device)
         self.host_y, self.host_u, self.host_v = y, u, v
-        self.y, self.u, self.v = dev(y), dev(u), dev(v)
-        self.u_rec, self.v_rec = torch.zeros_like(self.u), torch.zeros_like(self.v)
+        self.y = dev(y)
+        self.uv = dev(np.stack([u, v]))          # both chroma planes in one buffer: the per-frame refresh is one copy
+        self.uv_rec = torch.zeros_like(self.uv)  # deblocking works in place on this copy
+        self.u_rec, self.v_rec = self.uv_rec[0], self.uv_rec[1]
         self.sao_out = torch.zeros_like(self.y)
         self.scu = api.make_scu_table(layout.quadtree_scu_table(W, H, seed=t, qp=QP), device)
         rects = layout.ctu_rects(W, H)
@@ -232,8 +234,7 @@ def hot_path_step(fr, clock, timed, main, side):
     if side:
         for ev in fr.ev_chain:
             main.wait_event(ev)
-    fr.u_rec.copy_(fr.u)                         # torch copies run on the current (= main) stream
-    fr.v_rec.copy_(fr.v)
+    fr.uv_rec.copy_(fr.uv)                       # torch copies run on the current (= main) stream
     for name, fn, args in fr.tail:
         clock.launch(name, fn, args, main, timed, id(fr))
     fr.ev_done.record(main)
@@ -262,8 +263,7 @@ def hot_path_step_split(fr, clock, timed, main, sx, sy, sz):
             clock.launch(name, fn, args, sz, timed, id(fr))
     fr.ev_small.record(sz)
     main.wait_event(fr.ev_small)
-    fr.u_rec.copy_(fr.u)
-    fr.v_rec.copy_(fr.v)
+    fr.uv_rec.copy_(fr.uv)
     for name, fn, args in fr.tail:
         clock.launch(name, fn, args, main, timed, id(fr))
     fr.ev_done.record(main)
