@@ -257,9 +257,10 @@ def hot_path_step_split(fr, clock, timed, main, sx, sy, sz):
             name, fn, args = fr.chains[k][0]
             clock.launch(name, fn, args, st, timed, id(fr))
             fr.ev_chain[k].record(st)
-    for k, chain in enumerate(fr.chains):
+    order = (0, 1, 2, 3) if sy is None else (0, 2, 1, 3)       # the order in which the searches finish
+    for k in order:
         sz.wait_event(fr.ev_chain[k])
-        for name, fn, args in chain[1:]:
+        for name, fn, args in fr.chains[k][1:]:
             clock.launch(name, fn, args, sz, timed, id(fr))
     fr.ev_small.record(sz)
     main.wait_event(fr.ev_small)
