@@ -1036,7 +1036,8 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       sSoTab[i] = (uint16_t)(on_col ? 4 * (((256 + (x + 1) * Sm.inv) >> 9) + 1) : 0);
     }
     if (on) {
-      filter_ref_rows(base, base + L.RS, base + 2 * L.RS, base + 3 * L.RS, n, n, L.RS, mytid, tpb);
+      // 4x4 blocks never use the smoothed references (intra.c:690-726: no reference filtering for 4x4)
+      if constexpr (NFIX != 4) filter_ref_rows(base, base + L.RS, base + 2 * L.RS, base + 3 * L.RS, n, n, L.RS, mytid, tpb);
       if (mytid == 0) sDC[myb] = dc_value(base, base + L.RS, n, n);
     }
     __syncthreads();
@@ -1044,7 +1045,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
       // u16 image -> pair rows
       uint32_t *pr = sRef + (size_t)myb * L.BRS;
 #pragma unroll
-      for (int row = 0; row < 4; ++row)
+      for (int row = 0; row < (NFIX == 4 ? 2 : 4); ++row)
         for (int i = mytid; i < L.RS; i += tpb) {
           const int e = row * L.RS + i;
           pr[e] = (uint32_t)base[e] | (i + 1 < L.RS ? (uint32_t)base[e + 1] << 16 : 0u);
