@@ -350,6 +350,63 @@ tu_lane_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int ori
   }
 }
 
+// Stand-alone 4x4 / 8x8 transforms (uvghip_transform_batch without zero-out) on the same lane-per-block passes: the block
+// never leaves the lane's registers.  Forward: in[y][x] -> out[j][c] truncated to int16 (dct-generic.c:724-725); inverse:
+// in[j][c] -> out[y][x], both passes clipped to int16 (:735-736).
+template <int N, bool INV>
+__global__ void __launch_bounds__(256)
+tr_lane_kernel(tr_params P, const int16_t *__restrict__ in, int16_t *__restrict__ out, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int16_t *Th = tr_matrix_dev(P.type_hor, N), *Tv = tr_matrix_dev(P.type_ver, N);
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(in + (size_t)i * (N * N));
+  uint32_t *dst = reinterpret_cast<uint32_t *>(out + (size_t)i * (N * N));
+  uint32_t a[N][N / 2];
+  int v[N][N];
+  if constexpr (!INV) {
+#pragma unroll
+    for (int y = 0; y < N; ++y)
+#pragma unroll
+      for (int x = 0; x < N / 2; ++x) a[y][x] = src[y * (N / 2) + x];     // pairs along x are adjacent in memory
+    tu_lane_pass<N, true, false>(a, Th, P.f1.shift, v);            // v[y][c]
+    tu_repack<N>(v, a);                                             // a[c][y pairs]
+    tu_lane_pass<N, true, false>(a, Tv, P.f2.shift, v);            // v[c][j]
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+      for (int c = 0; c < N; c += 2) dst[j * (N / 2) + (c >> 1)] = __builtin_amdgcn_perm((uint32_t)v[c + 1][j], (uint32_t)v[c][j], 0x05040100u);
+  } else {
+    uint32_t rows[N][N / 2];
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+      for (int c = 0; c < N / 2; ++c) rows[j][c] = src[j * (N / 2) + c];   // (coeff[j][2c], coeff[j][2c+1])
+    // taps of the first inverse pass run over j: a[c][j/2] = (coeff[j][c], coeff[j+1][c])
+#pragma unroll
+    for (int c = 0; c < N; ++c)
+#pragma unroll
+      for (int j = 0; j < N; j += 2)
+        a[c][j >> 1] = __builtin_amdgcn_perm(rows[j + 1][c >> 1], rows[j][c >> 1], (c & 1) ? 0x07060302u : 0x05040100u);
+    tu_lane_pass<N, false, true>(a, Tv, P.i1.shift, v);            // v[c][y]
+    tu_repack<N>(v, a);                                             // a[y][c pairs]
+    tu_lane_pass<N, false, true>(a, Th, P.i2.shift, v);            // v[y][x]
+#pragma unroll
+    for (int y = 0; y < N; ++y)
+#pragma unroll
+      for (int x = 0; x < N; x += 2) dst[y * (N / 2) + (x >> 1)] = __builtin_amdgcn_perm((uint32_t)v[y][x + 1], (uint32_t)v[y][x], 0x05040100u);
+  }
+}
+
+// called by uvghip_transform_batch (dct.hip) for square 4x4 / 8x8 blocks without zero-out
+int uvghip_launch_tr_lane(const tr_params &P, bool inverse, const int16_t *in, int16_t *out, int n, hipStream_t st)
+{
+  const int g = (n + 255) / 256;
+  if (P.w == 4) { if (inverse) tr_lane_kernel<4, true><<<g, 256, 0, st>>>(P, in, out, n); else tr_lane_kernel<4, false><<<g, 256, 0, st>>>(P, in, out, n); }
+  else { if (inverse) tr_lane_kernel<8, true><<<g, 256, 0, st>>>(P, in, out, n); else tr_lane_kernel<8, false><<<g, 256, 0, st>>>(P, in, out, n); }
+  UVGHIP_CHECK_LAUNCH();
+}
+
 // ---- fused TU round trip, 16x16 / 32x32 without zero-out: one wave = 1024 coefficients ----------
 // A wave owns one 32x32 TU (or four 16x16 TUs) and walks the four passes on its own two LDS line
 // buffers with no workgroup barrier after the matrices are staged.  Each lane computes a 4 lines x 4
