@@ -74,6 +74,7 @@ transform_kernel(tr_params P, int inverse, const int16_t *__restrict__ in, int16
 }
 
 int uvghip_launch_tr_lane(const tr_params &P, bool inverse, const int16_t *in, int16_t *out, int n, hipStream_t st);   // quant.hip
+int uvghip_launch_tr_wave(const tr_params &P, bool inverse, const int16_t *in, int16_t *out, int n, hipStream_t st);
 
 extern "C" int uvghip_transform_batch(int bitdepth, int inverse, int type_hor, int type_ver, int width, int height,
                                       int skip_width, int skip_height, const int16_t *in, int16_t *out, int n,
@@ -86,8 +87,11 @@ extern "C" int uvghip_transform_batch(int bitdepth, int inverse, int type_hor, i
     return uvghip_set_error(hipErrorInvalidValue, __func__);
   if (n <= 0) return 0;
   const tr_params P = tr_make_params(bitdepth, type_hor, type_ver, width, height, skip_width, skip_height);
-  if (width == height && width <= 8 && skip_width == 0 && skip_height == 0 && in != out)
-    return uvghip_launch_tr_lane(P, inverse != 0, in, out, n, uvghip_stream(stream));     // lane-per-block passes (quant.hip)
+  // the TU kernels' passes (quant.hip) read and write whole dwords / quads: 16-byte aligned, non-aliasing buffers only
+  if (width == height && skip_width == 0 && skip_height == 0 && in != out && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
+    if (width <= 8) return uvghip_launch_tr_lane(P, inverse != 0, in, out, n, uvghip_stream(stream));
+    return uvghip_launch_tr_wave(P, inverse != 0, in, out, n, uvghip_stream(stream));
+  }
   const int bpg = 1024 / (width * height);
   const int grid = (n + bpg - 1) / bpg;
   transform_kernel<<<grid, 256, 0, uvghip_stream(stream)>>>(P, inverse != 0, in, out, n, bpg);

@@ -602,6 +602,101 @@ tu_wave_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int ori
   }
 }
 
+// Stand-alone 16x16 / 32x32 transforms (uvghip_transform_batch without zero-out) on the wave-per-1024-coefficient passes.
+// Forward: in[y][x] -> out[j][c] (int16 truncation, dct-generic.c:724-725); inverse: in[j][c] -> out[y][x], clipped after
+// each pass (:735-736).  The inverse stages its input transposed (its first pass contracts over j).
+template <int N, bool INV>
+__global__ void __launch_bounds__(256)
+tr_wave_kernel(tr_params P, const int16_t *__restrict__ in, int16_t *__restrict__ out, int n)
+{
+  using W = tuw<N>;
+  __shared__ __attribute__((aligned(16))) int16_t sM[2][W::MAT];
+  __shared__ __attribute__((aligned(16))) int16_t sBuf[4][2][W::BUF];
+  {
+    const int16_t *Th = tr_matrix_dev(P.type_hor, N), *Tv = tr_matrix_dev(P.type_ver, N);
+    for (int e = threadIdx.x; e < N * N; e += 256) {
+      const int r = e / N, c = e - r * N;
+      if constexpr (!INV) { sM[0][W::mrow(r) + c] = Th[e]; sM[1][W::mrow(r) + c] = Tv[e]; }      // Bf1[c'][k], Bf2[j][y]
+      else { sM[0][W::mrow(c) + r] = Tv[e]; sM[1][W::mrow(c) + r] = Th[e]; }                     // Bi1[y][j], Bi2[x][c']
+    }
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tu0 = (blockIdx.x * 4 + wave) * W::BPW;
+  if (tu0 >= n) return;
+  int16_t *bufA = sBuf[wave][0], *bufB = sBuf[wave][1];
+  const int b = N == 32 ? 0 : lane >> 4;
+  const int l0 = (N == 32 ? lane >> 3 : (lane >> 2) & 3) * 4;
+  const int o0 = (N == 32 ? lane & 7 : lane & 3) * 4;
+  const bool on = tu0 + b < n;
+  {
+    // one input row segment of 16 coefficients per lane
+    const int row = N == 32 ? lane >> 1 : lane & 15, x0 = N == 32 ? (lane & 1) * 16 : 0;
+    const int lb = N == 32 ? 0 : lane >> 4;
+    const int16_t *src = in + (size_t)(tu0 + lb < n ? tu0 + lb : tu0) * (N * N) + row * N + x0;
+    const uint4 v0 = *reinterpret_cast<const uint4 *>(src), v1 = *reinterpret_cast<const uint4 *>(src + 8);
+    if constexpr (!INV) {
+      int16_t *dst = bufA + lb * W::BLK + row * W::PITCH + x0;
+      *reinterpret_cast<uint4 *>(dst) = v0; *reinterpret_cast<uint4 *>(dst + 8) = v1;
+    } else {
+      // in[j = row][c = x0 + k] -> bufA[c][j]
+      const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      int16_t *dst = bufA + lb * W::BLK + x0 * W::PITCH + row;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dst[k * W::PITCH] = (int16_t)(w[k >> 1] >> (16 * (k & 1)));
+    }
+  }
+  tuw_sync();
+  int acc[4][4];
+  const tr_pass &p1 = INV ? P.i1 : P.f1, &p2 = INV ? P.i2 : P.f2;
+  tuw_mma<N>(bufA + b * W::BLK + l0 * W::PITCH, sM[0] + W::mrow(o0), acc);
+  {
+    const int add = p1.shift > 0 ? 1 << (p1.shift - 1) : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int v = (acc[i][j] + add) >> p1.shift;
+        acc[i][j] = INV ? clampi(v, -32768, 32767) : v;            // forward: int16 truncation on packing
+      }
+    tuw_store_transposed<N>(bufB + b * W::BLK + o0 * W::PITCH, l0, acc);
+  }
+  tuw_sync();
+  tuw_mma<N>(bufB + b * W::BLK + l0 * W::PITCH, sM[1] + W::mrow(o0), acc);
+  if (!on) return;
+  const int add2 = 1 << (p2.shift - 1);
+  int16_t *dstb = out + (size_t)(tu0 + b) * (N * N);
+  if constexpr (!INV) {
+    // lines c = l0 + i, outputs j = o0 + jj: out[j][c]
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      int v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = (acc[i][jj] + add2) >> p2.shift;
+      *reinterpret_cast<uint2 *>(dstb + (o0 + jj) * N + l0) =
+          make_uint2(__builtin_amdgcn_perm((uint32_t)v[1], (uint32_t)v[0], 0x05040100u), __builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[2], 0x05040100u));
+    }
+  } else {
+    // lines y = l0 + i, outputs x = o0 + jj: out[y][x]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int v[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) v[jj] = clampi((acc[i][jj] + add2) >> p2.shift, -32768, 32767);
+      *reinterpret_cast<uint2 *>(dstb + (l0 + i) * N + o0) =
+          make_uint2(__builtin_amdgcn_perm((uint32_t)v[1], (uint32_t)v[0], 0x05040100u), __builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[2], 0x05040100u));
+    }
+  }
+}
+
+int uvghip_launch_tr_wave(const tr_params &P, bool inverse, const int16_t *in, int16_t *out, int n, hipStream_t st)
+{
+  const int units = P.w == 32 ? n : (n + 3) / 4, g = (units + 3) / 4;
+  if (P.w == 16) { if (inverse) tr_wave_kernel<16, true><<<g, 256, 0, st>>>(P, in, out, n); else tr_wave_kernel<16, false><<<g, 256, 0, st>>>(P, in, out, n); }
+  else { if (inverse) tr_wave_kernel<32, true><<<g, 256, 0, st>>>(P, in, out, n); else tr_wave_kernel<32, false><<<g, 256, 0, st>>>(P, in, out, n); }
+  UVGHIP_CHECK_LAUNCH();
+}
+
 extern "C" int uvghip_tu_roundtrip_batch(int bitdepth, int type_hor, int type_ver, int skip_width, int skip_height,
                                          int width, int height, int qp_scaled, int slice_is_intra,
                                          const void *orig, int orig_stride, const void *pred, int pred_stride,
