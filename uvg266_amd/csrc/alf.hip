@@ -83,10 +83,11 @@ extern "C" int uvghip_alf_classify_frame(int bitdepth, const void *rec, int rec_
 {
   UVGHIP_REQUIRE_READY();
   if (width <= 0 || height <= 0 || (width & 3) || (height & 3)) return uvghip_set_error(hipErrorInvalidValue, __func__);
-  dim3 grid((width / 4 + 255) / 256, height / 4);
+  constexpr int THREADS = 64;          // one wave per workgroup: four times as many workgroups to spread over the CUs
+  dim3 grid((width / 4 + THREADS - 1) / THREADS, height / 4);
   hipStream_t st = uvghip_stream(stream);
-  if (bitdepth == 8) alf_classify_kernel<uint8_t><<<grid, 256, 0, st>>>((const uint8_t *)rec, rec_stride, width, height, shift, cls, cls_stride);
-  else alf_classify_kernel<uint16_t><<<grid, 256, 0, st>>>((const uint16_t *)rec, rec_stride, width, height, shift, cls, cls_stride);
+  if (bitdepth == 8) alf_classify_kernel<uint8_t><<<grid, THREADS, 0, st>>>((const uint8_t *)rec, rec_stride, width, height, shift, cls, cls_stride);
+  else alf_classify_kernel<uint16_t><<<grid, THREADS, 0, st>>>((const uint16_t *)rec, rec_stride, width, height, shift, cls, cls_stride);
   UVGHIP_CHECK_LAUNCH();
 }
 
@@ -94,6 +95,7 @@ extern "C" int uvghip_alf_classify_frame(int bitdepth, const void *rec, int rec_
 __device__ static const int8_t kPerm7[4][13] = {{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12}, {9, 4, 10, 8, 1, 5, 11, 7, 3, 0, 2, 6, 12},
                                                 {0, 3, 2, 1, 8, 7, 6, 5, 4, 9, 10, 11, 12}, {9, 8, 10, 4, 3, 7, 11, 5, 1, 0, 2, 6, 12}};
 
+#define ALF_FILTER_SPLIT 4
 template <typename PX, bool CHROMA>
 __global__ void __launch_bounds__(256)
 alf_filter_kernel(const PX *__restrict__ src, int sstride, PX *__restrict__ dst, int dstride, int pic_w, int pic_h,
@@ -105,13 +107,15 @@ alf_filter_kernel(const PX *__restrict__ src, int sstride, PX *__restrict__ dst,
   constexpr int vbh = CHROMA ? 32 : 64, vb_pos = CHROMA ? 30 : 60;
   constexpr int DEPTH = px_traits<PX>::depth;
   __shared__ int16_t sCoef[25 * 13], sClip[25 * 13];
-  const int si = set_idx[blockIdx.x];
+  const int rect_i = blockIdx.x / ALF_FILTER_SPLIT, part = blockIdx.x % ALF_FILTER_SPLIT;   // a rectangle = ALF_FILTER_SPLIT workgroups
+  const int si = set_idx[rect_i];
   if (si < 0) return;                       // CTU not filtered: dst keeps what it has (alf.c:5088)
-  const uvghip_rect_t R = rects[blockIdx.x];
+  const uvghip_rect_t R = rects[rect_i];
   for (int i = threadIdx.x; i < NSET; i += blockDim.x) { sCoef[i] = coef_sets[(size_t)si * NSET + i]; sClip[i] = clip_sets[(size_t)si * NSET + i]; }
   __syncthreads();
   const int shift = DEPTH - 1, offset = 1 << (shift - 1);
-  for (int i = threadIdx.x; i < R.w * R.h; i += blockDim.x) {
+  const int per = (R.w * R.h + ALF_FILTER_SPLIT - 1) / ALF_FILTER_SPLIT;
+  for (int i = part * per + threadIdx.x; i < min(R.w * R.h, (part + 1) * per); i += blockDim.x) {
     const int yy = i / R.w, x = R.x + (i - yy * R.w), y = R.y + yy;
     const int y_vb = y & (vbh - 1);
     int lim = 3;
@@ -153,7 +157,7 @@ extern "C" int uvghip_alf_filter_batch(int bitdepth, const void *src, int src_st
   UVGHIP_REQUIRE_READY();
   if (n <= 0) return 0;
   hipStream_t st = uvghip_stream(stream);
-#define F(PX, C) alf_filter_kernel<PX, C><<<n, 256, 0, st>>>((const PX *)src, src_stride, (PX *)dst, dst_stride, pic_w, pic_h, rects, set_idx, coef_sets, clip_sets, cls, cls_stride)
+#define F(PX, C) alf_filter_kernel<PX, C><<<n * ALF_FILTER_SPLIT, 256, 0, st>>>((const PX *)src, src_stride, (PX *)dst, dst_stride, pic_w, pic_h, rects, set_idx, coef_sets, clip_sets, cls, cls_stride)
   if (bitdepth == 8) { if (is_chroma) F(uint8_t, true); else F(uint8_t, false); }
   else { if (is_chroma) F(uint16_t, true); else F(uint16_t, false); }
 #undef F
