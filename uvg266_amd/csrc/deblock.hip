@@ -319,8 +319,17 @@ __global__ void __launch_bounds__(256)
 deblock_pass_kernel(PX *__restrict__ y, int y_stride, PX *__restrict__ u, PX *__restrict__ v, int c_stride, int width,
                     int height, const uvghip_scu_t *__restrict__ scu, int scu_stride, dbk_cfg cfg, int dir_hor)
 {
-  const int ux = blockIdx.x * blockDim.x + threadIdx.x;   // 4x4 unit column
-  const int uy = blockIdx.y;                              // 4x4 unit row
+  // blockIdx.z = 0: luma segments, one thread per 4x4 unit.  blockIdx.z = 1: the chroma segments (8-sample chroma grid =
+  // every fourth unit across the edge direction) on their own threads, so that no thread carries a luma and two chroma
+  // filters in one dependent chain.
+  int ux = blockIdx.x * blockDim.x + threadIdx.x;         // 4x4 unit column
+  int uy = blockIdx.y;                                    // 4x4 unit row
+  const bool chroma = blockIdx.z != 0;
+  if (chroma) {
+    if (!u) return;
+    if (dir_hor) { if (uy & 3) return; }                  // chroma rows of the grid: luma unit rows 0, 4, 8, ...
+    else ux *= 4;                                         // chroma columns: compacted, unit columns 0, 4, 8, ...
+  }
   const int bx = ux * 4, by = uy * 4;
   if (bx >= width || by >= height) return;
   if ((!dir_hor && bx == 0) || (dir_hor && by == 0)) return;
@@ -328,11 +337,8 @@ deblock_pass_kernel(PX *__restrict__ y, int y_stride, PX *__restrict__ u, PX *__
   const uvghip_scu_t *c = scu + uy * scu_stride + ux;
   const int le = c->luma_edges, ce = c->chroma_edges;
   if (!(le & bit)) return;
-  luma_segment<PX>(y, y_stride, scu, scu_stride, bx, by, dir_hor != 0, cfg);
-  if (u && (ce & bit)) {
-    const int xc = bx >> 1, yc = by >> 1;
-    if (dir_hor ? (yc & 7) == 0 : (xc & 7) == 0) chroma_segment<PX>(u, v, c_stride, scu, scu_stride, xc, yc, dir_hor != 0, cfg);
-  }
+  if (!chroma) luma_segment<PX>(y, y_stride, scu, scu_stride, bx, by, dir_hor != 0, cfg);
+  else if (ce & bit) chroma_segment<PX>(u, v, c_stride, scu, scu_stride, bx >> 1, by >> 1, dir_hor != 0, cfg);
 }
 
 extern "C" int uvghip_deblock_frame(int bitdepth, void *y, int y_stride, void *u, void *v, int c_stride, int width, int height,
@@ -347,7 +353,7 @@ extern "C" int uvghip_deblock_frame(int bitdepth, void *y, int y_stride, void *u
   for (int i = 0; i < 64; ++i) cfg.qp_map[i] = chroma_qp_map_host ? chroma_qp_map_host[i] : 0;
   const int ux = width / 4, uy = height / 4;
   constexpr int DBK_THREADS = 64;     // one wave per workgroup: 2160 workgroups at 1080p spread evenly over the 256 CUs (256-thread groups: 540)
-  dim3 grid((ux + DBK_THREADS - 1) / DBK_THREADS, uy);
+  dim3 grid((ux + DBK_THREADS - 1) / DBK_THREADS, uy, u ? 2 : 1);
   hipStream_t st = uvghip_stream(stream);
   for (int dir_hor = 0; dir_hor < 2; ++dir_hor) {
     if (bitdepth == 8)
