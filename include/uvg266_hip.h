@@ -410,7 +410,8 @@ UVGHIP_API int uvghip_alf_filter_batch(int bitdepth, const void *src, int src_st
  * x and width multiples of 4) and class c (luma: 25 classes from cls; chroma: c = 0):
  *   ee[r][c][k][l][b0][b1] (int64, full symmetric 13x13x4x4), y[r][c][k][b] (int32), pix_acc[r][c] (int64; the
  *   reference keeps this integer in a double) -- the fields of alf_covariance (alf.h:176-182).
- * Clipping values are the reference's defaults for the bit depth (alf.c:5248-5260). */
+ * Clipping values are the reference's defaults for the bit depth (alf.c:5248-5260).  Every entry of the three outputs is
+ * written exactly once (zeros for classes without a block in the rectangle): the buffers need no initialisation. */
 UVGHIP_API int uvghip_alf_stats_batch(int bitdepth, const void *org, int org_stride, const void *rec, int rec_stride, int pic_w,
                            int pic_h, int is_chroma, const uvghip_rect_t *rects, int n, const uint8_t *cls,
                            int cls_stride, int64_t *ee, int32_t *y, int64_t *pix_acc, void *stream);
