@@ -1076,10 +1076,15 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
   uint32_t my_best[BPL];
 #pragma unroll
   for (int q = 0; q < BPL; ++q) my_best[q] = 0xffffffffu;
+  int strip_main = -1;      // which reference row the upper half of this wave's strips currently holds (wave-uniform)
   {
     for (int m = wave; m < n_modes; m += WAVES) {
       const uint2 pm = sMode[m];
       const search_mode S = unpack_search_mode(__builtin_amdgcn_readfirstlane(pm.x), __builtin_amdgcn_readfirstlane(pm.y));
+      // the main-row half of a strip does not depend on the mode, only on which row is "main": it is copied when that
+      // changes (a wave's negative-angle candidates come as a run of horizontal and a run of vertical modes), the
+      // projected half is rebuilt for every mode
+      const bool copy_main = S.kind == 2 && S.sd < 0 && S.row_main != strip_main;
       // Everything per-lane is re-derived from one opaque copy of the lane's (block, tile) each iteration: left to itself
       // LICM hoists these pointers and a dozen per-column values (xd0 | i, 2 * (xd0 | i), ...) out of the mode loop and the
       // register allocator then spills them to scratch (measured: 18 MB of scratch writes per launch)
@@ -1108,20 +1113,20 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
           for (int j = 0; j <= T; ++j) sv[j] = pr_sample(side, min((j * S.inv + 256) >> 9, T));
 #pragma unroll
           for (int j = 1; j <= T; ++j) priv[T - j] = (uint32_t)sv[j] | ((uint32_t)sv[j - 1] << 16);
+          if (copy_main) {
 #pragma unroll
-          for (int i = 0; i <= T; ++i) priv[T + i] = mainr[i];
+            for (int i = 0; i <= T; ++i) priv[T + i] = mainr[i];
+          }
         } else {
           const int need = min(n, (__mul24(-S.sd, n) + 31) >> 5);   // deepest row reaches ext[-need]
-          for (int e = n - need + tile; e < 2 * n + 1; e += tiles) {
-            uint32_t v;
-            if (e < n) {
-              const int j = n - e;
-              const int a0 = pr_sample(side, min((__mul24(j, S.inv) + 256) >> 9, n));
-              const int a1 = pr_sample(side, min((__mul24(j - 1, S.inv) + 256) >> 9, n));
-              v = (uint32_t)a0 | ((uint32_t)a1 << 16);
-            } else v = mainr[e - n];
-            priv[e] = v;
+          for (int e = n - need + tile; e < n; e += tiles) {
+            const int j = n - e;
+            const int a0 = pr_sample(side, min((__mul24(j, S.inv) + 256) >> 9, n));
+            const int a1 = pr_sample(side, min((__mul24(j - 1, S.inv) + 256) >> 9, n));
+            priv[e] = (uint32_t)a0 | ((uint32_t)a1 << 16);
           }
+          if (copy_main)
+            for (int e = n + tile; e < 2 * n + 1; e += tiles) priv[e] = mainr[e - n];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1147,7 +1152,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
           // 8-bit 16x16 / 32x32: the smoothing modes took the A + h * B path above, which leaves only the two integer-slope
           // modes for the unclamped variant -- they go through the clamped one (same result, 64 ops more for two modes)
           // and the register-hungriest variant is not instantiated at all (it was the one that spilled)
-          constexpr bool kNoclampVariant = !((sizeof(PX) == 1 && NFIX >= 16) || (sizeof(PX) == 2 && NFIX == 16));   // 10-bit 16x16: spilled too
+          constexpr bool kNoclampVariant = NFIX < 16;   // (10-bit 16x16 / 32x32: their smoothing modes take the clamped variant too)
           if (kNoclampVariant && S.noclamp) search_tile_angular<T, 2, false, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, wrow, sorow, n, xd0, yd0, ot, maxv, d, sad);
           else search_tile_angular<T, 2, true, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, wrow, sorow, n, xd0, yd0, ot, maxv, d, sad);
         } else search_tile_angular<T, 3, false, sizeof(PX) == 1>(S, mainr, side, rowp, sCoef, wrow, sorow, n, xd0, yd0, ot, maxv, d, sad);   // pure H/V: integer phase
@@ -1174,6 +1179,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
         my_best[q] = min(my_best[q], (c << 7) | (uint32_t)m);       // c < 2^25: at most 2 * 1024 samples * 255 (after the depth shift)
       }
       }   // q
+      if (copy_main) strip_main = S.row_main;
     }
   }
   // fused arg-min (the strict "<" scan of search_intra.c:1089-1101: ties keep the earlier candidate):
