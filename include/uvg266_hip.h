@@ -54,6 +54,17 @@ UVGHIP_API const char *uvghip_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
 UVGHIP_API int uvghip_abi_version(void);
 
+/* A picture's kernel sequence is fixed once its descriptor tables exist, so the host captures it into a hipGraph and
+ * replays it with one call per picture (the per-launch host cost of 40 small kernels exceeds their GPU time):
+ *   uvghip_graph_begin(stream);  ...any uvghip_*_batch / _frame / _band calls on `stream`...;  uvghip_graph_end(stream, &g);
+ *   uvghip_graph_launch(g, any_stream);  ...;  uvghip_graph_destroy(g);
+ * Capture is thread-local (hipStreamCaptureModeThreadLocal).  uvghip_comm_* calls are not captured: issue them
+ * between graph segments. */
+UVGHIP_API int uvghip_graph_begin(void *stream);
+UVGHIP_API int uvghip_graph_end(void *stream, void **graph_exec_out);
+UVGHIP_API int uvghip_graph_launch(void *graph_exec, void *stream);
+UVGHIP_API int uvghip_graph_destroy(void *graph_exec);
+
 /* ---------------------------------------------- (1) drop-in registrars -- */
 /* replaces: the line a maintainer adds after
  *   src/strategies/strategies-picture.c:106-108 (avx2 registration), etc.
@@ -242,6 +253,13 @@ UVGHIP_API int uvghip_intra_pred_plane_batch(int bitdepth, const void *rec, int 
                                   const uvghip_intra_blk_t *blks, int n, const int8_t *modes,
                                   void *pred_plane, int pred_stride, void *stream);
 
+/* uvghip_intra_pred_plane_batch for a chroma plane (4:2:0): no reference smoothing, 2-tap interpolation, the chroma
+ * PDPC rules (intra-generic.c:55-295 with channel_type != COLOR_Y; intra.c:690-726).  modes[i]: the final chroma mode
+ * (0, 1, 2..66 -- for the derived mode that is the co-located luma mode, src/search_intra.c:1657). */
+UVGHIP_API int uvghip_intra_pred_plane_chroma_batch(int bitdepth, const void *rec, int rec_stride, int size,
+                                         const uvghip_intra_blk_t *blks, int n, const int8_t *modes,
+                                         void *pred_plane, int pred_stride, void *stream);
+
 /* Picks, per block, the candidate with the smallest cost; ties keep the earlier candidate, like
  * the strict "<" scans of search_intra_rough (src/search_intra.c:1089-1101).
  * best_mode[i] = modes[argmin_m costs[i*n_modes+m]], best_cost (may be NULL) the minimum. */
@@ -320,8 +338,10 @@ typedef struct uvghip_sao_param {
 } uvghip_sao_param_t;
 
 /* replaces: uvg_sao_reconstruct -> uvg_sao_reconstruct_color (src/sao.c:302-361,
- * sao-generic.c:84-124): out = SAO(rec) inside each rectangle with its parameters; edge classes
- * leave the picture's outermost row/column untouched.  rec and out must be different planes. */
+ * sao-generic.c:84-124): out = SAO(rec) inside each rectangle with its parameters.  Samples SAO does not
+ * modify -- type 0 rectangles and the picture's outermost row/column for edge classes (sao.c:321-348) -- are
+ * copied from rec, so every sample of every rectangle is written (the reference filters a copy of the picture in
+ * place and gets the same picture).  rec and out must be different planes. */
 UVGHIP_API int uvghip_sao_apply_batch(int bitdepth, const void *rec, int rec_stride, void *out, int out_stride,
                            int pic_w, int pic_h, const uvghip_rect_t *rects,
                            const uvghip_sao_param_t *params, int n, void *stream);
@@ -346,7 +366,9 @@ UVGHIP_API int uvghip_sao_edge_offsets_batch(const int32_t *edge_stats, const in
  * cu_info_t is shown in INTEGRATION.md. */
 typedef struct uvghip_scu {
   uint8_t luma_edges;          /* cu_info_t.luma_deblocking: bit0 (EDGE_VER=1) left edge, bit1 (EDGE_HOR=2) top edge */
-  uint8_t chroma_edges;        /* cu_info_t.chroma_deblocking, same bits */
+  uint8_t chroma_edges;        /* cu_info_t.chroma_deblocking, same bits; must be a subset of luma_edges (single tree: the
+                                * reference only visits chroma where filter_deblock_unit runs for luma, filter.c:1284-1289;
+                                * a dual tree's separate chroma cu_array, :1290-1292, is not modelled) */
   uint8_t type;                /* cu_type_t: 1 intra, 2 inter, 4 IBC */
   uint8_t cbf;                 /* bit0 Y, bit1 U, bit2 V (cbf_is_set, src/cu.h:581) */
   int8_t  qp;                  /* cu_info_t.qp */
@@ -415,6 +437,98 @@ UVGHIP_API int uvghip_alf_filter_batch(int bitdepth, const void *src, int src_st
 UVGHIP_API int uvghip_alf_stats_batch(int bitdepth, const void *org, int org_stride, const void *rec, int rec_stride, int pic_w,
                            int pic_h, int is_chroma, const uvghip_rect_t *rects, int n, const uint8_t *cls,
                            int cls_stride, int64_t *ee, int32_t *y, int64_t *pix_acc, void *stream);
+
+/* uvghip_alf_stats_batch with a compact output: the covariances are symmetric (ee[k][l][b0][b1] == ee[l][k][b1][b0];
+ * the reference symmetrises after the fact, alf-generic.c:984-997) and most of the 25 classes are absent from any one
+ * CTU, so only the classes PRESENT in a rectangle are written, and of ee only the pairs k <= l:
+ *   present[r]                       bit c set = class c occurs in rectangle r
+ *   records[(r * ncls + s)]          the s-th present class of r (increasing class order); ncls = 25 luma / 1 chroma;
+ *                                    slots s >= popcount(present[r]) are left untouched
+ * one record = UVGHIP_ALF_REC_WORDS int64:
+ *   [ (k*13 - k*(k-1)/2 + l-k) * 16 + b0*4 + b1 ]  ee[k][l][b0][b1], k <= l < 13      (91 * 16 words)
+ *   [1456 .. 1481] as int32[52]                     y[k][b]
+ *   [1482]                                          pix_acc;   [1483] zero
+ * i.e. 11.9 KB per present class instead of 21.9 KB for each of the 25. */
+#define UVGHIP_ALF_REC_WORDS 1484
+UVGHIP_API int uvghip_alf_stats_compact_batch(int bitdepth, const void *org, int org_stride, const void *rec, int rec_stride,
+                                   int pic_w, int pic_h, int is_chroma, const uvghip_rect_t *rects, int n,
+                                   const uint8_t *cls, int cls_stride, int64_t *records, uint32_t *present, void *stream);
+
+/* Compact records -> the full per-class layout uvghip_alf_stats_batch writes (zeros for absent classes). */
+UVGHIP_API int uvghip_alf_cov_expand(const int64_t *records, const uint32_t *present, int n, int is_chroma, int64_t *ee,
+                          int32_t *y, int64_t *pix_acc, void *stream);
+
+/* replaces: the accumulation of the CTU covariances into the frame covariances the filters are derived from
+ * (src/alf.c:792-835).  sums[c] = UVGHIP_ALF_SUM_WORDS int64 per class: the ee triangle as in a record (1456 words), then
+ * y[52] widened to int64, then pix_acc.  In a multi-GPU run every rank reduces its own CTUs and the ranks' sums meet
+ * in uvghip_comm_allreduce_i64. */
+#define UVGHIP_ALF_SUM_WORDS 1509
+UVGHIP_API int uvghip_alf_cov_reduce(const int64_t *records, const uint32_t *present, int n, int is_chroma, int64_t *sums,
+                          void *stream);
+
+/* ------------------------------- (2) batched ABI: CTU-row bands (multi-GPU) ---- */
+
+/* One picture sharded over the GPUs of a node by contiguous CTU rows (the reference's own row
+ * parallelism: one job per CTU row, src/encoderstate.c:1085-1189).  Every rank keeps full-size planes and fills / filters
+ * only the rows it owns plus the halo rows it received, so every kernel keeps picture coordinates and its
+ * picture-border behaviour.  Halo rows a band needs from its neighbours (luma rows; chroma = half):
+ *   deblocking   a horizontal edge on a band boundary is filtered by BOTH neighbours, each into its own copy.  At a
+ *                CTU boundary the P (upper) side reads 4 rows and the Q (lower) side 8 (src/filter.c:611-619,908-973
+ *                with the CTB-boundary shortening :224-226), after the vertical-edge pass; plus one row of
+ *                uvghip_scu_t on either side for Bs / QP / transform sizes.  The rows SAO reads across the boundary
+ *                (+-1) come out of this redundant filtering already final.
+ *   ALF          3 rows of SAO output either side (7x7 diamond and 8x8 Laplacian window, both clamped at the
+ *                virtual boundary 4 rows above the CTU boundary, src/alf.h:32-33); 4 are exchanged. */
+#define UVGHIP_HALO_DBK_P 4
+#define UVGHIP_HALO_DBK_Q 8
+#define UVGHIP_HALO_ALF   4
+
+typedef struct uvghip_band_plan {
+  int32_t rank, nranks;
+  int32_t ctu_rows;             /* CTU rows of the picture */
+  int32_t ctu_row0, ctu_row1;   /* this rank owns CTU rows [ctu_row0, ctu_row1): balanced, the first ctu_rows % nranks ranks get one more */
+  int32_t y0, y1;               /* = luma rows [y0, y1) (y1 clipped to the picture) */
+  int32_t up, down;             /* neighbour ranks, -1 at the picture border */
+} uvghip_band_plan_t;
+
+/* Host only, no device.  Fails when nranks exceeds the number of CTU rows. */
+UVGHIP_API int uvghip_band_plan(int pic_h, int nranks, int rank, uvghip_band_plan_t *out);
+
+/* uvghip_deblock_frame restricted to a band (rows multiples of 4).  passes bit 0: the vertical edges of rows
+ * [row0, row1); bit 1: the horizontal edges at y = row0 .. row1, INCLUDING y = row1 when that is not the picture's
+ * bottom -- both owners of a boundary edge filter it.  The horizontal pass of a band needs the vertical pass of the
+ * rows [row0 - UVGHIP_HALO_DBK_P, row1 + UVGHIP_HALO_DBK_Q) to have completed (own rows + received halos). */
+UVGHIP_API int uvghip_deblock_band(int bitdepth, void *y, int y_stride, void *u, void *v, int c_stride, int width, int height,
+                        const uvghip_scu_t *scu, int scu_stride, int beta_offset_div2, int tc_offset_div2,
+                        int slice_is_b, int frame_qp, const int8_t *chroma_qp_map_host, int row0, int row1, int passes,
+                        void *stream);
+
+/* uvghip_alf_classify_frame for the 4x4 blocks of rows [row0, row1). */
+UVGHIP_API int uvghip_alf_classify_band(int bitdepth, const void *rec, int rec_stride, int width, int height, int shift,
+                             uint8_t *cls, int cls_stride, int row0, int row1, void *stream);
+
+/* ---- data-path exchanges between the ranks: RCCL over xGMI, issued on the caller's stream ---- */
+#define UVGHIP_COMM_ID_BYTES 128
+/* rank 0: ncclGetUniqueId into a HOST buffer of UVGHIP_COMM_ID_BYTES; the host distributes it to the other ranks
+ * (any out-of-band channel: the launcher's store, MPI, a file). */
+UVGHIP_API int uvghip_comm_unique_id(void *id_host);
+/* every rank, after uvghip_init on its own device: ncclCommInitRank. */
+UVGHIP_API int uvghip_comm_create(const void *id_host, int nranks, int rank, void **comm_out);
+UVGHIP_API int uvghip_comm_destroy(void *comm);
+
+/* One pairwise transfer: send_bytes from `send` to `peer` and/or recv_bytes from `peer` into `recv` (device pointers). */
+typedef struct uvghip_xfer {
+  int32_t peer, reserved;
+  const void *send; uint64_t send_bytes;
+  void *recv;       uint64_t recv_bytes;
+} uvghip_xfer_t;
+/* ncclGroupStart; ncclSend / ncclRecv for every entry; ncclGroupEnd -- the halo exchange (two neighbours) and the
+ * all-to-all distribution of reconstructed bands (uneven sizes) are both lists of these.  xfers_host: HOST array. */
+UVGHIP_API int uvghip_comm_exchange(void *comm, const uvghip_xfer_t *xfers_host, int n, void *stream);
+/* ncclAllReduce(sum, int64) in place: the frame-level ALF covariances (src/alf.c:792-835 sums them over the CTUs). */
+UVGHIP_API int uvghip_comm_allreduce_i64(void *comm, int64_t *buf, size_t count, void *stream);
+/* ncclAllGather of equal-sized contributions (bytes_per_rank each). */
+UVGHIP_API int uvghip_comm_allgather(void *comm, const void *send, void *recv, size_t bytes_per_rank, void *stream);
 
 #ifdef __cplusplus
 }

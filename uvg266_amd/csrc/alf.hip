@@ -33,9 +33,10 @@ __device__ __forceinline__ int pxc(const PX *p, int stride, int w, int h, int x,
 // ------------------------------------------------------------------ classification ----
 template <typename PX>
 __global__ void __launch_bounds__(256)
-alf_classify_kernel(const PX *__restrict__ rec, int stride, int w, int h, int shift, uint8_t *__restrict__ cls, int cls_stride)
+alf_classify_kernel(const PX *__restrict__ rec, int stride, int w, int h, int shift, uint8_t *__restrict__ cls, int cls_stride,
+                    int unit_row0)
 {
-  const int bx4 = blockIdx.x * blockDim.x + threadIdx.x, by4 = blockIdx.y;
+  const int bx4 = blockIdx.x * blockDim.x + threadIdx.x, by4 = unit_row0 + blockIdx.y;
   const int bx = bx4 * 4, by = by4 * 4;
   if (bx >= w || by >= h) return;
   constexpr int vbh = 64, vb_pos = 60;
@@ -78,17 +79,31 @@ alf_classify_kernel(const PX *__restrict__ rec, int stride, int w, int h, int sh
   cls[by4 * cls_stride + bx4] = (uint8_t)(class_idx | (tt[main_dir * 2 + (sec_dir >> 1)] << 5));
 }
 
+static int alf_classify_launch(int bitdepth, const void *rec, int rec_stride, int width, int height, int shift, uint8_t *cls,
+                               int cls_stride, int row0, int row1, hipStream_t st, const char *who)
+{
+  if ((bitdepth != 8 && bitdepth != 10) || width <= 0 || height <= 0 || (width & 3) || (height & 3) || row0 < 0 ||
+      row1 > height || row0 >= row1 || (row0 & 3) || (row1 & 3))
+    return uvghip_set_error(hipErrorInvalidValue, who);
+  constexpr int THREADS = 64;          // one wave per workgroup: four times as many workgroups to spread over the CUs
+  dim3 grid((width / 4 + THREADS - 1) / THREADS, (row1 - row0) / 4);
+  if (bitdepth == 8) alf_classify_kernel<uint8_t><<<grid, THREADS, 0, st>>>((const uint8_t *)rec, rec_stride, width, height, shift, cls, cls_stride, row0 / 4);
+  else alf_classify_kernel<uint16_t><<<grid, THREADS, 0, st>>>((const uint16_t *)rec, rec_stride, width, height, shift, cls, cls_stride, row0 / 4);
+  UVGHIP_CHECK_LAUNCH();
+}
+
 extern "C" int uvghip_alf_classify_frame(int bitdepth, const void *rec, int rec_stride, int width, int height, int shift,
                                          uint8_t *cls, int cls_stride, void *stream)
 {
   UVGHIP_REQUIRE_READY();
-  if (width <= 0 || height <= 0 || (width & 3) || (height & 3)) return uvghip_set_error(hipErrorInvalidValue, __func__);
-  constexpr int THREADS = 64;          // one wave per workgroup: four times as many workgroups to spread over the CUs
-  dim3 grid((width / 4 + THREADS - 1) / THREADS, height / 4);
-  hipStream_t st = uvghip_stream(stream);
-  if (bitdepth == 8) alf_classify_kernel<uint8_t><<<grid, THREADS, 0, st>>>((const uint8_t *)rec, rec_stride, width, height, shift, cls, cls_stride);
-  else alf_classify_kernel<uint16_t><<<grid, THREADS, 0, st>>>((const uint16_t *)rec, rec_stride, width, height, shift, cls, cls_stride);
-  UVGHIP_CHECK_LAUNCH();
+  return alf_classify_launch(bitdepth, rec, rec_stride, width, height, shift, cls, cls_stride, 0, height, uvghip_stream(stream), __func__);
+}
+
+extern "C" int uvghip_alf_classify_band(int bitdepth, const void *rec, int rec_stride, int width, int height, int shift,
+                                        uint8_t *cls, int cls_stride, int row0, int row1, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  return alf_classify_launch(bitdepth, rec, rec_stride, width, height, shift, cls, cls_stride, row0, row1, uvghip_stream(stream), __func__);
 }
 
 // ------------------------------------------------------------------------- filter ----
@@ -244,11 +259,15 @@ typedef int alf_v16i __attribute__((ext_vector_type(16)));
 constexpr int ALF_KP = 272;        // bytes per operand row: 256 samples + pad (68 dwords = 4 mod 64: b128 reads of 16 rows tile the banks)
 constexpr int ALF_SLOTS = 16;      // 4x4 blocks per phase-A chunk (256 samples, one per thread)
 
-template <typename PX, bool CHROMA>
+// COMPACT: the output is one uvghip record (UVGHIP_ALF_REC_WORDS int64) per class PRESENT in the rectangle -- the upper
+// triangle k <= l of ee (ee[k][l][b0][b1] == ee[l][k][b1][b0]), y, pix_acc -- in class order, plus the rectangle's class
+// mask in `present`; absent classes cost no write at all.  `ee` then points at the records, `yv` / `pix` are unused.
+template <typename PX, bool CHROMA, bool COMPACT>
 __global__ void __launch_bounds__(256)
 alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__ rec, int rstride, int pic_w, int pic_h,
                  const uvghip_rect_t *__restrict__ rects, const uint8_t *__restrict__ cls, int cls_stride,
-                 long long *__restrict__ ee, int32_t *__restrict__ yv, long long *__restrict__ pix)
+                 long long *__restrict__ ee, int32_t *__restrict__ yv, long long *__restrict__ pix,
+                 uint32_t *__restrict__ present)
 {
   constexpr int NC = CHROMA ? 7 : 13, NCLS = CHROMA ? 1 : 25;
   constexpr int NE = NC * 4;                   // entries of e; index NE is d = org - rec
@@ -266,9 +285,10 @@ alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__
   __shared__ int sCnt[32], sPos[32];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const uvghip_rect_t R = rects[blockIdx.x];
-  long long *E = ee + (size_t)blockIdx.x * NCLS * 13 * 13 * 16;
-  int32_t *Y = yv + (size_t)blockIdx.x * NCLS * 13 * 4;
-  long long *PA = pix + (size_t)blockIdx.x * NCLS;
+  long long *E = ee + (size_t)blockIdx.x * NCLS * (COMPACT ? UVGHIP_ALF_REC_WORDS : 13 * 13 * 16);
+  int32_t *Y = COMPACT ? nullptr : yv + (size_t)blockIdx.x * NCLS * 13 * 4;
+  long long *PA = COMPACT ? nullptr : pix + (size_t)blockIdx.x * NCLS;
+  int n_done = 0;                               // COMPACT: records written so far (classes are visited in increasing order)
   int clipv[4];
   clipv[0] = 1 << DEPTH;
 #pragma unroll
@@ -337,13 +357,28 @@ alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__
       auto cval = [&](int i, int j2) -> long long {
         return sym(0, i, j2) * 16384 + (full(i, j2) + full(j2, i)) * 128 + sym(N_SYM, i, j2);
       };
-      long long *Ec = E + (size_t)cur_cls * 13 * 13 * 16;
-      for (int idx = t; idx < 13 * 13 * 16; idx += 256) {
-        const int b1 = idx & 3, b0 = (idx >> 2) & 3, kl = idx >> 4, k = kl / 13, l = kl - k * 13;
-        Ec[idx] = (k < NC && l < NC) ? cval(4 * k + b0, 4 * l + b1) : 0;
+      if constexpr (COMPACT) {
+        long long *Rc = E + (size_t)n_done * UVGHIP_ALF_REC_WORDS;
+        for (int idx = t; idx < 91 * 16; idx += 256) {
+          const int b1 = idx & 3, b0 = (idx >> 2) & 3, p = idx >> 4;
+          int k = 0, base = 0;                                        // pair p -> (k, l), k <= l: row k holds 13 - k pairs
+          while (p >= base + 13 - k) { base += 13 - k; ++k; }
+          const int l = k + (p - base);
+          Rc[idx] = (l < NC) ? cval(4 * k + b0, 4 * l + b1) : 0;
+        }
+        int32_t *Yc = reinterpret_cast<int32_t *>(Rc + 91 * 16);
+        for (int idx = t; idx < 13 * 4; idx += 256) Yc[idx] = (idx >> 2) < NC ? (int32_t)cval(idx, NE) : 0;
+        if (t == 0) { Rc[91 * 16 + 26] = cval(NE, NE); Rc[91 * 16 + 27] = 0; }
+        ++n_done;
+      } else {
+        long long *Ec = E + (size_t)cur_cls * 13 * 13 * 16;
+        for (int idx = t; idx < 13 * 13 * 16; idx += 256) {
+          const int b1 = idx & 3, b0 = (idx >> 2) & 3, kl = idx >> 4, k = kl / 13, l = kl - k * 13;
+          Ec[idx] = (k < NC && l < NC) ? cval(4 * k + b0, 4 * l + b1) : 0;
+        }
+        for (int idx = t; idx < 13 * 4; idx += 256) Y[cur_cls * 13 * 4 + idx] = (idx >> 2) < NC ? (int32_t)cval(idx, NE) : 0;
+        if (t == 0) PA[cur_cls] = cval(NE, NE);
       }
-      for (int idx = t; idx < 13 * 4; idx += 256) Y[cur_cls * 13 * 4 + idx] = (idx >> 2) < NC ? (int32_t)cval(idx, NE) : 0;
-      if (t == 0) PA[cur_cls] = cval(NE, NE);
       done_mask |= 1u << cur_cls;
     }
     __syncthreads();
@@ -411,6 +446,10 @@ alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__
   }
   flush();
   cur_cls = -1;
+  if constexpr (COMPACT) {
+    if (t == 0) present[blockIdx.x] = done_mask;
+    return;
+  }
   // classes without a block in this rectangle: zeros
   for (int c = 0; c < NCLS; ++c) {
     if (done_mask >> c & 1) continue;
@@ -425,11 +464,112 @@ extern "C" int uvghip_alf_stats_batch(int bitdepth, const void *org, int org_str
                                       int cls_stride, int64_t *ee, int32_t *y, int64_t *pix_acc, void *stream)
 {
   UVGHIP_REQUIRE_READY();
+  if (bitdepth != 8 && bitdepth != 10) return uvghip_set_error(hipErrorInvalidValue, __func__);
   if (n <= 0) return 0;
   hipStream_t st = uvghip_stream(stream);
-#define K(PX, C) alf_stats_kernel<PX, C><<<n, 256, 0, st>>>((const PX *)org, org_stride, (const PX *)rec, rec_stride, pic_w, pic_h, rects, cls, cls_stride, (long long *)ee, y, (long long *)pix_acc)
+#define K(PX, C) alf_stats_kernel<PX, C, false><<<n, 256, 0, st>>>((const PX *)org, org_stride, (const PX *)rec, rec_stride, pic_w, pic_h, rects, cls, cls_stride, (long long *)ee, y, (long long *)pix_acc, nullptr)
   if (bitdepth == 8) { if (is_chroma) K(uint8_t, true); else K(uint8_t, false); }
   else { if (is_chroma) K(uint16_t, true); else K(uint16_t, false); }
 #undef K
+  UVGHIP_CHECK_LAUNCH();
+}
+
+extern "C" int uvghip_alf_stats_compact_batch(int bitdepth, const void *org, int org_stride, const void *rec, int rec_stride,
+                                              int pic_w, int pic_h, int is_chroma, const uvghip_rect_t *rects, int n,
+                                              const uint8_t *cls, int cls_stride, int64_t *records, uint32_t *present,
+                                              void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if ((bitdepth != 8 && bitdepth != 10) || !records || !present) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (n <= 0) return 0;
+  hipStream_t st = uvghip_stream(stream);
+#define K(PX, C) alf_stats_kernel<PX, C, true><<<n, 256, 0, st>>>((const PX *)org, org_stride, (const PX *)rec, rec_stride, pic_w, pic_h, rects, cls, cls_stride, (long long *)records, nullptr, nullptr, present)
+  if (bitdepth == 8) { if (is_chroma) K(uint8_t, true); else K(uint8_t, false); }
+  else { if (is_chroma) K(uint16_t, true); else K(uint16_t, false); }
+#undef K
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// ---- consumers of the compact records ----
+__device__ __forceinline__ int alf_tri_index(int k, int l) { return k * 13 - (k * (k - 1)) / 2 + (l - k); }   // k <= l
+
+// The reference layout of alf_covariance (alf.h:176-182) back from the records: one workgroup per (rectangle, class).
+__global__ void __launch_bounds__(256)
+alf_cov_expand_kernel(const long long *__restrict__ records, const uint32_t *__restrict__ present, int ncls,
+                      long long *__restrict__ ee, int32_t *__restrict__ yv, long long *__restrict__ pix)
+{
+  const int r = blockIdx.x / ncls, c = blockIdx.x - r * ncls, t = threadIdx.x;
+  const uint32_t mask = present[r];
+  const bool has = (mask >> c) & 1;
+  const long long *R = records + ((size_t)r * ncls + __popc(mask & ((1u << c) - 1))) * UVGHIP_ALF_REC_WORDS;
+  long long *E = ee + ((size_t)r * ncls + c) * 13 * 13 * 16;
+  for (int idx = t; idx < 13 * 13 * 16; idx += 256) {
+    const int b1 = idx & 3, b0 = (idx >> 2) & 3, kl = idx >> 4, k = kl / 13, l = kl - k * 13;
+    long long v = 0;
+    if (has) v = k <= l ? R[alf_tri_index(k, l) * 16 + b0 * 4 + b1] : R[alf_tri_index(l, k) * 16 + b1 * 4 + b0];
+    E[idx] = v;
+  }
+  const int32_t *Yr = reinterpret_cast<const int32_t *>(R + 91 * 16);
+  if (t < 52) yv[((size_t)r * ncls + c) * 52 + t] = has ? Yr[t] : 0;
+  if (t == 0) pix[(size_t)r * ncls + c] = has ? R[91 * 16 + 26] : 0;
+}
+
+extern "C" int uvghip_alf_cov_expand(const int64_t *records, const uint32_t *present, int n, int is_chroma, int64_t *ee,
+                                     int32_t *y, int64_t *pix_acc, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (n <= 0) return 0;
+  const int ncls = is_chroma ? 1 : 25;
+  alf_cov_expand_kernel<<<n * ncls, 256, 0, uvghip_stream(stream)>>>((const long long *)records, present, ncls, (long long *)ee, y, (long long *)pix_acc);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// Frame-level sums per class (what alf.c:792-835 accumulates over the CTUs before deriving the filters), as
+// UVGHIP_ALF_SUM_WORDS int64 per class: the ee triangle, then y widened to int64, then pix_acc.  A workgroup owns
+// (class, a slice of the rectangles); slices meet through 64-bit atomics on the zeroed output.
+constexpr int ALF_REDUCE_SLICES = 16;
+__global__ void __launch_bounds__(256)
+alf_cov_reduce_kernel(const long long *__restrict__ records, const uint32_t *__restrict__ present, int n, int ncls,
+                      unsigned long long *__restrict__ sums)
+{
+  const int c = blockIdx.x, slice = blockIdx.y, t = threadIdx.x;
+  const int per = (n + ALF_REDUCE_SLICES - 1) / ALF_REDUCE_SLICES;
+  const int r0 = slice * per, r1 = min(n, r0 + per);
+  constexpr int NV = (UVGHIP_ALF_SUM_WORDS + 255) / 256;
+  long long acc[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) acc[j] = 0;
+  bool any = false;
+  for (int r = r0; r < r1; ++r) {
+    const uint32_t mask = present[r];
+    if (!((mask >> c) & 1)) continue;
+    any = true;
+    const long long *R = records + ((size_t)r * ncls + __popc(mask & ((1u << c) - 1))) * UVGHIP_ALF_REC_WORDS;
+    const int32_t *Yr = reinterpret_cast<const int32_t *>(R + 91 * 16);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int idx = t + 256 * j;
+      if (idx < 91 * 16) acc[j] += R[idx];
+      else if (idx < 91 * 16 + 52) acc[j] += Yr[idx - 91 * 16];
+      else if (idx == 91 * 16 + 52) acc[j] += R[91 * 16 + 26];
+    }
+  }
+  if (!any) return;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int idx = t + 256 * j;
+    if (idx < UVGHIP_ALF_SUM_WORDS && acc[j]) atomicAdd(&sums[(size_t)c * UVGHIP_ALF_SUM_WORDS + idx], (unsigned long long)acc[j]);
+  }
+}
+
+extern "C" int uvghip_alf_cov_reduce(const int64_t *records, const uint32_t *present, int n, int is_chroma, int64_t *sums,
+                                     void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  const int ncls = is_chroma ? 1 : 25;
+  hipStream_t st = uvghip_stream(stream);
+  UVGHIP_TRY(hipMemsetAsync(sums, 0, (size_t)ncls * UVGHIP_ALF_SUM_WORDS * 8, st));
+  if (n <= 0) return 0;
+  alf_cov_reduce_kernel<<<dim3(ncls, ALF_REDUCE_SLICES), 256, 0, st>>>((const long long *)records, present, n, ncls, (unsigned long long *)sums);
   UVGHIP_CHECK_LAUNCH();
 }

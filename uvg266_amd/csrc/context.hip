@@ -52,6 +52,40 @@ extern "C" int uvghip_init(int device)
   return 0;
 }
 
+// ---- launch plans as hipGraphs: a picture's fixed kernel sequence is captured once and replayed with one call ----
+extern "C" int uvghip_graph_begin(void *stream)
+{
+  if (!uvghip_ready()) return uvghip_set_error(hipErrorNotInitialized, __func__);
+  UVGHIP_TRY(hipStreamBeginCapture(uvghip_stream(stream), hipStreamCaptureModeThreadLocal));
+  return 0;
+}
+
+extern "C" int uvghip_graph_end(void *stream, void **graph_exec_out)
+{
+  if (!graph_exec_out) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  hipGraph_t g = nullptr;
+  UVGHIP_TRY(hipStreamEndCapture(uvghip_stream(stream), &g));
+  hipGraphExec_t ge = nullptr;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return uvghip_set_error(e, "hipGraphInstantiate");
+  *graph_exec_out = ge;
+  return 0;
+}
+
+extern "C" int uvghip_graph_launch(void *graph_exec, void *stream)
+{
+  if (!graph_exec) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  UVGHIP_TRY(hipGraphLaunch(static_cast<hipGraphExec_t>(graph_exec), uvghip_stream(stream)));
+  return 0;
+}
+
+extern "C" int uvghip_graph_destroy(void *graph_exec)
+{
+  if (graph_exec) UVGHIP_TRY(hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec)));
+  return 0;
+}
+
 extern "C" void uvghip_set_register_fn(uvghip_register_fn fn) { g_register_fn = fn; }
 
 int uvghip_do_register(void *opaque, const char *type, void *fptr)

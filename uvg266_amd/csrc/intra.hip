@@ -381,7 +381,7 @@ extern "C" int uvghip_intra_pred_batch(int bitdepth, const void *rec, int rec_st
 // the block's position -- what uvg_intra_recon_cu's predict step leaves in lcu->rec (intra.c:1537).
 // One thread per 4-sample segment: n*n/4 threads per block, 256/(n*n/4) blocks per workgroup
 // (64 4x4 blocks ... one 32x32 block); reference rows of 2n+4 samples per block in LDS.
-template <typename PX, int N>      // N: the block size, a compile-time constant (all the index arithmetic folds)
+template <typename PX, int N, bool CHROMA = false>      // N: the block size, a compile-time constant (all the index arithmetic folds)
 __global__ void __launch_bounds__(256)
 intra_pred_plane_kernel(const PX *__restrict__ rec, int stride, const uvghip_intra_blk_t *__restrict__ blks,
                         int n_blks, const int8_t *__restrict__ modes, PX *__restrict__ out, int out_stride)
@@ -403,7 +403,7 @@ intra_pred_plane_kernel(const PX *__restrict__ rec, int stride, const uvghip_int
   if (myb < here) {
     const uvghip_intra_blk_t b = blks[blk0 + myb];
     build_ref_rows_batched<PX, 3>(rec, stride, b.x, b.y, b.avail_top, b.avail_left, base, base + RS, RS, mytid, tpb);
-    if (mytid == 0) { sM[myb] = make_mode_info(modes[blk0 + myb], n, n, 0); sX[myb] = b.x; sY[myb] = b.y; }
+    if (mytid == 0) { sM[myb] = make_mode_info(modes[blk0 + myb], n, n, CHROMA ? 1 : 0); sX[myb] = b.x; sY[myb] = b.y; }
   }
   __syncthreads();
   if (myb < here) {
@@ -418,7 +418,7 @@ intra_pred_plane_kernel(const PX *__restrict__ rec, int stride, const uvghip_int
   const int maxv = px_traits<PX>::maxv;
   const int yd = mytid >> (lgn - 2), xd0 = (mytid & ((n >> 2) - 1)) * 4;
   int v[4];
-  predict_row<4>(M, R, sDC[myb], 0, n, n, yd, xd0, maxv, v);
+  predict_row<4>(M, R, sDC[myb], CHROMA ? 1 : 0, n, n, yd, xd0, maxv, v);
   PX *o = out + (size_t)sY[myb] * out_stride + sX[myb];
   if (!transposed) {
     PX *q = o + (size_t)yd * out_stride + xd0;
@@ -430,23 +430,37 @@ intra_pred_plane_kernel(const PX *__restrict__ rec, int stride, const uvghip_int
   }
 }
 
+static int pred_plane_launch(int bitdepth, const void *rec, int rec_stride, int size, const uvghip_intra_blk_t *blks, int n,
+                             const int8_t *modes, void *pred_plane, int pred_stride, bool chroma, hipStream_t st, const char *who)
+{
+  if (!(size == 4 || size == 8 || size == 16 || size == 32) || (bitdepth != 8 && bitdepth != 10)) return uvghip_set_error(hipErrorInvalidValue, who);
+  if (n <= 0) return 0;
+  const int bpg = 256 / (size * size / 4);
+  const int grid = (n + bpg - 1) / bpg;
+  const size_t lds = (size_t)bpg * 4 * (2 * size + 4) * 2 + (size_t)bpg * (sizeof(mode_info) + 12) + 16;
+#define PP(PX, N, C) intra_pred_plane_kernel<PX, N, C><<<grid, 256, lds, st>>>((const PX *)rec, rec_stride, blks, n, modes, (PX *)pred_plane, pred_stride)
+#define PPS(PX, C) do { if (size == 4) PP(PX, 4, C); else if (size == 8) PP(PX, 8, C); else if (size == 16) PP(PX, 16, C); else PP(PX, 32, C); } while (0)
+  if (chroma) { if (bitdepth == 8) PPS(uint8_t, true); else PPS(uint16_t, true); }
+  else { if (bitdepth == 8) PPS(uint8_t, false); else PPS(uint16_t, false); }
+#undef PPS
+#undef PP
+  UVGHIP_CHECK_LAUNCH();
+}
+
 extern "C" int uvghip_intra_pred_plane_batch(int bitdepth, const void *rec, int rec_stride, int size,
                                              const uvghip_intra_blk_t *blks, int n, const int8_t *modes,
                                              void *pred_plane, int pred_stride, void *stream)
 {
   UVGHIP_REQUIRE_READY();
-  if (!(size == 4 || size == 8 || size == 16 || size == 32)) return uvghip_set_error(hipErrorInvalidValue, __func__);
-  if (n <= 0) return 0;
-  const int bpg = 256 / (size * size / 4);
-  const int grid = (n + bpg - 1) / bpg;
-  const size_t lds = (size_t)bpg * 4 * (2 * size + 4) * 2 + (size_t)bpg * (sizeof(mode_info) + 12) + 16;
-  hipStream_t st = uvghip_stream(stream);
-#define PP(PX, N) intra_pred_plane_kernel<PX, N><<<grid, 256, lds, st>>>((const PX *)rec, rec_stride, blks, n, modes, (PX *)pred_plane, pred_stride)
-#define PPS(PX) do { if (size == 4) PP(PX, 4); else if (size == 8) PP(PX, 8); else if (size == 16) PP(PX, 16); else PP(PX, 32); } while (0)
-  if (bitdepth == 8) PPS(uint8_t); else PPS(uint16_t);
-#undef PPS
-#undef PP
-  UVGHIP_CHECK_LAUNCH();
+  return pred_plane_launch(bitdepth, rec, rec_stride, size, blks, n, modes, pred_plane, pred_stride, false, uvghip_stream(stream), __func__);
+}
+
+extern "C" int uvghip_intra_pred_plane_chroma_batch(int bitdepth, const void *rec, int rec_stride, int size,
+                                                    const uvghip_intra_blk_t *blks, int n, const int8_t *modes,
+                                                    void *pred_plane, int pred_stride, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  return pred_plane_launch(bitdepth, rec, rec_stride, size, blks, n, modes, pred_plane, pred_stride, true, uvghip_stream(stream), __func__);
 }
 
 // costs[n][n_modes] -> best[n] = index (into the mode list) of the first minimum, the tie-break of

@@ -137,7 +137,9 @@ extern "C" int uvghip_sao_stats_batch(int bitdepth, const void *orig, int orig_s
 
 // Apply one parameter set per rectangle.  Edge classes skip the picture's outermost
 // rows/columns (sao.c:321-348); band offsets are applied through the value test of
-// uvg_calc_sao_offset_array (sao.c:180-201) instead of a 2^depth LUT.
+// uvg_calc_sao_offset_array (sao.c:180-201) instead of a 2^depth LUT.  Samples SAO leaves alone (type 0
+// rectangles, the skipped border rows/columns) are copied from rec, so `out` is completely defined -- the
+// reference gets the same by filtering a copy of the picture in place.
 // One thread per 4-sample segment: the segment and its two neighbour segments (class-dependent) are three
 // unaligned 4-sample loads; offsets come from a 5-entry LDS table.
 template <typename PX>
@@ -148,46 +150,51 @@ sao_apply_kernel(const PX *__restrict__ rec, int rstride, PX *__restrict__ out, 
   __shared__ int sOff[8];
   const uvghip_rect_t R = rects[blockIdx.x];
   const uvghip_sao_param_t P = params[blockIdx.x];
-  if (P.type == 0) return;
   // straight from global memory: indexing the register copy P dynamically would make the compiler promote P to an
   // LDS alloca whose addressing reads the AQL dispatch packet (host memory) -- measured +13 us per launch
   if (threadIdx.x < 5) sOff[threadIdx.x] = params[blockIdx.x].offsets[threadIdx.x];
   __syncthreads();
   constexpr int maxv = px_traits<PX>::maxv;
   constexpr int bshift = px_traits<PX>::depth - 5;
-  int x0 = R.x, y0 = R.y, w = R.w, h = R.h;
+  // [ix0, ix1) x [iy0, iy1): the part of the rectangle SAO modifies, relative to the rectangle
+  int ix0 = 0, iy0 = 0, ix1 = R.w, iy1 = R.h;
   int ax = 0, ay = 0, bx = 0, by = 0;
   if (P.type == 2) {
     ax = kEoOfs[P.eo_class][0]; ay = kEoOfs[P.eo_class][1]; bx = kEoOfs[P.eo_class][2]; by = kEoOfs[P.eo_class][3];
-    if (x0 + w + ax > pic_w || x0 + w + bx > pic_w) w -= 1;
-    if (x0 + ax < 0 || x0 + bx < 0) { x0 += 1; w -= 1; }
-    if (y0 + h + ay > pic_h || y0 + h + by > pic_h) h -= 1;
-    if (y0 + ay < 0 || y0 + by < 0) { y0 += 1; h -= 1; }
-  }
-  if (w <= 0 || h <= 0) return;
-  const int segs_per_row = (w + 3) >> 2, nseg = segs_per_row * h;
+    if (R.x + R.w + ax > pic_w || R.x + R.w + bx > pic_w) ix1 -= 1;
+    if (R.x + ax < 0 || R.x + bx < 0) ix0 += 1;
+    if (R.y + R.h + ay > pic_h || R.y + R.h + by > pic_h) iy1 -= 1;
+    if (R.y + ay < 0 || R.y + by < 0) iy0 += 1;
+  } else if (P.type == 0) ix1 = 0;
+  if (R.w <= 0 || R.h <= 0) return;
+  const int segs_per_row = (R.w + 3) >> 2, nseg = segs_per_row * R.h;
   const ptrdiff_t oa = (ptrdiff_t)ay * rstride + ax, ob = (ptrdiff_t)by * rstride + bx;
   for (int sg = threadIdx.x; sg < nseg; sg += 256) {
     const int y = sg / segs_per_row, x = (sg - y * segs_per_row) * 4;
-    const PX *rp = rec + (size_t)(y0 + y) * rstride + x0 + x;
-    PX *q = out + (size_t)(y0 + y) * ostride + x0 + x;
-    const int nx = min(4, w - x);
+    const PX *rp = rec + (size_t)(R.y + y) * rstride + R.x + x;
+    PX *q = out + (size_t)(R.y + y) * ostride + R.x + x;
+    const int nx = min(4, R.w - x);
+    const bool row_in = y >= iy0 && y < iy1;
+    const bool whole = nx == 4 && row_in && x >= ix0 && x + 4 <= ix1;     // every sample of the segment is filtered
     int c[4], a[4], b[4], v[4];
-    if (nx == 4) {
+    if (whole) {
       load4(rp, c);
       if (P.type == 2) { load4(rp + oa, a); load4(rp + ob, b); }
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const bool in = i < nx;
+        const bool filt = in && row_in && x + i >= ix0 && x + i < ix1;
         c[i] = in ? rp[i] : 0;
-        a[i] = in && P.type == 2 ? rp[oa + i] : 0;
-        b[i] = in && P.type == 2 ? rp[ob + i] : 0;
+        a[i] = filt && P.type == 2 ? rp[oa + i] : 0;
+        b[i] = filt && P.type == 2 ? rp[ob + i] : 0;
       }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (P.type == 1) {
+      const bool filt = whole || (row_in && x + i >= ix0 && x + i < ix1);
+      if (!filt) v[i] = c[i];
+      else if (P.type == 1) {
         const int band = (c[i] >> bshift) - P.band_position;
         v[i] = (band >= 0 && band <= 3) ? clampi(c[i] + sOff[band + 1], 0, maxv) : c[i];
       } else v[i] = clampi(c[i] + sOff[eo_cat(a[i], b[i], c[i])], 0, maxv);

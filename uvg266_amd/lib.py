@@ -20,6 +20,17 @@ class Blk(ctypes.Structure):
                 ("ref_x", ctypes.c_int32), ("ref_y", ctypes.c_int32)]
 
 
+class BandPlan(ctypes.Structure):
+    """uvghip_band_plan_t."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("rank", "nranks", "ctu_rows", "ctu_row0", "ctu_row1", "y0", "y1", "up", "down")]
+
+
+class Xfer(ctypes.Structure):
+    """uvghip_xfer_t."""
+    _fields_ = [("peer", ctypes.c_int32), ("reserved", ctypes.c_int32), ("send", ctypes.c_void_p), ("send_bytes", ctypes.c_uint64),
+                ("recv", ctypes.c_void_p), ("recv_bytes", ctypes.c_uint64)]
+
+
 _lib = None
 _inited_device = None
 
@@ -32,6 +43,10 @@ SIGNATURES = {
     "uvghip_last_error": (ctypes.c_char_p, []),
     "uvghip_abi_version": (c_int, []),
     "uvghip_set_register_fn": (None, [c_vp]),
+    "uvghip_graph_begin": (c_int, [c_vp]),
+    "uvghip_graph_end": (c_int, [c_vp, c_vp]),
+    "uvghip_graph_launch": (c_int, [c_vp, c_vp]),
+    "uvghip_graph_destroy": (c_int, [c_vp]),
     "uvg_strategy_register_picture_hip": (c_int, [c_vp, ctypes.c_uint8]),
     "uvg_strategy_register_dct_hip": (c_int, [c_vp, ctypes.c_uint8]),
     "uvghip_transform_batch": (c_int, [c_int] * 8 + [c_vp, c_vp, c_int, c_vp]),
@@ -48,6 +63,7 @@ SIGNATURES = {
     "uvghip_intra_search_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_intra_search_best_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_intra_pred_plane_batch": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
+    "uvghip_intra_pred_plane_chroma_batch": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
     "uvghip_intra_select_best": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvghip_mc_batch": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
     "uvghip_frac_satd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
@@ -68,6 +84,19 @@ SIGNATURES = {
     "uvghip_satd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_ssd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_sad_surface": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "uvghip_alf_stats_compact_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "uvghip_alf_cov_expand": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "uvghip_alf_cov_reduce": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    "uvghip_band_plan": (c_int, [c_int, c_int, c_int, c_vp]),
+    "uvghip_deblock_band": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp,
+                                    c_int, c_int, c_int, c_vp]),
+    "uvghip_alf_classify_band": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp]),
+    "uvghip_comm_unique_id": (c_int, [c_vp]),
+    "uvghip_comm_create": (c_int, [c_vp, c_int, c_int, c_vp]),
+    "uvghip_comm_destroy": (c_int, [c_vp]),
+    "uvghip_comm_exchange": (c_int, [c_vp, c_vp, c_int, c_vp]),
+    "uvghip_comm_allreduce_i64": (c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "uvghip_comm_allgather": (c_int, [c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "uvghip_residual_plane": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp]),
 }
 

@@ -1,0 +1,236 @@
+"""The per-picture hot path as a prebuilt launch plan over the batched C ABI -- the rank driver of the CTU-row
+sharded encoder path and, with one rank, the whole-frame path `bench.py` times.
+
+One picture on one rank (`BandFrame`) = every device buffer (nothing is allocated per step), the descriptor tables
+of the CTU rows the rank owns, and lists of launches `(name, fn, args)` with the convention `fn(*args, stream)`:
+
+  chains[k]    block size N = 32, 16, 8, 4 (independent of each other, own prediction / reconstruction planes):
+               luma rough search (67 modes, fused arg-min) -> luma predict -> fused luma TU round trip, then for
+               N >= 8 the co-located chroma blocks (N/2) with the derived mode (search_intra.c:1657): predict U, V ->
+               TU round trip U, V
+  stage_a      deblocking, vertical edges of the band
+  xchg_dbk     halo exchange (rows around the band boundaries + per-4x4 side information)
+  stage_b      deblocking, horizontal edges incl. both boundary edges; SAO statistics / offsets / apply for Y, U, V
+  xchg_alf     halo exchange of SAO output rows                                   (ALF workloads only)
+  stage_c      ALF classification, covariance statistics (+ per-class sums), 7x7 luma and 5x5 chroma filters
+  reduce       all-reduce of the per-class covariance sums (frame-level filter derivation, alf.c:792-835)
+  xchg_gather  every band of the final picture to every rank (the next frame's inter reference)
+
+With nranks == 1 the exchanges are empty and the plan is the whole-frame hot path.  References are open-loop (the
+source picture) -- the closed-loop CU dependency is search control flow, not part of these kernels.
+"""
+import numpy as np
+import torch
+
+from . import api, layout
+from .bands import BandLayout, spec_bytes
+
+SIZES = (32, 16, 8, 4)            # --pu-depth-intra 1-4 (cfg.c:769-801)
+MODES = list(range(67))           # every luma mode; the reference's rough search visits a subset
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: 1920x1080 8-bit all-intra --preset medium (no ALF in medium)
+    "1080p8": dict(W=1920, H=1080, depth=8, alf=False),
+    # BASELINE.json configs[3]: 3840x2160 10-bit --preset medium --alf full
+    "2160p10alf": dict(W=3840, H=2160, depth=10, alf=True),
+    # small pictures for tests
+    "test8": dict(W=328, H=264, depth=8, alf=True),
+    "test10": dict(W=328, H=264, depth=10, alf=True),
+}
+
+
+def chroma_qp(qp):
+    """uvg_get_scaled_qp for chroma with the default (identity below 30) VVC mapping table, QP < 30 only."""
+    assert qp < 30
+    return qp
+
+
+class BandFrame:
+    def __init__(self, L, wl, t, device, modes_dev, rank=0, nranks=1, qp=22, transport=None, poison=False, gather=True):
+        W, H, depth, alf = wl["W"], wl["H"], wl["depth"], wl["alf"]
+        self.W, self.H, self.depth, self.alf, self.qp = W, H, depth, alf, qp
+        self.band = band = BandLayout(H, nranks, rank)
+        self.rank, self.nranks = rank, nranks
+        y0, y1 = band.y0, band.y1
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        P = lambda t_: t_.data_ptr()
+        y, u, v = layout.synthetic_yuv420(W, H, t, depth)
+        self.host = (y, u, v)
+        self.y, self.u, self.v = dev(y), dev(u), dev(v)                    # the source picture (every rank holds all of it)
+        ys, cs = self.y.stride(0), self.u.stride(0)
+        qps = qp + 6 * (depth - 8)                                          # uvg_get_scaled_qp(0, qp, (depth-8)*6, ..) transform.c:150
+        qpc = chroma_qp(qp) + 6 * (depth - 8)
+        nm = modes_dev.shape[0]
+        pz = 0x55 if poison else 0                                          # rows a rank does not own: a value no kernel produces by luck
+
+        def plane(like):
+            return torch.full_like(like, pz) if poison else torch.zeros_like(like)
+
+        # ---- intra search / predict / TU round trip, per block size, for the blocks of the owned rows ----
+        self.tables, self.bufs, self.chains = {}, {}, []
+        self.rec_y = None
+        for n in SIZES:
+            allb = layout.intra_availability(layout.block_grid(W, H, n), n, W, H)
+            own = allb[(allb[:, 1] >= y0) & (allb[:, 1] < y1)]
+            cnt = len(own)
+            blks, tus = api.make_intra_blocks(own, device), api.make_tus(own[:, :2], device)
+            b = {"best": torch.zeros(cnt, dtype=torch.int8, device=device), "cost": torch.zeros(cnt, dtype=torch.int32, device=device),
+                 "pred": plane(self.y), "rec": plane(self.y),
+                 "coeff": torch.zeros((cnt, n, n), dtype=torch.int16, device=device), "has": torch.zeros(cnt, dtype=torch.uint8, device=device)}
+            self.tables[n] = (blks, tus, cnt)
+            chain = [
+                (f"intra_search_{n}", L.uvghip_intra_search_best_batch,
+                 [depth, P(self.y), ys, P(self.y), ys, n, P(blks), cnt, P(modes_dev), nm, P(b["best"]), P(b["cost"]), None]),
+                (f"intra_pred_plane_{n}", L.uvghip_intra_pred_plane_batch,
+                 [depth, P(self.y), ys, n, P(blks), cnt, P(b["best"]), P(b["pred"]), ys]),
+                (f"tu_roundtrip_{n}", L.uvghip_tu_roundtrip_batch,
+                 [depth, 0, 0, 0, 0, n, n, qps, 1, P(self.y), ys, P(b["pred"]), ys, P(b["rec"]), ys, P(tus), cnt, P(b["coeff"]), P(b["has"])]),
+            ]
+            if n >= 8:
+                c = n // 2
+                cown = own // 2                                             # chroma block position and available reference counts
+                cblks, ctus = api.make_intra_blocks(cown, device), api.make_tus(cown[:, :2], device)
+                for name, src in (("u", self.u), ("v", self.v)):
+                    b["pred_" + name], b["rec_" + name] = plane(src), plane(src)
+                    b["coeff_" + name] = torch.zeros((cnt, c, c), dtype=torch.int16, device=device)
+                    b["has_" + name] = torch.zeros(cnt, dtype=torch.uint8, device=device)
+                b["cblks"], b["ctus"] = cblks, ctus
+                for name, src in (("u", self.u), ("v", self.v)):
+                    chain.append((f"intra_pred_chroma_{n}", L.uvghip_intra_pred_plane_chroma_batch,
+                                  [depth, P(src), cs, c, P(cblks), cnt, P(b["best"]), P(b["pred_" + name]), cs]))
+                for name, src in (("u", self.u), ("v", self.v)):
+                    chain.append((f"tu_roundtrip_chroma_{n}", L.uvghip_tu_roundtrip_batch,
+                                  [depth, 0, 0, 0, 0, c, c, qpc, 1, P(src), cs, P(b["pred_" + name]), cs, P(b["rec_" + name]), cs,
+                                   P(ctus), cnt, P(b["coeff_" + name]), P(b["has_" + name])]))
+            self.bufs[n] = b
+            self.chains.append(chain)
+
+        # ---- in-loop filters on the reconstruction of the finest passes (luma 4x4, chroma 4x4 = the N = 8 pass) ----
+        self.rec_y, self.rec_u, self.rec_v = self.bufs[4]["rec"], self.bufs[8]["rec_u"], self.bufs[8]["rec_v"]
+        tab = layout.quadtree_scu_table(W, H, seed=t, qp=qp)
+        if nranks > 1:                                                      # a rank only knows the side information of its own rows
+            keep = np.zeros(tab.shape[0], bool)
+            keep[y0 // 4:(y1 + 3) // 4] = True
+            tab = tab.copy()
+            tab[~keep] = np.zeros((), layout.SCU_DTYPE)
+        self.scu = api.make_scu_table(tab, device)
+        scu_stride = self.scu.shape[1] // 32
+        rects = layout.ctu_rects(W, H)
+        own_r = rects[(rects[:, 1] >= y0) & (rects[:, 1] < y1)]
+        crects = own_r // 2
+        self.n_ctu = n_ctu = len(own_r)
+        self.rects, self.crects = api.make_rects(own_r, device), api.make_rects(crects, device)
+        self.sao_y, self.sao_u, self.sao_v = plane(self.y), plane(self.u), plane(self.v)
+        comp = (("y", self.y, self.rec_y, self.sao_y, self.rects, ys, W, H),
+                ("u", self.u, self.rec_u, self.sao_u, self.crects, cs, W // 2, H // 2),
+                ("v", self.v, self.rec_v, self.sao_v, self.crects, cs, W // 2, H // 2))
+        self.edge = {k: torch.zeros((n_ctu, 4, 2, 5), dtype=torch.int32, device=device) for k in "yuv"}
+        self.bandst = {k: torch.zeros((n_ctu, 2, 32), dtype=torch.int32, device=device) for k in "yuv"}
+        self.params = {k: torch.zeros((n_ctu, 8), dtype=torch.int32, device=device) for k in "yuv"}
+        dbk = [depth, P(self.rec_y), ys, P(self.rec_u), P(self.rec_v), cs, W, H, P(self.scu), scu_stride, 0, 0, 0, qp, None, y0, y1]
+        self.stage_a = [("deblock_v_0", L.uvghip_deblock_band, dbk + [1])]
+        self.stage_b = [("deblock_h_0", L.uvghip_deblock_band, dbk + [2])]
+        for k, org, rec, out, rc, st, pw, ph in comp:
+            self.stage_b.append((f"sao_stats_{k}_0", L.uvghip_sao_stats_batch, [depth, P(org), st, P(rec), st, P(rc), n_ctu, P(self.edge[k]), P(self.bandst[k])]))
+        for k, *_ in comp:
+            self.stage_b.append((f"sao_offsets_{k}_0", L.uvghip_sao_edge_offsets_batch, [P(self.edge[k]), None, n_ctu, P(self.params[k]), None]))
+        for k, org, rec, out, rc, st, pw, ph in comp:
+            self.stage_b.append((f"sao_apply_{k}_0", L.uvghip_sao_apply_batch, [depth, P(rec), st, P(out), st, pw, ph, P(rc), P(self.params[k]), n_ctu]))
+        self.final = (self.sao_y, self.sao_u, self.sao_v)
+        self.stage_c, self.reduce = [], []
+        if alf:
+            # classify the SAO output, gather the per-CTU / class covariances against the source, filter with fixed
+            # coefficient sets (deriving the filters from the covariances is host-side, alf.c:792-835)
+            self.alf_cls = torch.zeros((H // 4, W // 4), dtype=torch.uint8, device=device)
+            self.alf_rec = torch.empty((n_ctu, 25, 1484), dtype=torch.int64, device=device)
+            self.alf_present = torch.zeros(n_ctu, dtype=torch.int32, device=device)
+            self.alf_sums = torch.zeros((25, 1509), dtype=torch.int64, device=device)
+            self.alf_y, self.alf_u, self.alf_v = plane(self.y), plane(self.u), plane(self.v)
+            g = torch.Generator().manual_seed(7)
+            coefs = torch.randint(-8, 9, (1, 25, 13), dtype=torch.int16, generator=g)
+            coefs[:, :, 12] = 0
+            ccoefs = torch.randint(-8, 9, (1, 7), dtype=torch.int16, generator=g)
+            ccoefs[:, 6] = 0
+            self.alf_coefs, self.alf_ccoefs = coefs.to(device), ccoefs.to(device)
+            self.alf_clips = torch.full((1, 25, 13), 1 << depth, dtype=torch.int16, device=device)
+            self.alf_cclips = torch.full((1, 7), 1 << depth, dtype=torch.int16, device=device)
+            self.alf_set = torch.zeros(n_ctu, dtype=torch.int32, device=device)
+            so, cst = self.sao_y, self.alf_cls.stride(0)
+            self.stage_c = [
+                ("alf_classify_0", L.uvghip_alf_classify_band, [depth, P(so), ys, W, H, depth + 4, P(self.alf_cls), cst, y0, y1]),
+                ("alf_stats_0", L.uvghip_alf_stats_compact_batch,
+                 [depth, P(self.y), ys, P(so), ys, W, H, 0, P(self.rects), n_ctu, P(self.alf_cls), cst, P(self.alf_rec), P(self.alf_present)]),
+                ("alf_cov_reduce_0", L.uvghip_alf_cov_reduce, [P(self.alf_rec), P(self.alf_present), n_ctu, 0, P(self.alf_sums)]),
+                ("alf_filter_y_0", L.uvghip_alf_filter_batch,
+                 [depth, P(so), ys, P(self.alf_y), ys, W, H, 0, P(self.rects), P(self.alf_set), n_ctu, P(self.alf_coefs), P(self.alf_clips), P(self.alf_cls), cst]),
+            ]
+            for k, src, dst in (("u", self.sao_u, self.alf_u), ("v", self.sao_v, self.alf_v)):
+                self.stage_c.append((f"alf_filter_{k}_0", L.uvghip_alf_filter_batch,
+                                     [depth, P(src), cs, P(dst), cs, W // 2, H // 2, 1, P(self.crects), P(self.alf_set), n_ctu,
+                                      P(self.alf_ccoefs), P(self.alf_cclips), None, 0]))
+            self.final = (self.alf_y, self.alf_u, self.alf_v)
+
+        # ---- exchanges ----
+        self.spec_dbk = band.halo_deblock(self.rec_y, self.rec_u, self.rec_v, self.scu)
+        self.spec_alf = band.halo_alf(self.sao_y, self.sao_u, self.sao_v) if alf else []
+        self.spec_gather = band.gather(*self.final) if gather else []
+        self.xchg_dbk, self.xchg_alf, self.xchg_gather = [], [], []
+        if transport is not None and nranks > 1:
+            for nm_, spec, dst in (("halo_dbk_0", self.spec_dbk, self.xchg_dbk), ("halo_alf_0", self.spec_alf, self.xchg_alf),
+                                   ("gather_0", self.spec_gather, self.xchg_gather)):
+                if spec:
+                    fn, args = transport.launch_args(spec)
+                    dst.append((nm_, fn, args))
+            if alf:
+                fn, args = transport.allreduce_args(self.alf_sums)
+                self.reduce.append(("allreduce_cov_0", fn, args))
+
+    # -- what one step moves over xGMI for this rank --
+    def comm_bytes(self):
+        out = {"halo_deblock": spec_bytes(self.spec_dbk), "halo_alf": spec_bytes(self.spec_alf), "gather": spec_bytes(self.spec_gather)}
+        out["allreduce_cov"] = (self.alf_sums.numel() * 8,) * 2 if (self.alf and self.nranks > 1) else (0, 0)
+        return out
+
+    def filter_launches(self):
+        """The in-loop filter part in order, exchanges included."""
+        return (self.stage_a + self.xchg_dbk + self.stage_b + self.xchg_alf + self.stage_c + self.reduce + self.xchg_gather)
+
+    def all_launches(self):
+        return [l for c in self.chains for l in c] + self.filter_launches()
+
+
+def run(launches, stream_handle, L=None):
+    """Issue a list of launches on one stream."""
+    from . import lib as _lib
+    for name, fn, args in launches:
+        rc = fn(*args, stream_handle)
+        if rc != 0:
+            raise RuntimeError(f"{name} failed ({rc}): {_lib.load_library().uvghip_last_error().decode()}")
+
+
+class Graph:
+    """A list of launches captured once into a hipGraph (uvghip_graph_*) and replayed with one call."""
+
+    def __init__(self, L, launches, capture_stream):
+        import ctypes
+        from . import lib as _lib
+        self.L, self.names = L, [l[0] for l in launches]
+        self.handle = ctypes.c_void_p()
+        h = capture_stream.cuda_stream
+        _lib.check(L.uvghip_graph_begin(h), "uvghip_graph_begin")
+        try:
+            run(launches, h)
+        finally:
+            rc = L.uvghip_graph_end(h, ctypes.byref(self.handle))
+        _lib.check(rc, "uvghip_graph_end")
+
+    def launch(self, stream_handle):
+        rc = self.L.uvghip_graph_launch(self.handle, stream_handle)
+        if rc != 0:
+            from . import lib as _lib
+            _lib.check(rc, "uvghip_graph_launch")
+
+    def destroy(self):
+        if self.handle:
+            self.L.uvghip_graph_destroy(self.handle)
+            self.handle = None
