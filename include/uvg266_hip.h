@@ -80,7 +80,7 @@ UVGHIP_API int uvg_strategy_register_dct_hip(void *opaque, uint8_t bitdepth);   
 UVGHIP_API int uvg_strategy_register_intra_hip(void *opaque, uint8_t bitdepth);   /* strategies-intra.h:81-103 */
 UVGHIP_API int uvg_strategy_register_sao_hip(void *opaque, uint8_t bitdepth);     /* strategies-sao.h:66-82    */
 UVGHIP_API int uvg_strategy_register_quant_hip(void *opaque, uint8_t bitdepth);   /* strategies-quant.h:93-111 (state-free functions only) */
-UVGHIP_API int uvg_strategy_register_ipol_hip(void *opaque, uint8_t bitdepth);    /* strategies-ipol.h:116-139 (all but get_extended_block*) */
+UVGHIP_API int uvg_strategy_register_ipol_hip(void *opaque, uint8_t bitdepth);    /* strategies-ipol.h:116-139 (all ten) */
 
 /* -------------------------------------------- (2) batched ABI: picture -- */
 
@@ -283,6 +283,15 @@ typedef struct uvghip_mc_blk {
  * width*height; pixels when hi == 0, int16 14-bit intermediates when hi != 0. */
 UVGHIP_API int uvghip_mc_batch(int bitdepth, const void *ref, int ref_stride, int pic_w, int pic_h, int is_chroma,
                     int width, int height, const uvghip_mc_blk_t *blks, int n, int hi, void *dst, void *stream);
+
+/* replaces: uvg_get_extended_block / uvg_get_extended_block_wraparound (ipol-generic.c:761-883; callers inter.c:103-232,
+ * search_inter.c:1106, image.c:541) for n blocks of one shape at pos[i] = (blk_x, blk_y): dst[i] = (pad_t + blk_h + pad_b +
+ * pad_b_simd) rows of (pad_l + blk_w + pad_r) samples -- rows clamped to the picture, columns edge-replicated
+ * (wraparound = 0) or taken modulo the picture width (wraparound = 1, 360-degree content), the pad_b_simd rows zero.
+ * A device batch always copies; the "block is inside, hand out a pointer" shortcut belongs to the per-call pointer. */
+UVGHIP_API int uvghip_extended_block_batch(int bitdepth, const void *src, int src_stride, int src_w, int src_h, int wraparound,
+                                int blk_w, int blk_h, int pad_l, int pad_r, int pad_t, int pad_b, int pad_b_simd,
+                                const uvghip_tu_t *pos, int n, void *dst, void *stream);
 
 /* replaces: one or more steps of search_frac (src/search_inter.c:1029-1216):
  * uvg_filter_{hpel,qpel}_blocks_{hor_ver,diag}_luma + uvg_satd_any_size_quad.

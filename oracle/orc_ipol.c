@@ -70,3 +70,41 @@ ORC_EXPORT void ORC_FN(frac_satd)(const orc_px *cur, int cur_stride, int cx, int
     costs[c] = ORC_FN(satd_any_size)(w, h, cur + (size_t)cy * cur_stride + cx, cur_stride, pred, w);
   }
 }
+
+/*
+ * uvg_get_extended_block_generic / _wraparound_generic (ipol-generic.c:761-883) with the uvg_epol_args fields as plain
+ * arguments.  Returns 1 when the block + padding lies inside the picture: the reference then hands out pointers into the
+ * source (*ext_off = offset of the padded top-left in src, *ext_s = src_s) and `buf` is not touched.  Otherwise 0:
+ * buf = (pad_t + blk_h + pad_b + pad_b_simd) rows of pad_l + blk_w + pad_r samples, edge-replicated (or taken modulo the
+ * picture width for the wrap-around variant; rows are clamped in both), the pad_b_simd rows zeroed.
+ */
+ORC_EXPORT int ORC_FN(get_extended_block)(int wrap, const orc_px *src, int src_w, int src_h, int src_s, int blk_x, int blk_y,
+                                          int blk_w, int blk_h, int pad_l, int pad_r, int pad_t, int pad_b, int pad_b_simd,
+                                          orc_px *buf, long *ext_off, int *ext_s)
+{
+  const int min_y = blk_y - pad_t, max_y = blk_y + blk_h + pad_b + pad_b_simd - 1;
+  const int min_x = blk_x - pad_l;
+  const int max_x = blk_x + blk_w + pad_r - (wrap ? 0 : 1);       /* :765 vs :823: the wrap-around variant's max_x is exclusive */
+  const int oob = min_y < 0 || max_y >= src_h || min_x < 0 || max_x >= src_w;
+  if (!oob) {
+    *ext_off = (long)(blk_y - pad_t) * src_s + (blk_x - pad_l);
+    *ext_s = src_s;
+    return 1;
+  }
+  const int es = pad_l + blk_w + pad_r;
+  *ext_off = 0;
+  *ext_s = es;
+  int y;
+  for (y = -pad_t; y < blk_h + pad_b; ++y) {
+    const orc_px *row = src + (size_t)orc_clip3(0, src_h - 1, blk_y + y) * src_s;
+    orc_px *dst = buf + (size_t)(y + pad_t) * es;
+    for (int i = 0; i < es; ++i) {
+      int x = min_x + i;
+      if (wrap) { if (x < 0) x += src_w; else if (x >= src_w) x -= src_w; }     /* :836-855: two memcpy pieces */
+      else x = orc_clip3(0, src_w - 1, x);                                     /* :780-795: left / middle / right runs */
+      dst[i] = row[x];
+    }
+  }
+  for (int k = 0; k < pad_b_simd; ++k) memset(buf + (size_t)(y + pad_t + k) * es, 0, sizeof(orc_px) * es);
+  return 0;
+}

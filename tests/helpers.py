@@ -145,6 +145,14 @@ class Oracle:
         return has, coeff, rec
 
 
+    def get_extended_block(self, d, wrap, src, src_w, src_h, bx, by, bw, bh, pl, pr, pt, pb, pbs):
+        """-> (inside, ext_off, ext_s, buf)"""
+        buf = np.full((pt + bh + pb + pbs) * (pl + bw + pr), 0x5a, src.dtype)
+        off, es = ctypes.c_long(), ctypes.c_int()
+        inside = self.fn(d, "get_extended_block")(int(wrap), ptr(src), src_w, src_h, src.shape[1], bx, by, bw, bh, pl, pr, pt, pb, pbs,
+                                                  ptr(buf), ctypes.byref(off), ctypes.byref(es))
+        return inside, off.value, es.value, buf
+
     # ---- intra -------------------------------------------------------------
     REF_LEN = 400
 

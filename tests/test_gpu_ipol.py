@@ -179,3 +179,69 @@ def test_registered_fme_blocks_vs_reference_costs(hip, orc, depth):
                 assert orc.satd_any_size(depth, w, h, cur, 64, np.ascontiguousarray(blk), 64) == costs[step * 4 + j]
         seen += 1
     assert seen >= 6
+
+
+class _Epol(__import__("ctypes").Structure):
+    """uvg_epol_args (strategies-ipol.h:67-92)."""
+    import ctypes as _c
+    _fields_ = [("src", _c.c_void_p), ("src_w", _c.c_int), ("src_h", _c.c_int), ("src_s", _c.c_int),
+                ("blk_x", _c.c_int), ("blk_y", _c.c_int), ("blk_w", _c.c_int), ("blk_h", _c.c_int),
+                ("pad_l", _c.c_int), ("pad_r", _c.c_int), ("pad_t", _c.c_int), ("pad_b", _c.c_int), ("pad_b_simd", _c.c_int),
+                ("buf", _c.c_void_p), ("ext", _c.c_void_p), ("ext_origin", _c.c_void_p), ("ext_s", _c.c_void_p)]
+
+
+def _ext_cases(rng, PW, PH):
+    """Block positions around every border and corner, far outside, and inside; the pads of the reference's callers
+    (inter.c:90-100: filter taps; search_inter.c:1085-1100: +1 ME border; image.c:530)."""
+    pads = [(3, 4, 3, 4, 0), (4, 4, 4, 4, 0), (1, 2, 1, 2, 5), (0, 0, 0, 0, 0), (3, 4, 3, 4, 3)]
+    xs = [-40, -9, -3, 0, 5, PW // 2, PW - 20, PW - 8, PW - 3, PW + 6]
+    ys = [-30, -4, 0, 7, PH // 2, PH - 16, PH - 5, PH + 3]
+    for k in range(60):
+        yield (int(rng.choice(xs)), int(rng.choice(ys)), int(rng.choice([4, 8, 16, 32])), int(rng.choice([4, 8, 16, 64])), pads[k % len(pads)])
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("wrap", [0, 1])
+def test_extended_block_batch_and_registered_pointers(hip, orc, depth, wrap):
+    """uvg_get_extended_block(_wraparound): the batched copy and the registered per-call pointers vs the oracle's
+    restatement of ipol-generic.c:761-883, including the 'inside: pointers into the frame' shortcut."""
+    import ctypes
+    import torch
+    from uvg266_amd import lib
+    reg = _ipol_registry(hip, depth)
+    f = ctypes.CFUNCTYPE(None, ctypes.c_void_p)(reg.table["get_extended_block_wraparound" if wrap else "get_extended_block"])
+    rng = np.random.default_rng(7 + depth + wrap)
+    PH, PW, S = 70, 96, 104
+    plane = rand_plane(rng, PH, S, depth)
+    dplane = dev(plane)
+    es = plane.itemsize
+    st = torch.cuda.current_stream().cuda_stream
+    n_in = n_out = 0
+    for bx, by, bw, bh, (pl, pr, pt, pb, pbs) in _ext_cases(rng, PW, PH):
+        if wrap and (bx - pl < -PW or bx + bw + pr > 2 * PW):
+            continue
+        inside, off, s_want, buf_want = orc.get_extended_block(depth, wrap, plane, PW, PH, bx, by, bw, bh, pl, pr, pt, pb, pbs)
+        rows, wdt = pt + bh + pb + pbs, pl + bw + pr
+        # per-call pointer
+        buf = np.full(rows * wdt, 0x5a, plane.dtype)
+        ext, org, ext_s = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int()
+        a = _Epol(plane.ctypes.data, PW, PH, S, bx, by, bw, bh, pl, pr, pt, pb, pbs, buf.ctypes.data,
+                  ctypes.addressof(ext), ctypes.addressof(org), ctypes.addressof(ext_s))
+        f(ctypes.addressof(a))
+        if inside:
+            n_in += 1
+            assert ext.value == plane.ctypes.data + off * es and ext_s.value == S == s_want
+            assert org.value == plane.ctypes.data + (by * S + bx) * es
+            assert np.all(buf == 0x5a)
+        else:
+            n_out += 1
+            assert ext.value == buf.ctypes.data and ext_s.value == wdt == s_want
+            assert org.value == buf.ctypes.data + (pt * wdt + pl) * es
+            assert np.array_equal(buf, buf_want), (bx, by, bw, bh, pl, pr, pt, pb, pbs)
+            # batched entry point: always the copy
+            pos = torch.tensor([[bx, by], [bx, by]], dtype=torch.int32, device="cuda")
+            out = torch.full((2, rows, wdt), 0x33, dtype=dplane.dtype, device="cuda")
+            lib.check(hip.uvghip_extended_block_batch(depth, dplane.data_ptr(), S, PW, PH, wrap, bw, bh, pl, pr, pt, pb, pbs,
+                                                      pos.data_ptr(), 2, out.data_ptr(), st), "ext batch")
+            assert np.array_equal(out[1].cpu().numpy().ravel(), buf_want)
+    assert n_in >= 3 and n_out >= 25

@@ -28,7 +28,26 @@ def test_vs_reference_goldens(hip, depth):
             params = api.make_sao_params([[typ, eo, bp[1 if is_v else 0], *o]])
             # torch slices keep the parent storage: pass the offset view directly
             api.sao_apply_batch(rec, out, api.make_rects([[fx, fy, w, h]]), params, pw, ph)
-            assert np.array_equal(out.cpu().numpy().ravel(), want)
+            # The reference writes only the samples it filters (the golden keeps the 0x55 fill elsewhere); the kernel
+            # also copies rec into the rest of the rectangle: type 0, and for edge classes the picture's outermost
+            # row / column on the sides the class looks at (sao.c:321-348).
+            fx, fy, w, h = int(fx), int(fy), int(w), int(h)
+            got = out.cpu().numpy()
+            expect = want.reshape(ph, ps).copy()
+            recn = plane.reshape(ph + 1, ps)[1:]
+            skip = np.zeros((ph, ps), bool)
+            if typ == 0:
+                skip[fy:fy + h, fx:fx + w] = True
+            elif typ == 2:
+                ofs = {0: (-1, 0, 1, 0), 1: (0, -1, 0, 1), 2: (-1, -1, 1, 1), 3: (1, -1, -1, 1)}[int(eo)]
+                ax, ay, bx, by = ofs
+                if min(ax, bx) < 0 and fx == 0: skip[fy:fy + h, 0] = True
+                if max(ax, bx) > 0 and fx + w == pw: skip[fy:fy + h, pw - 1] = True
+                if min(ay, by) < 0 and fy == 0: skip[0, fx:fx + w] = True
+                if max(ay, by) > 0 and fy + h == ph: skip[ph - 1, fx:fx + w] = True
+            assert (expect[skip] == 0x55).all()                 # the reference left exactly these alone
+            expect[skip] = recn[skip]
+            assert np.array_equal(got, expect)
             nr += 1
         elif name == "stats":
             (PW, PH), po, pr, rects, edge, band = arrs

@@ -16,6 +16,7 @@
 #include <type_traits>
 #include "uvghip_common.h"
 #include "percall.h"
+#include "ref_abi.h"
 #include "satd_dev.h"
 #include "satd_tile_dev.h"
 #include "vvc_tables.h"
@@ -308,6 +309,48 @@ extern "C" int uvghip_bipred_average_batch(int bitdepth, const void *l0, const v
   UVGHIP_CHECK_LAUNCH();
 }
 
+// ---------------------------------------------------------------- extended blocks ----
+// uvg_get_extended_block(_wraparound) (ipol-generic.c:761-883) for n blocks at once: always the copy (a device batch
+// has no use for "pointer into the frame"), rows clamped to the picture, columns edge-replicated or -- wrap-around
+// variant, :836-855 -- taken modulo the picture width; the pad_b_simd rows are zeroed like the reference's.
+template <typename PX>
+__global__ void __launch_bounds__(256)
+ext_block_kernel(const PX *__restrict__ src, int stride, int src_w, int src_h, int wrap, int blk_h, int pad_l, int pad_t,
+                 int pad_b, int es, int rows_total, const uvghip_tu_t *__restrict__ pos, PX *__restrict__ dst)
+{
+  const uvghip_tu_t b = pos[blockIdx.x];
+  PX *out = dst + (size_t)blockIdx.x * rows_total * es;
+  const int live_rows = pad_t + blk_h + pad_b;
+  for (int i = threadIdx.x; i < rows_total * es; i += blockDim.x) {
+    const int yy = i / es, xx = i - yy * es;
+    PX v = 0;
+    if (yy < live_rows) {
+      const int y = clampi(b.y - pad_t + yy, 0, src_h - 1);
+      int x = b.x - pad_l + xx;
+      if (wrap) { if (x < 0) x += src_w; else if (x >= src_w) x -= src_w; }
+      else x = clampi(x, 0, src_w - 1);
+      v = src[(size_t)y * stride + x];
+    }
+    out[i] = v;
+  }
+}
+
+extern "C" int uvghip_extended_block_batch(int bitdepth, const void *src, int src_stride, int src_w, int src_h, int wraparound,
+                                           int blk_w, int blk_h, int pad_l, int pad_r, int pad_t, int pad_b, int pad_b_simd,
+                                           const uvghip_tu_t *pos, int n, void *dst, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if ((bitdepth != 8 && bitdepth != 10) || blk_w <= 0 || blk_h <= 0 || pad_l < 0 || pad_r < 0 || pad_t < 0 || pad_b < 0 ||
+      pad_b_simd < 0 || src_w <= 0 || src_h <= 0)
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (n <= 0) return 0;
+  const int es = pad_l + blk_w + pad_r, rows = pad_t + blk_h + pad_b + pad_b_simd;
+  hipStream_t st = uvghip_stream(stream);
+  if (bitdepth == 8) ext_block_kernel<uint8_t><<<n, 256, 0, st>>>((const uint8_t *)src, src_stride, src_w, src_h, wraparound, blk_h, pad_l, pad_t, pad_b, es, rows, pos, (uint8_t *)dst);
+  else ext_block_kernel<uint16_t><<<n, 256, 0, st>>>((const uint16_t *)src, src_stride, src_w, src_h, wraparound, blk_h, pad_l, pad_t, pad_b, es, rows, pos, (uint16_t *)dst);
+  UVGHIP_CHECK_LAUNCH();
+}
+
 // ------------------------------------------------ drop-in "ipol" strategy functions (host buffers) ----
 // The ipol typedefs (strategies-ipol.h:62-114) take `const encoder_control_t *` first, but the generic
 // implementations never read it (ipol-generic.c:134-758: bit depth is the compile-time UVG_BIT_DEPTH), so
@@ -376,6 +419,43 @@ void fme_blocks_hip(const void *, PX *src, int16_t src_stride, int width, int he
       memcpy(filtered[j] + (size_t)y * FME_STRIDE, c->hp<PX>(oo) + ((size_t)j * height + y) * width, (size_t)width * sizeof(PX));
 }
 
+// get_extended_block / get_extended_block_wraparound (strategies-ipol.h:67-94, ipol-generic.c:761-883).  Inside the
+// picture the reference returns pointers into the caller's frame -- pure pointer arithmetic, done here exactly so.
+// Otherwise the rows the block can reach (clamped) are staged, the copy is built on the device and lands in args->buf.
+static inline int ext_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+template <typename PX, int WRAP>
+void get_extended_block_hip(ref_epol_args<PX> *a)
+{
+  const int min_y = a->blk_y - a->pad_t, max_y = a->blk_y + a->blk_h + a->pad_b + a->pad_b_simd - 1;
+  const int min_x = a->blk_x - a->pad_l, max_x = a->blk_x + a->blk_w + a->pad_r - (WRAP ? 0 : 1);
+  if (!(min_y < 0 || max_y >= a->src_h || min_x < 0 || max_x >= a->src_w)) {
+    *a->ext = a->src + (ptrdiff_t)(a->blk_y - a->pad_t) * a->src_s + (a->blk_x - a->pad_l);
+    *a->ext_origin = a->src + (ptrdiff_t)a->blk_y * a->src_s + a->blk_x;
+    *a->ext_s = a->src_s;
+    return;
+  }
+  const int es = a->pad_l + a->blk_w + a->pad_r, rows = a->pad_t + a->blk_h + a->pad_b + a->pad_b_simd;
+  // stage the source rows the block touches after clamping (whole rows: the wrap-around variant reads both ends)
+  const int y_lo = ext_clamp(min_y, 0, a->src_h - 1), y_hi = ext_clamp(a->blk_y + a->blk_h + a->pad_b - 1, 0, a->src_h - 1);
+  const int nrows = y_hi - y_lo + 1;
+  percall_ctx *c = percall_get((size_t)nrows * a->src_w * sizeof(PX) + (size_t)rows * es * sizeof(PX) + 2048);
+  const size_t os = c->stage_block(a->src + (ptrdiff_t)y_lo * a->src_s, (size_t)a->src_s, a->src_w, nrows, sizeof(PX));
+  const size_t op = c->take(sizeof(uvghip_tu_t));
+  *c->hp<uvghip_tu_t>(op) = uvghip_tu_t{a->blk_x, a->blk_y - y_lo};
+  c->upload(0, c->used);
+  const size_t oo = c->take((size_t)rows * es * sizeof(PX));
+  // the staged slab is a picture of nrows rows whose row 0 is picture row y_lo: clamping to it equals clamping to the picture
+  c->must(uvghip_extended_block_batch(px_traits<PX>::depth, c->dp<PX>(os), a->src_w, a->src_w, nrows, WRAP, a->blk_w, a->blk_h,
+                                      a->pad_l, a->pad_r, a->pad_t, a->pad_b, a->pad_b_simd, c->dp<uvghip_tu_t>(op), 1,
+                                      c->dp<PX>(oo), c->stream), "extended block");
+  c->download(oo, (size_t)rows * es * sizeof(PX));
+  c->sync();
+  memcpy(a->buf, c->hp<PX>(oo), (size_t)rows * es * sizeof(PX));
+  *a->ext = a->buf;
+  *a->ext_s = es;
+  *a->ext_origin = a->buf + (ptrdiff_t)a->pad_t * es + a->pad_l;
+}
+
 template <typename PX>
 int register_ipol(void *opaque)
 {
@@ -389,14 +469,14 @@ int register_ipol(void *opaque)
   REG("sample_octpel_chroma", (&sample_hip<PX, 4, false>));
   REG("sample_quarterpel_luma_hi", (&sample_hip<PX, 8, true>));
   REG("sample_octpel_chroma_hi", (&sample_hip<PX, 4, true>));
+  REG("get_extended_block", (&get_extended_block_hip<PX, 0>));
+  REG("get_extended_block_wraparound", (&get_extended_block_hip<PX, 1>));
 #undef REG
   return ok;
 }
 
 }  // namespace
 
-// Not registered: get_extended_block(_wraparound) -- pure host pointer logic / edge-replicating copy with no
-// arithmetic (ipol-generic.c:761-883); the batched kernels clamp coordinates instead.
 extern "C" int uvg_strategy_register_ipol_hip(void *opaque, uint8_t bitdepth)
 {
   if (!uvghip_ready() && uvghip_init(0) != 0) return 0;

@@ -59,3 +59,15 @@ typedef struct ref_sao_info {
   int offsets[10];
 } ref_sao_info;
 static_assert(sizeof(ref_sao_info) == 68, "sao_info_t mirror");
+
+#ifdef __cplusplus
+// uvg_epol_args : src/strategies/strategies-ipol.h:67-92 (PX = uvg_pixel of the build)
+template <typename PX> struct ref_epol_args {
+  PX *src; int src_w, src_h, src_s;
+  int blk_x, blk_y, blk_w, blk_h, pad_l, pad_r, pad_t, pad_b, pad_b_simd;
+  PX *buf;
+  PX **ext, **ext_origin;
+  int *ext_s;
+};
+static_assert(sizeof(ref_epol_args<uint8_t>) == 88, "uvg_epol_args mirror");
+#endif

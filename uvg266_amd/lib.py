@@ -66,6 +66,7 @@ SIGNATURES = {
     "uvghip_intra_pred_plane_chroma_batch": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
     "uvghip_intra_select_best": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvghip_mc_batch": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
+    "uvghip_extended_block_batch": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int] + [c_int] * 7 + [c_vp, c_int, c_vp, c_vp]),
     "uvghip_frac_satd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_bipred_average_batch": (c_int, [c_int, c_vp, c_vp, c_int, ctypes.c_size_t, c_vp, c_vp]),
     "uvg_strategy_register_sao_hip": (c_int, [c_vp, ctypes.c_uint8]),

@@ -103,7 +103,7 @@ class BandFrame:
                                   [depth, 0, 0, 0, 0, c, c, qpc, 1, P(src), cs, P(b["pred_" + name]), cs, P(b["rec_" + name]), cs,
                                    P(ctus), cnt, P(b["coeff_" + name]), P(b["has_" + name])]))
             self.bufs[n] = b
-            self.chains.append(chain)
+            self.chains.append(chain if cnt else [])      # a short last band may hold no block of this size
 
         # ---- in-loop filters on the reconstruction of the finest passes (luma 4x4, chroma 4x4 = the N = 8 pass) ----
         self.rec_y, self.rec_u, self.rec_v = self.bufs[4]["rec"], self.bufs[8]["rec_u"], self.bufs[8]["rec_v"]
