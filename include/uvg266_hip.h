@@ -179,6 +179,43 @@ UVGHIP_API int uvghip_coeff_abs_sum_batch(const int16_t *coeffs, int length, int
 UVGHIP_API int uvghip_fast_coeff_cost_batch(const int16_t *coeffs, int width, int height, int n, uint64_t weights,
                                  uint32_t *out, void *stream);
 
+/* ---- rate-distortion optimised quantisation ---- */
+
+/* Snapshot of the CABAC context models uvg_rdoq prices bins with (state->cabac.ctx, src/cabac.h:60-131), each reduced
+ * to CTX_STATE(ctx) = (ctx->state[0] + ctx->state[1]) >> 8 (cabac.h:175-176) -- all CTX_ENTROPY_BITS (rdo.h:106)
+ * looks at.  [0] = luma, [1] = chroma where the reference keeps separate models (unused tail entries zero).  The
+ * models are read-only during a call, which is what makes the blocks of a batch independent. */
+typedef struct uvghip_rdoq_ctx {
+  uint8_t sig_group[2][2];    /* sig_coeff_group_model[0..1] | [2..3] */
+  uint8_t sig[2][12];         /* cu_sig_model_luma[0][0..11] | cu_sig_model_chroma[0][0..7] */
+  uint8_t par[2][21];         /* cu_parity_flag_model_luma[21] | _chroma[11] */
+  uint8_t gt1[2][21];         /* cu_gtx_flag_model_luma[1][21] | _chroma[1][11] */
+  uint8_t gt2[2][21];         /* cu_gtx_flag_model_luma[0][21] | _chroma[0][11] */
+  uint8_t last_x[2][20];      /* cu_ctx_last_x_luma[20] | _chroma[3] */
+  uint8_t last_y[2][20];      /* cu_ctx_last_y_luma[20] | _chroma[3] */
+  uint8_t cbf_luma[4], cbf_cb[2], cbf_cr[3];   /* qt_cbf_model_luma / _cb / _cr */
+  uint8_t root_cbf;           /* cu_qt_root_cbf_model */
+} uvghip_rdoq_ctx_t;
+
+/* replaces: uvg_rdoq (src/rdo.c:1449-1870; called from uvg_quantize_residual when cfg.rdoq_enable,
+ * quant-generic.c:527-531) for n transformed blocks of one shape: q_coef[i] = the RD-optimal levels of coef[i]
+ * (both n contiguous blocks of width*height int16).  width, height in {4,8,16,32}.  What the reference reads from
+ * encoder_state_t is passed in:
+ *   qp_scaled  = uvg_get_scaled_qp(color, state->qp, (bitdepth-8)*6, qp_map[0])          (src/transform.c:150)
+ *   lambda     = color ? state->c_lambda : state->lambda
+ *   ctx_host   = the context snapshot above (HOST pointer, copied into the launch)
+ *   block_type = cu_type_t (1 intra), cbf_u = cbf_is_set(cbf, COLOR_U) (only read for color 2),
+ *   lfnst_idx / mts_idx as the reference's arguments.
+ * Scaling lists and sign-data hiding off (as in every preset of the target configs); diagonal scan.
+ * workspace: device memory of at least uvghip_rdoq_workspace_bytes(width, height, n) bytes (the per-position cost
+ * arrays the last-position search re-reads).  abs_sum_out[i] (may be NULL) = sum of |level|; has_coeffs[i] (may be
+ * NULL) = any level != 0.  Costs are IEEE doubles in the reference's operation order: levels are bit-exact. */
+UVGHIP_API size_t uvghip_rdoq_workspace_bytes(int width, int height, int n);
+UVGHIP_API int uvghip_rdoq_batch(int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n, int color,
+                      int block_type, int cbf_u, int lfnst_idx, int mts_idx, int qp_scaled, double lambda,
+                      const uvghip_rdoq_ctx_t *ctx_host, void *workspace, size_t workspace_bytes,
+                      uint32_t *abs_sum_out, uint8_t *has_coeffs, void *stream);
+
 /* top-left corner of a transform unit inside the planes */
 typedef struct uvghip_tu {
   int32_t x, y;

@@ -145,6 +145,17 @@ class Oracle:
         return has, coeff, rec
 
 
+    # ---- RDOQ ----------------------------------------------------------------
+    RDOQ_CTX_BYTES = 244
+
+    def rdoq(self, d, coef, w, h, color, block_type, cbf_u, lfnst, mts, qp_scaled, lam, ctx):
+        """-> (levels (h*w,) int16, abs_sum).  ctx: 244 uint8 = uvghip_rdoq_ctx_t."""
+        assert ctx.dtype == np.uint8 and ctx.size == self.RDOQ_CTX_BYTES
+        out = np.full(w * h, 0x33, np.int16)
+        s = self.fn(d, "rdoq")(ptr(np.ascontiguousarray(coef, np.int16)), ptr(out), w, h, color, block_type, cbf_u, lfnst, mts, qp_scaled,
+                               ctypes.c_double(lam), ptr(ctx))
+        return out, s
+
     def get_extended_block(self, d, wrap, src, src_w, src_h, bx, by, bw, bh, pl, pr, pt, pb, pbs):
         """-> (inside, ext_off, ext_s, buf)"""
         buf = np.full((pt + bh + pb + pbs) * (pl + bw + pr), 0x5a, src.dtype)

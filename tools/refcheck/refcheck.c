@@ -50,6 +50,7 @@ void check(const char *what, int ok)
 void check_picture(void);
 void check_dct(void);
 void check_quant(void);
+void check_rdoq(void);
 void check_intra(void);
 void check_ipol(void);
 void check_sao(void);
@@ -94,6 +95,9 @@ int main(int argc, char **argv)
   check_mip();
   check_dcfilt();
 #endif
+#ifdef HAVE_QUANT
+  check_rdoq();      /* last: the earlier groups keep their random streams, hence their committed goldens */
+#endif
   if (g_out) fclose(g_out);
   printf("refcheck %d-bit: %s (%d mismatches)\n", UVG_BIT_DEPTH, g_fail ? "FAIL" : "OK", g_fail);
   return g_fail ? 1 : 0;
@@ -105,6 +109,7 @@ int main(int argc, char **argv)
 #endif
 #ifdef HAVE_QUANT
 #include "rc_quant.inc"
+#include "rc_rdoq.inc"
 #endif
 #ifdef HAVE_INTRA
 #include "rc_intra.inc"

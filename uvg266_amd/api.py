@@ -426,3 +426,23 @@ def alf_stats_batch(org, rec, rects, cls=None, is_chroma=False, pic_w=None, pic_
                                         0 if cls is None else cls.stride(0), _dev(ee), _dev(yv), _dev(pa), _stream()),
                "uvghip_alf_stats_batch")
     return ee, yv, pa
+
+
+# ---- RDOQ ---------------------------------------------------------------------------
+def rdoq_batch(coef, bitdepth, color, block_type, cbf_u, lfnst_idx, mts_idx, qp_scaled, lam, ctx, workspace=None):
+    """coef (n, h, w) int16 transformed blocks -> (levels (n, h, w) int16, abs_sum (n,) int32, has_coeffs (n,) uint8).
+    ctx: 244 bytes (numpy uint8 or bytes) = uvghip_rdoq_ctx_t, a host-side snapshot."""
+    import ctypes
+    L = _lib.init(coef.device.index or 0)
+    n, h, w = coef.shape
+    out = torch.empty_like(coef)
+    abs_sum = torch.empty(n, dtype=torch.int32, device=coef.device)
+    has = torch.empty(n, dtype=torch.uint8, device=coef.device)
+    need = L.uvghip_rdoq_workspace_bytes(w, h, n)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty((need + 7) // 8, dtype=torch.float64, device=coef.device)
+    cbuf = (ctypes.c_uint8 * 244).from_buffer_copy(bytes(np.asarray(ctx, np.uint8).tobytes()))
+    _lib.check(L.uvghip_rdoq_batch(bitdepth, _dev(coef), _dev(out), w, h, n, color, block_type, cbf_u, lfnst_idx, mts_idx, qp_scaled,
+                                   float(lam), ctypes.cast(cbuf, ctypes.c_void_p), _dev(workspace), workspace.numel() * 8,
+                                   _dev(abs_sum), _dev(has), _stream()), "uvghip_rdoq_batch")
+    return out, abs_sum, has

@@ -56,6 +56,8 @@ SIGNATURES = {
     "uvghip_dequant_batch": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "uvghip_coeff_abs_sum_batch": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "uvghip_fast_coeff_cost_batch": (c_int, [c_vp, c_int, c_int, c_int, ctypes.c_uint64, c_vp, c_vp]),
+    "uvghip_rdoq_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
+    "uvghip_rdoq_batch": (c_int, [c_int, c_vp, c_vp] + [c_int] * 9 + [ctypes.c_double, c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp, c_vp]),
     "uvghip_tu_roundtrip_batch": (c_int, [c_int] * 9 + [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvg_strategy_register_intra_hip": (c_int, [c_vp, ctypes.c_uint8]),
     "uvghip_intra_pred_batch": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
