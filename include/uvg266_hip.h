@@ -168,6 +168,13 @@ UVGHIP_API int uvghip_mts_select(int width, int height, int color, int cu_type, 
 UVGHIP_API int uvghip_quant_batch(int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n,
                        int qp_scaled, int transform_skip, int slice_is_intra, void *stream);
 
+/* replaces: uvg_quant with lfnst_idx != 0 (quant-generic.c:101-120): only the first 8 (4x4 / 8x8 blocks) or 16 coefficients
+ * of the diagonal scan are quantised, everything else is zero.  This branch takes its scale from the (flat) encoder
+ * scaling-list array, which has no sqrt(2) variant for blocks with an odd log2 size sum (scalinglist.c:415-417) while
+ * q_bits keeps that adjustment -- reproduced, so that levels equal the reference's. */
+UVGHIP_API int uvghip_quant_lfnst_batch(int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n,
+                             int qp_scaled, int transform_skip, int slice_is_intra, void *stream);
+
 /* replaces: uvg_dequant (quant-generic.c:618-669), no scaling list / dep-quant. */
 UVGHIP_API int uvghip_dequant_batch(int bitdepth, const int16_t *q_coef, int16_t *coef, int width, int height, int n,
                          int qp_scaled, int transform_skip, void *stream);
@@ -233,6 +240,38 @@ UVGHIP_API int uvghip_tu_roundtrip_batch(int bitdepth, int type_hor, int type_ve
                               const void *orig, int orig_stride, const void *pred, int pred_stride,
                               void *rec, int rec_stride, const uvghip_tu_t *tus, int n,
                               int16_t *coeff_out, uint8_t *has_coeffs, void *stream);
+
+/* Everything uvg_quantize_residual reads from its arguments, the CU and the encoder state (quant-generic.c:460-612). */
+typedef struct uvghip_qr_params {
+  int32_t width, height, color;                          /* TU shape; COLOR_Y/U/V = 0/1/2 */
+  int32_t type_hor, type_ver, skip_width, skip_height;   /* uvghip_mts_select for this CU */
+  int32_t qp_scaled, slice_is_intra, cu_type;            /* as uvghip_quant_batch; cu_type = cur_cu->type (1 intra, 2 inter) */
+  int32_t use_trskip;                                    /* transform skip: identity transform + the quantiser's TS shifts */
+  int32_t rdoq_enable, rdoq_skip, dep_quant;             /* cfg.rdoq_enable / cfg.rdoq_skip / cfg.dep_quant (must be 0) */
+  int32_t cbf_u;                                         /* cbf_is_set(cur_cu->cbf, COLOR_U): RDOQ of a V block reads it */
+  int32_t mts_idx;                                       /* cur_cu->tr_idx (passed to RDOQ for luma) */
+  int32_t lfnst_idx;                                     /* lfnst_index as uvg_quant / uvg_rdoq receive it (cur_cu->lfnst_idx, or
+                                                          * cr_lfnst_idx for chroma of a chroma tree; :505): with it != 0 the
+                                                          * quantiser keeps only the first 8 / 16 scan positions (:101-120) even
+                                                          * where the transform itself does not apply */
+  int32_t reserved;
+  double lambda;                                         /* color ? state->c_lambda : state->lambda */
+  uvghip_rdoq_ctx_t ctx;                                 /* state->cabac context snapshot (RDOQ only) */
+} uvghip_qr_params_t;
+
+/* replaces: uvg_quantize_residual (quant-generic.c:460-612) on EVERY branch but dependent quantisation, transform-skip
+ * RDOQ, LMCS chroma scaling and scaling lists -- for n TUs of one shape at tus[i] in three co-located planes:
+ *   residual -> uvg_transform2d or uvg_transformskip -> [uvg_fwd_lfnst] -> uvg_rdoq | uvg_quant -> coeff_out[i], has_coeffs[i]
+ *   -> uvg_dequant -> [uvg_inv_lfnst] -> uvg_itransform2d | uvg_itransformskip -> rec = clip(pred + residual)
+ * as a chain of launches through `workspace` (device, >= uvghip_quantize_residual_workspace_bytes(p, n)).
+ * uvghip_tu_roundtrip_batch is the single-launch form of the plain-quant / no-LFNST branch.  lfnst_tus: device array of
+ * n entries for uvghip_lfnst_batch, or NULL where the LFNST transform does not apply (cfg.lfnst off, inter CU, chroma of
+ * a single tree: uvg_fwd_lfnst, transform.c:988).  p: HOST pointer. */
+UVGHIP_API size_t uvghip_quantize_residual_workspace_bytes(const uvghip_qr_params_t *p, int n);
+UVGHIP_API int uvghip_quantize_residual_batch(int bitdepth, const uvghip_qr_params_t *p, const void *orig, int orig_stride,
+                                   const void *pred, int pred_stride, void *rec, int rec_stride, const uvghip_tu_t *tus,
+                                   int n, const struct uvghip_lfnst_tu *lfnst_tus, int16_t *coeff_out, uint8_t *has_coeffs,
+                                   void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------ (2) batched ABI: intra -------- */
 

@@ -43,7 +43,7 @@ def test_random_batches_vs_oracle(hip, orc, depth):
     cases = [(w, h, 0, 1, 0, 0, 0) for w in (4, 8, 16, 32) for h in (4, 8, 16, 32)]
     cases += [(8, 8, 1, 1, 0, 0, 0), (16, 16, 2, 1, 1, 0, 0), (4, 4, 2, 2, 0, 0, 0), (32, 32, 0, 2, 0, 0, 0), (16, 8, 0, 1, 0, 1, 0),
               (8, 8, 0, 1, 0, 2, 0), (4, 4, 0, 1, 0, 1, 0), (32, 32, 0, 1, 0, 0, 2), (32, 16, 0, 1, 0, 0, 1), (16, 16, 0, 2, 0, 0, 3)]
-    checked = 0
+    checked = total_nz = 0
     for i, (w, h, color, bt, cbf_u, lfnst, mts) in enumerate(cases):
         n = 200 if w * h <= 256 else 70
         qp = int(rng.integers(17, 45))
@@ -63,9 +63,10 @@ def test_random_batches_vs_oracle(hip, orc, depth):
             assert np.array_equal(lv[b].ravel(), want), (w, h, color, bt, lfnst, mts, b)
             assert s[b] == ws and has[b] == int(want.any())
             nz += int(want.any())
-        assert nz > n // 10
-        checked += n
-    assert checked > 3000
+        if i % 5 in (0, 1, 3):
+            assert nz > n // 10
+        checked += n; total_nz += nz
+    assert checked > 3000 and total_nz > 1500
 
 
 def test_workspace_is_required(hip):
@@ -79,3 +80,73 @@ def test_workspace_is_required(hip):
                                None, 0, None, None, None)
     assert rc != 0 and b"workspace" in hip.uvghip_last_error()
     assert hip.uvghip_rdoq_workspace_bytes(8, 8, 4) == (3 * 64 + 64) * 4 * 8
+
+
+def _qr_hip(api, depth, c, ref, pred, tus):
+    """One golden / synthetic case through uvghip_quantize_residual_batch; planes and TU positions given."""
+    import torch
+    w, h, color = c["w"], c["h"], c["color"]
+    idx = c["lfnst"]
+    lf = idx if (c["cu_type"] == 1 and color == 0) else 0
+    hor, ver, sw, sh = api.mts_select(w, h, color, c["cu_type"], 0, idx, 0, 0, 0)
+    rec = torch.full_like(pred, 7 if depth == 8 else 0x0707)
+    n = tus.shape[0]
+    lt = api.make_lfnst_tus([[c["imode"], lf, w.bit_length() - 1, h.bit_length() - 1]] * n) if lf else None
+    coeff, has = api.quantize_residual_batch(ref, pred, rec, tus, w, h, depth, color, hor, ver, sw, sh, c["qps"], bool(c["intra"]), c["cu_type"],
+                                             bool(c["trskip"]), bool(c["rdoq"]), bool(c["rdoq_skip"]), 0, 0, idx, c["lam"], c["ctx"], lt)
+    return coeff, has, rec
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_quantize_residual_branches_vs_reference(hip, depth):
+    """RDOQ / LFNST / transform-skip branches of uvg_quantize_residual through the staged HIP path vs the vectors the
+    reference produced (levels, has_coeffs and the reconstruction)."""
+    from uvg266_amd import api
+    from test_gpu_picture import dev
+    from test_oracle_rdoq import qr_goldens
+    seen = set()
+    for c in qr_goldens(depth):
+        coeff, has, rec = _qr_hip(api, depth, c, dev(c["ref"]), dev(c["pred"]), api.make_tus([[0, 0]]))
+        tag = {k: v for k, v in c.items() if k in ("w", "h", "color", "qps", "intra", "trskip", "rdoq", "rdoq_skip", "lfnst", "imode")}
+        assert int(has[0]) == c["has"] and np.array_equal(coeff.cpu().numpy().ravel(), c["q"]), tag
+        assert np.array_equal(rec.cpu().numpy(), c["rec"]), tag
+        seen.add((c["rdoq"], c["lfnst"] > 0, c["trskip"], c["has"]))
+    assert len(seen) >= 7
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_quantize_residual_batches_vs_oracle(hip, orc, depth):
+    """Many TUs per launch at arbitrary positions of a picture, every branch, vs the oracle composition."""
+    import torch
+    from uvg266_amd import api
+    from test_gpu_picture import dev, rand_plane
+    from test_oracle_rdoq import oracle_quantize_residual
+    rng = np.random.default_rng(depth + 50)
+    PH, PW = 160, 224
+    sc = 1 << (depth - 8)
+    ref = rand_plane(rng, PH, PW, depth)
+    pred = np.clip(ref.astype(np.int32) + rng.integers(-20, 21, ref.shape) * sc, 0, (1 << depth) - 1).astype(ref.dtype)
+    dref, dpred = dev(ref), dev(pred)
+    cases = [dict(w=8, h=8, color=0, cu_type=1, intra=1, trskip=0, rdoq=1, rdoq_skip=0, lfnst=0, imode=0),
+             dict(w=4, h=4, color=0, cu_type=1, intra=1, trskip=0, rdoq=1, rdoq_skip=1, lfnst=0, imode=0),
+             dict(w=16, h=16, color=0, cu_type=1, intra=1, trskip=0, rdoq=1, rdoq_skip=0, lfnst=2, imode=34),
+             dict(w=32, h=8, color=0, cu_type=1, intra=1, trskip=0, rdoq=0, rdoq_skip=0, lfnst=1, imode=50),
+             dict(w=4, h=16, color=0, cu_type=2, intra=0, trskip=1, rdoq=0, rdoq_skip=0, lfnst=0, imode=0),
+             dict(w=32, h=32, color=0, cu_type=2, intra=0, trskip=0, rdoq=1, rdoq_skip=0, lfnst=0, imode=0),
+             dict(w=16, h=8, color=1, cu_type=1, intra=1, trskip=0, rdoq=1, rdoq_skip=0, lfnst=0, imode=0)]
+    for c in cases:
+        w, h = c["w"], c["h"]
+        qp = int(rng.integers(20, 38))
+        c.update(qps=qp + 6 * (depth - 8), lam=0.57 * 2.0 ** ((qp - 12) / 3.0), ctx=rng.integers(0, 256, 244).astype(np.uint8))
+        xy = np.array([[x, y] for y in range(0, PH - h + 1, h) for x in range(0, PW - w + 1, w)], np.int32)
+        xy = xy[rng.permutation(len(xy))[:40]]
+        coeff, has, rec = _qr_hip(api, depth, c, dref, dpred, api.make_tus(xy))
+        coeff, has, rec = coeff.cpu().numpy(), has.cpu().numpy(), rec.cpu().numpy()
+        nz = 0
+        for i, (x, y) in enumerate(xy):
+            cc = dict(c, ref=np.ascontiguousarray(ref[y:y + h, x:x + w]), pred=np.ascontiguousarray(pred[y:y + h, x:x + w]))
+            whas, wq, wrec = oracle_quantize_residual(orc, depth, cc)
+            assert has[i] == whas and np.array_equal(coeff[i].ravel(), wq), (c["w"], c["h"], c["rdoq"], c["lfnst"], c["trskip"], i)
+            assert np.array_equal(rec[y:y + h, x:x + w], wrec[:h, :w])
+            nz += whas
+        assert nz > 5

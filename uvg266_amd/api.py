@@ -446,3 +446,28 @@ def rdoq_batch(coef, bitdepth, color, block_type, cbf_u, lfnst_idx, mts_idx, qp_
                                    float(lam), ctypes.cast(cbuf, ctypes.c_void_p), _dev(workspace), workspace.numel() * 8,
                                    _dev(abs_sum), _dev(has), _stream()), "uvghip_rdoq_batch")
     return out, abs_sum, has
+
+
+def quantize_residual_batch(orig, pred, rec, tus, width, height, bitdepth, color=0, type_hor=0, type_ver=0, skip_w=0, skip_h=0,
+                            qp_scaled=22, slice_is_intra=True, cu_type=1, use_trskip=False, rdoq=False, rdoq_skip=False, cbf_u=0,
+                            mts_idx=0, lfnst_idx=0, lam=0.0, ctx=None, lfnst_tus=None):
+    """uvg_quantize_residual on any branch (staged launches) -> (coeff (n, h, w) int16, has_coeffs (n,) uint8); rec in place."""
+    import ctypes
+    L = _lib.init(orig.device.index or 0)
+    n = tus.shape[0]
+    p = _lib.QrParams()
+    p.width, p.height, p.color = width, height, color
+    p.type_hor, p.type_ver, p.skip_width, p.skip_height = type_hor, type_ver, skip_w, skip_h
+    p.qp_scaled, p.slice_is_intra, p.cu_type, p.use_trskip = qp_scaled, int(slice_is_intra), cu_type, int(use_trskip)
+    p.rdoq_enable, p.rdoq_skip, p.dep_quant, p.cbf_u, p.mts_idx, p.lfnst_idx = int(rdoq), int(rdoq_skip), 0, cbf_u, mts_idx, lfnst_idx
+    p.lambda_ = float(lam)
+    if ctx is not None:
+        ctypes.memmove(p.ctx, np.asarray(ctx, np.uint8).tobytes(), 244)
+    need = L.uvghip_quantize_residual_workspace_bytes(ctypes.byref(p), n)
+    ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=orig.device)
+    coeff = torch.empty((n, height, width), dtype=torch.int16, device=orig.device)
+    has = torch.empty(n, dtype=torch.uint8, device=orig.device)
+    _lib.check(L.uvghip_quantize_residual_batch(bitdepth, ctypes.byref(p), _dev(orig), orig.stride(0), _dev(pred), pred.stride(0), _dev(rec),
+                                                rec.stride(0), _dev(tus), n, None if lfnst_tus is None else _dev(lfnst_tus), _dev(coeff),
+                                                _dev(has), _dev(ws), ws.numel() * 8, _stream()), "uvghip_quantize_residual_batch")
+    return coeff, has

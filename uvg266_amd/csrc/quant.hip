@@ -114,6 +114,50 @@ extern "C" int uvghip_dequant_batch(int bitdepth, const int16_t *q_coef, int16_t
   UVGHIP_CHECK_LAUNCH();
 }
 
+// uvg_quant with lfnst_idx != 0 quantises only the first 8 (4x4 / 8x8 TUs) or 16 coefficients of the scan and zeroes the
+// rest (quant-generic.c:101-120).  Quantisation is element-wise, so masking the quantised block gives the same levels:
+// the first 16 scan positions are the top-left 4x4 group in its up-right diagonal order.
+__global__ void __launch_bounds__(256) lfnst_keep_kernel(int16_t *__restrict__ q, int width, int wh, size_t total, int keep)
+{
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int pos = (int)(i % wh), x = pos % width, y = pos / width;
+  bool kept = false;
+  if (x < 4 && y < 4) {
+    // rank of (x, y) in the 4x4 up-right diagonal order: diagonals d = x + y, each walked from x = 0 (y = d) upwards
+    const int d = x + y;
+    const int before = d <= 3 ? d * (d + 1) / 2 : 16 - (7 - d) * (8 - d) / 2;
+    const int in_diag = d <= 3 ? x : x - (d - 3);
+    kept = before + in_diag < keep;
+  }
+  if (!kept) q[i] = 0;
+}
+
+extern "C" int uvghip_quant_lfnst_batch(int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n,
+                                        int qp_scaled, int transform_skip, int slice_is_intra, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (int rc = check_qargs(bitdepth, width, height, qp_scaled)) return rc;
+  if (width < 4 || height < 4) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (n <= 0) return 0;
+  quant_params q = make_quant_params(bitdepth, width, height, qp_scaled, transform_skip, slice_is_intra);
+  // this branch reads the scaling-list array even with scaling lists off (quant_coeff[n], :113), and the flat encoder lists are
+  // built from uvg_g_quant_scales[0] without the sqrt(2) row ("TODO: the sqrt adjusted lists", scalinglist.c:415-417), while
+  // q_bits keeps the block-size adjustment: reproduced as is
+  {
+    static const int16_t qs0[6] = {26214, 23302, 20560, 18396, 16384, 14564};
+    int qp = qp_scaled;
+    if (transform_skip && qp < 4 + 6 * 2) qp = 4 + 6 * 2;
+    q.scale = qs0[qp % 6];
+  }
+  const size_t total = (size_t)n * width * height;
+  hipStream_t st = uvghip_stream(stream);
+  quant_kernel<<<(unsigned)((total / 4 + 255) / 256 + 1), 256, 0, st>>>(coef, q_coef, total, q, 0);
+  const int keep = ((width == 4 && height == 4) || (width == 8 && height == 8)) ? 8 : 16;
+  lfnst_keep_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(q_coef, width, width * height, total, keep);
+  UVGHIP_CHECK_LAUNCH();
+}
+
 // ---- per-block coefficient sums ------------------------------------------------
 // out[b] = sum |c| (mode 0, coeff_abs_sum) or (sum weights[min(|c|,3)] + 128) >> 8 (mode 1, fast_coeff_cost)
 __global__ void __launch_bounds__(256)
@@ -162,12 +206,17 @@ extern "C" int uvghip_fast_coeff_cost_batch(const int16_t *coeffs, int width, in
 
 // ---- fused TU round trip -----------------------------------------------------------
 
-template <typename PX>
+// MODE 0: the whole round trip.  The staged path (uvghip_quantize_residual_batch: RDOQ, LFNST, transform skip) cuts it
+// at the quantiser: MODE 1 = residual + forward transform, the coefficients (int16, as the reference's coeff_t buffer) go
+// to coeff_out; MODE 2 = coeff_out holds DEQUANTISED coefficients: inverse transform + reconstruction.  trskip replaces
+// the transform passes by the identity (uvg_transformskip / uvg_itransformskip, transform.c:222-247).
+enum { TU_FULL = 0, TU_FWD = 1, TU_INV = 2 };
+template <typename PX, int MODE = TU_FULL>
 __global__ void __launch_bounds__(256)
 tu_roundtrip_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int orig_stride,
                     const PX *__restrict__ pred, int pred_stride, PX *__restrict__ rec, int rec_stride,
                     const uvghip_tu_t *__restrict__ tus, int n, int bpg, int16_t *__restrict__ coeff_out,
-                    uint8_t *__restrict__ has_coeffs)
+                    uint8_t *__restrict__ has_coeffs, int trskip = 0)
 {
   __shared__ __attribute__((aligned(16))) int16_t sA[TR_LINEBUF_ELEMS];
   __shared__ __attribute__((aligned(16))) int16_t sT[TR_LINEBUF_ELEMS];
@@ -183,11 +232,38 @@ tu_roundtrip_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, in
   if (here <= 0) return;
 
   for (int b = threadIdx.x; b < here; b += blockDim.x) { sX[b] = tus[blk0 + b].x; sY[b] = tus[blk0 + b].y; sHas[b] = 0; }
-  tr_stage_matrix(sMf1, P.type_hor, w, false);
-  tr_stage_matrix(sMf2, P.type_ver, h, false);
-  tr_stage_matrix(sMi1, P.type_ver, h, true);
-  tr_stage_matrix(sMi2, P.type_hor, w, true);
+  if (MODE != TU_INV) { tr_stage_matrix(sMf1, P.type_hor, w, false); tr_stage_matrix(sMf2, P.type_ver, h, false); }
+  if (MODE != TU_FWD) { tr_stage_matrix(sMi1, P.type_ver, h, true); tr_stage_matrix(sMi2, P.type_hor, w, true); }
   __syncthreads();
+  int16_t *gco = coeff_out + (size_t)blk0 * wh;
+
+  if constexpr (MODE != TU_FULL) {
+    if (trskip) {                               // identity "transform": residual <-> coefficient, element by element
+      for (int e = threadIdx.x; e < here * wh; e += blockDim.x) {
+        const int b = e / wh, rem = e - b * wh, y = rem / w, x = rem - y * w;
+        const int p = pred[(size_t)(sY[b] + y) * pred_stride + sX[b] + x];
+        if constexpr (MODE == TU_FWD) {
+          const int o = orig[(size_t)(sY[b] + y) * orig_stride + sX[b] + x];
+          gco[e] = (int16_t)(o - p);
+        } else {
+          const int sres = (int)(int16_t)(gco[e] + p);
+          rec[(size_t)(sY[b] + y) * rec_stride + sX[b] + x] = (PX)clampi(sres, 0, px_traits<PX>::maxv);
+        }
+      }
+      return;
+    }
+  }
+  if constexpr (MODE == TU_INV) {
+    // dequantised coefficients -> the inverse line buffer A'[b][i][j] (lines = columns, K = h); prediction for the final add
+    const int pai1_ = tr_pitch(P.i1.K), ai1_blk_ = P.i1.R * pai1_;
+    for (int e = threadIdx.x; e < here * wh; e += blockDim.x) {
+      const int b = e / wh, rem = e - b * wh, y = rem / w, x = rem - y * w;
+      sPred[e] = (int16_t)pred[(size_t)(sY[b] + y) * pred_stride + sX[b] + x];
+      sA[b * ai1_blk_ + x * pai1_ + y] = gco[e];
+    }
+    __syncthreads();
+  }
+  if constexpr (MODE != TU_INV) {
 
   // residual = orig - pred (picture-generic.c:1360), forward line layout A[b][y][x]
   const int paf1 = tr_pitch(P.f1.K), af1_blk = P.f1.R * paf1;
@@ -208,14 +284,17 @@ tu_roundtrip_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, in
   // vertical pass -> coefficient (j,i); quantise; store the level; dequantise into the
   // inverse line buffer A'[b][i][j] (lines = columns, K = h)
   const int pai1 = tr_pitch(P.i1.K), ai1_blk = P.i1.R * pai1;
-  int16_t *gco = coeff_out + (size_t)blk0 * wh;
   tr_run_pass<false>(P.f2, sT, af2_blk, sMf2, true, here, [&](int b, int r, int c, int v) {
+    if constexpr (MODE == TU_FWD) { gco[b * wh + c * w + r] = (int16_t)v; return; }
     const int level = quant_one(v, Q);
     gco[b * wh + c * w + r] = (int16_t)level;
     if (level) sHas[b] = 1;                         // benign race: every writer stores 1
     sA[b * ai1_blk + r * pai1 + c] = (int16_t)dequant_one(level, Q);
   });
+  if constexpr (MODE == TU_FWD) return;
   __syncthreads();
+  }   // MODE != TU_INV
+  const int pai1 = tr_pitch(P.i1.K), ai1_blk = P.i1.R * pai1;
 
   const int pai2 = tr_pitch(P.i2.K), ai2_blk = P.i2.R * pai2;
   tr_run_pass<true>(P.i1, sA, ai1_blk, sMi1, true, here,
@@ -736,6 +815,91 @@ extern "C" int uvghip_tu_roundtrip_batch(int bitdepth, int type_hor, int type_ve
   else
     tu_roundtrip_kernel<uint16_t><<<grid, 256, 0, st>>>(P, Q, (const uint16_t *)orig, orig_stride, (const uint16_t *)pred, pred_stride,
                                                         (uint16_t *)rec, rec_stride, tus, n, bpg, coeff_out, has_coeffs);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// ---- the staged round trip: every branch of uvg_quantize_residual (quant-generic.c:460-612) ----
+__global__ void __launch_bounds__(256) has_coeffs_kernel(const int16_t *__restrict__ q, int len, int n, uint8_t *__restrict__ has)
+{
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= n) return;
+  int any = 0;
+  for (int i = lane; i < len; i += 64) any |= q[(size_t)b * len + i];
+  any = __any(any != 0);
+  if (lane == 0) has[b] = any ? 1 : 0;
+}
+
+int uvghip_rdoq_launch_checked(int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n, int color, int block_type,
+                               int cbf_u, int lfnst_idx, int mts_idx, int qp_scaled, double lambda, const uvghip_rdoq_ctx_t *ctx_host,
+                               void *workspace, size_t workspace_bytes, uint8_t *has_coeffs, void *stream)
+{
+  return uvghip_rdoq_batch(bitdepth, coef, q_coef, width, height, n, color, block_type, cbf_u, lfnst_idx, mts_idx, qp_scaled, lambda, ctx_host,
+                           workspace, workspace_bytes, nullptr, has_coeffs, stream);
+}
+
+static size_t qr_coef_bytes(int width, int height, int n) { return (((size_t)width * height * n * sizeof(int16_t)) + 255) & ~(size_t)255; }
+
+extern "C" size_t uvghip_quantize_residual_workspace_bytes(const uvghip_qr_params_t *p, int n)
+{
+  if (!p || n <= 0) return 0;
+  const bool rdoq = p->rdoq_enable && (p->width > 4 || !p->rdoq_skip) && !p->use_trskip;
+  return 2 * qr_coef_bytes(p->width, p->height, n) + (rdoq ? uvghip_rdoq_workspace_bytes(p->width, p->height, n) : 0);
+}
+
+extern "C" int uvghip_quantize_residual_batch(int bitdepth, const uvghip_qr_params_t *p, const void *orig, int orig_stride,
+                                              const void *pred, int pred_stride, void *rec, int rec_stride, const uvghip_tu_t *tus,
+                                              int n, const uvghip_lfnst_tu_t *lfnst_tus, int16_t *coeff_out, uint8_t *has_coeffs,
+                                              void *workspace, size_t workspace_bytes, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!p) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const int width = p->width, height = p->height;
+  if (!tr_valid_dim(width) || !tr_valid_dim(height) || p->type_hor < 0 || p->type_hor > 2 || p->type_ver < 0 || p->type_ver > 2 ||
+      p->skip_width < 0 || p->skip_width >= width || p->skip_height < 0 || p->skip_height >= height || p->color < 0 || p->color > 2 ||
+      !coeff_out || !has_coeffs)
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (int rc = check_qargs(bitdepth, width, height, p->qp_scaled)) return rc;
+  if (p->dep_quant) return uvghip_set_error(hipErrorNotSupported, "uvghip_quantize_residual_batch: dependent quantisation is not built");
+  if (p->rdoq_enable && p->use_trskip)
+    return uvghip_set_error(hipErrorNotSupported, "uvghip_quantize_residual_batch: transform-skip RDOQ (uvg_ts_rdoq) is not built");
+  if (n <= 0) return 0;
+  if (!workspace || workspace_bytes < uvghip_quantize_residual_workspace_bytes(p, n))
+    return uvghip_set_error(hipErrorInvalidValue, "uvghip_quantize_residual_batch: workspace");
+  const bool rdoq = p->rdoq_enable && (width > 4 || !p->rdoq_skip) && !p->use_trskip;
+  const tr_params P = tr_make_params(bitdepth, p->type_hor, p->type_ver, width, height, p->skip_width, p->skip_height);
+  const quant_params Q = make_quant_params(bitdepth, width, height, p->qp_scaled, p->use_trskip, p->slice_is_intra);
+  hipStream_t st = uvghip_stream(stream);
+  int16_t *coef = static_cast<int16_t *>(workspace);
+  int16_t *deq = reinterpret_cast<int16_t *>(static_cast<char *>(workspace) + qr_coef_bytes(width, height, n));
+  void *rdoq_ws = static_cast<char *>(workspace) + 2 * qr_coef_bytes(width, height, n);
+  const int bpg = 1024 / (width * height), grid = (n + bpg - 1) / bpg;
+  // (1) residual -> transform (or transform skip) -> coefficients
+#define TU_STAGE(PX, M, buf) tu_roundtrip_kernel<PX, M><<<grid, 256, 0, st>>>(P, Q, (const PX *)orig, orig_stride, (const PX *)pred, pred_stride, (PX *)rec, rec_stride, tus, n, bpg, buf, nullptr, p->use_trskip)
+  if (bitdepth == 8) TU_STAGE(uint8_t, TU_FWD, coef); else TU_STAGE(uint16_t, TU_FWD, coef);
+  { hipError_t e = hipGetLastError(); if (e != hipSuccess) return uvghip_set_error(e, __func__); }
+  // (2) forward LFNST (intra CUs, cfg.lfnst; :507-510): where it applies is the caller's call (uvg_fwd_lfnst, transform.c:988:
+  //     luma, or chroma of a separate tree) -- lfnst_tus == NULL means "nowhere", although quant / RDOQ still see lfnst_idx
+  if (lfnst_tus)
+    if (int rc = uvghip_lfnst_batch(0, coef, width, height, lfnst_tus, n, stream)) return rc;
+  // (3) quantisation: RDOQ (:527-531) or uvg_quant (:535-539)
+  if (rdoq) {
+    if (int rc = uvghip_rdoq_launch_checked(bitdepth, coef, coeff_out, width, height, n, p->color, p->cu_type, p->cbf_u, p->lfnst_idx,
+                                            p->color == 0 ? p->mts_idx : 0, p->qp_scaled, p->lambda, &p->ctx, rdoq_ws,
+                                            workspace_bytes - 2 * qr_coef_bytes(width, height, n), has_coeffs, stream))
+      return rc;
+  } else {
+    if (int rc = (p->lfnst_idx ? uvghip_quant_lfnst_batch : uvghip_quant_batch)(bitdepth, coef, coeff_out, width, height, n, p->qp_scaled,
+                                                                                  p->use_trskip, p->slice_is_intra, stream))
+      return rc;
+    has_coeffs_kernel<<<(n + 3) / 4, 256, 0, st>>>(coeff_out, width * height, n, has_coeffs);
+  }
+  // (4) dequantisation, inverse LFNST, inverse transform, reconstruction (:556-597; without coefficients the inverse of
+  //     zeros is zero and rec = pred, the copy of :599-609)
+  if (int rc = uvghip_dequant_batch(bitdepth, coeff_out, deq, width, height, n, p->qp_scaled, p->use_trskip, stream)) return rc;
+  if (lfnst_tus)
+    if (int rc = uvghip_lfnst_batch(1, deq, width, height, lfnst_tus, n, stream)) return rc;
+  if (bitdepth == 8) TU_STAGE(uint8_t, TU_INV, deq); else TU_STAGE(uint16_t, TU_INV, deq);
+#undef TU_STAGE
   UVGHIP_CHECK_LAUNCH();
 }
 

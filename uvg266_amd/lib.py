@@ -31,6 +31,13 @@ class Xfer(ctypes.Structure):
                 ("recv", ctypes.c_void_p), ("recv_bytes", ctypes.c_uint64)]
 
 
+class QrParams(ctypes.Structure):
+    """uvghip_qr_params_t."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("width", "height", "color", "type_hor", "type_ver", "skip_width", "skip_height", "qp_scaled",
+                                                "slice_is_intra", "cu_type", "use_trskip", "rdoq_enable", "rdoq_skip", "dep_quant", "cbf_u",
+                                                "mts_idx", "lfnst_idx", "reserved")] + [("lambda_", ctypes.c_double), ("ctx", ctypes.c_uint8 * 244)]
+
+
 _lib = None
 _inited_device = None
 
@@ -53,11 +60,15 @@ SIGNATURES = {
     "uvghip_mts_select": (c_int, [c_int] * 9 + [c_vp] * 4),
     "uvg_strategy_register_quant_hip": (c_int, [c_vp, ctypes.c_uint8]),
     "uvghip_quant_batch": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "uvghip_quant_lfnst_batch": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "uvghip_dequant_batch": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "uvghip_coeff_abs_sum_batch": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "uvghip_fast_coeff_cost_batch": (c_int, [c_vp, c_int, c_int, c_int, ctypes.c_uint64, c_vp, c_vp]),
     "uvghip_rdoq_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "uvghip_rdoq_batch": (c_int, [c_int, c_vp, c_vp] + [c_int] * 9 + [ctypes.c_double, c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp, c_vp]),
+    "uvghip_quantize_residual_workspace_bytes": (ctypes.c_size_t, [c_vp, c_int]),
+    "uvghip_quantize_residual_batch": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp,
+                                               ctypes.c_size_t, c_vp]),
     "uvghip_tu_roundtrip_batch": (c_int, [c_int] * 9 + [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvg_strategy_register_intra_hip": (c_int, [c_vp, ctypes.c_uint8]),
     "uvghip_intra_pred_batch": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
