@@ -134,9 +134,10 @@ def test_quantize_residual_batches_vs_oracle(hip, orc, depth):
              dict(w=4, h=16, color=0, cu_type=2, intra=0, trskip=1, rdoq=0, rdoq_skip=0, lfnst=0, imode=0),
              dict(w=32, h=32, color=0, cu_type=2, intra=0, trskip=0, rdoq=1, rdoq_skip=0, lfnst=0, imode=0),
              dict(w=16, h=8, color=1, cu_type=1, intra=1, trskip=0, rdoq=1, rdoq_skip=0, lfnst=0, imode=0)]
+    total_nz = 0
     for c in cases:
         w, h = c["w"], c["h"]
-        qp = int(rng.integers(20, 38))
+        qp = int(rng.integers(17, 30))
         c.update(qps=qp + 6 * (depth - 8), lam=0.57 * 2.0 ** ((qp - 12) / 3.0), ctx=rng.integers(0, 256, 244).astype(np.uint8))
         xy = np.array([[x, y] for y in range(0, PH - h + 1, h) for x in range(0, PW - w + 1, w)], np.int32)
         xy = xy[rng.permutation(len(xy))[:40]]
@@ -149,4 +150,5 @@ def test_quantize_residual_batches_vs_oracle(hip, orc, depth):
             assert has[i] == whas and np.array_equal(coeff[i].ravel(), wq), (c["w"], c["h"], c["rdoq"], c["lfnst"], c["trskip"], i)
             assert np.array_equal(rec[y:y + h, x:x + w], wrec[:h, :w])
             nz += whas
-        assert nz > 5
+        total_nz += nz
+    assert total_nz > 40
