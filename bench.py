@@ -57,11 +57,11 @@ def workload_text(wl, shard, world):
     sh = "" if world == 1 else (f"; each picture sharded over {world} ranks by CTU rows, halos + reconstructed bands over RCCL"
                                 if shard == "rows" else f"; whole pictures sharded over {world} ranks")
     return (f"{wl['W']}x{wl['H']} {wl['depth']}-bit yuv420p, all-intra medium hot path per frame: for N in 32,16,8,4 "
-            "{luma rough search 67 modes min(SATD,2SAD) on all NxN blocks with fused arg-min -> luma predict -> fused "
-            "residual/DCT-2/quant/dequant/IDCT/recon; N>=8: chroma (N/2) predict U,V with the derived mode -> fused chroma TU "
-            "round trip U,V}; then deblock (Y,U,V; seeded random quad-tree partition) -> SAO statistics / offsets / apply (Y,U,V) "
-            f"{alf}; open-loop references (source picture); plain quant (no RDOQ); serial RDOQ/CABAC excluded (out of hot-path "
-            f"scope){sh}")
+            "{luma rough search 67 modes min(SATD,2SAD) on all NxN blocks with fused arg-min -> luma predict -> TU round trip "
+            + ("residual/DCT-2 -> RDOQ (uvg_rdoq, synthetic context snapshot) -> dequant/IDCT/recon" if wl.get("rdoq") else
+               "fused residual/DCT-2/quant/dequant/IDCT/recon") +
+            "; N>=8: chroma (N/2) predict U,V with the derived mode -> chroma TU round trip U,V}; then deblock (Y,U,V; seeded random quad-tree partition) -> SAO statistics / offsets / apply (Y,U,V) "
+            f"{alf}; open-loop references (source picture); CABAC bitstream writing excluded (out of hot-path scope){sh}")
 
 
 class KernelClock:

@@ -29,14 +29,26 @@ SIZES = (32, 16, 8, 4)            # --pu-depth-intra 1-4 (cfg.c:769-801)
 MODES = list(range(67))           # every luma mode; the reference's rough search visits a subset
 
 WORKLOADS = {
-    # BASELINE.json configs[1]: 1920x1080 8-bit all-intra --preset medium (no ALF in medium)
-    "1080p8": dict(W=1920, H=1080, depth=8, alf=False),
+    # BASELINE.json configs[1]: 1920x1080 8-bit all-intra --preset medium (rdoq 1, no ALF: cfg.c:769-801)
+    "1080p8": dict(W=1920, H=1080, depth=8, alf=False, rdoq=True),
     # BASELINE.json configs[3]: 3840x2160 10-bit --preset medium --alf full
-    "2160p10alf": dict(W=3840, H=2160, depth=10, alf=True),
+    "2160p10alf": dict(W=3840, H=2160, depth=10, alf=True, rdoq=True),
     # small pictures for tests
-    "test8": dict(W=328, H=264, depth=8, alf=True),
-    "test10": dict(W=328, H=264, depth=10, alf=True),
+    "test8": dict(W=328, H=264, depth=8, alf=True, rdoq=True),
+    "test10": dict(W=328, H=264, depth=10, alf=True, rdoq=False),
 }
+
+
+def synthetic_rdoq_ctx(seed=22):
+    """A fixed CABAC context snapshot (uvghip_rdoq_ctx_t, 244 CTX_STATE bytes) for the synthetic workloads: moderately
+    skewed probabilities.  In the encoder this is state->cabac.ctx as it stands when the CU is coded."""
+    rng = np.random.default_rng(seed)
+    return rng.integers(40, 216, 244).astype(np.uint8)
+
+
+def intra_lambda(qp):
+    """The order of magnitude of the encoder's RD lambda at this QP (0.57 * 2^((qp-12)/3))."""
+    return 0.57 * 2.0 ** ((qp - 12) / 3.0)
 
 
 def chroma_qp(qp):
@@ -49,6 +61,8 @@ class BandFrame:
     def __init__(self, L, wl, t, device, modes_dev, rank=0, nranks=1, qp=22, transport=None, poison=False, gather=True):
         W, H, depth, alf = wl["W"], wl["H"], wl["depth"], wl["alf"]
         self.W, self.H, self.depth, self.alf, self.qp = W, H, depth, alf, qp
+        self.rdoq = rdoq = bool(wl.get("rdoq", False))
+        self._keep = []                                                     # ctypes parameter blocks referenced by launches
         self.band = band = BandLayout(H, nranks, rank)
         self.rank, self.nranks = rank, nranks
         y0, y1 = band.y0, band.y1
@@ -83,8 +97,7 @@ class BandFrame:
                  [depth, P(self.y), ys, P(self.y), ys, n, P(blks), cnt, P(modes_dev), nm, P(b["best"]), P(b["cost"]), None]),
                 (f"intra_pred_plane_{n}", L.uvghip_intra_pred_plane_batch,
                  [depth, P(self.y), ys, n, P(blks), cnt, P(b["best"]), P(b["pred"]), ys]),
-                (f"tu_roundtrip_{n}", L.uvghip_tu_roundtrip_batch,
-                 [depth, 0, 0, 0, 0, n, n, qps, 1, P(self.y), ys, P(b["pred"]), ys, P(b["rec"]), ys, P(tus), cnt, P(b["coeff"]), P(b["has"])]),
+                self._tu_launch(L, f"tu_roundtrip_{n}", 0, n, qps, self.y, b["pred"], b["rec"], tus, cnt, b["coeff"], b["has"], device),
             ]
             if n >= 8:
                 c = n // 2
@@ -98,10 +111,9 @@ class BandFrame:
                 for name, src in (("u", self.u), ("v", self.v)):
                     chain.append((f"intra_pred_chroma_{n}", L.uvghip_intra_pred_plane_chroma_batch,
                                   [depth, P(src), cs, c, P(cblks), cnt, P(b["best"]), P(b["pred_" + name]), cs]))
-                for name, src in (("u", self.u), ("v", self.v)):
-                    chain.append((f"tu_roundtrip_chroma_{n}", L.uvghip_tu_roundtrip_batch,
-                                  [depth, 0, 0, 0, 0, c, c, qpc, 1, P(src), cs, P(b["pred_" + name]), cs, P(b["rec_" + name]), cs,
-                                   P(ctus), cnt, P(b["coeff_" + name]), P(b["has_" + name])]))
+                for ci, (name, src) in enumerate((("u", self.u), ("v", self.v))):
+                    chain.append(self._tu_launch(L, f"tu_roundtrip_chroma_{n}", 1 + ci, c, qpc, src, b["pred_" + name], b["rec_" + name], ctus, cnt,
+                                                 b["coeff_" + name], b["has_" + name], device))
             self.bufs[n] = b
             self.chains.append(chain if cnt else [])      # a short last band may hold no block of this size
 
@@ -184,6 +196,30 @@ class BandFrame:
             if alf:
                 fn, args = transport.allreduce_args(self.alf_sums)
                 self.reduce.append(("allreduce_cov_0", fn, args))
+
+    def _tu_launch(self, L, name, color, n, qp_scaled, orig, pred, rec, tus, cnt, coeff, has, device):
+        """The reconstruction of n x n TUs: medium runs uvg_quantize_residual on its RDOQ branch (cfg.c:781, quant-generic.c:527);
+        without RDOQ the single-launch plain-quant round trip."""
+        P = lambda t_: t_.data_ptr()
+        st = orig.stride(0)
+        if not self.rdoq or cnt == 0:
+            return (name, L.uvghip_tu_roundtrip_batch,
+                    [self.depth, 0, 0, 0, 0, n, n, qp_scaled, 1, P(orig), st, P(pred), st, P(rec), st, P(tus), cnt, P(coeff), P(has)])
+        import ctypes
+        from . import lib as _lib
+        p = _lib.QrParams()
+        p.width = p.height = n
+        p.color, p.qp_scaled, p.slice_is_intra, p.cu_type = color, qp_scaled, 1, 1
+        p.rdoq_enable, p.rdoq_skip = 1, 0
+        lam = intra_lambda(self.qp)
+        p.lambda_ = lam if color == 0 else lam * 0.9
+        ctypes.memmove(p.ctx, synthetic_rdoq_ctx().tobytes(), 244)
+        need = L.uvghip_quantize_residual_workspace_bytes(ctypes.byref(p), cnt)
+        ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=device)
+        self._keep += [p, ws]
+        return (name, L.uvghip_quantize_residual_batch,
+                [self.depth, ctypes.cast(ctypes.pointer(p), ctypes.c_void_p), P(orig), st, P(pred), st, P(rec), st, P(tus), cnt, None, P(coeff), P(has),
+                 P(ws), ws.numel() * 8])
 
     # -- what one step moves over xGMI for this rank --
     def comm_bytes(self):
