@@ -161,30 +161,29 @@ class Slot:
     """One resident picture: its BandFrame, the eager head (the searches, which carry the roofline's events), and the
     rest of the plan as hipGraph segments between the exchanges."""
 
-    def __init__(self, L, fr, capture_stream, use_graphs):
+    def __init__(self, L, fr, capture_stream, use_graphs, side_streams=None):
         self.fr = fr
         self.searches = [c[0] for c in fr.chains if c]
-        rest = [l for c in fr.chains for l in c[1:]]
-        segs = [rest + fr.stage_a, fr.xchg_dbk, fr.stage_b, fr.xchg_alf, fr.stage_c, fr.reduce + fr.xchg_gather]
+        branches = [c[1:] for c in fr.chains if c]           # per block size: predict, TU round trips (luma, chroma): independent chains
+        segs = [fr.stage_a, fr.xchg_dbk, fr.stage_b, fr.xchg_alf, fr.stage_c, fr.reduce + fr.xchg_gather]
         # merge neighbouring kernel segments when no exchange sits between them (one rank: a single graph)
-        self.plan = []      # ("graph", Graph) | ("eager", launches)
+        self.plan = []      # ("kernels", launches) | ("comm", launches)
         acc = []
         for i, seg in enumerate(segs):
-            is_comm = i % 2 == 1
-            if is_comm:
+            if i % 2 == 1:
                 if seg:
-                    if acc:
-                        self.plan.append(("kernels", acc)); acc = []
+                    self.plan.append(("kernels", acc)); acc = []
                     self.plan.append(("comm", seg))
             else:
                 acc = acc + seg
         if acc:
             self.plan.append(("kernels", acc))
+        self.branches = branches
         self.graphs = {}
         if use_graphs:
             for i, (kind, ls) in enumerate(self.plan):
                 if kind == "kernels":
-                    self.graphs[i] = pipeline.Graph(L, ls, capture_stream)
+                    self.graphs[i] = pipeline.Graph(L, ls, capture_stream, branches if i == 0 else None, side_streams)
         self.ev_done = torch.cuda.Event()
         self.ev_done.record()
 
@@ -201,6 +200,9 @@ class Slot:
             if i in self.graphs:
                 self.graphs[i].launch(stream.cuda_stream)
             else:
+                if i == 0:
+                    for br in self.branches:
+                        pipeline.run(br, stream.cuda_stream)
                 pipeline.run(ls, stream.cuda_stream)
         self.ev_done.record(stream)
 
@@ -286,11 +288,12 @@ def measure(args, wl_name, L, device, rank, local_rank, world, dist, transport, 
     main_stream = torch.cuda.current_stream()
     streams = [torch.cuda.Stream(device=device) for _ in range(1 if args.serial else args.streams)]
     cap = torch.cuda.Stream(device=device)
+    cap_side = [torch.cuda.Stream(device=device) for _ in range(3)] if args.fork else None
     # one eager pass first: lazy per-kernel initialisation (function attributes) must not happen inside a capture
     for fr in frames:
         pipeline.run(fr.all_launches(), main_stream.cuda_stream)
     torch.cuda.synchronize()
-    slots = [Slot(L, fr, cap, use_graphs=not args.no_graphs) for fr in frames]
+    slots = [Slot(L, fr, cap, use_graphs=not args.no_graphs, side_streams=cap_side) for fr in frames]
     torch.cuda.synchronize()
     clock = KernelClock()
 
@@ -363,6 +366,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one stream: no overlap between pictures")
     ap.add_argument("--no-graphs", action="store_true", help="issue every launch eagerly instead of replaying hipGraph segments")
+    ap.add_argument("--no-fork", dest="fork", action="store_false", help="capture a picture's four block-size chains serially instead of as parallel graph branches")
+    ap.add_argument("--resident", type=int, default=0, help="pictures resident per workload (0 = 4 for 1080p8, 2 for 2160p10alf)")
     ap.add_argument("--streams", type=int, default=4, help="pictures in flight: consecutive steps go to consecutive streams")
     ap.add_argument("--profile-steps", type=int, default=4, help="untimed, fully instrumented steps for the per-kernel table")
     ap.add_argument("--shard", choices=("rows", "frames"), default="rows",
@@ -395,7 +400,7 @@ def main():
         transport = bands.RcclTransport(rank, world, bootstrap)
 
     wl_name = args.workload
-    n_res = 4 if wl_name == "1080p8" else 2
+    n_res = args.resident or (4 if wl_name == "1080p8" else 2)
     r = measure(args, wl_name, L, device, rank, local_rank, world, dist, transport, args.steps, args.warmup, n_res, True)
     extra = None
     if not args.no_extra and wl_name == "1080p8":
@@ -427,7 +432,7 @@ def main():
             out["config"]["band_rows_rank0"] = [fr.band.y0, fr.band.y1]
         if live:
             dom = max(live, key=lambda k: live[k]["avg_ms"])
-            alone_ms = per_kernel[dom]["avg_ms"]
+            alone_ms = per_kernel.get(dom, live[dom])["avg_ms"]
             v = VALU.get(dom) if wl_name == "1080p8" else None
             hbm = {"bound": "hbm", "kernel": dom, "achieved": live[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": round(live[dom]["gbs"] / HBM_PEAK_GBS, 5), "traffic": TRAFFIC.get(dom) if wl_name == "1080p8" else None,

@@ -241,6 +241,20 @@ UVGHIP_API int uvghip_tu_roundtrip_batch(int bitdepth, int type_hor, int type_ve
                               void *rec, int rec_stride, const uvghip_tu_t *tus, int n,
                               int16_t *coeff_out, uint8_t *has_coeffs, void *stream);
 
+/* The two halves of uvg_quantize_residual around the quantiser, for hosts that run the quantiser over a larger batch than
+ * the plane kernels (e.g. RDOQ over the TUs of several pictures in one launch):
+ *   forward: residual = orig - pred (uvg_generate_residual) -> uvg_transform2d | uvg_transformskip -> coef_out[i]
+ *            (quant-generic.c:483-502), n contiguous blocks of width*height int16, the reference's coeff_t buffer;
+ *   inverse: coef_in[i] = DEQUANTISED coefficients -> uvg_itransform2d | uvg_itransformskip -> rec = clip(pred + residual)
+ *            (:565-597).
+ * type_* / skip_* from uvghip_mts_select. */
+UVGHIP_API int uvghip_tu_forward_batch(int bitdepth, int type_hor, int type_ver, int skip_width, int skip_height, int width, int height,
+                            int use_trskip, const void *orig, int orig_stride, const void *pred, int pred_stride,
+                            const uvghip_tu_t *tus, int n, int16_t *coef_out, void *stream);
+UVGHIP_API int uvghip_tu_inverse_batch(int bitdepth, int type_hor, int type_ver, int skip_width, int skip_height, int width, int height,
+                            int use_trskip, const int16_t *coef_in, const void *pred, int pred_stride, void *rec, int rec_stride,
+                            const uvghip_tu_t *tus, int n, void *stream);
+
 /* Everything uvg_quantize_residual reads from its arguments, the CU and the encoder state (quant-generic.c:460-612). */
 typedef struct uvghip_qr_params {
   int32_t width, height, color;                          /* TU shape; COLOR_Y/U/V = 0/1/2 */

@@ -818,6 +818,49 @@ extern "C" int uvghip_tu_roundtrip_batch(int bitdepth, int type_hor, int type_ve
   UVGHIP_CHECK_LAUNCH();
 }
 
+// ---- the two halves of the round trip as entry points of their own (a host that batches the quantiser over several
+//      pictures, as the pipeline does for RDOQ, runs them per picture around one quantiser launch) ----
+static int tu_half_check(int bitdepth, int type_hor, int type_ver, int skip_width, int skip_height, int width, int height, const char *who)
+{
+  if ((bitdepth != 8 && bitdepth != 10) || !tr_valid_dim(width) || !tr_valid_dim(height) || type_hor < 0 || type_hor > 2 || type_ver < 0 ||
+      type_ver > 2 || skip_width < 0 || skip_width >= width || skip_height < 0 || skip_height >= height)
+    return uvghip_set_error(hipErrorInvalidValue, who);
+  return 0;
+}
+
+extern "C" int uvghip_tu_forward_batch(int bitdepth, int type_hor, int type_ver, int skip_width, int skip_height, int width, int height,
+                                       int use_trskip, const void *orig, int orig_stride, const void *pred, int pred_stride,
+                                       const uvghip_tu_t *tus, int n, int16_t *coef_out, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (int rc = tu_half_check(bitdepth, type_hor, type_ver, skip_width, skip_height, width, height, __func__)) return rc;
+  if (n <= 0) return 0;
+  const tr_params P = tr_make_params(bitdepth, type_hor, type_ver, width, height, skip_width, skip_height);
+  const quant_params Q = make_quant_params(bitdepth, width, height, 22, 0, 1);       // unused by this half
+  const int bpg = 1024 / (width * height), grid = (n + bpg - 1) / bpg;
+  hipStream_t st = uvghip_stream(stream);
+  if (bitdepth == 8) tu_roundtrip_kernel<uint8_t, TU_FWD><<<grid, 256, 0, st>>>(P, Q, (const uint8_t *)orig, orig_stride, (const uint8_t *)pred, pred_stride, nullptr, 0, tus, n, bpg, coef_out, nullptr, use_trskip);
+  else tu_roundtrip_kernel<uint16_t, TU_FWD><<<grid, 256, 0, st>>>(P, Q, (const uint16_t *)orig, orig_stride, (const uint16_t *)pred, pred_stride, nullptr, 0, tus, n, bpg, coef_out, nullptr, use_trskip);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+extern "C" int uvghip_tu_inverse_batch(int bitdepth, int type_hor, int type_ver, int skip_width, int skip_height, int width, int height,
+                                       int use_trskip, const int16_t *coef_in, const void *pred, int pred_stride, void *rec, int rec_stride,
+                                       const uvghip_tu_t *tus, int n, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (int rc = tu_half_check(bitdepth, type_hor, type_ver, skip_width, skip_height, width, height, __func__)) return rc;
+  if (n <= 0) return 0;
+  const tr_params P = tr_make_params(bitdepth, type_hor, type_ver, width, height, skip_width, skip_height);
+  const quant_params Q = make_quant_params(bitdepth, width, height, 22, 0, 1);
+  const int bpg = 1024 / (width * height), grid = (n + bpg - 1) / bpg;
+  hipStream_t st = uvghip_stream(stream);
+  int16_t *c = const_cast<int16_t *>(coef_in);
+  if (bitdepth == 8) tu_roundtrip_kernel<uint8_t, TU_INV><<<grid, 256, 0, st>>>(P, Q, nullptr, 0, (const uint8_t *)pred, pred_stride, (uint8_t *)rec, rec_stride, tus, n, bpg, c, nullptr, use_trskip);
+  else tu_roundtrip_kernel<uint16_t, TU_INV><<<grid, 256, 0, st>>>(P, Q, nullptr, 0, (const uint16_t *)pred, pred_stride, (uint16_t *)rec, rec_stride, tus, n, bpg, c, nullptr, use_trskip);
+  UVGHIP_CHECK_LAUNCH();
+}
+
 // ---- the staged round trip: every branch of uvg_quantize_residual (quant-generic.c:460-612) ----
 __global__ void __launch_bounds__(256) has_coeffs_kernel(const int16_t *__restrict__ q, int len, int n, uint8_t *__restrict__ has)
 {

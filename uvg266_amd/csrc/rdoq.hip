@@ -46,7 +46,7 @@ __device__ __forceinline__ int group_idx(int pos)
 __device__ __forceinline__ int go_rice_par(int s) { return (s >= 7) + (s >= 14) + (s >= 28); }
 
 // rdo.c:465-581 with use_limited_prefix_length = true (the only way uvg_get_coded_level calls it)
-__device__ inline int ic_rate(const uint32_t (*B)[2], int t, uint32_t abs_level, int ctx, int go_rice, uint32_t reg_bins)
+__device__ __forceinline__ int ic_rate(const uint32_t (*B)[2], int t, uint32_t abs_level, int ctx, int go_rice, uint32_t reg_bins)
 {
   int rate = 1 << 15;
   const int thr = 5, max_log2 = 15;
@@ -97,7 +97,7 @@ struct rdoq_decision { int level; int sig_code; double coded_cost, coded_sig; };
 
 // uvg_get_coded_level (rdo.c:597-640) + the context derivation in front of it (:1630-1651) for one position.
 // nb / has: levels of the neighbours right, right+1, below-right, below, below+1 (0 where outside the block).
-__device__ inline rdoq_decision rdoq_decide(const rdoq_params &P, const uint32_t (*B)[2], int t, bool is_last, int level_double, uint32_t max_abs_level,
+__device__ __forceinline__ rdoq_decision rdoq_decide(const rdoq_params &P, const uint32_t (*B)[2], int t, bool is_last, int level_double, uint32_t max_abs_level,
                                             double c0, const int (&nb)[5], const bool (&has)[5], uint32_t pos_x, uint32_t pos_y, int go_rice,
                                             uint32_t reg_bins)
 {
@@ -156,10 +156,17 @@ __device__ inline rdoq_decision rdoq_decide(const rdoq_params &P, const uint32_t
 // waves per SIMD hide the latency of the dependent steps).
 template <int TUS>
 __global__ void __launch_bounds__(64)
-rdoq_kernel(const rdoq_params P, const int16_t *__restrict__ coef, int16_t *__restrict__ q_coef, uint32_t *__restrict__ abs_sum_out,
-            uint8_t *__restrict__ has_coeffs)
+rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__restrict__ q_coef, double *__restrict__ ws,
+            uint32_t *__restrict__ abs_sum_out, uint8_t *__restrict__ has_coeffs)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char sDyn[];
+  // the parameter block is read through LDS: kept in scalar registers for the whole kernel it pushes the SGPR file over
+  // its limit (spills + a scratch slot, which makes every dispatch bind scratch memory)
+  __shared__ rdoq_params sP;
+  for (int i = threadIdx.x; i < (int)(sizeof(rdoq_params) / 4); i += 64)
+    reinterpret_cast<uint32_t *>(&sP)[i] = reinterpret_cast<const uint32_t *>(&Pk)[i];
+  __syncthreads();
+  const rdoq_params &P = sP;
   __shared__ uint32_t sB[N_CTX][2];
   __shared__ int sLastX[32], sLastY[32];
   __shared__ uint8_t sScanCg[64];
@@ -173,10 +180,12 @@ rdoq_kernel(const rdoq_params P, const int16_t *__restrict__ coef, int16_t *__re
   const bool live = grp < here;
   const int gq = live ? grp : 0;                                       // idle lanes alias block 0 for address arithmetic only
   const int tu = tu0 + gq;
-  // per block: cost_coeff double[wh] | coef int16[wh] | level int16[wh] | meta uint8[wh]; then 64 group costs per block
-  const size_t per_tu = (size_t)wh * 13;
-  double *sCost = reinterpret_cast<double *>(sDyn + gq * per_tu);
-  int16_t *sCoef = reinterpret_cast<int16_t *>(sDyn + gq * per_tu + (size_t)wh * 8);
+  // per block in LDS: coef int16[wh] | level int16[wh] | meta uint8[wh] (padded to 8 bytes); then 64 group costs per block.
+  // cost_coeff[] (a double per position, written once during the walk, re-read only for non-zero levels by the last-position
+  // search) goes to the caller's workspace: it would be 60 % of the LDS footprint and cap the blocks per wave.
+  const size_t per_tu = ((size_t)wh * 5 + 7) & ~(size_t)7;
+  double *gCost = ws + (size_t)tu * wh;
+  int16_t *sCoef = reinterpret_cast<int16_t *>(sDyn + gq * per_tu);
   int16_t *sLev = sCoef + wh;
   uint8_t *sMeta = reinterpret_cast<uint8_t *>(sLev + wh);
   double *sCgCost = reinterpret_cast<double *>(sDyn + TUS * per_tu) + gq * 64;
@@ -199,7 +208,7 @@ rdoq_kernel(const rdoq_params P, const int16_t *__restrict__ coef, int16_t *__re
   // ---- stage the coefficients (coalesced: the blocks of a workgroup are contiguous), clear the levels ----
   for (int e = tid; e < here * wh; e += 64) {
     const int b = e / wh, pos = e - b * wh;
-    int16_t *base = reinterpret_cast<int16_t *>(sDyn + b * per_tu + (size_t)wh * 8);
+    int16_t *base = reinterpret_cast<int16_t *>(sDyn + b * per_tu);
     base[pos] = coef[(size_t)tu0 * wh + e];
     base[wh + pos] = 0;
   }
@@ -261,7 +270,7 @@ rdoq_kernel(const rdoq_params P, const int16_t *__restrict__ coef, int16_t *__re
   auto cg_skipped = [&](int g) { return mts != 0 && ((g >> l2cgw) >= 4 || (g & (cgw - 1)) >= 4); };
   auto quad_or = [&](unsigned v) { v |= __shfl_xor(v, 1, 64); v |= __shfl_xor(v, 2, 64); return v; };
   auto quad_sum = [&](unsigned v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); return v; };
-  auto neighbours = [&](int blkpos, uint32_t pos_x, uint32_t pos_y, int (&nb)[5], bool (&has)[5]) {
+  auto neighbours = [&](int blkpos, uint32_t pos_x, uint32_t pos_y, int (&nb)[5], bool (&has)[5]) __attribute__((always_inline)) {
     const int16_t *D = sLev + blkpos;
 #pragma unroll
     for (int k = 0; k < 5; ++k) { nb[k] = 0; has[k] = false; }
@@ -345,7 +354,7 @@ rdoq_kernel(const rdoq_params P, const int16_t *__restrict__ coef, int16_t *__re
         sLev[blkpos] = (int16_t)d.level;
         sStage[gq][s4][0] = d.coded_cost; sStage[gq][s4][1] = d.coded_sig;
         sStageLv[gq][s4] = d.level;
-        sCost[blkpos] = d.coded_cost;
+        gCost[blkpos] = d.coded_cost;
         sMeta[blkpos] = (uint8_t)((sMeta[blkpos] & 3) | (d.sig_code << 2));
       }
       __syncthreads();
@@ -378,7 +387,7 @@ rdoq_kernel(const rdoq_params P, const int16_t *__restrict__ coef, int16_t *__re
           sLev[b2] = (int16_t)d2.level;
           sStage[gq][s2][0] = d2.coded_cost; sStage[gq][s2][1] = d2.coded_sig;
           sStageLv[gq][s2] = d2.level;
-          sCost[b2] = d2.coded_cost;
+          gCost[b2] = d2.coded_cost;
           sMeta[b2] = (uint8_t)((sMeta[b2] & 3) | (d2.sig_code << 2));
         }
         __syncthreads();
@@ -452,7 +461,7 @@ rdoq_kernel(const rdoq_params P, const int16_t *__restrict__ coef, int16_t *__re
         for (int r = 0; r < 4; ++r) {
           const int s4 = j + 4 * r;
           const int blkpos = blk_in(g, in_cg(s4));
-          if (s4 <= max_group && sLev[blkpos]) { sLev[blkpos] = 0; sCost[blkpos] = sStage[gq][s4][2]; sMeta[blkpos] &= 3; }
+          if (s4 <= max_group && sLev[blkpos]) { sLev[blkpos] = 0; gCost[blkpos] = sStage[gq][s4][2]; sMeta[blkpos] &= 3; }
         }
     } else if (has_last && j == 0) {
       sCgCost[cgs] = 0;                                                  // groups skipped by the MTS zero-out keep a zero flag cost
@@ -477,6 +486,13 @@ rdoq_kernel(const rdoq_params P, const int16_t *__restrict__ coef, int16_t *__re
       const int g = sScanCg[cgs];
       base_cost -= sCgCost[cgs];
       if ((sig_cg >> g) & 1) {
+        // the group's cost_coeff values: fetched by the four lanes together, then read from LDS by each of them
+        // (same-wave LDS traffic is in order: no barrier inside this block-divergent loop)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int s4 = j + 4 * r; if (s4 <= max_group) sStage[gq][s4][0] = gCost[blk_in(g, in_cg(s4))]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int s2 = max_group; s2 >= 0; s2--) {
           const int sc2 = cgs * 16 + s2;
           if (sc2 > last_scanpos) continue;
@@ -493,7 +509,7 @@ rdoq_kernel(const rdoq_params P, const int16_t *__restrict__ coef, int16_t *__re
             const double total = base_cost + cost_last - csig;
             if (total < best_cost) { best_last_idx_p1 = sc2 + 1; best_cost = total; }
             if (lv > 1) { found_last = true; break; }
-            base_cost -= sCost[b2];
+            base_cost -= sStage[gq][s2][0];
             base_cost += cost0_of(level_double_at(b2));
           } else {
             base_cost -= csig;
@@ -527,7 +543,7 @@ rdoq_kernel(const rdoq_params P, const int16_t *__restrict__ coef, int16_t *__re
   __syncthreads();
   for (int e = tid; e < here * wh; e += 64) {
     const int b = e / wh, pos = e - b * wh;
-    q_coef[(size_t)tu0 * wh + e] = reinterpret_cast<const int16_t *>(sDyn + b * per_tu + (size_t)wh * 8)[wh + pos];
+    q_coef[(size_t)tu0 * wh + e] = reinterpret_cast<const int16_t *>(sDyn + b * per_tu)[wh + pos];
   }
 }
 
@@ -536,8 +552,7 @@ rdoq_kernel(const rdoq_params P, const int16_t *__restrict__ coef, int16_t *__re
 extern "C" size_t uvghip_rdoq_workspace_bytes(int width, int height, int n)
 {
   if (width <= 0 || height <= 0 || n <= 0) return 0;
-  (void)width; (void)height;
-  return 256;                                  // the walk keeps its state in LDS; the argument stays in the ABI for larger transforms
+  return (size_t)width * height * (size_t)n * sizeof(double);      // cost_coeff[] of every block
 }
 
 extern "C" int uvghip_rdoq_batch(int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n, int color,
@@ -575,12 +590,13 @@ extern "C" int uvghip_rdoq_batch(int bitdepth, const int16_t *coef, int16_t *q_c
   // blocks per wave (four lanes each).  The kernel is issue-bound (SQ counters, tools/dev/rdoq_pmc.sh: ~1900 instructions per
   // coefficient group and wave, VALU active > 50 %); a wave's work does not depend on how many blocks share it, so more blocks
   // per wave = the same latency at a fraction of the GPU time.  16 while the LDS allows (<= 256 coefficients), else 4.
-  const int tus = wh <= 256 ? 16 : 4;
-  const size_t lds = (size_t)tus * wh * 13 + (size_t)tus * 64 * sizeof(double);
-  (void)workspace;
+  const int tus = wh <= 512 ? 16 : 8;
+  const size_t per_tu = ((size_t)wh * 5 + 7) & ~(size_t)7;
+  const size_t lds = (size_t)tus * per_tu + (size_t)tus * 64 * sizeof(double);
+  double *w = static_cast<double *>(workspace);
   hipStream_t st = uvghip_stream(stream);
   const int grid = (n + tus - 1) / tus;
-  if (tus == 16) rdoq_kernel<16><<<grid, 64, lds, st>>>(P, coef, q_coef, abs_sum_out, has_coeffs);
-  else rdoq_kernel<4><<<grid, 64, lds, st>>>(P, coef, q_coef, abs_sum_out, has_coeffs);
+  if (tus == 16) rdoq_kernel<16><<<grid, 64, lds, st>>>(P, coef, q_coef, w, abs_sum_out, has_coeffs);
+  else rdoq_kernel<8><<<grid, 64, lds, st>>>(P, coef, q_coef, w, abs_sum_out, has_coeffs);
   UVGHIP_CHECK_LAUNCH();
 }

@@ -66,6 +66,8 @@ SIGNATURES = {
     "uvghip_fast_coeff_cost_batch": (c_int, [c_vp, c_int, c_int, c_int, ctypes.c_uint64, c_vp, c_vp]),
     "uvghip_rdoq_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "uvghip_rdoq_batch": (c_int, [c_int, c_vp, c_vp] + [c_int] * 9 + [ctypes.c_double, c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp, c_vp]),
+    "uvghip_tu_forward_batch": (c_int, [c_int] * 8 + [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_tu_inverse_batch": (c_int, [c_int] * 8 + [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp]),
     "uvghip_quantize_residual_workspace_bytes": (ctypes.c_size_t, [c_vp, c_int]),
     "uvghip_quantize_residual_batch": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp,
                                                ctypes.c_size_t, c_vp]),

@@ -245,16 +245,35 @@ def run(launches, stream_handle, L=None):
 
 
 class Graph:
-    """A list of launches captured once into a hipGraph (uvghip_graph_*) and replayed with one call."""
+    """Launches captured once into a hipGraph (uvghip_graph_*) and replayed with one call.  `branches`: independent
+    launch lists that fork from the capture stream onto `side_streams` and join again before `launches` (the four block-size
+    chains of a picture: the graph then lets the long, narrow kernels of one chain run beside the others)."""
 
-    def __init__(self, L, launches, capture_stream):
+    def __init__(self, L, launches, capture_stream, branches=None, side_streams=None):
         import ctypes
         from . import lib as _lib
-        self.L, self.names = L, [l[0] for l in launches]
+        self.L = L
+        self.names = [l[0] for b in (branches or []) for l in b] + [l[0] for l in launches]
         self.handle = ctypes.c_void_p()
         h = capture_stream.cuda_stream
         _lib.check(L.uvghip_graph_begin(h), "uvghip_graph_begin")
         try:
+            if branches:
+                fork = torch.cuda.Event()
+                fork.record(capture_stream)
+                joins = []
+                for k, br in enumerate(branches):
+                    if k == 0 or not side_streams:
+                        run(br, h)
+                        continue
+                    st = side_streams[(k - 1) % len(side_streams)]
+                    st.wait_event(fork)                      # pulls the side stream into the capture
+                    run(br, st.cuda_stream)
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    joins.append(ev)
+                for ev in joins:
+                    capture_stream.wait_event(ev)
             run(launches, h)
         finally:
             rc = L.uvghip_graph_end(h, ctypes.byref(self.handle))
