@@ -103,10 +103,16 @@ def family(name):
     return name.rsplit("_", 1)[0]
 
 
-def algorithmic_bytes(fr, name):
+def algorithmic_bytes(fr, name, group=1):
     """SURVEY.md 8(d) per-unit figures x the units this launch processes (b = bytes per sample)."""
     kern, n = name.rsplit("_", 1)
     n = int(n)
+    if kern in ("rdoq", "dequant", "rdoq_chroma", "dequant_chroma"):       # one launch over the group's pictures: int16 in, int16 out
+        c = n // 2 if kern.endswith("chroma") else n
+        return group * fr.tables[n][2] * c * c * 4
+    if kern in ("tu_forward", "tu_forward_chroma", "tu_inverse", "tu_inverse_chroma"):   # two planes touched + int16 coefficients
+        c = n // 2 if kern.endswith("chroma") else n
+        return fr.tables[n][2] * c * c * (2 * (1 if fr.depth == 8 else 2) + 2)
     b = 1 if fr.depth == 8 else 2
     rows = fr.band.y1 - fr.band.y0
     W = fr.W
@@ -158,38 +164,44 @@ pipeline.BandFrame.alf_records_bytes = _alf_records_bytes
 
 
 class Slot:
-    """One resident picture: its BandFrame, the eager head (the searches, which carry the roofline's events), and the
-    rest of the plan as hipGraph segments between the exchanges."""
+    """One resident GROUP of pictures (pipeline.FrameGroup): the eager head (the searches, which carry the roofline's events)
+    and the rest of the plan as hipGraph segments between the exchanges."""
 
-    def __init__(self, L, fr, capture_stream, use_graphs, side_streams=None):
-        self.fr = fr
-        self.searches = [c[0] for c in fr.chains if c]
-        branches = [c[1:] for c in fr.chains if c]           # per block size: predict, TU round trips (luma, chroma): independent chains
-        segs = [fr.stage_a, fr.xchg_dbk, fr.stage_b, fr.xchg_alf, fr.stage_c, fr.reduce + fr.xchg_gather]
-        # merge neighbouring kernel segments when no exchange sits between them (one rank: a single graph)
-        self.plan = []      # ("kernels", launches) | ("comm", launches)
-        acc = []
-        for i, seg in enumerate(segs):
-            if i % 2 == 1:
-                if seg:
-                    self.plan.append(("kernels", acc)); acc = []
-                    self.plan.append(("comm", seg))
-            else:
-                acc = acc + seg
+    def __init__(self, L, grp, capture_stream, use_graphs, side_streams=None):
+        self.grp = grp
+        self.searches = grp.searches()
+        frs = grp.frames
+        # kernel segments between exchanges: [everything before the filters + vertical deblocking of every picture], then per
+        # picture [x_dbk] stage_b [x_alf] stage_c [reduce, gather]; neighbouring kernel segments merge when no exchange separates them
+        # the quantiser launches (RDOQ + dequantisation per block shape over the group) stay eager between two graphs: they are
+        # the long kernels, and the roofline's HIP events go around them when they are the dominant family
+        self.plan = []      # ("kernels", launches) | ("eager", launches) | ("comm", launches)
+        if grp.mid:
+            self.plan += [("kernels", grp.heads_rest()), ("eager", grp.mid)]
+            acc = grp.tails() + [l for fr in frs for l in fr.stage_a]
+        else:
+            acc = grp.before_filters() + [l for fr in frs for l in fr.stage_a]
+        for fr in frs:
+            for seg, comm in ((fr.xchg_dbk, True), (fr.stage_b, False), (fr.xchg_alf, True), (fr.stage_c, False), (fr.reduce + fr.xchg_gather, True)):
+                if comm:
+                    if seg:
+                        if acc:
+                            self.plan.append(("kernels", acc)); acc = []
+                        self.plan.append(("comm", seg))
+                else:
+                    acc = acc + seg
         if acc:
             self.plan.append(("kernels", acc))
-        self.branches = branches
         self.graphs = {}
         if use_graphs:
             for i, (kind, ls) in enumerate(self.plan):
                 if kind == "kernels":
-                    self.graphs[i] = pipeline.Graph(L, ls, capture_stream, branches if i == 0 else None, side_streams)
+                    self.graphs[i] = pipeline.Graph(L, ls, capture_stream)
         self.ev_done = torch.cuda.Event()
         self.ev_done.record()
 
     def issue(self, clock, stream, timed_heads):
-        fr = self.fr
-        self.ev_done.synchronize()              # at most n_resident pictures in flight; this slot's previous use has retired
+        self.ev_done.synchronize()              # at most n_resident groups in flight; this slot's previous use has retired
         clock.harvest(id(self))
         for name, fn, args in self.searches:
             if timed_heads:
@@ -199,10 +211,10 @@ class Slot:
         for i, (kind, ls) in enumerate(self.plan):
             if i in self.graphs:
                 self.graphs[i].launch(stream.cuda_stream)
+            elif kind == "eager" and timed_heads:
+                for name, fn, args in ls:
+                    clock.launch(name, fn, args, stream, id(self))
             else:
-                if i == 0:
-                    for br in self.branches:
-                        pipeline.run(br, stream.cuda_stream)
                 pipeline.run(ls, stream.cuda_stream)
         self.ev_done.record(stream)
 
@@ -210,7 +222,7 @@ class Slot:
         """Everything eager, every launch bracketed by events (untimed profile pass)."""
         self.ev_done.synchronize()
         clock.harvest(id(self))
-        for name, fn, args in self.fr.all_launches():
+        for name, fn, args in self.grp.all_launches():
             clock.launch(name, fn, args, stream, id(self))
         self.ev_done.record(stream)
 
@@ -280,34 +292,39 @@ def measure(args, wl_name, L, device, rank, local_rank, world, dist, transport, 
     wl = WORKLOADS[wl_name]
     shard_rows = world > 1 and args.shard == "rows"
     modes_dev = api.make_modes(MODES, device)
+    F = max(1, args.group)
+    while steps % F:                         # K pictures are timed exactly: the group size divides K
+        F -= 1
     if shard_rows:
-        frames = [pipeline.BandFrame(L, wl, k, device, modes_dev, rank=rank, nranks=world, qp=QP, transport=transport,
-                                     gather=not args.no_gather) for k in range(n_resident)]
-    else:
-        frames = [pipeline.BandFrame(L, wl, rank + k * world, device, modes_dev, qp=QP) for k in range(n_resident)]
+        groups = [pipeline.FrameGroup(L, wl, k * F, F, device, modes_dev, rank=rank, nranks=world, qp=QP, transport=transport,
+                                      gather=not args.no_gather) for k in range(n_resident)]
+    else:       # whole pictures per rank: rank r takes pictures r, r + world, ...
+        groups = [pipeline.FrameGroup(L, wl, rank + k * F * world, F, device, modes_dev, step=world, qp=QP) for k in range(n_resident)]
+    frames = [fr for g in groups for fr in g.frames]
     main_stream = torch.cuda.current_stream()
     streams = [torch.cuda.Stream(device=device) for _ in range(1 if args.serial else args.streams)]
     cap = torch.cuda.Stream(device=device)
-    cap_side = [torch.cuda.Stream(device=device) for _ in range(3)] if args.fork else None
     # one eager pass first: lazy per-kernel initialisation (function attributes) must not happen inside a capture
-    for fr in frames:
-        pipeline.run(fr.all_launches(), main_stream.cuda_stream)
+    for g in groups:
+        pipeline.run(g.all_launches(), main_stream.cuda_stream)
     torch.cuda.synchronize()
-    slots = [Slot(L, fr, cap, use_graphs=not args.no_graphs, side_streams=cap_side) for fr in frames]
+    slots = [Slot(L, g, cap, use_graphs=not args.no_graphs) for g in groups]
     torch.cuda.synchronize()
     clock = KernelClock()
 
-    def step(s, timed):
+    def step(s, timed):       # one call = one GROUP of F pictures
         slots[s % n_resident].issue(clock, streams[s % len(streams)], timed)
 
+    n_groups = steps // F
     clock.only = set()                       # warm-up: no events at all
-    for s in range(warmup):
+    for s in range((warmup + F - 1) // F):
         step(s, False)
     torch.cuda.synchronize()
 
     # untimed profile pass: every kernel bracketed by HIP events, one stream, nothing concurrent
     prof = KernelClock()
-    for s in range(args.profile_steps if want_tables else 0):
+    prof_groups = (args.profile_steps + F - 1) // F if want_tables else 0
+    for s in range(prof_groups):
         slots[s % n_resident].issue_profiled(prof, main_stream)
     torch.cuda.synchronize()
     prof_tot = prof.totals()
@@ -316,15 +333,15 @@ def measure(args, wl_name, L, device, rank, local_rank, world, dist, transport, 
         fam_ms[family(name)] = fam_ms.get(family(name), 0.0) + ms
     dom_family = max(fam_ms, key=fam_ms.get) if fam_ms else "intra_search"
 
-    clock.only = {dom_family} if dom_family == "intra_search" else set()
-    for s in range(min(4, warmup)):          # back to the streamed plan after the serial pass
+    clock.only = {k for k in fam_ms if k.split("_chroma")[0] == dom_family.split("_chroma")[0]} if dom_family in ("intra_search", "rdoq", "rdoq_chroma") else {"intra_search"}
+    for s in range(2):                       # back to the streamed plan after the serial pass
         step(s, False)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s in range(steps):
+    for s in range(n_groups):
         step(s, True)
     torch.cuda.synchronize()
     if dist:
@@ -337,20 +354,20 @@ def measure(args, wl_name, L, device, rank, local_rank, world, dist, transport, 
         elapsed = float(t.item())
     pics = steps if shard_rows else steps * world
     res = {"fps": pics / elapsed, "elapsed": elapsed, "frames": frames, "prof": prof_tot, "live": clock.totals(),
-           "dom_family": dom_family, "shard_rows": shard_rows, "wl": wl}
+           "dom_family": dom_family, "shard_rows": shard_rows, "wl": wl, "prof_pics": prof_groups * F, "group": F}
     for sl in slots:
         for g in sl.graphs.values():
             g.destroy()
     return res
 
 
-def kernel_table(fr, totals, steps):
-    """name -> per-launch average, per-step total, share of the step's kernel time, algorithmic bytes and GB/s."""
+def kernel_table(fr, totals, pictures, group):
+    """name -> per-launch average, per-picture total, share of a picture's kernel time, algorithmic bytes and GB/s."""
     t = {}
     for name, (ms, launches) in totals.items():
-        byts = algorithmic_bytes(fr, name)
+        byts = algorithmic_bytes(fr, name, group)
         avg_ms = ms / launches
-        t[name] = {"avg_ms": round(avg_ms, 4), "per_step_ms": round(ms / max(1, steps), 4), "share": 0.0, "alg_bytes": byts,
+        t[name] = {"avg_ms": round(avg_ms, 4), "per_step_ms": round(ms / max(1, pictures), 4), "share": 0.0, "alg_bytes": byts,
                    "launches": launches, "gbs": round(byts / (avg_ms * 1e-3) / 1e9, 2)}
     tot = sum(v["per_step_ms"] for v in t.values())
     for v in t.values():
@@ -366,8 +383,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one stream: no overlap between pictures")
     ap.add_argument("--no-graphs", action="store_true", help="issue every launch eagerly instead of replaying hipGraph segments")
-    ap.add_argument("--no-fork", dest="fork", action="store_false", help="capture a picture's four block-size chains serially instead of as parallel graph branches")
     ap.add_argument("--resident", type=int, default=0, help="pictures resident per workload (0 = 4 for 1080p8, 2 for 2160p10alf)")
+    ap.add_argument("--group", type=int, default=4, help="pictures per group: plane kernels run per picture, RDOQ once per block shape over the group")
     ap.add_argument("--streams", type=int, default=4, help="pictures in flight: consecutive steps go to consecutive streams")
     ap.add_argument("--profile-steps", type=int, default=4, help="untimed, fully instrumented steps for the per-kernel table")
     ap.add_argument("--shard", choices=("rows", "frames"), default="rows",
@@ -400,18 +417,19 @@ def main():
         transport = bands.RcclTransport(rank, world, bootstrap)
 
     wl_name = args.workload
-    n_res = args.resident or (4 if wl_name == "1080p8" else 2)
+    n_res = args.resident or 2                      # resident groups
     r = measure(args, wl_name, L, device, rank, local_rank, world, dist, transport, args.steps, args.warmup, n_res, True)
     extra = None
     if not args.no_extra and wl_name == "1080p8":
         ex_steps = max(8, min(args.steps, 40))
+        ex_steps = (ex_steps + args.group - 1) // args.group * args.group
         extra = measure(args, "2160p10alf", L, device, rank, local_rank, world, dist, transport, ex_steps, min(args.warmup, 4), 2, True)
         extra["steps"] = ex_steps
 
     if rank == 0:
         fr, wl = r["frames"][0], r["wl"]
-        per_kernel, tot_ms = kernel_table(fr, r["prof"], args.profile_steps)
-        live, _ = kernel_table(fr, r["live"], args.steps)
+        per_kernel, tot_ms = kernel_table(fr, r["prof"], r["prof_pics"], r["group"])
+        live, _ = kernel_table(fr, r["live"], args.steps, r["group"])
         fps = r["fps"]
         strong = r["shard_rows"]
         out = {
@@ -424,7 +442,9 @@ def main():
                        "parallelism": (f"CTU rows of every picture over {world} ranks (uvghip_band_plan), RCCL halo exchange + band gather"
                                        if strong else f"frames sharded over {world} rank(s), no data-path collective"),
                        "streams": 1 if args.serial else args.streams, "hipgraph": not args.no_graphs,
-                       "launches_per_step": len(fr.all_launches())},
+                       "pictures_per_group": r["group"],
+                       "note": "steps are pictures; they are issued in groups of pictures_per_group (frame-parallel operation, uvg266 --owf): "
+                               "plane kernels per picture, RDOQ + dequantisation once per block shape over the group"},
         }
         if strong:
             cb = fr.comm_bytes()
@@ -447,21 +467,23 @@ def main():
                     "frac": round(ach / VALU_PEAK_GINST, 4), "achieved_alone": round(ach_alone, 2), "frac_alone": round(ach_alone / VALU_PEAK_GINST, 4),
                     "traffic": hbm["traffic"], "insts_per_launch": insts, "avg_launch_ms": live[dom]["avg_ms"], "serial_avg_launch_ms": alone_ms,
                     "launches_timed": live[dom]["launches"],
-                    "note": "the dominant kernel (rough intra search) is integer-VALU-issue bound, not HBM bound: achieved = SQ_INSTS_VALU per "
-                            "launch (PMC pass, profiles/) / the launch's average duration from HIP events recorded inside the timed region on "
-                            "its own stream, where other pictures' kernels share the GPU; *_alone = the same launch with nothing else running "
-                            "(profile pass); peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 integer instruction "
-                            "(tools/dev/valu_rate.hip).  roofline_hbm carries the HBM view of the same launch"}
+                    "note": ("the dominant kernel family is RDOQ (uvg_rdoq: a sequential walk per transform block, double-precision costs in "
+                             "the reference's order); it is bound by instruction issue, not by HBM: " if dom.startswith("rdoq") else
+                             "the dominant kernel (rough intra search) is integer-VALU-issue bound, not HBM bound: ") +
+                            "achieved = SQ_INSTS_VALU per launch (PMC pass, profiles/) / the launch's average duration from HIP events "
+                            "recorded inside the timed region on its own stream, where other pictures' kernels share the GPU; *_alone = the "
+                            "same launch with nothing else running (profile pass); peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 integer "
+                            "instruction (tools/dev/valu_rate.hip).  roofline_hbm carries the HBM view of the same launch"}
                 out["roofline_hbm"] = hbm
             else:
-                hbm["note"] = "no SQ_INSTS_VALU capture under profiles/ for this workload: HBM view only (the kernel is VALU-bound, DESIGN.md)"
+                hbm["note"] = "no SQ_INSTS_VALU capture under profiles/ for this kernel / workload: HBM view only (the kernel is instruction-issue bound, DESIGN.md)"
                 out["roofline"] = hbm
         out["kernel_sum_ms"] = round(tot_ms, 4)
         out["kernels_timed_region"] = live
         out["kernels"] = per_kernel
         if extra is not None:
             efr, ewl = extra["frames"][0], extra["wl"]
-            ek, etot = kernel_table(efr, extra["prof"], args.profile_steps)
+            ek, etot = kernel_table(efr, extra["prof"], extra["prof_pics"], extra["group"])
             top = sorted(ek.items(), key=lambda kv: -kv[1]["per_step_ms"])[:14]
             out["extra_workloads"] = {"2160p10alf": {
                 "value": round(extra["fps"], 2), "unit": "frames/s", "steps": extra["steps"], "ms_per_step": round(1e3 * extra["elapsed"] / extra["steps"], 3),

@@ -57,12 +57,38 @@ def chroma_qp(qp):
     return qp
 
 
+class TuPool:
+    """Coefficient buffers of a GROUP of F pictures, per (block size, plane): what sits between the per-picture plane
+    kernels and the quantiser, which runs once per group (RDOQ is a long sequential walk per block: only many blocks per
+    launch fill the GPU).  Picture f uses slice f of every buffer."""
+
+    def __init__(self, device, frames):
+        self.device, self.F, self.jobs = device, frames, {}
+
+    def job(self, key, cnt, c):
+        """key = (block size, plane); cnt blocks of c x c per picture."""
+        if key not in self.jobs:
+            F, d = self.F, self.device
+            self.jobs[key] = dict(cnt=cnt, c=c,
+                                  coef=torch.zeros((F, cnt, c, c), dtype=torch.int16, device=d),     # transformed residual
+                                  lev=torch.zeros((F, cnt, c, c), dtype=torch.int16, device=d),      # levels = the reference's coeff_out
+                                  deq=torch.zeros((F, cnt, c, c), dtype=torch.int16, device=d),      # dequantised
+                                  has=torch.zeros((F, cnt), dtype=torch.uint8, device=d),
+                                  ws=torch.empty((F * cnt * c * c + 64,), dtype=torch.float64, device=d))
+        return self.jobs[key]
+
+
 class BandFrame:
-    def __init__(self, L, wl, t, device, modes_dev, rank=0, nranks=1, qp=22, transport=None, poison=False, gather=True):
+    def __init__(self, L, wl, t, device, modes_dev, rank=0, nranks=1, qp=22, transport=None, poison=False, gather=True, pool=None,
+                 slot=0):
         W, H, depth, alf = wl["W"], wl["H"], wl["depth"], wl["alf"]
         self.W, self.H, self.depth, self.alf, self.qp = W, H, depth, alf, qp
         self.rdoq = rdoq = bool(wl.get("rdoq", False))
         self._keep = []                                                     # ctypes parameter blocks referenced by launches
+        self.L, self.device = L, device
+        self.pool = pool if pool is not None else TuPool(device, 1)
+        self.slot = slot
+        self.heads, self.tails = [], []                                     # per block size: launches before / after the quantiser
         self.band = band = BandLayout(H, nranks, rank)
         self.rank, self.nranks = rank, nranks
         y0, y1 = band.y0, band.y1
@@ -89,33 +115,32 @@ class BandFrame:
             cnt = len(own)
             blks, tus = api.make_intra_blocks(own, device), api.make_tus(own[:, :2], device)
             b = {"best": torch.zeros(cnt, dtype=torch.int8, device=device), "cost": torch.zeros(cnt, dtype=torch.int32, device=device),
-                 "pred": plane(self.y), "rec": plane(self.y),
-                 "coeff": torch.zeros((cnt, n, n), dtype=torch.int16, device=device), "has": torch.zeros(cnt, dtype=torch.uint8, device=device)}
+                 "pred": plane(self.y), "rec": plane(self.y)}
             self.tables[n] = (blks, tus, cnt)
-            chain = [
+            head = [
                 (f"intra_search_{n}", L.uvghip_intra_search_best_batch,
                  [depth, P(self.y), ys, P(self.y), ys, n, P(blks), cnt, P(modes_dev), nm, P(b["best"]), P(b["cost"]), None]),
                 (f"intra_pred_plane_{n}", L.uvghip_intra_pred_plane_batch,
                  [depth, P(self.y), ys, n, P(blks), cnt, P(b["best"]), P(b["pred"]), ys]),
-                self._tu_launch(L, f"tu_roundtrip_{n}", 0, n, qps, self.y, b["pred"], b["rec"], tus, cnt, b["coeff"], b["has"], device),
             ]
+            mid, tail = [], []
+            self._tu_launches(f"{n}", 0, n, n, qps, self.y, b["pred"], b["rec"], tus, cnt, head, mid, tail)
             if n >= 8:
                 c = n // 2
                 cown = own // 2                                             # chroma block position and available reference counts
                 cblks, ctus = api.make_intra_blocks(cown, device), api.make_tus(cown[:, :2], device)
                 for name, src in (("u", self.u), ("v", self.v)):
                     b["pred_" + name], b["rec_" + name] = plane(src), plane(src)
-                    b["coeff_" + name] = torch.zeros((cnt, c, c), dtype=torch.int16, device=device)
-                    b["has_" + name] = torch.zeros(cnt, dtype=torch.uint8, device=device)
                 b["cblks"], b["ctus"] = cblks, ctus
                 for name, src in (("u", self.u), ("v", self.v)):
-                    chain.append((f"intra_pred_chroma_{n}", L.uvghip_intra_pred_plane_chroma_batch,
-                                  [depth, P(src), cs, c, P(cblks), cnt, P(b["best"]), P(b["pred_" + name]), cs]))
+                    head.append((f"intra_pred_chroma_{n}", L.uvghip_intra_pred_plane_chroma_batch,
+                                 [depth, P(src), cs, c, P(cblks), cnt, P(b["best"]), P(b["pred_" + name]), cs]))
                 for ci, (name, src) in enumerate((("u", self.u), ("v", self.v))):
-                    chain.append(self._tu_launch(L, f"tu_roundtrip_chroma_{n}", 1 + ci, c, qpc, src, b["pred_" + name], b["rec_" + name], ctus, cnt,
-                                                 b["coeff_" + name], b["has_" + name], device))
+                    self._tu_launches(f"chroma_{n}", 1 + ci, n, c, qpc, src, b["pred_" + name], b["rec_" + name], ctus, cnt, head, mid, tail)
             self.bufs[n] = b
-            self.chains.append(chain if cnt else [])      # a short last band may hold no block of this size
+            # a short last band may hold no block of this size
+            self.heads.append(head if cnt else []); self.tails.append(tail if cnt else [])
+            self.chains.append(head + mid + tail if cnt else [])      # the stand-alone chain of this picture (quantiser on its own slice)
 
         # ---- in-loop filters on the reconstruction of the finest passes (luma 4x4, chroma 4x4 = the N = 8 pass) ----
         self.rec_y, self.rec_u, self.rec_v = self.bufs[4]["rec"], self.bufs[8]["rec_u"], self.bufs[8]["rec_v"]
@@ -197,29 +222,26 @@ class BandFrame:
                 fn, args = transport.allreduce_args(self.alf_sums)
                 self.reduce.append(("allreduce_cov_0", fn, args))
 
-    def _tu_launch(self, L, name, color, n, qp_scaled, orig, pred, rec, tus, cnt, coeff, has, device):
-        """The reconstruction of n x n TUs: medium runs uvg_quantize_residual on its RDOQ branch (cfg.c:781, quant-generic.c:527);
-        without RDOQ the single-launch plain-quant round trip."""
-        P = lambda t_: t_.data_ptr()
+    def _tu_launches(self, tag, color, n, c, qp_scaled, orig, pred, rec, tus, cnt, head, mid, tail):
+        """The reconstruction of the c x c TUs of block size n in one plane.  Medium runs uvg_quantize_residual on its RDOQ
+        branch (cfg.c:781, quant-generic.c:527): residual + transform per picture (head), RDOQ + dequantisation on the picture's
+        slice of the group buffers (mid; a FrameGroup replaces these by one launch over all its pictures), inverse transform +
+        reconstruction per picture (tail).  Without RDOQ: the single-launch plain-quant round trip."""
+        L, P, depth = self.L, (lambda t_: t_.data_ptr()), self.depth
         st = orig.stride(0)
-        if not self.rdoq or cnt == 0:
-            return (name, L.uvghip_tu_roundtrip_batch,
-                    [self.depth, 0, 0, 0, 0, n, n, qp_scaled, 1, P(orig), st, P(pred), st, P(rec), st, P(tus), cnt, P(coeff), P(has)])
-        import ctypes
-        from . import lib as _lib
-        p = _lib.QrParams()
-        p.width = p.height = n
-        p.color, p.qp_scaled, p.slice_is_intra, p.cu_type = color, qp_scaled, 1, 1
-        p.rdoq_enable, p.rdoq_skip = 1, 0
-        lam = intra_lambda(self.qp)
-        p.lambda_ = lam if color == 0 else lam * 0.9
-        ctypes.memmove(p.ctx, synthetic_rdoq_ctx().tobytes(), 244)
-        need = L.uvghip_quantize_residual_workspace_bytes(ctypes.byref(p), cnt)
-        ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=device)
-        self._keep += [p, ws]
-        return (name, L.uvghip_quantize_residual_batch,
-                [self.depth, ctypes.cast(ctypes.pointer(p), ctypes.c_void_p), P(orig), st, P(pred), st, P(rec), st, P(tus), cnt, None, P(coeff), P(has),
-                 P(ws), ws.numel() * 8])
+        if cnt == 0:
+            return
+        j = self.pool.job((n, color), cnt, c)
+        f = self.slot
+        if not self.rdoq:
+            head.append((f"tu_roundtrip_{tag}", L.uvghip_tu_roundtrip_batch,
+                         [depth, 0, 0, 0, 0, c, c, qp_scaled, 1, P(orig), st, P(pred), st, P(rec), st, P(tus), cnt, P(j["lev"][f]), P(j["has"][f])]))
+            return
+        head.append((f"tu_forward_{tag}", L.uvghip_tu_forward_batch,
+                     [depth, 0, 0, 0, 0, c, c, 0, P(orig), st, P(pred), st, P(tus), cnt, P(j["coef"][f])]))
+        mid += quantiser_launches(L, self, tag, color, c, qp_scaled, j, f, 1)
+        tail.append((f"tu_inverse_{tag}", L.uvghip_tu_inverse_batch,
+                     [depth, 0, 0, 0, 0, c, c, 0, P(j["deq"][f]), P(pred), st, P(rec), st, P(tus), cnt]))
 
     # -- what one step moves over xGMI for this rank --
     def comm_bytes(self):
@@ -232,6 +254,7 @@ class BandFrame:
         return (self.stage_a + self.xchg_dbk + self.stage_b + self.xchg_alf + self.stage_c + self.reduce + self.xchg_gather)
 
     def all_launches(self):
+        """This picture on its own (tests, smoke): complete per-size chains, then the filters."""
         return [l for c in self.chains for l in c] + self.filter_launches()
 
 
@@ -242,6 +265,56 @@ def run(launches, stream_handle, L=None):
         rc = fn(*args, stream_handle)
         if rc != 0:
             raise RuntimeError(f"{name} failed ({rc}): {_lib.load_library().uvghip_last_error().decode()}")
+
+
+def quantiser_launches(L, fr, tag, color, c, qp_scaled, job, f0, nf):
+    """RDOQ + dequantisation over pictures [f0, f0 + nf) of a group job."""
+    import ctypes
+    P = lambda t_: t_.data_ptr()
+    if not hasattr(fr, "_rdoq_ctx"):
+        fr._rdoq_ctx = (ctypes.c_uint8 * 244).from_buffer_copy(synthetic_rdoq_ctx().tobytes())
+    lam = intra_lambda(fr.qp) * (1.0 if color == 0 else 0.9)
+    n = nf * job["cnt"]
+    off = lambda t_: t_[f0].data_ptr()
+    return [(f"rdoq_{tag}", L.uvghip_rdoq_batch,
+             [fr.depth, off(job["coef"]), off(job["lev"]), c, c, n, color, 1, 0, 0, 0, qp_scaled, ctypes.c_double(lam),
+              ctypes.cast(fr._rdoq_ctx, ctypes.c_void_p), P(job["ws"]), job["ws"].numel() * 8, None, off(job["has"])]),
+            (f"dequant_{tag}", L.uvghip_dequant_batch, [fr.depth, off(job["lev"]), off(job["deq"]), c, c, n, qp_scaled, 0])]
+
+
+class FrameGroup:
+    """F pictures processed together: the plane kernels run per picture, the quantiser (RDOQ) once per block shape over
+    all F pictures -- the frame-parallel operation of an all-intra encode (uvg266 --owf)."""
+
+    def __init__(self, L, wl, t0, F, device, modes_dev, step=1, **kw):
+        self.pool = TuPool(device, F)
+        self.frames = [BandFrame(L, wl, t0 + f * step, device, modes_dev, pool=self.pool, slot=f, **kw) for f in range(F)]
+        fr = self.frames[0]
+        self.F, self.rdoq = F, fr.rdoq
+        depth = fr.depth
+        qps, qpc = fr.qp + 6 * (depth - 8), chroma_qp(fr.qp) + 6 * (depth - 8)
+        self.mid = []
+        if fr.rdoq:
+            for (n, color), job in self.pool.jobs.items():
+                tag = f"{n}" if color == 0 else f"chroma_{n}"
+                self.mid += quantiser_launches(L, fr, tag, color, job["c"], qps if color == 0 else qpc, job, 0, F)
+
+    def searches(self):
+        return [h[0] for fr in self.frames for h in fr.heads if h]
+
+    def heads_rest(self):
+        """Per picture: predict + residual / forward transform (everything of the heads but the searches)."""
+        return [l for fr in self.frames for h in fr.heads for l in h[1:]]
+
+    def tails(self):
+        return [l for fr in self.frames for tl in fr.tails for l in tl]
+
+    def before_filters(self):
+        """Everything between the searches and the in-loop filters, in an order that respects the dependencies."""
+        return self.heads_rest() + self.mid + self.tails()
+
+    def all_launches(self):
+        return self.searches() + self.before_filters() + [l for fr in self.frames for l in fr.filter_launches()]
 
 
 class Graph:
