@@ -142,7 +142,9 @@ UVGHIP_API int uvghip_residual_plane(int bitdepth, const void *a, int a_stride, 
  * (src/strategies/generic/dct-generic.c:720-750,2560-2678) for n blocks of
  * one shape.  in/out: n contiguous blocks of width*height int16 (row-major,
  * stride = width), exactly the coeff_t buffers the reference passes.
- * width,height in {4,8,16,32}; type_*: UVGHIP_TR_*; skip_width/skip_height:
+ * width,height in {4,8,16,32}, or "thin" blocks with a dimension of 1 or 2 and at most 64 coefficients (ISP sub-partitions,
+ * 2xN chroma of multi-type trees: 2-point DCT-2 and the single-pass 1xN / Nx1 cases, dct-generic.c:1030-1090,2608-2612);
+ * type_*: UVGHIP_TR_*; skip_width/skip_height:
  * the reference's zero-out counts (0 for plain DCT-2; use uvghip_mts_select).
  * Forward truncates to int16, inverse clips, as the reference does. */
 UVGHIP_API int uvghip_transform_batch(int bitdepth, int inverse, int type_hor, int type_ver, int width, int height,

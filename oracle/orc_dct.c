@@ -184,13 +184,15 @@ ORC_EXPORT void ORC_FN(mts_skips)(int width, int height, int hor, int ver, int l
 }
 
 /* The two-pass cores of mts_dct_generic / mts_idct_generic (the `else` branch,
- * dct-generic.c:2602-2617 and :2654-2676) for width, height in {4,8,16,32}. */
+ * dct-generic.c:2602-2617 and :2654-2676) for width, height in {1,2,4,8,16,32} (1- and 2-point lines: DCT-2 only). */
 ORC_EXPORT void ORC_FN(tr_forward)(int bitdepth, int hor, int ver, int width, int height,
                                    int skip_w, int skip_h, const int16_t *in, int16_t *out)
 {
   int16_t tmp[32 * 32];
   const int s1 = orc_log2i(width) - 1 + bitdepth - 8;
   const int s2 = orc_log2i(height) - 1 + 7;
+  if (height == 1) { fwd_1d(hor, width, in, out, s1, 1, 0, skip_w); return; }                        /* dct-generic.c:2608-2609 */
+  if (width == 1) { fwd_1d(ver, height, in, out, orc_log2i(height) - 1 + 1 + bitdepth + 6 - 15, 1, 0, skip_h); return; }   /* :2610-2612 */
   fwd_1d(hor, width, in, tmp, s1, height, 0, skip_w);
   fwd_1d(ver, height, tmp, out, s2, width, skip_w, skip_h);
 }
@@ -200,6 +202,8 @@ ORC_EXPORT void ORC_FN(tr_inverse)(int bitdepth, int hor, int ver, int width, in
 {
   int16_t tmp[32 * 32];
   const int s1 = 7, s2 = 20 - bitdepth;
+  if (height == 1) { inv_1d(hor, width, in, out, s2 + 1, 1, 0, skip_w); return; }                     /* dct-generic.c:2669-2670 */
+  if (width == 1) { inv_1d(ver, height, in, out, s2 + 1, 1, 0, skip_h); return; }                      /* :2671-2672 */
   inv_1d(ver, height, in, tmp, s1, width, skip_w, skip_h);
   inv_1d(hor, width, tmp, out, s2, height, 0, skip_w);
 }

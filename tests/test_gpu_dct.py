@@ -115,3 +115,31 @@ def test_full_size_roundtrip_property(hip):
     assert int((y.int() - x.int()).abs().max()) <= 2
     c = api.transform_batch(torch.full((4, 8, 8), 7, dtype=torch.int16).cuda(), 8)
     assert int(c[:, 0, 0].float().std()) == 0 and int(c.flatten(1)[:, 1:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_thin_blocks(hip, orc, depth):
+    """Blocks with a dimension of 1 or 2 through uvghip_transform_batch and through the registered mts_dct / mts_idct
+    pointers (which used to abort on them), vs the reference-run vectors and the oracle."""
+    import ctypes
+    import torch
+    from uvg266_amd import api
+    from test_oracle_dct import thin_goldens
+    reg = Registry(hip)
+    assert hip.uvg_strategy_register_dct_hip(None, depth) == 1
+    sig = ctypes.CFUNCTYPE(None, I8, I, VP, I8, I8, VP, VP, I8)
+    f_fwd, f_inv = sig(reg.table["mts_dct"]), sig(reg.table["mts_idct"])
+    cu = (ctypes.c_uint8 * 40)()                     # cu_info_t mirror: type in the low 3 bits of byte 0, isp_mode at intra.isp_mode
+    seen = 0
+    for w, h, inverse, isp, mts_type, src, want in thin_goldens(depth):
+        hor, ver, sw, sh = api.mts_select(w, h, 0, 1, isp, 0, 0, 0, mts_type)
+        got = api.transform_batch(torch.from_numpy(np.stack([src.reshape(h, w)] * 3)).cuda(), depth, bool(inverse), hor, ver, sw, sh)
+        assert np.array_equal(got[2].cpu().numpy().ravel(), want), (w, h, inverse, isp, mts_type)
+        ctypes.memset(cu, 0, 40)
+        cu[0] = 1                                    # CU_INTRA
+        cu[25] = isp                                 # intra.isp_mode: offsetof(cu_info_t, intra) = 20, + mode, mode_chroma, multi_ref_idx, mip_flag, mip_is_transposed
+        out = np.full(w * h, 0x1111, np.int16)
+        (f_inv if inverse else f_fwd)(depth, 0, ctypes.cast(cu, VP), w, h, H.ptr(np.ascontiguousarray(src)), H.ptr(out), mts_type)
+        assert np.array_equal(out, want), ("registered", w, h, inverse, isp, mts_type)
+        seen += 1
+    assert seen == 80

@@ -65,3 +65,37 @@ def test_empty_batches_are_noops(hip):
     assert hip.uvghip_alf_stats_batch(8, _p(y), 64, _p(y), 64, 64, 64, 0, _p(blks), 0, None, 0, _p(out), _p(out), _p(out), None) == 0
     torch.cuda.synchronize()
     assert torch.all(out == 55)
+
+
+def test_unsupported_bit_depth_is_refused(hip):
+    """Every entry point that picks the pixel type from `bitdepth` refuses anything but 8 and 10 (12 used to be treated as 10)."""
+    from uvg266_amd import api
+    y = torch.zeros((64, 64), dtype=torch.uint8, device="cuda")
+    out = torch.full((4,), 77, dtype=torch.int32, device="cuda")
+    blks = api.make_blocks([[0, 0]], [[0, 0]])
+    ib = api.make_intra_blocks([[0, 0, 0, 0]])
+    modes = api.make_modes([0])
+    calls = [
+        ("uvghip_sad_batch", (12, _p(y), 64, _p(y), 64, 64, 64, 8, 8, _p(blks), 1, _p(out), None)),
+        ("uvghip_satd_batch", (12, _p(y), 64, _p(y), 64, 64, 64, 8, 8, _p(blks), 1, _p(out), None)),
+        ("uvghip_ssd_batch", (9, _p(y), 64, _p(y), 64, 8, 8, _p(blks), 1, _p(out), None)),
+        ("uvghip_mc_batch", (12, _p(y), 64, 64, 64, 0, 8, 8, _p(blks), 1, 0, _p(out), None)),
+        ("uvghip_intra_pred_batch", (12, _p(y), 64, 0, 8, 8, _p(ib), 1, _p(modes), 1, _p(out), None)),
+        ("uvghip_deblock_frame", (12, _p(y), 64, None, None, 0, 64, 64, _p(blks), 16, 0, 0, 0, 22, None, None)),
+        ("uvghip_transform_batch", (12, 0, 0, 0, 8, 8, 0, 0, _p(y), _p(y), 1, None)),
+        ("uvghip_sao_stats_batch", (12, _p(y), 64, _p(y), 64, _p(blks), 1, _p(out), _p(out), None)),
+        ("uvghip_alf_classify_frame", (12, _p(y), 64, 64, 64, 12, _p(out), 16, None)),
+    ]
+    for name, args in calls:
+        fn = getattr(hip, name)
+        assert len(args) == len(fn.argtypes), name
+        assert fn(*args) != 0, name
+    torch.cuda.synchronize()
+    assert torch.all(out == 77)
+
+
+def test_tiny_quant_blocks_are_refused(hip):
+    """Blocks of fewer than 8 coefficients make the dequantiser's rounding shift non-positive."""
+    c = torch.zeros((4, 2, 2), dtype=torch.int16, device="cuda")
+    assert hip.uvghip_quant_batch(8, _p(c), _p(c), 2, 2, 4, 22, 0, 1, None) != 0
+    assert hip.uvghip_dequant_batch(8, _p(c), _p(c), 1, 2, 4, 22, 0, None) != 0

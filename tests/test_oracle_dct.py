@@ -49,3 +49,26 @@ def test_square_equals_mts_path_without_skips(orc):
         x = rng.integers(-1023, 1024, n * n).astype(np.int16)
         assert np.array_equal(orc.dct_nxn(10, 10, n, x), orc.tr(10, 10, False, 0, 0, n, n, 0, 0, x))
         assert np.array_equal(orc.dct_nxn(10, 10, n, x, True), orc.tr(10, 10, True, 0, 0, n, n, 0, 0, x))
+
+
+def thin_goldens(depth):
+    out = []
+    for name, arrs in H.read_golden("rdoq", depth):
+        if name == "thin":
+            meta, src, want = arrs
+            w, h, inverse, isp, mts_type, bd = (int(v) for v in meta)
+            out.append((w, h, inverse, isp, mts_type, src, want))
+    return out
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_thin_blocks_vs_reference(orc, depth):
+    """1xN / Nx1 / 2xN / Nx2 blocks (ISP, 2xN chroma): mts_dct_generic's 2-point DCT-2 and single-pass cases."""
+    g = thin_goldens(depth)
+    assert len(g) == 80
+    shapes = set()
+    for w, h, inverse, isp, mts_type, src, want in g:
+        got = orc.mts_dct(depth, depth, 0, 1, 0, isp, 0, 0, 0, w, h, src, mts_type, inverse)
+        assert np.array_equal(got, want), (w, h, inverse, isp, mts_type)
+        shapes.add((w, h))
+    assert len(shapes) >= 12

@@ -170,6 +170,7 @@ extern "C" int uvghip_alf_filter_batch(int bitdepth, const void *src, int src_st
                                        int cls_stride, void *stream)
 {
   UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
   if (n <= 0) return 0;
   hipStream_t st = uvghip_stream(stream);
 #define F(PX, C) alf_filter_kernel<PX, C><<<n * ALF_FILTER_SPLIT, 256, 0, st>>>((const PX *)src, src_stride, (PX *)dst, dst_stride, pic_w, pic_h, rects, set_idx, coef_sets, clip_sets, cls, cls_stride)

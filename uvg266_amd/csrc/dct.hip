@@ -73,6 +73,80 @@ transform_kernel(tr_params P, int inverse, const int16_t *__restrict__ in, int16
   }
 }
 
+// ---- thin blocks: a dimension of 1 or 2 (ISP sub-partitions, 2xN chroma from multi-type trees) ----
+// mts_dct_generic / mts_idct_generic handle them with the 2-point DCT-2 (dct_table[DCT2][0], dct-generic.c:1030-1090) and,
+// for a dimension of 1, a single 1-D pass with its own shift (:2608-2612, :2669-2673).  Rare and tiny: one 64-thread
+// workgroup per block, plain loops, the intermediate in LDS.
+__device__ __forceinline__ int thin_coef(int type, int n, int row, int col)
+{
+  if (n == 2) return row == 1 && col == 1 ? -64 : 64;                 // uvg_g_DCT2P2 = {64, 64, 64, -64}
+  return tr_matrix_dev(type, n)[row * n + col];
+}
+
+// forward 1-D over `line` rows of n samples: dst[j * line + i] (the reference's transposed hand-off); inverse: dst[i * n + j]
+__device__ inline void thin_pass(bool inverse, int type, int n, const int16_t *src, int16_t *dst, int shift, int line, int skip_line,
+                                 int skip_line2)
+{
+  const int add = shift > 0 ? 1 << (shift - 1) : 0;
+  const int reduced = line - skip_line;
+  const int cut_f = (!inverse && type != TR_DCT2 && n >= 8) ? n - skip_line2 : n;      // which kernels honour skip_line2: transform_dev.h
+  const int kmax_i = (inverse && type != TR_DCT2 && n == 8) ? n - skip_line2 : n;
+  for (int e = threadIdx.x; e < n * line; e += blockDim.x) {
+    int v = 0;
+    if (!inverse) {
+      const int j = e / line, i = e - j * line;
+      if (j < cut_f && i < reduced) {
+        int acc = 0;
+        for (int k = 0; k < n; ++k) acc += thin_coef(type, n, j, k) * src[i * n + k];
+        v = (int)(int16_t)((acc + add) >> shift);
+      }
+      dst[j * line + i] = (int16_t)v;
+    } else {
+      const int i = e / n, j = e - i * n;
+      if (i < reduced) {
+        int acc = 0;
+        for (int k = 0; k < kmax_i; ++k) acc += src[k * line + i] * thin_coef(type, n, k, j);
+        v = clampi((acc + add) >> shift, -32768, 32767);
+      }
+      dst[i * n + j] = (int16_t)v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64)
+transform_thin_kernel(int bitdepth, int inverse, int type_hor, int type_ver, int w, int h, int skip_w, int skip_h,
+                      const int16_t *__restrict__ in, int16_t *__restrict__ out)
+{
+  __shared__ int16_t sIn[64], sTmp[64], sOut[64];
+  const int wh = w * h;
+  const int16_t *gin = in + (size_t)blockIdx.x * wh;
+  int16_t *gout = out + (size_t)blockIdx.x * wh;
+  for (int e = threadIdx.x; e < wh; e += blockDim.x) sIn[e] = gin[e];
+  __syncthreads();
+  const int lw = 31 - __clz(w), lh = 31 - __clz(h);
+  if (!inverse) {
+    const int s1 = lw - 1 + bitdepth - 8, s2 = lh - 1 + 7;
+    if (h == 1) thin_pass(false, type_hor, w, sIn, sOut, s1, 1, 0, skip_w);
+    else if (w == 1) thin_pass(false, type_ver, h, sIn, sOut, lh - 1 + 1 + bitdepth + 6 - 15, 1, 0, skip_h);
+    else {
+      thin_pass(false, type_hor, w, sIn, sTmp, s1, h, 0, skip_w);
+      __syncthreads();
+      thin_pass(false, type_ver, h, sTmp, sOut, s2, w, skip_w, skip_h);
+    }
+  } else {
+    const int s1 = 7, s2 = 20 - bitdepth;
+    if (h == 1) thin_pass(true, type_hor, w, sIn, sOut, s2 + 1, 1, 0, skip_w);
+    else if (w == 1) thin_pass(true, type_ver, h, sIn, sOut, s2 + 1, 1, 0, skip_h);
+    else {
+      thin_pass(true, type_ver, h, sIn, sTmp, s1, w, skip_w, skip_h);
+      __syncthreads();
+      thin_pass(true, type_hor, w, sTmp, sOut, s2, h, 0, skip_w);
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < wh; e += blockDim.x) gout[e] = sOut[e];
+}
+
 int uvghip_launch_tr_lane(const tr_params &P, bool inverse, const int16_t *in, int16_t *out, int n, hipStream_t st);   // quant.hip
 int uvghip_launch_tr_wave(const tr_params &P, bool inverse, const int16_t *in, int16_t *out, int n, hipStream_t st);
 
@@ -81,6 +155,20 @@ extern "C" int uvghip_transform_batch(int bitdepth, int inverse, int type_hor, i
                                       void *stream)
 {
   UVGHIP_REQUIRE_READY();
+  if (bitdepth != 8 && bitdepth != 10) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  {
+    // thin blocks (a dimension of 1 or 2, the other 1..32): ISP / 2xN chroma.  Only DCT-2 exists for 1- and 2-point lines.
+    auto pow2_le32 = [](int v) { return v >= 1 && v <= 32 && !(v & (v - 1)); };
+    if (pow2_le32(width) && pow2_le32(height) && (width <= 2 || height <= 2)) {
+      if ((width <= 2 && type_hor != TR_DCT2) || (height <= 2 && type_ver != TR_DCT2) || type_hor < 0 || type_hor > 2 || type_ver < 0 ||
+          type_ver > 2 || skip_width < 0 || skip_width >= width || skip_height < 0 || skip_height >= height || width * height > 64)
+        return uvghip_set_error(hipErrorInvalidValue, __func__);
+      if (n <= 0) return 0;
+      transform_thin_kernel<<<n, 64, 0, uvghip_stream(stream)>>>(bitdepth, inverse != 0, type_hor, type_ver, width, height, skip_width,
+                                                                 skip_height, in, out);
+      UVGHIP_CHECK_LAUNCH();
+    }
+  }
   if (!tr_valid_dim(width) || !tr_valid_dim(height) || type_hor < 0 || type_hor > 2 || type_ver < 0 || type_ver > 2 ||
       skip_width < 0 || skip_width >= width || skip_height < 0 || skip_height >= height ||
       (skip_width & 3) || (skip_height & 3))

@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "uvghip_common.h"
+#include <mutex>
 #include "percall.h"
 #include "ref_abi.h"
 #include "satd_dev.h"
@@ -363,6 +364,7 @@ extern "C" int uvghip_intra_pred_batch(int bitdepth, const void *rec, int rec_st
                                        void *preds_out, void *stream)
 {
   UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
   auto ok = [](int v) { return v == 4 || v == 8 || v == 16 || v == 32; };
   if (!ok(width) || !ok(height) || n_modes < 1 || n_modes > 128) return uvghip_set_error(hipErrorInvalidValue, __func__);
   if (n <= 0) return 0;
@@ -1228,8 +1230,13 @@ static int launch_intra_search(int bitdepth, const void *rec, int rec_stride, co
   hipStream_t st = uvghip_stream(stream);
   // 8x8 tiles: 8 waves per workgroup (two workgroups per CU = 4 waves per SIMD); 4x4: 4 waves, many workgroups
 #define LAUNCH(PX, T, W, B, NF) do { const search_layout L = make_search_layout(size, bpg, n_modes, W, (int)sizeof(PX)); \
-    static bool big_lds = false; /* allow more than the default 64 KiB of dynamic LDS, once per instantiation */ \
-    if (!big_lds) { UVGHIP_TRY(hipFuncSetAttribute((const void *)intra_search_kernel<PX, T, W, B, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); big_lds = true; } \
+    /* allow more than the default 64 KiB of dynamic LDS: once per instantiation AND device (the attribute is per device; \
+       strategy pointers are entered concurrently from all worker threads, threadqueue.c:275) */ \
+    { static std::mutex lds_m; static uint64_t lds_done = 0; int dev_ = 0; UVGHIP_TRY(hipGetDevice(&dev_)); \
+      std::lock_guard<std::mutex> lk_(lds_m); \
+      if (!((lds_done >> (dev_ & 63)) & 1)) { \
+        UVGHIP_TRY(hipFuncSetAttribute((const void *)intra_search_kernel<PX, T, W, B, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        lds_done |= 1ull << (dev_ & 63); } } \
     if (getenv("UVGHIP_DEBUG_OCC")) { int nb = -1; hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, intra_search_kernel<PX, T, W, B, NF>, W * 64, L.total); \
       fprintf(stderr, "intra_search<%d,%d,%d> size %d: lds %zu grid %d occupancy %d blocks/CU (err %d)\n", (int)sizeof(PX), T, W, size, (size_t)L.total, grid, nb, (int)oe); } \
     intra_search_kernel<PX, T, W, B, NF><<<grid, W * 64, L.total, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, blks, n, modes, n_modes, costs, best_mode, best_cost); } while (0)

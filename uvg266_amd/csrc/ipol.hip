@@ -82,6 +82,7 @@ extern "C" int uvghip_mc_batch(int bitdepth, const void *ref, int ref_stride, in
                                int width, int height, const uvghip_mc_blk_t *blks, int n, int hi, void *dst, void *stream)
 {
   UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
   if (width < 1 || height < 1 || width > 64 || height > 64) return uvghip_set_error(hipErrorInvalidValue, __func__);
   if (n <= 0) return 0;
   const int taps = is_chroma ? 4 : 8;
@@ -255,6 +256,7 @@ extern "C" int uvghip_frac_satd_batch(int bitdepth, const void *cur, int cur_str
                                       const int16_t *cand_mv, int n_cand, uint32_t *costs, void *stream)
 {
   UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
   if (width < 4 || height < 4 || (width & 3) || (height & 3) || width > 64 || height > 64 || n_cand < 1)
     return uvghip_set_error(hipErrorInvalidValue, __func__);
   if (n <= 0) return 0;
@@ -301,6 +303,7 @@ extern "C" int uvghip_bipred_average_batch(int bitdepth, const void *l0, const v
                                            void *dst, void *stream)
 {
   UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
   if (total == 0) return 0;
   const unsigned grid = (unsigned)((total + 255) / 256);
   hipStream_t st = uvghip_stream(stream);

@@ -119,6 +119,7 @@ extern "C" int uvghip_sad_batch(int bitdepth, const void *cur, int cur_stride, c
                                 uint32_t *out, void *stream)
 {
   UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
   if (bw < 1 || bh < 1 || bw > 128 || bh > 128) return uvghip_set_error(hipErrorInvalidValue, __func__);
   return bitdepth == 8 ? launch_sad<uint8_t>(cur, cur_stride, ref, ref_stride, ref_w, ref_h, bw, bh, blks, n, out, 1, uvghip_stream(stream))
                        : launch_sad<uint16_t>(cur, cur_stride, ref, ref_stride, ref_w, ref_h, bw, bh, blks, n, out, 1, uvghip_stream(stream));
@@ -194,6 +195,7 @@ extern "C" int uvghip_satd_batch(int bitdepth, const void *cur, int cur_stride, 
                                  uint32_t *out, void *stream)
 {
   UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
   if (bw < 4 || bh < 4 || (bw & 3) || (bh & 3) || bw > 128 || bh > 128)
     return uvghip_set_error(hipErrorInvalidValue, __func__);
   return bitdepth == 8 ? launch_satd<uint8_t>(cur, cur_stride, ref, ref_stride, ref_w, ref_h, bw, bh, blks, n, out, 1, 0, uvghip_stream(stream))
@@ -230,6 +232,7 @@ extern "C" int uvghip_ssd_batch(int bitdepth, const void *a, int a_stride, const
                                 int bw, int bh, const uvghip_blk_t *blks, int n, uint32_t *out, void *stream)
 {
   UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
   if (n <= 0) return 0;
   int lpb = pow2ceil(bw * bh); if (lpb > 64) lpb = 64;
   const int bpw = 64 / lpb, waves = (n + bpw - 1) / bpw, grid = (waves + 3) / 4;
@@ -265,6 +268,7 @@ extern "C" int uvghip_residual_plane(int bitdepth, const void *a, int a_stride, 
                                      int16_t *res, int res_stride, int w, int h, void *stream)
 {
   UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
   if (w <= 0 || h <= 0) return 0;
   dim3 grid(((w + 3) / 4 + 255) / 256, h);
   hipStream_t st = uvghip_stream(stream);
@@ -445,6 +449,7 @@ extern "C" int uvghip_sad_surface(int bitdepth, const void *cur, int cur_stride,
                                   int w, int h, int bw, int bh, int range, uint32_t *out, void *stream)
 {
   UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
   if (bw < 4 || bh < 4 || bw > 64 || bh > 64 || range < 0 || range > 64 || w < bw || h < bh)
     return uvghip_set_error(hipErrorInvalidValue, __func__);
   const int blocks_x = w / bw, blocks_y = h / bh;

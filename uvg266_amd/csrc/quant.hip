@@ -84,7 +84,9 @@ quant_kernel(const int16_t *__restrict__ in, int16_t *__restrict__ out, size_t t
 
 static int check_qargs(int bitdepth, int width, int height, int qp_scaled)
 {
-  if ((bitdepth != 8 && bitdepth != 10) || width < 1 || height < 1 || width > 64 || height > 64 ||
+  // at least 8 coefficients: below that the dequantiser's shift (20 - 14 - transform_shift) is not positive and its rounding
+  // term 1 << (shift - 1) is undefined (the reference has the same latent problem, quant-generic.c:655)
+  if ((bitdepth != 8 && bitdepth != 10) || width < 1 || height < 1 || width > 64 || height > 64 || width * height < 8 ||
       (width & (width - 1)) || (height & (height - 1)) || qp_scaled < 0 || qp_scaled > 63 + 12)
     return uvghip_set_error(hipErrorInvalidValue, "quant arguments");
   return 0;
@@ -787,6 +789,8 @@ extern "C" int uvghip_tu_roundtrip_batch(int bitdepth, int type_hor, int type_ve
       skip_width < 0 || skip_width >= width || skip_height < 0 || skip_height >= height)
     return uvghip_set_error(hipErrorInvalidValue, __func__);
   if (int rc = check_qargs(bitdepth, width, height, qp_scaled)) return rc;
+  // as uvghip_transform_batch: zero-out counts in units of 4, and the level buffer is written with 8 / 16 byte stores
+  if ((skip_width & 3) || (skip_height & 3) || ((uintptr_t)coeff_out & 15)) return uvghip_set_error(hipErrorInvalidValue, __func__);
   if (n <= 0) return 0;
   const tr_params P = tr_make_params(bitdepth, type_hor, type_ver, width, height, skip_width, skip_height);
   const quant_params Q = make_quant_params(bitdepth, width, height, qp_scaled, 0, slice_is_intra);

@@ -128,6 +128,7 @@ extern "C" int uvghip_sao_stats_batch(int bitdepth, const void *orig, int orig_s
                                       void *stream)
 {
   UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
   if (n <= 0) return 0;
   hipStream_t st = uvghip_stream(stream);
   if (bitdepth == 8) sao_stats_kernel<uint8_t><<<n, 256, 0, st>>>((const uint8_t *)orig, orig_stride, (const uint8_t *)rec, rec_stride, rects, edge_stats, band_stats);
@@ -214,6 +215,7 @@ extern "C" int uvghip_sao_apply_batch(int bitdepth, const void *rec, int rec_str
                                       const uvghip_sao_param_t *params, int n, void *stream)
 {
   UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
   if (n <= 0) return 0;
   hipStream_t st = uvghip_stream(stream);
   if (bitdepth == 8) sao_apply_kernel<uint8_t><<<n, 256, 0, st>>>((const uint8_t *)rec, rec_stride, (uint8_t *)out, out_stride, pic_w, pic_h, rects, params);

@@ -15,6 +15,12 @@ bool uvghip_ready();
     if (!uvghip_ready()) return uvghip_set_error(hipErrorNotInitialized, __func__); \
   } while (0)
 
+// every entry point that selects the pixel type from `bitdepth` refuses anything but the two depths the library is built for
+#define UVGHIP_REQUIRE_DEPTH(bd)                                                   \
+  do {                                                                             \
+    if ((bd) != 8 && (bd) != 10) return uvghip_set_error(hipErrorInvalidValue, __func__); \
+  } while (0)
+
 #define UVGHIP_CHECK_LAUNCH()                                         \
   do {                                                                \
     hipError_t e__ = hipGetLastError();                               \
