@@ -110,7 +110,8 @@ def _ipol_registry(hip, depth):
     assert set(reg.table) == {"filter_hpel_blocks_hor_ver_luma", "filter_hpel_blocks_diag_luma",
                               "filter_qpel_blocks_hor_ver_luma", "filter_qpel_blocks_diag_luma",
                               "sample_quarterpel_luma", "sample_octpel_chroma",
-                              "sample_quarterpel_luma_hi", "sample_octpel_chroma_hi"}
+                              "sample_quarterpel_luma_hi", "sample_octpel_chroma_hi",
+                              "get_extended_block", "get_extended_block_wraparound"}      # all ten of strategies-ipol.h:116-139
     return reg
 
 
