@@ -283,6 +283,7 @@ typedef struct uvghip_qr_params {
  * uvghip_tu_roundtrip_batch is the single-launch form of the plain-quant / no-LFNST branch.  lfnst_tus: device array of
  * n entries for uvghip_lfnst_batch, or NULL where the LFNST transform does not apply (cfg.lfnst off, inter CU, chroma of
  * a single tree: uvg_fwd_lfnst, transform.c:988).  p: HOST pointer. */
+struct uvghip_lfnst_tu;   /* defined in the LFNST section below */
 UVGHIP_API size_t uvghip_quantize_residual_workspace_bytes(const uvghip_qr_params_t *p, int n);
 UVGHIP_API int uvghip_quantize_residual_batch(int bitdepth, const uvghip_qr_params_t *p, const void *orig, int orig_stride,
                                    const void *pred, int pred_stride, void *rec, int rec_stride, const uvghip_tu_t *tus,
@@ -630,6 +631,54 @@ UVGHIP_API int uvghip_comm_exchange(void *comm, const uvghip_xfer_t *xfers_host,
 UVGHIP_API int uvghip_comm_allreduce_i64(void *comm, int64_t *buf, size_t count, void *stream);
 /* ncclAllGather of equal-sized contributions (bytes_per_rank each). */
 UVGHIP_API int uvghip_comm_allgather(void *comm, const void *send, void *recv, size_t bytes_per_rank, void *stream);
+
+/* ------------- (3) per-call entry points behind plain-value views (state-taking strategies) ------------- */
+
+/* The reference typedefs of quant / dequant / quantize_residual (strategies-quant.h:48-86) and inter_recon_bipred
+ * (strategies-picture.h:136-148) take encoder_state_t* / cu_info_t* / lcu_t*: encoder-private structs whose layout
+ * depends on the encoder's compile options.  The typedef-exact functions therefore live in a shim compiled in the encoder
+ * tree (uvg266_amd/csrc/shim/strategies-hip-state.c) that does nothing but copy the fields
+ * below out of those structs; everything else is behind these functions.  HOST buffers in and out, synchronous,
+ * re-entrant from any number of threads (each thread owns a stream and a staging arena). */
+typedef struct uvghip_state_view {
+  int32_t bitdepth;                 /* encoder_control->bitdepth */
+  int32_t qp;                       /* state->qp */
+  int32_t slice_is_intra;           /* state->frame->slicetype == UVG_SLICE_I */
+  int32_t rdoq_enable, rdoq_skip;   /* cfg.rdoq_enable, cfg.rdoq_skip */
+  int32_t dep_quant, signhide_enable, scaling_list_enabled;   /* cfg.dep_quant, cfg.signhide_enable, scaling_list.enable:
+                                                               * must all be 0 (the registrar of the shim checks) */
+  int32_t lfnst, mts;               /* cfg.lfnst, cfg.mts (enum uvg_mts) */
+  int32_t lmcs_chroma_adj_enabled;  /* lmcs_aps->m_sliceReshapeInfo.enableChromaAdj: must be 0 for chroma calls */
+  int32_t collocated_luma_mode;     /* state->collocated_luma_mode (LFNST of a CCLM chroma block) */
+  double lambda, c_lambda;          /* state->lambda, state->c_lambda */
+  int8_t qp_map[64];                /* encoder_control->qp_map[0] */
+  uvghip_rdoq_ctx_t cabac;          /* CTX_STATE of state->cabac.ctx's models (RDOQ only) */
+} uvghip_state_view_t;
+
+typedef struct uvghip_cu_view {     /* cu_info_t (src/cu.h:134-198), the fields uvg_quantize_residual's callees read */
+  int8_t type;                      /* cu_type_t: 1 intra, 2 inter */
+  int8_t tr_idx, lfnst_idx, cr_lfnst_idx;
+  int8_t log2_width, log2_height;
+  int8_t intra_mode, intra_mode_chroma, mip_flag, isp_mode;   /* intra.* (read only when type == 1) */
+  uint16_t cbf;
+} uvghip_cu_view_t;
+
+/* uvg_quant (quant-generic.c:51-232) / uvg_dequant (:618-669) for one block. */
+UVGHIP_API unsigned uvghip_quant_percall(const uvghip_state_view_t *sv, const int16_t *coef, int16_t *q_coef, int32_t width,
+                                         int32_t height, int color, int scan_idx, int block_type, int transform_skip,
+                                         int lfnst_idx);
+UVGHIP_API unsigned uvghip_dequant_percall(const uvghip_state_view_t *sv, const int16_t *q_coef, int16_t *coef, int32_t width,
+                                           int32_t height, int color, int block_type, int transform_skip);
+/* uvg_quantize_residual (quant-generic.c:460-612) for one TU: returns has_coeffs, writes coeff_out (width*height) and
+ * rec_out (reconstruction, or the prediction when nothing was coded / early_skip).  tree_type: enum uvg_tree_type. */
+UVGHIP_API int uvghip_quantize_residual_percall(const uvghip_state_view_t *sv, const uvghip_cu_view_t *cu, int width, int height,
+                                                int color, int scan_order, int use_trskip, int in_stride, int out_stride,
+                                                const void *ref_in, const void *pred_in, void *rec_out, int16_t *coeff_out,
+                                                int early_skip, int lmcs_chroma_adj, int tree_type);
+/* One plane of bipred_average_generic (picture-generic.c:1195-1262): dst rows of pu_w samples at dst_stride; l0 / l1 are
+ * pu_w*pu_h contiguous samples -- pixels, or 14-bit int16 intermediates where *_is_im. */
+UVGHIP_API void uvghip_bipred_average_percall(int bitdepth, void *dst, int dst_stride, const void *l0, int l0_is_im,
+                                              const void *l1, int l1_is_im, unsigned pu_w, unsigned pu_h);
 
 #ifdef __cplusplus
 }

@@ -379,3 +379,28 @@ def zorder_avail(x, y, n, pic_w, pic_h, ctu=64):
     while al < 2 * n and coded(x - 1, y + al):
         al += 4
     return min(at, 2 * n, pic_w - x), min(al, 2 * n, pic_h - y)
+
+
+# ---- records of the encoder-tree shim run against recording stand-ins (tools/refcheck/rc_shim.inc) ----
+def shim_goldens(depth):
+    """-> dict of lists: 'sq' (quant / dequant), 'sqr' (quantize_residual), 'sbp' (bipred plane calls).  The views are the bytes
+    the shim extracted from the reference's encoder_state_t / cu_info_t; the expectations are the generic strategies' results."""
+    from uvg266_amd.lib import StateView, CuView
+    px = px_dtype(depth)
+    out = {"sq": [], "sqr": [], "sbp": []}
+    for name, a in read_golden("shim", depth):
+        if name == "sq":
+            m = [int(v) for v in a[0]]
+            out["sq"].append(dict(inverse=m[0], w=m[1], h=m[2], color=m[3], scan_idx=m[4], block_type=m[5], ts=m[6], lfnst=m[7],
+                                  sv=StateView.from_buffer_copy(a[1].tobytes()), src=a[2], want=a[3]))
+        elif name == "sqr":
+            m = [int(v) for v in a[0]]
+            w, h, si, so = m[0], m[1], m[5], m[6]
+            out["sqr"].append(dict(w=w, h=h, color=m[2], scan_order=m[3], trskip=m[4], in_stride=si, out_stride=so, early_skip=m[7],
+                                   lmcs_adj=m[8], tree=m[9], has=m[10], branch=m[11], sv=StateView.from_buffer_copy(a[1].tobytes()),
+                                   cv=CuView.from_buffer_copy(a[2].tobytes()), ref=a[3].view(px) if a[3].dtype != px else a[3],
+                                   pred=a[4], q=a[5], rec=a[6]))
+        elif name == "sbp":
+            m = [int(v) for v in a[0]]
+            out["sbp"].append(dict(stride=m[0], i0=m[1], i1=m[2], w=m[3], h=m[4], l0=a[1], l1=a[2], want=a[3]))
+    return out

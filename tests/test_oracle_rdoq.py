@@ -88,19 +88,21 @@ def oracle_quantize_residual(orc, d, c):
     w, h, color = c["w"], c["h"], c["color"]
     res = (c["ref"][:h, :w].astype(np.int32) - c["pred"][:h, :w].astype(np.int32)).astype(np.int16).ravel()
     intra_cu, inter_cu = int(c["cu_type"] == 1), int(c["cu_type"] == 2)
-    idx = c["lfnst"]                              # cu.lfnst_idx = lfnst_index of quant-generic.c:505 (single tree)
+    idx = c["lfnst"]                              # lfnst_index of quant-generic.c:505 (cu.lfnst_idx, or cr_lfnst_idx: chroma tree)
     lw, lh = w.bit_length() - 1, h.bit_length() - 1
-    # the LFNST transform itself: cfg.lfnst && intra (:507), luma or a separate tree (transform.c:982,988; the harness CU is
-    # the TU for luma and twice its size for chroma, so chroma never qualifies)
-    lf = idx if (intra_cu and color == 0) else 0
-    hor, ver, sw, sh = orc.mts_select(d, w, h, color, intra_cu, inter_cu, 0, idx, 0, 0, 0)
-    if hor == 0 and ver == 0 and not idx and w == h:
+    # the LFNST transform itself: cfg.lfnst && intra (:507), luma or a separate tree (transform.c:982,988; the "qr" harness CU
+    # is the TU for luma and twice its size for chroma, so chroma never qualifies there).  The shim records say explicitly.
+    lf = c["lf_apply"] if "lf_apply" in c else (idx if (intra_cu and color == 0) else 0)
+    clw, clh = c.get("lf_log2", (lw, lh))
+    hor, ver, sw, sh = orc.mts_select(d, w, h, color, intra_cu, inter_cu, 0, c.get("cu_lfnst", idx), c.get("cu_cr_lfnst", 0),
+                                      c.get("tr_idx", 0), c.get("mts", 0))
+    if hor == 0 and ver == 0 and not (c.get("cu_lfnst", idx) if color == 0 else c.get("cu_cr_lfnst", 0)) and w == h and not c.get("mts", 0):
         sw = sh = 0
     coef = res.copy() if c["trskip"] else orc.tr(d, d, False, hor, ver, w, h, sw, sh, res)
     if lf:
-        coef = np.ascontiguousarray(coef); orc.lib.orc_lfnst_fwd(H.ptr(coef), w, h, c["imode"], lw, lh, lf)
+        coef = np.ascontiguousarray(coef); orc.lib.orc_lfnst_fwd(H.ptr(coef), w, h, c["imode"], clw, clh, lf)
     if c["rdoq"] and (w > 4 or not c["rdoq_skip"]) and not c["trskip"]:
-        q, _ = orc.rdoq(d, coef, w, h, color, c["cu_type"], 0, idx, 0, c["qps"], c["lam"], c["ctx"])
+        q, _ = orc.rdoq(d, coef, w, h, color, c["cu_type"], c.get("cbf_u", 0), idx, c.get("tr_idx", 0) if color == 0 else 0, c["qps"], c["lam"], c["ctx"])
     else:
         q = orc.quant(d, coef, w, h, d, c["qps"], c["trskip"], c["intra"])
         if idx:                                   # uvg_quant with lfnst_idx: only the first 8 / 16 scan positions (:101-120),
@@ -120,7 +122,7 @@ def oracle_quantize_residual(orc, d, c):
     if has:
         deq = orc.dequant(d, q, w, h, d, c["qps"], c["trskip"])
         if lf:
-            deq = np.ascontiguousarray(deq); orc.lib.orc_lfnst_inv(H.ptr(deq), w, h, c["imode"], lw, lh, lf)
+            deq = np.ascontiguousarray(deq); orc.lib.orc_lfnst_inv(H.ptr(deq), w, h, c["imode"], clw, clh, lf)
         r = deq if c["trskip"] else orc.tr(d, d, True, hor, ver, w, h, sw, sh, deq)
         s = (r.reshape(h, w).astype(np.int32) + c["pred"][:h, :w].astype(np.int32)).astype(np.int16)
         rec[:h, :w] = np.clip(s, 0, (1 << d) - 1)

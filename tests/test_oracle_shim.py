@@ -1,0 +1,87 @@
+"""The encoder-tree shim's records (tests/golden/ref_shim_*.bin, tools/refcheck/rc_shim.inc) against the oracle: the views the
+shim extracts are sufficient to reproduce the generic strategies' results.  tests/test_gpu_shim.py replays the same records
+through libuvg266hip.so."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import helpers as H
+from test_oracle_rdoq import oracle_quantize_residual
+
+
+def scaled_qp(sv, color):
+    """uvg_get_scaled_qp (transform.c:150-165) on the view."""
+    off = (sv.bitdepth - 8) * 6
+    return sv.qp + off if color == 0 else sv.qp_map[min(max(sv.qp, 0), 63)] + off
+
+
+def qr_case(d, r):
+    """The shim record as the dict oracle_quantize_residual takes -- the same derivation uvghip_quantize_residual_percall
+    does from the two views (quant-generic.c:497-540, transform.c:965-1009)."""
+    sv, cv, color, w, h = r["sv"], r["cv"], r["color"], r["w"], r["h"]
+    idx = cv.lfnst_idx if (r["tree"] != 2 or color == 0) else cv.cr_lfnst_idx
+    separate = cv.log2_height + cv.log2_width < 6 or r["tree"] != 0
+    mts_skip = cv.tr_idx == 1 and color == 0
+    lf = idx if (sv.lfnst and cv.type == 1 and idx and not mts_skip and (color == 0 or separate)) else 0
+    mode = cv.intra_mode if color == 0 else cv.intra_mode_chroma
+    if 81 <= mode <= 83:
+        mode = sv.collocated_luma_mode
+    if color == 0 and cv.mip_flag:
+        mode = 0
+    lw, lh = w.bit_length() - 1, h.bit_length() - 1
+    si = r["in_stride"]
+    return dict(w=w, h=h, color=color, ref=r["ref"].reshape(-1, si), pred=r["pred"].reshape(-1, si), cu_type=cv.type, lfnst=idx,
+                cu_lfnst=cv.lfnst_idx, cu_cr_lfnst=cv.cr_lfnst_idx, tr_idx=cv.tr_idx, mts=sv.mts, lf_apply=lf, imode=mode,
+                lf_log2=(cv.log2_width, cv.log2_height) if color == 0 else (lw, lh), trskip=r["trskip"], rdoq=sv.rdoq_enable,
+                rdoq_skip=sv.rdoq_skip, cbf_u=(cv.cbf >> 1) & 1, qps=scaled_qp(sv, color), lam=sv.c_lambda if color else sv.lambda_,
+                ctx=np.frombuffer(bytes(sv.cabac), np.uint8).copy(), intra=sv.slice_is_intra)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_shim_view_layout(depth):
+    from uvg266_amd.lib import StateView, CuView
+    assert ctypes.sizeof(StateView) == 376 and ctypes.sizeof(CuView) == 12      # sizeof in include/uvg266_hip.h (C layout)
+    g = H.shim_goldens(depth)
+    assert len(g["sqr"]) == 240 and len(g["sq"]) > 200 and len(g["sbp"]) > 100
+    assert all(r["sv"].bitdepth == depth and not r["sv"].signhide_enable and not r["sv"].dep_quant for r in g["sqr"])
+    assert {r["branch"] for r in g["sqr"]} == set(range(6))
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_shim_quant_records_vs_oracle(orc, depth):
+    for r in H.shim_goldens(depth)["sq"]:
+        sv, w, h = r["sv"], r["w"], r["h"]
+        qps = scaled_qp(sv, r["color"])
+        if r["inverse"]:
+            got = orc.dequant(depth, r["src"], w, h, depth, qps, r["ts"])
+        elif r["lfnst"]:
+            continue            # the lfnst form of uvg_quant is covered through quantize_residual below
+        else:
+            got = orc.quant(depth, r["src"], w, h, depth, qps, r["ts"], sv.slice_is_intra)
+        assert np.array_equal(got, r["want"]), (w, h, r["color"], r["inverse"])
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_shim_quantize_residual_records_vs_oracle(orc, depth):
+    n = 0
+    for r in H.shim_goldens(depth)["sqr"]:
+        c = qr_case(depth, r)
+        has, q, rec = oracle_quantize_residual(orc, depth, c)
+        tag = (r["branch"], r["w"], r["h"], r["color"], r["tree"], r["trskip"], r["early_skip"])
+        assert has == r["has"] and np.array_equal(q, r["q"]), tag
+        so, w, h = r["out_stride"], r["w"], r["h"]
+        want = r["rec"][: so * h].reshape(h, so)[:, :w]
+        if r["early_skip"] or not has:
+            assert np.array_equal(want, c["pred"][:h, :w]), tag
+        else:
+            assert np.array_equal(want, rec[:h, :w]), tag
+        n += has
+    assert n > 80
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_shim_bipred_records_vs_oracle(orc, depth):
+    for r in H.shim_goldens(depth)["sbp"]:
+        got = orc.bipred_average(depth, r["l0"], r["l1"], r["w"], r["h"])
+        assert np.array_equal(got, r["want"]), (r["w"], r["h"], r["i0"], r["i1"])

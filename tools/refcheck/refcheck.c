@@ -51,6 +51,7 @@ void check_picture(void);
 void check_dct(void);
 void check_quant(void);
 void check_rdoq(void);
+void check_shim(void);
 void check_intra(void);
 void check_ipol(void);
 void check_sao(void);
@@ -97,6 +98,7 @@ int main(int argc, char **argv)
 #endif
 #ifdef HAVE_QUANT
   check_rdoq();      /* last: the earlier groups keep their random streams, hence their committed goldens */
+  check_shim();      /* ... and this one after it */
 #endif
   if (g_out) fclose(g_out);
   printf("refcheck %d-bit: %s (%d mismatches)\n", UVG_BIT_DEPTH, g_fail ? "FAIL" : "OK", g_fail);
@@ -110,6 +112,7 @@ int main(int argc, char **argv)
 #ifdef HAVE_QUANT
 #include "rc_quant.inc"
 #include "rc_rdoq.inc"
+#include "rc_shim.inc"
 #endif
 #ifdef HAVE_INTRA
 #include "rc_intra.inc"

@@ -6,7 +6,7 @@ REF=${UVG_REF_ROOT:-/tmp/uvgref}
 make -s -C oracle
 for D in 8 10; do
   if [ $D = 8 ]; then LIB=$REF/_b/libuvg266.a; DEF=""; else LIB=$REF/_b10/libuvg266.a; DEF="-DUVG_BIT_DEPTH=10"; fi
-  gcc -O1 -g -std=gnu11 -w $DEF -DORC_BIT_DEPTH=$D -I$REF/src -I$REF/src/extras -I$REF/src/strategies -Ioracle \
+  gcc -O1 -g -std=gnu11 -w $DEF -DORC_BIT_DEPTH=$D -I$REF/src -I$REF/src/extras -I$REF/src/strategies -Ioracle -Iinclude \
       -DHAVE_DCT -DHAVE_QUANT -DHAVE_INTRA -DHAVE_IPOL -DHAVE_SAO -DHAVE_DEBLOCK -DHAVE_ALF -DHAVE_LFNST tools/refcheck/refcheck.c oracle/_build/*.$D.o $LIB -lm -lpthread -fopenmp -o /tmp/refcheck$D
   /tmp/refcheck$D "$@"
 done

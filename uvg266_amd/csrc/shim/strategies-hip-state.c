@@ -1,0 +1,165 @@
+/* Encoder-tree half of the hip backend for the strategies whose typedefs take encoder-private structs.
+ *
+ * This file is compiled INSIDE the uvg266 source tree (copy it to src/strategies/hip/ and add it to the build; see
+ * INTEGRATION.md section 2): it is the only code of the backend that sees encoder_state_t / cu_info_t / lcu_t.  It does
+ * field extraction and nothing else -- every sample and coefficient is handled by libuvg266hip.so behind the
+ * plain-value views of uvg266_hip.h.  It is not part of libuvg266hip.so; the repository only syntax-checks it against
+ * the encoder's headers (tools/refcheck/run.sh) and runs it against recording stand-ins of the four entry points
+ * (tools/refcheck/rc_shim.inc) to prove that the extraction picks the fields the generic strategies read.
+ *
+ * Typedefs implemented: quant_func, dequant_func, quant_residual_func (strategies-quant.h:48-86),
+ * inter_recon_bipred_func (strategies-picture.h:136-148).
+ */
+#include "strategyselector.h"
+#include "encoderstate.h"
+#include "encoder.h"
+#include "cabac.h"
+#include "context.h"
+#include "cu.h"
+#include "reshape.h"
+#include "uvg266_hip.h"
+
+#include <string.h>
+
+static void hip_snap(uint8_t *dst, const cabac_ctx_t *src, int n)
+{
+  for (int i = 0; i < n; ++i) dst[i] = (uint8_t)CTX_STATE(&src[i]);       /* cabac.h:175 */
+}
+
+/* What uvg_quant / uvg_dequant / uvg_rdoq / uvg_quantize_residual read through `state`. */
+static void hip_state_view(const encoder_state_t *const state, uvghip_state_view_t *v, int with_cabac)
+{
+  const encoder_control_t *const ctrl = state->encoder_control;
+  memset(v, 0, sizeof *v);
+  v->bitdepth = ctrl->bitdepth;
+  v->qp = state->qp;
+  v->slice_is_intra = state->frame->slicetype == UVG_SLICE_I;
+  v->rdoq_enable = ctrl->cfg.rdoq_enable;
+  v->rdoq_skip = ctrl->cfg.rdoq_skip;
+  v->dep_quant = ctrl->cfg.dep_quant;
+  v->signhide_enable = ctrl->cfg.signhide_enable;
+  v->scaling_list_enabled = ctrl->scaling_list.enable || ctrl->cfg.scaling_list != UVG_SCALING_LIST_OFF;
+  v->lfnst = ctrl->cfg.lfnst;
+  v->mts = ctrl->cfg.mts;
+  v->lmcs_chroma_adj_enabled = state->tile->frame->lmcs_aps ? state->tile->frame->lmcs_aps->m_sliceReshapeInfo.enableChromaAdj : 0;
+  v->collocated_luma_mode = state->collocated_luma_mode;
+  v->lambda = state->lambda;
+  v->c_lambda = state->c_lambda;
+  memcpy(v->qp_map, ctrl->qp_map[0], sizeof v->qp_map);
+  if (with_cabac) {
+    const cabac_data_t *const cb = &state->cabac;
+    uvghip_rdoq_ctx_t *const s = &v->cabac;
+    hip_snap(s->sig_group[0], &cb->ctx.sig_coeff_group_model[0], 2);
+    hip_snap(s->sig_group[1], &cb->ctx.sig_coeff_group_model[2], 2);
+    hip_snap(s->sig[0], cb->ctx.cu_sig_model_luma[0], 12);
+    hip_snap(s->sig[1], cb->ctx.cu_sig_model_chroma[0], 8);
+    hip_snap(s->par[0], cb->ctx.cu_parity_flag_model_luma, 21);
+    hip_snap(s->par[1], cb->ctx.cu_parity_flag_model_chroma, 11);
+    hip_snap(s->gt1[0], cb->ctx.cu_gtx_flag_model_luma[1], 21);
+    hip_snap(s->gt1[1], cb->ctx.cu_gtx_flag_model_chroma[1], 11);
+    hip_snap(s->gt2[0], cb->ctx.cu_gtx_flag_model_luma[0], 21);
+    hip_snap(s->gt2[1], cb->ctx.cu_gtx_flag_model_chroma[0], 11);
+    hip_snap(s->last_x[0], cb->ctx.cu_ctx_last_x_luma, 20);
+    hip_snap(s->last_x[1], cb->ctx.cu_ctx_last_x_chroma, 3);
+    hip_snap(s->last_y[0], cb->ctx.cu_ctx_last_y_luma, 20);
+    hip_snap(s->last_y[1], cb->ctx.cu_ctx_last_y_chroma, 3);
+    hip_snap(s->cbf_luma, cb->ctx.qt_cbf_model_luma, 4);
+    hip_snap(s->cbf_cb, cb->ctx.qt_cbf_model_cb, 2);
+    hip_snap(s->cbf_cr, cb->ctx.qt_cbf_model_cr, 3);
+    hip_snap(&s->root_cbf, &cb->ctx.cu_qt_root_cbf_model, 1);
+  }
+}
+
+static void hip_cu_view(const cu_info_t *const cu, uvghip_cu_view_t *v)
+{
+  memset(v, 0, sizeof *v);
+  v->type = cu->type;
+  v->tr_idx = cu->tr_idx;
+  v->lfnst_idx = cu->lfnst_idx;
+  v->cr_lfnst_idx = cu->cr_lfnst_idx;
+  v->log2_width = cu->log2_width;
+  v->log2_height = cu->log2_height;
+  v->cbf = cu->cbf;
+  if (cu->type == CU_INTRA) {
+    v->intra_mode = cu->intra.mode;
+    v->intra_mode_chroma = cu->intra.mode_chroma;
+    v->mip_flag = cu->intra.mip_flag;
+    v->isp_mode = cu->intra.isp_mode;
+  }
+}
+
+static unsigned uvg_quant_hip(const encoder_state_t *const state, coeff_t *coef, coeff_t *q_coef, int32_t width, int32_t height,
+                              color_t color, int8_t scan_idx, int8_t block_type, int8_t transform_skip, uint8_t lfnst_idx)
+{
+  uvghip_state_view_t sv;
+  hip_state_view(state, &sv, 0);
+  return uvghip_quant_percall(&sv, coef, q_coef, width, height, color, scan_idx, block_type, transform_skip, lfnst_idx);
+}
+
+static unsigned uvg_dequant_hip(const encoder_state_t *const state, coeff_t *q_coef, coeff_t *coef, int32_t width, int32_t height,
+                                color_t color, int8_t block_type, int8_t transform_skip)
+{
+  uvghip_state_view_t sv;
+  hip_state_view(state, &sv, 0);
+  return uvghip_dequant_percall(&sv, q_coef, coef, width, height, color, block_type, transform_skip);
+}
+
+static unsigned uvg_quantize_residual_hip(encoder_state_t *const state, const cu_info_t *const cur_cu, const int width, const int height,
+                                          const color_t color, const coeff_scan_order_t scan_order, const int use_trskip,
+                                          const int in_stride, const int out_stride, const uvg_pixel *const ref_in,
+                                          const uvg_pixel *const pred_in, uvg_pixel *rec_out, coeff_t *coeff_out, bool early_skip,
+                                          int lmcs_chroma_adj, enum uvg_tree_type tree_type)
+{
+  uvghip_state_view_t sv;
+  uvghip_cu_view_t cv;
+  hip_state_view(state, &sv, state->encoder_control->cfg.rdoq_enable);
+  hip_cu_view(cur_cu, &cv);
+  return (unsigned)uvghip_quantize_residual_percall(&sv, &cv, width, height, color, scan_order, use_trskip, in_stride, out_stride, ref_in,
+                                                    pred_in, rec_out, coeff_out, early_skip, lmcs_chroma_adj, tree_type);
+}
+
+/* bipred_average_generic's walk over the planes (picture-generic.c:1195-1262); the averaging itself is on the device. */
+static void uvg_inter_recon_bipred_hip(lcu_t *const lcu, const yuv_t *const px_L0, const yuv_t *const px_L1, const yuv_im_t *const im_L0,
+                                       const yuv_im_t *const im_L1, const unsigned pu_x, const unsigned pu_y, const unsigned pu_w,
+                                       const unsigned pu_h, const unsigned im_flags_L0, const unsigned im_flags_L1,
+                                       const bool predict_luma, const bool predict_chroma)
+{
+  if (predict_luma) {
+    const unsigned off = SUB_SCU(pu_y) * LCU_WIDTH + SUB_SCU(pu_x);
+    const int i0 = im_flags_L0 & 1, i1 = im_flags_L1 & 1;
+    uvghip_bipred_average_percall(UVG_BIT_DEPTH, lcu->rec.y + off, LCU_WIDTH, i0 ? (const void *)im_L0->y : (const void *)px_L0->y, i0,
+                                  i1 ? (const void *)im_L1->y : (const void *)px_L1->y, i1, pu_w, pu_h);
+  }
+  if (predict_chroma) {
+    const unsigned off = SUB_SCU(pu_y) / 2 * LCU_WIDTH_C + SUB_SCU(pu_x) / 2;
+    const int i0 = (im_flags_L0 & 2) != 0, i1 = (im_flags_L1 & 2) != 0;
+    uvghip_bipred_average_percall(UVG_BIT_DEPTH, lcu->rec.u + off, LCU_WIDTH_C, i0 ? (const void *)im_L0->u : (const void *)px_L0->u, i0,
+                                  i1 ? (const void *)im_L1->u : (const void *)px_L1->u, i1, pu_w / 2, pu_h / 2);
+    uvghip_bipred_average_percall(UVG_BIT_DEPTH, lcu->rec.v + off, LCU_WIDTH_C, i0 ? (const void *)im_L0->v : (const void *)px_L0->v, i0,
+                                  i1 ? (const void *)im_L1->v : (const void *)px_L1->v, i1, pu_w / 2, pu_h / 2);
+  }
+}
+
+/* The configurations the backend implements for these four strategies.  Call after the configuration is parsed; when it
+ * returns 0 start the encoder with UVG_OVERRIDE_quant=generic UVG_OVERRIDE_dequant=generic
+ * UVG_OVERRIDE_quantize_residual=generic (strategyselector.c reads them) -- the entry points abort rather than return a
+ * result that differs from the generic strategy's. */
+int uvg_hip_state_config_supported(const uvg_config *const cfg)
+{
+  return !cfg->dep_quant && !cfg->signhide_enable && cfg->scaling_list == UVG_SCALING_LIST_OFF && !cfg->lmcs_enable &&
+         !(cfg->rdoq_enable && cfg->trskip_enable);
+}
+
+/* Called from uvg_strategy_register_quant / _picture (strategies-quant.c:50-66, strategies-picture.c:62-84) next to the
+ * generic / avx2 registrars.  The state-free strategies of the same groups are registered by libuvg266hip.so itself
+ * (uvg_strategy_register_quant_hip / _picture_hip). */
+int uvg_strategy_register_state_hip(void *opaque, uint8_t bitdepth)
+{
+  bool success = true;
+  if (bitdepth != UVG_BIT_DEPTH || uvghip_init(0) != 0) return 1;       /* no gfx950 device: leave the other strategies in place */
+  success &= uvg_strategyselector_register(opaque, "quant", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_quant_hip);
+  success &= uvg_strategyselector_register(opaque, "dequant", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_dequant_hip);
+  success &= uvg_strategyselector_register(opaque, "quantize_residual", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_quantize_residual_hip);
+  success &= uvg_strategyselector_register(opaque, "bipred_average", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_inter_recon_bipred_hip);
+  return success;
+}

@@ -38,6 +38,19 @@ class QrParams(ctypes.Structure):
                                                 "mts_idx", "lfnst_idx", "reserved")] + [("lambda_", ctypes.c_double), ("ctx", ctypes.c_uint8 * 244)]
 
 
+class StateView(ctypes.Structure):
+    """uvghip_state_view_t: what the state-taking strategies read from encoder_state_t."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("bitdepth", "qp", "slice_is_intra", "rdoq_enable", "rdoq_skip", "dep_quant", "signhide_enable",
+                                                "scaling_list_enabled", "lfnst", "mts", "lmcs_chroma_adj_enabled", "collocated_luma_mode")] + \
+               [("lambda_", ctypes.c_double), ("c_lambda", ctypes.c_double), ("qp_map", ctypes.c_int8 * 64), ("cabac", ctypes.c_uint8 * 244)]
+
+
+class CuView(ctypes.Structure):
+    """uvghip_cu_view_t."""
+    _fields_ = [(n, ctypes.c_int8) for n in ("type", "tr_idx", "lfnst_idx", "cr_lfnst_idx", "log2_width", "log2_height", "intra_mode",
+                                               "intra_mode_chroma", "mip_flag", "isp_mode")] + [("cbf", ctypes.c_uint16)]
+
+
 _lib = None
 _inited_device = None
 
@@ -112,6 +125,10 @@ SIGNATURES = {
     "uvghip_comm_destroy": (c_int, [c_vp]),
     "uvghip_comm_exchange": (c_int, [c_vp, c_vp, c_int, c_vp]),
     "uvghip_comm_allreduce_i64": (c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "uvghip_quant_percall": (ctypes.c_uint, [c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32] + [c_int] * 5),
+    "uvghip_dequant_percall": (ctypes.c_uint, [c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32] + [c_int] * 3),
+    "uvghip_quantize_residual_percall": (c_int, [c_vp, c_vp] + [c_int] * 7 + [c_vp] * 4 + [c_int] * 3),
+    "uvghip_bipred_average_percall": (None, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, ctypes.c_uint, ctypes.c_uint]),
     "uvghip_comm_allgather": (c_int, [c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "uvghip_residual_plane": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp]),
 }
