@@ -11,12 +11,13 @@
 //     bit-exact; they do not feed back into the decisions inside the group;
 //   * the regular-bin budget (:1696) only matters once it is nearly spent: a group that could reach "fewer than 4 bins
 //     left" is walked position by position instead.
-// Mapping: 16 lanes = the 16 scan positions of the current coefficient group of one block, four blocks per wave.  Per
-// group: seven anti-diagonal phases of parallel decisions (levels exchanged through LDS), then every lane replays the
-// 16 costs in scan order (same values in all 16 lanes, no broadcast needed) and takes the group decision.  Per-position
-// cost_coeff / cost_sig for the last-position search (:1786-1823) stay in LDS (cost_sig as the code of the table entry
-// it was built from).  All cost arithmetic is IEEE double in the reference's operation order; this file is compiled with
-// -ffp-contract=off, and the one transcendental (pow(2, -2 * transform_shift), :1527) is evaluated on the host.
+// Mapping: four lanes per block (an anti-diagonal of a 4x4 coefficient group has at most four positions), 16 blocks per
+// wave; see the kernel's comment for the per-group stages.  All cost arithmetic is IEEE double in the reference's operation
+// order; this file is compiled with -ffp-contract=off, and the one transcendental (pow(2, -2 * transform_shift), :1527) is
+// evaluated on the host.  Where the time goes (tools/dev/rdoq_pmc.sh, tools/dev/rdoq_real.py on the 1080p bench data): the
+// wave issues an instruction ~50 % of its lifetime at <= 1 wave per SIMD (LDS-limited), so the instruction count per
+// coefficient group is what is optimised: context-free halves of the candidates' costs staged in parallel, lane-role replay
+// chains, last-position search on staged values.
 #include "uvghip_common.h"
 #include "vvc_rdoq_tables.h"
 #include <cmath>
@@ -151,9 +152,39 @@ __device__ __forceinline__ rdoq_decision rdoq_decide(const rdoq_params &P, const
   return d;
 }
 
-// Four lanes per block (an anti-diagonal of a 4x4 group has at most four positions), TUS blocks per wave: 16 for the small
-// shapes (plenty of blocks: lane utilisation matters), 4 / 1 for 256 / 512+ coefficients (few blocks, long chains: more
-// waves per SIMD hide the latency of the dependent steps).
+// value of lane K of the caller's quad (DPP quad_perm broadcast; all four lanes of a block's quad are active together)
+template <int K>
+__device__ __forceinline__ double quad_bcast(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, K * 0x55, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, K * 0x55, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// LDS traffic of a workgroup (= one wave) is ordered by program order; what the phases need between them is only that the
+// compiler keeps that order.  (__syncthreads would also wait for the global cost_coeff stores of the phase.)
+#define WAVE_SYNC()                                             \
+  do {                                                          \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      \
+    __builtin_amdgcn_wave_barrier();                            \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      \
+  } while (0)
+
+// Four lanes per block (an anti-diagonal of a 4x4 group has at most four positions), TUS blocks per wave.
+//
+// Per coefficient group:
+//   stage    every position (4 per lane): |coef| * q, its rounded level, cost0, and the context-free half of the two candidate
+//            levels' costs -- distortion and the sign / Golomb-Rice part of the rate (the Rice parameter is context-free while
+//            regular bins remain, see the header);
+//   7 phases the positions of one anti-diagonal pick their context from the neighbours' decided levels, add the three
+//            context-coded flag costs and the significance cost to the staged halves and choose -- ~1/4 of the instructions
+//            of a full uvg_get_coded_level per position, which is what the wave's time goes into (SQ counters: the kernel
+//            issues instructions > 50 % of its lifetime at one wave per SIMD);
+//   replay   the 16 costs in scan order (bit-exact double sums), group decision.
+// LDS per block: level int16[wh] (holds the input coefficient until the position's group is staged) + meta byte[wh]
+// (bits 0-1: Rice parameter after this position, bits 2-6: code of the significance-cost table entry); block strides are
+// odd in words so that the same position of the 16 blocks of a wave falls into 16 different banks.
 template <int TUS>
 __global__ void __launch_bounds__(64)
 rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__restrict__ q_coef, double *__restrict__ ws,
@@ -170,8 +201,11 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   __shared__ uint32_t sB[N_CTX][2];
   __shared__ int sLastX[32], sLastY[32];
   __shared__ uint8_t sScanCg[64];
-  __shared__ double sStage[TUS][16][3];                                // per group: coded_cost, coded_sig, cost0 of the 16 positions
-  __shared__ int sStageLv[TUS][16];
+  // per group and position s4: D[3*s4 + {0: distortion of candidate 1 -> coded_cost, 1: candidate 2 -> coded_sig, 2: cost0}],
+  // I[3*s4 + {0: rate half of candidate 1 -> level, 1: candidate 2, 2: level_double}]
+  __shared__ double sStageD[TUS][49];
+  __shared__ int sStageI[TUS][49];
+  __shared__ double sCgCostAll[TUS][65];
   const int tid = threadIdx.x, grp = tid >> 2, j = tid & 3;
   const int width = P.width, height = P.height, wh = width * height, l2w = P.l2w;
   const int n = P.n;
@@ -180,15 +214,14 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   const bool live = grp < here;
   const int gq = live ? grp : 0;                                       // idle lanes alias block 0 for address arithmetic only
   const int tu = tu0 + gq;
-  // per block in LDS: coef int16[wh] | level int16[wh] | meta uint8[wh] (padded to 8 bytes); then 64 group costs per block.
-  // cost_coeff[] (a double per position, written once during the walk, re-read only for non-zero levels by the last-position
-  // search) goes to the caller's workspace: it would be 60 % of the LDS footprint and cap the blocks per wave.
-  const size_t per_tu = ((size_t)wh * 5 + 7) & ~(size_t)7;
-  double *gCost = ws + (size_t)tu * wh;
-  int16_t *sCoef = reinterpret_cast<int16_t *>(sDyn + gq * per_tu);
-  int16_t *sLev = sCoef + wh;
+  const size_t per_tu = (size_t)wh * 3 + 4;
+  double *gCost = ws + (size_t)tu * wh;                                // cost_coeff[] of this block (re-read by the last-position search)
+  const int16_t *gCoef = coef + (size_t)tu * wh;
+  int16_t *sLev = reinterpret_cast<int16_t *>(sDyn + gq * per_tu);
   uint8_t *sMeta = reinterpret_cast<uint8_t *>(sLev + wh);
-  double *sCgCost = reinterpret_cast<double *>(sDyn + TUS * per_tu) + gq * 64;
+  double *D = sStageD[gq];
+  int *I = sStageI[gq];
+  double *sCgCost = sCgCostAll[gq];
   const int t = P.color ? 1 : 0;
   const int mts = P.mts_idx;
 
@@ -205,12 +238,24 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       y = x; x = 0;
     }
   }
-  // ---- stage the coefficients (coalesced: the blocks of a workgroup are contiguous), clear the levels ----
-  for (int e = tid; e < here * wh; e += 64) {
-    const int b = e / wh, pos = e - b * wh;
-    int16_t *base = reinterpret_cast<int16_t *>(sDyn + b * per_tu);
-    base[pos] = coef[(size_t)tu0 * wh + e];
-    base[wh + pos] = 0;
+  // ---- stage the coefficients into the level array (coalesced: the blocks of a workgroup are contiguous) ----
+  const int l2wh = l2w + P.l2h;
+  {
+    // two coefficients per lane and step (wh is a multiple of 16: pairs never straddle blocks; 4-byte aligned: the batch
+    // pointer is 2-byte aligned by contract, so pair loads need an even element offset -- tu0 * wh is a multiple of 16)
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(coef + (size_t)tu0 * wh);
+    const bool aligned = (reinterpret_cast<uintptr_t>(coef) & 3) == 0;
+    if (aligned) {
+      for (int e = tid; e < (here * wh) >> 1; e += 64) {
+        const int b = (2 * e) >> l2wh, pos = 2 * e - (b << l2wh);
+        *reinterpret_cast<uint32_t *>(sDyn + b * per_tu + 2 * pos) = src[e];
+      }
+    } else {
+      for (int e = tid; e < here * wh; e += 64) {
+        const int b = e >> l2wh, pos = e - (b << l2wh);
+        reinterpret_cast<int16_t *>(sDyn + b * per_tu)[pos] = coef[(size_t)tu0 * wh + e];
+      }
+    }
   }
   __syncthreads();
   if (tid == 0) {                                                      // calc_last_bits, rdo.c:667-700
@@ -235,7 +280,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   if (live)
     for (int pos = j; pos < wh; pos += 4) {
       const uint32_t pos_y = (uint32_t)pos >> l2w, pos_x = (uint32_t)pos - (pos_y << l2w);
-      const int16_t *c0p = sCoef + pos;
+      const int16_t *c0p = sLev + pos;
       int16_t sum = 0;                                                 // coeff_t accumulator: wraps like the reference's
       if (pos_x < (uint32_t)width - 1) {
         sum = (int16_t)(sum + ((mts && pos_x + 1 >= 16) ? 0 : abs((int)c0p[1])));
@@ -244,7 +289,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       }
       if (pos_y < (uint32_t)height - 1) {
         sum = (int16_t)(sum + ((mts && pos_y + 1 >= 16) ? 0 : abs((int)c0p[width])));
-        if (pos_y < (uint32_t)height - 2) sum = (int16_t)(sum + ((mts && pos_y + 2 >= 16) ? 0 : abs((int)c0p[2 * width])));
+        if (pos_y < (uint32_t)height - 2) sum = (int16_t)(sum + ((mts && (pos_y + 2 >= 16)) ? 0 : abs((int)c0p[2 * width])));
       }
       sMeta[pos] = (uint8_t)go_rice_par(clampi((int)sum - 20, 0, 31));
     }
@@ -261,8 +306,8 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   const uint32_t cg_width = (uint32_t)min(width, 32) >> 2, cg_height = (uint32_t)min(height, 32) >> 2;
   const int cg_num = P.lfnst_idx > 0 ? 1 : wh >> 4;
   const int max_group = P.lfnst_idx > 0 ? (((height == 4 && width == 4) || (height == 8 && width == 8)) ? 7 : 15) : 15;
-  auto level_double_at = [&](int blkpos) {
-    const long long prod = (long long)abs((int)sCoef[blkpos]) * q;
+  auto level_double_of = [&](int c) {
+    const long long prod = (long long)abs(c) * q;
     return (int)(prod < cap ? prod : cap);
   };
   auto cost0_of = [&](int level_double) { const double err = (double)level_double; return err * err * error_scale; };   // cost_coeff0[]
@@ -271,17 +316,17 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   auto quad_or = [&](unsigned v) { v |= __shfl_xor(v, 1, 64); v |= __shfl_xor(v, 2, 64); return v; };
   auto quad_sum = [&](unsigned v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); return v; };
   auto neighbours = [&](int blkpos, uint32_t pos_x, uint32_t pos_y, int (&nb)[5], bool (&has)[5]) __attribute__((always_inline)) {
-    const int16_t *D = sLev + blkpos;
+    const int16_t *Lv = sLev + blkpos;
 #pragma unroll
     for (int k = 0; k < 5; ++k) { nb[k] = 0; has[k] = false; }
     if (pos_x < (uint32_t)width - 1) {
-      has[0] = true; nb[0] = D[1];
-      if (pos_x < (uint32_t)width - 2) { has[1] = true; nb[1] = D[2]; }
-      if (pos_y < (uint32_t)height - 1) { has[2] = true; nb[2] = D[width + 1]; }
+      has[0] = true; nb[0] = Lv[1];
+      if (pos_x < (uint32_t)width - 2) { has[1] = true; nb[1] = Lv[2]; }
+      if (pos_y < (uint32_t)height - 1) { has[2] = true; nb[2] = Lv[width + 1]; }
     }
     if (pos_y < (uint32_t)height - 1) {
-      has[3] = true; nb[3] = D[width];
-      if (pos_y < (uint32_t)height - 2) { has[4] = true; nb[4] = D[2 * width]; }
+      has[3] = true; nb[3] = Lv[width];
+      if (pos_y < (uint32_t)height - 2) { has[4] = true; nb[4] = Lv[2 * width]; }
     }
   };
 
@@ -295,7 +340,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       for (int r = 0; r < 4; ++r) {
         const int s4 = j + 4 * r;
         if (s4 <= max_group) {
-          const int ld = level_double_at(blk_in(g, in_cg(s4)));
+          const int ld = level_double_of((int)sLev[blk_in(g, in_cg(s4))]);
           if (((uint32_t)(ld + (1 << (q_bits - 1))) >> q_bits) > 0) m |= 1u << s4;
         }
       }
@@ -303,19 +348,33 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
     if (last_scanpos < 0 && m) last_scanpos = cgs * 16 + (31 - __clz((int)m));
   }
   const int cg_last_scanpos = last_scanpos >> 4;                        // -1 >> 4 == -1
+  // groups the walk never stages keep reading as zero levels: the MTS zero-out region, and everything of a block without
+  // a significant position (its output is all zero)
+  WAVE_SYNC();
+  if (live && (mts != 0 || last_scanpos < 0 || P.lfnst_idx > 0))
+    for (int cgs = 0; cgs < (wh >> 4); ++cgs) {
+      const int g = sScanCg[cgs];
+      if (last_scanpos < 0 || cg_skipped(g) || cgs >= cg_num)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sLev[blk_in(g, in_cg(j + 4 * r))] = 0;
+      else if (max_group < 15)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (j + 4 * r > max_group) sLev[blk_in(g, in_cg(j + 4 * r))] = 0;
+    }
+  WAVE_SYNC();
 
   // ---- the walk, coefficient group by coefficient group (rdo.c:1604-1773) ----
   unsigned long long sig_cg = 0;                                       // sig_coeffgroup_flag as a bit set over group raster positions
   double block_uncoded_cost = 0, base_cost = 0;
   uint32_t reg_bins = (uint32_t)(wh * 28) >> 4;
-  int go_rice_state = 0;                                               // only tracked once a group is walked sequentially
-  bool slow = false;
+  int go_rice_state = 0;                                               // only tracked while a group is walked sequentially
+  bool exhausted = false;                                              // reg_bins < 4: it never recovers (:1692-1697 stop updating it)
   for (int cgs = cg_num - 1; cgs >= 0; --cgs) {
     const int g = sScanCg[cgs];
     const bool has_last = live && last_scanpos >= 0;
     const bool in_tail = has_last && cgs > cg_last_scanpos && !cg_skipped(g);   // beyond the last significant position: cost0 sums only (:1585)
     const bool in_walk = has_last && cgs <= cg_last_scanpos && !cg_skipped(g);
-    // every position of the group: rounded level into dest_coeff (:1620), cost0 staged, bins this group can spend at most
+    // -- stage: rounded level into dest_coeff (:1620), cost0, the context-free halves of the candidates, bins this group can spend at most --
     unsigned spend = 0;
     if (in_tail || in_walk)
 #pragma unroll
@@ -323,58 +382,157 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
         const int s4 = j + 4 * r;
         if (s4 > max_group) continue;
         const int blkpos = blk_in(g, in_cg(s4));
-        const int ld = level_double_at(blkpos);
-        const uint32_t mx = (uint32_t)(ld + (1 << (q_bits - 1))) >> q_bits;
-        sStage[gq][s4][2] = cost0_of(ld);
-        sStageLv[gq][s4] = 0;
-        if (in_walk && cgs * 16 + s4 <= last_scanpos) { sLev[blkpos] = (int16_t)mx; spend += (mx < 2 ? mx : 3) + 1; }
+        const int scanpos = cgs * 16 + s4;
+        const int ld = level_double_of((int)sLev[blkpos]);
+        const int mx = (int)((uint32_t)(ld + (1 << (q_bits - 1))) >> q_bits);
+        const bool walked = in_walk && scanpos <= last_scanpos;
+        const double c0 = cost0_of(ld);
+        D[3 * s4 + 2] = c0;
+        I[3 * s4 + 2] = ld;
+        I[3 * s4] = 0;
+        if (!walked) { D[3 * s4] = c0; D[3 * s4 + 1] = 0.0; }          // beyond the last significant position: base_cost += cost_coeff0 (:1585)
+        sLev[blkpos] = (int16_t)(walked ? mx : 0);
+        if (walked) {
+          spend += (unsigned)(mx < 2 ? mx : 3) + 1;
+          if (mx > 0) {
+            // Rice parameter left by the previously visited position (scanpos + 1): reset after every 16th (:1692), else the
+            // context-free value of that position; the last significant position starts with 0
+            const int go_rice = (scanpos == last_scanpos || s4 == 15) ? 0 : (sMeta[blk_in(g, in_cg(s4 + 1))] & 3);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const int a = mx - c;
+              if (a < 1) break;
+              const double err = (double)(ld - (a * (1 << q_bits)));
+              D[3 * s4 + c] = err * err * error_scale;
+              int rate = 1 << 15;                                      // sign
+              if (a >= 4) {                                            // remainder of abs_level - 4, rdo.c:520-547
+                const int thr = 5, max_log2 = 15;
+                const int symbol = a - 4;
+                if (symbol < (thr << go_rice)) {
+                  rate += ((symbol >> go_rice) + 1 + go_rice) << 15;
+                } else {
+                  const uint32_t max_prefix = 32 - (thr + max_log2);
+                  uint32_t prefix = 0;
+                  const uint32_t suffix = (uint32_t)(symbol >> go_rice) - thr;
+                  while (prefix < max_prefix && (int)suffix > ((2 << prefix) - 2)) prefix++;
+                  const uint32_t suffix_len = prefix == max_prefix ? (uint32_t)(max_log2 - go_rice) : prefix + 1;
+                  rate += (int)((thr + prefix + suffix_len + go_rice) << 15);
+                }
+              }
+              I[3 * s4 + c] = rate;
+            }
+          }
+        }
       }
     spend = quad_sum(spend);
-    // a group in which the regular-bin budget could fall below 4 is walked position by position, and so is everything after it
-    if (in_walk && !slow && reg_bins < 4 + spend) slow = true;
-    const bool any_slow = __any(in_walk && slow);
-    __syncthreads();
-    // -- fast path: the positions of one anti-diagonal decide together (their neighbours lie on later anti-diagonals) --
+    // Only the group in which the regular-bin budget could fall below 4 is walked position by position: before it the
+    // budget cannot run out inside a group; after it reg_bins is frozen below 4, the Rice parameter comes from the template of
+    // decided levels (:1645-1648) instead of being carried along the scan, and the positions of an anti-diagonal are
+    // independent of each other again.
+    const bool slow = in_walk && !exhausted && reg_bins < 4 + spend;
+    const bool plain = in_walk && !exhausted && !slow;
+    const bool any_slow = __any(slow), any_exh = __any(in_walk && exhausted);
+    WAVE_SYNC();
+    // -- the positions of one anti-diagonal decide together (their neighbours lie on later anti-diagonals) --
     for (int dg = 6; dg >= 0; --dg) {
       const int cnt = dg <= 3 ? dg + 1 : 7 - dg;
       const int s4 = (dg <= 3 ? dg * (dg + 1) / 2 : 16 - (7 - dg) * (8 - dg) / 2) + j;   // scan index inside the group
       const int scanpos = cgs * 16 + s4;
-      if (in_walk && !slow && j < cnt && s4 <= max_group && scanpos <= last_scanpos) {
+      if (plain && j < cnt && s4 <= max_group && scanpos <= last_scanpos) {
         const int blkpos = blk_in(g, in_cg(s4));
         const uint32_t pos_y = (uint32_t)blkpos >> l2w, pos_x = (uint32_t)blkpos - (pos_y << l2w);
-        const int ld = level_double_at(blkpos);
-        const uint32_t mx = (uint32_t)(ld + (1 << (q_bits - 1))) >> q_bits;
+        const int mx = (int)sLev[blkpos];
         const bool is_last = scanpos == last_scanpos;
-        int nb[5]; bool has[5];
-        neighbours(blkpos, pos_x, pos_y, nb, has);
-        // Rice parameter left by the previously visited position (scanpos + 1): reset after every 16th (:1692), else the
-        // context-free value of that position; the last significant position starts with 0
-        const int go_rice = (is_last || s4 == 15) ? 0 : (sMeta[blk_in(g, in_cg(s4 + 1))] & 3);
-        const rdoq_decision d = rdoq_decide(P, B, t, is_last, ld, mx, cost0_of(ld), nb, has, pos_x, pos_y, go_rice, 4);
-        sLev[blkpos] = (int16_t)d.level;
-        sStage[gq][s4][0] = d.coded_cost; sStage[gq][s4][1] = d.coded_sig;
-        sStageLv[gq][s4] = d.level;
-        gCost[blkpos] = d.coded_cost;
-        sMeta[blkpos] = (uint8_t)((sMeta[blkpos] & 3) | (d.sig_code << 2));
+        int ctx_sig = 0, ctx_set = 0;
+        if (!is_last) {                                                // context_get_sig_ctx_idx_abs + the ctx_set line, as rdoq_decide
+          int nb[5]; bool has[5];
+          neighbours(blkpos, pos_x, pos_y, nb, has);
+          const bool zz[5] = {mts && pos_x + 1 >= 16, mts && pos_x + 2 >= 16, mts && (pos_y + 1 >= 16 || pos_x + 1 >= 16),
+                              mts && pos_x + 1 >= 16, mts && pos_x + 2 >= 16};
+          int num_pos = 0, sum_abs = 0;
+#pragma unroll
+          for (int k = 0; k < 5; ++k)
+            if (has[k]) { const int a = zz[k] ? 0 : abs(nb[k]); sum_abs += min(4 + (a & 1), a); num_pos += a ? 1 : 0; }
+          const int diag = (int)(pos_x + pos_y);
+          ctx_sig = min((sum_abs + 1) >> 1, 3) + (diag < 2 ? 4 : 0);
+          if (P.color == 0) ctx_sig += diag < 5 ? 4 : 0;
+          const int temp_sum = sum_abs - num_pos;
+          ctx_set = (min(temp_sum, 4) + 1) + (!diag ? ((P.color == 0) ? 15 : 5) : (P.color == 0) ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0);
+        }
+        const double c0 = D[3 * s4 + 2];
+        const uint32_t sig0 = B[O_SIG + 12 * t + ctx_sig][0], sig1 = B[O_SIG + 12 * t + ctx_sig][1];
+        int level = 0, sig_code = 0;
+        double cs = 0, cc;
+        if (!is_last && mx < 3) {                                      // uvg_get_coded_level, rdo.c:612-640
+          cs = lambda * (double)sig0;
+          cc = c0 + cs;
+          sig_code = 1 + 2 * ctx_sig;
+        } else {
+          cc = 1.7e+308;
+        }
+        if (mx > 0) {
+          const double cur_cost_sig = is_last ? 0.0 : lambda * (double)sig1;
+          const uint32_t par0 = B[O_PAR + 21 * t + ctx_set][0], par1 = B[O_PAR + 21 * t + ctx_set][1];
+          const uint32_t g10 = B[O_GT1 + 21 * t + ctx_set][0], g11 = B[O_GT1 + 21 * t + ctx_set][1];
+          const uint32_t g20 = B[O_GT2 + 21 * t + ctx_set][0], g21 = B[O_GT2 + 21 * t + ctx_set][1];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int a = mx - c;
+            if (a < 1) break;
+            // the context-coded flags of uvg_get_ic_rate (:549-571): gt1; for levels >= 2 parity and gt2
+            int rate = I[3 * s4 + c] + (int)(a >= 2 ? g11 : g10);
+            if (a >= 2) rate += (int)((a & 1) ? par1 : par0) + (int)(a >= 4 ? g21 : g20);
+            double cur = D[3 * s4 + c] + lambda * (double)rate;
+            cur += cur_cost_sig;
+            if (cur < cc) { level = a; cc = cur; cs = cur_cost_sig; sig_code = is_last ? 0 : 2 + 2 * ctx_sig; }
+          }
+        }
+        sLev[blkpos] = (int16_t)level;
+        D[3 * s4] = cc; D[3 * s4 + 1] = cs;
+        I[3 * s4] = level;
+        sMeta[blkpos] = (uint8_t)((sMeta[blkpos] & 3) | (sig_code << 2));
       }
-      __syncthreads();
+      WAVE_SYNC();
     }
-    // -- slow path: the lanes of the block walk the group's positions in order (identical results in all four) --
+    // -- the same with the budget spent: full uvg_get_coded_level with reg_bins < 4 (bypass-coded levels, Rice parameter
+    //    from the decided neighbours) --
+    if (any_exh)
+      for (int dg = 6; dg >= 0; --dg) {
+        const int cnt = dg <= 3 ? dg + 1 : 7 - dg;
+        const int s4 = (dg <= 3 ? dg * (dg + 1) / 2 : 16 - (7 - dg) * (8 - dg) / 2) + j;
+        const int scanpos = cgs * 16 + s4;
+        if (in_walk && exhausted && j < cnt && s4 <= max_group && scanpos <= last_scanpos) {
+          const int blkpos = blk_in(g, in_cg(s4));
+          const uint32_t pos_y = (uint32_t)blkpos >> l2w, pos_x = (uint32_t)blkpos - (pos_y << l2w);
+          const int ld = I[3 * s4 + 2];
+          const uint32_t mx = (uint32_t)(ld + (1 << (q_bits - 1))) >> q_bits;
+          int nb[5]; bool has[5];
+          neighbours(blkpos, pos_x, pos_y, nb, has);
+          const rdoq_decision d = rdoq_decide(P, B, t, scanpos == last_scanpos, ld, mx, D[3 * s4 + 2], nb, has, pos_x, pos_y, 0, reg_bins);
+          sLev[blkpos] = (int16_t)d.level;
+          D[3 * s4] = d.coded_cost; D[3 * s4 + 1] = d.coded_sig;
+          I[3 * s4] = d.level;
+          sMeta[blkpos] = (uint8_t)((sMeta[blkpos] & 3) | (d.sig_code << 2));
+        }
+        WAVE_SYNC();
+      }
+    // -- the group that may run out of bins: the lanes of the block walk its positions in order (identical results in all four) --
     if (any_slow) {
+      go_rice_state = 0;                                                 // every group starts from 0 (:1692: reset after scan position 16k)
       for (int s2 = max_group; s2 >= 0; --s2) {
         const int sc2 = cgs * 16 + s2;
-        const bool act2 = in_walk && slow && sc2 <= last_scanpos;
+        const bool act2 = slow && sc2 <= last_scanpos;
         rdoq_decision d2;
         d2.level = 0; d2.sig_code = 0; d2.coded_cost = 0; d2.coded_sig = 0;
         const int b2 = blk_in(g, in_cg(s2));
         if (act2) {
           const uint32_t py = (uint32_t)b2 >> l2w, px = (uint32_t)b2 - (py << l2w);
-          const int ld2 = level_double_at(b2);
+          const int ld2 = I[3 * s2 + 2];
           const uint32_t mx2 = (uint32_t)(ld2 + (1 << (q_bits - 1))) >> q_bits;
           int nb[5]; bool has[5];
           neighbours(b2, px, py, nb, has);
           const bool last2 = sc2 == last_scanpos;
-          d2 = rdoq_decide(P, B, t, last2, ld2, mx2, cost0_of(ld2), nb, has, px, py, go_rice_state, reg_bins);
+          d2 = rdoq_decide(P, B, t, last2, ld2, mx2, D[3 * s2 + 2], nb, has, px, py, go_rice_state, reg_bins);
           // context set update (rdo.c:1691-1699), tracked here because the budget is nearly spent
           if ((sc2 % 16 == 0) && sc2 > 0) go_rice_state = 0;
           else if (reg_bins >= 4) {
@@ -382,47 +540,67 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
             go_rice_state = sMeta[b2] & 3;
           }
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (act2 && j == 0) {
           sLev[b2] = (int16_t)d2.level;
-          sStage[gq][s2][0] = d2.coded_cost; sStage[gq][s2][1] = d2.coded_sig;
-          sStageLv[gq][s2] = d2.level;
-          gCost[b2] = d2.coded_cost;
+          D[3 * s2] = d2.coded_cost; D[3 * s2 + 1] = d2.coded_sig;
+          I[3 * s2] = d2.level;
           sMeta[b2] = (uint8_t)((sMeta[b2] & 3) | (d2.sig_code << 2));
         }
-        __syncthreads();
+        WAVE_SYNC();
       }
     }
-    // -- replay the group's costs in scan order: every lane of the block computes the same sums --
-    if (in_tail) {
-      for (int s2 = max_group; s2 >= 0; --s2) { const double v = sStage[gq][s2][2]; block_uncoded_cost += v; base_cost += v; }
-    } else if (in_walk) {
-      double rd_coded = 0, rd_uncoded = 0, rd_sig = 0, rd_sig0 = 0;
-      int nnz_before_pos0 = 0;
-      bool any_level = false;
-      for (int s2 = max_group; s2 >= 0; --s2) {
-        const int sc2 = cgs * 16 + s2;
-        const double v0 = sStage[gq][s2][2];
-        if (sc2 > last_scanpos) {                                        // trailing zeros of the last group (:1585-1586)
-          block_uncoded_cost += v0; base_cost += v0;
-          continue;
-        }
-        const double cc = sStage[gq][s2][0], cs = sStage[gq][s2][1];
-        const int lv = sStageLv[gq][s2];
-        block_uncoded_cost += v0;
-        base_cost += cc;
-        if (!slow) {                                                     // budget bookkeeping of the fast path (:1692-1697)
-          if (!((sc2 % 16 == 0) && sc2 > 0) && reg_bins >= 4) reg_bins -= (uint32_t)((lv < 2 ? lv : 3) + (sc2 == last_scanpos ? 0 : 1));
-        }
-        rd_sig += cs;
-        if (s2 == 0) rd_sig0 = cs;
-        if (lv) {
-          any_level = true;
-          rd_coded += cc - cs;
-          rd_uncoded += v0;
-          if (s2 != 0) nnz_before_pos0++;
-        }
+    // cost_coeff[] of the group's walked positions
+    if (in_walk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int s4 = j + 4 * r;
+        if (s4 <= max_group && cgs * 16 + s4 <= last_scanpos) gCost[blk_in(g, in_cg(s4))] = D[3 * s4];
       }
+    // -- replay the group's costs in scan order (bit-exact double sums).  The five running sums are independent chains:
+    //    lane 0 of the block carries base_cost (+ cost_coeff), lane 1 block_uncoded_cost (+ cost_coeff0), lane 2 the group's
+    //    sig_cost (+ cost_sig) and uncoded_dist (+ cost_coeff0 of non-zero levels), lane 3 coded_level_and_dist
+    //    (+ cost_coeff - cost_sig of non-zero levels); x + 0.0 == x exactly, so "skip" is "add zero".  Then the sums are
+    //    exchanged inside the quad and every lane takes the group decision. --
+    unsigned m = 0;                                                      // non-zero levels of the group
+    double acc_a = 0.0, acc_b = 0.0;
+    if (in_tail || in_walk) {
+      unsigned dec = 0;                                                  // regular bins the group spends
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int s4 = j + 4 * r;
+        if (s4 > max_group) continue;
+        const int lv = I[3 * s4];
+        if (lv) m |= 1u << s4;
+        const int sc = cgs * 16 + s4;
+        if (in_walk && sc <= last_scanpos && !(s4 == 0 && cgs > 0)) dec += (unsigned)(lv < 2 ? lv : 3) + (sc == last_scanpos ? 0u : 1u);
+      }
+      m = quad_or(m); dec = quad_sum(dec);
+      // (:1692-1697) inside a group that is not walked sequentially the budget stays >= 4 (reg_bins >= 4 + spend >= 4 + dec)
+      if (in_walk && !slow && reg_bins >= 4) reg_bins -= dec;
+      const int o1 = j == 1 ? 2 : j == 2 ? 1 : 0, o2 = j == 2 ? 2 : 1;
+      acc_a = j == 0 ? base_cost : j == 1 ? block_uncoded_cost : 0.0;
+      const double *Dp = D + o1, *Dq = D + o2;
+      double pv[16], qv[16];
+#pragma unroll
+      for (int s2 = 15; s2 >= 0; --s2) { pv[s2] = Dp[3 * s2]; qv[s2] = Dq[3 * s2]; }     // (positions past max_group: stale, unused)
+#pragma unroll
+      for (int s2 = 15; s2 >= 0; --s2) {
+        if (s2 > max_group) continue;
+        const bool nz = (m >> s2) & 1;
+        const double dv = pv[s2] - qv[s2];
+        acc_a += j == 3 ? (nz ? dv : 0.0) : pv[s2];
+        acc_b += (j == 2 && nz) ? qv[s2] : 0.0;
+      }
+      base_cost = quad_bcast<0>(acc_a);
+      block_uncoded_cost = quad_bcast<1>(acc_a);
+    }
+    if (in_walk) {
+      double rd_sig = quad_bcast<2>(acc_a), rd_uncoded = quad_bcast<2>(acc_b), rd_coded = quad_bcast<3>(acc_a);
+      const double rd_sig0 = D[1];
+      const int nnz_before_pos0 = __popc(m & ~1u);
+      const bool any_level = m != 0;
+      if (reg_bins < 4) exhausted = true;
       if (any_level) sig_cg |= 1ull << g;
       // coefficient-group decision (rdo.c:1719-1772)
       double cg_cost = 0;
@@ -461,12 +639,12 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
         for (int r = 0; r < 4; ++r) {
           const int s4 = j + 4 * r;
           const int blkpos = blk_in(g, in_cg(s4));
-          if (s4 <= max_group && sLev[blkpos]) { sLev[blkpos] = 0; gCost[blkpos] = sStage[gq][s4][2]; sMeta[blkpos] &= 3; }
+          if (s4 <= max_group && sLev[blkpos]) { sLev[blkpos] = 0; gCost[blkpos] = D[3 * s4 + 2]; sMeta[blkpos] &= 3; }
         }
     } else if (has_last && j == 0) {
       sCgCost[cgs] = 0;                                                  // groups skipped by the MTS zero-out keep a zero flag cost
     }
-    __syncthreads();
+    WAVE_SYNC();
   }
 
   // ---- last position (rdo.c:1775-1829): one short sequential pass, identical in the lanes of a block ----
@@ -482,43 +660,73 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       base_cost += lambda * (double)B[m][1];
     }
     bool found_last = false;
+    // Per group the four lanes fetch what the walk over its positions needs -- cost_coeff (workspace), cost_coeff0 (from the
+    // input coefficient), cost_sig (from the code kept in the meta byte) and the bits of the last-position syntax -- one
+    // group ahead of the sequential pass, which is then a handful of double operations per position.
+    double pf_cost[4]; int pf_coef[4];
+    auto prefetch = [&](int cgs) {
+      const int g = sScanCg[cgs];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int s4 = j + 4 * r;
+        const int b2 = blk_in(g, in_cg(s4 <= max_group ? s4 : 0));
+        pf_cost[r] = gCost[b2]; pf_coef[r] = (int)gCoef[b2];
+      }
+    };
+    prefetch(cg_last_scanpos);
     for (int cgs = cg_last_scanpos; cgs >= 0 && !found_last; cgs--) {
       const int g = sScanCg[cgs];
       base_cost -= sCgCost[cgs];
-      if ((sig_cg >> g) & 1) {
-        // the group's cost_coeff values: fetched by the four lanes together, then read from LDS by each of them
-        // (same-wave LDS traffic is in order: no barrier inside this block-divergent loop)
+      const bool coded = (sig_cg >> g) & 1;
+      unsigned mnz = 0, mgt1 = 0;
+      if (coded)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int s4 = j + 4 * r; if (s4 <= max_group) sStage[gq][s4][0] = gCost[blk_in(g, in_cg(s4))]; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int s2 = max_group; s2 >= 0; s2--) {
-          const int sc2 = cgs * 16 + s2;
-          if (sc2 > last_scanpos) continue;
-          const int b2 = blk_in(g, in_cg(s2));
+        for (int r = 0; r < 4; ++r) {
+          const int s4 = j + 4 * r;
+          if (s4 > max_group || cgs * 16 + s4 > last_scanpos) continue;
+          const int b2 = blk_in(g, in_cg(s4));
           const int lv = sLev[b2];
-          const double csig = sig_cost_of(sMeta[b2] >> 2);
-          if (lv) {
+          D[3 * s4 + 1] = sig_cost_of(sMeta[b2] >> 2);
+          if (lv) {                                                      // get_rate_last (:645-658) without the final lambda *
+            mnz |= 1u << s4;
+            if (lv > 1) mgt1 |= 1u << s4;
+            D[3 * s4] = pf_cost[r];
+            D[3 * s4 + 2] = cost0_of(level_double_of(pf_coef[r]));
             const uint32_t py = (uint32_t)b2 >> l2w, px = (uint32_t)b2 - (py << l2w);
             const uint32_t cx = (uint32_t)group_idx((int)px), cy = (uint32_t)group_idx((int)py);
-            double ui = (double)(sLastX[cx] + sLastY[cy]);
-            if (cx > 3) ui += (double)(32768u * ((cx - 2) >> 1));
-            if (cy > 3) ui += (double)(32768u * ((cy - 2) >> 1));
-            const double cost_last = lambda * ui;
-            const double total = base_cost + cost_last - csig;
+            int ui = sLastX[cx] + sLastY[cy];
+            if (cx > 3) ui += (int)(32768u * ((cx - 2) >> 1));
+            if (cy > 3) ui += (int)(32768u * ((cy - 2) >> 1));
+            I[3 * s4 + 1] = ui;
+          }
+        }
+      if (cgs > 0) prefetch(cgs - 1);
+      WAVE_SYNC();
+      if (coded) {
+        mnz = quad_or(mnz); mgt1 = quad_or(mgt1);
+        double csv[16];
+#pragma unroll
+        for (int s2 = 15; s2 >= 0; --s2) csv[s2] = D[3 * s2 + 1];        // (positions not staged: stale, unused)
+#pragma unroll
+        for (int s2 = 15; s2 >= 0; --s2) {
+          const int sc2 = cgs * 16 + s2;
+          if (s2 > max_group || sc2 > last_scanpos || found_last) continue;
+          if ((mnz >> s2) & 1) {
+            const double cost_last = lambda * (double)I[3 * s2 + 1];
+            const double total = base_cost + cost_last - csv[s2];
             if (total < best_cost) { best_last_idx_p1 = sc2 + 1; best_cost = total; }
-            if (lv > 1) { found_last = true; break; }
-            base_cost -= sStage[gq][s2][0];
-            base_cost += cost0_of(level_double_at(b2));
+            if ((mgt1 >> s2) & 1) { found_last = true; continue; }
+            base_cost -= D[3 * s2];
+            base_cost += D[3 * s2 + 2];
           } else {
-            base_cost -= csig;
+            base_cost -= csv[s2];
           }
         }
       }
+      WAVE_SYNC();
     }
   }
-  __syncthreads();
+  WAVE_SYNC();
   // ---- signs, clean-up, outputs (rdo.c:1831-1858): parallel over the positions ----
   uint32_t my_abs = 0;
   if (live) {
@@ -532,7 +740,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
         if (last_scanpos < 0 || scanpos >= best_last_idx_p1) level = 0;
         else if (reduce) { const int bx = b & (width - 1), by = b >> l2w; if (bx >= 16 || by >= 16) level = 0; }
         my_abs += (uint32_t)level;
-        sLev[b] = (int16_t)((level != 0 && sCoef[b] < 0) ? -level : level);
+        sLev[b] = (int16_t)((level != 0 && gCoef[b] < 0) ? -level : level);
       }
   }
   my_abs = quad_sum(my_abs);
@@ -541,9 +749,17 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
     if (has_coeffs) has_coeffs[tu] = my_abs ? 1 : 0;
   }
   __syncthreads();
-  for (int e = tid; e < here * wh; e += 64) {
-    const int b = e / wh, pos = e - b * wh;
-    q_coef[(size_t)tu0 * wh + e] = reinterpret_cast<const int16_t *>(sDyn + b * per_tu)[wh + pos];
+  if ((reinterpret_cast<uintptr_t>(q_coef) & 3) == 0) {
+    uint32_t *dst = reinterpret_cast<uint32_t *>(q_coef + (size_t)tu0 * wh);
+    for (int e = tid; e < (here * wh) >> 1; e += 64) {
+      const int b = (2 * e) >> l2wh, pos = 2 * e - (b << l2wh);
+      dst[e] = *reinterpret_cast<const uint32_t *>(sDyn + b * per_tu + 2 * pos);
+    }
+  } else {
+    for (int e = tid; e < here * wh; e += 64) {
+      const int b = e >> l2wh, pos = e - (b << l2wh);
+      q_coef[(size_t)tu0 * wh + e] = reinterpret_cast<const int16_t *>(sDyn + b * per_tu)[pos];
+    }
   }
 }
 
@@ -586,17 +802,13 @@ extern "C" int uvghip_rdoq_batch(int bitdepth, const int16_t *coef, int16_t *q_c
   P.lambda = lambda;
   P.ctx = *ctx_host;
   const int wh = width * height;
-  // per block: cost_coeff (double) + coefficients + levels (int16) + meta (byte) per position; then 64 group costs per block
-  // blocks per wave (four lanes each).  The kernel is issue-bound (SQ counters, tools/dev/rdoq_pmc.sh: ~1900 instructions per
-  // coefficient group and wave, VALU active > 50 %); a wave's work does not depend on how many blocks share it, so more blocks
-  // per wave = the same latency at a fraction of the GPU time.  16 while the LDS allows (<= 256 coefficients), else 4.
-  const int tus = wh <= 512 ? 16 : 8;
-  const size_t per_tu = ((size_t)wh * 5 + 7) & ~(size_t)7;
-  const size_t lds = (size_t)tus * per_tu + (size_t)tus * 64 * sizeof(double);
+  // blocks per wave (four lanes each): 16.  LDS per block: levels (int16) + meta (byte) per position, odd word stride
+  const int tus = 16;
+  const size_t per_tu = (size_t)wh * 3 + 4;
+  const size_t lds = (size_t)tus * per_tu;
   double *w = static_cast<double *>(workspace);
   hipStream_t st = uvghip_stream(stream);
   const int grid = (n + tus - 1) / tus;
-  if (tus == 16) rdoq_kernel<16><<<grid, 64, lds, st>>>(P, coef, q_coef, w, abs_sum_out, has_coeffs);
-  else rdoq_kernel<8><<<grid, 64, lds, st>>>(P, coef, q_coef, w, abs_sum_out, has_coeffs);
+  rdoq_kernel<16><<<grid, 64, lds, st>>>(P, coef, q_coef, w, abs_sum_out, has_coeffs);
   UVGHIP_CHECK_LAUNCH();
 }
