@@ -288,6 +288,32 @@ def cpu_baseline(fr_host_y, fr_host_u, fr_host_v, W, H, DEPTH):
                       f"encoder: BASELINE.md has the reference's full 1080p medium encode at 2.2 fps on 8 vCPU (AVX2)"}
 
 
+def closed_loop_probe(L, wl, device, reps=3):
+    """The same picture coded CLOSED loop (pipeline.ClosedLoopIntra: fixed uniform CU partition, references from the
+    reconstruction, wavefront levels replayed from one hipGraph): the dependency-bound rate that goes next to the open-loop
+    throughput.  Reported, not part of `value`."""
+    n = 16 if (wl["W"] % 16 == 0 and wl["H"] % 16 == 0) else 8
+    cl = pipeline.ClosedLoopIntra(L, wl, 0, n, device, api.make_modes(MODES, device), qp=QP)
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    g = pipeline.Graph(L, cl.launches, st)
+    g.launch(st.cuda_stream)
+    st.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps):
+        g.launch(st.cuda_stream)
+    e1.record(st)
+    st.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    g.destroy()
+    return {"cu_size": n, "chroma": bool(cl.chroma), "rdoq": bool(cl.rdoq), "blocks": int(len(cl.blocks)), "wavefront_levels": int(cl.n_levels),
+            "launches_per_picture": len(cl.launches), "ms_per_picture": round(ms, 3), "frames_per_s": round(1e3 / ms, 2),
+            "us_per_level": round(1e3 * ms / cl.n_levels, 2),
+            "note": "one picture in flight; a level holds at most a few dozen CUs, so this is launch-latency bound, not throughput "
+                    "bound -- the encoder overlaps pictures (owf) and CTU rows of different pictures to fill the GPU"}
+
+
 def measure(args, wl_name, L, device, rank, local_rank, world, dist, transport, steps, warmup, n_resident, want_tables):
     wl = WORKLOADS[wl_name]
     shard_rows = world > 1 and args.shard == "rows"
@@ -393,6 +419,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="--shard rows: skip the all-to-all of reconstructed bands")
     ap.add_argument("--workload", choices=("1080p8", "2160p10alf"), default="1080p8",
                     help="1080p8 = BASELINE.json configs[1] (the judged line); 2160p10alf = configs[3]")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed-loop (dependency-bound) probe")
     ap.add_argument("--no-extra", action="store_true", help="do not also time the 2160p10alf workload (extra_workloads)")
     args = ap.parse_args()
 
@@ -491,6 +518,8 @@ def main():
                 "workload": workload_text(ewl, args.shard, world), "kernel_sum_ms": round(etot, 4),
                 "comm_bytes_per_step_rank0": ({k: {"sent": v[0], "received": v[1]} for k, v in efr.comm_bytes().items()} if extra["shard_rows"] else None),
                 "kernels_top": dict(top)}}
+        if world == 1 and not args.no_closed_loop:
+            out["closed_loop"] = closed_loop_probe(L, wl, device)
         if world == 1 and not args.no_cpu_baseline and wl_name == "1080p8":
             y, u, v = fr.host
             out["cpu_baseline"] = cpu_baseline(y, u, v, wl["W"], wl["H"], wl["depth"])

@@ -528,13 +528,14 @@ extern "C" int uvghip_alf_cov_expand(const int64_t *records, const uint32_t *pre
 // Frame-level sums per class (what alf.c:792-835 accumulates over the CTUs before deriving the filters), as
 // UVGHIP_ALF_SUM_WORDS int64 per class: the ee triangle, then y widened to int64, then pix_acc.  A workgroup owns
 // (class, a slice of the rectangles); slices meet through 64-bit atomics on the zeroed output.
-constexpr int ALF_REDUCE_SLICES = 16;
+// (a slice is a short serial chain of dependent loads -- mask, then the record it selects: many short slices, not few long ones)
+constexpr int ALF_REDUCE_PER_SLICE = 12;
 __global__ void __launch_bounds__(256)
 alf_cov_reduce_kernel(const long long *__restrict__ records, const uint32_t *__restrict__ present, int n, int ncls,
                       unsigned long long *__restrict__ sums)
 {
   const int c = blockIdx.x, slice = blockIdx.y, t = threadIdx.x;
-  const int per = (n + ALF_REDUCE_SLICES - 1) / ALF_REDUCE_SLICES;
+  const int per = (n + (int)gridDim.y - 1) / (int)gridDim.y;
   const int r0 = slice * per, r1 = min(n, r0 + per);
   constexpr int NV = (UVGHIP_ALF_SUM_WORDS + 255) / 256;
   long long acc[NV];
@@ -571,6 +572,7 @@ extern "C" int uvghip_alf_cov_reduce(const int64_t *records, const uint32_t *pre
   hipStream_t st = uvghip_stream(stream);
   UVGHIP_TRY(hipMemsetAsync(sums, 0, (size_t)ncls * UVGHIP_ALF_SUM_WORDS * 8, st));
   if (n <= 0) return 0;
-  alf_cov_reduce_kernel<<<dim3(ncls, ALF_REDUCE_SLICES), 256, 0, st>>>((const long long *)records, present, n, ncls, (unsigned long long *)sums);
+  const int slices = (n + ALF_REDUCE_PER_SLICE - 1) / ALF_REDUCE_PER_SLICE;
+  alf_cov_reduce_kernel<<<dim3(ncls, slices), 256, 0, st>>>((const long long *)records, present, n, ncls, (unsigned long long *)sums);
   UVGHIP_CHECK_LAUNCH();
 }

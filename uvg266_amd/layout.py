@@ -133,3 +133,38 @@ def frames_of_rank(rank, world, n_frames):
     """Frames a rank owns when a sequence is sharded over `world` ranks (all-intra: frames are
     independent units): frame t belongs to rank t % world."""
     return list(range(rank, n_frames, world))
+
+
+def coding_order(xy, n):
+    """Indices that put uniform n x n blocks into coding order: CTUs in raster order, quad-tree z-order inside a CTU."""
+    xy = np.asarray(xy, np.int64)
+    x, y = xy[:, 0], xy[:, 1]
+    z = _zindex((x % CTU) // 4, (y % CTU) // 4)
+    return np.lexsort((z, x // CTU, y // CTU))
+
+
+def dependency_levels(blks, n):
+    """Wavefront levels of closed-loop intra coding for uniform n x n blocks: level[b] = 1 + max(level of every block whose
+    reconstruction b's reference samples come from) -- the row above from x - 1 to x + avail_top - 1 and the column to the left
+    down to y + avail_left - 1 (uvg_intra_build_reference, src/intra.c:1252-1318).  `blks`: (k,4) rows of intra_availability.
+    Blocks of one level are independent; levels must run in order.  This is the reference's WPP dependency
+    (encoderstate.c:1085-1189: a CTU waits for its left and above-right neighbours) refined to CU granularity."""
+    blks = np.asarray(blks, np.int64)
+    index = {(int(bx), int(by)): i for i, (bx, by) in enumerate(zip(blks[:, 0] // n, blks[:, 1] // n))}
+    level = np.full(len(blks), -1, np.int32)
+    for i in coding_order(blks[:, :2], n):
+        x, y, at, al = (int(v) for v in blks[i])
+        bx, by = x // n, y // n
+        deps = []
+        if y > 0:
+            deps += [(k, by - 1) for k in range(bx - (1 if x > 0 else 0), (x + max(at, 1) - 1) // n + 1)]
+        if x > 0:
+            deps += [(bx - 1, k) for k in range(by, (y + max(al, 1) - 1) // n + 1)]
+        lv = -1
+        for d in deps:
+            j = index.get(d)
+            if j is not None:
+                assert level[j] >= 0, "reference to a block that is coded later"
+                lv = max(lv, int(level[j]))
+        level[i] = lv + 1
+    return level
