@@ -524,7 +524,8 @@ UVGHIP_API int uvghip_alf_classify_frame(int bitdepth, const void *rec, int rec_
  * untouched), else the filter set to use:
  *   luma   (is_chroma 0): coef_sets/clip_sets = [n_sets][25 classes][13] int16, per-4x4 class/transpose from cls
  *   chroma (is_chroma 1): coef_sets/clip_sets = [n_alternatives][7] int16, cls unused
- * src and dst must be different planes (src = the pre-ALF copy alf_tmp_*). */
+ * src and dst must be different planes (src = the pre-ALF copy alf_tmp_*).  Rectangles are CTUs or parts of CTUs: at most
+ * 64 x 64 samples, x and y multiples of 4 (the classification grid). */
 UVGHIP_API int uvghip_alf_filter_batch(int bitdepth, const void *src, int src_stride, void *dst, int dst_stride, int pic_w,
                             int pic_h, int is_chroma, const uvghip_rect_t *rects, const int32_t *set_idx, int n,
                             const int16_t *coef_sets, const int16_t *clip_sets, const uint8_t *cls, int cls_stride,

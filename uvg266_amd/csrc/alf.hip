@@ -110,7 +110,17 @@ extern "C" int uvghip_alf_classify_band(int bitdepth, const void *rec, int rec_s
 __device__ static const int8_t kPerm7[4][13] = {{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12}, {9, 4, 10, 8, 1, 5, 11, 7, 3, 0, 2, 6, 12},
                                                 {0, 3, 2, 1, 8, 7, 6, 5, 4, 9, 10, 11, 12}, {9, 8, 10, 4, 3, 7, 11, 5, 1, 0, 2, 6, 12}};
 
+// the same, padded to 16 bytes per transpose: fetched as three words (statistics kernel)
+__device__ static const int8_t kPermPad[4][16] __attribute__((aligned(16))) = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 0, 0, 0}, {9, 4, 10, 8, 1, 5, 11, 7, 3, 0, 2, 6, 12, 0, 0, 0},
+    {0, 3, 2, 1, 8, 7, 6, 5, 4, 9, 10, 11, 12, 0, 0, 0}, {9, 8, 10, 4, 3, 7, 11, 5, 1, 0, 2, 6, 12, 0, 0, 0}};
+
 #define ALF_FILTER_SPLIT 4
+// A rectangle (at most 64 x 64) is filtered by ALF_FILTER_SPLIT workgroups, each a band of its rows.  The band's source
+// window -- its rows +-3 (+-2 chroma), the rectangle's columns +-3, coordinates clamped to the picture exactly as the
+// per-sample fetch of the reference's padded picture would see them -- is staged once in LDS; a thread then filters four
+// horizontally adjacent samples (one row of a 4x4 block: same class, same transpose, so the 12 coefficient / clip pairs are
+// fetched once per four samples) and writes them with one store.
 template <typename PX, bool CHROMA>
 __global__ void __launch_bounds__(256)
 alf_filter_kernel(const PX *__restrict__ src, int sstride, PX *__restrict__ dst, int dstride, int pic_w, int pic_h,
@@ -121,46 +131,80 @@ alf_filter_kernel(const PX *__restrict__ src, int sstride, PX *__restrict__ dst,
   constexpr int NSET = CHROMA ? 7 : 25 * 13;
   constexpr int vbh = CHROMA ? 32 : 64, vb_pos = CHROMA ? 30 : 60;
   constexpr int DEPTH = px_traits<PX>::depth;
+  constexpr int HALF = CHROMA ? 2 : 3;
+  constexpr int WP = 64 + 2 * 3 + 2;        // window pitch in samples (72: rows start 16-byte aligned for 16-bit samples)
+  constexpr int MAXROWS = 64 / ALF_FILTER_SPLIT + 2 * 3 + 4;
   __shared__ int16_t sCoef[25 * 13], sClip[25 * 13];
-  const int rect_i = blockIdx.x / ALF_FILTER_SPLIT, part = blockIdx.x % ALF_FILTER_SPLIT;   // a rectangle = ALF_FILTER_SPLIT workgroups
+  __shared__ PX sWin[MAXROWS * WP];
+  const int rect_i = blockIdx.x / ALF_FILTER_SPLIT, part = blockIdx.x % ALF_FILTER_SPLIT;
   const int si = set_idx[rect_i];
   if (si < 0) return;                       // CTU not filtered: dst keeps what it has (alf.c:5088)
   const uvghip_rect_t R = rects[rect_i];
   for (int i = threadIdx.x; i < NSET; i += blockDim.x) { sCoef[i] = coef_sets[(size_t)si * NSET + i]; sClip[i] = clip_sets[(size_t)si * NSET + i]; }
+  // the band: whole 4-row block rows
+  const int brows = (R.h + 3) >> 2, per = (brows + ALF_FILTER_SPLIT - 1) / ALF_FILTER_SPLIT;
+  const int yb0 = min(R.h, part * per * 4), yb1 = min(R.h, (part + 1) * per * 4);
+  if (yb0 >= yb1) return;
+  const int wrows = yb1 - yb0 + 2 * HALF, wcols = R.w + 2 * HALF;
+  for (int i = threadIdx.x; i < wrows * wcols; i += blockDim.x) {
+    const int ry = i / wcols, rx = i - ry * wcols;
+    sWin[ry * WP + rx] = (PX)pxc<PX>(src, sstride, pic_w, pic_h, R.x - HALF + rx, R.y + yb0 - HALF + ry);
+  }
   __syncthreads();
   const int shift = DEPTH - 1, offset = 1 << (shift - 1);
-  const int per = (R.w * R.h + ALF_FILTER_SPLIT - 1) / ALF_FILTER_SPLIT;
-  for (int i = part * per + threadIdx.x; i < min(R.w * R.h, (part + 1) * per); i += blockDim.x) {
-    const int yy = i / R.w, x = R.x + (i - yy * R.w), y = R.y + yy;
+  const int quads = (R.w + 3) >> 2;
+  for (int i = threadIdx.x; i < quads * (yb1 - yb0); i += blockDim.x) {
+    const int yy = i / quads, xq = (i - yy * quads) * 4;
+    const int x = R.x + xq, y = R.y + yb0 + yy;
     const int y_vb = y & (vbh - 1);
     int lim = 3;
     if (y_vb < vb_pos && y_vb >= vb_pos - (CHROMA ? 2 : 4)) lim = vb_pos - 1 - y_vb;
     else if (y_vb >= vb_pos && y_vb <= vb_pos + (CHROMA ? 1 : 3)) lim = y_vb - vb_pos;
     const int r1 = min(1, lim), r2 = min(2, lim), r3 = min(3, lim);
     const bool near_vb = y_vb == vb_pos - 1 || y_vb == vb_pos;
-#define S(dx, dy) pxc<PX>(src, sstride, pic_w, pic_h, x + (dx), y + (dy))
-    const int cur = S(0, 0);
-    int sum = 0;
+    const PX *W0 = sWin + (yy + HALF) * WP + xq + HALF;          // the first of the four samples inside the window
+    int sum[4] = {0, 0, 0, 0}, cur[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur[q] = W0[q];
+    // one tap pair (coefficient cf, clip cc) at (+ax, +ay) / (-ax, -ay) for the four samples
+#define TAP(cf_, cc_, ax, ay)                                                                   \
+    {                                                                                           \
+      const int cf__ = (cf_), cc__ = (cc_);                                                     \
+      const PX *pa = W0 + (ay) * WP + (ax), *pb = W0 - (ay) * WP - (ax);                        \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) sum[q] += cf__ * clip_pair(cc__, cur[q], pa[q], pb[q]); \
+    }
     if constexpr (!CHROMA) {
       const int cl = cls[(y >> 2) * cls_stride + (x >> 2)];
       const int16_t *cf = sCoef + (cl & 31) * 13, *cc = sClip + (cl & 31) * 13;
       const int8_t *pm = kPerm7[cl >> 5];
-#define T(k, ax, ay, bx_, by_) sum += cf[pm[k]] * clip_pair(cc[pm[k]], cur, S(ax, ay), S(bx_, by_))
+#define T(k, ax, ay, bx_, by_) TAP(cf[pm[k]], cc[pm[k]], ax, ay)
       T(0, 0, r3, 0, -r3);
       T(1, 1, r2, -1, -r2); T(2, 0, r2, 0, -r2); T(3, -1, r2, 1, -r2);
       T(4, 2, r1, -2, -r1); T(5, 1, r1, -1, -r1); T(6, 0, r1, 0, -r1); T(7, -1, r1, 1, -r1); T(8, -2, r1, 2, -r1);
       T(9, 3, 0, -3, 0); T(10, 2, 0, -2, 0); T(11, 1, 0, -1, 0);
 #undef T
     } else {
-#define T(k, ax, ay, bx_, by_) sum += sCoef[k] * clip_pair(sClip[k], cur, S(ax, ay), S(bx_, by_))
+#define T(k, ax, ay, bx_, by_) TAP(sCoef[k], sClip[k], ax, ay)
       T(0, 0, r2, 0, -r2);
       T(1, 1, r1, -1, -r1); T(2, 0, r1, 0, -r1); T(3, -1, r1, 1, -r1);
       T(4, 2, 0, -2, 0); T(5, 1, 0, -1, 0);
 #undef T
     }
-#undef S
-    sum = near_vb ? (sum + (1 << (shift + 2))) >> (shift + 3) : (sum + offset) >> shift;
-    dst[(size_t)y * dstride + x] = (PX)clampi(sum + cur, 0, px_traits<PX>::maxv);
+#undef TAP
+    unsigned out[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int sq = near_vb ? (sum[q] + (1 << (shift + 2))) >> (shift + 3) : (sum[q] + offset) >> shift;
+      out[q] = (unsigned)clampi(sq + cur[q], 0, px_traits<PX>::maxv);
+    }
+    PX *d = dst + (size_t)y * dstride + x;
+    if (xq + 4 <= R.w && ((reinterpret_cast<uintptr_t>(d) & (4 * sizeof(PX) - 1)) == 0)) {
+      if constexpr (sizeof(PX) == 1) *reinterpret_cast<uint32_t *>(d) = out[0] | out[1] << 8 | out[2] << 16 | out[3] << 24;
+      else *reinterpret_cast<uint2 *>(d) = make_uint2(out[0] | out[1] << 16, out[2] | out[3] << 16);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (xq + q < R.w) d[q] = (PX)out[q];
+    }
   }
 }
 
@@ -181,69 +225,6 @@ extern "C" int uvghip_alf_filter_batch(int bitdepth, const void *src, int src_st
 }
 
 // --------------------------------------------------------------------- statistics ----
-// e[k][b] of one sample (alf-generic.c:742-905).  pat maps the tap visiting order of each
-// transpose to the coefficient index; center is the last coefficient.
-template <typename PX, bool CHROMA>
-__device__ inline void covariance_sample(int16_t *e /*[13][4]*/, const PX *rec, int stride, int pic_w, int pic_h, int x, int y,
-                                         int tr, int vb_distance, const int *clipv)
-{
-  constexpr int half = CHROMA ? 2 : 3;
-  constexpr int NC = CHROMA ? 7 : 13;
-  int top = -4, bot = 4;
-  if (vb_distance >= -3 && vb_distance < 0) { bot = -vb_distance - 1; top = -bot; }
-  else if (vb_distance >= 0 && vb_distance < 3) { top = -vb_distance; bot = -top; }
-  int acc[NC][4];
-#pragma unroll
-  for (int k = 0; k < NC; ++k)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[k][b] = 0;
-  const int cur = pxc<PX>(rec, stride, pic_w, pic_h, x, y);
-  // Visit the upper half of the diamond in the canonical (transpose 0) order; the coefficient a tap feeds
-  // under transpose t is found by mapping the tap position instead of re-ordering the loops:
-  //   t=1: (i,j) -> (j,i)   t=2: (i,j) -> (i,-j)   t=3: (i,j) -> (j,-i) composed as in the reference loops.
-  // Equivalent formulation used here: enumerate coefficient slots k in the order the reference's loops
-  // for transpose t produce them, and compute which sample pair each slot reads.
-  int k = 0;
-  auto add = [&](int kk, int dx0, int dy0, int dx1, int dy1) {
-    const int a = pxc<PX>(rec, stride, pic_w, pic_h, x + dx0, y + dy0), b2 = pxc<PX>(rec, stride, pic_w, pic_h, x + dx1, y + dy1);
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[kk][b] += clip_pair(clipv[b], cur, a, b2);
-  };
-  auto rowp = [&](int i) { return max(i, top); };
-  auto rown = [&](int i) { return -max(i, -bot); };
-  if (tr == 0 || tr == 2) {
-#pragma unroll
-    for (int i = -half; i < 0; ++i) {
-      const int n = 2 * (half + i) + 1;
-#pragma unroll
-      for (int s = 0; s < n; ++s, ++k) {
-        const int j = tr == 0 ? -half - i + s : half + i - s;
-        add(k, j, rowp(i), -j, rown(i));
-      }
-    }
-#pragma unroll
-    for (int j = -half; j < 0; ++j, ++k) add(k, j, 0, -j, 0);
-  } else {
-#pragma unroll
-    for (int j = -half; j < 0; ++j) {
-      const int n = 2 * (half + j) + 1;
-#pragma unroll
-      for (int s = 0; s < n; ++s, ++k) {
-        const int i = tr == 1 ? -half - j + s : half + j - s;
-        add(k, j, rowp(i), -j, rown(i));
-      }
-    }
-#pragma unroll
-    for (int i = -half; i < 0; ++i, ++k) add(k, 0, rowp(i), 0, rown(i));
-  }
-#pragma unroll
-  for (int b = 0; b < 4; ++b) acc[NC - 1][b] += cur;
-#pragma unroll
-  for (int kk = 0; kk < NC; ++kk)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) e[kk * 4 + b] = (int16_t)acc[kk][b];
-}
-
 // The covariance is the one dense contraction of the path: per class, C = [E | d]^T [E | d] with E the
 // n_samples x 52 matrix of clipped tap sums and d = org - rec; ee[k][l][b0][b1] = C[4k+b0][4l+b1], y[k][b] = C[4k+b][52],
 // pix_acc = C[52][52].  It runs on the i8 matrix cores with exact integer arithmetic: every 12-bit signed entry is
@@ -283,7 +264,8 @@ alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__
   __shared__ uint8_t sBlkCls[256];
   __shared__ uint16_t sSlot[256 + 32];         // class-ordered block list, 0xffff = padding slot
   __shared__ uint8_t sSlotCls[256 + 32];
-  __shared__ int sCnt[32], sPos[32];
+  __shared__ int sCnt[32], sPos[32], sFill[32];
+  __shared__ uint8_t sPairK[91], sPairL[91];   // COMPACT: pair index -> (k, l), k <= l
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const uvghip_rect_t R = rects[blockIdx.x];
   long long *E = ee + (size_t)blockIdx.x * NCLS * (COMPACT ? UVGHIP_ALF_REC_WORDS : 13 * 13 * 16);
@@ -297,7 +279,10 @@ alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__
 
   // ---- class-ordered slot list (stable counting sort; every class padded to an even number of blocks) ----
   const int bw = (R.w + 3) / 4, bhh = (R.h + 3) / 4, nblk = bw * bhh;      // <= 256 (rectangles are at most 64x64)
-  if (t < 32) sCnt[t] = 0;
+  if (t < 32) { sCnt[t] = 0; sFill[t] = 0; }
+  if (t < 91) { int k = 0, base = 0; while (t >= base + 13 - k) { base += 13 - k; ++k; } sPairK[t] = (uint8_t)k; sPairL[t] = (uint8_t)(k + (t - base)); }
+  const int half_fp = CHROMA ? 2 : 3;
+  const bool interior = R.x >= half_fp && R.y >= half_fp && R.x + R.w + half_fp <= pic_w && R.y + R.h + half_fp <= pic_h;
   for (int i = t; i < NROW * ALF_KP; i += 256) { sH[i] = 0; sL[i] = 0; }   // rows NE+1.. stay zero for good
   __syncthreads();
   for (int i = t; i < nblk; i += 256) {
@@ -310,10 +295,10 @@ alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__
   if (t == 0) { int run = 0; for (int c = 0; c < 32; ++c) { sPos[c] = run; run += (sCnt[c] + 1) & ~1; } }
   __syncthreads();
   const int nslot = sPos[31] + ((sCnt[31] + 1) & ~1);                      // even
+  // (the order of the blocks inside a class does not matter: integer sums)
   for (int i = t; i < nblk; i += 256) {
     const int c = sBlkCls[i];
-    int rank = 0;
-    for (int j = 0; j < i; ++j) rank += sBlkCls[j] == c;
+    const int rank = atomicAdd(&sFill[c], 1);
     sSlot[sPos[c] + rank] = (uint16_t)i; sSlotCls[sPos[c] + rank] = (uint8_t)c;
   }
   if (t < 32 && (sCnt[t] & 1)) { sSlot[sPos[t] + sCnt[t]] = 0xffffu; sSlotCls[sPos[t] + sCnt[t]] = (uint8_t)t; }
@@ -362,9 +347,7 @@ alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__
         long long *Rc = E + (size_t)n_done * UVGHIP_ALF_REC_WORDS;
         for (int idx = t; idx < 91 * 16; idx += 256) {
           const int b1 = idx & 3, b0 = (idx >> 2) & 3, p = idx >> 4;
-          int k = 0, base = 0;                                        // pair p -> (k, l), k <= l: row k holds 13 - k pairs
-          while (p >= base + 13 - k) { base += 13 - k; ++k; }
-          const int l = k + (p - base);
+          const int k = sPairK[p], l = sPairL[p];                     // pair p -> (k, l), k <= l: row k holds 13 - k pairs
           Rc[idx] = (l < NC) ? cval(4 * k + b0, 4 * l + b1) : 0;
         }
         int32_t *Yc = reinterpret_cast<int32_t *>(Rc + 91 * 16);
@@ -387,12 +370,20 @@ alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__
 
   for (int c0 = 0; c0 < nslot; c0 += ALF_SLOTS) {
     const int ns = min(ALF_SLOTS, nslot - c0);                    // even
-    // ---- phase A: one sample per thread: tap sums -> digit planes ----
+    // ---- phase A: one sample per thread: clipped tap-pair sums -> digit planes ----
+    // The pairs are visited in the geometric order of the filter (alf_filter_kernel) -- (+ax, +ay) / (-ax, -ay) with the row
+    // offsets limited at the virtual boundary -- and the sums of pair g go to the rows of the coefficient that pair feeds
+    // under the block's transpose, kPermPad[transpose][g] (alf-generic.c:742-905 enumerates the same pairs per transpose).
     {
       const int j = t >> 4, p = t & 15;
-      int16_t ev[52];
-      int dval = 0;
-      bool live = false;
+      constexpr int NG = CHROMA ? 6 : 12;
+      int pr[NG][4];
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) pr[g][b] = 0;
+      int dval = 0, cur = 0;
+      uint32_t pw[3] = {0x03020100u, 0x07060504u, 0x0b0a0908u};          // identity
       if (j < ns) {
         const int blk = sSlot[c0 + j];
         if (blk != 0xffff) {
@@ -400,19 +391,75 @@ alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__
           const int xx = bx * 4 + (p & 3), yy = by * 4 + (p >> 2);
           if (xx < R.w && yy < R.h) {
             const int x = R.x + xx, y = R.y + yy;
-            int tr = 0;
-            if constexpr (!CHROMA) tr = cls[(y >> 2) * cls_stride + (x >> 2)] >> 5;
-            covariance_sample<PX, CHROMA>(ev, rec, rstride, pic_w, pic_h, x, y, tr, (y % vbh) - vb_pos, clipv);
-            dval = (int)org[(size_t)y * ostride + x] - (int)rec[(size_t)y * rstride + x];
-            live = true;
+            int trv = 0;
+            if constexpr (!CHROMA) {
+              trv = cls[(y >> 2) * cls_stride + (x >> 2)] >> 5;
+              const uint32_t *pm = reinterpret_cast<const uint32_t *>(kPermPad[trv]);
+              pw[0] = pm[0]; pw[1] = pm[1]; pw[2] = pm[2];
+            }
+            (void)trv;
+            const int y_vb = y & (vbh - 1);
+            int lim = 3;
+            if (y_vb < vb_pos && y_vb >= vb_pos - (CHROMA ? 2 : 4)) lim = vb_pos - 1 - y_vb;
+            else if (y_vb >= vb_pos && y_vb <= vb_pos + (CHROMA ? 1 : 3)) lim = y_vb - vb_pos;
+            const int r1 = min(1, lim), r2 = min(2, lim), r3 = min(3, lim);
+            // alf-generic.c:742-905 clamps a pair's row offset at the virtual boundary only where its loop variable is
+            // negative; under transposes 1 and 3 the pairs (-1, 2), (-1, 1), (-2, 1) are visited with a positive one and keep
+            // their full offsets.  Reproduced.
+            const bool odd = CHROMA ? false : (trv & 1) != 0;
+            const int q2 = odd ? 2 : r2, q1 = odd ? 1 : r1;
+            // every sample of the footprint first (one batch of loads in flight), then the arithmetic
+            constexpr int NP = 2 * NG + 1;
+            int sv[NP];
+            int dxs[NG], dys[NG];
+            if constexpr (!CHROMA) {
+              const int tx[12] = {0, 1, 0, -1, 2, 1, 0, -1, -2, 3, 2, 1};
+              const int ty[12] = {r3, r2, r2, q2, r1, r1, r1, q1, q1, 0, 0, 0};
+#pragma unroll
+              for (int g = 0; g < 12; ++g) { dxs[g] = tx[g]; dys[g] = ty[g]; }
+            } else {
+              const int tx[6] = {0, 1, 0, -1, 2, 1};
+              const int ty[6] = {r2, r1, r1, r1, 0, 0};
+#pragma unroll
+              for (int g = 0; g < 6; ++g) { dxs[g] = tx[g]; dys[g] = ty[g]; }
+              (void)r3; (void)q2; (void)q1;
+            }
+            if (interior) {
+              const PX *c0 = rec + (size_t)y * rstride + x;
+              sv[2 * NG] = c0[0];
+#pragma unroll
+              for (int g = 0; g < NG; ++g) { const int o = dys[g] * rstride + dxs[g]; sv[2 * g] = c0[o]; sv[2 * g + 1] = c0[-o]; }
+            } else {
+              sv[2 * NG] = pxc<PX>(rec, rstride, pic_w, pic_h, x, y);
+#pragma unroll
+              for (int g = 0; g < NG; ++g) {
+                sv[2 * g] = pxc<PX>(rec, rstride, pic_w, pic_h, x + dxs[g], y + dys[g]);
+                sv[2 * g + 1] = pxc<PX>(rec, rstride, pic_w, pic_h, x - dxs[g], y - dys[g]);
+              }
+            }
+            cur = sv[2 * NG];
+            dval = (int)org[(size_t)y * ostride + x] - cur;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+              const int d0 = sv[2 * g] - cur, d1 = sv[2 * g + 1] - cur;
+              pr[g][0] = d0 + d1;                      // clipv[0] = 1 << depth never clips a sample difference
+#pragma unroll
+              for (int b = 1; b < 4; ++b) pr[g][b] = clampi(d0, -clipv[b], clipv[b]) + clampi(d1, -clipv[b], clipv[b]);
+            }
           }
         }
       }
       if (j < ns) {
 #pragma unroll
-        for (int q = 0; q < NE; ++q) {
-          const int v = live ? (int)ev[q] : 0;
-          sH[q * ALF_KP + t] = (int8_t)(v >> 7); sL[q * ALF_KP + t] = (int8_t)(v & 127);
+        for (int g = 0; g < NG; ++g) {
+          const int k = (int)((pw[g >> 2] >> (8 * (g & 3))) & 255);
+          int8_t *ph = sH + (4 * k) * ALF_KP + t, *pl = sL + (4 * k) * ALF_KP + t;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) { ph[b * ALF_KP] = (int8_t)(pr[g][b] >> 7); pl[b * ALF_KP] = (int8_t)(pr[g][b] & 127); }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {                                     // the centre coefficient: the sample itself
+          sH[(4 * (NC - 1) + b) * ALF_KP + t] = (int8_t)(cur >> 7); sL[(4 * (NC - 1) + b) * ALF_KP + t] = (int8_t)(cur & 127);
         }
         sH[NE * ALF_KP + t] = (int8_t)(dval >> 7); sL[NE * ALF_KP + t] = (int8_t)(dval & 127);
       }
