@@ -185,7 +185,9 @@ __device__ __forceinline__ double quad_bcast(double v)
 // LDS per block: level int16[wh] (holds the input coefficient until the position's group is staged) + meta byte[wh]
 // (bits 0-1: Rice parameter after this position, bits 2-6: code of the significance-cost table entry); block strides are
 // odd in words so that the same position of the 16 blocks of a wave falls into 16 different banks.
-template <int TUS>
+// SHAPE: log2 of the side of a square block (2..5) -- dimensions and plane type (CHROMA) become compile-time constants and
+// every shape is its own kernel symbol in a profile -- or 0 for the generic kernel (rectangles; everything from the parameters).
+template <int TUS, int SHAPE, int CHROMA>
 __global__ void __launch_bounds__(64)
 rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__restrict__ q_coef, double *__restrict__ ws,
             uint32_t *__restrict__ abs_sum_out, uint8_t *__restrict__ has_coeffs)
@@ -207,22 +209,11 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   __shared__ int sStageI[TUS][49];
   __shared__ double sCgCostAll[TUS][65];
   const int tid = threadIdx.x, grp = tid >> 2, j = tid & 3;
-  const int width = P.width, height = P.height, wh = width * height, l2w = P.l2w;
+  const int l2w = SHAPE ? SHAPE : P.l2w, l2h_ = SHAPE ? SHAPE : P.l2h;
+  const int width = 1 << l2w, height = 1 << l2h_, wh = width * height;
   const int n = P.n;
-  const int tu0 = blockIdx.x * TUS;
-  const int here = min(TUS, n - tu0);
-  const bool live = grp < here;
-  const int gq = live ? grp : 0;                                       // idle lanes alias block 0 for address arithmetic only
-  const int tu = tu0 + gq;
   const size_t per_tu = (size_t)wh * 3 + 4;
-  double *gCost = ws + (size_t)tu * wh;                                // cost_coeff[] of this block (re-read by the last-position search)
-  const int16_t *gCoef = coef + (size_t)tu * wh;
-  int16_t *sLev = reinterpret_cast<int16_t *>(sDyn + gq * per_tu);
-  uint8_t *sMeta = reinterpret_cast<uint8_t *>(sLev + wh);
-  double *D = sStageD[gq];
-  int *I = sStageI[gq];
-  double *sCgCost = sCgCostAll[gq];
-  const int t = P.color ? 1 : 0;
+  const int t = SHAPE ? CHROMA : (P.color ? 1 : 0);
   const int mts = P.mts_idx;
 
   // ---- per-workgroup tables ----
@@ -238,8 +229,41 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       y = x; x = 0;
     }
   }
+  __syncthreads();
+  if (tid == 0) {                                                      // calc_last_bits, rdo.c:667-700
+    auto prefix_ctx = [](int l2) { return l2 <= 2 ? 0 : l2 == 3 ? 3 : l2 == 4 ? 6 : 10; };   // {0,0,0,3,6,10,15,21}[log2 size]
+    const int l2h = l2h_;
+    const int ox = t ? 0 : prefix_ctx(l2w), oy = t ? 0 : prefix_ctx(l2h);
+    const int sx = t ? clampi(width >> 3, 0, 2) : ((l2w + 1) >> 2), sy = t ? clampi(height >> 3, 0, 2) : ((l2h + 1) >> 2);
+    int bits = 0, c;
+    for (c = 0; c < group_idx(width - 1); ++c) {
+      const int o = O_LASTX + 20 * t + ox + (c >> sx);
+      sLastX[c] = bits + (int)sB[o][0]; bits += (int)sB[o][1];
+    }
+    sLastX[c] = bits;
+    bits = 0;
+    for (c = 0; c < group_idx(height - 1); ++c) {
+      const int o = O_LASTY + 20 * t + oy + (c >> sy);
+      sLastY[c] = bits + (int)sB[o][0]; bits += (int)sB[o][1];
+    }
+    sLastY[c] = bits;
+  }
+  __syncthreads();
+  // ---- a workgroup takes batches of TUS blocks until none are left: the tables above are built once ----
+  for (int tu0 = blockIdx.x * TUS; tu0 < n; tu0 += gridDim.x * TUS) {
+  const int here = min(TUS, n - tu0);
+  const bool live = grp < here;
+  const int gq = live ? grp : 0;                                       // idle lanes alias block 0 for address arithmetic only
+  const int tu = tu0 + gq;
+  double *gCost = ws + (size_t)tu * wh;                                // cost_coeff[] of this block (re-read by the last-position search)
+  const int16_t *gCoef = coef + (size_t)tu * wh;
+  int16_t *sLev = reinterpret_cast<int16_t *>(sDyn + gq * per_tu);
+  uint8_t *sMeta = reinterpret_cast<uint8_t *>(sLev + wh);
+  double *D = sStageD[gq];
+  int *I = sStageI[gq];
+  double *sCgCost = sCgCostAll[gq];
   // ---- stage the coefficients into the level array (coalesced: the blocks of a workgroup are contiguous) ----
-  const int l2wh = l2w + P.l2h;
+  const int l2wh = l2w + l2h_;
   {
     // two coefficients per lane and step (wh is a multiple of 16: pairs never straddle blocks; 4-byte aligned: the batch
     // pointer is 2-byte aligned by contract, so pair loads need an even element offset -- tu0 * wh is a multiple of 16)
@@ -258,24 +282,6 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
     }
   }
   __syncthreads();
-  if (tid == 0) {                                                      // calc_last_bits, rdo.c:667-700
-    auto prefix_ctx = [](int l2) { return l2 <= 2 ? 0 : l2 == 3 ? 3 : l2 == 4 ? 6 : 10; };   // {0,0,0,3,6,10,15,21}[log2 size]
-    const int l2h = P.l2h;
-    const int ox = t ? 0 : prefix_ctx(l2w), oy = t ? 0 : prefix_ctx(l2h);
-    const int sx = t ? clampi(width >> 3, 0, 2) : ((l2w + 1) >> 2), sy = t ? clampi(height >> 3, 0, 2) : ((l2h + 1) >> 2);
-    int bits = 0, c;
-    for (c = 0; c < group_idx(width - 1); ++c) {
-      const int o = O_LASTX + 20 * t + ox + (c >> sx);
-      sLastX[c] = bits + (int)sB[o][0]; bits += (int)sB[o][1];
-    }
-    sLastX[c] = bits;
-    bits = 0;
-    for (c = 0; c < group_idx(height - 1); ++c) {
-      const int o = O_LASTY + 20 * t + oy + (c >> sy);
-      sLastY[c] = bits + (int)sB[o][0]; bits += (int)sB[o][1];
-    }
-    sLastY[c] = bits;
-  }
   // the Rice parameter after each position: templateAbsSum(coef, 4, ...) over the input block (rdo.c:846-871, 1697)
   if (live)
     for (int pos = j; pos < wh; pos += 4) {
@@ -455,9 +461,9 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
             if (has[k]) { const int a = zz[k] ? 0 : abs(nb[k]); sum_abs += min(4 + (a & 1), a); num_pos += a ? 1 : 0; }
           const int diag = (int)(pos_x + pos_y);
           ctx_sig = min((sum_abs + 1) >> 1, 3) + (diag < 2 ? 4 : 0);
-          if (P.color == 0) ctx_sig += diag < 5 ? 4 : 0;
+          if (t == 0) ctx_sig += diag < 5 ? 4 : 0;
           const int temp_sum = sum_abs - num_pos;
-          ctx_set = (min(temp_sum, 4) + 1) + (!diag ? ((P.color == 0) ? 15 : 5) : (P.color == 0) ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0);
+          ctx_set = (min(temp_sum, 4) + 1) + (!diag ? ((t == 0) ? 15 : 5) : (t == 0) ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0);
         }
         const double c0 = D[3 * s4 + 2];
         const uint32_t sig0 = B[O_SIG + 12 * t + ctx_sig][0], sig1 = B[O_SIG + 12 * t + ctx_sig][1];
@@ -761,6 +767,8 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       q_coef[(size_t)tu0 * wh + e] = reinterpret_cast<const int16_t *>(sDyn + b * per_tu)[pos];
     }
   }
+  __syncthreads();
+  }   // batches
 }
 
 }  // namespace
@@ -808,7 +816,21 @@ extern "C" int uvghip_rdoq_batch(int bitdepth, const int16_t *coef, int16_t *q_c
   const size_t lds = (size_t)tus * per_tu;
   double *w = static_cast<double *>(workspace);
   hipStream_t st = uvghip_stream(stream);
-  const int grid = (n + tus - 1) / tus;
-  rdoq_kernel<16><<<grid, 64, lds, st>>>(P, coef, q_coef, w, abs_sum_out, has_coeffs);
+  // one workgroup per batch of 16 blocks (measured: capping the grid and looping batches inside a workgroup to share the
+  // table set-up is slower -- the hardware dispatcher balances the uneven block times better); the in-kernel batch loop only
+  // matters beyond 2^20 batches
+  const int batches = (n + tus - 1) / tus;
+  const int grid = batches < (1 << 20) ? batches : (1 << 20);
+#define RDOQ_LAUNCH(SH, CH) rdoq_kernel<16, SH, CH><<<grid, 64, lds, st>>>(P, coef, q_coef, w, abs_sum_out, has_coeffs)
+  const int shape = width == height ? P.l2w : 0;
+  const bool ch = color != 0;
+  switch (shape) {
+    case 2: if (ch) RDOQ_LAUNCH(2, 1); else RDOQ_LAUNCH(2, 0); break;
+    case 3: if (ch) RDOQ_LAUNCH(3, 1); else RDOQ_LAUNCH(3, 0); break;
+    case 4: if (ch) RDOQ_LAUNCH(4, 1); else RDOQ_LAUNCH(4, 0); break;
+    case 5: if (ch) RDOQ_LAUNCH(5, 1); else RDOQ_LAUNCH(5, 0); break;
+    default: RDOQ_LAUNCH(0, 0); break;
+  }
+#undef RDOQ_LAUNCH
   UVGHIP_CHECK_LAUNCH();
 }
