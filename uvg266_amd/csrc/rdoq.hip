@@ -207,7 +207,8 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   // I[3*s4 + {0: rate half of candidate 1 -> level, 1: candidate 2, 2: level_double}]
   __shared__ double sStageD[TUS][49];
   __shared__ int sStageI[TUS][49];
-  __shared__ double sCgCostAll[TUS][65];
+  constexpr int NCG = SHAPE ? (1 << (2 * SHAPE - 4)) : 64;             // coefficient groups per block
+  __shared__ double sCgCostAll[TUS][NCG + 1];                          // (+1: odd stride in 8-byte units, see sStageD)
   const int tid = threadIdx.x, grp = tid >> 2, j = tid & 3;
   const int l2w = SHAPE ? SHAPE : P.l2w, l2h_ = SHAPE ? SHAPE : P.l2h;
   const int width = 1 << l2w, height = 1 << l2h_, wh = width * height;
@@ -375,6 +376,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   uint32_t reg_bins = (uint32_t)(wh * 28) >> 4;
   int go_rice_state = 0;                                               // only tracked while a group is walked sequentially
   bool exhausted = false;                                              // reg_bins < 4: it never recovers (:1692-1697 stop updating it)
+#pragma unroll 1
   for (int cgs = cg_num - 1; cgs >= 0; --cgs) {
     const int g = sScanCg[cgs];
     const bool has_last = live && last_scanpos >= 0;
@@ -587,16 +589,20 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       const int o1 = j == 1 ? 2 : j == 2 ? 1 : 0, o2 = j == 2 ? 2 : 1;
       acc_a = j == 0 ? base_cost : j == 1 ? block_uncoded_cost : 0.0;
       const double *Dp = D + o1, *Dq = D + o2;
-      double pv[16], qv[16];
 #pragma unroll
-      for (int s2 = 15; s2 >= 0; --s2) { pv[s2] = Dp[3 * s2]; qv[s2] = Dq[3 * s2]; }     // (positions past max_group: stale, unused)
+      for (int half = 1; half >= 0; --half) {                            // eight positions' operands in flight at a time
+        double pv[8], qv[8];
 #pragma unroll
-      for (int s2 = 15; s2 >= 0; --s2) {
-        if (s2 > max_group) continue;
-        const bool nz = (m >> s2) & 1;
-        const double dv = pv[s2] - qv[s2];
-        acc_a += j == 3 ? (nz ? dv : 0.0) : pv[s2];
-        acc_b += (j == 2 && nz) ? qv[s2] : 0.0;
+        for (int u = 7; u >= 0; --u) { pv[u] = Dp[3 * (8 * half + u)]; qv[u] = Dq[3 * (8 * half + u)]; }   // (past max_group: stale, unused)
+#pragma unroll
+        for (int u = 7; u >= 0; --u) {
+          const int s2 = 8 * half + u;
+          if (s2 > max_group) continue;
+          const bool nz = (m >> s2) & 1;
+          const double dv = pv[u] - qv[u];
+          acc_a += j == 3 ? (nz ? dv : 0.0) : pv[u];
+          acc_b += (j == 2 && nz) ? qv[u] : 0.0;
+        }
       }
       base_cost = quad_bcast<0>(acc_a);
       block_uncoded_cost = quad_bcast<1>(acc_a);
@@ -680,6 +686,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       }
     };
     prefetch(cg_last_scanpos);
+#pragma unroll 1
     for (int cgs = cg_last_scanpos; cgs >= 0 && !found_last; cgs--) {
       const int g = sScanCg[cgs];
       base_cost -= sCgCost[cgs];
@@ -710,22 +717,25 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       WAVE_SYNC();
       if (coded) {
         mnz = quad_or(mnz); mgt1 = quad_or(mgt1);
-        double csv[16];
 #pragma unroll
-        for (int s2 = 15; s2 >= 0; --s2) csv[s2] = D[3 * s2 + 1];        // (positions not staged: stale, unused)
+        for (int half = 1; half >= 0; --half) {
+          double csv[8];
 #pragma unroll
-        for (int s2 = 15; s2 >= 0; --s2) {
-          const int sc2 = cgs * 16 + s2;
-          if (s2 > max_group || sc2 > last_scanpos || found_last) continue;
-          if ((mnz >> s2) & 1) {
-            const double cost_last = lambda * (double)I[3 * s2 + 1];
-            const double total = base_cost + cost_last - csv[s2];
-            if (total < best_cost) { best_last_idx_p1 = sc2 + 1; best_cost = total; }
-            if ((mgt1 >> s2) & 1) { found_last = true; continue; }
-            base_cost -= D[3 * s2];
-            base_cost += D[3 * s2 + 2];
-          } else {
-            base_cost -= csv[s2];
+          for (int u = 7; u >= 0; --u) csv[u] = D[3 * (8 * half + u) + 1];   // (positions not staged: stale, unused)
+#pragma unroll
+          for (int u = 7; u >= 0; --u) {
+            const int s2 = 8 * half + u, sc2 = cgs * 16 + s2;
+            if (s2 > max_group || sc2 > last_scanpos || found_last) continue;
+            if ((mnz >> s2) & 1) {
+              const double cost_last = lambda * (double)I[3 * s2 + 1];
+              const double total = base_cost + cost_last - csv[u];
+              if (total < best_cost) { best_last_idx_p1 = sc2 + 1; best_cost = total; }
+              if ((mgt1 >> s2) & 1) { found_last = true; continue; }
+              base_cost -= D[3 * s2];
+              base_cost += D[3 * s2 + 2];
+            } else {
+              base_cost -= csv[u];
+            }
           }
         }
       }
