@@ -314,6 +314,43 @@ def closed_loop_probe(L, wl, device, reps=3):
                     "bound -- the encoder overlaps pictures (owf) and CTU rows of different pictures to fill the GPU"}
 
 
+def coeff_cost_probe(L, fr, reps=5):
+    """CABAC bit cost (uvg_get_coeff_cost's CABAC branch, count-mode coefficient coder: what the RD search prices every
+    candidate with) of all the levels one group of pictures produced -- one launch per block shape and plane over the group.
+    Reported per picture; not part of the step (the step has no RD mode decision)."""
+    import ctypes
+    models = lib.CabacModels()
+    rng = np.random.default_rng(5)
+    for i in range(244):                     # a plausible adapted state: both estimators near the same probability
+        p = int(rng.integers(2000, 30000))
+        models.state0[i], models.state1[i], models.rate[i] = p & 0x7fe0, p & 0x7ffe, (4 << 4) | 7
+    jobs = fr.pool.jobs
+    st = torch.cuda.current_stream().cuda_stream
+    outs = {k: (torch.empty(j["lev"].shape[0] * j["cnt"], dtype=torch.float64, device=j["lev"].device)) for k, j in jobs.items()}
+
+    def once():
+        for (n, color), j in jobs.items():
+            F = j["lev"].shape[0]
+            lib.check(L.uvghip_coeff_cost_batch(j["lev"].data_ptr(), j["c"], j["c"], F * j["cnt"], color, ctypes.byref(models),
+                                                outs[(n, color)].data_ptr(), None, st), "uvghip_coeff_cost_batch")
+    once()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        once()
+    e1.record()
+    torch.cuda.synchronize()
+    F = next(iter(jobs.values()))["lev"].shape[0]
+    blocks = sum(j["cnt"] for j in jobs.values())
+    ms = e0.elapsed_time(e1) / reps / F
+    bits = sum(float(o.sum()) for o in outs.values()) / F
+    return {"ms_per_picture": round(ms, 4), "blocks_per_picture": blocks, "launches_per_group": len(jobs), "pictures_per_group": F,
+            "kbits_per_picture": round(bits / 1e3, 1),
+            "note": "uvghip_coeff_cost_batch on the levels RDOQ produced (all block sizes of the step: the same picture is coded four "
+                    "times over, once per block size), synthetic adapted context models; one lane per block"}
+
+
 def measure(args, wl_name, L, device, rank, local_rank, world, dist, transport, steps, warmup, n_resident, want_tables):
     wl = WORKLOADS[wl_name]
     shard_rows = world > 1 and args.shard == "rows"
@@ -522,6 +559,8 @@ def main():
                 "kernels_top": dict(top)}}
         if world == 1 and not args.no_closed_loop:
             out["closed_loop"] = closed_loop_probe(L, wl, device)
+        if world == 1 and fr.rdoq:
+            out["coeff_cost"] = coeff_cost_probe(L, fr)
         if not args.no_extra and not strong:
             # what --shard rows would move per picture (the exchange lists of a middle rank; no communication happens here)
             pw = WORKLOADS["2160p10alf"]

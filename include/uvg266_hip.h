@@ -225,6 +225,28 @@ UVGHIP_API int uvghip_rdoq_batch(int bitdepth, const int16_t *coef, int16_t *q_c
                       const uvghip_rdoq_ctx_t *ctx_host, void *workspace, size_t workspace_bytes,
                       uint32_t *abs_sum_out, uint8_t *has_coeffs, void *stream);
 
+/* ---- CABAC bit cost of coefficient blocks ---- */
+
+/* The context models of the coefficient coder with their full state (cabac_ctx_t, src/cabac.h:47-51: two 16-bit probability
+ * states and the rate byte), in the index space of uvghip_rdoq_ctx_t: model i of that struct is entry i here, and
+ * CTX_STATE = (state0[i] + state1[i]) >> 8. */
+typedef struct uvghip_cabac_models {
+  uint16_t state0[244], state1[244];
+  uint8_t rate[244];
+} uvghip_cabac_models_t;
+
+/* replaces: uvg_get_coeff_cost on its CABAC branch = get_coeff_cabac_cost (src/rdo.c:297-356, taken when the QP is not below
+ * cfg.fast_residual_cost_limit; the other branch is uvghip_fast_coeff_cost_batch) -> uvg_encode_coeff_nxn in count mode
+ * (encode_coding_tree-generic.c:53-323) for n blocks of one shape: bits_out[i] = the bits the coefficient coder would spend on
+ * block i starting from the models in models_host (HOST pointer; every block starts from the same copy, as the reference copies
+ * its search CABAC per call), with the models adapting bin by bin inside the block.  0.0 for an all-zero block.
+ * flags_out[i] (may be NULL): what the coder records in cur_cu on the way -- bit 0 violates_lfnst_constrained_luma/_chroma,
+ * bit 1 lfnst_last_scan_pos, bit 2 mts_last_scan_pos, bit 3 violates_mts_coeff_constraint (:113-121, :303-317).
+ * width, height in {4,8,16,32}; diagonal scan; dependent quantisation and sign-data hiding off; not for transform-skip blocks
+ * (uvg_encode_ts_residual). */
+UVGHIP_API int uvghip_coeff_cost_batch(const int16_t *coeff, int width, int height, int n, int color,
+                            const uvghip_cabac_models_t *models_host, double *bits_out, uint8_t *flags_out, void *stream);
+
 /* top-left corner of a transform unit inside the planes */
 typedef struct uvghip_tu {
   int32_t x, y;

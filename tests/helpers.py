@@ -156,6 +156,15 @@ class Oracle:
                                ctypes.c_double(lam), ptr(ctx))
         return out, s
 
+    def coeff_cost(self, d, coeff, w, h, color, models):
+        """-> (bits, flags, adapted models bytes).  models: 1220 bytes = uvghip_cabac_models_t."""
+        m = np.ascontiguousarray(np.frombuffer(bytes(models), np.uint8)).copy()
+        assert m.size == 1220
+        out = np.zeros(1220, np.uint8)
+        flags = ctypes.c_uint32(0)
+        bits = self.fn(d, "coeff_cost", ctypes.c_double)(ptr(np.ascontiguousarray(coeff, np.int16)), w, h, color, ptr(m), ctypes.byref(flags), ptr(out))
+        return bits, flags.value, out
+
     def get_extended_block(self, d, wrap, src, src_w, src_h, bx, by, bw, bh, pl, pr, pt, pb, pbs):
         """-> (inside, ext_off, ext_s, buf)"""
         buf = np.full((pt + bh + pb + pbs) * (pl + bw + pr), 0x5a, src.dtype)
@@ -403,4 +412,14 @@ def shim_goldens(depth):
         elif name == "sbp":
             m = [int(v) for v in a[0]]
             out["sbp"].append(dict(stride=m[0], i0=m[1], i1=m[2], w=m[3], h=m[4], l0=a[1], l1=a[2], want=a[3]))
+    return out
+
+
+def coeffcost_goldens(depth):
+    """-> list of dicts: w, h, color, flags, style, models (1220 bytes), coeff (h*w,) int16, bits, after (1220 bytes)."""
+    out = []
+    for name, a in read_golden("coeffcost", depth):
+        if name == "cc":
+            m = [int(v) for v in a[0]]
+            out.append(dict(w=m[0], h=m[1], color=m[2], flags=m[3], style=m[4], models=a[1], coeff=a[2], bits=float(a[3][0]), after=a[4]))
     return out

@@ -52,6 +52,7 @@ void check_dct(void);
 void check_quant(void);
 void check_rdoq(void);
 void check_shim(void);
+void check_coeffcost(void);
 void check_intra(void);
 void check_ipol(void);
 void check_sao(void);
@@ -99,6 +100,7 @@ int main(int argc, char **argv)
 #ifdef HAVE_QUANT
   check_rdoq();      /* last: the earlier groups keep their random streams, hence their committed goldens */
   check_shim();      /* ... and this one after it */
+  check_coeffcost();
 #endif
   if (g_out) fclose(g_out);
   printf("refcheck %d-bit: %s (%d mismatches)\n", UVG_BIT_DEPTH, g_fail ? "FAIL" : "OK", g_fail);
@@ -113,6 +115,7 @@ int main(int argc, char **argv)
 #include "rc_quant.inc"
 #include "rc_rdoq.inc"
 #include "rc_shim.inc"
+#include "rc_coeffcost.inc"
 #endif
 #ifdef HAVE_INTRA
 #include "rc_intra.inc"

@@ -471,3 +471,18 @@ def quantize_residual_batch(orig, pred, rec, tus, width, height, bitdepth, color
                                                 rec.stride(0), _dev(tus), n, None if lfnst_tus is None else _dev(lfnst_tus), _dev(coeff),
                                                 _dev(has), _dev(ws), ws.numel() * 8, _stream()), "uvghip_quantize_residual_batch")
     return coeff, has
+
+
+def coeff_cost_batch(coeff, color, models):
+    """coeff (n, h, w) int16 levels -> (bits (n,) float64, flags (n,) uint8): the CABAC bit cost of every block starting from
+    `models` (lib.CabacModels or its 1220 bytes), uvg_get_coeff_cost's CABAC branch."""
+    import ctypes
+    L = _lib.init(coeff.device.index or 0)
+    n, h, w = coeff.shape
+    if not isinstance(models, _lib.CabacModels):
+        models = _lib.CabacModels.from_buffer_copy(bytes(np.asarray(models, np.uint8).tobytes()))
+    bits = torch.empty(n, dtype=torch.float64, device=coeff.device)
+    flags = torch.empty(n, dtype=torch.uint8, device=coeff.device)
+    _lib.check(L.uvghip_coeff_cost_batch(_dev(coeff), w, h, n, color, ctypes.byref(models), _dev(bits), _dev(flags), _stream()),
+               "uvghip_coeff_cost_batch")
+    return bits, flags

@@ -38,6 +38,11 @@ class QrParams(ctypes.Structure):
                                                 "mts_idx", "lfnst_idx", "reserved")] + [("lambda_", ctypes.c_double), ("ctx", ctypes.c_uint8 * 244)]
 
 
+class CabacModels(ctypes.Structure):
+    """uvghip_cabac_models_t: the coefficient coder's context models with their full state."""
+    _fields_ = [("state0", ctypes.c_uint16 * 244), ("state1", ctypes.c_uint16 * 244), ("rate", ctypes.c_uint8 * 244)]
+
+
 class StateView(ctypes.Structure):
     """uvghip_state_view_t: what the state-taking strategies read from encoder_state_t."""
     _fields_ = [(n, ctypes.c_int32) for n in ("bitdepth", "qp", "slice_is_intra", "rdoq_enable", "rdoq_skip", "dep_quant", "signhide_enable",
@@ -125,6 +130,7 @@ SIGNATURES = {
     "uvghip_comm_destroy": (c_int, [c_vp]),
     "uvghip_comm_exchange": (c_int, [c_vp, c_vp, c_int, c_vp]),
     "uvghip_comm_allreduce_i64": (c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "uvghip_coeff_cost_batch": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_quant_percall": (ctypes.c_uint, [c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32] + [c_int] * 5),
     "uvghip_dequant_percall": (ctypes.c_uint, [c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32] + [c_int] * 3),
     "uvghip_quantize_residual_percall": (c_int, [c_vp, c_vp] + [c_int] * 7 + [c_vp] * 4 + [c_int] * 3),
