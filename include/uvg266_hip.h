@@ -312,6 +312,20 @@ UVGHIP_API int uvghip_quantize_residual_batch(int bitdepth, const uvghip_qr_para
                                    int n, const struct uvghip_lfnst_tu *lfnst_tus, int16_t *coeff_out, uint8_t *has_coeffs,
                                    void *workspace, size_t workspace_bytes, void *stream);
 
+/* replaces: uvg_quant_cbcr_residual (quant-generic.c:241-442; cfg.jccr): joint coding of the Cb and Cr residuals of n TUs of one
+ * shape at tus[i] in the two chroma planes -- combined residual by joint_cb_cr (1..3) and the picture's jccr_sign ->
+ * uvg_transform2d -> [uvg_fwd_lfnst] -> uvg_rdoq | uvg_quant (contexts / QP of V for joint_cb_cr == 1, else of U) ->
+ * coeff_out[i] -> uvg_dequant -> [uvg_inv_lfnst] -> uvg_itransform2d -> both reconstructions.
+ * ret_out[i] = the function's return value: joint_cb_cr if the block has coefficients, else 0.  early_skip as the reference's
+ * argument (reconstruction = prediction).  p: as for uvghip_quantize_residual_batch (color is derived, use_trskip ignored;
+ * qp_scaled = the chroma QP).  workspace >= uvghip_quant_cbcr_residual_workspace_bytes(p, n). */
+UVGHIP_API size_t uvghip_quant_cbcr_residual_workspace_bytes(const uvghip_qr_params_t *p, int n);
+UVGHIP_API int uvghip_quant_cbcr_residual_batch(int bitdepth, const uvghip_qr_params_t *p, int joint_cb_cr, int jccr_sign,
+                                     const void *u_orig, const void *v_orig, int orig_stride, const void *u_pred,
+                                     const void *v_pred, int pred_stride, void *u_rec, void *v_rec, int rec_stride,
+                                     const uvghip_tu_t *tus, int n, const struct uvghip_lfnst_tu *lfnst_tus, int16_t *coeff_out,
+                                     uint8_t *ret_out, int early_skip, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------ (2) batched ABI: intra -------- */
 
 /* One intra block in a reconstructed plane.  avail_top / avail_left are the

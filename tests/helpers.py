@@ -423,3 +423,17 @@ def coeffcost_goldens(depth):
             m = [int(v) for v in a[0]]
             out.append(dict(w=m[0], h=m[1], color=m[2], flags=m[3], style=m[4], models=a[1], coeff=a[2], bits=float(a[3][0]), after=a[4]))
     return out
+
+
+def jccr_goldens(depth):
+    """uvg_quant_cbcr_residual records -> list of dicts (planes reshaped to (rows, stride))."""
+    out = []
+    for name, a in read_golden("jccr", depth):
+        if name != "jccr":
+            continue
+        m = [int(v) for v in a[0]]
+        S, so = m[11], m[12]
+        out.append(dict(w=m[0], h=m[1], joint=m[2], sign=m[3], qps=m[4], intra=m[5], cu_type=m[6], rdoq=m[7], rdoq_skip=m[8], cbf_u=m[9],
+                        early_skip=m[10], S=S, so=so, ret=m[13], lam=float(a[1][0]), ctx=a[2], uref=a[3].reshape(S, S), vref=a[4].reshape(S, S),
+                        upred=a[5].reshape(S, S), vpred=a[6].reshape(S, S), q=a[7], urec=a[8], vrec=a[9]))
+    return out

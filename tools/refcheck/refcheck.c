@@ -53,6 +53,7 @@ void check_quant(void);
 void check_rdoq(void);
 void check_shim(void);
 void check_coeffcost(void);
+void check_jccr(void);
 void check_intra(void);
 void check_ipol(void);
 void check_sao(void);
@@ -101,6 +102,7 @@ int main(int argc, char **argv)
   check_rdoq();      /* last: the earlier groups keep their random streams, hence their committed goldens */
   check_shim();      /* ... and this one after it */
   check_coeffcost();
+  check_jccr();
 #endif
   if (g_out) fclose(g_out);
   printf("refcheck %d-bit: %s (%d mismatches)\n", UVG_BIT_DEPTH, g_fail ? "FAIL" : "OK", g_fail);
@@ -116,6 +118,7 @@ int main(int argc, char **argv)
 #include "rc_rdoq.inc"
 #include "rc_shim.inc"
 #include "rc_coeffcost.inc"
+#include "rc_jccr.inc"
 #endif
 #ifdef HAVE_INTRA
 #include "rc_intra.inc"

@@ -486,3 +486,30 @@ def coeff_cost_batch(coeff, color, models):
     _lib.check(L.uvghip_coeff_cost_batch(_dev(coeff), w, h, n, color, ctypes.byref(models), _dev(bits), _dev(flags), _stream()),
                "uvghip_coeff_cost_batch")
     return bits, flags
+
+
+def quant_cbcr_residual_batch(u_orig, v_orig, u_pred, v_pred, u_rec, v_rec, tus, width, height, bitdepth, joint_cb_cr, jccr_sign,
+                              qp_scaled=22, slice_is_intra=True, cu_type=1, rdoq=False, rdoq_skip=False, cbf_u=0, lam=0.0, ctx=None,
+                              early_skip=False, lfnst_idx=0, lfnst_tus=None):
+    """uvg_quant_cbcr_residual (joint Cb-Cr coding) for the TUs at `tus` -> (coeff (n, h, w) int16, ret (n,) uint8 = joint_cb_cr
+    where the block has coefficients else 0); u_rec / v_rec written in place."""
+    import ctypes
+    L = _lib.init(u_orig.device.index or 0)
+    n = tus.shape[0]
+    p = _lib.QrParams()
+    p.width, p.height, p.color = width, height, 1
+    p.qp_scaled, p.slice_is_intra, p.cu_type = qp_scaled, int(slice_is_intra), cu_type
+    p.rdoq_enable, p.rdoq_skip, p.cbf_u, p.lfnst_idx = int(rdoq), int(rdoq_skip), cbf_u, lfnst_idx
+    p.lambda_ = float(lam)
+    if ctx is not None:
+        ctypes.memmove(p.ctx, np.asarray(ctx, np.uint8).tobytes(), 244)
+    need = L.uvghip_quant_cbcr_residual_workspace_bytes(ctypes.byref(p), n)
+    ws = torch.empty((need + 7) // 8, dtype=torch.float64, device=u_orig.device)
+    coeff = torch.empty((n, height, width), dtype=torch.int16, device=u_orig.device)
+    ret = torch.empty(n, dtype=torch.uint8, device=u_orig.device)
+    _lib.check(L.uvghip_quant_cbcr_residual_batch(bitdepth, ctypes.byref(p), joint_cb_cr, int(jccr_sign), _dev(u_orig), _dev(v_orig),
+                                                  u_orig.stride(0), _dev(u_pred), _dev(v_pred), u_pred.stride(0), _dev(u_rec), _dev(v_rec),
+                                                  u_rec.stride(0), _dev(tus), n, None if lfnst_tus is None else _dev(lfnst_tus), _dev(coeff),
+                                                  _dev(ret), int(early_skip), _dev(ws), ws.numel() * 8, _stream()),
+               "uvghip_quant_cbcr_residual_batch")
+    return coeff, ret

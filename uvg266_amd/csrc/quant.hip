@@ -950,6 +950,140 @@ extern "C" int uvghip_quantize_residual_batch(int bitdepth, const uvghip_qr_para
   UVGHIP_CHECK_LAUNCH();
 }
 
+// ---- joint Cb-Cr residual coding: uvg_quant_cbcr_residual (quant-generic.c:241-442) ----
+namespace {
+
+// combined residual of the TUs (:268-302): mask = joint_cb_cr * (jccr_sign ? -1 : 1); C division truncates toward zero
+template <typename PX>
+__global__ void __launch_bounds__(256)
+jccr_residual_kernel(const PX *__restrict__ u_orig, const PX *__restrict__ v_orig, int ostride, const PX *__restrict__ u_pred,
+                     const PX *__restrict__ v_pred, int pstride, const uvghip_tu_t *__restrict__ tus, int n, int l2w, int l2h, int mask,
+                     int16_t *__restrict__ res)
+{
+  const int wh = 1 << (l2w + l2h);
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)n << (l2w + l2h)) return;
+  const int b = (int)(e >> (l2w + l2h)), rem = (int)(e & (size_t)(wh - 1)), y = rem >> l2w, x = rem & ((1 << l2w) - 1);
+  const size_t po = (size_t)(tus[b].y + y) * ostride + tus[b].x + x, pp = (size_t)(tus[b].y + y) * pstride + tus[b].x + x;
+  const int cbx = (int16_t)((int)u_orig[po] - (int)u_pred[pp]), crx = (int16_t)((int)v_orig[po] - (int)v_pred[pp]);
+  int c;
+  switch (mask) {
+    case 2: c = (4 * cbx + 2 * crx) / 5; break;
+    case -2: c = (4 * cbx - 2 * crx) / 5; break;
+    case 3: c = (cbx + crx) / 2; break;
+    case -3: c = (cbx - crx) / 2; break;
+    case 1: c = (4 * crx + 2 * cbx) / 5; break;
+    default: c = (4 * crx - 2 * cbx) / 5; break;         // -1
+  }
+  res[e] = (int16_t)c;
+}
+
+// both reconstructions from the decoded joint residual (:381-424); early_skip / no coefficients: the predictions (:427-437)
+template <typename PX>
+__global__ void __launch_bounds__(256)
+jccr_recon_kernel(const int16_t *__restrict__ res, const uint8_t *__restrict__ has, const PX *__restrict__ u_pred,
+                  const PX *__restrict__ v_pred, int pstride, PX *__restrict__ u_rec, PX *__restrict__ v_rec, int rstride,
+                  const uvghip_tu_t *__restrict__ tus, int n, int l2w, int l2h, int mask, int early_skip)
+{
+  const int wh = 1 << (l2w + l2h);
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)n << (l2w + l2h)) return;
+  const int b = (int)(e >> (l2w + l2h)), rem = (int)(e & (size_t)(wh - 1)), y = rem >> l2w, x = rem & ((1 << l2w) - 1);
+  const size_t pp = (size_t)(tus[b].y + y) * pstride + tus[b].x + x, pr = (size_t)(tus[b].y + y) * rstride + tus[b].x + x;
+  const int pu = u_pred[pp], pv = v_pred[pp];
+  int ru = pu, rv = pv;
+  if (has[b] && !early_skip) {
+    const int c = res[e];
+    int16_t ur, vr;
+    switch (mask) {
+      case 2: ur = (int16_t)c; vr = (int16_t)(c >> 1); break;
+      case -2: ur = (int16_t)c; vr = (int16_t)(-c >> 1); break;
+      case 3: ur = (int16_t)c; vr = (int16_t)c; break;
+      case -3: ur = (int16_t)c; vr = (int16_t)(-c); break;
+      case 1: ur = (int16_t)(c >> 1); vr = (int16_t)c; break;
+      default: ur = (int16_t)(-c >> 1); vr = (int16_t)c; break;   // -1
+    }
+    ru = clampi((int)(int16_t)(ur + pu), 0, px_traits<PX>::maxv);
+    rv = clampi((int)(int16_t)(vr + pv), 0, px_traits<PX>::maxv);
+  }
+  u_rec[pr] = (PX)ru; v_rec[pr] = (PX)rv;
+}
+
+__global__ void __launch_bounds__(256)
+jccr_ret_kernel(const uint8_t *__restrict__ has, int n, int joint, uint8_t *__restrict__ ret)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ret[i] = has[i] ? (uint8_t)joint : 0;
+}
+
+}  // namespace
+
+extern "C" size_t uvghip_quant_cbcr_residual_workspace_bytes(const uvghip_qr_params_t *p, int n)
+{
+  if (!p || n <= 0) return 0;
+  const bool rdoq = p->rdoq_enable && (p->width > 4 || !p->rdoq_skip);
+  return 3 * qr_coef_bytes(p->width, p->height, n) + (((size_t)n + 255) & ~(size_t)255) +
+         (rdoq ? uvghip_rdoq_workspace_bytes(p->width, p->height, n) : 0);
+}
+
+extern "C" int uvghip_quant_cbcr_residual_batch(int bitdepth, const uvghip_qr_params_t *p, int joint_cb_cr, int jccr_sign,
+                                                const void *u_orig, const void *v_orig, int orig_stride, const void *u_pred,
+                                                const void *v_pred, int pred_stride, void *u_rec, void *v_rec, int rec_stride,
+                                                const uvghip_tu_t *tus, int n, const uvghip_lfnst_tu_t *lfnst_tus, int16_t *coeff_out,
+                                                uint8_t *ret_out, int early_skip, void *workspace, size_t workspace_bytes, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!p || joint_cb_cr < 1 || joint_cb_cr > 3 || !u_orig || !v_orig || !u_pred || !v_pred || !u_rec || !v_rec || !coeff_out || !ret_out)
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const int width = p->width, height = p->height;
+  if (!tr_valid_dim(width) || !tr_valid_dim(height) || width < 4 || height < 4 || p->type_hor < 0 || p->type_hor > 2 || p->type_ver < 0 ||
+      p->type_ver > 2 || p->skip_width < 0 || p->skip_width >= width || p->skip_height < 0 || p->skip_height >= height)
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (int rc = check_qargs(bitdepth, width, height, p->qp_scaled)) return rc;
+  if (p->dep_quant) return uvghip_set_error(hipErrorNotSupported, "uvghip_quant_cbcr_residual_batch: dependent quantisation is not built");
+  if (n <= 0) return 0;
+  if (!workspace || workspace_bytes < uvghip_quant_cbcr_residual_workspace_bytes(p, n))
+    return uvghip_set_error(hipErrorInvalidValue, "uvghip_quant_cbcr_residual_batch: workspace");
+  const bool rdoq = p->rdoq_enable && (width > 4 || !p->rdoq_skip);
+  const int color = joint_cb_cr == 1 ? 2 : 1;                      // the plane whose contexts / QP the joint block is coded with
+  const int mask = joint_cb_cr * (jccr_sign ? -1 : 1);
+  const int l2w = 31 - __builtin_clz(width), l2h = 31 - __builtin_clz(height);
+  hipStream_t st = uvghip_stream(stream);
+  char *wsb = static_cast<char *>(workspace);
+  const size_t cb = qr_coef_bytes(width, height, n);
+  int16_t *res = reinterpret_cast<int16_t *>(wsb), *coef = reinterpret_cast<int16_t *>(wsb + cb), *deq = reinterpret_cast<int16_t *>(wsb + 2 * cb);
+  uint8_t *has = reinterpret_cast<uint8_t *>(wsb + 3 * cb);
+  void *rdoq_ws = wsb + 3 * cb + (((size_t)n + 255) & ~(size_t)255);
+  const size_t total = (size_t)n * width * height;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (bitdepth == 8) jccr_residual_kernel<uint8_t><<<grid, 256, 0, st>>>((const uint8_t *)u_orig, (const uint8_t *)v_orig, orig_stride, (const uint8_t *)u_pred, (const uint8_t *)v_pred, pred_stride, tus, n, l2w, l2h, mask, res);
+  else jccr_residual_kernel<uint16_t><<<grid, 256, 0, st>>>((const uint16_t *)u_orig, (const uint16_t *)v_orig, orig_stride, (const uint16_t *)u_pred, (const uint16_t *)v_pred, pred_stride, tus, n, l2w, l2h, mask, res);
+  { hipError_t e = hipGetLastError(); if (e != hipSuccess) return uvghip_set_error(e, __func__); }
+  // uvg_transform2d (:305) -> [uvg_fwd_lfnst] -> uvg_rdoq | uvg_quant (:310-340) -> has_coeffs
+  if (int rc = uvghip_transform_batch(bitdepth, 0, p->type_hor, p->type_ver, width, height, p->skip_width, p->skip_height, res, coef, n, stream)) return rc;
+  if (lfnst_tus)
+    if (int rc = uvghip_lfnst_batch(0, coef, width, height, lfnst_tus, n, stream)) return rc;
+  if (rdoq) {
+    if (int rc = uvghip_rdoq_launch_checked(bitdepth, coef, coeff_out, width, height, n, color, p->cu_type, p->cbf_u, p->lfnst_idx, 0,
+                                            p->qp_scaled, p->lambda, &p->ctx, rdoq_ws, uvghip_rdoq_workspace_bytes(width, height, n), has, stream))
+      return rc;
+  } else {
+    if (int rc = (p->lfnst_idx ? uvghip_quant_lfnst_batch : uvghip_quant_batch)(bitdepth, coef, coeff_out, width, height, n, p->qp_scaled, 0,
+                                                                                  p->slice_is_intra, stream))
+      return rc;
+    has_coeffs_kernel<<<(n + 3) / 4, 256, 0, st>>>(coeff_out, width * height, n, has);
+  }
+  // uvg_dequant -> [uvg_inv_lfnst] -> uvg_itransform2d -> both reconstructions (:355-437)
+  if (int rc = uvghip_dequant_batch(bitdepth, coeff_out, deq, width, height, n, p->qp_scaled, 0, stream)) return rc;
+  if (lfnst_tus)
+    if (int rc = uvghip_lfnst_batch(1, deq, width, height, lfnst_tus, n, stream)) return rc;
+  if (int rc = uvghip_transform_batch(bitdepth, 1, p->type_hor, p->type_ver, width, height, p->skip_width, p->skip_height, deq, res, n, stream)) return rc;
+  if (bitdepth == 8) jccr_recon_kernel<uint8_t><<<grid, 256, 0, st>>>(res, has, (const uint8_t *)u_pred, (const uint8_t *)v_pred, pred_stride, (uint8_t *)u_rec, (uint8_t *)v_rec, rec_stride, tus, n, l2w, l2h, mask, early_skip);
+  else jccr_recon_kernel<uint16_t><<<grid, 256, 0, st>>>(res, has, (const uint16_t *)u_pred, (const uint16_t *)v_pred, pred_stride, (uint16_t *)u_rec, (uint16_t *)v_rec, rec_stride, tus, n, l2w, l2h, mask, early_skip);
+  jccr_ret_kernel<<<(n + 255) / 256, 256, 0, st>>>(has, n, joint_cb_cr, ret_out);
+  UVGHIP_CHECK_LAUNCH();
+}
+
 // =================================================== drop-in strategy layer ====
 namespace {
 

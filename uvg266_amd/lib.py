@@ -130,6 +130,9 @@ SIGNATURES = {
     "uvghip_comm_destroy": (c_int, [c_vp]),
     "uvghip_comm_exchange": (c_int, [c_vp, c_vp, c_int, c_vp]),
     "uvghip_comm_allreduce_i64": (c_int, [c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "uvghip_quant_cbcr_residual_workspace_bytes": (ctypes.c_size_t, [c_vp, c_int]),
+    "uvghip_quant_cbcr_residual_batch": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_int,
+                                                 c_vp, c_vp, c_vp, c_int, c_vp, ctypes.c_size_t, c_vp]),
     "uvghip_coeff_cost_batch": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_quant_percall": (ctypes.c_uint, [c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32] + [c_int] * 5),
     "uvghip_dequant_percall": (ctypes.c_uint, [c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32] + [c_int] * 3),
