@@ -687,6 +687,7 @@ typedef struct uvghip_state_view {
   int32_t lfnst, mts;               /* cfg.lfnst, cfg.mts (enum uvg_mts) */
   int32_t lmcs_chroma_adj_enabled;  /* lmcs_aps->m_sliceReshapeInfo.enableChromaAdj: must be 0 for chroma calls */
   int32_t collocated_luma_mode;     /* state->collocated_luma_mode (LFNST of a CCLM chroma block) */
+  int32_t jccr_sign, reserved;      /* state->frame->jccr_sign (joint Cb-Cr coding) */
   double lambda, c_lambda;          /* state->lambda, state->c_lambda */
   int8_t qp_map[64];                /* encoder_control->qp_map[0] */
   uvghip_rdoq_ctx_t cabac;          /* CTX_STATE of state->cabac.ctx's models (RDOQ only) */
@@ -698,6 +699,7 @@ typedef struct uvghip_cu_view {     /* cu_info_t (src/cu.h:134-198), the fields 
   int8_t log2_width, log2_height;
   int8_t intra_mode, intra_mode_chroma, mip_flag, isp_mode;   /* intra.* (read only when type == 1) */
   uint16_t cbf;
+  int8_t joint_cb_cr, reserved[3];
 } uvghip_cu_view_t;
 
 /* uvg_quant (quant-generic.c:51-232) / uvg_dequant (:618-669) for one block. */
@@ -712,6 +714,11 @@ UVGHIP_API int uvghip_quantize_residual_percall(const uvghip_state_view_t *sv, c
                                                 int color, int scan_order, int use_trskip, int in_stride, int out_stride,
                                                 const void *ref_in, const void *pred_in, void *rec_out, int16_t *coeff_out,
                                                 int early_skip, int lmcs_chroma_adj, int tree_type);
+/* uvg_quant_cbcr_residual (quant-generic.c:241-442) for one chroma TU pair: returns joint_cb_cr if coefficients were coded, else 0. */
+UVGHIP_API int uvghip_quant_cbcr_residual_percall(const uvghip_state_view_t *sv, const uvghip_cu_view_t *cu, int width, int height,
+                                                  int scan_order, int in_stride, int out_stride, const void *u_ref_in,
+                                                  const void *v_ref_in, const void *u_pred_in, const void *v_pred_in, void *u_rec_out,
+                                                  void *v_rec_out, int16_t *coeff_out, int early_skip, int lmcs_chroma_adj, int tree_type);
 /* One plane of bipred_average_generic (picture-generic.c:1195-1262): dst rows of pu_w samples at dst_stride; l0 / l1 are
  * pu_w*pu_h contiguous samples -- pixels, or 14-bit int16 intermediates where *_is_im. */
 UVGHIP_API void uvghip_bipred_average_percall(int bitdepth, void *dst, int dst_stride, const void *l0, int l0_is_im,

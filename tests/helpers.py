@@ -396,7 +396,7 @@ def shim_goldens(depth):
     the shim extracted from the reference's encoder_state_t / cu_info_t; the expectations are the generic strategies' results."""
     from uvg266_amd.lib import StateView, CuView
     px = px_dtype(depth)
-    out = {"sq": [], "sqr": [], "sbp": []}
+    out = {"sq": [], "sqr": [], "sbp": [], "sjc": []}
     for name, a in read_golden("shim", depth):
         if name == "sq":
             m = [int(v) for v in a[0]]
@@ -409,6 +409,11 @@ def shim_goldens(depth):
                                    lmcs_adj=m[8], tree=m[9], has=m[10], branch=m[11], sv=StateView.from_buffer_copy(a[1].tobytes()),
                                    cv=CuView.from_buffer_copy(a[2].tobytes()), ref=a[3].view(px) if a[3].dtype != px else a[3],
                                    pred=a[4], q=a[5], rec=a[6]))
+        elif name == "sjc":
+            m = [int(v) for v in a[0]]
+            out["sjc"].append(dict(w=m[0], h=m[1], scan_order=m[2], in_stride=m[3], out_stride=m[4], early_skip=m[5], lmcs_adj=m[6], tree=m[7],
+                                   ret=m[8], S=m[9], sv=StateView.from_buffer_copy(a[1].tobytes()), cv=CuView.from_buffer_copy(a[2].tobytes()),
+                                   uref=a[3], vref=a[4], upred=a[5], vpred=a[6], q=a[7], urec=a[8], vrec=a[9]))
         elif name == "sbp":
             m = [int(v) for v in a[0]]
             out["sbp"].append(dict(stride=m[0], i0=m[1], i1=m[2], w=m[3], h=m[4], l0=a[1], l1=a[2], want=a[3]))

@@ -63,6 +63,22 @@ def test_bipred_percall_replays_shim_records(hip, depth):
         assert (d2[:, w:] == 9).all()
 
 
+@pytest.mark.parametrize("depth", [8, 10])
+def test_quant_cbcr_percall_replays_shim_records(hip, depth):
+    px = H.px_dtype(depth)
+    for r in H.shim_goldens(depth)["sjc"]:
+        w, h = r["w"], r["h"]
+        fill = 7 if depth == 8 else 0x0707
+        urec, vrec = np.full(r["urec"].size, fill, px), np.full(r["vrec"].size, fill, px)
+        coeff = np.zeros(w * h, np.int16)
+        ret = hip.uvghip_quant_cbcr_residual_percall(ctypes.byref(r["sv"]), ctypes.byref(r["cv"]), w, h, r["scan_order"], r["in_stride"], r["out_stride"],
+                                                     H.ptr(r["uref"]), H.ptr(r["vref"]), H.ptr(r["upred"]), H.ptr(r["vpred"]), H.ptr(urec), H.ptr(vrec),
+                                                     H.ptr(coeff), r["early_skip"], r["lmcs_adj"], r["tree"])
+        tag = (w, r["cv"].joint_cb_cr, r["sv"].jccr_sign, r["early_skip"])
+        assert ret == r["ret"] and np.array_equal(coeff, r["q"]), tag
+        assert np.array_equal(urec, r["urec"]) and np.array_equal(vrec, r["vrec"]), tag
+
+
 def test_sixteen_threads_call_the_registered_pointers_concurrently(hip, orc):
     """Eight registered strategy pointers plus the three state-taking per-call entry points, hammered from 16 threads at
     once; every single result is checked.  ctypes drops the GIL around foreign calls, so the calls do overlap in the library:

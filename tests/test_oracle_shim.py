@@ -41,9 +41,9 @@ def qr_case(d, r):
 @pytest.mark.parametrize("depth", [8, 10])
 def test_shim_view_layout(depth):
     from uvg266_amd.lib import StateView, CuView
-    assert ctypes.sizeof(StateView) == 376 and ctypes.sizeof(CuView) == 12      # sizeof in include/uvg266_hip.h (C layout)
+    assert ctypes.sizeof(StateView) == 384 and ctypes.sizeof(CuView) == 16      # sizeof in include/uvg266_hip.h (C layout)
     g = H.shim_goldens(depth)
-    assert len(g["sqr"]) == 240 and len(g["sq"]) > 200 and len(g["sbp"]) > 100
+    assert len(g["sqr"]) == 240 and len(g["sq"]) > 200 and len(g["sbp"]) > 100 and len(g["sjc"]) == 48
     assert all(r["sv"].bitdepth == depth and not r["sv"].signhide_enable and not r["sv"].dep_quant for r in g["sqr"])
     assert {r["branch"] for r in g["sqr"]} == set(range(6))
 
@@ -85,3 +85,21 @@ def test_shim_bipred_records_vs_oracle(orc, depth):
     for r in H.shim_goldens(depth)["sbp"]:
         got = orc.bipred_average(depth, r["l0"], r["l1"], r["w"], r["h"])
         assert np.array_equal(got, r["want"]), (r["w"], r["h"], r["i0"], r["i1"])
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_shim_quant_cbcr_records_vs_oracle(orc, depth):
+    from test_oracle_jccr import oracle_quant_cbcr
+    n = 0
+    for r in H.shim_goldens(depth)["sjc"]:
+        sv, cv, S, w, h, so = r["sv"], r["cv"], r["S"], r["w"], r["h"], r["out_stride"]
+        color = 2 if cv.joint_cb_cr == 1 else 1
+        c = dict(w=w, h=h, joint=cv.joint_cb_cr, sign=sv.jccr_sign, qps=scaled_qp(sv, color), intra=sv.slice_is_intra, cu_type=cv.type,
+                 rdoq=sv.rdoq_enable, rdoq_skip=sv.rdoq_skip, cbf_u=(cv.cbf >> 1) & 1, early_skip=r["early_skip"], lam=sv.c_lambda,
+                 ctx=np.frombuffer(bytes(sv.cabac), np.uint8).copy(), uref=r["uref"].reshape(S, S), vref=r["vref"].reshape(S, S),
+                 upred=r["upred"].reshape(S, S), vpred=r["vpred"].reshape(S, S))
+        ret, q, ur, vr = oracle_quant_cbcr(orc, depth, c)
+        assert ret == r["ret"] and np.array_equal(q, r["q"]), (w, cv.joint_cb_cr, sv.jccr_sign)
+        assert np.array_equal(r["urec"][: so * h].reshape(h, so)[:, :w], ur) and np.array_equal(r["vrec"][: so * h].reshape(h, so)[:, :w], vr)
+        n += ret != 0
+    assert n > 10

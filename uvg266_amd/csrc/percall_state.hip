@@ -151,6 +151,69 @@ extern "C" int uvghip_quantize_residual_percall(const uvghip_state_view_t *sv, c
   return has;
 }
 
+// uvg_quant_cbcr_residual (quant-generic.c:241-442) for one pair of chroma TUs.
+extern "C" int uvghip_quant_cbcr_residual_percall(const uvghip_state_view_t *sv, const uvghip_cu_view_t *cu, int width, int height,
+                                                  int scan_order, int in_stride, int out_stride, const void *u_ref_in, const void *v_ref_in,
+                                                  const void *u_pred_in, const void *v_pred_in, void *u_rec_out, void *v_rec_out,
+                                                  int16_t *coeff_out, int early_skip, int lmcs_chroma_adj, int tree_type)
+{
+  (void)scan_order; (void)lmcs_chroma_adj;
+  check_view(sv);
+  if (sv->lmcs_chroma_adj_enabled) unsupported("LMCS chroma residual scaling");
+  const int es = sv->bitdepth == 8 ? 1 : 2;
+  const int color = cu->joint_cb_cr == 1 ? 2 : 1;
+  uvghip_qr_params_t p;
+  memset(&p, 0, sizeof p);
+  p.width = width; p.height = height; p.color = color;
+  const int lfnst_index = tree_type == 2 ? cu->cr_lfnst_idx : cu->lfnst_idx;               // :306
+  uvghip_mts_select(width, height, color, cu->type, 0, cu->lfnst_idx, cu->cr_lfnst_idx, cu->tr_idx, sv->mts, &p.type_hor, &p.type_ver,
+                    &p.skip_width, &p.skip_height);
+  p.qp_scaled = scaled_qp(sv, color);
+  p.slice_is_intra = sv->slice_is_intra; p.cu_type = cu->type;
+  p.rdoq_enable = sv->rdoq_enable; p.rdoq_skip = sv->rdoq_skip;
+  p.cbf_u = (cu->cbf >> 1) & 1;
+  p.lfnst_idx = lfnst_index;
+  p.lambda = sv->c_lambda;
+  p.ctx = sv->cabac;
+  // uvg_fwd_lfnst with COLOR_UV (:307-309): chroma rules -- only a separate tree carries an LFNST for chroma
+  const bool separate = cu->log2_height + cu->log2_width < 6 || tree_type != 0;
+  const bool lfnst_tr = lfnst_index && cu->type == 1 && separate;
+  uvghip_lfnst_tu_t lt;
+  if (lfnst_tr) {
+    int mode = cu->intra_mode_chroma;
+    if (mode >= 81 && mode <= 83) mode = sv->collocated_luma_mode;
+    int lw = 0, lh = 0;
+    while ((1 << lw) < width) ++lw;
+    while ((1 << lh) < height) ++lh;
+    lt.intra_mode = (int8_t)mode; lt.lfnst_idx = (int8_t)lfnst_index; lt.log2_cu_width = (int8_t)lw; lt.log2_cu_height = (int8_t)lh;
+  }
+  const size_t blk = (size_t)width * height * es, cb = (size_t)width * height * 2;
+  const size_t ws = uvghip_quant_cbcr_residual_workspace_bytes(&p, 1);
+  percall_ctx *c = percall_get(6 * blk + cb + ws + 4096);
+  const size_t o_ur = c->stage_block(u_ref_in, (size_t)in_stride, width, height, (size_t)es);
+  const size_t o_vr = c->stage_block(v_ref_in, (size_t)in_stride, width, height, (size_t)es);
+  const size_t o_up = c->stage_block(u_pred_in, (size_t)in_stride, width, height, (size_t)es);
+  const size_t o_vp = c->stage_block(v_pred_in, (size_t)in_stride, width, height, (size_t)es);
+  const size_t o_tu = c->take(sizeof(uvghip_tu_t)), o_lt = c->take(sizeof lt);
+  *c->hp<uvghip_tu_t>(o_tu) = uvghip_tu_t{0, 0};
+  if (lfnst_tr) *c->hp<uvghip_lfnst_tu_t>(o_lt) = lt;
+  c->upload(0, c->used);
+  const size_t o_uo = c->take(blk), o_vo = c->take(blk), o_co = c->take(cb), o_ret = c->take(16), o_ws = c->take(ws);
+  c->must(uvghip_quant_cbcr_residual_batch(sv->bitdepth, &p, cu->joint_cb_cr, sv->jccr_sign, c->dp<char>(o_ur), c->dp<char>(o_vr), width,
+                                           c->dp<char>(o_up), c->dp<char>(o_vp), width, c->dp<char>(o_uo), c->dp<char>(o_vo), width,
+                                           c->dp<uvghip_tu_t>(o_tu), 1, lfnst_tr ? c->dp<uvghip_lfnst_tu_t>(o_lt) : nullptr,
+                                           c->dp<int16_t>(o_co), c->dp<uint8_t>(o_ret), early_skip, c->dp<char>(o_ws), ws, c->stream),
+          "quant_cbcr_residual");
+  c->download(o_uo, (o_ret + 16) - o_uo);
+  c->sync();
+  memcpy(coeff_out, c->hp<int16_t>(o_co), cb);
+  for (int y = 0; y < height; ++y) {
+    memcpy((char *)u_rec_out + (size_t)y * out_stride * es, c->hp<char>(o_uo) + (size_t)y * width * es, (size_t)width * es);
+    memcpy((char *)v_rec_out + (size_t)y * out_stride * es, c->hp<char>(o_vo) + (size_t)y * width * es, (size_t)width * es);
+  }
+  return *c->hp<uint8_t>(o_ret);
+}
+
 // bipred_average_generic's three sample-wise forms (picture-generic.c:1132-1193) for one plane of a PU: the shim walks
 // lcu->rec.{y,u,v} / the L0 / L1 buffers exactly as :1195-1262 does and calls this once per plane.
 // l0 / l1: pu_w * pu_h contiguous samples, pixels or 14-bit int16 intermediates (l0_is_im / l1_is_im).

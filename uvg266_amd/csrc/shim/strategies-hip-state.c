@@ -7,7 +7,7 @@
  * the encoder's headers (tools/refcheck/run.sh) and runs it against recording stand-ins of the four entry points
  * (tools/refcheck/rc_shim.inc) to prove that the extraction picks the fields the generic strategies read.
  *
- * Typedefs implemented: quant_func, dequant_func, quant_residual_func (strategies-quant.h:48-86),
+ * Typedefs implemented: quant_func, dequant_func, quant_residual_func, quant_cbcr_func (strategies-quant.h:48-86),
  * inter_recon_bipred_func (strategies-picture.h:136-148).
  */
 #include "strategyselector.h"
@@ -43,6 +43,7 @@ static void hip_state_view(const encoder_state_t *const state, uvghip_state_view
   v->mts = ctrl->cfg.mts;
   v->lmcs_chroma_adj_enabled = state->tile->frame->lmcs_aps ? state->tile->frame->lmcs_aps->m_sliceReshapeInfo.enableChromaAdj : 0;
   v->collocated_luma_mode = state->collocated_luma_mode;
+  v->jccr_sign = state->frame->jccr_sign;
   v->lambda = state->lambda;
   v->c_lambda = state->c_lambda;
   memcpy(v->qp_map, ctrl->qp_map[0], sizeof v->qp_map);
@@ -80,6 +81,7 @@ static void hip_cu_view(const cu_info_t *const cu, uvghip_cu_view_t *v)
   v->log2_width = cu->log2_width;
   v->log2_height = cu->log2_height;
   v->cbf = cu->cbf;
+  v->joint_cb_cr = cu->joint_cb_cr;
   if (cu->type == CU_INTRA) {
     v->intra_mode = cu->intra.mode;
     v->intra_mode_chroma = cu->intra.mode_chroma;
@@ -116,6 +118,20 @@ static unsigned uvg_quantize_residual_hip(encoder_state_t *const state, const cu
   hip_cu_view(cur_cu, &cv);
   return (unsigned)uvghip_quantize_residual_percall(&sv, &cv, width, height, color, scan_order, use_trskip, in_stride, out_stride, ref_in,
                                                     pred_in, rec_out, coeff_out, early_skip, lmcs_chroma_adj, tree_type);
+}
+
+static int uvg_quant_cbcr_residual_hip(encoder_state_t *const state, const cu_info_t *const cur_cu, const int width, const int height,
+                                       const coeff_scan_order_t scan_order, const int in_stride, const int out_stride,
+                                       const uvg_pixel *const u_ref_in, const uvg_pixel *const v_ref_in, const uvg_pixel *const u_pred_in,
+                                       const uvg_pixel *const v_pred_in, uvg_pixel *u_rec_out, uvg_pixel *v_rec_out, coeff_t *coeff_out,
+                                       bool early_skip, int lmcs_chroma_adj, enum uvg_tree_type tree_type)
+{
+  uvghip_state_view_t sv;
+  uvghip_cu_view_t cv;
+  hip_state_view(state, &sv, state->encoder_control->cfg.rdoq_enable);
+  hip_cu_view(cur_cu, &cv);
+  return uvghip_quant_cbcr_residual_percall(&sv, &cv, width, height, scan_order, in_stride, out_stride, u_ref_in, v_ref_in, u_pred_in,
+                                            v_pred_in, u_rec_out, v_rec_out, coeff_out, early_skip, lmcs_chroma_adj, tree_type);
 }
 
 /* bipred_average_generic's walk over the planes (picture-generic.c:1195-1262); the averaging itself is on the device. */
@@ -160,6 +176,7 @@ int uvg_strategy_register_state_hip(void *opaque, uint8_t bitdepth)
   success &= uvg_strategyselector_register(opaque, "quant", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_quant_hip);
   success &= uvg_strategyselector_register(opaque, "dequant", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_dequant_hip);
   success &= uvg_strategyselector_register(opaque, "quantize_residual", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_quantize_residual_hip);
+  success &= uvg_strategyselector_register(opaque, "quant_cbcr_residual", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_quant_cbcr_residual_hip);
   success &= uvg_strategyselector_register(opaque, "bipred_average", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_inter_recon_bipred_hip);
   return success;
 }

@@ -46,14 +46,15 @@ class CabacModels(ctypes.Structure):
 class StateView(ctypes.Structure):
     """uvghip_state_view_t: what the state-taking strategies read from encoder_state_t."""
     _fields_ = [(n, ctypes.c_int32) for n in ("bitdepth", "qp", "slice_is_intra", "rdoq_enable", "rdoq_skip", "dep_quant", "signhide_enable",
-                                                "scaling_list_enabled", "lfnst", "mts", "lmcs_chroma_adj_enabled", "collocated_luma_mode")] + \
+                                                "scaling_list_enabled", "lfnst", "mts", "lmcs_chroma_adj_enabled", "collocated_luma_mode", "jccr_sign", "reserved")] + \
                [("lambda_", ctypes.c_double), ("c_lambda", ctypes.c_double), ("qp_map", ctypes.c_int8 * 64), ("cabac", ctypes.c_uint8 * 244)]
 
 
 class CuView(ctypes.Structure):
     """uvghip_cu_view_t."""
     _fields_ = [(n, ctypes.c_int8) for n in ("type", "tr_idx", "lfnst_idx", "cr_lfnst_idx", "log2_width", "log2_height", "intra_mode",
-                                               "intra_mode_chroma", "mip_flag", "isp_mode")] + [("cbf", ctypes.c_uint16)]
+                                               "intra_mode_chroma", "mip_flag", "isp_mode")] + [("cbf", ctypes.c_uint16), ("joint_cb_cr", ctypes.c_int8),
+                                                                                          ("reserved", ctypes.c_int8 * 3)]
 
 
 _lib = None
@@ -137,6 +138,7 @@ SIGNATURES = {
     "uvghip_quant_percall": (ctypes.c_uint, [c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32] + [c_int] * 5),
     "uvghip_dequant_percall": (ctypes.c_uint, [c_vp, c_vp, c_vp, ctypes.c_int32, ctypes.c_int32] + [c_int] * 3),
     "uvghip_quantize_residual_percall": (c_int, [c_vp, c_vp] + [c_int] * 7 + [c_vp] * 4 + [c_int] * 3),
+    "uvghip_quant_cbcr_residual_percall": (c_int, [c_vp, c_vp] + [c_int] * 5 + [c_vp] * 7 + [c_int] * 3),
     "uvghip_bipred_average_percall": (None, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, ctypes.c_uint, ctypes.c_uint]),
     "uvghip_comm_allgather": (c_int, [c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "uvghip_residual_plane": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp]),
