@@ -228,12 +228,12 @@ extern "C" int uvghip_alf_filter_batch(int bitdepth, const void *src, int src_st
 // The covariance is the one dense contraction of the path: per class, C = [E | d]^T [E | d] with E the
 // n_samples x 52 matrix of clipped tap sums and d = org - rec; ee[k][l][b0][b1] = C[4k+b0][4l+b1], y[k][b] = C[4k+b][52],
 // pix_acc = C[52][52].  It runs on the i8 matrix cores with exact integer arithmetic: every 12-bit signed entry is
-// split as v = 128 * h + l (l = v & 127 in 0..127, h = v >> 7 in -16..16), so
-//     C = 16384 * H^T H + 128 * (H^T L + (H^T L)^T) + L^T L
+// split as v = 256 * h + l (l = (int8)v in -128..127, h = (v + 128) >> 8 in -8..8), so
+//     C = 65536 * H^T H + 256 * (H^T L + (H^T L)^T) + L^T L
 // and the three products are v_mfma_i32_32x32x32_i8 accumulations (|sums| < 2^31 for the <= 4096 samples of a rectangle).
 // A and B fragments come from the same [entry][sample] byte layout with the same code, so the contraction does not depend
 // on how the hardware orders the 32 k values inside an instruction.  A workgroup owns a rectangle: its 4x4 blocks are
-// walked in class order (every class padded to an even number of blocks = whole K = 32 chunks), the int32 accumulators
+// walked in class order (every class padded to a multiple of four blocks = whole K = 64 groups), the int32 accumulators
 // are combined into the int64 outputs once per class, and every output entry of the rectangle is written exactly once
 // (zeros for absent classes) -- no atomics, no memset of the 540 KB per rectangle.
 typedef int alf_v4i __attribute__((ext_vector_type(4)));
@@ -259,11 +259,16 @@ alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__
   constexpr int DEPTH = px_traits<PX>::depth;
   // tile jobs: hh and ll are symmetric (upper tile triangle), hl needs all tiles
   constexpr int N_SYM = NT * (NT + 1) / 2, N_FULL = NT * NT, N_TILES = 2 * N_SYM + N_FULL;
-  __shared__ __attribute__((aligned(16))) int8_t sH[NROW * ALF_KP], sL[NROW * ALF_KP];
-  __shared__ int sAcc[N_TILES][32][33];
+  // digit planes: rows 0..NE hold data, the rest of the last 32-row tile reads as zero -- one shared zero row (the last) instead
+  // of 11; the int32 tiles are combined per output tile pair (four tiles at a time): 49 KB per workgroup, three per CU
+  constexpr int NROW_LDS = NT == 2 ? 56 : 32;
+  constexpr int N_ACC = NT == 2 ? 4 : 3;
+  __shared__ __attribute__((aligned(16))) int8_t sHL[2 * NROW_LDS * ALF_KP];   // the two digit planes, H then L
+  int8_t *const sH = sHL, *const sL = sHL + NROW_LDS * ALF_KP;
+  __shared__ int sAcc[N_ACC][32][33];
   __shared__ uint8_t sBlkCls[256];
-  __shared__ uint16_t sSlot[256 + 32];         // class-ordered block list, 0xffff = padding slot
-  __shared__ uint8_t sSlotCls[256 + 32];
+  __shared__ uint16_t sSlot[256 + 96];         // class-ordered block list, 0xffff = padding slot (every class to a multiple of 4)
+  __shared__ uint8_t sSlotCls[256 + 96];
   __shared__ int sCnt[32], sPos[32], sFill[32];
   __shared__ uint8_t sPairK[91], sPairL[91];   // COMPACT: pair index -> (k, l), k <= l
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -277,13 +282,13 @@ alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__
 #pragma unroll
   for (int i = 1; i < 4; ++i) clipv[i] = 1 << (7 - 2 * i + DEPTH - 8);     // alf.c:5248-5260
 
-  // ---- class-ordered slot list (stable counting sort; every class padded to an even number of blocks) ----
+  // ---- class-ordered slot list (counting sort; every class padded to a multiple of four blocks) ----
   const int bw = (R.w + 3) / 4, bhh = (R.h + 3) / 4, nblk = bw * bhh;      // <= 256 (rectangles are at most 64x64)
   if (t < 32) { sCnt[t] = 0; sFill[t] = 0; }
   if (t < 91) { int k = 0, base = 0; while (t >= base + 13 - k) { base += 13 - k; ++k; } sPairK[t] = (uint8_t)k; sPairL[t] = (uint8_t)(k + (t - base)); }
   const int half_fp = CHROMA ? 2 : 3;
   const bool interior = R.x >= half_fp && R.y >= half_fp && R.x + R.w + half_fp <= pic_w && R.y + R.h + half_fp <= pic_h;
-  for (int i = t; i < NROW * ALF_KP; i += 256) { sH[i] = 0; sL[i] = 0; }   // rows NE+1.. stay zero for good
+  for (int i = t; i < 2 * NROW_LDS * ALF_KP; i += 256) sHL[i] = 0;   // rows NE+1.. stay zero for good
   __syncthreads();
   for (int i = t; i < nblk; i += 256) {
     const int by = i / bw, bx = i - by * bw;
@@ -292,16 +297,17 @@ alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__
     atomicAdd(&sCnt[c], 1);
   }
   __syncthreads();
-  if (t == 0) { int run = 0; for (int c = 0; c < 32; ++c) { sPos[c] = run; run += (sCnt[c] + 1) & ~1; } }
+  if (t == 0) { int run = 0; for (int c = 0; c < 32; ++c) { sPos[c] = run; run += (sCnt[c] + 3) & ~3; } }
   __syncthreads();
-  const int nslot = sPos[31] + ((sCnt[31] + 1) & ~1);                      // even
+  const int nslot = sPos[31] + ((sCnt[31] + 3) & ~3);                      // a multiple of 4
   // (the order of the blocks inside a class does not matter: integer sums)
   for (int i = t; i < nblk; i += 256) {
     const int c = sBlkCls[i];
     const int rank = atomicAdd(&sFill[c], 1);
     sSlot[sPos[c] + rank] = (uint16_t)i; sSlotCls[sPos[c] + rank] = (uint8_t)c;
   }
-  if (t < 32 && (sCnt[t] & 1)) { sSlot[sPos[t] + sCnt[t]] = 0xffffu; sSlotCls[sPos[t] + sCnt[t]] = (uint8_t)t; }
+  if (t < 32)
+    for (int k = sCnt[t]; k < ((sCnt[t] + 3) & ~3); ++k) { sSlot[sPos[t] + k] = 0xffffu; sSlotCls[sPos[t] + k] = (uint8_t)t; }
   __syncthreads();
 
   // ---- which tiles this wave accumulates: hh on wave 0, ll on wave 1, hl split over waves 2 and 3 ----
@@ -320,173 +326,208 @@ alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__
   int cur_cls = -1;
   // combine the int32 tile sums into the class's int64 outputs (all threads) and clear the accumulators
   auto flush = [&]() {
-    if (cur_cls >= 0 && has_work) {
-      const int s0 = wave < 2 ? wave * N_SYM : 2 * N_SYM + hl_row * NT;
-      constexpr int NJ = NT == 1 ? 1 : 3;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        if (wave >= 2 && j >= NT) break;       // an hl tile row has NT tiles
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sAcc[s0 + j][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][lane & 31] = acc[j][r];
-        acc[j] = alf_v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      }
-    }
-    __syncthreads();
+    if (cur_cls < 0) return;                        // (uniform) nothing accumulated yet
+    constexpr int NPAIR = NT == 2 ? 3 : 1;          // output tile pairs (0,0) (0,1) (1,1)
+    long long *Rc = nullptr, *Ec = nullptr;
     if (cur_cls >= 0) {
-      auto sym = [&](int base, int i, int j2) -> long long {      // symmetric product stored as its upper tile triangle
-        int ti = i >> 5, tj = j2 >> 5;
-        if (ti > tj) { const int x = i; i = j2; j2 = x; ti = i >> 5; tj = j2 >> 5; }
-        const int q = ti == 0 ? tj : NT + tj - 1;                  // (0,0) (0,1) (1,1) -> 0 1 2
-        return sAcc[base + q][i & 31][j2 & 31];
+      if constexpr (COMPACT) Rc = E + (size_t)n_done * UVGHIP_ALF_REC_WORDS;
+      else Ec = E + (size_t)cur_cls * 13 * 13 * 16;
+    }
+#pragma unroll
+    for (int pq = 0; pq < NPAIR; ++pq) {
+      const int pa = pq == 2 ? 1 : 0, pb = pq == 0 ? 0 : 1;
+      auto put = [&](const alf_v16i &v, int dst) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sAcc[dst][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][lane & 31] = v[r];
       };
-      auto full = [&](int i, int j2) -> long long { return sAcc[2 * N_SYM + (i >> 5) * NT + (j2 >> 5)][i & 31][j2 & 31]; };
-      auto cval = [&](int i, int j2) -> long long {
-        return sym(0, i, j2) * 16384 + (full(i, j2) + full(j2, i)) * 128 + sym(N_SYM, i, j2);
-      };
-      if constexpr (COMPACT) {
-        long long *Rc = E + (size_t)n_done * UVGHIP_ALF_REC_WORDS;
-        for (int idx = t; idx < 91 * 16; idx += 256) {
-          const int b1 = idx & 3, b0 = (idx >> 2) & 3, p = idx >> 4;
-          const int k = sPairK[p], l = sPairL[p];                     // pair p -> (k, l), k <= l: row k holds 13 - k pairs
-          Rc[idx] = (l < NC) ? cval(4 * k + b0, 4 * l + b1) : 0;
-        }
-        int32_t *Yc = reinterpret_cast<int32_t *>(Rc + 91 * 16);
-        for (int idx = t; idx < 13 * 4; idx += 256) Yc[idx] = (idx >> 2) < NC ? (int32_t)cval(idx, NE) : 0;
-        if (t == 0) { Rc[91 * 16 + 26] = cval(NE, NE); Rc[91 * 16 + 27] = 0; }
-        ++n_done;
-      } else {
-        long long *Ec = E + (size_t)cur_cls * 13 * 13 * 16;
-        for (int idx = t; idx < 13 * 13 * 16; idx += 256) {
-          const int b1 = idx & 3, b0 = (idx >> 2) & 3, kl = idx >> 4, k = kl / 13, l = kl - k * 13;
-          Ec[idx] = (k < NC && l < NC) ? cval(4 * k + b0, 4 * l + b1) : 0;
-        }
-        for (int idx = t; idx < 13 * 4; idx += 256) Y[cur_cls * 13 * 4 + idx] = (idx >> 2) < NC ? (int32_t)cval(idx, NE) : 0;
-        if (t == 0) PA[cur_cls] = cval(NE, NE);
+      if (cur_cls >= 0) {
+        // sAcc[0] = hh(pa,pb), [1] = ll(pa,pb), [2] = hl(pa,pb), [3] = hl(pb,pa) where pa != pb
+        if (wave == 0) put(acc[NT == 2 ? pq : 0], 0);
+        else if (wave == 1) put(acc[NT == 2 ? pq : 0], 1);
+        else if (wave == 2) { if (pa == 0) put(acc[NT == 2 ? pb : 0], 2); }
+        else if (NT == 2) { if (pa == 1) put(acc[1], 2); else if (pb == 1) put(acc[0], 3); }
       }
+      __syncthreads();
+      if (cur_cls >= 0) {
+        // entry (i, j2) of the (NE + 1)-square result, symmetric: looked up with its lower tile first
+        auto in_pair = [&](int i, int j2) { const int ti = i >> 5, tj = j2 >> 5; return min(ti, tj) == pa && max(ti, tj) == pb; };
+        auto cval = [&](int i, int j2) -> long long {
+          if ((i >> 5) > (j2 >> 5)) { const int x = i; i = j2; j2 = x; }
+          const int a = i & 31, b = j2 & 31;
+          const long long hl = (long long)sAcc[2][a][b] + (long long)(pa == pb ? sAcc[2][b][a] : sAcc[N_ACC - 1][b][a]);
+          return (long long)sAcc[0][a][b] * 65536 + hl * 256 + (long long)sAcc[1][a][b];
+        };
+        if constexpr (COMPACT) {
+          for (int idx = t; idx < 91 * 16; idx += 256) {
+            const int b1 = idx & 3, b0 = (idx >> 2) & 3, p = idx >> 4;
+            const int k = sPairK[p], l = sPairL[p];                     // pair p -> (k, l), k <= l: row k holds 13 - k pairs
+            if (l >= NC) { if (pq == 0) Rc[idx] = 0; continue; }
+            if (in_pair(4 * k + b0, 4 * l + b1)) Rc[idx] = cval(4 * k + b0, 4 * l + b1);
+          }
+          int32_t *Yc = reinterpret_cast<int32_t *>(Rc + 91 * 16);
+          for (int idx = t; idx < 13 * 4; idx += 256) {
+            if ((idx >> 2) >= NC) { if (pq == 0) Yc[idx] = 0; continue; }
+            if (in_pair(idx, NE)) Yc[idx] = (int32_t)cval(idx, NE);
+          }
+          if (t == 0 && in_pair(NE, NE)) { Rc[91 * 16 + 26] = cval(NE, NE); Rc[91 * 16 + 27] = 0; }
+        } else {
+          for (int idx = t; idx < 13 * 13 * 16; idx += 256) {
+            const int b1 = idx & 3, b0 = (idx >> 2) & 3, kl = idx >> 4, k = kl / 13, l = kl - k * 13;
+            if (k >= NC || l >= NC) { if (pq == 0) Ec[idx] = 0; continue; }
+            if (in_pair(4 * k + b0, 4 * l + b1)) Ec[idx] = cval(4 * k + b0, 4 * l + b1);
+          }
+          for (int idx = t; idx < 13 * 4; idx += 256) {
+            if ((idx >> 2) >= NC) { if (pq == 0) Y[cur_cls * 13 * 4 + idx] = 0; continue; }
+            if (in_pair(idx, NE)) Y[cur_cls * 13 * 4 + idx] = (int32_t)cval(idx, NE);
+          }
+          if (t == 0 && in_pair(NE, NE)) PA[cur_cls] = cval(NE, NE);
+        }
+      }
+      __syncthreads();
+    }
+    if (cur_cls >= 0) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[j] = alf_v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if constexpr (COMPACT) ++n_done;
       done_mask |= 1u << cur_cls;
     }
-    __syncthreads();
   };
 
   for (int c0 = 0; c0 < nslot; c0 += ALF_SLOTS) {
-    const int ns = min(ALF_SLOTS, nslot - c0);                    // even
+    const int ns = min(ALF_SLOTS, nslot - c0);                    // a multiple of 4
     // ---- phase A: one sample per thread: clipped tap-pair sums -> digit planes ----
     // The pairs are visited in the geometric order of the filter (alf_filter_kernel) -- (+ax, +ay) / (-ax, -ay) with the row
     // offsets limited at the virtual boundary -- and the sums of pair g go to the rows of the coefficient that pair feeds
     // under the block's transpose, kPermPad[transpose][g] (alf-generic.c:742-905 enumerates the same pairs per transpose).
     {
-      const int j = t >> 4, p = t & 15;
+      // wave w, group a (four slots of one class), sample p of the block: slot 4a + w of the chunk, K column 64a + 4p + w:
+      // the four slots of a group fill one contiguous K block of 64 for the matrix cores
+      const int j = 4 * ((t >> 4) & 3) + (t >> 6), p = t & 15;
+      const int kcol = 64 * ((t >> 4) & 3) + 4 * p + (t >> 6);
       constexpr int NG = CHROMA ? 6 : 12;
-      int pr[NG][4];
-#pragma unroll
-      for (int g = 0; g < NG; ++g)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) pr[g][b] = 0;
-      int dval = 0, cur = 0;
-      uint32_t pw[3] = {0x03020100u, 0x07060504u, 0x0b0a0908u};          // identity
+      constexpr int PL = NROW_LDS * ALF_KP;                               // sHL: H plane, then L plane
+      // digits of v = 256 * h + l, l = (int8)v, h = (v + 128) >> 8: the low byte is stored as it is, the high digit is
+      // byte 2 of (v + 128) << 8 (one v_add_lshl, stored with ds_write_b8_d16_hi)
+      auto put = [&](int row, int v) {
+        int8_t *q = sHL + row * ALF_KP + kcol;
+        q[0] = (int8_t)(((uint32_t)(v + 128) << 8) >> 16);
+        q[PL] = (int8_t)v;
+      };
+      bool live = false;
+      int x = 0, y = 0;
       if (j < ns) {
         const int blk = sSlot[c0 + j];
         if (blk != 0xffff) {
           const int by = blk / bw, bx = blk - by * bw;
           const int xx = bx * 4 + (p & 3), yy = by * 4 + (p >> 2);
-          if (xx < R.w && yy < R.h) {
-            const int x = R.x + xx, y = R.y + yy;
-            int trv = 0;
-            if constexpr (!CHROMA) {
-              trv = cls[(y >> 2) * cls_stride + (x >> 2)] >> 5;
-              const uint32_t *pm = reinterpret_cast<const uint32_t *>(kPermPad[trv]);
-              pw[0] = pm[0]; pw[1] = pm[1]; pw[2] = pm[2];
-            }
-            (void)trv;
-            const int y_vb = y & (vbh - 1);
-            int lim = 3;
-            if (y_vb < vb_pos && y_vb >= vb_pos - (CHROMA ? 2 : 4)) lim = vb_pos - 1 - y_vb;
-            else if (y_vb >= vb_pos && y_vb <= vb_pos + (CHROMA ? 1 : 3)) lim = y_vb - vb_pos;
-            const int r1 = min(1, lim), r2 = min(2, lim), r3 = min(3, lim);
-            // alf-generic.c:742-905 clamps a pair's row offset at the virtual boundary only where its loop variable is
-            // negative; under transposes 1 and 3 the pairs (-1, 2), (-1, 1), (-2, 1) are visited with a positive one and keep
-            // their full offsets.  Reproduced.
-            const bool odd = CHROMA ? false : (trv & 1) != 0;
-            const int q2 = odd ? 2 : r2, q1 = odd ? 1 : r1;
-            // every sample of the footprint first (one batch of loads in flight), then the arithmetic
-            constexpr int NP = 2 * NG + 1;
-            int sv[NP];
-            int dxs[NG], dys[NG];
-            if constexpr (!CHROMA) {
-              const int tx[12] = {0, 1, 0, -1, 2, 1, 0, -1, -2, 3, 2, 1};
-              const int ty[12] = {r3, r2, r2, q2, r1, r1, r1, q1, q1, 0, 0, 0};
-#pragma unroll
-              for (int g = 0; g < 12; ++g) { dxs[g] = tx[g]; dys[g] = ty[g]; }
-            } else {
-              const int tx[6] = {0, 1, 0, -1, 2, 1};
-              const int ty[6] = {r2, r1, r1, r1, 0, 0};
-#pragma unroll
-              for (int g = 0; g < 6; ++g) { dxs[g] = tx[g]; dys[g] = ty[g]; }
-              (void)r3; (void)q2; (void)q1;
-            }
-            if (interior) {
-              const PX *c0 = rec + (size_t)y * rstride + x;
-              sv[2 * NG] = c0[0];
-#pragma unroll
-              for (int g = 0; g < NG; ++g) { const int o = dys[g] * rstride + dxs[g]; sv[2 * g] = c0[o]; sv[2 * g + 1] = c0[-o]; }
-            } else {
-              sv[2 * NG] = pxc<PX>(rec, rstride, pic_w, pic_h, x, y);
-#pragma unroll
-              for (int g = 0; g < NG; ++g) {
-                sv[2 * g] = pxc<PX>(rec, rstride, pic_w, pic_h, x + dxs[g], y + dys[g]);
-                sv[2 * g + 1] = pxc<PX>(rec, rstride, pic_w, pic_h, x - dxs[g], y - dys[g]);
-              }
-            }
-            cur = sv[2 * NG];
-            dval = (int)org[(size_t)y * ostride + x] - cur;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-              const int d0 = sv[2 * g] - cur, d1 = sv[2 * g + 1] - cur;
-              pr[g][0] = d0 + d1;                      // clipv[0] = 1 << depth never clips a sample difference
-#pragma unroll
-              for (int b = 1; b < 4; ++b) pr[g][b] = clampi(d0, -clipv[b], clipv[b]) + clampi(d1, -clipv[b], clipv[b]);
-            }
-          }
+          if (xx < R.w && yy < R.h) { live = true; x = R.x + xx; y = R.y + yy; }
         }
       }
-      if (j < ns) {
+      if (live) {
+        uint32_t pw[3] = {0x03020100u, 0x07060504u, 0x0b0a0908u};          // identity
+        int trv = 0;
+        if constexpr (!CHROMA) {
+          trv = cls[(y >> 2) * cls_stride + (x >> 2)] >> 5;
+          const uint32_t *pm = reinterpret_cast<const uint32_t *>(kPermPad[trv]);
+          pw[0] = pm[0]; pw[1] = pm[1]; pw[2] = pm[2];
+        }
+        const int y_vb = y & (vbh - 1);
+        int lim = 3;
+        if (y_vb < vb_pos && y_vb >= vb_pos - (CHROMA ? 2 : 4)) lim = vb_pos - 1 - y_vb;
+        else if (y_vb >= vb_pos && y_vb <= vb_pos + (CHROMA ? 1 : 3)) lim = y_vb - vb_pos;
+        const int r1 = min(1, lim), r2 = min(2, lim), r3 = min(3, lim);
+        // alf-generic.c:742-905 clamps a pair's row offset at the virtual boundary only where its loop variable is
+        // negative; under transposes 1 and 3 the pairs (-1, 2), (-1, 1), (-2, 1) are visited with a positive one and keep
+        // their full offsets.  Reproduced.
+        const bool odd = CHROMA ? false : (trv & 1) != 0;
+        const int q2 = odd ? 2 : r2, q1 = odd ? 1 : r1;
+        // every sample of the footprint first (one batch of loads in flight), then the arithmetic
+        int sv[2 * NG + 1];
+        int dxs[NG], dys[NG];
+        if constexpr (!CHROMA) {
+          const int tx[12] = {0, 1, 0, -1, 2, 1, 0, -1, -2, 3, 2, 1};
+          const int ty[12] = {r3, r2, r2, q2, r1, r1, r1, q1, q1, 0, 0, 0};
+#pragma unroll
+          for (int g = 0; g < 12; ++g) { dxs[g] = tx[g]; dys[g] = ty[g]; }
+        } else {
+          const int tx[6] = {0, 1, 0, -1, 2, 1};
+          const int ty[6] = {r2, r1, r1, r1, 0, 0};
+#pragma unroll
+          for (int g = 0; g < 6; ++g) { dxs[g] = tx[g]; dys[g] = ty[g]; }
+          (void)r3; (void)q2; (void)q1;
+        }
+        if (interior) {
+          // 32-bit element offsets from the plane base (one scalar base + per-lane offset per load; the five distinct row
+          // offsets are multiplied out once)
+          const uint32_t base = (uint32_t)(y * rstride + x);
+          sv[2 * NG] = rec[base];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            const int o = dys[g] * rstride + dxs[g];
+            sv[2 * g] = rec[base + (uint32_t)o]; sv[2 * g + 1] = rec[base - (uint32_t)o];
+          }
+        } else {
+          sv[2 * NG] = pxc<PX>(rec, rstride, pic_w, pic_h, x, y);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            sv[2 * g] = pxc<PX>(rec, rstride, pic_w, pic_h, x + dxs[g], y + dys[g]);
+            sv[2 * g + 1] = pxc<PX>(rec, rstride, pic_w, pic_h, x - dxs[g], y - dys[g]);
+          }
+        }
+        const int cur = sv[2 * NG];
+        const int dval = (int)org[(uint32_t)(y * ostride + x)] - cur;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           const int k = (int)((pw[g >> 2] >> (8 * (g & 3))) & 255);
-          int8_t *ph = sH + (4 * k) * ALF_KP + t, *pl = sL + (4 * k) * ALF_KP + t;
+          const int d0 = sv[2 * g] - cur, d1 = sv[2 * g + 1] - cur;
+          put(4 * k, d0 + d1);                       // clipv[0] = 1 << depth never clips a sample difference
 #pragma unroll
-          for (int b = 0; b < 4; ++b) { ph[b * ALF_KP] = (int8_t)(pr[g][b] >> 7); pl[b * ALF_KP] = (int8_t)(pr[g][b] & 127); }
+          for (int b = 1; b < 4; ++b) put(4 * k + b, clampi(d0, -clipv[b], clipv[b]) + clampi(d1, -clipv[b], clipv[b]));
         }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {                                     // the centre coefficient: the sample itself
-          sH[(4 * (NC - 1) + b) * ALF_KP + t] = (int8_t)(cur >> 7); sL[(4 * (NC - 1) + b) * ALF_KP + t] = (int8_t)(cur & 127);
-        }
-        sH[NE * ALF_KP + t] = (int8_t)(dval >> 7); sL[NE * ALF_KP + t] = (int8_t)(dval & 127);
+        for (int b = 0; b < 4; ++b) put(4 * (NC - 1) + b, cur);            // the centre coefficient: the sample itself
+        put(NE, dval);
+      } else if (j < ns) {                                                // padding slot / outside the rectangle: a zero column
+#pragma unroll
+        for (int q = 0; q <= NE; ++q) { sHL[q * ALF_KP + kcol] = 0; sHL[PL + q * ALF_KP + kcol] = 0; }
       }
     }
     __syncthreads();
-    // ---- phase B: K = 32 samples (two slots of one class) per step ----
-    for (int q = 0; q < ns; q += 2) {
+    // ---- phase B: a group (four slots of one class) = a K block of 64 = two matrix-core steps of K = 32; the fragments of
+    //      both steps are fetched before the first product is issued ----
+    for (int q = 0; q < ns; q += 4) {
       const int c = sSlotCls[c0 + q];
       if (c != cur_cls) { flush(); cur_cls = c; }
-      const int koff = q * 16 + 16 * (lane >> 5);
-      auto frag = [&](const int8_t *plane, int tile) {
-        return *reinterpret_cast<const alf_v4i *>(plane + (tile * 32 + (lane & 31)) * ALF_KP + koff);
+      const int koff = 64 * (q >> 2) + 16 * (lane >> 5);          // first half of the group's K block; the second is + 32
+      auto frag = [&](const int8_t *plane, int tile, int half) {
+        const int row = min(tile * 32 + (lane & 31), NROW_LDS - 1);
+        return *reinterpret_cast<const alf_v4i *>(plane + row * ALF_KP + koff + 32 * half);
       };
       if (wave < 2) {                           // symmetric products: the B fragments are the A fragments
-        const alf_v4i f0 = frag(opA, 0);
-        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f0, f0, acc[0], 0, 0, 0);
+        const alf_v4i f0a = frag(opA, 0, 0), f0b = frag(opA, 0, 1);
         if constexpr (NT == 2) {
-          const alf_v4i f1 = frag(opA, 1);
-          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f0, f1, acc[1], 0, 0, 0);
-          acc[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f1, f1, acc[2], 0, 0, 0);
+          const alf_v4i f1a = frag(opA, 1, 0), f1b = frag(opA, 1, 1);
+          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f0a, f0a, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f0a, f1a, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f1a, f1a, acc[2], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f0b, f0b, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f0b, f1b, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f1b, f1b, acc[2], 0, 0, 0);
+        } else {
+          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f0a, f0a, acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(f0b, f0b, acc[0], 0, 0, 0);
         }
       } else if (has_work) {
-        const alf_v4i fa = frag(opA, hl_row), fb0 = frag(opB, 0);
-        acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb0, acc[0], 0, 0, 0);
+        const alf_v4i faa = frag(opA, hl_row, 0), fab = frag(opA, hl_row, 1), fb0a = frag(opB, 0, 0), fb0b = frag(opB, 0, 1);
         if constexpr (NT == 2) {
-          const alf_v4i fb1 = frag(opB, 1);
-          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb1, acc[1], 0, 0, 0);
+          const alf_v4i fb1a = frag(opB, 1, 0), fb1b = frag(opB, 1, 1);
+          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(faa, fb0a, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(faa, fb1a, acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fab, fb0b, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fab, fb1b, acc[1], 0, 0, 0);
+        } else {
+          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(faa, fb0a, acc[0], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fab, fb0b, acc[0], 0, 0, 0);
         }
       }
     }
