@@ -135,7 +135,7 @@ def algorithmic_bytes(fr, name, group=1):
     if kern.startswith("sao_stats"):   # orig + rec read, 104 counters per CTU written
         return 2 * (luma if kern.endswith("_y") else chroma) + cnt * 104 * 4
     if kern.startswith("sao_offsets"):
-        return cnt * (40 + 8) * 4
+        return (3 if kern.endswith("_yuv") else 1) * cnt * (40 + 8) * 4
     if kern.startswith("sao_apply"):
         return 2 * (luma if kern.endswith("_y") else chroma) + cnt * 32
     if kern == "alf_classify":

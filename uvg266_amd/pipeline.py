@@ -161,16 +161,18 @@ class BandFrame:
         comp = (("y", self.y, self.rec_y, self.sao_y, self.rects, ys, W, H),
                 ("u", self.u, self.rec_u, self.sao_u, self.crects, cs, W // 2, H // 2),
                 ("v", self.v, self.rec_v, self.sao_v, self.crects, cs, W // 2, H // 2))
-        self.edge = {k: torch.zeros((n_ctu, 4, 2, 5), dtype=torch.int32, device=device) for k in "yuv"}
+        # the three planes' per-CTU statistics / parameters side by side: the offset derivation is one launch over all of them
+        self.edge_all = torch.zeros((3, n_ctu, 4, 2, 5), dtype=torch.int32, device=device)
+        self.params_all = torch.zeros((3, n_ctu, 8), dtype=torch.int32, device=device)
+        self.edge = {k: self.edge_all[i] for i, k in enumerate("yuv")}
         self.bandst = {k: torch.zeros((n_ctu, 2, 32), dtype=torch.int32, device=device) for k in "yuv"}
-        self.params = {k: torch.zeros((n_ctu, 8), dtype=torch.int32, device=device) for k in "yuv"}
+        self.params = {k: self.params_all[i] for i, k in enumerate("yuv")}
         dbk = [depth, P(self.rec_y), ys, P(self.rec_u), P(self.rec_v), cs, W, H, P(self.scu), scu_stride, 0, 0, 0, qp, None, y0, y1]
         self.stage_a = [("deblock_v_0", L.uvghip_deblock_band, dbk + [1])]
         self.stage_b = [("deblock_h_0", L.uvghip_deblock_band, dbk + [2])]
         for k, org, rec, out, rc, st, pw, ph in comp:
             self.stage_b.append((f"sao_stats_{k}_0", L.uvghip_sao_stats_batch, [depth, P(org), st, P(rec), st, P(rc), n_ctu, P(self.edge[k]), P(self.bandst[k])]))
-        for k, *_ in comp:
-            self.stage_b.append((f"sao_offsets_{k}_0", L.uvghip_sao_edge_offsets_batch, [P(self.edge[k]), None, n_ctu, P(self.params[k]), None]))
+        self.stage_b.append(("sao_offsets_yuv_0", L.uvghip_sao_edge_offsets_batch, [P(self.edge_all), None, 3 * n_ctu, P(self.params_all), None]))
         for k, org, rec, out, rc, st, pw, ph in comp:
             self.stage_b.append((f"sao_apply_{k}_0", L.uvghip_sao_apply_batch, [depth, P(rec), st, P(out), st, pw, ph, P(rc), P(self.params[k]), n_ctu]))
         self.final = (self.sao_y, self.sao_u, self.sao_v)
