@@ -49,6 +49,101 @@ ORC_EXPORT void ORC_FN(quant)(const int16_t *coef, int16_t *q_coef, int width, i
   }
 }
 
+void ORC_FN(rdoq_scans)(int width, int height, uint32_t *scan, uint32_t *scan_cg);
+
+/* uvg_quant with cfg.signhide_enable (quant-generic.c:51-232), lfnst_idx as the reference's argument.  Quirks kept: the
+ * lfnst form and every delta_u take their scale from the (flat) scaling-list array = quant_scales[0][qp % 6], the plain form
+ * its levels from the sqrt(2)-aware default (:94, :133, :113, :145). */
+ORC_EXPORT void ORC_FN(quant_sh)(const int16_t *coef, int16_t *q_coef, int width, int height, int bitdepth, int qp_scaled,
+                                 int transform_skip, int slice_is_intra, int lfnst_idx)
+{
+  const int lw = orc_log2i(width), lh = orc_log2i(height), wh = width * height;
+  if (transform_skip && qp_scaled < 4 + 6 * 2) qp_scaled = 4 + 6 * 2;
+  const int sqrt2 = !transform_skip && ((lw + lh) & 1);
+  const int transform_shift = 15 - bitdepth - ((lw + lh) >> 1) - sqrt2;
+  const int64_t q_bits = 14 + qp_scaled / 6 + (transform_skip ? 0 : transform_shift);
+  const int32_t add = (slice_is_intra ? 171 : 85) << (q_bits - 9);
+  const int32_t q_bits8 = (int32_t)q_bits - 8;
+  const int32_t scale = quant_scales[sqrt2][qp_scaled % 6], flat = quant_scales[0][qp_scaled % 6];
+  static uint32_t scan[1024], scan_cg[64];
+#pragma omp threadprivate(scan, scan_cg)
+  ORC_FN(rdoq_scans)(width, height, scan, scan_cg);
+  uint32_t ac_sum = 0;
+  static int32_t delta_u[1024];
+#pragma omp threadprivate(delta_u)
+  const int maxn = ((width == 4 && height == 4) || (width == 8 && height == 8)) ? 8 : 16;
+  if (lfnst_idx == 0) {
+    for (int n = 0; n < wh; ++n) {
+      const int32_t c = coef[n];
+      const int64_t a = c < 0 ? -(int64_t)c : c;
+      int32_t level = (int32_t)((a * scale + add) >> q_bits);
+      ac_sum += (uint32_t)level;
+      if (c < 0) level = -level;
+      q_coef[n] = (int16_t)orc_clip16(level);
+    }
+  } else {
+    for (int n = 0; n < wh; ++n) q_coef[n] = 0;
+    for (int n = 0; n < maxn; ++n) {
+      const uint32_t idx = scan[n];
+      const int32_t c = coef[idx];
+      const int64_t a = c < 0 ? -(int64_t)c : c;
+      int32_t level = (int32_t)((a * flat + add) >> q_bits);
+      ac_sum += (uint32_t)level;
+      if (c < 0) level = -level;
+      q_coef[idx] = (int16_t)orc_clip16(level);
+    }
+  }
+  if (ac_sum < 2) return;
+  if (lfnst_idx == 0) {
+    for (int n = 0; n < wh; ++n) {
+      const int32_t c = coef[n];
+      const int64_t a = c < 0 ? -(int64_t)c : c;
+      const int32_t level = (int32_t)((a * flat + add) >> q_bits);
+      delta_u[n] = (int32_t)((a * flat - ((int64_t)level << q_bits)) >> q_bits8);
+    }
+  } else {
+    for (int n = 0; n < wh; ++n) delta_u[n] = 0;       /* (the reference leaves the rest uninitialised; it never reads it) */
+    for (int n = 0; n < maxn; ++n) {
+      const uint32_t idx = scan[n];
+      const int32_t c = coef[idx];
+      const int64_t a = c < 0 ? -(int64_t)c : c;
+      const int32_t level = (int32_t)((a * flat + add) >> q_bits);
+      delta_u[idx] = (int32_t)((a * flat - ((int64_t)level << q_bits)) >> q_bits8);
+    }
+  }
+  int last_cg = -1;
+  for (int subset = (wh - 1) >> 4; subset >= 0; subset--) {
+    int first_nz = 16, last_nz = -1, abssum = 0;
+    const int subpos = subset << 4;
+    for (int n = 15; n >= 0; n--) if (q_coef[scan[n + subpos]]) { last_nz = n; break; }
+    for (int n = 0; n < 16; n++) if (q_coef[scan[n + subpos]]) { first_nz = n; break; }
+    for (int n = first_nz; n <= last_nz; n++) abssum += q_coef[scan[n + subpos]];
+    if (last_nz >= 0 && last_cg == -1) last_cg = 1;
+    if (last_nz - first_nz >= 4) {
+      const int signbit = q_coef[scan[subpos + first_nz]] > 0 ? 0 : 1;
+      if (signbit != (abssum & 1)) {
+        int32_t min_cost = 0x7fffffff, cur_cost = 0x7fffffff;
+        int min_pos = -1;
+        int16_t final_change = 0, cur_change = 0;
+        for (int n = (last_cg == 1 ? last_nz : 15); n >= 0; n--) {
+          const uint32_t b = scan[n + subpos];
+          if (q_coef[b] != 0) {
+            if (delta_u[b] > 0) { cur_cost = -delta_u[b]; cur_change = 1; }
+            else if (n == first_nz && abs((int)q_coef[b]) == 1) cur_cost = 0x7fffffff;
+            else { cur_cost = delta_u[b]; cur_change = -1; }
+          } else if (n < first_nz && ((coef[b] >= 0) ? 0 : 1) != signbit) cur_cost = 0x7fffffff;
+          else { cur_cost = -delta_u[b]; cur_change = 1; }
+          if (cur_cost < min_cost) { min_cost = cur_cost; final_change = cur_change; min_pos = (int)b; }
+        }
+        if (q_coef[min_pos] == 32767 || q_coef[min_pos] == -32768) final_change = -1;
+        if (coef[min_pos] >= 0) q_coef[min_pos] = (int16_t)(q_coef[min_pos] + final_change);
+        else q_coef[min_pos] = (int16_t)(q_coef[min_pos] - final_change);
+      }
+    }
+    if (last_cg == 1) last_cg = 0;
+  }
+}
+
 /* quant-generic.c:618-669 */
 ORC_EXPORT void ORC_FN(dequant)(const int16_t *q_coef, int16_t *coef, int width, int height, int bitdepth,
                                 int qp_scaled, int transform_skip)

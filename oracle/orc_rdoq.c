@@ -23,6 +23,9 @@
  */
 #include "orc_common.h"
 #include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
 
 /* CTX_STATE of every context model uvg_rdoq prices bins with; [0] luma, [1] chroma where split */
 typedef struct orc_rdoq_ctx {
@@ -254,10 +257,71 @@ static uint32_t sig_coeff_group_ctx(const uint32_t *flags, uint32_t px, uint32_t
  * uvg_rdoq.  color 0/1/2; block_type: cu_type_t (1 intra); cbf_u: cbf_is_set(cbf, COLOR_U) (only read for color 2).
  * Returns the sum of the absolute levels kept (abs_sum, rdo.c:1836).
  */
-ORC_EXPORT int ORC_FN(rdoq)(const int16_t *coef, int16_t *dest_coeff, int width, int height, int color, int block_type, int cbf_u,
-                            int lfnst_idx, int mts_idx, int qp_scaled, double lambda, const void *ctx_snapshot)
+/* what RDOQ records per position for sign-data hiding (struct sh_rates_t, rdo.c:214-223) */
+typedef struct { int32_t inc[1024], dec[1024], sig_coeff_inc[1024], quant_delta[1024]; } orc_sh_rates;
+
+/* uvg_rdoq_sign_hiding (rdo.c:700-845).  last_pos = best_last_idx_p1; need_sqrt_adjust: odd log2 size sum. */
+static void rdoq_sign_hiding(int qp_scaled, const uint32_t *scan, const orc_sh_rates *sh, int32_t last_pos, const int16_t *coeffs,
+                             int16_t *quant_coeffs, double lambda, int need_sqrt_adjust)
+{
+  static const int16_t inv_quant_scales[2][6] = {{40, 45, 51, 57, 64, 72}, {57, 64, 72, 80, 90, 102}};
+  const int inv_quant = inv_quant_scales[need_sqrt_adjust][qp_scaled % 6];
+  /* the reference forms this product in int (it wraps for qp_scaled / 6 >= 9) and divides in double */
+  const int32_t prod = (int32_t)((uint32_t)(inv_quant * inv_quant) * (1u << (2 * (qp_scaled / 6))));
+  const int64_t rd_factor = (int64_t)(prod / lambda / 16 / (1 << (2 * (ORC_BIT_DEPTH - 8))) + 0.5);
+  const int last_cg = (last_pos - 1) >> 4;
+  for (int32_t cg_scan = last_cg; cg_scan >= 0; cg_scan--) {
+    const int32_t cg0 = cg_scan << 4;
+    int32_t last_nz = -1, first_nz = 16;
+    for (int32_t i = 15; i >= 0; --i) if (quant_coeffs[scan[i + cg0]]) { last_nz = i; break; }
+    for (int32_t i = 0; i <= last_nz; i++) if (quant_coeffs[scan[i + cg0]]) { first_nz = i; break; }
+    if (last_nz - first_nz < 4) continue;                                      /* SBH_THRESHOLD */
+    const int32_t signbit = quant_coeffs[scan[cg0 + first_nz]] <= 0;
+    unsigned sum = 0;
+    for (int32_t i = first_nz; i <= last_nz; i++) sum += (unsigned)quant_coeffs[scan[i + cg0]];
+    if (signbit == (int32_t)(sum & 1)) continue;
+    int64_t best_cost = INT64_MAX;
+    int best_pos = 0, best_change = 0;
+    const int last_coeff_scan = cg_scan == last_cg ? last_nz : 15;
+    for (int cs = last_coeff_scan; cs >= 0; --cs) {
+      const int pos = (int)scan[cs + cg0];
+      int64_t cost;
+      int change;
+      const int64_t qbits = rd_factor * sh->quant_delta[pos];
+      const int a = abs((int)quant_coeffs[pos]);
+      if (a != 0) {
+        int64_t inc_bits = sh->inc[pos], dec_bits = sh->dec[pos];
+        if (a == 1) dec_bits -= sh->sig_coeff_inc[pos];
+        if (cg_scan == last_cg && last_nz == cs && a == 1) dec_bits -= 4 * 32768;
+        inc_bits = -qbits + inc_bits;
+        dec_bits = qbits + dec_bits;
+        if (inc_bits < dec_bits) { change = 1; cost = inc_bits; }
+        else {
+          change = -1; cost = dec_bits;
+          if (cs == first_nz && a == 1) cost = INT64_MAX;
+        }
+      } else {
+        const int bits = 32768 + sh->inc[pos] + sh->sig_coeff_inc[pos];
+        cost = -llabs(qbits) + bits;
+        change = 1;
+        if (cs < first_nz && ((coeffs[pos] >= 0) ? 0 : 1) != signbit) cost = INT64_MAX;
+      }
+      if (cost < best_cost) { best_cost = cost; best_pos = pos; best_change = change; }
+    }
+    if (quant_coeffs[best_pos] == 32767 || quant_coeffs[best_pos] == -32768) best_change = -1;
+    if (coeffs[best_pos] >= 0) quant_coeffs[best_pos] = (int16_t)(quant_coeffs[best_pos] + best_change);
+    else quant_coeffs[best_pos] = (int16_t)(quant_coeffs[best_pos] - best_change);
+  }
+}
+
+/* signhide: cfg.signhide_enable (rdo.c:1660-1687 record the rates, :1865-1867 apply the hiding) */
+ORC_EXPORT int ORC_FN(rdoq_sh)(const int16_t *coef, int16_t *dest_coeff, int width, int height, int color, int block_type, int cbf_u,
+                               int lfnst_idx, int mts_idx, int qp_scaled, double lambda, const void *ctx_snapshot, int signhide)
 {
   const orc_rdoq_ctx *c = (const orc_rdoq_ctx *)ctx_snapshot;
+  static orc_sh_rates sh;
+#pragma omp threadprivate(sh)
+  if (signhide) memset(&sh, 0, sizeof sh);
   const int t = color ? 1 : 0;
   const uint32_t l2w = (uint32_t)orc_log2i(width), l2h = (uint32_t)orc_log2i(height);
   const int sqrt2 = ((l2w + l2h) % 2 == 1);
@@ -350,6 +414,21 @@ ORC_EXPORT int ORC_FN(rdoq)(const int16_t *coef, int16_t *dest_coeff, int width,
         else
           level = (int32_t)coded_level(c, t, lambda, &cost_coeff[scanpos], &cost_coeff0[scanpos], &cost_sig[scanpos], level_double, max_abs_level,
                                        ctx_sig, ctx_set, ctx_set, ctx_set, go_rice_param, reg_bins, q_bits, error_scale, 0);
+        if (signhide) {
+          if (scanpos != last_scanpos)
+            sh.sig_coeff_inc[blkpos] = reg_bins < 4 ? 0 : (int32_t)BITS(c->sig[t][ctx_sig], 1) - (int32_t)BITS(c->sig[t][ctx_sig], 0);
+          sh.quant_delta[blkpos] = (level_double - level * (1 << q_bits)) >> (q_bits - 8);
+          if (level > 0) {
+            const int32_t now = ic_rate(c, t, (uint32_t)level, ctx_set, ctx_set, ctx_set, go_rice_param, reg_bins, 0);
+            sh.inc[blkpos] = ic_rate(c, t, (uint32_t)level + 1, ctx_set, ctx_set, ctx_set, go_rice_param, reg_bins, 0) - now;
+            sh.dec[blkpos] = ic_rate(c, t, (uint32_t)level - 1, ctx_set, ctx_set, ctx_set, go_rice_param, reg_bins, 0) - now;
+          } else if (reg_bins < 4) {
+            const int32_t now = ic_rate(c, t, 0, ctx_set, ctx_set, ctx_set, go_rice_param, reg_bins, 0);
+            sh.inc[blkpos] = ic_rate(c, t, 1, ctx_set, ctx_set, ctx_set, go_rice_param, reg_bins, 0) - now;
+          } else {
+            sh.inc[blkpos] = (int32_t)BITS(c->gt1[t][ctx_set], 0);
+          }
+        }
         dest_coeff[blkpos] = (int16_t)level;
         base_cost += cost_coeff[scanpos];
         if ((scanpos % 16 == 0) && scanpos > 0) go_rice_param = 0;
@@ -451,5 +530,12 @@ ORC_EXPORT int ORC_FN(rdoq)(const int16_t *coef, int16_t *dest_coeff, int width,
     }
   }
   for (int32_t scanpos = best_last_idx_p1; scanpos <= last_scanpos; scanpos++) dest_coeff[scan[scanpos]] = 0;
+  if (signhide && abs_sum >= 2) rdoq_sign_hiding(qp_scaled, scan, &sh, best_last_idx_p1, coef, dest_coeff, lambda, sqrt2);
   return (int)abs_sum;
+}
+
+ORC_EXPORT int ORC_FN(rdoq)(const int16_t *coef, int16_t *dest_coeff, int width, int height, int color, int block_type, int cbf_u,
+                            int lfnst_idx, int mts_idx, int qp_scaled, double lambda, const void *ctx_snapshot)
+{
+  return ORC_FN(rdoq_sh)(coef, dest_coeff, width, height, color, block_type, cbf_u, lfnst_idx, mts_idx, qp_scaled, lambda, ctx_snapshot, 0);
 }

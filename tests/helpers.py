@@ -156,6 +156,17 @@ class Oracle:
                                ctypes.c_double(lam), ptr(ctx))
         return out, s
 
+    def rdoq_sh(self, d, coef, w, h, color, block_type, cbf_u, lfnst, mts, qp_scaled, lam, ctx, signhide=1):
+        out = np.full(w * h, 0x33, np.int16)
+        s = self.fn(d, "rdoq_sh")(ptr(np.ascontiguousarray(coef, np.int16)), ptr(out), w, h, color, block_type, cbf_u, lfnst, mts, qp_scaled,
+                                  ctypes.c_double(lam), ptr(ctx), signhide)
+        return out, s
+
+    def quant_sh(self, d, coef, w, h, bitdepth, qp_scaled, ts, intra, lfnst):
+        out = np.zeros(w * h, np.int16)
+        self.fn(d, "quant_sh", None)(ptr(np.ascontiguousarray(coef, np.int16)), ptr(out), w, h, bitdepth, qp_scaled, ts, intra, lfnst)
+        return out
+
     def coeff_cost(self, d, coeff, w, h, color, models):
         """-> (bits, flags, adapted models bytes).  models: 1220 bytes = uvghip_cabac_models_t."""
         m = np.ascontiguousarray(np.frombuffer(bytes(models), np.uint8)).copy()
@@ -441,4 +452,19 @@ def jccr_goldens(depth):
         out.append(dict(w=m[0], h=m[1], joint=m[2], sign=m[3], qps=m[4], intra=m[5], cu_type=m[6], rdoq=m[7], rdoq_skip=m[8], cbf_u=m[9],
                         early_skip=m[10], S=S, so=so, ret=m[13], lam=float(a[1][0]), ctx=a[2], uref=a[3].reshape(S, S), vref=a[4].reshape(S, S),
                         upred=a[5].reshape(S, S), vpred=a[6].reshape(S, S), q=a[7], urec=a[8], vrec=a[9]))
+    return out
+
+
+def signhide_goldens(depth):
+    """cfg.signhide_enable = 1 records -> list of dicts; kind 0 = uvg_rdoq, 1 = uvg_quant."""
+    out = []
+    for name, a in read_golden("signhide", depth):
+        if name != "sh":
+            continue
+        m = [int(v) for v in a[0]]
+        if m[0] == 0:
+            out.append(dict(kind=0, w=m[1], h=m[2], color=m[3], qps=m[4], intra=m[5], cbf_u=m[6], lfnst=m[7], mts=m[8], cu_type=m[9],
+                            lam=float(a[1][0]), ctx=a[2], coef=a[3], q=a[4]))
+        else:
+            out.append(dict(kind=1, w=m[1], h=m[2], color=m[3], qps=m[4], intra=m[5], ts=m[6], lfnst=m[7], coef=a[3], q=a[4]))
     return out

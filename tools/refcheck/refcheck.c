@@ -54,6 +54,7 @@ void check_rdoq(void);
 void check_shim(void);
 void check_coeffcost(void);
 void check_jccr(void);
+void check_signhide(void);
 void check_intra(void);
 void check_ipol(void);
 void check_sao(void);
@@ -103,6 +104,7 @@ int main(int argc, char **argv)
   check_shim();      /* ... and this one after it */
   check_coeffcost();
   check_jccr();
+  check_signhide();
 #endif
   if (g_out) fclose(g_out);
   printf("refcheck %d-bit: %s (%d mismatches)\n", UVG_BIT_DEPTH, g_fail ? "FAIL" : "OK", g_fail);
@@ -119,6 +121,7 @@ int main(int argc, char **argv)
 #include "rc_shim.inc"
 #include "rc_coeffcost.inc"
 #include "rc_jccr.inc"
+#include "rc_signhide.inc"
 #endif
 #ifdef HAVE_INTRA
 #include "rc_intra.inc"
