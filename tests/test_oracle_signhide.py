@@ -20,7 +20,7 @@ def test_signhide_goldens(orc, depth):
             q = orc.quant_sh(depth, c["coef"], c["w"], c["h"], depth, c["qps"], c["ts"], c["intra"], c["lfnst"])
             nq += 1
         assert np.array_equal(q, c["q"]), (c["kind"], c["w"], c["h"], c["color"], c["lfnst"])
-    assert nr == 200 and nq == 100 and differs > 100
+    assert nr == 200 and nq == 200 and differs > 100
 
 
 def test_hidden_sign_parity_property(orc):
