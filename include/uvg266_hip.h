@@ -177,6 +177,13 @@ UVGHIP_API int uvghip_quant_batch(int bitdepth, const int16_t *coef, int16_t *q_
 UVGHIP_API int uvghip_quant_lfnst_batch(int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n,
                              int qp_scaled, int transform_skip, int slice_is_intra, void *stream);
 
+/* replaces: uvg_quant with cfg.signhide_enable = 1 (quant-generic.c:51-232; presets slow and slower): the levels of
+ * uvghip_quant_batch (lfnst_idx 0) or uvghip_quant_lfnst_batch, then sign-bit hiding per 4x4 coefficient group -- where the first
+ * and last non-zero levels of a group are at least 4 scan positions apart and the parity of their sum disagrees with the sign of
+ * the first one, the level with the smallest quantisation-error cost is moved by one.  width, height in {4,8,16,32}. */
+UVGHIP_API int uvghip_quant_signhide_batch(int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n,
+                                int qp_scaled, int transform_skip, int slice_is_intra, int lfnst_idx, void *stream);
+
 /* replaces: uvg_dequant (quant-generic.c:618-669), no scaling list / dep-quant. */
 UVGHIP_API int uvghip_dequant_batch(int bitdepth, const int16_t *q_coef, int16_t *coef, int width, int height, int n,
                          int qp_scaled, int transform_skip, void *stream);
@@ -224,6 +231,16 @@ UVGHIP_API int uvghip_rdoq_batch(int bitdepth, const int16_t *coef, int16_t *q_c
                       int block_type, int cbf_u, int lfnst_idx, int mts_idx, int qp_scaled, double lambda,
                       const uvghip_rdoq_ctx_t *ctx_host, void *workspace, size_t workspace_bytes,
                       uint32_t *abs_sum_out, uint8_t *has_coeffs, void *stream);
+
+/* uvg_rdoq with cfg.signhide_enable = 1 (presets slow and slower): the walk also records struct sh_rates_t (rdo.c:214-223,
+ * 1660-1687) and uvg_rdoq_sign_hiding (:700-845) runs at the end.  Same arguments as uvghip_rdoq_batch; the workspace holds the
+ * rate records too: >= uvghip_rdoq_signhide_workspace_bytes(width, height, n).  lambda must be > 0.  abs_sum_out / has_coeffs
+ * are the values before the hiding step (what :1865 tests). */
+UVGHIP_API size_t uvghip_rdoq_signhide_workspace_bytes(int width, int height, int n);
+UVGHIP_API int uvghip_rdoq_signhide_batch(int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n, int color,
+                               int block_type, int cbf_u, int lfnst_idx, int mts_idx, int qp_scaled, double lambda,
+                               const uvghip_rdoq_ctx_t *ctx_host, void *workspace, size_t workspace_bytes,
+                               uint32_t *abs_sum_out, uint8_t *has_coeffs, void *stream);
 
 /* ---- CABAC bit cost of coefficient blocks ---- */
 
@@ -292,7 +309,7 @@ typedef struct uvghip_qr_params {
                                                           * cr_lfnst_idx for chroma of a chroma tree; :505): with it != 0 the
                                                           * quantiser keeps only the first 8 / 16 scan positions (:101-120) even
                                                           * where the transform itself does not apply */
-  int32_t reserved;
+  int32_t signhide_enable;                               /* cfg.signhide_enable: sign-data hiding in uvg_quant / uvg_rdoq */
   double lambda;                                         /* color ? state->c_lambda : state->lambda */
   uvghip_rdoq_ctx_t ctx;                                 /* state->cabac context snapshot (RDOQ only) */
 } uvghip_qr_params_t;
@@ -683,7 +700,7 @@ typedef struct uvghip_state_view {
   int32_t slice_is_intra;           /* state->frame->slicetype == UVG_SLICE_I */
   int32_t rdoq_enable, rdoq_skip;   /* cfg.rdoq_enable, cfg.rdoq_skip */
   int32_t dep_quant, signhide_enable, scaling_list_enabled;   /* cfg.dep_quant, cfg.signhide_enable, scaling_list.enable:
-                                                               * must all be 0 (the registrar of the shim checks) */
+                                                               * dep_quant and scaling lists must be 0 (the shim checks) */
   int32_t lfnst, mts;               /* cfg.lfnst, cfg.mts (enum uvg_mts) */
   int32_t lmcs_chroma_adj_enabled;  /* lmcs_aps->m_sliceReshapeInfo.enableChromaAdj: must be 0 for chroma calls */
   int32_t collocated_luma_mode;     /* state->collocated_luma_mode (LFNST of a CCLM chroma block) */

@@ -102,7 +102,10 @@ def oracle_quantize_residual(orc, d, c):
     if lf:
         coef = np.ascontiguousarray(coef); orc.lib.orc_lfnst_fwd(H.ptr(coef), w, h, c["imode"], clw, clh, lf)
     if c["rdoq"] and (w > 4 or not c["rdoq_skip"]) and not c["trskip"]:
-        q, _ = orc.rdoq(d, coef, w, h, color, c["cu_type"], c.get("cbf_u", 0), idx, c.get("tr_idx", 0) if color == 0 else 0, c["qps"], c["lam"], c["ctx"])
+        q, _ = orc.rdoq_sh(d, coef, w, h, color, c["cu_type"], c.get("cbf_u", 0), idx, c.get("tr_idx", 0) if color == 0 else 0, c["qps"], c["lam"], c["ctx"],
+                           int(c.get("signhide", 0)))
+    elif c.get("signhide", 0):
+        q = orc.quant_sh(d, coef, w, h, d, c["qps"], c["trskip"], c["intra"], idx)
     else:
         q = orc.quant(d, coef, w, h, d, c["qps"], c["trskip"], c["intra"])
         if idx:                                   # uvg_quant with lfnst_idx: only the first 8 / 16 scan positions (:101-120),

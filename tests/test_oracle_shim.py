@@ -35,7 +35,7 @@ def qr_case(d, r):
                 cu_lfnst=cv.lfnst_idx, cu_cr_lfnst=cv.cr_lfnst_idx, tr_idx=cv.tr_idx, mts=sv.mts, lf_apply=lf, imode=mode,
                 lf_log2=(cv.log2_width, cv.log2_height) if color == 0 else (lw, lh), trskip=r["trskip"], rdoq=sv.rdoq_enable,
                 rdoq_skip=sv.rdoq_skip, cbf_u=(cv.cbf >> 1) & 1, qps=scaled_qp(sv, color), lam=sv.c_lambda if color else sv.lambda_,
-                ctx=np.frombuffer(bytes(sv.cabac), np.uint8).copy(), intra=sv.slice_is_intra)
+                ctx=np.frombuffer(bytes(sv.cabac), np.uint8).copy(), intra=sv.slice_is_intra, signhide=sv.signhide_enable)
 
 
 @pytest.mark.parametrize("depth", [8, 10])
@@ -44,7 +44,8 @@ def test_shim_view_layout(depth):
     assert ctypes.sizeof(StateView) == 384 and ctypes.sizeof(CuView) == 16      # sizeof in include/uvg266_hip.h (C layout)
     g = H.shim_goldens(depth)
     assert len(g["sqr"]) == 240 and len(g["sq"]) > 200 and len(g["sbp"]) > 100 and len(g["sjc"]) == 48
-    assert all(r["sv"].bitdepth == depth and not r["sv"].signhide_enable and not r["sv"].dep_quant for r in g["sqr"])
+    assert all(r["sv"].bitdepth == depth and not r["sv"].dep_quant for r in g["sqr"])
+    assert 20 < sum(r["sv"].signhide_enable for r in g["sqr"]) < 60
     assert {r["branch"] for r in g["sqr"]} == set(range(6))
 
 

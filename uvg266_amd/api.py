@@ -429,7 +429,7 @@ def alf_stats_batch(org, rec, rects, cls=None, is_chroma=False, pic_w=None, pic_
 
 
 # ---- RDOQ ---------------------------------------------------------------------------
-def rdoq_batch(coef, bitdepth, color, block_type, cbf_u, lfnst_idx, mts_idx, qp_scaled, lam, ctx, workspace=None):
+def rdoq_batch(coef, bitdepth, color, block_type, cbf_u, lfnst_idx, mts_idx, qp_scaled, lam, ctx, workspace=None, signhide=False):
     """coef (n, h, w) int16 transformed blocks -> (levels (n, h, w) int16, abs_sum (n,) int32, has_coeffs (n,) uint8).
     ctx: 244 bytes (numpy uint8 or bytes) = uvghip_rdoq_ctx_t, a host-side snapshot."""
     import ctypes
@@ -438,11 +438,11 @@ def rdoq_batch(coef, bitdepth, color, block_type, cbf_u, lfnst_idx, mts_idx, qp_
     out = torch.empty_like(coef)
     abs_sum = torch.empty(n, dtype=torch.int32, device=coef.device)
     has = torch.empty(n, dtype=torch.uint8, device=coef.device)
-    need = L.uvghip_rdoq_workspace_bytes(w, h, n)
+    need = (L.uvghip_rdoq_signhide_workspace_bytes if signhide else L.uvghip_rdoq_workspace_bytes)(w, h, n)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty((need + 7) // 8, dtype=torch.float64, device=coef.device)
     cbuf = (ctypes.c_uint8 * 244).from_buffer_copy(bytes(np.asarray(ctx, np.uint8).tobytes()))
-    _lib.check(L.uvghip_rdoq_batch(bitdepth, _dev(coef), _dev(out), w, h, n, color, block_type, cbf_u, lfnst_idx, mts_idx, qp_scaled,
+    _lib.check((L.uvghip_rdoq_signhide_batch if signhide else L.uvghip_rdoq_batch)(bitdepth, _dev(coef), _dev(out), w, h, n, color, block_type, cbf_u, lfnst_idx, mts_idx, qp_scaled,
                                    float(lam), ctypes.cast(cbuf, ctypes.c_void_p), _dev(workspace), workspace.numel() * 8,
                                    _dev(abs_sum), _dev(has), _stream()), "uvghip_rdoq_batch")
     return out, abs_sum, has
@@ -450,7 +450,7 @@ def rdoq_batch(coef, bitdepth, color, block_type, cbf_u, lfnst_idx, mts_idx, qp_
 
 def quantize_residual_batch(orig, pred, rec, tus, width, height, bitdepth, color=0, type_hor=0, type_ver=0, skip_w=0, skip_h=0,
                             qp_scaled=22, slice_is_intra=True, cu_type=1, use_trskip=False, rdoq=False, rdoq_skip=False, cbf_u=0,
-                            mts_idx=0, lfnst_idx=0, lam=0.0, ctx=None, lfnst_tus=None):
+                            mts_idx=0, lfnst_idx=0, lam=0.0, ctx=None, lfnst_tus=None, signhide=False):
     """uvg_quantize_residual on any branch (staged launches) -> (coeff (n, h, w) int16, has_coeffs (n,) uint8); rec in place."""
     import ctypes
     L = _lib.init(orig.device.index or 0)
@@ -461,6 +461,7 @@ def quantize_residual_batch(orig, pred, rec, tus, width, height, bitdepth, color
     p.qp_scaled, p.slice_is_intra, p.cu_type, p.use_trskip = qp_scaled, int(slice_is_intra), cu_type, int(use_trskip)
     p.rdoq_enable, p.rdoq_skip, p.dep_quant, p.cbf_u, p.mts_idx, p.lfnst_idx = int(rdoq), int(rdoq_skip), 0, cbf_u, mts_idx, lfnst_idx
     p.lambda_ = float(lam)
+    p.signhide_enable = int(signhide)
     if ctx is not None:
         ctypes.memmove(p.ctx, np.asarray(ctx, np.uint8).tobytes(), 244)
     need = L.uvghip_quantize_residual_workspace_bytes(ctypes.byref(p), n)
@@ -513,3 +514,13 @@ def quant_cbcr_residual_batch(u_orig, v_orig, u_pred, v_pred, u_rec, v_rec, tus,
                                                   _dev(ret), int(early_skip), _dev(ws), ws.numel() * 8, _stream()),
                "uvghip_quant_cbcr_residual_batch")
     return coeff, ret
+
+
+def quant_signhide_batch(coef, bitdepth, qp_scaled, transform_skip=False, slice_is_intra=True, lfnst_idx=0):
+    """uvg_quant with sign-data hiding on (n, h, w) int16 blocks -> levels."""
+    L = _lib.init(coef.device.index or 0)
+    n, h, w = coef.shape
+    out = torch.empty_like(coef)
+    _lib.check(L.uvghip_quant_signhide_batch(bitdepth, _dev(coef), _dev(out), w, h, n, qp_scaled, int(transform_skip), int(slice_is_intra), lfnst_idx,
+                                             _stream()), "uvghip_quant_signhide_batch")
+    return out

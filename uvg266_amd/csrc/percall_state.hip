@@ -33,7 +33,6 @@ int scaled_qp(const uvghip_state_view_t *sv, int color)
 void check_view(const uvghip_state_view_t *sv)
 {
   if (sv->bitdepth != 8 && sv->bitdepth != 10) unsupported("this bit depth");
-  if (sv->signhide_enable) unsupported("sign-data hiding (cfg.signhide_enable)");
   if (sv->scaling_list_enabled) unsupported("scaling lists");
   if (sv->dep_quant) unsupported("dependent quantisation");
 }
@@ -50,9 +49,13 @@ extern "C" unsigned uvghip_quant_percall(const uvghip_state_view_t *sv, const in
   const size_t oi = c->take(bytes), oo = c->take(bytes);
   memcpy(c->hp<int16_t>(oi), coef, bytes);
   c->upload(oi, bytes);
-  c->must((lfnst_idx ? uvghip_quant_lfnst_batch : uvghip_quant_batch)(sv->bitdepth, c->dp<int16_t>(oi), c->dp<int16_t>(oo), width, height, 1,
-                                                                       scaled_qp(sv, color), transform_skip, sv->slice_is_intra, c->stream),
-          "quant");
+  if (sv->signhide_enable)
+    c->must(uvghip_quant_signhide_batch(sv->bitdepth, c->dp<int16_t>(oi), c->dp<int16_t>(oo), width, height, 1, scaled_qp(sv, color),
+                                        transform_skip, sv->slice_is_intra, lfnst_idx, c->stream), "quant (sign hiding)");
+  else
+    c->must((lfnst_idx ? uvghip_quant_lfnst_batch : uvghip_quant_batch)(sv->bitdepth, c->dp<int16_t>(oi), c->dp<int16_t>(oo), width, height, 1,
+                                                                         scaled_qp(sv, color), transform_skip, sv->slice_is_intra, c->stream),
+            "quant");
   c->download(oo, bytes);
   c->sync();
   memcpy(q_coef, c->hp<int16_t>(oo), bytes);
@@ -101,6 +104,7 @@ extern "C" int uvghip_quantize_residual_percall(const uvghip_state_view_t *sv, c
   p.slice_is_intra = sv->slice_is_intra; p.cu_type = cu->type;
   p.use_trskip = use_trskip;
   p.rdoq_enable = sv->rdoq_enable; p.rdoq_skip = sv->rdoq_skip; p.dep_quant = 0;
+  p.signhide_enable = sv->signhide_enable;
   p.cbf_u = (cu->cbf >> 1) & 1;                                                    // cbf_is_set(cbf, COLOR_U)
   p.mts_idx = cu->tr_idx; p.lfnst_idx = lfnst_index;
   p.lambda = color ? sv->c_lambda : sv->lambda;
@@ -171,6 +175,7 @@ extern "C" int uvghip_quant_cbcr_residual_percall(const uvghip_state_view_t *sv,
   p.qp_scaled = scaled_qp(sv, color);
   p.slice_is_intra = sv->slice_is_intra; p.cu_type = cu->type;
   p.rdoq_enable = sv->rdoq_enable; p.rdoq_skip = sv->rdoq_skip;
+  p.signhide_enable = sv->signhide_enable;
   p.cbf_u = (cu->cbf >> 1) & 1;
   p.lfnst_idx = lfnst_index;
   p.lambda = sv->c_lambda;

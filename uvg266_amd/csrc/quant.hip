@@ -160,6 +160,120 @@ extern "C" int uvghip_quant_lfnst_batch(int bitdepth, const int16_t *coef, int16
   UVGHIP_CHECK_LAUNCH();
 }
 
+// ---- uvg_quant with sign-data hiding (cfg.signhide_enable; quant-generic.c:51-232) ----
+// A workgroup of 64 threads takes 1024 / (w h) blocks = 1024 positions = 64 coefficient groups.  Phase 1: every position's level
+// (the sqrt(2)-aware scale; the lfnst form quantises the first 8 / 16 scan positions with the flat scale) and delta_u (always
+// the flat scaling-list scale, :133/:145) into LDS, the block's level sum.  Phase 2: one thread per coefficient group runs the
+// hiding decision (:154-228) -- groups do not interact; "last_cg" (the first group from the end that holds a level, whose scan
+// starts at its last non-zero position) is found with a per-block reduction.
+__global__ void __launch_bounds__(64)
+quant_signhide_kernel(const int16_t *__restrict__ coef, int16_t *__restrict__ q_coef, int n, int l2w, int l2h, quant_params q, int flat_scale,
+                      int lfnst_idx)
+{
+  __shared__ int16_t sQ[1024];
+  __shared__ int sDelta[1024];
+  __shared__ uint16_t sScan[1024];               // scan position -> raster position inside a block
+  __shared__ uint8_t sScanCg[64];
+  __shared__ unsigned sSum[64], sLastCg[64];
+  const int tid = threadIdx.x;
+  const int l2wh = l2w + l2h, wh = 1 << l2wh, width = 1 << l2w, height = 1 << l2h;
+  const int bpw = 1024 >> l2wh;                  // blocks per workgroup
+  const int blk0 = blockIdx.x * bpw, here = min(bpw, n - blk0);
+  const int l2cgw = l2w - 2, cgw = 1 << l2cgw, cgh = height >> 2, ncg = wh >> 4;
+  if (tid == 0) {
+    int i = 0, x = 0, y = 0;
+    while (i < ncg) {
+      while (y >= 0) { if (x < cgw && y < cgh) sScanCg[i++] = (uint8_t)(y * cgw + x); y--; x++; }
+      y = x; x = 0;
+    }
+  }
+  if (tid < bpw) { sSum[tid] = 0; sLastCg[tid] = 0; }
+  __syncthreads();
+  constexpr unsigned long long kDiag4 = 0xFBE7AD369C258140ull;
+  for (int e = tid; e < wh; e += 64) {
+    const int g = sScanCg[e >> 4], k = (int)((kDiag4 >> (4 * (e & 15))) & 15);
+    sScan[e] = (uint16_t)(((((g >> l2cgw) << 2) + (k >> 2)) << l2w) + ((g & (cgw - 1)) << 2) + (k & 3));
+  }
+  __syncthreads();
+  const int maxn = ((width == 4 && height == 4) || (width == 8 && height == 8)) ? 8 : 16;
+  // ---- phase 1 ----
+  for (int e = tid; e < here * wh; e += 64) {
+    const int b = e >> l2wh, sp = e & (wh - 1);                   // walk in SCAN order so that the lfnst cut is a range test
+    const int pos = sScan[sp];
+    const int c = coef[(size_t)(blk0 + b) * wh + pos];
+    const long long a = c < 0 ? -(long long)c : (long long)c;
+    int level = 0, delta = 0;
+    if (!lfnst_idx || sp < maxn) {
+      const int lv_flat = (int)((a * flat_scale + q.add) >> q.q_bits);
+      level = lfnst_idx ? lv_flat : (int)((a * q.scale + q.add) >> q.q_bits);
+      delta = (int)((a * flat_scale - ((long long)lv_flat << q.q_bits)) >> (q.q_bits - 8));
+      if (level) atomicAdd(&sSum[b], (unsigned)level);
+    }
+    sQ[b * wh + pos] = (int16_t)clampi(c < 0 ? -level : level, -32768, 32767);
+    sDelta[b * wh + pos] = delta;
+  }
+  __syncthreads();
+  // ---- phase 2: one coefficient group per thread ----
+  const int gid = tid;                                            // group index inside the workgroup: block gid / ncg, group gid % ncg
+  const int gb = gid >> (l2wh - 4), subset = gid & (ncg - 1);
+  const bool act = gb < here;
+  const int16_t *Q = sQ + gb * wh;
+  int first_nz = 16, last_nz = -1;
+  if (act) {
+    for (int k = 15; k >= 0; k--) if (Q[sScan[subset * 16 + k]]) { last_nz = k; break; }
+    for (int k = 0; k < 16; k++) if (Q[sScan[subset * 16 + k]]) { first_nz = k; break; }
+    if (last_nz >= 0) atomicMax(&sLastCg[gb], (unsigned)subset + 1);
+  }
+  __syncthreads();
+  if (act && sSum[gb] >= 2 && last_nz - first_nz >= 4) {
+    const int subpos = subset * 16;
+    int abssum = 0;
+    for (int k = first_nz; k <= last_nz; k++) abssum += Q[sScan[subpos + k]];
+    const int signbit = Q[sScan[subpos + first_nz]] > 0 ? 0 : 1;
+    if (signbit != (abssum & 1)) {
+      const bool is_last_cg = sLastCg[gb] == (unsigned)subset + 1;
+      int min_cost = 0x7fffffff, cur_cost = 0x7fffffff, min_pos = -1, final_change = 0, cur_change = 0;
+      const int16_t *C = coef + (size_t)(blk0 + gb) * wh;
+      for (int k = is_last_cg ? last_nz : 15; k >= 0; k--) {
+        const int b = sScan[subpos + k];
+        const int qv = Q[b], du = sDelta[gb * wh + b];
+        if (qv != 0) {
+          if (du > 0) { cur_cost = -du; cur_change = 1; }
+          else if (k == first_nz && abs(qv) == 1) cur_cost = 0x7fffffff;
+          else { cur_cost = du; cur_change = -1; }
+        } else if (k < first_nz && ((C[b] >= 0) ? 0 : 1) != signbit) cur_cost = 0x7fffffff;
+        else { cur_cost = -du; cur_change = 1; }
+        if (cur_cost < min_cost) { min_cost = cur_cost; final_change = cur_change; min_pos = b; }
+      }
+      if (min_pos >= 0) {
+        const int qv = Q[min_pos];
+        if (qv == 32767 || qv == -32768) final_change = -1;
+        sQ[gb * wh + min_pos] = (int16_t)(C[min_pos] >= 0 ? qv + final_change : qv - final_change);
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < here * wh; e += 64) q_coef[(size_t)blk0 * wh + e] = sQ[e];
+}
+
+extern "C" int uvghip_quant_signhide_batch(int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n,
+                                           int qp_scaled, int transform_skip, int slice_is_intra, int lfnst_idx, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (int rc = check_qargs(bitdepth, width, height, qp_scaled)) return rc;
+  auto pow2 = [](int v) { return v == 4 || v == 8 || v == 16 || v == 32; };
+  if (!pow2(width) || !pow2(height) || !coef || !q_coef || lfnst_idx < 0 || lfnst_idx > 2) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (n <= 0) return 0;
+  const quant_params q = make_quant_params(bitdepth, width, height, qp_scaled, transform_skip, slice_is_intra);
+  static const int16_t qs0[6] = {26214, 23302, 20560, 18396, 16384, 14564};
+  int qp = qp_scaled;
+  if (transform_skip && qp < 4 + 6 * 2) qp = 4 + 6 * 2;
+  const int l2w = tr_ilog2(width), l2h = tr_ilog2(height);
+  const int bpw = 1024 / (width * height);
+  quant_signhide_kernel<<<(n + bpw - 1) / bpw, 64, 0, uvghip_stream(stream)>>>(coef, q_coef, n, l2w, l2h, q, qs0[qp % 6], lfnst_idx);
+  UVGHIP_CHECK_LAUNCH();
+}
+
 // ---- per-block coefficient sums ------------------------------------------------
 // out[b] = sum |c| (mode 0, coeff_abs_sum) or (sum weights[min(|c|,3)] + 128) >> 8 (mode 1, fast_coeff_cost)
 __global__ void __launch_bounds__(256)
@@ -878,9 +992,9 @@ __global__ void __launch_bounds__(256) has_coeffs_kernel(const int16_t *__restri
 
 int uvghip_rdoq_launch_checked(int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n, int color, int block_type,
                                int cbf_u, int lfnst_idx, int mts_idx, int qp_scaled, double lambda, const uvghip_rdoq_ctx_t *ctx_host,
-                               void *workspace, size_t workspace_bytes, uint8_t *has_coeffs, void *stream)
+                               void *workspace, size_t workspace_bytes, uint8_t *has_coeffs, void *stream, int signhide = 0)
 {
-  return uvghip_rdoq_batch(bitdepth, coef, q_coef, width, height, n, color, block_type, cbf_u, lfnst_idx, mts_idx, qp_scaled, lambda, ctx_host,
+  return (signhide ? uvghip_rdoq_signhide_batch : uvghip_rdoq_batch)(bitdepth, coef, q_coef, width, height, n, color, block_type, cbf_u, lfnst_idx, mts_idx, qp_scaled, lambda, ctx_host,
                            workspace, workspace_bytes, nullptr, has_coeffs, stream);
 }
 
@@ -890,7 +1004,8 @@ extern "C" size_t uvghip_quantize_residual_workspace_bytes(const uvghip_qr_param
 {
   if (!p || n <= 0) return 0;
   const bool rdoq = p->rdoq_enable && (p->width > 4 || !p->rdoq_skip) && !p->use_trskip;
-  return 2 * qr_coef_bytes(p->width, p->height, n) + (rdoq ? uvghip_rdoq_workspace_bytes(p->width, p->height, n) : 0);
+  return 2 * qr_coef_bytes(p->width, p->height, n) +
+         (rdoq ? (p->signhide_enable ? uvghip_rdoq_signhide_workspace_bytes : uvghip_rdoq_workspace_bytes)(p->width, p->height, n) : 0);
 }
 
 extern "C" int uvghip_quantize_residual_batch(int bitdepth, const uvghip_qr_params_t *p, const void *orig, int orig_stride,
@@ -932,14 +1047,18 @@ extern "C" int uvghip_quantize_residual_batch(int bitdepth, const uvghip_qr_para
   if (rdoq) {
     if (int rc = uvghip_rdoq_launch_checked(bitdepth, coef, coeff_out, width, height, n, p->color, p->cu_type, p->cbf_u, p->lfnst_idx,
                                             p->color == 0 ? p->mts_idx : 0, p->qp_scaled, p->lambda, &p->ctx, rdoq_ws,
-                                            workspace_bytes - 2 * qr_coef_bytes(width, height, n), has_coeffs, stream))
+                                            workspace_bytes - 2 * qr_coef_bytes(width, height, n), has_coeffs, stream, p->signhide_enable))
+      return rc;
+  } else if (p->signhide_enable) {
+    if (int rc = uvghip_quant_signhide_batch(bitdepth, coef, coeff_out, width, height, n, p->qp_scaled, p->use_trskip, p->slice_is_intra,
+                                             p->lfnst_idx, stream))
       return rc;
   } else {
     if (int rc = (p->lfnst_idx ? uvghip_quant_lfnst_batch : uvghip_quant_batch)(bitdepth, coef, coeff_out, width, height, n, p->qp_scaled,
                                                                                   p->use_trskip, p->slice_is_intra, stream))
       return rc;
-    has_coeffs_kernel<<<(n + 3) / 4, 256, 0, st>>>(coeff_out, width * height, n, has_coeffs);
   }
+  if (!rdoq || p->signhide_enable) has_coeffs_kernel<<<(n + 3) / 4, 256, 0, st>>>(coeff_out, width * height, n, has_coeffs);
   // (4) dequantisation, inverse LFNST, inverse transform, reconstruction (:556-597; without coefficients the inverse of
   //     zeros is zero and rec = pred, the copy of :599-609)
   if (int rc = uvghip_dequant_batch(bitdepth, coeff_out, deq, width, height, n, p->qp_scaled, p->use_trskip, stream)) return rc;
@@ -1023,7 +1142,7 @@ extern "C" size_t uvghip_quant_cbcr_residual_workspace_bytes(const uvghip_qr_par
   if (!p || n <= 0) return 0;
   const bool rdoq = p->rdoq_enable && (p->width > 4 || !p->rdoq_skip);
   return 3 * qr_coef_bytes(p->width, p->height, n) + (((size_t)n + 255) & ~(size_t)255) +
-         (rdoq ? uvghip_rdoq_workspace_bytes(p->width, p->height, n) : 0);
+         (rdoq ? (p->signhide_enable ? uvghip_rdoq_signhide_workspace_bytes : uvghip_rdoq_workspace_bytes)(p->width, p->height, n) : 0);
 }
 
 extern "C" int uvghip_quant_cbcr_residual_batch(int bitdepth, const uvghip_qr_params_t *p, int joint_cb_cr, int jccr_sign,
@@ -1065,14 +1184,19 @@ extern "C" int uvghip_quant_cbcr_residual_batch(int bitdepth, const uvghip_qr_pa
     if (int rc = uvghip_lfnst_batch(0, coef, width, height, lfnst_tus, n, stream)) return rc;
   if (rdoq) {
     if (int rc = uvghip_rdoq_launch_checked(bitdepth, coef, coeff_out, width, height, n, color, p->cu_type, p->cbf_u, p->lfnst_idx, 0,
-                                            p->qp_scaled, p->lambda, &p->ctx, rdoq_ws, uvghip_rdoq_workspace_bytes(width, height, n), has, stream))
+                                            p->qp_scaled, p->lambda, &p->ctx, rdoq_ws,
+                                            (p->signhide_enable ? uvghip_rdoq_signhide_workspace_bytes : uvghip_rdoq_workspace_bytes)(width, height, n),
+                                            has, stream, p->signhide_enable))
+      return rc;
+  } else if (p->signhide_enable) {
+    if (int rc = uvghip_quant_signhide_batch(bitdepth, coef, coeff_out, width, height, n, p->qp_scaled, 0, p->slice_is_intra, p->lfnst_idx, stream))
       return rc;
   } else {
     if (int rc = (p->lfnst_idx ? uvghip_quant_lfnst_batch : uvghip_quant_batch)(bitdepth, coef, coeff_out, width, height, n, p->qp_scaled, 0,
                                                                                   p->slice_is_intra, stream))
       return rc;
-    has_coeffs_kernel<<<(n + 3) / 4, 256, 0, st>>>(coeff_out, width * height, n, has);
   }
+  if (!rdoq || p->signhide_enable) has_coeffs_kernel<<<(n + 3) / 4, 256, 0, st>>>(coeff_out, width * height, n, has);
   // uvg_dequant -> [uvg_inv_lfnst] -> uvg_itransform2d -> both reconstructions (:355-437)
   if (int rc = uvghip_dequant_batch(bitdepth, coeff_out, deq, width, height, n, p->qp_scaled, 0, stream)) return rc;
   if (lfnst_tus)

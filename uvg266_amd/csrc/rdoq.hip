@@ -32,7 +32,8 @@ static_assert(sizeof(uvghip_rdoq_ctx_t) == N_CTX, "uvghip_rdoq_ctx_t layout");
 struct rdoq_params {
   int width, height, l2w, l2h, n;
   int color, block_type, cbf_u, lfnst_idx, mts_idx;
-  int q_bits, q;
+  int q_bits, q, signhide;
+  long long rd_factor;          // uvg_rdoq_sign_hiding's rd_factor (host, rdo.c:724-726)
   double lambda, error_scale;
   uvghip_rdoq_ctx_t ctx;
 };
@@ -94,7 +95,72 @@ __device__ __forceinline__ int ic_rate(const uint32_t (*B)[2], int t, uint32_t a
   return rate;
 }
 
-struct rdoq_decision { int level; int sig_code; double coded_cost, coded_sig; };
+// uvg_get_ic_rate with use_limited_prefix_length = false: what the sign-hiding bookkeeping calls (rdo.c:1674-1681)
+__device__ __noinline__ int ic_rate_sh(const uint32_t (*B)[2], int t, uint32_t abs_level, int ctx, int go_rice, uint32_t reg_bins)
+{
+  int rate = 1 << 15;
+  const int thr = 5;
+  if (reg_bins < 4) {
+    const uint32_t zero = 1u << go_rice;
+    uint32_t symbol = (abs_level == 0 ? zero : abs_level <= zero ? abs_level - 1 : abs_level);
+    if (symbol < ((uint32_t)thr << go_rice)) {
+      rate += (int)(((symbol >> go_rice) + 1 + go_rice) << 15);
+    } else {
+      uint32_t length = (uint32_t)go_rice;
+      symbol = symbol - ((uint32_t)thr << go_rice);
+      while ((int)symbol >= (1 << length)) symbol -= (1u << (length++));
+      rate += (int)((thr + length + 1 - go_rice + length) << 15);
+    }
+    return rate;
+  }
+  const int par = O_PAR + 21 * t + ctx, gt1 = O_GT1 + 21 * t + ctx, gt2 = O_GT2 + 21 * t + ctx;
+  if (abs_level >= 4) {
+    int symbol = (int)abs_level - 4;
+    if (symbol < (thr << go_rice)) {
+      rate += ((symbol >> go_rice) + 1 + go_rice) << 15;
+    } else {
+      int length = go_rice;
+      symbol = symbol - (thr << go_rice);
+      while (symbol >= (1 << length)) symbol -= (1 << (length++));
+      rate += (thr + length + 1 - go_rice + length) << 15;
+    }
+    rate += (int)B[par][(abs_level - 2) & 1];
+    rate += (int)B[gt1][1];
+    rate += (int)B[gt2][1];
+  } else if (abs_level == 1) {
+    rate += (int)B[gt1][0];
+  } else if (abs_level == 2) {
+    rate += (int)B[par][0]; rate += (int)B[gt1][1]; rate += (int)B[gt2][0];
+  } else if (abs_level == 3) {
+    rate += (int)B[par][1]; rate += (int)B[gt1][1]; rate += (int)B[gt2][0];
+  } else {
+    rate = 0;
+  }
+  return rate;
+}
+
+// struct sh_rates_t of one position (rdo.c:214-223, filled at :1660-1687): the caller's workspace holds them as
+// [block][inc | dec | sig_coeff_inc | quant_delta][position]
+__device__ __forceinline__ void sh_record(int32_t *gSh, int wh, int blkpos, const uint32_t (*B)[2], int t, bool is_last, int level,
+                                          int level_double, int q_bits, int ctx_sig, int ctx_set, int go_rice, uint32_t reg_bins)
+{
+  int inc, dec = 0;
+  if (level > 0) {
+    const int now = ic_rate_sh(B, t, (uint32_t)level, ctx_set, go_rice, reg_bins);
+    inc = ic_rate_sh(B, t, (uint32_t)level + 1, ctx_set, go_rice, reg_bins) - now;
+    dec = ic_rate_sh(B, t, (uint32_t)level - 1, ctx_set, go_rice, reg_bins) - now;
+  } else if (reg_bins < 4) {
+    inc = ic_rate_sh(B, t, 1, ctx_set, go_rice, reg_bins) - ic_rate_sh(B, t, 0, ctx_set, go_rice, reg_bins);
+  } else {
+    inc = (int)B[O_GT1 + 21 * t + ctx_set][0];
+  }
+  gSh[blkpos] = inc;
+  gSh[wh + blkpos] = dec;
+  gSh[2 * wh + blkpos] = is_last ? 0 : (reg_bins < 4 ? 0 : (int)B[O_SIG + 12 * t + ctx_sig][1] - (int)B[O_SIG + 12 * t + ctx_sig][0]);
+  gSh[3 * wh + blkpos] = (level_double - level * (1 << q_bits)) >> (q_bits - 8);
+}
+
+struct rdoq_decision { int level; int sig_code; double coded_cost, coded_sig; int ctx_sig, ctx_set, go_rice; };
 
 // uvg_get_coded_level (rdo.c:597-640) + the context derivation in front of it (:1630-1651) for one position.
 // nb / has: levels of the neighbours right, right+1, below-right, below, below+1 (0 where outside the block).
@@ -129,6 +195,7 @@ __device__ __forceinline__ rdoq_decision rdoq_decide(const rdoq_params &P, const
   }
   rdoq_decision d;
   d.level = 0; d.sig_code = 0; d.coded_sig = 0;
+  d.ctx_sig = ctx_sig; d.ctx_set = ctx_set; d.go_rice = go_rice;
   double cur_cost_sig = 0;
   bool done = false;
   if (!is_last && max_abs_level < 3) {
@@ -185,9 +252,10 @@ __device__ __forceinline__ double quad_bcast(double v)
 // LDS per block: level int16[wh] (holds the input coefficient until the position's group is staged) + meta byte[wh]
 // (bits 0-1: Rice parameter after this position, bits 2-6: code of the significance-cost table entry); block strides are
 // odd in words so that the same position of the 16 blocks of a wave falls into 16 different banks.
+// SIGNHIDE: sign-data hiding compiled in (its bookkeeping costs registers the plain kernel needs for occupancy).
 // SHAPE: log2 of the side of a square block (2..5) -- dimensions and plane type (CHROMA) become compile-time constants and
 // every shape is its own kernel symbol in a profile -- or 0 for the generic kernel (rectangles; everything from the parameters).
-template <int TUS, int SHAPE, int CHROMA>
+template <int TUS, int SHAPE, int CHROMA, int SIGNHIDE>
 __global__ void __launch_bounds__(64)
 rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__restrict__ q_coef, double *__restrict__ ws,
             uint32_t *__restrict__ abs_sum_out, uint8_t *__restrict__ has_coeffs)
@@ -257,6 +325,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   const int gq = live ? grp : 0;                                       // idle lanes alias block 0 for address arithmetic only
   const int tu = tu0 + gq;
   double *gCost = ws + (size_t)tu * wh;                                // cost_coeff[] of this block (re-read by the last-position search)
+  int32_t *gSh = reinterpret_cast<int32_t *>(ws + (size_t)n * wh) + (size_t)tu * 4 * wh;   // sign hiding: the block's sh_rates
   const int16_t *gCoef = coef + (size_t)tu * wh;
   int16_t *sLev = reinterpret_cast<int16_t *>(sDyn + gq * per_tu);
   uint8_t *sMeta = reinterpret_cast<uint8_t *>(sLev + wh);
@@ -363,7 +432,11 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       const int g = sScanCg[cgs];
       if (last_scanpos < 0 || cg_skipped(g) || cgs >= cg_num)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sLev[blk_in(g, in_cg(j + 4 * r))] = 0;
+        for (int r = 0; r < 4; ++r) {
+          const int bp = blk_in(g, in_cg(j + 4 * r));
+          sLev[bp] = 0;
+          if (SIGNHIDE) { gSh[bp] = 0; gSh[wh + bp] = 0; gSh[2 * wh + bp] = 0; gSh[3 * wh + bp] = 0; }   // FILL(sh_rates, 0), :1493
+        }
       else if (max_group < 15)
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (j + 4 * r > max_group) sLev[blk_in(g, in_cg(j + 4 * r))] = 0;
@@ -495,6 +568,10 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
             if (cur < cc) { level = a; cc = cur; cs = cur_cost_sig; sig_code = is_last ? 0 : 2 + 2 * ctx_sig; }
           }
         }
+        if (SIGNHIDE) {
+          const int go_rice = (is_last || s4 == 15) ? 0 : (sMeta[blk_in(g, in_cg(s4 + 1))] & 3);
+          sh_record(gSh, wh, blkpos, B, t, is_last, level, I[3 * s4 + 2], q_bits, ctx_sig, ctx_set, go_rice, 4);
+        }
         sLev[blkpos] = (int16_t)level;
         D[3 * s4] = cc; D[3 * s4 + 1] = cs;
         I[3 * s4] = level;
@@ -517,6 +594,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
           int nb[5]; bool has[5];
           neighbours(blkpos, pos_x, pos_y, nb, has);
           const rdoq_decision d = rdoq_decide(P, B, t, scanpos == last_scanpos, ld, mx, D[3 * s4 + 2], nb, has, pos_x, pos_y, 0, reg_bins);
+          if (SIGNHIDE) sh_record(gSh, wh, blkpos, B, t, scanpos == last_scanpos, d.level, ld, q_bits, d.ctx_sig, d.ctx_set, d.go_rice, reg_bins);
           sLev[blkpos] = (int16_t)d.level;
           D[3 * s4] = d.coded_cost; D[3 * s4 + 1] = d.coded_sig;
           I[3 * s4] = d.level;
@@ -541,6 +619,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
           neighbours(b2, px, py, nb, has);
           const bool last2 = sc2 == last_scanpos;
           d2 = rdoq_decide(P, B, t, last2, ld2, mx2, D[3 * s2 + 2], nb, has, px, py, go_rice_state, reg_bins);
+          if (SIGNHIDE && j == 0) sh_record(gSh, wh, b2, B, t, last2, d2.level, ld2, q_bits, d2.ctx_sig, d2.ctx_set, d2.go_rice, reg_bins);
           // context set update (rdo.c:1691-1699), tracked here because the budget is nearly spent
           if ((sc2 % 16 == 0) && sc2 > 0) go_rice_state = 0;
           else if (reg_bins >= 4) {
@@ -764,6 +843,57 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
     if (abs_sum_out) abs_sum_out[tu] = my_abs;
     if (has_coeffs) has_coeffs[tu] = my_abs ? 1 : 0;
   }
+  // ---- sign-data hiding (uvg_rdoq_sign_hiding, rdo.c:700-845): per coefficient group, groups do not interact: the four lanes
+  //      of a block take every fourth group ----
+  if (SIGNHIDE) {
+    __threadfence_block();                                             // the sh_rates records of the other lanes
+    WAVE_SYNC();
+    if (live && my_abs >= 2) {
+      const long long rd_factor = P.rd_factor;
+      const int last_cg = (best_last_idx_p1 - 1) >> 4;
+      for (int cgk = j; cgk <= last_cg; cgk += 4) {
+        const int g = sScanCg[cgk];
+        int last_nz = -1, first_nz = 16;
+        for (int k = 15; k >= 0; --k) if (sLev[blk_in(g, in_cg(k))]) { last_nz = k; break; }
+        for (int k = 0; k <= last_nz; ++k) if (sLev[blk_in(g, in_cg(k))]) { first_nz = k; break; }
+        if (last_nz - first_nz < 4) continue;                            // SBH_THRESHOLD
+        const int signbit = sLev[blk_in(g, in_cg(first_nz))] <= 0;
+        unsigned sum = 0;
+        for (int k = first_nz; k <= last_nz; ++k) sum += (unsigned)(int)sLev[blk_in(g, in_cg(k))];
+        if (signbit == (int)(sum & 1)) continue;
+        long long best_cost = 0x7fffffffffffffffll;
+        int best_pos = 0, best_change = 0;
+        for (int k = (cgk == last_cg ? last_nz : 15); k >= 0; --k) {
+          const int pos = blk_in(g, in_cg(k));
+          const long long qbits = rd_factor * (long long)gSh[3 * wh + pos];
+          const int a = abs((int)sLev[pos]);
+          long long cost;
+          int change;
+          if (a != 0) {
+            long long inc_bits = gSh[pos], dec_bits = gSh[wh + pos];
+            if (a == 1) dec_bits -= gSh[2 * wh + pos];
+            if (cgk == last_cg && last_nz == k && a == 1) dec_bits -= 4 * 32768;
+            inc_bits = -qbits + inc_bits;
+            dec_bits = qbits + dec_bits;
+            if (inc_bits < dec_bits) { change = 1; cost = inc_bits; }
+            else {
+              change = -1; cost = dec_bits;
+              if (k == first_nz && a == 1) cost = 0x7fffffffffffffffll;
+            }
+          } else {
+            const int bits = 32768 + gSh[pos] + gSh[2 * wh + pos];
+            cost = -(qbits < 0 ? -qbits : qbits) + bits;
+            change = 1;
+            if (k < first_nz && ((gCoef[pos] >= 0) ? 0 : 1) != signbit) cost = 0x7fffffffffffffffll;
+          }
+          if (cost < best_cost) { best_cost = cost; best_pos = pos; best_change = change; }
+        }
+        const int qv = sLev[best_pos];
+        if (qv == 32767 || qv == -32768) best_change = -1;
+        sLev[best_pos] = (int16_t)(gCoef[best_pos] >= 0 ? qv + best_change : qv - best_change);
+      }
+    }
+  }
   __syncthreads();
   if ((reinterpret_cast<uintptr_t>(q_coef) & 3) == 0) {
     uint32_t *dst = reinterpret_cast<uint32_t *>(q_coef + (size_t)tu0 * wh);
@@ -789,10 +919,39 @@ extern "C" size_t uvghip_rdoq_workspace_bytes(int width, int height, int n)
   return (size_t)width * height * (size_t)n * sizeof(double);      // cost_coeff[] of every block
 }
 
+extern "C" size_t uvghip_rdoq_signhide_workspace_bytes(int width, int height, int n)
+{
+  if (width <= 0 || height <= 0 || n <= 0) return 0;
+  return (size_t)width * height * (size_t)n * (sizeof(double) + 4 * sizeof(int32_t));   // + sh_rates of every block
+}
+
+static int rdoq_launch(int signhide, int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n, int color,
+                       int block_type, int cbf_u, int lfnst_idx, int mts_idx, int qp_scaled, double lambda,
+                       const uvghip_rdoq_ctx_t *ctx_host, void *workspace, size_t workspace_bytes, uint32_t *abs_sum_out,
+                       uint8_t *has_coeffs, void *stream);
+
 extern "C" int uvghip_rdoq_batch(int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n, int color,
                                  int block_type, int cbf_u, int lfnst_idx, int mts_idx, int qp_scaled, double lambda,
                                  const uvghip_rdoq_ctx_t *ctx_host, void *workspace, size_t workspace_bytes,
                                  uint32_t *abs_sum_out, uint8_t *has_coeffs, void *stream)
+{
+  return rdoq_launch(0, bitdepth, coef, q_coef, width, height, n, color, block_type, cbf_u, lfnst_idx, mts_idx, qp_scaled, lambda, ctx_host,
+                     workspace, workspace_bytes, abs_sum_out, has_coeffs, stream);
+}
+
+extern "C" int uvghip_rdoq_signhide_batch(int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n, int color,
+                                          int block_type, int cbf_u, int lfnst_idx, int mts_idx, int qp_scaled, double lambda,
+                                          const uvghip_rdoq_ctx_t *ctx_host, void *workspace, size_t workspace_bytes,
+                                          uint32_t *abs_sum_out, uint8_t *has_coeffs, void *stream)
+{
+  return rdoq_launch(1, bitdepth, coef, q_coef, width, height, n, color, block_type, cbf_u, lfnst_idx, mts_idx, qp_scaled, lambda, ctx_host,
+                     workspace, workspace_bytes, abs_sum_out, has_coeffs, stream);
+}
+
+static int rdoq_launch(int signhide, int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n, int color,
+                       int block_type, int cbf_u, int lfnst_idx, int mts_idx, int qp_scaled, double lambda,
+                       const uvghip_rdoq_ctx_t *ctx_host, void *workspace, size_t workspace_bytes, uint32_t *abs_sum_out,
+                       uint8_t *has_coeffs, void *stream)
 {
   UVGHIP_REQUIRE_READY();
   auto pow2 = [](int v) { return v == 4 || v == 8 || v == 16 || v == 32; };
@@ -800,7 +959,9 @@ extern "C" int uvghip_rdoq_batch(int bitdepth, const int16_t *coef, int16_t *q_c
       qp_scaled < 0 || lfnst_idx < 0 || lfnst_idx > 2 || mts_idx < 0 || !(lambda >= 0))
     return uvghip_set_error(hipErrorInvalidValue, __func__);
   if (n <= 0) return 0;
-  if (!workspace || workspace_bytes < uvghip_rdoq_workspace_bytes(width, height, n)) return uvghip_set_error(hipErrorInvalidValue, "uvghip_rdoq_batch: workspace");
+  if (!workspace || workspace_bytes < (signhide ? uvghip_rdoq_signhide_workspace_bytes(width, height, n) : uvghip_rdoq_workspace_bytes(width, height, n)))
+    return uvghip_set_error(hipErrorInvalidValue, "uvghip_rdoq_batch: workspace");
+  if (signhide && !(lambda > 0)) return uvghip_set_error(hipErrorInvalidValue, "uvghip_rdoq_signhide_batch: lambda");
   if (((uintptr_t)coef | (uintptr_t)q_coef) & 1) return uvghip_set_error(hipErrorInvalidValue, __func__);
   rdoq_params P;
   P.width = width; P.height = height; P.n = n;
@@ -819,6 +980,15 @@ extern "C" int uvghip_rdoq_batch(int bitdepth, const int16_t *coef, int16_t *q_c
   P.error_scale = scale / P.q / P.q;
   P.lambda = lambda;
   P.ctx = *ctx_host;
+  P.signhide = signhide;
+  P.rd_factor = 0;
+  if (signhide) {
+    // rdo.c:721-726.  The reference forms inv_quant^2 * 2^(2 (qp / 6)) in int (it wraps for qp_scaled >= 54) and divides in double.
+    static const int iqs[2][6] = {{40, 45, 51, 57, 64, 72}, {57, 64, 72, 80, 90, 102}};
+    const int inv_quant = iqs[sqrt2][qp_scaled % 6];
+    const int32_t prod = (int32_t)((uint32_t)(inv_quant * inv_quant) * (1u << (2 * (qp_scaled / 6))));
+    P.rd_factor = (long long)(prod / lambda / 16 / (1 << (2 * (bitdepth - 8))) + 0.5);
+  }
   const int wh = width * height;
   // blocks per wave (four lanes each): 16.  LDS per block: levels (int16) + meta (byte) per position, odd word stride
   const int tus = 16;
@@ -831,7 +1001,11 @@ extern "C" int uvghip_rdoq_batch(int bitdepth, const int16_t *coef, int16_t *q_c
   // matters beyond 2^20 batches
   const int batches = (n + tus - 1) / tus;
   const int grid = batches < (1 << 20) ? batches : (1 << 20);
-#define RDOQ_LAUNCH(SH, CH) rdoq_kernel<16, SH, CH><<<grid, 64, lds, st>>>(P, coef, q_coef, w, abs_sum_out, has_coeffs)
+#define RDOQ_LAUNCH(SH, CH)                                                                                              \
+  do {                                                                                                                   \
+    if (signhide) rdoq_kernel<16, SH, CH, 1><<<grid, 64, lds, st>>>(P, coef, q_coef, w, abs_sum_out, has_coeffs);        \
+    else rdoq_kernel<16, SH, CH, 0><<<grid, 64, lds, st>>>(P, coef, q_coef, w, abs_sum_out, has_coeffs);                 \
+  } while (0)
   const int shape = width == height ? P.l2w : 0;
   const bool ch = color != 0;
   switch (shape) {

@@ -162,7 +162,7 @@ static void uvg_inter_recon_bipred_hip(lcu_t *const lcu, const yuv_t *const px_L
  * result that differs from the generic strategy's. */
 int uvg_hip_state_config_supported(const uvg_config *const cfg)
 {
-  return !cfg->dep_quant && !cfg->signhide_enable && cfg->scaling_list == UVG_SCALING_LIST_OFF && !cfg->lmcs_enable &&
+  return !cfg->dep_quant && cfg->scaling_list == UVG_SCALING_LIST_OFF && !cfg->lmcs_enable &&
          !(cfg->rdoq_enable && cfg->trskip_enable);
 }
 

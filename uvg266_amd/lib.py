@@ -35,7 +35,7 @@ class QrParams(ctypes.Structure):
     """uvghip_qr_params_t."""
     _fields_ = [(n, ctypes.c_int32) for n in ("width", "height", "color", "type_hor", "type_ver", "skip_width", "skip_height", "qp_scaled",
                                                 "slice_is_intra", "cu_type", "use_trskip", "rdoq_enable", "rdoq_skip", "dep_quant", "cbf_u",
-                                                "mts_idx", "lfnst_idx", "reserved")] + [("lambda_", ctypes.c_double), ("ctx", ctypes.c_uint8 * 244)]
+                                                "mts_idx", "lfnst_idx", "signhide_enable")] + [("lambda_", ctypes.c_double), ("ctx", ctypes.c_uint8 * 244)]
 
 
 class CabacModels(ctypes.Structure):
@@ -80,11 +80,14 @@ SIGNATURES = {
     "uvg_strategy_register_quant_hip": (c_int, [c_vp, ctypes.c_uint8]),
     "uvghip_quant_batch": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "uvghip_quant_lfnst_batch": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "uvghip_quant_signhide_batch": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "uvghip_dequant_batch": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "uvghip_coeff_abs_sum_batch": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "uvghip_fast_coeff_cost_batch": (c_int, [c_vp, c_int, c_int, c_int, ctypes.c_uint64, c_vp, c_vp]),
     "uvghip_rdoq_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "uvghip_rdoq_batch": (c_int, [c_int, c_vp, c_vp] + [c_int] * 9 + [ctypes.c_double, c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp, c_vp]),
+    "uvghip_rdoq_signhide_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
+    "uvghip_rdoq_signhide_batch": (c_int, [c_int, c_vp, c_vp] + [c_int] * 9 + [ctypes.c_double, c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp, c_vp]),
     "uvghip_tu_forward_batch": (c_int, [c_int] * 8 + [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_tu_inverse_batch": (c_int, [c_int] * 8 + [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp]),
     "uvghip_quantize_residual_workspace_bytes": (ctypes.c_size_t, [c_vp, c_int]),
