@@ -456,7 +456,7 @@ def main():
     ap.add_argument("--serial", action="store_true", help="one stream: no overlap between pictures")
     ap.add_argument("--no-graphs", action="store_true", help="issue every launch eagerly instead of replaying hipGraph segments")
     ap.add_argument("--resident", type=int, default=0, help="pictures resident per workload (0 = 4 for 1080p8, 2 for 2160p10alf)")
-    ap.add_argument("--group", type=int, default=4, help="pictures per group: plane kernels run per picture, RDOQ once per block shape over the group")
+    ap.add_argument("--group", type=int, default=10, help="pictures per group: plane kernels run per picture, RDOQ once per block shape over the group")
     ap.add_argument("--streams", type=int, default=4, help="pictures in flight: consecutive steps go to consecutive streams")
     ap.add_argument("--profile-steps", type=int, default=4, help="untimed, fully instrumented steps for the per-kernel table")
     ap.add_argument("--shard", choices=("rows", "frames"), default="frames",

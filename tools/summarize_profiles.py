@@ -39,7 +39,7 @@ def bench_name(kernel, grid):
     k = short(kernel)
     if k.startswith("intra_search_kernel"):
         return SEARCH_GRID.get(grid)
-    m = re.match(r"rdoq_kernel<16, (\d), (\d)>", k)
+    m = re.match(r"rdoq_kernel<16, (\d), (\d)(?:, \d)?>", k)
     if m:
         return RDOQ.get((m.group(1), m.group(2)))
     return None
