@@ -219,6 +219,14 @@ __device__ __forceinline__ rdoq_decision rdoq_decide(const rdoq_params &P, const
   return d;
 }
 
+// LDS bytes of one block: level int16[wh] (holds the input coefficient until the position's group is staged) + the Rice
+// parameters, four per byte; block strides are odd in words so that the same position of the 16 blocks of a wave falls into
+// 16 different banks
+__host__ __device__ constexpr size_t rdoq_lds_per_block(int wh)
+{
+  return ((((size_t)wh * 2 + wh / 4) >> 2) & 1) ? (size_t)wh * 2 + wh / 4 : (size_t)wh * 2 + wh / 4 + 4;
+}
+
 // value of lane K of the caller's quad (DPP quad_perm broadcast; all four lanes of a block's quad are active together)
 template <int K>
 __device__ __forceinline__ double quad_bcast(double v)
@@ -249,14 +257,18 @@ __device__ __forceinline__ double quad_bcast(double v)
 //            of a full uvg_get_coded_level per position, which is what the wave's time goes into (SQ counters: the kernel
 //            issues instructions > 50 % of its lifetime at one wave per SIMD);
 //   replay   the 16 costs in scan order (bit-exact double sums), group decision.
-// LDS per block: level int16[wh] (holds the input coefficient until the position's group is staged) + meta byte[wh]
-// (bits 0-1: Rice parameter after this position, bits 2-6: code of the significance-cost table entry); block strides are
-// odd in words so that the same position of the 16 blocks of a wave falls into 16 different banks.
+// LDS per block (rdoq_lds_per_block): level int16[wh] (holds the input coefficient until the position's group is staged) +
+// the Rice parameter after each position, two bits each.  What the walk only writes and the last-position search reads back
+// once -- cost_coeff[], the code of each position's cost_sig[] entry, cost_coeffgroup_sig[] -- lives in the caller's
+// workspace, written and re-read by the same lane: the number of resident workgroups is bound by their LDS (the waves wait
+// on each other's latencies, not on the VALU), 32x32 blocks went from two to three workgroups per CU with it.
 // SIGNHIDE: sign-data hiding compiled in (its bookkeeping costs registers the plain kernel needs for occupancy).
 // SHAPE: log2 of the side of a square block (2..5) -- dimensions and plane type (CHROMA) become compile-time constants and
 // every shape is its own kernel symbol in a profile -- or 0 for the generic kernel (rectangles; everything from the parameters).
 template <int TUS, int SHAPE, int CHROMA, int SIGNHIDE>
-__global__ void __launch_bounds__(64)
+// (4x4 blocks: three waves per SIMD asked for -- 168 registers, no spills -- because there the registers, not the LDS, bound
+// the number of resident workgroups; the larger shapes are LDS-bound and spill when squeezed)
+__global__ void __launch_bounds__(64, (SHAPE == 2 && !SIGNHIDE) ? 3 : 1)
 rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__restrict__ q_coef, double *__restrict__ ws,
             uint32_t *__restrict__ abs_sum_out, uint8_t *__restrict__ has_coeffs)
 {
@@ -275,13 +287,11 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   // I[3*s4 + {0: rate half of candidate 1 -> level, 1: candidate 2, 2: level_double}]
   __shared__ double sStageD[TUS][49];
   __shared__ int sStageI[TUS][49];
-  constexpr int NCG = SHAPE ? (1 << (2 * SHAPE - 4)) : 64;             // coefficient groups per block
-  __shared__ double sCgCostAll[TUS][NCG + 1];                          // (+1: odd stride in 8-byte units, see sStageD)
   const int tid = threadIdx.x, grp = tid >> 2, j = tid & 3;
   const int l2w = SHAPE ? SHAPE : P.l2w, l2h_ = SHAPE ? SHAPE : P.l2h;
   const int width = 1 << l2w, height = 1 << l2h_, wh = width * height;
   const int n = P.n;
-  const size_t per_tu = (size_t)wh * 3 + 4;
+  const size_t per_tu = rdoq_lds_per_block(wh);
   const int t = SHAPE ? CHROMA : (P.color ? 1 : 0);
   const int mts = P.mts_idx;
 
@@ -324,14 +334,20 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   const bool live = grp < here;
   const int gq = live ? grp : 0;                                       // idle lanes alias block 0 for address arithmetic only
   const int tu = tu0 + gq;
+  // workspace: cost_coeff[n][wh] | cost_coeffgroup_sig[n][wh / 16] | (sign hiding: sh_rates [n][4][wh]) | cost_sig code [n][wh]
   double *gCost = ws + (size_t)tu * wh;                                // cost_coeff[] of this block (re-read by the last-position search)
-  int32_t *gSh = reinterpret_cast<int32_t *>(ws + (size_t)n * wh) + (size_t)tu * 4 * wh;   // sign hiding: the block's sh_rates
+  double *gCgCost = ws + (size_t)n * wh + (size_t)tu * (wh >> 4);      // cost_coeffgroup_sig[]: written and re-read by lane 0 of the block
+  int32_t *wsSh = reinterpret_cast<int32_t *>(ws + (size_t)n * wh + (size_t)n * (wh >> 4));
+  int32_t *gSh = wsSh + (size_t)tu * 4 * wh;                           // sign hiding: the block's sh_rates
+  // code of the significance-cost table entry of every walked position (cost_sig[] = sig_cost_of(code)); a position is
+  // written and re-read by the same lane (the j + 4r mapping)
+  uint8_t *gSig = reinterpret_cast<uint8_t *>(SIGNHIDE ? wsSh + (size_t)n * 4 * wh : wsSh) + (size_t)tu * wh;
   const int16_t *gCoef = coef + (size_t)tu * wh;
   int16_t *sLev = reinterpret_cast<int16_t *>(sDyn + gq * per_tu);
-  uint8_t *sMeta = reinterpret_cast<uint8_t *>(sLev + wh);
+  uint8_t *sRice = reinterpret_cast<uint8_t *>(sLev + wh);            // Rice parameter after each position, four positions per byte
+  auto rice_at = [&](int pos) { return (int)(sRice[pos >> 2] >> ((pos & 3) * 2)) & 3; };
   double *D = sStageD[gq];
   int *I = sStageI[gq];
-  double *sCgCost = sCgCostAll[gq];
   // ---- stage the coefficients into the level array (coalesced: the blocks of a workgroup are contiguous) ----
   const int l2wh = l2w + l2h_;
   {
@@ -354,20 +370,26 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   __syncthreads();
   // the Rice parameter after each position: templateAbsSum(coef, 4, ...) over the input block (rdo.c:846-871, 1697)
   if (live)
-    for (int pos = j; pos < wh; pos += 4) {
-      const uint32_t pos_y = (uint32_t)pos >> l2w, pos_x = (uint32_t)pos - (pos_y << l2w);
-      const int16_t *c0p = sLev + pos;
-      int16_t sum = 0;                                                 // coeff_t accumulator: wraps like the reference's
-      if (pos_x < (uint32_t)width - 1) {
-        sum = (int16_t)(sum + ((mts && pos_x + 1 >= 16) ? 0 : abs((int)c0p[1])));
-        if (pos_x < (uint32_t)width - 2) sum = (int16_t)(sum + ((mts && pos_x + 2 >= 16) ? 0 : abs((int)c0p[2])));
-        if (pos_y < (uint32_t)height - 1) sum = (int16_t)(sum + ((mts && (pos_y + 1 >= 16 || pos_x + 1 >= 16)) ? 0 : abs((int)c0p[width + 1])));
+    for (int q4 = j; q4 < (wh >> 2); q4 += 4) {                        // a lane owns whole bytes of the packed array
+      unsigned packed = 0;
+#pragma unroll 1
+      for (int k = 0; k < 4; ++k) {
+        const int pos = 4 * q4 + k;
+        const uint32_t pos_y = (uint32_t)pos >> l2w, pos_x = (uint32_t)pos - (pos_y << l2w);
+        const int16_t *c0p = sLev + pos;
+        int16_t sum = 0;                                               // coeff_t accumulator: wraps like the reference's
+        if (pos_x < (uint32_t)width - 1) {
+          sum = (int16_t)(sum + ((mts && pos_x + 1 >= 16) ? 0 : abs((int)c0p[1])));
+          if (pos_x < (uint32_t)width - 2) sum = (int16_t)(sum + ((mts && pos_x + 2 >= 16) ? 0 : abs((int)c0p[2])));
+          if (pos_y < (uint32_t)height - 1) sum = (int16_t)(sum + ((mts && (pos_y + 1 >= 16 || pos_x + 1 >= 16)) ? 0 : abs((int)c0p[width + 1])));
+        }
+        if (pos_y < (uint32_t)height - 1) {
+          sum = (int16_t)(sum + ((mts && pos_y + 1 >= 16) ? 0 : abs((int)c0p[width])));
+          if (pos_y < (uint32_t)height - 2) sum = (int16_t)(sum + ((mts && (pos_y + 2 >= 16)) ? 0 : abs((int)c0p[2 * width])));
+        }
+        packed |= (unsigned)go_rice_par(clampi((int)sum - 20, 0, 31)) << (2 * k);
       }
-      if (pos_y < (uint32_t)height - 1) {
-        sum = (int16_t)(sum + ((mts && pos_y + 1 >= 16) ? 0 : abs((int)c0p[width])));
-        if (pos_y < (uint32_t)height - 2) sum = (int16_t)(sum + ((mts && (pos_y + 2 >= 16)) ? 0 : abs((int)c0p[2 * width])));
-      }
-      sMeta[pos] = (uint8_t)go_rice_par(clampi((int)sum - 20, 0, 31));
+      sRice[q4] = (uint8_t)packed;
     }
   __syncthreads();
 
@@ -478,7 +500,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
           if (mx > 0) {
             // Rice parameter left by the previously visited position (scanpos + 1): reset after every 16th (:1692), else the
             // context-free value of that position; the last significant position starts with 0
-            const int go_rice = (scanpos == last_scanpos || s4 == 15) ? 0 : (sMeta[blk_in(g, in_cg(s4 + 1))] & 3);
+            const int go_rice = (scanpos == last_scanpos || s4 == 15) ? 0 : rice_at(blk_in(g, in_cg(s4 + 1)));
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
               const int a = mx - c;
@@ -569,13 +591,13 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
           }
         }
         if (SIGNHIDE) {
-          const int go_rice = (is_last || s4 == 15) ? 0 : (sMeta[blk_in(g, in_cg(s4 + 1))] & 3);
+          const int go_rice = (is_last || s4 == 15) ? 0 : rice_at(blk_in(g, in_cg(s4 + 1)));
           sh_record(gSh, wh, blkpos, B, t, is_last, level, I[3 * s4 + 2], q_bits, ctx_sig, ctx_set, go_rice, 4);
         }
         sLev[blkpos] = (int16_t)level;
         D[3 * s4] = cc; D[3 * s4 + 1] = cs;
         I[3 * s4] = level;
-        sMeta[blkpos] = (uint8_t)((sMeta[blkpos] & 3) | (sig_code << 2));
+        I[3 * s4 + 1] = sig_code;                                        // (the candidates' rate halves have been consumed)
       }
       WAVE_SYNC();
     }
@@ -598,7 +620,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
           sLev[blkpos] = (int16_t)d.level;
           D[3 * s4] = d.coded_cost; D[3 * s4 + 1] = d.coded_sig;
           I[3 * s4] = d.level;
-          sMeta[blkpos] = (uint8_t)((sMeta[blkpos] & 3) | (d.sig_code << 2));
+          I[3 * s4 + 1] = d.sig_code;
         }
         WAVE_SYNC();
       }
@@ -624,7 +646,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
           if ((sc2 % 16 == 0) && sc2 > 0) go_rice_state = 0;
           else if (reg_bins >= 4) {
             reg_bins -= (uint32_t)((d2.level < 2 ? d2.level : 3) + (last2 ? 0 : 1));
-            go_rice_state = sMeta[b2] & 3;
+            go_rice_state = rice_at(b2);
           }
         }
         WAVE_SYNC();
@@ -632,17 +654,21 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
           sLev[b2] = (int16_t)d2.level;
           D[3 * s2] = d2.coded_cost; D[3 * s2 + 1] = d2.coded_sig;
           I[3 * s2] = d2.level;
-          sMeta[b2] = (uint8_t)((sMeta[b2] & 3) | (d2.sig_code << 2));
+          I[3 * s2 + 1] = d2.sig_code;
         }
         WAVE_SYNC();
       }
     }
-    // cost_coeff[] of the group's walked positions
+    // cost_coeff[] and the cost_sig[] code of the group's walked positions
     if (in_walk)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int s4 = j + 4 * r;
-        if (s4 <= max_group && cgs * 16 + s4 <= last_scanpos) gCost[blk_in(g, in_cg(s4))] = D[3 * s4];
+        if (s4 <= max_group && cgs * 16 + s4 <= last_scanpos) {
+          const int bp = blk_in(g, in_cg(s4));
+          gCost[bp] = D[3 * s4];
+          gSig[bp] = (uint8_t)I[3 * s4 + 1];
+        }
       }
     // -- replay the group's costs in scan order (bit-exact double sums).  The five running sums are independent chains:
     //    lane 0 of the block carries base_cost (+ cost_coeff), lane 1 block_uncoded_cost (+ cost_coeff0), lane 2 the group's
@@ -669,13 +695,14 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       acc_a = j == 0 ? base_cost : j == 1 ? block_uncoded_cost : 0.0;
       const double *Dp = D + o1, *Dq = D + o2;
 #pragma unroll
-      for (int half = 1; half >= 0; --half) {                            // eight positions' operands in flight at a time
-        double pv[8], qv[8];
+      for (int part = 1; part >= 0; --part) {                            // eight positions' operands in flight at a time
+        constexpr int PW = 8;
+        double pv[PW], qv[PW];
 #pragma unroll
-        for (int u = 7; u >= 0; --u) { pv[u] = Dp[3 * (8 * half + u)]; qv[u] = Dq[3 * (8 * half + u)]; }   // (past max_group: stale, unused)
+        for (int u = PW - 1; u >= 0; --u) { pv[u] = Dp[3 * (PW * part + u)]; qv[u] = Dq[3 * (PW * part + u)]; }   // (past max_group: stale, unused)
 #pragma unroll
-        for (int u = 7; u >= 0; --u) {
-          const int s2 = 8 * half + u;
+        for (int u = PW - 1; u >= 0; --u) {
+          const int s2 = PW * part + u;
           if (s2 > max_group) continue;
           const bool nz = (m >> s2) & 1;
           const double dv = pv[u] - qv[u];
@@ -724,16 +751,16 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       } else {
         sig_cg |= 1ull << g;
       }
-      if (j == 0) sCgCost[cgs] = cg_cost;                                // cost_coeffgroup_sig[cgs]
+      if (j == 0) gCgCost[cgs] = cg_cost;                                // cost_coeffgroup_sig[cgs]
       if (zero_it)                                                       // reset the group (:1752-1762): cost_coeff = cost_coeff0, cost_sig = 0
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int s4 = j + 4 * r;
           const int blkpos = blk_in(g, in_cg(s4));
-          if (s4 <= max_group && sLev[blkpos]) { sLev[blkpos] = 0; gCost[blkpos] = D[3 * s4 + 2]; sMeta[blkpos] &= 3; }
+          if (s4 <= max_group && sLev[blkpos]) { sLev[blkpos] = 0; gCost[blkpos] = D[3 * s4 + 2]; gSig[blkpos] = 0; }
         }
     } else if (has_last && j == 0) {
-      sCgCost[cgs] = 0;                                                  // groups skipped by the MTS zero-out keep a zero flag cost
+      gCgCost[cgs] = 0;                                                  // groups skipped by the MTS zero-out keep a zero flag cost
     }
     WAVE_SYNC();
   }
@@ -754,21 +781,22 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
     // Per group the four lanes fetch what the walk over its positions needs -- cost_coeff (workspace), cost_coeff0 (from the
     // input coefficient), cost_sig (from the code kept in the meta byte) and the bits of the last-position syntax -- one
     // group ahead of the sequential pass, which is then a handful of double operations per position.
-    double pf_cost[4]; int pf_coef[4];
+    double pf_cost[4], pf_cg = 0.0; int pf_coef[4], pf_sig[4];
     auto prefetch = [&](int cgs) {
       const int g = sScanCg[cgs];
+      if (j == 0) pf_cg = gCgCost[cgs];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int s4 = j + 4 * r;
         const int b2 = blk_in(g, in_cg(s4 <= max_group ? s4 : 0));
-        pf_cost[r] = gCost[b2]; pf_coef[r] = (int)gCoef[b2];
+        pf_cost[r] = gCost[b2]; pf_coef[r] = (int)gCoef[b2]; pf_sig[r] = (int)gSig[b2];
       }
     };
     prefetch(cg_last_scanpos);
 #pragma unroll 1
     for (int cgs = cg_last_scanpos; cgs >= 0 && !found_last; cgs--) {
       const int g = sScanCg[cgs];
-      base_cost -= sCgCost[cgs];
+      base_cost -= quad_bcast<0>(pf_cg);
       const bool coded = (sig_cg >> g) & 1;
       unsigned mnz = 0, mgt1 = 0;
       if (coded)
@@ -778,7 +806,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
           if (s4 > max_group || cgs * 16 + s4 > last_scanpos) continue;
           const int b2 = blk_in(g, in_cg(s4));
           const int lv = sLev[b2];
-          D[3 * s4 + 1] = sig_cost_of(sMeta[b2] >> 2);
+          D[3 * s4 + 1] = sig_cost_of(pf_sig[r]);
           if (lv) {                                                      // get_rate_last (:645-658) without the final lambda *
             mnz |= 1u << s4;
             if (lv > 1) mgt1 |= 1u << s4;
@@ -916,13 +944,14 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
 extern "C" size_t uvghip_rdoq_workspace_bytes(int width, int height, int n)
 {
   if (width <= 0 || height <= 0 || n <= 0) return 0;
-  return (size_t)width * height * (size_t)n * sizeof(double);      // cost_coeff[] of every block
+  // cost_coeff[] + cost_coeffgroup_sig[] + the cost_sig[] codes of every block
+  return (size_t)width * height * (size_t)n * (sizeof(double) + 1) + (size_t)(width * height / 16) * (size_t)n * sizeof(double);
 }
 
 extern "C" size_t uvghip_rdoq_signhide_workspace_bytes(int width, int height, int n)
 {
   if (width <= 0 || height <= 0 || n <= 0) return 0;
-  return (size_t)width * height * (size_t)n * (sizeof(double) + 4 * sizeof(int32_t));   // + sh_rates of every block
+  return uvghip_rdoq_workspace_bytes(width, height, n) + (size_t)width * height * (size_t)n * 4 * sizeof(int32_t);   // + sh_rates of every block
 }
 
 static int rdoq_launch(int signhide, int bitdepth, const int16_t *coef, int16_t *q_coef, int width, int height, int n, int color,
@@ -992,8 +1021,7 @@ static int rdoq_launch(int signhide, int bitdepth, const int16_t *coef, int16_t 
   const int wh = width * height;
   // blocks per wave (four lanes each): 16.  LDS per block: levels (int16) + meta (byte) per position, odd word stride
   const int tus = 16;
-  const size_t per_tu = (size_t)wh * 3 + 4;
-  const size_t lds = (size_t)tus * per_tu;
+  const size_t lds = (size_t)tus * rdoq_lds_per_block(wh);
   double *w = static_cast<double *>(workspace);
   hipStream_t st = uvghip_stream(stream);
   // one workgroup per batch of 16 blocks (measured: capping the grid and looping batches inside a workgroup to share the

@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from . import api, layout
+from . import lib as _lib
 from .bands import BandLayout, spec_bytes
 
 SIZES = (32, 16, 8, 4)            # --pu-depth-intra 1-4 (cfg.c:769-801)
@@ -74,7 +75,7 @@ class TuPool:
                                   lev=torch.zeros((F, cnt, c, c), dtype=torch.int16, device=d),      # levels = the reference's coeff_out
                                   deq=torch.zeros((F, cnt, c, c), dtype=torch.int16, device=d),      # dequantised
                                   has=torch.zeros((F, cnt), dtype=torch.uint8, device=d),
-                                  ws=torch.empty((F * cnt * c * c + 64,), dtype=torch.float64, device=d))
+                                  ws=torch.empty((_lib.load_library().uvghip_rdoq_workspace_bytes(c, c, F * cnt) // 8 + 64,), dtype=torch.float64, device=d))
         return self.jobs[key]
 
 
@@ -419,7 +420,7 @@ class ClosedLoopIntra:
                                     lev=torch.zeros((cnt, c, c), dtype=torch.int16, device=device),
                                     deq=torch.zeros((cnt, c, c), dtype=torch.int16, device=device),
                                     has=torch.zeros(cnt, dtype=torch.uint8, device=device),
-                                    ws=torch.empty((cnt * c * c + 64,), dtype=torch.float64, device=device))
+                                    ws=torch.empty((_lib.load_library().uvghip_rdoq_workspace_bytes(c, c, cnt) // 8 + 64,), dtype=torch.float64, device=device))
         self._ctx = (ctypes.c_uint8 * 244).from_buffer_copy(synthetic_rdoq_ctx().tobytes())
         ys, cs = self.y.stride(0), self.u.stride(0)
         nm = modes_dev.shape[0]
