@@ -127,3 +127,51 @@ def test_full_size_tu_properties(hip):
     drec2 = dorig.clone()
     coeff2, has2 = api.tu_roundtrip_batch(dorig, dorig, drec2, tus, 8, 8, 22)
     assert int(has2.sum()) == 0 and int(coeff2.abs().sum()) == 0 and torch.equal(drec2, dorig)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("shape", [(4, 4), (8, 8), (16, 16), (32, 32), (16, 8), (8, 32)])
+@pytest.mark.parametrize("misalign", [0, 1])
+def test_tu_halves_vs_oracle(hip, orc, depth, shape, misalign):
+    """uvghip_tu_forward_batch -> quant -> dequant -> uvghip_tu_inverse_batch == the oracle's fused round trip: square blocks
+    on the register / wave kernels (coefficient buffer 16-byte aligned), rectangles and a buffer off by one coefficient on
+    the generic kernel; DCT-2 and the MTS kernels; the stored coefficients are the forward transform's int16 output."""
+    import torch
+    from uvg266_amd import api, lib
+    L = lib.init(0)
+    w, h = shape
+    rng = np.random.default_rng(5 * w + 3 * h + depth + misalign)
+    Hh, W = 160, 224
+    orig = rand_plane(rng, Hh, W, depth)
+    noise = rng.integers(-25, 26, (Hh, W))
+    pred = np.clip(orig.astype(np.int32) + noise * rng.integers(0, 2, (Hh, W)), 0, (1 << depth) - 1).astype(orig.dtype)
+    xs, ys = np.meshgrid(np.arange(0, W - w + 1, w), np.arange(0, Hh - h + 1, h))
+    xy = np.stack([xs.ravel(), ys.ravel()], 1)
+    xy = xy[rng.permutation(len(xy))[: 37]]
+    n = len(xy)
+    tus = api.make_tus(xy)
+    dorig, dpred = dev(orig), dev(pred)
+    st = orig.strides[0] // orig.itemsize
+    P = lambda t: t.data_ptr()
+    sk = lambda d: 16 if d == 32 else 0
+    for th, tv in ((0, 0), (1, 2), (2, 1)):
+        sw, sh = (sk(w), sk(h)) if (th or tv) else (0, 0)
+        qps, intra = 22 + 6 * (depth - 8), 1
+        store = torch.zeros(n * w * h + 8, dtype=torch.int16, device="cuda")
+        coef = store[misalign: misalign + n * w * h].view(n, h, w)
+        assert L.uvghip_tu_forward_batch(depth, th, tv, sw, sh, w, h, 0, P(dorig), st, P(dpred), st, P(tus), n, P(coef), None) == 0
+        lev = api.quant_batch(coef.contiguous(), depth, qps, False, bool(intra))
+        store2 = torch.zeros(n * w * h + 8, dtype=torch.int16, device="cuda")
+        deq = store2[misalign: misalign + n * w * h].view(n, h, w)
+        deq.copy_(api.dequant_batch(lev, depth, qps, False))
+        drec = dpred.clone()
+        assert L.uvghip_tu_inverse_batch(depth, th, tv, sw, sh, w, h, 0, P(deq), P(dpred), st, P(drec), st, P(tus), n, None) == 0
+        rec, lv, cf = drec.cpu().numpy(), lev.cpu().numpy(), coef.cpu().numpy()
+        want_rec = pred.copy()
+        for i, (x0, y0) in enumerate(xy):
+            whas, wq, wrec = orc.tu_roundtrip(depth, depth, th, tv, sw, sh, w, h, qps, intra, orig, pred, W, int(x0), int(y0))
+            assert np.array_equal(lv[i].ravel(), wq), (i, th, tv)
+            want_rec[y0:y0 + h, x0:x0 + w] = wrec[y0:y0 + h, x0:x0 + w]
+            res = np.ascontiguousarray((orig[y0:y0 + h, x0:x0 + w].astype(np.int32) - pred[y0:y0 + h, x0:x0 + w]).astype(np.int16))
+            assert np.array_equal(cf[i].ravel(), orc.tr(depth, depth, 0, th, tv, w, h, sw, sh, res.ravel())), (i, th, tv, "coef")
+        assert np.array_equal(rec, want_rec), (th, tv)

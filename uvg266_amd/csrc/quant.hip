@@ -471,7 +471,9 @@ __device__ __forceinline__ void tu_repack(const int (&v)[N][N], uint32_t (&next)
     for (int l = 0; l < N; l += 2) next[o][l >> 1] = __builtin_amdgcn_perm((uint32_t)v[l + 1][o], (uint32_t)v[l][o], 0x05040100u);
 }
 
-template <typename PX, int N>
+// MODE (as tu_roundtrip_kernel): TU_FWD stops after the forward transform (coefficients to coeff_out), TU_INV starts from
+// dequantised coefficients in coeff_out.
+template <typename PX, int N, int MODE = TU_FULL>
 __global__ void __launch_bounds__(256)
 tu_lane_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int orig_stride,
                const PX *__restrict__ pred, int pred_stride, PX *__restrict__ rec, int rec_stride,
@@ -484,21 +486,65 @@ tu_lane_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int ori
   int pr[N][N];
   uint32_t a[N][N / 2];
   int v[N][N];
+  int16_t *co = coeff_out + (size_t)i * (N * N);
+  if constexpr (MODE != TU_INV) {
 #pragma unroll
-  for (int y = 0; y < N; ++y) {
-    int o[N];
-    load_row<PX, N>(orig, orig_stride, tu.x, tu.y + y, o);
-    load_row<PX, N>(pred, pred_stride, tu.x, tu.y + y, pr[y]);
+    for (int y = 0; y < N; ++y) {
+      int o[N];
+      load_row<PX, N>(orig, orig_stride, tu.x, tu.y + y, o);
+      load_row<PX, N>(pred, pred_stride, tu.x, tu.y + y, pr[y]);
 #pragma unroll
-    for (int x = 0; x < N; x += 2)
-      a[y][x >> 1] = __builtin_amdgcn_perm((uint32_t)(o[x + 1] - pr[y][x + 1]), (uint32_t)(o[x] - pr[y][x]), 0x05040100u);
+      for (int x = 0; x < N; x += 2)
+        a[y][x >> 1] = __builtin_amdgcn_perm((uint32_t)(o[x + 1] - pr[y][x + 1]), (uint32_t)(o[x] - pr[y][x]), 0x05040100u);
+    }
+    tu_lane_pass<N, true, false>(a, Th, P.f1.shift, v);            // v[y][c]
+    tu_repack<N>(v, a);                                             // a[c][y pairs]
+    tu_lane_pass<N, true, false>(a, Tv, P.f2.shift, v);            // v[c][j]
   }
-  tu_lane_pass<N, true, false>(a, Th, P.f1.shift, v);            // v[y][c]
-  tu_repack<N>(v, a);                                             // a[c][y pairs]
-  tu_lane_pass<N, true, false>(a, Tv, P.f2.shift, v);            // v[c][j]
+  if constexpr (MODE == TU_FWD) {                                   // coefficients (int16 truncation, dct-generic.c:724-725) row-major [j][c]
+    uint32_t *dst = reinterpret_cast<uint32_t *>(co);
+    if constexpr (N == 8) {
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+        *reinterpret_cast<uint4 *>(dst + j * 4) =
+            make_uint4(__builtin_amdgcn_perm((uint32_t)v[1][j], (uint32_t)v[0][j], 0x05040100u), __builtin_amdgcn_perm((uint32_t)v[3][j], (uint32_t)v[2][j], 0x05040100u),
+                       __builtin_amdgcn_perm((uint32_t)v[5][j], (uint32_t)v[4][j], 0x05040100u), __builtin_amdgcn_perm((uint32_t)v[7][j], (uint32_t)v[6][j], 0x05040100u));
+    } else {
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+        *reinterpret_cast<uint2 *>(dst + j * 2) =
+            make_uint2(__builtin_amdgcn_perm((uint32_t)v[1][j], (uint32_t)v[0][j], 0x05040100u), __builtin_amdgcn_perm((uint32_t)v[3][j], (uint32_t)v[2][j], 0x05040100u));
+    }
+    return;
+  }
+  if constexpr (MODE == TU_INV) {
+    // prediction rows for the final add; dequantised coefficients [j][c] -> a[c][j pairs] (taps of inv1 run over j)
+#pragma unroll
+    for (int y = 0; y < N; ++y) load_row<PX, N>(pred, pred_stride, tu.x, tu.y + y, pr[y]);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(co);
+    uint32_t rows[N][N / 2];
+    if constexpr (N == 8) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(src + j * 4);
+        rows[j][0] = w.x; rows[j][1] = w.y; rows[j][2] = w.z; rows[j][3] = w.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(src + j * 2);
+        rows[j][0] = w.x; rows[j][1] = w.y;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c)
+#pragma unroll
+      for (int j = 0; j < N; j += 2)
+        a[c][j >> 1] = __builtin_amdgcn_perm(rows[j + 1][c >> 1], rows[j][c >> 1], (c & 1) ? 0x07060302u : 0x05040100u);
+  }
+  if constexpr (MODE == TU_FULL) {
   // quantise, store levels row-major [j][c], dequantise
   int any = 0;
-  int16_t *co = coeff_out + (size_t)i * (N * N);
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     int lv[N];
@@ -525,6 +571,7 @@ tu_lane_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int ori
   for (int c = 0; c < N; ++c)
 #pragma unroll
     for (int j = 0; j < N; j += 2) a[c][j >> 1] = __builtin_amdgcn_perm((uint32_t)v[c][j + 1], (uint32_t)v[c][j], 0x05040100u);
+  }   // MODE == TU_FULL
   tu_lane_pass<N, false, true>(a, Tv, P.i1.shift, v);            // v[c][y] = sum_j dq[j][c] Tv[j][y]
   tu_repack<N>(v, a);                                             // a[y][c pairs]
   tu_lane_pass<N, false, true>(a, Th, P.i2.shift, v);            // v[y][x] = sum_c u[y][c] Th[c][x]
@@ -665,23 +712,28 @@ __device__ __forceinline__ void tuw_store_transposed(int16_t *dst, int l0, const
                    __builtin_amdgcn_perm((uint32_t)v[3][j], (uint32_t)v[2][j], 0x05040100u));
 }
 
-template <typename PX, int N>
+template <typename PX, int N, int MODE = TU_FULL>
 __global__ void __launch_bounds__(256)
 tu_wave_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int orig_stride,
                const PX *__restrict__ pred, int pred_stride, PX *__restrict__ rec, int rec_stride,
                const uvghip_tu_t *__restrict__ tus, int n, int16_t *__restrict__ coeff_out, uint8_t *__restrict__ has_coeffs)
 {
   using W = tuw<N>;
-  __shared__ __attribute__((aligned(16))) int16_t sM[4][W::MAT];       // Bf1, Bf2, Bi1, Bi2
+  constexpr int MF = 0, MI = MODE == TU_FULL ? 2 : 0;                  // first forward / inverse matrix (the halves stage only their two)
+  __shared__ __attribute__((aligned(16))) int16_t sM[MODE == TU_FULL ? 4 : 2][W::MAT];   // Bf1, Bf2, Bi1, Bi2
   __shared__ __attribute__((aligned(16))) int16_t sBuf[4][2][W::BUF];  // per wave: two line buffers
   {
     const int16_t *Th = tr_matrix_dev(P.type_hor, N), *Tv = tr_matrix_dev(P.type_ver, N);
     for (int e = threadIdx.x; e < N * N; e += 256) {
       const int r = e / N, c = e - r * N;                                // compile-time N: shifts
-      sM[0][W::mrow(r) + c] = Th[e];                                     // Bf1[c'][k]  = Th[c'][k]
-      sM[1][W::mrow(r) + c] = Tv[e];                                     // Bf2[j][y]   = Tv[j][y]
-      sM[2][W::mrow(c) + r] = Tv[e];                                     // Bi1[y][j]   = Tv[j][y]
-      sM[3][W::mrow(c) + r] = Th[e];                                     // Bi2[x][c']  = Th[c'][x]
+      if constexpr (MODE != TU_INV) {
+        sM[MF][W::mrow(r) + c] = Th[e];                                  // Bf1[c'][k]  = Th[c'][k]
+        sM[MF + 1][W::mrow(r) + c] = Tv[e];                              // Bf2[j][y]   = Tv[j][y]
+      }
+      if constexpr (MODE != TU_FWD) {
+        sM[MI][W::mrow(c) + r] = Tv[e];                                  // Bi1[y][j]   = Tv[j][y]
+        sM[MI + 1][W::mrow(c) + r] = Th[e];                              // Bi2[x][c']  = Th[c'][x]
+      }
     }
   }
   __syncthreads();
@@ -697,6 +749,19 @@ tu_wave_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int ori
   const bool on = tu0 + b < n;
   const uvghip_tu_t tu = tus[on ? tu0 + b : tu0];
 
+  int acc[4][4];
+  if constexpr (MODE == TU_INV) {
+    // dequantised coefficients, one row segment of 16 per lane: in[j = row][c = x0 + k] -> bufA[c][j] (lines c, taps j)
+    const int row = N == 32 ? lane >> 1 : lane & 15, x0 = N == 32 ? (lane & 1) * 16 : 0;
+    const int lb = N == 32 ? 0 : lane >> 4;
+    const int16_t *src = coeff_out + (size_t)(tu0 + lb < n ? tu0 + lb : tu0) * (N * N) + row * N + x0;
+    const uint4 v0 = *reinterpret_cast<const uint4 *>(src), v1 = *reinterpret_cast<const uint4 *>(src + 8);
+    const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    int16_t *dst = bufA + lb * W::BLK + x0 * W::PITCH + row;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dst[k * W::PITCH] = (int16_t)(w[k >> 1] >> (16 * (k & 1)));
+  }
+  if constexpr (MODE != TU_INV) {
   // residual rows -> bufA[b][y][x]
   {
     const int row = N == 32 ? lane >> 1 : lane & 15, x0 = N == 32 ? (lane & 1) * 16 : 0;
@@ -720,9 +785,8 @@ tu_wave_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int ori
   }
   tuw_sync();
 
-  int acc[4][4];
   // fwd1: lines y, outputs c -> bufB[c][y]
-  tuw_mma<N>(bufA + b * W::BLK + l0 * W::PITCH, sM[0] + W::mrow(o0), acc);
+  tuw_mma<N>(bufA + b * W::BLK + l0 * W::PITCH, sM[MF] + W::mrow(o0), acc);
   {
     const int add = P.f1.shift > 0 ? 1 << (P.f1.shift - 1) : 0;
 #pragma unroll
@@ -733,7 +797,21 @@ tu_wave_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int ori
   }
   tuw_sync();
   // fwd2: lines c, outputs j -> quantise; levels to HBM [j][c]; dequantised -> bufA[c][j]
-  tuw_mma<N>(bufB + b * W::BLK + l0 * W::PITCH, sM[1] + W::mrow(o0), acc);
+  tuw_mma<N>(bufB + b * W::BLK + l0 * W::PITCH, sM[MF + 1] + W::mrow(o0), acc);
+  if constexpr (MODE == TU_FWD) {                                       // coefficients (int16 truncation) to HBM [j][c]
+    if (!on) return;
+    const int add = 1 << (P.f2.shift - 1);
+    int16_t *co = coeff_out + (size_t)(tu0 + b) * (N * N);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {     // row j = o0 + j, columns c = l0 .. l0+3
+      int cv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cv[i] = (acc[i][j] + add) >> P.f2.shift;
+      *reinterpret_cast<uint2 *>(co + (o0 + j) * N + l0) =
+          make_uint2(__builtin_amdgcn_perm((uint32_t)cv[1], (uint32_t)cv[0], 0x05040100u), __builtin_amdgcn_perm((uint32_t)cv[3], (uint32_t)cv[2], 0x05040100u));
+    }
+    return;
+  }
   int any = 0;
   {
     const int add = 1 << (P.f2.shift - 1);
@@ -764,9 +842,10 @@ tu_wave_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int ori
     if (N == 32) { if (lane == 0) has_coeffs[tu0] = m != 0; }
     else if ((lane & 15) == 0 && on) has_coeffs[tu0 + b] = ((m >> (lane & 48)) & 0xffffull) != 0;
   }
+  }   // MODE != TU_INV
   tuw_sync();
   // inv1: lines c, taps j, outputs y -> bufB[y][c]
-  tuw_mma<N>(bufA + b * W::BLK + l0 * W::PITCH, sM[2] + W::mrow(o0), acc);
+  tuw_mma<N>(bufA + b * W::BLK + l0 * W::PITCH, sM[MI] + W::mrow(o0), acc);
   {
     const int add = 1 << (P.i1.shift - 1);
 #pragma unroll
@@ -777,7 +856,7 @@ tu_wave_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int ori
   }
   tuw_sync();
   // inv2: lines y, taps c, outputs x -> + pred -> rec
-  tuw_mma<N>(bufB + b * W::BLK + l0 * W::PITCH, sM[3] + W::mrow(o0), acc);
+  tuw_mma<N>(bufB + b * W::BLK + l0 * W::PITCH, sM[MI + 1] + W::mrow(o0), acc);
   if (on) {
     const int add = 1 << (P.i2.shift - 1);
 #pragma unroll
@@ -946,6 +1025,33 @@ static int tu_half_check(int bitdepth, int type_hor, int type_ver, int skip_widt
   return 0;
 }
 
+// square blocks without zero-out or transform skip take the register / wave kernels of the fused round trip (their 8 / 16 byte
+// coefficient accesses want the buffer 16-byte aligned); everything else the generic LDS kernel
+static bool tu_half_fast(int width, int height, int skip_width, int skip_height, int use_trskip, const void *coef)
+{
+  return width == height && skip_width == 0 && skip_height == 0 && !use_trskip && ((uintptr_t)coef & 15) == 0;
+}
+#define TU_HALF_LAUNCH(KERNEL, PX, N, MODE, G, ORIG, OSTRIDE, COEF)                                                           \
+  KERNEL<PX, N, MODE><<<G, 256, 0, st>>>(P, Q, (const PX *)(ORIG), OSTRIDE, (const PX *)pred, pred_stride, (PX *)rec, rec_stride, \
+                                         tus, n, COEF, nullptr)
+#define TU_HALF_DISPATCH(MODE, ORIG, OSTRIDE, COEF)                                                                           \
+  do {                                                                                                                        \
+    if (width <= 8) {                                                                                                         \
+      const int g = (n + 255) / 256;                                                                                          \
+      if (bitdepth == 8) { if (width == 4) TU_HALF_LAUNCH(tu_lane_kernel, uint8_t, 4, MODE, g, ORIG, OSTRIDE, COEF);          \
+                           else TU_HALF_LAUNCH(tu_lane_kernel, uint8_t, 8, MODE, g, ORIG, OSTRIDE, COEF); }                   \
+      else { if (width == 4) TU_HALF_LAUNCH(tu_lane_kernel, uint16_t, 4, MODE, g, ORIG, OSTRIDE, COEF);                       \
+             else TU_HALF_LAUNCH(tu_lane_kernel, uint16_t, 8, MODE, g, ORIG, OSTRIDE, COEF); }                                \
+    } else {                                                                                                                  \
+      const int units = width == 32 ? n : (n + 3) / 4, g = (units + 3) / 4;                                                   \
+      if (bitdepth == 8) { if (width == 16) TU_HALF_LAUNCH(tu_wave_kernel, uint8_t, 16, MODE, g, ORIG, OSTRIDE, COEF);        \
+                           else TU_HALF_LAUNCH(tu_wave_kernel, uint8_t, 32, MODE, g, ORIG, OSTRIDE, COEF); }                  \
+      else { if (width == 16) TU_HALF_LAUNCH(tu_wave_kernel, uint16_t, 16, MODE, g, ORIG, OSTRIDE, COEF);                     \
+             else TU_HALF_LAUNCH(tu_wave_kernel, uint16_t, 32, MODE, g, ORIG, OSTRIDE, COEF); }                               \
+    }                                                                                                                         \
+    UVGHIP_CHECK_LAUNCH();                                                                                                    \
+  } while (0)
+
 extern "C" int uvghip_tu_forward_batch(int bitdepth, int type_hor, int type_ver, int skip_width, int skip_height, int width, int height,
                                        int use_trskip, const void *orig, int orig_stride, const void *pred, int pred_stride,
                                        const uvghip_tu_t *tus, int n, int16_t *coef_out, void *stream)
@@ -957,6 +1063,10 @@ extern "C" int uvghip_tu_forward_batch(int bitdepth, int type_hor, int type_ver,
   const quant_params Q = make_quant_params(bitdepth, width, height, 22, 0, 1);       // unused by this half
   const int bpg = 1024 / (width * height), grid = (n + bpg - 1) / bpg;
   hipStream_t st = uvghip_stream(stream);
+  if (tu_half_fast(width, height, skip_width, skip_height, use_trskip, coef_out)) {
+    void *rec = nullptr; const int rec_stride = 0;
+    TU_HALF_DISPATCH(TU_FWD, orig, orig_stride, coef_out);
+  }
   if (bitdepth == 8) tu_roundtrip_kernel<uint8_t, TU_FWD><<<grid, 256, 0, st>>>(P, Q, (const uint8_t *)orig, orig_stride, (const uint8_t *)pred, pred_stride, nullptr, 0, tus, n, bpg, coef_out, nullptr, use_trskip);
   else tu_roundtrip_kernel<uint16_t, TU_FWD><<<grid, 256, 0, st>>>(P, Q, (const uint16_t *)orig, orig_stride, (const uint16_t *)pred, pred_stride, nullptr, 0, tus, n, bpg, coef_out, nullptr, use_trskip);
   UVGHIP_CHECK_LAUNCH();
@@ -974,6 +1084,10 @@ extern "C" int uvghip_tu_inverse_batch(int bitdepth, int type_hor, int type_ver,
   const int bpg = 1024 / (width * height), grid = (n + bpg - 1) / bpg;
   hipStream_t st = uvghip_stream(stream);
   int16_t *c = const_cast<int16_t *>(coef_in);
+  if (tu_half_fast(width, height, skip_width, skip_height, use_trskip, coef_in)) {
+    const void *orig = nullptr; const int orig_stride = 0;
+    TU_HALF_DISPATCH(TU_INV, orig, orig_stride, c);
+  }
   if (bitdepth == 8) tu_roundtrip_kernel<uint8_t, TU_INV><<<grid, 256, 0, st>>>(P, Q, nullptr, 0, (const uint8_t *)pred, pred_stride, (uint8_t *)rec, rec_stride, tus, n, bpg, c, nullptr, use_trskip);
   else tu_roundtrip_kernel<uint16_t, TU_INV><<<grid, 256, 0, st>>>(P, Q, nullptr, 0, (const uint16_t *)pred, pred_stride, (uint16_t *)rec, rec_stride, tus, n, bpg, c, nullptr, use_trskip);
   UVGHIP_CHECK_LAUNCH();
@@ -1028,17 +1142,14 @@ extern "C" int uvghip_quantize_residual_batch(int bitdepth, const uvghip_qr_para
   if (!workspace || workspace_bytes < uvghip_quantize_residual_workspace_bytes(p, n))
     return uvghip_set_error(hipErrorInvalidValue, "uvghip_quantize_residual_batch: workspace");
   const bool rdoq = p->rdoq_enable && (width > 4 || !p->rdoq_skip) && !p->use_trskip;
-  const tr_params P = tr_make_params(bitdepth, p->type_hor, p->type_ver, width, height, p->skip_width, p->skip_height);
-  const quant_params Q = make_quant_params(bitdepth, width, height, p->qp_scaled, p->use_trskip, p->slice_is_intra);
   hipStream_t st = uvghip_stream(stream);
   int16_t *coef = static_cast<int16_t *>(workspace);
   int16_t *deq = reinterpret_cast<int16_t *>(static_cast<char *>(workspace) + qr_coef_bytes(width, height, n));
   void *rdoq_ws = static_cast<char *>(workspace) + 2 * qr_coef_bytes(width, height, n);
-  const int bpg = 1024 / (width * height), grid = (n + bpg - 1) / bpg;
   // (1) residual -> transform (or transform skip) -> coefficients
-#define TU_STAGE(PX, M, buf) tu_roundtrip_kernel<PX, M><<<grid, 256, 0, st>>>(P, Q, (const PX *)orig, orig_stride, (const PX *)pred, pred_stride, (PX *)rec, rec_stride, tus, n, bpg, buf, nullptr, p->use_trskip)
-  if (bitdepth == 8) TU_STAGE(uint8_t, TU_FWD, coef); else TU_STAGE(uint16_t, TU_FWD, coef);
-  { hipError_t e = hipGetLastError(); if (e != hipSuccess) return uvghip_set_error(e, __func__); }
+  if (int rc = uvghip_tu_forward_batch(bitdepth, p->type_hor, p->type_ver, p->skip_width, p->skip_height, width, height, p->use_trskip,
+                                       orig, orig_stride, pred, pred_stride, tus, n, coef, stream))
+    return rc;
   // (2) forward LFNST (intra CUs, cfg.lfnst; :507-510): where it applies is the caller's call (uvg_fwd_lfnst, transform.c:988:
   //     luma, or chroma of a separate tree) -- lfnst_tus == NULL means "nowhere", although quant / RDOQ still see lfnst_idx
   if (lfnst_tus)
@@ -1064,9 +1175,8 @@ extern "C" int uvghip_quantize_residual_batch(int bitdepth, const uvghip_qr_para
   if (int rc = uvghip_dequant_batch(bitdepth, coeff_out, deq, width, height, n, p->qp_scaled, p->use_trskip, stream)) return rc;
   if (lfnst_tus)
     if (int rc = uvghip_lfnst_batch(1, deq, width, height, lfnst_tus, n, stream)) return rc;
-  if (bitdepth == 8) TU_STAGE(uint8_t, TU_INV, deq); else TU_STAGE(uint16_t, TU_INV, deq);
-#undef TU_STAGE
-  UVGHIP_CHECK_LAUNCH();
+  return uvghip_tu_inverse_batch(bitdepth, p->type_hor, p->type_ver, p->skip_width, p->skip_height, width, height, p->use_trskip,
+                                 deq, pred, pred_stride, rec, rec_stride, tus, n, stream);
 }
 
 // ---- joint Cb-Cr residual coding: uvg_quant_cbcr_residual (quant-generic.c:241-442) ----
