@@ -245,7 +245,7 @@ constexpr int ALF_SLOTS = 16;      // 4x4 blocks per phase-A chunk (256 samples,
 // triangle k <= l of ee (ee[k][l][b0][b1] == ee[l][k][b1][b0]), y, pix_acc -- in class order, plus the rectangle's class
 // mask in `present`; absent classes cost no write at all.  `ee` then points at the records, `yv` / `pix` are unused.
 template <typename PX, bool CHROMA, bool COMPACT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__ rec, int rstride, int pic_w, int pic_h,
                  const uvghip_rect_t *__restrict__ rects, const uint8_t *__restrict__ cls, int cls_stride,
                  long long *__restrict__ ee, int32_t *__restrict__ yv, long long *__restrict__ pix,
