@@ -107,9 +107,20 @@ def algorithmic_bytes(fr, name, group=1):
     """SURVEY.md 8(d) per-unit figures x the units this launch processes (b = bytes per sample)."""
     kern, n = name.rsplit("_", 1)
     n = int(n)
-    if kern in ("rdoq", "dequant", "rdoq_chroma", "dequant_chroma"):       # one launch over the group's pictures: int16 in, int16 out
+    if kern in GROUP_KERNELS:                                              # one launch over the group's pictures
+        return group * _picture_bytes(fr, kern, n)
+    return _picture_bytes(fr, kern, n)
+
+
+# kernels that take block lists run once per block shape over all pictures of a group (pipeline.FrameGroup)
+GROUP_KERNELS = {"rdoq", "dequant", "rdoq_chroma", "dequant_chroma", "tu_forward", "tu_forward_chroma", "tu_inverse", "tu_inverse_chroma",
+                 "intra_search", "intra_pred_plane", "intra_pred_chroma", "tu_roundtrip", "tu_roundtrip_chroma"}
+
+
+def _picture_bytes(fr, kern, n):
+    if kern in ("rdoq", "dequant", "rdoq_chroma", "dequant_chroma"):       # int16 in, int16 out
         c = n // 2 if kern.endswith("chroma") else n
-        return group * fr.tables[n][2] * c * c * 4
+        return fr.tables[n][2] * c * c * 4
     if kern in ("tu_forward", "tu_forward_chroma", "tu_inverse", "tu_inverse_chroma"):   # two planes touched + int16 coefficients
         c = n // 2 if kern.endswith("chroma") else n
         return fr.tables[n][2] * c * c * (2 * (1 if fr.depth == 8 else 2) + 2)
@@ -150,7 +161,7 @@ def algorithmic_bytes(fr, name, group=1):
         cb = fr.comm_bytes()
         key = {"halo_dbk": "halo_deblock", "halo_alf": "halo_alf", "gather": "gather", "allreduce_cov": "allreduce_cov"}[kern]
         return sum(cb[key])
-    raise KeyError(name)
+    raise KeyError(kern)
 
 
 def _alf_records_bytes(self):

@@ -406,6 +406,20 @@ UVGHIP_API int uvghip_intra_pred_plane_chroma_batch(int bitdepth, const void *re
                                          const uvghip_intra_blk_t *blks, int n, const int8_t *modes,
                                          void *pred_plane, int pred_stride, void *stream);
 
+/* The three entry points above for a STACK of pictures: `rec` / `orig` / `pred_plane` hold several pictures of pic_rows rows
+ * each, one under the other with the same stride; blks[i].y is a row of the stack.  A block's neighbours are looked up in its
+ * own picture (a block on row 0 of its picture has no row above, whatever lies above it in the stack), so one launch
+ * serves the blocks of all pictures -- frame-parallel operation, where one picture alone does not fill the GPU.
+ * pic_rows == 0: as the plain entry points.  uvghip_intra_pred_plane_stacked_batch: is_chroma selects the chroma rules of
+ * uvghip_intra_pred_plane_chroma_batch. */
+UVGHIP_API int uvghip_intra_search_best_stacked_batch(int bitdepth, const void *rec, int rec_stride, const void *orig,
+                                           int orig_stride, int size, const uvghip_intra_blk_t *blks, int n,
+                                           const int8_t *modes, int n_modes, int8_t *best_mode, uint32_t *best_cost,
+                                           uint32_t *costs, int pic_rows, void *stream);
+UVGHIP_API int uvghip_intra_pred_plane_stacked_batch(int bitdepth, const void *rec, int rec_stride, int size,
+                                          const uvghip_intra_blk_t *blks, int n, const int8_t *modes,
+                                          void *pred_plane, int pred_stride, int pic_rows, int is_chroma, void *stream);
+
 /* Picks, per block, the candidate with the smallest cost; ties keep the earlier candidate, like
  * the strict "<" scans of search_intra_rough (src/search_intra.c:1089-1101).
  * best_mode[i] = modes[argmin_m costs[i*n_modes+m]], best_cost (may be NULL) the minimum. */

@@ -155,3 +155,33 @@ def test_rccl_entry_points_with_one_rank(hip):
         assert torch.equal(s.cpu(), torch.arange(25 * 1509, dtype=torch.int64).reshape(25, 1509))
     finally:
         tr.close()
+
+
+@pytest.mark.parametrize("wl_name", ["test8", "test10"])
+def test_frame_group_equals_single_pictures(hip, wl_name):
+    """pipeline.FrameGroup (F pictures stacked in a GroupArena: search, predict, transforms and the quantiser once per block
+    shape over the group) leaves every picture exactly as the per-picture chains of pipeline.BandFrame do."""
+    import torch
+    from uvg266_amd import api, pipeline
+    wl = pipeline.WORKLOADS[wl_name]
+    modes = api.make_modes(pipeline.MODES)
+    F = 3
+    grp = pipeline.FrameGroup(hip, wl, 5, F, "cuda", modes, step=2)
+    st = torch.cuda.current_stream().cuda_stream
+    pipeline.run(grp.all_launches(), st)
+    torch.cuda.synchronize()
+    for f in range(F):
+        one = pipeline.BandFrame(hip, wl, 5 + 2 * f, "cuda", modes)
+        _run([one], lambda fr: fr.all_launches())
+        got = grp.frames[f]
+        for n in pipeline.SIZES:
+            assert torch.equal(got.bufs[n]["best"], one.bufs[n]["best"]) and torch.equal(got.bufs[n]["cost"], one.bufs[n]["cost"]), n
+            assert torch.equal(got.bufs[n]["pred"], one.bufs[n]["pred"]), n
+            for color in ((0, 1, 2) if n >= 8 else (0,)):
+                a, b = grp.pool.jobs[(n, color)], one.pool.jobs[(n, color)]
+                assert torch.equal(a["lev"][f], b["lev"][0]) and torch.equal(a["has"][f], b["has"][0]), (n, color)
+        for a, b in zip(got.final, one.final):
+            assert torch.equal(a, b)
+        assert torch.equal(got.edge_all, one.edge_all) and torch.equal(got.params_all, one.params_all)
+        if wl["alf"]:
+            assert torch.equal(got.alf_sums, one.alf_sums)

@@ -25,7 +25,8 @@ except ValueError:
 W, H = 1920, 1080
 SEARCH_GRID = {}
 for n, bpg, thr in ((32, 4, 512), (16, 16, 512), (8, 64, 512), (4, 64, 256)):
-    SEARCH_GRID[str(-(-((W // n) * (H // n)) // bpg) * thr)] = f"intra_search_{n}"
+    for F in (1, 2, 4, 5, 8, 10, 16, 20):            # one launch covers the F pictures of a group (bench --group)
+        SEARCH_GRID.setdefault(str(-(-(F * (W // n) * (H // n)) // bpg) * thr), f"intra_search_{n}")
 RDOQ = {("5", "0"): "rdoq_32", ("4", "0"): "rdoq_16", ("3", "0"): "rdoq_8", ("2", "0"): "rdoq_4",
         ("4", "1"): "rdoq_chroma_32", ("3", "1"): "rdoq_chroma_16", ("2", "1"): "rdoq_chroma_8"}
 

@@ -150,11 +150,15 @@ __device__ inline void build_ref_rows(const PX *__restrict__ rec, int stride, in
 }
 // Same rows, but every thread first issues all of its (at most KR per row) global loads and only then
 // stores to LDS, so the round trips overlap instead of running one after the other.
+// pic_rows > 0: `rec` is a stack of pictures of pic_rows rows each (block rows are stack coordinates) -- "is there a row above"
+// is asked of the block's row inside its own picture.
 template <typename PX, int KR>
-__device__ __forceinline__ void build_ref_rows_batched(const PX *__restrict__ rec, int stride, int x, int y,
+__device__ __forceinline__ void build_ref_rows_batched(const PX *__restrict__ rec, int stride, int x, int y_abs,
                                                        int avail_top, int avail_left, uint16_t *top, uint16_t *left,
-                                                       int refn, int tid, int nthreads)
+                                                       int refn, int tid, int nthreads, int pic_rows = 0)
 {
+  rec += (size_t)(pic_rows > 0 ? y_abs / pic_rows : 0) * pic_rows * stride;       // origin of the block's picture
+  const int y = pic_rows > 0 ? y_abs % pic_rows : y_abs;
   const int dc = 1 << (px_traits<PX>::depth - 1);
   if (avail_left < 1) avail_left = 1;
   if (avail_top < 1) avail_top = 1;
@@ -386,7 +390,7 @@ extern "C" int uvghip_intra_pred_batch(int bitdepth, const void *rec, int rec_st
 template <typename PX, int N, bool CHROMA = false>      // N: the block size, a compile-time constant (all the index arithmetic folds)
 __global__ void __launch_bounds__(256)
 intra_pred_plane_kernel(const PX *__restrict__ rec, int stride, const uvghip_intra_blk_t *__restrict__ blks,
-                        int n_blks, const int8_t *__restrict__ modes, PX *__restrict__ out, int out_stride)
+                        int n_blks, const int8_t *__restrict__ modes, PX *__restrict__ out, int out_stride, int pic_rows)
 {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   constexpr int n = N;
@@ -404,7 +408,7 @@ intra_pred_plane_kernel(const PX *__restrict__ rec, int stride, const uvghip_int
   uint16_t *base = sRef + (size_t)myb * 4 * RS;
   if (myb < here) {
     const uvghip_intra_blk_t b = blks[blk0 + myb];
-    build_ref_rows_batched<PX, 3>(rec, stride, b.x, b.y, b.avail_top, b.avail_left, base, base + RS, RS, mytid, tpb);
+    build_ref_rows_batched<PX, 3>(rec, stride, b.x, b.y, b.avail_top, b.avail_left, base, base + RS, RS, mytid, tpb, pic_rows);
     if (mytid == 0) { sM[myb] = make_mode_info(modes[blk0 + myb], n, n, CHROMA ? 1 : 0); sX[myb] = b.x; sY[myb] = b.y; }
   }
   __syncthreads();
@@ -433,14 +437,15 @@ intra_pred_plane_kernel(const PX *__restrict__ rec, int stride, const uvghip_int
 }
 
 static int pred_plane_launch(int bitdepth, const void *rec, int rec_stride, int size, const uvghip_intra_blk_t *blks, int n,
-                             const int8_t *modes, void *pred_plane, int pred_stride, bool chroma, hipStream_t st, const char *who)
+                             const int8_t *modes, void *pred_plane, int pred_stride, bool chroma, hipStream_t st, const char *who,
+                             int pic_rows = 0)
 {
-  if (!(size == 4 || size == 8 || size == 16 || size == 32) || (bitdepth != 8 && bitdepth != 10)) return uvghip_set_error(hipErrorInvalidValue, who);
+  if (!(size == 4 || size == 8 || size == 16 || size == 32) || (bitdepth != 8 && bitdepth != 10) || pic_rows < 0) return uvghip_set_error(hipErrorInvalidValue, who);
   if (n <= 0) return 0;
   const int bpg = 256 / (size * size / 4);
   const int grid = (n + bpg - 1) / bpg;
   const size_t lds = (size_t)bpg * 4 * (2 * size + 4) * 2 + (size_t)bpg * (sizeof(mode_info) + 12) + 16;
-#define PP(PX, N, C) intra_pred_plane_kernel<PX, N, C><<<grid, 256, lds, st>>>((const PX *)rec, rec_stride, blks, n, modes, (PX *)pred_plane, pred_stride)
+#define PP(PX, N, C) intra_pred_plane_kernel<PX, N, C><<<grid, 256, lds, st>>>((const PX *)rec, rec_stride, blks, n, modes, (PX *)pred_plane, pred_stride, pic_rows)
 #define PPS(PX, C) do { if (size == 4) PP(PX, 4, C); else if (size == 8) PP(PX, 8, C); else if (size == 16) PP(PX, 16, C); else PP(PX, 32, C); } while (0)
   if (chroma) { if (bitdepth == 8) PPS(uint8_t, true); else PPS(uint16_t, true); }
   else { if (bitdepth == 8) PPS(uint8_t, false); else PPS(uint16_t, false); }
@@ -463,6 +468,15 @@ extern "C" int uvghip_intra_pred_plane_chroma_batch(int bitdepth, const void *re
 {
   UVGHIP_REQUIRE_READY();
   return pred_plane_launch(bitdepth, rec, rec_stride, size, blks, n, modes, pred_plane, pred_stride, true, uvghip_stream(stream), __func__);
+}
+
+extern "C" int uvghip_intra_pred_plane_stacked_batch(int bitdepth, const void *rec, int rec_stride, int size,
+                                                     const uvghip_intra_blk_t *blks, int n, const int8_t *modes,
+                                                     void *pred_plane, int pred_stride, int pic_rows, int is_chroma, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  return pred_plane_launch(bitdepth, rec, rec_stride, size, blks, n, modes, pred_plane, pred_stride, is_chroma != 0, uvghip_stream(stream),
+                           __func__, pic_rows);
 }
 
 // costs[n][n_modes] -> best[n] = index (into the mode list) of the first minimum, the tie-break of
@@ -964,7 +978,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 4 : (WAVES == 6 ? 3 :
 intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__restrict__ orig, int orig_stride,
                     int n_arg, const uvghip_intra_blk_t *__restrict__ blks, int n_blks,
                     const int8_t *__restrict__ modes, int n_modes, uint32_t *__restrict__ costs,
-                    int8_t *__restrict__ best_mode, uint32_t *__restrict__ best_cost)
+                    int8_t *__restrict__ best_mode, uint32_t *__restrict__ best_cost, int pic_rows)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n = NFIX ? NFIX : n_arg;
@@ -999,7 +1013,7 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
     uint16_t *base = sScratch + (size_t)myb * 4 * L.RS;     // u16 image: top | left | ftop | fleft
     if (on) {
       const uvghip_intra_blk_t b = blks[blk0 + myb];
-      build_ref_rows_batched<PX, 6>(rec, rec_stride, b.x, b.y, b.avail_top, b.avail_left, base, base + L.RS, L.RS, mytid, tpb);
+      build_ref_rows_batched<PX, 6>(rec, rec_stride, b.x, b.y, b.avail_top, b.avail_left, base, base + L.RS, L.RS, mytid, tpb, pic_rows);
       // original block in 4-sample segments: segment sg = (row, 4 columns)
       uint16_t *so = sOrig + (size_t)myb * L.OS, *sot = so + L.OT;
       auto band_off = [&](int row) { return (row / T) * L.BAND + (row % T) * n; };   // element offset of a row of the block
@@ -1217,10 +1231,10 @@ intra_search_kernel(const PX *__restrict__ rec, int rec_stride, const PX *__rest
 
 static int launch_intra_search(int bitdepth, const void *rec, int rec_stride, const void *orig, int orig_stride,
                                int size, const uvghip_intra_blk_t *blks, int n, const int8_t *modes, int n_modes,
-                               uint32_t *costs, int8_t *best_mode, uint32_t *best_cost, void *stream, const char *who)
+                               uint32_t *costs, int8_t *best_mode, uint32_t *best_cost, void *stream, const char *who, int pic_rows = 0)
 {
   UVGHIP_REQUIRE_READY();
-  if (!(size == 4 || size == 8 || size == 16 || size == 32) || n_modes < 1 || n_modes > 128)
+  if (!(size == 4 || size == 8 || size == 16 || size == 32) || n_modes < 1 || n_modes > 128 || pic_rows < 0)
     return uvghip_set_error(hipErrorInvalidValue, who);
   if (n <= 0) return 0;
   const int tiles = size == 4 ? 1 : (size / 8) * (size / 8);
@@ -1239,7 +1253,7 @@ static int launch_intra_search(int bitdepth, const void *rec, int rec_stride, co
         lds_done |= 1ull << (dev_ & 63); } } \
     if (getenv("UVGHIP_DEBUG_OCC")) { int nb = -1; hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, intra_search_kernel<PX, T, W, B, NF>, W * 64, L.total); \
       fprintf(stderr, "intra_search<%d,%d,%d> size %d: lds %zu grid %d occupancy %d blocks/CU (err %d)\n", (int)sizeof(PX), T, W, size, (size_t)L.total, grid, nb, (int)oe); } \
-    intra_search_kernel<PX, T, W, B, NF><<<grid, W * 64, L.total, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, blks, n, modes, n_modes, costs, best_mode, best_cost); } while (0)
+    intra_search_kernel<PX, T, W, B, NF><<<grid, W * 64, L.total, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, blks, n, modes, n_modes, costs, best_mode, best_cost, pic_rows); } while (0)
   if (bitdepth == 8) {
     if (size == 4) LAUNCH(uint8_t, 4, 4, UVGHIP_SEARCH_BPL4, 4);
     else if (size == 8) LAUNCH(uint8_t, 8, UVGHIP_SEARCH_WAVES, 1, 8);
@@ -1272,6 +1286,16 @@ extern "C" int uvghip_intra_search_best_batch(int bitdepth, const void *rec, int
   if (!best_mode) return uvghip_set_error(hipErrorInvalidValue, __func__);
   return launch_intra_search(bitdepth, rec, rec_stride, orig, orig_stride, size, blks, n, modes, n_modes, costs, best_mode,
                              best_cost, stream, __func__);
+}
+
+extern "C" int uvghip_intra_search_best_stacked_batch(int bitdepth, const void *rec, int rec_stride, const void *orig, int orig_stride,
+                                                      int size, const uvghip_intra_blk_t *blks, int n, const int8_t *modes,
+                                                      int n_modes, int8_t *best_mode, uint32_t *best_cost, uint32_t *costs,
+                                                      int pic_rows, void *stream)
+{
+  if (!best_mode) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  return launch_intra_search(bitdepth, rec, rec_stride, orig, orig_stride, size, blks, n, modes, n_modes, costs, best_mode,
+                             best_cost, stream, __func__, pic_rows);
 }
 
 // =================================================== drop-in strategy layer ====

@@ -101,6 +101,8 @@ SIGNATURES = {
     "uvghip_intra_search_best_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_intra_pred_plane_batch": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
     "uvghip_intra_pred_plane_chroma_batch": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp]),
+    "uvghip_intra_search_best_stacked_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "uvghip_intra_pred_plane_stacked_batch": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "uvghip_intra_select_best": (c_int, [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvghip_mc_batch": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_vp, c_vp]),
     "uvghip_extended_block_batch": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int] + [c_int] * 7 + [c_vp, c_int, c_vp, c_vp]),

@@ -79,9 +79,28 @@ class TuPool:
         return self.jobs[key]
 
 
+class GroupArena:
+    """Plane storage of a GROUP of F pictures: every named plane is one (F, rows, width) tensor, picture f owns slice f.  The
+    F slices stacked are one tall plane (F * rows, width) with the same stride, so the kernels that take block lists
+    (search, predict, transforms) run ONCE over the group with the lists of all pictures (y offset f * rows) -- a 1080p
+    picture alone does not fill 256 CUs for these kernels."""
+
+    def __init__(self, F, device):
+        self.F, self.device, self.t = F, device, {}
+
+    def take(self, name, slot, shape, dtype, fill=0):
+        if name not in self.t:
+            self.t[name] = torch.full((self.F,) + tuple(shape), fill, dtype=dtype, device=self.device)
+        return self.t[name][slot]
+
+    def stacked(self, name):
+        t = self.t[name]
+        return t.view(-1, *t.shape[2:])
+
+
 class BandFrame:
     def __init__(self, L, wl, t, device, modes_dev, rank=0, nranks=1, qp=22, transport=None, poison=False, gather=True, pool=None,
-                 slot=0):
+                 slot=0, arena=None):
         W, H, depth, alf = wl["W"], wl["H"], wl["depth"], wl["alf"]
         self.W, self.H, self.depth, self.alf, self.qp = W, H, depth, alf, qp
         self.rdoq = rdoq = bool(wl.get("rdoq", False))
@@ -97,27 +116,37 @@ class BandFrame:
         P = lambda t_: t_.data_ptr()
         y, u, v = layout.synthetic_yuv420(W, H, t, depth)
         self.host = (y, u, v)
-        self.y, self.u, self.v = dev(y), dev(u), dev(v)                    # the source picture (every rank holds all of it)
+        if arena is None:
+            self.y, self.u, self.v = dev(y), dev(u), dev(v)                # the source picture (every rank holds all of it)
+        else:
+            self.y, self.u, self.v = (arena.take(k, slot, a.shape, dev(a).dtype) for k, a in (("y", y), ("u", u), ("v", v)))
+            self.y.copy_(dev(y)); self.u.copy_(dev(u)); self.v.copy_(dev(v))
         ys, cs = self.y.stride(0), self.u.stride(0)
         qps = qp + 6 * (depth - 8)                                          # uvg_get_scaled_qp(0, qp, (depth-8)*6, ..) transform.c:150
         qpc = chroma_qp(qp) + 6 * (depth - 8)
         nm = modes_dev.shape[0]
         pz = 0x55 if poison else 0                                          # rows a rank does not own: a value no kernel produces by luck
 
-        def plane(like):
+        def plane(like, name=None):
+            if arena is not None and name is not None:
+                return arena.take(name, slot, like.shape, like.dtype, pz)
             return torch.full_like(like, pz) if poison else torch.zeros_like(like)
 
+        def vec(name, cnt, dtype):
+            return arena.take(name, slot, (cnt,), dtype) if arena is not None else torch.zeros(cnt, dtype=dtype, device=device)
+
         # ---- intra search / predict / TU round trip, per block size, for the blocks of the owned rows ----
-        self.tables, self.bufs, self.chains = {}, {}, []
+        self.tables, self.bufs, self.chains, self.own = {}, {}, [], {}
         self.rec_y = None
         for n in SIZES:
             allb = layout.intra_availability(layout.block_grid(W, H, n), n, W, H)
             own = allb[(allb[:, 1] >= y0) & (allb[:, 1] < y1)]
             cnt = len(own)
             blks, tus = api.make_intra_blocks(own, device), api.make_tus(own[:, :2], device)
-            b = {"best": torch.zeros(cnt, dtype=torch.int8, device=device), "cost": torch.zeros(cnt, dtype=torch.int32, device=device),
-                 "pred": plane(self.y), "rec": plane(self.y)}
+            b = {"best": vec(f"best{n}", cnt, torch.int8), "cost": vec(f"cost{n}", cnt, torch.int32),
+                 "pred": plane(self.y, f"pred{n}"), "rec": plane(self.y, f"rec{n}")}
             self.tables[n] = (blks, tus, cnt)
+            self.own[n] = own
             head = [
                 (f"intra_search_{n}", L.uvghip_intra_search_best_batch,
                  [depth, P(self.y), ys, P(self.y), ys, n, P(blks), cnt, P(modes_dev), nm, P(b["best"]), P(b["cost"]), None]),
@@ -131,7 +160,7 @@ class BandFrame:
                 cown = own // 2                                             # chroma block position and available reference counts
                 cblks, ctus = api.make_intra_blocks(cown, device), api.make_tus(cown[:, :2], device)
                 for name, src in (("u", self.u), ("v", self.v)):
-                    b["pred_" + name], b["rec_" + name] = plane(src), plane(src)
+                    b["pred_" + name], b["rec_" + name] = plane(src, f"pred{n}{name}"), plane(src, f"rec{n}{name}")
                 b["cblks"], b["ctus"] = cblks, ctus
                 for name, src in (("u", self.u), ("v", self.v)):
                     head.append((f"intra_pred_chroma_{n}", L.uvghip_intra_pred_plane_chroma_batch,
@@ -286,31 +315,76 @@ def quantiser_launches(L, fr, tag, color, c, qp_scaled, job, f0, nf):
 
 
 class FrameGroup:
-    """F pictures processed together: the plane kernels run per picture, the quantiser (RDOQ) once per block shape over
-    all F pictures -- the frame-parallel operation of an all-intra encode (uvg266 --owf)."""
+    """F pictures processed together (the frame-parallel operation of an all-intra encode, uvg266 --owf).  Their planes
+    live in a GroupArena, so every kernel that takes a block list -- rough search, predict, residual + forward
+    transform, RDOQ + dequantisation, inverse transform + reconstruction -- runs once per block shape over all F
+    pictures; the in-loop filters, which work on whole planes with picture-edge rules, run per picture."""
 
     def __init__(self, L, wl, t0, F, device, modes_dev, step=1, **kw):
         self.pool = TuPool(device, F)
-        self.frames = [BandFrame(L, wl, t0 + f * step, device, modes_dev, pool=self.pool, slot=f, **kw) for f in range(F)]
+        self.arena = GroupArena(F, device)
+        self.frames = [BandFrame(L, wl, t0 + f * step, device, modes_dev, pool=self.pool, slot=f, arena=self.arena, **kw) for f in range(F)]
         fr = self.frames[0]
         self.F, self.rdoq = F, fr.rdoq
-        depth = fr.depth
+        depth, H = fr.depth, fr.H
         qps, qpc = fr.qp + 6 * (depth - 8), chroma_qp(fr.qp) + 6 * (depth - 8)
-        self.mid = []
-        if fr.rdoq:
-            for (n, color), job in self.pool.jobs.items():
-                tag = f"{n}" if color == 0 else f"chroma_{n}"
-                self.mid += quantiser_launches(L, fr, tag, color, job["c"], qps if color == 0 else qpc, job, 0, F)
+        P = lambda t_: t_.data_ptr()
+        A = self.arena.stacked
+        nm = modes_dev.shape[0]
+        self._keep = []
+        self._searches, self._heads, self.mid, self._tails = [], [], [], []
+
+        def stack_blocks(per_frame, rows):
+            allb = np.concatenate([o + np.array([0, k * rows, 0, 0]) for k, o in enumerate(per_frame)])
+            blks, tus = api.make_intra_blocks(allb, device), api.make_tus(allb[:, :2], device)
+            self._keep += [blks, tus]
+            return blks, tus
+
+        def tu(tag, color, n, c, qp_scaled, orig, pred, rec, tus, cnt):
+            st = orig.stride(0)
+            j = self.pool.job((n, color), cnt // F, c)
+            if not fr.rdoq:
+                self._heads.append((f"tu_roundtrip_{tag}", L.uvghip_tu_roundtrip_batch,
+                                    [depth, 0, 0, 0, 0, c, c, qp_scaled, 1, P(orig), st, P(pred), st, P(rec), st, P(tus), cnt, P(j["lev"]), P(j["has"])]))
+                return
+            self._heads.append((f"tu_forward_{tag}", L.uvghip_tu_forward_batch,
+                                [depth, 0, 0, 0, 0, c, c, 0, P(orig), st, P(pred), st, P(tus), cnt, P(j["coef"])]))
+            self.mid += quantiser_launches(L, fr, tag, color, c, qp_scaled, j, 0, F)
+            self._tails.append((f"tu_inverse_{tag}", L.uvghip_tu_inverse_batch,
+                                [depth, 0, 0, 0, 0, c, c, 0, P(j["deq"]), P(pred), st, P(rec), st, P(tus), cnt]))
+
+        for n in SIZES:
+            cnt = fr.tables[n][2]
+            if cnt == 0:
+                continue
+            assert all(f.tables[n][2] == cnt for f in self.frames)
+            blks, tus = stack_blocks([f.own[n] for f in self.frames], H)
+            Y, ys = A("y"), A("y").stride(0)
+            best, cost = self.arena.t[f"best{n}"].view(-1), self.arena.t[f"cost{n}"].view(-1)
+            self._searches.append((f"intra_search_{n}", L.uvghip_intra_search_best_stacked_batch,
+                                   [depth, P(Y), ys, P(Y), ys, n, P(blks), F * cnt, P(modes_dev), nm, P(best), P(cost), None, H]))
+            self._heads.append((f"intra_pred_plane_{n}", L.uvghip_intra_pred_plane_stacked_batch,
+                                [depth, P(Y), ys, n, P(blks), F * cnt, P(best), P(A(f"pred{n}")), ys, H, 0]))
+            tu(f"{n}", 0, n, n, qps, Y, A(f"pred{n}"), A(f"rec{n}"), tus, F * cnt)
+            if n >= 8:
+                c = n // 2
+                cblks, ctus = stack_blocks([f.own[n] // 2 for f in self.frames], H // 2)
+                cs = A("u").stride(0)
+                for name in "uv":
+                    self._heads.append((f"intra_pred_chroma_{n}", L.uvghip_intra_pred_plane_stacked_batch,
+                                        [depth, P(A(name)), cs, c, P(cblks), F * cnt, P(best), P(A(f"pred{n}{name}")), cs, H // 2, 1]))
+                for ci, name in enumerate("uv"):
+                    tu(f"chroma_{n}", 1 + ci, n, c, qpc, A(name), A(f"pred{n}{name}"), A(f"rec{n}{name}"), ctus, F * cnt)
 
     def searches(self):
-        return [h[0] for fr in self.frames for h in fr.heads if h]
+        return list(self._searches)
 
     def heads_rest(self):
-        """Per picture: predict + residual / forward transform (everything of the heads but the searches)."""
-        return [l for fr in self.frames for h in fr.heads for l in h[1:]]
+        """Predict + residual / forward transform (everything before the quantiser but the searches), once per block shape."""
+        return list(self._heads)
 
     def tails(self):
-        return [l for fr in self.frames for tl in fr.tails for l in tl]
+        return list(self._tails)
 
     def before_filters(self):
         """Everything between the searches and the in-loop filters, in an order that respects the dependencies."""
