@@ -546,49 +546,48 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
         const uint32_t pos_y = (uint32_t)blkpos >> l2w, pos_x = (uint32_t)blkpos - (pos_y << l2w);
         const int mx = (int)sLev[blkpos];
         const bool is_last = scanpos == last_scanpos;
-        int ctx_sig = 0, ctx_set = 0;
-        if (!is_last) {                                                // context_get_sig_ctx_idx_abs + the ctx_set line, as rdoq_decide
-          int nb[5]; bool has[5];
-          neighbours(blkpos, pos_x, pos_y, nb, has);
-          const bool zz[5] = {mts && pos_x + 1 >= 16, mts && pos_x + 2 >= 16, mts && (pos_y + 1 >= 16 || pos_x + 1 >= 16),
-                              mts && pos_x + 1 >= 16, mts && pos_x + 2 >= 16};
-          int num_pos = 0, sum_abs = 0;
+        // Straight-line code (selects instead of branches: with 16 blocks in the wave every branch is taken by some lane anyway,
+        // and each divergent branch costs an exec-mask save / restore and a jump).
+        // context_get_sig_ctx_idx_abs + the ctx_set line, as rdoq_decide: an absent neighbour reads the position itself and counts as 0
+        const bool hx1 = pos_x < (uint32_t)width - 1, hx2 = pos_x < (uint32_t)width - 2;
+        const bool hy1 = pos_y < (uint32_t)height - 1, hy2 = pos_y < (uint32_t)height - 2;
+        const int16_t *Lv = sLev + blkpos;
+        const bool zx1 = mts && pos_x + 1 >= 16, zx2 = mts && pos_x + 2 >= 16, zy1 = mts && pos_y + 1 >= 16;
+        const int r0 = Lv[hx1 ? 1 : 0], r1 = Lv[hx2 ? 2 : 0], r2 = Lv[(hx1 && hy1) ? width + 1 : 0], r3 = Lv[hy1 ? width : 0],
+                  r4 = Lv[hy2 ? 2 * width : 0];
+        // (zero-out tests of the "below" terms use pos_x, as the reference does, rdo.c:1425)
+        const int nbv[5] = {(hx1 && !zx1) ? abs(r0) : 0, (hx2 && !zx2) ? abs(r1) : 0, (hx1 && hy1 && !(zy1 || zx1)) ? abs(r2) : 0,
+                            (hy1 && !zx1) ? abs(r3) : 0, (hy2 && !zx2) ? abs(r4) : 0};
+        int num_pos = 0, sum_abs = 0;
 #pragma unroll
-          for (int k = 0; k < 5; ++k)
-            if (has[k]) { const int a = zz[k] ? 0 : abs(nb[k]); sum_abs += min(4 + (a & 1), a); num_pos += a ? 1 : 0; }
-          const int diag = (int)(pos_x + pos_y);
-          ctx_sig = min((sum_abs + 1) >> 1, 3) + (diag < 2 ? 4 : 0);
-          if (t == 0) ctx_sig += diag < 5 ? 4 : 0;
-          const int temp_sum = sum_abs - num_pos;
-          ctx_set = (min(temp_sum, 4) + 1) + (!diag ? ((t == 0) ? 15 : 5) : (t == 0) ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0);
-        }
+        for (int k = 0; k < 5; ++k) { sum_abs += min(4 + (nbv[k] & 1), nbv[k]); num_pos += nbv[k] ? 1 : 0; }
+        const int diag = (int)(pos_x + pos_y);
+        int ctx_sig = min((sum_abs + 1) >> 1, 3) + (diag < 2 ? 4 : 0) + ((t == 0 && diag < 5) ? 4 : 0);
+        int ctx_set = (min(sum_abs - num_pos, 4) + 1) + (!diag ? ((t == 0) ? 15 : 5) : (t == 0) ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0);
+        ctx_sig = is_last ? 0 : ctx_sig;                               // the last significant position is the first one visited: no context
+        ctx_set = is_last ? 0 : ctx_set;
         const double c0 = D[3 * s4 + 2];
         const uint32_t sig0 = B[O_SIG + 12 * t + ctx_sig][0], sig1 = B[O_SIG + 12 * t + ctx_sig][1];
-        int level = 0, sig_code = 0;
-        double cs = 0, cc;
-        if (!is_last && mx < 3) {                                      // uvg_get_coded_level, rdo.c:612-640
-          cs = lambda * (double)sig0;
-          cc = c0 + cs;
-          sig_code = 1 + 2 * ctx_sig;
-        } else {
-          cc = 1.7e+308;
-        }
-        if (mx > 0) {
-          const double cur_cost_sig = is_last ? 0.0 : lambda * (double)sig1;
-          const uint32_t par0 = B[O_PAR + 21 * t + ctx_set][0], par1 = B[O_PAR + 21 * t + ctx_set][1];
-          const uint32_t g10 = B[O_GT1 + 21 * t + ctx_set][0], g11 = B[O_GT1 + 21 * t + ctx_set][1];
-          const uint32_t g20 = B[O_GT2 + 21 * t + ctx_set][0], g21 = B[O_GT2 + 21 * t + ctx_set][1];
+        const uint32_t par0 = B[O_PAR + 21 * t + ctx_set][0], par1 = B[O_PAR + 21 * t + ctx_set][1];
+        const uint32_t g10 = B[O_GT1 + 21 * t + ctx_set][0], g11 = B[O_GT1 + 21 * t + ctx_set][1];
+        const uint32_t g20 = B[O_GT2 + 21 * t + ctx_set][0], g21 = B[O_GT2 + 21 * t + ctx_set][1];
+        // uvg_get_coded_level, rdo.c:612-640: "not significant" where allowed, then the candidates mx and mx - 1 (those >= 1)
+        const bool zero_ok = !is_last && mx < 3;
+        const double cs0 = lambda * (double)sig0;
+        double cc = zero_ok ? c0 + cs0 : 1.7e+308, cs = zero_ok ? cs0 : 0.0;
+        int level = 0, sig_code = zero_ok ? 1 + 2 * ctx_sig : 0;
+        const double cur_cost_sig = is_last ? 0.0 : lambda * (double)sig1;
+        const int code_sig = is_last ? 0 : 2 + 2 * ctx_sig;
 #pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const int a = mx - c;
-            if (a < 1) break;
-            // the context-coded flags of uvg_get_ic_rate (:549-571): gt1; for levels >= 2 parity and gt2
-            int rate = I[3 * s4 + c] + (int)(a >= 2 ? g11 : g10);
-            if (a >= 2) rate += (int)((a & 1) ? par1 : par0) + (int)(a >= 4 ? g21 : g20);
-            double cur = D[3 * s4 + c] + lambda * (double)rate;
-            cur += cur_cost_sig;
-            if (cur < cc) { level = a; cc = cur; cs = cur_cost_sig; sig_code = is_last ? 0 : 2 + 2 * ctx_sig; }
-          }
+        for (int c = 0; c < 2; ++c) {
+          const int a = mx - c;                                          // (a < 1: the staged halves are stale, the result is not taken)
+          // the context-coded flags of uvg_get_ic_rate (:549-571): gt1; for levels >= 2 parity and gt2
+          const int flags = a >= 2 ? (int)g11 + (int)((a & 1) ? par1 : par0) + (int)(a >= 4 ? g21 : g20) : (int)g10;
+          const int rate = I[3 * s4 + c] + flags;
+          double cur = D[3 * s4 + c] + lambda * (double)rate;
+          cur += cur_cost_sig;
+          const bool take = a >= 1 && cur < cc;
+          level = take ? a : level; cc = take ? cur : cc; cs = take ? cur_cost_sig : cs; sig_code = take ? code_sig : sig_code;
         }
         if (SIGNHIDE) {
           const int go_rice = (is_last || s4 == 15) ? 0 : rice_at(blk_in(g, in_cg(s4 + 1)));
