@@ -282,6 +282,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   const rdoq_params &P = sP;
   __shared__ uint32_t sB[N_CTX][2];
   __shared__ int sLastX[32], sLastY[32];
+  __shared__ int sLastXp[32], sLastYp[32];                             // get_rate_last (:645-658) per coordinate: prefix bits + suffix bits
   __shared__ uint8_t sScanCg[64];
   // per group and position s4: D[3*s4 + {0: distortion of candidate 1 -> coded_cost, 1: candidate 2 -> coded_sig, 2: cost0}],
   // I[3*s4 + {0: rate half of candidate 1 -> level, 1: candidate 2, 2: level_double}]
@@ -326,6 +327,8 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       sLastY[c] = bits + (int)sB[o][0]; bits += (int)sB[o][1];
     }
     sLastY[c] = bits;
+    for (int p = 0; p < width; ++p) { const int cx = group_idx(p); sLastXp[p] = sLastX[cx] + (cx > 3 ? (int)(32768u * (uint32_t)((cx - 2) >> 1)) : 0); }
+    for (int p = 0; p < height; ++p) { const int cy = group_idx(p); sLastYp[p] = sLastY[cy] + (cy > 3 ? (int)(32768u * (uint32_t)((cy - 2) >> 1)) : 0); }
   }
   __syncthreads();
   // ---- a workgroup takes batches of TUS blocks until none are left: the tables above are built once ----
@@ -490,42 +493,40 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
         const int mx = (int)((uint32_t)(ld + (1 << (q_bits - 1))) >> q_bits);
         const bool walked = in_walk && scanpos <= last_scanpos;
         const double c0 = cost0_of(ld);
-        D[3 * s4 + 2] = c0;
-        I[3 * s4 + 2] = ld;
-        I[3 * s4] = 0;
-        if (!walked) { D[3 * s4] = c0; D[3 * s4 + 1] = 0.0; }          // beyond the last significant position: base_cost += cost_coeff0 (:1585)
-        sLev[blkpos] = (int16_t)(walked ? mx : 0);
-        if (walked) {
-          spend += (unsigned)(mx < 2 ? mx : 3) + 1;
-          if (mx > 0) {
-            // Rice parameter left by the previously visited position (scanpos + 1): reset after every 16th (:1692), else the
-            // context-free value of that position; the last significant position starts with 0
-            const int go_rice = (scanpos == last_scanpos || s4 == 15) ? 0 : rice_at(blk_in(g, in_cg(s4 + 1)));
+        // straight-line (see the phases): the candidates mx and mx - 1 are staged whether they exist or not -- a phase only takes
+        // candidates >= 1 -- and a position beyond the last significant one gets cost_coeff0 / 0 (:1585: base_cost += cost_coeff0)
+        // Rice parameter left by the previously visited position (scanpos + 1): reset after every 16th (:1692), else the
+        // context-free value of that position; the last significant position starts with 0
+        const int rice_next = rice_at(blk_in(g, in_cg((s4 + 1) & 15)));
+        const int go_rice = (scanpos == last_scanpos || s4 == 15) ? 0 : rice_next;
+        double dist[2]; int rate[2];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-              const int a = mx - c;
-              if (a < 1) break;
-              const double err = (double)(ld - (a * (1 << q_bits)));
-              D[3 * s4 + c] = err * err * error_scale;
-              int rate = 1 << 15;                                      // sign
-              if (a >= 4) {                                            // remainder of abs_level - 4, rdo.c:520-547
-                const int thr = 5, max_log2 = 15;
-                const int symbol = a - 4;
-                if (symbol < (thr << go_rice)) {
-                  rate += ((symbol >> go_rice) + 1 + go_rice) << 15;
-                } else {
-                  const uint32_t max_prefix = 32 - (thr + max_log2);
-                  uint32_t prefix = 0;
-                  const uint32_t suffix = (uint32_t)(symbol >> go_rice) - thr;
-                  while (prefix < max_prefix && (int)suffix > ((2 << prefix) - 2)) prefix++;
-                  const uint32_t suffix_len = prefix == max_prefix ? (uint32_t)(max_log2 - go_rice) : prefix + 1;
-                  rate += (int)((thr + prefix + suffix_len + go_rice) << 15);
-                }
-              }
-              I[3 * s4 + c] = rate;
-            }
+        for (int c = 0; c < 2; ++c) {
+          const int a = mx - c;
+          const double err = (double)(ld - (a * (1 << q_bits)));
+          dist[c] = err * err * error_scale;
+          // sign + the remainder of abs_level - 4 (rdo.c:520-547)
+          const int thr = 5, max_log2 = 15;
+          const int symbol = a - 4;
+          int golomb = ((symbol >> go_rice) + 1 + go_rice) << 15;
+          if (a >= 4 && symbol >= (thr << go_rice)) {                    // escape code: rare
+            const uint32_t max_prefix = 32 - (thr + max_log2);
+            uint32_t prefix = 0;
+            const uint32_t suffix = (uint32_t)(symbol >> go_rice) - thr;
+            while (prefix < max_prefix && (int)suffix > ((2 << prefix) - 2)) prefix++;
+            const uint32_t suffix_len = prefix == max_prefix ? (uint32_t)(max_log2 - go_rice) : prefix + 1;
+            golomb = (int)((thr + prefix + suffix_len + go_rice) << 15);
           }
+          rate[c] = (1 << 15) + (a >= 4 ? golomb : 0);
         }
+        D[3 * s4] = walked ? dist[0] : c0;
+        D[3 * s4 + 1] = walked ? dist[1] : 0.0;
+        D[3 * s4 + 2] = c0;
+        I[3 * s4] = walked ? rate[0] : 0;                                // (a position that is not walked reads as level 0 in the replay)
+        I[3 * s4 + 1] = rate[1];
+        I[3 * s4 + 2] = ld;
+        sLev[blkpos] = (int16_t)(walked ? mx : 0);
+        spend += walked ? (unsigned)(mx < 2 ? mx : 3) + 1 : 0u;
       }
     spend = quad_sum(spend);
     // Only the group in which the regular-bin budget could fall below 4 is walked position by position: before it the
@@ -798,50 +799,50 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       base_cost -= quad_bcast<0>(pf_cg);
       const bool coded = (sig_cg >> g) & 1;
       unsigned mnz = 0, mgt1 = 0;
+      // straight-line: per position what the pass subtracts from base_cost (cost_coeff of a level, cost_sig of a zero), what it
+      // adds back (cost_coeff0 of a level), cost_sig, and the bits of "last position here"; nothing for positions past the
+      // last significant one
       if (coded)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int s4 = j + 4 * r;
-          if (s4 > max_group || cgs * 16 + s4 > last_scanpos) continue;
-          const int b2 = blk_in(g, in_cg(s4));
+          const bool valid = s4 <= max_group && cgs * 16 + s4 <= last_scanpos;
+          const int b2 = blk_in(g, in_cg(s4 <= max_group ? s4 : 0));
           const int lv = sLev[b2];
-          D[3 * s4 + 1] = sig_cost_of(pf_sig[r]);
-          if (lv) {                                                      // get_rate_last (:645-658) without the final lambda *
-            mnz |= 1u << s4;
-            if (lv > 1) mgt1 |= 1u << s4;
-            D[3 * s4] = pf_cost[r];
-            D[3 * s4 + 2] = cost0_of(level_double_of(pf_coef[r]));
-            const uint32_t py = (uint32_t)b2 >> l2w, px = (uint32_t)b2 - (py << l2w);
-            const uint32_t cx = (uint32_t)group_idx((int)px), cy = (uint32_t)group_idx((int)py);
-            int ui = sLastX[cx] + sLastY[cy];
-            if (cx > 3) ui += (int)(32768u * ((cx - 2) >> 1));
-            if (cy > 3) ui += (int)(32768u * ((cy - 2) >> 1));
-            I[3 * s4 + 1] = ui;
-          }
+          const bool nz = valid && lv != 0;
+          const double cs = sig_cost_of(valid ? pf_sig[r] : 0);
+          const double c0 = cost0_of(level_double_of(pf_coef[r]));
+          D[3 * s4] = nz ? pf_cost[r] : cs;
+          D[3 * s4 + 1] = cs;
+          D[3 * s4 + 2] = nz ? c0 : 0.0;
+          const uint32_t py = (uint32_t)b2 >> l2w, px = (uint32_t)b2 - (py << l2w);
+          I[3 * s4 + 1] = sLastXp[px] + sLastYp[py];                     // get_rate_last without the final lambda *
+          mnz |= (nz ? 1u : 0u) << s4;
+          mgt1 |= ((nz && lv > 1) ? 1u : 0u) << s4;
         }
       if (cgs > 0) prefetch(cgs - 1);
       WAVE_SYNC();
       if (coded) {
         mnz = quad_or(mnz); mgt1 = quad_or(mgt1);
 #pragma unroll
-        for (int half = 1; half >= 0; --half) {
-          double csv[8];
+        for (int part = 3; part >= 0; --part) {
+          double sub[4], add[4], csv[4]; int ui[4];
 #pragma unroll
-          for (int u = 7; u >= 0; --u) csv[u] = D[3 * (8 * half + u) + 1];   // (positions not staged: stale, unused)
+          for (int u = 3; u >= 0; --u) {
+            const int s2 = 4 * part + u;
+            sub[u] = D[3 * s2]; csv[u] = D[3 * s2 + 1]; add[u] = D[3 * s2 + 2]; ui[u] = I[3 * s2 + 1];
+          }
 #pragma unroll
-          for (int u = 7; u >= 0; --u) {
-            const int s2 = 8 * half + u, sc2 = cgs * 16 + s2;
-            if (s2 > max_group || sc2 > last_scanpos || found_last) continue;
-            if ((mnz >> s2) & 1) {
-              const double cost_last = lambda * (double)I[3 * s2 + 1];
-              const double total = base_cost + cost_last - csv[u];
-              if (total < best_cost) { best_last_idx_p1 = sc2 + 1; best_cost = total; }
-              if ((mgt1 >> s2) & 1) { found_last = true; continue; }
-              base_cost -= D[3 * s2];
-              base_cost += D[3 * s2 + 2];
-            } else {
-              base_cost -= csv[u];
-            }
+          for (int u = 3; u >= 0; --u) {
+            const int s2 = 4 * part + u, sc2 = cgs * 16 + s2;
+            const bool nz = (mnz >> s2) & 1;
+            const double total = base_cost + lambda * (double)ui[u] - csv[u];
+            const bool upd = nz && !found_last && total < best_cost;
+            best_last_idx_p1 = upd ? sc2 + 1 : best_last_idx_p1;
+            best_cost = upd ? total : best_cost;
+            found_last = found_last || ((mgt1 >> s2) & 1);               // (the reference stops here; base_cost is not used any more)
+            base_cost -= sub[u];
+            base_cost += add[u];
           }
         }
       }
