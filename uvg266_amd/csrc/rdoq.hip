@@ -380,16 +380,14 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
         const int pos = 4 * q4 + k;
         const uint32_t pos_y = (uint32_t)pos >> l2w, pos_x = (uint32_t)pos - (pos_y << l2w);
         const int16_t *c0p = sLev + pos;
-        int16_t sum = 0;                                               // coeff_t accumulator: wraps like the reference's
-        if (pos_x < (uint32_t)width - 1) {
-          sum = (int16_t)(sum + ((mts && pos_x + 1 >= 16) ? 0 : abs((int)c0p[1])));
-          if (pos_x < (uint32_t)width - 2) sum = (int16_t)(sum + ((mts && pos_x + 2 >= 16) ? 0 : abs((int)c0p[2])));
-          if (pos_y < (uint32_t)height - 1) sum = (int16_t)(sum + ((mts && (pos_y + 1 >= 16 || pos_x + 1 >= 16)) ? 0 : abs((int)c0p[width + 1])));
-        }
-        if (pos_y < (uint32_t)height - 1) {
-          sum = (int16_t)(sum + ((mts && pos_y + 1 >= 16) ? 0 : abs((int)c0p[width])));
-          if (pos_y < (uint32_t)height - 2) sum = (int16_t)(sum + ((mts && (pos_y + 2 >= 16)) ? 0 : abs((int)c0p[2 * width])));
-        }
+        // straight-line: an absent neighbour reads the position itself and counts as zero; coeff_t accumulator: wraps like the reference's
+        const bool hx1 = pos_x < (uint32_t)width - 1, hx2 = pos_x < (uint32_t)width - 2;
+        const bool hy1 = pos_y < (uint32_t)height - 1, hy2 = pos_y < (uint32_t)height - 2;
+        const bool zx1 = mts && pos_x + 1 >= 16, zx2 = mts && pos_x + 2 >= 16, zy1 = mts && pos_y + 1 >= 16, zy2 = mts && pos_y + 2 >= 16;
+        const int r0 = c0p[hx1 ? 1 : 0], r1 = c0p[hx2 ? 2 : 0], r2 = c0p[(hx1 && hy1) ? width + 1 : 0], r3 = c0p[hy1 ? width : 0],
+                  r4 = c0p[hy2 ? 2 * width : 0];
+        const int16_t sum = (int16_t)(((hx1 && !zx1) ? abs(r0) : 0) + ((hx2 && !zx2) ? abs(r1) : 0) + ((hx1 && hy1 && !(zy1 || zx1)) ? abs(r2) : 0) +
+                                      ((hy1 && !zy1) ? abs(r3) : 0) + ((hy2 && !zy2) ? abs(r4) : 0));
         packed |= (unsigned)go_rice_par(clampi((int)sum - 20, 0, 31)) << (2 * k);
       }
       sRice[q4] = (uint8_t)packed;
