@@ -536,6 +536,8 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
     const bool any_slow = __any(slow), any_exh = __any(in_walk && exhausted);
     WAVE_SYNC();
     // -- the positions of one anti-diagonal decide together (their neighbours lie on later anti-diagonals) --
+    constexpr int PHASE_UNROLL = SHAPE == 2 ? 1 : 7;                   // (4x4: one group, and the unrolled body would spill at three waves per SIMD)
+#pragma unroll PHASE_UNROLL
     for (int dg = 6; dg >= 0; --dg) {
       const int cnt = dg <= 3 ? dg + 1 : 7 - dg;
       const int s4 = (dg <= 3 ? dg * (dg + 1) / 2 : 16 - (7 - dg) * (8 - dg) / 2) + j;   // scan index inside the group
