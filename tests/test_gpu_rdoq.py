@@ -69,6 +69,32 @@ def test_random_batches_vs_oracle(hip, orc, depth):
     assert checked > 3000 and total_nz > 1500
 
 
+@pytest.mark.parametrize("depth", [8, 10])
+def test_bin_budget_edge_vs_oracle(hip, orc, depth):
+    """Blocks whose regular-bin budget (28 bins per 16 coefficients, rdo.c:1470) runs out somewhere inside a coefficient
+    group, right at its end, or just not: flat spectra over a fine sweep of amplitudes, so that the kernel's choice between
+    the anti-diagonal phases and the position-by-position walk of a group lands on both sides of every threshold."""
+    import torch
+    from uvg266_amd import api
+    rng = np.random.default_rng(7 + depth)
+    checked = 0
+    for w, h, n in ((4, 4, 1600), (8, 8, 480), (16, 16, 96), (8, 4, 300)):
+        qp = 27
+        qps = qp + 6 * (depth - 8)
+        lam = 0.57 * 2.0 ** ((qp - 12) / 3.0)
+        ctx = rng.integers(40, 216, 244).astype(np.uint8)
+        step = 2.0 ** ((qps - 4) / 6.0) * (1 << max(0, 15 - depth - ((int(np.log2(w)) + int(np.log2(h))) >> 1)))
+        amp = np.linspace(0.4, 6.0, n)[:, None, None] * step
+        coef = np.clip(rng.uniform(-1, 1, (n, h, w)) * amp, -32768, 32767).astype(np.int16)
+        lv, s, has = api.rdoq_batch(torch.from_numpy(coef).cuda(), depth, 0, 1, 0, 0, 0, qps, lam, ctx)
+        lv = lv.cpu().numpy()
+        for b in range(n):
+            want, ws = orc.rdoq(depth, coef[b], w, h, 0, 1, 0, 0, 0, qps, lam, ctx)
+            assert np.array_equal(lv[b].ravel(), want), (w, h, b)
+        checked += n
+    assert checked > 2000
+
+
 def test_workspace_is_required(hip):
     import ctypes
     import torch

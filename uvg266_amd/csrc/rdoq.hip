@@ -524,7 +524,9 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
         I[3 * s4 + 1] = rate[1];
         I[3 * s4 + 2] = ld;
         sLev[blkpos] = (int16_t)(walked ? mx : 0);
-        spend += walked ? (unsigned)(mx < 2 ? mx : 3) + 1 : 0u;
+        // (what the positions decided BEFORE the group's last one can spend at most, :1695-1696: scan position 0 of a group is the
+        // last one decided, and the last significant position spends no significance bin)
+        spend += (walked && s4 >= 1) ? (unsigned)(mx < 2 ? mx : 3) + (scanpos != last_scanpos ? 1u : 0u) : 0u;
       }
     spend = quad_sum(spend);
     // Only the group in which the regular-bin budget could fall below 4 is walked position by position: before it the
