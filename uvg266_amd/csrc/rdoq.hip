@@ -539,6 +539,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
     WAVE_SYNC();
     // -- the positions of one anti-diagonal decide together (their neighbours lie on later anti-diagonals) --
     constexpr int PHASE_UNROLL = SHAPE == 2 ? 1 : 7;                   // (4x4: one group, and the unrolled body would spill at three waves per SIMD)
+    if (__any(plain))                                                  // (sparse planes: most groups lie beyond every block's last position)
 #pragma unroll PHASE_UNROLL
     for (int dg = 6; dg >= 0; --dg) {
       const int cnt = dg <= 3 ? dg + 1 : 7 - dg;
