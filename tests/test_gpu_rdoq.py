@@ -95,6 +95,33 @@ def test_bin_budget_edge_vs_oracle(hip, orc, depth):
     assert checked > 2000
 
 
+@pytest.mark.parametrize("depth", [8, 10])
+def test_large_levels_vs_oracle(hip, orc, depth):
+    """Levels far above 254 at a low QP, dense enough to exhaust the regular-bin budget: the 32x32 kernel keeps clamped levels
+    (254 + parity) in LDS and must fetch the exact neighbours for the template sums of the bypass-coded part (their int16
+    accumulator wraps, rdo.c:846-871); other shapes keep exact levels throughout."""
+    import torch
+    from uvg266_amd import api
+    rng = np.random.default_rng(41 + depth)
+    for w, h, n in ((32, 32, 10), (16, 16, 12), (32, 16, 6)):
+        for qp, amp in ((2, 32767), (7, 9000), (12, 2500)):
+            qps = qp + 6 * (depth - 8)
+            lam = 0.57 * 2.0 ** ((qp - 12) / 3.0)
+            ctx = rng.integers(30, 226, 244).astype(np.uint8)
+            coef = rng.integers(-amp, amp + 1, (n, h, w)).astype(np.int16)
+            coef[n // 2:, h // 2:, :] //= 64                            # some blocks with a quiet half
+            lv, s, has = api.rdoq_batch(torch.from_numpy(coef).cuda(), depth, 0, 1, 0, 0, 0, qps, lam, ctx)
+            lv, s = lv.cpu().numpy(), s.cpu().numpy()
+            big = 0
+            for b in range(n):
+                want, ws = orc.rdoq(depth, coef[b], w, h, 0, 1, 0, 0, 0, qps, lam, ctx)
+                assert np.array_equal(lv[b].ravel(), want), (w, h, qp, b)
+                assert s[b] == ws
+                big += int((np.abs(want.astype(np.int32)) >= 254).sum())
+            if amp >= 9000:
+                assert big > 100, (w, h, qp, big)
+
+
 def test_workspace_is_required(hip):
     import ctypes
     import torch

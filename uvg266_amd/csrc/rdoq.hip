@@ -22,12 +22,17 @@
 #include "vvc_rdoq_tables.h"
 #include <cmath>
 #include <mutex>
+#include <cstdio>
 
 namespace {
 
 enum : int { O_SIGGRP = 0, O_SIG = 4, O_PAR = 28, O_GT1 = 70, O_GT2 = 112, O_LASTX = 154, O_LASTY = 194, O_CBF_Y = 234, O_CBF_CB = 238,
              O_CBF_CR = 240, O_ROOT = 243, N_CTX = 244 };
 static_assert(sizeof(uvghip_rdoq_ctx_t) == N_CTX, "uvghip_rdoq_ctx_t layout");
+// the kernel's LDS table of the models' bit costs leaves out the 80 last-position models (they only feed the two small
+// per-coordinate tables built at kernel start): the models behind them move down
+enum : int { S_DROP = O_CBF_Y - O_LASTX, S_CBF_Y = O_CBF_Y - S_DROP, S_CBF_CB = O_CBF_CB - S_DROP, S_CBF_CR = O_CBF_CR - S_DROP,
+             S_ROOT = O_ROOT - S_DROP, N_CTXS = N_CTX - S_DROP };
 
 struct rdoq_params {
   int width, height, l2w, l2h, n;
@@ -222,9 +227,81 @@ __device__ __forceinline__ rdoq_decision rdoq_decide(const rdoq_params &P, const
 // LDS bytes of one block: level int16[wh] (holds the input coefficient until the position's group is staged) + the Rice
 // parameters, four per byte; block strides are odd in words so that the same position of the 16 blocks of a wave falls into
 // 16 different banks
-__host__ __device__ constexpr size_t rdoq_lds_per_block(int wh)
+// bytes == true (32x32 blocks): the level array holds bytes -- levels clamped to 254 + parity, which keeps every context of the
+// walk exact -- and no input coefficients: the exact levels go to the output as they are decided, the input is read from
+// global memory a group ahead.  1284 instead of 2308 bytes per block: five workgroups per CU instead of three.
+__host__ __device__ constexpr size_t rdoq_lds_per_block(int wh, bool bytes = false)
 {
-  return ((((size_t)wh * 2 + wh / 4) >> 2) & 1) ? (size_t)wh * 2 + wh / 4 : (size_t)wh * 2 + wh / 4 + 4;
+  const size_t raw = (size_t)wh * (bytes ? 1 : 2) + wh / 4;
+  return ((raw >> 2) & 1) ? raw : raw + 4;
+}
+
+// Everything about a block that does not depend on decisions, in one fully parallel pass in front of the walk (one thread per
+// four positions of a row, whole blocks per workgroup):
+//   * the Rice parameter after each position: templateAbsSum(coef, 4, ...) over the INPUT block (rdo.c:846-871, 1697), two
+//     bits per position, four positions per byte -> rice_out[block][wh / 4];
+//   * the last significant position (rdo.c:1561-1592): the highest scan position whose rounded level is non-zero, -1 if
+//     none -> last_out[block].
+__global__ void __launch_bounds__(256)
+rdoq_pre_kernel(const rdoq_params P, const int16_t *__restrict__ coef, uint8_t *__restrict__ rice_out, int *__restrict__ last_out)
+{
+  __shared__ uint8_t sInv[64];                                         // coefficient-group raster index -> index in scan order
+  __shared__ int sLast[64];
+  const int width = P.width, height = P.height, l2w = P.l2w, wh = width * height, n = P.n;
+  const int l2cgw = l2w - 2, cgw = 1 << l2cgw, cgh = height >> 2;
+  const int mts = P.mts_idx;
+  const int bpw = 1024 / wh, blk0 = blockIdx.x * bpw;
+  if ((int)threadIdx.x < cgw * cgh) {
+    // H.266 6.5.2 on the coefficient-group grid, every group for itself: the groups of the earlier anti-diagonals, then
+    // those before it on its own (an anti-diagonal runs from its bottom-left end upwards: x ascending)
+    const int cx = threadIdx.x & (cgw - 1), cy = threadIdx.x >> l2cgw, d = cx + cy;
+    int idx = cx - max(0, d - (cgh - 1));
+    for (int e = 0; e < d; ++e) idx += min(e, cgw - 1) - max(0, e - (cgh - 1)) + 1;
+    sInv[threadIdx.x] = (uint8_t)idx;
+  }
+  if (threadIdx.x < 64) sLast[threadIdx.x] = -1;
+  __syncthreads();
+  const int pos4 = threadIdx.x * 4, b = pos4 / wh, pos0 = pos4 - b * wh, tu = blk0 + b;
+  if (tu < n) {
+    const int16_t *c = coef + (size_t)tu * wh;
+    const int q_bits = P.q_bits, q = P.q;
+    const int cap = 0x7fffffff - (1 << (q_bits - 1));
+    const int cg_num = P.lfnst_idx > 0 ? 1 : wh >> 4;
+    const int max_group = P.lfnst_idx > 0 ? (((height == 4 && width == 4) || (height == 8 && width == 8)) ? 7 : 15) : 15;
+    constexpr unsigned long long kInvDiag4 = 0xFDA6EB73C8419520ull;    // (y * 4 + x) inside a 4x4 group -> index in its up-right diagonal scan
+    unsigned packed = 0;
+    int last = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int pos = pos0 + k;
+      const uint32_t pos_y = (uint32_t)pos >> l2w, pos_x = (uint32_t)pos - (pos_y << l2w);
+      const int16_t *c0p = c + pos;
+      const bool hx1 = pos_x < (uint32_t)width - 1, hx2 = pos_x < (uint32_t)width - 2;
+      const bool hy1 = pos_y < (uint32_t)height - 1, hy2 = pos_y < (uint32_t)height - 2;
+      const bool zx1 = mts && pos_x + 1 >= 16, zx2 = mts && pos_x + 2 >= 16, zy1 = mts && pos_y + 1 >= 16, zy2 = mts && pos_y + 2 >= 16;
+      const int r0 = c0p[hx1 ? 1 : 0], r1 = c0p[hx2 ? 2 : 0], r2 = c0p[(hx1 && hy1) ? width + 1 : 0], r3 = c0p[hy1 ? width : 0],
+                r4 = c0p[hy2 ? 2 * width : 0];
+      // coeff_t accumulator: wraps like the reference's
+      const int16_t sum = (int16_t)(((hx1 && !zx1) ? abs(r0) : 0) + ((hx2 && !zx2) ? abs(r1) : 0) + ((hx1 && hy1 && !(zy1 || zx1)) ? abs(r2) : 0) +
+                                    ((hy1 && !zy1) ? abs(r3) : 0) + ((hy2 && !zy2) ? abs(r4) : 0));
+      packed |= (unsigned)go_rice_par(clampi((int)sum - 20, 0, 31)) << (2 * k);
+      // is this position a candidate for the last significant one?
+      const int g = (int)((pos_y >> 2) << l2cgw) + (int)(pos_x >> 2);
+      const int cgs = sInv[g];
+      const int s4 = (int)((kInvDiag4 >> (4 * ((pos_y & 3) * 4 + (pos_x & 3)))) & 15);
+      const bool skipped = mts != 0 && ((g >> l2cgw) >= 4 || (g & (cgw - 1)) >= 4);
+      const long long prod = (long long)abs((int)c0p[0]) * q;
+      const int ld = (int)(prod < cap ? prod : cap);
+      const bool sig = ((uint32_t)(ld + (1 << (q_bits - 1))) >> q_bits) > 0;
+      if (sig && cgs < cg_num && !skipped && s4 <= max_group) last = max(last, cgs * 16 + s4);
+    }
+    rice_out[(size_t)tu * (wh >> 2) + (pos0 >> 2)] = (uint8_t)packed;
+    // the lanes of one block inside a wave (wh / 4 of them, an aligned power of two) reduce first
+    for (int o = min(32, wh >> 3); o; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+    if ((threadIdx.x & (min(64, wh >> 2) - 1)) == 0 && last >= 0) atomicMax(&sLast[b], last);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < bpw && blk0 + (int)threadIdx.x < n) last_out[blk0 + threadIdx.x] = sLast[threadIdx.x];
 }
 
 // value of lane K of the caller's quad (DPP quad_perm broadcast; all four lanes of a block's quad are active together)
@@ -280,8 +357,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
     reinterpret_cast<uint32_t *>(&sP)[i] = reinterpret_cast<const uint32_t *>(&Pk)[i];
   __syncthreads();
   const rdoq_params &P = sP;
-  __shared__ uint32_t sB[N_CTX][2];
-  __shared__ int sLastX[32], sLastY[32];
+  __shared__ uint32_t sB[N_CTXS][2];
   __shared__ int sLastXp[32], sLastYp[32];                             // get_rate_last (:645-658) per coordinate: prefix bits + suffix bits
   __shared__ uint8_t sScanCg[64];
   // per group and position s4: D[3*s4 + {0: distortion of candidate 1 -> coded_cost, 1: candidate 2 -> coded_sig, 2: cost0}],
@@ -292,14 +368,19 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   const int l2w = SHAPE ? SHAPE : P.l2w, l2h_ = SHAPE ? SHAPE : P.l2h;
   const int width = 1 << l2w, height = 1 << l2h_, wh = width * height;
   const int n = P.n;
-  const size_t per_tu = rdoq_lds_per_block(wh);
+  constexpr bool BYTES = SHAPE == 5 && !SIGNHIDE;                      // byte level array (see rdoq_lds_per_block)
+  const size_t per_tu = rdoq_lds_per_block(wh, BYTES);
   const int t = SHAPE ? CHROMA : (P.color ? 1 : 0);
   const int mts = P.mts_idx;
 
   // ---- per-workgroup tables ----
   {
     const uint8_t *st = reinterpret_cast<const uint8_t *>(&P.ctx);
-    for (int i = tid; i < N_CTX; i += 64) { const int s = st[i]; sB[i][0] = kEntropyBits[2 * s]; sB[i][1] = kEntropyBits[2 * s + 1]; }
+    for (int i = tid; i < N_CTX; i += 64) {
+      if (i >= O_LASTX && i < O_CBF_Y) continue;
+      const int s = st[i], k = i < O_LASTX ? i : i - S_DROP;
+      sB[k][0] = kEntropyBits[2 * s]; sB[k][1] = kEntropyBits[2 * s + 1];
+    }
   }
   const int l2cgw = l2w - 2, cgw = 1 << l2cgw, cgh = height >> 2;
   if (tid == 0) {                                                      // H.266 6.5.2 on the coefficient-group grid
@@ -315,16 +396,18 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
     const int l2h = l2h_;
     const int ox = t ? 0 : prefix_ctx(l2w), oy = t ? 0 : prefix_ctx(l2h);
     const int sx = t ? clampi(width >> 3, 0, 2) : ((l2w + 1) >> 2), sy = t ? clampi(height >> 3, 0, 2) : ((l2h + 1) >> 2);
+    const uint8_t *st = reinterpret_cast<const uint8_t *>(&P.ctx);
+    int *sLastX = &sStageI[0][0], *sLastY = &sStageI[1][0];          // scratch: the staging arrays are idle until the walk
     int bits = 0, c;
     for (c = 0; c < group_idx(width - 1); ++c) {
-      const int o = O_LASTX + 20 * t + ox + (c >> sx);
-      sLastX[c] = bits + (int)sB[o][0]; bits += (int)sB[o][1];
+      const int sm = st[O_LASTX + 20 * t + ox + (c >> sx)];
+      sLastX[c] = bits + (int)kEntropyBits[2 * sm]; bits += (int)kEntropyBits[2 * sm + 1];
     }
     sLastX[c] = bits;
     bits = 0;
     for (c = 0; c < group_idx(height - 1); ++c) {
-      const int o = O_LASTY + 20 * t + oy + (c >> sy);
-      sLastY[c] = bits + (int)sB[o][0]; bits += (int)sB[o][1];
+      const int sm = st[O_LASTY + 20 * t + oy + (c >> sy)];
+      sLastY[c] = bits + (int)kEntropyBits[2 * sm]; bits += (int)kEntropyBits[2 * sm + 1];
     }
     sLastY[c] = bits;
     for (int p = 0; p < width; ++p) { const int cx = group_idx(p); sLastXp[p] = sLastX[cx] + (cx > 3 ? (int)(32768u * (uint32_t)((cx - 2) >> 1)) : 0); }
@@ -344,16 +427,27 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   int32_t *gSh = wsSh + (size_t)tu * 4 * wh;                           // sign hiding: the block's sh_rates
   // code of the significance-cost table entry of every walked position (cost_sig[] = sig_cost_of(code)); a position is
   // written and re-read by the same lane (the j + 4r mapping)
-  uint8_t *gSig = reinterpret_cast<uint8_t *>(SIGNHIDE ? wsSh + (size_t)n * 4 * wh : wsSh) + (size_t)tu * wh;
+  uint8_t *wsSig = reinterpret_cast<uint8_t *>(SIGNHIDE ? wsSh + (size_t)n * 4 * wh : wsSh);
+  uint8_t *gSig = wsSig + (size_t)tu * wh;
+  // written by rdoq_pre_kernel: the Rice parameters (two bits per position) and the last significant position of every block
+  const uint8_t *wsRice = wsSig + (size_t)n * wh;
+  const int *wsLast = reinterpret_cast<const int *>(wsRice + (size_t)n * (wh >> 2));
   const int16_t *gCoef = coef + (size_t)tu * wh;
   int16_t *sLev = reinterpret_cast<int16_t *>(sDyn + gq * per_tu);
-  uint8_t *sRice = reinterpret_cast<uint8_t *>(sLev + wh);            // Rice parameter after each position, four positions per byte
+  uint8_t *sLevB = sDyn + gq * per_tu;                                 // BYTES: the same array as bytes
+  uint8_t *sRice = sDyn + gq * per_tu + (BYTES ? wh : 2 * wh);         // Rice parameter after each position, four positions per byte
+  int16_t *gOut = q_coef + (size_t)tu * wh;                            // BYTES: the exact levels, written and re-read by the same lane
+  auto lev_get = [&](int pos) { return BYTES ? (int)sLevB[pos] : (int)sLev[pos]; };
+  auto lev_set = [&](int pos, int v) {
+    if (BYTES) sLevB[pos] = (uint8_t)(v < 254 ? v : 254 + (v & 1));
+    else sLev[pos] = (int16_t)v;
+  };
   auto rice_at = [&](int pos) { return (int)(sRice[pos >> 2] >> ((pos & 3) * 2)) & 3; };
   double *D = sStageD[gq];
   int *I = sStageI[gq];
   // ---- stage the coefficients into the level array (coalesced: the blocks of a workgroup are contiguous) ----
   const int l2wh = l2w + l2h_;
-  {
+  if (!BYTES) {
     // two coefficients per lane and step (wh is a multiple of 16: pairs never straddle blocks; 4-byte aligned: the batch
     // pointer is 2-byte aligned by contract, so pair loads need an even element offset -- tu0 * wh is a multiple of 16)
     const uint32_t *src = reinterpret_cast<const uint32_t *>(coef + (size_t)tu0 * wh);
@@ -371,27 +465,37 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
     }
   }
   __syncthreads();
-  // the Rice parameter after each position: templateAbsSum(coef, 4, ...) over the input block (rdo.c:846-871, 1697)
-  if (live)
-    for (int q4 = j; q4 < (wh >> 2); q4 += 4) {                        // a lane owns whole bytes of the packed array
-      unsigned packed = 0;
-#pragma unroll 1
-      for (int k = 0; k < 4; ++k) {
-        const int pos = 4 * q4 + k;
-        const uint32_t pos_y = (uint32_t)pos >> l2w, pos_x = (uint32_t)pos - (pos_y << l2w);
-        const int16_t *c0p = sLev + pos;
-        // straight-line: an absent neighbour reads the position itself and counts as zero; coeff_t accumulator: wraps like the reference's
-        const bool hx1 = pos_x < (uint32_t)width - 1, hx2 = pos_x < (uint32_t)width - 2;
-        const bool hy1 = pos_y < (uint32_t)height - 1, hy2 = pos_y < (uint32_t)height - 2;
-        const bool zx1 = mts && pos_x + 1 >= 16, zx2 = mts && pos_x + 2 >= 16, zy1 = mts && pos_y + 1 >= 16, zy2 = mts && pos_y + 2 >= 16;
-        const int r0 = c0p[hx1 ? 1 : 0], r1 = c0p[hx2 ? 2 : 0], r2 = c0p[(hx1 && hy1) ? width + 1 : 0], r3 = c0p[hy1 ? width : 0],
-                  r4 = c0p[hy2 ? 2 * width : 0];
-        const int16_t sum = (int16_t)(((hx1 && !zx1) ? abs(r0) : 0) + ((hx2 && !zx2) ? abs(r1) : 0) + ((hx1 && hy1 && !(zy1 || zx1)) ? abs(r2) : 0) +
-                                      ((hy1 && !zy1) ? abs(r3) : 0) + ((hy2 && !zy2) ? abs(r4) : 0));
-        packed |= (unsigned)go_rice_par(clampi((int)sum - 20, 0, 31)) << (2 * k);
-      }
-      sRice[q4] = (uint8_t)packed;
+  // the Rice parameter after each position.  BYTES: from rdoq_pre_kernel (the input block is not in LDS), wh / 16 words per block
+  if (BYTES) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(wsRice + (size_t)tu0 * (wh >> 2));
+    const int l2wpb = l2wh - 4;                                        // log2(words per block)
+    for (int e = tid; e < here << l2wpb; e += 64) {
+      const int b = e >> l2wpb, wq = e - (b << l2wpb);
+      *reinterpret_cast<uint32_t *>(sDyn + b * per_tu + (BYTES ? wh : 2 * wh) + 4 * wq) = src[e];
     }
+  } else {
+    // templateAbsSum(coef, 4, ...) over the input block (rdo.c:846-871, 1697)
+    if (live)
+      for (int q4 = j; q4 < (wh >> 2); q4 += 4) {                        // a lane owns whole bytes of the packed array
+        unsigned packed = 0;
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+          const int pos = 4 * q4 + k;
+          const uint32_t pos_y = (uint32_t)pos >> l2w, pos_x = (uint32_t)pos - (pos_y << l2w);
+          const int16_t *c0p = sLev + pos;
+          // straight-line: an absent neighbour reads the position itself and counts as zero; coeff_t accumulator: wraps like the reference's
+          const bool hx1 = pos_x < (uint32_t)width - 1, hx2 = pos_x < (uint32_t)width - 2;
+          const bool hy1 = pos_y < (uint32_t)height - 1, hy2 = pos_y < (uint32_t)height - 2;
+          const bool zx1 = mts && pos_x + 1 >= 16, zx2 = mts && pos_x + 2 >= 16, zy1 = mts && pos_y + 1 >= 16, zy2 = mts && pos_y + 2 >= 16;
+          const int r0 = c0p[hx1 ? 1 : 0], r1 = c0p[hx2 ? 2 : 0], r2 = c0p[(hx1 && hy1) ? width + 1 : 0], r3 = c0p[hy1 ? width : 0],
+                    r4 = c0p[hy2 ? 2 * width : 0];
+          const int16_t sum = (int16_t)(((hx1 && !zx1) ? abs(r0) : 0) + ((hx2 && !zx2) ? abs(r1) : 0) + ((hx1 && hy1 && !(zy1 || zx1)) ? abs(r2) : 0) +
+                                        ((hy1 && !zy1) ? abs(r3) : 0) + ((hy2 && !zy2) ? abs(r4) : 0));
+          packed |= (unsigned)go_rice_par(clampi((int)sum - 20, 0, 31)) << (2 * k);
+        }
+        sRice[q4] = (uint8_t)packed;
+      }
+  }
   __syncthreads();
 
   // in-group up-right diagonal order of a 4x4 group as (y * 4 + x) nibbles, scan position 0 first
@@ -415,22 +519,49 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   auto quad_or = [&](unsigned v) { v |= __shfl_xor(v, 1, 64); v |= __shfl_xor(v, 2, 64); return v; };
   auto quad_sum = [&](unsigned v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); return v; };
   auto neighbours = [&](int blkpos, uint32_t pos_x, uint32_t pos_y, int (&nb)[5], bool (&has)[5]) __attribute__((always_inline)) {
-    const int16_t *Lv = sLev + blkpos;
 #pragma unroll
     for (int k = 0; k < 5; ++k) { nb[k] = 0; has[k] = false; }
     if (pos_x < (uint32_t)width - 1) {
-      has[0] = true; nb[0] = Lv[1];
-      if (pos_x < (uint32_t)width - 2) { has[1] = true; nb[1] = Lv[2]; }
-      if (pos_y < (uint32_t)height - 1) { has[2] = true; nb[2] = Lv[width + 1]; }
+      has[0] = true; nb[0] = lev_get(blkpos + 1);
+      if (pos_x < (uint32_t)width - 2) { has[1] = true; nb[1] = lev_get(blkpos + 2); }
+      if (pos_y < (uint32_t)height - 1) { has[2] = true; nb[2] = lev_get(blkpos + width + 1); }
     }
     if (pos_y < (uint32_t)height - 1) {
-      has[3] = true; nb[3] = Lv[width];
-      if (pos_y < (uint32_t)height - 2) { has[4] = true; nb[4] = Lv[2 * width]; }
+      has[3] = true; nb[3] = lev_get(blkpos + width);
+      if (pos_y < (uint32_t)height - 2) { has[4] = true; nb[4] = lev_get(blkpos + 2 * width); }
+    }
+    if (BYTES) {
+      // a clamped neighbour (level >= 254): the template sums of rdoq_decide want the exact value (int16 wrap of the sum,
+      // rdo.c:846-871) -- it was stored to the output by another lane of this wave: make that store visible, bypass L1
+      // (a neighbour inside the group being walked is not in the output yet: its exact level is in the staging array)
+      const int dxs[5] = {1, 2, 1, 0, 0}, dys[5] = {0, 0, 1, 1, 2};
+      constexpr unsigned long long kInvDiag4 = 0xFDA6EB73C8419520ull;  // (y * 4 + x) inside a 4x4 group -> index in its scan
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) any = any || nb[k] >= 254;
+      if (any) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          if (has[k] && nb[k] >= 254) {
+            const uint32_t nx = pos_x + dxs[k], ny = pos_y + dys[k];
+            if ((nx >> 2) == (pos_x >> 2) && (ny >> 2) == (pos_y >> 2)) {
+              nb[k] = I[3 * (int)((kInvDiag4 >> (4 * ((ny & 3) * 4 + (nx & 3)))) & 15)];
+            } else {
+              const int p2 = blkpos + dys[k] * width + dxs[k];
+              const unsigned wv = __hip_atomic_load(reinterpret_cast<const unsigned *>(gOut + (p2 & ~1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              nb[k] = (int)(int16_t)((p2 & 1) ? (wv >> 16) : (wv & 0xffffu));
+            }
+          }
+      }
     }
   };
 
   // ---- the last significant position (rdo.c:1561-1592): highest scan position whose rounded level is non-zero ----
   int last_scanpos = -1;
+  if (BYTES) last_scanpos = live ? wsLast[tu] : -1;                     // (rdoq_pre_kernel; the input block is not in LDS)
+  else
   for (int cgs = cg_num - 1; cgs >= 0; --cgs) {                        // uniform trip count; the blocks differ only in predicates
     const int g = sScanCg[cgs];
     unsigned m = 0;
@@ -457,12 +588,12 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int bp = blk_in(g, in_cg(j + 4 * r));
-          sLev[bp] = 0;
+          lev_set(bp, 0);
           if (SIGNHIDE) { gSh[bp] = 0; gSh[wh + bp] = 0; gSh[2 * wh + bp] = 0; gSh[3 * wh + bp] = 0; }   // FILL(sh_rates, 0), :1493
         }
       else if (max_group < 15)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (j + 4 * r > max_group) sLev[blk_in(g, in_cg(j + 4 * r))] = 0;
+        for (int r = 0; r < 4; ++r) if (j + 4 * r > max_group) lev_set(blk_in(g, in_cg(j + 4 * r)), 0);
     }
   WAVE_SYNC();
 
@@ -472,6 +603,13 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   uint32_t reg_bins = (uint32_t)(wh * 28) >> 4;
   int go_rice_state = 0;                                               // only tracked while a group is walked sequentially
   bool exhausted = false;                                              // reg_bins < 4: it never recovers (:1692-1697 stop updating it)
+  int pf_in[4] = {0, 0, 0, 0};                                         // BYTES: the input coefficients of the next group to stage
+  auto prefetch_in = [&](int cgs2) {
+    const int g2 = sScanCg[cgs2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pf_in[r] = (int)gCoef[blk_in(g2, in_cg(j + 4 * r))];
+  };
+  if (BYTES) prefetch_in(cg_num - 1);
 #pragma unroll 1
   for (int cgs = cg_num - 1; cgs >= 0; --cgs) {
     const int g = sScanCg[cgs];
@@ -487,7 +625,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
         if (s4 > max_group) continue;
         const int blkpos = blk_in(g, in_cg(s4));
         const int scanpos = cgs * 16 + s4;
-        const int ld = level_double_of((int)sLev[blkpos]);
+        const int ld = level_double_of(BYTES ? pf_in[r] : (int)sLev[blkpos]);
         const int mx = (int)((uint32_t)(ld + (1 << (q_bits - 1))) >> q_bits);
         const bool walked = in_walk && scanpos <= last_scanpos;
         const double c0 = cost0_of(ld);
@@ -523,11 +661,12 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
         I[3 * s4] = walked ? rate[0] : 0;                                // (a position that is not walked reads as level 0 in the replay)
         I[3 * s4 + 1] = rate[1];
         I[3 * s4 + 2] = ld;
-        sLev[blkpos] = (int16_t)(walked ? mx : 0);
+        lev_set(blkpos, walked ? mx : 0);
         // (what the positions decided BEFORE the group's last one can spend at most, :1695-1696: scan position 0 of a group is the
         // last one decided, and the last significant position spends no significance bin)
         spend += (walked && s4 >= 1) ? (unsigned)(mx < 2 ? mx : 3) + (scanpos != last_scanpos ? 1u : 0u) : 0u;
       }
+    if (BYTES && cgs > 0) prefetch_in(cgs - 1);
     spend = quad_sum(spend);
     // Only the group in which the regular-bin budget could fall below 4 is walked position by position: before it the
     // budget cannot run out inside a group; after it reg_bins is frozen below 4, the Rice parameter comes from the template of
@@ -548,17 +687,17 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       if (plain && j < cnt && s4 <= max_group && scanpos <= last_scanpos) {
         const int blkpos = blk_in(g, in_cg(s4));
         const uint32_t pos_y = (uint32_t)blkpos >> l2w, pos_x = (uint32_t)blkpos - (pos_y << l2w);
-        const int mx = (int)sLev[blkpos];
+        // (the byte array holds the clamped level: the rounded level again from the staged |coef| * q)
+        const int mx = BYTES ? (int)((uint32_t)(I[3 * s4 + 2] + (1 << (q_bits - 1))) >> q_bits) : (int)sLev[blkpos];
         const bool is_last = scanpos == last_scanpos;
         // Straight-line code (selects instead of branches: with 16 blocks in the wave every branch is taken by some lane anyway,
         // and each divergent branch costs an exec-mask save / restore and a jump).
         // context_get_sig_ctx_idx_abs + the ctx_set line, as rdoq_decide: an absent neighbour reads the position itself and counts as 0
         const bool hx1 = pos_x < (uint32_t)width - 1, hx2 = pos_x < (uint32_t)width - 2;
         const bool hy1 = pos_y < (uint32_t)height - 1, hy2 = pos_y < (uint32_t)height - 2;
-        const int16_t *Lv = sLev + blkpos;
         const bool zx1 = mts && pos_x + 1 >= 16, zx2 = mts && pos_x + 2 >= 16, zy1 = mts && pos_y + 1 >= 16;
-        const int r0 = Lv[hx1 ? 1 : 0], r1 = Lv[hx2 ? 2 : 0], r2 = Lv[(hx1 && hy1) ? width + 1 : 0], r3 = Lv[hy1 ? width : 0],
-                  r4 = Lv[hy2 ? 2 * width : 0];
+        const int r0 = lev_get(blkpos + (hx1 ? 1 : 0)), r1 = lev_get(blkpos + (hx2 ? 2 : 0)), r2 = lev_get(blkpos + ((hx1 && hy1) ? width + 1 : 0)),
+                  r3 = lev_get(blkpos + (hy1 ? width : 0)), r4 = lev_get(blkpos + (hy2 ? 2 * width : 0));
         // (zero-out tests of the "below" terms use pos_x, as the reference does, rdo.c:1425)
         const int nbv[5] = {(hx1 && !zx1) ? abs(r0) : 0, (hx2 && !zx2) ? abs(r1) : 0, (hx1 && hy1 && !(zy1 || zx1)) ? abs(r2) : 0,
                             (hy1 && !zx1) ? abs(r3) : 0, (hy2 && !zx2) ? abs(r4) : 0};
@@ -597,7 +736,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
           const int go_rice = (is_last || s4 == 15) ? 0 : rice_at(blk_in(g, in_cg(s4 + 1)));
           sh_record(gSh, wh, blkpos, B, t, is_last, level, I[3 * s4 + 2], q_bits, ctx_sig, ctx_set, go_rice, 4);
         }
-        sLev[blkpos] = (int16_t)level;
+        lev_set(blkpos, level);
         D[3 * s4] = cc; D[3 * s4 + 1] = cs;
         I[3 * s4] = level;
         I[3 * s4 + 1] = sig_code;                                        // (the candidates' rate halves have been consumed)
@@ -620,7 +759,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
           neighbours(blkpos, pos_x, pos_y, nb, has);
           const rdoq_decision d = rdoq_decide(P, B, t, scanpos == last_scanpos, ld, mx, D[3 * s4 + 2], nb, has, pos_x, pos_y, 0, reg_bins);
           if (SIGNHIDE) sh_record(gSh, wh, blkpos, B, t, scanpos == last_scanpos, d.level, ld, q_bits, d.ctx_sig, d.ctx_set, d.go_rice, reg_bins);
-          sLev[blkpos] = (int16_t)d.level;
+          lev_set(blkpos, d.level);
           D[3 * s4] = d.coded_cost; D[3 * s4 + 1] = d.coded_sig;
           I[3 * s4] = d.level;
           I[3 * s4 + 1] = d.sig_code;
@@ -654,7 +793,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
         }
         WAVE_SYNC();
         if (act2 && j == 0) {
-          sLev[b2] = (int16_t)d2.level;
+          lev_set(b2, d2.level);
           D[3 * s2] = d2.coded_cost; D[3 * s2 + 1] = d2.coded_sig;
           I[3 * s2] = d2.level;
           I[3 * s2 + 1] = d2.sig_code;
@@ -671,6 +810,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
           const int bp = blk_in(g, in_cg(s4));
           gCost[bp] = D[3 * s4];
           gSig[bp] = (uint8_t)I[3 * s4 + 1];
+          if (BYTES) gOut[bp] = (int16_t)I[3 * s4];
         }
       }
     // -- replay the group's costs in scan order (bit-exact double sums).  The five running sums are independent chains:
@@ -760,7 +900,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
         for (int r = 0; r < 4; ++r) {
           const int s4 = j + 4 * r;
           const int blkpos = blk_in(g, in_cg(s4));
-          if (s4 <= max_group && sLev[blkpos]) { sLev[blkpos] = 0; gCost[blkpos] = D[3 * s4 + 2]; gSig[blkpos] = 0; }
+          if (s4 <= max_group && lev_get(blkpos)) { lev_set(blkpos, 0); gCost[blkpos] = D[3 * s4 + 2]; gSig[blkpos] = 0; if (BYTES) gOut[blkpos] = 0; }
         }
     } else if (has_last && j == 0) {
       gCgCost[cgs] = 0;                                                  // groups skipped by the MTS zero-out keep a zero flag cost
@@ -773,10 +913,10 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   if (live && last_scanpos >= 0) {
     double best_cost;
     if (P.block_type != 1 && !P.color) {
-      best_cost = block_uncoded_cost + lambda * (double)B[O_ROOT][0];
-      base_cost += lambda * (double)B[O_ROOT][1];
+      best_cost = block_uncoded_cost + lambda * (double)B[S_ROOT][0];
+      base_cost += lambda * (double)B[S_ROOT][1];
     } else {
-      const int m = P.color == 0 ? O_CBF_Y : P.color == 1 ? O_CBF_CB : O_CBF_CR + (P.cbf_u ? 1 : 0);
+      const int m = P.color == 0 ? S_CBF_Y : P.color == 1 ? S_CBF_CB : S_CBF_CR + (P.cbf_u ? 1 : 0);
       best_cost = block_uncoded_cost + lambda * (double)B[m][0];
       base_cost += lambda * (double)B[m][1];
     }
@@ -811,7 +951,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
           const int s4 = j + 4 * r;
           const bool valid = s4 <= max_group && cgs * 16 + s4 <= last_scanpos;
           const int b2 = blk_in(g, in_cg(s4 <= max_group ? s4 : 0));
-          const int lv = sLev[b2];
+          const int lv = lev_get(b2);
           const bool nz = valid && lv != 0;
           const double cs = sig_cost_of(valid ? pf_sig[r] : 0);
           const double c0 = cost0_of(level_double_of(pf_coef[r]));
@@ -861,12 +1001,21 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int s4 = j + 4 * r, scanpos = cgs * 16 + s4;
-        const int b = blk_in(sScanCg[cgs], in_cg(s4));
-        int level = sLev[b];
-        if (last_scanpos < 0 || scanpos >= best_last_idx_p1) level = 0;
-        else if (reduce) { const int bx = b & (width - 1), by = b >> l2w; if (bx >= 16 || by >= 16) level = 0; }
+        const int g2 = sScanCg[cgs];
+        const int b = blk_in(g2, in_cg(s4));
+        int level;
+        if (BYTES) {                                                     // the exact level is in the output already where the walk decided one
+          const bool decided = last_scanpos >= 0 && scanpos < best_last_idx_p1 && cgs < cg_num && s4 <= max_group && !cg_skipped(g2);
+          level = decided ? (int)gOut[b] : 0;
+        } else {
+          level = sLev[b];
+          if (last_scanpos < 0 || scanpos >= best_last_idx_p1) level = 0;
+        }
+        if (level && reduce) { const int bx = b & (width - 1), by = b >> l2w; if (bx >= 16 || by >= 16) level = 0; }
         my_abs += (uint32_t)level;
-        sLev[b] = (int16_t)((level != 0 && gCoef[b] < 0) ? -level : level);
+        const int signed_level = (level != 0 && gCoef[b] < 0) ? -level : level;
+        if (BYTES) gOut[b] = (int16_t)signed_level;
+        else sLev[b] = (int16_t)signed_level;
       }
   }
   my_abs = quad_sum(my_abs);
@@ -926,7 +1075,8 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
     }
   }
   __syncthreads();
-  if ((reinterpret_cast<uintptr_t>(q_coef) & 3) == 0) {
+  if (BYTES) {
+  } else if ((reinterpret_cast<uintptr_t>(q_coef) & 3) == 0) {
     uint32_t *dst = reinterpret_cast<uint32_t *>(q_coef + (size_t)tu0 * wh);
     for (int e = tid; e < (here * wh) >> 1; e += 64) {
       const int b = (2 * e) >> l2wh, pos = 2 * e - (b << l2wh);
@@ -948,7 +1098,9 @@ extern "C" size_t uvghip_rdoq_workspace_bytes(int width, int height, int n)
 {
   if (width <= 0 || height <= 0 || n <= 0) return 0;
   // cost_coeff[] + cost_coeffgroup_sig[] + the cost_sig[] codes of every block
-  return (size_t)width * height * (size_t)n * (sizeof(double) + 1) + (size_t)(width * height / 16) * (size_t)n * sizeof(double);
+  // + the Rice parameters (2 bits per position) and the last significant position of every block (rdoq_pre_kernel)
+  return (size_t)width * height * (size_t)n * (sizeof(double) + 1) + (size_t)(width * height / 16) * (size_t)n * sizeof(double) +
+         (size_t)(width * height / 4) * (size_t)n + (size_t)n * sizeof(int);
 }
 
 extern "C" size_t uvghip_rdoq_signhide_workspace_bytes(int width, int height, int n)
@@ -1024,7 +1176,7 @@ static int rdoq_launch(int signhide, int bitdepth, const int16_t *coef, int16_t 
   const int wh = width * height;
   // blocks per wave (four lanes each): 16.  LDS per block: levels (int16) + meta (byte) per position, odd word stride
   const int tus = 16;
-  const size_t lds = (size_t)tus * rdoq_lds_per_block(wh);
+  const size_t lds = (size_t)tus * rdoq_lds_per_block(wh, width == 32 && height == 32 && !signhide);
   double *w = static_cast<double *>(workspace);
   hipStream_t st = uvghip_stream(stream);
   // one workgroup per batch of 16 blocks (measured: capping the grid and looping batches inside a workgroup to share the
@@ -1032,8 +1184,20 @@ static int rdoq_launch(int signhide, int bitdepth, const int16_t *coef, int16_t 
   // matters beyond 2^20 batches
   const int batches = (n + tus - 1) / tus;
   const int grid = batches < (1 << 20) ? batches : (1 << 20);
+  if (width == 32 && height == 32 && !signhide) {
+    // byte level array (rdoq_lds_per_block): the decision-free part first (Rice parameters, last significant position), into the
+    // tail of the workspace
+    uint8_t *ws_sig = reinterpret_cast<uint8_t *>(w + (size_t)n * wh + (size_t)n * (wh >> 4)) + (signhide ? (size_t)n * 4 * wh * sizeof(int32_t) : 0);
+    uint8_t *ws_rice = ws_sig + (size_t)n * wh;
+    int *ws_last = reinterpret_cast<int *>(ws_rice + (size_t)n * (wh >> 2));
+    const long long chunks = ((long long)n * wh + 1023) / 1024;
+    if (chunks > 0x7fffffffLL) return uvghip_set_error(hipErrorInvalidValue, "uvghip_rdoq_batch: n");
+    rdoq_pre_kernel<<<(int)chunks, 256, 0, st>>>(P, coef, ws_rice, ws_last);
+  }
 #define RDOQ_LAUNCH(SH, CH)                                                                                              \
   do {                                                                                                                   \
+    if (getenv("UVGHIP_DEBUG_OCC")) { for (size_t l2 = lds - 1024; l2 <= lds + 512; l2 += 256) { int nb = -1; hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rdoq_kernel<16, SH, CH, 0>, 64, l2); \
+      fprintf(stderr, "rdoq<%d,%d> dyn lds %zu: %d workgroups/CU (err %d)\n", SH, CH, l2, nb, (int)oe); } } \
     if (signhide) rdoq_kernel<16, SH, CH, 1><<<grid, 64, lds, st>>>(P, coef, q_coef, w, abs_sum_out, has_coeffs);        \
     else rdoq_kernel<16, SH, CH, 0><<<grid, 64, lds, st>>>(P, coef, q_coef, w, abs_sum_out, has_coeffs);                 \
   } while (0)
