@@ -345,7 +345,7 @@ __device__ __forceinline__ double quad_bcast(double v)
 template <int TUS, int SHAPE, int CHROMA, int SIGNHIDE>
 // (4x4 blocks: three waves per SIMD asked for -- 168 registers, no spills -- because there the registers, not the LDS, bound
 // the number of resident workgroups; the larger shapes are LDS-bound and spill when squeezed)
-__global__ void __launch_bounds__(64, (SHAPE == 2 && !SIGNHIDE) ? 3 : 1)
+__global__ void __launch_bounds__(64, ((SHAPE == 2 || SHAPE == 3) && !SIGNHIDE) ? 3 : 1)
 rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__restrict__ q_coef, double *__restrict__ ws,
             uint32_t *__restrict__ abs_sum_out, uint8_t *__restrict__ has_coeffs)
 {
@@ -677,7 +677,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
     const bool any_slow = __any(slow), any_exh = __any(in_walk && exhausted);
     WAVE_SYNC();
     // -- the positions of one anti-diagonal decide together (their neighbours lie on later anti-diagonals) --
-    constexpr int PHASE_UNROLL = SHAPE == 2 ? 1 : 7;                   // (4x4: one group, and the unrolled body would spill at three waves per SIMD)
+    constexpr int PHASE_UNROLL = (SHAPE == 2 || SHAPE == 3) ? 1 : 7;                   // (4x4: one group, and the unrolled body would spill at three waves per SIMD)
     if (__any(plain))                                                  // (sparse planes: most groups lie beyond every block's last position)
 #pragma unroll PHASE_UNROLL
     for (int dg = 6; dg >= 0; --dg) {
