@@ -107,7 +107,7 @@ def algorithmic_bytes(fr, name, group=1):
     """SURVEY.md 8(d) per-unit figures x the units this launch processes (b = bytes per sample)."""
     kern, n = name.rsplit("_", 1)
     n = int(n)
-    if kern in GROUP_KERNELS:                                              # one launch over the group's pictures
+    if kern in GROUP_KERNELS or (kern.startswith("sao_") and fr.nranks == 1):   # one launch over the group's pictures
         return group * _picture_bytes(fr, kern, n)
     return _picture_bytes(fr, kern, n)
 
@@ -189,9 +189,13 @@ class Slot:
         self.plan = []      # ("kernels", launches) | ("eager", launches) | ("comm", launches)
         if grp.mid:
             self.plan += [("kernels", grp.heads_rest()), ("eager", grp.mid)]
-            acc = grp.tails() + [l for fr in frs for l in fr.stage_a]
+            acc = grp.tails()
         else:
-            acc = grp.before_filters() + [l for fr in frs for l in fr.stage_a]
+            acc = grp.before_filters()
+        if grp.sao:         # whole pictures per rank: no exchange inside the filters, SAO once over the group
+            acc, frs = acc + grp.filters(), []
+        else:
+            acc = acc + [l for fr in frs for l in fr.stage_a]
         for fr in frs:
             for seg, comm in ((fr.xchg_dbk, True), (fr.stage_b, False), (fr.xchg_alf, True), (fr.stage_c, False), (fr.reduce + fr.xchg_gather, True)):
                 if comm:

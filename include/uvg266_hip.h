@@ -510,7 +510,9 @@ typedef struct uvghip_sao_param {
  * sao-generic.c:84-124): out = SAO(rec) inside each rectangle with its parameters.  Samples SAO does not
  * modify -- type 0 rectangles and the picture's outermost row/column for edge classes (sao.c:321-348) -- are
  * copied from rec, so every sample of every rectangle is written (the reference filters a copy of the picture in
- * place and gets the same picture).  rec and out must be different planes. */
+ * place and gets the same picture).  rec and out must be different planes.  The planes may hold several pictures of
+ * pic_height rows one under the other (frame-parallel operation): a rectangle's position relative to the picture's top and
+ * bottom edge is taken inside its own picture (y mod pic_height). */
 UVGHIP_API int uvghip_sao_apply_batch(int bitdepth, const void *rec, int rec_stride, void *out, int out_stride,
                            int pic_w, int pic_h, const uvghip_rect_t *rects,
                            const uvghip_sao_param_t *params, int n, void *stream);

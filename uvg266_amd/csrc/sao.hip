@@ -164,8 +164,10 @@ sao_apply_kernel(const PX *__restrict__ rec, int rstride, PX *__restrict__ out, 
     ax = kEoOfs[P.eo_class][0]; ay = kEoOfs[P.eo_class][1]; bx = kEoOfs[P.eo_class][2]; by = kEoOfs[P.eo_class][3];
     if (R.x + R.w + ax > pic_w || R.x + R.w + bx > pic_w) ix1 -= 1;
     if (R.x + ax < 0 || R.x + bx < 0) ix0 += 1;
-    if (R.y + R.h + ay > pic_h || R.y + R.h + by > pic_h) iy1 -= 1;
-    if (R.y + ay < 0 || R.y + by < 0) iy0 += 1;
+    // (the rectangle's row inside its own picture: `rec` may be a stack of pictures of pic_h rows each, one under the other)
+    const int ry = R.y % pic_h;
+    if (ry + R.h + ay > pic_h || ry + R.h + by > pic_h) iy1 -= 1;
+    if (ry + ay < 0 || ry + by < 0) iy0 += 1;
   } else if (P.type == 0) ix1 = 0;
   if (R.w <= 0 || R.h <= 0) return;
   const int segs_per_row = (R.w + 3) >> 2, nseg = segs_per_row * R.h;

@@ -187,7 +187,8 @@ class BandFrame:
         crects = own_r // 2
         self.n_ctu = n_ctu = len(own_r)
         self.rects, self.crects = api.make_rects(own_r, device), api.make_rects(crects, device)
-        self.sao_y, self.sao_u, self.sao_v = plane(self.y), plane(self.u), plane(self.v)
+        self.sao_y, self.sao_u, self.sao_v = plane(self.y, "sao_y"), plane(self.u, "sao_u"), plane(self.v, "sao_v")
+        self.own_rects = own_r
         comp = (("y", self.y, self.rec_y, self.sao_y, self.rects, ys, W, H),
                 ("u", self.u, self.rec_u, self.sao_u, self.crects, cs, W // 2, H // 2),
                 ("v", self.v, self.rec_v, self.sao_v, self.crects, cs, W // 2, H // 2))
@@ -200,6 +201,7 @@ class BandFrame:
         dbk = [depth, P(self.rec_y), ys, P(self.rec_u), P(self.rec_v), cs, W, H, P(self.scu), scu_stride, 0, 0, 0, qp, None, y0, y1]
         self.stage_a = [("deblock_v_0", L.uvghip_deblock_band, dbk + [1])]
         self.stage_b = [("deblock_h_0", L.uvghip_deblock_band, dbk + [2])]
+        self.stage_b_dbk = list(self.stage_b)                                # (a FrameGroup runs SAO once over the group instead)
         for k, org, rec, out, rc, st, pw, ph in comp:
             self.stage_b.append((f"sao_stats_{k}_0", L.uvghip_sao_stats_batch, [depth, P(org), st, P(rec), st, P(rc), n_ctu, P(self.edge[k]), P(self.bandst[k])]))
         self.stage_b.append(("sao_offsets_yuv_0", L.uvghip_sao_edge_offsets_batch, [P(self.edge_all), None, 3 * n_ctu, P(self.params_all), None]))
@@ -376,6 +378,40 @@ class FrameGroup:
                 for ci, name in enumerate("uv"):
                     tu(f"chroma_{n}", 1 + ci, n, c, qpc, A(name), A(f"pred{n}{name}"), A(f"rec{n}{name}"), ctus, F * cnt)
 
+        # ---- SAO once over the group (whole pictures per rank only: with CTU-row bands the halo exchanges sit between the
+        #      per-picture stages).  Statistics are per rectangle, the offsets per rectangle, and uvghip_sao_apply_batch looks
+        #      at a rectangle's row inside its own picture: one launch per plane over the rectangles of all pictures. ----
+        self.sao = []
+        if fr.nranks == 1:
+            W = fr.W
+            n_ctu = fr.n_ctu
+            ry = np.concatenate([f.own_rects + np.array([0, k * H, 0, 0]) for k, f in enumerate(self.frames)])
+            rc = np.concatenate([f.own_rects // 2 + np.array([0, k * (H // 2), 0, 0]) for k, f in enumerate(self.frames)])
+            rects_y, rects_c = api.make_rects(ry, device), api.make_rects(rc, device)
+            self.sao_edge = torch.zeros((3, F * n_ctu, 4, 2, 5), dtype=torch.int32, device=device)
+            self.sao_band = {k: torch.zeros((F * n_ctu, 2, 32), dtype=torch.int32, device=device) for k in "yuv"}
+            self.sao_params = torch.zeros((3, F * n_ctu, 8), dtype=torch.int32, device=device)
+            self._keep += [rects_y, rects_c]
+            rec_names = {"y": "rec4", "u": "rec8u", "v": "rec8v"}
+            comp = [(i, k, A(k), A(rec_names[k]), A("sao_" + k), rects_y if k == "y" else rects_c,
+                     W if k == "y" else W // 2, H if k == "y" else H // 2) for i, k in enumerate("yuv")]
+            for i, k, org, rec, out, rcts, pw, ph in comp:
+                st = org.stride(0)
+                self.sao.append((f"sao_stats_{k}_0", L.uvghip_sao_stats_batch,
+                                 [depth, P(org), st, P(rec), st, P(rcts), F * n_ctu, P(self.sao_edge[i]), P(self.sao_band[k])]))
+            self.sao.append(("sao_offsets_yuv_0", L.uvghip_sao_edge_offsets_batch, [P(self.sao_edge), None, 3 * F * n_ctu, P(self.sao_params), None]))
+            for i, k, org, rec, out, rcts, pw, ph in comp:
+                st = org.stride(0)
+                self.sao.append((f"sao_apply_{k}_0", L.uvghip_sao_apply_batch,
+                                 [depth, P(rec), st, P(out), st, pw, ph, P(rcts), P(self.sao_params[i]), F * n_ctu]))
+
+    def filters(self):
+        """The in-loop filters of the group in order (whole pictures per rank: SAO once over the group)."""
+        if not self.sao:
+            return [l for fr in self.frames for l in fr.filter_launches()]
+        return ([l for fr in self.frames for l in fr.stage_a] + [l for fr in self.frames for l in fr.stage_b_dbk] + self.sao +
+                [l for fr in self.frames for l in fr.stage_c + fr.reduce])
+
     def searches(self):
         return list(self._searches)
 
@@ -391,7 +427,7 @@ class FrameGroup:
         return self.heads_rest() + self.mid + self.tails()
 
     def all_launches(self):
-        return self.searches() + self.before_filters() + [l for fr in self.frames for l in fr.filter_launches()]
+        return self.searches() + self.before_filters() + self.filters()
 
 
 class Graph:
