@@ -254,11 +254,9 @@ alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__
   constexpr int NC = CHROMA ? 7 : 13, NCLS = CHROMA ? 1 : 25;
   constexpr int NE = NC * 4;                   // entries of e; index NE is d = org - rec
   constexpr int NT = CHROMA ? 1 : 2;           // 32-row tiles of the (NE + 1)-square result
-  constexpr int NROW = 32 * NT;
   constexpr int vbh = CHROMA ? 32 : 64, vb_pos = CHROMA ? 30 : 60;
   constexpr int DEPTH = px_traits<PX>::depth;
-  // tile jobs: hh and ll are symmetric (upper tile triangle), hl needs all tiles
-  constexpr int N_SYM = NT * (NT + 1) / 2, N_FULL = NT * NT, N_TILES = 2 * N_SYM + N_FULL;
+  // tile jobs: hh and ll are symmetric (upper tile triangle: NT (NT + 1) / 2 tiles each), hl needs all NT * NT tiles
   // digit planes: rows 0..NE hold data, the rest of the last 32-row tile reads as zero -- one shared zero row (the last) instead
   // of 11; the int32 tiles are combined per output tile pair (four tiles at a time): 49 KB per workgroup, three per CU
   constexpr int NROW_LDS = NT == 2 ? 56 : 32;
