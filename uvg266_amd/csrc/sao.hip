@@ -9,10 +9,11 @@
 //
 // Statistics kernel: one workgroup per rectangle.  Each thread walks its
 // pixels once, classifying them for all four edge classes from a 3x3
-// neighbourhood, keeps the 4x5 (sum,count) pairs in registers (select-adds,
-// no indexed register file), reduces them across the wave and adds them to
-// LDS once per wave; band histograms go to per-wave LDS histograms.  HBM
-// traffic: orig + rec read once, 104 integers written per rectangle.
+// neighbourhood, and adds (count, difference) to its own column of an LDS
+// table of 52 packed accumulators (20 edge class/category pairs + 32 bands):
+// no contended atomics, no select chains; the columns are summed at the end
+// (details at the kernel).  HBM traffic: orig + rec read once, 104 integers
+// written per rectangle.
 #include <climits>
 #include "uvghip_common.h"
 #include "percall.h"
