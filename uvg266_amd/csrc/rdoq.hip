@@ -247,6 +247,7 @@ rdoq_pre_kernel(const rdoq_params P, const int16_t *__restrict__ coef, uint8_t *
 {
   __shared__ uint8_t sInv[64];                                         // coefficient-group raster index -> index in scan order
   __shared__ int sLast[64];
+  __shared__ __attribute__((aligned(8))) int16_t sC[1024];             // the workgroup's 1024 coefficients: every one is read six times
   const int width = P.width, height = P.height, l2w = P.l2w, wh = width * height, n = P.n;
   const int l2cgw = l2w - 2, cgw = 1 << l2cgw, cgh = height >> 2;
   const int mts = P.mts_idx;
@@ -260,10 +261,15 @@ rdoq_pre_kernel(const rdoq_params P, const int16_t *__restrict__ coef, uint8_t *
     sInv[threadIdx.x] = (uint8_t)idx;
   }
   if (threadIdx.x < 64) sLast[threadIdx.x] = -1;
-  __syncthreads();
   const int pos4 = threadIdx.x * 4, b = pos4 / wh, pos0 = pos4 - b * wh, tu = blk0 + b;
+  if (tu < n) {                                                        // four coefficients per thread, one load where the pointer allows it
+    const int16_t *g = coef + (size_t)blk0 * wh + pos4;
+    if ((reinterpret_cast<uintptr_t>(g) & 7) == 0) *reinterpret_cast<uint2 *>(sC + pos4) = *reinterpret_cast<const uint2 *>(g);
+    else { sC[pos4] = g[0]; sC[pos4 + 1] = g[1]; sC[pos4 + 2] = g[2]; sC[pos4 + 3] = g[3]; }
+  }
+  __syncthreads();
   if (tu < n) {
-    const int16_t *c = coef + (size_t)tu * wh;
+    const int16_t *c = sC + b * wh;
     const int q_bits = P.q_bits, q = P.q;
     const int cap = 0x7fffffff - (1 << (q_bits - 1));
     const int cg_num = P.lfnst_idx > 0 ? 1 : wh >> 4;
