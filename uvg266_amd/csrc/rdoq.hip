@@ -556,8 +556,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
               nb[k] = I[3 * (int)((kInvDiag4 >> (4 * ((ny & 3) * 4 + (nx & 3)))) & 15)];
             } else {
               const int p2 = blkpos + dys[k] * width + dxs[k];
-              const unsigned wv = __hip_atomic_load(reinterpret_cast<const unsigned *>(gOut + (p2 & ~1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              nb[k] = (int)(int16_t)((p2 & 1) ? (wv >> 16) : (wv & 0xffffu));
+              nb[k] = (int)(int16_t)__hip_atomic_load(reinterpret_cast<const uint16_t *>(gOut + p2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
       }
