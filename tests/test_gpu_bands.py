@@ -187,3 +187,31 @@ def test_frame_group_equals_single_pictures(hip, wl_name):
         assert torch.equal(grp.sao_params[:, f * n_ctu:(f + 1) * n_ctu], one.params_all)
         if wl["alf"]:
             assert torch.equal(got.alf_sums, one.alf_sums)
+
+
+def test_frame_group_of_bands_equals_whole_pictures(hip):
+    """A FrameGroup of CTU-row bands (rank 1 of 2: the stacked block lists hold only the owned rows of every picture): what it
+    decides and reconstructs before the in-loop filters equals the same rows of the whole-picture group."""
+    import torch
+    from uvg266_amd import api, pipeline
+    wl = pipeline.WORKLOADS["test8"]
+    modes = api.make_modes(pipeline.MODES)
+    F = 2
+    st = torch.cuda.current_stream().cuda_stream
+    whole = pipeline.FrameGroup(hip, wl, 3, F, "cuda", modes)
+    band = pipeline.FrameGroup(hip, wl, 3, F, "cuda", modes, rank=1, nranks=2)
+    assert not band.sao and whole.sao
+    for g in (whole, band):
+        pipeline.run(g.searches() + g.before_filters(), st)
+    torch.cuda.synchronize()
+    y0, y1 = band.frames[0].band.y0, band.frames[0].band.y1
+    assert 0 < y0 < y1 <= wl["H"]
+    for f in range(F):
+        a, b = whole.frames[f], band.frames[f]
+        for n in pipeline.SIZES:
+            own = a.own[n][:, 1]
+            sel = torch.from_numpy(((own >= y0) & (own < y1))).cuda()
+            assert int(sel.sum()) == b.tables[n][2] > 0
+            assert torch.equal(a.bufs[n]["best"][sel], b.bufs[n]["best"]) and torch.equal(a.bufs[n]["cost"][sel], b.bufs[n]["cost"]), n
+            assert torch.equal(whole.pool.jobs[(n, 0)]["lev"][f][sel], band.pool.jobs[(n, 0)]["lev"][f]), n
+            assert torch.equal(a.bufs[n]["rec"][y0:y1], b.bufs[n]["rec"][y0:y1]), n
