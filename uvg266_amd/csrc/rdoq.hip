@@ -813,8 +813,10 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
         const int s4 = j + 4 * r;
         if (s4 <= max_group && cgs * 16 + s4 <= last_scanpos) {
           const int bp = blk_in(g, in_cg(s4));
-          gCost[bp] = D[3 * s4];
-          gSig[bp] = (uint8_t)I[3 * s4 + 1];
+          // (the workspace arrays are private to the kernel: indexed by SCAN position, so that the 16 positions of a group are 128
+          //  / 16 contiguous bytes -- with the block's own raster order every store was a partial 32-byte sector)
+          gCost[cgs * 16 + s4] = D[3 * s4];
+          gSig[cgs * 16 + s4] = (uint8_t)I[3 * s4 + 1];
           if (BYTES) gOut[bp] = (int16_t)I[3 * s4];
         }
       }
@@ -905,7 +907,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
         for (int r = 0; r < 4; ++r) {
           const int s4 = j + 4 * r;
           const int blkpos = blk_in(g, in_cg(s4));
-          if (s4 <= max_group && lev_get(blkpos)) { lev_set(blkpos, 0); gCost[blkpos] = D[3 * s4 + 2]; gSig[blkpos] = 0; if (BYTES) gOut[blkpos] = 0; }
+          if (s4 <= max_group && lev_get(blkpos)) { lev_set(blkpos, 0); gCost[cgs * 16 + s4] = D[3 * s4 + 2]; gSig[cgs * 16 + s4] = 0; if (BYTES) gOut[blkpos] = 0; }
         }
     } else if (has_last && j == 0) {
       gCgCost[cgs] = 0;                                                  // groups skipped by the MTS zero-out keep a zero flag cost
@@ -937,7 +939,8 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       for (int r = 0; r < 4; ++r) {
         const int s4 = j + 4 * r;
         const int b2 = blk_in(g, in_cg(s4 <= max_group ? s4 : 0));
-        pf_cost[r] = gCost[b2]; pf_coef[r] = (int)gCoef[b2]; pf_sig[r] = (int)gSig[b2];
+        const int sp = cgs * 16 + (s4 <= max_group ? s4 : 0);
+        pf_cost[r] = gCost[sp]; pf_coef[r] = (int)gCoef[b2]; pf_sig[r] = (int)gSig[sp];
       }
     };
     prefetch(cg_last_scanpos);
