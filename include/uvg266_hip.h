@@ -296,6 +296,13 @@ UVGHIP_API int uvghip_tu_inverse_batch(int bitdepth, int type_hor, int type_ver,
                             int use_trskip, const int16_t *coef_in, const void *pred, int pred_stride, void *rec, int rec_stride,
                             const uvghip_tu_t *tus, int n, void *stream);
 
+/* uvghip_dequant_batch (uvg_dequant, quant-generic.c:618-669, no transform skip / scaling list) followed by
+ * uvghip_tu_inverse_batch, in one launch: `levels` are dequantised as the inverse transform loads them.  Square blocks of
+ * 4..32 without zero-out, levels 16-byte aligned; other shapes: hipErrorNotSupported (use the two entry points). */
+UVGHIP_API int uvghip_tu_dequant_inverse_batch(int bitdepth, int type_hor, int type_ver, int width, int height, int qp_scaled,
+                                    const int16_t *levels, const void *pred, int pred_stride, void *rec, int rec_stride,
+                                    const uvghip_tu_t *tus, int n, void *stream);
+
 /* Everything uvg_quantize_residual reads from its arguments, the CU and the encoder state (quant-generic.c:460-612). */
 typedef struct uvghip_qr_params {
   int32_t width, height, color;                          /* TU shape; COLOR_Y/U/V = 0/1/2 */

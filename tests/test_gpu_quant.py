@@ -166,6 +166,12 @@ def test_tu_halves_vs_oracle(hip, orc, depth, shape, misalign):
         deq.copy_(api.dequant_batch(lev, depth, qps, False))
         drec = dpred.clone()
         assert L.uvghip_tu_inverse_batch(depth, th, tv, sw, sh, w, h, 0, P(deq), P(dpred), st, P(drec), st, P(tus), n, None) == 0
+        if w == h and not misalign:      # the fused dequantise-on-load inverse gives the same picture
+            drec2 = dpred.clone()
+            assert L.uvghip_tu_dequant_inverse_batch(depth, th, tv, w, h, qps, P(lev), P(dpred), st, P(drec2), st, P(tus), n, None) == 0
+            assert torch.equal(drec2, drec), (th, tv)
+        elif w != h:
+            assert L.uvghip_tu_dequant_inverse_batch(depth, th, tv, w, h, qps, P(lev), P(dpred), st, P(dpred.clone()), st, P(tus), n, None) != 0
         rec, lv, cf = drec.cpu().numpy(), lev.cpu().numpy(), coef.cpu().numpy()
         want_rec = pred.copy()
         for i, (x0, y0) in enumerate(xy):

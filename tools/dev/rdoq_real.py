@@ -10,8 +10,10 @@ g = pipeline.FrameGroup(L, wl, 0, F, "cuda", api.make_modes(pipeline.MODES))
 st = torch.cuda.current_stream().cuda_stream
 pipeline.run(g.searches() + g.heads_rest(), st)
 torch.cuda.synchronize()
-for k in range(0, len(g.mid), 2):
+for k in range(len(g.mid)):
     name, fn, args = g.mid[k]
+    if not name.startswith("rdoq"):
+        continue
     for _ in range(2):
         pipeline.run([g.mid[k]], st)
     torch.cuda.synchronize()

@@ -23,6 +23,7 @@
 struct quant_params {
   int scale, add; int q_bits;      // level = (|c| * scale + add) >> q_bits   (int64 product)
   int iscale, iadd, ishift;        // coef  = clip16((q * iscale + iadd) >> ishift)
+  int dq_on_load;                  // TU_INV kernels: the input holds LEVELS, dequantise them as they are loaded
 };
 
 static quant_params make_quant_params(int bitdepth, int width, int height, int qp_scaled, int transform_skip,
@@ -42,6 +43,7 @@ static quant_params make_quant_params(int bitdepth, int width, int height, int q
   q.ishift = 20 - 14 - (transform_skip ? 0 : tshift_d - sqrt2);
   q.iscale = iqs[sqrt2][qp_scaled % 6] << (qp_scaled / 6);
   q.iadd = 1 << (q.ishift - 1);
+  q.dq_on_load = 0;
   return q;
 }
 
@@ -536,6 +538,15 @@ tu_lane_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int ori
         rows[j][0] = w.x; rows[j][1] = w.y;
       }
     }
+    if (Q.dq_on_load) {                                              // (uniform) levels in: uvg_dequant on the way, quant-generic.c:618-669
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int c = 0; c < N / 2; ++c) {
+          const int lo = dequant_one((int)(int16_t)(rows[j][c] & 0xffffu), Q), hi = dequant_one((int)(int16_t)(rows[j][c] >> 16), Q);
+          rows[j][c] = __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
+        }
+    }
 #pragma unroll
     for (int c = 0; c < N; ++c)
 #pragma unroll
@@ -758,8 +769,12 @@ tu_wave_kernel(tr_params P, quant_params Q, const PX *__restrict__ orig, int ori
     const uint4 v0 = *reinterpret_cast<const uint4 *>(src), v1 = *reinterpret_cast<const uint4 *>(src + 8);
     const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
     int16_t *dst = bufA + lb * W::BLK + x0 * W::PITCH + row;
+    const bool dq = Q.dq_on_load != 0;                                  // (uniform) levels in: uvg_dequant on the way
 #pragma unroll
-    for (int k = 0; k < 16; ++k) dst[k * W::PITCH] = (int16_t)(w[k >> 1] >> (16 * (k & 1)));
+    for (int k = 0; k < 16; ++k) {
+      const int cv = (int)(int16_t)(w[k >> 1] >> (16 * (k & 1)));
+      dst[k * W::PITCH] = (int16_t)(dq ? dequant_one(cv, Q) : cv);
+    }
   }
   if constexpr (MODE != TU_INV) {
   // residual rows -> bufA[b][y][x]
@@ -1091,6 +1106,27 @@ extern "C" int uvghip_tu_inverse_batch(int bitdepth, int type_hor, int type_ver,
   if (bitdepth == 8) tu_roundtrip_kernel<uint8_t, TU_INV><<<grid, 256, 0, st>>>(P, Q, nullptr, 0, (const uint8_t *)pred, pred_stride, (uint8_t *)rec, rec_stride, tus, n, bpg, c, nullptr, use_trskip);
   else tu_roundtrip_kernel<uint16_t, TU_INV><<<grid, 256, 0, st>>>(P, Q, nullptr, 0, (const uint16_t *)pred, pred_stride, (uint16_t *)rec, rec_stride, tus, n, bpg, c, nullptr, use_trskip);
   UVGHIP_CHECK_LAUNCH();
+}
+
+// uvghip_dequant_batch + uvghip_tu_inverse_batch in one launch for the square shapes of the register / wave kernels: the
+// kernels dequantise the levels as they load them (one launch and one trip of the coefficients through HBM less).
+extern "C" int uvghip_tu_dequant_inverse_batch(int bitdepth, int type_hor, int type_ver, int width, int height, int qp_scaled,
+                                               const int16_t *levels, const void *pred, int pred_stride, void *rec, int rec_stride,
+                                               const uvghip_tu_t *tus, int n, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (int rc = tu_half_check(bitdepth, type_hor, type_ver, 0, 0, width, height, __func__)) return rc;
+  if (int rc = check_qargs(bitdepth, width, height, qp_scaled)) return rc;
+  if (!tu_half_fast(width, height, 0, 0, 0, levels))
+    return uvghip_set_error(hipErrorNotSupported, "uvghip_tu_dequant_inverse_batch: square blocks, 16-byte aligned levels (else dequant_batch + tu_inverse_batch)");
+  if (n <= 0) return 0;
+  const tr_params P = tr_make_params(bitdepth, type_hor, type_ver, width, height, 0, 0);
+  quant_params Q = make_quant_params(bitdepth, width, height, qp_scaled, 0, 1);
+  Q.dq_on_load = 1;
+  hipStream_t st = uvghip_stream(stream);
+  int16_t *c = const_cast<int16_t *>(levels);
+  const void *orig = nullptr; const int orig_stride = 0;
+  TU_HALF_DISPATCH(TU_INV, orig, orig_stride, c);
 }
 
 // ---- the staged round trip: every branch of uvg_quantize_residual (quant-generic.c:460-612) ----

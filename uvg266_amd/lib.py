@@ -90,6 +90,7 @@ SIGNATURES = {
     "uvghip_rdoq_signhide_batch": (c_int, [c_int, c_vp, c_vp] + [c_int] * 9 + [ctypes.c_double, c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp, c_vp]),
     "uvghip_tu_forward_batch": (c_int, [c_int] * 8 + [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_tu_inverse_batch": (c_int, [c_int] * 8 + [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp]),
+    "uvghip_tu_dequant_inverse_batch": (c_int, [c_int] * 6 + [c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp]),
     "uvghip_quantize_residual_workspace_bytes": (ctypes.c_size_t, [c_vp, c_int]),
     "uvghip_quantize_residual_batch": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp,
                                                ctypes.c_size_t, c_vp]),

@@ -351,9 +351,9 @@ class FrameGroup:
                 return
             self._heads.append((f"tu_forward_{tag}", L.uvghip_tu_forward_batch,
                                 [depth, 0, 0, 0, 0, c, c, 0, P(orig), st, P(pred), st, P(tus), cnt, P(j["coef"])]))
-            self.mid += quantiser_launches(L, fr, tag, color, c, qp_scaled, j, 0, F)
-            self._tails.append((f"tu_inverse_{tag}", L.uvghip_tu_inverse_batch,
-                                [depth, 0, 0, 0, 0, c, c, 0, P(j["deq"]), P(pred), st, P(rec), st, P(tus), cnt]))
+            self.mid += quantiser_launches(L, fr, tag, color, c, qp_scaled, j, 0, F)[:1]      # RDOQ; dequantisation rides on the inverse
+            self._tails.append((f"tu_inverse_{tag}", L.uvghip_tu_dequant_inverse_batch,
+                                [depth, 0, 0, c, c, qp_scaled, P(j["lev"]), P(pred), st, P(rec), st, P(tus), cnt]))
 
         for n in SIZES:
             cnt = fr.tables[n][2]
@@ -567,9 +567,8 @@ class ClosedLoopIntra:
                     ("cl_rdoq", L.uvghip_rdoq_batch,
                      [depth, off(j["coef"], 2 * c * c), off(j["lev"], 2 * c * c), c, c, k, color, 1, 0, 0, 0, q, ctypes.c_double(lam),
                       ctypes.cast(self._ctx, ctypes.c_void_p), P(j["ws"]), j["ws"].numel() * 8, None, off(j["has"], 1)]),
-                    ("cl_dequant", L.uvghip_dequant_batch, [depth, off(j["lev"], 2 * c * c), off(j["deq"], 2 * c * c), c, c, k, q, 0]),
-                    ("cl_tu_inverse", L.uvghip_tu_inverse_batch,
-                     [depth, 0, 0, 0, 0, c, c, 0, off(j["deq"], 2 * c * c), P(pred), st, P(rec), st, tp, k])]
+                    ("cl_tu_dequant_inverse", L.uvghip_tu_dequant_inverse_batch,
+                     [depth, 0, 0, c, c, q, off(j["lev"], 2 * c * c), P(pred), st, P(rec), st, tp, k])]
         del es
 
     def clear(self):
