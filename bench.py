@@ -184,7 +184,7 @@ class Slot:
         frs = grp.frames
         # kernel segments between exchanges: [everything before the filters + vertical deblocking of every picture], then per
         # picture [x_dbk] stage_b [x_alf] stage_c [reduce, gather]; neighbouring kernel segments merge when no exchange separates them
-        # the quantiser launches (RDOQ + dequantisation per block shape over the group) stay eager between two graphs: they are
+        # the quantiser launches (RDOQ per block shape over the group) stay eager between two graphs: they are
         # the long kernels, and the roofline's HIP events go around them when they are the dominant family
         self.plan = []      # ("kernels", launches) | ("eager", launches) | ("comm", launches)
         if grp.mid:
@@ -534,7 +534,7 @@ def main():
                        "streams": 1 if args.serial else args.streams, "hipgraph": not args.no_graphs,
                        "pictures_per_group": r["group"],
                        "note": "steps are pictures; they are issued in groups of pictures_per_group (frame-parallel operation, uvg266 --owf): "
-                               "plane kernels per picture, RDOQ + dequantisation once per block shape over the group"},
+                               "block-list kernels (search, predict, transforms, RDOQ) and SAO once per block shape over the group, deblocking / ALF per picture"},
         }
         if strong:
             cb = fr.comm_bytes()
