@@ -364,8 +364,10 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   __syncthreads();
   const rdoq_params &P = sP;
   __shared__ uint32_t sB[N_CTXS][2];
-  __shared__ int sLastXp[32], sLastYp[32];                             // get_rate_last (:645-658) per coordinate: prefix bits + suffix bits
-  __shared__ uint8_t sScanCg[64];
+  // (sized by the shape: the LDS allocator's granule is 1280 bytes, and 176 bytes less put an eighth 16x16 workgroup on a CU)
+  constexpr int NSIDE = SHAPE ? (1 << SHAPE) : 32, NCGS = SHAPE ? (1 << (2 * SHAPE - 4)) : 64;
+  __shared__ int sLastXp[NSIDE], sLastYp[NSIDE];                       // get_rate_last (:645-658) per coordinate: prefix bits + suffix bits
+  __shared__ uint8_t sScanCg[NCGS < 4 ? 4 : NCGS];
   // per group and position s4: D[3*s4 + {0: distortion of candidate 1 -> coded_cost, 1: candidate 2 -> coded_sig, 2: cost0}],
   // I[3*s4 + {0: rate half of candidate 1 -> level, 1: candidate 2, 2: level_double}]
   __shared__ double sStageD[TUS][49];
