@@ -364,10 +364,10 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   __syncthreads();
   const rdoq_params &P = sP;
   __shared__ uint32_t sB[N_CTXS][2];
-  // (sized by the shape: the LDS allocator's granule is 1280 bytes, and 176 bytes less put an eighth 16x16 workgroup on a CU)
-  constexpr int NSIDE = SHAPE ? (1 << SHAPE) : 32, NCGS = SHAPE ? (1 << (2 * SHAPE - 4)) : 64;
+  // (16x16: sized by the shape -- the LDS allocator's granule is 1280 bytes, and 176 bytes less put an eighth workgroup on a CU)
+  constexpr int NSIDE = SHAPE == 4 ? 16 : 32, NCGS = SHAPE == 4 ? 16 : 64;
   __shared__ int sLastXp[NSIDE], sLastYp[NSIDE];                       // get_rate_last (:645-658) per coordinate: prefix bits + suffix bits
-  __shared__ uint8_t sScanCg[NCGS < 4 ? 4 : NCGS];
+  __shared__ uint8_t sScanCg[NCGS];
   // per group and position s4: D[3*s4 + {0: distortion of candidate 1 -> coded_cost, 1: candidate 2 -> coded_sig, 2: cost0}],
   // I[3*s4 + {0: rate half of candidate 1 -> level, 1: candidate 2, 2: level_double}]
   __shared__ double sStageD[TUS][49];
@@ -377,6 +377,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
   const int width = 1 << l2w, height = 1 << l2h_, wh = width * height;
   const int n = P.n;
   constexpr bool BYTES = SHAPE == 5 && !SIGNHIDE;                      // byte level array (see rdoq_lds_per_block)
+  constexpr bool SCAN_WS = !(SHAPE == 2 || SHAPE == 3);                // cost / significance workspace indexed by scan position
   const size_t per_tu = rdoq_lds_per_block(wh, BYTES);
   const int t = SHAPE ? CHROMA : (P.color ? 1 : 0);
   const int mts = P.mts_idx;
@@ -817,8 +818,10 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
           const int bp = blk_in(g, in_cg(s4));
           // (the workspace arrays are private to the kernel: indexed by SCAN position, so that the 16 positions of a group are 128
           //  / 16 contiguous bytes -- with the block's own raster order every store was a partial 32-byte sector)
-          gCost[cgs * 16 + s4] = D[3 * s4];
-          gSig[cgs * 16 + s4] = (uint8_t)I[3 * s4 + 1];
+          //  (4x4 / 8x8 blocks keep the raster index: their few groups gain little and the extra index costs the 168-register fit)
+          const int wi = SCAN_WS ? cgs * 16 + s4 : bp;
+          gCost[wi] = D[3 * s4];
+          gSig[wi] = (uint8_t)I[3 * s4 + 1];
           if (BYTES) gOut[bp] = (int16_t)I[3 * s4];
         }
       }
@@ -846,9 +849,9 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       const int o1 = j == 1 ? 2 : j == 2 ? 1 : 0, o2 = j == 2 ? 2 : 1;
       acc_a = j == 0 ? base_cost : j == 1 ? block_uncoded_cost : 0.0;
       const double *Dp = D + o1, *Dq = D + o2;
+      constexpr int PW = 8;                                              // eight positions' operands in flight at a time
 #pragma unroll
-      for (int part = 1; part >= 0; --part) {                            // eight positions' operands in flight at a time
-        constexpr int PW = 8;
+      for (int part = 16 / PW - 1; part >= 0; --part) {
         double pv[PW], qv[PW];
 #pragma unroll
         for (int u = PW - 1; u >= 0; --u) { pv[u] = Dp[3 * (PW * part + u)]; qv[u] = Dq[3 * (PW * part + u)]; }   // (past max_group: stale, unused)
@@ -909,7 +912,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
         for (int r = 0; r < 4; ++r) {
           const int s4 = j + 4 * r;
           const int blkpos = blk_in(g, in_cg(s4));
-          if (s4 <= max_group && lev_get(blkpos)) { lev_set(blkpos, 0); gCost[cgs * 16 + s4] = D[3 * s4 + 2]; gSig[cgs * 16 + s4] = 0; if (BYTES) gOut[blkpos] = 0; }
+          if (s4 <= max_group && lev_get(blkpos)) { lev_set(blkpos, 0); const int wi = SCAN_WS ? cgs * 16 + s4 : blkpos; gCost[wi] = D[3 * s4 + 2]; gSig[wi] = 0; if (BYTES) gOut[blkpos] = 0; }
         }
     } else if (has_last && j == 0) {
       gCgCost[cgs] = 0;                                                  // groups skipped by the MTS zero-out keep a zero flag cost
@@ -941,7 +944,7 @@ rdoq_kernel(const rdoq_params Pk, const int16_t *__restrict__ coef, int16_t *__r
       for (int r = 0; r < 4; ++r) {
         const int s4 = j + 4 * r;
         const int b2 = blk_in(g, in_cg(s4 <= max_group ? s4 : 0));
-        const int sp = cgs * 16 + (s4 <= max_group ? s4 : 0);
+        const int sp = SCAN_WS ? cgs * 16 + (s4 <= max_group ? s4 : 0) : b2;
         pf_cost[r] = gCost[sp]; pf_coef[r] = (int)gCoef[b2]; pf_sig[r] = (int)gSig[sp];
       }
     };
