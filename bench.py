@@ -558,7 +558,10 @@ def main():
                     "traffic": hbm["traffic"], "insts_per_launch": insts, "avg_launch_ms": live[dom]["avg_ms"], "serial_avg_launch_ms": alone_ms,
                     "launches_timed": live[dom]["launches"],
                     "note": ("the dominant kernel family is RDOQ (uvg_rdoq: a sequential walk per transform block, double-precision costs in "
-                             "the reference's order); it is bound by instruction issue, not by HBM: " if dom.startswith("rdoq") else
+                             "the reference's order); a launch is rounds x wave latency (resident blocks are bound by LDS / registers, a wave "
+                             "issues an instruction every ~10 cycles), not HBM-bound; `traffic` (PMC) is mostly the kernel's private workspace "
+                             "-- cost_coeff[] as doubles, written once and partly re-read, the roles of the reference's three stack arrays -- "
+                             "and 2-byte gathers in scan order, not re-reads of the algorithmic bytes (coefficients in, levels out): " if dom.startswith("rdoq") else
                              "the dominant kernel (rough intra search) is integer-VALU-issue bound, not HBM bound: ") +
                             "achieved = SQ_INSTS_VALU per launch (PMC pass, profiles/) / the launch's average duration from HIP events "
                             "recorded inside the timed region on its own stream, where other pictures' kernels share the GPU; *_alone = the "
