@@ -280,6 +280,78 @@ class Oracle:
         return ee, yv, pa
 
 
+# ---- closed-loop CTU search (oracle/orc_search.c) ------------------------------
+class SearchParams(ctypes.Structure):
+    """orc_search_params: what the search reads from encoder_state_t / encoder_control_t."""
+    _fields_ = [("pic_w", ctypes.c_int32), ("pic_h", ctypes.c_int32), ("qp", ctypes.c_int32), ("qp_c", ctypes.c_int32),
+                ("depth_min", ctypes.c_int32), ("depth_max", ctypes.c_int32), ("wpp", ctypes.c_int32),
+                ("combine_intra_cus", ctypes.c_int32), ("rough_levels", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("lam", ctypes.c_double), ("lam_sqrt", ctypes.c_double), ("c_lam", ctypes.c_double),
+                ("cw_u", ctypes.c_double), ("cw_v", ctypes.c_double)]
+
+
+N_MODELS = 257
+MODELS_BYTES = 1286          # uint16 state0[257], state1[257], uint8 rate[257], padded to 2
+
+
+def search_params(W, H, qp, lam=None):
+    """--preset medium -p 1 (pu-depth-intra 1-4, WPP, combine-intra-cus, two rough-search levels); the default chroma QP
+    table is the identity, lambda = 0.57 * 2^((qp - 12) / 3) for an intra picture (rate_control.c qp_to_lambda)."""
+    lam = 0.57 * 2.0 ** ((qp - 12) / 3.0) if lam is None else lam
+    return SearchParams(W, H, qp, qp, 1, 4, 1, 1, 2, 0, lam, float(np.sqrt(lam)), lam, 1.0, 1.0)
+
+
+def oracle_search_picture(orc, depth, prm, y, u, v):
+    """-> dict(rec_y, rec_u, rec_v, cu [h16, w16, 11], trees [h16, w16, 2], coeff [ctus, 6144], models [ctus, 3, 1286])"""
+    W, H = prm.pic_w, prm.pic_h
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    px = px_dtype(depth)
+    y, u, v = (np.ascontiguousarray(a, px) for a in (y, u, v))
+    ry, ru, rv = np.zeros((H, W), px), np.zeros((H // 2, W // 2), px), np.zeros((H // 2, W // 2), px)
+    cu = np.zeros((hc * 16, wc * 16, 20), np.uint8)
+    co = np.zeros((wc * hc, 6144), np.int16)
+    mo = np.zeros((wc * hc, 3, MODELS_BYTES), np.uint8)
+    rc = orc.fn(depth, "search_intra_picture")(ctypes.byref(prm), ptr(y), ptr(u), ptr(v), ptr(ry), ptr(ru), ptr(rv), ptr(cu), ptr(co), ptr(mo))
+    assert rc == 0
+    trees = np.ascontiguousarray(cu[:, :, 12:]).view(np.uint32).reshape(hc * 16, wc * 16, 2)
+    return dict(rec_y=ry, rec_u=ru, rec_v=rv, cu=cu[:, :, :11].copy(), trees=trees, coeff=co, models=mo)
+
+
+def ctu_crcs(res, W, H):
+    """Per CTU CRC-32 of the in-picture cu fields + trees / reconstruction / levels / models after the coder, as
+    tools/refcheck/make_ctu_goldens.py computes them from the reference's records."""
+    import zlib
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    out = np.zeros((hc * wc, 4), np.uint32)
+    c = np.ascontiguousarray
+    for cy in range(hc):
+        for cx in range(wc):
+            x, y, k = cx * 64, cy * 64, cy * wc + cx
+            hh, ww = min(64, H - y), min(64, W - x)
+            out[k, 0] = zlib.crc32(c(res["cu"][y // 4:(y + hh) // 4, x // 4:(x + ww) // 4]).tobytes() +
+                                   c(res["trees"][y // 4:(y + hh) // 4, x // 4:(x + ww) // 4]).tobytes())
+            out[k, 1] = zlib.crc32(c(res["rec_y"][y:y + hh, x:x + ww]).tobytes() + c(res["rec_u"][y // 2:(y + hh) // 2, x // 2:(x + ww) // 2]).tobytes() +
+                                   c(res["rec_v"][y // 2:(y + hh) // 2, x // 2:(x + ww) // 2]).tobytes())
+            co = res["coeff"][k]
+            out[k, 2] = zlib.crc32(c(co[:4096].reshape(64, 64)[:hh, :ww]).tobytes() + c(co[4096:].reshape(2, 32, 32)[:, :hh // 2, :ww // 2]).tobytes())
+            out[k, 3] = zlib.crc32(c(res["models"][k, 2]).tobytes())
+    return out
+
+
+def ctu_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def golden_source(g):
+    """The synthetic source picture of a ref_ctu* golden; its CRC pins the generator."""
+    import zlib
+    from uvg266_amd import layout
+    W, H, depth, qp, t = (int(a) for a in g["meta"][:5])
+    y, u, v = layout.synthetic_yuv420(W, H, t, depth)
+    assert zlib.crc32(y.tobytes() + u.tobytes() + v.tobytes()) == int(g["src_crc"]), "synthetic generator drifted from the golden's source"
+    return W, H, depth, qp, y, u, v
+
+
 # ---- golden container (written by tools/refcheck/refcheck.c) ----------------
 _DT = {0: np.uint8, 1: np.uint16, 2: np.int16, 3: np.int32, 4: np.uint32, 5: np.int64, 6: np.float64}
 

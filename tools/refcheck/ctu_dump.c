@@ -1,0 +1,194 @@
+/*
+ * Dev-time tool: run the REAL reference encoder (libuvg266.a built from the unmodified reference, see README.md) on a yuv file
+ * and record, per CTU, what crosses the boundary of the closed-loop CTU search:
+ *   - the CABAC models the search starts from (state->cabac.ctx when uvg_search_lcu is entered, src/search.c:2386),
+ *   - lambda / qp of the CTU,
+ *   - after uvg_search_lcu: the models the search ends with, the CTU's cu_info_t entries (frame->cu_array), its
+ *     reconstruction before any in-loop filter (frame->rec, written by copy_lcu_to_cu_data, search.c:2331) and its
+ *     coefficients (lcu_coeff_t),
+ *   - after the CTU's uvg_encode_coding_tree (src/encoderstate.c:888): the models the real coder ends with.
+ * The two functions are intercepted with the linker (-Wl,--wrap=...); nothing in the reference is modified.  The .266
+ * bitstream the encoder produced is written next to the records.
+ *
+ *   ctu_dump <in.yuv> <W> <H> <frames> <out.bin> <out.266> [option value]...
+ *
+ * Not part of the product, the tests or the bench; tools/refcheck/ctu_dump.sh builds and runs it and
+ * tools/refcheck/ctu_to_npz.py turns the records into tests/golden/ref_ctu_*.npz.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+
+#include "uvg266.h"
+#include "encoderstate.h"
+#include "cabac.h"
+#include "cu.h"
+#include "videoframe.h"
+#include "search.h"
+#include "encode_coding_tree.h"
+
+static FILE *g_out;
+
+enum { NCTX = 257 };
+typedef struct { uint16_t state0[NCTX], state1[NCTX]; uint8_t rate[NCTX]; } models_t;
+
+static void put(models_t *s, int at, const cabac_ctx_t *src, int n)
+{
+  for (int i = 0; i < n; ++i) { s->state0[at + i] = src[i].state[0]; s->state1[at + i] = src[i].state[1]; s->rate[at + i] = src[i].rate; }
+}
+/* model index space of oracle/orc_search.c: the 244 residual models of orc_coeff_cost.c, then the CU-level ones */
+static void snapshot(const cabac_data_t *cb, models_t *s)
+{
+  memset(s, 0, sizeof *s);
+  put(s, 0, &cb->ctx.sig_coeff_group_model[0], 4);
+  put(s, 4, cb->ctx.cu_sig_model_luma[0], 12); put(s, 16, cb->ctx.cu_sig_model_chroma[0], 8);
+  put(s, 28, cb->ctx.cu_parity_flag_model_luma, 21); put(s, 49, cb->ctx.cu_parity_flag_model_chroma, 11);
+  put(s, 70, cb->ctx.cu_gtx_flag_model_luma[1], 21); put(s, 91, cb->ctx.cu_gtx_flag_model_chroma[1], 11);
+  put(s, 112, cb->ctx.cu_gtx_flag_model_luma[0], 21); put(s, 133, cb->ctx.cu_gtx_flag_model_chroma[0], 11);
+  put(s, 154, cb->ctx.cu_ctx_last_x_luma, 20); put(s, 174, cb->ctx.cu_ctx_last_x_chroma, 3);
+  put(s, 194, cb->ctx.cu_ctx_last_y_luma, 20); put(s, 214, cb->ctx.cu_ctx_last_y_chroma, 3);
+  put(s, 234, cb->ctx.qt_cbf_model_luma, 4); put(s, 238, cb->ctx.qt_cbf_model_cb, 2); put(s, 240, cb->ctx.qt_cbf_model_cr, 3);
+  put(s, 243, &cb->ctx.cu_qt_root_cbf_model, 1);
+  put(s, 244, cb->ctx.split_flag_model, 9);
+  put(s, 253, &cb->ctx.intra_luma_mpm_flag_model, 1);
+  put(s, 254, cb->ctx.luma_planar_model, 2);
+  put(s, 256, &cb->ctx.chroma_pred_model, 1);
+}
+
+static void rec_begin(const char *name, int narr)
+{
+  uint32_t magic = 0x52454631, nl = (uint32_t)strlen(name), na = (uint32_t)narr;
+  fwrite(&magic, 4, 1, g_out); fwrite(&nl, 4, 1, g_out); fwrite(name, 1, nl, g_out); fwrite(&na, 4, 1, g_out);
+}
+static void rec_arr(int code, const void *p, size_t n)
+{
+  static const int sz[] = {1, 2, 2, 4, 4, 8, 8};  /* u8 u16 i16 i32 u32 i64 f64 */
+  uint32_t c = (uint32_t)code, nn = (uint32_t)n;
+  fwrite(&c, 4, 1, g_out); fwrite(&nn, 4, 1, g_out); fwrite(p, (size_t)sz[code], n, g_out);
+}
+enum { A_U8 = 0, A_U16 = 1, A_I16 = 2, A_I32 = 3, A_U32 = 4, A_I64 = 5, A_F64 = 6 };
+#define A_PX (UVG_BIT_DEPTH == 8 ? A_U8 : A_U16)
+
+void __real_uvg_search_lcu(encoder_state_t *const state, const int x, const int y, const yuv_t *const hor_buf, const yuv_t *const ver_buf,
+                           lcu_coeff_t *coeff);
+void __wrap_uvg_search_lcu(encoder_state_t *const state, const int x, const int y, const yuv_t *const hor_buf, const yuv_t *const ver_buf,
+                           lcu_coeff_t *coeff)
+{
+  models_t before, after;
+  snapshot(&state->cabac, &before);
+  __real_uvg_search_lcu(state, x, y, hor_buf, ver_buf, coeff);
+  snapshot(&state->search_cabac, &after);
+  const videoframe_t *frame = state->tile->frame;
+  int32_t meta[8] = {(int32_t)state->frame->num, x, y, state->qp, frame->width, frame->height, state->frame->slicetype, state->frame->QP};
+  double lam[6] = {state->lambda, state->lambda_sqrt, state->c_lambda, state->chroma_weights[1], state->chroma_weights[2], state->chroma_weights[3]};
+  /* compact cu_info per 4x4 */
+  uint8_t cu[256][12];
+  uint32_t trees[256][2];
+  memset(cu, 0, sizeof cu); memset(trees, 0, sizeof trees);
+  static uvg_pixel ry[64 * 64], ru[32 * 32], rv[32 * 32];
+  memset(ry, 0, sizeof ry); memset(ru, 0, sizeof ru); memset(rv, 0, sizeof rv);
+  for (int yy = 0; yy < 64; yy += 4)
+    for (int xx = 0; xx < 64; xx += 4) {
+      if (x + xx >= frame->width || y + yy >= frame->height) continue;
+      const cu_info_t *c = uvg_cu_array_at_const(frame->cu_array, x + xx, y + yy);
+      uint8_t *o = cu[(yy >> 2) * 16 + (xx >> 2)];
+      o[0] = c->type; o[1] = c->log2_width; o[2] = c->log2_height; o[3] = c->log2_chroma_width; o[4] = c->log2_chroma_height;
+      o[5] = (uint8_t)c->cbf; o[6] = (uint8_t)c->intra.mode; o[7] = (uint8_t)c->intra.mode_chroma; o[8] = c->luma_deblocking;
+      o[9] = c->chroma_deblocking; o[10] = c->qp; o[11] = (uint8_t)(c->tr_skip | (c->tr_idx << 3) | (c->joint_cb_cr << 6));
+      trees[(yy >> 2) * 16 + (xx >> 2)][0] = c->split_tree;
+      trees[(yy >> 2) * 16 + (xx >> 2)][1] = c->mode_type_tree;
+    }
+  for (int yy = 0; yy < 64 && y + yy < frame->height; ++yy)
+    for (int xx = 0; xx < 64 && x + xx < frame->width; ++xx) ry[yy * 64 + xx] = frame->rec->y[(y + yy) * frame->rec->stride + x + xx];
+  for (int yy = 0; yy < 32 && y / 2 + yy < frame->height / 2; ++yy)
+    for (int xx = 0; xx < 32 && x / 2 + xx < frame->width / 2; ++xx) {
+      ru[yy * 32 + xx] = frame->rec->u[(y / 2 + yy) * (frame->rec->stride / 2) + x / 2 + xx];
+      rv[yy * 32 + xx] = frame->rec->v[(y / 2 + yy) * (frame->rec->stride / 2) + x / 2 + xx];
+    }
+  rec_begin("search", 11);
+  rec_arr(A_I32, meta, 8); rec_arr(A_F64, lam, 6);
+  rec_arr(A_U8, &before, sizeof before); rec_arr(A_U8, &after, sizeof after);
+  rec_arr(A_U8, cu, sizeof cu); rec_arr(A_U32, trees, 512);
+  rec_arr(A_PX, ry, 64 * 64); rec_arr(A_PX, ru, 32 * 32); rec_arr(A_PX, rv, 32 * 32);
+  rec_arr(A_I16, coeff->y, 64 * 64);
+  {
+    static int16_t uv[2 * 32 * 32];
+    memcpy(uv, coeff->u, 2 * 32 * 32); memcpy(uv + 32 * 32, coeff->v, 2 * 32 * 32);
+    rec_arr(A_I16, uv, 2 * 32 * 32);
+  }
+}
+
+void __real_uvg_encode_coding_tree(encoder_state_t *const state, lcu_coeff_t *coeff, enum uvg_tree_type tree_type, const cu_loc_t *const cu_loc,
+                                   const cu_loc_t *const chroma_loc, split_tree_t split_tree, bool has_chroma);
+void __wrap_uvg_encode_coding_tree(encoder_state_t *const state, lcu_coeff_t *coeff, enum uvg_tree_type tree_type, const cu_loc_t *const cu_loc,
+                                   const cu_loc_t *const chroma_loc, split_tree_t split_tree, bool has_chroma)
+{
+  models_t before, after;
+  snapshot(&state->cabac, &before);
+  __real_uvg_encode_coding_tree(state, coeff, tree_type, cu_loc, chroma_loc, split_tree, has_chroma);
+  snapshot(&state->cabac, &after);
+  int32_t meta[3] = {(int32_t)state->frame->num, cu_loc->x, cu_loc->y};
+  rec_begin("coded", 3);
+  rec_arr(A_I32, meta, 3); rec_arr(A_U8, &before, sizeof before); rec_arr(A_U8, &after, sizeof after);
+}
+
+int main(int argc, char **argv)
+{
+  if (argc < 7) { fprintf(stderr, "usage: %s in.yuv W H frames out.bin out.266 [opt val]...\n", argv[0]); return 2; }
+  const int W = atoi(argv[2]), H = atoi(argv[3]), nframes = atoi(argv[4]);
+  FILE *in = fopen(argv[1], "rb");
+  g_out = fopen(argv[5], "wb");
+  FILE *bs = fopen(argv[6], "wb");
+  if (!in || !g_out || !bs) { perror("open"); return 2; }
+  const uvg_api *api = uvg_api_get(UVG_BIT_DEPTH);
+  uvg_config *cfg = api->config_alloc();
+  api->config_init(cfg);
+  char res[64];
+  snprintf(res, sizeof res, "%dx%d", W, H);
+  int ok = api->config_parse(cfg, "input-res", res);
+  ok &= api->config_parse(cfg, "threads", "0");
+  ok &= api->config_parse(cfg, "owf", "0");
+  ok &= api->config_parse(cfg, "cpuid", "0");
+  for (int i = 7; i + 1 < argc; i += 2) {
+    if (!api->config_parse(cfg, argv[i], argv[i + 1])) { fprintf(stderr, "bad option %s %s\n", argv[i], argv[i + 1]); return 2; }
+  }
+  if (!ok) { fprintf(stderr, "config failed\n"); return 2; }
+  uvg_encoder *enc = api->encoder_open(cfg);
+  if (!enc) { fprintf(stderr, "encoder_open failed\n"); return 2; }
+  int fed = 0, done = 0;
+  for (;;) {
+    uvg_picture *pic = NULL;
+    if (fed < nframes) {
+      pic = api->picture_alloc(W, H);
+      for (int p = 0; p < 3; ++p) {
+        const int w = p ? W / 2 : W, h = p ? H / 2 : H;
+        uvg_pixel *dst = p == 0 ? pic->y : (p == 1 ? pic->u : pic->v);
+        const int stride = p ? pic->stride / 2 : pic->stride;
+        for (int y = 0; y < h; ++y)
+          if (fread(dst + (size_t)y * stride, sizeof(uvg_pixel), (size_t)w, in) != (size_t)w) { fprintf(stderr, "short read\n"); return 2; }
+      }
+      pic->pts = fed;
+      ++fed;
+    }
+    uvg_data_chunk *chunks = NULL;
+    uint32_t len = 0;
+    uvg_picture *rec = NULL, *src = NULL;
+    uvg_frame_info info;
+    if (!api->encoder_encode(enc, pic, &chunks, &len, &rec, &src, &info)) { fprintf(stderr, "encode failed\n"); return 2; }
+    api->picture_free(pic);
+    if (chunks) {
+      for (uvg_data_chunk *c = chunks; c; c = c->next) fwrite(c->data, 1, c->len, bs);
+      api->chunk_free(chunks);
+      ++done;
+    }
+    api->picture_free(rec); api->picture_free(src);
+    if (!pic && !chunks) break;
+    if (done >= nframes) break;
+  }
+  api->encoder_close(enc);
+  api->config_destroy(cfg);
+  fclose(g_out); fclose(bs); fclose(in);
+  fprintf(stderr, "ctu_dump: %d frames\n", done);
+  return 0;
+}

@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Dev-time: regenerate tests/golden/ref_ctu_*.npz / ref_ctucrc_*.npz from runs of the real reference encoder
+(tools/refcheck/ctu_dump.c through ctu_dump.sh; needs the survey's reference build, see README.md).
+
+  python tools/refcheck/make_ctu_goldens.py
+
+Full records (every CTU's models at its start / after its search / after the real coder, cu_info fields, reconstruction before
+the in-loop filters, levels) for two small pictures; per-CTU CRC-32 of the same items for BASELINE-sized pictures.
+The source pictures are uvg266_amd.layout.synthetic_yuv420; their CRC is stored so that a test notices a
+generator that drifted."""
+import os, struct, subprocess, sys, zlib
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from uvg266_amd import layout
+
+DT = [np.uint8, np.uint16, np.int16, np.int32, np.uint32, np.int64, np.float64]
+
+
+def read_records(path):
+    data = open(path, "rb").read()
+    p, recs = 0, []
+    while p < len(data):
+        magic, nl = struct.unpack_from("<II", data, p); p += 8
+        assert magic == 0x52454631
+        name = data[p:p + nl].decode(); p += nl
+        na, = struct.unpack_from("<I", data, p); p += 4
+        arrs = []
+        for _ in range(na):
+            c, n = struct.unpack_from("<II", data, p); p += 8
+            a = np.frombuffer(data, DT[c], n, p); p += a.nbytes
+            arrs.append(a)
+        recs.append((name, arrs))
+    return recs
+
+
+def run(W, H, depth, qp, t, tag):
+    px = np.uint8 if depth == 8 else np.uint16
+    y, u, v = layout.synthetic_yuv420(W, H, t, depth)
+    yuv = f"/tmp/gold_{tag}.yuv"
+    with open(yuv, "wb") as f:
+        for p in (y, u, v):
+            f.write(p.astype(px).tobytes())
+    out = f"/tmp/gold_{tag}"
+    subprocess.check_call([os.path.join(ROOT, "tools/refcheck/ctu_dump.sh"), str(depth), yuv, str(W), str(H), "1", out,
+                           "preset", "medium", "period", "1", "qp", str(qp)], stderr=subprocess.DEVNULL)
+    recs = read_records(out + ".bin")
+    S = [r for n, r in recs if n == "search"]
+    Cd = [r for n, r in recs if n == "coded"]
+    src_crc = zlib.crc32(y.tobytes() + u.tobytes() + v.tobytes())
+    bitstream = np.frombuffer(open(out + ".266", "rb").read(), np.uint8)
+    return S, Cd, src_crc, bitstream, px
+
+
+def items(s, c, W, H):
+    """In-picture parts of one CTU's record."""
+    x, y = int(s[0][1]), int(s[0][2])
+    hh, ww = min(64, H - y), min(64, W - x)
+    cu = s[4].reshape(16, 16, 12)[:hh // 4, :ww // 4, :11]
+    trees = s[5].reshape(16, 16, 2)[:hh // 4, :ww // 4]
+    ry, ru, rv = s[6].reshape(64, 64)[:hh, :ww], s[7].reshape(32, 32)[:hh // 2, :ww // 2], s[8].reshape(32, 32)[:hh // 2, :ww // 2]
+    cy = s[9].reshape(64, 64)[:hh, :ww]
+    cuv = s[10].reshape(2, 32, 32)[:, :hh // 2, :ww // 2]
+    return x, y, hh, ww, cu, trees, ry, ru, rv, cy, cuv
+
+
+def full(W, H, depth, qp, t=0):
+    tag = f"{W}x{H}_{depth}_qp{qp}"
+    S, Cd, src_crc, bs, px = run(W, H, depth, qp, t, tag)
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    assert len(S) == wc * hc == len(Cd)
+    models = np.zeros((hc * wc, 3, 1286), np.uint8)
+    cu = np.zeros((hc * 16, wc * 16, 11), np.uint8)
+    trees = np.zeros((hc * 16, wc * 16, 2), np.uint32)
+    rec = [np.zeros((H, W), px), np.zeros((H // 2, W // 2), px), np.zeros((H // 2, W // 2), px)]
+    coeff = np.zeros((hc * wc, 6144), np.int16)
+    for s, c in zip(S, Cd):
+        x, y, hh, ww, ccu, ctr, ry, ru, rv, cy, cuv = items(s, c, W, H)
+        k = (y // 64) * wc + x // 64
+        models[k, 0], models[k, 1], models[k, 2] = s[2][:1286], s[3][:1286], c[2][:1286]
+        cu[y // 4:y // 4 + hh // 4, x // 4:x // 4 + ww // 4] = ccu
+        trees[y // 4:y // 4 + hh // 4, x // 4:x // 4 + ww // 4] = ctr
+        rec[0][y:y + hh, x:x + ww] = ry
+        rec[1][y // 2:y // 2 + hh // 2, x // 2:x // 2 + ww // 2] = ru
+        rec[2][y // 2:y // 2 + hh // 2, x // 2:x // 2 + ww // 2] = rv
+        co = coeff[k]
+        co[:4096].reshape(64, 64)[:hh, :ww] = cy
+        co[4096:].reshape(2, 32, 32)[:, :hh // 2, :ww // 2] = cuv
+    meta = np.array([W, H, depth, qp, t, int(S[0][0][3])], np.int32)
+    np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_ctu_{tag}.npz"), meta=meta, lam=S[0][1], src_crc=np.uint32(src_crc), models=models,
+                        cu=cu, trees=trees, rec_y=rec[0], rec_u=rec[1], rec_v=rec[2], coeff=coeff, bitstream=bs)
+    print("wrote", tag, len(S), "CTUs")
+
+
+def crcs(W, H, depth, qp, t=0):
+    tag = f"{W}x{H}_{depth}_qp{qp}"
+    S, Cd, src_crc, bs, px = run(W, H, depth, qp, t, tag)
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    out = np.zeros((hc * wc, 4), np.uint32)          # cu+trees, reconstruction, levels, models after the coder
+    for s, c in zip(S, Cd):
+        x, y, hh, ww, ccu, ctr, ry, ru, rv, cy, cuv = items(s, c, W, H)
+        k = (y // 64) * wc + x // 64
+        out[k, 0] = zlib.crc32(np.ascontiguousarray(ccu).tobytes() + np.ascontiguousarray(ctr).tobytes())
+        out[k, 1] = zlib.crc32(np.ascontiguousarray(ry).tobytes() + np.ascontiguousarray(ru).tobytes() + np.ascontiguousarray(rv).tobytes())
+        out[k, 2] = zlib.crc32(np.ascontiguousarray(cy).tobytes() + np.ascontiguousarray(cuv).tobytes())
+        out[k, 3] = zlib.crc32(c[2][:1286].tobytes())
+    meta = np.array([W, H, depth, qp, t, int(S[0][0][3])], np.int32)
+    np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_ctucrc_{tag}.npz"), meta=meta, lam=S[0][1], src_crc=np.uint32(src_crc), crc=out,
+                        bitstream_crc=np.uint32(zlib.crc32(bs.tobytes())), bitstream_len=np.int64(len(bs)))
+    print("wrote crc", tag, len(S), "CTUs")
+
+
+if __name__ == "__main__":
+    full(832, 480, 8, 22)
+    full(416, 240, 10, 37)
+    crcs(1920, 1080, 8, 22)
+    crcs(1920, 1080, 10, 27, t=3)
+    crcs(3840, 2160, 10, 22)
