@@ -764,6 +764,58 @@ UVGHIP_API int uvghip_quant_cbcr_residual_percall(const uvghip_state_view_t *sv,
 UVGHIP_API void uvghip_bipred_average_percall(int bitdepth, void *dst, int dst_stride, const void *l0, int l0_is_im,
                                               const void *l1, int l1_is_im, unsigned pu_w, unsigned pu_h);
 
+/* ------------------- (4) closed-loop intra search of whole pictures: the CALLER of the block kernels, on the device ---- */
+
+/* replaces: encoder_state_worker_encode_lcu_search's uvg_search_lcu (src/encoderstate.c:808 -> src/search.c:2384-2479:
+ * search_cu's split / mode RD decisions, uvg_search_cu_intra's rough search, uvg_intra_recon_cu, uvg_rdoq, the bit costs of
+ * uvg_mock_encode_coding_unit / uvg_get_coeff_cost on state->search_cabac) for every CTU of n all-intra pictures, followed per CTU
+ * by the model adaptation of the real coder (uvg_encode_coding_tree, src/encoderstate.c:888) so that the next CTU -- and, under
+ * WPP, the first CTU of the next row (encoderstate.c:966-975) -- starts from the models the reference would hand it.
+ * One workgroup per CTU; CTUs of a picture are released along the WPP wavefront (left and upper neighbour done,
+ * encoderstate.c:1160-1167) through flags in device memory, pictures are independent (-p 1) and fill the device together.
+ * Configuration: what --preset medium -p 1 enables (rd 0, rdoq, pu-depth-intra min..max, quad-tree splits only, WPP,
+ * cu-split-termination zero, combine-intra-cus); anything else is refused.  Bit-exact with the reference: tests/golden/ref_ctu*.
+ *
+ * What the search reads from encoder_state_t / encoder_control_t: */
+typedef struct uvghip_ctu_params {
+  int32_t pic_w, pic_h;          /* multiples of 8 */
+  int32_t qp;                    /* state->qp */
+  int32_t qp_c;                  /* encoder_control->qp_map[0][qp] */
+  int32_t depth_min, depth_max;  /* cfg.pu_depth_intra */
+  int32_t wpp;                   /* cfg.wpp: must be 1 */
+  int32_t combine_intra_cus;     /* cfg.combine_intra_cus */
+  int32_t rough_levels;          /* cfg.intra_rough_search_levels: 2 or 3 */
+  int32_t reserved;
+  double lambda, lambda_sqrt;    /* state->lambda, state->lambda_sqrt */
+  double c_lambda;               /* state->c_lambda */
+  double chroma_weight_u, chroma_weight_v;   /* state->chroma_weights[1], [2] */
+  double c_lambda_tu;            /* uvg_calculate_chroma_lambda(state, 0, 0) (src/rate_control.c:1216): lambda / 2^((qp - qp_c) / 3) */
+} uvghip_ctu_params_t;
+
+/* One picture, everything in device memory.  src: the source planes.  rec: the reconstruction BEFORE the in-loop filters
+ * (frame->rec as copy_lcu_to_cu_data leaves it, search.c:2331).  cu: the picture's side information, one uvghip_scu_t per 4x4
+ * (frame->cu_array) with, for intra CUs, mv[0][0] = intra mode | chroma mode << 8, mv[0][1] = cu_info_t.split_tree,
+ * mv[1][0] = cu_info_t.mode_type_tree; cu_stride = 16 * CTUs per row.  coeff: per CTU an lcu_coeff_t (src/cu.h: y[64*64],
+ * u[32*32], v[32*32] levels, raster inside the CTU) -- with cu the hand-over to the bitstream coder (encoderstate.c:863-976).
+ * models: per CTU three sets of UVGHIP_CTU_MODELS context models (state[0] | state[1] << 16) -- at the CTU's start, at the end of
+ * its search (state->search_cabac), after the real coder (state->cabac); the model order is that of csrc/ctu_core.h. */
+#define UVGHIP_CTU_MODELS 257
+typedef struct uvghip_ctu_picture {
+  const void *src_y, *src_u, *src_v;
+  int32_t src_stride, src_stride_c;     /* in samples */
+  void *rec_y, *rec_u, *rec_v;
+  int32_t rec_stride, rec_stride_c;
+  uvghip_scu_t *cu;
+  int32_t cu_stride, reserved;
+  int16_t *coeff;
+  uint32_t *models;
+} uvghip_ctu_picture_t;
+
+UVGHIP_API size_t uvghip_ctu_search_workspace_bytes(int n_pictures, int pic_w, int pic_h);
+/* pictures: HOST array of n descriptors.  workspace: device memory of the size above (contents need not survive the call). */
+UVGHIP_API int uvghip_ctu_search_intra(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures,
+                                       int n_pictures, void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -317,6 +317,88 @@ def oracle_search_picture(orc, depth, prm, y, u, v):
     return dict(rec_y=ry, rec_u=ru, rec_v=rv, cu=cu[:, :, :11].copy(), trees=trees, coeff=co, models=mo)
 
 
+class CtuParams(ctypes.Structure):
+    """ctu::params (uvg266_amd/csrc/ctu_core.h) = uvghip_ctu_params_t: orc_search_params + the chroma lambda of the transform units."""
+    _fields_ = SearchParams._fields_ + [("c_lam_tu", ctypes.c_double)]
+
+
+def ctu_params(prm):
+    c = CtuParams()
+    for f, _ in SearchParams._fields_:
+        setattr(c, f, getattr(prm, f))
+    c.c_lam_tu = prm.lam / 2.0 ** ((prm.qp - prm.qp_c) / 3.0)       # uvg_calculate_chroma_lambda (rate_control.c:1216-1233)
+    return c
+
+
+SCU_NP = np.dtype([("luma_edges", "u1"), ("chroma_edges", "u1"), ("type", "u1"), ("cbf", "u1"), ("qp", "i1"), ("log2_width", "u1"),
+                   ("log2_height", "u1"), ("log2_chroma_width", "u1"), ("log2_chroma_height", "u1"), ("isp_mode", "u1"), ("mv_dir", "u1"),
+                   ("reserved", "u1"), ("ref_id", "<i2", (2,)), ("mv", "<i4", (2, 2))])      # uvghip_scu_t
+
+
+def search_result_from_device_layout(W, H, ry, ru, rv, scu, coeff, models):
+    """The closed-loop search's device-side outputs (uvghip_scu_t table, packed models) in the layout of oracle_search_picture."""
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    cu = np.zeros((hc * 16, wc * 16, 11), np.uint8)
+    t = scu.reshape(hc * 16, wc * 16)
+    for j, f in enumerate(("type", "log2_width", "log2_height", "log2_chroma_width", "log2_chroma_height", "cbf")):
+        cu[:, :, j] = t[f]
+    cu[:, :, 6] = t["mv"][:, :, 0, 0] & 0xff
+    cu[:, :, 7] = (t["mv"][:, :, 0, 0] >> 8) & 0xff
+    cu[:, :, 8], cu[:, :, 9], cu[:, :, 10] = t["luma_edges"], t["chroma_edges"], t["qp"].astype(np.uint8)
+    trees = np.stack([t["mv"][:, :, 0, 1].astype(np.uint32), t["mv"][:, :, 1, 0].astype(np.uint32)], axis=2)
+    m = models.reshape(hc * wc, 3, N_MODELS)
+    mb = np.zeros((hc * wc, 3, MODELS_BYTES), np.uint8)
+    mb[:, :, :514] = np.ascontiguousarray((m & 0xffff).astype(np.uint16)).view(np.uint8).reshape(hc * wc, 3, 514)
+    mb[:, :, 514:1028] = np.ascontiguousarray((m >> 16).astype(np.uint16)).view(np.uint8).reshape(hc * wc, 3, 514)
+    mb[:, :, 1028:1028 + N_MODELS] = model_rates()
+    return dict(rec_y=ry, rec_u=ru, rec_v=rv, cu=cu, trees=trees, coeff=coeff.reshape(hc * wc, 6144), models=mb)
+
+
+_RATES = None
+
+
+def model_rates():
+    """The window byte of every model: row 3 of k_ctx_init in uvg266_amd/csrc/vvc_ctx_init.h (0 for the gaps of the index space)."""
+    global _RATES
+    if _RATES is None:
+        import re
+        txt = open(os.path.join(ROOT, "uvg266_amd", "csrc", "vvc_ctx_init.h")).read()
+        rows = re.findall(r"\{([0-9,\s]+)\}", txt[txt.index("k_ctx_init"):])
+        tab = [np.array([int(v) for v in r.replace("\n", " ").split(",") if v.strip()], np.uint8) for r in rows[:4]]
+        assert all(len(t) == N_MODELS for t in tab)
+        _RATES = np.where(tab[2] == 255, 0, tab[3]).astype(np.uint8)
+    return _RATES
+
+
+_EMUL = None
+
+
+def load_ctu_emulation():
+    """tests/emul: the CTU search kernel's source built for the host with one emulated lane (CPU tests of the device logic)."""
+    global _EMUL
+    if _EMUL is None:
+        d = os.path.join(ROOT, "tests", "emul")
+        subprocess.check_call(["make", "-s", "-C", d])
+        _EMUL = ctypes.CDLL(os.path.join(d, "_build", "libctu_emul.so"))
+    return _EMUL
+
+
+def emul_search_picture(depth, prm, y, u, v):
+    lib = load_ctu_emulation()
+    W, H = prm.pic_w, prm.pic_h
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    px = px_dtype(depth)
+    y, u, v = (np.ascontiguousarray(a, px) for a in (y, u, v))
+    ry, ru, rv = np.zeros((H, W), px), np.zeros((H // 2, W // 2), px), np.zeros((H // 2, W // 2), px)
+    scu = np.zeros(hc * 16 * wc * 16, SCU_NP)
+    co = np.zeros(wc * hc * 6144, np.int16)
+    mo = np.zeros(wc * hc * 3 * N_MODELS, np.uint32)
+    cp = ctu_params(prm)
+    rc = lib.ctu_emul_search_picture(depth, ctypes.byref(cp), ptr(y), ptr(u), ptr(v), ptr(ry), ptr(ru), ptr(rv), ptr(scu), ptr(co), ptr(mo))
+    assert rc == 0
+    return search_result_from_device_layout(W, H, ry, ru, rv, scu, co, mo)
+
+
 def ctu_crcs(res, W, H):
     """Per CTU CRC-32 of the in-picture cu fields + trees / reconstruction / levels / models after the coder, as
     tools/refcheck/make_ctu_goldens.py computes them from the reference's records."""

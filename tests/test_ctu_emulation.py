@@ -1,0 +1,26 @@
+"""The CTU search kernel's LOGIC without a GPU: uvg266_amd/csrc/ctu_core.h built for the host with one emulated lane (tests/emul/)
+against the reference-run goldens.  (Barriers, lane mapping and the cross-workgroup wavefront are what the -m gpu tests add.)"""
+import numpy as np
+import pytest
+
+import helpers as H
+
+
+@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37"])
+def test_emulated_kernel_equals_the_reference_run(name):
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    r = H.emul_search_picture(depth, H.search_params(W, Hh, qp), y, u, v)
+    assert np.array_equal(r["models"], g["models"])
+    h4, w4 = Hh // 4, W // 4
+    assert np.array_equal(r["cu"][:h4, :w4], g["cu"][:h4, :w4]) and np.array_equal(r["trees"][:h4, :w4], g["trees"][:h4, :w4])
+    for p in ("rec_y", "rec_u", "rec_v"):
+        assert np.array_equal(r[p], g[p]), p
+    assert np.array_equal(H.ctu_crcs(r, W, Hh)[:, 2], H.ctu_crcs(dict(r, coeff=g["coeff"]), W, Hh)[:, 2])
+
+
+def test_emulated_kernel_1080p_crcs():
+    g = H.ctu_golden("ref_ctucrc_1920x1080_10_qp27")
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    r = H.emul_search_picture(depth, H.search_params(W, Hh, qp), y, u, v)
+    assert np.array_equal(H.ctu_crcs(r, W, Hh), g["crc"])

@@ -1,0 +1,68 @@
+"""uvghip_ctu_search_intra (the closed-loop intra search of whole pictures: split / mode RD decisions, reconstruction, levels, CABAC
+model adaptation, WPP wavefront across workgroups) against records of the real reference encoder (tests/golden/ref_ctu*.npz):
+item by item on two small pictures, per-CTU CRCs at 1080p and 2160p, several pictures in one launch."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gpu(hip, depth, prm, pictures):
+    import torch
+    from uvg266_amd import api
+    P = api.ctu_params(prm.pic_w, prm.pic_h, prm.qp, lam=prm.lam)
+    src = [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in yuv) for yuv in pictures]
+    cs = api.CtuSearch(P, src)
+    cs.run()
+    torch.cuda.synchronize()
+    out = []
+    for i in range(len(pictures)):
+        ry, ru, rv = (t.cpu().numpy() for t in cs.rec[i])
+        scu = cs.cu[i].cpu().numpy().reshape(-1).view(H.SCU_NP)
+        out.append(H.search_result_from_device_layout(prm.pic_w, prm.pic_h, ry, ru, rv, scu, cs.coeff[i].cpu().numpy(),
+                                                      cs.models[i].cpu().numpy().view(np.uint32)))
+    return out
+
+
+@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37"])
+def test_every_ctu_equals_the_reference_run(hip, name):
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    prm = H.search_params(W, Hh, qp)
+    r = run_gpu(hip, depth, prm, [(y, u, v)])[0]
+    wc = (W + 63) // 64
+    for k in range(len(g["models"])):
+        for j, what in enumerate(("at the CTU's start", "after the search", "after the coder")):
+            assert np.array_equal(r["models"][k, j], g["models"][k, j]), (k % wc, k // wc, what)
+    h4, w4 = Hh // 4, W // 4
+    assert np.array_equal(r["cu"][:h4, :w4], g["cu"][:h4, :w4])
+    assert np.array_equal(r["trees"][:h4, :w4], g["trees"][:h4, :w4])
+    for p in ("rec_y", "rec_u", "rec_v"):
+        assert np.array_equal(r[p], g[p]), p
+    assert np.array_equal(H.ctu_crcs(r, W, Hh)[:, 2], H.ctu_crcs(dict(r, coeff=g["coeff"]), W, Hh)[:, 2])
+
+
+@pytest.mark.parametrize("name", ["ref_ctucrc_1920x1080_8_qp22", "ref_ctucrc_1920x1080_10_qp27"])
+def test_1080p_equals_the_reference_run_ctu_by_ctu(hip, name):
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    r = run_gpu(hip, depth, H.search_params(W, Hh, qp), [(y, u, v)])[0]
+    bad = np.argwhere((H.ctu_crcs(r, W, Hh) != g["crc"]).any(axis=1)).ravel()
+    assert bad.size == 0, bad[:10]
+
+
+def test_several_pictures_in_one_launch(hip, orc):
+    """Pictures are independent (-p 1): a launch over four of them -- their wavefronts interleaved on the device -- gives each
+    the result it gets alone (checked against the reference-run golden for the first, the oracle for the others)."""
+    from uvg266_amd import layout
+    g = H.ctu_golden("ref_ctu_832x480_8_qp22")
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    prm = H.search_params(W, Hh, qp)
+    pics = [(y, u, v)] + [layout.synthetic_yuv420(W, Hh, t, depth) for t in (1, 2, 3)]
+    rs = run_gpu(hip, depth, prm, pics)
+    assert np.array_equal(rs[0]["rec_y"], g["rec_y"]) and np.array_equal(rs[0]["cu"][:Hh // 4, :W // 4], g["cu"][:Hh // 4, :W // 4])
+    for i in (1, 2, 3):
+        o = H.oracle_search_picture(orc, depth, prm, *pics[i])
+        assert np.array_equal(H.ctu_crcs(rs[i], W, Hh), H.ctu_crcs(o, W, Hh)), i

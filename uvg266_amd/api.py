@@ -524,3 +524,45 @@ def quant_signhide_batch(coef, bitdepth, qp_scaled, transform_skip=False, slice_
     _lib.check(L.uvghip_quant_signhide_batch(bitdepth, _dev(coef), _dev(out), w, h, n, qp_scaled, int(transform_skip), int(slice_is_intra), lfnst_idx,
                                              _stream()), "uvghip_quant_signhide_batch")
     return out
+
+
+# ---- closed-loop intra search of whole pictures (include/uvg266_hip.h part 4) ----------------------------------------------
+def ctu_params(pic_w, pic_h, qp, qp_c=None, lam=None, depth_min=1, depth_max=4, combine_intra_cus=1, rough_levels=2):
+    """uvghip_ctu_params_t for --preset medium -p 1: lambda = 0.57 * 2^((qp - 12) / 3) (src/rate_control.c qp_to_lambda for an intra
+    picture), the default chroma QP table (identity), chroma weights from the luma / chroma QP distance."""
+    qp_c = qp if qp_c is None else qp_c
+    lam = 0.57 * 2.0 ** ((qp - 12) / 3.0) if lam is None else lam
+    w = 2.0 ** ((qp - qp_c) / 3.0)
+    return _lib.CtuParams(pic_w, pic_h, qp, qp_c, depth_min, depth_max, 1, combine_intra_cus, rough_levels, 0,
+                          lam, float(np.sqrt(lam)), lam / w, w, w, lam / w)
+
+
+class CtuSearch:
+    """Device buffers of n pictures of one size and the call that searches them all (uvghip_ctu_search_intra).
+    src: list of (y, u, v) device planes.  Outputs stay on the device: rec[i] = (y, u, v), cu[i] (uvghip_scu_t table as bytes,
+    [rows of 4x4, 16 * CTUs per row, 32]), coeff[i] ([CTUs, 6144] int16), models[i] ([CTUs, 3, 257] uint32 as int32)."""
+
+    def __init__(self, params, src):
+        self.P = params
+        self.n = len(src)
+        W, H = params.pic_w, params.pic_h
+        self.wc, self.hc = (W + 63) // 64, (H + 63) // 64
+        dev = src[0][0].device
+        self.depth = _depth(src[0][0])
+        self.L = _lib.init(dev.index or 0)
+        self.src = src
+        self.rec = [tuple(torch.zeros_like(p) for p in s) for s in src]
+        ctus = self.wc * self.hc
+        self.cu = [torch.zeros((self.hc * 16, self.wc * 16, 32), dtype=torch.uint8, device=dev) for _ in src]
+        self.coeff = [torch.zeros((ctus, 6144), dtype=torch.int16, device=dev) for _ in src]
+        self.models = [torch.zeros((ctus, 3, 257), dtype=torch.int32, device=dev) for _ in src]
+        self.ws = torch.empty(self.L.uvghip_ctu_search_workspace_bytes(self.n, W, H), dtype=torch.uint8, device=dev)
+        self.pics = (_lib.CtuPicture * self.n)()
+        for i, (s, r) in enumerate(zip(src, self.rec)):
+            self.pics[i] = _lib.CtuPicture(_dev(s[0]), _dev(s[1]), _dev(s[2]), s[0].stride(0), s[1].stride(0), _dev(r[0]), _dev(r[1]), _dev(r[2]),
+                                           r[0].stride(0), r[1].stride(0), _dev(self.cu[i]), self.wc * 16, 0, _dev(self.coeff[i]), _dev(self.models[i]))
+
+    def run(self, stream=None):
+        import ctypes
+        rc = self.L.uvghip_ctu_search_intra(self.depth, ctypes.byref(self.P), self.pics, self.n, _dev(self.ws), _stream() if stream is None else stream)
+        _lib.check(rc, "uvghip_ctu_search_intra")

@@ -1,0 +1,1693 @@
+// Closed-loop intra search of one CTU by one workgroup (uvg_search_lcu / search_cu, src/search.c:1299-2479, for the all-intra
+// --preset medium configuration: quad-tree depths pu-depth-intra min..max, rd = 0, RDOQ, no MTS / LFNST / ISP / MRL / MIP / CCLM /
+// JCCR / transform skip / dual tree, WPP), followed by the real coder's model adaptation (uvg_encode_coding_tree) so that the next
+// CTU starts from the models the reference would hand it.
+//
+// NOT a translation of the reference's work tree.  The reference recurses with one lcu_t copy per depth and copies winners up;
+// here ONE set of "decided" planes (D) lives in LDS with a one-sample border holding the neighbouring CTUs' samples, so every
+// block's intra references -- inside or across the CTU edge -- are fetched the same way.  A CU is reconstructed straight into
+// D; if its split will be tried the result is parked in a per-depth candidate buffer, the children overwrite D, and the parked
+// candidate is put back only if the split loses (work_tree_copy_up inverted).  The walk is an explicit depth-first loop, not
+// recursion.  Dead work of the reference is not done: the chroma blocks are reconstructed once per CU (the reference does it
+// twice with the same inputs, search.c:1496 and :1572) and once per 8x8 area of 4x4 CUs (the reference redoes it for each of
+// the four, only the last survives).
+//
+// Execution model: regions that touch many samples run on all lanes (PAR_FOR: predictions + SATD of the rough search, residual,
+// transforms, dequantisation, reconstruction, SSD, copies); regions that are a recurrence through the CABAC models or through
+// floating-point sums whose order the reference fixes (RDOQ walk, coefficient bit cost, mode bits, the RD comparisons) run on
+// lane 0 (SERIAL).  Every hand-over between regions is a workgroup barrier.  The same source compiles for the host with one
+// "lane" and no barriers -- the CPU tests run that emulation against the CPU restatement of the reference (tests/emul/); the product only ever runs the
+// device build.
+//
+// All RD arithmetic is IEEE double in the reference's operation order; compile with -ffp-contract=off.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include "intra_pred_dev.h"
+#include "vvc_tables.h"
+#include "vvc_ctx_init.h"
+#include "vvc_rdoq_tables.h"
+#include "../../include/uvg266_hip.h"
+
+#if defined(__HIPCC__)
+#define CTU_DEV __device__
+#define CTU_TID ((int)threadIdx.x)
+#define CTU_NT ((int)blockDim.x)
+#define CTU_SYNC() __syncthreads()
+#else
+#define CTU_DEV static inline
+#define CTU_TID 0
+#define CTU_NT 1
+#define CTU_SYNC() ((void)0)
+#endif
+// a load that must see what another wave of this workgroup stored to global memory earlier (served by L2, not by this CU's L1)
+#if defined(__HIPCC__)
+#define CTU_GLOAD(p) __builtin_nontemporal_load(p)
+#else
+#define CTU_GLOAD(p) (*(p))
+#endif
+#define PAR_FOR(i, n) for (int i = CTU_TID; i < (n); i += CTU_NT)
+#define SERIAL if (CTU_TID == 0)
+
+namespace ctu {
+
+enum { LCU = 64, LCU_C = 32, PY = 68, PC = 36, NMODELS = 257, REFN = 136 };
+enum { M_SIGGRP = 0, M_SIG = 4, M_PAR = 28, M_GT1 = 70, M_GT2 = 112, M_LASTX = 154, M_LASTY = 194, M_CBF_LUMA = 234, M_CBF_CB = 238,
+       M_CBF_CR = 240, M_SPLIT = 244, M_MPM = 253, M_PLANAR = 254, M_CHROMA_PRED = 256 };
+enum { CU_NOTSET = 0, CU_INTRA = 1 };
+#define CTU_MAX_DOUBLE 1.7976931348623157e308
+
+// what the search reads from encoder_state_t / encoder_control_t (= uvghip_ctu_params_t, include/uvg266_hip.h)
+struct params {
+  int32_t pic_w, pic_h, qp, qp_c, depth_min, depth_max, wpp, combine_intra_cus, rough_levels, reserved;
+  double lambda, lambda_sqrt, c_lambda, cw_u, cw_v;
+  double c_lambda_tu;      // uvg_calculate_chroma_lambda (rate_control.c:1216-1233), evaluated by the host: lambda / 2^((qp - qp_c) / 3)
+};
+
+// one 4x4 unit of the CTU's side information while the search runs (the slice of cu_info_t this path reads back)
+struct cu4 {
+  uint8_t type, log2, cbf, luma_edges, chroma_edges, log2_c;
+  int8_t mode, mode_chroma;
+};
+
+struct level_state {        // search_cu's locals, per depth
+  double cost, split_cost;
+  int x, y;                 // picture coordinates
+  int child;                // next child to visit
+  int type, mode, cbf;      // the parked no-split candidate
+  int has_chroma;           // carries the chroma of its area
+  uint32_t split_tree, mode_type_tree;
+};
+
+template <typename PX> struct px_info;
+template <> struct px_info<uint8_t> { enum { depth = 8, maxv = 255 }; };
+template <> struct px_info<uint16_t> { enum { depth = 10, maxv = 1023 }; };
+
+// LDS image of a workgroup
+template <typename PX> struct lds {
+  PX Dy[65 * PY], Du[33 * PC], Dv[33 * PC];         // decided planes, index (y + 1) * pitch + x + 1
+  PX Sy[LCU * LCU], Su[LCU_C * LCU_C], Sv[LCU_C * LCU_C];
+  PX cand_px[2016];
+  int16_t cand_co[2016];
+  cu4 cu[17 * 17];                                  // index (y4 + 1) * 17 + x4 + 1
+  uint32_t tree[256], mtt[256];                     // split_tree / mode_type_tree per 4x4
+  uint32_t cur[NMODELS];                            // state->search_cabac models: state0 | state1 << 16
+  uint32_t pre[5][NMODELS], post[5][NMODELS];
+  uint32_t coder[NMODELS];                          // state->cabac models
+  uint8_t rdoq_state[244];                          // CTX_STATE of the coder's models at the CTU's start (what uvg_rdoq prices with)
+  uint16_t top[REFN], left[REFN], ftop[REFN], fleft[REFN];
+  int16_t t0[1024], t1[1024], t2[1024];             // transform scratch
+  int16_t lv[3][1024];                              // levels of the TUs being evaluated (y, u, v)
+  uint16_t scan[1024 + 256 + 64 + 16];              // coefficient scans of the four square shapes
+  uint32_t part[2 * 24 * 16];                       // rough search: (satd, sad) partial sums per (listed mode, tile)
+  double rs_cost[67];
+  int32_t rs_list[24];
+  int32_t red[8], partial[256];                     // reductions
+  level_state lvl[5];
+  // uniform scalars handed from lane 0 to everyone
+  int32_t u_avail_left, u_avail_top, u_mode, u_flag, u_n_modes, u_best[3];
+  double u_d0, u_d1;
+  int8_t mpm[6];
+};
+
+// per-workgroup scratch in global memory
+struct scratch {
+  double cost_coeff[1024], cost_sig[1024], cost_coeff0[1024];
+  uint16_t save_px[6144];          // the whole D of a CTU while the 64x64 candidate is tried
+  int16_t save_co[6144];
+  cu4 save_cu[256];
+  uint32_t save_tree[512];
+};
+
+// ------------------------------------------------------------------------------------------------------------ models ------
+#define kRate (k_ctx_init[3])      // the window byte of every model (rate0 << 4 | rate1)
+
+CTU_DEV int m_state(const uint32_t *m, int c) { return (int)(((m[c] & 0xffffu) + (m[c] >> 16)) >> 8); }
+CTU_DEV void m_update(uint32_t *m, int c, int bin)            // CTX_UPDATE, cabac.h:182-193
+{
+  const int r0 = kRate[c] >> 4, r1 = kRate[c] & 15;
+  uint32_t s0 = m[c] & 0xffffu, s1 = m[c] >> 16;
+  s0 -= (s0 >> r0) & 0x7fe0u;
+  s1 -= (s1 >> r1) & 0x7ffeu;
+  if (bin) { s0 += (0x7fffu >> r0) & 0x7fe0u; s1 += (0x7fffu >> r1) & 0x7ffeu; }
+  m[c] = (s0 & 0xffffu) | (s1 << 16);
+}
+// uvg_f_entropy_bits (rdo.c:143, a float table) = uvg_entropy_bits / 2^15: every entry is an integer below 2^24 over 2^15, so the
+// float and this double quotient are the same number
+CTU_DEV double m_fbits(const uint32_t *m, int c, int bin) { return (double)kEntropyBits[(m_state(m, c) << 1) ^ bin] / 32768.0; }
+// CABAC_FBITS_UPDATE with only_count = 1
+CTU_DEV void m_code(uint32_t *m, int update, int c, int bin, double &bits)
+{
+  bits += m_fbits(m, c, bin);
+  if (update) m_update(m, c, bin);
+}
+
+CTU_DEV void models_init_one(uint32_t *m, int i, int qp, int slice)     // uvg_ctx_init, context.c:471-492
+{
+  const int v = k_ctx_init[slice][i];
+  if (v == 255) { m[i] = 0; return; }
+  const int slope = (v >> 3) - 4, offset = ((v & 7) * 18) + 1;
+  int s = ((slope * (qp - 16)) >> 1) + offset;
+  s = s < 1 ? 1 : (s > 127 ? 127 : s);
+  const uint32_t p1 = (uint32_t)s << 8;
+  m[i] = (p1 & 0x7fe0u) | ((p1 & 0x7ffeu) << 16);
+}
+
+// ------------------------------------------------------------------------------------------------------------- scans ------
+CTU_DEV int scan_base(int log2n) { return log2n == 5 ? 0 : log2n == 4 ? 1024 : log2n == 3 ? 1280 : 1344; }
+// H.266 6.5.2 up-right diagonal scan of 4x4 groups, groups in diagonal order (tables.c g_scan_order, SCAN_DIAG)
+CTU_DEV void diag_order(int n, uint8_t *out)      // out[i] = y * n + x of the i-th position of an n x n diagonal scan
+{
+  int i = 0;
+  for (int d = 0; d < 2 * n - 1; ++d)
+    for (int x = 0; x <= d; ++x) {
+      const int y = d - x;
+      if (x < n && y < n) out[i++] = (uint8_t)(y * n + x);
+    }
+}
+template <typename PX> CTU_DEV void build_scans(lds<PX> *S)
+{
+  SERIAL {
+    uint8_t in[16], cg[64];
+    diag_order(4, in);
+    for (int l2 = 2; l2 <= 5; ++l2) {
+      const int n = 1 << l2, cgw = n >> 2;
+      diag_order(cgw, cg);
+      uint16_t *sc = S->scan + scan_base(l2);
+      for (int g = 0; g < cgw * cgw; ++g) {
+        const int gx = cg[g] % cgw, gy = cg[g] / cgw;
+        for (int k = 0; k < 16; ++k) sc[g * 16 + k] = (uint16_t)((gy * 4 + in[k] / 4) * n + gx * 4 + in[k] % 4);
+      }
+    }
+  }
+  CTU_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------- reference construction ------
+template <typename PX> CTU_DEV PX *plane(lds<PX> *S, int color) { return color == 0 ? S->Dy : (color == 1 ? S->Du : S->Dv); }
+CTU_DEV int pitch_of(int color) { return color == 0 ? PY : PC; }
+template <typename PX> CTU_DEV cu4 *cu_at(lds<PX> *S, int lx, int ly) { return &S->cu[((ly >> 2) + 1) * 17 + (lx >> 2) + 1]; }   // lx, ly >= -4
+
+// uvg_count_available_edge_cus (cu.c:516-537) for a square CU at CTU-local (lx, ly)
+template <typename PX> CTU_DEV int count_edge_cus(lds<PX> *S, int x, int y, int lx, int ly, int n, int left)
+{
+  if ((left && x == 0) || (!left && y == 0)) return 0;
+  if (left && lx == 0) return (LCU - ly) / 4;
+  if (!left && ly == 0) return n / 2;
+  int amount = n & ~3;
+  if (left) {
+    if (ly == 0 && lx == 32 && cu_at(S, lx, ly)->log2 == 6) return 8;
+    while (ly + amount < LCU && cu_at(S, lx - 4, ly + amount)->type != CU_NOTSET) amount += 4;
+  } else {
+    while (lx + amount < LCU && cu_at(S, lx + amount, ly - 4)->type != CU_NOTSET) amount += 4;
+  }
+  return (amount / 4) > (n / 4) ? amount / 4 : n / 4;
+}
+
+// uvg_intra_build_reference (intra.c:1344; _inner :1065-1341 when the block touches neither picture edge, _any :756-1063 else) for the
+// w x w block of `color` whose luma position is (x, y) / CTU-local (lx, ly) with luma size n; + the smoothed rows (:190-225)
+template <typename PX> CTU_DEV void build_refs(lds<PX> *S, const params &P, int color, int x, int y, int lx, int ly, int n)
+{
+  const int c = color != 0;
+  const int w = n >> c;
+  const int px_x = lx >> c, px_y = ly >> c;
+  const int pit = pitch_of(color);
+  const PX *D = plane(S, color) + (px_y + 1) * pit + px_x + 1;     // the block's top-left sample
+  SERIAL {
+    int al = count_edge_cus(S, x, y, lx, ly, n, 1) * (c ? 2 : 4);
+    if (al > 2 * w) al = 2 * w;
+    if (al > ((P.pic_h - y) >> c)) al = (P.pic_h - y) >> c;
+    int at = count_edge_cus(S, x, y, lx, ly, n, 0) * (c ? 2 : 4);
+    if (at > 2 * w) at = 2 * w;
+    if (at > ((P.pic_w - x) >> c)) at = (P.pic_w - x) >> c;
+    if (x > 0 && y > 0 && P.wpp && px_y == 0 && at > (LCU >> c) - px_x) at = (LCU >> c) - px_x;
+    S->u_avail_left = al; S->u_avail_top = at;
+  }
+  CTU_SYNC();
+  const int al = S->u_avail_left, at = S->u_avail_top;
+  const int dc = 1 << (px_info<PX>::depth - 1);
+  PAR_FOR(i, REFN - 1) {
+    int lv, tv;
+    if (x > 0) lv = D[(i < al ? i : al - 1) * pit - 1];
+    else lv = y > 0 ? D[-pit] : dc;
+    if (y > 0) tv = D[-pit + (i < at ? i : at - 1)];
+    else tv = x > 0 ? D[-1] : dc;
+    S->left[i + 1] = (uint16_t)lv;
+    S->top[i + 1] = (uint16_t)tv;
+  }
+  SERIAL {
+    int corner;
+    if (x > 0 && y > 0) corner = D[-pit - 1];
+    else corner = x > 0 ? D[-1] : (y > 0 ? D[-pit] : dc);       // "copy reference clockwise": left[1]
+    S->left[0] = S->top[0] = (uint16_t)corner;
+  }
+  CTU_SYNC();
+  PAR_FOR(i, REFN) {
+    int fl, ft;
+    if (i == 0) fl = ft = (S->left[1] + 2 * S->left[0] + S->top[1] + 2) >> 2;
+    else {
+      fl = i < 2 * w ? (S->left[i - 1] + 2 * S->left[i] + S->left[i + 1] + 2) >> 2 : S->left[i];
+      ft = i < 2 * w ? (S->top[i - 1] + 2 * S->top[i] + S->top[i + 1] + 2) >> 2 : S->top[i];
+    }
+    S->fleft[i] = (uint16_t)fl;
+    S->ftop[i] = (uint16_t)ft;
+  }
+  CTU_SYNC();
+}
+
+// prediction of the w x w block of `color` from the reference rows into dst (pitch dp)
+template <typename PX> CTU_DEV void predict_block(lds<PX> *S, int mode, int color, int w, PX *dst, int dp)
+{
+  const mode_info M = make_mode_info(mode, w, w, color != 0);
+  const ref_rows R = {S->top, S->left, S->ftop, S->fleft};
+  const int dc = mode == 1 ? dc_value(S->top, S->left, w, w) : 0;
+  const int segs = w >> 2;
+  PAR_FOR(t, w * segs) {
+    const int yd = t / segs, xd0 = (t - yd * segs) * 4;
+    int out[4];
+    predict_row<4>(M, R, dc, color != 0, w, w, yd, xd0, (int)px_info<PX>::maxv, out);
+    for (int i = 0; i < 4; ++i) {
+      const int bx = M.vertical ? xd0 + i : yd, by = M.vertical ? yd : xd0 + i;
+      dst[by * dp + bx] = (PX)out[i];
+    }
+  }
+  CTU_SYNC();
+}
+
+// --------------------------------------------------------------------------------------------------- rough search ------
+CTU_DEV int iabs_(int v) { return v < 0 ? -v : v; }
+// 8x8 / 4x4 Hadamard SATD of a difference tile (picture-generic.c:118-200, 256-348); the magnitude multiset is transpose-invariant
+CTU_DEV unsigned satd8_tile(int (&d)[64])
+{
+  for (int pass = 0; pass < 2; ++pass) {
+    const int s = pass ? 8 : 1, t = pass ? 1 : 8;      // pass 0: along rows, pass 1: along columns
+    for (int l = 0; l < 8; ++l) {
+      int *v = &d[l * t];
+      for (int half = 4; half >= 1; half >>= 1)
+        for (int base = 0; base < 8; base += 2 * half)
+          for (int i = 0; i < half; ++i) {
+            const int p = v[(base + i) * s], q = v[(base + i + half) * s];
+            v[(base + i) * s] = p + q;
+            v[(base + i + half) * s] = p - q;
+          }
+    }
+  }
+  unsigned sad = 0;
+  for (int i = 0; i < 64; ++i) sad += (unsigned)iabs_(d[i]);
+  sad -= (unsigned)iabs_(d[0]);
+  sad += (unsigned)iabs_(d[0]) >> 2;
+  return (sad + 2) >> 2;
+}
+CTU_DEV unsigned satd4_tile(int (&d)[16])
+{
+  for (int pass = 0; pass < 2; ++pass) {
+    const int s = pass ? 4 : 1, t = pass ? 1 : 4;
+    for (int l = 0; l < 4; ++l) {
+      int *v = &d[l * t];
+      const int a = v[0] + v[2 * s], b = v[0] - v[2 * s], c2 = v[s] + v[3 * s], e = v[s] - v[3 * s];
+      v[0] = a + c2; v[s] = a - c2; v[2 * s] = b + e; v[3 * s] = b - e;
+    }
+  }
+  unsigned satd = 0;
+  for (int i = 0; i < 16; ++i) satd += (unsigned)iabs_(d[i]);
+  satd -= (unsigned)iabs_(d[0]);
+  satd += (unsigned)iabs_(d[0]) >> 2;
+  return (satd + 1) >> 1;
+}
+
+// costs of the listed modes for the n x n luma block at (lx, ly): every (mode, tile) is one task -- the lane predicts the tile in
+// registers (in the mode's work domain: transposed for the horizontal modes) and reduces it at once; get_cost_dual (search_intra.c:133)
+template <typename PX> CTU_DEV void rough_costs(lds<PX> *S, int lx, int ly, int n, const int32_t *modes, int n_modes)
+{
+  const int T = n >= 8 ? 8 : 4, tiles_x = n / T, tiles = tiles_x * tiles_x;
+  const ref_rows R = {S->top, S->left, S->ftop, S->fleft};
+  const int dcv = dc_value(S->top, S->left, n, n);
+  PAR_FOR(task, n_modes * tiles) {
+    const int mi = task / tiles, tile = task - mi * tiles;
+    const int mode = modes[mi];
+    const mode_info M = make_mode_info(mode, n, n, 0);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    unsigned sad = 0, satd;
+    if (T == 8) {
+      int d[64];
+      for (int r = 0; r < 8; ++r) {
+        int out[8];
+        predict_row<8>(M, R, dcv, 0, n, n, ty * 8 + r, tx * 8, (int)px_info<PX>::maxv, out);
+        for (int i = 0; i < 8; ++i) {
+          const int wx = tx * 8 + i, wy = ty * 8 + r;
+          const int bx = M.vertical ? wx : wy, by = M.vertical ? wy : wx;
+          const int df = (int)S->Sy[(ly + by) * LCU + lx + bx] - out[i];
+          d[r * 8 + i] = df;
+          sad += (unsigned)iabs_(df);
+        }
+      }
+      satd = satd8_tile(d);
+    } else {
+      int d[16];
+      for (int r = 0; r < 4; ++r) {
+        int out[4];
+        predict_row<4>(M, R, dcv, 0, n, n, r, 0, (int)px_info<PX>::maxv, out);
+        for (int i = 0; i < 4; ++i) {
+          const int bx = M.vertical ? i : r, by = M.vertical ? r : i;
+          const int df = (int)S->Sy[(ly + by) * LCU + lx + bx] - out[i];
+          d[r * 4 + i] = df;
+          sad += (unsigned)iabs_(df);
+        }
+      }
+      satd = satd4_tile(d);
+    }
+    S->part[2 * task] = satd;
+    S->part[2 * task + 1] = sad;
+  }
+  CTU_SYNC();
+}
+
+// count_bits (search_intra.c:949-984)
+CTU_DEV double count_bits(const int8_t *preds, double planar, double not_planar, double mpm_bit, double not_mpm_bit, int mode)
+{
+  int i = 0, smaller = 0;
+  for (; i < 6; i++) {
+    if (preds[i] == mode) break;
+    if (mode > preds[i]) smaller += 1;
+  }
+  if (i == 0) return planar + mpm_bit;
+  if (i < 6) return not_planar + mpm_bit + (i < 4 ? i : 4);
+  return not_mpm_bit + 5 + (mode - smaller > 2);
+}
+
+// uvg_intra_get_dir_luma_predictor (intra.c:88-188), MIP off
+CTU_DEV void dir_luma_predictor(int y, int8_t *preds, const cu4 *left_pu, const cu4 *above_pu)
+{
+  int left_dir = 0, above_dir = 0;
+  if (left_pu && left_pu->type == CU_INTRA) left_dir = left_pu->mode;
+  if (above_pu && above_pu->type == CU_INTRA && y % LCU != 0) above_dir = above_pu->mode;
+  const int offset = 61, mod = 64;
+  preds[0] = 0; preds[1] = 1; preds[2] = 50; preds[3] = 18; preds[4] = 46; preds[5] = 54;
+  if (left_dir == above_dir) {
+    if (left_dir > 1) {
+      preds[0] = 0; preds[1] = (int8_t)left_dir;
+      preds[2] = (int8_t)(((left_dir + offset) % mod) + 2); preds[3] = (int8_t)(((left_dir - 1) % mod) + 2);
+      preds[4] = (int8_t)(((left_dir + offset - 1) % mod) + 2); preds[5] = (int8_t)((left_dir % mod) + 2);
+    }
+  } else if (left_dir > 1 && above_dir > 1) {
+    preds[0] = 0; preds[1] = (int8_t)left_dir; preds[2] = (int8_t)above_dir;
+    const int mx = preds[1] > preds[2] ? 1 : 2, mn = preds[1] > preds[2] ? 2 : 1;
+    const int diff = preds[mx] - preds[mn];
+    if (diff == 1) {
+      preds[3] = (int8_t)(((preds[mn] + offset) % mod) + 2); preds[4] = (int8_t)(((preds[mx] - 1) % mod) + 2);
+      preds[5] = (int8_t)(((preds[mn] + offset - 1) % mod) + 2);
+    } else if (diff >= 62) {
+      preds[3] = (int8_t)(((preds[mn] - 1) % mod) + 2); preds[4] = (int8_t)(((preds[mx] + offset) % mod) + 2);
+      preds[5] = (int8_t)((preds[mn] % mod) + 2);
+    } else if (diff == 2) {
+      preds[3] = (int8_t)(((preds[mn] - 1) % mod) + 2); preds[4] = (int8_t)(((preds[mn] + offset) % mod) + 2);
+      preds[5] = (int8_t)(((preds[mx] - 1) % mod) + 2);
+    } else {
+      preds[3] = (int8_t)(((preds[mn] + offset) % mod) + 2); preds[4] = (int8_t)(((preds[mn] - 1) % mod) + 2);
+      preds[5] = (int8_t)(((preds[mx] + offset) % mod) + 2);
+    }
+  } else if (left_dir + above_dir >= 2) {
+    preds[0] = 0;
+    preds[1] = (int8_t)(left_dir < above_dir ? above_dir : left_dir);
+    preds[2] = (int8_t)(((preds[1] + offset) % mod) + 2); preds[3] = (int8_t)(((preds[1] - 1) % mod) + 2);
+    preds[4] = (int8_t)(((preds[1] + offset - 1) % mod) + 2); preds[5] = (int8_t)((preds[1] % mod) + 2);
+  }
+}
+// the two neighbours uvg_search_cu_intra (search_intra.c:1792-1803) and uvg_encode_intra_luma_coding_unit (:1114-1150) look at
+template <typename PX> CTU_DEV void mpm_neighbours(lds<PX> *S, int x, int y, int lx, int ly, int n, const cu4 **left, const cu4 **above)
+{
+  *left = x > 0 ? cu_at(S, lx - 1, ly + n - 1) : nullptr;
+  *above = (ly > 0 && y > 0) ? cu_at(S, lx + n - 1, ly - 1) : nullptr;
+}
+
+// search_intra_rough (search_intra.c:986-1229), three survivors; the winner goes to S->u_mode
+template <typename PX> CTU_DEV void search_intra_rough(lds<PX> *S, const params &P, int x, int y, int lx, int ly, int n)
+{
+  const int T = n >= 8 ? 8 : 4, tiles = (n / T) * (n / T);
+  SERIAL {
+    const cu4 *l, *a;
+    mpm_neighbours(S, x, y, lx, ly, n, &l, &a);
+    dir_luma_predictor(y, S->mpm, l, a);
+    const int offset = 1 << P.rough_levels;
+    int k = 0;
+    S->rs_list[k++] = 0; S->rs_list[k++] = 1;
+    for (int mode = 2 + offset / 2; mode <= 66; mode += 2 * offset)
+      for (int i = 0; i < 2; ++i) if (mode + i * offset <= 66) S->rs_list[k++] = mode + i * offset;
+    S->u_n_modes = k;
+  }
+  CTU_SYNC();
+  // (rs_list holds at most 18 entries with rough_levels >= 2; the host refuses smaller values)
+  uint32_t chk[3] = {0, 0, 0};              // modes already costed (lane 0's own state across the rounds)
+  struct { int mode; double cost; } best[3];
+  double min_cost = 0, max_cost = 0;
+  int offset = 1 << P.rough_levels;
+  for (int round = 0;; ++round) {
+    rough_costs(S, lx, ly, n, S->rs_list, S->u_n_modes);
+    SERIAL {
+      const double mpm_bit = m_fbits(S->cur, M_MPM, 1), not_mpm_bit = m_fbits(S->cur, M_MPM, 0);
+      const double planar = m_fbits(S->cur, M_PLANAR + 1, 0), not_planar = m_fbits(S->cur, M_PLANAR + 1, 1);
+      const int nm = S->u_n_modes;
+      for (int mi = 0; mi < nm; ++mi) {
+        const int mode = S->rs_list[mi];
+        unsigned satd = 0, sad = 0;
+        for (int t = 0; t < tiles; ++t) { satd += S->part[2 * (mi * tiles + t)]; sad += S->part[2 * (mi * tiles + t) + 1]; }
+        if (n >= 8) satd >>= (px_info<PX>::depth - 8);       // satd_NxN shifts, the 4x4 function does not (picture-generic.c:170)
+        sad >>= (px_info<PX>::depth - 8);
+        double c = (double)(satd < sad * 2 ? satd : sad * 2);
+        c += count_bits(S->mpm, planar, not_planar, mpm_bit, not_mpm_bit, mode) * P.lambda_sqrt;
+        S->rs_cost[mode] = c;
+        chk[mode >> 5] |= 1u << (mode & 31);
+        if (round == 0 && mi < 2) {
+          if (mi == 1) {
+            const double c0 = S->rs_cost[0], c1 = S->rs_cost[1];
+            if (c0 < c1) { min_cost = c0; max_cost = c1; best[0].mode = 0; best[0].cost = c0; best[1].mode = 1; best[1].cost = c1; }
+            else { min_cost = c1; max_cost = c0; best[1].mode = 0; best[1].cost = c0; best[0].mode = 1; best[0].cost = c1; }
+            best[2].mode = 0; best[2].cost = CTU_MAX_DOUBLE;
+          }
+          continue;
+        }
+        if (round == 0) { if (c < min_cost) min_cost = c; if (c > max_cost) max_cost = c; }
+        for (int j = 0; j < 3; j++)
+          if (c < best[j].cost) {
+            for (int k = 2; k > j; k--) best[k] = best[k - 1];
+            best[j].cost = c; best[j].mode = mode;
+            break;
+          }
+      }
+      // next round's list (search_intra.c:1146-1215)
+      offset >>= 1;
+      int k = 0;
+      if (offset > 0 && min_cost != max_cost) {
+        for (int i = 0; i < 3; i++) {
+          const int center = best[i].mode;
+          if (center < 3 || center > 65) continue;
+          const int test[2] = {center - offset, center + offset};
+          for (int j = 0; j < 2; j++)
+            if (test[j] >= 2 && test[j] <= 66 && !((chk[test[j] >> 5] >> (test[j] & 31)) & 1)) { S->rs_list[k++] = test[j]; chk[test[j] >> 5] |= 1u << (test[j] & 31); }
+        }
+      }
+      S->u_n_modes = k;
+      S->u_flag = offset > 0 && min_cost != max_cost;
+      S->u_mode = best[0].mode;
+    }
+    CTU_SYNC();
+    if (!S->u_flag) break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- transforms ------
+CTU_DEV const int16_t *dct2_matrix(int n) { return n == 4 ? VVC_DCT2_4 : n == 8 ? VVC_DCT2_8 : n == 16 ? VVC_DCT2_16 : VVC_DCT2_32; }
+// dct_NxN (dct-generic.c:396-419, 720-729): dst[j * n + i] = trunc16((sum_k T[j][k] * src[i][k] + add) >> shift), twice
+CTU_DEV void fwd_pass(int n, const int16_t *src, int16_t *dst, int shift)
+{
+  const int16_t *T = dct2_matrix(n);
+  const int add = shift > 0 ? 1 << (shift - 1) : 0;
+  PAR_FOR(e, n * n) {
+    const int j = e / n, i = e - j * n;
+    int acc = 0;
+    for (int k = 0; k < n; ++k) acc += (int)T[j * n + k] * src[i * n + k];
+    dst[j * n + i] = (int16_t)((acc + add) >> shift);
+  }
+  CTU_SYNC();
+}
+// idct_NxN (:422-446, 731-740): dst[i * n + j] = clip16((sum_k src[k * n + i] * T[k][j] + add) >> shift), twice
+CTU_DEV void inv_pass(int n, const int16_t *src, int16_t *dst, int shift)
+{
+  const int16_t *T = dct2_matrix(n);
+  const int add = 1 << (shift - 1);
+  PAR_FOR(e, n * n) {
+    const int i = e / n, j = e - i * n;
+    int acc = 0;
+    for (int k = 0; k < n; ++k) acc += (int)src[k * n + i] * T[k * n + j];
+    dst[i * n + j] = (int16_t)clampi((acc + add) >> shift, -32768, 32767);
+  }
+  CTU_SYNC();
+}
+
+// ----------------------------------------------------------------------------------------------------------- RDOQ ------
+CTU_DEV int group_idx(int pos)
+{
+  if (pos < 4) return pos;
+  int l = 0;
+  while ((pos >> (l + 1)) != 0) ++l;
+  return 2 * l + ((pos >> (l - 1)) & 1);
+}
+CTU_DEV int go_rice_par(unsigned s) { return (s >= 7) + (s >= 14) + (s >= 28); }
+
+struct rdoq_env {
+  const uint8_t *st;      // CTX_STATE per model
+  int t;                  // 0 luma, 1 chroma
+  double lambda, error_scale;
+  int q_bits;
+};
+CTU_DEV int32_t rbits(const rdoq_env &E, int model, int bin) { return (int32_t)kEntropyBits[(E.st[model] << 1) ^ bin]; }
+
+// uvg_get_ic_rate (rdo.c:465-581), limited prefix length
+CTU_DEV int32_t ic_rate(const rdoq_env &E, uint32_t abs_level, int ctx, int go_rice, uint32_t reg_bins)
+{
+  int32_t rate = 1 << 15;
+  const uint32_t go_rice_zero = 1u << go_rice;
+  const int max_log2 = 15, thr = 5;
+  const int o_par = M_PAR + (E.t ? 21 : 0) + ctx, o_gt1 = M_GT1 + (E.t ? 21 : 0) + ctx, o_gt2 = M_GT2 + (E.t ? 21 : 0) + ctx;
+  if (reg_bins < 4) {
+    const uint32_t symbol = (abs_level == 0 ? go_rice_zero : abs_level <= go_rice_zero ? abs_level - 1 : abs_level);
+    if (symbol < ((uint32_t)thr << go_rice)) {
+      rate += (int32_t)(((symbol >> go_rice) + 1 + go_rice) << 15);
+    } else {
+      const uint32_t max_prefix = 32 - (thr + max_log2);
+      uint32_t prefix = 0;
+      const uint32_t suffix = (symbol >> go_rice) - thr;
+      while (prefix < max_prefix && (int32_t)suffix > ((2 << prefix) - 2)) prefix++;
+      const uint32_t suffix_len = prefix == max_prefix ? (uint32_t)(max_log2 - go_rice) : prefix + 1;
+      rate += (int32_t)((thr + prefix + suffix_len + go_rice) << 15);
+    }
+    return rate;
+  }
+  if (abs_level >= 4) {
+    const int32_t symbol = (int32_t)abs_level - 4;
+    if (symbol < (thr << go_rice)) {
+      rate += ((symbol >> go_rice) + 1 + go_rice) << 15;
+    } else {
+      const uint32_t max_prefix = 32 - (thr + max_log2);
+      uint32_t prefix = 0;
+      const uint32_t suffix = (uint32_t)(symbol >> go_rice) - thr;
+      while (prefix < max_prefix && (int32_t)suffix > ((2 << prefix) - 2)) prefix++;
+      const uint32_t suffix_len = prefix == max_prefix ? (uint32_t)(max_log2 - go_rice) : prefix + 1;
+      rate += (int32_t)((thr + prefix + suffix_len + go_rice) << 15);
+    }
+    rate += rbits(E, o_par, (abs_level - 2) & 1);
+    rate += rbits(E, o_gt1, 1);
+    rate += rbits(E, o_gt2, 1);
+  } else if (abs_level == 1) {
+    rate += rbits(E, o_gt1, 0);
+  } else if (abs_level == 2) {
+    rate += rbits(E, o_par, 0); rate += rbits(E, o_gt1, 1); rate += rbits(E, o_gt2, 0);
+  } else if (abs_level == 3) {
+    rate += rbits(E, o_par, 1); rate += rbits(E, o_gt1, 1); rate += rbits(E, o_gt2, 0);
+  } else {
+    rate = 0;
+  }
+  return rate;
+}
+
+// uvg_get_coded_level (rdo.c:597-640)
+CTU_DEV uint32_t coded_level(const rdoq_env &E, double *coded_cost, double coded_cost0, double *coded_cost_sig, int32_t level_double,
+                             uint32_t max_abs_level, int ctx_sig, int ctx_set, int go_rice, uint32_t reg_bins, int last)
+{
+  double cur_cost_sig = 0;
+  uint32_t best = 0;
+  const int o_sig = M_SIG + (E.t ? 12 : 0) + ctx_sig;
+  if (!last && max_abs_level < 3) {
+    *coded_cost_sig = E.lambda * rbits(E, o_sig, 0);
+    *coded_cost = coded_cost0 + *coded_cost_sig;
+    if (max_abs_level == 0) return best;
+  } else {
+    *coded_cost = 1.7e+308;
+  }
+  if (!last) cur_cost_sig = E.lambda * rbits(E, o_sig, 1);
+  const int32_t min_abs = max_abs_level > 1 ? (int32_t)max_abs_level - 1 : 1;
+  for (int32_t a = (int32_t)max_abs_level; a >= min_abs; a--) {
+    const double err = (double)(level_double - (a * (1 << E.q_bits)));
+    double cur = err * err * E.error_scale + E.lambda * ic_rate(E, (uint32_t)a, ctx_set, go_rice, reg_bins);
+    cur += cur_cost_sig;
+    if (cur < *coded_cost) { best = (uint32_t)a; *coded_cost = cur; *coded_cost_sig = cur_cost_sig; }
+  }
+  return best;
+}
+
+// context_get_sig_ctx_idx_abs / templateAbsSum on a level array (rdo.c:1400-1438, 846-871), no MTS zero-out
+CTU_DEV int sig_ctx_abs(const int16_t *lv, int px, int py, int n, int color, int *diag_out, int *sum_out)
+{
+  const int16_t *d = lv + px + py * n;
+  int num_pos = 0, sum_abs = 0;
+#define CTU_UPD(v) { const int a = iabs_((int)(v)); sum_abs += (4 + (a & 1)) < a ? (4 + (a & 1)) : a; num_pos += a ? 1 : 0; }
+  if (px < n - 1) {
+    CTU_UPD(d[1]);
+    if (px < n - 2) CTU_UPD(d[2]);
+    if (py < n - 1) CTU_UPD(d[n + 1]);
+  }
+  if (py < n - 1) {
+    CTU_UPD(d[n]);
+    if (py < n - 2) CTU_UPD(d[n << 1]);
+  }
+#undef CTU_UPD
+  const int diag = px + py;
+  int ofs = (((sum_abs + 1) >> 1) < 3 ? ((sum_abs + 1) >> 1) : 3) + (diag < 2 ? 4 : 0);
+  if (color == 0) ofs += diag < 5 ? 4 : 0;
+  *diag_out = diag;
+  *sum_out = sum_abs - num_pos;
+  return ofs;
+}
+CTU_DEV unsigned template_abs_sum(const int16_t *lv, int base_level, int px, int py, int n)
+{
+  const int16_t *p = lv + px + py * n;
+  int16_t sum = 0;                        // coeff_t accumulator, as in the reference (rdo.c:849)
+  if (px < n - 1) {
+    sum = (int16_t)(sum + iabs_(p[1]));
+    if (px < n - 2) sum = (int16_t)(sum + iabs_(p[2]));
+    if (py < n - 1) sum = (int16_t)(sum + iabs_(p[n + 1]));
+  }
+  if (py < n - 1) {
+    sum = (int16_t)(sum + iabs_(p[n]));
+    if (py < n - 2) sum = (int16_t)(sum + iabs_(p[n << 1]));
+  }
+  int v = sum - 5 * base_level;
+  v = v < 31 ? v : 31;
+  return (unsigned)(v > 0 ? v : 0);
+}
+
+__device__ static const int16_t kQuantScales[6] = {26214, 23302, 20560, 18396, 16384, 14564};      // uvg_g_quant_scales[0] (scalinglist.c:91)
+__device__ static const int16_t kInvQuantScales[6] = {40, 45, 51, 57, 64, 72};                     // uvg_g_inv_quant_scales[0]
+__device__ static const double kPow2[16] = {1.0, 2.0, 4.0, 8.0, 16.0, 32.0, 64.0, 128.0, 256.0, 512.0, 1024.0, 2048.0, 4096.0, 8192.0, 16384.0, 32768.0};
+
+// uvg_rdoq (rdo.c:1449-1870) of an n x n block (square: no sqrt2 scaling), intra, no LFNST / MTS / sign hiding; lane 0 only.
+// coef -> levels in dst (both n * n, raster).  Returns whether any level survived.
+CTU_DEV int rdoq_serial(const uint8_t *st, const uint16_t *scan, scratch *W, const int16_t *coef, int16_t *dst, int n, int color, int cbf_u,
+                        int qp_scaled, double lambda, int bitdepth)
+{
+  const int l2 = ilog2_dev(n);
+  rdoq_env E;
+  E.st = st; E.t = color ? 1 : 0; E.lambda = lambda;
+  const int transform_shift = 15 - bitdepth - l2;
+  uint32_t reg_bins = (uint32_t)(n * n * 28) >> 4;
+  E.q_bits = 14 + qp_scaled / 6 + transform_shift;
+  const int32_t q = kQuantScales[qp_scaled % 6];
+  // scale = 32768 * 2^(-2 * transform_shift) (rdo.c:1527: pow() of an integer exponent, exact), error_scale = scale / q / q
+  double scale = 32768;
+  scale = transform_shift >= 0 ? scale / kPow2[2 * transform_shift] : scale * kPow2[-2 * transform_shift];
+  E.error_scale = scale / q / q;
+  double *cost_coeff = W->cost_coeff, *cost_sig = W->cost_sig, *cost_coeff0 = W->cost_coeff0;
+  double block_uncoded_cost = 0, base_cost = 0;
+  const int cg_num = (n * n) >> 4, cgw = n >> 2;
+  double cost_cg_sig[64];
+  uint8_t cg_flag[64];
+  for (int i = 0; i < cg_num; ++i) cg_flag[i] = 0;
+  for (int i = 0; i < n * n; ++i) dst[i] = 0;
+  int ctx_set = 0, temp_diag = -1, temp_sum = -1;
+  int go_rice = 0;
+  int cg_last_scanpos = -1, last_scanpos = -1;
+  const int cap_half = 1 << (E.q_bits - 1);
+  int cgs;
+  for (cgs = cg_num - 1; cgs >= 0; cgs--) {
+    for (int sp = 15; sp >= 0; sp--) {
+      const int scanpos = cgs * 16 + sp;
+      const int blkpos = scan[scanpos];
+      const int64_t prod = (int64_t)iabs_((int)coef[blkpos]) * q;
+      const int32_t cap = 0x7fffffff - cap_half;
+      const int32_t level_double = (int32_t)(prod < cap ? prod : cap);
+      const uint32_t max_abs_level = (uint32_t)(level_double + cap_half) >> E.q_bits;
+      const double err = (double)level_double;
+      cost_coeff0[scanpos] = err * err * E.error_scale;
+      dst[blkpos] = (int16_t)max_abs_level;
+      if (max_abs_level > 0) { last_scanpos = scanpos; cg_last_scanpos = cgs; break; }
+      block_uncoded_cost += cost_coeff0[scanpos];
+      base_cost += cost_coeff0[scanpos];
+    }
+    if (last_scanpos != -1) break;
+  }
+  if (last_scanpos == -1) return 0;
+  for (; cgs >= 0; cgs--) cost_cg_sig[cgs] = 0;
+
+  for (cgs = cg_last_scanpos; cgs >= 0; cgs--) {
+    // the group's raster index = position of its first coefficient / 4
+    const int first = scan[cgs * 16];
+    const int cg_pos_x = (first & (n - 1)) >> 2, cg_pos_y = (first >> l2) >> 2;
+    const int cg_blkpos = cg_pos_y * cgw + cg_pos_x;
+    double rd_coded = 0, rd_uncoded = 0, rd_sig = 0, rd_sig0 = 0;
+    int nnz_before_pos0 = 0;
+    for (int sp = 15; sp >= 0; sp--) {
+      const int scanpos = cgs * 16 + sp;
+      if (scanpos > last_scanpos) continue;
+      const int blkpos = scan[scanpos];
+      const int64_t prod = (int64_t)iabs_((int)coef[blkpos]) * q;
+      const int32_t cap = 0x7fffffff - cap_half;
+      const int32_t level_double = (int32_t)(prod < cap ? prod : cap);
+      const uint32_t max_abs_level = (uint32_t)(level_double + cap_half) >> E.q_bits;
+      dst[blkpos] = (int16_t)max_abs_level;
+      const double err = (double)level_double;
+      cost_coeff0[scanpos] = err * err * E.error_scale;
+      block_uncoded_cost += cost_coeff0[scanpos];
+      {
+        const int pos_y = blkpos >> l2, pos_x = blkpos - (pos_y << l2);
+        int ctx_sig = 0;
+        if (scanpos != last_scanpos) ctx_sig = sig_ctx_abs(dst, pos_x, pos_y, n, color, &temp_diag, &temp_sum);
+        if (temp_diag != -1)
+          ctx_set = ((temp_sum < 4 ? temp_sum : 4) + 1) +
+                    (!temp_diag ? ((color == 0) ? 15 : 5) : (color == 0) ? (temp_diag < 3 ? 10 : (temp_diag < 10 ? 5 : 0)) : 0);
+        else ctx_set = 0;
+        if (reg_bins < 4) go_rice = go_rice_par(template_abs_sum(dst, 0, pos_x, pos_y, n));
+        const int level = (int)coded_level(E, &cost_coeff[scanpos], cost_coeff0[scanpos], &cost_sig[scanpos], level_double, max_abs_level,
+                                           scanpos == last_scanpos ? 0 : ctx_sig, ctx_set, go_rice, reg_bins, scanpos == last_scanpos);
+        dst[blkpos] = (int16_t)level;
+        base_cost += cost_coeff[scanpos];
+        if ((scanpos % 16 == 0) && scanpos > 0) go_rice = 0;
+        else if (reg_bins >= 4) {
+          reg_bins -= (uint32_t)((level < 2 ? level : 3) + (scanpos != last_scanpos));
+          go_rice = go_rice_par(template_abs_sum(coef, 4, pos_x, pos_y, n));       // sic: the INPUT coefficients (rdo.c:1697)
+        }
+      }
+      rd_sig += cost_sig[scanpos];
+      if (sp == 0) rd_sig0 = cost_sig[scanpos];
+      if (dst[blkpos]) {
+        cg_flag[cg_blkpos] = 1;
+        rd_coded += cost_coeff[scanpos] - cost_sig[scanpos];
+        rd_uncoded += cost_coeff0[scanpos];
+        if (sp != 0) nnz_before_pos0++;
+      }
+    }
+    if (cgs) {
+      unsigned right = 0, lower = 0;
+      if (cg_pos_x + 1 < cgw) right = cg_flag[cg_blkpos + 1];
+      if (cg_pos_y + 1 < cgw) lower = cg_flag[cg_blkpos + cgw];
+      const int o_grp = M_SIGGRP + (E.t ? 2 : 0) + ((right || lower) ? 1 : 0);
+      if (cg_flag[cg_blkpos] == 0) {
+        cost_cg_sig[cgs] = lambda * rbits(E, o_grp, 0);
+        base_cost += cost_cg_sig[cgs] - rd_sig;
+      } else if (cgs < cg_last_scanpos) {
+        if (nnz_before_pos0 == 0) { base_cost -= rd_sig0; rd_sig -= rd_sig0; }
+        double cost_zero_cg = base_cost;
+        cost_cg_sig[cgs] = lambda * rbits(E, o_grp, 1);
+        base_cost += cost_cg_sig[cgs];
+        cost_zero_cg += lambda * rbits(E, o_grp, 0);
+        cost_zero_cg += rd_uncoded;
+        cost_zero_cg -= rd_coded;
+        cost_zero_cg -= rd_sig;
+        if (cost_zero_cg < base_cost) {
+          cg_flag[cg_blkpos] = 0;
+          base_cost = cost_zero_cg;
+          cost_cg_sig[cgs] = lambda * rbits(E, o_grp, 0);
+          for (int sp = 15; sp >= 0; sp--) {
+            const int scanpos = cgs * 16 + sp;
+            const int blkpos = scan[scanpos];
+            if (dst[blkpos]) { dst[blkpos] = 0; cost_coeff[scanpos] = cost_coeff0[scanpos]; cost_sig[scanpos] = 0; }
+          }
+        }
+      }
+    } else {
+      cg_flag[cg_blkpos] = 1;
+    }
+  }
+
+  double best_cost;
+  int best_last_idx_p1 = 0;
+  {
+    const int o_cbf = color == 0 ? M_CBF_LUMA : color == 1 ? M_CBF_CB : M_CBF_CR + (cbf_u ? 1 : 0);
+    best_cost = block_uncoded_cost + lambda * rbits(E, o_cbf, 0);
+    base_cost += lambda * rbits(E, o_cbf, 1);
+  }
+  // calc_last_bits (rdo.c:664-700)
+  int32_t last_x_bits[32], last_y_bits[32];
+  {
+    const int prefix_ctx[8] = {0, 0, 0, 3, 6, 10, 15, 21};
+    const int off = E.t ? 0 : prefix_ctx[l2];
+    const int sh = E.t ? clampi(n >> 3, 0, 2) : ((l2 + 1) >> 2);
+    int32_t bx = 0, by = 0;
+    int ctx;
+    for (ctx = 0; ctx < group_idx(n - 1); ctx++) {
+      const int o = off + (ctx >> sh);
+      const int mx = M_LASTX + (E.t ? 20 : 0) + o, my = M_LASTY + (E.t ? 20 : 0) + o;
+      last_x_bits[ctx] = bx + rbits(E, mx, 0); bx += rbits(E, mx, 1);
+      last_y_bits[ctx] = by + rbits(E, my, 0); by += rbits(E, my, 1);
+    }
+    last_x_bits[ctx] = bx; last_y_bits[ctx] = by;
+  }
+  int found_last = 0;
+  for (cgs = cg_last_scanpos; cgs >= 0; cgs--) {
+    const int first = scan[cgs * 16];
+    const int cg_blkpos = ((first >> l2) >> 2) * cgw + ((first & (n - 1)) >> 2);
+    base_cost -= cost_cg_sig[cgs];
+    if (cg_flag[cg_blkpos]) {
+      for (int sp = 15; sp >= 0; sp--) {
+        const int scanpos = cgs * 16 + sp;
+        if (scanpos > last_scanpos) continue;
+        const int blkpos = scan[scanpos];
+        if (dst[blkpos]) {
+          const int pos_y = blkpos >> l2, pos_x = blkpos - (pos_y << l2);
+          const int cx = group_idx(pos_x), cy = group_idx(pos_y);
+          double cl = last_x_bits[cx] + last_y_bits[cy];
+          if (cx > 3) cl += 32768 * ((cx - 2) >> 1);
+          if (cy > 3) cl += 32768 * ((cy - 2) >> 1);
+          const double cost_last = lambda * cl;
+          const double total = base_cost + cost_last - cost_sig[scanpos];
+          if (total < best_cost) { best_last_idx_p1 = scanpos + 1; best_cost = total; }
+          if (dst[blkpos] > 1) { found_last = 1; break; }
+          base_cost -= cost_coeff[scanpos];
+          base_cost += cost_coeff0[scanpos];
+        } else {
+          base_cost -= cost_sig[scanpos];
+        }
+      }
+      if (found_last) break;
+    }
+  }
+  int any = 0;
+  for (int scanpos = 0; scanpos < best_last_idx_p1; scanpos++) {
+    const int b = scan[scanpos], level = dst[b];
+    any |= level;
+    dst[b] = (int16_t)((coef[b] < 0) ? -level : level);
+  }
+  for (int scanpos = best_last_idx_p1; scanpos <= last_scanpos; scanpos++) dst[scan[scanpos]] = 0;
+  return any != 0;
+}
+
+// -------------------------------------------------------------------------------------------- coefficient bit cost ------
+CTU_DEV int coeff_remain_bits(uint32_t remainder, uint32_t rice, unsigned cutoff)     // uvg_cabac_write_coeff_remain, cabac.c:318-354
+{
+  const unsigned threshold = cutoff << rice;
+  if (remainder < threshold) return (int)((remainder >> rice) + 1 + rice);
+  const unsigned max_prefix = 32 - cutoff - 15;
+  unsigned prefix = 0, suffix_len;
+  const unsigned code_value = (remainder >> rice) - cutoff;
+  if ((int32_t)code_value >= ((1 << max_prefix) - 1)) { prefix = max_prefix; suffix_len = 15; }
+  else { while ((int32_t)code_value > ((2 << prefix) - 2)) prefix++; suffix_len = prefix + rice + 1; }
+  return (int)(prefix + cutoff + suffix_len);
+}
+CTU_DEV int abs_sum_tmpl(const int16_t *coeff, int px, int py, int n, int baselevel)      // uvg_abs_sum, context.c:846-877
+{
+  const int16_t *d = coeff + px + py * n;
+  int sum = 0;
+  if (px < n - 1) {
+    sum += iabs_((int)d[1]);
+    if (px < n - 2) sum += iabs_((int)d[2]);
+    if (py < n - 1) sum += iabs_((int)d[n + 1]);
+  }
+  if (py < n - 1) {
+    sum += iabs_((int)d[n]);
+    if (py < n - 2) sum += iabs_((int)d[n << 1]);
+  }
+  int v = sum - 5 * baselevel;
+  v = v < 31 ? v : 31;
+  return v > 0 ? v : 0;
+}
+
+// uvg_encode_coeff_nxn in count mode (encode_coding_tree-generic.c:53-323, uvg_encode_last_significant_xy :415-470) on the models m,
+// which adapt bin by bin (get_coeff_cabac_cost always lets its COPY adapt; the caller decides whether to keep it); lane 0 only.
+// No dependent quantisation, no sign hiding, diagonal scan, regular residual coding.  Returns 0 for an all-zero block (rdo.c:312-320).
+CTU_DEV double coeff_bits_serial(uint32_t *m, const uint16_t *scan, const int16_t *coeff, int n, int color)
+{
+  const int l2 = ilog2_dev(n);
+  const int t = color ? 1 : 0;
+  const int cgw = n >> 2;
+  uint8_t sig_cg[64];
+  for (int i = 0; i < cgw * cgw; ++i) sig_cg[i] = 0;
+  int scan_pos_last = -1;
+  for (int i = 0; i < n * n; ++i)
+    if (coeff[scan[i]]) {
+      scan_pos_last = i;
+      const int f = scan[i & ~15];
+      sig_cg[((f >> l2) >> 2) * cgw + ((f & (n - 1)) >> 2)] = 1;
+    }
+  if (scan_pos_last < 0) return 0;
+  const int scan_cg_last = scan_pos_last >> 4;
+  double bits_out = 0;
+  {
+    const int pos_last = scan[scan_pos_last];
+    const int last_y = pos_last >> l2, last_x = pos_last - (last_y << l2);
+    const int prefix_ctx[8] = {0, 0, 0, 3, 6, 10, 15, 21};
+    const int off = t ? 0 : prefix_ctx[l2];
+    const int sh = t ? clampi(n >> 3, 0, 2) : ((l2 + 1) >> 2);
+    const int bx = M_LASTX + 20 * t + off, by = M_LASTY + 20 * t + off;
+    const int gx = group_idx(last_x), gy = group_idx(last_y), gmax = group_idx(n - 1);
+    double bits = 0;
+    int k = 0;
+    for (; k < gx; k++) m_code(m, 1, bx + (k >> sh), 1, bits);
+    if (gx < gmax) m_code(m, 1, bx + (k >> sh), 0, bits);
+    k = 0;
+    for (; k < gy; k++) m_code(m, 1, by + (k >> sh), 1, bits);
+    if (gy < gmax) m_code(m, 1, by + (k >> sh), 0, bits);
+    if (gx > 3) bits += (gx - 2) / 2;
+    if (gy > 3) bits += (gy - 2) / 2;
+    bits_out += bits;
+  }
+  double bits = 0;
+  uint8_t ctx_offset[16];
+  int temp_diag = -1, temp_sum = -1;
+  int32_t reg_bins = (n * n * 28) >> 4;
+  for (int i = scan_cg_last; i >= 0; i--) {
+    const int first = scan[i * 16];
+    const int cg_pos_x = (first & (n - 1)) >> 2, cg_pos_y = (first >> l2) >> 2;
+    const int cg_blk = cg_pos_y * cgw + cg_pos_x;
+    if (i == scan_cg_last || i == 0) {
+      sig_cg[cg_blk] = 1;
+    } else {
+      unsigned right = 0, lower = 0;
+      if (cg_pos_x + 1 < cgw) right = sig_cg[cg_blk + 1];
+      if (cg_pos_y + 1 < cgw) lower = sig_cg[cg_blk + cgw];
+      m_code(m, 1, M_SIGGRP + 2 * t + ((right || lower) ? 1 : 0), sig_cg[cg_blk] != 0, bits);
+    }
+    if (!sig_cg[cg_blk]) continue;
+    const int min_sub_pos = i << 4;
+    const int first_sig_pos = (i == scan_cg_last) ? scan_pos_last : (min_sub_pos + 15);
+    int next_sig_pos = first_sig_pos;
+    const int infer_sig_pos = (next_sig_pos != scan_pos_last) ? ((i != 0) ? min_sub_pos : -1) : next_sig_pos;
+    int num_non_zero = 0;
+    for (next_sig_pos = first_sig_pos; next_sig_pos >= min_sub_pos && reg_bins >= 4; next_sig_pos--) {
+      const int blk = scan[next_sig_pos];
+      const int py = blk >> l2, px = blk - (py << l2);
+      const int sig = coeff[blk] != 0;
+      if (num_non_zero || next_sig_pos != infer_sig_pos) {
+        const int ctx_sig = sig_ctx_abs(coeff, px, py, n, color, &temp_diag, &temp_sum);
+        m_code(m, 1, M_SIG + 12 * t + (t ? (ctx_sig < 7 ? ctx_sig : 7) : ctx_sig), sig, bits);
+        reg_bins--;
+      } else if (next_sig_pos != scan_pos_last) {
+        (void)sig_ctx_abs(coeff, px, py, n, color, &temp_diag, &temp_sum);
+      }
+      if (sig) {
+        uint8_t *offset = &ctx_offset[next_sig_pos - min_sub_pos];
+        num_non_zero++;
+        *offset = 0;
+        if (temp_diag != -1) {
+          *offset = (uint8_t)((temp_sum < 4 ? temp_sum : 4) + 1);
+          *offset = (uint8_t)(*offset + (!temp_diag ? (color == 0 ? 15 : 5) : color == 0 ? (temp_diag < 3 ? 10 : (temp_diag < 10 ? 5 : 0)) : 0));
+        }
+        int rem = iabs_((int)coeff[blk]) - 1;
+        const int gt1 = rem ? 1 : 0;
+        m_code(m, 1, M_GT1 + 21 * t + *offset, gt1, bits);
+        reg_bins--;
+        if (gt1) {
+          rem -= 1;
+          m_code(m, 1, M_PAR + 21 * t + *offset, rem & 1, bits);
+          rem >>= 1;
+          reg_bins--;
+          m_code(m, 1, M_GT2 + 21 * t + *offset, rem ? 1 : 0, bits);
+          reg_bins--;
+        }
+      }
+    }
+    for (int sp = first_sig_pos; sp > next_sig_pos; sp--) {
+      const int blk = scan[sp];
+      const unsigned a = (unsigned)iabs_((int)coeff[blk]);
+      if (a >= 4) {
+        const int py = blk >> l2, px = blk - (py << l2);
+        const int rice = go_rice_par((unsigned)abs_sum_tmpl(coeff, px, py, n, 4));
+        bits += coeff_remain_bits((a - 4) >> 1, (uint32_t)rice, 5);
+      }
+    }
+    for (int sp = next_sig_pos; sp >= min_sub_pos; sp--) {
+      const int blk = scan[sp];
+      const int py = blk >> l2, px = blk - (py << l2);
+      const unsigned a = (unsigned)iabs_((int)coeff[blk]);
+      const int rice = go_rice_par((unsigned)abs_sum_tmpl(coeff, px, py, n, 0));
+      const unsigned pos0 = 1u << rice;
+      const unsigned remainder = a == 0 ? pos0 : (a <= pos0 ? a - 1 : a);
+      bits += coeff_remain_bits(remainder, (uint32_t)rice, 5);
+      if (a) num_non_zero++;
+    }
+    bits += num_non_zero;
+  }
+  return bits_out + bits;
+}
+
+
+// =================================================================================================== the CTU search ======
+// everything one workgroup needs to know about its CTU
+template <typename PX> struct job {
+  params P;
+  const PX *src_y, *src_u, *src_v;       // source planes
+  int src_stride, src_stride_c;
+  PX *rec_y, *rec_u, *rec_v;             // reconstruction before the in-loop filters (also the neighbours' samples)
+  int rec_stride, rec_stride_c;
+  uvghip_scu_t *cu_tab;                  // the picture's side information, one entry per 4x4
+  int cu_stride;
+  int16_t *coeff;                        // this CTU's lcu_coeff_t: y[64*64], u[32*32], v[32*32]
+  uint32_t *models_out;                  // this CTU's three model sets [3][NMODELS]: at its start, after its search, after the coder
+  const uint32_t *models_in;             // the coder's models this CTU starts from (NULL: initialise for an I slice at P.qp)
+  scratch *W;
+  int x, y;                              // CTU origin
+};
+
+CTU_DEV int co_off(int color) { return color == 0 ? 0 : (color == 1 ? 4096 : 5120); }
+CTU_DEV int cand_px_off(int L, int color)      // L = 1..3
+{
+  const int base = L == 1 ? 0 : (L == 2 ? 1536 : 1920);
+  const int n = 64 >> L;
+  return base + (color == 0 ? 0 : n * n + (color - 1) * (n / 2) * (n / 2));
+}
+
+template <typename PX> CTU_DEV int scaled_qp(const params &P, int color) { return (color == 0 ? P.qp : P.qp_c) + 6 * ((int)px_info<PX>::depth - 8); }
+
+// predict + uvg_quantize_residual (quant-generic.c:460-612, RDOQ branch) of one transform block straight into D; its levels stay in
+// S->lv[color] and go to the CTU's coefficient array.  (x, y) / (lx, ly): luma position, n: luma size of the area.  -> has_coeffs
+template <typename PX> CTU_DEV int recon_tu(lds<PX> *S, const job<PX> &J, int color, int x, int y, int lx, int ly, int n, int mode, int cbf_u)
+{
+  const int c = color != 0, w = n >> c, l2 = ilog2_dev(w);
+  const int pit = pitch_of(color), spit = c ? LCU_C : LCU;
+  const int bx = lx >> c, by = ly >> c;
+  PX *D = plane(S, color) + (by + 1) * pit + bx + 1;
+  const PX *Sp = (color == 0 ? S->Sy : color == 1 ? S->Su : S->Sv) + by * spit + bx;
+  const int depth = (int)px_info<PX>::depth;
+  build_refs(S, J.P, color, x, y, lx, ly, n);
+  predict_block(S, mode, color, w, D, pit);
+  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); S->t0[e] = (int16_t)((int)Sp[r * spit + q] - (int)D[r * pit + q]); }
+  CTU_SYNC();
+  fwd_pass(w, S->t0, S->t1, l2 - 1 + depth - 8);
+  fwd_pass(w, S->t1, S->t2, l2 + 6);
+  const int qps = scaled_qp<PX>(J.P, color);
+  SERIAL {
+    // chroma blocks: state->c_lambda as uvg_quantize_lcu_residual replaces it (transform.c:1575)
+    const double lambda = c ? J.P.c_lambda_tu : J.P.lambda;
+    S->u_flag = rdoq_serial(S->rdoq_state, S->scan + scan_base(l2), J.W, S->t2, S->lv[color], w, color, cbf_u, qps, lambda, depth);
+  }
+  CTU_SYNC();
+  const int has = S->u_flag;
+  int16_t *co = J.coeff + co_off(color) + by * spit + bx;
+  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); co[r * spit + q] = S->lv[color][e]; }
+  if (has) {
+    const int transform_shift = 15 - depth - l2;
+    const int shift = 20 - 14 - transform_shift;
+    const int32_t scale = (int32_t)kInvQuantScales[qps % 6] << (qps / 6);
+    const int32_t add = 1 << (shift - 1);
+    PAR_FOR(e, w * w) S->t0[e] = (int16_t)clampi((S->lv[color][e] * scale + add) >> shift, -32768, 32767);      // uvg_dequant, quant-generic.c:618-669
+    CTU_SYNC();
+    inv_pass(w, S->t0, S->t1, 7);
+    inv_pass(w, S->t1, S->t0, 12 - (depth - 8));
+    PAR_FOR(e, w * w) {
+      const int r = e >> l2, q = e & (w - 1);
+      const int16_t val = (int16_t)(S->t0[e] + (int)D[r * pit + q]);
+      D[r * pit + q] = (PX)clampi(val, 0, (int)px_info<PX>::maxv);
+    }
+  }
+  CTU_SYNC();
+  return has;
+}
+
+// uvg_pixels_calc_ssd of a w x w block of D against the source, into S->red[slot] (valid after the barrier)
+template <typename PX> CTU_DEV void ssd_block(lds<PX> *S, int color, int lx, int ly, int n, int slot)
+{
+  const int c = color != 0, w = n >> c, l2 = ilog2_dev(w);
+  const int pit = pitch_of(color), spit = c ? LCU_C : LCU;
+  const PX *D = plane(S, color) + ((ly >> c) + 1) * pit + (lx >> c) + 1;
+  const PX *Sp = (color == 0 ? S->Sy : color == 1 ? S->Su : S->Sv) + (ly >> c) * spit + (lx >> c);
+  int acc = 0;
+  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); const int d = (int)Sp[r * spit + q] - (int)D[r * pit + q]; acc += d * d; }
+  S->partial[CTU_TID] = acc;
+  CTU_SYNC();
+  SERIAL {
+    int tot = 0;
+    for (int i = 0; i < CTU_NT; ++i) tot += S->partial[i];
+    S->red[slot] = tot >> (2 * ((int)px_info<PX>::depth - 8));
+  }
+  CTU_SYNC();
+}
+
+// uvg_write_split_flag (encode_coding_tree.c:1240-1363) with the multi-type splits off: only split_cu_flag exists; lane 0
+template <typename PX> CTU_DEV void split_flag_bits(lds<PX> *S, const params &P, uint32_t *m, int update, int x, int y, int lx, int ly, int n, int split,
+                                                    double &bits)
+{
+  const int inside = P.pic_w >= x + n && P.pic_h >= y + n;
+  if (!inside || n <= 4) return;                      // implicit split, or nothing to split: no flag
+  const cu4 *left = x > 0 ? cu_at(S, lx - 1, ly) : nullptr, *above = y > 0 ? cu_at(S, lx, ly - 1) : nullptr;
+  int model = 0;
+  if (left && (1 << left->log2) < n) model++;
+  if (above && (1 << above->log2) < n) model++;
+  m_code(m, update, M_SPLIT + model, split, bits);   // split_num = 1 -> + 3 * 0
+}
+
+// uvg_encode_intra_luma_coding_unit (encode_coding_tree.c:992-1238) in count mode; lane 0
+template <typename PX> CTU_DEV void luma_mode_bits(lds<PX> *S, uint32_t *m, int update, int x, int y, int lx, int ly, int n, int mode, double &bits_out)
+{
+  const cu4 *l, *a;
+  int8_t preds[6];
+  mpm_neighbours(S, x, y, lx, ly, n, &l, &a);
+  dir_luma_predictor(y, preds, l, a);
+  double bits = 0;
+  int mpm = -1;
+  for (int i = 0; i < 6; ++i) if (preds[i] == mode) { mpm = i; break; }
+  m_code(m, update, M_MPM, mpm != -1, bits);
+  if (mpm != -1) {
+    m_code(m, update, M_PLANAR + 1, mpm > 0, bits);
+    if (mpm > 0) bits += 1;
+    if (mpm > 1) bits += 1;
+    if (mpm > 2) bits += 1;
+    if (mpm > 3) bits += 1;
+  } else {
+    for (int i = 0; i < 6; ++i)
+      for (int j = i + 1; j < 6; ++j)
+        if ((uint8_t)preds[j] < (uint8_t)preds[i]) { const int8_t t = preds[i]; preds[i] = preds[j]; preds[j] = t; }
+    int tmp = mode;
+    for (int i = 5; i >= 0; --i) if (tmp > preds[i]) tmp--;
+    bits_out += (tmp < 3) ? 5 : 6;                    // truncated binary code of 61 symbols (cabac.c:203-229)
+  }
+  bits_out += bits;
+}
+CTU_DEV void chroma_mode_bits(uint32_t *m, int update, int chroma_mode, int luma_dir, double &bits)     // encode_chroma_intra_cu, :902-990
+{
+  const int derived = chroma_mode == luma_dir;
+  m_code(m, update, M_CHROMA_PRED, derived ? 0 : 1, bits);
+  if (!derived) bits += 2;
+}
+
+// mark_deblocking (search.c:1075-1174) for an n x n CU; sep: a 4x4 CU of an 8x8 area, chroma: it carries the area's chroma; lane 0
+template <typename PX> CTU_DEV void mark_deblocking(lds<PX> *S, int x, int y, int lx, int ly, int n, int sep, int chroma)
+{
+  if (x) {
+    for (int xx = lx; xx < lx + n; xx += 32)
+      for (int yy = ly; yy < ly + n; yy += 4) { cu_at(S, xx, yy)->luma_edges |= 1; if (!sep) cu_at(S, xx, yy)->chroma_edges |= 1; }
+  } else if (n == 64) {
+    for (int yy = ly; yy < ly + n; yy += 4) { cu_at(S, 32, yy)->luma_edges |= 1; if (!sep) cu_at(S, 32, yy)->chroma_edges |= 1; }
+  }
+  if (y) {
+    for (int yy = ly; yy < ly + n; yy += 32)
+      for (int xx = lx; xx < lx + n; xx += 4) { cu_at(S, xx, yy)->luma_edges |= 2; if (!sep) cu_at(S, xx, yy)->chroma_edges |= 2; }
+  } else if (n == 64) {
+    for (int xx = lx; xx < lx + n; xx += 4) { cu_at(S, xx, 32)->luma_edges |= 2; if (!sep) cu_at(S, xx, 32)->chroma_edges |= 2; }
+  }
+  if (sep && chroma) {
+    const int cx = lx & ~7, cy = ly & ~7;
+    if (x & ~7) for (int yy = cy; yy < cy + 8; yy += 4) cu_at(S, cx, yy)->chroma_edges |= 1;
+    if (y & ~7) for (int xx = cx; xx < cx + 8; xx += 4) cu_at(S, xx, cy)->chroma_edges |= 2;
+  }
+}
+
+// the transform-tree part of the RD cost of one <= 32 block whose levels are in S->lv (cu_rd_cost_tr_split_accurate, search.c:724-986);
+// red[0..2]: SSD of y, u, v.  lane 0.  update: state->search_cabac.update.
+template <typename PX> CTU_DEV double tr_cost(lds<PX> *S, const params &P, int update, int n, int cbf, int has_chroma, int cn)
+{
+  double coeff_bits = 0, luma_bits = 0, chroma_bits = 0;
+  const int cb_y = cbf & 1, cb_u = (cbf >> 1) & 1, cb_v = (cbf >> 2) & 1;
+  if (has_chroma) {
+    m_code(S->cur, update, M_CBF_CB + 0, cb_u, chroma_bits);
+    m_code(S->cur, update, M_CBF_CR + cb_u, cb_v, chroma_bits);
+  }
+  m_code(S->cur, update, M_CBF_LUMA + 0, cb_y, luma_bits);
+  const unsigned luma_ssd = (unsigned)S->red[0];
+  // uvg_get_coeff_cost counts on a copy of the models that is kept only when update is set (rdo.c:322-356)
+  uint32_t *mm = S->cur;
+  if (!update) { mm = S->post[0]; }       // (scratch copy: post[0] is free whenever update is 0 -- the 64x64 candidate at depth 0)
+  if (cb_y) {
+    if (!update) for (int i = 0; i < NMODELS; ++i) mm[i] = S->cur[i];
+    coeff_bits += coeff_bits_serial(mm, S->scan + scan_base(ilog2_dev(n)), S->lv[0], n, 0);
+  }
+  unsigned chroma_ssd = 0;
+  if (has_chroma) {
+    const unsigned ssd_u = (unsigned)((unsigned)S->red[1] * P.cw_u), ssd_v = (unsigned)((unsigned)S->red[2] * P.cw_v);
+    chroma_ssd = ssd_u + ssd_v;
+    if (!update) for (int i = 0; i < NMODELS; ++i) mm[i] = S->cur[i];
+    chroma_bits += coeff_bits_serial(mm, S->scan + scan_base(ilog2_dev(cn)), S->lv[1], cn, 1);
+    if (!update) for (int i = 0; i < NMODELS; ++i) mm[i] = S->cur[i];
+    chroma_bits += coeff_bits_serial(mm, S->scan + scan_base(ilog2_dev(cn)), S->lv[2], cn, 2);
+  }
+  const double bits = luma_bits + coeff_bits;
+  return luma_ssd * 1.0 + chroma_ssd * 1.0 + (bits + chroma_bits) * P.lambda;
+}
+
+// cur_cu->mode_type_tree: the tree's bits plus the parent's type at the CU's own depth (search.c:1387-1388)
+CTU_DEV uint32_t cu_mtt(uint32_t tree_mtt, int L) { return tree_mtt | ((tree_mtt >> ((L - 1 > 0 ? L - 1 : 0) * 2)) & 3u) << (L * 2); }
+
+// lcu_fill_cu_info (search.c:314-353) for an n x n intra CU; lane 0
+template <typename PX> CTU_DEV void fill_cu(lds<PX> *S, int lx, int ly, int n, int mode, int mode_chroma, int log2_c, uint32_t split_tree, uint32_t mtt)
+{
+  const int l2 = ilog2_dev(n);
+  for (int yy = ly; yy < ly + n; yy += 4)
+    for (int xx = lx; xx < lx + n; xx += 4) {
+      cu4 *c = cu_at(S, xx, yy);
+      c->type = CU_INTRA; c->log2 = (uint8_t)l2; c->log2_c = (uint8_t)log2_c; c->mode = (int8_t)mode; c->mode_chroma = (int8_t)mode_chroma;
+      S->tree[(yy >> 2) * 16 + (xx >> 2)] = split_tree;
+      S->mtt[(yy >> 2) * 16 + (xx >> 2)] = mtt;
+    }
+}
+
+// search + reconstruction + RD cost of the n x n CU at depth L as ONE coding unit (the part of search_cu before the split loop,
+// search.c:1395-1774).  Leaves the CU in D and its cost / mode / cbf in S->lvl[L]; the models move on as the mock coder saw the CU.
+template <typename PX> CTU_DEV void eval_cu(lds<PX> *S, const job<PX> &J, int L)
+{
+  const params &P = J.P;
+  level_state &N = S->lvl[L];
+  const int n = 64 >> L, x = N.x, y = N.y, lx = x & 63, ly = y & 63;
+  const int sep = n == 4;                                 // a 4x4 CU: its chroma belongs to the 8x8 area, carried by the fourth one
+  const int has_chroma = N.has_chroma;
+  SERIAL {                                                  // the CU's own entry is reset (search.c:1371-1388)
+    cu4 *c = cu_at(S, lx, ly);
+    c->type = CU_NOTSET; c->cbf = 0; c->luma_edges = 0; c->chroma_edges = 0; c->mode = 0; c->mode_chroma = 0; c->log2 = (uint8_t)ilog2_dev(n);
+    c->log2_c = (uint8_t)(sep ? 2 : ilog2_dev(n) - 1);
+  }
+  CTU_SYNC();
+  build_refs(S, P, 0, x, y, lx, ly, n);
+  search_intra_rough(S, P, x, y, lx, ly, n);
+  const int mode = S->u_mode;
+  SERIAL fill_cu(S, lx, ly, n, mode, mode, sep ? 2 : ilog2_dev(n) - 1, N.split_tree, cu_mtt(N.mode_type_tree, L));
+  CTU_SYNC();
+  int cbf = recon_tu(S, J, 0, x, y, lx, ly, n, mode, 0);
+  int cn = n >> 1, cx = x, cy = y;                        // the chroma area (luma coordinates) and its block size
+  if (sep) { cn = 4; cx = x & ~7; cy = y & ~7; }
+  if (has_chroma) {
+    const int area = sep ? 8 : n;
+    const int cu = recon_tu(S, J, 1, cx, cy, cx & 63, cy & 63, area, mode, 0);
+    const int cv = recon_tu(S, J, 2, cx, cy, cx & 63, cy & 63, area, mode, cu);
+    cbf |= cu << 1 | cv << 2;
+    ssd_block(S, 1, cx & 63, cy & 63, area, 1);
+    ssd_block(S, 2, cx & 63, cy & 63, area, 2);
+  }
+  ssd_block(S, 0, lx, ly, n, 0);
+  SERIAL {
+    cu4 *c = cu_at(S, lx, ly);
+    c->cbf = (uint8_t)(cbf & 1);
+    if (has_chroma) {
+      if (!sep) c->cbf = (uint8_t)cbf;
+      else {
+        // the area's chroma flags sit at its first entry and are copied to all four (lcu_fill_chroma_cbfs), with the chroma mode and
+        // chroma size of this, the last, CU (lcu_fill_chroma_cu_info, search.c:355-400)
+        for (int k = 0; k < 4; ++k) {
+          cu4 *q = cu_at(S, (cx & 63) + (k & 1) * 4, (cy & 63) + (k >> 1) * 4);
+          q->cbf = (uint8_t)((q->cbf & 1) | (cbf & 6));
+          q->mode_chroma = (int8_t)mode;
+          q->log2_c = 2;
+        }
+      }
+    }
+    // uvg_mock_encode_coding_unit + cu_rd_cost_tr_split_accurate with search_cabac.update = 1 (search.c:1700-1736)
+    double bits = 0;
+    split_flag_bits(S, P, S->cur, 1, x, y, lx, ly, n, 0, bits);
+    luma_mode_bits(S, S->cur, 1, x, y, lx, ly, n, mode, bits);
+    if (has_chroma) chroma_mode_bits(S->cur, 1, mode, mode, bits);
+    double cost = bits * P.lambda;
+    cost += tr_cost(S, P, 1, n, sep ? ((cbf & 1) | (cu_at(S, lx, ly)->cbf & 6)) : cbf, has_chroma, cn);
+    mark_deblocking(S, x, y, lx, ly, n, sep, has_chroma);
+    N.cost = cost; N.type = CU_INTRA; N.mode = mode; N.cbf = cu_at(S, lx, ly)->cbf;
+  }
+  CTU_SYNC();
+}
+
+// park the CU just evaluated at depth L (1..3) and clear its area of D's side information, as a fresh work-tree level would be
+// (initialize_partial_work_tree zeroes the entries from the CU's origin on, search.c:168-172)
+template <typename PX> CTU_DEV void park(lds<PX> *S, const job<PX> &J, int L)
+{
+  const level_state &N = S->lvl[L];
+  const int n = 64 >> L, lx = N.x & 63, ly = N.y & 63;
+  for (int color = 0; color < 3; ++color) {
+    const int c = color != 0, w = n >> c, l2 = ilog2_dev(w), pit = pitch_of(color), spit = c ? LCU_C : LCU;
+    const PX *D = plane(S, color) + ((ly >> c) + 1) * pit + (lx >> c) + 1;
+    const int16_t *co = J.coeff + co_off(color) + (ly >> c) * spit + (lx >> c);
+    const int off = cand_px_off(L, color);
+    PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); S->cand_px[off + e] = D[r * pit + q]; S->cand_co[off + e] = CTU_GLOAD(&co[r * spit + q]); }
+  }
+  PAR_FOR(e, (n >> 2) * (n >> 2)) {
+    const int r = e / (n >> 2), q = e - r * (n >> 2);
+    cu4 *c = cu_at(S, lx + q * 4, ly + r * 4);
+    c->type = CU_NOTSET; c->log2 = 0; c->cbf = 0; c->luma_edges = 0; c->chroma_edges = 0; c->log2_c = 0; c->mode = 0; c->mode_chroma = 0;
+  }
+  CTU_SYNC();
+}
+// put the parked CU back: the split lost
+template <typename PX> CTU_DEV void unpark(lds<PX> *S, const job<PX> &J, int L)
+{
+  const level_state &N = S->lvl[L];
+  const int n = 64 >> L, lx = N.x & 63, ly = N.y & 63;
+  for (int color = 0; color < 3; ++color) {
+    const int c = color != 0, w = n >> c, l2 = ilog2_dev(w), pit = pitch_of(color), spit = c ? LCU_C : LCU;
+    PX *D = plane(S, color) + ((ly >> c) + 1) * pit + (lx >> c) + 1;
+    int16_t *co = J.coeff + co_off(color) + (ly >> c) * spit + (lx >> c);
+    const int off = cand_px_off(L, color);
+    PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); D[r * pit + q] = S->cand_px[off + e]; co[r * spit + q] = S->cand_co[off + e]; }
+  }
+  SERIAL {
+    for (int yy = ly; yy < ly + n; yy += 4)
+      for (int xx = lx; xx < lx + n; xx += 4) { cu4 *c = cu_at(S, xx, yy); c->cbf = 0; c->luma_edges = 0; c->chroma_edges = 0; }
+    fill_cu(S, lx, ly, n, N.mode, N.mode, ilog2_dev(n) - 1, N.split_tree, cu_mtt(N.mode_type_tree, L));
+    cu_at(S, lx, ly)->cbf = (uint8_t)N.cbf;
+    mark_deblocking(S, N.x, N.y, lx, ly, n, 0, 1);
+  }
+  CTU_SYNC();
+}
+
+CTU_DEV void copy_models(uint32_t *dst, const uint32_t *src)
+{
+  PAR_FOR(i, NMODELS) dst[i] = src[i];
+  CTU_SYNC();
+}
+
+// the 64x64 CU tried with the mode of the first 32x32 CU after the four 32x32 areas are decided (combine_intra_cus, search.c:2082-2143).
+// Returns its cost in lvl[0].cost; D holds it afterwards, the split's result is in the scratch.
+template <typename PX> CTU_DEV void eval_cu64(lds<PX> *S, const job<PX> &J)
+{
+  const params &P = J.P;
+  level_state &N = S->lvl[0];
+  const int x = N.x, y = N.y;
+  scratch *W = J.W;
+  // save the split's result
+  for (int color = 0; color < 3; ++color) {
+    const int w = color ? 32 : 64, l2 = color ? 5 : 6, pit = pitch_of(color);
+    const PX *D = plane(S, color) + pit + 1;
+    PAR_FOR(e, w * w) { W->save_px[co_off(color) + e] = D[(e >> l2) * pit + (e & (w - 1))]; W->save_co[co_off(color) + e] = CTU_GLOAD(&J.coeff[co_off(color) + e]); }
+  }
+  PAR_FOR(e, 256) { W->save_cu[e] = *cu_at(S, (e & 15) * 4, (e >> 4) * 4); W->save_tree[e] = S->tree[e]; W->save_tree[256 + e] = S->mtt[e]; }
+  CTU_SYNC();
+  const int mode = cu_at(S, 0, 0)->mode, mode_chroma = cu_at(S, 0, 0)->mode_chroma;
+  SERIAL {
+    for (int e = 0; e < 256; ++e) { cu4 *c = cu_at(S, (e & 15) * 4, (e >> 4) * 4); c->cbf = 0; c->luma_edges = 0; c->chroma_edges = 0; }
+    fill_cu(S, 0, 0, 64, mode, mode_chroma, 5, N.split_tree, cu_mtt(N.mode_type_tree, 0));
+  }
+  CTU_SYNC();
+  // the models are the CU's entry models and do not adapt (search_cabac.update is 0 on this path): bits only
+  copy_models(S->cur, S->pre[0]);
+  double cost = 0;
+  for (int i = 0; i < 4; ++i) {
+    const int tx = x + (i & 1) * 32, ty = y + (i >> 1) * 32, lx = tx & 63, ly = ty & 63;
+    int cbf = recon_tu(S, J, 0, tx, ty, lx, ly, 32, mode, 0);
+    const int cu = recon_tu(S, J, 1, tx, ty, lx, ly, 32, mode_chroma, 0);
+    const int cv = recon_tu(S, J, 2, tx, ty, lx, ly, 32, mode_chroma, cu);
+    cbf |= cu << 1 | cv << 2;
+    SERIAL cu_at(S, lx, ly)->cbf = (uint8_t)cbf;
+    CTU_SYNC();
+  }
+  // every transform block's levels are needed again for the cost, in coding order: fetch them back from the coefficient array
+  for (int i = 0; i < 4; ++i) {
+    const int lx = (i & 1) * 32, ly = (i >> 1) * 32;
+    for (int color = 0; color < 3; ++color) {
+      const int c = color != 0, w = 32 >> c, l2 = c ? 4 : 5, spit = c ? LCU_C : LCU;
+      const int16_t *co = J.coeff + co_off(color) + (ly >> c) * spit + (lx >> c);
+      PAR_FOR(e, w * w) S->lv[color][e] = CTU_GLOAD(&co[(e >> l2) * spit + (e & (w - 1))]);
+    }
+    CTU_SYNC();
+    ssd_block(S, 0, lx, ly, 32, 0); ssd_block(S, 1, lx, ly, 32, 1); ssd_block(S, 2, lx, ly, 32, 2);
+    SERIAL {
+      if (i == 0) {
+        double bits = 0;
+        split_flag_bits(S, P, S->cur, 0, x, y, 0, 0, 64, 0, bits);
+        double mode_bits = 0;
+        {   // calc_mode_bits (search.c:988-1003): the luma mode on a copy of the models, the chroma mode without adaptation
+          for (int k = 0; k < NMODELS; ++k) S->post[0][k] = S->cur[k];
+          luma_mode_bits(S, S->post[0], 0, x, y, 0, 0, 64, mode, mode_bits);
+          if (mode_chroma == mode) mode_bits += m_fbits(S->cur, M_CHROMA_PRED, 0);
+          else mode_bits += 2.0 + m_fbits(S->cur, M_CHROMA_PRED, 1);
+        }
+        mode_bits += bits;
+        S->u_d0 = mode_bits * P.lambda;
+        S->u_d1 = 0;
+      }
+      S->u_d1 += tr_cost(S, P, 0, 32, cu_at(S, lx, ly)->cbf, 1, 16);
+      if (i == 3) {
+        double c2 = 0;
+        c2 += S->u_d0;
+        c2 += S->u_d1 + 0 * P.lambda;          // the sum of the four blocks + luma_bits (0) * lambda (search.c:779)
+        N.cost = c2;
+        mark_deblocking(S, x, y, 0, 0, 64, 0, 1);
+      }
+    }
+    CTU_SYNC();
+  }
+}
+// the split won after all: bring its result back
+template <typename PX> CTU_DEV void restore64(lds<PX> *S, const job<PX> &J)
+{
+  scratch *W = J.W;
+  for (int color = 0; color < 3; ++color) {
+    const int w = color ? 32 : 64, l2 = color ? 5 : 6, pit = pitch_of(color);
+    PX *D = plane(S, color) + pit + 1;
+    PAR_FOR(e, w * w) { D[(e >> l2) * pit + (e & (w - 1))] = (PX)CTU_GLOAD(&W->save_px[co_off(color) + e]); J.coeff[co_off(color) + e] = CTU_GLOAD(&W->save_co[co_off(color) + e]); }
+  }
+  PAR_FOR(e, 256) { *cu_at(S, (e & 15) * 4, (e >> 4) * 4) = W->save_cu[e]; S->tree[e] = W->save_tree[e]; S->mtt[e] = W->save_tree[256 + e]; }
+  CTU_SYNC();
+}
+
+// search_cu (search.c:1299-2221) as a depth-first loop over the quad tree of one CTU
+template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
+{
+  const params &P = J.P;
+  SERIAL {
+    level_state &R = S->lvl[0];
+    R.x = J.x; R.y = J.y; R.split_tree = 0; R.mode_type_tree = 0; R.has_chroma = 1; R.child = 0;
+  }
+  CTU_SYNC();
+  int L = 0;
+  int entering = 1;
+  double ret = 0;            // the cost a finished node hands to its parent (uniform: read from LDS after a barrier)
+  for (;;) {
+    level_state &N = S->lvl[L];
+    const int n = 64 >> L;
+    if (entering) {
+      const int x = N.x, y = N.y;
+      CTU_SYNC();            // every lane holds its copy before lane 0 may reach the parent's bookkeeping and rewrite this entry
+      if (x >= P.pic_w || y >= P.pic_h) { ret = 0; entering = 0; if (L == 0) break; --L; continue; }     // outside: nothing to code (search.c:1350)
+      copy_models(S->pre[L], S->cur);
+      const int inside = x + n <= P.pic_w && y + n <= P.pic_h;
+      // check_can_use_intra (search.c:1257-1287)
+      const int min_w = 64 >> P.depth_max;
+      const int can_intra = inside && ((L >= P.depth_min && L <= P.depth_max) || (x & ~(min_w - 1)) + min_w > P.pic_w || (y & ~(min_w - 1)) + min_w > P.pic_h);
+      if (can_intra) eval_cu(S, J, L);
+      else {
+        SERIAL { N.cost = CTU_MAX_DOUBLE; N.type = CU_NOTSET; }
+        CTU_SYNC();
+      }
+      copy_models(S->post[L], S->cur);
+      const int can_split = (N.type == CU_NOTSET || L < P.depth_max) && n > 4;
+      if (!can_split) { ret = N.cost; entering = 0; if (L == 0) break; --L; continue; }
+      // the split: its flag first (models from the CU's entry), then the pruning test of search.c:1952-1956
+      copy_models(S->cur, S->pre[L]);
+      SERIAL {
+        double split_bits = 0;
+        split_flag_bits(S, P, S->cur, 1, x, y, x & 63, y & 63, n, 1, split_bits);
+        const double factor = P.qp > 30 ? 1.1 : 1.075;
+        S->u_flag = split_bits * P.lambda + N.cost / factor > N.cost;
+        N.split_cost = split_bits * P.lambda;
+        N.child = 0;
+      }
+      CTU_SYNC();
+      if (S->u_flag) {
+        // no split tried: the CU stands (best_split_cost stays MAX_DOUBLE, search.c:2145-2169)
+        if (L > 0) copy_models(S->cur, S->post[L]);
+        ret = N.cost; entering = 0; if (L == 0) break; --L; continue;
+      }
+      if (N.type != CU_NOTSET) park(S, J, L);
+      // descend to the first child
+      SERIAL {
+        level_state &C = S->lvl[L + 1];
+        const int cond_infer = (N.mode_type_tree >> ((L - 1 > 0 ? L - 1 : 0) * 2) & 3) == 0 && n == 8;      // uvg_derive_mode_type_cond: MODE_TYPE_INFER
+        const uint32_t mode_type = cond_infer ? 2u : (N.mode_type_tree >> ((L - 1 > 0 ? L - 1 : 0) * 2) & 3);
+        C.split_tree = N.split_tree | 1u << (L * 3);
+        C.mode_type_tree = N.mode_type_tree | mode_type << (L * 2);
+        C.x = N.x; C.y = N.y; C.has_chroma = (n >> 1) == 4 ? 0 : 1;
+      }
+      CTU_SYNC();
+      ++L;
+      continue;
+    }
+    // a child of N came back with `ret`
+    SERIAL {
+      N.split_cost += ret;
+      const int k = N.child;
+      const int last = k == 3;
+      S->u_flag = (N.split_cost > N.cost) || last;       // (best_split_cost is still MAX_DOUBLE: one split type)
+      N.child = k + 1;
+      if (!S->u_flag) {
+        level_state &C = S->lvl[L + 1];
+        const int h = n >> 1, k1 = k + 1;
+        C.x = N.x + (k1 & 1) * h; C.y = N.y + (k1 >> 1) * h;
+        C.has_chroma = h == 4 ? (k1 == 3) : 1;
+        // mode_type_tree of the child: the parent's bits at the parent's depth were set when it descended, the child adds its parent's type
+        // at its own depth when it is entered (cur_cu->mode_type_tree, search.c:1387-1388) -- done below in the common path
+      }
+    }
+    CTU_SYNC();
+    if (!S->u_flag) { ++L; entering = 1; continue; }
+    // the split is complete (or was cut short): decide.  The comparison is taken by every lane BEFORE lane 0 may overwrite a cost.
+    const bool split_wins = N.split_cost < N.cost;
+    const int ntype = N.type;
+    CTU_SYNC();
+    if (L == 0 && ntype == CU_NOTSET && P.combine_intra_cus && N.x + 64 <= P.pic_w && N.y + 64 <= P.pic_h &&
+        cu_at(S, 0, 0)->type == CU_INTRA && cu_at(S, 0, 0)->log2 == 5) {
+      copy_models(S->post[4], S->cur);                   // temp_cabac: the models after the split (search.c:2093)
+      SERIAL { S->u_d0 = N.split_cost; }
+      CTU_SYNC();
+      eval_cu64(S, J);
+      // post_search_cabac = the unadapted entry models; search_cabac = temp_cabac (:2140-2141)
+      copy_models(S->cur, S->post[4]);
+      const bool split_wins64 = N.split_cost < N.cost;        // N.cost: the 64x64 CU's (eval_cu64 ends with a barrier)
+      CTU_SYNC();
+      if (split_wins64) { restore64(S, J); SERIAL N.cost = N.split_cost; CTU_SYNC(); }
+      else { SERIAL { N.type = CU_INTRA; } CTU_SYNC(); }
+      ret = N.cost;
+      break;
+    }
+    if (split_wins) {
+      SERIAL N.cost = N.split_cost;
+      CTU_SYNC();
+    } else {
+      if (L > 0) copy_models(S->cur, S->post[L]);
+      if (ntype != CU_NOTSET) unpark(S, J, L);
+    }
+    ret = N.cost;
+    if (L == 0) break;
+    --L;
+  }
+}
+
+
+// ====================================================================== the real coder's model adaptation + CTU in / out ======
+CTU_DEV int z_to_x(int z) { return (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4) | ((z >> 3) & 8); }
+
+// uvg_encode_coding_tree (encode_coding_tree.c:1365-1727) over the decided CTU: only which models see which bins matters here.
+// The quad tree is walked in z-order over the 4x4 units: a CU starts where a unit is aligned to its CU's size.
+template <typename PX> CTU_DEV void coder_pass(lds<PX> *S, const job<PX> &J)
+{
+  const params &P = J.P;
+  for (int z = 0; z < 256; ++z) {
+    const int lx = z_to_x(z) * 4, ly = z_to_x(z >> 1) * 4;
+    const int x = J.x + lx, y = J.y + ly;
+    if (x >= P.pic_w || y >= P.pic_h) continue;
+    const cu4 *c = cu_at(S, lx, ly);
+    const int n = 1 << c->log2;
+    if ((lx & (n - 1)) || (ly & (n - 1))) continue;
+    const int sep = n == 4, last4 = sep && (lx & 4) && (ly & 4);
+    const int tus = n == 64 ? 4 : 1, tn = n == 64 ? 32 : n;
+    for (int tu = 0; tu < tus; ++tu) {
+      const int tlx = lx + (tu & 1) * 32, tly = ly + (tu >> 1) * 32;
+      const cu4 *t = cu_at(S, tlx, tly);
+      // levels of this transform unit (and, for the last 4x4 CU of an 8x8 area, of the area's chroma)
+      {
+        const int16_t *co = J.coeff + tly * LCU + tlx;
+        const int l2 = ilog2_dev(tn);
+        PAR_FOR(e, tn * tn) S->lv[0][e] = CTU_GLOAD(&co[(e >> l2) * LCU + (e & (tn - 1))]);
+        if (!sep || last4) {
+          const int cw = sep ? 4 : tn >> 1, cl2 = ilog2_dev(cw);
+          const int cbx = (sep ? (tlx & ~7) : tlx) >> 1, cby = (sep ? (tly & ~7) : tly) >> 1;
+          PAR_FOR(e, cw * cw) {
+            S->lv[1][e] = CTU_GLOAD(&J.coeff[4096 + (cby + (e >> cl2)) * LCU_C + cbx + (e & (cw - 1))]);
+            S->lv[2][e] = CTU_GLOAD(&J.coeff[5120 + (cby + (e >> cl2)) * LCU_C + cbx + (e & (cw - 1))]);
+          }
+        }
+      }
+      CTU_SYNC();
+      SERIAL {
+        uint32_t *m = S->coder;
+        double dummy = 0;
+        if (tu == 0) {
+          // split flags of the enclosing quad-tree nodes that begin here, then this CU's own
+          for (int d = 0; (64 >> d) > n; ++d) {
+            const int s = 64 >> d;
+            if (!(lx & (s - 1)) && !(ly & (s - 1))) split_flag_bits(S, P, m, 1, x, y, lx, ly, s, 1, dummy);
+          }
+          split_flag_bits(S, P, m, 1, x, y, lx, ly, n, 0, dummy);
+          luma_mode_bits(S, m, 1, x, y, lx, ly, n, c->mode, dummy);
+          if (!sep) chroma_mode_bits(m, 1, c->mode_chroma, c->mode, dummy);
+        }
+        const int cb_y = t->cbf & 1, cb_u = (t->cbf >> 1) & 1, cb_v = (t->cbf >> 2) & 1;
+        if (!sep) {
+          m_code(m, 1, M_CBF_CB + 0, cb_u, dummy);
+          m_code(m, 1, M_CBF_CR + cb_u, cb_v, dummy);
+        }
+        m_code(m, 1, M_CBF_LUMA + 0, cb_y, dummy);      // luma_cbf_ctx stays 0: one transform unit per CU, or a CU that is not a TU
+        if (cb_y) (void)coeff_bits_serial(m, S->scan + scan_base(ilog2_dev(tn)), S->lv[0], tn, 0);
+        if (!sep) {
+          if (cb_u) (void)coeff_bits_serial(m, S->scan + scan_base(ilog2_dev(tn >> 1)), S->lv[1], tn >> 1, 1);
+          if (cb_v) (void)coeff_bits_serial(m, S->scan + scan_base(ilog2_dev(tn >> 1)), S->lv[2], tn >> 1, 2);
+        } else if (last4) {
+          // the area's chroma after its last luma CU: mode (the co-located luma CU is this one), cbfs of the area's first entry, levels
+          const cu4 *a = cu_at(S, lx & ~7, ly & ~7);
+          const int au = (a->cbf >> 1) & 1, av = (a->cbf >> 2) & 1;
+          chroma_mode_bits(m, 1, c->mode_chroma, c->mode, dummy);
+          m_code(m, 1, M_CBF_CB + 0, au, dummy);
+          m_code(m, 1, M_CBF_CR + au, av, dummy);
+          if (au) (void)coeff_bits_serial(m, S->scan + scan_base(2), S->lv[1], 4, 1);
+          if (av) (void)coeff_bits_serial(m, S->scan + scan_base(2), S->lv[2], 4, 2);
+        }
+      }
+      CTU_SYNC();
+    }
+  }
+}
+
+// init_lcu_t (search.c:2230-2330): neighbouring side information and samples, the source samples, the models
+template <typename PX> CTU_DEV void load_ctu(lds<PX> *S, const job<PX> &J)
+{
+  const params &P = J.P;
+  const int x = J.x, y = J.y, W = P.pic_w, H = P.pic_h;
+  PAR_FOR(i, 17 * 17) { cu4 z = {0, 0, 0, 0, 0, 0, 0, 0}; S->cu[i] = z; }
+  PAR_FOR(i, 256) { S->tree[i] = 0; S->mtt[i] = 0; }
+  CTU_SYNC();
+  PAR_FOR(i, 33) {
+    // i = 0: the corner, 1..16 the row above, 17..32 the column to the left
+    int ax, ay, ok;
+    if (i == 0) { ax = x - 4; ay = y - 4; ok = x > 0 && y > 0; }
+    else if (i <= 16) { ax = x + (i - 1) * 4; ay = y - 4; ok = y > 0 && ax < W; }
+    else { ax = x - 4; ay = y + (i - 17) * 4; ok = x > 0 && ay < H; }
+    if (ok) {
+      const uvghip_scu_t *s = &J.cu_tab[(ay >> 2) * J.cu_stride + (ax >> 2)];
+      cu4 *c = cu_at(S, ax - x, ay - y);
+      c->type = s->type; c->log2 = s->log2_width; c->cbf = s->cbf; c->log2_c = s->log2_chroma_width;
+      c->mode = (int8_t)(s->mv[0][0] & 0xff); c->mode_chroma = (int8_t)((s->mv[0][0] >> 8) & 0xff);
+    }
+  }
+  for (int color = 0; color < 3; ++color) {
+    const int c = color != 0, w = 64 >> c, pit = pitch_of(color);
+    PX *D = plane(S, color);
+    const PX *rec = color == 0 ? J.rec_y : (color == 1 ? J.rec_u : J.rec_v);
+    const int rs = c ? J.rec_stride_c : J.rec_stride;
+    const int px = x >> c, py = y >> c, pw = W >> c, ph = H >> c;
+    PAR_FOR(i, 2 * w + 1) {
+      // i = 0 corner, 1..w the row above, w + 1..2w the column to the left
+      if (i == 0) { if (px > 0 && py > 0) D[0] = rec[(py - 1) * rs + px - 1]; }
+      else if (i <= w) { const int q = px + i - 1; if (py > 0 && q < pw) D[i] = rec[(py - 1) * rs + q]; }
+      else { const int r = py + i - w - 1; if (px > 0 && r < ph) D[(i - w) * pit] = rec[r * rs + px - 1]; }
+    }
+    const PX *src = color == 0 ? J.src_y : (color == 1 ? J.src_u : J.src_v);
+    const int ss = c ? J.src_stride_c : J.src_stride;
+    PX *Sp = color == 0 ? S->Sy : (color == 1 ? S->Su : S->Sv);
+    PAR_FOR(e, w * w) {
+      const int r = e / w, q = e - r * w;
+      Sp[e] = (py + r < ph && px + q < pw) ? src[(py + r) * ss + px + q] : (PX)0;
+    }
+  }
+  PAR_FOR(i, NMODELS) {
+    if (J.models_in) S->coder[i] = J.models_in[i];
+    else models_init_one(S->coder, i, P.qp, 2);
+  }
+  CTU_SYNC();
+  PAR_FOR(i, NMODELS) {
+    const uint32_t v = S->coder[i];
+    S->cur[i] = v;
+    J.models_out[i] = v;
+    if (i < 244) S->rdoq_state[i] = (uint8_t)m_state(S->coder, i);
+  }
+  CTU_SYNC();
+}
+
+// copy_lcu_to_cu_data (search.c:2331-2377) + the models of the three checkpoints
+template <typename PX> CTU_DEV void store_ctu(lds<PX> *S, const job<PX> &J)
+{
+  const params &P = J.P;
+  const int x = J.x, y = J.y, W = P.pic_w, H = P.pic_h;
+  for (int color = 0; color < 3; ++color) {
+    const int c = color != 0, w = 64 >> c, pit = pitch_of(color);
+    const PX *D = plane(S, color) + pit + 1;
+    PX *rec = color == 0 ? J.rec_y : (color == 1 ? J.rec_u : J.rec_v);
+    const int rs = c ? J.rec_stride_c : J.rec_stride;
+    const int px = x >> c, py = y >> c, pw = W >> c, ph = H >> c;
+    PAR_FOR(e, w * w) {
+      const int r = e / w, q = e - r * w;
+      if (py + r < ph && px + q < pw) rec[(py + r) * rs + px + q] = D[r * pit + q];
+    }
+  }
+  PAR_FOR(e, 256) {
+    const int lx = (e & 15) * 4, ly = (e >> 4) * 4;
+    if (x + lx < W && y + ly < H) {
+      const cu4 *c = cu_at(S, lx, ly);
+      uvghip_scu_t s;
+      memset(&s, 0, sizeof s);
+      s.luma_edges = c->luma_edges; s.chroma_edges = c->chroma_edges; s.type = c->type; s.cbf = c->cbf; s.qp = (int8_t)P.qp;
+      s.log2_width = s.log2_height = c->log2; s.log2_chroma_width = s.log2_chroma_height = c->log2_c;
+      s.mv[0][0] = (int32_t)((uint32_t)(uint8_t)c->mode | (uint32_t)(uint8_t)c->mode_chroma << 8);
+      s.mv[0][1] = (int32_t)S->tree[e];
+      s.mv[1][0] = (int32_t)S->mtt[e];
+      J.cu_tab[((y + ly) >> 2) * J.cu_stride + ((x + lx) >> 2)] = s;
+    }
+  }
+}
+
+// one CTU, start to finish
+template <typename PX> CTU_DEV void run_ctu(lds<PX> *S, const job<PX> &J)
+{
+  build_scans(S);
+  load_ctu(S, J);
+  // the CTU's coefficient array starts empty (lcu->coeff = calloc, encoderstate.c:752)
+  PAR_FOR(e, 6144) J.coeff[e] = 0;
+  CTU_SYNC();
+  search_ctu(S, J);
+  PAR_FOR(i, NMODELS) J.models_out[NMODELS + i] = S->cur[i];
+  coder_pass(S, J);
+  PAR_FOR(i, NMODELS) J.models_out[2 * NMODELS + i] = S->coder[i];
+  store_ctu(S, J);
+  CTU_SYNC();
+}
+
+}  // namespace ctu

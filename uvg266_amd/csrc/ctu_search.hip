@@ -1,0 +1,153 @@
+// uvghip_ctu_search_intra: the closed-loop intra search of whole pictures on the device (include/uvg266_hip.h, part 4).
+// The per-CTU algorithm is csrc/ctu_core.h; this file is the launch: one workgroup per CTU, handed out in an order in which every
+// CTU comes after its left and upper neighbour (the WPP dependencies, src/encoderstate.c:1160-1167), pictures interleaved so that
+// the wavefronts of many pictures fill the device together.  A workgroup takes the next CTU of that order (a ticket from an atomic
+// counter -- so a waiting workgroup only ever waits for CTUs that are already running or done), spins on its neighbours' "done"
+// flags, runs the CTU, publishes its outputs (device-scope release) and raises its own flag.
+#include "uvghip_common.h"
+#include "ctu_core.h"
+#include <vector>
+#include <mutex>
+#include <cstring>
+
+namespace {
+
+struct pic_dev {
+  const void *src_y, *src_u, *src_v;
+  void *rec_y, *rec_u, *rec_v;
+  uvghip_scu_t *cu;
+  int16_t *coeff;
+  uint32_t *models;
+  int src_stride, src_stride_c, rec_stride, rec_stride_c, cu_stride, pad;
+};
+
+struct launch_args {
+  ctu::params P;
+  const pic_dev *pics;
+  const int32_t *order;       // [ticket] = pic << 16 | cy << 8 | cx
+  int32_t *ticket;            // the counter
+  int32_t *done;              // [pic * ctus + cy * wc + cx]
+  ctu::scratch *scratch;      // per ticket
+  int wc, hc, n_ctus;
+};
+
+template <typename PX>
+__global__ void __launch_bounds__(256) ctu_search_kernel(launch_args A)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  ctu::lds<PX> *S = reinterpret_cast<ctu::lds<PX> *>(smem);
+  __shared__ int s_ticket;
+  if (threadIdx.x == 0) s_ticket = atomicAdd(A.ticket, 1);
+  __syncthreads();
+  const int ticket = s_ticket;
+  const int32_t o = A.order[ticket];
+  const int pic = o >> 16, cy = (o >> 8) & 0xff, cx = o & 0xff;
+  const int ctus = A.wc * A.hc, k = cy * A.wc + cx;
+  int32_t *done = A.done + (size_t)pic * ctus;
+  if (threadIdx.x == 0) {
+    if (cx > 0) while (__hip_atomic_load(&done[k - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+    if (cy > 0) while (__hip_atomic_load(&done[k - A.wc], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+  }
+  __syncthreads();
+  __threadfence();          // every lane's later loads come after the neighbours' release
+  const pic_dev &D = A.pics[pic];
+  ctu::job<PX> J;
+  J.P = A.P;
+  J.src_y = (const PX *)D.src_y; J.src_u = (const PX *)D.src_u; J.src_v = (const PX *)D.src_v;
+  J.src_stride = D.src_stride; J.src_stride_c = D.src_stride_c;
+  J.rec_y = (PX *)D.rec_y; J.rec_u = (PX *)D.rec_u; J.rec_v = (PX *)D.rec_v;
+  J.rec_stride = D.rec_stride; J.rec_stride_c = D.rec_stride_c;
+  J.cu_tab = D.cu; J.cu_stride = D.cu_stride;
+  J.coeff = D.coeff + (size_t)k * 6144;
+  J.models_out = D.models + (size_t)k * 3 * ctu::NMODELS;
+  J.models_in = cx > 0 ? D.models + ((size_t)(k - 1) * 3 + 2) * ctu::NMODELS
+                       : (cy > 0 ? D.models + ((size_t)((cy - 1) * A.wc) * 3 + 2) * ctu::NMODELS : nullptr);
+  J.W = A.scratch + ticket;
+  J.x = cx * 64; J.y = cy * 64;
+  ctu::run_ctu(S, J);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&done[k], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct ws_layout { size_t ticket, done, order, pics, scratch, total; };
+ws_layout layout(int n_pictures, int pic_w, int pic_h)
+{
+  const size_t ctus = (size_t)((pic_w + 63) / 64) * ((pic_h + 63) / 64), total = ctus * n_pictures;
+  ws_layout L;
+  L.ticket = 0;
+  L.done = 256;
+  L.order = align_up(L.done + total * 4, 256);
+  L.pics = align_up(L.order + total * 4, 256);
+  L.scratch = align_up(L.pics + (size_t)n_pictures * sizeof(pic_dev), 256);
+  L.total = L.scratch + total * sizeof(ctu::scratch);
+  return L;
+}
+
+}  // namespace
+
+extern "C" size_t uvghip_ctu_search_workspace_bytes(int n_pictures, int pic_w, int pic_h)
+{
+  if (n_pictures <= 0 || pic_w <= 0 || pic_h <= 0) return 0;
+  return layout(n_pictures, pic_w, pic_h).total;
+}
+
+extern "C" int uvghip_ctu_search_intra(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, int n_pictures,
+                                       void *workspace, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
+  static_assert(sizeof(uvghip_ctu_params_t) == sizeof(ctu::params), "uvghip_ctu_params_t mirrors ctu::params");
+  if (!params || !pictures || n_pictures <= 0 || !workspace) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const uvghip_ctu_params_t &p = *params;
+  if (p.pic_w <= 0 || p.pic_h <= 0 || (p.pic_w & 7) || (p.pic_h & 7) || p.pic_w > 64 * 255 || p.pic_h > 64 * 255 || n_pictures > 32767)
+    return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_intra: picture size");
+  if (p.wpp != 1 || p.depth_min < 0 || p.depth_max > 4 || p.depth_min > p.depth_max || p.rough_levels < 2 || p.rough_levels > 3 || p.qp < 0 || p.qp > 63 ||
+      p.qp_c < 0 || p.qp_c > 63 || !(p.lambda > 0))
+    return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_intra: configuration outside the supported subset");
+  const int wc = (p.pic_w + 63) / 64, hc = (p.pic_h + 63) / 64, ctus = wc * hc, total = ctus * n_pictures;
+  const ws_layout L = layout(n_pictures, p.pic_w, p.pic_h);
+  unsigned char *ws = static_cast<unsigned char *>(workspace);
+  hipStream_t st = uvghip_stream(stream);
+  // hand-out order: wavefront index first, pictures interleaved inside a wavefront
+  std::vector<int32_t> order;
+  order.reserve(total);
+  for (int d = 0; d < wc + hc - 1; ++d)
+    for (int pic = 0; pic < n_pictures; ++pic)
+      for (int cy = 0; cy < hc; ++cy) {
+        const int cx = d - cy;
+        if (cx >= 0 && cx < wc) order.push_back(pic << 16 | cy << 8 | cx);
+      }
+  std::vector<pic_dev> pics(n_pictures);
+  for (int i = 0; i < n_pictures; ++i) {
+    const uvghip_ctu_picture_t &q = pictures[i];
+    if (!q.src_y || !q.src_u || !q.src_v || !q.rec_y || !q.rec_u || !q.rec_v || !q.cu || !q.coeff || !q.models || q.cu_stride < wc * 16)
+      return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_intra: picture descriptor");
+    pics[i] = pic_dev{q.src_y, q.src_u, q.src_v, q.rec_y, q.rec_u, q.rec_v, q.cu, q.coeff, q.models,
+                      q.src_stride, q.src_stride_c, q.rec_stride, q.rec_stride_c, q.cu_stride, 0};
+  }
+  UVGHIP_TRY(hipMemsetAsync(ws, 0, L.order, st));
+  UVGHIP_TRY(hipMemcpyAsync(ws + L.order, order.data(), (size_t)total * 4, hipMemcpyHostToDevice, st));
+  UVGHIP_TRY(hipMemcpyAsync(ws + L.pics, pics.data(), (size_t)n_pictures * sizeof(pic_dev), hipMemcpyHostToDevice, st));
+  UVGHIP_TRY(hipStreamSynchronize(st));      // the host vectors go out of scope
+  launch_args A;
+  memcpy(&A.P, params, sizeof A.P);
+  A.pics = reinterpret_cast<const pic_dev *>(ws + L.pics);
+  A.order = reinterpret_cast<const int32_t *>(ws + L.order);
+  A.ticket = reinterpret_cast<int32_t *>(ws + L.ticket);
+  A.done = reinterpret_cast<int32_t *>(ws + L.done);
+  A.scratch = reinterpret_cast<ctu::scratch *>(ws + L.scratch);
+  A.wc = wc; A.hc = hc; A.n_ctus = total;
+  if (bitdepth == 8) {
+    const size_t lds = sizeof(ctu::lds<uint8_t>);
+    UVGHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ctu_search_kernel<uint8_t>, dim3(total), dim3(256), lds, st, A);
+  } else {
+    const size_t lds = sizeof(ctu::lds<uint16_t>);
+    UVGHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ctu_search_kernel<uint16_t>, dim3(total), dim3(256), lds, st, A);
+  }
+  UVGHIP_CHECK_LAUNCH();
+}

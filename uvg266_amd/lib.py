@@ -57,6 +57,21 @@ class CuView(ctypes.Structure):
                                                                                           ("reserved", ctypes.c_int8 * 3)]
 
 
+class CtuParams(ctypes.Structure):
+    """uvghip_ctu_params_t: what the closed-loop CTU search reads from encoder_state_t / encoder_control_t."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("pic_w", "pic_h", "qp", "qp_c", "depth_min", "depth_max", "wpp", "combine_intra_cus", "rough_levels",
+                                                "reserved")] + \
+               [(n, ctypes.c_double) for n in ("lambda_", "lambda_sqrt", "c_lambda", "chroma_weight_u", "chroma_weight_v", "c_lambda_tu")]
+
+
+class CtuPicture(ctypes.Structure):
+    """uvghip_ctu_picture_t."""
+    _fields_ = [("src_y", ctypes.c_void_p), ("src_u", ctypes.c_void_p), ("src_v", ctypes.c_void_p), ("src_stride", ctypes.c_int32),
+                ("src_stride_c", ctypes.c_int32), ("rec_y", ctypes.c_void_p), ("rec_u", ctypes.c_void_p), ("rec_v", ctypes.c_void_p),
+                ("rec_stride", ctypes.c_int32), ("rec_stride_c", ctypes.c_int32), ("cu", ctypes.c_void_p), ("cu_stride", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("coeff", ctypes.c_void_p), ("models", ctypes.c_void_p)]
+
+
 _lib = None
 _inited_device = None
 
@@ -132,6 +147,8 @@ SIGNATURES = {
     "uvghip_deblock_band": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp,
                                     c_int, c_int, c_int, c_vp]),
     "uvghip_alf_classify_band": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp]),
+    "uvghip_ctu_search_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
+    "uvghip_ctu_search_intra": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
     "uvghip_comm_unique_id": (c_int, [c_vp]),
     "uvghip_comm_create": (c_int, [c_vp, c_int, c_int, c_vp]),
     "uvghip_comm_destroy": (c_int, [c_vp]),
