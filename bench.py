@@ -1,19 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the uvg266 per-CTU hot-path kernels on MI355X.
+"""bench.py -- uvg266's per-CTU hot path on MI355X: closed-loop all-intra encode rate and the kernels under it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one synthetic 1920x1080 8-bit yuv420p picture (BASELINE.json configs[1]:
-all-intra, --preset medium) that is already resident in HBM: luma rough search / predict / TU round trip for four block
-sizes, chroma predict / TU round trip with the derived mode, deblocking, SAO (Y, U, V) -- uvg266_amd/pipeline.py lists the
-launches, DESIGN.md "Measurement" the accounting.  Serial RDOQ / CABAC are outside the hot-path scope, so
-this is hot-path frames/s, not .266 frames/s.
+One "step" = one synthetic 1920x1080 8-bit yuv420p picture (BASELINE.json configs[1]: -p 1 --preset medium, QP 22), already
+resident in HBM, taken through the CLOSED loop the reference runs per CTU: uvghip_ctu_search_intra (one workgroup per CTU on
+the WPP wavefront: rough intra search with the reference's candidate schedule, reconstruction from the reconstructed
+neighbours, RDOQ, CABAC bit costs on evolving models, split / no-split RD decisions over depths 1-4 plus the 64x64 candidate,
+the coder's model adaptation) -> deblocking on the side information the search wrote -> SAO statistics / offsets / apply.
+The decisions, levels and reconstruction are bit-identical with the reference encoder's (tests/golden/ref_ctu*).  Pictures of
+an all-intra encode are independent: K pictures are issued `--in-flight` at a time (the reference's --owf), their wavefronts
+interleaved on the device.  Writing the bitstream itself (the arithmetic coder) is outside the hot-path scope.
 
---gpus N > 1 (default --shard rows): every picture is split over the N ranks by CTU rows (uvghip_band_plan), halo rows
-and reconstructed bands travel over RCCL ("scaling": "strong").  --shard frames: ranks take whole pictures, no data-path
-collective ("weak").  The 3840x2160 10-bit --alf full workload (configs[3]) is timed in the same run and reported under
-"extra_workloads".
+`value` = pictures/s of that closed loop.  The open-loop throughput of the same block kernels (every block size of every
+picture, no decisions: the previous rounds' headline) is reported under "open_loop", the 2160p 10-bit ALF workload under
+"extra_workloads".  --gpus N > 1: ranks take whole pictures (no data-path collective; "weak"); the CTU-row sharded filter
+chain over RCCL (uvghip_band_plan) is timed in the same run on 2160p10alf and reported under "row_sharded_rccl".
 """
 import argparse
 import json
@@ -375,6 +378,104 @@ def coeff_cost_probe(L, fr, reps=5):
                     "times over, once per block size), synthetic adapted context models; one lane per block"}
 
 
+def ctu_search_bytes(W, H, depth):
+    """Algorithmic bytes of one picture through uvghip_ctu_search_intra (SURVEY.md 8(d) style, b = bytes per sample): the source read
+    once (1.5 W H b), the reconstruction written once (1.5 W H b), the levels written once (1.5 W H x 2), the side information
+    (32 B per 4x4) and the three model checkpoints per CTU."""
+    b = 1 if depth == 8 else 2
+    ctus = ((W + 63) // 64) * ((H + 63) // 64)
+    return int(1.5 * W * H * b * 2 + 1.5 * W * H * 2 + (W // 4) * (H // 4) * 32 + ctus * 3 * 257 * 4)
+
+
+class ClosedLoop:
+    """K pictures through search -> deblock -> SAO, `in_flight` pictures per uvghip_ctu_search_intra launch."""
+
+    def __init__(self, wl, first_t, in_flight, device, step=1):
+        self.W, self.H, self.depth = wl["W"], wl["H"], wl["depth"]
+        self.P = api.ctu_params(self.W, self.H, QP)
+        self.host = [layout.synthetic_yuv420(self.W, self.H, first_t + k * step, self.depth) for k in range(in_flight)]
+        src = [tuple(torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in yuv) for yuv in self.host]
+        self.cs = api.CtuSearch(self.P, src)
+        self.src = src
+        self.rects = [torch.from_numpy(layout.ctu_rects(self.W >> c, self.H >> c, 64 >> c)).to(device) for c in (0, 1)]
+        self.out = [tuple(torch.empty_like(p) for p in s) for s in src]
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        self.search_ms, self.launches = 0.0, 0
+
+    def issue(self, timed=True):
+        cs = self.cs
+        if timed:
+            self.ev[0].record()
+        cs.run()
+        if timed:
+            self.ev[1].record()
+        for i in range(cs.n):
+            ry, ru, rv = cs.rec[i]
+            api.deblock_frame(ry, ru, rv, cs.cu[i].view(cs.cu[i].shape[0], -1), self.W, self.H, frame_qp=QP)
+            for c, (o, r, d) in enumerate(zip(self.src[i], cs.rec[i], self.out[i])):
+                rects = self.rects[0 if c == 0 else 1]
+                edge, _ = api.sao_stats_batch(o, r, rects)
+                api.sao_apply_batch(r, d, rects, api.sao_edge_offsets_batch(edge))
+        if timed:
+            torch.cuda.synchronize()
+            self.search_ms += self.ev[0].elapsed_time(self.ev[1]); self.launches += 1
+
+
+def closed_loop(wl, steps, warmup, in_flight, device, rank, world, dist):
+    F = max(1, min(in_flight, steps))
+    while steps % F:
+        F -= 1
+    cl = ClosedLoop(wl, rank * F, F, device)
+    for _ in range(max(1, (warmup + F - 1) // F) if warmup > 0 else 0):
+        cl.issue(False)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps // F):
+        cl.issue(True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return cl, F, elapsed
+
+
+def cpu_baseline_search(wl, seconds=12.0):
+    """The same closed loop (search + coder model adaptation; no filters) by the oracle -- the C restatement of the reference's
+    uvg_search_lcu / uvg_encode_coding_tree path that reproduces the reference-run goldens -- on the host cores: whole pictures in
+    parallel threads (pictures are independent; inside a picture the CTUs are a dependency chain), repeated for about `seconds`."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as Hh
+    from concurrent.futures import ThreadPoolExecutor
+    orc = Hh.load_oracle()
+    W, H, depth = wl["W"], wl["H"], wl["depth"]
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    threads = max(1, min(cores, 32))
+    prm = Hh.search_params(W, H, QP)
+    pics = [layout.synthetic_yuv420(W, H, t, depth) for t in range(threads)]
+    done = 0
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        while done == 0 or time.perf_counter() - t0 < seconds:
+            list(ex.map(lambda yuv: Hh.oracle_search_picture(orc, depth, prm, *yuv)["rec_y"][0, 0], pics))
+            done += threads
+    dt = time.perf_counter() - t0
+    return {"value": round(done / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{done} whole {W}x{H} pictures, {threads} at a time on {threads} of {cores} host threads ({dt:.1f} s): the closed-loop "
+                      "CTU search + coder model adaptation of the step (no deblocking / SAO), oracle C -O2 single-threaded per picture.  "
+                      "BASELINE.md has the reference's own full 1080p medium encode at 2.2 fps on 8 vCPU (AVX2)"}
+
+
 def measure(args, wl_name, L, device, rank, local_rank, world, dist, transport, steps, warmup, n_resident, want_tables):
     wl = WORKLOADS[wl_name]
     shard_rows = world > 1 and args.shard == "rows"
@@ -465,25 +566,26 @@ def kernel_table(fr, totals, pictures, group):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--in-flight", type=int, default=60, help="pictures per uvghip_ctu_search_intra launch (the reference's --owf)")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="the timed region is repeated (whole multiples of --steps) until it lasts this long")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--serial", action="store_true", help="one stream: no overlap between pictures")
-    ap.add_argument("--no-graphs", action="store_true", help="issue every launch eagerly instead of replaying hipGraph segments")
-    ap.add_argument("--resident", type=int, default=0, help="pictures resident per workload (0 = 4 for 1080p8, 2 for 2160p10alf)")
-    ap.add_argument("--group", type=int, default=10, help="pictures per group: plane kernels run per picture, RDOQ once per block shape over the group")
-    ap.add_argument("--streams", type=int, default=4, help="pictures in flight: consecutive steps go to consecutive streams")
-    ap.add_argument("--profile-steps", type=int, default=4, help="untimed, fully instrumented steps for the per-kernel table")
-    ap.add_argument("--shard", choices=("rows", "frames"), default="frames",
-                    help="--gpus N > 1: frames = whole pictures per rank, no data-path collective (weak scaling; pictures of an "
-                         "all-intra encode are independent units: the default); rows = every picture split over the ranks by CTU rows "
-                         "with RCCL halo exchanges, all-reduce of the ALF covariances and an all-to-all of the reconstructed bands "
-                         "(strong scaling: latency of ONE picture)")
+    ap.add_argument("--no-open-loop", action="store_true", help="skip the open-loop kernel-path measurement (previous rounds' headline)")
+    ap.add_argument("--open-loop-steps", type=int, default=40)
+    ap.add_argument("--serial", action="store_true", help="open loop: one stream, no overlap between pictures")
+    ap.add_argument("--no-graphs", action="store_true", help="open loop: issue every launch eagerly instead of replaying hipGraph segments")
+    ap.add_argument("--resident", type=int, default=0)
+    ap.add_argument("--group", type=int, default=10, help="open loop: pictures per group")
+    ap.add_argument("--streams", type=int, default=4, help="open loop: groups in flight")
+    ap.add_argument("--profile-steps", type=int, default=4, help="open loop: untimed, fully instrumented steps for the per-kernel table")
+    ap.add_argument("--shard", choices=("rows", "frames"), default="rows",
+                    help="--gpus N > 1, open-loop / filter chain: rows = every picture split over the ranks by CTU rows with RCCL halo "
+                         "exchanges (the secondary line \"row_sharded_rccl\"); the closed loop always shards whole pictures")
     ap.add_argument("--no-gather", action="store_true", help="--shard rows: skip the all-to-all of reconstructed bands")
     ap.add_argument("--workload", choices=("1080p8", "2160p10alf"), default="1080p8",
-                    help="1080p8 = BASELINE.json configs[1] (the judged line); 2160p10alf = configs[3]")
-    ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed-loop (dependency-bound) probe")
-    ap.add_argument("--no-extra", action="store_true", help="do not also time the 2160p10alf workload (extra_workloads)")
+                    help="1080p8 = BASELINE.json configs[1] (the judged line); 2160p10alf = configs[3] geometry")
+    ap.add_argument("--no-extra", action="store_true", help="do not also time the 2160p 10-bit closed loop (extra_workloads)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -499,109 +601,94 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
     L = lib.init(local_rank)
+
+    wl_name = args.workload
+    wl = WORKLOADS[wl_name]
+    # ---- the judged line: closed loop, K pictures per rank ----
+    steps = args.steps
+    cl, F, elapsed = closed_loop(wl, steps, args.warmup, args.in_flight, device, rank, world, dist)
+    reps = 1
+    while elapsed < args.min_seconds and reps < 64:          # bench hygiene: never report a timed region of a few milliseconds
+        more = closed_loop(wl, steps, 0, args.in_flight, device, rank, world, dist)
+        elapsed += more[2]; cl.search_ms += more[0].search_ms; cl.launches += more[0].launches; reps += 1
+        del more
+    pics = steps * reps * world
+    fps = pics / elapsed
+    extra = None
+    if not args.no_extra and wl_name == "1080p8":
+        ewl = WORKLOADS["2160p10alf"]
+        ek = max(8, min(steps, 24))
+        ecl, eF, eel = closed_loop(ewl, ek, 0, args.in_flight, device, rank, world, dist)
+        extra = {"value": round(ek * world / eel, 3), "unit": "frames/s", "steps": ek, "ms_per_step": round(1e3 * eel / ek, 2),
+                 "mpixels_per_s": round(ek * world / eel * ewl["W"] * ewl["H"] / 1e6, 1), "pictures_in_flight": eF,
+                 "search_launch_ms": round(ecl.search_ms / max(1, ecl.launches), 2),
+                 "workload": "3840x2160 10-bit yuv420p, QP 22: the same closed loop (search -> deblock -> SAO; ALF of configs[3] is in the open-loop chain only)"}
+        del ecl
+    open_loop = None
+    if not args.no_open_loop and world == 1:
+        ol_steps = (max(args.group, args.open_loop_steps) + args.group - 1) // args.group * args.group
+        r = measure(args, wl_name, L, device, rank, local_rank, world, None, None, ol_steps, min(args.warmup, 4), args.resident or 2, True)
+        fr = r["frames"][0]
+        per_kernel, tot_ms = kernel_table(fr, r["prof"], r["prof_pics"], r["group"])
+        top = sorted(per_kernel.items(), key=lambda kv: -kv[1]["per_step_ms"])[:12]
+        open_loop = {"value": round(r["fps"], 2), "unit": "frames/s", "steps": ol_steps, "kernel_sum_ms": round(tot_ms, 4), "kernels_top": dict(top),
+                     "workload": workload_text(r["wl"], "frames", 1),
+                     "note": "throughput of the batched block kernels with open-loop references and no RD decision: every picture is coded once per "
+                             "block size (four times over); NOT an encode rate -- kept for continuity with rounds 1-2"}
+    row_sharded = None
     if world > 1 and args.shard == "rows":
         def bootstrap(raw):                  # the 128-byte RCCL unique id travels over the launcher's process group
             box = [raw]
             dist.broadcast_object_list(box, src=0)
             return box[0]
         transport = bands.RcclTransport(rank, world, bootstrap)
-
-    wl_name = args.workload
-    n_res = args.resident or 2                      # resident groups
-    r = measure(args, wl_name, L, device, rank, local_rank, world, dist, transport, args.steps, args.warmup, n_res, True)
-    extra = None
-    if not args.no_extra and wl_name == "1080p8":
-        ex_steps = max(8, min(args.steps, 40))
-        ex_steps = (ex_steps + args.group - 1) // args.group * args.group
-        extra = measure(args, "2160p10alf", L, device, rank, local_rank, world, dist, transport, ex_steps, min(args.warmup, 4), 2, True)
-        extra["steps"] = ex_steps
+        rs_steps = (max(args.group, 20) + args.group - 1) // args.group * args.group
+        r = measure(args, "2160p10alf", L, device, rank, local_rank, world, dist, transport, rs_steps, 2, 2, False)
+        cb = r["frames"][0].comm_bytes()
+        row_sharded = {"value": round(r["fps"], 2), "unit": "frames/s", "rccl_ranks": world, "scaling": "strong", "steps": rs_steps,
+                       "workload": workload_text(r["wl"], "rows", world),
+                       "comm_bytes_per_step_rank0": {k: {"sent": v[0], "received": v[1]} for k, v in cb.items()},
+                       "note": "open-loop block kernels + in-loop filter chain of 2160p10alf with every picture split over the ranks by CTU rows: "
+                               "halo rows and reconstructed bands over RCCL (grouped ncclSend/ncclRecv, ncclAllReduce of the ALF covariances)"}
 
     if rank == 0:
-        fr, wl = r["frames"][0], r["wl"]
-        per_kernel, tot_ms = kernel_table(fr, r["prof"], r["prof_pics"], r["group"])
-        live, _ = kernel_table(fr, r["live"], args.steps, r["group"])
-        fps = r["fps"]
-        strong = r["shard_rows"]
+        launch_ms = cl.search_ms / max(1, cl.launches)
+        byts = ctu_search_bytes(wl["W"], wl["H"], wl["depth"]) * F
+        gbs = byts / (launch_ms * 1e-3) / 1e9
+        wc, hc = (wl["W"] + 63) // 64, (wl["H"] + 63) // 64
         out = {
-            "metric": f"hot-path fps ({wl['H']}p all-intra medium kernel path; Mpixels/s in config)",
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * r["elapsed"] / args.steps, 3), "higher_is_better": True,
-            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8" if wl["depth"] == 8 else "u16",
-            "data": "synthetic",
-            "config": {"workload": workload_text(wl, args.shard, world), "mpixels_per_s": round(fps * wl["W"] * wl["H"] / 1e6, 1), "qp": QP,
-                       "parallelism": (f"CTU rows of every picture over {world} ranks (uvghip_band_plan), RCCL halo exchange + band gather"
-                                       if strong else f"frames sharded over {world} rank(s), no data-path collective"),
-                       "streams": 1 if args.serial else args.streams, "hipgraph": not args.no_graphs,
-                       "pictures_per_group": r["group"],
-                       "note": "steps are pictures; they are issued in groups of pictures_per_group (frame-parallel operation, uvg266 --owf): "
-                               "block-list kernels (search, predict, transforms, RDOQ) and SAO once per block shape over the group, deblocking / ALF per picture"},
+            "metric": f"encoded fps ({wl['H']}p all-intra --preset medium closed loop: CTU search with the reference's RD decisions -> deblock -> SAO; Mpixels/s in config)",
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / (steps * reps), 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8" if wl["depth"] == 8 else "u16", "data": "synthetic",
+            "config": {"workload": f"{wl['W']}x{wl['H']} {wl['depth']}-bit yuv420p, -p 1 --preset medium at QP {QP} (BASELINE.json configs[1]): per picture "
+                                   "uvghip_ctu_search_intra (closed-loop CTU search bit-identical with the reference: partition, modes, levels, "
+                                   "reconstruction, CABAC models) -> uvghip_deblock_frame on the search's side information -> SAO statistics / "
+                                   "edge offsets / apply (Y, U, V); the arithmetic coder is out of the hot-path scope",
+                       "mpixels_per_s": round(fps * wl["W"] * wl["H"] / 1e6, 2), "qp": QP, "pictures_in_flight": F,
+                       "timed_region_s": round(elapsed, 3), "timed_region_repeats": reps,
+                       "ctus_per_picture": wc * hc, "wavefront_steps_per_picture": wc + hc - 1,
+                       "parallelism": f"whole pictures over {world} rank(s) (all-intra pictures are independent), {F} pictures in flight per launch; "
+                                      "inside a picture one workgroup per CTU on the WPP wavefront",
+                       "note": "SAO statistics run on the fully deblocked picture (the reference takes them on a per-CTU partially deblocked "
+                               "snapshot, sao.c:641-668): kernels exact, plan not yet the reference's"},
+            "roofline": {"bound": "hbm", "kernel": "ctu_search_kernel", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 6), "traffic": TRAFFIC.get("ctu_search"),
+                         "avg_launch_ms": round(launch_ms, 3), "alg_bytes_per_launch": byts, "launches_timed": cl.launches,
+                         "note": "the dominant kernel (> 99 % of the step) is the whole-CTU search: one workgroup walks one CTU's quad tree, "
+                                 "CTUs of a picture are a wavefront of dependent workgroups.  It is bound by the dependency chain inside a CTU "
+                                 "(serial RD bookkeeping on one lane at ~8 cycles per instruction; DESIGN.md section 4.6 has the phase profile), "
+                                 "not by HBM: achieved = algorithmic bytes (source in, reconstruction / levels / side information / models out) "
+                                 "/ average launch duration from HIP events on the launch stream"},
         }
-        if strong:
-            cb = fr.comm_bytes()
-            out["config"]["comm_bytes_per_step_rank0"] = {k: {"sent": v[0], "received": v[1]} for k, v in cb.items()}
-            out["config"]["band_rows_rank0"] = [fr.band.y0, fr.band.y1]
-        if live:
-            dom = max(live, key=lambda k: live[k]["avg_ms"])
-            alone_ms = per_kernel.get(dom, live[dom])["avg_ms"]
-            v = VALU.get(dom) if wl_name == "1080p8" else None
-            hbm = {"bound": "hbm", "kernel": dom, "achieved": live[dom]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": round(live[dom]["gbs"] / HBM_PEAK_GBS, 5), "traffic": TRAFFIC.get(dom) if wl_name == "1080p8" else None,
-                   "avg_launch_ms": live[dom]["avg_ms"], "alg_bytes_per_launch": live[dom]["alg_bytes"],
-                   "launches_timed": live[dom]["launches"], "serial_avg_launch_ms": alone_ms}
-            if v:
-                insts = v["valu_insts"]
-                ach = insts / (live[dom]["avg_ms"] * 1e-3) / 1e9
-                ach_alone = insts / (alone_ms * 1e-3) / 1e9
-                out["roofline"] = {
-                    "bound": "valu", "kernel": dom, "achieved": round(ach, 2), "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
-                    "frac": round(ach / VALU_PEAK_GINST, 4), "achieved_alone": round(ach_alone, 2), "frac_alone": round(ach_alone / VALU_PEAK_GINST, 4),
-                    "traffic": hbm["traffic"], "insts_per_launch": insts, "avg_launch_ms": live[dom]["avg_ms"], "serial_avg_launch_ms": alone_ms,
-                    "launches_timed": live[dom]["launches"],
-                    "note": ("the dominant kernel family is RDOQ (uvg_rdoq: a sequential walk per transform block, double-precision costs in "
-                             "the reference's order); a launch is rounds x wave latency (resident blocks are bound by LDS / registers, a wave "
-                             "issues an instruction every ~10 cycles), not HBM-bound; `traffic` (PMC) is mostly the kernel's private workspace "
-                             "-- cost_coeff[] as doubles, written once and partly re-read, the roles of the reference's three stack arrays -- "
-                             "and 2-byte gathers in scan order, not re-reads of the algorithmic bytes (coefficients in, levels out): " if dom.startswith("rdoq") else
-                             "the dominant kernel (rough intra search) is integer-VALU-issue bound, not HBM bound: ") +
-                            "achieved = SQ_INSTS_VALU per launch (PMC pass, profiles/) / the launch's average duration from HIP events "
-                            "recorded inside the timed region on its own stream, where other pictures' kernels share the GPU; *_alone = the "
-                            "same launch with nothing else running (profile pass); peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 integer "
-                            "instruction (tools/dev/valu_rate.hip).  roofline_hbm carries the HBM view of the same launch"}
-                out["roofline_hbm"] = hbm
-            else:
-                hbm["note"] = "no SQ_INSTS_VALU capture under profiles/ for this kernel / workload: HBM view only (the kernel is instruction-issue bound, DESIGN.md)"
-                out["roofline"] = hbm
-        out["kernel_sum_ms"] = round(tot_ms, 4)
-        out["kernels_timed_region"] = live
-        out["kernels"] = per_kernel
         if extra is not None:
-            efr, ewl = extra["frames"][0], extra["wl"]
-            ek, etot = kernel_table(efr, extra["prof"], extra["prof_pics"], extra["group"])
-            top = sorted(ek.items(), key=lambda kv: -kv[1]["per_step_ms"])[:14]
-            out["extra_workloads"] = {"2160p10alf": {
-                "value": round(extra["fps"], 2), "unit": "frames/s", "steps": extra["steps"], "ms_per_step": round(1e3 * extra["elapsed"] / extra["steps"], 3),
-                "mpixels_per_s": round(extra["fps"] * ewl["W"] * ewl["H"] / 1e6, 1), "scaling": "strong" if extra["shard_rows"] else "weak",
-                "workload": workload_text(ewl, args.shard, world), "kernel_sum_ms": round(etot, 4),
-                "comm_bytes_per_step_rank0": ({k: {"sent": v[0], "received": v[1]} for k, v in efr.comm_bytes().items()} if extra["shard_rows"] else None),
-                "kernels_top": dict(top)}}
-        if world == 1 and not args.no_closed_loop:
-            out["closed_loop"] = closed_loop_probe(L, wl, device)
-        if world == 1 and fr.rdoq:
-            out["coeff_cost"] = coeff_cost_probe(L, fr)
-        if not args.no_extra and not strong:
-            # what --shard rows would move per picture (the exchange lists of a middle rank; no communication happens here)
-            pw = WORKLOADS["2160p10alf"]
-            plan = pipeline.BandFrame(L, pw, 0, device, api.make_modes(MODES, device), rank=3, nranks=8, qp=QP)
-            out["row_sharding_plan"] = {
-                "workload": "2160p10alf", "ranks": 8, "rank": 3, "ctu_rows_owned": [plan.band.ctu_row0, plan.band.ctu_row1],
-                "bytes_per_picture": {k: {"sent": v[0], "received": v[1]} for k, v in plan.comm_bytes().items()},
-                "note": "python -m torch.distributed.run ... bench.py --gpus N --shard rows --workload 2160p10alf runs this plan over RCCL "
-                        "(halos: grouped ncclSend/ncclRecv with the two neighbours; ALF covariances: ncclAllReduce int64; final "
-                        "bands: pairwise send/recv on the xGMI mesh) and reports it as scaling=strong"}
-            del plan
+            out["extra_workloads"] = {"2160p10_closed_loop": extra}
+        if open_loop is not None:
+            out["open_loop"] = open_loop
+        if row_sharded is not None:
+            out["row_sharded_rccl"] = row_sharded
         if world == 1 and not args.no_cpu_baseline and wl_name == "1080p8":
-            y, u, v = fr.host
-            out["cpu_baseline"] = cpu_baseline(y, u, v, wl["W"], wl["H"], wl["depth"])
+            out["cpu_baseline"] = cpu_baseline_search(wl)
         print(json.dumps(out))
     if transport is not None:
         transport.close()

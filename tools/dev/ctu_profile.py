@@ -1,0 +1,23 @@
+"""dev: phase breakdown of the CTU search kernel (build csrc with EXTRA=-DCTU_PROFILE first)."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+import numpy as np, torch, time
+from uvg266_amd import lib, api, layout
+hip = lib.init(0)
+W, H, depth, n = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+P = api.ctu_params(W, H, 22)
+src = [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in layout.synthetic_yuv420(W, H, t, depth)) for t in range(n)]
+cs = api.CtuSearch(P, src)
+for rep in range(2):
+    torch.cuda.synchronize(); t = time.time(); cs.run(); torch.cuda.synchronize(); dt = time.time() - t
+    print(f"{n} pictures {W}x{H} {depth}-bit: {dt*1e3:.1f} ms -> {n/dt:.2f} pictures/s")
+ctus = ((W + 63) // 64) * ((H + 63) // 64) * n
+al = lambda v, a: (v + a - 1) // a * a
+off_order = al(256 + ctus * 4, 256); off_pics = al(off_order + ctus * 4, 256); off_scr = al(off_pics + n * 88, 256)
+ws = cs.ws.cpu().numpy()
+SZ = 53376 + 64
+prof = np.stack([ws[off_scr + i * SZ + SZ - 192: off_scr + i * SZ + SZ].view(np.uint64) for i in range(ctus)]).astype(np.float64)
+names = ["rough search", "refs+predict", "residual+transforms+recon", "RDOQ", "SSD", "RD cost bits", "park/unpark/models", "64x64 candidate", "coder pass", "load", "store", "TOTAL", "rq: candidates+last", "rq: pre-walk", "rq: decide", "rq: accumulate+group", "rq: copy-out", "rq: cbf+last search", "rq: signs"]
+tot = prof[:, 11].mean()
+print("mean ticks per CTU (s_memtime, 100 MHz): total %.0f = %.2f ms" % (tot, tot / 1e5))
+for i, nm in enumerate(names): print(f"  {nm:28s} {prof[:, i].mean():10.0f}  {100 * prof[:, i].mean() / tot:5.1f} %")

@@ -24,17 +24,22 @@
 #include <stdint.h>
 #include <string.h>
 #include "intra_pred_dev.h"
+#if defined(__HIPCC__)
+#include "satd_dev.h"
+#endif
 #include "vvc_tables.h"
 #include "vvc_ctx_init.h"
 #include "vvc_rdoq_tables.h"
 #include "../../include/uvg266_hip.h"
 
 #if defined(__HIPCC__)
+#define CTU_NOINLINE __attribute__((noinline))
 #define CTU_DEV __device__
 #define CTU_TID ((int)threadIdx.x)
 #define CTU_NT ((int)blockDim.x)
 #define CTU_SYNC() __syncthreads()
 #else
+#define CTU_NOINLINE
 #define CTU_DEV static inline
 #define CTU_TID 0
 #define CTU_NT 1
@@ -46,8 +51,27 @@
 #else
 #define CTU_GLOAD(p) (*(p))
 #endif
+// optional phase timers (lane 0, s_memtime ticks) -- compiled in with -DCTU_PROFILE, results in scratch::prof
+#if defined(__HIPCC__) && defined(CTU_PROFILE)
+#define CTU_T0() const unsigned long long ctu_t0__ = __builtin_amdgcn_s_memtime()
+#define CTU_T1(W, slot) do { if (CTU_TID == 0) (W)->prof[slot] += __builtin_amdgcn_s_memtime() - ctu_t0__; } while (0)
+#else
+#define CTU_T0() ((void)0)
+#define CTU_T1(W, slot) ((void)0)
+#endif
 #define PAR_FOR(i, n) for (int i = CTU_TID; i < (n); i += CTU_NT)
 #define SERIAL if (CTU_TID == 0)
+// regions run by the first wave alone, its lanes exchanging data through LDS without workgroup barriers (LDS operations of one
+// wave complete in program order; the fence only stops the compiler from moving them)
+#if defined(__HIPCC__)
+#define CTU_IN_WAVE0 (threadIdx.x < 64)
+#define WFOR(i, n) for (int i = CTU_TID; i < (n); i += 64)
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define CTU_IN_WAVE0 1
+#define WFOR(i, n) for (int i = 0; i < (n); ++i)
+#define WSYNC() ((void)0)
+#endif
 
 namespace ctu {
 
@@ -96,9 +120,16 @@ template <typename PX> struct lds {
   uint32_t coder[NMODELS];                          // state->cabac models
   uint8_t rdoq_state[244];                          // CTX_STATE of the coder's models at the CTU's start (what uvg_rdoq prices with)
   uint16_t top[REFN], left[REFN], ftop[REFN], fleft[REFN];
-  int16_t t0[1024], t1[1024], t2[1024];             // transform scratch
+  alignas(16) int16_t t0[1024], t1[1024], t2[1024]; // transform scratch
+  alignas(16) double rq_cc[256], rq_cs[256], rq_c0[256];   // RDOQ: cost of the kept level / of its significance flag / of level 0, per scan position (<= 16x16)
+  double rq_stage[3 * 16];                          // ... of the coefficient group in flight
+  int32_t rq_i[16];                                 // RDOQ scalars: 0 last_scanpos, 1 any level, 2..: per-lane partials
   int16_t lv[3][1024];                              // levels of the TUs being evaluated (y, u, v)
   uint16_t scan[1024 + 256 + 64 + 16];              // coefficient scans of the four square shapes
+  uint8_t inv4[16];                                 // scan index of the 4x4 group's raster position y * 4 + x
+  uint16_t deps4[16];                               // per scan index of a 4x4 group: the scan indices (bits) its context template reads inside the group
+  int32_t last_bits[2][4][2][12];                   // RDOQ: bit cost of the last-position prefix per (luma/chroma, log2 size - 2, x/y, group index)
+  uint8_t cg_flag[64];
   uint32_t part[2 * 24 * 16];                       // rough search: (satd, sad) partial sums per (listed mode, tile)
   double rs_cost[67];
   int32_t rs_list[24];
@@ -117,10 +148,23 @@ struct scratch {
   int16_t save_co[6144];
   cu4 save_cu[256];
   uint32_t save_tree[512];
+  unsigned long long prof[24];     // CTU_PROFILE: 0 rough search, 1 refs + prediction, 2 residual + transforms + reconstruction, 3 RDOQ, 4 SSD,
+                                   // 5 RD cost (bits), 6 park / unpark / model copies, 7 64x64 candidate, 8 coder pass, 9 load, 10 store, 11 total
 };
 
 // ------------------------------------------------------------------------------------------------------------ models ------
-#define kRate (k_ctx_init[3])      // the window byte of every model (rate0 << 4 | rate1)
+// Tables every serial walk reads per bin live in LDS (a lone lane pays the full latency of every load: out of device memory the
+// entropy table alone cost most of the search's time): the 512 bit costs, the models' window bytes, and the bit costs of the
+// models uvg_rdoq prices with (fixed for the CTU).  Function-scope LDS, filled by load_ctu.
+#if defined(__HIPCC__)
+#define CTU_SHARED __shared__
+#else
+#define CTU_SHARED static
+#endif
+CTU_DEV uint32_t *tab_ebits() { CTU_SHARED uint32_t t[512]; return t; }
+CTU_DEV uint8_t *tab_rate() { CTU_SHARED uint8_t t[264]; return t; }
+CTU_DEV uint32_t *tab_rdoq_bits() { CTU_SHARED uint32_t t[2 * 244]; return t; }
+#define kRate (tab_rate())         // the window byte of every model (rate0 << 4 | rate1)
 
 CTU_DEV int m_state(const uint32_t *m, int c) { return (int)(((m[c] & 0xffffu) + (m[c] >> 16)) >> 8); }
 CTU_DEV void m_update(uint32_t *m, int c, int bin)            // CTX_UPDATE, cabac.h:182-193
@@ -134,7 +178,7 @@ CTU_DEV void m_update(uint32_t *m, int c, int bin)            // CTX_UPDATE, cab
 }
 // uvg_f_entropy_bits (rdo.c:143, a float table) = uvg_entropy_bits / 2^15: every entry is an integer below 2^24 over 2^15, so the
 // float and this double quotient are the same number
-CTU_DEV double m_fbits(const uint32_t *m, int c, int bin) { return (double)kEntropyBits[(m_state(m, c) << 1) ^ bin] / 32768.0; }
+CTU_DEV double m_fbits(const uint32_t *m, int c, int bin) { return (double)tab_ebits()[(m_state(m, c) << 1) ^ bin] / 32768.0; }
 // CABAC_FBITS_UPDATE with only_count = 1
 CTU_DEV void m_code(uint32_t *m, int update, int c, int bin, double &bits)
 {
@@ -174,6 +218,19 @@ template <typename PX> CTU_DEV void build_scans(lds<PX> *S)
       const int n = 1 << l2, cgw = n >> 2;
       diag_order(cgw, cg);
       uint16_t *sc = S->scan + scan_base(l2);
+      if (l2 == 2) {
+        for (int k = 0; k < 16; ++k) S->inv4[in[k]] = (uint8_t)k;
+        for (int k = 0; k < 16; ++k) {
+          const int x = in[k] & 3, y = in[k] >> 2;
+          unsigned m = 0;
+          if (x + 1 < 4) m |= 1u << S->inv4[y * 4 + x + 1];
+          if (x + 2 < 4) m |= 1u << S->inv4[y * 4 + x + 2];
+          if (y + 1 < 4) m |= 1u << S->inv4[(y + 1) * 4 + x];
+          if (y + 2 < 4) m |= 1u << S->inv4[(y + 2) * 4 + x];
+          if (x + 1 < 4 && y + 1 < 4) m |= 1u << S->inv4[(y + 1) * 4 + x + 1];
+          S->deps4[k] = (uint16_t)m;
+        }
+      }
       for (int g = 0; g < cgw * cgw; ++g) {
         const int gx = cg[g] % cgw, gy = cg[g] / cgw;
         for (int k = 0; k < 16; ++k) sc[g * 16 + k] = (uint16_t)((gy * 4 + in[k] / 4) * n + gx * 4 + in[k] % 4);
@@ -206,7 +263,7 @@ template <typename PX> CTU_DEV int count_edge_cus(lds<PX> *S, int x, int y, int 
 
 // uvg_intra_build_reference (intra.c:1344; _inner :1065-1341 when the block touches neither picture edge, _any :756-1063 else) for the
 // w x w block of `color` whose luma position is (x, y) / CTU-local (lx, ly) with luma size n; + the smoothed rows (:190-225)
-template <typename PX> CTU_DEV void build_refs(lds<PX> *S, const params &P, int color, int x, int y, int lx, int ly, int n)
+template <typename PX> CTU_NOINLINE CTU_DEV void build_refs(lds<PX> *S, const params &P, int color, int x, int y, int lx, int ly, int n)
 {
   const int c = color != 0;
   const int w = n >> c;
@@ -256,7 +313,7 @@ template <typename PX> CTU_DEV void build_refs(lds<PX> *S, const params &P, int 
 }
 
 // prediction of the w x w block of `color` from the reference rows into dst (pitch dp)
-template <typename PX> CTU_DEV void predict_block(lds<PX> *S, int mode, int color, int w, PX *dst, int dp)
+template <typename PX> CTU_NOINLINE CTU_DEV void predict_block(lds<PX> *S, int mode, int color, int w, PX *dst, int dp)
 {
   const mode_info M = make_mode_info(mode, w, w, color != 0);
   const ref_rows R = {S->top, S->left, S->ftop, S->fleft};
@@ -315,13 +372,53 @@ CTU_DEV unsigned satd4_tile(int (&d)[16])
   return (satd + 1) >> 1;
 }
 
-// costs of the listed modes for the n x n luma block at (lx, ly): every (mode, tile) is one task -- the lane predicts the tile in
-// registers (in the mode's work domain: transposed for the horizontal modes) and reduces it at once; get_cost_dual (search_intra.c:133)
-template <typename PX> CTU_DEV void rough_costs(lds<PX> *S, int lx, int ly, int n, const int32_t *modes, int n_modes)
+// costs of the listed modes for the n x n luma block at (lx, ly); get_cost_dual (search_intra.c:133-192).
+// Device: every (mode, tile, row) is one lane -- a lane predicts one row of the tile in registers (in the mode's work domain:
+// transposed for the horizontal modes; SAD and the Hadamard magnitude multiset are transpose-invariant), the T lanes of a tile
+// finish the Hadamard with DPP exchanges (satd_dev.h).  Host emulation: the tile as a whole.
+template <typename PX> CTU_NOINLINE CTU_DEV void rough_costs(lds<PX> *S, int lx, int ly, int n, const int32_t *modes, int n_modes)
 {
   const int T = n >= 8 ? 8 : 4, tiles_x = n / T, tiles = tiles_x * tiles_x;
   const ref_rows R = {S->top, S->left, S->ftop, S->fleft};
   const int dcv = dc_value(S->top, S->left, n, n);
+#if defined(__HIPCC__)
+  const int total = n_modes * tiles * T;
+  for (int base = 0; base < total; base += CTU_NT) {
+    const int idx = base + CTU_TID;
+    const bool on = idx < total;
+    const int task = on ? idx / T : 0, r = idx & (T - 1);
+    const int mi = task / tiles, tile = task - mi * tiles;
+    const mode_info M = make_mode_info(modes[mi], n, n, 0);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    int sad = 0, satd;
+    if (T == 8) {
+      int d[8], out[8];
+      predict_row<8>(M, R, dcv, 0, n, n, ty * 8 + r, tx * 8, (int)px_info<PX>::maxv, out);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int wx = tx * 8 + i, wy = ty * 8 + r;
+        const int bx = M.vertical ? wx : wy, by = M.vertical ? wy : wx;
+        d[i] = on ? (int)S->Sy[(ly + by) * LCU + lx + bx] - out[i] : 0;
+        sad += iabs_(d[i]);
+      }
+      satd = satd8_cost(d, r);
+      sad = dpp_group_sum<8>(sad);
+    } else {
+      int d[4], out[4];
+      predict_row<4>(M, R, dcv, 0, n, n, r, 0, (int)px_info<PX>::maxv, out);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int bx = M.vertical ? i : r, by = M.vertical ? r : i;
+        d[i] = on ? (int)S->Sy[(ly + by) * LCU + lx + bx] - out[i] : 0;
+        sad += iabs_(d[i]);
+      }
+      satd = satd4_cost(d, r);
+      sad = dpp_group_sum<4>(sad);
+    }
+    if (on && r == 0) { S->part[2 * task] = (uint32_t)satd; S->part[2 * task + 1] = (uint32_t)sad; }
+  }
+  CTU_SYNC();
+#else
   PAR_FOR(task, n_modes * tiles) {
     const int mi = task / tiles, tile = task - mi * tiles;
     const int mode = modes[mi];
@@ -360,6 +457,7 @@ template <typename PX> CTU_DEV void rough_costs(lds<PX> *S, int lx, int ly, int 
     S->part[2 * task + 1] = sad;
   }
   CTU_SYNC();
+#endif
 }
 
 // count_bits (search_intra.c:949-984)
@@ -421,7 +519,7 @@ template <typename PX> CTU_DEV void mpm_neighbours(lds<PX> *S, int x, int y, int
 }
 
 // search_intra_rough (search_intra.c:986-1229), three survivors; the winner goes to S->u_mode
-template <typename PX> CTU_DEV void search_intra_rough(lds<PX> *S, const params &P, int x, int y, int lx, int ly, int n)
+template <typename PX> CTU_NOINLINE CTU_DEV void search_intra_rough(lds<PX> *S, const params &P, int x, int y, int lx, int ly, int n)
 {
   const int T = n >= 8 ? 8 : 4, tiles = (n / T) * (n / T);
   SERIAL {
@@ -443,19 +541,24 @@ template <typename PX> CTU_DEV void search_intra_rough(lds<PX> *S, const params 
   int offset = 1 << P.rough_levels;
   for (int round = 0;; ++round) {
     rough_costs(S, lx, ly, n, S->rs_list, S->u_n_modes);
-    SERIAL {
+    PAR_FOR(mi, S->u_n_modes) {                 // a lane per mode: tile sums, bit cost (count_bits reads the four flag costs itself)
       const double mpm_bit = m_fbits(S->cur, M_MPM, 1), not_mpm_bit = m_fbits(S->cur, M_MPM, 0);
       const double planar = m_fbits(S->cur, M_PLANAR + 1, 0), not_planar = m_fbits(S->cur, M_PLANAR + 1, 1);
+      const int mode = S->rs_list[mi];
+      unsigned satd = 0, sad = 0;
+      for (int t = 0; t < tiles; ++t) { satd += S->part[2 * (mi * tiles + t)]; sad += S->part[2 * (mi * tiles + t) + 1]; }
+      if (n >= 8) satd >>= (px_info<PX>::depth - 8);       // satd_NxN shifts, the 4x4 function does not (picture-generic.c:170)
+      sad >>= (px_info<PX>::depth - 8);
+      double c = (double)(satd < sad * 2 ? satd : sad * 2);
+      c += count_bits(S->mpm, planar, not_planar, mpm_bit, not_mpm_bit, mode) * P.lambda_sqrt;
+      S->rs_cost[mode] = c;
+    }
+    CTU_SYNC();
+    SERIAL {
       const int nm = S->u_n_modes;
       for (int mi = 0; mi < nm; ++mi) {
         const int mode = S->rs_list[mi];
-        unsigned satd = 0, sad = 0;
-        for (int t = 0; t < tiles; ++t) { satd += S->part[2 * (mi * tiles + t)]; sad += S->part[2 * (mi * tiles + t) + 1]; }
-        if (n >= 8) satd >>= (px_info<PX>::depth - 8);       // satd_NxN shifts, the 4x4 function does not (picture-generic.c:170)
-        sad >>= (px_info<PX>::depth - 8);
-        double c = (double)(satd < sad * 2 ? satd : sad * 2);
-        c += count_bits(S->mpm, planar, not_planar, mpm_bit, not_mpm_bit, mode) * P.lambda_sqrt;
-        S->rs_cost[mode] = c;
+        const double c = S->rs_cost[mode];
         chk[mode >> 5] |= 1u << (mode & 31);
         if (round == 0 && mi < 2) {
           if (mi == 1) {
@@ -498,7 +601,7 @@ template <typename PX> CTU_DEV void search_intra_rough(lds<PX> *S, const params 
 // ---------------------------------------------------------------------------------------------------- transforms ------
 CTU_DEV const int16_t *dct2_matrix(int n) { return n == 4 ? VVC_DCT2_4 : n == 8 ? VVC_DCT2_8 : n == 16 ? VVC_DCT2_16 : VVC_DCT2_32; }
 // dct_NxN (dct-generic.c:396-419, 720-729): dst[j * n + i] = trunc16((sum_k T[j][k] * src[i][k] + add) >> shift), twice
-CTU_DEV void fwd_pass(int n, const int16_t *src, int16_t *dst, int shift)
+CTU_NOINLINE CTU_DEV void fwd_pass(int n, const int16_t *src, int16_t *dst, int shift)
 {
   const int16_t *T = dct2_matrix(n);
   const int add = shift > 0 ? 1 << (shift - 1) : 0;
@@ -511,7 +614,7 @@ CTU_DEV void fwd_pass(int n, const int16_t *src, int16_t *dst, int shift)
   CTU_SYNC();
 }
 // idct_NxN (:422-446, 731-740): dst[i * n + j] = clip16((sum_k src[k * n + i] * T[k][j] + add) >> shift), twice
-CTU_DEV void inv_pass(int n, const int16_t *src, int16_t *dst, int shift)
+CTU_NOINLINE CTU_DEV void inv_pass(int n, const int16_t *src, int16_t *dst, int shift)
 {
   const int16_t *T = dct2_matrix(n);
   const int add = 1 << (shift - 1);
@@ -538,9 +641,9 @@ struct rdoq_env {
   const uint8_t *st;      // CTX_STATE per model
   int t;                  // 0 luma, 1 chroma
   double lambda, error_scale;
-  int q_bits;
+  int q_bits, q;
 };
-CTU_DEV int32_t rbits(const rdoq_env &E, int model, int bin) { return (int32_t)kEntropyBits[(E.st[model] << 1) ^ bin]; }
+CTU_DEV int32_t rbits(const rdoq_env &E, int model, int bin) { return (int32_t)tab_rdoq_bits()[2 * model + bin]; }
 
 // uvg_get_ic_rate (rdo.c:465-581), limited prefix length
 CTU_DEV int32_t ic_rate(const rdoq_env &E, uint32_t abs_level, int ctx, int go_rice, uint32_t reg_bins)
@@ -662,7 +765,7 @@ __device__ static const double kPow2[16] = {1.0, 2.0, 4.0, 8.0, 16.0, 32.0, 64.0
 
 // uvg_rdoq (rdo.c:1449-1870) of an n x n block (square: no sqrt2 scaling), intra, no LFNST / MTS / sign hiding; lane 0 only.
 // coef -> levels in dst (both n * n, raster).  Returns whether any level survived.
-CTU_DEV int rdoq_serial(const uint8_t *st, const uint16_t *scan, scratch *W, const int16_t *coef, int16_t *dst, int n, int color, int cbf_u,
+CTU_NOINLINE CTU_DEV int rdoq_serial(const uint8_t *st, const uint16_t *scan, scratch *W, const int16_t *coef, int16_t *dst, int n, int color, int cbf_u,
                         int qp_scaled, double lambda, int bitdepth)
 {
   const int l2 = ilog2_dev(n);
@@ -850,6 +953,326 @@ CTU_DEV int rdoq_serial(const uint8_t *st, const uint16_t *scan, scratch *W, con
   return any != 0;
 }
 
+// one position of uvg_rdoq's main walk (rdo.c:1600-1716): the level that survives, its cost and the cost of its significance flag.
+// regular: regular bins remain (reg_bins >= 4), go_rice is then the value carried from the position coded before; otherwise the
+// position is priced as bypass-coded and its Rice parameter comes from the levels decided around it.
+struct rdoq_pos { int level; double cc, cs; };
+CTU_NOINLINE CTU_DEV rdoq_pos rdoq_decide(const rdoq_env &E, const int16_t *coef, const int16_t *dst, int n, int l2, int color, int blkpos, bool is_last,
+                             bool regular, int go_rice, double c0, int *mal_out)
+{
+  const int cap_half = 1 << (E.q_bits - 1);
+  const int64_t prod = (int64_t)iabs_((int)coef[blkpos]) * E.q;
+  const int32_t cap = 0x7fffffff - cap_half;
+  const int32_t level_double = (int32_t)(prod < cap ? prod : cap);
+  const uint32_t max_abs_level = (uint32_t)(level_double + cap_half) >> E.q_bits;
+  const int pos_y = blkpos >> l2, pos_x = blkpos - (pos_y << l2);
+  int ctx_sig = 0, ctx_set = 0;
+  if (!is_last) {
+    int diag, tsum;
+    ctx_sig = sig_ctx_abs(dst, pos_x, pos_y, n, color, &diag, &tsum);
+    ctx_set = ((tsum < 4 ? tsum : 4) + 1) + (!diag ? ((color == 0) ? 15 : 5) : (color == 0) ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0);
+  }
+  if (!regular) go_rice = go_rice_par(template_abs_sum(dst, 0, pos_x, pos_y, n));
+  rdoq_pos r;
+  r.cs = 0;        // (the reference leaves cost_sig of the last position as it was: never read before it is written, see below)
+  r.level = (int)coded_level(E, &r.cc, c0, &r.cs, level_double, max_abs_level, ctx_sig, ctx_set, go_rice, regular ? 4u : 0u, is_last);
+  *mal_out = (int)max_abs_level;
+  return r;
+}
+
+// uvg_rdoq (rdo.c:1449-1870) by the first wave: same arithmetic as rdoq_serial, restructured around what is sequential in it.
+//   * every position's quantisation candidates and its level-0 cost: all positions at once;
+//   * a level decision reads only levels decided on later anti-diagonals (the context template looks right / down), so the <= 4
+//     positions of one anti-diagonal of a 4x4 group are decided together, 7 steps per group -- as long as the regular-bin budget
+//     cannot run out inside the group (an upper bound from the candidates says so) or has run out for good; the one or two groups
+//     where it does run out are walked position by position;
+//   * the double-precision sums the reference forms in scan order (base cost, group statistics) and the group decision that
+//     compares them: lane 0, from the group's staged costs; the final cbf / last-position search: lane 0.
+// Result: S->rq_i[1] = whether any level survived; levels in dst.
+template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *W, const int16_t *coef, int16_t *dst, int n, int color, int cbf_u, int qp_scaled,
+                                              double lambda, int bitdepth)
+{
+  const int l2 = ilog2_dev(n), nn = n * n, cgw = n >> 2;
+  const uint16_t *scan = S->scan + scan_base(l2);
+  rdoq_env E;
+  E.st = S->rdoq_state; E.t = color ? 1 : 0; E.lambda = lambda;
+  const int transform_shift = 15 - bitdepth - l2;
+  E.q_bits = 14 + qp_scaled / 6 + transform_shift;
+  E.q = kQuantScales[qp_scaled % 6];
+  double scale = 32768;
+  scale = transform_shift >= 0 ? scale / kPow2[2 * transform_shift] : scale * kPow2[-2 * transform_shift];
+  E.error_scale = scale / E.q / E.q;
+  const bool small = n <= 16;                    // the per-position cost arrays fit in LDS
+  double *CC = small ? S->rq_cc : W->cost_coeff, *CS = small ? S->rq_cs : W->cost_sig, *C0 = small ? S->rq_c0 : W->cost_coeff0;
+#define RQ_LD(p) (small ? *(p) : CTU_GLOAD(p))
+  double *cost_cg_sig = S->rs_cost;              // (free while a block is quantised)
+  const int cap_half = 1 << (E.q_bits - 1);
+  // ---- every position: candidate, level-0 cost; the last candidate in scan order ----
+#if defined(__HIPCC__) && defined(CTU_PROFILE)
+  unsigned long long tq = __builtin_amdgcn_s_memtime();
+#define RQ_T(slot) do { const unsigned long long t2 = __builtin_amdgcn_s_memtime(); if (CTU_TID == 0) W->prof[slot] += t2 - tq; tq = t2; } while (0)
+#else
+#define RQ_T(slot) ((void)0)
+#endif
+  int my_last = -1;
+  WFOR(sp, nn) {
+    const int blk = scan[sp];
+    const int64_t prod = (int64_t)iabs_((int)coef[blk]) * E.q;
+    const int32_t cap = 0x7fffffff - cap_half;
+    const int32_t level_double = (int32_t)(prod < cap ? prod : cap);
+    const int mal = (int)((uint32_t)(level_double + cap_half) >> E.q_bits);
+    const double err = (double)level_double;
+    C0[sp] = err * err * E.error_scale;
+    dst[blk] = (int16_t)mal;
+    if (mal > 0 && sp > my_last) my_last = sp;
+    if (sp < 64) S->cg_flag[sp] = 0;
+  }
+#if defined(__HIPCC__)
+  for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(my_last, o, 64); my_last = v > my_last ? v : my_last; }
+#endif
+  const int last_scanpos = my_last;
+  WSYNC();
+  if (last_scanpos < 0) { if (CTU_TID == 0) S->rq_i[1] = 0; WSYNC(); return; }
+  RQ_T(12);
+  const int cg_last = last_scanpos >> 4;
+  // lane 0's running sums (rdo.c:1556-1583: the positions behind the last candidate only add their level-0 cost)
+  double block_uncoded_cost = 0, base_cost = 0;
+  if (CTU_TID == 0) {
+    for (int sp = nn - 1; sp > last_scanpos; --sp) { const double c = RQ_LD(&C0[sp]); block_uncoded_cost += c; base_cost += c; }
+    for (int g = 0; g <= cg_last; ++g) cost_cg_sig[g] = 0;
+    S->rq_i[4] = (int)((uint32_t)(nn * 28) >> 4);      // reg_bins
+    S->rq_i[5] = 1;                                    // regular bins remain
+  }
+  WSYNC();
+  RQ_T(13);
+  for (int cgs = cg_last; cgs >= 0; --cgs) {
+    const int first = scan[cgs * 16];
+    const int cg_pos_x = (first & (n - 1)) >> 2, cg_pos_y = (first >> l2) >> 2;
+    const int cg_blkpos = cg_pos_y * cgw + cg_pos_x;
+    int reg_bins = S->rq_i[4];
+    const int regular = S->rq_i[5];
+    // can the regular-bin budget run out inside this group?  (a position spends at most min(candidate, 2 -> 3) + 1 bins)
+    int fast = !regular;
+    if (regular) {
+      int bound = 0;
+      WFOR(sp, 16) {
+        const int scanpos = cgs * 16 + sp;
+        if (scanpos <= last_scanpos) { const int mal = dst[scan[scanpos]]; bound += (mal < 2 ? mal : 3) + (scanpos != last_scanpos); }
+      }
+#if defined(__HIPCC__)
+      for (int o = 8; o >= 1; o >>= 1) bound += __shfl_xor(bound, o, 64);
+      bound = __shfl(bound, 0, 64);
+#endif
+      fast = reg_bins - bound >= 4;
+    }
+    if (fast) {
+      // a position can be decided once the positions of its context template that may keep a level are decided; the others hold
+      // their final 0 already.  Lanes 0..15 own the group's scan positions; the rounds follow the chains of candidates (<= 7).
+#if defined(__HIPCC__)
+      {
+        const int sp = CTU_TID & 15, scanpos = cgs * 16 + sp;
+        const bool mine = CTU_TID < 16 && scanpos <= last_scanpos;
+        const int blk = scan[mine ? scanpos : cgs * 16];
+        const int mal0 = mine ? (int)dst[blk] : 0;
+        const unsigned nz = (unsigned)__ballot(mine && mal0 > 0) & 0xffffu;
+        const unsigned deps = (unsigned)S->deps4[sp] & nz;
+        int go_rice = 0;
+        if (mine && regular && sp != 15 && scanpos != last_scanpos) {
+          const int nb = scan[scanpos + 1];
+          go_rice = go_rice_par(template_abs_sum(coef, 4, nb & (n - 1), nb >> l2, n));      // sic: the INPUT coefficients (rdo.c:1697)
+        }
+        const double c0 = mine ? RQ_LD(&C0[scanpos]) : 0.0;
+        bool done = !mine;
+        unsigned decided = 0;
+        for (;;) {
+          const bool ready = !done && (deps & ~decided) == 0;
+          if (ready) {
+            int mal;
+            const rdoq_pos r = rdoq_decide(E, coef, dst, n, l2, color, blk, scanpos == last_scanpos, regular != 0, go_rice, c0, &mal);
+            dst[blk] = (int16_t)r.level;
+            S->rq_stage[sp] = r.cc; S->rq_stage[16 + sp] = r.cs;
+            done = true;
+          }
+          WSYNC();
+          decided = (unsigned)__ballot(done) & 0xffffu;
+          if (decided == 0xffffu) break;
+        }
+      }
+#else
+      {
+        unsigned nz = 0, decided = 0, all = 0;
+        for (int sp = 0; sp < 16; ++sp) { const int scanpos = cgs * 16 + sp; if (scanpos <= last_scanpos) { all |= 1u << sp; if (dst[scan[scanpos]] > 0) nz |= 1u << sp; } }
+        decided = ~all & 0xffffu;
+        while (decided != 0xffffu) {
+          const unsigned before = decided;
+          int16_t newlev[16];
+          for (int sp = 0; sp < 16; ++sp) {
+            if ((before >> sp) & 1) continue;
+            if (((unsigned)S->deps4[sp] & nz) & ~before) continue;
+            const int scanpos = cgs * 16 + sp, blk = scan[scanpos];
+            int go_rice = 0;
+            if (regular && sp != 15 && scanpos != last_scanpos) {
+              const int nb = scan[scanpos + 1];
+              go_rice = go_rice_par(template_abs_sum(coef, 4, nb & (n - 1), nb >> l2, n));
+            }
+            int mal;
+            const rdoq_pos r = rdoq_decide(E, coef, dst, n, l2, color, blk, scanpos == last_scanpos, regular != 0, go_rice, RQ_LD(&C0[scanpos]), &mal);
+            newlev[sp] = (int16_t)r.level;
+            S->rq_stage[sp] = r.cc; S->rq_stage[16 + sp] = r.cs;
+            decided |= 1u << sp;
+          }
+          for (int sp = 0; sp < 16; ++sp) if (((decided & ~before) >> sp) & 1) dst[scan[cgs * 16 + sp]] = newlev[sp];    // a round's levels appear together
+        }
+      }
+#endif
+    } else if (CTU_TID == 0) {
+      // the budget may run out in this group: position by position, exactly as the reference walks
+      int go_rice = 0;
+      for (int sp = 15; sp >= 0; --sp) {
+        const int scanpos = cgs * 16 + sp;
+        if (scanpos > last_scanpos) continue;
+        const int blk = scan[scanpos];
+        int mal;
+        const rdoq_pos r = rdoq_decide(E, coef, dst, n, l2, color, blk, scanpos == last_scanpos, reg_bins >= 4, go_rice, RQ_LD(&C0[scanpos]), &mal);
+        dst[blk] = (int16_t)r.level;
+        S->rq_stage[sp] = r.cc; S->rq_stage[16 + sp] = r.cs;
+        if ((scanpos % 16 == 0) && scanpos > 0) go_rice = 0;
+        else if (reg_bins >= 4) {
+          reg_bins -= (r.level < 2 ? r.level : 3) + (scanpos != last_scanpos);
+          go_rice = go_rice_par(template_abs_sum(coef, 4, blk & (n - 1), blk >> l2, n));
+        }
+      }
+      S->rq_i[4] = reg_bins;
+      S->rq_i[5] = reg_bins >= 4;
+    }
+    WSYNC();
+    RQ_T(14);
+    if (CTU_TID == 0) {
+      // the sums in scan order and the group's decision (rdo.c:1689-1772)
+      double rd_coded = 0, rd_uncoded = 0, rd_sig = 0, rd_sig0 = 0;
+      int nnz_before_pos0 = 0, flag = 0, spent = 0;
+      for (int sp = 15; sp >= 0; --sp) {
+        const int scanpos = cgs * 16 + sp;
+        if (scanpos > last_scanpos) continue;
+        const double cc = S->rq_stage[sp], cs = S->rq_stage[16 + sp], c0 = RQ_LD(&C0[scanpos]);
+        const int level = dst[scan[scanpos]];
+        block_uncoded_cost += c0;
+        base_cost += cc;
+        spent += (level < 2 ? level : 3) + (scanpos != last_scanpos);
+        rd_sig += cs;
+        if (sp == 0) rd_sig0 = cs;
+        if (level) {
+          flag = 1;
+          rd_coded += cc - cs;
+          rd_uncoded += c0;
+          if (sp != 0) nnz_before_pos0++;
+        }
+      }
+      if (fast && regular) S->rq_i[4] = reg_bins - spent;
+      int zeroed = 0;
+      if (cgs) {
+        unsigned right = 0, lower = 0;
+        if (cg_pos_x + 1 < cgw) right = S->cg_flag[cg_blkpos + 1];
+        if (cg_pos_y + 1 < cgw) lower = S->cg_flag[cg_blkpos + cgw];
+        const int o_grp = M_SIGGRP + (E.t ? 2 : 0) + ((right || lower) ? 1 : 0);
+        if (!flag) {
+          cost_cg_sig[cgs] = lambda * rbits(E, o_grp, 0);
+          base_cost += cost_cg_sig[cgs] - rd_sig;
+        } else if (cgs < cg_last) {
+          if (nnz_before_pos0 == 0) { base_cost -= rd_sig0; rd_sig -= rd_sig0; }
+          double cost_zero_cg = base_cost;
+          cost_cg_sig[cgs] = lambda * rbits(E, o_grp, 1);
+          base_cost += cost_cg_sig[cgs];
+          cost_zero_cg += lambda * rbits(E, o_grp, 0);
+          cost_zero_cg += rd_uncoded;
+          cost_zero_cg -= rd_coded;
+          cost_zero_cg -= rd_sig;
+          if (cost_zero_cg < base_cost) {
+            flag = 0;
+            zeroed = 1;
+            base_cost = cost_zero_cg;
+            cost_cg_sig[cgs] = lambda * rbits(E, o_grp, 0);
+          }
+        }
+      } else {
+        flag = 1;
+      }
+      S->cg_flag[cg_blkpos] = (uint8_t)flag;
+      S->rq_i[6] = zeroed;
+    }
+    WSYNC();
+    RQ_T(15);
+    {
+      // the group's costs go to the per-position arrays the last-position search reads; a zeroed group's positions fall back to level 0
+      const int zeroed = S->rq_i[6];
+      WFOR(sp, 16) {
+        const int scanpos = cgs * 16 + sp;
+        if (scanpos <= last_scanpos) {
+          const int blk = scan[scanpos];
+          if (zeroed && dst[blk]) { dst[blk] = 0; CC[scanpos] = RQ_LD(&C0[scanpos]); CS[scanpos] = 0; }
+          else { CC[scanpos] = S->rq_stage[sp]; CS[scanpos] = S->rq_stage[16 + sp]; }
+        }
+      }
+    }
+    WSYNC();
+  }
+  RQ_T(16);
+  // ---- coded block flag and the last significant position (rdo.c:1774-1833) ----
+  if (CTU_TID == 0) {
+    double best_cost;
+    int best_last_idx_p1 = 0;
+    {
+      const int o_cbf = color == 0 ? M_CBF_LUMA : color == 1 ? M_CBF_CB : M_CBF_CR + (cbf_u ? 1 : 0);
+      best_cost = block_uncoded_cost + lambda * rbits(E, o_cbf, 0);
+      base_cost += lambda * rbits(E, o_cbf, 1);
+    }
+    const int32_t *last_x_bits = S->last_bits[E.t][l2 - 2][0], *last_y_bits = S->last_bits[E.t][l2 - 2][1];
+    int found_last = 0;
+    for (int cgs = cg_last; cgs >= 0; cgs--) {
+      const int first = scan[cgs * 16];
+      const int cg_blkpos = ((first >> l2) >> 2) * cgw + ((first & (n - 1)) >> 2);
+      base_cost -= cost_cg_sig[cgs];
+      if (S->cg_flag[cg_blkpos]) {
+        for (int sp = 15; sp >= 0; sp--) {
+          const int scanpos = cgs * 16 + sp;
+          if (scanpos > last_scanpos) continue;
+          const int blkpos = scan[scanpos];
+          if (dst[blkpos]) {
+            const int pos_y = blkpos >> l2, pos_x = blkpos - (pos_y << l2);
+            const int cx = group_idx(pos_x), cy = group_idx(pos_y);
+            double cl = last_x_bits[cx] + last_y_bits[cy];
+            if (cx > 3) cl += 32768 * ((cx - 2) >> 1);
+            if (cy > 3) cl += 32768 * ((cy - 2) >> 1);
+            const double cost_last = lambda * cl;
+            const double total = base_cost + cost_last - RQ_LD(&CS[scanpos]);
+            if (total < best_cost) { best_last_idx_p1 = scanpos + 1; best_cost = total; }
+            if (dst[blkpos] > 1) { found_last = 1; break; }
+            base_cost -= RQ_LD(&CC[scanpos]);
+            base_cost += RQ_LD(&C0[scanpos]);
+          } else {
+            base_cost -= RQ_LD(&CS[scanpos]);
+          }
+        }
+        if (found_last) break;
+      }
+    }
+    S->rq_i[0] = best_last_idx_p1;
+    S->rq_i[1] = best_last_idx_p1 > 0;
+  }
+  WSYNC();
+  RQ_T(17);
+  const int best_last_idx_p1 = S->rq_i[0];
+  WFOR(scanpos, last_scanpos + 1) {
+    const int b = scan[scanpos];
+    if (scanpos < best_last_idx_p1) { const int level = dst[b]; dst[b] = (int16_t)((coef[b] < 0) ? -level : level); }
+    else dst[b] = 0;
+  }
+  WSYNC();
+  RQ_T(18);
+#undef RQ_LD
+#undef RQ_T
+}
+
 // -------------------------------------------------------------------------------------------- coefficient bit cost ------
 CTU_DEV int coeff_remain_bits(uint32_t remainder, uint32_t rice, unsigned cutoff)     // uvg_cabac_write_coeff_remain, cabac.c:318-354
 {
@@ -883,7 +1306,7 @@ CTU_DEV int abs_sum_tmpl(const int16_t *coeff, int px, int py, int n, int basele
 // uvg_encode_coeff_nxn in count mode (encode_coding_tree-generic.c:53-323, uvg_encode_last_significant_xy :415-470) on the models m,
 // which adapt bin by bin (get_coeff_cabac_cost always lets its COPY adapt; the caller decides whether to keep it); lane 0 only.
 // No dependent quantisation, no sign hiding, diagonal scan, regular residual coding.  Returns 0 for an all-zero block (rdo.c:312-320).
-CTU_DEV double coeff_bits_serial(uint32_t *m, const uint16_t *scan, const int16_t *coeff, int n, int color)
+CTU_NOINLINE CTU_DEV double coeff_bits_serial(uint32_t *m, const uint16_t *scan, const int16_t *coeff, int n, int color)
 {
   const int l2 = ilog2_dev(n);
   const int t = color ? 1 : 0;
@@ -1028,7 +1451,7 @@ template <typename PX> CTU_DEV int scaled_qp(const params &P, int color) { retur
 
 // predict + uvg_quantize_residual (quant-generic.c:460-612, RDOQ branch) of one transform block straight into D; its levels stay in
 // S->lv[color] and go to the CTU's coefficient array.  (x, y) / (lx, ly): luma position, n: luma size of the area.  -> has_coeffs
-template <typename PX> CTU_DEV int recon_tu(lds<PX> *S, const job<PX> &J, int color, int x, int y, int lx, int ly, int n, int mode, int cbf_u)
+template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<PX> &J, int color, int x, int y, int lx, int ly, int n, int mode, int cbf_u)
 {
   const int c = color != 0, w = n >> c, l2 = ilog2_dev(w);
   const int pit = pitch_of(color), spit = c ? LCU_C : LCU;
@@ -1036,20 +1459,26 @@ template <typename PX> CTU_DEV int recon_tu(lds<PX> *S, const job<PX> &J, int co
   PX *D = plane(S, color) + (by + 1) * pit + bx + 1;
   const PX *Sp = (color == 0 ? S->Sy : color == 1 ? S->Su : S->Sv) + by * spit + bx;
   const int depth = (int)px_info<PX>::depth;
+  { CTU_T0();
   build_refs(S, J.P, color, x, y, lx, ly, n);
   predict_block(S, mode, color, w, D, pit);
+  CTU_T1(J.W, 1); }
+  { CTU_T0();
   PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); S->t0[e] = (int16_t)((int)Sp[r * spit + q] - (int)D[r * pit + q]); }
   CTU_SYNC();
   fwd_pass(w, S->t0, S->t1, l2 - 1 + depth - 8);
   fwd_pass(w, S->t1, S->t2, l2 + 6);
+  CTU_T1(J.W, 2); }
   const int qps = scaled_qp<PX>(J.P, color);
-  SERIAL {
+  CTU_T0();
+  if (CTU_IN_WAVE0) {
     // chroma blocks: state->c_lambda as uvg_quantize_lcu_residual replaces it (transform.c:1575)
     const double lambda = c ? J.P.c_lambda_tu : J.P.lambda;
-    S->u_flag = rdoq_serial(S->rdoq_state, S->scan + scan_base(l2), J.W, S->t2, S->lv[color], w, color, cbf_u, qps, lambda, depth);
+    rdoq_wave(S, J.W, S->t2, S->lv[color], w, color, cbf_u, qps, lambda, depth);
   }
   CTU_SYNC();
-  const int has = S->u_flag;
+  CTU_T1(J.W, 3);
+  const int has = S->rq_i[1];
   int16_t *co = J.coeff + co_off(color) + by * spit + bx;
   PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); co[r * spit + q] = S->lv[color][e]; }
   if (has) {
@@ -1072,7 +1501,7 @@ template <typename PX> CTU_DEV int recon_tu(lds<PX> *S, const job<PX> &J, int co
 }
 
 // uvg_pixels_calc_ssd of a w x w block of D against the source, into S->red[slot] (valid after the barrier)
-template <typename PX> CTU_DEV void ssd_block(lds<PX> *S, int color, int lx, int ly, int n, int slot)
+template <typename PX> CTU_NOINLINE CTU_DEV void ssd_block(lds<PX> *S, int color, int lx, int ly, int n, int slot)
 {
   const int c = color != 0, w = n >> c, l2 = ilog2_dev(w);
   const int pit = pitch_of(color), spit = c ? LCU_C : LCU;
@@ -1104,7 +1533,7 @@ template <typename PX> CTU_DEV void split_flag_bits(lds<PX> *S, const params &P,
 }
 
 // uvg_encode_intra_luma_coding_unit (encode_coding_tree.c:992-1238) in count mode; lane 0
-template <typename PX> CTU_DEV void luma_mode_bits(lds<PX> *S, uint32_t *m, int update, int x, int y, int lx, int ly, int n, int mode, double &bits_out)
+template <typename PX> CTU_NOINLINE CTU_DEV void luma_mode_bits(lds<PX> *S, uint32_t *m, int update, int x, int y, int lx, int ly, int n, int mode, double &bits_out)
 {
   const cu4 *l, *a;
   int8_t preds[6];
@@ -1138,7 +1567,7 @@ CTU_DEV void chroma_mode_bits(uint32_t *m, int update, int chroma_mode, int luma
 }
 
 // mark_deblocking (search.c:1075-1174) for an n x n CU; sep: a 4x4 CU of an 8x8 area, chroma: it carries the area's chroma; lane 0
-template <typename PX> CTU_DEV void mark_deblocking(lds<PX> *S, int x, int y, int lx, int ly, int n, int sep, int chroma)
+template <typename PX> CTU_NOINLINE CTU_DEV void mark_deblocking(lds<PX> *S, int x, int y, int lx, int ly, int n, int sep, int chroma)
 {
   if (x) {
     for (int xx = lx; xx < lx + n; xx += 32)
@@ -1161,7 +1590,7 @@ template <typename PX> CTU_DEV void mark_deblocking(lds<PX> *S, int x, int y, in
 
 // the transform-tree part of the RD cost of one <= 32 block whose levels are in S->lv (cu_rd_cost_tr_split_accurate, search.c:724-986);
 // red[0..2]: SSD of y, u, v.  lane 0.  update: state->search_cabac.update.
-template <typename PX> CTU_DEV double tr_cost(lds<PX> *S, const params &P, int update, int n, int cbf, int has_chroma, int cn)
+template <typename PX> CTU_NOINLINE CTU_DEV double tr_cost(lds<PX> *S, const params &P, int update, int n, int cbf, int has_chroma, int cn)
 {
   double coeff_bits = 0, luma_bits = 0, chroma_bits = 0;
   const int cb_y = cbf & 1, cb_u = (cbf >> 1) & 1, cb_v = (cbf >> 2) & 1;
@@ -1195,7 +1624,7 @@ template <typename PX> CTU_DEV double tr_cost(lds<PX> *S, const params &P, int u
 CTU_DEV uint32_t cu_mtt(uint32_t tree_mtt, int L) { return tree_mtt | ((tree_mtt >> ((L - 1 > 0 ? L - 1 : 0) * 2)) & 3u) << (L * 2); }
 
 // lcu_fill_cu_info (search.c:314-353) for an n x n intra CU; lane 0
-template <typename PX> CTU_DEV void fill_cu(lds<PX> *S, int lx, int ly, int n, int mode, int mode_chroma, int log2_c, uint32_t split_tree, uint32_t mtt)
+template <typename PX> CTU_NOINLINE CTU_DEV void fill_cu(lds<PX> *S, int lx, int ly, int n, int mode, int mode_chroma, int log2_c, uint32_t split_tree, uint32_t mtt)
 {
   const int l2 = ilog2_dev(n);
   for (int yy = ly; yy < ly + n; yy += 4)
@@ -1209,7 +1638,7 @@ template <typename PX> CTU_DEV void fill_cu(lds<PX> *S, int lx, int ly, int n, i
 
 // search + reconstruction + RD cost of the n x n CU at depth L as ONE coding unit (the part of search_cu before the split loop,
 // search.c:1395-1774).  Leaves the CU in D and its cost / mode / cbf in S->lvl[L]; the models move on as the mock coder saw the CU.
-template <typename PX> CTU_DEV void eval_cu(lds<PX> *S, const job<PX> &J, int L)
+template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<PX> &J, int L)
 {
   const params &P = J.P;
   level_state &N = S->lvl[L];
@@ -1222,8 +1651,10 @@ template <typename PX> CTU_DEV void eval_cu(lds<PX> *S, const job<PX> &J, int L)
     c->log2_c = (uint8_t)(sep ? 2 : ilog2_dev(n) - 1);
   }
   CTU_SYNC();
+  { CTU_T0();
   build_refs(S, P, 0, x, y, lx, ly, n);
   search_intra_rough(S, P, x, y, lx, ly, n);
+  CTU_T1(J.W, 0); }
   const int mode = S->u_mode;
   SERIAL fill_cu(S, lx, ly, n, mode, mode, sep ? 2 : ilog2_dev(n) - 1, N.split_tree, cu_mtt(N.mode_type_tree, L));
   CTU_SYNC();
@@ -1235,10 +1666,15 @@ template <typename PX> CTU_DEV void eval_cu(lds<PX> *S, const job<PX> &J, int L)
     const int cu = recon_tu(S, J, 1, cx, cy, cx & 63, cy & 63, area, mode, 0);
     const int cv = recon_tu(S, J, 2, cx, cy, cx & 63, cy & 63, area, mode, cu);
     cbf |= cu << 1 | cv << 2;
+    { CTU_T0();
     ssd_block(S, 1, cx & 63, cy & 63, area, 1);
     ssd_block(S, 2, cx & 63, cy & 63, area, 2);
+    CTU_T1(J.W, 4); }
   }
+  { CTU_T0();
   ssd_block(S, 0, lx, ly, n, 0);
+  CTU_T1(J.W, 4); }
+  CTU_T0();
   SERIAL {
     cu4 *c = cu_at(S, lx, ly);
     c->cbf = (uint8_t)(cbf & 1);
@@ -1266,11 +1702,12 @@ template <typename PX> CTU_DEV void eval_cu(lds<PX> *S, const job<PX> &J, int L)
     N.cost = cost; N.type = CU_INTRA; N.mode = mode; N.cbf = cu_at(S, lx, ly)->cbf;
   }
   CTU_SYNC();
+  CTU_T1(J.W, 5);
 }
 
 // park the CU just evaluated at depth L (1..3) and clear its area of D's side information, as a fresh work-tree level would be
 // (initialize_partial_work_tree zeroes the entries from the CU's origin on, search.c:168-172)
-template <typename PX> CTU_DEV void park(lds<PX> *S, const job<PX> &J, int L)
+template <typename PX> CTU_NOINLINE CTU_DEV void park(lds<PX> *S, const job<PX> &J, int L)
 {
   const level_state &N = S->lvl[L];
   const int n = 64 >> L, lx = N.x & 63, ly = N.y & 63;
@@ -1289,7 +1726,7 @@ template <typename PX> CTU_DEV void park(lds<PX> *S, const job<PX> &J, int L)
   CTU_SYNC();
 }
 // put the parked CU back: the split lost
-template <typename PX> CTU_DEV void unpark(lds<PX> *S, const job<PX> &J, int L)
+template <typename PX> CTU_NOINLINE CTU_DEV void unpark(lds<PX> *S, const job<PX> &J, int L)
 {
   const level_state &N = S->lvl[L];
   const int n = 64 >> L, lx = N.x & 63, ly = N.y & 63;
@@ -1310,7 +1747,7 @@ template <typename PX> CTU_DEV void unpark(lds<PX> *S, const job<PX> &J, int L)
   CTU_SYNC();
 }
 
-CTU_DEV void copy_models(uint32_t *dst, const uint32_t *src)
+CTU_NOINLINE CTU_DEV void copy_models(uint32_t *dst, const uint32_t *src)
 {
   PAR_FOR(i, NMODELS) dst[i] = src[i];
   CTU_SYNC();
@@ -1318,7 +1755,7 @@ CTU_DEV void copy_models(uint32_t *dst, const uint32_t *src)
 
 // the 64x64 CU tried with the mode of the first 32x32 CU after the four 32x32 areas are decided (combine_intra_cus, search.c:2082-2143).
 // Returns its cost in lvl[0].cost; D holds it afterwards, the split's result is in the scratch.
-template <typename PX> CTU_DEV void eval_cu64(lds<PX> *S, const job<PX> &J)
+template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu64(lds<PX> *S, const job<PX> &J)
 {
   const params &P = J.P;
   level_state &N = S->lvl[0];
@@ -1388,7 +1825,7 @@ template <typename PX> CTU_DEV void eval_cu64(lds<PX> *S, const job<PX> &J)
   }
 }
 // the split won after all: bring its result back
-template <typename PX> CTU_DEV void restore64(lds<PX> *S, const job<PX> &J)
+template <typename PX> CTU_NOINLINE CTU_DEV void restore64(lds<PX> *S, const job<PX> &J)
 {
   scratch *W = J.W;
   for (int color = 0; color < 3; ++color) {
@@ -1448,7 +1885,9 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
         if (L > 0) copy_models(S->cur, S->post[L]);
         ret = N.cost; entering = 0; if (L == 0) break; --L; continue;
       }
+      { CTU_T0();
       if (N.type != CU_NOTSET) park(S, J, L);
+      CTU_T1(J.W, 6); }
       // descend to the first child
       SERIAL {
         level_state &C = S->lvl[L + 1];
@@ -1489,7 +1928,9 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
       copy_models(S->post[4], S->cur);                   // temp_cabac: the models after the split (search.c:2093)
       SERIAL { S->u_d0 = N.split_cost; }
       CTU_SYNC();
+      { CTU_T0();
       eval_cu64(S, J);
+      CTU_T1(J.W, 7); }
       // post_search_cabac = the unadapted entry models; search_cabac = temp_cabac (:2140-2141)
       copy_models(S->cur, S->post[4]);
       const bool split_wins64 = N.split_cost < N.cost;        // N.cost: the 64x64 CU's (eval_cu64 ends with a barrier)
@@ -1503,8 +1944,10 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
       SERIAL N.cost = N.split_cost;
       CTU_SYNC();
     } else {
+      CTU_T0();
       if (L > 0) copy_models(S->cur, S->post[L]);
       if (ntype != CU_NOTSET) unpark(S, J, L);
+      CTU_T1(J.W, 6);
     }
     ret = N.cost;
     if (L == 0) break;
@@ -1518,7 +1961,7 @@ CTU_DEV int z_to_x(int z) { return (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4) | (
 
 // uvg_encode_coding_tree (encode_coding_tree.c:1365-1727) over the decided CTU: only which models see which bins matters here.
 // The quad tree is walked in z-order over the 4x4 units: a CU starts where a unit is aligned to its CU's size.
-template <typename PX> CTU_DEV void coder_pass(lds<PX> *S, const job<PX> &J)
+template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass(lds<PX> *S, const job<PX> &J)
 {
   const params &P = J.P;
   for (int z = 0; z < 256; ++z) {
@@ -1588,7 +2031,7 @@ template <typename PX> CTU_DEV void coder_pass(lds<PX> *S, const job<PX> &J)
 }
 
 // init_lcu_t (search.c:2230-2330): neighbouring side information and samples, the source samples, the models
-template <typename PX> CTU_DEV void load_ctu(lds<PX> *S, const job<PX> &J)
+template <typename PX> CTU_NOINLINE CTU_DEV void load_ctu(lds<PX> *S, const job<PX> &J)
 {
   const params &P = J.P;
   const int x = J.x, y = J.y, W = P.pic_w, H = P.pic_h;
@@ -1628,7 +2071,9 @@ template <typename PX> CTU_DEV void load_ctu(lds<PX> *S, const job<PX> &J)
       Sp[e] = (py + r < ph && px + q < pw) ? src[(py + r) * ss + px + q] : (PX)0;
     }
   }
+  PAR_FOR(i, 512) tab_ebits()[i] = kEntropyBits[i];
   PAR_FOR(i, NMODELS) {
+    tab_rate()[i] = k_ctx_init[3][i];
     if (J.models_in) S->coder[i] = J.models_in[i];
     else models_init_one(S->coder, i, P.qp, 2);
   }
@@ -1637,13 +2082,34 @@ template <typename PX> CTU_DEV void load_ctu(lds<PX> *S, const job<PX> &J)
     const uint32_t v = S->coder[i];
     S->cur[i] = v;
     J.models_out[i] = v;
-    if (i < 244) S->rdoq_state[i] = (uint8_t)m_state(S->coder, i);
+    if (i < 244) {
+      const int st = m_state(S->coder, i);
+      S->rdoq_state[i] = (uint8_t)st;
+      tab_rdoq_bits()[2 * i] = kEntropyBits[st << 1];
+      tab_rdoq_bits()[2 * i + 1] = kEntropyBits[(st << 1) ^ 1];
+    }
+  }
+  CTU_SYNC();
+  PAR_FOR(cfg, 16) {            // calc_last_bits (rdo.c:664-700) for every shape once: the models uvg_rdoq prices with are the CTU's
+    const int t = cfg >> 3, l2 = 2 + ((cfg >> 1) & 3), xy = cfg & 1, n = 1 << l2;
+    const int prefix_ctx[8] = {0, 0, 0, 3, 6, 10, 15, 21};
+    const int off = t ? 0 : prefix_ctx[l2];
+    const int sh = t ? clampi(n >> 3, 0, 2) : ((l2 + 1) >> 2);
+    const int base = (xy ? M_LASTY : M_LASTX) + (t ? 20 : 0) + off;
+    int32_t b = 0;
+    int ctx;
+    for (ctx = 0; ctx < group_idx(n - 1); ctx++) {
+      const int mdl = base + (ctx >> sh);
+      S->last_bits[t][l2 - 2][xy][ctx] = b + (int32_t)tab_rdoq_bits()[2 * mdl];
+      b += (int32_t)tab_rdoq_bits()[2 * mdl + 1];
+    }
+    S->last_bits[t][l2 - 2][xy][ctx] = b;
   }
   CTU_SYNC();
 }
 
 // copy_lcu_to_cu_data (search.c:2331-2377) + the models of the three checkpoints
-template <typename PX> CTU_DEV void store_ctu(lds<PX> *S, const job<PX> &J)
+template <typename PX> CTU_NOINLINE CTU_DEV void store_ctu(lds<PX> *S, const job<PX> &J)
 {
   const params &P = J.P;
   const int x = J.x, y = J.y, W = P.pic_w, H = P.pic_h;
@@ -1677,17 +2143,28 @@ template <typename PX> CTU_DEV void store_ctu(lds<PX> *S, const job<PX> &J)
 // one CTU, start to finish
 template <typename PX> CTU_DEV void run_ctu(lds<PX> *S, const job<PX> &J)
 {
+#if defined(__HIPCC__) && defined(CTU_PROFILE)
+  SERIAL { for (int i = 0; i < 24; ++i) J.W->prof[i] = 0; }
+#endif
+  CTU_T0();
+  { CTU_T0();
   build_scans(S);
   load_ctu(S, J);
   // the CTU's coefficient array starts empty (lcu->coeff = calloc, encoderstate.c:752)
   PAR_FOR(e, 6144) J.coeff[e] = 0;
   CTU_SYNC();
+  CTU_T1(J.W, 9); }
   search_ctu(S, J);
   PAR_FOR(i, NMODELS) J.models_out[NMODELS + i] = S->cur[i];
+  { CTU_T0();
   coder_pass(S, J);
+  CTU_T1(J.W, 8); }
+  { CTU_T0();
   PAR_FOR(i, NMODELS) J.models_out[2 * NMODELS + i] = S->coder[i];
   store_ctu(S, J);
   CTU_SYNC();
+  CTU_T1(J.W, 10); }
+  CTU_T1(J.W, 11);
 }
 
 }  // namespace ctu
