@@ -61,6 +61,7 @@
 #endif
 #define PAR_FOR(i, n) for (int i = CTU_TID; i < (n); i += CTU_NT)
 #define SERIAL if (CTU_TID == 0)
+#define LANE0 if (CTU_TID == 0)
 // regions run by the first wave alone, its lanes exchanging data through LDS without workgroup barriers (LDS operations of one
 // wave complete in program order; the fence only stops the compiler from moving them)
 #if defined(__HIPCC__)
@@ -130,6 +131,7 @@ template <typename PX> struct lds {
   uint16_t deps4[16];                               // per scan index of a 4x4 group: the scan indices (bits) its context template reads inside the group
   int32_t last_bits[2][4][2][12];                   // RDOQ: bit cost of the last-position prefix per (luma/chroma, log2 size - 2, x/y, group index)
   uint8_t cg_flag[64];
+  uint8_t lv_spend[1024];                           // coefficient bit cost: regular bins a scan position spends
   uint32_t part[2 * 24 * 16];                       // rough search: (satd, sad) partial sums per (listed mode, tile)
   double rs_cost[67];
   int32_t rs_list[24];
@@ -784,6 +786,7 @@ CTU_NOINLINE CTU_DEV int rdoq_serial(const uint8_t *st, const uint16_t *scan, sc
   const int cg_num = (n * n) >> 4, cgw = n >> 2;
   double cost_cg_sig[64];
   uint8_t cg_flag[64];
+  uint8_t lv_spend[1024];                           // coefficient bit cost: regular bins a scan position spends
   for (int i = 0; i < cg_num; ++i) cg_flag[i] = 0;
   for (int i = 0; i < n * n; ++i) dst[i] = 0;
   int ctx_set = 0, temp_diag = -1, temp_sum = -1;
@@ -1588,35 +1591,208 @@ template <typename PX> CTU_NOINLINE CTU_DEV void mark_deblocking(lds<PX> *S, int
   }
 }
 
+// Coefficient bit cost by the first wave (same bins, same model adaptation as coeff_bits_serial).  What is sequential in the
+// reference's coder is only the adaptation of each context model along ITS OWN bins, and the bit count is a sum of exact
+// multiples of 2^-15 (order-free).  So: every position's contexts / Rice parameters / bin values are derived by all lanes from the
+// levels (they depend on nothing else), the point where the regular-bin budget runs out is found from per-group totals, and then
+// each lane owns ONE model and walks the positions in coding order, adapting its model at the bins that use it -- two sweeps
+// (sig / gt1 / parity, then gt2) cover the <= 75 models of a block.  Lane 0 codes the last-position prefix and the group flags.
+// All 64 lanes of wave 0 call it; the returned value is the same on every lane.  Host emulation: the serial walk.
+template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32_t *m, int update, const int16_t *coeff, int n, int color)
+{
+#if !defined(__HIPCC__)
+  uint32_t tmp[NMODELS];
+  uint32_t *mm = m;
+  if (!update) { for (int i = 0; i < NMODELS; ++i) tmp[i] = m[i]; mm = tmp; }
+  return coeff_bits_serial(mm, S->scan + scan_base(ilog2_dev(n)), coeff, n, color);
+#else
+  const int lane = CTU_TID;
+  const int l2 = ilog2_dev(n), nn = n * n, cgw = n >> 2, ncg = nn >> 4, t = color ? 1 : 0;
+  const uint16_t *scan = S->scan + scan_base(l2);
+  uint32_t *recs = reinterpret_cast<uint32_t *>(S->t0);       // t0 + t1: 1024 words, free while costs are counted
+  uint8_t *cgf = S->cg_flag;                                   // per group (raster): has a level
+  int32_t *gtot = reinterpret_cast<int32_t *>(S->rq_stage);   // per group (scan order): regular bins it would spend, bit 30: a level among k = 1..15
+  // ---- last significant position, group flags ----
+  int my_last = -1;
+  for (int sp = lane; sp < nn; sp += 64) if (coeff[scan[sp]]) my_last = sp;
+  for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(my_last, o, 64); my_last = v > my_last ? v : my_last; }
+  const int last = my_last;
+  if (last < 0) return 0.0;
+  const int cg_last = last >> 4;
+  for (int g = lane; g < ncg; g += 64) {
+    int any0 = coeff[scan[g * 16]] != 0, anyr = 0;
+    for (int k = 1; k < 16; ++k) anyr |= coeff[scan[g * 16 + k]] != 0;
+    const int f = scan[g * 16];
+    cgf[((f >> l2) >> 2) * cgw + ((f & (n - 1)) >> 2)] = (uint8_t)(any0 | anyr);
+    gtot[g] = anyr << 30;
+  }
+  WSYNC();
+  // ---- per position: level, contexts, Rice parameters, whether its sig flag is coded, the regular bins it would spend ----
+  for (int sp = lane; sp <= last; sp += 64) {
+    const int blk = scan[sp], py = blk >> l2, px = blk - (py << l2), g = sp >> 4;
+    const int a = iabs_((int)coeff[blk]);
+    int diag, tsum;
+    int ctx_sig = sig_ctx_abs(coeff, px, py, n, color, &diag, &tsum);
+    if (t && ctx_sig > 7) ctx_sig = 7;
+    int ofs = 0;
+    if (sp != last) ofs = ((tsum < 4 ? tsum : 4) + 1) + (!diag ? (color == 0 ? 15 : 5) : color == 0 ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0);
+    const int r4 = go_rice_par((unsigned)abs_sum_tmpl(coeff, px, py, n, 4)), r0 = go_rice_par((unsigned)abs_sum_tmpl(coeff, px, py, n, 0));
+    const int inferred = (sp & 15) == 0 && g != 0 && g != cg_last && !((gtot[g] >> 30) & 1);
+    const int sig_coded = sp != last && !inferred;
+    const int spend = sig_coded + (a ? 1 + (a > 1 ? 2 : 0) : 0);
+    recs[sp] = (uint32_t)(a > 0xffff ? 0xffff : a) | (uint32_t)ctx_sig << 16 | (uint32_t)ofs << 20 | (uint32_t)r4 << 25 | (uint32_t)r0 << 27 |
+               (uint32_t)sig_coded << 29;
+    S->lv_spend[sp] = (uint8_t)spend;
+  }
+  WSYNC();
+  for (int g = lane; g <= cg_last; g += 64) {
+    int tot = 0;
+    for (int k = 0; k < 16; ++k) if (g * 16 + k <= last) tot += S->lv_spend[g * 16 + k];
+    gtot[g] = (gtot[g] & (1 << 30)) | tot;
+  }
+  WSYNC();
+  // ---- where the regular-bin budget runs out (lane 0; whole groups while they fit) ----
+  if (lane == 0) {
+    int rb = (nn * 28) >> 4, sw = -1;
+    for (int g = cg_last; g >= 0 && sw < 0; --g) {
+      const int f = scan[g * 16];
+      const int sig_grp = cgf[((f >> l2) >> 2) * cgw + ((f & (n - 1)) >> 2)] || g == 0;
+      if (!sig_grp) continue;
+      const int tot = gtot[g] & 0xffff;
+      if (rb - tot >= 4) { rb -= tot; continue; }
+      for (int sp = (g == cg_last ? last : g * 16 + 15); sp >= g * 16; --sp) {
+        if (rb < 4) { sw = sp; break; }
+        rb -= S->lv_spend[sp];
+      }
+      if (sw < 0 && rb < 4) sw = g * 16 - 1;          // ran out exactly at the group's end: everything below is bypass-coded
+    }
+    S->rq_i[8] = sw;
+  }
+  WSYNC();
+  const int sw = S->rq_i[8];          // scan positions <= sw are bypass-coded
+  // ---- the models, one per lane, along the positions in coding order ----
+  unsigned long long q15 = 0;         // sum of bit costs in units of 2^-15
+  for (int sweep = 0; sweep < 2; ++sweep) {
+    // roles: sweep 0: lanes 0..11 sig, 12..32 gt1, 33..53 parity; sweep 1: lanes 0..20 gt2
+    int role = -1, k = 0;
+    if (sweep == 0) { if (lane < 12) { role = 0; k = lane; } else if (lane < 33) { role = 1; k = lane - 12; } else if (lane < 54) { role = 2; k = lane - 33; } }
+    else if (lane < 21) { role = 3; k = lane; }
+    const int nk = role == 0 ? (t ? 8 : 12) : (t ? 11 : 21);
+    if (role >= 0 && k >= nk) role = -1;
+    const int model = role < 0 ? 0 : (role == 0 ? M_SIG + 12 * t : role == 1 ? M_GT1 + 21 * t : role == 2 ? M_PAR + 21 * t : M_GT2 + 21 * t) + k;
+    uint32_t st = m[model];
+    const int r0 = kRate[model] >> 4, r1 = kRate[model] & 15;
+    uint32_t acc = 0;
+    int prev_g = -1, grp_on = 0;
+    for (int sp = last; sp > sw; --sp) {
+      const int g = sp >> 4;
+      if (g != prev_g) { const int f = scan[g * 16]; grp_on = cgf[((f >> l2) >> 2) * cgw + ((f & (n - 1)) >> 2)] || g == 0; prev_g = g; }
+      if (!grp_on) { sp = g * 16; continue; }
+      const uint32_t rec = recs[sp];
+      const int a = (int)(rec & 0xffff);
+      int hit = 0, bin = 0;
+      if (role == 0) { hit = ((rec >> 29) & 1) && (int)((rec >> 16) & 15) == k; bin = a != 0; }
+      else if (role == 1) { hit = a != 0 && (int)((rec >> 20) & 31) == k; bin = a > 1; }
+      else if (role == 2) { hit = a > 1 && (int)((rec >> 20) & 31) == k; bin = a & 1; }
+      else if (role == 3) { hit = a > 1 && (int)((rec >> 20) & 31) == k; bin = a >= 4; }
+      if (hit) {
+        uint32_t s0 = st & 0xffffu, s1 = st >> 16;
+        acc += tab_ebits()[(((s0 + s1) >> 8) << 1) ^ (uint32_t)bin];
+        s0 -= (s0 >> r0) & 0x7fe0u;
+        s1 -= (s1 >> r1) & 0x7ffeu;
+        if (bin) { s0 += (0x7fffu >> r0) & 0x7fe0u; s1 += (0x7fffu >> r1) & 0x7ffeu; }
+        st = (s0 & 0xffffu) | (s1 << 16);
+      }
+    }
+    if (role >= 0 && update) m[model] = st;
+    q15 += acc;
+  }
+  // ---- bypass-coded parts: remainders, bypass positions, signs ----
+  int ibits = 0;
+  for (int sp = lane; sp <= last; sp += 64) {
+    const int g = sp >> 4, f = scan[g * 16];
+    if (!(cgf[((f >> l2) >> 2) * cgw + ((f & (n - 1)) >> 2)] || g == 0)) continue;
+    const uint32_t rec = recs[sp];
+    const unsigned a = (unsigned)iabs_((int)coeff[scan[sp]]);
+    if (sp > sw) { if (a >= 4) ibits += coeff_remain_bits((a - 4) >> 1, (rec >> 25) & 3, 5); }
+    else {
+      const unsigned rice = (rec >> 27) & 3, pos0 = 1u << rice;
+      ibits += coeff_remain_bits(a == 0 ? pos0 : (a <= pos0 ? a - 1 : a), rice, 5);
+    }
+    ibits += a != 0;
+  }
+  // ---- lane 0: last-position prefix and the group flags (their models are nobody else's) ----
+  if (lane == 0) {
+    double bits = 0;
+    uint32_t *mk = m;
+    if (!update) {
+      // counting only: these bins still adapt their models WITHIN the block (the reference counts on a copy) -- work on a copy
+      // of the few models involved (post[0] is free whenever nothing is kept: the 64x64 candidate at depth 0)
+      mk = S->post[0];
+      for (int i = 0; i < 4; ++i) mk[M_SIGGRP + i] = m[M_SIGGRP + i];
+      for (int i = M_LASTX; i < M_CBF_LUMA; ++i) mk[i] = m[i];
+    }
+    const int pos_last = scan[last];
+    const int last_y = pos_last >> l2, last_x = pos_last - (last_y << l2);
+    const int prefix_ctx[8] = {0, 0, 0, 3, 6, 10, 15, 21};
+    const int off = t ? 0 : prefix_ctx[l2];
+    const int sh = t ? clampi(n >> 3, 0, 2) : ((l2 + 1) >> 2);
+    const int bx = M_LASTX + 20 * t + off, by = M_LASTY + 20 * t + off;
+    const int gx = group_idx(last_x), gy = group_idx(last_y), gmax = group_idx(n - 1);
+    int k = 0;
+    for (; k < gx; k++) m_code(mk, 1, bx + (k >> sh), 1, bits);
+    if (gx < gmax) m_code(mk, 1, bx + (k >> sh), 0, bits);
+    k = 0;
+    for (; k < gy; k++) m_code(mk, 1, by + (k >> sh), 1, bits);
+    if (gy < gmax) m_code(mk, 1, by + (k >> sh), 0, bits);
+    if (gx > 3) ibits += (gx - 2) / 2;
+    if (gy > 3) ibits += (gy - 2) / 2;
+    for (int g = cg_last - 1; g >= 1; --g) {
+      const int f = scan[g * 16];
+      const int cx = (f & (n - 1)) >> 2, cy = (f >> l2) >> 2, cb = cy * cgw + cx;
+      unsigned right = 0, lower = 0;
+      if (cx + 1 < cgw) right = cgf[cb + 1];
+      if (cy + 1 < cgw) lower = cgf[cb + cgw];
+      m_code(mk, 1, M_SIGGRP + 2 * t + ((right || lower) ? 1 : 0), cgf[cb] != 0, bits);
+    }
+    q15 += (unsigned long long)(bits * 32768.0);        // exact: a sum of table entries / 2^15
+  }
+  // with update == 0 lane 0's m_code calls above must not move the models either: m_code honours the flag
+  for (int o = 32; o >= 1; o >>= 1) {
+    q15 += __shfl_xor(q15, o, 64);
+    ibits += __shfl_xor(ibits, o, 64);
+  }
+  WSYNC();
+  return (double)q15 / 32768.0 + (double)ibits;
+#endif
+}
+
 // the transform-tree part of the RD cost of one <= 32 block whose levels are in S->lv (cu_rd_cost_tr_split_accurate, search.c:724-986);
 // red[0..2]: SSD of y, u, v.  lane 0.  update: state->search_cabac.update.
 template <typename PX> CTU_NOINLINE CTU_DEV double tr_cost(lds<PX> *S, const params &P, int update, int n, int cbf, int has_chroma, int cn)
 {
-  double coeff_bits = 0, luma_bits = 0, chroma_bits = 0;
+  // called by all lanes of the first wave; the flag bins are lane 0's, the coefficient costs the wave's
+  double coeff_bits_ = 0, luma_bits = 0, chroma_bits = 0;
   const int cb_y = cbf & 1, cb_u = (cbf >> 1) & 1, cb_v = (cbf >> 2) & 1;
-  if (has_chroma) {
-    m_code(S->cur, update, M_CBF_CB + 0, cb_u, chroma_bits);
-    m_code(S->cur, update, M_CBF_CR + cb_u, cb_v, chroma_bits);
+  LANE0 {
+    if (has_chroma) {
+      m_code(S->cur, update, M_CBF_CB + 0, cb_u, chroma_bits);
+      m_code(S->cur, update, M_CBF_CR + cb_u, cb_v, chroma_bits);
+    }
+    m_code(S->cur, update, M_CBF_LUMA + 0, cb_y, luma_bits);
   }
-  m_code(S->cur, update, M_CBF_LUMA + 0, cb_y, luma_bits);
+  WSYNC();
   const unsigned luma_ssd = (unsigned)S->red[0];
   // uvg_get_coeff_cost counts on a copy of the models that is kept only when update is set (rdo.c:322-356)
-  uint32_t *mm = S->cur;
-  if (!update) { mm = S->post[0]; }       // (scratch copy: post[0] is free whenever update is 0 -- the 64x64 candidate at depth 0)
-  if (cb_y) {
-    if (!update) for (int i = 0; i < NMODELS; ++i) mm[i] = S->cur[i];
-    coeff_bits += coeff_bits_serial(mm, S->scan + scan_base(ilog2_dev(n)), S->lv[0], n, 0);
-  }
+  if (cb_y) coeff_bits_ += coeff_bits(S, S->cur, update, S->lv[0], n, 0);
   unsigned chroma_ssd = 0;
   if (has_chroma) {
     const unsigned ssd_u = (unsigned)((unsigned)S->red[1] * P.cw_u), ssd_v = (unsigned)((unsigned)S->red[2] * P.cw_v);
     chroma_ssd = ssd_u + ssd_v;
-    if (!update) for (int i = 0; i < NMODELS; ++i) mm[i] = S->cur[i];
-    chroma_bits += coeff_bits_serial(mm, S->scan + scan_base(ilog2_dev(cn)), S->lv[1], cn, 1);
-    if (!update) for (int i = 0; i < NMODELS; ++i) mm[i] = S->cur[i];
-    chroma_bits += coeff_bits_serial(mm, S->scan + scan_base(ilog2_dev(cn)), S->lv[2], cn, 2);
+    chroma_bits += coeff_bits(S, S->cur, update, S->lv[1], cn, 1);
+    chroma_bits += coeff_bits(S, S->cur, update, S->lv[2], cn, 2);
   }
-  const double bits = luma_bits + coeff_bits;
+  const double bits = luma_bits + coeff_bits_;
   return luma_ssd * 1.0 + chroma_ssd * 1.0 + (bits + chroma_bits) * P.lambda;
 }
 
@@ -1675,31 +1851,37 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
   ssd_block(S, 0, lx, ly, n, 0);
   CTU_T1(J.W, 4); }
   CTU_T0();
-  SERIAL {
-    cu4 *c = cu_at(S, lx, ly);
-    c->cbf = (uint8_t)(cbf & 1);
-    if (has_chroma) {
-      if (!sep) c->cbf = (uint8_t)cbf;
-      else {
-        // the area's chroma flags sit at its first entry and are copied to all four (lcu_fill_chroma_cbfs), with the chroma mode and
-        // chroma size of this, the last, CU (lcu_fill_chroma_cu_info, search.c:355-400)
-        for (int k = 0; k < 4; ++k) {
-          cu4 *q = cu_at(S, (cx & 63) + (k & 1) * 4, (cy & 63) + (k >> 1) * 4);
-          q->cbf = (uint8_t)((q->cbf & 1) | (cbf & 6));
-          q->mode_chroma = (int8_t)mode;
-          q->log2_c = 2;
+  if (CTU_IN_WAVE0) {
+    double bits = 0;
+    LANE0 {
+      cu4 *c = cu_at(S, lx, ly);
+      c->cbf = (uint8_t)(cbf & 1);
+      if (has_chroma) {
+        if (!sep) c->cbf = (uint8_t)cbf;
+        else {
+          // the area's chroma flags sit at its first entry and are copied to all four (lcu_fill_chroma_cbfs), with the chroma mode and
+          // chroma size of this, the last, CU (lcu_fill_chroma_cu_info, search.c:355-400)
+          for (int k = 0; k < 4; ++k) {
+            cu4 *q = cu_at(S, (cx & 63) + (k & 1) * 4, (cy & 63) + (k >> 1) * 4);
+            q->cbf = (uint8_t)((q->cbf & 1) | (cbf & 6));
+            q->mode_chroma = (int8_t)mode;
+            q->log2_c = 2;
+          }
         }
       }
+      // uvg_mock_encode_coding_unit with search_cabac.update = 1 (search.c:1700-1716)
+      split_flag_bits(S, P, S->cur, 1, x, y, lx, ly, n, 0, bits);
+      luma_mode_bits(S, S->cur, 1, x, y, lx, ly, n, mode, bits);
+      if (has_chroma) chroma_mode_bits(S->cur, 1, mode, mode, bits);
     }
-    // uvg_mock_encode_coding_unit + cu_rd_cost_tr_split_accurate with search_cabac.update = 1 (search.c:1700-1736)
-    double bits = 0;
-    split_flag_bits(S, P, S->cur, 1, x, y, lx, ly, n, 0, bits);
-    luma_mode_bits(S, S->cur, 1, x, y, lx, ly, n, mode, bits);
-    if (has_chroma) chroma_mode_bits(S->cur, 1, mode, mode, bits);
-    double cost = bits * P.lambda;
-    cost += tr_cost(S, P, 1, n, sep ? ((cbf & 1) | (cu_at(S, lx, ly)->cbf & 6)) : cbf, has_chroma, cn);
-    mark_deblocking(S, x, y, lx, ly, n, sep, has_chroma);
-    N.cost = cost; N.type = CU_INTRA; N.mode = mode; N.cbf = cu_at(S, lx, ly)->cbf;
+    WSYNC();
+    const double trc = tr_cost(S, P, 1, n, cbf, has_chroma, cn);       // cu_rd_cost_tr_split_accurate (:1718)
+    LANE0 {
+      double cost = bits * P.lambda;
+      cost += trc;
+      mark_deblocking(S, x, y, lx, ly, n, sep, has_chroma);
+      N.cost = cost; N.type = CU_INTRA; N.mode = mode; N.cbf = cu_at(S, lx, ly)->cbf;
+    }
   }
   CTU_SYNC();
   CTU_T1(J.W, 5);
@@ -1797,28 +1979,34 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu64(lds<PX> *S, const job
     }
     CTU_SYNC();
     ssd_block(S, 0, lx, ly, 32, 0); ssd_block(S, 1, lx, ly, 32, 1); ssd_block(S, 2, lx, ly, 32, 2);
-    SERIAL {
-      if (i == 0) {
-        double bits = 0;
-        split_flag_bits(S, P, S->cur, 0, x, y, 0, 0, 64, 0, bits);
-        double mode_bits = 0;
-        {   // calc_mode_bits (search.c:988-1003): the luma mode on a copy of the models, the chroma mode without adaptation
-          for (int k = 0; k < NMODELS; ++k) S->post[0][k] = S->cur[k];
-          luma_mode_bits(S, S->post[0], 0, x, y, 0, 0, 64, mode, mode_bits);
-          if (mode_chroma == mode) mode_bits += m_fbits(S->cur, M_CHROMA_PRED, 0);
-          else mode_bits += 2.0 + m_fbits(S->cur, M_CHROMA_PRED, 1);
+    if (CTU_IN_WAVE0) {
+      LANE0 {
+        if (i == 0) {
+          double bits = 0;
+          split_flag_bits(S, P, S->cur, 0, x, y, 0, 0, 64, 0, bits);
+          double mode_bits = 0;
+          {   // calc_mode_bits (search.c:988-1003): the luma mode on a copy of the models, the chroma mode without adaptation
+            for (int k = 0; k < NMODELS; ++k) S->post[0][k] = S->cur[k];
+            luma_mode_bits(S, S->post[0], 0, x, y, 0, 0, 64, mode, mode_bits);
+            if (mode_chroma == mode) mode_bits += m_fbits(S->cur, M_CHROMA_PRED, 0);
+            else mode_bits += 2.0 + m_fbits(S->cur, M_CHROMA_PRED, 1);
+          }
+          mode_bits += bits;
+          S->u_d0 = mode_bits * P.lambda;
+          S->u_d1 = 0;
         }
-        mode_bits += bits;
-        S->u_d0 = mode_bits * P.lambda;
-        S->u_d1 = 0;
       }
-      S->u_d1 += tr_cost(S, P, 0, 32, cu_at(S, lx, ly)->cbf, 1, 16);
-      if (i == 3) {
-        double c2 = 0;
-        c2 += S->u_d0;
-        c2 += S->u_d1 + 0 * P.lambda;          // the sum of the four blocks + luma_bits (0) * lambda (search.c:779)
-        N.cost = c2;
-        mark_deblocking(S, x, y, 0, 0, 64, 0, 1);
+      WSYNC();
+      const double trc = tr_cost(S, P, 0, 32, cu_at(S, lx, ly)->cbf, 1, 16);
+      LANE0 {
+        S->u_d1 += trc;
+        if (i == 3) {
+          double c2 = 0;
+          c2 += S->u_d0;
+          c2 += S->u_d1 + 0 * P.lambda;          // the sum of the four blocks + luma_bits (0) * lambda (search.c:779)
+          N.cost = c2;
+          mark_deblocking(S, x, y, 0, 0, 64, 0, 1);
+        }
       }
     }
     CTU_SYNC();
@@ -1991,38 +2179,44 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass(lds<PX> *S, const jo
         }
       }
       CTU_SYNC();
-      SERIAL {
+      if (CTU_IN_WAVE0) {
         uint32_t *m = S->coder;
         double dummy = 0;
-        if (tu == 0) {
-          // split flags of the enclosing quad-tree nodes that begin here, then this CU's own
-          for (int d = 0; (64 >> d) > n; ++d) {
-            const int s = 64 >> d;
-            if (!(lx & (s - 1)) && !(ly & (s - 1))) split_flag_bits(S, P, m, 1, x, y, lx, ly, s, 1, dummy);
-          }
-          split_flag_bits(S, P, m, 1, x, y, lx, ly, n, 0, dummy);
-          luma_mode_bits(S, m, 1, x, y, lx, ly, n, c->mode, dummy);
-          if (!sep) chroma_mode_bits(m, 1, c->mode_chroma, c->mode, dummy);
-        }
         const int cb_y = t->cbf & 1, cb_u = (t->cbf >> 1) & 1, cb_v = (t->cbf >> 2) & 1;
-        if (!sep) {
-          m_code(m, 1, M_CBF_CB + 0, cb_u, dummy);
-          m_code(m, 1, M_CBF_CR + cb_u, cb_v, dummy);
+        LANE0 {
+          if (tu == 0) {
+            // split flags of the enclosing quad-tree nodes that begin here, then this CU's own
+            for (int d = 0; (64 >> d) > n; ++d) {
+              const int s = 64 >> d;
+              if (!(lx & (s - 1)) && !(ly & (s - 1))) split_flag_bits(S, P, m, 1, x, y, lx, ly, s, 1, dummy);
+            }
+            split_flag_bits(S, P, m, 1, x, y, lx, ly, n, 0, dummy);
+            luma_mode_bits(S, m, 1, x, y, lx, ly, n, c->mode, dummy);
+            if (!sep) chroma_mode_bits(m, 1, c->mode_chroma, c->mode, dummy);
+          }
+          if (!sep) {
+            m_code(m, 1, M_CBF_CB + 0, cb_u, dummy);
+            m_code(m, 1, M_CBF_CR + cb_u, cb_v, dummy);
+          }
+          m_code(m, 1, M_CBF_LUMA + 0, cb_y, dummy);      // luma_cbf_ctx stays 0: one transform unit per CU, or a CU that is not a TU
         }
-        m_code(m, 1, M_CBF_LUMA + 0, cb_y, dummy);      // luma_cbf_ctx stays 0: one transform unit per CU, or a CU that is not a TU
-        if (cb_y) (void)coeff_bits_serial(m, S->scan + scan_base(ilog2_dev(tn)), S->lv[0], tn, 0);
+        WSYNC();
+        if (cb_y) (void)coeff_bits(S, m, 1, S->lv[0], tn, 0);
         if (!sep) {
-          if (cb_u) (void)coeff_bits_serial(m, S->scan + scan_base(ilog2_dev(tn >> 1)), S->lv[1], tn >> 1, 1);
-          if (cb_v) (void)coeff_bits_serial(m, S->scan + scan_base(ilog2_dev(tn >> 1)), S->lv[2], tn >> 1, 2);
+          if (cb_u) (void)coeff_bits(S, m, 1, S->lv[1], tn >> 1, 1);
+          if (cb_v) (void)coeff_bits(S, m, 1, S->lv[2], tn >> 1, 2);
         } else if (last4) {
           // the area's chroma after its last luma CU: mode (the co-located luma CU is this one), cbfs of the area's first entry, levels
           const cu4 *a = cu_at(S, lx & ~7, ly & ~7);
           const int au = (a->cbf >> 1) & 1, av = (a->cbf >> 2) & 1;
-          chroma_mode_bits(m, 1, c->mode_chroma, c->mode, dummy);
-          m_code(m, 1, M_CBF_CB + 0, au, dummy);
-          m_code(m, 1, M_CBF_CR + au, av, dummy);
-          if (au) (void)coeff_bits_serial(m, S->scan + scan_base(2), S->lv[1], 4, 1);
-          if (av) (void)coeff_bits_serial(m, S->scan + scan_base(2), S->lv[2], 4, 2);
+          LANE0 {
+            chroma_mode_bits(m, 1, c->mode_chroma, c->mode, dummy);
+            m_code(m, 1, M_CBF_CB + 0, au, dummy);
+            m_code(m, 1, M_CBF_CR + au, av, dummy);
+          }
+          WSYNC();
+          if (au) (void)coeff_bits(S, m, 1, S->lv[1], 4, 1);
+          if (av) (void)coeff_bits(S, m, 1, S->lv[2], 4, 2);
         }
       }
       CTU_SYNC();
