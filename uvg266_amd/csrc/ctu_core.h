@@ -111,7 +111,7 @@ template <> struct px_info<uint16_t> { enum { depth = 10, maxv = 1023 }; };
 // LDS image of a workgroup
 template <typename PX> struct lds {
   PX Dy[65 * PY], Du[33 * PC], Dv[33 * PC];         // decided planes, index (y + 1) * pitch + x + 1
-  PX Sy[LCU * LCU], Su[LCU_C * LCU_C], Sv[LCU_C * LCU_C];
+  PX Sy[LCU * LCU];                                 // the CTU's luma source (the chroma source is read from the picture: two parallel passes per block)
   PX cand_px[2016];
   int16_t cand_co[2016];
   cu4 cu[17 * 17];                                  // index (y4 + 1) * 17 + x4 + 1
@@ -125,14 +125,14 @@ template <typename PX> struct lds {
   alignas(16) double rq_cc[256], rq_cs[256], rq_c0[256];   // RDOQ: cost of the kept level / of its significance flag / of level 0, per scan position (<= 16x16)
   double rq_stage[3 * 16];                          // ... of the coefficient group in flight
   int32_t rq_i[16];                                 // RDOQ scalars: 0 last_scanpos, 1 any level, 2..: per-lane partials
-  int16_t lv[3][1024];                              // levels of the TUs being evaluated (y, u, v)
+  int16_t lv0[1024], lv1[256], lv2[256];            // levels of the transform blocks being evaluated (y, u, v)
   uint16_t scan[1024 + 256 + 64 + 16];              // coefficient scans of the four square shapes
   uint8_t inv4[16];                                 // scan index of the 4x4 group's raster position y * 4 + x
   uint16_t deps4[16];                               // per scan index of a 4x4 group: the scan indices (bits) its context template reads inside the group
   int32_t last_bits[2][4][2][12];                   // RDOQ: bit cost of the last-position prefix per (luma/chroma, log2 size - 2, x/y, group index)
   uint8_t cg_flag[64];
   uint8_t lv_spend[1024];                           // coefficient bit cost: regular bins a scan position spends
-  uint32_t part[2 * 24 * 16];                       // rough search: (satd, sad) partial sums per (listed mode, tile)
+  uint32_t part[2 * 18 * 16];                       // rough search: (satd, sad) partial sums per (listed mode, tile)
   double rs_cost[67];
   int32_t rs_list[24];
   int32_t red[8], partial[256];                     // reductions
@@ -243,6 +243,7 @@ template <typename PX> CTU_DEV void build_scans(lds<PX> *S)
 }
 
 // ------------------------------------------------------------------------------------------- reference construction ------
+template <typename PX> CTU_DEV int16_t *lv_of(lds<PX> *S, int color) { return color == 0 ? S->lv0 : (color == 1 ? S->lv1 : S->lv2); }
 template <typename PX> CTU_DEV PX *plane(lds<PX> *S, int color) { return color == 0 ? S->Dy : (color == 1 ? S->Du : S->Dv); }
 CTU_DEV int pitch_of(int color) { return color == 0 ? PY : PC; }
 template <typename PX> CTU_DEV cu4 *cu_at(lds<PX> *S, int lx, int ly) { return &S->cu[((ly >> 2) + 1) * 17 + (lx >> 2) + 1]; }   // lx, ly >= -4
@@ -1442,6 +1443,15 @@ template <typename PX> struct job {
   int x, y;                              // CTU origin
 };
 
+// the source samples of a block of `color` at CTU-local (bx, by) (in that plane's samples): luma from LDS, chroma from the picture
+// (blocks never reach outside the picture: a CU is only coded when it lies inside)
+template <typename PX> CTU_DEV const PX *src_block(lds<PX> *S, const job<PX> &J, int color, int bx, int by)
+{
+  if (color == 0) return S->Sy + by * LCU + bx;
+  const PX *p = color == 1 ? J.src_u : J.src_v;
+  return p + (size_t)((J.y >> 1) + by) * J.src_stride_c + (J.x >> 1) + bx;
+}
+
 CTU_DEV int co_off(int color) { return color == 0 ? 0 : (color == 1 ? 4096 : 5120); }
 CTU_DEV int cand_px_off(int L, int color)      // L = 1..3
 {
@@ -1453,21 +1463,22 @@ CTU_DEV int cand_px_off(int L, int color)      // L = 1..3
 template <typename PX> CTU_DEV int scaled_qp(const params &P, int color) { return (color == 0 ? P.qp : P.qp_c) + 6 * ((int)px_info<PX>::depth - 8); }
 
 // predict + uvg_quantize_residual (quant-generic.c:460-612, RDOQ branch) of one transform block straight into D; its levels stay in
-// S->lv[color] and go to the CTU's coefficient array.  (x, y) / (lx, ly): luma position, n: luma size of the area.  -> has_coeffs
+// lv_of(S, color) and go to the CTU's coefficient array.  (x, y) / (lx, ly): luma position, n: luma size of the area.  -> has_coeffs
 template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<PX> &J, int color, int x, int y, int lx, int ly, int n, int mode, int cbf_u)
 {
   const int c = color != 0, w = n >> c, l2 = ilog2_dev(w);
   const int pit = pitch_of(color), spit = c ? LCU_C : LCU;
   const int bx = lx >> c, by = ly >> c;
   PX *D = plane(S, color) + (by + 1) * pit + bx + 1;
-  const PX *Sp = (color == 0 ? S->Sy : color == 1 ? S->Su : S->Sv) + by * spit + bx;
+  const PX *Sp = src_block(S, J, color, bx, by);
+  const int sps = c ? J.src_stride_c : LCU;        // pitch of the source view
   const int depth = (int)px_info<PX>::depth;
   { CTU_T0();
   build_refs(S, J.P, color, x, y, lx, ly, n);
   predict_block(S, mode, color, w, D, pit);
   CTU_T1(J.W, 1); }
   { CTU_T0();
-  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); S->t0[e] = (int16_t)((int)Sp[r * spit + q] - (int)D[r * pit + q]); }
+  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); S->t0[e] = (int16_t)((int)Sp[r * sps + q] - (int)D[r * pit + q]); }
   CTU_SYNC();
   fwd_pass(w, S->t0, S->t1, l2 - 1 + depth - 8);
   fwd_pass(w, S->t1, S->t2, l2 + 6);
@@ -1477,19 +1488,19 @@ template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<P
   if (CTU_IN_WAVE0) {
     // chroma blocks: state->c_lambda as uvg_quantize_lcu_residual replaces it (transform.c:1575)
     const double lambda = c ? J.P.c_lambda_tu : J.P.lambda;
-    rdoq_wave(S, J.W, S->t2, S->lv[color], w, color, cbf_u, qps, lambda, depth);
+    rdoq_wave(S, J.W, S->t2, lv_of(S, color), w, color, cbf_u, qps, lambda, depth);
   }
   CTU_SYNC();
   CTU_T1(J.W, 3);
   const int has = S->rq_i[1];
   int16_t *co = J.coeff + co_off(color) + by * spit + bx;
-  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); co[r * spit + q] = S->lv[color][e]; }
+  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); co[r * spit + q] = lv_of(S, color)[e]; }
   if (has) {
     const int transform_shift = 15 - depth - l2;
     const int shift = 20 - 14 - transform_shift;
     const int32_t scale = (int32_t)kInvQuantScales[qps % 6] << (qps / 6);
     const int32_t add = 1 << (shift - 1);
-    PAR_FOR(e, w * w) S->t0[e] = (int16_t)clampi((S->lv[color][e] * scale + add) >> shift, -32768, 32767);      // uvg_dequant, quant-generic.c:618-669
+    PAR_FOR(e, w * w) S->t0[e] = (int16_t)clampi((lv_of(S, color)[e] * scale + add) >> shift, -32768, 32767);      // uvg_dequant, quant-generic.c:618-669
     CTU_SYNC();
     inv_pass(w, S->t0, S->t1, 7);
     inv_pass(w, S->t1, S->t0, 12 - (depth - 8));
@@ -1504,14 +1515,15 @@ template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<P
 }
 
 // uvg_pixels_calc_ssd of a w x w block of D against the source, into S->red[slot] (valid after the barrier)
-template <typename PX> CTU_NOINLINE CTU_DEV void ssd_block(lds<PX> *S, int color, int lx, int ly, int n, int slot)
+template <typename PX> CTU_NOINLINE CTU_DEV void ssd_block(lds<PX> *S, const job<PX> &J, int color, int lx, int ly, int n, int slot)
 {
   const int c = color != 0, w = n >> c, l2 = ilog2_dev(w);
   const int pit = pitch_of(color), spit = c ? LCU_C : LCU;
   const PX *D = plane(S, color) + ((ly >> c) + 1) * pit + (lx >> c) + 1;
-  const PX *Sp = (color == 0 ? S->Sy : color == 1 ? S->Su : S->Sv) + (ly >> c) * spit + (lx >> c);
+  const PX *Sp = src_block(S, J, color, lx >> c, ly >> c);
+  const int sps = c ? J.src_stride_c : LCU;
   int acc = 0;
-  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); const int d = (int)Sp[r * spit + q] - (int)D[r * pit + q]; acc += d * d; }
+  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); const int d = (int)Sp[r * sps + q] - (int)D[r * pit + q]; acc += d * d; }
   S->partial[CTU_TID] = acc;
   CTU_SYNC();
   SERIAL {
@@ -1784,13 +1796,13 @@ template <typename PX> CTU_NOINLINE CTU_DEV double tr_cost(lds<PX> *S, const par
   WSYNC();
   const unsigned luma_ssd = (unsigned)S->red[0];
   // uvg_get_coeff_cost counts on a copy of the models that is kept only when update is set (rdo.c:322-356)
-  if (cb_y) coeff_bits_ += coeff_bits(S, S->cur, update, S->lv[0], n, 0);
+  if (cb_y) coeff_bits_ += coeff_bits(S, S->cur, update, lv_of(S, 0), n, 0);
   unsigned chroma_ssd = 0;
   if (has_chroma) {
     const unsigned ssd_u = (unsigned)((unsigned)S->red[1] * P.cw_u), ssd_v = (unsigned)((unsigned)S->red[2] * P.cw_v);
     chroma_ssd = ssd_u + ssd_v;
-    chroma_bits += coeff_bits(S, S->cur, update, S->lv[1], cn, 1);
-    chroma_bits += coeff_bits(S, S->cur, update, S->lv[2], cn, 2);
+    chroma_bits += coeff_bits(S, S->cur, update, lv_of(S, 1), cn, 1);
+    chroma_bits += coeff_bits(S, S->cur, update, lv_of(S, 2), cn, 2);
   }
   const double bits = luma_bits + coeff_bits_;
   return luma_ssd * 1.0 + chroma_ssd * 1.0 + (bits + chroma_bits) * P.lambda;
@@ -1843,12 +1855,12 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
     const int cv = recon_tu(S, J, 2, cx, cy, cx & 63, cy & 63, area, mode, cu);
     cbf |= cu << 1 | cv << 2;
     { CTU_T0();
-    ssd_block(S, 1, cx & 63, cy & 63, area, 1);
-    ssd_block(S, 2, cx & 63, cy & 63, area, 2);
+    ssd_block(S, J, 1, cx & 63, cy & 63, area, 1);
+    ssd_block(S, J, 2, cx & 63, cy & 63, area, 2);
     CTU_T1(J.W, 4); }
   }
   { CTU_T0();
-  ssd_block(S, 0, lx, ly, n, 0);
+  ssd_block(S, J, 0, lx, ly, n, 0);
   CTU_T1(J.W, 4); }
   CTU_T0();
   if (CTU_IN_WAVE0) {
@@ -1975,10 +1987,10 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu64(lds<PX> *S, const job
     for (int color = 0; color < 3; ++color) {
       const int c = color != 0, w = 32 >> c, l2 = c ? 4 : 5, spit = c ? LCU_C : LCU;
       const int16_t *co = J.coeff + co_off(color) + (ly >> c) * spit + (lx >> c);
-      PAR_FOR(e, w * w) S->lv[color][e] = CTU_GLOAD(&co[(e >> l2) * spit + (e & (w - 1))]);
+      PAR_FOR(e, w * w) lv_of(S, color)[e] = CTU_GLOAD(&co[(e >> l2) * spit + (e & (w - 1))]);
     }
     CTU_SYNC();
-    ssd_block(S, 0, lx, ly, 32, 0); ssd_block(S, 1, lx, ly, 32, 1); ssd_block(S, 2, lx, ly, 32, 2);
+    ssd_block(S, J, 0, lx, ly, 32, 0); ssd_block(S, J, 1, lx, ly, 32, 1); ssd_block(S, J, 2, lx, ly, 32, 2);
     if (CTU_IN_WAVE0) {
       LANE0 {
         if (i == 0) {
@@ -2168,13 +2180,13 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass(lds<PX> *S, const jo
       {
         const int16_t *co = J.coeff + tly * LCU + tlx;
         const int l2 = ilog2_dev(tn);
-        PAR_FOR(e, tn * tn) S->lv[0][e] = CTU_GLOAD(&co[(e >> l2) * LCU + (e & (tn - 1))]);
+        PAR_FOR(e, tn * tn) lv_of(S, 0)[e] = CTU_GLOAD(&co[(e >> l2) * LCU + (e & (tn - 1))]);
         if (!sep || last4) {
           const int cw = sep ? 4 : tn >> 1, cl2 = ilog2_dev(cw);
           const int cbx = (sep ? (tlx & ~7) : tlx) >> 1, cby = (sep ? (tly & ~7) : tly) >> 1;
           PAR_FOR(e, cw * cw) {
-            S->lv[1][e] = CTU_GLOAD(&J.coeff[4096 + (cby + (e >> cl2)) * LCU_C + cbx + (e & (cw - 1))]);
-            S->lv[2][e] = CTU_GLOAD(&J.coeff[5120 + (cby + (e >> cl2)) * LCU_C + cbx + (e & (cw - 1))]);
+            lv_of(S, 1)[e] = CTU_GLOAD(&J.coeff[4096 + (cby + (e >> cl2)) * LCU_C + cbx + (e & (cw - 1))]);
+            lv_of(S, 2)[e] = CTU_GLOAD(&J.coeff[5120 + (cby + (e >> cl2)) * LCU_C + cbx + (e & (cw - 1))]);
           }
         }
       }
@@ -2201,10 +2213,10 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass(lds<PX> *S, const jo
           m_code(m, 1, M_CBF_LUMA + 0, cb_y, dummy);      // luma_cbf_ctx stays 0: one transform unit per CU, or a CU that is not a TU
         }
         WSYNC();
-        if (cb_y) (void)coeff_bits(S, m, 1, S->lv[0], tn, 0);
+        if (cb_y) (void)coeff_bits(S, m, 1, lv_of(S, 0), tn, 0);
         if (!sep) {
-          if (cb_u) (void)coeff_bits(S, m, 1, S->lv[1], tn >> 1, 1);
-          if (cb_v) (void)coeff_bits(S, m, 1, S->lv[2], tn >> 1, 2);
+          if (cb_u) (void)coeff_bits(S, m, 1, lv_of(S, 1), tn >> 1, 1);
+          if (cb_v) (void)coeff_bits(S, m, 1, lv_of(S, 2), tn >> 1, 2);
         } else if (last4) {
           // the area's chroma after its last luma CU: mode (the co-located luma CU is this one), cbfs of the area's first entry, levels
           const cu4 *a = cu_at(S, lx & ~7, ly & ~7);
@@ -2215,8 +2227,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass(lds<PX> *S, const jo
             m_code(m, 1, M_CBF_CR + au, av, dummy);
           }
           WSYNC();
-          if (au) (void)coeff_bits(S, m, 1, S->lv[1], 4, 1);
-          if (av) (void)coeff_bits(S, m, 1, S->lv[2], 4, 2);
+          if (au) (void)coeff_bits(S, m, 1, lv_of(S, 1), 4, 1);
+          if (av) (void)coeff_bits(S, m, 1, lv_of(S, 2), 4, 2);
         }
       }
       CTU_SYNC();
@@ -2257,12 +2269,11 @@ template <typename PX> CTU_NOINLINE CTU_DEV void load_ctu(lds<PX> *S, const job<
       else if (i <= w) { const int q = px + i - 1; if (py > 0 && q < pw) D[i] = rec[(py - 1) * rs + q]; }
       else { const int r = py + i - w - 1; if (px > 0 && r < ph) D[(i - w) * pit] = rec[r * rs + px - 1]; }
     }
-    const PX *src = color == 0 ? J.src_y : (color == 1 ? J.src_u : J.src_v);
-    const int ss = c ? J.src_stride_c : J.src_stride;
-    PX *Sp = color == 0 ? S->Sy : (color == 1 ? S->Su : S->Sv);
-    PAR_FOR(e, w * w) {
-      const int r = e / w, q = e - r * w;
-      Sp[e] = (py + r < ph && px + q < pw) ? src[(py + r) * ss + px + q] : (PX)0;
+    if (color == 0) {
+      PAR_FOR(e, w * w) {
+        const int r = e / w, q = e - r * w;
+        S->Sy[e] = (py + r < ph && px + q < pw) ? J.src_y[(py + r) * J.src_stride + px + q] : (PX)0;
+      }
     }
   }
   PAR_FOR(i, 512) tab_ebits()[i] = kEntropyBits[i];
