@@ -34,6 +34,8 @@ static int run_picture(const ctu::params &P, const PX *sy, const PX *su, const P
   return 0;
 }
 
+extern "C" __attribute__((visibility("default"))) void ctu_emul_set_lazy(int on) { ctu::g_emul_lazy = on; }
+
 extern "C" __attribute__((visibility("default")))
 int ctu_emul_search_picture(int bitdepth, const ctu::params *P, const void *sy, const void *su, const void *sv, void *ry, void *ru, void *rv,
                             uvghip_scu_t *cu_tab, int16_t *coeff, uint32_t *models)

@@ -383,8 +383,9 @@ def load_ctu_emulation():
     return _EMUL
 
 
-def emul_search_picture(depth, prm, y, u, v):
+def emul_search_picture(depth, prm, y, u, v, lazy=False):
     lib = load_ctu_emulation()
+    lib.ctu_emul_set_lazy(int(lazy))        # lazy: a CU's own cost only arrives after all its children (the slowest possible depth wave)
     W, H = prm.pic_w, prm.pic_h
     wc, hc = (W + 63) // 64, (H + 63) // 64
     px = px_dtype(depth)

@@ -24,3 +24,18 @@ def test_emulated_kernel_1080p_crcs():
     W, Hh, depth, qp, y, u, v = H.golden_source(g)
     r = H.emul_search_picture(depth, H.search_params(W, Hh, qp), y, u, v)
     assert np.array_equal(H.ctu_crcs(r, W, Hh), g["crc"])
+
+
+def test_outcome_does_not_depend_on_when_a_cu_cost_arrives():
+    """The depth pipeline evaluates a CU unsplit on another wave while its children are tried; the reference knows the CU's cost
+    first and uses it to cut the children short.  Whether that cost arrives at once or only after the last child must not change
+    anything (every cut decides "not split", and the final comparison decides the same)."""
+    g = H.ctu_golden("ref_ctu_416x240_10_qp37")
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    r = H.emul_search_picture(depth, H.search_params(W, Hh, qp), y, u, v, lazy=True)
+    assert np.array_equal(r["models"], g["models"]) and np.array_equal(r["rec_y"], g["rec_y"])
+    assert np.array_equal(r["cu"][:Hh // 4, :W // 4], g["cu"][:Hh // 4, :W // 4])
+    g = H.ctu_golden("ref_ctu_832x480_8_qp22")
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    r = H.emul_search_picture(depth, H.search_params(W, Hh, qp), y, u, v, lazy=True)
+    assert np.array_equal(r["models"], g["models"]) and np.array_equal(r["rec_y"], g["rec_y"])

@@ -17,7 +17,7 @@ off_order = al(256 + ctus * 4, 256); off_pics = al(off_order + ctus * 4, 256); o
 ws = cs.ws.cpu().numpy()
 SZ = 53376 + 64
 prof = np.stack([ws[off_scr + i * SZ + SZ - 192: off_scr + i * SZ + SZ].view(np.uint64) for i in range(ctus)]).astype(np.float64)
-names = ["rough search", "refs+predict", "residual+transforms+recon", "RDOQ", "SSD", "RD cost bits", "park/unpark/models", "64x64 candidate", "coder pass", "load", "store", "TOTAL", "rq: candidates+last", "rq: pre-walk", "rq: decide", "rq: accumulate+group", "rq: copy-out", "rq: cbf+last search", "rq: signs"]
+names = ["rough search", "refs+predict", "residual+transforms+recon", "RDOQ", "SSD", "RD cost bits", "park/unpark/models", "64x64 candidate", "coder pass", "load", "store", "TOTAL", "rq: candidates+last", "rq: pre-walk", "rq: decide", "rq: accumulate+group", "rq: copy-out", "rq: cbf+last search", "rq: signs", "eval depth 0", "eval depth 1 (32x32)", "eval depth 2 (16x16)", "eval depth 3 (8x8)", "eval depth 4 (4x4)"]
 tot = prof[:, 11].mean()
 print("mean ticks per CTU (s_memtime, 100 MHz): total %.0f = %.2f ms" % (tot, tot / 1e5))
 for i, nm in enumerate(names): print(f"  {nm:28s} {prof[:, i].mean():10.0f}  {100 * prof[:, i].mean() / tot:5.1f} %")

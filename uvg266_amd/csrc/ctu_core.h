@@ -35,15 +35,26 @@
 #if defined(__HIPCC__)
 #define CTU_NOINLINE __attribute__((noinline))
 #define CTU_DEV __device__
-#define CTU_TID ((int)threadIdx.x)
-#define CTU_NT ((int)blockDim.x)
-#define CTU_SYNC() __syncthreads()
+// Everything the search computes is WAVE-local: a depth of the quad tree is worked by one wave (see search_ctu), so "all lanes"
+// means the 64 lanes of that wave and a hand-over between regions is a wave-level fence, not a workgroup barrier.
+#define CTU_TID ((int)(threadIdx.x & 63))
+#define CTU_NT 64
+#define CTU_WAVE ((int)(threadIdx.x >> 6))
+#define CTU_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+// the few workgroup-wide regions (CTU load / store)
+#define BLK_TID ((int)threadIdx.x)
+#define BLK_NT ((int)blockDim.x)
+#define BLK_SYNC() __syncthreads()
 #else
 #define CTU_NOINLINE
 #define CTU_DEV static inline
 #define CTU_TID 0
 #define CTU_NT 1
+#define CTU_WAVE (ctu::g_emul_wave)
 #define CTU_SYNC() ((void)0)
+#define BLK_TID 0
+#define BLK_NT 1
+#define BLK_SYNC() ((void)0)
 #endif
 // a load that must see what another wave of this workgroup stored to global memory earlier (served by L2, not by this CU's L1)
 #if defined(__HIPCC__)
@@ -51,32 +62,29 @@
 #else
 #define CTU_GLOAD(p) (*(p))
 #endif
-// optional phase timers (lane 0, s_memtime ticks) -- compiled in with -DCTU_PROFILE, results in scratch::prof
+// optional phase timers (lane 0 of the wave, s_memtime ticks) -- compiled in with -DCTU_PROFILE, results in scratch::prof[wave]
 #if defined(__HIPCC__) && defined(CTU_PROFILE)
 #define CTU_T0() const unsigned long long ctu_t0__ = __builtin_amdgcn_s_memtime()
-#define CTU_T1(W, slot) do { if (CTU_TID == 0) (W)->prof[slot] += __builtin_amdgcn_s_memtime() - ctu_t0__; } while (0)
+#define CTU_T1(W, slot) do { if (CTU_TID == 0) (W)->prof[CTU_WAVE][slot] += __builtin_amdgcn_s_memtime() - ctu_t0__; } while (0)
 #else
 #define CTU_T0() ((void)0)
 #define CTU_T1(W, slot) ((void)0)
 #endif
 #define PAR_FOR(i, n) for (int i = CTU_TID; i < (n); i += CTU_NT)
+#define BLK_FOR(i, n) for (int i = BLK_TID; i < (n); i += BLK_NT)
 #define SERIAL if (CTU_TID == 0)
 #define LANE0 if (CTU_TID == 0)
-// regions run by the first wave alone, its lanes exchanging data through LDS without workgroup barriers (LDS operations of one
-// wave complete in program order; the fence only stops the compiler from moving them)
-#if defined(__HIPCC__)
-#define CTU_IN_WAVE0 (threadIdx.x < 64)
-#define WFOR(i, n) for (int i = CTU_TID; i < (n); i += 64)
-#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-#else
-#define CTU_IN_WAVE0 1
-#define WFOR(i, n) for (int i = 0; i < (n); ++i)
-#define WSYNC() ((void)0)
-#endif
+#define WFOR(i, n) PAR_FOR(i, n)
+#define WSYNC() CTU_SYNC()
 
 namespace ctu {
 
-enum { LCU = 64, LCU_C = 32, PY = 68, PC = 36, NMODELS = 257, REFN = 136 };
+#if !defined(__HIPCC__)
+static int g_emul_wave = 0;      // host emulation: which wave's scratch the code running now uses
+static int g_emul_lazy = 0;      // host emulation: pretend a CU's own cost is never known before all its children are done
+#endif
+
+enum { LCU = 64, LCU_C = 32, PY = 68, PC = 36, NMODELS = 257 };
 enum { M_SIGGRP = 0, M_SIG = 4, M_PAR = 28, M_GT1 = 70, M_GT2 = 112, M_LASTX = 154, M_LASTY = 194, M_CBF_LUMA = 234, M_CBF_CB = 238,
        M_CBF_CR = 240, M_SPLIT = 244, M_MPM = 253, M_PLANAR = 254, M_CHROMA_PRED = 256 };
 enum { CU_NOTSET = 0, CU_INTRA = 1 };
@@ -96,11 +104,12 @@ struct cu4 {
 };
 
 struct level_state {        // search_cu's locals, per depth
-  double cost, split_cost;
+  double cost, split_cost, split_bits;
   int x, y;                 // picture coordinates
   int child;                // next child to visit
   int type, mode, cbf;      // the parked no-split candidate
   int has_chroma;           // carries the chroma of its area
+  int pending;              // its unsplit evaluation was handed to the depth's wave
   uint32_t split_tree, mode_type_tree;
 };
 
@@ -109,39 +118,58 @@ template <> struct px_info<uint8_t> { enum { depth = 8, maxv = 255 }; };
 template <> struct px_info<uint16_t> { enum { depth = 10, maxv = 1023 }; };
 
 // LDS image of a workgroup
+// scratch of ONE wave (= one depth of the quad tree): pointers into the workgroup's arena, sized for that depth's blocks, and the
+// small fixed-size pieces inline
+struct wctx {
+  uint16_t *top, *left, *ftop, *fleft;              // reference rows: 4 n + 8 entries each
+  int16_t *t0, *t1, *t2;                            // transform scratch, n * n each (t0 and t1 adjacent: also the n * n words of coeff_bits)
+  int16_t *lv0, *lv1, *lv2;                         // levels of the transform blocks being evaluated (y, u, v)
+  double *rq_cc, *rq_cs, *rq_c0;                    // RDOQ per-position costs in LDS (nullptr: the depth uses the workgroup's global scratch)
+  uint32_t *part;                                   // rough search: (satd, sad) per (listed mode, tile)
+  uint8_t *lv_spend;                                // coefficient bit cost: regular bins a scan position spends
+  uint32_t *cur;                                    // the models this wave's bit counting works on
+  double rq_stage[3 * 16];                          // RDOQ: costs of the coefficient group in flight
+  double rs_cost[67];
+  double u_d0, u_d1;
+  int32_t rq_i[16];
+  int32_t rs_list[24];
+  int32_t red[8], partial[64];
+  int32_t u_avail_left, u_avail_top, u_mode, u_flag, u_n_modes;
+  uint8_t cg_flag[64];
+  int8_t mpm[6];
+  int16_t refn;                                     // entries of a reference row
+};
+
+constexpr int arena_bytes(int n)     // one depth's share of the arena (n = its luma block size)
+{
+  return (4 * (4 * n + 8) * 2 + 3 * n * n * 2 + (n * n + 2 * ((n / 2) * (n / 2) < 16 ? 16 : (n / 2) * (n / 2))) * 2 +
+          2 * 18 * (n >= 8 ? (n / 8) * (n / 8) : 1) * 4 + n * n + (n <= 16 ? 8 + 3 * n * n * 8 : 0) + 15) & ~15;
+}
+enum { ARENA_BYTES = arena_bytes(4) + arena_bytes(8) + arena_bytes(16) + arena_bytes(32) };
+
+// LDS image of a workgroup
 template <typename PX> struct lds {
   PX Dy[65 * PY], Du[33 * PC], Dv[33 * PC];         // decided planes, index (y + 1) * pitch + x + 1
-  PX Sy[LCU * LCU];                                 // the CTU's luma source (the chroma source is read from the picture: two parallel passes per block)
-  PX cand_px[2016];
+  PX cand_px[2016];                                 // a depth's CU while its split is being tried (depths 1..3)
   int16_t cand_co[2016];
   cu4 cu[17 * 17];                                  // index (y4 + 1) * 17 + x4 + 1
   uint32_t tree[256], mtt[256];                     // split_tree / mode_type_tree per 4x4
-  uint32_t cur[NMODELS];                            // state->search_cabac models: state0 | state1 << 16
-  uint32_t pre[5][NMODELS], post[5][NMODELS];
+  uint32_t cur[NMODELS];                            // state->search_cabac models of the walk: state0 | state1 << 16
+  uint32_t pre[5][NMODELS];                         // ... as they stood when the depth's CU was entered
+  uint32_t work[4][NMODELS];                        // ... as the depth's CU leaves them when it is coded unsplit ([0]: scratch)
   uint32_t coder[NMODELS];                          // state->cabac models
   uint8_t rdoq_state[244];                          // CTX_STATE of the coder's models at the CTU's start (what uvg_rdoq prices with)
-  uint16_t top[REFN], left[REFN], ftop[REFN], fleft[REFN];
-  alignas(16) int16_t t0[1024], t1[1024], t2[1024]; // transform scratch
-  alignas(16) double rq_cc[256], rq_cs[256], rq_c0[256];   // RDOQ: cost of the kept level / of its significance flag / of level 0, per scan position (<= 16x16)
-  double rq_stage[3 * 16];                          // ... of the coefficient group in flight
-  int32_t rq_i[16];                                 // RDOQ scalars: 0 last_scanpos, 1 any level, 2..: per-lane partials
-  int16_t lv0[1024], lv1[256], lv2[256];            // levels of the transform blocks being evaluated (y, u, v)
   uint16_t scan[1024 + 256 + 64 + 16];              // coefficient scans of the four square shapes
   uint8_t inv4[16];                                 // scan index of the 4x4 group's raster position y * 4 + x
   uint16_t deps4[16];                               // per scan index of a 4x4 group: the scan indices (bits) its context template reads inside the group
   int32_t last_bits[2][4][2][12];                   // RDOQ: bit cost of the last-position prefix per (luma/chroma, log2 size - 2, x/y, group index)
-  uint8_t cg_flag[64];
-  uint8_t lv_spend[1024];                           // coefficient bit cost: regular bins a scan position spends
-  uint32_t part[2 * 18 * 16];                       // rough search: (satd, sad) partial sums per (listed mode, tile)
-  double rs_cost[67];
-  int32_t rs_list[24];
-  int32_t red[8], partial[256];                     // reductions
   level_state lvl[5];
-  // uniform scalars handed from lane 0 to everyone
-  int32_t u_avail_left, u_avail_top, u_mode, u_flag, u_n_modes, u_best[3];
-  double u_d0, u_d1;
-  int8_t mpm[6];
+  wctx wv[4];                                       // [0] depth 4 (4x4), [1] depth 3, [2] depth 2, [3] depth 1 (32x32)
+  int32_t vsel[4];                                  // which wv[] a wave is using (a wave may borrow a larger one while its owner idles)
+  int32_t req[4], done[4];                          // depth pipeline: evaluation requests / completions per depth
+  alignas(16) unsigned char arena[ARENA_BYTES];
 };
+template <typename PX> CTU_DEV wctx *wv_of(lds<PX> *S) { return &S->wv[S->vsel[CTU_WAVE]]; }
 
 // per-workgroup scratch in global memory
 struct scratch {
@@ -150,9 +178,36 @@ struct scratch {
   int16_t save_co[6144];
   cu4 save_cu[256];
   uint32_t save_tree[512];
-  unsigned long long prof[24];     // CTU_PROFILE: 0 rough search, 1 refs + prediction, 2 residual + transforms + reconstruction, 3 RDOQ, 4 SSD,
+  unsigned long long prof[4][32];     // CTU_PROFILE: 0 rough search, 1 refs + prediction, 2 residual + transforms + reconstruction, 3 RDOQ, 4 SSD,
                                    // 5 RD cost (bits), 6 park / unpark / model copies, 7 64x64 candidate, 8 coder pass, 9 load, 10 store, 11 total
 };
+
+// everything one workgroup needs to know about its CTU
+template <typename PX> struct job {
+  params P;
+  const PX *src_y, *src_u, *src_v;       // source planes
+  int src_stride, src_stride_c;
+  PX *rec_y, *rec_u, *rec_v;             // reconstruction before the in-loop filters (also the neighbours' samples)
+  int rec_stride, rec_stride_c;
+  uvghip_scu_t *cu_tab;                  // the picture's side information, one entry per 4x4
+  int cu_stride;
+  int16_t *coeff;                        // this CTU's lcu_coeff_t: y[64*64], u[32*32], v[32*32]
+  uint32_t *models_out;                  // this CTU's three model sets [3][NMODELS]: at its start, after its search, after the coder
+  const uint32_t *models_in;             // the coder's models this CTU starts from (NULL: initialise for an I slice at P.qp)
+  scratch *W;
+  int x, y;                              // CTU origin
+};
+
+// the source samples of a block of `color` at CTU-local (bx, by) (in that plane's samples), read from the picture; -> pointer, pitch
+// (blocks never reach outside the picture: a CU is only coded when it lies inside)
+template <typename PX> CTU_DEV const PX *src_block(const job<PX> &J, int color, int bx, int by, int *pitch)
+{
+  const PX *p = color == 0 ? J.src_y : (color == 1 ? J.src_u : J.src_v);
+  const int st = color == 0 ? J.src_stride : J.src_stride_c, sh = color != 0;
+  *pitch = st;
+  return p + (size_t)((J.y >> sh) + by) * st + (J.x >> sh) + bx;
+}
+
 
 // ------------------------------------------------------------------------------------------------------------ models ------
 // Tables every serial walk reads per bin live in LDS (a lone lane pays the full latency of every load: out of device memory the
@@ -243,7 +298,7 @@ template <typename PX> CTU_DEV void build_scans(lds<PX> *S)
 }
 
 // ------------------------------------------------------------------------------------------- reference construction ------
-template <typename PX> CTU_DEV int16_t *lv_of(lds<PX> *S, int color) { return color == 0 ? S->lv0 : (color == 1 ? S->lv1 : S->lv2); }
+CTU_DEV int16_t *lv_of(wctx *V, int color) { return color == 0 ? V->lv0 : (color == 1 ? V->lv1 : V->lv2); }
 template <typename PX> CTU_DEV PX *plane(lds<PX> *S, int color) { return color == 0 ? S->Dy : (color == 1 ? S->Du : S->Dv); }
 CTU_DEV int pitch_of(int color) { return color == 0 ? PY : PC; }
 template <typename PX> CTU_DEV cu4 *cu_at(lds<PX> *S, int lx, int ly) { return &S->cu[((ly >> 2) + 1) * 17 + (lx >> 2) + 1]; }   // lx, ly >= -4
@@ -268,6 +323,7 @@ template <typename PX> CTU_DEV int count_edge_cus(lds<PX> *S, int x, int y, int 
 // w x w block of `color` whose luma position is (x, y) / CTU-local (lx, ly) with luma size n; + the smoothed rows (:190-225)
 template <typename PX> CTU_NOINLINE CTU_DEV void build_refs(lds<PX> *S, const params &P, int color, int x, int y, int lx, int ly, int n)
 {
+  wctx *const V = wv_of(S);
   const int c = color != 0;
   const int w = n >> c;
   const int px_x = lx >> c, px_y = ly >> c;
@@ -281,36 +337,36 @@ template <typename PX> CTU_NOINLINE CTU_DEV void build_refs(lds<PX> *S, const pa
     if (at > 2 * w) at = 2 * w;
     if (at > ((P.pic_w - x) >> c)) at = (P.pic_w - x) >> c;
     if (x > 0 && y > 0 && P.wpp && px_y == 0 && at > (LCU >> c) - px_x) at = (LCU >> c) - px_x;
-    S->u_avail_left = al; S->u_avail_top = at;
+    V->u_avail_left = al; V->u_avail_top = at;
   }
   CTU_SYNC();
-  const int al = S->u_avail_left, at = S->u_avail_top;
+  const int al = V->u_avail_left, at = V->u_avail_top;
   const int dc = 1 << (px_info<PX>::depth - 1);
-  PAR_FOR(i, REFN - 1) {
+  PAR_FOR(i, V->refn - 1) {
     int lv, tv;
     if (x > 0) lv = D[(i < al ? i : al - 1) * pit - 1];
     else lv = y > 0 ? D[-pit] : dc;
     if (y > 0) tv = D[-pit + (i < at ? i : at - 1)];
     else tv = x > 0 ? D[-1] : dc;
-    S->left[i + 1] = (uint16_t)lv;
-    S->top[i + 1] = (uint16_t)tv;
+    V->left[i + 1] = (uint16_t)lv;
+    V->top[i + 1] = (uint16_t)tv;
   }
   SERIAL {
     int corner;
     if (x > 0 && y > 0) corner = D[-pit - 1];
     else corner = x > 0 ? D[-1] : (y > 0 ? D[-pit] : dc);       // "copy reference clockwise": left[1]
-    S->left[0] = S->top[0] = (uint16_t)corner;
+    V->left[0] = V->top[0] = (uint16_t)corner;
   }
   CTU_SYNC();
-  PAR_FOR(i, REFN) {
+  PAR_FOR(i, V->refn) {
     int fl, ft;
-    if (i == 0) fl = ft = (S->left[1] + 2 * S->left[0] + S->top[1] + 2) >> 2;
+    if (i == 0) fl = ft = (V->left[1] + 2 * V->left[0] + V->top[1] + 2) >> 2;
     else {
-      fl = i < 2 * w ? (S->left[i - 1] + 2 * S->left[i] + S->left[i + 1] + 2) >> 2 : S->left[i];
-      ft = i < 2 * w ? (S->top[i - 1] + 2 * S->top[i] + S->top[i + 1] + 2) >> 2 : S->top[i];
+      fl = i < 2 * w ? (V->left[i - 1] + 2 * V->left[i] + V->left[i + 1] + 2) >> 2 : V->left[i];
+      ft = i < 2 * w ? (V->top[i - 1] + 2 * V->top[i] + V->top[i + 1] + 2) >> 2 : V->top[i];
     }
-    S->fleft[i] = (uint16_t)fl;
-    S->ftop[i] = (uint16_t)ft;
+    V->fleft[i] = (uint16_t)fl;
+    V->ftop[i] = (uint16_t)ft;
   }
   CTU_SYNC();
 }
@@ -318,9 +374,10 @@ template <typename PX> CTU_NOINLINE CTU_DEV void build_refs(lds<PX> *S, const pa
 // prediction of the w x w block of `color` from the reference rows into dst (pitch dp)
 template <typename PX> CTU_NOINLINE CTU_DEV void predict_block(lds<PX> *S, int mode, int color, int w, PX *dst, int dp)
 {
+  wctx *const V = wv_of(S);
   const mode_info M = make_mode_info(mode, w, w, color != 0);
-  const ref_rows R = {S->top, S->left, S->ftop, S->fleft};
-  const int dc = mode == 1 ? dc_value(S->top, S->left, w, w) : 0;
+  const ref_rows R = {V->top, V->left, V->ftop, V->fleft};
+  const int dc = mode == 1 ? dc_value(V->top, V->left, w, w) : 0;
   const int segs = w >> 2;
   PAR_FOR(t, w * segs) {
     const int yd = t / segs, xd0 = (t - yd * segs) * 4;
@@ -379,11 +436,14 @@ CTU_DEV unsigned satd4_tile(int (&d)[16])
 // Device: every (mode, tile, row) is one lane -- a lane predicts one row of the tile in registers (in the mode's work domain:
 // transposed for the horizontal modes; SAD and the Hadamard magnitude multiset are transpose-invariant), the T lanes of a tile
 // finish the Hadamard with DPP exchanges (satd_dev.h).  Host emulation: the tile as a whole.
-template <typename PX> CTU_NOINLINE CTU_DEV void rough_costs(lds<PX> *S, int lx, int ly, int n, const int32_t *modes, int n_modes)
+template <typename PX> CTU_NOINLINE CTU_DEV void rough_costs(lds<PX> *S, const job<PX> &J, int lx, int ly, int n, const int32_t *modes, int n_modes)
 {
+  wctx *const V = wv_of(S);
+  int sps;
+  const PX *Sy = src_block(J, 0, lx, ly, &sps);
   const int T = n >= 8 ? 8 : 4, tiles_x = n / T, tiles = tiles_x * tiles_x;
-  const ref_rows R = {S->top, S->left, S->ftop, S->fleft};
-  const int dcv = dc_value(S->top, S->left, n, n);
+  const ref_rows R = {V->top, V->left, V->ftop, V->fleft};
+  const int dcv = dc_value(V->top, V->left, n, n);
 #if defined(__HIPCC__)
   const int total = n_modes * tiles * T;
   for (int base = 0; base < total; base += CTU_NT) {
@@ -401,7 +461,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rough_costs(lds<PX> *S, int lx,
       for (int i = 0; i < 8; ++i) {
         const int wx = tx * 8 + i, wy = ty * 8 + r;
         const int bx = M.vertical ? wx : wy, by = M.vertical ? wy : wx;
-        d[i] = on ? (int)S->Sy[(ly + by) * LCU + lx + bx] - out[i] : 0;
+        d[i] = on ? (int)Sy[by * sps + bx] - out[i] : 0;
         sad += iabs_(d[i]);
       }
       satd = satd8_cost(d, r);
@@ -412,13 +472,13 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rough_costs(lds<PX> *S, int lx,
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int bx = M.vertical ? i : r, by = M.vertical ? r : i;
-        d[i] = on ? (int)S->Sy[(ly + by) * LCU + lx + bx] - out[i] : 0;
+        d[i] = on ? (int)Sy[by * sps + bx] - out[i] : 0;
         sad += iabs_(d[i]);
       }
       satd = satd4_cost(d, r);
       sad = dpp_group_sum<4>(sad);
     }
-    if (on && r == 0) { S->part[2 * task] = (uint32_t)satd; S->part[2 * task + 1] = (uint32_t)sad; }
+    if (on && r == 0) { V->part[2 * task] = (uint32_t)satd; V->part[2 * task + 1] = (uint32_t)sad; }
   }
   CTU_SYNC();
 #else
@@ -436,7 +496,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rough_costs(lds<PX> *S, int lx,
         for (int i = 0; i < 8; ++i) {
           const int wx = tx * 8 + i, wy = ty * 8 + r;
           const int bx = M.vertical ? wx : wy, by = M.vertical ? wy : wx;
-          const int df = (int)S->Sy[(ly + by) * LCU + lx + bx] - out[i];
+          const int df = (int)Sy[by * sps + bx] - out[i];
           d[r * 8 + i] = df;
           sad += (unsigned)iabs_(df);
         }
@@ -449,15 +509,15 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rough_costs(lds<PX> *S, int lx,
         predict_row<4>(M, R, dcv, 0, n, n, r, 0, (int)px_info<PX>::maxv, out);
         for (int i = 0; i < 4; ++i) {
           const int bx = M.vertical ? i : r, by = M.vertical ? r : i;
-          const int df = (int)S->Sy[(ly + by) * LCU + lx + bx] - out[i];
+          const int df = (int)Sy[by * sps + bx] - out[i];
           d[r * 4 + i] = df;
           sad += (unsigned)iabs_(df);
         }
       }
       satd = satd4_tile(d);
     }
-    S->part[2 * task] = satd;
-    S->part[2 * task + 1] = sad;
+    V->part[2 * task] = satd;
+    V->part[2 * task + 1] = sad;
   }
   CTU_SYNC();
 #endif
@@ -521,20 +581,22 @@ template <typename PX> CTU_DEV void mpm_neighbours(lds<PX> *S, int x, int y, int
   *above = (ly > 0 && y > 0) ? cu_at(S, lx + n - 1, ly - 1) : nullptr;
 }
 
-// search_intra_rough (search_intra.c:986-1229), three survivors; the winner goes to S->u_mode
-template <typename PX> CTU_NOINLINE CTU_DEV void search_intra_rough(lds<PX> *S, const params &P, int x, int y, int lx, int ly, int n)
+// search_intra_rough (search_intra.c:986-1229), three survivors; the winner goes to V->u_mode
+template <typename PX> CTU_NOINLINE CTU_DEV void search_intra_rough(lds<PX> *S, const job<PX> &J, int x, int y, int lx, int ly, int n)
 {
+  wctx *const V = wv_of(S);
+  const params &P = J.P;
   const int T = n >= 8 ? 8 : 4, tiles = (n / T) * (n / T);
   SERIAL {
     const cu4 *l, *a;
     mpm_neighbours(S, x, y, lx, ly, n, &l, &a);
-    dir_luma_predictor(y, S->mpm, l, a);
+    dir_luma_predictor(y, V->mpm, l, a);
     const int offset = 1 << P.rough_levels;
     int k = 0;
-    S->rs_list[k++] = 0; S->rs_list[k++] = 1;
+    V->rs_list[k++] = 0; V->rs_list[k++] = 1;
     for (int mode = 2 + offset / 2; mode <= 66; mode += 2 * offset)
-      for (int i = 0; i < 2; ++i) if (mode + i * offset <= 66) S->rs_list[k++] = mode + i * offset;
-    S->u_n_modes = k;
+      for (int i = 0; i < 2; ++i) if (mode + i * offset <= 66) V->rs_list[k++] = mode + i * offset;
+    V->u_n_modes = k;
   }
   CTU_SYNC();
   // (rs_list holds at most 18 entries with rough_levels >= 2; the host refuses smaller values)
@@ -543,29 +605,29 @@ template <typename PX> CTU_NOINLINE CTU_DEV void search_intra_rough(lds<PX> *S, 
   double min_cost = 0, max_cost = 0;
   int offset = 1 << P.rough_levels;
   for (int round = 0;; ++round) {
-    rough_costs(S, lx, ly, n, S->rs_list, S->u_n_modes);
-    PAR_FOR(mi, S->u_n_modes) {                 // a lane per mode: tile sums, bit cost (count_bits reads the four flag costs itself)
-      const double mpm_bit = m_fbits(S->cur, M_MPM, 1), not_mpm_bit = m_fbits(S->cur, M_MPM, 0);
-      const double planar = m_fbits(S->cur, M_PLANAR + 1, 0), not_planar = m_fbits(S->cur, M_PLANAR + 1, 1);
-      const int mode = S->rs_list[mi];
+    rough_costs(S, J, lx, ly, n, V->rs_list, V->u_n_modes);
+    PAR_FOR(mi, V->u_n_modes) {                 // a lane per mode: tile sums, bit cost (count_bits reads the four flag costs itself)
+      const double mpm_bit = m_fbits(V->cur, M_MPM, 1), not_mpm_bit = m_fbits(V->cur, M_MPM, 0);
+      const double planar = m_fbits(V->cur, M_PLANAR + 1, 0), not_planar = m_fbits(V->cur, M_PLANAR + 1, 1);
+      const int mode = V->rs_list[mi];
       unsigned satd = 0, sad = 0;
-      for (int t = 0; t < tiles; ++t) { satd += S->part[2 * (mi * tiles + t)]; sad += S->part[2 * (mi * tiles + t) + 1]; }
+      for (int t = 0; t < tiles; ++t) { satd += V->part[2 * (mi * tiles + t)]; sad += V->part[2 * (mi * tiles + t) + 1]; }
       if (n >= 8) satd >>= (px_info<PX>::depth - 8);       // satd_NxN shifts, the 4x4 function does not (picture-generic.c:170)
       sad >>= (px_info<PX>::depth - 8);
       double c = (double)(satd < sad * 2 ? satd : sad * 2);
-      c += count_bits(S->mpm, planar, not_planar, mpm_bit, not_mpm_bit, mode) * P.lambda_sqrt;
-      S->rs_cost[mode] = c;
+      c += count_bits(V->mpm, planar, not_planar, mpm_bit, not_mpm_bit, mode) * P.lambda_sqrt;
+      V->rs_cost[mode] = c;
     }
     CTU_SYNC();
     SERIAL {
-      const int nm = S->u_n_modes;
+      const int nm = V->u_n_modes;
       for (int mi = 0; mi < nm; ++mi) {
-        const int mode = S->rs_list[mi];
-        const double c = S->rs_cost[mode];
+        const int mode = V->rs_list[mi];
+        const double c = V->rs_cost[mode];
         chk[mode >> 5] |= 1u << (mode & 31);
         if (round == 0 && mi < 2) {
           if (mi == 1) {
-            const double c0 = S->rs_cost[0], c1 = S->rs_cost[1];
+            const double c0 = V->rs_cost[0], c1 = V->rs_cost[1];
             if (c0 < c1) { min_cost = c0; max_cost = c1; best[0].mode = 0; best[0].cost = c0; best[1].mode = 1; best[1].cost = c1; }
             else { min_cost = c1; max_cost = c0; best[1].mode = 0; best[1].cost = c0; best[0].mode = 1; best[0].cost = c1; }
             best[2].mode = 0; best[2].cost = CTU_MAX_DOUBLE;
@@ -589,15 +651,15 @@ template <typename PX> CTU_NOINLINE CTU_DEV void search_intra_rough(lds<PX> *S, 
           if (center < 3 || center > 65) continue;
           const int test[2] = {center - offset, center + offset};
           for (int j = 0; j < 2; j++)
-            if (test[j] >= 2 && test[j] <= 66 && !((chk[test[j] >> 5] >> (test[j] & 31)) & 1)) { S->rs_list[k++] = test[j]; chk[test[j] >> 5] |= 1u << (test[j] & 31); }
+            if (test[j] >= 2 && test[j] <= 66 && !((chk[test[j] >> 5] >> (test[j] & 31)) & 1)) { V->rs_list[k++] = test[j]; chk[test[j] >> 5] |= 1u << (test[j] & 31); }
         }
       }
-      S->u_n_modes = k;
-      S->u_flag = offset > 0 && min_cost != max_cost;
-      S->u_mode = best[0].mode;
+      V->u_n_modes = k;
+      V->u_flag = offset > 0 && min_cost != max_cost;
+      V->u_mode = best[0].mode;
     }
     CTU_SYNC();
-    if (!S->u_flag) break;
+    if (!V->u_flag) break;
   }
 }
 
@@ -992,10 +1054,11 @@ CTU_NOINLINE CTU_DEV rdoq_pos rdoq_decide(const rdoq_env &E, const int16_t *coef
 //     where it does run out are walked position by position;
 //   * the double-precision sums the reference forms in scan order (base cost, group statistics) and the group decision that
 //     compares them: lane 0, from the group's staged costs; the final cbf / last-position search: lane 0.
-// Result: S->rq_i[1] = whether any level survived; levels in dst.
+// Result: V->rq_i[1] = whether any level survived; levels in dst.
 template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *W, const int16_t *coef, int16_t *dst, int n, int color, int cbf_u, int qp_scaled,
                                               double lambda, int bitdepth)
 {
+  wctx *const V = wv_of(S);
   const int l2 = ilog2_dev(n), nn = n * n, cgw = n >> 2;
   const uint16_t *scan = S->scan + scan_base(l2);
   rdoq_env E;
@@ -1006,10 +1069,10 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
   double scale = 32768;
   scale = transform_shift >= 0 ? scale / kPow2[2 * transform_shift] : scale * kPow2[-2 * transform_shift];
   E.error_scale = scale / E.q / E.q;
-  const bool small = n <= 16;                    // the per-position cost arrays fit in LDS
-  double *CC = small ? S->rq_cc : W->cost_coeff, *CS = small ? S->rq_cs : W->cost_sig, *C0 = small ? S->rq_c0 : W->cost_coeff0;
+  const bool small = V->rq_cc != nullptr;        // the per-position cost arrays are in LDS (this wave's depth has them)
+  double *CC = small ? V->rq_cc : W->cost_coeff, *CS = small ? V->rq_cs : W->cost_sig, *C0 = small ? V->rq_c0 : W->cost_coeff0;
 #define RQ_LD(p) (small ? *(p) : CTU_GLOAD(p))
-  double *cost_cg_sig = S->rs_cost;              // (free while a block is quantised)
+  double *cost_cg_sig = V->rs_cost;              // (free while a block is quantised)
   const int cap_half = 1 << (E.q_bits - 1);
   // ---- every position: candidate, level-0 cost; the last candidate in scan order ----
 #if defined(__HIPCC__) && defined(CTU_PROFILE)
@@ -1029,14 +1092,14 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
     C0[sp] = err * err * E.error_scale;
     dst[blk] = (int16_t)mal;
     if (mal > 0 && sp > my_last) my_last = sp;
-    if (sp < 64) S->cg_flag[sp] = 0;
+    if (sp < 64) V->cg_flag[sp] = 0;
   }
 #if defined(__HIPCC__)
   for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(my_last, o, 64); my_last = v > my_last ? v : my_last; }
 #endif
   const int last_scanpos = my_last;
   WSYNC();
-  if (last_scanpos < 0) { if (CTU_TID == 0) S->rq_i[1] = 0; WSYNC(); return; }
+  if (last_scanpos < 0) { if (CTU_TID == 0) V->rq_i[1] = 0; WSYNC(); return; }
   RQ_T(12);
   const int cg_last = last_scanpos >> 4;
   // lane 0's running sums (rdo.c:1556-1583: the positions behind the last candidate only add their level-0 cost)
@@ -1044,8 +1107,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
   if (CTU_TID == 0) {
     for (int sp = nn - 1; sp > last_scanpos; --sp) { const double c = RQ_LD(&C0[sp]); block_uncoded_cost += c; base_cost += c; }
     for (int g = 0; g <= cg_last; ++g) cost_cg_sig[g] = 0;
-    S->rq_i[4] = (int)((uint32_t)(nn * 28) >> 4);      // reg_bins
-    S->rq_i[5] = 1;                                    // regular bins remain
+    V->rq_i[4] = (int)((uint32_t)(nn * 28) >> 4);      // reg_bins
+    V->rq_i[5] = 1;                                    // regular bins remain
   }
   WSYNC();
   RQ_T(13);
@@ -1053,8 +1116,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
     const int first = scan[cgs * 16];
     const int cg_pos_x = (first & (n - 1)) >> 2, cg_pos_y = (first >> l2) >> 2;
     const int cg_blkpos = cg_pos_y * cgw + cg_pos_x;
-    int reg_bins = S->rq_i[4];
-    const int regular = S->rq_i[5];
+    int reg_bins = V->rq_i[4];
+    const int regular = V->rq_i[5];
     // can the regular-bin budget run out inside this group?  (a position spends at most min(candidate, 2 -> 3) + 1 bins)
     int fast = !regular;
     if (regular) {
@@ -1094,7 +1157,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
             int mal;
             const rdoq_pos r = rdoq_decide(E, coef, dst, n, l2, color, blk, scanpos == last_scanpos, regular != 0, go_rice, c0, &mal);
             dst[blk] = (int16_t)r.level;
-            S->rq_stage[sp] = r.cc; S->rq_stage[16 + sp] = r.cs;
+            V->rq_stage[sp] = r.cc; V->rq_stage[16 + sp] = r.cs;
             done = true;
           }
           WSYNC();
@@ -1122,7 +1185,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
             int mal;
             const rdoq_pos r = rdoq_decide(E, coef, dst, n, l2, color, blk, scanpos == last_scanpos, regular != 0, go_rice, RQ_LD(&C0[scanpos]), &mal);
             newlev[sp] = (int16_t)r.level;
-            S->rq_stage[sp] = r.cc; S->rq_stage[16 + sp] = r.cs;
+            V->rq_stage[sp] = r.cc; V->rq_stage[16 + sp] = r.cs;
             decided |= 1u << sp;
           }
           for (int sp = 0; sp < 16; ++sp) if (((decided & ~before) >> sp) & 1) dst[scan[cgs * 16 + sp]] = newlev[sp];    // a round's levels appear together
@@ -1139,15 +1202,15 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
         int mal;
         const rdoq_pos r = rdoq_decide(E, coef, dst, n, l2, color, blk, scanpos == last_scanpos, reg_bins >= 4, go_rice, RQ_LD(&C0[scanpos]), &mal);
         dst[blk] = (int16_t)r.level;
-        S->rq_stage[sp] = r.cc; S->rq_stage[16 + sp] = r.cs;
+        V->rq_stage[sp] = r.cc; V->rq_stage[16 + sp] = r.cs;
         if ((scanpos % 16 == 0) && scanpos > 0) go_rice = 0;
         else if (reg_bins >= 4) {
           reg_bins -= (r.level < 2 ? r.level : 3) + (scanpos != last_scanpos);
           go_rice = go_rice_par(template_abs_sum(coef, 4, blk & (n - 1), blk >> l2, n));
         }
       }
-      S->rq_i[4] = reg_bins;
-      S->rq_i[5] = reg_bins >= 4;
+      V->rq_i[4] = reg_bins;
+      V->rq_i[5] = reg_bins >= 4;
     }
     WSYNC();
     RQ_T(14);
@@ -1158,7 +1221,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
       for (int sp = 15; sp >= 0; --sp) {
         const int scanpos = cgs * 16 + sp;
         if (scanpos > last_scanpos) continue;
-        const double cc = S->rq_stage[sp], cs = S->rq_stage[16 + sp], c0 = RQ_LD(&C0[scanpos]);
+        const double cc = V->rq_stage[sp], cs = V->rq_stage[16 + sp], c0 = RQ_LD(&C0[scanpos]);
         const int level = dst[scan[scanpos]];
         block_uncoded_cost += c0;
         base_cost += cc;
@@ -1172,12 +1235,12 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
           if (sp != 0) nnz_before_pos0++;
         }
       }
-      if (fast && regular) S->rq_i[4] = reg_bins - spent;
+      if (fast && regular) V->rq_i[4] = reg_bins - spent;
       int zeroed = 0;
       if (cgs) {
         unsigned right = 0, lower = 0;
-        if (cg_pos_x + 1 < cgw) right = S->cg_flag[cg_blkpos + 1];
-        if (cg_pos_y + 1 < cgw) lower = S->cg_flag[cg_blkpos + cgw];
+        if (cg_pos_x + 1 < cgw) right = V->cg_flag[cg_blkpos + 1];
+        if (cg_pos_y + 1 < cgw) lower = V->cg_flag[cg_blkpos + cgw];
         const int o_grp = M_SIGGRP + (E.t ? 2 : 0) + ((right || lower) ? 1 : 0);
         if (!flag) {
           cost_cg_sig[cgs] = lambda * rbits(E, o_grp, 0);
@@ -1201,20 +1264,20 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
       } else {
         flag = 1;
       }
-      S->cg_flag[cg_blkpos] = (uint8_t)flag;
-      S->rq_i[6] = zeroed;
+      V->cg_flag[cg_blkpos] = (uint8_t)flag;
+      V->rq_i[6] = zeroed;
     }
     WSYNC();
     RQ_T(15);
     {
       // the group's costs go to the per-position arrays the last-position search reads; a zeroed group's positions fall back to level 0
-      const int zeroed = S->rq_i[6];
+      const int zeroed = V->rq_i[6];
       WFOR(sp, 16) {
         const int scanpos = cgs * 16 + sp;
         if (scanpos <= last_scanpos) {
           const int blk = scan[scanpos];
           if (zeroed && dst[blk]) { dst[blk] = 0; CC[scanpos] = RQ_LD(&C0[scanpos]); CS[scanpos] = 0; }
-          else { CC[scanpos] = S->rq_stage[sp]; CS[scanpos] = S->rq_stage[16 + sp]; }
+          else { CC[scanpos] = V->rq_stage[sp]; CS[scanpos] = V->rq_stage[16 + sp]; }
         }
       }
     }
@@ -1236,7 +1299,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
       const int first = scan[cgs * 16];
       const int cg_blkpos = ((first >> l2) >> 2) * cgw + ((first & (n - 1)) >> 2);
       base_cost -= cost_cg_sig[cgs];
-      if (S->cg_flag[cg_blkpos]) {
+      if (V->cg_flag[cg_blkpos]) {
         for (int sp = 15; sp >= 0; sp--) {
           const int scanpos = cgs * 16 + sp;
           if (scanpos > last_scanpos) continue;
@@ -1260,12 +1323,12 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
         if (found_last) break;
       }
     }
-    S->rq_i[0] = best_last_idx_p1;
-    S->rq_i[1] = best_last_idx_p1 > 0;
+    V->rq_i[0] = best_last_idx_p1;
+    V->rq_i[1] = best_last_idx_p1 > 0;
   }
   WSYNC();
   RQ_T(17);
-  const int best_last_idx_p1 = S->rq_i[0];
+  const int best_last_idx_p1 = V->rq_i[0];
   WFOR(scanpos, last_scanpos + 1) {
     const int b = scan[scanpos];
     if (scanpos < best_last_idx_p1) { const int level = dst[b]; dst[b] = (int16_t)((coef[b] < 0) ? -level : level); }
@@ -1427,31 +1490,6 @@ CTU_NOINLINE CTU_DEV double coeff_bits_serial(uint32_t *m, const uint16_t *scan,
 
 
 // =================================================================================================== the CTU search ======
-// everything one workgroup needs to know about its CTU
-template <typename PX> struct job {
-  params P;
-  const PX *src_y, *src_u, *src_v;       // source planes
-  int src_stride, src_stride_c;
-  PX *rec_y, *rec_u, *rec_v;             // reconstruction before the in-loop filters (also the neighbours' samples)
-  int rec_stride, rec_stride_c;
-  uvghip_scu_t *cu_tab;                  // the picture's side information, one entry per 4x4
-  int cu_stride;
-  int16_t *coeff;                        // this CTU's lcu_coeff_t: y[64*64], u[32*32], v[32*32]
-  uint32_t *models_out;                  // this CTU's three model sets [3][NMODELS]: at its start, after its search, after the coder
-  const uint32_t *models_in;             // the coder's models this CTU starts from (NULL: initialise for an I slice at P.qp)
-  scratch *W;
-  int x, y;                              // CTU origin
-};
-
-// the source samples of a block of `color` at CTU-local (bx, by) (in that plane's samples): luma from LDS, chroma from the picture
-// (blocks never reach outside the picture: a CU is only coded when it lies inside)
-template <typename PX> CTU_DEV const PX *src_block(lds<PX> *S, const job<PX> &J, int color, int bx, int by)
-{
-  if (color == 0) return S->Sy + by * LCU + bx;
-  const PX *p = color == 1 ? J.src_u : J.src_v;
-  return p + (size_t)((J.y >> 1) + by) * J.src_stride_c + (J.x >> 1) + bx;
-}
-
 CTU_DEV int co_off(int color) { return color == 0 ? 0 : (color == 1 ? 4096 : 5120); }
 CTU_DEV int cand_px_off(int L, int color)      // L = 1..3
 {
@@ -1463,73 +1501,71 @@ CTU_DEV int cand_px_off(int L, int color)      // L = 1..3
 template <typename PX> CTU_DEV int scaled_qp(const params &P, int color) { return (color == 0 ? P.qp : P.qp_c) + 6 * ((int)px_info<PX>::depth - 8); }
 
 // predict + uvg_quantize_residual (quant-generic.c:460-612, RDOQ branch) of one transform block straight into D; its levels stay in
-// lv_of(S, color) and go to the CTU's coefficient array.  (x, y) / (lx, ly): luma position, n: luma size of the area.  -> has_coeffs
-template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<PX> &J, int color, int x, int y, int lx, int ly, int n, int mode, int cbf_u)
+// lv_of(V, color) and go to the CTU's coefficient array.  (x, y) / (lx, ly): luma position, n: luma size of the area.  -> has_coeffs
+template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<PX> &J, int color, int x, int y, int lx, int ly, int n, int mode, int cbf_u,
+                                                         PX *dst, int dp, int16_t *co, int cp)
 {
+  // dst / dp: where the block is reconstructed (the decided planes, or the depth's candidate buffer); co / cp: where its levels go
+  wctx *const V = wv_of(S);
   const int c = color != 0, w = n >> c, l2 = ilog2_dev(w);
-  const int pit = pitch_of(color), spit = c ? LCU_C : LCU;
-  const int bx = lx >> c, by = ly >> c;
-  PX *D = plane(S, color) + (by + 1) * pit + bx + 1;
-  const PX *Sp = src_block(S, J, color, bx, by);
-  const int sps = c ? J.src_stride_c : LCU;        // pitch of the source view
+  int sps;
+  const PX *Sp = src_block(J, color, lx >> c, ly >> c, &sps);
   const int depth = (int)px_info<PX>::depth;
   { CTU_T0();
   build_refs(S, J.P, color, x, y, lx, ly, n);
-  predict_block(S, mode, color, w, D, pit);
+  predict_block(S, mode, color, w, dst, dp);
   CTU_T1(J.W, 1); }
   { CTU_T0();
-  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); S->t0[e] = (int16_t)((int)Sp[r * sps + q] - (int)D[r * pit + q]); }
+  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); V->t0[e] = (int16_t)((int)Sp[r * sps + q] - (int)dst[r * dp + q]); }
   CTU_SYNC();
-  fwd_pass(w, S->t0, S->t1, l2 - 1 + depth - 8);
-  fwd_pass(w, S->t1, S->t2, l2 + 6);
+  fwd_pass(w, V->t0, V->t1, l2 - 1 + depth - 8);
+  fwd_pass(w, V->t1, V->t2, l2 + 6);
   CTU_T1(J.W, 2); }
   const int qps = scaled_qp<PX>(J.P, color);
   CTU_T0();
-  if (CTU_IN_WAVE0) {
+  {
     // chroma blocks: state->c_lambda as uvg_quantize_lcu_residual replaces it (transform.c:1575)
     const double lambda = c ? J.P.c_lambda_tu : J.P.lambda;
-    rdoq_wave(S, J.W, S->t2, lv_of(S, color), w, color, cbf_u, qps, lambda, depth);
+    rdoq_wave(S, J.W, V->t2, lv_of(V, color), w, color, cbf_u, qps, lambda, depth);
   }
   CTU_SYNC();
   CTU_T1(J.W, 3);
-  const int has = S->rq_i[1];
-  int16_t *co = J.coeff + co_off(color) + by * spit + bx;
-  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); co[r * spit + q] = lv_of(S, color)[e]; }
+  const int has = V->rq_i[1];
+  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); co[r * cp + q] = lv_of(V, color)[e]; }
   if (has) {
     const int transform_shift = 15 - depth - l2;
     const int shift = 20 - 14 - transform_shift;
     const int32_t scale = (int32_t)kInvQuantScales[qps % 6] << (qps / 6);
     const int32_t add = 1 << (shift - 1);
-    PAR_FOR(e, w * w) S->t0[e] = (int16_t)clampi((lv_of(S, color)[e] * scale + add) >> shift, -32768, 32767);      // uvg_dequant, quant-generic.c:618-669
+    PAR_FOR(e, w * w) V->t0[e] = (int16_t)clampi((lv_of(V, color)[e] * scale + add) >> shift, -32768, 32767);      // uvg_dequant, quant-generic.c:618-669
     CTU_SYNC();
-    inv_pass(w, S->t0, S->t1, 7);
-    inv_pass(w, S->t1, S->t0, 12 - (depth - 8));
+    inv_pass(w, V->t0, V->t1, 7);
+    inv_pass(w, V->t1, V->t0, 12 - (depth - 8));
     PAR_FOR(e, w * w) {
       const int r = e >> l2, q = e & (w - 1);
-      const int16_t val = (int16_t)(S->t0[e] + (int)D[r * pit + q]);
-      D[r * pit + q] = (PX)clampi(val, 0, (int)px_info<PX>::maxv);
+      const int16_t val = (int16_t)(V->t0[e] + (int)dst[r * dp + q]);
+      dst[r * dp + q] = (PX)clampi(val, 0, (int)px_info<PX>::maxv);
     }
   }
   CTU_SYNC();
   return has;
 }
 
-// uvg_pixels_calc_ssd of a w x w block of D against the source, into S->red[slot] (valid after the barrier)
-template <typename PX> CTU_NOINLINE CTU_DEV void ssd_block(lds<PX> *S, const job<PX> &J, int color, int lx, int ly, int n, int slot)
+// uvg_pixels_calc_ssd of a w x w block of D against the source, into V->red[slot] (valid after the barrier)
+template <typename PX> CTU_NOINLINE CTU_DEV void ssd_block(lds<PX> *S, const job<PX> &J, int color, int lx, int ly, int n, int slot, const PX *rec, int rp)
 {
+  wctx *const V = wv_of(S);
   const int c = color != 0, w = n >> c, l2 = ilog2_dev(w);
-  const int pit = pitch_of(color), spit = c ? LCU_C : LCU;
-  const PX *D = plane(S, color) + ((ly >> c) + 1) * pit + (lx >> c) + 1;
-  const PX *Sp = src_block(S, J, color, lx >> c, ly >> c);
-  const int sps = c ? J.src_stride_c : LCU;
+  int sps;
+  const PX *Sp = src_block(J, color, lx >> c, ly >> c, &sps);
   int acc = 0;
-  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); const int d = (int)Sp[r * sps + q] - (int)D[r * pit + q]; acc += d * d; }
-  S->partial[CTU_TID] = acc;
+  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); const int d = (int)Sp[r * sps + q] - (int)rec[r * rp + q]; acc += d * d; }
+  V->partial[CTU_TID] = acc;
   CTU_SYNC();
   SERIAL {
     int tot = 0;
-    for (int i = 0; i < CTU_NT; ++i) tot += S->partial[i];
-    S->red[slot] = tot >> (2 * ((int)px_info<PX>::depth - 8));
+    for (int i = 0; i < CTU_NT; ++i) tot += V->partial[i];
+    V->red[slot] = tot >> (2 * ((int)px_info<PX>::depth - 8));
   }
   CTU_SYNC();
 }
@@ -1612,6 +1648,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void mark_deblocking(lds<PX> *S, int
 // All 64 lanes of wave 0 call it; the returned value is the same on every lane.  Host emulation: the serial walk.
 template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32_t *m, int update, const int16_t *coeff, int n, int color)
 {
+  wctx *const V = wv_of(S);
 #if !defined(__HIPCC__)
   uint32_t tmp[NMODELS];
   uint32_t *mm = m;
@@ -1621,9 +1658,9 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
   const int lane = CTU_TID;
   const int l2 = ilog2_dev(n), nn = n * n, cgw = n >> 2, ncg = nn >> 4, t = color ? 1 : 0;
   const uint16_t *scan = S->scan + scan_base(l2);
-  uint32_t *recs = reinterpret_cast<uint32_t *>(S->t0);       // t0 + t1: 1024 words, free while costs are counted
-  uint8_t *cgf = S->cg_flag;                                   // per group (raster): has a level
-  int32_t *gtot = reinterpret_cast<int32_t *>(S->rq_stage);   // per group (scan order): regular bins it would spend, bit 30: a level among k = 1..15
+  uint32_t *recs = reinterpret_cast<uint32_t *>(V->t0);       // t0 + t1: 1024 words, free while costs are counted
+  uint8_t *cgf = V->cg_flag;                                   // per group (raster): has a level
+  int32_t *gtot = reinterpret_cast<int32_t *>(V->rq_stage);   // per group (scan order): regular bins it would spend, bit 30: a level among k = 1..15
   // ---- last significant position, group flags ----
   int my_last = -1;
   for (int sp = lane; sp < nn; sp += 64) if (coeff[scan[sp]]) my_last = sp;
@@ -1654,12 +1691,12 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
     const int spend = sig_coded + (a ? 1 + (a > 1 ? 2 : 0) : 0);
     recs[sp] = (uint32_t)(a > 0xffff ? 0xffff : a) | (uint32_t)ctx_sig << 16 | (uint32_t)ofs << 20 | (uint32_t)r4 << 25 | (uint32_t)r0 << 27 |
                (uint32_t)sig_coded << 29;
-    S->lv_spend[sp] = (uint8_t)spend;
+    V->lv_spend[sp] = (uint8_t)spend;
   }
   WSYNC();
   for (int g = lane; g <= cg_last; g += 64) {
     int tot = 0;
-    for (int k = 0; k < 16; ++k) if (g * 16 + k <= last) tot += S->lv_spend[g * 16 + k];
+    for (int k = 0; k < 16; ++k) if (g * 16 + k <= last) tot += V->lv_spend[g * 16 + k];
     gtot[g] = (gtot[g] & (1 << 30)) | tot;
   }
   WSYNC();
@@ -1674,14 +1711,14 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
       if (rb - tot >= 4) { rb -= tot; continue; }
       for (int sp = (g == cg_last ? last : g * 16 + 15); sp >= g * 16; --sp) {
         if (rb < 4) { sw = sp; break; }
-        rb -= S->lv_spend[sp];
+        rb -= V->lv_spend[sp];
       }
       if (sw < 0 && rb < 4) sw = g * 16 - 1;          // ran out exactly at the group's end: everything below is bypass-coded
     }
-    S->rq_i[8] = sw;
+    V->rq_i[8] = sw;
   }
   WSYNC();
-  const int sw = S->rq_i[8];          // scan positions <= sw are bypass-coded
+  const int sw = V->rq_i[8];          // scan positions <= sw are bypass-coded
   // ---- the models, one per lane, along the positions in coding order ----
   unsigned long long q15 = 0;         // sum of bit costs in units of 2^-15
   for (int sweep = 0; sweep < 2; ++sweep) {
@@ -1739,8 +1776,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
     uint32_t *mk = m;
     if (!update) {
       // counting only: these bins still adapt their models WITHIN the block (the reference counts on a copy) -- work on a copy
-      // of the few models involved (post[0] is free whenever nothing is kept: the 64x64 candidate at depth 0)
-      mk = S->post[0];
+      // of the few models involved (work[0] is nobody's: depth 0 has no unsplit candidate of its own)
+      mk = S->work[0];
       for (int i = 0; i < 4; ++i) mk[M_SIGGRP + i] = m[M_SIGGRP + i];
       for (int i = M_LASTX; i < M_CBF_LUMA; ++i) mk[i] = m[i];
     }
@@ -1783,26 +1820,27 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
 // red[0..2]: SSD of y, u, v.  lane 0.  update: state->search_cabac.update.
 template <typename PX> CTU_NOINLINE CTU_DEV double tr_cost(lds<PX> *S, const params &P, int update, int n, int cbf, int has_chroma, int cn)
 {
+  wctx *const V = wv_of(S);
   // called by all lanes of the first wave; the flag bins are lane 0's, the coefficient costs the wave's
   double coeff_bits_ = 0, luma_bits = 0, chroma_bits = 0;
   const int cb_y = cbf & 1, cb_u = (cbf >> 1) & 1, cb_v = (cbf >> 2) & 1;
   LANE0 {
     if (has_chroma) {
-      m_code(S->cur, update, M_CBF_CB + 0, cb_u, chroma_bits);
-      m_code(S->cur, update, M_CBF_CR + cb_u, cb_v, chroma_bits);
+      m_code(V->cur, update, M_CBF_CB + 0, cb_u, chroma_bits);
+      m_code(V->cur, update, M_CBF_CR + cb_u, cb_v, chroma_bits);
     }
-    m_code(S->cur, update, M_CBF_LUMA + 0, cb_y, luma_bits);
+    m_code(V->cur, update, M_CBF_LUMA + 0, cb_y, luma_bits);
   }
   WSYNC();
-  const unsigned luma_ssd = (unsigned)S->red[0];
+  const unsigned luma_ssd = (unsigned)V->red[0];
   // uvg_get_coeff_cost counts on a copy of the models that is kept only when update is set (rdo.c:322-356)
-  if (cb_y) coeff_bits_ += coeff_bits(S, S->cur, update, lv_of(S, 0), n, 0);
+  if (cb_y) coeff_bits_ += coeff_bits(S, V->cur, update, lv_of(V, 0), n, 0);
   unsigned chroma_ssd = 0;
   if (has_chroma) {
-    const unsigned ssd_u = (unsigned)((unsigned)S->red[1] * P.cw_u), ssd_v = (unsigned)((unsigned)S->red[2] * P.cw_v);
+    const unsigned ssd_u = (unsigned)((unsigned)V->red[1] * P.cw_u), ssd_v = (unsigned)((unsigned)V->red[2] * P.cw_v);
     chroma_ssd = ssd_u + ssd_v;
-    chroma_bits += coeff_bits(S, S->cur, update, lv_of(S, 1), cn, 1);
-    chroma_bits += coeff_bits(S, S->cur, update, lv_of(S, 2), cn, 2);
+    chroma_bits += coeff_bits(S, V->cur, update, lv_of(V, 1), cn, 1);
+    chroma_bits += coeff_bits(S, V->cur, update, lv_of(V, 2), cn, 2);
   }
   const double bits = luma_bits + coeff_bits_;
   return luma_ssd * 1.0 + chroma_ssd * 1.0 + (bits + chroma_bits) * P.lambda;
@@ -1825,101 +1863,107 @@ template <typename PX> CTU_NOINLINE CTU_DEV void fill_cu(lds<PX> *S, int lx, int
 }
 
 // search + reconstruction + RD cost of the n x n CU at depth L as ONE coding unit (the part of search_cu before the split loop,
-// search.c:1395-1774).  Leaves the CU in D and its cost / mode / cbf in S->lvl[L]; the models move on as the mock coder saw the CU.
-template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<PX> &J, int L)
+// search.c:1395-1774), by the calling wave.  to_cand = 0 (a CU that cannot be split): straight into the decided planes / side
+// information / coefficient array, on the walk's models.  to_cand = 1 (its split is tried as well, by another wave at the same
+// time): into the depth's candidate buffers, on the depth's own copy of the entry models -- nothing another wave reads is touched.
+// Cost / mode / cbf go to S->lvl[L].
+template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<PX> &J, int L, int to_cand)
 {
+  wctx *const V = wv_of(S);
   const params &P = J.P;
   level_state &N = S->lvl[L];
   const int n = 64 >> L, x = N.x, y = N.y, lx = x & 63, ly = y & 63;
   const int sep = n == 4;                                 // a 4x4 CU: its chroma belongs to the 8x8 area, carried by the fourth one
   const int has_chroma = N.has_chroma;
-  SERIAL {                                                  // the CU's own entry is reset (search.c:1371-1388)
-    cu4 *c = cu_at(S, lx, ly);
-    c->type = CU_NOTSET; c->cbf = 0; c->luma_edges = 0; c->chroma_edges = 0; c->mode = 0; c->mode_chroma = 0; c->log2 = (uint8_t)ilog2_dev(n);
-    c->log2_c = (uint8_t)(sep ? 2 : ilog2_dev(n) - 1);
+  if (to_cand) {
+    PAR_FOR(i, NMODELS) S->work[L][i] = S->pre[L][i];
+    LANE0 V->cur = S->work[L];
+  } else {
+    LANE0 {
+      V->cur = S->cur;
+      cu4 *c = cu_at(S, lx, ly);                           // the CU's own entry is reset (search.c:1371-1388)
+      c->type = CU_NOTSET; c->cbf = 0; c->luma_edges = 0; c->chroma_edges = 0; c->mode = 0; c->mode_chroma = 0; c->log2 = (uint8_t)ilog2_dev(n);
+      c->log2_c = (uint8_t)(sep ? 2 : ilog2_dev(n) - 1);
+    }
   }
   CTU_SYNC();
   { CTU_T0();
   build_refs(S, P, 0, x, y, lx, ly, n);
-  search_intra_rough(S, P, x, y, lx, ly, n);
+  search_intra_rough(S, J, x, y, lx, ly, n);
   CTU_T1(J.W, 0); }
-  const int mode = S->u_mode;
-  SERIAL fill_cu(S, lx, ly, n, mode, mode, sep ? 2 : ilog2_dev(n) - 1, N.split_tree, cu_mtt(N.mode_type_tree, L));
-  CTU_SYNC();
-  int cbf = recon_tu(S, J, 0, x, y, lx, ly, n, mode, 0);
+  const int mode = V->u_mode;
+  if (!to_cand) { SERIAL fill_cu(S, lx, ly, n, mode, mode, sep ? 2 : ilog2_dev(n) - 1, N.split_tree, cu_mtt(N.mode_type_tree, L)); CTU_SYNC(); }
+  // where the three blocks are reconstructed and where their levels go
   int cn = n >> 1, cx = x, cy = y;                        // the chroma area (luma coordinates) and its block size
   if (sep) { cn = 4; cx = x & ~7; cy = y & ~7; }
+  const int area = sep ? 8 : n;
+  PX *ry, *ru, *rv;
+  int16_t *ky, *ku, *kv;
+  int rpy, rpc, kpy, kpc;
+  if (to_cand) {
+    ry = S->cand_px + cand_px_off(L, 0); ru = S->cand_px + cand_px_off(L, 1); rv = S->cand_px + cand_px_off(L, 2);
+    ky = S->cand_co + cand_px_off(L, 0); ku = S->cand_co + cand_px_off(L, 1); kv = S->cand_co + cand_px_off(L, 2);
+    rpy = kpy = n; rpc = kpc = cn;
+  } else {
+    ry = S->Dy + (ly + 1) * PY + lx + 1;
+    ru = S->Du + (((cy & 63) >> 1) + 1) * PC + ((cx & 63) >> 1) + 1; rv = S->Dv + (((cy & 63) >> 1) + 1) * PC + ((cx & 63) >> 1) + 1;
+    ky = J.coeff + ly * LCU + lx;
+    ku = J.coeff + 4096 + ((cy & 63) >> 1) * LCU_C + ((cx & 63) >> 1); kv = J.coeff + 5120 + ((cy & 63) >> 1) * LCU_C + ((cx & 63) >> 1);
+    rpy = PY; rpc = PC; kpy = LCU; kpc = LCU_C;
+  }
+  int cbf = recon_tu(S, J, 0, x, y, lx, ly, n, mode, 0, ry, rpy, ky, kpy);
   if (has_chroma) {
-    const int area = sep ? 8 : n;
-    const int cu = recon_tu(S, J, 1, cx, cy, cx & 63, cy & 63, area, mode, 0);
-    const int cv = recon_tu(S, J, 2, cx, cy, cx & 63, cy & 63, area, mode, cu);
+    const int cu = recon_tu(S, J, 1, cx, cy, cx & 63, cy & 63, area, mode, 0, ru, rpc, ku, kpc);
+    const int cv = recon_tu(S, J, 2, cx, cy, cx & 63, cy & 63, area, mode, cu, rv, rpc, kv, kpc);
     cbf |= cu << 1 | cv << 2;
     { CTU_T0();
-    ssd_block(S, J, 1, cx & 63, cy & 63, area, 1);
-    ssd_block(S, J, 2, cx & 63, cy & 63, area, 2);
+    ssd_block(S, J, 1, cx & 63, cy & 63, area, 1, ru, rpc);
+    ssd_block(S, J, 2, cx & 63, cy & 63, area, 2, rv, rpc);
     CTU_T1(J.W, 4); }
   }
   { CTU_T0();
-  ssd_block(S, J, 0, lx, ly, n, 0);
+  ssd_block(S, J, 0, lx, ly, n, 0, ry, rpy);
   CTU_T1(J.W, 4); }
   CTU_T0();
-  if (CTU_IN_WAVE0) {
+  {
     double bits = 0;
     LANE0 {
-      cu4 *c = cu_at(S, lx, ly);
-      c->cbf = (uint8_t)(cbf & 1);
-      if (has_chroma) {
-        if (!sep) c->cbf = (uint8_t)cbf;
-        else {
-          // the area's chroma flags sit at its first entry and are copied to all four (lcu_fill_chroma_cbfs), with the chroma mode and
-          // chroma size of this, the last, CU (lcu_fill_chroma_cu_info, search.c:355-400)
-          for (int k = 0; k < 4; ++k) {
-            cu4 *q = cu_at(S, (cx & 63) + (k & 1) * 4, (cy & 63) + (k >> 1) * 4);
-            q->cbf = (uint8_t)((q->cbf & 1) | (cbf & 6));
-            q->mode_chroma = (int8_t)mode;
-            q->log2_c = 2;
+      if (!to_cand) {
+        cu4 *c = cu_at(S, lx, ly);
+        c->cbf = (uint8_t)(cbf & 1);
+        if (has_chroma) {
+          if (!sep) c->cbf = (uint8_t)cbf;
+          else {
+            // the area's chroma flags sit at its first entry and are copied to all four (lcu_fill_chroma_cbfs), with the chroma mode and
+            // chroma size of this, the last, CU (lcu_fill_chroma_cu_info, search.c:355-400)
+            for (int k = 0; k < 4; ++k) {
+              cu4 *q = cu_at(S, (cx & 63) + (k & 1) * 4, (cy & 63) + (k >> 1) * 4);
+              q->cbf = (uint8_t)((q->cbf & 1) | (cbf & 6));
+              q->mode_chroma = (int8_t)mode;
+              q->log2_c = 2;
+            }
           }
         }
       }
       // uvg_mock_encode_coding_unit with search_cabac.update = 1 (search.c:1700-1716)
-      split_flag_bits(S, P, S->cur, 1, x, y, lx, ly, n, 0, bits);
-      luma_mode_bits(S, S->cur, 1, x, y, lx, ly, n, mode, bits);
-      if (has_chroma) chroma_mode_bits(S->cur, 1, mode, mode, bits);
+      split_flag_bits(S, P, V->cur, 1, x, y, lx, ly, n, 0, bits);
+      luma_mode_bits(S, V->cur, 1, x, y, lx, ly, n, mode, bits);
+      if (has_chroma) chroma_mode_bits(V->cur, 1, mode, mode, bits);
     }
-    WSYNC();
+    CTU_SYNC();
     const double trc = tr_cost(S, P, 1, n, cbf, has_chroma, cn);       // cu_rd_cost_tr_split_accurate (:1718)
     LANE0 {
       double cost = bits * P.lambda;
       cost += trc;
-      mark_deblocking(S, x, y, lx, ly, n, sep, has_chroma);
-      N.cost = cost; N.type = CU_INTRA; N.mode = mode; N.cbf = cu_at(S, lx, ly)->cbf;
+      if (!to_cand) mark_deblocking(S, x, y, lx, ly, n, sep, has_chroma);
+      N.cost = cost; N.type = CU_INTRA; N.mode = mode; N.cbf = cbf;
     }
   }
   CTU_SYNC();
   CTU_T1(J.W, 5);
 }
 
-// park the CU just evaluated at depth L (1..3) and clear its area of D's side information, as a fresh work-tree level would be
-// (initialize_partial_work_tree zeroes the entries from the CU's origin on, search.c:168-172)
-template <typename PX> CTU_NOINLINE CTU_DEV void park(lds<PX> *S, const job<PX> &J, int L)
-{
-  const level_state &N = S->lvl[L];
-  const int n = 64 >> L, lx = N.x & 63, ly = N.y & 63;
-  for (int color = 0; color < 3; ++color) {
-    const int c = color != 0, w = n >> c, l2 = ilog2_dev(w), pit = pitch_of(color), spit = c ? LCU_C : LCU;
-    const PX *D = plane(S, color) + ((ly >> c) + 1) * pit + (lx >> c) + 1;
-    const int16_t *co = J.coeff + co_off(color) + (ly >> c) * spit + (lx >> c);
-    const int off = cand_px_off(L, color);
-    PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); S->cand_px[off + e] = D[r * pit + q]; S->cand_co[off + e] = CTU_GLOAD(&co[r * spit + q]); }
-  }
-  PAR_FOR(e, (n >> 2) * (n >> 2)) {
-    const int r = e / (n >> 2), q = e - r * (n >> 2);
-    cu4 *c = cu_at(S, lx + q * 4, ly + r * 4);
-    c->type = CU_NOTSET; c->log2 = 0; c->cbf = 0; c->luma_edges = 0; c->chroma_edges = 0; c->log2_c = 0; c->mode = 0; c->mode_chroma = 0;
-  }
-  CTU_SYNC();
-}
-// put the parked CU back: the split lost
+// the depth's unsplit candidate becomes the decision: the split lost (work_tree_copy_up in reverse)
 template <typename PX> CTU_NOINLINE CTU_DEV void unpark(lds<PX> *S, const job<PX> &J, int L)
 {
   const level_state &N = S->lvl[L];
@@ -1948,9 +1992,10 @@ CTU_NOINLINE CTU_DEV void copy_models(uint32_t *dst, const uint32_t *src)
 }
 
 // the 64x64 CU tried with the mode of the first 32x32 CU after the four 32x32 areas are decided (combine_intra_cus, search.c:2082-2143).
-// Returns its cost in lvl[0].cost; D holds it afterwards, the split's result is in the scratch.
+// Returns its cost in lvl[0].cost; D holds it afterwards, the split's result is in the scratch.  (The walk's wave, on the depth-1 scratch.)
 template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu64(lds<PX> *S, const job<PX> &J)
 {
+  wctx *const V = wv_of(S);
   const params &P = J.P;
   level_state &N = S->lvl[0];
   const int x = N.x, y = N.y;
@@ -1964,19 +2009,22 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu64(lds<PX> *S, const job
   PAR_FOR(e, 256) { W->save_cu[e] = *cu_at(S, (e & 15) * 4, (e >> 4) * 4); W->save_tree[e] = S->tree[e]; W->save_tree[256 + e] = S->mtt[e]; }
   CTU_SYNC();
   const int mode = cu_at(S, 0, 0)->mode, mode_chroma = cu_at(S, 0, 0)->mode_chroma;
+  CTU_SYNC();
   SERIAL {
+    V->cur = S->cur;
     for (int e = 0; e < 256; ++e) { cu4 *c = cu_at(S, (e & 15) * 4, (e >> 4) * 4); c->cbf = 0; c->luma_edges = 0; c->chroma_edges = 0; }
     fill_cu(S, 0, 0, 64, mode, mode_chroma, 5, N.split_tree, cu_mtt(N.mode_type_tree, 0));
   }
   CTU_SYNC();
   // the models are the CU's entry models and do not adapt (search_cabac.update is 0 on this path): bits only
   copy_models(S->cur, S->pre[0]);
-  double cost = 0;
   for (int i = 0; i < 4; ++i) {
     const int tx = x + (i & 1) * 32, ty = y + (i >> 1) * 32, lx = tx & 63, ly = ty & 63;
-    int cbf = recon_tu(S, J, 0, tx, ty, lx, ly, 32, mode, 0);
-    const int cu = recon_tu(S, J, 1, tx, ty, lx, ly, 32, mode_chroma, 0);
-    const int cv = recon_tu(S, J, 2, tx, ty, lx, ly, 32, mode_chroma, cu);
+    PX *ry = S->Dy + (ly + 1) * PY + lx + 1, *ru = S->Du + ((ly >> 1) + 1) * PC + (lx >> 1) + 1, *rv = S->Dv + ((ly >> 1) + 1) * PC + (lx >> 1) + 1;
+    int16_t *ky = J.coeff + ly * LCU + lx, *ku = J.coeff + 4096 + (ly >> 1) * LCU_C + (lx >> 1), *kv = J.coeff + 5120 + (ly >> 1) * LCU_C + (lx >> 1);
+    int cbf = recon_tu(S, J, 0, tx, ty, lx, ly, 32, mode, 0, ry, PY, ky, LCU);
+    const int cu = recon_tu(S, J, 1, tx, ty, lx, ly, 32, mode_chroma, 0, ru, PC, ku, LCU_C);
+    const int cv = recon_tu(S, J, 2, tx, ty, lx, ly, 32, mode_chroma, cu, rv, PC, kv, LCU_C);
     cbf |= cu << 1 | cv << 2;
     SERIAL cu_at(S, lx, ly)->cbf = (uint8_t)cbf;
     CTU_SYNC();
@@ -1987,35 +2035,37 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu64(lds<PX> *S, const job
     for (int color = 0; color < 3; ++color) {
       const int c = color != 0, w = 32 >> c, l2 = c ? 4 : 5, spit = c ? LCU_C : LCU;
       const int16_t *co = J.coeff + co_off(color) + (ly >> c) * spit + (lx >> c);
-      PAR_FOR(e, w * w) lv_of(S, color)[e] = CTU_GLOAD(&co[(e >> l2) * spit + (e & (w - 1))]);
+      PAR_FOR(e, w * w) lv_of(V, color)[e] = CTU_GLOAD(&co[(e >> l2) * spit + (e & (w - 1))]);
     }
     CTU_SYNC();
-    ssd_block(S, J, 0, lx, ly, 32, 0); ssd_block(S, J, 1, lx, ly, 32, 1); ssd_block(S, J, 2, lx, ly, 32, 2);
-    if (CTU_IN_WAVE0) {
+    ssd_block(S, J, 0, lx, ly, 32, 0, S->Dy + (ly + 1) * PY + lx + 1, PY);
+    ssd_block(S, J, 1, lx, ly, 32, 1, S->Du + ((ly >> 1) + 1) * PC + (lx >> 1) + 1, PC);
+    ssd_block(S, J, 2, lx, ly, 32, 2, S->Dv + ((ly >> 1) + 1) * PC + (lx >> 1) + 1, PC);
+    {
       LANE0 {
         if (i == 0) {
           double bits = 0;
           split_flag_bits(S, P, S->cur, 0, x, y, 0, 0, 64, 0, bits);
           double mode_bits = 0;
           {   // calc_mode_bits (search.c:988-1003): the luma mode on a copy of the models, the chroma mode without adaptation
-            for (int k = 0; k < NMODELS; ++k) S->post[0][k] = S->cur[k];
-            luma_mode_bits(S, S->post[0], 0, x, y, 0, 0, 64, mode, mode_bits);
+            for (int k = 0; k < NMODELS; ++k) S->work[0][k] = S->cur[k];
+            luma_mode_bits(S, S->work[0], 0, x, y, 0, 0, 64, mode, mode_bits);
             if (mode_chroma == mode) mode_bits += m_fbits(S->cur, M_CHROMA_PRED, 0);
             else mode_bits += 2.0 + m_fbits(S->cur, M_CHROMA_PRED, 1);
           }
           mode_bits += bits;
-          S->u_d0 = mode_bits * P.lambda;
-          S->u_d1 = 0;
+          V->u_d0 = mode_bits * P.lambda;
+          V->u_d1 = 0;
         }
       }
-      WSYNC();
+      CTU_SYNC();
       const double trc = tr_cost(S, P, 0, 32, cu_at(S, lx, ly)->cbf, 1, 16);
       LANE0 {
-        S->u_d1 += trc;
+        V->u_d1 += trc;
         if (i == 3) {
           double c2 = 0;
-          c2 += S->u_d0;
-          c2 += S->u_d1 + 0 * P.lambda;          // the sum of the four blocks + luma_bits (0) * lambda (search.c:779)
+          c2 += V->u_d0;
+          c2 += V->u_d1 + 0 * P.lambda;          // the sum of the four blocks + luma_bits (0) * lambda (search.c:779)
           N.cost = c2;
           mark_deblocking(S, x, y, 0, 0, 64, 0, 1);
         }
@@ -2037,7 +2087,67 @@ template <typename PX> CTU_NOINLINE CTU_DEV void restore64(lds<PX> *S, const job
   CTU_SYNC();
 }
 
-// search_cu (search.c:1299-2221) as a depth-first loop over the quad tree of one CTU
+#define V_flag(S) (wv_of(S)->u_flag)
+
+// ---- the depth pipeline ---------------------------------------------------------------------------------------------------
+// A CU whose split is tried as well is evaluated unsplit by the wave of ITS depth while the walk goes on into its children: the
+// evaluation needs only what is decided before the CU (samples, side information, the entry models) and writes only its own
+// candidate buffers.  The reference evaluates the CU first and uses its cost to cut the children short (search.c:1952-1956,
+// 2002-2005); evaluating children it would have skipped changes nothing: every cut decides "not split", and so does the final
+// comparison whenever a cut would have applied (costs only grow child by child; the pruning test is re-applied when the cost is known).
+#if defined(__HIPCC__)
+CTU_DEV int mb_load(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+CTU_DEV void mb_store(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
+
+// ask the wave of depth L (1..3) to evaluate the CU described by lvl[L] / pre[L] (walk's wave, lane 0 has written both)
+template <typename PX> CTU_DEV void post_eval(lds<PX> *S, const job<PX> &J, int L)
+{
+#if defined(__HIPCC__)
+  CTU_SYNC();
+  LANE0 mb_store(&S->req[L], S->req[L] + 1);
+#else
+  const int me = g_emul_wave;
+  g_emul_wave = 4 - L;                  // host emulation: the other wave's work happens right here
+  eval_cu(S, J, L, 1);
+  g_emul_wave = me;
+  S->done[L] = ++S->req[L];
+#endif
+}
+template <typename PX> CTU_DEV bool eval_ready(lds<PX> *S, int L)
+{
+#if defined(__HIPCC__)
+  return __builtin_amdgcn_readfirstlane(mb_load(&S->done[L]) == S->req[L]) != 0;      // lane 0's view, for every lane
+#else
+  return !g_emul_lazy;
+#endif
+}
+template <typename PX> CTU_DEV void wait_eval(lds<PX> *S, int L)
+{
+#if defined(__HIPCC__)
+  while (mb_load(&S->done[L]) != S->req[L]) __builtin_amdgcn_s_sleep(2);
+  CTU_SYNC();
+#endif
+}
+#if defined(__HIPCC__)
+// waves 1..3: evaluate depth 4 - wave whenever asked, until told to stop (req < 0)
+template <typename PX> CTU_DEV void worker_loop(lds<PX> *S, const job<PX> &J)
+{
+  const int L = 4 - CTU_WAVE;
+  int seen = 0;
+  for (;;) {
+    int r;
+    while ((r = mb_load(&S->req[L])) == seen) __builtin_amdgcn_s_sleep(4);
+    if (r < 0) break;
+    seen = r;
+    eval_cu(S, J, L, 1);
+    CTU_SYNC();
+    LANE0 mb_store(&S->done[L], r);
+  }
+}
+#endif
+
+// search_cu (search.c:1299-2221) as a depth-first loop over the quad tree of one CTU, run by the first wave
 template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
 {
   const params &P = J.P;
@@ -2048,7 +2158,7 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
   CTU_SYNC();
   int L = 0;
   int entering = 1;
-  double ret = 0;            // the cost a finished node hands to its parent (uniform: read from LDS after a barrier)
+  double ret = 0;            // the cost a finished node hands to its parent (uniform: read from LDS after a fence)
   for (;;) {
     level_state &N = S->lvl[L];
     const int n = 64 >> L;
@@ -2061,35 +2171,30 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
       // check_can_use_intra (search.c:1257-1287)
       const int min_w = 64 >> P.depth_max;
       const int can_intra = inside && ((L >= P.depth_min && L <= P.depth_max) || (x & ~(min_w - 1)) + min_w > P.pic_w || (y & ~(min_w - 1)) + min_w > P.pic_h);
-      if (can_intra) eval_cu(S, J, L);
-      else {
-        SERIAL { N.cost = CTU_MAX_DOUBLE; N.type = CU_NOTSET; }
-        CTU_SYNC();
+      const int can_split = (!can_intra || L < P.depth_max) && n > 4;
+      if (!can_split) {
+        // a leaf: evaluated here, straight into the decided state
+        if (can_intra) {
+          CTU_T0();
+          LANE0 S->vsel[CTU_WAVE] = 4 - L;          // the scratch sized for this depth (its own wave has nothing to do for a leaf)
+          CTU_SYNC();
+          eval_cu(S, J, L, 0);
+          LANE0 S->vsel[CTU_WAVE] = 0;
+          CTU_SYNC();
+          CTU_T1(J.W, 19 + L);
+        }
+        else { SERIAL { N.cost = CTU_MAX_DOUBLE; N.type = CU_NOTSET; } CTU_SYNC(); }
+        ret = N.cost; entering = 0; if (L == 0) break; --L; continue;
       }
-      copy_models(S->post[L], S->cur);
-      const int can_split = (N.type == CU_NOTSET || L < P.depth_max) && n > 4;
-      if (!can_split) { ret = N.cost; entering = 0; if (L == 0) break; --L; continue; }
-      // the split: its flag first (models from the CU's entry), then the pruning test of search.c:1952-1956
-      copy_models(S->cur, S->pre[L]);
+      SERIAL { N.type = can_intra ? CU_INTRA : CU_NOTSET; N.cost = CTU_MAX_DOUBLE; N.pending = can_intra; }
+      if (can_intra) post_eval(S, J, L);          // its own wave evaluates the CU unsplit ...
+      // ... while the walk tries the split: its flag first (models from the CU's entry: cur still holds them)
       SERIAL {
         double split_bits = 0;
         split_flag_bits(S, P, S->cur, 1, x, y, x & 63, y & 63, n, 1, split_bits);
-        const double factor = P.qp > 30 ? 1.1 : 1.075;
-        S->u_flag = split_bits * P.lambda + N.cost / factor > N.cost;
+        N.split_bits = split_bits;
         N.split_cost = split_bits * P.lambda;
         N.child = 0;
-      }
-      CTU_SYNC();
-      if (S->u_flag) {
-        // no split tried: the CU stands (best_split_cost stays MAX_DOUBLE, search.c:2145-2169)
-        if (L > 0) copy_models(S->cur, S->post[L]);
-        ret = N.cost; entering = 0; if (L == 0) break; --L; continue;
-      }
-      { CTU_T0();
-      if (N.type != CU_NOTSET) park(S, J, L);
-      CTU_T1(J.W, 6); }
-      // descend to the first child
-      SERIAL {
         level_state &C = S->lvl[L + 1];
         const int cond_infer = (N.mode_type_tree >> ((L - 1 > 0 ? L - 1 : 0) * 2) & 3) == 0 && n == 8;      // uvg_derive_mode_type_cond: MODE_TYPE_INFER
         const uint32_t mode_type = cond_infer ? 2u : (N.mode_type_tree >> ((L - 1 > 0 ? L - 1 : 0) * 2) & 3);
@@ -2102,41 +2207,47 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
       continue;
     }
     // a child of N came back with `ret`
+    const bool known = !N.pending || eval_ready(S, L);      // is the CU's own cost there yet?  (only to stop early; never changes the outcome)
+    if (known && N.pending) wait_eval(S, L);
     SERIAL {
       N.split_cost += ret;
       const int k = N.child;
       const int last = k == 3;
-      S->u_flag = (N.split_cost > N.cost) || last;       // (best_split_cost is still MAX_DOUBLE: one split type)
+      V_flag(S) = (known && N.split_cost > N.cost) || last;       // (best_split_cost is still MAX_DOUBLE: one split type)
       N.child = k + 1;
-      if (!S->u_flag) {
+      if (!V_flag(S)) {
         level_state &C = S->lvl[L + 1];
         const int h = n >> 1, k1 = k + 1;
         C.x = N.x + (k1 & 1) * h; C.y = N.y + (k1 >> 1) * h;
         C.has_chroma = h == 4 ? (k1 == 3) : 1;
-        // mode_type_tree of the child: the parent's bits at the parent's depth were set when it descended, the child adds its parent's type
-        // at its own depth when it is entered (cur_cu->mode_type_tree, search.c:1387-1388) -- done below in the common path
       }
     }
     CTU_SYNC();
-    if (!S->u_flag) { ++L; entering = 1; continue; }
-    // the split is complete (or was cut short): decide.  The comparison is taken by every lane BEFORE lane 0 may overwrite a cost.
-    const bool split_wins = N.split_cost < N.cost;
+    if (!V_flag(S)) { ++L; entering = 1; continue; }
+    // the split is complete (or was cut short): the CU's own cost is needed now
+    if (N.pending) wait_eval(S, L);
+    // The comparison is taken by every lane BEFORE lane 0 may overwrite a cost.
+    const double factor = P.qp > 30 ? 1.1 : 1.075;
+    const bool pruned = N.type != CU_NOTSET && N.split_bits * P.lambda + N.cost / factor > N.cost;      // the reference would not have tried the split (search.c:1952-1956)
+    const bool split_wins = !pruned && N.split_cost < N.cost;
     const int ntype = N.type;
     CTU_SYNC();
     if (L == 0 && ntype == CU_NOTSET && P.combine_intra_cus && N.x + 64 <= P.pic_w && N.y + 64 <= P.pic_h &&
         cu_at(S, 0, 0)->type == CU_INTRA && cu_at(S, 0, 0)->log2 == 5) {
-      copy_models(S->post[4], S->cur);                   // temp_cabac: the models after the split (search.c:2093)
-      SERIAL { S->u_d0 = N.split_cost; }
+      copy_models(S->work[1], S->cur);                   // temp_cabac: the models after the split (search.c:2093); depth 1 is idle by now
+      LANE0 S->vsel[CTU_WAVE] = 3;                       // the depth-1 scratch: 32x32 blocks
       CTU_SYNC();
       { CTU_T0();
       eval_cu64(S, J);
       CTU_T1(J.W, 7); }
       // post_search_cabac = the unadapted entry models; search_cabac = temp_cabac (:2140-2141)
-      copy_models(S->cur, S->post[4]);
-      const bool split_wins64 = N.split_cost < N.cost;        // N.cost: the 64x64 CU's (eval_cu64 ends with a barrier)
+      copy_models(S->cur, S->work[1]);
+      const bool split_wins64 = N.split_cost < N.cost;        // N.cost: the 64x64 CU's (eval_cu64 ends with a fence)
       CTU_SYNC();
       if (split_wins64) { restore64(S, J); SERIAL N.cost = N.split_cost; CTU_SYNC(); }
       else { SERIAL { N.type = CU_INTRA; } CTU_SYNC(); }
+      LANE0 S->vsel[CTU_WAVE] = 0;
+      CTU_SYNC();
       ret = N.cost;
       break;
     }
@@ -2145,7 +2256,7 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
       CTU_SYNC();
     } else {
       CTU_T0();
-      if (L > 0) copy_models(S->cur, S->post[L]);
+      if (L > 0) copy_models(S->cur, S->work[L]);          // post_search_cabac: the models as the unsplit CU leaves them
       if (ntype != CU_NOTSET) unpark(S, J, L);
       CTU_T1(J.W, 6);
     }
@@ -2155,7 +2266,6 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
   }
 }
 
-
 // ====================================================================== the real coder's model adaptation + CTU in / out ======
 CTU_DEV int z_to_x(int z) { return (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4) | ((z >> 3) & 8); }
 
@@ -2163,6 +2273,7 @@ CTU_DEV int z_to_x(int z) { return (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4) | (
 // The quad tree is walked in z-order over the 4x4 units: a CU starts where a unit is aligned to its CU's size.
 template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass(lds<PX> *S, const job<PX> &J)
 {
+  wctx *const V = wv_of(S);
   const params &P = J.P;
   for (int z = 0; z < 256; ++z) {
     const int lx = z_to_x(z) * 4, ly = z_to_x(z >> 1) * 4;
@@ -2180,18 +2291,18 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass(lds<PX> *S, const jo
       {
         const int16_t *co = J.coeff + tly * LCU + tlx;
         const int l2 = ilog2_dev(tn);
-        PAR_FOR(e, tn * tn) lv_of(S, 0)[e] = CTU_GLOAD(&co[(e >> l2) * LCU + (e & (tn - 1))]);
+        PAR_FOR(e, tn * tn) lv_of(V, 0)[e] = CTU_GLOAD(&co[(e >> l2) * LCU + (e & (tn - 1))]);
         if (!sep || last4) {
           const int cw = sep ? 4 : tn >> 1, cl2 = ilog2_dev(cw);
           const int cbx = (sep ? (tlx & ~7) : tlx) >> 1, cby = (sep ? (tly & ~7) : tly) >> 1;
           PAR_FOR(e, cw * cw) {
-            lv_of(S, 1)[e] = CTU_GLOAD(&J.coeff[4096 + (cby + (e >> cl2)) * LCU_C + cbx + (e & (cw - 1))]);
-            lv_of(S, 2)[e] = CTU_GLOAD(&J.coeff[5120 + (cby + (e >> cl2)) * LCU_C + cbx + (e & (cw - 1))]);
+            lv_of(V, 1)[e] = CTU_GLOAD(&J.coeff[4096 + (cby + (e >> cl2)) * LCU_C + cbx + (e & (cw - 1))]);
+            lv_of(V, 2)[e] = CTU_GLOAD(&J.coeff[5120 + (cby + (e >> cl2)) * LCU_C + cbx + (e & (cw - 1))]);
           }
         }
       }
       CTU_SYNC();
-      if (CTU_IN_WAVE0) {
+      {
         uint32_t *m = S->coder;
         double dummy = 0;
         const int cb_y = t->cbf & 1, cb_u = (t->cbf >> 1) & 1, cb_v = (t->cbf >> 2) & 1;
@@ -2213,10 +2324,10 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass(lds<PX> *S, const jo
           m_code(m, 1, M_CBF_LUMA + 0, cb_y, dummy);      // luma_cbf_ctx stays 0: one transform unit per CU, or a CU that is not a TU
         }
         WSYNC();
-        if (cb_y) (void)coeff_bits(S, m, 1, lv_of(S, 0), tn, 0);
+        if (cb_y) (void)coeff_bits(S, m, 1, lv_of(V, 0), tn, 0);
         if (!sep) {
-          if (cb_u) (void)coeff_bits(S, m, 1, lv_of(S, 1), tn >> 1, 1);
-          if (cb_v) (void)coeff_bits(S, m, 1, lv_of(S, 2), tn >> 1, 2);
+          if (cb_u) (void)coeff_bits(S, m, 1, lv_of(V, 1), tn >> 1, 1);
+          if (cb_v) (void)coeff_bits(S, m, 1, lv_of(V, 2), tn >> 1, 2);
         } else if (last4) {
           // the area's chroma after its last luma CU: mode (the co-located luma CU is this one), cbfs of the area's first entry, levels
           const cu4 *a = cu_at(S, lx & ~7, ly & ~7);
@@ -2227,8 +2338,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass(lds<PX> *S, const jo
             m_code(m, 1, M_CBF_CR + au, av, dummy);
           }
           WSYNC();
-          if (au) (void)coeff_bits(S, m, 1, lv_of(S, 1), 4, 1);
-          if (av) (void)coeff_bits(S, m, 1, lv_of(S, 2), 4, 2);
+          if (au) (void)coeff_bits(S, m, 1, lv_of(V, 1), 4, 1);
+          if (av) (void)coeff_bits(S, m, 1, lv_of(V, 2), 4, 2);
         }
       }
       CTU_SYNC();
@@ -2241,10 +2352,10 @@ template <typename PX> CTU_NOINLINE CTU_DEV void load_ctu(lds<PX> *S, const job<
 {
   const params &P = J.P;
   const int x = J.x, y = J.y, W = P.pic_w, H = P.pic_h;
-  PAR_FOR(i, 17 * 17) { cu4 z = {0, 0, 0, 0, 0, 0, 0, 0}; S->cu[i] = z; }
-  PAR_FOR(i, 256) { S->tree[i] = 0; S->mtt[i] = 0; }
-  CTU_SYNC();
-  PAR_FOR(i, 33) {
+  BLK_FOR(i, 17 * 17) { cu4 z = {0, 0, 0, 0, 0, 0, 0, 0}; S->cu[i] = z; }
+  BLK_FOR(i, 256) { S->tree[i] = 0; S->mtt[i] = 0; }
+  BLK_SYNC();
+  BLK_FOR(i, 33) {
     // i = 0: the corner, 1..16 the row above, 17..32 the column to the left
     int ax, ay, ok;
     if (i == 0) { ax = x - 4; ay = y - 4; ok = x > 0 && y > 0; }
@@ -2263,27 +2374,21 @@ template <typename PX> CTU_NOINLINE CTU_DEV void load_ctu(lds<PX> *S, const job<
     const PX *rec = color == 0 ? J.rec_y : (color == 1 ? J.rec_u : J.rec_v);
     const int rs = c ? J.rec_stride_c : J.rec_stride;
     const int px = x >> c, py = y >> c, pw = W >> c, ph = H >> c;
-    PAR_FOR(i, 2 * w + 1) {
+    BLK_FOR(i, 2 * w + 1) {
       // i = 0 corner, 1..w the row above, w + 1..2w the column to the left
       if (i == 0) { if (px > 0 && py > 0) D[0] = rec[(py - 1) * rs + px - 1]; }
       else if (i <= w) { const int q = px + i - 1; if (py > 0 && q < pw) D[i] = rec[(py - 1) * rs + q]; }
       else { const int r = py + i - w - 1; if (px > 0 && r < ph) D[(i - w) * pit] = rec[r * rs + px - 1]; }
     }
-    if (color == 0) {
-      PAR_FOR(e, w * w) {
-        const int r = e / w, q = e - r * w;
-        S->Sy[e] = (py + r < ph && px + q < pw) ? J.src_y[(py + r) * J.src_stride + px + q] : (PX)0;
-      }
-    }
   }
-  PAR_FOR(i, 512) tab_ebits()[i] = kEntropyBits[i];
-  PAR_FOR(i, NMODELS) {
+  BLK_FOR(i, 512) tab_ebits()[i] = kEntropyBits[i];
+  BLK_FOR(i, NMODELS) {
     tab_rate()[i] = k_ctx_init[3][i];
     if (J.models_in) S->coder[i] = J.models_in[i];
     else models_init_one(S->coder, i, P.qp, 2);
   }
-  CTU_SYNC();
-  PAR_FOR(i, NMODELS) {
+  BLK_SYNC();
+  BLK_FOR(i, NMODELS) {
     const uint32_t v = S->coder[i];
     S->cur[i] = v;
     J.models_out[i] = v;
@@ -2294,8 +2399,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void load_ctu(lds<PX> *S, const job<
       tab_rdoq_bits()[2 * i + 1] = kEntropyBits[(st << 1) ^ 1];
     }
   }
-  CTU_SYNC();
-  PAR_FOR(cfg, 16) {            // calc_last_bits (rdo.c:664-700) for every shape once: the models uvg_rdoq prices with are the CTU's
+  BLK_SYNC();
+  BLK_FOR(cfg, 16) {            // calc_last_bits (rdo.c:664-700) for every shape once: the models uvg_rdoq prices with are the CTU's
     const int t = cfg >> 3, l2 = 2 + ((cfg >> 1) & 3), xy = cfg & 1, n = 1 << l2;
     const int prefix_ctx[8] = {0, 0, 0, 3, 6, 10, 15, 21};
     const int off = t ? 0 : prefix_ctx[l2];
@@ -2310,7 +2415,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void load_ctu(lds<PX> *S, const job<
     }
     S->last_bits[t][l2 - 2][xy][ctx] = b;
   }
-  CTU_SYNC();
+  BLK_SYNC();
 }
 
 // copy_lcu_to_cu_data (search.c:2331-2377) + the models of the three checkpoints
@@ -2324,12 +2429,12 @@ template <typename PX> CTU_NOINLINE CTU_DEV void store_ctu(lds<PX> *S, const job
     PX *rec = color == 0 ? J.rec_y : (color == 1 ? J.rec_u : J.rec_v);
     const int rs = c ? J.rec_stride_c : J.rec_stride;
     const int px = x >> c, py = y >> c, pw = W >> c, ph = H >> c;
-    PAR_FOR(e, w * w) {
+    BLK_FOR(e, w * w) {
       const int r = e / w, q = e - r * w;
       if (py + r < ph && px + q < pw) rec[(py + r) * rs + px + q] = D[r * pit + q];
     }
   }
-  PAR_FOR(e, 256) {
+  BLK_FOR(e, 256) {
     const int lx = (e & 15) * 4, ly = (e >> 4) * 4;
     if (x + lx < W && y + ly < H) {
       const cu4 *c = cu_at(S, lx, ly);
@@ -2345,29 +2450,69 @@ template <typename PX> CTU_NOINLINE CTU_DEV void store_ctu(lds<PX> *S, const job
   }
 }
 
-// one CTU, start to finish
+// carve the arena: wv[k] serves depth 4 - k (blocks of 4 << k)
+template <typename PX> CTU_DEV void setup_waves(lds<PX> *S)
+{
+  BLK_FOR(k, 4) {
+    const int n = 4 << k, nn = n * n, c2 = (n / 2) * (n / 2) < 16 ? 16 : (n / 2) * (n / 2), tiles = n >= 8 ? (n / 8) * (n / 8) : 1;
+    int off = 0;
+    for (int j = 0; j < k; ++j) off += arena_bytes(4 << j);
+    unsigned char *a = S->arena + off;
+    wctx *V = &S->wv[k];
+    const int rn = 4 * n + 8;
+    V->refn = (int16_t)rn;
+    V->top = (uint16_t *)a; V->left = V->top + rn; V->ftop = V->left + rn; V->fleft = V->ftop + rn; a += 4 * rn * 2;
+    V->t0 = (int16_t *)a; V->t1 = V->t0 + nn; V->t2 = V->t1 + nn; a += 3 * nn * 2;
+    V->lv0 = (int16_t *)a; V->lv1 = V->lv0 + nn; V->lv2 = V->lv1 + c2; a += (nn + 2 * c2) * 2;
+    V->part = (uint32_t *)a; a += 2 * 18 * tiles * 4;
+    V->lv_spend = a; a += nn;
+    a = S->arena + ((a - S->arena + 7) & ~7);
+    if (n <= 16) { V->rq_cc = (double *)a; V->rq_cs = V->rq_cc + nn; V->rq_c0 = V->rq_cs + nn; }
+    else V->rq_cc = V->rq_cs = V->rq_c0 = nullptr;
+    V->cur = S->cur;
+    S->vsel[k] = k;
+    S->req[k] = 0; S->done[k] = 0;
+  }
+  BLK_SYNC();
+}
+
+// one CTU, start to finish (all four waves)
 template <typename PX> CTU_DEV void run_ctu(lds<PX> *S, const job<PX> &J)
 {
 #if defined(__HIPCC__) && defined(CTU_PROFILE)
-  SERIAL { for (int i = 0; i < 24; ++i) J.W->prof[i] = 0; }
+  BLK_FOR(i, 4 * 32) J.W->prof[i >> 5][i & 31] = 0;
 #endif
   CTU_T0();
   { CTU_T0();
-  build_scans(S);
+  setup_waves(S);
+  if (CTU_WAVE == 0) build_scans(S);
+  BLK_SYNC();
   load_ctu(S, J);
   // the CTU's coefficient array starts empty (lcu->coeff = calloc, encoderstate.c:752)
-  PAR_FOR(e, 6144) J.coeff[e] = 0;
-  CTU_SYNC();
+  BLK_FOR(e, 6144) J.coeff[e] = 0;
+  BLK_SYNC();
   CTU_T1(J.W, 9); }
-  search_ctu(S, J);
-  PAR_FOR(i, NMODELS) J.models_out[NMODELS + i] = S->cur[i];
+#if defined(__HIPCC__)
+  if (CTU_WAVE == 0) {
+#endif
+    search_ctu(S, J);
+    PAR_FOR(i, NMODELS) J.models_out[NMODELS + i] = S->cur[i];
+    { CTU_T0();
+    LANE0 S->vsel[CTU_WAVE] = 3;          // the depth-1 scratch for the coder's 32x32 blocks: the other waves are idle now
+    CTU_SYNC();
+    coder_pass(S, J);
+    CTU_T1(J.W, 8); }
+#if defined(__HIPCC__)
+    LANE0 { for (int L = 1; L <= 3; ++L) mb_store(&S->req[L], -1); }
+  } else {
+    worker_loop(S, J);
+  }
+#endif
+  BLK_SYNC();
   { CTU_T0();
-  coder_pass(S, J);
-  CTU_T1(J.W, 8); }
-  { CTU_T0();
-  PAR_FOR(i, NMODELS) J.models_out[2 * NMODELS + i] = S->coder[i];
+  BLK_FOR(i, NMODELS) J.models_out[2 * NMODELS + i] = S->coder[i];
   store_ctu(S, J);
-  CTU_SYNC();
+  BLK_SYNC();
   CTU_T1(J.W, 10); }
   CTU_T1(J.W, 11);
 }
