@@ -15,9 +15,12 @@ ctus = ((W + 63) // 64) * ((H + 63) // 64) * n
 al = lambda v, a: (v + a - 1) // a * a
 off_order = al(256 + ctus * 4, 256); off_pics = al(off_order + ctus * 4, 256); off_scr = al(off_pics + n * 88, 256)
 ws = cs.ws.cpu().numpy()
-SZ = 53376 + 64
-prof = np.stack([ws[off_scr + i * SZ + SZ - 192: off_scr + i * SZ + SZ].view(np.uint64) for i in range(ctus)]).astype(np.float64)
-names = ["rough search", "refs+predict", "residual+transforms+recon", "RDOQ", "SSD", "RD cost bits", "park/unpark/models", "64x64 candidate", "coder pass", "load", "store", "TOTAL", "rq: candidates+last", "rq: pre-walk", "rq: decide", "rq: accumulate+group", "rq: copy-out", "rq: cbf+last search", "rq: signs", "eval depth 0", "eval depth 1 (32x32)", "eval depth 2 (16x16)", "eval depth 3 (8x8)", "eval depth 4 (4x4)"]
-tot = prof[:, 11].mean()
-print("mean ticks per CTU (s_memtime, 100 MHz): total %.0f = %.2f ms" % (tot, tot / 1e5))
-for i, nm in enumerate(names): print(f"  {nm:28s} {prof[:, i].mean():10.0f}  {100 * prof[:, i].mean() / tot:5.1f} %")
+SZ = 54272
+prof = np.stack([ws[off_scr + i * SZ + SZ - 1024: off_scr + i * SZ + SZ].view(np.uint64).reshape(4, 32) for i in range(ctus)]).astype(np.float64)
+names = ["rough search", "refs+predict", "residual+transforms+recon", "RDOQ", "SSD", "RD cost bits", "unpark/models", "64x64 candidate", "coder pass", "load", "store", "TOTAL",
+         "rq: candidates+last", "rq: pre-walk", "rq: decide", "rq: accumulate+group", "rq: copy-out", "rq: cbf+last search", "rq: signs", "leaf depth 0", "leaf depth 1", "leaf depth 2", "leaf depth 3", "leaf depth 4 (4x4)", "rs: setup", "rs: rough_costs", "rs: mode cost", "rs: select", "cb: last+flags", "cb: records+budget", "cb: sweeps", "cb: bypass+lane0"]
+tot = prof[:, 0, 11].mean()
+print("mean cycles per CTU: total %.0f (%.2f ms at 2.1 GHz)" % (tot, tot / 2.1e6))
+print("%-28s %12s %12s %12s %12s" % ("", "wave0 (4x4+walk)", "wave1 (8x8)", "wave2 (16x16)", "wave3 (32x32)"))
+for i, nm in enumerate(names):
+    print("  %-26s" % nm + "".join("%12.0f" % prof[:, w, i].mean() for w in range(4)))

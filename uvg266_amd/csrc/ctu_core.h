@@ -59,8 +59,12 @@
 // a load that must see what another wave of this workgroup stored to global memory earlier (served by L2, not by this CU's L1)
 #if defined(__HIPCC__)
 #define CTU_GLOAD(p) __builtin_nontemporal_load(p)
+#define CTU_LDS __attribute__((address_space(3)))
+#define CTU_GLB __attribute__((address_space(1)))
 #else
 #define CTU_GLOAD(p) (*(p))
+#define CTU_LDS
+#define CTU_GLB
 #endif
 // optional phase timers (lane 0 of the wave, s_memtime ticks) -- compiled in with -DCTU_PROFILE, results in scratch::prof[wave]
 #if defined(__HIPCC__) && defined(CTU_PROFILE)
@@ -70,6 +74,12 @@
 #define CTU_T0() ((void)0)
 #define CTU_T1(W, slot) ((void)0)
 #endif
+#if defined(__HIPCC__) && defined(CTU_PROFILE)
+#define RQ_T(slot) do { const unsigned long long t2 = __builtin_amdgcn_s_memtime(); if (CTU_TID == 0) W->prof[CTU_WAVE][slot] += t2 - tq; tq = t2; } while (0)
+#else
+#define RQ_T(slot) ((void)0)
+#endif
+#define LDSP(T, p) ((CTU_LDS T *)(p))          // a pointer known to point into the workgroup's LDS image (device: ds_* instead of flat_*)
 #define PAR_FOR(i, n) for (int i = CTU_TID; i < (n); i += CTU_NT)
 #define BLK_FOR(i, n) for (int i = BLK_TID; i < (n); i += BLK_NT)
 #define SERIAL if (CTU_TID == 0)
@@ -130,9 +140,11 @@ struct wctx {
   uint32_t *cur;                                    // the models this wave's bit counting works on
   double rq_stage[3 * 16];                          // RDOQ: costs of the coefficient group in flight
   double rs_cost[67];
+  double rs_cand[3 + 24], rs_best_cost[2][3];      // rough search: costs of the survivors and of the listed modes; the survivors, double-buffered
   double u_d0, u_d1;
   int32_t rq_i[16];
-  int32_t rs_list[24];
+  int32_t rs_list[24], rs_best_mode[2][3];
+  uint32_t rs_chk[3];
   int32_t red[8], partial[64];
   int32_t u_avail_left, u_avail_top, u_mode, u_flag, u_n_modes;
   uint8_t cg_flag[64];
@@ -147,8 +159,12 @@ constexpr int arena_bytes(int n)     // one depth's share of the arena (n = its 
 }
 enum { ARENA_BYTES = arena_bytes(4) + arena_bytes(8) + arena_bytes(16) + arena_bytes(32) };
 
+struct scratch;
 // LDS image of a workgroup
 template <typename PX> struct lds {
+#if defined(CTU_PROFILE)
+  scratch *prof_w;
+#endif
   PX Dy[65 * PY], Du[33 * PC], Dv[33 * PC];         // decided planes, index (y + 1) * pitch + x + 1
   PX cand_px[2016];                                 // a depth's CU while its split is being tried (depths 1..3)
   int16_t cand_co[2016];
@@ -200,12 +216,12 @@ template <typename PX> struct job {
 
 // the source samples of a block of `color` at CTU-local (bx, by) (in that plane's samples), read from the picture; -> pointer, pitch
 // (blocks never reach outside the picture: a CU is only coded when it lies inside)
-template <typename PX> CTU_DEV const PX *src_block(const job<PX> &J, int color, int bx, int by, int *pitch)
+template <typename PX> CTU_DEV CTU_GLB const PX *src_block(const job<PX> &J, int color, int bx, int by, int *pitch)
 {
   const PX *p = color == 0 ? J.src_y : (color == 1 ? J.src_u : J.src_v);
   const int st = color == 0 ? J.src_stride : J.src_stride_c, sh = color != 0;
   *pitch = st;
-  return p + (size_t)((J.y >> sh) + by) * st + (J.x >> sh) + bx;
+  return (CTU_GLB const PX *)(p + (size_t)((J.y >> sh) + by) * st + (J.x >> sh) + bx);
 }
 
 
@@ -223,8 +239,8 @@ CTU_DEV uint8_t *tab_rate() { CTU_SHARED uint8_t t[264]; return t; }
 CTU_DEV uint32_t *tab_rdoq_bits() { CTU_SHARED uint32_t t[2 * 244]; return t; }
 #define kRate (tab_rate())         // the window byte of every model (rate0 << 4 | rate1)
 
-CTU_DEV int m_state(const uint32_t *m, int c) { return (int)(((m[c] & 0xffffu) + (m[c] >> 16)) >> 8); }
-CTU_DEV void m_update(uint32_t *m, int c, int bin)            // CTX_UPDATE, cabac.h:182-193
+template <typename MP> CTU_DEV int m_state(MP m, int c) { return (int)(((m[c] & 0xffffu) + (m[c] >> 16)) >> 8); }
+template <typename MP> CTU_DEV void m_update(MP m, int c, int bin)            // CTX_UPDATE, cabac.h:182-193
 {
   const int r0 = kRate[c] >> 4, r1 = kRate[c] & 15;
   uint32_t s0 = m[c] & 0xffffu, s1 = m[c] >> 16;
@@ -235,9 +251,9 @@ CTU_DEV void m_update(uint32_t *m, int c, int bin)            // CTX_UPDATE, cab
 }
 // uvg_f_entropy_bits (rdo.c:143, a float table) = uvg_entropy_bits / 2^15: every entry is an integer below 2^24 over 2^15, so the
 // float and this double quotient are the same number
-CTU_DEV double m_fbits(const uint32_t *m, int c, int bin) { return (double)tab_ebits()[(m_state(m, c) << 1) ^ bin] / 32768.0; }
+template <typename MP> CTU_DEV double m_fbits(MP m, int c, int bin) { return (double)tab_ebits()[(m_state(m, c) << 1) ^ bin] / 32768.0; }
 // CABAC_FBITS_UPDATE with only_count = 1
-CTU_DEV void m_code(uint32_t *m, int update, int c, int bin, double &bits)
+template <typename MP> CTU_DEV void m_code(MP m, int update, int c, int bin, double &bits)
 {
   bits += m_fbits(m, c, bin);
   if (update) m_update(m, c, bin);
@@ -342,42 +358,45 @@ template <typename PX> CTU_NOINLINE CTU_DEV void build_refs(lds<PX> *S, const pa
   CTU_SYNC();
   const int al = V->u_avail_left, at = V->u_avail_top;
   const int dc = 1 << (px_info<PX>::depth - 1);
+  CTU_LDS uint16_t *const r_top = LDSP(uint16_t, V->top), *const r_left = LDSP(uint16_t, V->left);
+  CTU_LDS uint16_t *const r_ftop = LDSP(uint16_t, V->ftop), *const r_fleft = LDSP(uint16_t, V->fleft);
   PAR_FOR(i, V->refn - 1) {
     int lv, tv;
     if (x > 0) lv = D[(i < al ? i : al - 1) * pit - 1];
     else lv = y > 0 ? D[-pit] : dc;
     if (y > 0) tv = D[-pit + (i < at ? i : at - 1)];
     else tv = x > 0 ? D[-1] : dc;
-    V->left[i + 1] = (uint16_t)lv;
-    V->top[i + 1] = (uint16_t)tv;
+    r_left[i + 1] = (uint16_t)lv;
+    r_top[i + 1] = (uint16_t)tv;
   }
   SERIAL {
     int corner;
     if (x > 0 && y > 0) corner = D[-pit - 1];
     else corner = x > 0 ? D[-1] : (y > 0 ? D[-pit] : dc);       // "copy reference clockwise": left[1]
-    V->left[0] = V->top[0] = (uint16_t)corner;
+    r_left[0] = r_top[0] = (uint16_t)corner;
   }
   CTU_SYNC();
   PAR_FOR(i, V->refn) {
     int fl, ft;
-    if (i == 0) fl = ft = (V->left[1] + 2 * V->left[0] + V->top[1] + 2) >> 2;
+    if (i == 0) fl = ft = (r_left[1] + 2 * r_left[0] + r_top[1] + 2) >> 2;
     else {
-      fl = i < 2 * w ? (V->left[i - 1] + 2 * V->left[i] + V->left[i + 1] + 2) >> 2 : V->left[i];
-      ft = i < 2 * w ? (V->top[i - 1] + 2 * V->top[i] + V->top[i + 1] + 2) >> 2 : V->top[i];
+      fl = i < 2 * w ? (r_left[i - 1] + 2 * r_left[i] + r_left[i + 1] + 2) >> 2 : r_left[i];
+      ft = i < 2 * w ? (r_top[i - 1] + 2 * r_top[i] + r_top[i + 1] + 2) >> 2 : r_top[i];
     }
-    V->fleft[i] = (uint16_t)fl;
-    V->ftop[i] = (uint16_t)ft;
+    r_fleft[i] = (uint16_t)fl;
+    r_ftop[i] = (uint16_t)ft;
   }
   CTU_SYNC();
 }
 
 // prediction of the w x w block of `color` from the reference rows into dst (pitch dp)
-template <typename PX> CTU_NOINLINE CTU_DEV void predict_block(lds<PX> *S, int mode, int color, int w, PX *dst, int dp)
+template <typename PX> CTU_NOINLINE CTU_DEV void predict_block(lds<PX> *S, int mode, int color, int w, PX *dst_, int dp)
 {
   wctx *const V = wv_of(S);
   const mode_info M = make_mode_info(mode, w, w, color != 0);
-  const ref_rows R = {V->top, V->left, V->ftop, V->fleft};
-  const int dc = mode == 1 ? dc_value(V->top, V->left, w, w) : 0;
+  const ref_rows_t<CTU_LDS const uint16_t *> R = {LDSP(const uint16_t, V->top), LDSP(const uint16_t, V->left), LDSP(const uint16_t, V->ftop), LDSP(const uint16_t, V->fleft)};
+  const int dc = mode == 1 ? dc_value(R.top, R.left, w, w) : 0;
+  CTU_LDS PX *const dst = LDSP(PX, dst_);
   const int segs = w >> 2;
   PAR_FOR(t, w * segs) {
     const int yd = t / segs, xd0 = (t - yd * segs) * 4;
@@ -440,10 +459,11 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rough_costs(lds<PX> *S, const j
 {
   wctx *const V = wv_of(S);
   int sps;
-  const PX *Sy = src_block(J, 0, lx, ly, &sps);
+  CTU_GLB const PX *Sy = src_block(J, 0, lx, ly, &sps);
   const int T = n >= 8 ? 8 : 4, tiles_x = n / T, tiles = tiles_x * tiles_x;
-  const ref_rows R = {V->top, V->left, V->ftop, V->fleft};
-  const int dcv = dc_value(V->top, V->left, n, n);
+  const ref_rows_t<CTU_LDS const uint16_t *> R = {LDSP(const uint16_t, V->top), LDSP(const uint16_t, V->left), LDSP(const uint16_t, V->ftop), LDSP(const uint16_t, V->fleft)};
+  const int dcv = dc_value(R.top, R.left, n, n);
+  CTU_LDS uint32_t *const part = LDSP(uint32_t, V->part);
 #if defined(__HIPCC__)
   const int total = n_modes * tiles * T;
   for (int base = 0; base < total; base += CTU_NT) {
@@ -478,7 +498,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rough_costs(lds<PX> *S, const j
       satd = satd4_cost(d, r);
       sad = dpp_group_sum<4>(sad);
     }
-    if (on && r == 0) { V->part[2 * task] = (uint32_t)satd; V->part[2 * task + 1] = (uint32_t)sad; }
+    if (on && r == 0) { part[2 * task] = (uint32_t)satd; part[2 * task + 1] = (uint32_t)sad; }
   }
   CTU_SYNC();
 #else
@@ -516,8 +536,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rough_costs(lds<PX> *S, const j
       }
       satd = satd4_tile(d);
     }
-    V->part[2 * task] = satd;
-    V->part[2 * task + 1] = sad;
+    part[2 * task] = satd;
+    part[2 * task + 1] = sad;
   }
   CTU_SYNC();
 #endif
@@ -587,87 +607,110 @@ template <typename PX> CTU_NOINLINE CTU_DEV void search_intra_rough(lds<PX> *S, 
   wctx *const V = wv_of(S);
   const params &P = J.P;
   const int T = n >= 8 ? 8 : 4, tiles = (n / T) * (n / T);
+#if defined(__HIPCC__) && defined(CTU_PROFILE)
+  scratch *const W = J.W;
+  unsigned long long tq = __builtin_amdgcn_s_memtime();
+#endif
   SERIAL {
     const cu4 *l, *a;
     mpm_neighbours(S, x, y, lx, ly, n, &l, &a);
     dir_luma_predictor(y, V->mpm, l, a);
     const int offset = 1 << P.rough_levels;
     int k = 0;
+    uint32_t h0 = 3, h1 = 0, h2 = 0;            // modes costed so far
     V->rs_list[k++] = 0; V->rs_list[k++] = 1;
     for (int mode = 2 + offset / 2; mode <= 66; mode += 2 * offset)
-      for (int i = 0; i < 2; ++i) if (mode + i * offset <= 66) V->rs_list[k++] = mode + i * offset;
+      for (int i = 0; i < 2; ++i) {
+        const int m = mode + i * offset;
+        if (m > 66) continue;
+        V->rs_list[k++] = m;
+        const uint32_t bit = 1u << (m & 31);
+        if (m < 32) h0 |= bit; else if (m < 64) h1 |= bit; else h2 |= bit;
+      }
+    V->rs_chk[0] = h0; V->rs_chk[1] = h1; V->rs_chk[2] = h2;
     V->u_n_modes = k;
   }
   CTU_SYNC();
+  RQ_T(24);
   // (rs_list holds at most 18 entries with rough_levels >= 2; the host refuses smaller values)
-  uint32_t chk[3] = {0, 0, 0};              // modes already costed (lane 0's own state across the rounds)
-  struct { int mode; double cost; } best[3];
-  double min_cost = 0, max_cost = 0;
+  // The reference inserts every costed mode into a three-entry list with a strict "<" (search_intra.c:1071-1143), i.e. the list is
+  // the three smallest of everything costed so far under the order (cost, insertion sequence); DC is inserted ahead of planar when
+  // the two tie (:1089-1106).  Here a lane per candidate counts the candidates ahead of it -- no loop-carried list.
   int offset = 1 << P.rough_levels;
   for (int round = 0;; ++round) {
     rough_costs(S, J, lx, ly, n, V->rs_list, V->u_n_modes);
-    PAR_FOR(mi, V->u_n_modes) {                 // a lane per mode: tile sums, bit cost (count_bits reads the four flag costs itself)
-      const double mpm_bit = m_fbits(V->cur, M_MPM, 1), not_mpm_bit = m_fbits(V->cur, M_MPM, 0);
-      const double planar = m_fbits(V->cur, M_PLANAR + 1, 0), not_planar = m_fbits(V->cur, M_PLANAR + 1, 1);
+    RQ_T(25);
+    const int nm = V->u_n_modes;
+    CTU_LDS const uint32_t *const mdl = LDSP(const uint32_t, V->cur), *const part = LDSP(const uint32_t, V->part);
+    PAR_FOR(mi, nm) {                           // a lane per mode: tile sums, bit cost (count_bits reads the four flag costs itself)
+      const double mpm_bit = m_fbits(mdl, M_MPM, 1), not_mpm_bit = m_fbits(mdl, M_MPM, 0);
+      const double planar = m_fbits(mdl, M_PLANAR + 1, 0), not_planar = m_fbits(mdl, M_PLANAR + 1, 1);
       const int mode = V->rs_list[mi];
       unsigned satd = 0, sad = 0;
-      for (int t = 0; t < tiles; ++t) { satd += V->part[2 * (mi * tiles + t)]; sad += V->part[2 * (mi * tiles + t) + 1]; }
+      for (int t = 0; t < tiles; ++t) { satd += part[2 * (mi * tiles + t)]; sad += part[2 * (mi * tiles + t) + 1]; }
       if (n >= 8) satd >>= (px_info<PX>::depth - 8);       // satd_NxN shifts, the 4x4 function does not (picture-generic.c:170)
       sad >>= (px_info<PX>::depth - 8);
       double c = (double)(satd < sad * 2 ? satd : sad * 2);
       c += count_bits(V->mpm, planar, not_planar, mpm_bit, not_mpm_bit, mode) * P.lambda_sqrt;
-      V->rs_cost[mode] = c;
+      V->rs_cand[3 + mi] = c;
+    }
+    CTU_SYNC();
+    RQ_T(26);
+    // candidates: the survivors so far (sequence 0..2, rounds > 0), then the listed modes (sequence 3 + index; round 0: DC 0, planar 1)
+    const int first = round ? 0 : 3;
+    const int cur = round & 1;
+    PAR_FOR(ci0, nm + 3 - first) {
+      const int ci = ci0 + first;
+      const double c = V->rs_cand[ci];
+      const int seq = (round == 0 && ci < 5) ? 4 - ci : ci;
+      int rank = 0, differs = 0;
+      const double c_first = V->rs_cand[first];
+      for (int cj = first; cj < nm + 3; ++cj) {
+        const double o = V->rs_cand[cj];
+        const int oseq = (round == 0 && cj < 5) ? 4 - cj : cj;
+        rank += (o < c || (o == c && oseq < seq)) ? 1 : 0;
+        differs |= o != c_first;
+      }
+      if (rank < 3) { V->rs_best_mode[cur][rank] = ci < 3 ? V->rs_best_mode[cur ^ 1][ci] : V->rs_list[ci - 3]; V->rs_best_cost[cur][rank] = c; }
+      if (round == 0 && ci0 == 0) V->u_flag = differs;          // min_cost != max_cost (:1082-1143): only the first round moves them
     }
     CTU_SYNC();
     SERIAL {
-      const int nm = V->u_n_modes;
-      for (int mi = 0; mi < nm; ++mi) {
-        const int mode = V->rs_list[mi];
-        const double c = V->rs_cost[mode];
-        chk[mode >> 5] |= 1u << (mode & 31);
-        if (round == 0 && mi < 2) {
-          if (mi == 1) {
-            const double c0 = V->rs_cost[0], c1 = V->rs_cost[1];
-            if (c0 < c1) { min_cost = c0; max_cost = c1; best[0].mode = 0; best[0].cost = c0; best[1].mode = 1; best[1].cost = c1; }
-            else { min_cost = c1; max_cost = c0; best[1].mode = 0; best[1].cost = c0; best[0].mode = 1; best[0].cost = c1; }
-            best[2].mode = 0; best[2].cost = CTU_MAX_DOUBLE;
-          }
-          continue;
-        }
-        if (round == 0) { if (c < min_cost) min_cost = c; if (c > max_cost) max_cost = c; }
-        for (int j = 0; j < 3; j++)
-          if (c < best[j].cost) {
-            for (int k = 2; k > j; k--) best[k] = best[k - 1];
-            best[j].cost = c; best[j].mode = mode;
-            break;
-          }
-      }
       // next round's list (search_intra.c:1146-1215)
-      offset >>= 1;
+      const int b0 = V->rs_best_mode[cur][0], b1 = V->rs_best_mode[cur][1], b2 = V->rs_best_mode[cur][2];
+      const double k0 = V->rs_best_cost[cur][0], k1 = V->rs_best_cost[cur][1], k2 = V->rs_best_cost[cur][2];
+      uint32_t h0 = V->rs_chk[0], h1 = V->rs_chk[1], h2 = V->rs_chk[2];
+      const int go = (offset >> 1) > 0 && V->u_flag;
       int k = 0;
-      if (offset > 0 && min_cost != max_cost) {
-        for (int i = 0; i < 3; i++) {
-          const int center = best[i].mode;
-          if (center < 3 || center > 65) continue;
-          const int test[2] = {center - offset, center + offset};
-          for (int j = 0; j < 2; j++)
-            if (test[j] >= 2 && test[j] <= 66 && !((chk[test[j] >> 5] >> (test[j] & 31)) & 1)) { V->rs_list[k++] = test[j]; chk[test[j] >> 5] |= 1u << (test[j] & 31); }
-        }
+      if (go) {
+        const int off = offset >> 1;
+#define CTU_TRY(m_) do { const int m = (m_); if (m >= 2 && m <= 66) { const uint32_t bit = 1u << (m & 31); const uint32_t w = m < 32 ? h0 : (m < 64 ? h1 : h2); \
+          if (!(w & bit)) { V->rs_list[k++] = m; if (m < 32) h0 |= bit; else if (m < 64) h1 |= bit; else h2 |= bit; } } } while (0)
+        if (b0 >= 3 && b0 <= 65) { CTU_TRY(b0 - off); CTU_TRY(b0 + off); }
+        if (b1 >= 3 && b1 <= 65) { CTU_TRY(b1 - off); CTU_TRY(b1 + off); }
+        if (b2 >= 3 && b2 <= 65) { CTU_TRY(b2 - off); CTU_TRY(b2 + off); }
+#undef CTU_TRY
       }
+      V->rs_chk[0] = h0; V->rs_chk[1] = h1; V->rs_chk[2] = h2;
+      V->rs_cand[0] = k0; V->rs_cand[1] = k1; V->rs_cand[2] = k2;
       V->u_n_modes = k;
-      V->u_flag = offset > 0 && min_cost != max_cost;
-      V->u_mode = best[0].mode;
+      V->u_d0 = go;
+      V->u_mode = b0;
     }
+    offset >>= 1;
     CTU_SYNC();
-    if (!V->u_flag) break;
+    RQ_T(27);
+    if (V->u_d0 == 0) break;
   }
 }
 
 // ---------------------------------------------------------------------------------------------------- transforms ------
 CTU_DEV const int16_t *dct2_matrix(int n) { return n == 4 ? VVC_DCT2_4 : n == 8 ? VVC_DCT2_8 : n == 16 ? VVC_DCT2_16 : VVC_DCT2_32; }
 // dct_NxN (dct-generic.c:396-419, 720-729): dst[j * n + i] = trunc16((sum_k T[j][k] * src[i][k] + add) >> shift), twice
-CTU_NOINLINE CTU_DEV void fwd_pass(int n, const int16_t *src, int16_t *dst, int shift)
+CTU_NOINLINE CTU_DEV void fwd_pass(int n, const int16_t *src_, int16_t *dst_, int shift)
 {
+  CTU_LDS const int16_t *const src = LDSP(const int16_t, src_);
+  CTU_LDS int16_t *const dst = LDSP(int16_t, dst_);
   const int16_t *T = dct2_matrix(n);
   const int add = shift > 0 ? 1 << (shift - 1) : 0;
   PAR_FOR(e, n * n) {
@@ -679,8 +722,10 @@ CTU_NOINLINE CTU_DEV void fwd_pass(int n, const int16_t *src, int16_t *dst, int 
   CTU_SYNC();
 }
 // idct_NxN (:422-446, 731-740): dst[i * n + j] = clip16((sum_k src[k * n + i] * T[k][j] + add) >> shift), twice
-CTU_NOINLINE CTU_DEV void inv_pass(int n, const int16_t *src, int16_t *dst, int shift)
+CTU_NOINLINE CTU_DEV void inv_pass(int n, const int16_t *src_, int16_t *dst_, int shift)
 {
+  CTU_LDS const int16_t *const src = LDSP(const int16_t, src_);
+  CTU_LDS int16_t *const dst = LDSP(int16_t, dst_);
   const int16_t *T = dct2_matrix(n);
   const int add = 1 << (shift - 1);
   PAR_FOR(e, n * n) {
@@ -784,9 +829,9 @@ CTU_DEV uint32_t coded_level(const rdoq_env &E, double *coded_cost, double coded
 }
 
 // context_get_sig_ctx_idx_abs / templateAbsSum on a level array (rdo.c:1400-1438, 846-871), no MTS zero-out
-CTU_DEV int sig_ctx_abs(const int16_t *lv, int px, int py, int n, int color, int *diag_out, int *sum_out)
+template <typename LP> CTU_DEV int sig_ctx_abs(LP lv, int px, int py, int n, int color, int *diag_out, int *sum_out)
 {
-  const int16_t *d = lv + px + py * n;
+  const auto d = lv + px + py * n;
   int num_pos = 0, sum_abs = 0;
 #define CTU_UPD(v) { const int a = iabs_((int)(v)); sum_abs += (4 + (a & 1)) < a ? (4 + (a & 1)) : a; num_pos += a ? 1 : 0; }
   if (px < n - 1) {
@@ -806,9 +851,9 @@ CTU_DEV int sig_ctx_abs(const int16_t *lv, int px, int py, int n, int color, int
   *sum_out = sum_abs - num_pos;
   return ofs;
 }
-CTU_DEV unsigned template_abs_sum(const int16_t *lv, int base_level, int px, int py, int n)
+template <typename LP> CTU_DEV unsigned template_abs_sum(LP lv, int base_level, int px, int py, int n)
 {
-  const int16_t *p = lv + px + py * n;
+  const auto p = lv + px + py * n;
   int16_t sum = 0;                        // coeff_t accumulator, as in the reference (rdo.c:849)
   if (px < n - 1) {
     sum = (int16_t)(sum + iabs_(p[1]));
@@ -1023,7 +1068,7 @@ CTU_NOINLINE CTU_DEV int rdoq_serial(const uint8_t *st, const uint16_t *scan, sc
 // regular: regular bins remain (reg_bins >= 4), go_rice is then the value carried from the position coded before; otherwise the
 // position is priced as bypass-coded and its Rice parameter comes from the levels decided around it.
 struct rdoq_pos { int level; double cc, cs; };
-CTU_NOINLINE CTU_DEV rdoq_pos rdoq_decide(const rdoq_env &E, const int16_t *coef, const int16_t *dst, int n, int l2, int color, int blkpos, bool is_last,
+CTU_NOINLINE CTU_DEV rdoq_pos rdoq_decide(const rdoq_env &E, CTU_LDS const int16_t *coef, CTU_LDS const int16_t *dst, int n, int l2, int color, int blkpos, bool is_last,
                              bool regular, int go_rice, double c0, int *mal_out)
 {
   const int cap_half = 1 << (E.q_bits - 1);
@@ -1046,6 +1091,7 @@ CTU_NOINLINE CTU_DEV rdoq_pos rdoq_decide(const rdoq_env &E, const int16_t *coef
   return r;
 }
 
+#if !defined(__HIPCC__)
 // uvg_rdoq (rdo.c:1449-1870) by the first wave: same arithmetic as rdoq_serial, restructured around what is sequential in it.
 //   * every position's quantisation candidates and its level-0 cost: all positions at once;
 //   * a level decision reads only levels decided on later anti-diagonals (the context template looks right / down), so the <= 4
@@ -1055,10 +1101,12 @@ CTU_NOINLINE CTU_DEV rdoq_pos rdoq_decide(const rdoq_env &E, const int16_t *coef
 //   * the double-precision sums the reference forms in scan order (base cost, group statistics) and the group decision that
 //     compares them: lane 0, from the group's staged costs; the final cbf / last-position search: lane 0.
 // Result: V->rq_i[1] = whether any level survived; levels in dst.
-template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *W, const int16_t *coef, int16_t *dst, int n, int color, int cbf_u, int qp_scaled,
+template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *W, const int16_t *coef_, int16_t *dst_, int n, int color, int cbf_u, int qp_scaled,
                                               double lambda, int bitdepth)
 {
   wctx *const V = wv_of(S);
+  CTU_LDS const int16_t *const coef = LDSP(const int16_t, coef_);
+  CTU_LDS int16_t *const dst = LDSP(int16_t, dst_);
   const int l2 = ilog2_dev(n), nn = n * n, cgw = n >> 2;
   const uint16_t *scan = S->scan + scan_base(l2);
   rdoq_env E;
@@ -1077,9 +1125,6 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
   // ---- every position: candidate, level-0 cost; the last candidate in scan order ----
 #if defined(__HIPCC__) && defined(CTU_PROFILE)
   unsigned long long tq = __builtin_amdgcn_s_memtime();
-#define RQ_T(slot) do { const unsigned long long t2 = __builtin_amdgcn_s_memtime(); if (CTU_TID == 0) W->prof[slot] += t2 - tq; tq = t2; } while (0)
-#else
-#define RQ_T(slot) ((void)0)
 #endif
   int my_last = -1;
   WFOR(sp, nn) {
@@ -1336,9 +1381,281 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
   }
   WSYNC();
   RQ_T(18);
-#undef RQ_LD
-#undef RQ_T
 }
+#else
+// uvg_rdoq (rdo.c:1449-1870) by one wave: same arithmetic as rdoq_serial, restructured around what is sequential in it.
+//   * every position's quantisation candidate: all positions at once;
+//   * the positions of a 4x4 group are decided together by lanes 0..15.  A decision reads only levels of positions later in scan
+//     order (the context template looks right / down), so the group's decisions are the unique solution of a set of equations over
+//     a DAG: the lanes start from the candidates, re-decide against each other's current levels and stop when a round changes
+//     nothing -- at that point every position holds exactly what the reference's walk leaves there (<= 8 rounds, mostly 2).
+//     This needs the regular-bin budget not to run out inside the group (an upper bound from the candidates says so) or to have run
+//     out for good; the one or two groups where it does run out are walked position by position by lane 0;
+//   * the double-precision sums the reference forms in scan order (base cost, group statistics, the last-position search): every
+//     lane forms them, in the reference's order, from the owners' registers (v_readlane) -- no memory in the chain.
+// Result: V->rq_i[1] = whether any level survived; levels in dst.
+CTU_DEV double rl64(double v, int lane)
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *W, const int16_t *coef_, int16_t *dst_, int n, int color, int cbf_u, int qp_scaled,
+                                              double lambda, int bitdepth)
+{
+  wctx *const V = wv_of(S);
+  CTU_LDS const int16_t *const coef = LDSP(const int16_t, coef_);
+  CTU_LDS int16_t *const dst = LDSP(int16_t, dst_);
+  const int l2 = ilog2_dev(n), nn = n * n, cgw = n >> 2;
+  const uint16_t *scan = S->scan + scan_base(l2);
+  rdoq_env E;
+  E.st = S->rdoq_state; E.t = color ? 1 : 0; E.lambda = lambda;
+  const int transform_shift = 15 - bitdepth - l2;
+  E.q_bits = 14 + qp_scaled / 6 + transform_shift;
+  E.q = kQuantScales[qp_scaled % 6];
+  double scale = 32768;
+  scale = transform_shift >= 0 ? scale / kPow2[2 * transform_shift] : scale * kPow2[-2 * transform_shift];
+  E.error_scale = scale / E.q / E.q;
+  const bool small = V->rq_cc != nullptr;        // the per-position cost arrays are in LDS (this wave's depth has them)
+  CTU_LDS double *const CCl = LDSP(double, V->rq_cc), *const CSl = LDSP(double, V->rq_cs);
+  double *const CCg = W->cost_coeff, *const CSg = W->cost_sig;
+  double *cost_cg_sig = V->rs_cost;              // (free while a block is quantised)
+  const int cap_half = 1 << (E.q_bits - 1);
+  const int32_t cap = 0x7fffffff - cap_half;
+#if defined(CTU_PROFILE)
+  unsigned long long tq = __builtin_amdgcn_s_memtime();
+#endif
+  // ---- every position: candidate; the last candidate in scan order ----
+  int my_last = -1;
+  WFOR(sp, nn) {
+    const int blk = scan[sp];
+    const int64_t prod = (int64_t)iabs_((int)coef[blk]) * E.q;
+    const int32_t level_double = (int32_t)(prod < cap ? prod : cap);
+    const int mal = (int)((uint32_t)(level_double + cap_half) >> E.q_bits);
+    dst[blk] = (int16_t)mal;
+    if (mal > 0 && sp > my_last) my_last = sp;
+    if (sp < 64) V->cg_flag[sp] = 0;
+  }
+  for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(my_last, o, 64); my_last = v > my_last ? v : my_last; }
+  const int last_scanpos = my_last;
+  WSYNC();
+  if (last_scanpos < 0) { if (CTU_TID == 0) V->rq_i[1] = 0; WSYNC(); return; }
+  RQ_T(12);
+  const int cg_last = last_scanpos >> 4;
+  const int lane = CTU_TID, sp = lane & 15;
+  const bool own = lane < 16;
+  // the positions behind the last candidate only add their level-0 cost (rdo.c:1556-1583), in descending scan order
+  double block_uncoded_cost = 0, base_cost = 0;
+  for (int top = nn - 16; top + 15 > last_scanpos; top -= 16) {
+    const int scanpos = top + sp;
+    const int64_t prod = (int64_t)iabs_((int)coef[scan[scanpos]]) * E.q;
+    const double err = (double)(int32_t)(prod < cap ? prod : cap);
+    const double c0 = err * err * E.error_scale;
+#pragma nounroll
+    for (int k = 15; k >= 0; --k) if (top + k > last_scanpos) { const double c = rl64(c0, k); block_uncoded_cost += c; base_cost += c; }
+  }
+  if (CTU_TID == 0) for (int g = 0; g <= cg_last; ++g) cost_cg_sig[g] = 0;
+  int reg_bins = (int)((uint32_t)(nn * 28) >> 4);
+  WSYNC();
+  RQ_T(13);
+  for (int cgs = cg_last; cgs >= 0; --cgs) {
+    const int first = scan[cgs * 16];
+    const int cg_pos_x = (first & (n - 1)) >> 2, cg_pos_y = (first >> l2) >> 2;
+    const int cg_blkpos = cg_pos_y * cgw + cg_pos_x;
+    const int regular = reg_bins >= 4;
+    const int scanpos = cgs * 16 + sp;
+    const bool mine = own && scanpos <= last_scanpos;
+    const int blk = scan[mine ? scanpos : cgs * 16];
+    const bool is_last = scanpos == last_scanpos;
+    const int64_t prod = (int64_t)iabs_((int)coef[blk]) * E.q;
+    const int32_t level_double = (int32_t)(prod < cap ? prod : cap);
+    const int mal0 = mine ? (int)((uint32_t)(level_double + cap_half) >> E.q_bits) : 0;
+    const double c0 = mine ? (double)level_double * (double)level_double * E.error_scale : 0.0;
+    // can the regular-bin budget run out inside this group?  (a position spends at most min(candidate, 2 -> 3) + 1 bins)
+    int fast = !regular;
+    if (regular) {
+      int bound = mine ? (mal0 < 2 ? mal0 : 3) + (is_last ? 0 : 1) : 0;
+      for (int o = 8; o >= 1; o >>= 1) bound += __shfl_xor(bound, o, 64);
+      bound = __builtin_amdgcn_readfirstlane(bound);
+      fast = reg_bins - bound >= 4;
+    }
+    double cc = 0, cs = 0;
+    int lev = 0;
+    if (fast) {
+      int go_rice = 0;
+      if (mine && regular && sp != 15 && !is_last) {
+        const int nb = scan[scanpos + 1];
+        go_rice = go_rice_par(template_abs_sum(coef, 4, nb & (n - 1), nb >> l2, n));      // sic: the INPUT coefficients (rdo.c:1697)
+      }
+      lev = mal0;
+      for (;;) {
+        bool changed = false;
+        if (mine) {
+          int mal;
+          const rdoq_pos r = rdoq_decide(E, coef, dst, n, l2, color, blk, is_last, regular != 0, go_rice, c0, &mal);
+          cc = r.cc; cs = r.cs;
+          changed = r.level != lev;
+          lev = r.level;
+        }
+        WSYNC();                               // every lane has read the levels it needs
+        if (changed) dst[blk] = (int16_t)lev;
+        const bool any = __ballot(changed) != 0;
+        WSYNC();
+        if (!any) break;
+      }
+    } else {
+      // the budget may run out in this group: position by position, exactly as the reference walks
+      if (CTU_TID == 0) {
+        int go_rice = 0, rb = reg_bins;
+        for (int k = 15; k >= 0; --k) {
+          const int spos = cgs * 16 + k;
+          if (spos > last_scanpos) continue;
+          const int b = scan[spos];
+          const int64_t pr = (int64_t)iabs_((int)coef[b]) * E.q;
+          const double e0 = (double)(int32_t)(pr < cap ? pr : cap);
+          int mal;
+          const rdoq_pos r = rdoq_decide(E, coef, dst, n, l2, color, b, spos == last_scanpos, rb >= 4, go_rice, e0 * e0 * E.error_scale, &mal);
+          dst[b] = (int16_t)r.level;
+          V->rq_stage[k] = r.cc; V->rq_stage[16 + k] = r.cs;
+          if ((spos % 16 == 0) && spos > 0) go_rice = 0;
+          else if (rb >= 4) {
+            rb -= (r.level < 2 ? r.level : 3) + (spos != last_scanpos);
+            go_rice = go_rice_par(template_abs_sum(coef, 4, b & (n - 1), b >> l2, n));
+          }
+        }
+        V->rq_i[4] = rb;
+      }
+      WSYNC();
+      if (mine) { cc = V->rq_stage[sp]; cs = V->rq_stage[16 + sp]; lev = dst[blk]; }
+      reg_bins = V->rq_i[4];
+      WSYNC();
+    }
+    RQ_T(14);
+    // the sums in scan order and the group's decision (rdo.c:1689-1772): every lane, from the owners' registers
+    double rd_coded = 0, rd_uncoded = 0, rd_sig = 0, rd_sig0 = 0;
+    int nnz_before_pos0 = 0, flag = 0, spent = 0;
+#pragma nounroll
+    for (int k = 15; k >= 0; --k) {
+      if (cgs * 16 + k > last_scanpos) continue;
+      const double kc = rl64(cc, k), ks = rl64(cs, k), k0 = rl64(c0, k);
+      const int level = __builtin_amdgcn_readlane(lev, k);
+      block_uncoded_cost += k0;
+      base_cost += kc;
+      spent += (level < 2 ? level : 3) + (cgs * 16 + k != last_scanpos);
+      rd_sig += ks;
+      if (k == 0) rd_sig0 = ks;
+      if (level) {
+        flag = 1;
+        rd_coded += kc - ks;
+        rd_uncoded += k0;
+        if (k != 0) nnz_before_pos0++;
+      }
+    }
+    if (fast && regular) reg_bins -= spent;
+    int zeroed = 0;
+    if (cgs) {
+      unsigned right = 0, lower = 0;
+      if (cg_pos_x + 1 < cgw) right = V->cg_flag[cg_blkpos + 1];
+      if (cg_pos_y + 1 < cgw) lower = V->cg_flag[cg_blkpos + cgw];
+      const int o_grp = M_SIGGRP + (E.t ? 2 : 0) + ((right || lower) ? 1 : 0);
+      double cgc = 0;
+      if (!flag) {
+        cgc = lambda * rbits(E, o_grp, 0);
+        base_cost += cgc - rd_sig;
+      } else if (cgs < cg_last) {
+        if (nnz_before_pos0 == 0) { base_cost -= rd_sig0; rd_sig -= rd_sig0; }
+        double cost_zero_cg = base_cost;
+        cgc = lambda * rbits(E, o_grp, 1);
+        base_cost += cgc;
+        cost_zero_cg += lambda * rbits(E, o_grp, 0);
+        cost_zero_cg += rd_uncoded;
+        cost_zero_cg -= rd_coded;
+        cost_zero_cg -= rd_sig;
+        if (cost_zero_cg < base_cost) {
+          flag = 0;
+          zeroed = 1;
+          base_cost = cost_zero_cg;
+          cgc = lambda * rbits(E, o_grp, 0);
+        }
+      }
+      WSYNC();                                 // (the neighbours' flags are read)
+      if (CTU_TID == 0) cost_cg_sig[cgs] = cgc;
+    } else {
+      flag = 1;
+    }
+    if (CTU_TID == 0) V->cg_flag[cg_blkpos] = (uint8_t)flag;
+    // the group's costs go to the per-position arrays the last-position search reads; a zeroed group's positions fall back to level 0
+    if (mine) {
+      const double wc = (zeroed && lev) ? c0 : cc, ws = (zeroed && lev) ? 0.0 : cs;
+      if (zeroed && lev) dst[blk] = 0;
+      if (small) { CCl[scanpos] = wc; CSl[scanpos] = ws; } else { CCg[scanpos] = wc; CSg[scanpos] = ws; }
+    }
+    WSYNC();
+    RQ_T(15);
+  }
+  RQ_T(16);
+  // ---- coded block flag and the last significant position (rdo.c:1774-1833) ----
+  double best_cost;
+  int best_last_idx_p1 = 0;
+  {
+    const int o_cbf = color == 0 ? M_CBF_LUMA : color == 1 ? M_CBF_CB : M_CBF_CR + (cbf_u ? 1 : 0);
+    best_cost = block_uncoded_cost + lambda * rbits(E, o_cbf, 0);
+    base_cost += lambda * rbits(E, o_cbf, 1);
+  }
+  const int32_t *last_x_bits = S->last_bits[E.t][l2 - 2][0], *last_y_bits = S->last_bits[E.t][l2 - 2][1];
+  int found_last = 0;
+  for (int cgs = cg_last; cgs >= 0 && !found_last; cgs--) {
+    const int first = scan[cgs * 16];
+    const int cg_blkpos = ((first >> l2) >> 2) * cgw + ((first & (n - 1)) >> 2);
+    base_cost -= cost_cg_sig[cgs];
+    if (!V->cg_flag[cg_blkpos]) continue;
+    // the owners fetch their position's numbers, then the walk runs over registers
+    const int scanpos = cgs * 16 + sp;
+    const bool mine = own && scanpos <= last_scanpos;
+    const int blkpos = scan[mine ? scanpos : cgs * 16];
+    const int lev = mine ? (int)dst[blkpos] : 0;
+    double kcs = 0, kcc = 0, k0 = 0, klast = 0;
+    if (mine) {
+      kcs = small ? CSl[scanpos] : CTU_GLOAD(&CSg[scanpos]);
+      if (lev) {
+        kcc = small ? CCl[scanpos] : CTU_GLOAD(&CCg[scanpos]);
+        const int64_t prod = (int64_t)iabs_((int)coef[blkpos]) * E.q;
+        const double err = (double)(int32_t)(prod < cap ? prod : cap);
+        k0 = err * err * E.error_scale;
+        const int pos_y = blkpos >> l2, pos_x = blkpos - (pos_y << l2);
+        const int cx = group_idx(pos_x), cy = group_idx(pos_y);
+        double cl = last_x_bits[cx] + last_y_bits[cy];
+        if (cx > 3) cl += 32768 * ((cx - 2) >> 1);
+        if (cy > 3) cl += 32768 * ((cy - 2) >> 1);
+        klast = lambda * cl;
+      }
+    }
+#pragma nounroll
+    for (int k = 15; k >= 0; --k) {
+      if (found_last || cgs * 16 + k > last_scanpos) continue;
+      const int level = __builtin_amdgcn_readlane(lev, k);
+      const double s_ = rl64(kcs, k);
+      if (level) {
+        const double total = base_cost + rl64(klast, k) - s_;
+        if (total < best_cost) { best_last_idx_p1 = cgs * 16 + k + 1; best_cost = total; }
+        if (level > 1) { found_last = 1; continue; }
+        base_cost -= rl64(kcc, k);
+        base_cost += rl64(k0, k);
+      } else {
+        base_cost -= s_;
+      }
+    }
+  }
+  if (CTU_TID == 0) V->rq_i[1] = best_last_idx_p1 > 0;
+  RQ_T(17);
+  WFOR(scanpos, last_scanpos + 1) {
+    const int b = scan[scanpos];
+    if (scanpos < best_last_idx_p1) { const int level = dst[b]; dst[b] = (int16_t)((coef[b] < 0) ? -level : level); }
+    else dst[b] = 0;
+  }
+  WSYNC();
+  RQ_T(18);
+}
+#endif
 
 // -------------------------------------------------------------------------------------------- coefficient bit cost ------
 CTU_DEV int coeff_remain_bits(uint32_t remainder, uint32_t rice, unsigned cutoff)     // uvg_cabac_write_coeff_remain, cabac.c:318-354
@@ -1352,9 +1669,9 @@ CTU_DEV int coeff_remain_bits(uint32_t remainder, uint32_t rice, unsigned cutoff
   else { while ((int32_t)code_value > ((2 << prefix) - 2)) prefix++; suffix_len = prefix + rice + 1; }
   return (int)(prefix + cutoff + suffix_len);
 }
-CTU_DEV int abs_sum_tmpl(const int16_t *coeff, int px, int py, int n, int baselevel)      // uvg_abs_sum, context.c:846-877
+template <typename LP> CTU_DEV int abs_sum_tmpl(LP coeff, int px, int py, int n, int baselevel)      // uvg_abs_sum, context.c:846-877
 {
-  const int16_t *d = coeff + px + py * n;
+  const auto d = coeff + px + py * n;
   int sum = 0;
   if (px < n - 1) {
     sum += iabs_((int)d[1]);
@@ -1503,20 +1820,22 @@ template <typename PX> CTU_DEV int scaled_qp(const params &P, int color) { retur
 // predict + uvg_quantize_residual (quant-generic.c:460-612, RDOQ branch) of one transform block straight into D; its levels stay in
 // lv_of(V, color) and go to the CTU's coefficient array.  (x, y) / (lx, ly): luma position, n: luma size of the area.  -> has_coeffs
 template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<PX> &J, int color, int x, int y, int lx, int ly, int n, int mode, int cbf_u,
-                                                         PX *dst, int dp, int16_t *co, int cp)
+                                                         PX *dst_, int dp, int16_t *co, int cp)
 {
   // dst / dp: where the block is reconstructed (the decided planes, or the depth's candidate buffer); co / cp: where its levels go
   wctx *const V = wv_of(S);
+  CTU_LDS PX *const dst = LDSP(PX, dst_);
+  CTU_LDS int16_t *const t0 = LDSP(int16_t, V->t0), *const lv = LDSP(int16_t, lv_of(V, color));
   const int c = color != 0, w = n >> c, l2 = ilog2_dev(w);
   int sps;
-  const PX *Sp = src_block(J, color, lx >> c, ly >> c, &sps);
+  CTU_GLB const PX *Sp = src_block(J, color, lx >> c, ly >> c, &sps);
   const int depth = (int)px_info<PX>::depth;
   { CTU_T0();
   build_refs(S, J.P, color, x, y, lx, ly, n);
-  predict_block(S, mode, color, w, dst, dp);
+  predict_block(S, mode, color, w, dst_, dp);
   CTU_T1(J.W, 1); }
   { CTU_T0();
-  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); V->t0[e] = (int16_t)((int)Sp[r * sps + q] - (int)dst[r * dp + q]); }
+  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); t0[e] = (int16_t)((int)Sp[r * sps + q] - (int)dst[r * dp + q]); }
   CTU_SYNC();
   fwd_pass(w, V->t0, V->t1, l2 - 1 + depth - 8);
   fwd_pass(w, V->t1, V->t2, l2 + 6);
@@ -1531,19 +1850,19 @@ template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<P
   CTU_SYNC();
   CTU_T1(J.W, 3);
   const int has = V->rq_i[1];
-  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); co[r * cp + q] = lv_of(V, color)[e]; }
+  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); co[r * cp + q] = lv[e]; }
   if (has) {
     const int transform_shift = 15 - depth - l2;
     const int shift = 20 - 14 - transform_shift;
     const int32_t scale = (int32_t)kInvQuantScales[qps % 6] << (qps / 6);
     const int32_t add = 1 << (shift - 1);
-    PAR_FOR(e, w * w) V->t0[e] = (int16_t)clampi((lv_of(V, color)[e] * scale + add) >> shift, -32768, 32767);      // uvg_dequant, quant-generic.c:618-669
+    PAR_FOR(e, w * w) t0[e] = (int16_t)clampi((lv[e] * scale + add) >> shift, -32768, 32767);      // uvg_dequant, quant-generic.c:618-669
     CTU_SYNC();
     inv_pass(w, V->t0, V->t1, 7);
     inv_pass(w, V->t1, V->t0, 12 - (depth - 8));
     PAR_FOR(e, w * w) {
       const int r = e >> l2, q = e & (w - 1);
-      const int16_t val = (int16_t)(V->t0[e] + (int)dst[r * dp + q]);
+      const int16_t val = (int16_t)(t0[e] + (int)dst[r * dp + q]);
       dst[r * dp + q] = (PX)clampi(val, 0, (int)px_info<PX>::maxv);
     }
   }
@@ -1552,28 +1871,29 @@ template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<P
 }
 
 // uvg_pixels_calc_ssd of a w x w block of D against the source, into V->red[slot] (valid after the barrier)
-template <typename PX> CTU_NOINLINE CTU_DEV void ssd_block(lds<PX> *S, const job<PX> &J, int color, int lx, int ly, int n, int slot, const PX *rec, int rp)
+template <typename PX> CTU_NOINLINE CTU_DEV void ssd_block(lds<PX> *S, const job<PX> &J, int color, int lx, int ly, int n, int slot, const PX *rec_, int rp)
 {
   wctx *const V = wv_of(S);
+  CTU_LDS const PX *const rec = LDSP(const PX, rec_);
   const int c = color != 0, w = n >> c, l2 = ilog2_dev(w);
   int sps;
-  const PX *Sp = src_block(J, color, lx >> c, ly >> c, &sps);
+  CTU_GLB const PX *Sp = src_block(J, color, lx >> c, ly >> c, &sps);
   int acc = 0;
   PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); const int d = (int)Sp[r * sps + q] - (int)rec[r * rp + q]; acc += d * d; }
-  V->partial[CTU_TID] = acc;
-  CTU_SYNC();
-  SERIAL {
-    int tot = 0;
-    for (int i = 0; i < CTU_NT; ++i) tot += V->partial[i];
-    V->red[slot] = tot >> (2 * ((int)px_info<PX>::depth - 8));
-  }
+#if defined(__HIPCC__)
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  LANE0 V->red[slot] = acc >> (2 * ((int)px_info<PX>::depth - 8));
+#else
+  V->red[slot] = acc >> (2 * ((int)px_info<PX>::depth - 8));
+#endif
   CTU_SYNC();
 }
 
 // uvg_write_split_flag (encode_coding_tree.c:1240-1363) with the multi-type splits off: only split_cu_flag exists; lane 0
-template <typename PX> CTU_DEV void split_flag_bits(lds<PX> *S, const params &P, uint32_t *m, int update, int x, int y, int lx, int ly, int n, int split,
+template <typename PX> CTU_DEV void split_flag_bits(lds<PX> *S, const params &P, uint32_t *m_, int update, int x, int y, int lx, int ly, int n, int split,
                                                     double &bits)
 {
+  CTU_LDS uint32_t *const m = LDSP(uint32_t, m_);
   const int inside = P.pic_w >= x + n && P.pic_h >= y + n;
   if (!inside || n <= 4) return;                      // implicit split, or nothing to split: no flag
   const cu4 *left = x > 0 ? cu_at(S, lx - 1, ly) : nullptr, *above = y > 0 ? cu_at(S, lx, ly - 1) : nullptr;
@@ -1584,8 +1904,9 @@ template <typename PX> CTU_DEV void split_flag_bits(lds<PX> *S, const params &P,
 }
 
 // uvg_encode_intra_luma_coding_unit (encode_coding_tree.c:992-1238) in count mode; lane 0
-template <typename PX> CTU_NOINLINE CTU_DEV void luma_mode_bits(lds<PX> *S, uint32_t *m, int update, int x, int y, int lx, int ly, int n, int mode, double &bits_out)
+template <typename PX> CTU_NOINLINE CTU_DEV void luma_mode_bits(lds<PX> *S, uint32_t *m_, int update, int x, int y, int lx, int ly, int n, int mode, double &bits_out)
 {
+  CTU_LDS uint32_t *const m = LDSP(uint32_t, m_);
   const cu4 *l, *a;
   int8_t preds[6];
   mpm_neighbours(S, x, y, lx, ly, n, &l, &a);
@@ -1601,17 +1922,16 @@ template <typename PX> CTU_NOINLINE CTU_DEV void luma_mode_bits(lds<PX> *S, uint
     if (mpm > 2) bits += 1;
     if (mpm > 3) bits += 1;
   } else {
-    for (int i = 0; i < 6; ++i)
-      for (int j = i + 1; j < 6; ++j)
-        if ((uint8_t)preds[j] < (uint8_t)preds[i]) { const int8_t t = preds[i]; preds[i] = preds[j]; preds[j] = t; }
+    // the reference sorts the list and steps the mode down past every smaller entry (:1197-1215): mode - #{entries < mode}
     int tmp = mode;
-    for (int i = 5; i >= 0; --i) if (tmp > preds[i]) tmp--;
+    for (int i = 0; i < 6; ++i) tmp -= preds[i] < mode;
     bits_out += (tmp < 3) ? 5 : 6;                    // truncated binary code of 61 symbols (cabac.c:203-229)
   }
   bits_out += bits;
 }
-CTU_DEV void chroma_mode_bits(uint32_t *m, int update, int chroma_mode, int luma_dir, double &bits)     // encode_chroma_intra_cu, :902-990
+CTU_DEV void chroma_mode_bits(uint32_t *m_, int update, int chroma_mode, int luma_dir, double &bits)     // encode_chroma_intra_cu, :902-990
 {
+  CTU_LDS uint32_t *const m = LDSP(uint32_t, m_);
   const int derived = chroma_mode == luma_dir;
   m_code(m, update, M_CHROMA_PRED, derived ? 0 : 1, bits);
   if (!derived) bits += 2;
@@ -1646,10 +1966,11 @@ template <typename PX> CTU_NOINLINE CTU_DEV void mark_deblocking(lds<PX> *S, int
 // each lane owns ONE model and walks the positions in coding order, adapting its model at the bins that use it -- two sweeps
 // (sig / gt1 / parity, then gt2) cover the <= 75 models of a block.  Lane 0 codes the last-position prefix and the group flags.
 // All 64 lanes of wave 0 call it; the returned value is the same on every lane.  Host emulation: the serial walk.
-template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32_t *m, int update, const int16_t *coeff, int n, int color)
+template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32_t *m_, int update, const int16_t *coeff_, int n, int color)
 {
   wctx *const V = wv_of(S);
 #if !defined(__HIPCC__)
+  uint32_t *const m = m_; const int16_t *const coeff = coeff_;
   uint32_t tmp[NMODELS];
   uint32_t *mm = m;
   if (!update) { for (int i = 0; i < NMODELS; ++i) tmp[i] = m[i]; mm = tmp; }
@@ -1658,9 +1979,16 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
   const int lane = CTU_TID;
   const int l2 = ilog2_dev(n), nn = n * n, cgw = n >> 2, ncg = nn >> 4, t = color ? 1 : 0;
   const uint16_t *scan = S->scan + scan_base(l2);
-  uint32_t *recs = reinterpret_cast<uint32_t *>(V->t0);       // t0 + t1: 1024 words, free while costs are counted
-  uint8_t *cgf = V->cg_flag;                                   // per group (raster): has a level
-  int32_t *gtot = reinterpret_cast<int32_t *>(V->rq_stage);   // per group (scan order): regular bins it would spend, bit 30: a level among k = 1..15
+  CTU_LDS uint32_t *const m = (CTU_LDS uint32_t *)m_;
+  CTU_LDS const int16_t *const coeff = (CTU_LDS const int16_t *)coeff_;
+  CTU_LDS uint32_t *recs = (CTU_LDS uint32_t *)(V->t0);       // t0 + t1: 1024 words, free while costs are counted
+  CTU_LDS uint8_t *cgf = (CTU_LDS uint8_t *)V->cg_flag;                                   // per group (raster): has a level
+  CTU_LDS int32_t *gtot = (CTU_LDS int32_t *)(V->rq_stage);   // per group (scan order): regular bins it would spend, bit 30: a level among k = 1..15
+  CTU_LDS uint8_t *const lv_spend = (CTU_LDS uint8_t *)V->lv_spend;
+#if defined(CTU_PROFILE)
+  scratch *const W = S->prof_w;
+  unsigned long long tq = __builtin_amdgcn_s_memtime();
+#endif
   // ---- last significant position, group flags ----
   int my_last = -1;
   for (int sp = lane; sp < nn; sp += 64) if (coeff[scan[sp]]) my_last = sp;
@@ -1676,6 +2004,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
     gtot[g] = anyr << 30;
   }
   WSYNC();
+  RQ_T(28);
   // ---- per position: level, contexts, Rice parameters, whether its sig flag is coded, the regular bins it would spend ----
   for (int sp = lane; sp <= last; sp += 64) {
     const int blk = scan[sp], py = blk >> l2, px = blk - (py << l2), g = sp >> 4;
@@ -1691,12 +2020,12 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
     const int spend = sig_coded + (a ? 1 + (a > 1 ? 2 : 0) : 0);
     recs[sp] = (uint32_t)(a > 0xffff ? 0xffff : a) | (uint32_t)ctx_sig << 16 | (uint32_t)ofs << 20 | (uint32_t)r4 << 25 | (uint32_t)r0 << 27 |
                (uint32_t)sig_coded << 29;
-    V->lv_spend[sp] = (uint8_t)spend;
+    lv_spend[sp] = (uint8_t)spend;
   }
   WSYNC();
   for (int g = lane; g <= cg_last; g += 64) {
     int tot = 0;
-    for (int k = 0; k < 16; ++k) if (g * 16 + k <= last) tot += V->lv_spend[g * 16 + k];
+    for (int k = 0; k < 16; ++k) if (g * 16 + k <= last) tot += lv_spend[g * 16 + k];
     gtot[g] = (gtot[g] & (1 << 30)) | tot;
   }
   WSYNC();
@@ -1711,7 +2040,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
       if (rb - tot >= 4) { rb -= tot; continue; }
       for (int sp = (g == cg_last ? last : g * 16 + 15); sp >= g * 16; --sp) {
         if (rb < 4) { sw = sp; break; }
-        rb -= V->lv_spend[sp];
+        rb -= lv_spend[sp];
       }
       if (sw < 0 && rb < 4) sw = g * 16 - 1;          // ran out exactly at the group's end: everything below is bypass-coded
     }
@@ -1719,43 +2048,63 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
   }
   WSYNC();
   const int sw = V->rq_i[8];          // scan positions <= sw are bypass-coded
+  RQ_T(29);
   // ---- the models, one per lane, along the positions in coding order ----
+  // A group's 16 records are fetched by lanes 0..15 at once and handed out with v_readlane: no memory in the adaptation chain.
+  // 4x4 luma blocks use 16 of the 21 greater-1 / parity / greater-2 models (the diagonal classes of larger blocks never occur) and
+  // chroma has 8 + 3 * 11 models: one sweep covers them; other luma blocks take two (sig / gt1 / parity, then gt2).
   unsigned long long q15 = 0;         // sum of bit costs in units of 2^-15
-  for (int sweep = 0; sweep < 2; ++sweep) {
-    // roles: sweep 0: lanes 0..11 sig, 12..32 gt1, 33..53 parity; sweep 1: lanes 0..20 gt2
+  unsigned long long grp_mask = 0;    // bit g: group g (scan order) is coded
+  for (int g0 = 0; g0 <= cg_last; g0 += 64) {
+    const int g = g0 + lane;
+    int on = 0;
+    if (g <= cg_last) { const int f = scan[g * 16]; on = cgf[((f >> l2) >> 2) * cgw + ((f & (n - 1)) >> 2)] || g == 0; }
+    grp_mask = __ballot(on);            // (ncg <= 64)
+  }
+  const int compact = !t && n == 4;     // 4x4 luma: set offsets 0, 6..20 -> k 0, 1..15
+  const int nk0 = t ? 8 : 12, nks = t ? 11 : (compact ? 16 : 21);
+  const int sweeps = nk0 + 3 * nks <= 64 ? 1 : 2;
+  for (int sweep = 0; sweep < sweeps; ++sweep) {
     int role = -1, k = 0;
-    if (sweep == 0) { if (lane < 12) { role = 0; k = lane; } else if (lane < 33) { role = 1; k = lane - 12; } else if (lane < 54) { role = 2; k = lane - 33; } }
+    if (sweeps == 1) {
+      if (lane < nk0) { role = 0; k = lane; }
+      else if (lane < nk0 + 3 * nks) { role = 1 + (lane - nk0) / nks; k = (lane - nk0) % nks; }
+      if (compact && role > 0 && k > 0) k += 5;
+    } else if (sweep == 0) { if (lane < 12) { role = 0; k = lane; } else if (lane < 33) { role = 1; k = lane - 12; } else if (lane < 54) { role = 2; k = lane - 33; } }
     else if (lane < 21) { role = 3; k = lane; }
-    const int nk = role == 0 ? (t ? 8 : 12) : (t ? 11 : 21);
-    if (role >= 0 && k >= nk) role = -1;
     const int model = role < 0 ? 0 : (role == 0 ? M_SIG + 12 * t : role == 1 ? M_GT1 + 21 * t : role == 2 ? M_PAR + 21 * t : M_GT2 + 21 * t) + k;
     uint32_t st = m[model];
     const int r0 = kRate[model] >> 4, r1 = kRate[model] & 15;
+    const uint32_t add0 = (0x7fffu >> r0) & 0x7fe0u, add1 = (0x7fffu >> r1) & 0x7ffeu;
+    // what a record must show for this lane's model to code a bin: field (sig: bits 16..19, others: 20..24) == k, and the gate
+    const uint32_t fsh = role == 0 ? 16 : 20, fmask = role == 0 ? 15u : 31u;
     uint32_t acc = 0;
-    int prev_g = -1, grp_on = 0;
-    for (int sp = last; sp > sw; --sp) {
-      const int g = sp >> 4;
-      if (g != prev_g) { const int f = scan[g * 16]; grp_on = cgf[((f >> l2) >> 2) * cgw + ((f & (n - 1)) >> 2)] || g == 0; prev_g = g; }
-      if (!grp_on) { sp = g * 16; continue; }
-      const uint32_t rec = recs[sp];
-      const int a = (int)(rec & 0xffff);
-      int hit = 0, bin = 0;
-      if (role == 0) { hit = ((rec >> 29) & 1) && (int)((rec >> 16) & 15) == k; bin = a != 0; }
-      else if (role == 1) { hit = a != 0 && (int)((rec >> 20) & 31) == k; bin = a > 1; }
-      else if (role == 2) { hit = a > 1 && (int)((rec >> 20) & 31) == k; bin = a & 1; }
-      else if (role == 3) { hit = a > 1 && (int)((rec >> 20) & 31) == k; bin = a >= 4; }
-      if (hit) {
-        uint32_t s0 = st & 0xffffu, s1 = st >> 16;
-        acc += tab_ebits()[(((s0 + s1) >> 8) << 1) ^ (uint32_t)bin];
-        s0 -= (s0 >> r0) & 0x7fe0u;
-        s1 -= (s1 >> r1) & 0x7ffeu;
-        if (bin) { s0 += (0x7fffu >> r0) & 0x7fe0u; s1 += (0x7fffu >> r1) & 0x7ffeu; }
-        st = (s0 & 0xffffu) | (s1 << 16);
+    for (int g = cg_last; g >= 0 && g * 16 + 15 > sw; --g) {
+      if (!((grp_mask >> g) & 1)) continue;
+      const uint32_t myrec = recs[g * 16 + (lane & 15)];
+#pragma nounroll
+      for (int j = 15; j >= 0; --j) {
+        const int sp = g * 16 + j;
+        if (sp > last || sp <= sw) continue;
+        const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)myrec, j);
+        const int a = (int)(rec & 0xffff);
+        if (a == 0 && !((rec >> 29) & 1)) continue;          // nothing coded with a context here
+        const int gate = role == 0 ? (int)((rec >> 29) & 1) : role == 1 ? a != 0 : a > 1;
+        const int bin = role == 0 ? a != 0 : role == 1 ? a > 1 : role == 2 ? (a & 1) : a >= 4;
+        if (role >= 0 && gate && ((rec >> fsh) & fmask) == (uint32_t)k) {
+          uint32_t s0 = st & 0xffffu, s1 = st >> 16;
+          acc += tab_ebits()[(((s0 + s1) >> 8) << 1) ^ (uint32_t)bin];
+          s0 -= (s0 >> r0) & 0x7fe0u;
+          s1 -= (s1 >> r1) & 0x7ffeu;
+          if (bin) { s0 += add0; s1 += add1; }
+          st = (s0 & 0xffffu) | (s1 << 16);
+        }
       }
     }
     if (role >= 0 && update) m[model] = st;
     q15 += acc;
   }
+  RQ_T(30);
   // ---- bypass-coded parts: remainders, bypass positions, signs ----
   int ibits = 0;
   for (int sp = lane; sp <= last; sp += 64) {
@@ -1773,11 +2122,11 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
   // ---- lane 0: last-position prefix and the group flags (their models are nobody else's) ----
   if (lane == 0) {
     double bits = 0;
-    uint32_t *mk = m;
+    CTU_LDS uint32_t *mk = m;
     if (!update) {
       // counting only: these bins still adapt their models WITHIN the block (the reference counts on a copy) -- work on a copy
       // of the few models involved (work[0] is nobody's: depth 0 has no unsplit candidate of its own)
-      mk = S->work[0];
+      mk = (CTU_LDS uint32_t *)S->work[0];
       for (int i = 0; i < 4; ++i) mk[M_SIGGRP + i] = m[M_SIGGRP + i];
       for (int i = M_LASTX; i < M_CBF_LUMA; ++i) mk[i] = m[i];
     }
@@ -1812,6 +2161,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
     ibits += __shfl_xor(ibits, o, 64);
   }
   WSYNC();
+  RQ_T(31);
   return (double)q15 / 32768.0 + (double)ibits;
 #endif
 }
@@ -1825,11 +2175,12 @@ template <typename PX> CTU_NOINLINE CTU_DEV double tr_cost(lds<PX> *S, const par
   double coeff_bits_ = 0, luma_bits = 0, chroma_bits = 0;
   const int cb_y = cbf & 1, cb_u = (cbf >> 1) & 1, cb_v = (cbf >> 2) & 1;
   LANE0 {
+    CTU_LDS uint32_t *const m = LDSP(uint32_t, V->cur);
     if (has_chroma) {
-      m_code(V->cur, update, M_CBF_CB + 0, cb_u, chroma_bits);
-      m_code(V->cur, update, M_CBF_CR + cb_u, cb_v, chroma_bits);
+      m_code(m, update, M_CBF_CB + 0, cb_u, chroma_bits);
+      m_code(m, update, M_CBF_CR + cb_u, cb_v, chroma_bits);
     }
-    m_code(V->cur, update, M_CBF_LUMA + 0, cb_y, luma_bits);
+    m_code(m, update, M_CBF_LUMA + 0, cb_y, luma_bits);
   }
   WSYNC();
   const unsigned luma_ssd = (unsigned)V->red[0];
@@ -1985,8 +2336,10 @@ template <typename PX> CTU_NOINLINE CTU_DEV void unpark(lds<PX> *S, const job<PX
   CTU_SYNC();
 }
 
-CTU_NOINLINE CTU_DEV void copy_models(uint32_t *dst, const uint32_t *src)
+CTU_NOINLINE CTU_DEV void copy_models(uint32_t *dst_, const uint32_t *src_)
 {
+  CTU_LDS uint32_t *const dst = LDSP(uint32_t, dst_);
+  CTU_LDS const uint32_t *const src = LDSP(const uint32_t, src_);
   PAR_FOR(i, NMODELS) dst[i] = src[i];
   CTU_SYNC();
 }
@@ -2481,6 +2834,7 @@ template <typename PX> CTU_DEV void run_ctu(lds<PX> *S, const job<PX> &J)
 {
 #if defined(__HIPCC__) && defined(CTU_PROFILE)
   BLK_FOR(i, 4 * 32) J.W->prof[i >> 5][i & 31] = 0;
+  S->prof_w = J.W;
 #endif
   CTU_T0();
   { CTU_T0();

@@ -106,13 +106,14 @@ __device__ inline mode_info make_mode_info(int mode, int w, int h, int is_chroma
 }
 
 // LDS image of one block's reference rows: [top | left | ftop | fleft], `refn` entries each.
-struct ref_rows {
-  const uint16_t *top, *left, *ftop, *fleft;
+template <typename RP> struct ref_rows_t {       // RP: pointer to const uint16_t (any address space)
+  RP top, left, ftop, fleft;
 };
+typedef ref_rows_t<const uint16_t *> ref_rows;
 
 
 // intra.c:236-273
-__device__ inline int dc_value(const uint16_t *top, const uint16_t *left, int w, int h)
+template <typename RP> __device__ inline int dc_value(RP top, RP left, int w, int h)
 {
   int sum = 0;
   if (w >= h) for (int i = 0; i < w; ++i) sum += top[1 + i];
@@ -124,12 +125,12 @@ __device__ inline int dc_value(const uint16_t *top, const uint16_t *left, int w,
 // NP consecutive predicted samples of one row of the WORK domain (for horizontal
 // modes the work domain is the transposed block): row yd, columns xd0..xd0+NP-1.
 // wd/hd: work-domain width/height.
-template <int NP>
-__device__ __forceinline__ void predict_row(const mode_info &M, const ref_rows &R, int dc, int is_chroma, int wd, int hd,
+template <int NP, typename RR>
+__device__ __forceinline__ void predict_row(const mode_info &M, const RR &R, int dc, int is_chroma, int wd, int hd,
                                             int yd, int xd0, int maxv, int (&out)[NP])
 {
-  const uint16_t *top = M.filtered ? R.ftop : R.top;
-  const uint16_t *left = M.filtered ? R.fleft : R.left;
+  const auto top = M.filtered ? R.ftop : R.top;
+  const auto left = M.filtered ? R.fleft : R.left;
   if (M.mode < 2) {
     const int lw = ilog2_dev(wd), lh = ilog2_dev(hd);
     const int scale = (lw + lh - 2) >> 2;
@@ -160,8 +161,8 @@ __device__ __forceinline__ void predict_row(const mode_info &M, const ref_rows &
     return;
   }
   // angular: main/side in the work domain
-  const uint16_t *mainr = M.vertical ? top : left;
-  const uint16_t *side = M.vertical ? left : top;
+  const auto mainr = M.vertical ? top : left;
+  const auto side = M.vertical ? left : top;
   const int sd = M.sample_disp;
   if (sd != 0) {
     const int inv = M.inv_disp;
