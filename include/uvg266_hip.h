@@ -812,7 +812,18 @@ typedef struct uvghip_ctu_picture {
 } uvghip_ctu_picture_t;
 
 UVGHIP_API size_t uvghip_ctu_search_workspace_bytes(int n_pictures, int pic_w, int pic_h);
-/* pictures: HOST array of n descriptors.  workspace: device memory of the size above (contents need not survive the call). */
+/* A plan binds a configuration, n picture descriptors (HOST array) and a workspace (device memory of the size above, owned by
+ * the caller, in use until the plan is destroyed): the release order of the CTUs and the picture table are uploaded once.
+ * uvghip_ctu_plan_run enqueues the search of all n pictures on `stream` (a memset of the counters + one launch; the host does not
+ * wait) -- this is what an encoder calls once per group of pictures where the reference queues its per-CTU search jobs
+ * (encoderstate.c:1130-1200); plans on different streams run side by side.  A plan may be run any number of times (new source
+ * samples in the same buffers), one run at a time. */
+typedef struct uvghip_ctu_plan uvghip_ctu_plan_t;
+UVGHIP_API int uvghip_ctu_plan_create(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures,
+                                      int n_pictures, void *workspace, uvghip_ctu_plan_t **plan_out);
+UVGHIP_API int uvghip_ctu_plan_run(uvghip_ctu_plan_t *plan, void *stream);
+UVGHIP_API void uvghip_ctu_plan_destroy(uvghip_ctu_plan_t *plan);
+/* One-shot form: plan + run + wait for the stream + destroy. */
 UVGHIP_API int uvghip_ctu_search_intra(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures,
                                        int n_pictures, void *workspace, void *stream);
 

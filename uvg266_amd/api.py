@@ -562,7 +562,25 @@ class CtuSearch:
             self.pics[i] = _lib.CtuPicture(_dev(s[0]), _dev(s[1]), _dev(s[2]), s[0].stride(0), s[1].stride(0), _dev(r[0]), _dev(r[1]), _dev(r[2]),
                                            r[0].stride(0), r[1].stride(0), _dev(self.cu[i]), self.wc * 16, 0, _dev(self.coeff[i]), _dev(self.models[i]))
 
+        import ctypes
+        self.plan = ctypes.c_void_p()
+        _lib.check(self.L.uvghip_ctu_plan_create(self.depth, ctypes.byref(self.P), self.pics, self.n, _dev(self.ws), ctypes.byref(self.plan)),
+                   "uvghip_ctu_plan_create")
+
     def run(self, stream=None):
+        """Enqueue the search of all n pictures on the current (or the given) stream; returns at once (uvghip_ctu_plan_run)."""
+        _lib.check(self.L.uvghip_ctu_plan_run(self.plan, _stream() if stream is None else stream), "uvghip_ctu_plan_run")
+
+    def run_oneshot(self, stream=None):
+        """uvghip_ctu_search_intra: plan + run + wait, in one call."""
         import ctypes
         rc = self.L.uvghip_ctu_search_intra(self.depth, ctypes.byref(self.P), self.pics, self.n, _dev(self.ws), _stream() if stream is None else stream)
         _lib.check(rc, "uvghip_ctu_search_intra")
+
+    def __del__(self):
+        plan, self.plan = getattr(self, "plan", None), None
+        if plan:
+            try:
+                torch.cuda.synchronize()
+            finally:
+                self.L.uvghip_ctu_plan_destroy(plan)

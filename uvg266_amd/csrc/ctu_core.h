@@ -134,18 +134,17 @@ struct wctx {
   uint16_t *top, *left, *ftop, *fleft;              // reference rows: 4 n + 8 entries each
   int16_t *t0, *t1, *t2;                            // transform scratch, n * n each (t0 and t1 adjacent: also the n * n words of coeff_bits)
   int16_t *lv0, *lv1, *lv2;                         // levels of the transform blocks being evaluated (y, u, v)
-  double *rq_cc, *rq_cs, *rq_c0;                    // RDOQ per-position costs in LDS (nullptr: the depth uses the workgroup's global scratch)
+  double *rq_cc, *rq_cs;                            // RDOQ per-position costs in LDS (nullptr: the depth uses the workgroup's global scratch)
   uint32_t *part;                                   // rough search: (satd, sad) per (listed mode, tile)
   uint8_t *lv_spend;                                // coefficient bit cost: regular bins a scan position spends
   uint32_t *cur;                                    // the models this wave's bit counting works on
   double rq_stage[3 * 16];                          // RDOQ: costs of the coefficient group in flight
-  double rs_cost[67];
   double rs_cand[3 + 24], rs_best_cost[2][3];      // rough search: costs of the survivors and of the listed modes; the survivors, double-buffered
   double u_d0, u_d1;
   int32_t rq_i[16];
   int32_t rs_list[24], rs_best_mode[2][3];
   uint32_t rs_chk[3];
-  int32_t red[8], partial[64];
+  int32_t red[8];
   int32_t u_avail_left, u_avail_top, u_mode, u_flag, u_n_modes;
   uint8_t cg_flag[64];
   int8_t mpm[6];
@@ -154,8 +153,10 @@ struct wctx {
 
 constexpr int arena_bytes(int n)     // one depth's share of the arena (n = its luma block size)
 {
+  // reference rows, three transform buffers, levels (y, u, v), [4x4 only: the rough search's partial costs -- larger blocks keep
+  // them in the transform buffers, idle during the rough search], [<= 8x8: RDOQ's two per-position cost arrays]
   return (4 * (4 * n + 8) * 2 + 3 * n * n * 2 + (n * n + 2 * ((n / 2) * (n / 2) < 16 ? 16 : (n / 2) * (n / 2))) * 2 +
-          2 * 18 * (n >= 8 ? (n / 8) * (n / 8) : 1) * 4 + n * n + (n <= 16 ? 8 + 3 * n * n * 8 : 0) + 15) & ~15;
+          (n >= 8 ? 0 : 2 * 18 * 4) + (n <= 8 ? 8 + 2 * n * n * 8 : 0) + 15) & ~15;
 }
 enum { ARENA_BYTES = arena_bytes(4) + arena_bytes(8) + arena_bytes(16) + arena_bytes(32) };
 
@@ -167,11 +168,11 @@ template <typename PX> struct lds {
 #endif
   PX Dy[65 * PY], Du[33 * PC], Dv[33 * PC];         // decided planes, index (y + 1) * pitch + x + 1
   PX cand_px[2016];                                 // a depth's CU while its split is being tried (depths 1..3)
-  int16_t cand_co[2016];
+  int16_t cand_co[480];                             // ... its levels (depths 2, 3; depth 1's 1536 are in the workgroup's global scratch)
   cu4 cu[17 * 17];                                  // index (y4 + 1) * 17 + x4 + 1
-  uint32_t tree[256], mtt[256];                     // split_tree / mode_type_tree per 4x4
+  uint16_t tree[256], mtt[256];                     // split_tree / mode_type_tree per 4x4 (3 / 2 bits per depth, depths 0..4)
   uint32_t cur[NMODELS];                            // state->search_cabac models of the walk: state0 | state1 << 16
-  uint32_t pre[5][NMODELS];                         // ... as they stood when the depth's CU was entered
+  uint32_t pre[4][NMODELS];                         // ... as they stood when the depth's CU was entered
   uint32_t work[4][NMODELS];                        // ... as the depth's CU leaves them when it is coded unsplit ([0]: scratch)
   uint32_t coder[NMODELS];                          // state->cabac models
   uint8_t rdoq_state[244];                          // CTX_STATE of the coder's models at the CTU's start (what uvg_rdoq prices with)
@@ -193,6 +194,7 @@ struct scratch {
   uint16_t save_px[6144];          // the whole D of a CTU while the 64x64 candidate is tried
   int16_t save_co[6144];
   cu4 save_cu[256];
+  int16_t cand_co1[1536];          // levels of the depth-1 (32x32) candidate CU
   uint32_t save_tree[512];
   unsigned long long prof[4][32];     // CTU_PROFILE: 0 rough search, 1 refs + prediction, 2 residual + transforms + reconstruction, 3 RDOQ, 4 SSD,
                                    // 5 RD cost (bits), 6 park / unpark / model copies, 7 64x64 candidate, 8 coder pass, 9 load, 10 store, 11 total
@@ -1118,9 +1120,9 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
   scale = transform_shift >= 0 ? scale / kPow2[2 * transform_shift] : scale * kPow2[-2 * transform_shift];
   E.error_scale = scale / E.q / E.q;
   const bool small = V->rq_cc != nullptr;        // the per-position cost arrays are in LDS (this wave's depth has them)
-  double *CC = small ? V->rq_cc : W->cost_coeff, *CS = small ? V->rq_cs : W->cost_sig, *C0 = small ? V->rq_c0 : W->cost_coeff0;
+  double *CC = small ? V->rq_cc : W->cost_coeff, *CS = small ? V->rq_cs : W->cost_sig, *C0 = W->cost_coeff0;
 #define RQ_LD(p) (small ? *(p) : CTU_GLOAD(p))
-  double *cost_cg_sig = V->rs_cost;              // (free while a block is quantised)
+  double *cost_cg_sig = (double *)V->t0;         // (the residual / first-pass buffer: dead while a block is quantised; <= 64 groups)
   const int cap_half = 1 << (E.q_bits - 1);
   // ---- every position: candidate, level-0 cost; the last candidate in scan order ----
 #if defined(__HIPCC__) && defined(CTU_PROFILE)
@@ -1418,7 +1420,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
   const bool small = V->rq_cc != nullptr;        // the per-position cost arrays are in LDS (this wave's depth has them)
   CTU_LDS double *const CCl = LDSP(double, V->rq_cc), *const CSl = LDSP(double, V->rq_cs);
   double *const CCg = W->cost_coeff, *const CSg = W->cost_sig;
-  double *cost_cg_sig = V->rs_cost;              // (free while a block is quantised)
+  double *cost_cg_sig = (double *)V->t0;         // (the residual / first-pass buffer: dead while a block is quantised; <= 64 groups)
   const int cap_half = 1 << (E.q_bits - 1);
   const int32_t cap = 0x7fffffff - cap_half;
 #if defined(CTU_PROFILE)
@@ -2208,8 +2210,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void fill_cu(lds<PX> *S, int lx, int
     for (int xx = lx; xx < lx + n; xx += 4) {
       cu4 *c = cu_at(S, xx, yy);
       c->type = CU_INTRA; c->log2 = (uint8_t)l2; c->log2_c = (uint8_t)log2_c; c->mode = (int8_t)mode; c->mode_chroma = (int8_t)mode_chroma;
-      S->tree[(yy >> 2) * 16 + (xx >> 2)] = split_tree;
-      S->mtt[(yy >> 2) * 16 + (xx >> 2)] = mtt;
+      S->tree[(yy >> 2) * 16 + (xx >> 2)] = (uint16_t)split_tree;
+      S->mtt[(yy >> 2) * 16 + (xx >> 2)] = (uint16_t)mtt;
     }
 }
 
@@ -2253,7 +2255,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
   int rpy, rpc, kpy, kpc;
   if (to_cand) {
     ry = S->cand_px + cand_px_off(L, 0); ru = S->cand_px + cand_px_off(L, 1); rv = S->cand_px + cand_px_off(L, 2);
-    ky = S->cand_co + cand_px_off(L, 0); ku = S->cand_co + cand_px_off(L, 1); kv = S->cand_co + cand_px_off(L, 2);
+    int16_t *const kb = L == 1 ? J.W->cand_co1 : S->cand_co - 1536;
+    ky = kb + cand_px_off(L, 0); ku = kb + cand_px_off(L, 1); kv = kb + cand_px_off(L, 2);
     rpy = kpy = n; rpc = kpc = cn;
   } else {
     ry = S->Dy + (ly + 1) * PY + lx + 1;
@@ -2324,7 +2327,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void unpark(lds<PX> *S, const job<PX
     PX *D = plane(S, color) + ((ly >> c) + 1) * pit + (lx >> c) + 1;
     int16_t *co = J.coeff + co_off(color) + (ly >> c) * spit + (lx >> c);
     const int off = cand_px_off(L, color);
-    PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); D[r * pit + q] = S->cand_px[off + e]; co[r * spit + q] = S->cand_co[off + e]; }
+    if (L == 1) PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); D[r * pit + q] = S->cand_px[off + e]; co[r * spit + q] = CTU_GLOAD(&J.W->cand_co1[off + e]); }
+    else PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); D[r * pit + q] = S->cand_px[off + e]; co[r * spit + q] = S->cand_co[off - 1536 + e]; }
   }
   SERIAL {
     for (int yy = ly; yy < ly + n; yy += 4)
@@ -2436,7 +2440,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void restore64(lds<PX> *S, const job
     PX *D = plane(S, color) + pit + 1;
     PAR_FOR(e, w * w) { D[(e >> l2) * pit + (e & (w - 1))] = (PX)CTU_GLOAD(&W->save_px[co_off(color) + e]); J.coeff[co_off(color) + e] = CTU_GLOAD(&W->save_co[co_off(color) + e]); }
   }
-  PAR_FOR(e, 256) { *cu_at(S, (e & 15) * 4, (e >> 4) * 4) = W->save_cu[e]; S->tree[e] = W->save_tree[e]; S->mtt[e] = W->save_tree[256 + e]; }
+  PAR_FOR(e, 256) { *cu_at(S, (e & 15) * 4, (e >> 4) * 4) = W->save_cu[e]; S->tree[e] = (uint16_t)W->save_tree[e]; S->mtt[e] = (uint16_t)W->save_tree[256 + e]; }
   CTU_SYNC();
 }
 
@@ -2519,7 +2523,7 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
       const int x = N.x, y = N.y;
       CTU_SYNC();            // every lane holds its copy before lane 0 may reach the parent's bookkeeping and rewrite this entry
       if (x >= P.pic_w || y >= P.pic_h) { ret = 0; entering = 0; if (L == 0) break; --L; continue; }     // outside: nothing to code (search.c:1350)
-      copy_models(S->pre[L], S->cur);
+      if (L < 4) copy_models(S->pre[L], S->cur);          // (a 4x4 CU is never a candidate: nobody reads its entry models)
       const int inside = x + n <= P.pic_w && y + n <= P.pic_h;
       // check_can_use_intra (search.c:1257-1287)
       const int min_w = 64 >> P.depth_max;
@@ -2817,11 +2821,14 @@ template <typename PX> CTU_DEV void setup_waves(lds<PX> *S)
     V->top = (uint16_t *)a; V->left = V->top + rn; V->ftop = V->left + rn; V->fleft = V->ftop + rn; a += 4 * rn * 2;
     V->t0 = (int16_t *)a; V->t1 = V->t0 + nn; V->t2 = V->t1 + nn; a += 3 * nn * 2;
     V->lv0 = (int16_t *)a; V->lv1 = V->lv0 + nn; V->lv2 = V->lv1 + c2; a += (nn + 2 * c2) * 2;
-    V->part = (uint32_t *)a; a += 2 * 18 * tiles * 4;
-    V->lv_spend = a; a += nn;
+    // the rough search's (satd, sad) per (mode, tile) -- 2 * 18 * tiles words -- fit the three transform buffers from 8x8 on, which
+    // idle until the mode is chosen; the coefficient bit count's per-position byte lives in t2 (RDOQ's input, dead by then)
+    if (n >= 8) V->part = (uint32_t *)V->t0;
+    else { V->part = (uint32_t *)a; a += 2 * 18 * tiles * 4; }
+    V->lv_spend = (uint8_t *)V->t2;
     a = S->arena + ((a - S->arena + 7) & ~7);
-    if (n <= 16) { V->rq_cc = (double *)a; V->rq_cs = V->rq_cc + nn; V->rq_c0 = V->rq_cs + nn; }
-    else V->rq_cc = V->rq_cs = V->rq_c0 = nullptr;
+    if (n <= 8) { V->rq_cc = (double *)a; V->rq_cs = V->rq_cc + nn; }
+    else V->rq_cc = V->rq_cs = nullptr;
     V->cur = S->cur;
     S->vsel[k] = k;
     S->req[k] = 0; S->done[k] = 0;

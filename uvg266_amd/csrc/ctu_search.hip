@@ -9,6 +9,7 @@
 #include <vector>
 #include <mutex>
 #include <cstring>
+#include <new>
 
 namespace {
 
@@ -32,7 +33,7 @@ struct launch_args {
 };
 
 template <typename PX>
-__global__ void __launch_bounds__(256, 2) ctu_search_kernel(launch_args A)
+__global__ void __launch_bounds__(256, 3) ctu_search_kernel(launch_args A)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   ctu::lds<PX> *S = reinterpret_cast<ctu::lds<PX> *>(smem);
@@ -94,23 +95,32 @@ extern "C" size_t uvghip_ctu_search_workspace_bytes(int n_pictures, int pic_w, i
   return layout(n_pictures, pic_w, pic_h).total;
 }
 
-extern "C" int uvghip_ctu_search_intra(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, int n_pictures,
-                                       void *workspace, void *stream)
+// A plan: the validated configuration, the hand-out order and the picture table uploaded once; a run is a memset of the
+// counters and one launch -- nothing on the host waits, so launches of several plans on several streams overlap (the thin
+// start of one plan's wavefronts fills the device while another's drain).
+struct uvghip_ctu_plan {
+  launch_args A;
+  int bitdepth, total;
+  size_t counters;            // bytes of (ticket, done flags) at the head of the workspace
+  unsigned char *ws;
+};
+
+extern "C" int uvghip_ctu_plan_create(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, int n_pictures,
+                                      void *workspace, uvghip_ctu_plan_t **plan_out)
 {
   UVGHIP_REQUIRE_READY();
   UVGHIP_REQUIRE_DEPTH(bitdepth);
   static_assert(sizeof(uvghip_ctu_params_t) == sizeof(ctu::params), "uvghip_ctu_params_t mirrors ctu::params");
-  if (!params || !pictures || n_pictures <= 0 || !workspace) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (!params || !pictures || n_pictures <= 0 || !workspace || !plan_out) return uvghip_set_error(hipErrorInvalidValue, __func__);
   const uvghip_ctu_params_t &p = *params;
   if (p.pic_w <= 0 || p.pic_h <= 0 || (p.pic_w & 7) || (p.pic_h & 7) || p.pic_w > 64 * 255 || p.pic_h > 64 * 255 || n_pictures > 32767)
-    return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_intra: picture size");
+    return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_plan_create: picture size");
   if (p.wpp != 1 || p.depth_min < 0 || p.depth_max > 4 || p.depth_min > p.depth_max || p.rough_levels < 2 || p.rough_levels > 3 || p.qp < 0 || p.qp > 63 ||
       p.qp_c < 0 || p.qp_c > 63 || !(p.lambda > 0))
-    return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_intra: configuration outside the supported subset");
+    return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_plan_create: configuration outside the supported subset");
   const int wc = (p.pic_w + 63) / 64, hc = (p.pic_h + 63) / 64, ctus = wc * hc, total = ctus * n_pictures;
   const ws_layout L = layout(n_pictures, p.pic_w, p.pic_h);
   unsigned char *ws = static_cast<unsigned char *>(workspace);
-  hipStream_t st = uvghip_stream(stream);
   // hand-out order: wavefront index first, pictures interleaved inside a wavefront
   std::vector<int32_t> order;
   order.reserve(total);
@@ -124,30 +134,56 @@ extern "C" int uvghip_ctu_search_intra(int bitdepth, const uvghip_ctu_params_t *
   for (int i = 0; i < n_pictures; ++i) {
     const uvghip_ctu_picture_t &q = pictures[i];
     if (!q.src_y || !q.src_u || !q.src_v || !q.rec_y || !q.rec_u || !q.rec_v || !q.cu || !q.coeff || !q.models || q.cu_stride < wc * 16)
-      return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_intra: picture descriptor");
+      return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_plan_create: picture descriptor");
     pics[i] = pic_dev{q.src_y, q.src_u, q.src_v, q.rec_y, q.rec_u, q.rec_v, q.cu, q.coeff, q.models,
                       q.src_stride, q.src_stride_c, q.rec_stride, q.rec_stride_c, q.cu_stride, 0};
   }
-  UVGHIP_TRY(hipMemsetAsync(ws, 0, L.order, st));
-  UVGHIP_TRY(hipMemcpyAsync(ws + L.order, order.data(), (size_t)total * 4, hipMemcpyHostToDevice, st));
-  UVGHIP_TRY(hipMemcpyAsync(ws + L.pics, pics.data(), (size_t)n_pictures * sizeof(pic_dev), hipMemcpyHostToDevice, st));
-  UVGHIP_TRY(hipStreamSynchronize(st));      // the host vectors go out of scope
-  launch_args A;
-  memcpy(&A.P, params, sizeof A.P);
-  A.pics = reinterpret_cast<const pic_dev *>(ws + L.pics);
-  A.order = reinterpret_cast<const int32_t *>(ws + L.order);
-  A.ticket = reinterpret_cast<int32_t *>(ws + L.ticket);
-  A.done = reinterpret_cast<int32_t *>(ws + L.done);
-  A.scratch = reinterpret_cast<ctu::scratch *>(ws + L.scratch);
-  A.wc = wc; A.hc = hc; A.n_ctus = total;
-  if (bitdepth == 8) {
-    const size_t lds = sizeof(ctu::lds<uint8_t>);
-    UVGHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ctu_search_kernel<uint8_t>, dim3(total), dim3(256), lds, st, A);
-  } else {
-    const size_t lds = sizeof(ctu::lds<uint16_t>);
-    UVGHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ctu_search_kernel<uint16_t>, dim3(total), dim3(256), lds, st, A);
-  }
+  UVGHIP_TRY(hipMemcpy(ws + L.order, order.data(), (size_t)total * 4, hipMemcpyHostToDevice));
+  UVGHIP_TRY(hipMemcpy(ws + L.pics, pics.data(), (size_t)n_pictures * sizeof(pic_dev), hipMemcpyHostToDevice));
+  uvghip_ctu_plan *pl = new (std::nothrow) uvghip_ctu_plan;
+  if (!pl) return uvghip_set_error(hipErrorOutOfMemory, __func__);
+  memcpy(&pl->A.P, params, sizeof pl->A.P);
+  pl->A.pics = reinterpret_cast<const pic_dev *>(ws + L.pics);
+  pl->A.order = reinterpret_cast<const int32_t *>(ws + L.order);
+  pl->A.ticket = reinterpret_cast<int32_t *>(ws + L.ticket);
+  pl->A.done = reinterpret_cast<int32_t *>(ws + L.done);
+  pl->A.scratch = reinterpret_cast<ctu::scratch *>(ws + L.scratch);
+  pl->A.wc = wc; pl->A.hc = hc; pl->A.n_ctus = total;
+  pl->bitdepth = bitdepth; pl->total = total; pl->counters = L.order; pl->ws = ws;
+  const size_t lds = bitdepth == 8 ? sizeof(ctu::lds<uint8_t>) : sizeof(ctu::lds<uint16_t>);
+  const hipError_t e = bitdepth == 8
+      ? hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+      : hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) { delete pl; return uvghip_set_error(e, "uvghip_ctu_plan_create: dynamic LDS size"); }
+  *plan_out = pl;
+  return 0;
+}
+
+extern "C" int uvghip_ctu_plan_run(uvghip_ctu_plan_t *pl, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  hipStream_t st = uvghip_stream(stream);
+  UVGHIP_TRY(hipMemsetAsync(pl->ws, 0, pl->counters, st));
+  if (pl->bitdepth == 8) hipLaunchKernelGGL(ctu_search_kernel<uint8_t>, dim3(pl->total), dim3(256), sizeof(ctu::lds<uint8_t>), st, pl->A);
+  else hipLaunchKernelGGL(ctu_search_kernel<uint16_t>, dim3(pl->total), dim3(256), sizeof(ctu::lds<uint16_t>), st, pl->A);
   UVGHIP_CHECK_LAUNCH();
+}
+
+extern "C" void uvghip_ctu_plan_destroy(uvghip_ctu_plan_t *pl) { delete pl; }
+
+// one-shot form: plan, run, wait, drop the plan
+extern "C" int uvghip_ctu_search_intra(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, int n_pictures,
+                                       void *workspace, void *stream)
+{
+  uvghip_ctu_plan_t *pl = nullptr;
+  int rc = uvghip_ctu_plan_create(bitdepth, params, pictures, n_pictures, workspace, &pl);
+  if (rc) return rc;
+  rc = uvghip_ctu_plan_run(pl, stream);
+  if (!rc) {
+    const hipError_t e = hipStreamSynchronize(uvghip_stream(stream));
+    if (e != hipSuccess) rc = uvghip_set_error(e, "uvghip_ctu_search_intra");
+  }
+  uvghip_ctu_plan_destroy(pl);
+  return rc;
 }

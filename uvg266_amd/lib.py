@@ -149,6 +149,9 @@ SIGNATURES = {
     "uvghip_alf_classify_band": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp]),
     "uvghip_ctu_search_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "uvghip_ctu_search_intra": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_ctu_plan_create": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_ctu_plan_run": (c_int, [c_vp, c_vp]),
+    "uvghip_ctu_plan_destroy": (None, [c_vp]),
     "uvghip_comm_unique_id": (c_int, [c_vp]),
     "uvghip_comm_create": (c_int, [c_vp, c_int, c_int, c_vp]),
     "uvghip_comm_destroy": (c_int, [c_vp]),
