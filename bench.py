@@ -579,7 +579,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6, help="timed steps; a step is one group of --in-flight pictures through the closed loop")
     ap.add_argument("--warmup", type=int, default=2, help="untimed steps")
-    ap.add_argument("--in-flight", type=int, default=60, help="pictures per step = per uvghip_ctu_plan_run launch (the reference's --owf)")
+    ap.add_argument("--in-flight", type=int, default=160, help="pictures per step = per uvghip_ctu_plan_run launch (the reference's --owf)")
     ap.add_argument("--groups", type=int, default=2, help="launches in flight at a time, each on its own stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-open-loop", action="store_true", help="skip the open-loop kernel-path measurement (previous rounds' headline)")
@@ -682,7 +682,8 @@ def main():
                        "note": "SAO statistics run on the fully deblocked picture (the reference takes them on a per-CTU partially deblocked "
                                "snapshot, sao.c:641-668): kernels exact, plan not yet the reference's"},
             "roofline": {"bound": "hbm", "kernel": "ctu_search_kernel", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(gbs / HBM_PEAK_GBS, 6), "traffic": TRAFFIC.get("ctu_search"),
+                         "frac": round(gbs / HBM_PEAK_GBS, 6),
+                         "traffic": (TRAFFIC["ctu_search"]["bytes_per_picture"] * F if isinstance(TRAFFIC.get("ctu_search"), dict) else None),
                          "avg_launch_ms": round(launch_ms, 3), "alg_bytes_per_launch": byts, "launches_timed": launches, "launches_in_flight": n_groups,
                          "effective_gbs": round(byts * launches / elapsed / 1e9, 3),
                          "note": "the dominant kernel (> 99 % of the step) is the whole-CTU search: one workgroup walks one CTU's quad tree, "

@@ -66,3 +66,34 @@ def test_several_pictures_in_one_launch(hip, orc):
     for i in (1, 2, 3):
         o = H.oracle_search_picture(orc, depth, prm, *pics[i])
         assert np.array_equal(H.ctu_crcs(rs[i], W, Hh), H.ctu_crcs(o, W, Hh)), i
+
+
+def test_plan_is_reusable_and_the_one_shot_call_agrees(hip, orc):
+    """uvghip_ctu_plan_run twice on the same plan (new source samples in the same buffers in between), then the one-shot
+    uvghip_ctu_search_intra on the same buffers: each pass gives the oracle's result for the samples it saw."""
+    import torch
+    from uvg266_amd import api, layout
+    W, Hh, depth, qp = 256, 128, 8, 32
+    prm = H.search_params(W, Hh, qp)
+    P = api.ctu_params(W, Hh, qp, lam=prm.lam)
+    pics = [layout.synthetic_yuv420(W, Hh, t, depth) for t in (0, 5)]
+    src = [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in pics[0])]
+    cs = api.CtuSearch(P, src)
+
+    def result():
+        torch.cuda.synchronize()
+        ry, ru, rv = (t.cpu().numpy() for t in cs.rec[0])
+        scu = cs.cu[0].cpu().numpy().reshape(-1).view(H.SCU_NP)
+        return H.ctu_crcs(H.search_result_from_device_layout(W, Hh, ry, ru, rv, scu, cs.coeff[0].cpu().numpy(),
+                                                            cs.models[0].cpu().numpy().view(np.uint32)), W, Hh)
+    want = [H.ctu_crcs(H.oracle_search_picture(orc, depth, prm, *p), W, Hh) for p in pics]
+    cs.run()
+    assert np.array_equal(result(), want[0])
+    for d, s in zip(src[0], pics[1]):
+        d.copy_(torch.from_numpy(np.ascontiguousarray(s)))
+    cs.run()
+    assert np.array_equal(result(), want[1])
+    for t in cs.rec[0]:
+        t.zero_()
+    cs.run_oneshot()
+    assert np.array_equal(result(), want[1])
