@@ -354,3 +354,41 @@ ORC_EXPORT void ORC_FN(deblock_frame)(orc_px *y, int y_stride, orc_px *u, orc_px
       }
   }
 }
+
+/*
+ * uvg_filter_deblock_lcu (filter.c:1372-1380) for the CTU at (x_px, y_px), in place, in the reference's own order:
+ * the CTU's vertical edges (left boundary included), the horizontal edges of the last 8 luma columns of the CTU to the
+ * left (filter_deblock_lcu_rightmost, :1303-1340), then the CTU's horizontal edges minus its own last 8 columns unless it
+ * is the picture's last CTU of the row (filter_deblock_unit, :1224-1238).  Calling it for every CTU in raster order gives the
+ * picture of deblock_frame; what matters here is the state in between: uvg_sao_search_lcu (encoderstate.c:849) reads the CTU's
+ * block right after this call.
+ */
+static void deblock_unit(orc_px *y, int y_stride, orc_px *u, orc_px *v, int c_stride, const orc_scu *scu, int scu_stride,
+                         int bx, int by, int dir_hor, const orc_dbk_cfg *cfg)
+{
+  const int bit = dir_hor ? 2 : 1;
+  if ((!dir_hor && bx == 0) || (dir_hor && by == 0)) return;
+  const orc_scu *c = scu + (by >> 2) * scu_stride + (bx >> 2);
+  if (c->luma_edges & bit) luma_segment(y, y_stride, scu, scu_stride, bx, by, dir_hor, cfg);
+  if (u && (c->luma_edges & bit) && (c->chroma_edges & bit)) {
+    const int xc = bx >> 1, yc = by >> 1;
+    if (dir_hor ? (yc & 7) == 0 : (xc & 7) == 0) chroma_segment(u, v, c_stride, scu, scu_stride, xc, yc, dir_hor, cfg);
+  }
+}
+ORC_EXPORT void ORC_FN(deblock_lcu)(orc_px *y, int y_stride, orc_px *u, orc_px *v, int c_stride, int width, int height,
+                                    const orc_scu *scu, int scu_stride, int beta_offset_div2, int tc_offset_div2,
+                                    int slice_is_b, int frame_qp, const int8_t *chroma_qp_map, int x_px, int y_px)
+{
+  const orc_dbk_cfg cfg = {beta_offset_div2, tc_offset_div2, slice_is_b, frame_qp, chroma_qp_map};
+  const int end_x = imin(x_px + 64, width), end_y = imin(y_px + 64, height);
+  for (int by = y_px; by < end_y; by += 4)
+    for (int bx = x_px; bx < end_x; bx += 4) deblock_unit(y, y_stride, u, v, c_stride, scu, scu_stride, bx, by, 0, &cfg);
+  if (x_px > 0)
+    for (int bx = x_px - 8; bx < x_px; bx += 4)
+      for (int by = y_px; by < end_y; by += 4) deblock_unit(y, y_stride, u, v, c_stride, scu, scu_stride, bx, by, 1, &cfg);
+  for (int by = y_px; by < end_y; by += 4)
+    for (int bx = x_px; bx < end_x; bx += 4) {
+      if ((bx & 63) >= 56 && bx < width - 8) continue;        /* "the last 8 pixels will be deblocked when processing the next LCU" */
+      deblock_unit(y, y_stride, u, v, c_stride, scu, scu_stride, bx, by, 1, &cfg);
+    }
+}

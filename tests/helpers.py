@@ -421,6 +421,65 @@ def ctu_crcs(res, W, H):
     return out
 
 
+def scu_from_cu(cu, qp):
+    """uvghip_scu_t / orc_scu table (one entry per 4x4, all rows of whole CTUs) from the compact cu fields [h4, w4, 11] of
+    oracle_search_picture / the ref_ctu goldens: what the deblocking filter reads of an intra picture."""
+    t = np.zeros(cu.shape[:2], SCU_NP)
+    for j, f in enumerate(("type", "log2_width", "log2_height", "log2_chroma_width", "log2_chroma_height", "cbf")):
+        t[f] = cu[:, :, j]
+    t["luma_edges"], t["chroma_edges"] = cu[:, :, 8], cu[:, :, 9]
+    t["qp"] = qp
+    return t
+
+
+def oracle_sao_picture(orc, depth, W, H, qp, lam, src, rec, scu, sao_type=3):
+    """orcN_sao_search_picture: per-CTU deblocking in the encoder's order, the SAO decision of every CTU on the block it sees at
+    that moment, SAO of the deblocked picture.  rec: reconstruction before the in-loop filters (not modified).
+    -> dict(sao [ctus, 2, 17], sao_models [ctus, 6], snap_y/u/v, final_y/u/v, deblocked_y/u/v)"""
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    px = px_dtype(depth)
+    s = [np.ascontiguousarray(a, px) for a in src]
+    r = [np.ascontiguousarray(a, px).copy() for a in rec]
+    scu = np.ascontiguousarray(scu)
+    info = np.zeros((wc * hc, 2, 17), np.int32)
+    models = np.zeros((wc * hc, 6), np.uint16)
+    snap = [np.zeros_like(a) for a in r]
+    out = [np.zeros_like(a) for a in r]
+    fn = orc.fn(depth, "sao_search_picture")
+    fn.restype = None
+    fn(ptr(s[0]), ptr(s[1]), ptr(s[2]), ptr(r[0]), ptr(r[1]), ptr(r[2]), ctypes.c_int(W), ctypes.c_int(H), ptr(scu), ctypes.c_int(scu.shape[1]),
+       ctypes.c_int(qp), ctypes.c_double(lam), ctypes.c_int(sao_type), ptr(info), ptr(models), ptr(snap[0]), ptr(snap[1]), ptr(snap[2]),
+       ptr(out[0]), ptr(out[1]), ptr(out[2]))
+    return dict(sao=info, sao_models=models, snap_y=snap[0], snap_u=snap[1], snap_v=snap[2], final_y=out[0], final_u=out[1], final_v=out[2],
+                deblocked_y=r[0], deblocked_u=r[1], deblocked_v=r[2])
+
+
+def sao_info_comparable(info):
+    """sao_info_t records with the entries the encoder leaves undefined masked out: offsets[0] / offsets[5] of a band decision
+    are copies of uninitialised stack (sao.c:453,478: temp_offsets[0], [5] are never written), the second half of a luma
+    record's offsets likewise (one buffer), and merges pass both on."""
+    a = info.copy()
+    a[:, :, 7] = 0              # category 0 / the slot in front of the four band offsets: 0 for an edge decision, stack garbage for a
+    a[:, :, 12] = 0             # band decision -- also when "nothing" then beat the band decision and only the type changed
+    a[:, 0, 12:] = 0            # luma: one buffer, offsets[5..9] are whatever edge_offset[5..9] held (sao.c:373,436)
+    a[:, 0, 6] = 0              # ... and band_position[1] of a luma band decision is never written (sao.c:462)
+    return a
+
+
+def filter_crcs(res, W, H):
+    """Per CTU CRC-32 of (the block the SAO decision saw, the block of the final picture), Y + U + V, as
+    tools/refcheck/make_ctu_goldens.py computes them (filter_crc)."""
+    import zlib
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    out = np.zeros((wc * hc, 2), np.uint32)
+    for k in range(wc * hc):
+        y, x = (k // wc) * 64, (k % wc) * 64
+        for j, pre in enumerate(("snap_", "final_")):
+            out[k, j] = zlib.crc32(b"".join(np.ascontiguousarray(res[pre + n][(y >> c):(y >> c) + (64 >> c), (x >> c):(x >> c) + (64 >> c)]).tobytes()
+                                            for n, c in (("y", 0), ("u", 1), ("v", 1))))
+    return out
+
+
 def ctu_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 

@@ -129,8 +129,57 @@ void __wrap_uvg_encode_coding_tree(encoder_state_t *const state, lcu_coeff_t *co
   __real_uvg_encode_coding_tree(state, coeff, tree_type, cu_loc, chroma_loc, split_tree, has_chroma);
   snapshot(&state->cabac, &after);
   int32_t meta[3] = {(int32_t)state->frame->num, cu_loc->x, cu_loc->y};
-  rec_begin("coded", 3);
+  uint16_t m_sao[6];
+  m_sao[0] = state->cabac.ctx.sao_merge_flag_model.state[0]; m_sao[1] = state->cabac.ctx.sao_merge_flag_model.state[1]; m_sao[2] = state->cabac.ctx.sao_merge_flag_model.rate;
+  m_sao[3] = state->cabac.ctx.sao_type_idx_model.state[0]; m_sao[4] = state->cabac.ctx.sao_type_idx_model.state[1]; m_sao[5] = state->cabac.ctx.sao_type_idx_model.rate;
+  rec_begin("coded", 4);
   rec_arr(A_I32, meta, 3); rec_arr(A_U8, &before, sizeof before); rec_arr(A_U8, &after, sizeof after);
+  rec_arr(A_U16, m_sao, 6);        /* the two SAO models after this CTU's SAO syntax (encode_sao precedes the coding tree) */
+}
+
+/* uvg_sao_search_lcu (src/sao.c:670, called at src/encoderstate.c:849 right after the CTU's own uvg_filter_deblock_lcu): the CTU's
+ * block of frame->rec as the decision sees it (deblocked by the CTU's own edges only), the two SAO context models the bit
+ * estimates read (state->search_cabac) with that structure's flags, and the decision. */
+#include "sao.h"
+static void sao_models(const cabac_data_t *cb, uint16_t *o)
+{
+  o[0] = cb->ctx.sao_merge_flag_model.state[0]; o[1] = cb->ctx.sao_merge_flag_model.state[1]; o[2] = cb->ctx.sao_merge_flag_model.rate;
+  o[3] = cb->ctx.sao_type_idx_model.state[0]; o[4] = cb->ctx.sao_type_idx_model.state[1]; o[5] = cb->ctx.sao_type_idx_model.rate;
+}
+static void sao_pack(const sao_info_t *s, int32_t *o)
+{
+  o[0] = s->type; o[1] = s->eo_class; o[2] = s->ddistortion; o[3] = s->merge_left_flag; o[4] = s->merge_up_flag;
+  o[5] = s->band_position[0]; o[6] = s->band_position[1];
+  for (int i = 0; i < 10; ++i) o[7 + i] = s->offsets[i];
+}
+void __real_uvg_sao_search_lcu(const encoder_state_t *const state, int lcu_x, int lcu_y);
+void __wrap_uvg_sao_search_lcu(const encoder_state_t *const state, int lcu_x, int lcu_y)
+{
+  const videoframe_t *frame = state->tile->frame;
+  const int x = lcu_x * 64, y = lcu_y * 64;
+  static uvg_pixel ry[64 * 64], ru[32 * 32], rv[32 * 32];
+  memset(ry, 0, sizeof ry); memset(ru, 0, sizeof ru); memset(rv, 0, sizeof rv);
+  for (int yy = 0; yy < 64 && y + yy < frame->height; ++yy)
+    for (int xx = 0; xx < 64 && x + xx < frame->width; ++xx) ry[yy * 64 + xx] = frame->rec->y[(y + yy) * frame->rec->stride + x + xx];
+  for (int yy = 0; yy < 32 && y / 2 + yy < frame->height / 2; ++yy)
+    for (int xx = 0; xx < 32 && x / 2 + xx < frame->width / 2; ++xx) {
+      ru[yy * 32 + xx] = frame->rec->u[(y / 2 + yy) * (frame->rec->stride / 2) + x / 2 + xx];
+      rv[yy * 32 + xx] = frame->rec->v[(y / 2 + yy) * (frame->rec->stride / 2) + x / 2 + xx];
+    }
+  uint16_t m_search[6], m_coder[6], m_after[6];
+  sao_models(&state->search_cabac, m_search); sao_models(&state->cabac, m_coder);
+  int32_t meta[6] = {(int32_t)state->frame->num, lcu_x, lcu_y, state->search_cabac.update, state->search_cabac.only_count, state->encoder_control->cfg.sao_type};
+  double lam[1] = {state->lambda};
+  __real_uvg_sao_search_lcu(state, lcu_x, lcu_y);
+  sao_models(&state->search_cabac, m_after);
+  int32_t luma[17], chroma[17];
+  sao_pack(&frame->sao_luma[lcu_y * frame->width_in_lcu + lcu_x], luma);
+  sao_pack(&frame->sao_chroma[lcu_y * frame->width_in_lcu + lcu_x], chroma);
+  rec_begin("sao", 10);
+  rec_arr(A_I32, meta, 6); rec_arr(A_F64, lam, 1);
+  rec_arr(A_U16, m_search, 6); rec_arr(A_U16, m_coder, 6); rec_arr(A_U16, m_after, 6);
+  rec_arr(A_I32, luma, 17); rec_arr(A_I32, chroma, 17);
+  rec_arr(A_PX, ry, 64 * 64); rec_arr(A_PX, ru, 32 * 32); rec_arr(A_PX, rv, 32 * 32);
 }
 
 int main(int argc, char **argv)
@@ -181,6 +230,21 @@ int main(int argc, char **argv)
       for (uvg_data_chunk *c = chunks; c; c = c->next) fwrite(c->data, 1, c->len, bs);
       api->chunk_free(chunks);
       ++done;
+    }
+    if (rec) {
+      /* the picture after all in-loop filters (deblocking + SAO; ALF and LMCS are off by default, src/cfg.c:62-67) */
+      int32_t meta[3] = {(int32_t)rec->pts, W, H};
+      rec_begin("final", 4);
+      rec_arr(A_I32, meta, 3);
+      for (int p = 0; p < 3; ++p) {
+        const int w = p ? W / 2 : W, h = p ? H / 2 : H;
+        const uvg_pixel *srcp = p == 0 ? rec->y : (p == 1 ? rec->u : rec->v);
+        const int stride = p ? rec->stride / 2 : rec->stride;
+        uvg_pixel *tmp = malloc(sizeof(uvg_pixel) * (size_t)w * h);
+        for (int y = 0; y < h; ++y) memcpy(tmp + (size_t)y * w, srcp + (size_t)y * stride, sizeof(uvg_pixel) * (size_t)w);
+        rec_arr(A_PX, tmp, (size_t)w * h);
+        free(tmp);
+      }
     }
     api->picture_free(rec); api->picture_free(src);
     if (!pic && !chunks) break;

@@ -48,9 +48,38 @@ def run(W, H, depth, qp, t, tag):
     recs = read_records(out + ".bin")
     S = [r for n, r in recs if n == "search"]
     Cd = [r for n, r in recs if n == "coded"]
+    global SAO, FINAL
+    SAO = [r for n, r in recs if n == "sao"]
+    FINAL = [r for n, r in recs if n == "final"][0]
     src_crc = zlib.crc32(y.tobytes() + u.tobytes() + v.tobytes())
     bitstream = np.frombuffer(open(out + ".266", "rb").read(), np.uint8)
     return S, Cd, src_crc, bitstream, px
+
+
+def sao_items(W, H, Cd, px):
+    """The in-loop filter side of the run: per CTU the SAO decision (luma, chroma sao_info_t as 17 ints), the two SAO context
+    models after the CTU's SAO syntax, the CTU's block as uvg_sao_search_lcu saw it (deblocked by the CTU's own edges only),
+    and the picture the encoder returned (after deblocking + SAO)."""
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    info = np.zeros((hc * wc, 2, 17), np.int32)
+    models = np.zeros((hc * wc, 6), np.uint16)
+    snap = [np.zeros((H, W), px), np.zeros((H // 2, W // 2), px), np.zeros((H // 2, W // 2), px)]
+    assert len(SAO) == wc * hc
+    for r in SAO:
+        cx, cy = int(r[0][1]), int(r[0][2])
+        assert int(r[0][3]) == 0 and int(r[0][4]) == 1 and int(r[0][5]) == 3          # search_cabac.update, only_count, cfg.sao_type
+        assert (r[2] == r[3]).all() and (r[2] == r[4]).all()                          # the decision reads the coder's models and leaves them
+        k = cy * wc + cx
+        info[k, 0], info[k, 1] = r[5], r[6]
+        x, y = cx * 64, cy * 64
+        hh, ww = min(64, H - y), min(64, W - x)
+        snap[0][y:y + hh, x:x + ww] = r[7].reshape(64, 64)[:hh, :ww]
+        snap[1][y // 2:(y + hh) // 2, x // 2:(x + ww) // 2] = r[8].reshape(32, 32)[:hh // 2, :ww // 2]
+        snap[2][y // 2:(y + hh) // 2, x // 2:(x + ww) // 2] = r[9].reshape(32, 32)[:hh // 2, :ww // 2]
+    for c in Cd:
+        models[(int(c[0][2]) // 64) * wc + int(c[0][1]) // 64] = c[3]
+    final = [FINAL[1].reshape(H, W), FINAL[2].reshape(H // 2, W // 2), FINAL[3].reshape(H // 2, W // 2)]
+    return info, models, snap, final
 
 
 def items(s, c, W, H):
@@ -88,8 +117,10 @@ def full(W, H, depth, qp, t=0):
         co[:4096].reshape(64, 64)[:hh, :ww] = cy
         co[4096:].reshape(2, 32, 32)[:, :hh // 2, :ww // 2] = cuv
     meta = np.array([W, H, depth, qp, t, int(S[0][0][3])], np.int32)
+    info, sm, snap, final = sao_items(W, H, Cd, px)
     np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_ctu_{tag}.npz"), meta=meta, lam=S[0][1], src_crc=np.uint32(src_crc), models=models,
-                        cu=cu, trees=trees, rec_y=rec[0], rec_u=rec[1], rec_v=rec[2], coeff=coeff, bitstream=bs)
+                        cu=cu, trees=trees, rec_y=rec[0], rec_u=rec[1], rec_v=rec[2], coeff=coeff, bitstream=bs,
+                        sao=info, sao_models=sm, snap_y=snap[0], snap_u=snap[1], snap_v=snap[2], final_y=final[0], final_u=final[1], final_v=final[2])
     print("wrote", tag, len(S), "CTUs")
 
 
@@ -106,8 +137,14 @@ def crcs(W, H, depth, qp, t=0):
         out[k, 2] = zlib.crc32(np.ascontiguousarray(cy).tobytes() + np.ascontiguousarray(cuv).tobytes())
         out[k, 3] = zlib.crc32(c[2][:1286].tobytes())
     meta = np.array([W, H, depth, qp, t, int(S[0][0][3])], np.int32)
+    info, sm, snap, final = sao_items(W, H, Cd, px)
+    fcrc = np.zeros((hc * wc, 2), np.uint32)          # per CTU: the block the SAO decision saw, the block of the final picture (Y, U, V)
+    for k in range(hc * wc):
+        y, x = (k // wc) * 64, (k % wc) * 64
+        blk = lambda P: b"".join(np.ascontiguousarray(p[(y >> c):(y >> c) + (64 >> c), (x >> c):(x >> c) + (64 >> c)]).tobytes() for p, c in zip(P, (0, 1, 1)))
+        fcrc[k] = zlib.crc32(blk(snap)), zlib.crc32(blk(final))
     np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_ctucrc_{tag}.npz"), meta=meta, lam=S[0][1], src_crc=np.uint32(src_crc), crc=out,
-                        bitstream_crc=np.uint32(zlib.crc32(bs.tobytes())), bitstream_len=np.int64(len(bs)))
+                        bitstream_crc=np.uint32(zlib.crc32(bs.tobytes())), bitstream_len=np.int64(len(bs)), sao=info, sao_models=sm, filter_crc=fcrc)
     print("wrote crc", tag, len(S), "CTUs")
 
 
