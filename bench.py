@@ -399,11 +399,20 @@ class ClosedLoop:
         self.src = src
         self.rects = [torch.from_numpy(layout.ctu_rects(self.W >> c, self.H >> c, 64 >> c)).to(device) for c in (0, 1)]
         self.out = [tuple(torch.empty_like(p) for p in s) for s in src]
+        self.snap = [tuple(torch.empty_like(p) for p in s) for s in src]            # the pictures as the SAO decisions see them
+        n_ctus = in_flight * self.rects[0].shape[0]
+        self.edge = [torch.empty((n_ctus, 4, 2, 5), dtype=torch.int32, device=device) for _ in range(3)]
+        self.band = [torch.empty((n_ctus, 2, 32), dtype=torch.int32, device=device) for _ in range(3)]
+        self.decision = api.sao_decide_buffers(in_flight, self.W, self.H, device)
         self.stream = torch.cuda.Stream(device=device)
         self.ev = []                    # (start, end) of every timed search launch, on this group's stream
         self.done = torch.cuda.Event()
 
     def issue(self, timed=True):
+        """search -> [copy of the reconstruction deblocked CTU by CTU by its own edges only -> SAO statistics of Y, U, V on it ->
+        the SAO decision of every CTU, all pictures of the group in one call] -> deblocking of the reconstruction -> SAO apply:
+        the reference's own schedule (encoderstate.c:841-853: uvg_filter_deblock_lcu, uvg_sao_search_lcu per CTU; the frame's
+        uvg_sao_reconstruct afterwards), bit-identical with the picture the encoder returns (tests/test_gpu_sao_decide.py)."""
         cs = self.cs
         with torch.cuda.stream(self.stream):
             if timed:
@@ -413,13 +422,23 @@ class ClosedLoop:
             if timed:
                 e1.record()
                 self.ev.append((e0, e1))
-            for i in range(cs.n):
+            n, ctus = cs.n, self.rects[0].shape[0]
+            for i in range(n):
+                scu = cs.cu[i].view(cs.cu[i].shape[0], -1)
+                for c in range(3):
+                    self.snap[i][c].copy_(cs.rec[i][c])
+                sy, su, sv = self.snap[i]
+                api.deblock_frame(sy, su, sv, scu, self.W, self.H, frame_qp=QP, sao_snapshot=True)
+                for c in range(3):
+                    api.sao_stats_batch(self.src[i][c], self.snap[i][c], self.rects[0 if c == 0 else 1],
+                                        edge=self.edge[c][i * ctus:(i + 1) * ctus], band=self.band[c][i * ctus:(i + 1) * ctus])
+            _, _, params = api.sao_decide_pictures(n, self.W, self.H, self.depth, QP, self.P.lambda_, [(self.edge[c], self.band[c]) for c in range(3)],
+                                                   out=self.decision)
+            for i in range(n):
                 ry, ru, rv = cs.rec[i]
                 api.deblock_frame(ry, ru, rv, cs.cu[i].view(cs.cu[i].shape[0], -1), self.W, self.H, frame_qp=QP)
-                for c, (o, r, d) in enumerate(zip(self.src[i], cs.rec[i], self.out[i])):
-                    rects = self.rects[0 if c == 0 else 1]
-                    edge, _ = api.sao_stats_batch(o, r, rects)
-                    api.sao_apply_batch(r, d, rects, api.sao_edge_offsets_batch(edge))
+                for c in range(3):
+                    api.sao_apply_batch(cs.rec[i][c], self.out[i][c], self.rects[0 if c == 0 else 1], params[c][i * ctus:(i + 1) * ctus])
             self.done.record()
 
     def search_ms(self):
@@ -670,17 +689,19 @@ def main():
             "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8" if wl["depth"] == 8 else "u16", "data": "synthetic",
             "config": {"workload": f"{wl['W']}x{wl['H']} {wl['depth']}-bit yuv420p, -p 1 --preset medium at QP {QP} (BASELINE.json configs[1]): per picture "
-                                   "uvghip_ctu_search_intra (closed-loop CTU search bit-identical with the reference: partition, modes, levels, "
-                                   "reconstruction, CABAC models) -> uvghip_deblock_frame on the search's side information -> SAO statistics / "
-                                   "edge offsets / apply (Y, U, V); the arithmetic coder is out of the hot-path scope",
+                                   "uvghip_ctu_plan_run (closed-loop CTU search bit-identical with the reference: partition, modes, levels, "
+                                   "reconstruction, CABAC models) -> deblocking on the search's side information -> SAO statistics / decision "
+                                   "(edge, band, merge) / apply for Y, U, V; the arithmetic coder is out of the hot-path scope",
                        "mpixels_per_s": round(fps * wl["W"] * wl["H"] / 1e6, 2), "qp": QP,
                        "step": f"one group of {F} pictures through the closed loop (one uvghip_ctu_plan_run + the filter chain of its pictures)",
                        "pictures_per_step": F, "pictures_timed": steps * F * world, "groups_in_flight": n_groups, "timed_region_s": round(elapsed, 3),
                        "ctus_per_picture": wc * hc, "wavefront_steps_per_picture": wc + hc - 1,
                        "parallelism": f"whole pictures over {world} rank(s) (all-intra pictures are independent), {F} pictures per launch, "
                                       f"{n_groups} launches in flight on their own streams; inside a picture one workgroup per CTU on the WPP wavefront",
-                       "note": "SAO statistics run on the fully deblocked picture (the reference takes them on a per-CTU partially deblocked "
-                               "snapshot, sao.c:641-668): kernels exact, plan not yet the reference's"},
+                       "note": "the in-loop filters follow the reference's schedule: SAO statistics on every CTU deblocked by its own edges only "
+                               "(uvghip_deblock_frame_sao_snapshot; sao.c:641-668), the whole sao_search_best_mode decision with the coder's SAO "
+                               "models (uvghip_sao_decide_pictures), SAO of the deblocked picture -- the output is the picture the encoder returns, "
+                               "bit for bit (tests/test_gpu_sao_decide.py against reference-run records at 1080p and 2160p)"},
             "roofline": {"bound": "hbm", "kernel": "ctu_search_kernel", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBS, 6),
                          "traffic": (TRAFFIC["ctu_search"]["bytes_per_picture"] * F if isinstance(TRAFFIC.get("ctu_search"), dict) else None),

@@ -535,6 +535,25 @@ UVGHIP_API int uvghip_sao_apply_batch(int bitdepth, const void *rec, int rec_str
 UVGHIP_API int uvghip_sao_edge_offsets_batch(const int32_t *edge_stats, const int32_t *rate_cost, int n,
                                   uvghip_sao_param_t *params_out, int32_t *ddist_out, void *stream);
 
+/* replaces: uvg_sao_search_lcu (src/sao.c:670-742) for every CTU of n_pictures all-intra pictures of one size -- the whole
+ * decision: sao_search_best_mode (:490-603: edge classes, band position, "nothing", the merge candidates), the bit estimates
+ * sao_mode_bits_* (:52-178) on the coder's two SAO context models, and those models' adaptation by encode_sao
+ * (src/encoderstate.c:523-608) from CTU to CTU in coding order (WPP: a row starts from the models after the first CTU of the
+ * row above).  Input: the statistics of uvghip_sao_stats_batch taken with one rectangle per CTU (raster order, pictures one
+ * after the other: [picture][ctu]) on the picture uvghip_deblock_frame_sao_snapshot produced, per plane; every distortion the
+ * reference measures on samples is an exact function of them.  qp / lambda: state->qp / state->lambda of the (intra) slice;
+ * sao_type: cfg.sao_type (1 edge, 2 band, 3 both).
+ * Output per CTU: info_out[34] = the reference's two sao_info_t (luma, chroma: type, eo_class, ddistortion, merge_left_flag,
+ * merge_up_flag, band_position[2], offsets[10]; entries the reference leaves uninitialised are 0), models_out[6] = the two models
+ * (sao_merge_flag, sao_type_idx: state[0], state[1], rate) after the CTU's SAO syntax, and the three uvghip_sao_param_t
+ * uvghip_sao_apply_batch takes.  workspace: uvghip_sao_decide_workspace_bytes of device memory. */
+UVGHIP_API size_t uvghip_sao_decide_workspace_bytes(int n_pictures, int pic_w, int pic_h);
+UVGHIP_API int uvghip_sao_decide_pictures(int bitdepth, int n_pictures, int pic_w, int pic_h, int qp, double lambda, int sao_type,
+                                          const int32_t *edge_y, const int32_t *band_y, const int32_t *edge_u, const int32_t *band_u,
+                                          const int32_t *edge_v, const int32_t *band_v, void *workspace, int32_t *info_out,
+                                          uint16_t *models_out, uvghip_sao_param_t *params_y, uvghip_sao_param_t *params_u,
+                                          uvghip_sao_param_t *params_v, void *stream);
+
 /* ------------------------------------------ (2) batched ABI: deblocking ---- */
 
 /* Side information of one 4x4 luma block ("SCU"), the subset of cu_info_t
@@ -681,6 +700,18 @@ UVGHIP_API int uvghip_deblock_band(int bitdepth, void *y, int y_stride, void *u,
                         const uvghip_scu_t *scu, int scu_stride, int beta_offset_div2, int tc_offset_div2,
                         int slice_is_b, int frame_qp, const int8_t *chroma_qp_map_host, int row0, int row1, int passes,
                         void *stream);
+
+/* The picture as uvg_sao_search_lcu sees it (src/sao.c:641-668, called at src/encoderstate.c:849 right after the CTU's own
+ * uvg_filter_deblock_lcu): every CTU deblocked by its OWN edges only.  Same arguments and in-place operation as
+ * uvghip_deblock_frame, but an edge on a CTU boundary does not write into the CTU before it (that CTU took its SAO statistics
+ * before this edge was filtered, filter.c:1372-1380) and horizontal edges skip the last 8 luma columns of every CTU that is not
+ * the last of its row (filter.c:1224-1238: they wait for the next CTU).  Every sample of the result is the value the
+ * reference's SAO decision of the CTU containing it reads; run uvghip_sao_stats_batch on it, uvghip_sao_apply_batch on the
+ * picture uvghip_deblock_frame produces from the same input. */
+UVGHIP_API int uvghip_deblock_frame_sao_snapshot(int bitdepth, void *y, int y_stride, void *u, void *v, int c_stride, int width,
+                                                 int height, const uvghip_scu_t *scu, int scu_stride, int beta_offset_div2,
+                                                 int tc_offset_div2, int slice_is_b, int frame_qp, const int8_t *chroma_qp_map_host,
+                                                 void *stream);
 
 /* uvghip_alf_classify_frame for the 4x4 blocks of rows [row0, row1). */
 UVGHIP_API int uvghip_alf_classify_band(int bitdepth, const void *rec, int rec_stride, int width, int height, int shift,

@@ -1,0 +1,77 @@
+"""The in-loop filter side of the closed loop on the device -- uvghip_deblock_frame_sao_snapshot (every CTU deblocked by its own
+edges only: what the reference's SAO decision reads), uvghip_sao_stats_batch on it, uvghip_sao_decide_pictures (edge / band / merge
+decision with the coder's SAO models carried CTU to CTU), uvghip_deblock_frame + uvghip_sao_apply_batch -- against records of
+the real encoder (tests/golden/ref_ctu*.npz): the block every decision saw, the decisions, the models, the final picture."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def filters_on_device(W, Hh, depth, qp, lam, src, rec, scu_np, n_copies=1):
+    """-> dict like helpers.oracle_sao_picture for picture 0 of n_copies identical pictures decided in one call."""
+    import torch
+    from uvg266_amd import api, layout
+    dev = "cuda"
+    S = [torch.from_numpy(np.ascontiguousarray(p)).to(dev) for p in src]
+    R = [torch.from_numpy(np.ascontiguousarray(p)).to(dev) for p in rec]
+    scu = torch.from_numpy(np.ascontiguousarray(scu_np).view(np.uint8).reshape(scu_np.shape[0], -1)).to(dev)
+    snap = [r.clone() for r in R]
+    api.deblock_frame(snap[0], snap[1], snap[2], scu, W, Hh, frame_qp=qp, sao_snapshot=True)
+    rects = [torch.from_numpy(layout.ctu_rects(W >> c, Hh >> c, 64 >> c)).to(dev) for c in (0, 1)]
+    stats = []
+    for c in range(3):
+        e, b = api.sao_stats_batch(S[c], snap[c], rects[0 if c == 0 else 1])
+        stats.append((e.repeat(n_copies, 1, 1, 1).contiguous(), b.repeat(n_copies, 1, 1).contiguous()))
+    info, models, params = api.sao_decide_pictures(n_copies, W, Hh, depth, qp, lam, stats)
+    ctus = rects[0].shape[0]
+    api.deblock_frame(R[0], R[1], R[2], scu, W, Hh, frame_qp=qp)
+    out = [torch.zeros_like(r) for r in R]
+    for c in range(3):
+        api.sao_apply_batch(R[c], out[c], rects[0 if c == 0 else 1], params[c][:ctus].contiguous())
+    torch.cuda.synchronize()
+    inf = info.cpu().numpy().reshape(n_copies, ctus, 2, 17)
+    mod = models.cpu().numpy().view(np.uint16).reshape(n_copies, ctus, 6)
+    for k in range(1, n_copies):
+        assert np.array_equal(inf[k], inf[0]) and np.array_equal(mod[k], mod[0])
+    names = ("y", "u", "v")
+    d = dict(sao=inf[0], sao_models=mod[0])
+    for c in range(3):
+        d["snap_" + names[c]] = snap[c].cpu().numpy()
+        d["final_" + names[c]] = out[c].cpu().numpy()
+    return d
+
+
+@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37"])
+def test_filters_and_sao_decisions_equal_the_encoder_run(hip, name):
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    r = filters_on_device(W, Hh, depth, qp, float(g["lam"][0]), (y, u, v), (g["rec_y"], g["rec_u"], g["rec_v"]), H.scu_from_cu(g["cu"], qp), n_copies=3)
+    for k in ("snap_y", "snap_u", "snap_v"):
+        assert np.array_equal(r[k], g[k]), k
+    assert np.array_equal(H.sao_info_comparable(r["sao"]), H.sao_info_comparable(g["sao"]))
+    assert np.array_equal(r["sao_models"], g["sao_models"])
+    for k in ("final_y", "final_u", "final_v"):
+        assert np.array_equal(r[k], g[k]), k
+
+
+@pytest.mark.parametrize("name", ["ref_ctucrc_1920x1080_8_qp22", "ref_ctucrc_1920x1080_10_qp27", "ref_ctucrc_3840x2160_10_qp22"])
+def test_search_then_filters_equal_the_encoder_run(hip, name):
+    """End to end on the device: the CTU search's own reconstruction and side information feed the filters; the picture that comes
+    out is the picture the encoder returned."""
+    import torch
+    from uvg266_amd import api
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    prm = H.search_params(W, Hh, qp)
+    cs = api.CtuSearch(api.ctu_params(W, Hh, qp, lam=prm.lam), [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in (y, u, v))])
+    cs.run()
+    torch.cuda.synchronize()
+    rec = [t.cpu().numpy() for t in cs.rec[0]]
+    scu = cs.cu[0].cpu().numpy().reshape(-1).view(H.SCU_NP).reshape(cs.cu[0].shape[0], -1)
+    r = filters_on_device(W, Hh, depth, qp, float(g["lam"][0]), (y, u, v), rec, scu)
+    assert np.array_equal(H.sao_info_comparable(r["sao"]), H.sao_info_comparable(g["sao"]))
+    assert np.array_equal(r["sao_models"], g["sao_models"])
+    assert np.array_equal(H.filter_crcs(r, W, Hh), g["filter_crc"])

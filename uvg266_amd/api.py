@@ -316,12 +316,12 @@ def make_sao_params(rows, device="cuda"):
     return torch.from_numpy(np.ascontiguousarray(np.asarray(rows, np.int32).reshape(-1, 8))).to(device)
 
 
-def sao_stats_batch(orig, rec, rects):
-    """-> (edge (n,4,2,5) int32, band (n,2,32) int32)."""
+def sao_stats_batch(orig, rec, rects, edge=None, band=None):
+    """-> (edge (n,4,2,5) int32, band (n,2,32) int32); written into `edge` / `band` when given (contiguous)."""
     L = _lib.init(rec.device.index or 0)
     n = rects.shape[0]
-    edge = torch.empty((n, 4, 2, 5), dtype=torch.int32, device=rec.device)
-    band = torch.empty((n, 2, 32), dtype=torch.int32, device=rec.device)
+    edge = torch.empty((n, 4, 2, 5), dtype=torch.int32, device=rec.device) if edge is None else edge
+    band = torch.empty((n, 2, 32), dtype=torch.int32, device=rec.device) if band is None else band
     _lib.check(L.uvghip_sao_stats_batch(_depth(rec), _dev(orig), orig.stride(0), _dev(rec), rec.stride(0), _dev(rects), n,
                                         _dev(edge), _dev(band), _stream()), "uvghip_sao_stats_batch")
     return edge, band
@@ -337,6 +337,29 @@ def sao_edge_offsets_batch(edge, rate_cost=None, params=None, ddist=None):
                                                _dev(ddist) if ddist is not None else None, _stream()),
                "uvghip_sao_edge_offsets_batch")
     return params
+
+
+def sao_decide_buffers(n_pictures, pic_w, pic_h, device):
+    """Workspace and outputs of sao_decide_pictures, for callers that decide again and again."""
+    L = _lib.init(torch.device(device).index or 0)
+    n = n_pictures * ((pic_w + 63) // 64) * ((pic_h + 63) // 64)
+    return dict(ws=torch.empty(L.uvghip_sao_decide_workspace_bytes(n_pictures, pic_w, pic_h), dtype=torch.uint8, device=device),
+                info=torch.zeros((n, 2, 17), dtype=torch.int32, device=device), models=torch.zeros((n, 6), dtype=torch.int16, device=device),
+                params=[torch.empty((n, 8), dtype=torch.int32, device=device) for _ in range(3)])
+
+
+def sao_decide_pictures(n_pictures, pic_w, pic_h, depth, qp, lam, stats, sao_type=3, out=None):
+    """uvghip_sao_decide_pictures.  stats: ((edge_y, band_y), (edge_u, band_u), (edge_v, band_v)) from sao_stats_batch over the CTU
+    grids of the pictures ([picture][ctu]).  -> info (n*ctus, 2, 17) int32, models (n*ctus, 6) uint16 (as int16 storage),
+    (params_y, params_u, params_v) each (n*ctus, 8) int32."""
+    dev = stats[0][0].device
+    L = _lib.init(dev.index or 0)
+    b = sao_decide_buffers(n_pictures, pic_w, pic_h, dev) if out is None else out
+    (ey, by), (eu, bu), (ev, bv) = stats
+    _lib.check(L.uvghip_sao_decide_pictures(depth, n_pictures, pic_w, pic_h, qp, float(lam), sao_type, _dev(ey), _dev(by), _dev(eu), _dev(bu),
+                                            _dev(ev), _dev(bv), _dev(b["ws"]), _dev(b["info"]), _dev(b["models"]), _dev(b["params"][0]),
+                                            _dev(b["params"][1]), _dev(b["params"][2]), _stream()), "uvghip_sao_decide_pictures")
+    return b["info"], b["models"], b["params"]
 
 
 def sao_apply_batch(rec, out, rects, params, pic_w=None, pic_h=None):
@@ -361,18 +384,21 @@ def make_scu_table(table, device="cuda"):
 
 
 def deblock_frame(y, u, v, scu, width, height, beta_offset_div2=0, tc_offset_div2=0, slice_is_b=False, frame_qp=-1,
-                  chroma_qp_map=None):
-    """In-place deblocking of a picture.  scu: device table from make_scu_table (row stride = cols)."""
+                  chroma_qp_map=None, sao_snapshot=False):
+    """In-place deblocking of a picture.  scu: device table from make_scu_table (row stride = cols).
+    sao_snapshot: uvghip_deblock_frame_sao_snapshot instead -- every CTU deblocked by its own edges only, what the reference's
+    SAO decision reads."""
     import ctypes
     L = _lib.init(y.device.index or 0)
     qm = None
     if chroma_qp_map is not None:
         qm_arr = np.ascontiguousarray(np.asarray(chroma_qp_map, np.int8)[:64])
         qm = qm_arr.ctypes.data_as(ctypes.c_void_p)
-    _lib.check(L.uvghip_deblock_frame(_depth(y), _dev(y), y.stride(0), None if u is None else _dev(u),
-                                      None if v is None else _dev(v), 0 if u is None else u.stride(0), width, height,
-                                      _dev(scu), scu.shape[1] // 32, beta_offset_div2, tc_offset_div2, int(slice_is_b),
-                                      frame_qp, qm, _stream()), "uvghip_deblock_frame")
+    fn = L.uvghip_deblock_frame_sao_snapshot if sao_snapshot else L.uvghip_deblock_frame
+    _lib.check(fn(_depth(y), _dev(y), y.stride(0), None if u is None else _dev(u),
+                  None if v is None else _dev(v), 0 if u is None else u.stride(0), width, height,
+                  _dev(scu), scu.shape[1] // 32, beta_offset_div2, tc_offset_div2, int(slice_is_b),
+                  frame_qp, qm, _stream()), "uvghip_deblock_frame")
     return y
 
 

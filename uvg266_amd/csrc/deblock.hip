@@ -30,6 +30,8 @@ __device__ static const uint8_t kBeta[64] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
 struct dbk_cfg {
   int beta_offset_div2, tc_offset_div2, slice_is_b, frame_qp;
   int has_qp_map;
+  int snapshot;        // the picture as uvg_sao_search_lcu sees each CTU: an edge on a CTU boundary leaves the CTU before it alone,
+                       // and horizontal edges skip a CTU's last 8 luma columns unless they are the picture's (filter.c:1224-1238, 1341-1380)
   int8_t qp_map[64];
 };
 
@@ -135,7 +137,7 @@ __device__ inline void large_block_line(int *P, int *Q, int tc, int lenP, int le
 
 template <typename PX>
 __device__ inline void luma_segment(PX *plane, int stride, const uvghip_scu_t *scu, int scu_stride, int x, int y, bool dir_hor,
-                                    const dbk_cfg &cfg)
+                                    const dbk_cfg &cfg, bool keep_p)
 {
   constexpr int DEPTH = px_traits<PX>::depth;
   constexpr int MAXV = px_traits<PX>::maxv;
@@ -244,14 +246,14 @@ __device__ inline void luma_segment(PX *plane, int stride, const uvghip_scu_t *s
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
-      if (k < wP[i]) e[i * ys - (k + 1) * xs] = (PX)P[i][k];
+      if (k < wP[i] && !keep_p) e[i * ys - (k + 1) * xs] = (PX)P[i][k];
       if (k < wQ[i]) e[i * ys + k * xs] = (PX)Q[i][k];
     }
 }
 
 template <typename PX>
 __device__ inline void chroma_segment(PX *pu, PX *pv, int stride, const uvghip_scu_t *scu, int scu_stride, int xc, int yc,
-                                      bool dir_hor, const dbk_cfg &cfg)
+                                      bool dir_hor, const dbk_cfg &cfg, bool keep_p)
 {
   constexpr int DEPTH = px_traits<PX>::depth;
   constexpr int MAXV = px_traits<PX>::maxv;
@@ -295,19 +297,21 @@ __device__ inline void chroma_segment(PX *pu, PX *pv, int stride, const uvghip_s
       const int m0 = P[i][3], m1 = P[i][2], m2 = P[i][1], m3 = P[i][0], m4 = Q[i][0], m5 = Q[i][1], m6 = Q[i][2], m7 = Q[i][3];
       if (sw) {
         if (ctb) {
-          e[i * ys - xs] = (PX)clampi((3 * m2 + 2 * m3 + m4 + m5 + m6 + 4) >> 3, m3 - tc, m3 + tc);
+          if (!keep_p) e[i * ys - xs] = (PX)clampi((3 * m2 + 2 * m3 + m4 + m5 + m6 + 4) >> 3, m3 - tc, m3 + tc);
           e[i * ys] = (PX)clampi((2 * m2 + m3 + 2 * m4 + m5 + m6 + m7 + 4) >> 3, m4 - tc, m4 + tc);
         } else {
-          e[i * ys - 3 * xs] = (PX)clampi((3 * m0 + 2 * m1 + m2 + m3 + m4 + 4) >> 3, m1 - tc, m1 + tc);
-          e[i * ys - 2 * xs] = (PX)clampi((2 * m0 + m1 + 2 * m2 + m3 + m4 + m5 + 4) >> 3, m2 - tc, m2 + tc);
-          e[i * ys - xs] = (PX)clampi((m0 + m1 + m2 + 2 * m3 + m4 + m5 + m6 + 4) >> 3, m3 - tc, m3 + tc);
+          if (!keep_p) {
+            e[i * ys - 3 * xs] = (PX)clampi((3 * m0 + 2 * m1 + m2 + m3 + m4 + 4) >> 3, m1 - tc, m1 + tc);
+            e[i * ys - 2 * xs] = (PX)clampi((2 * m0 + m1 + 2 * m2 + m3 + m4 + m5 + 4) >> 3, m2 - tc, m2 + tc);
+            e[i * ys - xs] = (PX)clampi((m0 + m1 + m2 + 2 * m3 + m4 + m5 + m6 + 4) >> 3, m3 - tc, m3 + tc);
+          }
           e[i * ys] = (PX)clampi((m1 + m2 + m3 + 2 * m4 + m5 + m6 + m7 + 4) >> 3, m4 - tc, m4 + tc);
         }
         e[i * ys + xs] = (PX)clampi((m2 + m3 + m4 + 2 * m5 + m6 + 2 * m7 + 4) >> 3, m5 - tc, m5 + tc);
         e[i * ys + 2 * xs] = (PX)clampi((m3 + m4 + m5 + 2 * m6 + 3 * m7 + 4) >> 3, m6 - tc, m6 + tc);
       } else {
         const int delta = clampi((((m4 - m3) * 4) + m2 - m5 + 4) >> 3, -tc, tc);
-        e[i * ys - xs] = (PX)clampi(m3 + delta, 0, MAXV);
+        if (!keep_p) e[i * ys - xs] = (PX)clampi(m3 + delta, 0, MAXV);
         e[i * ys] = (PX)clampi(m4 - delta, 0, MAXV);
       }
     }
@@ -340,14 +344,19 @@ deblock_pass_kernel(PX *__restrict__ y, int y_stride, PX *__restrict__ u, PX *__
   // the header states chroma_edges must be a subset of luma_edges.
   const int le = c->luma_edges, ce = c->chroma_edges;
   if (!(le & bit)) return;
-  if (!chroma) luma_segment<PX>(y, y_stride, scu, scu_stride, bx, by, dir_hor != 0, cfg);
-  else if (ce & bit) chroma_segment<PX>(u, v, c_stride, scu, scu_stride, bx >> 1, by >> 1, dir_hor != 0, cfg);
+  bool keep_p = false;
+  if (cfg.snapshot) {
+    if (dir_hor && (bx & 63) >= 56 && bx < width - 8) return;      // "the last 8 pixels will be deblocked when processing the next LCU"
+    keep_p = ((dir_hor ? by : bx) & 63) == 0;                       // the CTU on the other side has not seen this edge yet
+  }
+  if (!chroma) luma_segment<PX>(y, y_stride, scu, scu_stride, bx, by, dir_hor != 0, cfg, keep_p);
+  else if (ce & bit) chroma_segment<PX>(u, v, c_stride, scu, scu_stride, bx >> 1, by >> 1, dir_hor != 0, cfg, keep_p);
 }
 
 static int deblock_launch(int bitdepth, void *y, int y_stride, void *u, void *v, int c_stride, int width, int height,
                           const uvghip_scu_t *scu, int scu_stride, int beta_offset_div2, int tc_offset_div2, int slice_is_b,
                           int frame_qp, const int8_t *chroma_qp_map_host, int row0, int row1, int passes, hipStream_t st,
-                          const char *who)
+                          const char *who, int snapshot = 0)
 {
   if (bitdepth != 8 && bitdepth != 10) return uvghip_set_error(hipErrorInvalidValue, who);
   if (width <= 0 || height <= 0 || (width & 3) || (height & 3) || row0 < 0 || row1 > height || row0 >= row1 ||
@@ -356,6 +365,7 @@ static int deblock_launch(int bitdepth, void *y, int y_stride, void *u, void *v,
   dbk_cfg cfg;
   cfg.beta_offset_div2 = beta_offset_div2; cfg.tc_offset_div2 = tc_offset_div2; cfg.slice_is_b = slice_is_b; cfg.frame_qp = frame_qp;
   cfg.has_qp_map = chroma_qp_map_host != nullptr;
+  cfg.snapshot = snapshot;
   for (int i = 0; i < 64; ++i) cfg.qp_map[i] = chroma_qp_map_host ? chroma_qp_map_host[i] : 0;
   const int ux = width / 4;
   constexpr int DBK_THREADS = 64;     // one wave per workgroup: 2160 workgroups at 1080p spread evenly over the 256 CUs (256-thread groups: 540)
@@ -393,4 +403,13 @@ extern "C" int uvghip_deblock_band(int bitdepth, void *y, int y_stride, void *u,
   UVGHIP_REQUIRE_READY();
   return deblock_launch(bitdepth, y, y_stride, u, v, c_stride, width, height, scu, scu_stride, beta_offset_div2, tc_offset_div2,
                         slice_is_b, frame_qp, chroma_qp_map_host, row0, row1, passes, uvghip_stream(stream), __func__);
+}
+
+extern "C" int uvghip_deblock_frame_sao_snapshot(int bitdepth, void *y, int y_stride, void *u, void *v, int c_stride, int width, int height,
+                                                 const uvghip_scu_t *scu, int scu_stride, int beta_offset_div2, int tc_offset_div2,
+                                                 int slice_is_b, int frame_qp, const int8_t *chroma_qp_map_host, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  return deblock_launch(bitdepth, y, y_stride, u, v, c_stride, width, height, scu, scu_stride, beta_offset_div2, tc_offset_div2,
+                        slice_is_b, frame_qp, chroma_qp_map_host, 0, height, 3, uvghip_stream(stream), __func__, 1);
 }

@@ -130,6 +130,7 @@ SIGNATURES = {
     "uvghip_sao_apply_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
     "uvghip_sao_edge_offsets_batch": (c_int, [c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvghip_deblock_frame": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "uvghip_deblock_frame_sao_snapshot": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "uvghip_lfnst_batch": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "uvghip_alf_classify_frame": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "uvghip_alf_filter_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
@@ -147,6 +148,9 @@ SIGNATURES = {
     "uvghip_deblock_band": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp,
                                     c_int, c_int, c_int, c_vp]),
     "uvghip_alf_classify_band": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp]),
+    "uvghip_sao_decide_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
+    "uvghip_sao_decide_pictures": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.c_double, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                           c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_ctu_search_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "uvghip_ctu_search_intra": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
     "uvghip_ctu_plan_create": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
