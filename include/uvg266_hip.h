@@ -308,7 +308,8 @@ typedef struct uvghip_qr_params {
   int32_t width, height, color;                          /* TU shape; COLOR_Y/U/V = 0/1/2 */
   int32_t type_hor, type_ver, skip_width, skip_height;   /* uvghip_mts_select for this CU */
   int32_t qp_scaled, slice_is_intra, cu_type;            /* as uvghip_quant_batch; cu_type = cur_cu->type (1 intra, 2 inter) */
-  int32_t use_trskip;                                    /* transform skip: identity transform + the quantiser's TS shifts */
+  int32_t use_trskip;                                    /* uvg_quantize_residual's use_trskip: identity transform; the quantiser's TS
+                                                          * shifts only for luma (tr_idx == MTS_SKIP && color == COLOR_Y, :537-539) */
   int32_t rdoq_enable, rdoq_skip, dep_quant;             /* cfg.rdoq_enable / cfg.rdoq_skip / cfg.dep_quant (must be 0) */
   int32_t cbf_u;                                         /* cbf_is_set(cur_cu->cbf, COLOR_U): RDOQ of a V block reads it */
   int32_t mts_idx;                                       /* cur_cu->tr_idx (passed to RDOQ for luma) */

@@ -1049,8 +1049,6 @@ static int launch_intra_search(int bitdepth, const void *rec, int rec_stride, co
       if (!((lds_done >> (dev_ & 63)) & 1)) { \
         UVGHIP_TRY(hipFuncSetAttribute((const void *)intra_search_kernel<PX, T, W, B, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         lds_done |= 1ull << (dev_ & 63); } } \
-    if (getenv("UVGHIP_DEBUG_OCC")) { int nb = -1; hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, intra_search_kernel<PX, T, W, B, NF>, W * 64, L.total); \
-      fprintf(stderr, "intra_search<%d,%d,%d> size %d: lds %zu grid %d occupancy %d blocks/CU (err %d)\n", (int)sizeof(PX), T, W, size, (size_t)L.total, grid, nb, (int)oe); } \
     intra_search_kernel<PX, T, W, B, NF><<<grid, W * 64, L.total, st>>>((const PX *)rec, rec_stride, (const PX *)orig, orig_stride, size, blks, n, modes, n_modes, costs, best_mode, best_cost, pic_rows); } while (0)
   if (bitdepth == 8) {
     if (size == 4) LAUNCH(uint8_t, 4, 4, UVGHIP_SEARCH_BPL4, 4);

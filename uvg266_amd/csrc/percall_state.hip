@@ -24,8 +24,10 @@ int scaled_qp(const uvghip_state_view_t *sv, int color)
 [[noreturn]] void unsupported(const char *what)
 {
   // the strategy typedefs have no error channel: a configuration this backend does not implement must not
-  // produce a silently different result.  The shim's registrar refuses to register under such a configuration; reaching
-  // this means it was bypassed.
+  // produce a silently different result.  The shim's registrar has the reference's registrar signature (opaque, bitdepth) and
+  // cannot see the configuration, so it registers unconditionally; the integrator's duty is to ask
+  // uvg_hip_state_config_supported(cfg) before uvg_strategyselector_init and to leave these five strategy types to the generic
+  // backend (UVG_OVERRIDE_<type>=generic) when it says no.  Reaching this line means that check was skipped.
   fprintf(stderr, "uvg266hip: %s is not implemented by the hip backend (register the generic strategy for this configuration)\n", what);
   abort();
 }

@@ -1178,6 +1178,10 @@ extern "C" int uvghip_quantize_residual_batch(int bitdepth, const uvghip_qr_para
   if (!workspace || workspace_bytes < uvghip_quantize_residual_workspace_bytes(p, n))
     return uvghip_set_error(hipErrorInvalidValue, "uvghip_quantize_residual_batch: workspace");
   const bool rdoq = p->rdoq_enable && (width > 4 || !p->rdoq_skip) && !p->use_trskip;
+  // The quantiser's and dequantiser's transform-skip flag is NOT use_trskip: the reference passes
+  // cur_cu->tr_idx == MTS_SKIP && color == COLOR_Y (quant-generic.c:537-539, 558-559), so a chroma block coded with transform
+  // skip (cur_pu->tr_skip & (1 << color)) gets the identity transform but the ordinary quantiser shifts.
+  const int quant_ts = p->use_trskip && p->color == 0;
   hipStream_t st = uvghip_stream(stream);
   int16_t *coef = static_cast<int16_t *>(workspace);
   int16_t *deq = reinterpret_cast<int16_t *>(static_cast<char *>(workspace) + qr_coef_bytes(width, height, n));
@@ -1197,18 +1201,18 @@ extern "C" int uvghip_quantize_residual_batch(int bitdepth, const uvghip_qr_para
                                             workspace_bytes - 2 * qr_coef_bytes(width, height, n), has_coeffs, stream, p->signhide_enable))
       return rc;
   } else if (p->signhide_enable) {
-    if (int rc = uvghip_quant_signhide_batch(bitdepth, coef, coeff_out, width, height, n, p->qp_scaled, p->use_trskip, p->slice_is_intra,
+    if (int rc = uvghip_quant_signhide_batch(bitdepth, coef, coeff_out, width, height, n, p->qp_scaled, quant_ts, p->slice_is_intra,
                                              p->lfnst_idx, stream))
       return rc;
   } else {
     if (int rc = (p->lfnst_idx ? uvghip_quant_lfnst_batch : uvghip_quant_batch)(bitdepth, coef, coeff_out, width, height, n, p->qp_scaled,
-                                                                                  p->use_trskip, p->slice_is_intra, stream))
+                                                                                  quant_ts, p->slice_is_intra, stream))
       return rc;
   }
   if (!rdoq || p->signhide_enable) has_coeffs_kernel<<<(n + 3) / 4, 256, 0, st>>>(coeff_out, width * height, n, has_coeffs);
   // (4) dequantisation, inverse LFNST, inverse transform, reconstruction (:556-597; without coefficients the inverse of
   //     zeros is zero and rec = pred, the copy of :599-609)
-  if (int rc = uvghip_dequant_batch(bitdepth, coeff_out, deq, width, height, n, p->qp_scaled, p->use_trskip, stream)) return rc;
+  if (int rc = uvghip_dequant_batch(bitdepth, coeff_out, deq, width, height, n, p->qp_scaled, quant_ts, stream)) return rc;
   if (lfnst_tus)
     if (int rc = uvghip_lfnst_batch(1, deq, width, height, lfnst_tus, n, stream)) return rc;
   return uvghip_tu_inverse_batch(bitdepth, p->type_hor, p->type_ver, p->skip_width, p->skip_height, width, height, p->use_trskip,

@@ -1209,8 +1209,6 @@ static int rdoq_launch(int signhide, int bitdepth, const int16_t *coef, int16_t 
   }
 #define RDOQ_LAUNCH(SH, CH)                                                                                              \
   do {                                                                                                                   \
-    if (getenv("UVGHIP_DEBUG_OCC")) { for (size_t l2 = lds - 1024; l2 <= lds + 512; l2 += 256) { int nb = -1; hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rdoq_kernel<16, SH, CH, 0>, 64, l2); \
-      fprintf(stderr, "rdoq<%d,%d> dyn lds %zu: %d workgroups/CU (err %d)\n", SH, CH, l2, nb, (int)oe); } } \
     if (signhide) rdoq_kernel<16, SH, CH, 1><<<grid, 64, lds, st>>>(P, coef, q_coef, w, abs_sum_out, has_coeffs);        \
     else rdoq_kernel<16, SH, CH, 0><<<grid, 64, lds, st>>>(P, coef, q_coef, w, abs_sum_out, has_coeffs);                 \
   } while (0)
