@@ -1210,6 +1210,7 @@ extern "C" int uvghip_quantize_residual_batch(int bitdepth, const uvghip_qr_para
       return rc;
   }
   if (!rdoq || p->signhide_enable) has_coeffs_kernel<<<(n + 3) / 4, 256, 0, st>>>(coeff_out, width * height, n, has_coeffs);
+  { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return uvghip_set_error(e__, __func__); }
   // (4) dequantisation, inverse LFNST, inverse transform, reconstruction (:556-597; without coefficients the inverse of
   //     zeros is zero and rec = pred, the copy of :599-609)
   if (int rc = uvghip_dequant_batch(bitdepth, coeff_out, deq, width, height, n, p->qp_scaled, quant_ts, stream)) return rc;
@@ -1327,6 +1328,7 @@ extern "C" int uvghip_quant_cbcr_residual_batch(int bitdepth, const uvghip_qr_pa
   const unsigned grid = (unsigned)((total + 255) / 256);
   if (bitdepth == 8) jccr_residual_kernel<uint8_t><<<grid, 256, 0, st>>>((const uint8_t *)u_orig, (const uint8_t *)v_orig, orig_stride, (const uint8_t *)u_pred, (const uint8_t *)v_pred, pred_stride, tus, n, l2w, l2h, mask, res);
   else jccr_residual_kernel<uint16_t><<<grid, 256, 0, st>>>((const uint16_t *)u_orig, (const uint16_t *)v_orig, orig_stride, (const uint16_t *)u_pred, (const uint16_t *)v_pred, pred_stride, tus, n, l2w, l2h, mask, res);
+  { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return uvghip_set_error(e__, __func__); }
   { hipError_t e = hipGetLastError(); if (e != hipSuccess) return uvghip_set_error(e, __func__); }
   // uvg_transform2d (:305) -> [uvg_fwd_lfnst] -> uvg_rdoq | uvg_quant (:310-340) -> has_coeffs
   if (int rc = uvghip_transform_batch(bitdepth, 0, p->type_hor, p->type_ver, width, height, p->skip_width, p->skip_height, res, coef, n, stream)) return rc;
@@ -1347,6 +1349,7 @@ extern "C" int uvghip_quant_cbcr_residual_batch(int bitdepth, const uvghip_qr_pa
       return rc;
   }
   if (!rdoq || p->signhide_enable) has_coeffs_kernel<<<(n + 3) / 4, 256, 0, st>>>(coeff_out, width * height, n, has);
+  { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return uvghip_set_error(e__, __func__); }
   // uvg_dequant -> [uvg_inv_lfnst] -> uvg_itransform2d -> both reconstructions (:355-437)
   if (int rc = uvghip_dequant_batch(bitdepth, coeff_out, deq, width, height, n, p->qp_scaled, 0, stream)) return rc;
   if (lfnst_tus)
@@ -1354,6 +1357,7 @@ extern "C" int uvghip_quant_cbcr_residual_batch(int bitdepth, const uvghip_qr_pa
   if (int rc = uvghip_transform_batch(bitdepth, 1, p->type_hor, p->type_ver, width, height, p->skip_width, p->skip_height, deq, res, n, stream)) return rc;
   if (bitdepth == 8) jccr_recon_kernel<uint8_t><<<grid, 256, 0, st>>>(res, has, (const uint8_t *)u_pred, (const uint8_t *)v_pred, pred_stride, (uint8_t *)u_rec, (uint8_t *)v_rec, rec_stride, tus, n, l2w, l2h, mask, early_skip);
   else jccr_recon_kernel<uint16_t><<<grid, 256, 0, st>>>(res, has, (const uint16_t *)u_pred, (const uint16_t *)v_pred, pred_stride, (uint16_t *)u_rec, (uint16_t *)v_rec, rec_stride, tus, n, l2w, l2h, mask, early_skip);
+  { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return uvghip_set_error(e__, __func__); }
   jccr_ret_kernel<<<(n + 255) / 256, 256, 0, st>>>(has, n, joint_cb_cr, ret_out);
   UVGHIP_CHECK_LAUNCH();
 }

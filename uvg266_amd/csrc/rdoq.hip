@@ -1206,6 +1206,7 @@ static int rdoq_launch(int signhide, int bitdepth, const int16_t *coef, int16_t 
     const long long chunks = ((long long)n * wh + 1023) / 1024;
     if (chunks > 0x7fffffffLL) return uvghip_set_error(hipErrorInvalidValue, "uvghip_rdoq_batch: n");
     rdoq_pre_kernel<<<(int)chunks, 256, 0, st>>>(P, coef, ws_rice, ws_last);
+    { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return uvghip_set_error(e__, "uvghip_rdoq_batch: rdoq_pre_kernel"); }
   }
 #define RDOQ_LAUNCH(SH, CH)                                                                                              \
   do {                                                                                                                   \

@@ -461,8 +461,17 @@ class Graph:
                 for ev in joins:
                     capture_stream.wait_event(ev)
             run(launches, h)
-        finally:
-            rc = L.uvghip_graph_end(h, ctypes.byref(self.handle))
+        except BaseException:
+            # a launch failed mid-capture: pull every forked side stream back into the capture stream before ending the capture
+            # (an unjoined branch would make hipStreamEndCapture fail and hide the real error), drop whatever was captured
+            for st in (side_streams or []):
+                ev = torch.cuda.Event()
+                ev.record(st)
+                capture_stream.wait_event(ev)
+            L.uvghip_graph_end(h, ctypes.byref(self.handle))
+            self.destroy()
+            raise
+        rc = L.uvghip_graph_end(h, ctypes.byref(self.handle))
         _lib.check(rc, "uvghip_graph_end")
 
     def launch(self, stream_handle):
