@@ -1395,9 +1395,11 @@ uint32_t fast_coeff_cost_hip(const int16_t *coeff, int32_t width, int32_t height
 
 // quant / dequant / quantize_residual / quant_cbcr_residual take encoder_state_t*
 // (strategies-quant.h:48-86): they cannot be bound without the encoder's own
-// headers, so they are registered by the host-side shim of INTEGRATION.md,
-// which forwards to uvghip_quant_batch / uvghip_dequant_batch /
-// uvghip_tu_roundtrip_batch.  The two state-free functions register here.
+// headers, so they are registered by the host-side shim of INTEGRATION.md
+// (csrc/shim/strategies-hip-state.c), which extracts plain-value views and calls
+// the uvghip_*_percall entry points of csrc/percall_state.hip; those run
+// uvghip_quant_batch / uvghip_dequant_batch / uvghip_quantize_residual_batch /
+// uvghip_quant_cbcr_residual_batch on one block.  The two state-free functions register here.
 extern "C" int uvg_strategy_register_quant_hip(void *opaque, uint8_t bitdepth)
 {
   if (!uvghip_ready() && uvghip_init(0) != 0) return 0;
