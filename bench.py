@@ -378,6 +378,18 @@ def coeff_cost_probe(L, fr, reps=5):
                     "times over, once per block size), synthetic adapted context models; one lane per block"}
 
 
+def ctu_search_traffic(pictures):
+    """HBM bytes per launch of the search kernel from the committed PMC passes (profiles/hbm_traffic_latest.json) -- only if they were
+    taken on the kernel sources this run uses (a stale capture is not reported)."""
+    import hashlib
+    t = TRAFFIC.get("ctu_search")
+    if not isinstance(t, dict):
+        return None
+    here = os.path.dirname(os.path.abspath(__file__))
+    sha = hashlib.sha1(b"".join(open(os.path.join(here, "uvg266_amd", "csrc", f), "rb").read() for f in ("ctu_core.h", "ctu_search.hip"))).hexdigest()
+    return t["bytes_per_picture"] * pictures if t.get("source_sha1") == sha else None
+
+
 def ctu_search_bytes(W, H, depth):
     """Algorithmic bytes of one picture through uvghip_ctu_search_intra (SURVEY.md 8(d) style, b = bytes per sample): the source read
     once (1.5 W H b), the reconstruction written once (1.5 W H b), the levels written once (1.5 W H x 2), the side information
@@ -704,7 +716,7 @@ def main():
                                "bit for bit (tests/test_gpu_sao_decide.py against reference-run records at 1080p and 2160p)"},
             "roofline": {"bound": "hbm", "kernel": "ctu_search_kernel", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBS, 6),
-                         "traffic": (TRAFFIC["ctu_search"]["bytes_per_picture"] * F if isinstance(TRAFFIC.get("ctu_search"), dict) else None),
+                         "traffic": ctu_search_traffic(F),
                          "avg_launch_ms": round(launch_ms, 3), "alg_bytes_per_launch": byts, "launches_timed": launches, "launches_in_flight": n_groups,
                          "effective_gbs": round(byts * launches / elapsed / 1e9, 3),
                          "note": "the dominant kernel (> 99 % of the step) is the whole-CTU search: one workgroup walks one CTU's quad tree, "

@@ -51,11 +51,14 @@ json.dump(out, open(f"profiles/{tag}_bench_hbm_traffic.json", "w"), indent=1)
 latest = {}
 if os.path.exists("profiles/hbm_traffic_latest.json"):
     latest = json.load(open("profiles/hbm_traffic_latest.json"))
+import hashlib
+sha = hashlib.sha1(b"".join(open(os.path.join("uvg266_amd", "csrc", f), "rb").read() for f in ("ctu_core.h", "ctu_search.hip"))).hexdigest()
 ck = [k for k in traffic if k.startswith("ctu_search_kernel")]
 if ck:
     t = traffic[ck[0]]
     latest["ctu_search"] = {"bytes_per_launch": t["hbm_bytes_per_launch"], "pictures_per_launch": pics,
-                            "bytes_per_picture": round(t["hbm_bytes_per_launch"] / pics), "tag": tag}
+                            "bytes_per_picture": round(t["hbm_bytes_per_launch"] / pics), "tag": tag,
+                            "source_sha1": sha}          # of ctu_core.h + ctu_search.hip as profiled: bench.py refuses the number for other sources
 json.dump(latest, open("profiles/hbm_traffic_latest.json", "w"), indent=1)
 sq = per_kernel("prof3_sq", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"])
 json.dump({c: {k: {"per_launch": round(v[0]), "launches": v[1]} for k, v in d.items()} for c, d in sq.items()},
