@@ -859,6 +859,33 @@ UVGHIP_API void uvghip_ctu_plan_destroy(uvghip_ctu_plan_t *plan);
 UVGHIP_API int uvghip_ctu_search_intra(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures,
                                        int n_pictures, void *workspace, void *stream);
 
+/* ------------------- (5) the per-picture loop of the CTU worker as one call per group of pictures ---------------------- */
+
+/* replaces, for all-intra pictures: encoder_state_worker_encode_lcu_search for every CTU (src/encoderstate.c:808-976 minus the
+ * bitstream writer) and the frame's SAO reconstruction (:256-343) -- uvghip_ctu_plan_run, then per picture
+ * uvghip_deblock_frame_sao_snapshot on a copy of the reconstruction + uvghip_sao_stats_batch (Y, U, V), once
+ * uvghip_sao_decide_pictures, then per picture uvghip_deblock_frame (in place on rec) + uvghip_sao_apply_batch into out.
+ * A picture: the search's descriptor (outputs as described there; rec_* end up deblocked) + where the filtered picture goes --
+ * the picture uvg_encoder_encode returns in pic_out / the next picture's reference.  Everything on `stream`, nothing waits.
+ * sao_type: cfg.sao_type.  workspace: uvghip_loop_workspace_bytes of device memory, in use until the plan is destroyed.
+ * uvghip_loop_plan_results: device pointers to the decisions ([picture][ctu][34] int32, the reference's two sao_info_t) and the
+ * two SAO context models after every CTU's SAO syntax ([picture][ctu][6] uint16) -- what encode_sao codes. */
+typedef struct uvghip_loop_picture {
+  uvghip_ctu_picture_t search;
+  void *out_y, *out_u, *out_v;
+  int32_t out_stride, out_stride_c;     /* in samples */
+} uvghip_loop_picture_t;
+typedef struct uvghip_loop_plan uvghip_loop_plan_t;
+UVGHIP_API size_t uvghip_loop_workspace_bytes(int bitdepth, int n_pictures, int pic_w, int pic_h);
+UVGHIP_API int uvghip_loop_plan_create(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_loop_picture_t *pictures,
+                                       int n_pictures, int sao_type, void *workspace, uvghip_loop_plan_t **plan_out);
+UVGHIP_API int uvghip_loop_plan_run(uvghip_loop_plan_t *plan, void *stream);
+/* The two halves of uvghip_loop_plan_run on their own (a caller that wants events or other work between them). */
+UVGHIP_API int uvghip_loop_plan_run_search(uvghip_loop_plan_t *plan, void *stream);
+UVGHIP_API int uvghip_loop_plan_run_filters(uvghip_loop_plan_t *plan, void *stream);
+UVGHIP_API int uvghip_loop_plan_results(const uvghip_loop_plan_t *plan, const int32_t **sao_info, const uint16_t **sao_models);
+UVGHIP_API void uvghip_loop_plan_destroy(uvghip_loop_plan_t *plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,3 +75,31 @@ def test_search_then_filters_equal_the_encoder_run(hip, name):
     assert np.array_equal(H.sao_info_comparable(r["sao"]), H.sao_info_comparable(g["sao"]))
     assert np.array_equal(r["sao_models"], g["sao_models"])
     assert np.array_equal(H.filter_crcs(r, W, Hh), g["filter_crc"])
+
+
+def test_loop_plan_is_the_same_chain_in_one_call(hip):
+    """uvghip_loop_plan_run (search + filters strung together in C) on two pictures: the encoder's returned picture and its SAO
+    decisions for the golden one, and the same for a second picture as the step-by-step calls give."""
+    import torch
+    from uvg266_amd import api, layout
+    g = H.ctu_golden("ref_ctu_832x480_8_qp22")
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    prm = H.search_params(W, Hh, qp)
+    pics = [(y, u, v), layout.synthetic_yuv420(W, Hh, 7, depth)]
+    src = [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in yuv) for yuv in pics]
+    cl = api.ClosedLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), src)
+    cl.run()
+    info, models = cl.results()
+    out = [[t.cpu().numpy() for t in o] for o in cl.out]
+    for k, n in enumerate(("final_y", "final_u", "final_v")):
+        assert np.array_equal(out[0][k], g[n]), n
+    assert np.array_equal(H.sao_info_comparable(info[0]), H.sao_info_comparable(g["sao"])) and np.array_equal(models[0], g["sao_models"])
+    # second picture: search alone, then the filters step by step
+    cs = api.CtuSearch(api.ctu_params(W, Hh, qp, lam=prm.lam), [src[1]])
+    cs.run()
+    torch.cuda.synchronize()
+    scu = cs.cu[0].cpu().numpy().reshape(-1).view(H.SCU_NP).reshape(cs.cu[0].shape[0], -1)
+    r = filters_on_device(W, Hh, depth, qp, prm.lam, pics[1], [t.cpu().numpy() for t in cs.rec[0]], scu)
+    for k, n in enumerate(("final_y", "final_u", "final_v")):
+        assert np.array_equal(out[1][k], r[n]), n
+    assert np.array_equal(info[1], r["sao"]) and np.array_equal(models[1], r["sao_models"])

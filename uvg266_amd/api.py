@@ -610,3 +610,56 @@ class CtuSearch:
                 torch.cuda.synchronize()
             finally:
                 self.L.uvghip_ctu_plan_destroy(plan)
+
+
+class ClosedLoop(CtuSearch):
+    """uvghip_loop_plan_*: the search of CtuSearch followed by the in-loop filters on the reference's schedule, one call per
+    group of pictures.  Adds out[i] = (y, u, v), the pictures after deblocking + SAO, and after a run sao_info ([n, ctus, 2, 17]
+    int32) / sao_models ([n, ctus, 6] as int16 storage of uint16) as device tensors over the plan's own buffers."""
+
+    def __init__(self, params, src, sao_type=3):
+        import ctypes
+        super().__init__(params, src)
+        dev = src[0][0].device
+        self.out = [tuple(torch.empty_like(p) for p in s) for s in src]
+        W, H = params.pic_w, params.pic_h
+        self.loop_ws = torch.empty(self.L.uvghip_loop_workspace_bytes(self.depth, self.n, W, H), dtype=torch.uint8, device=dev)
+        lp = (_lib.LoopPicture * self.n)()
+        for i in range(self.n):
+            o = self.out[i]
+            lp[i] = _lib.LoopPicture(self.pics[i], _dev(o[0]), _dev(o[1]), _dev(o[2]), o[0].stride(0), o[1].stride(0))
+        self.loop_pics = lp
+        self.loop = ctypes.c_void_p()
+        _lib.check(self.L.uvghip_loop_plan_create(self.depth, ctypes.byref(self.P), lp, self.n, sao_type, _dev(self.loop_ws), ctypes.byref(self.loop)),
+                   "uvghip_loop_plan_create")
+
+    def run(self, stream=None):
+        """Enqueue search + filters of all n pictures (uvghip_loop_plan_run); returns at once."""
+        _lib.check(self.L.uvghip_loop_plan_run(self.loop, _stream() if stream is None else stream), "uvghip_loop_plan_run")
+
+    def run_search(self, stream=None):
+        _lib.check(self.L.uvghip_loop_plan_run_search(self.loop, _stream() if stream is None else stream), "uvghip_loop_plan_run_search")
+
+    def run_filters(self, stream=None):
+        _lib.check(self.L.uvghip_loop_plan_run_filters(self.loop, _stream() if stream is None else stream), "uvghip_loop_plan_run_filters")
+
+    def results(self):
+        """-> (sao_info [n, ctus, 2, 17] int32, sao_models [n, ctus, 6] uint16) copied to the host (synchronises)."""
+        import ctypes
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(self.L.uvghip_loop_plan_results(self.loop, ctypes.byref(a), ctypes.byref(b)), "uvghip_loop_plan_results")
+        torch.cuda.synchronize()
+        ctus = self.wc * self.hc
+        base = self.loop_ws.data_ptr()
+        info = self.loop_ws[a.value - base:a.value - base + self.n * ctus * 34 * 4].cpu().numpy().view(np.int32).reshape(self.n, ctus, 2, 17)
+        models = self.loop_ws[b.value - base:b.value - base + self.n * ctus * 6 * 2].cpu().numpy().view(np.uint16).reshape(self.n, ctus, 6)
+        return info, models
+
+    def __del__(self):
+        loop, self.loop = getattr(self, "loop", None), None
+        if loop:
+            try:
+                torch.cuda.synchronize()
+            finally:
+                self.L.uvghip_loop_plan_destroy(loop)
+        CtuSearch.__del__(self)

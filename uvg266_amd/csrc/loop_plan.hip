@@ -1,0 +1,172 @@
+// uvghip_loop_plan_*: one call per group of all-intra pictures for the whole per-picture loop of the encoder's CTU worker
+// (src/encoderstate.c:808-976 without the bitstream writer): the closed-loop CTU search, then the in-loop filters on the
+// reference's own schedule -- every CTU deblocked by its own edges only (what uvg_sao_search_lcu reads), SAO statistics, the
+// SAO decision of every CTU of every picture, deblocking of the reconstruction, SAO apply.  Host code only: a plan strings the
+// library's own entry points together on the caller's stream and owns the tables they need.
+#include "uvghip_common.h"
+#include <new>
+#include <vector>
+
+struct uvghip_loop_plan {
+  int bitdepth, n, w, h, qp, sao_type, ctus;
+  double lambda;
+  uvghip_ctu_plan_t *search;
+  std::vector<uvghip_loop_picture_t> pics;
+  // carved out of the caller's workspace
+  unsigned char *snap;                    // per picture: Y, U, V of the snapshot, tightly packed
+  uvghip_rect_t *rects_y, *rects_c;
+  int32_t *edge[3], *band[3];
+  void *decide_ws;
+  int32_t *sao_info;
+  uint16_t *sao_models;
+  uvghip_sao_param_t *params[3];
+  size_t snap_bytes;                      // of one picture
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct layout_t { size_t search, snap, rects_y, rects_c, edge[3], band[3], decide, info, models, params[3], total; };
+
+layout_t layout_of(int bitdepth, int n, int w, int h)
+{
+  const size_t ctus = (size_t)((w + 63) / 64) * ((h + 63) / 64), b = bitdepth == 8 ? 1 : 2;
+  layout_t L;
+  size_t at = 0;
+  auto take = [&](size_t bytes) { const size_t o = at; at = align_up(at + bytes, 256); return o; };
+  L.search = take(uvghip_ctu_search_workspace_bytes(n, w, h));
+  L.snap = take((size_t)n * ((size_t)w * h * 3 / 2) * b);
+  L.rects_y = take(ctus * sizeof(uvghip_rect_t));
+  L.rects_c = take(ctus * sizeof(uvghip_rect_t));
+  for (int c = 0; c < 3; ++c) { L.edge[c] = take((size_t)n * ctus * 40 * 4); L.band[c] = take((size_t)n * ctus * 64 * 4); }
+  L.decide = take(uvghip_sao_decide_workspace_bytes(n, w, h));
+  L.info = take((size_t)n * ctus * 34 * 4);
+  L.models = take((size_t)n * ctus * 6 * 2);
+  for (int c = 0; c < 3; ++c) L.params[c] = take((size_t)n * ctus * sizeof(uvghip_sao_param_t));
+  L.total = at;
+  return L;
+}
+
+}  // namespace
+
+extern "C" size_t uvghip_loop_workspace_bytes(int bitdepth, int n_pictures, int pic_w, int pic_h)
+{
+  if ((bitdepth != 8 && bitdepth != 10) || n_pictures <= 0 || pic_w <= 0 || pic_h <= 0) return 0;
+  return layout_of(bitdepth, n_pictures, pic_w, pic_h).total;
+}
+
+extern "C" int uvghip_loop_plan_create(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_loop_picture_t *pictures, int n_pictures,
+                                       int sao_type, void *workspace, uvghip_loop_plan_t **plan_out)
+{
+  UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
+  if (!params || !pictures || n_pictures <= 0 || !workspace || !plan_out || sao_type < 1 || sao_type > 3)
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const int w = params->pic_w, h = params->pic_h;
+  std::vector<uvghip_ctu_picture_t> sp(n_pictures);
+  for (int i = 0; i < n_pictures; ++i) {
+    if (!pictures[i].out_y || !pictures[i].out_u || !pictures[i].out_v) return uvghip_set_error(hipErrorInvalidValue, "uvghip_loop_plan_create: output planes");
+    sp[i] = pictures[i].search;
+  }
+  const layout_t L = layout_of(bitdepth, n_pictures, w, h);
+  unsigned char *ws = static_cast<unsigned char *>(workspace);
+  uvghip_loop_plan *pl = new (std::nothrow) uvghip_loop_plan;
+  if (!pl) return uvghip_set_error(hipErrorOutOfMemory, __func__);
+  pl->search = nullptr;
+  if (int rc = uvghip_ctu_plan_create(bitdepth, params, sp.data(), n_pictures, ws + L.search, &pl->search)) { delete pl; return rc; }
+  const int wc = (w + 63) / 64, hc = (h + 63) / 64;
+  pl->bitdepth = bitdepth; pl->n = n_pictures; pl->w = w; pl->h = h; pl->qp = params->qp; pl->lambda = params->lambda; pl->sao_type = sao_type;
+  pl->ctus = wc * hc;
+  pl->pics.assign(pictures, pictures + n_pictures);
+  pl->snap = ws + L.snap;
+  pl->snap_bytes = (size_t)w * h * 3 / 2 * (bitdepth == 8 ? 1 : 2);
+  pl->rects_y = reinterpret_cast<uvghip_rect_t *>(ws + L.rects_y);
+  pl->rects_c = reinterpret_cast<uvghip_rect_t *>(ws + L.rects_c);
+  for (int c = 0; c < 3; ++c) {
+    pl->edge[c] = reinterpret_cast<int32_t *>(ws + L.edge[c]); pl->band[c] = reinterpret_cast<int32_t *>(ws + L.band[c]);
+    pl->params[c] = reinterpret_cast<uvghip_sao_param_t *>(ws + L.params[c]);
+  }
+  pl->decide_ws = ws + L.decide;
+  pl->sao_info = reinterpret_cast<int32_t *>(ws + L.info);
+  pl->sao_models = reinterpret_cast<uint16_t *>(ws + L.models);
+  // the CTU grids clipped to the picture: the rectangles sao_search_luma / _chroma hand to the decision (sao.c:605-668)
+  std::vector<uvghip_rect_t> ry(pl->ctus), rc(pl->ctus);
+  for (int cy = 0; cy < hc; ++cy)
+    for (int cx = 0; cx < wc; ++cx) {
+      const int x = cx * 64, y = cy * 64, bw = x + 64 > w ? w - x : 64, bh = y + 64 > h ? h - y : 64;
+      ry[cy * wc + cx] = uvghip_rect_t{x, y, bw, bh};
+      rc[cy * wc + cx] = uvghip_rect_t{x / 2, y / 2, bw / 2, bh / 2};
+    }
+  hipError_t e = hipMemcpy(pl->rects_y, ry.data(), ry.size() * sizeof(uvghip_rect_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(pl->rects_c, rc.data(), rc.size() * sizeof(uvghip_rect_t), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { uvghip_ctu_plan_destroy(pl->search); delete pl; return uvghip_set_error(e, "uvghip_loop_plan_create: rectangle tables"); }
+  *plan_out = pl;
+  return 0;
+}
+
+extern "C" int uvghip_loop_plan_run_filters(uvghip_loop_plan_t *pl, void *stream);
+extern "C" int uvghip_loop_plan_run(uvghip_loop_plan_t *pl, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (int rc = uvghip_ctu_plan_run(pl->search, stream)) return rc;
+  return uvghip_loop_plan_run_filters(pl, stream);
+}
+
+extern "C" int uvghip_loop_plan_run_search(uvghip_loop_plan_t *pl, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  return uvghip_ctu_plan_run(pl->search, stream);
+}
+
+extern "C" int uvghip_loop_plan_run_filters(uvghip_loop_plan_t *pl, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  hipStream_t st = uvghip_stream(stream);
+  const size_t b = pl->bitdepth == 8 ? 1 : 2;
+  const int w = pl->w, h = pl->h, cw = w / 2, ch = h / 2;
+  for (int i = 0; i < pl->n; ++i) {
+    const uvghip_ctu_picture_t &p = pl->pics[i].search;
+    unsigned char *sy = pl->snap + (size_t)i * pl->snap_bytes, *su = sy + (size_t)w * h * b, *sv = su + (size_t)cw * ch * b;
+    UVGHIP_TRY(hipMemcpy2DAsync(sy, (size_t)w * b, p.rec_y, (size_t)p.rec_stride * b, (size_t)w * b, h, hipMemcpyDeviceToDevice, st));
+    UVGHIP_TRY(hipMemcpy2DAsync(su, (size_t)cw * b, p.rec_u, (size_t)p.rec_stride_c * b, (size_t)cw * b, ch, hipMemcpyDeviceToDevice, st));
+    UVGHIP_TRY(hipMemcpy2DAsync(sv, (size_t)cw * b, p.rec_v, (size_t)p.rec_stride_c * b, (size_t)cw * b, ch, hipMemcpyDeviceToDevice, st));
+    if (int rc = uvghip_deblock_frame_sao_snapshot(pl->bitdepth, sy, w, su, sv, cw, w, h, p.cu, p.cu_stride, 0, 0, 0, pl->qp, nullptr, stream)) return rc;
+    const size_t o = (size_t)i * pl->ctus;
+    if (int rc = uvghip_sao_stats_batch(pl->bitdepth, p.src_y, p.src_stride, sy, w, pl->rects_y, pl->ctus, pl->edge[0] + o * 40, pl->band[0] + o * 64, stream)) return rc;
+    if (int rc = uvghip_sao_stats_batch(pl->bitdepth, p.src_u, p.src_stride_c, su, cw, pl->rects_c, pl->ctus, pl->edge[1] + o * 40, pl->band[1] + o * 64, stream)) return rc;
+    if (int rc = uvghip_sao_stats_batch(pl->bitdepth, p.src_v, p.src_stride_c, sv, cw, pl->rects_c, pl->ctus, pl->edge[2] + o * 40, pl->band[2] + o * 64, stream)) return rc;
+  }
+  if (int rc = uvghip_sao_decide_pictures(pl->bitdepth, pl->n, w, h, pl->qp, pl->lambda, pl->sao_type, pl->edge[0], pl->band[0], pl->edge[1], pl->band[1],
+                                          pl->edge[2], pl->band[2], pl->decide_ws, pl->sao_info, pl->sao_models, pl->params[0], pl->params[1],
+                                          pl->params[2], stream))
+    return rc;
+  for (int i = 0; i < pl->n; ++i) {
+    const uvghip_loop_picture_t &q = pl->pics[i];
+    const uvghip_ctu_picture_t &p = q.search;
+    if (int rc = uvghip_deblock_frame(pl->bitdepth, p.rec_y, p.rec_stride, p.rec_u, p.rec_v, p.rec_stride_c, w, h, p.cu, p.cu_stride, 0, 0, 0, pl->qp, nullptr, stream)) return rc;
+    const size_t o = (size_t)i * pl->ctus;
+    if (int rc = uvghip_sao_apply_batch(pl->bitdepth, p.rec_y, p.rec_stride, q.out_y, q.out_stride, w, h, pl->rects_y, pl->params[0] + o, pl->ctus, stream)) return rc;
+    if (int rc = uvghip_sao_apply_batch(pl->bitdepth, p.rec_u, p.rec_stride_c, q.out_u, q.out_stride_c, cw, ch, pl->rects_c, pl->params[1] + o, pl->ctus, stream)) return rc;
+    if (int rc = uvghip_sao_apply_batch(pl->bitdepth, p.rec_v, p.rec_stride_c, q.out_v, q.out_stride_c, cw, ch, pl->rects_c, pl->params[2] + o, pl->ctus, stream)) return rc;
+  }
+  return 0;
+}
+
+extern "C" int uvghip_loop_plan_results(const uvghip_loop_plan_t *pl, const int32_t **sao_info, const uint16_t **sao_models)
+{
+  if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (sao_info) *sao_info = pl->sao_info;
+  if (sao_models) *sao_models = pl->sao_models;
+  return 0;
+}
+
+extern "C" void uvghip_loop_plan_destroy(uvghip_loop_plan_t *pl)
+{
+  if (!pl) return;
+  uvghip_ctu_plan_destroy(pl->search);
+  delete pl;
+}

@@ -72,6 +72,12 @@ class CtuPicture(ctypes.Structure):
                 ("reserved", ctypes.c_int32), ("coeff", ctypes.c_void_p), ("models", ctypes.c_void_p)]
 
 
+class LoopPicture(ctypes.Structure):
+    """uvghip_loop_picture_t."""
+    _fields_ = [("search", CtuPicture), ("out_y", ctypes.c_void_p), ("out_u", ctypes.c_void_p), ("out_v", ctypes.c_void_p),
+                ("out_stride", ctypes.c_int32), ("out_stride_c", ctypes.c_int32)]
+
+
 _lib = None
 _inited_device = None
 
@@ -156,6 +162,13 @@ SIGNATURES = {
     "uvghip_ctu_plan_create": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
     "uvghip_ctu_plan_run": (c_int, [c_vp, c_vp]),
     "uvghip_ctu_plan_destroy": (None, [c_vp]),
+    "uvghip_loop_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
+    "uvghip_loop_plan_create": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    "uvghip_loop_plan_run": (c_int, [c_vp, c_vp]),
+    "uvghip_loop_plan_run_search": (c_int, [c_vp, c_vp]),
+    "uvghip_loop_plan_run_filters": (c_int, [c_vp, c_vp]),
+    "uvghip_loop_plan_results": (c_int, [c_vp, c_vp, c_vp]),
+    "uvghip_loop_plan_destroy": (None, [c_vp]),
     "uvghip_comm_unique_id": (c_int, [c_vp]),
     "uvghip_comm_create": (c_int, [c_vp, c_int, c_int, c_vp]),
     "uvghip_comm_destroy": (c_int, [c_vp]),
