@@ -43,10 +43,33 @@ ORC_EXPORT void ORC_FN(f_entropy_table)(float *out512)
 }
 
 /* CABAC_FBITS_UPDATE with only_count = 1, update = 1 */
+/* Count mode of the arithmetic coder (uvg_cabac_encode_bin, cabac.c:76-109): when switched on, every context-coded bin also
+ * moves the coder's range and counts the renormalisation shifts it causes -- the bits the real coder consumes for it.  Bypass
+ * bins cost one bit each whatever the range is, so a walk's exact size is shifts + (its bit estimate - regular_fbits).
+ * Shared with orc_search.c (the bins of the coding tree outside the coefficients). */
+orc_cabac_sim ORC_FN(cabac_sim) = {0, 510, 0, 0.0};
+void ORC_FN(cabac_sim_bin)(int state, int bin)
+{
+  static const uint8_t renorm[32] = {6, 5, 4, 4, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};   /* uvg_g_auc_renorm_table */
+  orc_cabac_sim *c = &ORC_FN(cabac_sim);
+  const uint32_t q = (state & 0x80) ? (uint32_t)(state ^ 0xff) : (uint32_t)state;
+  const uint32_t lps = (uint8_t)((((q >> 2) * (c->range >> 5)) >> 1) + 4);        /* CTX_LPS (cabac.h:182) */
+  c->range -= lps;
+  if ((bin ? 1 : 0) != (state >> 7)) {                                               /* CTX_MPS */
+    const int nb = renorm[lps >> 3];
+    c->range = lps << nb;
+    c->shifts += (uint64_t)nb;
+  } else if (c->range < 256) {
+    c->range <<= 1;
+    c->shifts += 1;
+  }
+}
+
 static void code_bin(orc_cabac_models *m, int ctx, int bin, double *bits)
 {
   const int st = (m->state0[ctx] + m->state1[ctx]) >> 8;                         /* CTX_STATE */
   *bits += f_entropy_bits(st, bin);
+  if (ORC_FN(cabac_sim).on) { ORC_FN(cabac_sim).regular_fbits += f_entropy_bits(st, bin); ORC_FN(cabac_sim_bin)(st, bin); }
   const int rate0 = m->rate[ctx] >> 4, rate1 = m->rate[ctx] & 15;                /* CTX_UPDATE */
   const unsigned mask0 = (~(~0u << 10)) << 5, mask1 = (~(~0u << 14)) << 1;       /* CTX_MASK_0, CTX_MASK_1 */
   m->state0[ctx] = (uint16_t)(m->state0[ctx] - ((m->state0[ctx] >> rate0) & mask0));

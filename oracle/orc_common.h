@@ -48,4 +48,7 @@ static inline orc_px orc_clip_px(int v) { return (orc_px)orc_clip3(0, ORC_PX_MAX
 static inline int orc_iabs(int v) { return v < 0 ? -v : v; }
 static inline int orc_log2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
+/* count mode of the arithmetic coder (orc_coeff_cost.c): range, renormalisation shifts and the estimate share of the regular bins */
+typedef struct orc_cabac_sim { int on; uint32_t range; uint64_t shifts; double regular_fbits; } orc_cabac_sim;
+
 #endif

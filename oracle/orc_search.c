@@ -128,9 +128,12 @@ static void ctx_update(orc_models *m, int c, int bin)           /* CTX_UPDATE, c
   }
 }
 /* CABAC_FBITS_UPDATE with only_count = 1 */
+extern orc_cabac_sim ORC_FN(cabac_sim);
+void ORC_FN(cabac_sim_bin)(int state, int bin);
 static void fbits_update(s_cabac *cb, int c, int bin, double *bits)
 {
   *bits += ctx_fbits(&cb->m, c, bin);
+  if (ORC_FN(cabac_sim).on) { ORC_FN(cabac_sim).regular_fbits += ctx_fbits(&cb->m, c, bin); ORC_FN(cabac_sim_bin)(ctx_state(&cb->m, c), bin); }
   if (cb->update) ctx_update(&cb->m, c, bin);
 }
 
@@ -1077,16 +1080,16 @@ typedef struct s_frame {
 } s_frame;
 static const s_cu *cua_at(const s_frame *f, int x, int y) { return &f->cua[(y >> 2) * f->cu_stride + (x >> 2)]; }
 
+static double g_tree_bits;        /* the bit estimate of everything encode_coding_tree codes (count mode: bypass bins = this - the regular share) */
 static void code_coeffs(s_cabac *cb, const int16_t *plane, int stride, int lx, int ly, int w, int h, int color)
 {
-  coeff_cost_cu(cb, plane, stride, lx, ly, w, h, color);
+  g_tree_bits += coeff_cost_cu(cb, plane, stride, lx, ly, w, h, color);
 }
 
 static void encode_transform_coeff(const s_frame *f, s_cabac *cb, const s_loc *loc, int only_chroma, const int16_t *cy, const int16_t *cu, const int16_t *cv,
                                    int *luma_cbf_ctx, const s_loc *chroma_loc)
 {
   const s_cu *cur_tu = cua_at(f, loc->x, loc->y);
-  double dummy = 0;
   if (loc->w > 32 || loc->h > 32) {
     const int hw = loc->w >> 1, hh = loc->h >> 1;
     for (int i = 0; i < 4; ++i) {
@@ -1098,11 +1101,11 @@ static void encode_transform_coeff(const s_frame *f, s_cabac *cb, const s_loc *l
   }
   const int cb_flag_y = cur_tu->cbf & 1, cb_flag_u = (cur_tu->cbf >> 1) & 1, cb_flag_v = (cur_tu->cbf >> 2) & 1;
   if (chroma_loc || only_chroma) {
-    fbits_update(cb, M_CBF_CB + 0, cb_flag_u, &dummy);
-    fbits_update(cb, M_CBF_CR + (cb_flag_u ? 1 : 0), cb_flag_v, &dummy);
+    fbits_update(cb, M_CBF_CB + 0, cb_flag_u, &g_tree_bits);
+    fbits_update(cb, M_CBF_CR + (cb_flag_u ? 1 : 0), cb_flag_v, &g_tree_bits);
   }
   if (!only_chroma) {
-    fbits_update(cb, M_CBF_LUMA + *luma_cbf_ctx, cb_flag_y, &dummy);
+    fbits_update(cb, M_CBF_LUMA + *luma_cbf_ctx, cb_flag_y, &g_tree_bits);
     if (cur_tu->log2_w <= 5 && cur_tu->log2_h <= 5) *luma_cbf_ctx = 2 + cb_flag_y;      /* PU_IS_TU */
   }
   if (cb_flag_y | cb_flag_u | cb_flag_v) {
@@ -1127,12 +1130,11 @@ static void encode_coding_tree(const s_frame *f, s_state *st, s_cabac *cb, const
   const s_cu *left_cu = x > 0 ? cua_at(f, x - 1, y) : NULL, *above_cu = y > 0 ? cua_at(f, x, y - 1) : NULL;
   const int depth = tree.depth;
   const int mode_type_curr = (int)((cur_cu->mode_type_tree >> (depth * 2)) & 3);
-  double dummy = 0;
   if (loc->w + loc->h > 8) {
     tree.split_tree = cur_cu->split_tree;
     tree.mode_type_tree = cur_cu->mode_type_tree;
     int is_implicit;
-    write_split_flag(st, cb, left_cu, above_cu, loc, tree, &is_implicit, &dummy);
+    write_split_flag(st, cb, left_cu, above_cu, loc, tree, &is_implicit, &g_tree_bits);
     const int split_flag = (int)((tree.split_tree >> (depth * 3)) & 7);
     if (split_flag != NO_SPLIT) {
       s_tree nt = {cur_cu->split_tree, cur_cu->mode_type_tree, depth + 1, tree.mtt_depth, tree.implicit_mtt_depth, 0};
@@ -1154,16 +1156,16 @@ static void encode_coding_tree(const s_frame *f, s_state *st, s_cabac *cb, const
     const s_cu *left_pu = NULL, *above_pu = NULL;
     if (x > 0) left_pu = cua_at(f, x - 1, y + loc->h - 1);
     if (y % LCU > 0 && y > 0) above_pu = cua_at(f, x + loc->w - 1, y - 1);
-    encode_intra_luma(cb, cur_cu->mode, loc, left_pu, above_pu, &dummy);
+    encode_intra_luma(cb, cur_cu->mode, loc, left_pu, above_pu, &g_tree_bits);
   }
   const int is_local_dual_tree = chroma_loc->w != loc->w || chroma_loc->h != loc->h;
-  if (!is_local_dual_tree) encode_chroma_intra(cb, cur_cu->mode_chroma, cur_cu->mode, &dummy);
+  if (!is_local_dual_tree) encode_chroma_intra(cb, cur_cu->mode_chroma, cur_cu->mode, &g_tree_bits);
   int luma_cbf_ctx = 0;
   encode_transform_coeff(f, cb, loc, 0, cy, cu, cv, &luma_cbf_ctx, is_local_dual_tree ? NULL : chroma_loc);
   if (is_local_dual_tree && has_chroma) {
     /* uvg_get_co_located_luma_mode on the cu array: the centre of the chroma area */
     const int luma_dir = cua_at(f, chroma_loc->x + (chroma_loc->w >> 1), chroma_loc->y + (chroma_loc->h >> 1))->mode;
-    encode_chroma_intra(cb, cur_cu->mode_chroma, luma_dir, &dummy);
+    encode_chroma_intra(cb, cur_cu->mode_chroma, luma_dir, &g_tree_bits);
     encode_transform_coeff(f, cb, chroma_loc, 1, cy, cu, cv, &luma_cbf_ctx, chroma_loc);
   }
 }
@@ -1261,5 +1263,50 @@ ORC_EXPORT int ORC_FN(search_intra_picture)(const orc_search_params *p, const or
       memcpy(o + 12, &c->split_tree, 4); memcpy(o + 16, &c->mode_type_tree, 4);
     }
   free(f.cua); free(row_start); free(lcu); free(st);
+  return 0;
+}
+
+
+/*
+ * The hand-over consumer: what a bitstream coder does with the search's outputs, in count mode.  cu: the compact side information
+ * written above (20 bytes per 4x4: the cu_info_t fields uvg_encode_coding_tree reads + the two trees), coeff: lcu_coeff_t per
+ * CTU, start[ctu]: the coder's models when the CTU's coding tree begins, range_in[ctu]: the arithmetic coder's range at that
+ * point.  Walks uvg_encode_coding_tree (encode_coding_tree.c:1365-1727) for every CTU with the arithmetic coder's range
+ * arithmetic (uvg_cabac_encode_bin, cabac.c:76-109) and returns per CTU the bits the coder consumes for the tree
+ * (renormalisation shifts of the context-coded bins + one per bypass bin), its range afterwards and the models afterwards.
+ */
+ORC_EXPORT int ORC_FN(count_picture_bits)(const orc_search_params *p, const uint8_t *cu, const int16_t *coeff, const orc_models *start,
+                                          const int64_t *range_in, int64_t *bits_out, int64_t *range_out, orc_models *after)
+{
+  fbits_init();
+  const int W = p->pic_w, H = p->pic_h, wc = (W + 63) / 64, hc = (H + 63) / 64, cu_stride = wc * 16;
+  s_frame f = {p, (s_cu *)calloc((size_t)cu_stride * hc * 16, sizeof(s_cu)), cu_stride};
+  for (int j = 0; j < hc * 16; ++j)
+    for (int i = 0; i < cu_stride; ++i) {
+      s_cu *c = &f.cua[j * cu_stride + i];
+      const uint8_t *o = &cu[((size_t)j * cu_stride + i) * 20];
+      c->type = o[0]; c->log2_w = o[1]; c->log2_h = o[2]; c->log2_cw = o[3]; c->log2_ch = o[4]; c->cbf = o[5]; c->mode = (int8_t)o[6];
+      c->mode_chroma = (int8_t)o[7]; c->luma_deblocking = o[8]; c->chroma_deblocking = o[9]; c->qp = o[10];
+      memcpy(&c->split_tree, o + 12, 4); memcpy(&c->mode_type_tree, o + 16, 4);
+    }
+  s_state *st = (s_state *)calloc(1, sizeof(s_state));
+  st->p = p;
+  for (int k = 0; k < wc * hc; ++k) {
+    const int16_t *co = &coeff[(size_t)k * 6144];
+    s_cabac cb;
+    cb.m = start[k]; cb.update = 1;
+    orc_cabac_sim *sim = &ORC_FN(cabac_sim);
+    sim->on = 1; sim->range = (uint32_t)range_in[k]; sim->shifts = 0; sim->regular_fbits = 0.0;
+    g_tree_bits = 0.0;
+    s_loc start_loc;
+    loc_ctor(&start_loc, (k % wc) * 64, (k / wc) * 64, 64, 64);
+    s_tree tree = {0, MODE_TYPE_ALL, 0, 0, 0, 0};
+    encode_coding_tree(&f, st, &cb, co, co + 4096, co + 4096 + 1024, &start_loc, &start_loc, tree, 1);
+    sim->on = 0;
+    bits_out[k] = (int64_t)sim->shifts + (int64_t)floor(g_tree_bits - sim->regular_fbits + 0.5);
+    range_out[k] = sim->range;
+    after[k] = cb.m;
+  }
+  free(f.cua); free(st);
   return 0;
 }

@@ -466,6 +466,26 @@ def sao_info_comparable(info):
     return a
 
 
+def oracle_count_bits(orc, depth, prm, res, range_in):
+    """The hand-over consumer (orcN_count_picture_bits): a count-mode walk of uvg_encode_coding_tree over a search result in the
+    layout of oracle_search_picture / search_result_from_device_layout -- cu fields + trees, levels, the models every CTU starts
+    from -- with the arithmetic coder's range arithmetic.  range_in: the coder's range at every CTU's start.
+    -> (bits [ctus], range afterwards [ctus], models afterwards [ctus, 1286])"""
+    W, H = prm.pic_w, prm.pic_h
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    cu = np.zeros((hc * 16, wc * 16, 20), np.uint8)
+    cu[:, :, :11] = res["cu"]
+    cu[:, :, 12:] = np.ascontiguousarray(res["trees"].astype(np.uint32)).view(np.uint8).reshape(hc * 16, wc * 16, 8)
+    co = np.ascontiguousarray(res["coeff"], np.int16)
+    start = np.ascontiguousarray(res["models"][:, 0])
+    rin = np.ascontiguousarray(range_in, np.int64)
+    bits, rout = np.zeros(wc * hc, np.int64), np.zeros(wc * hc, np.int64)
+    after = np.zeros((wc * hc, MODELS_BYTES), np.uint8)
+    rc = orc.fn(depth, "count_picture_bits")(ctypes.byref(prm), ptr(cu), ptr(co), ptr(start), ptr(rin), ptr(bits), ptr(rout), ptr(after))
+    assert rc == 0
+    return bits, rout, after
+
+
 def filter_crcs(res, W, H):
     """Per CTU CRC-32 of (the block the SAO decision saw, the block of the final picture), Y + U + V, as
     tools/refcheck/make_ctu_goldens.py computes them (filter_crc)."""

@@ -1,0 +1,51 @@
+"""The hand-over to the bitstream coder (first slice).  What the search returns per CTU -- the reference's
+lcu_coeff_t levels and the cu_info_t fields uvg_encode_coding_tree reads (src/encoderstate.c:863-976) -- is fed to a count-mode
+coder (orcN_count_picture_bits: the coding tree's bins in the reference's order through the arithmetic coder's range arithmetic)
+and must give, CTU by CTU, the number of bits the real encoder's arithmetic coder consumed for that CTU's coding tree, its range
+afterwards and its models afterwards (tests/golden/ref_ctu*.npz: coder, models[:, 2]; tools/refcheck/ctu_dump.c)."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+
+@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37"])
+def test_golden_handover_counts_the_encoders_bits(orc, name):
+    """The consumer itself, on the encoder's own hand-over (the golden's cu fields, trees, levels, start models)."""
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    res = dict(cu=g["cu"], trees=g["trees"], coeff=g["coeff"], models=g["models"])
+    bits, rng, after = H.oracle_count_bits(orc, depth, H.search_params(W, Hh, qp), res, g["coder"][:, 1])
+    assert np.array_equal(bits, g["coder"][:, 0])
+    assert np.array_equal(rng, g["coder"][:, 2])
+    assert np.array_equal(after, g["models"][:, 2])
+    assert bits.sum() < 8 * len(g["bitstream"])       # (the rest of the stream: parameter sets, slice header, SAO syntax, row ends)
+
+
+@pytest.mark.parametrize("name", ["ref_ctucrc_1920x1080_8_qp22"])
+def test_oracle_search_handover_counts_the_encoders_bits(orc, name):
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    prm = H.search_params(W, Hh, qp)
+    s = H.oracle_search_picture(orc, depth, prm, y, u, v)
+    bits, rng, _ = H.oracle_count_bits(orc, depth, prm, s, g["coder"][:, 1])
+    assert np.array_equal(bits, g["coder"][:, 0]) and np.array_equal(rng, g["coder"][:, 2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctucrc_1920x1080_8_qp22", "ref_ctucrc_1920x1080_10_qp27", "ref_ctucrc_3840x2160_10_qp22"])
+def test_device_handover_counts_the_encoders_bits(hip, orc, name):
+    """From the device's outputs: uvghip_scu_t table + levels + start models of uvghip_ctu_plan_run -> the count-mode coder."""
+    import torch
+    from uvg266_amd import api
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    prm = H.search_params(W, Hh, qp)
+    cs = api.CtuSearch(api.ctu_params(W, Hh, qp, lam=prm.lam), [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in (y, u, v))])
+    cs.run()
+    torch.cuda.synchronize()
+    ry, ru, rv = (t.cpu().numpy() for t in cs.rec[0])
+    scu = cs.cu[0].cpu().numpy().reshape(-1).view(H.SCU_NP)
+    res = H.search_result_from_device_layout(W, Hh, ry, ru, rv, scu, cs.coeff[0].cpu().numpy(), cs.models[0].cpu().numpy().view(np.uint32))
+    bits, rng, _ = H.oracle_count_bits(orc, depth, prm, res, g["coder"][:, 1])
+    assert np.array_equal(bits, g["coder"][:, 0]) and np.array_equal(rng, g["coder"][:, 2])

@@ -119,6 +119,16 @@ void __wrap_uvg_search_lcu(encoder_state_t *const state, const int x, const int 
   }
 }
 
+/* payload bytes the arithmetic coder hands to the bitstream (uvg_bitstream_put_byte, called from uvg_cabac_write): counted
+ * here rather than with uvg_bitstream_tell, which also sees the emulation-prevention bytes the bitstream layer inserts */
+static int64_t g_cabac_bytes;
+void __real_uvg_bitstream_put_byte(bitstream_t *const stream, const uint32_t data);
+void __wrap_uvg_bitstream_put_byte(bitstream_t *const stream, const uint32_t data)
+{
+  ++g_cabac_bytes;
+  __real_uvg_bitstream_put_byte(stream, data);
+}
+
 void __real_uvg_encode_coding_tree(encoder_state_t *const state, lcu_coeff_t *coeff, enum uvg_tree_type tree_type, const cu_loc_t *const cu_loc,
                                    const cu_loc_t *const chroma_loc, split_tree_t split_tree, bool has_chroma);
 void __wrap_uvg_encode_coding_tree(encoder_state_t *const state, lcu_coeff_t *coeff, enum uvg_tree_type tree_type, const cu_loc_t *const cu_loc,
@@ -126,15 +136,23 @@ void __wrap_uvg_encode_coding_tree(encoder_state_t *const state, lcu_coeff_t *co
 {
   models_t before, after;
   snapshot(&state->cabac, &before);
+  /* bits the arithmetic coder has consumed so far (every renormalisation shift and every bypass bin takes one from bits_left,
+   * uvg_cabac_write gives eight back per byte it moves on) and its range: the hand-over test counts the same bins */
+  int64_t coder[4];
+  coder[0] = 8 * g_cabac_bytes + 8 * (int64_t)state->cabac.num_buffered_bytes + 23 - state->cabac.bits_left;
+  coder[1] = state->cabac.range;
   __real_uvg_encode_coding_tree(state, coeff, tree_type, cu_loc, chroma_loc, split_tree, has_chroma);
+  coder[2] = 8 * g_cabac_bytes + 8 * (int64_t)state->cabac.num_buffered_bytes + 23 - state->cabac.bits_left;
+  coder[3] = state->cabac.range;
   snapshot(&state->cabac, &after);
   int32_t meta[3] = {(int32_t)state->frame->num, cu_loc->x, cu_loc->y};
   uint16_t m_sao[6];
   m_sao[0] = state->cabac.ctx.sao_merge_flag_model.state[0]; m_sao[1] = state->cabac.ctx.sao_merge_flag_model.state[1]; m_sao[2] = state->cabac.ctx.sao_merge_flag_model.rate;
   m_sao[3] = state->cabac.ctx.sao_type_idx_model.state[0]; m_sao[4] = state->cabac.ctx.sao_type_idx_model.state[1]; m_sao[5] = state->cabac.ctx.sao_type_idx_model.rate;
-  rec_begin("coded", 4);
+  rec_begin("coded", 5);
   rec_arr(A_I32, meta, 3); rec_arr(A_U8, &before, sizeof before); rec_arr(A_U8, &after, sizeof after);
   rec_arr(A_U16, m_sao, 6);        /* the two SAO models after this CTU's SAO syntax (encode_sao precedes the coding tree) */
+  rec_arr(A_I64, coder, 4);
 }
 
 /* uvg_sao_search_lcu (src/sao.c:670, called at src/encoderstate.c:849 right after the CTU's own uvg_filter_deblock_lcu): the CTU's

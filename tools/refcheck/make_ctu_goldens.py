@@ -76,8 +76,12 @@ def sao_items(W, H, Cd, px):
         snap[0][y:y + hh, x:x + ww] = r[7].reshape(64, 64)[:hh, :ww]
         snap[1][y // 2:(y + hh) // 2, x // 2:(x + ww) // 2] = r[8].reshape(32, 32)[:hh // 2, :ww // 2]
         snap[2][y // 2:(y + hh) // 2, x // 2:(x + ww) // 2] = r[9].reshape(32, 32)[:hh // 2, :ww // 2]
+    global CODER
+    CODER = np.zeros((hc * wc, 3), np.int64)          # per CTU: bits its coding tree took in the arithmetic coder, the coder's range before / after
     for c in Cd:
-        models[(int(c[0][2]) // 64) * wc + int(c[0][1]) // 64] = c[3]
+        k = (int(c[0][2]) // 64) * wc + int(c[0][1]) // 64
+        models[k] = c[3]
+        CODER[k] = int(c[4][2]) - int(c[4][0]), int(c[4][1]), int(c[4][3])
     final = [FINAL[1].reshape(H, W), FINAL[2].reshape(H // 2, W // 2), FINAL[3].reshape(H // 2, W // 2)]
     return info, models, snap, final
 
@@ -120,7 +124,7 @@ def full(W, H, depth, qp, t=0):
     info, sm, snap, final = sao_items(W, H, Cd, px)
     np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_ctu_{tag}.npz"), meta=meta, lam=S[0][1], src_crc=np.uint32(src_crc), models=models,
                         cu=cu, trees=trees, rec_y=rec[0], rec_u=rec[1], rec_v=rec[2], coeff=coeff, bitstream=bs,
-                        sao=info, sao_models=sm, snap_y=snap[0], snap_u=snap[1], snap_v=snap[2], final_y=final[0], final_u=final[1], final_v=final[2])
+                        sao=info, sao_models=sm, coder=CODER, snap_y=snap[0], snap_u=snap[1], snap_v=snap[2], final_y=final[0], final_u=final[1], final_v=final[2])
     print("wrote", tag, len(S), "CTUs")
 
 
@@ -144,7 +148,7 @@ def crcs(W, H, depth, qp, t=0):
         blk = lambda P: b"".join(np.ascontiguousarray(p[(y >> c):(y >> c) + (64 >> c), (x >> c):(x >> c) + (64 >> c)]).tobytes() for p, c in zip(P, (0, 1, 1)))
         fcrc[k] = zlib.crc32(blk(snap)), zlib.crc32(blk(final))
     np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_ctucrc_{tag}.npz"), meta=meta, lam=S[0][1], src_crc=np.uint32(src_crc), crc=out,
-                        bitstream_crc=np.uint32(zlib.crc32(bs.tobytes())), bitstream_len=np.int64(len(bs)), sao=info, sao_models=sm, filter_crc=fcrc)
+                        bitstream_crc=np.uint32(zlib.crc32(bs.tobytes())), bitstream_len=np.int64(len(bs)), sao=info, sao_models=sm, filter_crc=fcrc, coder=CODER)
     print("wrote crc", tag, len(S), "CTUs")
 
 
