@@ -1961,6 +1961,109 @@ template <typename PX> CTU_NOINLINE CTU_DEV void mark_deblocking(lds<PX> *S, int
   }
 }
 
+#if defined(__HIPCC__)
+// coeff_bits for a 4x4 block (one coefficient group): the shape the 4x4 leaves, their 8x8 areas' chroma and most of the coder
+// pass consist of.  Same bins and adaptation as the general function below, but nothing goes through memory: lane sp (0..15) holds
+// position sp's record, the budget of regular bins is a lane sum, the models' sweep (one: 12 + 3 * 16 luma / 8 + 3 * 11 chroma
+// models) hands the records out with v_readlane and runs branch-free.
+template <typename PX> CTU_DEV double coeff_bits4(lds<PX> *S, CTU_LDS uint32_t *m, int update, CTU_LDS const int16_t *coeff, int color)
+{
+  const int lane = CTU_TID, sp = lane & 15, t = color ? 1 : 0;
+  const uint16_t *scan = S->scan + scan_base(2);
+  const int blk = scan[sp], py = blk >> 2, px = blk & 3;
+  const int a = iabs_((int)coeff[blk]);
+  const unsigned nzmask = (unsigned)__ballot(a != 0) & 0xffffu;
+  if (nzmask == 0) return 0.0;
+  const int last = 31 - __clz((int)nzmask);
+  int diag, tsum;
+  int ctx_sig = sig_ctx_abs(coeff, px, py, 4, color, &diag, &tsum);
+  if (t && ctx_sig > 7) ctx_sig = 7;
+  int ofs = 0;
+  if (sp != last) ofs = ((tsum < 4 ? tsum : 4) + 1) + (!diag ? (color == 0 ? 15 : 5) : color == 0 ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0);
+  const int r4 = go_rice_par((unsigned)abs_sum_tmpl(coeff, px, py, 4, 4)), r0 = go_rice_par((unsigned)abs_sum_tmpl(coeff, px, py, 4, 0));
+  const bool live = sp <= last;
+  const int sig_coded = live && sp != last;
+  const int spend = live ? sig_coded + (a ? 1 + (a > 1 ? 2 : 0) : 0) : 0;
+  const uint32_t rec = (uint32_t)(a > 0xffff ? 0xffff : a) | (uint32_t)ctx_sig << 16 | (uint32_t)ofs << 20 | (uint32_t)sig_coded << 29;
+  // where the regular-bin budget (28 for 16 coefficients) runs out: positions <= sw are bypass-coded
+  int tot = spend;
+  for (int o = 8; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, 64);
+  int sw = -1;
+  if (28 - tot < 4) {
+    int rb = 28;
+    for (int j = last; j >= 0; --j) {
+      if (rb < 4) { sw = j; break; }
+      rb -= __builtin_amdgcn_readlane(spend, j);
+    }
+  }
+  // ---- the models, one per lane ----
+  const int nk0 = t ? 8 : 12, nks = t ? 11 : 16;
+  int role = -1, k = 0;
+  if (lane < nk0) { role = 0; k = lane; }
+  else if (lane < nk0 + 3 * nks) { role = 1 + (lane - nk0) / nks; k = (lane - nk0) % nks; }
+  if (!t && role > 0 && k > 0) k += 5;          // 4x4 luma: set offsets 0, 6..20
+  const int model = role < 0 ? 0 : (role == 0 ? M_SIG + 12 * t : role == 1 ? M_GT1 + 21 * t : role == 2 ? M_PAR + 21 * t : M_GT2 + 21 * t) + k;
+  uint32_t st = m[model];
+  const int rw = kRate[model], r0w = rw >> 4, r1w = rw & 15;
+  const uint32_t add0 = (0x7fffu >> r0w) & 0x7fe0u, add1 = (0x7fffu >> r1w) & 0x7ffeu;
+  const uint32_t fsh = role == 0 ? 16 : 20, fmask = role == 0 ? 15u : 31u, rsel = role < 0 ? 31u : (uint32_t)role;
+  CTU_LDS const uint32_t *const ebits = LDSP(const uint32_t, tab_ebits());
+  uint32_t acc = 0;
+  for (int j = last; j > sw; --j) {
+    const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)rec, j);
+    const uint32_t aj = rj & 0xffffu;
+    // per role: does the position code a bin with one of the role's models, and which   (sig, gt1, parity, gt2)
+    const uint32_t gates = ((rj >> 29) & 1u) | (aj != 0 ? 2u : 0u) | (aj > 1 ? 12u : 0u);
+    if (gates == 0) continue;
+    const uint32_t bins = (aj != 0 ? 1u : 0u) | (aj > 1 ? 2u : 0u) | ((aj & 1u) << 2) | (aj >= 4 ? 8u : 0u);
+    const bool hit = ((gates >> rsel) & 1u) && ((rj >> fsh) & fmask) == (uint32_t)k;
+    const uint32_t bin = (bins >> rsel) & 1u;
+    uint32_t s0 = st & 0xffffu, s1 = st >> 16;
+    const uint32_t cost = ebits[(((s0 + s1) >> 8) << 1) ^ bin];
+    s0 -= (s0 >> r0w) & 0x7fe0u;
+    s1 -= (s1 >> r1w) & 0x7ffeu;
+    s0 += bin ? add0 : 0u;
+    s1 += bin ? add1 : 0u;
+    st = hit ? ((s0 & 0xffffu) | (s1 << 16)) : st;
+    acc += hit ? cost : 0u;
+  }
+  if (role >= 0 && update) m[model] = st;
+  unsigned long long q15 = acc;
+  // ---- bypass-coded parts: remainders, bypass positions, signs ----
+  int ibits = 0;
+  if (lane < 16 && live) {
+    if (sp > sw) { if (a >= 4) ibits += coeff_remain_bits(((unsigned)a - 4) >> 1, (uint32_t)r4, 5); }
+    else {
+      const unsigned pos0 = 1u << r0;
+      ibits += coeff_remain_bits(a == 0 ? pos0 : ((unsigned)a <= pos0 ? (unsigned)a - 1 : (unsigned)a), (uint32_t)r0, 5);
+    }
+    ibits += a != 0;
+  }
+  // ---- lane 0: the last-position prefix (its models are nobody else's; counting only: on a copy) ----
+  if (lane == 0) {
+    double bits = 0;
+    CTU_LDS uint32_t *mk = m;
+    if (!update) {
+      mk = LDSP(uint32_t, S->work[0]);
+      for (int i = M_LASTX; i < M_CBF_LUMA; ++i) mk[i] = m[i];
+    }
+    const int pos_last = scan[last], last_y = pos_last >> 2, last_x = pos_last & 3;
+    const int bx = M_LASTX + 20 * t, by = M_LASTY + 20 * t;      // 4x4: prefix offset 0, shift 0, three prefix models per axis
+    for (int q = 0; q < last_x; q++) m_code(mk, 1, bx + q, 1, bits);
+    if (last_x < 3) m_code(mk, 1, bx + last_x, 0, bits);
+    for (int q = 0; q < last_y; q++) m_code(mk, 1, by + q, 1, bits);
+    if (last_y < 3) m_code(mk, 1, by + last_y, 0, bits);
+    q15 += (unsigned long long)(bits * 32768.0);
+  }
+  for (int o = 32; o >= 1; o >>= 1) {
+    q15 += __shfl_xor(q15, o, 64);
+    ibits += __shfl_xor(ibits, o, 64);
+  }
+  WSYNC();
+  return (double)q15 / 32768.0 + (double)ibits;
+}
+#endif
+
 // Coefficient bit cost by the first wave (same bins, same model adaptation as coeff_bits_serial).  What is sequential in the
 // reference's coder is only the adaptation of each context model along ITS OWN bins, and the bit count is a sum of exact
 // multiples of 2^-15 (order-free).  So: every position's contexts / Rice parameters / bin values are derived by all lanes from the
@@ -1983,6 +2086,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
   const uint16_t *scan = S->scan + scan_base(l2);
   CTU_LDS uint32_t *const m = (CTU_LDS uint32_t *)m_;
   CTU_LDS const int16_t *const coeff = (CTU_LDS const int16_t *)coeff_;
+  if (n == 4) return coeff_bits4(S, m, update, coeff, color);
   CTU_LDS uint32_t *recs = (CTU_LDS uint32_t *)(V->t0);       // t0 + t1: 1024 words, free while costs are counted
   CTU_LDS uint8_t *cgf = (CTU_LDS uint8_t *)V->cg_flag;                                   // per group (raster): has a level
   CTU_LDS int32_t *gtot = (CTU_LDS int32_t *)(V->rq_stage);   // per group (scan order): regular bins it would spend, bit 30: a level among k = 1..15
@@ -2079,7 +2183,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
     const int r0 = kRate[model] >> 4, r1 = kRate[model] & 15;
     const uint32_t add0 = (0x7fffu >> r0) & 0x7fe0u, add1 = (0x7fffu >> r1) & 0x7ffeu;
     // what a record must show for this lane's model to code a bin: field (sig: bits 16..19, others: 20..24) == k, and the gate
-    const uint32_t fsh = role == 0 ? 16 : 20, fmask = role == 0 ? 15u : 31u;
+    const uint32_t fsh = role == 0 ? 16 : 20, fmask = role == 0 ? 15u : 31u, rsel = role < 0 ? 31u : (uint32_t)role;
+    CTU_LDS const uint32_t *const ebits = LDSP(const uint32_t, tab_ebits());
     uint32_t acc = 0;
     for (int g = cg_last; g >= 0 && g * 16 + 15 > sw; --g) {
       if (!((grp_mask >> g) & 1)) continue;
@@ -2088,19 +2193,22 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
       for (int j = 15; j >= 0; --j) {
         const int sp = g * 16 + j;
         if (sp > last || sp <= sw) continue;
-        const uint32_t rec = (uint32_t)__builtin_amdgcn_readlane((int)myrec, j);
-        const int a = (int)(rec & 0xffff);
-        if (a == 0 && !((rec >> 29) & 1)) continue;          // nothing coded with a context here
-        const int gate = role == 0 ? (int)((rec >> 29) & 1) : role == 1 ? a != 0 : a > 1;
-        const int bin = role == 0 ? a != 0 : role == 1 ? a > 1 : role == 2 ? (a & 1) : a >= 4;
-        if (role >= 0 && gate && ((rec >> fsh) & fmask) == (uint32_t)k) {
-          uint32_t s0 = st & 0xffffu, s1 = st >> 16;
-          acc += tab_ebits()[(((s0 + s1) >> 8) << 1) ^ (uint32_t)bin];
-          s0 -= (s0 >> r0) & 0x7fe0u;
-          s1 -= (s1 >> r1) & 0x7ffeu;
-          if (bin) { s0 += add0; s1 += add1; }
-          st = (s0 & 0xffffu) | (s1 << 16);
-        }
+        const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)myrec, j);
+        const uint32_t aj = rj & 0xffffu;
+        // per role (sig, gt1, parity, gt2): does the position code a bin with one of the role's models, and which -- branch-free
+        const uint32_t gates = ((rj >> 29) & 1u) | (aj != 0 ? 2u : 0u) | (aj > 1 ? 12u : 0u);
+        if (gates == 0) continue;
+        const uint32_t bins = (aj != 0 ? 1u : 0u) | (aj > 1 ? 2u : 0u) | ((aj & 1u) << 2) | (aj >= 4 ? 8u : 0u);
+        const bool hit = ((gates >> rsel) & 1u) && ((rj >> fsh) & fmask) == (uint32_t)k;
+        const uint32_t bin = (bins >> rsel) & 1u;
+        uint32_t s0 = st & 0xffffu, s1 = st >> 16;
+        const uint32_t cost = ebits[(((s0 + s1) >> 8) << 1) ^ bin];
+        s0 -= (s0 >> r0) & 0x7fe0u;
+        s1 -= (s1 >> r1) & 0x7ffeu;
+        s0 += bin ? add0 : 0u;
+        s1 += bin ? add1 : 0u;
+        st = hit ? ((s0 & 0xffffu) | (s1 << 16)) : st;
+        acc += hit ? cost : 0u;
       }
     }
     if (role >= 0 && update) m[model] = st;
