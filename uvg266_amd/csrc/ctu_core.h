@@ -467,11 +467,17 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rough_costs(lds<PX> *S, const j
   const int dcv = dc_value(R.top, R.left, n, n);
   CTU_LDS uint32_t *const part = LDSP(uint32_t, V->part);
 #if defined(__HIPCC__)
-  const int total = n_modes * tiles * T;
+  // Two segments: the angular modes of the list, then planar / DC (the first round's list starts with them).  A pass whose lanes
+  // are all of one kind skips the other kind's code (no lane enters it); mixed passes would run both for everybody -- for a 4x4
+  // block 16 angular modes x 4 rows fill one pass exactly and planar + DC become a short second one.
+  const int n_flat = (n_modes > 0 && modes[0] < 2) + (n_modes > 1 && modes[1] < 2);
+  for (int seg = 0; seg < 2; ++seg) {
+  const int m_first = seg ? 0 : n_flat, total = (seg ? n_flat : n_modes - n_flat) * tiles * T;
   for (int base = 0; base < total; base += CTU_NT) {
     const int idx = base + CTU_TID;
     const bool on = idx < total;
-    const int task = on ? idx / T : 0, r = idx & (T - 1);
+    const int task0 = on ? idx / T : 0, r = idx & (T - 1);
+    const int task = task0 + m_first * tiles;
     const int mi = task / tiles, tile = task - mi * tiles;
     const mode_info M = make_mode_info(modes[mi], n, n, 0);
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -501,6 +507,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rough_costs(lds<PX> *S, const j
       sad = dpp_group_sum<4>(sad);
     }
     if (on && r == 0) { part[2 * task] = (uint32_t)satd; part[2 * task + 1] = (uint32_t)sad; }
+  }
   }
   CTU_SYNC();
 #else
@@ -1070,7 +1077,12 @@ CTU_NOINLINE CTU_DEV int rdoq_serial(const uint8_t *st, const uint16_t *scan, sc
 // regular: regular bins remain (reg_bins >= 4), go_rice is then the value carried from the position coded before; otherwise the
 // position is priced as bypass-coded and its Rice parameter comes from the levels decided around it.
 struct rdoq_pos { int level; double cc, cs; };
-CTU_NOINLINE CTU_DEV rdoq_pos rdoq_decide(const rdoq_env &E, CTU_LDS const int16_t *coef, CTU_LDS const int16_t *dst, int n, int l2, int color, int blkpos, bool is_last,
+#if defined(__HIPCC__)
+#define CTU_INLINE __attribute__((always_inline))
+#else
+#define CTU_INLINE
+#endif
+CTU_INLINE CTU_DEV rdoq_pos rdoq_decide_inl(const rdoq_env &E, CTU_LDS const int16_t *coef, CTU_LDS const int16_t *dst, int n, int l2, int color, int blkpos, bool is_last,
                              bool regular, int go_rice, double c0, int *mal_out)
 {
   const int cap_half = 1 << (E.q_bits - 1);
@@ -1091,6 +1103,11 @@ CTU_NOINLINE CTU_DEV rdoq_pos rdoq_decide(const rdoq_env &E, CTU_LDS const int16
   r.level = (int)coded_level(E, &r.cc, c0, &r.cs, level_double, max_abs_level, ctx_sig, ctx_set, go_rice, regular ? 4u : 0u, is_last);
   *mal_out = (int)max_abs_level;
   return r;
+}
+CTU_NOINLINE CTU_DEV rdoq_pos rdoq_decide(const rdoq_env &E, CTU_LDS const int16_t *coef, CTU_LDS const int16_t *dst, int n, int l2, int color, int blkpos, bool is_last,
+                             bool regular, int go_rice, double c0, int *mal_out)
+{
+  return rdoq_decide_inl(E, coef, dst, n, l2, color, blkpos, is_last, regular, go_rice, c0, mal_out);
 }
 
 #if !defined(__HIPCC__)
@@ -1459,6 +1476,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
   int reg_bins = (int)((uint32_t)(nn * 28) >> 4);
   WSYNC();
   RQ_T(13);
+  double f_cc = 0, f_cs = 0, f_c0 = 0;          // cg_last == 0 (every 4x4 block, sparse larger ones): the group's numbers stay in
+  int f_lev = 0;                                 // registers for the last-position search -- no cost arrays
   for (int cgs = cg_last; cgs >= 0; --cgs) {
     const int first = scan[cgs * 16];
     const int cg_pos_x = (first & (n - 1)) >> 2, cg_pos_y = (first >> l2) >> 2;
@@ -1493,7 +1512,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
         bool changed = false;
         if (mine) {
           int mal;
-          const rdoq_pos r = rdoq_decide(E, coef, dst, n, l2, color, blk, is_last, regular != 0, go_rice, c0, &mal);
+          const rdoq_pos r = rdoq_decide_inl(E, coef, dst, n, l2, color, blk, is_last, regular != 0, go_rice, c0, &mal);
           cc = r.cc; cs = r.cs;
           changed = r.level != lev;
           lev = r.level;
@@ -1543,13 +1562,15 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
       block_uncoded_cost += k0;
       base_cost += kc;
       spent += (level < 2 ? level : 3) + (cgs * 16 + k != last_scanpos);
-      rd_sig += ks;
-      if (k == 0) rd_sig0 = ks;
-      if (level) {
-        flag = 1;
-        rd_coded += kc - ks;
-        rd_uncoded += k0;
-        if (k != 0) nnz_before_pos0++;
+      if (cgs) {                                // the group statistics only matter where a group can be zeroed out
+        rd_sig += ks;
+        if (k == 0) rd_sig0 = ks;
+        if (level) {
+          flag = 1;
+          rd_coded += kc - ks;
+          rd_uncoded += k0;
+          if (k != 0) nnz_before_pos0++;
+        }
       }
     }
     if (fast && regular) reg_bins -= spent;
@@ -1586,7 +1607,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
     }
     if (CTU_TID == 0) V->cg_flag[cg_blkpos] = (uint8_t)flag;
     // the group's costs go to the per-position arrays the last-position search reads; a zeroed group's positions fall back to level 0
-    if (mine) {
+    if (cg_last == 0) { f_cc = cc; f_cs = cs; f_c0 = c0; f_lev = lev; }
+    else if (mine) {
       const double wc = (zeroed && lev) ? c0 : cc, ws = (zeroed && lev) ? 0.0 : cs;
       if (zeroed && lev) dst[blk] = 0;
       if (small) { CCl[scanpos] = wc; CSl[scanpos] = ws; } else { CCg[scanpos] = wc; CSg[scanpos] = ws; }
@@ -1614,15 +1636,18 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
     const int scanpos = cgs * 16 + sp;
     const bool mine = own && scanpos <= last_scanpos;
     const int blkpos = scan[mine ? scanpos : cgs * 16];
-    const int lev = mine ? (int)dst[blkpos] : 0;
+    const int lev = cg_last == 0 ? f_lev : (mine ? (int)dst[blkpos] : 0);
     double kcs = 0, kcc = 0, k0 = 0, klast = 0;
     if (mine) {
-      kcs = small ? CSl[scanpos] : CTU_GLOAD(&CSg[scanpos]);
+      kcs = cg_last == 0 ? f_cs : (small ? CSl[scanpos] : CTU_GLOAD(&CSg[scanpos]));
       if (lev) {
-        kcc = small ? CCl[scanpos] : CTU_GLOAD(&CCg[scanpos]);
-        const int64_t prod = (int64_t)iabs_((int)coef[blkpos]) * E.q;
-        const double err = (double)(int32_t)(prod < cap ? prod : cap);
-        k0 = err * err * E.error_scale;
+        if (cg_last == 0) { kcc = f_cc; k0 = f_c0; }
+        else {
+          kcc = small ? CCl[scanpos] : CTU_GLOAD(&CCg[scanpos]);
+          const int64_t prod = (int64_t)iabs_((int)coef[blkpos]) * E.q;
+          const double err = (double)(int32_t)(prod < cap ? prod : cap);
+          k0 = err * err * E.error_scale;
+        }
         const int pos_y = blkpos >> l2, pos_x = blkpos - (pos_y << l2);
         const int cx = group_idx(pos_x), cy = group_idx(pos_y);
         double cl = last_x_bits[cx] + last_y_bits[cy];
