@@ -97,3 +97,36 @@ def test_plan_is_reusable_and_the_one_shot_call_agrees(hip, orc):
         t.zero_()
     cs.run_oneshot()
     assert np.array_equal(result(), want[1])
+
+
+def test_plan_refuses_what_the_search_does_not_implement(hip):
+    """uvghip_ctu_plan_create / uvghip_loop_plan_create fail loudly (an error code and a message, never a different result) on
+    configurations outside --preset medium -p 1 and on malformed descriptors."""
+    import ctypes
+    import torch
+    from uvg266_amd import api, lib, layout
+    L = lib.init(0)
+    W, Hh = 128, 64
+    y, u, v = layout.synthetic_yuv420(W, Hh, 0, 8)
+    src = [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in (y, u, v))]
+    good = api.CtuSearch(api.ctu_params(W, Hh, 27), src)
+
+    def create(params, pics=None, n=1, ws=None):
+        plan = ctypes.c_void_p()
+        return L.uvghip_ctu_plan_create(8, ctypes.byref(params), good.pics if pics is None else pics, n, api._dev(good.ws) if ws is None else ws, ctypes.byref(plan))
+    for change in (dict(wpp=0), dict(depth_max=5), dict(depth_min=3, depth_max=2), dict(rough_levels=1), dict(qp=64), dict(pic_w=W + 4), dict(lambda_=0.0)):
+        p = api.ctu_params(W, Hh, 27)
+        for k, val in change.items():
+            setattr(p, k, val)
+        assert create(p) != 0, change
+    assert create(api.ctu_params(W, Hh, 27), n=0) != 0
+    assert create(api.ctu_params(W, Hh, 27), ws=None if False else 0) != 0
+    bad = (lib.CtuPicture * 1)()
+    ctypes.memmove(bad, good.pics, ctypes.sizeof(bad))
+    bad[0].coeff = None
+    assert create(api.ctu_params(W, Hh, 27), pics=bad) != 0
+    assert L.uvghip_ctu_plan_run(None, None) != 0
+    assert L.uvghip_ctu_search_workspace_bytes(0, W, Hh) == 0
+    # 12-bit samples are not a build of this library
+    plan = ctypes.c_void_p()
+    assert L.uvghip_ctu_plan_create(12, ctypes.byref(api.ctu_params(W, Hh, 27)), good.pics, 1, api._dev(good.ws), ctypes.byref(plan)) != 0

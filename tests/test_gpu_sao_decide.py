@@ -103,3 +103,29 @@ def test_loop_plan_is_the_same_chain_in_one_call(hip):
     for k, n in enumerate(("final_y", "final_u", "final_v")):
         assert np.array_equal(out[1][k], r[n]), n
     assert np.array_equal(info[1], r["sao"]) and np.array_equal(models[1], r["sao_models"])
+
+
+@pytest.mark.parametrize("W,Hh,depth,qp", [(8, 8, 8, 27), (64, 64, 10, 22), (72, 40, 8, 12), (136, 200, 10, 32), (328, 264, 8, 47), (192, 64, 8, 37),
+                                           (64, 192, 10, 42)])
+def test_ragged_sizes_and_qp_range_against_the_oracle(hip, orc, W, Hh, depth, qp):
+    """Pictures that are one CTU, a fraction of one, one row / one column of CTUs, with partial CTUs on both edges, at both bit
+    depths and across the QP range: uvghip_loop_plan_run (search + filters) against the oracle's search + filters -- every
+    search output per CTU, every SAO decision, the SAO models and the final picture."""
+    import torch
+    from uvg266_amd import api, layout
+    prm = H.search_params(W, Hh, qp)
+    y, u, v = layout.synthetic_yuv420(W, Hh, 11, depth)
+    cl = api.ClosedLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in (y, u, v))])
+    cl.run_search()
+    torch.cuda.synchronize()
+    ry, ru, rv = (t.cpu().numpy() for t in cl.rec[0])          # before the filters run in place
+    scu = cl.cu[0].cpu().numpy().reshape(-1).view(H.SCU_NP)
+    got = H.search_result_from_device_layout(W, Hh, ry, ru, rv, scu, cl.coeff[0].cpu().numpy(), cl.models[0].cpu().numpy().view(np.uint32))
+    want = H.oracle_search_picture(orc, depth, prm, y, u, v)
+    assert np.array_equal(H.ctu_crcs(got, W, Hh), H.ctu_crcs(want, W, Hh))
+    cl.run_filters()
+    info, models = cl.results()
+    o = H.oracle_sao_picture(orc, depth, W, Hh, qp, prm.lam, (y, u, v), (want["rec_y"], want["rec_u"], want["rec_v"]), H.scu_from_cu(want["cu"], qp))
+    assert np.array_equal(H.sao_info_comparable(info[0]), H.sao_info_comparable(o["sao"])) and np.array_equal(models[0], o["sao_models"])
+    for k, n in enumerate(("final_y", "final_u", "final_v")):
+        assert np.array_equal(cl.out[0][k].cpu().numpy(), o[n]), n
