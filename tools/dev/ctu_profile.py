@@ -13,10 +13,12 @@ for rep in range(2):
     print(f"{n} pictures {W}x{H} {depth}-bit: {dt*1e3:.1f} ms -> {n/dt:.2f} pictures/s")
 ctus = ((W + 63) // 64) * ((H + 63) // 64) * n
 al = lambda v, a: (v + a - 1) // a * a
-off_order = al(256 + ctus * 4, 256); off_pics = al(off_order + ctus * 4, 256); off_scr = al(off_pics + n * 96, 256)
+off_order = al(512 + ctus * 4, 256); off_pics = al(off_order + ctus * 4, 256); off_scr = al(off_pics + n * 96, 256)
+n_slots = min(2048, al(ctus, 32))          # a slot keeps the profile of the last CTU that ran on it
 ws = cs.ws.cpu().numpy()
 SZ = 57344
-prof = np.stack([ws[off_scr + i * SZ + SZ - 1024: off_scr + i * SZ + SZ].view(np.uint64).reshape(4, 32) for i in range(ctus)]).astype(np.float64)
+prof = np.stack([ws[off_scr + i * SZ + SZ - 1024: off_scr + i * SZ + SZ].view(np.uint64).reshape(4, 32) for i in range(n_slots)]).astype(np.float64)
+prof = prof[prof[:, 0, 11] > 0]
 names = ["rough search", "refs+predict", "residual+transforms+recon", "RDOQ", "SSD", "RD cost bits", "unpark/models", "64x64 candidate", "coder pass", "load", "store", "TOTAL",
          "rq: candidates+last", "rq: pre-walk", "rq: decide", "rq: accumulate+group", "rq: copy-out", "rq: cbf+last search", "rq: signs", "leaf depth 0", "leaf depth 1", "leaf depth 2", "leaf depth 3", "leaf depth 4 (4x4)", "rs: setup", "rs: rough_costs", "rs: mode cost", "rs: select", "cb: last+flags", "cb: records+budget", "cb: sweeps", "cb: bypass+lane0"]
 tot = prof[:, 0, 11].mean()

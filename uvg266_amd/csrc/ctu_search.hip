@@ -28,7 +28,9 @@ struct launch_args {
   const int32_t *order;       // [ticket] = pic << 16 | cy << 8 | cx
   int32_t *ticket;            // the counter
   int32_t *done;              // [pic * ctus + cy * wc + cx]
-  ctu::scratch *scratch;      // per ticket
+  ctu::scratch *scratch;      // per slot: a running workgroup owns one (far fewer slots than CTUs: the memory stays cache-resident)
+  uint32_t *slots;            // bitmap of the slots in use
+  int n_slots;
   int wc, hc, n_ctus;
 };
 
@@ -38,7 +40,21 @@ __global__ void __launch_bounds__(256, 3) ctu_search_kernel(launch_args A)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   ctu::lds<PX> *S = reinterpret_cast<ctu::lds<PX> *>(smem);
   __shared__ int s_ticket;
-  if (threadIdx.x == 0) s_ticket = atomicAdd(A.ticket, 1);
+  __shared__ int s_slot;
+  if (threadIdx.x == 0) {
+    s_ticket = atomicAdd(A.ticket, 1);
+    // claim a scratch slot: more slots than workgroups can ever be resident, so a free bit always exists
+    const int words = A.n_slots >> 5;
+    int got = -1;
+    for (int i = s_ticket % words; got < 0; i = (i + 1 == words ? 0 : i + 1)) {
+      const uint32_t cur = __hip_atomic_load(&A.slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == 0xffffffffu) continue;
+      const int bit = __ffs((int)~cur) - 1;
+      const uint32_t prev = atomicOr(&A.slots[i], 1u << bit);
+      if (!(prev & (1u << bit))) got = i * 32 + bit;
+    }
+    s_slot = got;
+  }
   __syncthreads();
   const int ticket = s_ticket;
   const int32_t o = A.order[ticket];
@@ -63,27 +79,35 @@ __global__ void __launch_bounds__(256, 3) ctu_search_kernel(launch_args A)
   J.models_out = D.models + (size_t)k * 3 * ctu::NMODELS;
   J.models_in = cx > 0 ? D.models + ((size_t)(k - 1) * 3 + 2) * ctu::NMODELS
                        : (cy > 0 ? D.models + ((size_t)((cy - 1) * A.wc) * 3 + 2) * ctu::NMODELS : nullptr);
-  J.W = A.scratch + ticket;
+  J.W = A.scratch + s_slot;
   J.x = cx * 64; J.y = cy * 64;
   ctu::run_ctu(S, J);
   __threadfence();
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(&done[k], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&done[k], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    atomicAnd(&A.slots[s_slot >> 5], ~(1u << (s_slot & 31)));          // the scratch is free again
+  }
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-struct ws_layout { size_t ticket, done, order, pics, scratch, total; };
+// Scratch slots: a workgroup claims one while it runs.  2048 = 256 CUs x 8 is more than the device can hold of this kernel
+// (3 per CU); small jobs take one slot per CTU, rounded up to whole bitmap words.
+enum { MAX_SLOTS = 2048 };
+struct ws_layout { size_t ticket, slots, done, order, pics, scratch, total; int n_slots; };
 ws_layout layout(int n_pictures, int pic_w, int pic_h)
 {
   const size_t ctus = (size_t)((pic_w + 63) / 64) * ((pic_h + 63) / 64), total = ctus * n_pictures;
   ws_layout L;
+  L.n_slots = (int)(total < MAX_SLOTS ? align_up(total, 32) : MAX_SLOTS);
   L.ticket = 0;
-  L.done = 256;
-  L.order = align_up(L.done + total * 4, 256);
+  L.slots = 256;
+  L.done = L.slots + MAX_SLOTS / 8;
+  L.order = align_up(L.done + total * 4, 256);          // [0, order): zeroed before every run
   L.pics = align_up(L.order + total * 4, 256);
   L.scratch = align_up(L.pics + (size_t)n_pictures * sizeof(pic_dev), 256);
-  L.total = L.scratch + total * sizeof(ctu::scratch);
+  L.total = L.scratch + (size_t)L.n_slots * sizeof(ctu::scratch);
   return L;
 }
 
@@ -148,6 +172,8 @@ extern "C" int uvghip_ctu_plan_create(int bitdepth, const uvghip_ctu_params_t *p
   pl->A.ticket = reinterpret_cast<int32_t *>(ws + L.ticket);
   pl->A.done = reinterpret_cast<int32_t *>(ws + L.done);
   pl->A.scratch = reinterpret_cast<ctu::scratch *>(ws + L.scratch);
+  pl->A.slots = reinterpret_cast<uint32_t *>(ws + L.slots);
+  pl->A.n_slots = L.n_slots;
   pl->A.wc = wc; pl->A.hc = hc; pl->A.n_ctus = total;
   pl->bitdepth = bitdepth; pl->total = total; pl->counters = L.order; pl->ws = ws;
   const size_t lds = bitdepth == 8 ? sizeof(ctu::lds<uint8_t>) : sizeof(ctu::lds<uint16_t>);
