@@ -47,8 +47,31 @@ ORC_EXPORT void ORC_FN(f_entropy_table)(float *out512)
  * moves the coder's range and counts the renormalisation shifts it causes -- the bits the real coder consumes for it.  Bypass
  * bins cost one bit each whatever the range is, so a walk's exact size is shifts + (its bit estimate - regular_fbits).
  * Shared with orc_search.c (the bins of the coding tree outside the coefficients). */
-orc_cabac_sim ORC_FN(cabac_sim) = {0, 510, 0, 0.0};
-void ORC_FN(cabac_sim_bin)(int state, int bin)
+orc_cabac_sim ORC_FN(cabac_sim) = {0, 510, 0, 0.0, 0, 0xff, 23, 0, NULL, 0, 0};
+static void sim_put_byte(orc_cabac_sim *c, uint32_t byte)
+{
+  if (c->out_len == c->out_cap) { c->out_cap = c->out_cap ? 2 * c->out_cap : 4096; c->out = (uint8_t *)realloc(c->out, c->out_cap); }
+  c->out[c->out_len++] = (uint8_t)byte;
+}
+static void sim_write(orc_cabac_sim *c)                                     /* uvg_cabac_write (cabac.c:114-144) */
+{
+  const uint32_t lead_byte = c->low >> (24 - c->bits_left);
+  c->bits_left += 8;
+  c->low &= 0xffffffffu >> c->bits_left;
+  if (lead_byte == 0xff) { c->num_buffered_bytes++; return; }
+  if (c->num_buffered_bytes > 0) {
+    const uint32_t carry = lead_byte >> 8;
+    uint32_t byte = c->buffered_byte + carry;
+    c->buffered_byte = lead_byte & 0xff;
+    sim_put_byte(c, byte);
+    byte = (0xff + carry) & 0xff;
+    while (c->num_buffered_bytes > 1) { sim_put_byte(c, byte); c->num_buffered_bytes--; }
+  } else {
+    c->num_buffered_bytes = 1;
+    c->buffered_byte = lead_byte;
+  }
+}
+void ORC_FN(cabac_sim_bin)(int state, int bin)                            /* uvg_cabac_encode_bin (cabac.c:76-109) */
 {
   static const uint8_t renorm[32] = {6, 5, 4, 4, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};   /* uvg_g_auc_renorm_table */
   orc_cabac_sim *c = &ORC_FN(cabac_sim);
@@ -57,11 +80,78 @@ void ORC_FN(cabac_sim_bin)(int state, int bin)
   c->range -= lps;
   if ((bin ? 1 : 0) != (state >> 7)) {                                               /* CTX_MPS */
     const int nb = renorm[lps >> 3];
+    c->low = (c->low + c->range) << nb;
     c->range = lps << nb;
     c->shifts += (uint64_t)nb;
+    c->bits_left -= nb;
+    if (c->on == 2 && c->bits_left < 12) sim_write(c);
   } else if (c->range < 256) {
+    c->low <<= 1;
     c->range <<= 1;
     c->shifts += 1;
+    c->bits_left--;
+    if (c->on == 2 && c->bits_left < 12) sim_write(c);
+  }
+}
+void ORC_FN(cabac_sim_ep)(uint32_t bin)                                     /* uvg_cabac_encode_bin_ep (cabac.c:235-246) */
+{
+  orc_cabac_sim *c = &ORC_FN(cabac_sim);
+  if (c->on != 2) return;
+  c->low <<= 1;
+  if (bin) c->low += c->range;
+  c->bits_left--;
+  if (c->bits_left < 12) sim_write(c);
+}
+void ORC_FN(cabac_sim_eps)(uint32_t bin_values, int num_bins)               /* uvg_cabac_encode_bins_ep / _aligned_bins_ep (cabac.c:249-311) */
+{
+  orc_cabac_sim *c = &ORC_FN(cabac_sim);
+  if (c->on != 2) return;
+  if (c->range == 256) {
+    uint32_t rem = (uint32_t)num_bins;
+    while (rem > 0) {
+      const uint32_t n = rem < 8 ? rem : 8, mask = (1u << n) - 1;
+      const uint32_t nb = (bin_values >> (rem - n)) & mask;
+      c->low = (c->low << n) + (nb << 8);
+      rem -= n;
+      c->bits_left -= (int32_t)n;
+      if (c->bits_left < 12) sim_write(c);
+    }
+    return;
+  }
+  while (num_bins > 8) {
+    num_bins -= 8;
+    const uint32_t pattern = bin_values >> num_bins;
+    c->low <<= 8;
+    c->low += c->range * pattern;
+    bin_values -= pattern << num_bins;
+    c->bits_left -= 8;
+    if (c->bits_left < 12) sim_write(c);
+  }
+  c->low <<= num_bins;
+  c->low += c->range * bin_values;
+  c->bits_left -= num_bins;
+  if (c->bits_left < 12) sim_write(c);
+}
+/* uvg_cabac_write_coeff_remain (cabac.c:318-354): the bins, not their count */
+static void sim_coeff_remain(uint32_t remainder, uint32_t rice, unsigned cutoff)
+{
+  if (ORC_FN(cabac_sim).on != 2) return;
+  const unsigned threshold = cutoff << rice;
+  if (remainder < threshold) {
+    const uint32_t length = (remainder >> rice) + 1;
+    ORC_FN(cabac_sim_eps)((1u << length) - 2, (int)length);
+    ORC_FN(cabac_sim_eps)(remainder & ((1u << rice) - 1), (int)rice);
+  } else {
+    const unsigned max_prefix = 32 - cutoff - 15;
+    unsigned prefix_length = 0, suffix_length;
+    const unsigned code_value = (remainder >> rice) - cutoff;
+    if ((int32_t)code_value >= ((1 << max_prefix) - 1)) { prefix_length = max_prefix; suffix_length = 15; }
+    else { while ((int32_t)code_value > ((2 << prefix_length) - 2)) prefix_length++; suffix_length = prefix_length + rice + 1; }
+    const unsigned total_prefix = prefix_length + cutoff;
+    const unsigned prefix = (1u << total_prefix) - 1;
+    const unsigned suffix = ((code_value - ((1u << prefix_length) - 1)) << rice) | (remainder & ((1u << rice) - 1));
+    ORC_FN(cabac_sim_eps)(prefix, (int)total_prefix);
+    ORC_FN(cabac_sim_eps)(suffix, (int)suffix_length);
   }
 }
 
@@ -194,8 +284,9 @@ ORC_EXPORT double ORC_FN(coeff_cost)(const int16_t *coeff, int width, int height
     k = 0;
     for (; k < gy; k++) code_bin(&m, CC_LASTY + 20 * t + off_y + (k >> sh_y), 1, &bits);
     if (gy < group_idx_cc((height < 32 ? height : 32) - 1)) code_bin(&m, CC_LASTY + 20 * t + off_y + (k >> sh_y), 0, &bits);
-    if (gx > 3) bits += (gx - 2) / 2;
-    if (gy > 3) bits += (gy - 2) / 2;
+    static const int min_in_group[14] = {0, 1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96};      /* g_min_in_group */
+    if (gx > 3) { bits += (gx - 2) / 2; ORC_FN(cabac_sim_eps)((uint32_t)(last_x - min_in_group[gx]), (gx - 2) / 2); }
+    if (gy > 3) { bits += (gy - 2) / 2; ORC_FN(cabac_sim_eps)((uint32_t)(last_y - min_in_group[gy]), (gy - 2) / 2); }
     bits_out += bits;
   }
   /* ---- the coefficient groups ---- */
@@ -221,6 +312,7 @@ ORC_EXPORT double ORC_FN(coeff_cost)(const int16_t *coeff, int width, int height
       int next_sig_pos = first_sig_pos;
       const int infer_sig_pos = (next_sig_pos != scan_pos_last) ? ((i != 0) ? min_sub_pos : -1) : next_sig_pos;
       int num_non_zero = 0;
+      uint32_t coeff_signs = 0;                /* one bit per non-zero level in coding order, first coded = most significant */
       /* first pass: context-coded flags while regular bins remain */
       for (next_sig_pos = first_sig_pos; next_sig_pos >= min_sub_pos && reg_bins >= 4; next_sig_pos--) {
         const uint32_t blk_pos = scan[next_sig_pos];
@@ -236,6 +328,7 @@ ORC_EXPORT double ORC_FN(coeff_cost)(const int16_t *coeff, int width, int height
         if (sig) {
           uint8_t *offset = &ctx_offset[next_sig_pos - min_sub_pos];
           num_non_zero++;
+          coeff_signs = (coeff_signs << 1) | (coeff[blk_pos] < 0);
           *offset = 0;
           if (temp_diag != -1) {
             *offset = (uint8_t)((temp_sum < 4 ? temp_sum : 4) + 1);
@@ -261,7 +354,7 @@ ORC_EXPORT double ORC_FN(coeff_cost)(const int16_t *coeff, int width, int height
         const uint32_t pos_y = blk_pos / (uint32_t)width, pos_x = blk_pos - pos_y * (uint32_t)width;
         const int rice = go_rice(abs_sum(coeff, pos_x, pos_y, (uint32_t)width, (uint32_t)height, 4));
         const uint32_t a = (uint32_t)abs((int)coeff[blk_pos]);
-        if (a >= 4) bits += coeff_remain_bits((a - 4) >> 1, (uint32_t)rice, 5);
+        if (a >= 4) { bits += coeff_remain_bits((a - 4) >> 1, (uint32_t)rice, 5); sim_coeff_remain((a - 4) >> 1, (uint32_t)rice, 5); }
       }
       /* bypass-coded positions (regular bins spent) */
       for (int scan_pos = next_sig_pos; scan_pos >= min_sub_pos; scan_pos--) {
@@ -272,10 +365,12 @@ ORC_EXPORT double ORC_FN(coeff_cost)(const int16_t *coeff, int width, int height
         const uint32_t pos0 = 1u << rice;                                       /* quant_state < 2 */
         const uint32_t remainder = a == 0 ? pos0 : (a <= pos0 ? a - 1 : a);
         bits += coeff_remain_bits(remainder, (uint32_t)rice, 5);
-        if (a) num_non_zero++;
+        sim_coeff_remain(remainder, (uint32_t)rice, 5);
+        if (a) { num_non_zero++; coeff_signs = (coeff_signs << 1) | (coeff[blk_pos] < 0); }
       }
       if (color == 0 && first_sig_pos > 0) flags |= 4;                          /* mts_last_scan_pos (tr_idx != MTS_SKIP assumed) */
       bits += num_non_zero;                                                     /* coeff_signs, bypass */
+      ORC_FN(cabac_sim_eps)(coeff_signs, num_non_zero);
     }
     if (color == 0 && (cg_pos_y > 3 || cg_pos_x > 3) && sig_cg[cg_blk_pos] != 0) flags |= 8;
   }

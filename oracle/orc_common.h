@@ -49,6 +49,11 @@ static inline int orc_iabs(int v) { return v < 0 ? -v : v; }
 static inline int orc_log2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 /* count mode of the arithmetic coder (orc_coeff_cost.c): range, renormalisation shifts and the estimate share of the regular bins */
-typedef struct orc_cabac_sim { int on; uint32_t range; uint64_t shifts; double regular_fbits; } orc_cabac_sim;
+typedef struct orc_cabac_sim {
+  int on;                       /* 0 off, 1 count (range + shifts), 2 the whole arithmetic coder (low, carries, bytes) */
+  uint32_t range; uint64_t shifts; double regular_fbits;
+  uint32_t low, buffered_byte; int32_t bits_left, num_buffered_bytes;      /* cabac_data_t (cabac.h:56-66) */
+  uint8_t *out; size_t out_len, out_cap;                                    /* payload bytes handed to the bitstream */
+} orc_cabac_sim;
 
 #endif

@@ -130,6 +130,8 @@ static void ctx_update(orc_models *m, int c, int bin)           /* CTX_UPDATE, c
 /* CABAC_FBITS_UPDATE with only_count = 1 */
 extern orc_cabac_sim ORC_FN(cabac_sim);
 void ORC_FN(cabac_sim_bin)(int state, int bin);
+void ORC_FN(cabac_sim_ep)(uint32_t bin);
+void ORC_FN(cabac_sim_eps)(uint32_t bin_values, int num_bins);
 static void fbits_update(s_cabac *cb, int c, int bin, double *bits)
 {
   *bits += ctx_fbits(&cb->m, c, bin);
@@ -415,10 +417,10 @@ static void encode_intra_luma(s_cabac *cb, int mode, const s_loc *loc, const s_c
   fbits_update(cb, M_MPM, mpm != -1, &bits);
   if (mpm != -1) {
     fbits_update(cb, M_PLANAR + 1, mpm > 0, &bits);
-    if (mpm > 0) bits += 1;
-    if (mpm > 1) bits += 1;
-    if (mpm > 2) bits += 1;
-    if (mpm > 3) bits += 1;
+    if (mpm > 0) { bits += 1; ORC_FN(cabac_sim_ep)(mpm > 1); }          /* mpm_idx: one bypass bin each (encode_coding_tree.c:1174-1189) */
+    if (mpm > 1) { bits += 1; ORC_FN(cabac_sim_ep)(mpm > 2); }
+    if (mpm > 2) { bits += 1; ORC_FN(cabac_sim_ep)(mpm > 3); }
+    if (mpm > 3) { bits += 1; ORC_FN(cabac_sim_ep)(mpm > 4); }
   } else {
     /* sort the candidates, remove them from the mode's index, truncated binary code of 61 symbols (cabac.c:203-229) */
     int8_t sorted[6];
@@ -429,6 +431,8 @@ static void encode_intra_luma(s_cabac *cb, int mode, const s_loc *loc, const s_c
     int tmp = mode;
     for (int i = 5; i >= 0; --i) if (tmp > sorted[i]) tmp--;
     if (bits_out) *bits_out += (tmp < 3) ? 5 : 6;       /* uvg_cabac_encode_trunc_bin adds to bits_out directly */
+    if (tmp < 3) ORC_FN(cabac_sim_eps)((uint32_t)tmp, 5);        /* 61 symbols: 2^5 = 32, 29 above: the first 3 take 5 bits (cabac.c:203-229) */
+    else ORC_FN(cabac_sim_eps)((uint32_t)tmp + 3, 6);
   }
   if (bits_out) *bits_out += bits;
 }
@@ -439,7 +443,13 @@ static void encode_chroma_intra(s_cabac *cb, int chroma_mode, int luma_dir, doub
   double bits = 0;
   const int derived = chroma_mode == luma_dir;
   fbits_update(cb, M_CHROMA_PRED, derived ? 0 : 1, &bits);
-  if (!derived) bits += 2;
+  if (!derived) {
+    bits += 2;
+    int modes[4] = {0, 50, 18, 1}, idx = 0;              /* :909-915, 943-947: the entry equal to the luma mode stands for 66 */
+    for (int i = 0; i < 4; ++i) if (modes[i] == luma_dir) modes[i] = 66;
+    while (idx < 4 && modes[idx] != chroma_mode) ++idx;
+    ORC_FN(cabac_sim_eps)((uint32_t)idx, 2);
+  }
   if (bits_out) *bits_out += bits;
 }
 
@@ -1309,4 +1319,54 @@ ORC_EXPORT int ORC_FN(count_picture_bits)(const orc_search_params *p, const uint
   }
   free(f.cua); free(st);
   return 0;
+}
+
+
+/*
+ * The same consumer as a bitstream coder: the whole arithmetic coder (uvg_cabac_encode_bin / _bin_ep / _bins_ep / uvg_cabac_write,
+ * cabac.c:76-311) over every CTU's coding tree.  state_in[ctu][5]: low, range, bits_left, num_buffered_bytes, buffered_byte when
+ * the tree begins; state_out likewise when it ends; bytes_out / byte_off[ctu + 1]: the payload bytes the coder hands to the
+ * bitstream during each CTU's tree (before emulation prevention).  Returns the total number of bytes, or -1 if bytes_cap is too small.
+ */
+ORC_EXPORT long ORC_FN(encode_picture_ctus)(const orc_search_params *p, const uint8_t *cu, const int16_t *coeff, const orc_models *start,
+                                            const int64_t *state_in, int64_t *state_out, uint8_t *bytes_out, long bytes_cap, int64_t *byte_off)
+{
+  fbits_init();
+  const int W = p->pic_w, H = p->pic_h, wc = (W + 63) / 64, hc = (H + 63) / 64, cu_stride = wc * 16;
+  s_frame f = {p, (s_cu *)calloc((size_t)cu_stride * hc * 16, sizeof(s_cu)), cu_stride};
+  for (int j = 0; j < hc * 16; ++j)
+    for (int i = 0; i < cu_stride; ++i) {
+      s_cu *c = &f.cua[j * cu_stride + i];
+      const uint8_t *o = &cu[((size_t)j * cu_stride + i) * 20];
+      c->type = o[0]; c->log2_w = o[1]; c->log2_h = o[2]; c->log2_cw = o[3]; c->log2_ch = o[4]; c->cbf = o[5]; c->mode = (int8_t)o[6];
+      c->mode_chroma = (int8_t)o[7]; c->luma_deblocking = o[8]; c->chroma_deblocking = o[9]; c->qp = o[10];
+      memcpy(&c->split_tree, o + 12, 4); memcpy(&c->mode_type_tree, o + 16, 4);
+    }
+  s_state *st = (s_state *)calloc(1, sizeof(s_state));
+  st->p = p;
+  orc_cabac_sim *sim = &ORC_FN(cabac_sim);
+  long total = 0;
+  byte_off[0] = 0;
+  for (int k = 0; k < wc * hc; ++k) {
+    const int16_t *co = &coeff[(size_t)k * 6144];
+    s_cabac cb;
+    cb.m = start[k]; cb.update = 1;
+    sim->on = 2; sim->shifts = 0; sim->regular_fbits = 0.0; sim->out_len = 0;
+    sim->low = (uint32_t)state_in[5 * k]; sim->range = (uint32_t)state_in[5 * k + 1]; sim->bits_left = (int32_t)state_in[5 * k + 2];
+    sim->num_buffered_bytes = (int32_t)state_in[5 * k + 3]; sim->buffered_byte = (uint32_t)state_in[5 * k + 4];
+    g_tree_bits = 0.0;
+    s_loc start_loc;
+    loc_ctor(&start_loc, (k % wc) * 64, (k / wc) * 64, 64, 64);
+    s_tree tree = {0, MODE_TYPE_ALL, 0, 0, 0, 0};
+    encode_coding_tree(&f, st, &cb, co, co + 4096, co + 4096 + 1024, &start_loc, &start_loc, tree, 1);
+    sim->on = 0;
+    state_out[5 * k] = sim->low; state_out[5 * k + 1] = sim->range; state_out[5 * k + 2] = sim->bits_left;
+    state_out[5 * k + 3] = sim->num_buffered_bytes; state_out[5 * k + 4] = sim->buffered_byte;
+    if (total + (long)sim->out_len > bytes_cap) { free(f.cua); free(st); return -1; }
+    memcpy(bytes_out + total, sim->out, sim->out_len);
+    total += (long)sim->out_len;
+    byte_off[k + 1] = total;
+  }
+  free(f.cua); free(st);
+  return total;
 }

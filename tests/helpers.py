@@ -486,6 +486,29 @@ def oracle_count_bits(orc, depth, prm, res, range_in):
     return bits, rout, after
 
 
+def oracle_encode_ctus(orc, depth, prm, res, state_in):
+    """orcN_encode_picture_ctus: the arithmetic coder itself over every CTU's coding tree (same inputs as oracle_count_bits;
+    state_in [ctus, 5]: low, range, bits_left, num_buffered_bytes, buffered_byte when the tree begins).
+    -> (state afterwards [ctus, 5], payload bytes, offsets [ctus + 1])"""
+    W, H = prm.pic_w, prm.pic_h
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    cu = np.zeros((hc * 16, wc * 16, 20), np.uint8)
+    cu[:, :, :11] = res["cu"]
+    cu[:, :, 12:] = np.ascontiguousarray(res["trees"].astype(np.uint32)).view(np.uint8).reshape(hc * 16, wc * 16, 8)
+    co = np.ascontiguousarray(res["coeff"], np.int16)
+    start = np.ascontiguousarray(res["models"][:, 0])
+    sin = np.ascontiguousarray(state_in, np.int64)
+    sout = np.zeros((wc * hc, 5), np.int64)
+    cap = 64 + wc * hc * 16384
+    out = np.zeros(cap, np.uint8)
+    off = np.zeros(wc * hc + 1, np.int64)
+    fn = orc.fn(depth, "encode_picture_ctus")
+    fn.restype = ctypes.c_long
+    n = fn(ctypes.byref(prm), ptr(cu), ptr(co), ptr(start), ptr(sin), ptr(sout), ptr(out), ctypes.c_long(cap), ptr(off))
+    assert n >= 0
+    return sout, out[:n].copy(), off
+
+
 def filter_crcs(res, W, H):
     """Per CTU CRC-32 of (the block the SAO decision saw, the block of the final picture), Y + U + V, as
     tools/refcheck/make_ctu_goldens.py computes them (filter_crc)."""

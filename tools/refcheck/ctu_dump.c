@@ -122,10 +122,13 @@ void __wrap_uvg_search_lcu(encoder_state_t *const state, const int x, const int 
 /* payload bytes the arithmetic coder hands to the bitstream (uvg_bitstream_put_byte, called from uvg_cabac_write): counted
  * here rather than with uvg_bitstream_tell, which also sees the emulation-prevention bytes the bitstream layer inserts */
 static int64_t g_cabac_bytes;
+static uint8_t g_tree_bytes[1 << 16];      /* the bytes of the coding tree being recorded */
+static int g_tree_n = -1;
 void __real_uvg_bitstream_put_byte(bitstream_t *const stream, const uint32_t data);
 void __wrap_uvg_bitstream_put_byte(bitstream_t *const stream, const uint32_t data)
 {
   ++g_cabac_bytes;
+  if (g_tree_n >= 0 && g_tree_n < (int)sizeof g_tree_bytes) g_tree_bytes[g_tree_n++] = (uint8_t)data;
   __real_uvg_bitstream_put_byte(stream, data);
 }
 
@@ -141,7 +144,13 @@ void __wrap_uvg_encode_coding_tree(encoder_state_t *const state, lcu_coeff_t *co
   int64_t coder[4];
   coder[0] = 8 * g_cabac_bytes + 8 * (int64_t)state->cabac.num_buffered_bytes + 23 - state->cabac.bits_left;
   coder[1] = state->cabac.range;
+  int64_t full[10];        /* the arithmetic coder's whole state before / after: low, range, bits_left, num_buffered_bytes, buffered_byte */
+  full[0] = state->cabac.low; full[1] = state->cabac.range; full[2] = state->cabac.bits_left; full[3] = state->cabac.num_buffered_bytes; full[4] = state->cabac.buffered_byte;
+  g_tree_n = 0;
   __real_uvg_encode_coding_tree(state, coeff, tree_type, cu_loc, chroma_loc, split_tree, has_chroma);
+  const int n_bytes = g_tree_n;
+  g_tree_n = -1;
+  full[5] = state->cabac.low; full[6] = state->cabac.range; full[7] = state->cabac.bits_left; full[8] = state->cabac.num_buffered_bytes; full[9] = state->cabac.buffered_byte;
   coder[2] = 8 * g_cabac_bytes + 8 * (int64_t)state->cabac.num_buffered_bytes + 23 - state->cabac.bits_left;
   coder[3] = state->cabac.range;
   snapshot(&state->cabac, &after);
@@ -149,10 +158,12 @@ void __wrap_uvg_encode_coding_tree(encoder_state_t *const state, lcu_coeff_t *co
   uint16_t m_sao[6];
   m_sao[0] = state->cabac.ctx.sao_merge_flag_model.state[0]; m_sao[1] = state->cabac.ctx.sao_merge_flag_model.state[1]; m_sao[2] = state->cabac.ctx.sao_merge_flag_model.rate;
   m_sao[3] = state->cabac.ctx.sao_type_idx_model.state[0]; m_sao[4] = state->cabac.ctx.sao_type_idx_model.state[1]; m_sao[5] = state->cabac.ctx.sao_type_idx_model.rate;
-  rec_begin("coded", 5);
+  rec_begin("coded", 7);
   rec_arr(A_I32, meta, 3); rec_arr(A_U8, &before, sizeof before); rec_arr(A_U8, &after, sizeof after);
   rec_arr(A_U16, m_sao, 6);        /* the two SAO models after this CTU's SAO syntax (encode_sao precedes the coding tree) */
   rec_arr(A_I64, coder, 4);
+  rec_arr(A_I64, full, 10);
+  rec_arr(A_U8, g_tree_bytes, (size_t)n_bytes);
 }
 
 /* uvg_sao_search_lcu (src/sao.c:670, called at src/encoderstate.c:849 right after the CTU's own uvg_filter_deblock_lcu): the CTU's

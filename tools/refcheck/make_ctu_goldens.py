@@ -76,12 +76,18 @@ def sao_items(W, H, Cd, px):
         snap[0][y:y + hh, x:x + ww] = r[7].reshape(64, 64)[:hh, :ww]
         snap[1][y // 2:(y + hh) // 2, x // 2:(x + ww) // 2] = r[8].reshape(32, 32)[:hh // 2, :ww // 2]
         snap[2][y // 2:(y + hh) // 2, x // 2:(x + ww) // 2] = r[9].reshape(32, 32)[:hh // 2, :ww // 2]
-    global CODER
+    global CODER, CODER_STATE, TREE_BYTES, TREE_OFF
     CODER = np.zeros((hc * wc, 3), np.int64)          # per CTU: bits its coding tree took in the arithmetic coder, the coder's range before / after
+    CODER_STATE = np.zeros((hc * wc, 2, 5), np.int64) # per CTU: low, range, bits_left, num_buffered_bytes, buffered_byte before / after its coding tree
+    chunks = [b""] * (hc * wc)
     for c in Cd:
         k = (int(c[0][2]) // 64) * wc + int(c[0][1]) // 64
         models[k] = c[3]
         CODER[k] = int(c[4][2]) - int(c[4][0]), int(c[4][1]), int(c[4][3])
+        CODER_STATE[k] = c[5].reshape(2, 5)
+        chunks[k] = c[6].tobytes()
+    TREE_OFF = np.concatenate([[0], np.cumsum([len(b) for b in chunks])]).astype(np.int64)
+    TREE_BYTES = np.frombuffer(b"".join(chunks), np.uint8)
     final = [FINAL[1].reshape(H, W), FINAL[2].reshape(H // 2, W // 2), FINAL[3].reshape(H // 2, W // 2)]
     return info, models, snap, final
 
@@ -124,7 +130,7 @@ def full(W, H, depth, qp, t=0):
     info, sm, snap, final = sao_items(W, H, Cd, px)
     np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_ctu_{tag}.npz"), meta=meta, lam=S[0][1], src_crc=np.uint32(src_crc), models=models,
                         cu=cu, trees=trees, rec_y=rec[0], rec_u=rec[1], rec_v=rec[2], coeff=coeff, bitstream=bs,
-                        sao=info, sao_models=sm, coder=CODER, snap_y=snap[0], snap_u=snap[1], snap_v=snap[2], final_y=final[0], final_u=final[1], final_v=final[2])
+                        sao=info, sao_models=sm, coder=CODER, coder_state=CODER_STATE, tree_bytes=TREE_BYTES, tree_off=TREE_OFF, snap_y=snap[0], snap_u=snap[1], snap_v=snap[2], final_y=final[0], final_u=final[1], final_v=final[2])
     print("wrote", tag, len(S), "CTUs")
 
 
@@ -148,7 +154,8 @@ def crcs(W, H, depth, qp, t=0):
         blk = lambda P: b"".join(np.ascontiguousarray(p[(y >> c):(y >> c) + (64 >> c), (x >> c):(x >> c) + (64 >> c)]).tobytes() for p, c in zip(P, (0, 1, 1)))
         fcrc[k] = zlib.crc32(blk(snap)), zlib.crc32(blk(final))
     np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_ctucrc_{tag}.npz"), meta=meta, lam=S[0][1], src_crc=np.uint32(src_crc), crc=out,
-                        bitstream_crc=np.uint32(zlib.crc32(bs.tobytes())), bitstream_len=np.int64(len(bs)), sao=info, sao_models=sm, filter_crc=fcrc, coder=CODER)
+                        bitstream_crc=np.uint32(zlib.crc32(bs.tobytes())), bitstream_len=np.int64(len(bs)), sao=info, sao_models=sm, filter_crc=fcrc, coder=CODER, coder_state=CODER_STATE,
+                        tree_crc=np.array([zlib.crc32(TREE_BYTES[TREE_OFF[k]:TREE_OFF[k + 1]].tobytes()) for k in range(hc * wc)], np.uint32), tree_off=TREE_OFF)
     print("wrote crc", tag, len(S), "CTUs")
 
 
