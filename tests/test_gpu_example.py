@@ -1,0 +1,37 @@
+"""examples/closed_loop: the library driven by a C++ host program over the C ABI alone (the encoder's side of the boundary) gives
+the pictures the Python-driven path gives."""
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cpp_host_program_equals_the_python_driven_path(hip, tmp_path):
+    import torch
+    from uvg266_amd import api, layout
+    exe = os.path.join(H.ROOT, "examples", "closed_loop")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(H.ROOT, "examples")])
+    W, Hh, depth, qp, n = 328, 200, 8, 27, 3
+    pics = [layout.synthetic_yuv420(W, Hh, t, depth) for t in range(n)]
+    yuv = tmp_path / "in.yuv"
+    with open(yuv, "wb") as f:
+        for p in pics:
+            for plane in p:
+                f.write(np.ascontiguousarray(plane).tobytes())
+    out = subprocess.check_output([exe, str(W), str(Hh), str(depth), str(qp), str(n), str(yuv)], text=True)
+    lines = [l.split() for l in out.splitlines() if l.startswith("picture")]
+    assert len(lines) == n
+    cl = api.ClosedLoop(api.ctu_params(W, Hh, qp), [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in yuv_) for yuv_ in pics])
+    cl.run()
+    torch.cuda.synchronize()
+    for i in range(n):
+        want = zlib.crc32(b"".join(t.cpu().numpy().tobytes() for t in cl.out[i]))
+        assert int(lines[i][5], 16) == want, (i, lines[i])
+        assert int(lines[i][3], 16) == zlib.crc32(b"".join(np.ascontiguousarray(p).tobytes() for p in pics[i]))
