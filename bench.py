@@ -633,7 +633,7 @@ def main():
     extra = None
     if not args.no_extra and wl_name == "1080p8":
         ewl = WORKLOADS["2160p10alf"]
-        ek, eF = 4, max(1, args.in_flight // 4)
+        ek, eF = 4, max(1, args.in_flight // 2)          # (a 4K picture has 93 diagonals of at most 34 CTUs: 80 pictures keep 768 workgroups fed)
         ecl, eF, eel, ems, eln = closed_loop(ewl, ek, 0, eF, device, rank, world, dist, args.groups)
         del ecl
         extra = {"value": round(ek * eF * world / eel, 3), "unit": "frames/s", "steps": ek, "pictures_per_step": eF, "ms_per_step": round(1e3 * eel / ek, 2),

@@ -132,11 +132,10 @@ template <> struct px_info<uint16_t> { enum { depth = 10, maxv = 1023 }; };
 // small fixed-size pieces inline
 struct wctx {
   uint16_t *top, *left, *ftop, *fleft;              // reference rows: 4 n + 8 entries each
-  int16_t *t0, *t1, *t2;                            // transform scratch, n * n each (t0 and t1 adjacent: also the n * n words of coeff_bits)
+  int16_t *t0, *t1;                                 // transform scratch, n * n each, adjacent (together also the n * n words of coeff_bits)
   int16_t *lv0, *lv1, *lv2;                         // levels of the transform blocks being evaluated (y, u, v)
   double *rq_cc, *rq_cs;                            // RDOQ per-position costs in LDS (nullptr: the depth uses the workgroup's global scratch)
   uint32_t *part;                                   // rough search: (satd, sad) per (listed mode, tile)
-  uint8_t *lv_spend;                                // coefficient bit cost: regular bins a scan position spends
   uint32_t *cur;                                    // the models this wave's bit counting works on
   double rq_stage[3 * 16];                          // RDOQ: costs of the coefficient group in flight
   double rs_cand[3 + 24], rs_best_cost[2][3];      // rough search: costs of the survivors and of the listed modes; the survivors, double-buffered
@@ -153,9 +152,9 @@ struct wctx {
 
 constexpr int arena_bytes(int n)     // one depth's share of the arena (n = its luma block size)
 {
-  // reference rows, three transform buffers, levels (y, u, v), [4x4 only: the rough search's partial costs -- larger blocks keep
+  // reference rows, two transform buffers, levels (y, u, v), [4x4 only: the rough search's partial costs -- larger blocks keep
   // them in the transform buffers, idle during the rough search], [<= 8x8: RDOQ's two per-position cost arrays]
-  return (4 * (4 * n + 8) * 2 + 3 * n * n * 2 + (n * n + 2 * ((n / 2) * (n / 2) < 16 ? 16 : (n / 2) * (n / 2))) * 2 +
+  return (4 * (4 * n + 8) * 2 + 2 * n * n * 2 + (n * n + 2 * ((n / 2) * (n / 2) < 16 ? 16 : (n / 2) * (n / 2))) * 2 +
           (n >= 8 ? 0 : 2 * 18 * 4) + (n <= 8 ? 8 + 2 * n * n * 8 : 0) + 15) & ~15;
 }
 enum { ARENA_BYTES = arena_bytes(4) + arena_bytes(8) + arena_bytes(16) + arena_bytes(32) };
@@ -168,12 +167,11 @@ template <typename PX> struct lds {
 #endif
   PX Dy[65 * PY], Du[33 * PC], Dv[33 * PC];         // decided planes, index (y + 1) * pitch + x + 1
   PX cand_px[2016];                                 // a depth's CU while its split is being tried (depths 1..3)
-  int16_t cand_co[480];                             // ... its levels (depths 2, 3; depth 1's 1536 are in the workgroup's global scratch)
   cu4 cu[17 * 17];                                  // index (y4 + 1) * 17 + x4 + 1
   uint16_t tree[256], mtt[256];                     // split_tree / mode_type_tree per 4x4 (3 / 2 bits per depth, depths 0..4)
   uint32_t cur[NMODELS];                            // state->search_cabac models of the walk: state0 | state1 << 16
-  uint32_t pre[4][NMODELS];                         // ... as they stood when the depth's CU was entered
-  uint32_t work[4][NMODELS];                        // ... as the depth's CU leaves them when it is coded unsplit ([0]: scratch)
+  uint32_t work[3][NMODELS];                        // [L - 1], L = 1..3: the models the depth-L candidate starts from (written by the walk when it
+                                                    // posts the evaluation) and, adapted in place, leaves behind; [2] doubles as scratch for the 64x64 candidate
   uint32_t coder[NMODELS];                          // state->cabac models
   uint8_t rdoq_state[244];                          // CTX_STATE of the coder's models at the CTU's start (what uvg_rdoq prices with)
   uint16_t scan[1024 + 256 + 64 + 16];              // coefficient scans of the four square shapes
@@ -194,7 +192,7 @@ struct scratch {
   uint16_t save_px[6144];          // the whole D of a CTU while the 64x64 candidate is tried
   int16_t save_co[6144];
   cu4 save_cu[256];
-  int16_t cand_co1[1536];          // levels of the depth-1 (32x32) candidate CU
+  int16_t cand_co[2016];           // levels of the candidate CUs of depths 1..3 (cand_px_off)
   uint32_t save_tree[512];
   unsigned long long prof[4][32];     // CTU_PROFILE: 0 rough search, 1 refs + prediction, 2 residual + transforms + reconstruction, 3 RDOQ, 4 SSD,
                                    // 5 RD cost (bits), 6 park / unpark / model copies, 7 64x64 candidate, 8 coder pass, 9 load, 10 store, 11 total
@@ -1139,7 +1137,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
   const bool small = V->rq_cc != nullptr;        // the per-position cost arrays are in LDS (this wave's depth has them)
   double *CC = small ? V->rq_cc : W->cost_coeff, *CS = small ? V->rq_cs : W->cost_sig, *C0 = W->cost_coeff0;
 #define RQ_LD(p) (small ? *(p) : CTU_GLOAD(p))
-  double *cost_cg_sig = (double *)V->t0;         // (the residual / first-pass buffer: dead while a block is quantised; <= 64 groups)
+  double *cost_cg_sig = (double *)V->t1;         // (the transform's other buffer: dead while a block is quantised; <= 64 groups)
   const int cap_half = 1 << (E.q_bits - 1);
   // ---- every position: candidate, level-0 cost; the last candidate in scan order ----
 #if defined(__HIPCC__) && defined(CTU_PROFILE)
@@ -1437,7 +1435,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
   const bool small = V->rq_cc != nullptr;        // the per-position cost arrays are in LDS (this wave's depth has them)
   CTU_LDS double *const CCl = LDSP(double, V->rq_cc), *const CSl = LDSP(double, V->rq_cs);
   double *const CCg = W->cost_coeff, *const CSg = W->cost_sig;
-  double *cost_cg_sig = (double *)V->t0;         // (the residual / first-pass buffer: dead while a block is quantised; <= 64 groups)
+  double *cost_cg_sig = (double *)V->t1;         // (the transform's other buffer: dead while a block is quantised; <= 64 groups)
   const int cap_half = 1 << (E.q_bits - 1);
   const int32_t cap = 0x7fffffff - cap_half;
 #if defined(CTU_PROFILE)
@@ -1865,14 +1863,14 @@ template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<P
   PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); t0[e] = (int16_t)((int)Sp[r * sps + q] - (int)dst[r * dp + q]); }
   CTU_SYNC();
   fwd_pass(w, V->t0, V->t1, l2 - 1 + depth - 8);
-  fwd_pass(w, V->t1, V->t2, l2 + 6);
+  fwd_pass(w, V->t1, V->t0, l2 + 6);                     // (two buffers: the coefficients end up where the residual was)
   CTU_T1(J.W, 2); }
   const int qps = scaled_qp<PX>(J.P, color);
   CTU_T0();
   {
     // chroma blocks: state->c_lambda as uvg_quantize_lcu_residual replaces it (transform.c:1575)
     const double lambda = c ? J.P.c_lambda_tu : J.P.lambda;
-    rdoq_wave(S, J.W, V->t2, lv_of(V, color), w, color, cbf_u, qps, lambda, depth);
+    rdoq_wave(S, J.W, V->t0, lv_of(V, color), w, color, cbf_u, qps, lambda, depth);
   }
   CTU_SYNC();
   CTU_T1(J.W, 3);
@@ -1986,6 +1984,9 @@ template <typename PX> CTU_NOINLINE CTU_DEV void mark_deblocking(lds<PX> *S, int
   }
 }
 
+// regular bins a scan position spends, from its record (level in bits 0..15, "its sig flag is coded" in bit 29)
+CTU_DEV int rec_spend(uint32_t rec) { const uint32_t a = rec & 0xffffu; return (int)((rec >> 29) & 1u) + (a ? 1 + (a > 1 ? 2 : 0) : 0); }
+
 #if defined(__HIPCC__)
 // coeff_bits for a 4x4 block (one coefficient group): the shape the 4x4 leaves, their 8x8 areas' chroma and most of the coder
 // pass consist of.  Same bins and adaptation as the general function below, but nothing goes through memory: lane sp (0..15) holds
@@ -2069,7 +2070,7 @@ template <typename PX> CTU_DEV double coeff_bits4(lds<PX> *S, CTU_LDS uint32_t *
     double bits = 0;
     CTU_LDS uint32_t *mk = m;
     if (!update) {
-      mk = LDSP(uint32_t, S->work[0]);
+      mk = LDSP(uint32_t, S->work[2]);
       for (int i = M_LASTX; i < M_CBF_LUMA; ++i) mk[i] = m[i];
     }
     const int pos_last = scan[last], last_y = pos_last >> 2, last_x = pos_last & 3;
@@ -2115,7 +2116,6 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
   CTU_LDS uint32_t *recs = (CTU_LDS uint32_t *)(V->t0);       // t0 + t1: 1024 words, free while costs are counted
   CTU_LDS uint8_t *cgf = (CTU_LDS uint8_t *)V->cg_flag;                                   // per group (raster): has a level
   CTU_LDS int32_t *gtot = (CTU_LDS int32_t *)(V->rq_stage);   // per group (scan order): regular bins it would spend, bit 30: a level among k = 1..15
-  CTU_LDS uint8_t *const lv_spend = (CTU_LDS uint8_t *)V->lv_spend;
 #if defined(CTU_PROFILE)
   scratch *const W = S->prof_w;
   unsigned long long tq = __builtin_amdgcn_s_memtime();
@@ -2151,12 +2151,11 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
     const int spend = sig_coded + (a ? 1 + (a > 1 ? 2 : 0) : 0);
     recs[sp] = (uint32_t)(a > 0xffff ? 0xffff : a) | (uint32_t)ctx_sig << 16 | (uint32_t)ofs << 20 | (uint32_t)r4 << 25 | (uint32_t)r0 << 27 |
                (uint32_t)sig_coded << 29;
-    lv_spend[sp] = (uint8_t)spend;
   }
   WSYNC();
   for (int g = lane; g <= cg_last; g += 64) {
     int tot = 0;
-    for (int k = 0; k < 16; ++k) if (g * 16 + k <= last) tot += lv_spend[g * 16 + k];
+    for (int k = 0; k < 16; ++k) if (g * 16 + k <= last) tot += rec_spend(recs[g * 16 + k]);
     gtot[g] = (gtot[g] & (1 << 30)) | tot;
   }
   WSYNC();
@@ -2171,7 +2170,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
       if (rb - tot >= 4) { rb -= tot; continue; }
       for (int sp = (g == cg_last ? last : g * 16 + 15); sp >= g * 16; --sp) {
         if (rb < 4) { sw = sp; break; }
-        rb -= lv_spend[sp];
+        rb -= rec_spend(recs[sp]);
       }
       if (sw < 0 && rb < 4) sw = g * 16 - 1;          // ran out exactly at the group's end: everything below is bypass-coded
     }
@@ -2261,7 +2260,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
     if (!update) {
       // counting only: these bins still adapt their models WITHIN the block (the reference counts on a copy) -- work on a copy
       // of the few models involved (work[0] is nobody's: depth 0 has no unsplit candidate of its own)
-      mk = (CTU_LDS uint32_t *)S->work[0];
+      mk = (CTU_LDS uint32_t *)S->work[2];
       for (int i = 0; i < 4; ++i) mk[M_SIGGRP + i] = m[M_SIGGRP + i];
       for (int i = M_LASTX; i < M_CBF_LUMA; ++i) mk[i] = m[i];
     }
@@ -2362,8 +2361,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
   const int sep = n == 4;                                 // a 4x4 CU: its chroma belongs to the 8x8 area, carried by the fourth one
   const int has_chroma = N.has_chroma;
   if (to_cand) {
-    PAR_FOR(i, NMODELS) S->work[L][i] = S->pre[L][i];
-    LANE0 V->cur = S->work[L];
+    LANE0 V->cur = S->work[L - 1];             // (the walk put the CU's entry models there before posting the request)
   } else {
     LANE0 {
       V->cur = S->cur;
@@ -2388,7 +2386,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
   int rpy, rpc, kpy, kpc;
   if (to_cand) {
     ry = S->cand_px + cand_px_off(L, 0); ru = S->cand_px + cand_px_off(L, 1); rv = S->cand_px + cand_px_off(L, 2);
-    int16_t *const kb = L == 1 ? J.W->cand_co1 : S->cand_co - 1536;
+    int16_t *const kb = J.W->cand_co;
     ky = kb + cand_px_off(L, 0); ku = kb + cand_px_off(L, 1); kv = kb + cand_px_off(L, 2);
     rpy = kpy = n; rpc = kpc = cn;
   } else {
@@ -2460,8 +2458,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void unpark(lds<PX> *S, const job<PX
     PX *D = plane(S, color) + ((ly >> c) + 1) * pit + (lx >> c) + 1;
     int16_t *co = J.coeff + co_off(color) + (ly >> c) * spit + (lx >> c);
     const int off = cand_px_off(L, color);
-    if (L == 1) PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); D[r * pit + q] = S->cand_px[off + e]; co[r * spit + q] = CTU_GLOAD(&J.W->cand_co1[off + e]); }
-    else PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); D[r * pit + q] = S->cand_px[off + e]; co[r * spit + q] = S->cand_co[off - 1536 + e]; }
+    PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); D[r * pit + q] = S->cand_px[off + e]; co[r * spit + q] = CTU_GLOAD(&J.W->cand_co[off + e]); }
   }
   SERIAL {
     for (int yy = ly; yy < ly + n; yy += 4)
@@ -2507,7 +2504,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu64(lds<PX> *S, const job
   }
   CTU_SYNC();
   // the models are the CU's entry models and do not adapt (search_cabac.update is 0 on this path): bits only
-  copy_models(S->cur, S->pre[0]);
+  copy_models(S->cur, S->coder);                 // (the CTU's entry models: the coder's, untouched until its pass after the search)
   for (int i = 0; i < 4; ++i) {
     const int tx = x + (i & 1) * 32, ty = y + (i >> 1) * 32, lx = tx & 63, ly = ty & 63;
     PX *ry = S->Dy + (ly + 1) * PY + lx + 1, *ru = S->Du + ((ly >> 1) + 1) * PC + (lx >> 1) + 1, *rv = S->Dv + ((ly >> 1) + 1) * PC + (lx >> 1) + 1;
@@ -2538,8 +2535,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu64(lds<PX> *S, const job
           split_flag_bits(S, P, S->cur, 0, x, y, 0, 0, 64, 0, bits);
           double mode_bits = 0;
           {   // calc_mode_bits (search.c:988-1003): the luma mode on a copy of the models, the chroma mode without adaptation
-            for (int k = 0; k < NMODELS; ++k) S->work[0][k] = S->cur[k];
-            luma_mode_bits(S, S->work[0], 0, x, y, 0, 0, 64, mode, mode_bits);
+            for (int k = 0; k < NMODELS; ++k) S->work[2][k] = S->cur[k];
+            luma_mode_bits(S, S->work[2], 0, x, y, 0, 0, 64, mode, mode_bits);
             if (mode_chroma == mode) mode_bits += m_fbits(S->cur, M_CHROMA_PRED, 0);
             else mode_bits += 2.0 + m_fbits(S->cur, M_CHROMA_PRED, 1);
           }
@@ -2656,7 +2653,6 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
       const int x = N.x, y = N.y;
       CTU_SYNC();            // every lane holds its copy before lane 0 may reach the parent's bookkeeping and rewrite this entry
       if (x >= P.pic_w || y >= P.pic_h) { ret = 0; entering = 0; if (L == 0) break; --L; continue; }     // outside: nothing to code (search.c:1350)
-      if (L < 4) copy_models(S->pre[L], S->cur);          // (a 4x4 CU is never a candidate: nobody reads its entry models)
       const int inside = x + n <= P.pic_w && y + n <= P.pic_h;
       // check_can_use_intra (search.c:1257-1287)
       const int min_w = 64 >> P.depth_max;
@@ -2677,7 +2673,7 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
         ret = N.cost; entering = 0; if (L == 0) break; --L; continue;
       }
       SERIAL { N.type = can_intra ? CU_INTRA : CU_NOTSET; N.cost = CTU_MAX_DOUBLE; N.pending = can_intra; }
-      if (can_intra) post_eval(S, J, L);          // its own wave evaluates the CU unsplit ...
+      if (can_intra) { copy_models(S->work[L - 1], S->cur); post_eval(S, J, L); }          // its own wave evaluates the CU unsplit from these models ...
       // ... while the walk tries the split: its flag first (models from the CU's entry: cur still holds them)
       SERIAL {
         double split_bits = 0;
@@ -2724,14 +2720,14 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
     CTU_SYNC();
     if (L == 0 && ntype == CU_NOTSET && P.combine_intra_cus && N.x + 64 <= P.pic_w && N.y + 64 <= P.pic_h &&
         cu_at(S, 0, 0)->type == CU_INTRA && cu_at(S, 0, 0)->log2 == 5) {
-      copy_models(S->work[1], S->cur);                   // temp_cabac: the models after the split (search.c:2093); depth 1 is idle by now
+      copy_models(S->work[0], S->cur);                   // temp_cabac: the models after the split (search.c:2093); depth 1 is idle by now
       LANE0 S->vsel[CTU_WAVE] = 3;                       // the depth-1 scratch: 32x32 blocks
       CTU_SYNC();
       { CTU_T0();
       eval_cu64(S, J);
       CTU_T1(J.W, 7); }
       // post_search_cabac = the unadapted entry models; search_cabac = temp_cabac (:2140-2141)
-      copy_models(S->cur, S->work[1]);
+      copy_models(S->cur, S->work[0]);
       const bool split_wins64 = N.split_cost < N.cost;        // N.cost: the 64x64 CU's (eval_cu64 ends with a fence)
       CTU_SYNC();
       if (split_wins64) { restore64(S, J); SERIAL N.cost = N.split_cost; CTU_SYNC(); }
@@ -2746,7 +2742,7 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
       CTU_SYNC();
     } else {
       CTU_T0();
-      if (L > 0) copy_models(S->cur, S->work[L]);          // post_search_cabac: the models as the unsplit CU leaves them
+      if (L > 0) copy_models(S->cur, S->work[L - 1]);      // post_search_cabac: the models as the unsplit CU leaves them
       if (ntype != CU_NOTSET) unpark(S, J, L);
       CTU_T1(J.W, 6);
     }
@@ -2952,13 +2948,12 @@ template <typename PX> CTU_DEV void setup_waves(lds<PX> *S)
     const int rn = 4 * n + 8;
     V->refn = (int16_t)rn;
     V->top = (uint16_t *)a; V->left = V->top + rn; V->ftop = V->left + rn; V->fleft = V->ftop + rn; a += 4 * rn * 2;
-    V->t0 = (int16_t *)a; V->t1 = V->t0 + nn; V->t2 = V->t1 + nn; a += 3 * nn * 2;
+    V->t0 = (int16_t *)a; V->t1 = V->t0 + nn; a += 2 * nn * 2;
     V->lv0 = (int16_t *)a; V->lv1 = V->lv0 + nn; V->lv2 = V->lv1 + c2; a += (nn + 2 * c2) * 2;
     // the rough search's (satd, sad) per (mode, tile) -- 2 * 18 * tiles words -- fit the three transform buffers from 8x8 on, which
-    // idle until the mode is chosen; the coefficient bit count's per-position byte lives in t2 (RDOQ's input, dead by then)
+    // idle until the mode is chosen
     if (n >= 8) V->part = (uint32_t *)V->t0;
     else { V->part = (uint32_t *)a; a += 2 * 18 * tiles * 4; }
-    V->lv_spend = (uint8_t *)V->t2;
     a = S->arena + ((a - S->arena + 7) & ~7);
     if (n <= 8) { V->rq_cc = (double *)a; V->rq_cs = V->rq_cc + nn; }
     else V->rq_cc = V->rq_cs = nullptr;
