@@ -137,8 +137,10 @@ struct wctx {
   double *rq_cc, *rq_cs;                            // RDOQ per-position costs in LDS (nullptr: the depth uses the workgroup's global scratch)
   uint32_t *part;                                   // rough search: (satd, sad) per (listed mode, tile)
   uint32_t *cur;                                    // the models this wave's bit counting works on
-  double rq_stage[3 * 16];                          // RDOQ: costs of the coefficient group in flight
-  double rs_cand[3 + 24], rs_best_cost[2][3];      // rough search: costs of the survivors and of the listed modes; the survivors, double-buffered
+  union {                                           // a wave is in one phase at a time
+    double rq_stage[2 * 16];                        // RDOQ: costs of the coefficient group in flight (also the coefficient bit count's 64 group totals)
+    struct { double rs_cand[3 + 24], rs_best_cost[2][3]; };      // rough search: costs of the survivors and of the listed modes; the survivors, double-buffered
+  };
   double u_d0, u_d1;
   int32_t rq_i[16];
   int32_t rs_list[24], rs_best_mode[2][3];
@@ -168,7 +170,7 @@ template <typename PX> struct lds {
   PX Dy[65 * PY], Du[33 * PC], Dv[33 * PC];         // decided planes, index (y + 1) * pitch + x + 1
   PX cand_px[2016];                                 // a depth's CU while its split is being tried (depths 1..3)
   cu4 cu[17 * 17];                                  // index (y4 + 1) * 17 + x4 + 1
-  uint16_t tree[256], mtt[256];                     // split_tree / mode_type_tree per 4x4 (3 / 2 bits per depth, depths 0..4)
+  scratch *scr;                                     // the workgroup's global scratch (the split / mode-type trees per 4x4 live there)
   uint32_t cur[NMODELS];                            // state->search_cabac models of the walk: state0 | state1 << 16
   uint32_t work[3][NMODELS];                        // [L - 1], L = 1..3: the models the depth-L candidate starts from (written by the walk when it
                                                     // posts the evaluation) and, adapted in place, leaves behind; [2] doubles as scratch for the 64x64 candidate
@@ -194,6 +196,7 @@ struct scratch {
   cu4 save_cu[256];
   int16_t cand_co[2016];           // levels of the candidate CUs of depths 1..3 (cand_px_off)
   uint32_t save_tree[512];
+  uint16_t tree[256], mtt[256];    // split_tree / mode_type_tree per 4x4 of the decided CTU (3 / 2 bits per depth, depths 0..4)
   unsigned long long prof[4][32];     // CTU_PROFILE: 0 rough search, 1 refs + prediction, 2 residual + transforms + reconstruction, 3 RDOQ, 4 SSD,
                                    // 5 RD cost (bits), 6 park / unpark / model copies, 7 64x64 candidate, 8 coder pass, 9 load, 10 store, 11 total
 };
@@ -2342,8 +2345,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void fill_cu(lds<PX> *S, int lx, int
     for (int xx = lx; xx < lx + n; xx += 4) {
       cu4 *c = cu_at(S, xx, yy);
       c->type = CU_INTRA; c->log2 = (uint8_t)l2; c->log2_c = (uint8_t)log2_c; c->mode = (int8_t)mode; c->mode_chroma = (int8_t)mode_chroma;
-      S->tree[(yy >> 2) * 16 + (xx >> 2)] = (uint16_t)split_tree;
-      S->mtt[(yy >> 2) * 16 + (xx >> 2)] = (uint16_t)mtt;
+      S->scr->tree[(yy >> 2) * 16 + (xx >> 2)] = (uint16_t)split_tree;
+      S->scr->mtt[(yy >> 2) * 16 + (xx >> 2)] = (uint16_t)mtt;
     }
 }
 
@@ -2493,7 +2496,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu64(lds<PX> *S, const job
     const PX *D = plane(S, color) + pit + 1;
     PAR_FOR(e, w * w) { W->save_px[co_off(color) + e] = D[(e >> l2) * pit + (e & (w - 1))]; W->save_co[co_off(color) + e] = CTU_GLOAD(&J.coeff[co_off(color) + e]); }
   }
-  PAR_FOR(e, 256) { W->save_cu[e] = *cu_at(S, (e & 15) * 4, (e >> 4) * 4); W->save_tree[e] = S->tree[e]; W->save_tree[256 + e] = S->mtt[e]; }
+  PAR_FOR(e, 256) { W->save_cu[e] = *cu_at(S, (e & 15) * 4, (e >> 4) * 4); W->save_tree[e] = CTU_GLOAD(&W->tree[e]); W->save_tree[256 + e] = CTU_GLOAD(&W->mtt[e]); }
   CTU_SYNC();
   const int mode = cu_at(S, 0, 0)->mode, mode_chroma = cu_at(S, 0, 0)->mode_chroma;
   CTU_SYNC();
@@ -2570,7 +2573,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void restore64(lds<PX> *S, const job
     PX *D = plane(S, color) + pit + 1;
     PAR_FOR(e, w * w) { D[(e >> l2) * pit + (e & (w - 1))] = (PX)CTU_GLOAD(&W->save_px[co_off(color) + e]); J.coeff[co_off(color) + e] = CTU_GLOAD(&W->save_co[co_off(color) + e]); }
   }
-  PAR_FOR(e, 256) { *cu_at(S, (e & 15) * 4, (e >> 4) * 4) = W->save_cu[e]; S->tree[e] = (uint16_t)W->save_tree[e]; S->mtt[e] = (uint16_t)W->save_tree[256 + e]; }
+  PAR_FOR(e, 256) { *cu_at(S, (e & 15) * 4, (e >> 4) * 4) = W->save_cu[e]; W->tree[e] = (uint16_t)CTU_GLOAD(&W->save_tree[e]); W->mtt[e] = (uint16_t)CTU_GLOAD(&W->save_tree[256 + e]); }
   CTU_SYNC();
 }
 
@@ -2839,7 +2842,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void load_ctu(lds<PX> *S, const job<
   const params &P = J.P;
   const int x = J.x, y = J.y, W = P.pic_w, H = P.pic_h;
   BLK_FOR(i, 17 * 17) { cu4 z = {0, 0, 0, 0, 0, 0, 0, 0}; S->cu[i] = z; }
-  BLK_FOR(i, 256) { S->tree[i] = 0; S->mtt[i] = 0; }
+  BLK_FOR(i, 256) { J.W->tree[i] = 0; J.W->mtt[i] = 0; }
+  if (BLK_TID == 0) S->scr = J.W;
   BLK_SYNC();
   BLK_FOR(i, 33) {
     // i = 0: the corner, 1..16 the row above, 17..32 the column to the left
@@ -2929,8 +2933,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void store_ctu(lds<PX> *S, const job
       s.luma_edges = c->luma_edges; s.chroma_edges = c->chroma_edges; s.type = c->type; s.cbf = c->cbf; s.qp = (int8_t)P.qp;
       s.log2_width = s.log2_height = c->log2; s.log2_chroma_width = s.log2_chroma_height = c->log2_c;
       s.mv[0][0] = (int32_t)((uint32_t)(uint8_t)c->mode | (uint32_t)(uint8_t)c->mode_chroma << 8);
-      s.mv[0][1] = (int32_t)S->tree[e];
-      s.mv[1][0] = (int32_t)S->mtt[e];
+      s.mv[0][1] = (int32_t)CTU_GLOAD(&J.W->tree[e]);
+      s.mv[1][0] = (int32_t)CTU_GLOAD(&J.W->mtt[e]);
       J.cu_tab[((y + ly) >> 2) * J.cu_stride + ((x + lx) >> 2)] = s;
     }
   }

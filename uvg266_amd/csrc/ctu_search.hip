@@ -35,7 +35,7 @@ struct launch_args {
 };
 
 template <typename PX>
-__global__ void __launch_bounds__(256, 3) ctu_search_kernel(launch_args A)
+__global__ void __launch_bounds__(256, 4) ctu_search_kernel(launch_args A)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   ctu::lds<PX> *S = reinterpret_cast<ctu::lds<PX> *>(smem);
