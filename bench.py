@@ -586,7 +586,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6, help="timed steps; a step is one group of --in-flight pictures through the closed loop")
     ap.add_argument("--warmup", type=int, default=2, help="untimed steps")
-    ap.add_argument("--in-flight", type=int, default=160, help="pictures per step = per uvghip_ctu_plan_run launch (the reference's --owf)")
+    ap.add_argument("--in-flight", type=int, default=224, help="pictures per step = per uvghip_ctu_plan_run launch (the reference's --owf)")
     ap.add_argument("--groups", type=int, default=2, help="launches in flight at a time, each on its own stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-open-loop", action="store_true", help="skip the open-loop kernel-path measurement (previous rounds' headline)")
