@@ -132,6 +132,40 @@ void ORC_FN(cabac_sim_eps)(uint32_t bin_values, int num_bins)               /* u
   c->bits_left -= num_bins;
   if (c->bits_left < 12) sim_write(c);
 }
+void ORC_FN(cabac_sim_start)(void)                                           /* uvg_cabac_start (cabac.c:63-72) */
+{
+  orc_cabac_sim *c = &ORC_FN(cabac_sim);
+  c->low = 0; c->range = 510; c->bits_left = 23; c->num_buffered_bytes = 0; c->buffered_byte = 0xff; c->out_len = 0;
+}
+/* the end of a substream (encoderstate.c:925-938): end_of_sub_stream_one_bit = uvg_cabac_encode_bin_trm(1) (cabac.c:179-199),
+ * uvg_cabac_finish (:149-174), a one bit and the zero bits up to the byte boundary */
+void ORC_FN(cabac_sim_row_end)(void)
+{
+  orc_cabac_sim *c = &ORC_FN(cabac_sim);
+  c->range -= 2;
+  c->low += c->range;
+  c->low <<= 7;
+  c->range = 2 << 7;
+  c->bits_left -= 7;
+  if (c->bits_left < 12) sim_write(c);
+  if (c->low >> (32 - c->bits_left)) {
+    sim_put_byte(c, c->buffered_byte + 1);
+    while (c->num_buffered_bytes > 1) { sim_put_byte(c, 0); c->num_buffered_bytes--; }
+    c->low -= 1u << (32 - c->bits_left);
+  } else {
+    if (c->num_buffered_bytes > 0) sim_put_byte(c, c->buffered_byte);
+    while (c->num_buffered_bytes > 1) { sim_put_byte(c, 0xff); c->num_buffered_bytes--; }
+  }
+  /* uvg_bitstream_put(stream, low >> 8, 24 - bits_left), then the one bit, then zeros to the boundary */
+  uint32_t acc = 0;
+  int nacc = 0;
+  const int nb = 24 - c->bits_left;
+  const uint32_t v = c->low >> 8;
+  for (int i = nb - 1; i >= 0; --i) { acc = (acc << 1) | ((v >> i) & 1u); if (++nacc == 8) { sim_put_byte(c, acc); acc = 0; nacc = 0; } }
+  acc = (acc << 1) | 1u; if (++nacc == 8) { sim_put_byte(c, acc); acc = 0; nacc = 0; }
+  if (nacc) sim_put_byte(c, acc << (8 - nacc));
+}
+
 /* uvg_cabac_write_coeff_remain (cabac.c:318-354): the bins, not their count */
 static void sim_coeff_remain(uint32_t remainder, uint32_t rice, unsigned cutoff)
 {

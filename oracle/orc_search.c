@@ -132,6 +132,8 @@ extern orc_cabac_sim ORC_FN(cabac_sim);
 void ORC_FN(cabac_sim_bin)(int state, int bin);
 void ORC_FN(cabac_sim_ep)(uint32_t bin);
 void ORC_FN(cabac_sim_eps)(uint32_t bin_values, int num_bins);
+void ORC_FN(cabac_sim_start)(void);
+void ORC_FN(cabac_sim_row_end)(void);
 static void fbits_update(s_cabac *cb, int c, int bin, double *bits)
 {
   *bits += ctx_fbits(&cb->m, c, bin);
@@ -1369,4 +1371,124 @@ ORC_EXPORT long ORC_FN(encode_picture_ctus)(const orc_search_params *p, const ui
   }
   free(f.cua); free(st);
   return total;
+}
+
+
+/* ---- the whole slice data: every WPP row's substream (encoderstate.c:862-939) -------------------------------------------------- */
+typedef struct { uint16_t s0[2], s1[2]; uint8_t rate[2]; } sao_models2;      /* sao_merge_flag_model, sao_type_idx_model */
+static void sao_models2_init(sao_models2 *m, int qp)
+{
+  for (int i = 0; i < 2; ++i) {
+    const int v = k_ctx_init_sao[2][i];
+    const int slope = (v >> 3) - 4, offset = ((v & 7) * 18) + 1;
+    int s = ((slope * (qp - 16)) >> 1) + offset;
+    s = s < 1 ? 1 : (s > 127 ? 127 : s);
+    m->s0[i] = (uint16_t)((s << 8) & 0x7fe0); m->s1[i] = (uint16_t)((s << 8) & 0x7ffe);
+    m->rate[i] = k_ctx_init_sao[3][i];
+  }
+}
+static void sao_bin(sao_models2 *m, int c, int bin)                          /* CABAC_BIN on one of the two SAO models */
+{
+  ORC_FN(cabac_sim_bin)((m->s0[c] + m->s1[c]) >> 8, bin);
+  const int r0 = m->rate[c] >> 4, r1 = m->rate[c] & 15;
+  m->s0[c] = (uint16_t)(m->s0[c] - ((m->s0[c] >> r0) & 0x7fe0u));
+  m->s1[c] = (uint16_t)(m->s1[c] - ((m->s1[c] >> r1) & 0x7ffeu));
+  if (bin) { m->s0[c] = (uint16_t)(m->s0[c] + ((0x7fffu >> r0) & 0x7fe0u)); m->s1[c] = (uint16_t)(m->s1[c] + ((0x7fffu >> r1) & 0x7ffeu)); }
+}
+/* encode_sao_color (encoderstate.c:523-573); info: sao_info_t as 17 ints (type, eo_class, ddistortion, merge_left, merge_up,
+ * band_position[2], offsets[10]) */
+static void encode_sao_color(sao_models2 *m, const int32_t *info, int color)
+{
+  const int type = info[0], off = color == 2 ? 5 : 0;
+  const int max_off = (1 << ((ORC_BIT_DEPTH < 10 ? ORC_BIT_DEPTH : 10) - 5)) - 1;
+  if (color != 2) {
+    sao_bin(m, 1, type != 0);
+    if (type == 1) ORC_FN(cabac_sim_ep)(0);
+    else if (type == 2) ORC_FN(cabac_sim_ep)(1);
+  }
+  if (type == 0) return;
+  for (int i = 1; i <= 4; ++i) {                                              /* uvg_cabac_write_unary_max_symbol_ep (cabac.c:388-413) */
+    unsigned symbol = (unsigned)abs(info[7 + i + off]);
+    const int code_last = (unsigned)max_off > symbol;
+    ORC_FN(cabac_sim_ep)(symbol ? 1 : 0);
+    if (!symbol) continue;
+    while (--symbol) ORC_FN(cabac_sim_ep)(1);
+    if (code_last) ORC_FN(cabac_sim_ep)(0);
+  }
+  if (type == 1) {
+    for (int i = 1; i <= 4; ++i) if (info[7 + i + off] != 0) ORC_FN(cabac_sim_ep)(info[7 + i + off] < 0 ? 1 : 0);
+    ORC_FN(cabac_sim_eps)((uint32_t)info[5 + (color == 2 ? 1 : 0)], 5);
+  } else if (color != 2) {
+    ORC_FN(cabac_sim_eps)((uint32_t)info[1], 2);
+  }
+}
+
+/*
+ * sao: per CTU the two sao_info_t (34 ints; NULL = SAO off).  Out: every row's substream, emulation prevention applied
+ * (uvg_bitstream_put_byte, bitstream.c:215-226), rows concatenated, row_off[rows + 1]; after[ctu] (optional): the models when the
+ * CTU is coded.  The slice data of the picture is exactly these bytes.
+ */
+ORC_EXPORT long ORC_FN(encode_picture_rows)(const orc_search_params *p, const uint8_t *cu, const int16_t *coeff, const int32_t *sao,
+                                            uint8_t *bytes_out, long bytes_cap, int64_t *row_off, orc_models *after)
+{
+  fbits_init();
+  const int W = p->pic_w, H = p->pic_h, wc = (W + 63) / 64, hc = (H + 63) / 64, cu_stride = wc * 16;
+  s_frame f = {p, (s_cu *)calloc((size_t)cu_stride * hc * 16, sizeof(s_cu)), cu_stride};
+  for (int j = 0; j < hc * 16; ++j)
+    for (int i = 0; i < cu_stride; ++i) {
+      s_cu *c = &f.cua[j * cu_stride + i];
+      const uint8_t *o = &cu[((size_t)j * cu_stride + i) * 20];
+      c->type = o[0]; c->log2_w = o[1]; c->log2_h = o[2]; c->log2_cw = o[3]; c->log2_ch = o[4]; c->cbf = o[5]; c->mode = (int8_t)o[6];
+      c->mode_chroma = (int8_t)o[7]; c->luma_deblocking = o[8]; c->chroma_deblocking = o[9]; c->qp = o[10];
+      memcpy(&c->split_tree, o + 12, 4); memcpy(&c->mode_type_tree, o + 16, 4);
+    }
+  s_state *st = (s_state *)calloc(1, sizeof(s_state));
+  st->p = p;
+  orc_cabac_sim *sim = &ORC_FN(cabac_sim);
+  orc_models *row_m = (orc_models *)calloc((size_t)hc, sizeof(orc_models));
+  sao_models2 *row_s = (sao_models2 *)calloc((size_t)hc, sizeof(sao_models2));
+  long total = 0;
+  row_off[0] = 0;
+  for (int cy = 0; cy < hc; ++cy) {
+    s_cabac cb;
+    sao_models2 sm;
+    if (cy == 0) { models_init(&cb.m, p->qp, 2); sao_models2_init(&sm, p->qp); }
+    else { cb.m = row_m[cy - 1]; sm = row_s[cy - 1]; }
+    cb.update = 1;
+    sim->on = 2; sim->shifts = 0; sim->regular_fbits = 0.0;
+    ORC_FN(cabac_sim_start)();
+    for (int cx = 0; cx < wc; ++cx) {
+      const int k = cy * wc + cx;
+      if (sao) {                                                              /* encode_sao (encoderstate.c:593-608) */
+        const int32_t *l = sao + (size_t)k * 34, *c = l + 17;
+        if (cx > 0) sao_bin(&sm, 0, l[3]);
+        if (cy > 0 && !l[3]) sao_bin(&sm, 0, l[4]);
+        if (!l[3] && !l[4]) { encode_sao_color(&sm, l, 0); encode_sao_color(&sm, c, 1); encode_sao_color(&sm, c, 2); }
+      }
+      const int16_t *co = &coeff[(size_t)k * 6144];
+      s_loc start_loc;
+      loc_ctor(&start_loc, cx * 64, cy * 64, 64, 64);
+      s_tree tree = {0, MODE_TYPE_ALL, 0, 0, 0, 0};
+      g_tree_bits = 0.0;
+      encode_coding_tree(&f, st, &cb, co, co + 4096, co + 4096 + 1024, &start_loc, &start_loc, tree, 1);
+      if (after) after[k] = cb.m;
+      if (cx == 0) { row_m[cy] = cb.m; row_s[cy] = sm; }                      /* the next row's start (encoderstate.c:966-975) */
+    }
+    ORC_FN(cabac_sim_row_end)();
+    sim->on = 0;
+    int zeros = 0;                                                            /* emulation prevention */
+    for (size_t i = 0; i < sim->out_len; ++i) {
+      const uint8_t b = sim->out[i];
+      if (zeros == 2 && b < 4) { if (total >= bytes_cap) goto fail; bytes_out[total++] = 3; zeros = 0; }
+      zeros = b == 0 ? zeros + 1 : 0;
+      if (total >= bytes_cap) goto fail;
+      bytes_out[total++] = b;
+    }
+    row_off[cy + 1] = total;
+  }
+  free(f.cua); free(st); free(row_m); free(row_s);
+  return total;
+fail:
+  free(f.cua); free(st); free(row_m); free(row_s);
+  return -1;
 }

@@ -132,6 +132,30 @@ void __wrap_uvg_bitstream_put_byte(bitstream_t *const stream, const uint32_t dat
   __real_uvg_bitstream_put_byte(stream, data);
 }
 
+/* the end of a WPP row's substream (src/encoderstate.c:921-938): end_of_sub_stream_one_bit, uvg_cabac_finish, a one bit and
+ * the alignment -- after that the row's stream holds the whole substream (emulation prevention included). */
+static int g_row_end_pending, g_last_coded_y;
+void __real_uvg_cabac_finish(cabac_data_t *const data);
+void __wrap_uvg_cabac_finish(cabac_data_t *const data)
+{
+  g_row_end_pending = 1;
+  __real_uvg_cabac_finish(data);
+}
+void __real_uvg_bitstream_align_zero(bitstream_t *const stream);
+void __wrap_uvg_bitstream_align_zero(bitstream_t *const stream)
+{
+  __real_uvg_bitstream_align_zero(stream);
+  if (!g_row_end_pending) return;
+  g_row_end_pending = 0;
+  static uint8_t buf[1 << 22];
+  size_t n = 0;
+  for (const uvg_data_chunk *c = stream->first; c; c = c->next) { if (n + c->len > sizeof buf) break; memcpy(buf + n, c->data, c->len); n += c->len; }
+  int32_t meta[2] = {g_last_coded_y / 64, (int32_t)stream->len};
+  rec_begin("row", 2);
+  rec_arr(A_I32, meta, 2);
+  rec_arr(A_U8, buf, n);
+}
+
 void __real_uvg_encode_coding_tree(encoder_state_t *const state, lcu_coeff_t *coeff, enum uvg_tree_type tree_type, const cu_loc_t *const cu_loc,
                                    const cu_loc_t *const chroma_loc, split_tree_t split_tree, bool has_chroma);
 void __wrap_uvg_encode_coding_tree(encoder_state_t *const state, lcu_coeff_t *coeff, enum uvg_tree_type tree_type, const cu_loc_t *const cu_loc,
@@ -147,6 +171,7 @@ void __wrap_uvg_encode_coding_tree(encoder_state_t *const state, lcu_coeff_t *co
   int64_t full[10];        /* the arithmetic coder's whole state before / after: low, range, bits_left, num_buffered_bytes, buffered_byte */
   full[0] = state->cabac.low; full[1] = state->cabac.range; full[2] = state->cabac.bits_left; full[3] = state->cabac.num_buffered_bytes; full[4] = state->cabac.buffered_byte;
   g_tree_n = 0;
+  g_last_coded_y = cu_loc->y;
   __real_uvg_encode_coding_tree(state, coeff, tree_type, cu_loc, chroma_loc, split_tree, has_chroma);
   const int n_bytes = g_tree_n;
   g_tree_n = -1;

@@ -48,8 +48,9 @@ def run(W, H, depth, qp, t, tag):
     recs = read_records(out + ".bin")
     S = [r for n, r in recs if n == "search"]
     Cd = [r for n, r in recs if n == "coded"]
-    global SAO, FINAL
+    global SAO, FINAL, ROWS
     SAO = [r for n, r in recs if n == "sao"]
+    ROWS = [r for n, r in recs if n == "row"]
     FINAL = [r for n, r in recs if n == "final"][0]
     src_crc = zlib.crc32(y.tobytes() + u.tobytes() + v.tobytes())
     bitstream = np.frombuffer(open(out + ".266", "rb").read(), np.uint8)
@@ -88,6 +89,10 @@ def sao_items(W, H, Cd, px):
         chunks[k] = c[6].tobytes()
     TREE_OFF = np.concatenate([[0], np.cumsum([len(b) for b in chunks])]).astype(np.int64)
     TREE_BYTES = np.frombuffer(b"".join(chunks), np.uint8)
+    global ROW_BYTES, ROW_OFF
+    assert len(ROWS) == hc and [int(r[0][0]) for r in ROWS] == list(range(hc)) and all(int(r[0][1]) == len(r[1]) for r in ROWS)
+    ROW_OFF = np.concatenate([[0], np.cumsum([len(r[1]) for r in ROWS])]).astype(np.int64)      # the WPP substreams, row by row
+    ROW_BYTES = np.concatenate([r[1] for r in ROWS])
     final = [FINAL[1].reshape(H, W), FINAL[2].reshape(H // 2, W // 2), FINAL[3].reshape(H // 2, W // 2)]
     return info, models, snap, final
 
@@ -130,7 +135,7 @@ def full(W, H, depth, qp, t=0):
     info, sm, snap, final = sao_items(W, H, Cd, px)
     np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_ctu_{tag}.npz"), meta=meta, lam=S[0][1], src_crc=np.uint32(src_crc), models=models,
                         cu=cu, trees=trees, rec_y=rec[0], rec_u=rec[1], rec_v=rec[2], coeff=coeff, bitstream=bs,
-                        sao=info, sao_models=sm, coder=CODER, coder_state=CODER_STATE, tree_bytes=TREE_BYTES, tree_off=TREE_OFF, snap_y=snap[0], snap_u=snap[1], snap_v=snap[2], final_y=final[0], final_u=final[1], final_v=final[2])
+                        sao=info, sao_models=sm, coder=CODER, coder_state=CODER_STATE, tree_bytes=TREE_BYTES, tree_off=TREE_OFF, row_bytes=ROW_BYTES, row_off=ROW_OFF, snap_y=snap[0], snap_u=snap[1], snap_v=snap[2], final_y=final[0], final_u=final[1], final_v=final[2])
     print("wrote", tag, len(S), "CTUs")
 
 
@@ -155,7 +160,8 @@ def crcs(W, H, depth, qp, t=0):
         fcrc[k] = zlib.crc32(blk(snap)), zlib.crc32(blk(final))
     np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_ctucrc_{tag}.npz"), meta=meta, lam=S[0][1], src_crc=np.uint32(src_crc), crc=out,
                         bitstream_crc=np.uint32(zlib.crc32(bs.tobytes())), bitstream_len=np.int64(len(bs)), sao=info, sao_models=sm, filter_crc=fcrc, coder=CODER, coder_state=CODER_STATE,
-                        tree_crc=np.array([zlib.crc32(TREE_BYTES[TREE_OFF[k]:TREE_OFF[k + 1]].tobytes()) for k in range(hc * wc)], np.uint32), tree_off=TREE_OFF)
+                        tree_crc=np.array([zlib.crc32(TREE_BYTES[TREE_OFF[k]:TREE_OFF[k + 1]].tobytes()) for k in range(hc * wc)], np.uint32), tree_off=TREE_OFF,
+                        row_crc=np.array([zlib.crc32(ROW_BYTES[ROW_OFF[k]:ROW_OFF[k + 1]].tobytes()) for k in range(hc)], np.uint32), row_off=ROW_OFF)
     print("wrote crc", tag, len(S), "CTUs")
 
 
