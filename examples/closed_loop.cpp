@@ -95,6 +95,10 @@ int main(int argc, char **argv)
   for (int i = 0; i < n; ++i) HIP_OK(hipMemcpyAsync(dsrc[i], src[i].data(), psz, hipMemcpyHostToDevice, st));
   UVG_OK(uvghip_loop_plan_run(plan, st));
   std::vector<uint8_t> out(psz);
+  const uint8_t *d_rows; const int32_t *d_row_bytes; int row_cap, n_rows;
+  UVG_OK(uvghip_loop_plan_slice_data(plan, &d_rows, &d_row_bytes, &row_cap, &n_rows));
+  std::vector<int32_t> row_bytes((size_t)n * n_rows);
+  HIP_OK(hipMemcpyAsync(row_bytes.data(), d_row_bytes, row_bytes.size() * 4, hipMemcpyDeviceToHost, st));
   const int32_t *d_info;
   UVG_OK(uvghip_loop_plan_results(plan, &d_info, nullptr));
   std::vector<int32_t> info((size_t)n * ctus * 34);
@@ -104,7 +108,17 @@ int main(int argc, char **argv)
     HIP_OK(hipStreamSynchronize(st));
     int types[3] = {0, 0, 0};
     for (int k = 0; k < ctus; ++k) types[info[((size_t)i * ctus + k) * 34] % 3]++;
-    printf("picture %d src %08x out %08x sao luma none/band/edge %d/%d/%d\n", i, crc32(src[i].data(), psz), crc32(out.data(), psz), types[0], types[1], types[2]);
+    // the slice data: the rows' substreams one after the other (what follows the slice header in the .266)
+    uint32_t scrc = 0; size_t sbytes = 0;
+    std::vector<uint8_t> row;
+    for (int r = 0; r < n_rows; ++r) {
+      const int nb = row_bytes[(size_t)i * n_rows + r];
+      row.resize(nb);
+      HIP_OK(hipMemcpy(row.data(), d_rows + ((size_t)i * n_rows + r) * row_cap, nb, hipMemcpyDeviceToHost));
+      scrc = crc32(row.data(), nb, scrc); sbytes += nb;
+    }
+    printf("picture %d src %08x out %08x sao luma none/band/edge %d/%d/%d slice data %zu bytes crc %08x\n", i, crc32(src[i].data(), psz),
+           crc32(out.data(), psz), types[0], types[1], types[2], sbytes, scrc);
   }
   if (repeats > 0) {
     HIP_OK(hipStreamSynchronize(st));

@@ -884,7 +884,31 @@ UVGHIP_API int uvghip_loop_plan_run(uvghip_loop_plan_t *plan, void *stream);
 UVGHIP_API int uvghip_loop_plan_run_search(uvghip_loop_plan_t *plan, void *stream);
 UVGHIP_API int uvghip_loop_plan_run_filters(uvghip_loop_plan_t *plan, void *stream);
 UVGHIP_API int uvghip_loop_plan_results(const uvghip_loop_plan_t *plan, const int32_t **sao_info, const uint16_t **sao_models);
+/* The plan also codes the slice data (uvghip_encode_slice_rows, section 6) as the last thing of a run: device pointers to the rows'
+ * bytes (row r of picture p at rows + (p * n_rows + r) * row_cap) and their lengths ([picture][row]). */
+UVGHIP_API int uvghip_loop_plan_slice_data(const uvghip_loop_plan_t *plan, const uint8_t **rows, const int32_t **row_bytes, int *row_cap,
+                                           int *n_rows);
 UVGHIP_API void uvghip_loop_plan_destroy(uvghip_loop_plan_t *plan);
+
+/* ------------------- (6) the slice data: the arithmetic coder on the device -------------------------------------------- */
+
+/* replaces: encoder_state_worker_encode_lcu_bitstream for every CTU of n all-intra pictures (src/encoderstate.c:862-939):
+ * encode_sao, uvg_encode_coding_tree with uvg_encode_coeff_nxn, through the arithmetic coder of src/cabac.c, one substream per
+ * WPP row (uvg_cabac_start ... end_of_sub_stream_one_bit, uvg_cabac_finish, alignment), emulation prevention applied
+ * (uvg_bitstream_put_byte).  pictures: HOST array of the descriptors the search ran on (cu, cu_stride, coeff, models are read --
+ * the row's start models are the third model set of the first CTU of the row above); sao_info / sao_models: the decisions and
+ * models of uvghip_sao_decide_pictures ([picture][ctu][34] / [6]; both NULL = SAO off: no SAO syntax).
+ * out: device buffer, row r of picture p at out + (p * rows + r) * row_cap; row_bytes[p * rows + r] = its length (if larger than
+ * row_cap the buffer was too small and the row is truncated: 2 * 64 * pic_w * 1.5 bytes per row is a safe capacity).
+ * The slice data of picture p is its rows one after the other; entry points = the row lengths.  One wave per row.
+ * workspace: uvghip_slice_rows_workspace_bytes(n_pictures) of device memory; it receives the picture table (a synchronous
+ * upload).  uvghip_slice_rows_prepare does only that; a later uvghip_encode_slice_rows with pictures == NULL reuses the table in the
+ * workspace and just enqueues the kernel. */
+UVGHIP_API size_t uvghip_slice_rows_workspace_bytes(int n_pictures);
+UVGHIP_API int uvghip_slice_rows_prepare(const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, int n_pictures, void *workspace);
+UVGHIP_API int uvghip_encode_slice_rows(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures,
+                                        int n_pictures, const int32_t *sao_info, const uint16_t *sao_models, void *workspace,
+                                        uint8_t *out, int row_cap, int32_t *row_bytes, void *stream);
 
 #ifdef __cplusplus
 }

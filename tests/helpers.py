@@ -531,6 +531,23 @@ def oracle_encode_rows(orc, depth, prm, res, sao):
     return out[:n].copy(), off, after
 
 
+def oracle_encode_rows_no_sao(orc, depth, prm, res):
+    """oracle_encode_rows with SAO off: no SAO syntax in the substreams."""
+    W, H = prm.pic_w, prm.pic_h
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    cu = np.zeros((hc * 16, wc * 16, 20), np.uint8)
+    cu[:, :, :11] = res["cu"]
+    cu[:, :, 12:] = np.ascontiguousarray(res["trees"].astype(np.uint32)).view(np.uint8).reshape(hc * 16, wc * 16, 8)
+    co = np.ascontiguousarray(res["coeff"], np.int16)
+    cap = 4096 + wc * hc * 20000
+    out, off, after = np.zeros(cap, np.uint8), np.zeros(hc + 1, np.int64), np.zeros((wc * hc, MODELS_BYTES), np.uint8)
+    fn = orc.fn(depth, "encode_picture_rows")
+    fn.restype = ctypes.c_long
+    n = fn(ctypes.byref(prm), ptr(cu), ptr(co), None, ptr(out), ctypes.c_long(cap), ptr(off), ptr(after))
+    assert n >= 0
+    return out[:n].copy(), off, after
+
+
 def filter_crcs(res, W, H):
     """Per CTU CRC-32 of (the block the SAO decision saw, the block of the final picture), Y + U + V, as
     tools/refcheck/make_ctu_goldens.py computes them (filter_crc)."""

@@ -1,0 +1,63 @@
+"""uvghip_encode_slice_rows -- the arithmetic coder on the device: from the search's outputs and the SAO decisions in device memory
+to the slice data (one substream per WPP row) -- against the .266 the real encoder wrote (tests/golden/ref_ctu*.npz: row_bytes /
+row_crc, row_off; tools/refcheck/ctu_dump.c records every row's stream when its substream ends)."""
+import zlib
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctucrc_1920x1080_8_qp22", "ref_ctucrc_1920x1080_10_qp27",
+                                  "ref_ctucrc_3840x2160_10_qp22"])
+def test_slice_data_equals_the_encoders(hip, name):
+    import torch
+    from uvg266_amd import api
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    prm = H.search_params(W, Hh, qp)
+    cl = api.ClosedLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in (y, u, v))])
+    cl.run()                                  # search -> filters -> slice data, one call
+    out, nbytes = cl.slice_data()
+    torch.cuda.synchronize()
+    nb = nbytes.cpu().numpy()[0]
+    assert (nb <= out.shape[2]).all()
+    assert np.array_equal(np.concatenate([[0], np.cumsum(nb)]), g["row_off"])
+    rows = [out[0, r, :nb[r]].cpu().numpy() for r in range(len(nb))]
+    if "row_bytes" in g.files:
+        data = np.concatenate(rows)
+        assert np.array_equal(data, g["row_bytes"])
+        assert g["bitstream"].tobytes().find(data.tobytes()) > 0          # ... and that is the slice data inside the encoder's .266
+    else:
+        assert np.array_equal(np.array([zlib.crc32(r.tobytes()) for r in rows], np.uint32), g["row_crc"])
+
+
+def test_standalone_entry_point_and_sao_off(hip, orc):
+    """uvghip_encode_slice_rows called on its own (not through the loop plan), with and without SAO syntax, against the oracle's
+    row coder on the same hand-over."""
+    import torch
+    from uvg266_amd import api, layout
+    W, Hh, depth, qp = 200, 136, 8, 32
+    prm = H.search_params(W, Hh, qp)
+    y, u, v = layout.synthetic_yuv420(W, Hh, 5, depth)
+    cl = api.ClosedLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in (y, u, v))])
+    cl.run_search()
+    torch.cuda.synchronize()
+    ry, ru, rv = (t.cpu().numpy() for t in cl.rec[0])
+    res = H.search_result_from_device_layout(W, Hh, ry, ru, rv, cl.cu[0].cpu().numpy().reshape(-1).view(H.SCU_NP), cl.coeff[0].cpu().numpy(),
+                                             cl.models[0].cpu().numpy().view(np.uint32))
+    cl.run_filters()
+    info, _ = cl.results()
+    for sao in (True, False):
+        out, nbytes = cl.encode_rows(sao=sao)
+        torch.cuda.synchronize()
+        nb = nbytes.cpu().numpy()[0]
+        got = np.concatenate([out[0, r, :nb[r]].cpu().numpy() for r in range(len(nb))])
+        if sao:
+            want, off, _ = H.oracle_encode_rows(orc, depth, prm, res, info[0])
+        else:
+            want, off, _ = H.oracle_encode_rows_no_sao(orc, depth, prm, res)
+        assert np.array_equal(np.concatenate([[0], np.cumsum(nb)]), off) and np.array_equal(got, want), sao

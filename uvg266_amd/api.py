@@ -655,6 +655,43 @@ class ClosedLoop(CtuSearch):
         models = self.loop_ws[b.value - base:b.value - base + self.n * ctus * 6 * 2].cpu().numpy().view(np.uint16).reshape(self.n, ctus, 6)
         return info, models
 
+    def sao_device(self):
+        """Device views of the plan's SAO decisions ([n * ctus * 34] int32) and SAO models ([n * ctus * 6] as int16)."""
+        import ctypes
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(self.L.uvghip_loop_plan_results(self.loop, ctypes.byref(a), ctypes.byref(b)), "uvghip_loop_plan_results")
+        ctus, base = self.wc * self.hc, self.loop_ws.data_ptr()
+        return (self.loop_ws[a.value - base:a.value - base + self.n * ctus * 34 * 4].view(torch.int32),
+                self.loop_ws[b.value - base:b.value - base + self.n * ctus * 6 * 2].view(torch.int16))
+
+    def slice_data(self):
+        """The rows' substreams the plan coded as the last thing of run(): (rows [n, n_rows, row_cap] uint8, row_bytes [n, n_rows] int32)
+        as device views of the plan's buffers."""
+        import ctypes
+        a, b, cap, nr = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(self.L.uvghip_loop_plan_slice_data(self.loop, ctypes.byref(a), ctypes.byref(b), ctypes.byref(cap), ctypes.byref(nr)), "uvghip_loop_plan_slice_data")
+        base = self.loop_ws.data_ptr()
+        rows = self.loop_ws[a.value - base:a.value - base + self.n * nr.value * cap.value].view(self.n, nr.value, cap.value)
+        nbytes = self.loop_ws[b.value - base:b.value - base + self.n * nr.value * 4].view(torch.int32).view(self.n, nr.value)
+        return rows, nbytes
+
+    def encode_rows(self, row_cap=None, sao=True, stream=None):
+        """uvghip_encode_slice_rows on the plan's pictures (after run()): -> (out [n, rows, row_cap] uint8, row_bytes [n, rows] int32),
+        device tensors; the slice data of picture i is out[i, r, :row_bytes[i, r]] for r = 0, 1, ..."""
+        W, H = self.P.pic_w, self.P.pic_h
+        row_cap = 3 * 64 * W if row_cap is None else row_cap
+        dev = self.loop_ws.device
+        if not hasattr(self, "_rows") or self._rows[0].shape[2] != row_cap:
+            self._rows = (torch.empty((self.n, self.hc, row_cap), dtype=torch.uint8, device=dev), torch.zeros((self.n, self.hc), dtype=torch.int32, device=dev),
+                          torch.empty(self.L.uvghip_slice_rows_workspace_bytes(self.n), dtype=torch.uint8, device=dev))
+        out, nbytes, ws = self._rows
+        info, models = self.sao_device() if sao else (None, None)
+        import ctypes
+        _lib.check(self.L.uvghip_encode_slice_rows(self.depth, ctypes.byref(self.P), self.pics, self.n, None if info is None else _dev(info),
+                                                   None if models is None else _dev(models), _dev(ws), _dev(out), row_cap, _dev(nbytes),
+                                                   _stream() if stream is None else stream), "uvghip_encode_slice_rows")
+        return out, nbytes
+
     def __del__(self):
         loop, self.loop = getattr(self, "loop", None), None
         if loop:

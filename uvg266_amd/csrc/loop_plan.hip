@@ -21,13 +21,18 @@ struct uvghip_loop_plan {
   uint16_t *sao_models;
   uvghip_sao_param_t *params[3];
   size_t snap_bytes;                      // of one picture
+  void *coder_ws;                         // the slice coder's picture table
+  uint8_t *rows;                          // the slice data: row r of picture p at rows + (p * hc + r) * row_cap
+  int32_t *row_bytes;
+  int row_cap, hc;
+  uvghip_ctu_params_t ctu_params;
 };
 
 namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-struct layout_t { size_t search, snap, rects_y, rects_c, edge[3], band[3], decide, info, models, params[3], total; };
+struct layout_t { size_t search, snap, rects_y, rects_c, edge[3], band[3], decide, info, models, params[3], coder, row_bytes, rows, total; int row_cap; };
 
 layout_t layout_of(int bitdepth, int n, int w, int h)
 {
@@ -44,6 +49,11 @@ layout_t layout_of(int bitdepth, int n, int w, int h)
   L.info = take((size_t)n * ctus * 34 * 4);
   L.models = take((size_t)n * ctus * 6 * 2);
   for (int c = 0; c < 3; ++c) L.params[c] = take((size_t)n * ctus * sizeof(uvghip_sao_param_t));
+  const size_t hc = (size_t)((h + 63) / 64);
+  L.row_cap = 3 * 64 * w;                 // twice the raw size of a CTU row of 8-bit 4:2:0 samples: no row of real content comes near
+  L.coder = take(uvghip_slice_rows_workspace_bytes(n));
+  L.row_bytes = take((size_t)n * hc * 4);
+  L.rows = take((size_t)n * hc * L.row_cap);
   L.total = at;
   return L;
 }
@@ -90,6 +100,12 @@ extern "C" int uvghip_loop_plan_create(int bitdepth, const uvghip_ctu_params_t *
   pl->decide_ws = ws + L.decide;
   pl->sao_info = reinterpret_cast<int32_t *>(ws + L.info);
   pl->sao_models = reinterpret_cast<uint16_t *>(ws + L.models);
+  pl->coder_ws = ws + L.coder;
+  pl->rows = ws + L.rows;
+  pl->row_bytes = reinterpret_cast<int32_t *>(ws + L.row_bytes);
+  pl->row_cap = L.row_cap; pl->hc = hc;
+  pl->ctu_params = *params;
+  if (int rc = uvghip_slice_rows_prepare(params, sp.data(), n_pictures, pl->coder_ws)) { uvghip_ctu_plan_destroy(pl->search); delete pl; return rc; }
   // the CTU grids clipped to the picture: the rectangles sao_search_luma / _chroma hand to the decision (sao.c:605-668)
   std::vector<uvghip_rect_t> ry(pl->ctus), rc(pl->ctus);
   for (int cy = 0; cy < hc; ++cy)
@@ -153,6 +169,18 @@ extern "C" int uvghip_loop_plan_run_filters(uvghip_loop_plan_t *pl, void *stream
     if (int rc = uvghip_sao_apply_batch(pl->bitdepth, p.rec_u, p.rec_stride_c, q.out_u, q.out_stride_c, cw, ch, pl->rects_c, pl->params[1] + o, pl->ctus, stream)) return rc;
     if (int rc = uvghip_sao_apply_batch(pl->bitdepth, p.rec_v, p.rec_stride_c, q.out_v, q.out_stride_c, cw, ch, pl->rects_c, pl->params[2] + o, pl->ctus, stream)) return rc;
   }
+  // the slice data: every WPP row's substream from the levels, the side information and the SAO decisions
+  return uvghip_encode_slice_rows(pl->bitdepth, &pl->ctu_params, nullptr, pl->n, pl->sao_info, pl->sao_models, pl->coder_ws, pl->rows, pl->row_cap,
+                                  pl->row_bytes, stream);
+}
+
+extern "C" int uvghip_loop_plan_slice_data(const uvghip_loop_plan_t *pl, const uint8_t **rows, const int32_t **row_bytes, int *row_cap, int *n_rows)
+{
+  if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (rows) *rows = pl->rows;
+  if (row_bytes) *row_bytes = pl->row_bytes;
+  if (row_cap) *row_cap = pl->row_cap;
+  if (n_rows) *n_rows = pl->hc;
   return 0;
 }
 

@@ -1,0 +1,546 @@
+// uvghip_encode_slice_rows: the arithmetic coder on the device -- the slice data of all-intra pictures from what the CTU search
+// and the SAO decision left in device memory.
+// replaces: encoder_state_worker_encode_lcu_bitstream for every CTU (src/encoderstate.c:862-939): encode_sao (:523-608),
+// uvg_encode_coding_tree (src/encode_coding_tree.c:1365-1727: uvg_write_split_flag :1240-1363, the intra luma / chroma mode syntax
+// :902-1238, cbf flags and encode_transform_coeff :628-900), uvg_encode_coeff_nxn (strategies/generic/encode_coding_tree-generic.c:53-323)
+// with uvg_encode_last_significant_xy (encode_coding_tree.c:415-470), and the arithmetic coder itself (src/cabac.c:63-413) down to
+// the end of the substream (end_of_sub_stream_one_bit, uvg_cabac_finish, alignment) and the emulation prevention of
+// uvg_bitstream_put_byte (src/bitstream.c:215-226).
+//
+// A WPP row is one substream: its coder starts fresh (uvg_cabac_start) and its context models start from the models after the
+// first CTU of the row above -- which the search already returned per CTU (the third model set) and uvghip_sao_decide_pictures
+// returned for the two SAO models.  So rows are independent: one workgroup (one wave) per (picture, row).  Inside a row the coder is
+// a chain bin after bin; lane 0 walks it, the other lanes only help to stage a transform block's levels into LDS.
+#include "uvghip_common.h"
+#include "ctu_core.h"
+
+namespace {
+
+using namespace ctu;
+
+struct row_state {
+  uint32_t models[NMODELS + 2];        // state0 | state1 << 16; [NMODELS] sao_merge_flag, [NMODELS + 1] sao_type_idx
+  uint8_t rate[NMODELS + 2];
+  uint16_t scan[1360];                 // diagonal scans of 32, 16, 8, 4 (scan_base)
+  int16_t lv[1024];                    // the levels of the transform block being coded, raster
+  struct cui { uint8_t type, log2w, cbf, mode, mode_c, pad[3]; } cu[17 * 17];      // the CTU's side information + the row / column before it
+};
+
+struct coder {                          // cabac_data_t (cabac.h:56-66) + the substream's output
+  uint32_t low, range, buffered;
+  int bits_left, nbuf;
+  uint8_t *out;
+  int n, cap, zeros;
+};
+
+__device__ __forceinline__ void put_byte(coder &c, uint32_t b)          // uvg_bitstream_put_byte: emulation prevention
+{
+  b &= 0xff;
+  if (c.zeros == 2 && b < 4) { if (c.n < c.cap) c.out[c.n] = 3; c.n++; c.zeros = 0; }
+  c.zeros = b == 0 ? c.zeros + 1 : 0;
+  if (c.n < c.cap) c.out[c.n] = (uint8_t)b;
+  c.n++;
+}
+__device__ __forceinline__ void cwrite(coder &c)                          // uvg_cabac_write
+{
+  const uint32_t lead = c.low >> (24 - c.bits_left);
+  c.bits_left += 8;
+  c.low &= 0xffffffffu >> c.bits_left;
+  if (lead == 0xff) { c.nbuf++; return; }
+  if (c.nbuf > 0) {
+    const uint32_t carry = lead >> 8;
+    put_byte(c, c.buffered + carry);
+    c.buffered = lead & 0xff;
+    const uint32_t fill = (0xff + carry) & 0xff;
+    while (c.nbuf > 1) { put_byte(c, fill); c.nbuf--; }
+  } else { c.nbuf = 1; c.buffered = lead; }
+}
+__device__ __forceinline__ void enc_bin(coder &c, row_state *R, int idx, int bin)      // uvg_cabac_encode_bin + CTX_UPDATE
+{
+  const uint32_t st = R->models[idx];
+  uint32_t s0 = st & 0xffffu, s1 = st >> 16;
+  const uint32_t state = (s0 + s1) >> 8;
+  const uint32_t q = (state & 0x80) ? (state ^ 0xff) : state;
+  const uint32_t lps = ((((q >> 2) * (c.range >> 5)) >> 1) + 4) & 0xff;
+  c.range -= lps;
+  if ((uint32_t)(bin ? 1 : 0) != (state >> 7)) {
+    const int nb = __clz((int)lps) - 23;            // uvg_g_auc_renorm_table[lps >> 3]: shifts that bring lps (>= 4) to 256..511
+    c.low = (c.low + c.range) << nb;
+    c.range = lps << nb;
+    c.bits_left -= nb;
+    if (c.bits_left < 12) cwrite(c);
+  } else if (c.range < 256) {
+    c.low <<= 1; c.range <<= 1; c.bits_left--;
+    if (c.bits_left < 12) cwrite(c);
+  }
+  const int r0 = R->rate[idx] >> 4, r1 = R->rate[idx] & 15;
+  s0 -= (s0 >> r0) & 0x7fe0u;
+  s1 -= (s1 >> r1) & 0x7ffeu;
+  if (bin) { s0 += (0x7fffu >> r0) & 0x7fe0u; s1 += (0x7fffu >> r1) & 0x7ffeu; }
+  R->models[idx] = (s0 & 0xffffu) | (s1 << 16);
+}
+__device__ __forceinline__ void enc_ep(coder &c, int bin)                 // uvg_cabac_encode_bin_ep
+{
+  c.low <<= 1;
+  if (bin) c.low += c.range;
+  c.bits_left--;
+  if (c.bits_left < 12) cwrite(c);
+}
+__device__ __forceinline__ void enc_eps(coder &c, uint32_t v, int n)      // uvg_cabac_encode_bins_ep / _aligned_bins_ep
+{
+  if (c.range == 256) {
+    int rem = n;
+    while (rem > 0) {
+      const int k = rem < 8 ? rem : 8;
+      const uint32_t nb = (v >> (rem - k)) & ((1u << k) - 1);
+      c.low = (c.low << k) + (nb << 8);
+      rem -= k;
+      c.bits_left -= k;
+      if (c.bits_left < 12) cwrite(c);
+    }
+    return;
+  }
+  while (n > 8) {
+    n -= 8;
+    const uint32_t pattern = v >> n;
+    c.low <<= 8;
+    c.low += c.range * pattern;
+    v -= pattern << n;
+    c.bits_left -= 8;
+    if (c.bits_left < 12) cwrite(c);
+  }
+  c.low <<= n;
+  c.low += c.range * v;
+  c.bits_left -= n;
+  if (c.bits_left < 12) cwrite(c);
+}
+__device__ __forceinline__ void enc_remain(coder &c, uint32_t remainder, uint32_t rice)   // uvg_cabac_write_coeff_remain, cutoff 5
+{
+  const unsigned cutoff = 5, threshold = cutoff << rice;
+  if (remainder < threshold) {
+    const uint32_t length = (remainder >> rice) + 1;
+    enc_eps(c, (1u << length) - 2, (int)length);
+    enc_eps(c, remainder & ((1u << rice) - 1), (int)rice);
+  } else {
+    const unsigned max_prefix = 32 - cutoff - 15;
+    unsigned prefix_length = 0, suffix_length;
+    const unsigned code_value = (remainder >> rice) - cutoff;
+    if ((int32_t)code_value >= ((1 << max_prefix) - 1)) { prefix_length = max_prefix; suffix_length = 15; }
+    else { while ((int32_t)code_value > ((2 << prefix_length) - 2)) prefix_length++; suffix_length = prefix_length + rice + 1; }
+    const unsigned total_prefix = prefix_length + cutoff;
+    enc_eps(c, (1u << total_prefix) - 1, (int)total_prefix);
+    enc_eps(c, ((code_value - ((1u << prefix_length) - 1)) << rice) | (remainder & ((1u << rice) - 1)), (int)suffix_length);
+  }
+}
+
+// context_get_sig_ctx_idx_abs (rdo.c:1400-1438) on the staged levels: the sig context, the diagonal and the template sum
+__device__ __forceinline__ int sig_ctx_of(const int16_t *lv, int px, int py, int n, int color, int &diag, int &tsum)
+{
+  const int16_t *d = lv + px + py * n;
+  int num_pos = 0, sum_abs = 0;
+#define SLC_UPD(v) { const int a = iabs_((int)(v)); sum_abs += (4 + (a & 1)) < a ? (4 + (a & 1)) : a; num_pos += a ? 1 : 0; }
+  if (px < n - 1) {
+    SLC_UPD(d[1]);
+    if (px < n - 2) SLC_UPD(d[2]);
+    if (py < n - 1) SLC_UPD(d[n + 1]);
+  }
+  if (py < n - 1) {
+    SLC_UPD(d[n]);
+    if (py < n - 2) SLC_UPD(d[n << 1]);
+  }
+#undef SLC_UPD
+  diag = px + py;
+  int ofs = (((sum_abs + 1) >> 1) < 3 ? ((sum_abs + 1) >> 1) : 3) + (diag < 2 ? 4 : 0);
+  if (color == 0) ofs += diag < 5 ? 4 : 0;
+  tsum = sum_abs - num_pos;
+  return ofs;
+}
+
+// uvg_encode_coeff_nxn on the levels staged in R->lv (n x n, raster); lane 0
+__device__ __forceinline__ void code_coeffs(coder &c, row_state *R, int n, int color)
+{
+  const int l2 = ilog2_dev(n), nn = n * n, cgw = n >> 2, t = color ? 1 : 0;
+  const uint16_t *scan = R->scan + scan_base(l2);
+  const int16_t *lv = R->lv;
+  int last = -1;
+  for (int sp = nn - 1; sp >= 0; --sp) if (lv[scan[sp]]) { last = sp; break; }
+  if (last < 0) return;
+  unsigned long long sig_cg = 0, sig_r = 0;            // per group, by scan index / by raster position: has a level
+  for (int g = 0; g <= (last >> 4); ++g) {
+    int any = 0;
+    for (int k = 0; k < 16; ++k) any |= lv[scan[g * 16 + k]] != 0;
+    if (any || g == (last >> 4)) {                     // (the last group counts as significant for its neighbours)
+      const int f = scan[g * 16];
+      sig_cg |= 1ull << g;
+      sig_r |= 1ull << (((f >> l2) >> 2) * cgw + ((f & (n - 1)) >> 2));
+    }
+  }
+  const int cg_last = last >> 4;
+  {   // uvg_encode_last_significant_xy
+    const int pos_last = scan[last], last_y = pos_last >> l2, last_x = pos_last - (last_y << l2);
+    const int off = t ? 0 : (l2 == 2 ? 0 : l2 == 3 ? 3 : l2 == 4 ? 6 : 10);          // prefix_ctx[log2 size]
+    const int sh = t ? clampi(n >> 3, 0, 2) : ((l2 + 1) >> 2);
+    const int bx = M_LASTX + 20 * t + off, by = M_LASTY + 20 * t + off;
+    const int gx = group_idx(last_x), gy = group_idx(last_y), gmax = group_idx(n - 1);
+    int k = 0;
+    for (; k < gx; k++) enc_bin(c, R, bx + (k >> sh), 1);
+    if (gx < gmax) enc_bin(c, R, bx + (k >> sh), 0);
+    k = 0;
+    for (; k < gy; k++) enc_bin(c, R, by + (k >> sh), 1);
+    if (gy < gmax) enc_bin(c, R, by + (k >> sh), 0);
+    // g_min_in_group[g] for g > 3: 4, 6, 8, 12, 16, 24 = (2 + (g & 1)) << ((g >> 1) - 1)
+    if (gx > 3) enc_eps(c, (uint32_t)(last_x - ((2 + (gx & 1)) << ((gx >> 1) - 1))), (gx - 2) / 2);
+    if (gy > 3) enc_eps(c, (uint32_t)(last_y - ((2 + (gy & 1)) << ((gy >> 1) - 1))), (gy - 2) / 2);
+  }
+  int reg_bins = (nn * 28) >> 4;
+  // the groups' positions in the block: group g of the scan sits at the 4x4 whose first coefficient is scan[g * 16]
+  for (int g = cg_last; g >= 0; --g) {
+    const int first = scan[g * 16];
+    const int cx = (first & (n - 1)) >> 2, cy = (first >> l2) >> 2;
+    int sig = (int)((sig_cg >> g) & 1);
+    if (g == cg_last || g == 0) sig = 1;
+    else {
+      const int right = cx + 1 < cgw ? (int)((sig_r >> (cy * cgw + cx + 1)) & 1) : 0;
+      const int lower = cy + 1 < cgw ? (int)((sig_r >> ((cy + 1) * cgw + cx)) & 1) : 0;
+      enc_bin(c, R, M_SIGGRP + 2 * t + ((right || lower) ? 1 : 0), sig);
+    }
+    if (!sig) continue;
+    const int min_sub = g << 4;
+    const int first_sig = (g == cg_last) ? last : (min_sub + 15);
+    const int infer_sig = (first_sig != last) ? ((g != 0) ? min_sub : -1) : first_sig;
+    int num_nz = 0, next_sig;
+    uint32_t signs = 0;
+    int diag = -1, tsum = -1;
+    for (next_sig = first_sig; next_sig >= min_sub && reg_bins >= 4; next_sig--) {
+      const int blk = scan[next_sig], py = blk >> l2, px = blk - (py << l2);
+      const int s = lv[blk] != 0;
+      if (num_nz || next_sig != infer_sig) {
+        int ctx_sig = sig_ctx_of(lv, px, py, n, color, diag, tsum);
+        if (t && ctx_sig > 7) ctx_sig = 7;
+        enc_bin(c, R, M_SIG + 12 * t + ctx_sig, s);
+        reg_bins--;
+      } else if (next_sig != last) {
+        (void)sig_ctx_of(lv, px, py, n, color, diag, tsum);
+      }
+      if (s) {
+        num_nz++;
+        signs = (signs << 1) | (lv[blk] < 0);
+        int ofs = 0;
+        if (diag != -1) ofs = ((tsum < 4 ? tsum : 4) + 1) + (!diag ? (color == 0 ? 15 : 5) : color == 0 ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0);
+        int rem = iabs_((int)lv[blk]) - 1;
+        const int gt1 = rem ? 1 : 0;
+        enc_bin(c, R, M_GT1 + 21 * t + ofs, gt1);
+        reg_bins--;
+        if (gt1) {
+          rem -= 1;
+          enc_bin(c, R, M_PAR + 21 * t + ofs, rem & 1);
+          rem >>= 1;
+          reg_bins--;
+          enc_bin(c, R, M_GT2 + 21 * t + ofs, rem ? 1 : 0);
+          reg_bins--;
+        }
+      }
+    }
+    for (int sp = first_sig; sp > next_sig; sp--) {               // Golomb-Rice remainders of the context-coded positions
+      const int blk = scan[sp], py = blk >> l2, px = blk - (py << l2);
+      const uint32_t a = (uint32_t)iabs_((int)lv[blk]);
+      if (a >= 4) enc_remain(c, (a - 4) >> 1, (uint32_t)go_rice_par((unsigned)abs_sum_tmpl(lv, px, py, n, 4)));
+    }
+    for (int sp = next_sig; sp >= min_sub; sp--) {                 // positions coded in bypass once the regular bins are spent
+      const int blk = scan[sp], py = blk >> l2, px = blk - (py << l2);
+      const uint32_t a = (uint32_t)iabs_((int)lv[blk]);
+      const uint32_t rice = (uint32_t)go_rice_par((unsigned)abs_sum_tmpl(lv, px, py, n, 0)), pos0 = 1u << rice;
+      enc_remain(c, a == 0 ? pos0 : (a <= pos0 ? a - 1 : a), rice);
+      if (a) { num_nz++; signs = (signs << 1) | (lv[blk] < 0); }
+    }
+    enc_eps(c, signs, num_nz);
+  }
+}
+
+struct pic_dev { const uvghip_scu_t *cu; const int16_t *coeff; const uint32_t *models; int cu_stride, pad; };
+
+// side information of the 4x4 unit at picture position (x, y), from the CTU's LDS copy (x0, y0: the CTU's origin; one unit of
+// border to the left and above)
+__device__ __forceinline__ const row_state::cui &cu_of(const row_state *R, int x0, int y0, int x, int y)
+{
+  return R->cu[(((y - y0) >> 2) + 1) * 17 + ((x - x0) >> 2) + 1];
+}
+
+__device__ __forceinline__ void stage(row_state *R, const int16_t *src, int stride, int n)        // all lanes: n x n levels -> R->lv
+{
+  __syncthreads();
+  const int l2 = ilog2_dev(n);
+  for (int e = threadIdx.x; e < n * n; e += blockDim.x) R->lv[e] = src[(e >> l2) * stride + (e & (n - 1))];
+  __syncthreads();
+}
+
+__device__ __forceinline__ void code_split_flag(coder &c, row_state *R, int x0, int y0, int W, int H, int x, int y, int s, int split)
+{
+  if (!(W >= x + s && H >= y + s) || s <= 4) return;                // implicit split, or nothing to split
+  int model = 0;
+  if (x > 0 && (1 << cu_of(R, x0, y0, x - 4, y).log2w) < s) model++;
+  if (y > 0 && (1 << cu_of(R, x0, y0, x, y - 4).log2w) < s) model++;
+  enc_bin(c, R, M_SPLIT + model, split);
+}
+
+__device__ __forceinline__ void code_luma_mode(coder &c, row_state *R, int x0, int y0, int x, int y, int n, int mode)
+{
+  // uvg_intra_get_dir_luma_predictor (intra.c:88-188), MIP off, on the two neighbours' modes (0 = not intra / not there)
+  int left_dir = 0, above_dir = 0;
+  if (x > 0) { const row_state::cui &q = cu_of(R, x0, y0, x - 4, y + n - 4); if (q.type == 1) left_dir = q.mode; }
+  if ((y & 63) > 0 && y > 0) { const row_state::cui &q = cu_of(R, x0, y0, x + n - 4, y - 4); if (q.type == 1) above_dir = q.mode; }
+  int p0 = 0, p1 = 1, p2 = 50, p3 = 18, p4 = 46, p5 = 54;
+  const int offset = 61, mod = 64;
+  if (left_dir == above_dir) {
+    if (left_dir > 1) {
+      p1 = left_dir; p2 = ((left_dir + offset) % mod) + 2; p3 = ((left_dir - 1) % mod) + 2;
+      p4 = ((left_dir + offset - 1) % mod) + 2; p5 = (left_dir % mod) + 2;
+    }
+  } else if (left_dir > 1 && above_dir > 1) {
+    p1 = left_dir; p2 = above_dir;
+    const int mx = p1 > p2 ? p1 : p2, mn = p1 > p2 ? p2 : p1, diff = mx - mn;
+    if (diff == 1) { p3 = ((mn + offset) % mod) + 2; p4 = ((mx - 1) % mod) + 2; p5 = ((mn + offset - 1) % mod) + 2; }
+    else if (diff >= 62) { p3 = ((mn - 1) % mod) + 2; p4 = ((mx + offset) % mod) + 2; p5 = (mn % mod) + 2; }
+    else if (diff == 2) { p3 = ((mn - 1) % mod) + 2; p4 = ((mn + offset) % mod) + 2; p5 = ((mx - 1) % mod) + 2; }
+    else { p3 = ((mn + offset) % mod) + 2; p4 = ((mn - 1) % mod) + 2; p5 = ((mx + offset) % mod) + 2; }
+  } else if (left_dir + above_dir >= 2) {
+    p1 = left_dir < above_dir ? above_dir : left_dir;
+    p2 = ((p1 + offset) % mod) + 2; p3 = ((p1 - 1) % mod) + 2; p4 = ((p1 + offset - 1) % mod) + 2; p5 = (p1 % mod) + 2;
+  }
+  const int preds[6] = {p0, p1, p2, p3, p4, p5};
+  int mpm = -1;
+#pragma unroll
+  for (int i = 5; i >= 0; --i) if (preds[i] == mode) mpm = i;
+  enc_bin(c, R, M_MPM, mpm != -1);
+  if (mpm != -1) {
+    enc_bin(c, R, M_PLANAR + 1, mpm > 0);
+    if (mpm > 0) enc_ep(c, mpm > 1);
+    if (mpm > 1) enc_ep(c, mpm > 2);
+    if (mpm > 2) enc_ep(c, mpm > 3);
+    if (mpm > 3) enc_ep(c, mpm > 4);
+  } else {
+    int tmp = mode;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) tmp -= preds[i] < mode;
+    if (tmp < 3) enc_eps(c, (uint32_t)tmp, 5); else enc_eps(c, (uint32_t)tmp + 3, 6);      // truncated binary, 61 symbols
+  }
+}
+
+__device__ __forceinline__ void code_chroma_mode(coder &c, row_state *R, int chroma_mode, int luma_dir)
+{
+  const int derived = chroma_mode == luma_dir;
+  enc_bin(c, R, M_CHROMA_PRED, derived ? 0 : 1);
+  if (!derived) {
+    // the list {planar, vertical, horizontal, DC} with the entry equal to the luma mode standing for 66
+    const int m0 = luma_dir == 0 ? 66 : 0, m1 = luma_dir == 50 ? 66 : 50, m2 = luma_dir == 18 ? 66 : 18;
+    const int idx = chroma_mode == m0 ? 0 : chroma_mode == m1 ? 1 : chroma_mode == m2 ? 2 : 3;
+    enc_eps(c, (uint32_t)idx, 2);
+  }
+}
+
+__device__ __forceinline__ void code_sao_color(coder &c, row_state *R, const int32_t *info, int color, int max_off)
+{
+  const int type = info[0], off = color == 2 ? 5 : 0;
+  if (color != 2) {
+    enc_bin(c, R, NMODELS + 1, type != 0);
+    if (type == 1) enc_ep(c, 0); else if (type == 2) enc_ep(c, 1);
+  }
+  if (type == 0) return;
+  for (int i = 1; i <= 4; ++i) {
+    int symbol = info[7 + i + off] < 0 ? -info[7 + i + off] : info[7 + i + off];
+    const int code_last = max_off > symbol;
+    enc_ep(c, symbol ? 1 : 0);
+    if (!symbol) continue;
+    while (--symbol) enc_ep(c, 1);
+    if (code_last) enc_ep(c, 0);
+  }
+  if (type == 1) {
+    for (int i = 1; i <= 4; ++i) if (info[7 + i + off] != 0) enc_ep(c, info[7 + i + off] < 0 ? 1 : 0);
+    enc_eps(c, (uint32_t)info[5 + (color == 2 ? 1 : 0)], 5);
+  } else if (color != 2) {
+    enc_eps(c, (uint32_t)info[1], 2);
+  }
+}
+
+__device__ inline int z_to_xy(int z) { return (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4) | ((z >> 3) & 8); }
+
+__global__ void __launch_bounds__(64)
+slice_rows_kernel(const pic_dev *__restrict__ pics, const int32_t *__restrict__ sao, const uint16_t *__restrict__ sao_models, int W, int H, int qp,
+                  int bitdepth, uint8_t *__restrict__ out, int row_cap, int32_t *__restrict__ row_bytes)
+{
+  __shared__ row_state Rs;
+  row_state *R = &Rs;
+  const int wc = (W + 63) / 64, hc = (H + 63) / 64;
+  const int pic = blockIdx.x / hc, cy = blockIdx.x - pic * hc;
+  const pic_dev D = pics[pic];
+  const bool lane0 = threadIdx.x == 0;
+  // scans, window bytes, the row's start models
+  for (int i = threadIdx.x; i < NMODELS; i += blockDim.x) {
+    R->rate[i] = k_ctx_init[3][i];
+    if (cy == 0) models_init_one(R->models, i, qp, 2);
+    else R->models[i] = D.models[((size_t)((cy - 1) * wc) * 3 + 2) * NMODELS + i];
+  }
+  if (threadIdx.x < 2) {
+    const int i = threadIdx.x;
+    R->rate[NMODELS + i] = k_ctx_init_sao[3][i];
+    if (cy == 0 || !sao_models) {
+      const int v = k_ctx_init_sao[2][i];
+      const int slope = (v >> 3) - 4, offset = ((v & 7) * 18) + 1;
+      int s = ((slope * (qp - 16)) >> 1) + offset;
+      s = s < 1 ? 1 : (s > 127 ? 127 : s);
+      R->models[NMODELS + i] = (uint32_t)((s << 8) & 0x7fe0) | ((uint32_t)((s << 8) & 0x7ffe) << 16);
+    } else {
+      const uint16_t *m = sao_models + ((size_t)pic * wc * hc + (size_t)(cy - 1) * wc) * 6 + 3 * i;
+      R->models[NMODELS + i] = (uint32_t)m[0] | ((uint32_t)m[1] << 16);
+    }
+  }
+  if (lane0) {
+    // H.266 6.5.2: up-right diagonal scan of 4x4 groups, groups in diagonal order
+    int16_t *in = R->lv;                         // (free until the first block is staged)
+    int q = 0;
+    for (int d = 0; d < 7; ++d) for (int x = 0; x <= d; ++x) { const int y = d - x; if (x < 4 && y < 4) in[q++] = (int16_t)(y * 4 + x); }
+    for (int l2 = 2; l2 <= 5; ++l2) {
+      const int n = 1 << l2, cgw = n >> 2;
+      uint16_t *sc = R->scan + scan_base(l2);
+      int g = 0;
+      for (int d = 0; d < 2 * cgw - 1; ++d)
+        for (int x = 0; x <= d; ++x) {
+          const int y = d - x;
+          if (x >= cgw || y >= cgw) continue;
+          for (int k = 0; k < 16; ++k) sc[g * 16 + k] = (uint16_t)((y * 4 + (in[k] >> 2)) * n + x * 4 + (in[k] & 3));
+          ++g;
+        }
+    }
+  }
+  __syncthreads();
+  coder c;
+  c.low = 0; c.range = 510; c.bits_left = 23; c.nbuf = 0; c.buffered = 0xff;       // uvg_cabac_start
+  c.out = out + ((size_t)pic * hc + cy) * row_cap; c.n = 0; c.cap = row_cap; c.zeros = 0;
+  const int max_off = (1 << ((bitdepth < 10 ? bitdepth : 10) - 5)) - 1;
+  for (int cx = 0; cx < wc; ++cx) {
+    const int k = cy * wc + cx, x0 = cx * 64, y0 = cy * 64;
+    const int16_t *co = D.coeff + (size_t)k * 6144;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 17 * 17; e += blockDim.x) {       // the CTU's 16 x 16 units and one unit of border (left, above, corner)
+      const int ux = e % 17 - 1, uy = e / 17 - 1, x = x0 + ux * 4, y = y0 + uy * 4;
+      row_state::cui q = {};
+      if (x >= 0 && y >= 0 && x < W && y < H) {
+        const uvghip_scu_t *g = &D.cu[(y >> 2) * D.cu_stride + (x >> 2)];
+        q.type = g->type; q.log2w = g->log2_width; q.cbf = g->cbf; q.mode = (uint8_t)(g->mv[0][0] & 0xff); q.mode_c = (uint8_t)((g->mv[0][0] >> 8) & 0xff);
+      }
+      R->cu[e] = q;
+    }
+    __syncthreads();
+    if (lane0 && sao) {                                             // encode_sao
+      const int32_t *l = sao + ((size_t)pic * wc * hc + k) * 34, *ch = l + 17;
+      if (cx > 0) enc_bin(c, R, NMODELS, l[3]);
+      if (cy > 0 && !l[3]) enc_bin(c, R, NMODELS, l[4]);
+      if (!l[3] && !l[4]) { code_sao_color(c, R, l, 0, max_off); code_sao_color(c, R, ch, 1, max_off); code_sao_color(c, R, ch, 2, max_off); }
+    }
+    // uvg_encode_coding_tree: z-order over the 4x4 units; a CU starts where a unit is aligned to its CU's size
+    for (int z = 0; z < 256; ++z) {
+      const int lx = z_to_xy(z) * 4, ly = z_to_xy(z >> 1) * 4, x = x0 + lx, y = y0 + ly;
+      if (x >= W || y >= H) continue;                               // (uniform: every lane takes the same path)
+      const row_state::cui cu = cu_of(R, x0, y0, x, y);
+      const int n = 1 << cu.log2w;
+      if ((lx & (n - 1)) || (ly & (n - 1))) continue;
+      const int mode = cu.mode, mode_c = cu.mode_c;
+      const int sep = n == 4, last4 = sep && (lx & 4) && (ly & 4);
+      if (lane0) {
+        for (int d = 0; (64 >> d) > n; ++d) {
+          const int s = 64 >> d;
+          if (!(lx & (s - 1)) && !(ly & (s - 1))) code_split_flag(c, R, x0, y0, W, H, x, y, s, 1);
+        }
+        code_split_flag(c, R, x0, y0, W, H, x, y, n, 0);
+        code_luma_mode(c, R, x0, y0, x, y, n, mode);
+        if (!sep) code_chroma_mode(c, R, mode_c, mode);
+      }
+      const int tus = n == 64 ? 4 : 1, tn = n == 64 ? 32 : n;
+      for (int tu = 0; tu < tus; ++tu) {
+        const int tlx = lx + (tu & 1) * 32, tly = ly + (tu >> 1) * 32;
+        const int tcbf = cu_of(R, x0, y0, x0 + tlx, y0 + tly).cbf;
+        const int cb_y = tcbf & 1, cb_u = (tcbf >> 1) & 1, cb_v = (tcbf >> 2) & 1;
+        if (lane0) {
+          if (!sep) { enc_bin(c, R, M_CBF_CB, cb_u); enc_bin(c, R, M_CBF_CR + cb_u, cb_v); }
+          enc_bin(c, R, M_CBF_LUMA, cb_y);
+        }
+        if (cb_y) { stage(R, co + tly * 64 + tlx, 64, tn); if (lane0) code_coeffs(c, R, tn, 0); }
+        if (!sep) {
+          if (cb_u) { stage(R, co + 4096 + (tly >> 1) * 32 + (tlx >> 1), 32, tn >> 1); if (lane0) code_coeffs(c, R, tn >> 1, 1); }
+          if (cb_v) { stage(R, co + 5120 + (tly >> 1) * 32 + (tlx >> 1), 32, tn >> 1); if (lane0) code_coeffs(c, R, tn >> 1, 2); }
+        } else if (last4) {
+          // the 8x8 area's chroma after its last luma CU: mode (the co-located luma CU is this one), cbfs of the area's first entry, levels
+          const int acbf = cu_of(R, x0, y0, x & ~7, y & ~7).cbf;
+          const int au = (acbf >> 1) & 1, av = (acbf >> 2) & 1;
+          if (lane0) { code_chroma_mode(c, R, mode_c, mode); enc_bin(c, R, M_CBF_CB, au); enc_bin(c, R, M_CBF_CR + au, av); }
+          const int cbx = (lx & ~7) >> 1, cby = (ly & ~7) >> 1;
+          if (au) { stage(R, co + 4096 + cby * 32 + cbx, 32, 4); if (lane0) code_coeffs(c, R, 4, 1); }
+          if (av) { stage(R, co + 5120 + cby * 32 + cbx, 32, 4); if (lane0) code_coeffs(c, R, 4, 2); }
+        }
+      }
+    }
+  }
+  if (lane0) {
+    // end_of_sub_stream_one_bit (uvg_cabac_encode_bin_trm(1)), uvg_cabac_finish, a one bit, zeros to the byte boundary
+    c.range -= 2;
+    c.low += c.range;
+    c.low <<= 7;
+    c.range = 2 << 7;
+    c.bits_left -= 7;
+    if (c.bits_left < 12) cwrite(c);
+    if (c.low >> (32 - c.bits_left)) {
+      put_byte(c, c.buffered + 1);
+      while (c.nbuf > 1) { put_byte(c, 0); c.nbuf--; }
+      c.low -= 1u << (32 - c.bits_left);
+    } else {
+      if (c.nbuf > 0) put_byte(c, c.buffered);
+      while (c.nbuf > 1) { put_byte(c, 0xff); c.nbuf--; }
+    }
+    uint32_t acc = 0;
+    int nacc = 0;
+    const int nb = 24 - c.bits_left;
+    const uint32_t v = c.low >> 8;
+    for (int i = nb - 1; i >= 0; --i) { acc = (acc << 1) | ((v >> i) & 1u); if (++nacc == 8) { put_byte(c, acc); acc = 0; nacc = 0; } }
+    acc = (acc << 1) | 1u; if (++nacc == 8) { put_byte(c, acc); acc = 0; nacc = 0; }
+    if (nacc) put_byte(c, acc << (8 - nacc));
+    row_bytes[(size_t)pic * hc + cy] = c.n;            // (> row_cap: the buffer was too small, the row is truncated)
+  }
+}
+
+}  // namespace
+
+extern "C" size_t uvghip_slice_rows_workspace_bytes(int n_pictures) { return n_pictures > 0 ? (size_t)n_pictures * sizeof(pic_dev) : 0; }
+
+// the picture table the kernel reads, uploaded once (synchronously); uvghip_encode_slice_rows with pictures == NULL reuses it
+extern "C" int uvghip_slice_rows_prepare(const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, int n_pictures, void *workspace)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!params || !pictures || n_pictures <= 0 || !workspace) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const int wc = (params->pic_w + 63) / 64;
+  std::vector<pic_dev> pd(n_pictures);
+  for (int i = 0; i < n_pictures; ++i) {
+    if (!pictures[i].cu || !pictures[i].coeff || !pictures[i].models || pictures[i].cu_stride < wc * 16)
+      return uvghip_set_error(hipErrorInvalidValue, "uvghip_slice_rows_prepare: picture descriptor");
+    pd[i] = pic_dev{pictures[i].cu, pictures[i].coeff, pictures[i].models, pictures[i].cu_stride, 0};
+  }
+  UVGHIP_TRY(hipMemcpy(workspace, pd.data(), pd.size() * sizeof(pic_dev), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int uvghip_encode_slice_rows(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, int n_pictures,
+                                        const int32_t *sao_info, const uint16_t *sao_models, void *workspace, uint8_t *out, int row_cap,
+                                        int32_t *row_bytes, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
+  if (!params || n_pictures <= 0 || !workspace || !out || row_cap <= 0 || !row_bytes || (sao_info && !sao_models))
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const int W = params->pic_w, H = params->pic_h, hc = (H + 63) / 64;
+  if (W <= 0 || H <= 0 || (W & 7) || (H & 7) || params->qp < 0 || params->qp > 63) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (pictures)
+    if (int rc = uvghip_slice_rows_prepare(params, pictures, n_pictures, workspace)) return rc;
+  hipStream_t st = uvghip_stream(stream);
+  slice_rows_kernel<<<n_pictures * hc, 64, 0, st>>>(static_cast<const pic_dev *>(workspace), sao_info, sao_models, W, H, params->qp, bitdepth, out,
+                                                    row_cap, row_bytes);
+  UVGHIP_CHECK_LAUNCH();
+}

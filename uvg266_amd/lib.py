@@ -162,6 +162,10 @@ SIGNATURES = {
     "uvghip_ctu_plan_create": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
     "uvghip_ctu_plan_run": (c_int, [c_vp, c_vp]),
     "uvghip_ctu_plan_destroy": (None, [c_vp]),
+    "uvghip_slice_rows_workspace_bytes": (ctypes.c_size_t, [c_int]),
+    "uvghip_slice_rows_prepare": (c_int, [c_vp, c_vp, c_int, c_vp]),
+    "uvghip_loop_plan_slice_data": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "uvghip_encode_slice_rows": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "uvghip_loop_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
     "uvghip_loop_plan_create": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "uvghip_loop_plan_run": (c_int, [c_vp, c_vp]),
