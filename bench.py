@@ -401,10 +401,11 @@ def ctu_search_bytes(W, H, depth):
 
 class ClosedLoop:
     """One group of `in_flight` pictures on its own stream: one uvghip_loop_plan_run per issue = the closed-loop CTU search
-    (uvghip_ctu_plan_run) and the in-loop filters on the reference's schedule (encoderstate.c:841-853 per CTU, the frame's
+    (uvghip_ctu_plan_run), the in-loop filters on the reference's schedule (encoderstate.c:841-853 per CTU, the frame's
     uvg_sao_reconstruct afterwards: snapshot deblocking -> SAO statistics -> the SAO decision of every CTU -> deblocking -> SAO
-    apply), strung together in C (csrc/loop_plan.hip); the output is bit-identical with the picture the encoder returns
-    (tests/test_gpu_sao_decide.py)."""
+    apply) and the arithmetic coder (uvghip_encode_slice_rows: every WPP row's substream), strung together in C
+    (csrc/loop_plan.hip); outputs: the picture the encoder returns and the slice data of its .266, bit for bit
+    (tests/test_gpu_sao_decide.py, tests/test_gpu_slice_coder.py)."""
 
     def __init__(self, wl, first_t, in_flight, device, step=1):
         self.W, self.H, self.depth = wl["W"], wl["H"], wl["depth"]
@@ -658,7 +659,7 @@ def main():
             gbs = byts / (launch_ms * 1e-3) / 1e9
             wc, hc = (wl["W"] + 63) // 64, (wl["H"] + 63) // 64
             out = {
-                "metric": f"encoded fps ({wl['H']}p all-intra --preset medium closed loop: CTU search with the reference's RD decisions -> deblock -> SAO; Mpixels/s in config)",
+                "metric": f"encoded fps ({wl['H']}p all-intra --preset medium closed loop: CTU search with the reference's RD decisions -> deblock -> SAO -> slice data; Mpixels/s in config)",
                 "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
                 "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "u8" if wl["depth"] == 8 else "u16", "data": "synthetic",
