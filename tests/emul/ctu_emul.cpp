@@ -16,7 +16,8 @@ static int run_picture(const ctu::params &P, const PX *sy, const PX *su, const P
   ctu::scratch *Wk = new ctu::scratch;
   for (int cy = 0; cy < hc; ++cy)
     for (int cx = 0; cx < wc; ++cx) {
-      memset(S, 0xA5, sizeof *S);          // nothing may depend on what the LDS held before
+      memset(S, 0xA5, sizeof *S);          // nothing may depend on what the LDS or the global scratch held before
+      memset(Wk, 0xA5, sizeof *Wk);
       ctu::job<PX> J;
       J.P = P;
       J.src_y = sy; J.src_u = su; J.src_v = sv; J.src_stride = W; J.src_stride_c = W / 2;

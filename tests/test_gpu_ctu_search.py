@@ -26,7 +26,7 @@ def run_gpu(hip, depth, prm, pictures):
     return out
 
 
-@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37"])
+@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_320x192_8_qp42", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7"])
 def test_every_ctu_equals_the_reference_run(hip, name):
     g = H.ctu_golden(name)
     W, Hh, depth, qp, y, u, v = H.golden_source(g)
@@ -51,6 +51,22 @@ def test_1080p_equals_the_reference_run_ctu_by_ctu(hip, name):
     r = run_gpu(hip, depth, H.search_params(W, Hh, qp), [(y, u, v)])[0]
     bad = np.argwhere((H.ctu_crcs(r, W, Hh) != g["crc"]).any(axis=1)).ravel()
     assert bad.size == 0, bad[:10]
+
+
+@pytest.mark.parametrize("name", ["ref_ctu_320x192_8_qp42", "ref_ctu_832x480_8_qp22"])
+def test_repeated_runs_give_the_reference_result_every_time(hip, name):
+    """The four waves of a workgroup run concurrently (the depth pipeline): whatever two of them can touch at the same moment must
+    be private to each.  (Two depths once shared RDOQ's per-position cost arrays in the global scratch: at QP 42 about half of
+    the runs of the 320x192 picture decided one CTU differently.)  Twelve runs in one process, each checked in full."""
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    prm = H.search_params(W, Hh, qp)
+    for rep in range(12):
+        r = run_gpu(hip, depth, prm, [(y, u, v)])[0]
+        assert np.array_equal(r["models"], g["models"]), rep
+        assert np.array_equal(r["coeff"], g["coeff"]), rep
+        for p in ("rec_y", "rec_u", "rec_v"):
+            assert np.array_equal(r[p], g[p]), (rep, p)
 
 
 def test_several_pictures_in_one_launch(hip, orc):

@@ -168,6 +168,9 @@ def crcs(W, H, depth, qp, t=0):
 if __name__ == "__main__":
     full(832, 480, 8, 22)
     full(416, 240, 10, 37)
+    full(320, 192, 8, 42, t=5)           # high QP: empty blocks, 64x64 CUs
+    full(192, 128, 10, 12, t=9)          # low QP: dense blocks, the regular-bin budget runs out
+    full(256, 128, 8, 7, t=2)
     crcs(1920, 1080, 8, 22)
     crcs(1920, 1080, 10, 27, t=3)
     crcs(3840, 2160, 10, 22)

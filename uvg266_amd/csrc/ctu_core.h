@@ -1290,7 +1290,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
         const int level = dst[scan[scanpos]];
         block_uncoded_cost += c0;
         base_cost += cc;
-        spent += (level < 2 ? level : 3) + (scanpos != last_scanpos);
+        // (the first position of a group other than group 0 resets the Rice parameter INSTEAD of paying: rdo.c:1690-1697)
+        if (!(sp == 0 && cgs > 0)) spent += (level < 2 ? level : 3) + (scanpos != last_scanpos);
         rd_sig += cs;
         if (sp == 0) rd_sig0 = cs;
         if (level) {
@@ -1437,7 +1438,10 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
   E.error_scale = scale / E.q / E.q;
   const bool small = V->rq_cc != nullptr;        // the per-position cost arrays are in LDS (this wave's depth has them)
   CTU_LDS double *const CCl = LDSP(double, V->rq_cc), *const CSl = LDSP(double, V->rq_cs);
-  double *const CCg = W->cost_coeff, *const CSg = W->cost_sig;
+  // blocks larger than 8x8 keep them in the workgroup's global scratch, and TWO waves can be quantising such a block at the same
+  // moment (depth 1: 32x32 luma, 16x16 chroma; depth 2: 16x16 luma): each depth has its own pair of arrays
+  const bool d1 = S->vsel[CTU_WAVE] == 3;
+  double *const CCg = d1 ? W->cost_coeff : W->cost_coeff0, *const CSg = d1 ? W->cost_sig : W->cost_coeff0 + 512;
   double *cost_cg_sig = (double *)V->t1;         // (the transform's other buffer: dead while a block is quantised; <= 64 groups)
   const int cap_half = 1 << (E.q_bits - 1);
   const int32_t cap = 0x7fffffff - cap_half;
@@ -1562,7 +1566,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
       const int level = __builtin_amdgcn_readlane(lev, k);
       block_uncoded_cost += k0;
       base_cost += kc;
-      spent += (level < 2 ? level : 3) + (cgs * 16 + k != last_scanpos);
+      // (the first position of a group other than group 0 resets the Rice parameter INSTEAD of paying: rdo.c:1690-1697)
+      if (!(k == 0 && cgs > 0)) spent += (level < 2 ? level : 3) + (cgs * 16 + k != last_scanpos);
       if (cgs) {                                // the group statistics only matter where a group can be zeroed out
         rd_sig += ks;
         if (k == 0) rd_sig0 = ks;

@@ -41,6 +41,10 @@ __global__ void __launch_bounds__(256, 4) ctu_search_kernel(launch_args A)
   ctu::lds<PX> *S = reinterpret_cast<ctu::lds<PX> *>(smem);
   __shared__ int s_ticket;
   __shared__ int s_slot;
+#if defined(CTU_POISON_LDS)          // debug builds (make EXTRA=-DCTU_POISON_LDS=0xA5): nothing may depend on what the LDS held before
+  for (unsigned i = threadIdx.x; i < sizeof(ctu::lds<PX>); i += 256) smem[i] = (unsigned char)(CTU_POISON_LDS);
+  __syncthreads();
+#endif
   if (threadIdx.x == 0) {
     s_ticket = atomicAdd(A.ticket, 1);
     // claim a scratch slot: more slots than workgroups can ever be resident, so a free bit always exists
