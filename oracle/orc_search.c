@@ -456,6 +456,14 @@ static void encode_chroma_intra(s_cabac *cb, int chroma_mode, int luma_dir, doub
 }
 
 /* intra_predict_regular + DC/planar/angular/PDPC (intra.c:660-753) through orc_intra.c */
+/* fw x fh: the size the smoothing filter covers -- the CU's, not the transform block's (intra.c:715-725: a 32x32 block of a 64x64 CU
+   has its entry 2N smoothed too, against the padding behind it) */
+static void predict_in_cu(int mode, int color, int w, int h, int fw, int fh, const orc_px *top, const orc_px *left, orc_px *dst)
+{
+  orc_px ftop[REF_LEN], fleft[REF_LEN];
+  ORC_FN(intra_filter_refs)(top, left, fw, fh, ftop, fleft);
+  ORC_FN(intra_predict)(mode, color != 0, w, h, top, left, ftop, fleft, dst);
+}
 static void predict(int mode, int color, int w, int h, const orc_px *top, const orc_px *left, orc_px *dst)
 {
   orc_px ftop[REF_LEN], fleft[REF_LEN];
@@ -599,14 +607,15 @@ static void quantize_tr_residual(s_state *st, int color, const s_loc *loc, s_cu 
 }
 
 /* intra_recon_tb_leaf (intra.c:1537-1614) */
-static void recon_tb_leaf(s_state *st, const s_loc *loc, s_lcu *lcu, int color, int mode)
+static void recon_tb_leaf(s_state *st, const s_loc *loc, s_lcu *lcu, int color, int mode, const s_cu *cu)
 {
   orc_px top[REF_LEN], left[REF_LEN], pred[32 * 32];
   const int shift = color == 0 ? 0 : 1;
   const int w = color == 0 ? loc->w : loc->cw, h = color == 0 ? loc->h : loc->ch;
   const int lw = LCU >> shift;
   build_reference(st, loc, color, lcu, top, left);
-  predict(mode, color, w, h, top, left, pred);
+  if (color == 0) predict_in_cu(mode, color, w, h, 1 << cu->log2_w, 1 << cu->log2_h, top, left, pred);
+  else predict(mode, color, w, h, top, left, pred);
   orc_px *block = (color == 0 ? lcu->rec_y : color == 1 ? lcu->rec_u : lcu->rec_v) + (loc->lx >> shift) + (loc->ly >> shift) * lw;
   for (int y = 0; y < h; ++y) memcpy(&block[y * lw], &pred[y * w], (size_t)w * sizeof(orc_px));
 }
@@ -626,8 +635,8 @@ static void intra_recon_cu(s_state *st, int mode, int mode_chroma, const s_loc *
     }
     return;
   }
-  if (recon_luma) recon_tb_leaf(st, loc, lcu, 0, mode);
-  if (recon_chroma) { recon_tb_leaf(st, loc, lcu, 1, mode_chroma); recon_tb_leaf(st, loc, lcu, 2, mode_chroma); }
+  if (recon_luma) recon_tb_leaf(st, loc, lcu, 0, mode, cur_cu);
+  if (recon_chroma) { recon_tb_leaf(st, loc, lcu, 1, mode_chroma, cur_cu); recon_tb_leaf(st, loc, lcu, 2, mode_chroma, cur_cu); }
   /* uvg_quantize_lcu_residual */
   if (recon_luma) cur_cu->cbf &= (uint8_t)~1;
   if (recon_chroma) cur_cu->cbf &= (uint8_t)~6;

@@ -764,3 +764,36 @@ def signhide_goldens(depth):
         else:
             out.append(dict(kind=1, w=m[1], h=m[2], color=m[3], qps=m[4], intra=m[5], ts=m[6], lfnst=m[7], coef=a[3], q=a[4]))
     return out
+
+
+def varied_picture(W, Hh, t, depth):
+    """Pictures for parity sweeps.  t < 1000: uvg266_amd.layout.synthetic_yuv420 of seed t.  t >= 1000: that picture plus noise
+    (t // 1000: 1 -> +-4, 2 -> +-32, 3 -> white noise over the full range, 4 -> sparse impulses on flat grey: lone large coefficients)."""
+    from uvg266_amd import layout
+    y, u, v = layout.synthetic_yuv420(W, Hh, t % 1000, depth)
+    kind = t // 1000
+    if kind == 0:
+        return y, u, v
+    rng = np.random.default_rng(t)
+    top = (1 << depth) - 1
+    out = []
+    for p in (y, u, v):
+        if kind == 3:
+            q = rng.integers(0, top + 1, p.shape)
+        elif kind == 4:
+            q = np.full(p.shape, 1 << (depth - 1), np.int64)
+            m = rng.random(p.shape) < 0.01
+            q[m] = rng.integers(0, top + 1, int(m.sum()))
+        else:
+            a = (4 if kind == 1 else 32) << (depth - 8)
+            q = p.astype(np.int64) + rng.integers(-a, a + 1, p.shape)
+        out.append(np.clip(q, 0, top).astype(p.dtype))
+    return tuple(out)
+
+
+def sweep_cases(n, seed):
+    """n (W, H, depth, qp, t) combinations: sizes with 8-sample CTUs at the edges, both depths, QP 0..51, every picture kind."""
+    import random
+    rng = random.Random(seed)
+    return [(rng.choice([64, 72, 128, 136, 192, 200, 256, 264, 320]), rng.choice([64, 72, 128, 136, 192]), rng.choice([8, 10]),
+             rng.choice([0, 3, 10, 17, 22, 27, 32, 37, 45, 51]), rng.randrange(0, 64) + 1000 * rng.choice([0, 1, 2, 3, 4])) for _ in range(n)]

@@ -6,7 +6,7 @@ import pytest
 import helpers as H
 
 
-@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_320x192_8_qp42", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7"])
+@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_320x192_8_qp42", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7", "ref_ctu_264x136_10_qp32"])
 def test_emulated_kernel_equals_the_reference_run(name):
     g = H.ctu_golden(name)
     W, Hh, depth, qp, y, u, v = H.golden_source(g)

@@ -26,7 +26,7 @@ def run_gpu(hip, depth, prm, pictures):
     return out
 
 
-@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_320x192_8_qp42", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7"])
+@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_320x192_8_qp42", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7", "ref_ctu_264x136_10_qp32"])
 def test_every_ctu_equals_the_reference_run(hip, name):
     g = H.ctu_golden(name)
     W, Hh, depth, qp, y, u, v = H.golden_source(g)
@@ -67,6 +67,19 @@ def test_repeated_runs_give_the_reference_result_every_time(hip, name):
         assert np.array_equal(r["coeff"], g["coeff"]), rep
         for p in ("rec_y", "rec_u", "rec_v"):
             assert np.array_equal(r[p], g[p]), (rep, p)
+
+
+def test_sweep_of_small_pictures_equals_the_oracle(hip, orc):
+    """48 pictures over sizes (incl. 8-sample CTUs at the right / bottom edge), both bit depths, QP 0..51 and five kinds of content
+    (smooth, noisy, white noise, lone impulses): the device search against the oracle, which tools/refcheck/sweep_ctu.py holds to the
+    real encoder on the same grid (1000 combinations at the time of writing)."""
+    for W, Hh, depth, qp, t in H.sweep_cases(48, 2024):
+        prm = H.search_params(W, Hh, qp)
+        pic = H.varied_picture(W, Hh, t, depth)
+        r = run_gpu(hip, depth, prm, [pic])[0]
+        o = H.oracle_search_picture(orc, depth, prm, *pic)
+        assert np.array_equal(H.ctu_crcs(r, W, Hh), H.ctu_crcs(o, W, Hh)), (W, Hh, depth, qp, t)
+        assert np.array_equal(r["models"], o["models"]), (W, Hh, depth, qp, t)
 
 
 def test_several_pictures_in_one_launch(hip, orc):

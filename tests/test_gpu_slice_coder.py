@@ -11,7 +11,7 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_320x192_8_qp42", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7",
+@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_320x192_8_qp42", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7", "ref_ctu_264x136_10_qp32",
                                   "ref_ctucrc_1920x1080_8_qp22", "ref_ctucrc_1920x1080_10_qp27",
                                   "ref_ctucrc_3840x2160_10_qp22"])
 def test_slice_data_equals_the_encoders(hip, name):

@@ -9,7 +9,7 @@ import pytest
 import helpers as H
 
 
-@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_320x192_8_qp42", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7"])
+@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_320x192_8_qp42", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7", "ref_ctu_264x136_10_qp32"])
 def test_golden_handover_counts_the_encoders_bits(orc, name):
     """The consumer itself, on the encoder's own hand-over (the golden's cu fields, trees, levels, start models)."""
     g = H.ctu_golden(name)
@@ -22,7 +22,7 @@ def test_golden_handover_counts_the_encoders_bits(orc, name):
     assert bits.sum() < 8 * len(g["bitstream"])       # (the rest of the stream: parameter sets, slice header, SAO syntax, row ends)
 
 
-@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_320x192_8_qp42", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7"])
+@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_320x192_8_qp42", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7", "ref_ctu_264x136_10_qp32"])
 def test_golden_handover_gives_the_encoders_bytes(orc, name):
     """The consumer as a real coder: every CTU's coding tree through the arithmetic coder (low, carries, bypass bins with their
     values) from the coder state the encoder had at that point -> the payload bytes the encoder's coder emitted during that tree
@@ -36,7 +36,7 @@ def test_golden_handover_gives_the_encoders_bytes(orc, name):
     assert np.array_equal(sout, g["coder_state"][:, 1])
 
 
-@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_320x192_8_qp42", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7"])
+@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_320x192_8_qp42", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7", "ref_ctu_264x136_10_qp32"])
 def test_golden_handover_gives_the_slice_data_of_the_encoders_stream(orc, name):
     """Everything between the slice header and the end of the slice NAL: the WPP rows' substreams -- SAO syntax and coding tree of
     every CTU through the arithmetic coder, models carried CTU to CTU and row to row, end_of_sub_stream_one_bit, the coder's
@@ -65,7 +65,7 @@ def test_oracle_search_handover_counts_the_encoders_bits(orc, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7", "ref_ctucrc_1920x1080_8_qp22",
+@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7", "ref_ctu_264x136_10_qp32", "ref_ctucrc_1920x1080_8_qp22",
                                   "ref_ctucrc_1920x1080_10_qp27", "ref_ctucrc_3840x2160_10_qp22"])
 def test_device_handover_counts_the_encoders_bits(hip, orc, name):
     """From the device's outputs: uvghip_scu_t table + levels + start models of uvghip_ctu_plan_run -> the count-mode coder."""

@@ -7,7 +7,7 @@ import pytest
 import helpers as H
 
 
-@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_320x192_8_qp42", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7"])
+@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_320x192_8_qp42", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7", "ref_ctu_264x136_10_qp32"])
 def test_every_ctu_equals_the_reference_run(orc, name):
     g = H.ctu_golden(name)
     W, Hh, depth, qp, y, u, v = H.golden_source(g)
@@ -27,7 +27,7 @@ def test_every_ctu_equals_the_reference_run(orc, name):
     assert np.array_equal(H.ctu_crcs(r, W, Hh)[:, 2], H.ctu_crcs(dict(r, coeff=g["coeff"]), W, Hh)[:, 2])
     # the partition really is a mix of sizes, and the search's final models differ from the coder's somewhere (why both are kept)
     sizes = set(np.unique(g["cu"][:h4, :w4, 1]).tolist())
-    assert {2, 3, 4, 5} <= sizes
+    assert len(sizes) >= 4 and sizes <= {2, 3, 4, 5, 6}
     assert any(not np.array_equal(g["models"][k, 1], g["models"][k, 2]) for k in range(len(g["models"])))
 
 

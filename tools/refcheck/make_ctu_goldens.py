@@ -35,9 +35,9 @@ def read_records(path):
     return recs
 
 
-def run(W, H, depth, qp, t, tag):
+def run(W, H, depth, qp, t, tag, picture=None):
     px = np.uint8 if depth == 8 else np.uint16
-    y, u, v = layout.synthetic_yuv420(W, H, t, depth)
+    y, u, v = (picture or layout.synthetic_yuv420)(W, H, t, depth)
     yuv = f"/tmp/gold_{tag}.yuv"
     with open(yuv, "wb") as f:
         for p in (y, u, v):
@@ -171,6 +171,7 @@ if __name__ == "__main__":
     full(320, 192, 8, 42, t=5)           # high QP: empty blocks, 64x64 CUs
     full(192, 128, 10, 12, t=9)          # low QP: dense blocks, the regular-bin budget runs out
     full(256, 128, 8, 7, t=2)
+    full(264, 136, 10, 32, t=26)         # 8-sample CTUs at both edges; a 64x64 CU with mode 66 (the smoothing filter's span is the CU's)
     crcs(1920, 1080, 8, 22)
     crcs(1920, 1080, 10, 27, t=3)
     crcs(3840, 2160, 10, 22)

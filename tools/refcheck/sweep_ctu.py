@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Dev-time parity sweep (CPU only, needs the survey's reference build like make_ctu_goldens.py): runs the real reference encoder
+on small synthetic pictures over a grid of sizes / bit depths / QPs / seeds and compares, CTU by CTU, the search kernel's source
+built for the host (tests/emul) with the reference's records: the three model sets, cu fields, trees, reconstruction, levels.
+Nothing is written to tests/golden; a combination that differs is what to turn into a golden (make_ctu_goldens.full).
+
+  python tools/refcheck/sweep_ctu.py [n_cases] [seed]"""
+import os, sys, random
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import make_ctu_goldens as M
+import helpers as H
+from uvg266_amd import layout
+
+ORC = H.load_oracle()
+
+
+def one(W, Hh, depth, qp, t):
+    tag = f"sweep_{W}x{Hh}_{depth}_qp{qp}_t{t}"
+    S, Cd, src_crc, bs, px = M.run(W, Hh, depth, qp, t, tag, picture=H.varied_picture)
+    wc, hc = (W + 63) // 64, (Hh + 63) // 64
+    y, u, v = H.varied_picture(W, Hh, t, depth)
+    prm = H.search_params(W, Hh, qp)
+    lam = float(S[0][1][0]) if hasattr(S[0][1], "__len__") else float(S[0][1])
+    assert abs(lam - prm.lam) < 1e-12 * max(1.0, lam), (lam, prm.lam)
+    bad = []
+    for who, r in (("emul", H.emul_search_picture(depth, prm, y, u, v)), ("oracle", H.oracle_search_picture(ORC, depth, prm, y, u, v))):
+      for s, c in zip(S, Cd):
+          x, yy, hh, ww, ccu, ctr, ry, ru, rv, cy, cuv = M.items(s, c, W, Hh)
+          k = (yy // 64) * wc + x // 64
+          ok = (np.array_equal(r["models"][k, 0], s[2][:1286]) and np.array_equal(r["models"][k, 1], s[3][:1286]) and np.array_equal(r["models"][k, 2], c[2][:1286])
+                and np.array_equal(r["cu"][yy // 4:yy // 4 + hh // 4, x // 4:x // 4 + ww // 4], ccu)
+                and np.array_equal(r["trees"][yy // 4:yy // 4 + hh // 4, x // 4:x // 4 + ww // 4], ctr)
+                and np.array_equal(r["rec_y"][yy:yy + hh, x:x + ww], ry) and np.array_equal(r["rec_u"][yy // 2:(yy + hh) // 2, x // 2:(x + ww) // 2], ru)
+                and np.array_equal(r["rec_v"][yy // 2:(yy + hh) // 2, x // 2:(x + ww) // 2], rv)
+                and np.array_equal(r["coeff"][k][:4096].reshape(64, 64)[:hh, :ww], cy)
+                and np.array_equal(r["coeff"][k][4096:].reshape(2, 32, 32)[:, :hh // 2, :ww // 2], cuv))
+          if not ok: bad.append((who, x // 64, yy // 64))
+    return bad
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    fails = 0
+    for W, Hh, depth, qp, t in H.sweep_cases(n, int(sys.argv[2]) if len(sys.argv) > 2 else 1):
+        bad = one(W, Hh, depth, qp, t)
+        print(f"{W}x{Hh} {depth}-bit qp {qp} t {t}: {'ok' if not bad else 'DIFFERS at CTUs ' + str(bad[:6])}", flush=True)
+        fails += bool(bad)
+    print("cases that differ:", fails)

@@ -340,7 +340,9 @@ template <typename PX> CTU_DEV int count_edge_cus(lds<PX> *S, int x, int y, int 
 
 // uvg_intra_build_reference (intra.c:1344; _inner :1065-1341 when the block touches neither picture edge, _any :756-1063 else) for the
 // w x w block of `color` whose luma position is (x, y) / CTU-local (lx, ly) with luma size n; + the smoothed rows (:190-225)
-template <typename PX> CTU_NOINLINE CTU_DEV void build_refs(lds<PX> *S, const params &P, int color, int x, int y, int lx, int ly, int n)
+// cu_n: the size of the CU the block belongs to.  The smoothing filter covers 2 * (the CU's size) entries, not 2 * (the block's)
+// (intra.c:715-725): in a 32x32 transform block of a 64x64 CU entry 2N is smoothed too, against the padding behind it.
+template <typename PX> CTU_NOINLINE CTU_DEV void build_refs(lds<PX> *S, const params &P, int color, int x, int y, int lx, int ly, int n, int cu_n)
 {
   wctx *const V = wv_of(S);
   const int c = color != 0;
@@ -379,12 +381,13 @@ template <typename PX> CTU_NOINLINE CTU_DEV void build_refs(lds<PX> *S, const pa
     r_left[0] = r_top[0] = (uint16_t)corner;
   }
   CTU_SYNC();
+  const int flim = 2 * (cu_n >> c) < V->refn - 1 ? 2 * (cu_n >> c) : V->refn - 1;
   PAR_FOR(i, V->refn) {
     int fl, ft;
     if (i == 0) fl = ft = (r_left[1] + 2 * r_left[0] + r_top[1] + 2) >> 2;
     else {
-      fl = i < 2 * w ? (r_left[i - 1] + 2 * r_left[i] + r_left[i + 1] + 2) >> 2 : r_left[i];
-      ft = i < 2 * w ? (r_top[i - 1] + 2 * r_top[i] + r_top[i + 1] + 2) >> 2 : r_top[i];
+      fl = i < flim ? (r_left[i - 1] + 2 * r_left[i] + r_left[i + 1] + 2) >> 2 : r_left[i];
+      ft = i < flim ? (r_top[i - 1] + 2 * r_top[i] + r_top[i + 1] + 2) >> 2 : r_top[i];
     }
     r_fleft[i] = (uint16_t)fl;
     r_ftop[i] = (uint16_t)ft;
@@ -1853,7 +1856,7 @@ template <typename PX> CTU_DEV int scaled_qp(const params &P, int color) { retur
 // predict + uvg_quantize_residual (quant-generic.c:460-612, RDOQ branch) of one transform block straight into D; its levels stay in
 // lv_of(V, color) and go to the CTU's coefficient array.  (x, y) / (lx, ly): luma position, n: luma size of the area.  -> has_coeffs
 template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<PX> &J, int color, int x, int y, int lx, int ly, int n, int mode, int cbf_u,
-                                                         PX *dst_, int dp, int16_t *co, int cp)
+                                                         PX *dst_, int dp, int16_t *co, int cp, int cu_n)
 {
   // dst / dp: where the block is reconstructed (the decided planes, or the depth's candidate buffer); co / cp: where its levels go
   wctx *const V = wv_of(S);
@@ -1864,7 +1867,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<P
   CTU_GLB const PX *Sp = src_block(J, color, lx >> c, ly >> c, &sps);
   const int depth = (int)px_info<PX>::depth;
   { CTU_T0();
-  build_refs(S, J.P, color, x, y, lx, ly, n);
+  build_refs(S, J.P, color, x, y, lx, ly, n, cu_n);
   predict_block(S, mode, color, w, dst_, dp);
   CTU_T1(J.W, 1); }
   { CTU_T0();
@@ -2380,7 +2383,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
   }
   CTU_SYNC();
   { CTU_T0();
-  build_refs(S, P, 0, x, y, lx, ly, n);
+  build_refs(S, P, 0, x, y, lx, ly, n, n);
   search_intra_rough(S, J, x, y, lx, ly, n);
   CTU_T1(J.W, 0); }
   const int mode = V->u_mode;
@@ -2404,10 +2407,10 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
     ku = J.coeff + 4096 + ((cy & 63) >> 1) * LCU_C + ((cx & 63) >> 1); kv = J.coeff + 5120 + ((cy & 63) >> 1) * LCU_C + ((cx & 63) >> 1);
     rpy = PY; rpc = PC; kpy = LCU; kpc = LCU_C;
   }
-  int cbf = recon_tu(S, J, 0, x, y, lx, ly, n, mode, 0, ry, rpy, ky, kpy);
+  int cbf = recon_tu(S, J, 0, x, y, lx, ly, n, mode, 0, ry, rpy, ky, kpy, n);
   if (has_chroma) {
-    const int cu = recon_tu(S, J, 1, cx, cy, cx & 63, cy & 63, area, mode, 0, ru, rpc, ku, kpc);
-    const int cv = recon_tu(S, J, 2, cx, cy, cx & 63, cy & 63, area, mode, cu, rv, rpc, kv, kpc);
+    const int cu = recon_tu(S, J, 1, cx, cy, cx & 63, cy & 63, area, mode, 0, ru, rpc, ku, kpc, area);
+    const int cv = recon_tu(S, J, 2, cx, cy, cx & 63, cy & 63, area, mode, cu, rv, rpc, kv, kpc, area);
     cbf |= cu << 1 | cv << 2;
     { CTU_T0();
     ssd_block(S, J, 1, cx & 63, cy & 63, area, 1, ru, rpc);
@@ -2517,9 +2520,9 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu64(lds<PX> *S, const job
     const int tx = x + (i & 1) * 32, ty = y + (i >> 1) * 32, lx = tx & 63, ly = ty & 63;
     PX *ry = S->Dy + (ly + 1) * PY + lx + 1, *ru = S->Du + ((ly >> 1) + 1) * PC + (lx >> 1) + 1, *rv = S->Dv + ((ly >> 1) + 1) * PC + (lx >> 1) + 1;
     int16_t *ky = J.coeff + ly * LCU + lx, *ku = J.coeff + 4096 + (ly >> 1) * LCU_C + (lx >> 1), *kv = J.coeff + 5120 + (ly >> 1) * LCU_C + (lx >> 1);
-    int cbf = recon_tu(S, J, 0, tx, ty, lx, ly, 32, mode, 0, ry, PY, ky, LCU);
-    const int cu = recon_tu(S, J, 1, tx, ty, lx, ly, 32, mode_chroma, 0, ru, PC, ku, LCU_C);
-    const int cv = recon_tu(S, J, 2, tx, ty, lx, ly, 32, mode_chroma, cu, rv, PC, kv, LCU_C);
+    int cbf = recon_tu(S, J, 0, tx, ty, lx, ly, 32, mode, 0, ry, PY, ky, LCU, 64);
+    const int cu = recon_tu(S, J, 1, tx, ty, lx, ly, 32, mode_chroma, 0, ru, PC, ku, LCU_C, 64);
+    const int cv = recon_tu(S, J, 2, tx, ty, lx, ly, 32, mode_chroma, cu, rv, PC, kv, LCU_C, 64);
     cbf |= cu << 1 | cv << 2;
     SERIAL cu_at(S, lx, ly)->cbf = (uint8_t)cbf;
     CTU_SYNC();
