@@ -571,7 +571,7 @@ def golden_source(g):
     import zlib
     from uvg266_amd import layout
     W, H, depth, qp, t = (int(a) for a in g["meta"][:5])
-    y, u, v = layout.synthetic_yuv420(W, H, t, depth)
+    y, u, v = varied_picture(W, H, t, depth)        # (t < 1000: layout.synthetic_yuv420 itself)
     assert zlib.crc32(y.tobytes() + u.tobytes() + v.tobytes()) == int(g["src_crc"]), "synthetic generator drifted from the golden's source"
     return W, H, depth, qp, y, u, v
 

@@ -62,3 +62,30 @@ def test_standalone_entry_point_and_sao_off(hip, orc):
         else:
             want, off, _ = H.oracle_encode_rows_no_sao(orc, depth, prm, res)
         assert np.array_equal(np.concatenate([[0], np.cumsum(nb)]), off) and np.array_equal(got, want), sao
+
+
+def test_sweep_whole_loop_equals_the_oracle_chain(hip, orc):
+    """uvghip_loop_plan_run (search -> per-CTU deblocking -> SAO decisions -> final picture -> slice data) on 32 combinations of the
+    sweep grid (sizes with 8-sample edge CTUs, both depths, QP 0..51, smooth / noisy / white-noise / impulse pictures) against the
+    oracle's chain on the same source: final picture, SAO decisions, slice data byte for byte.  tools/refcheck/sweep_ctu.py holds the
+    oracle's chain to the real encoder on the same grid."""
+    import torch
+    from uvg266_amd import api
+    for W, Hh, depth, qp, t in H.sweep_cases(32, 31337):
+        prm = H.search_params(W, Hh, qp)
+        y, u, v = H.varied_picture(W, Hh, t, depth)
+        cl = api.ClosedLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in (y, u, v))])
+        cl.run()
+        out, nbytes = cl.slice_data()
+        info, models = cl.results()
+        nb = nbytes.cpu().numpy()[0]
+        got = np.concatenate([out[0, r, :nb[r]].cpu().numpy() for r in range(len(nb))])
+        final = [p.cpu().numpy() for p in cl.out[0]]
+        s = H.oracle_search_picture(orc, depth, prm, y, u, v)
+        f = H.oracle_sao_picture(orc, depth, W, Hh, qp, prm.lam, (y, u, v), (s["rec_y"], s["rec_u"], s["rec_v"]), H.scu_from_cu(s["cu"], qp))
+        want, off, _ = H.oracle_encode_rows(orc, depth, prm, s, f["sao"])
+        case = (W, Hh, depth, qp, t)
+        assert np.array_equal(H.sao_info_comparable(info[0]), H.sao_info_comparable(f["sao"])), case
+        for a, k in zip(final, ("final_y", "final_u", "final_v")):
+            assert np.array_equal(a, f[k]), (case, k)
+        assert np.array_equal(np.concatenate([[0], np.cumsum(nb)]), off) and np.array_equal(got, want), case

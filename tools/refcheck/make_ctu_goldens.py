@@ -109,9 +109,9 @@ def items(s, c, W, H):
     return x, y, hh, ww, cu, trees, ry, ru, rv, cy, cuv
 
 
-def full(W, H, depth, qp, t=0):
+def full(W, H, depth, qp, t=0, picture=None, out_dir=None):
     tag = f"{W}x{H}_{depth}_qp{qp}"
-    S, Cd, src_crc, bs, px = run(W, H, depth, qp, t, tag)
+    S, Cd, src_crc, bs, px = run(W, H, depth, qp, t, tag, picture)
     wc, hc = (W + 63) // 64, (H + 63) // 64
     assert len(S) == wc * hc == len(Cd)
     models = np.zeros((hc * wc, 3, 1286), np.uint8)
@@ -133,10 +133,10 @@ def full(W, H, depth, qp, t=0):
         co[4096:].reshape(2, 32, 32)[:, :hh // 2, :ww // 2] = cuv
     meta = np.array([W, H, depth, qp, t, int(S[0][0][3])], np.int32)
     info, sm, snap, final = sao_items(W, H, Cd, px)
-    np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_ctu_{tag}.npz"), meta=meta, lam=S[0][1], src_crc=np.uint32(src_crc), models=models,
+    np.savez_compressed(os.path.join(out_dir or os.path.join(ROOT, "tests/golden"), f"ref_ctu_{tag}.npz"), meta=meta, lam=S[0][1], src_crc=np.uint32(src_crc), models=models,
                         cu=cu, trees=trees, rec_y=rec[0], rec_u=rec[1], rec_v=rec[2], coeff=coeff, bitstream=bs,
                         sao=info, sao_models=sm, coder=CODER, coder_state=CODER_STATE, tree_bytes=TREE_BYTES, tree_off=TREE_OFF, row_bytes=ROW_BYTES, row_off=ROW_OFF, snap_y=snap[0], snap_u=snap[1], snap_v=snap[2], final_y=final[0], final_u=final[1], final_v=final[2])
-    print("wrote", tag, len(S), "CTUs")
+    if not out_dir: print("wrote", tag, len(S), "CTUs")
 
 
 def crcs(W, H, depth, qp, t=0):

@@ -40,11 +40,29 @@ def one(W, Hh, depth, qp, t):
     return bad
 
 
+def filters_and_coder(W, Hh, depth, qp, t):
+    """The other half of the closed loop, oracle against the encoder's records: per-CTU deblocking + SAO decisions + final picture
+    (tests/test_oracle_sao_search.py) and the slice data (tests/test_handover.py), from a golden written to /tmp."""
+    M.full(W, Hh, depth, qp, t, picture=H.varied_picture, out_dir="/tmp")
+    g = np.load(f"/tmp/ref_ctu_{W}x{Hh}_{depth}_qp{qp}.npz")
+    _, _, _, _, y, u, v = H.golden_source(g)
+    bad = []
+    r = H.oracle_sao_picture(ORC, depth, W, Hh, qp, float(g["lam"][0]), (y, u, v), (g["rec_y"], g["rec_u"], g["rec_v"]), H.scu_from_cu(g["cu"], qp))
+    for k in ("snap_y", "snap_u", "snap_v", "final_y", "final_u", "final_v", "sao_models"):
+        if not np.array_equal(r[k], g[k]): bad.append(k)
+    if not np.array_equal(H.sao_info_comparable(r["sao"]), H.sao_info_comparable(g["sao"])): bad.append("sao")
+    res = dict(cu=g["cu"], trees=g["trees"], coeff=g["coeff"])
+    data, off, after = H.oracle_encode_rows(ORC, depth, H.search_params(W, Hh, qp), res, g["sao"])
+    if not (np.array_equal(off, g["row_off"]) and np.array_equal(data, g["row_bytes"]) and np.array_equal(after, g["models"][:, 2])): bad.append("slice data")
+    elif g["bitstream"].tobytes().find(data.tobytes()) <= 0: bad.append("slice data not in the .266")
+    return bad
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     fails = 0
     for W, Hh, depth, qp, t in H.sweep_cases(n, int(sys.argv[2]) if len(sys.argv) > 2 else 1):
-        bad = one(W, Hh, depth, qp, t)
-        print(f"{W}x{Hh} {depth}-bit qp {qp} t {t}: {'ok' if not bad else 'DIFFERS at CTUs ' + str(bad[:6])}", flush=True)
+        bad = one(W, Hh, depth, qp, t) + filters_and_coder(W, Hh, depth, qp, t)
+        print(f"{W}x{Hh} {depth}-bit qp {qp} t {t}: {'ok' if not bad else 'DIFFERS: ' + str(bad[:6])}", flush=True)
         fails += bool(bad)
     print("cases that differ:", fails)

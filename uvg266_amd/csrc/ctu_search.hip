@@ -66,11 +66,18 @@ __global__ void __launch_bounds__(256, 4) ctu_search_kernel(launch_args A)
   const int ctus = A.wc * A.hc, k = cy * A.wc + cx;
   int32_t *done = A.done + (size_t)pic * ctus;
   if (threadIdx.x == 0) {
-    if (cx > 0) while (__hip_atomic_load(&done[k - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
-    if (cy > 0) while (__hip_atomic_load(&done[k - A.wc], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+    // Relaxed polls with a growing nap (an acquire per poll would invalidate this CU's L1 and the XCD's L2 under the other workgroups
+    // every microsecond), then ONE agent-scope acquire: the L1 is the CU's, so the other waves' loads after the barrier are behind it.
+    int naps = 1;
+    const int32_t *deps[2] = {cx > 0 ? &done[k - 1] : nullptr, cy > 0 ? &done[k - A.wc] : nullptr};
+    for (int d = 0; d < 2; ++d)
+      while (deps[d] && __hip_atomic_load(deps[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);
+        if (naps < 8) naps <<= 1;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
-  __threadfence();          // every lane's later loads come after the neighbours' release
   const pic_dev &D = A.pics[pic];
   ctu::job<PX> J;
   J.P = A.P;
@@ -86,9 +93,9 @@ __global__ void __launch_bounds__(256, 4) ctu_search_kernel(launch_args A)
   J.W = A.scratch + s_slot;
   J.x = cx * 64; J.y = cy * 64;
   ctu::run_ctu(S, J);
-  __threadfence();
-  __syncthreads();
+  __syncthreads();          // every wave's stores are complete (workgroup-scope release) ...
   if (threadIdx.x == 0) {
+    // ... and ONE agent-scope release writes the XCD's L2 back (it is shared by the waves): a fence per wave did that four times over
     __hip_atomic_store(&done[k], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     atomicAnd(&A.slots[s_slot >> 5], ~(1u << (s_slot & 31)));          // the scratch is free again
   }

@@ -72,7 +72,7 @@ __global__ void sao_candidates_kernel(const int32_t *__restrict__ edge_y, const 
       // the reference steps the offset towards 0 and keeps the LAST step's values (its best_dist is never lowered, :233-241): +-1
       const int of = o > 0 ? 1 : (o < 0 ? -1 : 0);
       const int dist = of ? cnt * of * of - 2 * of * s : 0;
-      if (band >= 3) {
+      if (band >= 3 && band < 31) {          // starting positions 0..27 only (sao.c:248: band < 28), although 28 would fit
         const int tot = (int)((unsigned)d0 + (unsigned)d1 + (unsigned)d2 + (unsigned)dist);
         if (tot < best) { best = tot; best_pos = band - 3; }
       }
