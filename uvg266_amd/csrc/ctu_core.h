@@ -34,7 +34,8 @@
 
 #if defined(__HIPCC__)
 #define CTU_NOINLINE __attribute__((noinline))
-#define CTU_DEV __device__
+#define CTU_INLINE1 __attribute__((always_inline))          // one call site: no call, no callee-saved registers through the stack
+#define CTU_DEV static __device__
 // Everything the search computes is WAVE-local: a depth of the quad tree is worked by one wave (see search_ctu), so "all lanes"
 // means the 64 lanes of that wave and a hand-over between regions is a wave-level fence, not a workgroup barrier.
 #define CTU_TID ((int)(threadIdx.x & 63))
@@ -47,6 +48,7 @@
 #define BLK_SYNC() __syncthreads()
 #else
 #define CTU_NOINLINE
+#define CTU_INLINE1
 #define CTU_DEV static inline
 #define CTU_TID 0
 #define CTU_NT 1
@@ -615,7 +617,7 @@ template <typename PX> CTU_DEV void mpm_neighbours(lds<PX> *S, int x, int y, int
 }
 
 // search_intra_rough (search_intra.c:986-1229), three survivors; the winner goes to V->u_mode
-template <typename PX> CTU_NOINLINE CTU_DEV void search_intra_rough(lds<PX> *S, const job<PX> &J, int x, int y, int lx, int ly, int n)
+template <typename PX> CTU_INLINE1 CTU_DEV void search_intra_rough(lds<PX> *S, const job<PX> &J, int x, int y, int lx, int ly, int n)
 {
   wctx *const V = wv_of(S);
   const params &P = J.P;
@@ -1423,7 +1425,7 @@ CTU_DEV double rl64(double v, int lane)
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
 }
-template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *W, const int16_t *coef_, int16_t *dst_, int n, int color, int cbf_u, int qp_scaled,
+template <typename PX> CTU_INLINE1 CTU_DEV void rdoq_wave(lds<PX> *S, scratch *W, const int16_t *coef_, int16_t *dst_, int n, int color, int cbf_u, int qp_scaled,
                                               double lambda, int bitdepth)
 {
   wctx *const V = wv_of(S);
@@ -1855,8 +1857,8 @@ template <typename PX> CTU_DEV int scaled_qp(const params &P, int color) { retur
 
 // predict + uvg_quantize_residual (quant-generic.c:460-612, RDOQ branch) of one transform block straight into D; its levels stay in
 // lv_of(V, color) and go to the CTU's coefficient array.  (x, y) / (lx, ly): luma position, n: luma size of the area.  -> has_coeffs
-template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<PX> &J, int color, int x, int y, int lx, int ly, int n, int mode, int cbf_u,
-                                                         PX *dst_, int dp, int16_t *co, int cp, int cu_n)
+template <typename PX> CTU_INLINE1 CTU_DEV int recon_tu_inl(lds<PX> *S, const job<PX> &J, int color, int x, int y, int lx, int ly, int n, int mode, int cbf_u,
+                                                            PX *dst_, int dp, int16_t *co, int cp, int cu_n)
 {
   // dst / dp: where the block is reconstructed (the decided planes, or the depth's candidate buffer); co / cp: where its levels go
   wctx *const V = wv_of(S);
@@ -1904,6 +1906,14 @@ template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<P
   }
   CTU_SYNC();
   return has;
+}
+// Called per block, a noinline function saves ~45 callee-saved VGPRs to the stack and reloads them (256 B each): with RDOQ and the
+// rough search, 20 MB of stack traffic per CTU.  The CU evaluation therefore has ONE call site (a loop over the colours) with the body
+// inlined; the rare 64x64 candidate goes through this out-of-line copy.
+template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<PX> &J, int color, int x, int y, int lx, int ly, int n, int mode, int cbf_u,
+                                                         PX *dst_, int dp, int16_t *co, int cp, int cu_n)
+{
+  return recon_tu_inl(S, J, color, x, y, lx, ly, n, mode, cbf_u, dst_, dp, co, cp, cu_n);
 }
 
 // uvg_pixels_calc_ssd of a w x w block of D against the source, into V->red[slot] (valid after the barrier)
@@ -2407,11 +2417,17 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
     ku = J.coeff + 4096 + ((cy & 63) >> 1) * LCU_C + ((cx & 63) >> 1); kv = J.coeff + 5120 + ((cy & 63) >> 1) * LCU_C + ((cx & 63) >> 1);
     rpy = PY; rpc = PC; kpy = LCU; kpc = LCU_C;
   }
-  int cbf = recon_tu(S, J, 0, x, y, lx, ly, n, mode, 0, ry, rpy, ky, kpy, n);
+  int cbf = 0;
+#if defined(__HIPCC__)
+#pragma nounroll
+#endif
+  for (int color = 0; color < (has_chroma ? 3 : 1); ++color) {
+    const bool c = color != 0;
+    const int has = recon_tu_inl(S, J, color, c ? cx : x, c ? cy : y, c ? cx & 63 : lx, c ? cy & 63 : ly, c ? area : n, mode, color == 2 ? (cbf >> 1) & 1 : 0,
+                                 color == 0 ? ry : (color == 1 ? ru : rv), c ? rpc : rpy, color == 0 ? ky : (color == 1 ? ku : kv), c ? kpc : kpy, c ? area : n);
+    cbf |= has << color;
+  }
   if (has_chroma) {
-    const int cu = recon_tu(S, J, 1, cx, cy, cx & 63, cy & 63, area, mode, 0, ru, rpc, ku, kpc, area);
-    const int cv = recon_tu(S, J, 2, cx, cy, cx & 63, cy & 63, area, mode, cu, rv, rpc, kv, kpc, area);
-    cbf |= cu << 1 | cv << 2;
     { CTU_T0();
     ssd_block(S, J, 1, cx & 63, cy & 63, area, 1, ru, rpc);
     ssd_block(S, J, 2, cx & 63, cy & 63, area, 2, rv, rpc);
