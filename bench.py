@@ -686,7 +686,7 @@ def main():
                                      "CTUs of a picture are a wavefront of dependent workgroups.  It is bound by the dependency chain inside a CTU "
                                      "(serial RD bookkeeping on one lane at ~8 cycles per instruction; DESIGN.md section 4.6 has the phase profile), "
                                      "not by HBM: achieved = algorithmic bytes (source in, reconstruction / levels / side information / models out) "
-                                     "/ average launch duration from HIP events on the launch stream.  traffic (PMC, fabric side of the L2) is ~100x "
+                                     "/ average launch duration from HIP events on the launch stream.  traffic (PMC, fabric side of the L2) is two orders of magnitude above "
                                      "the algorithmic bytes and is not re-reads of them: it is the call stack -- callee-saved VGPRs saved and reloaded "
                                      "by the out-of-line functions of the 133 KB kernel (SQ_INSTS_VMEM_WR 29 k per CTU), written through to the fabric "
                                      "(TCC_EA0_WRREQ 73 k 64-byte requests per CTU, L2 hit rate 89 %); ~0.6 TB/s while the kernel runs, 7 % of the peak"},
