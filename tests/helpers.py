@@ -791,9 +791,9 @@ def varied_picture(W, Hh, t, depth):
     return tuple(out)
 
 
-def sweep_cases(n, seed):
+def sweep_cases(n, seed, widths=(64, 72, 128, 136, 192, 200, 256, 264, 320), heights=(64, 72, 128, 136, 192)):
     """n (W, H, depth, qp, t) combinations: sizes with 8-sample CTUs at the edges, both depths, QP 0..51, every picture kind."""
     import random
     rng = random.Random(seed)
-    return [(rng.choice([64, 72, 128, 136, 192, 200, 256, 264, 320]), rng.choice([64, 72, 128, 136, 192]), rng.choice([8, 10]),
+    return [(rng.choice(list(widths)), rng.choice(list(heights)), rng.choice([8, 10]),
              rng.choice([0, 3, 10, 17, 22, 27, 32, 37, 45, 51]), rng.randrange(0, 64) + 1000 * rng.choice([0, 1, 2, 3, 4])) for _ in range(n)]

@@ -4,7 +4,7 @@ on small synthetic pictures over a grid of sizes / bit depths / QPs / seeds and 
 built for the host (tests/emul) with the reference's records: the three model sets, cu fields, trees, reconstruction, levels.
 Nothing is written to tests/golden; a combination that differs is what to turn into a golden (make_ctu_goldens.full).
 
-  python tools/refcheck/sweep_ctu.py [n_cases] [seed]"""
+  python tools/refcheck/sweep_ctu.py [n_cases] [seed] [default|small|large]"""
 import os, sys, random
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -61,7 +61,10 @@ def filters_and_coder(W, Hh, depth, qp, t):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     fails = 0
-    for W, Hh, depth, qp, t in H.sweep_cases(n, int(sys.argv[2]) if len(sys.argv) > 2 else 1):
+    grid = sys.argv[3] if len(sys.argv) > 3 else "default"          # default | small (sides 8..56 too) | large (up to 640x384)
+    kw = dict(small=dict(widths=(8, 16, 24, 40, 56, 64, 104), heights=(8, 16, 32, 48, 56, 64, 88)),
+              large=dict(widths=(384, 448, 520, 640), heights=(264, 320, 384))).get(grid, {})
+    for W, Hh, depth, qp, t in H.sweep_cases(n, int(sys.argv[2]) if len(sys.argv) > 2 else 1, **kw):
         bad = one(W, Hh, depth, qp, t) + filters_and_coder(W, Hh, depth, qp, t)
         print(f"{W}x{Hh} {depth}-bit qp {qp} t {t}: {'ok' if not bad else 'DIFFERS: ' + str(bad[:6])}", flush=True)
         fails += bool(bad)
