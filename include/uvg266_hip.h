@@ -910,6 +910,26 @@ UVGHIP_API int uvghip_encode_slice_rows(int bitdepth, const uvghip_ctu_params_t 
                                         int n_pictures, const int32_t *sao_info, const uint16_t *sao_models, void *workspace,
                                         uint8_t *out, int row_cap, int32_t *row_bytes, void *stream);
 
+/* ------------------- (7) the picture's NAL units behind the parameter sets -------------------------------------------- */
+
+/* replaces: uvg_image_checksum / array_checksum_generic (src/nal.c:91-115, src/strategies/generic/nal-generic.c:68-92) on the
+ * picture after the in-loop filters: per plane the sum of (low byte ^ m) [+ (high byte ^ m) above 8 bits], m = (x ^ y ^ x >> 8 ^
+ * y >> 8) & 0xff, modulo 2^32.  sums: three uint32 in DEVICE memory (Y, U, V), zeroed and filled on the stream. */
+UVGHIP_API int uvghip_picture_checksum(int bitdepth, const void *plane_y, int stride_y, const void *plane_u, const void *plane_v,
+                                       int stride_c, int width, int height, uint32_t *sums, void *stream);
+
+/* replaces: for an IDR picture of an all-intra (-p 1) stream in the configuration of uvghip_ctu_plan_create (WPP, one slice, picture
+ * header in the slice header): uvg_nal_write + uvg_encoder_state_write_bitstream_slice_header with the entry points
+ * (src/encoder_state-bitstream.c:993-1139, 1248-1411, src/nal.c:43-74), the rows' substreams appended as the encoder's
+ * uvg_bitstream_move does, and add_checksum (:1420-1477), with the emulation prevention of src/bitstream.c:215-226.
+ * A HOST function (works without a device): rows = the slice data of uvghip_encode_slice_rows copied to host memory (row r at rows +
+ * r * row_pitch, row_bytes[r] bytes), checksum = the three sums of uvghip_picture_checksum (NULL: no SEI), sao != 0: the stream has
+ * SAO on (two flags in the header).  Writes at most cap bytes to out, *len = the bytes needed (an error if that is more than cap).
+ * Behind the encoder's parameter sets (SPS, PPS, version SEI -- control plane, independent of the picture) these bytes complete the
+ * .266 of a one-picture encode, byte for byte (tests/test_picture_nal.py). */
+UVGHIP_API int uvghip_write_picture_nals(int poc, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
+                                         const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len);
+
 #ifdef __cplusplus
 }
 #endif

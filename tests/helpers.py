@@ -797,3 +797,50 @@ def sweep_cases(n, seed, widths=(64, 72, 128, 136, 192, 200, 256, 264, 320), hei
     rng = random.Random(seed)
     return [(rng.choice(list(widths)), rng.choice(list(heights)), rng.choice([8, 10]),
              rng.choice([0, 3, 10, 17, 22, 27, 32, 37, 45, 51]), rng.randrange(0, 64) + 1000 * rng.choice([0, 1, 2, 3, 4])) for _ in range(n)]
+
+
+# ---- the picture's NAL units behind the parameter sets (checker for uvghip_write_picture_nals / uvghip_picture_checksum) ----
+def picture_checksum(plane, depth):
+    """uvg_image_checksum of one plane (src/strategies/generic/nal-generic.c:68-92): sum of (byte ^ mask) over the samples' bytes."""
+    h, w = plane.shape
+    yy, xx = np.mgrid[0:h, 0:w]
+    mask = ((xx & 0xff) ^ (yy & 0xff) ^ (xx >> 8) ^ (yy >> 8)) & 0xff
+    p = plane.astype(np.int64)
+    s = ((p & 0xff) ^ mask).sum()
+    if depth > 8:
+        s += (((p >> 8) & 0xff) ^ mask).sum()
+    return int(s) & 0xffffffff
+
+
+def picture_nals(row_sizes, rows, checksums, poc=0, sao=True):
+    """Slice NAL (header with the entry points + the rows) and the decoded-picture-hash SEI as the encoder writes them for an IDR
+    picture of an all-intra stream (src/encoder_state-bitstream.c:993-1139, 1248-1477; src/nal.c:43-74; emulation prevention of
+    src/bitstream.c:215-226), restated bit by bit.  rows: list of bytes objects.  -> bytes"""
+    def ue(v):
+        v += 1
+        n = v.bit_length()
+        return "0" * (n - 1) + format(v, "b")
+
+    def payload(bits):
+        assert len(bits) % 8 == 0
+        out, zeros = bytearray(), 0
+        for i in range(0, len(bits), 8):
+            b = int(bits[i:i + 8], 2)
+            if zeros == 2 and b < 4:
+                out.append(3)
+                zeros = 0
+            zeros = zeros + 1 if b == 0 else 0
+            out.append(b)
+        return bytes(out)
+
+    bits = "1" + "1" + "0" + "0" + "0" + ue(0) + format(poc & 15, "04b") + "0" + "1" + ("11" if sao else "")
+    if len(row_sizes) > 1:
+        ol = int(max(row_sizes)).bit_length()
+        bits += ue(ol - 1) + "".join(format(int(s) - 1, "0%db" % ol) for s in row_sizes[:-1])
+    bits += "1"
+    bits += "0" * (-len(bits) % 8)
+    out = b"\x00\x00\x01\x00\x41" + payload(bits) + b"".join(rows)
+    if checksums is not None:
+        sei = format(132, "08b") + format(14, "08b") + format(2, "08b") + format(0, "08b") + "".join(format(int(c), "032b") for c in checksums) + "10000000"
+        out += b"\x00\x00\x01\x00\xc1" + payload(sei)
+    return out

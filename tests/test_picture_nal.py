@@ -1,0 +1,98 @@
+"""uvghip_write_picture_nals (a host function of the library: slice NAL with the entry points + the rows' substreams, decoded
+picture hash SEI) and uvghip_picture_checksum: behind the encoder's parameter sets they complete the .266 of a one-picture
+all-intra encode.  Checked against the files the real encoder wrote (tests/golden/ref_ctu*.npz: bitstream) and, on random row
+sizes / checksums incl. the zero runs that need emulation prevention, against the bit-by-bit restatement in helpers.py."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+FULL = ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_320x192_8_qp42", "ref_ctu_192x128_10_qp12", "ref_ctu_256x128_8_qp7", "ref_ctu_264x136_10_qp32"]
+
+
+def write_nals(L, sizes, rows_2d, sums, poc=0, sao=1, cap=None):
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    rows_2d = np.ascontiguousarray(rows_2d, np.uint8)
+    cap = int(sizes.sum()) + 64 + 4 * len(sizes) if cap is None else cap
+    out = np.zeros(max(cap, 1), np.uint8)
+    n = ctypes.c_size_t(0)
+    ck = None if sums is None else np.ascontiguousarray(sums, np.uint32)
+    rc = L.uvghip_write_picture_nals(poc, sao, H.ptr(rows_2d), rows_2d.shape[1], H.ptr(sizes), len(sizes), None if ck is None else H.ptr(ck), H.ptr(out), cap, ctypes.byref(n))
+    return rc, out[:min(n.value, cap)].tobytes(), n.value
+
+
+def golden_rows(g):
+    off = g["row_off"]
+    sizes = np.diff(off).astype(np.int32)
+    rows = np.zeros((len(sizes), int(sizes.max())), np.uint8)
+    for r in range(len(sizes)):
+        rows[r, :sizes[r]] = g["row_bytes"][off[r]:off[r + 1]]
+    return sizes, rows
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_whole_file_of_the_encoder_from_its_rows_and_final_picture(name):
+    from uvg266_amd import lib
+    L = lib.load_library()            # host function: no device
+    g = H.ctu_golden(name)
+    depth = int(g["meta"][2])
+    stream = g["bitstream"].tobytes()
+    sizes, rows = golden_rows(g)
+    sums = [H.picture_checksum(g[k], depth) for k in ("final_y", "final_u", "final_v")]
+    rc, nals, n = write_nals(L, sizes, rows, sums)
+    assert rc == 0 and n == len(nals)
+    at = stream.find(b"\x00\x00\x01\x00\x41")
+    assert at > 0 and stream[at:] == nals, "slice NAL + hash SEI"
+    assert stream[:at] + nals == stream                      # parameter sets (the encoder's) + these bytes = the whole .266
+    assert nals == H.picture_nals(sizes, [rows[r, :sizes[r]].tobytes() for r in range(len(sizes))], sums)
+
+
+def test_random_sizes_and_checksums_against_the_restatement():
+    from uvg266_amd import lib
+    L = lib.load_library()
+    rng = np.random.default_rng(5)
+    for trial in range(300):
+        n_rows = int(rng.integers(1, 40))
+        sizes = rng.choice([1, 2, 3, 255, 256, 257, 511, 512, 65535, 65536, 70000], n_rows) if trial % 3 == 0 else rng.integers(1, 3000, n_rows)
+        rows = rng.integers(0, 256, (n_rows, int(max(sizes))), dtype=np.uint8)
+        sums = rng.choice([0, 1, 2, 3, 0x300, 0x10000, 0x3000000, 0xffffffff, 0x00000100], 3) if trial % 2 == 0 else rng.integers(0, 2 ** 32, 3)
+        ck = None if trial % 7 == 0 else sums
+        poc, sao = int(rng.integers(0, 40)), int(rng.integers(0, 2))
+        rc, nals, n = write_nals(L, sizes, rows, ck, poc, sao)
+        assert rc == 0
+        assert nals == H.picture_nals(list(sizes), [rows[r, :sizes[r]].tobytes() for r in range(n_rows)], ck, poc, bool(sao)), trial
+
+
+def test_refuses_what_it_cannot_write():
+    from uvg266_amd import lib
+    L = lib.load_library()
+    rows = np.zeros((2, 8), np.uint8)
+    rc, _, n = write_nals(L, [4, 4], rows, [1, 2, 3], cap=10)          # too small: says how much it needs
+    assert rc != 0 and n > 10
+    assert write_nals(L, [4, 9], rows, None)[0] != 0                   # a row longer than its slot
+    assert write_nals(L, [4, 0], rows, None)[0] != 0                   # an empty row cannot be a substream
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_264x136_10_qp32"])
+def test_device_outputs_complete_the_encoders_file(hip, name):
+    """Search -> filters -> SAO -> arithmetic coder on the device (uvghip_loop_plan_run), the picture's checksum on the device, the
+    NAL units on the host: parameter sets of the encoder + these bytes = the encoder's .266, the whole file."""
+    import torch
+    from uvg266_amd import api
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    prm = H.search_params(W, Hh, qp)
+    cl = api.ClosedLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in (y, u, v))])
+    cl.run()
+    out, nbytes = cl.slice_data()
+    sums = api.picture_checksum(*cl.out[0]).cpu().numpy().view(np.uint32)
+    assert [int(s) for s in sums] == [H.picture_checksum(g[k], depth) for k in ("final_y", "final_u", "final_v")]
+    nb = nbytes.cpu().numpy()[0]
+    rc, nals, n = write_nals(hip, nb, out[0].cpu().numpy(), sums)
+    assert rc == 0
+    stream = g["bitstream"].tobytes()
+    at = stream.find(b"\x00\x00\x01\x00\x41")
+    assert stream[:at] + nals == stream

@@ -1,4 +1,4 @@
-"""dev: the loop plan (search -> filters -> SAO -> slice data) on N combinations of the sweep grid against the oracle chain.  usage: loop_sweep.py N seed"""
+"""dev: the loop plan (search -> filters -> SAO -> slice data) on N combinations of the sweep grid against the oracle chain.  usage: loop_sweep.py N seed [small|large]"""
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import helpers as H
@@ -6,7 +6,8 @@ from uvg266_amd import api, lib
 lib.init(0)
 orc = H.load_oracle()
 fails = 0
-for W, Hh, depth, qp, t in H.sweep_cases(int(sys.argv[1]), int(sys.argv[2])):
+kw = dict(small=dict(widths=(8, 16, 24, 40, 56, 64, 104), heights=(8, 16, 32, 48, 56, 64, 88)), large=dict(widths=(384, 448, 520, 640), heights=(264, 320, 384))).get(sys.argv[3] if len(sys.argv) > 3 else '', {})
+for W, Hh, depth, qp, t in H.sweep_cases(int(sys.argv[1]), int(sys.argv[2]), **kw):
     prm = H.search_params(W, Hh, qp)
     y, u, v = H.varied_picture(W, Hh, t, depth)
     cl = api.ClosedLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in (y, u, v))])

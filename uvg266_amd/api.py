@@ -700,3 +700,14 @@ class ClosedLoop(CtuSearch):
             finally:
                 self.L.uvghip_loop_plan_destroy(loop)
         CtuSearch.__del__(self)
+
+
+def picture_checksum(y, u, v, stream=None):
+    """uvghip_picture_checksum: the three plane sums of the decoded picture hash SEI (uvg_image_checksum) -> tensor [3] on the device
+    (the uint32 values in an int32 tensor: .cpu().numpy().view(np.uint32))."""
+    depth = 8 if y.dtype == torch.uint8 else 10
+    sums = torch.empty(4, dtype=torch.int32, device=y.device)
+    L = _lib.init(y.device.index or 0)
+    _lib.check(L.uvghip_picture_checksum(depth, _dev(y), y.stride(0), _dev(u), _dev(v), u.stride(0), y.shape[1], y.shape[0], _dev(sums),
+                                         _stream() if stream is None else stream), "uvghip_picture_checksum")
+    return sums[:3]

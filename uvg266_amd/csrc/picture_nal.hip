@@ -1,0 +1,144 @@
+// The picture-level NAL units that depend on what the hot path produced: the slice NAL (its header carries the entry points = the
+// lengths of the WPP rows' substreams) and the decoded-picture-hash SEI (a checksum of the picture after the in-loop filters).
+// With them, the bytes behind the parameter sets of a one-picture all-intra .266 come entirely from device outputs
+// (tests/test_picture_nal.py: the encoder's whole file = its SPS / PPS / version-SEI bytes + what this file writes).
+//
+// replaces, for an IDR picture of an all-intra (-p 1) stream with WPP on, one slice, picture header in the slice header, no ALF /
+// LMCS / dependent quantisation / sign hiding / transform skip (what --preset medium configures):
+//   uvg_encoder_state_write_bitstream_slice_header + _picture_header (src/encoder_state-bitstream.c:1009-1139, 1248-1411),
+//   encoder_state_write_bitstream_entry_points_write (:993-1007), uvg_nal_write (src/nal.c:43-74), add_checksum (:1420-1477) with
+//   uvg_image_checksum / array_checksum_generic (src/nal.c:91-115, src/strategies/generic/nal-generic.c:68-92), and the emulation
+//   prevention of uvg_bitstream_put_byte (src/bitstream.c:215-226) on the header and SEI bytes.
+// The parameter sets and the version SEI are the encoder's (control plane): they do not depend on the picture.
+#include "uvghip_common.h"
+#include <cstring>
+
+namespace {
+
+// sum over the samples of (low byte ^ mask) [+ (high byte ^ mask)], mask = (x ^ y ^ x >> 8 ^ y >> 8) & 0xff, modulo 2^32
+template <typename PX>
+__global__ void __launch_bounds__(256) checksum_kernel(const PX *__restrict__ plane, int stride, int width, int height, uint32_t *__restrict__ sum)
+{
+  uint32_t acc = 0;
+  const size_t n = (size_t)width * height;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int y = (int)(i / width), x = (int)(i - (size_t)y * width);
+    const uint32_t v = plane[(size_t)y * stride + x];
+    const uint32_t mask = (uint32_t)((x & 0xff) ^ (y & 0xff) ^ (x >> 8) ^ (y >> 8)) & 0xffu;
+    acc += (v & 0xffu) ^ mask;
+    if (sizeof(PX) == 2) acc += ((v >> 8) & 0xffu) ^ mask;
+  }
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(sum, acc);
+}
+
+// bytes of one NAL unit's payload with the reference's emulation prevention: 00 00 0x (x < 4) gets a 03 in front of x
+struct nal_writer {
+  uint8_t *out;
+  size_t cap, n;
+  int zeros;
+  uint32_t acc;       // bits not yet a whole byte, MSB first
+  int nacc;
+  void raw(uint8_t b) { if (n < cap) out[n] = b; ++n; }
+  void byte(uint8_t b)
+  {
+    if (zeros == 2 && b < 4) { raw(3); zeros = 0; }
+    zeros = b == 0 ? zeros + 1 : 0;
+    raw(b);
+  }
+  void bits(uint32_t v, int len)
+  {
+    for (int i = len - 1; i >= 0; --i) {
+      acc = acc << 1 | ((v >> i) & 1u);
+      if (++nacc == 8) { byte((uint8_t)acc); acc = 0; nacc = 0; }
+    }
+  }
+  void ue(uint32_t v)
+  {
+    int len = 0;
+    for (uint32_t t = v + 1; t > 1; t >>= 1) ++len;
+    bits(0, len);
+    bits(v + 1, len + 1);
+  }
+  void align_with_one() { bits(1, 1); while (nacc) bits(0, 1); }
+  void start(int nal_type)       // 3-byte start code, two header bytes: none of them counts towards the emulation prevention
+  {
+    raw(0); raw(0); raw(1); raw(0); raw((uint8_t)(nal_type << 3 | 1));
+  }
+};
+
+enum { NAL_IDR_N_LP = 8, NAL_SUFFIX_SEI = 24 };
+
+}  // namespace
+
+extern "C" int uvghip_picture_checksum(int bitdepth, const void *plane_y, int stride_y, const void *plane_u, const void *plane_v, int stride_c,
+                                       int width, int height, uint32_t *sums, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
+  if (!plane_y || !plane_u || !plane_v || !sums || width <= 0 || height <= 0 || (width & 1) || (height & 1) || stride_y < width || stride_c < width / 2)
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  hipStream_t st = uvghip_stream(stream);
+  UVGHIP_TRY(hipMemsetAsync(sums, 0, 3 * sizeof(uint32_t), st));
+  const void *planes[3] = {plane_y, plane_u, plane_v};
+  for (int c = 0; c < 3; ++c) {
+    const int w = c ? width / 2 : width, h = c ? height / 2 : height, stride = c ? stride_c : stride_y;
+    const size_t n = (size_t)w * h;
+    const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16) < 2048 ? (n + 256 * 16 - 1) / (256 * 16) : 2048);
+    if (bitdepth == 8) checksum_kernel<uint8_t><<<blocks, 256, 0, st>>>(static_cast<const uint8_t *>(planes[c]), stride, w, h, sums + c);
+    else checksum_kernel<uint16_t><<<blocks, 256, 0, st>>>(static_cast<const uint16_t *>(planes[c]), stride, w, h, sums + c);
+  }
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// Host function (no device needed): rows / row_bytes / checksum are HOST memory.
+extern "C" int uvghip_write_picture_nals(int poc, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
+                                         const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len)
+{
+  if (!rows || !row_bytes || n_rows <= 0 || !len || (!out && cap) || poc < 0)
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  int32_t longest = 0;
+  for (int r = 0; r < n_rows; ++r) {
+    if (row_bytes[r] <= 0 || (size_t)row_bytes[r] > row_pitch) return uvghip_set_error(hipErrorInvalidValue, "uvghip_write_picture_nals: a row is empty or longer than its slot");
+    if (row_bytes[r] > longest) longest = row_bytes[r];
+  }
+  nal_writer w = {out, cap, 0, 0, 0, 0};
+  // ---- the slice: header (picture header inside), byte alignment, the rows' substreams as they are ----
+  w.start(NAL_IDR_N_LP);
+  w.bits(1, 1);                      // sh_picture_header_in_slice_header_flag
+  w.bits(1, 1);                      // ph_gdr_or_irap_pic_flag
+  w.bits(0, 1);                      // ph_non_ref_pic_flag
+  w.bits(0, 1);                      // ph_gdr_pic_flag
+  w.bits(0, 1);                      // ph_inter_slice_allowed_flag
+  w.ue(0);                           // ph_pic_parameter_set_id
+  w.bits((uint32_t)poc & 15u, 4);    // ph_pic_order_cnt_lsb (the SPS of this configuration signals 4 bits)
+  w.bits(0, 1);                      // sh_no_output_of_prior_pics_flag
+  w.bits(1, 1);                      // sh_qp_delta = 0 as se(v)
+  if (sao) w.bits(3, 2);             // sh_sao_luma_used_flag, sh_sao_chroma_used_flag
+  if (n_rows > 1) {                  // entry points: every row but the last, in offset_len bits each (:1386-1404)
+    int offset_len = 0;
+    for (int32_t t = longest; t; t >>= 1) ++offset_len;
+    w.ue((uint32_t)offset_len - 1);
+    for (int r = 0; r + 1 < n_rows; ++r) w.bits((uint32_t)row_bytes[r] - 1, offset_len);
+  }
+  w.align_with_one();
+  for (int r = 0; r < n_rows; ++r) {
+    const size_t nb = (size_t)row_bytes[r];
+    if (w.n + nb <= cap) memcpy(out + w.n, rows + (size_t)r * row_pitch, nb);
+    w.n += nb;
+  }
+  // ---- decoded picture hash SEI (checksum), if asked for ----
+  if (checksum) {
+    w.zeros = 0;                     // (the last row ends with its stop bit: the zero run does not reach across)
+    w.start(NAL_SUFFIX_SEI);
+    w.bits(132, 8);                  // payload type: decoded picture hash
+    w.bits(2 + 3 * 4, 8);            // payload size
+    w.bits(2, 8);                    // hash type: checksum
+    w.bits(0, 8);                    // dph_sei_single_component_flag = 0, seven reserved bits
+    for (int c = 0; c < 3; ++c) w.bits(checksum[c], 32);
+    w.align_with_one();              // (already aligned: the trailing bits are a byte of their own)
+  }
+  *len = w.n;
+  if (w.n > cap) return uvghip_set_error(hipErrorInvalidValue, "uvghip_write_picture_nals: the output buffer is too small (see *len)");
+  return 0;
+}
