@@ -924,7 +924,8 @@ UVGHIP_API int uvghip_picture_checksum(int bitdepth, const void *plane_y, int st
  * uvg_bitstream_move does, and add_checksum (:1420-1477), with the emulation prevention of src/bitstream.c:215-226.
  * A HOST function (works without a device): rows = the slice data of uvghip_encode_slice_rows copied to host memory (row r at rows +
  * r * row_pitch, row_bytes[r] bytes), checksum = the three sums of uvghip_picture_checksum (NULL: no SEI), sao != 0: the stream has
- * SAO on (two flags in the header).  Writes at most cap bytes to out, *len = the bytes needed (an error if that is more than cap).
+ * SAO on (two flags in the header).  poc = the picture's index in the stream: picture 0 follows the parameter sets (IDR_N_LP, short
+ * start code), later pictures open their access unit (IDR_W_RADL, long start code; src/encoderstate.c:1965-1966).  Writes at most cap bytes to out, *len = the bytes needed (an error if that is more than cap).
  * Behind the encoder's parameter sets (SPS, PPS, version SEI -- control plane, independent of the picture) these bytes complete the
  * .266 of a one-picture encode, byte for byte (tests/test_picture_nal.py). */
 UVGHIP_API int uvghip_write_picture_nals(int poc, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,

@@ -839,7 +839,7 @@ def picture_nals(row_sizes, rows, checksums, poc=0, sao=True):
         bits += ue(ol - 1) + "".join(format(int(s) - 1, "0%db" % ol) for s in row_sizes[:-1])
     bits += "1"
     bits += "0" * (-len(bits) % 8)
-    out = b"\x00\x00\x01\x00\x41" + payload(bits) + b"".join(rows)
+    out = (b"\x00\x00\x01\x00\x41" if poc == 0 else b"\x00\x00\x00\x01\x00\x39") + payload(bits) + b"".join(rows)
     if checksums is not None:
         sei = format(132, "08b") + format(14, "08b") + format(2, "08b") + format(0, "08b") + "".join(format(int(c), "032b") for c in checksums) + "10000000"
         out += b"\x00\x00\x01\x00\xc1" + payload(sei)

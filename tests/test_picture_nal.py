@@ -49,6 +49,37 @@ def test_whole_file_of_the_encoder_from_its_rows_and_final_picture(name):
     assert nals == H.picture_nals(sizes, [rows[r, :sizes[r]].tobytes() for r in range(len(sizes))], sums)
 
 
+@pytest.mark.parametrize("name", ["ref_stream_192x128_8_qp27_3frames", "ref_stream_136x72_10_qp32_18frames"])
+def test_whole_multi_picture_stream_from_the_oracle_chain(orc, name):
+    """Several pictures of one -p 1 stream: parameter sets once, then per picture slice NAL + hash SEI (IDR_N_LP first, IDR_W_RADL with
+    a long start code afterwards, the 4-bit POC wrapping at 16).  Every picture through the oracle's chain (search -> filters -> SAO ->
+    row coder), the NAL units from the library's host function: parameter sets of the encoder + these bytes = the encoder's file."""
+    from uvg266_amd import lib, layout
+    import zlib
+    L = lib.load_library()
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp = (int(a) for a in g["meta"])
+    prm = H.search_params(W, Hh, qp)
+    stream = g["bitstream"].tobytes()
+    mine = b""
+    for poc, t in enumerate(g["ts"]):
+        y, u, v = layout.synthetic_yuv420(W, Hh, int(t), depth)
+        assert zlib.crc32(y.tobytes() + u.tobytes() + v.tobytes()) == int(g["src_crc"][poc])
+        s = H.oracle_search_picture(orc, depth, prm, y, u, v)
+        f = H.oracle_sao_picture(orc, depth, W, Hh, qp, prm.lam, (y, u, v), (s["rec_y"], s["rec_u"], s["rec_v"]), H.scu_from_cu(s["cu"], qp))
+        data, off, _ = H.oracle_encode_rows(orc, depth, prm, s, f["sao"])
+        sizes = np.diff(off).astype(np.int32)
+        rows = np.zeros((len(sizes), int(sizes.max())), np.uint8)
+        for r in range(len(sizes)):
+            rows[r, :sizes[r]] = data[off[r]:off[r + 1]]
+        sums = [H.picture_checksum(f[k], depth) for k in ("final_y", "final_u", "final_v")]
+        rc, nals, n = write_nals(L, sizes, rows, sums, poc=poc)
+        assert rc == 0
+        mine += nals
+    at = stream.find(b"\x00\x00\x01\x00\x41")
+    assert at > 0 and stream[:at] + mine == stream
+
+
 def test_random_sizes_and_checksums_against_the_restatement():
     from uvg266_amd import lib
     L = lib.load_library()
@@ -96,3 +127,30 @@ def test_device_outputs_complete_the_encoders_file(hip, name):
     stream = g["bitstream"].tobytes()
     at = stream.find(b"\x00\x00\x01\x00\x41")
     assert stream[:at] + nals == stream
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ref_stream_192x128_8_qp27_3frames", "ref_stream_136x72_10_qp32_18frames"])
+def test_device_outputs_complete_a_multi_picture_stream(hip, name):
+    """All pictures of the stream in ONE uvghip_loop_plan_run (they are independent under -p 1): rows, row lengths and final pictures
+    from the device, checksums from uvghip_picture_checksum, NAL units from uvghip_write_picture_nals -> the encoder's whole .266."""
+    import torch
+    from uvg266_amd import api, layout
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp = (int(a) for a in g["meta"])
+    prm = H.search_params(W, Hh, qp)
+    pics = [layout.synthetic_yuv420(W, Hh, int(t), depth) for t in g["ts"]]
+    cl = api.ClosedLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in yuv) for yuv in pics])
+    cl.run()
+    out, nbytes = cl.slice_data()
+    nb = nbytes.cpu().numpy()
+    rows = out.cpu().numpy()
+    mine = b""
+    for poc in range(len(pics)):
+        sums = api.picture_checksum(*cl.out[poc]).cpu().numpy().view(np.uint32)
+        rc, nals, n = write_nals(hip, nb[poc], rows[poc], sums, poc=poc)
+        assert rc == 0
+        mine += nals
+    stream = g["bitstream"].tobytes()
+    at = stream.find(b"\x00\x00\x01\x00\x41")
+    assert stream[:at] + mine == stream

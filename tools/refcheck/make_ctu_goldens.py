@@ -165,6 +165,27 @@ def crcs(W, H, depth, qp, t=0):
     print("wrote crc", tag, len(S), "CTUs")
 
 
+def stream(W, H, depth, qp, ts):
+    """A whole multi-picture -p 1 stream of the encoder (no per-CTU records kept): the .266 and what it was made from."""
+    px = np.uint8 if depth == 8 else np.uint16
+    tag = f"{W}x{H}_{depth}_qp{qp}_{len(ts)}frames"
+    yuv = f"/tmp/gold_{tag}.yuv"
+    crcs = []
+    with open(yuv, "wb") as f:
+        for t in ts:
+            y, u, v = layout.synthetic_yuv420(W, H, t, depth)
+            crcs.append(zlib.crc32(y.tobytes() + u.tobytes() + v.tobytes()))
+            for p in (y, u, v):
+                f.write(p.astype(px).tobytes())
+    out = f"/tmp/gold_{tag}"
+    subprocess.check_call([os.path.join(ROOT, "tools/refcheck/ctu_dump.sh"), str(depth), yuv, str(W), str(H), str(len(ts)), out,
+                           "preset", "medium", "period", "1", "qp", str(qp)], stderr=subprocess.DEVNULL)
+    bs = np.frombuffer(open(out + ".266", "rb").read(), np.uint8)
+    np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_stream_{tag}.npz"), meta=np.array([W, H, depth, qp], np.int32), ts=np.array(ts, np.int32),
+                        src_crc=np.array(crcs, np.uint32), bitstream=bs)
+    print("wrote stream", tag, len(bs), "bytes")
+
+
 if __name__ == "__main__":
     full(832, 480, 8, 22)
     full(416, 240, 10, 37)
@@ -175,3 +196,5 @@ if __name__ == "__main__":
     crcs(1920, 1080, 8, 22)
     crcs(1920, 1080, 10, 27, t=3)
     crcs(3840, 2160, 10, 22)
+    stream(192, 128, 8, 27, (3, 4, 5))          # three pictures of one -p 1 stream: POC, NAL types, start codes of the later pictures
+    stream(136, 72, 10, 32, tuple(range(18)))   # eighteen: the 4-bit POC wraps

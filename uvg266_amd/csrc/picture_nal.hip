@@ -61,13 +61,14 @@ struct nal_writer {
     bits(v + 1, len + 1);
   }
   void align_with_one() { bits(1, 1); while (nacc) bits(0, 1); }
-  void start(int nal_type)       // 3-byte start code, two header bytes: none of them counts towards the emulation prevention
+  void start(int nal_type, bool long_code = false)       // start code, two header bytes: none of them counts towards the emulation prevention
   {
+    if (long_code) raw(0);
     raw(0); raw(0); raw(1); raw(0); raw((uint8_t)(nal_type << 3 | 1));
   }
 };
 
-enum { NAL_IDR_N_LP = 8, NAL_SUFFIX_SEI = 24 };
+enum { NAL_IDR_W_RADL = 7, NAL_IDR_N_LP = 8, NAL_SUFFIX_SEI = 24 };
 
 }  // namespace
 
@@ -104,7 +105,10 @@ extern "C" int uvghip_write_picture_nals(int poc, int sao, const uint8_t *rows, 
   }
   nal_writer w = {out, cap, 0, 0, 0, 0};
   // ---- the slice: header (picture header inside), byte alignment, the rows' substreams as they are ----
-  w.start(NAL_IDR_N_LP);
+  // picture 0 of the stream follows the parameter sets in its access unit: IDR_N_LP, short start code; every later picture of a
+  // -p 1 stream is IDR_W_RADL (src/encoderstate.c:1965-1966) and the first NAL unit of its access unit: long start code
+  // (src/encoder_state-bitstream.c:1519-1531)
+  if (poc == 0) w.start(NAL_IDR_N_LP); else w.start(NAL_IDR_W_RADL, true);
   w.bits(1, 1);                      // sh_picture_header_in_slice_header_flag
   w.bits(1, 1);                      // ph_gdr_or_irap_pic_flag
   w.bits(0, 1);                      // ph_non_ref_pic_flag
