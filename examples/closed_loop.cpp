@@ -1,7 +1,9 @@
 // A host program over the C ABI alone (no Python, no torch): what an encoder's frame loop does with the library for a group of
 // all-intra pictures -- allocate device planes, upload the sources, uvghip_loop_plan_create once, uvghip_loop_plan_run per group,
 // download the filtered pictures.  Build:  make -C examples   (hipcc, links ../uvg266_amd/libuvg266hip.so)
-// Usage:  closed_loop <width> <height> <bitdepth 8|10> <qp> <pictures> [in.yuv] [repeats]
+// Usage:  closed_loop <width> <height> <bitdepth 8|10> <qp> <pictures> [in.yuv] [repeats] [out.nals]
+//   out.nals: every picture's slice NAL + hash SEI (uvghip_picture_checksum, uvghip_write_picture_nals) one after the other -- behind the
+//   encoder's parameter sets this is the encoder's .266 of the same pictures (tests/test_gpu_example.py)
 //   without in.yuv a deterministic synthetic source is used (a moving gradient with texture; NOT layout.synthetic_yuv420).
 // Prints per picture the CRC-32 of the source and of the output picture (Y, U, V) and the decided SAO types' histogram, then the
 // rate of `repeats` further runs of the same plan.  tests/test_gpu_example.py runs it on a yuv file the tests wrote and compares the
@@ -34,6 +36,7 @@ int main(int argc, char **argv)
   const int W = atoi(argv[1]), H = atoi(argv[2]), depth = atoi(argv[3]), qp = atoi(argv[4]), n = atoi(argv[5]);
   const char *yuv = argc > 6 && strcmp(argv[6], "-") ? argv[6] : nullptr;
   const int repeats = argc > 7 ? atoi(argv[7]) : 0;
+  const char *nals_path = argc > 8 ? argv[8] : nullptr;
   const size_t b = depth == 8 ? 1 : 2, ysz = (size_t)W * H * b, csz = ysz / 4, psz = ysz + 2 * csz;
   const int wc = (W + 63) / 64, hc = (H + 63) / 64, ctus = wc * hc;
   UVG_OK(uvghip_init(0));
@@ -103,6 +106,10 @@ int main(int argc, char **argv)
   UVG_OK(uvghip_loop_plan_results(plan, &d_info, nullptr));
   std::vector<int32_t> info((size_t)n * ctus * 34);
   HIP_OK(hipMemcpyAsync(info.data(), d_info, info.size() * 4, hipMemcpyDeviceToHost, st));
+  FILE *nf = nals_path ? fopen(nals_path, "wb") : nullptr;
+  if (nals_path && !nf) { fprintf(stderr, "cannot write %s\n", nals_path); return 1; }
+  uint32_t *d_sums;
+  HIP_OK(hipMalloc(&d_sums, 3 * sizeof(uint32_t)));
   for (int i = 0; i < n; ++i) {
     HIP_OK(hipMemcpyAsync(out.data(), dout[i], psz, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
@@ -119,7 +126,21 @@ int main(int argc, char **argv)
     }
     printf("picture %d src %08x out %08x sao luma none/band/edge %d/%d/%d slice data %zu bytes crc %08x\n", i, crc32(src[i].data(), psz),
            crc32(out.data(), psz), types[0], types[1], types[2], sbytes, scrc);
+    if (nf) {
+      // the picture's NAL units: the checksum of the final picture on the device, header + rows + SEI on the host
+      uint32_t sums[3];
+      UVG_OK(uvghip_picture_checksum(depth, dout[i], W, dout[i] + ysz, dout[i] + ysz + csz, W / 2, W, H, d_sums, st));
+      HIP_OK(hipMemcpyAsync(sums, d_sums, sizeof sums, hipMemcpyDeviceToHost, st));
+      std::vector<uint8_t> rows((size_t)n_rows * row_cap);
+      HIP_OK(hipMemcpyAsync(rows.data(), d_rows + (size_t)i * n_rows * row_cap, rows.size(), hipMemcpyDeviceToHost, st));
+      HIP_OK(hipStreamSynchronize(st));
+      std::vector<uint8_t> nals(sbytes + 64 + 4 * (size_t)n_rows);
+      size_t len = 0;
+      UVG_OK(uvghip_write_picture_nals(i, 1, rows.data(), (size_t)row_cap, &row_bytes[(size_t)i * n_rows], n_rows, sums, nals.data(), nals.size(), &len));
+      if (fwrite(nals.data(), 1, len, nf) != len) { fprintf(stderr, "short write\n"); return 1; }
+    }
   }
+  if (nf) fclose(nf);
   if (repeats > 0) {
     HIP_OK(hipStreamSynchronize(st));
     const auto t0 = std::chrono::steady_clock::now();

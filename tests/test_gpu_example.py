@@ -35,3 +35,23 @@ def test_cpp_host_program_equals_the_python_driven_path(hip, tmp_path):
         want = zlib.crc32(b"".join(t.cpu().numpy().tobytes() for t in cl.out[i]))
         assert int(lines[i][5], 16) == want, (i, lines[i])
         assert int(lines[i][3], 16) == zlib.crc32(b"".join(np.ascontiguousarray(p).tobytes() for p in pics[i]))
+
+
+def test_cpp_host_program_writes_the_encoders_stream(hip, tmp_path):
+    """The C++ program alone, from a .yuv of three pictures: its NAL units behind the encoder's parameter sets are the encoder's .266
+    (tests/golden/ref_stream_192x128_8_qp27_3frames.npz)."""
+    from uvg266_amd import layout
+    exe = os.path.join(H.ROOT, "examples", "closed_loop")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(H.ROOT, "examples")])
+    g = H.ctu_golden("ref_stream_192x128_8_qp27_3frames")
+    W, Hh, depth, qp = (int(a) for a in g["meta"])
+    yuv, nals = tmp_path / "in.yuv", tmp_path / "out.nals"
+    with open(yuv, "wb") as f:
+        for t in g["ts"]:
+            for plane in layout.synthetic_yuv420(W, Hh, int(t), depth):
+                f.write(np.ascontiguousarray(plane).tobytes())
+    subprocess.check_call([exe, str(W), str(Hh), str(depth), str(qp), str(len(g["ts"])), str(yuv), "0", str(nals)], stdout=subprocess.DEVNULL)
+    stream = g["bitstream"].tobytes()
+    at = stream.find(b"\x00\x00\x01\x00\x41")
+    assert stream[:at] + open(nals, "rb").read() == stream
