@@ -844,3 +844,109 @@ def picture_nals(row_sizes, rows, checksums, poc=0, sao=True):
         sei = format(132, "08b") + format(14, "08b") + format(2, "08b") + format(0, "08b") + "".join(format(int(c), "032b") for c in checksums) + "10000000"
         out += b"\x00\x00\x01\x00\xc1" + payload(sei)
     return out
+
+
+# ---- reconstruction of the encoder's inter decisions (tests/test_oracle_inter_recon.py, tests/test_gpu_inter_recon.py) ----
+class OracleBlocks:
+    """The block functions of the oracle behind the three operations inter reconstruction needs."""
+    def __init__(self, orc, depth):
+        self.orc, self.depth = orc, depth
+
+    def picture(self, planes):
+        return planes
+
+    def sample(self, plane, pw, ph, x0, y0, w, h, fx, fy, chroma, hi):
+        return self.orc.ipol_sample(self.depth, plane, pw, ph, x0, y0, w, h, fx, fy, chroma=chroma, hi=hi)
+
+    def average(self, a, b, w, h):
+        return self.orc.bipred_average(self.depth, np.ascontiguousarray(a), np.ascontiguousarray(b), w, h)
+
+    def residual(self, levels, n, qp, color):
+        d = self.depth
+        qs = self.orc.fn(d, "get_scaled_qp", int)(color, qp, 6 * (d - 8), None)
+        co = self.orc.dequant(d, np.ascontiguousarray(levels.reshape(-1)), n, n, d, qs, 0)
+        out = np.zeros(n * n, np.int16)
+        self.orc.fn(d, "idct_nxn", None)(d, n, ptr(co), ptr(out))
+        return out.reshape(n, n).astype(np.int32)
+
+
+def inter_reconstruct(g, B):
+    """Every inter CU of a ref_inter_* golden: motion compensation as uvg_inter_pred_pu does it (src/inter.c:400-530, 532-602, 685-748:
+    integer copies, fractional samplers, high-precision intermediates + uvg_bipred_average for bi-prediction, border replication)
+    + dequantised, inverse-transformed levels, through the block functions B -> asserts the encoder's reconstruction before the
+    in-loop filters; returns what was exercised."""
+    W, Hh, depth, qp0, frames = (int(a) for a in g["dims"])
+    top = (1 << depth) - 1
+    final = [B.picture((g["final_y"][f], g["final_u"][f], g["final_v"][f])) for f in range(frames)]
+    seen = dict(inter=0, bi=0, frac=0, resid=0, outside=0)
+
+    def predict_list(ref, x, y, n, mv, want_hi):
+        int_x = (mv[0] + 7) >> 4 if mv[0] >= 0 else (mv[0] + 8) >> 4        # uvg_change_precision_vector2d(INTERNAL_MV_PREC, 0)
+        int_y = (mv[1] + 7) >> 4 if mv[1] >= 0 else (mv[1] + 8) >> 4
+        frac_l = (mv[0] & 15) != 0 or (mv[1] & 15) != 0
+        frac_c = (int_x & 1) != 0 or (int_y & 1) != 0
+        if frac_l:
+            luma = B.sample(ref[0], W, Hh, x + (mv[0] >> 4), y + (mv[1] >> 4), n, n, mv[0] & 15, mv[1] & 15, False, want_hi)
+        else:
+            luma = B.sample(ref[0], W, Hh, x + int_x, y + int_y, n, n, 0, 0, False, False)
+        c = n // 2
+        if frac_l or frac_c:
+            cx, cy = x // 2 + (mv[0] >> 5), y // 2 + (mv[1] >> 5)
+            u = B.sample(ref[1], W // 2, Hh // 2, cx, cy, c, c, mv[0] & 31, mv[1] & 31, True, want_hi)
+            v = B.sample(ref[2], W // 2, Hh // 2, cx, cy, c, c, mv[0] & 31, mv[1] & 31, True, want_hi)
+        else:
+            cx, cy = (x + int_x) // 2, (y + int_y) // 2
+            u = B.sample(ref[1], W // 2, Hh // 2, cx, cy, c, c, 0, 0, True, False)
+            v = B.sample(ref[2], W // 2, Hh // 2, cx, cy, c, c, 0, 0, True, False)
+        return luma, u, v
+
+    for k in range(len(g["meta"])):
+        fr, x0, y0, qp = (int(a) for a in g["meta"][k][:4])
+        refs = g["refs"][k]
+        pocs = refs[1:1 + refs[0]]
+        lists = [refs[19:19 + refs[17]], refs[35:35 + refs[18]]]
+        cu, mot, co = g["cu"][k], g["motion"][k], g["coeff"][k]
+        for i in range(256):
+            lx, ly = (i & 15) * 4, (i >> 4) * 4
+            c = cu[i]
+            if c[0] != 2:
+                continue
+            n = 1 << int(c[1])
+            if (lx & (n - 1)) or (ly & (n - 1)):
+                continue                               # not the CU's first unit
+            assert int(c[2]) == int(c[1])              # square CUs only in this configuration
+            x, y = x0 + lx, y0 + ly
+            m = [int(a) for a in mot[i]]
+            mvs, ridx, mdir = [(m[0], m[1]), (m[2], m[3])], [m[4], m[5]], m[6]
+            used = [l for l in (0, 1) if mdir & (1 << l)]
+            preds = []
+            for l in used:
+                poc = int(pocs[int(lists[l][ridx[l]])])
+                preds.append(predict_list(final[poc], x, y, n, mvs[l], len(used) == 2))
+                seen["frac"] += (mvs[l][0] & 15) != 0
+                seen["outside"] += x + (mvs[l][0] >> 4) < 0 or y + (mvs[l][1] >> 4) < 0 or x + (mvs[l][0] >> 4) + n > W
+            if len(used) == 2:
+                pred = [B.average(a, b, n >> (p > 0), n >> (p > 0)) for p, (a, b) in enumerate(zip(*preds))]
+                seen["bi"] += 1
+            else:
+                pred = list(preds[0])
+            seen["inter"] += 1
+            # residual: one transform unit per CU up to 32x32, four 32x32 units in a 64x64 CU (each with its own flags)
+            tn = min(n, 32)
+            rec = [np.asarray(p).reshape(n >> (j > 0), n >> (j > 0)).astype(np.int32) for j, p in enumerate(pred)]
+            for ty in range(0, n, tn):
+                for tx in range(0, n, tn):
+                    t = cu[((ly + ty) >> 2) * 16 + ((lx + tx) >> 2)]
+                    cbf = int(t[5])
+                    if cbf & 1:
+                        lv = co[:4096].reshape(64, 64)[ly + ty:ly + ty + tn, lx + tx:lx + tx + tn]
+                        rec[0][ty:ty + tn, tx:tx + tn] += B.residual(lv, tn, int(t[10]), 0)
+                        seen["resid"] += 1
+                    for j in (1, 2):
+                        if cbf & (1 << j):
+                            lv = co[4096 + (j - 1) * 1024:4096 + j * 1024].reshape(32, 32)[(ly + ty) // 2:(ly + ty + tn) // 2, (lx + tx) // 2:(lx + tx + tn) // 2]
+                            rec[j][ty // 2:(ty + tn) // 2, tx // 2:(tx + tn) // 2] += B.residual(lv, tn // 2, int(t[10]), j)
+            want = (g["rec_y"][fr][y:y + n, x:x + n], g["rec_u"][fr][y // 2:(y + n) // 2, x // 2:(x + n) // 2], g["rec_v"][fr][y // 2:(y + n) // 2, x // 2:(x + n) // 2])
+            for j in range(3):
+                assert np.array_equal(np.clip(rec[j], 0, top), want[j]), (fr, x, y, n, "YUV"[j], m)
+    return seen

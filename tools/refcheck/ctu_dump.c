@@ -106,7 +106,27 @@ void __wrap_uvg_search_lcu(encoder_state_t *const state, const int x, const int 
       ru[yy * 32 + xx] = frame->rec->u[(y / 2 + yy) * (frame->rec->stride / 2) + x / 2 + xx];
       rv[yy * 32 + xx] = frame->rec->v[(y / 2 + yy) * (frame->rec->stride / 2) + x / 2 + xx];
     }
-  rec_begin("search", 11);
+  /* inter side information per 4x4 and the picture's reference lists (P / B pictures; zeros in an intra picture) */
+  static int32_t inter[256][8];
+  memset(inter, 0, sizeof inter);
+  for (int yy = 0; yy < 64; yy += 4)
+    for (int xx = 0; xx < 64; xx += 4) {
+      if (x + xx >= frame->width || y + yy >= frame->height) continue;
+      const cu_info_t *c = uvg_cu_array_at_const(frame->cu_array, x + xx, y + yy);
+      if (c->type != CU_INTER) continue;
+      int32_t *o = inter[(yy >> 2) * 16 + (xx >> 2)];
+      o[0] = c->inter.mv[0][0]; o[1] = c->inter.mv[0][1]; o[2] = c->inter.mv[1][0]; o[3] = c->inter.mv[1][1];
+      o[4] = c->inter.mv_ref[0]; o[5] = c->inter.mv_ref[1]; o[6] = c->inter.mv_dir;
+      o[7] = c->skipped | c->merged << 1 | c->merge_idx << 2 | c->inter.imv << 5;
+    }
+  int32_t refs[1 + 16 + 2 + 32 + 1];
+  memset(refs, 0, sizeof refs);
+  refs[0] = (int32_t)state->frame->ref->used_size;
+  for (unsigned i = 0; i < state->frame->ref->used_size && i < 16; ++i) refs[1 + i] = state->frame->ref->pocs[i];
+  refs[17] = state->frame->ref_LX_size[0]; refs[18] = state->frame->ref_LX_size[1];
+  for (int l = 0; l < 2; ++l) for (int i = 0; i < 16; ++i) refs[19 + 16 * l + i] = state->frame->ref_LX[l][i];
+  refs[51] = state->frame->poc;
+  rec_begin("search", 13);
   rec_arr(A_I32, meta, 8); rec_arr(A_F64, lam, 6);
   rec_arr(A_U8, &before, sizeof before); rec_arr(A_U8, &after, sizeof after);
   rec_arr(A_U8, cu, sizeof cu); rec_arr(A_U32, trees, 512);
@@ -117,6 +137,8 @@ void __wrap_uvg_search_lcu(encoder_state_t *const state, const int x, const int 
     memcpy(uv, coeff->u, 2 * 32 * 32); memcpy(uv + 32 * 32, coeff->v, 2 * 32 * 32);
     rec_arr(A_I16, uv, 2 * 32 * 32);
   }
+  rec_arr(A_I32, inter, 256 * 8);
+  rec_arr(A_I32, refs, 52);
 }
 
 /* payload bytes the arithmetic coder hands to the bitstream (uvg_bitstream_put_byte, called from uvg_cabac_write): counted

@@ -186,6 +186,65 @@ def stream(W, H, depth, qp, ts):
     print("wrote stream", tag, len(bs), "bytes")
 
 
+def moving_picture(W, H, t, depth):
+    """Picture t of a sequence with fractional motion: a window into a 4x larger noisy picture, shifted by quarter samples per
+    picture and box-filtered down -- the left and the right half move differently (partitions, uni- and bi-prediction)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    base = helpers.varied_picture(4 * (W + 32), 4 * (H + 32), 2007, depth)
+    out = []
+    for b, c in zip(base, (0, 1, 1)):
+        w, h = W >> c, H >> c
+
+        def window(sx, sy):
+            a = b.astype(np.int64)[sy:sy + 4 * h, sx:sx + 4 * w]
+            return ((a.reshape(h, 4, w, 4).sum(axis=(1, 3)) + 8) >> 4).astype(b.dtype)
+        p = window((40 + 5 * t) >> c, (40 + 3 * t) >> c)
+        p[:, w // 2:] = window((100 - 7 * t) >> c, (40 + 2 * t) >> c)[:, w // 2:]
+        out.append(p)
+    return tuple(out)
+
+
+def inter(W, H, depth, qp, frames):
+    """Low-delay inter encode (--gop lp-g4d3t1, BASELINE configs[2]): per picture the reference lists and the picture after the in-loop
+    filters, per CTU the side information incl. motion, the levels and the reconstruction before the filters -- what a reconstruction
+    of the encoder's decisions (motion compensation + residual) needs."""
+    px = np.uint8 if depth == 8 else np.uint16
+    tag = f"{W}x{H}_{depth}_qp{qp}_{frames}frames"
+    yuv = f"/tmp/gold_inter_{tag}.yuv"
+    with open(yuv, "wb") as f:
+        for t in range(frames):
+            for p in moving_picture(W, H, t, depth):
+                f.write(p.astype(px).tobytes())
+    out = f"/tmp/gold_inter_{tag}"
+    subprocess.check_call([os.path.join(ROOT, "tools/refcheck/ctu_dump.sh"), str(depth), yuv, str(W), str(H), str(frames), out,
+                           "preset", "medium", "gop", "lp-g4d3t1", "qp", str(qp)], stderr=subprocess.DEVNULL)
+    recs = read_records(out + ".bin")
+    S = [r for n, r in recs if n == "search"]
+    F = sorted([r for n, r in recs if n == "final"], key=lambda r: int(r[0][0]))
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    n = frames * wc * hc
+    meta = np.zeros((n, 8), np.int32)
+    cu = np.zeros((n, 256, 12), np.uint8)
+    mot = np.zeros((n, 256, 8), np.int32)
+    refs = np.zeros((n, 52), np.int32)
+    rec = [np.zeros((frames, H, W), px), np.zeros((frames, H // 2, W // 2), px), np.zeros((frames, H // 2, W // 2), px)]
+    coeff = np.zeros((n, 6144), np.int16)
+    for k, s in enumerate(S):
+        fr, x, y = int(s[0][0]), int(s[0][1]), int(s[0][2])
+        hh, ww = min(64, H - y), min(64, W - x)
+        meta[k], cu[k], mot[k], refs[k] = s[0], s[4].reshape(256, 12), s[11].reshape(256, 8), s[12]
+        rec[0][fr, y:y + hh, x:x + ww] = s[6].reshape(64, 64)[:hh, :ww]
+        rec[1][fr, y // 2:(y + hh) // 2, x // 2:(x + ww) // 2] = s[7].reshape(32, 32)[:hh // 2, :ww // 2]
+        rec[2][fr, y // 2:(y + hh) // 2, x // 2:(x + ww) // 2] = s[8].reshape(32, 32)[:hh // 2, :ww // 2]
+        coeff[k, :4096] = s[9]
+        coeff[k, 4096:] = s[10]
+    final = [np.stack([f[1 + c].reshape(H >> (c > 0), W >> (c > 0)) for f in F]) for c in range(3)]
+    np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_inter_{tag}.npz"), dims=np.array([W, H, depth, qp, frames], np.int32), meta=meta, cu=cu,
+                        motion=mot, refs=refs, rec_y=rec[0], rec_u=rec[1], rec_v=rec[2], coeff=coeff, final_y=final[0], final_u=final[1], final_v=final[2])
+    print("wrote inter", tag, n, "CTU records")
+
+
 if __name__ == "__main__":
     full(832, 480, 8, 22)
     full(416, 240, 10, 37)
@@ -198,3 +257,5 @@ if __name__ == "__main__":
     crcs(3840, 2160, 10, 22)
     stream(192, 128, 8, 27, (3, 4, 5))          # three pictures of one -p 1 stream: POC, NAL types, start codes of the later pictures
     stream(136, 72, 10, 32, tuple(range(18)))   # eighteen: the 4-bit POC wraps
+    inter(192, 128, 8, 17, 5)
+    inter(136, 72, 10, 22, 4)
