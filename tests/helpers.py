@@ -950,3 +950,35 @@ def inter_reconstruct(g, B):
             for j in range(3):
                 assert np.array_equal(np.clip(rec[j], 0, top), want[j]), (fr, x, y, n, "YUV"[j], m)
     return seen
+
+
+def inter_scu_table(g, frame):
+    """The uvghip_scu_t / orc_scu table of one picture of a ref_inter_* golden: what the deblocking filter reads of a P / B picture
+    (type, sizes, coded flags, edge flags, QP, motion; ref_id = the POC of the reference picture, -1 where a list is unused)."""
+    W, Hh = int(g["dims"][0]), int(g["dims"][1])
+    wc, hc = (W + 63) // 64, (Hh + 63) // 64
+    t = np.zeros((hc * 16, wc * 16), SCU_NP)
+    for k in range(len(g["meta"])):
+        fr, x0, y0 = (int(a) for a in g["meta"][k][:3])
+        if fr != frame:
+            continue
+        refs = g["refs"][k]
+        pocs = refs[1:1 + refs[0]]
+        lists = [refs[19:19 + refs[17]], refs[35:35 + refs[18]]]
+        cu, mot = g["cu"][k].reshape(16, 16, 12), g["motion"][k].reshape(16, 16, 8)
+        blk = t[y0 // 4:y0 // 4 + 16, x0 // 4:x0 // 4 + 16]
+        for j, f in enumerate(("type", "log2_width", "log2_height", "log2_chroma_width", "log2_chroma_height", "cbf")):
+            blk[f] = cu[:, :, j]
+        blk["luma_edges"], blk["chroma_edges"], blk["qp"] = cu[:, :, 8], cu[:, :, 9], cu[:, :, 10].astype(np.int8)
+        blk["mv_dir"] = mot[:, :, 6]
+        mv = np.zeros((16, 16, 2, 2), np.int32)
+        mv[:, :, 0, 0], mv[:, :, 0, 1], mv[:, :, 1, 0], mv[:, :, 1, 1] = mot[:, :, 0], mot[:, :, 1], mot[:, :, 2], mot[:, :, 3]
+        blk["mv"] = mv
+        rid = np.full((16, 16, 2), -1, np.int16)
+        for l in (0, 1):
+            use = (mot[:, :, 6] & (1 << l)) != 0
+            if len(lists[l]):
+                poc_of = np.array([int(pocs[int(i)]) for i in lists[l]], np.int16)
+                rid[:, :, l][use] = poc_of[np.clip(mot[:, :, 4 + l][use], 0, len(poc_of) - 1)]
+        blk["ref_id"] = rid
+    return t

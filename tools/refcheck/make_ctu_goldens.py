@@ -205,12 +205,12 @@ def moving_picture(W, H, t, depth):
     return tuple(out)
 
 
-def inter(W, H, depth, qp, frames):
+def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True):
     """Low-delay inter encode (--gop lp-g4d3t1, BASELINE configs[2]): per picture the reference lists and the picture after the in-loop
     filters, per CTU the side information incl. motion, the levels and the reconstruction before the filters -- what a reconstruction
     of the encoder's decisions (motion compensation + residual) needs."""
     px = np.uint8 if depth == 8 else np.uint16
-    tag = f"{W}x{H}_{depth}_qp{qp}_{frames}frames"
+    tag = f"{W}x{H}_{depth}_qp{qp}_{frames}frames{suffix}"
     yuv = f"/tmp/gold_inter_{tag}.yuv"
     with open(yuv, "wb") as f:
         for t in range(frames):
@@ -218,7 +218,7 @@ def inter(W, H, depth, qp, frames):
                 f.write(p.astype(px).tobytes())
     out = f"/tmp/gold_inter_{tag}"
     subprocess.check_call([os.path.join(ROOT, "tools/refcheck/ctu_dump.sh"), str(depth), yuv, str(W), str(H), str(frames), out,
-                           "preset", "medium", "gop", "lp-g4d3t1", "qp", str(qp)], stderr=subprocess.DEVNULL)
+                           "preset", "medium", "gop", "lp-g4d3t1", "qp", str(qp)] + list(extra), stderr=subprocess.DEVNULL)
     recs = read_records(out + ".bin")
     S = [r for n, r in recs if n == "search"]
     F = sorted([r for n, r in recs if n == "final"], key=lambda r: int(r[0][0]))
@@ -241,7 +241,8 @@ def inter(W, H, depth, qp, frames):
         coeff[k, 4096:] = s[10]
     final = [np.stack([f[1 + c].reshape(H >> (c > 0), W >> (c > 0)) for f in F]) for c in range(3)]
     np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_inter_{tag}.npz"), dims=np.array([W, H, depth, qp, frames], np.int32), meta=meta, cu=cu,
-                        motion=mot, refs=refs, rec_y=rec[0], rec_u=rec[1], rec_v=rec[2], coeff=coeff, final_y=final[0], final_u=final[1], final_v=final[2])
+                        motion=mot, refs=refs, rec_y=rec[0], rec_u=rec[1], rec_v=rec[2], coeff=coeff if with_levels else coeff[:0], final_y=final[0], final_u=final[1],
+                        final_v=final[2])
     print("wrote inter", tag, n, "CTU records")
 
 
@@ -259,3 +260,5 @@ if __name__ == "__main__":
     stream(136, 72, 10, 32, tuple(range(18)))   # eighteen: the 4-bit POC wraps
     inter(192, 128, 8, 17, 5)
     inter(136, 72, 10, 22, 4)
+    inter(192, 128, 8, 32, 5, extra=("sao", "off"), suffix="_nosao", with_levels=False)        # final picture = the deblocked picture
+    inter(136, 72, 10, 22, 4, extra=("sao", "off"), suffix="_nosao", with_levels=False)
