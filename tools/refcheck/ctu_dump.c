@@ -258,8 +258,79 @@ void __wrap_uvg_sao_search_lcu(const encoder_state_t *const state, int lcu_x, in
   rec_arr(A_PX, ry, 64 * 64); rec_arr(A_PX, ru, 32 * 32); rec_arr(A_PX, rv, 32 * 32);
 }
 
+/* uvg_inter_get_merge_cand (src/inter.c:1989-2192) as the inter search calls it: every g_merge_every-th call is recorded with all it
+ * reads -- the lcu_t's side information as it stands at that moment (work-tree state: 17 x 17 + 1 entries), the picture's reference
+ * lists, the collocated picture's motion at the 8x8 grid (with the POCs its vectors point to), the row's HMVP table -- and what it
+ * returned.  (inter_clear_cu_unused modifies neighbours it looks at: the table is taken BEFORE the call.) */
+#include "inter.h"
+static int g_merge_every = 0, g_merge_calls = 0;
+static void pack_cu(const cu_info_t *c, int32_t *o)
+{
+  o[0] = c->type; o[1] = c->inter.mv[0][0]; o[2] = c->inter.mv[0][1]; o[3] = c->inter.mv[1][0]; o[4] = c->inter.mv[1][1];
+  o[5] = c->inter.mv_ref[0]; o[6] = c->inter.mv_ref[1]; o[7] = c->inter.mv_dir;
+}
+uint8_t __real_uvg_inter_get_merge_cand(const encoder_state_t *const state, const cu_loc_t *const cu_loc, inter_merge_cand_t mv_cand[MRG_MAX_NUM_CANDS], lcu_t *lcu);
+uint8_t __wrap_uvg_inter_get_merge_cand(const encoder_state_t *const state, const cu_loc_t *const cu_loc, inter_merge_cand_t mv_cand[MRG_MAX_NUM_CANDS], lcu_t *lcu)
+{
+  const int take = g_merge_every > 0 && (g_merge_calls++ % g_merge_every) == 0;
+  static int32_t tab[LCU_T_CU_WIDTH * LCU_T_CU_WIDTH + 1][8];
+  if (take) for (int i = 0; i < LCU_T_CU_WIDTH * LCU_T_CU_WIDTH + 1; ++i) pack_cu(&lcu->cu[i], tab[i]);
+  const uint8_t n = __real_uvg_inter_get_merge_cand(state, cu_loc, mv_cand, lcu);
+  if (!take) return n;
+  const videoframe_t *frame = state->tile->frame;
+  int32_t ctx[64];
+  memset(ctx, 0, sizeof ctx);
+  ctx[0] = (int32_t)state->frame->num; ctx[1] = cu_loc->x; ctx[2] = cu_loc->y; ctx[3] = cu_loc->width; ctx[4] = cu_loc->height;
+  ctx[5] = state->frame->poc; ctx[6] = state->frame->slicetype; ctx[7] = frame->width; ctx[8] = frame->height;
+  ctx[9] = state->encoder_control->cfg.tmvp_enable; ctx[10] = state->encoder_control->cfg.max_merge;
+  ctx[11] = state->encoder_control->cfg.log2_parallel_merge_level; ctx[12] = state->encoder_control->cfg.wpp;
+  ctx[13] = (int32_t)state->frame->ref->used_size;
+  for (unsigned i = 0; i < state->frame->ref->used_size && i < 16; ++i) ctx[14 + i] = state->frame->ref->pocs[i];
+  ctx[30] = state->frame->ref_LX_size[0]; ctx[31] = state->frame->ref_LX_size[1];
+  for (int l = 0; l < 2; ++l) for (int i = 0; i < 8; ++i) ctx[32 + 8 * l + i] = state->frame->ref_LX[l][i];
+  ctx[48] = n;
+  /* the collocated picture (L0[0]) at the 8x8 grid: type, vectors, direction, the POCs the vectors point to */
+  const int gw = (frame->width + 7) / 8, gh = (frame->height + 7) / 8;
+  int32_t *col = calloc((size_t)gw * gh * 8, sizeof(int32_t));
+  if (state->frame->ref->used_size && state->frame->ref_LX_size[0] > 0) {
+    const int cr = state->frame->ref_LX[0][0];
+    const cu_array_t *ca = state->frame->ref->cu_arrays[cr];
+    for (int gy = 0; gy < gh; ++gy)
+      for (int gx = 0; gx < gw; ++gx) {
+        const cu_info_t *c = &ca->data[(gx * 8) / SCU_WIDTH + ((gy * 8) / SCU_WIDTH) * (ca->width / SCU_WIDTH)];
+        int32_t *o = col + ((size_t)gy * gw + gx) * 8;
+        o[0] = c->type; o[1] = c->inter.mv[0][0]; o[2] = c->inter.mv[0][1]; o[3] = c->inter.mv[1][0]; o[4] = c->inter.mv[1][1]; o[5] = c->inter.mv_dir;
+        for (int l = 0; l < 2; ++l)
+          o[6 + l] = (c->type == CU_INTER && (c->inter.mv_dir & (1 << l)))
+                         ? state->frame->ref->images[cr]->ref_pocs[state->frame->ref->ref_LXs[cr][l][c->inter.mv_ref[l]]] : -1;
+      }
+  }
+  const uint32_t row = (uint32_t)cu_loc->y >> LOG2_LCU_WIDTH;
+  int32_t hm[1 + MAX_NUM_HMVP_CANDS * 8];
+  memset(hm, 0, sizeof hm);
+  hm[0] = frame->hmvp_size[row];
+  for (int i = 0; i < MAX_NUM_HMVP_CANDS; ++i) pack_cu(&frame->hmvp_lut[row * MAX_NUM_HMVP_CANDS + i], hm + 1 + 8 * i);
+  int32_t out[MRG_MAX_NUM_CANDS][7];
+  memset(out, 0, sizeof out);
+  for (int i = 0; i < n && i < MRG_MAX_NUM_CANDS; ++i) {
+    out[i][0] = mv_cand[i].dir; out[i][1] = mv_cand[i].ref[0]; out[i][2] = mv_cand[i].ref[1];
+    out[i][3] = mv_cand[i].mv[0][0]; out[i][4] = mv_cand[i].mv[0][1]; out[i][5] = mv_cand[i].mv[1][0]; out[i][6] = mv_cand[i].mv[1][1];
+  }
+  const cu_info_t *cur = LCU_GET_CU_AT_PX(lcu, SUB_SCU(cu_loc->x), SUB_SCU(cu_loc->y));
+  ctx[49] = (int32_t)cur->split_tree;
+  rec_begin("merge", 5);
+  rec_arr(A_I32, ctx, 64);
+  rec_arr(A_I32, tab, (LCU_T_CU_WIDTH * LCU_T_CU_WIDTH + 1) * 8);
+  rec_arr(A_I32, col, (size_t)gw * gh * 8);
+  rec_arr(A_I32, hm, 1 + MAX_NUM_HMVP_CANDS * 8);
+  rec_arr(A_I32, out, MRG_MAX_NUM_CANDS * 7);
+  free(col);
+  return n;
+}
+
 int main(int argc, char **argv)
 {
+  if (getenv("CTU_DUMP_MERGE_EVERY")) g_merge_every = atoi(getenv("CTU_DUMP_MERGE_EVERY"));
   if (argc < 7) { fprintf(stderr, "usage: %s in.yuv W H frames out.bin out.266 [opt val]...\n", argv[0]); return 2; }
   const int W = atoi(argv[2]), H = atoi(argv[3]), nframes = atoi(argv[4]);
   FILE *in = fopen(argv[1], "rb");

@@ -246,6 +246,25 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True):
     print("wrote inter", tag, n, "CTU records")
 
 
+def merge(W, H, depth, qp, frames, every):
+    """Calls of uvg_inter_get_merge_cand during a low-delay encode (every `every`-th one): everything the function reads and what it
+    returned (tools/refcheck/ctu_dump.c, record "merge")."""
+    px = np.uint8 if depth == 8 else np.uint16
+    tag = f"{W}x{H}_{depth}_qp{qp}_{frames}frames"
+    yuv = f"/tmp/gold_merge_{tag}.yuv"
+    with open(yuv, "wb") as f:
+        for t in range(frames):
+            for p in moving_picture(W, H, t, depth):
+                f.write(p.astype(px).tobytes())
+    out = f"/tmp/gold_merge_{tag}"
+    subprocess.check_call([os.path.join(ROOT, "tools/refcheck/ctu_dump.sh"), str(depth), yuv, str(W), str(H), str(frames), out,
+                           "preset", "medium", "gop", "lp-g4d3t1", "qp", str(qp)], stderr=subprocess.DEVNULL, env=dict(os.environ, CTU_DUMP_MERGE_EVERY=str(every)))
+    R = [r for n, r in read_records(out + ".bin") if n == "merge"]
+    np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_merge_{tag}.npz"), ctx=np.stack([r[0] for r in R]), lcu=np.stack([r[1].reshape(-1, 8) for r in R]),
+                        col=np.stack([r[2] for r in R]), hmvp=np.stack([r[3] for r in R]), out=np.stack([r[4].reshape(6, 7) for r in R]))
+    print("wrote merge", tag, len(R), "calls")
+
+
 if __name__ == "__main__":
     full(832, 480, 8, 22)
     full(416, 240, 10, 37)
@@ -260,5 +279,7 @@ if __name__ == "__main__":
     stream(136, 72, 10, 32, tuple(range(18)))   # eighteen: the 4-bit POC wraps
     inter(192, 128, 8, 17, 5)
     inter(136, 72, 10, 22, 4)
+    merge(192, 128, 8, 17, 6, 3)
+    merge(136, 72, 10, 27, 8, 2)
     inter(192, 128, 8, 32, 5, extra=("sao", "off"), suffix="_nosao", with_levels=False)        # final picture = the deblocked picture
     inter(136, 72, 10, 22, 4, extra=("sao", "off"), suffix="_nosao", with_levels=False)
