@@ -100,25 +100,11 @@ static void scale_pocs(int cur_poc, int cur_ref_poc, int nb_poc, int nb_ref_poc,
   mv[1] = scaled_mv(mv[1], scale);
 }
 
-/*
- * ctx: the 64 ints of a "merge" record (tools/refcheck/ctu_dump.c): [1..4] x, y, width, height of the CU; [5] POC; [6] slice type
- * (0 = B); [7..8] picture size; [9] tmvp; [10] max merge candidates; [11] log2 parallel merge level; [12] wpp; [13] references in
- * use, [14..29] their POCs; [30..31] list sizes, [32..39] / [40..47] L0 / L1 (indices into the POC array); [49] the CU's split tree.
- * lcu: 17 * 17 + 1 entries of 8 ints (the lcu_t's table at the moment of the call; MODIFIED like the reference does);
- * col: the collocated picture (L0[0]) on the 8x8 grid, 8 ints per position: type, mv[2][2], dir, the POC each list's vector points to;
- * hmvp: [0] entries in the row's table, then 5 entries of 8 ints.  out: 6 candidates of 7 ints; returns their number.
- */
-ORC_EXPORT int ORC_FN(merge_candidates)(const int32_t *ctx, int32_t *lcu, const int32_t *col, const int32_t *hmvp, int32_t *out)
+/* get_spatial_merge_candidates (src/inter.c:1368-1455) */
+static void spatial_candidates(cand_cu *tab, int x, int y, int w, int h, int pic_w, int pic_h, int wpp, uint32_t split_tree,
+                               cand_cu **a0_, cand_cu **a1_, cand_cu **b0_, cand_cu **b1_, cand_cu **b2_)
 {
-  cand_cu *tab = (cand_cu *)lcu;
-  merge_cand *mc = (merge_cand *)out;
-  const int x = ctx[1], y = ctx[2], w = ctx[3], h = ctx[4], poc = ctx[5], is_b = ctx[6] == 0, pic_w = ctx[7], pic_h = ctx[8];
-  const int tmvp = ctx[9], max_cands = ctx[10], mer = ctx[11], wpp = ctx[12], used = ctx[13];
-  const int32_t *pocs = ctx + 14, *lsize = ctx + 30, *L[2] = {ctx + 32, ctx + 40};
-  const uint32_t split_tree = (uint32_t)ctx[49];
   const int lx = x & 63, ly = y & 63;
-  memset(mc, 0, 6 * sizeof *mc);
-  /* ---- spatial ---- */
   cand_cu *a0 = NULL, *a1 = NULL, *b0 = NULL, *b1 = NULL, *b2 = NULL;
   if (x != 0) {
     cand_cu *c = lcu_at(tab, lx - 1, ly + h - 1);
@@ -142,6 +128,61 @@ ORC_EXPORT int ORC_FN(merge_candidates)(const int32_t *ctx, int32_t *lcu, const 
       if (c->type == CU_INTER_T) { clear_unused(c); b2 = c; }
     }
   }
+  *a0_ = a0; *a1_ = a1; *b0_ = b0; *b1_ = b1; *b2_ = b2;
+}
+
+/* get_temporal_merge_candidates (src/inter.c:1031-1097) for list L0, index 0: C0 if there, else C1 */
+static const int32_t *temporal_cu(const int32_t *col, int x, int y, int w, int h, int pic_w, int pic_h, int l0_size)
+{
+  const int gw = (pic_w + 7) / 8;
+  const int32_t *c0 = NULL, *c1 = NULL;
+  if (l0_size <= 0) return NULL;
+  const int xbr = x + w, ybr = y + h;
+  if (xbr < pic_w && ybr < pic_h && (ybr % LCU_W) != 0) {
+    const int32_t *c = col + ((size_t)(ybr >> 3) * gw + (xbr >> 3)) * 8;
+    if (c[0] == CU_INTER_T) c0 = c;
+  }
+  const int xc = x + w / 2, yc = y + h / 2;
+  if (xc < pic_w && yc < pic_h) {
+    const int32_t *c = col + ((size_t)(yc >> 3) * gw + (xc >> 3)) * 8;
+    if (c[0] == CU_INTER_T) c1 = c;
+  }
+  return c0 ? c0 : c1;
+}
+
+/* add_temporal_candidate (src/inter.c:1547-1601): the collocated vector, compressed, scaled from its POC distance to the current one */
+static int temporal_vector(const int32_t *tc, int reflist, int poc, const int32_t *pocs, int used, int cur_ref_poc, int col_poc, int32_t mv[2])
+{
+  if (!tc) return 0;
+  int col_list = reflist;
+  for (int i = 0; i < used; ++i) if (pocs[i] > poc) { col_list = 1; break; }
+  if ((tc[5] & (col_list + 1)) == 0) col_list = 1 - col_list;
+  mv[0] = round_mv_comp(tc[1 + 2 * col_list]);
+  mv[1] = round_mv_comp(tc[2 + 2 * col_list]);
+  scale_pocs(poc, cur_ref_poc, col_poc, tc[6 + col_list], mv);
+  return 1;
+}
+
+/*
+ * ctx: the 64 ints of a "merge" record (tools/refcheck/ctu_dump.c): [1..4] x, y, width, height of the CU; [5] POC; [6] slice type
+ * (0 = B); [7..8] picture size; [9] tmvp; [10] max merge candidates; [11] log2 parallel merge level; [12] wpp; [13] references in
+ * use, [14..29] their POCs; [30..31] list sizes, [32..39] / [40..47] L0 / L1 (indices into the POC array); [49] the CU's split tree.
+ * lcu: 17 * 17 + 1 entries of 8 ints (the lcu_t's table at the moment of the call; MODIFIED like the reference does);
+ * col: the collocated picture (L0[0]) on the 8x8 grid, 8 ints per position: type, mv[2][2], dir, the POC each list's vector points to;
+ * hmvp: [0] entries in the row's table, then 5 entries of 8 ints.  out: 6 candidates of 7 ints; returns their number.
+ */
+ORC_EXPORT int ORC_FN(merge_candidates)(const int32_t *ctx, int32_t *lcu, const int32_t *col, const int32_t *hmvp, int32_t *out)
+{
+  cand_cu *tab = (cand_cu *)lcu;
+  merge_cand *mc = (merge_cand *)out;
+  const int x = ctx[1], y = ctx[2], w = ctx[3], h = ctx[4], poc = ctx[5], is_b = ctx[6] == 0, pic_w = ctx[7], pic_h = ctx[8];
+  const int tmvp = ctx[9], max_cands = ctx[10], mer = ctx[11], wpp = ctx[12], used = ctx[13];
+  const int32_t *pocs = ctx + 14, *lsize = ctx + 30, *L[2] = {ctx + 32, ctx + 40};
+  const uint32_t split_tree = (uint32_t)ctx[49];
+  memset(mc, 0, 6 * sizeof *mc);
+  /* ---- spatial ---- */
+  cand_cu *a0, *a1, *b0, *b1, *b2;
+  spatial_candidates(tab, x, y, w, h, pic_w, pic_h, wpp, split_tree, &a0, &a1, &b0, &b1, &b2);
   int n = 0;
   if (different_mer(x, y, x, y - 1, mer) && add_merge(b1, NULL, NULL, &mc[n])) n++;
   if (different_mer(x, y, x - 1, y, mer) && add_merge(a1, b1, NULL, &mc[n])) n++;
@@ -151,29 +192,11 @@ ORC_EXPORT int ORC_FN(merge_candidates)(const int32_t *ctx, int32_t *lcu, const 
   /* ---- temporal ---- */
   if (tmvp && n < max_cands && used) {
     mc[n].dir = 0;
-    const int gw = (pic_w + 7) / 8;
-    const int32_t *c0 = NULL, *c1 = NULL;
-    if (lsize[0] > 0) {
-      const int xbr = x + w, ybr = y + h;
-      if (xbr < pic_w && ybr < pic_h && (ybr % LCU_W) != 0) {
-        const int32_t *c = col + ((size_t)(ybr >> 3) * gw + (xbr >> 3)) * 8;
-        if (c[0] == CU_INTER_T) c0 = c;
-      }
-      const int xc = x + w / 2, yc = y + h / 2;
-      if (xc < pic_w && yc < pic_h) {
-        const int32_t *c = col + ((size_t)(yc >> 3) * gw + (xc >> 3)) * 8;
-        if (c[0] == CU_INTER_T) c1 = c;
-      }
-    }
-    const int32_t *tc = c0 ? c0 : c1;
+    const int32_t *tc = temporal_cu(col, x, y, w, h, pic_w, pic_h, lsize[0]);
     for (int reflist = 0; reflist <= (is_b ? 1 : 0); ++reflist) {
-      if (!tc || lsize[0] <= 0) continue;
-      int col_list = reflist;
-      for (int i = 0; i < used; ++i) if (pocs[i] > poc) { col_list = 1; break; }
-      if ((tc[5] & (col_list + 1)) == 0) col_list = 1 - col_list;
-      int32_t mv[2] = {round_mv_comp(tc[1 + 2 * col_list]), round_mv_comp(tc[2 + 2 * col_list])};
+      int32_t mv[2];
       /* current reference: index 0 of L0 for either list (sic, :2041-2048); the collocated picture is L0[0] */
-      scale_pocs(poc, pocs[L[0][0]], pocs[L[0][0]], tc[6 + col_list], mv);
+      if (lsize[0] <= 0 || !temporal_vector(tc, reflist, poc, pocs, used, pocs[L[0][0]], pocs[L[0][0]], mv)) continue;
       mc[n].mv[reflist][0] = mv[0]; mc[n].mv[reflist][1] = mv[1];
       mc[n].ref[reflist] = 0;
       mc[n].dir |= 1 << reflist;
@@ -231,4 +254,63 @@ ORC_EXPORT int ORC_FN(merge_candidates)(const int32_t *ctx, int32_t *lcu, const 
     n++;
   }
   return n;
+}
+
+/* add_mvp_candidate without scaling (src/inter.c:1185-1219): a neighbour's vector that points to the picture being searched */
+static int add_mvp(const cand_cu *c, int reflist, int target, const int32_t *const L[2], int32_t mv[2])
+{
+  if (!c) return 0;
+  for (int i = 0; i < 2; ++i) {
+    const int cl = i == 0 ? reflist : !reflist;
+    if (!(c->dir & (1 << cl))) continue;
+    if (L[cl][c->ref[cl]] == target) { mv[0] = c->mv[cl][0]; mv[1] = c->mv[cl][1]; return 1; }
+  }
+  return 0;
+}
+static int32_t round_quarter(int32_t v)         /* uvg_round_precision(INTERNAL_MV_PREC, 2): to quarter samples and back */
+{
+  v = v >= 0 ? (v + 1) >> 2 : (v + 2) >> 2;
+  return (int32_t)((uint32_t)v << 2);
+}
+
+/*
+ * uvg_inter_get_mv_cand (src/inter.c:1606-1737): the two AMVP predictors for list ctx[50] and the reference index ctx[51 + list] being
+ * searched.  Same inputs as merge_candidates; out: mv_cand[2][2].
+ */
+ORC_EXPORT void ORC_FN(amvp_candidates)(const int32_t *ctx, int32_t *lcu, const int32_t *col, const int32_t *hmvp, int32_t *out)
+{
+  cand_cu *tab = (cand_cu *)lcu;
+  const int x = ctx[1], y = ctx[2], w = ctx[3], h = ctx[4], poc = ctx[5], pic_w = ctx[7], pic_h = ctx[8];
+  const int tmvp = ctx[9], wpp = ctx[12], used = ctx[13], reflist = ctx[50];
+  const int32_t *pocs = ctx + 14, *lsize = ctx + 30;
+  const int32_t *const L[2] = {ctx + 32, ctx + 40};
+  const int target = L[reflist][ctx[51 + reflist]];            /* ref_LX[reflist][cur_cu->inter.mv_ref[reflist]] */
+  cand_cu *a0, *a1, *b0, *b1, *b2;
+  spatial_candidates(tab, x, y, w, h, pic_w, pic_h, wpp, (uint32_t)ctx[49], &a0, &a1, &b0, &b1, &b2);
+  const int32_t *tc = temporal_cu(col, x, y, w, h, pic_w, pic_h, used ? lsize[0] : 0);
+  int32_t mv[2][2] = {{0, 0}, {0, 0}};
+  int n = 0, nb = 0;
+  if (add_mvp(a0, reflist, target, L, mv[n])) n++;
+  else if (add_mvp(a1, reflist, target, L, mv[n])) n++;
+  if (add_mvp(b0, reflist, target, L, mv[n])) nb++;
+  else if (add_mvp(b1, reflist, target, L, mv[n])) nb++;
+  else if (add_mvp(b2, reflist, target, L, mv[n])) nb++;
+  n += nb;
+  if (n > 0) { mv[0][0] = round_quarter(mv[0][0]); mv[0][1] = round_quarter(mv[0][1]); }
+  if (n > 1) { mv[1][0] = round_quarter(mv[1][0]); mv[1][1] = round_quarter(mv[1][1]); }
+  if (n == 2 && mv[0][0] == mv[1][0] && mv[0][1] == mv[1][1]) n = 1;
+  if (tmvp && poc > 1 && used && n < 2 && tc && lsize[0] > 0 && temporal_vector(tc, reflist, poc, pocs, used, pocs[target], pocs[L[0][0]], mv[n])) n++;
+  if (n < 2) {
+    const cand_cu *lut = (const cand_cu *)(hmvp + 1);
+    const int num = hmvp[0];
+    for (int i = 0; i < (num < 4 ? num : 4) && n < 2; ++i)
+      for (int ps = 0; ps < 2 && n < 2; ++ps) {
+        const int cl = ps == 0 ? reflist : !reflist;
+        const cand_cu *c = &lut[num - 1 - i];
+        if (!(c->dir & (1 << cl))) continue;
+        if (L[cl][c->ref[cl]] == target) { mv[n][0] = c->mv[cl][0]; mv[n][1] = c->mv[cl][1]; n++; }
+      }
+  }
+  while (n < 2) { mv[n][0] = 0; mv[n][1] = 0; n++; }
+  out[0] = round_quarter(mv[0][0]); out[1] = round_quarter(mv[0][1]); out[2] = round_quarter(mv[1][0]); out[3] = round_quarter(mv[1][1]);
 }

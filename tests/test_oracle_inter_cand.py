@@ -31,3 +31,21 @@ def test_merge_candidates_equal_the_encoders(orc, name):
         kinds["sizes"].add(int(ctx[3]))
         kinds["history"] += int(g["hmvp"][k][0] > 0)
     assert kinds["sizes"] >= {8, 16, 32, 64} and kinds["bi"] > 100 and kinds["history"] > 100, kinds
+
+
+@pytest.mark.parametrize("name", ["ref_amvp_192x128_8_qp17_6frames", "ref_amvp_136x72_10_qp27_8frames"])
+def test_amvp_predictors_equal_the_encoders(orc, name):
+    """uvg_inter_get_mv_cand (src/inter.c:1606-1737): the two motion vector predictors of a reference list -- left, above, temporal,
+    history, zero; rounded to quarter samples."""
+    g = {k: v for k, v in H.ctu_golden(name).items()}
+    fn = orc.fn(8, "amvp_candidates", None)
+    lists, nonzero = set(), 0
+    for k in range(len(g["ctx"])):
+        ctx = np.ascontiguousarray(g["ctx"][k])
+        lcu = np.ascontiguousarray(g["lcu"][k]).copy()
+        out = np.zeros(4, np.int32)
+        fn(H.ptr(ctx), H.ptr(lcu), H.ptr(np.ascontiguousarray(g["col"][k])), H.ptr(np.ascontiguousarray(g["hmvp"][k])), H.ptr(out))
+        assert (out == g["out"][k]).all(), (k, ctx[:13].tolist(), ctx[50:53].tolist(), out.tolist(), g["out"][k].tolist())
+        lists.add(int(ctx[50]))
+        nonzero += bool(g["out"][k].any())
+    assert lists == {0, 1} and nonzero > 200

@@ -269,6 +269,71 @@ static void pack_cu(const cu_info_t *c, int32_t *o)
   o[0] = c->type; o[1] = c->inter.mv[0][0]; o[2] = c->inter.mv[0][1]; o[3] = c->inter.mv[1][0]; o[4] = c->inter.mv[1][1];
   o[5] = c->inter.mv_ref[0]; o[6] = c->inter.mv_ref[1]; o[7] = c->inter.mv_dir;
 }
+static void cand_context(const encoder_state_t *const state, const cu_loc_t *const cu_loc, const lcu_t *lcu, int32_t ctx[64], int32_t **col_out, size_t *col_n,
+                         int32_t hm[1 + MAX_NUM_HMVP_CANDS * 8])
+{
+  const videoframe_t *frame = state->tile->frame;
+  memset(ctx, 0, 64 * sizeof(int32_t));
+  ctx[0] = (int32_t)state->frame->num; ctx[1] = cu_loc->x; ctx[2] = cu_loc->y; ctx[3] = cu_loc->width; ctx[4] = cu_loc->height;
+  ctx[5] = state->frame->poc; ctx[6] = state->frame->slicetype; ctx[7] = frame->width; ctx[8] = frame->height;
+  ctx[9] = state->encoder_control->cfg.tmvp_enable; ctx[10] = state->encoder_control->cfg.max_merge;
+  ctx[11] = state->encoder_control->cfg.log2_parallel_merge_level; ctx[12] = state->encoder_control->cfg.wpp;
+  ctx[13] = (int32_t)state->frame->ref->used_size;
+  for (unsigned i = 0; i < state->frame->ref->used_size && i < 16; ++i) ctx[14 + i] = state->frame->ref->pocs[i];
+  ctx[30] = state->frame->ref_LX_size[0]; ctx[31] = state->frame->ref_LX_size[1];
+  for (int l = 0; l < 2; ++l) for (int i = 0; i < 8; ++i) ctx[32 + 8 * l + i] = state->frame->ref_LX[l][i];
+  const cu_info_t *cur = LCU_GET_CU_AT_PX(lcu, SUB_SCU(cu_loc->x), SUB_SCU(cu_loc->y));
+  ctx[49] = (int32_t)cur->split_tree;
+  const int gw = (frame->width + 7) / 8, gh = (frame->height + 7) / 8;
+  int32_t *col = calloc((size_t)gw * gh * 8, sizeof(int32_t));
+  if (state->frame->ref->used_size && state->frame->ref_LX_size[0] > 0) {
+    const int cr = state->frame->ref_LX[0][0];
+    const cu_array_t *ca = state->frame->ref->cu_arrays[cr];
+    for (int gy = 0; gy < gh; ++gy)
+      for (int gx = 0; gx < gw; ++gx) {
+        const cu_info_t *c = &ca->data[(gx * 8) / SCU_WIDTH + ((gy * 8) / SCU_WIDTH) * (ca->width / SCU_WIDTH)];
+        int32_t *o = col + ((size_t)gy * gw + gx) * 8;
+        o[0] = c->type; o[1] = c->inter.mv[0][0]; o[2] = c->inter.mv[0][1]; o[3] = c->inter.mv[1][0]; o[4] = c->inter.mv[1][1]; o[5] = c->inter.mv_dir;
+        for (int l = 0; l < 2; ++l)
+          o[6 + l] = (c->type == CU_INTER && (c->inter.mv_dir & (1 << l)))
+                         ? state->frame->ref->images[cr]->ref_pocs[state->frame->ref->ref_LXs[cr][l][c->inter.mv_ref[l]]] : -1;
+      }
+  }
+  *col_out = col; *col_n = (size_t)gw * gh * 8;
+  const uint32_t row = (uint32_t)cu_loc->y >> LOG2_LCU_WIDTH;
+  memset(hm, 0, (1 + MAX_NUM_HMVP_CANDS * 8) * sizeof(int32_t));
+  hm[0] = frame->hmvp_size[row];
+  for (int i = 0; i < MAX_NUM_HMVP_CANDS; ++i) pack_cu(&frame->hmvp_lut[row * MAX_NUM_HMVP_CANDS + i], hm + 1 + 8 * i);
+}
+
+/* uvg_inter_get_mv_cand (src/inter.c:1711-1737; the two AMVP predictors of a reference list): recorded like the merge calls */
+static int g_amvp_calls = 0;
+void __real_uvg_inter_get_mv_cand(const encoder_state_t *const state, mv_t mv_cand[2][2], const cu_info_t *const cur_cu, lcu_t *lcu, int8_t reflist,
+                                  const cu_loc_t *const cu_loc);
+void __wrap_uvg_inter_get_mv_cand(const encoder_state_t *const state, mv_t mv_cand[2][2], const cu_info_t *const cur_cu, lcu_t *lcu, int8_t reflist,
+                                  const cu_loc_t *const cu_loc)
+{
+  const int take = g_merge_every > 0 && cur_cu->type != CU_IBC && (g_amvp_calls++ % g_merge_every) == 0;
+  static int32_t tab[LCU_T_CU_WIDTH * LCU_T_CU_WIDTH + 1][8];
+  int32_t ctx[64], hm[1 + MAX_NUM_HMVP_CANDS * 8], *col = NULL;
+  size_t col_n = 0;
+  if (take) {
+    for (int i = 0; i < LCU_T_CU_WIDTH * LCU_T_CU_WIDTH + 1; ++i) pack_cu(&lcu->cu[i], tab[i]);
+    cand_context(state, cu_loc, lcu, ctx, &col, &col_n, hm);
+    ctx[50] = reflist; ctx[51] = cur_cu->inter.mv_ref[0]; ctx[52] = cur_cu->inter.mv_ref[1];
+  }
+  __real_uvg_inter_get_mv_cand(state, mv_cand, cur_cu, lcu, reflist, cu_loc);
+  if (!take) return;
+  int32_t out[4] = {mv_cand[0][0], mv_cand[0][1], mv_cand[1][0], mv_cand[1][1]};
+  rec_begin("amvp", 5);
+  rec_arr(A_I32, ctx, 64);
+  rec_arr(A_I32, tab, (LCU_T_CU_WIDTH * LCU_T_CU_WIDTH + 1) * 8);
+  rec_arr(A_I32, col, col_n);
+  rec_arr(A_I32, hm, 1 + MAX_NUM_HMVP_CANDS * 8);
+  rec_arr(A_I32, out, 4);
+  free(col);
+}
+
 uint8_t __real_uvg_inter_get_merge_cand(const encoder_state_t *const state, const cu_loc_t *const cu_loc, inter_merge_cand_t mv_cand[MRG_MAX_NUM_CANDS], lcu_t *lcu);
 uint8_t __wrap_uvg_inter_get_merge_cand(const encoder_state_t *const state, const cu_loc_t *const cu_loc, inter_merge_cand_t mv_cand[MRG_MAX_NUM_CANDS], lcu_t *lcu)
 {

@@ -246,7 +246,7 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True):
     print("wrote inter", tag, n, "CTU records")
 
 
-def merge(W, H, depth, qp, frames, every):
+def merge(W, H, depth, qp, frames, every, amvp_step=4):
     """Calls of uvg_inter_get_merge_cand during a low-delay encode (every `every`-th one): everything the function reads and what it
     returned (tools/refcheck/ctu_dump.c, record "merge")."""
     px = np.uint8 if depth == 8 else np.uint16
@@ -259,10 +259,14 @@ def merge(W, H, depth, qp, frames, every):
     out = f"/tmp/gold_merge_{tag}"
     subprocess.check_call([os.path.join(ROOT, "tools/refcheck/ctu_dump.sh"), str(depth), yuv, str(W), str(H), str(frames), out,
                            "preset", "medium", "gop", "lp-g4d3t1", "qp", str(qp)], stderr=subprocess.DEVNULL, env=dict(os.environ, CTU_DUMP_MERGE_EVERY=str(every)))
-    R = [r for n, r in read_records(out + ".bin") if n == "merge"]
+    recs = read_records(out + ".bin")
+    R = [r for n, r in recs if n == "merge"]
     np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_merge_{tag}.npz"), ctx=np.stack([r[0] for r in R]), lcu=np.stack([r[1].reshape(-1, 8) for r in R]),
                         col=np.stack([r[2] for r in R]), hmvp=np.stack([r[3] for r in R]), out=np.stack([r[4].reshape(6, 7) for r in R]))
-    print("wrote merge", tag, len(R), "calls")
+    A = [r for n, r in recs if n == "amvp"][::amvp_step]
+    np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_amvp_{tag}.npz"), ctx=np.stack([r[0] for r in A]), lcu=np.stack([r[1].reshape(-1, 8) for r in A]),
+                        col=np.stack([r[2] for r in A]), hmvp=np.stack([r[3] for r in A]), out=np.stack([r[4] for r in A]))
+    print("wrote merge", tag, len(R), "calls; amvp", len(A), "calls")
 
 
 if __name__ == "__main__":
