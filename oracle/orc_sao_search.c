@@ -218,10 +218,24 @@ static void encode_sao(sao_models *m, int cx, int cy, const sao_info *luma, cons
  * SAO models after the CTU's SAO syntax: s0, s1, rate each), snap_y/u/v (optional, picture-sized): every CTU's block as the
  * decision saw it, out_y/u/v: the picture after SAO.
  */
+/* slice: 2 = I, 1 = P, 0 = B (the row of the context initialisation table; a B slice also switches the deblocking filter's
+ * boundary-strength rule, filter.c:734-818) */
+ORC_EXPORT void ORC_FN(sao_search_picture_slice)(const orc_px *src_y, const orc_px *src_u, const orc_px *src_v, orc_px *rec_y, orc_px *rec_u,
+                                                 orc_px *rec_v, int width, int height, const void *scu, int scu_stride, int qp, double lambda,
+                                                 int sao_type, int slice, int32_t *info_out, uint16_t *models_out, orc_px *snap_y, orc_px *snap_u,
+                                                 orc_px *snap_v, orc_px *out_y, orc_px *out_u, orc_px *out_v);
 ORC_EXPORT void ORC_FN(sao_search_picture)(const orc_px *src_y, const orc_px *src_u, const orc_px *src_v, orc_px *rec_y, orc_px *rec_u,
                                            orc_px *rec_v, int width, int height, const void *scu, int scu_stride, int qp, double lambda,
                                            int sao_type, int32_t *info_out, uint16_t *models_out, orc_px *snap_y, orc_px *snap_u,
                                            orc_px *snap_v, orc_px *out_y, orc_px *out_u, orc_px *out_v)
+{
+  ORC_FN(sao_search_picture_slice)(src_y, src_u, src_v, rec_y, rec_u, rec_v, width, height, scu, scu_stride, qp, lambda, sao_type, 2, info_out,
+                                   models_out, snap_y, snap_u, snap_v, out_y, out_u, out_v);
+}
+ORC_EXPORT void ORC_FN(sao_search_picture_slice)(const orc_px *src_y, const orc_px *src_u, const orc_px *src_v, orc_px *rec_y, orc_px *rec_u,
+                                                 orc_px *rec_v, int width, int height, const void *scu, int scu_stride, int qp, double lambda,
+                                                 int sao_type, int slice, int32_t *info_out, uint16_t *models_out, orc_px *snap_y, orc_px *snap_u,
+                                                 orc_px *snap_v, orc_px *out_y, orc_px *out_u, orc_px *out_v)
 {
   const int wc = (width + 63) / 64, hc = (height + 63) / 64, cw = width / 2, ch = height / 2;
   sao_info *luma = calloc((size_t)wc * hc, sizeof(sao_info)), *chroma = calloc((size_t)wc * hc, sizeof(sao_info));
@@ -230,11 +244,11 @@ ORC_EXPORT void ORC_FN(sao_search_picture)(const orc_px *src_y, const orc_px *sr
   for (int cy = 0; cy < hc; ++cy)
     for (int cx = 0; cx < wc; ++cx) {
       const int k = cy * wc + cx, x = cx * 64, y = cy * 64;
-      ORC_FN(deblock_lcu)(rec_y, width, rec_u, rec_v, cw, width, height, scu, scu_stride, 0, 0, 0, qp, NULL, x, y);
+      ORC_FN(deblock_lcu)(rec_y, width, rec_u, rec_v, cw, width, height, scu, scu_stride, 0, 0, slice == 0, qp, NULL, x, y);
       sao_models m;
       if (cx > 0) m = after[k - 1];
       else if (cy > 0) m = after[(cy - 1) * wc];
-      else models_init(&m, qp, 2);
+      else models_init(&m, qp, slice);
       const sao_info *top_l = cy ? &luma[k - wc] : NULL, *left_l = cx ? &luma[k - 1] : NULL;
       const sao_info *top_c = cy ? &chroma[k - wc] : NULL, *left_c = cx ? &chroma[k - 1] : NULL;
       int32_t mc_l[3] = {INT_MAX, 0, 0}, mc_c[3] = {INT_MAX, 0, 0};

@@ -432,7 +432,7 @@ def scu_from_cu(cu, qp):
     return t
 
 
-def oracle_sao_picture(orc, depth, W, H, qp, lam, src, rec, scu, sao_type=3):
+def oracle_sao_picture(orc, depth, W, H, qp, lam, src, rec, scu, sao_type=3, slice_type=2):
     """orcN_sao_search_picture: per-CTU deblocking in the encoder's order, the SAO decision of every CTU on the block it sees at
     that moment, SAO of the deblocked picture.  rec: reconstruction before the in-loop filters (not modified).
     -> dict(sao [ctus, 2, 17], sao_models [ctus, 6], snap_y/u/v, final_y/u/v, deblocked_y/u/v)"""
@@ -445,10 +445,10 @@ def oracle_sao_picture(orc, depth, W, H, qp, lam, src, rec, scu, sao_type=3):
     models = np.zeros((wc * hc, 6), np.uint16)
     snap = [np.zeros_like(a) for a in r]
     out = [np.zeros_like(a) for a in r]
-    fn = orc.fn(depth, "sao_search_picture")
+    fn = orc.fn(depth, "sao_search_picture_slice")          # slice_type: 2 = I, 1 = P, 0 = B
     fn.restype = None
     fn(ptr(s[0]), ptr(s[1]), ptr(s[2]), ptr(r[0]), ptr(r[1]), ptr(r[2]), ctypes.c_int(W), ctypes.c_int(H), ptr(scu), ctypes.c_int(scu.shape[1]),
-       ctypes.c_int(qp), ctypes.c_double(lam), ctypes.c_int(sao_type), ptr(info), ptr(models), ptr(snap[0]), ptr(snap[1]), ptr(snap[2]),
+       ctypes.c_int(qp), ctypes.c_double(lam), ctypes.c_int(sao_type), ctypes.c_int(slice_type), ptr(info), ptr(models), ptr(snap[0]), ptr(snap[1]), ptr(snap[2]),
        ptr(out[0]), ptr(out[1]), ptr(out[2]))
     return dict(sao=info, sao_models=models, snap_y=snap[0], snap_u=snap[1], snap_v=snap[2], final_y=out[0], final_u=out[1], final_v=out[2],
                 deblocked_y=r[0], deblocked_u=r[1], deblocked_v=r[2])
@@ -982,3 +982,20 @@ def inter_scu_table(g, frame):
                 rid[:, :, l][use] = poc_of[np.clip(mot[:, :, 4 + l][use], 0, len(poc_of) - 1)]
         blk["ref_id"] = rid
     return t
+
+
+def moving_picture(W, H, t, depth):
+    """Picture t of a sequence with fractional motion: a window into a 4x larger noisy picture, shifted by quarter samples per
+    picture and box-filtered down -- the left and the right half move differently (partitions, uni- and bi-prediction)."""
+    base = varied_picture(4 * (W + 32), 4 * (H + 32), 2007, depth)
+    out = []
+    for b, c in zip(base, (0, 1, 1)):
+        w, h = W >> c, H >> c
+
+        def window(sx, sy):
+            a = b.astype(np.int64)[sy:sy + 4 * h, sx:sx + 4 * w]
+            return ((a.reshape(h, 4, w, 4).sum(axis=(1, 3)) + 8) >> 4).astype(b.dtype)
+        p = window((40 + 5 * t) >> c, (40 + 3 * t) >> c)
+        p[:, w // 2:] = window((100 - 7 * t) >> c, (40 + 2 * t) >> c)[:, w // 2:]
+        out.append(p)
+    return tuple(out)

@@ -6,7 +6,12 @@ cd "$(dirname "$0")/../.."
 REF=${UVG_REF_ROOT:-/tmp/uvgref}
 D=$1; shift
 if [ $D = 8 ]; then LIB=$REF/_b/libuvg266.a; DEF=""; else LIB=$REF/_b10/libuvg266.a; DEF="-DUVG_BIT_DEPTH=10"; fi
-gcc -O1 -g -std=gnu11 -w $DEF -I$REF/src -I$REF/src/extras -I$REF/src/strategies tools/refcheck/ctu_dump.c $LIB \
-    -Wl,--wrap=uvg_search_lcu -Wl,--wrap=uvg_encode_coding_tree -Wl,--wrap=uvg_sao_search_lcu -Wl,--wrap=uvg_bitstream_put_byte -Wl,--wrap=uvg_cabac_finish -Wl,--wrap=uvg_bitstream_align_zero -Wl,--wrap=uvg_inter_get_merge_cand -Wl,--wrap=uvg_inter_get_mv_cand -lm -lpthread -o /tmp/ctu_dump$D
+BIN=/tmp/ctu_dump$D
+# (re)build only when the dumper's source is newer; build to a private name and rename, so that concurrent runs never see a half-written binary
+if [ ! -x $BIN ] || [ tools/refcheck/ctu_dump.c -nt $BIN ] || [ tools/refcheck/ctu_dump.sh -nt $BIN ]; then
+  gcc -O1 -g -std=gnu11 -w $DEF -I$REF/src -I$REF/src/extras -I$REF/src/strategies tools/refcheck/ctu_dump.c $LIB \
+      -Wl,--wrap=uvg_search_lcu -Wl,--wrap=uvg_encode_coding_tree -Wl,--wrap=uvg_sao_search_lcu -Wl,--wrap=uvg_bitstream_put_byte -Wl,--wrap=uvg_cabac_finish \
+      -Wl,--wrap=uvg_bitstream_align_zero -Wl,--wrap=uvg_inter_get_merge_cand -Wl,--wrap=uvg_inter_get_mv_cand -lm -lpthread -o $BIN.$$ && mv -f $BIN.$$ $BIN
+fi
 IN=$1; W=$2; H=$3; N=$4; OUT=$5; shift 5
-/tmp/ctu_dump$D $IN $W $H $N $OUT.bin $OUT.266 "$@"
+$BIN $IN $W $H $N $OUT.bin $OUT.266 "$@"

@@ -187,22 +187,9 @@ def stream(W, H, depth, qp, ts):
 
 
 def moving_picture(W, H, t, depth):
-    """Picture t of a sequence with fractional motion: a window into a 4x larger noisy picture, shifted by quarter samples per
-    picture and box-filtered down -- the left and the right half move differently (partitions, uni- and bi-prediction)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers
-    base = helpers.varied_picture(4 * (W + 32), 4 * (H + 32), 2007, depth)
-    out = []
-    for b, c in zip(base, (0, 1, 1)):
-        w, h = W >> c, H >> c
-
-        def window(sx, sy):
-            a = b.astype(np.int64)[sy:sy + 4 * h, sx:sx + 4 * w]
-            return ((a.reshape(h, 4, w, 4).sum(axis=(1, 3)) + 8) >> 4).astype(b.dtype)
-        p = window((40 + 5 * t) >> c, (40 + 3 * t) >> c)
-        p[:, w // 2:] = window((100 - 7 * t) >> c, (40 + 2 * t) >> c)[:, w // 2:]
-        out.append(p)
-    return tuple(out)
+    return helpers.moving_picture(W, H, t, depth)
 
 
 def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True):
@@ -225,6 +212,9 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True):
     wc, hc = (W + 63) // 64, (H + 63) // 64
     n = frames * wc * hc
     meta = np.zeros((n, 8), np.int32)
+    lam = np.zeros((n, 6), np.float64)
+    sao = np.zeros((n, 2, 17), np.int32)
+    SA = {(int(r[0][0]), int(r[0][1]), int(r[0][2])): r for nm, r in recs if nm == "sao"}
     cu = np.zeros((n, 256, 12), np.uint8)
     mot = np.zeros((n, 256, 8), np.int32)
     refs = np.zeros((n, 52), np.int32)
@@ -233,14 +223,17 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True):
     for k, s in enumerate(S):
         fr, x, y = int(s[0][0]), int(s[0][1]), int(s[0][2])
         hh, ww = min(64, H - y), min(64, W - x)
-        meta[k], cu[k], mot[k], refs[k] = s[0], s[4].reshape(256, 12), s[11].reshape(256, 8), s[12]
+        meta[k], cu[k], mot[k], refs[k], lam[k] = s[0], s[4].reshape(256, 12), s[11].reshape(256, 8), s[12], s[1]
+        if (fr, x // 64, y // 64) in SA:
+            sao[k, 0], sao[k, 1] = SA[(fr, x // 64, y // 64)][5], SA[(fr, x // 64, y // 64)][6]
         rec[0][fr, y:y + hh, x:x + ww] = s[6].reshape(64, 64)[:hh, :ww]
         rec[1][fr, y // 2:(y + hh) // 2, x // 2:(x + ww) // 2] = s[7].reshape(32, 32)[:hh // 2, :ww // 2]
         rec[2][fr, y // 2:(y + hh) // 2, x // 2:(x + ww) // 2] = s[8].reshape(32, 32)[:hh // 2, :ww // 2]
         coeff[k, :4096] = s[9]
         coeff[k, 4096:] = s[10]
     final = [np.stack([f[1 + c].reshape(H >> (c > 0), W >> (c > 0)) for f in F]) for c in range(3)]
-    np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_inter_{tag}.npz"), dims=np.array([W, H, depth, qp, frames], np.int32), meta=meta, cu=cu,
+    src_crc = np.array([zlib.crc32(b"".join(p.tobytes() for p in moving_picture(W, H, t, depth))) for t in range(frames)], np.uint32)
+    np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_inter_{tag}.npz"), dims=np.array([W, H, depth, qp, frames], np.int32), meta=meta, cu=cu, lam=lam, sao=sao, src_crc=src_crc,
                         motion=mot, refs=refs, rec_y=rec[0], rec_u=rec[1], rec_v=rec[2], coeff=coeff if with_levels else coeff[:0], final_y=final[0], final_u=final[1],
                         final_v=final[2])
     print("wrote inter", tag, n, "CTU records")
