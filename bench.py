@@ -666,9 +666,10 @@ def main():
                 "config": {"workload": f"{wl['W']}x{wl['H']} {wl['depth']}-bit yuv420p, -p 1 --preset medium at QP {QP} (BASELINE.json configs[1]): per picture "
                                        "uvghip_ctu_plan_run (closed-loop CTU search bit-identical with the reference: partition, modes, levels, "
                                        "reconstruction, CABAC models) -> deblocking on the search's side information -> SAO statistics / decision "
-                                       "(edge, band, merge) / apply for Y, U, V; the arithmetic coder is out of the hot-path scope",
+                                       "(edge, band, merge) / apply for Y, U, V -> the arithmetic coder (uvghip_encode_slice_rows: the slice data of the encoder's .266, "
+                                       "byte for byte); all of it one uvghip_loop_plan_run per group",
                            "mpixels_per_s": round(fps * wl["W"] * wl["H"] / 1e6, 2), "qp": QP,
-                           "step": f"one group of {F} pictures through the closed loop (one uvghip_ctu_plan_run + the filter chain of its pictures)",
+                           "step": f"one group of {F} pictures through the closed loop (one uvghip_loop_plan_run: the search launch, the filter chain of its pictures, the slice coder launch)",
                            "pictures_per_step": F, "pictures_timed": steps * F * world, "groups_in_flight": n_groups, "timed_region_s": round(elapsed, 3),
                            "ctus_per_picture": wc * hc, "wavefront_steps_per_picture": wc + hc - 1,
                            "parallelism": f"whole pictures over {world} rank(s) (all-intra pictures are independent), {F} pictures per launch, "
