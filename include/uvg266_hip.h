@@ -931,6 +931,11 @@ UVGHIP_API int uvghip_picture_checksum(int bitdepth, const void *plane_y, int st
 UVGHIP_API int uvghip_write_picture_nals(int poc, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
                                          const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len);
 
+/* After uvghip_loop_plan_run: the NAL units (slice + hash SEI) of picture `picture` of the plan's group as picture number `poc` of the
+ * stream, into HOST memory -- uvghip_picture_checksum on its output picture, its rows brought to the host, uvghip_write_picture_nals.
+ * Waits for the stream.  *len = bytes needed; an error if that exceeds cap. */
+UVGHIP_API int uvghip_loop_plan_picture_nals(uvghip_loop_plan_t *plan, int picture, int poc, uint8_t *out, size_t cap, size_t *len, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -150,6 +150,7 @@ def test_device_outputs_complete_a_multi_picture_stream(hip, name):
         sums = api.picture_checksum(*cl.out[poc]).cpu().numpy().view(np.uint32)
         rc, nals, n = write_nals(hip, nb[poc], rows[poc], sums, poc=poc)
         assert rc == 0
+        assert cl.picture_nals(poc, poc) == nals          # the plan's own entry point: checksum, download and NAL units in one call
         mine += nals
     stream = g["bitstream"].tobytes()
     at = stream.find(b"\x00\x00\x01\x00\x41")

@@ -664,6 +664,16 @@ class ClosedLoop(CtuSearch):
         return (self.loop_ws[a.value - base:a.value - base + self.n * ctus * 34 * 4].view(torch.int32),
                 self.loop_ws[b.value - base:b.value - base + self.n * ctus * 6 * 2].view(torch.int16))
 
+    def picture_nals(self, picture, poc):
+        """uvghip_loop_plan_picture_nals: after run(), the slice NAL + hash SEI of picture `picture` as picture `poc` of the stream -> bytes."""
+        import ctypes
+        rows = self.hc * (3 * 64 * int(self.P.pic_w)) + 64 + 4 * self.hc
+        buf = np.zeros(rows, np.uint8)
+        n = ctypes.c_size_t(0)
+        _lib.check(self.L.uvghip_loop_plan_picture_nals(self.loop, picture, poc, buf.ctypes.data_as(ctypes.c_void_p), buf.size, ctypes.byref(n), _stream()),
+                   "uvghip_loop_plan_picture_nals")
+        return buf[:n.value].tobytes()
+
     def slice_data(self):
         """The rows' substreams the plan coded as the last thing of run(): (rows [n, n_rows, row_cap] uint8, row_bytes [n, n_rows] int32)
         as device views of the plan's buffers."""

@@ -25,6 +25,7 @@ struct uvghip_loop_plan {
   uint8_t *rows;                          // the slice data: row r of picture p at rows + (p * hc + r) * row_cap
   int32_t *row_bytes;
   int row_cap, hc;
+  uint32_t *sums;                         // per picture: the three plane checksums of the hash SEI (filled on demand)
   uvghip_ctu_params_t ctu_params;
 };
 
@@ -32,7 +33,7 @@ namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-struct layout_t { size_t search, snap, rects_y, rects_c, edge[3], band[3], decide, info, models, params[3], coder, row_bytes, rows, total; int row_cap; };
+struct layout_t { size_t search, snap, rects_y, rects_c, edge[3], band[3], decide, info, models, params[3], coder, row_bytes, rows, sums, total; int row_cap; };
 
 layout_t layout_of(int bitdepth, int n, int w, int h)
 {
@@ -54,6 +55,7 @@ layout_t layout_of(int bitdepth, int n, int w, int h)
   L.coder = take(uvghip_slice_rows_workspace_bytes(n));
   L.row_bytes = take((size_t)n * hc * 4);
   L.rows = take((size_t)n * hc * L.row_cap);
+  L.sums = take((size_t)n * 3 * sizeof(uint32_t));
   L.total = at;
   return L;
 }
@@ -104,6 +106,7 @@ extern "C" int uvghip_loop_plan_create(int bitdepth, const uvghip_ctu_params_t *
   pl->rows = ws + L.rows;
   pl->row_bytes = reinterpret_cast<int32_t *>(ws + L.row_bytes);
   pl->row_cap = L.row_cap; pl->hc = hc;
+  pl->sums = reinterpret_cast<uint32_t *>(ws + L.sums);
   pl->ctu_params = *params;
   if (int rc = uvghip_slice_rows_prepare(params, sp.data(), n_pictures, pl->coder_ws)) { uvghip_ctu_plan_destroy(pl->search); delete pl; return rc; }
   // the CTU grids clipped to the picture: the rectangles sao_search_luma / _chroma hand to the decision (sao.c:605-668)
@@ -182,6 +185,33 @@ extern "C" int uvghip_loop_plan_slice_data(const uvghip_loop_plan_t *pl, const u
   if (row_cap) *row_cap = pl->row_cap;
   if (n_rows) *n_rows = pl->hc;
   return 0;
+}
+
+// The NAL units of one picture of the group after a run: the checksum of its output picture on the device, its rows and their
+// lengths brought to the host, uvghip_write_picture_nals.  Waits for the stream (the bytes are host memory).
+extern "C" int uvghip_loop_plan_picture_nals(uvghip_loop_plan_t *pl, int picture, int poc, uint8_t *out, size_t cap, size_t *len, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!pl || picture < 0 || picture >= pl->n || poc < 0 || !len || (!out && cap)) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  hipStream_t st = uvghip_stream(stream);
+  const uvghip_loop_picture_t &q = pl->pics[picture];
+  uint32_t *d_sums = pl->sums + 3 * (size_t)picture;
+  if (int rc = uvghip_picture_checksum(pl->bitdepth, q.out_y, q.out_stride, q.out_u, q.out_v, q.out_stride_c, pl->w, pl->h, d_sums, stream)) return rc;
+  uint32_t sums[3];
+  std::vector<int32_t> nb(pl->hc);
+  UVGHIP_TRY(hipMemcpyAsync(sums, d_sums, sizeof sums, hipMemcpyDeviceToHost, st));
+  UVGHIP_TRY(hipMemcpyAsync(nb.data(), pl->row_bytes + (size_t)picture * pl->hc, (size_t)pl->hc * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  UVGHIP_TRY(hipStreamSynchronize(st));
+  size_t pitch = 1;
+  for (int r = 0; r < pl->hc; ++r) {
+    if (nb[r] <= 0 || nb[r] > pl->row_cap) return uvghip_set_error(hipErrorInvalidValue, "uvghip_loop_plan_picture_nals: a row overflowed its slot (or the plan has not run)");
+    if ((size_t)nb[r] > pitch) pitch = (size_t)nb[r];
+  }
+  std::vector<uint8_t> rows(pitch * pl->hc);
+  for (int r = 0; r < pl->hc; ++r)
+    UVGHIP_TRY(hipMemcpyAsync(rows.data() + (size_t)r * pitch, pl->rows + ((size_t)picture * pl->hc + r) * pl->row_cap, (size_t)nb[r], hipMemcpyDeviceToHost, st));
+  UVGHIP_TRY(hipStreamSynchronize(st));
+  return uvghip_write_picture_nals(poc, 1, rows.data(), pitch, nb.data(), pl->hc, sums, out, cap, len);
 }
 
 extern "C" int uvghip_loop_plan_results(const uvghip_loop_plan_t *pl, const int32_t **sao_info, const uint16_t **sao_models)
