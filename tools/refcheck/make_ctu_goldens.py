@@ -192,7 +192,7 @@ def moving_picture(W, H, t, depth):
     return helpers.moving_picture(W, H, t, depth)
 
 
-def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True):
+def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_dir=None):
     """Low-delay inter encode (--gop lp-g4d3t1, BASELINE configs[2]): per picture the reference lists and the picture after the in-loop
     filters, per CTU the side information incl. motion, the levels and the reconstruction before the filters -- what a reconstruction
     of the encoder's decisions (motion compensation + residual) needs."""
@@ -233,10 +233,11 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True):
         coeff[k, 4096:] = s[10]
     final = [np.stack([f[1 + c].reshape(H >> (c > 0), W >> (c > 0)) for f in F]) for c in range(3)]
     src_crc = np.array([zlib.crc32(b"".join(p.tobytes() for p in moving_picture(W, H, t, depth))) for t in range(frames)], np.uint32)
-    np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_inter_{tag}.npz"), dims=np.array([W, H, depth, qp, frames], np.int32), meta=meta, cu=cu, lam=lam, sao=sao, src_crc=src_crc,
+    np.savez_compressed(os.path.join(out_dir or os.path.join(ROOT, "tests/golden"), f"ref_inter_{tag}.npz"), dims=np.array([W, H, depth, qp, frames], np.int32), meta=meta, cu=cu, lam=lam, sao=sao, src_crc=src_crc,
                         motion=mot, refs=refs, rec_y=rec[0], rec_u=rec[1], rec_v=rec[2], coeff=coeff if with_levels else coeff[:0], final_y=final[0], final_u=final[1],
                         final_v=final[2])
-    print("wrote inter", tag, n, "CTU records")
+    if not out_dir: print("wrote inter", tag, n, "CTU records")
+    return tag
 
 
 def merge(W, H, depth, qp, frames, every, amvp_step=4):

@@ -4,7 +4,7 @@ on small synthetic pictures over a grid of sizes / bit depths / QPs / seeds and 
 built for the host (tests/emul) with the reference's records: the three model sets, cu fields, trees, reconstruction, levels.
 Nothing is written to tests/golden; a combination that differs is what to turn into a golden (make_ctu_goldens.full).
 
-  python tools/refcheck/sweep_ctu.py [n_cases] [seed] [default|small|large]"""
+  python tools/refcheck/sweep_ctu.py [n_cases] [seed] [default|small|large|inter]"""
 import os, sys, random
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -58,7 +58,49 @@ def filters_and_coder(W, Hh, depth, qp, t):
     return bad
 
 
+def inter_case(W, Hh, depth, qp, frames, sao):
+    """A low-delay encode (--gop lp-g4d3t1) of the moving test sequence: every inter CU reconstructed from the encoder's decisions
+    (helpers.inter_reconstruct through the oracle's block functions), then the in-loop filters of every picture (deblocking with the
+    B-slice rule, and with SAO on the decisions and the output picture)."""
+    import zlib
+    tag = M.inter(W, Hh, depth, qp, frames, extra=() if sao else ("sao", "off"), suffix="" if sao else "_nosao", out_dir="/tmp")
+    g = {k: v for k, v in np.load(f"/tmp/ref_inter_{tag}.npz").items()}
+    bad = []
+    try:
+        seen = H.inter_reconstruct(g, H.OracleBlocks(ORC, depth))
+    except AssertionError as e:
+        bad.append(("reconstruction", str(e)[:120]))
+        seen = {}
+    for fr in range(frames):
+        ks = [k for k in range(len(g["meta"])) if int(g["meta"][k][0]) == fr]
+        meta = g["meta"][ks[0]]
+        scu = H.inter_scu_table(g, fr)
+        if sao:
+            src = H.moving_picture(W, Hh, fr, depth)
+            r = H.oracle_sao_picture(ORC, depth, W, Hh, int(meta[7]), float(g["lam"][ks[0]][0]), src, (g["rec_y"][fr], g["rec_u"][fr], g["rec_v"][fr]), scu,
+                                     slice_type=int(meta[6]))
+            if not np.array_equal(H.sao_info_comparable(r["sao"]), H.sao_info_comparable(np.stack([g["sao"][k] for k in ks]))): bad.append(("sao", fr))
+            if not all(np.array_equal(r[k], g[k][fr]) for k in ("final_y", "final_u", "final_v")): bad.append(("final", fr))
+        else:
+            y, u, v = (np.ascontiguousarray(g[k][fr]).copy() for k in ("rec_y", "rec_u", "rec_v"))
+            ORC.deblock_frame(depth, y, u, v, W, Hh, scu.view(np.uint8).reshape(scu.shape[0], -1), scu.shape[1], 0, 0, int(meta[6]) == 0, -1, None)
+            if not (np.array_equal(y, g["final_y"][fr]) and np.array_equal(u, g["final_u"][fr]) and np.array_equal(v, g["final_v"][fr])): bad.append(("deblocked", fr))
+    return bad, seen
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "inter":
+        import random
+        rng = random.Random(int(sys.argv[2]))
+        fails = 0
+        for _ in range(int(sys.argv[1])):
+            W, Hh = rng.choice([64, 72, 128, 136, 192, 264]), rng.choice([64, 72, 128, 136])
+            depth, qp, frames, sao = rng.choice([8, 10]), rng.choice([12, 17, 22, 27, 32, 37]), rng.choice([3, 4, 6]), rng.choice([True, False])
+            bad, seen = inter_case(W, Hh, depth, qp, frames, sao)
+            print(f"inter {W}x{Hh} {depth}-bit qp {qp} {frames} frames sao {int(sao)}: {'ok' if not bad else 'DIFFERS: ' + str(bad[:4])} {seen}", flush=True)
+            fails += bool(bad)
+        print("cases that differ:", fails)
+        sys.exit(0)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     fails = 0
     grid = sys.argv[3] if len(sys.argv) > 3 else "default"          # default | small (sides 8..56 too) | large (up to 640x384)
