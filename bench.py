@@ -434,6 +434,58 @@ class ClosedLoop:
         return sum(a.elapsed_time(b) for a, b in self.ev), len(self.ev)
 
 
+def parity_check(group, golden):
+    """Picture 0 of a group AFTER the timed region -- the buffers hold what its last timed pass wrote, with the other group's launch
+    sharing the device -- against the record of the real encoder's run on the same picture (tests/golden/<golden>.npz, data only):
+    per-CTU CRCs of side information + trees / reconstruction / levels / the models after the coder, the SAO decisions and models,
+    per-CTU CRCs of the output picture, every WPP row's substream (length and CRC).  Raises on any difference."""
+    import zlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as Hh
+    g = Hh.ctu_golden(golden)
+    W, H, depth, qp, t = (int(a) for a in g["meta"][:5])
+    cs = group.cs
+    assert (W, H, depth, qp) == (group.W, group.H, group.depth, QP), "golden and workload disagree"
+    y, u, v = group.host[0]
+    if zlib.crc32(y.tobytes() + u.tobytes() + v.tobytes()) != int(g["src_crc"]):
+        raise SystemExit(f"parity check: picture 0 of the group is not the golden's source picture ({golden})")
+    torch.cuda.synchronize()
+    ry, ru, rv = (x.cpu().numpy() for x in cs.out[0])
+    # the reconstruction before the filters was deblocked in place by the loop plan: what remains comparable of the search are the
+    # side information, the levels and the models; the pictures are compared after the filters
+    scu = cs.cu[0].cpu().numpy().reshape(-1).view(Hh.SCU_NP)
+    res = Hh.search_result_from_device_layout(W, H, ry, ru, rv, scu, cs.coeff[0].cpu().numpy(), cs.models[0].cpu().numpy().view(np.uint32))
+    crc = Hh.ctu_crcs(res, W, H)
+    bad = {}
+    for col, what in ((0, "cu+trees"), (2, "levels"), (3, "models")):
+        n = int((crc[:, col] != g["crc"][:, col]).sum())
+        if n:
+            bad[what] = n
+    info, models = cs.results()
+    if not np.array_equal(Hh.sao_info_comparable(info[0]), Hh.sao_info_comparable(g["sao"])):
+        bad["sao"] = 1
+    if not np.array_equal(models[0], g["sao_models"]):
+        bad["sao_models"] = 1
+    fin = Hh.filter_crcs(dict(snap_y=ry, snap_u=ru, snap_v=rv, final_y=ry, final_u=ru, final_v=rv), W, H)[:, 1]
+    n = int((fin != g["filter_crc"][:, 1]).sum())
+    if n:
+        bad["output picture"] = n
+    rows, nbytes = cs.slice_data()
+    nb = nbytes[0].cpu().numpy()
+    if not np.array_equal(np.concatenate([[0], np.cumsum(nb)]), g["row_off"]):
+        bad["row lengths"] = 1
+    else:
+        rc = np.array([zlib.crc32(rows[0, r, :nb[r]].cpu().numpy().tobytes()) for r in range(len(nb))], np.uint32)
+        n = int((rc != g["row_crc"]).sum())
+        if n:
+            bad["slice data rows"] = n
+    if bad:
+        raise SystemExit(f"parity check FAILED against {golden}: {bad}")
+    return {"golden": golden, "ctus": int(len(crc)), "rows": int(len(nb)),
+            "items": "per-CTU CRC of cu fields + trees, levels, models after the coder; SAO decisions + models; per-CTU CRC of the output picture; "
+                     "every WPP row's slice data (length + CRC) -- picture 0 of group 0 after the timed region vs the reference encoder's record"}
+
+
 def closed_loop(wl, steps, warmup, in_flight, device, rank, world, dist, groups=2):
     """`steps` timed launches of `in_flight` pictures each (a step = one group of pictures through search -> deblock -> SAO) after
     `warmup` untimed ones; `groups` launches are in flight at a time on their own streams, so the thin start of one launch's
@@ -590,6 +642,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=224, help="pictures per step = per uvghip_ctu_plan_run launch (the reference's --owf)")
     ap.add_argument("--groups", type=int, default=2, help="launches in flight at a time, each on its own stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the post-run check of picture 0 against the reference encoder's record")
     ap.add_argument("--no-open-loop", action="store_true", help="skip the open-loop kernel-path measurement (previous rounds' headline)")
     ap.add_argument("--open-loop-steps", type=int, default=40)
     ap.add_argument("--serial", action="store_true", help="open loop: one stream, no overlap between pictures")
@@ -628,6 +681,9 @@ def main():
     steps = args.steps
     cl, F, elapsed, search_ms, launches = closed_loop(wl, steps, args.warmup, args.in_flight, device, rank, world, dist, args.groups)
     n_groups = len(cl)
+    parity = None
+    if rank == 0 and not args.no_parity:
+        parity = [parity_check(cl[0], {"1080p8": "ref_ctucrc_1920x1080_8_qp22", "2160p10alf": "ref_ctucrc_3840x2160_10_qp22"}[wl_name])]
     del cl
     pics = steps * F * world
     fps = pics / elapsed
@@ -636,6 +692,8 @@ def main():
         ewl = WORKLOADS["2160p10alf"]
         ek, eF = 4, max(1, args.in_flight // 2)          # (a 4K picture has 93 diagonals of at most 34 CTUs: 80 pictures keep 768 workgroups fed)
         ecl, eF, eel, ems, eln = closed_loop(ewl, ek, 0, eF, device, rank, world, dist, args.groups)
+        if parity is not None:
+            parity.append(parity_check(ecl[0], "ref_ctucrc_3840x2160_10_qp22"))
         del ecl
         extra = {"value": round(ek * eF * world / eel, 3), "unit": "frames/s", "steps": ek, "pictures_per_step": eF, "ms_per_step": round(1e3 * eel / ek, 2),
                  "mpixels_per_s": round(ek * eF * world / eel * ewl["W"] * ewl["H"] / 1e6, 1),
@@ -663,6 +721,7 @@ def main():
                 "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
                 "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "u8" if wl["depth"] == 8 else "u16", "data": "synthetic",
+                "parity_checked": parity is not None, "parity": parity,
                 "config": {"workload": f"{wl['W']}x{wl['H']} {wl['depth']}-bit yuv420p, -p 1 --preset medium at QP {QP} (BASELINE.json configs[1]): per picture "
                                        "uvghip_ctu_plan_run (closed-loop CTU search bit-identical with the reference: partition, modes, levels, "
                                        "reconstruction, CABAC models) -> deblocking on the search's side information -> SAO statistics / decision "

@@ -154,6 +154,11 @@ def test_plan_refuses_what_the_search_does_not_implement(hip):
     ctypes.memmove(bad, good.pics, ctypes.sizeof(bad))
     bad[0].coeff = None
     assert create(api.ctu_params(W, Hh, 27), pics=bad) != 0
+    for field in ("src_stride", "rec_stride", "src_stride_c", "rec_stride_c"):        # strides smaller than the picture (or negative) are refused
+        for val in (W // 4, -W):
+            ctypes.memmove(bad, good.pics, ctypes.sizeof(bad))
+            setattr(bad[0], field, val)
+            assert create(api.ctu_params(W, Hh, 27), pics=bad) != 0, field
     assert L.uvghip_ctu_plan_run(None, None) != 0
     assert L.uvghip_ctu_search_workspace_bytes(0, W, Hh) == 0
     # 12-bit samples are not a build of this library

@@ -568,7 +568,7 @@ class CtuSearch:
     src: list of (y, u, v) device planes.  Outputs stay on the device: rec[i] = (y, u, v), cu[i] (uvghip_scu_t table as bytes,
     [rows of 4x4, 16 * CTUs per row, 32]), coeff[i] ([CTUs, 6144] int16), models[i] ([CTUs, 3, 257] uint32 as int32)."""
 
-    def __init__(self, params, src):
+    def __init__(self, params, src, _make_plan=True):
         self.P = params
         self.n = len(src)
         W, H = params.pic_w, params.pic_h
@@ -582,13 +582,16 @@ class CtuSearch:
         self.cu = [torch.zeros((self.hc * 16, self.wc * 16, 32), dtype=torch.uint8, device=dev) for _ in src]
         self.coeff = [torch.zeros((ctus, 6144), dtype=torch.int16, device=dev) for _ in src]
         self.models = [torch.zeros((ctus, 3, 257), dtype=torch.int32, device=dev) for _ in src]
-        self.ws = torch.empty(self.L.uvghip_ctu_search_workspace_bytes(self.n, W, H), dtype=torch.uint8, device=dev)
         self.pics = (_lib.CtuPicture * self.n)()
         for i, (s, r) in enumerate(zip(src, self.rec)):
             self.pics[i] = _lib.CtuPicture(_dev(s[0]), _dev(s[1]), _dev(s[2]), s[0].stride(0), s[1].stride(0), _dev(r[0]), _dev(r[1]), _dev(r[2]),
                                            r[0].stride(0), r[1].stride(0), _dev(self.cu[i]), self.wc * 16, 0, _dev(self.coeff[i]), _dev(self.models[i]))
 
+        self.plan = None
+        if not _make_plan:          # ClosedLoop: uvghip_loop_plan_create builds the search plan inside its own workspace
+            return
         import ctypes
+        self.ws = torch.empty(self.L.uvghip_ctu_search_workspace_bytes(self.n, W, H), dtype=torch.uint8, device=dev)
         self.plan = ctypes.c_void_p()
         _lib.check(self.L.uvghip_ctu_plan_create(self.depth, ctypes.byref(self.P), self.pics, self.n, _dev(self.ws), ctypes.byref(self.plan)),
                    "uvghip_ctu_plan_create")
@@ -619,7 +622,7 @@ class ClosedLoop(CtuSearch):
 
     def __init__(self, params, src, sao_type=3):
         import ctypes
-        super().__init__(params, src)
+        super().__init__(params, src, _make_plan=False)
         dev = src[0][0].device
         self.out = [tuple(torch.empty_like(p) for p in s) for s in src]
         W, H = params.pic_w, params.pic_h
@@ -667,7 +670,7 @@ class ClosedLoop(CtuSearch):
     def picture_nals(self, picture, poc):
         """uvghip_loop_plan_picture_nals: after run(), the slice NAL + hash SEI of picture `picture` as picture `poc` of the stream -> bytes."""
         import ctypes
-        rows = self.hc * (3 * 64 * int(self.P.pic_w)) + 64 + 4 * self.hc
+        rows = self.hc * (3 * 64 * int(self.P.pic_w)) * (1 if self.depth == 8 else 2) + 64 + 4 * self.hc
         buf = np.zeros(rows, np.uint8)
         n = ctypes.c_size_t(0)
         _lib.check(self.L.uvghip_loop_plan_picture_nals(self.loop, picture, poc, buf.ctypes.data_as(ctypes.c_void_p), buf.size, ctypes.byref(n), _stream()),

@@ -170,6 +170,8 @@ extern "C" int uvghip_ctu_plan_create(int bitdepth, const uvghip_ctu_params_t *p
     const uvghip_ctu_picture_t &q = pictures[i];
     if (!q.src_y || !q.src_u || !q.src_v || !q.rec_y || !q.rec_u || !q.rec_v || !q.cu || !q.coeff || !q.models || q.cu_stride < wc * 16)
       return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_plan_create: picture descriptor");
+    if (q.src_stride < p.pic_w || q.rec_stride < p.pic_w || q.src_stride_c < p.pic_w / 2 || q.rec_stride_c < p.pic_w / 2)
+      return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_plan_create: a sample stride is smaller than the picture");
     pics[i] = pic_dev{q.src_y, q.src_u, q.src_v, q.rec_y, q.rec_u, q.rec_v, q.cu, q.coeff, q.models,
                       q.src_stride, q.src_stride_c, q.rec_stride, q.rec_stride_c, q.cu_stride, 0};
   }

@@ -51,7 +51,7 @@ layout_t layout_of(int bitdepth, int n, int w, int h)
   L.models = take((size_t)n * ctus * 6 * 2);
   for (int c = 0; c < 3; ++c) L.params[c] = take((size_t)n * ctus * sizeof(uvghip_sao_param_t));
   const size_t hc = (size_t)((h + 63) / 64);
-  L.row_cap = 3 * 64 * w;                 // twice the raw size of a CTU row of 8-bit 4:2:0 samples: no row of real content comes near
+  L.row_cap = 3 * 64 * w * (int)b;        // twice the raw storage of a CTU row of 4:2:0 samples: no row of real content comes near
   L.coder = take(uvghip_slice_rows_workspace_bytes(n));
   L.row_bytes = take((size_t)n * hc * 4);
   L.rows = take((size_t)n * hc * L.row_cap);
@@ -76,9 +76,13 @@ extern "C" int uvghip_loop_plan_create(int bitdepth, const uvghip_ctu_params_t *
   if (!params || !pictures || n_pictures <= 0 || !workspace || !plan_out || sao_type < 1 || sao_type > 3)
     return uvghip_set_error(hipErrorInvalidValue, __func__);
   const int w = params->pic_w, h = params->pic_h;
+  // the filters run without a chroma QP table (deblock.hip: identity), so a search that quantises chroma at another QP than luma
+  // would be filtered with the wrong tc: refused rather than silently different (the reference's default table is the identity)
+  if (params->qp_c != params->qp) return uvghip_set_error(hipErrorInvalidValue, "uvghip_loop_plan_create: qp_c != qp needs a chroma QP table, which the loop plan does not take");
   std::vector<uvghip_ctu_picture_t> sp(n_pictures);
   for (int i = 0; i < n_pictures; ++i) {
     if (!pictures[i].out_y || !pictures[i].out_u || !pictures[i].out_v) return uvghip_set_error(hipErrorInvalidValue, "uvghip_loop_plan_create: output planes");
+    if (pictures[i].out_stride < w || pictures[i].out_stride_c < w / 2) return uvghip_set_error(hipErrorInvalidValue, "uvghip_loop_plan_create: output strides");
     sp[i] = pictures[i].search;
   }
   const layout_t L = layout_of(bitdepth, n_pictures, w, h);

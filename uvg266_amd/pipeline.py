@@ -443,6 +443,7 @@ class Graph:
         self.handle = ctypes.c_void_p()
         h = capture_stream.cuda_stream
         _lib.check(L.uvghip_graph_begin(h), "uvghip_graph_begin")
+        forked = []          # the side streams that were really pulled into the capture (only those may be joined back)
         try:
             if branches:
                 fork = torch.cuda.Event()
@@ -454,6 +455,8 @@ class Graph:
                         continue
                     st = side_streams[(k - 1) % len(side_streams)]
                     st.wait_event(fork)                      # pulls the side stream into the capture
+                    if st not in forked:
+                        forked.append(st)
                     run(br, st.cuda_stream)
                     ev = torch.cuda.Event()
                     ev.record(st)
@@ -463,13 +466,19 @@ class Graph:
             run(launches, h)
         except BaseException:
             # a launch failed mid-capture: pull every forked side stream back into the capture stream before ending the capture
-            # (an unjoined branch would make hipStreamEndCapture fail and hide the real error), drop whatever was captured
-            for st in (side_streams or []):
-                ev = torch.cuda.Event()
-                ev.record(st)
-                capture_stream.wait_event(ev)
-            L.uvghip_graph_end(h, ctypes.byref(self.handle))
-            self.destroy()
+            # (an unjoined branch would make hipStreamEndCapture fail and hide the real error), drop whatever was captured.
+            # Streams that never joined the capture are left alone (waiting on their events from a capturing stream is an error),
+            # and the capture is always ended so that the original exception is the one that propagates.
+            try:
+                for st in forked:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    capture_stream.wait_event(ev)
+            except BaseException:
+                pass
+            finally:
+                L.uvghip_graph_end(h, ctypes.byref(self.handle))
+                self.destroy()
             raise
         rc = L.uvghip_graph_end(h, ctypes.byref(self.handle))
         _lib.check(rc, "uvghip_graph_end")
