@@ -37,10 +37,16 @@ void ORC_FN(dequant)(const int16_t *q_coef, int16_t *coef, int width, int height
 int ORC_FN(rdoq)(const int16_t *coef, int16_t *dest_coeff, int width, int height, int color, int block_type, int cbf_u, int lfnst_idx, int mts_idx,
                  int qp_scaled, double lambda, const void *ctx_snapshot);
 
-enum { NMODELS = 257, NRES = 244 };
-enum { M_CBF_LUMA = 234, M_CBF_CB = 238, M_CBF_CR = 240, M_SPLIT = 244, M_MPM = 253, M_PLANAR = 254, M_CHROMA_PRED = 256 };
+enum { NMODELS = 257, NRES = 244, NINTER = 18, NM = NMODELS + NINTER };
+enum { M_CBF_LUMA = 234, M_CBF_CB = 238, M_CBF_CR = 240, M_ROOT_CBF = 243, M_SPLIT = 244, M_MPM = 253, M_PLANAR = 254, M_CHROMA_PRED = 256,
+       /* the inter syntax (P / B slices), order of snapshot_inter in tools/refcheck/ctu_dump.c */
+       M_SKIP = 257, M_PRED_MODE = 260, M_MERGE_FLAG = 262, M_MERGE_IDX = 263, M_INTER_DIR = 264, M_REF_PIC = 270, M_MVD = 272, M_MVP_IDX = 274 };
 
-typedef struct orc_models { uint16_t state0[NMODELS], state1[NMODELS]; uint8_t rate[NMODELS]; } orc_models;
+/* the exported layouts: the 257 models of an intra picture's search (rounds 1-3) and, beside them, the 18 of the inter syntax */
+typedef struct orc_models_ext { uint16_t state0[NMODELS], state1[NMODELS]; uint8_t rate[NMODELS]; } orc_models_ext;
+typedef struct orc_models_inter { uint16_t state0[NINTER], state1[NINTER]; uint8_t rate[NINTER]; } orc_models_inter;
+/* internal: one index space */
+typedef struct orc_models { uint16_t state0[NM], state1[NM]; uint8_t rate[NM]; } orc_models;
 typedef struct orc_cabac_models { uint16_t state0[NRES], state1[NRES]; uint8_t rate[NRES]; } orc_cabac_models;
 double ORC_FN(coeff_cost)(const int16_t *coeff, int width, int height, int color, const orc_cabac_models *models_in, uint32_t *flags_out,
                           orc_cabac_models *models_out);
@@ -67,8 +73,27 @@ typedef struct s_cu {
   int8_t mode, mode_chroma;
   uint8_t luma_deblocking, chroma_deblocking, qp, pad;
   uint32_t split_tree, mode_type_tree;
+  /* P / B slices (cu_info_t: skipped, merged, merge_idx, root_cbf; inter.mv_dir, mv_ref, mv_cand0/1, mv) */
+  uint8_t skipped, merged, merge_idx, root_cbf, mv_dir, mv_cand0, mv_cand1, pad2;
+  uint8_t mv_ref[2], pad3[2];
+  int32_t mv[2][2];
 } s_cu;
-enum { CU_NOTSET = 0, CU_INTRA = 1 };
+enum { CU_NOTSET = 0, CU_INTRA = 1, CU_INTER = 2 };
+
+/* what the reference reads of encoder_state_t / the picture's reference lists on the inter path (all of it host-side bookkeeping of
+ * the encoder: the GOP structure, the reference picture sets and the per-picture QP / lambda stay with the caller) */
+typedef struct orc_inter_frame {
+  int32_t slice_type;             /* state->frame->slicetype: 0 B, 1 P, 2 I */
+  int32_t poc;
+  int32_t n_refs;                 /* state->frame->ref->used_size */
+  int32_t ref_pocs[16];           /* state->frame->ref->pocs */
+  int32_t l_size[2];              /* state->frame->ref_LX_size */
+  int32_t l[2][16];               /* state->frame->ref_LX: indices into the reference array */
+  int32_t tmvp, max_merge, merge_level, bipred, fme_level, early_skip, depth_inter_min, depth_inter_max;
+  int32_t ref_cu_stride, reserved;
+  const orc_px *ref_y[16], *ref_u[16], *ref_v[16];      /* the reference pictures after the in-loop filters, pic_w x pic_h, tightly packed */
+  const int32_t *ref_cu[16];      /* per reference picture and 4x4 (stride ref_cu_stride): type, mv[2][2], mv_dir, the POC the L0 / L1 vector points to */
+} orc_inter_frame;
 enum { NO_SPLIT = 0, QT_SPLIT = 1 };
 enum { MODE_TYPE_ALL = 0, MODE_TYPE_INTER = 1, MODE_TYPE_INTRA = 2 };
 enum { EDGE_VER = 1, EDGE_HOR = 2 };     /* filter.h edge_dir */
@@ -95,6 +120,13 @@ typedef struct s_state {
   s_cabac search;               /* state->search_cabac */
   orc_rdoq_ctx rdoq;            /* CTX_STATE of state->cabac at the CTU's start: uvg_rdoq prices with THAT (rdo.c:1462) */
   double c_lambda;              /* state->c_lambda (temporarily replaced in uvg_quantize_lcu_residual, transform.c:1575) */
+  /* P / B pictures */
+  const orc_inter_frame *fr;    /* NULL: an intra picture */
+  const orc_px *src_y;          /* frame->source->y */
+  const int32_t *col;           /* the collocated picture (L0[0]) on the 8x8 grid, layout of orc_inter_cand.c */
+  int32_t *hmvp;                /* the CTU row's history table: [size, 5 x 8 ints] */
+  const s_cu *cua;              /* the picture's cu array (the real coder's predictors) */
+  int cu_stride;
 } s_state;
 
 static void loc_ctor(s_loc *l, int x, int y, int w, int h)
@@ -144,8 +176,8 @@ static void fbits_update(s_cabac *cb, int c, int bin, double *bits)
 static void models_init(orc_models *m, int qp, int slice)      /* uvg_init_contexts / uvg_ctx_init, context.c:471-500 */
 {
   memset(m, 0, sizeof *m);
-  for (int i = 0; i < NMODELS; ++i) {
-    const int v = k_ctx_init[slice][i];
+  for (int i = 0; i < NM; ++i) {
+    const int v = i < NMODELS ? k_ctx_init[slice][i] : k_ctx_init_inter[slice][i - NMODELS];
     if (v == 255) continue;
     const int slope = (v >> 3) - 4, offset = ((v & 7) * 18) + 1;
     int s = ((slope * (qp - 16)) >> 1) + offset;
@@ -153,8 +185,18 @@ static void models_init(orc_models *m, int qp, int slice)      /* uvg_init_conte
     const int p1 = s << 8;
     m->state0[i] = (uint16_t)(p1 & ((~(~0u << 10)) << 5));
     m->state1[i] = (uint16_t)(p1 & ((~(~0u << 14)) << 1));
-    m->rate[i] = k_ctx_init[3][i];
+    m->rate[i] = i < NMODELS ? k_ctx_init[3][i] : k_ctx_init_inter[3][i - NMODELS];
   }
+}
+static void models_to_ext(const orc_models *m, orc_models_ext *e, orc_models_inter *x)
+{
+  memcpy(e->state0, m->state0, sizeof e->state0); memcpy(e->state1, m->state1, sizeof e->state1); memcpy(e->rate, m->rate, sizeof e->rate);
+  if (x) { memcpy(x->state0, m->state0 + NMODELS, sizeof x->state0); memcpy(x->state1, m->state1 + NMODELS, sizeof x->state1); memcpy(x->rate, m->rate + NMODELS, sizeof x->rate); }
+}
+static void models_from_ext(orc_models *m, const orc_models_ext *e)
+{
+  memset(m, 0, sizeof *m);
+  memcpy(m->state0, e->state0, sizeof e->state0); memcpy(m->state1, e->state1, sizeof e->state1); memcpy(m->rate, e->rate, sizeof e->rate);
 }
 
 static void rdoq_ctx_from(const orc_models *m, orc_rdoq_ctx *c)
@@ -570,7 +612,7 @@ static int scaled_qp(const s_state *st, int color)
 }
 
 /* quantize_tr_residual -> uvg_quantize_residual (transform.c:1283-1480, quant-generic.c:460-612): the prediction is in rec */
-static void quantize_tr_residual(s_state *st, int color, const s_loc *loc, s_cu *cur_pu, s_lcu *lcu)
+static void quantize_tr_residual(s_state *st, int color, const s_loc *loc, s_cu *cur_pu, s_lcu *lcu, int early_skip)
 {
   const int shift = color == 0 ? 0 : 1;
   const int lx = loc->lx >> shift, ly = loc->ly >> shift;
@@ -585,10 +627,10 @@ static void quantize_tr_residual(s_state *st, int color, const s_loc *loc, s_cu 
   ORC_FN(dct_nxn)(ORC_BIT_DEPTH, w, residual, coeff);
   memset(q, 0, sizeof q);
   const double lambda = color == 0 ? st->p->lambda : st->c_lambda;
-  ORC_FN(rdoq)(coeff, q, w, h, color, CU_INTRA, (cur_pu->cbf >> 1) & 1, 0, 0, scaled_qp(st, color), lambda, &st->rdoq);
+  ORC_FN(rdoq)(coeff, q, w, h, color, cur_pu->type, (cur_pu->cbf >> 1) & 1, 0, 0, scaled_qp(st, color), lambda, &st->rdoq);
   int has_coeffs = 0;
   for (int i = 0; i < w * h; ++i) if (q[i]) { has_coeffs = 1; break; }
-  if (has_coeffs) {
+  if (has_coeffs && !early_skip) {
     ORC_FN(dequant)(q, coeff, w, h, ORC_BIT_DEPTH, scaled_qp(st, color), 0);
     ORC_FN(idct_nxn)(ORC_BIT_DEPTH, w, coeff, residual);
     for (int y = 0; y < h; ++y)
@@ -640,7 +682,7 @@ static void intra_recon_cu(s_state *st, int mode, int mode_chroma, const s_loc *
   /* uvg_quantize_lcu_residual */
   if (recon_luma) cur_cu->cbf &= (uint8_t)~1;
   if (recon_chroma) cur_cu->cbf &= (uint8_t)~6;
-  if (recon_luma) quantize_tr_residual(st, 0, loc, cur_cu, lcu);
+  if (recon_luma) quantize_tr_residual(st, 0, loc, cur_cu, lcu, 0);
   const double c_lambda = st->c_lambda;
   {   /* uvg_calculate_chroma_lambda (rate_control.c:1216-1233), no dep-quant, no JCCR */
     double lambda = st->p->lambda;
@@ -651,8 +693,37 @@ static void intra_recon_cu(s_state *st, int mode, int mode_chroma, const s_loc *
   }
   if (recon_chroma) {
     /* handled_elsewhere (transform.c:1301): a chroma block of a luma CU narrower than 8 that is not on the 8x8 grid */
-    quantize_tr_residual(st, 1, loc, cur_cu, lcu);
-    quantize_tr_residual(st, 2, loc, cur_cu, lcu);
+    quantize_tr_residual(st, 1, loc, cur_cu, lcu, 0);
+    quantize_tr_residual(st, 2, loc, cur_cu, lcu, 0);
+  }
+  st->c_lambda = c_lambda;
+}
+
+/* uvg_quantize_lcu_residual (transform.c:1487-1603) as the inter path calls it: the prediction is in rec; cur_pu == NULL: the entry of the
+ * lcu_t.  Blocks wider than 32 are four transform units, each with the flags of its own entry; the first one's root_cbf collects them. */
+static void quantize_lcu_residual(s_state *st, int luma, int chroma, const s_loc *loc, s_cu *cur_pu, s_lcu *lcu, int early_skip)
+{
+  if (cur_pu == NULL) cur_pu = CU_AT(lcu, loc->lx, loc->ly);
+  if (luma) cur_pu->cbf &= (uint8_t)~1;
+  if (chroma) cur_pu->cbf &= (uint8_t)~6;
+  if (loc->w > 32 || loc->h > 32) {
+    const int hw = loc->w >> 1, hh = loc->h >> 1;
+    uint8_t child_cbfs[3] = {0, 0, 0};
+    for (int i = 0; i < 4; ++i) {
+      s_loc sl;
+      loc_ctor(&sl, loc->x + (i & 1) * hw, loc->y + (i >> 1) * hh, hw, hh);
+      quantize_lcu_residual(st, luma, chroma, &sl, NULL, lcu, early_skip);
+      if (i != 0) child_cbfs[i - 1] = CU_AT(lcu, sl.lx, sl.ly)->cbf;
+    }
+    cur_pu->root_cbf = (cur_pu->cbf & 7) || (child_cbfs[0] & 7) || (child_cbfs[1] & 7) || (child_cbfs[2] & 7);
+    return;
+  }
+  if (luma) quantize_tr_residual(st, 0, loc, cur_pu, lcu, early_skip);
+  const double c_lambda = st->c_lambda;
+  st->c_lambda = st->p->lambda / pow(2.0, (st->p->qp - st->p->qp_c) / 3.0) * 1.0;     /* uvg_calculate_chroma_lambda, no JCCR */
+  if (chroma) {
+    quantize_tr_residual(st, 1, loc, cur_pu, lcu, early_skip);
+    quantize_tr_residual(st, 2, loc, cur_pu, lcu, early_skip);
   }
   st->c_lambda = c_lambda;
 }
@@ -683,7 +754,9 @@ static double cu_rd_cost_tr_split_accurate(s_state *st, const s_cu *pred_cu, s_l
   s_cu *tr_cu = CU_AT(lcu, loc->lx, loc->ly);
   double coeff_bits = 0, luma_bits = 0, chroma_bits = 0;
   const int cb_flag_u = (tr_cu->cbf >> 1) & 1, cb_flag_v = (tr_cu->cbf >> 2) & 1;
+  const int skip_residual_coding = pred_cu->skipped || (pred_cu->type != CU_INTRA && pred_cu->cbf == 0);
   s_cabac *cb = &st->search;
+  if (pred_cu->type != CU_INTRA && !pred_cu->merged) fbits_update(cb, M_ROOT_CBF, (tr_cu->cbf & 7) != 0, &luma_bits);      /* at every level of the recursion (:744-751) */
   if (loc->w > 32 || loc->h > 32) {
     double sum = 0;
     const int hw = loc->w >> 1, hh = loc->h >> 1;
@@ -695,12 +768,12 @@ static double cu_rd_cost_tr_split_accurate(s_state *st, const s_cu *pred_cu, s_l
     }
     return sum + luma_bits * st->p->lambda;
   }
-  if (has_chroma) {
+  if (!skip_residual_coding && has_chroma) {
     fbits_update(cb, M_CBF_CB + 0, cb_flag_u, &chroma_bits);
     fbits_update(cb, M_CBF_CR + cb_flag_u, cb_flag_v, &chroma_bits);
   }
   const int cb_flag_y = tr_cu->cbf & 1;
-  fbits_update(cb, M_CBF_LUMA + 0, cb_flag_y, &luma_bits);
+  if ((pred_cu->type == CU_INTRA || cb_flag_u || cb_flag_v) && !skip_residual_coding) fbits_update(cb, M_CBF_LUMA + 0, cb_flag_y, &luma_bits);
   const int index = loc->lx + LCU * loc->ly;
   const unsigned luma_ssd = ORC_FN(pixels_calc_ssd)(&lcu->ref_y[index], &lcu->rec_y[index], LCU, LCU, loc->w, loc->h);
   if (cb_flag_y) coeff_bits += coeff_cost_cu(cb, lcu->coeff_y, LCU, loc->lx, loc->ly, loc->w, loc->h, 0);
@@ -751,6 +824,20 @@ static void lcu_fill_cu_info(s_lcu *lcu, int lx, int ly, int w, int h, const s_c
       to->type = cu->type; to->qp = cu->qp; to->split_tree = cu->split_tree; to->mode_type_tree = cu->mode_type_tree;
       to->log2_h = cu->log2_h; to->log2_w = cu->log2_w; to->log2_ch = cu->log2_ch; to->log2_cw = cu->log2_cw;
       if (cu->type == CU_INTRA) { to->mode = cu->mode; to->mode_chroma = cu->mode_chroma; }
+      else {
+        to->skipped = cu->skipped; to->merged = cu->merged; to->merge_idx = cu->merge_idx;
+        to->mv_dir = cu->mv_dir; to->mv_cand0 = cu->mv_cand0; to->mv_cand1 = cu->mv_cand1; to->mv_ref[0] = cu->mv_ref[0]; to->mv_ref[1] = cu->mv_ref[1];
+        memcpy(to->mv, cu->mv, sizeof to->mv);
+      }
+    }
+}
+static void lcu_fill_cbf(s_lcu *lcu, int lx, int ly, int w, int h)                           /* search.c:402-420, single tree */
+{
+  for (int y = 0; y < h; y += 4)
+    for (int x = 0; x < w; x += 4) {
+      const s_cu *from = CU_AT(lcu, lx + (x & ~31), ly + (y & ~31));
+      s_cu *to = CU_AT(lcu, lx + x, ly + y);
+      if (from != to) to->cbf = (uint8_t)((to->cbf & ~7) | (from->cbf & 7));
     }
 }
 static void lcu_fill_chroma_cu_info(s_lcu *lcu, const s_loc *loc)                           /* search.c:355-378 */
@@ -851,27 +938,31 @@ static void work_tree_copy_up(const s_lcu *from, s_lcu *to, const s_loc *loc, co
 }
 
 /* mark_deblocking (search.c:1075-1174), single tree, not skipped */
-static void mark_deblocking(const s_loc *loc, const s_loc *chroma_loc, s_lcu *lcu, int has_chroma, int is_separate_tree)
+static void mark_deblocking(const s_loc *loc, const s_loc *chroma_loc, s_lcu *lcu, int has_chroma, int is_separate_tree, int is_skip)
 {
   if (loc->x) {
-    for (int x = loc->lx; x < loc->lx + loc->w; x += 32)
+    for (int x = loc->lx; x < loc->lx + loc->w; x += 32) {
       for (int y = loc->ly; y < loc->ly + loc->h; y += 4) {
         CU_AT(lcu, x, y)->luma_deblocking |= EDGE_VER;
         if (!is_separate_tree) CU_AT(lcu, x, y)->chroma_deblocking |= EDGE_VER;
       }
-  } else if (loc->w == 64) {
+      if (is_skip) break;
+    }
+  } else if (loc->w == 64 && !is_skip) {
     for (int y = loc->ly; y < loc->ly + loc->h; y += 4) {
       CU_AT(lcu, 32, y)->luma_deblocking |= EDGE_VER;
       if (!is_separate_tree) CU_AT(lcu, 32, y)->chroma_deblocking |= EDGE_VER;
     }
   }
   if (loc->y) {
-    for (int y = loc->ly; y < loc->ly + loc->h; y += 32)
+    for (int y = loc->ly; y < loc->ly + loc->h; y += 32) {
       for (int x = loc->lx; x < loc->lx + loc->w; x += 4) {
         CU_AT(lcu, x, y)->luma_deblocking |= EDGE_HOR;
         if (!is_separate_tree) CU_AT(lcu, x, y)->chroma_deblocking |= EDGE_HOR;
       }
-  } else if (loc->h == 64) {
+      if (is_skip) break;
+    }
+  } else if (loc->h == 64 && !is_skip) {
     for (int x = loc->lx; x < loc->lx + loc->w; x += 4) {
       CU_AT(lcu, x, 32)->luma_deblocking |= EDGE_HOR;
       if (!is_separate_tree) CU_AT(lcu, x, 32)->chroma_deblocking |= EDGE_HOR;
@@ -986,7 +1077,7 @@ static double search_cu(s_state *st, const s_loc *loc, const s_loc *chroma_loc, 
     cost = bits * p->lambda;
     cost += cu_rd_cost_tr_split_accurate(st, cur_cu, lcu, loc, chroma_loc, has_chroma);
     cb->update = 0;
-    mark_deblocking(loc, chroma_loc, lcu, has_chroma, is_separate_tree);
+    mark_deblocking(loc, chroma_loc, lcu, has_chroma, is_separate_tree, cur_cu->skipped);
   }
 
   int can_split_cu = cur_cu->type == CU_NOTSET || depth < p->depth_max;
@@ -1074,7 +1165,7 @@ static double search_cu(s_state *st, const s_loc *loc, const s_loc *chroma_loc, 
         mode_bits += bits;
         cost += mode_bits * p->lambda;
         cost += cu_rd_cost_tr_split_accurate(st, cur_cu, lcu, loc, chroma_loc, has_chroma);
-        mark_deblocking(loc, chroma_loc, lcu, has_chroma, is_separate_tree);
+        mark_deblocking(loc, chroma_loc, lcu, has_chroma, is_separate_tree, cur_cu->skipped);
         post_search_cabac = st->search;
         st->search = temp_cabac;
       }
@@ -1201,7 +1292,7 @@ static void encode_coding_tree(const s_frame *f, s_state *st, s_cabac *cb, const
  *   models_out: per CTU three model sets: at the CTU's start, at the end of its search, after the real coder
  */
 ORC_EXPORT int ORC_FN(search_intra_picture)(const orc_search_params *p, const orc_px *src_y, const orc_px *src_u, const orc_px *src_v,
-                                            orc_px *rec_y, orc_px *rec_u, orc_px *rec_v, uint8_t *cu_out, int16_t *coeff_out, orc_models *models_out)
+                                            orc_px *rec_y, orc_px *rec_u, orc_px *rec_v, uint8_t *cu_out, int16_t *coeff_out, orc_models_ext *models_out)
 {
   fbits_init();
   if (p->pic_w % 8 || p->pic_h % 8) return -1;
@@ -1221,8 +1312,8 @@ ORC_EXPORT int ORC_FN(search_intra_picture)(const orc_search_params *p, const or
         if (cyi == 0 || !p->wpp) { if (cyi == 0) models_init(&coder, p->qp, 2); }
         else coder = row_start[cyi - 1];
       }
-      orc_models *mo = &models_out[(size_t)(cyi * wc + cxi) * 3];
-      mo[0] = coder;
+      orc_models_ext *mo = &models_out[(size_t)(cyi * wc + cxi) * 3];
+      models_to_ext(&coder, &mo[0], NULL);
       /* uvg_search_lcu */
       st->search.m = coder;
       st->search.update = 0;
@@ -1253,7 +1344,7 @@ ORC_EXPORT int ORC_FN(search_intra_picture)(const orc_search_params *p, const or
       loc_ctor(&start, x, y, 64, 64);
       s_tree tree = {0, MODE_TYPE_ALL, 0, 0, 0, 0};
       search_cu(st, &start, &start, lcu, tree, 1);
-      mo[1] = st->search.m;
+      models_to_ext(&st->search.m, &mo[1], NULL);
       /* copy_lcu_to_cu_data + coefficients */
       for (int j = 0; j < y_max; j += 4) for (int i = 0; i < x_max; i += 4) f.cua[((y + j) >> 2) * cu_stride + ((x + i) >> 2)] = *CU_AT(lcu, i, j);
       for (int j = 0; j < y_max; ++j) memcpy(&rec_y[(y + j) * W + x], &lcu->rec_y[j * LCU], (size_t)x_max * sizeof(orc_px));
@@ -1270,7 +1361,7 @@ ORC_EXPORT int ORC_FN(search_intra_picture)(const orc_search_params *p, const or
         encode_coding_tree(&f, st, &cb, co, co + 4096, co + 4096 + 1024, &start, &start, tree, 1);
         coder = cb.m;
       }
-      mo[2] = coder;
+      models_to_ext(&coder, &mo[2], NULL);
       if (cxi == 0) row_start[cyi] = coder;
     }
   }
@@ -1296,8 +1387,8 @@ ORC_EXPORT int ORC_FN(search_intra_picture)(const orc_search_params *p, const or
  * arithmetic (uvg_cabac_encode_bin, cabac.c:76-109) and returns per CTU the bits the coder consumes for the tree
  * (renormalisation shifts of the context-coded bins + one per bypass bin), its range afterwards and the models afterwards.
  */
-ORC_EXPORT int ORC_FN(count_picture_bits)(const orc_search_params *p, const uint8_t *cu, const int16_t *coeff, const orc_models *start,
-                                          const int64_t *range_in, int64_t *bits_out, int64_t *range_out, orc_models *after)
+ORC_EXPORT int ORC_FN(count_picture_bits)(const orc_search_params *p, const uint8_t *cu, const int16_t *coeff, const orc_models_ext *start,
+                                          const int64_t *range_in, int64_t *bits_out, int64_t *range_out, orc_models_ext *after)
 {
   fbits_init();
   const int W = p->pic_w, H = p->pic_h, wc = (W + 63) / 64, hc = (H + 63) / 64, cu_stride = wc * 16;
@@ -1315,7 +1406,7 @@ ORC_EXPORT int ORC_FN(count_picture_bits)(const orc_search_params *p, const uint
   for (int k = 0; k < wc * hc; ++k) {
     const int16_t *co = &coeff[(size_t)k * 6144];
     s_cabac cb;
-    cb.m = start[k]; cb.update = 1;
+    models_from_ext(&cb.m, &start[k]); cb.update = 1;
     orc_cabac_sim *sim = &ORC_FN(cabac_sim);
     sim->on = 1; sim->range = (uint32_t)range_in[k]; sim->shifts = 0; sim->regular_fbits = 0.0;
     g_tree_bits = 0.0;
@@ -1326,7 +1417,7 @@ ORC_EXPORT int ORC_FN(count_picture_bits)(const orc_search_params *p, const uint
     sim->on = 0;
     bits_out[k] = (int64_t)sim->shifts + (int64_t)floor(g_tree_bits - sim->regular_fbits + 0.5);
     range_out[k] = sim->range;
-    after[k] = cb.m;
+    models_to_ext(&cb.m, &after[k], NULL);
   }
   free(f.cua); free(st);
   return 0;
@@ -1339,7 +1430,7 @@ ORC_EXPORT int ORC_FN(count_picture_bits)(const orc_search_params *p, const uint
  * the tree begins; state_out likewise when it ends; bytes_out / byte_off[ctu + 1]: the payload bytes the coder hands to the
  * bitstream during each CTU's tree (before emulation prevention).  Returns the total number of bytes, or -1 if bytes_cap is too small.
  */
-ORC_EXPORT long ORC_FN(encode_picture_ctus)(const orc_search_params *p, const uint8_t *cu, const int16_t *coeff, const orc_models *start,
+ORC_EXPORT long ORC_FN(encode_picture_ctus)(const orc_search_params *p, const uint8_t *cu, const int16_t *coeff, const orc_models_ext *start,
                                             const int64_t *state_in, int64_t *state_out, uint8_t *bytes_out, long bytes_cap, int64_t *byte_off)
 {
   fbits_init();
@@ -1361,7 +1452,7 @@ ORC_EXPORT long ORC_FN(encode_picture_ctus)(const orc_search_params *p, const ui
   for (int k = 0; k < wc * hc; ++k) {
     const int16_t *co = &coeff[(size_t)k * 6144];
     s_cabac cb;
-    cb.m = start[k]; cb.update = 1;
+    models_from_ext(&cb.m, &start[k]); cb.update = 1;
     sim->on = 2; sim->shifts = 0; sim->regular_fbits = 0.0; sim->out_len = 0;
     sim->low = (uint32_t)state_in[5 * k]; sim->range = (uint32_t)state_in[5 * k + 1]; sim->bits_left = (int32_t)state_in[5 * k + 2];
     sim->num_buffered_bytes = (int32_t)state_in[5 * k + 3]; sim->buffered_byte = (uint32_t)state_in[5 * k + 4];
@@ -1438,7 +1529,7 @@ static void encode_sao_color(sao_models2 *m, const int32_t *info, int color)
  * CTU is coded.  The slice data of the picture is exactly these bytes.
  */
 ORC_EXPORT long ORC_FN(encode_picture_rows)(const orc_search_params *p, const uint8_t *cu, const int16_t *coeff, const int32_t *sao,
-                                            uint8_t *bytes_out, long bytes_cap, int64_t *row_off, orc_models *after)
+                                            uint8_t *bytes_out, long bytes_cap, int64_t *row_off, orc_models_ext *after)
 {
   fbits_init();
   const int W = p->pic_w, H = p->pic_h, wc = (W + 63) / 64, hc = (H + 63) / 64, cu_stride = wc * 16;
@@ -1480,7 +1571,7 @@ ORC_EXPORT long ORC_FN(encode_picture_rows)(const orc_search_params *p, const ui
       s_tree tree = {0, MODE_TYPE_ALL, 0, 0, 0, 0};
       g_tree_bits = 0.0;
       encode_coding_tree(&f, st, &cb, co, co + 4096, co + 4096 + 1024, &start_loc, &start_loc, tree, 1);
-      if (after) after[k] = cb.m;
+      if (after) models_to_ext(&cb.m, &after[k], NULL);
       if (cx == 0) { row_m[cy] = cb.m; row_s[cy] = sm; }                      /* the next row's start (encoderstate.c:966-975) */
     }
     ORC_FN(cabac_sim_row_end)();

@@ -56,6 +56,27 @@ static void snapshot(const cabac_data_t *cb, models_t *s)
   put(s, 256, &cb->ctx.chroma_pred_model, 1);
 }
 
+/* the models of the inter syntax (P / B slices), index space of oracle/orc_search.c behind the 257 above:
+ * skip flag [3], pred mode [2], merge flag, merge idx, inter dir [6], ref idx [2], mvd [2], mvp idx = 18 */
+enum { NCTX_INTER = 18 };
+typedef struct { uint16_t state0[NCTX_INTER], state1[NCTX_INTER]; uint8_t rate[NCTX_INTER]; } models_inter_t;
+static void put2(models_inter_t *s, int at, const cabac_ctx_t *src, int n)
+{
+  for (int i = 0; i < n; ++i) { s->state0[at + i] = src[i].state[0]; s->state1[at + i] = src[i].state[1]; s->rate[at + i] = src[i].rate; }
+}
+static void snapshot_inter(const cabac_data_t *cb, models_inter_t *s)
+{
+  memset(s, 0, sizeof *s);
+  put2(s, 0, cb->ctx.cu_skip_flag_model, 3);
+  put2(s, 3, cb->ctx.cu_pred_mode_model, 2);
+  put2(s, 5, &cb->ctx.cu_merge_flag_ext_model, 1);
+  put2(s, 6, &cb->ctx.cu_merge_idx_ext_model, 1);
+  put2(s, 7, cb->ctx.inter_dir, 6);
+  put2(s, 13, cb->ctx.cu_ref_pic_model, 2);
+  put2(s, 15, cb->ctx.cu_mvd_model, 2);
+  put2(s, 17, &cb->ctx.mvp_idx_model, 1);
+}
+
 static void rec_begin(const char *name, int narr)
 {
   uint32_t magic = 0x52454631, nl = (uint32_t)strlen(name), na = (uint32_t)narr;
@@ -76,9 +97,12 @@ void __wrap_uvg_search_lcu(encoder_state_t *const state, const int x, const int 
                            lcu_coeff_t *coeff)
 {
   models_t before, after;
+  models_inter_t before2, after2;
   snapshot(&state->cabac, &before);
+  snapshot_inter(&state->cabac, &before2);
   __real_uvg_search_lcu(state, x, y, hor_buf, ver_buf, coeff);
   snapshot(&state->search_cabac, &after);
+  snapshot_inter(&state->search_cabac, &after2);
   const videoframe_t *frame = state->tile->frame;
   int32_t meta[8] = {(int32_t)state->frame->num, x, y, state->qp, frame->width, frame->height, state->frame->slicetype, state->frame->QP};
   double lam[6] = {state->lambda, state->lambda_sqrt, state->c_lambda, state->chroma_weights[1], state->chroma_weights[2], state->chroma_weights[3]};
@@ -126,7 +150,7 @@ void __wrap_uvg_search_lcu(encoder_state_t *const state, const int x, const int 
   refs[17] = state->frame->ref_LX_size[0]; refs[18] = state->frame->ref_LX_size[1];
   for (int l = 0; l < 2; ++l) for (int i = 0; i < 16; ++i) refs[19 + 16 * l + i] = state->frame->ref_LX[l][i];
   refs[51] = state->frame->poc;
-  rec_begin("search", 13);
+  rec_begin("search", 15);
   rec_arr(A_I32, meta, 8); rec_arr(A_F64, lam, 6);
   rec_arr(A_U8, &before, sizeof before); rec_arr(A_U8, &after, sizeof after);
   rec_arr(A_U8, cu, sizeof cu); rec_arr(A_U32, trees, 512);
@@ -139,6 +163,7 @@ void __wrap_uvg_search_lcu(encoder_state_t *const state, const int x, const int 
   }
   rec_arr(A_I32, inter, 256 * 8);
   rec_arr(A_I32, refs, 52);
+  rec_arr(A_U8, &before2, sizeof before2); rec_arr(A_U8, &after2, sizeof after2);
 }
 
 /* payload bytes the arithmetic coder hands to the bitstream (uvg_bitstream_put_byte, called from uvg_cabac_write): counted
@@ -201,16 +226,37 @@ void __wrap_uvg_encode_coding_tree(encoder_state_t *const state, lcu_coeff_t *co
   coder[2] = 8 * g_cabac_bytes + 8 * (int64_t)state->cabac.num_buffered_bytes + 23 - state->cabac.bits_left;
   coder[3] = state->cabac.range;
   snapshot(&state->cabac, &after);
+  models_inter_t after2;
+  snapshot_inter(&state->cabac, &after2);
   int32_t meta[3] = {(int32_t)state->frame->num, cu_loc->x, cu_loc->y};
   uint16_t m_sao[6];
   m_sao[0] = state->cabac.ctx.sao_merge_flag_model.state[0]; m_sao[1] = state->cabac.ctx.sao_merge_flag_model.state[1]; m_sao[2] = state->cabac.ctx.sao_merge_flag_model.rate;
   m_sao[3] = state->cabac.ctx.sao_type_idx_model.state[0]; m_sao[4] = state->cabac.ctx.sao_type_idx_model.state[1]; m_sao[5] = state->cabac.ctx.sao_type_idx_model.rate;
-  rec_begin("coded", 7);
+  rec_begin("coded", 8);
   rec_arr(A_I32, meta, 3); rec_arr(A_U8, &before, sizeof before); rec_arr(A_U8, &after, sizeof after);
   rec_arr(A_U16, m_sao, 6);        /* the two SAO models after this CTU's SAO syntax (encode_sao precedes the coding tree) */
   rec_arr(A_I64, coder, 4);
   rec_arr(A_I64, full, 10);
   rec_arr(A_U8, g_tree_bytes, (size_t)n_bytes);
+  rec_arr(A_U8, &after2, sizeof after2);
+}
+
+/* uvg_search_cu_inter (src/search_inter.c:2329): every call with what it decided -- the costs it returned and the CU's entry of the
+ * lcu_t afterwards (CTU_DUMP_CU_INTER=1).  The sequence of calls is the trace of search_cu's walk over a P / B picture. */
+#include "search_inter.h"
+static int g_cu_inter = 0;
+void __real_uvg_search_cu_inter(encoder_state_t *const state, const cu_loc_t *const cu_loc, lcu_t *lcu, double *inter_cost, double *inter_bitcost);
+void __wrap_uvg_search_cu_inter(encoder_state_t *const state, const cu_loc_t *const cu_loc, lcu_t *lcu, double *inter_cost, double *inter_bitcost)
+{
+  __real_uvg_search_cu_inter(state, cu_loc, lcu, inter_cost, inter_bitcost);
+  if (!g_cu_inter) return;
+  const cu_info_t *c = LCU_GET_CU_AT_PX(lcu, SUB_SCU(cu_loc->x), SUB_SCU(cu_loc->y));
+  int32_t v[20] = {(int32_t)state->frame->num, cu_loc->x, cu_loc->y, cu_loc->width, cu_loc->height, c->type, c->skipped, c->merged, c->merge_idx,
+                   c->inter.mv_dir, c->inter.mv[0][0], c->inter.mv[0][1], c->inter.mv[1][0], c->inter.mv[1][1], c->inter.mv_ref[0], c->inter.mv_ref[1],
+                   c->inter.mv_cand0, c->inter.mv_cand1, (int32_t)c->cbf, c->root_cbf};
+  double d[2] = {*inter_cost, *inter_bitcost};
+  rec_begin("cuinter", 2);
+  rec_arr(A_I32, v, 20); rec_arr(A_F64, d, 2);
 }
 
 /* uvg_sao_search_lcu (src/sao.c:670, called at src/encoderstate.c:849 right after the CTU's own uvg_filter_deblock_lcu): the CTU's
@@ -396,6 +442,7 @@ uint8_t __wrap_uvg_inter_get_merge_cand(const encoder_state_t *const state, cons
 int main(int argc, char **argv)
 {
   if (getenv("CTU_DUMP_MERGE_EVERY")) g_merge_every = atoi(getenv("CTU_DUMP_MERGE_EVERY"));
+  if (getenv("CTU_DUMP_CU_INTER")) g_cu_inter = atoi(getenv("CTU_DUMP_CU_INTER"));
   if (argc < 7) { fprintf(stderr, "usage: %s in.yuv W H frames out.bin out.266 [opt val]...\n", argv[0]); return 2; }
   const int W = atoi(argv[2]), H = atoi(argv[3]), nframes = atoi(argv[4]);
   FILE *in = fopen(argv[1], "rb");

@@ -103,6 +103,14 @@ __global__ void __launch_bounds__(256, 4) ctu_search_kernel(launch_args A)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Profiling knob (tools/dev/pmc_icache.sh): UVGHIP_CTU_LDS_PAD=<bytes> pads the dynamic LDS of the search kernel so that fewer
+// workgroups fit a CU (occupancy experiments: 1 / 2 / 4 workgroups per CU).  Unset = 0; results never depend on it.
+size_t lds_pad()
+{
+  static const size_t pad = [] { const char *e = getenv("UVGHIP_CTU_LDS_PAD"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 && v < 120 * 1024 ? v : 0); }();
+  return pad;
+}
+
 // Scratch slots: a workgroup claims one while it runs.  2048 = 256 CUs x 8 is more than the device can hold of this kernel
 // (3 per CU); small jobs take one slot per CTU, rounded up to whole bitmap words.
 enum { MAX_SLOTS = 2048 };
@@ -189,7 +197,7 @@ extern "C" int uvghip_ctu_plan_create(int bitdepth, const uvghip_ctu_params_t *p
   pl->A.n_slots = L.n_slots;
   pl->A.wc = wc; pl->A.hc = hc; pl->A.n_ctus = total;
   pl->bitdepth = bitdepth; pl->total = total; pl->counters = L.order; pl->ws = ws;
-  const size_t lds = bitdepth == 8 ? sizeof(ctu::lds<uint8_t>) : sizeof(ctu::lds<uint16_t>);
+  const size_t lds = (bitdepth == 8 ? sizeof(ctu::lds<uint8_t>) : sizeof(ctu::lds<uint16_t>)) + lds_pad();
   const hipError_t e = bitdepth == 8
       ? hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
       : hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -204,8 +212,8 @@ extern "C" int uvghip_ctu_plan_run(uvghip_ctu_plan_t *pl, void *stream)
   if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);
   hipStream_t st = uvghip_stream(stream);
   UVGHIP_TRY(hipMemsetAsync(pl->ws, 0, pl->counters, st));
-  if (pl->bitdepth == 8) hipLaunchKernelGGL(ctu_search_kernel<uint8_t>, dim3(pl->total), dim3(256), sizeof(ctu::lds<uint8_t>), st, pl->A);
-  else hipLaunchKernelGGL(ctu_search_kernel<uint16_t>, dim3(pl->total), dim3(256), sizeof(ctu::lds<uint16_t>), st, pl->A);
+  if (pl->bitdepth == 8) hipLaunchKernelGGL(ctu_search_kernel<uint8_t>, dim3(pl->total), dim3(256), sizeof(ctu::lds<uint8_t>) + lds_pad(), st, pl->A);
+  else hipLaunchKernelGGL(ctu_search_kernel<uint16_t>, dim3(pl->total), dim3(256), sizeof(ctu::lds<uint16_t>) + lds_pad(), st, pl->A);
   UVGHIP_CHECK_LAUNCH();
 }
 
