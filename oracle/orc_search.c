@@ -22,6 +22,8 @@
 #include "orc_common.h"
 #include "orc_ctx_init.h"
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 /* ---- other oracle files ---- */
 #define REF_LEN 400
@@ -90,7 +92,7 @@ typedef struct orc_inter_frame {
   int32_t l_size[2];              /* state->frame->ref_LX_size */
   int32_t l[2][16];               /* state->frame->ref_LX: indices into the reference array */
   int32_t tmvp, max_merge, merge_level, bipred, fme_level, early_skip, depth_inter_min, depth_inter_max;
-  int32_t ref_cu_stride, reserved;
+  int32_t ref_cu_stride, frame_qp;    /* frame_qp: state->frame->QP, what the slice's context models are initialised with */
   const orc_px *ref_y[16], *ref_u[16], *ref_v[16];      /* the reference pictures after the in-loop filters, pic_w x pic_h, tightly packed */
   const int32_t *ref_cu[16];      /* per reference picture and 4x4 (stride ref_cu_stride): type, mv[2][2], mv_dir, the POC the L0 / L1 vector points to */
 } orc_inter_frame;
@@ -535,7 +537,8 @@ static double cost_of(const orc_px *pred, const orc_px *orig, int n)   /* get_co
 }
 
 /* search_intra_rough (search_intra.c:986-1229) for mode_list_size = 3; returns the best mode */
-static int search_intra_rough(const s_state *st, const s_loc *loc, const s_lcu *lcu, const orc_px *top, const orc_px *left, const int8_t *intra_preds)
+static int search_intra_rough(const s_state *st, const s_loc *loc, const s_lcu *lcu, const orc_px *top, const orc_px *left, const int8_t *intra_preds,
+                              double *best_cost_out)
 {
   const int n = loc->w;
   orc_px orig[32 * 32], pred[32 * 32];
@@ -602,6 +605,7 @@ static int search_intra_rough(const s_state *st, const s_loc *loc, const s_lcu *
     }
   }
 #undef EVAL
+  *best_cost_out = best[0].cost;
   return best[0].mode;
 }
 
@@ -728,6 +732,9 @@ static void quantize_lcu_residual(s_state *st, int luma, int chroma, const s_loc
   st->c_lambda = c_lambda;
 }
 
+#define MAX_DOUBLE 1.7976931348623157e308
+#include "orc_search_inter.inc"
+
 /* ------------------------------------------------------------------------------------------------------------- RD costs -- */
 /* uvg_cu_rd_cost_chroma (search.c:625-722) */
 static double cu_rd_cost_chroma(s_state *st, const s_cu *pred_cu, s_lcu *lcu, const s_loc *loc)
@@ -802,6 +809,32 @@ static double mock_encode_coding_unit(s_state *st, s_cabac *cb, const s_loc *loc
     int is_implicit;
     s_tree t = tree;                                    /* the CU itself is not split at this depth: the flag's value is NO_SPLIT */
     write_split_flag(st, cb, left_cu, above_cu, loc, t, &is_implicit, &bits);
+  }
+  const int non_i = st->fr && st->fr->slice_type != 2;
+  if (non_i && (loc->w != 4 || loc->h != 4)) {           /* skip flag (:1788-1823) */
+    int ctx_skip = 0;
+    if (left_cu && left_cu->skipped) ctx_skip++;
+    if (above_cu && above_cu->skipped) ctx_skip++;
+    fbits_update(cb, M_SKIP + ctx_skip, cur_cu->skipped, &bits);
+    if (cur_cu->skipped) {
+      const int num_cand = st->fr->max_merge;
+      if (num_cand > 1)
+        for (int ui = 0; ui < num_cand - 1; ui++) {
+          const int symbol = ui != cur_cu->merge_idx;
+          if (ui == 0) fbits_update(cb, M_MERGE_IDX, symbol, &bits);
+          else { ORC_FN(cabac_sim_ep)((uint32_t)symbol); bits += 1; }
+          if (symbol == 0) break;
+        }
+      return bits;
+    }
+  }
+  if (non_i && (loc->w != 4 || loc->h != 4)) {           /* prediction mode (:1824-1834) */
+    const int ctx_predmode = (left_cu && left_cu->type == CU_INTRA) || (above_cu && above_cu->type == CU_INTRA);
+    fbits_update(cb, M_PRED_MODE + ctx_predmode, cur_cu->type == CU_INTRA, &bits);
+  }
+  if (cur_cu->type == CU_INTER) {
+    encode_inter_prediction_unit(st, cb, cur_cu, lcu, &bits, loc);       /* (amvr off: no imv flag) */
+    return bits;
   }
   const s_cu *left_pu, *above_pu;
   mpm_neighbours(loc, lcu, &left_pu, &above_pu);
@@ -981,7 +1014,6 @@ static void mark_deblocking(const s_loc *loc, const s_loc *chroma_loc, s_lcu *lc
 }
 
 /* ------------------------------------------------------------------------------------------------------------- search_cu -- */
-#define MAX_DOUBLE 1.7976931348623157e308
 
 static double search_cu(s_state *st, const s_loc *loc, const s_loc *chroma_loc, s_lcu *lcu, s_tree tree, int has_chroma)
 {
@@ -990,8 +1022,12 @@ static double search_cu(s_state *st, const s_loc *loc, const s_loc *chroma_loc, 
   const int x = loc->x, y = loc->y, cu_width = loc->w, cu_height = loc->h;
   const int is_separate_tree = chroma_loc == NULL || loc->h != chroma_loc->h || loc->w != chroma_loc->w;
   double cost = MAX_DOUBLE;
+  double inter_bitcost = 2147483647;
   s_cabac pre_search_cabac = st->search;
   const int x_local = x % LCU, y_local = y % LCU;
+  const int non_i = st->fr && st->fr->slice_type != 2;
+  int32_t hmvp_lut[41];                    /* the row's history table at this CU's start (search.c:1330-1337) */
+  if (non_i) memcpy(hmvp_lut, st->hmvp, sizeof hmvp_lut);
   if (x >= p->pic_w || y >= p->pic_h) return 0;
 
   s_cu *cur_cu = CU_AT(lcu, x_local, y_local);
@@ -1009,12 +1045,29 @@ static double search_cu(s_state *st, const s_loc *loc, const s_loc *chroma_loc, 
   memset(&pred_cu, 0, sizeof pred_cu);
   const int completely_inside = x + cu_width <= p->pic_w && y + cu_height <= p->pic_h;
   if (completely_inside) {
+    /* check_can_use_inter (search.c:1212-1255) */
+    int can_use_inter = non_i;
+    if (can_use_inter) {
+      const int dmin = st->fr->depth_inter_min, dmax = st->fr->depth_inter_max, min_wi = LCU >> dmax;
+      if (depth > 6 || !((depth >= dmin && depth <= dmax) || (x & ~(min_wi - 1)) + min_wi > p->pic_w || (y & ~(min_wi - 1)) + min_wi > p->pic_h)) can_use_inter = 0;
+      if (cu_width == 4 && cu_height == 4) can_use_inter = 0;
+      if (loc->ch * loc->cw < 16) can_use_inter = 0;
+      if (mode_type_parent == MODE_TYPE_INTRA) can_use_inter = 0;
+    }
+    if (can_use_inter) {
+      double mode_cost, mode_bitcost;
+      search_cu_inter(st, loc, lcu, &mode_cost, &mode_bitcost);
+      if (mode_cost < cost) { cost = mode_cost; inter_bitcost = mode_bitcost; cur_cu->type = CU_INTER; }
+    }
+    /* rd = 0: no intra search when the inter cost per sample is below INTRA_THRESHOLD = 8, or after an early skip */
+    const int skip_intra = (cur_cu->type != CU_NOTSET && cost / (cu_width * cu_width) < 8) || (st->fr && st->fr->early_skip && cur_cu->skipped);
     /* check_can_use_intra (search.c:1257-1287) */
     const int min_w = LCU >> p->depth_max;
     int can_use_intra = 1;
     if (!((depth >= p->depth_min && depth <= p->depth_max) || (x & ~(min_w - 1)) + min_w > p->pic_w || (y & ~(min_w - 1)) + min_w > p->pic_h)) can_use_intra = 0;
     if (mode_type_parent == MODE_TYPE_INTER) can_use_intra = 0;
-    if (can_use_intra) {
+    if (can_use_intra && !skip_intra) {
+      double intra_cost0 = 0;
       pred_cu = *cur_cu;
       /* uvg_search_cu_intra (search_intra.c:1771-1988) */
       {
@@ -1027,12 +1080,14 @@ static double search_cu(s_state *st, const s_loc *loc, const s_loc *chroma_loc, 
         orc_px top[REF_LEN], left[REF_LEN];
         build_reference(st, loc, 0, lcu, top, left);
         pred_cu.type = CU_INTRA;
-        const int best = search_intra_rough(st, loc, lcu, top, left, cand);
+        double rough_cost = 0;
+        const int best = search_intra_rough(st, loc, lcu, top, left, cand, &rough_cost);
         pred_cu.mode = (int8_t)best;
         pred_cu.mode_chroma = (int8_t)best;
+        intra_cost0 = rough_cost;
       }
-      double intra_cost = 0;      /* the rough cost; only compared with MAX_DOUBLE in an I slice */
-      {
+      double intra_cost = intra_cost0;      /* intra_search.cost: the rough cost of the best mode */
+      if (intra_cost < cost) {
         int intra_mode = pred_cu.mode;
         if (has_chroma) {
           if (is_separate_tree) {
@@ -1051,6 +1106,8 @@ static double search_cu(s_state *st, const s_loc *loc, const s_loc *chroma_loc, 
         cost = intra_cost;
         *cur_cu = pred_cu;
         cur_cu->type = CU_INTRA;
+        cur_cu->skipped = 0;
+        cur_cu->merged = 0;
       }
     }
     if (cur_cu->type == CU_INTRA) {
@@ -1066,10 +1123,31 @@ static double search_cu(s_state *st, const s_loc *loc, const s_loc *chroma_loc, 
         lcu_fill_chroma_cbfs(lcu, chroma_loc);
       }
       lcu_fill_cu_info(lcu, x_local, y_local, cu_width, cu_height, cur_cu);
+    } else if (cur_cu->type == CU_INTER) {
+      if (!cur_cu->skipped) {
+        if (!cur_cu->merged) {          /* uvg_round_precision(INTERNAL_MV_PREC, 2): to quarter samples and back */
+          for (int l = 0; l < 2; ++l)
+            if (cur_cu->mv_dir & (1 << l)) { cur_cu->mv[l][0] = (int32_t)((uint32_t)to_quarter(cur_cu->mv[l][0]) << 2); cur_cu->mv[l][1] = (int32_t)((uint32_t)to_quarter(cur_cu->mv[l][1]) << 2); }
+        }
+        inter_pred_pu(st, lcu, 1, 1, loc);
+        quantize_lcu_residual(st, 1, 1, loc, NULL, lcu, 0);
+        const int cbf = (cur_cu->cbf & 7) != 0 || cur_cu->root_cbf;
+        if (cur_cu->merged && !cbf) {
+          cur_cu->merged = 0;
+          cur_cu->skipped = 1;
+          const int skip_ctx = get_skip_context(x, y, lcu, NULL);
+          inter_bitcost = ctx_fbits(&st->search.m, M_SKIP + skip_ctx, 1);
+          inter_bitcost += ctx_fbits(&st->search.m, M_MERGE_IDX, cur_cu->merge_idx != 0);
+          inter_bitcost += cur_cu->merge_idx;
+        }
+      }
+      lcu_fill_cu_info(lcu, x_local, y_local, cu_width, cu_height, cur_cu);
+      lcu_fill_cbf(lcu, x_local, y_local, cu_width, cu_height);
     }
   }
+  (void)inter_bitcost;
 
-  if (cur_cu->type == CU_INTRA) {
+  if (cur_cu->type == CU_INTRA || cur_cu->type == CU_INTER) {
     double bits = 0;
     s_cabac *cb = &st->search;
     cb->update = 1;
@@ -1096,6 +1174,8 @@ static double search_cu(s_state *st, const s_loc *loc, const s_loc *chroma_loc, 
     double best_split_cost = MAX_DOUBLE;
     s_cabac post_search_cabac = st->search, best_split_cabac = st->search;
     int have_split = 0;
+    int32_t best_split_hmvp[41];
+    if (non_i) memcpy(best_split_hmvp, st->hmvp, sizeof best_split_hmvp);
     if (can_split[QT_SPLIT]) {
       double split_cost = 0.0, split_bits = 0;
       const int cond = derive_mode_type_cond(loc, mode_type_parent);
@@ -1125,6 +1205,8 @@ static double search_cu(s_state *st, const s_loc *loc, const s_loc *chroma_loc, 
         loc_ctor(&nl[0], x, y, hw, hh); loc_ctor(&nl[1], x + hw, y, hw, hh); loc_ctor(&nl[2], x, y + hh, hw, hh); loc_ctor(&nl[3], x + hw, y + hh, hw, hh);
         int separate_chroma = hh == 4;
         separate_chroma |= !has_chroma;
+        separate_chroma &= mode_type != MODE_TYPE_INTER;
+        if (non_i) memcpy(st->hmvp, hmvp_lut, sizeof hmvp_lut);         /* (search.c:1972-1975) */
         initialize_partial_work_tree(st, lcu, split_lcu, loc, separate_chroma ? chroma_loc : loc);
         for (int split = 0; split < 4; ++split) {
           new_split.part_index = split;
@@ -1133,7 +1215,10 @@ static double search_cu(s_state *st, const s_loc *loc, const s_loc *chroma_loc, 
           if (split_cost > cost || split_cost > best_split_cost) break;
         }
         have_split = 1;
-        if (split_cost < best_split_cost) { best_split_cost = split_cost; best_split_cabac = st->search; }
+        if (split_cost < best_split_cost) {
+          best_split_cost = split_cost; best_split_cabac = st->search;
+          if (non_i) memcpy(best_split_hmvp, st->hmvp, sizeof best_split_hmvp);
+        }
       }
       (void)pruned;
     }
@@ -1175,10 +1260,14 @@ static double search_cu(s_state *st, const s_loc *loc, const s_loc *chroma_loc, 
       cost = best_split_cost;
       st->search = best_split_cabac;
       work_tree_copy_up(split_lcu, lcu, loc, is_separate_tree && !has_chroma ? NULL : chroma_loc);
+      if (non_i) memcpy(st->hmvp, best_split_hmvp, sizeof best_split_hmvp);
     } else if (depth > 0) {
       st->search = post_search_cabac;
+      if (non_i) { memcpy(st->hmvp, hmvp_lut, sizeof hmvp_lut); hmvp_add(st->hmvp, cur_cu); }
     }
     free(split_lcu);
+  } else if (cur_cu->log2_h + cur_cu->log2_w > 4) {
+    if (non_i) { memcpy(st->hmvp, hmvp_lut, sizeof hmvp_lut); hmvp_add(st->hmvp, cur_cu); }
   }
   return cost;
 }
@@ -1216,9 +1305,10 @@ static void encode_transform_coeff(const s_frame *f, s_cabac *cb, const s_loc *l
     fbits_update(cb, M_CBF_CB + 0, cb_flag_u, &g_tree_bits);
     fbits_update(cb, M_CBF_CR + (cb_flag_u ? 1 : 0), cb_flag_v, &g_tree_bits);
   }
-  if (!only_chroma) {
+  const int pu_is_tu = cur_tu->log2_w <= 5 && cur_tu->log2_h <= 5;
+  if ((cur_tu->type == CU_INTRA || !pu_is_tu || cb_flag_u || cb_flag_v) && !only_chroma) {
     fbits_update(cb, M_CBF_LUMA + *luma_cbf_ctx, cb_flag_y, &g_tree_bits);
-    if (cur_tu->log2_w <= 5 && cur_tu->log2_h <= 5) *luma_cbf_ctx = 2 + cb_flag_y;      /* PU_IS_TU */
+    if (pu_is_tu) *luma_cbf_ctx = 2 + cb_flag_y;
   }
   if (cb_flag_y | cb_flag_u | cb_flag_v) {
     /* encode_transform_unit (:530-626) */
@@ -1263,6 +1353,42 @@ static void encode_coding_tree(const s_frame *f, s_state *st, s_cabac *cb, const
       return;
     }
   }
+  const int non_i = st->fr && st->fr->slice_type != 2;
+  if (non_i) {                  /* skip flag, prediction mode, the inter prediction unit (encode_coding_tree.c:1470-1640) */
+    int ctx_skip = 0;
+    if (left_cu && left_cu->skipped) ctx_skip++;
+    if (above_cu && above_cu->skipped) ctx_skip++;
+    if ((loc->w != 4 || loc->h != 4) && mode_type_curr != MODE_TYPE_INTRA) fbits_update(cb, M_SKIP + ctx_skip, cur_cu->skipped, &g_tree_bits);
+    if (cur_cu->skipped) {
+      hmvp_add(st->hmvp, cur_cu);
+      const int num_cand = st->fr->max_merge;
+      if (num_cand > 1)
+        for (int ui = 0; ui < num_cand - 1; ui++) {
+          const int symbol = ui != cur_cu->merge_idx;
+          if (ui == 0) fbits_update(cb, M_MERGE_IDX, symbol, &g_tree_bits);
+          else { ORC_FN(cabac_sim_ep)((uint32_t)symbol); g_tree_bits += 1; }
+          if (symbol == 0) break;
+        }
+      return;
+    }
+    if ((loc->w != 4 || loc->h != 4) && mode_type_curr == MODE_TYPE_ALL) {
+      const int ctx_predmode = (left_cu && left_cu->type == CU_INTRA) || (above_cu && above_cu->type == CU_INTRA);
+      fbits_update(cb, M_PRED_MODE + ctx_predmode, cur_cu->type == CU_INTRA, &g_tree_bits);
+    }
+    if (cur_cu->type == CU_INTER) {
+      double pu_bits = 0;
+      encode_inter_prediction_unit(st, cb, cur_cu, NULL, &pu_bits, loc);
+      g_tree_bits += pu_bits;          /* (an estimate only: uvg_encode_mvd's assignment loses part of it; nothing reads it for P / B pictures) */
+      hmvp_add(st->hmvp, cur_cu);
+      const int has_coeffs = cur_cu->root_cbf || cur_cu->cbf;
+      if (!cur_cu->merged) fbits_update(cb, M_ROOT_CBF, has_coeffs, &g_tree_bits);
+      if (has_coeffs) {
+        int luma_cbf_ctx = 0;
+        encode_transform_coeff(f, cb, loc, 0, cy, cu, cv, &luma_cbf_ctx, loc);
+      }
+      return;
+    }
+  }
   /* an intra CU */
   {
     const s_cu *left_pu = NULL, *above_pu = NULL;
@@ -1282,6 +1408,46 @@ static void encode_coding_tree(const s_frame *f, s_state *st, s_cabac *cb, const
   }
 }
 
+/*
+ * A side effect of the deblocking filter on the picture's cu array that the inter path sees: where filter_deblock_edge_luma derives the
+ * boundary strength from motion (both sides inter, no coded luma residual at the edge, a B slice or a bi-predicted side) it first zeroes
+ * the vectors of the unused lists of BOTH cu_info_t entries, in place (src/filter.c:745-765).  The entries feed the coder's history
+ * table, the next CTUs' neighbour rows and -- through merge_candidate_in_list's comparison of all fields (search_inter.c:1639-1658) -- later
+ * decisions.  uvg_filter_deblock_lcu (filter.c:1372-1380) runs between a CTU's search and its coding tree; the units it visits are those
+ * of oracle/orc_deblock.c's deblock_lcu (the zeroing is idempotent and its condition does not depend on it, so the order inside the
+ * call does not matter).
+ */
+static void deblock_zeroes_at(s_frame *f, int bx, int by, int dir_hor, int is_b)
+{
+  if ((!dir_hor && bx == 0) || (dir_hor && by == 0)) return;
+  if (bx >= f->p->pic_w || by >= f->p->pic_h) return;
+  s_cu *q = &f->cua[(by >> 2) * f->cu_stride + (bx >> 2)];
+  if (!(q->luma_deblocking & (dir_hor ? EDGE_HOR : EDGE_VER))) return;
+  s_cu *p = dir_hor ? q - f->cu_stride : q - 1;
+  if (q->type == CU_INTRA || p->type == CU_INTRA) return;
+  if ((q->cbf & 1) || (p->cbf & 1)) return;              /* tu_boundary && nonzero_coeffs: strength 1 without looking at motion */
+  if (!(p->mv_dir == 3 || q->mv_dir == 3 || is_b)) return;
+  for (int l = 0; l < 2; ++l) {
+    if (!(q->mv_dir & (1 << l))) { q->mv[l][0] = 0; q->mv[l][1] = 0; }
+    if (!(p->mv_dir & (1 << l))) { p->mv[l][0] = 0; p->mv[l][1] = 0; }
+  }
+}
+static void deblock_zeroes_unused_vectors(s_frame *f, int x_px, int y_px, int is_b)
+{
+  const int W = f->p->pic_w, H = f->p->pic_h;
+  const int end_x = x_px + 64 < W ? x_px + 64 : W, end_y = y_px + 64 < H ? y_px + 64 : H;
+  for (int by = y_px; by < end_y; by += 4)
+    for (int bx = x_px; bx < end_x; bx += 4) deblock_zeroes_at(f, bx, by, 0, is_b);
+  if (x_px > 0)
+    for (int bx = x_px - 8; bx < x_px; bx += 4)
+      for (int by = y_px; by < end_y; by += 4) deblock_zeroes_at(f, bx, by, 1, is_b);
+  for (int by = y_px; by < end_y; by += 4)
+    for (int bx = x_px; bx < end_x; bx += 4) {
+      if ((bx & 63) >= 56 && bx < W - 8) continue;
+      deblock_zeroes_at(f, bx, by, 1, is_b);
+    }
+}
+
 /* ---------------------------------------------------------------------------------------------------------- the picture -- */
 /*
  * One all-intra picture, CTU by CTU in raster order (any order that respects the WPP dependencies gives the same result):
@@ -1291,11 +1457,13 @@ static void encode_coding_tree(const s_frame *f, s_state *st, s_cabac *cb, const
  *   coeff_out: per CTU 64*64 + 2*32*32 levels (lcu_coeff_t order: y, u, v; raster inside the CTU)
  *   models_out: per CTU three model sets: at the CTU's start, at the end of its search, after the real coder
  */
-ORC_EXPORT int ORC_FN(search_intra_picture)(const orc_search_params *p, const orc_px *src_y, const orc_px *src_u, const orc_px *src_v,
-                                            orc_px *rec_y, orc_px *rec_u, orc_px *rec_v, uint8_t *cu_out, int16_t *coeff_out, orc_models_ext *models_out)
+static int search_picture(const orc_search_params *p, const orc_inter_frame *fr, const orc_px *src_y, const orc_px *src_u, const orc_px *src_v,
+                          orc_px *rec_y, orc_px *rec_u, orc_px *rec_v, uint8_t *cu_out, int16_t *coeff_out, orc_models_ext *models_out,
+                          int32_t *motion_out, uint8_t *inter_extra_out, orc_models_inter *models_inter_out)
 {
   fbits_init();
   if (p->pic_w % 8 || p->pic_h % 8) return -1;
+  const int non_i = fr && fr->slice_type != 2;
   const int W = p->pic_w, H = p->pic_h, wc = (W + 63) / 64, hc = (H + 63) / 64;
   const int cu_stride = wc * 16;
   s_frame f = {p, (s_cu *)calloc((size_t)cu_stride * hc * 16, sizeof(s_cu)), cu_stride};
@@ -1304,16 +1472,35 @@ ORC_EXPORT int ORC_FN(search_intra_picture)(const orc_search_params *p, const or
   s_state *st = (s_state *)calloc(1, sizeof(s_state));
   st->p = p;
   st->c_lambda = p->c_lambda;
+  st->fr = fr;
+  st->src_y = src_y;
+  st->cua = f.cua; st->cu_stride = cu_stride;
+  int32_t hmvp[41];
+  int32_t *col = NULL;
+  if (non_i) {
+    /* the collocated picture (L0[0]) on the 8x8 grid, as uvg_inter_get_merge_cand / _mv_cand read it through get_temporal_merge_candidates */
+    const int gw = (W + 7) / 8, gh = (H + 7) / 8;
+    col = (int32_t *)calloc((size_t)gw * gh * 8, sizeof(int32_t));
+    if (fr->n_refs && fr->l_size[0] > 0) {
+      const int32_t *rc = fr->ref_cu[fr->l[0][0]];
+      for (int gy = 0; gy < gh; ++gy)
+        for (int gx = 0; gx < gw; ++gx) memcpy(col + ((size_t)gy * gw + gx) * 8, rc + ((size_t)(gy * 2) * fr->ref_cu_stride + gx * 2) * 8, 8 * sizeof(int32_t));
+    }
+    st->col = col;
+    st->hmvp = hmvp;
+  }
   orc_models coder;     /* state->cabac.ctx of the CTU row */
   for (int cyi = 0; cyi < hc; ++cyi) {
+    if (non_i) memset(hmvp, 0, sizeof hmvp);         /* the row's history table starts empty (encoderstate.c:1021-1028) */
     for (int cxi = 0; cxi < wc; ++cxi) {
       const int x = cxi * 64, y = cyi * 64;
       if (cxi == 0) {
-        if (cyi == 0 || !p->wpp) { if (cyi == 0) models_init(&coder, p->qp, 2); }
+        if (cyi == 0 || !p->wpp) { if (cyi == 0) models_init(&coder, fr ? fr->frame_qp : p->qp, fr ? fr->slice_type : 2); }
         else coder = row_start[cyi - 1];
       }
       orc_models_ext *mo = &models_out[(size_t)(cyi * wc + cxi) * 3];
-      models_to_ext(&coder, &mo[0], NULL);
+      orc_models_inter *mi = models_inter_out ? &models_inter_out[(size_t)(cyi * wc + cxi) * 3] : NULL;
+      models_to_ext(&coder, &mo[0], mi ? &mi[0] : NULL);
       /* uvg_search_lcu */
       st->search.m = coder;
       st->search.update = 0;
@@ -1343,8 +1530,11 @@ ORC_EXPORT int ORC_FN(search_intra_picture)(const orc_search_params *p, const or
       s_loc start;
       loc_ctor(&start, x, y, 64, 64);
       s_tree tree = {0, MODE_TYPE_ALL, 0, 0, 0, 0};
+      int32_t hmvp_before[41];
+      if (non_i) memcpy(hmvp_before, hmvp, sizeof hmvp);
       search_cu(st, &start, &start, lcu, tree, 1);
-      models_to_ext(&st->search.m, &mo[1], NULL);
+      if (non_i) memcpy(hmvp, hmvp_before, sizeof hmvp);         /* the search's additions are dropped (encoderstate.c:757-813); the coder's stay */
+      models_to_ext(&st->search.m, &mo[1], mi ? &mi[1] : NULL);
       /* copy_lcu_to_cu_data + coefficients */
       for (int j = 0; j < y_max; j += 4) for (int i = 0; i < x_max; i += 4) f.cua[((y + j) >> 2) * cu_stride + ((x + i) >> 2)] = *CU_AT(lcu, i, j);
       for (int j = 0; j < y_max; ++j) memcpy(&rec_y[(y + j) * W + x], &lcu->rec_y[j * LCU], (size_t)x_max * sizeof(orc_px));
@@ -1352,6 +1542,22 @@ ORC_EXPORT int ORC_FN(search_intra_picture)(const orc_search_params *p, const or
         memcpy(&rec_u[(y / 2 + j) * (W / 2) + x / 2], &lcu->rec_u[j * LCU_C], (size_t)(x_max / 2) * sizeof(orc_px));
         memcpy(&rec_v[(y / 2 + j) * (W / 2) + x / 2], &lcu->rec_v[j * LCU_C], (size_t)(x_max / 2) * sizeof(orc_px));
       }
+      if (motion_out || inter_extra_out)          /* as the records of tools/refcheck/ctu_dump.c: the cu array right after the CTU's search */
+        for (int j = 0; j < 64; j += 4)
+          for (int i = 0; i < 64; i += 4) {
+            const size_t at = (size_t)((y + j) >> 2) * cu_stride + ((x + i) >> 2);
+            const s_cu *c = &f.cua[at];
+            if (motion_out) {
+              int32_t *m = &motion_out[at * 8];
+              memset(m, 0, 8 * sizeof(int32_t));
+              if (c->type == CU_INTER && x + i < W && y + j < H) {
+                m[0] = c->mv[0][0]; m[1] = c->mv[0][1]; m[2] = c->mv[1][0]; m[3] = c->mv[1][1]; m[4] = c->mv_ref[0]; m[5] = c->mv_ref[1]; m[6] = c->mv_dir;
+                m[7] = c->skipped | c->merged << 1 | c->merge_idx << 2;
+              }
+            }
+            if (inter_extra_out) { uint8_t *e = &inter_extra_out[at * 4]; e[0] = c->root_cbf; e[1] = c->mv_cand0; e[2] = c->mv_cand1; e[3] = 0; }
+          }
+      if (non_i) deblock_zeroes_unused_vectors(&f, x, y, fr->slice_type == 0);
       int16_t *co = &coeff_out[(size_t)(cyi * wc + cxi) * (64 * 64 + 2 * 32 * 32)];
       memcpy(co, lcu->coeff_y, sizeof lcu->coeff_y); memcpy(co + 4096, lcu->coeff_u, sizeof lcu->coeff_u); memcpy(co + 4096 + 1024, lcu->coeff_v, sizeof lcu->coeff_v);
       /* encoder_state_worker_encode_lcu_bitstream: the real coder adapts the row's models */
@@ -1361,7 +1567,7 @@ ORC_EXPORT int ORC_FN(search_intra_picture)(const orc_search_params *p, const or
         encode_coding_tree(&f, st, &cb, co, co + 4096, co + 4096 + 1024, &start, &start, tree, 1);
         coder = cb.m;
       }
-      models_to_ext(&coder, &mo[2], NULL);
+      models_to_ext(&coder, &mo[2], mi ? &mi[2] : NULL);
       if (cxi == 0) row_start[cyi] = coder;
     }
   }
@@ -1374,9 +1580,34 @@ ORC_EXPORT int ORC_FN(search_intra_picture)(const orc_search_params *p, const or
       o[7] = (uint8_t)c->mode_chroma; o[8] = c->luma_deblocking; o[9] = c->chroma_deblocking; o[10] = c->qp; o[11] = 0;
       memcpy(o + 12, &c->split_tree, 4); memcpy(o + 16, &c->mode_type_tree, 4);
     }
-  free(f.cua); free(row_start); free(lcu); free(st);
+  free(f.cua); free(row_start); free(lcu); free(st); free(col);
   return 0;
 }
+
+ORC_EXPORT int ORC_FN(search_intra_picture)(const orc_search_params *p, const orc_px *src_y, const orc_px *src_u, const orc_px *src_v,
+                                            orc_px *rec_y, orc_px *rec_u, orc_px *rec_v, uint8_t *cu_out, int16_t *coeff_out, orc_models_ext *models_out)
+{
+  return search_picture(p, NULL, src_y, src_u, src_v, rec_y, rec_u, rec_v, cu_out, coeff_out, models_out, NULL, NULL, NULL);
+}
+
+/*
+ * One P / B picture of a low-delay encode (BASELINE configs[2]: --gop lp-g4d3t1 --preset medium), CTU by CTU: uvg_search_lcu with the
+ * inter search (orc_search_inter.inc) competing with the intra search, the real coder's model adaptation and history table in between.
+ * fr: the picture's reference lists and reference pictures (orc_inter_frame).  p->qp / lambda: the PICTURE's (the encoder's QP offsets per
+ * GOP layer and its lambda derivation stay with the caller).  Outputs as search_intra_picture, plus motion_out [per 4x4][8] (mv[2][2],
+ * mv_ref[2], mv_dir, skipped | merged << 1 | merge_idx << 2), inter_extra_out [per 4x4][4] (root_cbf, mv_cand0, mv_cand1, 0) and the
+ * 18 inter-syntax models beside each of the three model sets.
+ */
+ORC_EXPORT int ORC_FN(search_inter_picture)(const orc_search_params *p, const orc_inter_frame *fr, const orc_px *src_y, const orc_px *src_u,
+                                            const orc_px *src_v, orc_px *rec_y, orc_px *rec_u, orc_px *rec_v, uint8_t *cu_out, int16_t *coeff_out,
+                                            orc_models_ext *models_out, int32_t *motion_out, uint8_t *inter_extra_out, orc_models_inter *models_inter_out)
+{
+  return search_picture(p, fr, src_y, src_u, src_v, rec_y, rec_u, rec_v, cu_out, coeff_out, models_out, motion_out, inter_extra_out, models_inter_out);
+}
+
+/* a trace of search_cu_inter's calls for debugging against the "cuinter" records of tools/refcheck/ctu_dump.c: 22 doubles per call */
+ORC_EXPORT void ORC_FN(search_trace)(double *buf, int cap) { g_trace = buf; g_trace_cap = cap; g_trace_n = 0; }
+ORC_EXPORT int ORC_FN(search_trace_count)(void) { return g_trace_n; }
 
 
 /*

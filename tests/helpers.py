@@ -999,3 +999,184 @@ def moving_picture(W, H, t, depth):
         p[:, w // 2:] = window((100 - 7 * t) >> c, (40 + 2 * t) >> c)[:, w // 2:]
         out.append(p)
     return tuple(out)
+
+
+# ---- P / B pictures: the inter search of the oracle (oracle/orc_search.c + orc_search_inter.inc) ---------------------------------
+class InterFrame(ctypes.Structure):
+    """orc_inter_frame: the picture's reference lists and reference pictures, as the encoder's frame-level bookkeeping hands them over."""
+    _fields_ = [("slice_type", ctypes.c_int32), ("poc", ctypes.c_int32), ("n_refs", ctypes.c_int32), ("ref_pocs", ctypes.c_int32 * 16),
+                ("l_size", ctypes.c_int32 * 2), ("l", (ctypes.c_int32 * 16) * 2),
+                ("tmvp", ctypes.c_int32), ("max_merge", ctypes.c_int32), ("merge_level", ctypes.c_int32), ("bipred", ctypes.c_int32),
+                ("fme_level", ctypes.c_int32), ("early_skip", ctypes.c_int32), ("depth_inter_min", ctypes.c_int32), ("depth_inter_max", ctypes.c_int32),
+                ("ref_cu_stride", ctypes.c_int32), ("frame_qp", ctypes.c_int32),
+                ("ref_y", ctypes.c_void_p * 16), ("ref_u", ctypes.c_void_p * 16), ("ref_v", ctypes.c_void_p * 16), ("ref_cu", ctypes.c_void_p * 16)]
+
+
+MODELS_INTER_BYTES = 18 * 5
+
+
+def ref_cu_table(cu, motion, pocs_of_lists):
+    """The per-4x4 table of a reference picture the inter search reads: [type, mv[2][2], mv_dir, the POC the L0 / L1 vector points to].
+    cu [h4, w4, >= 1] (type in [..., 0]), motion [h4, w4, 8] (the 'inter' array of ctu_dump.c), pocs_of_lists: ([POC per L0 index], [.. L1])."""
+    h4, w4 = cu.shape[:2]
+    t = np.zeros((h4, w4, 8), np.int32)
+    t[:, :, 0] = cu[:, :, 0]
+    t[:, :, 1:5] = motion[:, :, 0:4]
+    t[:, :, 5] = motion[:, :, 6]
+    t[:, :, 6:8] = -1
+    inter = cu[:, :, 0] == 2
+    for l in (0, 1):
+        lut = np.asarray(list(pocs_of_lists[l]) + [-1] * 256, np.int32)
+        use = inter & ((motion[:, :, 6] & (1 << l)) != 0)
+        t[:, :, 6 + l] = np.where(use, lut[np.clip(motion[:, :, 4 + l], 0, 255)], -1)
+    return np.ascontiguousarray(t)
+
+
+def oracle_search_inter_picture(orc, depth, prm, fr, y, u, v, keep):
+    """orcN_search_inter_picture -> dict like oracle_search_picture + motion [h16, w16, 8], extra [h16, w16, 4], models_inter [ctus, 3, 90].
+    `keep`: the arrays fr's pointers refer to (held alive by the caller)."""
+    W, H = prm.pic_w, prm.pic_h
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    px = px_dtype(depth)
+    y, u, v = (np.ascontiguousarray(a, px) for a in (y, u, v))
+    ry, ru, rv = np.zeros((H, W), px), np.zeros((H // 2, W // 2), px), np.zeros((H // 2, W // 2), px)
+    cu = np.zeros((hc * 16, wc * 16, 20), np.uint8)
+    co = np.zeros((wc * hc, 6144), np.int16)
+    mo = np.zeros((wc * hc, 3, MODELS_BYTES), np.uint8)
+    mot = np.zeros((hc * 16, wc * 16, 8), np.int32)
+    ext = np.zeros((hc * 16, wc * 16, 4), np.uint8)
+    mi = np.zeros((wc * hc, 3, MODELS_INTER_BYTES), np.uint8)
+    rc = orc.fn(depth, "search_inter_picture")(ctypes.byref(prm), ctypes.byref(fr), ptr(y), ptr(u), ptr(v), ptr(ry), ptr(ru), ptr(rv), ptr(cu), ptr(co), ptr(mo),
+                                               ptr(mot), ptr(ext), ptr(mi))
+    assert rc == 0
+    trees = np.ascontiguousarray(cu[:, :, 12:]).view(np.uint32).reshape(hc * 16, wc * 16, 2)
+    return dict(rec_y=ry, rec_u=ru, rec_v=rv, cu=cu[:, :, :11].copy(), trees=trees, coeff=co, models=mo, motion=mot, extra=ext, models_inter=mi)
+
+
+def run_inter_oracle(orc, W, H, depth, pics, P):
+    """The oracle on every picture in coding order, references = the ENCODER's output pictures and side information (so one picture's
+    mismatch does not spread) -> yields (frame, record dict, oracle result, trace rows, n_trace)"""
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    by_poc = {}
+    for fr in sorted(P):
+        d = P[fr]
+        refs = d["refs"]
+        n_refs, pocs = int(refs[0]), [int(a) for a in refs[1:17]]
+        lsz = [int(refs[17]), int(refs[18])]
+        lists = [[int(a) for a in refs[19:35]], [int(a) for a in refs[35:51]]]
+        poc, slice_type = int(refs[51]), int(d["meta"][6])
+        lam = d["lam"]
+        prm = SearchParams(W, H, int(d["meta"][3]), int(d["meta"][3]), 1, 4, 1, 1, 2, 0, float(lam[0]), float(lam[1]), float(lam[2]), float(lam[3]), float(lam[4]))
+        F = InterFrame()
+        F.slice_type, F.poc, F.n_refs = slice_type, poc, n_refs
+        for i in range(16):
+            F.ref_pocs[i] = pocs[i]
+            F.l[0][i], F.l[1][i] = lists[0][i], lists[1][i]
+        F.l_size[0], F.l_size[1] = lsz
+        F.tmvp, F.max_merge, F.merge_level, F.bipred, F.fme_level, F.early_skip, F.depth_inter_min, F.depth_inter_max = 1, 6, 2, 1, 4, 1, 0, 3
+        F.ref_cu_stride, F.frame_qp = wc * 16, int(d["meta"][7])
+        keep = []
+        for i in range(n_refs):
+            rp = by_poc[pocs[i]]
+            planes = [np.ascontiguousarray(p) for p in rp["final"]]
+            keep += planes + [rp["ref_cu"]]
+            F.ref_y[i], F.ref_u[i], F.ref_v[i] = (p.ctypes.data for p in planes)
+            F.ref_cu[i] = rp["ref_cu"].ctypes.data
+        buf = np.zeros((wc * hc * 400, 22), np.float64)
+        orc.fn(depth, "search_trace", None)(ptr(buf), len(buf))
+        y, u, v = pics[fr]
+        r = oracle_search_inter_picture(orc, depth, prm, F, y, u, v, keep)
+        ntr = orc.fn(depth, "search_trace_count")()
+        orc.fn(depth, "search_trace", None)(None, 0)
+        # this picture as a reference of later ones
+        own_pocs = ([pocs[lists[0][i]] for i in range(lsz[0])], [pocs[lists[1][i]] for i in range(lsz[1])])
+        d["ref_cu"] = ref_cu_table(d["cu"], d["motion"], own_pocs)
+        by_poc[poc] = d
+        d["info"] = (poc, slice_type, pocs[:n_refs], lists[0][:lsz[0]], lists[1][:lsz[1]])
+        yield fr, d, r, buf, ntr
+
+
+
+def compare_inter_picture(W, H, d, r, buf, ntr):
+    """One picture of the oracle's inter search (r, trace rows buf[:ntr]) against the encoder's records d -> list of differences."""
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+# ---- compare
+    msgs = []
+    tr = d["cuinter"]
+    for i in range(min(ntr, len(tr))):
+        a, c = buf[i], tr[i]
+        want = np.concatenate([c[0][1:20].astype(np.float64), c[1]])
+        got = a[1:22]
+        ok = np.array_equal(got[:5], want[:5]) and got[19] == want[19]
+        if ok and want[4] == 2 and want[19] < 1e300:        # an inter decision: everything must agree
+            sel = [4, 5, 6, 7, 8, 13, 14, 15, 16, 19, 20] + [9 + 2 * l + j for l in (0, 1) if int(want[8]) & (1 << l) for j in (0, 1)]
+            ok = all(got[j] == want[j] for j in sel)
+        if not ok:
+            msgs.append(f"cuinter call {i}: got {got.tolist()} want {want.tolist()}")
+            break
+    if ntr != len(tr):
+        msgs.append(f"cuinter calls: {ntr} vs {len(tr)}")
+    h4, w4 = H // 4, W // 4
+    if not np.array_equal(r["cu"][:h4, :w4, :6], d["cu"][:h4, :w4, :6]):
+        j = np.argwhere((r["cu"][:h4, :w4, :6] != d["cu"][:h4, :w4, :6]).any(axis=2))[0]
+        msgs.append(f"cu differs first at 4x4 {j.tolist()}: got {r['cu'][j[0], j[1]].tolist()} want {d['cu'][j[0], j[1]].tolist()}")
+    intra = d["cu"][:h4, :w4, 0] == 1
+    if not np.array_equal(r["cu"][:h4, :w4, 6:8][intra], d["cu"][:h4, :w4, 6:8][intra]):
+        msgs.append("intra modes differ")
+    if not np.array_equal(r["cu"][:h4, :w4, 8:11], d["cu"][:h4, :w4, 8:11]):
+        msgs.append("edge flags / qp differ")
+    if not np.array_equal(r["trees"][:h4, :w4], d["trees"][:h4, :w4]):
+        msgs.append("trees differ")
+    if not np.array_equal(r["motion"][:h4, :w4], d["motion"][:h4, :w4] & np.array([-1, -1, -1, -1, -1, -1, -1, 0x1f], np.int32)):
+        j = np.argwhere((r["motion"][:h4, :w4] != (d["motion"][:h4, :w4] & np.array([-1, -1, -1, -1, -1, -1, -1, 0x1f], np.int32))).any(axis=2))[0]
+        msgs.append(f"motion differs first at 4x4 {j.tolist()}: got {r['motion'][j[0], j[1]].tolist()} want {d['motion'][j[0], j[1]].tolist()}")
+    for c, nme in enumerate(("rec_y", "rec_u", "rec_v")):
+        if not np.array_equal(r[nme], d["rec"][c]):
+            msgs.append(nme + " differs")
+    for k in range(wc * hc):             # the levels inside the picture (a partial CTU's lcu_coeff_t holds leftovers beyond it)
+        hh, ww = min(64, H - (k // wc) * 64), min(64, W - (k % wc) * 64)
+        for a, b in ((r["coeff"][k], d["coeff"][k]),):
+            if not (np.array_equal(a[:4096].reshape(64, 64)[:hh, :ww], b[:4096].reshape(64, 64)[:hh, :ww]) and
+                    np.array_equal(a[4096:].reshape(2, 32, 32)[:, :hh // 2, :ww // 2], b[4096:].reshape(2, 32, 32)[:, :hh // 2, :ww // 2])):
+                msgs.append(f"levels differ in CTU {k}")
+                break
+    for j, what in enumerate(("start", "after search", "after coder")):
+        a, b = r["models"][:, j, :1285], d["models"][:, j, :1285]
+        if not np.array_equal(a, b):
+            msgs.append(f"models {what}: first CTU {int(np.argwhere((a != b).any(axis=1))[0][0])}")
+        a, b = r["models_inter"][:, j], d["models_inter"][:, j]
+        if not np.array_equal(a, b):
+            k = int(np.argwhere((a != b).any(axis=1))[0][0])
+            msgs.append(f"inter models {what}: first CTU {k} entries {np.argwhere(a[k] != b[k]).ravel().tolist()[:8]}")
+    return msgs
+
+
+def inter_pictures_from_golden(g):
+    """A ref_inter_* golden (tools/refcheck/make_ctu_goldens.py::inter) as the per-picture records run_inter_oracle / compare_inter_picture
+    take, plus the source pictures -> (W, H, depth, [source (y, u, v) per frame], {frame: record dict})"""
+    W, H, depth, qp0, frames = (int(a) for a in g["dims"])
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    import zlib
+    pics = [moving_picture(W, H, t, depth) for t in range(frames)]
+    for t in range(frames):
+        assert zlib.crc32(b"".join(p.tobytes() for p in pics[t])) == int(g["src_crc"][t]), "the sequence generator drifted from the golden's source"
+    P = {}
+    for k in range(len(g["meta"])):
+        fr, x, y = (int(a) for a in g["meta"][k][:3])
+        d = P.setdefault(fr, dict(cu=np.zeros((hc * 16, wc * 16, 12), np.uint8), trees=np.zeros((hc * 16, wc * 16, 2), np.uint32),
+                                  motion=np.zeros((hc * 16, wc * 16, 8), np.int32), coeff=np.zeros((wc * hc, 6144), np.int16),
+                                  models=np.zeros((wc * hc, 3, MODELS_BYTES), np.uint8), models_inter=np.zeros((wc * hc, 3, MODELS_INTER_BYTES), np.uint8),
+                                  cuinter=[]))
+        d["meta"], d["lam"], d["refs"] = g["meta"][k], g["lam"][k], g["refs"][k]
+        kk = (y // 64) * wc + x // 64
+        d["cu"][y // 4:y // 4 + 16, x // 4:x // 4 + 16] = g["cu"][k].reshape(16, 16, 12)
+        d["trees"][y // 4:y // 4 + 16, x // 4:x // 4 + 16] = g["trees"][k].reshape(16, 16, 2)
+        d["motion"][y // 4:y // 4 + 16, x // 4:x // 4 + 16] = g["motion"][k].reshape(16, 16, 8)
+        d["coeff"][kk] = g["coeff"][k]
+        d["models"][kk], d["models_inter"][kk] = g["models"][k], g["models_inter"][k]
+    for fr, d in P.items():
+        d["rec"] = [g["rec_y"][fr], g["rec_u"][fr], g["rec_v"][fr]]
+        d["final"] = (g["final_y"][fr], g["final_u"][fr], g["final_v"][fr])
+    for a, b in zip(g["cuinter_i"], g["cuinter_d"]):
+        P[int(a[0])]["cuinter"].append((a, b))
+    return W, H, depth, pics, P

@@ -1,0 +1,38 @@
+"""The oracle's inter search (oracle/orc_search.c + orc_search_inter.inc: uvg_search_cu_inter with merge analysis, early skip, hexagon
+search, fractional search and bi-prediction competing with the intra search inside search_cu, the coder's model adaptation and history
+table between CTUs) against records of low-delay encodes of the real encoder (BASELINE configs[2]: --gop lp-g4d3t1 --preset medium;
+tests/golden/ref_inter_*.npz): every call of uvg_search_cu_inter with the motion it decided and both costs (doubles, bit for bit), and
+per CTU the side information, motion, split trees, levels, reconstruction before the in-loop filters and all three sets of context
+models (257 + the 18 of the inter syntax) of every picture.  tools/refcheck/sweep_inter.py repeats this on fresh encodes of the
+reference (sizes 64..320, both depths, QP 10..44, 2..10 pictures, four kinds of content)."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+
+@pytest.mark.parametrize("name", ["ref_inter_192x128_8_qp17_5frames", "ref_inter_136x72_10_qp22_4frames", "ref_inter_264x136_8_qp32_9frames"])
+def test_every_picture_of_a_low_delay_encode(name):
+    orc = H.load_oracle()
+    g = H.ctu_golden(name)
+    W, Hh, depth, pics, P = H.inter_pictures_from_golden(g)
+    seen = dict(pictures=0, calls=0, skip=0, merge=0, amvp=0, bi=0, intra_in_b=0)
+    for fr, d, r, buf, ntr in H.run_inter_oracle(orc, W, Hh, depth, pics, P):
+        msgs = H.compare_inter_picture(W, Hh, d, r, buf, ntr)
+        assert not msgs, (name, fr, msgs)
+        assert ntr == len(d["cuinter"])
+        seen["pictures"] += 1
+        seen["calls"] += ntr
+        m, c = d["motion"][:Hh // 4, :W // 4], d["cu"][:Hh // 4, :W // 4]
+        inter = c[:, :, 0] == 2
+        seen["skip"] += int(((m[:, :, 7] & 1) != 0)[inter].sum())
+        seen["merge"] += int(((m[:, :, 7] & 2) != 0)[inter].sum())
+        seen["amvp"] += int(((m[:, :, 7] & 3) == 0)[inter].sum())
+        seen["bi"] += int((m[:, :, 6] == 3)[inter].sum())
+        if int(d["meta"][6]) != 2:
+            seen["intra_in_b"] += int((c[:, :, 0] == 1).sum())
+    # what the golden exercises (counts of 4x4 units): every kind of decision in the two 8-bit encodes
+    print(name, seen)
+    assert seen["calls"] > 100 and seen["bi"] and seen["amvp"], seen
+    if depth == 8:
+        assert seen["merge"] and seen["skip"], seen

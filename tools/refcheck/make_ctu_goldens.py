@@ -205,10 +205,13 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
                 f.write(p.astype(px).tobytes())
     out = f"/tmp/gold_inter_{tag}"
     subprocess.check_call([os.path.join(ROOT, "tools/refcheck/ctu_dump.sh"), str(depth), yuv, str(W), str(H), str(frames), out,
-                           "preset", "medium", "gop", "lp-g4d3t1", "qp", str(qp)] + list(extra), stderr=subprocess.DEVNULL)
+                           "preset", "medium", "gop", "lp-g4d3t1", "qp", str(qp)] + list(extra), stderr=subprocess.DEVNULL,
+                          env=dict(os.environ, CTU_DUMP_CU_INTER="1"))
     recs = read_records(out + ".bin")
     S = [r for n, r in recs if n == "search"]
     F = sorted([r for n, r in recs if n == "final"], key=lambda r: int(r[0][0]))
+    CD = {(int(r[0][0]), int(r[0][1]), int(r[0][2])): r for nm, r in recs if nm == "coded"}
+    CI = [r for nm, r in recs if nm == "cuinter"]
     wc, hc = (W + 63) // 64, (H + 63) // 64
     n = frames * wc * hc
     meta = np.zeros((n, 8), np.int32)
@@ -220,10 +223,16 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
     refs = np.zeros((n, 52), np.int32)
     rec = [np.zeros((frames, H, W), px), np.zeros((frames, H // 2, W // 2), px), np.zeros((frames, H // 2, W // 2), px)]
     coeff = np.zeros((n, 6144), np.int16)
+    trees = np.zeros((n, 256, 2), np.uint32)
+    models = np.zeros((n, 3, 1286), np.uint8)            # at the CTU's start / after its search / after the coder (257 models: state0, state1, rate)
+    models_inter = np.zeros((n, 3, 90), np.uint8)        # the 18 models of the inter syntax beside them
     for k, s in enumerate(S):
         fr, x, y = int(s[0][0]), int(s[0][1]), int(s[0][2])
         hh, ww = min(64, H - y), min(64, W - x)
         meta[k], cu[k], mot[k], refs[k], lam[k] = s[0], s[4].reshape(256, 12), s[11].reshape(256, 8), s[12], s[1]
+        trees[k] = s[5].reshape(256, 2)
+        models[k, 0], models[k, 1], models[k, 2] = s[2], s[3], CD[(fr, x, y)][2]
+        models_inter[k, 0], models_inter[k, 1], models_inter[k, 2] = s[13], s[14], CD[(fr, x, y)][7]
         if (fr, x // 64, y // 64) in SA:
             sao[k, 0], sao[k, 1] = SA[(fr, x // 64, y // 64)][5], SA[(fr, x // 64, y // 64)][6]
         rec[0][fr, y:y + hh, x:x + ww] = s[6].reshape(64, 64)[:hh, :ww]
@@ -235,7 +244,10 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
     src_crc = np.array([zlib.crc32(b"".join(p.tobytes() for p in moving_picture(W, H, t, depth))) for t in range(frames)], np.uint32)
     np.savez_compressed(os.path.join(out_dir or os.path.join(ROOT, "tests/golden"), f"ref_inter_{tag}.npz"), dims=np.array([W, H, depth, qp, frames], np.int32), meta=meta, cu=cu, lam=lam, sao=sao, src_crc=src_crc,
                         motion=mot, refs=refs, rec_y=rec[0], rec_u=rec[1], rec_v=rec[2], coeff=coeff if with_levels else coeff[:0], final_y=final[0], final_u=final[1],
-                        final_v=final[2])
+                        final_v=final[2], trees=trees, models=models if with_levels else models[:0], models_inter=models_inter if with_levels else models_inter[:0],
+                        # every call of uvg_search_cu_inter in coding order: frame, x, y, w, h, then the decided cu_info_t fields; its two costs
+                        cuinter_i=np.stack([r[0] for r in CI]).astype(np.int32) if with_levels else np.zeros((0, 20), np.int32),
+                        cuinter_d=np.stack([r[1] for r in CI]) if with_levels else np.zeros((0, 2)))
     if not out_dir: print("wrote inter", tag, n, "CTU records")
     return tag
 
@@ -277,6 +289,7 @@ if __name__ == "__main__":
     stream(136, 72, 10, 32, tuple(range(18)))   # eighteen: the 4-bit POC wraps
     inter(192, 128, 8, 17, 5)
     inter(136, 72, 10, 22, 4)
+    inter(264, 136, 8, 32, 9)            # nine pictures: three reference pictures per list, a whole GOP of QP offsets
     merge(192, 128, 8, 17, 6, 3)
     merge(136, 72, 10, 27, 8, 2)
     inter(192, 128, 8, 32, 5, extra=("sao", "off"), suffix="_nosao", with_levels=False)        # final picture = the deblocked picture
