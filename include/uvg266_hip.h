@@ -936,6 +936,57 @@ UVGHIP_API int uvghip_write_picture_nals(int poc, int sao, const uint8_t *rows, 
  * Waits for the stream.  *len = bytes needed; an error if that exceeds cap. */
 UVGHIP_API int uvghip_loop_plan_picture_nals(uvghip_loop_plan_t *plan, int picture, int poc, uint8_t *out, size_t cap, size_t *len, void *stream);
 
+/* ------------------- (8) P / B pictures: candidate lists of the inter search ---------------------------------------------- */
+
+/* replaces: uvg_inter_get_merge_cand (src/inter.c:1989-2192) for n calls at once, one lane per call: the spatial candidates A0 / A1 /
+ * B0 / B1 / B2 with the coding-order and duplicate tests (get_spatial_merge_candidates :1368-1455, is_cand_coded :770-876), the
+ * temporal candidate from the collocated picture with POC scaling and the stored-vector round trip (:1031-1165, 1547-1601), the history
+ * table, the pairwise average, the zero vectors.  All arrays in DEVICE memory:
+ *   ctx  [n][64]       the call: [1..4] x, y, width, height of the CU; [5] POC; [6] slice type (0 = B, 1 = P); [7..8] picture size;
+ *                      [9] tmvp; [10] max merge candidates; [11] log2 parallel merge level; [12] wpp; [13] reference pictures in use,
+ *                      [14..29] their POCs; [30..31] list sizes, [32..39] / [40..47] ref_LX[0] / [1]; [49] the CU's split_tree;
+ *                      (uvghip_amvp_cand_batch: [50] the list, [51..52] the CU's mv_ref[0..1])
+ *   lcu  [n][290][8]   lcu_t.cu at the moment of the call (17 x 17 + 1 entries: type, mv[2][2], mv_ref[2], mv_dir); MODIFIED like the
+ *                      reference does (inter_clear_cu_unused on the neighbours it looks at, :749-758)
+ *   col  [n] x col_stride ints: the collocated picture ref_LX[0][0] on its 8x8 grid ((pic_w + 7) / 8 positions per row), 8 ints per
+ *                      position: type, mv[2][2], mv_dir, the POC the L0 / L1 vector points to (col_stride 0: one picture for all calls)
+ *   hmvp [n][41]       [0] entries in the CTU row's history table, then its five entries (most recent first) in the lcu layout
+ *   cands [n][6][7]    inter_merge_cand_t: dir, ref[2], mv[2][2];  counts [n]: the function's return value */
+UVGHIP_API int uvghip_merge_cand_batch(const int32_t *ctx, int32_t *lcu, const int32_t *col, long col_stride, const int32_t *hmvp, int n,
+                                       int32_t *cands, int32_t *counts, void *stream);
+/* replaces: uvg_inter_get_mv_cand (src/inter.c:1606-1737): the two AMVP predictors of list ctx[50] for the reference index being
+ * searched, rounded to quarter samples.  mv_cand [n][2][2]. */
+UVGHIP_API int uvghip_amvp_cand_batch(const int32_t *ctx, int32_t *lcu, const int32_t *col, long col_stride, const int32_t *hmvp, int n,
+                                      int32_t *mv_cand, void *stream);
+
+/* replaces: for n prediction units at once, what search_pu_inter_ref and search_frac do for one reference picture once the predictors
+ * are known (src/search_inter.c:1404-1500, 1029-1226): select_starting_point (:297-375), early_terminate (:491-539), hexagon_search
+ * (:767-847), then the four fractional steps on SATD (:1133-1216), every point priced as SAD / SATD + bits * lambda_sqrt with the bits
+ * of get_mvd_coding_cost against the cheaper of the two AMVP predictors (:378-488).  --preset medium: me = hexbs, subme = 4,
+ * me-early-termination = on, mv-rdo = 0, no mv constraint.  One wave per unit; all units of a call have the same size. */
+typedef struct uvghip_me_job_t {
+  int32_t x, y;                /* the unit's position in the picture (luma samples) */
+  int32_t ref;                 /* index into refs_dev */
+  int32_t mv_cand[2][2];       /* uvg_inter_get_mv_cand's two predictors, 1/16 sample units */
+  int32_t extra_mv[2];         /* the reference picture's own vector at the unit's centre, scaled (search_inter.c:1346-1402); (0, 0): none */
+  int32_t n_start;             /* the uni-predicted merge candidates' vectors, in list order (dir != 3), 1/16 units */
+  int32_t start[6][2];
+} uvghip_me_job_t;
+typedef struct uvghip_me_result_t {
+  int32_t mv[2];               /* the vector after the fractional search (the integer vector if fme_level == 0), 1/16 units */
+  int32_t int_mv[2];           /* after the integer search */
+  double cost, bits;           /* search_frac's best_cost / best_bits (or the integer search's) */
+  double int_cost, int_bits;
+  int32_t mv_cand;             /* select_mv_cand for mv: which predictor codes it cheaper */
+  int32_t skipped_hexagon;     /* early_terminate said stop */
+} uvghip_me_result_t;
+/* cur: the source luma plane; refs_dev: DEVICE array of pointers to the reference pictures' luma planes (pic_w x pic_h samples, stride
+ * ref_stride; blocks reaching outside are edge-replicated as uvg_image_calc_sad / uvg_get_extended_block do); size: 8, 16, 32 or 64;
+ * fme_level: 0 or 4; jobs / results: DEVICE arrays. */
+UVGHIP_API int uvghip_me_search_batch(int bitdepth, const void *cur, int cur_stride, const void *const *refs_dev, int ref_stride, int pic_w,
+                                      int pic_h, double lambda_sqrt, int fme_level, int size, const uvghip_me_job_t *jobs, int n,
+                                      uvghip_me_result_t *results, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

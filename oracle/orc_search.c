@@ -1823,3 +1823,44 @@ fail:
   free(f.cua); free(st); free(row_m); free(row_s);
   return -1;
 }
+
+/*
+ * The motion search of one reference picture for one prediction unit, as a function of its inputs: what search_pu_inter_ref does between
+ * uvg_inter_get_mv_cand and the unit_stats_map entries (select_starting_point, early_terminate, hexagon_search; src/search_inter.c:1404-1446)
+ * followed by search_frac and select_mv_cand as search_pu_inter applies them to the best unit of a list (:1908-1960).
+ * job (24 ints): x, y, size, ref, mv_cand[2][2], extra_mv[2], n_start, start[6][2], (pad);  refs: the reference luma planes (pic_w x pic_h, tight).
+ * out_i: mv[2], int_mv[2], mv_cand, skipped_hexagon;  out_d: cost, bits, int_cost, int_bits.
+ */
+ORC_EXPORT void ORC_FN(me_search_job)(int pic_w, int pic_h, double lambda_sqrt, int fme_level, const orc_px *src_y, const orc_px *const *refs, int n_refs,
+                                      const int32_t *job, int32_t *out_i, double *out_d)
+{
+  orc_search_params p;
+  memset(&p, 0, sizeof p);
+  p.pic_w = pic_w; p.pic_h = pic_h; p.lambda_sqrt = lambda_sqrt;
+  orc_inter_frame fr;
+  memset(&fr, 0, sizeof fr);
+  fr.fme_level = fme_level;
+  fr.n_refs = n_refs;
+  for (int i = 0; i < n_refs && i < 16; ++i) fr.ref_y[i] = refs[i];
+  s_state st;
+  memset(&st, 0, sizeof st);
+  st.p = &p; st.fr = &fr; st.src_y = src_y;
+  s_info info;
+  memset(&info, 0, sizeof info);
+  info.st = &st;
+  info.origin.x = job[0]; info.origin.y = job[1]; info.width = info.height = job[2];
+  info.ref_idx = job[3];
+  info.mv_cand[0][0] = job[4]; info.mv_cand[0][1] = job[5]; info.mv_cand[1][0] = job[6]; info.mv_cand[1][1] = job[7];
+  info.num_merge_cand = job[10];
+  for (int i = 0; i < job[10]; ++i) { info.merge_cand[i].dir = 1; info.merge_cand[i].mv[0][0] = job[11 + 2 * i]; info.merge_cand[i].mv[0][1] = job[12 + 2 * i]; }
+  s_vec best_mv = {job[8], job[9]};
+  double best_cost = MAX_DOUBLE, best_bits = 2147483647;
+  select_starting_point(&info, best_mv, &best_cost, &best_bits, &best_mv);
+  const int skip_me = early_terminate(&info, &best_cost, &best_bits, &best_mv);
+  if (!skip_me) hexagon_search(&info, 0xffffffffu, &best_cost, &best_bits, &best_mv);
+  out_i[2] = best_mv.x; out_i[3] = best_mv.y; out_d[2] = best_cost; out_d[3] = best_bits;
+  if (fme_level > 0) search_frac(&info, &best_cost, &best_bits, &best_mv);
+  out_i[0] = best_mv.x; out_i[1] = best_mv.y; out_d[0] = best_cost; out_d[1] = best_bits;
+  out_i[4] = select_mv_cand(info.mv_cand, best_mv.x, best_mv.y, NULL);
+  out_i[5] = skip_me;
+}

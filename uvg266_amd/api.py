@@ -724,3 +724,47 @@ def picture_checksum(y, u, v, stream=None):
     _lib.check(L.uvghip_picture_checksum(depth, _dev(y), y.stride(0), _dev(u), _dev(v), u.stride(0), y.shape[1], y.shape[0], _dev(sums),
                                          _stream() if stream is None else stream), "uvghip_picture_checksum")
     return sums[:3]
+
+
+# ---- P / B pictures: candidate lists ----------------------------------------------------------------------------------------
+def merge_cand_batch(ctx, lcu, col, hmvp, stream=None):
+    """uvghip_merge_cand_batch: ctx [n, 64], lcu [n, 290, 8] (modified in place like the reference's lcu_t), col [n, L] (or [L]: one
+    collocated picture for all calls), hmvp [n, 41], int32 device tensors -> (cands [n, 6, 7], counts [n])."""
+    n = ctx.shape[0]
+    cands = torch.zeros((n, 6, 7), dtype=torch.int32, device=ctx.device)
+    counts = torch.zeros((n,), dtype=torch.int32, device=ctx.device)
+    L = _lib.init(ctx.device.index or 0)
+    _lib.check(L.uvghip_merge_cand_batch(_dev(ctx), _dev(lcu), _dev(col), col.shape[1] if col.dim() == 2 else 0, _dev(hmvp), n, _dev(cands), _dev(counts),
+                                         _stream() if stream is None else stream), "uvghip_merge_cand_batch")
+    return cands, counts
+
+
+def amvp_cand_batch(ctx, lcu, col, hmvp, stream=None):
+    """uvghip_amvp_cand_batch -> mv_cand [n, 2, 2] int32."""
+    n = ctx.shape[0]
+    out = torch.zeros((n, 2, 2), dtype=torch.int32, device=ctx.device)
+    L = _lib.init(ctx.device.index or 0)
+    _lib.check(L.uvghip_amvp_cand_batch(_dev(ctx), _dev(lcu), _dev(col), col.shape[1] if col.dim() == 2 else 0, _dev(hmvp), n, _dev(out),
+                                        _stream() if stream is None else stream), "uvghip_amvp_cand_batch")
+    return out
+
+
+ME_JOB_NP = np.dtype([("x", "<i4"), ("y", "<i4"), ("ref", "<i4"), ("mv_cand", "<i4", (2, 2)), ("extra_mv", "<i4", (2,)), ("n_start", "<i4"), ("start", "<i4", (6, 2))])
+ME_RESULT_NP = np.dtype([("mv", "<i4", (2,)), ("int_mv", "<i4", (2,)), ("cost", "<f8"), ("bits", "<f8"), ("int_cost", "<f8"), ("int_bits", "<f8"), ("mv_cand", "<i4"),
+                         ("skipped_hexagon", "<i4")])
+
+
+def ref_table(planes):
+    """A device array of pointers to the reference pictures' luma planes (what uvghip_me_search_batch takes as refs_dev)."""
+    return torch.tensor([p.data_ptr() for p in planes], dtype=torch.int64, device=planes[0].device)
+
+
+def me_search_batch(cur, refs, ref_tab, jobs, size, lambda_sqrt, fme_level=4, stream=None):
+    """uvghip_me_search_batch: cur [H, W] device plane, refs: list of [H, W] planes (kept alive by the caller), ref_tab = ref_table(refs),
+    jobs: uint8 device tensor over n ME_JOB_NP records -> uint8 device tensor over n ME_RESULT_NP records."""
+    n = jobs.numel() // ME_JOB_NP.itemsize
+    out = torch.zeros(n * ME_RESULT_NP.itemsize, dtype=torch.uint8, device=cur.device)
+    L = _lib.init(cur.device.index or 0)
+    _lib.check(L.uvghip_me_search_batch(_depth(cur), _dev(cur), cur.stride(0), _dev(ref_tab), refs[0].stride(0), cur.shape[1], cur.shape[0], float(lambda_sqrt),
+                                        fme_level, size, _dev(jobs), n, _dev(out), _stream() if stream is None else stream), "uvghip_me_search_batch")
+    return out

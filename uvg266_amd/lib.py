@@ -72,6 +72,18 @@ class CtuPicture(ctypes.Structure):
                 ("reserved", ctypes.c_int32), ("coeff", ctypes.c_void_p), ("models", ctypes.c_void_p)]
 
 
+class MeJob(ctypes.Structure):
+    """uvghip_me_job_t."""
+    _fields_ = [("x", ctypes.c_int32), ("y", ctypes.c_int32), ("ref", ctypes.c_int32), ("mv_cand", (ctypes.c_int32 * 2) * 2), ("extra_mv", ctypes.c_int32 * 2),
+                ("n_start", ctypes.c_int32), ("start", (ctypes.c_int32 * 2) * 6)]
+
+
+class MeResult(ctypes.Structure):
+    """uvghip_me_result_t."""
+    _fields_ = [("mv", ctypes.c_int32 * 2), ("int_mv", ctypes.c_int32 * 2), ("cost", ctypes.c_double), ("bits", ctypes.c_double), ("int_cost", ctypes.c_double),
+                ("int_bits", ctypes.c_double), ("mv_cand", ctypes.c_int32), ("skipped_hexagon", ctypes.c_int32)]
+
+
 class LoopPicture(ctypes.Structure):
     """uvghip_loop_picture_t."""
     _fields_ = [("search", CtuPicture), ("out_y", ctypes.c_void_p), ("out_u", ctypes.c_void_p), ("out_v", ctypes.c_void_p),
@@ -169,6 +181,9 @@ SIGNATURES = {
     "uvghip_loop_plan_picture_nals": (c_int, [c_vp, c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_vp]),
     "uvghip_picture_checksum": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "uvghip_write_picture_nals": (c_int, [c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_int, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "uvghip_merge_cand_batch": (c_int, [c_vp, c_vp, c_vp, ctypes.c_long, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "uvghip_amvp_cand_batch": (c_int, [c_vp, c_vp, c_vp, ctypes.c_long, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_me_search_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, ctypes.c_double, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_loop_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
     "uvghip_loop_plan_create": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "uvghip_loop_plan_run": (c_int, [c_vp, c_vp]),
