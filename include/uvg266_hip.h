@@ -987,6 +987,20 @@ UVGHIP_API int uvghip_me_search_batch(int bitdepth, const void *cur, int cur_str
                                       int pic_h, double lambda_sqrt, int fme_level, int size, const uvghip_me_job_t *jobs, int n,
                                       uvghip_me_result_t *results, void *stream);
 
+/* replaces: uvg_inter_pred_pu (luma) + uvg_satd_any_size as the inter search uses them per candidate motion (src/search_inter.c:
+ * 1758-1775 merge analysis, :2018-2031 the bi-prediction of the two best uni-predictions) and, with `pred` given, the luma of
+ * uvg_inter_recon_cu (src/inter.c:400-748: integer copy or 8-tap interpolation per list with border replication, 14-bit intermediates and
+ * uvg_bipred_average for two lists).  One wave per candidate; all candidates of a call have the same square size (8 .. 64). */
+typedef struct uvghip_motion_t {
+  int32_t x, y;                /* the unit's position in the picture */
+  int32_t dir;                 /* 1: list 0, 2: list 1, 3: both */
+  int32_t ref[2];              /* per list: index into refs_dev (the PICTURE, i.e. ref_LX[l][mv_ref[l]]) */
+  int32_t mv[2][2];            /* 1/16 sample units */
+} uvghip_motion_t;
+/* satd[n]: uvg_satd_any_size(prediction, source) >> (bitdepth - 8);  pred (optional): n blocks of size x size samples */
+UVGHIP_API int uvghip_inter_pred_satd_batch(int bitdepth, const void *cur, int cur_stride, const void *const *refs_dev, int ref_stride, int pic_w,
+                                            int pic_h, int size, const uvghip_motion_t *cands, int n, uint32_t *satd, void *pred, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1864,3 +1864,38 @@ ORC_EXPORT void ORC_FN(me_search_job)(int pic_w, int pic_h, double lambda_sqrt, 
   out_i[4] = select_mv_cand(info.mv_cand, best_mv.x, best_mv.y, NULL);
   out_i[5] = skip_me;
 }
+
+/*
+ * The luma prediction of one motion and its SATD against the source: uvg_inter_pred_pu (predict_luma only) + uvg_satd_any_size as the merge
+ * analysis and the bi-prediction test use them (src/search_inter.c:1758-1775, 2018-2031).  motion (9 ints): x, y, dir, ref[2] (picture
+ * indices), mv[2][2];  pred_out: size x size samples (may be NULL).
+ */
+ORC_EXPORT unsigned ORC_FN(inter_pred_satd)(int pic_w, int pic_h, const orc_px *src_y, const orc_px *const *refs, int n_refs, const int32_t *motion, int size,
+                                            orc_px *pred_out)
+{
+  orc_search_params p;
+  memset(&p, 0, sizeof p);
+  p.pic_w = pic_w; p.pic_h = pic_h;
+  orc_inter_frame fr;
+  memset(&fr, 0, sizeof fr);
+  fr.n_refs = n_refs;
+  for (int i = 0; i < n_refs && i < 16; ++i) fr.ref_y[i] = refs[i];
+  s_state st;
+  memset(&st, 0, sizeof st);
+  st.p = &p; st.fr = &fr; st.src_y = src_y;
+  s_loc loc;
+  loc_ctor(&loc, motion[0], motion[1], size, size);
+  static __thread orc_px pred[64 * 64];
+  static __thread int16_t b0[64 * 64], b1[64 * 64];
+  const int dir = motion[2];
+  int32_t mv[2][2] = {{motion[5], motion[6]}, {motion[7], motion[8]}};
+  if (dir == 3) {
+    const unsigned f0 = recon_unipred(&st, motion[3], mv[0], &loc, 1, 1, 0, b0, NULL, NULL);
+    const unsigned f1 = recon_unipred(&st, motion[4], mv[1], &loc, 1, 1, 0, b1, NULL, NULL);
+    ORC_FN(bipred_average)(pred, size, b0, b1, (int)((f0 & 1) | ((f1 & 1) << 1)), size, size);
+  } else {
+    recon_unipred(&st, motion[3 + dir - 1], mv[dir - 1], &loc, 0, 1, 0, pred, NULL, NULL);
+  }
+  if (pred_out) memcpy(pred_out, pred, (size_t)size * size * sizeof(orc_px));
+  return ORC_FN(satd_any_size)(size, size, src_y + (size_t)motion[1] * pic_w + motion[0], pic_w, pred, size);
+}

@@ -768,3 +768,17 @@ def me_search_batch(cur, refs, ref_tab, jobs, size, lambda_sqrt, fme_level=4, st
     _lib.check(L.uvghip_me_search_batch(_depth(cur), _dev(cur), cur.stride(0), _dev(ref_tab), refs[0].stride(0), cur.shape[1], cur.shape[0], float(lambda_sqrt),
                                         fme_level, size, _dev(jobs), n, _dev(out), _stream() if stream is None else stream), "uvghip_me_search_batch")
     return out
+
+
+MOTION_NP = np.dtype([("x", "<i4"), ("y", "<i4"), ("dir", "<i4"), ("ref", "<i4", (2,)), ("mv", "<i4", (2, 2))])
+
+
+def inter_pred_satd_batch(cur, refs, ref_tab, cands, size, want_pred=False, stream=None):
+    """uvghip_inter_pred_satd_batch: cands = uint8 device tensor over n MOTION_NP records -> (satd [n] int32, pred [n, size, size] or None)."""
+    n = cands.numel() // MOTION_NP.itemsize
+    satd = torch.zeros(n, dtype=torch.int32, device=cur.device)
+    pred = torch.zeros((n, size, size), dtype=cur.dtype, device=cur.device) if want_pred else None
+    L = _lib.init(cur.device.index or 0)
+    _lib.check(L.uvghip_inter_pred_satd_batch(_depth(cur), _dev(cur), cur.stride(0), _dev(ref_tab), refs[0].stride(0), cur.shape[1], cur.shape[0], size, _dev(cands), n,
+                                              _dev(satd), None if pred is None else _dev(pred), _stream() if stream is None else stream), "uvghip_inter_pred_satd_batch")
+    return satd, pred

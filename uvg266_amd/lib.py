@@ -183,6 +183,7 @@ SIGNATURES = {
     "uvghip_write_picture_nals": (c_int, [c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_int, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "uvghip_merge_cand_batch": (c_int, [c_vp, c_vp, c_vp, ctypes.c_long, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvghip_amvp_cand_batch": (c_int, [c_vp, c_vp, c_vp, ctypes.c_long, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_inter_pred_satd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvghip_me_search_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, ctypes.c_double, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_loop_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
     "uvghip_loop_plan_create": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
