@@ -486,6 +486,79 @@ def parity_check(group, golden):
                      "every WPP row's slice data (length + CRC) -- picture 0 of group 0 after the timed region vs the reference encoder's record"}
 
 
+def inter_hot_path(device, reps=5):
+    """BASELINE.json configs[2] (1920x1080 8-bit, --gop lp-g4d3t1 --preset medium): the inter search's hot path on the device, OPEN LOOP --
+    for every prediction unit of every size (64, 32, 16, 8: 510 + 2040 + 8100 + 32400 units) and each of two reference pictures the whole
+    motion search of search_pu_inter_ref + search_frac (uvghip_me_search_batch: starting point, early termination, hexagon search on SAD,
+    four fractional steps on SATD), then the bi-prediction of the two results against the source (uvghip_inter_pred_satd_batch: two
+    interpolations, average, SATD).  Open loop: the references are source pictures, the AMVP predictors zero, no merge candidates -- the
+    closed loop (search_cu's inter / intra competition on reconstructed references) is the oracle's so far.  Not part of `value`."""
+    W, H, depth = 1920, 1080, 8
+    cur = torch.from_numpy(np.ascontiguousarray(layout.synthetic_yuv420(W, H, 4, depth)[0])).to(device)
+    refs = [torch.from_numpy(np.ascontiguousarray(layout.synthetic_yuv420(W, H, t, depth)[0])).to(device) for t in (3, 2)]
+    tab = api.ref_table(refs)
+    lam_sqrt = float(np.sqrt(0.57 * 2.0 ** ((QP + 5 - 12) / 3.0)))
+    jobs, bi, n_units = {}, {}, 0
+    for size in (64, 32, 16, 8):
+        xs, ys = np.arange(0, W - size + 1, size), np.arange(0, H - size + 1, size)
+        gx, gy = np.meshgrid(xs, ys)
+        n = gx.size
+        j = np.zeros(2 * n, api.ME_JOB_NP)
+        j["x"], j["y"] = np.tile(gx.ravel(), 2), np.tile(gy.ravel(), 2)
+        j["ref"] = np.repeat([0, 1], n)
+        jobs[size] = torch.from_numpy(j.view(np.uint8)).to(device)
+        m = np.zeros(n, api.MOTION_NP)
+        m["x"], m["y"], m["dir"], m["ref"] = gx.ravel(), gy.ravel(), 3, [0, 1]
+        bi[size] = m
+        n_units += n
+    st = torch.cuda.current_stream()
+
+    def one(timed=None):
+        res = {}
+        for size in (64, 32, 16, 8):
+            if timed is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            res[size] = api.me_search_batch(cur, refs, tab, jobs[size], size, lam_sqrt, 4)
+            if timed is not None:
+                e1.record()
+                timed.setdefault(size, []).append((e0, e1))
+        return res
+    res = one()
+    torch.cuda.synchronize()
+    # the bi-prediction candidates from the first pass's vectors (fixed for the timed passes)
+    cands = {}
+    for size in (64, 32, 16, 8):
+        r = res[size].cpu().numpy().view(api.ME_RESULT_NP)
+        n = len(r) // 2
+        m = bi[size]
+        m["mv"][:, 0], m["mv"][:, 1] = r["mv"][:n], r["mv"][n:]
+        cands[size] = torch.from_numpy(m.view(np.uint8)).to(device)
+    frac = float(np.mean([((res[s].cpu().numpy().view(api.ME_RESULT_NP)["mv"] & 15) != 0).any(axis=1).mean() for s in (64, 32, 16, 8)]))
+    ev = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one(ev)
+        for size in (64, 32, 16, 8):
+            api.inter_pred_satd_batch(cur, refs, tab, cands[size], size)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    per_size = {str(s): round(sum(a.elapsed_time(b) for a, b in ev[s]) / len(ev[s]), 3) for s in ev}
+    b = 1
+    alg = 2 * 2 * W * H * b                                  # SURVEY 8(d): ME of one size against R references reads (1 + 1) W H b per reference ideally
+    me_ms = sum(per_size.values())
+    return {"value": round(1.0 / dt, 2), "unit": "pictures/s (open loop)", "ms_per_picture": round(1e3 * dt, 3), "prediction_units": n_units, "references": 2,
+            "me_search_ms_by_size": per_size, "units_per_s": round(2 * n_units / (me_ms * 1e-3)),
+            "roofline": {"bound": "hbm", "kernel": "me_search_kernel", "achieved": round(4 * alg / (me_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(4 * alg / (me_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                         "note": "algorithmic bytes: (source + reference) once per size and reference = 4 sizes x 2 references x 2 W H; the search is a chain of "
+                                 "dependent steps per unit (one wave each), latency-bound on the small units"},
+            "fractional_vectors": round(frac, 3),
+            "workload": "1920x1080 8-bit, configs[2] geometry: motion search (hexagon + 4 fractional steps) of every 8..64 unit against 2 reference pictures + "
+                        "bi-prediction SATD of the two results; open loop (source pictures as references, zero predictors)"}
+
+
 def closed_loop(wl, steps, warmup, in_flight, device, rank, world, dist, groups=2):
     """`steps` timed launches of `in_flight` pictures each (a step = one group of pictures through search -> deblock -> SAO) after
     `warmup` untimed ones; `groups` launches are in flight at a time on their own streams, so the thin start of one launch's
@@ -699,6 +772,9 @@ def main():
                  "mpixels_per_s": round(ek * eF * world / eel * ewl["W"] * ewl["H"] / 1e6, 1),
                  "search_launch_ms": round(ems / max(1, eln), 2),
                  "workload": "3840x2160 10-bit yuv420p, QP 22: the same closed loop (search -> deblock -> SAO; ALF of configs[3] is in the open-loop chain only)"}
+    c3 = None
+    if not args.no_extra and wl_name == "1080p8" and rank == 0:
+        c3 = inter_hot_path(device)
     open_loop = None
     if not args.no_open_loop and world == 1:
         ol_steps = (max(args.group, args.open_loop_steps) + args.group - 1) // args.group * args.group
@@ -753,6 +829,8 @@ def main():
             }
             if extra is not None:
                 out["extra_workloads"] = {"2160p10_closed_loop": extra}
+            if c3 is not None:
+                out.setdefault("extra_workloads", {})["c3_inter_hot_path_open_loop"] = c3
             if open_loop is not None:
                 out["open_loop"] = open_loop
             if row_sharded is not None:

@@ -969,7 +969,8 @@ typedef struct uvghip_me_job_t {
   int32_t ref;                 /* index into refs_dev */
   int32_t mv_cand[2][2];       /* uvg_inter_get_mv_cand's two predictors, 1/16 sample units */
   int32_t extra_mv[2];         /* the reference picture's own vector at the unit's centre, scaled (search_inter.c:1346-1402); (0, 0): none */
-  int32_t n_start;             /* the uni-predicted merge candidates' vectors, in list order (dir != 3), 1/16 units */
+  int32_t n_start;             /* the uni-predicted merge candidates' vectors, in list order (dir != 3), 1/16 units;
+                                  -1: no integer search -- search_frac alone around the integer vector extra_mv (a multiple of 16) */
   int32_t start[6][2];
 } uvghip_me_job_t;
 typedef struct uvghip_me_result_t {

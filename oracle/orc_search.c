@@ -1608,6 +1608,9 @@ ORC_EXPORT int ORC_FN(search_inter_picture)(const orc_search_params *p, const or
 /* a trace of search_cu_inter's calls for debugging against the "cuinter" records of tools/refcheck/ctu_dump.c: 22 doubles per call */
 ORC_EXPORT void ORC_FN(search_trace)(double *buf, int cap) { g_trace = buf; g_trace_cap = cap; g_trace_n = 0; }
 ORC_EXPORT int ORC_FN(search_trace_count)(void) { return g_trace_n; }
+/* per-call inputs of search_pu_inter (see orc_search_inter.inc: CTXT_I ints, CTXT_D doubles per call) */
+ORC_EXPORT void ORC_FN(search_ctx_trace)(int32_t *ints, double *doubles, int cap) { g_ctxt_i = ints; g_ctxt_d = doubles; g_ctxt_cap = cap; g_ctxt_n = 0; }
+ORC_EXPORT int ORC_FN(search_ctx_trace_count)(void) { return g_ctxt_n; }
 
 
 /*
@@ -1851,13 +1854,16 @@ ORC_EXPORT void ORC_FN(me_search_job)(int pic_w, int pic_h, double lambda_sqrt, 
   info.origin.x = job[0]; info.origin.y = job[1]; info.width = info.height = job[2];
   info.ref_idx = job[3];
   info.mv_cand[0][0] = job[4]; info.mv_cand[0][1] = job[5]; info.mv_cand[1][0] = job[6]; info.mv_cand[1][1] = job[7];
-  info.num_merge_cand = job[10];
+  info.num_merge_cand = job[10] < 0 ? 0 : job[10];
   for (int i = 0; i < job[10]; ++i) { info.merge_cand[i].dir = 1; info.merge_cand[i].mv[0][0] = job[11 + 2 * i]; info.merge_cand[i].mv[0][1] = job[12 + 2 * i]; }
   s_vec best_mv = {job[8], job[9]};
   double best_cost = MAX_DOUBLE, best_bits = 2147483647;
-  select_starting_point(&info, best_mv, &best_cost, &best_bits, &best_mv);
-  const int skip_me = early_terminate(&info, &best_cost, &best_bits, &best_mv);
-  if (!skip_me) hexagon_search(&info, 0xffffffffu, &best_cost, &best_bits, &best_mv);
+  int skip_me = 0;
+  if (job[10] >= 0) {
+    select_starting_point(&info, best_mv, &best_cost, &best_bits, &best_mv);
+    skip_me = early_terminate(&info, &best_cost, &best_bits, &best_mv);
+    if (!skip_me) hexagon_search(&info, 0xffffffffu, &best_cost, &best_bits, &best_mv);
+  } else { best_cost = 0; best_bits = 0; }            /* search_frac alone around best_mv = extra_mv */
   out_i[2] = best_mv.x; out_i[3] = best_mv.y; out_d[2] = best_cost; out_d[3] = best_bits;
   if (fme_level > 0) search_frac(&info, &best_cost, &best_bits, &best_mv);
   out_i[0] = best_mv.x; out_i[1] = best_mv.y; out_d[0] = best_cost; out_d[1] = best_bits;

@@ -1053,9 +1053,10 @@ def oracle_search_inter_picture(orc, depth, prm, fr, y, u, v, keep):
     return dict(rec_y=ry, rec_u=ru, rec_v=rv, cu=cu[:, :, :11].copy(), trees=trees, coeff=co, models=mo, motion=mot, extra=ext, models_inter=mi)
 
 
-def run_inter_oracle(orc, W, H, depth, pics, P):
+def run_inter_oracle(orc, W, H, depth, pics, P, ctx_trace=False):
     """The oracle on every picture in coding order, references = the ENCODER's output pictures and side information (so one picture's
-    mismatch does not spread) -> yields (frame, record dict, oracle result, trace rows, n_trace)"""
+    mismatch does not spread) -> yields (frame, record dict, oracle result, trace rows, n_trace).  ctx_trace: d["ctx_trace"] = (ints, doubles)
+    of every search_pu_inter call (orcN_search_ctx_trace), d["frame"] = the picture's reference lists, planes and tables."""
     wc, hc = (W + 63) // 64, (H + 63) // 64
     by_poc = {}
     for fr in sorted(P):
@@ -1084,10 +1085,19 @@ def run_inter_oracle(orc, W, H, depth, pics, P):
             F.ref_cu[i] = rp["ref_cu"].ctypes.data
         buf = np.zeros((wc * hc * 400, 22), np.float64)
         orc.fn(depth, "search_trace", None)(ptr(buf), len(buf))
+        if ctx_trace:
+            ci, cd = np.zeros((wc * hc * 100, 64 + 290 * 8 + 41 + 7), np.int32), np.zeros((wc * hc * 100, 8), np.float64)
+            orc.fn(depth, "search_ctx_trace", None)(ptr(ci), ptr(cd), len(ci))
         y, u, v = pics[fr]
         r = oracle_search_inter_picture(orc, depth, prm, F, y, u, v, keep)
         ntr = orc.fn(depth, "search_trace_count")()
         orc.fn(depth, "search_trace", None)(None, 0)
+        if ctx_trace:
+            nct = orc.fn(depth, "search_ctx_trace_count")()
+            orc.fn(depth, "search_ctx_trace", None)(None, None, 0)
+            d["ctx_trace"] = (ci[:nct], cd[:nct])
+            d["frame"] = dict(poc=poc, slice_type=slice_type, n_refs=n_refs, pocs=pocs, l_size=lsz, lists=lists,
+                              ref_planes=[by_poc[pocs[i]]["final"] for i in range(n_refs)], ref_cu=[by_poc[pocs[i]]["ref_cu"] for i in range(n_refs)])
         # this picture as a reference of later ones
         own_pocs = ([pocs[lists[0][i]] for i in range(lsz[0])], [pocs[lists[1][i]] for i in range(lsz[1])])
         d["ref_cu"] = ref_cu_table(d["cu"], d["motion"], own_pocs)

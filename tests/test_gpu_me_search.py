@@ -28,6 +28,9 @@ def make_jobs(rng, W, Hh, size, n, n_refs):
         j["start"] = rng.integers(-span, span + 1, (6, 2))
         if j["n_start"] and rng.random() < 0.3:
             j["start"][0] = (j["extra_mv"] >> 4) << 4                # the extra vector is one of the merge vectors: it is not tried twice
+        if rng.random() < 0.15:                                      # search_frac alone around a given integer vector
+            j["n_start"] = -1
+            j["extra_mv"] = (j["extra_mv"] >> 4) << 4
     return jobs
 
 

@@ -152,8 +152,11 @@ me_search_kernel(me_args A)
   best_t B;
   B.cost = 1.7976931348623157e308; B.bits = 2147483647.0; B.mx = 0; B.my = 0;
 
+  bool skip_me = false;
+  const bool frac_only = J.n_start < 0;          // only search_frac, around the integer vector extra_mv (a multiple of 16)
+  if (frac_only) { B.mx = J.extra_mv[0]; B.my = J.extra_mv[1]; B.cost = 0; B.bits = 0; }
   // ---- select_starting_point: the zero vector, the reference picture's own vector unless a merge candidate has it, the merge vectors ----
-  {
+  if (!frac_only) {
     int K = 0;
     const int ex = J.extra_mv[0] >> 4, ey = J.extra_mv[1] >> 4;
     bool in_merge = false;
@@ -174,8 +177,7 @@ me_search_kernel(me_args A)
     take_points(C, K, sPx, sPy, B);
   }
   // ---- early_terminate: two rounds of the small diamond ----
-  bool skip_me = false;
-  {
+  if (!frac_only) {
     const int dxs[7] = {0, -1, 0, 1, 0, -1, 0}, dys[7] = {-1, 0, 1, 0, -1, 0, 0};
     int mx = B.mx >> 4, my = B.my >> 4, first = 0, lastp = 3;
     for (int k = 0; k < 2; ++k) {
@@ -197,7 +199,7 @@ me_search_kernel(me_args A)
     }
   }
   // ---- hexagon_search ----
-  if (!skip_me) {
+  if (!skip_me && !frac_only) {
     const int hx[9] = {0, 1, 2, 1, -1, -2, -1, 1, 2}, hy[9] = {0, -2, 0, 2, 2, 0, -2, -2, 0};
     int mx = B.mx >> 4, my = B.my >> 4, best_index = 0;
     if (lane < 6) { sPx[lane] = mx + hx[1 + lane]; sPy[lane] = my + hy[1 + lane]; }
