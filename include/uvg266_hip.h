@@ -910,6 +910,31 @@ UVGHIP_API int uvghip_encode_slice_rows(int bitdepth, const uvghip_ctu_params_t 
                                         int n_pictures, const int32_t *sao_info, const uint16_t *sao_models, void *workspace,
                                         uint8_t *out, int row_cap, int32_t *row_bytes, void *stream);
 
+/* P / B pictures.  Beside uvghip_scu_t (type, sizes, cbf, mv_dir, mv[2][2] in 1/16 units; an intra CU keeps its modes in mv[0][0] as an
+ * all-intra picture does) a second table holds what only the coder reads of an inter CU (cu_info_t: skipped, merged, merge_idx, root_cbf,
+ * inter.mv_cand0 / 1, inter.mv_ref[2]); same indexing as the scu table. */
+typedef struct uvghip_inter4_t { uint8_t skipped, merged, merge_idx, root_cbf, mv_cand0, mv_cand1, mv_ref0, mv_ref1; } uvghip_inter4_t;
+/* the picture's slice-level state (encoder_state_t::frame: slicetype, poc, ref, ref_LX, ref_LX_size; cfg: tmvp_enable, max_merge,
+ * log2_parallel_merge_level) and its side tables */
+typedef struct uvghip_slice_pb_t {
+  int32_t slice_type;              /* 0 B, 1 P (2 = I: the plain entry point does that) */
+  int32_t poc, n_refs, ref_pocs[16], l_size[2], l[2][16];
+  int32_t tmvp, max_merge, merge_level;
+  int32_t frame_qp;                /* state->frame->QP: the slice's context models are initialised with it (params->qp is the CTUs' QP) */
+  const int32_t *col;              /* DEVICE: the collocated picture ref_LX[0][0] on its 8x8 grid (uvghip_merge_cand_batch's layout) */
+  const uvghip_inter4_t *inter4;   /* DEVICE, cu_stride entries per row */
+  const uint32_t *models_inter;    /* DEVICE: per CTU three sets of the 18 inter-syntax models (state0 | state1 << 16), as `models` holds the 257 */
+} uvghip_slice_pb_t;
+/* uvghip_encode_slice_rows for P / B pictures: the skip flag, prediction mode, merge flag / index, inter direction, reference indices,
+ * motion vector differences against the AMVP predictor the CU chose (uvg_inter_get_mv_cand_cua on the picture's side information with the
+ * row's history table, which the coder feeds as uvg_encode_coding_tree does), the root cbf and the transform tree of inter CUs
+ * (src/encode_coding_tree.c:1470-1640, 769-900, 1865-1910, 628-760), intra CUs as in an I slice; models initialised for the slice type.
+ * pb: HOST array, one per picture.  workspace: uvghip_slice_rows_pb_workspace_bytes(n_pictures). */
+UVGHIP_API size_t uvghip_slice_rows_pb_workspace_bytes(int n_pictures);
+UVGHIP_API int uvghip_encode_slice_rows_pb(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures,
+                                           const uvghip_slice_pb_t *pb, int n_pictures, const int32_t *sao_info, const uint16_t *sao_models,
+                                           void *workspace, uint8_t *out, int row_cap, int32_t *row_bytes, void *stream);
+
 /* ------------------- (7) the picture's NAL units behind the parameter sets -------------------------------------------- */
 
 /* replaces: uvg_image_checksum / array_checksum_generic (src/nal.c:91-115, src/strategies/generic/nal-generic.c:68-92) on the

@@ -141,7 +141,7 @@ void __wrap_uvg_search_lcu(encoder_state_t *const state, const int x, const int 
       int32_t *o = inter[(yy >> 2) * 16 + (xx >> 2)];
       o[0] = c->inter.mv[0][0]; o[1] = c->inter.mv[0][1]; o[2] = c->inter.mv[1][0]; o[3] = c->inter.mv[1][1];
       o[4] = c->inter.mv_ref[0]; o[5] = c->inter.mv_ref[1]; o[6] = c->inter.mv_dir;
-      o[7] = c->skipped | c->merged << 1 | c->merge_idx << 2 | c->inter.imv << 5;
+      o[7] = c->skipped | c->merged << 1 | c->merge_idx << 2 | c->inter.imv << 5 | c->inter.mv_cand0 << 8 | c->inter.mv_cand1 << 11 | c->root_cbf << 14;
     }
   int32_t refs[1 + 16 + 2 + 32 + 1];
   memset(refs, 0, sizeof refs);

@@ -212,6 +212,7 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
     F = sorted([r for n, r in recs if n == "final"], key=lambda r: int(r[0][0]))
     CD = {(int(r[0][0]), int(r[0][1]), int(r[0][2])): r for nm, r in recs if nm == "coded"}
     CI = [r for nm, r in recs if nm == "cuinter"]
+    ROWS = [r for nm, r in recs if nm == "row"]                        # in coding order: picture by picture, row by row
     wc, hc = (W + 63) // 64, (H + 63) // 64
     n = frames * wc * hc
     meta = np.zeros((n, 8), np.int32)
@@ -226,6 +227,10 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
     trees = np.zeros((n, 256, 2), np.uint32)
     models = np.zeros((n, 3, 1286), np.uint8)            # at the CTU's start / after its search / after the coder (257 models: state0, state1, rate)
     models_inter = np.zeros((n, 3, 90), np.uint8)        # the 18 models of the inter syntax beside them
+    sao_models = np.zeros((n, 6), np.uint16)             # the two SAO models after the CTU's SAO syntax
+    assert len(ROWS) == frames * hc
+    row_off = np.concatenate([[0], np.cumsum([len(r[1]) for r in ROWS])]).astype(np.int64).reshape(-1)
+    row_bytes = np.concatenate([r[1] for r in ROWS])     # every WPP row's substream (emulation prevention included), pictures in coding order
     for k, s in enumerate(S):
         fr, x, y = int(s[0][0]), int(s[0][1]), int(s[0][2])
         hh, ww = min(64, H - y), min(64, W - x)
@@ -233,6 +238,7 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
         trees[k] = s[5].reshape(256, 2)
         models[k, 0], models[k, 1], models[k, 2] = s[2], s[3], CD[(fr, x, y)][2]
         models_inter[k, 0], models_inter[k, 1], models_inter[k, 2] = s[13], s[14], CD[(fr, x, y)][7]
+        sao_models[k] = CD[(fr, x, y)][3]
         if (fr, x // 64, y // 64) in SA:
             sao[k, 0], sao[k, 1] = SA[(fr, x // 64, y // 64)][5], SA[(fr, x // 64, y // 64)][6]
         rec[0][fr, y:y + hh, x:x + ww] = s[6].reshape(64, 64)[:hh, :ww]
@@ -247,7 +253,8 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
                         final_v=final[2], trees=trees, models=models if with_levels else models[:0], models_inter=models_inter if with_levels else models_inter[:0],
                         # every call of uvg_search_cu_inter in coding order: frame, x, y, w, h, then the decided cu_info_t fields; its two costs
                         cuinter_i=np.stack([r[0] for r in CI]).astype(np.int32) if with_levels else np.zeros((0, 20), np.int32),
-                        cuinter_d=np.stack([r[1] for r in CI]) if with_levels else np.zeros((0, 2)))
+                        cuinter_d=np.stack([r[1] for r in CI]) if with_levels else np.zeros((0, 2)),
+                        sao_models=sao_models, row_bytes=row_bytes, row_off=row_off, bitstream=np.frombuffer(open(out + ".266", "rb").read(), np.uint8))
     if not out_dir: print("wrote inter", tag, n, "CTU records")
     return tag
 

@@ -36,7 +36,7 @@ __device__ void ctx_of(const int32_t *c, icand::frame_ctx &f)
 
 // a lane's working set (the call's context, the list being built) lives in the workgroup's LDS, one slot per lane: indexed arrays in
 // registers would go to scratch
-struct lane_slot { icand::frame_ctx f; icand::merge_cand mc[6]; };
+struct lane_slot { icand::frame_ctx f; icand::merge_cand mc[6]; icand::amvp_ws ws; int32_t ref_idx[2], out[4]; };
 
 __global__ void merge_cand_kernel(const int32_t *ctx, int32_t *lcu, const int32_t *col, long col_stride, const int32_t *hmvp, int n, int32_t *cands,
                                   int32_t *counts)
@@ -68,9 +68,9 @@ __global__ void amvp_cand_kernel(const int32_t *ctx, int32_t *lcu, const int32_t
   ctx_of(c, f);
   global_tab tab{lcu + (size_t)i * (icand::TCW * icand::TCW + 1) * 8};
   global_col cl{col + (size_t)i * col_stride};
-  const int32_t ref_idx[2] = {c[51], c[52]};
-  int32_t out[4];
-  icand::amvp_candidates(f, tab, cl, hmvp + (size_t)i * 41, c[50], ref_idx, out);
+  int32_t *ref_idx = slots[threadIdx.x].ref_idx, *out = slots[threadIdx.x].out;
+  ref_idx[0] = c[51]; ref_idx[1] = c[52];
+  icand::amvp_candidates(f, tab, cl, hmvp + (size_t)i * 41, c[50], ref_idx, out, &slots[threadIdx.x].ws);
   for (int j = 0; j < 4; ++j) mv_cand[(size_t)i * 4 + j] = out[j];
 }
 

@@ -272,15 +272,19 @@ __device__ inline bool predictor_from(const unit *c, int reflist, int target, co
   return false;
 }
 
+// what amvp_candidates indexes dynamically: the caller gives it a place that is not a register (LDS)
+struct amvp_ws { int32_t mv[2][2]; col_unit tc; };
 // uvg_inter_get_mv_cand: the two predictors of list `reflist` for the reference index ref_idx[reflist] being searched -> out[2][2]
 template <typename TAB, typename COL>
-__device__ inline void amvp_candidates(const frame_ctx &f, TAB &tab, COL &col, const int32_t *hmvp, int reflist, const int32_t ref_idx[2], int32_t out[4])
+__device__ inline void amvp_candidates(const frame_ctx &f, TAB &tab, COL &col, const int32_t *hmvp, int reflist, const int32_t ref_idx[2], int32_t out[4],
+                                       amvp_ws *ws)
 {
   const int target = f.l[reflist][ref_idx[reflist] & 7];
   const neighbours nb = spatial(tab, f);
-  col_unit tc;
+  col_unit &tc = ws->tc;
   const bool have_tc = f.n_refs ? temporal_unit(col, f, &tc) : false;
-  int32_t mv[2][2] = {{0, 0}, {0, 0}};
+  int32_t (&mv)[2][2] = ws->mv;
+  mv[0][0] = mv[0][1] = mv[1][0] = mv[1][1] = 0;
   int n = 0, nbn = 0;
   if (predictor_from(nb.a0, reflist, target, f, mv[n])) n++;
   else if (predictor_from(nb.a1, reflist, target, f, mv[n])) n++;

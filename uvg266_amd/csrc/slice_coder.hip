@@ -13,17 +13,43 @@
 // a chain bin after bin; lane 0 walks it, the other lanes only help to stage a transform block's levels into LDS.
 #include "uvghip_common.h"
 #include "ctu_core.h"
+#include "inter_cand_dev.h"
 
 namespace {
 
 using namespace ctu;
 
+// the 18 models of the inter syntax behind the others (the order of tools/refcheck/ctu_dump.c's snapshot_inter and of the oracle)
+enum { NM_INTER = 18, MI = NMODELS + 2, MI_SKIP = MI + 0, MI_PRED_MODE = MI + 3, MI_MERGE_FLAG = MI + 5, MI_MERGE_IDX = MI + 6, MI_INTER_DIR = MI + 7,
+       MI_REF_PIC = MI + 13, MI_MVD = MI + 15, MI_MVP_IDX = MI + 17, M_ROOT_CBF_ = 243 };
+
 struct row_state {
-  uint32_t models[NMODELS + 2];        // state0 | state1 << 16; [NMODELS] sao_merge_flag, [NMODELS + 1] sao_type_idx
-  uint8_t rate[NMODELS + 2];
+  uint32_t models[NMODELS + 2 + NM_INTER];   // state0 | state1 << 16; [NMODELS] sao_merge_flag, [NMODELS + 1] sao_type_idx, then the inter syntax
+  uint8_t rate[NMODELS + 2 + NM_INTER];
   uint16_t scan[1360];                 // diagonal scans of 32, 16, 8, 4 (scan_base)
   int16_t lv[1024];                    // the levels of the transform block being coded, raster
-  struct cui { uint8_t type, log2w, cbf, mode, mode_c, pad[3]; } cu[17 * 17];      // the CTU's side information + the row / column before it
+  struct cui { uint8_t type, log2w, cbf, mode, mode_c, skipped, pad[2]; } cu[17 * 17];      // the CTU's side information + the row / column before it
+};
+// P / B slices: the CTU's motion for the AMVP predictors (the table uvg_inter_get_mv_cand_cua reads of the picture's cu array), the row's
+// history table, the picture's reference lists
+struct row_state_pb {
+  icand::unit tab[17 * 17 + 1];
+  uint8_t flags[17 * 17][8];           // uvghip_inter4_t of the CTU's units (border included)
+  int32_t hmvp[41];
+  int32_t pred[4], ref_idx[2];         // (indexed dynamically: not in registers)
+  icand::amvp_ws ws;
+  icand::frame_ctx f;
+};
+struct lds_tab { icand::unit *p; __device__ icand::unit &at(int i) { return p[i]; } };
+struct glb_col {
+  const int32_t *p;
+  __device__ icand::col_unit at(int i) const
+  {
+    const int32_t *o = p + (size_t)i * 8;
+    icand::col_unit c;
+    c.type = o[0]; c.mv[0][0] = o[1]; c.mv[0][1] = o[2]; c.mv[1][0] = o[3]; c.mv[1][1] = o[4]; c.dir = o[5]; c.poc[0] = o[6]; c.poc[1] = o[7];
+    return c;
+  }
 };
 
 struct coder {                          // cabac_data_t (cabac.h:56-66) + the substream's output
@@ -130,6 +156,30 @@ __device__ __forceinline__ void enc_remain(coder &c, uint32_t remainder, uint32_
     const unsigned total_prefix = prefix_length + cutoff;
     enc_eps(c, (1u << total_prefix) - 1, (int)total_prefix);
     enc_eps(c, ((code_value - ((1u << prefix_length) - 1)) << rice) | (remainder & ((1u << rice) - 1)), (int)suffix_length);
+  }
+}
+
+__device__ inline void code_mvd(coder &c, row_state *R, int mvd_hor, int mvd_ver)
+{
+  const uint32_t ah = (uint32_t)(mvd_hor < 0 ? -mvd_hor : mvd_hor), av = (uint32_t)(mvd_ver < 0 ? -mvd_ver : mvd_ver);
+  enc_bin(c, R, MI_MVD + 0, mvd_hor != 0);
+  enc_bin(c, R, MI_MVD + 0, mvd_ver != 0);
+  if (ah) enc_bin(c, R, MI_MVD + 1, ah > 1);
+  if (av) enc_bin(c, R, MI_MVD + 1, av > 1);
+  for (int k = 0; k < 2; ++k) {
+    const uint32_t a = k ? av : ah;
+    const int v = k ? mvd_ver : mvd_hor;
+    if (!a) continue;
+    if (a > 1) {                                  // uvg_cabac_write_ep_ex_golomb(a - 2, 1) (cabac.c:320-354)
+      uint32_t symbol = a - 2, count = 1, bins = 0;
+      int num_bins = 0;
+      while (symbol >= (1u << count)) { bins = 2 * bins + 1; ++num_bins; symbol -= 1u << count; ++count; }
+      bins = 2 * bins; ++num_bins;
+      bins = (bins << count) | symbol;
+      num_bins += (int)count;
+      enc_eps(c, bins, num_bins);
+    }
+    enc_ep(c, v > 0 ? 0 : 1);
   }
 }
 
@@ -258,6 +308,34 @@ __device__ __forceinline__ void code_coeffs(coder &c, row_state *R, int n, int c
 }
 
 struct pic_dev { const uvghip_scu_t *cu; const int16_t *coeff; const uint32_t *models; int cu_stride, pad; };
+// a P / B picture's reference lists and side tables (uvghip_slice_pb_t with device pointers), behind the pic_dev table in the workspace
+struct pb_dev {
+  int32_t slice_type, poc, n_refs, ref_pocs[16], l_size[2], l[2][16], tmvp, max_merge, merge_level, frame_qp;
+  const int32_t *col;
+  const uvghip_inter4_t *inter4;
+  const uint32_t *models_inter;
+};
+
+// uvg_hmvp_add_mv (src/inter.c:1831-1905) on the row's table: [0] size, then five units, most recent first
+__device__ inline void hmvp_push(int32_t *hm, const icand::unit &u)
+{
+  icand::unit *lut = reinterpret_cast<icand::unit *>(hm + 1);
+  const int size = hm[0];
+  int dup = -1;
+  for (int i = 0; i < size; ++i) if (icand::same_motion(u, &lut[i])) { dup = i; break; }
+  if (dup != 0) {
+    int end = dup == -1 ? 5 : dup;
+    if (end > 4) end = 4;
+    if (end == 0 && size == 1) end = 1;
+    for (int i = end - 1; i >= 0; --i) lut[i + 1] = lut[i];
+  }
+  lut[0] = u;
+  if (dup == -1 && hm[0] < 5) hm[0]++;
+}
+
+__device__ __forceinline__ void enc_eps(coder &c, uint32_t v, int n);
+// uvg_encode_mvd (src/encode_coding_tree.c:1865-1910): greater-than-0 / -1 flags, the remainder as Exp-Golomb of order 1, the sign
+__device__ inline void code_mvd(coder &c, row_state *R, int mvd_hor, int mvd_ver);
 
 // side information of the 4x4 unit at picture position (x, y), from the CTU's LDS copy (x0, y0: the CTU's origin; one unit of
 // border to the left and above)
@@ -365,28 +443,54 @@ __device__ __forceinline__ void code_sao_color(coder &c, row_state *R, const int
 __device__ inline int z_to_xy(int z) { return (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4) | ((z >> 3) & 8); }
 
 __global__ void __launch_bounds__(64)
-slice_rows_kernel(const pic_dev *__restrict__ pics, const int32_t *__restrict__ sao, const uint16_t *__restrict__ sao_models, int W, int H, int qp,
-                  int bitdepth, uint8_t *__restrict__ out, int row_cap, int32_t *__restrict__ row_bytes)
+slice_rows_kernel(const pic_dev *__restrict__ pics, const pb_dev *__restrict__ pbs, const int32_t *__restrict__ sao, const uint16_t *__restrict__ sao_models,
+                  int W, int H, int qp, int bitdepth, uint8_t *__restrict__ out, int row_cap, int32_t *__restrict__ row_bytes)
 {
   __shared__ row_state Rs;
+  extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem[];          // row_state_pb for P / B pictures (none for I)
   row_state *R = &Rs;
+  row_state_pb *Q = reinterpret_cast<row_state_pb *>(pb_smem);
   const int wc = (W + 63) / 64, hc = (H + 63) / 64;
   const int pic = blockIdx.x / hc, cy = blockIdx.x - pic * hc;
   const pic_dev D = pics[pic];
+  const pb_dev *PB = pbs ? &pbs[pic] : nullptr;
+  const int slice = PB ? PB->slice_type : 2, init_qp = PB ? PB->frame_qp : qp;
   const bool lane0 = threadIdx.x == 0;
   // scans, window bytes, the row's start models
   for (int i = threadIdx.x; i < NMODELS; i += blockDim.x) {
     R->rate[i] = k_ctx_init[3][i];
-    if (cy == 0) models_init_one(R->models, i, qp, 2);
+    if (cy == 0) models_init_one(R->models, i, init_qp, slice);
     else R->models[i] = D.models[((size_t)((cy - 1) * wc) * 3 + 2) * NMODELS + i];
+  }
+  if (PB) {
+    if (threadIdx.x < NM_INTER) {
+      const int i = threadIdx.x;
+      R->rate[MI + i] = k_ctx_init_inter[3][i];
+      if (cy == 0) {
+        const int v = k_ctx_init_inter[slice][i];
+        const int slope = (v >> 3) - 4, offset = ((v & 7) * 18) + 1;
+        int s = ((slope * (init_qp - 16)) >> 1) + offset;
+        s = s < 1 ? 1 : (s > 127 ? 127 : s);
+        R->models[MI + i] = (uint32_t)((s << 8) & 0x7fe0) | ((uint32_t)((s << 8) & 0x7ffe) << 16);
+      } else R->models[MI + i] = PB->models_inter[((size_t)((cy - 1) * wc) * 3 + 2) * NM_INTER + i];
+    }
+    if (lane0) {
+      for (int i = 0; i < 41; ++i) Q->hmvp[i] = 0;                 // the row's history table starts empty (encoderstate.c:1021-1028)
+      icand::frame_ctx &f = Q->f;
+      f.poc = PB->poc; f.is_b = PB->slice_type == 0; f.pic_w = W; f.pic_h = H; f.tmvp = PB->tmvp; f.max_cands = PB->max_merge; f.mer_level = PB->merge_level;
+      f.wpp = 1; f.n_refs = PB->n_refs;
+      for (int i = 0; i < 16; ++i) f.ref_pocs[i] = PB->ref_pocs[i];
+      f.l_size[0] = PB->l_size[0]; f.l_size[1] = PB->l_size[1];
+      for (int i = 0; i < 8; ++i) { f.l[0][i] = PB->l[0][i]; f.l[1][i] = PB->l[1][i]; }
+    }
   }
   if (threadIdx.x < 2) {
     const int i = threadIdx.x;
     R->rate[NMODELS + i] = k_ctx_init_sao[3][i];
     if (cy == 0 || !sao_models) {
-      const int v = k_ctx_init_sao[2][i];
+      const int v = k_ctx_init_sao[slice][i];
       const int slope = (v >> 3) - 4, offset = ((v & 7) * 18) + 1;
-      int s = ((slope * (qp - 16)) >> 1) + offset;
+      int s = ((slope * (init_qp - 16)) >> 1) + offset;
       s = s < 1 ? 1 : (s > 127 ? 127 : s);
       R->models[NMODELS + i] = (uint32_t)((s << 8) & 0x7fe0) | ((uint32_t)((s << 8) & 0x7ffe) << 16);
     } else {
@@ -427,9 +531,22 @@ slice_rows_kernel(const pic_dev *__restrict__ pics, const int32_t *__restrict__ 
       if (x >= 0 && y >= 0 && x < W && y < H) {
         const uvghip_scu_t *g = &D.cu[(y >> 2) * D.cu_stride + (x >> 2)];
         q.type = g->type; q.log2w = g->log2_width; q.cbf = g->cbf; q.mode = (uint8_t)(g->mv[0][0] & 0xff); q.mode_c = (uint8_t)((g->mv[0][0] >> 8) & 0xff);
+        if (PB) {
+          const uvghip_inter4_t t = PB->inter4[(y >> 2) * D.cu_stride + (x >> 2)];
+          q.skipped = t.skipped;
+          icand::unit &u = Q->tab[e];
+          u.type = g->type; u.dir = g->mv_dir; u.mv[0][0] = g->mv[0][0]; u.mv[0][1] = g->mv[0][1]; u.mv[1][0] = g->mv[1][0]; u.mv[1][1] = g->mv[1][1];
+          u.ref[0] = t.mv_ref0; u.ref[1] = t.mv_ref1;
+          uint8_t *fl = Q->flags[e];
+          fl[0] = t.skipped; fl[1] = t.merged; fl[2] = t.merge_idx; fl[3] = t.root_cbf; fl[4] = t.mv_cand0; fl[5] = t.mv_cand1; fl[6] = t.mv_ref0; fl[7] = t.mv_ref1;
+        }
+      } else if (PB) {
+        icand::unit &u = Q->tab[e];
+        u.type = 0; u.dir = 0; u.mv[0][0] = u.mv[0][1] = u.mv[1][0] = u.mv[1][1] = 0; u.ref[0] = u.ref[1] = 0;
       }
       R->cu[e] = q;
     }
+    if (PB && lane0) Q->tab[17 * 17].type = 0;                      // the CTU above right: not a candidate under WPP
     __syncthreads();
     if (lane0 && sao) {                                             // encode_sao
       const int32_t *l = sao + ((size_t)pic * wc * hc + k) * 34, *ch = l + 17;
@@ -452,6 +569,105 @@ slice_rows_kernel(const pic_dev *__restrict__ pics, const int32_t *__restrict__ 
           if (!(lx & (s - 1)) && !(ly & (s - 1))) code_split_flag(c, R, x0, y0, W, H, x, y, s, 1);
         }
         code_split_flag(c, R, x0, y0, W, H, x, y, n, 0);
+      }
+      if (PB) {
+        // ---- P / B slice: skip flag, prediction mode, the inter prediction unit (encode_coding_tree.c:1470-1640) ----
+        const int e = ((ly >> 2) + 1) * 17 + (lx >> 2) + 1;
+        const uint8_t *fl = Q->flags[e];
+        const int skipped = fl[0], merged = fl[1], merge_idx = fl[2];
+        const bool inter = cu.type == 2;
+        if (lane0 && n != 4) {
+          int ctx_skip = 0;
+          if (x > 0 && cu_of(R, x0, y0, x - 4, y).skipped) ctx_skip++;
+          if (y > 0 && cu_of(R, x0, y0, x, y - 4).skipped) ctx_skip++;
+          enc_bin(c, R, MI_SKIP + ctx_skip, skipped);
+        }
+        if (skipped) {
+          if (lane0) {
+            hmvp_push(Q->hmvp, Q->tab[e]);
+            for (int ui = 0; ui < PB->max_merge - 1; ui++) {
+              const int symbol = ui != merge_idx;
+              if (ui == 0) enc_bin(c, R, MI_MERGE_IDX, symbol); else enc_ep(c, symbol);
+              if (!symbol) break;
+            }
+          }
+          continue;
+        }
+        if (lane0 && n != 4) {
+          const int ctx_pm = (x > 0 && cu_of(R, x0, y0, x - 4, y).type == 1) || (y > 0 && cu_of(R, x0, y0, x, y - 4).type == 1);
+          enc_bin(c, R, MI_PRED_MODE + ctx_pm, cu.type == 1);
+        }
+        if (inter) {
+          const icand::unit &me = Q->tab[e];
+          if (lane0) {
+            // uvg_encode_inter_prediction_unit (:769-900)
+            enc_bin(c, R, MI_MERGE_FLAG, merged);
+            if (merged) {
+              for (int ui = 0; ui < PB->max_merge - 1; ui++) {
+                const int symbol = ui != merge_idx;
+                if (ui == 0) enc_bin(c, R, MI_MERGE_IDX, symbol); else enc_ep(c, symbol);
+                if (!symbol) break;
+              }
+            } else {
+              if (PB->slice_type == 0) {
+                if (n + n > 12) enc_bin(c, R, MI_INTER_DIR + (7 - ((2 * ilog2_dev(n) + 1) >> 1)), me.dir == 3);
+                if (me.dir < 3) enc_bin(c, R, MI_INTER_DIR + 5, me.dir == 2);
+              }
+              for (int l = 0; l < 2; ++l) {
+                if (!(me.dir & (1 << l))) continue;
+                const int lsz = PB->l_size[l], ref_frame = me.ref[l];
+                if (lsz > 1) {
+                  enc_bin(c, R, MI_REF_PIC + 0, ref_frame != 0);
+                  if (ref_frame > 0 && lsz > 2) {
+                    enc_bin(c, R, MI_REF_PIC + 1, ref_frame > 1);
+                    if (ref_frame > 1 && lsz > 3)
+                      for (int idx = 3; idx < lsz; idx++) { const int val = ref_frame > idx - 1; enc_ep(c, val); if (!val) break; }
+                  }
+                }
+                // the predictor the CU chose: uvg_inter_get_mv_cand_cua on the picture's side information (a scratch copy of the CU's
+                // context: the derivation clears unused lists of the neighbours it looks at, which the cu array version does not)
+                icand::frame_ctx &f = Q->f;
+                f.x = x; f.y = y; f.w = n; f.h = n;
+                uint32_t tree = 0;                                    // the split tree down to this CU: quad splits
+                for (int d = 0; (64 >> d) > n; ++d) tree |= 1u << (3 * d);
+                f.split_tree = tree;
+                lds_tab tab{Q->tab};
+                glb_col colp{PB->col};
+                int32_t *pred = Q->pred;
+                Q->ref_idx[0] = me.ref[0]; Q->ref_idx[1] = me.ref[1];
+                icand::amvp_candidates(f, tab, colp, Q->hmvp, l, Q->ref_idx, pred, &Q->ws);
+                const int which = l == 0 ? fl[4] : fl[5];
+                int dh = me.mv[l][0] - pred[2 * which], dv = me.mv[l][1] - pred[2 * which + 1];
+                dh = dh >= 0 ? (dh + 1) >> 2 : (dh + 2) >> 2;         // uvg_change_precision(INTERNAL_MV_PREC, 2)
+                dv = dv >= 0 ? (dv + 1) >> 2 : (dv + 2) >> 2;
+                code_mvd(c, R, dh, dv);
+                enc_bin(c, R, MI_MVP_IDX, which);
+              }
+            }
+            hmvp_push(Q->hmvp, me);
+          }
+          const int first_cbf = cu.cbf;
+          const int has_coeffs = fl[3] || first_cbf;
+          if (lane0 && !merged) enc_bin(c, R, M_ROOT_CBF_, has_coeffs);
+          if (has_coeffs) {
+            const int tus = n == 64 ? 4 : 1, tn = n == 64 ? 32 : n;
+            for (int tu = 0; tu < tus; ++tu) {
+              const int tlx = lx + (tu & 1) * 32, tly = ly + (tu >> 1) * 32;
+              const int tcbf = cu_of(R, x0, y0, x0 + tlx, y0 + tly).cbf;
+              const int cb_y = tcbf & 1, cb_u = (tcbf >> 1) & 1, cb_v = (tcbf >> 2) & 1;
+              if (lane0) {
+                enc_bin(c, R, M_CBF_CB, cb_u); enc_bin(c, R, M_CBF_CR + cb_u, cb_v);
+                if (n == 64 || cb_u || cb_v) enc_bin(c, R, M_CBF_LUMA, cb_y);       // otherwise inferred 1 (:705-716)
+              }
+              if (cb_y) { stage(R, co + tly * 64 + tlx, 64, tn); if (lane0) code_coeffs(c, R, tn, 0); }
+              if (cb_u) { stage(R, co + 4096 + (tly >> 1) * 32 + (tlx >> 1), 32, tn >> 1); if (lane0) code_coeffs(c, R, tn >> 1, 1); }
+              if (cb_v) { stage(R, co + 5120 + (tly >> 1) * 32 + (tlx >> 1), 32, tn >> 1); if (lane0) code_coeffs(c, R, tn >> 1, 2); }
+            }
+          }
+          continue;
+        }
+      }
+      if (lane0) {
         code_luma_mode(c, R, x0, y0, x, y, n, mode);
         if (!sep) code_chroma_mode(c, R, mode_c, mode);
       }
@@ -510,6 +726,10 @@ slice_rows_kernel(const pic_dev *__restrict__ pics, const int32_t *__restrict__ 
 }  // namespace
 
 extern "C" size_t uvghip_slice_rows_workspace_bytes(int n_pictures) { return n_pictures > 0 ? (size_t)n_pictures * sizeof(pic_dev) : 0; }
+extern "C" size_t uvghip_slice_rows_pb_workspace_bytes(int n_pictures)
+{
+  return n_pictures > 0 ? ((size_t)n_pictures * sizeof(pic_dev) + 255) / 256 * 256 + (size_t)n_pictures * sizeof(pb_dev) : 0;
+}
 
 // the picture table the kernel reads, uploaded once (synchronously); uvghip_encode_slice_rows with pictures == NULL reuses it
 extern "C" int uvghip_slice_rows_prepare(const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, int n_pictures, void *workspace)
@@ -540,7 +760,37 @@ extern "C" int uvghip_encode_slice_rows(int bitdepth, const uvghip_ctu_params_t 
   if (pictures)
     if (int rc = uvghip_slice_rows_prepare(params, pictures, n_pictures, workspace)) return rc;
   hipStream_t st = uvghip_stream(stream);
-  slice_rows_kernel<<<n_pictures * hc, 64, 0, st>>>(static_cast<const pic_dev *>(workspace), sao_info, sao_models, W, H, params->qp, bitdepth, out,
+  slice_rows_kernel<<<n_pictures * hc, 64, 0, st>>>(static_cast<const pic_dev *>(workspace), nullptr, sao_info, sao_models, W, H, params->qp, bitdepth, out,
                                                     row_cap, row_bytes);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+extern "C" int uvghip_encode_slice_rows_pb(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, const uvghip_slice_pb_t *pb,
+                                           int n_pictures, const int32_t *sao_info, const uint16_t *sao_models, void *workspace, uint8_t *out, int row_cap,
+                                           int32_t *row_bytes, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
+  if (!params || !pictures || !pb || n_pictures <= 0 || !workspace || !out || row_cap <= 0 || !row_bytes || (sao_info && !sao_models))
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const int W = params->pic_w, H = params->pic_h, hc = (H + 63) / 64;
+  if (W <= 0 || H <= 0 || (W & 7) || (H & 7) || params->qp < 0 || params->qp > 63) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (int rc = uvghip_slice_rows_prepare(params, pictures, n_pictures, workspace)) return rc;
+  std::vector<pb_dev> pd(n_pictures);
+  for (int i = 0; i < n_pictures; ++i) {
+    const uvghip_slice_pb_t &q = pb[i];
+    if ((q.slice_type != 0 && q.slice_type != 1) || !q.inter4 || !q.models_inter || q.n_refs < 1 || q.n_refs > 16 || q.l_size[0] < 1 || q.l_size[0] > 8 ||
+        q.l_size[1] < 0 || q.l_size[1] > 8 || q.max_merge < 1 || q.max_merge > 6 || (q.tmvp && !q.col) || q.frame_qp < 0 || q.frame_qp > 63)
+      return uvghip_set_error(hipErrorInvalidValue, "uvghip_encode_slice_rows_pb: slice descriptor");
+    pb_dev &d = pd[i];
+    d.slice_type = q.slice_type; d.poc = q.poc; d.n_refs = q.n_refs; d.tmvp = q.tmvp; d.max_merge = q.max_merge; d.merge_level = q.merge_level; d.frame_qp = q.frame_qp;
+    memcpy(d.ref_pocs, q.ref_pocs, sizeof d.ref_pocs); memcpy(d.l_size, q.l_size, sizeof d.l_size); memcpy(d.l, q.l, sizeof d.l);
+    d.col = q.col; d.inter4 = q.inter4; d.models_inter = q.models_inter;
+  }
+  unsigned char *pbw = static_cast<unsigned char *>(workspace) + ((size_t)n_pictures * sizeof(pic_dev) + 255) / 256 * 256;
+  UVGHIP_TRY(hipMemcpy(pbw, pd.data(), pd.size() * sizeof(pb_dev), hipMemcpyHostToDevice));
+  hipStream_t st = uvghip_stream(stream);
+  slice_rows_kernel<<<n_pictures * hc, 64, sizeof(row_state_pb), st>>>(static_cast<const pic_dev *>(workspace), reinterpret_cast<const pb_dev *>(pbw), sao_info, sao_models,
+                                                                       W, H, params->qp, bitdepth, out, row_cap, row_bytes);
   UVGHIP_CHECK_LAUNCH();
 }

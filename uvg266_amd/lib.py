@@ -72,6 +72,14 @@ class CtuPicture(ctypes.Structure):
                 ("reserved", ctypes.c_int32), ("coeff", ctypes.c_void_p), ("models", ctypes.c_void_p)]
 
 
+class SlicePb(ctypes.Structure):
+    """uvghip_slice_pb_t."""
+    _fields_ = [("slice_type", ctypes.c_int32), ("poc", ctypes.c_int32), ("n_refs", ctypes.c_int32), ("ref_pocs", ctypes.c_int32 * 16),
+                ("l_size", ctypes.c_int32 * 2), ("l", (ctypes.c_int32 * 16) * 2), ("tmvp", ctypes.c_int32), ("max_merge", ctypes.c_int32),
+                ("merge_level", ctypes.c_int32), ("frame_qp", ctypes.c_int32), ("col", ctypes.c_void_p), ("inter4", ctypes.c_void_p),
+                ("models_inter", ctypes.c_void_p)]
+
+
 class MeJob(ctypes.Structure):
     """uvghip_me_job_t."""
     _fields_ = [("x", ctypes.c_int32), ("y", ctypes.c_int32), ("ref", ctypes.c_int32), ("mv_cand", (ctypes.c_int32 * 2) * 2), ("extra_mv", ctypes.c_int32 * 2),
@@ -181,6 +189,8 @@ SIGNATURES = {
     "uvghip_loop_plan_picture_nals": (c_int, [c_vp, c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_vp]),
     "uvghip_picture_checksum": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "uvghip_write_picture_nals": (c_int, [c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_int, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "uvghip_slice_rows_pb_workspace_bytes": (ctypes.c_size_t, [c_int]),
+    "uvghip_encode_slice_rows_pb": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "uvghip_merge_cand_batch": (c_int, [c_vp, c_vp, c_vp, ctypes.c_long, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvghip_amvp_cand_batch": (c_int, [c_vp, c_vp, c_vp, ctypes.c_long, c_vp, c_int, c_vp, c_vp]),
     "uvghip_inter_pred_satd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
