@@ -1,0 +1,69 @@
+// CPU emulation of uvg266_amd/csrc/ctu_pb.h (the closed-loop CTU search of P / B pictures) for the "-m not gpu" tests: the kernel's
+// source compiled for the host, one lane playing the wave, CTUs in raster order.  Test infrastructure (see ctu_emul.cpp); never
+// linked into libuvg266hip.so.
+#include <cstdlib>
+#include <cstring>
+#include <cstdio>
+#include "ctu_pb.h"
+
+// the picture's inter state as the tests hand it over (the layout of oracle/orc_search.c's orc_inter_frame)
+struct emul_frame {
+  int32_t slice_type, poc, n_refs, ref_pocs[16], l_size[2], l[2][16];
+  int32_t tmvp, max_merge, merge_level, bipred, fme_level, early_skip, depth_inter_min, depth_inter_max, ref_cu_stride, frame_qp;
+  const void *ref_y[16], *ref_u[16], *ref_v[16];
+  const int32_t *ref_cu[16];
+};
+
+template <typename PX>
+static int run_picture(const ctu::params &P, const emul_frame &F, const PX *sy, const PX *su, const PX *sv, PX *ry, PX *ru, PX *rv, uvghip_scu_t *cu_tab,
+                       uvghip_inter4_t *inter4, uint32_t *trees, int32_t *motion_out, int16_t *coeff, uint32_t *models, uint32_t *models_inter)
+{
+  const int W = P.pic_w, H = P.pic_h, wc = (W + 63) / 64, hc = (H + 63) / 64;
+  ctu::lds<PX> *S = new ctu::lds<PX>;
+  ctu::scratch *Wk = new ctu::scratch;
+  int32_t *hmvp_rows = (int32_t *)calloc((size_t)hc * 41, sizeof(int32_t));
+  ctu::pb_job B;
+  memset(&B, 0, sizeof B);
+  B.slice_type = F.slice_type; B.poc = F.poc; B.n_refs = F.n_refs;
+  memcpy(B.ref_pocs, F.ref_pocs, sizeof B.ref_pocs); memcpy(B.l_size, F.l_size, sizeof B.l_size); memcpy(B.l, F.l, sizeof B.l);
+  B.tmvp = F.tmvp; B.max_merge = F.max_merge; B.merge_level = F.merge_level; B.frame_qp = F.frame_qp;
+  B.bipred = F.bipred; B.fme_level = F.fme_level; B.early_skip = F.early_skip; B.depth_inter_min = F.depth_inter_min; B.depth_inter_max = F.depth_inter_max;
+  for (int i = 0; i < 16; ++i) { B.ref_y[i] = F.ref_y[i]; B.ref_u[i] = F.ref_u[i]; B.ref_v[i] = F.ref_v[i]; B.ref_cu[i] = F.ref_cu[i]; }
+  B.ref_stride = W; B.ref_stride_c = W / 2; B.ref_cu_stride = F.ref_cu_stride;
+  B.inter4 = inter4; B.trees = trees; B.motion_out = motion_out; B.hmvp_rows = hmvp_rows;
+  for (int cy = 0; cy < hc; ++cy)
+    for (int cx = 0; cx < wc; ++cx) {
+      memset(S, 0xA5, sizeof *S);
+      memset(Wk, 0xA5, sizeof *Wk);
+      ctu::job<PX> J;
+      J.P = P;
+      J.src_y = sy; J.src_u = su; J.src_v = sv; J.src_stride = W; J.src_stride_c = W / 2;
+      J.rec_y = ry; J.rec_u = ru; J.rec_v = rv; J.rec_stride = W; J.rec_stride_c = W / 2;
+      J.cu_tab = cu_tab; J.cu_stride = wc * 16;
+      const int k = cy * wc + cx;
+      J.coeff = coeff + (size_t)k * 6144;
+      J.models_out = models + (size_t)k * 3 * ctu::NMODELS;
+      J.pbm_out = models_inter + (size_t)k * 3 * 18;
+      const int from = cx > 0 ? k - 1 : (cy > 0 ? (cy - 1) * wc : -1);
+      J.models_in = from >= 0 ? models + ((size_t)from * 3 + 2) * ctu::NMODELS : nullptr;
+      J.pbm_in = from >= 0 ? models_inter + ((size_t)from * 3 + 2) * 18 : nullptr;
+      J.slice_type = F.slice_type; J.init_qp = F.frame_qp;
+      J.pb = &B;
+      J.W = Wk;
+      J.x = cx * 64; J.y = cy * 64;
+      ctu::run_ctu_pb(S, J);
+    }
+  free(hmvp_rows);
+  delete S; delete Wk;
+  return 0;
+}
+
+extern "C" __attribute__((visibility("default")))
+int ctu_pb_emul_search_picture(int bitdepth, const ctu::params *P, const emul_frame *F, const void *sy, const void *su, const void *sv, void *ry, void *ru, void *rv,
+                               uvghip_scu_t *cu_tab, uvghip_inter4_t *inter4, uint32_t *trees, int32_t *motion_out, int16_t *coeff, uint32_t *models,
+                               uint32_t *models_inter)
+{
+  if (bitdepth == 8) return run_picture<uint8_t>(*P, *F, (const uint8_t *)sy, (const uint8_t *)su, (const uint8_t *)sv, (uint8_t *)ry, (uint8_t *)ru, (uint8_t *)rv, cu_tab, inter4, trees, motion_out, coeff, models, models_inter);
+  if (bitdepth == 10) return run_picture<uint16_t>(*P, *F, (const uint16_t *)sy, (const uint16_t *)su, (const uint16_t *)sv, (uint16_t *)ry, (uint16_t *)ru, (uint16_t *)rv, cu_tab, inter4, trees, motion_out, coeff, models, models_inter);
+  return -1;
+}

@@ -1053,6 +1053,139 @@ def oracle_search_inter_picture(orc, depth, prm, fr, y, u, v, keep):
     return dict(rec_y=ry, rec_u=ru, rec_v=rv, cu=cu[:, :, :11].copy(), trees=trees, coeff=co, models=mo, motion=mot, extra=ext, models_inter=mi)
 
 
+def iter_inter_frames(W, H, P):
+    """The P / B pictures of a golden's records in coding order with their frame-level state -> (frame, record dict, SearchParams,
+    InterFrame, keep-alive list).  References are the ENCODER's output pictures and side information."""
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    by_poc = {}
+    for fr in sorted(P):
+        d = P[fr]
+        refs = d["refs"]
+        n_refs, pocs = int(refs[0]), [int(a) for a in refs[1:17]]
+        lsz = [int(refs[17]), int(refs[18])]
+        lists = [[int(a) for a in refs[19:35]], [int(a) for a in refs[35:51]]]
+        poc, slice_type = int(refs[51]), int(d["meta"][6])
+        lam = d["lam"]
+        prm = SearchParams(W, H, int(d["meta"][3]), int(d["meta"][3]), 1, 4, 1, 1, 2, 0, float(lam[0]), float(lam[1]), float(lam[2]), float(lam[3]), float(lam[4]))
+        F = InterFrame()
+        F.slice_type, F.poc, F.n_refs = slice_type, poc, n_refs
+        for i in range(16):
+            F.ref_pocs[i] = pocs[i]
+            F.l[0][i], F.l[1][i] = lists[0][i], lists[1][i]
+        F.l_size[0], F.l_size[1] = lsz
+        F.tmvp, F.max_merge, F.merge_level, F.bipred, F.fme_level, F.early_skip, F.depth_inter_min, F.depth_inter_max = 1, 6, 2, 1, 4, 1, 0, 3
+        F.ref_cu_stride, F.frame_qp = wc * 16, int(d["meta"][7])
+        keep = []
+        for i in range(n_refs):
+            rp = by_poc[pocs[i]]
+            planes = [np.ascontiguousarray(p) for p in rp["final"]]
+            keep += planes + [rp["ref_cu"]]
+            F.ref_y[i], F.ref_u[i], F.ref_v[i] = (p.ctypes.data for p in planes)
+            F.ref_cu[i] = rp["ref_cu"].ctypes.data
+        own_pocs = ([pocs[lists[0][i]] for i in range(lsz[0])], [pocs[lists[1][i]] for i in range(lsz[1])])
+        d["ref_cu"] = ref_cu_table(d["cu"], d["motion"], own_pocs)
+        by_poc[poc] = d
+        yield fr, d, prm, F, keep
+
+
+INTER4_NP = np.dtype([("skipped", "u1"), ("merged", "u1"), ("merge_idx", "u1"), ("root_cbf", "u1"), ("mv_cand0", "u1"), ("mv_cand1", "u1"),
+                      ("mv_ref0", "u1"), ("mv_ref1", "u1")])      # uvghip_inter4_t
+_EMUL_PB = None
+
+
+def emul_search_inter_picture(depth, prm, F, y, u, v):
+    """tests/emul/ctu_pb_emul.cpp: the P / B CTU search kernel's source on the host -> the device-layout outputs as a dict."""
+    global _EMUL_PB
+    if _EMUL_PB is None:
+        d = os.path.join(ROOT, "tests", "emul")
+        subprocess.check_call(["make", "-s", "-C", d])
+        _EMUL_PB = ctypes.CDLL(os.path.join(d, "_build", "libctu_pb_emul.so"))
+    W, H = prm.pic_w, prm.pic_h
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    px = px_dtype(depth)
+    y, u, v = (np.ascontiguousarray(a, px) for a in (y, u, v))
+    ry, ru, rv = np.zeros((H, W), px), np.zeros((H // 2, W // 2), px), np.zeros((H // 2, W // 2), px)
+    n4 = hc * 16 * wc * 16
+    scu, i4, trees, mot = np.zeros(n4, SCU_NP), np.zeros(n4, INTER4_NP), np.zeros(n4, np.uint32), np.zeros((n4, 8), np.int32)
+    co = np.zeros(wc * hc * 6144, np.int16)
+    mo, mi = np.zeros(wc * hc * 3 * N_MODELS, np.uint32), np.zeros(wc * hc * 3 * 18, np.uint32)
+    cp = ctu_params(prm)
+    rc = _EMUL_PB.ctu_pb_emul_search_picture(depth, ctypes.byref(cp), ctypes.byref(F), ptr(y), ptr(u), ptr(v), ptr(ry), ptr(ru), ptr(rv), ptr(scu), ptr(i4),
+                                             ptr(trees), ptr(mot), ptr(co), ptr(mo), ptr(mi))
+    assert rc == 0
+    return inter_result_from_device_layout(W, H, ry, ru, rv, scu, i4, trees, mot, co, mo, mi)
+
+
+def inter_result_from_device_layout(W, H, ry, ru, rv, scu, i4, trees, mot, co, mo, mi):
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    r = search_result_from_device_layout(W, H, ry, ru, rv, scu, co, mo)
+    t = trees.reshape(hc * 16, wc * 16)
+    r["trees"] = np.stack([t & 0xffff, t >> 16], axis=2).astype(np.uint32)
+    r["scu"], r["inter4"], r["motion_dev"] = scu.reshape(hc * 16, wc * 16), i4.reshape(hc * 16, wc * 16), mot.reshape(hc * 16, wc * 16, 8)
+    m = mi.reshape(hc * wc, 3, 18)
+    r["models_inter_states"] = np.concatenate([(m & 0xffff).astype(np.uint16), (m >> 16).astype(np.uint16)], axis=2)      # [ctus, 3, 36]
+    return r
+
+
+def compare_device_inter_picture(W, H, d, r):
+    """The device-layout result of a P / B picture's CTU search (the emulation or the GPU) against the encoder's records d -> differences.
+    Vectors and reference indices of lists a unit does not use are not compared (see csrc/ctu_pb.h: one motion table for every depth)."""
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    h4, w4 = H // 4, W // 4
+    msgs = []
+    got, want = r["cu"][:h4, :w4], d["cu"][:h4, :w4]
+    if not np.array_equal(got[:, :, :6], want[:, :, :6]):
+        j = np.argwhere((got[:, :, :6] != want[:, :, :6]).any(axis=2))[0]
+        msgs.append(f"cu differs first at 4x4 {j.tolist()}: got {got[j[0], j[1]].tolist()} want {want[j[0], j[1]].tolist()}")
+        return msgs
+    intra, inter = want[:, :, 0] == 1, want[:, :, 0] == 2
+    if not np.array_equal(got[:, :, 6:8][intra], want[:, :, 6:8][intra]):
+        msgs.append("intra modes differ")
+    if not np.array_equal(got[:, :, 8:11], want[:, :, 8:11]):
+        j = np.argwhere((got[:, :, 8:11] != want[:, :, 8:11]).any(axis=2))[0]
+        msgs.append(f"edge flags / qp differ first at {j.tolist()}: got {got[j[0], j[1]].tolist()} want {want[j[0], j[1]].tolist()}")
+    if not np.array_equal(r["trees"][:h4, :w4], d["trees"][:h4, :w4]):
+        msgs.append("trees differ")
+    s, f4, wm = r["scu"][:h4, :w4], r["inter4"][:h4, :w4], d["motion"][:h4, :w4]
+    if not np.array_equal(s["mv_dir"][inter], wm[:, :, 6][inter]):
+        msgs.append("mv_dir differs")
+    for l in (0, 1):
+        use = inter & ((wm[:, :, 6] & (1 << l)) != 0)
+        for k in (0, 1):
+            if not np.array_equal(s["mv"][:, :, l, k][use], wm[:, :, 2 * l + k][use]):
+                j = np.argwhere(use & (s["mv"][:, :, l, k] != wm[:, :, 2 * l + k]))[0]
+                msgs.append(f"mv[{l}][{k}] differs first at 4x4 {j.tolist()}: got {s['mv'][j[0], j[1]].tolist()} want {wm[j[0], j[1]].tolist()}")
+        if not np.array_equal(f4["mv_ref%d" % l][use], wm[:, :, 4 + l][use]):
+            msgs.append(f"mv_ref{l} differs")
+    flags = wm[:, :, 7]
+    for nme, val in (("skipped", flags & 1), ("merged", (flags >> 1) & 1), ("merge_idx", (flags >> 2) & 7), ("mv_cand0", (flags >> 8) & 7), ("mv_cand1", (flags >> 11) & 7)):
+        if not np.array_equal(f4[nme][inter], val[inter]):
+            j = np.argwhere(inter & (f4[nme] != val))[0]
+            msgs.append(f"{nme} differs first at 4x4 {j.tolist()}")
+    for c, nme in enumerate(("rec_y", "rec_u", "rec_v")):
+        if not np.array_equal(r[nme], d["rec"][c]):
+            j = np.argwhere(r[nme] != d["rec"][c])[0]
+            msgs.append(f"{nme} differs first at {j.tolist()}")
+    for k in range(wc * hc):
+        hh, ww = min(64, H - (k // wc) * 64), min(64, W - (k % wc) * 64)
+        a, b = r["coeff"][k], d["coeff"][k]
+        if not (np.array_equal(a[:4096].reshape(64, 64)[:hh, :ww], b[:4096].reshape(64, 64)[:hh, :ww]) and
+                np.array_equal(a[4096:].reshape(2, 32, 32)[:, :hh // 2, :ww // 2], b[4096:].reshape(2, 32, 32)[:, :hh // 2, :ww // 2])):
+            msgs.append(f"levels differ in CTU {k}")
+            break
+    for j, what in enumerate(("start", "after search", "after coder")):
+        a, b = r["models"][:, j, :1028], d["models"][:, j, :1028]
+        if not np.array_equal(a, b):
+            k = int(np.argwhere((a != b).any(axis=1))[0][0])
+            av, bv = a[k].view(np.uint16), b[k].view(np.uint16)
+            msgs.append(f"models {what}: first CTU {k} entries {(np.argwhere(av != bv).ravel() % 257).tolist()[:8]}")
+        a, b = r["models_inter_states"][:, j], np.ascontiguousarray(d["models_inter"][:, j, :72]).view(np.uint16)
+        if not np.array_equal(a, b):
+            k = int(np.argwhere((a != b).any(axis=1))[0][0])
+            msgs.append(f"inter models {what}: first CTU {k} entries {(np.argwhere(a[k] != b[k]).ravel() % 18).tolist()[:8]}")
+    return msgs
+
+
 def run_inter_oracle(orc, W, H, depth, pics, P, ctx_trace=False):
     """The oracle on every picture in coding order, references = the ENCODER's output pictures and side information (so one picture's
     mismatch does not spread) -> yields (frame, record dict, oracle result, trace rows, n_trace).  ctx_trace: d["ctx_trace"] = (ints, doubles)

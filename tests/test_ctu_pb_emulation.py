@@ -1,0 +1,23 @@
+"""The P / B CTU search kernel's LOGIC without a GPU: uvg266_amd/csrc/ctu_pb.h built for the host with one emulated lane (tests/emul/)
+against the reference encoder's own records of low-delay encodes (tests/golden/ref_inter_*: decisions, motion, reconstruction, levels,
+the three model sets of every CTU, through the real coder's model adaptation and history table)."""
+import os
+import numpy as np
+import pytest
+import helpers as H
+
+GOLDENS = ["ref_inter_136x72_10_qp22_4frames", "ref_inter_192x128_8_qp17_5frames", "ref_inter_264x136_8_qp32_9frames"]
+
+
+@pytest.mark.parametrize("name", GOLDENS)
+def test_emulated_pb_kernel_equals_the_reference_run(name):
+    g = np.load(os.path.join(H.GOLDEN, name + ".npz"))
+    W, Hh, depth, pics, P = H.inter_pictures_from_golden(g)
+    n = 0
+    for fr, d, prm, F, keep in H.iter_inter_frames(W, Hh, P):
+        if int(d["meta"][6]) == 2:
+            continue
+        r = H.emul_search_inter_picture(depth, prm, F, *pics[fr])
+        assert H.compare_device_inter_picture(W, Hh, d, r) == [], f"frame {fr}"
+        n += 1
+    assert n >= 3

@@ -31,6 +31,9 @@
 #include "vvc_ctx_init.h"
 #include "vvc_rdoq_tables.h"
 #include "../../include/uvg266_hip.h"
+#if defined(CTU_PB)
+#include "inter_cand_dev.h"
+#endif
 
 #if defined(__HIPCC__)
 #define CTU_NOINLINE __attribute__((noinline))
@@ -97,9 +100,15 @@ static int g_emul_lazy = 0;      // host emulation: pretend a CU's own cost is n
 #endif
 
 enum { LCU = 64, LCU_C = 32, PY = 68, PC = 36, NMODELS = 257 };
+// P / B pictures (ctu_pb.h, compiled with -DCTU_PB): the 18 models of the inter syntax sit behind the 257 in every LDS model set
+#if defined(CTU_PB)
+enum { NMX = NMODELS + 18 };
+#else
+enum { NMX = NMODELS };
+#endif
 enum { M_SIGGRP = 0, M_SIG = 4, M_PAR = 28, M_GT1 = 70, M_GT2 = 112, M_LASTX = 154, M_LASTY = 194, M_CBF_LUMA = 234, M_CBF_CB = 238,
        M_CBF_CR = 240, M_SPLIT = 244, M_MPM = 253, M_PLANAR = 254, M_CHROMA_PRED = 256 };
-enum { CU_NOTSET = 0, CU_INTRA = 1 };
+enum { CU_NOTSET = 0, CU_INTRA = 1, CU_INTER = 2 };
 #define CTU_MAX_DOUBLE 1.7976931348623157e308
 
 // what the search reads from encoder_state_t / encoder_control_t (= uvghip_ctu_params_t, include/uvg266_hip.h)
@@ -123,6 +132,11 @@ struct level_state {        // search_cu's locals, per depth
   int has_chroma;           // carries the chroma of its area
   int pending;              // its unsplit evaluation was handed to the depth's wave
   uint32_t split_tree, mode_type_tree;
+#if defined(CTU_PB)
+  int32_t mot[8];           // the parked candidate's motion (icand::unit: type, mv[2][2], ref[2], dir)
+  uint8_t fl[8];            // uvghip_inter4_t: skipped, merged, merge_idx, root_cbf, mv_cand0, mv_cand1, mv_ref0, mv_ref1
+  int32_t cbf4[4];          // a 64x64 inter CU: the flags of its four transform units
+#endif
 };
 
 template <typename PX> struct px_info;
@@ -152,7 +166,15 @@ struct wctx {
   uint8_t cg_flag[64];
   int8_t mpm[6];
   int16_t refn;                                     // entries of a reference row
+#if defined(CTU_PB)
+  int32_t rq_root;                                  // RDOQ prices a luma block's "no coefficients" with the root cbf (a block of an inter CU, rdo.c:1774)
+#endif
 };
+#if defined(CTU_PB)
+#define CTU_RQ_ROOT(V) ((V)->rq_root)
+#else
+#define CTU_RQ_ROOT(V) 0
+#endif
 
 constexpr int arena_bytes(int n)     // one depth's share of the arena (n = its luma block size)
 {
@@ -164,6 +186,35 @@ constexpr int arena_bytes(int n)     // one depth's share of the arena (n = its 
 enum { ARENA_BYTES = arena_bytes(4) + arena_bytes(8) + arena_bytes(16) + arena_bytes(32) };
 
 struct scratch;
+#if defined(CTU_PB)
+// ---- P / B pictures: what the inter search keeps beside the intra state (ctu_pb.h) ----
+struct pb_cand {            // one entry of the reference's unit_stats_map_t: a candidate motion with its cost
+  icand::unit m;
+  uint8_t merged, skipped, merge_idx, cand0, cand1, pad[3];
+  double cost, bits;
+};
+struct pb_state {
+  icand::unit mot[17 * 17 + 1];        // motion of every 4x4 unit of the CTU and of the row / column before it ([289]: the CTU above right, unused with WPP)
+  uint8_t fl[17 * 17][8];              // uvghip_inter4_t of the same units
+  int32_t hmvp[41];                    // the row's history table as the search sees it: [0] entries, then 5 units, most recent first
+  int32_t hmvp_entry[4][41];           // ... at the entry of the node of each depth 0..3 (search_cu's hmvp_lut)
+  int32_t hmvp_coder[41];              // ... as the real coder leaves it (what the next CTU of the row starts from)
+  uint32_t work0[NMX];                 // the models the 64x64 candidate works on (work[L - 1] of depth 0)
+  icand::frame_ctx f;                  // the call context of the candidate derivations
+  icand::amvp_ws ws;
+  icand::merge_cand mc[6];
+  int32_t n_mc;
+  pb_cand cur;                         // search_pu_inter's cur_pu
+  pb_cand merge[6], amvp[3][8];
+  int8_t merge_keys[8], amvp_keys[3][8];
+  int32_t merge_size, amvp_size[3];
+  int32_t mv_cand[2][2];               // info->mv_cand
+  int32_t out4[4];
+  int32_t ref_idx2[2];
+  int32_t i0, i1, i2, i3;              // small hand-overs from lane 0 to the wave
+  double d0, d1;
+};
+#endif
 // LDS image of a workgroup
 template <typename PX> struct lds {
 #if defined(CTU_PROFILE)
@@ -173,10 +224,10 @@ template <typename PX> struct lds {
   PX cand_px[2016];                                 // a depth's CU while its split is being tried (depths 1..3)
   cu4 cu[17 * 17];                                  // index (y4 + 1) * 17 + x4 + 1
   scratch *scr;                                     // the workgroup's global scratch (the split / mode-type trees per 4x4 live there)
-  uint32_t cur[NMODELS];                            // state->search_cabac models of the walk: state0 | state1 << 16
-  uint32_t work[3][NMODELS];                        // [L - 1], L = 1..3: the models the depth-L candidate starts from (written by the walk when it
+  uint32_t cur[NMX];                                // state->search_cabac models of the walk: state0 | state1 << 16
+  uint32_t work[3][NMX];                            // [L - 1], L = 1..3: the models the depth-L candidate starts from (written by the walk when it
                                                     // posts the evaluation) and, adapted in place, leaves behind; [2] doubles as scratch for the 64x64 candidate
-  uint32_t coder[NMODELS];                          // state->cabac models
+  uint32_t coder[NMX];                              // state->cabac models
   uint8_t rdoq_state[244];                          // CTX_STATE of the coder's models at the CTU's start (what uvg_rdoq prices with)
   uint16_t scan[1024 + 256 + 64 + 16];              // coefficient scans of the four square shapes
   uint8_t inv4[16];                                 // scan index of the 4x4 group's raster position y * 4 + x
@@ -187,6 +238,9 @@ template <typename PX> struct lds {
   int32_t vsel[4];                                  // which wv[] a wave is using (a wave may borrow a larger one while its owner idles)
   int32_t req[4], done[4];                          // depth pipeline: evaluation requests / completions per depth
   alignas(16) unsigned char arena[ARENA_BYTES];
+#if defined(CTU_PB)
+  pb_state pb;
+#endif
 };
 template <typename PX> CTU_DEV wctx *wv_of(lds<PX> *S) { return &S->wv[S->vsel[CTU_WAVE]]; }
 
@@ -199,6 +253,10 @@ struct scratch {
   int16_t cand_co[2016];           // levels of the candidate CUs of depths 1..3 (cand_px_off)
   uint32_t save_tree[512];
   uint16_t tree[256], mtt[256];    // split_tree / mode_type_tree per 4x4 of the decided CTU (3 / 2 bits per depth, depths 0..4)
+#if defined(CTU_PB)
+  int32_t save_mot[256][8];        // the 64x64 candidate of a P / B picture while its split is tried: motion, flags
+  uint8_t save_fl[256][8];
+#endif
   unsigned long long prof[4][32];     // CTU_PROFILE: 0 rough search, 1 refs + prediction, 2 residual + transforms + reconstruction, 3 RDOQ, 4 SSD,
                                    // 5 RD cost (bits), 6 park / unpark / model copies, 7 64x64 candidate, 8 coder pass, 9 load, 10 store, 11 total
 };
@@ -217,6 +275,12 @@ template <typename PX> struct job {
   const uint32_t *models_in;             // the coder's models this CTU starts from (NULL: initialise for an I slice at P.qp)
   scratch *W;
   int x, y;                              // CTU origin
+#if defined(CTU_PB)
+  const struct pb_job *pb;               // the picture's inter state (ctu_pb.h)
+  uint32_t *pbm_out;                     // this CTU's three sets of the 18 inter-syntax models
+  const uint32_t *pbm_in;                // ... of the CTU it starts from (NULL with models_in)
+  int slice_type, init_qp;               // what the slice's models are initialised with (0 B, 1 P; state->frame->QP)
+#endif
 };
 
 // the source samples of a block of `color` at CTU-local (bx, by) (in that plane's samples), read from the picture; -> pointer, pitch
@@ -240,7 +304,7 @@ template <typename PX> CTU_DEV CTU_GLB const PX *src_block(const job<PX> &J, int
 #define CTU_SHARED static
 #endif
 CTU_DEV uint32_t *tab_ebits() { CTU_SHARED uint32_t t[512]; return t; }
-CTU_DEV uint8_t *tab_rate() { CTU_SHARED uint8_t t[264]; return t; }
+CTU_DEV uint8_t *tab_rate() { CTU_SHARED uint8_t t[(NMX + 7) & ~7]; return t; }
 CTU_DEV uint32_t *tab_rdoq_bits() { CTU_SHARED uint32_t t[2 * 244]; return t; }
 #define kRate (tab_rate())         // the window byte of every model (rate0 << 4 | rate1)
 
@@ -1360,7 +1424,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
     double best_cost;
     int best_last_idx_p1 = 0;
     {
-      const int o_cbf = color == 0 ? M_CBF_LUMA : color == 1 ? M_CBF_CB : M_CBF_CR + (cbf_u ? 1 : 0);
+      const int o_cbf = color == 0 ? (CTU_RQ_ROOT(V) ? 243 : M_CBF_LUMA) : color == 1 ? M_CBF_CB : M_CBF_CR + (cbf_u ? 1 : 0);
       best_cost = block_uncoded_cost + lambda * rbits(E, o_cbf, 0);
       base_cost += lambda * rbits(E, o_cbf, 1);
     }
@@ -1632,7 +1696,7 @@ template <typename PX> CTU_INLINE1 CTU_DEV void rdoq_wave(lds<PX> *S, scratch *W
   double best_cost;
   int best_last_idx_p1 = 0;
   {
-    const int o_cbf = color == 0 ? M_CBF_LUMA : color == 1 ? M_CBF_CB : M_CBF_CR + (cbf_u ? 1 : 0);
+    const int o_cbf = color == 0 ? (CTU_RQ_ROOT(V) ? 243 : M_CBF_LUMA) : color == 1 ? M_CBF_CB : M_CBF_CR + (cbf_u ? 1 : 0);
     best_cost = block_uncoded_cost + lambda * rbits(E, o_cbf, 0);
     base_cost += lambda * rbits(E, o_cbf, 1);
   }
@@ -1857,8 +1921,14 @@ template <typename PX> CTU_DEV int scaled_qp(const params &P, int color) { retur
 
 // predict + uvg_quantize_residual (quant-generic.c:460-612, RDOQ branch) of one transform block straight into D; its levels stay in
 // lv_of(V, color) and go to the CTU's coefficient array.  (x, y) / (lx, ly): luma position, n: luma size of the area.  -> has_coeffs
+// CTU_PB, flags: 1 the prediction is already in dst (a block of an inter CU), 2 no reconstruction (the early-skip test only wants
+// has_coeffs), 4 RDOQ prices "no luma coefficients" with the root cbf
 template <typename PX> CTU_INLINE1 CTU_DEV int recon_tu_inl(lds<PX> *S, const job<PX> &J, int color, int x, int y, int lx, int ly, int n, int mode, int cbf_u,
-                                                            PX *dst_, int dp, int16_t *co, int cp, int cu_n)
+                                                            PX *dst_, int dp, int16_t *co, int cp, int cu_n
+#if defined(CTU_PB)
+                                                            , int flags = 0
+#endif
+                                                            )
 {
   // dst / dp: where the block is reconstructed (the decided planes, or the depth's candidate buffer); co / cp: where its levels go
   wctx *const V = wv_of(S);
@@ -1868,6 +1938,10 @@ template <typename PX> CTU_INLINE1 CTU_DEV int recon_tu_inl(lds<PX> *S, const jo
   int sps;
   CTU_GLB const PX *Sp = src_block(J, color, lx >> c, ly >> c, &sps);
   const int depth = (int)px_info<PX>::depth;
+#if defined(CTU_PB)
+  LANE0 V->rq_root = (flags & 4) && color == 0;
+  if (!(flags & 1))
+#endif
   { CTU_T0();
   build_refs(S, J.P, color, x, y, lx, ly, n, cu_n);
   predict_block(S, mode, color, w, dst_, dp);
@@ -1889,7 +1963,11 @@ template <typename PX> CTU_INLINE1 CTU_DEV int recon_tu_inl(lds<PX> *S, const jo
   CTU_T1(J.W, 3);
   const int has = V->rq_i[1];
   PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); co[r * cp + q] = lv[e]; }
+#if defined(CTU_PB)
+  if (has && !(flags & 2)) {
+#else
   if (has) {
+#endif
     const int transform_shift = 15 - depth - l2;
     const int shift = 20 - 14 - transform_shift;
     const int32_t scale = (int32_t)kInvQuantScales[qps % 6] << (qps / 6);
@@ -1911,9 +1989,17 @@ template <typename PX> CTU_INLINE1 CTU_DEV int recon_tu_inl(lds<PX> *S, const jo
 // rough search, 20 MB of stack traffic per CTU.  The CU evaluation therefore has ONE call site (a loop over the colours) with the body
 // inlined; the rare 64x64 candidate goes through this out-of-line copy.
 template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<PX> &J, int color, int x, int y, int lx, int ly, int n, int mode, int cbf_u,
-                                                         PX *dst_, int dp, int16_t *co, int cp, int cu_n)
+                                                         PX *dst_, int dp, int16_t *co, int cp, int cu_n
+#if defined(CTU_PB)
+                                                         , int flags = 0
+#endif
+                                                         )
 {
+#if defined(CTU_PB)
+  return recon_tu_inl(S, J, color, x, y, lx, ly, n, mode, cbf_u, dst_, dp, co, cp, cu_n, flags);
+#else
   return recon_tu_inl(S, J, color, x, y, lx, ly, n, mode, cbf_u, dst_, dp, co, cp, cu_n);
+#endif
 }
 
 // uvg_pixels_calc_ssd of a w x w block of D against the source, into V->red[slot] (valid after the barrier)
@@ -2363,17 +2449,27 @@ template <typename PX> CTU_NOINLINE CTU_DEV void fill_cu(lds<PX> *S, int lx, int
     for (int xx = lx; xx < lx + n; xx += 4) {
       cu4 *c = cu_at(S, xx, yy);
       c->type = CU_INTRA; c->log2 = (uint8_t)l2; c->log2_c = (uint8_t)log2_c; c->mode = (int8_t)mode; c->mode_chroma = (int8_t)mode_chroma;
+#if defined(CTU_PB)
+      { const int u = ((yy >> 2) + 1) * 17 + (xx >> 2) + 1; S->pb.mot[u].type = CU_INTRA; S->pb.fl[u][0] = 0; S->pb.fl[u][1] = 0; }   // (skipped / merged: what the neighbours' contexts read)
+#endif
       S->scr->tree[(yy >> 2) * 16 + (xx >> 2)] = (uint16_t)split_tree;
       S->scr->mtt[(yy >> 2) * 16 + (xx >> 2)] = (uint16_t)mtt;
     }
 }
 
+#if defined(CTU_PB)
+template <typename PX> CTU_DEV void pb_intra_flag_bits(lds<PX> *S, const job<PX> &J, uint32_t *m_, int update, int x, int y, int lx, int ly, int n, double &bits);
+#endif
 // search + reconstruction + RD cost of the n x n CU at depth L as ONE coding unit (the part of search_cu before the split loop,
 // search.c:1395-1774), by the calling wave.  to_cand = 0 (a CU that cannot be split): straight into the decided planes / side
 // information / coefficient array, on the walk's models.  to_cand = 1 (its split is tried as well, by another wave at the same
 // time): into the depth's candidate buffers, on the depth's own copy of the entry models -- nothing another wave reads is touched.
 // Cost / mode / cbf go to S->lvl[L].
-template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<PX> &J, int L, int to_cand)
+template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<PX> &J, int L, int to_cand
+#if defined(CTU_PB)
+                                                         , int forced_mode = -1      // P / B: the rough search already ran (ctu_pb.h); >= 0: its mode
+#endif
+                                                         )
 {
   wctx *const V = wv_of(S);
   const params &P = J.P;
@@ -2389,14 +2485,24 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
       cu4 *c = cu_at(S, lx, ly);                           // the CU's own entry is reset (search.c:1371-1388)
       c->type = CU_NOTSET; c->cbf = 0; c->luma_edges = 0; c->chroma_edges = 0; c->mode = 0; c->mode_chroma = 0; c->log2 = (uint8_t)ilog2_dev(n);
       c->log2_c = (uint8_t)(sep ? 2 : ilog2_dev(n) - 1);
+#if defined(CTU_PB)
+      { const int u = ((ly >> 2) + 1) * 17 + (lx >> 2) + 1; S->pb.mot[u].type = CU_NOTSET; S->pb.fl[u][0] = 0; S->pb.fl[u][1] = 0; }
+#endif
     }
   }
   CTU_SYNC();
+#if defined(CTU_PB)
+  if (forced_mode < 0)
+#endif
   { CTU_T0();
   build_refs(S, P, 0, x, y, lx, ly, n, n);
   search_intra_rough(S, J, x, y, lx, ly, n);
   CTU_T1(J.W, 0); }
+#if defined(CTU_PB)
+  const int mode = forced_mode < 0 ? V->u_mode : forced_mode;
+#else
   const int mode = V->u_mode;
+#endif
   if (!to_cand) { SERIAL fill_cu(S, lx, ly, n, mode, mode, sep ? 2 : ilog2_dev(n) - 1, N.split_tree, cu_mtt(N.mode_type_tree, L)); CTU_SYNC(); }
   // where the three blocks are reconstructed and where their levels go
   int cn = n >> 1, cx = x, cy = y;                        // the chroma area (luma coordinates) and its block size
@@ -2459,6 +2565,9 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
       }
       // uvg_mock_encode_coding_unit with search_cabac.update = 1 (search.c:1700-1716)
       split_flag_bits(S, P, V->cur, 1, x, y, lx, ly, n, 0, bits);
+#if defined(CTU_PB)
+      pb_intra_flag_bits(S, J, V->cur, 1, x, y, lx, ly, n, bits);       // a P / B slice: skip flag 0, prediction mode "intra"
+#endif
       luma_mode_bits(S, V->cur, 1, x, y, lx, ly, n, mode, bits);
       if (has_chroma) chroma_mode_bits(V->cur, 1, mode, mode, bits);
     }
@@ -2501,7 +2610,7 @@ CTU_NOINLINE CTU_DEV void copy_models(uint32_t *dst_, const uint32_t *src_)
 {
   CTU_LDS uint32_t *const dst = LDSP(uint32_t, dst_);
   CTU_LDS const uint32_t *const src = LDSP(const uint32_t, src_);
-  PAR_FOR(i, NMODELS) dst[i] = src[i];
+  PAR_FOR(i, NMX) dst[i] = src[i];
   CTU_SYNC();
 }
 
@@ -2899,9 +3008,29 @@ template <typename PX> CTU_NOINLINE CTU_DEV void load_ctu(lds<PX> *S, const job<
   BLK_FOR(i, NMODELS) {
     tab_rate()[i] = k_ctx_init[3][i];
     if (J.models_in) S->coder[i] = J.models_in[i];
+#if defined(CTU_PB)
+    else models_init_one(S->coder, i, J.init_qp, J.slice_type);
+#else
     else models_init_one(S->coder, i, P.qp, 2);
+#endif
   }
+#if defined(CTU_PB)
+  BLK_FOR(i, NMX - NMODELS) {
+    tab_rate()[NMODELS + i] = k_ctx_init_inter[3][i];
+    if (J.models_in) S->coder[NMODELS + i] = J.pbm_in[i];
+    else {
+      const int v = k_ctx_init_inter[J.slice_type][i];
+      const int slope = (v >> 3) - 4, offset = ((v & 7) * 18) + 1;
+      int st = ((slope * (J.init_qp - 16)) >> 1) + offset;
+      st = st < 1 ? 1 : (st > 127 ? 127 : st);
+      S->coder[NMODELS + i] = (uint32_t)((st << 8) & 0x7fe0) | ((uint32_t)((st << 8) & 0x7ffe) << 16);
+    }
+  }
+#endif
   BLK_SYNC();
+#if defined(CTU_PB)
+  BLK_FOR(i, NMX - NMODELS) { const uint32_t v = S->coder[NMODELS + i]; S->cur[NMODELS + i] = v; J.pbm_out[i] = v; }
+#endif
   BLK_FOR(i, NMODELS) {
     const uint32_t v = S->coder[i];
     S->cur[i] = v;
