@@ -1027,6 +1027,54 @@ typedef struct uvghip_motion_t {
 UVGHIP_API int uvghip_inter_pred_satd_batch(int bitdepth, const void *cur, int cur_stride, const void *const *refs_dev, int ref_stride, int pic_w,
                                             int pic_h, int size, const uvghip_motion_t *cands, int n, uint32_t *satd, void *pred, void *stream);
 
+/* ------------------- (9) P / B pictures: the closed-loop CTU search ------------------------------------------------------- */
+
+/* replaces, for the CTUs of P / B pictures of a low-delay encode (BASELINE configs[2]: --gop lp-g4d3t1 --preset medium):
+ * encoder_state_worker_encode_lcu_search (src/encoderstate.c:808-976) minus the bitstream writer -- uvg_search_lcu / search_cu
+ * (src/search.c:1299-2479) with uvg_search_cu_inter (src/search_inter.c:2329-2406: merge analysis with SATD, the early skip test,
+ * per reference picture the starting points + early termination + hexagon search + fractional search, bi-prediction of the two best)
+ * competing with the intra search, 64x64 CUs, the history table (src/inter.c:1831-1905), RDOQ with the root cbf, the reconstruction of
+ * inter CUs (src/inter.c:400-748), then the deblocking filter's side effect on the stored motion (src/filter.c:745-765) and the real
+ * coder's model adaptation (uvg_encode_coding_tree) so that the next CTU starts from the reference's models and history table.
+ * Configuration subset: rd = 0, me = hexbs, subme = 0 or 4, bipred, early-skip, me-early-termination on, mv-rdo off, max-merge <= 6,
+ * pu-depth-inter 0-3, pu-depth-intra 1..4 / 2..4, WPP, owf = 0 (every vector inside the reference is legal), one slice per picture.
+ * Bit-exact with the reference: tests/golden/ref_inter_* (tests/test_gpu_ctu_search_pb.py; the CPU tests run the same source on the
+ * host, tests/test_ctu_pb_emulation.py).  Vectors and reference indices of the lists a 4x4 unit does NOT use may differ from the
+ * reference's cu_array in units on the right / bottom edge of a CU (csrc/ctu_pb.h); nothing reads them.
+ *
+ * One picture: `params` are ITS QP and lambdas (the GOP layer's); `pic` as for an intra picture (an inter CU's entry of `cu` holds
+ * mv_dir, mv[2][2] in 1/16 units and ref_id[] = the position of each used list's picture in the reference array; an intra CU's
+ * mv[0][0] its modes); inter4 / models_inter / trees / motion_out: the outputs beside it -- the coder's second side table
+ * (uvghip_encode_slice_rows_pb reads cu, inter4, coeff, models, models_inter as they are), three sets of the 18 inter-syntax models
+ * per CTU, split_tree | mode_type_tree << 16 per 4x4 (optional), and this picture's motion in the layout of ref_motion (optional;
+ * what later pictures that refer to this one are given).
+ * ref_y/u/v[i], ref_motion[i]: reference picture i of state->frame->ref (planes AFTER its in-loop filters; motion [per 4x4][8] int32:
+ * cu type, mv[2][2], mv_dir, the POC the L0 / L1 vector points to or -1; rows of ref_motion_stride units; an intra picture: type 1
+ * everywhere).  ref_pocs / l_size / l: state->frame->ref->pocs, ref_LX_size, ref_LX.  All pointers DEVICE memory. */
+typedef struct uvghip_ctu_pb_picture {
+  uvghip_ctu_params_t params;
+  uvghip_ctu_picture_t pic;
+  int32_t slice_type;              /* 0 B, 1 P */
+  int32_t poc, n_refs, ref_pocs[16], l_size[2], l[2][16];
+  int32_t tmvp, max_merge, merge_level;      /* cfg.tmvp_enable, cfg.max_merge, cfg.log2_parallel_merge_level */
+  int32_t frame_qp;                /* state->frame->QP: the slice's context models are initialised with it */
+  int32_t bipred, fme_level, early_skip;     /* cfg.bipred, cfg.fme_level, cfg.early_skip */
+  int32_t depth_inter_min, depth_inter_max;  /* cfg.pu_depth_inter: 0, 3 */
+  int32_t ref_stride, ref_stride_c, ref_motion_stride, reserved;
+  const void *ref_y[16], *ref_u[16], *ref_v[16];
+  const int32_t *ref_motion[16];
+  uvghip_inter4_t *inter4;
+  uint32_t *models_inter;
+  uint32_t *trees;
+  int32_t *motion_out;
+} uvghip_ctu_pb_picture_t;
+/* pictures: HOST array of n pictures that do not depend on each other (each one's references are complete).  workspace:
+ * uvghip_ctu_search_pb_workspace_bytes of device memory, in use until the work enqueued on `stream` is done.  Uploads the picture
+ * table (a synchronous copy, after waiting for `stream`), then enqueues one launch: one wave per CTU, released in an order that
+ * respects the left / upper / upper-right dependencies, pictures interleaved. */
+UVGHIP_API size_t uvghip_ctu_search_pb_workspace_bytes(int n_pictures, int pic_w, int pic_h);
+UVGHIP_API int uvghip_ctu_search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictures, void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,7 +78,7 @@ def test_no_kernel_uses_scratch():
     assert len(files) >= 10, "build with `python __graft_entry__.py` first"
     kernels = 0
     for f in files:
-        if os.path.basename(f) == "ctu_search.usage":
+        if os.path.basename(f) in ("ctu_search.usage", "ctu_search_pb.usage"):
             # the whole-CTU search kernel is one long-running workgroup per CTU, not a per-launch latency path: its rough-search
             # tile arrays (64 differences per lane) live in scratch for now -- see DESIGN.md, "closed-loop CTU search"
             continue

@@ -1,0 +1,86 @@
+"""uvghip_ctu_search_pb on the GPU: the closed-loop CTU search of the P / B pictures of three low-delay encodes of the reference encoder
+(tests/golden/ref_inter_*), every picture of a sequence in ONE call (their references are the encoder's own output pictures, so they do
+not depend on each other and their wavefronts interleave) -- decisions, motion, reconstruction, levels and the three model sets of every
+CTU equal the encoder's records; then the device coder turns the device search's hand-over into the encoder's slice data."""
+import ctypes
+import os
+import numpy as np
+import pytest
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+GOLDENS = ["ref_inter_136x72_10_qp22_4frames", "ref_inter_192x128_8_qp17_5frames", "ref_inter_264x136_8_qp32_9frames"]
+
+
+def device_pictures(W, Hh, depth, pics, P, repeat=1):
+    """-> (list of lib.CtuPbPicture, per-picture dict of the device tensors behind them, the records in the same order)"""
+    import torch
+    from uvg266_amd import lib
+    wc, hc = (W + 63) // 64, (Hh + 63) // 64
+    n4 = hc * 16 * wc * 16
+    tdt = torch.uint8 if depth == 8 else torch.uint16
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    cache = {}
+
+    def ref_dev(key, a):
+        if key not in cache:
+            cache[key] = dev(a)
+        return cache[key]
+    descs, tens, recs = [], [], []
+    for rep in range(repeat):
+        for fr, d, prm, F, keep in H.iter_inter_frames(W, Hh, P):
+            if int(d["meta"][6]) == 2:
+                continue
+            q = lib.CtuPbPicture()
+            cp = H.ctu_params(prm)
+            assert ctypes.sizeof(cp) == ctypes.sizeof(q.params)
+            ctypes.memmove(ctypes.byref(q.params), ctypes.byref(cp), ctypes.sizeof(cp))
+            t = dict(src=[dev(p) for p in pics[fr]], rec=[torch.zeros((Hh >> c, W >> c), dtype=tdt, device="cuda") for c in (0, 1, 1)],
+                     scu=torch.zeros(n4 * H.SCU_NP.itemsize, dtype=torch.uint8, device="cuda"), i4=torch.zeros(n4 * 8, dtype=torch.uint8, device="cuda"),
+                     trees=torch.zeros(n4, dtype=torch.int32, device="cuda"), mot=torch.zeros(n4 * 8, dtype=torch.int32, device="cuda"),
+                     co=torch.zeros(wc * hc * 6144, dtype=torch.int16, device="cuda"), mo=torch.zeros(wc * hc * 3 * 257, dtype=torch.int32, device="cuda"),
+                     mi=torch.zeros(wc * hc * 3 * 18, dtype=torch.int32, device="cuda"), refs=[])
+            c = q.pic
+            c.src_y, c.src_u, c.src_v = (a.data_ptr() for a in t["src"])
+            c.rec_y, c.rec_u, c.rec_v = (a.data_ptr() for a in t["rec"])
+            c.src_stride = c.rec_stride = W
+            c.src_stride_c = c.rec_stride_c = W // 2
+            c.cu, c.cu_stride, c.coeff, c.models = t["scu"].data_ptr(), wc * 16, t["co"].data_ptr(), t["mo"].data_ptr()
+            for f in ("slice_type", "poc", "n_refs", "tmvp", "max_merge", "merge_level", "frame_qp", "bipred", "fme_level", "early_skip", "depth_inter_min",
+                      "depth_inter_max"):
+                setattr(q, f, getattr(F, f))
+            for i in range(16):
+                q.ref_pocs[i], q.l[0][i], q.l[1][i] = F.ref_pocs[i], F.l[0][i], F.l[1][i]
+            q.l_size[0], q.l_size[1] = F.l_size[0], F.l_size[1]
+            q.ref_stride, q.ref_stride_c, q.ref_motion_stride = W, W // 2, wc * 16
+            for i in range(F.n_refs):
+                planes = [ref_dev((F.ref_pocs[i], k), keep[4 * i + k]) for k in range(3)]
+                rm = ref_dev((F.ref_pocs[i], 3), keep[4 * i + 3])
+                t["refs"] += planes + [rm]
+                q.ref_y[i], q.ref_u[i], q.ref_v[i], q.ref_motion[i] = planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(), rm.data_ptr()
+            q.inter4, q.models_inter, q.trees, q.motion_out = t["i4"].data_ptr(), t["mi"].data_ptr(), t["trees"].data_ptr(), t["mot"].data_ptr()
+            descs.append(q); tens.append(t); recs.append((fr, d))
+    return descs, tens, recs
+
+
+def result_of(W, Hh, t):
+    wc, hc = (W + 63) // 64, (Hh + 63) // 64
+    n4 = hc * 16 * wc * 16
+    return H.inter_result_from_device_layout(
+        W, Hh, *(a.cpu().numpy() for a in t["rec"]), t["scu"].cpu().numpy().view(H.SCU_NP), t["i4"].cpu().numpy().view(H.INTER4_NP),
+        t["trees"].cpu().numpy().view(np.uint32), t["mot"].cpu().numpy().reshape(n4, 8), t["co"].cpu().numpy(), t["mo"].cpu().numpy().view(np.uint32),
+        t["mi"].cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.parametrize("name", GOLDENS)
+def test_pb_ctu_search_equals_the_encoders_records(hip, name):
+    import torch
+    from uvg266_amd import api
+    g = np.load(os.path.join(H.GOLDEN, name + ".npz"))
+    W, Hh, depth, pics, P = H.inter_pictures_from_golden(g)
+    descs, tens, recs = device_pictures(W, Hh, depth, pics, P, repeat=2)         # every picture twice: more wavefronts in flight, same answers
+    ws = api.ctu_search_pb(descs, depth)
+    torch.cuda.synchronize()
+    assert len(descs) >= 6
+    for t, (fr, d) in zip(tens, recs):
+        assert H.compare_device_inter_picture(W, Hh, d, result_of(W, Hh, t)) == [], f"frame {fr}"

@@ -5,6 +5,8 @@ enqueues the kernel on torch's current stream and returns device tensors.
 Planes are 2-D tensors (rows x stride) of dtype uint8 (8-bit) or uint16/int16
 (10-bit); `width` is the visible width when the stride is larger.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -782,3 +784,15 @@ def inter_pred_satd_batch(cur, refs, ref_tab, cands, size, want_pred=False, stre
     _lib.check(L.uvghip_inter_pred_satd_batch(_depth(cur), _dev(cur), cur.stride(0), _dev(ref_tab), refs[0].stride(0), cur.shape[1], cur.shape[0], size, _dev(cands), n,
                                               _dev(satd), None if pred is None else _dev(pred), _stream() if stream is None else stream), "uvghip_inter_pred_satd_batch")
     return satd, pred
+
+
+def ctu_search_pb(pictures, depth, stream=None):
+    """uvghip_ctu_search_pb: the closed-loop CTU search of n independent P / B pictures.  pictures: list of lib.CtuPbPicture whose pointers
+    refer to device tensors the caller keeps alive.  Returns the workspace tensor (in use until the stream has run the launch)."""
+    n = len(pictures)
+    L = _lib.init(torch.cuda.current_device())
+    arr = (_lib.CtuPbPicture * n)(*pictures)
+    W, H = pictures[0].params.pic_w, pictures[0].params.pic_h
+    ws = torch.zeros(L.uvghip_ctu_search_pb_workspace_bytes(n, W, H), dtype=torch.uint8, device="cuda")
+    _lib.check(L.uvghip_ctu_search_pb(depth, ctypes.byref(arr), n, _dev(ws), _stream() if stream is None else stream), "uvghip_ctu_search_pb")
+    return ws

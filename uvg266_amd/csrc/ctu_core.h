@@ -200,6 +200,7 @@ struct pb_state {
   int32_t hmvp_entry[4][41];           // ... at the entry of the node of each depth 0..3 (search_cu's hmvp_lut)
   int32_t hmvp_coder[41];              // ... as the real coder leaves it (what the next CTU of the row starts from)
   uint32_t work0[NMX];                 // the models the 64x64 candidate works on (work[L - 1] of depth 0)
+  uint32_t cnt_models[NMX];            // a counting-only bit cost adapts the last-position / group-flag models on this copy
   icand::frame_ctx f;                  // the call context of the candidate derivations
   icand::amvp_ws ws;
   icand::merge_cand mc[6];
@@ -2177,7 +2178,11 @@ template <typename PX> CTU_DEV double coeff_bits4(lds<PX> *S, CTU_LDS uint32_t *
     double bits = 0;
     CTU_LDS uint32_t *mk = m;
     if (!update) {
+#if defined(CTU_PB)
+      mk = LDSP(uint32_t, S->pb.cnt_models);
+#else
       mk = LDSP(uint32_t, S->work[2]);
+#endif
       for (int i = M_LASTX; i < M_CBF_LUMA; ++i) mk[i] = m[i];
     }
     const int pos_last = scan[last], last_y = pos_last >> 2, last_x = pos_last & 3;
@@ -2367,7 +2372,11 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
     if (!update) {
       // counting only: these bins still adapt their models WITHIN the block (the reference counts on a copy) -- work on a copy
       // of the few models involved (work[0] is nobody's: depth 0 has no unsplit candidate of its own)
+#if defined(CTU_PB)
+      mk = (CTU_LDS uint32_t *)S->pb.cnt_models;       // (every work[] set is some depth's here)
+#else
       mk = (CTU_LDS uint32_t *)S->work[2];
+#endif
       for (int i = 0; i < 4; ++i) mk[M_SIGGRP + i] = m[M_SIGGRP + i];
       for (int i = M_LASTX; i < M_CBF_LUMA; ++i) mk[i] = m[i];
     }

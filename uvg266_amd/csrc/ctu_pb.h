@@ -358,7 +358,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void me_integer(lds<PX> *S, const me
     for (int i = 1; i < 9; ++i) check_mv_cost(I, mx + qx[i], my + qy[i], b);
   }
 }
-// search_frac (:1029-1226): every candidate block of a step is the prediction at that fractional position (oracle/orc_ipol.c header)
+// search_frac (:1029-1226): every candidate block of a step is the prediction at that fractional position (tools/refcheck proves the identity against the four-block functions)
 template <typename PX> CTU_NOINLINE CTU_DEV void me_frac(lds<PX> *S, const me_info<PX> &I, PX *pred, int pp, me_best &b)
 {
   wctx *const V = wv_of(S);

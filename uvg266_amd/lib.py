@@ -80,6 +80,17 @@ class SlicePb(ctypes.Structure):
                 ("models_inter", ctypes.c_void_p)]
 
 
+class CtuPbPicture(ctypes.Structure):
+    """uvghip_ctu_pb_picture_t: one P / B picture of the closed-loop CTU search."""
+    _fields_ = [("params", CtuParams), ("pic", CtuPicture), ("slice_type", ctypes.c_int32), ("poc", ctypes.c_int32), ("n_refs", ctypes.c_int32),
+                ("ref_pocs", ctypes.c_int32 * 16), ("l_size", ctypes.c_int32 * 2), ("l", (ctypes.c_int32 * 16) * 2), ("tmvp", ctypes.c_int32),
+                ("max_merge", ctypes.c_int32), ("merge_level", ctypes.c_int32), ("frame_qp", ctypes.c_int32), ("bipred", ctypes.c_int32),
+                ("fme_level", ctypes.c_int32), ("early_skip", ctypes.c_int32), ("depth_inter_min", ctypes.c_int32), ("depth_inter_max", ctypes.c_int32),
+                ("ref_stride", ctypes.c_int32), ("ref_stride_c", ctypes.c_int32), ("ref_motion_stride", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("ref_y", ctypes.c_void_p * 16), ("ref_u", ctypes.c_void_p * 16), ("ref_v", ctypes.c_void_p * 16), ("ref_motion", ctypes.c_void_p * 16),
+                ("inter4", ctypes.c_void_p), ("models_inter", ctypes.c_void_p), ("trees", ctypes.c_void_p), ("motion_out", ctypes.c_void_p)]
+
+
 class MeJob(ctypes.Structure):
     """uvghip_me_job_t."""
     _fields_ = [("x", ctypes.c_int32), ("y", ctypes.c_int32), ("ref", ctypes.c_int32), ("mv_cand", (ctypes.c_int32 * 2) * 2), ("extra_mv", ctypes.c_int32 * 2),
@@ -191,6 +202,8 @@ SIGNATURES = {
     "uvghip_write_picture_nals": (c_int, [c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_int, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "uvghip_slice_rows_pb_workspace_bytes": (ctypes.c_size_t, [c_int]),
     "uvghip_encode_slice_rows_pb": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_ctu_search_pb_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
+    "uvghip_ctu_search_pb": (c_int, [c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_merge_cand_batch": (c_int, [c_vp, c_vp, c_vp, ctypes.c_long, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvghip_amvp_cand_batch": (c_int, [c_vp, c_vp, c_vp, ctypes.c_long, c_vp, c_int, c_vp, c_vp]),
     "uvghip_inter_pred_satd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
