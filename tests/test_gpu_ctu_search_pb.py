@@ -84,3 +84,57 @@ def test_pb_ctu_search_equals_the_encoders_records(hip, name):
     assert len(descs) >= 6
     for t, (fr, d) in zip(tens, recs):
         assert H.compare_device_inter_picture(W, Hh, d, result_of(W, Hh, t)) == [], f"frame {fr}"
+
+
+@pytest.mark.parametrize("name", GOLDENS)
+def test_device_search_then_device_coder_gives_the_encoders_slice_data(hip, name):
+    """Both halves on the device, nothing of the encoder's in between: uvghip_ctu_search_pb's hand-over (side information, second table,
+    levels, models) goes straight into uvghip_encode_slice_rows_pb; with the encoder's SAO decisions the rows are the slice data of
+    every P / B picture inside the encoder's .266, byte for byte."""
+    import torch
+    from uvg266_amd import api, lib
+    L = lib.init(0)
+    g = np.load(os.path.join(H.GOLDEN, name + ".npz"))
+    W, Hh, depth, pics, P = H.inter_pictures_from_golden(g)
+    wc, hc = (W + 63) // 64, (Hh + 63) // 64
+    ctus = wc * hc
+    descs, tens, recs = device_pictures(W, Hh, depth, pics, P)
+    ws = api.ctu_search_pb(descs, depth)
+    torch.cuda.synchronize()
+    stream = g["bitstream"].tobytes()
+    gw, gh = (W + 7) // 8, (Hh + 7) // 8
+    total = 0
+    for q0, t, (fr, d) in zip(descs, tens, recs):
+        sel = [k for k in range(len(g["meta"])) if int(g["meta"][k][0]) == fr]
+        order = sorted(sel, key=lambda k: (int(g["meta"][k][2]), int(g["meta"][k][1])))
+        dsao = torch.from_numpy(np.ascontiguousarray(g["sao"][order].reshape(1, ctus, 34))).cuda()
+        dsaom = torch.from_numpy(np.ascontiguousarray(g["sao_models"][order].reshape(1, ctus, 6)).view(np.int16)).cuda()
+        refm = t["refs"][4 * q0.l[0][0] + 3]                               # the collocated picture's motion: L0[0]
+        col = refm.reshape(hc * 16, wc * 16, 8)[0:2 * gh:2, 0:2 * gw:2][:gh, :gw].contiguous()
+        pic = (lib.CtuPicture * 1)()
+        pic[0] = lib.CtuPicture(None, None, None, 0, 0, None, None, None, 0, 0, t["scu"].data_ptr(), wc * 16, 0, t["co"].data_ptr(), t["mo"].data_ptr())
+        pb = (lib.SlicePb * 1)()
+        q = pb[0]
+        for f in ("slice_type", "poc", "n_refs", "tmvp", "max_merge", "merge_level", "frame_qp"):
+            setattr(q, f, getattr(q0, f))
+        for i in range(16):
+            q.ref_pocs[i], q.l[0][i], q.l[1][i] = q0.ref_pocs[i], q0.l[0][i], q0.l[1][i]
+        q.l_size[0], q.l_size[1] = q0.l_size[0], q0.l_size[1]
+        q.col, q.inter4, q.models_inter = col.data_ptr(), t["i4"].data_ptr(), t["mi"].data_ptr()
+        wsc = torch.empty(L.uvghip_slice_rows_pb_workspace_bytes(1), dtype=torch.uint8, device="cuda")
+        cap = 3 * 64 * W * 2
+        out = torch.zeros((hc, cap), dtype=torch.uint8, device="cuda")
+        nb = torch.zeros(hc, dtype=torch.int32, device="cuda")
+        lib.check(L.uvghip_encode_slice_rows_pb(depth, ctypes.byref(q0.params), pic, pb, 1, dsao.data_ptr(), dsaom.data_ptr(), wsc.data_ptr(), out.data_ptr(), cap,
+                                                nb.data_ptr(), None), "uvghip_encode_slice_rows_pb")
+        torch.cuda.synchronize()
+        nbh, outh = nb.cpu().numpy(), out.cpu().numpy()
+        off = g["row_off"][fr * hc:fr * hc + hc + 1]
+        whole = b""
+        for r in range(hc):
+            want = g["row_bytes"][off[r]:off[r + 1]]
+            assert nbh[r] == len(want) and np.array_equal(outh[r, :nbh[r]], want), (name, fr, r, int(nbh[r]), len(want))
+            whole += outh[r, :nbh[r]].tobytes()
+        assert stream.find(whole) > 0, (name, fr)
+        total += len(whole)
+    assert total > 300
