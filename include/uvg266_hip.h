@@ -555,6 +555,14 @@ UVGHIP_API int uvghip_sao_decide_pictures(int bitdepth, int n_pictures, int pic_
                                           uint16_t *models_out, uvghip_sao_param_t *params_y, uvghip_sao_param_t *params_u,
                                           uvghip_sao_param_t *params_v, void *stream);
 
+/* the same for the pictures of a P / B slice: slice_type 0 B, 1 P, 2 I selects the row of the context initialisation the two SAO models
+ * start from (uvg_init_contexts, src/context.c:471-500); qp / lambda are the picture's */
+UVGHIP_API int uvghip_sao_decide_pictures_slice(int bitdepth, int n_pictures, int pic_w, int pic_h, int qp, double lambda, int sao_type,
+                                                int slice_type, const int32_t *edge_y, const int32_t *band_y, const int32_t *edge_u,
+                                                const int32_t *band_u, const int32_t *edge_v, const int32_t *band_v, void *workspace,
+                                                int32_t *info_out, uint16_t *models_out, uvghip_sao_param_t *params_y,
+                                                uvghip_sao_param_t *params_u, uvghip_sao_param_t *params_v, void *stream);
+
 /* ------------------------------------------ (2) batched ABI: deblocking ---- */
 
 /* Side information of one 4x4 luma block ("SCU"), the subset of cu_info_t
@@ -924,6 +932,8 @@ typedef struct uvghip_slice_pb_t {
   const int32_t *col;              /* DEVICE: the collocated picture ref_LX[0][0] on its 8x8 grid (uvghip_merge_cand_batch's layout) */
   const uvghip_inter4_t *inter4;   /* DEVICE, cu_stride entries per row */
   const uint32_t *models_inter;    /* DEVICE: per CTU three sets of the 18 inter-syntax models (state0 | state1 << 16), as `models` holds the 257 */
+  int32_t col_stride, reserved;    /* > 0: `col` is the collocated picture's per-4x4 motion table (uvghip_ctu_pb_picture_t.motion_out) with this many
+                                    * units per row, read at its even positions; 0: `col` is already the 8x8 grid */
 } uvghip_slice_pb_t;
 /* uvghip_encode_slice_rows for P / B pictures: the skip flag, prediction mode, merge flag / index, inter direction, reference indices,
  * motion vector differences against the AMVP predictor the CU chose (uvg_inter_get_mv_cand_cua on the picture's side information with the
@@ -1074,6 +1084,24 @@ typedef struct uvghip_ctu_pb_picture {
  * respects the left / upper / upper-right dependencies, pictures interleaved. */
 UVGHIP_API size_t uvghip_ctu_search_pb_workspace_bytes(int n_pictures, int pic_w, int pic_h);
 UVGHIP_API int uvghip_ctu_search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictures, void *workspace, void *stream);
+
+/* replaces, for a group of independent P / B pictures: the whole per-picture loop of the CTU worker (src/encoderstate.c:808-976) --
+ * uvghip_ctu_search_pb, then per picture uvghip_deblock_frame_sao_snapshot on a copy of the reconstruction + uvghip_sao_stats_batch,
+ * uvghip_sao_decide_pictures_slice (the picture's QP, lambda and slice type), uvghip_deblock_frame in place on rec (boundary strengths
+ * from the motion the search stored) + uvghip_sao_apply_batch into `out` -- the picture uvg_encoder_encode returns and the next pictures'
+ * reference -- and uvghip_encode_slice_rows_pb.  sao_type: cfg.sao_type (0: no SAO, out = the deblocked picture).
+ * uvghip_loop_pb_results: device pointers into the workspace -- SAO decisions [picture][ctu][34] / models [picture][ctu][6], the rows'
+ * bytes (row r of picture p at rows + (p * n_rows + r) * row_cap) and lengths [picture][row].  The run waits for the stream between
+ * pictures (the coder's table upload); everything else is enqueued. */
+typedef struct uvghip_loop_pb_picture {
+  uvghip_ctu_pb_picture_t search;
+  void *out_y, *out_u, *out_v;
+  int32_t out_stride, out_stride_c;     /* in samples */
+} uvghip_loop_pb_picture_t;
+UVGHIP_API size_t uvghip_loop_pb_workspace_bytes(int bitdepth, int n_pictures, int pic_w, int pic_h);
+UVGHIP_API int uvghip_loop_pb_run(int bitdepth, const uvghip_loop_pb_picture_t *pictures, int n_pictures, int sao_type, void *workspace, void *stream);
+UVGHIP_API int uvghip_loop_pb_results(int bitdepth, int n_pictures, int pic_w, int pic_h, void *workspace, const int32_t **sao_info,
+                                      const uint16_t **sao_models, const uint8_t **rows, const int32_t **row_bytes, int *row_cap, int *n_rows);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,89 @@
+"""A low-delay sequence through the device, picture after picture, with NOTHING of the reference encoder in between: the I picture through
+the all-intra loop (uvghip_loop_plan_*), every P / B picture through uvghip_loop_pb_run with the DEVICE's own earlier output pictures and
+motion as its references.  Every output picture equals the picture the reference encoder produced (tests/golden/ref_inter_*: final_y/u/v),
+every picture's slice data is in the encoder's .266 byte for byte."""
+import ctypes
+import os
+import numpy as np
+import pytest
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+GOLDENS = ["ref_inter_136x72_10_qp22_4frames", "ref_inter_192x128_8_qp17_5frames", "ref_inter_264x136_8_qp32_9frames"]
+
+
+@pytest.mark.parametrize("name", GOLDENS)
+def test_sequence_closed_loop_on_the_device(hip, name):
+    import torch
+    from uvg266_amd import api, lib
+    g = np.load(os.path.join(H.GOLDEN, name + ".npz"))
+    W, Hh, depth, pics, P = H.inter_pictures_from_golden(g)
+    wc, hc = (W + 63) // 64, (Hh + 63) // 64
+    ctus, n4 = wc * hc, hc * 16 * wc * 16
+    tdt = torch.uint8 if depth == 8 else torch.uint16
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    stream = g["bitstream"].tobytes()
+    by_poc = {}                       # poc -> (planes, motion table) made by the device
+    keep = []
+    coded = 0
+    for fr, d, prm, F, _ in H.iter_inter_frames(W, Hh, P):
+        src = [dev(p) for p in pics[fr]]
+        slice_type, poc = int(d["meta"][6]), int(d["refs"][51])
+        off = g["row_off"][fr * hc:fr * hc + hc + 1]
+        if slice_type == 2:
+            cp = api.ctu_params(W, Hh, prm.qp, lam=prm.lam)
+            loop = api.ClosedLoop(cp, [tuple(src)])
+            loop.run()
+            torch.cuda.synchronize()
+            out = loop.out[0]
+            mot = torch.zeros((hc * 16, wc * 16, 8), dtype=torch.int32, device="cuda")
+            mot[:, :, 0] = loop.cu[0][:, :, 2].to(torch.int32)
+            mot[:, :, 6:8] = -1
+            rows, nb = loop.slice_data()
+            rows, nb = rows[0].cpu().numpy(), nb[0].cpu().numpy()
+            keep.append(loop)
+        else:
+            q = lib.LoopPbPicture()
+            s = q.search
+            cp = H.ctu_params(prm)
+            ctypes.memmove(ctypes.byref(s.params), ctypes.byref(cp), ctypes.sizeof(cp))
+            t = dict(rec=[torch.zeros((Hh >> c, W >> c), dtype=tdt, device="cuda") for c in (0, 1, 1)],
+                     out=[torch.zeros((Hh >> c, W >> c), dtype=tdt, device="cuda") for c in (0, 1, 1)],
+                     scu=torch.zeros(n4 * 32, dtype=torch.uint8, device="cuda"), i4=torch.zeros(n4 * 8, dtype=torch.uint8, device="cuda"),
+                     mot=torch.zeros((hc * 16, wc * 16, 8), dtype=torch.int32, device="cuda"), co=torch.zeros(ctus * 6144, dtype=torch.int16, device="cuda"),
+                     mo=torch.zeros(ctus * 3 * 257, dtype=torch.int32, device="cuda"), mi=torch.zeros(ctus * 3 * 18, dtype=torch.int32, device="cuda"))
+            c = s.pic
+            c.src_y, c.src_u, c.src_v = (a.data_ptr() for a in src)
+            c.rec_y, c.rec_u, c.rec_v = (a.data_ptr() for a in t["rec"])
+            c.src_stride = c.rec_stride = W
+            c.src_stride_c = c.rec_stride_c = W // 2
+            c.cu, c.cu_stride, c.coeff, c.models = t["scu"].data_ptr(), wc * 16, t["co"].data_ptr(), t["mo"].data_ptr()
+            for f in ("slice_type", "poc", "n_refs", "tmvp", "max_merge", "merge_level", "frame_qp", "bipred", "fme_level", "early_skip", "depth_inter_min",
+                      "depth_inter_max"):
+                setattr(s, f, getattr(F, f))
+            for i in range(16):
+                s.ref_pocs[i], s.l[0][i], s.l[1][i] = F.ref_pocs[i], F.l[0][i], F.l[1][i]
+            s.l_size[0], s.l_size[1] = F.l_size[0], F.l_size[1]
+            s.ref_stride, s.ref_stride_c, s.ref_motion_stride = W, W // 2, wc * 16
+            for i in range(F.n_refs):
+                planes, rm = by_poc[F.ref_pocs[i]]
+                s.ref_y[i], s.ref_u[i], s.ref_v[i], s.ref_motion[i] = planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(), rm.data_ptr()
+            s.inter4, s.models_inter, s.trees, s.motion_out = t["i4"].data_ptr(), t["mi"].data_ptr(), None, t["mot"].data_ptr()
+            q.out_y, q.out_u, q.out_v = (a.data_ptr() for a in t["out"])
+            q.out_stride, q.out_stride_c = W, W // 2
+            ws, info, models, rows, nb = api.loop_pb_run([q], depth)
+            torch.cuda.synchronize()
+            out, mot = t["out"], t["mot"]
+            rows, nb = rows[0].cpu().numpy(), nb[0].cpu().numpy()
+            keep += [t, ws, src]
+        by_poc[poc] = (out, mot)
+        for cidx, nme in enumerate(("final_y", "final_u", "final_v")):
+            assert np.array_equal(out[cidx].cpu().numpy(), g[nme][fr]), (name, fr, nme)
+        whole = b""
+        for r in range(hc):
+            want = g["row_bytes"][off[r]:off[r + 1]]
+            assert nb[r] == len(want) and np.array_equal(rows[r, :nb[r]], want), (name, fr, "row", r, int(nb[r]), len(want))
+            whole += rows[r, :nb[r]].tobytes()
+        assert stream.find(whole) > 0, (name, fr)
+        coded += 1
+    assert coded == int(g["dims"][4])

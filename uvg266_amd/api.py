@@ -796,3 +796,23 @@ def ctu_search_pb(pictures, depth, stream=None):
     ws = torch.zeros(L.uvghip_ctu_search_pb_workspace_bytes(n, W, H), dtype=torch.uint8, device="cuda")
     _lib.check(L.uvghip_ctu_search_pb(depth, ctypes.byref(arr), n, _dev(ws), _stream() if stream is None else stream), "uvghip_ctu_search_pb")
     return ws
+
+
+def loop_pb_run(pictures, depth, sao_type=3, stream=None):
+    """uvghip_loop_pb_run: search + in-loop filters + slice data of n independent P / B pictures (list of lib.LoopPbPicture over device
+    tensors the caller keeps alive) -> (workspace, sao_info [n, ctus, 34] int32, sao_models [n, ctus, 6] int16, rows [n, hc, row_cap]
+    uint8, row_bytes [n, hc] int32), device views into the workspace."""
+    n = len(pictures)
+    L = _lib.init(torch.cuda.current_device())
+    arr = (_lib.LoopPbPicture * n)(*pictures)
+    W, H = pictures[0].search.params.pic_w, pictures[0].search.params.pic_h
+    ws = torch.zeros(L.uvghip_loop_pb_workspace_bytes(depth, n, W, H), dtype=torch.uint8, device="cuda")
+    _lib.check(L.uvghip_loop_pb_run(depth, ctypes.byref(arr), n, sao_type, _dev(ws), _stream() if stream is None else stream), "uvghip_loop_pb_run")
+    a, b, c, d = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    cap, nr = ctypes.c_int(), ctypes.c_int()
+    _lib.check(L.uvghip_loop_pb_results(depth, n, W, H, _dev(ws), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d), ctypes.byref(cap), ctypes.byref(nr)),
+               "uvghip_loop_pb_results")
+    ctus, base = ((W + 63) // 64) * ((H + 63) // 64), ws.data_ptr()
+    view = lambda p, nbytes: ws[p.value - base:p.value - base + nbytes]
+    return (ws, view(a, n * ctus * 34 * 4).view(torch.int32).view(n, ctus, 34), view(b, n * ctus * 6 * 2).view(torch.int16).view(n, ctus, 6),
+            view(c, n * nr.value * cap.value).view(n, nr.value, cap.value), view(d, n * nr.value * 4).view(torch.int32).view(n, nr.value))

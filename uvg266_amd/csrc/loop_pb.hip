@@ -1,0 +1,149 @@
+// uvghip_loop_pb_*: one call per group of independent P / B pictures for the whole per-picture loop of the encoder's CTU worker
+// (src/encoderstate.c:808-976): the closed-loop CTU search (uvghip_ctu_search_pb), then per picture the in-loop filters on the
+// reference's schedule -- every CTU deblocked by its own edges only (what uvg_sao_search_lcu reads), SAO statistics and decisions with
+// the slice type's models, deblocking of the reconstruction, SAO apply into the output picture (the next pictures' reference) -- and
+// the slice data (uvghip_encode_slice_rows_pb).  Host code only: it strings the library's own entry points together on the caller's
+// stream inside one workspace.
+#include "uvghip_common.h"
+#include <vector>
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct layout_t { size_t search, snap, rects_y, rects_c, edge[3], band[3], decide, info, models, params[3], coder, row_bytes, rows, total; int row_cap; };
+
+layout_t layout_of(int bitdepth, int n, int w, int h)
+{
+  const size_t ctus = (size_t)((w + 63) / 64) * ((h + 63) / 64), b = bitdepth == 8 ? 1 : 2;
+  layout_t L;
+  size_t at = 0;
+  auto take = [&](size_t bytes) { const size_t o = at; at = align_up(at + bytes, 256); return o; };
+  L.search = take(uvghip_ctu_search_pb_workspace_bytes(n, w, h));
+  L.snap = take(((size_t)w * h * 3 / 2) * b);                     // one picture at a time
+  L.rects_y = take(ctus * sizeof(uvghip_rect_t));
+  L.rects_c = take(ctus * sizeof(uvghip_rect_t));
+  for (int c = 0; c < 3; ++c) { L.edge[c] = take(ctus * 40 * 4); L.band[c] = take(ctus * 64 * 4); }
+  L.decide = take(uvghip_sao_decide_workspace_bytes(1, w, h));
+  L.info = take((size_t)n * ctus * 34 * 4);
+  L.models = take((size_t)n * ctus * 6 * 2);
+  for (int c = 0; c < 3; ++c) L.params[c] = take(ctus * sizeof(uvghip_sao_param_t));
+  const size_t hc = (size_t)((h + 63) / 64);
+  L.row_cap = 3 * 64 * w * (int)b;
+  L.coder = take(uvghip_slice_rows_pb_workspace_bytes(1));
+  L.row_bytes = take((size_t)n * hc * 4);
+  L.rows = take((size_t)n * hc * L.row_cap);
+  L.total = at;
+  return L;
+}
+
+}  // namespace
+
+extern "C" size_t uvghip_loop_pb_workspace_bytes(int bitdepth, int n_pictures, int pic_w, int pic_h)
+{
+  if ((bitdepth != 8 && bitdepth != 10) || n_pictures <= 0 || pic_w <= 0 || pic_h <= 0) return 0;
+  return layout_of(bitdepth, n_pictures, pic_w, pic_h).total;
+}
+
+extern "C" int uvghip_loop_pb_results(int bitdepth, int n_pictures, int pic_w, int pic_h, void *workspace, const int32_t **sao_info, const uint16_t **sao_models,
+                                      const uint8_t **rows, const int32_t **row_bytes, int *row_cap, int *n_rows)
+{
+  if ((bitdepth != 8 && bitdepth != 10) || n_pictures <= 0 || pic_w <= 0 || pic_h <= 0 || !workspace) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const layout_t L = layout_of(bitdepth, n_pictures, pic_w, pic_h);
+  unsigned char *ws = static_cast<unsigned char *>(workspace);
+  if (sao_info) *sao_info = reinterpret_cast<const int32_t *>(ws + L.info);
+  if (sao_models) *sao_models = reinterpret_cast<const uint16_t *>(ws + L.models);
+  if (rows) *rows = ws + L.rows;
+  if (row_bytes) *row_bytes = reinterpret_cast<const int32_t *>(ws + L.row_bytes);
+  if (row_cap) *row_cap = L.row_cap;
+  if (n_rows) *n_rows = (pic_h + 63) / 64;
+  return 0;
+}
+
+extern "C" int uvghip_loop_pb_run(int bitdepth, const uvghip_loop_pb_picture_t *pictures, int n_pictures, int sao_type, void *workspace, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
+  if (!pictures || n_pictures <= 0 || !workspace || sao_type < 0 || sao_type > 3) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const int w = pictures[0].search.params.pic_w, h = pictures[0].search.params.pic_h;
+  if (w <= 0 || h <= 0) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  std::vector<uvghip_ctu_pb_picture_t> sp(n_pictures);
+  for (int i = 0; i < n_pictures; ++i) {
+    const uvghip_loop_pb_picture_t &q = pictures[i];
+    if (!q.out_y || !q.out_u || !q.out_v || q.out_stride < w || q.out_stride_c < w / 2) return uvghip_set_error(hipErrorInvalidValue, "uvghip_loop_pb_run: output planes");
+    // the filters run without a chroma QP table (deblock.hip: identity)
+    if (q.search.params.qp_c != q.search.params.qp) return uvghip_set_error(hipErrorInvalidValue, "uvghip_loop_pb_run: qp_c != qp needs a chroma QP table");
+    sp[i] = q.search;
+  }
+  const layout_t L = layout_of(bitdepth, n_pictures, w, h);
+  unsigned char *ws = static_cast<unsigned char *>(workspace);
+  hipStream_t st = uvghip_stream(stream);
+  if (int rc = uvghip_ctu_search_pb(bitdepth, sp.data(), n_pictures, ws + L.search, stream)) return rc;
+  const int wc = (w + 63) / 64, hc = (h + 63) / 64, ctus = wc * hc, cw = w / 2, ch = h / 2;
+  const size_t b = bitdepth == 8 ? 1 : 2;
+  uvghip_rect_t *rects_y = reinterpret_cast<uvghip_rect_t *>(ws + L.rects_y), *rects_c = reinterpret_cast<uvghip_rect_t *>(ws + L.rects_c);
+  {
+    std::vector<uvghip_rect_t> ry(ctus), rc(ctus);
+    for (int cy = 0; cy < hc; ++cy)
+      for (int cx = 0; cx < wc; ++cx) {
+        const int x = cx * 64, y = cy * 64, bw = x + 64 > w ? w - x : 64, bh = y + 64 > h ? h - y : 64;
+        ry[cy * wc + cx] = uvghip_rect_t{x, y, bw, bh};
+        rc[cy * wc + cx] = uvghip_rect_t{x / 2, y / 2, bw / 2, bh / 2};
+      }
+    UVGHIP_TRY(hipMemcpy(rects_y, ry.data(), ry.size() * sizeof(uvghip_rect_t), hipMemcpyHostToDevice));
+    UVGHIP_TRY(hipMemcpy(rects_c, rc.data(), rc.size() * sizeof(uvghip_rect_t), hipMemcpyHostToDevice));
+  }
+  int32_t *edge[3], *band[3];
+  uvghip_sao_param_t *prm[3];
+  for (int c = 0; c < 3; ++c) {
+    edge[c] = reinterpret_cast<int32_t *>(ws + L.edge[c]); band[c] = reinterpret_cast<int32_t *>(ws + L.band[c]);
+    prm[c] = reinterpret_cast<uvghip_sao_param_t *>(ws + L.params[c]);
+  }
+  int32_t *sao_info = reinterpret_cast<int32_t *>(ws + L.info), *row_bytes = reinterpret_cast<int32_t *>(ws + L.row_bytes);
+  uint16_t *sao_models = reinterpret_cast<uint16_t *>(ws + L.models);
+  unsigned char *sy = ws + L.snap, *su = sy + (size_t)w * h * b, *sv = su + (size_t)cw * ch * b;
+  for (int i = 0; i < n_pictures; ++i) {
+    const uvghip_loop_pb_picture_t &q = pictures[i];
+    const uvghip_ctu_pb_picture_t &s = q.search;
+    const uvghip_ctu_picture_t &p = s.pic;
+    const int is_b = s.slice_type == 0, qp = s.params.qp;
+    int32_t *info_i = sao_info + (size_t)i * ctus * 34;
+    uint16_t *models_i = sao_models + (size_t)i * ctus * 6;
+    if (sao_type) {
+      UVGHIP_TRY(hipMemcpy2DAsync(sy, (size_t)w * b, p.rec_y, (size_t)p.rec_stride * b, (size_t)w * b, h, hipMemcpyDeviceToDevice, st));
+      UVGHIP_TRY(hipMemcpy2DAsync(su, (size_t)cw * b, p.rec_u, (size_t)p.rec_stride_c * b, (size_t)cw * b, ch, hipMemcpyDeviceToDevice, st));
+      UVGHIP_TRY(hipMemcpy2DAsync(sv, (size_t)cw * b, p.rec_v, (size_t)p.rec_stride_c * b, (size_t)cw * b, ch, hipMemcpyDeviceToDevice, st));
+      if (int rc = uvghip_deblock_frame_sao_snapshot(bitdepth, sy, w, su, sv, cw, w, h, p.cu, p.cu_stride, 0, 0, is_b, qp, nullptr, stream)) return rc;
+      if (int rc = uvghip_sao_stats_batch(bitdepth, p.src_y, p.src_stride, sy, w, rects_y, ctus, edge[0], band[0], stream)) return rc;
+      if (int rc = uvghip_sao_stats_batch(bitdepth, p.src_u, p.src_stride_c, su, cw, rects_c, ctus, edge[1], band[1], stream)) return rc;
+      if (int rc = uvghip_sao_stats_batch(bitdepth, p.src_v, p.src_stride_c, sv, cw, rects_c, ctus, edge[2], band[2], stream)) return rc;
+      if (int rc = uvghip_sao_decide_pictures_slice(bitdepth, 1, w, h, qp, s.params.lambda, sao_type, s.slice_type, edge[0], band[0], edge[1], band[1], edge[2], band[2],
+                                                    ws + L.decide, info_i, models_i, prm[0], prm[1], prm[2], stream))
+        return rc;
+    }
+    if (int rc = uvghip_deblock_frame(bitdepth, p.rec_y, p.rec_stride, p.rec_u, p.rec_v, p.rec_stride_c, w, h, p.cu, p.cu_stride, 0, 0, is_b, qp, nullptr, stream)) return rc;
+    if (sao_type) {
+      if (int rc = uvghip_sao_apply_batch(bitdepth, p.rec_y, p.rec_stride, q.out_y, q.out_stride, w, h, rects_y, prm[0], ctus, stream)) return rc;
+      if (int rc = uvghip_sao_apply_batch(bitdepth, p.rec_u, p.rec_stride_c, q.out_u, q.out_stride_c, cw, ch, rects_c, prm[1], ctus, stream)) return rc;
+      if (int rc = uvghip_sao_apply_batch(bitdepth, p.rec_v, p.rec_stride_c, q.out_v, q.out_stride_c, cw, ch, rects_c, prm[2], ctus, stream)) return rc;
+    } else {
+      UVGHIP_TRY(hipMemcpy2DAsync(q.out_y, (size_t)q.out_stride * b, p.rec_y, (size_t)p.rec_stride * b, (size_t)w * b, h, hipMemcpyDeviceToDevice, st));
+      UVGHIP_TRY(hipMemcpy2DAsync(q.out_u, (size_t)q.out_stride_c * b, p.rec_u, (size_t)p.rec_stride_c * b, (size_t)cw * b, ch, hipMemcpyDeviceToDevice, st));
+      UVGHIP_TRY(hipMemcpy2DAsync(q.out_v, (size_t)q.out_stride_c * b, p.rec_v, (size_t)p.rec_stride_c * b, (size_t)cw * b, ch, hipMemcpyDeviceToDevice, st));
+    }
+    // the slice data: the search's hand-over and the SAO decisions through the arithmetic coder
+    uvghip_slice_pb_t sl;
+    sl.slice_type = s.slice_type; sl.poc = s.poc; sl.n_refs = s.n_refs;
+    for (int k = 0; k < 16; ++k) { sl.ref_pocs[k] = s.ref_pocs[k]; sl.l[0][k] = s.l[0][k]; sl.l[1][k] = s.l[1][k]; }
+    sl.l_size[0] = s.l_size[0]; sl.l_size[1] = s.l_size[1];
+    sl.tmvp = s.tmvp; sl.max_merge = s.max_merge; sl.merge_level = s.merge_level; sl.frame_qp = s.frame_qp;
+    sl.col = s.ref_motion[s.l[0][0]]; sl.col_stride = s.ref_motion_stride; sl.reserved = 0;
+    sl.inter4 = s.inter4; sl.models_inter = s.models_inter;
+    // (the coder's table upload is a synchronous copy: the stream is drained first so that the previous picture's coder is done with it)
+    UVGHIP_TRY(hipStreamSynchronize(st));
+    if (int rc = uvghip_encode_slice_rows_pb(bitdepth, &s.params, &p, &sl, 1, sao_type ? info_i : nullptr, sao_type ? models_i : nullptr, ws + L.coder,
+                                             ws + L.rows + (size_t)i * hc * L.row_cap, L.row_cap, row_bytes + (size_t)i * hc, stream))
+      return rc;
+  }
+  return 0;
+}

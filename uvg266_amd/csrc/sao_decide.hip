@@ -172,7 +172,7 @@ __device__ void best_mode(const models2 &m, double lambda, int sao_type, const c
 
 __global__ void sao_decide_kernel(const int32_t *__restrict__ edge_y, const int32_t *__restrict__ band_y, const int32_t *__restrict__ edge_u,
                                   const int32_t *__restrict__ band_u, const int32_t *__restrict__ edge_v, const int32_t *__restrict__ band_v,
-                                  const cand *__restrict__ cands, int n_pictures, int wc, int hc, int qp, double lambda, int sao_type,
+                                  const cand *__restrict__ cands, int n_pictures, int wc, int hc, int qp, double lambda, int sao_type, int slice_type,
                                   int32_t *__restrict__ info_out, uint16_t *__restrict__ models_out, uvghip_sao_param_t *__restrict__ py,
                                   uvghip_sao_param_t *__restrict__ pu, uvghip_sao_param_t *__restrict__ pv)
 {
@@ -188,8 +188,8 @@ __global__ void sao_decide_kernel(const int32_t *__restrict__ edge_y, const int3
       const size_t g = (size_t)pic * ctus + k;
       if (cx == 0) {
         if (cy == 0) {
-          for (int i = 0; i < 2; ++i) {         // uvg_init_contexts for an I slice (context.c:471-500)
-            const int v = k_ctx_init_sao[2][i];
+          for (int i = 0; i < 2; ++i) {         // uvg_init_contexts for the slice type (context.c:471-500)
+            const int v = k_ctx_init_sao[slice_type][i];
             const int slope = (v >> 3) - 4, offset = ((v & 7) * 18) + 1;
             int s = ((slope * (qp - 16)) >> 1) + offset;
             s = s < 1 ? 1 : (s > 127 ? 127 : s);
@@ -243,8 +243,19 @@ extern "C" int uvghip_sao_decide_pictures(int bitdepth, int n_pictures, int pic_
                                           uint16_t *models_out, uvghip_sao_param_t *params_y, uvghip_sao_param_t *params_u,
                                           uvghip_sao_param_t *params_v, void *stream)
 {
+  return uvghip_sao_decide_pictures_slice(bitdepth, n_pictures, pic_w, pic_h, qp, lambda, sao_type, 2, edge_y, band_y, edge_u, band_u, edge_v, band_v, workspace,
+                                          info_out, models_out, params_y, params_u, params_v, stream);
+}
+
+extern "C" int uvghip_sao_decide_pictures_slice(int bitdepth, int n_pictures, int pic_w, int pic_h, int qp, double lambda, int sao_type, int slice_type,
+                                                const int32_t *edge_y, const int32_t *band_y, const int32_t *edge_u, const int32_t *band_u,
+                                                const int32_t *edge_v, const int32_t *band_v, void *workspace, int32_t *info_out,
+                                                uint16_t *models_out, uvghip_sao_param_t *params_y, uvghip_sao_param_t *params_u,
+                                                uvghip_sao_param_t *params_v, void *stream)
+{
   UVGHIP_REQUIRE_READY();
   UVGHIP_REQUIRE_DEPTH(bitdepth);
+  if (slice_type < 0 || slice_type > 2) return uvghip_set_error(hipErrorInvalidValue, __func__);
   if (n_pictures <= 0 || pic_w <= 0 || pic_h <= 0 || qp < 0 || qp > 63 || !(lambda > 0) || sao_type < 1 || sao_type > 3 || !edge_y || !band_y ||
       !edge_u || !band_u || !edge_v || !band_v || !workspace || !info_out || !models_out || !params_y || !params_u || !params_v)
     return uvghip_set_error(hipErrorInvalidValue, __func__);
@@ -255,6 +266,6 @@ extern "C" int uvghip_sao_decide_pictures(int bitdepth, int n_pictures, int pic_
   cand *cw = static_cast<cand *>(workspace);
   sao_candidates_kernel<<<(2 * n + 127) / 128, 128, 0, st>>>(edge_y, band_y, edge_u, band_u, edge_v, band_v, n, omax, cw);
   sao_decide_kernel<<<(n_pictures + 63) / 64, 64, 0, st>>>(edge_y, band_y, edge_u, band_u, edge_v, band_v, cw, n_pictures, wc, hc, qp, lambda,
-                                                           sao_type, info_out, models_out, params_y, params_u, params_v);
+                                                           sao_type, slice_type, info_out, models_out, params_y, params_u, params_v);
   UVGHIP_CHECK_LAUNCH();
 }

@@ -43,9 +43,11 @@ struct row_state_pb {
 struct lds_tab { icand::unit *p; __device__ icand::unit &at(int i) { return p[i]; } };
 struct glb_col {
   const int32_t *p;
+  int stride, gw;                     // stride > 0: p is a per-4x4 table of `stride` units per row, read at the even positions
   __device__ icand::col_unit at(int i) const
   {
-    const int32_t *o = p + (size_t)i * 8;
+    const int gy = stride > 0 ? i / gw : 0, gx = i - gy * gw;
+    const int32_t *o = stride > 0 ? p + ((size_t)(gy * 2) * stride + gx * 2) * 8 : p + (size_t)i * 8;
     icand::col_unit c;
     c.type = o[0]; c.mv[0][0] = o[1]; c.mv[0][1] = o[2]; c.mv[1][0] = o[3]; c.mv[1][1] = o[4]; c.dir = o[5]; c.poc[0] = o[6]; c.poc[1] = o[7];
     return c;
@@ -314,6 +316,7 @@ struct pb_dev {
   const int32_t *col;
   const uvghip_inter4_t *inter4;
   const uint32_t *models_inter;
+  int32_t col_stride, pad;
 };
 
 // uvg_hmvp_add_mv (src/inter.c:1831-1905) on the row's table: [0] size, then five units, most recent first
@@ -632,7 +635,7 @@ slice_rows_kernel(const pic_dev *__restrict__ pics, const pb_dev *__restrict__ p
                 for (int d = 0; (64 >> d) > n; ++d) tree |= 1u << (3 * d);
                 f.split_tree = tree;
                 lds_tab tab{Q->tab};
-                glb_col colp{PB->col};
+                glb_col colp{PB->col, PB->col_stride, (W + 7) / 8};
                 int32_t *pred = Q->pred;
                 Q->ref_idx[0] = me.ref[0]; Q->ref_idx[1] = me.ref[1];
                 icand::amvp_candidates(f, tab, colp, Q->hmvp, l, Q->ref_idx, pred, &Q->ws);
@@ -785,7 +788,7 @@ extern "C" int uvghip_encode_slice_rows_pb(int bitdepth, const uvghip_ctu_params
     pb_dev &d = pd[i];
     d.slice_type = q.slice_type; d.poc = q.poc; d.n_refs = q.n_refs; d.tmvp = q.tmvp; d.max_merge = q.max_merge; d.merge_level = q.merge_level; d.frame_qp = q.frame_qp;
     memcpy(d.ref_pocs, q.ref_pocs, sizeof d.ref_pocs); memcpy(d.l_size, q.l_size, sizeof d.l_size); memcpy(d.l, q.l, sizeof d.l);
-    d.col = q.col; d.inter4 = q.inter4; d.models_inter = q.models_inter;
+    d.col = q.col; d.inter4 = q.inter4; d.models_inter = q.models_inter; d.col_stride = q.col_stride; d.pad = 0;
   }
   unsigned char *pbw = static_cast<unsigned char *>(workspace) + ((size_t)n_pictures * sizeof(pic_dev) + 255) / 256 * 256;
   UVGHIP_TRY(hipMemcpy(pbw, pd.data(), pd.size() * sizeof(pb_dev), hipMemcpyHostToDevice));

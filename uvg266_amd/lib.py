@@ -77,7 +77,7 @@ class SlicePb(ctypes.Structure):
     _fields_ = [("slice_type", ctypes.c_int32), ("poc", ctypes.c_int32), ("n_refs", ctypes.c_int32), ("ref_pocs", ctypes.c_int32 * 16),
                 ("l_size", ctypes.c_int32 * 2), ("l", (ctypes.c_int32 * 16) * 2), ("tmvp", ctypes.c_int32), ("max_merge", ctypes.c_int32),
                 ("merge_level", ctypes.c_int32), ("frame_qp", ctypes.c_int32), ("col", ctypes.c_void_p), ("inter4", ctypes.c_void_p),
-                ("models_inter", ctypes.c_void_p)]
+                ("models_inter", ctypes.c_void_p), ("col_stride", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class CtuPbPicture(ctypes.Structure):
@@ -89,6 +89,12 @@ class CtuPbPicture(ctypes.Structure):
                 ("ref_stride", ctypes.c_int32), ("ref_stride_c", ctypes.c_int32), ("ref_motion_stride", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("ref_y", ctypes.c_void_p * 16), ("ref_u", ctypes.c_void_p * 16), ("ref_v", ctypes.c_void_p * 16), ("ref_motion", ctypes.c_void_p * 16),
                 ("inter4", ctypes.c_void_p), ("models_inter", ctypes.c_void_p), ("trees", ctypes.c_void_p), ("motion_out", ctypes.c_void_p)]
+
+
+class LoopPbPicture(ctypes.Structure):
+    """uvghip_loop_pb_picture_t."""
+    _fields_ = [("search", CtuPbPicture), ("out_y", ctypes.c_void_p), ("out_u", ctypes.c_void_p), ("out_v", ctypes.c_void_p), ("out_stride", ctypes.c_int32),
+                ("out_stride_c", ctypes.c_int32)]
 
 
 class MeJob(ctypes.Structure):
@@ -188,6 +194,8 @@ SIGNATURES = {
     "uvghip_sao_decide_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "uvghip_sao_decide_pictures": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.c_double, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                            c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "uvghip_sao_decide_pictures_slice": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.c_double, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                 c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_ctu_search_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "uvghip_ctu_search_intra": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
     "uvghip_ctu_plan_create": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
@@ -204,6 +212,9 @@ SIGNATURES = {
     "uvghip_encode_slice_rows_pb": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "uvghip_ctu_search_pb_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "uvghip_ctu_search_pb": (c_int, [c_int, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_loop_pb_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
+    "uvghip_loop_pb_run": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_vp]),
+    "uvghip_loop_pb_results": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_merge_cand_batch": (c_int, [c_vp, c_vp, c_vp, ctypes.c_long, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvghip_amvp_cand_batch": (c_int, [c_vp, c_vp, c_vp, ctypes.c_long, c_vp, c_int, c_vp, c_vp]),
     "uvghip_inter_pred_satd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
