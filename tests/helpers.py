@@ -1088,6 +1088,16 @@ def iter_inter_frames(W, H, P):
         yield fr, d, prm, F, keep
 
 
+def frame_states_from_records(meta, lam, refs):
+    """Per-picture rows of a golden (meta [8], lam [6], refs [52] as tools/refcheck/ctu_dump.c writes them) -> the dicts api.LowDelayLoop takes."""
+    out = []
+    for m, l, r in zip(meta, lam, refs):
+        out.append(dict(slice_type=int(m[6]), poc=int(r[51]), qp=int(m[3]), lam=float(l[0]), lam_sqrt=float(l[1]), c_lam=float(l[2]), cw_u=float(l[3]), cw_v=float(l[4]),
+                        frame_qp=int(m[7]), n_refs=int(r[0]), ref_pocs=[int(a) for a in r[1:17]], l_size=[int(r[17]), int(r[18])],
+                        lists=[[int(a) for a in r[19:35]], [int(a) for a in r[35:51]]]))
+    return out
+
+
 INTER4_NP = np.dtype([("skipped", "u1"), ("merged", "u1"), ("merge_idx", "u1"), ("root_cbf", "u1"), ("mv_cand0", "u1"), ("mv_cand1", "u1"),
                       ("mv_ref0", "u1"), ("mv_ref1", "u1")])      # uvghip_inter4_t
 _EMUL_PB = None

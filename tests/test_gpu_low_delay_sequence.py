@@ -87,3 +87,50 @@ def test_sequence_closed_loop_on_the_device(hip, name):
         assert stream.find(whole) > 0, (name, fr)
         coded += 1
     assert coded == int(g["dims"][4])
+
+
+def _frame_rows(g):
+    """Per-picture (meta, lam, refs) of a full ref_inter_* golden (its records are per CTU)."""
+    frames = int(g["dims"][4])
+    first = {}
+    for k in range(len(g["meta"])):
+        first.setdefault(int(g["meta"][k][0]), k)
+    ks = [first[f] for f in range(frames)]
+    return g["meta"][ks], g["lam"][ks], g["refs"][ks]
+
+
+@pytest.mark.parametrize("name,n_seq", [("ref_inter_264x136_8_qp32_9frames", 3), ("ref_intercrc_1920x1080_8_qp27_5frames", 2)])
+def test_low_delay_loop_of_several_sequences(hip, name, n_seq):
+    """api.LowDelayLoop (what bench.py times for BASELINE configs[2]): n_seq sequences side by side, every picture group one call.  The
+    1080p case is checked through the CRCs of tests/golden/ref_intercrc_* (output pictures and every row's bytes of the reference's run)."""
+    import zlib
+    import torch
+    from uvg266_amd import api
+    g = np.load(os.path.join(H.GOLDEN, name + ".npz"))
+    W, Hh, depth, qp0, frames = (int(a) for a in g["dims"])
+    hc = (Hh + 63) // 64
+    crc_only = "final_crc" in g.files
+    meta, lam, refs = (g["meta"], g["lam"], g["refs"]) if crc_only else _frame_rows(g)
+    states = H.frame_states_from_records(meta, lam, refs)
+    pics = [H.moving_picture(W, Hh, t, depth) for t in range(frames)]
+    for t in range(frames):
+        assert zlib.crc32(b"".join(p.tobytes() for p in pics[t])) == int(g["src_crc"][t])
+    src = [[tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in pics[f]) for f in range(frames)] for _ in range(n_seq)]
+    loop = api.LowDelayLoop(W, Hh, depth, n_seq, states, src)
+    loop.run()
+    torch.cuda.synchronize()
+    for f in range(frames):
+        rows, nb = loop.rows[f].cpu().numpy(), loop.row_bytes[f].cpu().numpy()
+        for s in range(n_seq):
+            planes = [a.cpu().numpy() for a in loop.out[f][s]]
+            if crc_only:
+                assert zlib.crc32(b"".join(np.ascontiguousarray(a).tobytes() for a in planes)) == int(g["final_crc"][f]), (name, "picture", f, "sequence", s)
+                for r in range(hc):
+                    assert nb[s, r] == int(g["row_len"][f * hc + r]) and zlib.crc32(rows[s, r, :nb[s, r]].tobytes()) == int(g["row_crc"][f * hc + r]), (name, f, s, "row", r)
+            else:
+                for cidx, nme in enumerate(("final_y", "final_u", "final_v")):
+                    assert np.array_equal(planes[cidx], g[nme][f]), (name, f, s, nme)
+                off = g["row_off"][f * hc:f * hc + hc + 1]
+                for r in range(hc):
+                    want = g["row_bytes"][off[r]:off[r + 1]]
+                    assert nb[s, r] == len(want) and np.array_equal(rows[s, r, :nb[s, r]], want), (name, f, s, "row", r)

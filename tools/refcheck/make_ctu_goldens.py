@@ -259,6 +259,36 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
     return tag
 
 
+def inter_crcs(W, H, depth, qp, frames):
+    """A low-delay encode at a size whose records are too large to keep (BASELINE configs[2]: 1080p): per picture its frame-level state
+    and CRC-32s -- of the picture after the in-loop filters, of the reconstruction before them, of every WPP row's bytes -- and per CTU the
+    CRC of its reconstruction (to localise a difference)."""
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    tag = inter(W, H, depth, qp, frames, out_dir=tmp)
+    g = np.load(os.path.join(tmp, f"ref_inter_{tag}.npz"))
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    c = np.ascontiguousarray
+    final_crc = np.array([zlib.crc32(c(g["final_y"][f]).tobytes() + c(g["final_u"][f]).tobytes() + c(g["final_v"][f]).tobytes()) for f in range(frames)], np.uint32)
+    rec_crc = np.array([zlib.crc32(c(g["rec_y"][f]).tobytes() + c(g["rec_u"][f]).tobytes() + c(g["rec_v"][f]).tobytes()) for f in range(frames)], np.uint32)
+    row_off, row_bytes = g["row_off"], g["row_bytes"]
+    row_crc = np.array([zlib.crc32(row_bytes[row_off[k]:row_off[k + 1]].tobytes()) for k in range(frames * hc)], np.uint32)
+    ctu_crc = np.zeros((frames, wc * hc), np.uint32)
+    frame_meta, frame_lam, frame_refs = np.zeros((frames, 8), np.int32), np.zeros((frames, 6)), np.zeros((frames, 52), np.int32)
+    types = np.zeros((frames, 3), np.int64)            # 4x4 units per CU type (0 outside, 1 intra, 2 inter)
+    for k in range(len(g["meta"])):
+        fr, x, y = (int(a) for a in g["meta"][k][:3])
+        hh, ww = min(64, H - y), min(64, W - x)
+        ctu_crc[fr, (y // 64) * wc + x // 64] = zlib.crc32(c(g["rec_y"][fr][y:y + hh, x:x + ww]).tobytes() + c(g["rec_u"][fr][y // 2:(y + hh) // 2, x // 2:(x + ww) // 2]).tobytes() +
+                                                           c(g["rec_v"][fr][y // 2:(y + hh) // 2, x // 2:(x + ww) // 2]).tobytes())
+        frame_meta[fr], frame_lam[fr], frame_refs[fr] = g["meta"][k], g["lam"][k], g["refs"][k]
+        types[fr] += np.bincount(g["cu"][k][:, 0].reshape(16, 16)[:hh // 4, :ww // 4].ravel(), minlength=3)[:3]
+    np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_intercrc_{tag}.npz"), dims=g["dims"], src_crc=g["src_crc"], meta=frame_meta, lam=frame_lam, refs=frame_refs,
+                        final_crc=final_crc, rec_crc=rec_crc, row_crc=row_crc, row_len=np.diff(row_off).astype(np.int64), ctu_crc=ctu_crc, types=types,
+                        bitstream_crc=np.uint32(zlib.crc32(g["bitstream"].tobytes())), bitstream_len=np.int64(len(g["bitstream"])))
+    print("wrote inter crc", tag, "unit types per picture", types.tolist())
+
+
 def merge(W, H, depth, qp, frames, every, amvp_step=4):
     """Calls of uvg_inter_get_merge_cand during a low-delay encode (every `every`-th one): everything the function reads and what it
     returned (tools/refcheck/ctu_dump.c, record "merge")."""
@@ -298,6 +328,7 @@ if __name__ == "__main__":
     inter(136, 72, 10, 22, 4)
     inter(264, 136, 8, 32, 9)            # nine pictures: three reference pictures per list, a whole GOP of QP offsets
     merge(192, 128, 8, 17, 6, 3)
+    inter_crcs(1920, 1080, 8, 27, 5)     # BASELINE configs[2] at full size
     merge(136, 72, 10, 27, 8, 2)
     inter(192, 128, 8, 32, 5, extra=("sao", "off"), suffix="_nosao", with_levels=False)        # final picture = the deblocked picture
     inter(136, 72, 10, 22, 4, extra=("sao", "off"), suffix="_nosao", with_levels=False)

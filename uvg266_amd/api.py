@@ -816,3 +816,88 @@ def loop_pb_run(pictures, depth, sao_type=3, stream=None):
     view = lambda p, nbytes: ws[p.value - base:p.value - base + nbytes]
     return (ws, view(a, n * ctus * 34 * 4).view(torch.int32).view(n, ctus, 34), view(b, n * ctus * 6 * 2).view(torch.int16).view(n, ctus, 6),
             view(c, n * nr.value * cap.value).view(n, nr.value, cap.value), view(d, n * nr.value * 4).view(torch.int32).view(n, nr.value))
+
+
+class LowDelayLoop:
+    """The per-picture loop of the encoder's CTU workers for n_seq independent low-delay sequences of the same shape (BASELINE configs[2]),
+    picture after picture on the device: an I picture of every sequence through uvghip_loop_plan_* (ClosedLoop), a P / B picture of every
+    sequence through uvghip_loop_pb_run with the device's own earlier output pictures and motion tables as references.  The frame-level
+    bookkeeping stays with the caller (the reference's encoder_state / GOP code): `frames` is one dict per picture in coding order with
+    slice_type (2 I, 1 P, 0 B), poc, qp, lam, lam_sqrt, c_lam, cw_u, cw_v, frame_qp, n_refs, ref_pocs[16], l_size[2], lists[2][16].
+    After run(): out[f][s] = (y, u, v) output pictures, rows[f] / row_bytes[f] = the slice data ([n_seq, rows, row_cap] / [n_seq, rows])."""
+
+    def __init__(self, W, H, depth, n_seq, frames, src, sao_type=3, tmvp=1, max_merge=6, merge_level=2, bipred=1, fme_level=4, early_skip=1):
+        self.W, self.H, self.depth, self.n_seq, self.frames, self.sao_type = W, H, depth, n_seq, frames, sao_type
+        wc, hc = (W + 63) // 64, (H + 63) // 64
+        ctus, n4 = wc * hc, hc * 16 * wc * 16
+        self.hc = hc
+        tdt = torch.uint8 if depth == 8 else torch.uint16
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")
+        self.out, self.mot, self.steps, self.keep = [], [], [], []
+        by_poc = {}
+        for f, fs in enumerate(frames):
+            srcs = [tuple(src[s][f]) for s in range(n_seq)]
+            if fs["slice_type"] == 2:
+                loop = ClosedLoop(ctu_params(W, H, fs["qp"], lam=fs["lam"]), srcs, sao_type=sao_type)
+                outs = loop.out
+                mots = [z((hc * 16, wc * 16, 8), torch.int32) for _ in range(n_seq)]
+                self.steps.append(("I", loop, mots))
+            else:
+                arr = (_lib.LoopPbPicture * n_seq)()
+                outs, mots, bufs = [], [], []
+                for s in range(n_seq):
+                    q = arr[s]
+                    p = q.search
+                    w = 2.0 ** 0
+                    p.params = _lib.CtuParams(W, H, fs["qp"], fs["qp"], 1, 4, 1, 1, 2, 0, fs["lam"], fs["lam_sqrt"], fs["c_lam"], fs["cw_u"], fs["cw_v"], fs["lam"])
+                    t = dict(rec=[z((H >> c, W >> c), tdt) for c in (0, 1, 1)], out=tuple(z((H >> c, W >> c), tdt) for c in (0, 1, 1)),
+                             scu=z(n4 * 32, torch.uint8), i4=z(n4 * 8, torch.uint8), mot=z((hc * 16, wc * 16, 8), torch.int32), co=z(ctus * 6144, torch.int16),
+                             mo=z(ctus * 3 * 257, torch.int32), mi=z(ctus * 3 * 18, torch.int32))
+                    c = p.pic
+                    c.src_y, c.src_u, c.src_v = (_dev(a) for a in srcs[s])
+                    c.rec_y, c.rec_u, c.rec_v = (_dev(a) for a in t["rec"])
+                    c.src_stride, c.src_stride_c, c.rec_stride, c.rec_stride_c = srcs[s][0].stride(0), srcs[s][1].stride(0), W, W // 2
+                    c.cu, c.cu_stride, c.coeff, c.models = _dev(t["scu"]), wc * 16, _dev(t["co"]), _dev(t["mo"])
+                    p.slice_type, p.poc, p.n_refs, p.frame_qp = fs["slice_type"], fs["poc"], fs["n_refs"], fs["frame_qp"]
+                    p.tmvp, p.max_merge, p.merge_level, p.bipred, p.fme_level, p.early_skip, p.depth_inter_min, p.depth_inter_max = tmvp, max_merge, merge_level, bipred, fme_level, early_skip, 0, 3
+                    for i in range(16):
+                        p.ref_pocs[i], p.l[0][i], p.l[1][i] = fs["ref_pocs"][i], fs["lists"][0][i], fs["lists"][1][i]
+                    p.l_size[0], p.l_size[1] = fs["l_size"]
+                    p.ref_stride, p.ref_stride_c, p.ref_motion_stride = W, W // 2, wc * 16
+                    for i in range(fs["n_refs"]):
+                        planes, rm = by_poc[(s, fs["ref_pocs"][i])]
+                        p.ref_y[i], p.ref_u[i], p.ref_v[i], p.ref_motion[i] = _dev(planes[0]), _dev(planes[1]), _dev(planes[2]), _dev(rm)
+                    p.inter4, p.models_inter, p.trees, p.motion_out = _dev(t["i4"]), _dev(t["mi"]), None, _dev(t["mot"])
+                    q.out_y, q.out_u, q.out_v = (_dev(a) for a in t["out"])
+                    q.out_stride, q.out_stride_c = W, W // 2
+                    outs.append(t["out"]); mots.append(t["mot"]); bufs.append(t)
+                L = _lib.init(torch.cuda.current_device())
+                ws = z(L.uvghip_loop_pb_workspace_bytes(depth, n_seq, W, H), torch.uint8)
+                self.steps.append(("PB", arr, ws, bufs))
+            for s in range(n_seq):
+                by_poc[(s, fs["poc"])] = (outs[s], mots[s])
+            self.out.append(outs); self.mot.append(mots)
+        self.L = _lib.init(torch.cuda.current_device())
+        self.rows, self.row_bytes = [None] * len(frames), [None] * len(frames)
+
+    def run(self, stream=None):
+        """Enqueue every picture of every sequence (the P / B groups wait for the stream where the coder's tables are uploaded)."""
+        st = _stream() if stream is None else stream
+        wc = (self.W + 63) // 64
+        for f, step in enumerate(self.steps):
+            if step[0] == "I":
+                _, loop, mots = step
+                loop.run(st)
+                for s in range(self.n_seq):      # an intra picture as a reference: its units' type, no vectors
+                    mots[s][:, :, 0] = loop.cu[s][:, :, 2].to(torch.int32)
+                    mots[s][:, :, 6:8] = -1
+                self.rows[f], self.row_bytes[f] = loop.slice_data()
+            else:
+                _, arr, ws, _ = step
+                _lib.check(self.L.uvghip_loop_pb_run(self.depth, ctypes.byref(arr), self.n_seq, self.sao_type, _dev(ws), st), "uvghip_loop_pb_run")
+                c, d, cap, nr = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
+                _lib.check(self.L.uvghip_loop_pb_results(self.depth, self.n_seq, self.W, self.H, _dev(ws), None, None, ctypes.byref(c), ctypes.byref(d), ctypes.byref(cap),
+                                                         ctypes.byref(nr)), "uvghip_loop_pb_results")
+                base = ws.data_ptr()
+                self.rows[f] = ws[c.value - base:c.value - base + self.n_seq * nr.value * cap.value].view(self.n_seq, nr.value, cap.value)
+                self.row_bytes[f] = ws[d.value - base:d.value - base + self.n_seq * nr.value * 4].view(torch.int32).view(self.n_seq, nr.value)

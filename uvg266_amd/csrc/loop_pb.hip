@@ -20,17 +20,17 @@ layout_t layout_of(int bitdepth, int n, int w, int h)
   size_t at = 0;
   auto take = [&](size_t bytes) { const size_t o = at; at = align_up(at + bytes, 256); return o; };
   L.search = take(uvghip_ctu_search_pb_workspace_bytes(n, w, h));
-  L.snap = take(((size_t)w * h * 3 / 2) * b);                     // one picture at a time
+  L.snap = take((size_t)n * ((size_t)w * h * 3 / 2) * b);
   L.rects_y = take(ctus * sizeof(uvghip_rect_t));
   L.rects_c = take(ctus * sizeof(uvghip_rect_t));
-  for (int c = 0; c < 3; ++c) { L.edge[c] = take(ctus * 40 * 4); L.band[c] = take(ctus * 64 * 4); }
-  L.decide = take(uvghip_sao_decide_workspace_bytes(1, w, h));
+  for (int c = 0; c < 3; ++c) { L.edge[c] = take((size_t)n * ctus * 40 * 4); L.band[c] = take((size_t)n * ctus * 64 * 4); }
+  L.decide = take(uvghip_sao_decide_workspace_bytes(n, w, h));
   L.info = take((size_t)n * ctus * 34 * 4);
   L.models = take((size_t)n * ctus * 6 * 2);
-  for (int c = 0; c < 3; ++c) L.params[c] = take(ctus * sizeof(uvghip_sao_param_t));
+  for (int c = 0; c < 3; ++c) L.params[c] = take((size_t)n * ctus * sizeof(uvghip_sao_param_t));
   const size_t hc = (size_t)((h + 63) / 64);
   L.row_cap = 3 * 64 * w * (int)b;
-  L.coder = take(uvghip_slice_rows_pb_workspace_bytes(1));
+  L.coder = take(uvghip_slice_rows_pb_workspace_bytes(n));
   L.row_bytes = take((size_t)n * hc * 4);
   L.rows = take((size_t)n * hc * L.row_cap);
   L.total = at;
@@ -101,49 +101,68 @@ extern "C" int uvghip_loop_pb_run(int bitdepth, const uvghip_loop_pb_picture_t *
   }
   int32_t *sao_info = reinterpret_cast<int32_t *>(ws + L.info), *row_bytes = reinterpret_cast<int32_t *>(ws + L.row_bytes);
   uint16_t *sao_models = reinterpret_cast<uint16_t *>(ws + L.models);
-  unsigned char *sy = ws + L.snap, *su = sy + (size_t)w * h * b, *sv = su + (size_t)cw * ch * b;
-  for (int i = 0; i < n_pictures; ++i) {
-    const uvghip_loop_pb_picture_t &q = pictures[i];
-    const uvghip_ctu_pb_picture_t &s = q.search;
-    const uvghip_ctu_picture_t &p = s.pic;
-    const int is_b = s.slice_type == 0, qp = s.params.qp;
-    int32_t *info_i = sao_info + (size_t)i * ctus * 34;
-    uint16_t *models_i = sao_models + (size_t)i * ctus * 6;
+  const size_t snap_bytes = (size_t)w * h * 3 / 2 * b;
+  // pictures that share QP, lambda and slice type (the same temporal position of several sequences) go through the SAO decision and
+  // the coder together: runs of such pictures
+  for (int i0 = 0; i0 < n_pictures;) {
+    const uvghip_ctu_pb_picture_t &s0 = pictures[i0].search;
+    int i1 = i0 + 1;
+    while (i1 < n_pictures && pictures[i1].search.params.qp == s0.params.qp && pictures[i1].search.params.lambda == s0.params.lambda &&
+           pictures[i1].search.slice_type == s0.slice_type && pictures[i1].search.frame_qp == s0.frame_qp)
+      ++i1;
+    const int m = i1 - i0, is_b = s0.slice_type == 0, qp = s0.params.qp;
+    const size_t o0 = (size_t)i0 * ctus;
     if (sao_type) {
-      UVGHIP_TRY(hipMemcpy2DAsync(sy, (size_t)w * b, p.rec_y, (size_t)p.rec_stride * b, (size_t)w * b, h, hipMemcpyDeviceToDevice, st));
-      UVGHIP_TRY(hipMemcpy2DAsync(su, (size_t)cw * b, p.rec_u, (size_t)p.rec_stride_c * b, (size_t)cw * b, ch, hipMemcpyDeviceToDevice, st));
-      UVGHIP_TRY(hipMemcpy2DAsync(sv, (size_t)cw * b, p.rec_v, (size_t)p.rec_stride_c * b, (size_t)cw * b, ch, hipMemcpyDeviceToDevice, st));
-      if (int rc = uvghip_deblock_frame_sao_snapshot(bitdepth, sy, w, su, sv, cw, w, h, p.cu, p.cu_stride, 0, 0, is_b, qp, nullptr, stream)) return rc;
-      if (int rc = uvghip_sao_stats_batch(bitdepth, p.src_y, p.src_stride, sy, w, rects_y, ctus, edge[0], band[0], stream)) return rc;
-      if (int rc = uvghip_sao_stats_batch(bitdepth, p.src_u, p.src_stride_c, su, cw, rects_c, ctus, edge[1], band[1], stream)) return rc;
-      if (int rc = uvghip_sao_stats_batch(bitdepth, p.src_v, p.src_stride_c, sv, cw, rects_c, ctus, edge[2], band[2], stream)) return rc;
-      if (int rc = uvghip_sao_decide_pictures_slice(bitdepth, 1, w, h, qp, s.params.lambda, sao_type, s.slice_type, edge[0], band[0], edge[1], band[1], edge[2], band[2],
-                                                    ws + L.decide, info_i, models_i, prm[0], prm[1], prm[2], stream))
+      for (int i = i0; i < i1; ++i) {
+        const uvghip_ctu_picture_t &p = pictures[i].search.pic;
+        unsigned char *sy = ws + L.snap + (size_t)i * snap_bytes, *su = sy + (size_t)w * h * b, *sv = su + (size_t)cw * ch * b;
+        UVGHIP_TRY(hipMemcpy2DAsync(sy, (size_t)w * b, p.rec_y, (size_t)p.rec_stride * b, (size_t)w * b, h, hipMemcpyDeviceToDevice, st));
+        UVGHIP_TRY(hipMemcpy2DAsync(su, (size_t)cw * b, p.rec_u, (size_t)p.rec_stride_c * b, (size_t)cw * b, ch, hipMemcpyDeviceToDevice, st));
+        UVGHIP_TRY(hipMemcpy2DAsync(sv, (size_t)cw * b, p.rec_v, (size_t)p.rec_stride_c * b, (size_t)cw * b, ch, hipMemcpyDeviceToDevice, st));
+        if (int rc = uvghip_deblock_frame_sao_snapshot(bitdepth, sy, w, su, sv, cw, w, h, p.cu, p.cu_stride, 0, 0, is_b, qp, nullptr, stream)) return rc;
+        const size_t o = (size_t)i * ctus;
+        if (int rc = uvghip_sao_stats_batch(bitdepth, p.src_y, p.src_stride, sy, w, rects_y, ctus, edge[0] + o * 40, band[0] + o * 64, stream)) return rc;
+        if (int rc = uvghip_sao_stats_batch(bitdepth, p.src_u, p.src_stride_c, su, cw, rects_c, ctus, edge[1] + o * 40, band[1] + o * 64, stream)) return rc;
+        if (int rc = uvghip_sao_stats_batch(bitdepth, p.src_v, p.src_stride_c, sv, cw, rects_c, ctus, edge[2] + o * 40, band[2] + o * 64, stream)) return rc;
+      }
+      if (int rc = uvghip_sao_decide_pictures_slice(bitdepth, m, w, h, qp, s0.params.lambda, sao_type, s0.slice_type, edge[0] + o0 * 40, band[0] + o0 * 64,
+                                                    edge[1] + o0 * 40, band[1] + o0 * 64, edge[2] + o0 * 40, band[2] + o0 * 64,
+                                                    ws + L.decide, sao_info + o0 * 34, sao_models + o0 * 6, prm[0] + o0, prm[1] + o0, prm[2] + o0, stream))
         return rc;
     }
-    if (int rc = uvghip_deblock_frame(bitdepth, p.rec_y, p.rec_stride, p.rec_u, p.rec_v, p.rec_stride_c, w, h, p.cu, p.cu_stride, 0, 0, is_b, qp, nullptr, stream)) return rc;
-    if (sao_type) {
-      if (int rc = uvghip_sao_apply_batch(bitdepth, p.rec_y, p.rec_stride, q.out_y, q.out_stride, w, h, rects_y, prm[0], ctus, stream)) return rc;
-      if (int rc = uvghip_sao_apply_batch(bitdepth, p.rec_u, p.rec_stride_c, q.out_u, q.out_stride_c, cw, ch, rects_c, prm[1], ctus, stream)) return rc;
-      if (int rc = uvghip_sao_apply_batch(bitdepth, p.rec_v, p.rec_stride_c, q.out_v, q.out_stride_c, cw, ch, rects_c, prm[2], ctus, stream)) return rc;
-    } else {
-      UVGHIP_TRY(hipMemcpy2DAsync(q.out_y, (size_t)q.out_stride * b, p.rec_y, (size_t)p.rec_stride * b, (size_t)w * b, h, hipMemcpyDeviceToDevice, st));
-      UVGHIP_TRY(hipMemcpy2DAsync(q.out_u, (size_t)q.out_stride_c * b, p.rec_u, (size_t)p.rec_stride_c * b, (size_t)cw * b, ch, hipMemcpyDeviceToDevice, st));
-      UVGHIP_TRY(hipMemcpy2DAsync(q.out_v, (size_t)q.out_stride_c * b, p.rec_v, (size_t)p.rec_stride_c * b, (size_t)cw * b, ch, hipMemcpyDeviceToDevice, st));
+    std::vector<uvghip_ctu_picture_t> cp(m);
+    std::vector<uvghip_slice_pb_t> sl(m);
+    for (int i = i0; i < i1; ++i) {
+      const uvghip_loop_pb_picture_t &q = pictures[i];
+      const uvghip_ctu_pb_picture_t &s = q.search;
+      const uvghip_ctu_picture_t &p = s.pic;
+      const size_t o = (size_t)i * ctus;
+      if (int rc = uvghip_deblock_frame(bitdepth, p.rec_y, p.rec_stride, p.rec_u, p.rec_v, p.rec_stride_c, w, h, p.cu, p.cu_stride, 0, 0, is_b, qp, nullptr, stream)) return rc;
+      if (sao_type) {
+        if (int rc = uvghip_sao_apply_batch(bitdepth, p.rec_y, p.rec_stride, q.out_y, q.out_stride, w, h, rects_y, prm[0] + o, ctus, stream)) return rc;
+        if (int rc = uvghip_sao_apply_batch(bitdepth, p.rec_u, p.rec_stride_c, q.out_u, q.out_stride_c, cw, ch, rects_c, prm[1] + o, ctus, stream)) return rc;
+        if (int rc = uvghip_sao_apply_batch(bitdepth, p.rec_v, p.rec_stride_c, q.out_v, q.out_stride_c, cw, ch, rects_c, prm[2] + o, ctus, stream)) return rc;
+      } else {
+        UVGHIP_TRY(hipMemcpy2DAsync(q.out_y, (size_t)q.out_stride * b, p.rec_y, (size_t)p.rec_stride * b, (size_t)w * b, h, hipMemcpyDeviceToDevice, st));
+        UVGHIP_TRY(hipMemcpy2DAsync(q.out_u, (size_t)q.out_stride_c * b, p.rec_u, (size_t)p.rec_stride_c * b, (size_t)cw * b, ch, hipMemcpyDeviceToDevice, st));
+        UVGHIP_TRY(hipMemcpy2DAsync(q.out_v, (size_t)q.out_stride_c * b, p.rec_v, (size_t)p.rec_stride_c * b, (size_t)cw * b, ch, hipMemcpyDeviceToDevice, st));
+      }
+      cp[i - i0] = p;
+      uvghip_slice_pb_t &d = sl[i - i0];
+      d.slice_type = s.slice_type; d.poc = s.poc; d.n_refs = s.n_refs;
+      for (int k = 0; k < 16; ++k) { d.ref_pocs[k] = s.ref_pocs[k]; d.l[0][k] = s.l[0][k]; d.l[1][k] = s.l[1][k]; }
+      d.l_size[0] = s.l_size[0]; d.l_size[1] = s.l_size[1];
+      d.tmvp = s.tmvp; d.max_merge = s.max_merge; d.merge_level = s.merge_level; d.frame_qp = s.frame_qp;
+      d.col = s.ref_motion[s.l[0][0]]; d.col_stride = s.ref_motion_stride; d.reserved = 0;
+      d.inter4 = s.inter4; d.models_inter = s.models_inter;
     }
-    // the slice data: the search's hand-over and the SAO decisions through the arithmetic coder
-    uvghip_slice_pb_t sl;
-    sl.slice_type = s.slice_type; sl.poc = s.poc; sl.n_refs = s.n_refs;
-    for (int k = 0; k < 16; ++k) { sl.ref_pocs[k] = s.ref_pocs[k]; sl.l[0][k] = s.l[0][k]; sl.l[1][k] = s.l[1][k]; }
-    sl.l_size[0] = s.l_size[0]; sl.l_size[1] = s.l_size[1];
-    sl.tmvp = s.tmvp; sl.max_merge = s.max_merge; sl.merge_level = s.merge_level; sl.frame_qp = s.frame_qp;
-    sl.col = s.ref_motion[s.l[0][0]]; sl.col_stride = s.ref_motion_stride; sl.reserved = 0;
-    sl.inter4 = s.inter4; sl.models_inter = s.models_inter;
-    // (the coder's table upload is a synchronous copy: the stream is drained first so that the previous picture's coder is done with it)
-    UVGHIP_TRY(hipStreamSynchronize(st));
-    if (int rc = uvghip_encode_slice_rows_pb(bitdepth, &s.params, &p, &sl, 1, sao_type ? info_i : nullptr, sao_type ? models_i : nullptr, ws + L.coder,
-                                             ws + L.rows + (size_t)i * hc * L.row_cap, L.row_cap, row_bytes + (size_t)i * hc, stream))
+    // the slice data of the run's pictures: the search's hand-over and the SAO decisions through the arithmetic coder.  (Its table upload
+    // is a synchronous copy: the stream is drained first so that an earlier run's coder is done with the table.)
+    if (i0 > 0) UVGHIP_TRY(hipStreamSynchronize(st));
+    if (int rc = uvghip_encode_slice_rows_pb(bitdepth, &s0.params, cp.data(), sl.data(), m, sao_type ? sao_info + o0 * 34 : nullptr, sao_type ? sao_models + o0 * 6 : nullptr,
+                                             ws + L.coder, ws + L.rows + (size_t)i0 * hc * L.row_cap, L.row_cap, row_bytes + (size_t)i0 * hc, stream))
       return rc;
+    i0 = i1;
   }
   return 0;
 }
