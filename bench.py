@@ -11,11 +11,13 @@ neighbours, RDOQ, CABAC bit costs on evolving models, split / no-split RD decisi
 the coder's model adaptation) -> deblocking on the side information the search wrote -> SAO statistics / offsets / apply.
 The decisions, levels and reconstruction are bit-identical with the reference encoder's (tests/golden/ref_ctu*).  Pictures of
 an all-intra encode are independent: K pictures are issued `--in-flight` at a time (the reference's --owf), their wavefronts
-interleaved on the device.  Writing the bitstream itself (the arithmetic coder) is outside the hot-path scope.
+interleaved on the device.  The arithmetic coder runs on the device as the last thing of every group (uvghip_encode_slice_rows: the
+slice data of the encoder's .266, byte for byte); the parameter sets and NAL framing are host code (uvghip_write_picture_nals).
 
 `value` = pictures/s of that closed loop.  The open-loop throughput of the same block kernels (every block size of every
-picture, no decisions: the previous rounds' headline) is reported under "open_loop", the 2160p 10-bit ALF workload under
-"extra_workloads".  --gpus N > 1: ranks take whole pictures (no data-path collective; "weak"); the CTU-row sharded filter
+picture, no decisions: the previous rounds' headline) is reported under "open_loop"; "extra_workloads" holds the 2160p 10-bit closed
+loop and BASELINE configs[2] -- low-delay P / B sequences through the closed loop with the inter search on the device
+(c3_low_delay_closed_loop, parity-checked against the reference's own 1080p run) beside the open-loop motion search kernels.  --gpus N > 1: ranks take whole pictures (no data-path collective; "weak"); the CTU-row sharded filter
 chain over RCCL (uvghip_band_plan) is timed in the same run on 2160p10alf and reported under "row_sharded_rccl".
 """
 import argparse
@@ -559,6 +561,61 @@ def inter_hot_path(device, reps=5):
                         "bi-prediction SATD of the two results; open loop (source pictures as references, zero predictors)"}
 
 
+def low_delay_closed_loop(device, n_seq=8, reps=2):
+    """BASELINE.json configs[2] (1920x1080 8-bit, --gop lp-g4d3t1 --preset medium, QP 27): n_seq independent sequences of 5 pictures
+    (I B B B B, up to four reference pictures) through the CLOSED loop on the device, picture group after picture group
+    (api.LowDelayLoop): the I pictures through uvghip_loop_plan_run, every B picture group through uvghip_loop_pb_run -- the CTU search
+    with the inter search inside (uvghip_ctu_search_pb: merge / AMVP candidates, hexagon + fractional motion search, bi-prediction, early
+    skip, inter / intra competition, 64x64 CUs, history table) on the device's OWN earlier output pictures, deblocking with boundary
+    strengths from the stored motion, SAO with the slice type's models, the arithmetic coder.  Parity: before the timed passes the output
+    picture and every WPP row's slice data of every picture of sequence 0 and of the last sequence are compared (CRC) with the reference
+    encoder's own run on the same source (tests/golden/ref_intercrc_1920x1080_8_qp27_5frames.npz).  Not part of `value`."""
+    import zlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as Hh
+    golden = "ref_intercrc_1920x1080_8_qp27_5frames"
+    g = np.load(os.path.join(ROOT, "tests", "golden", golden + ".npz"))
+    W, H, depth, qp0, frames = (int(a) for a in g["dims"])
+    hc = (H + 63) // 64
+    states = Hh.frame_states_from_records(g["meta"], g["lam"], g["refs"])
+    pics = [Hh.moving_picture(W, H, t, depth) for t in range(frames)]
+    for t in range(frames):
+        if zlib.crc32(b"".join(p.tobytes() for p in pics[t])) != int(g["src_crc"][t]):
+            raise SystemExit("c3 parity check: the sequence generator drifted from the golden's source")
+    one = [tuple(torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in pics[f]) for f in range(frames)]
+    src = [one for _ in range(n_seq)]                     # (the sequences read the same source planes; every other buffer is their own)
+    loop = api.LowDelayLoop(W, H, depth, n_seq, states, src)
+    loop.run()
+    torch.cuda.synchronize()
+    bad = {}
+    for f in range(frames):
+        rows, nb = loop.rows[f].cpu().numpy(), loop.row_bytes[f].cpu().numpy()
+        for s in sorted({0, n_seq - 1}):
+            planes = [a.cpu().numpy() for a in loop.out[f][s]]
+            if zlib.crc32(b"".join(np.ascontiguousarray(a).tobytes() for a in planes)) != int(g["final_crc"][f]):
+                bad[f"picture {f} sequence {s}"] = "output picture"
+            for r in range(hc):
+                if nb[s, r] != int(g["row_len"][f * hc + r]) or zlib.crc32(rows[s, r, :nb[s, r]].tobytes()) != int(g["row_crc"][f * hc + r]):
+                    bad[f"picture {f} sequence {s} row {r}"] = "slice data"
+    if bad:
+        raise SystemExit(f"c3 parity check FAILED against {golden}: {dict(list(bad.items())[:6])}")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        loop.run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    n_pic = n_seq * frames
+    return {"value": round(n_pic / dt, 2), "unit": "frames/s (closed loop, low delay)", "ms_per_sequence_group": round(1e3 * dt, 1), "sequences": n_seq, "pictures_per_sequence": frames,
+            "mpixels_per_s": round(n_pic / dt * W * H / 1e6, 2), "parity_checked": True,
+            "parity": {"golden": golden, "pictures": frames, "sequences_checked": sorted({0, n_seq - 1}),
+                       "items": "CRC of every output picture (after deblocking + SAO) and length + CRC of every WPP row's slice data vs the reference encoder's run"},
+            "workload": f"{W}x{H} {depth}-bit yuv420p, --gop lp-g4d3t1 --preset medium at QP {qp0} (BASELINE.json configs[2]): {n_seq} sequences x {frames} pictures (I B B B B), "
+                        "per picture group one call: closed-loop CTU search with the inter search (device references) -> deblocking -> SAO -> arithmetic coder",
+            "note": "one wave per CTU walks the CTU in the reference's own order; the pictures of a sequence are a dependency chain, parallelism comes from the "
+                    "sequences and the 2-CTU-lag wavefront inside a picture (DESIGN.md 4.12)"}
+
+
 def closed_loop(wl, steps, warmup, in_flight, device, rank, world, dist, groups=2):
     """`steps` timed launches of `in_flight` pictures each (a step = one group of pictures through search -> deblock -> SAO) after
     `warmup` untimed ones; `groups` launches are in flight at a time on their own streams, so the thin start of one launch's
@@ -731,6 +788,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="--shard rows: skip the all-to-all of reconstructed bands")
     ap.add_argument("--workload", choices=("1080p8", "2160p10alf"), default="1080p8",
                     help="1080p8 = BASELINE.json configs[1] (the judged line); 2160p10alf = configs[3] geometry")
+    ap.add_argument("--c3-sequences", type=int, default=8, help="extra_workloads.c3_low_delay_closed_loop: independent low-delay sequences side by side")
     ap.add_argument("--no-extra", action="store_true", help="do not also time the 2160p 10-bit closed loop (extra_workloads)")
     args = ap.parse_args()
 
@@ -772,9 +830,10 @@ def main():
                  "mpixels_per_s": round(ek * eF * world / eel * ewl["W"] * ewl["H"] / 1e6, 1),
                  "search_launch_ms": round(ems / max(1, eln), 2),
                  "workload": "3840x2160 10-bit yuv420p, QP 22: the same closed loop (search -> deblock -> SAO; ALF of configs[3] is in the open-loop chain only)"}
-    c3 = None
+    c3 = c3_loop = None
     if not args.no_extra and wl_name == "1080p8" and rank == 0:
         c3 = inter_hot_path(device)
+        c3_loop = low_delay_closed_loop(device, n_seq=args.c3_sequences)
     open_loop = None
     if not args.no_open_loop and world == 1:
         ol_steps = (max(args.group, args.open_loop_steps) + args.group - 1) // args.group * args.group
@@ -831,6 +890,8 @@ def main():
                 out["extra_workloads"] = {"2160p10_closed_loop": extra}
             if c3 is not None:
                 out.setdefault("extra_workloads", {})["c3_inter_hot_path_open_loop"] = c3
+            if c3_loop is not None:
+                out.setdefault("extra_workloads", {})["c3_low_delay_closed_loop"] = c3_loop
             if open_loop is not None:
                 out["open_loop"] = open_loop
             if row_sharded is not None:
