@@ -788,7 +788,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="--shard rows: skip the all-to-all of reconstructed bands")
     ap.add_argument("--workload", choices=("1080p8", "2160p10alf"), default="1080p8",
                     help="1080p8 = BASELINE.json configs[1] (the judged line); 2160p10alf = configs[3] geometry")
-    ap.add_argument("--c3-sequences", type=int, default=8, help="extra_workloads.c3_low_delay_closed_loop: independent low-delay sequences side by side")
+    ap.add_argument("--only-c3", action="store_true", help="time only extra_workloads.c3_low_delay_closed_loop and print it (development)")
+    ap.add_argument("--c3-sequences", type=int, default=32, help="extra_workloads.c3_low_delay_closed_loop: independent low-delay sequences side by side")
     ap.add_argument("--no-extra", action="store_true", help="do not also time the 2160p 10-bit closed loop (extra_workloads)")
     args = ap.parse_args()
 
@@ -805,6 +806,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
     L = lib.init(local_rank)
+    if args.only_c3:
+        print(json.dumps({"c3_low_delay_closed_loop": low_delay_closed_loop(device, n_seq=args.c3_sequences)}), flush=True)
+        return
 
     wl_name = args.workload
     wl = WORKLOADS[wl_name]

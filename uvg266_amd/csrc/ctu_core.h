@@ -210,6 +210,9 @@ struct pb_state {
   int8_t merge_keys[8], amvp_keys[3][8];
   int32_t merge_size, amvp_size[3];
   int32_t mv_cand[2][2];               // info->mv_cand
+  int32_t amvp_cache[2][8][4];         // the predictors of (list, reference index) for the CU being evaluated: derived once
+  uint32_t amvp_have[2];
+  int32_t amvp_key[3];                 // the CU (x, y, size) the cache belongs to
   int32_t out4[4];
   int32_t ref_idx2[2];
   int32_t i0, i1, i2, i3;              // small hand-overs from lane 0 to the wave
@@ -257,6 +260,9 @@ struct scratch {
 #if defined(CTU_PB)
   int32_t save_mot[256][8];        // the 64x64 candidate of a P / B picture while its split is tried: motion, flags
   uint8_t save_fl[256][8];
+#endif
+#if defined(CTU_PB)
+  unsigned long long prof_pb[16];     // CTU_PROFILE, ctu_pb.h: cycles of the phases of the P / B walk (lane 0 of the wave)
 #endif
   unsigned long long prof[4][32];     // CTU_PROFILE: 0 rough search, 1 refs + prediction, 2 residual + transforms + reconstruction, 3 RDOQ, 4 SSD,
                                    // 5 RD cost (bits), 6 park / unpark / model copies, 7 64x64 candidate, 8 coder pass, 9 load, 10 store, 11 total

@@ -30,6 +30,17 @@
 #include "satd_tile_dev.h"
 #endif
 
+#if defined(__HIPCC__) && defined(CTU_PROFILE)
+#define PB_T0() const unsigned long long pb_t0__ = __builtin_amdgcn_s_memtime()
+#define PB_T1(W, slot) do { if (CTU_TID == 0) (W)->prof_pb[slot] += __builtin_amdgcn_s_memtime() - pb_t0__; } while (0)
+#else
+#define PB_T0() ((void)0)
+#define PB_T1(W, slot) ((void)0)
+#endif
+// prof_pb slots: 0 candidate lists, 1 merge analysis (prediction + SATD), 2 early skip test, 3 integer motion search, 4 fractional search,
+// 5 bi-prediction, 6 intra rough search + chroma trial, 7 the inter CU's prediction + residual, 8 its bits + cost, 9 the intra CU (eval_cu),
+// 10 unpark / 64x64 save + restore, 11 load, 12 store + deblock side effect, 13 coder pass, 14 total, 15 4x4 leaves
+
 namespace ctu {
 
 enum { MI_SKIP = NMODELS, MI_PRED_MODE = NMODELS + 3, MI_MERGE_FLAG = NMODELS + 5, MI_MERGE_IDX = NMODELS + 6, MI_INTER_DIR = NMODELS + 7,
@@ -132,37 +143,69 @@ template <typename PX> CTU_DEV int ref_px(CTU_GLB const PX *ref, int stride, int
 // A w x h block whose top-left INTEGER position in the reference plane is (x0, y0), at phase (fx, fy) (luma: 1/16 with the 8-tap
 // filter, chroma: 1/32 with the 4-tap filter): horizontal pass into tmp (rows y0 - off .. of w int16 each), vertical pass into dst.
 // out 0: samples; 1: the 14-bit intermediates (int16); 2: samples of the bi-prediction with the other list's intermediates in `other`.
+// A lane takes SEG outputs in a row (horizontal pass) or in a column (vertical pass) at a time: SEG + TAPS - 1 loads for SEG outputs.
+template <typename PX, int TAPS, int SEG> CTU_DEV void ipol_passes(CTU_GLB const PX *ref, int stride, int pw, int ph, int x0, int y0, int w, int h, int fx, int fy,
+                                                                    int out, void *dst_, int dp, const int16_t *other_, int op, CTU_LDS int16_t *tmp)
+{
+  const int depth = (int)px_info<PX>::depth;
+  const int off = TAPS == 4 ? 1 : 3;
+  const int8_t *const fh = TAPS == 4 ? VVC_CHROMA_FILTER + 4 * fx : VVC_LUMA_FILTER + 8 * fx;
+  const int8_t *const fv = TAPS == 4 ? VVC_CHROMA_FILTER + 4 * fy : VVC_LUMA_FILTER + 8 * fy;
+  const int shift1 = depth - 8;
+  const int rows = h + TAPS - 1, segs = w / SEG;
+  int ch[TAPS], cv[TAPS];
+  for (int k = 0; k < TAPS; ++k) { ch[k] = fh[k]; cv[k] = fv[k]; }
+  PAR_FOR(e, rows * segs) {
+    const int r = e / segs, q0 = (e - r * segs) * SEG;
+    CTU_GLB const PX *row = ref + (size_t)clampi(y0 + r - off, 0, ph - 1) * stride;
+    const int xs = x0 + q0 - off;
+    if (fx == 0) {
+      if (xs + off >= 0 && xs + off + SEG <= pw) { for (int j = 0; j < SEG; ++j) tmp[r * w + q0 + j] = (int16_t)((64 * (int)row[xs + off + j]) >> shift1); }
+      else for (int j = 0; j < SEG; ++j) tmp[r * w + q0 + j] = (int16_t)((64 * (int)row[clampi(xs + off + j, 0, pw - 1)]) >> shift1);
+    } else {
+      int px[SEG + TAPS - 1];
+      if (xs >= 0 && xs + SEG + TAPS - 1 <= pw) { for (int j = 0; j < SEG + TAPS - 1; ++j) px[j] = (int)row[xs + j]; }
+      else for (int j = 0; j < SEG + TAPS - 1; ++j) px[j] = (int)row[clampi(xs + j, 0, pw - 1)];
+      for (int j = 0; j < SEG; ++j) {
+        int acc = 0;
+        for (int k = 0; k < TAPS; ++k) acc += ch[k] * px[j + k];
+        tmp[r * w + q0 + j] = (int16_t)(acc >> shift1);
+      }
+    }
+  }
+  CTU_SYNC();
+  const int wp_shift = 14 - depth, wp_off = 1 << (wp_shift - 1), bi_shift = 15 - depth, bi_off = 1 << (bi_shift - 1);
+  const int vsegs = h / SEG;
+  PAR_FOR(e, vsegs * w) {
+    const int sg = e / w, q = e - sg * w, r0 = sg * SEG;
+    int hi[SEG];
+    if (fy == 0) { for (int j = 0; j < SEG; ++j) hi[j] = (int)(int16_t)((64 * (int)tmp[(r0 + j + off) * w + q]) >> 6); }
+    else {
+      int t[SEG + TAPS - 1];
+      for (int j = 0; j < SEG + TAPS - 1; ++j) t[j] = (int)tmp[(r0 + j) * w + q];
+      for (int j = 0; j < SEG; ++j) {
+        int acc = 0;
+        for (int k = 0; k < TAPS; ++k) acc += cv[k] * t[j + k];
+        hi[j] = (int)(int16_t)(acc >> 6);
+      }
+    }
+    for (int j = 0; j < SEG; ++j) {
+      const int r = r0 + j;
+      if (out == 1) LDSP(int16_t, dst_)[r * dp + q] = (int16_t)hi[j];
+      else if (out == 0) LDSP(PX, dst_)[r * dp + q] = (PX)clampi((hi[j] + wp_off) >> wp_shift, 0, (int)px_info<PX>::maxv);
+      else LDSP(PX, dst_)[r * dp + q] = (PX)clampi((hi[j] + (int)LDSP(const int16_t, other_)[r * op + q] + bi_off) >> bi_shift, 0, (int)px_info<PX>::maxv);
+    }
+  }
+  CTU_SYNC();
+}
 template <typename PX> CTU_NOINLINE CTU_DEV void ipol_block(const PX *ref_, int stride, int pw, int ph, int x0, int y0, int w, int h, int fx, int fy, int is_chroma,
                                                             int out, void *dst_, int dp, const int16_t *other_, int op, int16_t *tmp_)
 {
   CTU_GLB const PX *const ref = (CTU_GLB const PX *)ref_;
   CTU_LDS int16_t *const tmp = LDSP(int16_t, tmp_);
-  const int depth = (int)px_info<PX>::depth;
-  const int taps = is_chroma ? 4 : 8, off = is_chroma ? 1 : 3;
-  const int8_t *const fh = is_chroma ? VVC_CHROMA_FILTER + 4 * fx : VVC_LUMA_FILTER + 8 * fx;
-  const int8_t *const fv = is_chroma ? VVC_CHROMA_FILTER + 4 * fy : VVC_LUMA_FILTER + 8 * fy;
-  const int shift1 = depth - 8;
-  const int rows = h + taps - 1;
-  PAR_FOR(e, rows * w) {
-    const int r = e / w, q = e - r * w;
-    int acc;
-    if (fx == 0) acc = 64 * ref_px(ref, stride, pw, ph, x0 + q, y0 + r - off);
-    else { acc = 0; for (int k = 0; k < taps; ++k) acc += fh[k] * ref_px(ref, stride, pw, ph, x0 + q - off + k, y0 + r - off); }
-    tmp[e] = (int16_t)(acc >> shift1);
-  }
-  CTU_SYNC();
-  const int wp_shift = 14 - depth, wp_off = 1 << (wp_shift - 1), bi_shift = 15 - depth, bi_off = 1 << (bi_shift - 1);
-  PAR_FOR(e, w * h) {
-    const int r = e / w, q = e - r * w;
-    int acc;
-    if (fy == 0) acc = 64 * (int)tmp[(r + off) * w + q];
-    else { acc = 0; for (int k = 0; k < taps; ++k) acc += fv[k] * (int)tmp[(r + k) * w + q]; }
-    const int hi = (int)(int16_t)(acc >> 6);
-    if (out == 1) LDSP(int16_t, dst_)[r * dp + q] = (int16_t)hi;
-    else if (out == 0) LDSP(PX, dst_)[r * dp + q] = (PX)clampi((hi + wp_off) >> wp_shift, 0, (int)px_info<PX>::maxv);
-    else LDSP(PX, dst_)[r * dp + q] = (PX)clampi((hi + (int)LDSP(const int16_t, other_)[r * op + q] + bi_off) >> bi_shift, 0, (int)px_info<PX>::maxv);
-  }
-  CTU_SYNC();
+  if (!is_chroma) ipol_passes<PX, 8, 8>(ref, stride, pw, ph, x0, y0, w, h, fx, fy, out, dst_, dp, other_, op, tmp);
+  else if (w >= 8) ipol_passes<PX, 4, 8>(ref, stride, pw, ph, x0, y0, w, h, fx, fy, out, dst_, dp, other_, op, tmp);
+  else ipol_passes<PX, 4, 4>(ref, stride, pw, ph, x0, y0, w, h, fx, fy, out, dst_, dp, other_, op, tmp);
 }
 
 // the prediction of the n x n CU at picture position (x, y) with motion m (icand::unit fields: mv, ref = list indices, dir) into
@@ -227,13 +270,21 @@ template <typename PX> CTU_DEV unsigned satd_vs_source(const job<PX> &J, int x, 
 #if defined(__HIPCC__)
     uint32_t d[8][4];
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
+    for (int r = 0; r < 8; ++r) {
+      // the source row of the tile as sample pairs: whole words (the block's x is a multiple of 8)
+      uint32_t cp[4];
+      const CTU_GLB uint32_t *c32 = (const CTU_GLB uint32_t *)(cur + (size_t)(ty * 8 + r) * J.src_stride + tx * 8);
+      if (sizeof(PX) == 1) {
+        const uint32_t a = c32[0], b = c32[1];
+        cp[0] = (a & 0xffu) | ((a & 0xff00u) << 8); cp[1] = ((a >> 16) & 0xffu) | ((a >> 24) << 16);
+        cp[2] = (b & 0xffu) | ((b & 0xff00u) << 8); cp[3] = ((b >> 16) & 0xffu) | ((b >> 24) << 16);
+      } else { cp[0] = c32[0]; cp[1] = c32[1]; cp[2] = c32[2]; cp[3] = c32[3]; }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const CTU_GLB PX *c = cur + (size_t)(ty * 8 + r) * J.src_stride + tx * 8 + 2 * q;
         const CTU_LDS PX *p = pred + (ty * 8 + r) * pp + tx * 8 + 2 * q;
-        d[r][q] = pk_sub((uint32_t)c[0] | ((uint32_t)c[1] << 16), (uint32_t)p[0] | ((uint32_t)p[1] << 16));
+        d[r][q] = pk_sub(cp[q], (uint32_t)p[0] | ((uint32_t)p[1] << 16));
       }
+    }
     acc += (int)satd8_tile_lane(d);
 #else
     int d[64];
@@ -455,13 +506,28 @@ template <typename PX> CTU_DEV void set_cand_ctx(lds<PX> *S, int x, int y, int n
 {
   S->pb.f.x = x; S->pb.f.y = y; S->pb.f.w = n; S->pb.f.h = n; S->pb.f.split_tree = split_tree;
 }
+// (During a CU's evaluation nothing the derivation reads changes -- the history table is the search's at the CU's entry, the neighbours
+// only lose unused vectors -- so the predictors of a (list, reference index) are derived once per CU; the coder's calls, on its own
+// history table, are not cached.)
 template <typename PX> CTU_DEV void amvp_for(lds<PX> *S, const job<PX> &J, const int32_t *hmvp, int reflist, int ref0, int ref1, int32_t (*out)[2])
 {
-  pb_tab tab = {S->pb.mot};
+  pb_state &Q = S->pb;
+  const int ri = (reflist ? ref1 : ref0) & 7;
+  const bool cacheable = hmvp == Q.hmvp;
+  if (cacheable && (Q.amvp_key[0] != Q.f.x || Q.amvp_key[1] != Q.f.y || Q.amvp_key[2] != Q.f.w)) {
+    Q.amvp_key[0] = Q.f.x; Q.amvp_key[1] = Q.f.y; Q.amvp_key[2] = Q.f.w; Q.amvp_have[0] = Q.amvp_have[1] = 0;
+  }
+  if (cacheable && ((Q.amvp_have[reflist] >> ri) & 1u)) {
+    const int32_t *c = Q.amvp_cache[reflist][ri];
+    out[0][0] = c[0]; out[0][1] = c[1]; out[1][0] = c[2]; out[1][1] = c[3];
+    return;
+  }
+  pb_tab tab = {Q.mot};
   pb_col col = col_of(J);
-  S->pb.ref_idx2[0] = ref0; S->pb.ref_idx2[1] = ref1;
-  icand::amvp_candidates(S->pb.f, tab, col, hmvp, reflist, S->pb.ref_idx2, S->pb.out4, &S->pb.ws);
-  out[0][0] = S->pb.out4[0]; out[0][1] = S->pb.out4[1]; out[1][0] = S->pb.out4[2]; out[1][1] = S->pb.out4[3];
+  Q.ref_idx2[0] = ref0; Q.ref_idx2[1] = ref1;
+  icand::amvp_candidates(Q.f, tab, col, hmvp, reflist, Q.ref_idx2, Q.out4, &Q.ws);
+  out[0][0] = Q.out4[0]; out[0][1] = Q.out4[1]; out[1][0] = Q.out4[2]; out[1][1] = Q.out4[3];
+  if (cacheable) { int32_t *c = Q.amvp_cache[reflist][ri]; c[0] = Q.out4[0]; c[1] = Q.out4[1]; c[2] = Q.out4[2]; c[3] = Q.out4[3]; Q.amvp_have[reflist] |= 1u << ri; }
 }
 
 CTU_DEV void cand_from_merge(pb_cand *pu, const icand::merge_cand &c)          // the motion fields search_pu_inter copies out of a merge candidate
@@ -514,6 +580,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
   level_state &N = S->lvl[L];
   const int n = 64 >> L, x = N.x, y = N.y, lx = x & 63, ly = y & 63;
   CTU_LDS const uint32_t *const mdl = LDSP(const uint32_t, V->cur);
+  { PB_T0();
   SERIAL {
     memset(&Q.cur, 0, sizeof Q.cur);                     // cur_pu: the CU's entry after search_cu's memset (type NOTSET)
     set_cand_ctx(S, x, y, n, N.split_tree);
@@ -524,8 +591,10 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
     for (int i = 0; i < 6; ++i) { Q.merge_keys[i] = -1; Q.merge[i].cost = CTU_MAX_DOUBLE; }
   }
   CTU_SYNC();
+  PB_T1(J.W, 0); }
   const double merge_flag_cost = m_fbits(mdl, MI_MERGE_FLAG, 1);
   const int n_mc = Q.n_mc;
+  { PB_T0();
   for (int merge_idx = 0; merge_idx < n_mc; ++merge_idx) {
     SERIAL cand_from_merge(&Q.cur, Q.mc[merge_idx]);
     CTU_SYNC();
@@ -553,8 +622,10 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
   }
   SERIAL sort_keys(Q.merge, Q.merge_keys, Q.merge_size);
   CTU_SYNC();
+  PB_T1(J.W, 1); }
   const int num_rdo_cands = Q.merge_size < 1 ? Q.merge_size : 1;
   if (B.early_skip) {
+    PB_T0();
     for (int k = 0; k < num_rdo_cands; ++k) {
       const int merge_idx = Q.merge[Q.merge_keys[k]].merge_idx;
       SERIAL cand_from_merge(&Q.cur, Q.mc[merge_idx]);
@@ -571,8 +642,10 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
         Q.merge[0] = Q.cur;
       }
       CTU_SYNC();
+      PB_T1(J.W, 2);
       return 1;
     }
+    PB_T1(J.W, 2);
   }
   // ---- AMVP: every reference picture (search_pu_inter_ref) ----
   SERIAL { Q.amvp_size[0] = Q.amvp_size[1] = Q.amvp_size[2] = 0; }
@@ -584,11 +657,13 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
         if (B.l[rl][i] == ref_pic) { active[rl] = 1; idx[rl] = i; break; }
     int ref_list = active[0] ? 0 : 1;
     int LX_idx = idx[ref_list];
+    { PB_T0();
     SERIAL {
       Q.cur.m.ref[ref_list] = LX_idx & 255;
       amvp_for(S, J, Q.hmvp, ref_list, Q.cur.m.ref[0], Q.cur.m.ref[1], Q.mv_cand);
     }
     CTU_SYNC();
+    PB_T1(J.W, 0); }
     me_info<PX> I;
     I.J = &J; I.ref_pic = ref_pic; I.x = x; I.y = y; I.n = n;
     I.cand[0][0] = Q.mv_cand[0][0]; I.cand[0][1] = Q.mv_cand[0][1]; I.cand[1][0] = Q.mv_cand[1][0]; I.cand[1][1] = Q.mv_cand[1][1];
@@ -610,7 +685,9 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
         b.mx = px; b.my = py;
       }
     }
+    { PB_T0();
     me_integer(S, I, b.mx, b.my, b);
+    PB_T1(J.W, 3); }
     if (B.fme_level == 0 && b.cost < CTU_MAX_DOUBLE) {
       const int q = n > 32 ? 32 : n, nq = n / q;
       for (int qy = 0; qy < nq; ++qy)
@@ -673,7 +750,9 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
         I.J = &J; I.ref_pic = B.l[list][LX_idx & 15]; I.x = x; I.y = y; I.n = n;
         I.cand[0][0] = Q.mv_cand[0][0]; I.cand[0][1] = Q.mv_cand[0][1]; I.cand[1][0] = Q.mv_cand[1][0]; I.cand[1][1] = Q.mv_cand[1][1];
         me_best b = {CTU_MAX_DOUBLE, 2147483647.0, Q.amvp[list][key].m.mv[list][0], Q.amvp[list][key].m.mv[list][1]};
+        { PB_T0();
         me_frac(S, I, T.ry, T.rpy, b);
+        PB_T1(J.W, 4); }
         const int cu_mv_cand = select_mv_cand(I.cand, b.mx, b.my, nullptr);
         const int extra_bits = list + LX_idx;
         b.cost += extra_bits * P.lambda_sqrt;
@@ -694,6 +773,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
   }
   const int can_use_bipred = B.slice_type == 0 && B.bipred && n + n >= 16;
   if (can_use_bipred) {
+    PB_T0();
     if (Q.amvp_size[0] > 0 && Q.amvp_size[1] > 0) {
       SERIAL {
         pb_cand &u = Q.amvp[2][0];
@@ -729,6 +809,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
       }
       CTU_SYNC();
     }
+    PB_T1(J.W, 5);
   }
   SERIAL {
     int cs, cp;
@@ -899,6 +980,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void finish_inter(lds<PX> *S, const 
   const int q = n > 32 ? 32 : n, ntu = n > 32 ? 4 : 1;
   int32_t cbf4[4] = {0, 0, 0, 0};
   int root_cbf = 0;
+  { PB_T0();
   if (!Q.cur.skipped) {
     SERIAL {
       if (!Q.cur.merged)
@@ -922,8 +1004,10 @@ template <typename PX> CTU_NOINLINE CTU_DEV void finish_inter(lds<PX> *S, const 
     }
     CTU_SYNC();
   }
+  PB_T1(J.W, 7); }
   const pb_cand cu = Q.cur;
   CTU_SYNC();
+  PB_T0();
   // ---- bits: uvg_mock_encode_coding_unit (encode_coding_tree.c:1730-1862), update = 1 ----
   SERIAL {
     CTU_LDS uint32_t *const m = LDSP(uint32_t, V->cur);
@@ -996,6 +1080,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void finish_inter(lds<PX> *S, const 
     N.fl[6] = (uint8_t)cu.m.ref[0]; N.fl[7] = (uint8_t)cu.m.ref[1];
   }
   CTU_SYNC();
+  PB_T1(J.W, 8);
 }
 
 // The CU of depth L (0..3, completely inside the picture) evaluated unsplit: search_cu up to the split loop (search.c:1395-1774) --
@@ -1026,6 +1111,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_pb(lds<PX> *S, const job<P
   const int skip_intra = (type != CU_NOTSET && cost / (double)(n * n) < 8) || (B.early_skip && early_skipped);
   int mode = 0;
   if (can_intra && !skip_intra) {
+    PB_T0();
     build_refs(S, P, 0, x, y, lx, ly, n, n);
     search_intra_rough(S, J, x, y, lx, ly, n);
     mode = V->u_mode;
@@ -1053,10 +1139,11 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_pb(lds<PX> *S, const job<P
       intra_cost = Q.d0;
     }
     if (intra_cost < cost) { cost = intra_cost; type = CU_INTRA; }
+    PB_T1(J.W, 6);
   }
   if (type == CU_INTRA) {
     if (L == 0) { SERIAL { N.cost = CTU_MAX_DOUBLE; N.type = CU_NOTSET; } CTU_SYNC(); }     // (refused by the host: pu-depth-intra starts below 64)
-    else eval_cu(S, J, L, 1, mode);
+    else { PB_T0(); eval_cu(S, J, L, 1, mode); PB_T1(J.W, 9); }
   } else if (type == CU_INTER) {
     finish_inter(S, J, L, T);
     if (L == 0) { SERIAL place_inter_cu(S, 0); CTU_SYNC(); }
@@ -1160,7 +1247,9 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
       if (n == 4) {
         // a 4x4 CU: intra only, nothing to split, no history entry
         if (can_intra) {
+          PB_T0();
           eval_cu(S, J, L, 0);
+          PB_T1(J.W, 15);
         } else { SERIAL { N.cost = CTU_MAX_DOUBLE; N.type = CU_NOTSET; } CTU_SYNC(); }
         ret = N.cost; entering = 0; --L; continue;
       }
@@ -1202,7 +1291,7 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
       CTU_SYNC();
       if (N.pending) decide = true;
       else {
-        if (L == 0 && ntype != CU_NOTSET) save64_pb(S, J);
+        if (L == 0 && ntype != CU_NOTSET) { PB_T0(); save64_pb(S, J); PB_T1(J.W, 10); }
         ++L;
         continue;
       }
@@ -1237,8 +1326,8 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
         copy_models(S->cur, S->work[L - 1]);             // post_search_cabac
         SERIAL { for (int i = 0; i < 41; ++i) Q.hmvp[i] = Q.hmvp_entry[L][i]; hmvp_add(Q.hmvp, N.mot); }
         CTU_SYNC();
-        if (ntype != CU_NOTSET) unpark_pb(S, J, L);
-      } else if (!pruned && ntype != CU_NOTSET) restore64_pb(S, J);
+        if (ntype != CU_NOTSET) { PB_T0(); unpark_pb(S, J, L); PB_T1(J.W, 10); }
+      } else if (!pruned && ntype != CU_NOTSET) { PB_T0(); restore64_pb(S, J); PB_T1(J.W, 10); }
     }
     ret = N.cost;
     entering = 0;
@@ -1286,6 +1375,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void load_ctu_pb(lds<PX> *S, const j
     Q.hmvp[i] = v; Q.hmvp_coder[i] = v;
   }
   if (BLK_TID == 0) {
+    Q.amvp_key[0] = Q.amvp_key[1] = Q.amvp_key[2] = -1; Q.amvp_have[0] = Q.amvp_have[1] = 0;
     icand::frame_ctx &f = Q.f;
     f.x = f.y = f.w = f.h = 0;
     f.poc = B.poc; f.is_b = B.slice_type == 0; f.pic_w = W; f.pic_h = H;
@@ -1512,6 +1602,13 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass_pb(lds<PX> *S, const
 // one CTU of a P / B picture, start to finish (one wave)
 template <typename PX> CTU_DEV void run_ctu_pb(lds<PX> *S, const job<PX> &J)
 {
+#if defined(__HIPCC__) && defined(CTU_PROFILE)
+  BLK_FOR(i, 16) J.W->prof_pb[i] = 0;
+  BLK_FOR(i, 4 * 32) J.W->prof[i >> 5][i & 31] = 0;
+  S->prof_w = J.W;
+#endif
+  PB_T0();
+  { PB_T0();
   setup_waves(S);
   BLK_FOR(k, 4) S->wv[k].rq_root = 0;
   build_scans(S);
@@ -1520,22 +1617,28 @@ template <typename PX> CTU_DEV void run_ctu_pb(lds<PX> *S, const job<PX> &J)
   load_ctu_pb(S, J);
   BLK_FOR(e, 6144) J.coeff[e] = 0;
   BLK_SYNC();
+  PB_T1(J.W, 11); }
   search_ctu_pb(S, J);
   PAR_FOR(i, NMODELS) J.models_out[NMODELS + i] = S->cur[i];
   PAR_FOR(i, NMX - NMODELS) J.pbm_out[(NMX - NMODELS) + i] = S->cur[NMODELS + i];
   BLK_SYNC();
+  { PB_T0();
   store_ctu(S, J);
   store_ctu_pb(S, J);
   deblock_zeroes_unused_vectors(S, J);
+  PB_T1(J.W, 12); }
   LANE0 S->vsel[CTU_WAVE] = 3;
   CTU_SYNC();
+  { PB_T0();
   coder_pass_pb(S, J);
+  PB_T1(J.W, 13); }
   LANE0 S->vsel[CTU_WAVE] = 0;
   BLK_SYNC();
   BLK_FOR(i, NMODELS) J.models_out[2 * NMODELS + i] = S->coder[i];
   BLK_FOR(i, NMX - NMODELS) J.pbm_out[2 * (NMX - NMODELS) + i] = S->coder[NMODELS + i];
   BLK_FOR(i, 41) J.pb->hmvp_rows[(size_t)(J.y >> 6) * 41 + i] = S->pb.hmvp_coder[i];
   BLK_SYNC();
+  PB_T1(J.W, 14);
 }
 
 }  // namespace ctu

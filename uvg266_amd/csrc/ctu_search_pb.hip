@@ -124,6 +124,16 @@ ws_layout layout(int n_pictures, int pic_w, int pic_h)
 
 }  // namespace
 
+#if defined(CTU_PROFILE)
+// development builds: where the scratch slots (whose tails hold the phase counters) sit in the workspace
+extern "C" __attribute__((visibility("default"))) size_t uvghip_ctu_search_pb_debug_scratch(int n_pictures, int pic_w, int pic_h, size_t *slot_bytes, int *n_slots)
+{
+  const ws_layout L = layout(n_pictures, pic_w, pic_h);
+  *slot_bytes = sizeof(ctu::scratch); *n_slots = L.n_slots;
+  return L.scratch;
+}
+#endif
+
 extern "C" size_t uvghip_ctu_search_pb_workspace_bytes(int n_pictures, int pic_w, int pic_h)
 {
   if (n_pictures <= 0 || pic_w <= 0 || pic_h <= 0) return 0;
