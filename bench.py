@@ -648,6 +648,41 @@ def closed_loop(wl, steps, warmup, in_flight, device, rank, world, dist, groups=
     return cls, F, elapsed, sum(m[0] for m in ms), sum(m[1] for m in ms)
 
 
+def cpu_baseline_reference(wl, frames=24):
+    """The reference encoder itself (oracle/_ref/uvg266_8: /root/reference built by oracle/build_ref.sh with plain gcc, AVX2 strategies
+    and its own thread pool) on the GPU box's host cores: `frames` synthetic pictures of the workload, -p 1 --preset medium at the
+    bench's QP, threads and frame parallelism at the encoder's defaults (auto).  A WHOLE encode (search, filters, bitstream): what the
+    device's closed loop + coder replaces.  -> None when the binary is not there (then the oracle port is timed instead)."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "uvg266_8" if wl["depth"] == 8 else "uvg266_10")
+    if not os.access(exe, os.X_OK):
+        return None
+    W, H, depth = wl["W"], wl["H"], wl["depth"]
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    with tempfile.TemporaryDirectory() as tmp:
+        yuv = os.path.join(tmp, "in.yuv")
+        with open(yuv, "wb") as f:
+            for t in range(frames):
+                for pl in layout.synthetic_yuv420(W, H, t, depth):
+                    f.write(np.ascontiguousarray(pl).tobytes())
+        cmd = [exe, "-i", yuv, "--input-res", f"{W}x{H}", "-n", str(frames), "-p", "1", "--preset", "medium", "-q", str(QP), "-o", os.path.join(tmp, "out.266")]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+        except (OSError, subprocess.TimeoutExpired):
+            return None
+        dt = time.perf_counter() - t0
+        if r.returncode != 0 or not os.path.getsize(os.path.join(tmp, "out.266")):
+            return None
+    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "reference",
+            "sample": f"{frames} synthetic {W}x{H} {depth}-bit pictures through the reference encoder's CLI (-p 1 --preset medium -q {QP}, --threads / --owf auto "
+                      f"on {cores} host threads, AVX2 strategies), wall time {dt:.1f} s incl. reading the input: a whole encode"}
+
+
 def cpu_baseline_search(wl, seconds=12.0):
     """The same closed loop (search + coder model adaptation; no filters) by the oracle -- the C restatement of the reference's
     uvg_search_lcu / uvg_encode_coding_tree path that reproduces the reference-run goldens -- on the host cores: whole pictures in
@@ -901,7 +936,7 @@ def main():
             if row_sharded is not None:
                 out["row_sharded_rccl"] = row_sharded
             if world == 1 and not args.no_cpu_baseline and wl_name == "1080p8":
-                out["cpu_baseline"] = cpu_baseline_search(wl)
+                out["cpu_baseline"] = cpu_baseline_reference(wl) or cpu_baseline_search(wl)
             print(json.dumps(out), flush=True)
 
     row_sharded = None
