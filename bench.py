@@ -648,7 +648,7 @@ def closed_loop(wl, steps, warmup, in_flight, device, rank, world, dist, groups=
     return cls, F, elapsed, sum(m[0] for m in ms), sum(m[1] for m in ms)
 
 
-def cpu_baseline_reference(wl, frames=24):
+def cpu_baseline_reference(wl, frames=96):
     """The reference encoder itself (oracle/_ref/uvg266_8: /root/reference built by oracle/build_ref.sh with plain gcc, AVX2 strategies
     and its own thread pool) on the GPU box's host cores: `frames` synthetic pictures of the workload, -p 1 --preset medium at the
     bench's QP, threads and frame parallelism at the encoder's defaults (auto).  A WHOLE encode (search, filters, bitstream): what the
