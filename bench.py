@@ -308,41 +308,6 @@ def cpu_baseline(fr_host_y, fr_host_u, fr_host_v, W, H, DEPTH):
                       f"encoder: BASELINE.md has the reference's full 1080p medium encode at 2.2 fps on 8 vCPU (AVX2)"}
 
 
-def closed_loop_probe(L, wl, device, reps=3, in_flight=4):
-    """The same picture coded CLOSED loop (pipeline.ClosedLoopIntra: fixed uniform CU partition, references from the
-    reconstruction, wavefront levels replayed from one hipGraph): the dependency-bound rate that goes next to the open-loop
-    throughput -- with one picture in flight (latency) and with `in_flight` pictures on as many streams.  Reported, not part
-    of `value`."""
-    n = 16 if (wl["W"] % 16 == 0 and wl["H"] % 16 == 0) else 8
-    modes = api.make_modes(MODES, device)
-    pics = [pipeline.ClosedLoopIntra(L, wl, k, n, device, modes, qp=QP) for k in range(in_flight)]
-    streams = [torch.cuda.Stream() for _ in pics]
-    torch.cuda.synchronize()
-    graphs = [pipeline.Graph(L, cl.launches, st) for cl, st in zip(pics, streams)]
-    for g, st in zip(graphs, streams):
-        g.launch(st.cuda_stream)
-    torch.cuda.synchronize()
-
-    def timed(k):
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            for g, st in zip(graphs[:k], streams[:k]):
-                g.launch(st.cuda_stream)
-        torch.cuda.synchronize()
-        return 1e3 * (time.perf_counter() - t0) / reps
-
-    ms1, msk = timed(1), timed(in_flight)
-    for g in graphs:
-        g.destroy()
-    cl = pics[0]
-    return {"cu_size": n, "chroma": bool(cl.chroma), "rdoq": bool(cl.rdoq), "blocks": int(len(cl.blocks)), "wavefront_levels": int(cl.n_levels),
-            "launches_per_picture": len(cl.launches), "ms_per_picture": round(ms1, 3), "frames_per_s": round(1e3 / ms1, 2),
-            "us_per_level": round(1e3 * ms1 / cl.n_levels, 2),
-            "pictures_in_flight": in_flight, "frames_per_s_in_flight": round(1e3 * in_flight / msk, 2),
-            "note": "a level holds at most a few dozen CUs, so one picture is launch-latency bound, not throughput bound; pictures "
-                    "are independent (all-intra), so several in flight on their own streams overlap (owf)"}
-
-
 def coeff_cost_probe(L, fr, reps=5):
     """CABAC bit cost (uvg_get_coeff_cost's CABAC branch, count-mode coefficient coder: what the RD search prices every
     candidate with) of all the levels one group of pictures produced -- one launch per block shape and plane over the group.

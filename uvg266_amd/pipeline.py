@@ -493,102 +493,3 @@ class Graph:
         if self.handle:
             self.L.uvghip_graph_destroy(self.handle)
             self.handle = None
-
-
-class ClosedLoopIntra:
-    """Closed-loop intra coding of one picture with a fixed partition into uniform N x N CUs -- the first slice of the
-    GPU-resident search driver (the reference's search_cu -> uvg_search_cu_intra -> uvg_intra_recon_cu,
-    search.c:1299, search_intra.c:1883, intra.c:1890, run by one worker per CTU under the WPP dependency of
-    encoderstate.c:1085-1189).
-
-    Every CU takes its reference samples from the RECONSTRUCTION of the CUs coded before it, so the picture is a dependency
-    graph, not a batch: layout.dependency_levels() cuts it into wavefront levels, and each level is the open-loop chain of
-    this module on that level's blocks -- rough search (67 modes, min(SATD, 2 SAD), first minimum) against the
-    reconstruction -> predict -> residual / DCT-2 -> RDOQ | quant -> dequant / IDCT -> reconstruction; for N >= 8 the two
-    co-located chroma blocks with the derived mode.  The launch list of the whole picture is captured once into a hipGraph;
-    its replay time is dependency-bound (a level holds a few dozen blocks), which is the number `bench.py` reports as
-    closed_loop_fps next to the open-loop throughput.
-    """
-
-    def __init__(self, L, wl, t, n, device, modes_dev, qp=22, chroma=True):
-        import ctypes
-        W, H, depth = wl["W"], wl["H"], wl["depth"]
-        if W % n or H % n:
-            raise ValueError("ClosedLoopIntra: the fixed partition needs picture dimensions that are multiples of the CU size")
-        self.L, self.W, self.H, self.depth, self.n, self.qp = L, W, H, depth, n, qp
-        self.rdoq = bool(wl.get("rdoq", False))
-        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
-        P = lambda t_: t_.data_ptr()
-        y, u, v = layout.synthetic_yuv420(W, H, t, depth)
-        self.host = (y, u, v)
-        self.y, self.u, self.v = dev(y), dev(u), dev(v)
-        self.chroma = chroma and n >= 8
-        blks = layout.intra_availability(layout.block_grid(W, H, n), n, W, H)
-        level = layout.dependency_levels(blks, n)
-        order = np.lexsort((layout.coding_order(blks[:, :2], n).argsort(), level))   # by level, coding order inside a level
-        self.blocks, self.level = blks[order], level[order]
-        self.n_levels = int(level.max()) + 1
-        cnt = len(blks)
-        self.bounds = np.searchsorted(self.level, np.arange(self.n_levels + 1))
-        self.blks, self.tus = api.make_intra_blocks(self.blocks, device), api.make_tus(self.blocks[:, :2], device)
-        self.best = torch.zeros(cnt, dtype=torch.int8, device=device)
-        self.cost = torch.zeros(cnt, dtype=torch.int32, device=device)
-        self.pred, self.rec = torch.zeros_like(self.y), torch.zeros_like(self.y)
-        planes = [(0, n, self.y, self.pred, self.rec, self.tus)]
-        if self.chroma:
-            cb = self.blocks // 2
-            self.cblks, self.ctus = api.make_intra_blocks(cb, device), api.make_tus(cb[:, :2], device)
-            self.pred_u, self.rec_u, self.pred_v, self.rec_v = (torch.zeros_like(self.u) for _ in range(4))
-            planes += [(1, n // 2, self.u, self.pred_u, self.rec_u, self.ctus), (2, n // 2, self.v, self.pred_v, self.rec_v, self.ctus)]
-        qps = qp + 6 * (depth - 8)
-        qpc = chroma_qp(qp) + 6 * (depth - 8)
-        self.jobs = {}
-        for color, c, *_ in planes:
-            self.jobs[color] = dict(coef=torch.zeros((cnt, c, c), dtype=torch.int16, device=device),
-                                    lev=torch.zeros((cnt, c, c), dtype=torch.int16, device=device),
-                                    deq=torch.zeros((cnt, c, c), dtype=torch.int16, device=device),
-                                    has=torch.zeros(cnt, dtype=torch.uint8, device=device),
-                                    ws=torch.empty((_lib.load_library().uvghip_rdoq_workspace_bytes(c, c, cnt) // 8 + 64,), dtype=torch.float64, device=device))
-        self._ctx = (ctypes.c_uint8 * 244).from_buffer_copy(synthetic_rdoq_ctx().tobytes())
-        ys, cs = self.y.stride(0), self.u.stride(0)
-        nm = modes_dev.shape[0]
-        es = self.y.element_size()
-        self.launches = []
-        for lv in range(self.n_levels):
-            s, e = int(self.bounds[lv]), int(self.bounds[lv + 1])
-            k = e - s
-            bo, to = P(self.blks) + 16 * s, P(self.tus) + 8 * s
-            self.launches += [
-                ("cl_search", L.uvghip_intra_search_best_batch,
-                 [depth, P(self.rec), ys, P(self.y), ys, n, bo, k, P(modes_dev), nm, P(self.best) + s, P(self.cost) + 4 * s, None]),
-                ("cl_pred", L.uvghip_intra_pred_plane_batch, [depth, P(self.rec), ys, n, bo, k, P(self.best) + s, P(self.pred), ys])]
-            if self.chroma:
-                cbo = P(self.cblks) + 16 * s
-                for color, c, src, pred, rec, tus in planes[1:]:
-                    self.launches.append(("cl_pred_chroma", L.uvghip_intra_pred_plane_chroma_batch,
-                                          [depth, P(rec), cs, c, cbo, k, P(self.best) + s, P(pred), cs]))
-            for color, c, src, pred, rec, tus in planes:
-                st = src.stride(0)
-                tp = P(tus) + 8 * s
-                j = self.jobs[color]
-                off = lambda t_, per: P(t_) + per * s
-                q = qps if color == 0 else qpc
-                if not self.rdoq:
-                    self.launches.append(("cl_tu_roundtrip", L.uvghip_tu_roundtrip_batch,
-                                          [depth, 0, 0, 0, 0, c, c, q, 1, P(src), st, P(pred), st, P(rec), st, tp, k,
-                                           off(j["lev"], 2 * c * c), off(j["has"], 1)]))
-                    continue
-                lam = intra_lambda(qp) * (1.0 if color == 0 else 0.9)
-                self.launches += [
-                    ("cl_tu_forward", L.uvghip_tu_forward_batch,
-                     [depth, 0, 0, 0, 0, c, c, 0, P(src), st, P(pred), st, tp, k, off(j["coef"], 2 * c * c)]),
-                    ("cl_rdoq", L.uvghip_rdoq_batch,
-                     [depth, off(j["coef"], 2 * c * c), off(j["lev"], 2 * c * c), c, c, k, color, 1, 0, 0, 0, q, ctypes.c_double(lam),
-                      ctypes.cast(self._ctx, ctypes.c_void_p), P(j["ws"]), j["ws"].numel() * 8, None, off(j["has"], 1)]),
-                    ("cl_tu_dequant_inverse", L.uvghip_tu_dequant_inverse_batch,
-                     [depth, 0, 0, c, c, q, off(j["lev"], 2 * c * c), P(pred), st, P(rec), st, tp, k])]
-        del es
-
-    def clear(self):
-        for t_ in (self.rec, self.pred) + ((self.rec_u, self.rec_v, self.pred_u, self.pred_v) if self.chroma else ()):
-            t_.zero_()
