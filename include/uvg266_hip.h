@@ -965,6 +965,19 @@ UVGHIP_API int uvghip_picture_checksum(int bitdepth, const void *plane_y, int st
  * .266 of a one-picture encode, byte for byte (tests/test_picture_nal.py). */
 UVGHIP_API int uvghip_write_picture_nals(int poc, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
                                          const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len);
+/* the same with a slice QP offset: sh_qp_delta = state->frame->QP - cfg.qp (the intra QP offset of the first picture of a low-delay stream) */
+UVGHIP_API int uvghip_write_idr_nals(int poc, int qp_delta, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
+                                     const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len);
+/* ... and for a P / B picture of a low-delay stream (pictype TRAIL, one temporal layer, long start code).
+ * replaces: uvg_encoder_state_write_bitstream_slice_header (src/encoder_state-bitstream.c:1248-1411) with _picture_header (:1009-1139)
+ * and _ref_pic_list (:1141-1246): inter / intra slice allowed, ph_pic_temporal_mvp_enabled_flag, slice type, the reference picture
+ * list syntax -- list 0's entries written twice when cfg.bipred (copy_rpl1: the low-delay list 1 is a copy, :1165), the active
+ * override, the collocated picture -- and sh_qp_delta.  delta_neg[n_ref_neg]: poc - POC of every reference picture in the order of the
+ * GOP structure's ref_neg[] (uvg_config_process_lp_gop, src/cfg.c:1640-1720: ascending distance); poc_lsb_bits: encoder_control->
+ * poc_lsb_bits; slice_type 0 B, 1 P; tmvp: cfg.tmvp_enable; qp_delta: state->frame->QP - cfg.qp. */
+UVGHIP_API int uvghip_write_picture_nals_pb(int poc, int poc_lsb_bits, int slice_type, int n_ref_neg, const int32_t *delta_neg, int copy_rpl1, int tmvp,
+                                            int qp_delta, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
+                                            const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len);
 
 /* After uvghip_loop_plan_run: the NAL units (slice + hash SEI) of picture `picture` of the plan's group as picture number `poc` of the
  * stream, into HOST memory -- uvghip_picture_checksum on its output picture, its rows brought to the host, uvghip_write_picture_nals.

@@ -26,6 +26,8 @@ def test_sequence_closed_loop_on_the_device(hip, name):
     by_poc = {}                       # poc -> (planes, motion table) made by the device
     keep = []
     coded = 0
+    qp0 = int(g["dims"][3])
+    mine = b""                        # the NAL units of every picture, from device outputs only
     for fr, d, prm, F, _ in H.iter_inter_frames(W, Hh, P):
         src = [dev(p) for p in pics[fr]]
         slice_type, poc = int(d["meta"][6]), int(d["refs"][51])
@@ -85,8 +87,25 @@ def test_sequence_closed_loop_on_the_device(hip, name):
             assert nb[r] == len(want) and np.array_equal(rows[r, :nb[r]], want), (name, fr, "row", r, int(nb[r]), len(want))
             whole += rows[r, :nb[r]].tobytes()
         assert stream.find(whole) > 0, (name, fr)
+        # the picture's NAL units: hash SEI from the device's checksum of its output picture, slice header from the rows' lengths
+        sums = np.ascontiguousarray(api.picture_checksum(*out).cpu().numpy().view(np.uint32))
+        sizes = np.ascontiguousarray(nb, np.int32)
+        rows_h = np.ascontiguousarray(rows[:, :int(sizes.max())])
+        cap = int(sizes.sum()) + 128 + 4 * hc
+        buf, n = np.zeros(cap, np.uint8), ctypes.c_size_t(0)
+        frame_qp = int(d["meta"][7])
+        if slice_type == 2:
+            rc = hip.uvghip_write_idr_nals(poc, frame_qp - qp0, 1, H.ptr(rows_h), rows_h.shape[1], H.ptr(sizes), hc, H.ptr(sums), H.ptr(buf), cap, ctypes.byref(n))
+        else:
+            deltas = np.ascontiguousarray(sorted(poc - F.ref_pocs[i] for i in range(F.n_refs)), np.int32)
+            rc = hip.uvghip_write_picture_nals_pb(poc, 4, slice_type, F.n_refs, H.ptr(deltas), 1, 1, frame_qp - qp0, 1, H.ptr(rows_h), rows_h.shape[1], H.ptr(sizes), hc,
+                                                  H.ptr(sums), H.ptr(buf), cap, ctypes.byref(n))
+        assert rc == 0
+        mine += buf[:n.value].tobytes()
         coded += 1
     assert coded == int(g["dims"][4])
+    at = stream.find(b"\x00\x00\x01\x00\x41")
+    assert at > 0 and stream[:at] + mine == stream, "the encoder's parameter sets + the device's pictures = the encoder's whole .266"
 
 
 def _frame_rows(g):

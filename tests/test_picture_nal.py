@@ -155,3 +155,49 @@ def test_device_outputs_complete_a_multi_picture_stream(hip, name):
     stream = g["bitstream"].tobytes()
     at = stream.find(b"\x00\x00\x01\x00\x41")
     assert stream[:at] + mine == stream
+
+
+@pytest.mark.parametrize("name", ["ref_inter_136x72_10_qp22_4frames", "ref_inter_192x128_8_qp17_5frames", "ref_inter_264x136_8_qp32_9frames"])
+def test_whole_low_delay_file_from_rows_and_final_pictures(name):
+    """A low-delay stream (--gop lp-g4d3t1): behind the encoder's parameter sets, the IDR picture's NAL units (with its slice QP offset)
+    and every B picture's -- picture header with the inter flags, slice type, reference picture lists, collocated picture, QP offset,
+    entry points, the rows, the hash SEI -- from the library's host functions make up the encoder's whole .266."""
+    import os
+    from uvg266_amd import lib
+    L = lib.load_library()
+    g = np.load(os.path.join(H.GOLDEN, name + ".npz"))
+    W, Hh, depth, qp0, frames = (int(a) for a in g["dims"])
+    hc = (Hh + 63) // 64
+    stream = g["bitstream"].tobytes()
+    first = {}
+    for k in range(len(g["meta"])):
+        first.setdefault(int(g["meta"][k][0]), k)
+    mine = b""
+    for f in range(frames):
+        k = first[f]
+        off = g["row_off"][f * hc:f * hc + hc + 1]
+        sizes = np.diff(off).astype(np.int32)
+        rows = np.zeros((hc, int(sizes.max())), np.uint8)
+        for r in range(hc):
+            rows[r, :sizes[r]] = g["row_bytes"][off[r]:off[r + 1]]
+        sums = np.ascontiguousarray([H.picture_checksum(g[nme][f], depth) for nme in ("final_y", "final_u", "final_v")], np.uint32)
+        slice_type, frame_qp, poc = int(g["meta"][k][6]), int(g["meta"][k][7]), int(g["refs"][k][51])
+        cap = int(sizes.sum()) + 128 + 4 * hc
+        out = np.zeros(cap, np.uint8)
+        n = ctypes.c_size_t(0)
+        if slice_type == 2:
+            rc = L.uvghip_write_idr_nals(poc, frame_qp - qp0, 1, H.ptr(rows), rows.shape[1], H.ptr(sizes), hc, H.ptr(sums), H.ptr(out), cap, ctypes.byref(n))
+        else:
+            n_refs = int(g["refs"][k][0])
+            deltas = np.ascontiguousarray(sorted(poc - int(p) for p in g["refs"][k][1:1 + n_refs]), np.int32)
+            rc = L.uvghip_write_picture_nals_pb(poc, 4, slice_type, n_refs, H.ptr(deltas), 1, 1, frame_qp - qp0, 1, H.ptr(rows), rows.shape[1], H.ptr(sizes), hc,
+                                                H.ptr(sums), H.ptr(out), cap, ctypes.byref(n))
+        assert rc == 0
+        mine += out[:n.value].tobytes()
+    at = stream.find(b"\x00\x00\x01\x00\x41")
+    assert at > 0
+    body = stream[at:]
+    if body != mine:
+        i = next(j for j in range(min(len(body), len(mine))) if body[j] != mine[j])
+        assert False, (name, "first differing byte", i, body[max(0, i - 8):i + 8].hex(), mine[max(0, i - 8):i + 8].hex(), len(body), len(mine))
+    assert stream[:at] + mine == stream

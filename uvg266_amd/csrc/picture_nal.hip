@@ -60,6 +60,7 @@ struct nal_writer {
     bits(0, len);
     bits(v + 1, len + 1);
   }
+  void se(int v) { ue(v > 0 ? 2u * (uint32_t)v - 1u : 2u * (uint32_t)(-v)); }
   void align_with_one() { bits(1, 1); while (nacc) bits(0, 1); }
   void start(int nal_type, bool long_code = false)       // start code, two header bytes: none of them counts towards the emulation prevention
   {
@@ -68,7 +69,35 @@ struct nal_writer {
   }
 };
 
-enum { NAL_IDR_W_RADL = 7, NAL_IDR_N_LP = 8, NAL_SUFFIX_SEI = 24 };
+enum { NAL_TRAIL = 0, NAL_IDR_W_RADL = 7, NAL_IDR_N_LP = 8, NAL_SUFFIX_SEI = 24 };
+
+// entry points, byte alignment, the rows' substreams, then the decoded picture hash SEI (shared by both writers)
+void finish_picture(nal_writer &w, uint8_t *out, size_t cap, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows, int32_t longest,
+                    const uint32_t *checksum)
+{
+  if (n_rows > 1) {                  // entry points: every row but the last, in offset_len bits each (:1386-1404)
+    int offset_len = 0;
+    for (int32_t t = longest; t; t >>= 1) ++offset_len;
+    w.ue((uint32_t)offset_len - 1);
+    for (int r = 0; r + 1 < n_rows; ++r) w.bits((uint32_t)row_bytes[r] - 1, offset_len);
+  }
+  w.align_with_one();
+  for (int r = 0; r < n_rows; ++r) {
+    const size_t nb = (size_t)row_bytes[r];
+    if (w.n + nb <= cap) memcpy(out + w.n, rows + (size_t)r * row_pitch, nb);
+    w.n += nb;
+  }
+  if (checksum) {
+    w.zeros = 0;                     // (the last row ends with its stop bit: the zero run does not reach across)
+    w.start(NAL_SUFFIX_SEI);
+    w.bits(132, 8);                  // payload type: decoded picture hash
+    w.bits(2 + 3 * 4, 8);            // payload size
+    w.bits(2, 8);                    // hash type: checksum
+    w.bits(0, 8);                    // dph_sei_single_component_flag = 0, seven reserved bits
+    for (int c = 0; c < 3; ++c) w.bits(checksum[c], 32);
+    w.align_with_one();              // (already aligned: the trailing bits are a byte of their own)
+  }
+}
 
 }  // namespace
 
@@ -96,6 +125,12 @@ extern "C" int uvghip_picture_checksum(int bitdepth, const void *plane_y, int st
 extern "C" int uvghip_write_picture_nals(int poc, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
                                          const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len)
 {
+  return uvghip_write_idr_nals(poc, 0, sao, rows, row_pitch, row_bytes, n_rows, checksum, out, cap, len);
+}
+// ... with the slice QP offset (sh_qp_delta = state->frame->QP - cfg.qp: the intra QP offset of a low-delay stream's first picture)
+extern "C" int uvghip_write_idr_nals(int poc, int qp_delta, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
+                                     const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len)
+{
   if (!rows || !row_bytes || n_rows <= 0 || !len || (!out && cap) || poc < 0)
     return uvghip_set_error(hipErrorInvalidValue, __func__);
   int32_t longest = 0;
@@ -117,32 +152,68 @@ extern "C" int uvghip_write_picture_nals(int poc, int sao, const uint8_t *rows, 
   w.ue(0);                           // ph_pic_parameter_set_id
   w.bits((uint32_t)poc & 15u, 4);    // ph_pic_order_cnt_lsb (the SPS of this configuration signals 4 bits)
   w.bits(0, 1);                      // sh_no_output_of_prior_pics_flag
-  w.bits(1, 1);                      // sh_qp_delta = 0 as se(v)
+  w.se(qp_delta);                    // sh_qp_delta
   if (sao) w.bits(3, 2);             // sh_sao_luma_used_flag, sh_sao_chroma_used_flag
-  if (n_rows > 1) {                  // entry points: every row but the last, in offset_len bits each (:1386-1404)
-    int offset_len = 0;
-    for (int32_t t = longest; t; t >>= 1) ++offset_len;
-    w.ue((uint32_t)offset_len - 1);
-    for (int r = 0; r + 1 < n_rows; ++r) w.bits((uint32_t)row_bytes[r] - 1, offset_len);
-  }
-  w.align_with_one();
-  for (int r = 0; r < n_rows; ++r) {
-    const size_t nb = (size_t)row_bytes[r];
-    if (w.n + nb <= cap) memcpy(out + w.n, rows + (size_t)r * row_pitch, nb);
-    w.n += nb;
-  }
-  // ---- decoded picture hash SEI (checksum), if asked for ----
-  if (checksum) {
-    w.zeros = 0;                     // (the last row ends with its stop bit: the zero run does not reach across)
-    w.start(NAL_SUFFIX_SEI);
-    w.bits(132, 8);                  // payload type: decoded picture hash
-    w.bits(2 + 3 * 4, 8);            // payload size
-    w.bits(2, 8);                    // hash type: checksum
-    w.bits(0, 8);                    // dph_sei_single_component_flag = 0, seven reserved bits
-    for (int c = 0; c < 3; ++c) w.bits(checksum[c], 32);
-    w.align_with_one();              // (already aligned: the trailing bits are a byte of their own)
-  }
+  finish_picture(w, out, cap, rows, row_pitch, row_bytes, n_rows, longest, checksum);
   *len = w.n;
   if (w.n > cap) return uvghip_set_error(hipErrorInvalidValue, "uvghip_write_picture_nals: the output buffer is too small (see *len)");
+  return 0;
+}
+
+// The same for a P / B picture of a low-delay stream (TRAIL pictures, one temporal layer): the picture header's inter flags, the slice
+// type, the reference picture list syntax, the collocated picture, the slice QP offset.
+// replaces: uvg_encoder_state_write_bitstream_slice_header (:1248-1411) with _picture_header (:1009-1139) and _ref_pic_list (:1141-1246)
+// for pictype TRAIL; gop_lowdelay, so list 1 is signalled as a copy of list 0's entries when bi-prediction is on (:1165) and every
+// reference lies in the past.  delta_neg: poc - the POC of each reference picture, in the order of the GOP structure's ref_neg[]
+// (uvg_config_process_lp_gop, src/cfg.c:1640-1720: ascending); copy_rpl1 = cfg.bipred; qp_delta = state->frame->QP - cfg.qp.
+extern "C" int uvghip_write_picture_nals_pb(int poc, int poc_lsb_bits, int slice_type, int n_ref_neg, const int32_t *delta_neg, int copy_rpl1, int tmvp, int qp_delta,
+                                            int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows, const uint32_t *checksum,
+                                            uint8_t *out, size_t cap, size_t *len)
+{
+  if (!rows || !row_bytes || n_rows <= 0 || !len || (!out && cap) || poc < 0 || poc_lsb_bits < 4 || poc_lsb_bits > 16 || (slice_type != 0 && slice_type != 1) ||
+      n_ref_neg < 1 || n_ref_neg > 15 || !delta_neg)
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  int32_t longest = 0;
+  for (int r = 0; r < n_rows; ++r) {
+    if (row_bytes[r] <= 0 || (size_t)row_bytes[r] > row_pitch) return uvghip_set_error(hipErrorInvalidValue, "uvghip_write_picture_nals_pb: a row is empty or longer than its slot");
+    if (row_bytes[r] > longest) longest = row_bytes[r];
+  }
+  nal_writer w = {out, cap, 0, 0, 0, 0};
+  w.start(NAL_TRAIL, true);          // the first NAL unit of its access unit: long start code; temporal id 0
+  w.bits(1, 1);                      // sh_picture_header_in_slice_header_flag
+  w.bits(0, 1);                      // ph_gdr_or_irap_pic_flag
+  w.bits(0, 1);                      // ph_non_ref_pic_flag
+  w.bits(1, 1);                      // ph_inter_slice_allowed_flag
+  w.bits(1, 1);                      // ph_intra_slice_allowed_flag
+  w.ue(0);                           // ph_pic_parameter_set_id
+  w.bits((uint32_t)poc & ((1u << poc_lsb_bits) - 1u), poc_lsb_bits);
+  if (tmvp) w.bits(1, 1);            // ph_pic_temporal_mvp_enabled_flag
+  w.bits(0, 1);                      // ph_mvd_l1_zero_flag
+  w.ue((uint32_t)slice_type);        // sh_slice_type
+  const int lists = 1 + (copy_rpl1 ? 1 : 0);
+  for (int list = 0; list < lists; ++list) {
+    w.ue((uint32_t)n_ref_neg);       // num_ref_entries
+    int last = 0;
+    for (int j = 0; j < n_ref_neg; ++j) {
+      const int d = delta_neg[j];
+      w.ue(d ? (uint32_t)(d - last - 1) : 0u);      // abs_delta_poc_st
+      if (d + 1) w.bits(1, 1);                       // strp_entry_sign_flag
+      last = d;
+    }
+  }
+  if (!copy_rpl1) w.ue(0);           // num_ref_entries[1]: no reference in the future
+  if (n_ref_neg > 1) {
+    w.bits(1, 1);                    // sh_num_ref_idx_active_override_flag
+    for (int list = 0; list < lists; ++list) w.ue((uint32_t)n_ref_neg - 1);
+  }
+  if (tmvp) {
+    if (slice_type == 0) w.bits(1, 1);               // sh_collocated_from_l0_flag
+    if (n_ref_neg > 1) w.ue(0);                      // sh_collocated_ref_idx
+  }
+  w.se(qp_delta);                    // sh_qp_delta
+  if (sao) w.bits(3, 2);             // sh_sao_luma_used_flag, sh_sao_chroma_used_flag
+  finish_picture(w, out, cap, rows, row_pitch, row_bytes, n_rows, longest, checksum);
+  *len = w.n;
+  if (w.n > cap) return uvghip_set_error(hipErrorInvalidValue, "uvghip_write_picture_nals_pb: the output buffer is too small (see *len)");
   return 0;
 }
