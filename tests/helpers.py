@@ -1073,7 +1073,8 @@ def iter_inter_frames(W, H, P):
             F.ref_pocs[i] = pocs[i]
             F.l[0][i], F.l[1][i] = lists[0][i], lists[1][i]
         F.l_size[0], F.l_size[1] = lsz
-        F.tmvp, F.max_merge, F.merge_level, F.bipred, F.fme_level, F.early_skip, F.depth_inter_min, F.depth_inter_max = 1, 6, 2, 1, 4, 1, 0, 3
+        F.tmvp, F.max_merge, F.merge_level, F.bipred, F.fme_level, F.early_skip = (int(a) for a in d.get("cfg", (1, 6, 2, 1, 4, 1)))
+        F.depth_inter_min, F.depth_inter_max = 0, 3
         F.ref_cu_stride, F.frame_qp = wc * 16, int(d["meta"][7])
         keep = []
         for i in range(n_refs):
@@ -1217,7 +1218,8 @@ def run_inter_oracle(orc, W, H, depth, pics, P, ctx_trace=False):
             F.ref_pocs[i] = pocs[i]
             F.l[0][i], F.l[1][i] = lists[0][i], lists[1][i]
         F.l_size[0], F.l_size[1] = lsz
-        F.tmvp, F.max_merge, F.merge_level, F.bipred, F.fme_level, F.early_skip, F.depth_inter_min, F.depth_inter_max = 1, 6, 2, 1, 4, 1, 0, 3
+        F.tmvp, F.max_merge, F.merge_level, F.bipred, F.fme_level, F.early_skip = (int(a) for a in d.get("cfg", (1, 6, 2, 1, 4, 1)))
+        F.depth_inter_min, F.depth_inter_max = 0, 3
         F.ref_cu_stride, F.frame_qp = wc * 16, int(d["meta"][7])
         keep = []
         for i in range(n_refs):
@@ -1328,6 +1330,8 @@ def inter_pictures_from_golden(g):
         d["coeff"][kk] = g["coeff"][k]
         d["models"][kk], d["models_inter"][kk] = g["models"][k], g["models_inter"][k]
     for fr, d in P.items():
+        if "cfg" in g.files:
+            d["cfg"] = g["cfg"]          # the tools of the run (tmvp, max_merge, merge_level, bipred, fme_level, early_skip); absent: --preset medium's
         d["rec"] = [g["rec_y"][fr], g["rec_u"][fr], g["rec_v"][fr]]
         d["final"] = (g["final_y"][fr], g["final_u"][fr], g["final_v"][fr])
     for a, b in zip(g["cuinter_i"], g["cuinter_d"]):

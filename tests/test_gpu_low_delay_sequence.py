@@ -9,7 +9,9 @@ import pytest
 import helpers as H
 
 pytestmark = pytest.mark.gpu
-GOLDENS = ["ref_inter_136x72_10_qp22_4frames", "ref_inter_192x128_8_qp17_5frames", "ref_inter_264x136_8_qp32_9frames"]
+GOLDENS = ["ref_inter_136x72_10_qp22_4frames", "ref_inter_192x128_8_qp17_5frames", "ref_inter_264x136_8_qp32_9frames",
+           # other tools than --preset medium's: P slices (no bi-prediction) without the temporal candidate; no fractional search, no early skip
+           "ref_inter_136x72_8_qp27_4frames_p_notmvp", "ref_inter_192x128_10_qp24_4frames_subme0_noskip"]
 
 
 @pytest.mark.parametrize("name", GOLDENS)
@@ -98,7 +100,7 @@ def test_sequence_closed_loop_on_the_device(hip, name):
             rc = hip.uvghip_write_idr_nals(poc, frame_qp - qp0, 1, H.ptr(rows_h), rows_h.shape[1], H.ptr(sizes), hc, H.ptr(sums), H.ptr(buf), cap, ctypes.byref(n))
         else:
             deltas = np.ascontiguousarray(sorted(poc - F.ref_pocs[i] for i in range(F.n_refs)), np.int32)
-            rc = hip.uvghip_write_picture_nals_pb(poc, 4, slice_type, F.n_refs, H.ptr(deltas), 1, 1, frame_qp - qp0, 1, H.ptr(rows_h), rows_h.shape[1], H.ptr(sizes), hc,
+            rc = hip.uvghip_write_picture_nals_pb(poc, 4, slice_type, F.n_refs, H.ptr(deltas), F.bipred, F.tmvp, frame_qp - qp0, 1, H.ptr(rows_h), rows_h.shape[1], H.ptr(sizes), hc,
                                                   H.ptr(sums), H.ptr(buf), cap, ctypes.byref(n))
         assert rc == 0
         mine += buf[:n.value].tobytes()

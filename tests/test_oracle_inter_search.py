@@ -11,7 +11,8 @@ import pytest
 import helpers as H
 
 
-@pytest.mark.parametrize("name", ["ref_inter_192x128_8_qp17_5frames", "ref_inter_136x72_10_qp22_4frames", "ref_inter_264x136_8_qp32_9frames"])
+@pytest.mark.parametrize("name", ["ref_inter_192x128_8_qp17_5frames", "ref_inter_136x72_10_qp22_4frames", "ref_inter_264x136_8_qp32_9frames",
+                                  "ref_inter_136x72_8_qp27_4frames_p_notmvp", "ref_inter_192x128_10_qp24_4frames_subme0_noskip"])
 def test_every_picture_of_a_low_delay_encode(name):
     orc = H.load_oracle()
     g = H.ctu_golden(name)
@@ -33,6 +34,7 @@ def test_every_picture_of_a_low_delay_encode(name):
             seen["intra_in_b"] += int((c[:, :, 0] == 1).sum())
     # what the golden exercises (counts of 4x4 units): every kind of decision in the two 8-bit encodes
     print(name, seen)
-    assert seen["calls"] > 100 and seen["bi"] and seen["amvp"], seen
-    if depth == 8:
+    variant = "cfg" in g.files          # a golden with other tools than --preset medium's: P slices only / no early skip
+    assert seen["calls"] > 100 and seen["amvp"] and (seen["bi"] or variant), seen
+    if depth == 8 and not variant:
         assert seen["merge"] and seen["skip"], seen

@@ -157,7 +157,8 @@ def test_device_outputs_complete_a_multi_picture_stream(hip, name):
     assert stream[:at] + mine == stream
 
 
-@pytest.mark.parametrize("name", ["ref_inter_136x72_10_qp22_4frames", "ref_inter_192x128_8_qp17_5frames", "ref_inter_264x136_8_qp32_9frames"])
+@pytest.mark.parametrize("name", ["ref_inter_136x72_10_qp22_4frames", "ref_inter_192x128_8_qp17_5frames", "ref_inter_264x136_8_qp32_9frames",
+                                  "ref_inter_136x72_8_qp27_4frames_p_notmvp", "ref_inter_192x128_10_qp24_4frames_subme0_noskip"])
 def test_whole_low_delay_file_from_rows_and_final_pictures(name):
     """A low-delay stream (--gop lp-g4d3t1): behind the encoder's parameter sets, the IDR picture's NAL units (with its slice QP offset)
     and every B picture's -- picture header with the inter flags, slice type, reference picture lists, collocated picture, QP offset,
@@ -190,7 +191,8 @@ def test_whole_low_delay_file_from_rows_and_final_pictures(name):
         else:
             n_refs = int(g["refs"][k][0])
             deltas = np.ascontiguousarray(sorted(poc - int(p) for p in g["refs"][k][1:1 + n_refs]), np.int32)
-            rc = L.uvghip_write_picture_nals_pb(poc, 4, slice_type, n_refs, H.ptr(deltas), 1, 1, frame_qp - qp0, 1, H.ptr(rows), rows.shape[1], H.ptr(sizes), hc,
+            cfg = g["cfg"] if "cfg" in g.files else (1, 6, 2, 1, 4, 1)
+            rc = L.uvghip_write_picture_nals_pb(poc, 4, slice_type, n_refs, H.ptr(deltas), int(cfg[3]), int(cfg[0]), frame_qp - qp0, 1, H.ptr(rows), rows.shape[1], H.ptr(sizes), hc,
                                                 H.ptr(sums), H.ptr(out), cap, ctypes.byref(n))
         assert rc == 0
         mine += out[:n.value].tobytes()

@@ -207,6 +207,7 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
     subprocess.check_call([os.path.join(ROOT, "tools/refcheck/ctu_dump.sh"), str(depth), yuv, str(W), str(H), str(frames), out,
                            "preset", "medium", "gop", "lp-g4d3t1", "qp", str(qp)] + list(extra), stderr=subprocess.DEVNULL,
                           env=dict(os.environ, CTU_DUMP_CU_INTER="1"))
+    opt = dict(zip(extra[0::2], extra[1::2]))
     recs = read_records(out + ".bin")
     S = [r for n, r in recs if n == "search"]
     F = sorted([r for n, r in recs if n == "final"], key=lambda r: int(r[0][0]))
@@ -254,7 +255,10 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
                         # every call of uvg_search_cu_inter in coding order: frame, x, y, w, h, then the decided cu_info_t fields; its two costs
                         cuinter_i=np.stack([r[0] for r in CI]).astype(np.int32) if with_levels else np.zeros((0, 20), np.int32),
                         cuinter_d=np.stack([r[1] for r in CI]) if with_levels else np.zeros((0, 2)),
-                        sao_models=sao_models, row_bytes=row_bytes, row_off=row_off, bitstream=np.frombuffer(open(out + ".266", "rb").read(), np.uint8))
+                        sao_models=sao_models, row_bytes=row_bytes, row_off=row_off, bitstream=np.frombuffer(open(out + ".266", "rb").read(), np.uint8),
+                        # the tools the run had on, for the tests' frame state: tmvp, max_merge, merge_level, bipred, fme_level, early_skip
+                        cfg=np.array([int(opt.get("tmvp", 1)), int(opt.get("max-merge", 6)), 2, int(opt.get("bipred", 1)), {0: 0, 1: 1, 2: 2, 3: 3, 4: 4}[int(opt.get("subme", 4))],
+                                      int(opt.get("early-skip", 1))], np.int32))
     if not out_dir: print("wrote inter", tag, n, "CTU records")
     return tag
 
