@@ -569,6 +569,103 @@ template <typename PX> CTU_NOINLINE CTU_DEV int quantize_inter(lds<PX> *S, const
   return any;
 }
 
+// The merge analysis of an 8x8 CU, all candidates at once.  One candidate's prediction occupies 15 of the wave's 64 lanes and waits for
+// memory at every step; the (up to six) candidates are independent, so their rows are fetched and filtered together, then their
+// columns, then each candidate's 8x8 SATD on a lane of its own.  Scratch: the 32x32 depth's transform buffers, idle while one wave walks
+// the CTU -- tmp [candidate][list][15 rows][8] int16, the predictions [candidate][64] behind the first list's intermediates.
+// Same arithmetic as ipol_passes<PX, 8, 8> / uvg_bipred_average.  -> S->wv[3].rq_i[c]: the SATD of candidate c; its samples stay in pred8(c)
+template <typename PX> CTU_DEV PX *pred8_of(lds<PX> *S, int c) { return (PX *)(S->wv[3].lv0 + 512) + c * 64; }
+template <typename PX> CTU_NOINLINE CTU_DEV void merge_batch8(lds<PX> *S, const job<PX> &J, int x, int y, int n_mc)
+{
+  const pb_job &B = *J.pb;
+  pb_state &Q = S->pb;
+  wctx &K = S->wv[3];
+  CTU_LDS int16_t *const tmp = LDSP(int16_t, K.t0);
+  const int depth = (int)px_info<PX>::depth, shift1 = depth - 8;
+  const int W = J.P.pic_w, H = J.P.pic_h;
+  PAR_FOR(e, n_mc * 2 * 15) {
+    const int c = e / 30, l = (e / 15) & 1, r = e % 15;
+    const icand::merge_cand &m = Q.mc[c];
+    if (!(m.dir & (1 << l))) continue;
+    CTU_GLB const PX *const ref = (CTU_GLB const PX *)B.ref_y[B.l[l][m.ref[l] & 15]];
+    const int mvx = m.mv[l][0], mvy = m.mv[l][1], fx = mvx & 15;
+    const int x0 = x + (mvx >> 4), y0 = y + (mvy >> 4);
+    CTU_GLB const PX *row = ref + (size_t)clampi(y0 + r - 3, 0, H - 1) * B.ref_stride;
+    CTU_LDS int16_t *o = tmp + ((c * 2 + l) * 15 + r) * 8;
+    const int xs = x0 - 3;
+    if (fx == 0) {
+      for (int j = 0; j < 8; ++j) o[j] = (int16_t)((64 * (int)row[clampi(xs + 3 + j, 0, W - 1)]) >> shift1);
+    } else {
+      const int8_t *fh = VVC_LUMA_FILTER + 8 * fx;
+      int px[15];
+      if (xs >= 0 && xs + 15 <= W) { for (int j = 0; j < 15; ++j) px[j] = (int)row[xs + j]; }
+      else for (int j = 0; j < 15; ++j) px[j] = (int)row[clampi(xs + j, 0, W - 1)];
+      for (int j = 0; j < 8; ++j) {
+        int acc = 0;
+        for (int k = 0; k < 8; ++k) acc += fh[k] * px[j + k];
+        o[j] = (int16_t)(acc >> shift1);
+      }
+    }
+  }
+  CTU_SYNC();
+  const int wp_shift = 14 - depth, wp_off = 1 << (wp_shift - 1), bi_shift = 15 - depth, bi_off = 1 << (bi_shift - 1);
+  PAR_FOR(e, n_mc * 8) {
+    const int c = e >> 3, q = e & 7;
+    const icand::merge_cand &m = Q.mc[c];
+    int hi[2][8];
+    for (int l = 0; l < 2; ++l) {
+      if (!(m.dir & (1 << l))) continue;
+      const int fy = m.mv[l][1] & 15;
+      const CTU_LDS int16_t *t = tmp + (c * 2 + l) * 120 + q;
+      if (fy == 0) { for (int j = 0; j < 8; ++j) hi[l][j] = (int)t[(j + 3) * 8]; }
+      else {
+        const int8_t *fv = VVC_LUMA_FILTER + 8 * fy;
+        int v[15];
+        for (int j = 0; j < 15; ++j) v[j] = (int)t[j * 8];
+        for (int j = 0; j < 8; ++j) {
+          int acc = 0;
+          for (int k = 0; k < 8; ++k) acc += fv[k] * v[j + k];
+          hi[l][j] = (int)(int16_t)(acc >> 6);
+        }
+      }
+    }
+    CTU_LDS PX *p = LDSP(PX, pred8_of(S, c)) + q;
+    for (int j = 0; j < 8; ++j) {
+      int v;
+      if (m.dir == 3) v = (hi[0][j] + hi[1][j] + bi_off) >> bi_shift;
+      else v = (hi[m.dir - 1][j] + wp_off) >> wp_shift;
+      p[j * 8] = (PX)clampi(v, 0, (int)px_info<PX>::maxv);
+    }
+  }
+  CTU_SYNC();
+  PAR_FOR(c, n_mc) {
+    CTU_GLB const PX *const cur = (CTU_GLB const PX *)J.src_y + (size_t)y * J.src_stride + x;
+    CTU_LDS const PX *const pred = LDSP(const PX, pred8_of(S, c));
+#if defined(__HIPCC__)
+    uint32_t d[8][4];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      uint32_t cp[4];
+      const CTU_GLB uint32_t *c32 = (const CTU_GLB uint32_t *)(cur + (size_t)r * J.src_stride);
+      if (sizeof(PX) == 1) {
+        const uint32_t a = c32[0], b = c32[1];
+        cp[0] = (a & 0xffu) | ((a & 0xff00u) << 8); cp[1] = ((a >> 16) & 0xffu) | ((a >> 24) << 16);
+        cp[2] = (b & 0xffu) | ((b & 0xff00u) << 8); cp[3] = ((b >> 16) & 0xffu) | ((b >> 24) << 16);
+      } else { cp[0] = c32[0]; cp[1] = c32[1]; cp[2] = c32[2]; cp[3] = c32[3]; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[r][q] = pk_sub(cp[q], (uint32_t)pred[r * 8 + 2 * q] | ((uint32_t)pred[r * 8 + 2 * q + 1] << 16));
+    }
+    K.rq_i[c] = (int32_t)(satd8_tile_lane(d) >> (depth - 8));
+#else
+    int d[64];
+    for (int r = 0; r < 8; ++r)
+      for (int q = 0; q < 8; ++q) d[r * 8 + q] = (int)cur[(size_t)r * J.src_stride + q] - (int)pred[r * 8 + q];
+    K.rq_i[c] = (int32_t)(satd8_tile(d) >> (depth - 8));
+#endif
+  }
+  CTU_SYNC();
+}
+
 // search_pu_inter (search_inter.c:1671-2101): merge analysis, the early skip test, the motion search per reference picture, the
 // fractional search of each list's best, the bi-prediction of the two; the maps stay in S->pb.  -> 1: early skip (S->pb.cur is the CU)
 template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, const job<PX> &J, int L, const cu_target<PX> &T)
@@ -594,7 +691,9 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
   PB_T1(J.W, 0); }
   const double merge_flag_cost = m_fbits(mdl, MI_MERGE_FLAG, 1);
   const int n_mc = Q.n_mc;
+  const bool batch8 = n == 8;
   { PB_T0();
+  if (batch8) merge_batch8(S, J, x, y, n_mc);
   for (int merge_idx = 0; merge_idx < n_mc; ++merge_idx) {
     SERIAL cand_from_merge(&Q.cur, Q.mc[merge_idx]);
     CTU_SYNC();
@@ -604,8 +703,12 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
     bool dup = false;
     for (int i = 0; i < Q.merge_size && !dup; ++i) dup = same_merge(Q.mc[merge_idx], Q.mc[Q.merge[Q.merge_keys[i]].merge_idx]);
     if (dup) continue;
-    pred_cu(S, J, x, y, n, &Q.cur.m, 1, 0, T.ry, T.rpy, T.ru, T.rv, T.rpc);
-    const unsigned satd = satd_vs_source(J, x, y, n, T.ry, T.rpy);
+    unsigned satd;
+    if (batch8) satd = (unsigned)S->wv[3].rq_i[merge_idx];
+    else {
+      pred_cu(S, J, x, y, n, &Q.cur.m, 1, 0, T.ry, T.rpy, T.ru, T.rv, T.rpc);
+      satd = satd_vs_source(J, x, y, n, T.ry, T.rpy);
+    }
     SERIAL {
       const int e = Q.merge_size;
       pb_cand &u = Q.merge[e];
@@ -630,7 +733,10 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
       const int merge_idx = Q.merge[Q.merge_keys[k]].merge_idx;
       SERIAL cand_from_merge(&Q.cur, Q.mc[merge_idx]);
       CTU_SYNC();
-      pred_cu(S, J, x, y, n, &Q.cur.m, 1, 0, T.ry, T.rpy, T.ru, T.rv, T.rpc);
+      if (batch8) {
+        PAR_FOR(e, 64) LDSP(PX, T.ry)[(e >> 3) * T.rpy + (e & 7)] = LDSP(const PX, pred8_of(S, merge_idx))[e];
+        CTU_SYNC();
+      } else pred_cu(S, J, x, y, n, &Q.cur.m, 1, 0, T.ry, T.rpy, T.ru, T.rv, T.rpc);
       int32_t cbf4[4] = {0, 0, 0, 0};
       if (quantize_inter(S, J, x, y, n, T, 1, 0, 1, cbf4)) continue;
       pred_cu(S, J, x, y, n, &Q.cur.m, 0, 1, T.ry, T.rpy, T.ru, T.rv, T.rpc);
