@@ -144,24 +144,28 @@ template <typename PX> CTU_DEV int ref_px(CTU_GLB const PX *ref, int stride, int
 // filter, chroma: 1/32 with the 4-tap filter): horizontal pass into tmp (rows y0 - off .. of w int16 each), vertical pass into dst.
 // out 0: samples; 1: the 14-bit intermediates (int16); 2: samples of the bi-prediction with the other list's intermediates in `other`.
 // A lane takes SEG outputs in a row (horizontal pass) or in a column (vertical pass) at a time: SEG + TAPS - 1 loads for SEG outputs.
-template <typename PX, int TAPS, int SEG> CTU_DEV void ipol_passes(CTU_GLB const PX *ref, int stride, int pw, int ph, int x0, int y0, int w, int h, int fx, int fy,
-                                                                    int out, void *dst_, int dp, const int16_t *other_, int op, CTU_LDS int16_t *tmp)
+// Two planes of the same geometry (U and V) go through the passes together when ref2 is given: their rows are one batch of loads.
+template <typename PX, int TAPS, int SEG> CTU_DEV void ipol_passes(CTU_GLB const PX *ref, CTU_GLB const PX *ref2, int stride, int pw, int ph, int x0, int y0, int w, int h,
+                                                                    int fx, int fy, int out, void *dst_, void *dst2_, int dp, const int16_t *other_, const int16_t *other2_,
+                                                                    int op, CTU_LDS int16_t *tmp)
 {
   const int depth = (int)px_info<PX>::depth;
   const int off = TAPS == 4 ? 1 : 3;
   const int8_t *const fh = TAPS == 4 ? VVC_CHROMA_FILTER + 4 * fx : VVC_LUMA_FILTER + 8 * fx;
   const int8_t *const fv = TAPS == 4 ? VVC_CHROMA_FILTER + 4 * fy : VVC_LUMA_FILTER + 8 * fy;
   const int shift1 = depth - 8;
-  const int rows = h + TAPS - 1, segs = w / SEG;
+  const int rows = h + TAPS - 1, segs = w / SEG, planes = ref2 ? 2 : 1, plane_sz = rows * w;
   int ch[TAPS], cv[TAPS];
   for (int k = 0; k < TAPS; ++k) { ch[k] = fh[k]; cv[k] = fv[k]; }
-  PAR_FOR(e, rows * segs) {
+  PAR_FOR(e0, planes * rows * segs) {
+    const int pl = e0 >= rows * segs, e = e0 - pl * rows * segs;
     const int r = e / segs, q0 = (e - r * segs) * SEG;
-    CTU_GLB const PX *row = ref + (size_t)clampi(y0 + r - off, 0, ph - 1) * stride;
+    CTU_GLB const PX *row = (pl ? ref2 : ref) + (size_t)clampi(y0 + r - off, 0, ph - 1) * stride;
+    CTU_LDS int16_t *o = tmp + pl * plane_sz + r * w + q0;
     const int xs = x0 + q0 - off;
     if (fx == 0) {
-      if (xs + off >= 0 && xs + off + SEG <= pw) { for (int j = 0; j < SEG; ++j) tmp[r * w + q0 + j] = (int16_t)((64 * (int)row[xs + off + j]) >> shift1); }
-      else for (int j = 0; j < SEG; ++j) tmp[r * w + q0 + j] = (int16_t)((64 * (int)row[clampi(xs + off + j, 0, pw - 1)]) >> shift1);
+      if (xs + off >= 0 && xs + off + SEG <= pw) { for (int j = 0; j < SEG; ++j) o[j] = (int16_t)((64 * (int)row[xs + off + j]) >> shift1); }
+      else for (int j = 0; j < SEG; ++j) o[j] = (int16_t)((64 * (int)row[clampi(xs + off + j, 0, pw - 1)]) >> shift1);
     } else {
       int px[SEG + TAPS - 1];
       if (xs >= 0 && xs + SEG + TAPS - 1 <= pw) { for (int j = 0; j < SEG + TAPS - 1; ++j) px[j] = (int)row[xs + j]; }
@@ -169,43 +173,48 @@ template <typename PX, int TAPS, int SEG> CTU_DEV void ipol_passes(CTU_GLB const
       for (int j = 0; j < SEG; ++j) {
         int acc = 0;
         for (int k = 0; k < TAPS; ++k) acc += ch[k] * px[j + k];
-        tmp[r * w + q0 + j] = (int16_t)(acc >> shift1);
+        o[j] = (int16_t)(acc >> shift1);
       }
     }
   }
   CTU_SYNC();
   const int wp_shift = 14 - depth, wp_off = 1 << (wp_shift - 1), bi_shift = 15 - depth, bi_off = 1 << (bi_shift - 1);
   const int vsegs = h / SEG;
-  PAR_FOR(e, vsegs * w) {
+  PAR_FOR(e0, planes * vsegs * w) {
+    const int pl = e0 >= vsegs * w, e = e0 - pl * vsegs * w;
     const int sg = e / w, q = e - sg * w, r0 = sg * SEG;
+    const CTU_LDS int16_t *tp = tmp + pl * plane_sz;
     int hi[SEG];
-    if (fy == 0) { for (int j = 0; j < SEG; ++j) hi[j] = (int)(int16_t)((64 * (int)tmp[(r0 + j + off) * w + q]) >> 6); }
+    if (fy == 0) { for (int j = 0; j < SEG; ++j) hi[j] = (int)(int16_t)((64 * (int)tp[(r0 + j + off) * w + q]) >> 6); }
     else {
       int t[SEG + TAPS - 1];
-      for (int j = 0; j < SEG + TAPS - 1; ++j) t[j] = (int)tmp[(r0 + j) * w + q];
+      for (int j = 0; j < SEG + TAPS - 1; ++j) t[j] = (int)tp[(r0 + j) * w + q];
       for (int j = 0; j < SEG; ++j) {
         int acc = 0;
         for (int k = 0; k < TAPS; ++k) acc += cv[k] * t[j + k];
         hi[j] = (int)(int16_t)(acc >> 6);
       }
     }
+    void *const d_ = pl ? dst2_ : dst_;
+    const int16_t *const oth_ = pl ? other2_ : other_;
     for (int j = 0; j < SEG; ++j) {
       const int r = r0 + j;
-      if (out == 1) LDSP(int16_t, dst_)[r * dp + q] = (int16_t)hi[j];
-      else if (out == 0) LDSP(PX, dst_)[r * dp + q] = (PX)clampi((hi[j] + wp_off) >> wp_shift, 0, (int)px_info<PX>::maxv);
-      else LDSP(PX, dst_)[r * dp + q] = (PX)clampi((hi[j] + (int)LDSP(const int16_t, other_)[r * op + q] + bi_off) >> bi_shift, 0, (int)px_info<PX>::maxv);
+      if (out == 1) LDSP(int16_t, d_)[r * dp + q] = (int16_t)hi[j];
+      else if (out == 0) LDSP(PX, d_)[r * dp + q] = (PX)clampi((hi[j] + wp_off) >> wp_shift, 0, (int)px_info<PX>::maxv);
+      else LDSP(PX, d_)[r * dp + q] = (PX)clampi((hi[j] + (int)LDSP(const int16_t, oth_)[r * op + q] + bi_off) >> bi_shift, 0, (int)px_info<PX>::maxv);
     }
   }
   CTU_SYNC();
 }
 template <typename PX> CTU_NOINLINE CTU_DEV void ipol_block(const PX *ref_, int stride, int pw, int ph, int x0, int y0, int w, int h, int fx, int fy, int is_chroma,
-                                                            int out, void *dst_, int dp, const int16_t *other_, int op, int16_t *tmp_)
+                                                            int out, void *dst_, int dp, const int16_t *other_, int op, int16_t *tmp_,
+                                                            const PX *ref2_ = nullptr, void *dst2_ = nullptr, const int16_t *other2_ = nullptr)
 {
-  CTU_GLB const PX *const ref = (CTU_GLB const PX *)ref_;
+  CTU_GLB const PX *const ref = (CTU_GLB const PX *)ref_, *const ref2 = (CTU_GLB const PX *)ref2_;
   CTU_LDS int16_t *const tmp = LDSP(int16_t, tmp_);
-  if (!is_chroma) ipol_passes<PX, 8, 8>(ref, stride, pw, ph, x0, y0, w, h, fx, fy, out, dst_, dp, other_, op, tmp);
-  else if (w >= 8) ipol_passes<PX, 4, 8>(ref, stride, pw, ph, x0, y0, w, h, fx, fy, out, dst_, dp, other_, op, tmp);
-  else ipol_passes<PX, 4, 4>(ref, stride, pw, ph, x0, y0, w, h, fx, fy, out, dst_, dp, other_, op, tmp);
+  if (!is_chroma) ipol_passes<PX, 8, 8>(ref, ref2, stride, pw, ph, x0, y0, w, h, fx, fy, out, dst_, dst2_, dp, other_, other2_, op, tmp);
+  else if (w >= 8) ipol_passes<PX, 4, 8>(ref, ref2, stride, pw, ph, x0, y0, w, h, fx, fy, out, dst_, dst2_, dp, other_, other2_, op, tmp);
+  else ipol_passes<PX, 4, 4>(ref, ref2, stride, pw, ph, x0, y0, w, h, fx, fy, out, dst_, dst2_, dp, other_, other2_, op, tmp);
 }
 
 // the prediction of the n x n CU at picture position (x, y) with motion m (icand::unit fields: mv, ref = list indices, dir) into
@@ -237,9 +246,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void pred_cu(lds<PX> *S, const job<P
           const int cq = q >> 1, bx = (x >> 1) + qx * cq, by = (y >> 1) + qy * cq;
           PX *du = ru + (qy * cq) * rpc + qx * cq, *dv = rv + (qy * cq) * rpc + qx * cq;
           ipol_block<PX>((const PX *)B.ref_u[ri], B.ref_stride_c, W >> 1, H >> 1, bx + (mvx >> 5), by + (mvy >> 5), cq, cq, mvx & 31, mvy & 31, 1, out,
-                         out == 1 ? (void *)V->lv1 : (void *)du, out == 1 ? cq : rpc, V->lv1, cq, V->t0);
-          ipol_block<PX>((const PX *)B.ref_v[ri], B.ref_stride_c, W >> 1, H >> 1, bx + (mvx >> 5), by + (mvy >> 5), cq, cq, mvx & 31, mvy & 31, 1, out,
-                         out == 1 ? (void *)V->lv2 : (void *)dv, out == 1 ? cq : rpc, V->lv2, cq, V->t0);
+                         out == 1 ? (void *)V->lv1 : (void *)du, out == 1 ? cq : rpc, V->lv1, cq, V->t0,
+                         (const PX *)B.ref_v[ri], out == 1 ? (void *)V->lv2 : (void *)dv, V->lv2);       // U and V together
         }
       }
 }
