@@ -165,3 +165,51 @@ def test_gloo_processes_run_the_schedule(world, height):
         p.join(60)
         assert p.exitcode == 0
     assert got == [(r, True) for r in range(world)]
+
+
+def _search_halo_worker(rank, nranks, port, height, q):
+    import torch
+    import torch.distributed as dist
+    from uvg266_amd import bands
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=nranks)
+    try:
+        W, wc = 192, 3
+        hc = (height + 63) // 64
+        lay = bands.BandLayout(height, nranks, rank)
+        mk = lambda shape, dt: torch.full(shape, -1, dtype=dt)
+        y, u, v = mk((height, W), torch.int16), mk((height // 2, W // 2), torch.int16), mk((height // 2, W // 2), torch.int16)
+        scu, mod = mk((hc * 16, wc * 16 * 32), torch.uint8), mk((wc * hc, 3 * 257), torch.int32)
+        # what this rank "produced": its own rows carry rank + 1 in every table
+        y[lay.y0:lay.y1] = rank + 1; u[lay.y0 // 2:lay.y1 // 2] = rank + 1; v[lay.y0 // 2:lay.y1 // 2] = rank + 1
+        scu[lay.y0 // 4:lay.y1 // 4] = rank + 1; mod[lay.ctu_row0 * wc:lay.ctu_row1 * wc] = rank + 1
+        tr = bands.TorchTransport(dist)
+        tr.exchange(lay.halo_search(y, u, v, scu, mod, wc))
+        ok = True
+        if rank > 0:
+            a = lay.y0
+            ok &= bool((y[a - 1] == rank).all() and (u[a // 2 - 1] == rank).all() and (v[a // 2 - 1] == rank).all() and (scu[a // 4 - 1] == rank).all())
+            ok &= bool((mod[(lay.ctu_row0 - 1) * wc] == rank).all())
+            # and nothing else arrived: the line above the received one is still untouched
+            ok &= bool(a < 2 or (y[a - 2] == -1).all())
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nranks,height", [(2, 256), (3, 448)])
+def test_search_halo_goes_down_one_band_over_gloo(nranks, height):
+    """The halo of the row-sharded closed-loop search (bands.BandLayout.halo_search): every rank receives from the band above exactly the
+    last reconstruction line, the last row of side information and the models of that band's last row's first CTU -- executed by real
+    processes over gloo with the exchange lists the RCCL transport takes."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_search_halo_worker, args=(r, nranks, port, height, q)) for r in range(nranks)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert got == [(r, True) for r in range(nranks)]

@@ -570,7 +570,9 @@ class CtuSearch:
     src: list of (y, u, v) device planes.  Outputs stay on the device: rec[i] = (y, u, v), cu[i] (uvghip_scu_t table as bytes,
     [rows of 4x4, 16 * CTUs per row, 32]), coeff[i] ([CTUs, 6144] int16), models[i] ([CTUs, 3, 257] uint32 as int32)."""
 
-    def __init__(self, params, src, _make_plan=True):
+    def __init__(self, params, src, _make_plan=True, rows=None):
+        """rows = (ctu_row0, ctu_row1): search only that band of CTU rows of every picture (uvghip_ctu_plan_create_rows; the caller
+        provides the halo of the row above in rec / cu / models, bands.BandLayout.halo_search)."""
         self.P = params
         self.n = len(src)
         W, H = params.pic_w, params.pic_h
@@ -595,8 +597,12 @@ class CtuSearch:
         import ctypes
         self.ws = torch.empty(self.L.uvghip_ctu_search_workspace_bytes(self.n, W, H), dtype=torch.uint8, device=dev)
         self.plan = ctypes.c_void_p()
-        _lib.check(self.L.uvghip_ctu_plan_create(self.depth, ctypes.byref(self.P), self.pics, self.n, _dev(self.ws), ctypes.byref(self.plan)),
-                   "uvghip_ctu_plan_create")
+        if rows is None:
+            _lib.check(self.L.uvghip_ctu_plan_create(self.depth, ctypes.byref(self.P), self.pics, self.n, _dev(self.ws), ctypes.byref(self.plan)),
+                       "uvghip_ctu_plan_create")
+        else:
+            _lib.check(self.L.uvghip_ctu_plan_create_rows(self.depth, ctypes.byref(self.P), self.pics, self.n, int(rows[0]), int(rows[1]), _dev(self.ws),
+                                                          ctypes.byref(self.plan)), "uvghip_ctu_plan_create_rows")
 
     def run(self, stream=None):
         """Enqueue the search of all n pictures on the current (or the given) stream; returns at once (uvghip_ctu_plan_run)."""

@@ -65,6 +65,22 @@ class BandLayout:
                          self._rows(scu, b, b + 4, 4)]))
         return ops
 
+    def halo_search(self, y, u, v, scu, models, ctus_per_row):
+        """The closed-loop CTU search of a band (uvghip_ctu_plan_create_rows) reads of the band above: its last line of the reconstruction
+        (hor_buf_search), its last row of per-4x4 side information and the models the coder holds after its last row's FIRST CTU (the
+        WPP context hand-over).  One direction: sent down after the band is searched, received from above before the search starts.
+        y, u, v: reconstruction planes; scu: [rows of 4x4 units, bytes]; models: [CTUs, words] (row = CTU index)."""
+        ops = []
+        if self.up >= 0:
+            a = self.y0
+            k = (self.ctu_row0 - 1) * ctus_per_row
+            ops.append((self.up, [], [self._rows(y, a - 1, a, 1), (u, a // 2 - 1, a // 2), (v, a // 2 - 1, a // 2), (scu, a // 4 - 1, a // 4), (models, k, k + 1)]))
+        if self.down >= 0:
+            b = self.y1
+            k = (self.ctu_row1 - 1) * ctus_per_row
+            ops.append((self.down, [self._rows(y, b - 1, b, 1), (u, b // 2 - 1, b // 2), (v, b // 2 - 1, b // 2), (scu, b // 4 - 1, b // 4), (models, k, k + 1)], []))
+        return ops
+
     def halo_alf(self, y, u, v):
         """After SAO: ALF classification, filtering and statistics of a band read 3 rows of SAO output across either
         boundary (clamped at the virtual boundary, src/alf.h:32-33); 4 luma / 2 chroma rows are exchanged."""
@@ -188,6 +204,8 @@ def emulate(all_ops):
             back = [o for o in all_ops[peer] if o[0] == r]
             assert len(back) == 1, f"rank {peer} has no exchange entry for rank {r}"
             sends = back[0][1]
+            if not recvs:
+                continue              # a one-directional exchange: this side only sends
             assert len(sends) == len(recvs), (r, peer)
             for (dt, d0, d1), (st, s0, s1) in zip(recvs, sends):
                 assert d1 - d0 == s1 - s0 and (d0, d1) == (s0, s1), "halo rows keep their picture coordinates"

@@ -32,6 +32,7 @@ struct launch_args {
   uint32_t *slots;            // bitmap of the slots in use
   int n_slots;
   int wc, hc, n_ctus;
+  int row0;                   // first CTU row of this launch (a band of a picture sharded by CTU rows): the row above it is complete in the buffers
 };
 
 template <typename PX>
@@ -69,7 +70,7 @@ __global__ void __launch_bounds__(256, 4) ctu_search_kernel(launch_args A)
     // Relaxed polls with a growing nap (an acquire per poll would invalidate this CU's L1 and the XCD's L2 under the other workgroups
     // every microsecond), then ONE agent-scope acquire: the L1 is the CU's, so the other waves' loads after the barrier are behind it.
     int naps = 1;
-    const int32_t *deps[2] = {cx > 0 ? &done[k - 1] : nullptr, cy > 0 ? &done[k - A.wc] : nullptr};
+    const int32_t *deps[2] = {cx > 0 ? &done[k - 1] : nullptr, cy > A.row0 ? &done[k - A.wc] : nullptr};
     for (int d = 0; d < 2; ++d)
       while (deps[d] && __hip_atomic_load(deps[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
         for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);
@@ -151,6 +152,16 @@ struct uvghip_ctu_plan {
 extern "C" int uvghip_ctu_plan_create(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, int n_pictures,
                                       void *workspace, uvghip_ctu_plan_t **plan_out)
 {
+  return uvghip_ctu_plan_create_rows(bitdepth, params, pictures, n_pictures, 0, params ? (params->pic_h + 63) / 64 : 0, workspace, plan_out);
+}
+
+// A band of CTU rows [ctu_row0, ctu_row1) of every picture (one picture sharded over GPUs by CTU rows): the same search,
+// released in the same order, with the row above the band taken as complete -- the caller has put its last sample line, its last row of
+// side information and the models of its first CTU into the pictures' buffers (the halo a band receives from the band above,
+// encoderstate.c:196-323, 966-975: hor_buf_search, the cu_array row, the WPP context hand-over).
+extern "C" int uvghip_ctu_plan_create_rows(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, int n_pictures,
+                                           int ctu_row0, int ctu_row1, void *workspace, uvghip_ctu_plan_t **plan_out)
+{
   UVGHIP_REQUIRE_READY();
   UVGHIP_REQUIRE_DEPTH(bitdepth);
   static_assert(sizeof(uvghip_ctu_params_t) == sizeof(ctu::params), "uvghip_ctu_params_t mirrors ctu::params");
@@ -161,7 +172,9 @@ extern "C" int uvghip_ctu_plan_create(int bitdepth, const uvghip_ctu_params_t *p
   if (p.wpp != 1 || p.depth_min < 1 || p.depth_max > 4 || p.depth_min > p.depth_max || p.rough_levels < 2 || p.rough_levels > 3 || p.qp < 0 || p.qp > 63 ||
       p.qp_c < 0 || p.qp_c > 63 || !(p.lambda > 0))
     return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_plan_create: configuration outside the supported subset");
-  const int wc = (p.pic_w + 63) / 64, hc = (p.pic_h + 63) / 64, ctus = wc * hc, total = ctus * n_pictures;
+  const int wc = (p.pic_w + 63) / 64, hc = (p.pic_h + 63) / 64, ctus = wc * hc;
+  if (ctu_row0 < 0 || ctu_row1 > hc || ctu_row0 >= ctu_row1) return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_plan_create_rows: CTU row range");
+  const int total = wc * (ctu_row1 - ctu_row0) * n_pictures;
   const ws_layout L = layout(n_pictures, p.pic_w, p.pic_h);
   unsigned char *ws = static_cast<unsigned char *>(workspace);
   // hand-out order: wavefront index first, pictures interleaved inside a wavefront
@@ -169,7 +182,7 @@ extern "C" int uvghip_ctu_plan_create(int bitdepth, const uvghip_ctu_params_t *p
   order.reserve(total);
   for (int d = 0; d < wc + hc - 1; ++d)
     for (int pic = 0; pic < n_pictures; ++pic)
-      for (int cy = 0; cy < hc; ++cy) {
+      for (int cy = ctu_row0; cy < ctu_row1; ++cy) {
         const int cx = d - cy;
         if (cx >= 0 && cx < wc) order.push_back(pic << 16 | cy << 8 | cx);
       }
@@ -195,7 +208,7 @@ extern "C" int uvghip_ctu_plan_create(int bitdepth, const uvghip_ctu_params_t *p
   pl->A.scratch = reinterpret_cast<ctu::scratch *>(ws + L.scratch);
   pl->A.slots = reinterpret_cast<uint32_t *>(ws + L.slots);
   pl->A.n_slots = L.n_slots;
-  pl->A.wc = wc; pl->A.hc = hc; pl->A.n_ctus = total;
+  pl->A.wc = wc; pl->A.hc = hc; pl->A.n_ctus = total; pl->A.row0 = ctu_row0;
   pl->bitdepth = bitdepth; pl->total = total; pl->counters = L.order; pl->ws = ws;
   const size_t lds = (bitdepth == 8 ? sizeof(ctu::lds<uint8_t>) : sizeof(ctu::lds<uint16_t>)) + lds_pad();
   const hipError_t e = bitdepth == 8

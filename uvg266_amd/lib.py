@@ -199,6 +199,7 @@ SIGNATURES = {
     "uvghip_ctu_search_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "uvghip_ctu_search_intra": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
     "uvghip_ctu_plan_create": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_ctu_plan_create_rows": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "uvghip_ctu_plan_run": (c_int, [c_vp, c_vp]),
     "uvghip_ctu_plan_destroy": (None, [c_vp]),
     "uvghip_slice_rows_workspace_bytes": (ctypes.c_size_t, [c_int]),
