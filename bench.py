@@ -581,6 +581,69 @@ def low_delay_closed_loop(device, n_seq=8, reps=2):
                     "sequences and the 2-CTU-lag wavefront inside a picture (DESIGN.md 4.12)"}
 
 
+def search_rows(wl, device, rank, world, dist, transport, n_pic=64, steps=3):
+    """The closed-loop CTU search with every picture sharded over the ranks by CTU rows (uvghip_ctu_plan_create_rows):
+    a step = one launch of this rank's band of `n_pic` pictures, between the halo it receives from the band above (last reconstruction
+    line, last side-information row, WPP models of each picture) and the halo it sends down -- grouped ncclSend / ncclRecv on the launch's
+    stream, so rank r works on step s while rank r + 1 works on step s - 1.  Picture 0's band is compared with the reference encoder's
+    record (per-CTU CRCs of the rows this rank owns) after the timed steps.  Not part of `value`."""
+    import zlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as Hh
+    W, H, depth = wl["W"], wl["H"], wl["depth"]
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    lay = bands.BandLayout(H, world, rank)
+    P = api.ctu_params(W, H, QP)
+    host = layout.synthetic_yuv420(W, H, 0, depth)
+    one = tuple(torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in host)
+    cs = api.CtuSearch(P, [one] * n_pic, rows=(lay.ctu_row0, lay.ctu_row1))
+    up, down = [], []
+    for i in range(n_pic):
+        spec = lay.halo_search(cs.rec[i][0], cs.rec[i][1], cs.rec[i][2], cs.cu[i].view(hc * 16, wc * 16 * 32), cs.models[i].view(wc * hc, 3 * 257), wc)
+        up += [o for o in spec if o[0] == lay.up and o[2]]
+        down += [o for o in spec if o[0] == lay.down and o[1]]
+    st = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        if up:
+            transport.exchange(up, st)
+        cs.run()
+        if down:
+            transport.exchange(down, st)
+    step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # parity of this rank's band of picture 0 against the reference's record
+    g = Hh.ctu_golden("ref_ctucrc_1920x1080_8_qp22" if (W, H, depth) == (1920, 1080, 8) else "ref_ctucrc_3840x2160_10_qp22")
+    parity = None
+    if zlib.crc32(b"".join(p.tobytes() for p in host)) == int(g["src_crc"]):
+        ry, ru, rv = (x.cpu().numpy() for x in cs.rec[0])
+        res = Hh.search_result_from_device_layout(W, H, ry, ru, rv, cs.cu[0].cpu().numpy().reshape(-1).view(Hh.SCU_NP), cs.coeff[0].cpu().numpy(),
+                                                  cs.models[0].cpu().numpy().view(np.uint32))
+        k0, k1 = lay.ctu_row0 * wc, lay.ctu_row1 * wc
+        bad = int((Hh.ctu_crcs(res, W, H)[k0:k1] != g["crc"][k0:k1]).any(axis=1).sum())
+        if bad:
+            raise SystemExit(f"row-sharded search: {bad} CTUs of rank {rank}'s band differ from the reference's record")
+        parity = {"ctus": k1 - k0, "items": "per-CTU CRC of side information + trees, reconstruction, levels, models: this rank's rows of picture 0"}
+    sent, recv = bands.spec_bytes(down)[0], bands.spec_bytes(up)[1]
+    return {"value": round(n_pic * steps / elapsed, 2), "unit": "frames/s", "ranks": world, "scaling": "strong", "pictures_per_step": n_pic, "steps": steps,
+            "ctu_rows_of_rank0": [lay.ctu_row0, lay.ctu_row1], "halo_bytes_per_step": {"sent": int(sent), "received": int(recv)}, "parity_rank0_band": parity,
+            "note": "the search only (the filters' row sharding is the open-loop line's); a band launch is a narrower wavefront than a whole picture, so "
+                    "pictures per step matter more than on one GPU"}
+
+
 def closed_loop(wl, steps, warmup, in_flight, device, rank, world, dist, groups=2):
     """`steps` timed launches of `in_flight` pictures each (a step = one group of pictures through search -> deblock -> SAO) after
     `warmup` untimed ones; `groups` launches are in flight at a time on their own streams, so the thin start of one launch's
@@ -788,6 +851,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="--shard rows: skip the all-to-all of reconstructed bands")
     ap.add_argument("--workload", choices=("1080p8", "2160p10alf"), default="1080p8",
                     help="1080p8 = BASELINE.json configs[1] (the judged line); 2160p10alf = configs[3] geometry")
+    ap.add_argument("--only-search-rows", action="store_true", help="time only the row-sharded closed-loop search (one rank: a band = the whole picture; development)")
     ap.add_argument("--only-c3", action="store_true", help="time only extra_workloads.c3_low_delay_closed_loop and print it (development)")
     ap.add_argument("--c3-sequences", type=int, default=32, help="extra_workloads.c3_low_delay_closed_loop: independent low-delay sequences side by side")
     ap.add_argument("--no-extra", action="store_true", help="do not also time the 2160p 10-bit closed loop (extra_workloads)")
@@ -806,6 +870,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
     L = lib.init(local_rank)
+    if args.only_search_rows:
+        print(json.dumps({"row_sharded_closed_loop_search": search_rows(WORKLOADS[args.workload], device, rank, world, dist, None)}), flush=True)
+        return
     if args.only_c3:
         print(json.dumps({"c3_low_delay_closed_loop": low_delay_closed_loop(device, n_seq=args.c3_sequences)}), flush=True)
         return
@@ -930,6 +997,11 @@ def main():
                            "comm_bytes_per_step_rank0": {k: {"sent": v[0], "received": v[1]} for k, v in cb.items()},
                            "note": "open-loop block kernels + in-loop filter chain of 2160p10alf with every picture split over the ranks by CTU rows: "
                                    "halo rows and reconstructed bands over RCCL (grouped ncclSend/ncclRecv, ncclAllReduce of the ALF covariances)"}
+            try:
+                rs = search_rows(WORKLOADS["1080p8"], device, rank, world, dist, transport)
+            except Exception as e:               # noqa: BLE001
+                rs = {"error": f"{type(e).__name__}: {e}"}
+            row_sharded["closed_loop_search_rows"] = rs
         except Exception as e:                   # noqa: BLE001 -- reported, not fatal: the judged line does not depend on it
             row_sharded = {"error": f"{type(e).__name__}: {e}", "rccl_ranks": world}
         dog.cancel()
