@@ -1087,7 +1087,8 @@ typedef struct uvghip_ctu_pb_picture {
   uvghip_ctu_picture_t pic;
   int32_t slice_type;              /* 0 B, 1 P */
   int32_t poc, n_refs, ref_pocs[16], l_size[2], l[2][16];
-  int32_t tmvp, max_merge, merge_level;      /* cfg.tmvp_enable, cfg.max_merge, cfg.log2_parallel_merge_level */
+  int32_t tmvp, max_merge, merge_level;      /* cfg.tmvp_enable, cfg.max_merge (5 or 6: below 5 the reference's own list construction
+                                              * overruns its array, src/inter.c:2028-2176), cfg.log2_parallel_merge_level */
   int32_t frame_qp;                /* state->frame->QP: the slice's context models are initialised with it */
   int32_t bipred, fme_level, early_skip;     /* cfg.bipred, cfg.fme_level, cfg.early_skip */
   int32_t depth_inter_min, depth_inter_max;  /* cfg.pu_depth_inter: 0, 3 */

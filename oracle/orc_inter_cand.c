@@ -204,9 +204,9 @@ ORC_EXPORT int ORC_FN(merge_candidates)(const int32_t *ctx, int32_t *lcu, const 
     }
     if (mc[n].dir != 0) n++;
   }
-  if (n == max_cands) return n;
+  if (n >= max_cands) return n;
   /* ---- history ---- */
-  if (n != max_cands - 1) {
+  if (n < max_cands - 1) {
     const cand_cu *lut = (const cand_cu *)(hmvp + 1);
     for (int i = 0; i < hmvp[0]; ++i) {
       if (i > 1 || (!duplicate(&lut[i], a1) && !duplicate(&lut[i], b1))) {
@@ -236,7 +236,7 @@ ORC_EXPORT int ORC_FN(merge_candidates)(const int32_t *ctx, int32_t *lcu, const 
     mc[n].dir = inter_dir;
     if (inter_dir > 0) n++;
   }
-  if (n == max_cands) return n;
+  if (n >= max_cands) return n;
   /* ---- zero vectors ---- */
   int num_ref = used;
   if (n < max_cands && is_b) {
@@ -245,7 +245,7 @@ ORC_EXPORT int ORC_FN(merge_candidates)(const int32_t *ctx, int32_t *lcu, const 
     num_ref = neg < pos ? neg : pos;
   }
   int zero_idx = 0;
-  while (n != max_cands) {
+  while (n < max_cands) {
     mc[n].mv[0][0] = 0; mc[n].mv[0][1] = 0;
     mc[n].ref[0] = (zero_idx >= num_ref - 1) ? 0 : zero_idx;
     mc[n].dir = 1;

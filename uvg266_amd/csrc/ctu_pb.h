@@ -1382,7 +1382,7 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
       if (!can_split) {
         // (cannot happen with pu-depth-intra max = 4: every CU above 4x4 may split)
         if (L > 0) { copy_models(S->cur, S->work[L - 1]); if (ntype != CU_NOTSET) unpark_pb(S, J, L); }
-        SERIAL hmvp_add(Q.hmvp, N.mot);
+        SERIAL { if (ntype == CU_INTER) hmvp_add(Q.hmvp, N.mot); }        // (an intra CU adds nothing; N.mot is only the depth's last INTER candidate)
         CTU_SYNC();
         ret = ncost; entering = 0; if (L == 0) break; --L; continue;
       }
@@ -1438,7 +1438,7 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
     } else {
       if (L > 0) {
         copy_models(S->cur, S->work[L - 1]);             // post_search_cabac
-        SERIAL { for (int i = 0; i < 41; ++i) Q.hmvp[i] = Q.hmvp_entry[L][i]; hmvp_add(Q.hmvp, N.mot); }
+        SERIAL { for (int i = 0; i < 41; ++i) Q.hmvp[i] = Q.hmvp_entry[L][i]; if (ntype == CU_INTER) hmvp_add(Q.hmvp, N.mot); }      // (uvg_hmvp_add_mv ignores an intra CU)
         CTU_SYNC();
         if (ntype != CU_NOTSET) { PB_T0(); unpark_pb(S, J, L); PB_T1(J.W, 10); }
       } else if (!pruned && ntype != CU_NOTSET) { PB_T0(); restore64_pb(S, J); PB_T1(J.W, 10); }

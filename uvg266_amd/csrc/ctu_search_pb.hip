@@ -161,7 +161,7 @@ extern "C" int uvghip_ctu_search_pb(int bitdepth, const uvghip_ctu_pb_picture_t 
         p.qp_c < 0 || p.qp_c > 63 || !(p.lambda > 0) || !(p.lambda_sqrt > 0))
       return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_pb: configuration outside the supported subset");
     if ((q.slice_type != 0 && q.slice_type != 1) || q.n_refs < 1 || q.n_refs > 16 || q.l_size[0] < 1 || q.l_size[0] > 8 || q.l_size[1] < 0 || q.l_size[1] > 8 ||
-        (q.slice_type == 1 && q.l_size[1] != 0) || q.depth_inter_min != 0 || q.depth_inter_max != 3 || q.max_merge < 1 || q.max_merge > 6 || q.fme_level < 0 ||
+        (q.slice_type == 1 && q.l_size[1] != 0) || q.depth_inter_min != 0 || q.depth_inter_max != 3 || q.max_merge < 5 || q.max_merge > 6 || q.fme_level < 0 ||
         q.fme_level > 4 || q.merge_level < 2)
       return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_pb: slice state outside the supported subset");
     const uvghip_ctu_picture_t &c = q.pic;

@@ -182,6 +182,9 @@ __device__ inline bool take_spatial(const unit *c, const unit *d1, const unit *d
   return true;
 }
 
+// (max_cands = cfg.max_merge: the reference's own construction assumes at least 5 -- four spatial candidates are taken before the count is
+// first compared with it, and its closing loops test for equality, inter.c:2028-2176; with fewer it overruns its array.  The comparisons
+// here are ">=" / "<" so that a smaller value cannot run away; uvghip_ctu_search_pb refuses it.)
 // uvg_inter_get_merge_cand.  hmvp: [0] entries in the CTU row's table, then 5 units (most recent first).  -> number of candidates
 template <typename TAB, typename COL>
 __device__ inline int merge_candidates(const frame_ctx &f, TAB &tab, COL &col, const int32_t *hmvp, merge_cand *mc)
@@ -211,8 +214,8 @@ __device__ inline int merge_candidates(const frame_ctx &f, TAB &tab, COL &col, c
     }
     if (mc[n].dir != 0) n++;
   }
-  if (n == max_cands) return n;
-  if (n != max_cands - 1) {               // history
+  if (n >= max_cands) return n;
+  if (n < max_cands - 1) {               // history
     const unit *lut = reinterpret_cast<const unit *>(hmvp + 1);
     for (int i = 0; i < hmvp[0]; ++i) {
       if (i > 1 || (!same_motion(lut[i], nb.a1) && !same_motion(lut[i], nb.b1))) {
@@ -241,7 +244,7 @@ __device__ inline int merge_candidates(const frame_ctx &f, TAB &tab, COL &col, c
     mc[n].dir = inter_dir;
     if (inter_dir > 0) n++;
   }
-  if (n == max_cands) return n;
+  if (n >= max_cands) return n;
   int num_ref = f.n_refs;                 // zero vectors
   if (n < max_cands && f.is_b) {
     int neg = 0, pos = 0;
@@ -249,7 +252,7 @@ __device__ inline int merge_candidates(const frame_ctx &f, TAB &tab, COL &col, c
     num_ref = neg < pos ? neg : pos;
   }
   int zero_idx = 0;
-  while (n != max_cands) {
+  while (n < max_cands) {
     mc[n].mv[0][0] = 0; mc[n].mv[0][1] = 0;
     mc[n].ref[0] = (zero_idx >= num_ref - 1) ? 0 : zero_idx;
     mc[n].dir = 1;
