@@ -93,6 +93,10 @@ def check(W, H, depth, qp, frames, t0=0, extra=(), verbose=True, kind="moving"):
     orc = Hh.load_oracle()
     pics, recs = encode(W, H, depth, qp, frames, t0, extra, kind)
     P = pictures_from_records(W, H, depth, frames, recs)
+    opt = dict(zip(extra[0::2], extra[1::2]))            # the tools of the run, for the oracle's frame state (helpers.iter_inter_frames)
+    cfg = (int(opt.get("tmvp", 1)), int(opt.get("max-merge", 6)), 2, int(opt.get("bipred", 1)), int(opt.get("subme", 4)), int(opt.get("early-skip", 1)))
+    for d in P.values():
+        d["cfg"] = cfg
     wc, hc = (W + 63) // 64, (H + 63) // 64
     bad = 0
     for fr, d, r, buf, ntr in Hh.run_inter_oracle(orc, W, H, depth, pics, P):
@@ -104,6 +108,14 @@ def check(W, H, depth, qp, frames, t0=0, extra=(), verbose=True, kind="moving"):
         for m in msgs:
             print("   ", m)
         bad += bool(msgs)
+    if os.environ.get("CHECK_KERNEL_SOURCE"):      # ... and the device kernel's source built for the host (tests/emul) against the same records
+        for fr, d, prm, F, keep in Hh.iter_inter_frames(W, H, P):
+            if int(d["meta"][6]) == 2:
+                continue
+            msgs = Hh.compare_device_inter_picture(W, H, d, Hh.emul_search_inter_picture(depth, prm, F, *pics[fr]))
+            if verbose or msgs:
+                print(f"frame {fr} kernel source on the host: {'OK' if not msgs else msgs[:3]}")
+            bad += bool(msgs)
     return bad
 
 
