@@ -401,6 +401,36 @@ class ClosedLoop:
         return sum(a.elapsed_time(b) for a, b in self.ev), len(self.ev)
 
 
+def c2_clip(wl, device, frames=60, reps=2):
+    """What BASELINE configs[1] itself would see: its 60-picture clip from HOST memory to the `.266` bytes of its pictures in HOST memory,
+    wall clock -- upload of the source planes (pageable host memory, the default stream), one uvghip_loop_plan_run over the 60 pictures
+    (search -> filters -> slice data), then per picture the checksum of the output picture, the download of its rows and the NAL
+    assembly (uvghip_loop_plan_picture_nals: slice NAL + hash SEI).  60 pictures put ~660 CTUs in flight, below the device's 1024
+    workgroup slots, and nothing overlaps the fill and drain of the single launch: this is the latency of ONE clip, the judged `value`
+    is the throughput of many.  The plan and its buffers exist before the clock starts (an encoder keeps them).  Not part of `value`."""
+    W, H, depth = wl["W"], wl["H"], wl["depth"]
+    P = api.ctu_params(W, H, QP)
+    host = [tuple(np.ascontiguousarray(p) for p in layout.synthetic_yuv420(W, H, t, depth)) for t in range(frames)]
+    src = [tuple(torch.empty(p.shape, dtype=torch.uint8 if depth == 8 else torch.uint16, device=device) for p in yuv) for yuv in host]
+    cs = api.ClosedLoop(P, src)
+    best, nbytes = None, 0
+    for _ in range(reps + 1):                     # the first pass is the warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for yuv, dst in zip(host, src):
+            for p, d in zip(yuv, dst):
+                d.copy_(torch.from_numpy(p), non_blocking=True)
+        cs.run()
+        out = [cs.picture_nals(i, i) for i in range(frames)]
+        dt = time.perf_counter() - t0
+        nbytes = sum(len(b) for b in out)
+        best = dt if best is None or dt < best else best
+    return {"value": round(frames / best, 2), "unit": "frames/s (one 60-picture clip, host memory to .266 bytes in host memory)", "frames": frames,
+            "wall_ms": round(1e3 * best, 1), "bytes_out": int(nbytes), "upload_mb": round(frames * W * H * 1.5 * (1 if depth == 8 else 2) / 1e6, 1),
+            "note": "one launch of 60 pictures: the wavefronts' fill and drain are not hidden by a second launch, 660 of 1024 workgroup slots busy at best; "
+                    "the NAL units are written per picture (checksum kernel, row download, host assembly)"}
+
+
 def parity_check(group, golden):
     """Picture 0 of a group AFTER the timed region -- the buffers hold what its last timed pass wrote, with the other group's launch
     sharing the device -- against the record of the real encoder's run on the same picture (tests/golden/<golden>.npz, data only):
@@ -852,6 +882,7 @@ def main():
     ap.add_argument("--workload", choices=("1080p8", "2160p10alf"), default="1080p8",
                     help="1080p8 = BASELINE.json configs[1] (the judged line); 2160p10alf = configs[3] geometry")
     ap.add_argument("--only-search-rows", action="store_true", help="time only the row-sharded closed-loop search (one rank: a band = the whole picture; development)")
+    ap.add_argument("--only-clip", action="store_true", help="time only extra_workloads.c2_clip (development)")
     ap.add_argument("--only-c3", action="store_true", help="time only extra_workloads.c3_low_delay_closed_loop and print it (development)")
     ap.add_argument("--c3-sequences", type=int, default=32, help="extra_workloads.c3_low_delay_closed_loop: independent low-delay sequences side by side")
     ap.add_argument("--no-extra", action="store_true", help="do not also time the 2160p 10-bit closed loop (extra_workloads)")
@@ -872,6 +903,9 @@ def main():
     L = lib.init(local_rank)
     if args.only_search_rows:
         print(json.dumps({"row_sharded_closed_loop_search": search_rows(WORKLOADS[args.workload], device, rank, world, dist, None)}), flush=True)
+        return
+    if args.only_clip:
+        print(json.dumps({"c2_clip": c2_clip(WORKLOADS[args.workload], device)}), flush=True)
         return
     if args.only_c3:
         print(json.dumps({"c3_low_delay_closed_loop": low_delay_closed_loop(device, n_seq=args.c3_sequences)}), flush=True)
@@ -901,8 +935,9 @@ def main():
                  "mpixels_per_s": round(ek * eF * world / eel * ewl["W"] * ewl["H"] / 1e6, 1),
                  "search_launch_ms": round(ems / max(1, eln), 2),
                  "workload": "3840x2160 10-bit yuv420p, QP 22: the same closed loop (search -> deblock -> SAO; ALF of configs[3] is in the open-loop chain only)"}
-    c3 = c3_loop = None
+    c3 = c3_loop = clip = None
     if not args.no_extra and wl_name == "1080p8" and rank == 0:
+        clip = c2_clip(wl, device)
         c3 = inter_hot_path(device)
         c3_loop = low_delay_closed_loop(device, n_seq=args.c3_sequences)
     open_loop = None
@@ -963,6 +998,8 @@ def main():
                 out.setdefault("extra_workloads", {})["c3_inter_hot_path_open_loop"] = c3
             if c3_loop is not None:
                 out.setdefault("extra_workloads", {})["c3_low_delay_closed_loop"] = c3_loop
+            if clip is not None:
+                out.setdefault("extra_workloads", {})["c2_clip"] = clip
             if open_loop is not None:
                 out["open_loop"] = open_loop
             if row_sharded is not None:
