@@ -183,7 +183,12 @@ constexpr int arena_bytes(int n)     // one depth's share of the arena (n = its 
   return (4 * (4 * n + 8) * 2 + 2 * n * n * 2 + (n * n + 2 * ((n / 2) * (n / 2) < 16 ? 16 : (n / 2) * (n / 2))) * 2 +
           (n >= 8 ? 0 : 2 * 18 * 4) + (n <= 8 ? 8 + 2 * n * n * 8 : 0) + 15) & ~15;
 }
+#if defined(CTU_PB)
+// one wave walks a P / B CTU, a depth at a time: the depths' scratch areas share ONE region sized for the largest (ctu_pb.h)
+enum { ARENA_BYTES = arena_bytes(32) };
+#else
 enum { ARENA_BYTES = arena_bytes(4) + arena_bytes(8) + arena_bytes(16) + arena_bytes(32) };
+#endif
 
 struct scratch;
 #if defined(CTU_PB)
@@ -3114,7 +3119,9 @@ template <typename PX> CTU_DEV void setup_waves(lds<PX> *S)
   BLK_FOR(k, 4) {
     const int n = 4 << k, nn = n * n, c2 = (n / 2) * (n / 2) < 16 ? 16 : (n / 2) * (n / 2), tiles = n >= 8 ? (n / 8) * (n / 8) : 1;
     int off = 0;
+#if !defined(CTU_PB)
     for (int j = 0; j < k; ++j) off += arena_bytes(4 << j);
+#endif
     unsigned char *a = S->arena + off;
     wctx *V = &S->wv[k];
     const int rn = 4 * n + 8;
