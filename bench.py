@@ -884,7 +884,7 @@ def main():
     ap.add_argument("--only-search-rows", action="store_true", help="time only the row-sharded closed-loop search (one rank: a band = the whole picture; development)")
     ap.add_argument("--only-clip", action="store_true", help="time only extra_workloads.c2_clip (development)")
     ap.add_argument("--only-c3", action="store_true", help="time only extra_workloads.c3_low_delay_closed_loop and print it (development)")
-    ap.add_argument("--c3-sequences", type=int, default=32, help="extra_workloads.c3_low_delay_closed_loop: independent low-delay sequences side by side")
+    ap.add_argument("--c3-sequences", type=int, default=96, help="extra_workloads.c3_low_delay_closed_loop: independent low-delay sequences side by side")
     ap.add_argument("--no-extra", action="store_true", help="do not also time the 2160p 10-bit closed loop (extra_workloads)")
     args = ap.parse_args()
 
