@@ -218,6 +218,8 @@ struct pb_state {
   int32_t amvp_cache[2][8][4];         // the predictors of (list, reference index) for the CU being evaluated: derived once
   uint32_t amvp_have[2];
   int32_t amvp_key[3];                 // the CU (x, y, size) the cache belongs to
+  int32_t colc[2][8];                  // the two positions of the collocated picture a CU's temporal candidate can come from, fetched once per CU
+  int32_t colc_idx[2];                 // ... their indices on the 8x8 grid (-1: none)
   int32_t out4[4];
   int32_t ref_idx2[2];
   int32_t i0, i1, i2, i3;              // small hand-overs from lane 0 to the wave

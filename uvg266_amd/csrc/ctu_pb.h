@@ -66,20 +66,41 @@ struct pb_tab { icand::unit *p; __device__ icand::unit &at(int i) { return p[i];
 // the collocated picture = L0[0]'s motion on the 8x8 grid (get_temporal_merge_candidates, inter.c:935-1010)
 struct pb_col {
   const int32_t *p; int stride, gw;
+  const int32_t (*cache)[8]; const int32_t *cache_idx;        // two entries fetched ahead for the CU being evaluated (search_pu_inter)
   __device__ icand::col_unit at(int i) const
   {
     const int gy = i / gw, gx = i - gy * gw;
     const int32_t *o = p + ((size_t)(gy * 2) * stride + gx * 2) * 8;
+    if (cache_idx[0] == i) o = cache[0]; else if (cache_idx[1] == i) o = cache[1];
     icand::col_unit c;
     c.type = o[0]; c.mv[0][0] = o[1]; c.mv[0][1] = o[2]; c.mv[1][0] = o[3]; c.mv[1][1] = o[4]; c.dir = o[5]; c.poc[0] = o[6]; c.poc[1] = o[7];
     return c;
   }
 };
-template <typename PX> CTU_DEV pb_col col_of(const job<PX> &J)
+template <typename PX> CTU_DEV pb_col col_of(lds<PX> *S, const job<PX> &J)
 {
   const pb_job &B = *J.pb;
-  pb_col c = {B.ref_cu[B.l_size[0] > 0 ? B.l[0][0] : 0], B.ref_cu_stride, (J.P.pic_w + 7) / 8};
+  pb_col c = {B.ref_cu[B.l_size[0] > 0 ? B.l[0][0] : 0], B.ref_cu_stride, (J.P.pic_w + 7) / 8, S->pb.colc, S->pb.colc_idx};
   return c;
+}
+// The collocated picture's units a CU's temporal candidate can come from (temporal_unit, inter_cand_dev.h: below-right of the CU, else
+// its centre) into LDS, by 16 lanes at once: the merge list and every AMVP derivation of the CU read them, lane 0 alone would wait for
+// device memory each time.
+template <typename PX> CTU_DEV void prefetch_col(lds<PX> *S, const job<PX> &J, int x, int y, int n)
+{
+  const pb_job &B = *J.pb;
+  pb_state &Q = S->pb;
+  const int W = J.P.pic_w, H = J.P.pic_h, gw = (W + 7) / 8;
+  const int xbr = x + n, ybr = y + n, xc = x + n / 2, yc = y + n / 2;
+  const int i0 = (xbr < W && ybr < H && (ybr % 64) != 0) ? (ybr >> 3) * gw + (xbr >> 3) : -1;
+  const int i1 = (xc < W && yc < H) ? (yc >> 3) * gw + (xc >> 3) : -1;
+  const int32_t *tab = B.ref_cu[B.l_size[0] > 0 ? B.l[0][0] : 0];
+  PAR_FOR(e, 16) {
+    const int k = e >> 3, i = k ? i1 : i0;
+    if (i >= 0) { const int gy = i / gw, gx = i - gy * gw; Q.colc[k][e & 7] = tab[((size_t)(gy * 2) * B.ref_cu_stride + gx * 2) * 8 + (e & 7)]; }
+    if ((e & 7) == 0) Q.colc_idx[k] = i;
+  }
+  CTU_SYNC();
 }
 CTU_DEV int u_idx(int lx, int ly) { return ((ly >> 2) + 1) * 17 + (lx >> 2) + 1; }       // lx, ly >= -4
 
@@ -531,7 +552,7 @@ template <typename PX> CTU_DEV void amvp_for(lds<PX> *S, const job<PX> &J, const
     return;
   }
   pb_tab tab = {Q.mot};
-  pb_col col = col_of(J);
+  pb_col col = col_of(S, J);
   Q.ref_idx2[0] = ref0; Q.ref_idx2[1] = ref1;
   icand::amvp_candidates(Q.f, tab, col, hmvp, reflist, Q.ref_idx2, Q.out4, &Q.ws);
   out[0][0] = Q.out4[0]; out[0][1] = Q.out4[1]; out[1][0] = Q.out4[2]; out[1][1] = Q.out4[3];
@@ -686,11 +707,12 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
   const int n = 64 >> L, x = N.x, y = N.y, lx = x & 63, ly = y & 63;
   CTU_LDS const uint32_t *const mdl = LDSP(const uint32_t, V->cur);
   { PB_T0();
+  if (B.tmvp && B.n_refs) prefetch_col(S, J, x, y, n);
   SERIAL {
     memset(&Q.cur, 0, sizeof Q.cur);                     // cur_pu: the CU's entry after search_cu's memset (type NOTSET)
     set_cand_ctx(S, x, y, n, N.split_tree);
     pb_tab tab = {Q.mot};
-    pb_col col = col_of(J);
+    pb_col col = col_of(S, J);
     Q.n_mc = icand::merge_candidates(Q.f, tab, col, Q.hmvp, Q.mc);
     Q.merge_size = 0;
     for (int i = 0; i < 6; ++i) { Q.merge_keys[i] = -1; Q.merge[i].cost = CTU_MAX_DOUBLE; }
@@ -1290,10 +1312,17 @@ template <typename PX> CTU_NOINLINE CTU_DEV void unpark_pb(lds<PX> *S, const job
 template <typename PX> CTU_NOINLINE CTU_DEV void save64_pb(lds<PX> *S, const job<PX> &J)
 {
   scratch *W = J.W;
-  for (int color = 0; color < 3; ++color) {
+  for (int color = 0; color < 3; ++color) {            // four samples / levels per step: 64-bit accesses to the scratch and the level array
     const int w = color ? 32 : 64, l2 = color ? 5 : 6, pit = pitch_of(color);
-    const PX *D = plane(S, color) + pit + 1;
-    PAR_FOR(e, w * w) { W->save_px[co_off(color) + e] = D[(e >> l2) * pit + (e & (w - 1))]; W->save_co[co_off(color) + e] = CTU_GLOAD(&J.coeff[co_off(color) + e]); J.coeff[co_off(color) + e] = 0; }
+    CTU_LDS const PX *D = LDSP(const PX, plane(S, color) + pit + 1);
+    uint64_t *const spx = (uint64_t *)(W->save_px + co_off(color)), *const sco = (uint64_t *)(W->save_co + co_off(color)), *const co = (uint64_t *)(J.coeff + co_off(color));
+    PAR_FOR(e4, (w * w) >> 2) {
+      const int e = e4 << 2;
+      CTU_LDS const PX *d = D + (e >> l2) * pit + (e & (w - 1));
+      spx[e4] = (uint64_t)d[0] | (uint64_t)d[1] << 16 | (uint64_t)d[2] << 32 | (uint64_t)d[3] << 48;
+      sco[e4] = CTU_GLOAD(&co[e4]);
+      co[e4] = 0;
+    }
   }
   PAR_FOR(e, 256) {
     const int lx = (e & 15) * 4, ly = (e >> 4) * 4, u = u_idx(lx, ly);
@@ -1318,7 +1347,21 @@ template <typename PX> CTU_NOINLINE CTU_DEV void save64_pb(lds<PX> *S, const job
 template <typename PX> CTU_NOINLINE CTU_DEV void restore64_pb(lds<PX> *S, const job<PX> &J)
 {
   scratch *W = J.W;
-  restore64(S, J);
+  for (int color = 0; color < 3; ++color) {
+    const int w = color ? 32 : 64, l2 = color ? 5 : 6, pit = pitch_of(color);
+    CTU_LDS PX *D = LDSP(PX, plane(S, color) + pit + 1);
+    const uint64_t *const spx = (const uint64_t *)(W->save_px + co_off(color)), *const sco = (const uint64_t *)(W->save_co + co_off(color));
+    uint64_t *const co = (uint64_t *)(J.coeff + co_off(color));
+    PAR_FOR(e4, (w * w) >> 2) {
+      const int e = e4 << 2;
+      CTU_LDS PX *d = D + (e >> l2) * pit + (e & (w - 1));
+      const uint64_t v = CTU_GLOAD(&spx[e4]);
+      d[0] = (PX)(v & 0xffff); d[1] = (PX)((v >> 16) & 0xffff); d[2] = (PX)((v >> 32) & 0xffff); d[3] = (PX)(v >> 48);
+      co[e4] = CTU_GLOAD(&sco[e4]);
+    }
+  }
+  PAR_FOR(e, 256) { *cu_at(S, (e & 15) * 4, (e >> 4) * 4) = W->save_cu[e]; W->tree[e] = (uint16_t)CTU_GLOAD(&W->save_tree[e]); W->mtt[e] = (uint16_t)CTU_GLOAD(&W->save_tree[256 + e]); }
+  CTU_SYNC();
   PAR_FOR(e, 256) {
     const int lx = (e & 15) * 4, ly = (e >> 4) * 4, u = u_idx(lx, ly);
     icand::unit &m = S->pb.mot[u];
@@ -1490,6 +1533,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void load_ctu_pb(lds<PX> *S, const j
   }
   if (BLK_TID == 0) {
     Q.amvp_key[0] = Q.amvp_key[1] = Q.amvp_key[2] = -1; Q.amvp_have[0] = Q.amvp_have[1] = 0;
+    Q.colc_idx[0] = Q.colc_idx[1] = -1;
     icand::frame_ctx &f = Q.f;
     f.x = f.y = f.w = f.h = 0;
     f.poc = B.poc; f.is_b = B.slice_type == 0; f.pic_w = W; f.pic_h = H;
