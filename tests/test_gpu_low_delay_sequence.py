@@ -120,7 +120,8 @@ def _frame_rows(g):
     return g["meta"][ks], g["lam"][ks], g["refs"][ks]
 
 
-@pytest.mark.parametrize("name,n_seq", [("ref_inter_264x136_8_qp32_9frames", 3), ("ref_intercrc_1920x1080_8_qp27_5frames", 2)])
+@pytest.mark.parametrize("name,n_seq", [("ref_inter_264x136_8_qp32_9frames", 3), ("ref_intercrc_1920x1080_8_qp27_5frames", 2),
+                                        ("ref_intercrc_1920x1080_10_qp32_3frames", 1)])
 def test_low_delay_loop_of_several_sequences(hip, name, n_seq):
     """api.LowDelayLoop (what bench.py times for BASELINE configs[2]): n_seq sequences side by side, every picture group one call.  The
     1080p case is checked through the CRCs of tests/golden/ref_intercrc_* (output pictures and every row's bytes of the reference's run)."""
