@@ -13,7 +13,7 @@ for rep in range(2):
     print(f"{n} pictures {W}x{H} {depth}-bit: {dt*1e3:.1f} ms -> {n/dt:.2f} pictures/s")
 ctus = ((W + 63) // 64) * ((H + 63) // 64) * n
 al = lambda v, a: (v + a - 1) // a * a
-off_order = al(512 + ctus * 4, 256); off_pics = al(off_order + ctus * 4, 256); off_scr = al(off_pics + n * 96, 256)
+off_order = al(512 + 32768 + ctus * 4, 256); off_pics = al(off_order + ctus * 4, 256); off_scr = al(off_pics + n * 96, 256)
 n_slots = min(2048, al(ctus, 32))          # a slot keeps the profile of the last CTU that ran on it
 ws = cs.ws.cpu().numpy()
 SZ = 59328
@@ -26,3 +26,8 @@ print("mean cycles per CTU: total %.0f (%.2f ms at 2.1 GHz)" % (tot, tot / 2.1e6
 print("%-28s %12s %12s %12s %12s" % ("", "wave0 (4x4+walk)", "wave1 (8x8)", "wave2 (16x16)", "wave3 (32x32)"))
 for i, nm in enumerate(names):
     print("  %-26s" % nm + "".join("%12.0f" % prof[:, w, i].mean() for w in range(4)))
+
+hw = prof[:, :, 19].astype(np.int64)
+simd = (hw >> 4) & 3
+print("SIMD of waves 0..3 per workgroup (first 12):", simd[:12].tolist())
+print("histogram of wave 0's SIMD:", np.bincount(simd[:, 0], minlength=4).tolist(), " distinct SIMDs per workgroup:", np.bincount([len(set(r)) for r in simd.tolist()], minlength=5).tolist())

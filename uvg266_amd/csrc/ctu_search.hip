@@ -32,6 +32,7 @@ struct launch_args {
   uint32_t *slots;            // bitmap of the slots in use
   int n_slots;
   int wc, hc, n_ctus;
+  int32_t *simd_load;         // [XCD * 256 + (SE, SH, CU)][4]: walkers resident per SIMD of every CU
   int row0;                   // first CTU row of this launch (a band of a picture sharded by CTU rows): the row above it is complete in the buffers
 };
 
@@ -42,6 +43,7 @@ __global__ void __launch_bounds__(256, 4) ctu_search_kernel(launch_args A)
   ctu::lds<PX> *S = reinterpret_cast<ctu::lds<PX> *>(smem);
   __shared__ int s_ticket;
   __shared__ int s_slot;
+  __shared__ int s_load;               // index of this workgroup's walker's counter in A.simd_load
 #if defined(CTU_POISON_LDS)          // debug builds (make EXTRA=-DCTU_POISON_LDS=0xA5): nothing may depend on what the LDS held before
   for (unsigned i = threadIdx.x; i < sizeof(ctu::lds<PX>); i += 256) smem[i] = (unsigned char)(CTU_POISON_LDS);
   __syncthreads();
@@ -59,6 +61,20 @@ __global__ void __launch_bounds__(256, 4) ctu_search_kernel(launch_args A)
       if (!(prev & (1u << bit))) got = i * 32 + bit;
     }
     s_slot = got;
+    // Which wave walks the CTU: the one on the SIMD that carries the fewest walkers of the workgroups resident on this CU (the four
+    // waves of a workgroup sit on the four SIMDs; a walker is the one wave that never idles).  Counters per CU in the workspace.
+    {
+      const uint32_t hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508) & 7u;      // HW_REG_HW_ID, HW_REG_XCC_ID
+      int32_t *const c = A.simd_load + (size_t)((xcc << 8) | ((hw >> 8) & 0xffu)) * 4;
+      int best = s_ticket & 3, lo = __hip_atomic_load(&c[best], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int k = 1; k < 4; ++k) {
+        const int sd = (s_ticket + k) & 3, v = __hip_atomic_load(&c[sd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v < lo) { lo = v; best = sd; }
+      }
+      atomicAdd(&c[best], 1);
+      S->rot = best;
+      s_load = (int)(&c[best] - A.simd_load);
+    }
   }
   __syncthreads();
   const int ticket = s_ticket;
@@ -99,6 +115,7 @@ __global__ void __launch_bounds__(256, 4) ctu_search_kernel(launch_args A)
     // ... and ONE agent-scope release writes the XCD's L2 back (it is shared by the waves): a fence per wave did that four times over
     __hip_atomic_store(&done[k], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     atomicAnd(&A.slots[s_slot >> 5], ~(1u << (s_slot & 31)));          // the scratch is free again
+    atomicSub(&A.simd_load[s_load], 1);
   }
 }
 
@@ -115,7 +132,7 @@ size_t lds_pad()
 // Scratch slots: a workgroup claims one while it runs.  2048 = 256 CUs x 8 is more than the device can hold of this kernel
 // (3 per CU); small jobs take one slot per CTU, rounded up to whole bitmap words.
 enum { MAX_SLOTS = 2048 };
-struct ws_layout { size_t ticket, slots, done, order, pics, scratch, total; int n_slots; };
+struct ws_layout { size_t ticket, slots, simd_load, done, order, pics, scratch, total; int n_slots; };
 ws_layout layout(int n_pictures, int pic_w, int pic_h)
 {
   const size_t ctus = (size_t)((pic_w + 63) / 64) * ((pic_h + 63) / 64), total = ctus * n_pictures;
@@ -123,7 +140,8 @@ ws_layout layout(int n_pictures, int pic_w, int pic_h)
   L.n_slots = (int)(total < MAX_SLOTS ? align_up(total, 32) : MAX_SLOTS);
   L.ticket = 0;
   L.slots = 256;
-  L.done = L.slots + MAX_SLOTS / 8;
+  L.simd_load = L.slots + MAX_SLOTS / 8;
+  L.done = L.simd_load + 8 * 256 * 4 * sizeof(int32_t);
   L.order = align_up(L.done + total * 4, 256);          // [0, order): zeroed before every run
   L.pics = align_up(L.order + total * 4, 256);
   L.scratch = align_up(L.pics + (size_t)n_pictures * sizeof(pic_dev), 256);
@@ -207,6 +225,7 @@ extern "C" int uvghip_ctu_plan_create_rows(int bitdepth, const uvghip_ctu_params
   pl->A.done = reinterpret_cast<int32_t *>(ws + L.done);
   pl->A.scratch = reinterpret_cast<ctu::scratch *>(ws + L.scratch);
   pl->A.slots = reinterpret_cast<uint32_t *>(ws + L.slots);
+  pl->A.simd_load = reinterpret_cast<int32_t *>(ws + L.simd_load);
   pl->A.n_slots = L.n_slots;
   pl->A.wc = wc; pl->A.hc = hc; pl->A.n_ctus = total; pl->A.row0 = ctu_row0;
   pl->bitdepth = bitdepth; pl->total = total; pl->counters = L.order; pl->ws = ws;
