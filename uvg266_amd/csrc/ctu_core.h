@@ -3169,6 +3169,7 @@ template <typename PX> CTU_DEV void run_ctu(lds<PX> *S, const job<PX> &J)
   CTU_T1(J.W, 9); }
 #if defined(__HIPCC__)
   if (CTU_WAVE == 0) {
+    __builtin_amdgcn_s_setprio(3);        // the walker is the CTU's critical path: it wins the issue slot against the depth waves sharing its SIMD
 #endif
     search_ctu(S, J);
     PAR_FOR(i, NMODELS) J.models_out[NMODELS + i] = S->cur[i];
