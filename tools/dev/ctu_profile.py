@@ -27,7 +27,4 @@ print("%-28s %12s %12s %12s %12s" % ("", "wave0 (4x4+walk)", "wave1 (8x8)", "wav
 for i, nm in enumerate(names):
     print("  %-26s" % nm + "".join("%12.0f" % prof[:, w, i].mean() for w in range(4)))
 
-hw = prof[:, :, 19].astype(np.int64)
-simd = (hw >> 4) & 3
-print("SIMD of waves 0..3 per workgroup (first 12):", simd[:12].tolist())
-print("histogram of wave 0's SIMD:", np.bincount(simd[:, 0], minlength=4).tolist(), " distinct SIMDs per workgroup:", np.bincount([len(set(r)) for r in simd.tolist()], minlength=5).tolist())
+print("chroma helper per CTU: Cb blocks handed to depth 3's wave %.1f, kept by the walk (wave busy) %.1f, the walk's wait for them %.0f cycles" % (prof[:, 1, 19].mean(), prof[:, 1, 20].mean(), prof[:, 1, 21].mean()))

@@ -253,6 +253,7 @@ template <typename PX> struct lds {
   int32_t vsel[4];                                  // which wv[] a wave is using (a wave may borrow a larger one while its owner idles)
   int32_t rot;                                      // the SIMD of the wave with role 0 (CTU_WAVE)
   int32_t req[4], done[4];                          // depth pipeline: evaluation requests / completions per depth
+  int32_t hreq, hdone, help[4];                     // the chroma helper (help_post): requests / completions; area x, y, mode -> has_coeffs
   alignas(16) unsigned char arena[ARENA_BYTES];
 #if defined(CTU_PB)
   pb_state pb;
@@ -2492,6 +2493,68 @@ template <typename PX> CTU_DEV void pb_intra_flag_bits(lds<PX> *S, const job<PX>
 // information / coefficient array, on the walk's models.  to_cand = 1 (its split is tried as well, by another wave at the same
 // time): into the depth's candidate buffers, on the depth's own copy of the entry models -- nothing another wave reads is touched.
 // Cost / mode / cbf go to S->lvl[L].
+#if defined(__HIPCC__)
+CTU_DEV int mb_load(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+CTU_DEV void mb_store(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
+
+#if !defined(CTU_PB)
+// ---- the chroma helper ------------------------------------------------------------------------------------------------------
+// The fourth 4x4 CU of an 8x8 area carries the area's two 4x4 chroma blocks (search.c:355-400).  They depend on that CU's luma MODE
+// only, not on its luma block, and the walk's chain of 4x4 CUs is what a CTU's time is made of: the Cb block goes to the wave of
+// depth 3 -- idle by then, the area's own 8x8 evaluation was posted four CUs ago -- while the walk reconstructs the luma block; Cr
+// follows on the walk (its cbf context wants Cb's flag).  Same arithmetic on the same inputs either way: when the wave is still
+// busy the walk simply does all three blocks itself.
+template <typename PX> CTU_DEV void help_run(lds<PX> *S, const job<PX> &J)          // depth 3's wave
+{
+#if defined(__HIPCC__)
+  __builtin_amdgcn_s_setprio(3);                   // the walk waits for this block
+#endif
+  const int cx = S->help[0], cy = S->help[1], mode = S->help[2];
+  const int lx = cx & 63, ly = cy & 63;
+  PX *const ru = S->Du + ((ly >> 1) + 1) * PC + (lx >> 1) + 1;
+  int16_t *const ku = J.coeff + 4096 + (ly >> 1) * LCU_C + (lx >> 1);
+  const int has = recon_tu(S, J, 1, cx, cy, lx, ly, 8, mode, 0, ru, PC, ku, LCU_C, 8);
+  {
+    CTU_LDS const int16_t *const from = LDSP(const int16_t, wv_of(S)->lv1);          // the walk counts the levels' bits from ITS scratch
+    CTU_LDS int16_t *const to = LDSP(int16_t, S->wv[0].lv1);
+    PAR_FOR(e, 16) to[e] = from[e];
+  }
+  LANE0 S->help[3] = has;
+  CTU_SYNC();
+#if defined(__HIPCC__)
+  __builtin_amdgcn_s_setprio(0);
+#endif
+}
+// the walk: hand the Cb block of the area at (cx, cy) over if depth 3's wave has nothing to do
+template <typename PX> CTU_DEV bool help_post(lds<PX> *S, const job<PX> &J, int cx, int cy, int mode)
+{
+#if defined(__HIPCC__)
+  if (__builtin_amdgcn_readfirstlane(mb_load(&S->done[3]) == S->req[3]) == 0) return false;
+  LANE0 { S->help[0] = cx; S->help[1] = cy; S->help[2] = mode; }
+  CTU_SYNC();
+  LANE0 mb_store(&S->hreq, S->hreq + 1);
+  return true;
+#else
+  if (g_emul_lazy) return false;                   // (the host tests take both roads)
+  S->help[0] = cx; S->help[1] = cy; S->help[2] = mode;
+  const int me = g_emul_wave;
+  g_emul_wave = 1;
+  help_run(S, J);
+  g_emul_wave = me;
+  return true;
+#endif
+}
+template <typename PX> CTU_DEV int help_wait(lds<PX> *S)
+{
+#if defined(__HIPCC__)
+  while (mb_load(&S->hdone) != S->hreq) __builtin_amdgcn_s_sleep(1);
+  CTU_SYNC();
+#endif
+  return S->help[3];
+}
+#endif
+
 template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<PX> &J, int L, int to_cand
 #if defined(CTU_PB)
                                                          , int forced_mode = -1      // P / B: the rough search already ran (ctu_pb.h); >= 0: its mode
@@ -2551,11 +2614,31 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
     rpy = PY; rpc = PC; kpy = LCU; kpc = LCU_C;
   }
   int cbf = 0;
+#if !defined(CTU_PB)
+  const bool helped = sep && has_chroma && !to_cand && help_post(S, J, cx, cy, mode);
+#if defined(__HIPCC__) && defined(CTU_PROFILE)
+  if (sep && has_chroma && !to_cand) { LANE0 J.W->prof[1][helped ? 19 : 20] += 1; }
+#endif
+#else
+  const bool helped = false;
+#endif
 #if defined(__HIPCC__)
 #pragma nounroll
 #endif
   for (int color = 0; color < (has_chroma ? 3 : 1); ++color) {
     const bool c = color != 0;
+#if !defined(CTU_PB)
+    if (helped && color == 1) {
+#if defined(__HIPCC__) && defined(CTU_PROFILE)
+      const unsigned long long tw = __builtin_amdgcn_s_memtime();
+#endif
+      cbf |= help_wait(S) << 1;
+#if defined(__HIPCC__) && defined(CTU_PROFILE)
+      LANE0 J.W->prof[1][21] += __builtin_amdgcn_s_memtime() - tw;
+#endif
+      continue;
+    }
+#endif
     const int has = recon_tu_inl(S, J, color, c ? cx : x, c ? cy : y, c ? cx & 63 : lx, c ? cy & 63 : ly, c ? area : n, mode, color == 2 ? (cbf >> 1) & 1 : 0,
                                  color == 0 ? ry : (color == 1 ? ru : rv), c ? rpc : rpy, color == 0 ? ky : (color == 1 ? ku : kv), c ? kpc : kpy, c ? area : n);
     cbf |= has << color;
@@ -2745,10 +2828,6 @@ template <typename PX> CTU_NOINLINE CTU_DEV void restore64(lds<PX> *S, const job
 // candidate buffers.  The reference evaluates the CU first and uses its cost to cut the children short (search.c:1952-1956,
 // 2002-2005); evaluating children it would have skipped changes nothing: every cut decides "not split", and so does the final
 // comparison whenever a cut would have applied (costs only grow child by child; the pruning test is re-applied when the cost is known).
-#if defined(__HIPCC__)
-CTU_DEV int mb_load(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-CTU_DEV void mb_store(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-#endif
 
 // ask the wave of depth L (1..3) to evaluate the CU described by lvl[L] / pre[L] (walk's wave, lane 0 has written both)
 template <typename PX> CTU_DEV void post_eval(lds<PX> *S, const job<PX> &J, int L)
@@ -2784,15 +2863,26 @@ template <typename PX> CTU_DEV void wait_eval(lds<PX> *S, int L)
 template <typename PX> CTU_DEV void worker_loop(lds<PX> *S, const job<PX> &J)
 {
   const int L = 4 - CTU_WAVE;
-  int seen = 0;
+  int seen = 0, hseen = 0;
   for (;;) {
-    int r;
-    while ((r = mb_load(&S->req[L])) == seen) __builtin_amdgcn_s_sleep(4);
-    if (r < 0) break;
-    seen = r;
-    eval_cu(S, J, L, 1);
-    CTU_SYNC();
-    LANE0 mb_store(&S->done[L], r);
+    int r, h = hseen;
+    for (;;) {
+      r = mb_load(&S->req[L]);
+      if (r != seen) break;
+      if (L == 3) { h = mb_load(&S->hreq); if (h != hseen) break; }        // depth 3's wave also takes the walk's Cb blocks (help_post)
+      if (L == 3) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4);
+    }
+    if (r != seen) {
+      if (r < 0) break;
+      seen = r;
+      eval_cu(S, J, L, 1);
+      CTU_SYNC();
+      LANE0 mb_store(&S->done[L], r);
+    } else {
+      hseen = h;
+      help_run(S, J);
+      LANE0 mb_store(&S->hdone, h);
+    }
   }
 }
 #endif
@@ -3146,6 +3236,7 @@ template <typename PX> CTU_DEV void setup_waves(lds<PX> *S)
     V->cur = S->cur;
     S->vsel[k] = k;
     S->req[k] = 0; S->done[k] = 0;
+    if (k == 0) { S->hreq = 0; S->hdone = 0; }
   }
   BLK_SYNC();
 }
