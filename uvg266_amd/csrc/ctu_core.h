@@ -43,11 +43,12 @@
 // means the 64 lanes of that wave and a hand-over between regions is a wave-level fence, not a workgroup barrier.
 #define CTU_TID ((int)(threadIdx.x & 63))
 #define CTU_NT 64
-// The four waves of a workgroup sit on the CU's four SIMDs, one each (measured: profiles/r04_simd_placement.txt); a wave's ROLE -- 0 walks
-// the CTU, 1..3 evaluate the depths 3..1 -- is its SIMD relative to S->rot, which the launcher picks so that the walkers of the
-// workgroups sharing a CU spread over the SIMDs (four walkers on one SIMD cost 9 %).  `S` is in scope wherever the role is asked for.
-#define CTU_HW_SIMD() ((int)((__builtin_amdgcn_s_getreg(63492) >> 4) & 3))      /* HW_REG_HW_ID [5:4] */
-#define CTU_WAVE ((CTU_HW_SIMD() - S->rot) & 3)
+// A wave's ROLE -- 0 walks the CTU, 1..3 evaluate the depths 3..1 -- is its index in the workgroup relative to S->rot, which the launcher
+// picks so that the walkers of the workgroups sharing a CU spread over the SIMDs (four walkers on one SIMD cost 9 %,
+// profiles/r04_simd_placement.txt).  The role must NOT be read off the hardware (HW_REG_HW_ID): with several queues busy the
+// scheduler saves waves and restores them elsewhere, and a role that changes under a wave is a wrong CTU.  Where a wave sits
+// when its workgroup starts is only a hint for S->rot.  `S` is in scope wherever the role is asked for.
+#define CTU_WAVE (__builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) - S->rot) & 3))
 #define CTU_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 // the few workgroup-wide regions (CTU load / store)
 #define BLK_TID ((int)threadIdx.x)
@@ -251,7 +252,7 @@ template <typename PX> struct lds {
   level_state lvl[5];
   wctx wv[4];                                       // [0] depth 4 (4x4), [1] depth 3, [2] depth 2, [3] depth 1 (32x32)
   int32_t vsel[4];                                  // which wv[] a wave is using (a wave may borrow a larger one while its owner idles)
-  int32_t rot;                                      // the SIMD of the wave with role 0 (CTU_WAVE)
+  int32_t rot;                                      // index of the wave with role 0 (CTU_WAVE)
   int32_t req[4], done[4];                          // depth pipeline: evaluation requests / completions per depth
   int32_t hreq, hdone, help[4];                     // the chroma helper (help_post): requests / completions; area x, y, mode -> has_coeffs
   alignas(16) unsigned char arena[ARENA_BYTES];

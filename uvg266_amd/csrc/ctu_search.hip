@@ -44,10 +44,13 @@ __global__ void __launch_bounds__(256, 4) ctu_search_kernel(launch_args A)
   __shared__ int s_ticket;
   __shared__ int s_slot;
   __shared__ int s_load;               // index of this workgroup's walker's counter in A.simd_load
+  __shared__ int s_simd[4];            // the SIMD every wave sits on as the workgroup starts
 #if defined(CTU_POISON_LDS)          // debug builds (make EXTRA=-DCTU_POISON_LDS=0xA5): nothing may depend on what the LDS held before
   for (unsigned i = threadIdx.x; i < sizeof(ctu::lds<PX>); i += 256) smem[i] = (unsigned char)(CTU_POISON_LDS);
   __syncthreads();
 #endif
+  if ((threadIdx.x & 63) == 0) s_simd[threadIdx.x >> 6] = (int)((__builtin_amdgcn_s_getreg(63492) >> 4) & 3);      // HW_REG_HW_ID [5:4]
+  __syncthreads();
   if (threadIdx.x == 0) {
     s_ticket = atomicAdd(A.ticket, 1);
     // claim a scratch slot: more slots than workgroups can ever be resident, so a free bit always exists
@@ -61,19 +64,20 @@ __global__ void __launch_bounds__(256, 4) ctu_search_kernel(launch_args A)
       if (!(prev & (1u << bit))) got = i * 32 + bit;
     }
     s_slot = got;
-    // Which wave walks the CTU: the one on the SIMD that carries the fewest walkers of the workgroups resident on this CU (the four
-    // waves of a workgroup sit on the four SIMDs; a walker is the one wave that never idles).  Counters per CU in the workspace.
+    // Which wave walks the CTU: the one that sits on the SIMD carrying the fewest walkers of the workgroups resident on this CU (a
+    // walker is the one wave that never idles; the four waves of a workgroup normally start on the four SIMDs).  Counters per CU in
+    // the workspace.  A hint for speed only: nothing depends on where a wave really runs (ctu_core.h CTU_WAVE).
     {
       const uint32_t hw = __builtin_amdgcn_s_getreg(63492), xcc = __builtin_amdgcn_s_getreg(63508) & 7u;      // HW_REG_HW_ID, HW_REG_XCC_ID
       int32_t *const c = A.simd_load + (size_t)((xcc << 8) | ((hw >> 8) & 0xffu)) * 4;
-      int best = s_ticket & 3, lo = __hip_atomic_load(&c[best], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int best = s_ticket & 3, lo = __hip_atomic_load(&c[s_simd[best]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       for (int k = 1; k < 4; ++k) {
-        const int sd = (s_ticket + k) & 3, v = __hip_atomic_load(&c[sd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v < lo) { lo = v; best = sd; }
+        const int w = (s_ticket + k) & 3, v = __hip_atomic_load(&c[s_simd[w]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v < lo) { lo = v; best = w; }
       }
-      atomicAdd(&c[best], 1);
+      atomicAdd(&c[s_simd[best]], 1);
       S->rot = best;
-      s_load = (int)(&c[best] - A.simd_load);
+      s_load = (int)(&c[s_simd[best]] - A.simd_load);
     }
   }
   __syncthreads();

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(64) ctu_search_pb_kernel(pb_launch_args A)
     }
     s_slot = got;
   }
-  if (threadIdx.x == 0) S->rot = (int)((__builtin_amdgcn_s_getreg(63492) >> 4) & 3);       // one wave: role 0 on whatever SIMD it sits (ctu_core.h CTU_WAVE)
+  if (threadIdx.x == 0) S->rot = 0;       // one wave: role 0 (ctu_core.h CTU_WAVE)
   __syncthreads();
   const int ticket = s_ticket;
   const int32_t o = A.order[ticket];
