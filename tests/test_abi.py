@@ -93,3 +93,18 @@ def test_no_kernel_uses_scratch():
             if line.startswith("Dynamic Stack:"):
                 assert line.endswith("False"), f"{os.path.basename(f)}: {name}: {line}"
     assert kernels >= 60
+
+
+def test_a_waves_role_is_not_read_off_the_hardware():
+    """The CTU kernels give the waves of a workgroup roles (walker, depth 3 / 2 / 1).  A role derived from HW_REG_HW_ID was measurably
+    faster and wrong: with several queues busy the scheduler saves waves and restores them on other SIMDs, and the role changed under
+    a running wave (tests/test_gpu_bench_config.py saw differing CTUs; DESIGN.md 4.6, profiles/r04_simd_placement.txt).  Hardware ids
+    may only be hints read once when a workgroup starts."""
+    import os
+    import re
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "uvg266_amd", "csrc")
+    core = open(os.path.join(src, "ctu_core.h")).read()
+    role = [ln for ln in core.splitlines() if re.match(r"\s*#define\s+CTU_WAVE\b", ln)]
+    assert len(role) == 2                                   # the device's and the host emulation's
+    assert not any("getreg" in ln for ln in role)
+    assert "getreg" not in core and "getreg" not in open(os.path.join(src, "ctu_pb.h")).read()      # only the launchers read ids (once, as hints)
