@@ -984,16 +984,33 @@ def inter_scu_table(g, frame):
     return t
 
 
+_MOVING_BASE = {}
+
+
+def _moving_base(W, H, depth):
+    """The 4x larger picture moving_picture's windows look into: the same for every picture of a sequence (kept for the last geometry)."""
+    key = (W, H, depth)
+    if key not in _MOVING_BASE:
+        _MOVING_BASE.clear()
+        _MOVING_BASE[key] = varied_picture(4 * (W + 32), 4 * (H + 32), 2007, depth)
+    return _MOVING_BASE[key]
+
+
 def moving_picture(W, H, t, depth):
     """Picture t of a sequence with fractional motion: a window into a 4x larger noisy picture, shifted by quarter samples per
     picture and box-filtered down -- the left and the right half move differently (partitions, uni- and bi-prediction)."""
-    base = varied_picture(4 * (W + 32), 4 * (H + 32), 2007, depth)
+    if W > 1920 or H > 1088:
+        # above 1080p the window would look into a 16x larger picture (minutes on the GPU box's host): the 960x544 sequence tiled instead
+        # (same motion everywhere, tile seams are just more edges)
+        tile = moving_picture(960, 544, t, depth)
+        return tuple(np.ascontiguousarray(np.tile(p, ((H + 543) // 544, (W + 959) // 960))[:H >> c, :W >> c]) for p, c in zip(tile, (0, 1, 1)))
+    base = _moving_base(W, H, depth)
     out = []
     for b, c in zip(base, (0, 1, 1)):
         w, h = W >> c, H >> c
 
         def window(sx, sy):
-            a = b.astype(np.int64)[sy:sy + 4 * h, sx:sx + 4 * w]
+            a = b[sy:sy + 4 * h, sx:sx + 4 * w].astype(np.int32)
             return ((a.reshape(h, 4, w, 4).sum(axis=(1, 3)) + 8) >> 4).astype(b.dtype)
         p = window((40 + 5 * t) >> c, (40 + 3 * t) >> c)
         p[:, w // 2:] = window((100 - 7 * t) >> c, (40 + 2 * t) >> c)[:, w // 2:]

@@ -121,10 +121,11 @@ def _frame_rows(g):
 
 
 @pytest.mark.parametrize("name,n_seq", [("ref_inter_264x136_8_qp32_9frames", 3), ("ref_intercrc_1920x1080_8_qp27_5frames", 2),
-                                        ("ref_intercrc_1920x1080_10_qp32_3frames", 1)])
+                                        ("ref_intercrc_1920x1080_10_qp32_3frames", 1), ("ref_intercrc_3840x2160_10_qp27_3frames", 1)])
 def test_low_delay_loop_of_several_sequences(hip, name, n_seq):
     """api.LowDelayLoop (what bench.py times for BASELINE configs[2]): n_seq sequences side by side, every picture group one call.  The
-    1080p case is checked through the CRCs of tests/golden/ref_intercrc_* (output pictures and every row's bytes of the reference's run)."""
+    1080p and 2160p cases are checked through the CRCs of tests/golden/ref_intercrc_* (output pictures and every row's bytes of the
+    reference's run; 2160p 10-bit is the geometry of BASELINE configs[3])."""
     import zlib
     import torch
     from uvg266_amd import api

@@ -334,6 +334,7 @@ if __name__ == "__main__":
     merge(192, 128, 8, 17, 6, 3)
     inter_crcs(1920, 1080, 8, 27, 5)     # BASELINE configs[2] at full size
     inter_crcs(1920, 1080, 10, 32, 3)    # ... and at 10 bit
+    inter_crcs(3840, 2160, 10, 27, 3)    # ... and at the size / depth of configs[3]
     merge(136, 72, 10, 27, 8, 2)
     inter(192, 128, 8, 32, 5, extra=("sao", "off"), suffix="_nosao", with_levels=False)        # final picture = the deblocked picture
     inter(136, 72, 10, 22, 4, extra=("sao", "off"), suffix="_nosao", with_levels=False)
