@@ -270,7 +270,8 @@ def inter_crcs(W, H, depth, qp, frames):
     import tempfile
     tmp = tempfile.mkdtemp()
     tag = inter(W, H, depth, qp, frames, out_dir=tmp)
-    g = np.load(os.path.join(tmp, f"ref_inter_{tag}.npz"))
+    with np.load(os.path.join(tmp, f"ref_inter_{tag}.npz")) as z:
+        g = {k: z[k] for k in z.files}          # (every access to the archive itself inflates the array again)
     wc, hc = (W + 63) // 64, (H + 63) // 64
     c = np.ascontiguousarray
     final_crc = np.array([zlib.crc32(c(g["final_y"][f]).tobytes() + c(g["final_u"][f]).tobytes() + c(g["final_v"][f]).tobytes()) for f in range(frames)], np.uint32)
