@@ -439,6 +439,120 @@ uint8_t __wrap_uvg_inter_get_merge_cand(const encoder_state_t *const state, cons
   return n;
 }
 
+/* ---- ALF: the whole per-picture process (src/alf.c:5193, called from encoderstate.c:1045 once every CTU of the picture is through SAO).
+ * Recorded around it: the picture it gets and the picture it leaves, and every decision the reconstruction half (alf_reconstruct
+ * :5032, apply_cc_alf_filter :1726) and the syntax need: the slice's flags and APS ids, the APSs' coded coefficients, the CTU flags,
+ * filter set indices, chroma alternatives and CC-ALF controls. */
+#include "alf.h"
+static void planes_of(const videoframe_t *frame, uvg_pixel *y, uvg_pixel *u, uvg_pixel *v)
+{
+  const int W = frame->width, H = frame->height, S = frame->rec->stride;
+  for (int r = 0; r < H; ++r) memcpy(y + (size_t)r * W, frame->rec->y + (size_t)r * S, sizeof(uvg_pixel) * W);
+  for (int r = 0; r < H / 2; ++r) {
+    memcpy(u + (size_t)r * (W / 2), frame->rec->u + (size_t)r * (S / 2), sizeof(uvg_pixel) * (W / 2));
+    memcpy(v + (size_t)r * (W / 2), frame->rec->v + (size_t)r * (S / 2), sizeof(uvg_pixel) * (W / 2));
+  }
+}
+/* the classification is freed before the process returns (alf.c:3382): taken when the luma filter first runs, through its strategy pointer */
+#include "strategies/strategies-alf.h"
+static alf_filter_7x7_blk_func *g_filter7_real;
+static uint8_t *g_cls;
+static int g_cls_taken;
+static void filter7_hook(encoder_state_t *const state, const uvg_pixel *src_pixels, uvg_pixel *dst_pixels, const int src_stride, const int dst_stride,
+                         const short *filter_set, const int16_t *fClipSet, clp_rng clp_rng, const int width, const int height, int x_pos, int y_pos,
+                         int blk_dst_x, int blk_dst_y, int vb_pos, const int vb_ctu_height)
+{
+  if (!g_cls_taken) {
+    const videoframe_t *frame = state->tile->frame;
+    const int cw = (frame->width + 3) / 4, chh = (frame->height + 3) / 4;
+    alf_classifier **cl = frame->alf_info->classifier;
+    for (int by = 0; by < chh; ++by) for (int bx = 0; bx < cw; ++bx) g_cls[by * cw + bx] = (uint8_t)(cl[by * 4][bx * 4].class_idx | cl[by * 4][bx * 4].transpose_idx << 5);
+    g_cls_taken = 1;
+  }
+  g_filter7_real(state, src_pixels, dst_pixels, src_stride, dst_stride, filter_set, fClipSet, clp_rng, width, height, x_pos, y_pos, blk_dst_x, blk_dst_y, vb_pos, vb_ctu_height);
+}
+void __real_uvg_alf_enc_process(encoder_state_t *const state);
+void __wrap_uvg_alf_enc_process(encoder_state_t *const state)
+{
+  videoframe_t *frame = state->tile->frame;
+  const int W = frame->width, H = frame->height, n = frame->width_in_lcu * frame->height_in_lcu;
+  uvg_pixel *pre[3], *post[3];
+  for (int c = 0; c < 3; ++c) { pre[c] = malloc(sizeof(uvg_pixel) * (size_t)W * H); post[c] = malloc(sizeof(uvg_pixel) * (size_t)W * H); }
+  planes_of(frame, pre[0], pre[1], pre[2]);
+  g_cls = calloc((size_t)((W + 3) / 4) * ((H + 3) / 4), 1); g_cls_taken = 0;
+  g_filter7_real = uvg_alf_filter_7x7_blk; uvg_alf_filter_7x7_blk = filter7_hook;
+  __real_uvg_alf_enc_process(state);
+  uvg_alf_filter_7x7_blk = g_filter7_real;
+  planes_of(frame, post[0], post[1], post[2]);
+  const encoder_state_config_alf_t *sa = state->slice->alf;
+  const alf_info_t *ai = frame->alf_info;
+  int32_t meta[32] = {0};
+  meta[0] = (int32_t)state->frame->num; meta[1] = W; meta[2] = H; meta[3] = state->encoder_control->cfg.alf_type;
+  meta[4] = sa->tile_group_alf_enabled_flag[0]; meta[5] = sa->tile_group_alf_enabled_flag[1]; meta[6] = sa->tile_group_alf_enabled_flag[2];
+  meta[7] = sa->tile_group_num_aps; meta[8] = sa->tile_group_chroma_aps_id;
+  for (int i = 0; i < ALF_CTB_MAX_NUM_APS; ++i) meta[9 + i] = i < sa->tile_group_num_aps ? sa->tile_group_luma_aps_id[i] : -1;
+  meta[17] = sa->cc_filter_param->cc_alf_filter_enabled[0]; meta[18] = sa->cc_filter_param->cc_alf_filter_enabled[1];
+  meta[19] = sa->cc_filter_param->cc_alf_filter_count[0]; meta[20] = sa->cc_filter_param->cc_alf_filter_count[1];
+  meta[21] = sa->tile_group_cc_alf_cb_enabled_flag; meta[22] = sa->tile_group_cc_alf_cr_enabled_flag;
+  meta[23] = sa->tile_group_cc_alf_cb_aps_id; meta[24] = sa->tile_group_cc_alf_cr_aps_id;
+  meta[25] = (int32_t)state->frame->poc; meta[26] = state->frame->slicetype; meta[27] = state->frame->QP;
+  meta[28] = state->encoder_control->cfg.input_bitdepth;      /* the classification's activity shift is input_bitdepth + 4 (alf.c:5185): the INPUT's depth, 8 unless --input-bitdepth says otherwise */
+  uint8_t *flags = calloc((size_t)n, 7);                       /* enable Y / Cb / Cr, alternative Cb / Cr, CC-ALF control Cb / Cr */
+  int16_t *set_idx = calloc((size_t)n, sizeof(int16_t));
+  for (int k = 0; k < n; ++k) {
+    for (int c = 0; c < 3; ++c) flags[c * n + k] = ai->ctu_enable_flag[c][k];
+    flags[3 * n + k] = ai->ctu_alternative[1][k]; flags[4 * n + k] = ai->ctu_alternative[2][k];
+    flags[5 * n + k] = ai->cc_alf_filter_control[0][k]; flags[6 * n + k] = ai->cc_alf_filter_control[1][k];
+    set_idx[k] = ai->alf_ctb_filter_index[k];
+  }
+  /* the APSs the slice refers to, as coded (before alf_reconstruct_coeff expands them per class) */
+  enum { LN = MAX_NUM_ALF_CLASSES * MAX_NUM_ALF_LUMA_COEFF };
+  int16_t *luma = calloc((size_t)ALF_CTB_MAX_NUM_APS * (2 * LN + MAX_NUM_ALF_CLASSES + 2), sizeof(int16_t));
+  for (int i = 0; i < sa->tile_group_num_aps; ++i) {
+    const alf_aps *a = &sa->apss[sa->tile_group_luma_aps_id[i]];
+    int16_t *o = luma + (size_t)i * (2 * LN + MAX_NUM_ALF_CLASSES + 2);
+    for (int k = 0; k < LN; ++k) { o[k] = a->luma_coeff[k]; o[LN + k] = a->luma_clipp[k]; }
+    for (int k = 0; k < MAX_NUM_ALF_CLASSES; ++k) o[2 * LN + k] = a->filter_coeff_delta_idx[k];
+    o[2 * LN + MAX_NUM_ALF_CLASSES] = (int16_t)a->num_luma_filters; o[2 * LN + MAX_NUM_ALF_CLASSES + 1] = a->non_linear_flag[0];
+  }
+  int16_t chroma[2 * MAX_NUM_ALF_ALTERNATIVES_CHROMA * MAX_NUM_ALF_CHROMA_COEFF + 2] = {0};
+  if (sa->tile_group_chroma_aps_id >= 0 && sa->tile_group_chroma_aps_id < ALF_CTB_MAX_NUM_APS) {
+    const alf_aps *a = &sa->apss[sa->tile_group_chroma_aps_id];
+    for (int t = 0; t < MAX_NUM_ALF_ALTERNATIVES_CHROMA; ++t)
+      for (int k = 0; k < MAX_NUM_ALF_CHROMA_COEFF; ++k) {
+        chroma[t * MAX_NUM_ALF_CHROMA_COEFF + k] = a->chroma_coeff[t][k];
+        chroma[(MAX_NUM_ALF_ALTERNATIVES_CHROMA + t) * MAX_NUM_ALF_CHROMA_COEFF + k] = a->chroma_clipp[t][k];
+      }
+    chroma[2 * MAX_NUM_ALF_ALTERNATIVES_CHROMA * MAX_NUM_ALF_CHROMA_COEFF] = (int16_t)a->num_alternatives_chroma;
+    chroma[2 * MAX_NUM_ALF_ALTERNATIVES_CHROMA * MAX_NUM_ALF_CHROMA_COEFF + 1] = a->non_linear_flag[1];
+  }
+  int16_t cc[2 * MAX_NUM_CC_ALF_FILTERS * MAX_NUM_CC_ALF_CHROMA_COEFF];
+  for (int c = 0; c < 2; ++c) for (int f = 0; f < MAX_NUM_CC_ALF_FILTERS; ++f) for (int k = 0; k < MAX_NUM_CC_ALF_CHROMA_COEFF; ++k)
+    cc[(c * MAX_NUM_CC_ALF_FILTERS + f) * MAX_NUM_CC_ALF_CHROMA_COEFF + k] = sa->cc_filter_param->cc_alf_coeff[c][f][k];
+  /* the two tables of the standard the fixed filter sets are made of (alf.h:46-133) */
+  static int32_t fixed[64 * MAX_NUM_ALF_LUMA_COEFF + ALF_NUM_FIXED_FILTER_SETS * MAX_NUM_ALF_CLASSES];
+  for (int i = 0; i < 64; ++i) for (int k = 0; k < MAX_NUM_ALF_LUMA_COEFF; ++k) fixed[i * MAX_NUM_ALF_LUMA_COEFF + k] = g_fixed_filter_set_coeff[i][k];
+  for (int i = 0; i < ALF_NUM_FIXED_FILTER_SETS; ++i) for (int k = 0; k < MAX_NUM_ALF_CLASSES; ++k)
+    fixed[64 * MAX_NUM_ALF_LUMA_COEFF + i * MAX_NUM_ALF_CLASSES + k] = g_class_to_filter_mapping[i][k];
+  /* the classification the luma filter worked from, one byte per 4x4 block (all zero when no CTU was filtered) */
+  const int cw = (W + 3) / 4, chh = (H + 3) / 4;
+  uint8_t *cls = g_cls;
+  rec_begin("alf", 14);
+  rec_arr(A_I32, meta, 32);
+  for (int c = 0; c < 3; ++c) rec_arr(A_PX, pre[c], c ? (size_t)(W / 2) * (H / 2) : (size_t)W * H);
+  for (int c = 0; c < 3; ++c) rec_arr(A_PX, post[c], c ? (size_t)(W / 2) * (H / 2) : (size_t)W * H);
+  rec_arr(A_U8, flags, (size_t)n * 7);
+  rec_arr(A_I16, set_idx, (size_t)n);
+  rec_arr(A_I16, luma, (size_t)ALF_CTB_MAX_NUM_APS * (2 * LN + MAX_NUM_ALF_CLASSES + 2));
+  rec_arr(A_I16, chroma, sizeof chroma / sizeof chroma[0]);
+  rec_arr(A_I16, cc, sizeof cc / sizeof cc[0]);
+  rec_arr(A_I32, fixed, sizeof fixed / sizeof fixed[0]);
+  rec_arr(A_U8, cls, (size_t)cw * chh);
+  free(cls);
+  for (int c = 0; c < 3; ++c) { free(pre[c]); free(post[c]); }
+  free(flags); free(set_idx); free(luma);
+}
+
 int main(int argc, char **argv)
 {
   if (getenv("CTU_DUMP_MERGE_EVERY")) g_merge_every = atoi(getenv("CTU_DUMP_MERGE_EVERY"));

@@ -294,6 +294,41 @@ def inter_crcs(W, H, depth, qp, frames):
     print("wrote inter crc", tag, "unit types per picture", types.tolist())
 
 
+def alf(W, H, depth, qp, frames, t0, kind):
+    """All-intra encode with --alf full: around every uvg_alf_enc_process (alf.c:5193) the picture it got (deblocked + SAO) and the
+    picture it left, and the decisions the reconstruction half and the syntax work from (tools/refcheck/ctu_dump.c, record "alf"):
+    slice flags and APS ids, the APSs' coded coefficients, per CTU enable flags / filter set index / chroma alternative / CC-ALF control,
+    the CC-ALF coefficients.  Source: helpers.varied_picture(kind * 1000 + t0 + t)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    px = np.uint8 if depth == 8 else np.uint16
+    tag = f"{W}x{H}_{depth}_qp{qp}_{frames}frames"
+    yuv = f"/tmp/gold_alf_{tag}.yuv"
+    src = [helpers.varied_picture(W, H, kind * 1000 + t0 + t, depth) for t in range(frames)]
+    with open(yuv, "wb") as f:
+        for pic in src:
+            for p in pic:
+                f.write(p.astype(px).tobytes())
+    out = f"/tmp/gold_alf_{tag}"
+    subprocess.check_call([os.path.join(ROOT, "tools/refcheck/ctu_dump.sh"), str(depth), yuv, str(W), str(H), str(frames), out,
+                           "preset", "medium", "period", "1", "qp", str(qp), "alf", "full"], stderr=subprocess.DEVNULL)
+    A = sorted([r for n, r in read_records(out + ".bin") if n == "alf"], key=lambda r: int(r[0][0]))
+    assert len(A) == frames
+    planes = lambda k: [np.stack([a[k + c].reshape(H >> (c > 0), W >> (c > 0)) for a in A]) for c in range(3)]
+    pre, post = planes(1), planes(4)
+    n = ((W + 63) // 64) * ((H + 63) // 64)
+    np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_alf_{tag}.npz"), dims=np.array([W, H, depth, qp, frames, t0, kind], np.int32),
+                        src_crc=np.array([zlib.crc32(b"".join(p.tobytes() for p in pic)) for pic in src], np.uint32),
+                        meta=np.stack([a[0] for a in A]), pre_y=pre[0], pre_u=pre[1], pre_v=pre[2], post_y=post[0], post_u=post[1], post_v=post[2],
+                        flags=np.stack([a[7].reshape(7, n) for a in A]), set_idx=np.stack([a[8] for a in A]), luma_aps=np.stack([a[9].reshape(8, -1) for a in A]),
+                        chroma_aps=np.stack([a[10] for a in A]), cc_coeff=np.stack([a[11].reshape(2, 4, 8) for a in A]),
+                        cls=np.stack([a[13].reshape((H + 3) // 4, (W + 3) // 4) for a in A]),          # the classification the luma filter worked from (zeros: no CTU filtered)
+                        bitstream=np.frombuffer(open(out + ".266", "rb").read(), np.uint8))
+    fixed = A[0][12]
+    np.save(os.path.join(ROOT, "tests/golden", "ref_alf_fixed.npy"), fixed.astype(np.int16))          # alf.h:46-133: 64 x 13 coefficients, 16 x 25 class -> filter
+    print("wrote alf", tag, "pictures with ALF on:", [int(a[0][4]) for a in A], "CC-ALF:", [a[0][17:19].tolist() for a in A])
+
+
 def merge(W, H, depth, qp, frames, every, amvp_step=4):
     """Calls of uvg_inter_get_merge_cand during a low-delay encode (every `every`-th one): everything the function reads and what it
     returned (tools/refcheck/ctu_dump.c, record "merge")."""
@@ -336,6 +371,9 @@ if __name__ == "__main__":
     inter_crcs(1920, 1080, 8, 27, 5)     # BASELINE configs[2] at full size
     inter_crcs(1920, 1080, 10, 32, 3)    # ... and at 10 bit
     inter_crcs(3840, 2160, 10, 27, 3)    # ... and at the size / depth of configs[3]
+    alf(320, 192, 10, 27, 3, 7, 2)       # --alf full: new filters, chroma alternatives, CC-ALF with per-CTU controls
+    alf(192, 128, 8, 27, 3, 0, 1)        # ... a picture left alone, one on a new APS, one on the fixed filter sets only
+    alf(192, 128, 10, 23, 2, 30, 1)      # ... 10 bit where the activity shift matters (cfg.input_bitdepth + 4, alf.c:5185: the runs leave it at 8 + 4)
     merge(136, 72, 10, 27, 8, 2)
     inter(192, 128, 8, 32, 5, extra=("sao", "off"), suffix="_nosao", with_levels=False)        # final picture = the deblocked picture
     inter(136, 72, 10, 22, 4, extra=("sao", "off"), suffix="_nosao", with_levels=False)
