@@ -673,6 +673,52 @@ UVGHIP_API int uvghip_alf_cov_expand(const int64_t *records, const uint32_t *pre
 UVGHIP_API int uvghip_alf_cov_reduce(const int64_t *records, const uint32_t *present, int n, int is_chroma, int64_t *sums,
                           void *stream);
 
+/* replaces: apply_cc_alf_filter -> filter_blk_cc_alf over the CTUs of one chroma plane (src/alf.c:1726-1775, 1626-1725; 4:2:0).
+ * rects: the CTUs' chroma rectangles; filter_idx[i] < 0 -> rectangle i untouched (cc_alf_filter_control 0), else the filter
+ * control - 1 into coef[4][8] (int16, seven taps used).  luma: the picture BEFORE ALF (the reference reads alf_tmp_y), pic_w / pic_h
+ * its size; chroma: the plane after the chroma ALF, filtered in place. */
+UVGHIP_API int uvghip_cc_alf_filter_batch(int bitdepth, const void *luma, int luma_stride, void *chroma, int chroma_stride, int pic_w,
+                               int pic_h, const uvghip_rect_t *rects, const int32_t *filter_idx, int n, const int16_t *coef,
+                               void *stream);
+
+/* replaces: alf_reconstruct_coeff_aps / alf_reconstruct_coeff (src/alf.c:4332-4368, 2925-2986, is_rdo = 0) and the fixed filter
+ * sets and clipping values uvg_alf_enc_process prepares (:5244-5279).  HOST function, no device involved.
+ *   luma_aps[n_luma_aps][UVGHIP_ALF_LUMA_APS_WORDS] int16: luma_coeff[25][13], luma_clipp[25][13] (clip indices), filter_coeff_delta_idx[25],
+ *     num_luma_filters, non_linear_flag -- the fields of alf_aps (alf.h:213-232) as coded;
+ *   chroma_aps[UVGHIP_ALF_CHROMA_APS_WORDS] int16 (may be NULL with the chroma outputs): chroma_coeff[8][7], chroma_clipp[8][7], num_alternatives, non_linear_flag.
+ * -> luma_coef / luma_clip [24][25][13]: sets 0..15 the fixed filter sets, 16 + i APS i (unused APSs zero); chroma_coef / chroma_clip [8][7]:
+ *    what uvghip_alf_filter_batch takes as coef_sets / clip_sets. */
+#define UVGHIP_ALF_LUMA_APS_WORDS 677
+#define UVGHIP_ALF_CHROMA_APS_WORDS 114
+UVGHIP_API int uvghip_alf_expand_tables(int bitdepth, int n_luma_aps, const int16_t *luma_aps, const int16_t *chroma_aps, int16_t *luma_coef,
+                             int16_t *luma_clip, int16_t *chroma_coef, int16_t *chroma_clip);
+
+/* replaces: alf_reconstruct + the CC-ALF tail of uvg_alf_enc_process (src/alf.c:5032-5137, 5363-5440) for one picture, given
+ * the decisions the encoder's derivation took (alf_encoder, alf_encoder_ctb, derive_cc_alf_filter stay host work upstream):
+ * out = the picture ALF leaves.  Planes are device memory, the decisions host memory (read before the call returns).
+ *   slice_enabled[3]            tile_group_alf_enabled_flag (Y off: nothing is filtered, alf.c:5035)
+ *   ctu_flags[7][n_ctus] u8     per CTU in raster order: ctu_enable_flag Y / Cb / Cr, ctu_alternative Cb / Cr, cc_alf_filter_control Cb / Cr
+ *   filter_set_idx[n_ctus]      alf_ctb_filter_index: < 16 a fixed filter set, else 16 + index into the slice's luma APS list
+ *   luma_aps / chroma_aps       as for uvghip_alf_expand_tables (the APSs the slice refers to, in tile_group_luma_aps_id order)
+ *   alf_full, cc_alf_enabled[2], cc_coeff[2][4][8]   CC-ALF (cfg.alf_type == UVG_ALF_FULL): cc_alf_filter_enabled, cc_alf_coeff
+ *   classification_shift        cfg.input_bitdepth + 4 (alf.c:5185: the depth of the INPUT, not the encoder's)
+ * width / height multiples of 8.  CC-ALF without luma ALF is refused (the reference reads a buffer it never filled, alf.c:5066). */
+typedef struct uvghip_alf_picture {
+  const void *in_y, *in_u, *in_v; int32_t in_stride, in_stride_c;
+  void *out_y, *out_u, *out_v; int32_t out_stride, out_stride_c;
+  int32_t width, height;
+  int32_t slice_enabled[3];
+  int32_t n_luma_aps;
+  const uint8_t *ctu_flags;
+  const int16_t *filter_set_idx;
+  const int16_t *luma_aps, *chroma_aps;
+  int32_t alf_full, cc_alf_enabled[2];
+  const int16_t *cc_coeff;
+  int32_t classification_shift;
+} uvghip_alf_picture_t;
+UVGHIP_API size_t uvghip_alf_reconstruct_workspace_bytes(int pic_w, int pic_h);
+UVGHIP_API int uvghip_alf_reconstruct_picture(int bitdepth, const uvghip_alf_picture_t *picture, void *workspace, void *stream);
+
 /* ------------------------------- (2) batched ABI: CTU-row bands (multi-GPU) ---- */
 
 /* One picture sharded over the GPUs of a node by contiguous CTU rows (the reference's own row

@@ -440,6 +440,40 @@ def alf_filter_batch(src, dst, rects, set_idx, coef_sets, clip_sets, cls=None, i
     return dst
 
 
+def alf_reconstruct_picture(planes, slice_enabled, ctu_flags, filter_set_idx, luma_aps, chroma_aps, alf_full=False, cc_alf_enabled=(0, 0), cc_coeff=None,
+                            classification_shift=None):
+    """uvghip_alf_reconstruct_picture: the picture ALF leaves, from the picture it gets (three device planes: deblocked + SAO) and the
+    encoder's decisions (numpy arrays, the layouts of include/uvg266_hip.h: ctu_flags u8 [7][n], filter_set_idx i16 [n], luma_aps i16
+    [k][677], chroma_aps i16 [114], cc_coeff i16 [2][4][8]).  -> three new device planes."""
+    L = _lib.init(planes[0].device.index or 0)
+    depth = _depth(planes[0])
+    h, w = planes[0].shape
+    out = [torch.empty_like(p) for p in planes]
+    flags = np.ascontiguousarray(ctu_flags, np.uint8)
+    sets = np.ascontiguousarray(filter_set_idx, np.int16)
+    laps = np.ascontiguousarray(luma_aps, np.int16).reshape(-1, 677)
+    caps = None if chroma_aps is None else np.ascontiguousarray(chroma_aps, np.int16)
+    ccc = None if cc_coeff is None else np.ascontiguousarray(cc_coeff, np.int16)
+    ptr = lambda a: None if a is None or a.size == 0 else a.ctypes.data_as(ctypes.c_void_p)
+    P = _lib.AlfPicture()
+    P.in_y, P.in_u, P.in_v = (_dev(p) for p in planes)
+    P.in_stride, P.in_stride_c = planes[0].stride(0), planes[1].stride(0)
+    P.out_y, P.out_u, P.out_v = (_dev(o) for o in out)
+    P.out_stride, P.out_stride_c = out[0].stride(0), out[1].stride(0)
+    P.width, P.height = w, h
+    for i in range(3):
+        P.slice_enabled[i] = int(slice_enabled[i])
+    P.n_luma_aps = laps.shape[0]
+    P.ctu_flags, P.filter_set_idx, P.luma_aps, P.chroma_aps, P.cc_coeff = ptr(flags), ptr(sets), ptr(laps), ptr(caps), ptr(ccc)
+    P.alf_full = int(bool(alf_full))
+    for i in range(2):
+        P.cc_alf_enabled[i] = int(cc_alf_enabled[i])
+    P.classification_shift = int(classification_shift if classification_shift is not None else depth + 4)
+    ws = torch.empty(L.uvghip_alf_reconstruct_workspace_bytes(w, h), dtype=torch.uint8, device=planes[0].device)
+    _lib.check(L.uvghip_alf_reconstruct_picture(depth, ctypes.byref(P), _dev(ws), _stream()), "uvghip_alf_reconstruct_picture")
+    return out
+
+
 def alf_stats_batch(org, rec, rects, cls=None, is_chroma=False, pic_w=None, pic_h=None):
     """-> (ee (n,C,13,13,4,4) int64, y (n,C,13,4) int32, pix_acc (n,C) int64), C = 25 (luma) or 1 (chroma)."""
     L = _lib.init(rec.device.index or 0)

@@ -97,6 +97,15 @@ class LoopPbPicture(ctypes.Structure):
                 ("out_stride_c", ctypes.c_int32)]
 
 
+class AlfPicture(ctypes.Structure):
+    """uvghip_alf_picture_t."""
+    _fields_ = [("in_y", ctypes.c_void_p), ("in_u", ctypes.c_void_p), ("in_v", ctypes.c_void_p), ("in_stride", ctypes.c_int32), ("in_stride_c", ctypes.c_int32),
+                ("out_y", ctypes.c_void_p), ("out_u", ctypes.c_void_p), ("out_v", ctypes.c_void_p), ("out_stride", ctypes.c_int32), ("out_stride_c", ctypes.c_int32),
+                ("width", ctypes.c_int32), ("height", ctypes.c_int32), ("slice_enabled", ctypes.c_int32 * 3), ("n_luma_aps", ctypes.c_int32),
+                ("ctu_flags", ctypes.c_void_p), ("filter_set_idx", ctypes.c_void_p), ("luma_aps", ctypes.c_void_p), ("chroma_aps", ctypes.c_void_p),
+                ("alf_full", ctypes.c_int32), ("cc_alf_enabled", ctypes.c_int32 * 2), ("cc_coeff", ctypes.c_void_p), ("classification_shift", ctypes.c_int32)]
+
+
 class MeJob(ctypes.Structure):
     """uvghip_me_job_t."""
     _fields_ = [("x", ctypes.c_int32), ("y", ctypes.c_int32), ("ref", ctypes.c_int32), ("mv_cand", (ctypes.c_int32 * 2) * 2), ("extra_mv", ctypes.c_int32 * 2),
@@ -190,6 +199,10 @@ SIGNATURES = {
     "uvghip_band_plan": (c_int, [c_int, c_int, c_int, c_vp]),
     "uvghip_deblock_band": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp,
                                     c_int, c_int, c_int, c_vp]),
+    "uvghip_cc_alf_filter_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_alf_expand_tables": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "uvghip_alf_reconstruct_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
+    "uvghip_alf_reconstruct_picture": (c_int, [c_int, c_vp, c_vp, c_vp]),
     "uvghip_alf_classify_band": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp]),
     "uvghip_sao_decide_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "uvghip_sao_decide_pictures": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.c_double, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
