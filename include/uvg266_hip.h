@@ -681,6 +681,15 @@ UVGHIP_API int uvghip_cc_alf_filter_batch(int bitdepth, const void *luma, int lu
                                int pic_h, const uvghip_rect_t *rects, const int32_t *filter_idx, int n, const int16_t *coef,
                                void *stream);
 
+/* replaces: get_blk_stats_cc_alf per CTU (src/alf.c:2613-2779, called from derive_stats_for_cc_alf_filtering :2780; 4:2:0) for one chroma
+ * plane.  For rectangle r (a CTU's chroma rectangle: <= 32 x 32, y a multiple of 32): ee[r][7][7] (int64, full symmetric: the fields
+ * ee[k][l][0][0] of alf_covariance), y[r][7] (int32: y[k][0]), pix_acc[r] (int64; the reference keeps this integer in a double).
+ * org / rec: the source chroma plane and the chroma plane AFTER its ALF (alf_tmp_u / _v at that point); luma: the picture BEFORE ALF
+ * (alf_tmp_y), pic_w / pic_h its size.  Every entry of the three outputs is written. */
+UVGHIP_API int uvghip_cc_alf_stats_batch(int bitdepth, const void *org, int org_stride, const void *rec, int rec_stride, const void *luma,
+                              int luma_stride, int pic_w, int pic_h, const uvghip_rect_t *rects, int n, int64_t *ee, int32_t *y,
+                              int64_t *pix_acc, void *stream);
+
 /* replaces: alf_reconstruct_coeff_aps / alf_reconstruct_coeff (src/alf.c:4332-4368, 2925-2986, is_rdo = 0) and the fixed filter
  * sets and clipping values uvg_alf_enc_process prepares (:5244-5279).  HOST function, no device involved.
  *   luma_aps[n_luma_aps][UVGHIP_ALF_LUMA_APS_WORDS] int16: luma_coeff[25][13], luma_clipp[25][13] (clip indices), filter_coeff_delta_idx[25],

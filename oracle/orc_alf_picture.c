@@ -82,6 +82,45 @@ static void cc_alf_rect(orc_px *dst, int cstride, const orc_px *luma, int lstrid
 }
 
 /*
+ * get_blk_stats_cc_alf / calc_covariance_cc_alf (alf.c:2583-2779), 4:2:0: the CC-ALF covariance of the chroma rectangle (x0, y0, w, h)
+ * (chroma samples; a CTU: y0 a multiple of 32) -- per sample e[k] = the seven luma tap differences around (2x, 2y) of the picture BEFORE
+ * ALF, d = org - rec of the chroma plane AFTER its ALF; ee[k][l] = sum e[k] e[l] (full symmetric 7x7), y[k] = sum e[k] d, pix = sum d d.
+ * The rows bend at the luma virtual boundary like the filter's -- except in the picture's last CTU row, where the reference moves the
+ * boundary out of reach (vb_pos = frame_height, :2652-2655).  Pinned function by function: tools/refcheck/rc_alfstatic.c reaches the
+ * reference's static functions by compiling its alf.c into the dev tool.
+ */
+ORC_EXPORT void ORC_FN(cc_alf_stats_rect)(const orc_px *org, int ostride, const orc_px *rec_c, int cstride, const orc_px *luma, int lstride, int W, int H,
+                                          int x0, int y0, int w, int h, int64_t *ee, int32_t *yv, int64_t *pix)
+{
+  int64_t e2[7][7] = {{0}}, ys[7] = {0}, pa = 0;
+  const int last_row = (y0 << 1) + 64 >= H;
+  for (int i = 0; i < h; ++i) {
+    const int vbd = last_row ? -(1 << 20) : (((i << 1) % 64) - 60);
+    int o_m1 = -1, o_p1 = 1, o_p2 = 2;
+    if (vbd == -2 || vbd == 1) o_p2 = o_p1;
+    else if (vbd == -1 || vbd == 0) { o_m1 = 0; o_p1 = 0; o_p2 = 0; }
+    for (int j = 0; j < w; ++j) {
+      const int lx = (x0 + j) << 1, ly = (y0 + i) << 1;
+#define L(dx, dy) at(luma, lstride, W, H, lx + (dx), ly + (dy))
+      const int c = L(0, 0);
+      const int e[7] = {L(0, o_m1) - c, L(-1, 0) - c, L(1, 0) - c, L(-1, o_p1) - c, L(0, o_p1) - c, L(1, o_p1) - c, L(0, o_p2) - c};
+#undef L
+      const int d = (int)org[(size_t)(y0 + i) * ostride + x0 + j] - (int)rec_c[(size_t)(y0 + i) * cstride + x0 + j];
+      for (int k = 0; k < 7; ++k) {
+        for (int l = k; l < 7; ++l) e2[k][l] += (int64_t)e[k] * e[l];
+        ys[k] += (int64_t)e[k] * d;
+      }
+      pa += (int64_t)d * d;
+    }
+  }
+  for (int k = 0; k < 7; ++k) {
+    for (int l = 0; l < 7; ++l) ee[k * 7 + l] = k <= l ? e2[k][l] : e2[l][k];
+    yv[k] = (int32_t)ys[k];
+  }
+  *pix = pa;
+}
+
+/*
  * meta: the record's header (ctu_dump.c): [3] alf_type, [4..6] slice enable Y / Cb / Cr, [7] number of luma APSs, [17..18] CC-ALF on for Cb / Cr,
  * [28] cfg.input_bitdepth (the classification's activity shift is that + 4 -- the depth of the INPUT, which the runs behind the goldens leave at 8).
  * flags[7][n]: CTU enable Y / Cb / Cr, chroma alternative Cb / Cr, CC-ALF control Cb / Cr.  set_idx[n]: < 16 a fixed set, else luma APS set_idx - 16.

@@ -126,3 +126,24 @@ def test_full_size_properties(hip):
     assert torch.equal(e, e.permute(0, 1, 3, 2, 5, 4))
     # center-tap row of y: sum_px cur * (org - rec), independent of class split
     assert int(y[:, :, 12, 0].sum()) == int((rec.long() * (org.long() - rec.long())).sum())
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_cc_alf_statistics_vs_reference(hip, depth):
+    """uvghip_cc_alf_stats_batch against get_blk_stats_cc_alf of the reference (vectors of tools/refcheck/rc_alf.inc; the oracle is held to the
+    same ones in tests/test_oracle_alf.py): every CTU of a 136 x 136 picture incl. the partial ones and the last row's boundary rule."""
+    from uvg266_amd import api
+    from test_oracle_alf import cc_ctus
+    recs = alf_goldens(depth)["ccstats"]
+    assert len(recs) == 2
+    for (W, Hh, it), luma, rec_u, rec_v, org_u, org_v, ee, yv, pix in recs:
+        W, Hh = int(W), int(Hh)
+        CW, CH = W // 2, Hh // 2
+        rects = api.make_rects(cc_ctus(W, Hh))
+        dl = dev(luma.reshape(Hh, W))
+        for c, (org, rec) in enumerate(((org_u, rec_u), (org_v, rec_v))):
+            e, y, p = api.cc_alf_stats_batch(dev(org.reshape(CH, CW)), dev(rec.reshape(CH, CW)), dl, rects)
+            e, y, p = e.cpu().numpy(), y.cpu().numpy(), p.cpu().numpy()
+            for k in range(9):
+                i = k * 2 + c
+                assert np.array_equal(e[k].ravel(), ee[i * 49:(i + 1) * 49]) and np.array_equal(y[k], yv[i * 7:(i + 1) * 7]) and p[k] == pix[i], (int(it), k, c)

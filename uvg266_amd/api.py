@@ -440,6 +440,18 @@ def alf_filter_batch(src, dst, rects, set_idx, coef_sets, clip_sets, cls=None, i
     return dst
 
 
+def cc_alf_stats_batch(org_c, rec_c, luma, rects):
+    """uvghip_cc_alf_stats_batch: per chroma rectangle (a CTU) the CC-ALF covariance -> (ee [n][7][7] int64, y [n][7] int32, pix_acc [n] int64)."""
+    L = _lib.init(org_c.device.index or 0)
+    n = rects.shape[0]
+    ee = torch.empty((n, 7, 7), dtype=torch.int64, device=org_c.device)
+    y = torch.empty((n, 7), dtype=torch.int32, device=org_c.device)
+    pix = torch.empty((n,), dtype=torch.int64, device=org_c.device)
+    _lib.check(L.uvghip_cc_alf_stats_batch(_depth(org_c), _dev(org_c), org_c.stride(0), _dev(rec_c), rec_c.stride(0), _dev(luma), luma.stride(0), luma.shape[1], luma.shape[0],
+                                           _dev(rects), n, _dev(ee), _dev(y), _dev(pix), _stream()), "uvghip_cc_alf_stats_batch")
+    return ee, y, pix
+
+
 def alf_reconstruct_picture(planes, slice_enabled, ctu_flags, filter_set_idx, luma_aps, chroma_aps, alf_full=False, cc_alf_enabled=(0, 0), cc_coeff=None,
                             classification_shift=None):
     """uvghip_alf_reconstruct_picture: the picture ALF leaves, from the picture it gets (three device planes: deblocked + SAO) and the

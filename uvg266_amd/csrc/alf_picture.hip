@@ -45,6 +45,63 @@ cc_alf_kernel(const PX *__restrict__ luma, int lstride, PX *__restrict__ chroma,
   }
 }
 
+// get_blk_stats_cc_alf / calc_covariance_cc_alf (alf.c:2583-2779), 4:2:0: the CC-ALF covariance of one chroma rectangle (a CTU) -- per
+// sample the seven luma tap differences e[k] around (2x, 2y) of the picture before ALF and d = org - rec of the chroma plane after its
+// ALF; ee = sum e e^T (symmetric 7 x 7), y = sum e d, pix = sum d d.  HBM-bound and tiny (36 sums over <= 1024 samples): one workgroup
+// per rectangle, <= 4 samples per thread in 32-bit partial sums (|e|, |d| < 2^10), 64-bit wave and workgroup reduction.
+template <typename PX>
+__global__ void __launch_bounds__(256)
+cc_alf_stats_kernel(const PX *__restrict__ org, int ostride, const PX *__restrict__ rec_c, int cstride, const PX *__restrict__ luma, int lstride,
+                    int pic_w, int pic_h, const uvghip_rect_t *__restrict__ rects, long long *__restrict__ ee, int32_t *__restrict__ yv,
+                    long long *__restrict__ pix)
+{
+  const uvghip_rect_t R = rects[blockIdx.x];
+  constexpr int NS = 36;                        // 28 products k <= l, 7 cross terms, the energy
+  int acc[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) acc[i] = 0;
+  const bool last_row = (R.y << 1) + 64 >= pic_h;        // the reference moves the virtual boundary out of reach there (alf.c:2652-2655)
+  for (int i = threadIdx.x; i < R.w * R.h; i += blockDim.x) {
+    const int yy = i / R.w, xx = i - yy * R.w;
+    const int vbd = last_row ? -1000 : (((yy << 1) & 63) - 60);
+    int o_m1 = -1, o_p1 = 1, o_p2 = 2;
+    if (vbd == -2 || vbd == 1) o_p2 = o_p1;
+    else if (vbd == -1 || vbd == 0) { o_m1 = 0; o_p1 = 0; o_p2 = 0; }
+    const int lx = (R.x + xx) << 1, ly = (R.y + yy) << 1;
+    auto L = [&](int dx, int dy) { return (int)luma[(size_t)clampi(ly + dy, 0, pic_h - 1) * lstride + clampi(lx + dx, 0, pic_w - 1)]; };
+    const int c = L(0, 0);
+    const int e[7] = {L(0, o_m1) - c, L(-1, 0) - c, L(1, 0) - c, L(-1, o_p1) - c, L(0, o_p1) - c, L(1, o_p1) - c, L(0, o_p2) - c};
+    const int d = (int)org[(size_t)(R.y + yy) * ostride + R.x + xx] - (int)rec_c[(size_t)(R.y + yy) * cstride + R.x + xx];
+    int at = 0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+#pragma unroll
+      for (int l = k; l < 7; ++l) acc[at++] += e[k] * e[l];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc[28 + k] += e[k] * d;
+    acc[35] += d * d;
+  }
+  __shared__ long long sSum[4][NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    long long v = acc[i];
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sSum[threadIdx.x >> 6][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    const long long v = sSum[0][threadIdx.x] + sSum[1][threadIdx.x] + sSum[2][threadIdx.x] + sSum[3][threadIdx.x];
+    const int i = threadIdx.x;
+    if (i < 28) {
+      int k = 0, base = 0;
+      while (i >= base + 7 - k) { base += 7 - k; ++k; }
+      const int l = k + (i - base);
+      ee[(size_t)blockIdx.x * 49 + k * 7 + l] = v; ee[(size_t)blockIdx.x * 49 + l * 7 + k] = v;
+    } else if (i < 35) yv[(size_t)blockIdx.x * 7 + (i - 28)] = (int32_t)v;
+    else pix[blockIdx.x] = v;
+  }
+}
+
 void clip_values(int bitdepth, int16_t v[4])       // alf.c:5248-5260
 {
   v[0] = (int16_t)(1 << bitdepth);
@@ -63,6 +120,23 @@ extern "C" int uvghip_cc_alf_filter_batch(int bitdepth, const void *luma, int lu
   hipStream_t st = uvghip_stream(stream);
   if (bitdepth == 8) cc_alf_kernel<uint8_t><<<n, 256, 0, st>>>((const uint8_t *)luma, luma_stride, (uint8_t *)chroma, chroma_stride, pic_w, pic_h, rects, filter_idx, coef);
   else cc_alf_kernel<uint16_t><<<n, 256, 0, st>>>((const uint16_t *)luma, luma_stride, (uint16_t *)chroma, chroma_stride, pic_w, pic_h, rects, filter_idx, coef);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+extern "C" int uvghip_cc_alf_stats_batch(int bitdepth, const void *org, int org_stride, const void *rec, int rec_stride, const void *luma, int luma_stride,
+                                         int pic_w, int pic_h, const uvghip_rect_t *rects, int n, int64_t *ee, int32_t *y, int64_t *pix_acc, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
+  if (n <= 0) return 0;
+  if (!org || !rec || !luma || !rects || !ee || !y || !pix_acc || pic_w <= 0 || pic_h <= 0) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  hipStream_t st = uvghip_stream(stream);
+  if (bitdepth == 8)
+    cc_alf_stats_kernel<uint8_t><<<n, 256, 0, st>>>((const uint8_t *)org, org_stride, (const uint8_t *)rec, rec_stride, (const uint8_t *)luma, luma_stride, pic_w, pic_h, rects,
+                                                    (long long *)ee, y, (long long *)pix_acc);
+  else
+    cc_alf_stats_kernel<uint16_t><<<n, 256, 0, st>>>((const uint16_t *)org, org_stride, (const uint16_t *)rec, rec_stride, (const uint16_t *)luma, luma_stride, pic_w, pic_h, rects,
+                                                     (long long *)ee, y, (long long *)pix_acc);
   UVGHIP_CHECK_LAUNCH();
 }
 

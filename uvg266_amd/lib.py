@@ -200,6 +200,7 @@ SIGNATURES = {
     "uvghip_deblock_band": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp,
                                     c_int, c_int, c_int, c_vp]),
     "uvghip_cc_alf_filter_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_cc_alf_stats_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_alf_expand_tables": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_alf_reconstruct_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "uvghip_alf_reconstruct_picture": (c_int, [c_int, c_vp, c_vp, c_vp]),
