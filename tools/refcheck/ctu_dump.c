@@ -553,6 +553,37 @@ void __wrap_uvg_alf_enc_process(encoder_state_t *const state)
   free(flags); free(set_idx); free(luma);
 }
 
+/* ---- the APS NAL units a picture is preceded by (alf.c:1610 -> encode_alf_aps :1575): every parameter set the map marks as changed,
+ * with all the fields encode_alf_aps_flags (:1452-1545) writes. */
+void __real_uvg_encode_alf_adaptive_parameter_set(encoder_state_t *const state);
+void __wrap_uvg_encode_alf_adaptive_parameter_set(encoder_state_t *const state)
+{
+  const encoder_control_t *const encoder = state->encoder_control;
+  const encoder_state_config_alf_t *sa = state->slice->alf;
+  if (encoder->cfg.alf_type && (sa->tile_group_alf_enabled_flag[COMPONENT_Y] || sa->tile_group_cc_alf_cb_enabled_flag || sa->tile_group_cc_alf_cr_enabled_flag)) {
+    const param_set_map *map = state->tile->frame->alf_param_set_map;
+    for (int id = 0; id < ALF_CTB_MAX_NUM_APS; ++id) {
+      if (!map[id + T_ALF_APS].b_changed) continue;
+      const alf_aps *a = &map[id + T_ALF_APS].parameter_set;
+      enum { LN = MAX_NUM_ALF_CLASSES * MAX_NUM_ALF_LUMA_COEFF };
+      int32_t meta[16] = {(int32_t)state->frame->num, id, a->aps_id, (int32_t)a->aps_type, a->new_filter_flag[0], a->new_filter_flag[1], a->non_linear_flag[0], a->non_linear_flag[1],
+                          a->num_luma_filters, a->num_alternatives_chroma, a->cc_alf_aps_param.new_cc_alf_filter[0], a->cc_alf_aps_param.new_cc_alf_filter[1],
+                          a->cc_alf_aps_param.cc_alf_filter_count[0], a->cc_alf_aps_param.cc_alf_filter_count[1], encoder->cfg.alf_type, 0};
+      int16_t luma[2 * LN + MAX_NUM_ALF_CLASSES], chroma[2 * MAX_NUM_ALF_ALTERNATIVES_CHROMA * MAX_NUM_ALF_CHROMA_COEFF], cc[2 * MAX_NUM_CC_ALF_FILTERS * MAX_NUM_CC_ALF_CHROMA_COEFF];
+      for (int k = 0; k < LN; ++k) { luma[k] = a->luma_coeff[k]; luma[LN + k] = a->luma_clipp[k]; }
+      for (int k = 0; k < MAX_NUM_ALF_CLASSES; ++k) luma[2 * LN + k] = a->filter_coeff_delta_idx[k];
+      for (int t = 0; t < MAX_NUM_ALF_ALTERNATIVES_CHROMA; ++t) for (int k = 0; k < MAX_NUM_ALF_CHROMA_COEFF; ++k) {
+        chroma[t * MAX_NUM_ALF_CHROMA_COEFF + k] = a->chroma_coeff[t][k]; chroma[(MAX_NUM_ALF_ALTERNATIVES_CHROMA + t) * MAX_NUM_ALF_CHROMA_COEFF + k] = a->chroma_clipp[t][k];
+      }
+      for (int c = 0; c < 2; ++c) for (int f = 0; f < MAX_NUM_CC_ALF_FILTERS; ++f) for (int k = 0; k < MAX_NUM_CC_ALF_CHROMA_COEFF; ++k)
+        cc[(c * MAX_NUM_CC_ALF_FILTERS + f) * MAX_NUM_CC_ALF_CHROMA_COEFF + k] = a->cc_alf_aps_param.cc_alf_coeff[c][f][k];
+      rec_begin("aps", 4);
+      rec_arr(A_I32, meta, 16); rec_arr(A_I16, luma, 2 * LN + MAX_NUM_ALF_CLASSES); rec_arr(A_I16, chroma, sizeof chroma / sizeof chroma[0]); rec_arr(A_I16, cc, sizeof cc / sizeof cc[0]);
+    }
+  }
+  __real_uvg_encode_alf_adaptive_parameter_set(state);
+}
+
 int main(int argc, char **argv)
 {
   if (getenv("CTU_DUMP_MERGE_EVERY")) g_merge_every = atoi(getenv("CTU_DUMP_MERGE_EVERY"));

@@ -12,7 +12,7 @@ BIN=/tmp/ctu_dump$D
 if [ ! -x $BIN ] || [ tools/refcheck/ctu_dump.c -nt $BIN ] || [ tools/refcheck/ctu_dump.sh -nt $BIN ] || [ $LIB -nt $BIN ]; then
   gcc -O1 -g -std=gnu11 -w $DEF -Ioracle/_ref/gen -I$REF/src -I$REF/src/extras -I$REF/src/strategies tools/refcheck/ctu_dump.c $LIB \
       -Wl,--wrap=uvg_search_lcu -Wl,--wrap=uvg_encode_coding_tree -Wl,--wrap=uvg_sao_search_lcu -Wl,--wrap=uvg_bitstream_put_byte -Wl,--wrap=uvg_cabac_finish \
-      -Wl,--wrap=uvg_bitstream_align_zero -Wl,--wrap=uvg_inter_get_merge_cand -Wl,--wrap=uvg_inter_get_mv_cand -Wl,--wrap=uvg_search_cu_inter -Wl,--wrap=uvg_alf_enc_process -lm -lpthread -o $BIN.$$ && mv -f $BIN.$$ $BIN
+      -Wl,--wrap=uvg_bitstream_align_zero -Wl,--wrap=uvg_inter_get_merge_cand -Wl,--wrap=uvg_inter_get_mv_cand -Wl,--wrap=uvg_search_cu_inter -Wl,--wrap=uvg_alf_enc_process -Wl,--wrap=uvg_encode_alf_adaptive_parameter_set -lm -lpthread -o $BIN.$$ && mv -f $BIN.$$ $BIN
 fi
 IN=$1; W=$2; H=$3; N=$4; OUT=$5; shift 5
 $BIN $IN $W $H $N $OUT.bin $OUT.266 "$@"

@@ -35,7 +35,7 @@ def read_records(path):
     return recs
 
 
-def run(W, H, depth, qp, t, tag, picture=None):
+def run(W, H, depth, qp, t, tag, picture=None, extra=()):
     px = np.uint8 if depth == 8 else np.uint16
     y, u, v = (picture or layout.synthetic_yuv420)(W, H, t, depth)
     yuv = f"/tmp/gold_{tag}.yuv"
@@ -44,13 +44,20 @@ def run(W, H, depth, qp, t, tag, picture=None):
             f.write(p.astype(px).tobytes())
     out = f"/tmp/gold_{tag}"
     subprocess.check_call([os.path.join(ROOT, "tools/refcheck/ctu_dump.sh"), str(depth), yuv, str(W), str(H), "1", out,
-                           "preset", "medium", "period", "1", "qp", str(qp)], stderr=subprocess.DEVNULL)
+                           "preset", "medium", "period", "1", "qp", str(qp)] + list(extra), stderr=subprocess.DEVNULL)
     recs = read_records(out + ".bin")
     S = [r for n, r in recs if n == "search"]
     Cd = [r for n, r in recs if n == "coded"]
-    global SAO, FINAL, ROWS
+    global SAO, FINAL, ROWS, ALF, APS
     SAO = [r for n, r in recs if n == "sao"]
     ROWS = [r for n, r in recs if n == "row"]
+    ALF = [r for n, r in recs if n == "alf"]
+    APS = [r for n, r in recs if n == "aps"]
+    if ALF:
+        # with ALF on the coding of the CTUs is simulated during the search and done for real after uvg_alf_enc_process
+        # (encoderstate.c:1040-1052): every coding tree and every row is recorded twice -- the second pass is the bitstream
+        assert len(Cd) == 2 * len(S) and len(ROWS) % 2 == 0
+        Cd, ROWS = Cd[len(S):], ROWS[len(ROWS) // 2:]
     FINAL = [r for n, r in recs if n == "final"][0]
     src_crc = zlib.crc32(y.tobytes() + u.tobytes() + v.tobytes())
     bitstream = np.frombuffer(open(out + ".266", "rb").read(), np.uint8)
@@ -109,9 +116,11 @@ def items(s, c, W, H):
     return x, y, hh, ww, cu, trees, ry, ru, rv, cy, cuv
 
 
-def full(W, H, depth, qp, t=0, picture=None, out_dir=None):
-    tag = f"{W}x{H}_{depth}_qp{qp}"
-    S, Cd, src_crc, bs, px = run(W, H, depth, qp, t, tag, picture)
+def full(W, H, depth, qp, t=0, picture=None, out_dir=None, alf=False):
+    tag = f"{W}x{H}_{depth}_qp{qp}" + ("_alf" if alf else "")
+    # (one worker thread: without threads the queue runs a job the moment it is submitted (threadqueue.c:452) and a CTU's bitstream job
+    # runs before the picture's ALF job -- the .266 of such a run is not what the encoder produces with its dependencies honoured)
+    S, Cd, src_crc, bs, px = run(W, H, depth, qp, t, tag, picture, extra=("alf", "full", "threads", "1") if alf else ())
     wc, hc = (W + 63) // 64, (H + 63) // 64
     assert len(S) == wc * hc == len(Cd)
     models = np.zeros((hc * wc, 3, 1286), np.uint8)
@@ -133,7 +142,19 @@ def full(W, H, depth, qp, t=0, picture=None, out_dir=None):
         co[4096:].reshape(2, 32, 32)[:, :hh // 2, :ww // 2] = cuv
     meta = np.array([W, H, depth, qp, t, int(S[0][0][3])], np.int32)
     info, sm, snap, final = sao_items(W, H, Cd, px)
-    np.savez_compressed(os.path.join(out_dir or os.path.join(ROOT, "tests/golden"), f"ref_ctu_{tag}.npz"), meta=meta, lam=S[0][1], src_crc=np.uint32(src_crc), models=models,
+    more = {}
+    if alf:
+        # the ALF decisions of the picture (record "alf", see alf()) and the parameter sets written in front of it (record "aps":
+        # meta = frame, map index, aps_id, aps_type, new_filter_flag[2], non_linear_flag[2], num_luma_filters, num_alternatives_chroma,
+        # new_cc_alf_filter[2], cc_alf_filter_count[2], alf_type; luma = coeff[25][13], clipp[25][13], filter_coeff_delta_idx[25];
+        # chroma = coeff[8][7], clipp[8][7]; cc = coeff[2][4][8])
+        assert len(ALF) == 1
+        a, n = ALF[0], wc * hc
+        more = dict(alf_meta=a[0], alf_flags=a[7].reshape(7, n), alf_set_idx=a[8], alf_luma_aps=a[9].reshape(8, -1), alf_chroma_aps=a[10], alf_cc_coeff=a[11].reshape(2, 4, 8),
+                    alf_pre_y=a[1].reshape(H, W), alf_pre_u=a[2].reshape(H // 2, W // 2), alf_pre_v=a[3].reshape(H // 2, W // 2),
+                    aps_meta=np.stack([r[0] for r in APS]) if APS else np.zeros((0, 16), np.int32), aps_luma=np.stack([r[1] for r in APS]) if APS else np.zeros((0, 675), np.int16),
+                    aps_chroma=np.stack([r[2] for r in APS]) if APS else np.zeros((0, 112), np.int16), aps_cc=np.stack([r[3] for r in APS]) if APS else np.zeros((0, 64), np.int16))
+    np.savez_compressed(os.path.join(out_dir or os.path.join(ROOT, "tests/golden"), f"ref_ctu_{tag}.npz"), **more, meta=meta, lam=S[0][1], src_crc=np.uint32(src_crc), models=models,
                         cu=cu, trees=trees, rec_y=rec[0], rec_u=rec[1], rec_v=rec[2], coeff=coeff, bitstream=bs,
                         sao=info, sao_models=sm, coder=CODER, coder_state=CODER_STATE, tree_bytes=TREE_BYTES, tree_off=TREE_OFF, row_bytes=ROW_BYTES, row_off=ROW_OFF, snap_y=snap[0], snap_u=snap[1], snap_v=snap[2], final_y=final[0], final_u=final[1], final_v=final[2])
     if not out_dir: print("wrote", tag, len(S), "CTUs")
@@ -184,6 +205,12 @@ def stream(W, H, depth, qp, ts):
     np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_stream_{tag}.npz"), meta=np.array([W, H, depth, qp], np.int32), ts=np.array(ts, np.int32),
                         src_crc=np.array(crcs, np.uint32), bitstream=bs)
     print("wrote stream", tag, len(bs), "bytes")
+
+
+def helpers_varied():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    return helpers.varied_picture
 
 
 def moving_picture(W, H, t, depth):
@@ -294,7 +321,7 @@ def inter_crcs(W, H, depth, qp, frames):
     print("wrote inter crc", tag, "unit types per picture", types.tolist())
 
 
-def alf(W, H, depth, qp, frames, t0, kind):
+def alf(W, H, depth, qp, frames, t0, kind, threads=1):
     """All-intra encode with --alf full: around every uvg_alf_enc_process (alf.c:5193) the picture it got (deblocked + SAO) and the
     picture it left, and the decisions the reconstruction half and the syntax work from (tools/refcheck/ctu_dump.c, record "alf"):
     slice flags and APS ids, the APSs' coded coefficients, per CTU enable flags / filter set index / chroma alternative / CC-ALF control,
@@ -311,7 +338,7 @@ def alf(W, H, depth, qp, frames, t0, kind):
                 f.write(p.astype(px).tobytes())
     out = f"/tmp/gold_alf_{tag}"
     subprocess.check_call([os.path.join(ROOT, "tools/refcheck/ctu_dump.sh"), str(depth), yuv, str(W), str(H), str(frames), out,
-                           "preset", "medium", "period", "1", "qp", str(qp), "alf", "full"], stderr=subprocess.DEVNULL)
+                           "preset", "medium", "period", "1", "qp", str(qp), "alf", "full", "threads", str(threads)], stderr=subprocess.DEVNULL)
     A = sorted([r for n, r in read_records(out + ".bin") if n == "alf"], key=lambda r: int(r[0][0]))
     assert len(A) == frames
     planes = lambda k: [np.stack([a[k + c].reshape(H >> (c > 0), W >> (c > 0)) for a in A]) for c in range(3)]
@@ -372,8 +399,11 @@ if __name__ == "__main__":
     inter_crcs(1920, 1080, 10, 32, 3)    # ... and at 10 bit
     inter_crcs(3840, 2160, 10, 27, 3)    # ... and at the size / depth of configs[3]
     alf(320, 192, 10, 27, 3, 7, 2)       # --alf full: new filters, chroma alternatives, CC-ALF with per-CTU controls
-    alf(192, 128, 8, 27, 3, 0, 1)        # ... a picture left alone, one on a new APS, one on the fixed filter sets only
+    alf(192, 128, 8, 27, 3, 0, 1, threads=0)    # ... a picture left alone, one on a new APS, one on the fixed filter sets only (the job order of a run without
+                                                # threads leads to other decisions than the threaded flow; the process itself is the same function of its inputs)
     alf(192, 128, 10, 23, 2, 30, 1)      # ... 10 bit where the activity shift matters (cfg.input_bitdepth + 4, alf.c:5185: the runs leave it at 8 + 4)
+    full(320, 192, 10, 27, t=2007, picture=helpers_varied(), alf=True)        # whole pictures of --alf full runs with everything the coder and the NAL writer need
+    full(192, 128, 8, 22, t=1001, picture=helpers_varied(), alf=True)
     merge(136, 72, 10, 27, 8, 2)
     inter(192, 128, 8, 32, 5, extra=("sao", "off"), suffix="_nosao", with_levels=False)        # final picture = the deblocked picture
     inter(136, 72, 10, 22, 4, extra=("sao", "off"), suffix="_nosao", with_levels=False)
