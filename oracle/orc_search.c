@@ -1757,13 +1757,79 @@ static void encode_sao_color(sao_models2 *m, const int32_t *info, int color)
   }
 }
 
+/* ---- the CTU-level ALF syntax: uvg_encode_alf_bits (alf.c:1365-1413) between a CTU's SAO syntax and its coding tree (encoderstate.c:880) ----
+ * models: alf_ctb_flag [9] (component * 3 + enabled neighbours), the "APS, not a fixed set" flag, the chroma alternatives [2], the CC-ALF control [6] */
+typedef struct { uint16_t s0[18], s1[18]; uint8_t rate[18]; } alf_models;
+static void alf_models_init(alf_models *m, int qp)
+{
+  for (int i = 0; i < 18; ++i) {
+    const int v = k_ctx_init_alf[2][i];
+    const int slope = (v >> 3) - 4, offset = ((v & 7) * 18) + 1;
+    int s = ((slope * (qp - 16)) >> 1) + offset;
+    s = s < 1 ? 1 : (s > 127 ? 127 : s);
+    m->s0[i] = (uint16_t)((s << 8) & 0x7fe0); m->s1[i] = (uint16_t)((s << 8) & 0x7ffe);
+    m->rate[i] = k_ctx_init_alf[3][i];
+  }
+}
+static void alf_bin(alf_models *m, int c, int bin)
+{
+  ORC_FN(cabac_sim_bin)((m->s0[c] + m->s1[c]) >> 8, bin);
+  const int r0 = m->rate[c] >> 4, r1 = m->rate[c] & 15;
+  m->s0[c] = (uint16_t)(m->s0[c] - ((m->s0[c] >> r0) & 0x7fe0u));
+  m->s1[c] = (uint16_t)(m->s1[c] - ((m->s1[c] >> r1) & 0x7ffeu));
+  if (bin) { m->s0[c] = (uint16_t)(m->s0[c] + ((0x7fffu >> r0) & 0x7fe0u)); m->s1[c] = (uint16_t)(m->s1[c] + ((0x7fffu >> r1) & 0x7ffeu)); }
+}
+static void trunc_bin_ep(unsigned symbol, unsigned max_value)                     /* uvg_cabac_encode_trunc_bin (cabac.c:203-229), max_value <= 256 */
+{
+  int thresh = 0;
+  while ((2u << thresh) <= max_value) ++thresh;                                  /* uvg_tb_max: floor(log2(max_value)) */
+  const unsigned val = 1u << thresh, b = max_value - val;
+  if (symbol < val - b) ORC_FN(cabac_sim_eps)(symbol, thresh);
+  else ORC_FN(cabac_sim_eps)(symbol + val - b, thresh + 1);
+}
+/* meta: the "alf" record's header (ctu_dump.c): [3] alf_type, [4..6] slice enable Y / Cb / Cr, [7] luma APSs, [17..18] CC-ALF on, [19..20] CC-ALF filters;
+ * flags [7][n]: CTU enable Y / Cb / Cr, alternative Cb / Cr, CC-ALF control Cb / Cr; n_alts: num_alternatives_chroma of the slice's chroma APS */
+static void encode_alf_ctu(alf_models *m, const int32_t *meta, const uint8_t *flags, const int16_t *set_idx, int n_alts, int k, int wc, int n)
+{
+  const int left = k % wc ? k - 1 : -1, above = k >= wc ? k - wc : -1;
+  for (int c = 0; c < 3; ++c) {
+    const uint8_t *en = flags + (size_t)c * n;
+    if (meta[4 + c]) alf_bin(m, c * 3 + (left >= 0 && en[left]) + (above >= 0 && en[above]), en[k]);      /* code_alf_ctu_enable_flag (:1147) */
+    if (c == 0) {
+      if (en[k] && meta[4]) {                                                    /* code_alf_ctu_filter_index (:1209) */
+        const unsigned set = (unsigned)set_idx[k], n_aps = (unsigned)meta[7];
+        if (n_aps > 0) {
+          alf_bin(m, 9, set >= 16);
+          if (set >= 16) { if (n_aps > 1) trunc_bin_ep(set - 16, n_aps); }
+          else trunc_bin_ep(set, 16);
+        } else trunc_bin_ep(set, 16);
+      }
+    } else if (meta[4 + c] && en[k]) {                                           /* code_alf_ctu_alternative_ctu (:1255) */
+      const int ones = flags[(size_t)(2 + c) * n + k];
+      for (int i = 0; i < ones; ++i) alf_bin(m, 10 + c - 1, 1);
+      if (ones < n_alts - 1) alf_bin(m, 10 + c - 1, 0);
+    }
+  }
+  if (meta[3] == 2)
+    for (int c = 0; c < 2; ++c) {
+      if (!meta[17 + c]) continue;                                                /* code_cc_alf_filter_control_idc (:1321) */
+      const uint8_t *ctl = flags + (size_t)(5 + c) * n;
+      const int idc = ctl[k], count = meta[19 + c];
+      alf_bin(m, 12 + (left >= 0 && ctl[left]) + (above >= 0 && ctl[above]) + 3 * c, idc != 0);
+      if (idc > 0) {
+        for (int v = idc - 1; v > 0; --v) ORC_FN(cabac_sim_ep)(1);
+        if (idc < count) ORC_FN(cabac_sim_ep)(0);
+      }
+    }
+}
+
 /*
  * sao: per CTU the two sao_info_t (34 ints; NULL = SAO off).  Out: every row's substream, emulation prevention applied
  * (uvg_bitstream_put_byte, bitstream.c:215-226), rows concatenated, row_off[rows + 1]; after[ctu] (optional): the models when the
  * CTU is coded.  The slice data of the picture is exactly these bytes.
  */
-ORC_EXPORT long ORC_FN(encode_picture_rows)(const orc_search_params *p, const uint8_t *cu, const int16_t *coeff, const int32_t *sao,
-                                            uint8_t *bytes_out, long bytes_cap, int64_t *row_off, orc_models_ext *after)
+static long encode_rows_impl(const orc_search_params *p, const uint8_t *cu, const int16_t *coeff, const int32_t *sao, const int32_t *alf_meta, const uint8_t *alf_flags,
+                             const int16_t *alf_set_idx, int alf_n_alts, uint8_t *bytes_out, long bytes_cap, int64_t *row_off, orc_models_ext *after)
 {
   fbits_init();
   const int W = p->pic_w, H = p->pic_h, wc = (W + 63) / 64, hc = (H + 63) / 64, cu_stride = wc * 16;
@@ -1781,13 +1847,15 @@ ORC_EXPORT long ORC_FN(encode_picture_rows)(const orc_search_params *p, const ui
   orc_cabac_sim *sim = &ORC_FN(cabac_sim);
   orc_models *row_m = (orc_models *)calloc((size_t)hc, sizeof(orc_models));
   sao_models2 *row_s = (sao_models2 *)calloc((size_t)hc, sizeof(sao_models2));
+  alf_models *row_a = (alf_models *)calloc((size_t)hc, sizeof(alf_models));
   long total = 0;
   row_off[0] = 0;
   for (int cy = 0; cy < hc; ++cy) {
     s_cabac cb;
     sao_models2 sm;
-    if (cy == 0) { models_init(&cb.m, p->qp, 2); sao_models2_init(&sm, p->qp); }
-    else { cb.m = row_m[cy - 1]; sm = row_s[cy - 1]; }
+    alf_models am;
+    if (cy == 0) { models_init(&cb.m, p->qp, 2); sao_models2_init(&sm, p->qp); alf_models_init(&am, p->qp); }
+    else { cb.m = row_m[cy - 1]; sm = row_s[cy - 1]; am = row_a[cy - 1]; }
     cb.update = 1;
     sim->on = 2; sim->shifts = 0; sim->regular_fbits = 0.0;
     ORC_FN(cabac_sim_start)();
@@ -1799,6 +1867,7 @@ ORC_EXPORT long ORC_FN(encode_picture_rows)(const orc_search_params *p, const ui
         if (cy > 0 && !l[3]) sao_bin(&sm, 0, l[4]);
         if (!l[3] && !l[4]) { encode_sao_color(&sm, l, 0); encode_sao_color(&sm, c, 1); encode_sao_color(&sm, c, 2); }
       }
+      if (alf_meta) encode_alf_ctu(&am, alf_meta, alf_flags, alf_set_idx, alf_n_alts, k, wc, wc * hc);
       const int16_t *co = &coeff[(size_t)k * 6144];
       s_loc start_loc;
       loc_ctor(&start_loc, cx * 64, cy * 64, 64, 64);
@@ -1806,7 +1875,7 @@ ORC_EXPORT long ORC_FN(encode_picture_rows)(const orc_search_params *p, const ui
       g_tree_bits = 0.0;
       encode_coding_tree(&f, st, &cb, co, co + 4096, co + 4096 + 1024, &start_loc, &start_loc, tree, 1);
       if (after) models_to_ext(&cb.m, &after[k], NULL);
-      if (cx == 0) { row_m[cy] = cb.m; row_s[cy] = sm; }                      /* the next row's start (encoderstate.c:966-975) */
+      if (cx == 0) { row_m[cy] = cb.m; row_s[cy] = sm; row_a[cy] = am; }                      /* the next row's start (encoderstate.c:966-975) */
     }
     ORC_FN(cabac_sim_row_end)();
     sim->on = 0;
@@ -1820,11 +1889,22 @@ ORC_EXPORT long ORC_FN(encode_picture_rows)(const orc_search_params *p, const ui
     }
     row_off[cy + 1] = total;
   }
-  free(f.cua); free(st); free(row_m); free(row_s);
+  free(f.cua); free(st); free(row_m); free(row_s); free(row_a);
   return total;
 fail:
-  free(f.cua); free(st); free(row_m); free(row_s);
+  free(f.cua); free(st); free(row_m); free(row_s); free(row_a);
   return -1;
+}
+ORC_EXPORT long ORC_FN(encode_picture_rows)(const orc_search_params *p, const uint8_t *cu, const int16_t *coeff, const int32_t *sao,
+                                            uint8_t *bytes_out, long bytes_cap, int64_t *row_off, orc_models_ext *after)
+{
+  return encode_rows_impl(p, cu, coeff, sao, NULL, NULL, NULL, 0, bytes_out, bytes_cap, row_off, after);
+}
+/* ... of a picture of an --alf full / --alf on run: the CTU-level ALF syntax between SAO and the coding tree (see encode_alf_ctu for the arguments) */
+ORC_EXPORT long ORC_FN(encode_picture_rows_alf)(const orc_search_params *p, const uint8_t *cu, const int16_t *coeff, const int32_t *sao, const int32_t *alf_meta,
+                                                const uint8_t *alf_flags, const int16_t *alf_set_idx, int alf_n_alts, uint8_t *bytes_out, long bytes_cap, int64_t *row_off)
+{
+  return encode_rows_impl(p, cu, coeff, sao, alf_meta, alf_flags, alf_set_idx, alf_n_alts, bytes_out, bytes_cap, row_off, NULL);
 }
 
 /*
