@@ -1042,6 +1042,25 @@ UVGHIP_API int uvghip_write_picture_nals_pb(int poc, int poc_lsb_bits, int slice
                                             int qp_delta, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
                                             const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len);
 
+/* ... of a picture of an --alf on / --alf full all-intra stream: the ALF APS NAL units written in front of the slice
+ * (uvg_encode_alf_adaptive_parameter_set, src/alf.c:1610 -> encode_alf_aps :1575, encoder_state_write_adaptation_parameter_set :1547,
+ * encode_alf_aps_flags :1452, encode_alf_aps_filter :1415; called at src/encoder_state-bitstream.c:1562) and the slice header's ALF fields
+ * (:1283-1330).  HOST function.  aps[n_aps]: the parameter sets the encoder's map marks as changed for this picture, in aps id order.
+ *   uvghip_alf_slice_t: alf_type = cfg.alf_type (1 no CC-ALF, 2 full); enabled = tile_group_alf_enabled_flag; n_luma_aps / luma_aps_id =
+ *     tile_group_num_aps / tile_group_luma_aps_id; chroma_aps_id; cc_enabled = cc_filter_param->cc_alf_filter_enabled; cc_aps_id =
+ *     tile_group_cc_alf_cb_aps_id / _cr_aps_id
+ *   uvghip_alf_aps_t: the fields of alf_aps (alf.h:213-232) as coded: luma = luma_coeff[25][13], luma_clipp[25][13], filter_coeff_delta_idx[25]
+ *     (int16, 675 words); chroma = chroma_coeff[8][7], chroma_clipp[8][7] (112 words); cc = cc_alf_coeff[2][4][8] (64 words) */
+typedef struct uvghip_alf_slice {
+  int32_t alf_type, enabled[3], n_luma_aps, luma_aps_id[8], chroma_aps_id, cc_enabled[2], cc_aps_id[2];
+} uvghip_alf_slice_t;
+typedef struct uvghip_alf_aps {
+  int32_t aps_id, new_filter[2], non_linear[2], num_luma_filters, num_alternatives_chroma, new_cc_filter[2], cc_filter_count[2];
+  const int16_t *luma, *chroma, *cc;
+} uvghip_alf_aps_t;
+UVGHIP_API int uvghip_write_idr_nals_alf(int poc, int qp_delta, int sao, const uvghip_alf_slice_t *alf, const uvghip_alf_aps_t *aps, int n_aps, const uint8_t *rows,
+                                         size_t row_pitch, const int32_t *row_bytes, int n_rows, const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len);
+
 /* After uvghip_loop_plan_run: the NAL units (slice + hash SEI) of picture `picture` of the plan's group as picture number `poc` of the
  * stream, into HOST memory -- uvghip_picture_checksum on its output picture, its rows brought to the host, uvghip_write_picture_nals.
  * Waits for the stream.  *len = bytes needed; an error if that exceeds cap. */

@@ -48,3 +48,60 @@ def test_without_the_alf_syntax_the_rows_differ(orc):
     W, Hh, depth, qp = (int(a) for a in g["meta"][:4])
     data, off, _ = H.oracle_encode_rows(orc, depth, H.search_params(W, Hh, qp), dict(cu=g["cu"], trees=g["trees"], coeff=g["coeff"]), g["sao"])
     assert not np.array_equal(off, g["row_off"])
+
+
+def write_alf_picture_nals(L, g, rows, sizes, sums, poc=0):
+    from uvg266_amd import lib
+    m = g["alf_meta"]
+    S = lib.AlfSlice()
+    S.alf_type = int(m[3])
+    for c in range(3):
+        S.enabled[c] = int(m[4 + c])
+    S.n_luma_aps = int(m[7])
+    for i in range(8):
+        S.luma_aps_id[i] = int(m[9 + i])
+    S.chroma_aps_id = int(m[8])
+    for c in range(2):
+        S.cc_enabled[c] = int(m[17 + c]); S.cc_aps_id[c] = int(m[23 + c])
+    n_aps = len(g["aps_meta"])
+    A = (lib.AlfAps * max(n_aps, 1))()
+    keep = []
+    for i in range(n_aps):
+        a = g["aps_meta"][i]
+        A[i].aps_id = int(a[2])
+        for c in range(2):
+            A[i].new_filter[c] = int(a[4 + c]); A[i].non_linear[c] = int(a[6 + c]); A[i].new_cc_filter[c] = int(a[10 + c]); A[i].cc_filter_count[c] = int(a[12 + c])
+        A[i].num_luma_filters, A[i].num_alternatives_chroma = int(a[8]), int(a[9])
+        arrs = [np.ascontiguousarray(g[k][i], np.int16) for k in ("aps_luma", "aps_chroma", "aps_cc")]
+        keep.append(arrs)
+        A[i].luma, A[i].chroma, A[i].cc = (x.ctypes.data_as(ctypes.c_void_p) for x in arrs)
+    cap = int(sizes.sum()) + 4096
+    out = np.zeros(cap, np.uint8)
+    n = ctypes.c_size_t(0)
+    ck = np.ascontiguousarray(sums, np.uint32)
+    rc = L.uvghip_write_idr_nals_alf(poc, 0, 1, ctypes.byref(S), A, n_aps, H.ptr(rows), rows.shape[1], H.ptr(sizes), len(sizes), H.ptr(ck), H.ptr(out), cap, ctypes.byref(n))
+    assert rc == 0
+    return out[:n.value].tobytes()
+
+
+@pytest.mark.parametrize("name", ALF_GOLDENS)
+def test_whole_file_of_an_alf_run(orc, name):
+    """The encoder's parameter sets + what the library's host writer makes of the ALF decisions (APS NAL units, the slice header's ALF
+    fields, entry points), the rows of the coder and the checksum of the picture ALF left = the encoder's whole .266."""
+    from uvg266_amd import lib
+    from test_picture_nal import golden_rows
+    L = lib.load_library()            # host function: no device
+    g = H.ctu_golden(name)
+    depth = int(g["meta"][2])
+    data, off = oracle_rows_alf(orc, g)
+    sizes = np.diff(off).astype(np.int32)
+    rows = np.zeros((len(sizes), int(sizes.max())), np.uint8)
+    for r in range(len(sizes)):
+        rows[r, :sizes[r]] = data[off[r]:off[r + 1]]
+    sums = [H.picture_checksum(g[k], depth) for k in ("final_y", "final_u", "final_v")]
+    nals = write_alf_picture_nals(L, g, rows, sizes, sums)
+    stream = g["bitstream"].tobytes()
+    at = stream.find(b"\x00\x00\x01\x00\x89")              # the first APS NAL unit (type 17) behind the parameter sets
+    assert at > 0 and len(g["aps_meta"]) >= 1
+    assert stream[at:] == nals, (len(stream) - at, len(nals))
+    assert stream[:at] + nals == stream

@@ -69,7 +69,70 @@ struct nal_writer {
   }
 };
 
-enum { NAL_TRAIL = 0, NAL_IDR_W_RADL = 7, NAL_IDR_N_LP = 8, NAL_SUFFIX_SEI = 24 };
+enum { NAL_TRAIL = 0, NAL_IDR_W_RADL = 7, NAL_IDR_N_LP = 8, NAL_PREFIX_APS = 17, NAL_SUFFIX_SEI = 24 };
+
+int ceil_log2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+int floor_log2(int v) { int l = 0; while ((2 << l) <= v) ++l; return l; }
+
+// encode_alf_aps_filter (alf.c:1415-1450): the coefficients of a filter set as ue(|c|) + sign, then two bits per clip index
+void write_alf_filters(nal_writer &w, const int16_t *coeff, const int16_t *clipp, int n_filters, int n_coeff, int non_linear)
+{
+  for (int f = 0; f < n_filters; ++f)
+    for (int i = 0; i < n_coeff - 1; ++i) {
+      const int c = coeff[f * 13 + i];
+      w.ue((uint32_t)(c < 0 ? -c : c));
+      if (c) w.bits(c < 0, 1);
+    }
+  if (non_linear)
+    for (int f = 0; f < n_filters; ++f)
+      for (int i = 0; i < n_coeff - 1; ++i) w.bits((uint32_t)clipp[f * 13 + i], 2);
+}
+
+// one ALF APS NAL unit: encoder_state_write_adaptation_parameter_set + encode_alf_aps_flags (alf.c:1547-1573, 1452-1545), 4:2:0
+void write_alf_aps(nal_writer &w, const uvghip_alf_aps_t &a, int alf_full, bool long_code)
+{
+  w.zeros = 0;
+  w.start(NAL_PREFIX_APS, long_code);
+  w.bits(0, 3);                      // aps_params_type: ALF
+  w.bits((uint32_t)a.aps_id, 5);     // adaptation_parameter_set_id
+  w.bits(1, 1);                      // aps_chroma_present_flag
+  w.bits(a.new_filter[0] != 0, 1);   // alf_luma_new_filter
+  w.bits(a.new_filter[1] != 0, 1);   // alf_chroma_new_filter
+  w.bits(alf_full && a.new_cc_filter[0], 1);      // alf_cc_cb_filter_signal_flag
+  w.bits(alf_full && a.new_cc_filter[1], 1);      // alf_cc_cr_filter_signal_flag
+  if (a.new_filter[0]) {
+    w.bits(a.non_linear[0] != 0, 1);              // alf_luma_clip
+    w.ue((uint32_t)a.num_luma_filters - 1);
+    if (a.num_luma_filters > 1) {
+      const int length = ceil_log2(a.num_luma_filters);
+      for (int i = 0; i < 25; ++i) w.bits((uint32_t)a.luma[2 * 325 + i], length);          // alf_luma_coeff_delta_idx
+    }
+    write_alf_filters(w, a.luma, a.luma + 325, a.num_luma_filters, 13, a.non_linear[0]);
+  }
+  if (a.new_filter[1]) {
+    w.bits(a.non_linear[1] != 0, 1);
+    w.ue((uint32_t)a.num_alternatives_chroma - 1);
+    for (int t = 0; t < a.num_alternatives_chroma; ++t) {
+      // (the chroma arrays are [alternative][7]: one "filter" of seven at a time)
+      const int16_t *co = a.chroma + t * 7, *cl = a.chroma + (8 + t) * 7;
+      for (int i = 0; i < 6; ++i) { const int c = co[i]; w.ue((uint32_t)(c < 0 ? -c : c)); if (c) w.bits(c < 0, 1); }
+      if (a.non_linear[1]) for (int i = 0; i < 6; ++i) w.bits((uint32_t)cl[i], 2);
+    }
+  }
+  if (alf_full)
+    for (int c = 0; c < 2; ++c) {
+      if (!a.new_cc_filter[c]) continue;
+      w.ue((uint32_t)a.cc_filter_count[c] - 1);
+      for (int f = 0; f < a.cc_filter_count[c]; ++f)
+        for (int i = 0; i < 7; ++i) {
+          const int v = a.cc[(c * 4 + f) * 8 + i];
+          if (v == 0) w.bits(0, 3);
+          else { w.bits((uint32_t)(1 + floor_log2(v < 0 ? -v : v)), 3); w.bits(v < 0, 1); }
+        }
+    }
+  w.bits(0, 1);                      // aps_extension_flag
+  w.align_with_one();                // rbsp_trailing_bits
+}
 
 // entry points, byte alignment, the rows' substreams, then the decoded picture hash SEI (shared by both writers)
 void finish_picture(nal_writer &w, uint8_t *out, size_t cap, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows, int32_t longest,
@@ -157,6 +220,58 @@ extern "C" int uvghip_write_idr_nals(int poc, int qp_delta, int sao, const uint8
   finish_picture(w, out, cap, rows, row_pitch, row_bytes, n_rows, longest, checksum);
   *len = w.n;
   if (w.n > cap) return uvghip_set_error(hipErrorInvalidValue, "uvghip_write_picture_nals: the output buffer is too small (see *len)");
+  return 0;
+}
+
+// ... of an --alf on / --alf full stream: the APS NAL units the picture is preceded by (uvg_encode_alf_adaptive_parameter_set, alf.c:1610; written
+// between the parameter sets / the start of the access unit and the slice, encoder_state-bitstream.c:1562) and the slice header's ALF
+// fields (:1283-1330).  Host function.
+extern "C" int uvghip_write_idr_nals_alf(int poc, int qp_delta, int sao, const uvghip_alf_slice_t *alf, const uvghip_alf_aps_t *aps, int n_aps, const uint8_t *rows,
+                                         size_t row_pitch, const int32_t *row_bytes, int n_rows, const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len)
+{
+  if (!rows || !row_bytes || n_rows <= 0 || !len || (!out && cap) || poc < 0 || !alf || n_aps < 0 || (n_aps && !aps) || (alf->alf_type != 1 && alf->alf_type != 2) ||
+      alf->n_luma_aps < 0 || alf->n_luma_aps > 7)
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  for (int i = 0; i < n_aps; ++i)
+    if (aps[i].aps_id < 0 || aps[i].aps_id > 7 || (aps[i].new_filter[0] && (!aps[i].luma || aps[i].num_luma_filters < 1 || aps[i].num_luma_filters > 25)) ||
+        (aps[i].new_filter[1] && (!aps[i].chroma || aps[i].num_alternatives_chroma < 1 || aps[i].num_alternatives_chroma > 8)) ||
+        ((aps[i].new_cc_filter[0] || aps[i].new_cc_filter[1]) && !aps[i].cc) || aps[i].cc_filter_count[0] > 4 || aps[i].cc_filter_count[1] > 4)
+      return uvghip_set_error(hipErrorInvalidValue, "uvghip_write_idr_nals_alf: a parameter set");
+  int32_t longest = 0;
+  for (int r = 0; r < n_rows; ++r) {
+    if (row_bytes[r] <= 0 || (size_t)row_bytes[r] > row_pitch) return uvghip_set_error(hipErrorInvalidValue, "uvghip_write_idr_nals_alf: a row is empty or longer than its slot");
+    if (row_bytes[r] > longest) longest = row_bytes[r];
+  }
+  nal_writer w = {out, cap, 0, 0, 0, 0};
+  bool first_nal = poc != 0;         // picture 0 follows the parameter sets in its access unit; later pictures open theirs (long start code on the first NAL unit)
+  for (int i = 0; i < n_aps; ++i) { write_alf_aps(w, aps[i], alf->alf_type == 2, first_nal); first_nal = false; }
+  w.zeros = 0;
+  if (poc == 0) w.start(NAL_IDR_N_LP); else w.start(NAL_IDR_W_RADL, first_nal);
+  w.bits(1, 1);                      // sh_picture_header_in_slice_header_flag
+  w.bits(1, 1);                      // ph_gdr_or_irap_pic_flag
+  w.bits(0, 1);                      // ph_non_ref_pic_flag
+  w.bits(0, 1);                      // ph_gdr_pic_flag
+  w.bits(0, 1);                      // ph_inter_slice_allowed_flag
+  w.ue(0);                           // ph_pic_parameter_set_id
+  w.bits((uint32_t)poc & 15u, 4);    // ph_pic_order_cnt_lsb
+  w.bits(0, 1);                      // sh_no_output_of_prior_pics_flag
+  w.bits(alf->enabled[0] != 0, 1);   // slice_alf_enabled_flag
+  if (alf->enabled[0]) {
+    w.bits((uint32_t)alf->n_luma_aps, 3);
+    for (int i = 0; i < alf->n_luma_aps; ++i) w.bits((uint32_t)alf->luma_aps_id[i], 3);
+    w.bits(alf->enabled[1] != 0, 1); w.bits(alf->enabled[2] != 0, 1);
+    if (alf->enabled[1] || alf->enabled[2]) w.bits((uint32_t)alf->chroma_aps_id, 3);
+    if (alf->alf_type == 2)
+      for (int c = 0; c < 2; ++c) {
+        w.bits(alf->cc_enabled[c] != 0, 1);
+        if (alf->cc_enabled[c]) w.bits((uint32_t)alf->cc_aps_id[c], 3);
+      }
+  }
+  w.se(qp_delta);                    // sh_qp_delta
+  if (sao) w.bits(3, 2);             // sh_sao_luma_used_flag, sh_sao_chroma_used_flag
+  finish_picture(w, out, cap, rows, row_pitch, row_bytes, n_rows, longest, checksum);
+  *len = w.n;
+  if (w.n > cap) return uvghip_set_error(hipErrorInvalidValue, "uvghip_write_idr_nals_alf: the output buffer is too small (see *len)");
   return 0;
 }
 

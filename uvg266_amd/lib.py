@@ -106,6 +106,19 @@ class AlfPicture(ctypes.Structure):
                 ("alf_full", ctypes.c_int32), ("cc_alf_enabled", ctypes.c_int32 * 2), ("cc_coeff", ctypes.c_void_p), ("classification_shift", ctypes.c_int32)]
 
 
+class AlfSlice(ctypes.Structure):
+    """uvghip_alf_slice_t."""
+    _fields_ = [("alf_type", ctypes.c_int32), ("enabled", ctypes.c_int32 * 3), ("n_luma_aps", ctypes.c_int32), ("luma_aps_id", ctypes.c_int32 * 8),
+                ("chroma_aps_id", ctypes.c_int32), ("cc_enabled", ctypes.c_int32 * 2), ("cc_aps_id", ctypes.c_int32 * 2)]
+
+
+class AlfAps(ctypes.Structure):
+    """uvghip_alf_aps_t."""
+    _fields_ = [("aps_id", ctypes.c_int32), ("new_filter", ctypes.c_int32 * 2), ("non_linear", ctypes.c_int32 * 2), ("num_luma_filters", ctypes.c_int32),
+                ("num_alternatives_chroma", ctypes.c_int32), ("new_cc_filter", ctypes.c_int32 * 2), ("cc_filter_count", ctypes.c_int32 * 2),
+                ("luma", ctypes.c_void_p), ("chroma", ctypes.c_void_p), ("cc", ctypes.c_void_p)]
+
+
 class MeJob(ctypes.Structure):
     """uvghip_me_job_t."""
     _fields_ = [("x", ctypes.c_int32), ("y", ctypes.c_int32), ("ref", ctypes.c_int32), ("mv_cand", (ctypes.c_int32 * 2) * 2), ("extra_mv", ctypes.c_int32 * 2),
@@ -200,6 +213,7 @@ SIGNATURES = {
     "uvghip_deblock_band": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp,
                                     c_int, c_int, c_int, c_vp]),
     "uvghip_cc_alf_filter_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_write_idr_nals_alf": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, ctypes.c_size_t, c_vp, c_int, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "uvghip_cc_alf_stats_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_alf_expand_tables": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_alf_reconstruct_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
