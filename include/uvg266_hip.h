@@ -1008,6 +1008,24 @@ UVGHIP_API int uvghip_encode_slice_rows_pb(int bitdepth, const uvghip_ctu_params
                                            const uvghip_slice_pb_t *pb, int n_pictures, const int32_t *sao_info, const uint16_t *sao_models,
                                            void *workspace, uint8_t *out, int row_cap, int32_t *row_bytes, void *stream);
 
+/* uvghip_encode_slice_rows for all-intra pictures of an --alf on / --alf full run: the CTU-level ALF syntax (uvg_encode_alf_bits,
+ * src/alf.c:1365-1413, called at src/encoderstate.c:880) between a CTU's SAO syntax and its coding tree -- alf_ctb_flag per component by the
+ * neighbours' flags, the APS / fixed filter set choice and its truncated-binary index, the chroma alternative, the CC-ALF control.  The 18
+ * models of that syntax follow the WPP hand-over like the others; a row's coder derives its start from the first CTUs of the rows above.
+ *   alf[n_pictures] (HOST array; ctu_flags / filter_set_idx are DEVICE memory in the layout of uvghip_alf_picture_t): alf_type = cfg.alf_type
+ *   (1 / 2), enabled = tile_group_alf_enabled_flag, n_luma_aps = tile_group_num_aps, n_alternatives_chroma of the slice's chroma APS,
+ *   cc_enabled / cc_filter_count = cc_filter_param->cc_alf_filter_enabled / _count.
+ * workspace: uvghip_slice_rows_alf_workspace_bytes(n_pictures). */
+typedef struct uvghip_slice_alf {
+  int32_t alf_type, enabled[3], n_luma_aps, n_alternatives_chroma, cc_enabled[2], cc_filter_count[2];
+  const uint8_t *ctu_flags;
+  const int16_t *filter_set_idx;
+} uvghip_slice_alf_t;
+UVGHIP_API size_t uvghip_slice_rows_alf_workspace_bytes(int n_pictures);
+UVGHIP_API int uvghip_encode_slice_rows_alf(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, const uvghip_slice_alf_t *alf,
+                                            int n_pictures, const int32_t *sao_info, const uint16_t *sao_models, void *workspace, uint8_t *out, int row_cap,
+                                            int32_t *row_bytes, void *stream);
+
 /* ------------------- (7) the picture's NAL units behind the parameter sets -------------------------------------------- */
 
 /* replaces: uvg_image_checksum / array_checksum_generic (src/nal.c:91-115, src/strategies/generic/nal-generic.c:68-92) on the

@@ -65,3 +65,31 @@ def test_against_the_oracle_on_a_partial_ctu_picture(hip, orc):
         torch.cuda.synchronize()
         for o, w_, k in zip(out, want, "yuv"):
             assert np.array_equal(o.cpu().numpy(), w_), (depth, k)
+
+
+@pytest.mark.parametrize("name", ["ref_ctu_320x192_10_qp27_alf", "ref_ctu_192x128_8_qp22_alf"])
+def test_slice_data_with_the_alf_syntax_equals_the_encoders(hip, name):
+    """uvghip_encode_slice_rows_alf: the device's own search + filters of the golden's source (ALF does not change them), then the arithmetic
+    coder with the CTU-level ALF syntax from the encoder's recorded decisions -> the slice data of the encoder's --alf full .266."""
+    import torch
+    from uvg266_amd import api
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    prm = H.search_params(W, Hh, qp)
+    cl = api.ClosedLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in (y, u, v))])
+    cl.run()
+    m = g["alf_meta"]
+    alf = dict(alf_type=m[3], enabled=m[4:7], n_luma_aps=m[7], n_alternatives_chroma=g["alf_chroma_aps"][112], cc_enabled=m[17:19], cc_filter_count=m[19:21],
+               ctu_flags=g["alf_flags"], filter_set_idx=g["alf_set_idx"])
+    out, nbytes = cl.encode_rows_alf([alf])
+    nb = nbytes.cpu().numpy()[0]
+    assert np.array_equal(np.concatenate([[0], np.cumsum(nb)]), g["row_off"])
+    data = np.concatenate([out[0, r, :nb[r]].cpu().numpy() for r in range(len(nb))])
+    assert np.array_equal(data, g["row_bytes"])
+    # ... and the plain coder on the same picture is unchanged by the ALF code in the kernel: its rows are the oracle's / the other tests' business,
+    # here only that they differ from the ALF rows (the bins are really written)
+    out2, nb2 = cl.encode_rows()
+    torch.cuda.synchronize()
+    nb2 = nb2.cpu().numpy()[0]
+    plain = np.concatenate([out2[0, r, :nb2[r]].cpu().numpy() for r in range(len(nb2))])
+    assert len(plain) != len(data) or not np.array_equal(plain, data)

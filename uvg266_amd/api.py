@@ -759,6 +759,34 @@ class ClosedLoop(CtuSearch):
                                                    _stream() if stream is None else stream), "uvghip_encode_slice_rows")
         return out, nbytes
 
+    def encode_rows_alf(self, alf, row_cap=None, stream=None):
+        """uvghip_encode_slice_rows_alf on the plan's pictures (after run()): the slice data with the CTU-level ALF syntax.  alf: per picture a dict
+        with alf_type, enabled (3), n_luma_aps, n_alternatives_chroma, cc_enabled (2), cc_filter_count (2), ctu_flags (u8 [7][ctus]) and
+        filter_set_idx (i16 [ctus]) as numpy arrays.  -> (out, row_bytes) like encode_rows."""
+        W, H = self.P.pic_w, self.P.pic_h
+        row_cap = 3 * 64 * W if row_cap is None else row_cap
+        dev = self.loop_ws.device
+        out = torch.empty((self.n, self.hc, row_cap), dtype=torch.uint8, device=dev)
+        nbytes = torch.zeros((self.n, self.hc), dtype=torch.int32, device=dev)
+        ws = torch.empty(self.L.uvghip_slice_rows_alf_workspace_bytes(self.n), dtype=torch.uint8, device=dev)
+        info, models = self.sao_device()
+        A = (_lib.SliceAlf * self.n)()
+        keep = []
+        for i, a in enumerate(alf):
+            A[i].alf_type, A[i].n_luma_aps, A[i].n_alternatives_chroma = int(a["alf_type"]), int(a["n_luma_aps"]), int(a["n_alternatives_chroma"])
+            for c in range(3):
+                A[i].enabled[c] = int(a["enabled"][c])
+            for c in range(2):
+                A[i].cc_enabled[c] = int(a["cc_enabled"][c]); A[i].cc_filter_count[c] = int(a["cc_filter_count"][c])
+            fl = torch.from_numpy(np.ascontiguousarray(a["ctu_flags"], np.uint8)).to(dev)
+            si = torch.from_numpy(np.ascontiguousarray(a["filter_set_idx"], np.int16)).to(dev)
+            keep += [fl, si]
+            A[i].ctu_flags, A[i].filter_set_idx = _dev(fl), _dev(si)
+        _lib.check(self.L.uvghip_encode_slice_rows_alf(self.depth, ctypes.byref(self.P), self.pics, A, self.n, _dev(info), _dev(models), _dev(ws), _dev(out), row_cap,
+                                                       _dev(nbytes), _stream() if stream is None else stream), "uvghip_encode_slice_rows_alf")
+        torch.cuda.synchronize()          # (the decisions' device copies go out of scope with this call)
+        return out, nbytes
+
     def __del__(self):
         loop, self.loop = getattr(self, "loop", None), None
         if loop:

@@ -23,9 +23,14 @@ using namespace ctu;
 enum { NM_INTER = 18, MI = NMODELS + 2, MI_SKIP = MI + 0, MI_PRED_MODE = MI + 3, MI_MERGE_FLAG = MI + 5, MI_MERGE_IDX = MI + 6, MI_INTER_DIR = MI + 7,
        MI_REF_PIC = MI + 13, MI_MVD = MI + 15, MI_MVP_IDX = MI + 17, M_ROOT_CBF_ = 243 };
 
+// the 18 models of the CTU-level ALF syntax behind those (alf_ctb_flag [9], the APS / fixed set switch, chroma alternatives [2], CC-ALF control [6])
+enum { NM_ALF = 18, MA = NMODELS + 2 + NM_INTER };
+// one picture's ALF decisions as the coder needs them (uvghip_slice_alf_t with device pointers)
+struct alf_dev { int32_t alf_type, enabled[3], n_luma_aps, cc_enabled[2], cc_count[2], n_alts; const uint8_t *flags; const int16_t *set_idx; };
+
 struct row_state {
-  uint32_t models[NMODELS + 2 + NM_INTER];   // state0 | state1 << 16; [NMODELS] sao_merge_flag, [NMODELS + 1] sao_type_idx, then the inter syntax
-  uint8_t rate[NMODELS + 2 + NM_INTER];
+  uint32_t models[NMODELS + 2 + NM_INTER + NM_ALF];   // state0 | state1 << 16; [NMODELS] sao_merge_flag, [NMODELS + 1] sao_type_idx, the inter syntax, the ALF syntax
+  uint8_t rate[NMODELS + 2 + NM_INTER + NM_ALF];
   uint16_t scan[1360];                 // diagonal scans of 32, 16, 8, 4 (scan_base)
   int16_t lv[1024];                    // the levels of the transform block being coded, raster
   struct cui { uint8_t type, log2w, cbf, mode, mode_c, skipped, pad[2]; } cu[17 * 17];      // the CTU's side information + the row / column before it
@@ -101,6 +106,16 @@ __device__ __forceinline__ void enc_bin(coder &c, row_state *R, int idx, int bin
     c.low <<= 1; c.range <<= 1; c.bits_left--;
     if (c.bits_left < 12) cwrite(c);
   }
+  const int r0 = R->rate[idx] >> 4, r1 = R->rate[idx] & 15;
+  s0 -= (s0 >> r0) & 0x7fe0u;
+  s1 -= (s1 >> r1) & 0x7ffeu;
+  if (bin) { s0 += (0x7fffu >> r0) & 0x7fe0u; s1 += (0x7fffu >> r1) & 0x7ffeu; }
+  R->models[idx] = (s0 & 0xffffu) | (s1 << 16);
+}
+__device__ inline void ctx_update(row_state *R, int idx, int bin)          // CTX_UPDATE alone: a bin another row's coder sent through this model
+{
+  const uint32_t st = R->models[idx];
+  uint32_t s0 = st & 0xffffu, s1 = st >> 16;
   const int r0 = R->rate[idx] >> 4, r1 = R->rate[idx] & 15;
   s0 -= (s0 >> r0) & 0x7fe0u;
   s1 -= (s1 >> r1) & 0x7ffeu;
@@ -445,9 +460,54 @@ __device__ __forceinline__ void code_sao_color(coder &c, row_state *R, const int
 
 __device__ inline int z_to_xy(int z) { return (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4) | ((z >> 3) & 8); }
 
+// uvg_encode_alf_bits (src/alf.c:1365-1413) of CTU k, between its SAO syntax and its coding tree (encoderstate.c:880).  CODE = false: only the
+// models move -- what the first CTU of every row above did to them before this row's coder started (the WPP hand-over, encoderstate.c:966-975).
+template <bool CODE>
+__device__ inline void alf_ctu(coder &c, row_state *R, const alf_dev &A, int k, int wc, int n)
+{
+  auto bin = [&](int idx, int b) { if (CODE) enc_bin(c, R, idx, b); else ctx_update(R, idx, b); };
+  const int left = k % wc ? k - 1 : -1, above = k >= wc ? k - wc : -1;
+  for (int comp = 0; comp < 3; ++comp) {
+    const uint8_t *en = A.flags + (size_t)comp * n;
+    if (A.enabled[comp]) bin(MA + comp * 3 + (left >= 0 && en[left]) + (above >= 0 && en[above]), en[k]);      // code_alf_ctu_enable_flag (:1147)
+    if (comp == 0) {
+      if (en[k] && A.enabled[0]) {                                             // code_alf_ctu_filter_index (:1209)
+        const unsigned set = (unsigned)A.set_idx[k], n_aps = (unsigned)A.n_luma_aps;
+        unsigned sym = set, max_v = 16;
+        bool coded = true;
+        if (n_aps > 0) {
+          bin(MA + 9, set >= 16);
+          if (set >= 16) { sym = set - 16; max_v = n_aps; coded = n_aps > 1; }
+        }
+        if (coded && CODE) {                                                   // uvg_cabac_encode_trunc_bin (cabac.c:203-229)
+          int thresh = 0;
+          while ((2u << thresh) <= max_v) ++thresh;
+          const unsigned val = 1u << thresh, b = max_v - val;
+          if (sym < val - b) enc_eps(c, sym, thresh); else enc_eps(c, sym + val - b, thresh + 1);
+        }
+      }
+    } else if (A.enabled[comp] && en[k]) {                                     // code_alf_ctu_alternative_ctu (:1255)
+      const int ones = A.flags[(size_t)(2 + comp) * n + k];
+      for (int i = 0; i < ones; ++i) bin(MA + 10 + comp - 1, 1);
+      if (ones < A.n_alts - 1) bin(MA + 10 + comp - 1, 0);
+    }
+  }
+  if (A.alf_type == 2)
+    for (int comp = 0; comp < 2; ++comp) {
+      if (!A.cc_enabled[comp]) continue;                                       // code_cc_alf_filter_control_idc (:1321)
+      const uint8_t *ctl = A.flags + (size_t)(5 + comp) * n;
+      const int idc = ctl[k];
+      bin(MA + 12 + (left >= 0 && ctl[left]) + (above >= 0 && ctl[above]) + 3 * comp, idc != 0);
+      if (idc > 0 && CODE) {
+        for (int v = idc - 1; v > 0; --v) enc_ep(c, 1);
+        if (idc < A.cc_count[comp]) enc_ep(c, 0);
+      }
+    }
+}
+
 __global__ void __launch_bounds__(64)
 slice_rows_kernel(const pic_dev *__restrict__ pics, const pb_dev *__restrict__ pbs, const int32_t *__restrict__ sao, const uint16_t *__restrict__ sao_models,
-                  int W, int H, int qp, int bitdepth, uint8_t *__restrict__ out, int row_cap, int32_t *__restrict__ row_bytes)
+                  int W, int H, int qp, int bitdepth, uint8_t *__restrict__ out, int row_cap, int32_t *__restrict__ row_bytes, const alf_dev *__restrict__ alfs = nullptr)
 {
   __shared__ row_state Rs;
   extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem[];          // row_state_pb for P / B pictures (none for I)
@@ -523,6 +583,19 @@ slice_rows_kernel(const pic_dev *__restrict__ pics, const pb_dev *__restrict__ p
   coder c;
   c.low = 0; c.range = 510; c.bits_left = 23; c.nbuf = 0; c.buffered = 0xff;       // uvg_cabac_start
   c.out = out + ((size_t)pic * hc + cy) * row_cap; c.n = 0; c.cap = row_cap; c.zeros = 0;
+  if (alfs && lane0) {
+    // the ALF models of this row's start: initialised for the slice, then what the first CTU of every row above sent through them
+    const alf_dev &A = alfs[pic];
+    for (int i = 0; i < NM_ALF; ++i) {
+      R->rate[MA + i] = k_ctx_init_alf[3][i];
+      const int v = k_ctx_init_alf[slice][i];
+      const int slope = (v >> 3) - 4, offset = ((v & 7) * 18) + 1;
+      int s = ((slope * (init_qp - 16)) >> 1) + offset;
+      s = s < 1 ? 1 : (s > 127 ? 127 : s);
+      R->models[MA + i] = (uint32_t)((s << 8) & 0x7fe0) | ((uint32_t)((s << 8) & 0x7ffe) << 16);
+    }
+    for (int r = 0; r < cy; ++r) alf_ctu<false>(c, R, A, r * wc, wc, wc * hc);
+  }
   const int max_off = (1 << ((bitdepth < 10 ? bitdepth : 10) - 5)) - 1;
   for (int cx = 0; cx < wc; ++cx) {
     const int k = cy * wc + cx, x0 = cx * 64, y0 = cy * 64;
@@ -557,6 +630,7 @@ slice_rows_kernel(const pic_dev *__restrict__ pics, const pb_dev *__restrict__ p
       if (cy > 0 && !l[3]) enc_bin(c, R, NMODELS, l[4]);
       if (!l[3] && !l[4]) { code_sao_color(c, R, l, 0, max_off); code_sao_color(c, R, ch, 1, max_off); code_sao_color(c, R, ch, 2, max_off); }
     }
+    if (lane0 && alfs) alf_ctu<true>(c, R, alfs[pic], k, wc, wc * hc);
     // uvg_encode_coding_tree: z-order over the 4x4 units; a CU starts where a unit is aligned to its CU's size
     for (int z = 0; z < 256; ++z) {
       const int lx = z_to_xy(z) * 4, ly = z_to_xy(z >> 1) * 4, x = x0 + lx, y = y0 + ly;
@@ -729,6 +803,10 @@ slice_rows_kernel(const pic_dev *__restrict__ pics, const pb_dev *__restrict__ p
 }  // namespace
 
 extern "C" size_t uvghip_slice_rows_workspace_bytes(int n_pictures) { return n_pictures > 0 ? (size_t)n_pictures * sizeof(pic_dev) : 0; }
+extern "C" size_t uvghip_slice_rows_alf_workspace_bytes(int n_pictures)
+{
+  return n_pictures > 0 ? ((size_t)n_pictures * sizeof(pic_dev) + 255) / 256 * 256 + (size_t)n_pictures * sizeof(alf_dev) : 0;
+}
 extern "C" size_t uvghip_slice_rows_pb_workspace_bytes(int n_pictures)
 {
   return n_pictures > 0 ? ((size_t)n_pictures * sizeof(pic_dev) + 255) / 256 * 256 + (size_t)n_pictures * sizeof(pb_dev) : 0;
@@ -765,6 +843,36 @@ extern "C" int uvghip_encode_slice_rows(int bitdepth, const uvghip_ctu_params_t 
   hipStream_t st = uvghip_stream(stream);
   slice_rows_kernel<<<n_pictures * hc, 64, 0, st>>>(static_cast<const pic_dev *>(workspace), nullptr, sao_info, sao_models, W, H, params->qp, bitdepth, out,
                                                     row_cap, row_bytes);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// ... of pictures of an --alf on / --alf full run: the CTU-level ALF syntax between a CTU's SAO syntax and its coding tree.
+extern "C" int uvghip_encode_slice_rows_alf(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, const uvghip_slice_alf_t *alf, int n_pictures,
+                                            const int32_t *sao_info, const uint16_t *sao_models, void *workspace, uint8_t *out, int row_cap, int32_t *row_bytes, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
+  if (!params || !pictures || !alf || n_pictures <= 0 || !workspace || !out || row_cap <= 0 || !row_bytes || (sao_info && !sao_models))
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const int W = params->pic_w, H = params->pic_h, hc = (H + 63) / 64;
+  if (W <= 0 || H <= 0 || (W & 7) || (H & 7) || params->qp < 0 || params->qp > 63) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (int rc = uvghip_slice_rows_prepare(params, pictures, n_pictures, workspace)) return rc;
+  std::vector<alf_dev> ad(n_pictures);
+  for (int i = 0; i < n_pictures; ++i) {
+    const uvghip_slice_alf_t &q = alf[i];
+    if ((q.alf_type != 1 && q.alf_type != 2) || q.n_luma_aps < 0 || q.n_luma_aps > 8 || q.n_alternatives_chroma < 0 || q.n_alternatives_chroma > 8 || q.cc_filter_count[0] > 4 ||
+        q.cc_filter_count[1] > 4 || ((q.enabled[0] || q.cc_enabled[0] || q.cc_enabled[1]) && (!q.ctu_flags || !q.filter_set_idx)))
+      return uvghip_set_error(hipErrorInvalidValue, "uvghip_encode_slice_rows_alf: slice descriptor");
+    alf_dev &d = ad[i];
+    d.alf_type = q.alf_type; d.n_luma_aps = q.n_luma_aps; d.n_alts = q.n_alternatives_chroma; d.flags = q.ctu_flags; d.set_idx = q.filter_set_idx;
+    for (int c = 0; c < 3; ++c) d.enabled[c] = q.enabled[c] != 0;
+    for (int c = 0; c < 2; ++c) { d.cc_enabled[c] = q.cc_enabled[c] != 0; d.cc_count[c] = q.cc_filter_count[c]; }
+  }
+  unsigned char *aw = static_cast<unsigned char *>(workspace) + ((size_t)n_pictures * sizeof(pic_dev) + 255) / 256 * 256;
+  UVGHIP_TRY(hipMemcpy(aw, ad.data(), ad.size() * sizeof(alf_dev), hipMemcpyHostToDevice));
+  hipStream_t st = uvghip_stream(stream);
+  slice_rows_kernel<<<n_pictures * hc, 64, 0, st>>>(static_cast<const pic_dev *>(workspace), nullptr, sao_info, sao_models, W, H, params->qp, bitdepth, out, row_cap, row_bytes,
+                                                    reinterpret_cast<const alf_dev *>(aw));
   UVGHIP_CHECK_LAUNCH();
 }
 

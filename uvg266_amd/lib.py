@@ -106,6 +106,12 @@ class AlfPicture(ctypes.Structure):
                 ("alf_full", ctypes.c_int32), ("cc_alf_enabled", ctypes.c_int32 * 2), ("cc_coeff", ctypes.c_void_p), ("classification_shift", ctypes.c_int32)]
 
 
+class SliceAlf(ctypes.Structure):
+    """uvghip_slice_alf_t."""
+    _fields_ = [("alf_type", ctypes.c_int32), ("enabled", ctypes.c_int32 * 3), ("n_luma_aps", ctypes.c_int32), ("n_alternatives_chroma", ctypes.c_int32),
+                ("cc_enabled", ctypes.c_int32 * 2), ("cc_filter_count", ctypes.c_int32 * 2), ("ctu_flags", ctypes.c_void_p), ("filter_set_idx", ctypes.c_void_p)]
+
+
 class AlfSlice(ctypes.Structure):
     """uvghip_alf_slice_t."""
     _fields_ = [("alf_type", ctypes.c_int32), ("enabled", ctypes.c_int32 * 3), ("n_luma_aps", ctypes.c_int32), ("luma_aps_id", ctypes.c_int32 * 8),
@@ -213,6 +219,8 @@ SIGNATURES = {
     "uvghip_deblock_band": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp,
                                     c_int, c_int, c_int, c_vp]),
     "uvghip_cc_alf_filter_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_slice_rows_alf_workspace_bytes": (ctypes.c_size_t, [c_int]),
+    "uvghip_encode_slice_rows_alf": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "uvghip_write_idr_nals_alf": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, ctypes.c_size_t, c_vp, c_int, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "uvghip_cc_alf_stats_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_alf_expand_tables": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
