@@ -105,3 +105,30 @@ def test_whole_file_of_an_alf_run(orc, name):
     assert at > 0 and len(g["aps_meta"]) >= 1
     assert stream[at:] == nals, (len(stream) - at, len(nals))
     assert stream[:at] + nals == stream
+
+
+@pytest.mark.parametrize("name", ALF_GOLDENS)
+def test_the_picture_behind_the_hash_is_the_one_alf_left(orc, name):
+    """The same goldens close the loop on the picture side: the picture uvg_alf_enc_process got (deblocked + SAO: what the closed loop's filters
+    produce) through the oracle's ALF reconstruction with the recorded decisions = the picture the encoder returned and hashed."""
+    import os
+    g = H.ctu_golden(name)
+    W, Hh, depth = (int(a) for a in g["meta"][:3])
+    px = H.px_dtype(depth)
+    pre = [np.ascontiguousarray(g[k], px) for k in ("alf_pre_y", "alf_pre_u", "alf_pre_v")]
+    out = [np.zeros_like(p) for p in pre]
+    fixed = np.ascontiguousarray(np.load(os.path.join(H.GOLDEN, "ref_alf_fixed.npy")), np.int16)
+    rc = orc.fn(depth, "alf_reconstruct_picture", ctypes.c_int)(*(H.ptr(p) for p in pre), W, Hh, *(H.ptr(o) for o in out), H.ptr(np.ascontiguousarray(g["alf_meta"], np.int32)),
+                                                                H.ptr(np.ascontiguousarray(g["alf_flags"], np.uint8)), H.ptr(np.ascontiguousarray(g["alf_set_idx"], np.int16)),
+                                                                H.ptr(np.ascontiguousarray(g["alf_luma_aps"], np.int16)), H.ptr(np.ascontiguousarray(g["alf_chroma_aps"], np.int16)),
+                                                                H.ptr(np.ascontiguousarray(g["alf_cc_coeff"], np.int16)), H.ptr(fixed))
+    assert rc == 0
+    for o, k in zip(out, ("final_y", "final_u", "final_v")):
+        assert np.array_equal(o, g[k]), k
+    # ... and what ALF got is what the oracle's search + filter chain produces from the source (ALF changes nothing before it)
+    _, _, _, qp, y, u, v = H.golden_source(g)
+    prm = H.search_params(W, Hh, qp)
+    s = H.oracle_search_picture(orc, depth, prm, y, u, v)
+    f = H.oracle_sao_picture(orc, depth, W, Hh, qp, prm.lam, (y, u, v), (s["rec_y"], s["rec_u"], s["rec_v"]), H.scu_from_cu(s["cu"], qp))
+    for k, p in zip(("final_y", "final_u", "final_v"), pre):
+        assert np.array_equal(f[k], p), ("pre-ALF", k)
