@@ -132,3 +132,49 @@ def test_the_picture_behind_the_hash_is_the_one_alf_left(orc, name):
     f = H.oracle_sao_picture(orc, depth, W, Hh, qp, prm.lam, (y, u, v), (s["rec_y"], s["rec_u"], s["rec_v"]), H.scu_from_cu(s["cu"], qp))
     for k, p in zip(("final_y", "final_u", "final_v"), pre):
         assert np.array_equal(f[k], p), ("pre-ALF", k)
+
+
+def test_whole_multi_picture_alf_stream_from_the_oracle_chain(orc):
+    """Four pictures of one -p 1 --alf full stream: per picture the oracle's chain on the source (search -> filters -> SAO), ALF reconstruction
+    and coder with the encoder's recorded decisions, the library's host writer for the APS NAL units, slice header and hash SEI -- parameter
+    sets of the encoder + these bytes = the encoder's file.  Later pictures open their access unit with the APS (long start code there, short
+    one on the slice), refer to APSs of earlier pictures and use fixed filter sets only."""
+    import os
+    import zlib
+    from uvg266_amd import lib
+    L = lib.load_library()
+    g = H.ctu_golden("ref_stream_192x128_8_qp27_4frames_alf")
+    W, Hh, depth, qp = (int(a) for a in g["meta"])
+    prm = H.search_params(W, Hh, qp)
+    px = H.px_dtype(depth)
+    fixed = np.ascontiguousarray(np.load(os.path.join(H.GOLDEN, "ref_alf_fixed.npy")), np.int16)
+    stream = g["bitstream"].tobytes()
+    mine = b""
+    seen_fixed_only = False
+    for poc, t in enumerate(g["ts"]):
+        y, u, v = H.varied_picture(W, Hh, int(t), depth)
+        assert zlib.crc32(y.tobytes() + u.tobytes() + v.tobytes()) == int(g["src_crc"][poc])
+        s = H.oracle_search_picture(orc, depth, prm, y, u, v)
+        f = H.oracle_sao_picture(orc, depth, W, Hh, qp, prm.lam, (y, u, v), (s["rec_y"], s["rec_u"], s["rec_v"]), H.scu_from_cu(s["cu"], qp))
+        pic = {k[4:]: g[k][poc] for k in ("alf_meta", "alf_flags", "alf_set_idx", "alf_luma_aps", "alf_chroma_aps", "alf_cc_coeff")}
+        seen_fixed_only |= bool(pic["meta"][4]) and int(pic["meta"][7]) == 0
+        pre = [np.ascontiguousarray(f[k], px) for k in ("final_y", "final_u", "final_v")]
+        post = [np.zeros_like(p) for p in pre]
+        rc = orc.fn(depth, "alf_reconstruct_picture", ctypes.c_int)(*(H.ptr(p) for p in pre), W, Hh, *(H.ptr(o) for o in post), H.ptr(np.ascontiguousarray(pic["meta"], np.int32)),
+                                                                    H.ptr(np.ascontiguousarray(pic["flags"], np.uint8)), H.ptr(np.ascontiguousarray(pic["set_idx"], np.int16)),
+                                                                    H.ptr(np.ascontiguousarray(pic["luma_aps"], np.int16)), H.ptr(np.ascontiguousarray(pic["chroma_aps"], np.int16)),
+                                                                    H.ptr(np.ascontiguousarray(pic["cc_coeff"], np.int16)), H.ptr(fixed))
+        assert rc == 0
+        sel = g["aps_meta"][:, 0] == poc
+        one = dict(meta=np.array([W, Hh, depth, qp]), cu=s["cu"], trees=s["trees"], coeff=s["coeff"], sao=f["sao"], alf_meta=pic["meta"], alf_flags=pic["flags"],
+                   alf_set_idx=pic["set_idx"], alf_chroma_aps=pic["chroma_aps"], aps_meta=g["aps_meta"][sel], aps_luma=g["aps_luma"][sel], aps_chroma=g["aps_chroma"][sel],
+                   aps_cc=g["aps_cc"][sel])
+        data, off = oracle_rows_alf(orc, one)
+        sizes = np.diff(off).astype(np.int32)
+        rows = np.zeros((len(sizes), int(sizes.max())), np.uint8)
+        for r in range(len(sizes)):
+            rows[r, :sizes[r]] = data[off[r]:off[r + 1]]
+        mine += write_alf_picture_nals(L, one, rows, sizes, [H.picture_checksum(p, depth) for p in post], poc=poc)
+    at = stream.find(b"\x00\x00\x01\x00\x89")
+    assert at > 0 and seen_fixed_only
+    assert stream[:at] + mine == stream

@@ -207,6 +207,40 @@ def stream(W, H, depth, qp, ts):
     print("wrote stream", tag, len(bs), "bytes")
 
 
+def stream_alf(W, H, depth, qp, ts):
+    """A whole multi-picture -p 1 --alf full stream (one worker thread): the .266, its source pictures and per picture the ALF decisions and
+    the APSs written in front of it (records "alf" / "aps" of ctu_dump.c) -- the rest of every picture follows from the source."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    px = np.uint8 if depth == 8 else np.uint16
+    tag = f"{W}x{H}_{depth}_qp{qp}_{len(ts)}frames_alf"
+    yuv = f"/tmp/gold_{tag}.yuv"
+    crcs = []
+    with open(yuv, "wb") as f:
+        for t in ts:
+            y, u, v = helpers.varied_picture(W, H, t, depth)
+            crcs.append(zlib.crc32(y.tobytes() + u.tobytes() + v.tobytes()))
+            for p in (y, u, v):
+                f.write(p.astype(px).tobytes())
+    out = f"/tmp/gold_{tag}"
+    subprocess.check_call([os.path.join(ROOT, "tools/refcheck/ctu_dump.sh"), str(depth), yuv, str(W), str(H), str(len(ts)), out,
+                           "preset", "medium", "period", "1", "qp", str(qp), "alf", "full", "threads", "1"], stderr=subprocess.DEVNULL)
+    recs = read_records(out + ".bin")
+    A = sorted([r for n, r in recs if n == "alf"], key=lambda r: int(r[0][0]))
+    P = [r for n, r in recs if n == "aps"]
+    assert len(A) == len(ts)
+    n = ((W + 63) // 64) * ((H + 63) // 64)
+    bs = np.frombuffer(open(out + ".266", "rb").read(), np.uint8)
+    np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_stream_{tag}.npz"), meta=np.array([W, H, depth, qp], np.int32), ts=np.array(ts, np.int32),
+                        src_crc=np.array(crcs, np.uint32), bitstream=bs, alf_meta=np.stack([a[0] for a in A]), alf_flags=np.stack([a[7].reshape(7, n) for a in A]),
+                        alf_set_idx=np.stack([a[8] for a in A]), alf_luma_aps=np.stack([a[9].reshape(8, -1) for a in A]), alf_chroma_aps=np.stack([a[10] for a in A]),
+                        alf_cc_coeff=np.stack([a[11].reshape(2, 4, 8) for a in A]),
+                        aps_meta=np.stack([r[0] for r in P]) if P else np.zeros((0, 16), np.int32), aps_luma=np.stack([r[1] for r in P]) if P else np.zeros((0, 675), np.int16),
+                        aps_chroma=np.stack([r[2] for r in P]) if P else np.zeros((0, 112), np.int16), aps_cc=np.stack([r[3] for r in P]) if P else np.zeros((0, 64), np.int16))
+    print("wrote alf stream", tag, len(bs), "bytes; ALF on:", [int(a[0][4]) for a in A], "luma APSs:", [int(a[0][7]) for a in A], "APSs written per picture:",
+          [sum(int(r[0][0]) == i for r in P) for i in range(len(ts))])
+
+
 def helpers_varied():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers
@@ -404,6 +438,7 @@ if __name__ == "__main__":
     alf(192, 128, 10, 23, 2, 30, 1)      # ... 10 bit where the activity shift matters (cfg.input_bitdepth + 4, alf.c:5185: the runs leave it at 8 + 4)
     full(320, 192, 10, 27, t=2007, picture=helpers_varied(), alf=True)        # whole pictures of --alf full runs with everything the coder and the NAL writer need
     full(192, 128, 8, 22, t=1001, picture=helpers_varied(), alf=True)
+    stream_alf(192, 128, 8, 27, (1000, 1001, 1002, 1003))      # four pictures of one --alf full stream: APSs of earlier pictures reused, NAL order of later access units
     merge(136, 72, 10, 27, 8, 2)
     inter(192, 128, 8, 32, 5, extra=("sao", "off"), suffix="_nosao", with_levels=False)        # final picture = the deblocked picture
     inter(136, 72, 10, 22, 4, extra=("sao", "off"), suffix="_nosao", with_levels=False)
