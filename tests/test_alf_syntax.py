@@ -8,7 +8,7 @@ import pytest
 
 import helpers as H
 
-ALF_GOLDENS = ["ref_ctu_320x192_10_qp27_alf", "ref_ctu_192x128_8_qp22_alf"]
+ALF_GOLDENS = ["ref_ctu_320x192_10_qp27_alf", "ref_ctu_192x128_8_qp22_alf", "ref_ctu_256x128_10_qp27_alf_nocc"]          # the last: --alf no-cc (alf_type 1)
 
 
 def oracle_rows_alf(orc, g):

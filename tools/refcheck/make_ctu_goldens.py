@@ -117,10 +117,12 @@ def items(s, c, W, H):
 
 
 def full(W, H, depth, qp, t=0, picture=None, out_dir=None, alf=False):
-    tag = f"{W}x{H}_{depth}_qp{qp}" + ("_alf" if alf else "")
+    # alf: False, True (= "full") or the --alf value ("no-cc": ALF without the cross-component filter)
+    alf_mode = "full" if alf is True else alf
+    tag = f"{W}x{H}_{depth}_qp{qp}" + ("_alf" if alf else "") + ("_nocc" if alf_mode == "no-cc" else "")
     # (one worker thread: without threads the queue runs a job the moment it is submitted (threadqueue.c:452) and a CTU's bitstream job
     # runs before the picture's ALF job -- the .266 of such a run is not what the encoder produces with its dependencies honoured)
-    S, Cd, src_crc, bs, px = run(W, H, depth, qp, t, tag, picture, extra=("alf", "full", "threads", "1") if alf else ())
+    S, Cd, src_crc, bs, px = run(W, H, depth, qp, t, tag, picture, extra=("alf", alf_mode, "threads", "1") if alf else ())
     wc, hc = (W + 63) // 64, (H + 63) // 64
     assert len(S) == wc * hc == len(Cd)
     models = np.zeros((hc * wc, 3, 1286), np.uint8)
@@ -438,6 +440,7 @@ if __name__ == "__main__":
     alf(192, 128, 10, 23, 2, 30, 1)      # ... 10 bit where the activity shift matters (cfg.input_bitdepth + 4, alf.c:5185: the runs leave it at 8 + 4)
     full(320, 192, 10, 27, t=2007, picture=helpers_varied(), alf=True)        # whole pictures of --alf full runs with everything the coder and the NAL writer need
     full(192, 128, 8, 22, t=1001, picture=helpers_varied(), alf=True)
+    full(256, 128, 10, 27, t=2003, picture=helpers_varied(), alf="no-cc")      # --alf no-cc: no CC-ALF fields anywhere
     stream_alf(192, 128, 8, 27, (1000, 1001, 1002, 1003))      # four pictures of one --alf full stream: APSs of earlier pictures reused, NAL order of later access units
     merge(136, 72, 10, 27, 8, 2)
     inter(192, 128, 8, 32, 5, extra=("sao", "off"), suffix="_nosao", with_levels=False)        # final picture = the deblocked picture
