@@ -19,6 +19,8 @@
 #include "reshape.h"
 #include "uvg266_hip.h"
 
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 static void hip_snap(uint8_t *dst, const cabac_ctx_t *src, int n)
@@ -166,17 +168,43 @@ int uvg_hip_state_config_supported(const uvg_config *const cfg)
          !(cfg->rdoq_enable && cfg->trskip_enable);
 }
 
+/* Which groups take the hip backend: UVG266_HIP unset -> none; "1" / "all" -> every group; otherwise a comma-separated list of
+ * group names ("picture,dct").  Used by the registration blocks of INTEGRATION.md section 1. */
+int uvg_hip_group_enabled(const char *group)
+{
+  const char *e = getenv("UVG266_HIP");
+  if (!e || !*e || !strcmp(e, "0")) return 0;
+  if (!strcmp(e, "1") || !strcmp(e, "all")) return 1;
+  const size_t n = strlen(group);
+  for (const char *p = e; *p;) {
+    const char *q = strchr(p, ',');
+    const size_t len = q ? (size_t)(q - p) : strlen(p);
+    if (len == n && !strncmp(p, group, n)) return 1;
+    p += len + (q ? 1 : 0);
+  }
+  return 0;
+}
+
 /* Called from uvg_strategy_register_quant / _picture (strategies-quant.c:50-66, strategies-picture.c:62-84) next to the
  * generic / avx2 registrars.  The state-free strategies of the same groups are registered by libuvg266hip.so itself
- * (uvg_strategy_register_quant_hip / _picture_hip). */
-int uvg_strategy_register_state_hip(void *opaque, uint8_t bitdepth)
+ * (uvg_strategy_register_quant_hip / _picture_hip).  Returning 0 makes uvg_strategyselector_init fail: with the backend asked
+ * for and no gfx950 device there is no silent fall-back to the CPU strategies. */
+int uvg_strategy_register_state_hip_quant(void *opaque, uint8_t bitdepth)
 {
   bool success = true;
-  if (bitdepth != UVG_BIT_DEPTH || uvghip_init(0) != 0) return 1;       /* no gfx950 device: leave the other strategies in place */
+  if (bitdepth != UVG_BIT_DEPTH || uvghip_init(0) != 0) { fprintf(stderr, "hip backend: %s\n", uvghip_last_error()); return 0; }
   success &= uvg_strategyselector_register(opaque, "quant", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_quant_hip);
   success &= uvg_strategyselector_register(opaque, "dequant", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_dequant_hip);
   success &= uvg_strategyselector_register(opaque, "quantize_residual", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_quantize_residual_hip);
   success &= uvg_strategyselector_register(opaque, "quant_cbcr_residual", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_quant_cbcr_residual_hip);
-  success &= uvg_strategyselector_register(opaque, "bipred_average", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_inter_recon_bipred_hip);
   return success;
+}
+int uvg_strategy_register_state_hip_picture(void *opaque, uint8_t bitdepth)
+{
+  if (bitdepth != UVG_BIT_DEPTH || uvghip_init(0) != 0) { fprintf(stderr, "hip backend: %s\n", uvghip_last_error()); return 0; }
+  return uvg_strategyselector_register(opaque, "bipred_average", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_inter_recon_bipred_hip);
+}
+int uvg_strategy_register_state_hip(void *opaque, uint8_t bitdepth)
+{
+  return uvg_strategy_register_state_hip_quant(opaque, bitdepth) && uvg_strategy_register_state_hip_picture(opaque, bitdepth);
 }

@@ -3,7 +3,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libuvg266hip.so")
+LIB_PATH = os.environ.get("UVGHIP_LIB") or os.path.join(_HERE, "libuvg266hip.so")      # UVGHIP_LIB: a variant build of the same library (profiling builds, tools/dev)
 
 
 class LibraryMissing(RuntimeError):
