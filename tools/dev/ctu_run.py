@@ -13,3 +13,4 @@ cs = api.CtuSearch(P, src)
 for rep in range(reps):
     torch.cuda.synchronize(); t = time.time(); cs.run(); torch.cuda.synchronize(); dt = time.time() - t
     print(f"{n} pictures {W}x{H} {depth}-bit: {dt*1e3:.1f} ms -> {n/dt:.2f} pictures/s", flush=True)
+del cs

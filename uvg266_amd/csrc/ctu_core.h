@@ -97,6 +97,12 @@
 #define WFOR(i, n) PAR_FOR(i, n)
 #define WSYNC() CTU_SYNC()
 
+// the 4x4 leaves of an I picture's CTU go through the register-resident formulation of ctu_leaf4.h (device builds; -DCTU_LEAF_OLD keeps
+// the general CU evaluation for them: the A/B build of tools/dev)
+#if defined(__HIPCC__) && !defined(CTU_PB) && !defined(CTU_LEAF_OLD)
+#define CTU_LEAF4 1
+#endif
+
 namespace ctu {
 
 #if !defined(__HIPCC__)
@@ -185,6 +191,10 @@ constexpr int arena_bytes(int n)     // one depth's share of the arena (n = its 
 {
   // reference rows, two transform buffers, levels (y, u, v), [4x4 only: the rough search's partial costs -- larger blocks keep
   // them in the transform buffers, idle during the rough search], [<= 8x8: RDOQ's two per-position cost arrays]
+#if defined(CTU_LEAF4)
+  // (the 4x4 leaf keeps the rough search's costs and RDOQ's per-position costs in registers: reference rows, transform buffers, levels only)
+  if (n == 4) return (4 * (4 * n + 8) * 2 + 2 * n * n * 2 + (n * n + 2 * 16) * 2 + 15) & ~15;
+#endif
   return (4 * (4 * n + 8) * 2 + 2 * n * n * 2 + (n * n + 2 * ((n / 2) * (n / 2) < 16 ? 16 : (n / 2) * (n / 2))) * 2 +
           (n >= 8 ? 0 : 2 * 18 * 4) + (n <= 8 ? 8 + 2 * n * n * 8 : 0) + 15) & ~15;
 }
@@ -254,7 +264,15 @@ template <typename PX> struct lds {
   int32_t vsel[4];                                  // which wv[] a wave is using (a wave may borrow a larger one while its owner idles)
   int32_t rot;                                      // index of the wave with role 0 (CTU_WAVE)
   int32_t req[4], done[4];                          // depth pipeline: evaluation requests / completions per depth
-  int32_t hreq, hdone, help[4];                     // the chroma helper (help_post): requests / completions; area x, y, mode -> has_coeffs
+  int32_t hreq, hdone, help[6];                     // the chroma helper (help_post): requests / completions; area x, y, mode -> has_coeffs, SSD
+#if defined(CTU_LEAF4)
+  // ctu_leaf4.h: the cubic interpolation filter (4 x int8 per phase), intraPredAngle | invAngle << 8 per |mode distance|, per raster
+  // position of a 4x4 block (positions later in scan order | scan index << 16 | raster of the next scan index << 20), the 8x8 area
+  // whose source samples are parked in lf_src ([0, 64) luma, [64, 80) Cb, [80, 96) Cr)
+  uint32_t lf_cubic[32], lf_disp[17], lf_rq[16];
+  int32_t lf_tag;
+  PX lf_src[96];
+#endif
   alignas(16) unsigned char arena[ARENA_BYTES];
 #if defined(CTU_PB)
   pb_state pb;
@@ -2499,6 +2517,10 @@ CTU_DEV int mb_load(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQ
 CTU_DEV void mb_store(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #endif
 
+#if defined(CTU_LEAF4)
+#include "ctu_leaf4.h"
+#endif
+
 #if !defined(CTU_PB)
 // ---- the chroma helper ------------------------------------------------------------------------------------------------------
 // The fourth 4x4 CU of an 8x8 area carries the area's two 4x4 chroma blocks (search.c:355-400).  They depend on that CU's luma MODE
@@ -2515,7 +2537,13 @@ template <typename PX> CTU_DEV void help_run(lds<PX> *S, const job<PX> &J)      
   const int lx = cx & 63, ly = cy & 63;
   PX *const ru = S->Du + ((ly >> 1) + 1) * PC + (lx >> 1) + 1;
   int16_t *const ku = J.coeff + 4096 + (ly >> 1) * LCU_C + (lx >> 1);
+#if defined(CTU_LEAF4)
+  int ssd;
+  const int has = leaf_recon(S, J, wv_of(S), 1, mode, 0, cx, cy, lx, ly, 8, 0, ru, PC, ku, LCU_C, &ssd);
+  LANE0 S->help[4] = ssd;
+#else
   const int has = recon_tu(S, J, 1, cx, cy, lx, ly, 8, mode, 0, ru, PC, ku, LCU_C, 8);
+#endif
   {
     CTU_LDS const int16_t *const from = LDSP(const int16_t, wv_of(S)->lv1);          // the walk counts the levels' bits from ITS scratch
     CTU_LDS int16_t *const to = LDSP(int16_t, S->wv[0].lv1);
@@ -2694,6 +2722,91 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
   CTU_SYNC();
   CTU_T1(J.W, 5);
 }
+
+#if defined(CTU_LEAF4)
+// eval_cu(S, J, 4, 0) for the 4x4 CU described by lvl[4] on the register-resident formulation of ctu_leaf4.h: same decisions, same
+// models, same reconstruction; the walk's wave, on wv[0].
+template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu4(lds<PX> *S, const job<PX> &J)
+{
+  wctx *const V = wv_of(S);
+  const params &P = J.P;
+  level_state &N = S->lvl[4];
+  const int x = N.x, y = N.y, lx = x & 63, ly = y & 63;
+  const int has_chroma = N.has_chroma;
+  LANE0 {
+    V->cur = S->cur;
+    cu4 *c = cu_at(S, lx, ly);                           // the CU's own entry is reset (search.c:1371-1388)
+    c->type = CU_NOTSET; c->cbf = 0; c->luma_edges = 0; c->chroma_edges = 0; c->mode = 0; c->mode_chroma = 0; c->log2 = 2; c->log2_c = 2;
+  }
+  leaf_load_area(S, J, lx, ly);
+  CTU_SYNC();
+  int mode;
+  { CTU_T0();
+  leaf_refs(S, P, V, 0, x, y, lx, ly, 4);
+  mode = leaf_rough(S, J, V, x, y, lx, ly, leaf_src(S, 0, lx, ly));
+  CTU_T1(J.W, 0); }
+  SERIAL fill_cu(S, lx, ly, 4, mode, mode, 2, N.split_tree, cu_mtt(N.mode_type_tree, 4));
+  CTU_SYNC();
+  const int cx = x & ~7, cy = y & ~7, clx = cx & 63, cly = cy & 63;          // the chroma area
+  PX *const ry = S->Dy + (ly + 1) * PY + lx + 1;
+  PX *const ru = S->Du + ((cly >> 1) + 1) * PC + (clx >> 1) + 1, *const rv = S->Dv + ((cly >> 1) + 1) * PC + (clx >> 1) + 1;
+  int16_t *const ky = J.coeff + ly * LCU + lx;
+  int16_t *const ku = J.coeff + 4096 + (cly >> 1) * LCU_C + (clx >> 1), *const kv = J.coeff + 5120 + (cly >> 1) * LCU_C + (clx >> 1);
+  const bool helped = has_chroma && help_post(S, J, cx, cy, mode);
+#if defined(CTU_PROFILE)
+  if (has_chroma) { LANE0 J.W->prof[1][helped ? 19 : 20] += 1; }
+#endif
+  int ssd_y = 0, ssd_u = 0, ssd_v = 0, cbf;
+  { CTU_T0();
+  cbf = leaf_recon(S, J, V, 0, mode, 0, x, y, lx, ly, 4, 1, ry, PY, ky, LCU, &ssd_y);
+  if (has_chroma) {
+    if (helped) {
+#if defined(CTU_PROFILE)
+      const unsigned long long tw = __builtin_amdgcn_s_memtime();
+#endif
+      cbf |= help_wait(S) << 1;
+      ssd_u = S->help[4];
+#if defined(CTU_PROFILE)
+      LANE0 J.W->prof[1][21] += __builtin_amdgcn_s_memtime() - tw;
+#endif
+    } else {
+      cbf |= leaf_recon(S, J, V, 1, mode, 0, cx, cy, clx, cly, 8, 0, ru, PC, ku, LCU_C, &ssd_u) << 1;
+    }
+    cbf |= leaf_recon(S, J, V, 2, mode, (cbf >> 1) & 1, cx, cy, clx, cly, 8, 0, rv, PC, kv, LCU_C, &ssd_v) << 2;
+  }
+  CTU_T1(J.W, 3); }
+  CTU_T0();
+  double bits = 0;
+  LANE0 {
+    V->red[0] = ssd_y; V->red[1] = ssd_u; V->red[2] = ssd_v;
+    cu4 *c = cu_at(S, lx, ly);
+    c->cbf = (uint8_t)(cbf & 1);
+    if (has_chroma) {
+      // the area's chroma flags sit at its first entry and are copied to all four (lcu_fill_chroma_cbfs), with the chroma mode and
+      // chroma size of this, the last, CU (lcu_fill_chroma_cu_info, search.c:355-400)
+      for (int k = 0; k < 4; ++k) {
+        cu4 *q = cu_at(S, clx + (k & 1) * 4, cly + (k >> 1) * 4);
+        q->cbf = (uint8_t)((q->cbf & 1) | (cbf & 6));
+        q->mode_chroma = (int8_t)mode;
+        q->log2_c = 2;
+      }
+    }
+    // uvg_mock_encode_coding_unit with search_cabac.update = 1 (search.c:1700-1716); a 4x4 CU has no split flag
+    luma_mode_bits(S, V->cur, 1, x, y, lx, ly, 4, mode, bits);
+    if (has_chroma) chroma_mode_bits(V->cur, 1, mode, mode, bits);
+  }
+  CTU_SYNC();
+  const double trc = tr_cost(S, P, 1, 4, cbf, has_chroma, 4);       // cu_rd_cost_tr_split_accurate (:1718)
+  LANE0 {
+    double cost = bits * P.lambda;
+    cost += trc;
+    mark_deblocking(S, x, y, lx, ly, 4, 1, has_chroma);
+    N.cost = cost; N.type = CU_INTRA; N.mode = mode; N.cbf = cbf;
+  }
+  CTU_SYNC();
+  CTU_T1(J.W, 5);
+}
+#endif
 
 // the depth's unsplit candidate becomes the decision: the split lost (work_tree_copy_up in reverse)
 template <typename PX> CTU_NOINLINE CTU_DEV void unpark(lds<PX> *S, const job<PX> &J, int L)
@@ -2918,6 +3031,9 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
           CTU_T0();
           LANE0 S->vsel[CTU_WAVE] = 4 - L;          // the scratch sized for this depth (its own wave has nothing to do for a leaf)
           CTU_SYNC();
+#if defined(CTU_LEAF4)
+          if (L == 4) eval_cu4(S, J); else
+#endif
           eval_cu(S, J, L, 0);
           LANE0 S->vsel[CTU_WAVE] = 0;
           CTU_SYNC();
@@ -3229,11 +3345,17 @@ template <typename PX> CTU_DEV void setup_waves(lds<PX> *S)
     V->lv0 = (int16_t *)a; V->lv1 = V->lv0 + nn; V->lv2 = V->lv1 + c2; a += (nn + 2 * c2) * 2;
     // the rough search's (satd, sad) per (mode, tile) -- 2 * 18 * tiles words -- fit the three transform buffers from 8x8 on, which
     // idle until the mode is chosen
+#if defined(CTU_LEAF4)
+    if (n == 4) { V->part = nullptr; V->rq_cc = V->rq_cs = nullptr; }       // (the general evaluation never runs on this scratch: eval_cu4)
+    else
+#endif
+    {
     if (n >= 8) V->part = (uint32_t *)V->t0;
     else { V->part = (uint32_t *)a; a += 2 * 18 * tiles * 4; }
     a = S->arena + ((a - S->arena + 7) & ~7);
     if (n <= 8) { V->rq_cc = (double *)a; V->rq_cs = V->rq_cc + nn; }
     else V->rq_cc = V->rq_cs = nullptr;
+    }
     V->cur = S->cur;
     S->vsel[k] = k;
     S->req[k] = 0; S->done[k] = 0;
@@ -3252,6 +3374,9 @@ template <typename PX> CTU_DEV void run_ctu(lds<PX> *S, const job<PX> &J)
   CTU_T0();
   { CTU_T0();
   setup_waves(S);
+#if defined(CTU_LEAF4)
+  leaf_tables(S);
+#endif
   if (CTU_WAVE == 0) build_scans(S);
   BLK_SYNC();
   load_ctu(S, J);
