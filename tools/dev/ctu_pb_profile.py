@@ -34,7 +34,7 @@ for f, step in enumerate(loop.steps):
     ws = step[2].cpu().numpy()
     off = L.uvghip_ctu_search_pb_debug_scratch(n_seq, W, Hh, ctypes.byref(sb), ctypes.byref(ns))
     SZ = sb.value
-    prof = np.stack([ws[off + i * SZ + SZ - 1024 - 128: off + i * SZ + SZ - 1024].view(np.uint64) for i in range(ns.value)]).astype(np.float64)
+    prof = np.stack([ws[off + i * SZ + SZ - 1024 - 256: off + i * SZ + SZ - 1024 - 128].view(np.uint64) for i in range(ns.value)]).astype(np.float64)
     prof = prof[prof[:, 14] > 0]
     tot = prof[:, 14].mean()
     print(f"picture {f}: {len(prof)} slots, mean cycles per CTU {tot:.0f} ({tot / 1e5:.2f} ms at 100 MHz s_memtime)")

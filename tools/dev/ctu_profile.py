@@ -16,8 +16,10 @@ al = lambda v, a: (v + a - 1) // a * a
 off_order = al(512 + 32768 + ctus * 4, 256); off_pics = al(off_order + ctus * 4, 256); off_scr = al(off_pics + n * 96, 256)
 n_slots = min(2048, al(ctus, 32))          # a slot keeps the profile of the last CTU that ran on it
 ws = cs.ws.cpu().numpy()
-SZ = 59328
+SZ = 59328 + 128
 prof = np.stack([ws[off_scr + i * SZ + SZ - 1024: off_scr + i * SZ + SZ].view(np.uint64).reshape(4, 32) for i in range(n_slots)]).astype(np.float64)
+lf = np.stack([ws[off_scr + i * SZ + SZ - 1024 - 128: off_scr + i * SZ + SZ - 1024].view(np.uint64) for i in range(n_slots)]).astype(np.float64)
+lf = lf[prof[:, 0, 11] > 0]
 prof = prof[prof[:, 0, 11] > 0]
 names = ["rough search", "refs+predict", "residual+transforms+recon", "RDOQ", "SSD", "RD cost bits", "unpark/models", "64x64 candidate", "coder pass", "load", "store", "TOTAL",
          "rq: candidates+last", "rq: pre-walk", "rq: decide", "rq: accumulate+group", "rq: copy-out", "rq: cbf+last search", "rq: signs", "leaf depth 0", "leaf depth 1", "leaf depth 2", "leaf depth 3", "leaf depth 4 (4x4)", "rs: setup", "rs: rough_costs", "rs: mode cost", "rs: select", "cb: last+flags", "cb: records+budget", "cb: sweeps", "cb: bypass+lane0"]
@@ -28,3 +30,8 @@ for i, nm in enumerate(names):
     print("  %-26s" % nm + "".join("%12.0f" % prof[:, w, i].mean() for w in range(4)))
 
 print("chroma helper per CTU: Cb blocks handed to depth 3's wave %.1f, kept by the walk (wave busy) %.1f, the walk's wait for them %.0f cycles" % (prof[:, 1, 19].mean(), prof[:, 1, 20].mean(), prof[:, 1, 21].mean()))
+
+lfn = ["area source load", "refs (luma)", "src->sgpr, mpm, planar/DC", "pass A (modes 4..65)", "selection (+ pass B)", "recon: refs (chroma)", "recon: predict + residual + DCT", "recon: RDOQ", "recon: dequant + IDCT + store + SSD", "fill_cu + help + between", "-", "bits: flags + mode bits (lane 0)", "bits: tr_cost (cbf + coeff_bits4)", "bits: cost + deblock marks"]
+print("4x4 leaf, cycles per CTU (walk's wave):")
+for i, nm in enumerate(lfn):
+    if nm != "-": print("  %-44s %10.0f   per CU %7.0f" % (nm, lf[:, i].mean(), lf[:, i].mean() / 256))

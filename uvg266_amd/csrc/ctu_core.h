@@ -89,6 +89,13 @@
 #else
 #define RQ_T(slot) ((void)0)
 #endif
+#if defined(__HIPCC__) && defined(CTU_PROFILE)
+#define LF_T(slot) do { const unsigned long long t2 = __builtin_amdgcn_s_memtime(); if (CTU_TID == 0 && CTU_WAVE == 0) J.W->prof_lf[slot] += t2 - tq; tq = t2; } while (0)
+#define LF_T0() unsigned long long tq = __builtin_amdgcn_s_memtime()
+#else
+#define LF_T(slot) ((void)0)
+#define LF_T0() ((void)0)
+#endif
 #define LDSP(T, p) ((CTU_LDS T *)(p))          // a pointer known to point into the workgroup's LDS image (device: ds_* instead of flat_*)
 #define PAR_FOR(i, n) for (int i = CTU_TID; i < (n); i += CTU_NT)
 #define BLK_FOR(i, n) for (int i = BLK_TID; i < (n); i += BLK_NT)
@@ -270,6 +277,8 @@ template <typename PX> struct lds {
   // position of a 4x4 block (positions later in scan order | scan index << 16 | raster of the next scan index << 20), the 8x8 area
   // whose source samples are parked in lf_src ([0, 64) luma, [64, 80) Cb, [80, 96) Cr)
   uint32_t lf_cubic[32], lf_disp[17], lf_rq[16];
+  double lf_escale[2];                              // uvg_rdoq's error scale of a 4x4 block: luma, chroma
+  int32_t lf_qbits[2], lf_q[2];                     // ... q_bits, quantiser scale
   int32_t lf_tag;
   PX lf_src[96];
 #endif
@@ -296,6 +305,7 @@ struct scratch {
 #if defined(CTU_PB)
   unsigned long long prof_pb[16];     // CTU_PROFILE, ctu_pb.h: cycles of the phases of the P / B walk (lane 0 of the wave)
 #endif
+  unsigned long long prof_lf[16];     // CTU_PROFILE, ctu_leaf4.h: cycles of the 4x4 leaf's steps (the walk's wave)
   unsigned long long prof[4][32];     // CTU_PROFILE: 0 rough search, 1 refs + prediction, 2 residual + transforms + reconstruction, 3 RDOQ, 4 SSD,
                                    // 5 RD cost (bits), 6 park / unpark / model copies, 7 64x64 candidate, 8 coder pass, 9 load, 10 store, 11 total
 };
@@ -2133,6 +2143,10 @@ template <typename PX> CTU_NOINLINE CTU_DEV void mark_deblocking(lds<PX> *S, int
 // regular bins a scan position spends, from its record (level in bits 0..15, "its sig flag is coded" in bit 29)
 CTU_DEV int rec_spend(uint32_t rec) { const uint32_t a = rec & 0xffffu; return (int)((rec >> 29) & 1u) + (a ? 1 + (a > 1 ? 2 : 0) : 0); }
 
+#if defined(CTU_LEAF4)
+#include "ctu_leaf4.h"
+#endif
+
 #if defined(__HIPCC__)
 // coeff_bits for a 4x4 block (one coefficient group): the shape the 4x4 leaves, their 8x8 areas' chroma and most of the coder
 // pass consist of.  Same bins and adaptation as the general function below, but nothing goes through memory: lane sp (0..15) holds
@@ -2262,7 +2276,11 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
   const uint16_t *scan = S->scan + scan_base(l2);
   CTU_LDS uint32_t *const m = (CTU_LDS uint32_t *)m_;
   CTU_LDS const int16_t *const coeff = (CTU_LDS const int16_t *)coeff_;
+#if defined(CTU_LEAF4)
+  if (n == 4) return coeff_bits4r(S, m, update, (int)coeff[lane & 15], color);
+#else
   if (n == 4) return coeff_bits4(S, m, update, coeff, color);
+#endif
   CTU_LDS uint32_t *recs = (CTU_LDS uint32_t *)(V->t0);       // t0 + t1: 1024 words, free while costs are counted
   CTU_LDS uint8_t *cgf = (CTU_LDS uint8_t *)V->cg_flag;                                   // per group (raster): has a level
   CTU_LDS int32_t *gtot = (CTU_LDS int32_t *)(V->rq_stage);   // per group (scan order): regular bins it would spend, bit 30: a level among k = 1..15
@@ -2517,10 +2535,6 @@ CTU_DEV int mb_load(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_ACQ
 CTU_DEV void mb_store(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #endif
 
-#if defined(CTU_LEAF4)
-#include "ctu_leaf4.h"
-#endif
-
 #if !defined(CTU_PB)
 // ---- the chroma helper ------------------------------------------------------------------------------------------------------
 // The fourth 4x4 CU of an 8x8 area carries the area's two 4x4 chroma blocks (search.c:355-400).  They depend on that CU's luma MODE
@@ -2538,9 +2552,9 @@ template <typename PX> CTU_DEV void help_run(lds<PX> *S, const job<PX> &J)      
   PX *const ru = S->Du + ((ly >> 1) + 1) * PC + (lx >> 1) + 1;
   int16_t *const ku = J.coeff + 4096 + (ly >> 1) * LCU_C + (lx >> 1);
 #if defined(CTU_LEAF4)
-  int ssd;
-  const int has = leaf_recon(S, J, wv_of(S), 1, mode, 0, cx, cy, lx, ly, 8, 0, ru, PC, ku, LCU_C, &ssd);
-  LANE0 S->help[4] = ssd;
+  const lf_block B = leaf_recon(S, J, wv_of(S), 1, mode, 0, cx, cy, lx, ly, 8, 0, ru, PC, ku, LCU_C);
+  const int has = B.has;
+  LANE0 S->help[4] = B.ssd;
 #else
   const int has = recon_tu(S, J, 1, cx, cy, lx, ly, 8, mode, 0, ru, PC, ku, LCU_C, 8);
 #endif
@@ -2738,12 +2752,15 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu4(lds<PX> *S, const job<
     cu4 *c = cu_at(S, lx, ly);                           // the CU's own entry is reset (search.c:1371-1388)
     c->type = CU_NOTSET; c->cbf = 0; c->luma_edges = 0; c->chroma_edges = 0; c->mode = 0; c->mode_chroma = 0; c->log2 = 2; c->log2_c = 2;
   }
+  LF_T0();
   leaf_load_area(S, J, lx, ly);
   CTU_SYNC();
-  int mode;
+  LF_T(0);
+  int mode, mpm[6];
   { CTU_T0();
   leaf_refs(S, P, V, 0, x, y, lx, ly, 4);
-  mode = leaf_rough(S, J, V, x, y, lx, ly, leaf_src(S, 0, lx, ly));
+  LF_T(1);
+  mode = leaf_rough(S, J, V, x, y, lx, ly, leaf_src(S, 0, lx, ly), mpm);
   CTU_T1(J.W, 0); }
   SERIAL fill_cu(S, lx, ly, 4, mode, mode, 2, N.split_tree, cu_mtt(N.mode_type_tree, 4));
   CTU_SYNC();
@@ -2756,9 +2773,12 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu4(lds<PX> *S, const job<
 #if defined(CTU_PROFILE)
   if (has_chroma) { LANE0 J.W->prof[1][helped ? 19 : 20] += 1; }
 #endif
-  int ssd_y = 0, ssd_u = 0, ssd_v = 0, cbf;
+  int ssd_y = 0, ssd_u = 0, ssd_v = 0, cbf, lev_y, lev_u = 0, lev_v = 0;
   { CTU_T0();
-  cbf = leaf_recon(S, J, V, 0, mode, 0, x, y, lx, ly, 4, 1, ry, PY, ky, LCU, &ssd_y);
+  {
+    const lf_block B = leaf_recon(S, J, V, 0, mode, 0, x, y, lx, ly, 4, 1, ry, PY, ky, LCU);
+    cbf = B.has; ssd_y = B.ssd; lev_y = B.level;
+  }
   if (has_chroma) {
     if (helped) {
 #if defined(CTU_PROFILE)
@@ -2766,21 +2786,27 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu4(lds<PX> *S, const job<
 #endif
       cbf |= help_wait(S) << 1;
       ssd_u = S->help[4];
+      lev_u = (int)LDSP(const int16_t, V->lv1)[CTU_TID & 15];         // (help_run left the levels in the walk's scratch)
 #if defined(CTU_PROFILE)
       LANE0 J.W->prof[1][21] += __builtin_amdgcn_s_memtime() - tw;
 #endif
     } else {
-      cbf |= leaf_recon(S, J, V, 1, mode, 0, cx, cy, clx, cly, 8, 0, ru, PC, ku, LCU_C, &ssd_u) << 1;
+      const lf_block B = leaf_recon(S, J, V, 1, mode, 0, cx, cy, clx, cly, 8, 0, ru, PC, ku, LCU_C);
+      cbf |= B.has << 1; ssd_u = B.ssd; lev_u = B.level;
     }
-    cbf |= leaf_recon(S, J, V, 2, mode, (cbf >> 1) & 1, cx, cy, clx, cly, 8, 0, rv, PC, kv, LCU_C, &ssd_v) << 2;
+    const lf_block B = leaf_recon(S, J, V, 2, mode, (cbf >> 1) & 1, cx, cy, clx, cly, 8, 0, rv, PC, kv, LCU_C);
+    cbf |= B.has << 2; ssd_v = B.ssd; lev_v = B.level;
   }
   CTU_T1(J.W, 3); }
   CTU_T0();
+  LF_T(9);
+  // ---- the CU's side information and RD cost (search.c:1700-1774) ----
   double bits = 0;
   LANE0 {
-    V->red[0] = ssd_y; V->red[1] = ssd_u; V->red[2] = ssd_v;
     cu4 *c = cu_at(S, lx, ly);
     c->cbf = (uint8_t)(cbf & 1);
+    // mark_deblocking (search.c:1075-1174) for a 4x4 CU: its own luma edges; the area's chroma edges with the CU that carries the chroma
+    c->luma_edges = (uint8_t)((x ? 1 : 0) | (y ? 2 : 0));
     if (has_chroma) {
       // the area's chroma flags sit at its first entry and are copied to all four (lcu_fill_chroma_cbfs), with the chroma mode and
       // chroma size of this, the last, CU (lcu_fill_chroma_cu_info, search.c:355-400)
@@ -2789,21 +2815,50 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu4(lds<PX> *S, const job<
         q->cbf = (uint8_t)((q->cbf & 1) | (cbf & 6));
         q->mode_chroma = (int8_t)mode;
         q->log2_c = 2;
+        if ((cx & ~7) && !(k & 1)) q->chroma_edges |= 1;
+        if ((cy & ~7) && !(k >> 1)) q->chroma_edges |= 2;
       }
     }
     // uvg_mock_encode_coding_unit with search_cabac.update = 1 (search.c:1700-1716); a 4x4 CU has no split flag
-    luma_mode_bits(S, V->cur, 1, x, y, lx, ly, 4, mode, bits);
+    lf_luma_mode_bits(V->cur, mpm, mode, bits);
     if (has_chroma) chroma_mode_bits(V->cur, 1, mode, mode, bits);
   }
-  CTU_SYNC();
-  const double trc = tr_cost(S, P, 1, 4, cbf, has_chroma, 4);       // cu_rd_cost_tr_split_accurate (:1718)
+  LF_T(11);
+  // cu_rd_cost_tr_split_accurate (search.c:724-986): the three coded block flags, a lane each (their models are distinct) ...
+  double tbits;
+  {
+    CTU_LDS uint32_t *const m = LDSP(uint32_t, V->cur);
+    const int lane = CTU_TID;
+    const int fmodel = lane == 0 ? M_CBF_LUMA : (lane == 1 ? M_CBF_CB : M_CBF_CR + ((cbf >> 1) & 1));
+    const int fbin = lane == 0 ? cbf & 1 : (lane == 1 ? (cbf >> 1) & 1 : (cbf >> 2) & 1);
+    int fq = 0;
+    if (lane == 0 || (lane < 3 && has_chroma)) {
+      const uint32_t st = m[fmodel];
+      const int rw = LDSP(const uint8_t, kRate)[fmodel], r0 = rw >> 4, r1 = rw & 15;
+      uint32_t s0 = st & 0xffffu, s1 = st >> 16;
+      fq = (int)LDSP(const uint32_t, tab_ebits())[(((s0 + s1) >> 8) << 1) ^ (uint32_t)fbin];
+      s0 -= (s0 >> r0) & 0x7fe0u;
+      s1 -= (s1 >> r1) & 0x7ffeu;
+      if (fbin) { s0 += (0x7fffu >> r0) & 0x7fe0u; s1 += (0x7fffu >> r1) & 0x7ffeu; }
+      m[fmodel] = (s0 & 0xffffu) | (s1 << 16);
+    }
+    const int fsum = __builtin_amdgcn_readlane(fq, 0) + __builtin_amdgcn_readlane(fq, 1) + __builtin_amdgcn_readlane(fq, 2);
+    CTU_SYNC();
+    // ... and the levels' bits (every term a multiple of 2^-15: the order of the sum is immaterial)
+    tbits = (double)fsum / 32768.0;
+    if (cbf & 1) tbits += coeff_bits4r(S, m, 1, lev_y, 0);
+    if (has_chroma) { tbits += coeff_bits4r(S, m, 1, lev_u, 1); tbits += coeff_bits4r(S, m, 1, lev_v, 2); }
+  }
+  LF_T(12);
   LANE0 {
+    const unsigned chroma_ssd = has_chroma ? (unsigned)((unsigned)ssd_u * P.cw_u) + (unsigned)((unsigned)ssd_v * P.cw_v) : 0u;
+    const double trc = (unsigned)ssd_y * 1.0 + chroma_ssd * 1.0 + tbits * P.lambda;
     double cost = bits * P.lambda;
     cost += trc;
-    mark_deblocking(S, x, y, lx, ly, 4, 1, has_chroma);
     N.cost = cost; N.type = CU_INTRA; N.mode = mode; N.cbf = cbf;
   }
   CTU_SYNC();
+  LF_T(13);
   CTU_T1(J.W, 5);
 }
 #endif
@@ -3369,13 +3424,14 @@ template <typename PX> CTU_DEV void run_ctu(lds<PX> *S, const job<PX> &J)
 {
 #if defined(__HIPCC__) && defined(CTU_PROFILE)
   BLK_FOR(i, 4 * 32) J.W->prof[i >> 5][i & 31] = 0;
+  BLK_FOR(i, 16) J.W->prof_lf[i] = 0;
   S->prof_w = J.W;
 #endif
   CTU_T0();
   { CTU_T0();
   setup_waves(S);
 #if defined(CTU_LEAF4)
-  leaf_tables(S);
+  leaf_tables(S, J.P);
 #endif
   if (CTU_WAVE == 0) build_scans(S);
   BLK_SYNC();

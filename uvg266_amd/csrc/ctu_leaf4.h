@@ -43,8 +43,18 @@ CTU_DEV int lf_row_sum(int v)
 }
 
 // ---- per-CTU tables (LDS) ------------------------------------------------------------------------------------------------------
-template <typename PX> CTU_DEV void leaf_tables(lds<PX> *S)
+template <typename PX> CTU_DEV void leaf_tables(lds<PX> *S, const params &P)
 {
+  BLK_FOR(t, 2) {           // uvg_rdoq's per-block constants (rdo.c:1500-1530) for a 4x4 block of luma / chroma
+    const int qps = (t ? P.qp_c : P.qp) + 6 * ((int)px_info<PX>::depth - 8);
+    const int transform_shift = 15 - (int)px_info<PX>::depth - 2;
+    const int q = kQuantScales[qps % 6];
+    double scale = 32768;
+    scale = transform_shift >= 0 ? scale / kPow2[2 * transform_shift] : scale * kPow2[-2 * transform_shift];
+    S->lf_escale[t] = scale / q / q;
+    S->lf_qbits[t] = 14 + qps / 6 + transform_shift;
+    S->lf_q[t] = q;
+  }
   BLK_FOR(i, 32) S->lf_cubic[i] = (uint32_t)(uint8_t)kCubic[i][0] | (uint32_t)(uint8_t)kCubic[i][1] << 8 | (uint32_t)(uint8_t)kCubic[i][2] << 16 | (uint32_t)(uint8_t)kCubic[i][3] << 24;
   BLK_FOR(i, 17) S->lf_disp[i] = (uint32_t)kSampleDisp[i] | (uint32_t)kInvDisp[i] << 8;
   BLK_FOR(r, 16) {
@@ -230,6 +240,193 @@ template <typename PX> CTU_DEV int leaf_predict(lds<PX> *S, wctx *V, int mode, i
   return xd == 0 ? out[0] : xd == 1 ? out[1] : xd == 2 ? out[2] : out[3];
 }
 
+// ---- most probable modes, mode bits ----------------------------------------------------------------------------------------------
+// uvg_intra_get_dir_luma_predictor (intra.c:88-188, MIP off) from the two neighbours' modes (0 where there is no intra neighbour)
+CTU_DEV void lf_mpm(int left_dir, int above_dir, int (&p)[6])
+{
+  const int offset = 61, mod = 64;
+  p[0] = 0; p[1] = 1; p[2] = 50; p[3] = 18; p[4] = 46; p[5] = 54;
+  if (left_dir == above_dir) {
+    if (left_dir > 1) {
+      p[1] = left_dir;
+      p[2] = ((left_dir + offset) % mod) + 2; p[3] = ((left_dir - 1) % mod) + 2;
+      p[4] = ((left_dir + offset - 1) % mod) + 2; p[5] = (left_dir % mod) + 2;
+    }
+  } else if (left_dir > 1 && above_dir > 1) {
+    p[1] = left_dir; p[2] = above_dir;
+    const int mx = left_dir > above_dir ? left_dir : above_dir, mn = left_dir > above_dir ? above_dir : left_dir;
+    const int diff = mx - mn;
+    if (diff == 1) {
+      p[3] = ((mn + offset) % mod) + 2; p[4] = ((mx - 1) % mod) + 2; p[5] = ((mn + offset - 1) % mod) + 2;
+    } else if (diff >= 62) {
+      p[3] = ((mn - 1) % mod) + 2; p[4] = ((mx + offset) % mod) + 2; p[5] = (mn % mod) + 2;
+    } else if (diff == 2) {
+      p[3] = ((mn - 1) % mod) + 2; p[4] = ((mn + offset) % mod) + 2; p[5] = ((mx - 1) % mod) + 2;
+    } else {
+      p[3] = ((mn + offset) % mod) + 2; p[4] = ((mn - 1) % mod) + 2; p[5] = ((mx + offset) % mod) + 2;
+    }
+  } else if (left_dir + above_dir >= 2) {
+    p[1] = left_dir < above_dir ? above_dir : left_dir;
+    p[2] = ((p[1] + offset) % mod) + 2; p[3] = ((p[1] - 1) % mod) + 2;
+    p[4] = ((p[1] + offset - 1) % mod) + 2; p[5] = (p[1] % mod) + 2;
+  }
+}
+// uvg_encode_intra_luma_coding_unit (encode_coding_tree.c:992-1238) in count mode with the list already derived; lane 0.
+// (every term is a multiple of 2^-15: the order of the additions is immaterial)
+CTU_DEV void lf_luma_mode_bits(uint32_t *m_, const int (&p)[6], int mode, double &bits_out)
+{
+  CTU_LDS uint32_t *const m = LDSP(uint32_t, m_);
+  int mpm = -1;
+#pragma unroll
+  for (int i = 5; i >= 0; --i) if (p[i] == mode) mpm = i;
+  double bits = 0;
+  m_code(m, 1, M_MPM, mpm != -1, bits);
+  if (mpm != -1) {
+    m_code(m, 1, M_PLANAR + 1, mpm > 0, bits);
+    bits += (mpm > 0) + (mpm > 1) + (mpm > 2) + (mpm > 3);
+  } else {
+    int tmp = mode;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) tmp -= p[i] < mode;
+    bits += (tmp < 3) ? 5 : 6;                      // truncated binary code of 61 symbols (cabac.c:203-229)
+  }
+  bits_out += bits;
+}
+
+// ---- coefficient bit cost of a 4x4 block -------------------------------------------------------------------------------------------
+// coeff_bits4 (ctu_core.h) with the block in RASTER order over the lanes 0..15 (`lev`: the signed level of position lane & 15; every
+// row of 16 lanes may repeat it): the context template's neighbours are DPP row shifts, what is counted along the scan reads the
+// owners' registers in scan order, and the entropy-table lookups are taken out of the adaptation chain (a model's state after a bin
+// does not depend on the bin's cost): the sixteen steps of the sweep are pure register arithmetic, the sixteen lookups go out together.
+// Same bins, same adaptation, same sum as uvg_encode_coeff_nxn in count mode (encode_coding_tree-generic.c:53-323).
+template <typename PX> CTU_DEV double coeff_bits4r(lds<PX> *S, CTU_LDS uint32_t *m, int update, int lev, int color)
+{
+  const int lane = CTU_TID, r = lane & 15, px = r & 3, py = r >> 2, t = color ? 1 : 0;
+  const int a = iabs_(lev);
+  const unsigned nz = (unsigned)__ballot(a != 0) & 0xffffu;
+  if (nz == 0) return 0.0;
+  const uint32_t tab = LDSP(const uint32_t, S->lf_rq)[r];
+  const unsigned later = tab & 0xffffu;
+  const int sp = (int)((tab >> 16) & 15);
+  const bool is_last = a != 0 && (nz & later) == 0;
+  const int last_lane = __builtin_ctzll(__ballot(is_last));
+  const int last = __builtin_amdgcn_readlane(sp, last_lane);           // scan index of the last significant position
+  // this lane's models: the sweep's (one per lane, 12 + 3 * 16 luma / 8 + 3 * 11 chroma) and, lanes 0..5, a last-position prefix model
+  const int nk0 = t ? 8 : 12, nks = t ? 11 : 16;
+  int role = -1, k = 0;
+  if (lane < nk0) { role = 0; k = lane; }
+  else if (lane < nk0 + 3 * nks) { role = 1 + (lane - nk0) / nks; k = (lane - nk0) % nks; }
+  if (!t && role > 0 && k > 0) k += 5;          // 4x4 luma: set offsets 0, 6..20
+  const int model = role < 0 ? 0 : (role == 0 ? M_SIG + 12 * t : role == 1 ? M_GT1 + 21 * t : role == 2 ? M_PAR + 21 * t : M_GT2 + 21 * t) + k;
+  const int paxis = lane >= 3, pq = lane - 3 * paxis;                // prefix: lanes 0..2 x, 3..5 y; a 4x4 block: offset 0, shift 0, three models per axis
+  const int pmodel = (paxis ? M_LASTY : M_LASTX) + 20 * t + (lane < 6 ? pq : 0);
+  uint32_t st = m[model];
+  const uint32_t pst = m[pmodel];
+  CTU_LDS const uint8_t *const rate = LDSP(const uint8_t, kRate);
+  const int rw = rate[model], prw = rate[pmodel];
+  // ---- per position: contexts, Rice parameters, whether its sig flag is coded, the regular bins it spends ----
+  int ctx_sig, ofs = 0, r4, r0;
+  {
+    const int a1 = lf_nb<1>(a), a2 = lf_nb<2>(a), a5 = lf_nb<5>(a), a4 = lf_nb<4>(a), a8 = lf_nb<8>(a);
+    int num_pos = 0, sum_abs = 0, sum = 0;
+#define LF_UPD(v) { const int q = (v); sum_abs += (4 + (q & 1)) < q ? (4 + (q & 1)) : q; num_pos += q ? 1 : 0; sum += q; }
+    if (px < 3) { LF_UPD(a1); if (px < 2) LF_UPD(a2); if (py < 3) LF_UPD(a5); }
+    if (py < 3) { LF_UPD(a4); if (py < 2) LF_UPD(a8); }
+#undef LF_UPD
+    const int diag = px + py, tsum = sum_abs - num_pos;
+    ctx_sig = (((sum_abs + 1) >> 1) < 3 ? ((sum_abs + 1) >> 1) : 3) + (diag < 2 ? 4 : 0);
+    if (color == 0) ctx_sig += diag < 5 ? 4 : 0;
+    if (t && ctx_sig > 7) ctx_sig = 7;
+    if (sp != last) ofs = ((tsum < 4 ? tsum : 4) + 1) + (!diag ? (color == 0 ? 15 : 5) : color == 0 ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0);
+    int v4 = sum - 20, v0 = sum;
+    v4 = v4 < 31 ? v4 : 31; v0 = v0 < 31 ? v0 : 31;
+    r4 = go_rice_par((unsigned)(v4 > 0 ? v4 : 0)); r0 = go_rice_par((unsigned)(v0 > 0 ? v0 : 0));
+  }
+  const bool live = sp <= last;
+  const int sig_coded = live && sp != last;
+  const int spend = live ? sig_coded + (a ? 1 + (a > 1 ? 2 : 0) : 0) : 0;
+  const uint32_t rec = (uint32_t)(a > 0xffff ? 0xffff : a) | (uint32_t)ctx_sig << 16 | (uint32_t)ofs << 20 | (uint32_t)sig_coded << 29;
+  // where the regular-bin budget (28 for 16 coefficients) runs out: scan positions <= sw are bypass-coded
+  const int tot = __popc((unsigned)__ballot(spend & 1) & 0xffffu) + 2 * __popc((unsigned)__ballot(spend & 2) & 0xffffu) + 4 * __popc((unsigned)__ballot(spend & 4) & 0xffffu);
+  int sw = -1;
+  if (28 - tot < 4) {
+    int rb = 28;
+    for (int j = last; j >= 0; --j) {
+      if (rb < 4) { sw = j; break; }
+      rb -= __builtin_amdgcn_readlane(spend, LF_SCAN(j));
+    }
+  }
+  // ---- the sweep: every model along the positions in coding order; states only ----
+  const int r0w = rw >> 4, r1w = rw & 15;
+  const uint32_t add0 = (0x7fffu >> r0w) & 0x7fe0u, add1 = (0x7fffu >> r1w) & 0x7ffeu;
+  const uint32_t fsh = role == 0 ? 16 : 20, fmask = role == 0 ? 15u : 31u, rsel = role < 0 ? 31u : (uint32_t)role;
+  uint32_t idx[16];
+  uint32_t hits = 0;
+#pragma unroll
+  for (int j = 15; j >= 0; --j) {
+    const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)rec, LF_SCAN(j));
+    const uint32_t aj = rj & 0xffffu;
+    // per role (sig, gt1, parity, gt2): does the position code a bin with one of the role's models, and which
+    const uint32_t gates = ((rj >> 29) & 1u) | (aj != 0 ? 2u : 0u) | (aj > 1 ? 12u : 0u);
+    const uint32_t bins = (aj != 0 ? 1u : 0u) | (aj > 1 ? 2u : 0u) | ((aj & 1u) << 2) | (aj >= 4 ? 8u : 0u);
+    const bool on = j <= last && j > sw;
+    const bool hit = on && ((gates >> rsel) & 1u) && ((rj >> fsh) & fmask) == (uint32_t)k;
+    const uint32_t bin = (bins >> rsel) & 1u;
+    uint32_t s0 = st & 0xffffu, s1 = st >> 16;
+    idx[j] = (((s0 + s1) >> 8) << 1) ^ bin;
+    s0 -= (s0 >> r0w) & 0x7fe0u;
+    s1 -= (s1 >> r1w) & 0x7ffeu;
+    s0 += bin ? add0 : 0u;
+    s1 += bin ? add1 : 0u;
+    st = hit ? ((s0 & 0xffffu) | (s1 << 16)) : st;
+    hits |= hit ? 1u << j : 0u;
+  }
+  if (role >= 0 && update) m[model] = st;
+  // the last-position prefix (uvg_encode_last_significant_xy, :415-470): model q of an axis sees one bin at most -- 1 below the
+  // position's coordinate, 0 at it (none at 3)
+  const int last_r = LF_SCAN(last), pos = paxis ? last_r >> 2 : last_r & 3;
+  const bool phit = lane < 6 && pq <= pos && pq < 3;
+  const uint32_t pbin = pq < pos ? 1u : 0u;
+  uint32_t pidx;
+  {
+    uint32_t s0 = pst & 0xffffu, s1 = pst >> 16;
+    pidx = (((s0 + s1) >> 8) << 1) ^ pbin;
+    const int p0w = prw >> 4, p1w = prw & 15;
+    s0 -= (s0 >> p0w) & 0x7fe0u;
+    s1 -= (s1 >> p1w) & 0x7ffeu;
+    if (pbin) { s0 += (0x7fffu >> p0w) & 0x7fe0u; s1 += (0x7fffu >> p1w) & 0x7ffeu; }
+    if (phit && update) m[pmodel] = (s0 & 0xffffu) | (s1 << 16);
+  }
+  // ---- the bins' costs, all lookups in flight together ----
+  CTU_LDS const uint32_t *const ebits = LDSP(const uint32_t, tab_ebits());
+  uint32_t acc = 0;
+  {
+    uint32_t c[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) c[j] = ebits[idx[j]];
+    const uint32_t pc = ebits[pidx];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc += (hits >> j) & 1u ? c[j] : 0u;
+    acc += phit ? pc : 0u;
+  }
+  // ---- bypass-coded parts: remainders, bypass positions, signs ----
+  int ibits = 0;
+  if (lane < 16 && live) {
+    if (sp > sw) { if (a >= 4) ibits += coeff_remain_bits(((unsigned)a - 4) >> 1, (uint32_t)r4, 5); }
+    else {
+      const unsigned pos0 = 1u << r0;
+      ibits += coeff_remain_bits(a == 0 ? pos0 : ((unsigned)a <= pos0 ? (unsigned)a - 1 : (unsigned)a), (uint32_t)r0, 5);
+    }
+    ibits += a != 0;
+  }
+  const int racc = lf_row_sum((int)acc);
+  const unsigned q15 = (unsigned)__builtin_amdgcn_readlane(racc, 0) + (unsigned)__builtin_amdgcn_readlane(racc, 16) + (unsigned)__builtin_amdgcn_readlane(racc, 32) +
+                       (unsigned)__builtin_amdgcn_readlane(racc, 48);
+  const int ib = __builtin_amdgcn_readlane(lf_row_sum(ibits), 0);
+  WSYNC();
+  return (double)q15 / 32768.0 + (double)ib;
+}
+
 // ---- rough search --------------------------------------------------------------------------------------------------------------
 // count_bits (search_intra.c:949-984) with the predictor list in six scalars
 CTU_DEV double lf_count_bits(int p0, int p1, int p2, int p3, int p4, int p5, double planar, double not_planar, double mpm_bit, double not_mpm_bit, int mode)
@@ -265,22 +462,25 @@ template <typename PX> CTU_DEV double lf_cost(int (&d)[16], double bits, double 
 
 // search_intra_rough (search_intra.c:986-1229) for the 4x4 luma CU at (lx, ly) whose reference rows are in V; srcv: lane e < 16 holds
 // source sample e.  Returns the mode (wave-uniform).
-template <typename PX> CTU_NOINLINE CTU_DEV int leaf_rough(lds<PX> *S, const job<PX> &J, wctx *V, int x, int y, int lx, int ly, int srcv)
+template <typename PX> CTU_INLINE1 CTU_DEV int leaf_rough(lds<PX> *S, const job<PX> &J, wctx *V, int x, int y, int lx, int ly, int srcv, int (&mpm)[6])
 {
   const params &P = J.P;
   const int lane = CTU_TID;
+  LF_T0();
   int s[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_readlane(srcv, e);
   // the most probable modes and the four flag costs (every lane; wave-uniform)
   int p0, p1, p2, p3, p4, p5;
   {
+    // uvg_intra_get_dir_luma_predictor (intra.c:88-188) on scalars: the two neighbours' modes are wave-uniform
     const cu4 *l, *a;
     mpm_neighbours(S, x, y, lx, ly, 4, &l, &a);
-    int8_t preds[6];
-    dir_luma_predictor(y, preds, l, a);
-    p0 = __builtin_amdgcn_readfirstlane((int)preds[0]); p1 = __builtin_amdgcn_readfirstlane((int)preds[1]); p2 = __builtin_amdgcn_readfirstlane((int)preds[2]);
-    p3 = __builtin_amdgcn_readfirstlane((int)preds[3]); p4 = __builtin_amdgcn_readfirstlane((int)preds[4]); p5 = __builtin_amdgcn_readfirstlane((int)preds[5]);
+    int left_dir = 0, above_dir = 0;
+    if (l && l->type == CU_INTRA) left_dir = l->mode;
+    if (a && a->type == CU_INTRA && y % LCU != 0) above_dir = a->mode;
+    lf_mpm(__builtin_amdgcn_readfirstlane(left_dir), __builtin_amdgcn_readfirstlane(above_dir), mpm);
+    p0 = mpm[0]; p1 = mpm[1]; p2 = mpm[2]; p3 = mpm[3]; p4 = mpm[4]; p5 = mpm[5];
   }
   CTU_LDS const uint32_t *const mdl = LDSP(const uint32_t, V->cur);
   const double mpm_bit = m_fbits(mdl, M_MPM, 1), not_mpm_bit = m_fbits(mdl, M_MPM, 0);
@@ -307,6 +507,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int leaf_rough(lds<PX> *S, const job
     c_planar = rl64(c, 0);
     c_dc = rl64(c, 4);
   }
+  LF_T(2);
   // ---- pass A: lanes 2..63 = modes 4..65 (lanes 0, 1 idle along) ----
   double cA;
   {
@@ -323,6 +524,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int leaf_rough(lds<PX> *S, const job
     cA = lf_cost<PX>(d, lf_count_bits(p0, p1, p2, p3, p4, p5, planar, not_planar, mpm_bit, not_mpm_bit, mode), P.lambda_sqrt);
   }
   cA = lane == 0 ? c_planar : (lane == 1 ? c_dc : cA);
+  LF_T(3);
   // cost of a (wave-uniform) mode: pass A's lanes, or pass B's (lanes 0..2 = modes 2, 3, 66)
   double cB = 0;
 #define LF_LANE_A(m) ((m) < 2 ? (m) : (m) - 2)
@@ -332,20 +534,19 @@ template <typename PX> CTU_NOINLINE CTU_DEV int leaf_rough(lds<PX> *S, const job
   // ---- round 0: planar, DC, every 2^levels-th angular mode (search_intra.c:1071-1143) ----
   // The reference's three-entry list under strict "<" insertion = the three smallest under (cost, insertion sequence); DC is inserted
   // ahead of planar when the two tie (:1089-1106).  Candidates sit one per lane: (mode, cost, sequence); a lane counts who is ahead of it.
-  int offset = 1 << P.rough_levels;
-  int cm, cseq, ncand;
+  const int levels = __builtin_amdgcn_readfirstlane(P.rough_levels);
+  int offset = 1 << levels;
+  const int first_m = 2 + offset / 2;                                   // listed angular modes: first_m + k * offset <= 66
+  int ncand = 2 + (66 - first_m) / offset + 1;
+  int cm = lane < 2 ? lane : first_m + (lane - 2) * offset, cseq = lane == 0 ? 1 : (lane == 1 ? 0 : 3 + lane);
+  if (lane >= ncand) cm = 0;
   double cc;
   {
-    const int first_m = 2 + offset / 2;                                 // listed angular modes: first_m + k * offset <= 66
-    ncand = 2 + (66 - first_m) / offset + 1;
-    cm = lane < 2 ? lane : first_m + (lane - 2) * offset;
-    if (lane >= ncand) cm = 0;
-    cseq = lane == 0 ? 1 : (lane == 1 ? 0 : 3 + lane);
     const int src = LF_LANE_A(cm);                                      // (round 0 never lists a mode of pass B: first_m >= 4)
     cc = __hiloint2double(lf_shfl(__double2hiint(cA), src), lf_shfl(__double2loint(cA), src));
   }
-  unsigned long long chk_lo = 3, chk_hi = 0;                           // modes costed so far (bit m; 64..66 in chk_hi)
-  for (int k = 2; k < ncand; ++k) { const int m = 2 + offset / 2 + (k - 2) * offset; if (m < 64) chk_lo |= 1ull << m; else chk_hi |= 1ull << (m - 64); }
+  // modes costed so far: a flag in the mode's own lane of pass A / pass B
+  int seenA = (lane < 2 || (lane + 2 >= first_m && ((lane + 2 - first_m) & (offset - 1)) == 0)) ? 1 : 0, seenB = 0;
   int b0, b1, b2;
   double k0, k1, k2;
   bool have_B = false;
@@ -367,9 +568,10 @@ template <typename PX> CTU_NOINLINE CTU_DEV int leaf_rough(lds<PX> *S, const job
     const int off = offset >> 1;
     if (!(off > 0 && differs)) break;
     if (!have_B) {
-      // modes 2, 3, 66 are only reachable from the first / last listed angular mode: cost them when one of those survives
-      const int lo_m = 2 + (1 << P.rough_levels) / 2, hi_m = lo_m + ((66 - lo_m) / (1 << P.rough_levels)) * (1 << P.rough_levels);
-      const bool edge = b0 == lo_m || b1 == lo_m || b2 == lo_m || b0 == hi_m || b1 == hi_m || b2 == hi_m || b0 <= 5 || b1 <= 5 || b2 <= 5 || b0 >= 63 || b1 >= 63 || b2 >= 63;
+      // (2, 3, 66 can only be listed from a survivor within 4 of them: 2 + off, 3 +- off, 66 - off with off <= 4)
+#define LF_EDGE(b) (((b) >= 2 && (b) <= 7) || (b) >= 62)
+      const bool edge = LF_EDGE(b0) || LF_EDGE(b1) || LF_EDGE(b2);
+#undef LF_EDGE
       if (edge) {
         const int mode = lane == 0 ? 2 : (lane == 1 ? 3 : 66);
         const lf_mode M = leaf_mode(S, V, mode);
@@ -385,26 +587,24 @@ template <typename PX> CTU_NOINLINE CTU_DEV int leaf_rough(lds<PX> *S, const job
         have_B = true;
       }
     }
-    // survivors in lanes 0..2 (sequence 0..2), the new modes behind them (sequence 3 + index)
+    // survivors in lanes 0..2 (sequence 0..2), the new modes behind them (sequence 3 + index): written lane by lane from scalars
+    int cclo = __double2loint(cc), cchi = __double2hiint(cc);
+#define LF_PUT(ln, m_, c_) do { const double c__ = (c_); const bool me__ = lane == (ln); cm = me__ ? (m_) : cm; cclo = me__ ? __double2loint(c__) : cclo; \
+      cchi = me__ ? __double2hiint(c__) : cchi; } while (0)
+    LF_PUT(0, b0, k0); LF_PUT(1, b1, k1); LF_PUT(2, b2, k2);
     int n_new = 0;
-    int nm = 0;                    // this lane's new mode (lane 3 + index)
-#define LF_TRY(m_) do { const int m = (m_); if (m >= 2 && m <= 66) { const bool seen = m < 64 ? (chk_lo >> m) & 1 : (chk_hi >> (m - 64)) & 1; \
-      if (!seen) { if (lane == 3 + n_new) nm = m; ++n_new; if (m < 64) chk_lo |= 1ull << m; else chk_hi |= 1ull << (m - 64); } } } while (0)
+#define LF_TRY(m_) do { const int m = (m_); if (m >= 2 && m <= 66) { const bool inb = LF_IN_B(m); const int ln = inb ? LF_LANE_B(m) : LF_LANE_A(m); \
+      const int was = inb ? __builtin_amdgcn_readlane(seenB, ln) : __builtin_amdgcn_readlane(seenA, ln); \
+      if (!was) { if (inb) { seenB = lane == ln ? 1 : seenB; LF_PUT(3 + n_new, m, rl64(cB, ln)); } \
+                  else { seenA = lane == ln ? 1 : seenA; LF_PUT(3 + n_new, m, rl64(cA, ln)); } ++n_new; } } } while (0)
     if (b0 >= 3 && b0 <= 65) { LF_TRY(b0 - off); LF_TRY(b0 + off); }
     if (b1 >= 3 && b1 <= 65) { LF_TRY(b1 - off); LF_TRY(b1 + off); }
     if (b2 >= 3 && b2 <= 65) { LF_TRY(b2 - off); LF_TRY(b2 + off); }
 #undef LF_TRY
+#undef LF_PUT
+    cc = __hiloint2double(cchi, cclo);
     ncand = 3 + n_new;
-    cm = lane == 0 ? b0 : (lane == 1 ? b1 : (lane == 2 ? b2 : nm));
     cseq = lane;
-    {
-      // the new modes' costs: from pass A's lane, or pass B's (have_B holds whenever such a mode can be listed)
-      const bool inb = LF_IN_B(cm);
-      const int src = inb ? LF_LANE_B(cm) : LF_LANE_A(cm);
-      const double fa = __hiloint2double(lf_shfl(__double2hiint(cA), src), lf_shfl(__double2loint(cA), src));
-      const double fb = __hiloint2double(lf_shfl(__double2hiint(cB), src), lf_shfl(__double2loint(cB), src));
-      cc = lane == 0 ? k0 : (lane == 1 ? k1 : (lane == 2 ? k2 : (inb ? fb : fa)));
-    }
     offset = off;
   }
 #undef LF_LANE_A
@@ -412,6 +612,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int leaf_rough(lds<PX> *S, const job
 #undef LF_LANE_B
 #undef LF_COST
   (void)k0; (void)k1; (void)k2; (void)b1; (void)b2;
+  LF_T(4);
   return b0;
 }
 
@@ -450,12 +651,10 @@ template <typename PX> CTU_DEV int leaf_rdoq(lds<PX> *S, int coef, int color, in
   const int sp = (int)((tab >> 16) & 15), next_r = (int)((tab >> 20) & 15);
   rdoq_env E;
   E.st = S->rdoq_state; E.t = color ? 1 : 0; E.lambda = lambda;
-  const int transform_shift = 15 - bitdepth - 2;
-  E.q_bits = 14 + qp_scaled / 6 + transform_shift;
-  E.q = kQuantScales[qp_scaled % 6];
-  double scale = 32768;
-  scale = transform_shift >= 0 ? scale / kPow2[2 * transform_shift] : scale * kPow2[-2 * transform_shift];
-  E.error_scale = scale / E.q / E.q;
+  E.q_bits = __builtin_amdgcn_readfirstlane(LDSP(const int32_t, S->lf_qbits)[E.t]);
+  E.q = __builtin_amdgcn_readfirstlane(LDSP(const int32_t, S->lf_q)[E.t]);
+  E.error_scale = LDSP(const double, S->lf_escale)[E.t];
+  (void)bitdepth; (void)qp_scaled;
   const int cap_half = 1 << (E.q_bits - 1);
   const int32_t cap = 0x7fffffff - cap_half;
   const int ac = iabs_(coef);
@@ -566,14 +765,17 @@ template <typename PX> CTU_DEV int leaf_rdoq(lds<PX> *S, int coef, int color, in
 // ---- one 4x4 transform block, start to finish --------------------------------------------------------------------------------------
 // predict + uvg_quantize_residual (quant-generic.c:460-612, RDOQ branch) + reconstruction of the 4x4 block of `color` belonging to the
 // luma area (x, y) / (lx, ly) of size n (4: the luma block of a 4x4 CU; 8: a chroma block of an 8x8 area), into dst (pitch dp, LDS);
-// levels to lv_of(V, color) (LDS, for the bit count) and to co (pitch cp, the CTU's coefficient array).  refs_ready: V's reference rows
-// already belong to this block.  Returns has_coeffs; *ssd_out = the block's SSD against the source (uvg_pixels_calc_ssd).
-template <typename PX> CTU_NOINLINE CTU_DEV int leaf_recon(lds<PX> *S, const job<PX> &J, wctx *V, int color, int mode, int cbf_u, int x, int y, int lx, int ly, int n,
-                                                          int refs_ready, PX *dst_, int dp, int16_t *co, int cp, int *ssd_out)
+// levels to lv_of(V, color) (LDS) and to co (pitch cp, the CTU's coefficient array).  refs_ready: V's reference rows already belong
+// to this block.  Returns has_coeffs, the block's SSD against the source (uvg_pixels_calc_ssd) and every lane's level.
+struct lf_block { int has, ssd, level; };       // has_coeffs, SSD (wave-uniform); the level of position lane & 15
+template <typename PX> CTU_NOINLINE CTU_DEV lf_block leaf_recon(lds<PX> *S, const job<PX> &J, wctx *V, int color, int mode, int cbf_u, int x, int y, int lx, int ly, int n,
+                                                               int refs_ready, PX *dst_, int dp, int16_t *co, int cp)
 {
   const int depth = (int)px_info<PX>::depth;
   const int lane = CTU_TID, e = lane & 15, r = e >> 2, q = e & 3;
+  LF_T0();
   if (!refs_ready) leaf_refs(S, J.P, V, color, x, y, lx, ly, n);
+  LF_T(5);
   const int pred = leaf_predict(S, V, mode, color);
   const int src = leaf_src(S, color, lx, ly);
   int v = (int)(int16_t)(src - pred);
@@ -581,7 +783,9 @@ template <typename PX> CTU_NOINLINE CTU_DEV int leaf_recon(lds<PX> *S, const job
   v = lf_fwd_pass(v, 2 + 6);
   const int qps = scaled_qp<PX>(J.P, color);
   int has;
+  LF_T(6);
   const int level = leaf_rdoq(S, v, color, cbf_u, qps, color ? J.P.c_lambda_tu : J.P.lambda, &has);
+  LF_T(7);
   CTU_LDS int16_t *const lv = LDSP(int16_t, lv_of(V, color));
   if (lane < 16) { lv[e] = (int16_t)level; co[r * cp + q] = (int16_t)level; }
   int rec = pred;
@@ -599,7 +803,10 @@ template <typename PX> CTU_NOINLINE CTU_DEV int leaf_recon(lds<PX> *S, const job
   if (lane < 16) LDSP(PX, dst_)[r * dp + q] = (PX)rec;
   int dd = src - rec;
   dd = lane < 16 ? dd * dd : 0;
-  *ssd_out = __builtin_amdgcn_readfirstlane(lf_row_sum(dd)) >> (2 * (depth - 8));
+  lf_block B;
+  B.has = has; B.level = level;
+  B.ssd = __builtin_amdgcn_readfirstlane(lf_row_sum(dd)) >> (2 * (depth - 8));
   CTU_SYNC();
-  return has;
+  LF_T(8);
+  return B;
 }
