@@ -281,6 +281,10 @@ template <typename PX> struct lds {
   int32_t lf_qbits[2], lf_q[2];                     // ... q_bits, quantiser scale
   int32_t lf_tag;
   PX lf_src[96];
+  // the 64x64 candidate's chroma, taken by depth 2's wave while the walk does the luma (eval_cu64): the request's chroma mode; per
+  // 32x32 area the two flags, the two SSDs and the chroma part of the bit count
+  int32_t j64, j64_mode;
+  struct { int32_t cu, cv, ssd_u, ssd_v, cy, ssd_y; double bits, bits_y; } h64[4];      // (cy, ssd_y, bits_y: the walk's own luma part)
 #endif
   alignas(16) unsigned char arena[ARENA_BYTES];
 #if defined(CTU_PB)
@@ -2431,7 +2435,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
 #if defined(CTU_PB)
       mk = (CTU_LDS uint32_t *)S->pb.cnt_models;       // (every work[] set is some depth's here)
 #else
-      mk = (CTU_LDS uint32_t *)S->work[2];
+      mk = (CTU_LDS uint32_t *)S->work[CTU_WAVE == 0 ? 2 : 1];      // (the 64x64 candidate: the walk and depth 2's wave count at the same time)
 #endif
       for (int i = 0; i < 4; ++i) mk[M_SIGGRP + i] = m[M_SIGGRP + i];
       for (int i = M_LASTX; i < M_CBF_LUMA; ++i) mk[i] = m[i];
@@ -2637,6 +2641,9 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
   const int mode = V->u_mode;
 #endif
   if (!to_cand) { SERIAL fill_cu(S, lx, ly, n, mode, mode, sep ? 2 : ilog2_dev(n) - 1, N.split_tree, cu_mtt(N.mode_type_tree, L)); CTU_SYNC(); }
+#if defined(CTU_LEAF4)
+  if (n == 8 && !to_cand) leaf_load_area(S, J, lx, ly);          // (an 8x8 leaf: the walk's own wave)
+#endif
   // where the three blocks are reconstructed and where their levels go
   int cn = n >> 1, cx = x, cy = y;                        // the chroma area (luma coordinates) and its block size
   if (sep) { cn = 4; cx = x & ~7; cy = y & ~7; }
@@ -2682,11 +2689,27 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
       continue;
     }
 #endif
+#if defined(CTU_LEAF4)
+    if (c && n == 8) {
+      // the 4x4 chroma blocks of an 8x8 CU: the register-resident block of ctu_leaf4.h (the area's source samples are in S->lf_src)
+      CTU_T0();
+      const lf_block B = leaf_recon(S, J, V, color, mode, color == 2 ? (cbf >> 1) & 1 : 0, x, y, lx, ly, 8, 0, color == 1 ? ru : rv, rpc, color == 1 ? ku : kv, kpc);
+      LANE0 V->red[color] = B.ssd;
+      cbf |= B.has << color;
+      CTU_T1(J.W, 3);
+      continue;
+    }
+#endif
     const int has = recon_tu_inl(S, J, color, c ? cx : x, c ? cy : y, c ? cx & 63 : lx, c ? cy & 63 : ly, c ? area : n, mode, color == 2 ? (cbf >> 1) & 1 : 0,
                                  color == 0 ? ry : (color == 1 ? ru : rv), c ? rpc : rpy, color == 0 ? ky : (color == 1 ? ku : kv), c ? kpc : kpy, c ? area : n);
     cbf |= has << color;
   }
-  if (has_chroma) {
+#if defined(CTU_LEAF4)
+  if (has_chroma && n != 8)
+#else
+  if (has_chroma)
+#endif
+  {
     { CTU_T0();
     ssd_block(S, J, 1, cx & 63, cy & 63, area, 1, ru, rpc);
     ssd_block(S, J, 2, cx & 63, cy & 63, area, 2, rv, rpc);
@@ -2920,6 +2943,88 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu64(lds<PX> *S, const job
   CTU_SYNC();
   // the models are the CU's entry models and do not adapt (search_cabac.update is 0 on this path): bits only
   copy_models(S->cur, S->coder);                 // (the CTU's entry models: the coder's, untouched until its pass after the search)
+#if defined(CTU_LEAF4)
+  // The three colours of the candidate depend on nothing of each other but Cr's flag context (Cb's flag), and its models do not adapt:
+  // depth 2's wave -- idle, like every depth's, once the four 32x32 areas are decided -- reconstructs and prices the chroma of the
+  // four areas (chroma64_job) while this wave does the luma; the parts meet below in the reference's order of summation.
+  SERIAL { S->j64 = 1; S->j64_mode = mode_chroma; }
+  post_eval(S, J, 2);
+  for (int i = 0; i < 4; ++i) {
+    const int tx = x + (i & 1) * 32, ty = y + (i >> 1) * 32, lx = tx & 63, ly = ty & 63;
+    PX *ry = S->Dy + (ly + 1) * PY + lx + 1;
+    int16_t *ky = J.coeff + ly * LCU + lx;
+    const int cy = recon_tu(S, J, 0, tx, ty, lx, ly, 32, mode, 0, ry, PY, ky, LCU, 64);
+    ssd_block(S, J, 0, lx, ly, 32, 0, ry, PY);
+    double by = 0;
+    LANE0 m_code(LDSP(uint32_t, S->cur), 0, M_CBF_LUMA + 0, cy, by);
+    WSYNC();
+    if (cy) by += coeff_bits(S, S->cur, 0, lv_of(V, 0), 32, 0);
+    LANE0 { S->h64[i].cy = cy; S->h64[i].ssd_y = V->red[0]; S->h64[i].bits_y = by; }
+    CTU_SYNC();
+  }
+  wait_eval(S, 2);
+  LANE0 {
+    S->j64 = 0;
+    double bits = 0;
+    split_flag_bits(S, P, S->cur, 0, x, y, 0, 0, 64, 0, bits);
+    double mode_bits = 0;
+    {   // calc_mode_bits (search.c:988-1003): the luma mode on a copy of the models, the chroma mode without adaptation
+      for (int k = 0; k < NMODELS; ++k) S->work[2][k] = S->cur[k];
+      luma_mode_bits(S, S->work[2], 0, x, y, 0, 0, 64, mode, mode_bits);
+      if (mode_chroma == mode) mode_bits += m_fbits(S->cur, M_CHROMA_PRED, 0);
+      else mode_bits += 2.0 + m_fbits(S->cur, M_CHROMA_PRED, 1);
+    }
+    mode_bits += bits;
+    const double d0 = mode_bits * P.lambda;
+    double d1 = 0;
+    for (int i = 0; i < 4; ++i) {
+      const int lx = (i & 1) * 32, ly = (i >> 1) * 32;
+      cu_at(S, lx, ly)->cbf = (uint8_t)(S->h64[i].cy | S->h64[i].cu << 1 | S->h64[i].cv << 2);
+      // cu_rd_cost_tr_split_accurate of the area (tr_cost): SSDs + (luma bits + chroma bits) * lambda
+      const unsigned chroma_ssd = (unsigned)((unsigned)S->h64[i].ssd_u * P.cw_u) + (unsigned)((unsigned)S->h64[i].ssd_v * P.cw_v);
+      d1 += (unsigned)S->h64[i].ssd_y * 1.0 + chroma_ssd * 1.0 + (S->h64[i].bits_y + S->h64[i].bits) * P.lambda;
+    }
+    double c2 = 0;
+    c2 += d0;
+    c2 += d1 + 0 * P.lambda;          // the sum of the four blocks + luma_bits (0) * lambda (search.c:779)
+    N.cost = c2;
+    mark_deblocking(S, x, y, 0, 0, 64, 0, 1);
+  }
+  CTU_SYNC();
+}
+// the chroma of the 64x64 candidate (eval_cu64), by depth 2's wave on its own scratch: a 16x16 block is that depth's luma size, so the
+// levels of Cb and Cr take turns in its luma level array
+template <typename PX> CTU_DEV void chroma64_job(lds<PX> *S, const job<PX> &J)
+{
+  wctx *const V = wv_of(S);
+  const params &P = J.P;
+  const int x = S->lvl[0].x, y = S->lvl[0].y, mode_chroma = S->j64_mode;
+  int16_t *const keep1 = V->lv1, *const keep2 = V->lv2;
+  uint32_t *const keepc = V->cur;
+  LANE0 { V->lv1 = V->lv0; V->lv2 = V->lv0; V->cur = S->cur; }
+  CTU_SYNC();
+  for (int i = 0; i < 4; ++i) {
+    const int tx = x + (i & 1) * 32, ty = y + (i >> 1) * 32, lx = tx & 63, ly = ty & 63;
+    PX *ru = S->Du + ((ly >> 1) + 1) * PC + (lx >> 1) + 1, *rv = S->Dv + ((ly >> 1) + 1) * PC + (lx >> 1) + 1;
+    int16_t *ku = J.coeff + 4096 + (ly >> 1) * LCU_C + (lx >> 1), *kv = J.coeff + 5120 + (ly >> 1) * LCU_C + (lx >> 1);
+    const int cu = recon_tu(S, J, 1, tx, ty, lx, ly, 32, mode_chroma, 0, ru, PC, ku, LCU_C, 64);
+    ssd_block(S, J, 1, lx, ly, 32, 1, ru, PC);
+    double cb = coeff_bits(S, S->cur, 0, V->lv0, 16, 1);
+    const int cv = recon_tu(S, J, 2, tx, ty, lx, ly, 32, mode_chroma, cu, rv, PC, kv, LCU_C, 64);
+    ssd_block(S, J, 2, lx, ly, 32, 2, rv, PC);
+    cb += coeff_bits(S, S->cur, 0, V->lv0, 16, 2);
+    LANE0 {
+      double fb = 0;
+      m_code(LDSP(uint32_t, S->cur), 0, M_CBF_CB + 0, cu, fb);
+      m_code(LDSP(uint32_t, S->cur), 0, M_CBF_CR + cu, cv, fb);
+      S->h64[i].cu = cu; S->h64[i].cv = cv; S->h64[i].ssd_u = V->red[1]; S->h64[i].ssd_v = V->red[2]; S->h64[i].bits = fb + cb;
+    }
+    CTU_SYNC();
+  }
+  LANE0 { V->lv1 = keep1; V->lv2 = keep2; V->cur = keepc; }
+  CTU_SYNC();
+}
+#else
   for (int i = 0; i < 4; ++i) {
     const int tx = x + (i & 1) * 32, ty = y + (i >> 1) * 32, lx = tx & 63, ly = ty & 63;
     PX *ry = S->Dy + (ly + 1) * PY + lx + 1, *ru = S->Du + ((ly >> 1) + 1) * PC + (lx >> 1) + 1, *rv = S->Dv + ((ly >> 1) + 1) * PC + (lx >> 1) + 1;
@@ -2976,6 +3081,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu64(lds<PX> *S, const job
     CTU_SYNC();
   }
 }
+#endif
 // the split won after all: bring its result back
 template <typename PX> CTU_NOINLINE CTU_DEV void restore64(lds<PX> *S, const job<PX> &J)
 {
@@ -3044,6 +3150,9 @@ template <typename PX> CTU_DEV void worker_loop(lds<PX> *S, const job<PX> &J)
     if (r != seen) {
       if (r < 0) break;
       seen = r;
+#if defined(CTU_LEAF4)
+      if (L == 2 && S->j64) chroma64_job(S, J); else
+#endif
       eval_cu(S, J, L, 1);
       CTU_SYNC();
       LANE0 mb_store(&S->done[L], r);
@@ -3098,6 +3207,9 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
         ret = N.cost; entering = 0; if (L == 0) break; --L; continue;
       }
       SERIAL { N.type = can_intra ? CU_INTRA : CU_NOTSET; N.cost = CTU_MAX_DOUBLE; N.pending = can_intra; }
+#if defined(CTU_LEAF4)
+      if (n == 8) leaf_load_area(S, J, x & 63, y & 63);          // (the 8x8 CU's chroma blocks and the four 4x4 CUs below it read the source from there)
+#endif
       if (can_intra) { copy_models(S->work[L - 1], S->cur); post_eval(S, J, L); }          // its own wave evaluates the CU unsplit from these models ...
       // ... while the walk tries the split: its flag first (models from the CU's entry: cur still holds them)
       SERIAL {
@@ -3180,6 +3292,64 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
 // ====================================================================== the real coder's model adaptation + CTU in / out ======
 CTU_DEV int z_to_x(int z) { return (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4) | ((z >> 3) & 8); }
 
+#if defined(CTU_LEAF4)
+// the real coder's walk over an 8x8 area of four 4x4 CUs (the shape most of a detailed CTU consists of): the area's 64 + 32 levels are
+// fetched once, a lane each; every block's bins go through coeff_bits4r from registers.  Same bins in the same order as coder_pass.
+template <typename PX> CTU_DEV void coder_area4(lds<PX> *S, const job<PX> &J, int lx, int ly)
+{
+  const params &P = J.P;
+  const int lane = CTU_TID, r = lane & 15;
+  int lev_all, clev = 0;
+  {
+    const int k = lane >> 4;
+    lev_all = CTU_GLOAD(&J.coeff[(ly + (k >> 1) * 4 + (r >> 2)) * LCU + lx + (k & 1) * 4 + (r & 3)]);
+    if (lane < 32) clev = CTU_GLOAD(&J.coeff[4096 + k * 1024 + ((ly >> 1) + (r >> 2)) * LCU_C + (lx >> 1) + (r & 3)]);
+  }
+  CTU_LDS uint32_t *const m = LDSP(uint32_t, S->coder);
+  for (int k = 0; k < 4; ++k) {
+    const int clx = lx + (k & 1) * 4, cly = ly + (k >> 1) * 4, x = J.x + clx, y = J.y + cly;
+    const cu4 *c = cu_at(S, clx, cly);
+    const int mode = __builtin_amdgcn_readfirstlane((int)c->mode), cb_y = __builtin_amdgcn_readfirstlane((int)c->cbf) & 1;
+    int mpm[6];
+    {
+      const cu4 *l, *a;
+      mpm_neighbours(S, x, y, clx, cly, 4, &l, &a);
+      int left_dir = 0, above_dir = 0;
+      if (l && l->type == CU_INTRA) left_dir = l->mode;
+      if (a && a->type == CU_INTRA && y % LCU != 0) above_dir = a->mode;
+      lf_mpm(__builtin_amdgcn_readfirstlane(left_dir), __builtin_amdgcn_readfirstlane(above_dir), mpm);
+    }
+    LANE0 {
+      double dummy = 0;
+      if (k == 0)          // split flags of the enclosing quad-tree nodes that begin here (a 4x4 CU has none of its own)
+        for (int d = 0; (64 >> d) > 4; ++d) {
+          const int sz = 64 >> d;
+          if (!(lx & (sz - 1)) && !(ly & (sz - 1))) split_flag_bits(S, P, S->coder, 1, x, y, lx, ly, sz, 1, dummy);
+        }
+      lf_luma_mode_bits(S->coder, mpm, mode, dummy);
+      m_code(m, 1, M_CBF_LUMA + 0, cb_y, dummy);
+    }
+    WSYNC();
+    if (cb_y) (void)coeff_bits4r(S, m, 1, lf_shfl(lev_all, k * 16 + r), 0);
+    if (k == 3) {
+      // the area's chroma after its last luma CU: mode (the co-located luma CU is this one), cbfs of the area's first entry, levels
+      const cu4 *a = cu_at(S, lx, ly);
+      const int acbf = __builtin_amdgcn_readfirstlane((int)a->cbf), au = (acbf >> 1) & 1, av = (acbf >> 2) & 1;
+      LANE0 {
+        double dummy = 0;
+        chroma_mode_bits(S->coder, 1, c->mode_chroma, c->mode, dummy);
+        m_code(m, 1, M_CBF_CB + 0, au, dummy);
+        m_code(m, 1, M_CBF_CR + au, av, dummy);
+      }
+      WSYNC();
+      if (au) (void)coeff_bits4r(S, m, 1, lf_shfl(clev, r), 1);
+      if (av) (void)coeff_bits4r(S, m, 1, lf_shfl(clev, 16 + r), 2);
+    }
+  }
+  CTU_SYNC();
+}
+#endif
+
 // uvg_encode_coding_tree (encode_coding_tree.c:1365-1727) over the decided CTU: only which models see which bins matters here.
 // The quad tree is walked in z-order over the 4x4 units: a CU starts where a unit is aligned to its CU's size.
 template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass(lds<PX> *S, const job<PX> &J)
@@ -3193,6 +3363,12 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass(lds<PX> *S, const jo
     const cu4 *c = cu_at(S, lx, ly);
     const int n = 1 << c->log2;
     if ((lx & (n - 1)) || (ly & (n - 1))) continue;
+#if defined(CTU_LEAF4)
+    if (n == 4) {              // (4x4 CUs come as whole 8x8 areas, the first of the four at the area's origin)
+      if (!(lx & 4) && !(ly & 4)) coder_area4(S, J, lx, ly);
+      continue;
+    }
+#endif
     const int sep = n == 4, last4 = sep && (lx & 4) && (ly & 4);
     const int tus = n == 64 ? 4 : 1, tn = n == 64 ? 32 : n;
     for (int tu = 0; tu < tus; ++tu) {
@@ -3415,6 +3591,9 @@ template <typename PX> CTU_DEV void setup_waves(lds<PX> *S)
     S->vsel[k] = k;
     S->req[k] = 0; S->done[k] = 0;
     if (k == 0) { S->hreq = 0; S->hdone = 0; }
+#if defined(CTU_LEAF4)
+    if (k == 0) S->j64 = 0;
+#endif
   }
   BLK_SYNC();
 }
