@@ -611,6 +611,77 @@ def low_delay_closed_loop(device, n_seq=8, reps=2):
                     "sequences and the 2-CTU-lag wavefront inside a picture (DESIGN.md 4.12)"}
 
 
+def c3_clip(device, frames=24, with_cpu=True):
+    """BASELINE.json configs[2] as BASELINE defines it: ONE 1920x1080 8-bit clip, --gop lp-g4d3t1 --preset medium at QP 27, pictures in
+    coding order through the device's closed low-delay loop (api.LowDelayLoop with one sequence: every picture waits for the one before
+    it), wall clock from the first enqueue to the last picture's slice data.  The clip is 120 pictures (intra period 64: I at 0 and 64);
+    the frame-level state -- slice types, QPs, lambdas, reference lists, the reference encoder's own for this configuration -- comes from
+    tests/golden/ref_lowdelay_states_qp27_120frames.npz (tools/refcheck/make_ctu_goldens.py lowdelay_states; independent of the picture
+    size).  `frames` pictures of the clip are timed (the default run keeps to a prefix so that the bench finishes in minutes; the
+    rate per picture does not depend on the position in the clip).  The reference encoder's CLI on the host cores runs the WHOLE clip
+    beside it (cpu_baseline)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as Hh
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_lowdelay_states_qp27_120frames.npz"))
+    W, H, depth, qp = 1920, 1080, 8, int(g["dims"][0])
+    total = int(g["dims"][1])
+    frames = min(frames, total)
+    states = Hh.frame_states_from_records(g["meta"], g["lam"], g["refs"])[:frames]
+    src = [[tuple(torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in Hh.clip_picture(W, H, t, depth)) for t in range(frames)]]
+    loop = api.LowDelayLoop(W, H, depth, 1, states, src)
+    loop.run()                                            # warm-up (plans, first-touch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop.run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nbytes = int(sum(int(loop.row_bytes[f].sum().item()) for f in range(frames)))
+    out = {"value": round(frames / dt, 3), "unit": "frames/s (one low-delay clip, pictures strictly in sequence)", "frames_timed": frames, "clip_frames": total,
+           "wall_ms": round(1e3 * dt, 1), "slice_data_bytes": nbytes,
+           "workload": f"{W}x{H} {depth}-bit yuv420p, ONE clip, --gop lp-g4d3t1 --preset medium at QP {qp} (BASELINE.json configs[2]); per picture: closed-loop CTU search "
+                       "with the inter search on the device's own reference pictures -> deblocking -> SAO -> arithmetic coder",
+           "note": "a single sequence: nothing overlaps but the CTUs of one picture's wavefront (the P / B kernel walks a CTU on one wave; dependent pictures are not "
+                   "in flight together) -- the aggregate rate of many sequences side by side is extra_workloads.c3_low_delay_closed_loop"}
+    del loop
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline_low_delay(W, H, depth, qp, total)
+    return out
+
+
+def cpu_baseline_low_delay(W, H, depth, qp, frames):
+    """The reference encoder's CLI (oracle/_ref, AVX2 strategies, its own thread pool at the defaults) on the same clip: --gop lp-g4d3t1
+    --preset medium -q <qp>, all `frames` pictures, wall clock incl. reading the input."""
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as Hh
+    exe = os.path.join(ROOT, "oracle", "_ref", "uvg266_8" if depth == 8 else "uvg266_10")
+    if not os.access(exe, os.X_OK):
+        return None
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count()
+    with tempfile.TemporaryDirectory() as tmp:
+        yuv = os.path.join(tmp, "in.yuv")
+        with open(yuv, "wb") as f:
+            for t in range(frames):
+                for pl in Hh.clip_picture(W, H, t, depth):
+                    f.write(np.ascontiguousarray(pl).tobytes())
+        cmd = [exe, "-i", yuv, "--input-res", f"{W}x{H}", "-n", str(frames), "--gop", "lp-g4d3t1", "--preset", "medium", "-q", str(qp), "-o", os.path.join(tmp, "out.266")]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
+        except (OSError, subprocess.TimeoutExpired):
+            return None
+        dt = time.perf_counter() - t0
+        if r.returncode != 0 or not os.path.getsize(os.path.join(tmp, "out.266")):
+            return None
+    return {"value": round(frames / dt, 3), "unit": "frames/s", "cores": cores, "kind": "reference",
+            "sample": f"the whole {frames}-picture {W}x{H} clip through the reference encoder's CLI (--gop lp-g4d3t1 --preset medium -q {qp}, --threads / --owf auto on "
+                      f"{cores} host threads, AVX2 strategies), wall time {dt:.1f} s incl. reading the input"}
+
+
 def search_rows(wl, device, rank, world, dist, transport, n_pic=64, steps=3):
     """The closed-loop CTU search with every picture sharded over the ranks by CTU rows (uvghip_ctu_plan_create_rows):
     a step = one launch of this rank's band of `n_pic` pictures, between the halo it receives from the band above (last reconstruction
@@ -884,6 +955,8 @@ def main():
     ap.add_argument("--only-search-rows", action="store_true", help="time only the row-sharded closed-loop search (one rank: a band = the whole picture; development)")
     ap.add_argument("--only-clip", action="store_true", help="time only extra_workloads.c2_clip (development)")
     ap.add_argument("--only-c3", action="store_true", help="time only extra_workloads.c3_low_delay_closed_loop and print it (development)")
+    ap.add_argument("--c3-clip-frames", type=int, default=24, help="extra_workloads.c3_clip: pictures of the ONE 120-picture low-delay clip that are timed (0: skip; 120: the whole clip)")
+    ap.add_argument("--only-c3-clip", action="store_true", help="time only extra_workloads.c3_clip and print it (development)")
     ap.add_argument("--c3-sequences", type=int, default=96, help="extra_workloads.c3_low_delay_closed_loop: independent low-delay sequences side by side")
     ap.add_argument("--no-extra", action="store_true", help="do not also time the 2160p 10-bit closed loop (extra_workloads)")
     args = ap.parse_args()
@@ -906,6 +979,9 @@ def main():
         return
     if args.only_clip:
         print(json.dumps({"c2_clip": c2_clip(WORKLOADS[args.workload], device)}), flush=True)
+        return
+    if args.only_c3_clip:
+        print(json.dumps({"c3_clip": c3_clip(device, frames=args.c3_clip_frames or 24, with_cpu=not args.no_cpu_baseline)}), flush=True)
         return
     if args.only_c3:
         print(json.dumps({"c3_low_delay_closed_loop": low_delay_closed_loop(device, n_seq=args.c3_sequences)}), flush=True)
@@ -935,11 +1011,12 @@ def main():
                  "mpixels_per_s": round(ek * eF * world / eel * ewl["W"] * ewl["H"] / 1e6, 1),
                  "search_launch_ms": round(ems / max(1, eln), 2),
                  "workload": "3840x2160 10-bit yuv420p, QP 22: the same closed loop (search -> deblock -> SAO; ALF of configs[3] is in the open-loop chain only)"}
-    c3 = c3_loop = clip = None
+    c3 = c3_loop = clip = c3_one = None
     if not args.no_extra and wl_name == "1080p8" and rank == 0:
         clip = c2_clip(wl, device)
         c3 = inter_hot_path(device)
         c3_loop = low_delay_closed_loop(device, n_seq=args.c3_sequences)
+        c3_one = c3_clip(device, frames=args.c3_clip_frames, with_cpu=not args.no_cpu_baseline) if args.c3_clip_frames > 0 else None
     open_loop = None
     if not args.no_open_loop and world == 1:
         ol_steps = (max(args.group, args.open_loop_steps) + args.group - 1) // args.group * args.group
@@ -998,6 +1075,8 @@ def main():
                 out.setdefault("extra_workloads", {})["c3_inter_hot_path_open_loop"] = c3
             if c3_loop is not None:
                 out.setdefault("extra_workloads", {})["c3_low_delay_closed_loop"] = c3_loop
+            if c3_one is not None:
+                out.setdefault("extra_workloads", {})["c3_clip"] = c3_one
             if clip is not None:
                 out.setdefault("extra_workloads", {})["c2_clip"] = clip
             if open_loop is not None:

@@ -1018,6 +1018,12 @@ def moving_picture(W, H, t, depth):
     return tuple(out)
 
 
+def clip_picture(W, H, t, depth):
+    """Picture t of an arbitrarily long clip: moving_picture's motion run forth and back (the window stays inside its base picture);
+    the first 13 pictures are moving_picture's."""
+    return moving_picture(W, H, 12 - abs(t % 24 - 12), depth)
+
+
 # ---- P / B pictures: the inter search of the oracle (oracle/orc_search.c + orc_search_inter.inc) ---------------------------------
 class InterFrame(ctypes.Structure):
     """orc_inter_frame: the picture's reference lists and reference pictures, as the encoder's frame-level bookkeeping hands them over."""

@@ -357,6 +357,29 @@ def inter_crcs(W, H, depth, qp, frames):
     print("wrote inter crc", tag, "unit types per picture", types.tolist())
 
 
+def lowdelay_states(qp, frames):
+    """The frame-level state of a --gop lp-g4d3t1 --preset medium run (BASELINE configs[2]) picture by picture: slice type, QP, lambdas, the
+    reference lists.  None of it depends on the picture size or content (no rate control): taken from a 136x72 run and used by bench.py to
+    drive ONE long clip at 1080p (extra_workloads.c3_clip), for which full records would be far too large to keep."""
+    import tempfile
+    global moving_picture
+    tmp = tempfile.mkdtemp()
+    keep = moving_picture
+    moving_picture = lambda W, H, t, depth: keep(W, H, 12 - abs(t % 24 - 12), depth)      # (the window stays inside its base picture)
+    try:
+        tag = inter(136, 72, 8, qp, frames, out_dir=tmp, with_levels=False)
+    finally:
+        moving_picture = keep
+    with np.load(os.path.join(tmp, f"ref_inter_{tag}.npz")) as z:
+        meta, lam, refs = z["meta"], z["lam"], z["refs"]
+    fm, fl, fr = np.zeros((frames, 8), np.int32), np.zeros((frames, 6)), np.zeros((frames, 52), np.int32)
+    for k in range(len(meta)):
+        f = int(meta[k][0])
+        fm[f], fl[f], fr[f] = meta[k], lam[k], refs[k]
+    np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_lowdelay_states_qp{qp}_{frames}frames.npz"), dims=np.array([qp, frames], np.int32), meta=fm, lam=fl, refs=fr)
+    print("wrote low-delay states", qp, frames)
+
+
 def alf(W, H, depth, qp, frames, t0, kind, threads=1):
     """All-intra encode with --alf full: around every uvg_alf_enc_process (alf.c:5193) the picture it got (deblocked + SAO) and the
     picture it left, and the decisions the reconstruction half and the syntax work from (tools/refcheck/ctu_dump.c, record "alf"):
@@ -445,3 +468,6 @@ if __name__ == "__main__":
     merge(136, 72, 10, 27, 8, 2)
     inter(192, 128, 8, 32, 5, extra=("sao", "off"), suffix="_nosao", with_levels=False)        # final picture = the deblocked picture
     inter(136, 72, 10, 22, 4, extra=("sao", "off"), suffix="_nosao", with_levels=False)
+    inter(136, 72, 8, 27, 4, extra=("bipred", "0", "tmvp", "0"), suffix="_p_notmvp")           # P pictures only, no temporal candidate
+    inter(192, 128, 10, 24, 4, extra=("subme", "0", "early-skip", "0"), suffix="_subme0_noskip")   # integer motion only, no early skip
+    lowdelay_states(27, 120)             # the frame-level state of a 120-picture low-delay clip (bench.py c3_clip)

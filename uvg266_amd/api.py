@@ -746,7 +746,7 @@ class ClosedLoop(CtuSearch):
         """uvghip_encode_slice_rows on the plan's pictures (after run()): -> (out [n, rows, row_cap] uint8, row_bytes [n, rows] int32),
         device tensors; the slice data of picture i is out[i, r, :row_bytes[i, r]] for r = 0, 1, ..."""
         W, H = self.P.pic_w, self.P.pic_h
-        row_cap = 3 * 64 * W if row_cap is None else row_cap
+        row_cap = 3 * 64 * W * (1 if self.depth == 8 else 2) if row_cap is None else row_cap      # (the library's own bound: twice the bytes at 10 bit)
         dev = self.loop_ws.device
         if not hasattr(self, "_rows") or self._rows[0].shape[2] != row_cap:
             self._rows = (torch.empty((self.n, self.hc, row_cap), dtype=torch.uint8, device=dev), torch.zeros((self.n, self.hc), dtype=torch.int32, device=dev),
@@ -764,7 +764,7 @@ class ClosedLoop(CtuSearch):
         with alf_type, enabled (3), n_luma_aps, n_alternatives_chroma, cc_enabled (2), cc_filter_count (2), ctu_flags (u8 [7][ctus]) and
         filter_set_idx (i16 [ctus]) as numpy arrays.  -> (out, row_bytes) like encode_rows."""
         W, H = self.P.pic_w, self.P.pic_h
-        row_cap = 3 * 64 * W if row_cap is None else row_cap
+        row_cap = 3 * 64 * W * (1 if self.depth == 8 else 2) if row_cap is None else row_cap      # (the library's own bound: twice the bytes at 10 bit)
         dev = self.loop_ws.device
         out = torch.empty((self.n, self.hc, row_cap), dtype=torch.uint8, device=dev)
         nbytes = torch.zeros((self.n, self.hc), dtype=torch.int32, device=dev)
@@ -968,9 +968,10 @@ class LowDelayLoop:
             if step[0] == "I":
                 _, loop, mots = step
                 loop.run(st)
-                for s in range(self.n_seq):      # an intra picture as a reference: its units' type, no vectors
-                    mots[s][:, :, 0] = loop.cu[s][:, :, 2].to(torch.int32)
-                    mots[s][:, :, 6:8] = -1
+                with torch.cuda.stream(torch.cuda.ExternalStream(st)):      # (on the SAME stream as the search that writes loop.cu and the P / B search that reads mots)
+                    for s in range(self.n_seq):      # an intra picture as a reference: its units' type, no vectors
+                        mots[s][:, :, 0] = loop.cu[s][:, :, 2].to(torch.int32)
+                        mots[s][:, :, 6:8] = -1
                 self.rows[f], self.row_bytes[f] = loop.slice_data()
             else:
                 _, arr, ws, _ = step

@@ -161,9 +161,10 @@ extern "C" int uvghip_alf_expand_tables(int bitdepth, int n_luma_aps, const int1
     if (a >= n_luma_aps) { memset(c0, 0, sizeof(int16_t) * LN); memset(k0, 0, sizeof(int16_t) * LN); continue; }
     const int16_t *aps = luma_aps + (size_t)a * APS_WORDS, *co = aps, *ki = aps + LN, *map = aps + 2 * LN;
     const int n_filters = aps[2 * LN + CLASSES], non_linear = aps[2 * LN + CLASSES + 1];
+    if (n_filters < 1 || n_filters > CLASSES) return uvghip_set_error(hipErrorInvalidValue, "uvghip_alf_expand_tables: number of signalled luma filters");
     for (int cl = 0; cl < CLASSES; ++cl) {
       const int f = map[cl];
-      if (f < 0 || f >= CLASSES || f > n_filters) return uvghip_set_error(hipErrorInvalidValue, "uvghip_alf_expand_tables: class -> filter index");
+      if (f < 0 || f >= n_filters) return uvghip_set_error(hipErrorInvalidValue, "uvghip_alf_expand_tables: class -> filter index");
       for (int i = 0; i < LC - 1; ++i) {
         const int ci = non_linear ? ki[f * LC + i] : 0;
         if (ci < 0 || ci > 3) return uvghip_set_error(hipErrorInvalidValue, "uvghip_alf_expand_tables: clip index");

@@ -191,7 +191,7 @@ __device__ inline int merge_candidates(const frame_ctx &f, TAB &tab, COL &col, c
 {
   for (int i = 0; i < 6; ++i) { mc[i].dir = 0; mc[i].ref[0] = mc[i].ref[1] = 0; mc[i].mv[0][0] = mc[i].mv[0][1] = mc[i].mv[1][0] = mc[i].mv[1][1] = 0; }
   const neighbours nb = spatial(tab, f);
-  const int x = f.x, y = f.y, mer = f.mer_level, max_cands = f.max_cands;
+  const int x = f.x, y = f.y, mer = f.mer_level, max_cands = f.max_cands < 6 ? f.max_cands : 6;      // (mc[] has six entries whatever the caller's context says)
   int n = 0;
   if (other_mer(x, y, x, y - 1, mer) && take_spatial(nb.b1, nullptr, nullptr, &mc[n])) n++;
   if (other_mer(x, y, x - 1, y, mer) && take_spatial(nb.a1, nb.b1, nullptr, &mc[n])) n++;

@@ -111,6 +111,10 @@ extern "C" int uvghip_loop_pb_run(int bitdepth, const uvghip_loop_pb_picture_t *
            pictures[i1].search.slice_type == s0.slice_type && pictures[i1].search.frame_qp == s0.frame_qp)
       ++i1;
     const int m = i1 - i0, is_b = s0.slice_type == 0, qp = s0.params.qp;
+    // The slice's context models start from frame_qp everywhere (uvg_init_contexts with state->frame->QP: the search, the coder); the SAO
+    // decision below takes ONE QP for its models and its CTUs.  A picture whose CTUs' QP differs from the frame's (per-CTU QP offsets) is not
+    // something this loop implements: refuse it instead of deciding SAO on other models than the coder's.
+    if (s0.params.qp != s0.frame_qp) return uvghip_set_error(hipErrorInvalidValue, "uvghip_loop_pb_run: params.qp differs from frame_qp");
     const size_t o0 = (size_t)i0 * ctus;
     if (sao_type) {
       for (int i = i0; i < i1; ++i) {
