@@ -2785,7 +2785,13 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu4(lds<PX> *S, const job<
   LF_T(1);
   mode = leaf_rough(S, J, V, x, y, lx, ly, leaf_src(S, 0, lx, ly), mpm);
   CTU_T1(J.W, 0); }
-  SERIAL fill_cu(S, lx, ly, 4, mode, mode, 2, N.split_tree, cu_mtt(N.mode_type_tree, 4));
+  LANE0 {          // lcu_fill_cu_info (search.c:314-353) for the one entry of a 4x4 CU
+    cu4 *c = cu_at(S, lx, ly);
+    c->type = CU_INTRA; c->log2 = 2; c->log2_c = 2; c->mode = (int8_t)mode; c->mode_chroma = (int8_t)mode;
+    scratch *const W = S->scr;
+    W->tree[(ly >> 2) * 16 + (lx >> 2)] = (uint16_t)N.split_tree;
+    W->mtt[(ly >> 2) * 16 + (lx >> 2)] = (uint16_t)cu_mtt(N.mode_type_tree, 4);
+  }
   CTU_SYNC();
   const int cx = x & ~7, cy = y & ~7, clx = cx & 63, cly = cy & 63;          // the chroma area
   PX *const ry = S->Dy + (ly + 1) * PY + lx + 1;
@@ -2994,7 +3000,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu64(lds<PX> *S, const job
 }
 // the chroma of the 64x64 candidate (eval_cu64), by depth 2's wave on its own scratch: a 16x16 block is that depth's luma size, so the
 // levels of Cb and Cr take turns in its luma level array
-template <typename PX> CTU_DEV void chroma64_job(lds<PX> *S, const job<PX> &J)
+template <typename PX> CTU_NOINLINE CTU_DEV void chroma64_job(lds<PX> *S, const job<PX> &J)
 {
   wctx *const V = wv_of(S);
   const params &P = J.P;

@@ -364,13 +364,15 @@ template <typename PX> CTU_DEV double coeff_bits4r(lds<PX> *S, CTU_LDS uint32_t 
   uint32_t hits = 0;
 #pragma unroll
   for (int j = 15; j >= 0; --j) {
+    idx[j] = 0;
+    if (j > last || j <= sw) continue;              // (wave-uniform: the steps beyond the last position / behind the budget's end cost nothing)
     const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)rec, LF_SCAN(j));
     const uint32_t aj = rj & 0xffffu;
     // per role (sig, gt1, parity, gt2): does the position code a bin with one of the role's models, and which
     const uint32_t gates = ((rj >> 29) & 1u) | (aj != 0 ? 2u : 0u) | (aj > 1 ? 12u : 0u);
+    if (gates == 0) continue;
     const uint32_t bins = (aj != 0 ? 1u : 0u) | (aj > 1 ? 2u : 0u) | ((aj & 1u) << 2) | (aj >= 4 ? 8u : 0u);
-    const bool on = j <= last && j > sw;
-    const bool hit = on && ((gates >> rsel) & 1u) && ((rj >> fsh) & fmask) == (uint32_t)k;
+    const bool hit = ((gates >> rsel) & 1u) && ((rj >> fsh) & fmask) == (uint32_t)k;
     const uint32_t bin = (bins >> rsel) & 1u;
     uint32_t s0 = st & 0xffffu, s1 = st >> 16;
     idx[j] = (((s0 + s1) >> 8) << 1) ^ bin;
@@ -402,9 +404,9 @@ template <typename PX> CTU_DEV double coeff_bits4r(lds<PX> *S, CTU_LDS uint32_t 
   uint32_t acc = 0;
   {
     uint32_t c[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) c[j] = ebits[idx[j]];
     const uint32_t pc = ebits[pidx];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { c[j] = 0; if (j <= last && j > sw) c[j] = ebits[idx[j]]; }
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc += (hits >> j) & 1u ? c[j] : 0u;
     acc += phit ? pc : 0u;
