@@ -2365,19 +2365,23 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
   }
   const int compact = !t && n == 4;     // 4x4 luma: set offsets 0, 6..20 -> k 0, 1..15
   const int nk0 = t ? 8 : 12, nks = t ? 11 : (compact ? 16 : 21);
-  const int sweeps = nk0 + 3 * nks <= 64 ? 1 : 2;
-  for (int sweep = 0; sweep < sweeps; ++sweep) {
+  // 8 + 3 * 11 chroma / 12 + 3 * 16 compact-luma models fit the 64 lanes; other luma blocks have 12 + 3 * 21 = 75: there the lanes 0..20
+  // own a SECOND model (greater-2, set k = lane) beside their first -- one walk over the positions serves both (the two lookups of a
+  // step are in flight together; two walks cost twice the steps)
+  const bool dual = nk0 + 3 * nks > 64;
+  {
     int role = -1, k = 0;
-    if (sweeps == 1) {
+    if (!dual) {
       if (lane < nk0) { role = 0; k = lane; }
       else if (lane < nk0 + 3 * nks) { role = 1 + (lane - nk0) / nks; k = (lane - nk0) % nks; }
       if (compact && role > 0 && k > 0) k += 5;
-    } else if (sweep == 0) { if (lane < 12) { role = 0; k = lane; } else if (lane < 33) { role = 1; k = lane - 12; } else if (lane < 54) { role = 2; k = lane - 33; } }
-    else if (lane < 21) { role = 3; k = lane; }
+    } else { if (lane < 12) { role = 0; k = lane; } else if (lane < 33) { role = 1; k = lane - 12; } else if (lane < 54) { role = 2; k = lane - 33; } }
+    const bool two = dual && lane < 21;
     const int model = role < 0 ? 0 : (role == 0 ? M_SIG + 12 * t : role == 1 ? M_GT1 + 21 * t : role == 2 ? M_PAR + 21 * t : M_GT2 + 21 * t) + k;
-    uint32_t st = m[model];
-    const int r0 = kRate[model] >> 4, r1 = kRate[model] & 15;
-    const uint32_t add0 = (0x7fffu >> r0) & 0x7fe0u, add1 = (0x7fffu >> r1) & 0x7ffeu;
+    const int model2 = M_GT2 + 21 * t + (two ? lane : 0);
+    uint32_t st = m[model], st2 = m[model2];
+    const int r0 = kRate[model] >> 4, r1 = kRate[model] & 15, q0 = kRate[model2] >> 4, q1 = kRate[model2] & 15;
+    const uint32_t add0 = (0x7fffu >> r0) & 0x7fe0u, add1 = (0x7fffu >> r1) & 0x7ffeu, bdd0 = (0x7fffu >> q0) & 0x7fe0u, bdd1 = (0x7fffu >> q1) & 0x7ffeu;
     // what a record must show for this lane's model to code a bin: field (sig: bits 16..19, others: 20..24) == k, and the gate
     const uint32_t fsh = role == 0 ? 16 : 20, fmask = role == 0 ? 15u : 31u, rsel = role < 0 ? 31u : (uint32_t)role;
     CTU_LDS const uint32_t *const ebits = LDSP(const uint32_t, tab_ebits());
@@ -2405,9 +2409,22 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
         s1 += bin ? add1 : 0u;
         st = hit ? ((s0 & 0xffffu) | (s1 << 16)) : st;
         acc += hit ? cost : 0u;
+        if (dual && (gates & 8u)) {                 // (wave-uniform: the position codes a greater-2 bin)
+          const bool hit2 = two && ((rj >> 20) & 31u) == (uint32_t)lane;
+          const uint32_t bin2 = (bins >> 3) & 1u;
+          uint32_t t0 = st2 & 0xffffu, t1 = st2 >> 16;
+          const uint32_t cost2 = ebits[(((t0 + t1) >> 8) << 1) ^ bin2];
+          t0 -= (t0 >> q0) & 0x7fe0u;
+          t1 -= (t1 >> q1) & 0x7ffeu;
+          t0 += bin2 ? bdd0 : 0u;
+          t1 += bin2 ? bdd1 : 0u;
+          st2 = hit2 ? ((t0 & 0xffffu) | (t1 << 16)) : st2;
+          acc += hit2 ? cost2 : 0u;
+        }
       }
     }
     if (role >= 0 && update) m[model] = st;
+    if (two && update) m[model2] = st2;
     q15 += acc;
   }
   RQ_T(30);
