@@ -34,6 +34,10 @@ struct row_state {
   uint16_t scan[1360];                 // diagonal scans of 32, 16, 8, 4 (scan_base)
   int16_t lv[1024];                    // the levels of the transform block being coded, raster
   struct cui { uint8_t type, log2w, cbf, mode, mode_c, skipped, pad[2]; } cu[17 * 17];      // the CTU's side information + the row / column before it
+  // what stage() finds out about the staged block with all lanes, so that the coding lane does not walk 1024 positions for it: the last
+  // significant scan position (-1: none), the groups that hold a level by scan index / by raster position (the last group counted in)
+  int32_t ci_last;
+  unsigned long long ci_cg, ci_r;
 };
 // P / B slices: the CTU's motion for the AMVP predictors (the table uvg_inter_get_mv_cand_cua reads of the picture's cu array), the row's
 // history table, the picture's reference lists
@@ -229,19 +233,10 @@ __device__ __forceinline__ void code_coeffs(coder &c, row_state *R, int n, int c
   const int l2 = ilog2_dev(n), nn = n * n, cgw = n >> 2, t = color ? 1 : 0;
   const uint16_t *scan = R->scan + scan_base(l2);
   const int16_t *lv = R->lv;
-  int last = -1;
-  for (int sp = nn - 1; sp >= 0; --sp) if (lv[scan[sp]]) { last = sp; break; }
+  const int last = R->ci_last;                         // (stage() looked at the whole block with all lanes)
   if (last < 0) return;
-  unsigned long long sig_cg = 0, sig_r = 0;            // per group, by scan index / by raster position: has a level
-  for (int g = 0; g <= (last >> 4); ++g) {
-    int any = 0;
-    for (int k = 0; k < 16; ++k) any |= lv[scan[g * 16 + k]] != 0;
-    if (any || g == (last >> 4)) {                     // (the last group counts as significant for its neighbours)
-      const int f = scan[g * 16];
-      sig_cg |= 1ull << g;
-      sig_r |= 1ull << (((f >> l2) >> 2) * cgw + ((f & (n - 1)) >> 2));
-    }
-  }
+  const unsigned long long sig_cg = R->ci_cg, sig_r = R->ci_r;      // per group, by scan index / by raster position: has a level
+  (void)nn;
   const int cg_last = last >> 4;
   {   // uvg_encode_last_significant_xy
     const int pos_last = scan[last], last_y = pos_last >> l2, last_x = pos_last - (last_y << l2);
@@ -365,8 +360,34 @@ __device__ __forceinline__ const row_state::cui &cu_of(const row_state *R, int x
 __device__ __forceinline__ void stage(row_state *R, const int16_t *src, int stride, int n)        // all lanes: n x n levels -> R->lv
 {
   __syncthreads();
-  const int l2 = ilog2_dev(n);
-  for (int e = threadIdx.x; e < n * n; e += blockDim.x) R->lv[e] = src[(e >> l2) * stride + (e & (n - 1))];
+  const int l2 = ilog2_dev(n), nn = n * n, cgw = n >> 2;
+  for (int e = threadIdx.x; e < nn; e += blockDim.x) R->lv[e] = src[(e >> l2) * stride + (e & (n - 1))];
+  __syncthreads();
+  // (one wave per row: blockDim.x == 64)
+  const uint16_t *scan = R->scan + scan_base(l2);
+  int last = -1;
+  for (int sp = threadIdx.x; sp < nn; sp += 64) if (R->lv[scan[sp]]) last = sp;
+  for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(last, o, 64); last = v > last ? v : last; }
+  unsigned long long cg = 0, rr = 0;
+  if (last >= 0) {
+    const int g = threadIdx.x;
+    bool mine = false;
+    unsigned long long rb = 0;
+    if (g <= (last >> 4)) {
+      int any = 0;
+      for (int k = 0; k < 16; ++k) any |= R->lv[scan[g * 16 + k]] != 0;
+      if (any || g == (last >> 4)) {                     // (the last group counts as significant for its neighbours)
+        const int f = scan[g * 16];
+        mine = true;
+        rb = 1ull << (((f >> l2) >> 2) * cgw + ((f & (n - 1)) >> 2));
+      }
+    }
+    cg = __ballot(mine);
+    unsigned lo = (unsigned)rb, hi = (unsigned)(rb >> 32);
+    for (int o = 32; o >= 1; o >>= 1) { lo |= (unsigned)__shfl_xor((int)lo, o, 64); hi |= (unsigned)__shfl_xor((int)hi, o, 64); }
+    rr = (unsigned long long)hi << 32 | lo;
+  }
+  if (threadIdx.x == 0) { R->ci_last = last; R->ci_cg = cg; R->ci_r = rr; }
   __syncthreads();
 }
 
