@@ -353,7 +353,7 @@ def ctu_search_traffic(pictures):
     if not isinstance(t, dict):
         return None
     here = os.path.dirname(os.path.abspath(__file__))
-    sha = hashlib.sha1(b"".join(open(os.path.join(here, "uvg266_amd", "csrc", f), "rb").read() for f in ("ctu_core.h", "ctu_search.hip"))).hexdigest()
+    sha = hashlib.sha1(b"".join(open(os.path.join(here, "uvg266_amd", "csrc", f), "rb").read() for f in ("ctu_core.h", "ctu_leaf4.h", "ctu_search.hip"))).hexdigest()
     return t["bytes_per_picture"] * pictures if t.get("source_sha1") == sha else None
 
 
