@@ -1060,14 +1060,16 @@ def main():
                              "traffic": ctu_search_traffic(F),
                              "avg_launch_ms": round(launch_ms, 3), "alg_bytes_per_launch": byts, "launches_timed": launches, "launches_in_flight": n_groups,
                              "effective_gbs": round(byts * launches / elapsed / 1e9, 3),
-                             "note": "the dominant kernel (> 99 % of the step) is the whole-CTU search: one workgroup walks one CTU's quad tree, "
-                                     "CTUs of a picture are a wavefront of dependent workgroups.  It is bound by the dependency chain inside a CTU "
-                                     "(serial RD bookkeeping on one lane at ~8 cycles per instruction; DESIGN.md section 4.6 has the phase profile), "
-                                     "not by HBM: achieved = algorithmic bytes (source in, reconstruction / levels / side information / models out) "
-                                     "/ average launch duration from HIP events on the launch stream.  traffic (PMC, fabric side of the L2) is two orders of magnitude above "
-                                     "the algorithmic bytes and is not re-reads of them: it is the call stack -- callee-saved VGPRs saved and reloaded "
-                                     "by the out-of-line functions of the 133 KB kernel (SQ_INSTS_VMEM_WR 29 k per CTU), written through to the fabric "
-                                     "(TCC_EA0_WRREQ 73 k 64-byte requests per CTU, L2 hit rate 89 %); ~0.6 TB/s while the kernel runs, 7 % of the peak"},
+                             "note": "the dominant kernel (~ 90 % of the GPU time of the step) is the whole-CTU search: one workgroup walks one CTU's quad tree, "
+                                     "CTUs of a picture are a wavefront of dependent workgroups.  It is an instruction chain per CTU, not a streaming kernel "
+                                     "(DESIGN.md 4.13: a lone wave pays ~8 cycles per dependent instruction, an LDS round trip 52): achieved = algorithmic bytes "
+                                     "(source in, reconstruction / levels / side information / models out) / average launch duration from HIP events on the "
+                                     "launch stream.  Round-5 counters (profiles/r05_bench_sq_insts.json, _sq_occupancy.json, one launch in flight): 4.3 M VALU + "
+                                     "3.0 M scalar + 0.4 M LDS instructions per CTU (round 4: 10.4 M + 7.1 M), i.e. ~58 % of the wave64 VALU issue peak while it "
+                                     "runs, 57 % of the wave cycles waiting.  traffic (PMC FETCH_SIZE x 2 + WRITE_SIZE, fabric side of the L2, "
+                                     "profiles/r05_bench_hbm_traffic.json) is ~114 x the algorithmic bytes (round 3: 197 x): the call stack of the out-of-line "
+                                     "functions (callee-saved VGPRs written through to the fabric) and the per-workgroup global scratch, not re-reads of the "
+                                     "pictures; ~0.34 TB/s while the kernel runs, 4 % of the peak"},
             }
             if extra is not None:
                 out["extra_workloads"] = {"2160p10_closed_loop": extra}
