@@ -1002,7 +1002,7 @@ def main():
     extra = None
     if not args.no_extra and wl_name == "1080p8":
         ewl = WORKLOADS["2160p10alf"]
-        ek, eF = 6, max(1, args.in_flight // 2)          # (a 4K picture has 93 diagonals of at most 34 CTUs: 80 pictures keep 768 workgroups fed)
+        ek, eF = 8, max(1, args.in_flight // 2)          # (a 4K picture has 93 diagonals of at most 34 CTUs: 80 pictures keep 768 workgroups fed)
         ecl, eF, eel, ems, eln = closed_loop(ewl, ek, 2, eF, device, rank, world, dist, args.groups)
         if parity is not None:
             parity.append(parity_check(ecl[0], "ref_ctucrc_3840x2160_10_qp22"))

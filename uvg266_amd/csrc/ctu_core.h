@@ -2819,14 +2819,11 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu4(lds<PX> *S, const job<
 #if defined(CTU_PROFILE)
   if (has_chroma) { LANE0 J.W->prof[1][helped ? 19 : 20] += 1; }
 #endif
-  int ssd_y = 0, ssd_u = 0, ssd_v = 0, cbf, lev_y, lev_u = 0, lev_v = 0;
+  int ssd_y = 0, ssd_u = 0, ssd_v = 0, cbf = 0, lev_y = 0, lev_u = 0, lev_v = 0;
   { CTU_T0();
-  {
-    const lf_block B = leaf_recon(S, J, V, 0, mode, 0, x, y, lx, ly, 4, 1, ry, PY, ky, LCU);
-    cbf = B.has; ssd_y = B.ssd; lev_y = B.level;
-  }
-  if (has_chroma) {
-    if (helped) {
+#pragma nounroll
+  for (int color = 0; color < (has_chroma ? 3 : 1); ++color) {          // ONE call site of the block function (see leaf_recon)
+    if (helped && color == 1) {
 #if defined(CTU_PROFILE)
       const unsigned long long tw = __builtin_amdgcn_s_memtime();
 #endif
@@ -2836,12 +2833,13 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu4(lds<PX> *S, const job<
 #if defined(CTU_PROFILE)
       LANE0 J.W->prof[1][21] += __builtin_amdgcn_s_memtime() - tw;
 #endif
-    } else {
-      const lf_block B = leaf_recon(S, J, V, 1, mode, 0, cx, cy, clx, cly, 8, 0, ru, PC, ku, LCU_C);
-      cbf |= B.has << 1; ssd_u = B.ssd; lev_u = B.level;
+      continue;
     }
-    const lf_block B = leaf_recon(S, J, V, 2, mode, (cbf >> 1) & 1, cx, cy, clx, cly, 8, 0, rv, PC, kv, LCU_C);
-    cbf |= B.has << 2; ssd_v = B.ssd; lev_v = B.level;
+    const bool c = color != 0;
+    const lf_block B = leaf_recon_inl(S, J, V, color, mode, color == 2 ? (cbf >> 1) & 1 : 0, c ? cx : x, c ? cy : y, c ? clx : lx, c ? cly : ly, c ? 8 : 4, c ? 0 : 1,
+                                      color == 0 ? ry : (color == 1 ? ru : rv), c ? PC : PY, color == 0 ? ky : (color == 1 ? ku : kv), c ? LCU_C : LCU);
+    cbf |= B.has << color;
+    if (color == 0) { ssd_y = B.ssd; lev_y = B.level; } else if (color == 1) { ssd_u = B.ssd; lev_u = B.level; } else { ssd_v = B.ssd; lev_v = B.level; }
   }
   CTU_T1(J.W, 3); }
   CTU_T0();

@@ -770,8 +770,8 @@ template <typename PX> CTU_DEV int leaf_rdoq(lds<PX> *S, int coef, int color, in
 // levels to lv_of(V, color) (LDS) and to co (pitch cp, the CTU's coefficient array).  refs_ready: V's reference rows already belong
 // to this block.  Returns has_coeffs, the block's SSD against the source (uvg_pixels_calc_ssd) and every lane's level.
 struct lf_block { int has, ssd, level; };       // has_coeffs, SSD (wave-uniform); the level of position lane & 15
-template <typename PX> CTU_NOINLINE CTU_DEV lf_block leaf_recon(lds<PX> *S, const job<PX> &J, wctx *V, int color, int mode, int cbf_u, int x, int y, int lx, int ly, int n,
-                                                               int refs_ready, PX *dst_, int dp, int16_t *co, int cp)
+template <typename PX> CTU_INLINE1 CTU_DEV lf_block leaf_recon_inl(lds<PX> *S, const job<PX> &J, wctx *V, int color, int mode, int cbf_u, int x, int y, int lx, int ly, int n,
+                                                                  int refs_ready, PX *dst_, int dp, int16_t *co, int cp)
 {
   const int depth = (int)px_info<PX>::depth;
   const int lane = CTU_TID, e = lane & 15, r = e >> 2, q = e & 3;
@@ -811,4 +811,11 @@ template <typename PX> CTU_NOINLINE CTU_DEV lf_block leaf_recon(lds<PX> *S, cons
   CTU_SYNC();
   LF_T(8);
   return B;
+}
+// (an out-of-line call saves and reloads ~45 callee-saved VGPRs through the stack -- 2.5 k cycles a block: the CU evaluations have ONE
+// call site each, a loop over the colours around the inlined body; the rare helper goes through this copy)
+template <typename PX> CTU_NOINLINE CTU_DEV lf_block leaf_recon(lds<PX> *S, const job<PX> &J, wctx *V, int color, int mode, int cbf_u, int x, int y, int lx, int ly, int n,
+                                                               int refs_ready, PX *dst_, int dp, int16_t *co, int cp)
+{
+  return leaf_recon_inl(S, J, V, color, mode, cbf_u, x, y, lx, ly, n, refs_ready, dst_, dp, co, cp);
 }
