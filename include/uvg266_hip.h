@@ -1049,6 +1049,10 @@ UVGHIP_API int uvghip_write_picture_nals(int poc, int sao, const uint8_t *rows, 
 /* the same with a slice QP offset: sh_qp_delta = state->frame->QP - cfg.qp (the intra QP offset of the first picture of a low-delay stream) */
 UVGHIP_API int uvghip_write_idr_nals(int poc, int qp_delta, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
                                      const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len);
+/* the same with the POC width of the stream's SPS: poc_lsb_bits = encoder_control->poc_lsb_bits = max(4, ceil_log2(2 gop_len + 1))
+ * (src/encoder.c:242; ph_pic_order_cnt_lsb, src/encoder_state-bitstream.c:1041-1042).  The two functions above write 4 bits. */
+UVGHIP_API int uvghip_write_idr_nals_ra(int poc, int poc_lsb_bits, int qp_delta, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes,
+                                        int n_rows, const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len);
 /* ... and for a P / B picture of a low-delay stream (pictype TRAIL, one temporal layer, long start code).
  * replaces: uvg_encoder_state_write_bitstream_slice_header (src/encoder_state-bitstream.c:1248-1411) with _picture_header (:1009-1139)
  * and _ref_pic_list (:1141-1246): inter / intra slice allowed, ph_pic_temporal_mvp_enabled_flag, slice type, the reference picture
@@ -1059,6 +1063,15 @@ UVGHIP_API int uvghip_write_idr_nals(int poc, int qp_delta, int sao, const uint8
 UVGHIP_API int uvghip_write_picture_nals_pb(int poc, int poc_lsb_bits, int slice_type, int n_ref_neg, const int32_t *delta_neg, int copy_rpl1, int tmvp,
                                             int qp_delta, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
                                             const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len);
+/* ... and for a P / B picture of a random-access stream (--gop 8 / --gop 16, the hierarchical structures of src/gop.h; what --preset
+ * medium and slower run with): the same syntax with list 1 holding the references in the FUTURE -- num_ref_entries[1] and its entries
+ * with strp_entry_sign_flag 0 (:1200-1234), sh_num_ref_idx_active_minus1[1] when it has more than one (:1237-1241).  delta_pos[n_ref_pos]:
+ * POC of the reference - poc, in the order of the GOP entry's ref_pos[] restricted to the pictures in the reference buffer (ascending);
+ * delta_neg likewise from ref_neg[].  poc_lsb_bits: max(4, ceil_log2(2 gop_len + 1)) (src/encoder.c:242; 6 for --gop 16).  Pictures of
+ * such a stream are written in CODING order. */
+UVGHIP_API int uvghip_write_picture_nals_ra(int poc, int poc_lsb_bits, int slice_type, int n_ref_neg, const int32_t *delta_neg, int n_ref_pos,
+                                            const int32_t *delta_pos, int tmvp, int qp_delta, int sao, const uint8_t *rows, size_t row_pitch,
+                                            const int32_t *row_bytes, int n_rows, const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len);
 
 /* ... of a picture of an --alf on / --alf full all-intra stream: the ALF APS NAL units written in front of the slice
  * (uvg_encode_alf_adaptive_parameter_set, src/alf.c:1610 -> encode_alf_aps :1575, encoder_state_write_adaptation_parameter_set :1547,

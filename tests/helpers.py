@@ -1335,9 +1335,13 @@ def inter_pictures_from_golden(g):
     W, H, depth, qp0, frames = (int(a) for a in g["dims"])
     wc, hc = (W + 63) // 64, (H + 63) // 64
     import zlib
-    pics = [moving_picture(W, H, t, depth) for t in range(frames)]
+    gen = clip_picture if ("clip" in g.files and int(g["clip"])) else moving_picture
+    shown = [gen(W, H, t, depth) for t in range(frames)]
     for t in range(frames):
-        assert zlib.crc32(b"".join(p.tobytes() for p in pics[t])) == int(g["src_crc"][t]), "the sequence generator drifted from the golden's source"
+        assert zlib.crc32(b"".join(p.tobytes() for p in shown[t])) == int(g["src_crc"][t]), "the sequence generator drifted from the golden's source"
+    # every per-picture array of the golden is in CODING order; the source of coded picture f is display picture display[f] (random access)
+    display = [int(a) for a in g["display"]] if "display" in g.files else list(range(frames))
+    pics = [shown[display[f]] for f in range(frames)]
     P = {}
     for k in range(len(g["meta"])):
         fr, x, y = (int(a) for a in g["meta"][k][:3])
@@ -1360,3 +1364,28 @@ def inter_pictures_from_golden(g):
     for a, b in zip(g["cuinter_i"], g["cuinter_d"]):
         P[int(a[0])]["cuinter"].append((a, b))
     return W, H, depth, pics, P
+
+
+def is_random_access(g):
+    return "display" in g.files and not np.array_equal(g["display"], np.arange(len(g["display"])))
+
+
+def poc_lsb_bits(g):
+    """encoder_control->poc_lsb_bits (src/encoder.c:242) of golden g's stream: --gop 16 for the random-access goldens, else 4."""
+    return max(4, int(np.ceil(np.log2(2 * 16 + 1)))) if is_random_access(g) else 4
+
+
+def write_inter_nals(L, g, poc, slice_type, ref_pocs, bipred, tmvp, qp_delta, rows, sizes, sums, out, n):
+    """The NAL units of a P / B picture of golden g's stream from the library's host functions: uvghip_write_picture_nals_pb for a low-delay
+    stream, uvghip_write_picture_nals_ra for a random-access one (g has `display`: pictures coded out of order, references in the future,
+    poc_lsb_bits from the GOP length, src/encoder.c:242)."""
+    import ctypes
+    hc = len(sizes)
+    neg = np.ascontiguousarray(sorted(poc - p for p in ref_pocs if p < poc), np.int32)
+    pos = np.ascontiguousarray(sorted(p - poc for p in ref_pocs if p > poc), np.int32)
+    if is_random_access(g):
+        return L.uvghip_write_picture_nals_ra(poc, poc_lsb_bits(g), slice_type, len(neg), ptr(neg), len(pos), ptr(pos) if len(pos) else None, tmvp, qp_delta, 1, ptr(rows), rows.shape[1],
+                                              ptr(sizes), hc, ptr(sums), ptr(out), len(out), ctypes.byref(n))
+    assert len(pos) == 0
+    return L.uvghip_write_picture_nals_pb(poc, 4, slice_type, len(neg), ptr(neg), bipred, tmvp, qp_delta, 1, ptr(rows), rows.shape[1], ptr(sizes), hc,
+                                          ptr(sums), ptr(out), len(out), ctypes.byref(n))

@@ -158,9 +158,11 @@ def test_device_outputs_complete_a_multi_picture_stream(hip, name):
 
 
 @pytest.mark.parametrize("name", ["ref_inter_136x72_10_qp22_4frames", "ref_inter_192x128_8_qp17_5frames", "ref_inter_264x136_8_qp32_9frames",
-                                  "ref_inter_136x72_8_qp27_4frames_p_notmvp", "ref_inter_192x128_10_qp24_4frames_subme0_noskip"])
+                                  "ref_inter_136x72_8_qp27_4frames_p_notmvp", "ref_inter_192x128_10_qp24_4frames_subme0_noskip",
+           "ref_inter_136x72_8_qp27_17frames_ra16"])
 def test_whole_low_delay_file_from_rows_and_final_pictures(name):
-    """A low-delay stream (--gop lp-g4d3t1): behind the encoder's parameter sets, the IDR picture's NAL units (with its slice QP offset)
+    """A low-delay stream (--gop lp-g4d3t1) or a random-access one (--gop 16: pictures in coding order, lists with references in the future,
+    six POC bits): behind the encoder's parameter sets, the IDR picture's NAL units (with its slice QP offset)
     and every B picture's -- picture header with the inter flags, slice type, reference picture lists, collocated picture, QP offset,
     entry points, the rows, the hash SEI -- from the library's host functions make up the encoder's whole .266."""
     import os
@@ -187,13 +189,11 @@ def test_whole_low_delay_file_from_rows_and_final_pictures(name):
         out = np.zeros(cap, np.uint8)
         n = ctypes.c_size_t(0)
         if slice_type == 2:
-            rc = L.uvghip_write_idr_nals(poc, frame_qp - qp0, 1, H.ptr(rows), rows.shape[1], H.ptr(sizes), hc, H.ptr(sums), H.ptr(out), cap, ctypes.byref(n))
+            rc = L.uvghip_write_idr_nals_ra(poc, H.poc_lsb_bits(g), frame_qp - qp0, 1, H.ptr(rows), rows.shape[1], H.ptr(sizes), hc, H.ptr(sums), H.ptr(out), cap, ctypes.byref(n))
         else:
             n_refs = int(g["refs"][k][0])
-            deltas = np.ascontiguousarray(sorted(poc - int(p) for p in g["refs"][k][1:1 + n_refs]), np.int32)
             cfg = g["cfg"] if "cfg" in g.files else (1, 6, 2, 1, 4, 1)
-            rc = L.uvghip_write_picture_nals_pb(poc, 4, slice_type, n_refs, H.ptr(deltas), int(cfg[3]), int(cfg[0]), frame_qp - qp0, 1, H.ptr(rows), rows.shape[1], H.ptr(sizes), hc,
-                                                H.ptr(sums), H.ptr(out), cap, ctypes.byref(n))
+            rc = H.write_inter_nals(L, g, poc, slice_type, [int(p) for p in g["refs"][k][1:1 + n_refs]], int(cfg[3]), int(cfg[0]), frame_qp - qp0, rows, sizes, sums, out, n)
         assert rc == 0
         mine += out[:n.value].tobytes()
     at = stream.find(b"\x00\x00\x01\x00\x41")

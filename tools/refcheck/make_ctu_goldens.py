@@ -255,10 +255,18 @@ def moving_picture(W, H, t, depth):
     return helpers.moving_picture(W, H, t, depth)
 
 
-def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_dir=None):
-    """Low-delay inter encode (--gop lp-g4d3t1, BASELINE configs[2]): per picture the reference lists and the picture after the in-loop
+def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_dir=None, clip=False):
+    """Inter encode -- low delay (--gop lp-g4d3t1, BASELINE configs[2]) unless `extra` names another GOP ("gop", "16": the random-access
+    structure --preset medium / slow run with by default): per picture the reference lists and the picture after the in-loop
     filters, per CTU the side information incl. motion, the levels and the reconstruction before the filters -- what a reconstruction
-    of the encoder's decisions (motion compensation + residual) needs."""
+    of the encoder's decisions (motion compensation + residual) needs.  Every per-picture array is in CODING order; `display[f]` is the
+    display index (= the source picture) of coded picture f.  clip: sources from helpers.clip_picture (any length) instead of moving_picture."""
+    if clip:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import helpers
+        moving_picture = helpers.clip_picture
+    else:
+        moving_picture = globals()["moving_picture"]
     px = np.uint8 if depth == 8 else np.uint16
     tag = f"{W}x{H}_{depth}_qp{qp}_{frames}frames{suffix}"
     yuv = f"/tmp/gold_inter_{tag}.yuv"
@@ -267,10 +275,10 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
             for p in moving_picture(W, H, t, depth):
                 f.write(p.astype(px).tobytes())
     out = f"/tmp/gold_inter_{tag}"
-    subprocess.check_call([os.path.join(ROOT, "tools/refcheck/ctu_dump.sh"), str(depth), yuv, str(W), str(H), str(frames), out,
-                           "preset", "medium", "gop", "lp-g4d3t1", "qp", str(qp)] + list(extra), stderr=subprocess.DEVNULL,
-                          env=dict(os.environ, CTU_DUMP_CU_INTER="1"))
     opt = dict(zip(extra[0::2], extra[1::2]))
+    subprocess.check_call([os.path.join(ROOT, "tools/refcheck/ctu_dump.sh"), str(depth), yuv, str(W), str(H), str(frames), out,
+                           "preset", "medium"] + ([] if "gop" in opt else ["gop", "lp-g4d3t1"]) + ["qp", str(qp)] + list(extra), stderr=subprocess.DEVNULL,
+                          env=dict(os.environ, CTU_DUMP_CU_INTER="1"))
     recs = read_records(out + ".bin")
     S = [r for n, r in recs if n == "search"]
     F = sorted([r for n, r in recs if n == "final"], key=lambda r: int(r[0][0]))
@@ -310,7 +318,16 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
         rec[2][fr, y // 2:(y + hh) // 2, x // 2:(x + ww) // 2] = s[8].reshape(32, 32)[:hh // 2, :ww // 2]
         coeff[k, :4096] = s[9]
         coeff[k, 4096:] = s[10]
-    final = [np.stack([f[1 + c].reshape(H >> (c > 0), W >> (c > 0)) for f in F]) for c in range(3)]
+    # the encoder returns its pictures in display order ("final" is keyed by pts); the search records are in coding order: display[f] =
+    # pts of coded picture f = (pts of its intra period's I picture) + its POC
+    display, base = np.zeros(frames, np.int32), 0
+    for k in range(len(S)):
+        fr = int(meta[k][0])
+        if int(meta[k][6]) == 2:
+            base = fr
+        display[fr] = base + int(refs[k][51])
+    assert sorted(display.tolist()) == list(range(frames)), display
+    final = [np.stack([F[display[f]][1 + c].reshape(H >> (c > 0), W >> (c > 0)) for f in range(frames)]) for c in range(3)]
     src_crc = np.array([zlib.crc32(b"".join(p.tobytes() for p in moving_picture(W, H, t, depth))) for t in range(frames)], np.uint32)
     np.savez_compressed(os.path.join(out_dir or os.path.join(ROOT, "tests/golden"), f"ref_inter_{tag}.npz"), dims=np.array([W, H, depth, qp, frames], np.int32), meta=meta, cu=cu, lam=lam, sao=sao, src_crc=src_crc,
                         motion=mot, refs=refs, rec_y=rec[0], rec_u=rec[1], rec_v=rec[2], coeff=coeff if with_levels else coeff[:0], final_y=final[0], final_u=final[1],
@@ -318,6 +335,7 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
                         # every call of uvg_search_cu_inter in coding order: frame, x, y, w, h, then the decided cu_info_t fields; its two costs
                         cuinter_i=np.stack([r[0] for r in CI]).astype(np.int32) if with_levels else np.zeros((0, 20), np.int32),
                         cuinter_d=np.stack([r[1] for r in CI]) if with_levels else np.zeros((0, 2)),
+                        display=display, clip=np.int32(bool(clip)),
                         sao_models=sao_models, row_bytes=row_bytes, row_off=row_off, bitstream=np.frombuffer(open(out + ".266", "rb").read(), np.uint8),
                         # the tools the run had on, for the tests' frame state: tmvp, max_merge, merge_level, bipred, fme_level, early_skip
                         cfg=np.array([int(opt.get("tmvp", 1)), int(opt.get("max-merge", 6)), 2, int(opt.get("bipred", 1)), {0: 0, 1: 1, 2: 2, 3: 3, 4: 4}[int(opt.get("subme", 4))],
@@ -362,14 +380,8 @@ def lowdelay_states(qp, frames):
     reference lists.  None of it depends on the picture size or content (no rate control): taken from a 136x72 run and used by bench.py to
     drive ONE long clip at 1080p (extra_workloads.c3_clip), for which full records would be far too large to keep."""
     import tempfile
-    global moving_picture
     tmp = tempfile.mkdtemp()
-    keep = moving_picture
-    moving_picture = lambda W, H, t, depth: keep(W, H, 12 - abs(t % 24 - 12), depth)      # (the window stays inside its base picture)
-    try:
-        tag = inter(136, 72, 8, qp, frames, out_dir=tmp, with_levels=False)
-    finally:
-        moving_picture = keep
+    tag = inter(136, 72, 8, qp, frames, out_dir=tmp, with_levels=False, clip=True)
     with np.load(os.path.join(tmp, f"ref_inter_{tag}.npz")) as z:
         meta, lam, refs = z["meta"], z["lam"], z["refs"]
     fm, fl, fr = np.zeros((frames, 8), np.int32), np.zeros((frames, 6)), np.zeros((frames, 52), np.int32)
@@ -471,3 +483,4 @@ if __name__ == "__main__":
     inter(136, 72, 8, 27, 4, extra=("bipred", "0", "tmvp", "0"), suffix="_p_notmvp")           # P pictures only, no temporal candidate
     inter(192, 128, 10, 24, 4, extra=("subme", "0", "early-skip", "0"), suffix="_subme0_noskip")   # integer motion only, no early skip
     lowdelay_states(27, 120)             # the frame-level state of a 120-picture low-delay clip (bench.py c3_clip)
+    inter(136, 72, 8, 27, 17, extra=("gop", "16"), suffix="_ra16", clip=True)      # random access, --preset medium's own GOP: coding order 0 16 8 4 2 1 3 6 5 7 12 ..., future references, five temporal layers

@@ -194,7 +194,14 @@ extern "C" int uvghip_write_picture_nals(int poc, int sao, const uint8_t *rows, 
 extern "C" int uvghip_write_idr_nals(int poc, int qp_delta, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
                                      const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len)
 {
-  if (!rows || !row_bytes || n_rows <= 0 || !len || (!out && cap) || poc < 0)
+  return uvghip_write_idr_nals_ra(poc, 4, qp_delta, sao, rows, row_pitch, row_bytes, n_rows, checksum, out, cap, len);
+}
+// ... and with the POC width of the stream's SPS (encoder_control->poc_lsb_bits, src/encoder.c:242: 4 without a GOP structure or with a
+// low-delay one of up to 7 pictures, 6 for --gop 16)
+extern "C" int uvghip_write_idr_nals_ra(int poc, int poc_lsb_bits, int qp_delta, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
+                                        const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len)
+{
+  if (!rows || !row_bytes || n_rows <= 0 || !len || (!out && cap) || poc < 0 || poc_lsb_bits < 4 || poc_lsb_bits > 16)
     return uvghip_set_error(hipErrorInvalidValue, __func__);
   int32_t longest = 0;
   for (int r = 0; r < n_rows; ++r) {
@@ -213,7 +220,7 @@ extern "C" int uvghip_write_idr_nals(int poc, int qp_delta, int sao, const uint8
   w.bits(0, 1);                      // ph_gdr_pic_flag
   w.bits(0, 1);                      // ph_inter_slice_allowed_flag
   w.ue(0);                           // ph_pic_parameter_set_id
-  w.bits((uint32_t)poc & 15u, 4);    // ph_pic_order_cnt_lsb (the SPS of this configuration signals 4 bits)
+  w.bits((uint32_t)poc & ((1u << poc_lsb_bits) - 1u), poc_lsb_bits);      // ph_pic_order_cnt_lsb
   w.bits(0, 1);                      // sh_no_output_of_prior_pics_flag
   w.se(qp_delta);                    // sh_qp_delta
   if (sao) w.bits(3, 2);             // sh_sao_luma_used_flag, sh_sao_chroma_used_flag
@@ -275,22 +282,24 @@ extern "C" int uvghip_write_idr_nals_alf(int poc, int qp_delta, int sao, const u
   return 0;
 }
 
-// The same for a P / B picture of a low-delay stream (TRAIL pictures, one temporal layer): the picture header's inter flags, the slice
-// type, the reference picture list syntax, the collocated picture, the slice QP offset.
+// The same for a P / B picture (TRAIL pictures, temporal id 0: uvg266 only signals a sub-layer for STSA pictures, :1484): the picture
+// header's inter flags, the slice type, the reference picture list syntax, the collocated picture, the slice QP offset.
 // replaces: uvg_encoder_state_write_bitstream_slice_header (:1248-1411) with _picture_header (:1009-1139) and _ref_pic_list (:1141-1246)
-// for pictype TRAIL; gop_lowdelay, so list 1 is signalled as a copy of list 0's entries when bi-prediction is on (:1165) and every
-// reference lies in the past.  delta_neg: poc - the POC of each reference picture, in the order of the GOP structure's ref_neg[]
-// (uvg_config_process_lp_gop, src/cfg.c:1640-1720: ascending); copy_rpl1 = cfg.bipred; qp_delta = state->frame->QP - cfg.qp.
-extern "C" int uvghip_write_picture_nals_pb(int poc, int poc_lsb_bits, int slice_type, int n_ref_neg, const int32_t *delta_neg, int copy_rpl1, int tmvp, int qp_delta,
-                                            int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows, const uint32_t *checksum,
-                                            uint8_t *out, size_t cap, size_t *len)
+// for pictype TRAIL.  List 0 carries the references in the past, list 1 those in the future (gop_len != 0 && !gop_lowdelay), or is
+// signalled as a copy of list 0's entries (copy_rpl1 = (gop_lowdelay || !gop_len) && bipred, :1165).  delta_neg / delta_pos: the POC
+// distance of each reference picture, in the order of the GOP structure's ref_neg[] / ref_pos[] (src/gop.h, uvg_config_process_lp_gop
+// src/cfg.c:1640-1720: ascending) restricted to the pictures that are in the reference buffer (:1176-1190).
+static int write_inter_picture(const char *who, int poc, int poc_lsb_bits, int slice_type, int n_ref_neg, const int32_t *delta_neg, int n_ref_pos, const int32_t *delta_pos,
+                               int copy_rpl1, int tmvp, int qp_delta, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
+                               const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len)
 {
   if (!rows || !row_bytes || n_rows <= 0 || !len || (!out && cap) || poc < 0 || poc_lsb_bits < 4 || poc_lsb_bits > 16 || (slice_type != 0 && slice_type != 1) ||
-      n_ref_neg < 1 || n_ref_neg > 15 || !delta_neg)
-    return uvghip_set_error(hipErrorInvalidValue, __func__);
+      n_ref_neg < 0 || n_ref_neg > 15 || n_ref_pos < 0 || n_ref_pos > 15 || n_ref_neg + n_ref_pos < 1 || (n_ref_neg && !delta_neg) || (n_ref_pos && !delta_pos) ||
+      (copy_rpl1 && n_ref_pos))
+    return uvghip_set_error(hipErrorInvalidValue, who);
   int32_t longest = 0;
   for (int r = 0; r < n_rows; ++r) {
-    if (row_bytes[r] <= 0 || (size_t)row_bytes[r] > row_pitch) return uvghip_set_error(hipErrorInvalidValue, "uvghip_write_picture_nals_pb: a row is empty or longer than its slot");
+    if (row_bytes[r] <= 0 || (size_t)row_bytes[r] > row_pitch) return uvghip_set_error(hipErrorInvalidValue, "uvghip_write_picture_nals_pb / _ra: a row is empty or longer than its slot");
     if (row_bytes[r] > longest) longest = row_bytes[r];
   }
   nal_writer w = {out, cap, 0, 0, 0, 0};
@@ -307,19 +316,29 @@ extern "C" int uvghip_write_picture_nals_pb(int poc, int poc_lsb_bits, int slice
   w.ue((uint32_t)slice_type);        // sh_slice_type
   const int lists = 1 + (copy_rpl1 ? 1 : 0);
   for (int list = 0; list < lists; ++list) {
-    w.ue((uint32_t)n_ref_neg);       // num_ref_entries
+    w.ue((uint32_t)n_ref_neg);       // num_ref_entries[0]
     int last = 0;
     for (int j = 0; j < n_ref_neg; ++j) {
       const int d = delta_neg[j];
       w.ue(d ? (uint32_t)(d - last - 1) : 0u);      // abs_delta_poc_st
-      if (d + 1) w.bits(1, 1);                       // strp_entry_sign_flag
+      if (d + 1) w.bits(1, 1);                       // strp_entry_sign_flag: in the past
       last = d;
     }
   }
-  if (!copy_rpl1) w.ue(0);           // num_ref_entries[1]: no reference in the future
-  if (n_ref_neg > 1) {
+  if (!copy_rpl1) {
+    w.ue((uint32_t)n_ref_pos);       // num_ref_entries[1]
+    int last = 0;
+    for (int j = 0; j < n_ref_pos; ++j) {
+      const int d = delta_pos[j];
+      w.ue(d ? (uint32_t)(d - last - 1) : 0u);      // abs_delta_poc_st
+      if (d + 1) w.bits(0, 1);                       // strp_entry_sign_flag: in the future
+      last = d;
+    }
+  }
+  if (n_ref_neg > 1 || n_ref_pos > 1) {
     w.bits(1, 1);                    // sh_num_ref_idx_active_override_flag
-    for (int list = 0; list < lists; ++list) w.ue((uint32_t)n_ref_neg - 1);
+    if (n_ref_neg > 1) for (int list = 0; list < lists; ++list) w.ue((uint32_t)n_ref_neg - 1);
+    if (!copy_rpl1 && n_ref_pos > 1) w.ue((uint32_t)n_ref_pos - 1);
   }
   if (tmvp) {
     if (slice_type == 0) w.bits(1, 1);               // sh_collocated_from_l0_flag
@@ -329,6 +348,25 @@ extern "C" int uvghip_write_picture_nals_pb(int poc, int poc_lsb_bits, int slice
   if (sao) w.bits(3, 2);             // sh_sao_luma_used_flag, sh_sao_chroma_used_flag
   finish_picture(w, out, cap, rows, row_pitch, row_bytes, n_rows, longest, checksum);
   *len = w.n;
-  if (w.n > cap) return uvghip_set_error(hipErrorInvalidValue, "uvghip_write_picture_nals_pb: the output buffer is too small (see *len)");
+  if (w.n > cap) return uvghip_set_error(hipErrorInvalidValue, "uvghip_write_picture_nals_pb / _ra: the output buffer is too small (see *len)");
   return 0;
+}
+
+// a picture of a low-delay stream (--gop lp-*, or no GOP structure): every reference in the past
+extern "C" int uvghip_write_picture_nals_pb(int poc, int poc_lsb_bits, int slice_type, int n_ref_neg, const int32_t *delta_neg, int copy_rpl1, int tmvp, int qp_delta,
+                                            int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows, const uint32_t *checksum,
+                                            uint8_t *out, size_t cap, size_t *len)
+{
+  if (n_ref_neg < 1) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  return write_inter_picture(__func__, poc, poc_lsb_bits, slice_type, n_ref_neg, delta_neg, 0, nullptr, copy_rpl1 != 0, tmvp, qp_delta, sao, rows, row_pitch, row_bytes, n_rows,
+                             checksum, out, cap, len);
+}
+
+// a picture of a random-access stream (--gop 8 / 16, the hierarchical structures of src/gop.h): references in the past and in the future
+extern "C" int uvghip_write_picture_nals_ra(int poc, int poc_lsb_bits, int slice_type, int n_ref_neg, const int32_t *delta_neg, int n_ref_pos, const int32_t *delta_pos,
+                                            int tmvp, int qp_delta, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
+                                            const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len)
+{
+  return write_inter_picture(__func__, poc, poc_lsb_bits, slice_type, n_ref_neg, delta_neg, n_ref_pos, delta_pos, 0, tmvp, qp_delta, sao, rows, row_pitch, row_bytes, n_rows,
+                             checksum, out, cap, len);
 }
