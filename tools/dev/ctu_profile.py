@@ -16,7 +16,7 @@ al = lambda v, a: (v + a - 1) // a * a
 off_order = al(512 + 32768 + ctus * 4, 256); off_pics = al(off_order + ctus * 4, 256); off_scr = al(off_pics + n * 96, 256)
 n_slots = min(2048, al(ctus, 32))          # a slot keeps the profile of the last CTU that ran on it
 ws = cs.ws.cpu().numpy()
-SZ = 59328 + 128
+SZ = 68160
 prof = np.stack([ws[off_scr + i * SZ + SZ - 1024: off_scr + i * SZ + SZ].view(np.uint64).reshape(4, 32) for i in range(n_slots)]).astype(np.float64)
 lf = np.stack([ws[off_scr + i * SZ + SZ - 1024 - 128: off_scr + i * SZ + SZ - 1024].view(np.uint64) for i in range(n_slots)]).astype(np.float64)
 lf = lf[prof[:, 0, 11] > 0]

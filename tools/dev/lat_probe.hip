@@ -28,6 +28,10 @@ __global__ void k(unsigned long long *out, int *sink, const int *gmem)
   { T0(); for (int i = 0; i < N_ITER; ++i) { REP64(asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(*(unsigned long long *)&d));) } T1(12); }
   { int a = (threadIdx.x * 4) & 4092; int b; T0(); for (int i = 0; i < N_ITER; ++i) { REP64(asm volatile("ds_write_b32 %0, %0\n ds_read_b32 %1, %0\n s_waitcnt lgkmcnt(0)\n v_and_b32 %0, 4092, %1" : "+v"(a), "=v"(b));) } T1(13); v += a; }
   { T0(); for (int i = 0; i < N_ITER; ++i) { REP64(asm volatile("v_add_u32 %0, %0, %1\n v_add_u32 %1, %1, %1" : "+v"(v), "+v"(w));) } T1(14); }
+  { unsigned long long fp = (unsigned long long)(void *)lds; unsigned hi = (unsigned)(fp >> 32), a = (unsigned)fp + ((threadIdx.x * 4) & 4092);
+    T0(); for (int i = 0; i < N_ITER; ++i) { REP64({ unsigned long long ad = ((unsigned long long)hi << 32) | a; asm volatile("flat_load_dword %0, %1\n s_waitcnt vmcnt(0) lgkmcnt(0)" : "=v"(a) : "v"(ad)); }) } T1(8); v += a; }
+  { unsigned long long fp = (unsigned long long)(void *)lds; unsigned hi = (unsigned)(fp >> 32), a = (unsigned)fp + ((threadIdx.x * 4) & 4092), b;
+    T0(); for (int i = 0; i < N_ITER; ++i) { REP64({ unsigned long long ad = ((unsigned long long)hi << 32) | a; asm volatile("flat_store_dword %1, %2\n flat_load_dword %0, %1\n s_waitcnt vmcnt(0) lgkmcnt(0)" : "=v"(b) : "v"(ad), "v"(a)); a = b; }) } T1(15); v += a; }
   sink[threadIdx.x] = v + (int)d + w;
 }
 int main()
@@ -37,9 +41,9 @@ int main()
   unsigned long long h[16]; hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   const char *nm[16] = {"v_add_u32 (dependent)", "v_add_f64 (dependent)", "v_mul_lo_u32 (dependent)", "ds_read_b32 -> address", "ds_bpermute_b32 -> address", "v_readlane -> s_nop -> v_add", "v_mov_dpp row_shl:1 (dependent)",
-                        "v_cmp + v_cndmask", "s_add_i32 (dependent)", "global_load (L2/L1 hit) -> address", "s_load_dword -> offset", "v_cmp -> s_ff1 -> v_readlane -> v_add", "s_memtime + wait", "ds_write + ds_read + wait + v_and", "2 independent v_add", "v_add + 2 s_add (interleaved)"};
+                        "v_cmp + v_cndmask", "flat_load_dword (LDS aperture) -> address", "global_load (L2/L1 hit) -> address", "s_load_dword -> offset", "v_cmp -> s_ff1 -> v_readlane -> v_add", "s_memtime + wait", "ds_write + ds_read + wait + v_and", "2 independent v_add", "flat_store + flat_load (LDS aperture) + wait"};
   const int per[16] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 16, 16, 64, 64, 64, 64, 64};
   printf("one wave of 64 lanes alone on a CU; s_memtime ticks (= shader cycles: a CTU of 43 M ticks takes 20.6 ms) per operation group\n");
-  for (int i = 0; i < 16; ++i) if (i != 8 && i != 15) printf("%-44s %8.2f ticks\n", nm[i], (double)h[i] / (per[i] * N_ITER));
+  for (int i = 0; i < 16; ++i) printf("%-44s %8.2f ticks\n", nm[i], (double)h[i] / (per[i] * N_ITER));
   return 0;
 }

@@ -97,6 +97,9 @@
 #define LF_T0() ((void)0)
 #endif
 #define LDSP(T, p) ((CTU_LDS T *)(p))          // a pointer known to point into the workgroup's LDS image (device: ds_* instead of flat_*)
+// ... and one that points into the LDS image OR, in a slim build (lds_cfg below), into the workgroup's global scratch: a generic pointer
+// there (flat_*: the LDS aperture costs a lone wave the same 52 cycles as ds_read, profiles/r05_lat_probe.txt)
+#define MGP(PX, T, p) ((typename ctu::mg_ptr<PX, T>::type)(p))
 #define PAR_FOR(i, n) for (int i = CTU_TID; i < (n); i += CTU_NT)
 #define BLK_FOR(i, n) for (int i = BLK_TID; i < (n); i += BLK_NT)
 #define SERIAL if (CTU_TID == 0)
@@ -157,6 +160,17 @@ struct level_state {        // search_cu's locals, per depth
 #endif
 };
 
+// The LDS diet of the 10-bit I-picture kernel: with 2-byte samples the image is 8.9 KB over a quarter of the CU's 160 KB, which costs
+// the fourth workgroup per CU.  A slim build keeps out of LDS what only the 32x32 depth (the least loaded wave) and the rare 64x64
+// candidate touch: the depth-1 candidate's samples, the depth-1 scratch's levels, the 16x16 / 32x32 coefficient scans -- they live in
+// the workgroup's global scratch (L1 / L2 resident) behind generic pointers.  8-bit, P / B and host builds are not slim.
+template <typename PX> struct lds_cfg { enum { slim = 0 }; };
+#if defined(CTU_LEAF4) && !defined(CTU_NO_SLIM)
+template <> struct lds_cfg<uint16_t> { enum { slim = 1 }; };
+#endif
+template <typename PX, typename T, bool SLIM = (lds_cfg<PX>::slim != 0)> struct mg_ptr { typedef CTU_LDS T *type; };
+template <typename PX, typename T> struct mg_ptr<PX, T, true> { typedef T *type; };
+
 template <typename PX> struct px_info;
 template <> struct px_info<uint8_t> { enum { depth = 8, maxv = 255 }; };
 template <> struct px_info<uint16_t> { enum { depth = 10, maxv = 1023 }; };
@@ -194,8 +208,9 @@ struct wctx {
 #define CTU_RQ_ROOT(V) 0
 #endif
 
-constexpr int arena_bytes(int n)     // one depth's share of the arena (n = its luma block size)
+constexpr int arena_bytes(int n, bool slim = false)     // one depth's share of the arena (n = its luma block size)
 {
+  if (slim && n == 32) return (4 * (4 * n + 8) * 2 + 2 * n * n * 2 + 15) & ~15;      // (the levels live in scratch::lv32)
   // reference rows, two transform buffers, levels (y, u, v), [4x4 only: the rough search's partial costs -- larger blocks keep
   // them in the transform buffers, idle during the rough search], [<= 8x8: RDOQ's two per-position cost arrays]
 #if defined(CTU_LEAF4)
@@ -211,6 +226,7 @@ enum { ARENA_BYTES = arena_bytes(32) };
 #else
 enum { ARENA_BYTES = arena_bytes(4) + arena_bytes(8) + arena_bytes(16) + arena_bytes(32) };
 #endif
+enum { ARENA_BYTES_SLIM = arena_bytes(4) + arena_bytes(8) + arena_bytes(16) + arena_bytes(32, true) };
 
 struct scratch;
 #if defined(CTU_PB)
@@ -254,7 +270,7 @@ template <typename PX> struct lds {
   scratch *prof_w;
 #endif
   PX Dy[65 * PY], Du[33 * PC], Dv[33 * PC];         // decided planes, index (y + 1) * pitch + x + 1
-  PX cand_px[2016];                                 // a depth's CU while its split is being tried (depths 1..3)
+  PX cand_px[lds_cfg<PX>::slim ? 480 : 2016];       // a depth's CU while its split is being tried (depths 1..3; slim: 2..3, depth 1 in scratch::cand_px32)
   cu4 cu[17 * 17];                                  // index (y4 + 1) * 17 + x4 + 1
   scratch *scr;                                     // the workgroup's global scratch (the split / mode-type trees per 4x4 live there)
   uint32_t cur[NMX];                                // state->search_cabac models of the walk: state0 | state1 << 16
@@ -262,10 +278,10 @@ template <typename PX> struct lds {
                                                     // posts the evaluation) and, adapted in place, leaves behind; [2] doubles as scratch for the 64x64 candidate
   uint32_t coder[NMX];                              // state->cabac models
   uint8_t rdoq_state[244];                          // CTX_STATE of the coder's models at the CTU's start (what uvg_rdoq prices with)
-  uint16_t scan[1024 + 256 + 64 + 16];              // coefficient scans of the four square shapes
+  uint16_t scan[lds_cfg<PX>::slim ? 64 + 16 : 1024 + 256 + 64 + 16];      // coefficient scans of the four square shapes (slim: 8x8 and 4x4, the others in scratch::scan_g)
   uint8_t inv4[16];                                 // scan index of the 4x4 group's raster position y * 4 + x
   uint16_t deps4[16];                               // per scan index of a 4x4 group: the scan indices (bits) its context template reads inside the group
-  int32_t last_bits[2][4][2][12];                   // RDOQ: bit cost of the last-position prefix per (luma/chroma, log2 size - 2, x/y, group index)
+  int32_t last_bits[92];                            // RDOQ: bit cost of the last-position prefix per (luma/chroma, log2 size, x/y, group index): last_bits_off
   level_state lvl[5];
   wctx wv[4];                                       // [0] depth 4 (4x4), [1] depth 3, [2] depth 2, [3] depth 1 (32x32)
   int32_t vsel[4];                                  // which wv[] a wave is using (a wave may borrow a larger one while its owner idles)
@@ -286,7 +302,7 @@ template <typename PX> struct lds {
   int32_t j64, j64_mode;
   struct { int32_t cu, cv, ssd_u, ssd_v, cy, ssd_y; double bits, bits_y; } h64[4];      // (cy, ssd_y, bits_y: the walk's own luma part)
 #endif
-  alignas(16) unsigned char arena[ARENA_BYTES];
+  alignas(16) unsigned char arena[lds_cfg<PX>::slim ? (int)ARENA_BYTES_SLIM : (int)ARENA_BYTES];
 #if defined(CTU_PB)
   pb_state pb;
 #endif
@@ -300,6 +316,10 @@ struct scratch {
   int16_t save_co[6144];
   cu4 save_cu[256];
   int16_t cand_co[2016];           // levels of the candidate CUs of depths 1..3 (cand_px_off)
+  // a slim build (lds_cfg): the depth-1 candidate's samples, the levels of the depth-1 scratch (y, u, v), the scans of 32x32 and 16x16
+  uint16_t cand_px32[1536];
+  int16_t lv32[1536];
+  uint16_t scan_g[1024 + 256];
   uint32_t save_tree[512];
   uint16_t tree[256], mtt[256];    // split_tree / mode_type_tree per 4x4 of the decided CTU (3 / 2 bits per depth, depths 0..4)
 #if defined(CTU_PB)
@@ -394,6 +414,19 @@ CTU_DEV void models_init_one(uint32_t *m, int i, int qp, int slice)     // uvg_c
 
 // ------------------------------------------------------------------------------------------------------------- scans ------
 CTU_DEV int scan_base(int log2n) { return log2n == 5 ? 0 : log2n == 4 ? 1024 : log2n == 3 ? 1280 : 1344; }
+// the scan of the 1 << log2n square: the LDS table, or (slim build, 16x16 and 32x32) the workgroup's global copy
+template <typename PX> CTU_DEV uint16_t *scan_of(lds<PX> *S, int log2n)
+{
+  if (lds_cfg<PX>::slim) return log2n >= 4 ? S->scr->scan_g + (log2n == 5 ? 0 : 1024) : S->scan + (log2n == 3 ? 0 : 64);
+  return S->scan + scan_base(log2n);
+}
+// last_bits: [luma 4, 8, 16, 32; chroma 4, 8, 16][x, y][group index 0 .. group_idx(n - 1)]
+CTU_DEV int last_bits_off(int t, int log2n, int xy)
+{
+  const int cnt = 2 * log2n;                                       // 4, 6, 8, 10 entries
+  const int base = log2n == 2 ? 0 : (log2n == 3 ? 8 : (log2n == 4 ? 20 : 36));
+  return (t ? 56 : 0) + base + (xy ? cnt : 0);
+}
 // H.266 6.5.2 up-right diagonal scan of 4x4 groups, groups in diagonal order (tables.c g_scan_order, SCAN_DIAG)
 CTU_DEV void diag_order(int n, uint8_t *out)      // out[i] = y * n + x of the i-th position of an n x n diagonal scan
 {
@@ -412,7 +445,7 @@ template <typename PX> CTU_DEV void build_scans(lds<PX> *S)
     for (int l2 = 2; l2 <= 5; ++l2) {
       const int n = 1 << l2, cgw = n >> 2;
       diag_order(cgw, cg);
-      uint16_t *sc = S->scan + scan_base(l2);
+      uint16_t *sc = scan_of(S, l2);
       if (l2 == 2) {
         for (int k = 0; k < 16; ++k) S->inv4[in[k]] = (uint8_t)k;
         for (int k = 0; k < 16; ++k) {
@@ -521,7 +554,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void predict_block(lds<PX> *S, int m
   const mode_info M = make_mode_info(mode, w, w, color != 0);
   const ref_rows_t<CTU_LDS const uint16_t *> R = {LDSP(const uint16_t, V->top), LDSP(const uint16_t, V->left), LDSP(const uint16_t, V->ftop), LDSP(const uint16_t, V->fleft)};
   const int dc = mode == 1 ? dc_value(R.top, R.left, w, w) : 0;
-  CTU_LDS PX *const dst = LDSP(PX, dst_);
+  typename mg_ptr<PX, PX>::type const dst = MGP(PX, PX, dst_);
   const int segs = w >> 2;
   PAR_FOR(t, w * segs) {
     const int yd = t / segs, xd0 = (t - yd * segs) * 4;
@@ -1205,7 +1238,7 @@ struct rdoq_pos { int level; double cc, cs; };
 #else
 #define CTU_INLINE
 #endif
-CTU_INLINE CTU_DEV rdoq_pos rdoq_decide_inl(const rdoq_env &E, CTU_LDS const int16_t *coef, CTU_LDS const int16_t *dst, int n, int l2, int color, int blkpos, bool is_last,
+template <typename DP> CTU_INLINE CTU_DEV rdoq_pos rdoq_decide_inl(const rdoq_env &E, CTU_LDS const int16_t *coef, DP dst, int n, int l2, int color, int blkpos, bool is_last,
                              bool regular, int go_rice, double c0, int *mal_out)
 {
   const int cap_half = 1 << (E.q_bits - 1);
@@ -1227,7 +1260,7 @@ CTU_INLINE CTU_DEV rdoq_pos rdoq_decide_inl(const rdoq_env &E, CTU_LDS const int
   *mal_out = (int)max_abs_level;
   return r;
 }
-CTU_NOINLINE CTU_DEV rdoq_pos rdoq_decide(const rdoq_env &E, CTU_LDS const int16_t *coef, CTU_LDS const int16_t *dst, int n, int l2, int color, int blkpos, bool is_last,
+template <typename DP> CTU_NOINLINE CTU_DEV rdoq_pos rdoq_decide(const rdoq_env &E, CTU_LDS const int16_t *coef, DP dst, int n, int l2, int color, int blkpos, bool is_last,
                              bool regular, int go_rice, double c0, int *mal_out)
 {
   return rdoq_decide_inl(E, coef, dst, n, l2, color, blkpos, is_last, regular, go_rice, c0, mal_out);
@@ -1248,9 +1281,9 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
 {
   wctx *const V = wv_of(S);
   CTU_LDS const int16_t *const coef = LDSP(const int16_t, coef_);
-  CTU_LDS int16_t *const dst = LDSP(int16_t, dst_);
+  typename mg_ptr<PX, int16_t>::type const dst = MGP(PX, int16_t, dst_);
   const int l2 = ilog2_dev(n), nn = n * n, cgw = n >> 2;
-  const uint16_t *scan = S->scan + scan_base(l2);
+  const uint16_t *scan = scan_of(S, l2);
   rdoq_env E;
   E.st = S->rdoq_state; E.t = color ? 1 : 0; E.lambda = lambda;
   const int transform_shift = 15 - bitdepth - l2;
@@ -1481,7 +1514,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave(lds<PX> *S, scratch *
       best_cost = block_uncoded_cost + lambda * rbits(E, o_cbf, 0);
       base_cost += lambda * rbits(E, o_cbf, 1);
     }
-    const int32_t *last_x_bits = S->last_bits[E.t][l2 - 2][0], *last_y_bits = S->last_bits[E.t][l2 - 2][1];
+    const int32_t *last_x_bits = S->last_bits + last_bits_off(E.t, l2, 0), *last_y_bits = S->last_bits + last_bits_off(E.t, l2, 1);
     int found_last = 0;
     for (int cgs = cg_last; cgs >= 0; cgs--) {
       const int first = scan[cgs * 16];
@@ -1547,9 +1580,9 @@ template <typename PX> CTU_INLINE1 CTU_DEV void rdoq_wave(lds<PX> *S, scratch *W
 {
   wctx *const V = wv_of(S);
   CTU_LDS const int16_t *const coef = LDSP(const int16_t, coef_);
-  CTU_LDS int16_t *const dst = LDSP(int16_t, dst_);
+  typename mg_ptr<PX, int16_t>::type const dst = MGP(PX, int16_t, dst_);
   const int l2 = ilog2_dev(n), nn = n * n, cgw = n >> 2;
-  const uint16_t *scan = S->scan + scan_base(l2);
+  const uint16_t *scan = scan_of(S, l2);
   rdoq_env E;
   E.st = S->rdoq_state; E.t = color ? 1 : 0; E.lambda = lambda;
   const int transform_shift = 15 - bitdepth - l2;
@@ -1753,7 +1786,7 @@ template <typename PX> CTU_INLINE1 CTU_DEV void rdoq_wave(lds<PX> *S, scratch *W
     best_cost = block_uncoded_cost + lambda * rbits(E, o_cbf, 0);
     base_cost += lambda * rbits(E, o_cbf, 1);
   }
-  const int32_t *last_x_bits = S->last_bits[E.t][l2 - 2][0], *last_y_bits = S->last_bits[E.t][l2 - 2][1];
+  const int32_t *last_x_bits = S->last_bits + last_bits_off(E.t, l2, 0), *last_y_bits = S->last_bits + last_bits_off(E.t, l2, 1);
   int found_last = 0;
   for (int cgs = cg_last; cgs >= 0 && !found_last; cgs--) {
     const int first = scan[cgs * 16];
@@ -1963,11 +1996,19 @@ CTU_NOINLINE CTU_DEV double coeff_bits_serial(uint32_t *m, const uint16_t *scan,
 
 // =================================================================================================== the CTU search ======
 CTU_DEV int co_off(int color) { return color == 0 ? 0 : (color == 1 ? 4096 : 5120); }
+// where the depth-L candidate's samples are kept: LDS, or (slim build, depth 1) the workgroup's global scratch
+template <typename PX> CTU_DEV PX *cand_px_of(lds<PX> *S, const job<PX> &J, int L, int color);
 CTU_DEV int cand_px_off(int L, int color)      // L = 1..3
 {
   const int base = L == 1 ? 0 : (L == 2 ? 1536 : 1920);
   const int n = 64 >> L;
   return base + (color == 0 ? 0 : n * n + (color - 1) * (n / 2) * (n / 2));
+}
+
+template <typename PX> CTU_DEV PX *cand_px_of(lds<PX> *S, const job<PX> &J, int L, int color)
+{
+  if (lds_cfg<PX>::slim) return L == 1 ? (PX *)J.W->cand_px32 + cand_px_off(1, color) : S->cand_px + cand_px_off(L, color) - 1536;
+  return S->cand_px + cand_px_off(L, color);
 }
 
 template <typename PX> CTU_DEV int scaled_qp(const params &P, int color) { return (color == 0 ? P.qp : P.qp_c) + 6 * ((int)px_info<PX>::depth - 8); }
@@ -1985,8 +2026,9 @@ template <typename PX> CTU_INLINE1 CTU_DEV int recon_tu_inl(lds<PX> *S, const jo
 {
   // dst / dp: where the block is reconstructed (the decided planes, or the depth's candidate buffer); co / cp: where its levels go
   wctx *const V = wv_of(S);
-  CTU_LDS PX *const dst = LDSP(PX, dst_);
-  CTU_LDS int16_t *const t0 = LDSP(int16_t, V->t0), *const lv = LDSP(int16_t, lv_of(V, color));
+  typename mg_ptr<PX, PX>::type const dst = MGP(PX, PX, dst_);
+  CTU_LDS int16_t *const t0 = LDSP(int16_t, V->t0);
+  typename mg_ptr<PX, int16_t>::type const lv = MGP(PX, int16_t, lv_of(V, color));
   const int c = color != 0, w = n >> c, l2 = ilog2_dev(w);
   int sps;
   CTU_GLB const PX *Sp = src_block(J, color, lx >> c, ly >> c, &sps);
@@ -2059,7 +2101,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<P
 template <typename PX> CTU_NOINLINE CTU_DEV void ssd_block(lds<PX> *S, const job<PX> &J, int color, int lx, int ly, int n, int slot, const PX *rec_, int rp)
 {
   wctx *const V = wv_of(S);
-  CTU_LDS const PX *const rec = LDSP(const PX, rec_);
+  typename mg_ptr<PX, const PX>::type const rec = MGP(PX, const PX, rec_);
   const int c = color != 0, w = n >> c, l2 = ilog2_dev(w);
   int sps;
   CTU_GLB const PX *Sp = src_block(J, color, lx >> c, ly >> c, &sps);
@@ -2159,7 +2201,7 @@ CTU_DEV int rec_spend(uint32_t rec) { const uint32_t a = rec & 0xffffu; return (
 template <typename PX> CTU_DEV double coeff_bits4(lds<PX> *S, CTU_LDS uint32_t *m, int update, CTU_LDS const int16_t *coeff, int color)
 {
   const int lane = CTU_TID, sp = lane & 15, t = color ? 1 : 0;
-  const uint16_t *scan = S->scan + scan_base(2);
+  const uint16_t *scan = scan_of(S, 2);
   const int blk = scan[sp], py = blk >> 2, px = blk & 3;
   const int a = iabs_((int)coeff[blk]);
   const unsigned nzmask = (unsigned)__ballot(a != 0) & 0xffffu;
@@ -2273,13 +2315,13 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
   uint32_t tmp[NMODELS];
   uint32_t *mm = m;
   if (!update) { for (int i = 0; i < NMODELS; ++i) tmp[i] = m[i]; mm = tmp; }
-  return coeff_bits_serial(mm, S->scan + scan_base(ilog2_dev(n)), coeff, n, color);
+  return coeff_bits_serial(mm, scan_of(S, ilog2_dev(n)), coeff, n, color);
 #else
   const int lane = CTU_TID;
   const int l2 = ilog2_dev(n), nn = n * n, cgw = n >> 2, ncg = nn >> 4, t = color ? 1 : 0;
-  const uint16_t *scan = S->scan + scan_base(l2);
+  const uint16_t *scan = scan_of(S, l2);
   CTU_LDS uint32_t *const m = (CTU_LDS uint32_t *)m_;
-  CTU_LDS const int16_t *const coeff = (CTU_LDS const int16_t *)coeff_;
+  typename mg_ptr<PX, const int16_t>::type const coeff = MGP(PX, const int16_t, coeff_);
 #if defined(CTU_LEAF4)
   if (n == 4) return coeff_bits4r(S, m, update, (int)coeff[lane & 15], color);
 #else
@@ -2669,7 +2711,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
   int16_t *ky, *ku, *kv;
   int rpy, rpc, kpy, kpc;
   if (to_cand) {
-    ry = S->cand_px + cand_px_off(L, 0); ru = S->cand_px + cand_px_off(L, 1); rv = S->cand_px + cand_px_off(L, 2);
+    ry = cand_px_of(S, J, L, 0); ru = cand_px_of(S, J, L, 1); rv = cand_px_of(S, J, L, 2);
     int16_t *const kb = J.W->cand_co;
     ky = kb + cand_px_off(L, 0); ku = kb + cand_px_off(L, 1); kv = kb + cand_px_off(L, 2);
     rpy = kpy = n; rpc = kpc = cn;
@@ -2917,7 +2959,13 @@ template <typename PX> CTU_NOINLINE CTU_DEV void unpark(lds<PX> *S, const job<PX
     PX *D = plane(S, color) + ((ly >> c) + 1) * pit + (lx >> c) + 1;
     int16_t *co = J.coeff + co_off(color) + (ly >> c) * spit + (lx >> c);
     const int off = cand_px_off(L, color);
-    PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); D[r * pit + q] = S->cand_px[off + e]; co[r * spit + q] = CTU_GLOAD(&J.W->cand_co[off + e]); }
+    if (lds_cfg<PX>::slim && L == 1) {
+      const PX *const from = (const PX *)J.W->cand_px32 + off;
+      PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); D[r * pit + q] = CTU_GLOAD(&from[e]); co[r * spit + q] = CTU_GLOAD(&J.W->cand_co[off + e]); }
+      continue;
+    }
+    const PX *const from = cand_px_of(S, J, L, color);
+    PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); D[r * pit + q] = from[e]; co[r * spit + q] = CTU_GLOAD(&J.W->cand_co[off + e]); }
   }
   SERIAL {
     for (int yy = ly; yy < ly + n; yy += 4)
@@ -3537,12 +3585,14 @@ template <typename PX> CTU_NOINLINE CTU_DEV void load_ctu(lds<PX> *S, const job<
     const int base = (xy ? M_LASTY : M_LASTX) + (t ? 20 : 0) + off;
     int32_t b = 0;
     int ctx;
+    if (t && l2 == 5) continue;                 // (no 32x32 chroma block)
+    int32_t *const lb = S->last_bits + last_bits_off(t, l2, xy);
     for (ctx = 0; ctx < group_idx(n - 1); ctx++) {
       const int mdl = base + (ctx >> sh);
-      S->last_bits[t][l2 - 2][xy][ctx] = b + (int32_t)tab_rdoq_bits()[2 * mdl];
+      lb[ctx] = b + (int32_t)tab_rdoq_bits()[2 * mdl];
       b += (int32_t)tab_rdoq_bits()[2 * mdl + 1];
     }
-    S->last_bits[t][l2 - 2][xy][ctx] = b;
+    lb[ctx] = b;
   }
   BLK_SYNC();
 }
@@ -3580,13 +3630,14 @@ template <typename PX> CTU_NOINLINE CTU_DEV void store_ctu(lds<PX> *S, const job
 }
 
 // carve the arena: wv[k] serves depth 4 - k (blocks of 4 << k)
-template <typename PX> CTU_DEV void setup_waves(lds<PX> *S)
+template <typename PX> CTU_DEV void setup_waves(lds<PX> *S, scratch *W = nullptr)
 {
+  if (lds_cfg<PX>::slim) { if (BLK_TID == 0) S->scr = W; }      // (scan_of reads it before load_ctu sets it again)
   BLK_FOR(k, 4) {
     const int n = 4 << k, nn = n * n, c2 = (n / 2) * (n / 2) < 16 ? 16 : (n / 2) * (n / 2), tiles = n >= 8 ? (n / 8) * (n / 8) : 1;
     int off = 0;
 #if !defined(CTU_PB)
-    for (int j = 0; j < k; ++j) off += arena_bytes(4 << j);
+    for (int j = 0; j < k; ++j) off += arena_bytes(4 << j);          // (the slim depth-1 share is the last one)
 #endif
     unsigned char *a = S->arena + off;
     wctx *V = &S->wv[k];
@@ -3594,7 +3645,8 @@ template <typename PX> CTU_DEV void setup_waves(lds<PX> *S)
     V->refn = (int16_t)rn;
     V->top = (uint16_t *)a; V->left = V->top + rn; V->ftop = V->left + rn; V->fleft = V->ftop + rn; a += 4 * rn * 2;
     V->t0 = (int16_t *)a; V->t1 = V->t0 + nn; a += 2 * nn * 2;
-    V->lv0 = (int16_t *)a; V->lv1 = V->lv0 + nn; V->lv2 = V->lv1 + c2; a += (nn + 2 * c2) * 2;
+    if (lds_cfg<PX>::slim && n == 32) { V->lv0 = W->lv32; V->lv1 = V->lv0 + nn; V->lv2 = V->lv1 + c2; }
+    else { V->lv0 = (int16_t *)a; V->lv1 = V->lv0 + nn; V->lv2 = V->lv1 + c2; a += (nn + 2 * c2) * 2; }
     // the rough search's (satd, sad) per (mode, tile) -- 2 * 18 * tiles words -- fit the three transform buffers from 8x8 on, which
     // idle until the mode is chosen
 #if defined(CTU_LEAF4)
@@ -3629,7 +3681,7 @@ template <typename PX> CTU_DEV void run_ctu(lds<PX> *S, const job<PX> &J)
 #endif
   CTU_T0();
   { CTU_T0();
-  setup_waves(S);
+  setup_waves(S, J.W);
 #if defined(CTU_LEAF4)
   leaf_tables(S, J.P);
 #endif

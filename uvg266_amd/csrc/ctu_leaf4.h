@@ -740,7 +740,7 @@ template <typename PX> CTU_DEV int leaf_rdoq(lds<PX> *S, int coef, int color, in
   }
   double klast = 0;
   if (lev) {
-    const int32_t *last_x_bits = S->last_bits[E.t][0][0], *last_y_bits = S->last_bits[E.t][0][1];
+    const int32_t *last_x_bits = S->last_bits + last_bits_off(E.t, 2, 0), *last_y_bits = S->last_bits + last_bits_off(E.t, 2, 1);
     const double cl = last_x_bits[px] + last_y_bits[py];
     klast = lambda * cl;
   }

@@ -39,6 +39,7 @@ struct launch_args {
 // Four workgroups per CU at 8 bit is 40 960 B each: the dynamic image below + 4 304 B of function-scope tables (the build's .usage file
 // shows "LDS Size [bytes/block]: 4304").  One more word and the device holds three workgroups per CU instead of four (-25 %).
 static_assert(sizeof(ctu::lds<uint8_t>) + 4304 <= 40960, "the 8-bit LDS image of a CTU no longer fits four workgroups per CU");
+static_assert(!ctu::lds_cfg<uint16_t>::slim || sizeof(ctu::lds<uint16_t>) + 4304 <= 40960, "the slim 10-bit LDS image of a CTU no longer fits four workgroups per CU");
 
 template <typename PX>
 __global__ void __launch_bounds__(256, 4) ctu_search_kernel(launch_args A)
