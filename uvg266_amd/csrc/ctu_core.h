@@ -164,9 +164,14 @@ struct level_state {        // search_cu's locals, per depth
 // the fourth workgroup per CU.  A slim build keeps out of LDS what only the 32x32 depth (the least loaded wave) and the rare 64x64
 // candidate touch: the depth-1 candidate's samples, the depth-1 scratch's levels, the 16x16 / 32x32 coefficient scans -- they live in
 // the workgroup's global scratch (L1 / L2 resident) behind generic pointers.  8-bit, P / B and host builds are not slim.
-template <typename PX> struct lds_cfg { enum { slim = 0 }; };
+// (slim_scan alone: only the two large scans move -- the P / B kernel, whose image also carries the inter state)
+#if defined(CTU_PB) && defined(__HIPCC__) && !defined(CTU_NO_SLIM)
+template <typename PX> struct lds_cfg { enum { slim = 0, slim_scan = 1 }; };
+#else
+template <typename PX> struct lds_cfg { enum { slim = 0, slim_scan = 0 }; };
+#endif
 #if defined(CTU_LEAF4) && !defined(CTU_NO_SLIM)
-template <> struct lds_cfg<uint16_t> { enum { slim = 1 }; };
+template <> struct lds_cfg<uint16_t> { enum { slim = 1, slim_scan = 1 }; };
 #endif
 template <typename PX, typename T, bool SLIM = (lds_cfg<PX>::slim != 0)> struct mg_ptr { typedef CTU_LDS T *type; };
 template <typename PX, typename T> struct mg_ptr<PX, T, true> { typedef T *type; };
@@ -237,8 +242,11 @@ struct pb_cand {            // one entry of the reference's unit_stats_map_t: a 
   double cost, bits;
 };
 struct pb_state {
-  icand::unit mot[17 * 17 + 1];        // motion of every 4x4 unit of the CTU and of the row / column before it ([289]: the CTU above right, unused with WPP)
-  uint8_t fl[17 * 17][8];              // uvghip_inter4_t of the same units
+  // motion of every 4x4 unit of the CTU and of the row / column before it ([289]: the CTU above right, unused with WPP) and the
+  // uvghip_inter4_t of the same units: in the workgroup's global scratch (scratch::pb_mot / pb_fl) -- 11.6 KB of LDS were the fourth
+  // workgroup per CU, and the tables are read a few entries per candidate list
+  icand::unit *mot;
+  uint8_t (*fl)[8];
   int32_t hmvp[41];                    // the row's history table as the search sees it: [0] entries, then 5 units, most recent first
   int32_t hmvp_entry[4][41];           // ... at the entry of the node of each depth 0..3 (search_cu's hmvp_lut)
   int32_t hmvp_coder[41];              // ... as the real coder leaves it (what the next CTU of the row starts from)
@@ -278,7 +286,7 @@ template <typename PX> struct lds {
                                                     // posts the evaluation) and, adapted in place, leaves behind; [2] doubles as scratch for the 64x64 candidate
   uint32_t coder[NMX];                              // state->cabac models
   uint8_t rdoq_state[244];                          // CTX_STATE of the coder's models at the CTU's start (what uvg_rdoq prices with)
-  uint16_t scan[lds_cfg<PX>::slim ? 64 + 16 : 1024 + 256 + 64 + 16];      // coefficient scans of the four square shapes (slim: 8x8 and 4x4, the others in scratch::scan_g)
+  uint16_t scan[lds_cfg<PX>::slim_scan ? 64 + 16 : 1024 + 256 + 64 + 16];      // coefficient scans of the four square shapes (slim: 8x8 and 4x4, the others in scratch::scan_g)
   uint8_t inv4[16];                                 // scan index of the 4x4 group's raster position y * 4 + x
   uint16_t deps4[16];                               // per scan index of a 4x4 group: the scan indices (bits) its context template reads inside the group
   int32_t last_bits[92];                            // RDOQ: bit cost of the last-position prefix per (luma/chroma, log2 size, x/y, group index): last_bits_off
@@ -325,6 +333,8 @@ struct scratch {
 #if defined(CTU_PB)
   int32_t save_mot[256][8];        // the 64x64 candidate of a P / B picture while its split is tried: motion, flags
   uint8_t save_fl[256][8];
+  int32_t pb_mot[17 * 17 + 1][8];  // pb_state::mot / fl (icand::unit is eight int32)
+  uint8_t pb_fl[17 * 17][8];
 #endif
 #if defined(CTU_PB)
   unsigned long long prof_pb[16];     // CTU_PROFILE, ctu_pb.h: cycles of the phases of the P / B walk (lane 0 of the wave)
@@ -417,7 +427,7 @@ CTU_DEV int scan_base(int log2n) { return log2n == 5 ? 0 : log2n == 4 ? 1024 : l
 // the scan of the 1 << log2n square: the LDS table, or (slim build, 16x16 and 32x32) the workgroup's global copy
 template <typename PX> CTU_DEV uint16_t *scan_of(lds<PX> *S, int log2n)
 {
-  if (lds_cfg<PX>::slim) return log2n >= 4 ? S->scr->scan_g + (log2n == 5 ? 0 : 1024) : S->scan + (log2n == 3 ? 0 : 64);
+  if (lds_cfg<PX>::slim_scan) return log2n >= 4 ? S->scr->scan_g + (log2n == 5 ? 0 : 1024) : S->scan + (log2n == 3 ? 0 : 64);
   return S->scan + scan_base(log2n);
 }
 // last_bits: [luma 4, 8, 16, 32; chroma 4, 8, 16][x, y][group index 0 .. group_idx(n - 1)]
@@ -3632,7 +3642,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void store_ctu(lds<PX> *S, const job
 // carve the arena: wv[k] serves depth 4 - k (blocks of 4 << k)
 template <typename PX> CTU_DEV void setup_waves(lds<PX> *S, scratch *W = nullptr)
 {
-  if (lds_cfg<PX>::slim) { if (BLK_TID == 0) S->scr = W; }      // (scan_of reads it before load_ctu sets it again)
+  if (lds_cfg<PX>::slim_scan) { if (BLK_TID == 0) S->scr = W; }      // (scan_of reads it before load_ctu sets it again)
   BLK_FOR(k, 4) {
     const int n = 4 << k, nn = n * n, c2 = (n / 2) * (n / 2) < 16 ? 16 : (n / 2) * (n / 2), tiles = n >= 8 ? (n / 8) * (n / 8) : 1;
     int off = 0;

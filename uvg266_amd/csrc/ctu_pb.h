@@ -1767,7 +1767,9 @@ template <typename PX> CTU_DEV void run_ctu_pb(lds<PX> *S, const job<PX> &J)
 #endif
   PB_T0();
   { PB_T0();
-  setup_waves(S);
+  static_assert(sizeof(icand::unit) == 32, "scratch::pb_mot holds icand::unit as eight int32");
+  if (BLK_TID == 0) { S->pb.mot = reinterpret_cast<icand::unit *>(J.W->pb_mot); S->pb.fl = J.W->pb_fl; }
+  setup_waves(S, J.W);
   BLK_FOR(k, 4) S->wv[k].rq_root = 0;
   build_scans(S);
   BLK_SYNC();

@@ -36,6 +36,8 @@ struct pb_launch_args {
   int wc, hc, n_ctus;
 };
 
+// four workgroups (= four waves: the kernel's registers allow one per SIMD) per CU at 8 bit: 160 KB / 4 incl. the 4288 bytes of static tables
+static_assert(sizeof(ctu::lds<uint8_t>) + 4288 <= 40960, "the 8-bit LDS image of a P / B CTU no longer fits four workgroups per CU");
 template <typename PX>
 __global__ void __launch_bounds__(64) ctu_search_pb_kernel(pb_launch_args A)
 {
