@@ -648,9 +648,63 @@ def c3_clip(device, frames=24, with_cpu=True):
     return out
 
 
-def cpu_baseline_low_delay(W, H, depth, qp, frames):
+def ra_clip(device, frames=65, with_cpu=True):
+    """ONE 1920x1080 8-bit clip with --preset medium's own GOP (random access, --gop 16: hierarchical B pictures, references in the future;
+    what BASELINE.json configs[3] / [4] run with): pictures in CODING order through api.LowDelayLoop, every picture issued as soon as the
+    pictures in its reference buffer are done (by_level: the pictures at one depth of the reference DAG share a uvghip_loop_pb_run):
+    pictures of one temporal layer and of neighbouring GOPs are in flight together.  Frame-level state (slice types, the hierarchical QPs / lambdas, reference lists, coding order) from
+    tests/golden/ref_gop16_states_qp27_65frames.npz (the reference encoder's own, independent of the picture size); the first 17 coded
+    pictures are compared with the reference encoder's run of this clip (tests/golden/ref_intercrc_1920x1080_8_qp27_17frames_ra16.npz)."""
+    import zlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as Hh
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_gop16_states_qp27_65frames.npz"))
+    W, H, depth, qp = 1920, 1080, 8, int(g["dims"][0])
+    total = int(g["dims"][1])
+    frames = min(frames, total)
+    states = Hh.frame_states_from_records(g["meta"], g["lam"], g["refs"])[:frames]
+    display = [int(a) for a in g["display"][:frames]]
+    shown = {t: tuple(torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in Hh.clip_picture(W, H, t, depth)) for t in sorted(set(display))}
+    src = [[shown[display[f]] for f in range(frames)]]
+    loop = api.LowDelayLoop(W, H, depth, 1, states, src, by_level=True)
+    loop.run()                                            # warm-up (plans, first-touch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop.run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nbytes = int(sum(int(loop.row_bytes[f].sum().item()) for f in range(frames)))
+    # parity: the first GOP against the reference encoder's record of the same clip
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "ref_intercrc_1920x1080_8_qp27_17frames_ra16.npz"))
+    n_chk, hc = min(frames, int(ref["dims"][4])), (H + 63) // 64
+    ok = [int(a) for a in ref["display"][:n_chk]] == display[:n_chk]
+    for f in range(n_chk):
+        planes = [a.cpu().numpy() for a in loop.out[f][0]]
+        ok = ok and zlib.crc32(b"".join(np.ascontiguousarray(a).tobytes() for a in planes)) == int(ref["final_crc"][f])
+        rows, nb = loop.rows[f].cpu().numpy(), loop.row_bytes[f].cpu().numpy()
+        for r in range(hc):
+            ok = ok and int(nb[0, r]) == int(ref["row_len"][f * hc + r]) and zlib.crc32(rows[0, r, :nb[0, r]].tobytes()) == int(ref["row_crc"][f * hc + r])
+    if not ok:
+        raise SystemExit("ra_clip: the device's pictures / slice data differ from the reference encoder's run")
+    out = {"value": round(frames / dt, 3), "unit": "frames/s (one random-access clip, pictures in flight along the reference DAG)", "frames_timed": frames, "wall_ms": round(1e3 * dt, 1),
+           "slice_data_bytes": nbytes, "dependency_levels": 1 + max(loop.level), "launches": len(loop.order), "parity_checked": True,
+           "parity": {"golden": "ref_intercrc_1920x1080_8_qp27_17frames_ra16", "pictures": n_chk,
+                      "items": "CRC of every output picture (after deblocking + SAO) and length + CRC of every WPP row's slice data of the first GOP vs the reference encoder's run"},
+           "workload": f"{W}x{H} {depth}-bit yuv420p, ONE clip, --preset medium as it stands (--gop 16: coding order 0 16 8 4 2 1 3 6 5 7 12 ..., five temporal layers, up to five "
+                       f"reference pictures in both directions) at QP {qp}; per picture: closed-loop CTU search with the inter search on the device's own reference pictures -> "
+                       "deblocking -> SAO -> arithmetic coder",
+           "note": "the pictures at one depth of the reference DAG (the same temporal layer of one GOP, other layers of its neighbours) go through one uvghip_loop_pb_run, their "
+                   "wavefronts interleaved in the search kernel: the longest chain of dependent pictures, not the picture count, bounds the wall time; a picture by itself is "
+                   "still one wavefront of one-wave CTUs (extra_workloads.c3_clip)"}
+    del loop
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline_low_delay(W, H, depth, qp, total, gop="16")
+    return out
+
+
+def cpu_baseline_low_delay(W, H, depth, qp, frames, gop="lp-g4d3t1"):
     """The reference encoder's CLI (oracle/_ref, AVX2 strategies, its own thread pool at the defaults) on the same clip: --gop lp-g4d3t1
-    --preset medium -q <qp>, all `frames` pictures, wall clock incl. reading the input."""
+    (or the given GOP) --preset medium -q <qp>, all `frames` pictures, wall clock incl. reading the input."""
     import subprocess
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -668,7 +722,7 @@ def cpu_baseline_low_delay(W, H, depth, qp, frames):
             for t in range(frames):
                 for pl in Hh.clip_picture(W, H, t, depth):
                     f.write(np.ascontiguousarray(pl).tobytes())
-        cmd = [exe, "-i", yuv, "--input-res", f"{W}x{H}", "-n", str(frames), "--gop", "lp-g4d3t1", "--preset", "medium", "-q", str(qp), "-o", os.path.join(tmp, "out.266")]
+        cmd = [exe, "-i", yuv, "--input-res", f"{W}x{H}", "-n", str(frames), "--preset", "medium", "--gop", gop, "-q", str(qp), "-o", os.path.join(tmp, "out.266")]
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
@@ -678,7 +732,7 @@ def cpu_baseline_low_delay(W, H, depth, qp, frames):
         if r.returncode != 0 or not os.path.getsize(os.path.join(tmp, "out.266")):
             return None
     return {"value": round(frames / dt, 3), "unit": "frames/s", "cores": cores, "kind": "reference",
-            "sample": f"the whole {frames}-picture {W}x{H} clip through the reference encoder's CLI (--gop lp-g4d3t1 --preset medium -q {qp}, --threads / --owf auto on "
+            "sample": f"the whole {frames}-picture {W}x{H} clip through the reference encoder's CLI (--preset medium --gop {gop} -q {qp}, --threads / --owf auto on "
                       f"{cores} host threads, AVX2 strategies), wall time {dt:.1f} s incl. reading the input"}
 
 
@@ -957,6 +1011,8 @@ def main():
     ap.add_argument("--only-c3", action="store_true", help="time only extra_workloads.c3_low_delay_closed_loop and print it (development)")
     ap.add_argument("--c3-clip-frames", type=int, default=24, help="extra_workloads.c3_clip: pictures of the ONE 120-picture low-delay clip that are timed (0: skip; 120: the whole clip)")
     ap.add_argument("--only-c3-clip", action="store_true", help="time only extra_workloads.c3_clip and print it (development)")
+    ap.add_argument("--ra-clip-frames", type=int, default=65, help="extra_workloads.ra_clip: coded pictures of the ONE random-access (--gop 16) clip that are timed (0: skip)")
+    ap.add_argument("--only-ra-clip", action="store_true", help="time only extra_workloads.ra_clip and print it (development)")
     ap.add_argument("--c3-sequences", type=int, default=96, help="extra_workloads.c3_low_delay_closed_loop: independent low-delay sequences side by side")
     ap.add_argument("--no-extra", action="store_true", help="do not also time the 2160p 10-bit closed loop (extra_workloads)")
     args = ap.parse_args()
@@ -979,6 +1035,9 @@ def main():
         return
     if args.only_clip:
         print(json.dumps({"c2_clip": c2_clip(WORKLOADS[args.workload], device)}), flush=True)
+        return
+    if args.only_ra_clip:
+        print(json.dumps({"ra_clip": ra_clip(device, frames=args.ra_clip_frames or 65, with_cpu=not args.no_cpu_baseline)}), flush=True)
         return
     if args.only_c3_clip:
         print(json.dumps({"c3_clip": c3_clip(device, frames=args.c3_clip_frames or 24, with_cpu=not args.no_cpu_baseline)}), flush=True)
@@ -1017,6 +1076,7 @@ def main():
         c3 = inter_hot_path(device)
         c3_loop = low_delay_closed_loop(device, n_seq=args.c3_sequences)
         c3_one = c3_clip(device, frames=args.c3_clip_frames, with_cpu=not args.no_cpu_baseline) if args.c3_clip_frames > 0 else None
+        ra_one = ra_clip(device, frames=args.ra_clip_frames, with_cpu=not args.no_cpu_baseline) if args.ra_clip_frames > 0 else None
     open_loop = None
     if not args.no_open_loop and world == 1:
         ol_steps = (max(args.group, args.open_loop_steps) + args.group - 1) // args.group * args.group
@@ -1079,6 +1139,8 @@ def main():
                 out.setdefault("extra_workloads", {})["c3_low_delay_closed_loop"] = c3_loop
             if c3_one is not None:
                 out.setdefault("extra_workloads", {})["c3_clip"] = c3_one
+            if ra_one is not None:
+                out.setdefault("extra_workloads", {})["ra_clip"] = ra_one
             if clip is not None:
                 out.setdefault("extra_workloads", {})["c2_clip"] = clip
             if open_loop is not None:

@@ -1329,19 +1329,26 @@ def compare_inter_picture(W, H, d, r, buf, ntr):
     return msgs
 
 
-def inter_pictures_from_golden(g):
-    """A ref_inter_* golden (tools/refcheck/make_ctu_goldens.py::inter) as the per-picture records run_inter_oracle / compare_inter_picture
-    take, plus the source pictures -> (W, H, depth, [source (y, u, v) per frame], {frame: record dict})"""
-    W, H, depth, qp0, frames = (int(a) for a in g["dims"])
-    wc, hc = (W + 63) // 64, (H + 63) // 64
+def golden_sources(g):
+    """The source pictures of a ref_inter_* / ref_intercrc_* golden's run, one (y, u, v) per coded picture in CODING order (checked
+    against the golden's CRCs of what the encoder was fed)."""
     import zlib
+    W, H, depth, qp0, frames = (int(a) for a in g["dims"])
     gen = clip_picture if ("clip" in g.files and int(g["clip"])) else moving_picture
     shown = [gen(W, H, t, depth) for t in range(frames)]
     for t in range(frames):
         assert zlib.crc32(b"".join(p.tobytes() for p in shown[t])) == int(g["src_crc"][t]), "the sequence generator drifted from the golden's source"
     # every per-picture array of the golden is in CODING order; the source of coded picture f is display picture display[f] (random access)
     display = [int(a) for a in g["display"]] if "display" in g.files else list(range(frames))
-    pics = [shown[display[f]] for f in range(frames)]
+    return [shown[display[f]] for f in range(frames)]
+
+
+def inter_pictures_from_golden(g):
+    """A ref_inter_* golden (tools/refcheck/make_ctu_goldens.py::inter) as the per-picture records run_inter_oracle / compare_inter_picture
+    take, plus the source pictures -> (W, H, depth, [source (y, u, v) per frame], {frame: record dict})"""
+    W, H, depth, qp0, frames = (int(a) for a in g["dims"])
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    pics = golden_sources(g)
     P = {}
     for k in range(len(g["meta"])):
         fr, x, y = (int(a) for a in g["meta"][k][:3])

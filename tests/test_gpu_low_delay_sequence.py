@@ -119,10 +119,13 @@ def _frame_rows(g):
     return g["meta"][ks], g["lam"][ks], g["refs"][ks]
 
 
-@pytest.mark.parametrize("name,n_seq", [("ref_inter_264x136_8_qp32_9frames", 3), ("ref_inter_136x72_8_qp27_17frames_ra16", 2), ("ref_intercrc_1920x1080_8_qp27_5frames", 2),
-                                        ("ref_intercrc_1920x1080_10_qp32_3frames", 1), ("ref_intercrc_3840x2160_10_qp27_3frames", 1)])
-def test_low_delay_loop_of_several_sequences(hip, name, n_seq):
+@pytest.mark.parametrize("name,n_seq,in_flight", [("ref_inter_264x136_8_qp32_9frames", 3, 1), ("ref_inter_136x72_8_qp27_17frames_ra16", 2, 1), ("ref_inter_136x72_8_qp27_17frames_ra16", 2, 8),
+                                                  ("ref_intercrc_1920x1080_8_qp27_5frames", 2, 1), ("ref_intercrc_1920x1080_8_qp27_17frames_ra16", 1, 16), ("ref_inter_264x136_8_qp32_9frames", 2, 4),
+                                                  ("ref_inter_136x72_8_qp27_17frames_ra16", 2, -1), ("ref_intercrc_1920x1080_8_qp27_17frames_ra16", 1, -1), ("ref_inter_264x136_8_qp32_9frames", 2, -1),
+                                                  ("ref_intercrc_1920x1080_10_qp32_3frames", 1, 1), ("ref_intercrc_3840x2160_10_qp27_3frames", 1, 1)])
+def test_low_delay_loop_of_several_sequences(hip, name, n_seq, in_flight):
     """api.LowDelayLoop (what bench.py times for BASELINE configs[2]): n_seq sequences side by side, every picture group one call.  The
+    random-access cases (_ra16) also run with their pictures in flight (deps from the reference lists).  The
     1080p and 2160p cases are checked through the CRCs of tests/golden/ref_intercrc_* (output pictures and every row's bytes of the
     reference's run; 2160p 10-bit is the geometry of BASELINE configs[3])."""
     import zlib
@@ -134,16 +137,15 @@ def test_low_delay_loop_of_several_sequences(hip, name, n_seq):
     crc_only = "final_crc" in g.files
     meta, lam, refs = (g["meta"], g["lam"], g["refs"]) if crc_only else _frame_rows(g)
     states = H.frame_states_from_records(meta, lam, refs)
-    if crc_only:
-        pics = [H.moving_picture(W, Hh, t, depth) for t in range(frames)]
-        for t in range(frames):
-            assert zlib.crc32(b"".join(p.tobytes() for p in pics[t])) == int(g["src_crc"][t])
-    else:
-        pics = H.inter_pictures_from_golden(g)[3]          # coding order (random access: not the display order)
+    pics = H.golden_sources(g)          # coding order (random access: not the display order)
     src = [[tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in pics[f]) for f in range(frames)] for _ in range(n_seq)]
-    loop = api.LowDelayLoop(W, Hh, depth, n_seq, states, src)
-    loop.run()
+    loop = api.LowDelayLoop(W, Hh, depth, n_seq, states, src, by_level=in_flight < 0)          # (in_flight -1: the pictures of a DAG level share a launch)
+    in_flight = max(in_flight, 1)
+    import time
+    t0 = time.time()
+    loop.run(in_flight=in_flight)          # (in_flight > 1: a picture waits only for the pictures it references -- a random-access GOP's layers side by side)
     torch.cuda.synchronize()
+    print(f"{name}: {frames} pictures x {n_seq} sequence(s), {in_flight} in flight: {time.time() - t0:.2f} s")
     for f in range(frames):
         rows, nb = loop.rows[f].cpu().numpy(), loop.row_bytes[f].cpu().numpy()
         for s in range(n_seq):

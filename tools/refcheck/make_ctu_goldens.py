@@ -323,7 +323,7 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
     display, base = np.zeros(frames, np.int32), 0
     for k in range(len(S)):
         fr = int(meta[k][0])
-        if int(meta[k][6]) == 2:
+        if int(meta[k][6]) == 2 and int(refs[k][51]) == 0:         # (an IDR picture restarts the count; the I picture of a later intra period of a --gop 16 run keeps its POC)
             base = fr
         display[fr] = base + int(refs[k][51])
     assert sorted(display.tolist()) == list(range(frames)), display
@@ -344,13 +344,13 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
     return tag
 
 
-def inter_crcs(W, H, depth, qp, frames):
+def inter_crcs(W, H, depth, qp, frames, extra=(), suffix="", clip=False):
     """A low-delay encode at a size whose records are too large to keep (BASELINE configs[2]: 1080p): per picture its frame-level state
     and CRC-32s -- of the picture after the in-loop filters, of the reconstruction before them, of every WPP row's bytes -- and per CTU the
     CRC of its reconstruction (to localise a difference)."""
     import tempfile
     tmp = tempfile.mkdtemp()
-    tag = inter(W, H, depth, qp, frames, out_dir=tmp)
+    tag = inter(W, H, depth, qp, frames, extra=extra, suffix=suffix, out_dir=tmp, clip=clip)
     with np.load(os.path.join(tmp, f"ref_inter_{tag}.npz")) as z:
         g = {k: z[k] for k in z.files}          # (every access to the archive itself inflates the array again)
     wc, hc = (W + 63) // 64, (H + 63) // 64
@@ -370,26 +370,29 @@ def inter_crcs(W, H, depth, qp, frames):
         frame_meta[fr], frame_lam[fr], frame_refs[fr] = g["meta"][k], g["lam"][k], g["refs"][k]
         types[fr] += np.bincount(g["cu"][k][:, 0].reshape(16, 16)[:hh // 4, :ww // 4].ravel(), minlength=3)[:3]
     np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_intercrc_{tag}.npz"), dims=g["dims"], src_crc=g["src_crc"], meta=frame_meta, lam=frame_lam, refs=frame_refs,
-                        final_crc=final_crc, rec_crc=rec_crc, row_crc=row_crc, row_len=np.diff(row_off).astype(np.int64), ctu_crc=ctu_crc, types=types,
+                        display=g["display"], clip=g["clip"], final_crc=final_crc, rec_crc=rec_crc, row_crc=row_crc, row_len=np.diff(row_off).astype(np.int64), ctu_crc=ctu_crc, types=types,
                         bitstream_crc=np.uint32(zlib.crc32(g["bitstream"].tobytes())), bitstream_len=np.int64(len(g["bitstream"])))
     print("wrote inter crc", tag, "unit types per picture", types.tolist())
 
 
-def lowdelay_states(qp, frames):
+def lowdelay_states(qp, frames, extra=(), name="lowdelay"):
     """The frame-level state of a --gop lp-g4d3t1 --preset medium run (BASELINE configs[2]) picture by picture: slice type, QP, lambdas, the
     reference lists.  None of it depends on the picture size or content (no rate control): taken from a 136x72 run and used by bench.py to
     drive ONE long clip at 1080p (extra_workloads.c3_clip), for which full records would be far too large to keep."""
     import tempfile
     tmp = tempfile.mkdtemp()
-    tag = inter(136, 72, 8, qp, frames, out_dir=tmp, with_levels=False, clip=True)
+    tag = inter(136, 72, 8, qp, frames, extra=extra, out_dir=tmp, with_levels=False, clip=True)
     with np.load(os.path.join(tmp, f"ref_inter_{tag}.npz")) as z:
-        meta, lam, refs = z["meta"], z["lam"], z["refs"]
+        meta, lam, refs, display = z["meta"], z["lam"], z["refs"], z["display"]
     fm, fl, fr = np.zeros((frames, 8), np.int32), np.zeros((frames, 6)), np.zeros((frames, 52), np.int32)
     for k in range(len(meta)):
         f = int(meta[k][0])
         fm[f], fl[f], fr[f] = meta[k], lam[k], refs[k]
-    np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_lowdelay_states_qp{qp}_{frames}frames.npz"), dims=np.array([qp, frames], np.int32), meta=fm, lam=fl, refs=fr)
-    print("wrote low-delay states", qp, frames)
+    # (display: the source picture of coded picture f -- the identity for a low-delay run; extra=("gop", "16"), name="gop16": --preset
+    # medium's own random-access structure, bench.py's ra_clip)
+    np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_{name}_states_qp{qp}_{frames}frames.npz"), dims=np.array([qp, frames], np.int32), meta=fm, lam=fl, refs=fr,
+                        display=display)
+    print("wrote", name, "states", qp, frames)
 
 
 def alf(W, H, depth, qp, frames, t0, kind, threads=1):
@@ -483,4 +486,6 @@ if __name__ == "__main__":
     inter(136, 72, 8, 27, 4, extra=("bipred", "0", "tmvp", "0"), suffix="_p_notmvp")           # P pictures only, no temporal candidate
     inter(192, 128, 10, 24, 4, extra=("subme", "0", "early-skip", "0"), suffix="_subme0_noskip")   # integer motion only, no early skip
     lowdelay_states(27, 120)             # the frame-level state of a 120-picture low-delay clip (bench.py c3_clip)
+    lowdelay_states(27, 65, extra=("gop", "16"), name="gop16")      # ... of a 65-picture random-access clip (bench.py ra_clip)
+    inter_crcs(1920, 1080, 8, 27, 17, extra=("gop", "16"), suffix="_ra16", clip=True)      # the same structure at BASELINE's size, by CRC
     inter(136, 72, 8, 27, 17, extra=("gop", "16"), suffix="_ra16", clip=True)      # random access, --preset medium's own GOP: coding order 0 16 8 4 2 1 3 6 5 7 12 ..., future references, five temporal layers

@@ -664,7 +664,8 @@ class CtuSearch:
         plan, self.plan = getattr(self, "plan", None), None
         if plan:
             try:
-                torch.cuda.synchronize()
+                if torch is not None:          # (None at interpreter shutdown)
+                    torch.cuda.synchronize()
             finally:
                 self.L.uvghip_ctu_plan_destroy(plan)
 
@@ -791,7 +792,8 @@ class ClosedLoop(CtuSearch):
         loop, self.loop = getattr(self, "loop", None), None
         if loop:
             try:
-                torch.cuda.synchronize()
+                if torch is not None:          # (None at interpreter shutdown)
+                    torch.cuda.synchronize()
             finally:
                 self.L.uvghip_loop_plan_destroy(loop)
         CtuSearch.__del__(self)
@@ -904,17 +906,23 @@ class LowDelayLoop:
     sequence through uvghip_loop_pb_run with the device's own earlier output pictures and motion tables as references.  The frame-level
     bookkeeping stays with the caller (the reference's encoder_state / GOP code): `frames` is one dict per picture in coding order with
     slice_type (2 I, 1 P, 0 B), poc, qp, lam, lam_sqrt, c_lam, cw_u, cw_v, frame_qp, n_refs, ref_pocs[16], l_size[2], lists[2][16].
-    After run(): out[f][s] = (y, u, v) output pictures, rows[f] / row_bytes[f] = the slice data ([n_seq, rows, row_cap] / [n_seq, rows])."""
+    After run(): out[f][s] = (y, u, v) output pictures, rows[f] / row_bytes[f] = the slice data ([n_seq, rows, row_cap] / [n_seq, rows]).
+    The same loop serves a random-access GOP (--gop 16: pictures out of display order, references in the future): `frames` and `src` are in
+    CODING order there, and run(in_flight=k) issues every picture as soon as the pictures it references are done -- pictures of the same
+    temporal layer, and of neighbouring GOPs, run side by side on k streams (deps[f]: the coded pictures f reads)."""
 
-    def __init__(self, W, H, depth, n_seq, frames, src, sao_type=3, tmvp=1, max_merge=6, merge_level=2, bipred=1, fme_level=4, early_skip=1):
+    def __init__(self, W, H, depth, n_seq, frames, src, sao_type=3, tmvp=1, max_merge=6, merge_level=2, bipred=1, fme_level=4, early_skip=1, by_level=False):
+        """by_level: the P / B pictures that sit at the same depth of the reference DAG (deps) go through ONE uvghip_loop_pb_run together --
+        the pictures of one temporal layer of a random-access GOP, and of neighbouring GOPs, share a launch (their wavefronts interleave in the
+        search kernel); a low-delay sequence has one picture per level and is unchanged."""
         self.W, self.H, self.depth, self.n_seq, self.frames, self.sao_type = W, H, depth, n_seq, frames, sao_type
         wc, hc = (W + 63) // 64, (H + 63) // 64
         ctus, n4 = wc * hc, hc * 16 * wc * 16
         self.hc = hc
         tdt = torch.uint8 if depth == 8 else torch.uint16
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")
-        self.out, self.mot, self.steps, self.keep = [], [], [], []
-        by_poc = {}
+        self.out, self.mot, self.steps, self.keep, self.deps = [], [], [], [], []
+        by_poc, coded_as = {}, {}
         for f, fs in enumerate(frames):
             srcs = [tuple(src[s][f]) for s in range(n_seq)]
             if fs["slice_type"] == 2:
@@ -954,17 +962,57 @@ class LowDelayLoop:
                 L = _lib.init(torch.cuda.current_device())
                 ws = z(L.uvghip_loop_pb_workspace_bytes(depth, n_seq, W, H), torch.uint8)
                 self.steps.append(("PB", arr, ws, bufs))
+            self.deps.append([] if fs["slice_type"] == 2 else sorted({coded_as[fs["ref_pocs"][i]] for i in range(fs["n_refs"])}))
+            coded_as[fs["poc"]] = f
             for s in range(n_seq):
                 by_poc[(s, fs["poc"])] = (outs[s], mots[s])
             self.out.append(outs); self.mot.append(mots)
         self.L = _lib.init(torch.cuda.current_device())
         self.rows, self.row_bytes = [None] * len(frames), [None] * len(frames)
+        self.level = []
+        for f in range(len(frames)):
+            self.level.append(1 + max([self.level[d] for d in self.deps[f]], default=-1))
+        # order[i] = (coded pictures of the step, step): per frame, or per level of the DAG with the P / B pictures of a level merged
+        self.order = [([f], st) for f, st in enumerate(self.steps)]
+        if by_level:
+            self.order = []
+            for lv in range(1 + max(self.level)):
+                fr = [f for f in range(len(frames)) if self.level[f] == lv]
+                self.order += [([f], self.steps[f]) for f in fr if self.steps[f][0] == "I"]
+                pb = sorted([f for f in fr if self.steps[f][0] == "PB"], key=lambda f: (frames[f]["qp"], frames[f]["slice_type"], f))      # (runs of equal QP / type share the SAO decision and the coder)
+                if len(pb) == 1:
+                    self.order.append((pb, self.steps[pb[0]]))
+                elif pb:
+                    arr = (_lib.LoopPbPicture * (n_seq * len(pb)))()
+                    for j, f in enumerate(pb):
+                        ctypes.memmove(ctypes.addressof(arr) + j * n_seq * ctypes.sizeof(_lib.LoopPbPicture), ctypes.addressof(self.steps[f][1]), n_seq * ctypes.sizeof(_lib.LoopPbPicture))
+                    ws = z(self.L.uvghip_loop_pb_workspace_bytes(depth, n_seq * len(pb), W, H), torch.uint8)
+                    self.order.append((pb, ("PB", arr, ws, None)))
+            for f in range(len(frames)):          # (the per-frame workspaces are not needed)
+                if self.steps[f][0] == "PB" and not any(st is self.steps[f] for _, st in self.order):
+                    self.steps[f] = ("PB", self.steps[f][1], None, self.steps[f][3])
 
-    def run(self, stream=None):
-        """Enqueue every picture of every sequence (the P / B groups wait for the stream where the coder's tables are uploaded)."""
+    def run(self, stream=None, in_flight=1):
+        """Enqueue every picture of every sequence (the P / B groups wait for the stream where the coder's tables are uploaded).
+        in_flight > 1: coded picture f goes to stream f % in_flight of the loop's own streams and waits only for the pictures it references
+        (and for the caller's stream at the start; the caller's stream waits for all of them at the end)."""
         st = _stream() if stream is None else stream
         wc = (self.W + 63) // 64
-        for f, step in enumerate(self.steps):
+        if in_flight > 1:
+            if not hasattr(self, "_streams") or len(self._streams) < in_flight:
+                self._streams = [torch.cuda.Stream() for _ in range(in_flight)]
+            start = torch.cuda.Event()
+            start.record(torch.cuda.ExternalStream(st))
+            for t in self._streams[:in_flight]:
+                t.wait_event(start)
+            done = {}
+        for k, (fr, step) in enumerate(self.order):
+            f = fr[0]
+            if in_flight > 1:
+                own = self._streams[k % in_flight]
+                for d in sorted({d for g in fr for d in self.deps[g]}):
+                    own.wait_event(done[d])
+                st = own.cuda_stream
             if step[0] == "I":
                 _, loop, mots = step
                 loop.run(st)
@@ -975,10 +1023,24 @@ class LowDelayLoop:
                 self.rows[f], self.row_bytes[f] = loop.slice_data()
             else:
                 _, arr, ws, _ = step
-                _lib.check(self.L.uvghip_loop_pb_run(self.depth, ctypes.byref(arr), self.n_seq, self.sao_type, _dev(ws), st), "uvghip_loop_pb_run")
+                n = self.n_seq * len(fr)
+                _lib.check(self.L.uvghip_loop_pb_run(self.depth, ctypes.byref(arr), n, self.sao_type, _dev(ws), st), "uvghip_loop_pb_run")
                 c, d, cap, nr = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
-                _lib.check(self.L.uvghip_loop_pb_results(self.depth, self.n_seq, self.W, self.H, _dev(ws), None, None, ctypes.byref(c), ctypes.byref(d), ctypes.byref(cap),
+                _lib.check(self.L.uvghip_loop_pb_results(self.depth, n, self.W, self.H, _dev(ws), None, None, ctypes.byref(c), ctypes.byref(d), ctypes.byref(cap),
                                                          ctypes.byref(nr)), "uvghip_loop_pb_results")
                 base = ws.data_ptr()
-                self.rows[f] = ws[c.value - base:c.value - base + self.n_seq * nr.value * cap.value].view(self.n_seq, nr.value, cap.value)
-                self.row_bytes[f] = ws[d.value - base:d.value - base + self.n_seq * nr.value * 4].view(torch.int32).view(self.n_seq, nr.value)
+                rows = ws[c.value - base:c.value - base + n * nr.value * cap.value].view(n, nr.value, cap.value)
+                row_bytes = ws[d.value - base:d.value - base + n * nr.value * 4].view(torch.int32).view(n, nr.value)
+                for j, g in enumerate(fr):
+                    self.rows[g], self.row_bytes[g] = rows[j * self.n_seq:(j + 1) * self.n_seq], row_bytes[j * self.n_seq:(j + 1) * self.n_seq]
+            if in_flight > 1:
+                ev = torch.cuda.Event()
+                ev.record(own)
+                for g in fr:
+                    done[g] = ev
+        if in_flight > 1:
+            caller = torch.cuda.ExternalStream(_stream() if stream is None else stream)
+            for t in self._streams[:in_flight]:
+                e = torch.cuda.Event()
+                e.record(t)
+                caller.wait_event(e)

@@ -49,11 +49,11 @@ __global__ void __launch_bounds__(64) ctu_search_pb_kernel(pb_launch_args A)
   for (unsigned i = threadIdx.x; i < sizeof(ctu::lds<PX>); i += 64) smem[i] = (unsigned char)(CTU_POISON_LDS);
   __syncthreads();
 #endif
+  // a scratch slot for the workgroup's lifetime
   if (threadIdx.x == 0) {
-    s_ticket = atomicAdd(A.ticket, 1);
     const int words = A.n_slots >> 5;
     int got = -1;
-    for (int i = s_ticket % words; got < 0; i = (i + 1 == words ? 0 : i + 1)) {
+    for (int i = (int)(blockIdx.x % (unsigned)words); got < 0; i = (i + 1 == words ? 0 : i + 1)) {
       const uint32_t cur = __hip_atomic_load(&A.slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (cur == 0xffffffffu) continue;
       const int bit = __ffs((int)~cur) - 1;
@@ -61,49 +61,88 @@ __global__ void __launch_bounds__(64) ctu_search_pb_kernel(pb_launch_args A)
       if (!(prev & (1u << bit))) got = i * 32 + bit;
     }
     s_slot = got;
+    S->rot = 0;       // one wave: role 0 (ctu_core.h CTU_WAVE)
   }
-  if (threadIdx.x == 0) S->rot = 0;       // one wave: role 0 (ctu_core.h CTU_WAVE)
-  __syncthreads();
-  const int ticket = s_ticket;
-  const int32_t o = A.order[ticket];
-  const int pic = o >> 16, cy = (o >> 8) & 0xff, cx = o & 0xff;
-  const int ctus = A.wc * A.hc, k = cy * A.wc + cx;
-  int32_t *done = A.done + (size_t)pic * ctus;
+  // The workgroup takes CTU after CTU in the hand-out order until none is left.  The grid is a few workgroups per CTU of a picture's
+  // widest diagonal (uvghip_ctu_search_pb), not one per CTU: a workgroup waiting for its neighbours holds a quarter of a CU, and with
+  // several calls in flight (pictures of a random-access GOP on their own streams) the waiting ones of one picture would keep the
+  // runnable ones of another off the device.  No deadlock at any grid size: a ticket's neighbours hold smaller tickets, which are
+  // done or in the hands of running workgroups.
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = atomicAdd(A.ticket, 1);
+    __syncthreads();
+    const int ticket = s_ticket;
+    if (ticket >= A.n_ctus) break;
+    const int32_t o = A.order[ticket];
+    const int pic = o >> 16, cy = (o >> 8) & 0xff, cx = o & 0xff;
+    const int ctus = A.wc * A.hc, k = cy * A.wc + cx;
+    int32_t *done = A.done + (size_t)pic * ctus;
+    if (threadIdx.x == 0) {
+      int naps = 1;
+      const int32_t *deps[3] = {cx > 0 ? &done[k - 1] : nullptr, cy > 0 ? &done[k - A.wc] : nullptr, cy > 0 && cx + 1 < A.wc ? &done[k - A.wc + 1] : nullptr};
+      for (int d = 0; d < 3; ++d)
+        while (deps[d] && __hip_atomic_load(deps[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+          for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);
+          if (naps < 8) naps <<= 1;
+        }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    const pb_pic_dev &D = A.pics[pic];
+    ctu::job<PX> J;
+    J.P = D.P;
+    J.src_y = (const PX *)D.src_y; J.src_u = (const PX *)D.src_u; J.src_v = (const PX *)D.src_v;
+    J.src_stride = D.src_stride; J.src_stride_c = D.src_stride_c;
+    J.rec_y = (PX *)D.rec_y; J.rec_u = (PX *)D.rec_u; J.rec_v = (PX *)D.rec_v;
+    J.rec_stride = D.rec_stride; J.rec_stride_c = D.rec_stride_c;
+    J.cu_tab = D.cu; J.cu_stride = D.cu_stride;
+    J.coeff = D.coeff + (size_t)k * 6144;
+    J.models_out = D.models + (size_t)k * 3 * ctu::NMODELS;
+    J.pbm_out = D.models_inter + (size_t)k * 3 * 18;
+    const int from = cx > 0 ? k - 1 : (cy > 0 ? (cy - 1) * A.wc : -1);
+    J.models_in = from >= 0 ? D.models + ((size_t)from * 3 + 2) * ctu::NMODELS : nullptr;
+    J.pbm_in = from >= 0 ? D.models_inter + ((size_t)from * 3 + 2) * 18 : nullptr;
+    J.slice_type = D.B.slice_type; J.init_qp = D.B.frame_qp;
+    J.pb = &D.B;
+    J.W = A.scratch + s_slot;
+    J.x = cx * 64; J.y = cy * 64;
+    ctu::run_ctu_pb(S, J);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&done[k], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x == 0) atomicAnd(&A.slots[s_slot >> 5], ~(1u << (s_slot & 31)));
+}
+
+// The hand-out order, written on the device (stream-ordered: no host copy to wait for): index cx + 2 * cy first -- left, upper and
+// upper-right neighbours all have a smaller one --, pictures interleaved.  One block.
+__global__ void __launch_bounds__(256) pb_order_kernel(int32_t *order, int wc, int hc, int n_pictures)
+{
+  __shared__ int base[768];
+  const int nd = wc + 2 * (hc - 1);
   if (threadIdx.x == 0) {
-    int naps = 1;
-    const int32_t *deps[3] = {cx > 0 ? &done[k - 1] : nullptr, cy > 0 ? &done[k - A.wc] : nullptr, cy > 0 && cx + 1 < A.wc ? &done[k - A.wc + 1] : nullptr};
-    for (int d = 0; d < 3; ++d)
-      while (deps[d] && __hip_atomic_load(deps[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);
-        if (naps < 8) naps <<= 1;
-      }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    int at = 0;
+    for (int d = 0; d < nd; ++d) {
+      const int lo = d - (wc - 1) > 0 ? (d - (wc - 1) + 1) / 2 : 0, hi = d / 2 < hc - 1 ? d / 2 : hc - 1;
+      base[d] = at;
+      at += (hi >= lo ? hi - lo + 1 : 0) * n_pictures;
+    }
   }
   __syncthreads();
-  const pb_pic_dev &D = A.pics[pic];
-  ctu::job<PX> J;
-  J.P = D.P;
-  J.src_y = (const PX *)D.src_y; J.src_u = (const PX *)D.src_u; J.src_v = (const PX *)D.src_v;
-  J.src_stride = D.src_stride; J.src_stride_c = D.src_stride_c;
-  J.rec_y = (PX *)D.rec_y; J.rec_u = (PX *)D.rec_u; J.rec_v = (PX *)D.rec_v;
-  J.rec_stride = D.rec_stride; J.rec_stride_c = D.rec_stride_c;
-  J.cu_tab = D.cu; J.cu_stride = D.cu_stride;
-  J.coeff = D.coeff + (size_t)k * 6144;
-  J.models_out = D.models + (size_t)k * 3 * ctu::NMODELS;
-  J.pbm_out = D.models_inter + (size_t)k * 3 * 18;
-  const int from = cx > 0 ? k - 1 : (cy > 0 ? (cy - 1) * A.wc : -1);
-  J.models_in = from >= 0 ? D.models + ((size_t)from * 3 + 2) * ctu::NMODELS : nullptr;
-  J.pbm_in = from >= 0 ? D.models_inter + ((size_t)from * 3 + 2) * 18 : nullptr;
-  J.slice_type = D.B.slice_type; J.init_qp = D.B.frame_qp;
-  J.pb = &D.B;
-  J.W = A.scratch + s_slot;
-  J.x = cx * 64; J.y = cy * 64;
-  ctu::run_ctu_pb(S, J);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(&done[k], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    atomicAnd(&A.slots[s_slot >> 5], ~(1u << (s_slot & 31)));
+  for (int d = 0; d < nd; ++d) {
+    const int lo = d - (wc - 1) > 0 ? (d - (wc - 1) + 1) / 2 : 0, hi = d / 2 < hc - 1 ? d / 2 : hc - 1, cnt = hi >= lo ? hi - lo + 1 : 0;
+    for (int i = threadIdx.x; i < cnt * n_pictures; i += blockDim.x) {
+      const int pic = i / cnt, cy = lo + (i - pic * cnt);
+      order[base[d] + i] = pic << 16 | cy << 8 | (d - 2 * cy);
+    }
   }
+}
+// A small host table into device memory in stream order, through kernel arguments: hipMemcpy would have to drain the stream first (an
+// earlier call on this workspace may still read the table), which stalls a host that has independent pictures to issue.
+struct pb_chunk { unsigned char b[3072]; };
+__global__ void __launch_bounds__(256) pb_upload_kernel(unsigned char *dst, pb_chunk c, int n)
+{
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = c.b[i];
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -196,19 +235,20 @@ extern "C" int uvghip_ctu_search_pb(int bitdepth, const uvghip_ctu_pb_picture_t 
     d.cu = c.cu; d.coeff = c.coeff; d.models = c.models; d.models_inter = q.models_inter;
     d.src_stride = c.src_stride; d.src_stride_c = c.src_stride_c; d.rec_stride = c.rec_stride; d.rec_stride_c = c.rec_stride_c; d.cu_stride = c.cu_stride;
   }
-  // hand-out order: index cx + 2 * cy first (left, upper and upper-right neighbours all have a smaller one), pictures interleaved
-  std::vector<int32_t> order;
-  order.reserve(total);
-  for (int d = 0; d < wc + 2 * (hc - 1); ++d)
-    for (int pic = 0; pic < n_pictures; ++pic)
-      for (int cy = 0; cy < hc; ++cy) {
-        const int cx = d - 2 * cy;
-        if (cx >= 0 && cx < wc) order.push_back(pic << 16 | cy << 8 | cx);
-      }
+  // the hand-out order and the pictures' descriptors, in stream order (nothing here waits for the stream: a caller with independent
+  // pictures to issue -- api.LowDelayLoop.run(in_flight) -- is not held up by this one's references)
   hipStream_t st = uvghip_stream(stream);
-  UVGHIP_TRY(hipStreamSynchronize(st));          // (the tables of an earlier call on this workspace may still be in use)
-  UVGHIP_TRY(hipMemcpy(ws + L.order, order.data(), (size_t)total * 4, hipMemcpyHostToDevice));
-  UVGHIP_TRY(hipMemcpy(ws + L.pics, pics.data(), (size_t)n_pictures * sizeof(pb_pic_dev), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(pb_order_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<int32_t *>(ws + L.order), wc, hc, n_pictures);
+  {
+    const unsigned char *src = reinterpret_cast<const unsigned char *>(pics.data());
+    const size_t bytes = (size_t)n_pictures * sizeof(pb_pic_dev);
+    for (size_t at = 0; at < bytes; at += sizeof(pb_chunk)) {
+      pb_chunk c;
+      const int n = (int)(bytes - at < sizeof(pb_chunk) ? bytes - at : sizeof(pb_chunk));
+      memcpy(c.b, src + at, (size_t)n);
+      hipLaunchKernelGGL(pb_upload_kernel, dim3(1), dim3(256), 0, st, ws + L.pics + at, c, n);
+    }
+  }
   pb_launch_args A;
   A.pics = reinterpret_cast<const pb_pic_dev *>(ws + L.pics);
   A.order = reinterpret_cast<const int32_t *>(ws + L.order);
@@ -224,7 +264,11 @@ extern "C" int uvghip_ctu_search_pb(int bitdepth, const uvghip_ctu_pb_picture_t 
       : hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return uvghip_set_error(e, "uvghip_ctu_search_pb: dynamic LDS size");
   UVGHIP_TRY(hipMemsetAsync(ws, 0, L.order, st));
-  if (bitdepth == 8) hipLaunchKernelGGL(ctu_search_pb_kernel<uint8_t>, dim3(total), dim3(64), lds, st, A);
-  else hipLaunchKernelGGL(ctu_search_pb_kernel<uint16_t>, dim3(total), dim3(64), lds, st, A);
+  // workgroups: twice the CTUs a picture's wavefront can have in progress (the widest diagonal of cx + 2 cy), per picture
+  const int width = (wc + 1) / 2 < hc ? (wc + 1) / 2 : hc;
+  const long long want = 2LL * width * n_pictures;
+  const int grid = (int)(want < total ? want : total);
+  if (bitdepth == 8) hipLaunchKernelGGL(ctu_search_pb_kernel<uint8_t>, dim3(grid), dim3(64), lds, st, A);
+  else hipLaunchKernelGGL(ctu_search_pb_kernel<uint16_t>, dim3(grid), dim3(64), lds, st, A);
   UVGHIP_CHECK_LAUNCH();
 }
