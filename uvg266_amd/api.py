@@ -796,7 +796,8 @@ class ClosedLoop(CtuSearch):
                     torch.cuda.synchronize()
             finally:
                 self.L.uvghip_loop_plan_destroy(loop)
-        CtuSearch.__del__(self)
+        if CtuSearch is not None:
+            CtuSearch.__del__(self)
 
 
 def picture_checksum(y, u, v, stream=None):
@@ -900,6 +901,20 @@ def loop_pb_run(pictures, depth, sao_type=3, stream=None):
             view(c, n * nr.value * cap.value).view(n, nr.value, cap.value), view(d, n * nr.value * 4).view(torch.int32).view(n, nr.value))
 
 
+def reference_dag(frames):
+    """The dependencies between the coded pictures of a sequence: frames = one dict per picture in CODING order with slice_type (2 I, 1 P,
+    0 B), poc, n_refs, ref_pocs (the reference buffer the encoder coded the picture with: uvg_encoder_create_ref_lists) ->
+    (deps, level): deps[f] = the coded pictures whose output picture f reads (the most recently coded picture of each POC in its buffer),
+    level[f] = the length of the longest chain of dependent pictures before f.  Pictures of one level are independent of each other: the
+    temporal layer of a random-access GOP, and other layers of neighbouring GOPs; a low-delay sequence has one picture per level."""
+    deps, level, coded_as = [], [], {}
+    for f, fs in enumerate(frames):
+        deps.append([] if fs["slice_type"] == 2 else sorted({coded_as[fs["ref_pocs"][i]] for i in range(fs["n_refs"])}))
+        level.append(1 + max([level[d] for d in deps[f]], default=-1))
+        coded_as[fs["poc"]] = f
+    return deps, level
+
+
 class LowDelayLoop:
     """The per-picture loop of the encoder's CTU workers for n_seq independent low-delay sequences of the same shape (BASELINE configs[2]),
     picture after picture on the device: an I picture of every sequence through uvghip_loop_plan_* (ClosedLoop), a P / B picture of every
@@ -921,8 +936,9 @@ class LowDelayLoop:
         self.hc = hc
         tdt = torch.uint8 if depth == 8 else torch.uint16
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")
-        self.out, self.mot, self.steps, self.keep, self.deps = [], [], [], [], []
-        by_poc, coded_as = {}, {}
+        self.out, self.mot, self.steps, self.keep = [], [], [], []
+        self.deps, self.level = reference_dag(frames)
+        by_poc = {}
         for f, fs in enumerate(frames):
             srcs = [tuple(src[s][f]) for s in range(n_seq)]
             if fs["slice_type"] == 2:
@@ -962,16 +978,11 @@ class LowDelayLoop:
                 L = _lib.init(torch.cuda.current_device())
                 ws = z(L.uvghip_loop_pb_workspace_bytes(depth, n_seq, W, H), torch.uint8)
                 self.steps.append(("PB", arr, ws, bufs))
-            self.deps.append([] if fs["slice_type"] == 2 else sorted({coded_as[fs["ref_pocs"][i]] for i in range(fs["n_refs"])}))
-            coded_as[fs["poc"]] = f
             for s in range(n_seq):
                 by_poc[(s, fs["poc"])] = (outs[s], mots[s])
             self.out.append(outs); self.mot.append(mots)
         self.L = _lib.init(torch.cuda.current_device())
         self.rows, self.row_bytes = [None] * len(frames), [None] * len(frames)
-        self.level = []
-        for f in range(len(frames)):
-            self.level.append(1 + max([self.level[d] for d in self.deps[f]], default=-1))
         # order[i] = (coded pictures of the step, step): per frame, or per level of the DAG with the P / B pictures of a level merged
         self.order = [([f], st) for f, st in enumerate(self.steps)]
         if by_level:

@@ -38,6 +38,12 @@ struct row_state {
   // significant scan position (-1: none), the groups that hold a level by scan index / by raster position (the last group counted in)
   int32_t ci_last;
   unsigned long long ci_cg, ci_r;
+  // ... and per raster position (of the scan positions up to the last one): what the coding lane needs of the position's context
+  // template -- the five levels right of and below it -- so that it reads one word where it would read five levels and do the
+  // arithmetic of context_get_sig_ctx_idx_abs / uvg_abs_sum per coefficient: sig context (4 bits, chroma's cap applied) | context
+  // offset of the gt1 / parity / gt2 flags << 4 (5 bits) | Rice parameter of a remainder behind the context-coded flags << 9 |
+  // Rice parameter of a bypass-coded position << 11
+  uint16_t ci_pos[1024];
 };
 // P / B slices: the CTU's motion for the AMVP predictors (the table uvg_inter_get_mv_cand_cua reads of the picture's cu array), the row's
 // history table, the picture's reference lists
@@ -204,29 +210,6 @@ __device__ inline void code_mvd(coder &c, row_state *R, int mvd_hor, int mvd_ver
   }
 }
 
-// context_get_sig_ctx_idx_abs (rdo.c:1400-1438) on the staged levels: the sig context, the diagonal and the template sum
-__device__ __forceinline__ int sig_ctx_of(const int16_t *lv, int px, int py, int n, int color, int &diag, int &tsum)
-{
-  const int16_t *d = lv + px + py * n;
-  int num_pos = 0, sum_abs = 0;
-#define SLC_UPD(v) { const int a = iabs_((int)(v)); sum_abs += (4 + (a & 1)) < a ? (4 + (a & 1)) : a; num_pos += a ? 1 : 0; }
-  if (px < n - 1) {
-    SLC_UPD(d[1]);
-    if (px < n - 2) SLC_UPD(d[2]);
-    if (py < n - 1) SLC_UPD(d[n + 1]);
-  }
-  if (py < n - 1) {
-    SLC_UPD(d[n]);
-    if (py < n - 2) SLC_UPD(d[n << 1]);
-  }
-#undef SLC_UPD
-  diag = px + py;
-  int ofs = (((sum_abs + 1) >> 1) < 3 ? ((sum_abs + 1) >> 1) : 3) + (diag < 2 ? 4 : 0);
-  if (color == 0) ofs += diag < 5 ? 4 : 0;
-  tsum = sum_abs - num_pos;
-  return ofs;
-}
-
 // uvg_encode_coeff_nxn on the levels staged in R->lv (n x n, raster); lane 0
 __device__ __forceinline__ void code_coeffs(coder &c, row_state *R, int n, int color)
 {
@@ -272,23 +255,19 @@ __device__ __forceinline__ void code_coeffs(coder &c, row_state *R, int n, int c
     const int infer_sig = (first_sig != last) ? ((g != 0) ? min_sub : -1) : first_sig;
     int num_nz = 0, next_sig;
     uint32_t signs = 0;
-    int diag = -1, tsum = -1;
     for (next_sig = first_sig; next_sig >= min_sub && reg_bins >= 4; next_sig--) {
-      const int blk = scan[next_sig], py = blk >> l2, px = blk - (py << l2);
+      const int blk = scan[next_sig];
       const int s = lv[blk] != 0;
+      const int rec = R->ci_pos[blk];                       // (stage(): the position's context template, all lanes)
       if (num_nz || next_sig != infer_sig) {
-        int ctx_sig = sig_ctx_of(lv, px, py, n, color, diag, tsum);
-        if (t && ctx_sig > 7) ctx_sig = 7;
-        enc_bin(c, R, M_SIG + 12 * t + ctx_sig, s);
+        enc_bin(c, R, M_SIG + 12 * t + (rec & 15), s);
         reg_bins--;
-      } else if (next_sig != last) {
-        (void)sig_ctx_of(lv, px, py, n, color, diag, tsum);
       }
       if (s) {
         num_nz++;
         signs = (signs << 1) | (lv[blk] < 0);
-        int ofs = 0;
-        if (diag != -1) ofs = ((tsum < 4 ? tsum : 4) + 1) + (!diag ? (color == 0 ? 15 : 5) : color == 0 ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0);
+        // (the block's last position is coded before any template was looked at: offset 0, encode_coding_tree-generic.c:203-215)
+        const int ofs = next_sig == last ? 0 : (rec >> 4) & 31;
         int rem = iabs_((int)lv[blk]) - 1;
         const int gt1 = rem ? 1 : 0;
         enc_bin(c, R, M_GT1 + 21 * t + ofs, gt1);
@@ -304,14 +283,14 @@ __device__ __forceinline__ void code_coeffs(coder &c, row_state *R, int n, int c
       }
     }
     for (int sp = first_sig; sp > next_sig; sp--) {               // Golomb-Rice remainders of the context-coded positions
-      const int blk = scan[sp], py = blk >> l2, px = blk - (py << l2);
+      const int blk = scan[sp];
       const uint32_t a = (uint32_t)iabs_((int)lv[blk]);
-      if (a >= 4) enc_remain(c, (a - 4) >> 1, (uint32_t)go_rice_par((unsigned)abs_sum_tmpl(lv, px, py, n, 4)));
+      if (a >= 4) enc_remain(c, (a - 4) >> 1, (uint32_t)((R->ci_pos[blk] >> 9) & 3));
     }
     for (int sp = next_sig; sp >= min_sub; sp--) {                 // positions coded in bypass once the regular bins are spent
-      const int blk = scan[sp], py = blk >> l2, px = blk - (py << l2);
+      const int blk = scan[sp];
       const uint32_t a = (uint32_t)iabs_((int)lv[blk]);
-      const uint32_t rice = (uint32_t)go_rice_par((unsigned)abs_sum_tmpl(lv, px, py, n, 0)), pos0 = 1u << rice;
+      const uint32_t rice = (uint32_t)((R->ci_pos[blk] >> 11) & 3), pos0 = 1u << rice;
       enc_remain(c, a == 0 ? pos0 : (a <= pos0 ? a - 1 : a), rice);
       if (a) { num_nz++; signs = (signs << 1) | (lv[blk] < 0); }
     }
@@ -357,7 +336,7 @@ __device__ __forceinline__ const row_state::cui &cu_of(const row_state *R, int x
   return R->cu[(((y - y0) >> 2) + 1) * 17 + ((x - x0) >> 2) + 1];
 }
 
-__device__ __forceinline__ void stage(row_state *R, const int16_t *src, int stride, int n)        // all lanes: n x n levels -> R->lv
+__device__ __forceinline__ void stage(row_state *R, const int16_t *src, int stride, int n, int color)        // all lanes: n x n levels -> R->lv
 {
   __syncthreads();
   const int l2 = ilog2_dev(n), nn = n * n, cgw = n >> 2;
@@ -388,6 +367,30 @@ __device__ __forceinline__ void stage(row_state *R, const int16_t *src, int stri
     rr = (unsigned long long)hi << 32 | lo;
   }
   if (threadIdx.x == 0) { R->ci_last = last; R->ci_cg = cg; R->ci_r = rr; }
+  // the context template of every position the coder will visit (context_get_sig_ctx_idx_abs rdo.c:1400-1438, uvg_abs_sum context.c:846-877)
+  for (int sp = threadIdx.x; sp <= last; sp += 64) {
+    const int blk = scan[sp], py = blk >> l2, px = blk - (py << l2);
+    const int16_t *d = R->lv + blk;
+    int num_pos = 0, sum_cap = 0, sum = 0;
+#define SLC_UPD(v) { const int a = iabs_((int)(v)); sum += a; sum_cap += (4 + (a & 1)) < a ? (4 + (a & 1)) : a; num_pos += a ? 1 : 0; }
+    if (px < n - 1) {
+      SLC_UPD(d[1]);
+      if (px < n - 2) SLC_UPD(d[2]);
+      if (py < n - 1) SLC_UPD(d[n + 1]);
+    }
+    if (py < n - 1) {
+      SLC_UPD(d[n]);
+      if (py < n - 2) SLC_UPD(d[n << 1]);
+    }
+#undef SLC_UPD
+    const int diag = px + py, tsum = sum_cap - num_pos;
+    int ctx_sig = (((sum_cap + 1) >> 1) < 3 ? ((sum_cap + 1) >> 1) : 3) + (diag < 2 ? 4 : 0);
+    if (color == 0) ctx_sig += diag < 5 ? 4 : 0;
+    else if (ctx_sig > 7) ctx_sig = 7;
+    const int ofs = ((tsum < 4 ? tsum : 4) + 1) + (!diag ? (color == 0 ? 15 : 5) : color == 0 ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0);
+    const int s4 = sum - 20 < 0 ? 0 : (sum - 20 < 31 ? sum - 20 : 31), s0 = sum < 31 ? sum : 31;
+    R->ci_pos[blk] = (uint16_t)(ctx_sig | ofs << 4 | go_rice_par((unsigned)s4) << 9 | go_rice_par((unsigned)s0) << 11);
+  }
   __syncthreads();
 }
 
@@ -757,9 +760,9 @@ slice_rows_kernel(const pic_dev *__restrict__ pics, const pb_dev *__restrict__ p
                 enc_bin(c, R, M_CBF_CB, cb_u); enc_bin(c, R, M_CBF_CR + cb_u, cb_v);
                 if (n == 64 || cb_u || cb_v) enc_bin(c, R, M_CBF_LUMA, cb_y);       // otherwise inferred 1 (:705-716)
               }
-              if (cb_y) { stage(R, co + tly * 64 + tlx, 64, tn); if (lane0) code_coeffs(c, R, tn, 0); }
-              if (cb_u) { stage(R, co + 4096 + (tly >> 1) * 32 + (tlx >> 1), 32, tn >> 1); if (lane0) code_coeffs(c, R, tn >> 1, 1); }
-              if (cb_v) { stage(R, co + 5120 + (tly >> 1) * 32 + (tlx >> 1), 32, tn >> 1); if (lane0) code_coeffs(c, R, tn >> 1, 2); }
+              if (cb_y) { stage(R, co + tly * 64 + tlx, 64, tn, 0); if (lane0) code_coeffs(c, R, tn, 0); }
+              if (cb_u) { stage(R, co + 4096 + (tly >> 1) * 32 + (tlx >> 1), 32, tn >> 1, 1); if (lane0) code_coeffs(c, R, tn >> 1, 1); }
+              if (cb_v) { stage(R, co + 5120 + (tly >> 1) * 32 + (tlx >> 1), 32, tn >> 1, 2); if (lane0) code_coeffs(c, R, tn >> 1, 2); }
             }
           }
           continue;
@@ -778,18 +781,18 @@ slice_rows_kernel(const pic_dev *__restrict__ pics, const pb_dev *__restrict__ p
           if (!sep) { enc_bin(c, R, M_CBF_CB, cb_u); enc_bin(c, R, M_CBF_CR + cb_u, cb_v); }
           enc_bin(c, R, M_CBF_LUMA, cb_y);
         }
-        if (cb_y) { stage(R, co + tly * 64 + tlx, 64, tn); if (lane0) code_coeffs(c, R, tn, 0); }
+        if (cb_y) { stage(R, co + tly * 64 + tlx, 64, tn, 0); if (lane0) code_coeffs(c, R, tn, 0); }
         if (!sep) {
-          if (cb_u) { stage(R, co + 4096 + (tly >> 1) * 32 + (tlx >> 1), 32, tn >> 1); if (lane0) code_coeffs(c, R, tn >> 1, 1); }
-          if (cb_v) { stage(R, co + 5120 + (tly >> 1) * 32 + (tlx >> 1), 32, tn >> 1); if (lane0) code_coeffs(c, R, tn >> 1, 2); }
+          if (cb_u) { stage(R, co + 4096 + (tly >> 1) * 32 + (tlx >> 1), 32, tn >> 1, 1); if (lane0) code_coeffs(c, R, tn >> 1, 1); }
+          if (cb_v) { stage(R, co + 5120 + (tly >> 1) * 32 + (tlx >> 1), 32, tn >> 1, 2); if (lane0) code_coeffs(c, R, tn >> 1, 2); }
         } else if (last4) {
           // the 8x8 area's chroma after its last luma CU: mode (the co-located luma CU is this one), cbfs of the area's first entry, levels
           const int acbf = cu_of(R, x0, y0, x & ~7, y & ~7).cbf;
           const int au = (acbf >> 1) & 1, av = (acbf >> 2) & 1;
           if (lane0) { code_chroma_mode(c, R, mode_c, mode); enc_bin(c, R, M_CBF_CB, au); enc_bin(c, R, M_CBF_CR + au, av); }
           const int cbx = (lx & ~7) >> 1, cby = (ly & ~7) >> 1;
-          if (au) { stage(R, co + 4096 + cby * 32 + cbx, 32, 4); if (lane0) code_coeffs(c, R, 4, 1); }
-          if (av) { stage(R, co + 5120 + cby * 32 + cbx, 32, 4); if (lane0) code_coeffs(c, R, 4, 2); }
+          if (au) { stage(R, co + 4096 + cby * 32 + cbx, 32, 4, 1); if (lane0) code_coeffs(c, R, 4, 1); }
+          if (av) { stage(R, co + 5120 + cby * 32 + cbx, 32, 4, 2); if (lane0) code_coeffs(c, R, 4, 2); }
         }
       }
     }
