@@ -1009,7 +1009,7 @@ def main():
     ap.add_argument("--only-search-rows", action="store_true", help="time only the row-sharded closed-loop search (one rank: a band = the whole picture; development)")
     ap.add_argument("--only-clip", action="store_true", help="time only extra_workloads.c2_clip (development)")
     ap.add_argument("--only-c3", action="store_true", help="time only extra_workloads.c3_low_delay_closed_loop and print it (development)")
-    ap.add_argument("--c3-clip-frames", type=int, default=24, help="extra_workloads.c3_clip: pictures of the ONE 120-picture low-delay clip that are timed (0: skip; 120: the whole clip)")
+    ap.add_argument("--c3-clip-frames", type=int, default=16, help="extra_workloads.c3_clip: pictures of the ONE 120-picture low-delay clip that are timed (0: skip; 120: the whole clip)")
     ap.add_argument("--only-c3-clip", action="store_true", help="time only extra_workloads.c3_clip and print it (development)")
     ap.add_argument("--ra-clip-frames", type=int, default=65, help="extra_workloads.ra_clip: coded pictures of the ONE random-access (--gop 16) clip that are timed (0: skip)")
     ap.add_argument("--only-ra-clip", action="store_true", help="time only extra_workloads.ra_clip and print it (development)")
@@ -1061,7 +1061,7 @@ def main():
     extra = None
     if not args.no_extra and wl_name == "1080p8":
         ewl = WORKLOADS["2160p10alf"]
-        ek, eF = 8, max(1, args.in_flight // 2)          # (a 4K picture has 93 diagonals of at most 34 CTUs: 80 pictures keep 768 workgroups fed)
+        ek, eF = 8, max(1, args.in_flight // 2)          # (a 4K picture has 93 diagonals of at most 34 CTUs: 112 pictures keep the 1024 workgroup slots fed)
         ecl, eF, eel, ems, eln = closed_loop(ewl, ek, 2, eF, device, rank, world, dist, args.groups)
         if parity is not None:
             parity.append(parity_check(ecl[0], "ref_ctucrc_3840x2160_10_qp22"))
@@ -1070,7 +1070,7 @@ def main():
                  "mpixels_per_s": round(ek * eF * world / eel * ewl["W"] * ewl["H"] / 1e6, 1),
                  "search_launch_ms": round(ems / max(1, eln), 2),
                  "workload": "3840x2160 10-bit yuv420p, QP 22: the same closed loop (search -> deblock -> SAO; ALF of configs[3] is in the open-loop chain only)"}
-    c3 = c3_loop = clip = c3_one = None
+    c3 = c3_loop = clip = c3_one = ra_one = None
     if not args.no_extra and wl_name == "1080p8" and rank == 0:
         clip = c2_clip(wl, device)
         c3 = inter_hot_path(device)

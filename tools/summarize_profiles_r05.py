@@ -20,8 +20,10 @@ def short(kernel):
 
 shutil.copy(newest("gpurun_out/prof5_stats/**/*kernel_stats.csv"), f"profiles/{tag}_bench_kernel_stats.csv")
 shutil.copy(newest("gpurun_out/prof5_stats_1/**/*kernel_stats.csv"), f"profiles/{tag}_bench_kernel_stats_one_launch_in_flight.csv")
-shutil.copy("gpurun_out/prof5_bench_line.json", f"profiles/{tag}_bench_line_profiled.json")
-shutil.copy("gpurun_out/prof5_bench_line_1.json", f"profiles/{tag}_bench_line_profiled_one_launch_in_flight.json")
+for a, b in (("gpurun_out/prof5_bench_line.json", f"profiles/{tag}_bench_line_profiled.json"),
+             ("gpurun_out/prof5_bench_line_1.json", f"profiles/{tag}_bench_line_profiled_one_launch_in_flight.json")):
+    if os.path.getsize(a):          # (empty: the profiled run did not print its line -- the kernel tables are complete all the same)
+        shutil.copy(a, b)
 shutil.copy("gpurun_out/prof5_command.txt", f"profiles/{tag}_profiled_command.txt")
 
 
@@ -36,8 +38,10 @@ def per_kernel(dirname, counters):
 
 fetch = per_kernel("prof5_fetch", ["FETCH_SIZE"])["FETCH_SIZE"]
 write = per_kernel("prof5_write", ["WRITE_SIZE"])["WRITE_SIZE"]
-line = json.loads(open("gpurun_out/prof5_bench_line_1.json").read())
-pics = line["config"]["pictures_per_step"]
+try:
+    pics = json.loads(open("gpurun_out/prof5_bench_line_1.json").read())["config"]["pictures_per_step"]
+except Exception:          # noqa: BLE001
+    pics = 224          # bench.py's default group (--in-flight)
 traffic = {}
 for k in sorted(set(fetch) | set(write)):
     f, nf = fetch.get(k, (0.0, 0))
@@ -60,9 +64,12 @@ if ck:
                             "bytes_per_picture": round(t["hbm_bytes_per_launch"] / pics), "tag": tag,
                             "source_sha1": sha}          # of ctu_core.h + ctu_search.hip as profiled: bench.py refuses the number for other sources
 json.dump(latest, open("profiles/hbm_traffic_latest.json", "w"), indent=1)
-sq = per_kernel("prof5_sq", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"])
-json.dump({c: {k: {"per_launch": round(v[0]), "launches": v[1]} for k, v in d.items()} for c, d in sq.items()},
-          open(f"profiles/{tag}_bench_sq_insts.json", "w"), indent=1)
+try:
+    sq = per_kernel("prof5_sq", ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"])
+    json.dump({c: {k: {"per_launch": round(v[0]), "launches": v[1]} for k, v in d.items()} for c, d in sq.items()},
+              open(f"profiles/{tag}_bench_sq_insts.json", "w"), indent=1)
+except Exception as e:          # noqa: BLE001 -- an optional pass
+    print("no SQ instruction pass:", e, file=sys.stderr)
 try:
     occ = per_kernel("prof5_occ", ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES"])
     json.dump({c: {k: {"per_launch": round(v[0]), "launches": v[1]} for k, v in d.items()} for c, d in occ.items()},

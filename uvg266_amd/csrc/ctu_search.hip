@@ -139,7 +139,7 @@ size_t lds_pad()
 }
 
 // Scratch slots: a workgroup claims one while it runs.  2048 = 256 CUs x 8 is more than the device can hold of this kernel
-// (3 per CU); small jobs take one slot per CTU, rounded up to whole bitmap words.
+// (4 per CU); small jobs take one slot per CTU, rounded up to whole bitmap words.
 enum { MAX_SLOTS = 2048 };
 struct ws_layout { size_t ticket, slots, simd_load, done, order, pics, scratch, total; int n_slots; };
 ws_layout layout(int n_pictures, int pic_w, int pic_h)
