@@ -122,12 +122,13 @@ def _frame_rows(g):
 @pytest.mark.parametrize("name,n_seq,in_flight", [("ref_inter_264x136_8_qp32_9frames", 3, 1), ("ref_inter_136x72_8_qp27_17frames_ra16", 2, 1), ("ref_inter_136x72_8_qp27_17frames_ra16", 2, 8),
                                                   ("ref_intercrc_1920x1080_8_qp27_5frames", 2, 1), ("ref_intercrc_1920x1080_8_qp27_17frames_ra16", 1, 16), ("ref_inter_264x136_8_qp32_9frames", 2, 4),
                                                   ("ref_inter_136x72_8_qp27_17frames_ra16", 2, -1), ("ref_inter_136x72_10_qp22_17frames_ra16", 1, -1), ("ref_intercrc_1920x1080_8_qp27_17frames_ra16", 1, -1), ("ref_inter_264x136_8_qp32_9frames", 2, -1),
-                                                  ("ref_intercrc_1920x1080_10_qp32_3frames", 1, 1), ("ref_intercrc_3840x2160_10_qp27_3frames", 1, 1)])
+                                                  ("ref_intercrc_1920x1080_10_qp32_3frames", 1, 1), ("ref_intercrc_3840x2160_10_qp27_3frames", 1, 1),
+                                                  ("ref_intercrc_3840x2160_10_qp27_17frames_ra16", 1, -1)])
 def test_low_delay_loop_of_several_sequences(hip, name, n_seq, in_flight):
     """api.LowDelayLoop (what bench.py times for BASELINE configs[2]): n_seq sequences side by side, every picture group one call.  The
     random-access cases (_ra16) also run with their pictures in flight (deps from the reference lists).  The
     1080p and 2160p cases are checked through the CRCs of tests/golden/ref_intercrc_* (output pictures and every row's bytes of the
-    reference's run; 2160p 10-bit is the geometry of BASELINE configs[3])."""
+    reference's run; 2160p 10-bit is the geometry of BASELINE configs[3], and its _ra16 case that configuration's GOP -- without ALF)."""
     import zlib
     import torch
     from uvg266_amd import api
