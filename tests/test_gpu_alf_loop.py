@@ -1,0 +1,101 @@
+"""ALF in the picture loop (BASELINE configs[3]: --alf full) with the derivation where SURVEY.md keeps it -- on the host, behind a
+callback: api.ClosedLoop.alf_stage.  The device runs the closed loop of the source pictures (search -> deblocking -> SAO), hands the
+frame statistics to `decide`, reconstructs with what it returns and codes the slice data with the ALF syntax.  Here `decide` replays the
+decisions a real `--alf full` run made (tests/golden/ref_stream_*_alf, ref_ctu_*_alf: tools/refcheck/ctu_dump.c around
+uvg_alf_enc_process): the pictures ALF leaves, the slice data and -- with the library's host writer for the APS NAL units, the slice header
+and the hash SEI over the device's checksum of its own output -- the encoder's whole .266 come out of the device."""
+import ctypes
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import helpers as H
+from test_alf_syntax import write_alf_picture_nals
+
+pytestmark = pytest.mark.gpu
+
+
+def replay(pictures, seen=None):
+    """decide(i, stats) returning picture i's recorded decisions (and, once, asking for every statistic the derivation would read)."""
+    def decide(i, stats):
+        p = pictures[i]
+        m = p["meta"]
+        if seen is not None and not seen:
+            cls = stats.classification()
+            ee, yv, pa = stats.luma()
+            ce, cy, cp = stats.chroma(1)
+            xe, xy, xp = stats.cc(2)
+            n = stats.rects_y.shape[0]
+            assert tuple(cls.shape) == (stats.H // 4, stats.W // 4) and tuple(ee.shape) == (n, 25, 13, 13, 4, 4) and tuple(ce.shape) == (n, 1, 13, 13, 4, 4) and tuple(xe.shape) == (n, 7, 7)
+            assert int(pa.sum().item()) >= 0 and int(xp.sum().item()) >= 0
+            seen.append(1)
+        return dict(alf_type=int(m[3]), enabled=[int(a) for a in m[4:7]], n_luma_aps=int(m[7]), luma_aps=p["luma_aps"], chroma_aps=p["chroma_aps"],
+                    cc_enabled=[int(a) for a in m[17:19]], cc_filter_count=[int(a) for a in m[19:21]], cc_coeff=p["cc_coeff"], ctu_flags=p["flags"], filter_set_idx=p["set_idx"])
+    return decide
+
+
+def host_rows(rows, nbytes, i):
+    nb = np.ascontiguousarray(nbytes[i].cpu().numpy(), np.int32)
+    return np.ascontiguousarray(rows[i, :, :int(nb.max())].cpu().numpy()), nb
+
+
+def test_a_four_picture_alf_stream_through_the_loop(hip):
+    """Four pictures of one -p 1 --alf full stream as ONE group of the closed loop; later pictures open their access unit with the APS, refer
+    to APSs of earlier pictures and use fixed filter sets only."""
+    import torch
+    from uvg266_amd import api
+    g = H.ctu_golden("ref_stream_192x128_8_qp27_4frames_alf")
+    W, Hh, depth, qp = (int(a) for a in g["meta"])
+    prm = H.search_params(W, Hh, qp)
+    src = []
+    for poc, t in enumerate(g["ts"]):
+        y, u, v = H.varied_picture(W, Hh, int(t), depth)
+        assert zlib.crc32(y.tobytes() + u.tobytes() + v.tobytes()) == int(g["src_crc"][poc])
+        src.append(tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in (y, u, v)))
+    pictures = [{k[4:]: g[k][poc] for k in ("alf_meta", "alf_flags", "alf_set_idx", "alf_luma_aps", "alf_chroma_aps", "alf_cc_coeff")} for poc in range(len(src))]
+    cl = api.ClosedLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), src)
+    cl.run()
+    seen = []
+    alf_out, rows, nbytes = cl.alf_stage(replay(pictures, seen), source=src, classification_shift=int(pictures[0]["meta"][28]) + 4)
+    torch.cuda.synchronize()
+    assert seen
+    mine = b""
+    for poc in range(len(src)):
+        sums = api.picture_checksum(*alf_out[poc]).cpu().numpy().view(np.uint32)
+        r, nb = host_rows(rows, nbytes, poc)
+        sel = g["aps_meta"][:, 0] == poc
+        one = dict(alf_meta=pictures[poc]["meta"], aps_meta=g["aps_meta"][sel], aps_luma=g["aps_luma"][sel], aps_chroma=g["aps_chroma"][sel], aps_cc=g["aps_cc"][sel])
+        mine += write_alf_picture_nals(hip, one, r, nb, sums, poc=poc)
+    stream = g["bitstream"].tobytes()
+    at = stream.find(b"\x00\x00\x01\x00\x89")
+    assert at > 0 and stream[:at] + mine == stream, "the encoder's parameter sets + the device's pictures (APS, slice, hash SEI) = the encoder's --alf full .266"
+
+
+@pytest.mark.parametrize("name", ["ref_ctu_320x192_10_qp27_alf", "ref_ctu_192x128_8_qp22_alf", "ref_ctu_256x128_10_qp27_alf_nocc"])
+def test_one_picture_item_by_item(hip, name):
+    """A picture of an --alf full (the last: --alf no-cc) run: the picture ALF got, the picture it left, the slice data, the file."""
+    import torch
+    from uvg266_amd import api
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    prm = H.search_params(W, Hh, qp)
+    src = [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in (y, u, v))]
+    cl = api.ClosedLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), src)
+    cl.run()
+    for o, k in zip(cl.out[0], ("alf_pre_y", "alf_pre_u", "alf_pre_v")):
+        assert np.array_equal(o.cpu().numpy(), g[k]), ("the picture ALF gets", k)
+    pic = {k[4:]: g[k] for k in ("alf_meta", "alf_flags", "alf_set_idx", "alf_luma_aps", "alf_chroma_aps", "alf_cc_coeff")}
+    alf_out, rows, nbytes = cl.alf_stage(replay([pic]), source=src, classification_shift=int(pic["meta"][28]) + 4)
+    torch.cuda.synchronize()
+    for o, k in zip(alf_out[0], ("final_y", "final_u", "final_v")):
+        assert np.array_equal(o.cpu().numpy(), g[k]), ("the picture ALF leaves", k)
+    r, nb = host_rows(rows, nbytes, 0)
+    assert np.array_equal(np.concatenate([[0], np.cumsum(nb)]), g["row_off"])
+    assert np.array_equal(np.concatenate([r[i, :nb[i]] for i in range(len(nb))]), g["row_bytes"])
+    sums = api.picture_checksum(*alf_out[0]).cpu().numpy().view(np.uint32)
+    nals = write_alf_picture_nals(hip, g, r, nb, sums)
+    stream = g["bitstream"].tobytes()
+    at = stream.find(b"\x00\x00\x01\x00\x89")
+    assert at > 0 and stream[:at] + nals == stream

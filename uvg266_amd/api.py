@@ -788,6 +788,37 @@ class ClosedLoop(CtuSearch):
         torch.cuda.synchronize()          # (the decisions' device copies go out of scope with this call)
         return out, nbytes
 
+    def alf_stage(self, decide, source=None, classification_shift=None):
+        """The ALF stage of the picture loop (BASELINE configs[3]: --alf full), after run(): for every picture of the plan
+          1. the frame's ALF statistics from the loop's SAO output on the device, handed over on demand (AlfStatistics: classification,
+             luma covariance per class and CTU, chroma covariance, CC-ALF covariance -- what alf_derive_stats_for_filtering leaves, alf.c:4227),
+          2. `decide(i, stats)` on the host -> the picture's decisions: the derivation the reference keeps in alf_encoder / alf_encoder_ctb /
+             derive_cc_alf_filter (alf.c:3994, 4369, 2212); the tests replay a real run's.  A dict with alf_type (1 no-cc, 2 full), enabled
+             (3), n_luma_aps, luma_aps (i16 [k][677]), chroma_aps (i16 [114], [112] = the number of alternatives), cc_enabled (2),
+             cc_filter_count (2), cc_coeff (i16 [2][4][8]), ctu_flags (u8 [7][ctus]), filter_set_idx (i16 [ctus]) -- the layouts of
+             uvghip_alf_picture_t / uvghip_slice_alf_t,
+          3. uvghip_alf_reconstruct_picture on the SAO output -> alf_out[i], the picture the encoder returns and hashes,
+          4. uvghip_encode_slice_rows_alf: the slice data with the CTU-level ALF syntax.
+        -> (alf_out: per picture three device planes, rows [n, n_rows, row_cap] uint8, row_bytes [n, n_rows] int32).  source: the plan's
+        source pictures (the statistics compare with them); classification_shift: cfg.input_bitdepth + 4 (alf.c:5185; default depth + 4)."""
+        shift = self.depth + 4 if classification_shift is None else classification_shift
+        decisions, self.alf_out = [], []
+        for i in range(self.n):
+            stats = AlfStatistics(self.out[i], None if source is None else source[i], int(self.P.pic_w), int(self.P.pic_h), shift)
+            d = decide(i, stats)
+            decisions.append(d)
+            if int(d["enabled"][0]) or int(d["enabled"][1]) or int(d["enabled"][2]) or int(d["cc_enabled"][0]) or int(d["cc_enabled"][1]):
+                k = int(d["n_luma_aps"])
+                self.alf_out.append(alf_reconstruct_picture(list(self.out[i]), d["enabled"], d["ctu_flags"], d["filter_set_idx"], np.asarray(d["luma_aps"]).reshape(-1, 677)[:k],
+                                                            d["chroma_aps"], alf_full=int(d["alf_type"]) == 2, cc_alf_enabled=d["cc_enabled"], cc_coeff=d["cc_coeff"],
+                                                            classification_shift=shift))
+            else:
+                self.alf_out.append(list(self.out[i]))          # (a picture ALF leaves alone)
+        rows, nbytes = self.encode_rows_alf([dict(alf_type=d["alf_type"], enabled=d["enabled"], n_luma_aps=d["n_luma_aps"], n_alternatives_chroma=int(np.asarray(d["chroma_aps"]).ravel()[112]),
+                                                  cc_enabled=d["cc_enabled"], cc_filter_count=d["cc_filter_count"], ctu_flags=d["ctu_flags"], filter_set_idx=d["filter_set_idx"])
+                                             for d in decisions])
+        return self.alf_out, rows, nbytes
+
     def __del__(self):
         loop, self.loop = getattr(self, "loop", None), None
         if loop:
@@ -913,6 +944,43 @@ def reference_dag(frames):
         level.append(1 + max([level[d] for d in deps[f]], default=-1))
         coded_as[fs["poc"]] = f
     return deps, level
+
+
+class AlfStatistics:
+    """What ClosedLoop.alf_stage hands the host's ALF derivation: the frame's statistics, computed on the device when asked for.
+    rec: the picture ALF gets (deblocked + SAO), org: the source picture (three device planes each)."""
+
+    def __init__(self, rec, org, width, height, shift):
+        self.rec, self.org, self.W, self.H, self.shift = rec, org, width, height, shift
+        wc, hc = (width + 63) // 64, (height + 63) // 64
+        ry, rc = [], []
+        for cy in range(hc):
+            for cx in range(wc):
+                x, y = cx * 64, cy * 64
+                bw, bh = min(64, width - x), min(64, height - y)
+                ry.append((x, y, bw, bh)); rc.append((x // 2, y // 2, bw // 2, bh // 2))
+        dev = rec[0].device
+        self.rects_y = torch.from_numpy(np.asarray(ry, np.int32)).to(dev)
+        self.rects_c = torch.from_numpy(np.asarray(rc, np.int32)).to(dev)
+        self._cls = None
+
+    def classification(self):
+        """uvghip_alf_classify_frame: class | transpose << 5 per 4x4 luma block (alf_derive_classification, alf.c:5157)."""
+        if self._cls is None:
+            self._cls = alf_classify_frame(self.rec[0], self.W, self.H, self.shift)
+        return self._cls
+
+    def luma(self):
+        """Per CTU and class the covariance of get_blk_stats (alf.c:2378; -> ee, y, pix_acc as alf_stats_batch returns them)."""
+        return alf_stats_batch(self.org[0], self.rec[0], self.rects_y, cls=self.classification(), pic_w=self.W, pic_h=self.H)
+
+    def chroma(self, c):
+        """Per CTU the chroma covariance of plane c = 1, 2."""
+        return alf_stats_batch(self.org[c], self.rec[c], self.rects_c, is_chroma=True, pic_w=self.W // 2, pic_h=self.H // 2)
+
+    def cc(self, c):
+        """Per CTU the CC-ALF covariance of plane c = 1, 2 (get_blk_stats_cc_alf, alf.c:2613)."""
+        return cc_alf_stats_batch(self.org[c], self.rec[c], self.rec[0], self.rects_c)
 
 
 class LowDelayLoop:
