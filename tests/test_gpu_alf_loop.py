@@ -99,3 +99,30 @@ def test_one_picture_item_by_item(hip, name):
     stream = g["bitstream"].tobytes()
     at = stream.find(b"\x00\x00\x01\x00\x89")
     assert at > 0 and stream[:at] + nals == stream
+
+
+def test_a_2160p_10bit_picture_by_crc(hip):
+    """BASELINE configs[3]'s size: one 3840x2160 10-bit --alf full picture (ref_stream_3840x2160_10_qp22_1frames_alf_crc: the run's decisions
+    and APSs, of its .266 the parameter sets and length + CRC of the rest) -- the source through the device's loop, the ALF stage with the
+    decisions replayed, the library's NAL writer."""
+    import torch
+    from uvg266_amd import api
+    g = np.load(os.path.join(H.GOLDEN, "ref_stream_3840x2160_10_qp22_1frames_alf_crc.npz"))
+    W, Hh, depth, qp = (int(a) for a in g["meta"])
+    y, u, v = H.varied_picture(W, Hh, int(g["ts"][0]), depth)
+    assert zlib.crc32(y.tobytes() + u.tobytes() + v.tobytes()) == int(g["src_crc"][0])
+    prm = H.search_params(W, Hh, qp)
+    src = [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in (y, u, v))]
+    cl = api.ClosedLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), src)
+    cl.run()
+    pic = {k[4:]: g[k][0] for k in ("alf_meta", "alf_flags", "alf_set_idx", "alf_luma_aps", "alf_chroma_aps", "alf_cc_coeff")}
+    seen = []
+    alf_out, rows, nbytes = cl.alf_stage(replay([pic], seen), source=src, classification_shift=int(pic["meta"][28]) + 4)
+    # the frame-level luma statistics: 25 classes x (the ee triangle, y, pix_acc), summed over the 2040 CTUs on the device
+    sums = api.AlfStatistics(cl.out[0], src[0], W, Hh, int(pic["meta"][28]) + 4).luma_frame()
+    torch.cuda.synchronize()
+    assert tuple(sums.shape) == (25, 1509) and int((sums[:, 1508] > 0).sum().item()) > 0
+    r, nb = host_rows(rows, nbytes, 0)
+    ck = api.picture_checksum(*alf_out[0]).cpu().numpy().view(np.uint32)
+    nals = write_alf_picture_nals(hip, dict(alf_meta=pic["meta"], aps_meta=g["aps_meta"], aps_luma=g["aps_luma"], aps_chroma=g["aps_chroma"], aps_cc=g["aps_cc"]), r, nb, ck)
+    assert len(nals) == int(g["bitstream_tail_len"]) and zlib.crc32(nals) == int(g["bitstream_tail_crc"])

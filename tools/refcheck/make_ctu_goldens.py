@@ -209,7 +209,7 @@ def stream(W, H, depth, qp, ts):
     print("wrote stream", tag, len(bs), "bytes")
 
 
-def stream_alf(W, H, depth, qp, ts):
+def stream_alf(W, H, depth, qp, ts, crc_only=False):
     """A whole multi-picture -p 1 --alf full stream (one worker thread): the .266, its source pictures and per picture the ALF decisions and
     the APSs written in front of it (records "alf" / "aps" of ctu_dump.c) -- the rest of every picture follows from the source."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -233,8 +233,16 @@ def stream_alf(W, H, depth, qp, ts):
     assert len(A) == len(ts)
     n = ((W + 63) // 64) * ((H + 63) // 64)
     bs = np.frombuffer(open(out + ".266", "rb").read(), np.uint8)
+    more = dict(bitstream=bs)
+    if crc_only:
+        # a size whose .266 is too large to keep (BASELINE configs[3]: 2160p): the parameter sets in front of the first APS NAL unit as they
+        # are, of everything behind them the length and the CRC
+        at = bs.tobytes().find(b"\x00\x00\x01\x00\x89")
+        assert at > 0
+        more = dict(bitstream_head=bs[:at].copy(), bitstream_tail_len=np.int64(len(bs) - at), bitstream_tail_crc=np.uint32(zlib.crc32(bs[at:].tobytes())))
+        tag += "_crc"
     np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_stream_{tag}.npz"), meta=np.array([W, H, depth, qp], np.int32), ts=np.array(ts, np.int32),
-                        src_crc=np.array(crcs, np.uint32), bitstream=bs, alf_meta=np.stack([a[0] for a in A]), alf_flags=np.stack([a[7].reshape(7, n) for a in A]),
+                        src_crc=np.array(crcs, np.uint32), **more, alf_meta=np.stack([a[0] for a in A]), alf_flags=np.stack([a[7].reshape(7, n) for a in A]),
                         alf_set_idx=np.stack([a[8] for a in A]), alf_luma_aps=np.stack([a[9].reshape(8, -1) for a in A]), alf_chroma_aps=np.stack([a[10] for a in A]),
                         alf_cc_coeff=np.stack([a[11].reshape(2, 4, 8) for a in A]),
                         aps_meta=np.stack([r[0] for r in P]) if P else np.zeros((0, 16), np.int32), aps_luma=np.stack([r[1] for r in P]) if P else np.zeros((0, 675), np.int16),
@@ -485,6 +493,7 @@ if __name__ == "__main__":
     inter(136, 72, 10, 22, 4, extra=("sao", "off"), suffix="_nosao", with_levels=False)
     inter(136, 72, 8, 27, 4, extra=("bipred", "0", "tmvp", "0"), suffix="_p_notmvp")           # P pictures only, no temporal candidate
     inter(192, 128, 10, 24, 4, extra=("subme", "0", "early-skip", "0"), suffix="_subme0_noskip")   # integer motion only, no early skip
+    stream_alf(3840, 2160, 10, 22, [0], crc_only=True)      # one --alf full picture at configs[3]'s size: the decisions, the .266 by CRC (bench.py 2160p10_closed_loop's ALF stage)
     lowdelay_states(27, 120)             # the frame-level state of a 120-picture low-delay clip (bench.py c3_clip)
     lowdelay_states(27, 65, extra=("gop", "16"), name="gop16")      # ... of a 65-picture random-access clip (bench.py ra_clip)
     inter_crcs(1920, 1080, 8, 27, 17, extra=("gop", "16"), suffix="_ra16", clip=True)      # the same structure at BASELINE's size, by CRC

@@ -974,6 +974,23 @@ class AlfStatistics:
         """Per CTU and class the covariance of get_blk_stats (alf.c:2378; -> ee, y, pix_acc as alf_stats_batch returns them)."""
         return alf_stats_batch(self.org[0], self.rec[0], self.rects_y, cls=self.classification(), pic_w=self.W, pic_h=self.H)
 
+    def luma_frame(self, scratch=None):
+        """The FRAME's luma covariance per class, as the derivation reads it first (alf.c:792-835 accumulates the CTUs'): compact per-CTU
+        records (only the classes present in a CTU, the upper triangle of ee) summed on the device -> sums int64 [25][UVGHIP_ALF_SUM_WORDS = 1509]
+        (the ee triangle, y widened, pix_acc).  scratch: a dict that keeps the record buffer between pictures (12 KB per CTU and class)."""
+        L = _lib.init(self.rec[0].device.index or 0)
+        n, dev = self.rects_y.shape[0], self.rec[0].device
+        scratch = {} if scratch is None else scratch
+        if scratch.get("n") != n:
+            scratch.update(n=n, rec=torch.empty((n, 25, 1484), dtype=torch.int64, device=dev), present=torch.zeros(n, dtype=torch.int32, device=dev))
+        sums = torch.zeros((25, 1509), dtype=torch.int64, device=dev)
+        cls = self.classification()
+        depth = _depth(self.rec[0])
+        _lib.check(L.uvghip_alf_stats_compact_batch(depth, _dev(self.org[0]), self.org[0].stride(0), _dev(self.rec[0]), self.rec[0].stride(0), self.W, self.H, 0, _dev(self.rects_y), n,
+                                                    _dev(cls), cls.stride(0), _dev(scratch["rec"]), _dev(scratch["present"]), _stream()), "uvghip_alf_stats_compact_batch")
+        _lib.check(L.uvghip_alf_cov_reduce(_dev(scratch["rec"]), _dev(scratch["present"]), n, 0, _dev(sums), _stream()), "uvghip_alf_cov_reduce")
+        return sums
+
     def chroma(self, c):
         """Per CTU the chroma covariance of plane c = 1, 2."""
         return alf_stats_batch(self.org[c], self.rec[c], self.rects_c, is_chroma=True, pic_w=self.W // 2, pic_h=self.H // 2)
