@@ -1396,3 +1396,17 @@ def write_inter_nals(L, g, poc, slice_type, ref_pocs, bipred, tmvp, qp_delta, ro
     assert len(pos) == 0
     return L.uvghip_write_picture_nals_pb(poc, 4, slice_type, len(neg), ptr(neg), bipred, tmvp, qp_delta, 1, ptr(rows), rows.shape[1], ptr(sizes), hc,
                                           ptr(sums), ptr(out), len(out), ctypes.byref(n))
+
+
+def alf_sum_layout(ee, yv, pa, n_coeff):
+    """Per-class ALF covariances (ee [C][13][13][4][4], y [C][13][4], pix_acc [C]) -> uvghip_alf_cov_reduce's sum layout [C][1509] int64: the ee
+    triangle k <= l at (k * 13 - k (k - 1) / 2 + l - k) * 16 + b0 * 4 + b1, y[k][b] at 1456 + 4 k + b, pix_acc at 1508."""
+    C = ee.shape[0]
+    out = np.zeros((C, 1509), np.int64)
+    for k in range(n_coeff):
+        for l in range(k, n_coeff):
+            at = (k * 13 - k * (k - 1) // 2 + l - k) * 16
+            out[:, at:at + 16] = ee[:, k, l].reshape(C, 16)
+    out[:, 1456:1456 + 4 * n_coeff] = yv[:, :n_coeff].reshape(C, 4 * n_coeff)
+    out[:, 1508] = pa
+    return out

@@ -126,3 +126,47 @@ def test_a_2160p_10bit_picture_by_crc(hip):
     ck = api.picture_checksum(*alf_out[0]).cpu().numpy().view(np.uint32)
     nals = write_alf_picture_nals(hip, dict(alf_meta=pic["meta"], aps_meta=g["aps_meta"], aps_luma=g["aps_luma"], aps_chroma=g["aps_chroma"], aps_cc=g["aps_cc"]), r, nb, ck)
     assert len(nals) == int(g["bitstream_tail_len"]) and zlib.crc32(nals) == int(g["bitstream_tail_crc"])
+
+
+# (the 8-bit golden is a run WITHOUT worker threads, kept for its job order: there the ALF job runs the moment it is submitted, before the last
+# CTUs' deferred SAO columns are written -- the picture it got is not the finished SAO picture, so the statistics are taken on the golden's)
+@pytest.mark.parametrize("name,own", [("ref_alf_320x192_10_qp27_3frames", True), ("ref_alf_192x128_8_qp27_3frames", False), ("ref_alf_192x128_10_qp23_2frames", True)])
+def test_the_frame_statistics_of_the_devices_own_picture_equal_the_encoders(hip, name, own):
+    """The statistics the ALF stage hands the derivation, held to a real run: the device's closed loop of the run's source pictures (search ->
+    deblocking -> SAO: the picture uvg_alf_enc_process got, sample for sample), then api.AlfStatistics on that output -- classification, the
+    luma covariance per class summed over the CTUs (uvghip_alf_stats_compact_batch + uvghip_alf_cov_reduce), the chroma covariances -- against
+    what alf_derive_stats_for_filtering (alf.c:4227) gathered in the encoder (cov_luma / cov_chroma of the goldens, taken by ctu_dump.c while
+    the process still held them).  int64 sums and pix_acc exact."""
+    import torch
+    from uvg266_amd import api
+    g = np.load(os.path.join(H.GOLDEN, name + ".npz"))
+    W, Hh, depth, qp, frames, t0, kind = (int(a) for a in g["dims"])
+    prm = H.search_params(W, Hh, qp)
+    host = [H.varied_picture(W, Hh, kind * 1000 + t0 + f, depth) for f in range(frames)]
+    for f in range(frames):
+        assert zlib.crc32(b"".join(p.tobytes() for p in host[f])) == int(g["src_crc"][f])
+    src = [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in pic) for pic in host]
+    if own:
+        cl = api.ClosedLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), src)
+        cl.run()
+        torch.cuda.synchronize()
+    checked = 0
+    for f in range(frames):
+        if own:
+            got = cl.out[f]
+            for o, k in zip(got, ("pre_y", "pre_u", "pre_v")):
+                assert np.array_equal(o.cpu().numpy(), g[k][f]), (name, f, "the picture ALF gets", k)
+        else:
+            got = tuple(torch.from_numpy(np.ascontiguousarray(g[k][f])).cuda() for k in ("pre_y", "pre_u", "pre_v"))
+        if not int(g["meta"][f][29]):
+            continue                      # (no CTU of the picture was filtered: the run's statistics were freed unseen)
+        st = api.AlfStatistics(got, src[f], W, Hh, int(g["meta"][f][28]) + 4)
+        assert np.array_equal(st.classification().cpu().numpy(), g["cls"][f]), (name, f, "classification")
+        luma = st.luma_frame().cpu().numpy()
+        assert np.array_equal(luma, g["cov_luma"][f]), (name, f, "luma", np.argwhere(luma != g["cov_luma"][f])[:4].tolist())
+        for c in (1, 2):
+            e, yv, pa = (a.cpu().numpy() for a in st.chroma(c))
+            mine = H.alf_sum_layout(e.sum(axis=0), yv.astype(np.int64).sum(axis=0), pa.sum(axis=0), 7)[0]
+            assert np.array_equal(mine, g["cov_chroma"][f][c - 1]), (name, f, "chroma", c)
+        checked += 1
+    assert checked >= 2

@@ -61,3 +61,35 @@ def test_the_goldens_cover_the_branches(orc):
         for k, v in check(orc, name).items():
             tot[k] = tot.get(k, 0) + v
     assert all(v > 0 for v in tot.values()), tot
+
+
+@pytest.mark.parametrize("name", GOLDENS)
+def test_the_frame_statistics_equal_the_encoders(orc, name):
+    """What alf_derive_stats_for_filtering (alf.c:4227) gathered in a real --alf full run -- the per-CTU covariances of every luma class and of
+    the two chroma planes, summed over the picture (ctu_dump.c takes them while the process still holds them; cov_luma / cov_chroma) -- against
+    the oracle's get_blk_stats on the picture ALF got and the run's source picture, CTU by CTU, summed the same way.  int64 sums and pix_acc
+    exact."""
+    g = np.load(os.path.join(H.GOLDEN, name + ".npz"))
+    W, Hh, depth, qp, frames, t0, kind = (int(a) for a in g["dims"])
+    checked = 0
+    for f in range(frames):
+        if not int(g["meta"][f][29]):
+            continue                      # (no CTU of the picture was filtered: the run's statistics were freed unseen)
+        src = H.varied_picture(W, Hh, kind * 1000 + t0 + f, depth)
+        import zlib
+        assert zlib.crc32(b"".join(p.tobytes() for p in src)) == int(g["src_crc"][f])
+        pre = [np.ascontiguousarray(g[k][f]) for k in ("pre_y", "pre_u", "pre_v")]
+        cls = orc.alf_classify_frame(depth, pre[0], W, Hh, int(g["meta"][f][28]) + 4)
+        luma, chroma = np.zeros((25, 1509), np.int64), np.zeros((2, 1509), np.int64)
+        for y in range(0, Hh, 64):
+            for x in range(0, W, 64):
+                w, h = min(64, W - x), min(64, Hh - y)
+                e, yv, pa = orc.alf_stats_rect(depth, np.ascontiguousarray(src[0]), pre[0], W, Hh, x, y, w, h, False, cls)
+                luma += H.alf_sum_layout(e, yv, pa, 13)
+                for c in (1, 2):
+                    e, yv, pa = orc.alf_stats_rect(depth, np.ascontiguousarray(src[c]), pre[c], W // 2, Hh // 2, x // 2, y // 2, w // 2, h // 2, True, None)
+                    chroma[c - 1] += H.alf_sum_layout(e, yv, pa, 7)[0]
+        assert np.array_equal(luma, g["cov_luma"][f]), (name, f, "luma", np.argwhere(luma != g["cov_luma"][f])[:4].tolist())
+        assert np.array_equal(chroma, g["cov_chroma"][f]), (name, f, "chroma", np.argwhere(chroma != g["cov_chroma"][f])[:4].tolist())
+        checked += 1
+    assert checked >= 2

@@ -458,6 +458,34 @@ static void planes_of(const videoframe_t *frame, uvg_pixel *y, uvg_pixel *u, uvg
 static alf_filter_7x7_blk_func *g_filter7_real;
 static uint8_t *g_cls;
 static int g_cls_taken;
+/* The frame's statistics as alf_derive_stats_for_filtering (alf.c:4227) left them in the per-CTU covariances -- freed, like the classification,
+ * before the process returns (alf_covariance_destroy, :5446), and untouched by the derivation in between: summed over the CTUs, per luma class and
+ * per chroma plane, in the layout of uvghip_alf_cov_reduce -- the ee triangle k <= l ((k * 13 - k (k - 1) / 2 + l - k) * 16 + b0 * 4 + b1),
+ * y[k][b] at 1456 + 4 k + b, pix_acc (an integer kept in a double) at 1508.  Taken with the classification (a picture no CTU of which is
+ * filtered has neither). */
+enum { SUMW = 1509 };
+static int64_t *g_cov_luma, *g_cov_chroma;
+static void take_covariances(const videoframe_t *frame)
+{
+  const alf_info_t *ai = frame->alf_info;
+  const int n = frame->width_in_lcu * frame->height_in_lcu;
+  for (int pass = 0; pass < 3; ++pass) {
+    const alf_covariance *base = pass == 0 ? ai->alf_covariance_y : (pass == 1 ? ai->alf_covariance_u : ai->alf_covariance_v);
+    const int ncls = pass == 0 ? MAX_NUM_ALF_CLASSES : 1, nco = pass == 0 ? MAX_NUM_ALF_LUMA_COEFF : MAX_NUM_ALF_CHROMA_COEFF;
+    if (!base) continue;
+    for (int ctu = 0; ctu < n; ++ctu)
+      for (int c = 0; c < ncls; ++c) {
+        const alf_covariance *cv = &base[ctu * ncls + c];
+        int64_t *o = pass == 0 ? g_cov_luma + (size_t)c * SUMW : g_cov_chroma + (size_t)(pass - 1) * SUMW;
+        for (int k = 0; k < nco; ++k)
+          for (int l = k; l < nco; ++l)
+            for (int b0 = 0; b0 < 4; ++b0) for (int b1 = 0; b1 < 4; ++b1)
+              o[(k * 13 - k * (k - 1) / 2 + l - k) * 16 + b0 * 4 + b1] += cv->ee[k][l][b0][b1];
+        for (int k = 0; k < nco; ++k) for (int b = 0; b < 4; ++b) o[1456 + 4 * k + b] += cv->y[k][b];
+        o[1508] += (int64_t)cv->pix_acc;
+      }
+  }
+}
 static void filter7_hook(encoder_state_t *const state, const uvg_pixel *src_pixels, uvg_pixel *dst_pixels, const int src_stride, const int dst_stride,
                          const short *filter_set, const int16_t *fClipSet, clp_rng clp_rng, const int width, const int height, int x_pos, int y_pos,
                          int blk_dst_x, int blk_dst_y, int vb_pos, const int vb_ctu_height)
@@ -467,6 +495,7 @@ static void filter7_hook(encoder_state_t *const state, const uvg_pixel *src_pixe
     const int cw = (frame->width + 3) / 4, chh = (frame->height + 3) / 4;
     alf_classifier **cl = frame->alf_info->classifier;
     for (int by = 0; by < chh; ++by) for (int bx = 0; bx < cw; ++bx) g_cls[by * cw + bx] = (uint8_t)(cl[by * 4][bx * 4].class_idx | cl[by * 4][bx * 4].transpose_idx << 5);
+    take_covariances(frame);
     g_cls_taken = 1;
   }
   g_filter7_real(state, src_pixels, dst_pixels, src_stride, dst_stride, filter_set, fClipSet, clp_rng, width, height, x_pos, y_pos, blk_dst_x, blk_dst_y, vb_pos, vb_ctu_height);
@@ -480,6 +509,7 @@ void __wrap_uvg_alf_enc_process(encoder_state_t *const state)
   for (int c = 0; c < 3; ++c) { pre[c] = malloc(sizeof(uvg_pixel) * (size_t)W * H); post[c] = malloc(sizeof(uvg_pixel) * (size_t)W * H); }
   planes_of(frame, pre[0], pre[1], pre[2]);
   g_cls = calloc((size_t)((W + 3) / 4) * ((H + 3) / 4), 1); g_cls_taken = 0;
+  g_cov_luma = calloc((size_t)MAX_NUM_ALF_CLASSES * SUMW, sizeof(int64_t)); g_cov_chroma = calloc((size_t)2 * SUMW, sizeof(int64_t));
   g_filter7_real = uvg_alf_filter_7x7_blk; uvg_alf_filter_7x7_blk = filter7_hook;
   __real_uvg_alf_enc_process(state);
   uvg_alf_filter_7x7_blk = g_filter7_real;
@@ -496,6 +526,7 @@ void __wrap_uvg_alf_enc_process(encoder_state_t *const state)
   meta[21] = sa->tile_group_cc_alf_cb_enabled_flag; meta[22] = sa->tile_group_cc_alf_cr_enabled_flag;
   meta[23] = sa->tile_group_cc_alf_cb_aps_id; meta[24] = sa->tile_group_cc_alf_cr_aps_id;
   meta[25] = (int32_t)state->frame->poc; meta[26] = state->frame->slicetype; meta[27] = state->frame->QP;
+  meta[29] = g_cls_taken;              /* the classification and the covariance sums below were taken (a CTU was filtered) */
   meta[28] = state->encoder_control->cfg.input_bitdepth;      /* the classification's activity shift is input_bitdepth + 4 (alf.c:5185): the INPUT's depth, 8 unless --input-bitdepth says otherwise */
   uint8_t *flags = calloc((size_t)n, 7);                       /* enable Y / Cb / Cr, alternative Cb / Cr, CC-ALF control Cb / Cr */
   int16_t *set_idx = calloc((size_t)n, sizeof(int16_t));
@@ -537,7 +568,7 @@ void __wrap_uvg_alf_enc_process(encoder_state_t *const state)
   /* the classification the luma filter worked from, one byte per 4x4 block (all zero when no CTU was filtered) */
   const int cw = (W + 3) / 4, chh = (H + 3) / 4;
   uint8_t *cls = g_cls;
-  rec_begin("alf", 14);
+  rec_begin("alf", 16);
   rec_arr(A_I32, meta, 32);
   for (int c = 0; c < 3; ++c) rec_arr(A_PX, pre[c], c ? (size_t)(W / 2) * (H / 2) : (size_t)W * H);
   for (int c = 0; c < 3; ++c) rec_arr(A_PX, post[c], c ? (size_t)(W / 2) * (H / 2) : (size_t)W * H);
@@ -548,6 +579,9 @@ void __wrap_uvg_alf_enc_process(encoder_state_t *const state)
   rec_arr(A_I16, cc, sizeof cc / sizeof cc[0]);
   rec_arr(A_I32, fixed, sizeof fixed / sizeof fixed[0]);
   rec_arr(A_U8, cls, (size_t)cw * chh);
+  rec_arr(A_I64, g_cov_luma, (size_t)MAX_NUM_ALF_CLASSES * SUMW);
+  rec_arr(A_I64, g_cov_chroma, (size_t)2 * SUMW);
+  free(g_cov_luma); free(g_cov_chroma);
   free(cls);
   for (int c = 0; c < 3; ++c) { free(pre[c]); free(post[c]); }
   free(flags); free(set_idx); free(luma);

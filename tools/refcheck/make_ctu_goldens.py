@@ -432,6 +432,9 @@ def alf(W, H, depth, qp, frames, t0, kind, threads=1):
                         flags=np.stack([a[7].reshape(7, n) for a in A]), set_idx=np.stack([a[8] for a in A]), luma_aps=np.stack([a[9].reshape(8, -1) for a in A]),
                         chroma_aps=np.stack([a[10] for a in A]), cc_coeff=np.stack([a[11].reshape(2, 4, 8) for a in A]),
                         cls=np.stack([a[13].reshape((H + 3) // 4, (W + 3) // 4) for a in A]),          # the classification the luma filter worked from (zeros: no CTU filtered)
+                        # the frame statistics alf_derive_stats_for_filtering gathered, per luma class / chroma plane summed over the CTUs in
+                        # uvghip_alf_cov_reduce's layout (meta[29]: taken, i.e. some CTU was filtered)
+                        cov_luma=np.stack([a[14].reshape(25, 1509) for a in A]), cov_chroma=np.stack([a[15].reshape(2, 1509) for a in A]),
                         bitstream=np.frombuffer(open(out + ".266", "rb").read(), np.uint8))
     fixed = A[0][12]
     np.save(os.path.join(ROOT, "tests/golden", "ref_alf_fixed.npy"), fixed.astype(np.int16))          # alf.h:46-133: 64 x 13 coefficients, 16 x 25 class -> filter
