@@ -1378,8 +1378,11 @@ def is_random_access(g):
 
 
 def poc_lsb_bits(g):
-    """encoder_control->poc_lsb_bits (src/encoder.c:242) of golden g's stream: --gop 16 for the random-access goldens, else 4."""
-    return max(4, int(np.ceil(np.log2(2 * 16 + 1)))) if is_random_access(g) else 4
+    """encoder_control->poc_lsb_bits (src/encoder.c:242) of golden g's stream: from the GOP length of a random-access golden (16 where it is not recorded), else 4."""
+    if not is_random_access(g):
+        return 4
+    gop_len = int(g["gop_len"]) if "gop_len" in g.files and int(g["gop_len"]) else 16
+    return max(4, int(np.ceil(np.log2(2 * gop_len + 1))))
 
 
 def write_inter_nals(L, g, poc, slice_type, ref_pocs, bipred, tmvp, qp_delta, rows, sizes, sums, out, n):
