@@ -203,3 +203,30 @@ def test_whole_low_delay_file_from_rows_and_final_pictures(name):
         i = next(j for j in range(min(len(body), len(mine))) if body[j] != mine[j])
         assert False, (name, "first differing byte", i, body[max(0, i - 8):i + 8].hex(), mine[max(0, i - 8):i + 8].hex(), len(body), len(mine))
     assert stream[:at] + mine == stream
+
+
+def test_the_inter_writers_refuse_what_no_gop_structure_lists():
+    """uvghip_write_picture_nals_pb / _ra (host functions): reference distances are positive, ascending and do not reach before the stream's
+    first picture; a copied list 1 has no references in the future; at least one reference."""
+    from uvg266_amd import lib
+    L = lib.load_library()
+    rows = np.zeros((2, 8), np.uint8); rows[:, 0] = 1
+    sizes = np.array([4, 4], np.int32)
+    sums = np.zeros(3, np.uint32)
+    out = np.zeros(256, np.uint8)
+    n = ctypes.c_size_t(0)
+    def ra(poc, neg, pos, lsb=6):
+        a, b = np.ascontiguousarray(neg, np.int32), np.ascontiguousarray(pos, np.int32)
+        return L.uvghip_write_picture_nals_ra(poc, lsb, 0, len(a), H.ptr(a) if len(a) else None, len(b), H.ptr(b) if len(b) else None, 1, 0, 1, H.ptr(rows), rows.shape[1], H.ptr(sizes), 2,
+                                              H.ptr(sums), H.ptr(out), len(out), ctypes.byref(n))
+    assert ra(8, [8], [8]) == 0 and n.value > 0
+    assert ra(8, [8, 16], [8]) != 0            # POC -8 does not exist
+    assert ra(8, [4, 4], [8]) != 0             # not ascending
+    assert ra(8, [0], [8]) != 0                # the picture itself
+    assert ra(8, [], []) != 0                  # no reference at all
+    assert ra(8, [8], [8], lsb=3) != 0         # fewer POC bits than the SPS can signal
+    assert ra(4, [4], [4, 12]) == 0
+    neg = np.array([1, 2], np.int32)
+    assert L.uvghip_write_picture_nals_pb(3, 4, 0, 2, H.ptr(neg), 1, 1, 0, 1, H.ptr(rows), rows.shape[1], H.ptr(sizes), 2, H.ptr(sums), H.ptr(out), len(out), ctypes.byref(n)) == 0
+    bad = np.array([2, 1], np.int32)
+    assert L.uvghip_write_picture_nals_pb(3, 4, 0, 2, H.ptr(bad), 1, 1, 0, 1, H.ptr(rows), rows.shape[1], H.ptr(sizes), 2, H.ptr(sums), H.ptr(out), len(out), ctypes.byref(n)) != 0

@@ -297,6 +297,13 @@ static int write_inter_picture(const char *who, int poc, int poc_lsb_bits, int s
       n_ref_neg < 0 || n_ref_neg > 15 || n_ref_pos < 0 || n_ref_pos > 15 || n_ref_neg + n_ref_pos < 1 || (n_ref_neg && !delta_neg) || (n_ref_pos && !delta_pos) ||
       (copy_rpl1 && n_ref_pos))
     return uvghip_set_error(hipErrorInvalidValue, who);
+  // the distances of a list: positive and ascending, as the GOP structures list them (a reference at distance 0 is the picture itself)
+  for (int list = 0; list < 2; ++list) {
+    const int32_t *d = list ? delta_pos : delta_neg;
+    const int n = list ? n_ref_pos : n_ref_neg;
+    for (int j = 0; j < n; ++j)
+      if (d[j] < 1 || (j && d[j] <= d[j - 1]) || (!list && d[j] > poc)) return uvghip_set_error(hipErrorInvalidValue, "uvghip_write_picture_nals_pb / _ra: reference distances must be positive, ascending and inside the stream");
+  }
   int32_t longest = 0;
   for (int r = 0; r < n_rows; ++r) {
     if (row_bytes[r] <= 0 || (size_t)row_bytes[r] > row_pitch) return uvghip_set_error(hipErrorInvalidValue, "uvghip_write_picture_nals_pb / _ra: a row is empty or longer than its slot");
