@@ -700,8 +700,9 @@ def ra_clip(device, frames=65, with_cpu=True):
     what BASELINE.json configs[3] / [4] run with): pictures in CODING order through api.LowDelayLoop, every picture issued as soon as the
     pictures in its reference buffer are done (by_level: the pictures at one depth of the reference DAG share a uvghip_loop_pb_run):
     pictures of one temporal layer and of neighbouring GOPs are in flight together.  Frame-level state (slice types, the hierarchical QPs / lambdas, reference lists, coding order) from
-    tests/golden/ref_gop16_states_qp27_65frames.npz (the reference encoder's own, independent of the picture size); the first 17 coded
-    pictures are compared with the reference encoder's run of this clip (tests/golden/ref_intercrc_1920x1080_8_qp27_17frames_ra16.npz)."""
+    tests/golden/ref_gop16_states_qp27_65frames.npz (the reference encoder's own, independent of the picture size); the coded pictures
+    are compared with the reference encoder's run of this clip (tests/golden/ref_intercrc_1920x1080_8_qp27_65frames_ra16.npz: all 65,
+    incl. the I picture of the second intra period at POC 64 and the pictures before it in display order that are coded after it)."""
     import zlib
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as Hh
@@ -722,7 +723,10 @@ def ra_clip(device, frames=65, with_cpu=True):
     dt = time.perf_counter() - t0
     nbytes = int(sum(int(loop.row_bytes[f].sum().item()) for f in range(frames)))
     # parity: the first GOP against the reference encoder's record of the same clip
-    ref = np.load(os.path.join(ROOT, "tests", "golden", "ref_intercrc_1920x1080_8_qp27_17frames_ra16.npz"))
+    golden = "ref_intercrc_1920x1080_8_qp27_65frames_ra16"          # (every picture of the clip incl. the second intra period; the 17-picture golden where it is absent)
+    if not os.path.exists(os.path.join(ROOT, "tests", "golden", golden + ".npz")):
+        golden = "ref_intercrc_1920x1080_8_qp27_17frames_ra16"
+    ref = np.load(os.path.join(ROOT, "tests", "golden", golden + ".npz"))
     n_chk, hc = min(frames, int(ref["dims"][4])), (H + 63) // 64
     ok = [int(a) for a in ref["display"][:n_chk]] == display[:n_chk]
     for f in range(n_chk):
@@ -735,8 +739,8 @@ def ra_clip(device, frames=65, with_cpu=True):
         raise SystemExit("ra_clip: the device's pictures / slice data differ from the reference encoder's run")
     out = {"value": round(frames / dt, 3), "unit": "frames/s (one random-access clip, pictures in flight along the reference DAG)", "frames_timed": frames, "wall_ms": round(1e3 * dt, 1),
            "slice_data_bytes": nbytes, "dependency_levels": 1 + max(loop.level), "launches": len(loop.order), "parity_checked": True,
-           "parity": {"golden": "ref_intercrc_1920x1080_8_qp27_17frames_ra16", "pictures": n_chk,
-                      "items": "CRC of every output picture (after deblocking + SAO) and length + CRC of every WPP row's slice data of the first GOP vs the reference encoder's run"},
+           "parity": {"golden": golden, "pictures": n_chk,
+                      "items": "CRC of every output picture (after deblocking + SAO) and length + CRC of every WPP row's slice data vs the reference encoder's run of this clip"},
            "workload": f"{W}x{H} {depth}-bit yuv420p, ONE clip, --preset medium as it stands (--gop 16: coding order 0 16 8 4 2 1 3 6 5 7 12 ..., five temporal layers, up to five "
                        f"reference pictures in both directions) at QP {qp}; per picture: closed-loop CTU search with the inter search on the device's own reference pictures -> "
                        "deblocking -> SAO -> arithmetic coder",

@@ -121,7 +121,7 @@ def _frame_rows(g):
 
 @pytest.mark.parametrize("name,n_seq,in_flight", [("ref_inter_264x136_8_qp32_9frames", 3, 1), ("ref_inter_136x72_8_qp27_17frames_ra16", 2, 1), ("ref_inter_136x72_8_qp27_17frames_ra16", 2, 8),
                                                   ("ref_intercrc_1920x1080_8_qp27_5frames", 2, 1), ("ref_intercrc_1920x1080_8_qp27_17frames_ra16", 1, 16), ("ref_inter_264x136_8_qp32_9frames", 2, 4),
-                                                  ("ref_inter_136x72_8_qp27_17frames_ra16", 2, -1), ("ref_inter_136x72_10_qp22_17frames_ra16", 1, -1), ("ref_inter_136x72_8_qp27_9frames_ra8", 2, -1), ("ref_intercrc_1920x1080_8_qp27_17frames_ra16", 1, -1), ("ref_inter_264x136_8_qp32_9frames", 2, -1),
+                                                  ("ref_inter_136x72_8_qp27_17frames_ra16", 2, -1), ("ref_inter_136x72_10_qp22_17frames_ra16", 1, -1), ("ref_inter_136x72_8_qp27_9frames_ra8", 2, -1), ("ref_intercrc_136x72_8_qp27_65frames_ra16", 2, -1), ("ref_intercrc_1920x1080_8_qp27_17frames_ra16", 1, -1), ("ref_inter_264x136_8_qp32_9frames", 2, -1),
                                                   ("ref_intercrc_1920x1080_10_qp32_3frames", 1, 1), ("ref_intercrc_3840x2160_10_qp27_3frames", 1, 1),
                                                   ("ref_intercrc_3840x2160_10_qp27_17frames_ra16", 1, -1)])
 def test_low_delay_loop_of_several_sequences(hip, name, n_seq, in_flight):

@@ -501,6 +501,8 @@ if __name__ == "__main__":
     lowdelay_states(27, 65, extra=("gop", "16"), name="gop16")      # ... of a 65-picture random-access clip (bench.py ra_clip)
     inter_crcs(1920, 1080, 8, 27, 17, extra=("gop", "16"), suffix="_ra16", clip=True)      # the same structure at BASELINE's size, by CRC
     inter_crcs(3840, 2160, 10, 27, 17, extra=("gop", "16"), suffix="_ra16", clip=True)    # ... and at configs[3]'s size and depth
+    inter_crcs(136, 72, 8, 27, 65, extra=("gop", "16"), suffix="_ra16", clip=True)        # four GOPs and the I picture of the second intra period (POC 64, coded before POC 49..63)
+    inter_crcs(1920, 1080, 8, 27, 65, extra=("gop", "16"), suffix="_ra16", clip=True)     # ... bench.py's ra_clip, picture by picture
     inter(136, 72, 8, 27, 17, extra=("gop", "16"), suffix="_ra16", clip=True)      # random access, --preset medium's own GOP: coding order 0 16 8 4 2 1 3 6 5 7 12 ..., future references, five temporal layers
     inter(136, 72, 10, 22, 17, extra=("gop", "16"), suffix="_ra16", clip=True)     # ... at 10 bit, QP 22
     inter(136, 72, 8, 27, 9, extra=("gop", "8"), suffix="_ra8", clip=True)         # the 8-picture random-access GOP (what the presets up to "faster" run with): five POC bits
