@@ -722,7 +722,7 @@ def ra_clip(device, frames=65, with_cpu=True):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     nbytes = int(sum(int(loop.row_bytes[f].sum().item()) for f in range(frames)))
-    # parity: the first GOP against the reference encoder's record of the same clip
+    # parity: every coded picture the golden holds against the reference encoder's record of the same clip
     golden = "ref_intercrc_1920x1080_8_qp27_65frames_ra16"          # (every picture of the clip incl. the second intra period; the 17-picture golden where it is absent)
     if not os.path.exists(os.path.join(ROOT, "tests", "golden", golden + ".npz")):
         golden = "ref_intercrc_1920x1080_8_qp27_17frames_ra16"

@@ -1073,6 +1073,14 @@ UVGHIP_API int uvghip_write_picture_nals_ra(int poc, int poc_lsb_bits, int slice
                                             const int32_t *delta_pos, int tmvp, int qp_delta, int sao, const uint8_t *rows, size_t row_pitch,
                                             const int32_t *row_bytes, int n_rows, const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len);
 
+/* ... with the NAL unit type as a parameter, for a random-access stream with several intra periods and an open GOP (cfg.open_gop, the
+ * default): nal_type 9 (CRA: the I picture opening a later period -- slice_type 2; its header still carries the reference picture lists
+ * of the buffer, :1326-1329, and sh_no_output_of_prior_pics_flag, :1278), 3 (RASL: a picture before the CRA picture in display order
+ * coded after it; pictype at src/encoderstate.c:1957-1972) or 0 (TRAIL = uvghip_write_picture_nals_ra). */
+UVGHIP_API int uvghip_write_picture_nals_gop(int nal_type, int poc, int poc_lsb_bits, int slice_type, int n_ref_neg, const int32_t *delta_neg, int n_ref_pos,
+                                             const int32_t *delta_pos, int tmvp, int qp_delta, int sao, const uint8_t *rows, size_t row_pitch,
+                                             const int32_t *row_bytes, int n_rows, const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len);
+
 /* ... of a picture of an --alf on / --alf full all-intra stream: the ALF APS NAL units written in front of the slice
  * (uvg_encode_alf_adaptive_parameter_set, src/alf.c:1610 -> encode_alf_aps :1575, encoder_state_write_adaptation_parameter_set :1547,
  * encode_alf_aps_flags :1452, encode_alf_aps_filter :1415; called at src/encoder_state-bitstream.c:1562) and the slice header's ALF fields

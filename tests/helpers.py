@@ -1385,7 +1385,7 @@ def poc_lsb_bits(g):
     return max(4, int(np.ceil(np.log2(2 * gop_len + 1))))
 
 
-def write_inter_nals(L, g, poc, slice_type, ref_pocs, bipred, tmvp, qp_delta, rows, sizes, sums, out, n):
+def write_inter_nals(L, g, poc, slice_type, ref_pocs, bipred, tmvp, qp_delta, rows, sizes, sums, out, n, irap_poc=0):
     """The NAL units of a P / B picture of golden g's stream from the library's host functions: uvghip_write_picture_nals_pb for a low-delay
     stream, uvghip_write_picture_nals_ra for a random-access one (g has `display`: pictures coded out of order, references in the future,
     poc_lsb_bits from the GOP length, src/encoder.c:242)."""
@@ -1393,6 +1393,11 @@ def write_inter_nals(L, g, poc, slice_type, ref_pocs, bipred, tmvp, qp_delta, ro
     hc = len(sizes)
     neg = np.ascontiguousarray(sorted(poc - p for p in ref_pocs if p < poc), np.int32)
     pos = np.ascontiguousarray(sorted(p - poc for p in ref_pocs if p > poc), np.int32)
+    if is_random_access(g) and (slice_type == 2 or poc < irap_poc):
+        # a later intra period of an open-GOP stream: its I picture is a CRA picture, the pictures before it that are coded after it RASL pictures
+        # (src/encoderstate.c:1957-1972; irap_poc: the POC of the most recent I picture in coding order)
+        return L.uvghip_write_picture_nals_gop(9 if slice_type == 2 else 3, poc, poc_lsb_bits(g), slice_type, len(neg), ptr(neg) if len(neg) else None, len(pos),
+                                               ptr(pos) if len(pos) else None, tmvp, qp_delta, 1, ptr(rows), rows.shape[1], ptr(sizes), hc, ptr(sums), ptr(out), len(out), ctypes.byref(n))
     if is_random_access(g):
         return L.uvghip_write_picture_nals_ra(poc, poc_lsb_bits(g), slice_type, len(neg), ptr(neg), len(pos), ptr(pos) if len(pos) else None, tmvp, qp_delta, 1, ptr(rows), rows.shape[1],
                                               ptr(sizes), hc, ptr(sums), ptr(out), len(out), ctypes.byref(n))

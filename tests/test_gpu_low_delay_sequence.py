@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 GOLDENS = ["ref_inter_136x72_10_qp22_4frames", "ref_inter_192x128_8_qp17_5frames", "ref_inter_264x136_8_qp32_9frames",
            # other tools than --preset medium's: P slices (no bi-prediction) without the temporal candidate; no fractional search, no early skip
            "ref_inter_136x72_8_qp27_4frames_p_notmvp", "ref_inter_192x128_10_qp24_4frames_subme0_noskip",
-           "ref_inter_136x72_8_qp27_17frames_ra16", "ref_inter_136x72_10_qp22_17frames_ra16", "ref_inter_136x72_8_qp27_9frames_ra8"]
+           "ref_inter_136x72_8_qp27_17frames_ra16", "ref_inter_136x72_10_qp22_17frames_ra16", "ref_inter_136x72_8_qp27_9frames_ra8", "ref_inter_136x72_8_qp27_33frames_ra16p16"]
 
 
 @pytest.mark.parametrize("name", GOLDENS)
@@ -31,6 +31,7 @@ def test_sequence_closed_loop_on_the_device(hip, name):
     coded = 0
     qp0 = int(g["dims"][3])
     mine = b""                        # the NAL units of every picture, from device outputs only
+    irap_poc = 0
     for fr, d, prm, F, _ in H.iter_inter_frames(W, Hh, P):
         src = [dev(p) for p in pics[fr]]
         slice_type, poc = int(d["meta"][6]), int(d["refs"][51])
@@ -97,10 +98,16 @@ def test_sequence_closed_loop_on_the_device(hip, name):
         cap = int(sizes.sum()) + 128 + 4 * hc
         buf, n = np.zeros(cap, np.uint8), ctypes.c_size_t(0)
         frame_qp = int(d["meta"][7])
-        if slice_type == 2:
+        if slice_type == 2 and poc == 0:
             rc = hip.uvghip_write_idr_nals_ra(poc, H.poc_lsb_bits(g), frame_qp - qp0, 1, H.ptr(rows_h), rows_h.shape[1], H.ptr(sizes), hc, H.ptr(sums), H.ptr(buf), cap, ctypes.byref(n))
+        elif slice_type == 2:          # the CRA picture of a later intra period: its reference buffer is in the record
+            n_refs = int(d["refs"][0])
+            cfg = g["cfg"] if "cfg" in g.files else (1, 6, 2, 1, 4, 1)
+            rc = H.write_inter_nals(hip, g, poc, 2, [int(p) for p in d["refs"][1:1 + n_refs]], int(cfg[3]), int(cfg[0]), frame_qp - qp0, rows_h, sizes, sums, buf, n, irap_poc=irap_poc)
         else:
-            rc = H.write_inter_nals(hip, g, poc, slice_type, [F.ref_pocs[i] for i in range(F.n_refs)], F.bipred, F.tmvp, frame_qp - qp0, rows_h, sizes, sums, buf, n)
+            rc = H.write_inter_nals(hip, g, poc, slice_type, [F.ref_pocs[i] for i in range(F.n_refs)], F.bipred, F.tmvp, frame_qp - qp0, rows_h, sizes, sums, buf, n, irap_poc=irap_poc)
+        if slice_type == 2:
+            irap_poc = poc
         assert rc == 0
         mine += buf[:n.value].tobytes()
         coded += 1
@@ -121,7 +128,7 @@ def _frame_rows(g):
 
 @pytest.mark.parametrize("name,n_seq,in_flight", [("ref_inter_264x136_8_qp32_9frames", 3, 1), ("ref_inter_136x72_8_qp27_17frames_ra16", 2, 1), ("ref_inter_136x72_8_qp27_17frames_ra16", 2, 8),
                                                   ("ref_intercrc_1920x1080_8_qp27_5frames", 2, 1), ("ref_intercrc_1920x1080_8_qp27_17frames_ra16", 1, 16), ("ref_inter_264x136_8_qp32_9frames", 2, 4),
-                                                  ("ref_inter_136x72_8_qp27_17frames_ra16", 2, -1), ("ref_inter_136x72_10_qp22_17frames_ra16", 1, -1), ("ref_inter_136x72_8_qp27_9frames_ra8", 2, -1), ("ref_intercrc_136x72_8_qp27_65frames_ra16", 2, -1), ("ref_intercrc_1920x1080_8_qp27_17frames_ra16", 1, -1), ("ref_inter_264x136_8_qp32_9frames", 2, -1),
+                                                  ("ref_inter_136x72_8_qp27_17frames_ra16", 2, -1), ("ref_inter_136x72_10_qp22_17frames_ra16", 1, -1), ("ref_inter_136x72_8_qp27_9frames_ra8", 2, -1), ("ref_intercrc_136x72_8_qp27_65frames_ra16", 2, -1), ("ref_inter_136x72_8_qp27_33frames_ra16p16", 1, -1), ("ref_intercrc_1920x1080_8_qp27_17frames_ra16", 1, -1), ("ref_inter_264x136_8_qp32_9frames", 2, -1),
                                                   ("ref_intercrc_1920x1080_10_qp32_3frames", 1, 1), ("ref_intercrc_3840x2160_10_qp27_3frames", 1, 1),
                                                   ("ref_intercrc_3840x2160_10_qp27_17frames_ra16", 1, -1)])
 def test_low_delay_loop_of_several_sequences(hip, name, n_seq, in_flight):

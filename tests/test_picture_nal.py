@@ -159,7 +159,7 @@ def test_device_outputs_complete_a_multi_picture_stream(hip, name):
 
 @pytest.mark.parametrize("name", ["ref_inter_136x72_10_qp22_4frames", "ref_inter_192x128_8_qp17_5frames", "ref_inter_264x136_8_qp32_9frames",
                                   "ref_inter_136x72_8_qp27_4frames_p_notmvp", "ref_inter_192x128_10_qp24_4frames_subme0_noskip",
-           "ref_inter_136x72_8_qp27_17frames_ra16", "ref_inter_136x72_10_qp22_17frames_ra16", "ref_inter_136x72_8_qp27_9frames_ra8"])
+           "ref_inter_136x72_8_qp27_17frames_ra16", "ref_inter_136x72_10_qp22_17frames_ra16", "ref_inter_136x72_8_qp27_9frames_ra8", "ref_inter_136x72_8_qp27_33frames_ra16p16"])
 def test_whole_low_delay_file_from_rows_and_final_pictures(name):
     """A low-delay stream (--gop lp-g4d3t1) or a random-access one (--gop 16: pictures in coding order, lists with references in the future,
     six POC bits): behind the encoder's parameter sets, the IDR picture's NAL units (with its slice QP offset)
@@ -176,6 +176,7 @@ def test_whole_low_delay_file_from_rows_and_final_pictures(name):
     for k in range(len(g["meta"])):
         first.setdefault(int(g["meta"][k][0]), k)
     mine = b""
+    irap_poc = 0
     for f in range(frames):
         k = first[f]
         off = g["row_off"][f * hc:f * hc + hc + 1]
@@ -188,12 +189,14 @@ def test_whole_low_delay_file_from_rows_and_final_pictures(name):
         cap = int(sizes.sum()) + 128 + 4 * hc
         out = np.zeros(cap, np.uint8)
         n = ctypes.c_size_t(0)
-        if slice_type == 2:
+        n_refs = int(g["refs"][k][0])
+        cfg = g["cfg"] if "cfg" in g.files else (1, 6, 2, 1, 4, 1)
+        if slice_type == 2 and poc == 0:
             rc = L.uvghip_write_idr_nals_ra(poc, H.poc_lsb_bits(g), frame_qp - qp0, 1, H.ptr(rows), rows.shape[1], H.ptr(sizes), hc, H.ptr(sums), H.ptr(out), cap, ctypes.byref(n))
-        else:
-            n_refs = int(g["refs"][k][0])
-            cfg = g["cfg"] if "cfg" in g.files else (1, 6, 2, 1, 4, 1)
-            rc = H.write_inter_nals(L, g, poc, slice_type, [int(p) for p in g["refs"][k][1:1 + n_refs]], int(cfg[3]), int(cfg[0]), frame_qp - qp0, rows, sizes, sums, out, n)
+        else:          # (an I picture with a POC: the CRA picture of a later intra period, its reference buffer in the lists)
+            rc = H.write_inter_nals(L, g, poc, slice_type, [int(p) for p in g["refs"][k][1:1 + n_refs]], int(cfg[3]), int(cfg[0]), frame_qp - qp0, rows, sizes, sums, out, n, irap_poc=irap_poc)
+        if slice_type == 2:
+            irap_poc = poc
         assert rc == 0
         mine += out[:n.value].tobytes()
     at = stream.find(b"\x00\x00\x01\x00\x41")

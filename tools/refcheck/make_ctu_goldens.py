@@ -506,3 +506,4 @@ if __name__ == "__main__":
     inter(136, 72, 8, 27, 17, extra=("gop", "16"), suffix="_ra16", clip=True)      # random access, --preset medium's own GOP: coding order 0 16 8 4 2 1 3 6 5 7 12 ..., future references, five temporal layers
     inter(136, 72, 10, 22, 17, extra=("gop", "16"), suffix="_ra16", clip=True)     # ... at 10 bit, QP 22
     inter(136, 72, 8, 27, 9, extra=("gop", "8"), suffix="_ra8", clip=True)         # the 8-picture random-access GOP (what the presets up to "faster" run with): five POC bits
+    inter(136, 72, 8, 27, 33, extra=("gop", "16", "period", "16"), suffix="_ra16p16", clip=True)      # three intra periods of an open GOP: CRA pictures at POC 16 and 32, RASL pictures behind them

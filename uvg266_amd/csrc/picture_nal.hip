@@ -69,7 +69,7 @@ struct nal_writer {
   }
 };
 
-enum { NAL_TRAIL = 0, NAL_IDR_W_RADL = 7, NAL_IDR_N_LP = 8, NAL_PREFIX_APS = 17, NAL_SUFFIX_SEI = 24 };
+enum { NAL_TRAIL = 0, NAL_RASL = 3, NAL_IDR_W_RADL = 7, NAL_IDR_N_LP = 8, NAL_CRA = 9, NAL_PREFIX_APS = 17, NAL_SUFFIX_SEI = 24 };
 
 int ceil_log2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 int floor_log2(int v) { int l = 0; while ((2 << l) <= v) ++l; return l; }
@@ -289,12 +289,14 @@ extern "C" int uvghip_write_idr_nals_alf(int poc, int qp_delta, int sao, const u
 // signalled as a copy of list 0's entries (copy_rpl1 = (gop_lowdelay || !gop_len) && bipred, :1165).  delta_neg / delta_pos: the POC
 // distance of each reference picture, in the order of the GOP structure's ref_neg[] / ref_pos[] (src/gop.h, uvg_config_process_lp_gop
 // src/cfg.c:1640-1720: ascending) restricted to the pictures that are in the reference buffer (:1176-1190).
-static int write_inter_picture(const char *who, int poc, int poc_lsb_bits, int slice_type, int n_ref_neg, const int32_t *delta_neg, int n_ref_pos, const int32_t *delta_pos,
+static int write_inter_picture(const char *who, int nal_type, int poc, int poc_lsb_bits, int slice_type, int n_ref_neg, const int32_t *delta_neg, int n_ref_pos, const int32_t *delta_pos,
                                int copy_rpl1, int tmvp, int qp_delta, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
                                const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len)
 {
-  if (!rows || !row_bytes || n_rows <= 0 || !len || (!out && cap) || poc < 0 || poc_lsb_bits < 4 || poc_lsb_bits > 16 || (slice_type != 0 && slice_type != 1) ||
-      n_ref_neg < 0 || n_ref_neg > 15 || n_ref_pos < 0 || n_ref_pos > 15 || n_ref_neg + n_ref_pos < 1 || (n_ref_neg && !delta_neg) || (n_ref_pos && !delta_pos) ||
+  // (a CRA picture is an I slice with the reference buffer of the pictures that follow it in its lists; every other picture here is P or B)
+  if (!rows || !row_bytes || n_rows <= 0 || !len || (!out && cap) || poc < 0 || poc_lsb_bits < 4 || poc_lsb_bits > 16 ||
+      (nal_type == NAL_CRA ? slice_type != 2 : (slice_type != 0 && slice_type != 1)) || (nal_type != NAL_TRAIL && nal_type != NAL_RASL && nal_type != NAL_CRA) ||
+      n_ref_neg < 0 || n_ref_neg > 15 || n_ref_pos < 0 || n_ref_pos > 15 || (n_ref_neg + n_ref_pos < 1 && slice_type != 2) || (n_ref_neg && !delta_neg) || (n_ref_pos && !delta_pos) ||
       (copy_rpl1 && n_ref_pos))
     return uvghip_set_error(hipErrorInvalidValue, who);
   // the distances of a list: positive and ascending, as the GOP structures list them (a reference at distance 0 is the picture itself)
@@ -310,7 +312,7 @@ static int write_inter_picture(const char *who, int poc, int poc_lsb_bits, int s
     if (row_bytes[r] > longest) longest = row_bytes[r];
   }
   nal_writer w = {out, cap, 0, 0, 0, 0};
-  w.start(NAL_TRAIL, true);          // the first NAL unit of its access unit: long start code; temporal id 0
+  w.start(nal_type, true);           // the first NAL unit of its access unit: long start code; temporal id 0
   w.bits(1, 1);                      // sh_picture_header_in_slice_header_flag
   w.bits(0, 1);                      // ph_gdr_or_irap_pic_flag
   w.bits(0, 1);                      // ph_non_ref_pic_flag
@@ -321,6 +323,7 @@ static int write_inter_picture(const char *who, int poc, int poc_lsb_bits, int s
   if (tmvp) w.bits(1, 1);            // ph_pic_temporal_mvp_enabled_flag
   w.bits(0, 1);                      // ph_mvd_l1_zero_flag
   w.ue((uint32_t)slice_type);        // sh_slice_type
+  if (nal_type == NAL_CRA) w.bits(0, 1);             // sh_no_output_of_prior_pics_flag (:1278)
   const int lists = 1 + (copy_rpl1 ? 1 : 0);
   for (int list = 0; list < lists; ++list) {
     w.ue((uint32_t)n_ref_neg);       // num_ref_entries[0]
@@ -342,12 +345,12 @@ static int write_inter_picture(const char *who, int poc, int poc_lsb_bits, int s
       last = d;
     }
   }
-  if (n_ref_neg > 1 || n_ref_pos > 1) {
+  if ((slice_type != 2 && n_ref_neg > 1) || n_ref_pos > 1) {        // (:1237)
     w.bits(1, 1);                    // sh_num_ref_idx_active_override_flag
     if (n_ref_neg > 1) for (int list = 0; list < lists; ++list) w.ue((uint32_t)n_ref_neg - 1);
     if (!copy_rpl1 && n_ref_pos > 1) w.ue((uint32_t)n_ref_pos - 1);
   }
-  if (tmvp) {
+  if (tmvp && slice_type != 2) {
     if (slice_type == 0) w.bits(1, 1);               // sh_collocated_from_l0_flag
     if (n_ref_neg > 1) w.ue(0);                      // sh_collocated_ref_idx
   }
@@ -365,7 +368,7 @@ extern "C" int uvghip_write_picture_nals_pb(int poc, int poc_lsb_bits, int slice
                                             uint8_t *out, size_t cap, size_t *len)
 {
   if (n_ref_neg < 1) return uvghip_set_error(hipErrorInvalidValue, __func__);
-  return write_inter_picture(__func__, poc, poc_lsb_bits, slice_type, n_ref_neg, delta_neg, 0, nullptr, copy_rpl1 != 0, tmvp, qp_delta, sao, rows, row_pitch, row_bytes, n_rows,
+  return write_inter_picture(__func__, NAL_TRAIL, poc, poc_lsb_bits, slice_type, n_ref_neg, delta_neg, 0, nullptr, copy_rpl1 != 0, tmvp, qp_delta, sao, rows, row_pitch, row_bytes, n_rows,
                              checksum, out, cap, len);
 }
 
@@ -374,6 +377,19 @@ extern "C" int uvghip_write_picture_nals_ra(int poc, int poc_lsb_bits, int slice
                                             int tmvp, int qp_delta, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
                                             const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len)
 {
-  return write_inter_picture(__func__, poc, poc_lsb_bits, slice_type, n_ref_neg, delta_neg, n_ref_pos, delta_pos, 0, tmvp, qp_delta, sao, rows, row_pitch, row_bytes, n_rows,
+  return write_inter_picture(__func__, NAL_TRAIL, poc, poc_lsb_bits, slice_type, n_ref_neg, delta_neg, n_ref_pos, delta_pos, 0, tmvp, qp_delta, sao, rows, row_pitch, row_bytes, n_rows,
+                             checksum, out, cap, len);
+}
+
+// ... of a random-access stream with more than one intra period and an open GOP (cfg.open_gop, the default): the I picture that opens a
+// later period is a CRA picture (pictype, src/encoderstate.c:1957-1972) -- an I slice whose header still carries the reference picture lists
+// (the buffer the following pictures use, :1326-1329) and sh_no_output_of_prior_pics_flag (:1278) --, the pictures before it in display
+// order that are coded after it are RASL pictures (the same syntax as TRAIL under another NAL unit type).  nal_type: 0 TRAIL, 3 RASL, 9 CRA
+// (slice_type 2 with CRA only).
+extern "C" int uvghip_write_picture_nals_gop(int nal_type, int poc, int poc_lsb_bits, int slice_type, int n_ref_neg, const int32_t *delta_neg, int n_ref_pos,
+                                             const int32_t *delta_pos, int tmvp, int qp_delta, int sao, const uint8_t *rows, size_t row_pitch, const int32_t *row_bytes, int n_rows,
+                                             const uint32_t *checksum, uint8_t *out, size_t cap, size_t *len)
+{
+  return write_inter_picture(__func__, nal_type, poc, poc_lsb_bits, slice_type, n_ref_neg, delta_neg, n_ref_pos, delta_pos, 0, tmvp, qp_delta, sao, rows, row_pitch, row_bytes, n_rows,
                              checksum, out, cap, len);
 }

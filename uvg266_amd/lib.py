@@ -247,6 +247,7 @@ SIGNATURES = {
     "uvghip_write_picture_nals": (c_int, [c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_int, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "uvghip_write_idr_nals": (c_int, [c_int, c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_int, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "uvghip_write_picture_nals_pb": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_int, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "uvghip_write_picture_nals_gop": (c_int, [c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_int, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "uvghip_write_idr_nals_ra": (c_int, [c_int, c_int, c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_int, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "uvghip_write_picture_nals_ra": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_int, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "uvghip_slice_rows_pb_workspace_bytes": (ctypes.c_size_t, [c_int]),
