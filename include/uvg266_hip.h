@@ -880,7 +880,10 @@ typedef struct uvghip_ctu_params {
   int32_t wpp;                   /* cfg.wpp: must be 1 */
   int32_t combine_intra_cus;     /* cfg.combine_intra_cus */
   int32_t rough_levels;          /* cfg.intra_rough_search_levels: 2 or 3 */
-  int32_t reserved;
+  int32_t rd;                    /* cfg.rdo: 0 (--preset medium and faster) or 1 (--preset slow).  The two differ in ONE decision: with rd 0 a CU of
+                                  * a P / B picture whose inter cost per sample is below INTRA_THRESHOLD skips its intra search (search.c:1413-1419);
+                                  * I pictures are searched the same way.  rd >= 2 (full RD of several intra modes, of the merge / AMVP candidates)
+                                  * is refused by uvghip_ctu_search_pb. */
   double lambda, lambda_sqrt;    /* state->lambda, state->lambda_sqrt */
   double c_lambda;               /* state->c_lambda */
   double chroma_weight_u, chroma_weight_v;   /* state->chroma_weights[1], [2] */

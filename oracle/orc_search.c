@@ -65,7 +65,7 @@ typedef struct orc_search_params {
   int32_t qp_c;               /* encoder->qp_map[0][qp] (transform.c:158) */
   int32_t depth_min, depth_max;   /* pu-depth-intra */
   int32_t wpp, combine_intra_cus, rough_levels;   /* cfg.wpp, cfg.combine_intra_cus, cfg.intra_rough_search_levels */
-  int32_t reserved;
+  int32_t rd;                 /* cfg.rdo: 0 or 1 (they differ in the P / B CU's skip of the intra search, search.c:1413-1419) */
   double lambda, lambda_sqrt, c_lambda, cw_u, cw_v;   /* state->lambda ..., state->chroma_weights[1..2] */
 } orc_search_params;
 
@@ -1059,8 +1059,8 @@ static double search_cu(s_state *st, const s_loc *loc, const s_loc *chroma_loc, 
       search_cu_inter(st, loc, lcu, &mode_cost, &mode_bitcost);
       if (mode_cost < cost) { cost = mode_cost; inter_bitcost = mode_bitcost; cur_cu->type = CU_INTER; }
     }
-    /* rd = 0: no intra search when the inter cost per sample is below INTRA_THRESHOLD = 8, or after an early skip */
-    const int skip_intra = (cur_cu->type != CU_NOTSET && cost / (cu_width * cu_width) < 8) || (st->fr && st->fr->early_skip && cur_cu->skipped);
+    /* no intra search when -- rd = 0 only -- the inter cost per sample is below INTRA_THRESHOLD = 8, or after an early skip (search.c:1413-1419) */
+    const int skip_intra = (p->rd == 0 && cur_cu->type != CU_NOTSET && cost / (cu_width * cu_width) < 8) || (st->fr && st->fr->early_skip && cur_cu->skipped);
     /* check_can_use_intra (search.c:1257-1287) */
     const int min_w = LCU >> p->depth_max;
     int can_use_intra = 1;

@@ -285,7 +285,7 @@ class SearchParams(ctypes.Structure):
     """orc_search_params: what the search reads from encoder_state_t / encoder_control_t."""
     _fields_ = [("pic_w", ctypes.c_int32), ("pic_h", ctypes.c_int32), ("qp", ctypes.c_int32), ("qp_c", ctypes.c_int32),
                 ("depth_min", ctypes.c_int32), ("depth_max", ctypes.c_int32), ("wpp", ctypes.c_int32),
-                ("combine_intra_cus", ctypes.c_int32), ("rough_levels", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("combine_intra_cus", ctypes.c_int32), ("rough_levels", ctypes.c_int32), ("rd", ctypes.c_int32),
                 ("lam", ctypes.c_double), ("lam_sqrt", ctypes.c_double), ("c_lam", ctypes.c_double),
                 ("cw_u", ctypes.c_double), ("cw_v", ctypes.c_double)]
 
@@ -1024,6 +1024,16 @@ def clip_picture(W, H, t, depth):
     return moving_picture(W, H, 12 - abs(t % 24 - 12), depth)
 
 
+def plateau_picture(W, H, t, depth):
+    """clip_picture with the samples of every plane posterised to plateaus of 32 (8 bit): flat areas whose intra prediction is exact, so that
+    intra and inter candidates of a P / B CU compete at costs near zero -- where cfg.rdo 0 and 1 part ways (search.c:1413-1419)."""
+    sh = depth - 3
+    return tuple(np.ascontiguousarray(((p.astype(np.int32) >> sh) << sh).astype(p.dtype)) for p in clip_picture(W, H, t, depth))
+
+
+CLIP_GENERATORS = {0: None, 1: "clip_picture", 2: "plateau_picture"}          # the `clip` key of a ref_inter_* golden
+
+
 # ---- P / B pictures: the inter search of the oracle (oracle/orc_search.c + orc_search_inter.inc) ---------------------------------
 class InterFrame(ctypes.Structure):
     """orc_inter_frame: the picture's reference lists and reference pictures, as the encoder's frame-level bookkeeping hands them over."""
@@ -1089,14 +1099,16 @@ def iter_inter_frames(W, H, P):
         lists = [[int(a) for a in refs[19:35]], [int(a) for a in refs[35:51]]]
         poc, slice_type = int(refs[51]), int(d["meta"][6])
         lam = d["lam"]
-        prm = SearchParams(W, H, int(d["meta"][3]), int(d["meta"][3]), 1, 4, 1, 1, 2, 0, float(lam[0]), float(lam[1]), float(lam[2]), float(lam[3]), float(lam[4]))
+        cfg = [int(a) for a in d.get("cfg", (1, 6, 2, 1, 4, 1))]
+        rd = cfg[6] if len(cfg) > 6 else 0          # cfg.rdo of the run (0: --preset medium, 1: --preset slow)
+        prm = SearchParams(W, H, int(d["meta"][3]), int(d["meta"][3]), 1, 4, 1, 1, 2, rd, float(lam[0]), float(lam[1]), float(lam[2]), float(lam[3]), float(lam[4]))
         F = InterFrame()
         F.slice_type, F.poc, F.n_refs = slice_type, poc, n_refs
         for i in range(16):
             F.ref_pocs[i] = pocs[i]
             F.l[0][i], F.l[1][i] = lists[0][i], lists[1][i]
         F.l_size[0], F.l_size[1] = lsz
-        F.tmvp, F.max_merge, F.merge_level, F.bipred, F.fme_level, F.early_skip = (int(a) for a in d.get("cfg", (1, 6, 2, 1, 4, 1)))
+        F.tmvp, F.max_merge, F.merge_level, F.bipred, F.fme_level, F.early_skip = cfg[:6]
         F.depth_inter_min, F.depth_inter_max = 0, 3
         F.ref_cu_stride, F.frame_qp = wc * 16, int(d["meta"][7])
         keep = []
@@ -1234,14 +1246,16 @@ def run_inter_oracle(orc, W, H, depth, pics, P, ctx_trace=False):
         lists = [[int(a) for a in refs[19:35]], [int(a) for a in refs[35:51]]]
         poc, slice_type = int(refs[51]), int(d["meta"][6])
         lam = d["lam"]
-        prm = SearchParams(W, H, int(d["meta"][3]), int(d["meta"][3]), 1, 4, 1, 1, 2, 0, float(lam[0]), float(lam[1]), float(lam[2]), float(lam[3]), float(lam[4]))
+        cfg = [int(a) for a in d.get("cfg", (1, 6, 2, 1, 4, 1))]
+        rd = cfg[6] if len(cfg) > 6 else 0          # cfg.rdo of the run (0: --preset medium, 1: --preset slow)
+        prm = SearchParams(W, H, int(d["meta"][3]), int(d["meta"][3]), 1, 4, 1, 1, 2, rd, float(lam[0]), float(lam[1]), float(lam[2]), float(lam[3]), float(lam[4]))
         F = InterFrame()
         F.slice_type, F.poc, F.n_refs = slice_type, poc, n_refs
         for i in range(16):
             F.ref_pocs[i] = pocs[i]
             F.l[0][i], F.l[1][i] = lists[0][i], lists[1][i]
         F.l_size[0], F.l_size[1] = lsz
-        F.tmvp, F.max_merge, F.merge_level, F.bipred, F.fme_level, F.early_skip = (int(a) for a in d.get("cfg", (1, 6, 2, 1, 4, 1)))
+        F.tmvp, F.max_merge, F.merge_level, F.bipred, F.fme_level, F.early_skip = cfg[:6]
         F.depth_inter_min, F.depth_inter_max = 0, 3
         F.ref_cu_stride, F.frame_qp = wc * 16, int(d["meta"][7])
         keep = []
@@ -1334,7 +1348,7 @@ def golden_sources(g):
     against the golden's CRCs of what the encoder was fed)."""
     import zlib
     W, H, depth, qp0, frames = (int(a) for a in g["dims"])
-    gen = clip_picture if ("clip" in g.files and int(g["clip"])) else moving_picture
+    gen = globals()[CLIP_GENERATORS[int(g["clip"])]] if ("clip" in g.files and int(g["clip"])) else moving_picture
     shown = [gen(W, H, t, depth) for t in range(frames)]
     for t in range(frames):
         assert zlib.crc32(b"".join(p.tobytes() for p in shown[t])) == int(g["src_crc"][t]), "the sequence generator drifted from the golden's source"

@@ -159,7 +159,7 @@ def test_device_outputs_complete_a_multi_picture_stream(hip, name):
 
 @pytest.mark.parametrize("name", ["ref_inter_136x72_10_qp22_4frames", "ref_inter_192x128_8_qp17_5frames", "ref_inter_264x136_8_qp32_9frames",
                                   "ref_inter_136x72_8_qp27_4frames_p_notmvp", "ref_inter_192x128_10_qp24_4frames_subme0_noskip",
-           "ref_inter_136x72_8_qp27_17frames_ra16", "ref_inter_136x72_10_qp22_17frames_ra16", "ref_inter_136x72_8_qp27_9frames_ra8", "ref_inter_136x72_8_qp27_33frames_ra16p16"])
+           "ref_inter_136x72_8_qp27_17frames_ra16", "ref_inter_136x72_10_qp22_17frames_ra16", "ref_inter_136x72_8_qp27_9frames_ra8", "ref_inter_136x72_8_qp27_5frames_rd1", "ref_inter_136x72_8_qp27_33frames_ra16p16"])
 def test_whole_low_delay_file_from_rows_and_final_pictures(name):
     """A low-delay stream (--gop lp-g4d3t1) or a random-access one (--gop 16: pictures in coding order, lists with references in the future,
     six POC bits): behind the encoder's parameter sets, the IDR picture's NAL units (with its slice QP offset)

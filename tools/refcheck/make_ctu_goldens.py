@@ -269,10 +269,10 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
     filters, per CTU the side information incl. motion, the levels and the reconstruction before the filters -- what a reconstruction
     of the encoder's decisions (motion compensation + residual) needs.  Every per-picture array is in CODING order; `display[f]` is the
     display index (= the source picture) of coded picture f.  clip: sources from helpers.clip_picture (any length) instead of moving_picture."""
-    if clip:
+    if clip:          # True / 1: helpers.clip_picture; 2: helpers.plateau_picture (helpers.CLIP_GENERATORS)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import helpers
-        moving_picture = helpers.clip_picture
+        moving_picture = getattr(helpers, helpers.CLIP_GENERATORS[int(clip)])
     else:
         moving_picture = globals()["moving_picture"]
     px = np.uint8 if depth == 8 else np.uint16
@@ -343,11 +343,11 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
                         # every call of uvg_search_cu_inter in coding order: frame, x, y, w, h, then the decided cu_info_t fields; its two costs
                         cuinter_i=np.stack([r[0] for r in CI]).astype(np.int32) if with_levels else np.zeros((0, 20), np.int32),
                         cuinter_d=np.stack([r[1] for r in CI]) if with_levels else np.zeros((0, 2)),
-                        display=display, clip=np.int32(bool(clip)), gop_len=np.int32(int(opt["gop"]) if opt.get("gop", "").isdigit() else 0),      # (0: a low-delay structure)
+                        display=display, clip=np.int32(int(clip)), gop_len=np.int32(int(opt["gop"]) if opt.get("gop", "").isdigit() else 0),      # (0: a low-delay structure)
                         sao_models=sao_models, row_bytes=row_bytes, row_off=row_off, bitstream=np.frombuffer(open(out + ".266", "rb").read(), np.uint8),
                         # the tools the run had on, for the tests' frame state: tmvp, max_merge, merge_level, bipred, fme_level, early_skip
                         cfg=np.array([int(opt.get("tmvp", 1)), int(opt.get("max-merge", 6)), 2, int(opt.get("bipred", 1)), {0: 0, 1: 1, 2: 2, 3: 3, 4: 4}[int(opt.get("subme", 4))],
-                                      int(opt.get("early-skip", 1))], np.int32))
+                                      int(opt.get("early-skip", 1)), int(opt.get("rd", 0))], np.int32))
     if not out_dir: print("wrote inter", tag, n, "CTU records")
     return tag
 
@@ -506,4 +506,5 @@ if __name__ == "__main__":
     inter(136, 72, 8, 27, 17, extra=("gop", "16"), suffix="_ra16", clip=True)      # random access, --preset medium's own GOP: coding order 0 16 8 4 2 1 3 6 5 7 12 ..., future references, five temporal layers
     inter(136, 72, 10, 22, 17, extra=("gop", "16"), suffix="_ra16", clip=True)     # ... at 10 bit, QP 22
     inter(136, 72, 8, 27, 9, extra=("gop", "8"), suffix="_ra8", clip=True)         # the 8-picture random-access GOP (what the presets up to "faster" run with): five POC bits
+    inter(136, 72, 8, 27, 5, extra=("rd", "1"), suffix="_rd1", clip=2)                 # --preset slow = medium + rd 1 (a P / B CU never skips its intra search on a low inter cost); plateau content
     inter(136, 72, 8, 27, 33, extra=("gop", "16", "period", "16"), suffix="_ra16p16", clip=True)      # three intra periods of an open GOP: CRA pictures at POC 16 and 32, RASL pictures behind them

@@ -601,13 +601,13 @@ def quant_signhide_batch(coef, bitdepth, qp_scaled, transform_skip=False, slice_
 
 
 # ---- closed-loop intra search of whole pictures (include/uvg266_hip.h part 4) ----------------------------------------------
-def ctu_params(pic_w, pic_h, qp, qp_c=None, lam=None, depth_min=1, depth_max=4, combine_intra_cus=1, rough_levels=2):
+def ctu_params(pic_w, pic_h, qp, qp_c=None, lam=None, depth_min=1, depth_max=4, combine_intra_cus=1, rough_levels=2, rd=0):
     """uvghip_ctu_params_t for --preset medium -p 1: lambda = 0.57 * 2^((qp - 12) / 3) (src/rate_control.c qp_to_lambda for an intra
     picture), the default chroma QP table (identity), chroma weights from the luma / chroma QP distance."""
     qp_c = qp if qp_c is None else qp_c
     lam = 0.57 * 2.0 ** ((qp - 12) / 3.0) if lam is None else lam
     w = 2.0 ** ((qp - qp_c) / 3.0)
-    return _lib.CtuParams(pic_w, pic_h, qp, qp_c, depth_min, depth_max, 1, combine_intra_cus, rough_levels, 0,
+    return _lib.CtuParams(pic_w, pic_h, qp, qp_c, depth_min, depth_max, 1, combine_intra_cus, rough_levels, rd,
                           lam, float(np.sqrt(lam)), lam / w, w, w, lam / w)
 
 
@@ -1011,8 +1011,9 @@ class LowDelayLoop:
     CODING order there, and run(in_flight=k) issues every picture as soon as the pictures it references are done -- pictures of the same
     temporal layer, and of neighbouring GOPs, run side by side on k streams (deps[f]: the coded pictures f reads)."""
 
-    def __init__(self, W, H, depth, n_seq, frames, src, sao_type=3, tmvp=1, max_merge=6, merge_level=2, bipred=1, fme_level=4, early_skip=1, by_level=False):
-        """by_level: the P / B pictures that sit at the same depth of the reference DAG (deps) go through ONE uvghip_loop_pb_run together --
+    def __init__(self, W, H, depth, n_seq, frames, src, sao_type=3, tmvp=1, max_merge=6, merge_level=2, bipred=1, fme_level=4, early_skip=1, by_level=False, rd=0):
+        """rd: cfg.rdo, 0 (--preset medium) or 1 (--preset slow: a P / B CU never skips its intra search on a low inter cost).
+        by_level: the P / B pictures that sit at the same depth of the reference DAG (deps) go through ONE uvghip_loop_pb_run together --
         the pictures of one temporal layer of a random-access GOP, and of neighbouring GOPs, share a launch (their wavefronts interleave in the
         search kernel); a low-delay sequence has one picture per level and is unchanged."""
         self.W, self.H, self.depth, self.n_seq, self.frames, self.sao_type = W, H, depth, n_seq, frames, sao_type
@@ -1038,7 +1039,7 @@ class LowDelayLoop:
                     q = arr[s]
                     p = q.search
                     w = 2.0 ** 0
-                    p.params = _lib.CtuParams(W, H, fs["qp"], fs["qp"], 1, 4, 1, 1, 2, 0, fs["lam"], fs["lam_sqrt"], fs["c_lam"], fs["cw_u"], fs["cw_v"], fs["lam"])
+                    p.params = _lib.CtuParams(W, H, fs["qp"], fs["qp"], 1, 4, 1, 1, 2, rd, fs["lam"], fs["lam_sqrt"], fs["c_lam"], fs["cw_u"], fs["cw_v"], fs["lam"])
                     t = dict(rec=[z((H >> c, W >> c), tdt) for c in (0, 1, 1)], out=tuple(z((H >> c, W >> c), tdt) for c in (0, 1, 1)),
                              scu=z(n4 * 32, torch.uint8), i4=z(n4 * 8, torch.uint8), mot=z((hc * 16, wc * 16, 8), torch.int32), co=z(ctus * 6144, torch.int16),
                              mo=z(ctus * 3 * 257, torch.int32), mi=z(ctus * 3 * 18, torch.int32))

@@ -200,7 +200,7 @@ extern "C" int uvghip_ctu_search_pb(int bitdepth, const uvghip_ctu_pb_picture_t 
     const uvghip_ctu_params_t &p = q.params;
     if (p.pic_w != p0.pic_w || p.pic_h != p0.pic_h) return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_pb: the pictures of a call share one size");
     if (p.wpp != 1 || p.depth_min < 1 || p.depth_max != 4 || p.depth_min > p.depth_max || p.rough_levels < 2 || p.rough_levels > 3 || p.qp < 0 || p.qp > 63 ||
-        p.qp_c < 0 || p.qp_c > 63 || !(p.lambda > 0) || !(p.lambda_sqrt > 0))
+        p.qp_c < 0 || p.qp_c > 63 || !(p.lambda > 0) || !(p.lambda_sqrt > 0) || p.rd < 0 || p.rd > 1)
       return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_pb: configuration outside the supported subset");
     if ((q.slice_type != 0 && q.slice_type != 1) || q.n_refs < 1 || q.n_refs > 16 || q.l_size[0] < 1 || q.l_size[0] > 8 || q.l_size[1] < 0 || q.l_size[1] > 8 ||
         (q.slice_type == 1 && q.l_size[1] != 0) || q.depth_inter_min != 0 || q.depth_inter_max != 3 || q.max_merge < 5 || q.max_merge > 6 || q.fme_level < 0 ||

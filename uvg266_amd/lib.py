@@ -60,7 +60,7 @@ class CuView(ctypes.Structure):
 class CtuParams(ctypes.Structure):
     """uvghip_ctu_params_t: what the closed-loop CTU search reads from encoder_state_t / encoder_control_t."""
     _fields_ = [(n, ctypes.c_int32) for n in ("pic_w", "pic_h", "qp", "qp_c", "depth_min", "depth_max", "wpp", "combine_intra_cus", "rough_levels",
-                                                "reserved")] + \
+                                                "rd")] + \
                [(n, ctypes.c_double) for n in ("lambda_", "lambda_sqrt", "c_lambda", "chroma_weight_u", "chroma_weight_v", "c_lambda_tu")]
 
 
