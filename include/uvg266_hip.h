@@ -1029,6 +1029,36 @@ UVGHIP_API int uvghip_encode_slice_rows_alf(int bitdepth, const uvghip_ctu_param
                                             int n_pictures, const int32_t *sao_info, const uint16_t *sao_models, void *workspace, uint8_t *out, int row_cap,
                                             int32_t *row_bytes, void *stream);
 
+/* The ALF stage of a picture group behind uvghip_loop_plan_run (BASELINE configs[3]: --alf full) -- where the encoder runs
+ * uvg_alf_enc_process (src/alf.c:5193) on pictures whose search, deblocking and SAO the device did.  The derivation of the decisions
+ * (alf_encoder :3994, alf_encoder_ctb :4369, derive_cc_alf_filter :2212) stays with the host behind `decide`:
+ *   decide(user, i, picture, decision): picture->out_* = the picture ALF gets (device planes), picture->search.src_* = the source; the
+ *     statistics of alf_derive_stats_for_filtering (:4227) are the callback's to gather from them (uvghip_alf_classify_frame,
+ *     uvghip_alf_stats_compact_batch + uvghip_alf_cov_reduce, uvghip_alf_stats_batch for chroma, uvghip_cc_alf_stats_batch; it
+ *     synchronises what it reads back).  It fills *decision with HOST arrays in the layouts of uvghip_alf_picture_t / uvghip_slice_alf_t,
+ *     valid until it is called again or the stage returns; 0 = ok.
+ * Per picture the stage then runs uvghip_alf_reconstruct_picture from the SAO output into alf_out[i] (a picture without any enabled
+ * component is copied), and for the group uvghip_encode_slice_rows_alf: rows / row_bytes as in uvghip_encode_slice_rows_alf
+ * ([picture][row][row_cap] bytes, [picture][row] lengths; device memory).  classification_shift: cfg.input_bitdepth + 4 (:5185).
+ * workspace: uvghip_loop_plan_alf_workspace_bytes(plan) of device memory.  The call returns with the stream's work enqueued; it
+ * synchronises the stream between pictures (the decisions are host data). */
+typedef struct uvghip_alf_decision {
+  int32_t alf_type;                  /* cfg.alf_type: 1 --alf no-cc, 2 --alf full */
+  int32_t enabled[3];                /* slice->alf->tile_group_alf_enabled_flag[c] */
+  int32_t n_luma_aps;                /* tile_group_num_aps */
+  const int16_t *luma_aps;           /* [n_luma_aps][677] as uvghip_alf_picture_t.luma_aps */
+  const int16_t *chroma_aps;         /* [114] as uvghip_alf_picture_t.chroma_aps ([112] = num_alternatives_chroma) */
+  int32_t cc_enabled[2], cc_filter_count[2];
+  const int16_t *cc_coeff;           /* [2][4][8] */
+  const uint8_t *ctu_flags;          /* [7][ctus] as uvghip_alf_picture_t.ctu_flags */
+  const int16_t *filter_set_idx;     /* [ctus] */
+} uvghip_alf_decision_t;
+typedef struct uvghip_alf_planes { void *y, *u, *v; int32_t stride, stride_c; } uvghip_alf_planes_t;      /* device planes, strides in samples */
+typedef int (*uvghip_alf_decide_fn)(void *user, int picture, const uvghip_loop_picture_t *planes, uvghip_alf_decision_t *decision);
+UVGHIP_API size_t uvghip_loop_plan_alf_workspace_bytes(const uvghip_loop_plan_t *plan);
+UVGHIP_API int uvghip_loop_plan_alf_stage(uvghip_loop_plan_t *plan, uvghip_alf_decide_fn decide, void *user, int classification_shift, const uvghip_alf_planes_t *alf_out,
+                                          void *workspace, uint8_t *rows, int row_cap, int32_t *row_bytes, void *stream);
+
 /* ------------------- (7) the picture's NAL units behind the parameter sets -------------------------------------------- */
 
 /* replaces: uvg_image_checksum / array_checksum_generic (src/nal.c:91-115, src/strategies/generic/nal-generic.c:68-92) on the

@@ -789,7 +789,7 @@ class ClosedLoop(CtuSearch):
         return out, nbytes
 
     def alf_stage(self, decide, source=None, classification_shift=None):
-        """The ALF stage of the picture loop (BASELINE configs[3]: --alf full), after run(): for every picture of the plan
+        """uvghip_loop_plan_alf_stage: the ALF stage of the picture loop (BASELINE configs[3]: --alf full), after run(): for every picture of the plan
           1. the frame's ALF statistics from the loop's SAO output on the device, handed over on demand (AlfStatistics: classification,
              luma covariance per class and CTU, chroma covariance, CC-ALF covariance -- what alf_derive_stats_for_filtering leaves, alf.c:4227),
           2. `decide(i, stats)` on the host -> the picture's decisions: the derivation the reference keeps in alf_encoder / alf_encoder_ctb /
@@ -802,21 +802,44 @@ class ClosedLoop(CtuSearch):
         -> (alf_out: per picture three device planes, rows [n, n_rows, row_cap] uint8, row_bytes [n, n_rows] int32).  source: the plan's
         source pictures (the statistics compare with them); classification_shift: cfg.input_bitdepth + 4 (alf.c:5185; default depth + 4)."""
         shift = self.depth + 4 if classification_shift is None else classification_shift
-        decisions, self.alf_out = [], []
-        for i in range(self.n):
-            stats = AlfStatistics(self.out[i], None if source is None else source[i], int(self.P.pic_w), int(self.P.pic_h), shift)
-            d = decide(i, stats)
-            decisions.append(d)
-            if int(d["enabled"][0]) or int(d["enabled"][1]) or int(d["enabled"][2]) or int(d["cc_enabled"][0]) or int(d["cc_enabled"][1]):
-                k = int(d["n_luma_aps"])
-                self.alf_out.append(alf_reconstruct_picture(list(self.out[i]), d["enabled"], d["ctu_flags"], d["filter_set_idx"], np.asarray(d["luma_aps"]).reshape(-1, 677)[:k],
-                                                            d["chroma_aps"], alf_full=int(d["alf_type"]) == 2, cc_alf_enabled=d["cc_enabled"], cc_coeff=d["cc_coeff"],
-                                                            classification_shift=shift))
-            else:
-                self.alf_out.append(list(self.out[i]))          # (a picture ALF leaves alone)
-        rows, nbytes = self.encode_rows_alf([dict(alf_type=d["alf_type"], enabled=d["enabled"], n_luma_aps=d["n_luma_aps"], n_alternatives_chroma=int(np.asarray(d["chroma_aps"]).ravel()[112]),
-                                                  cc_enabled=d["cc_enabled"], cc_filter_count=d["cc_filter_count"], ctu_flags=d["ctu_flags"], filter_set_idx=d["filter_set_idx"])
-                                             for d in decisions])
+        dev = self.loop_ws.device
+        W, H = int(self.P.pic_w), int(self.P.pic_h)
+        self.alf_out = [[torch.empty_like(p) for p in self.out[i]] for i in range(self.n)]
+        planes = (_lib.AlfPlanes * self.n)()
+        for i, o in enumerate(self.alf_out):
+            planes[i] = _lib.AlfPlanes(_dev(o[0]), _dev(o[1]), _dev(o[2]), o[0].stride(0), o[1].stride(0))
+        keep, failure = [], []
+
+        def trampoline(user, i, picture, decision):          # uvghip_alf_decide_fn: the library calls back once per picture
+            try:
+                stats = AlfStatistics(self.out[i], None if source is None else source[i], W, H, shift)
+                d = decide(i, stats)
+                arr = dict(luma_aps=np.ascontiguousarray(np.asarray(d["luma_aps"], np.int16).reshape(-1, 677)[:int(d["n_luma_aps"])]),
+                           chroma_aps=np.ascontiguousarray(d["chroma_aps"], np.int16), cc_coeff=np.ascontiguousarray(d["cc_coeff"], np.int16),
+                           ctu_flags=np.ascontiguousarray(d["ctu_flags"], np.uint8), filter_set_idx=np.ascontiguousarray(d["filter_set_idx"], np.int16))
+                keep[:] = [arr]                               # (valid until the next call, as the ABI asks)
+                o = decision.contents
+                o.alf_type, o.n_luma_aps = int(d["alf_type"]), int(d["n_luma_aps"])
+                for c in range(3):
+                    o.enabled[c] = int(d["enabled"][c])
+                for c in range(2):
+                    o.cc_enabled[c], o.cc_filter_count[c] = int(d["cc_enabled"][c]), int(d["cc_filter_count"][c])
+                for k, a in arr.items():
+                    setattr(o, k, a.ctypes.data if a.size else None)
+                return 0
+            except Exception as e:                            # noqa: BLE001 -- an exception must not unwind through the C frames
+                failure.append(e)
+                return 1
+        cb = _lib.ALF_DECIDE_FN(trampoline)
+        row_cap = 3 * 64 * W * (1 if self.depth == 8 else 2)
+        rows = torch.empty((self.n, self.hc, row_cap), dtype=torch.uint8, device=dev)
+        nbytes = torch.zeros((self.n, self.hc), dtype=torch.int32, device=dev)
+        ws = torch.empty(self.L.uvghip_loop_plan_alf_workspace_bytes(self.loop), dtype=torch.uint8, device=dev)
+        rc = self.L.uvghip_loop_plan_alf_stage(self.loop, cb, None, shift, ctypes.byref(planes), _dev(ws), _dev(rows), row_cap, _dev(nbytes), _stream())
+        if failure:
+            raise failure[0]
+        _lib.check(rc, "uvghip_loop_plan_alf_stage")
+        torch.cuda.synchronize()          # (the stage's workspace goes out of scope with this call)
         return self.alf_out, rows, nbytes
 
     def __del__(self):

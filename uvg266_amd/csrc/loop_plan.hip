@@ -6,6 +6,7 @@
 #include "uvghip_common.h"
 #include <new>
 #include <vector>
+#include <cstring>
 
 struct uvghip_loop_plan {
   int bitdepth, n, w, h, qp, sao_type, ctus;
@@ -224,6 +225,78 @@ extern "C" int uvghip_loop_plan_results(const uvghip_loop_plan_t *pl, const int3
   if (sao_info) *sao_info = pl->sao_info;
   if (sao_models) *sao_models = pl->sao_models;
   return 0;
+}
+
+// The ALF stage of the group (BASELINE configs[3]: --alf full), after uvghip_loop_plan_run: where the encoder runs uvg_alf_enc_process
+// (src/alf.c:5193) on a picture whose search and SAO the device did.  Per picture the caller's `decide` is called with the picture's planes
+// -- what ALF gets (the plan's SAO output) and the source -- and returns the decisions; the derivation itself (alf_encoder :3994,
+// alf_encoder_ctb :4369, derive_cc_alf_filter :2212 on the statistics of alf_derive_stats_for_filtering :4227, which `decide` gathers with
+// uvghip_alf_classify_frame / uvghip_alf_stats_compact_batch / uvghip_alf_cov_reduce / uvghip_cc_alf_stats_batch on the given planes and
+// stream) stays host code.  Then uvghip_alf_reconstruct_picture into the caller's output planes and, for the whole group,
+// uvghip_encode_slice_rows_alf: the slice data with the CTU-level ALF syntax.
+extern "C" size_t uvghip_loop_plan_alf_workspace_bytes(const uvghip_loop_plan_t *pl)
+{
+  if (!pl) return 0;
+  return align_up(uvghip_alf_reconstruct_workspace_bytes(pl->w, pl->h), 256) + align_up(uvghip_slice_rows_alf_workspace_bytes(pl->n), 256) +
+         (size_t)pl->n * align_up((size_t)pl->ctus * 7 + (size_t)pl->ctus * sizeof(int16_t), 256);
+}
+
+extern "C" int uvghip_loop_plan_alf_stage(uvghip_loop_plan_t *pl, uvghip_alf_decide_fn decide, void *user, int classification_shift, const uvghip_alf_planes_t *alf_out,
+                                          void *workspace, uint8_t *rows, int row_cap, int32_t *row_bytes, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!pl || !decide || !alf_out || !workspace || !rows || row_cap <= 0 || !row_bytes || classification_shift < 8 || classification_shift > 20)
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  hipStream_t st = uvghip_stream(stream);
+  unsigned char *ws = static_cast<unsigned char *>(workspace);
+  unsigned char *ws_rec = ws, *ws_coder = ws_rec + align_up(uvghip_alf_reconstruct_workspace_bytes(pl->w, pl->h), 256);
+  unsigned char *ws_flags = ws_coder + align_up(uvghip_slice_rows_alf_workspace_bytes(pl->n), 256);
+  const size_t per = align_up((size_t)pl->ctus * 7 + (size_t)pl->ctus * sizeof(int16_t), 256), b = pl->bitdepth == 8 ? 1 : 2;
+  std::vector<uvghip_slice_alf_t> sl(pl->n);
+  std::vector<uvghip_ctu_picture_t> cp(pl->n);
+  for (int i = 0; i < pl->n; ++i) {
+    const uvghip_loop_picture_t &q = pl->pics[i];
+    const uvghip_alf_planes_t &o = alf_out[i];
+    if (!o.y || !o.u || !o.v || o.stride < pl->w || o.stride_c < pl->w / 2) return uvghip_set_error(hipErrorInvalidValue, "uvghip_loop_plan_alf_stage: output planes");
+    uvghip_alf_decision_t d;
+    memset(&d, 0, sizeof d);
+    if (int rc = decide(user, i, &q, &d)) return uvghip_set_error(hipErrorInvalidValue, rc > 0 ? "uvghip_loop_plan_alf_stage: decide() failed" : "uvghip_loop_plan_alf_stage: decide() refused");
+    const bool any = d.enabled[0] || d.enabled[1] || d.enabled[2] || d.cc_enabled[0] || d.cc_enabled[1];
+    if ((d.alf_type != 1 && d.alf_type != 2) || d.n_luma_aps < 0 || d.n_luma_aps > 8 || (any && (!d.ctu_flags || !d.filter_set_idx)) || (d.n_luma_aps && !d.luma_aps) ||
+        ((d.enabled[1] || d.enabled[2]) && !d.chroma_aps) || ((d.cc_enabled[0] || d.cc_enabled[1]) && !d.cc_coeff))
+      return uvghip_set_error(hipErrorInvalidValue, "uvghip_loop_plan_alf_stage: the decision decide() returned");
+    if (any) {
+      uvghip_alf_picture_t a;
+      memset(&a, 0, sizeof a);
+      a.in_y = q.out_y; a.in_u = q.out_u; a.in_v = q.out_v; a.in_stride = q.out_stride; a.in_stride_c = q.out_stride_c;
+      a.out_y = o.y; a.out_u = o.u; a.out_v = o.v; a.out_stride = o.stride; a.out_stride_c = o.stride_c;
+      a.width = pl->w; a.height = pl->h;
+      for (int c = 0; c < 3; ++c) a.slice_enabled[c] = d.enabled[c];
+      a.n_luma_aps = d.n_luma_aps; a.ctu_flags = d.ctu_flags; a.filter_set_idx = d.filter_set_idx; a.luma_aps = d.luma_aps; a.chroma_aps = d.chroma_aps;
+      a.alf_full = d.alf_type == 2; a.cc_alf_enabled[0] = d.cc_enabled[0]; a.cc_alf_enabled[1] = d.cc_enabled[1]; a.cc_coeff = d.cc_coeff;
+      a.classification_shift = classification_shift;
+      if (int rc = uvghip_alf_reconstruct_picture(pl->bitdepth, &a, ws_rec, stream)) return rc;
+    } else {          // a picture ALF leaves alone
+      UVGHIP_TRY(hipMemcpy2DAsync(o.y, (size_t)o.stride * b, q.out_y, (size_t)q.out_stride * b, (size_t)pl->w * b, pl->h, hipMemcpyDeviceToDevice, st));
+      UVGHIP_TRY(hipMemcpy2DAsync(o.u, (size_t)o.stride_c * b, q.out_u, (size_t)q.out_stride_c * b, (size_t)(pl->w / 2) * b, pl->h / 2, hipMemcpyDeviceToDevice, st));
+      UVGHIP_TRY(hipMemcpy2DAsync(o.v, (size_t)o.stride_c * b, q.out_v, (size_t)q.out_stride_c * b, (size_t)(pl->w / 2) * b, pl->h / 2, hipMemcpyDeviceToDevice, st));
+    }
+    // the slice's side of the decision: the flags and set indices on the device, where the coder reads them
+    uvghip_slice_alf_t &s = sl[i];
+    memset(&s, 0, sizeof s);
+    s.alf_type = d.alf_type; s.n_luma_aps = d.n_luma_aps; s.n_alternatives_chroma = d.chroma_aps ? d.chroma_aps[112] : 0;
+    for (int c = 0; c < 3; ++c) s.enabled[c] = d.enabled[c];
+    for (int c = 0; c < 2; ++c) { s.cc_enabled[c] = d.cc_enabled[c]; s.cc_filter_count[c] = d.cc_filter_count[c]; }
+    unsigned char *fl = ws_flags + (size_t)i * per;
+    if (d.ctu_flags && d.filter_set_idx) {
+      UVGHIP_TRY(hipMemcpyAsync(fl, d.ctu_flags, (size_t)pl->ctus * 7, hipMemcpyHostToDevice, st));
+      UVGHIP_TRY(hipMemcpyAsync(fl + (size_t)pl->ctus * 7 + ((size_t)pl->ctus & 1), d.filter_set_idx, (size_t)pl->ctus * sizeof(int16_t), hipMemcpyHostToDevice, st));
+      UVGHIP_TRY(hipStreamSynchronize(st));          // (decide()'s arrays need not outlive the next call)
+      s.ctu_flags = fl; s.filter_set_idx = reinterpret_cast<const int16_t *>(fl + (size_t)pl->ctus * 7 + ((size_t)pl->ctus & 1));
+    }
+    cp[i] = q.search;
+  }
+  return uvghip_encode_slice_rows_alf(pl->bitdepth, &pl->ctu_params, cp.data(), sl.data(), pl->n, pl->sao_info, pl->sao_models, ws_coder, rows, row_cap, row_bytes, stream);
 }
 
 extern "C" void uvghip_loop_plan_destroy(uvghip_loop_plan_t *pl)

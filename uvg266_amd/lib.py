@@ -143,6 +143,20 @@ class LoopPicture(ctypes.Structure):
                 ("out_stride", ctypes.c_int32), ("out_stride_c", ctypes.c_int32)]
 
 
+class AlfDecision(ctypes.Structure):
+    """uvghip_alf_decision_t: what the host's ALF derivation returns for one picture (host arrays)."""
+    _fields_ = [("alf_type", ctypes.c_int32), ("enabled", ctypes.c_int32 * 3), ("n_luma_aps", ctypes.c_int32), ("luma_aps", ctypes.c_void_p), ("chroma_aps", ctypes.c_void_p),
+                ("cc_enabled", ctypes.c_int32 * 2), ("cc_filter_count", ctypes.c_int32 * 2), ("cc_coeff", ctypes.c_void_p), ("ctu_flags", ctypes.c_void_p),
+                ("filter_set_idx", ctypes.c_void_p)]
+
+
+class AlfPlanes(ctypes.Structure):
+    """uvghip_alf_planes_t."""
+    _fields_ = [("y", ctypes.c_void_p), ("u", ctypes.c_void_p), ("v", ctypes.c_void_p), ("stride", ctypes.c_int32), ("stride_c", ctypes.c_int32)]
+
+
+ALF_DECIDE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(LoopPicture), ctypes.POINTER(AlfDecision))      # uvghip_alf_decide_fn
+
 _lib = None
 _inited_device = None
 
@@ -243,6 +257,8 @@ SIGNATURES = {
     "uvghip_loop_plan_slice_data": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_encode_slice_rows": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "uvghip_loop_plan_picture_nals": (c_int, [c_vp, c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_vp]),
+    "uvghip_loop_plan_alf_workspace_bytes": (ctypes.c_size_t, [c_vp]),
+    "uvghip_loop_plan_alf_stage": (c_int, [c_vp, ALF_DECIDE_FN, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "uvghip_picture_checksum": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     "uvghip_write_picture_nals": (c_int, [c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_int, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "uvghip_write_idr_nals": (c_int, [c_int, c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_int, c_vp, c_vp, ctypes.c_size_t, c_vp]),
