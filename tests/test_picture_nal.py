@@ -231,5 +231,15 @@ def test_the_inter_writers_refuse_what_no_gop_structure_lists():
     assert ra(4, [4], [4, 12]) == 0
     neg = np.array([1, 2], np.int32)
     assert L.uvghip_write_picture_nals_pb(3, 4, 0, 2, H.ptr(neg), 1, 1, 0, 1, H.ptr(rows), rows.shape[1], H.ptr(sizes), 2, H.ptr(sums), H.ptr(out), len(out), ctypes.byref(n)) == 0
+    def gop(nal, slice_type, neg):
+        a = np.ascontiguousarray(neg, np.int32)
+        return L.uvghip_write_picture_nals_gop(nal, 16, 6, slice_type, len(a), H.ptr(a) if len(a) else None, 0, None, 1, 0, 1, H.ptr(rows), rows.shape[1], H.ptr(sizes), 2,
+                                               H.ptr(sums), H.ptr(out), len(out), ctypes.byref(n))
+    assert gop(9, 2, [16]) == 0                # a CRA picture: an I slice that lists its reference buffer
+    assert gop(9, 2, []) == 0                  # ... or none
+    assert gop(9, 0, [16]) != 0                # CRA is an I slice
+    assert gop(3, 2, [16]) != 0                # an I slice is CRA (or IDR: uvghip_write_idr_nals_ra)
+    assert gop(3, 0, [16]) == 0 and gop(0, 1, [16]) == 0
+    assert gop(5, 0, [16]) != 0                # not a NAL unit type of this writer
     bad = np.array([2, 1], np.int32)
     assert L.uvghip_write_picture_nals_pb(3, 4, 0, 2, H.ptr(bad), 1, 1, 0, 1, H.ptr(rows), rows.shape[1], H.ptr(sizes), 2, H.ptr(sums), H.ptr(out), len(out), ctypes.byref(n)) != 0
