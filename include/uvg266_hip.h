@@ -1246,10 +1246,12 @@ typedef struct uvghip_ctu_pb_picture {
   uint32_t *trees;
   int32_t *motion_out;
 } uvghip_ctu_pb_picture_t;
-/* pictures: HOST array of n pictures that do not depend on each other (each one's references are complete).  workspace:
- * uvghip_ctu_search_pb_workspace_bytes of device memory, in use until the work enqueued on `stream` is done.  Uploads the picture
- * table (a synchronous copy, after waiting for `stream`), then enqueues one launch: one wave per CTU, released in an order that
- * respects the left / upper / upper-right dependencies, pictures interleaved. */
+/* pictures: HOST array of n pictures that do not depend on each other (each one's references are complete: the pictures of several
+ * sequences, or of one sequence's reference DAG at the same depth -- slice types, QPs and reference lists may differ).  workspace:
+ * uvghip_ctu_search_pb_workspace_bytes of device memory, in use until the work enqueued on `stream` is done.  The call does not wait for
+ * the stream: the picture table is written in stream order, then one launch of persistent one-wave workgroups (a few per CTU of a
+ * picture's widest wavefront diagonal) that take CTU after CTU in an order that respects the left / upper / upper-right dependencies,
+ * pictures interleaved.  params.rd: 0 or 1 (uvghip_ctu_params_t). */
 UVGHIP_API size_t uvghip_ctu_search_pb_workspace_bytes(int n_pictures, int pic_w, int pic_h);
 UVGHIP_API int uvghip_ctu_search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictures, void *workspace, void *stream);
 
