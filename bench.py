@@ -675,7 +675,9 @@ def c3_clip(device, frames=24, with_cpu=True):
     frames = min(frames, total)
     states = Hh.frame_states_from_records(g["meta"], g["lam"], g["refs"])[:frames]
     src = [[tuple(torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in Hh.clip_picture(W, H, t, depth)) for t in range(frames)]]
-    loop = api.LowDelayLoop(W, H, depth, 1, states, src)
+    # (by_level: pictures at the same depth of the reference DAG share a launch -- in a low-delay GOP that is one picture per level, except
+    # across an IDR picture: with --c3-clip-frames 120 the second intra period, pictures 64..119, runs beside the first)
+    loop = api.LowDelayLoop(W, H, depth, 1, states, src, by_level=True)
     loop.run()                                            # warm-up (plans, first-touch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -684,6 +686,7 @@ def c3_clip(device, frames=24, with_cpu=True):
     dt = time.perf_counter() - t0
     nbytes = int(sum(int(loop.row_bytes[f].sum().item()) for f in range(frames)))
     out = {"value": round(frames / dt, 3), "unit": "frames/s (one low-delay clip, pictures strictly in sequence)", "frames_timed": frames, "clip_frames": total,
+           "dependency_levels": 1 + max(loop.level),
            "wall_ms": round(1e3 * dt, 1), "slice_data_bytes": nbytes,
            "workload": f"{W}x{H} {depth}-bit yuv420p, ONE clip, --gop lp-g4d3t1 --preset medium at QP {qp} (BASELINE.json configs[2]); per picture: closed-loop CTU search "
                        "with the inter search on the device's own reference pictures -> deblocking -> SAO -> arithmetic coder",
