@@ -95,6 +95,10 @@ typedef struct orc_inter_frame {
   int32_t ref_cu_stride, frame_qp;    /* frame_qp: state->frame->QP, what the slice's context models are initialised with */
   const orc_px *ref_y[16], *ref_u[16], *ref_v[16];      /* the reference pictures after the in-loop filters, pic_w x pic_h, tightly packed */
   const int32_t *ref_cu[16];      /* per reference picture and 4x4 (stride ref_cu_stride): type, mv[2][2], mv_dir, the POC the L0 / L1 vector points to */
+  /* cfg.owf != 0 (with cfg.wpp): pictures are coded while their reference pictures are still being coded, so no vector may reach beyond what is
+   * final there -- fracmv_within_tile, search_inter.c:94-149.  owf_margin: the samples the in-loop filters still change above the frontier
+   * (SAO_DELAY_PX 10 with cfg.sao_type, else DEBLOCK_DELAY_PX 8 with deblocking, else 0; global.h:240-252) */
+  int32_t owf, owf_margin;
 } orc_inter_frame;
 enum { NO_SPLIT = 0, QT_SPLIT = 1 };
 enum { MODE_TYPE_ALL = 0, MODE_TYPE_INTER = 1, MODE_TYPE_INTRA = 2 };

@@ -1031,7 +1031,29 @@ def plateau_picture(W, H, t, depth):
     return tuple(np.ascontiguousarray(((p.astype(np.int32) >> sh) << sh).astype(p.dtype)) for p in clip_picture(W, H, t, depth))
 
 
-CLIP_GENERATORS = {0: None, 1: "clip_picture", 2: "plateau_picture"}          # the `clip` key of a ref_inter_* golden
+_RISING_BASE = {}
+
+
+def rising_picture(W, H, t, depth):
+    """Picture t (0..12) of a sequence whose content moves UP faster and faster, 6 t samples per picture (the window runs down a tall base):
+    the search follows it through its predictors, and its candidates come to reach more than a CTU row below the block -- where an encoder with
+    frames in flight (cfg.owf) may not look (search_inter.c:94-149): the content on which --owf 0 and --owf 1 write different streams."""
+    key = (W, H, depth)
+    pos = lambda k: 3 * k * (k + 1)
+    if key not in _RISING_BASE:
+        _RISING_BASE.clear()
+        _RISING_BASE[key] = varied_picture(4 * (W + 32), 4 * (H + 32) + 4 * pos(12) + 64, 2011, depth)
+    base = _RISING_BASE[key]
+    out = []
+    for b, c in zip(base, (0, 1, 1)):
+        w, h = W >> c, H >> c
+        sx, sy = 40 >> c, (40 + 4 * pos(t)) >> c
+        a = b[sy:sy + 4 * h, sx:sx + 4 * w].astype(np.int32)
+        out.append(((a.reshape(h, 4, w, 4).sum(axis=(1, 3)) + 8) >> 4).astype(b.dtype))
+    return tuple(out)
+
+
+CLIP_GENERATORS = {0: None, 1: "clip_picture", 2: "plateau_picture", 3: "rising_picture"}          # the `clip` key of a ref_inter_* golden
 
 
 # ---- P / B pictures: the inter search of the oracle (oracle/orc_search.c + orc_search_inter.inc) ---------------------------------
@@ -1042,7 +1064,8 @@ class InterFrame(ctypes.Structure):
                 ("tmvp", ctypes.c_int32), ("max_merge", ctypes.c_int32), ("merge_level", ctypes.c_int32), ("bipred", ctypes.c_int32),
                 ("fme_level", ctypes.c_int32), ("early_skip", ctypes.c_int32), ("depth_inter_min", ctypes.c_int32), ("depth_inter_max", ctypes.c_int32),
                 ("ref_cu_stride", ctypes.c_int32), ("frame_qp", ctypes.c_int32),
-                ("ref_y", ctypes.c_void_p * 16), ("ref_u", ctypes.c_void_p * 16), ("ref_v", ctypes.c_void_p * 16), ("ref_cu", ctypes.c_void_p * 16)]
+                ("ref_y", ctypes.c_void_p * 16), ("ref_u", ctypes.c_void_p * 16), ("ref_v", ctypes.c_void_p * 16), ("ref_cu", ctypes.c_void_p * 16),
+                ("owf", ctypes.c_int32), ("owf_margin", ctypes.c_int32)]          # (frames in flight: vectors restricted to what is final in the reference, oracle only)
 
 
 MODELS_INTER_BYTES = 18 * 5
@@ -1101,6 +1124,7 @@ def iter_inter_frames(W, H, P):
         lam = d["lam"]
         cfg = [int(a) for a in d.get("cfg", (1, 6, 2, 1, 4, 1))]
         rd = cfg[6] if len(cfg) > 6 else 0          # cfg.rdo of the run (0: --preset medium, 1: --preset slow)
+        owf = cfg[7] if len(cfg) > 7 else 0         # cfg.owf != 0: vectors restricted to what is final in the reference picture (oracle only so far)
         prm = SearchParams(W, H, int(d["meta"][3]), int(d["meta"][3]), 1, 4, 1, 1, 2, rd, float(lam[0]), float(lam[1]), float(lam[2]), float(lam[3]), float(lam[4]))
         F = InterFrame()
         F.slice_type, F.poc, F.n_refs = slice_type, poc, n_refs
@@ -1109,6 +1133,7 @@ def iter_inter_frames(W, H, P):
             F.l[0][i], F.l[1][i] = lists[0][i], lists[1][i]
         F.l_size[0], F.l_size[1] = lsz
         F.tmvp, F.max_merge, F.merge_level, F.bipred, F.fme_level, F.early_skip = cfg[:6]
+        F.owf, F.owf_margin = int(owf != 0), 10       # (SAO_DELAY_PX: the goldens' runs have SAO on)
         F.depth_inter_min, F.depth_inter_max = 0, 3
         F.ref_cu_stride, F.frame_qp = wc * 16, int(d["meta"][7])
         keep = []
@@ -1248,6 +1273,7 @@ def run_inter_oracle(orc, W, H, depth, pics, P, ctx_trace=False):
         lam = d["lam"]
         cfg = [int(a) for a in d.get("cfg", (1, 6, 2, 1, 4, 1))]
         rd = cfg[6] if len(cfg) > 6 else 0          # cfg.rdo of the run (0: --preset medium, 1: --preset slow)
+        owf = cfg[7] if len(cfg) > 7 else 0         # cfg.owf != 0: vectors restricted to what is final in the reference picture (oracle only so far)
         prm = SearchParams(W, H, int(d["meta"][3]), int(d["meta"][3]), 1, 4, 1, 1, 2, rd, float(lam[0]), float(lam[1]), float(lam[2]), float(lam[3]), float(lam[4]))
         F = InterFrame()
         F.slice_type, F.poc, F.n_refs = slice_type, poc, n_refs
@@ -1256,6 +1282,7 @@ def run_inter_oracle(orc, W, H, depth, pics, P, ctx_trace=False):
             F.l[0][i], F.l[1][i] = lists[0][i], lists[1][i]
         F.l_size[0], F.l_size[1] = lsz
         F.tmvp, F.max_merge, F.merge_level, F.bipred, F.fme_level, F.early_skip = cfg[:6]
+        F.owf, F.owf_margin = int(owf != 0), 10       # (SAO_DELAY_PX: the goldens' runs have SAO on)
         F.depth_inter_min, F.depth_inter_max = 0, 3
         F.ref_cu_stride, F.frame_qp = wc * 16, int(d["meta"][7])
         keep = []

@@ -39,3 +39,29 @@ def test_every_picture_of_a_low_delay_encode(name):
     assert seen["calls"] > 100 and seen["amvp"] and (seen["bi"] or variant), seen
     if depth == 8 and not variant:
         assert seen["merge"] and seen["skip"], seen
+
+
+def test_frames_in_flight_restrict_the_vectors():
+    """cfg.owf != 0: pictures are coded while their reference pictures are still in the making, and no candidate vector may reach beyond what
+    is final there (fracmv_within_tile, search_inter.c:94-149: one CTU row below, two CTUs down-right, a margin for the interpolation and the
+    in-loop filters).  tests/golden/ref_inter_136x200_8_qp27_11frames_owf1 is an `--owf 1` run on content that rises ever faster
+    (helpers.rising_picture), where that changes the stream; the oracle with the restriction reproduces every call and every CTU, and
+    without it does not."""
+    name = "ref_inter_136x200_8_qp27_11frames_owf1"
+    orc = H.load_oracle()
+    g = H.ctu_golden(name)
+    assert int(g["cfg"][7]) == 1
+    W, Hh, depth, pics, P = H.inter_pictures_from_golden(g)
+    calls = 0
+    for fr, d, r, buf, ntr in H.run_inter_oracle(orc, W, Hh, depth, pics, P):
+        msgs = H.compare_inter_picture(W, Hh, d, r, buf, ntr)
+        assert not msgs, (name, fr, msgs)
+        calls += ntr
+    assert calls > 500
+    # the same records against the unrestricted search (the --owf 0 of every other golden): somewhere a decision differs
+    for d in P.values():
+        d["cfg"] = np.concatenate([np.asarray(d["cfg"][:7]), [0]])
+    differs = False
+    for fr, d, r, buf, ntr in H.run_inter_oracle(orc, W, Hh, depth, pics, P):
+        differs = differs or bool(H.compare_inter_picture(W, Hh, d, r, buf, ntr))
+    assert differs, "the golden does not exercise the restriction"

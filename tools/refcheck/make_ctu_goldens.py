@@ -347,7 +347,7 @@ def inter(W, H, depth, qp, frames, extra=(), suffix="", with_levels=True, out_di
                         sao_models=sao_models, row_bytes=row_bytes, row_off=row_off, bitstream=np.frombuffer(open(out + ".266", "rb").read(), np.uint8),
                         # the tools the run had on, for the tests' frame state: tmvp, max_merge, merge_level, bipred, fme_level, early_skip
                         cfg=np.array([int(opt.get("tmvp", 1)), int(opt.get("max-merge", 6)), 2, int(opt.get("bipred", 1)), {0: 0, 1: 1, 2: 2, 3: 3, 4: 4}[int(opt.get("subme", 4))],
-                                      int(opt.get("early-skip", 1)), int(opt.get("rd", 0))], np.int32))
+                                      int(opt.get("early-skip", 1)), int(opt.get("rd", 0)), int(opt.get("owf", 0))], np.int32))
     if not out_dir: print("wrote inter", tag, n, "CTU records")
     return tag
 
@@ -506,5 +506,6 @@ if __name__ == "__main__":
     inter(136, 72, 8, 27, 17, extra=("gop", "16"), suffix="_ra16", clip=True)      # random access, --preset medium's own GOP: coding order 0 16 8 4 2 1 3 6 5 7 12 ..., future references, five temporal layers
     inter(136, 72, 10, 22, 17, extra=("gop", "16"), suffix="_ra16", clip=True)     # ... at 10 bit, QP 22
     inter(136, 72, 8, 27, 9, extra=("gop", "8"), suffix="_ra8", clip=True)         # the 8-picture random-access GOP (what the presets up to "faster" run with): five POC bits
+    inter(136, 200, 8, 27, 11, extra=("owf", "1"), suffix="_owf1", clip=3)             # frames in flight: the vectors restricted to what is final in the reference picture; content that rises ever faster
     inter(136, 72, 8, 27, 5, extra=("rd", "1"), suffix="_rd1", clip=2)                 # --preset slow = medium + rd 1 (a P / B CU never skips its intra search on a low inter cost); plateau content
     inter(136, 72, 8, 27, 33, extra=("gop", "16", "period", "16"), suffix="_ra16p16", clip=True)      # three intra periods of an open GOP: CRA pictures at POC 16 and 32, RASL pictures behind them
