@@ -1238,7 +1238,12 @@ typedef struct uvghip_ctu_pb_picture {
   int32_t frame_qp;                /* state->frame->QP: the slice's context models are initialised with it */
   int32_t bipred, fme_level, early_skip;     /* cfg.bipred, cfg.fme_level, cfg.early_skip */
   int32_t depth_inter_min, depth_inter_max;  /* cfg.pu_depth_inter: 0, 3 */
-  int32_t ref_stride, ref_stride_c, ref_motion_stride, reserved;
+  int32_t ref_stride, ref_stride_c, ref_motion_stride;
+  int32_t inflight_margin;         /* 0: cfg.owf == 0, every vector inside the reference picture is legal (the pictures of a call and their references
+                                    * are complete).  Else 1 + the in-loop filters' delay in samples (11 = 1 + SAO_DELAY_PX with cfg.sao_type, 9 with
+                                    * deblocking only, 1 without filters; global.h:240-252): the search of an encoder with frames in flight, whose
+                                    * vectors may not reach beyond what is final in a reference picture still being coded -- one CTU row below the
+                                    * block's own, two CTUs down-right (fracmv_within_tile, src/search_inter.c:94-149; encoder.c:244-245) */
   const void *ref_y[16], *ref_u[16], *ref_v[16];
   const int32_t *ref_motion[16];
   uvghip_inter4_t *inter4;

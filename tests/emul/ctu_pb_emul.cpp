@@ -12,6 +12,7 @@ struct emul_frame {
   int32_t tmvp, max_merge, merge_level, bipred, fme_level, early_skip, depth_inter_min, depth_inter_max, ref_cu_stride, frame_qp;
   const void *ref_y[16], *ref_u[16], *ref_v[16];
   const int32_t *ref_cu[16];
+  int32_t owf, owf_margin;          // frames in flight: the vectors restricted to what is final in the reference picture
 };
 
 template <typename PX>
@@ -30,6 +31,7 @@ static int run_picture(const ctu::params &P, const emul_frame &F, const PX *sy, 
   B.bipred = F.bipred; B.fme_level = F.fme_level; B.early_skip = F.early_skip; B.depth_inter_min = F.depth_inter_min; B.depth_inter_max = F.depth_inter_max;
   for (int i = 0; i < 16; ++i) { B.ref_y[i] = F.ref_y[i]; B.ref_u[i] = F.ref_u[i]; B.ref_v[i] = F.ref_v[i]; B.ref_cu[i] = F.ref_cu[i]; }
   B.ref_stride = W; B.ref_stride_c = W / 2; B.ref_cu_stride = F.ref_cu_stride;
+  B.inflight_margin = F.owf ? 1 + F.owf_margin : 0;
   B.inter4 = inter4; B.trees = trees; B.motion_out = motion_out; B.hmvp_rows = hmvp_rows;
   for (int cy = 0; cy < hc; ++cy)
     for (int cx = 0; cx < wc; ++cx) {

@@ -60,6 +60,7 @@ struct pb_job {
   uint32_t *trees;                     // OUT, optional: split_tree | mode_type_tree << 16 per 4x4
   int32_t *motion_out;                 // OUT, optional: this picture in the ref_cu layout (what later pictures read)
   int32_t *hmvp_rows;                  // [CTU row][41]: the coder's history table, carried from CTU to CTU of the row
+  int32_t inflight_margin;             // 0: cfg.owf == 0; else 1 + the in-loop filters' delay in samples: frames in flight (mv_within)
 };
 
 struct pb_tab { icand::unit *p; __device__ icand::unit &at(int i) { return p[i]; } };
@@ -361,6 +362,20 @@ CTU_DEV double calc_mvd_cost(double lambda_sqrt, int x, int y, int mv_shift, con
   return mvd_cost * lambda_sqrt;
 }
 
+// fracmv_within_tile (search_inter.c:94-149) with cfg.wpp on and no mv constraint: with frames in flight (cfg.owf) the block a vector (1/16
+// samples) refers to -- a margin for the interpolation taps and the in-loop filters' delay included -- may lie at most max_inter_ref_lcu.down = 1
+// CTU rows below the block's own CTU and, rows and columns together, 2 CTUs down-right (encoder.c:244-245): the reference picture is still
+// being coded below that.
+CTU_DEV bool mv_within(const pb_job &B, int x, int y, int n, int mvx, int mvy)
+{
+  if (!B.inflight_margin) return true;
+  const bool frac_luma = (mvx & 15) != 0 || (mvy & 15) != 0, frac_chroma = (mvx & 31) != 0 || (mvy & 31) != 0;
+  const int margin = 2 + (frac_luma ? 4 : (frac_chroma ? 2 : 0)) + B.inflight_margin - 1;
+  const int lx = ((x + n + margin) * 16 + mvx) / (64 << 4) - x / 64;
+  const int ly = ((y + n + margin) * 16 + mvy) / (64 << 4) - y / 64;
+  return ly <= 1 && lx + ly <= 2;
+}
+
 // ---- the integer and fractional motion search of one reference picture (wave-uniform) ----
 struct me_best { double cost, bits; int mx, my; };        // vector in 1/16 units
 template <typename PX> struct me_info {
@@ -370,6 +385,7 @@ template <typename PX> struct me_info {
 };
 template <typename PX> CTU_DEV int check_mv_cost(const me_info<PX> &I, int dx, int dy, me_best &b)
 {
+  if (!mv_within(*I.J->pb, I.x, I.y, I.n, dx * 16, dy * 16)) return 0;
   double bitcost = 0;
   double cost = (double)sad_at(*I.J, I.ref_pic, I.x, I.y, I.n, dx, dy);
   if (cost >= b.cost) return 0;
@@ -462,8 +478,11 @@ template <typename PX> CTU_NOINLINE CTU_DEV void me_frac(lds<PX> *S, const me_in
   int i = 1;
   for (int step = 0; step < fme_level; ++step) {
     const int mv_shift = step < 2 ? 3 : 2;
+    bool within[4];
     for (int j = 0; j < 4; ++j) {
       const int fxp = (mx + sqx[i + j]) * (1 << mv_shift), fyp = (my + sqy[i + j]) * (1 << mv_shift);
+      within[j] = mv_within(B, I.x, I.y, n, fxp, fyp);
+      if (!within[j]) continue;          // (the reference measures the candidate and then ignores it, search_inter.c:1160-1194)
       for (int qy = 0; qy < nq; ++qy)
         for (int qx = 0; qx < nq; ++qx)
           ipol_block<PX>((const PX *)B.ref_y[I.ref_pic], B.ref_stride, W, H, I.x + qx * q + (fxp >> 4), I.y + qy * q + (fyp >> 4), q, q, fxp & 15, fyp & 15, 0, 0,
@@ -472,7 +491,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void me_frac(lds<PX> *S, const me_in
       costs[j] += (uint32_t)calc_mvd_cost(J.P.lambda_sqrt, mx + sqx[i + j], my + sqy[i + j], mv_shift, I.cand, &bitcosts[j]);
     }
     for (int j = 0; j < 4; ++j)
-      if (costs[j] < cost) { cost = costs[j]; bitcost = bitcosts[j]; best_index = (unsigned)(i + j); }
+      if (within[j] && costs[j] < cost) { cost = costs[j]; bitcost = bitcosts[j]; best_index = (unsigned)(i + j); }
     i += 4;
     if (step == 1 || step == fme_level - 1) {
       mx += sqx[best_index]; my += sqy[best_index];
@@ -732,7 +751,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
     if (dir == 3 && !(n + n > 12)) continue;
     bool dup = false;
     for (int i = 0; i < Q.merge_size && !dup; ++i) dup = same_merge(Q.mc[merge_idx], Q.mc[Q.merge[Q.merge_keys[i]].merge_idx]);
-    if (dup) continue;
+    // (candidates whose vectors reach beyond what is final in the reference picture are not tried, search_inter.c:1749-1757)
+    if (((dir & 1) && !mv_within(B, x, y, n, Q.cur.m.mv[0][0], Q.cur.m.mv[0][1])) || ((dir & 2) && !mv_within(B, x, y, n, Q.cur.m.mv[1][0], Q.cur.m.mv[1][1])) || dup) continue;
     unsigned satd;
     if (batch8) satd = (unsigned)S->wv[3].rq_i[merge_idx];
     else {
@@ -818,7 +838,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
           const int nb_idx = B.l[ref_list][LX_idx & 15];
           apply_mv_scaling(B.poc, B.ref_pocs[B.l[ref_list][LX_idx & 15]], B.ref_pocs[nb_idx], rc[6 + col_list], &px, &py);
         }
-        b.mx = px; b.my = py;
+        if (mv_within(B, x, y, n, px, py)) { b.mx = px; b.my = py; }
       }
     }
     { PB_T0();
@@ -836,7 +856,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
     for (; ref_list < 2 && active[ref_list]; ++ref_list) {
       LX_idx = idx[ref_list];
       const int cu_mv_cand = select_mv_cand(I.cand, b.mx, b.my, nullptr);
-      if (b.cost < CTU_MAX_DOUBLE) {
+      if (mv_within(B, x, y, n, b.mx, b.my) && b.cost < CTU_MAX_DOUBLE) {
         SERIAL {
           const int e = Q.amvp_size[ref_list];
           pb_cand &u = Q.amvp[ref_list][e];
@@ -893,7 +913,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
         const int extra_bits = list + LX_idx;
         b.cost += extra_bits * P.lambda_sqrt;
         b.bits += extra_bits;
-        SERIAL {
+        if (mv_within(B, x, y, n, b.mx, b.my)) SERIAL {
           pb_cand &u = Q.amvp[list][key];
           u.m.mv[list][0] = b.mx; u.m.mv[list][1] = b.my;
           if (list == 0) u.cand0 = (uint8_t)cu_mv_cand; else u.cand1 = (uint8_t)cu_mv_cand;

@@ -229,6 +229,8 @@ extern "C" int uvghip_ctu_search_pb(int bitdepth, const uvghip_ctu_pb_picture_t 
     B.tmvp = q.tmvp; B.max_merge = q.max_merge; B.merge_level = q.merge_level; B.frame_qp = q.frame_qp;
     B.bipred = q.bipred; B.fme_level = q.fme_level; B.early_skip = q.early_skip; B.depth_inter_min = q.depth_inter_min; B.depth_inter_max = q.depth_inter_max;
     B.ref_stride = q.ref_stride; B.ref_stride_c = q.ref_stride_c; B.ref_cu_stride = q.ref_motion_stride;
+    if (q.inflight_margin < 0 || q.inflight_margin > 64) return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_pb: inflight_margin");
+    B.inflight_margin = q.inflight_margin;
     B.inter4 = q.inter4; B.trees = q.trees; B.motion_out = q.motion_out;
     B.hmvp_rows = reinterpret_cast<int32_t *>(ws + L.hmvp) + (size_t)i * hc * 41;
     d.src_y = c.src_y; d.src_u = c.src_u; d.src_v = c.src_v; d.rec_y = c.rec_y; d.rec_u = c.rec_u; d.rec_v = c.rec_v;

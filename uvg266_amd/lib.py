@@ -86,7 +86,7 @@ class CtuPbPicture(ctypes.Structure):
                 ("ref_pocs", ctypes.c_int32 * 16), ("l_size", ctypes.c_int32 * 2), ("l", (ctypes.c_int32 * 16) * 2), ("tmvp", ctypes.c_int32),
                 ("max_merge", ctypes.c_int32), ("merge_level", ctypes.c_int32), ("frame_qp", ctypes.c_int32), ("bipred", ctypes.c_int32),
                 ("fme_level", ctypes.c_int32), ("early_skip", ctypes.c_int32), ("depth_inter_min", ctypes.c_int32), ("depth_inter_max", ctypes.c_int32),
-                ("ref_stride", ctypes.c_int32), ("ref_stride_c", ctypes.c_int32), ("ref_motion_stride", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("ref_stride", ctypes.c_int32), ("ref_stride_c", ctypes.c_int32), ("ref_motion_stride", ctypes.c_int32), ("inflight_margin", ctypes.c_int32),
                 ("ref_y", ctypes.c_void_p * 16), ("ref_u", ctypes.c_void_p * 16), ("ref_v", ctypes.c_void_p * 16), ("ref_motion", ctypes.c_void_p * 16),
                 ("inter4", ctypes.c_void_p), ("models_inter", ctypes.c_void_p), ("trees", ctypes.c_void_p), ("motion_out", ctypes.c_void_p)]
 
