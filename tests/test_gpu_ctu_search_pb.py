@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 GOLDENS = ["ref_inter_136x72_10_qp22_4frames", "ref_inter_192x128_8_qp17_5frames", "ref_inter_264x136_8_qp32_9frames",
            # other tools than --preset medium's: P slices (no bi-prediction) without the temporal candidate; no fractional search, no early skip
            "ref_inter_136x72_8_qp27_4frames_p_notmvp", "ref_inter_192x128_10_qp24_4frames_subme0_noskip",
-           "ref_inter_136x72_8_qp27_17frames_ra16", "ref_inter_136x72_10_qp22_17frames_ra16", "ref_inter_136x72_8_qp27_9frames_ra8", "ref_inter_136x72_8_qp27_5frames_rd1", "ref_inter_136x72_8_qp27_33frames_ra16p16"]
+           "ref_inter_136x72_8_qp27_17frames_ra16", "ref_inter_136x72_10_qp22_17frames_ra16", "ref_inter_136x72_8_qp27_9frames_ra8", "ref_inter_136x200_8_qp27_11frames_owf1", "ref_inter_136x72_8_qp27_5frames_rd1", "ref_inter_136x72_8_qp27_33frames_ra16p16"]
 
 
 def device_pictures(W, Hh, depth, pics, P, repeat=1):
@@ -56,6 +56,7 @@ def device_pictures(W, Hh, depth, pics, P, repeat=1):
                 q.ref_pocs[i], q.l[0][i], q.l[1][i] = F.ref_pocs[i], F.l[0][i], F.l[1][i]
             q.l_size[0], q.l_size[1] = F.l_size[0], F.l_size[1]
             q.ref_stride, q.ref_stride_c, q.ref_motion_stride = W, W // 2, wc * 16
+            q.inflight_margin = 1 + F.owf_margin if F.owf else 0          # (a golden of an --owf run: the vectors restricted as the encoder's were)
             for i in range(F.n_refs):
                 planes = [ref_dev((F.ref_pocs[i], k), keep[4 * i + k]) for k in range(3)]
                 rm = ref_dev((F.ref_pocs[i], 3), keep[4 * i + 3])
