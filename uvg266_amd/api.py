@@ -1034,8 +1034,10 @@ class LowDelayLoop:
     CODING order there, and run(in_flight=k) issues every picture as soon as the pictures it references are done -- pictures of the same
     temporal layer, and of neighbouring GOPs, run side by side on k streams (deps[f]: the coded pictures f reads)."""
 
-    def __init__(self, W, H, depth, n_seq, frames, src, sao_type=3, tmvp=1, max_merge=6, merge_level=2, bipred=1, fme_level=4, early_skip=1, by_level=False, rd=0):
-        """rd: cfg.rdo, 0 (--preset medium) or 1 (--preset slow: a P / B CU never skips its intra search on a low inter cost).
+    def __init__(self, W, H, depth, n_seq, frames, src, sao_type=3, tmvp=1, max_merge=6, merge_level=2, bipred=1, fme_level=4, early_skip=1, by_level=False, rd=0, inflight_margin=0):
+        """inflight_margin: uvghip_ctu_pb_picture_t.inflight_margin (0: every vector inside a reference picture is legal; 11: the search of an
+        encoder with frames in flight and SAO on, cfg.owf != 0).
+        rd: cfg.rdo, 0 (--preset medium) or 1 (--preset slow: a P / B CU never skips its intra search on a low inter cost).
         by_level: the P / B pictures that sit at the same depth of the reference DAG (deps) go through ONE uvghip_loop_pb_run together --
         the pictures of one temporal layer of a random-access GOP, and of neighbouring GOPs, share a launch (their wavefronts interleave in the
         search kernel); a low-delay sequence has one picture per level and is unchanged."""
@@ -1077,6 +1079,7 @@ class LowDelayLoop:
                         p.ref_pocs[i], p.l[0][i], p.l[1][i] = fs["ref_pocs"][i], fs["lists"][0][i], fs["lists"][1][i]
                     p.l_size[0], p.l_size[1] = fs["l_size"]
                     p.ref_stride, p.ref_stride_c, p.ref_motion_stride = W, W // 2, wc * 16
+                    p.inflight_margin = inflight_margin
                     for i in range(fs["n_refs"]):
                         planes, rm = by_poc[(s, fs["ref_pocs"][i])]
                         p.ref_y[i], p.ref_u[i], p.ref_v[i], p.ref_motion[i] = _dev(planes[0]), _dev(planes[1]), _dev(planes[2]), _dev(rm)
