@@ -31,6 +31,39 @@ def one(case):
             if msgs:
                 return case, f"picture {fr}: {msgs[:2]}"
             calls += ntr
+        # the whole .266 from the rows' bytes and the library's host NAL writers (tests/test_picture_nal.py's whole-file test)
+        import ctypes
+        from uvg266_amd import lib
+        L = lib.load_library()
+        qp0, hc = int(g["dims"][3]), (H2 + 63) // 64
+        first = {}
+        for k in range(len(g["meta"])):
+            first.setdefault(int(g["meta"][k][0]), k)
+        stream, mine, irap_poc = g["bitstream"].tobytes(), b"", 0
+        for f in range(int(g["dims"][4])):
+            k = first[f]
+            off = g["row_off"][f * hc:f * hc + hc + 1]
+            sizes = np.diff(off).astype(np.int32)
+            rows = np.zeros((hc, int(sizes.max())), np.uint8)
+            for r in range(hc):
+                rows[r, :sizes[r]] = g["row_bytes"][off[r]:off[r + 1]]
+            sums = np.ascontiguousarray([H.picture_checksum(g[nme][f], d2) for nme in ("final_y", "final_u", "final_v")], np.uint32)
+            slice_type, frame_qp, poc = int(g["meta"][k][6]), int(g["meta"][k][7]), int(g["refs"][k][51])
+            cap = int(sizes.sum()) + 128 + 4 * hc
+            out, n = np.zeros(cap, np.uint8), ctypes.c_size_t(0)
+            n_refs, cfg = int(g["refs"][k][0]), g["cfg"]
+            if slice_type == 2 and poc == 0:
+                rc = L.uvghip_write_idr_nals_ra(poc, H.poc_lsb_bits(g), frame_qp - qp0, 1, H.ptr(rows), rows.shape[1], H.ptr(sizes), hc, H.ptr(sums), H.ptr(out), cap, ctypes.byref(n))
+            else:
+                rc = H.write_inter_nals(L, g, poc, slice_type, [int(p) for p in g["refs"][k][1:1 + n_refs]], int(cfg[3]), int(cfg[0]), frame_qp - qp0, rows, sizes, sums, out, n, irap_poc=irap_poc)
+            if slice_type == 2:
+                irap_poc = poc
+            if rc != 0:
+                return case, f"NAL writer refused picture {f} (poc {poc})"
+            mine += out[:n.value].tobytes()
+        at = stream.find(b"\x00\x00\x01\x00\x41")
+        if at <= 0 or stream[:at] + mine != stream:
+            return case, "whole file: the parameter sets + the library's NAL units differ from the encoder's .266"
         if os.environ.get("SWEEP_EMUL"):          # ... and the P / B kernel's source on the host (tests/emul), against the same records
             for fr, d, prm, F, keep in H.iter_inter_frames(W2, H2, P):
                 if int(d["meta"][6]) == 2:
