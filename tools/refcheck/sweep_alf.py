@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Dev-time: N all-intra `--alf full` encodes of the real reference (sizes incl. partial CTUs, depths, QPs, kinds of content drawn from
 `seed`); for every picture the oracle's ALF reconstruction (oracle/orc_alf_picture.c) from the recorded decisions against the picture
-uvg_alf_enc_process left.  Nothing is written.   python tools/refcheck/sweep_alf.py N seed"""
+uvg_alf_enc_process left, and the oracle's frame statistics against the covariances the encoder gathered.  Nothing is written.   python tools/refcheck/sweep_alf.py N seed"""
 import ctypes, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,6 +42,26 @@ if __name__ == "__main__":
                 continue
             if rc != 0 or any(not np.array_equal(o, r[4 + c]) for c, o in enumerate(res)):
                 ok = False
+            # the frame statistics alf_derive_stats_for_filtering gathered (record arrays 14, 15: per luma class / chroma plane, summed over the
+            # CTUs) against the oracle's get_blk_stats on the picture ALF got and the source, summed the same way
+            if int(r[0][29]):
+                t = int(r[0][0])
+                src = H.varied_picture(W, Hh, kind * 1000 + t0 + t, depth)
+                pre2 = [p.reshape(Hh >> (c > 0), W >> (c > 0)) for c, p in enumerate(pre)]
+                cls = orc.alf_classify_frame(depth, pre2[0], W, Hh, int(r[0][28]) + 4)
+                luma, chroma = np.zeros((25, 1509), np.int64), np.zeros((2, 1509), np.int64)
+                for y in range(0, Hh, 64):
+                    for x in range(0, W, 64):
+                        w, h = min(64, W - x), min(64, Hh - y)
+                        e, yv, pa = orc.alf_stats_rect(depth, np.ascontiguousarray(src[0]), pre2[0], W, Hh, x, y, w, h, False, cls)
+                        luma += H.alf_sum_layout(e, yv, pa, 13)
+                        for c in (1, 2):
+                            e, yv, pa = orc.alf_stats_rect(depth, np.ascontiguousarray(src[c]), pre2[c], W // 2, Hh // 2, x // 2, y // 2, w // 2, h // 2, True, None)
+                            chroma[c - 1] += H.alf_sum_layout(e, yv, pa, 7)[0]
+                tot["stats"] = tot.get("stats", 0) + 1
+                if not np.array_equal(luma, r[14].reshape(25, 1509)) or not np.array_equal(chroma, r[15].reshape(2, 1509)):
+                    ok = False
+                    print("  frame statistics differ, picture", t)
         print((W, Hh, depth, qp, frames, t0, kind), "OK" if ok else "MISMATCH", flush=True)
         bad += not ok
     print(f"{n} encodes, {bad} with a mismatch;", tot)
