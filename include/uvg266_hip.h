@@ -1260,6 +1260,31 @@ typedef struct uvghip_ctu_pb_picture {
 UVGHIP_API size_t uvghip_ctu_search_pb_workspace_bytes(int n_pictures, int pic_w, int pic_h);
 UVGHIP_API int uvghip_ctu_search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictures, void *workspace, void *stream);
 
+/* Pictures IN FLIGHT behind their references -- the encoder's --owf schedule (src/encoderstate.c:1060-1116: with cfg.owf != 0 the search
+ * of CTU (x, y) of a picture waits for CTU (x + 2, y + 1) of its reference, clamped to the picture; encoder.c:244-245 max_inter_ref_lcu =
+ * {1, 1}; its vectors stay inside what is final there, fracmv_within_tile src/search_inter.c:94-149 = inflight_margin).  The pictures of
+ * ONE call may refer to each other: they are given in coding order, ref_in_call[i * 16 + k] = the index (< i) of the picture of this call
+ * whose OUTPUT picture reference k of picture i is (its filters[].out_* planes and pictures[].motion_out), or -1 for a reference that is
+ * complete before the call.  Every CTU runs its in-loop filters right behind its search inside the persistent kernel (what
+ * encoder_state_worker_encode_lcu_search does after uvg_search_lcu, encoderstate.c:841-853): deblocking, uvg_sao_search_lcu's statistics
+ * and decision, encoder_sao_reconstruct -- so the output picture becomes final CTU by CTU, and a per-CTU flag releases the CTUs of the
+ * pictures behind.  pic.rec_* stay the UNFILTERED reconstruction (uvghip_loop_pb_run deblocks them in place); filters[i].dbk_* receive
+ * the deblocked picture, out_* the picture uvg_encoder_encode returns (after SAO; sao_type 0: the deblocked picture), sao_info
+ * [ctu][34] / sao_models [ctu][6] the decisions in uvghip_sao_decide_pictures_slice's layout.  Requirements beyond uvghip_ctu_search_pb:
+ * params.qp == params.qp_c == frame_qp; a picture with a reference inside the call has inflight_margin = 11 (sao_type != 0) or 9.
+ * Everything is enqueued on `stream` in stream order; nothing waits for the device. */
+typedef struct uvghip_pb_filter {
+  void *dbk_y, *dbk_u, *dbk_v;          /* DEVICE, pic_w x pic_h (+ chroma) */
+  void *out_y, *out_u, *out_v;
+  int32_t dbk_stride, dbk_stride_c, out_stride, out_stride_c;     /* in samples */
+  int32_t *sao_info;
+  uint16_t *sao_models;
+  int32_t sao_type, reserved;           /* cfg.sao_type: 0 off, 1 edge, 2 band, 3 both */
+} uvghip_pb_filter_t;
+UVGHIP_API size_t uvghip_ctu_search_pb_inflight_workspace_bytes(int n_pictures, int pic_w, int pic_h);
+UVGHIP_API int uvghip_ctu_search_pb_inflight(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, const uvghip_pb_filter_t *filters, const int32_t *ref_in_call,
+                                             int n_pictures, void *workspace, void *stream);
+
 /* replaces, for a group of independent P / B pictures: the whole per-picture loop of the CTU worker (src/encoderstate.c:808-976) --
  * uvghip_ctu_search_pb, then per picture uvghip_deblock_frame_sao_snapshot on a copy of the reconstruction + uvghip_sao_stats_batch,
  * uvghip_sao_decide_pictures_slice (the picture's QP, lambda and slice type), uvghip_deblock_frame in place on rec (boundary strengths
@@ -1277,6 +1302,16 @@ UVGHIP_API size_t uvghip_loop_pb_workspace_bytes(int bitdepth, int n_pictures, i
 UVGHIP_API int uvghip_loop_pb_run(int bitdepth, const uvghip_loop_pb_picture_t *pictures, int n_pictures, int sao_type, void *workspace, void *stream);
 UVGHIP_API int uvghip_loop_pb_results(int bitdepth, int n_pictures, int pic_w, int pic_h, void *workspace, const int32_t **sao_info,
                                       const uint16_t **sao_models, const uint8_t **rows, const int32_t **row_bytes, int *row_cap, int *n_rows);
+
+/* uvghip_loop_pb_run for pictures IN FLIGHT behind their references (uvghip_ctu_search_pb_inflight above: pictures in coding order,
+ * ref_in_call[i * 16 + k]): one persistent launch for the search + the per-CTU in-loop filters of the whole reference DAG of the call,
+ * then one launch of the arithmetic coder over all its pictures.  pic.rec_* stay unfiltered; the deblocked pictures live in the workspace.
+ * Results as uvghip_loop_pb_results.  Nothing waits for the stream. */
+UVGHIP_API size_t uvghip_loop_pb_inflight_workspace_bytes(int bitdepth, int n_pictures, int pic_w, int pic_h);
+UVGHIP_API int uvghip_loop_pb_run_inflight(int bitdepth, const uvghip_loop_pb_picture_t *pictures, int n_pictures, int sao_type, const int32_t *ref_in_call,
+                                           void *workspace, void *stream);
+UVGHIP_API int uvghip_loop_pb_inflight_results(int bitdepth, int n_pictures, int pic_w, int pic_h, void *workspace, const int32_t **sao_info,
+                                               const uint16_t **sao_models, const uint8_t **rows, const int32_t **row_bytes, int *row_cap, int *n_rows);
 
 #ifdef __cplusplus
 }

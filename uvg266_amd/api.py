@@ -1034,8 +1034,13 @@ class LowDelayLoop:
     CODING order there, and run(in_flight=k) issues every picture as soon as the pictures it references are done -- pictures of the same
     temporal layer, and of neighbouring GOPs, run side by side on k streams (deps[f]: the coded pictures f reads)."""
 
-    def __init__(self, W, H, depth, n_seq, frames, src, sao_type=3, tmvp=1, max_merge=6, merge_level=2, bipred=1, fme_level=4, early_skip=1, by_level=False, rd=0, inflight_margin=0):
-        """inflight_margin: uvghip_ctu_pb_picture_t.inflight_margin (0: every vector inside a reference picture is legal; 11: the search of an
+    def __init__(self, W, H, depth, n_seq, frames, src, sao_type=3, tmvp=1, max_merge=6, merge_level=2, bipred=1, fme_level=4, early_skip=1, by_level=False, rd=0, inflight_margin=0,
+                 inflight=False):
+        """inflight: the encoder's --owf schedule (encoderstate.c:1060-1116): ALL P / B pictures go through ONE uvghip_loop_pb_run_inflight -- a
+        picture's CTU (x, y) starts when CTU (x + 2, y + 1) of the pictures it reads is final, the in-loop filters run per CTU inside the
+        search kernel -- after the I pictures (which depend on nothing).  Needs inflight_margin = 11 (9 without SAO): the vector restriction
+        of an encoder run with --owf != 0, whose bitstream this then is.
+        inflight_margin: uvghip_ctu_pb_picture_t.inflight_margin (0: every vector inside a reference picture is legal; 11: the search of an
         encoder with frames in flight and SAO on, cfg.owf != 0).
         rd: cfg.rdo, 0 (--preset medium) or 1 (--preset slow: a P / B CU never skips its intra search on a low inter cost).
         by_level: the P / B pictures that sit at the same depth of the reference DAG (deps) go through ONE uvghip_loop_pb_run together --
@@ -1049,9 +1054,13 @@ class LowDelayLoop:
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device="cuda")
         self.out, self.mot, self.steps, self.keep = [], [], [], []
         self.deps, self.level = reference_dag(frames)
-        by_poc = {}
+        by_poc, coded_as = {}, {}
+        self.ref_frame = [[-1] * 16 for _ in frames]          # per coded picture and reference: the coded picture whose output it is
         for f, fs in enumerate(frames):
             srcs = [tuple(src[s][f]) for s in range(n_seq)]
+            if fs["slice_type"] != 2:
+                for i in range(fs["n_refs"]):
+                    self.ref_frame[f][i] = coded_as[fs["ref_pocs"][i]]
             if fs["slice_type"] == 2:
                 loop = ClosedLoop(ctu_params(W, H, fs["qp"], lam=fs["lam"]), srcs, sao_type=sao_type)
                 outs = loop.out
@@ -1088,10 +1097,11 @@ class LowDelayLoop:
                     q.out_stride, q.out_stride_c = W, W // 2
                     outs.append(t["out"]); mots.append(t["mot"]); bufs.append(t)
                 L = _lib.init(torch.cuda.current_device())
-                ws = z(L.uvghip_loop_pb_workspace_bytes(depth, n_seq, W, H), torch.uint8)
+                ws = None if inflight else z(L.uvghip_loop_pb_workspace_bytes(depth, n_seq, W, H), torch.uint8)
                 self.steps.append(("PB", arr, ws, bufs))
             for s in range(n_seq):
                 by_poc[(s, fs["poc"])] = (outs[s], mots[s])
+            coded_as[fs["poc"]] = f
             self.out.append(outs); self.mot.append(mots)
         self.L = _lib.init(torch.cuda.current_device())
         self.rows, self.row_bytes = [None] * len(frames), [None] * len(frames)
@@ -1114,6 +1124,25 @@ class LowDelayLoop:
             for f in range(len(frames)):          # (the per-frame workspaces are not needed)
                 if self.steps[f][0] == "PB" and not any(st is self.steps[f] for _, st in self.order):
                     self.steps[f] = ("PB", self.steps[f][1], None, self.steps[f][3])
+        if inflight:
+            pb = [f for f in range(len(frames)) if self.steps[f][0] == "PB"]
+            self.order = [([f], self.steps[f]) for f in range(len(frames)) if self.steps[f][0] == "I"]
+            if pb:
+                at = {f: j for j, f in enumerate(pb)}
+                n = n_seq * len(pb)
+                arr = (_lib.LoopPbPicture * n)()
+                ric = np.full((n, 16), -1, np.int32)
+                for j, f in enumerate(pb):
+                    ctypes.memmove(ctypes.addressof(arr) + j * n_seq * ctypes.sizeof(_lib.LoopPbPicture), ctypes.addressof(self.steps[f][1]), n_seq * ctypes.sizeof(_lib.LoopPbPicture))
+                    for i in range(frames[f]["n_refs"]):
+                        g = self.ref_frame[f][i]
+                        if g in at:
+                            for s_ in range(n_seq):
+                                ric[j * n_seq + s_, i] = at[g] * n_seq + s_
+                ws = z(self.L.uvghip_loop_pb_inflight_workspace_bytes(depth, n, W, H), torch.uint8)
+                self.order.append((pb, ("FLIGHT", arr, ws, np.ascontiguousarray(ric))))
+            for f in pb:          # (the per-frame workspaces are not needed)
+                self.steps[f] = ("PB", self.steps[f][1], None, self.steps[f][3])
 
     def run(self, stream=None, in_flight=1):
         """Enqueue every picture of every sequence (the P / B groups wait for the stream where the coder's tables are uploaded).
@@ -1145,12 +1174,17 @@ class LowDelayLoop:
                         mots[s][:, :, 6:8] = -1
                 self.rows[f], self.row_bytes[f] = loop.slice_data()
             else:
-                _, arr, ws, _ = step
+                kind, arr, ws, ric = step
                 n = self.n_seq * len(fr)
-                _lib.check(self.L.uvghip_loop_pb_run(self.depth, ctypes.byref(arr), n, self.sao_type, _dev(ws), st), "uvghip_loop_pb_run")
                 c, d, cap, nr = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
-                _lib.check(self.L.uvghip_loop_pb_results(self.depth, n, self.W, self.H, _dev(ws), None, None, ctypes.byref(c), ctypes.byref(d), ctypes.byref(cap),
-                                                         ctypes.byref(nr)), "uvghip_loop_pb_results")
+                if kind == "FLIGHT":
+                    _lib.check(self.L.uvghip_loop_pb_run_inflight(self.depth, ctypes.byref(arr), n, self.sao_type, ric.ctypes.data, _dev(ws), st), "uvghip_loop_pb_run_inflight")
+                    _lib.check(self.L.uvghip_loop_pb_inflight_results(self.depth, n, self.W, self.H, _dev(ws), None, None, ctypes.byref(c), ctypes.byref(d), ctypes.byref(cap),
+                                                                      ctypes.byref(nr)), "uvghip_loop_pb_inflight_results")
+                else:
+                    _lib.check(self.L.uvghip_loop_pb_run(self.depth, ctypes.byref(arr), n, self.sao_type, _dev(ws), st), "uvghip_loop_pb_run")
+                    _lib.check(self.L.uvghip_loop_pb_results(self.depth, n, self.W, self.H, _dev(ws), None, None, ctypes.byref(c), ctypes.byref(d), ctypes.byref(cap),
+                                                             ctypes.byref(nr)), "uvghip_loop_pb_results")
                 base = ws.data_ptr()
                 rows = ws[c.value - base:c.value - base + n * nr.value * cap.value].view(n, nr.value, cap.value)
                 row_bytes = ws[d.value - base:d.value - base + n * nr.value * 4].view(torch.int32).view(n, nr.value)

@@ -52,6 +52,28 @@ extern "C" int uvghip_init(int device)
   return 0;
 }
 
+// ---- a small host table into device memory in STREAM ORDER, through kernel arguments: hipMemcpy would have to drain the stream first (an
+// earlier call on the same workspace may still read the table), and a host with independent pictures to issue must not be held up ----
+namespace {
+struct up_chunk { unsigned char b[3072]; };
+__global__ void __launch_bounds__(256) upload_kernel(unsigned char *dst, up_chunk c, int n)
+{
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = c.b[i];
+}
+}  // namespace
+int uvghip_upload_ordered(void *dst, const void *host, size_t bytes, hipStream_t st)
+{
+  const unsigned char *src = static_cast<const unsigned char *>(host);
+  for (size_t at = 0; at < bytes; at += sizeof(up_chunk)) {
+    up_chunk c;
+    const int n = (int)(bytes - at < sizeof(up_chunk) ? bytes - at : sizeof(up_chunk));
+    memcpy(c.b, src + at, (size_t)n);
+    hipLaunchKernelGGL(upload_kernel, dim3(1), dim3(256), 0, st, static_cast<unsigned char *>(dst) + at, c, n);
+  }
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : uvghip_set_error(e, "uvghip_upload_ordered");
+}
+
 // ---- launch plans as hipGraphs: a picture's fixed kernel sequence is captured once and replayed with one call ----
 extern "C" int uvghip_graph_begin(void *stream)
 {

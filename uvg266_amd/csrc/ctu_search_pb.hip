@@ -8,6 +8,7 @@
 #define CTU_PB 1
 #include "uvghip_common.h"
 #include "ctu_pb.h"
+#include "ctu_filter.h"
 #include <vector>
 #include <cstring>
 #include <new>
@@ -23,6 +24,9 @@ struct pb_pic_dev {
   int16_t *coeff;
   uint32_t *models, *models_inter;
   int src_stride, src_stride_c, rec_stride, rec_stride_c, cu_stride, pad;
+  // pictures in flight (uvghip_ctu_search_pb_inflight): the pictures of this call whose output this one reads, its depth in that DAG
+  int n_wait, level;
+  int wait_pic[16];
 };
 
 struct pb_launch_args {
@@ -34,6 +38,9 @@ struct pb_launch_args {
   uint32_t *slots;
   int n_slots;
   int wc, hc, n_ctus;
+  // pictures in flight: the filter stage of every picture (NULL: search only, the pictures of the call are independent), its flags
+  const ctuf::filt_pic *fpics;
+  int32_t *sao_done, *final_done;   // [pic * ctus + cy * wc + cx]
 };
 
 // four workgroups (= four waves: the kernel's registers allow one per SIMD) per CU at 8 bit: 160 KB / 4 incl. the 4288 bytes of static tables
@@ -86,6 +93,13 @@ __global__ void __launch_bounds__(64) ctu_search_pb_kernel(pb_launch_args A)
           for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);
           if (naps < 8) naps <<= 1;
         }
+      // a picture in flight behind its references: CTU (x + 2, y + 1) of each of them is final (encoderstate.c:1103-1112 with
+      // max_inter_ref_lcu = {1, 1}, encoder.c:244-245) -- and with it everything up and left of that CTU's corner
+      if (A.fpics) {
+        const pb_pic_dev &Dw = A.pics[pic];
+        const int kd = (cy + 1 < A.hc ? cy + 1 : A.hc - 1) * A.wc + (cx + 2 < A.wc ? cx + 2 : A.wc - 1);
+        for (int r = 0; r < Dw.n_wait; ++r) ctuf::wait_set(A.final_done + (size_t)Dw.wait_pic[r] * ctus + kd);
+      }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -110,6 +124,17 @@ __global__ void __launch_bounds__(64) ctu_search_pb_kernel(pb_launch_args A)
     ctu::run_ctu_pb(S, J);
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&done[k], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (A.fpics) {
+      // the CTU's in-loop filters while its right and lower neighbours search on (ctu_filter.h); the LDS image is free until the next CTU
+      ctuf::filt_ctu F;
+      F.rec_y = D.rec_y; F.rec_u = D.rec_u; F.rec_v = D.rec_v; F.src_y = D.src_y; F.src_u = D.src_u; F.src_v = D.src_v;
+      F.rec_stride = D.rec_stride; F.rec_stride_c = D.rec_stride_c; F.src_stride = D.src_stride; F.src_stride_c = D.src_stride_c;
+      F.scu = D.cu; F.scu_stride = D.cu_stride;
+      F.W = D.P.pic_w; F.H = D.P.pic_h; F.cx = cx; F.cy = cy; F.wc = A.wc; F.hc = A.hc;
+      F.sao_done = A.sao_done + (size_t)pic * ctus; F.final_done = A.final_done + (size_t)pic * ctus;
+      ctuf::filter_ctu<PX>(smem, A.fpics[pic], F);
+      if (threadIdx.x == 0) S->rot = 0;
+    }
   }
   if (threadIdx.x == 0) atomicAnd(&A.slots[s_slot >> 5], ~(1u << (s_slot & 31)));
 }
@@ -137,29 +162,57 @@ __global__ void __launch_bounds__(256) pb_order_kernel(int32_t *order, int wc, i
     }
   }
 }
-// A small host table into device memory in stream order, through kernel arguments: hipMemcpy would have to drain the stream first (an
-// earlier call on this workspace may still read the table), which stalls a host that has independent pictures to issue.
-struct pb_chunk { unsigned char b[3072]; };
-__global__ void __launch_bounds__(256) pb_upload_kernel(unsigned char *dst, pb_chunk c, int n)
+// ... for pictures in flight: the key of a CTU is its index cx + 2 cy plus LAG times its picture's depth in the call's reference DAG.  A CTU
+// waits for CTU (x + 2, y + 1) of the pictures it reads -- index + 4, depth at least one less: a smaller key, so every wait is for a
+// smaller ticket (no deadlock at any grid size).  cnt / cur: [keys] zeroed; any order inside a key will do.  One block.
+enum { LAG = 5 };
+__global__ void __launch_bounds__(256) pb_order_levels_kernel(int32_t *order, int32_t *cnt, int32_t *cur, const pb_pic_dev *pics, int wc, int hc, int n_pictures, int n_keys)
 {
-  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = c.b[i];
+  const int nd = wc + 2 * (hc - 1);
+  for (int p = threadIdx.x; p < n_pictures; p += blockDim.x) {
+    const int lv = pics[p].level;
+    for (int d = 0; d < nd; ++d) {
+      const int lo = d - (wc - 1) > 0 ? (d - (wc - 1) + 1) / 2 : 0, hi = d / 2 < hc - 1 ? d / 2 : hc - 1;
+      if (hi >= lo) atomicAdd(&cnt[d + LAG * lv], hi - lo + 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int at = 0;
+    for (int k = 0; k < n_keys; ++k) { const int c = cnt[k]; cnt[k] = at; at += c; }
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < n_pictures; p += blockDim.x) {
+    const int lv = pics[p].level;
+    for (int d = 0; d < nd; ++d) {
+      const int lo = d - (wc - 1) > 0 ? (d - (wc - 1) + 1) / 2 : 0, hi = d / 2 < hc - 1 ? d / 2 : hc - 1;
+      if (hi < lo) continue;
+      const int key = d + LAG * lv, at = cnt[key] + atomicAdd(&cur[key], hi - lo + 1);
+      for (int cy = lo; cy <= hi; ++cy) order[at + cy - lo] = p << 16 | cy << 8 | (d - 2 * cy);
+    }
+  }
 }
-
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 enum { MAX_SLOTS = 2048 };
-struct ws_layout { size_t ticket, slots, done, hmvp, order, pics, scratch, total; int n_slots; };
+struct ws_layout { size_t ticket, slots, done, hmvp, sao_done, final_done, key_cnt, key_cur, order, pics, filt, scratch, total; int n_slots, n_keys; };
 ws_layout layout(int n_pictures, int pic_w, int pic_h)
 {
-  const size_t hc = (size_t)((pic_h + 63) / 64), ctus = (size_t)((pic_w + 63) / 64) * hc, total = ctus * n_pictures;
+  const size_t wc = (size_t)((pic_w + 63) / 64), hc = (size_t)((pic_h + 63) / 64), ctus = wc * hc, total = ctus * n_pictures;
   ws_layout L;
   L.n_slots = (int)(total < MAX_SLOTS ? align_up(total, 32) : MAX_SLOTS);
+  L.n_keys = (int)(wc + 2 * (hc - 1)) + LAG * n_pictures;
   L.ticket = 0;
   L.slots = 256;
   L.done = L.slots + MAX_SLOTS / 8;
   L.hmvp = align_up(L.done + total * 4, 256);
-  L.order = align_up(L.hmvp + (size_t)n_pictures * hc * 41 * 4, 256);        // [0, order): zeroed before every run
+  L.sao_done = align_up(L.hmvp + (size_t)n_pictures * hc * 41 * 4, 256);
+  L.final_done = L.sao_done + total * 4;
+  L.key_cnt = L.final_done + total * 4;
+  L.key_cur = L.key_cnt + (size_t)L.n_keys * 4;
+  L.order = align_up(L.key_cur + (size_t)L.n_keys * 4, 256);                  // [0, order): zeroed before every run
   L.pics = align_up(L.order + total * 4, 256);
-  L.scratch = align_up(L.pics + (size_t)n_pictures * sizeof(pb_pic_dev), 256);
+  L.filt = align_up(L.pics + (size_t)n_pictures * sizeof(pb_pic_dev), 256);
+  L.scratch = align_up(L.filt + (size_t)n_pictures * sizeof(ctuf::filt_pic), 256);
   L.total = L.scratch + (size_t)L.n_slots * sizeof(ctu::scratch);
   return L;
 }
@@ -182,7 +235,25 @@ extern "C" size_t uvghip_ctu_search_pb_workspace_bytes(int n_pictures, int pic_w
   return layout(n_pictures, pic_w, pic_h).total;
 }
 
+namespace {
+int search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictures, const uvghip_pb_filter_t *filters, const int32_t *ref_in_call, void *workspace,
+              void *stream);
+}
 extern "C" int uvghip_ctu_search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictures, void *workspace, void *stream)
+{
+  return search_pb(bitdepth, pictures, n_pictures, nullptr, nullptr, workspace, stream);
+}
+extern "C" size_t uvghip_ctu_search_pb_inflight_workspace_bytes(int n_pictures, int pic_w, int pic_h) { return uvghip_ctu_search_pb_workspace_bytes(n_pictures, pic_w, pic_h); }
+extern "C" int uvghip_ctu_search_pb_inflight(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, const uvghip_pb_filter_t *filters, const int32_t *ref_in_call,
+                                             int n_pictures, void *workspace, void *stream)
+{
+  if (!filters || !ref_in_call) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  return search_pb(bitdepth, pictures, n_pictures, filters, ref_in_call, workspace, stream);
+}
+
+namespace {
+int search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictures, const uvghip_pb_filter_t *filters, const int32_t *ref_in_call, void *workspace,
+              void *stream)
 {
   UVGHIP_REQUIRE_READY();
   UVGHIP_REQUIRE_DEPTH(bitdepth);
@@ -195,6 +266,7 @@ extern "C" int uvghip_ctu_search_pb(int bitdepth, const uvghip_ctu_pb_picture_t 
   const ws_layout L = layout(n_pictures, p0.pic_w, p0.pic_h);
   unsigned char *ws = static_cast<unsigned char *>(workspace);
   std::vector<pb_pic_dev> pics(n_pictures);
+  std::vector<ctuf::filt_pic> filt(filters ? n_pictures : 0);
   for (int i = 0; i < n_pictures; ++i) {
     const uvghip_ctu_pb_picture_t &q = pictures[i];
     const uvghip_ctu_params_t &p = q.params;
@@ -236,21 +308,45 @@ extern "C" int uvghip_ctu_search_pb(int bitdepth, const uvghip_ctu_pb_picture_t 
     d.src_y = c.src_y; d.src_u = c.src_u; d.src_v = c.src_v; d.rec_y = c.rec_y; d.rec_u = c.rec_u; d.rec_v = c.rec_v;
     d.cu = c.cu; d.coeff = c.coeff; d.models = c.models; d.models_inter = q.models_inter;
     d.src_stride = c.src_stride; d.src_stride_c = c.src_stride_c; d.rec_stride = c.rec_stride; d.rec_stride_c = c.rec_stride_c; d.cu_stride = c.cu_stride;
+    if (filters) {
+      // the picture's references inside this call (pictures are in coding order: a reference is an earlier entry), its depth in that DAG
+      const uvghip_pb_filter_t &f = filters[i];
+      if (!f.dbk_y || !f.dbk_u || !f.dbk_v || !f.out_y || !f.out_u || !f.out_v || f.dbk_stride < p.pic_w || f.dbk_stride_c < p.pic_w / 2 || f.out_stride < p.pic_w ||
+          f.out_stride_c < p.pic_w / 2 || f.sao_type < 0 || f.sao_type > 3 || (f.sao_type && (!f.sao_info || !f.sao_models)))
+        return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_pb_inflight: filter stage");
+      if (p.qp_c != p.qp || p.qp != q.frame_qp) return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_pb_inflight: qp_c != qp or params.qp != frame_qp");
+      d.n_wait = 0; d.level = 0;
+      for (int k = 0; k < q.n_refs; ++k) {
+        const int r = ref_in_call[(size_t)i * 16 + k];
+        if (r < 0) continue;
+        if (r >= i) return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_pb_inflight: a reference inside the call must be an earlier picture of it");
+        const uvghip_pb_filter_t &fr = filters[r];
+        if (q.ref_y[k] != fr.out_y || q.ref_u[k] != fr.out_u || q.ref_v[k] != fr.out_v || q.ref_motion[k] != pictures[r].motion_out || q.ref_stride != fr.out_stride ||
+            q.ref_stride_c != fr.out_stride_c)
+          return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_pb_inflight: ref_in_call names a picture whose output is not this reference");
+        // a reference still being coded: the vectors must stay inside what is final in it (fracmv_within_tile's margin: 1 + the filters' delay)
+        if (q.inflight_margin != (fr.sao_type ? 11 : 9)) return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_pb_inflight: inflight_margin must be 11 (SAO) / 9 with a reference in flight");
+        bool seen = false;
+        for (int j = 0; j < d.n_wait; ++j) seen = seen || d.wait_pic[j] == r;
+        if (!seen) d.wait_pic[d.n_wait++] = r;
+        if (pics[r].level + 1 > d.level) d.level = pics[r].level + 1;
+      }
+      ctuf::filt_pic &g = filt[i];
+      g.dbk_y = f.dbk_y; g.dbk_u = f.dbk_u; g.dbk_v = f.dbk_v; g.out_y = f.out_y; g.out_u = f.out_u; g.out_v = f.out_v;
+      g.dbk_stride = f.dbk_stride; g.dbk_stride_c = f.dbk_stride_c; g.out_stride = f.out_stride; g.out_stride_c = f.out_stride_c;
+      g.sao_info = f.sao_info; g.sao_models = f.sao_models; g.lambda = p.lambda; g.sao_type = f.sao_type; g.slice_type = q.slice_type; g.qp = p.qp; g.is_b = q.slice_type == 0;
+    }
   }
   // the hand-out order and the pictures' descriptors, in stream order (nothing here waits for the stream: a caller with independent
   // pictures to issue -- api.LowDelayLoop.run(in_flight) -- is not held up by this one's references)
   hipStream_t st = uvghip_stream(stream);
-  hipLaunchKernelGGL(pb_order_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<int32_t *>(ws + L.order), wc, hc, n_pictures);
-  {
-    const unsigned char *src = reinterpret_cast<const unsigned char *>(pics.data());
-    const size_t bytes = (size_t)n_pictures * sizeof(pb_pic_dev);
-    for (size_t at = 0; at < bytes; at += sizeof(pb_chunk)) {
-      pb_chunk c;
-      const int n = (int)(bytes - at < sizeof(pb_chunk) ? bytes - at : sizeof(pb_chunk));
-      memcpy(c.b, src + at, (size_t)n);
-      hipLaunchKernelGGL(pb_upload_kernel, dim3(1), dim3(256), 0, st, ws + L.pics + at, c, n);
-    }
-  }
+  UVGHIP_TRY(hipMemsetAsync(ws, 0, L.order, st));
+  if (int rc = uvghip_upload_ordered(ws + L.pics, pics.data(), (size_t)n_pictures * sizeof(pb_pic_dev), st)) return rc;
+  if (filters) {
+    if (int rc = uvghip_upload_ordered(ws + L.filt, filt.data(), (size_t)n_pictures * sizeof(ctuf::filt_pic), st)) return rc;
+    hipLaunchKernelGGL(pb_order_levels_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<int32_t *>(ws + L.order), reinterpret_cast<int32_t *>(ws + L.key_cnt),
+                       reinterpret_cast<int32_t *>(ws + L.key_cur), reinterpret_cast<const pb_pic_dev *>(ws + L.pics), wc, hc, n_pictures, L.n_keys);
+  } else hipLaunchKernelGGL(pb_order_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<int32_t *>(ws + L.order), wc, hc, n_pictures);
   pb_launch_args A;
   A.pics = reinterpret_cast<const pb_pic_dev *>(ws + L.pics);
   A.order = reinterpret_cast<const int32_t *>(ws + L.order);
@@ -260,17 +356,23 @@ extern "C" int uvghip_ctu_search_pb(int bitdepth, const uvghip_ctu_pb_picture_t 
   A.slots = reinterpret_cast<uint32_t *>(ws + L.slots);
   A.n_slots = L.n_slots;
   A.wc = wc; A.hc = hc; A.n_ctus = total;
+  A.fpics = filters ? reinterpret_cast<const ctuf::filt_pic *>(ws + L.filt) : nullptr;
+  A.sao_done = reinterpret_cast<int32_t *>(ws + L.sao_done);
+  A.final_done = reinterpret_cast<int32_t *>(ws + L.final_done);
   const size_t lds = bitdepth == 8 ? sizeof(ctu::lds<uint8_t>) : sizeof(ctu::lds<uint16_t>);
   const hipError_t e = bitdepth == 8
       ? hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
       : hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return uvghip_set_error(e, "uvghip_ctu_search_pb: dynamic LDS size");
-  UVGHIP_TRY(hipMemsetAsync(ws, 0, L.order, st));
-  // workgroups: twice the CTUs a picture's wavefront can have in progress (the widest diagonal of cx + 2 cy), per picture
+  // workgroups: twice the CTUs a picture's wavefront can have in progress (the widest diagonal of cx + 2 cy), per picture.  Pictures in
+  // flight behind each other: a picture follows its reference LAG diagonals later, so a chain holds a picture's CTUs / LAG in progress
+  // whatever its length -- a device's worth of workgroups is plenty (the rest would only wait)
   const int width = (wc + 1) / 2 < hc ? (wc + 1) / 2 : hc;
-  const long long want = 2LL * width * n_pictures;
+  long long want = 2LL * width * n_pictures;
+  if (filters && want > 1024) want = 1024;
   const int grid = (int)(want < total ? want : total);
   if (bitdepth == 8) hipLaunchKernelGGL(ctu_search_pb_kernel<uint8_t>, dim3(grid), dim3(64), lds, st, A);
   else hipLaunchKernelGGL(ctu_search_pb_kernel<uint16_t>, dim3(grid), dim3(64), lds, st, A);
   UVGHIP_CHECK_LAUNCH();
 }
+}  // namespace

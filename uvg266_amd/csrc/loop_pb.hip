@@ -90,8 +90,9 @@ extern "C" int uvghip_loop_pb_run(int bitdepth, const uvghip_loop_pb_picture_t *
         ry[cy * wc + cx] = uvghip_rect_t{x, y, bw, bh};
         rc[cy * wc + cx] = uvghip_rect_t{x / 2, y / 2, bw / 2, bh / 2};
       }
-    UVGHIP_TRY(hipMemcpy(rects_y, ry.data(), ry.size() * sizeof(uvghip_rect_t), hipMemcpyHostToDevice));
-    UVGHIP_TRY(hipMemcpy(rects_c, rc.data(), rc.size() * sizeof(uvghip_rect_t), hipMemcpyHostToDevice));
+    // (in stream order: an earlier run on this workspace may still read the tables)
+    if (int e = uvghip_upload_ordered(rects_y, ry.data(), ry.size() * sizeof(uvghip_rect_t), st)) return e;
+    if (int e = uvghip_upload_ordered(rects_c, rc.data(), rc.size() * sizeof(uvghip_rect_t), st)) return e;
   }
   int32_t *edge[3], *band[3];
   uvghip_sao_param_t *prm[3];
@@ -160,13 +161,101 @@ extern "C" int uvghip_loop_pb_run(int bitdepth, const uvghip_loop_pb_picture_t *
       d.col = s.ref_motion[s.l[0][0]]; d.col_stride = s.ref_motion_stride; d.reserved = 0;
       d.inter4 = s.inter4; d.models_inter = s.models_inter;
     }
-    // the slice data of the run's pictures: the search's hand-over and the SAO decisions through the arithmetic coder.  (Its table upload
-    // is a synchronous copy: the stream is drained first so that an earlier run's coder is done with the table.)
-    if (i0 > 0) UVGHIP_TRY(hipStreamSynchronize(st));
+    // the slice data of the run's pictures: the search's hand-over and the SAO decisions through the arithmetic coder (its tables are
+    // uploaded in stream order: a later run's upload comes after the earlier run's coder on the stream)
     if (int rc = uvghip_encode_slice_rows_pb(bitdepth, &s0.params, cp.data(), sl.data(), m, sao_type ? sao_info + o0 * 34 : nullptr, sao_type ? sao_models + o0 * 6 : nullptr,
                                              ws + L.coder, ws + L.rows + (size_t)i0 * hc * L.row_cap, L.row_cap, row_bytes + (size_t)i0 * hc, stream))
       return rc;
     i0 = i1;
   }
   return 0;
+}
+
+// ---- pictures in flight behind their references: one call = one persistent launch for the whole DAG (uvghip_ctu_search_pb_inflight: the
+// search with the per-CTU filters inside), then ONE coder launch over all pictures -- their QPs, lambdas and slice types may differ ----
+namespace {
+struct flight_t { size_t search, dbk, info, models, coder, row_bytes, rows, total; int row_cap; };
+flight_t flight_of(int bitdepth, int n, int w, int h)
+{
+  const size_t ctus = (size_t)((w + 63) / 64) * ((h + 63) / 64), b = bitdepth == 8 ? 1 : 2, hc = (size_t)((h + 63) / 64);
+  flight_t L;
+  size_t at = 0;
+  auto take = [&](size_t bytes) { const size_t o = at; at = align_up(at + bytes, 256); return o; };
+  L.search = take(uvghip_ctu_search_pb_inflight_workspace_bytes(n, w, h));
+  L.dbk = take((size_t)n * ((size_t)w * h * 3 / 2) * b);
+  L.info = take((size_t)n * ctus * 34 * 4);
+  L.models = take((size_t)n * ctus * 6 * 2);
+  L.row_cap = 3 * 64 * w * (int)b;
+  L.coder = take(uvghip_slice_rows_pb_workspace_bytes(n));
+  L.row_bytes = take((size_t)n * hc * 4);
+  L.rows = take((size_t)n * hc * L.row_cap);
+  L.total = at;
+  return L;
+}
+}  // namespace
+
+extern "C" size_t uvghip_loop_pb_inflight_workspace_bytes(int bitdepth, int n_pictures, int pic_w, int pic_h)
+{
+  if ((bitdepth != 8 && bitdepth != 10) || n_pictures <= 0 || pic_w <= 0 || pic_h <= 0) return 0;
+  return flight_of(bitdepth, n_pictures, pic_w, pic_h).total;
+}
+
+extern "C" int uvghip_loop_pb_inflight_results(int bitdepth, int n_pictures, int pic_w, int pic_h, void *workspace, const int32_t **sao_info, const uint16_t **sao_models,
+                                               const uint8_t **rows, const int32_t **row_bytes, int *row_cap, int *n_rows)
+{
+  if ((bitdepth != 8 && bitdepth != 10) || n_pictures <= 0 || pic_w <= 0 || pic_h <= 0 || !workspace) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const flight_t L = flight_of(bitdepth, n_pictures, pic_w, pic_h);
+  unsigned char *ws = static_cast<unsigned char *>(workspace);
+  if (sao_info) *sao_info = reinterpret_cast<const int32_t *>(ws + L.info);
+  if (sao_models) *sao_models = reinterpret_cast<const uint16_t *>(ws + L.models);
+  if (rows) *rows = ws + L.rows;
+  if (row_bytes) *row_bytes = reinterpret_cast<const int32_t *>(ws + L.row_bytes);
+  if (row_cap) *row_cap = L.row_cap;
+  if (n_rows) *n_rows = (pic_h + 63) / 64;
+  return 0;
+}
+
+extern "C" int uvghip_loop_pb_run_inflight(int bitdepth, const uvghip_loop_pb_picture_t *pictures, int n_pictures, int sao_type, const int32_t *ref_in_call, void *workspace,
+                                           void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
+  if (!pictures || n_pictures <= 0 || !workspace || !ref_in_call || sao_type < 0 || sao_type > 3) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const int w = pictures[0].search.params.pic_w, h = pictures[0].search.params.pic_h;
+  if (w <= 0 || h <= 0) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const flight_t L = flight_of(bitdepth, n_pictures, w, h);
+  unsigned char *ws = static_cast<unsigned char *>(workspace);
+  const int wc = (w + 63) / 64, hc = (h + 63) / 64, ctus = wc * hc;
+  const size_t b = bitdepth == 8 ? 1 : 2, plane = (size_t)w * h * b, planes = plane * 3 / 2;
+  int32_t *sao_info = reinterpret_cast<int32_t *>(ws + L.info), *row_bytes = reinterpret_cast<int32_t *>(ws + L.row_bytes);
+  uint16_t *sao_models = reinterpret_cast<uint16_t *>(ws + L.models);
+  std::vector<uvghip_ctu_pb_picture_t> sp(n_pictures);
+  std::vector<uvghip_pb_filter_t> fl(n_pictures);
+  std::vector<uvghip_ctu_picture_t> cp(n_pictures);
+  std::vector<uvghip_slice_pb_t> sl(n_pictures);
+  for (int i = 0; i < n_pictures; ++i) {
+    const uvghip_loop_pb_picture_t &q = pictures[i];
+    const uvghip_ctu_pb_picture_t &s = q.search;
+    if (!q.out_y || !q.out_u || !q.out_v || q.out_stride < w || q.out_stride_c < w / 2) return uvghip_set_error(hipErrorInvalidValue, "uvghip_loop_pb_run_inflight: output planes");
+    sp[i] = s;
+    uvghip_pb_filter_t &f = fl[i];
+    unsigned char *d = ws + L.dbk + (size_t)i * planes;
+    f.dbk_y = d; f.dbk_u = d + plane; f.dbk_v = d + plane + plane / 4;
+    f.dbk_stride = w; f.dbk_stride_c = w / 2;
+    f.out_y = q.out_y; f.out_u = q.out_u; f.out_v = q.out_v; f.out_stride = q.out_stride; f.out_stride_c = q.out_stride_c;
+    f.sao_info = sao_info + (size_t)i * ctus * 34; f.sao_models = sao_models + (size_t)i * ctus * 6;
+    f.sao_type = sao_type; f.reserved = 0;
+    cp[i] = s.pic;
+    uvghip_slice_pb_t &o = sl[i];
+    o.slice_type = s.slice_type; o.poc = s.poc; o.n_refs = s.n_refs;
+    for (int k = 0; k < 16; ++k) { o.ref_pocs[k] = s.ref_pocs[k]; o.l[0][k] = s.l[0][k]; o.l[1][k] = s.l[1][k]; }
+    o.l_size[0] = s.l_size[0]; o.l_size[1] = s.l_size[1];
+    o.tmvp = s.tmvp; o.max_merge = s.max_merge; o.merge_level = s.merge_level; o.frame_qp = s.frame_qp;
+    o.col = s.ref_motion[s.l[0][0]]; o.col_stride = s.ref_motion_stride; o.reserved = 0;
+    o.inter4 = s.inter4; o.models_inter = s.models_inter;
+  }
+  if (int rc = uvghip_ctu_search_pb_inflight(bitdepth, sp.data(), fl.data(), ref_in_call, n_pictures, ws + L.search, stream)) return rc;
+  // the slice data of every picture in one launch (a P / B picture's models start from its own frame_qp and slice type: `params` only names the size)
+  return uvghip_encode_slice_rows_pb(bitdepth, &pictures[0].search.params, cp.data(), sl.data(), n_pictures, sao_type ? sao_info : nullptr, sao_type ? sao_models : nullptr,
+                                     ws + L.coder, ws + L.rows, L.row_cap, row_bytes, stream);
 }

@@ -852,6 +852,19 @@ extern "C" int uvghip_slice_rows_prepare(const uvghip_ctu_params_t *params, cons
   return 0;
 }
 
+// ... the same table in stream order (the callers that take a stream: nothing waits for it)
+static int prepare_ordered(const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, int n_pictures, void *workspace, hipStream_t st)
+{
+  const int wc = (params->pic_w + 63) / 64;
+  std::vector<pic_dev> pd(n_pictures);
+  for (int i = 0; i < n_pictures; ++i) {
+    if (!pictures[i].cu || !pictures[i].coeff || !pictures[i].models || pictures[i].cu_stride < wc * 16)
+      return uvghip_set_error(hipErrorInvalidValue, "uvghip_encode_slice_rows: picture descriptor");
+    pd[i] = pic_dev{pictures[i].cu, pictures[i].coeff, pictures[i].models, pictures[i].cu_stride, 0};
+  }
+  return uvghip_upload_ordered(workspace, pd.data(), pd.size() * sizeof(pic_dev), st);
+}
+
 extern "C" int uvghip_encode_slice_rows(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, int n_pictures,
                                         const int32_t *sao_info, const uint16_t *sao_models, void *workspace, uint8_t *out, int row_cap,
                                         int32_t *row_bytes, void *stream)
@@ -880,7 +893,8 @@ extern "C" int uvghip_encode_slice_rows_alf(int bitdepth, const uvghip_ctu_param
     return uvghip_set_error(hipErrorInvalidValue, __func__);
   const int W = params->pic_w, H = params->pic_h, hc = (H + 63) / 64;
   if (W <= 0 || H <= 0 || (W & 7) || (H & 7) || params->qp < 0 || params->qp > 63) return uvghip_set_error(hipErrorInvalidValue, __func__);
-  if (int rc = uvghip_slice_rows_prepare(params, pictures, n_pictures, workspace)) return rc;
+  hipStream_t st = uvghip_stream(stream);
+  if (int rc = prepare_ordered(params, pictures, n_pictures, workspace, st)) return rc;
   std::vector<alf_dev> ad(n_pictures);
   for (int i = 0; i < n_pictures; ++i) {
     const uvghip_slice_alf_t &q = alf[i];
@@ -893,8 +907,7 @@ extern "C" int uvghip_encode_slice_rows_alf(int bitdepth, const uvghip_ctu_param
     for (int c = 0; c < 2; ++c) { d.cc_enabled[c] = q.cc_enabled[c] != 0; d.cc_count[c] = q.cc_filter_count[c]; }
   }
   unsigned char *aw = static_cast<unsigned char *>(workspace) + ((size_t)n_pictures * sizeof(pic_dev) + 255) / 256 * 256;
-  UVGHIP_TRY(hipMemcpy(aw, ad.data(), ad.size() * sizeof(alf_dev), hipMemcpyHostToDevice));
-  hipStream_t st = uvghip_stream(stream);
+  if (int rc = uvghip_upload_ordered(aw, ad.data(), ad.size() * sizeof(alf_dev), st)) return rc;
   slice_rows_kernel<<<n_pictures * hc, 64, 0, st>>>(static_cast<const pic_dev *>(workspace), nullptr, sao_info, sao_models, W, H, params->qp, bitdepth, out, row_cap, row_bytes,
                                                     reinterpret_cast<const alf_dev *>(aw));
   UVGHIP_CHECK_LAUNCH();
@@ -910,7 +923,8 @@ extern "C" int uvghip_encode_slice_rows_pb(int bitdepth, const uvghip_ctu_params
     return uvghip_set_error(hipErrorInvalidValue, __func__);
   const int W = params->pic_w, H = params->pic_h, hc = (H + 63) / 64;
   if (W <= 0 || H <= 0 || (W & 7) || (H & 7) || params->qp < 0 || params->qp > 63) return uvghip_set_error(hipErrorInvalidValue, __func__);
-  if (int rc = uvghip_slice_rows_prepare(params, pictures, n_pictures, workspace)) return rc;
+  hipStream_t st = uvghip_stream(stream);
+  if (int rc = prepare_ordered(params, pictures, n_pictures, workspace, st)) return rc;
   std::vector<pb_dev> pd(n_pictures);
   for (int i = 0; i < n_pictures; ++i) {
     const uvghip_slice_pb_t &q = pb[i];
@@ -923,8 +937,7 @@ extern "C" int uvghip_encode_slice_rows_pb(int bitdepth, const uvghip_ctu_params
     d.col = q.col; d.inter4 = q.inter4; d.models_inter = q.models_inter; d.col_stride = q.col_stride; d.pad = 0;
   }
   unsigned char *pbw = static_cast<unsigned char *>(workspace) + ((size_t)n_pictures * sizeof(pic_dev) + 255) / 256 * 256;
-  UVGHIP_TRY(hipMemcpy(pbw, pd.data(), pd.size() * sizeof(pb_dev), hipMemcpyHostToDevice));
-  hipStream_t st = uvghip_stream(stream);
+  if (int rc = uvghip_upload_ordered(pbw, pd.data(), pd.size() * sizeof(pb_dev), st)) return rc;
   slice_rows_kernel<<<n_pictures * hc, 64, sizeof(row_state_pb), st>>>(static_cast<const pic_dev *>(workspace), reinterpret_cast<const pb_dev *>(pbw), sao_info, sao_models,
                                                                        W, H, params->qp, bitdepth, out, row_cap, row_bytes);
   UVGHIP_CHECK_LAUNCH();

@@ -9,6 +9,8 @@
 // ---- host side -----------------------------------------------------------
 int uvghip_set_error(hipError_t e, const char *where);
 bool uvghip_ready();
+// a small host table -> device memory in stream order (through kernel arguments; the host never waits for the stream): context.hip
+int uvghip_upload_ordered(void *dst, const void *host, size_t bytes, hipStream_t st);
 
 #define UVGHIP_REQUIRE_READY()                                                   \
   do {                                                                           \

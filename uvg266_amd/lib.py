@@ -273,6 +273,11 @@ SIGNATURES = {
     "uvghip_loop_pb_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
     "uvghip_loop_pb_run": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_vp]),
     "uvghip_loop_pb_results": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "uvghip_ctu_search_pb_inflight_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
+    "uvghip_ctu_search_pb_inflight": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_loop_pb_inflight_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
+    "uvghip_loop_pb_run_inflight": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "uvghip_loop_pb_inflight_results": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_merge_cand_batch": (c_int, [c_vp, c_vp, c_vp, ctypes.c_long, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvghip_amvp_cand_batch": (c_int, [c_vp, c_vp, c_vp, ctypes.c_long, c_vp, c_int, c_vp, c_vp]),
     "uvghip_inter_pred_satd_batch": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
