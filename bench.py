@@ -658,40 +658,60 @@ def low_delay_closed_loop(device, n_seq=8, reps=2):
                     "sequences and the 2-CTU-lag wavefront inside a picture (DESIGN.md 4.12)"}
 
 
-def c3_clip(device, frames=24, with_cpu=True):
-    """BASELINE.json configs[2] as BASELINE defines it: ONE 1920x1080 8-bit clip, --gop lp-g4d3t1 --preset medium at QP 27, pictures in
-    coding order through the device's closed low-delay loop (api.LowDelayLoop with one sequence: every picture waits for the one before
-    it), wall clock from the first enqueue to the last picture's slice data.  The clip is 120 pictures (intra period 64: I at 0 and 64);
-    the frame-level state -- slice types, QPs, lambdas, reference lists, the reference encoder's own for this configuration -- comes from
-    tests/golden/ref_lowdelay_states_qp27_120frames.npz (tools/refcheck/make_ctu_goldens.py lowdelay_states; independent of the picture
-    size).  `frames` pictures of the clip are timed (the default run keeps to a prefix so that the bench finishes in minutes; the
-    rate per picture does not depend on the position in the clip).  The reference encoder's CLI on the host cores runs the WHOLE clip
-    beside it (cpu_baseline)."""
+def c3_clip(device, frames=120, with_cpu=True):
+    """BASELINE.json configs[2] as BASELINE defines it: ONE 1920x1080 8-bit clip of 120 pictures, --gop lp-g4d3t1 --preset medium at QP 27
+    (intra period 64: I pictures at 0 and 64), host memory to slice data: the sources are uploaded inside the timed region, the I
+    pictures go through the all-intra loop, ALL P / B pictures through ONE uvghip_loop_pb_run_inflight -- the encoder's --owf schedule
+    (encoderstate.c:1060-1116): CTU (x, y) of a picture starts when CTU (x + 2, y + 1) of the pictures it reads is final, deblocking and
+    SAO run per CTU inside the persistent search kernel, the vectors keep to what is final in a reference still being coded
+    (inflight_margin 11 = cfg.owf != 0).  Every picture and every WPP row's bytes are compared with the reference encoder's --owf 1 run of
+    this clip (tests/golden/ref_intercrc_1920x1080_8_qp27_120frames_owf1.npz, which also holds the frame-level state: slice types, QPs,
+    lambdas, reference lists).  The reference encoder's CLI on the host cores runs the same clip beside it (cpu_baseline)."""
+    import zlib
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as Hh
-    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_lowdelay_states_qp27_120frames.npz"))
-    W, H, depth, qp = 1920, 1080, 8, int(g["dims"][0])
-    total = int(g["dims"][1])
+    golden = "ref_intercrc_1920x1080_8_qp27_120frames_owf1"
+    g = np.load(os.path.join(ROOT, "tests", "golden", golden + ".npz"))
+    W, H, depth, qp, total = (int(a) for a in g["dims"])
     frames = min(frames, total)
+    hc = (H + 63) // 64
     states = Hh.frame_states_from_records(g["meta"], g["lam"], g["refs"])[:frames]
-    src = [[tuple(torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in Hh.clip_picture(W, H, t, depth)) for t in range(frames)]]
-    # (by_level: pictures at the same depth of the reference DAG share a launch -- in a low-delay GOP that is one picture per level, except
-    # across an IDR picture: with --c3-clip-frames 120 the second intra period, pictures 64..119, runs beside the first)
-    loop = api.LowDelayLoop(W, H, depth, 1, states, src, by_level=True)
-    loop.run()                                            # warm-up (plans, first-touch)
+    host = [[torch.from_numpy(np.ascontiguousarray(p)).pin_memory() for p in Hh.clip_picture(W, H, t, depth)] for t in range(frames)]
+    src = [[tuple(torch.empty_like(p, device=device) for p in host[t]) for t in range(frames)]]
+    loop = api.LowDelayLoop(W, H, depth, 1, states, src, inflight=True, inflight_margin=11)
+
+    def run():
+        for t in range(frames):
+            for d, h in zip(src[0][t], host[t]):
+                d.copy_(h, non_blocking=True)
+        loop.run()
+    run()                                                 # warm-up (plans, first-touch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    loop.run()
+    run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     nbytes = int(sum(int(loop.row_bytes[f].sum().item()) for f in range(frames)))
-    out = {"value": round(frames / dt, 3), "unit": "frames/s (one low-delay clip, pictures strictly in sequence)", "frames_timed": frames, "clip_frames": total,
-           "dependency_levels": 1 + max(loop.level),
-           "wall_ms": round(1e3 * dt, 1), "slice_data_bytes": nbytes,
-           "workload": f"{W}x{H} {depth}-bit yuv420p, ONE clip, --gop lp-g4d3t1 --preset medium at QP {qp} (BASELINE.json configs[2]); per picture: closed-loop CTU search "
-                       "with the inter search on the device's own reference pictures -> deblocking -> SAO -> arithmetic coder",
-           "note": "a single sequence: nothing overlaps but the CTUs of one picture's wavefront (the P / B kernel walks a CTU on one wave; dependent pictures are not "
-                   "in flight together) -- the aggregate rate of many sequences side by side is extra_workloads.c3_low_delay_closed_loop"}
+    bad = []
+    for f in range(frames):
+        planes = [a.cpu().numpy() for a in loop.out[f][0]]
+        if zlib.crc32(b"".join(np.ascontiguousarray(a).tobytes() for a in planes)) != int(g["final_crc"][f]):
+            bad.append(f"picture {f}")
+        rows, nb = loop.rows[f].cpu().numpy(), loop.row_bytes[f].cpu().numpy()
+        for r in range(hc):
+            if int(nb[0, r]) != int(g["row_len"][f * hc + r]) or zlib.crc32(rows[0, r, :nb[0, r]].tobytes()) != int(g["row_crc"][f * hc + r]):
+                bad.append(f"picture {f} row {r}")
+    n_pb = sum(1 for fs in states if fs["slice_type"] != 2)
+    out = {"value": round(frames / dt, 3), "unit": "frames/s (one low-delay clip, host memory -> slice data, pictures in flight on the encoder's --owf schedule)",
+           "frames_timed": frames, "clip_frames": total, "wall_ms": round(1e3 * dt, 1), "slice_data_bytes": nbytes, "parity_checked": not bad,
+           "parity": {"golden": golden, "pictures": frames, "mismatches": bad[:8],
+                      "items": "CRC of every output picture (after deblocking + SAO) and length + CRC of every WPP row's slice data vs the reference encoder's --owf 1 run of this clip"},
+           "launches": {"intra_loops": frames - n_pb, "inflight_calls": 1, "pictures_in_the_inflight_call": n_pb},
+           "workload": f"{W}x{H} {depth}-bit yuv420p, ONE clip of {frames} pictures, --gop lp-g4d3t1 --preset medium --owf 1 at QP {qp} (BASELINE.json configs[2]); upload -> I pictures "
+                       "through the all-intra loop -> every P / B picture in ONE persistent launch: closed-loop CTU search with the inter search on the device's own reference "
+                       "pictures while they are still being coded, per-CTU deblocking + SAO, cross-picture CTU flags -> one arithmetic-coder launch",
+           "note": "a picture follows its reference five wavefront diagonals behind (cx + 2 cy; the reference's frame_delay of 4, encoder.c:94-95, + the CTU itself): a chain of "
+                   "dependent pictures costs five CTU times per picture instead of a picture's 62 diagonals; the two intra periods of the clip are independent and run side by side"}
     del loop
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline_low_delay(W, H, depth, qp, total)
@@ -1063,7 +1083,7 @@ def main():
     ap.add_argument("--only-search-rows", action="store_true", help="time only the row-sharded closed-loop search (one rank: a band = the whole picture; development)")
     ap.add_argument("--only-clip", action="store_true", help="time only extra_workloads.c2_clip (development)")
     ap.add_argument("--only-c3", action="store_true", help="time only extra_workloads.c3_low_delay_closed_loop and print it (development)")
-    ap.add_argument("--c3-clip-frames", type=int, default=16, help="extra_workloads.c3_clip: pictures of the ONE 120-picture low-delay clip that are timed (0: skip; 120: the whole clip)")
+    ap.add_argument("--c3-clip-frames", type=int, default=120, help="extra_workloads.c3_clip: pictures of the ONE 120-picture low-delay clip that are timed (0: skip; 120: the whole clip)")
     ap.add_argument("--only-c3-clip", action="store_true", help="time only extra_workloads.c3_clip and print it (development)")
     ap.add_argument("--ra-clip-frames", type=int, default=65, help="extra_workloads.ra_clip: coded pictures of the ONE random-access (--gop 16) clip that are timed (0: skip)")
     ap.add_argument("--only-2160p", action="store_true", help="time only extra_workloads.2160p10_closed_loop (with its ALF stage) and print it (development)")
@@ -1108,7 +1128,7 @@ def main():
         print(json.dumps({"ra_clip": ra_clip(device, frames=args.ra_clip_frames or 65, with_cpu=not args.no_cpu_baseline)}), flush=True)
         return
     if args.only_c3_clip:
-        print(json.dumps({"c3_clip": c3_clip(device, frames=args.c3_clip_frames or 24, with_cpu=not args.no_cpu_baseline)}), flush=True)
+        print(json.dumps({"c3_clip": c3_clip(device, frames=args.c3_clip_frames or 120, with_cpu=not args.no_cpu_baseline)}), flush=True)
         return
     if args.only_c3:
         print(json.dumps({"c3_low_delay_closed_loop": low_delay_closed_loop(device, n_seq=args.c3_sequences)}), flush=True)

@@ -19,7 +19,9 @@ else:
     ks = [first[f] for f in range(frames)]
     meta, lam, refs = g["meta"][ks], g["lam"][ks], g["refs"][ks]
 states = H.frame_states_from_records(meta, lam, refs)
-pics = [H.moving_picture(W, Hh, t, depth) for t in range(frames)]
+frames = int(os.environ.get("PROFILE_FRAMES", frames))
+states = states[:frames]
+pics = H.golden_sources(g)[:frames] if int(os.environ.get("PROFILE_GOLDEN_SOURCES", "1")) else [H.moving_picture(W, Hh, t, depth) for t in range(frames)]
 one = [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in pics[f]) for f in range(frames)]
 loop = api.LowDelayLoop(W, Hh, depth, n_seq, states, [one] * n_seq)
 torch.cuda.synchronize(); t = time.time(); loop.run(); torch.cuda.synchronize()

@@ -1056,16 +1056,30 @@ class LowDelayLoop:
         self.deps, self.level = reference_dag(frames)
         by_poc, coded_as = {}, {}
         self.ref_frame = [[-1] * 16 for _ in frames]          # per coded picture and reference: the coded picture whose output it is
+        # inflight: the I pictures depend on nothing -- those of one QP / lambda go through ONE all-intra loop, ahead of everything else
+        igroup = {}
+        if inflight:
+            for f, fs in enumerate(frames):
+                if fs["slice_type"] == 2:
+                    igroup.setdefault((fs["qp"], fs["lam"]), []).append(f)
+            for key, fl in igroup.items():
+                loop = ClosedLoop(ctu_params(W, H, key[0], lam=key[1]), [tuple(src[s][f]) for f in fl for s in range(n_seq)], sao_type=sao_type)
+                igroup[key] = (fl, loop, [z((hc * 16, wc * 16, 8), torch.int32) for _ in range(n_seq * len(fl))])
         for f, fs in enumerate(frames):
             srcs = [tuple(src[s][f]) for s in range(n_seq)]
             if fs["slice_type"] != 2:
                 for i in range(fs["n_refs"]):
                     self.ref_frame[f][i] = coded_as[fs["ref_pocs"][i]]
-            if fs["slice_type"] == 2:
+            if fs["slice_type"] == 2 and inflight:
+                fl, loop, gm = igroup[(fs["qp"], fs["lam"])]
+                j = fl.index(f)
+                outs, mots = loop.out[j * n_seq:(j + 1) * n_seq], gm[j * n_seq:(j + 1) * n_seq]
+                self.steps.append(("I", loop, gm, fl))
+            elif fs["slice_type"] == 2:
                 loop = ClosedLoop(ctu_params(W, H, fs["qp"], lam=fs["lam"]), srcs, sao_type=sao_type)
                 outs = loop.out
                 mots = [z((hc * 16, wc * 16, 8), torch.int32) for _ in range(n_seq)]
-                self.steps.append(("I", loop, mots))
+                self.steps.append(("I", loop, mots, [f]))
             else:
                 arr = (_lib.LoopPbPicture * n_seq)()
                 outs, mots, bufs = [], [], []
@@ -1126,7 +1140,7 @@ class LowDelayLoop:
                     self.steps[f] = ("PB", self.steps[f][1], None, self.steps[f][3])
         if inflight:
             pb = [f for f in range(len(frames)) if self.steps[f][0] == "PB"]
-            self.order = [([f], self.steps[f]) for f in range(len(frames)) if self.steps[f][0] == "I"]
+            self.order = [(fl, ("I", loop, gm, fl)) for fl, loop, gm in igroup.values()]
             if pb:
                 at = {f: j for j, f in enumerate(pb)}
                 n = n_seq * len(pb)
@@ -1166,13 +1180,15 @@ class LowDelayLoop:
                     own.wait_event(done[d])
                 st = own.cuda_stream
             if step[0] == "I":
-                _, loop, mots = step
+                _, loop, mots, fl = step
                 loop.run(st)
                 with torch.cuda.stream(torch.cuda.ExternalStream(st)):      # (on the SAME stream as the search that writes loop.cu and the P / B search that reads mots)
-                    for s in range(self.n_seq):      # an intra picture as a reference: its units' type, no vectors
+                    for s in range(len(mots)):       # an intra picture as a reference: its units' type, no vectors
                         mots[s][:, :, 0] = loop.cu[s][:, :, 2].to(torch.int32)
                         mots[s][:, :, 6:8] = -1
-                self.rows[f], self.row_bytes[f] = loop.slice_data()
+                rows, nb = loop.slice_data()
+                for j, g in enumerate(fl):
+                    self.rows[g], self.row_bytes[g] = rows[j * self.n_seq:(j + 1) * self.n_seq], nb[j * self.n_seq:(j + 1) * self.n_seq]
             else:
                 kind, arr, ws, ric = step
                 n = self.n_seq * len(fr)

@@ -19,7 +19,8 @@
 //   F(x, y) = [64 cx - 10, 64 cx + 54) x [64 cy - 10, 64 cy + 54) (SAO_DELAY_PX 10: one more sample for the edge classes' neighbours,
 //           encoderstate.c:316-364) of dbk + the decisions of the up to four CTUs it overlaps -> the output picture.
 // Flags (agent scope, release / acquire): sao_done[k] after D is written and the decision is out; final_done[k] after F is written AND
-// the left and upper CTU are final -- so a set flag means everything up and left of the CTU's lower right corner minus 10 is final.
+// the left, upper and upper-right CTU are final -- so a set flag means: final is everything up and left of the CTU's lower right corner
+// minus 10, and of the corners of the CTUs (x + j, y - j) up the diagonal -- the shape a vector of a picture in flight may reach into.
 #pragma once
 #include "deblock_dev.h"
 #include "sao_decide_dev.h"
@@ -294,6 +295,7 @@ __device__ __attribute__((noinline)) void filter_ctu(unsigned char *smem, const 
   if (threadIdx.x == 0) {
     if (cx) wait_set(&J.final_done[k - 1]);
     if (cy) wait_set(&J.final_done[k - wc]);
+    if (cy && cx + 1 < wc) wait_set(&J.final_done[k - wc + 1]);
     __hip_atomic_store(&J.final_done[k], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();

@@ -41,6 +41,7 @@ struct pb_launch_args {
   // pictures in flight: the filter stage of every picture (NULL: search only, the pictures of the call are independent), its flags
   const ctuf::filt_pic *fpics;
   int32_t *sao_done, *final_done;   // [pic * ctus + cy * wc + cx]
+  unsigned long long *times;        // CTU_PROFILE builds: per CTU the s_memtime at ticket, start of the search, end of the search, end of the filters
 };
 
 // four workgroups (= four waves: the kernel's registers allow one per SIMD) per CU at 8 bit: 160 KB / 4 incl. the 4288 bytes of static tables
@@ -81,6 +82,9 @@ __global__ void __launch_bounds__(64) ctu_search_pb_kernel(pb_launch_args A)
     __syncthreads();
     const int ticket = s_ticket;
     if (ticket >= A.n_ctus) break;
+#if defined(CTU_PROFILE)
+    const unsigned long long t_ticket = __builtin_amdgcn_s_memtime();
+#endif
     const int32_t o = A.order[ticket];
     const int pic = o >> 16, cy = (o >> 8) & 0xff, cx = o & 0xff;
     const int ctus = A.wc * A.hc, k = cy * A.wc + cx;
@@ -93,16 +97,23 @@ __global__ void __launch_bounds__(64) ctu_search_pb_kernel(pb_launch_args A)
           for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);
           if (naps < 8) naps <<= 1;
         }
-      // a picture in flight behind its references: CTU (x + 2, y + 1) of each of them is final (encoderstate.c:1103-1112 with
-      // max_inter_ref_lcu = {1, 1}, encoder.c:244-245) -- and with it everything up and left of that CTU's corner
+      // a picture in flight behind its references.  The reference encoder lets CTU (x, y) wait for CTU (x + 2, y + 1) of the reference
+      // (encoderstate.c:1103-1112, max_inter_ref_lcu = {1, 1}); what the vectors can actually reach under fracmv_within_tile (mv_within:
+      // ly <= 1, lx + ly <= 2, the filters' delay in the margin) is final earlier: the staircase of CTUs (x + 2 + j, y - j), j >= 0, and
+      // CTU (x + 1, y + 1), with everything left of and above them.  final_done is monotone over exactly that shape (a CTU's flag is
+      // set after its left, upper and upper-right neighbour's, ctu_filter.h), so ONE flag says it: (x + 1, y + 1), or (x + 2, y) in the
+      // last row.  Same pictures, same stream -- a shorter wait: a picture follows its reference four diagonals behind, not five.
       if (A.fpics) {
         const pb_pic_dev &Dw = A.pics[pic];
-        const int kd = (cy + 1 < A.hc ? cy + 1 : A.hc - 1) * A.wc + (cx + 2 < A.wc ? cx + 2 : A.wc - 1);
+        const int kd = cy + 1 < A.hc ? (cy + 1) * A.wc + (cx + 1 < A.wc ? cx + 1 : A.wc - 1) : cy * A.wc + (cx + 2 < A.wc ? cx + 2 : A.wc - 1);
         for (int r = 0; r < Dw.n_wait; ++r) ctuf::wait_set(A.final_done + (size_t)Dw.wait_pic[r] * ctus + kd);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+#if defined(CTU_PROFILE)
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
     const pb_pic_dev &D = A.pics[pic];
     ctu::job<PX> J;
     J.P = D.P;
@@ -124,6 +135,9 @@ __global__ void __launch_bounds__(64) ctu_search_pb_kernel(pb_launch_args A)
     ctu::run_ctu_pb(S, J);
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&done[k], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(CTU_PROFILE)
+    const unsigned long long t_searched = __builtin_amdgcn_s_memtime();
+#endif
     if (A.fpics) {
       // the CTU's in-loop filters while its right and lower neighbours search on (ctu_filter.h); the LDS image is free until the next CTU
       ctuf::filt_ctu F;
@@ -135,6 +149,12 @@ __global__ void __launch_bounds__(64) ctu_search_pb_kernel(pb_launch_args A)
       ctuf::filter_ctu<PX>(smem, A.fpics[pic], F);
       if (threadIdx.x == 0) S->rot = 0;
     }
+#if defined(CTU_PROFILE)
+    if (threadIdx.x == 0) {
+      unsigned long long *t = A.times + ((size_t)pic * ctus + k) * 4;
+      t[0] = t_ticket; t[1] = t_start; t[2] = t_searched; t[3] = __builtin_amdgcn_s_memtime();
+    }
+#endif
   }
   if (threadIdx.x == 0) atomicAnd(&A.slots[s_slot >> 5], ~(1u << (s_slot & 31)));
 }
@@ -163,9 +183,9 @@ __global__ void __launch_bounds__(256) pb_order_kernel(int32_t *order, int wc, i
   }
 }
 // ... for pictures in flight: the key of a CTU is its index cx + 2 cy plus LAG times its picture's depth in the call's reference DAG.  A CTU
-// waits for CTU (x + 2, y + 1) of the pictures it reads -- index + 4, depth at least one less: a smaller key, so every wait is for a
+// waits for CTU (x + 1, y + 1) of the pictures it reads -- index + 3, depth at least one less: a smaller key, so every wait is for a
 // smaller ticket (no deadlock at any grid size).  cnt / cur: [keys] zeroed; any order inside a key will do.  One block.
-enum { LAG = 5 };
+enum { LAG = 4 };
 __global__ void __launch_bounds__(256) pb_order_levels_kernel(int32_t *order, int32_t *cnt, int32_t *cur, const pb_pic_dev *pics, int wc, int hc, int n_pictures, int n_keys)
 {
   const int nd = wc + 2 * (hc - 1);
@@ -194,7 +214,7 @@ __global__ void __launch_bounds__(256) pb_order_levels_kernel(int32_t *order, in
 }
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 enum { MAX_SLOTS = 2048 };
-struct ws_layout { size_t ticket, slots, done, hmvp, sao_done, final_done, key_cnt, key_cur, order, pics, filt, scratch, total; int n_slots, n_keys; };
+struct ws_layout { size_t ticket, slots, done, hmvp, sao_done, final_done, key_cnt, key_cur, order, pics, filt, times, scratch, total; int n_slots, n_keys; };
 ws_layout layout(int n_pictures, int pic_w, int pic_h)
 {
   const size_t wc = (size_t)((pic_w + 63) / 64), hc = (size_t)((pic_h + 63) / 64), ctus = wc * hc, total = ctus * n_pictures;
@@ -212,7 +232,12 @@ ws_layout layout(int n_pictures, int pic_w, int pic_h)
   L.order = align_up(L.key_cur + (size_t)L.n_keys * 4, 256);                  // [0, order): zeroed before every run
   L.pics = align_up(L.order + total * 4, 256);
   L.filt = align_up(L.pics + (size_t)n_pictures * sizeof(pb_pic_dev), 256);
-  L.scratch = align_up(L.filt + (size_t)n_pictures * sizeof(ctuf::filt_pic), 256);
+  L.times = align_up(L.filt + (size_t)n_pictures * sizeof(ctuf::filt_pic), 256);
+#if defined(CTU_PROFILE)
+  L.scratch = align_up(L.times + total * 32, 256);
+#else
+  L.scratch = L.times;
+#endif
   L.total = L.scratch + (size_t)L.n_slots * sizeof(ctu::scratch);
   return L;
 }
@@ -227,6 +252,8 @@ extern "C" __attribute__((visibility("default"))) size_t uvghip_ctu_search_pb_de
   *slot_bytes = sizeof(ctu::scratch); *n_slots = L.n_slots;
   return L.scratch;
 }
+// ... and the per-CTU timestamps [picture][ctu][4] (uint64 s_memtime ticks: ticket taken, search started, search done, filters done)
+extern "C" __attribute__((visibility("default"))) size_t uvghip_ctu_search_pb_debug_times(int n_pictures, int pic_w, int pic_h) { return layout(n_pictures, pic_w, pic_h).times; }
 #endif
 
 extern "C" size_t uvghip_ctu_search_pb_workspace_bytes(int n_pictures, int pic_w, int pic_h)
@@ -359,6 +386,7 @@ int search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictu
   A.fpics = filters ? reinterpret_cast<const ctuf::filt_pic *>(ws + L.filt) : nullptr;
   A.sao_done = reinterpret_cast<int32_t *>(ws + L.sao_done);
   A.final_done = reinterpret_cast<int32_t *>(ws + L.final_done);
+  A.times = reinterpret_cast<unsigned long long *>(ws + L.times);
   const size_t lds = bitdepth == 8 ? sizeof(ctu::lds<uint8_t>) : sizeof(ctu::lds<uint16_t>);
   const hipError_t e = bitdepth == 8
       ? hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
