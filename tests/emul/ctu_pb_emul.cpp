@@ -69,3 +69,6 @@ int ctu_pb_emul_search_picture(int bitdepth, const ctu::params *P, const emul_fr
   if (bitdepth == 10) return run_picture<uint16_t>(*P, *F, (const uint16_t *)sy, (const uint16_t *)su, (const uint16_t *)sv, (uint16_t *)ry, (uint16_t *)ru, (uint16_t *)rv, cu_tab, inter4, trees, motion_out, coeff, models, models_inter);
   return -1;
 }
+
+// the two-wave build's order of work (ctu_pb.h post_leaves): the four 4x4 CUs of every 8x8 area before the area's unsplit CU, all four always
+extern "C" __attribute__((visibility("default"))) void ctu_pb_emul_set_leafwave(int on) { ctu::g_emul_leafwave = on; }

@@ -118,6 +118,7 @@ namespace ctu {
 #if !defined(__HIPCC__)
 static int g_emul_wave = 0;      // host emulation: which wave's scratch the code running now uses
 static int g_emul_lazy = 0;      // host emulation: pretend a CU's own cost is never known before all its children are done
+static int g_emul_leafwave = 0;  // host emulation of the P / B kernel's two-wave build: the four 4x4 CUs of an 8x8 area go to the leaf wave (ctu_pb.h)
 #endif
 
 enum { LCU = 64, LCU_C = 32, PY = 68, PC = 36, NMODELS = 257 };
@@ -226,8 +227,9 @@ constexpr int arena_bytes(int n, bool slim = false)     // one depth's share of 
           (n >= 8 ? 0 : 2 * 18 * 4) + (n <= 8 ? 8 + 2 * n * n * 8 : 0) + 15) & ~15;
 }
 #if defined(CTU_PB)
-// one wave walks a P / B CTU, a depth at a time: the depths' scratch areas share ONE region sized for the largest (ctu_pb.h)
-enum { ARENA_BYTES = arena_bytes(32) };
+// one wave walks a P / B CTU, a depth at a time: the depths' scratch areas share ONE region sized for the largest (ctu_pb.h); the 4x4
+// depth has its own behind it -- in the two-wave build the leaf wave works there while the walk evaluates the 8x8 CU above
+enum { ARENA_BYTES = arena_bytes(32) + arena_bytes(4) };
 #else
 enum { ARENA_BYTES = arena_bytes(4) + arena_bytes(8) + arena_bytes(16) + arena_bytes(32) };
 #endif
@@ -313,6 +315,9 @@ template <typename PX> struct lds {
   alignas(16) unsigned char arena[lds_cfg<PX>::slim ? (int)ARENA_BYTES_SLIM : (int)ARENA_BYTES];
 #if defined(CTU_PB)
   pb_state pb;
+  // the leaf wave of the two-wave build (ctu_pb.h post_leaves): on / off, the costs of the four 4x4 CUs of the area it was handed
+  int32_t leaf_wave;
+  double leaf_cost[4];
 #endif
 };
 template <typename PX> CTU_DEV wctx *wv_of(lds<PX> *S) { return &S->wv[S->vsel[CTU_WAVE]]; }
@@ -2287,7 +2292,7 @@ template <typename PX> CTU_DEV double coeff_bits4(lds<PX> *S, CTU_LDS uint32_t *
     CTU_LDS uint32_t *mk = m;
     if (!update) {
 #if defined(CTU_PB)
-      mk = LDSP(uint32_t, S->pb.cnt_models);
+      mk = LDSP(uint32_t, CTU_WAVE == 0 ? S->pb.cnt_models : S->pb.work0);      // (the leaf wave counts on the 64x64 candidate's set: idle once the walk is below depth 0)
 #else
       mk = LDSP(uint32_t, S->work[2]);
 #endif
@@ -2502,7 +2507,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
       // counting only: these bins still adapt their models WITHIN the block (the reference counts on a copy) -- work on a copy
       // of the few models involved (work[0] is nobody's: depth 0 has no unsplit candidate of its own)
 #if defined(CTU_PB)
-      mk = (CTU_LDS uint32_t *)S->pb.cnt_models;       // (every work[] set is some depth's here)
+      mk = (CTU_LDS uint32_t *)(CTU_WAVE == 0 ? S->pb.cnt_models : S->pb.work0);       // (every work[] set is some depth's here; the leaf wave: see coeff_bits)
 #else
       mk = (CTU_LDS uint32_t *)S->work[CTU_WAVE == 0 ? 2 : 1];      // (the 64x64 candidate: the walk and depth 2's wave count at the same time)
 #endif
@@ -3648,6 +3653,8 @@ template <typename PX> CTU_DEV void setup_waves(lds<PX> *S, scratch *W = nullptr
     int off = 0;
 #if !defined(CTU_PB)
     for (int j = 0; j < k; ++j) off += arena_bytes(4 << j);          // (the slim depth-1 share is the last one)
+#else
+    if (k == 0) off = arena_bytes(32);
 #endif
     unsigned char *a = S->arena + off;
     wctx *V = &S->wv[k];

@@ -1393,6 +1393,70 @@ template <typename PX> CTU_NOINLINE CTU_DEV void restore64_pb(lds<PX> *S, const 
   CTU_SYNC();
 }
 
+// ---- the leaf wave (two-wave build: 128 threads per CTU) -------------------------------------------------------------------------
+// The four 4x4 CUs an 8x8 area splits into are intra CUs: they read only what is decided before the area (samples, side information,
+// the models at the area's entry + its split flag) and write the area's own decided state -- nothing the evaluation of the unsplit 8x8
+// CU reads or writes (that one works on the depth's candidate buffers and its own copy of the models).  So the second wave takes them
+// while the walk evaluates the 8x8 CU.  The reference evaluates the CU first and may cut the split short (the pruning test and the
+// child-by-child comparison, search.c:1952-1956, 2002-2005); every cut decides "not split" and so does the final comparison whenever a cut
+// would have applied (the split's cost only grows child by child), so doing all four changes no decision -- and when the split loses,
+// the unsplit candidate is put back over whatever the children left, exactly as after a split that was tried and lost.  On low-QP
+// pictures of a low-delay GOP the leaves are 38 % of a CTU's time (profiles/r06_ctu_pb_phases.txt).
+template <typename PX> CTU_DEV void leaves_run(lds<PX> *S, const job<PX> &J)          // the leaf wave (or, one wave / host emulation, the walk itself)
+{
+  const params &P = J.P;
+  for (int k = 0; k < 4; ++k) {
+    LANE0 {
+      level_state &C = S->lvl[4];
+      const level_state &N = S->lvl[3];
+      C.x = N.x + (k & 1) * 4; C.y = N.y + (k >> 1) * 4; C.has_chroma = k == 3;
+    }
+    CTU_SYNC();
+    const level_state &C = S->lvl[4];
+    const int mode_type_parent = (int)((C.mode_type_tree >> (3 * 2)) & 3);
+    const int can_intra = mode_type_parent != 1 && P.depth_max >= 4;          // (an 8x8 area of a picture whose sides are multiples of 8 lies inside it)
+    if (can_intra) { PB_T0(); eval_cu(S, J, 4, 0); PB_T1(J.W, 15); }
+    else { SERIAL { S->lvl[4].cost = CTU_MAX_DOUBLE; S->lvl[4].type = CU_NOTSET; } CTU_SYNC(); }
+    LANE0 S->leaf_cost[k] = S->lvl[4].cost;
+    CTU_SYNC();
+  }
+}
+template <typename PX> CTU_DEV void post_leaves(lds<PX> *S, const job<PX> &J)
+{
+#if defined(__HIPCC__)
+  CTU_SYNC();
+  LANE0 mb_store(&S->req[0], S->req[0] + 1);
+#else
+  const int me = g_emul_wave;
+  g_emul_wave = 1;                      // host emulation: the leaf wave's work happens right here
+  leaves_run(S, J);
+  g_emul_wave = me;
+#endif
+}
+template <typename PX> CTU_DEV void wait_leaves(lds<PX> *S)
+{
+#if defined(__HIPCC__)
+  while (mb_load(&S->done[0]) != S->req[0]) __builtin_amdgcn_s_sleep(1);
+  CTU_SYNC();
+#endif
+}
+#if defined(__HIPCC__)
+template <typename PX> CTU_DEV void leaf_worker_loop(lds<PX> *S, const job<PX> &J)
+{
+  int seen = 0;
+  for (;;) {
+    int r;
+    while ((r = mb_load(&S->req[0])) == seen) __builtin_amdgcn_s_sleep(1);
+    if (r < 0) break;
+    seen = r;
+    CTU_SYNC();
+    leaves_run(S, J);
+    CTU_SYNC();
+    LANE0 mb_store(&S->done[0], r);
+  }
+}
+#endif
+
 // search_cu (search.c:1299-2221) of a P / B slice as a depth-first loop over the quad tree, in the reference's order
 template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
 {
@@ -1436,6 +1500,37 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
         N.type = CU_NOTSET; N.cost = CTU_MAX_DOUBLE; N.pending = 0;
       }
       CTU_SYNC();
+      if (n == 8 && S->leaf_wave && P.depth_max >= 4) {
+        // an 8x8 area with the leaf wave: its four 4x4 CUs go there now, the unsplit CU is evaluated here meanwhile
+        const bool will_eval = inside && (can_inter || can_intra);
+        if (will_eval) copy_models(S->work[L - 1], S->cur);
+        SERIAL {
+          double split_bits = 0;
+          split_flag_bits(S, P, S->cur, 1, x, y, x & 63, y & 63, n, 1, split_bits);
+          N.split_bits = split_bits;
+          N.split_cost = split_bits * P.lambda;
+          N.child = 0;
+          level_state &C = S->lvl[L + 1];
+          const int cond_infer = mode_type_parent == 0;
+          const uint32_t mode_type = cond_infer ? 2u : (uint32_t)mode_type_parent;
+          C.split_tree = N.split_tree | 1u << (L * 3);
+          C.mode_type_tree = N.mode_type_tree | mode_type << (L * 2);
+        }
+        post_leaves(S, J);
+        if (will_eval) eval_pb(S, J, L, can_inter, can_intra);
+        wait_leaves(S);
+        SERIAL {
+          const double factor = P.qp > 30 ? 1.1 : 1.075;
+          N.pending = N.split_bits * P.lambda + N.cost / factor > N.cost;          // pruned (search.c:1952-1956): the reference would not have tried the split
+          if (!N.pending)
+            for (int k = 0; k < 4; ++k) {
+              N.split_cost += S->leaf_cost[k];
+              if (N.split_cost > N.cost) break;                                      // (where the reference stops: the split has lost)
+            }
+        }
+        CTU_SYNC();
+        decide = true;
+      } else {
       if (inside && (can_inter || can_intra)) {
         copy_models(L == 0 ? Q.work0 : S->work[L - 1], S->cur);
         eval_pb(S, J, L, can_inter, can_intra);
@@ -1472,6 +1567,7 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
         if (L == 0 && ntype != CU_NOTSET) { PB_T0(); save64_pb(S, J); PB_T1(J.W, 10); }
         ++L;
         continue;
+      }
       }
     }
     if (!decide) {
@@ -1792,6 +1888,14 @@ template <typename PX> CTU_DEV void run_ctu_pb(lds<PX> *S, const job<PX> &J)
   if (BLK_TID == 0) { S->pb.mot = reinterpret_cast<icand::unit *>(J.W->pb_mot); S->pb.fl = J.W->pb_fl; }
   setup_waves(S, J.W);
   BLK_FOR(k, 4) S->wv[k].rq_root = 0;
+  if (BLK_TID == 0) {
+#if defined(__HIPCC__)
+    S->leaf_wave = BLK_NT > 64;           // the two-wave build
+#else
+    S->leaf_wave = g_emul_leafwave;
+#endif
+    S->vsel[1] = 0;                       // the leaf wave works on the 4x4 scratch (the walk's wave picks its scratch per depth)
+  }
   build_scans(S);
   BLK_SYNC();
   load_ctu(S, J);
@@ -1799,21 +1903,30 @@ template <typename PX> CTU_DEV void run_ctu_pb(lds<PX> *S, const job<PX> &J)
   BLK_FOR(e, 6144) J.coeff[e] = 0;
   BLK_SYNC();
   PB_T1(J.W, 11); }
-  search_ctu_pb(S, J);
-  PAR_FOR(i, NMODELS) J.models_out[NMODELS + i] = S->cur[i];
-  PAR_FOR(i, NMX - NMODELS) J.pbm_out[(NMX - NMODELS) + i] = S->cur[NMODELS + i];
+#if defined(__HIPCC__)
+  if (CTU_WAVE == 0) {
+#endif
+    search_ctu_pb(S, J);
+    PAR_FOR(i, NMODELS) J.models_out[NMODELS + i] = S->cur[i];
+    PAR_FOR(i, NMX - NMODELS) J.pbm_out[(NMX - NMODELS) + i] = S->cur[NMODELS + i];
+#if defined(__HIPCC__)
+    LANE0 { if (S->leaf_wave) mb_store(&S->req[0], -1); }
+  } else leaf_worker_loop(S, J);
+#endif
   BLK_SYNC();
   { PB_T0();
   store_ctu(S, J);
   store_ctu_pb(S, J);
   deblock_zeroes_unused_vectors(S, J);
   PB_T1(J.W, 12); }
-  LANE0 S->vsel[CTU_WAVE] = 3;
-  CTU_SYNC();
-  { PB_T0();
-  coder_pass_pb(S, J);
-  PB_T1(J.W, 13); }
-  LANE0 S->vsel[CTU_WAVE] = 0;
+  if (CTU_WAVE == 0) {
+    LANE0 S->vsel[CTU_WAVE] = 3;
+    CTU_SYNC();
+    { PB_T0();
+    coder_pass_pb(S, J);
+    PB_T1(J.W, 13); }
+    LANE0 S->vsel[CTU_WAVE] = 0;
+  }
   BLK_SYNC();
   BLK_FOR(i, NMODELS) J.models_out[2 * NMODELS + i] = S->coder[i];
   BLK_FOR(i, NMX - NMODELS) J.pbm_out[2 * (NMX - NMODELS) + i] = S->coder[NMODELS + i];
