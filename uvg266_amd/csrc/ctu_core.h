@@ -109,8 +109,13 @@
 
 // the 4x4 leaves of an I picture's CTU go through the register-resident formulation of ctu_leaf4.h (device builds; -DCTU_LEAF_OLD keeps
 // the general CU evaluation for them: the A/B build of tools/dev)
-#if defined(__HIPCC__) && !defined(CTU_PB) && !defined(CTU_LEAF_OLD)
+#if defined(__HIPCC__) && !defined(CTU_LEAF_OLD)
 #define CTU_LEAF4 1
+#endif
+// ... what the I-picture kernel builds on top of it (the 8x8 CU's chroma blocks and the 64x64 candidate's chroma on other waves, the
+// coder pass by 8x8 areas, the slim 10-bit image); the P / B kernel (ctu_pb.h) takes the 4x4 CU itself and the 4x4 bit count
+#if defined(CTU_LEAF4) && !defined(CTU_PB)
+#define CTU_LEAF4X 1
 #endif
 
 namespace ctu {
@@ -171,7 +176,7 @@ template <typename PX> struct lds_cfg { enum { slim = 0, slim_scan = 1 }; };
 #else
 template <typename PX> struct lds_cfg { enum { slim = 0, slim_scan = 0 }; };
 #endif
-#if defined(CTU_LEAF4) && !defined(CTU_NO_SLIM)
+#if defined(CTU_LEAF4X) && !defined(CTU_NO_SLIM)
 template <> struct lds_cfg<uint16_t> { enum { slim = 1, slim_scan = 1 }; };
 #endif
 template <typename PX, typename T, bool SLIM = (lds_cfg<PX>::slim != 0)> struct mg_ptr { typedef CTU_LDS T *type; };
@@ -307,6 +312,8 @@ template <typename PX> struct lds {
   int32_t lf_qbits[2], lf_q[2];                     // ... q_bits, quantiser scale
   int32_t lf_tag;
   PX lf_src[96];
+#endif
+#if defined(CTU_LEAF4X)
   // the 64x64 candidate's chroma, taken by depth 2's wave while the walk does the luma (eval_cu64): the request's chroma mode; per
   // 32x32 area the two flags, the two SSDs and the chroma part of the bit count
   int32_t j64, j64_mode;
@@ -2715,7 +2722,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
   const int mode = V->u_mode;
 #endif
   if (!to_cand) { SERIAL fill_cu(S, lx, ly, n, mode, mode, sep ? 2 : ilog2_dev(n) - 1, N.split_tree, cu_mtt(N.mode_type_tree, L)); CTU_SYNC(); }
-#if defined(CTU_LEAF4)
+#if defined(CTU_LEAF4X)
   if (n == 8 && !to_cand) leaf_load_area(S, J, lx, ly);          // (an 8x8 leaf: the walk's own wave)
 #endif
   // where the three blocks are reconstructed and where their levels go
@@ -2763,7 +2770,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
       continue;
     }
 #endif
-#if defined(CTU_LEAF4)
+#if defined(CTU_LEAF4X)
     if (c && n == 8) {
       // the 4x4 chroma blocks of an 8x8 CU: the register-resident block of ctu_leaf4.h (the area's source samples are in S->lf_src)
       CTU_T0();
@@ -2778,7 +2785,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu(lds<PX> *S, const job<P
                                  color == 0 ? ry : (color == 1 ? ru : rv), c ? rpc : rpy, color == 0 ? ky : (color == 1 ? ku : kv), c ? kpc : kpy, c ? area : n);
     cbf |= has << color;
   }
-#if defined(CTU_LEAF4)
+#if defined(CTU_LEAF4X)
   if (has_chroma && n != 8)
 #else
   if (has_chroma)
@@ -2848,6 +2855,9 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu4(lds<PX> *S, const job<
     V->cur = S->cur;
     cu4 *c = cu_at(S, lx, ly);                           // the CU's own entry is reset (search.c:1371-1388)
     c->type = CU_NOTSET; c->cbf = 0; c->luma_edges = 0; c->chroma_edges = 0; c->mode = 0; c->mode_chroma = 0; c->log2 = 2; c->log2_c = 2;
+#if defined(CTU_PB)
+    { const int u = ((ly >> 2) + 1) * 17 + (lx >> 2) + 1; S->pb.mot[u].type = CU_NOTSET; S->pb.fl[u][0] = 0; S->pb.fl[u][1] = 0; }
+#endif
   }
   LF_T0();
   leaf_load_area(S, J, lx, ly);
@@ -2862,6 +2872,9 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu4(lds<PX> *S, const job<
   LANE0 {          // lcu_fill_cu_info (search.c:314-353) for the one entry of a 4x4 CU
     cu4 *c = cu_at(S, lx, ly);
     c->type = CU_INTRA; c->log2 = 2; c->log2_c = 2; c->mode = (int8_t)mode; c->mode_chroma = (int8_t)mode;
+#if defined(CTU_PB)
+    { const int u = ((ly >> 2) + 1) * 17 + (lx >> 2) + 1; S->pb.mot[u].type = CU_INTRA; S->pb.fl[u][0] = 0; S->pb.fl[u][1] = 0; }   // (as fill_cu: what the neighbours' contexts read)
+#endif
     scratch *const W = S->scr;
     W->tree[(ly >> 2) * 16 + (lx >> 2)] = (uint16_t)N.split_tree;
     W->mtt[(ly >> 2) * 16 + (lx >> 2)] = (uint16_t)cu_mtt(N.mode_type_tree, 4);
@@ -2872,14 +2885,19 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu4(lds<PX> *S, const job<
   PX *const ru = S->Du + ((cly >> 1) + 1) * PC + (clx >> 1) + 1, *const rv = S->Dv + ((cly >> 1) + 1) * PC + (clx >> 1) + 1;
   int16_t *const ky = J.coeff + ly * LCU + lx;
   int16_t *const ku = J.coeff + 4096 + (cly >> 1) * LCU_C + (clx >> 1), *const kv = J.coeff + 5120 + (cly >> 1) * LCU_C + (clx >> 1);
+#if defined(CTU_PB)
+  const bool helped = false;              // (no chroma helper: the P / B CTU has no depth waves)
+#else
   const bool helped = has_chroma && help_post(S, J, cx, cy, mode);
 #if defined(CTU_PROFILE)
   if (has_chroma) { LANE0 J.W->prof[1][helped ? 19 : 20] += 1; }
+#endif
 #endif
   int ssd_y = 0, ssd_u = 0, ssd_v = 0, cbf = 0, lev_y = 0, lev_u = 0, lev_v = 0;
   { CTU_T0();
 #pragma nounroll
   for (int color = 0; color < (has_chroma ? 3 : 1); ++color) {          // ONE call site of the block function (see leaf_recon)
+#if !defined(CTU_PB)
     if (helped && color == 1) {
 #if defined(CTU_PROFILE)
       const unsigned long long tw = __builtin_amdgcn_s_memtime();
@@ -2892,6 +2910,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu4(lds<PX> *S, const job<
 #endif
       continue;
     }
+#endif
     const bool c = color != 0;
     const lf_block B = leaf_recon_inl(S, J, V, color, mode, color == 2 ? (cbf >> 1) & 1 : 0, c ? cx : x, c ? cy : y, c ? clx : lx, c ? cly : ly, c ? 8 : 4, c ? 0 : 1,
                                       color == 0 ? ry : (color == 1 ? ru : rv), c ? PC : PY, color == 0 ? ky : (color == 1 ? ku : kv), c ? LCU_C : LCU);
@@ -3681,7 +3700,7 @@ template <typename PX> CTU_DEV void setup_waves(lds<PX> *S, scratch *W = nullptr
     S->vsel[k] = k;
     S->req[k] = 0; S->done[k] = 0;
     if (k == 0) { S->hreq = 0; S->hdone = 0; }
-#if defined(CTU_LEAF4)
+#if defined(CTU_LEAF4X)
     if (k == 0) S->j64 = 0;
 #endif
   }

@@ -1415,7 +1415,11 @@ template <typename PX> CTU_DEV void leaves_run(lds<PX> *S, const job<PX> &J)    
     const level_state &C = S->lvl[4];
     const int mode_type_parent = (int)((C.mode_type_tree >> (3 * 2)) & 3);
     const int can_intra = mode_type_parent != 1 && P.depth_max >= 4;          // (an 8x8 area of a picture whose sides are multiples of 8 lies inside it)
+#if defined(CTU_LEAF4)
+    if (can_intra) { PB_T0(); eval_cu4(S, J); PB_T1(J.W, 15); }          // the register-resident 4x4 CU of ctu_leaf4.h (device builds)
+#else
     if (can_intra) { PB_T0(); eval_cu(S, J, 4, 0); PB_T1(J.W, 15); }
+#endif
     else { SERIAL { S->lvl[4].cost = CTU_MAX_DOUBLE; S->lvl[4].type = CU_NOTSET; } CTU_SYNC(); }
     LANE0 S->leaf_cost[k] = S->lvl[4].cost;
     CTU_SYNC();
@@ -1490,7 +1494,11 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
         // a 4x4 CU: intra only, nothing to split, no history entry
         if (can_intra) {
           PB_T0();
+#if defined(CTU_LEAF4)
+          eval_cu4(S, J);
+#else
           eval_cu(S, J, L, 0);
+#endif
           PB_T1(J.W, 15);
         } else { SERIAL { N.cost = CTU_MAX_DOUBLE; N.type = CU_NOTSET; } CTU_SYNC(); }
         ret = N.cost; entering = 0; --L; continue;
@@ -1887,6 +1895,9 @@ template <typename PX> CTU_DEV void run_ctu_pb(lds<PX> *S, const job<PX> &J)
   static_assert(sizeof(icand::unit) == 32, "scratch::pb_mot holds icand::unit as eight int32");
   if (BLK_TID == 0) { S->pb.mot = reinterpret_cast<icand::unit *>(J.W->pb_mot); S->pb.fl = J.W->pb_fl; }
   setup_waves(S, J.W);
+#if defined(CTU_LEAF4)
+  leaf_tables(S, J.P);
+#endif
   BLK_FOR(k, 4) S->wv[k].rq_root = 0;
   if (BLK_TID == 0) {
 #if defined(__HIPCC__)
