@@ -737,7 +737,7 @@ def ra_clip(device, frames=65, with_cpu=True):
     display = [int(a) for a in g["display"][:frames]]
     shown = {t: tuple(torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in Hh.clip_picture(W, H, t, depth)) for t in sorted(set(display))}
     src = [[shown[display[f]] for f in range(frames)]]
-    loop = api.LowDelayLoop(W, H, depth, 1, states, src, by_level=True)
+    loop = api.LowDelayLoop(W, H, depth, 1, states, src, inflight=True, inflight_margin=11)
     loop.run()                                            # warm-up (plans, first-touch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
