@@ -27,9 +27,13 @@ off = L.uvghip_ctu_search_pb_debug_times(npb, W, H)
 t = ws[off:off + npb * ctus * 32].cpu().numpy().view(np.uint64).reshape(npb, ctus, 4).astype(np.int64)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 np.savez_compressed(os.path.join(ROOT, "gpurun_out", "flight_times.npz"), t=t, frames=np.array(fr), qp=np.array([states[f]["qp"] for f in fr]))
-s = (t[:, :, 2] - t[:, :, 1]) / 1e5
+s = (t[:, :, 2] - t[:, :, 1]) / 1e5          # 100 MHz wall clock -> ms
 f = (t[:, :, 3] - t[:, :, 2]) / 1e5
 w = (t[:, :, 1] - t[:, :, 0]) / 1e5
+qps = np.array([states[f_]["qp"] for f_ in fr])
+for q in sorted(set(qps.tolist())):
+    m = s[qps == q]
+    print("qp %d: %d pictures, CTU search ms mean %.2f median %.2f p90 %.2f max %.2f" % (q, (qps == q).sum(), m.mean(), np.median(m), np.percentile(m, 90), m.max()))
 print("search ms: mean %.2f median %.2f p90 %.2f max %.2f | filters ms: mean %.3f max %.3f | wait ms: mean %.1f" % (s.mean(), np.median(s), np.percentile(s, 90), s.max(), f.mean(), f.max(), w.mean()))
 st = t[:, 0, 1]
 print("picture start-to-start ms:", np.round(np.diff(st) / 1e5, 1).tolist()[:40])

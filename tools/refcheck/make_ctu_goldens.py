@@ -509,3 +509,5 @@ if __name__ == "__main__":
     inter(136, 200, 8, 27, 11, extra=("owf", "1"), suffix="_owf1", clip=3)             # frames in flight: the vectors restricted to what is final in the reference picture; content that rises ever faster
     inter(136, 72, 8, 27, 5, extra=("rd", "1"), suffix="_rd1", clip=2)                 # --preset slow = medium + rd 1 (a P / B CU never skips its intra search on a low inter cost); plateau content
     inter(136, 72, 8, 27, 33, extra=("gop", "16", "period", "16"), suffix="_ra16p16", clip=True)      # three intra periods of an open GOP: CRA pictures at POC 16 and 32, RASL pictures behind them
+    if not os.environ.get("GOLDENS_SKIP_CLIP120"):      # (ten minutes and 4 GB of records by itself)
+        inter_crcs(1920, 1080, 8, 27, 120, extra=("owf", "1"), suffix="_owf1", clip=True)     # bench.py's c3_clip, picture by picture: BASELINE configs[2] as written, --owf 1 (frames in flight), crosses the second intra period at POC 64

@@ -42,7 +42,7 @@ struct pb_launch_args {
   // pictures in flight: the filter stage of every picture (NULL: search only, the pictures of the call are independent), its flags
   const ctuf::filt_pic *fpics;
   int32_t *sao_done, *final_done;   // [pic * ctus + cy * wc + cx]
-  unsigned long long *times;        // CTU_PROFILE builds: per CTU the s_memtime at ticket, start of the search, end of the search, end of the filters
+  unsigned long long *times;        // CTU_PROFILE builds: per CTU the wall clock (100 MHz, the same on every CU) at ticket, start of the search, end of the search, end of the filters
 };
 
 // four workgroups (= four waves: the kernel's registers allow one per SIMD) per CU at 8 bit: 160 KB / 4 incl. the 4288 bytes of static tables
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(NT) ctu_search_pb_kernel(pb_launch_args A)
     const int ticket = s_ticket;
     if (ticket >= A.n_ctus) break;
 #if defined(CTU_PROFILE)
-    const unsigned long long t_ticket = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_ticket = wall_clock64();
 #endif
     const int32_t o = A.order[ticket];
     const int pic = o >> 16, cy = (o >> 8) & 0xff, cx = o & 0xff;
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(NT) ctu_search_pb_kernel(pb_launch_args A)
     }
     __syncthreads();
 #if defined(CTU_PROFILE)
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_start = wall_clock64();
 #endif
     const pb_pic_dev &D = A.pics[pic];
     ctu::job<PX> J;
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(NT) ctu_search_pb_kernel(pb_launch_args A)
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&done[k], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #if defined(CTU_PROFILE)
-    const unsigned long long t_searched = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_searched = wall_clock64();
 #endif
     if (A.fpics) {
       // the CTU's in-loop filters while its right and lower neighbours search on (ctu_filter.h); the LDS image is free until the next CTU
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(NT) ctu_search_pb_kernel(pb_launch_args A)
 #if defined(CTU_PROFILE)
     if (threadIdx.x == 0) {
       unsigned long long *t = A.times + ((size_t)pic * ctus + k) * 4;
-      t[0] = t_ticket; t[1] = t_start; t[2] = t_searched; t[3] = __builtin_amdgcn_s_memtime();
+      t[0] = t_ticket; t[1] = t_start; t[2] = t_searched; t[3] = wall_clock64();
     }
 #endif
   }
@@ -257,7 +257,7 @@ extern "C" __attribute__((visibility("default"))) size_t uvghip_ctu_search_pb_de
   *slot_bytes = sizeof(ctu::scratch); *n_slots = L.n_slots;
   return L.scratch;
 }
-// ... and the per-CTU timestamps [picture][ctu][4] (uint64 s_memtime ticks: ticket taken, search started, search done, filters done)
+// ... and the per-CTU timestamps [picture][ctu][4] (uint64 ticks of the 100 MHz wall clock: ticket taken, search started, search done, filters done)
 extern "C" __attribute__((visibility("default"))) size_t uvghip_ctu_search_pb_debug_times(int n_pictures, int pic_w, int pic_h) { return layout(n_pictures, pic_w, pic_h).times; }
 #endif
 
