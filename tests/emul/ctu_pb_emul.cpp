@@ -72,3 +72,6 @@ int ctu_pb_emul_search_picture(int bitdepth, const ctu::params *P, const emul_fr
 
 // the two-wave build's order of work (ctu_pb.h post_leaves): the four 4x4 CUs of every 8x8 area before the area's unsplit CU, all four always
 extern "C" __attribute__((visibility("default"))) void ctu_pb_emul_set_leafwave(int on) { ctu::g_emul_leafwave = on; }
+// ... the three-wave build's: 32x32 / 16x16 CUs evaluated "on the depth wave" while the walk goes on into their children; lazy = their results
+// are withheld until the children are done (no cut is ever applied early)
+extern "C" __attribute__((visibility("default"))) void ctu_pb_emul_set_depthwave(int on, int lazy) { ctu::g_emul_depthwave = on; ctu::g_emul_lazy = lazy; }

@@ -1164,7 +1164,7 @@ INTER4_NP = np.dtype([("skipped", "u1"), ("merged", "u1"), ("merge_idx", "u1"), 
 _EMUL_PB = None
 
 
-def emul_search_inter_picture(depth, prm, F, y, u, v, leafwave=0):
+def emul_search_inter_picture(depth, prm, F, y, u, v, leafwave=0, depthwave=0, lazy=0):
     """tests/emul/ctu_pb_emul.cpp: the P / B CTU search kernel's source on the host -> the device-layout outputs as a dict.
     leafwave: the order of work of the two-wave build (the 4x4 CUs of an 8x8 area on the leaf wave, all four, beside the area's unsplit CU)."""
     global _EMUL_PB
@@ -1173,6 +1173,7 @@ def emul_search_inter_picture(depth, prm, F, y, u, v, leafwave=0):
         subprocess.check_call(["make", "-s", "-C", d])
         _EMUL_PB = ctypes.CDLL(os.path.join(d, "_build", "libctu_pb_emul.so"))
     _EMUL_PB.ctu_pb_emul_set_leafwave(int(leafwave))
+    _EMUL_PB.ctu_pb_emul_set_depthwave(int(depthwave), int(lazy))      # (the three-wave build's order of work; lazy: evaluations come in only when waited for)
     W, H = prm.pic_w, prm.pic_h
     wc, hc = (W + 63) // 64, (H + 63) // 64
     px = px_dtype(depth)

@@ -12,9 +12,13 @@ GOLDENS = ["ref_inter_136x72_10_qp22_4frames", "ref_inter_192x128_8_qp17_5frames
            "ref_inter_136x72_8_qp27_17frames_ra16", "ref_inter_136x72_10_qp22_17frames_ra16", "ref_inter_136x72_8_qp27_9frames_ra8", "ref_inter_136x200_8_qp27_11frames_owf1", "ref_inter_136x72_8_qp27_5frames_rd1", "ref_inter_136x72_8_qp27_33frames_ra16p16"]
 
 
-@pytest.mark.parametrize("leafwave", [0, 1])
+# (leaf wave, depth wave, lazy): one wave; two waves; three waves with every evaluation in at once / only when the walk waits for it
+BUILDS = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 1, 1)]
+
+
+@pytest.mark.parametrize("leafwave,depthwave,lazy", BUILDS)
 @pytest.mark.parametrize("name", GOLDENS)
-def test_emulated_pb_kernel_equals_the_reference_run(name, leafwave):
+def test_emulated_pb_kernel_equals_the_reference_run(name, leafwave, depthwave, lazy):
     """leafwave 1: the two-wave build's order of work -- the four 4x4 CUs of an 8x8 area are all evaluated, before the cost of the area's unsplit
     CU is known (on the device: beside it, on the second wave); the reference's cuts are re-applied afterwards (ctu_pb.h post_leaves)."""
     g = np.load(os.path.join(H.GOLDEN, name + ".npz"))
@@ -23,7 +27,7 @@ def test_emulated_pb_kernel_equals_the_reference_run(name, leafwave):
     for fr, d, prm, F, keep in H.iter_inter_frames(W, Hh, P):
         if int(d["meta"][6]) == 2:
             continue
-        r = H.emul_search_inter_picture(depth, prm, F, *pics[fr], leafwave=leafwave)
+        r = H.emul_search_inter_picture(depth, prm, F, *pics[fr], leafwave=leafwave, depthwave=depthwave, lazy=lazy)
         assert H.compare_device_inter_picture(W, Hh, d, r) == [], f"frame {fr}"
         n += 1
     assert n >= 3
@@ -41,6 +45,6 @@ def test_emulated_pb_kernel_equals_the_oracle_on_other_content(case):
     W, Hh, depth, pics, jobs = oracle_chain(case)
     assert jobs
     for f, fs, prm, F, keep, r in jobs:
-        for leafwave in (0, 1):
-            got = H.emul_search_inter_picture(depth, prm, F, *pics[f], leafwave=leafwave)
-            assert H.compare_device_inter_picture(W, Hh, oracle_as_record(r), got) == [], (CASES[case], "picture", f, "leafwave", leafwave)
+        for build in BUILDS:
+            got = H.emul_search_inter_picture(depth, prm, F, *pics[f], leafwave=build[0], depthwave=build[1], lazy=build[2])
+            assert H.compare_device_inter_picture(W, Hh, oracle_as_record(r), got) == [], (CASES[case], "picture", f, "build", build)

@@ -22,6 +22,7 @@
 // All RD arithmetic is IEEE double in the reference's operation order; compile with -ffp-contract=off.
 #pragma once
 #include <stdint.h>
+#include <stddef.h>
 #include <string.h>
 #include "intra_pred_dev.h"
 #if defined(__HIPCC__)
@@ -123,6 +124,7 @@ namespace ctu {
 #if !defined(__HIPCC__)
 static int g_emul_wave = 0;      // host emulation: which wave's scratch the code running now uses
 static int g_emul_lazy = 0;      // host emulation: pretend a CU's own cost is never known before all its children are done
+static int g_emul_depthwave = 0; // ... of its three-wave build: 32x32 / 16x16 CUs handed to the depth wave, the walk goes on into their children
 static int g_emul_leafwave = 0;  // host emulation of the P / B kernel's two-wave build: the four 4x4 CUs of an 8x8 area go to the leaf wave (ctu_pb.h)
 #endif
 
@@ -158,6 +160,7 @@ struct level_state {        // search_cu's locals, per depth
   int type, mode, cbf;      // the parked no-split candidate
   int has_chroma;           // carries the chroma of its area
   int pending;              // its unsplit evaluation was handed to the depth's wave
+  int evalp, known, can;    // P / B depth wave (ctu_pb.h): evaluation posted; its result has been taken; can_inter | can_intra << 1 of the request
   uint32_t split_tree, mode_type_tree;
 #if defined(CTU_PB)
   int32_t mot[8];           // the parked candidate's motion (icand::unit: type, mv[2][2], ref[2], dir)
@@ -254,6 +257,7 @@ struct pb_state {
   // workgroup per CU, and the tables are read a few entries per candidate list
   icand::unit *mot;
   uint8_t (*fl)[8];
+  const int32_t *hm;                   // the history table the evaluation in progress reads: the one at the entry of its node (hmvp_entry[L])
   int32_t hmvp[41];                    // the row's history table as the search sees it: [0] entries, then 5 units, most recent first
   int32_t hmvp_entry[4][41];           // ... at the entry of the node of each depth 0..3 (search_cu's hmvp_lut)
   int32_t hmvp_coder[41];              // ... as the real coder leaves it (what the next CTU of the row starts from)
@@ -325,8 +329,24 @@ template <typename PX> struct lds {
   // the leaf wave of the two-wave build (ctu_pb.h post_leaves): on / off, the costs of the four 4x4 CUs of the area it was handed
   int32_t leaf_wave;
   double leaf_cost[4];
+  // the three-wave build (ctu_pb.h): the wave that evaluates the 32x32 / 16x16 CUs ahead of the walk has its own search state (of `pb`
+  // it reads the shared tables only: mot, fl, hmvp_entry) and the 8x8 depth its own scratch; the one- and two-wave launches ask for
+  // the image up to here (pb_lds_bytes)
+  int32_t depth_wave, skip_eval[4];
+  pb_state pbx;
+  alignas(16) unsigned char arena8[arena_bytes(8)];
+  // ... and the 8x8 CU's batched merge analysis (ctu_pb.h merge_batch8) its own scratch: [candidate][list][15][8] intermediates, the
+  // predictions [candidate][64], the SATDs (the one-wave build borrows the 32x32 depth's transform buffers for them)
+  alignas(16) int16_t b8_tmp[6 * 2 * 120];
+  PX b8_pred[6 * 64];
+  int32_t b8_satd[8];
 #endif
 };
+#if defined(CTU_PB)
+template <typename PX> constexpr size_t pb_lds_bytes(int waves) { return waves >= 3 ? sizeof(lds<PX>) : offsetof(lds<PX>, pbx); }
+// the search state of the wave that asks (role 2: the depth wave)
+template <typename PX> CTU_DEV pb_state &pbq(lds<PX> *S) { return CTU_WAVE == 2 ? S->pbx : S->pb; }
+#endif
 template <typename PX> CTU_DEV wctx *wv_of(lds<PX> *S) { return &S->wv[S->vsel[CTU_WAVE]]; }
 
 // per-workgroup scratch in global memory
@@ -2299,7 +2319,7 @@ template <typename PX> CTU_DEV double coeff_bits4(lds<PX> *S, CTU_LDS uint32_t *
     CTU_LDS uint32_t *mk = m;
     if (!update) {
 #if defined(CTU_PB)
-      mk = LDSP(uint32_t, CTU_WAVE == 0 ? S->pb.cnt_models : S->pb.work0);      // (the leaf wave counts on the 64x64 candidate's set: idle once the walk is below depth 0)
+      mk = LDSP(uint32_t, CTU_WAVE == 0 ? S->pb.cnt_models : (CTU_WAVE == 1 ? S->pb.work0 : S->pbx.cnt_models));      // (the leaf wave counts on the 64x64 candidate's set: idle once the walk is below depth 0)
 #else
       mk = LDSP(uint32_t, S->work[2]);
 #endif
@@ -2514,7 +2534,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
       // counting only: these bins still adapt their models WITHIN the block (the reference counts on a copy) -- work on a copy
       // of the few models involved (work[0] is nobody's: depth 0 has no unsplit candidate of its own)
 #if defined(CTU_PB)
-      mk = (CTU_LDS uint32_t *)(CTU_WAVE == 0 ? S->pb.cnt_models : S->pb.work0);       // (every work[] set is some depth's here; the leaf wave: see coeff_bits)
+      mk = (CTU_LDS uint32_t *)(CTU_WAVE == 0 ? S->pb.cnt_models : (CTU_WAVE == 1 ? S->pb.work0 : S->pbx.cnt_models));       // (every work[] set is some depth's here; the leaf wave: see coeff_bits)
 #else
       mk = (CTU_LDS uint32_t *)S->work[CTU_WAVE == 0 ? 2 : 1];      // (the 64x64 candidate: the walk and depth 2's wave count at the same time)
 #endif
@@ -3676,6 +3696,10 @@ template <typename PX> CTU_DEV void setup_waves(lds<PX> *S, scratch *W = nullptr
     if (k == 0) off = arena_bytes(32);
 #endif
     unsigned char *a = S->arena + off;
+#if defined(CTU_PB)
+    if (k == 1 && BLK_NT > 128) a = S->arena8;             // (three waves: the walk evaluates 8x8 CUs while the depth wave is in the big region)
+#endif
+    unsigned char *const a0 = a;
     wctx *V = &S->wv[k];
     const int rn = 4 * n + 8;
     V->refn = (int16_t)rn;
@@ -3692,7 +3716,7 @@ template <typename PX> CTU_DEV void setup_waves(lds<PX> *S, scratch *W = nullptr
     {
     if (n >= 8) V->part = (uint32_t *)V->t0;
     else { V->part = (uint32_t *)a; a += 2 * 18 * tiles * 4; }
-    a = S->arena + ((a - S->arena + 7) & ~7);
+    a = a0 + ((a - a0 + 7) & ~7);
     if (n <= 8) { V->rq_cc = (double *)a; V->rq_cs = V->rq_cc + nn; }
     else V->rq_cc = V->rq_cs = nullptr;
     }

@@ -81,7 +81,7 @@ struct pb_col {
 template <typename PX> CTU_DEV pb_col col_of(lds<PX> *S, const job<PX> &J)
 {
   const pb_job &B = *J.pb;
-  pb_col c = {B.ref_cu[B.l_size[0] > 0 ? B.l[0][0] : 0], B.ref_cu_stride, (J.P.pic_w + 7) / 8, S->pb.colc, S->pb.colc_idx};
+  pb_col c = {B.ref_cu[B.l_size[0] > 0 ? B.l[0][0] : 0], B.ref_cu_stride, (J.P.pic_w + 7) / 8, pbq(S).colc, pbq(S).colc_idx};
   return c;
 }
 // The collocated picture's units a CU's temporal candidate can come from (temporal_unit, inter_cand_dev.h: below-right of the CU, else
@@ -90,7 +90,7 @@ template <typename PX> CTU_DEV pb_col col_of(lds<PX> *S, const job<PX> &J)
 template <typename PX> CTU_DEV void prefetch_col(lds<PX> *S, const job<PX> &J, int x, int y, int n)
 {
   const pb_job &B = *J.pb;
-  pb_state &Q = S->pb;
+  pb_state &Q = pbq(S);
   const int W = J.P.pic_w, H = J.P.pic_h, gw = (W + 7) / 8;
   const int xbr = x + n, ybr = y + n, xc = x + n / 2, yc = y + n / 2;
   const int i0 = (xbr < W && ybr < H && (ybr % 64) != 0) ? (ybr >> 3) * gw + (xbr >> 3) : -1;
@@ -396,8 +396,8 @@ template <typename PX> CTU_DEV int check_mv_cost(const me_info<PX> &I, int dx, i
 }
 template <typename PX> CTU_DEV bool mv_in_merge(lds<PX> *S, int mx, int my)
 {
-  for (int i = 0; i < S->pb.n_mc; ++i) {
-    const icand::merge_cand &c = S->pb.mc[i];
+  for (int i = 0; i < pbq(S).n_mc; ++i) {
+    const icand::merge_cand &c = pbq(S).mc[i];
     if (c.dir == 3) continue;
     const int l = c.dir - 1;
     if (c.mv[l][0] == mx * 16 && c.mv[l][1] == my * 16) return true;
@@ -410,8 +410,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void me_integer(lds<PX> *S, const me
   check_mv_cost(I, 0, 0, b);
   ex >>= 4; ey >>= 4;
   if ((ex != 0 || ey != 0) && !mv_in_merge(S, ex, ey)) check_mv_cost(I, ex, ey, b);
-  for (int i = 0; i < S->pb.n_mc; ++i) {
-    const icand::merge_cand &c = S->pb.mc[i];
+  for (int i = 0; i < pbq(S).n_mc; ++i) {
+    const icand::merge_cand &c = pbq(S).mc[i];
     if (c.dir == 3) continue;
     const int l = c.dir - 1;
     const int px = (c.mv[l][0] + 8) >> 4, py = (c.mv[l][1] + 8) >> 4;
@@ -552,16 +552,16 @@ template <typename PX> CTU_DEV cu_target<PX> target_of(lds<PX> *S, const job<PX>
 // the candidate lists of the CU at (x, y), n x n, through csrc/inter_cand_dev.h; lane 0
 template <typename PX> CTU_DEV void set_cand_ctx(lds<PX> *S, int x, int y, int n, uint32_t split_tree)
 {
-  S->pb.f.x = x; S->pb.f.y = y; S->pb.f.w = n; S->pb.f.h = n; S->pb.f.split_tree = split_tree;
+  { icand::frame_ctx &f = pbq(S).f; f.x = x; f.y = y; f.w = n; f.h = n; f.split_tree = split_tree; }
 }
 // (During a CU's evaluation nothing the derivation reads changes -- the history table is the search's at the CU's entry, the neighbours
 // only lose unused vectors -- so the predictors of a (list, reference index) are derived once per CU; the coder's calls, on its own
 // history table, are not cached.)
 template <typename PX> CTU_DEV void amvp_for(lds<PX> *S, const job<PX> &J, const int32_t *hmvp, int reflist, int ref0, int ref1, int32_t (*out)[2])
 {
-  pb_state &Q = S->pb;
+  pb_state &Q = pbq(S);
   const int ri = (reflist ? ref1 : ref0) & 7;
-  const bool cacheable = hmvp == Q.hmvp;
+  const bool cacheable = hmvp == Q.hm;
   if (cacheable && (Q.amvp_key[0] != Q.f.x || Q.amvp_key[1] != Q.f.y || Q.amvp_key[2] != Q.f.w)) {
     Q.amvp_key[0] = Q.f.x; Q.amvp_key[1] = Q.f.y; Q.amvp_key[2] = Q.f.w; Q.amvp_have[0] = Q.amvp_have[1] = 0;
   }
@@ -570,7 +570,7 @@ template <typename PX> CTU_DEV void amvp_for(lds<PX> *S, const job<PX> &J, const
     out[0][0] = c[0]; out[0][1] = c[1]; out[1][0] = c[2]; out[1][1] = c[3];
     return;
   }
-  pb_tab tab = {Q.mot};
+  pb_tab tab = {S->pb.mot};
   pb_col col = col_of(S, J);
   Q.ref_idx2[0] = ref0; Q.ref_idx2[1] = ref1;
   icand::amvp_candidates(Q.f, tab, col, hmvp, reflist, Q.ref_idx2, Q.out4, &Q.ws);
@@ -622,13 +622,14 @@ template <typename PX> CTU_NOINLINE CTU_DEV int quantize_inter(lds<PX> *S, const
 // columns, then each candidate's 8x8 SATD on a lane of its own.  Scratch: the 32x32 depth's transform buffers, idle while one wave walks
 // the CTU -- tmp [candidate][list][15 rows][8] int16, the predictions [candidate][64] behind the first list's intermediates.
 // Same arithmetic as ipol_passes<PX, 8, 8> / uvg_bipred_average.  -> S->wv[3].rq_i[c]: the SATD of candidate c; its samples stay in pred8(c)
-template <typename PX> CTU_DEV PX *pred8_of(lds<PX> *S, int c) { return (PX *)(S->wv[3].lv0 + 512) + c * 64; }
+template <typename PX> CTU_DEV PX *pred8_of(lds<PX> *S, int c) { return (S->depth_wave ? S->b8_pred : (PX *)(S->wv[3].lv0 + 512)) + c * 64; }
+template <typename PX> CTU_DEV int32_t *satd8_of(lds<PX> *S) { return S->depth_wave ? S->b8_satd : S->wv[3].rq_i; }
 template <typename PX> CTU_NOINLINE CTU_DEV void merge_batch8(lds<PX> *S, const job<PX> &J, int x, int y, int n_mc)
 {
   const pb_job &B = *J.pb;
-  pb_state &Q = S->pb;
-  wctx &K = S->wv[3];
-  CTU_LDS int16_t *const tmp = LDSP(int16_t, K.t0);
+  pb_state &Q = pbq(S);
+  CTU_LDS int16_t *const tmp = LDSP(int16_t, S->depth_wave ? S->b8_tmp : S->wv[3].t0);
+  int32_t *const satd_out = satd8_of(S);
   const int depth = (int)px_info<PX>::depth, shift1 = depth - 8;
   const int W = J.P.pic_w, H = J.P.pic_h;
   PAR_FOR(e, n_mc * 2 * 15) {
@@ -703,12 +704,12 @@ template <typename PX> CTU_NOINLINE CTU_DEV void merge_batch8(lds<PX> *S, const 
 #pragma unroll
       for (int q = 0; q < 4; ++q) d[r][q] = pk_sub(cp[q], (uint32_t)pred[r * 8 + 2 * q] | ((uint32_t)pred[r * 8 + 2 * q + 1] << 16));
     }
-    K.rq_i[c] = (int32_t)(satd8_tile_lane(d) >> (depth - 8));
+    satd_out[c] = (int32_t)(satd8_tile_lane(d) >> (depth - 8));
 #else
     int d[64];
     for (int r = 0; r < 8; ++r)
       for (int q = 0; q < 8; ++q) d[r * 8 + q] = (int)cur[(size_t)r * J.src_stride + q] - (int)pred[r * 8 + q];
-    K.rq_i[c] = (int32_t)(satd8_tile(d) >> (depth - 8));
+    satd_out[c] = (int32_t)(satd8_tile(d) >> (depth - 8));
 #endif
   }
   CTU_SYNC();
@@ -721,7 +722,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
   wctx *const V = wv_of(S);
   const params &P = J.P;
   const pb_job &B = *J.pb;
-  pb_state &Q = S->pb;
+  pb_state &Q = pbq(S);
   level_state &N = S->lvl[L];
   const int n = 64 >> L, x = N.x, y = N.y, lx = x & 63, ly = y & 63;
   CTU_LDS const uint32_t *const mdl = LDSP(const uint32_t, V->cur);
@@ -730,9 +731,9 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
   SERIAL {
     memset(&Q.cur, 0, sizeof Q.cur);                     // cur_pu: the CU's entry after search_cu's memset (type NOTSET)
     set_cand_ctx(S, x, y, n, N.split_tree);
-    pb_tab tab = {Q.mot};
+    pb_tab tab = {S->pb.mot};
     pb_col col = col_of(S, J);
-    Q.n_mc = icand::merge_candidates(Q.f, tab, col, Q.hmvp, Q.mc);
+    Q.n_mc = icand::merge_candidates(Q.f, tab, col, Q.hm, Q.mc);
     Q.merge_size = 0;
     for (int i = 0; i < 6; ++i) { Q.merge_keys[i] = -1; Q.merge[i].cost = CTU_MAX_DOUBLE; }
   }
@@ -754,7 +755,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
     // (candidates whose vectors reach beyond what is final in the reference picture are not tried, search_inter.c:1749-1757)
     if (((dir & 1) && !mv_within(B, x, y, n, Q.cur.m.mv[0][0], Q.cur.m.mv[0][1])) || ((dir & 2) && !mv_within(B, x, y, n, Q.cur.m.mv[1][0], Q.cur.m.mv[1][1])) || dup) continue;
     unsigned satd;
-    if (batch8) satd = (unsigned)S->wv[3].rq_i[merge_idx];
+    if (batch8) satd = (unsigned)satd8_of(S)[merge_idx];
     else {
       pred_cu(S, J, x, y, n, &Q.cur.m, 1, 0, T.ry, T.rpy, T.ru, T.rv, T.rpc);
       satd = satd_vs_source(J, x, y, n, T.ry, T.rpy);
@@ -816,7 +817,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
     { PB_T0();
     SERIAL {
       Q.cur.m.ref[ref_list] = LX_idx & 255;
-      amvp_for(S, J, Q.hmvp, ref_list, Q.cur.m.ref[0], Q.cur.m.ref[1], Q.mv_cand);
+      amvp_for(S, J, Q.hm, ref_list, Q.cur.m.ref[0], Q.cur.m.ref[1], Q.mv_cand);
     }
     CTU_SYNC();
     PB_T1(J.W, 0); }
@@ -900,7 +901,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
       for (int i = 0; i < n_best; ++i) {
         const int key = Q.amvp_keys[list][i];
         const int LX_idx = Q.amvp[list][key].m.ref[list];
-        SERIAL amvp_for(S, J, Q.hmvp, list, Q.amvp[list][key].m.ref[0], Q.amvp[list][key].m.ref[1], Q.mv_cand);
+        SERIAL amvp_for(S, J, Q.hm, list, Q.amvp[list][key].m.ref[0], Q.amvp[list][key].m.ref[1], Q.mv_cand);
         CTU_SYNC();
         me_info<PX> I;
         I.J = &J; I.ref_pic = B.l[list][LX_idx & 15]; I.x = x; I.y = y; I.n = n;
@@ -941,7 +942,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
         u.m.mv[1][0] = u1.m.mv[1][0]; u.m.mv[1][1] = u1.m.mv[1][1];
         u.merged = 0; u.skipped = 0;
         // (sic) the predictors of the LAST list fetched price both vectors (search_inter.c:2010-2036)
-        for (int reflist = 0; reflist < 2; reflist++) amvp_for(S, J, Q.hmvp, reflist, u.m.ref[0], u.m.ref[1], Q.mv_cand);
+        for (int reflist = 0; reflist < 2; reflist++) amvp_for(S, J, Q.hm, reflist, u.m.ref[0], u.m.ref[1], Q.mv_cand);
       }
       CTU_SYNC();
       pred_cu(S, J, x, y, n, &Q.amvp[2][0].m, 1, 0, T.ry, T.rpy, T.ru, T.rv, T.rpc);
@@ -987,7 +988,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
 // uvg_search_cu_inter (search_inter.c:2329-2406): the best of the maps becomes S->pb.cur; -> its cost (MAX_DOUBLE: none)
 template <typename PX> CTU_NOINLINE CTU_DEV double search_cu_inter(lds<PX> *S, const job<PX> &J, int L, const cu_target<PX> &T)
 {
-  pb_state &Q = S->pb;
+  pb_state &Q = pbq(S);
   if (search_pu_inter(S, J, L, T)) return Q.merge[0].cost;           // early skip: cost 0
   SERIAL {
     double inter_cost = CTU_MAX_DOUBLE;
@@ -1130,7 +1131,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void finish_inter(lds<PX> *S, const 
   wctx *const V = wv_of(S);
   const params &P = J.P;
   const pb_job &B = *J.pb;
-  pb_state &Q = S->pb;
+  pb_state &Q = pbq(S);
   level_state &N = S->lvl[L];
   const int n = 64 >> L, x = N.x, y = N.y, lx = x & 63, ly = y & 63;
   const int q = n > 32 ? 32 : n, ntu = n > 32 ? 4 : 1;
@@ -1175,7 +1176,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void finish_inter(lds<PX> *S, const 
     if (cu.skipped) merge_idx_bits(m, 1, B.max_merge, cu.merge_idx, bits);
     else {
       m_code(m, 1, MI_PRED_MODE + cp, 0, bits);
-      inter_pu_bits(S, J, m, 1, Q.cur, Q.hmvp, x, y, n, N.split_tree, bits);
+      inter_pu_bits(S, J, m, 1, Q.cur, Q.hm, x, y, n, N.split_tree, bits);
     }
     Q.d0 = bits * P.lambda;
   }
@@ -1247,13 +1248,13 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_pb(lds<PX> *S, const job<P
 {
   const params &P = J.P;
   const pb_job &B = *J.pb;
-  pb_state &Q = S->pb;
+  pb_state &Q = pbq(S);
   level_state &N = S->lvl[L];
   const int n = 64 >> L, x = N.x, y = N.y, lx = x & 63, ly = y & 63;
   LANE0 S->vsel[CTU_WAVE] = L == 0 ? 3 : 4 - L;
   CTU_SYNC();
   wctx *const V = wv_of(S);
-  LANE0 V->cur = L == 0 ? Q.work0 : S->work[L - 1];
+  LANE0 { V->cur = L == 0 ? S->pb.work0 : S->work[L - 1]; Q.hm = S->pb.hmvp_entry[L]; }
   CTU_SYNC();
   const cu_target<PX> T = target_of(S, J, L);
   double cost = CTU_MAX_DOUBLE;
@@ -1461,12 +1462,77 @@ template <typename PX> CTU_DEV void leaf_worker_loop(lds<PX> *S, const job<PX> &
 }
 #endif
 
+// ---- the depth wave (three-wave build: 192 threads per CTU) ------------------------------------------------------------------------
+// A 32x32 or 16x16 CU whose split will be tried needs only what is decided before it -- samples, side information, motion, the models
+// and the history table at its entry -- and writes only its depth's candidate buffers, its own copy of the models and lvl[L]: the
+// third wave evaluates it (eval_pb, on its own search state `pbx` and the big scratch region) while the walk goes on into the
+// children, as the I-picture kernel's depth waves do (ctu_core.h post_eval).  The reference evaluates the CU first and lets its cost cut
+// the split short: the pruning test (search.c:1952-1956) before the first child, the child-by-child comparison after each.  Both cuts
+// decide "not split", both are re-applied as soon as the evaluation is in -- after every child, and on the way into every node below
+// (a pruned ancestor ends the walk under it at once) -- and a split that was started in vain is undone exactly like one that was tried
+// and lost: the candidate is put back over the CU's whole area, models and history table restart from the node's entry.
+template <typename PX> CTU_DEV void post_eval_pb(lds<PX> *S, const job<PX> &J, int L)
+{
+#if defined(__HIPCC__)
+  CTU_SYNC();
+  LANE0 mb_store(&S->req[L], S->req[L] + 1);
+#else
+  const int me = g_emul_wave;
+  g_emul_wave = 2;                      // host emulation: the depth wave's work happens right here
+  eval_pb(S, J, L, S->lvl[L].can & 1, S->lvl[L].can >> 1);
+  g_emul_wave = me;
+  S->done[L] = ++S->req[L];
+#endif
+}
+template <typename PX> CTU_DEV bool eval_ready_pb(lds<PX> *S, int L)
+{
+#if defined(__HIPCC__)
+  return __builtin_amdgcn_readfirstlane(mb_load(&S->done[L]) == S->req[L]) != 0;
+#else
+  return !g_emul_lazy;
+#endif
+}
+template <typename PX> CTU_DEV void wait_eval_pb(lds<PX> *S, int L)
+{
+#if defined(__HIPCC__)
+  while (mb_load(&S->done[L]) != S->req[L]) __builtin_amdgcn_s_sleep(1);
+  CTU_SYNC();
+#endif
+}
+#if defined(__HIPCC__)
+template <typename PX> CTU_DEV void depth_worker_loop(lds<PX> *S, const job<PX> &J)
+{
+  int seen[3] = {0, 0, 0};
+  for (;;) {
+    const int r1 = mb_load(&S->req[1]), r2 = mb_load(&S->req[2]);
+    if (r1 < 0) break;
+    int L = 0, r = 0;
+    if (r2 != seen[2]) { L = 2; r = r2; }            // the deeper request first: the walk comes back for it sooner
+    else if (r1 != seen[1]) { L = 1; r = r1; }
+    if (!L) { __builtin_amdgcn_s_sleep(2); continue; }
+    seen[L] = r;
+    CTU_SYNC();
+    if (!mb_load(&S->skip_eval[L])) eval_pb(S, J, L, S->lvl[L].can & 1, S->lvl[L].can >> 1);
+    CTU_SYNC();
+    LANE0 mb_store(&S->done[L], r);
+  }
+}
+#endif
+// the pruning test of a node whose evaluation is in (search.c:1952-1956); lane 0
+template <typename PX> CTU_DEV void take_eval_pb(lds<PX> *S, const params &P, int L)
+{
+  level_state &N = S->lvl[L];
+  const double factor = P.qp > 30 ? 1.1 : 1.075;
+  N.known = 1;
+  N.pending = N.split_bits * P.lambda + N.cost / factor > N.cost;
+}
+
 // search_cu (search.c:1299-2221) of a P / B slice as a depth-first loop over the quad tree, in the reference's order
 template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
 {
   const params &P = J.P;
   const pb_job &B = *J.pb;
-  pb_state &Q = S->pb;
+  pb_state &Q = pbq(S);
   SERIAL {
     level_state &R = S->lvl[0];
     R.x = J.x; R.y = J.y; R.split_tree = 0; R.mode_type_tree = 0; R.has_chroma = 1; R.child = 0;
@@ -1490,6 +1556,40 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
                             ((L >= B.depth_inter_min && L <= B.depth_inter_max) || (x & ~(min_wi - 1)) + min_wi > P.pic_w || (y & ~(min_wi - 1)) + min_wi > P.pic_h);
       const int can_intra = inside && mode_type_parent != 1 &&
                             ((L >= P.depth_min && L <= P.depth_max) || (x & ~(min_w - 1)) + min_w > P.pic_w || (y & ~(min_w - 1)) + min_w > P.pic_h);
+      // a node under a CU whose evaluation has come in meanwhile and says "not split" (pruned, or the split already costs more): nothing
+      // below it is wanted any more -- back to that CU's decision
+      if (S->depth_wave && L >= 2) {
+        int A = 0;
+        for (int a = 1; a < L && !A; ++a) {
+          level_state &M = S->lvl[a];
+          if (!M.evalp) continue;
+          if (!M.known && eval_ready_pb(S, a)) { SERIAL take_eval_pb(S, P, a); CTU_SYNC(); }
+          if (M.known && (M.pending || M.split_cost > M.cost)) A = a;
+        }
+        if (A) {
+          for (int a = A + 1; a < L; ++a)
+            if (S->lvl[a].evalp && !S->lvl[a].known) {          // an evaluation of a node in between is still out: not wanted, but its buffers are in use
+#if defined(__HIPCC__)
+              LANE0 mb_store(&S->skip_eval[a], 1);
+              wait_eval_pb(S, a);
+              LANE0 mb_store(&S->skip_eval[a], 0);
+              CTU_SYNC();
+#endif
+            }
+          L = A;
+          level_state &M = S->lvl[L];
+          const int ntype = M.type;
+          CTU_SYNC();
+          copy_models(S->cur, S->work[L - 1]);
+          SERIAL { for (int i = 0; i < 41; ++i) S->pb.hmvp[i] = S->pb.hmvp_entry[L][i]; if (ntype == CU_INTER) hmvp_add(S->pb.hmvp, M.mot); }
+          CTU_SYNC();
+          if (ntype != CU_NOTSET) { PB_T0(); unpark_pb(S, J, L); PB_T1(J.W, 10); }
+          ret = M.cost;
+          entering = 0;
+          --L;
+          continue;
+        }
+      }
       if (n == 4) {
         // a 4x4 CU: intra only, nothing to split, no history entry
         if (can_intra) {
@@ -1504,10 +1604,33 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
         ret = N.cost; entering = 0; --L; continue;
       }
       SERIAL {
-        for (int i = 0; i < 41; ++i) Q.hmvp_entry[L][i] = Q.hmvp[i];
-        N.type = CU_NOTSET; N.cost = CTU_MAX_DOUBLE; N.pending = 0;
+        for (int i = 0; i < 41; ++i) S->pb.hmvp_entry[L][i] = S->pb.hmvp[i];
+        N.type = CU_NOTSET; N.cost = CTU_MAX_DOUBLE; N.pending = 0; N.evalp = 0; N.known = 1;
       }
       CTU_SYNC();
+      if (S->depth_wave && (L == 1 || L == 2) && P.depth_max >= 4) {
+        // a 32x32 / 16x16 CU with the depth wave: evaluated there from now on, the walk goes into the children
+        const bool will_eval = inside && (can_inter || can_intra);
+        if (will_eval) copy_models(S->work[L - 1], S->cur);
+        SERIAL {
+          double split_bits = 0;
+          split_flag_bits(S, P, S->cur, 1, x, y, x & 63, y & 63, n, 1, split_bits);
+          N.split_bits = split_bits;
+          N.split_cost = split_bits * P.lambda;
+          N.child = 0;
+          N.can = can_inter | can_intra << 1;
+          N.evalp = will_eval; N.known = !will_eval;
+          level_state &C = S->lvl[L + 1];
+          const uint32_t mode_type = (uint32_t)mode_type_parent;          // (MODE_TYPE_INFER only at n == 8)
+          C.split_tree = N.split_tree | 1u << (L * 3);
+          C.mode_type_tree = N.mode_type_tree | mode_type << (L * 2);
+          C.x = N.x; C.y = N.y; C.has_chroma = 1;
+        }
+        CTU_SYNC();
+        if (will_eval) post_eval_pb(S, J, L);
+        ++L;
+        continue;
+      }
       if (n == 8 && S->leaf_wave && P.depth_max >= 4) {
         // an 8x8 area with the leaf wave: its four 4x4 CUs go there now, the unsplit CU is evaluated here meanwhile
         const bool will_eval = inside && (can_inter || can_intra);
@@ -1540,7 +1663,7 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
         decide = true;
       } else {
       if (inside && (can_inter || can_intra)) {
-        copy_models(L == 0 ? Q.work0 : S->work[L - 1], S->cur);
+        copy_models(L == 0 ? S->pb.work0 : S->work[L - 1], S->cur);
         eval_pb(S, J, L, can_inter, can_intra);
       }
       const int ntype = N.type;
@@ -1549,7 +1672,7 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
       if (!can_split) {
         // (cannot happen with pu-depth-intra max = 4: every CU above 4x4 may split)
         if (L > 0) { copy_models(S->cur, S->work[L - 1]); if (ntype != CU_NOTSET) unpark_pb(S, J, L); }
-        SERIAL { if (ntype == CU_INTER) hmvp_add(Q.hmvp, N.mot); }        // (an intra CU adds nothing; N.mot is only the depth's last INTER candidate)
+        SERIAL { if (ntype == CU_INTER) hmvp_add(S->pb.hmvp, N.mot); }        // (an intra CU adds nothing; N.mot is only the depth's last INTER candidate)
         CTU_SYNC();
         ret = ncost; entering = 0; if (L == 0) break; --L; continue;
       }
@@ -1580,10 +1703,11 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
     }
     if (!decide) {
       // a child of N came back with `ret`
+      if (N.evalp && !N.known && eval_ready_pb(S, L)) { SERIAL take_eval_pb(S, P, L); CTU_SYNC(); }
       SERIAL {
         N.split_cost += ret;
         const int k = N.child;
-        V_flag(S) = N.split_cost > N.cost || k == 3;
+        V_flag(S) = (N.known && (N.pending || N.split_cost > N.cost)) || k == 3;
         N.child = k + 1;
         if (!V_flag(S)) {
           level_state &C = S->lvl[L + 1];
@@ -1594,6 +1718,7 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
       }
       CTU_SYNC();
       if (!V_flag(S)) { ++L; entering = 1; continue; }
+      if (N.evalp && !N.known) { wait_eval_pb(S, L); SERIAL take_eval_pb(S, P, L); CTU_SYNC(); }          // the CU's own cost is needed now
     }
     // the decision between the CU and its split
     const bool pruned = N.pending != 0;
@@ -1606,7 +1731,7 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
     } else {
       if (L > 0) {
         copy_models(S->cur, S->work[L - 1]);             // post_search_cabac
-        SERIAL { for (int i = 0; i < 41; ++i) Q.hmvp[i] = Q.hmvp_entry[L][i]; if (ntype == CU_INTER) hmvp_add(Q.hmvp, N.mot); }      // (uvg_hmvp_add_mv ignores an intra CU)
+        SERIAL { for (int i = 0; i < 41; ++i) S->pb.hmvp[i] = S->pb.hmvp_entry[L][i]; if (ntype == CU_INTER) hmvp_add(S->pb.hmvp, N.mot); }      // (uvg_hmvp_add_mv ignores an intra CU)
         CTU_SYNC();
         if (ntype != CU_NOTSET) { PB_T0(); unpark_pb(S, J, L); PB_T1(J.W, 10); }
       } else if (!pruned && ntype != CU_NOTSET) { PB_T0(); restore64_pb(S, J); PB_T1(J.W, 10); }
@@ -1624,12 +1749,12 @@ template <typename PX> CTU_NOINLINE CTU_DEV void load_ctu_pb(lds<PX> *S, const j
 {
   const params &P = J.P;
   const pb_job &B = *J.pb;
-  pb_state &Q = S->pb;
+  
   const int x = J.x, y = J.y, W = P.pic_w, H = P.pic_h;
   BLK_FOR(i, 17 * 17 + 1) {
-    icand::unit &m = Q.mot[i];
+    icand::unit &m = S->pb.mot[i];
     m.type = 0; m.mv[0][0] = m.mv[0][1] = m.mv[1][0] = m.mv[1][1] = 0; m.ref[0] = m.ref[1] = 0; m.dir = 0;
-    if (i < 17 * 17) for (int k = 0; k < 8; ++k) Q.fl[i][k] = 0;
+    if (i < 17 * 17) for (int k = 0; k < 8; ++k) S->pb.fl[i][k] = 0;
   }
   BLK_SYNC();
   BLK_FOR(i, 33) {
@@ -1642,23 +1767,25 @@ template <typename PX> CTU_NOINLINE CTU_DEV void load_ctu_pb(lds<PX> *S, const j
       const uvghip_scu_t *s = &J.cu_tab[at];
       const uvghip_inter4_t *f = &B.inter4[at];
       const int u = u_idx(ax - x, ay - y);
-      icand::unit &m = Q.mot[u];
+      icand::unit &m = S->pb.mot[u];
       m.type = s->type;
       if (s->type == CU_INTER) {
         m.mv[0][0] = s->mv[0][0]; m.mv[0][1] = s->mv[0][1]; m.mv[1][0] = s->mv[1][0]; m.mv[1][1] = s->mv[1][1];
         m.ref[0] = f->mv_ref0; m.ref[1] = f->mv_ref1; m.dir = s->mv_dir;
-        Q.fl[u][0] = f->skipped; Q.fl[u][1] = f->merged; Q.fl[u][2] = f->merge_idx; Q.fl[u][3] = f->root_cbf; Q.fl[u][4] = f->mv_cand0; Q.fl[u][5] = f->mv_cand1;
-        Q.fl[u][6] = f->mv_ref0; Q.fl[u][7] = f->mv_ref1;
+        S->pb.fl[u][0] = f->skipped; S->pb.fl[u][1] = f->merged; S->pb.fl[u][2] = f->merge_idx; S->pb.fl[u][3] = f->root_cbf; S->pb.fl[u][4] = f->mv_cand0; S->pb.fl[u][5] = f->mv_cand1;
+        S->pb.fl[u][6] = f->mv_ref0; S->pb.fl[u][7] = f->mv_ref1;
       }
     }
   }
   BLK_FOR(i, 41) {
     const int32_t v = J.x > 0 ? B.hmvp_rows[(size_t)(y >> 6) * 41 + i] : 0;       // the row's table starts empty (encoderstate.c:1021-1028)
-    Q.hmvp[i] = v; Q.hmvp_coder[i] = v;
+    S->pb.hmvp[i] = v; S->pb.hmvp_coder[i] = v;
   }
-  if (BLK_TID == 0) {
+  if (BLK_TID == 0) for (int inst = 0; inst < (S->depth_wave ? 2 : 1); ++inst) {          // the walk's search state and the depth wave's
+    pb_state &Q = inst == 0 ? S->pb : S->pbx;
     Q.amvp_key[0] = Q.amvp_key[1] = Q.amvp_key[2] = -1; Q.amvp_have[0] = Q.amvp_have[1] = 0;
     Q.colc_idx[0] = Q.colc_idx[1] = -1;
+    Q.hm = S->pb.hmvp;
     icand::frame_ctx &f = Q.f;
     f.x = f.y = f.w = f.h = 0;
     f.poc = B.poc; f.is_b = B.slice_type == 0; f.pic_w = W; f.pic_h = H;
@@ -1677,16 +1804,16 @@ template <typename PX> CTU_NOINLINE CTU_DEV void store_ctu_pb(lds<PX> *S, const 
 {
   const params &P = J.P;
   const pb_job &B = *J.pb;
-  pb_state &Q = S->pb;
+  pb_state &Q = pbq(S);
   const int x = J.x, y = J.y, W = P.pic_w, H = P.pic_h;
   BLK_FOR(e, 256) {
     const int lx = (e & 15) * 4, ly = (e >> 4) * 4;
     if (x + lx < W && y + ly < H) {
       const size_t at = (size_t)((y + ly) >> 2) * J.cu_stride + ((x + lx) >> 2);
       const int u = u_idx(lx, ly);
-      const icand::unit &m = Q.mot[u];
+      const icand::unit &m = S->pb.mot[u];
       uvghip_inter4_t f;
-      f.skipped = Q.fl[u][0]; f.merged = Q.fl[u][1]; f.merge_idx = Q.fl[u][2]; f.root_cbf = Q.fl[u][3]; f.mv_cand0 = Q.fl[u][4]; f.mv_cand1 = Q.fl[u][5];
+      f.skipped = S->pb.fl[u][0]; f.merged = S->pb.fl[u][1]; f.merge_idx = S->pb.fl[u][2]; f.root_cbf = S->pb.fl[u][3]; f.mv_cand0 = S->pb.fl[u][4]; f.mv_cand1 = S->pb.fl[u][5];
       f.mv_ref0 = (uint8_t)m.ref[0]; f.mv_ref1 = (uint8_t)m.ref[1];
       if (cu_at(S, lx, ly)->type == CU_INTER) {
         uvghip_scu_t *s = &J.cu_tab[at];
@@ -1778,7 +1905,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass_pb(lds<PX> *S, const
   wctx *const V = wv_of(S);
   const params &P = J.P;
   const pb_job &B = *J.pb;
-  pb_state &Q = S->pb;
+  pb_state &Q = pbq(S);
   for (int z = 0; z < 256; ++z) {
     const int lx = z_to_x(z) * 4, ly = z_to_x(z >> 1) * 4;
     const int x = J.x + lx, y = J.y + ly;
@@ -1791,7 +1918,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass_pb(lds<PX> *S, const
     const int sep = n == 4, last4 = sep && (lx & 4) && (ly & 4);
     const int L = 6 - c->log2;
     const int mode_type_curr = (int)((CTU_GLOAD(&J.W->mtt[(ly >> 2) * 16 + (lx >> 2)]) >> (L * 2)) & 3);
-    const int skipped = is_inter && Q.fl[u0][0];
+    const int skipped = is_inter && S->pb.fl[u0][0];
     CTU_SYNC();
     // ---- the CU's header ----
     LANE0 {
@@ -1806,18 +1933,18 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass_pb(lds<PX> *S, const
       pb_flag_ctx(S, x, y, lx, ly, &cs, &cp);
       if (n != 4 && mode_type_curr != 2) m_code(m, 1, MI_SKIP + cs, skipped, dummy);
       if (skipped) {
-        hmvp_add(Q.hmvp_coder, (const int32_t *)&Q.mot[u0]);
-        merge_idx_bits(m, 1, B.max_merge, Q.fl[u0][2], dummy);
+        hmvp_add(S->pb.hmvp_coder, (const int32_t *)&S->pb.mot[u0]);
+        merge_idx_bits(m, 1, B.max_merge, S->pb.fl[u0][2], dummy);
       } else {
         if (n != 4 && mode_type_curr == 0) m_code(m, 1, MI_PRED_MODE + cp, !is_inter, dummy);
         if (is_inter) {
           pb_cand &k = Q.cur;                     // (free after the search)
-          k.m = Q.mot[u0];
-          k.skipped = 0; k.merged = Q.fl[u0][1]; k.merge_idx = Q.fl[u0][2]; k.cand0 = Q.fl[u0][4]; k.cand1 = Q.fl[u0][5];
+          k.m = S->pb.mot[u0];
+          k.skipped = 0; k.merged = S->pb.fl[u0][1]; k.merge_idx = S->pb.fl[u0][2]; k.cand0 = S->pb.fl[u0][4]; k.cand1 = S->pb.fl[u0][5];
           const uint32_t tree = CTU_GLOAD(&J.W->tree[(ly >> 2) * 16 + (lx >> 2)]);
-          inter_pu_bits(S, J, m, 1, k, Q.hmvp_coder, x, y, n, tree, dummy);
-          hmvp_add(Q.hmvp_coder, (const int32_t *)&Q.mot[u0]);
-          const int has_coeffs = Q.fl[u0][3] || c->cbf;
+          inter_pu_bits(S, J, m, 1, k, S->pb.hmvp_coder, x, y, n, tree, dummy);
+          hmvp_add(S->pb.hmvp_coder, (const int32_t *)&S->pb.mot[u0]);
+          const int has_coeffs = S->pb.fl[u0][3] || c->cbf;
           if (!k.merged) m_code(m, 1, M_ROOT_CBF, has_coeffs, dummy);
         } else {
           luma_mode_bits(S, S->coder, 1, x, y, lx, ly, n, c->mode, dummy);
@@ -1827,7 +1954,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass_pb(lds<PX> *S, const
     }
     CTU_SYNC();
     if (skipped) continue;
-    if (is_inter && !(Q.fl[u0][3] || c->cbf)) continue;
+    if (is_inter && !(S->pb.fl[u0][3] || c->cbf)) continue;
     // ---- the transform units ----
     const int tus = n == 64 ? 4 : 1, tn = n == 64 ? 32 : n;
     for (int tu = 0; tu < tus; ++tu) {
@@ -1906,6 +2033,12 @@ template <typename PX> CTU_DEV void run_ctu_pb(lds<PX> *S, const job<PX> &J)
     S->leaf_wave = g_emul_leafwave;
 #endif
     S->vsel[1] = 0;                       // the leaf wave works on the 4x4 scratch (the walk's wave picks its scratch per depth)
+#if defined(__HIPCC__)
+    S->depth_wave = BLK_NT > 128;         // the three-wave build
+#else
+    S->depth_wave = g_emul_depthwave;
+#endif
+    for (int k = 0; k < 4; ++k) S->skip_eval[k] = 0;
   }
   build_scans(S);
   BLK_SYNC();
@@ -1921,8 +2054,9 @@ template <typename PX> CTU_DEV void run_ctu_pb(lds<PX> *S, const job<PX> &J)
     PAR_FOR(i, NMODELS) J.models_out[NMODELS + i] = S->cur[i];
     PAR_FOR(i, NMX - NMODELS) J.pbm_out[(NMX - NMODELS) + i] = S->cur[NMODELS + i];
 #if defined(__HIPCC__)
-    LANE0 { if (S->leaf_wave) mb_store(&S->req[0], -1); }
-  } else leaf_worker_loop(S, J);
+    LANE0 { if (S->leaf_wave) mb_store(&S->req[0], -1); if (S->depth_wave) mb_store(&S->req[1], -1); }
+  } else if (CTU_WAVE == 1) leaf_worker_loop(S, J);
+  else depth_worker_loop(S, J);
 #endif
   BLK_SYNC();
   { PB_T0();

@@ -46,11 +46,12 @@ struct pb_launch_args {
 };
 
 // four workgroups (= four waves: the kernel's registers allow one per SIMD) per CU at 8 bit: 160 KB / 4 incl. the 4288 bytes of static tables
-static_assert(sizeof(ctu::lds<uint8_t>) + 4288 <= 40960, "the 8-bit LDS image of a P / B CTU no longer fits four workgroups per CU");
+static_assert(ctu::pb_lds_bytes<uint8_t>(1) + 4288 <= 40960, "the 8-bit LDS image of a P / B CTU no longer fits four workgroups per CU");
 // NT = 64: one wave walks the CTU (four workgroups per CU: many independent pictures side by side).  NT = 128: the walk's wave + the leaf
 // wave that takes the 4x4 CUs of every 8x8 area (ctu_pb.h post_leaves) -- a shorter CTU for pictures in flight behind each other, where
 // the CTU's latency, not the device's occupancy, sets the pace.
-static_assert(sizeof(ctuf::filt_lds<uint8_t>) <= sizeof(ctu::lds<uint8_t>) && sizeof(ctuf::filt_lds<uint16_t>) <= sizeof(ctu::lds<uint16_t>), "the filter job works inside the CTU's LDS image");
+static_assert(sizeof(ctuf::filt_lds<uint8_t>) <= ctu::pb_lds_bytes<uint8_t>(1) && sizeof(ctuf::filt_lds<uint16_t>) <= ctu::pb_lds_bytes<uint16_t>(1), "the filter job works inside the CTU's LDS image");
+// NT = 192: ... + the depth wave that evaluates the 32x32 / 16x16 CUs while the walk is in their children (ctu_pb.h post_eval_pb).
 template <typename PX, int NT>
 __global__ void __launch_bounds__(NT) ctu_search_pb_kernel(pb_launch_args A)
 {
@@ -59,7 +60,7 @@ __global__ void __launch_bounds__(NT) ctu_search_pb_kernel(pb_launch_args A)
   __shared__ int s_ticket;
   __shared__ int s_slot;
 #if defined(CTU_POISON_LDS)
-  for (unsigned i = threadIdx.x; i < sizeof(ctu::lds<PX>); i += NT) smem[i] = (unsigned char)(CTU_POISON_LDS);
+  for (unsigned i = threadIdx.x; i < ctu::pb_lds_bytes<PX>(NT / 64); i += NT) smem[i] = (unsigned char)(CTU_POISON_LDS);
   __syncthreads();
 #endif
   // a scratch slot for the workgroup's lifetime
@@ -392,26 +393,30 @@ int search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictu
   A.sao_done = reinterpret_cast<int32_t *>(ws + L.sao_done);
   A.final_done = reinterpret_cast<int32_t *>(ws + L.final_done);
   A.times = reinterpret_cast<unsigned long long *>(ws + L.times);
-  const size_t lds = bitdepth == 8 ? sizeof(ctu::lds<uint8_t>) : sizeof(ctu::lds<uint16_t>);
-  // pictures in flight: two waves per CTU (UVGHIP_PB_WAVES=1 / 2 overrides, development)
-  int waves = filters ? 2 : 1;
-  if (const char *e = getenv("UVGHIP_PB_WAVES")) waves = e[0] == '2' ? 2 : 1;
-  const void *fn = bitdepth == 8 ? (waves == 2 ? reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint8_t, 128>) : reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint8_t, 64>))
-                                 : (waves == 2 ? reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint16_t, 128>) : reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint16_t, 64>));
-  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // pictures in flight: three waves per CTU (UVGHIP_PB_WAVES=1 / 2 / 3 overrides, development)
+  int waves = filters ? 3 : 1;
+  if (const char *e = getenv("UVGHIP_PB_WAVES")) waves = e[0] == '3' ? 3 : (e[0] == '2' ? 2 : 1);
+  const size_t lds = bitdepth == 8 ? ctu::pb_lds_bytes<uint8_t>(waves) : ctu::pb_lds_bytes<uint16_t>(waves);
+  const void *fn8[3] = {reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint8_t, 64>), reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint8_t, 128>),
+                        reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint8_t, 192>)};
+  const void *fn10[3] = {reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint16_t, 64>), reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint16_t, 128>),
+                         reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint16_t, 192>)};
+  const hipError_t e = hipFuncSetAttribute(bitdepth == 8 ? fn8[waves - 1] : fn10[waves - 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return uvghip_set_error(e, "uvghip_ctu_search_pb: dynamic LDS size");
   // workgroups: twice the CTUs a picture's wavefront can have in progress (the widest diagonal of cx + 2 cy), per picture.  Pictures in
   // flight behind each other: a picture follows its reference LAG diagonals later, so a chain holds a picture's CTUs / LAG in progress
   // whatever its length -- a device's worth of workgroups is plenty (the rest would only wait)
   const int width = (wc + 1) / 2 < hc ? (wc + 1) / 2 : hc;
   long long want = 2LL * width * n_pictures;
-  if (filters && want > 1024 / waves) want = 1024 / waves;
+  if (filters && want > (waves == 3 ? 256 : 1024 / waves)) want = waves == 3 ? 256 : 1024 / waves;
   const int grid = (int)(want < total ? want : total);
   if (bitdepth == 8) {
-    if (waves == 2) hipLaunchKernelGGL((ctu_search_pb_kernel<uint8_t, 128>), dim3(grid), dim3(128), lds, st, A);
+    if (waves == 3) hipLaunchKernelGGL((ctu_search_pb_kernel<uint8_t, 192>), dim3(grid), dim3(192), lds, st, A);
+    else if (waves == 2) hipLaunchKernelGGL((ctu_search_pb_kernel<uint8_t, 128>), dim3(grid), dim3(128), lds, st, A);
     else hipLaunchKernelGGL((ctu_search_pb_kernel<uint8_t, 64>), dim3(grid), dim3(64), lds, st, A);
   } else {
-    if (waves == 2) hipLaunchKernelGGL((ctu_search_pb_kernel<uint16_t, 128>), dim3(grid), dim3(128), lds, st, A);
+    if (waves == 3) hipLaunchKernelGGL((ctu_search_pb_kernel<uint16_t, 192>), dim3(grid), dim3(192), lds, st, A);
+    else if (waves == 2) hipLaunchKernelGGL((ctu_search_pb_kernel<uint16_t, 128>), dim3(grid), dim3(128), lds, st, A);
     else hipLaunchKernelGGL((ctu_search_pb_kernel<uint16_t, 64>), dim3(grid), dim3(64), lds, st, A);
   }
   UVGHIP_CHECK_LAUNCH();
