@@ -12,8 +12,8 @@ GOLDENS = ["ref_inter_136x72_10_qp22_4frames", "ref_inter_192x128_8_qp17_5frames
            "ref_inter_136x72_8_qp27_17frames_ra16", "ref_inter_136x72_10_qp22_17frames_ra16", "ref_inter_136x72_8_qp27_9frames_ra8", "ref_inter_136x200_8_qp27_11frames_owf1", "ref_inter_136x72_8_qp27_5frames_rd1", "ref_inter_136x72_8_qp27_33frames_ra16p16"]
 
 
-# (leaf wave, depth wave, lazy): one wave; two waves; three waves with every evaluation in at once / only when the walk waits for it
-BUILDS = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 1, 1)]
+# (leaf wave, depth waves, lazy): one wave; two waves; three waves with every evaluation in at once / only when the walk waits for it; four waves
+BUILDS = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 1, 1), (1, 2, 1)]
 
 
 @pytest.mark.parametrize("leafwave,depthwave,lazy", BUILDS)

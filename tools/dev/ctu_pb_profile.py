@@ -29,14 +29,15 @@ print(f"{n_seq} x {frames} pictures {W}x{Hh}: {time.time() - t:.2f} s")
 L.uvghip_ctu_search_pb_debug_scratch.restype = ctypes.c_size_t
 sb, ns = ctypes.c_size_t(), ctypes.c_int()
 names = ["candidate lists", "merge analysis", "early skip test", "integer ME", "fractional ME", "bi-prediction", "intra rough + chroma trial", "inter CU: pred + residual",
-         "inter CU: bits + cost", "intra CU (eval_cu)", "unpark / save64 / restore64", "load", "store + deblock side effect", "coder pass", "TOTAL", "4x4 leaves"]
+         "inter CU: bits + cost", "intra CU (eval_cu)", "unpark / save64 / restore64", "load", "store + deblock side effect", "coder pass", "TOTAL", "4x4 leaves (inside the leaf wave's time)",
+         "walk waits for the leaf wave", "walk waits for the depth wave", "aborts (count)", "depth wave: 16x16 evals", "depth wave: 32x32 evals", "leaf wave busy", "-", "-"]
 for f, step in enumerate(loop.steps):
     if step[0] != "PB":
         continue
     ws = step[2].cpu().numpy()
     off = L.uvghip_ctu_search_pb_debug_scratch(n_seq, W, Hh, ctypes.byref(sb), ctypes.byref(ns))
     SZ = sb.value
-    prof = np.stack([ws[off + i * SZ + SZ - 1024 - 256: off + i * SZ + SZ - 1024 - 128].view(np.uint64) for i in range(ns.value)]).astype(np.float64)
+    prof = np.stack([ws[off + i * SZ + SZ - 1024 - 128 - 192: off + i * SZ + SZ - 1024 - 128].view(np.uint64) for i in range(ns.value)]).astype(np.float64)
     prof = prof[prof[:, 14] > 0]
     tot = prof[:, 14].mean()
     print(f"picture {f}: {len(prof)} slots, mean cycles per CTU {tot:.0f} ({tot / 1e5:.2f} ms at 100 MHz s_memtime)")

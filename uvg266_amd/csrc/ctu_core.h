@@ -340,12 +340,16 @@ template <typename PX> struct lds {
   alignas(16) int16_t b8_tmp[6 * 2 * 120];
   PX b8_pred[6 * 64];
   int32_t b8_satd[8];
+  double leaf_limit;                   // the leaf wave stops when the costs of its 4x4 CUs exceed it (the walk lowers it when the 8x8 CU's cost is in)
+  // the four-wave build: 32x32 CUs on a wave of their own (search state and, for the 16x16 depth, scratch)
+  pb_state pbx2;
+  alignas(16) unsigned char arena16[arena_bytes(16)];
 #endif
 };
 #if defined(CTU_PB)
-template <typename PX> constexpr size_t pb_lds_bytes(int waves) { return waves >= 3 ? sizeof(lds<PX>) : offsetof(lds<PX>, pbx); }
-// the search state of the wave that asks (role 2: the depth wave)
-template <typename PX> CTU_DEV pb_state &pbq(lds<PX> *S) { return CTU_WAVE == 2 ? S->pbx : S->pb; }
+template <typename PX> constexpr size_t pb_lds_bytes(int waves) { return waves >= 4 ? sizeof(lds<PX>) : (waves == 3 ? offsetof(lds<PX>, pbx2) : offsetof(lds<PX>, pbx)); }
+// the search state of the wave that asks (roles 2, 3: the depth waves)
+template <typename PX> CTU_DEV pb_state &pbq(lds<PX> *S) { const int r = CTU_WAVE; return r == 2 ? S->pbx : (r == 3 ? S->pbx2 : S->pb); }
 #endif
 template <typename PX> CTU_DEV wctx *wv_of(lds<PX> *S) { return &S->wv[S->vsel[CTU_WAVE]]; }
 
@@ -369,7 +373,7 @@ struct scratch {
   uint8_t pb_fl[17 * 17][8];
 #endif
 #if defined(CTU_PB)
-  unsigned long long prof_pb[16];     // CTU_PROFILE, ctu_pb.h: cycles of the phases of the P / B walk (lane 0 of the wave)
+  unsigned long long prof_pb[24];     // CTU_PROFILE, ctu_pb.h: cycles of the phases of the P / B walk (lane 0 of the wave); 16.. : waits of the walk, the other waves' busy time
 #endif
   unsigned long long prof_lf[16];     // CTU_PROFILE, ctu_leaf4.h: cycles of the 4x4 leaf's steps (the walk's wave)
   unsigned long long prof[4][32];     // CTU_PROFILE: 0 rough search, 1 refs + prediction, 2 residual + transforms + reconstruction, 3 RDOQ, 4 SSD,
@@ -2319,7 +2323,7 @@ template <typename PX> CTU_DEV double coeff_bits4(lds<PX> *S, CTU_LDS uint32_t *
     CTU_LDS uint32_t *mk = m;
     if (!update) {
 #if defined(CTU_PB)
-      mk = LDSP(uint32_t, CTU_WAVE == 0 ? S->pb.cnt_models : (CTU_WAVE == 1 ? S->pb.work0 : S->pbx.cnt_models));      // (the leaf wave counts on the 64x64 candidate's set: idle once the walk is below depth 0)
+      mk = LDSP(uint32_t, CTU_WAVE == 0 ? S->pb.cnt_models : (CTU_WAVE == 1 ? S->pb.work0 : pbq(S).cnt_models));      // (the leaf wave counts on the 64x64 candidate's set: idle once the walk is below depth 0)
 #else
       mk = LDSP(uint32_t, S->work[2]);
 #endif
@@ -2534,7 +2538,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
       // counting only: these bins still adapt their models WITHIN the block (the reference counts on a copy) -- work on a copy
       // of the few models involved (work[0] is nobody's: depth 0 has no unsplit candidate of its own)
 #if defined(CTU_PB)
-      mk = (CTU_LDS uint32_t *)(CTU_WAVE == 0 ? S->pb.cnt_models : (CTU_WAVE == 1 ? S->pb.work0 : S->pbx.cnt_models));       // (every work[] set is some depth's here; the leaf wave: see coeff_bits)
+      mk = (CTU_LDS uint32_t *)(CTU_WAVE == 0 ? S->pb.cnt_models : (CTU_WAVE == 1 ? S->pb.work0 : pbq(S).cnt_models));       // (every work[] set is some depth's here; the leaf wave: see coeff_bits)
 #else
       mk = (CTU_LDS uint32_t *)S->work[CTU_WAVE == 0 ? 2 : 1];      // (the 64x64 candidate: the walk and depth 2's wave count at the same time)
 #endif
@@ -3698,6 +3702,7 @@ template <typename PX> CTU_DEV void setup_waves(lds<PX> *S, scratch *W = nullptr
     unsigned char *a = S->arena + off;
 #if defined(CTU_PB)
     if (k == 1 && BLK_NT > 128) a = S->arena8;             // (three waves: the walk evaluates 8x8 CUs while the depth wave is in the big region)
+    if (k == 2 && BLK_NT > 192) a = S->arena16;            // (four waves: 16x16 and 32x32 CUs on a wave each)
 #endif
     unsigned char *const a0 = a;
     wctx *V = &S->wv[k];

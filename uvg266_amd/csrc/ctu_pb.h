@@ -1413,6 +1413,15 @@ template <typename PX> CTU_DEV void leaves_run(lds<PX> *S, const job<PX> &J)    
       C.x = N.x + (k & 1) * 4; C.y = N.y + (k >> 1) * 4; C.has_chroma = k == 3;
     }
     CTU_SYNC();
+#if defined(__HIPCC__)
+    // the walk has the 8x8 CU's cost by now and the split is already beaten (or was pruned): the rest is not wanted
+    if (k > 0 && S->leaf_wave) {
+      double sum = 0;
+      for (int j = 0; j < k; ++j) sum += S->leaf_cost[j];
+      const double lim = __hip_atomic_load(&S->leaf_limit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (sum > lim) { LANE0 { for (int j = k; j < 4; ++j) S->leaf_cost[j] = CTU_MAX_DOUBLE; } CTU_SYNC(); break; }
+    }
+#endif
     const level_state &C = S->lvl[4];
     const int mode_type_parent = (int)((C.mode_type_tree >> (3 * 2)) & 3);
     const int can_intra = mode_type_parent != 1 && P.depth_max >= 4;          // (an 8x8 area of a picture whose sides are multiples of 8 lies inside it)
@@ -1455,7 +1464,9 @@ template <typename PX> CTU_DEV void leaf_worker_loop(lds<PX> *S, const job<PX> &
     if (r < 0) break;
     seen = r;
     CTU_SYNC();
+    { PB_T0();
     leaves_run(S, J);
+    PB_T1(J.W, 21); }
     CTU_SYNC();
     LANE0 mb_store(&S->done[0], r);
   }
@@ -1478,7 +1489,7 @@ template <typename PX> CTU_DEV void post_eval_pb(lds<PX> *S, const job<PX> &J, i
   LANE0 mb_store(&S->req[L], S->req[L] + 1);
 #else
   const int me = g_emul_wave;
-  g_emul_wave = 2;                      // host emulation: the depth wave's work happens right here
+  g_emul_wave = S->depth_wave == 2 && L == 1 ? 3 : 2;                      // host emulation: the depth wave's work happens right here
   eval_pb(S, J, L, S->lvl[L].can & 1, S->lvl[L].can >> 1);
   g_emul_wave = me;
   S->done[L] = ++S->req[L];
@@ -1503,16 +1514,21 @@ template <typename PX> CTU_DEV void wait_eval_pb(lds<PX> *S, int L)
 template <typename PX> CTU_DEV void depth_worker_loop(lds<PX> *S, const job<PX> &J)
 {
   int seen[3] = {0, 0, 0};
+  // one depth wave (three-wave build): both depths; two: role 2 the 16x16 CUs, role 3 the 32x32 CUs
+  const int role = CTU_WAVE, two = S->depth_wave == 2;
+  const bool mine1 = !two || role == 3, mine2 = !two || role == 2;
   for (;;) {
     const int r1 = mb_load(&S->req[1]), r2 = mb_load(&S->req[2]);
     if (r1 < 0) break;
     int L = 0, r = 0;
-    if (r2 != seen[2]) { L = 2; r = r2; }            // the deeper request first: the walk comes back for it sooner
-    else if (r1 != seen[1]) { L = 1; r = r1; }
+    if (mine2 && r2 != seen[2]) { L = 2; r = r2; }            // the deeper request first: the walk comes back for it sooner
+    else if (mine1 && r1 != seen[1]) { L = 1; r = r1; }
     if (!L) { __builtin_amdgcn_s_sleep(2); continue; }
     seen[L] = r;
     CTU_SYNC();
+    { PB_T0();
     if (!mb_load(&S->skip_eval[L])) eval_pb(S, J, L, S->lvl[L].can & 1, S->lvl[L].can >> 1);
+    PB_T1(J.W, 19 + (L == 1)); }
     CTU_SYNC();
     LANE0 mb_store(&S->done[L], r);
   }
@@ -1577,6 +1593,9 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
 #endif
             }
           L = A;
+#if defined(__HIPCC__) && defined(CTU_PROFILE)
+          LANE0 J.W->prof_pb[18] += 1;
+#endif
           level_state &M = S->lvl[L];
           const int ntype = M.type;
           CTU_SYNC();
@@ -1647,9 +1666,18 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
           C.split_tree = N.split_tree | 1u << (L * 3);
           C.mode_type_tree = N.mode_type_tree | mode_type << (L * 2);
         }
+        LANE0 S->leaf_limit = CTU_MAX_DOUBLE;
         post_leaves(S, J);
         if (will_eval) eval_pb(S, J, L, can_inter, can_intra);
-        wait_leaves(S);
+#if defined(__HIPCC__)
+        // the CU's cost is in: what the split may cost at most before it has lost (pruned: nothing) -- the leaf wave stops there
+        LANE0 {
+          const double factor = P.qp > 30 ? 1.1 : 1.075;
+          const bool pruned = N.split_bits * P.lambda + N.cost / factor > N.cost;
+          __hip_atomic_store(&S->leaf_limit, pruned ? -1.0 : N.cost - N.split_bits * P.lambda, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#endif
+        { PB_T0(); wait_leaves(S); PB_T1(J.W, 16); }
         SERIAL {
           const double factor = P.qp > 30 ? 1.1 : 1.075;
           N.pending = N.split_bits * P.lambda + N.cost / factor > N.cost;          // pruned (search.c:1952-1956): the reference would not have tried the split
@@ -1718,7 +1746,7 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
       }
       CTU_SYNC();
       if (!V_flag(S)) { ++L; entering = 1; continue; }
-      if (N.evalp && !N.known) { wait_eval_pb(S, L); SERIAL take_eval_pb(S, P, L); CTU_SYNC(); }          // the CU's own cost is needed now
+      if (N.evalp && !N.known) { PB_T0(); wait_eval_pb(S, L); PB_T1(J.W, 17); SERIAL take_eval_pb(S, P, L); CTU_SYNC(); }          // the CU's own cost is needed now
     }
     // the decision between the CU and its split
     const bool pruned = N.pending != 0;
@@ -1781,8 +1809,8 @@ template <typename PX> CTU_NOINLINE CTU_DEV void load_ctu_pb(lds<PX> *S, const j
     const int32_t v = J.x > 0 ? B.hmvp_rows[(size_t)(y >> 6) * 41 + i] : 0;       // the row's table starts empty (encoderstate.c:1021-1028)
     S->pb.hmvp[i] = v; S->pb.hmvp_coder[i] = v;
   }
-  if (BLK_TID == 0) for (int inst = 0; inst < (S->depth_wave ? 2 : 1); ++inst) {          // the walk's search state and the depth wave's
-    pb_state &Q = inst == 0 ? S->pb : S->pbx;
+  if (BLK_TID == 0) for (int inst = 0; inst < 1 + S->depth_wave; ++inst) {          // the walk's search state and the depth waves'
+    pb_state &Q = inst == 0 ? S->pb : (inst == 1 ? S->pbx : S->pbx2);
     Q.amvp_key[0] = Q.amvp_key[1] = Q.amvp_key[2] = -1; Q.amvp_have[0] = Q.amvp_have[1] = 0;
     Q.colc_idx[0] = Q.colc_idx[1] = -1;
     Q.hm = S->pb.hmvp;
@@ -2013,7 +2041,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass_pb(lds<PX> *S, const
 template <typename PX> CTU_DEV void run_ctu_pb(lds<PX> *S, const job<PX> &J)
 {
 #if defined(__HIPCC__) && defined(CTU_PROFILE)
-  BLK_FOR(i, 16) J.W->prof_pb[i] = 0;
+  BLK_FOR(i, 24) J.W->prof_pb[i] = 0;
   BLK_FOR(i, 4 * 32) J.W->prof[i >> 5][i & 31] = 0;
   S->prof_w = J.W;
 #endif
@@ -2034,7 +2062,7 @@ template <typename PX> CTU_DEV void run_ctu_pb(lds<PX> *S, const job<PX> &J)
 #endif
     S->vsel[1] = 0;                       // the leaf wave works on the 4x4 scratch (the walk's wave picks its scratch per depth)
 #if defined(__HIPCC__)
-    S->depth_wave = BLK_NT > 128;         // the three-wave build
+    S->depth_wave = BLK_NT > 192 ? 2 : (BLK_NT > 128 ? 1 : 0);         // the three- / four-wave build
 #else
     S->depth_wave = g_emul_depthwave;
 #endif

@@ -52,6 +52,7 @@ static_assert(ctu::pb_lds_bytes<uint8_t>(1) + 4288 <= 40960, "the 8-bit LDS imag
 // the CTU's latency, not the device's occupancy, sets the pace.
 static_assert(sizeof(ctuf::filt_lds<uint8_t>) <= ctu::pb_lds_bytes<uint8_t>(1) && sizeof(ctuf::filt_lds<uint16_t>) <= ctu::pb_lds_bytes<uint16_t>(1), "the filter job works inside the CTU's LDS image");
 // NT = 192: ... + the depth wave that evaluates the 32x32 / 16x16 CUs while the walk is in their children (ctu_pb.h post_eval_pb).
+// NT = 256: ... two depth waves, one for the 16x16 CUs and one for the 32x32 CUs -- a CU, four SIMDs, one CTU.
 template <typename PX, int NT>
 __global__ void __launch_bounds__(NT) ctu_search_pb_kernel(pb_launch_args A)
 {
@@ -394,13 +395,13 @@ int search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictu
   A.final_done = reinterpret_cast<int32_t *>(ws + L.final_done);
   A.times = reinterpret_cast<unsigned long long *>(ws + L.times);
   // pictures in flight: three waves per CTU (UVGHIP_PB_WAVES=1 / 2 / 3 overrides, development)
-  int waves = filters ? 3 : 1;
-  if (const char *e = getenv("UVGHIP_PB_WAVES")) waves = e[0] == '3' ? 3 : (e[0] == '2' ? 2 : 1);
+  int waves = filters ? 4 : 1;
+  if (const char *e = getenv("UVGHIP_PB_WAVES")) waves = e[0] >= '1' && e[0] <= '4' ? e[0] - '0' : waves;
   const size_t lds = bitdepth == 8 ? ctu::pb_lds_bytes<uint8_t>(waves) : ctu::pb_lds_bytes<uint16_t>(waves);
-  const void *fn8[3] = {reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint8_t, 64>), reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint8_t, 128>),
-                        reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint8_t, 192>)};
-  const void *fn10[3] = {reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint16_t, 64>), reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint16_t, 128>),
-                         reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint16_t, 192>)};
+  const void *fn8[4] = {reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint8_t, 64>), reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint8_t, 128>),
+                        reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint8_t, 192>), reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint8_t, 256>)};
+  const void *fn10[4] = {reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint16_t, 64>), reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint16_t, 128>),
+                         reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint16_t, 192>), reinterpret_cast<const void *>(&ctu_search_pb_kernel<uint16_t, 256>)};
   const hipError_t e = hipFuncSetAttribute(bitdepth == 8 ? fn8[waves - 1] : fn10[waves - 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return uvghip_set_error(e, "uvghip_ctu_search_pb: dynamic LDS size");
   // workgroups: twice the CTUs a picture's wavefront can have in progress (the widest diagonal of cx + 2 cy), per picture.  Pictures in
@@ -408,14 +409,16 @@ int search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictu
   // whatever its length -- a device's worth of workgroups is plenty (the rest would only wait)
   const int width = (wc + 1) / 2 < hc ? (wc + 1) / 2 : hc;
   long long want = 2LL * width * n_pictures;
-  if (filters && want > (waves == 3 ? 256 : 1024 / waves)) want = waves == 3 ? 256 : 1024 / waves;
+  if (filters && want > (waves >= 3 ? 256 : 1024 / waves)) want = waves >= 3 ? 256 : 1024 / waves;
   const int grid = (int)(want < total ? want : total);
   if (bitdepth == 8) {
-    if (waves == 3) hipLaunchKernelGGL((ctu_search_pb_kernel<uint8_t, 192>), dim3(grid), dim3(192), lds, st, A);
+    if (waves == 4) hipLaunchKernelGGL((ctu_search_pb_kernel<uint8_t, 256>), dim3(grid), dim3(256), lds, st, A);
+    else if (waves == 3) hipLaunchKernelGGL((ctu_search_pb_kernel<uint8_t, 192>), dim3(grid), dim3(192), lds, st, A);
     else if (waves == 2) hipLaunchKernelGGL((ctu_search_pb_kernel<uint8_t, 128>), dim3(grid), dim3(128), lds, st, A);
     else hipLaunchKernelGGL((ctu_search_pb_kernel<uint8_t, 64>), dim3(grid), dim3(64), lds, st, A);
   } else {
-    if (waves == 3) hipLaunchKernelGGL((ctu_search_pb_kernel<uint16_t, 192>), dim3(grid), dim3(192), lds, st, A);
+    if (waves == 4) hipLaunchKernelGGL((ctu_search_pb_kernel<uint16_t, 256>), dim3(grid), dim3(256), lds, st, A);
+    else if (waves == 3) hipLaunchKernelGGL((ctu_search_pb_kernel<uint16_t, 192>), dim3(grid), dim3(192), lds, st, A);
     else if (waves == 2) hipLaunchKernelGGL((ctu_search_pb_kernel<uint16_t, 128>), dim3(grid), dim3(128), lds, st, A);
     else hipLaunchKernelGGL((ctu_search_pb_kernel<uint16_t, 64>), dim3(grid), dim3(64), lds, st, A);
   }
