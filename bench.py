@@ -478,6 +478,50 @@ def c2_clip(wl, device, frames=60, reps=2):
                     "the NAL units are written per picture (checksum kernel, row download, host assembly)"}
 
 
+def c4_clip(device, frames=60, with_cpu=True):
+    """The 60-picture 3840x2160 10-bit clip of BASELINE configs[3]'s geometry, all-intra (-p 1 --preset medium at the bench's QP; the P / B
+    + ALF combination of configs[3] as written is not built: DESIGN.md section 7), host memory to `.266` bytes in host memory as c2_clip:
+    once as ONE uvghip_loop_plan_run over the 60 pictures, once as TWO plans of 30 on two streams (the second launch's thin first
+    diagonals overlap the first one's drain).  The reference encoder's CLI (oracle/_ref/uvg266_10, host cores) on the same clip beside it."""
+    wl = WORKLOADS["2160p10alf"]
+    W, H, depth = wl["W"], wl["H"], wl["depth"]
+    P = api.ctu_params(W, H, QP)
+    host = [tuple(torch.from_numpy(np.ascontiguousarray(p)).pin_memory() for p in layout.synthetic_yuv420(W, H, t, depth)) for t in range(frames)]
+    src = [tuple(torch.empty_like(p, device=device) for p in yuv) for yuv in host]
+    res = {}
+    for n_groups in (1, 2):
+        per = frames // n_groups
+        loops = [api.ClosedLoop(P, src[g * per:(g + 1) * per]) for g in range(n_groups)]
+        streams = [torch.cuda.Stream() for _ in range(n_groups)]
+        best, nbytes = None, 0
+        for _ in range(2):                        # the first pass is the warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for g, (cs, st) in enumerate(zip(loops, streams)):
+                with torch.cuda.stream(st):
+                    for yuv, dst in zip(host[g * per:(g + 1) * per], src[g * per:(g + 1) * per]):
+                        for p, d in zip(yuv, dst):
+                            d.copy_(p, non_blocking=True)
+                    cs.run(st.cuda_stream)
+            out = []
+            for g, (cs, st) in enumerate(zip(loops, streams)):
+                with torch.cuda.stream(st):
+                    out += [cs.picture_nals(i, g * per + i) for i in range(per)]
+            dt = time.perf_counter() - t0
+            nbytes = sum(len(b) for b in out)
+            best = dt if best is None or dt < best else best
+        res[f"{n_groups}_launch" + ("es" if n_groups > 1 else "")] = {"value": round(frames / best, 2), "wall_ms": round(1e3 * best, 1), "bytes_out": int(nbytes)}
+        del loops
+    out = {"value": max(v["value"] for v in res.values()), "unit": "frames/s (one 60-picture 2160p 10-bit all-intra clip, host memory to .266 bytes in host memory)",
+           "frames": frames, "variants": res, "upload_mb": round(frames * W * H * 1.5 * 2 / 1e6, 1),
+           "workload": f"{W}x{H} {depth}-bit yuv420p, -p 1 --preset medium at QP {QP}, {frames} pictures: upload -> closed-loop CTU search -> deblocking -> SAO -> arithmetic coder -> "
+                       "per picture checksum, row download, NAL assembly",
+           "note": "the latency of ONE clip: a 2160p picture has 93 diagonals of at most 34 CTUs, 60 pictures keep the 1024 workgroup slots busy only in the middle of the launch"}
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline_reference(wl, frames=frames)
+    return out
+
+
 def parity_check(group, golden):
     """Picture 0 of a group AFTER the timed region -- the buffers hold what its last timed pass wrote, with the other group's launch
     sharing the device -- against the record of the real encoder's run on the same picture (tests/golden/<golden>.npz, data only):
@@ -1085,6 +1129,8 @@ def main():
     ap.add_argument("--c3-clip-frames", type=int, default=120, help="extra_workloads.c3_clip: pictures of the ONE 120-picture low-delay clip that are timed (0: skip; 120: the whole clip)")
     ap.add_argument("--only-c3-clip", action="store_true", help="time only extra_workloads.c3_clip and print it (development)")
     ap.add_argument("--ra-clip-frames", type=int, default=65, help="extra_workloads.ra_clip: coded pictures of the ONE random-access (--gop 16) clip that are timed (0: skip)")
+    ap.add_argument("--no-c4-clip", dest="c4_clip", action="store_false", help="skip extra_workloads.c4_clip (the 60-picture 2160p 10-bit clip and its CPU baseline)")
+    ap.add_argument("--only-c4-clip", action="store_true", help="time only extra_workloads.c4_clip and print it (development)")
     ap.add_argument("--only-2160p", action="store_true", help="time only extra_workloads.2160p10_closed_loop (with its ALF stage) and print it (development)")
     ap.add_argument("--only-ra-clip", action="store_true", help="time only extra_workloads.ra_clip and print it (development)")
     ap.add_argument("--c3-sequences", type=int, default=96, help="extra_workloads.c3_low_delay_closed_loop: independent low-delay sequences side by side")
@@ -1122,6 +1168,9 @@ def main():
         if alf_t and alf_t.get("parity_checked"):
             out["value_with_alf_stage"] = round(ek * eF / (eel + ek * alf_t["ms_per_group"] * 1e-3), 3)
         print(json.dumps({"2160p10_closed_loop": out}), flush=True)
+        return
+    if args.only_c4_clip:
+        print(json.dumps({"c4_clip": c4_clip(device, with_cpu=not args.no_cpu_baseline)}), flush=True)
         return
     if args.only_ra_clip:
         print(json.dumps({"ra_clip": ra_clip(device, frames=args.ra_clip_frames or 65, with_cpu=not args.no_cpu_baseline)}), flush=True)
@@ -1167,7 +1216,7 @@ def main():
             extra["alf_stage"] = alf_t
         if alf_t is not None and "ms_per_group" in alf_t and alf_t.get("parity_checked"):
             extra["value_with_alf_stage"] = round(ek * eF * world / (eel + ek * alf_t["ms_per_group"] * 1e-3), 3)        # (sequential: nothing of the stage overlaps the loop)
-    c3 = c3_loop = clip = c3_one = ra_one = None
+    c3 = c3_loop = clip = c3_one = ra_one = c4_one = None
     if not args.no_extra and wl_name == "1080p8" and rank == 0:
         def side(fn, *a, **k):          # a side workload must not take the judged line down with it
             try:
@@ -1177,6 +1226,7 @@ def main():
         clip = side(c2_clip, wl, device)
         c3 = side(inter_hot_path, device)
         c3_loop = side(low_delay_closed_loop, device, n_seq=args.c3_sequences)
+        c4_one = side(c4_clip, device, with_cpu=not args.no_cpu_baseline) if args.c4_clip else None
         c3_one = side(c3_clip, device, frames=args.c3_clip_frames, with_cpu=not args.no_cpu_baseline) if args.c3_clip_frames > 0 else None
         ra_one = side(ra_clip, device, frames=args.ra_clip_frames, with_cpu=not args.no_cpu_baseline) if args.ra_clip_frames > 0 else None
     open_loop = None
@@ -1245,6 +1295,8 @@ def main():
                 out.setdefault("extra_workloads", {})["ra_clip"] = ra_one
             if clip is not None:
                 out.setdefault("extra_workloads", {})["c2_clip"] = clip
+            if c4_one is not None:
+                out.setdefault("extra_workloads", {})["c4_clip"] = c4_one
             if open_loop is not None:
                 out["open_loop"] = open_loop
             if row_sharded is not None:
