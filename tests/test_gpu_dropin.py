@@ -53,12 +53,12 @@ def clip(tmp_path_factory):
     return d, str(p)
 
 
-def encode(binary, yuv, out, env_extra, extra=(), threads=4):
+def encode(binary, yuv, out, env_extra, extra=(), threads=4, args=None):
     env = dict(os.environ)
     for k in [k for k in env if k.startswith("UVG266_")]:
         del env[k]
     env.update(env_extra)
-    r = subprocess.run([binary, "-i", yuv, "-o", out, "--threads", str(threads)] + ARGS + list(extra), env=env, capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([binary, "-i", yuv, "-o", out, "--threads", str(threads)] + (ARGS if args is None else list(args)) + list(extra), env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     return hashlib.md5(open(out, "rb").read()).hexdigest(), r.stderr
 
@@ -120,3 +120,45 @@ def test_without_a_request_the_backend_stays_out(clip, generic_md5):
     md5, err = encode(need(os.path.join(REF, "uvg266_8_hip")), yuv, str(d / "hip_off.266"), {})
     assert "hip" not in set(chosen(err).values())
     assert md5 == generic_md5
+
+
+def _small_clip(d, name, w, h, frames, depth):
+    import sys
+    sys.path.insert(0, ROOT)
+    from uvg266_amd import layout
+    p = d / name
+    with open(p, "wb") as f:
+        for t in range(frames):
+            for plane in layout.synthetic_yuv420(w, h, t, depth):
+                f.write(np.ascontiguousarray(plane).tobytes())
+    return str(p)
+
+
+def test_the_10_bit_build_of_the_drop_in(clip):
+    """oracle/_ref/uvg266_10_hip (-DUVG_BIT_DEPTH=10: uvg_pixel is 16 bits wide, every registrar is called with bitdepth 10) on a
+    configs[0]-shaped 10-bit clip: the same .266 as the 10-bit generic-C build."""
+    d, _ = clip
+    w, h, frames = 416, 240, 4
+    yuv = _small_clip(d, "c0_10.yuv", w, h, frames, 10)
+    args = ["--input-res", f"{w}x{h}", "--input-bitdepth", "10", "-n", str(frames), "-p", "1", "--preset", "ultrafast", "--no-sao", "--no-deblock", "-q", "27"]
+    want, _ = encode(need(os.path.join(REF, "uvg266_10")), yuv, str(d / "generic10.266"), {}, ["--no-cpuid"], args=args)
+    got, err = encode(need(os.path.join(REF, "uvg266_10_hip")), yuv, str(d / "hip10.266"), {"UVG266_HIP": "1"}, args=args)
+    sel = chosen(err)
+    for g in GROUPS:
+        for t in TYPES[g]:
+            assert sel.get(t) == "hip", (t, sel.get(t))
+    assert got == want
+
+
+def test_preset_medium_through_the_per_call_strategies(clip):
+    """--preset medium -p 1 (RDOQ on, SAO and deblocking on, the full intra search: BASELINE configs[1]'s settings) on a short small clip
+    with every hip strategy selected: uvg_quantize_residual's RDOQ branch goes through quantize_residual_hip, the SAO group through its
+    four pointers -- the .266 of the generic-C run."""
+    d, _ = clip
+    w, h, frames = 192, 128, 2
+    yuv = _small_clip(d, "medium.yuv", w, h, frames, 8)
+    args = ["--input-res", f"{w}x{h}", "-n", str(frames), "-p", "1", "--preset", "medium", "-q", "27"]
+    want, _ = encode(need(os.path.join(REF, "uvg266_8")), yuv, str(d / "generic_medium.266"), {}, ["--no-cpuid"], args=args)
+    got, err = encode(need(os.path.join(REF, "uvg266_8_hip")), yuv, str(d / "hip_medium.266"), {"UVG266_HIP": "1"}, args=args)
+    assert chosen(err).get("quantize_residual") == "hip" and chosen(err).get("sao_edge_ddistortion") == "hip"
+    assert got == want
