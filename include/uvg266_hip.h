@@ -1285,6 +1285,13 @@ UVGHIP_API size_t uvghip_ctu_search_pb_inflight_workspace_bytes(int n_pictures, 
 UVGHIP_API int uvghip_ctu_search_pb_inflight(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, const uvghip_pb_filter_t *filters, const int32_t *ref_in_call,
                                              int n_pictures, void *workspace, void *stream);
 
+/* The same filter stage inside the all-intra search launch (uvghip_ctu_plan_*): filters[i] for picture i of the plan (HOST array, copied;
+ * slice type I, the plan's QP and lambda).  pic.rec_* then stay unfiltered.  uvghip_loop_plan_* uses it by default (the whole-picture
+ * filter kernels behind the search remain as UVGHIP_LOOP_UNFUSED=1).  uvghip_ctu_plan_final_flags: the per-CTU flags [picture][ctu]
+ * (device memory, zeroed by every run) a consumer on the device can wait for. */
+UVGHIP_API int uvghip_ctu_plan_set_filters(uvghip_ctu_plan_t *plan, const uvghip_pb_filter_t *filters);
+UVGHIP_API const int32_t *uvghip_ctu_plan_final_flags(const uvghip_ctu_plan_t *plan);
+
 /* replaces, for a group of independent P / B pictures: the whole per-picture loop of the CTU worker (src/encoderstate.c:808-976) --
  * uvghip_ctu_search_pb, then per picture uvghip_deblock_frame_sao_snapshot on a copy of the reconstruction + uvghip_sao_stats_batch,
  * uvghip_sao_decide_pictures_slice (the picture's QP, lambda and slice type), uvghip_deblock_frame in place on rec (boundary strengths

@@ -7,6 +7,7 @@
 #include <new>
 #include <vector>
 #include <cstring>
+#include <cstdlib>
 
 struct uvghip_loop_plan {
   int bitdepth, n, w, h, qp, sao_type, ctus;
@@ -28,6 +29,7 @@ struct uvghip_loop_plan {
   int row_cap, hc;
   uint32_t *sums;                         // per picture: the three plane checksums of the hash SEI (filled on demand)
   uvghip_ctu_params_t ctu_params;
+  int fused;                              // the filters run per CTU inside the search launch (ctu_filter.h); `snap` holds the deblocked pictures
 };
 
 namespace {
@@ -114,6 +116,26 @@ extern "C" int uvghip_loop_plan_create(int bitdepth, const uvghip_ctu_params_t *
   pl->sums = reinterpret_cast<uint32_t *>(ws + L.sums);
   pl->ctu_params = *params;
   if (int rc = uvghip_slice_rows_prepare(params, sp.data(), n_pictures, pl->coder_ws)) { uvghip_ctu_plan_destroy(pl->search); delete pl; return rc; }
+  // The in-loop filters inside the search launch, CTU by CTU (ctu_filter.h) -- the default; UVGHIP_LOOP_UNFUSED=1 keeps the chain of
+  // whole-picture kernels behind the search (deblock snapshot, SAO statistics, decision, deblocking in place, SAO apply: the same
+  // pictures and decisions, ~40 launches per picture).
+  {
+    const char *e = getenv("UVGHIP_LOOP_UNFUSED");
+    pl->fused = !(e && e[0] == '1');
+    if (pl->fused) {
+      std::vector<uvghip_pb_filter_t> fl(n_pictures);
+      const size_t b = bitdepth == 8 ? 1 : 2, plane = (size_t)w * h * b;
+      for (int i = 0; i < n_pictures; ++i) {
+        uvghip_pb_filter_t &f = fl[i];
+        unsigned char *d = pl->snap + (size_t)i * pl->snap_bytes;
+        f.dbk_y = d; f.dbk_u = d + plane; f.dbk_v = d + plane + plane / 4; f.dbk_stride = w; f.dbk_stride_c = w / 2;
+        f.out_y = pictures[i].out_y; f.out_u = pictures[i].out_u; f.out_v = pictures[i].out_v; f.out_stride = pictures[i].out_stride; f.out_stride_c = pictures[i].out_stride_c;
+        f.sao_info = pl->sao_info + (size_t)i * pl->ctus * 34; f.sao_models = pl->sao_models + (size_t)i * pl->ctus * 6;
+        f.sao_type = sao_type; f.reserved = 0;
+      }
+      if (int rc = uvghip_ctu_plan_set_filters(pl->search, fl.data())) { uvghip_ctu_plan_destroy(pl->search); delete pl; return rc; }
+    }
+  }
   // the CTU grids clipped to the picture: the rectangles sao_search_luma / _chroma hand to the decision (sao.c:605-668)
   std::vector<uvghip_rect_t> ry(pl->ctus), rc(pl->ctus);
   for (int cy = 0; cy < hc; ++cy)
@@ -152,6 +174,8 @@ extern "C" int uvghip_loop_plan_run_filters(uvghip_loop_plan_t *pl, void *stream
   hipStream_t st = uvghip_stream(stream);
   const size_t b = pl->bitdepth == 8 ? 1 : 2;
   const int w = pl->w, h = pl->h, cw = w / 2, ch = h / 2;
+  if (pl->fused)          // the search launch has filtered every CTU: what is left is the slice data
+    return uvghip_encode_slice_rows(pl->bitdepth, &pl->ctu_params, nullptr, pl->n, pl->sao_info, pl->sao_models, pl->coder_ws, pl->rows, pl->row_cap, pl->row_bytes, stream);
   for (int i = 0; i < pl->n; ++i) {
     const uvghip_ctu_picture_t &p = pl->pics[i].search;
     unsigned char *sy = pl->snap + (size_t)i * pl->snap_bytes, *su = sy + (size_t)w * h * b, *sv = su + (size_t)cw * ch * b;
