@@ -1285,12 +1285,15 @@ UVGHIP_API size_t uvghip_ctu_search_pb_inflight_workspace_bytes(int n_pictures, 
 UVGHIP_API int uvghip_ctu_search_pb_inflight(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, const uvghip_pb_filter_t *filters, const int32_t *ref_in_call,
                                              int n_pictures, void *workspace, void *stream);
 
-/* The same filter stage inside the all-intra search launch (uvghip_ctu_plan_*): filters[i] for picture i of the plan (HOST array, copied;
- * slice type I, the plan's QP and lambda).  pic.rec_* then stay unfiltered.  uvghip_loop_plan_* uses it by default (the whole-picture
- * filter kernels behind the search remain as UVGHIP_LOOP_UNFUSED=1).  uvghip_ctu_plan_final_flags: the per-CTU flags [picture][ctu]
- * (device memory, zeroed by every run) a consumer on the device can wait for. */
-UVGHIP_API int uvghip_ctu_plan_set_filters(uvghip_ctu_plan_t *plan, const uvghip_pb_filter_t *filters);
-UVGHIP_API const int32_t *uvghip_ctu_plan_final_flags(const uvghip_ctu_plan_t *plan);
+/* The same filter stage as ONE launch over a group of searched pictures, a workgroup per CTU (csrc/filters.hip) -- what the loop plans
+ * run behind the search instead of the chain of whole-picture kernels (snapshot deblocking, SAO statistics, decision, deblocking, SAO apply:
+ * the same pictures, decisions and models).  pictures[i].rec_* / cu / src_*: the search's outputs (rec stays unfiltered), filters[i] as for
+ * pictures in flight; slice_type 0 B / 1 P / 2 I (the SAO models' initialisation) and params->qp / lambda of the whole group.
+ * prepare: the picture table into the workspace (synchronous, once); run: a memset of the flags + the launch, nothing waits. */
+UVGHIP_API size_t uvghip_filter_pictures_workspace_bytes(int n_pictures, int pic_w, int pic_h);
+UVGHIP_API int uvghip_filter_pictures_prepare(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, const uvghip_pb_filter_t *filters,
+                                              int n_pictures, int slice_type, void *workspace);
+UVGHIP_API int uvghip_filter_pictures_run(int bitdepth, int n_pictures, int pic_w, int pic_h, void *workspace, void *stream);
 
 /* replaces, for a group of independent P / B pictures: the whole per-picture loop of the CTU worker (src/encoderstate.c:808-976) --
  * uvghip_ctu_search_pb, then per picture uvghip_deblock_frame_sao_snapshot on a copy of the reconstruction + uvghip_sao_stats_batch,

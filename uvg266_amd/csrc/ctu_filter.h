@@ -164,8 +164,11 @@ template <typename PX> __device__ inline void sao_region(const PX *dbk, int dstr
 }
 
 // The job.  smem: the workgroup's dynamic LDS image (free between two CTUs), at least sizeof(filt_lds<PX>).
+#if !defined(CTUF_CALL)
+#define CTUF_CALL __attribute__((noinline))          // (inside the P / B search kernel: a call, not a copy of the stage in the kernel's body)
+#endif
 template <typename PX>
-__device__ __attribute__((noinline)) void filter_ctu(unsigned char *smem, const filt_pic &P, const filt_ctu &J)
+__device__ CTUF_CALL void filter_ctu(unsigned char *smem, const filt_pic &P, const filt_ctu &J)
 {
   filt_lds<PX> *F = reinterpret_cast<filt_lds<PX> *>(smem);
   const int W = J.W, H = J.H, cx = J.cx, cy = J.cy, wc = J.wc, hc = J.hc, k = cy * wc + cx;

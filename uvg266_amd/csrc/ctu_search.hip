@@ -6,7 +6,6 @@
 // flags, runs the CTU, publishes its outputs (device-scope release) and raises its own flag.
 #include "uvghip_common.h"
 #include "ctu_core.h"
-#include "ctu_filter.h"
 #include <vector>
 #include <mutex>
 #include <cstring>
@@ -35,11 +34,7 @@ struct launch_args {
   int wc, hc, n_ctus;
   int32_t *simd_load;         // [XCD * 256 + (SE, SH, CU)][4]: walkers resident per SIMD of every CU
   int row0;                   // first CTU row of this launch (a band of a picture sharded by CTU rows): the row above it is complete in the buffers
-  // the in-loop filters of every CTU right behind its search (ctu_filter.h; uvghip_ctu_plan_set_filters): NULL = search only
-  const ctuf::filt_pic *fpics;
-  int32_t *sao_done, *final_done;   // [pic * ctus + cy * wc + cx]
 };
-static_assert(sizeof(ctuf::filt_lds<uint8_t>) <= sizeof(ctu::lds<uint8_t>) && sizeof(ctuf::filt_lds<uint16_t>) <= sizeof(ctu::lds<uint16_t>), "the filter job works inside the CTU's LDS image");
 
 // Four workgroups per CU at 8 bit is 40 960 B each: the dynamic image below + 4 304 B of function-scope tables (the build's .usage file
 // shows "LDS Size [bytes/block]: 4304").  One more word and the device holds three workgroups per CU instead of four (-25 %).
@@ -131,17 +126,6 @@ __global__ void __launch_bounds__(256, 4) ctu_search_kernel(launch_args A)
     atomicAnd(&A.slots[s_slot >> 5], ~(1u << (s_slot & 31)));          // the scratch is free again
     atomicSub(&A.simd_load[s_load], 1);
   }
-  if (A.fpics) {
-    // the CTU's in-loop filters while its right and lower neighbours search on: deblocking of what this CTU completes, its SAO statistics and
-    // decision, SAO into the output picture (ctu_filter.h); the LDS image is free now
-    ctuf::filt_ctu F;
-    F.rec_y = D.rec_y; F.rec_u = D.rec_u; F.rec_v = D.rec_v; F.src_y = D.src_y; F.src_u = D.src_u; F.src_v = D.src_v;
-    F.rec_stride = D.rec_stride; F.rec_stride_c = D.rec_stride_c; F.src_stride = D.src_stride; F.src_stride_c = D.src_stride_c;
-    F.scu = D.cu; F.scu_stride = D.cu_stride;
-    F.W = A.P.pic_w; F.H = A.P.pic_h; F.cx = cx; F.cy = cy; F.wc = A.wc; F.hc = A.hc;
-    F.sao_done = A.sao_done + (size_t)pic * ctus; F.final_done = A.final_done + (size_t)pic * ctus;
-    ctuf::filter_ctu<PX>(smem, A.fpics[pic], F);
-  }
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -157,7 +141,7 @@ size_t lds_pad()
 // Scratch slots: a workgroup claims one while it runs.  2048 = 256 CUs x 8 is more than the device can hold of this kernel
 // (4 per CU); small jobs take one slot per CTU, rounded up to whole bitmap words.
 enum { MAX_SLOTS = 2048 };
-struct ws_layout { size_t ticket, slots, simd_load, done, sao_done, final_done, order, pics, filt, scratch, total; int n_slots; };
+struct ws_layout { size_t ticket, slots, simd_load, done, order, pics, scratch, total; int n_slots; };
 ws_layout layout(int n_pictures, int pic_w, int pic_h)
 {
   const size_t ctus = (size_t)((pic_w + 63) / 64) * ((pic_h + 63) / 64), total = ctus * n_pictures;
@@ -167,12 +151,9 @@ ws_layout layout(int n_pictures, int pic_w, int pic_h)
   L.slots = 256;
   L.simd_load = L.slots + MAX_SLOTS / 8;
   L.done = L.simd_load + 8 * 256 * 4 * sizeof(int32_t);
-  L.sao_done = L.done + total * 4;
-  L.final_done = L.sao_done + total * 4;
-  L.order = align_up(L.final_done + total * 4, 256);    // [0, order): zeroed before every run
+  L.order = align_up(L.done + total * 4, 256);          // [0, order): zeroed before every run
   L.pics = align_up(L.order + total * 4, 256);
-  L.filt = align_up(L.pics + (size_t)n_pictures * sizeof(pic_dev), 256);
-  L.scratch = align_up(L.filt + (size_t)n_pictures * sizeof(ctuf::filt_pic), 256);
+  L.scratch = align_up(L.pics + (size_t)n_pictures * sizeof(pic_dev), 256);
   L.total = L.scratch + (size_t)L.n_slots * sizeof(ctu::scratch);
   return L;
 }
@@ -190,8 +171,7 @@ extern "C" size_t uvghip_ctu_search_workspace_bytes(int n_pictures, int pic_w, i
 // start of one plan's wavefronts fills the device while another's drain).
 struct uvghip_ctu_plan {
   launch_args A;
-  int bitdepth, total, n_pictures;
-  size_t filt_off;
+  int bitdepth, total;
   size_t counters;            // bytes of (ticket, done flags) at the head of the workspace
   unsigned char *ws;
 };
@@ -257,10 +237,6 @@ extern "C" int uvghip_ctu_plan_create_rows(int bitdepth, const uvghip_ctu_params
   pl->A.simd_load = reinterpret_cast<int32_t *>(ws + L.simd_load);
   pl->A.n_slots = L.n_slots;
   pl->A.wc = wc; pl->A.hc = hc; pl->A.n_ctus = total; pl->A.row0 = ctu_row0;
-  pl->A.fpics = nullptr;
-  pl->A.sao_done = reinterpret_cast<int32_t *>(ws + L.sao_done);
-  pl->A.final_done = reinterpret_cast<int32_t *>(ws + L.final_done);
-  pl->n_pictures = n_pictures; pl->filt_off = L.filt;
   pl->bitdepth = bitdepth; pl->total = total; pl->counters = L.order; pl->ws = ws;
   const size_t lds = (bitdepth == 8 ? sizeof(ctu::lds<uint8_t>) : sizeof(ctu::lds<uint16_t>)) + lds_pad();
   const hipError_t e = bitdepth == 8
@@ -281,35 +257,6 @@ extern "C" int uvghip_ctu_plan_run(uvghip_ctu_plan_t *pl, void *stream)
   else hipLaunchKernelGGL(ctu_search_kernel<uint16_t>, dim3(pl->total), dim3(256), sizeof(ctu::lds<uint16_t>) + lds_pad(), st, pl->A);
   UVGHIP_CHECK_LAUNCH();
 }
-
-// The in-loop filters of every CTU inside the search launch (ctu_filter.h: what encoder_state_worker_encode_lcu_search does after
-// uvg_search_lcu, encoderstate.c:841-853): filters[i] for picture i of the plan (HOST array, copied).  pic.rec_* then stay the unfiltered
-// reconstruction.  Whole pictures only (a band of CTU rows has no filter stage).
-extern "C" int uvghip_ctu_plan_set_filters(uvghip_ctu_plan_t *pl, const uvghip_pb_filter_t *filters)
-{
-  UVGHIP_REQUIRE_READY();
-  if (!pl || !filters) return uvghip_set_error(hipErrorInvalidValue, __func__);
-  const int w = pl->A.P.pic_w;
-  if (pl->A.row0 != 0 || pl->total != pl->A.wc * pl->A.hc * pl->n_pictures) return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_plan_set_filters: a plan of whole pictures");
-  if (pl->A.P.qp_c != pl->A.P.qp) return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_plan_set_filters: qp_c != qp needs a chroma QP table");
-  std::vector<ctuf::filt_pic> fp(pl->n_pictures);
-  for (int i = 0; i < pl->n_pictures; ++i) {
-    const uvghip_pb_filter_t &f = filters[i];
-    if (!f.dbk_y || !f.dbk_u || !f.dbk_v || !f.out_y || !f.out_u || !f.out_v || f.dbk_stride < w || f.dbk_stride_c < w / 2 || f.out_stride < w || f.out_stride_c < w / 2 ||
-        f.sao_type < 0 || f.sao_type > 3 || (f.sao_type && (!f.sao_info || !f.sao_models)))
-      return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_plan_set_filters: filter stage");
-    ctuf::filt_pic &g = fp[i];
-    g.dbk_y = f.dbk_y; g.dbk_u = f.dbk_u; g.dbk_v = f.dbk_v; g.out_y = f.out_y; g.out_u = f.out_u; g.out_v = f.out_v;
-    g.dbk_stride = f.dbk_stride; g.dbk_stride_c = f.dbk_stride_c; g.out_stride = f.out_stride; g.out_stride_c = f.out_stride_c;
-    g.sao_info = f.sao_info; g.sao_models = f.sao_models; g.lambda = pl->A.P.lambda; g.sao_type = f.sao_type; g.slice_type = 2; g.qp = pl->A.P.qp; g.is_b = 0;
-  }
-  UVGHIP_TRY(hipMemcpy(pl->ws + pl->filt_off, fp.data(), fp.size() * sizeof(ctuf::filt_pic), hipMemcpyHostToDevice));
-  pl->A.fpics = reinterpret_cast<const ctuf::filt_pic *>(pl->ws + pl->filt_off);
-  return 0;
-}
-// ... its per-CTU "final" flags [picture][ctu] (device memory, zeroed by every run): set when everything up and left of the CTU's lower
-// right corner minus the filters' delay is final in the output picture -- what a picture in flight behind this one waits for
-extern "C" const int32_t *uvghip_ctu_plan_final_flags(const uvghip_ctu_plan_t *pl) { return pl ? pl->A.final_done : nullptr; }
 
 extern "C" void uvghip_ctu_plan_destroy(uvghip_ctu_plan_t *pl) { delete pl; }
 

@@ -29,14 +29,15 @@ struct uvghip_loop_plan {
   int row_cap, hc;
   uint32_t *sums;                         // per picture: the three plane checksums of the hash SEI (filled on demand)
   uvghip_ctu_params_t ctu_params;
-  int fused;                              // the filters run per CTU inside the search launch (ctu_filter.h); `snap` holds the deblocked pictures
+  int fused;                              // the filters are ONE launch behind the search (uvghip_filter_pictures); `snap` holds the deblocked pictures
+  void *filt_ws;
 };
 
 namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-struct layout_t { size_t search, snap, rects_y, rects_c, edge[3], band[3], decide, info, models, params[3], coder, row_bytes, rows, sums, total; int row_cap; };
+struct layout_t { size_t search, snap, rects_y, rects_c, edge[3], band[3], decide, info, models, params[3], coder, row_bytes, rows, sums, filt, total; int row_cap; };
 
 layout_t layout_of(int bitdepth, int n, int w, int h)
 {
@@ -59,6 +60,7 @@ layout_t layout_of(int bitdepth, int n, int w, int h)
   L.row_bytes = take((size_t)n * hc * 4);
   L.rows = take((size_t)n * hc * L.row_cap);
   L.sums = take((size_t)n * 3 * sizeof(uint32_t));
+  L.filt = take(uvghip_filter_pictures_workspace_bytes(n, w, h));
   L.total = at;
   return L;
 }
@@ -116,12 +118,13 @@ extern "C" int uvghip_loop_plan_create(int bitdepth, const uvghip_ctu_params_t *
   pl->sums = reinterpret_cast<uint32_t *>(ws + L.sums);
   pl->ctu_params = *params;
   if (int rc = uvghip_slice_rows_prepare(params, sp.data(), n_pictures, pl->coder_ws)) { uvghip_ctu_plan_destroy(pl->search); delete pl; return rc; }
-  // The in-loop filters inside the search launch, CTU by CTU (ctu_filter.h) -- the default; UVGHIP_LOOP_UNFUSED=1 keeps the chain of
-  // whole-picture kernels behind the search (deblock snapshot, SAO statistics, decision, deblocking in place, SAO apply: the same
-  // pictures and decisions, ~40 launches per picture).
+  // The in-loop filters as ONE launch behind the search, a workgroup per CTU (uvghip_filter_pictures, ctu_filter.h) -- the default;
+  // UVGHIP_LOOP_UNFUSED=1 keeps the chain of whole-picture kernels (deblock snapshot, SAO statistics, decision, deblocking in place,
+  // SAO apply: the same pictures and decisions, ~40 launches per picture).
   {
     const char *e = getenv("UVGHIP_LOOP_UNFUSED");
     pl->fused = !(e && e[0] == '1');
+    pl->filt_ws = ws + L.filt;
     if (pl->fused) {
       std::vector<uvghip_pb_filter_t> fl(n_pictures);
       const size_t b = bitdepth == 8 ? 1 : 2, plane = (size_t)w * h * b;
@@ -133,7 +136,7 @@ extern "C" int uvghip_loop_plan_create(int bitdepth, const uvghip_ctu_params_t *
         f.sao_info = pl->sao_info + (size_t)i * pl->ctus * 34; f.sao_models = pl->sao_models + (size_t)i * pl->ctus * 6;
         f.sao_type = sao_type; f.reserved = 0;
       }
-      if (int rc = uvghip_ctu_plan_set_filters(pl->search, fl.data())) { uvghip_ctu_plan_destroy(pl->search); delete pl; return rc; }
+      if (int rc = uvghip_filter_pictures_prepare(bitdepth, params, sp.data(), fl.data(), n_pictures, 2, pl->filt_ws)) { uvghip_ctu_plan_destroy(pl->search); delete pl; return rc; }
     }
   }
   // the CTU grids clipped to the picture: the rectangles sao_search_luma / _chroma hand to the decision (sao.c:605-668)
@@ -174,8 +177,10 @@ extern "C" int uvghip_loop_plan_run_filters(uvghip_loop_plan_t *pl, void *stream
   hipStream_t st = uvghip_stream(stream);
   const size_t b = pl->bitdepth == 8 ? 1 : 2;
   const int w = pl->w, h = pl->h, cw = w / 2, ch = h / 2;
-  if (pl->fused)          // the search launch has filtered every CTU: what is left is the slice data
+  if (pl->fused) {        // one launch for the filters of every picture, one for the slice data
+    if (int rc = uvghip_filter_pictures_run(pl->bitdepth, pl->n, w, h, pl->filt_ws, stream)) return rc;
     return uvghip_encode_slice_rows(pl->bitdepth, &pl->ctu_params, nullptr, pl->n, pl->sao_info, pl->sao_models, pl->coder_ws, pl->rows, pl->row_cap, pl->row_bytes, stream);
+  }
   for (int i = 0; i < pl->n; ++i) {
     const uvghip_ctu_picture_t &p = pl->pics[i].search;
     unsigned char *sy = pl->snap + (size_t)i * pl->snap_bytes, *su = sy + (size_t)w * h * b, *sv = su + (size_t)cw * ch * b;

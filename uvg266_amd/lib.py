@@ -273,8 +273,9 @@ SIGNATURES = {
     "uvghip_loop_pb_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
     "uvghip_loop_pb_run": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_vp]),
     "uvghip_loop_pb_results": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "uvghip_ctu_plan_set_filters": (c_int, [c_vp, c_vp]),
-    "uvghip_ctu_plan_final_flags": (c_vp, [c_vp]),
+    "uvghip_filter_pictures_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
+    "uvghip_filter_pictures_prepare": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    "uvghip_filter_pictures_run": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "uvghip_ctu_search_pb_inflight_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "uvghip_ctu_search_pb_inflight": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "uvghip_loop_pb_inflight_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
