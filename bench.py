@@ -1212,6 +1212,15 @@ def main():
                  "mpixels_per_s": round(ek * eF * world / eel * ewl["W"] * ewl["H"] / 1e6, 1),
                  "search_launch_ms": round(ems / max(1, eln), 2),
                  "workload": "3840x2160 10-bit yuv420p, QP 22: the same closed loop (search -> deblock -> SAO -> slice data); alf_stage: the ALF stage of configs[3] behind it"}
+        if eln:
+            e_ms = ems / eln
+            e_bytes = ctu_search_bytes(ewl["W"], ewl["H"], ewl["depth"]) * eF
+            e_gbs = e_bytes / (e_ms * 1e-3) / 1e9
+            extra["roofline"] = {"bound": "hbm", "kernel": "ctu_search_kernel<uint16_t>", "achieved": round(e_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(e_gbs / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(e_ms, 3), "alg_bytes_per_launch": e_bytes,
+                                 "launches_timed": eln,
+                                 "note": "as the headline's: algorithmic bytes of the search launch (source in; reconstruction, levels, side information, models out) / its "
+                                         "average duration from HIP events on the launch's stream; an instruction chain per CTU, not a streaming kernel (no PMC pass at this size)"}
         if alf_t is not None:
             extra["alf_stage"] = alf_t
         if alf_t is not None and "ms_per_group" in alf_t and alf_t.get("parity_checked"):

@@ -856,6 +856,16 @@ UVGHIP_API int uvghip_quant_cbcr_residual_percall(const uvghip_state_view_t *sv,
                                                   void *v_rec_out, int16_t *coeff_out, int early_skip, int lmcs_chroma_adj, int tree_type);
 /* One plane of bipred_average_generic (picture-generic.c:1195-1262): dst rows of pu_w samples at dst_stride; l0 / l1 are
  * pu_w*pu_h contiguous samples -- pixels, or 14-bit int16 intermediates where *_is_im. */
+/* The `alf` strategy group behind plain values (strategies-alf.h:48-109; csrc/alf_percall.hip): what the shim's four typedef-exact
+ * functions call.  Host planes in (whole planes of pic_w x pic_h, stride in samples), host results out.
+ *   classify: cls_out[h / 4][w / 4] = class_idx | transpose_idx << 5 of the 4x4 blocks of [x, x + w) x [y, y + h)
+ *   filter:   one filter set (luma: coef / clip [25][13] + the plane's class bytes `cls`; chroma: [7], cls NULL) over the block -> dst_block[h][w]
+ *   stats:    the block's own sums in uvghip_alf_stats_batch's layout, ee[ncls][13][13][4][4] / yv[ncls][13][4] / pix_acc[ncls] (ncls 25 / 1) */
+UVGHIP_API int uvghip_alf_classify_percall(int bitdepth, const void *rec, int rec_stride, int pic_w, int pic_h, int shift, int x, int y, int w, int h, uint8_t *cls_out);
+UVGHIP_API int uvghip_alf_filter_percall(int bitdepth, int is_chroma, const void *src, int src_stride, int pic_w, int pic_h, int x, int y, int w, int h,
+                                         const int16_t *coef, const int16_t *clip, const uint8_t *cls, int cls_stride, void *dst_block);
+UVGHIP_API int uvghip_alf_stats_percall(int bitdepth, int is_chroma, const void *org, int org_stride, const void *rec, int rec_stride, int pic_w, int pic_h, int x, int y,
+                                        int w, int h, const uint8_t *cls, int cls_stride, int64_t *ee, int32_t *yv, int64_t *pix_acc);
 UVGHIP_API void uvghip_bipred_average_percall(int bitdepth, void *dst, int dst_stride, const void *l0, int l0_is_im,
                                               const void *l1, int l1_is_im, unsigned pu_w, unsigned pu_h);
 
@@ -1265,14 +1275,20 @@ UVGHIP_API int uvghip_ctu_search_pb(int bitdepth, const uvghip_ctu_pb_picture_t 
  * {1, 1}; its vectors stay inside what is final there, fracmv_within_tile src/search_inter.c:94-149 = inflight_margin).  The pictures of
  * ONE call may refer to each other: they are given in coding order, ref_in_call[i * 16 + k] = the index (< i) of the picture of this call
  * whose OUTPUT picture reference k of picture i is (its filters[].out_* planes and pictures[].motion_out), or -1 for a reference that is
- * complete before the call.  Every CTU runs its in-loop filters right behind its search inside the persistent kernel (what
+ * complete before the call.  The device waits for less than the reference and for enough: CTU (x, y) starts when CTU (x + 1, y + 1) of
+ * every reference inside the call is FINAL ((x + 2, y) in the last CTU row) -- under the vector restriction nothing beyond the CTUs
+ * (x + 2 + j, y - j), j >= 0, and (x + 1, y + 1) can be read, and a CTU's "final" flag is raised after its left, upper and upper-right
+ * neighbour's, so that one flag covers exactly that shape.  Same pictures, same stream, a shorter wait.
+ * Every CTU runs its in-loop filters right behind its search inside the persistent kernel (what
  * encoder_state_worker_encode_lcu_search does after uvg_search_lcu, encoderstate.c:841-853): deblocking, uvg_sao_search_lcu's statistics
  * and decision, encoder_sao_reconstruct -- so the output picture becomes final CTU by CTU, and a per-CTU flag releases the CTUs of the
  * pictures behind.  pic.rec_* stay the UNFILTERED reconstruction (uvghip_loop_pb_run deblocks them in place); filters[i].dbk_* receive
  * the deblocked picture, out_* the picture uvg_encoder_encode returns (after SAO; sao_type 0: the deblocked picture), sao_info
  * [ctu][34] / sao_models [ctu][6] the decisions in uvghip_sao_decide_pictures_slice's layout.  Requirements beyond uvghip_ctu_search_pb:
  * params.qp == params.qp_c == frame_qp; a picture with a reference inside the call has inflight_margin = 11 (sao_type != 0) or 9.
- * Everything is enqueued on `stream` in stream order; nothing waits for the device. */
+ * Everything is enqueued on `stream` in stream order; nothing waits for the device.  The launch has four waves per CTU (the walk, the
+ * 4x4 CUs of 8x8 areas, the 16x16 and the 32x32 CUs on a wave each, ahead of the walk: csrc/ctu_pb.h; UVGHIP_PB_WAVES=1..4 for
+ * development) -- a CTU's latency, not the device's occupancy, sets the pace of dependent pictures. */
 typedef struct uvghip_pb_filter {
   void *dbk_y, *dbk_u, *dbk_v;          /* DEVICE, pic_w x pic_h (+ chroma) */
   void *out_y, *out_u, *out_v;

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref")
 W, H, FRAMES = 832, 480, 10
 ARGS = ["--input-res", f"{W}x{H}", "-n", str(FRAMES), "-p", "1", "--preset", "ultrafast", "--no-sao", "--no-deblock", "-q", "27"]
-GROUPS = ("picture", "dct", "intra", "sao", "quant", "ipol")
+GROUPS = ("picture", "dct", "intra", "sao", "quant", "ipol", "alf")
 # the strategy types each group of the backend registers
 TYPES = {
     "picture": ["reg_sad", "sad_8x8", "sad_16x16", "satd_4x4", "satd_8x8", "satd_16x16", "satd_32x32", "satd_any_size", "pixels_calc_ssd", "generate_residual",
@@ -30,6 +30,7 @@ TYPES = {
     "sao": ["sao_edge_ddistortion", "calc_sao_edge_dir", "sao_reconstruct_color", "sao_band_ddistortion"],
     "quant": ["quant", "dequant", "quantize_residual", "coeff_abs_sum", "fast_coeff_cost"],
     "ipol": ["filter_hpel_blocks_hor_ver_luma", "sample_quarterpel_luma", "sample_octpel_chroma", "get_extended_block"],
+    "alf": ["alf_derive_classification_blk", "alf_filter_5x5_blk", "alf_filter_7x7_blk", "alf_get_blk_stats"],
 }
 
 
@@ -161,4 +162,24 @@ def test_preset_medium_through_the_per_call_strategies(clip):
     want, _ = encode(need(os.path.join(REF, "uvg266_8")), yuv, str(d / "generic_medium.266"), {}, ["--no-cpuid"], args=args)
     got, err = encode(need(os.path.join(REF, "uvg266_8_hip")), yuv, str(d / "hip_medium.266"), {"UVG266_HIP": "1"}, args=args)
     assert chosen(err).get("quantize_residual") == "hip" and chosen(err).get("sao_edge_ddistortion") == "hip"
+    assert got == want
+
+
+ALF_TYPES = TYPES["alf"]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_the_alf_group_in_an_alf_full_run(clip, depth):
+    """uvg_strategy_register_state_hip_alf (the shim) + csrc/alf_percall.hip: classification, the 7x7 / 5x5 filters and the covariance statistics
+    of a -p 1 --alf full run go through the "hip" strategies -- the .266 of the generic-C run (the derivation in between works on the
+    device's statistics: any difference in a covariance would change the filters it derives)."""
+    d, _ = clip
+    w, h, frames = 192, 128, 3
+    yuv = _small_clip(d, f"alf{depth}.yuv", w, h, frames, depth)
+    args = ["--input-res", f"{w}x{h}", "-n", str(frames), "-p", "1", "--preset", "ultrafast", "-q", "27", "--alf", "full"] + (["--input-bitdepth", "10"] if depth == 10 else [])
+    want, _ = encode(need(os.path.join(REF, f"uvg266_{depth}")), yuv, str(d / f"generic_alf{depth}.266"), {}, ["--no-cpuid"], args=args, threads=1)
+    got, err = encode(need(os.path.join(REF, f"uvg266_{depth}_hip")), yuv, str(d / f"hip_alf{depth}.266"), {"UVG266_HIP": "alf"}, args=args, threads=1)
+    sel = chosen(err)
+    for t in ALF_TYPES:
+        assert sel.get(t) == "hip", (t, sel.get(t))
     assert got == want

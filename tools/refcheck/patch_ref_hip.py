@@ -17,6 +17,7 @@ GROUPS = {
     "sao": ("strategies/strategies-sao.c", ["uvg_strategy_register_sao_hip"]),
     "quant": ("strategies/strategies-quant.c", ["uvg_strategy_register_quant_hip", "uvg_strategy_register_state_hip_quant"]),
     "ipol": ("strategies/strategies-ipol.c", ["uvg_strategy_register_ipol_hip"]),
+    "alf": ("strategies/strategies-alf.c", ["uvg_strategy_register_state_hip_alf"]),
 }
 
 

@@ -8,7 +8,7 @@
  * (tools/refcheck/rc_shim.inc) to prove that the extraction picks the fields the generic strategies read.
  *
  * Typedefs implemented: quant_func, dequant_func, quant_residual_func, quant_cbcr_func (strategies-quant.h:48-86),
- * inter_recon_bipred_func (strategies-picture.h:136-148).
+ * inter_recon_bipred_func (strategies-picture.h:136-148), and the four of the alf group (strategies-alf.h:48-109).
  */
 #include "strategyselector.h"
 #include "encoderstate.h"
@@ -17,6 +17,9 @@
 #include "context.h"
 #include "cu.h"
 #include "reshape.h"
+#include "alf.h"
+#include "videoframe.h"
+#include "strategies/strategies-alf.h"
 #include "uvg266_hip.h"
 
 #include <stdio.h>
@@ -158,6 +161,116 @@ static void uvg_inter_recon_bipred_hip(lcu_t *const lcu, const yuv_t *const px_L
   }
 }
 
+/* ---- the alf group (strategies-alf.h:48-109) ------------------------------------------------------------------------------------
+ * The library's whole-picture kernels derive the virtual boundary from a block's place in the picture and clamp at the picture's edges
+ * where the encoder's planes carry replicated padding (alf.c:5150-5170): what these four functions add is the extraction of the
+ * planes, the conversion between the encoder's per-sample alf_classifier and the library's byte per 4x4 block, and the accumulation
+ * into alf_covariance.  Anything alf.c never passes (another virtual boundary, a destination offset, other clipping values) aborts. */
+static void hip_alf_die(const char *what)
+{
+  fprintf(stderr, "hip backend (alf): %s: %s\n", what, uvghip_last_error());
+  abort();
+}
+static void hip_alf_vb(int is_chroma, int vb_ctu_height, int vb_pos)
+{
+  const int hgt = is_chroma ? LCU_WIDTH >> 1 : LCU_WIDTH, pos = hgt - (is_chroma ? ALF_VB_POS_ABOVE_CTUROW_CHMA : ALF_VB_POS_ABOVE_CTUROW_LUMA);
+  if (vb_ctu_height != hgt || vb_pos != pos) hip_alf_die("a virtual boundary other than alf.c's (4:2:0, 64x64 CTUs)");
+}
+/* the plane's classes as one byte per 4x4 block (class_idx | transpose_idx << 5), rows of (w + 3) / 4 bytes; only the blocks of
+ * [x, x + bw) x [y, y + bh) are filled in */
+static uint8_t *hip_alf_class_bytes(alf_classifier **classifier, int w, int h, int x, int y, int bw, int bh)
+{
+  const int cw = (w + 3) / 4, ch = (h + 3) / 4;
+  uint8_t *b = calloc((size_t)cw * ch, 1);
+  if (!b) hip_alf_die("out of memory");
+  for (int i = y; i < y + bh; i += 4)
+    for (int j = x; j < x + bw; j += 4)
+      b[(i / 4) * cw + j / 4] = (uint8_t)(classifier[i][j].class_idx | classifier[i][j].transpose_idx << 5);
+  return b;
+}
+
+static void uvg_alf_derive_classification_blk_hip(encoder_state_t *const state, const int shift, const int n_height, const int n_width, const int blk_pos_x,
+                                                  const int blk_pos_y, const int blk_dst_x, const int blk_dst_y, const int vb_ctu_height, int vb_pos)
+{
+  videoframe_t *const frame = state->tile->frame;
+  hip_alf_vb(0, vb_ctu_height, vb_pos);
+  uint8_t cls[(CLASSIFICATION_BLK_SIZE / 4) * (CLASSIFICATION_BLK_SIZE / 4)];
+  if (n_width > CLASSIFICATION_BLK_SIZE || n_height > CLASSIFICATION_BLK_SIZE) hip_alf_die("classification block larger than 32x32");
+  if (uvghip_alf_classify_percall(UVG_BIT_DEPTH, frame->rec->y, frame->rec->stride, frame->rec->width, frame->rec->height, shift, blk_pos_x, blk_pos_y, n_width, n_height, cls))
+    hip_alf_die("classification");
+  alf_classifier **classifier = frame->alf_info->classifier;
+  for (int i = 0; i < n_height; ++i)
+    for (int j = 0; j < n_width; ++j) {
+      const uint8_t c = cls[(i / 4) * (n_width / 4) + j / 4];
+      classifier[blk_dst_y + i][blk_dst_x + j].class_idx = c & 31;
+      classifier[blk_dst_y + i][blk_dst_x + j].transpose_idx = c >> 5;
+    }
+}
+
+static void hip_alf_filter(encoder_state_t *const state, int is_chroma, const uvg_pixel *src_pixels, uvg_pixel *dst_pixels, const int src_stride, const int dst_stride,
+                           const short *filter_set, const int16_t *clip_set, const int width, const int height, int x_pos, int y_pos, int blk_dst_x, int blk_dst_y,
+                           int vb_pos, const int vb_ctu_height)
+{
+  videoframe_t *const frame = state->tile->frame;
+  const int w = frame->rec->width >> is_chroma, h = frame->rec->height >> is_chroma;
+  hip_alf_vb(is_chroma, vb_ctu_height, vb_pos);
+  uint8_t *cls = is_chroma ? NULL : hip_alf_class_bytes(frame->alf_info->classifier, w, h, x_pos, y_pos, width, height);
+  uvg_pixel *blk = malloc((size_t)width * height * sizeof(uvg_pixel));
+  if (!blk) hip_alf_die("out of memory");
+  if (uvghip_alf_filter_percall(UVG_BIT_DEPTH, is_chroma, src_pixels, src_stride, w, h, x_pos, y_pos, width, height, filter_set, clip_set, cls, (w + 3) / 4, blk))
+    hip_alf_die("filter");
+  for (int i = 0; i < height; ++i) memcpy(dst_pixels + (size_t)(blk_dst_y + i) * dst_stride + blk_dst_x, blk + (size_t)i * width, (size_t)width * sizeof(uvg_pixel));
+  free(blk); free(cls);
+}
+static void uvg_alf_filter_7x7_blk_hip(encoder_state_t *const state, const uvg_pixel *src_pixels, uvg_pixel *dst_pixels, const int src_stride, const int dst_stride,
+                                       const short *filter_set, const int16_t *fClipSet, clp_rng clp_rng, const int width, const int height, int x_pos, int y_pos,
+                                       int blk_dst_x, int blk_dst_y, int vb_pos, const int vb_ctu_height)
+{
+  (void)clp_rng;          /* [0, 2^depth - 1]: the kernel's own clamp */
+  hip_alf_filter(state, 0, src_pixels, dst_pixels, src_stride, dst_stride, filter_set, fClipSet, width, height, x_pos, y_pos, blk_dst_x, blk_dst_y, vb_pos, vb_ctu_height);
+}
+static void uvg_alf_filter_5x5_blk_hip(encoder_state_t *const state, const uvg_pixel *src_pixels, uvg_pixel *dst_pixels, const int src_stride, const int dst_stride,
+                                       const short *filter_set, const int16_t *fClipSet, clp_rng clp_rng, const int width, const int height, int x_pos, int y_pos,
+                                       int blk_dst_x, int blk_dst_y, int vb_pos, const int vb_ctu_height)
+{
+  (void)clp_rng;
+  hip_alf_filter(state, 1, src_pixels, dst_pixels, src_stride, dst_stride, filter_set, fClipSet, width, height, x_pos, y_pos, blk_dst_x, blk_dst_y, vb_pos, vb_ctu_height);
+}
+
+static void uvg_alf_get_blk_stats_hip(encoder_state_t *const state, channel_type channel, alf_covariance *cov, alf_classifier **g_classifier, uvg_pixel *org,
+                                      int32_t org_stride, uvg_pixel *rec, int32_t rec_stride, const int x_pos, const int y_pos, const int x_dst, const int y_dst,
+                                      const int width, const int height, int vb_ctu_height, int vb_pos, short alf_clipping_values[MAX_NUM_CHANNEL_TYPE][MAX_ALF_NUM_CLIPPING_VALUES])
+{
+  videoframe_t *const frame = state->tile->frame;
+  const int is_chroma = channel != CHANNEL_TYPE_LUMA;
+  const int w = frame->rec->width >> is_chroma, h = frame->rec->height >> is_chroma, ncls = g_classifier ? MAX_NUM_ALF_CLASSES : 1, ncoef = is_chroma ? 7 : 13;
+  (void)alf_clipping_values;          /* the defaults of the bit depth (alf.c:5248-5260): what the kernel computes with */
+  hip_alf_vb(is_chroma, vb_ctu_height, vb_pos);
+  if (x_dst != x_pos || y_dst != y_pos || (!is_chroma) != (g_classifier != NULL)) hip_alf_die("a call alf.c does not make");
+  uint8_t *cls = g_classifier ? hip_alf_class_bytes(g_classifier, w, h, x_pos, y_pos, width, height) : NULL;
+  int64_t *ee = malloc((size_t)ncls * 13 * 13 * 16 * sizeof(int64_t)), *pix = malloc((size_t)ncls * sizeof(int64_t));
+  int32_t *yv = malloc((size_t)ncls * 13 * 4 * sizeof(int32_t));
+  if (!ee || !pix || !yv) hip_alf_die("out of memory");
+  /* org / rec point at the block (alf.c:4305-4306): the planes start x_pos + y_pos * stride before */
+  if (uvghip_alf_stats_percall(UVG_BIT_DEPTH, is_chroma, org - ((size_t)y_pos * org_stride + x_pos), org_stride, rec - ((size_t)y_pos * rec_stride + x_pos), rec_stride, w, h,
+                               x_pos, y_pos, width, height, cls, (w + 3) / 4, ee, yv, pix))
+    hip_alf_die("statistics");
+  for (int c = 0; c < ncls; ++c) {
+    for (int k = 0; k < ncoef; ++k) {
+      for (int l = k; l < ncoef; ++l)
+        for (int b0 = 0; b0 < 4; ++b0)
+          for (int b1 = 0; b1 < 4; ++b1) cov[c].ee[k][l][b0][b1] += ee[((((size_t)c * 13 + k) * 13 + l) * 4 + b0) * 4 + b1];
+      for (int b = 0; b < 4; ++b) cov[c].y[k][b] += yv[((size_t)c * 13 + k) * 4 + b];
+    }
+    cov[c].pix_acc += (double)pix[c];
+    for (int k = 1; k < ncoef; ++k)          /* the lower triangle mirrors the upper (alf-generic.c:982-998) */
+      for (int l = 0; l < k; ++l)
+        for (int b0 = 0; b0 < 4; ++b0)
+          for (int b1 = 0; b1 < 4; ++b1) cov[c].ee[k][l][b0][b1] = cov[c].ee[l][k][b1][b0];
+  }
+  free(ee); free(pix); free(yv); free(cls);
+}
+
 /* The configurations the backend implements for these four strategies.  Call after the configuration is parsed; when it
  * returns 0 start the encoder with UVG_OVERRIDE_quant=generic UVG_OVERRIDE_dequant=generic
  * UVG_OVERRIDE_quantize_residual=generic (strategyselector.c reads them) -- the entry points abort rather than return a
@@ -204,7 +317,18 @@ int uvg_strategy_register_state_hip_picture(void *opaque, uint8_t bitdepth)
   if (bitdepth != UVG_BIT_DEPTH || uvghip_init(0) != 0) { fprintf(stderr, "hip backend: %s\n", uvghip_last_error()); return 0; }
   return uvg_strategyselector_register(opaque, "bipred_average", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_inter_recon_bipred_hip);
 }
+int uvg_strategy_register_state_hip_alf(void *opaque, uint8_t bitdepth)
+{
+  bool success = true;
+  if (bitdepth != UVG_BIT_DEPTH || uvghip_init(0) != 0) { fprintf(stderr, "hip backend: %s\n", uvghip_last_error()); return 0; }
+  success &= uvg_strategyselector_register(opaque, "alf_derive_classification_blk", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_alf_derive_classification_blk_hip);
+  success &= uvg_strategyselector_register(opaque, "alf_filter_5x5_blk", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_alf_filter_5x5_blk_hip);
+  success &= uvg_strategyselector_register(opaque, "alf_filter_7x7_blk", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_alf_filter_7x7_blk_hip);
+  success &= uvg_strategyselector_register(opaque, "alf_get_blk_stats", UVGHIP_STRATEGY_NAME, UVGHIP_STRATEGY_PRIORITY, &uvg_alf_get_blk_stats_hip);
+  return success;
+}
 int uvg_strategy_register_state_hip(void *opaque, uint8_t bitdepth)
 {
-  return uvg_strategy_register_state_hip_quant(opaque, bitdepth) && uvg_strategy_register_state_hip_picture(opaque, bitdepth);
+  return uvg_strategy_register_state_hip_quant(opaque, bitdepth) && uvg_strategy_register_state_hip_picture(opaque, bitdepth) &&
+         uvg_strategy_register_state_hip_alf(opaque, bitdepth);
 }

@@ -306,6 +306,9 @@ SIGNATURES = {
     "uvghip_quantize_residual_percall": (c_int, [c_vp, c_vp] + [c_int] * 7 + [c_vp] * 4 + [c_int] * 3),
     "uvghip_quant_cbcr_residual_percall": (c_int, [c_vp, c_vp] + [c_int] * 5 + [c_vp] * 7 + [c_int] * 3),
     "uvghip_bipred_average_percall": (None, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, ctypes.c_uint, ctypes.c_uint]),
+    "uvghip_alf_classify_percall": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "uvghip_alf_filter_percall": (c_int, [c_int, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "uvghip_alf_stats_percall": (c_int, [c_int, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp, c_vp]),
     "uvghip_comm_allgather": (c_int, [c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "uvghip_residual_plane": (c_int, [c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp]),
 }
