@@ -28,7 +28,9 @@ def _frame_rows(g):
 CASES = [("ref_inter_136x200_8_qp27_11frames_owf1", 1, 3), ("ref_inter_136x200_8_qp27_11frames_owf1", 3, 3), ("ref_inter_264x136_8_qp32_9frames", 2, 3),
          ("ref_inter_136x72_10_qp22_4frames", 1, 3), ("ref_inter_192x128_8_qp17_5frames", 1, 3), ("ref_inter_136x72_8_qp27_17frames_ra16", 2, 3),
          ("ref_inter_136x72_10_qp22_17frames_ra16", 1, 3), ("ref_inter_136x72_8_qp27_9frames_ra8", 1, 3), ("ref_inter_136x72_8_qp27_33frames_ra16p16", 1, 3),
-         ("ref_intercrc_136x72_8_qp27_65frames_ra16", 1, 3), ("ref_intercrc_1920x1080_8_qp27_5frames", 1, 3), ("ref_intercrc_1920x1080_8_qp27_17frames_ra16", 1, 3), ("ref_intercrc_1920x1080_10_qp32_3frames", 1, 3)]
+         ("ref_intercrc_136x72_8_qp27_65frames_ra16", 1, 3), ("ref_intercrc_1920x1080_8_qp27_5frames", 1, 3), ("ref_intercrc_1920x1080_8_qp27_17frames_ra16", 1, 3), ("ref_intercrc_1920x1080_10_qp32_3frames", 1, 3),
+         # BASELINE configs[3]'s geometry and depth: 3840x2160 10-bit, low delay and --gop 16 (the four-wave build's 10-bit LDS image)
+         ("ref_intercrc_3840x2160_10_qp27_3frames", 1, 3), ("ref_intercrc_3840x2160_10_qp27_17frames_ra16", 1, 3)]
 
 
 @pytest.mark.parametrize("name,n_seq,sao_type", CASES)

@@ -814,16 +814,17 @@ class ClosedLoop(CtuSearch):
             try:
                 stats = AlfStatistics(self.out[i], None if source is None else source[i], W, H, shift)
                 d = decide(i, stats)
-                arr = dict(luma_aps=np.ascontiguousarray(np.asarray(d["luma_aps"], np.int16).reshape(-1, 677)[:int(d["n_luma_aps"])]),
-                           chroma_aps=np.ascontiguousarray(d["chroma_aps"], np.int16), cc_coeff=np.ascontiguousarray(d["cc_coeff"], np.int16),
-                           ctu_flags=np.ascontiguousarray(d["ctu_flags"], np.uint8), filter_set_idx=np.ascontiguousarray(d["filter_set_idx"], np.int16))
+                opt = lambda key, dt: np.zeros(0, dt) if d.get(key) is None else np.ascontiguousarray(d[key], dt)      # (a disabled component's arrays may be absent / None)
+                arr = dict(luma_aps=np.ascontiguousarray(np.asarray(opt("luma_aps", np.int16)).reshape(-1, 677)[:int(d.get("n_luma_aps", 0))]) if int(d.get("n_luma_aps", 0)) else np.zeros(0, np.int16),
+                           chroma_aps=opt("chroma_aps", np.int16), cc_coeff=opt("cc_coeff", np.int16), ctu_flags=opt("ctu_flags", np.uint8),
+                           filter_set_idx=opt("filter_set_idx", np.int16))
                 keep[:] = [arr]                               # (valid until the next call, as the ABI asks)
                 o = decision.contents
-                o.alf_type, o.n_luma_aps = int(d["alf_type"]), int(d["n_luma_aps"])
+                o.alf_type, o.n_luma_aps = int(d["alf_type"]), int(d.get("n_luma_aps", 0))
                 for c in range(3):
                     o.enabled[c] = int(d["enabled"][c])
                 for c in range(2):
-                    o.cc_enabled[c], o.cc_filter_count[c] = int(d["cc_enabled"][c]), int(d["cc_filter_count"][c])
+                    o.cc_enabled[c], o.cc_filter_count[c] = int(d.get("cc_enabled", (0, 0))[c]), int(d.get("cc_filter_count", (0, 0))[c])
                 for k, a in arr.items():
                     setattr(o, k, a.ctypes.data if a.size else None)
                 return 0

@@ -142,10 +142,13 @@ enum { CU_NOTSET = 0, CU_INTRA = 1, CU_INTER = 2 };
 
 // what the search reads from encoder_state_t / encoder_control_t (= uvghip_ctu_params_t, include/uvg266_hip.h)
 struct params {
-  int32_t pic_w, pic_h, qp, qp_c, depth_min, depth_max, wpp, combine_intra_cus, rough_levels, reserved;
+  int32_t pic_w, pic_h, qp, qp_c, depth_min, depth_max, wpp, combine_intra_cus, rough_levels, rd;       // rd: cfg.rdo, 0 or 1 (uvghip_ctu_params_t.rd)
   double lambda, lambda_sqrt, c_lambda, cw_u, cw_v;
   double c_lambda_tu;      // uvg_calculate_chroma_lambda (rate_control.c:1216-1233), evaluated by the host: lambda / 2^((qp - qp_c) / 3)
 };
+
+static_assert(sizeof(params) == sizeof(uvghip_ctu_params_t) && offsetof(params, rd) == offsetof(uvghip_ctu_params_t, rd) && offsetof(params, lambda) == offsetof(uvghip_ctu_params_t, lambda) &&
+              offsetof(params, c_lambda_tu) == offsetof(uvghip_ctu_params_t, c_lambda_tu), "ctu::params mirrors uvghip_ctu_params_t field by field");
 
 // one 4x4 unit of the CTU's side information while the search runs (the slice of cu_info_t this path reads back)
 struct cu4 {

@@ -1265,8 +1265,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_pb(lds<PX> *S, const job<P
     early_skipped = type == CU_INTER && Q.cur.skipped;
   }
   // no intra search when -- rd = 0 only -- the inter cost per sample is below INTRA_THRESHOLD = 8, or after an early skip (search.c:1413-1419).
-  // (P.reserved is uvghip_ctu_params_t.rd: cfg.rdo, 0 or 1)
-  const int skip_intra = (P.reserved == 0 && type != CU_NOTSET && cost / (double)(n * n) < 8) || (B.early_skip && early_skipped);
+  const int skip_intra = (P.rd == 0 && type != CU_NOTSET && cost / (double)(n * n) < 8) || (B.early_skip && early_skipped);
   int mode = 0;
   if (can_intra && !skip_intra) {
     PB_T0();

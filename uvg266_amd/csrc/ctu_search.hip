@@ -197,7 +197,7 @@ extern "C" int uvghip_ctu_plan_create_rows(int bitdepth, const uvghip_ctu_params
   if (p.pic_w <= 0 || p.pic_h <= 0 || (p.pic_w & 7) || (p.pic_h & 7) || p.pic_w > 64 * 255 || p.pic_h > 64 * 255 || n_pictures > 32767)
     return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_plan_create: picture size");
   if (p.wpp != 1 || p.depth_min < 1 || p.depth_max > 4 || p.depth_min > p.depth_max || p.rough_levels < 2 || p.rough_levels > 3 || p.qp < 0 || p.qp > 63 ||
-      p.qp_c < 0 || p.qp_c > 63 || !(p.lambda > 0))
+      p.qp_c < 0 || p.qp_c > 63 || !(p.lambda > 0) || p.rd < 0 || p.rd > 1)
     return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_plan_create: configuration outside the supported subset");
   const int wc = (p.pic_w + 63) / 64, hc = (p.pic_h + 63) / 64, ctus = wc * hc;
   if (ctu_row0 < 0 || ctu_row1 > hc || ctu_row0 >= ctu_row1) return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_plan_create_rows: CTU row range");

@@ -304,11 +304,11 @@ static int write_inter_picture(const char *who, int nal_type, int poc, int poc_l
     const int32_t *d = list ? delta_pos : delta_neg;
     const int n = list ? n_ref_pos : n_ref_neg;
     for (int j = 0; j < n; ++j)
-      if (d[j] < 1 || (j && d[j] <= d[j - 1]) || (!list && d[j] > poc)) return uvghip_set_error(hipErrorInvalidValue, "uvghip_write_picture_nals_pb / _ra: reference distances must be positive, ascending and inside the stream");
+      if (d[j] < 1 || (j && d[j] <= d[j - 1]) || (!list && d[j] > poc)) return uvghip_set_error(hipErrorInvalidValue, who);          // (reference distances must be positive, ascending and inside the stream: a no-GOP stream passes 1, 2, 3, ...)
   }
   int32_t longest = 0;
   for (int r = 0; r < n_rows; ++r) {
-    if (row_bytes[r] <= 0 || (size_t)row_bytes[r] > row_pitch) return uvghip_set_error(hipErrorInvalidValue, "uvghip_write_picture_nals_pb / _ra: a row is empty or longer than its slot");
+    if (row_bytes[r] <= 0 || (size_t)row_bytes[r] > row_pitch) return uvghip_set_error(hipErrorInvalidValue, who);          // (a row is empty or longer than its slot)
     if (row_bytes[r] > longest) longest = row_bytes[r];
   }
   nal_writer w = {out, cap, 0, 0, 0, 0};
@@ -330,8 +330,8 @@ static int write_inter_picture(const char *who, int nal_type, int poc, int poc_l
     int last = 0;
     for (int j = 0; j < n_ref_neg; ++j) {
       const int d = delta_neg[j];
-      w.ue(d ? (uint32_t)(d - last - 1) : 0u);      // abs_delta_poc_st
-      if (d + 1) w.bits(1, 1);                       // strp_entry_sign_flag: in the past
+      w.ue((uint32_t)(d - last - 1));               // abs_delta_poc_st (distances are >= 1 and ascending: checked above)
+      w.bits(1, 1);                                  // strp_entry_sign_flag: in the past
       last = d;
     }
   }
@@ -340,8 +340,8 @@ static int write_inter_picture(const char *who, int nal_type, int poc, int poc_l
     int last = 0;
     for (int j = 0; j < n_ref_pos; ++j) {
       const int d = delta_pos[j];
-      w.ue(d ? (uint32_t)(d - last - 1) : 0u);      // abs_delta_poc_st
-      if (d + 1) w.bits(0, 1);                       // strp_entry_sign_flag: in the future
+      w.ue((uint32_t)(d - last - 1));               // abs_delta_poc_st
+      w.bits(0, 1);                                  // strp_entry_sign_flag: in the future
       last = d;
     }
   }
