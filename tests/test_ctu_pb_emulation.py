@@ -13,7 +13,7 @@ GOLDENS = ["ref_inter_136x72_10_qp22_4frames", "ref_inter_192x128_8_qp17_5frames
 
 
 # (leaf wave, depth waves, lazy): one wave; two waves; three waves with every evaluation in at once / only when the walk waits for it; four waves
-BUILDS = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 1, 1), (1, 2, 1)]
+BUILDS = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 1, 1), (1, 2, 0), (1, 2, 1)]
 
 
 @pytest.mark.parametrize("leafwave,depthwave,lazy", BUILDS)

@@ -30,7 +30,7 @@ L.uvghip_ctu_search_pb_debug_scratch.restype = ctypes.c_size_t
 sb, ns = ctypes.c_size_t(), ctypes.c_int()
 names = ["candidate lists", "merge analysis", "early skip test", "integer ME", "fractional ME", "bi-prediction", "intra rough + chroma trial", "inter CU: pred + residual",
          "inter CU: bits + cost", "intra CU (eval_cu)", "unpark / save64 / restore64", "load", "store + deblock side effect", "coder pass", "TOTAL", "4x4 leaves (inside the leaf wave's time)",
-         "walk waits for the leaf wave", "walk waits for the depth wave", "aborts (count)", "depth wave: 16x16 evals", "depth wave: 32x32 evals", "leaf wave busy", "-", "-"]
+         "walk waits for the leaf wave", "walk waits for the depth wave", "aborts (count)", "depth wave: 16x16 evals", "depth wave: 32x32 evals", "leaf wave busy", "walk: CUs evaluated in place (64x64; every depth in the one-wave build)", "walk: 8x8 CUs beside the leaf wave"]
 for f, step in enumerate(loop.steps):
     if step[0] != "PB":
         continue

@@ -347,6 +347,11 @@ template <typename PX> struct lds {
   // the four-wave build: 32x32 CUs on a wave of their own (search state and, for the 16x16 depth, scratch)
   pb_state pbx2;
   alignas(16) unsigned char arena16[arena_bytes(16)];
+  // ... and the 64x64 CU evaluated there as well, beside the walk: its samples and levels (64x64 + 2 x 32x32) while the split is tried,
+  // the walk's models as they were after the CU's split flag (what a pruned CTU goes on with)
+  alignas(16) PX cand64_px[6144];
+  int16_t cand64_co[6144];
+  uint32_t cur64[NMX];
 #endif
 };
 #if defined(CTU_PB)

@@ -535,7 +535,11 @@ template <typename PX> struct cu_target {
 template <typename PX> CTU_DEV cu_target<PX> target_of(lds<PX> *S, const job<PX> &J, int L)
 {
   cu_target<PX> T;
-  if (L == 0) {
+  if (L == 0 && S->depth_wave == 2) {          // four waves: the 64x64 CU is a candidate like the others (the walk is already in its children)
+    T.ry = S->cand64_px; T.ru = S->cand64_px + 4096; T.rv = S->cand64_px + 5120;
+    T.ky = S->cand64_co; T.ku = S->cand64_co + 4096; T.kv = S->cand64_co + 5120;
+    T.rpy = T.kpy = LCU; T.rpc = T.kpc = LCU_C;
+  } else if (L == 0) {
     T.ry = S->Dy + PY + 1; T.ru = S->Du + PC + 1; T.rv = S->Dv + PC + 1;
     T.ky = J.coeff; T.ku = J.coeff + 4096; T.kv = J.coeff + 5120;
     T.rpy = PY; T.rpc = PC; T.kpy = LCU; T.kpc = LCU_C;
@@ -1303,7 +1307,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_pb(lds<PX> *S, const job<P
     else { PB_T0(); eval_cu(S, J, L, 1, mode); PB_T1(J.W, 9); }
   } else if (type == CU_INTER) {
     finish_inter(S, J, L, T);
-    if (L == 0) { SERIAL place_inter_cu(S, 0); CTU_SYNC(); }
+    if (L == 0 && S->depth_wave != 2) { SERIAL place_inter_cu(S, 0); CTU_SYNC(); }          // (in place; four waves: placed when its split has lost, unpark64_pb)
   } else {
     SERIAL { N.cost = CTU_MAX_DOUBLE; N.type = CU_NOTSET; }
     CTU_SYNC();
@@ -1326,6 +1330,21 @@ template <typename PX> CTU_NOINLINE CTU_DEV void unpark_pb(lds<PX> *S, const job
     PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); D[r * pit + q] = S->cand_px[off + e]; co[r * spit + q] = CTU_GLOAD(&J.W->cand_co[off + e]); }
   }
   SERIAL place_inter_cu(S, L);
+  CTU_SYNC();
+}
+
+// four waves: the 64x64 candidate, evaluated beside its children into cand64_px / cand64_co, becomes the CTU
+template <typename PX> CTU_NOINLINE CTU_DEV void unpark64_pb(lds<PX> *S, const job<PX> &J)
+{
+  for (int color = 0; color < 3; ++color) {
+    const int w = color ? 32 : 64, l2 = color ? 5 : 6, pit = pitch_of(color);
+    PX *D = plane(S, color) + pit + 1;
+    const PX *from = S->cand64_px + co_off(color);
+    const int16_t *cf = S->cand64_co + co_off(color);
+    int16_t *co = J.coeff + co_off(color);
+    PAR_FOR(e, w * w) { D[(e >> l2) * pit + (e & (w - 1))] = from[e]; co[e] = cf[e]; }
+  }
+  SERIAL place_inter_cu(S, 0);
   CTU_SYNC();
 }
 
@@ -1481,23 +1500,24 @@ template <typename PX> CTU_DEV void leaf_worker_loop(lds<PX> *S, const job<PX> &
 // decide "not split", both are re-applied as soon as the evaluation is in -- after every child, and on the way into every node below
 // (a pruned ancestor ends the walk under it at once) -- and a split that was started in vain is undone exactly like one that was tried
 // and lost: the candidate is put back over the CU's whole area, models and history table restart from the node's entry.
+CTU_DEV int mb_of(int L) { return L ? L : 3; }          // the mailbox of depth L (index 3, the 8x8 depth's, is free: the walk evaluates those itself)
 template <typename PX> CTU_DEV void post_eval_pb(lds<PX> *S, const job<PX> &J, int L)
 {
 #if defined(__HIPCC__)
   CTU_SYNC();
-  LANE0 mb_store(&S->req[L], S->req[L] + 1);
+  LANE0 mb_store(&S->req[mb_of(L)], S->req[mb_of(L)] + 1);
 #else
   const int me = g_emul_wave;
-  g_emul_wave = S->depth_wave == 2 && L == 1 ? 3 : 2;                      // host emulation: the depth wave's work happens right here
+  g_emul_wave = S->depth_wave == 2 && L <= 1 ? 3 : 2;                      // host emulation: the depth wave's work happens right here
   eval_pb(S, J, L, S->lvl[L].can & 1, S->lvl[L].can >> 1);
   g_emul_wave = me;
-  S->done[L] = ++S->req[L];
+  S->done[mb_of(L)] = ++S->req[mb_of(L)];
 #endif
 }
 template <typename PX> CTU_DEV bool eval_ready_pb(lds<PX> *S, int L)
 {
 #if defined(__HIPCC__)
-  return __builtin_amdgcn_readfirstlane(mb_load(&S->done[L]) == S->req[L]) != 0;
+  return __builtin_amdgcn_readfirstlane(mb_load(&S->done[mb_of(L)]) == S->req[mb_of(L)]) != 0;
 #else
   return !g_emul_lazy;
 #endif
@@ -1505,31 +1525,32 @@ template <typename PX> CTU_DEV bool eval_ready_pb(lds<PX> *S, int L)
 template <typename PX> CTU_DEV void wait_eval_pb(lds<PX> *S, int L)
 {
 #if defined(__HIPCC__)
-  while (mb_load(&S->done[L]) != S->req[L]) __builtin_amdgcn_s_sleep(1);
+  while (mb_load(&S->done[mb_of(L)]) != S->req[mb_of(L)]) __builtin_amdgcn_s_sleep(1);
   CTU_SYNC();
 #endif
 }
 #if defined(__HIPCC__)
 template <typename PX> CTU_DEV void depth_worker_loop(lds<PX> *S, const job<PX> &J)
 {
-  int seen[3] = {0, 0, 0};
-  // one depth wave (three-wave build): both depths; two: role 2 the 16x16 CUs, role 3 the 32x32 CUs
+  int seen[4] = {0, 0, 0, 0};
+  // one depth wave (three-wave build): both depths; two: role 2 the 16x16 CUs, role 3 the 32x32 CUs and the 64x64 CU
   const int role = CTU_WAVE, two = S->depth_wave == 2;
-  const bool mine1 = !two || role == 3, mine2 = !two || role == 2;
+  const bool mine1 = !two || role == 3, mine2 = !two || role == 2, mine0 = two && role == 3;
   for (;;) {
-    const int r1 = mb_load(&S->req[1]), r2 = mb_load(&S->req[2]);
+    const int r1 = mb_load(&S->req[1]), r2 = mb_load(&S->req[2]), r0 = mb_load(&S->req[3]);
     if (r1 < 0) break;
-    int L = 0, r = 0;
+    int L = -1, r = 0;
     if (mine2 && r2 != seen[2]) { L = 2; r = r2; }            // the deeper request first: the walk comes back for it sooner
     else if (mine1 && r1 != seen[1]) { L = 1; r = r1; }
-    if (!L) { __builtin_amdgcn_s_sleep(2); continue; }
-    seen[L] = r;
+    else if (mine0 && r0 != seen[3]) { L = 0; r = r0; }
+    if (L < 0) { __builtin_amdgcn_s_sleep(2); continue; }
+    seen[mb_of(L)] = r;
     CTU_SYNC();
     { PB_T0();
-    if (!mb_load(&S->skip_eval[L])) eval_pb(S, J, L, S->lvl[L].can & 1, S->lvl[L].can >> 1);
-    PB_T1(J.W, 19 + (L == 1)); }
+    if (!mb_load(&S->skip_eval[mb_of(L)])) eval_pb(S, J, L, S->lvl[L].can & 1, S->lvl[L].can >> 1);
+    PB_T1(J.W, L == 2 ? 19 : (L == 1 ? 20 : 22)); }
     CTU_SYNC();
-    LANE0 mb_store(&S->done[L], r);
+    LANE0 mb_store(&S->done[mb_of(L)], r);
   }
 }
 #endif
@@ -1573,21 +1594,21 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
                             ((L >= P.depth_min && L <= P.depth_max) || (x & ~(min_w - 1)) + min_w > P.pic_w || (y & ~(min_w - 1)) + min_w > P.pic_h);
       // a node under a CU whose evaluation has come in meanwhile and says "not split" (pruned, or the split already costs more): nothing
       // below it is wanted any more -- back to that CU's decision
-      if (S->depth_wave && L >= 2) {
-        int A = 0;
-        for (int a = 1; a < L && !A; ++a) {
+      if (S->depth_wave && L >= (S->depth_wave == 2 ? 1 : 2)) {
+        int A = -1;
+        for (int a = S->depth_wave == 2 ? 0 : 1; a < L && A < 0; ++a) {
           level_state &M = S->lvl[a];
-          if (!M.evalp) continue;
+          if (M.evalp != 1) continue;          // (2: the 64x64 CU's request is not out yet)
           if (!M.known && eval_ready_pb(S, a)) { SERIAL take_eval_pb(S, P, a); CTU_SYNC(); }
           if (M.known && (M.pending || M.split_cost > M.cost)) A = a;
         }
-        if (A) {
+        if (A >= 0) {
           for (int a = A + 1; a < L; ++a)
             if (S->lvl[a].evalp && !S->lvl[a].known) {          // an evaluation of a node in between is still out: not wanted, but its buffers are in use
 #if defined(__HIPCC__)
-              LANE0 mb_store(&S->skip_eval[a], 1);
+              LANE0 mb_store(&S->skip_eval[mb_of(a)], 1);
               wait_eval_pb(S, a);
-              LANE0 mb_store(&S->skip_eval[a], 0);
+              LANE0 mb_store(&S->skip_eval[mb_of(a)], 0);
               CTU_SYNC();
 #endif
             }
@@ -1598,6 +1619,14 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
           level_state &M = S->lvl[L];
           const int ntype = M.type;
           CTU_SYNC();
+          if (L == 0) {
+            // the 64x64 CU: a pruned CTU goes on as the one-wave build leaves it -- the models behind the CU's split flag, the history table
+            // of the CTU's entry, the CU in place; a split that lost after its children ran keeps the children's models (search_ctu_pb below)
+            if (M.pending) { copy_models(S->cur, S->cur64); SERIAL { for (int i = 0; i < 41; ++i) S->pb.hmvp[i] = S->pb.hmvp_entry[0][i]; } CTU_SYNC(); }
+            if (ntype != CU_NOTSET) { PB_T0(); unpark64_pb(S, J); PB_T1(J.W, 10); }
+            ret = M.cost;
+            break;
+          }
           copy_models(S->cur, S->work[L - 1]);
           SERIAL { for (int i = 0; i < 41; ++i) S->pb.hmvp[i] = S->pb.hmvp_entry[L][i]; if (ntype == CU_INTER) hmvp_add(S->pb.hmvp, M.mot); }
           CTU_SYNC();
@@ -1626,10 +1655,10 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
         N.type = CU_NOTSET; N.cost = CTU_MAX_DOUBLE; N.pending = 0; N.evalp = 0; N.known = 1;
       }
       CTU_SYNC();
-      if (S->depth_wave && (L == 1 || L == 2) && P.depth_max >= 4) {
-        // a 32x32 / 16x16 CU with the depth wave: evaluated there from now on, the walk goes into the children
+      if (S->depth_wave && (L == 1 || L == 2 || (L == 0 && S->depth_wave == 2)) && P.depth_max >= 4) {
+        // a 32x32 / 16x16 CU with the depth wave (four waves: the 64x64 CU too): evaluated there from now on, the walk goes into the children
         const bool will_eval = inside && (can_inter || can_intra);
-        if (will_eval) copy_models(S->work[L - 1], S->cur);
+        if (will_eval) copy_models(L == 0 ? S->pb.work0 : S->work[L - 1], S->cur);
         SERIAL {
           double split_bits = 0;
           split_flag_bits(S, P, S->cur, 1, x, y, x & 63, y & 63, n, 1, split_bits);
@@ -1645,7 +1674,12 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
           C.x = N.x; C.y = N.y; C.has_chroma = 1;
         }
         CTU_SYNC();
-        if (will_eval) post_eval_pb(S, J, L);
+        if (L == 0) copy_models(S->cur64, S->cur);          // (what a pruned CTU goes on with)
+        // the 64x64 CU's request goes out behind the first 32x32 CU's: the wave that takes both takes the deeper one first, and the walk
+        // comes back for that one long before it needs the 64x64 CU's cost
+        if (will_eval && L > 0) post_eval_pb(S, J, L);
+        if (L == 1 && S->lvl[0].evalp == 2) { SERIAL S->lvl[0].evalp = 1; CTU_SYNC(); post_eval_pb(S, J, 0); }
+        if (L == 0 && will_eval) { SERIAL N.evalp = 2; CTU_SYNC(); }
         ++L;
         continue;
       }
@@ -1667,7 +1701,7 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
         }
         LANE0 S->leaf_limit = CTU_MAX_DOUBLE;
         post_leaves(S, J);
-        if (will_eval) eval_pb(S, J, L, can_inter, can_intra);
+        if (will_eval) { PB_T0(); eval_pb(S, J, L, can_inter, can_intra); PB_T1(J.W, 23); }
 #if defined(__HIPCC__)
         // the CU's cost is in: what the split may cost at most before it has lost (pruned: nothing) -- the leaf wave stops there
         LANE0 {
@@ -1691,7 +1725,7 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
       } else {
       if (inside && (can_inter || can_intra)) {
         copy_models(L == 0 ? S->pb.work0 : S->work[L - 1], S->cur);
-        eval_pb(S, J, L, can_inter, can_intra);
+        { PB_T0(); eval_pb(S, J, L, can_inter, can_intra); PB_T1(J.W, 22); }
       }
       const int ntype = N.type;
       const double ncost = N.cost;
@@ -1730,7 +1764,7 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
     }
     if (!decide) {
       // a child of N came back with `ret`
-      if (N.evalp && !N.known && eval_ready_pb(S, L)) { SERIAL take_eval_pb(S, P, L); CTU_SYNC(); }
+      if (N.evalp == 1 && !N.known && eval_ready_pb(S, L)) { SERIAL take_eval_pb(S, P, L); CTU_SYNC(); }
       SERIAL {
         N.split_cost += ret;
         const int k = N.child;
@@ -1761,6 +1795,10 @@ template <typename PX> CTU_DEV void search_ctu_pb(lds<PX> *S, const job<PX> &J)
         SERIAL { for (int i = 0; i < 41; ++i) S->pb.hmvp[i] = S->pb.hmvp_entry[L][i]; if (ntype == CU_INTER) hmvp_add(S->pb.hmvp, N.mot); }      // (uvg_hmvp_add_mv ignores an intra CU)
         CTU_SYNC();
         if (ntype != CU_NOTSET) { PB_T0(); unpark_pb(S, J, L); PB_T1(J.W, 10); }
+      } else if (S->depth_wave == 2) {
+        // the 64x64 CU of the four-wave build (evaluated beside its children): see the abort above
+        if (pruned) { copy_models(S->cur, S->cur64); SERIAL { for (int i = 0; i < 41; ++i) S->pb.hmvp[i] = S->pb.hmvp_entry[0][i]; } CTU_SYNC(); }
+        if (ntype != CU_NOTSET) { PB_T0(); unpark64_pb(S, J); PB_T1(J.W, 10); }
       } else if (!pruned && ntype != CU_NOTSET) { PB_T0(); restore64_pb(S, J); PB_T1(J.W, 10); }
     }
     ret = N.cost;
