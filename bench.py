@@ -722,7 +722,7 @@ def c3_clip(device, frames=120, with_cpu=True):
     states = Hh.frame_states_from_records(g["meta"], g["lam"], g["refs"])[:frames]
     host = [[torch.from_numpy(np.ascontiguousarray(p)).pin_memory() for p in Hh.clip_picture(W, H, t, depth)] for t in range(frames)]
     src = [[tuple(torch.empty_like(p, device=device) for p in host[t]) for t in range(frames)]]
-    loop = api.LowDelayLoop(W, H, depth, 1, states, src, inflight=True, inflight_margin=11)
+    loop = api.LowDelayLoop(W, H, depth, 1, states, src, inflight=True, inflight_margin=11, intra_in_flight=True)
 
     def run():
         for t in range(frames):
@@ -781,7 +781,7 @@ def ra_clip(device, frames=65, with_cpu=True):
     display = [int(a) for a in g["display"][:frames]]
     shown = {t: tuple(torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in Hh.clip_picture(W, H, t, depth)) for t in sorted(set(display))}
     src = [[shown[display[f]] for f in range(frames)]]
-    loop = api.LowDelayLoop(W, H, depth, 1, states, src, inflight=True, inflight_margin=11)
+    loop = api.LowDelayLoop(W, H, depth, 1, states, src, inflight=True, inflight_margin=11, intra_in_flight=True)
     loop.run()                                            # warm-up (plans, first-touch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

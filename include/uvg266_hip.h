@@ -1333,6 +1333,36 @@ UVGHIP_API int uvghip_loop_pb_results(int bitdepth, int n_pictures, int pic_w, i
  * ref_in_call[i * 16 + k]): one persistent launch for the search + the per-CTU in-loop filters of the whole reference DAG of the call,
  * then one launch of the arithmetic coder over all its pictures.  pic.rec_* stay unfiltered; the deblocked pictures live in the workspace.
  * Results as uvghip_loop_pb_results.  Nothing waits for the stream. */
+/* ... with I pictures IN the flight (round 6): a picture of the call whose SEARCH runs in the all-intra launch on ANOTHER stream beside this
+ * call (ext[i].searched_flags = uvghip_loop_plan_searched_flags(plan) + picture * ctus; pictures[i].search.slice_type 2, .params / .pic the
+ * plan's picture, out_* its output planes).  This call runs its filter stage CTU by CTU as that launch finishes its CTUs and the P / B
+ * pictures that refer to it follow four diagonals behind, as behind any other picture.  Its SAO decisions go to ext[i].sao_info /
+ * sao_models (the plan's arrays, uvghip_loop_plan_results), its slice data comes from uvghip_loop_plan_run_coder afterwards.  A picture that
+ * refers to it names it in ref_in_call; its ref_motion is the caller's table for an intra picture (type 1 everywhere, no vectors).
+ * The caller's duties: (1) uvghip_loop_plan_search_reset on the plan's stream, an event behind it, THIS call's stream waits for the event
+ * (the flags must be zero before this call's kernel can look at them), then uvghip_loop_plan_search_launch; (2) the plan's launch must be
+ * small enough to run beside this call's workgroups, which take whole CUs: uvghip_loop_plan_set_search_grid(plan, G) makes it G persistent
+ * workgroups, and other_workgroups = G here leaves them their CUs (G / 4).  ext == NULL: uvghip_loop_pb_run_inflight. */
+typedef struct uvghip_inflight_external {
+  const int32_t *searched_flags;        /* DEVICE, [ctus]; NULL: an ordinary picture of the call */
+  int32_t *sao_info;                    /* DEVICE, [ctus][34] / [ctus][6]: where the picture's SAO decisions go (NULL: the call's own results) */
+  uint16_t *sao_models;
+} uvghip_inflight_external_t;
+UVGHIP_API int uvghip_loop_pb_run_inflight_ext(int bitdepth, const uvghip_loop_pb_picture_t *pictures, int n_pictures, int sao_type, const int32_t *ref_in_call,
+                                               const uvghip_inflight_external_t *ext, int other_workgroups, void *workspace, void *stream);
+UVGHIP_API int uvghip_ctu_search_pb_inflight_ext(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, const uvghip_pb_filter_t *filters, const int32_t *ref_in_call,
+                                                 const int32_t *const *searched_flags, int other_workgroups, int n_pictures, void *workspace, void *stream);
+/* the all-intra plan's side of it: the search launch in two halves (reset: counters and flags to zero in stream order; launch), as G
+ * persistent workgroups (0: one per CTU), its per-CTU "searched" flags [picture][ctu], and the slice data alone */
+UVGHIP_API int uvghip_loop_plan_search_reset(uvghip_loop_plan_t *plan, void *stream);
+UVGHIP_API int uvghip_loop_plan_search_launch(uvghip_loop_plan_t *plan, void *stream);
+UVGHIP_API int uvghip_loop_plan_set_search_grid(uvghip_loop_plan_t *plan, int max_workgroups);
+UVGHIP_API const int32_t *uvghip_loop_plan_searched_flags(const uvghip_loop_plan_t *plan);
+UVGHIP_API int uvghip_loop_plan_run_coder(uvghip_loop_plan_t *plan, void *stream);
+UVGHIP_API int uvghip_ctu_plan_reset(uvghip_ctu_plan_t *plan, void *stream);
+UVGHIP_API int uvghip_ctu_plan_launch(uvghip_ctu_plan_t *plan, void *stream);
+UVGHIP_API int uvghip_ctu_plan_set_grid(uvghip_ctu_plan_t *plan, int max_workgroups);
+UVGHIP_API const int32_t *uvghip_ctu_plan_done_flags(const uvghip_ctu_plan_t *plan);
 UVGHIP_API size_t uvghip_loop_pb_inflight_workspace_bytes(int bitdepth, int n_pictures, int pic_w, int pic_h);
 UVGHIP_API int uvghip_loop_pb_run_inflight(int bitdepth, const uvghip_loop_pb_picture_t *pictures, int n_pictures, int sao_type, const int32_t *ref_in_call,
                                            void *workspace, void *stream);

@@ -33,8 +33,19 @@ CASES = [("ref_inter_136x200_8_qp27_11frames_owf1", 1, 3), ("ref_inter_136x200_8
          ("ref_intercrc_3840x2160_10_qp27_3frames", 1, 3), ("ref_intercrc_3840x2160_10_qp27_17frames_ra16", 1, 3)]
 
 
+# the I pictures in the flight too: searched by a few persistent workgroups on a second stream, filtered CTU by CTU by the in-flight launch
+INTRA_CASES = [("ref_inter_136x200_8_qp27_11frames_owf1", 1), ("ref_inter_264x136_8_qp32_9frames", 2), ("ref_inter_136x72_10_qp22_17frames_ra16", 1),
+               ("ref_inter_136x72_8_qp27_33frames_ra16p16", 1), ("ref_intercrc_1920x1080_8_qp27_5frames", 1), ("ref_intercrc_1920x1080_8_qp27_17frames_ra16", 1),
+               ("ref_intercrc_1920x1080_10_qp32_3frames", 1)]
+
+
+@pytest.mark.parametrize("name,n_seq", INTRA_CASES)
+def test_intra_pictures_in_the_flight(hip, name, n_seq):
+    test_pictures_in_flight_reproduce_the_encoder(hip, name, n_seq, 3, intra_in_flight=True)
+
+
 @pytest.mark.parametrize("name,n_seq,sao_type", CASES)
-def test_pictures_in_flight_reproduce_the_encoder(hip, name, n_seq, sao_type):
+def test_pictures_in_flight_reproduce_the_encoder(hip, name, n_seq, sao_type, intra_in_flight=False):
     import time
     import torch
     from uvg266_amd import api
@@ -48,7 +59,7 @@ def test_pictures_in_flight_reproduce_the_encoder(hip, name, n_seq, sao_type):
     pics = H.golden_sources(g)
     src = [[tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in pics[f]) for f in range(frames)] for _ in range(n_seq)]
     loop = api.LowDelayLoop(W, Hh, depth, n_seq, states, src, sao_type=sao_type, tmvp=cfg[0], max_merge=cfg[1], merge_level=cfg[2], bipred=cfg[3], fme_level=cfg[4],
-                            early_skip=cfg[5], rd=cfg[6] if len(cfg) > 6 else 0, inflight=True, inflight_margin=11 if sao_type else 9)
+                            early_skip=cfg[5], rd=cfg[6] if len(cfg) > 6 else 0, inflight=True, inflight_margin=11 if sao_type else 9, intra_in_flight=intra_in_flight)
     for rep in range(2):          # twice: the second run starts from a used workspace
         t0 = time.time()
         loop.run()

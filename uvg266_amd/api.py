@@ -1036,8 +1036,11 @@ class LowDelayLoop:
     temporal layer, and of neighbouring GOPs, run side by side on k streams (deps[f]: the coded pictures f reads)."""
 
     def __init__(self, W, H, depth, n_seq, frames, src, sao_type=3, tmvp=1, max_merge=6, merge_level=2, bipred=1, fme_level=4, early_skip=1, by_level=False, rd=0, inflight_margin=0,
-                 inflight=False):
-        """inflight: the encoder's --owf schedule (encoderstate.c:1060-1116): ALL P / B pictures go through ONE uvghip_loop_pb_run_inflight -- a
+                 inflight=False, intra_in_flight=False, intra_grid=64):
+        """intra_in_flight (with inflight): the I pictures are part of the flight too -- their search runs as `intra_grid` persistent workgroups on a
+        second stream BESIDE the in-flight launch, which filters them CTU by CTU as they are searched (uvghip_loop_pb_run_inflight_ext), so the
+        P / B pictures behind an I picture follow it four diagonals behind instead of waiting for the whole picture.
+        inflight: the encoder's --owf schedule (encoderstate.c:1060-1116): ALL P / B pictures go through ONE uvghip_loop_pb_run_inflight -- a
         picture's CTU (x, y) starts when CTU (x + 2, y + 1) of the pictures it reads is final, the in-loop filters run per CTU inside the
         search kernel -- after the I pictures (which depend on nothing).  Needs inflight_margin = 11 (9 without SAO): the vector restriction
         of an encoder run with --owf != 0, whose bitstream this then is.
@@ -1139,7 +1142,54 @@ class LowDelayLoop:
             for f in range(len(frames)):          # (the per-frame workspaces are not needed)
                 if self.steps[f][0] == "PB" and not any(st is self.steps[f] for _, st in self.order):
                     self.steps[f] = ("PB", self.steps[f][1], None, self.steps[f][3])
-        if inflight:
+        self.intra_in_flight = bool(inflight and intra_in_flight)
+        if self.intra_in_flight:
+            # an intra picture as a reference: type 1 inside the picture, no vectors -- known before anything runs
+            for fl, loop, gm in igroup.values():
+                if loop.n * ctus > intra_grid:
+                    _lib.check(self.L.uvghip_loop_plan_set_search_grid(loop.loop, int(intra_grid)), "uvghip_loop_plan_set_search_grid")
+                for m in gm:
+                    m.zero_()
+                    m[:H // 4, :W // 4, 0] = 1
+                    m[:, :, 6:8] = -1
+            pb = [f for f in range(len(frames)) if self.steps[f][0] == "PB"]
+            ent = []                                   # the flight's pictures: (kind, coded picture, sequence) -- the I pictures first
+            for fl, loop, gm in igroup.values():
+                for j, f in enumerate(fl):
+                    ent += [("I", f, s_, loop, j * n_seq + s_) for s_ in range(n_seq)]
+            n_ext = len(ent)
+            ent += [("PB", f, s_, None, 0) for f in pb for s_ in range(n_seq)]
+            at = {(e[1], e[2]): i for i, e in enumerate(ent)}
+            n = len(ent)
+            arr = (_lib.LoopPbPicture * n)()
+            ext = (_lib.InflightExternal * n)()
+            ric = np.full((n, 16), -1, np.int32)
+            a_, b_ = ctypes.c_void_p(), ctypes.c_void_p()
+            for i, (kind, f, s_, loop, idx) in enumerate(ent):
+                if kind == "I":
+                    q = arr[i]
+                    q.search.params = loop.P
+                    q.search.pic = loop.pics[idx]
+                    q.search.slice_type = 2
+                    o = loop.out[idx]
+                    q.out_y, q.out_u, q.out_v = (_dev(a) for a in o)
+                    q.out_stride, q.out_stride_c = o[0].stride(0), o[1].stride(0)
+                    _lib.check(self.L.uvghip_loop_plan_results(loop.loop, ctypes.byref(a_), ctypes.byref(b_)), "uvghip_loop_plan_results")
+                    ext[i].searched_flags = self.L.uvghip_loop_plan_searched_flags(loop.loop) + idx * ctus * 4
+                    ext[i].sao_info, ext[i].sao_models = a_.value + idx * ctus * 34 * 4, b_.value + idx * ctus * 6 * 2
+                else:
+                    ctypes.memmove(ctypes.addressof(arr) + i * ctypes.sizeof(_lib.LoopPbPicture), ctypes.addressof(self.steps[f][1]) + s_ * ctypes.sizeof(_lib.LoopPbPicture),
+                                   ctypes.sizeof(_lib.LoopPbPicture))
+                    for k in range(frames[f]["n_refs"]):
+                        g = self.ref_frame[f][k]
+                        if (g, s_) in at:
+                            ric[i, k] = at[(g, s_)]
+            ws = z(self.L.uvghip_loop_pb_inflight_workspace_bytes(depth, n, W, H), torch.uint8)
+            grid_sum = sum(min(int(intra_grid), loop.n * ctus) for _, loop, _ in igroup.values())
+            self.order = [(list(range(len(frames))), ("FLIGHT_EXT", arr, ws, (np.ascontiguousarray(ric), ext, ent, n_ext, grid_sum, list(igroup.values()))))]
+            for f in pb:
+                self.steps[f] = ("PB", self.steps[f][1], None, self.steps[f][3])
+        elif inflight:
             pb = [f for f in range(len(frames)) if self.steps[f][0] == "PB"]
             self.order = [(fl, ("I", loop, gm, fl)) for fl, loop, gm in igroup.values()]
             if pb:
@@ -1173,6 +1223,8 @@ class LowDelayLoop:
             for t in self._streams[:in_flight]:
                 t.wait_event(start)
             done = {}
+        if self.intra_in_flight:
+            return self._run_intra_in_flight(st)
         for k, (fr, step) in enumerate(self.order):
             f = fr[0]
             if in_flight > 1:
@@ -1218,3 +1270,46 @@ class LowDelayLoop:
                 e = torch.cuda.Event()
                 e.record(t)
                 caller.wait_event(e)
+
+    def _run_intra_in_flight(self, st):
+        """The I pictures' searches on stream A, the flight (their filters + every P / B picture) on stream B, both behind the caller's stream;
+        the I pictures' slice data behind the flight; the caller's stream waits for both."""
+        _, (kind, arr, ws, (ric, ext, ent, n_ext, grid_sum, groups)) = self.order[0]
+        if not hasattr(self, "_ab"):
+            self._ab = (torch.cuda.Stream(), torch.cuda.Stream())
+        A, B = self._ab
+        caller = torch.cuda.ExternalStream(st)
+        start = torch.cuda.Event()
+        start.record(caller)
+        A.wait_event(start); B.wait_event(start)
+        for fl, loop, gm in groups:          # flags back to zero before the flight's kernel can look at them
+            _lib.check(self.L.uvghip_loop_plan_search_reset(loop.loop, A.cuda_stream), "uvghip_loop_plan_search_reset")
+        cleared = torch.cuda.Event()
+        cleared.record(A)
+        B.wait_event(cleared)
+        for fl, loop, gm in groups:
+            _lib.check(self.L.uvghip_loop_plan_search_launch(loop.loop, A.cuda_stream), "uvghip_loop_plan_search_launch")
+        n = len(ent)
+        _lib.check(self.L.uvghip_loop_pb_run_inflight_ext(self.depth, ctypes.byref(arr), n, self.sao_type, ric.ctypes.data, ctypes.byref(ext), grid_sum, _dev(ws), B.cuda_stream),
+                   "uvghip_loop_pb_run_inflight_ext")
+        searched = torch.cuda.Event()
+        searched.record(A)
+        B.wait_event(searched)          # (the coder reads the search's levels and models: all there when the flight is done, this says so to the stream)
+        for fl, loop, gm in groups:
+            _lib.check(self.L.uvghip_loop_plan_run_coder(loop.loop, B.cuda_stream), "uvghip_loop_plan_run_coder")
+            rows, nb = loop.slice_data()
+            for j, g in enumerate(fl):
+                self.rows[g], self.row_bytes[g] = rows[j * self.n_seq:(j + 1) * self.n_seq], nb[j * self.n_seq:(j + 1) * self.n_seq]
+        c, d, cap, nr = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(self.L.uvghip_loop_pb_inflight_results(self.depth, n, self.W, self.H, _dev(ws), None, None, ctypes.byref(c), ctypes.byref(d), ctypes.byref(cap), ctypes.byref(nr)),
+                   "uvghip_loop_pb_inflight_results")
+        base = ws.data_ptr()
+        rows = ws[c.value - base:c.value - base + n * nr.value * cap.value].view(n, nr.value, cap.value)
+        row_bytes = ws[d.value - base:d.value - base + n * nr.value * 4].view(torch.int32).view(n, nr.value)
+        pb = sorted({e[1] for e in ent[n_ext:]})
+        for j, g in enumerate(pb):
+            i0 = n_ext + j * self.n_seq
+            self.rows[g], self.row_bytes[g] = rows[i0:i0 + self.n_seq], row_bytes[i0:i0 + self.n_seq]
+        done = torch.cuda.Event()
+        done.record(B)
+        caller.wait_event(done)

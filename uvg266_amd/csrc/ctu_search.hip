@@ -41,7 +41,10 @@ struct launch_args {
 static_assert(sizeof(ctu::lds<uint8_t>) + 4304 <= 40960, "the 8-bit LDS image of a CTU no longer fits four workgroups per CU");
 static_assert(!ctu::lds_cfg<uint16_t>::slim || sizeof(ctu::lds<uint16_t>) + 4304 <= 40960, "the slim 10-bit LDS image of a CTU no longer fits four workgroups per CU");
 
-template <typename PX>
+// PERSIST: a small grid of workgroups that take CTU after CTU (uvghip_ctu_plan_set_grid) -- for a few pictures whose search runs BESIDE
+// another kernel (the I pictures of a clip beside the in-flight P / B launch, which takes whole CUs): the launch then holds G workgroup
+// slots instead of one per CTU, most of them waiting.  Same CTUs, same order, same results.
+template <typename PX, bool PERSIST>
 __global__ void __launch_bounds__(256, 4) ctu_search_kernel(launch_args A)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -86,7 +89,9 @@ __global__ void __launch_bounds__(256, 4) ctu_search_kernel(launch_args A)
     }
   }
   __syncthreads();
+  for (;;) {
   const int ticket = s_ticket;
+  if (PERSIST && ticket >= A.n_ctus) break;
   const int32_t o = A.order[ticket];
   const int pic = o >> 16, cy = (o >> 8) & 0xff, cx = o & 0xff;
   const int ctus = A.wc * A.hc, k = cy * A.wc + cx;
@@ -123,6 +128,12 @@ __global__ void __launch_bounds__(256, 4) ctu_search_kernel(launch_args A)
   if (threadIdx.x == 0) {
     // ... and ONE agent-scope release writes the XCD's L2 back (it is shared by the waves): a fence per wave did that four times over
     __hip_atomic_store(&done[k], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (PERSIST) s_ticket = atomicAdd(A.ticket, 1);
+  }
+  if (!PERSIST) break;
+  __syncthreads();
+  }
+  if (threadIdx.x == 0) {
     atomicAnd(&A.slots[s_slot >> 5], ~(1u << (s_slot & 31)));          // the scratch is free again
     atomicSub(&A.simd_load[s_load], 1);
   }
@@ -172,6 +183,7 @@ extern "C" size_t uvghip_ctu_search_workspace_bytes(int n_pictures, int pic_w, i
 struct uvghip_ctu_plan {
   launch_args A;
   int bitdepth, total;
+  int grid;                   // 0: a workgroup per CTU; else that many persistent workgroups (uvghip_ctu_plan_set_grid)
   size_t counters;            // bytes of (ticket, done flags) at the head of the workspace
   unsigned char *ws;
 };
@@ -237,26 +249,59 @@ extern "C" int uvghip_ctu_plan_create_rows(int bitdepth, const uvghip_ctu_params
   pl->A.simd_load = reinterpret_cast<int32_t *>(ws + L.simd_load);
   pl->A.n_slots = L.n_slots;
   pl->A.wc = wc; pl->A.hc = hc; pl->A.n_ctus = total; pl->A.row0 = ctu_row0;
-  pl->bitdepth = bitdepth; pl->total = total; pl->counters = L.order; pl->ws = ws;
+  pl->bitdepth = bitdepth; pl->total = total; pl->counters = L.order; pl->ws = ws; pl->grid = 0;
   const size_t lds = (bitdepth == 8 ? sizeof(ctu::lds<uint8_t>) : sizeof(ctu::lds<uint16_t>)) + lds_pad();
   const hipError_t e = bitdepth == 8
-      ? hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-      : hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      ? hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_kernel<uint8_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+      : hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_kernel<uint16_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) { delete pl; return uvghip_set_error(e, "uvghip_ctu_plan_create: dynamic LDS size"); }
+  const hipError_t e2 = bitdepth == 8
+      ? hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_kernel<uint8_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+      : hipFuncSetAttribute(reinterpret_cast<const void *>(&ctu_search_kernel<uint16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e2 != hipSuccess) { delete pl; return uvghip_set_error(e2, "uvghip_ctu_plan_create: dynamic LDS size"); }
   *plan_out = pl;
   return 0;
 }
 
-extern "C" int uvghip_ctu_plan_run(uvghip_ctu_plan_t *pl, void *stream)
+// A run in two halves, for a caller that lets ANOTHER stream's kernel wait for this plan's per-CTU flags (pictures in flight behind an I
+// picture, uvghip_loop_pb_run_inflight_ext): reset -- the counters and flags back to zero, in stream order; the other stream waits for
+// an event recorded behind it -- then launch.  uvghip_ctu_plan_run is the two in a row.
+extern "C" int uvghip_ctu_plan_reset(uvghip_ctu_plan_t *pl, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  UVGHIP_TRY(hipMemsetAsync(pl->ws, 0, pl->counters, uvghip_stream(stream)));
+  return 0;
+}
+extern "C" int uvghip_ctu_plan_launch(uvghip_ctu_plan_t *pl, void *stream)
 {
   UVGHIP_REQUIRE_READY();
   if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);
   hipStream_t st = uvghip_stream(stream);
-  UVGHIP_TRY(hipMemsetAsync(pl->ws, 0, pl->counters, st));
-  if (pl->bitdepth == 8) hipLaunchKernelGGL(ctu_search_kernel<uint8_t>, dim3(pl->total), dim3(256), sizeof(ctu::lds<uint8_t>) + lds_pad(), st, pl->A);
-  else hipLaunchKernelGGL(ctu_search_kernel<uint16_t>, dim3(pl->total), dim3(256), sizeof(ctu::lds<uint16_t>) + lds_pad(), st, pl->A);
+  const size_t lds = (pl->bitdepth == 8 ? sizeof(ctu::lds<uint8_t>) : sizeof(ctu::lds<uint16_t>)) + lds_pad();
+  if (pl->grid > 0 && pl->grid < pl->total) {
+    if (pl->bitdepth == 8) hipLaunchKernelGGL((ctu_search_kernel<uint8_t, true>), dim3(pl->grid), dim3(256), lds, st, pl->A);
+    else hipLaunchKernelGGL((ctu_search_kernel<uint16_t, true>), dim3(pl->grid), dim3(256), lds, st, pl->A);
+  } else {
+    if (pl->bitdepth == 8) hipLaunchKernelGGL((ctu_search_kernel<uint8_t, false>), dim3(pl->total), dim3(256), lds, st, pl->A);
+    else hipLaunchKernelGGL((ctu_search_kernel<uint16_t, false>), dim3(pl->total), dim3(256), lds, st, pl->A);
+  }
   UVGHIP_CHECK_LAUNCH();
 }
+extern "C" int uvghip_ctu_plan_run(uvghip_ctu_plan_t *pl, void *stream)
+{
+  if (int rc = uvghip_ctu_plan_reset(pl, stream)) return rc;
+  return uvghip_ctu_plan_launch(pl, stream);
+}
+// ... max_workgroups > 0: the launch is that many persistent workgroups (0: one per CTU, the default)
+extern "C" int uvghip_ctu_plan_set_grid(uvghip_ctu_plan_t *pl, int max_workgroups)
+{
+  if (!pl || max_workgroups < 0) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  pl->grid = max_workgroups;
+  return 0;
+}
+// ... the per-CTU "searched" flags [picture][ctu] (DEVICE memory; zero after the reset, 1 when the CTU's outputs are published)
+extern "C" const int32_t *uvghip_ctu_plan_done_flags(const uvghip_ctu_plan_t *pl) { return pl ? pl->A.done : nullptr; }
 
 extern "C" void uvghip_ctu_plan_destroy(uvghip_ctu_plan_t *pl) { delete pl; }
 

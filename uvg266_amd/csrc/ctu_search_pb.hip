@@ -28,6 +28,9 @@ struct pb_pic_dev {
   // pictures in flight (uvghip_ctu_search_pb_inflight): the pictures of this call whose output this one reads, its depth in that DAG
   int n_wait, level;
   int wait_pic[16];
+  // a picture whose SEARCH runs elsewhere (an I picture in the all-intra launch beside this call): its per-CTU "searched" flags; the
+  // kernel waits for them and runs the picture's filter stage only
+  const int32_t *ext_done;
 };
 
 struct pb_launch_args {
@@ -96,9 +99,12 @@ __global__ void __launch_bounds__(NT) ctu_search_pb_kernel(pb_launch_args A)
     const int pic = o >> 16, cy = (o >> 8) & 0xff, cx = o & 0xff;
     const int ctus = A.wc * A.hc, k = cy * A.wc + cx;
     int32_t *done = A.done + (size_t)pic * ctus;
+    const int32_t *const ext = A.fpics ? A.pics[pic].ext_done : nullptr;
     if (threadIdx.x == 0) {
       int naps = 1;
-      const int32_t *deps[3] = {cx > 0 ? &done[k - 1] : nullptr, cy > 0 ? &done[k - A.wc] : nullptr, cy > 0 && cx + 1 < A.wc ? &done[k - A.wc + 1] : nullptr};
+      // (an externally searched picture: that launch's own order has the CTU's neighbours done before the CTU)
+      const int32_t *deps[3] = {ext ? &ext[k] : (cx > 0 ? &done[k - 1] : nullptr), !ext && cy > 0 ? &done[k - A.wc] : nullptr,
+                                !ext && cy > 0 && cx + 1 < A.wc ? &done[k - A.wc + 1] : nullptr};
       for (int d = 0; d < 3; ++d)
         while (deps[d] && __hip_atomic_load(deps[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
           for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);
@@ -139,7 +145,7 @@ __global__ void __launch_bounds__(NT) ctu_search_pb_kernel(pb_launch_args A)
     J.pb = &D.B;
     J.W = A.scratch + s_slot;
     J.x = cx * 64; J.y = cy * 64;
-    ctu::run_ctu_pb(S, J);
+    if (!ext) ctu::run_ctu_pb(S, J);
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&done[k], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #if defined(CTU_PROFILE)
@@ -270,24 +276,30 @@ extern "C" size_t uvghip_ctu_search_pb_workspace_bytes(int n_pictures, int pic_w
 }
 
 namespace {
-int search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictures, const uvghip_pb_filter_t *filters, const int32_t *ref_in_call, void *workspace,
-              void *stream);
+int search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictures, const uvghip_pb_filter_t *filters, const int32_t *ref_in_call,
+              const int32_t *const *searched_flags, int other_workgroups, void *workspace, void *stream);
 }
 extern "C" int uvghip_ctu_search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictures, void *workspace, void *stream)
 {
-  return search_pb(bitdepth, pictures, n_pictures, nullptr, nullptr, workspace, stream);
+  return search_pb(bitdepth, pictures, n_pictures, nullptr, nullptr, nullptr, 0, workspace, stream);
 }
 extern "C" size_t uvghip_ctu_search_pb_inflight_workspace_bytes(int n_pictures, int pic_w, int pic_h) { return uvghip_ctu_search_pb_workspace_bytes(n_pictures, pic_w, pic_h); }
 extern "C" int uvghip_ctu_search_pb_inflight(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, const uvghip_pb_filter_t *filters, const int32_t *ref_in_call,
                                              int n_pictures, void *workspace, void *stream)
 {
   if (!filters || !ref_in_call) return uvghip_set_error(hipErrorInvalidValue, __func__);
-  return search_pb(bitdepth, pictures, n_pictures, filters, ref_in_call, workspace, stream);
+  return search_pb(bitdepth, pictures, n_pictures, filters, ref_in_call, nullptr, 0, workspace, stream);
+}
+extern "C" int uvghip_ctu_search_pb_inflight_ext(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, const uvghip_pb_filter_t *filters, const int32_t *ref_in_call,
+                                                 const int32_t *const *searched_flags, int other_workgroups, int n_pictures, void *workspace, void *stream)
+{
+  if (!filters || !ref_in_call || !searched_flags || other_workgroups < 0 || other_workgroups > 512) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  return search_pb(bitdepth, pictures, n_pictures, filters, ref_in_call, searched_flags, other_workgroups, workspace, stream);
 }
 
 namespace {
-int search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictures, const uvghip_pb_filter_t *filters, const int32_t *ref_in_call, void *workspace,
-              void *stream)
+int search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictures, const uvghip_pb_filter_t *filters, const int32_t *ref_in_call,
+              const int32_t *const *searched_flags, int other_workgroups, void *workspace, void *stream)
 {
   UVGHIP_REQUIRE_READY();
   UVGHIP_REQUIRE_DEPTH(bitdepth);
@@ -308,6 +320,28 @@ int search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictu
     if (p.wpp != 1 || p.depth_min < 1 || p.depth_max != 4 || p.depth_min > p.depth_max || p.rough_levels < 2 || p.rough_levels > 3 || p.qp < 0 || p.qp > 63 ||
         p.qp_c < 0 || p.qp_c > 63 || !(p.lambda > 0) || !(p.lambda_sqrt > 0) || p.rd < 0 || p.rd > 1)
       return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_pb: configuration outside the supported subset");
+    if (searched_flags && searched_flags[i]) {
+      // a picture searched elsewhere (an I picture in uvghip_ctu_plan_launch beside this call): the filter stage only, behind that launch's flags
+      const uvghip_ctu_picture_t &c = q.pic;
+      if (!filters || !c.src_y || !c.src_u || !c.src_v || !c.rec_y || !c.rec_u || !c.rec_v || !c.cu || c.cu_stride < wc * 16 || c.src_stride < p.pic_w || c.rec_stride < p.pic_w ||
+          c.src_stride_c < p.pic_w / 2 || c.rec_stride_c < p.pic_w / 2 || q.slice_type != 2 || p.qp_c != p.qp)
+        return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_pb_inflight_ext: an externally searched picture");
+      const uvghip_pb_filter_t &f = filters[i];
+      if (!f.dbk_y || !f.dbk_u || !f.dbk_v || !f.out_y || !f.out_u || !f.out_v || f.dbk_stride < p.pic_w || f.dbk_stride_c < p.pic_w / 2 || f.out_stride < p.pic_w ||
+          f.out_stride_c < p.pic_w / 2 || f.sao_type < 0 || f.sao_type > 3 || (f.sao_type && (!f.sao_info || !f.sao_models)))
+        return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_pb_inflight_ext: filter stage");
+      pb_pic_dev &d = pics[i];
+      memset(&d, 0, sizeof d);
+      memcpy(&d.P, &p, sizeof d.P);
+      d.src_y = c.src_y; d.src_u = c.src_u; d.src_v = c.src_v; d.rec_y = c.rec_y; d.rec_u = c.rec_u; d.rec_v = c.rec_v; d.cu = c.cu;
+      d.src_stride = c.src_stride; d.src_stride_c = c.src_stride_c; d.rec_stride = c.rec_stride; d.rec_stride_c = c.rec_stride_c; d.cu_stride = c.cu_stride;
+      d.ext_done = searched_flags[i];
+      ctuf::filt_pic &g = filt[i];
+      g.dbk_y = f.dbk_y; g.dbk_u = f.dbk_u; g.dbk_v = f.dbk_v; g.out_y = f.out_y; g.out_u = f.out_u; g.out_v = f.out_v;
+      g.dbk_stride = f.dbk_stride; g.dbk_stride_c = f.dbk_stride_c; g.out_stride = f.out_stride; g.out_stride_c = f.out_stride_c;
+      g.sao_info = f.sao_info; g.sao_models = f.sao_models; g.lambda = p.lambda; g.sao_type = f.sao_type; g.slice_type = 2; g.qp = p.qp; g.is_b = 0;
+      continue;
+    }
     if ((q.slice_type != 0 && q.slice_type != 1) || q.n_refs < 1 || q.n_refs > 16 || q.l_size[0] < 1 || q.l_size[0] > 8 || q.l_size[1] < 0 || q.l_size[1] > 8 ||
         (q.slice_type == 1 && q.l_size[1] != 0) || q.depth_inter_min != 0 || q.depth_inter_max != 3 || q.max_merge < 5 || q.max_merge > 6 || q.fme_level < 0 ||
         q.fme_level > 4 || q.merge_level < 2)
@@ -355,7 +389,8 @@ int search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictu
         if (r < 0) continue;
         if (r >= i) return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_pb_inflight: a reference inside the call must be an earlier picture of it");
         const uvghip_pb_filter_t &fr = filters[r];
-        if (q.ref_y[k] != fr.out_y || q.ref_u[k] != fr.out_u || q.ref_v[k] != fr.out_v || q.ref_motion[k] != pictures[r].motion_out || q.ref_stride != fr.out_stride ||
+        const bool r_ext = searched_flags && searched_flags[r];          // (an I picture: its motion table is the caller's constant "intra everywhere")
+        if (q.ref_y[k] != fr.out_y || q.ref_u[k] != fr.out_u || q.ref_v[k] != fr.out_v || (!r_ext && q.ref_motion[k] != pictures[r].motion_out) || q.ref_stride != fr.out_stride ||
             q.ref_stride_c != fr.out_stride_c)
           return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_search_pb_inflight: ref_in_call names a picture whose output is not this reference");
         // a reference still being coded: the vectors must stay inside what is final in it (fracmv_within_tile's margin: 1 + the filters' delay)
@@ -410,6 +445,9 @@ int search_pb(int bitdepth, const uvghip_ctu_pb_picture_t *pictures, int n_pictu
   const int width = (wc + 1) / 2 < hc ? (wc + 1) / 2 : hc;
   long long want = 2LL * width * n_pictures;
   if (filters && want > (waves >= 3 ? 256 : 1024 / waves)) want = waves >= 3 ? 256 : 1024 / waves;
+  // a launch that runs BESIDE this one and is waited for (externally searched pictures): this launch's workgroups take whole CUs and
+  // must leave that one its own -- four of its workgroups fit a CU
+  if (searched_flags && other_workgroups > 0 && waves >= 3) { const int room = 256 - (other_workgroups + 3) / 4; if (want > room) want = room > 16 ? room : 16; }
   const int grid = (int)(want < total ? want : total);
   if (bitdepth == 8) {
     if (waves == 4) hipLaunchKernelGGL((ctu_search_pb_kernel<uint8_t, 256>), dim3(grid), dim3(256), lds, st, A);

@@ -6,6 +6,7 @@
 // stream inside one workspace.
 #include "uvghip_common.h"
 #include <vector>
+#include <cstring>
 
 namespace {
 
@@ -218,6 +219,16 @@ extern "C" int uvghip_loop_pb_inflight_results(int bitdepth, int n_pictures, int
 extern "C" int uvghip_loop_pb_run_inflight(int bitdepth, const uvghip_loop_pb_picture_t *pictures, int n_pictures, int sao_type, const int32_t *ref_in_call, void *workspace,
                                            void *stream)
 {
+  return uvghip_loop_pb_run_inflight_ext(bitdepth, pictures, n_pictures, sao_type, ref_in_call, nullptr, 0, workspace, stream);
+}
+
+// ... with pictures whose SEARCH runs in another launch beside this one (ext[i].searched_flags != NULL: an I picture of the all-intra plan,
+// uvghip_loop_plan_search_launch on another stream): this call filters them CTU by CTU as that launch finishes their CTUs, so that the
+// P / B pictures behind them are in flight behind an I picture as behind any other.  Their SAO decisions go to ext[i].sao_info / sao_models
+// (the all-intra plan's arrays: its coder, uvghip_loop_plan_run_coder, reads them); they get no slice data here.
+extern "C" int uvghip_loop_pb_run_inflight_ext(int bitdepth, const uvghip_loop_pb_picture_t *pictures, int n_pictures, int sao_type, const int32_t *ref_in_call,
+                                               const uvghip_inflight_external_t *ext, int other_workgroups, void *workspace, void *stream)
+{
   UVGHIP_REQUIRE_READY();
   UVGHIP_REQUIRE_DEPTH(bitdepth);
   if (!pictures || n_pictures <= 0 || !workspace || !ref_in_call || sao_type < 0 || sao_type > 3) return uvghip_set_error(hipErrorInvalidValue, __func__);
@@ -233,10 +244,13 @@ extern "C" int uvghip_loop_pb_run_inflight(int bitdepth, const uvghip_loop_pb_pi
   std::vector<uvghip_pb_filter_t> fl(n_pictures);
   std::vector<uvghip_ctu_picture_t> cp(n_pictures);
   std::vector<uvghip_slice_pb_t> sl(n_pictures);
+  std::vector<const int32_t *> flags(n_pictures, nullptr);
+  std::vector<int> coded;          // the pictures this call codes (all but the externally searched ones)
   for (int i = 0; i < n_pictures; ++i) {
     const uvghip_loop_pb_picture_t &q = pictures[i];
     const uvghip_ctu_pb_picture_t &s = q.search;
     if (!q.out_y || !q.out_u || !q.out_v || q.out_stride < w || q.out_stride_c < w / 2) return uvghip_set_error(hipErrorInvalidValue, "uvghip_loop_pb_run_inflight: output planes");
+    if (ext && ext[i].searched_flags) flags[i] = ext[i].searched_flags; else coded.push_back(i);
     sp[i] = s;
     uvghip_pb_filter_t &f = fl[i];
     unsigned char *d = ws + L.dbk + (size_t)i * planes;
@@ -244,9 +258,11 @@ extern "C" int uvghip_loop_pb_run_inflight(int bitdepth, const uvghip_loop_pb_pi
     f.dbk_stride = w; f.dbk_stride_c = w / 2;
     f.out_y = q.out_y; f.out_u = q.out_u; f.out_v = q.out_v; f.out_stride = q.out_stride; f.out_stride_c = q.out_stride_c;
     f.sao_info = sao_info + (size_t)i * ctus * 34; f.sao_models = sao_models + (size_t)i * ctus * 6;
+    if (flags[i] && ext[i].sao_info && ext[i].sao_models) { f.sao_info = ext[i].sao_info; f.sao_models = ext[i].sao_models; }
     f.sao_type = sao_type; f.reserved = 0;
     cp[i] = s.pic;
     uvghip_slice_pb_t &o = sl[i];
+    if (flags[i]) { memset(&o, 0, sizeof o); continue; }          // (not coded here)
     o.slice_type = s.slice_type; o.poc = s.poc; o.n_refs = s.n_refs;
     for (int k = 0; k < 16; ++k) { o.ref_pocs[k] = s.ref_pocs[k]; o.l[0][k] = s.l[0][k]; o.l[1][k] = s.l[1][k]; }
     o.l_size[0] = s.l_size[0]; o.l_size[1] = s.l_size[1];
@@ -254,8 +270,20 @@ extern "C" int uvghip_loop_pb_run_inflight(int bitdepth, const uvghip_loop_pb_pi
     o.col = s.ref_motion[s.l[0][0]]; o.col_stride = s.ref_motion_stride; o.reserved = 0;
     o.inter4 = s.inter4; o.models_inter = s.models_inter;
   }
-  if (int rc = uvghip_ctu_search_pb_inflight(bitdepth, sp.data(), fl.data(), ref_in_call, n_pictures, ws + L.search, stream)) return rc;
-  // the slice data of every picture in one launch (a P / B picture's models start from its own frame_qp and slice type: `params` only names the size)
-  return uvghip_encode_slice_rows_pb(bitdepth, &pictures[0].search.params, cp.data(), sl.data(), n_pictures, sao_type ? sao_info : nullptr, sao_type ? sao_models : nullptr,
-                                     ws + L.coder, ws + L.rows, L.row_cap, row_bytes, stream);
+  if (ext) {
+    if (int rc = uvghip_ctu_search_pb_inflight_ext(bitdepth, sp.data(), fl.data(), ref_in_call, flags.data(), other_workgroups, n_pictures, ws + L.search, stream)) return rc;
+  } else if (int rc = uvghip_ctu_search_pb_inflight(bitdepth, sp.data(), fl.data(), ref_in_call, n_pictures, ws + L.search, stream)) return rc;
+  // the slice data of every picture in one launch (a P / B picture's models start from its own frame_qp and slice type: `params` only names the size).
+  // The coded pictures are a suffix of the call in practice (I pictures first); runs of them keep their place in the results' arrays.
+  for (size_t a = 0; a < coded.size();) {
+    size_t b = a + 1;
+    while (b < coded.size() && coded[b] == coded[b - 1] + 1) ++b;
+    const int i0 = coded[a], m = (int)(b - a);
+    if (int rc = uvghip_encode_slice_rows_pb(bitdepth, &pictures[i0].search.params, cp.data() + i0, sl.data() + i0, m, sao_type ? sao_info + (size_t)i0 * ctus * 34 : nullptr,
+                                             sao_type ? sao_models + (size_t)i0 * ctus * 6 : nullptr, ws + L.coder, ws + L.rows + (size_t)i0 * hc * L.row_cap, L.row_cap,
+                                             row_bytes + (size_t)i0 * hc, stream))
+      return rc;
+    a = b;
+  }
+  return 0;
 }

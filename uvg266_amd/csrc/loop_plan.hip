@@ -211,6 +211,24 @@ extern "C" int uvghip_loop_plan_run_filters(uvghip_loop_plan_t *pl, void *stream
                                   pl->row_bytes, stream);
 }
 
+// ---- an all-intra plan whose pictures are filtered ELSEWHERE: the I pictures of a clip, searched here beside the in-flight P / B launch that
+// filters them CTU by CTU as they are searched (uvghip_loop_pb_run_inflight_ext) ----
+extern "C" int uvghip_ctu_plan_reset(uvghip_ctu_plan_t *pl, void *stream);
+extern "C" int uvghip_ctu_plan_launch(uvghip_ctu_plan_t *pl, void *stream);
+extern "C" int uvghip_ctu_plan_set_grid(uvghip_ctu_plan_t *pl, int max_workgroups);
+extern "C" const int32_t *uvghip_ctu_plan_done_flags(const uvghip_ctu_plan_t *pl);
+extern "C" int uvghip_loop_plan_search_reset(uvghip_loop_plan_t *pl, void *stream) { return pl ? uvghip_ctu_plan_reset(pl->search, stream) : uvghip_set_error(hipErrorInvalidValue, __func__); }
+extern "C" int uvghip_loop_plan_search_launch(uvghip_loop_plan_t *pl, void *stream) { return pl ? uvghip_ctu_plan_launch(pl->search, stream) : uvghip_set_error(hipErrorInvalidValue, __func__); }
+extern "C" int uvghip_loop_plan_set_search_grid(uvghip_loop_plan_t *pl, int max_workgroups) { return pl ? uvghip_ctu_plan_set_grid(pl->search, max_workgroups) : uvghip_set_error(hipErrorInvalidValue, __func__); }
+extern "C" const int32_t *uvghip_loop_plan_searched_flags(const uvghip_loop_plan_t *pl) { return pl ? uvghip_ctu_plan_done_flags(pl->search) : nullptr; }
+// the slice data alone (the pictures' SAO decisions are in the plan's arrays: uvghip_loop_plan_results)
+extern "C" int uvghip_loop_plan_run_coder(uvghip_loop_plan_t *pl, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  return uvghip_encode_slice_rows(pl->bitdepth, &pl->ctu_params, nullptr, pl->n, pl->sao_info, pl->sao_models, pl->coder_ws, pl->rows, pl->row_cap, pl->row_bytes, stream);
+}
+
 extern "C" int uvghip_loop_plan_slice_data(const uvghip_loop_plan_t *pl, const uint8_t **rows, const int32_t **row_bytes, int *row_cap, int *n_rows)
 {
   if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);

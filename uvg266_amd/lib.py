@@ -97,6 +97,11 @@ class LoopPbPicture(ctypes.Structure):
                 ("out_stride_c", ctypes.c_int32)]
 
 
+class InflightExternal(ctypes.Structure):
+    """uvghip_inflight_external_t."""
+    _fields_ = [("searched_flags", ctypes.c_void_p), ("sao_info", ctypes.c_void_p), ("sao_models", ctypes.c_void_p)]
+
+
 class AlfPicture(ctypes.Structure):
     """uvghip_alf_picture_t."""
     _fields_ = [("in_y", ctypes.c_void_p), ("in_u", ctypes.c_void_p), ("in_v", ctypes.c_void_p), ("in_stride", ctypes.c_int32), ("in_stride_c", ctypes.c_int32),
@@ -278,6 +283,17 @@ SIGNATURES = {
     "uvghip_filter_pictures_run": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "uvghip_ctu_search_pb_inflight_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int]),
     "uvghip_ctu_search_pb_inflight": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_loop_pb_run_inflight_ext": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_ctu_search_pb_inflight_ext": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    "uvghip_loop_plan_search_reset": (c_int, [c_vp, c_vp]),
+    "uvghip_loop_plan_search_launch": (c_int, [c_vp, c_vp]),
+    "uvghip_loop_plan_set_search_grid": (c_int, [c_vp, c_int]),
+    "uvghip_loop_plan_searched_flags": (c_vp, [c_vp]),
+    "uvghip_loop_plan_run_coder": (c_int, [c_vp, c_vp]),
+    "uvghip_ctu_plan_reset": (c_int, [c_vp, c_vp]),
+    "uvghip_ctu_plan_launch": (c_int, [c_vp, c_vp]),
+    "uvghip_ctu_plan_set_grid": (c_int, [c_vp, c_int]),
+    "uvghip_ctu_plan_done_flags": (c_vp, [c_vp]),
     "uvghip_loop_pb_inflight_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
     "uvghip_loop_pb_run_inflight": (c_int, [c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "uvghip_loop_pb_inflight_results": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
