@@ -6,6 +6,7 @@ Planes are 2-D tensors (rows x stride) of dtype uint8 (8-bit) or uint16/int16
 (10-bit); `width` is the visible width when the stride is larger.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -1036,10 +1037,12 @@ class LowDelayLoop:
     temporal layer, and of neighbouring GOPs, run side by side on k streams (deps[f]: the coded pictures f reads)."""
 
     def __init__(self, W, H, depth, n_seq, frames, src, sao_type=3, tmvp=1, max_merge=6, merge_level=2, bipred=1, fme_level=4, early_skip=1, by_level=False, rd=0, inflight_margin=0,
-                 inflight=False, intra_in_flight=False, intra_grid=64):
+                 inflight=False, intra_in_flight=False, intra_grid=None):
         """intra_in_flight (with inflight): the I pictures are part of the flight too -- their search runs as `intra_grid` persistent workgroups on a
         second stream BESIDE the in-flight launch, which filters them CTU by CTU as they are searched (uvghip_loop_pb_run_inflight_ext), so the
-        P / B pictures behind an I picture follow it four diagonals behind instead of waiting for the whole picture.
+        P / B pictures behind an I picture follow it four diagonals behind instead of waiting for the whole picture.  intra_grid: workgroups of
+        an I group's launch (None: one per CTU its pictures' wavefronts can have in progress, min(wc, hc) per picture -- measured best: more only wait
+        and take CUs from the flight, whose workgroups need whole ones).
         inflight: the encoder's --owf schedule (encoderstate.c:1060-1116): ALL P / B pictures go through ONE uvghip_loop_pb_run_inflight -- a
         picture's CTU (x, y) starts when CTU (x + 2, y + 1) of the pictures it reads is final, the in-loop filters run per CTU inside the
         search kernel -- after the I pictures (which depend on nothing).  Needs inflight_margin = 11 (9 without SAO): the vector restriction
@@ -1143,11 +1146,15 @@ class LowDelayLoop:
                 if self.steps[f][0] == "PB" and not any(st is self.steps[f] for _, st in self.order):
                     self.steps[f] = ("PB", self.steps[f][1], None, self.steps[f][3])
         self.intra_in_flight = bool(inflight and intra_in_flight)
+        if os.environ.get("UVGHIP_INTRA_GRID"):          # (development)
+            intra_grid = int(os.environ["UVGHIP_INTRA_GRID"])
         if self.intra_in_flight:
             # an intra picture as a reference: type 1 inside the picture, no vectors -- known before anything runs
             for fl, loop, gm in igroup.values():
-                if loop.n * ctus > intra_grid:
-                    _lib.check(self.L.uvghip_loop_plan_set_search_grid(loop.loop, int(intra_grid)), "uvghip_loop_plan_set_search_grid")
+                grid = int(intra_grid) if intra_grid else min(wc, hc) * loop.n
+                loop.search_grid = min(grid, loop.n * ctus)
+                if loop.n * ctus > grid:
+                    _lib.check(self.L.uvghip_loop_plan_set_search_grid(loop.loop, grid), "uvghip_loop_plan_set_search_grid")
                 for m in gm:
                     m.zero_()
                     m[:H // 4, :W // 4, 0] = 1
@@ -1185,7 +1192,7 @@ class LowDelayLoop:
                         if (g, s_) in at:
                             ric[i, k] = at[(g, s_)]
             ws = z(self.L.uvghip_loop_pb_inflight_workspace_bytes(depth, n, W, H), torch.uint8)
-            grid_sum = sum(min(int(intra_grid), loop.n * ctus) for _, loop, _ in igroup.values())
+            grid_sum = sum(loop.search_grid for _, loop, _ in igroup.values())
             self.order = [(list(range(len(frames))), ("FLIGHT_EXT", arr, ws, (np.ascontiguousarray(ric), ext, ent, n_ext, grid_sum, list(igroup.values()))))]
             for f in pb:
                 self.steps[f] = ("PB", self.steps[f][1], None, self.steps[f][3])
