@@ -704,8 +704,9 @@ def low_delay_closed_loop(device, n_seq=8, reps=2):
 
 def c3_clip(device, frames=120, with_cpu=True):
     """BASELINE.json configs[2] as BASELINE defines it: ONE 1920x1080 8-bit clip of 120 pictures, --gop lp-g4d3t1 --preset medium at QP 27
-    (intra period 64: I pictures at 0 and 64), host memory to slice data: the sources are uploaded inside the timed region, the I
-    pictures go through the all-intra loop, ALL P / B pictures through ONE uvghip_loop_pb_run_inflight -- the encoder's --owf schedule
+    (intra period 64: I pictures at 0 and 64), host memory to slice data: the sources are uploaded inside the timed region, ALL
+    pictures go through ONE uvghip_loop_pb_run_inflight_ext (the two I pictures searched by the all-intra kernel on a second stream and
+    filtered inside the in-flight launch) -- the encoder's --owf schedule
     (encoderstate.c:1060-1116): CTU (x, y) of a picture starts when CTU (x + 2, y + 1) of the pictures it reads is final, deblocking and
     SAO run per CTU inside the persistent search kernel, the vectors keep to what is final in a reference still being coded
     (inflight_margin 11 = cfg.owf != 0).  Every picture and every WPP row's bytes are compared with the reference encoder's --owf 1 run of
@@ -750,12 +751,13 @@ def c3_clip(device, frames=120, with_cpu=True):
            "frames_timed": frames, "clip_frames": total, "wall_ms": round(1e3 * dt, 1), "slice_data_bytes": nbytes, "parity_checked": not bad,
            "parity": {"golden": golden, "pictures": frames, "mismatches": bad[:8],
                       "items": "CRC of every output picture (after deblocking + SAO) and length + CRC of every WPP row's slice data vs the reference encoder's --owf 1 run of this clip"},
-           "launches": {"intra_loops": frames - n_pb, "inflight_calls": 1, "pictures_in_the_inflight_call": n_pb},
-           "workload": f"{W}x{H} {depth}-bit yuv420p, ONE clip of {frames} pictures, --gop lp-g4d3t1 --preset medium --owf 1 at QP {qp} (BASELINE.json configs[2]); upload -> I pictures "
-                       "through the all-intra loop -> every P / B picture in ONE persistent launch: closed-loop CTU search with the inter search on the device's own reference "
-                       "pictures while they are still being coded, per-CTU deblocking + SAO, cross-picture CTU flags -> one arithmetic-coder launch",
-           "note": "a picture follows its reference five wavefront diagonals behind (cx + 2 cy; the reference's frame_delay of 4, encoder.c:94-95, + the CTU itself): a chain of "
-                   "dependent pictures costs five CTU times per picture instead of a picture's 62 diagonals; the two intra periods of the clip are independent and run side by side"}
+           "launches": {"inflight_calls": 1, "pictures_in_the_inflight_call": frames, "of_them_searched_by_the_all_intra_kernel_beside_it": frames - n_pb},
+           "workload": f"{W}x{H} {depth}-bit yuv420p, ONE clip of {frames} pictures, --gop lp-g4d3t1 --preset medium --owf 1 at QP {qp} (BASELINE.json configs[2]); upload -> every "
+                       "picture in ONE persistent launch: closed-loop CTU search with the inter search on the device's own reference pictures while they are still being coded "
+                       "(four waves per CTU; the I pictures' search by the all-intra kernel on a second stream), per-CTU deblocking + SAO, cross-picture CTU flags -> the arithmetic coder",
+           "note": "a picture follows its reference four wavefront diagonals behind (cx + 2 cy; one flag per reference, final_done(x + 1, y + 1), covers what a restricted vector "
+                   "can reach): a chain of dependent pictures costs four CTU times per picture instead of a picture's 62 diagonals; the two intra periods of the clip are "
+                   "independent and run side by side"}
     del loop
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline_low_delay(W, H, depth, qp, total)
@@ -764,9 +766,9 @@ def c3_clip(device, frames=120, with_cpu=True):
 
 def ra_clip(device, frames=65, with_cpu=True):
     """ONE 1920x1080 8-bit clip with --preset medium's own GOP (random access, --gop 16: hierarchical B pictures, references in the future;
-    what BASELINE.json configs[3] / [4] run with): pictures in CODING order through api.LowDelayLoop, every picture issued as soon as the
-    pictures in its reference buffer are done (by_level: the pictures at one depth of the reference DAG share a uvghip_loop_pb_run):
-    pictures of one temporal layer and of neighbouring GOPs are in flight together.  Frame-level state (slice types, the hierarchical QPs / lambdas, reference lists, coding order) from
+    what BASELINE.json configs[3] / [4] run with): pictures in CODING order through api.LowDelayLoop(inflight=True, intra_in_flight=True): the whole clip is ONE
+    uvghip_loop_pb_run_inflight_ext, a CTU starts when the CTUs a restricted vector can reach in its reference pictures are final
+    (DESIGN.md 4.15), the I pictures searched by the all-intra kernel beside it.  Frame-level state (slice types, the hierarchical QPs / lambdas, reference lists, coding order) from
     tests/golden/ref_gop16_states_qp27_65frames.npz (the reference encoder's own, independent of the picture size); the coded pictures
     are compared with the reference encoder's run of this clip (tests/golden/ref_intercrc_1920x1080_8_qp27_65frames_ra16.npz: all 65,
     incl. the I picture of the second intra period at POC 64 and the pictures before it in display order that are coded after it)."""
@@ -808,10 +810,9 @@ def ra_clip(device, frames=65, with_cpu=True):
                       "items": "CRC of every output picture (after deblocking + SAO) and length + CRC of every WPP row's slice data vs the reference encoder's run of this clip"},
            "workload": f"{W}x{H} {depth}-bit yuv420p, ONE clip, --preset medium as it stands (--gop 16: coding order 0 16 8 4 2 1 3 6 5 7 12 ..., five temporal layers, up to five "
                        f"reference pictures in both directions) at QP {qp}; per picture: closed-loop CTU search with the inter search on the device's own reference pictures -> "
-                       "deblocking -> SAO -> arithmetic coder",
-           "note": "the pictures at one depth of the reference DAG (the same temporal layer of one GOP, other layers of its neighbours) go through one uvghip_loop_pb_run, their "
-                   "wavefronts interleaved in the search kernel: the longest chain of dependent pictures, not the picture count, bounds the wall time; a picture by itself is "
-                   "still one wavefront of one-wave CTUs (extra_workloads.c3_clip)"}
+                       "per-CTU deblocking + SAO -> arithmetic coder",
+           "note": "the whole clip is one persistent launch: hand-out key cx + 2 cy + 4 x depth in the reference DAG, cross-picture per-CTU flags; the longest chain of "
+                   "dependent pictures (11 levels for 65 pictures), not the picture count, bounds the wall time"}
     del loop
     if with_cpu:
         out["cpu_baseline"] = cpu_baseline_low_delay(W, H, depth, qp, total, gop="16")
