@@ -320,11 +320,12 @@ template <typename PX> struct lds {
   int32_t lf_tag;
   PX lf_src[96];
 #endif
-#if defined(CTU_LEAF4X)
-  // the 64x64 candidate's chroma, taken by depth 2's wave while the walk does the luma (eval_cu64): the request's chroma mode; per
-  // 32x32 area the two flags, the two SSDs and the chroma part of the bit count
-  int32_t j64, j64_mode;
-  struct { int32_t cu, cv, ssd_u, ssd_v, cy, ssd_y; double bits, bits_y; } h64[4];      // (cy, ssd_y, bits_y: the walk's own luma part)
+#if !defined(CTU_PB)
+  // the 64x64 candidate (post64 / finish64): posted once the first 32x32 area is decided, its luma blocks taken by depth 1's wave and
+  // its chroma blocks by depth 2's between their evaluations; the modes (luma, chroma) of the request; per 32x32 transform unit the
+  // flags, the SSDs and the bit counts (bits: chroma, bits_y: luma)
+  int32_t req64, done64[2], m64[2];
+  struct { int32_t cu, cv, ssd_u, ssd_v, cy, ssd_y; double bits, bits_y; } h64[4];
 #endif
   alignas(16) unsigned char arena[lds_cfg<PX>::slim ? (int)ARENA_BYTES_SLIM : (int)ARENA_BYTES];
 #if defined(CTU_PB)
@@ -364,8 +365,8 @@ template <typename PX> CTU_DEV wctx *wv_of(lds<PX> *S) { return &S->wv[S->vsel[C
 // per-workgroup scratch in global memory
 struct scratch {
   double cost_coeff[1024], cost_sig[1024], cost_coeff0[1024];
-  uint16_t save_px[6144];          // the whole D of a CTU while the 64x64 candidate is tried
-  int16_t save_co[6144];
+  uint16_t save_px[6144];          // the 64x64 candidate's samples and levels beside the split's (I pictures: post64; P / B one-wave build: the
+  int16_t save_co[6144];           // whole D of a CTU while the candidate is tried in place)
   cu4 save_cu[256];
   int16_t cand_co[2016];           // levels of the candidate CUs of depths 1..3 (cand_px_off)
   // a slim build (lds_cfg): the depth-1 candidate's samples, the levels of the depth-1 scratch (y, u, v), the scans of 32x32 and 16x16
@@ -2071,7 +2072,12 @@ template <typename PX> CTU_DEV int scaled_qp(const params &P, int color) { retur
 // lv_of(V, color) and go to the CTU's coefficient array.  (x, y) / (lx, ly): luma position, n: luma size of the area.  -> has_coeffs
 // CTU_PB, flags: 1 the prediction is already in dst (a block of an inter CU), 2 no reconstruction (the early-skip test only wants
 // has_coeffs), 4 RDOQ prices "no luma coefficients" with the root cbf
-template <typename PX> CTU_INLINE1 CTU_DEV int recon_tu_inl(lds<PX> *S, const job<PX> &J, int color, int x, int y, int lx, int ly, int n, int mode, int cbf_u,
+template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave_ool(lds<PX> *S, scratch *W, const int16_t *coef_, int16_t *dst_, int n, int color, int cbf_u, int qp_scaled,
+                                                           double lambda, int bitdepth)
+{
+  rdoq_wave(S, W, coef_, dst_, n, color, cbf_u, qp_scaled, lambda, bitdepth);
+}
+template <typename PX, bool OOL = false> CTU_INLINE1 CTU_DEV int recon_tu_inl(lds<PX> *S, const job<PX> &J, int color, int x, int y, int lx, int ly, int n, int mode, int cbf_u,
                                                             PX *dst_, int dp, int16_t *co, int cp, int cu_n
 #if defined(CTU_PB)
                                                             , int flags = 0
@@ -2106,7 +2112,8 @@ template <typename PX> CTU_INLINE1 CTU_DEV int recon_tu_inl(lds<PX> *S, const jo
   {
     // chroma blocks: state->c_lambda as uvg_quantize_lcu_residual replaces it (transform.c:1575)
     const double lambda = c ? J.P.c_lambda_tu : J.P.lambda;
-    rdoq_wave(S, J.W, V->t0, lv_of(V, color), w, color, cbf_u, qps, lambda, depth);
+    if constexpr (OOL) rdoq_wave_ool(S, J.W, V->t0, lv_of(V, color), w, color, cbf_u, qps, lambda, depth);
+    else rdoq_wave(S, J.W, V->t0, lv_of(V, color), w, color, cbf_u, qps, lambda, depth);
   }
   CTU_SYNC();
   CTU_T1(J.W, 3);
@@ -2136,7 +2143,7 @@ template <typename PX> CTU_INLINE1 CTU_DEV int recon_tu_inl(lds<PX> *S, const jo
 }
 // Called per block, a noinline function saves ~45 callee-saved VGPRs to the stack and reloads them (256 B each): with RDOQ and the
 // rough search, 20 MB of stack traffic per CTU.  The CU evaluation therefore has ONE call site (a loop over the colours) with the body
-// inlined; the rare 64x64 candidate goes through this out-of-line copy.
+// inlined; the P / B walk's blocks go through this out-of-line copy (the I pictures' 64x64 candidate has its own: recon_tu64).
 template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<PX> &J, int color, int x, int y, int lx, int ly, int n, int mode, int cbf_u,
                                                          PX *dst_, int dp, int16_t *co, int cp, int cu_n
 #if defined(CTU_PB)
@@ -2147,7 +2154,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu(lds<PX> *S, const job<P
 #if defined(CTU_PB)
   return recon_tu_inl(S, J, color, x, y, lx, ly, n, mode, cbf_u, dst_, dp, co, cp, cu_n, flags);
 #else
-  return recon_tu_inl(S, J, color, x, y, lx, ly, n, mode, cbf_u, dst_, dp, co, cp, cu_n);
+  return recon_tu_inl<PX, true>(S, J, color, x, y, lx, ly, n, mode, cbf_u, dst_, dp, co, cp, cu_n);      // (RDOQ through the copy it shares with recon_tu64)
 #endif
 }
 
@@ -2541,17 +2548,25 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
   // ---- lane 0: last-position prefix and the group flags (their models are nobody else's) ----
   if (lane == 0) {
     double bits = 0;
-    CTU_LDS uint32_t *mk = m;
+    CTU_LDS uint32_t *mk = m, *mg = m;        // the models of the last position / of the group flags
     if (!update) {
       // counting only: these bins still adapt their models WITHIN the block (the reference counts on a copy) -- work on a copy
-      // of the few models involved (work[0] is nobody's: depth 0 has no unsplit candidate of its own)
+      // of the few models involved
 #if defined(CTU_PB)
       mk = (CTU_LDS uint32_t *)(CTU_WAVE == 0 ? S->pb.cnt_models : (CTU_WAVE == 1 ? S->pb.work0 : pbq(S).cnt_models));       // (every work[] set is some depth's here; the leaf wave: see coeff_bits)
+      mg = mk;
 #else
-      mk = (CTU_LDS uint32_t *)S->work[CTU_WAVE == 0 ? 2 : 1];      // (the 64x64 candidate: the walk and depth 2's wave count at the same time)
+      // (the 64x64 candidate, counted beside the walk by two waves at a time while every work[] set is some depth's: the 84 models live in
+      // the wave's reference rows -- a block is counted after its reconstruction -- behind the 4 group-flag models)
+      mk = (CTU_LDS uint32_t *)V->top - (M_LASTX - 4);
+      mg = (CTU_LDS uint32_t *)V->top;
+      for (int i = 0; i < 4; ++i) mg[M_SIGGRP + i] = m[M_SIGGRP + i];
+      for (int i = M_LASTX; i < M_CBF_LUMA; ++i) mk[i] = m[i];
 #endif
+#if defined(CTU_PB)
       for (int i = 0; i < 4; ++i) mk[M_SIGGRP + i] = m[M_SIGGRP + i];
       for (int i = M_LASTX; i < M_CBF_LUMA; ++i) mk[i] = m[i];
+#endif
     }
     const int pos_last = scan[last];
     const int last_y = pos_last >> l2, last_x = pos_last - (last_y << l2);
@@ -2574,7 +2589,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV double coeff_bits(lds<PX> *S, uint32
       unsigned right = 0, lower = 0;
       if (cx + 1 < cgw) right = cgf[cb + 1];
       if (cy + 1 < cgw) lower = cgf[cb + cgw];
-      m_code(mk, 1, M_SIGGRP + 2 * t + ((right || lower) ? 1 : 0), cgf[cb] != 0, bits);
+      m_code(mg, 1, M_SIGGRP + 2 * t + ((right || lower) ? 1 : 0), cgf[cb] != 0, bits);
     }
     q15 += (unsigned long long)(bits * 32768.0);        // exact: a sum of table entries / 2^15
   }
@@ -3051,71 +3066,245 @@ CTU_NOINLINE CTU_DEV void copy_models(uint32_t *dst_, const uint32_t *src_)
   CTU_SYNC();
 }
 
-// the 64x64 CU tried with the mode of the first 32x32 CU after the four 32x32 areas are decided (combine_intra_cus, search.c:2082-2143).
-// Returns its cost in lvl[0].cost; D holds it afterwards, the split's result is in the scratch.  (The walk's wave, on the depth-1 scratch.)
-template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu64(lds<PX> *S, const job<PX> &J)
+#if !defined(CTU_PB)
+// ---- the 64x64 CU tried with the mode of the first 32x32 CU (combine_intra_cus, search.c:2082-2143) ------------------------------
+// The reference tries it after the four 32x32 areas are decided, in place, on the CTU's entry models without adaptation.  Nothing it
+// computes depends on the split's outcome but the two modes, and those are the first area's: so the candidate is POSTED when the first
+// area is decided (post64) and built beside the walk -- its four luma transform blocks by depth 1's wave, its chroma blocks by depth 2's,
+// each between the evaluations that wave is asked for (worker_loop) -- into the workgroup's global scratch (save_px / save_co, laid
+// out like the decided planes / the coefficient array), never into D.  A block's references come from the CTU's border (D's row and
+// column -1, fixed for the CTU) and from the candidate's own earlier blocks (build_refs64).  At the end of the walk finish64 waits for
+// the two chains, prices the CU in the reference's order of summation and, if it wins, brings it into D (unpark64); if the split wins
+// there is nothing to undo.  (Rounds 3-5 built it on the walk's wave after the split, saving and restoring the whole CTU around it:
+// 4.7 M of a CTU's 25.4 M cycles, profiles/r05_ctu_intra_phases_1080p8.txt.)
+
+// uvg_intra_build_reference for transform block i (raster order) of the candidate: what build_refs computes when the side information says
+// "one 64x64 intra CU" -- the counts of uvg_count_available_edge_cus (cu.c:516-537) are those of that state, whatever the split left
+// in S->cu -- with the samples inside the CTU taken from the candidate's own planes.
+template <typename PX> CTU_NOINLINE CTU_DEV void build_refs64(lds<PX> *S, const job<PX> &J, int color, int i)
 {
   wctx *const V = wv_of(S);
   const params &P = J.P;
-  level_state &N = S->lvl[0];
-  const int x = N.x, y = N.y;
+  const int c = color != 0, w = 32 >> c, pw = 64 >> c;
+  const int lx = (i & 1) * 32, ly = (i >> 1) * 32, x = J.x + lx, y = J.y + ly;
+  const int px_x = lx >> c, px_y = ly >> c;
+  const int pit = pitch_of(color);
+  const PX *const Dp = plane(S, color);
+  const uint16_t *const C = J.W->save_px + co_off(color);
+  // a sample at (row, column) of the plane relative to the CTU's origin
+  auto at_ = [&](int r, int q) -> int { return (r < 0 || q < 0) ? (int)Dp[(r + 1) * pit + q + 1] : (int)CTU_GLOAD(&C[r * pw + q]); };
+  SERIAL {
+    const int lcnt = x == 0 ? 0 : (lx == 0 ? (LCU - ly) / 4 : 8);
+    const int tcnt = y == 0 ? 0 : ((ly == 0 || lx == 0) ? 16 : 8);
+    int al = lcnt * (c ? 2 : 4);
+    if (al > 2 * w) al = 2 * w;
+    if (al > ((P.pic_h - y) >> c)) al = (P.pic_h - y) >> c;
+    int at = tcnt * (c ? 2 : 4);
+    if (at > 2 * w) at = 2 * w;
+    if (at > ((P.pic_w - x) >> c)) at = (P.pic_w - x) >> c;
+    if (x > 0 && y > 0 && P.wpp && px_y == 0 && at > (LCU >> c) - px_x) at = (LCU >> c) - px_x;
+    V->u_avail_left = al; V->u_avail_top = at;
+  }
+  CTU_SYNC();
+  const int al = V->u_avail_left, at = V->u_avail_top;
+  const int dc = 1 << (px_info<PX>::depth - 1);
+  CTU_LDS uint16_t *const r_top = LDSP(uint16_t, V->top), *const r_left = LDSP(uint16_t, V->left);
+  CTU_LDS uint16_t *const r_ftop = LDSP(uint16_t, V->ftop), *const r_fleft = LDSP(uint16_t, V->fleft);
+  PAR_FOR(k, V->refn - 1) {
+    int lv, tv;
+    if (x > 0) lv = at_(px_y + (k < al ? k : al - 1), px_x - 1);
+    else lv = y > 0 ? at_(px_y - 1, px_x) : dc;
+    if (y > 0) tv = at_(px_y - 1, px_x + (k < at ? k : at - 1));
+    else tv = x > 0 ? at_(px_y, px_x - 1) : dc;
+    r_left[k + 1] = (uint16_t)lv;
+    r_top[k + 1] = (uint16_t)tv;
+  }
+  SERIAL {
+    int corner;
+    if (x > 0 && y > 0) corner = at_(px_y - 1, px_x - 1);
+    else corner = x > 0 ? at_(px_y, px_x - 1) : (y > 0 ? at_(px_y - 1, px_x) : dc);
+    r_left[0] = r_top[0] = (uint16_t)corner;
+  }
+  CTU_SYNC();
+  const int flim = 2 * (64 >> c) < V->refn - 1 ? 2 * (64 >> c) : V->refn - 1;
+  PAR_FOR(k, V->refn) {
+    int fl, ft;
+    if (k == 0) fl = ft = (r_left[1] + 2 * r_left[0] + r_top[1] + 2) >> 2;
+    else {
+      fl = k < flim ? (r_left[k - 1] + 2 * r_left[k] + r_left[k + 1] + 2) >> 2 : r_left[k];
+      ft = k < flim ? (r_top[k - 1] + 2 * r_top[k] + r_top[k + 1] + 2) >> 2 : r_top[k];
+    }
+    r_fleft[k] = (uint16_t)fl;
+    r_ftop[k] = (uint16_t)ft;
+  }
+  CTU_SYNC();
+}
+
+// predict + quantise (RDOQ) + reconstruct transform block i of the candidate, colour `color`, on the calling wave's scratch: the
+// prediction is staged in the transform's second buffer and made AGAIN after the inverse transform (it is the cheap part, and the
+// image has no room for another tile); samples and levels go to the scratch planes, the levels stay in lv, the SSD lands in
+// V->red[color].  -> has_coeffs
+template <typename PX> CTU_NOINLINE CTU_DEV int recon_tu64(lds<PX> *S, const job<PX> &J, int color, int i, int mode, int cbf_u, int16_t *lv_)
+{
+  wctx *const V = wv_of(S);
+  scratch *const W = J.W;
+  const int c = color != 0, w = 32 >> c, l2 = c ? 4 : 5, pw = 64 >> c;
+  const int lx = (i & 1) * 32, ly = (i >> 1) * 32;
+  CTU_LDS int16_t *const t0 = LDSP(int16_t, V->t0);
+  PX *const pred_ = (PX *)V->t1;
+  typename mg_ptr<PX, PX>::type const pred = MGP(PX, PX, pred_);
+  typename mg_ptr<PX, int16_t>::type const lv = MGP(PX, int16_t, lv_);
+  int sps;
+  CTU_GLB const PX *Sp = src_block(J, color, lx >> c, ly >> c, &sps);
+  const int depth = (int)px_info<PX>::depth;
+  { CTU_T0();
+  build_refs64(S, J, color, i);
+  predict_block(S, mode, color, w, pred_, w);
+  CTU_T1(J.W, 1); }
+  { CTU_T0();
+  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); t0[e] = (int16_t)((int)Sp[r * sps + q] - (int)pred[e]); }
+  CTU_SYNC();
+  fwd_pass(w, V->t0, V->t1, l2 - 1 + depth - 8);
+  fwd_pass(w, V->t1, V->t0, l2 + 6);
+  CTU_T1(J.W, 2); }
+  const int qps = scaled_qp<PX>(J.P, color);
+  { CTU_T0();
+  const double lambda = c ? J.P.c_lambda_tu : J.P.lambda;
+  rdoq_wave_ool(S, W, V->t0, lv_, w, color, cbf_u, qps, lambda, depth);
+  CTU_SYNC();
+  CTU_T1(J.W, 3); }
+  const int has = V->rq_i[1];
+  uint16_t *const px64 = W->save_px + co_off(color) + (ly >> c) * pw + (lx >> c);
+  int16_t *const co64 = W->save_co + co_off(color) + (ly >> c) * pw + (lx >> c);
+  PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); co64[r * pw + q] = lv[e]; }
+  if (has) {
+    const int transform_shift = 15 - depth - l2;
+    const int shift = 20 - 14 - transform_shift;
+    const int32_t scale = (int32_t)kInvQuantScales[qps % 6] << (qps / 6);
+    const int32_t add = 1 << (shift - 1);
+    PAR_FOR(e, w * w) t0[e] = (int16_t)clampi((lv[e] * scale + add) >> shift, -32768, 32767);
+    CTU_SYNC();
+    inv_pass(w, V->t0, V->t1, 7);
+    inv_pass(w, V->t1, V->t0, 12 - (depth - 8));
+  }
+  predict_block(S, mode, color, w, pred_, w);
+  int acc = 0;
+  PAR_FOR(e, w * w) {
+    const int r = e >> l2, q = e & (w - 1);
+    int v = (int)pred[e];
+    if (has) v = clampi((int16_t)(t0[e] + v), 0, (int)px_info<PX>::maxv);
+    px64[r * pw + q] = (uint16_t)v;
+    const int d = (int)Sp[r * sps + q] - v;
+    acc += d * d;
+  }
+#if defined(__HIPCC__)
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+#endif
+  LANE0 V->red[color] = acc >> (2 * (depth - 8));
+  CTU_SYNC();
+  return has;
+}
+
+// luma transform block i of the candidate (depth 1's wave, its own scratch)
+template <typename PX> CTU_NOINLINE CTU_DEV void luma64_step(lds<PX> *S, const job<PX> &J, int i)
+{
+  wctx *const V = wv_of(S);
+  const int cy = recon_tu64(S, J, 0, i, S->m64[0], 0, V->lv0);
+  double by = 0;
+  LANE0 m_code(LDSP(uint32_t, S->coder), 0, M_CBF_LUMA + 0, cy, by);
+  WSYNC();
+  if (cy) by += coeff_bits(S, S->coder, 0, V->lv0, 32, 0);
+  LANE0 { S->h64[i].cy = cy; S->h64[i].ssd_y = V->red[0]; S->h64[i].bits_y = by; }
+  CTU_SYNC();
+}
+// a chroma block of transform unit i (depth 2's wave: a 16x16 block is that depth's luma size, so the levels of Cb and Cr take turns
+// in its luma level array)
+template <typename PX> CTU_NOINLINE CTU_DEV void chroma64_step(lds<PX> *S, const job<PX> &J, int i, int color)
+{
+  wctx *const V = wv_of(S);
+  const int cu = color == 2 ? S->h64[i].cu : 0;
+  const int has = recon_tu64(S, J, color, i, S->m64[1], cu, V->lv0);
+  const double cb = coeff_bits(S, S->coder, 0, V->lv0, 16, color);
+  LANE0 {
+    if (color == 1) { S->h64[i].cu = has; S->h64[i].ssd_u = V->red[1]; S->h64[i].bits = cb; }
+    else {
+      double fb = 0;
+      m_code(LDSP(uint32_t, S->coder), 0, M_CBF_CB + 0, cu, fb);
+      m_code(LDSP(uint32_t, S->coder), 0, M_CBF_CR + cu, has, fb);
+      double both = S->h64[i].bits;
+      both += cb;
+      S->h64[i].cv = has; S->h64[i].ssd_v = V->red[2]; S->h64[i].bits = fb + both;
+    }
+  }
+  CTU_SYNC();
+}
+
+// the walk: the first 32x32 area is decided and is one intra CU -- ask for the candidate
+template <typename PX> CTU_DEV void post64(lds<PX> *S, const job<PX> &J)
+{
+  SERIAL { S->m64[0] = cu_at(S, 0, 0)->mode; S->m64[1] = cu_at(S, 0, 0)->mode_chroma; }
+  CTU_SYNC();
+#if defined(__HIPCC__)
+  LANE0 mb_store(&S->req64, 1);
+#else
+  const int me = g_emul_wave;           // host emulation: the other waves' work happens right here
+  S->req64 = 1;
+  g_emul_wave = 3;
+  for (int i = 0; i < 4; ++i) luma64_step(S, J, i);
+  g_emul_wave = 2;
+  for (int i = 0; i < 4; ++i) { chroma64_step(S, J, i, 1); chroma64_step(S, J, i, 2); }
+  g_emul_wave = me;
+  S->done64[0] = S->done64[1] = 1;
+#endif
+}
+
+// the candidate won: into the decided planes, the coefficient array and the side information (the walk's wave)
+template <typename PX> CTU_NOINLINE CTU_DEV void unpark64(lds<PX> *S, const job<PX> &J)
+{
   scratch *W = J.W;
-  // save the split's result
+  level_state &N = S->lvl[0];
   for (int color = 0; color < 3; ++color) {
     const int w = color ? 32 : 64, l2 = color ? 5 : 6, pit = pitch_of(color);
-    const PX *D = plane(S, color) + pit + 1;
-    PAR_FOR(e, w * w) { W->save_px[co_off(color) + e] = D[(e >> l2) * pit + (e & (w - 1))]; W->save_co[co_off(color) + e] = CTU_GLOAD(&J.coeff[co_off(color) + e]); }
+    PX *D = plane(S, color) + pit + 1;
+    PAR_FOR(e, w * w) { D[(e >> l2) * pit + (e & (w - 1))] = (PX)CTU_GLOAD(&W->save_px[co_off(color) + e]); J.coeff[co_off(color) + e] = CTU_GLOAD(&W->save_co[co_off(color) + e]); }
   }
-  PAR_FOR(e, 256) { W->save_cu[e] = *cu_at(S, (e & 15) * 4, (e >> 4) * 4); W->save_tree[e] = CTU_GLOAD(&W->tree[e]); W->save_tree[256 + e] = CTU_GLOAD(&W->mtt[e]); }
-  CTU_SYNC();
-  const int mode = cu_at(S, 0, 0)->mode, mode_chroma = cu_at(S, 0, 0)->mode_chroma;
-  CTU_SYNC();
   SERIAL {
-    V->cur = S->cur;
     for (int e = 0; e < 256; ++e) { cu4 *c = cu_at(S, (e & 15) * 4, (e >> 4) * 4); c->cbf = 0; c->luma_edges = 0; c->chroma_edges = 0; }
-    fill_cu(S, 0, 0, 64, mode, mode_chroma, 5, N.split_tree, cu_mtt(N.mode_type_tree, 0));
+    fill_cu(S, 0, 0, 64, S->m64[0], S->m64[1], 5, N.split_tree, cu_mtt(N.mode_type_tree, 0));
+    for (int i = 0; i < 4; ++i) cu_at(S, (i & 1) * 32, (i >> 1) * 32)->cbf = (uint8_t)(S->h64[i].cy | S->h64[i].cu << 1 | S->h64[i].cv << 2);
+    mark_deblocking(S, N.x, N.y, 0, 0, 64, 0, 1);
+    N.type = CU_INTRA;
   }
   CTU_SYNC();
-  // the models are the CU's entry models and do not adapt (search_cabac.update is 0 on this path): bits only
-  copy_models(S->cur, S->coder);                 // (the CTU's entry models: the coder's, untouched until its pass after the search)
-#if defined(CTU_LEAF4)
-  // The three colours of the candidate depend on nothing of each other but Cr's flag context (Cb's flag), and its models do not adapt:
-  // depth 2's wave -- idle, like every depth's, once the four 32x32 areas are decided -- reconstructs and prices the chroma of the
-  // four areas (chroma64_job) while this wave does the luma; the parts meet below in the reference's order of summation.
-  SERIAL { S->j64 = 1; S->j64_mode = mode_chroma; }
-  post_eval(S, J, 2);
-  for (int i = 0; i < 4; ++i) {
-    const int tx = x + (i & 1) * 32, ty = y + (i >> 1) * 32, lx = tx & 63, ly = ty & 63;
-    PX *ry = S->Dy + (ly + 1) * PY + lx + 1;
-    int16_t *ky = J.coeff + ly * LCU + lx;
-    const int cy = recon_tu(S, J, 0, tx, ty, lx, ly, 32, mode, 0, ry, PY, ky, LCU, 64);
-    ssd_block(S, J, 0, lx, ly, 32, 0, ry, PY);
-    double by = 0;
-    LANE0 m_code(LDSP(uint32_t, S->cur), 0, M_CBF_LUMA + 0, cy, by);
-    WSYNC();
-    if (cy) by += coeff_bits(S, S->cur, 0, lv_of(V, 0), 32, 0);
-    LANE0 { S->h64[i].cy = cy; S->h64[i].ssd_y = V->red[0]; S->h64[i].bits_y = by; }
-    CTU_SYNC();
-  }
-  wait_eval(S, 2);
+}
+
+// the walk, after the four 32x32 areas: the candidate's cost into lvl[0].cost; -> the split wins
+template <typename PX> CTU_DEV bool finish64(lds<PX> *S, const job<PX> &J)
+{
+  const params &P = J.P;
+  level_state &N = S->lvl[0];
+#if defined(__HIPCC__)
+  while (mb_load(&S->done64[0]) == 0 || mb_load(&S->done64[1]) == 0) __builtin_amdgcn_s_sleep(2);
+#endif
+  CTU_SYNC();
   LANE0 {
-    S->j64 = 0;
+    // the models are the CTU's entry models (the coder's, untouched until its pass after the search) and do not adapt
+    // (search_cabac.update is 0 on this path): bits only
+    const int mode = S->m64[0], mode_chroma = S->m64[1];
     double bits = 0;
-    split_flag_bits(S, P, S->cur, 0, x, y, 0, 0, 64, 0, bits);
+    split_flag_bits(S, P, S->coder, 0, N.x, N.y, 0, 0, 64, 0, bits);
     double mode_bits = 0;
     {   // calc_mode_bits (search.c:988-1003): the luma mode on a copy of the models, the chroma mode without adaptation
-      for (int k = 0; k < NMODELS; ++k) S->work[2][k] = S->cur[k];
-      luma_mode_bits(S, S->work[2], 0, x, y, 0, 0, 64, mode, mode_bits);
-      if (mode_chroma == mode) mode_bits += m_fbits(S->cur, M_CHROMA_PRED, 0);
-      else mode_bits += 2.0 + m_fbits(S->cur, M_CHROMA_PRED, 1);
+      for (int k = 0; k < NMODELS; ++k) S->work[2][k] = S->coder[k];          // (depth 3's entry models: nobody's after the walk)
+      luma_mode_bits(S, S->work[2], 0, N.x, N.y, 0, 0, 64, mode, mode_bits);
+      if (mode_chroma == mode) mode_bits += m_fbits(S->coder, M_CHROMA_PRED, 0);
+      else mode_bits += 2.0 + m_fbits(S->coder, M_CHROMA_PRED, 1);
     }
     mode_bits += bits;
     const double d0 = mode_bits * P.lambda;
     double d1 = 0;
     for (int i = 0; i < 4; ++i) {
-      const int lx = (i & 1) * 32, ly = (i >> 1) * 32;
-      cu_at(S, lx, ly)->cbf = (uint8_t)(S->h64[i].cy | S->h64[i].cu << 1 | S->h64[i].cv << 2);
-      // cu_rd_cost_tr_split_accurate of the area (tr_cost): SSDs + (luma bits + chroma bits) * lambda
+      // cu_rd_cost_tr_split_accurate of the unit (tr_cost): SSDs + (luma bits + chroma bits) * lambda
       const unsigned chroma_ssd = (unsigned)((unsigned)S->h64[i].ssd_u * P.cw_u) + (unsigned)((unsigned)S->h64[i].ssd_v * P.cw_v);
       d1 += (unsigned)S->h64[i].ssd_y * 1.0 + chroma_ssd * 1.0 + (S->h64[i].bits_y + S->h64[i].bits) * P.lambda;
     }
@@ -3123,112 +3312,16 @@ template <typename PX> CTU_NOINLINE CTU_DEV void eval_cu64(lds<PX> *S, const job
     c2 += d0;
     c2 += d1 + 0 * P.lambda;          // the sum of the four blocks + luma_bits (0) * lambda (search.c:779)
     N.cost = c2;
-    mark_deblocking(S, x, y, 0, 0, 64, 0, 1);
   }
   CTU_SYNC();
-}
-// the chroma of the 64x64 candidate (eval_cu64), by depth 2's wave on its own scratch: a 16x16 block is that depth's luma size, so the
-// levels of Cb and Cr take turns in its luma level array
-template <typename PX> CTU_NOINLINE CTU_DEV void chroma64_job(lds<PX> *S, const job<PX> &J)
-{
-  wctx *const V = wv_of(S);
-  const params &P = J.P;
-  const int x = S->lvl[0].x, y = S->lvl[0].y, mode_chroma = S->j64_mode;
-  int16_t *const keep1 = V->lv1, *const keep2 = V->lv2;
-  uint32_t *const keepc = V->cur;
-  LANE0 { V->lv1 = V->lv0; V->lv2 = V->lv0; V->cur = S->cur; }
+  const bool split_wins = N.split_cost < N.cost;
   CTU_SYNC();
-  for (int i = 0; i < 4; ++i) {
-    const int tx = x + (i & 1) * 32, ty = y + (i >> 1) * 32, lx = tx & 63, ly = ty & 63;
-    PX *ru = S->Du + ((ly >> 1) + 1) * PC + (lx >> 1) + 1, *rv = S->Dv + ((ly >> 1) + 1) * PC + (lx >> 1) + 1;
-    int16_t *ku = J.coeff + 4096 + (ly >> 1) * LCU_C + (lx >> 1), *kv = J.coeff + 5120 + (ly >> 1) * LCU_C + (lx >> 1);
-    const int cu = recon_tu(S, J, 1, tx, ty, lx, ly, 32, mode_chroma, 0, ru, PC, ku, LCU_C, 64);
-    ssd_block(S, J, 1, lx, ly, 32, 1, ru, PC);
-    double cb = coeff_bits(S, S->cur, 0, V->lv0, 16, 1);
-    const int cv = recon_tu(S, J, 2, tx, ty, lx, ly, 32, mode_chroma, cu, rv, PC, kv, LCU_C, 64);
-    ssd_block(S, J, 2, lx, ly, 32, 2, rv, PC);
-    cb += coeff_bits(S, S->cur, 0, V->lv0, 16, 2);
-    LANE0 {
-      double fb = 0;
-      m_code(LDSP(uint32_t, S->cur), 0, M_CBF_CB + 0, cu, fb);
-      m_code(LDSP(uint32_t, S->cur), 0, M_CBF_CR + cu, cv, fb);
-      S->h64[i].cu = cu; S->h64[i].cv = cv; S->h64[i].ssd_u = V->red[1]; S->h64[i].ssd_v = V->red[2]; S->h64[i].bits = fb + cb;
-    }
-    CTU_SYNC();
-  }
-  LANE0 { V->lv1 = keep1; V->lv2 = keep2; V->cur = keepc; }
-  CTU_SYNC();
-}
-#else
-  for (int i = 0; i < 4; ++i) {
-    const int tx = x + (i & 1) * 32, ty = y + (i >> 1) * 32, lx = tx & 63, ly = ty & 63;
-    PX *ry = S->Dy + (ly + 1) * PY + lx + 1, *ru = S->Du + ((ly >> 1) + 1) * PC + (lx >> 1) + 1, *rv = S->Dv + ((ly >> 1) + 1) * PC + (lx >> 1) + 1;
-    int16_t *ky = J.coeff + ly * LCU + lx, *ku = J.coeff + 4096 + (ly >> 1) * LCU_C + (lx >> 1), *kv = J.coeff + 5120 + (ly >> 1) * LCU_C + (lx >> 1);
-    int cbf = recon_tu(S, J, 0, tx, ty, lx, ly, 32, mode, 0, ry, PY, ky, LCU, 64);
-    const int cu = recon_tu(S, J, 1, tx, ty, lx, ly, 32, mode_chroma, 0, ru, PC, ku, LCU_C, 64);
-    const int cv = recon_tu(S, J, 2, tx, ty, lx, ly, 32, mode_chroma, cu, rv, PC, kv, LCU_C, 64);
-    cbf |= cu << 1 | cv << 2;
-    SERIAL cu_at(S, lx, ly)->cbf = (uint8_t)cbf;
-    CTU_SYNC();
-  }
-  // every transform block's levels are needed again for the cost, in coding order: fetch them back from the coefficient array
-  for (int i = 0; i < 4; ++i) {
-    const int lx = (i & 1) * 32, ly = (i >> 1) * 32;
-    for (int color = 0; color < 3; ++color) {
-      const int c = color != 0, w = 32 >> c, l2 = c ? 4 : 5, spit = c ? LCU_C : LCU;
-      const int16_t *co = J.coeff + co_off(color) + (ly >> c) * spit + (lx >> c);
-      PAR_FOR(e, w * w) lv_of(V, color)[e] = CTU_GLOAD(&co[(e >> l2) * spit + (e & (w - 1))]);
-    }
-    CTU_SYNC();
-    ssd_block(S, J, 0, lx, ly, 32, 0, S->Dy + (ly + 1) * PY + lx + 1, PY);
-    ssd_block(S, J, 1, lx, ly, 32, 1, S->Du + ((ly >> 1) + 1) * PC + (lx >> 1) + 1, PC);
-    ssd_block(S, J, 2, lx, ly, 32, 2, S->Dv + ((ly >> 1) + 1) * PC + (lx >> 1) + 1, PC);
-    {
-      LANE0 {
-        if (i == 0) {
-          double bits = 0;
-          split_flag_bits(S, P, S->cur, 0, x, y, 0, 0, 64, 0, bits);
-          double mode_bits = 0;
-          {   // calc_mode_bits (search.c:988-1003): the luma mode on a copy of the models, the chroma mode without adaptation
-            for (int k = 0; k < NMODELS; ++k) S->work[2][k] = S->cur[k];
-            luma_mode_bits(S, S->work[2], 0, x, y, 0, 0, 64, mode, mode_bits);
-            if (mode_chroma == mode) mode_bits += m_fbits(S->cur, M_CHROMA_PRED, 0);
-            else mode_bits += 2.0 + m_fbits(S->cur, M_CHROMA_PRED, 1);
-          }
-          mode_bits += bits;
-          V->u_d0 = mode_bits * P.lambda;
-          V->u_d1 = 0;
-        }
-      }
-      CTU_SYNC();
-      const double trc = tr_cost(S, P, 0, 32, cu_at(S, lx, ly)->cbf, 1, 16);
-      LANE0 {
-        V->u_d1 += trc;
-        if (i == 3) {
-          double c2 = 0;
-          c2 += V->u_d0;
-          c2 += V->u_d1 + 0 * P.lambda;          // the sum of the four blocks + luma_bits (0) * lambda (search.c:779)
-          N.cost = c2;
-          mark_deblocking(S, x, y, 0, 0, 64, 0, 1);
-        }
-      }
-    }
-    CTU_SYNC();
-  }
+  // post_search_cabac = the unadapted entry models; search_cabac = temp_cabac, the models after the split (:2140-2141): S->cur as it is
+  if (split_wins) { SERIAL N.cost = N.split_cost; CTU_SYNC(); }
+  else unpark64(S, J);
+  return split_wins;
 }
 #endif
-// the split won after all: bring its result back
-template <typename PX> CTU_NOINLINE CTU_DEV void restore64(lds<PX> *S, const job<PX> &J)
-{
-  scratch *W = J.W;
-  for (int color = 0; color < 3; ++color) {
-    const int w = color ? 32 : 64, l2 = color ? 5 : 6, pit = pitch_of(color);
-    PX *D = plane(S, color) + pit + 1;
-    PAR_FOR(e, w * w) { D[(e >> l2) * pit + (e & (w - 1))] = (PX)CTU_GLOAD(&W->save_px[co_off(color) + e]); J.coeff[co_off(color) + e] = CTU_GLOAD(&W->save_co[co_off(color) + e]); }
-  }
-  PAR_FOR(e, 256) { *cu_at(S, (e & 15) * 4, (e >> 4) * 4) = W->save_cu[e]; W->tree[e] = (uint16_t)CTU_GLOAD(&W->save_tree[e]); W->mtt[e] = (uint16_t)CTU_GLOAD(&W->save_tree[256 + e]); }
-  CTU_SYNC();
-}
 
 #define V_flag(S) (wv_of(S)->u_flag)
 
@@ -3274,23 +3367,29 @@ template <typename PX> CTU_DEV void worker_loop(lds<PX> *S, const job<PX> &J)
 {
   const int L = 4 - CTU_WAVE;
   int seen = 0, hseen = 0;
+  // the 64x64 candidate (post64): depth 1's wave owes it four luma blocks, depth 2's eight chroma blocks, one at a time whenever the
+  // wave has no evaluation to do
+  const int steps64 = L == 1 ? 4 : (L == 2 ? 8 : 0);
+  int n64 = 0;
   for (;;) {
     int r, h = hseen;
+    bool step = false;
     for (;;) {
       r = mb_load(&S->req[L]);
       if (r != seen) break;
       if (L == 3) { h = mb_load(&S->hreq); if (h != hseen) break; }        // depth 3's wave also takes the walk's Cb blocks (help_post)
+      if (n64 < steps64 && mb_load(&S->req64)) { step = true; break; }
       if (L == 3) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4);
     }
     if (r != seen) {
       if (r < 0) break;
       seen = r;
-#if defined(CTU_LEAF4)
-      if (L == 2 && S->j64) chroma64_job(S, J); else
-#endif
       eval_cu(S, J, L, 1);
       CTU_SYNC();
       LANE0 mb_store(&S->done[L], r);
+    } else if (step) {
+      if (L == 1) luma64_step(S, J, n64); else chroma64_step(S, J, n64 >> 1, 1 + (n64 & 1));
+      if (++n64 == steps64) { CTU_SYNC(); LANE0 mb_store(&S->done64[L - 1], 1); }
     } else {
       hseen = h;
       help_run(S, J);
@@ -3381,6 +3480,12 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
       }
     }
     CTU_SYNC();
+#if !defined(CTU_PB)
+    // the first 32x32 area is decided: if it is one intra CU the 64x64 candidate will be tried with its modes (combine_intra_cus) -- ask
+    // for it now, the depth waves build it beside the walk (post64).  Only when no leaf can borrow those waves' scratch (vsel).
+    if (L == 0 && N.child == 1 && N.type == CU_NOTSET && P.combine_intra_cus && P.depth_max >= 3 && N.x + 64 <= P.pic_w && N.y + 64 <= P.pic_h &&
+        cu_at(S, 0, 0)->type == CU_INTRA && cu_at(S, 0, 0)->log2 == 5) post64(S, J);
+#endif
     if (!V_flag(S)) { ++L; entering = 1; continue; }
     // the split is complete (or was cut short): the CU's own cost is needed now
     if (N.pending) wait_eval(S, L);
@@ -3390,25 +3495,17 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
     const bool split_wins = !pruned && N.split_cost < N.cost;
     const int ntype = N.type;
     CTU_SYNC();
+#if !defined(CTU_PB)
     if (L == 0 && ntype == CU_NOTSET && P.combine_intra_cus && N.x + 64 <= P.pic_w && N.y + 64 <= P.pic_h &&
         cu_at(S, 0, 0)->type == CU_INTRA && cu_at(S, 0, 0)->log2 == 5) {
-      copy_models(S->work[0], S->cur);                   // temp_cabac: the models after the split (search.c:2093); depth 1 is idle by now
-      LANE0 S->vsel[CTU_WAVE] = 3;                       // the depth-1 scratch: 32x32 blocks
-      CTU_SYNC();
-      { CTU_T0();
-      eval_cu64(S, J);
-      CTU_T1(J.W, 7); }
-      // post_search_cabac = the unadapted entry models; search_cabac = temp_cabac (:2140-2141)
-      copy_models(S->cur, S->work[0]);
-      const bool split_wins64 = N.split_cost < N.cost;        // N.cost: the 64x64 CU's (eval_cu64 ends with a fence)
-      CTU_SYNC();
-      if (split_wins64) { restore64(S, J); SERIAL N.cost = N.split_cost; CTU_SYNC(); }
-      else { SERIAL { N.type = CU_INTRA; } CTU_SYNC(); }
-      LANE0 S->vsel[CTU_WAVE] = 0;
-      CTU_SYNC();
+      CTU_T0();
+      if (!S->req64) post64(S, J);                       // (leaves above depth 3 borrow the depth waves' scratch: nothing was posted beside them)
+      (void)finish64(S, J);
+      CTU_T1(J.W, 7);
       ret = N.cost;
       break;
     }
+#endif
     if (split_wins) {
       SERIAL N.cost = N.split_cost;
       CTU_SYNC();
@@ -3737,8 +3834,8 @@ template <typename PX> CTU_DEV void setup_waves(lds<PX> *S, scratch *W = nullptr
     S->vsel[k] = k;
     S->req[k] = 0; S->done[k] = 0;
     if (k == 0) { S->hreq = 0; S->hdone = 0; }
-#if defined(CTU_LEAF4X)
-    if (k == 0) S->j64 = 0;
+#if !defined(CTU_PB)
+    if (k == 0) { S->req64 = 0; S->done64[0] = 0; S->done64[1] = 0; }
 #endif
   }
   BLK_SYNC();
