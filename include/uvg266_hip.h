@@ -886,7 +886,8 @@ typedef struct uvghip_ctu_params {
   int32_t pic_w, pic_h;          /* multiples of 8 */
   int32_t qp;                    /* state->qp */
   int32_t qp_c;                  /* encoder_control->qp_map[0][qp] */
-  int32_t depth_min, depth_max;  /* cfg.pu_depth_intra */
+  int32_t depth_min, depth_max;  /* cfg.pu_depth_intra: 1 <= min <= max <= 4; min > 1 only with combine_intra_cus = 0 (the reference combines at every depth
+                                  * without a search, search.c:2082-2143; the kernel at depth 0 only) */
   int32_t wpp;                   /* cfg.wpp: must be 1 */
   int32_t combine_intra_cus;     /* cfg.combine_intra_cus */
   int32_t rough_levels;          /* cfg.intra_rough_search_levels: 2 or 3 */

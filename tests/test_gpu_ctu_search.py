@@ -13,6 +13,7 @@ def run_gpu(hip, depth, prm, pictures):
     import torch
     from uvg266_amd import api
     P = api.ctu_params(prm.pic_w, prm.pic_h, prm.qp, lam=prm.lam)
+    P.depth_min, P.depth_max, P.combine_intra_cus = prm.depth_min, prm.depth_max, prm.combine_intra_cus
     src = [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in yuv) for yuv in pictures]
     cs = api.CtuSearch(P, src)
     cs.run()
@@ -67,6 +68,28 @@ def test_repeated_runs_give_the_reference_result_every_time(hip, name):
         assert np.array_equal(r["coeff"], g["coeff"]), rep
         for p in ("rec_y", "rec_u", "rec_v"):
             assert np.array_equal(r[p], g[p]), (rep, p)
+
+
+@pytest.mark.parametrize("dmin,dmax,combine", [(1, 3, 1), (1, 2, 1), (1, 1, 1), (2, 4, 0), (2, 2, 0), (3, 4, 0)])
+def test_other_pu_depth_ranges_equal_the_oracle(hip, orc, dmin, dmax, combine):
+    """--pu-depth-intra other than 1-4 (tests/test_ctu_emulation.py has the same cases on the host): leaves above the 4x4 depth on
+    the depth waves' scratch; with depth_max < 3 the 64x64 candidate is built after the walk instead of beside it."""
+    wins64 = 0
+    cases = []
+    for name in ("ref_ctu_320x192_8_qp42", "ref_ctu_192x128_10_qp12"):
+        W, Hh, depth, qp, y, u, v = H.golden_source(H.ctu_golden(name))
+        cases.append((W, Hh, depth, qp, (y, u, v)))
+    cases.append((200, 136, 10, 27, H.varied_picture(200, 136, 7, 10)))
+    cases.append((128, 128, 8, 45, H.varied_picture(128, 128, 1011, 8)))
+    for W, Hh, depth, qp, pic in cases:
+        prm = H.search_params(W, Hh, qp)
+        prm.depth_min, prm.depth_max, prm.combine_intra_cus = dmin, dmax, combine
+        r = run_gpu(hip, depth, prm, [pic])[0]
+        o = H.oracle_search_picture(orc, depth, prm, *pic)
+        assert np.array_equal(H.ctu_crcs(r, W, Hh), H.ctu_crcs(o, W, Hh)), (W, Hh, depth, qp)
+        assert np.array_equal(r["models"], o["models"]), (W, Hh, depth, qp)
+        wins64 += int((o["cu"][:Hh // 4:16, :W // 4:16, 1] == 6).sum())
+    assert wins64 > 0 or not combine
 
 
 def test_sweep_of_small_pictures_equals_the_oracle(hip, orc):
@@ -143,7 +166,7 @@ def test_plan_refuses_what_the_search_does_not_implement(hip):
     def create(params, pics=None, n=1, ws=None):
         plan = ctypes.c_void_p()
         return L.uvghip_ctu_plan_create(8, ctypes.byref(params), good.pics if pics is None else pics, n, api._dev(good.ws) if ws is None else ws, ctypes.byref(plan))
-    for change in (dict(wpp=0), dict(depth_max=5), dict(depth_min=3, depth_max=2), dict(rough_levels=1), dict(qp=64), dict(pic_w=W + 4), dict(lambda_=0.0)):
+    for change in (dict(wpp=0), dict(depth_max=5), dict(depth_min=3, depth_max=2), dict(depth_min=2), dict(rough_levels=1), dict(qp=64), dict(pic_w=W + 4), dict(lambda_=0.0)):
         p = api.ctu_params(W, Hh, 27)
         for k, val in change.items():
             setattr(p, k, val)

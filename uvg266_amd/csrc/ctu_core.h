@@ -3284,7 +3284,9 @@ template <typename PX> CTU_DEV bool finish64(lds<PX> *S, const job<PX> &J)
   const params &P = J.P;
   level_state &N = S->lvl[0];
 #if defined(__HIPCC__)
+  { CTU_T0();
   while (mb_load(&S->done64[0]) == 0 || mb_load(&S->done64[1]) == 0) __builtin_amdgcn_s_sleep(2);
+  CTU_T1(J.W, 12); }        // (profile slots 12 / 13 of the walk's wave: the wait for the two chains, unpark64)
 #endif
   CTU_SYNC();
   LANE0 {
@@ -3318,7 +3320,7 @@ template <typename PX> CTU_DEV bool finish64(lds<PX> *S, const job<PX> &J)
   CTU_SYNC();
   // post_search_cabac = the unadapted entry models; search_cabac = temp_cabac, the models after the split (:2140-2141): S->cur as it is
   if (split_wins) { SERIAL N.cost = N.split_cost; CTU_SYNC(); }
-  else unpark64(S, J);
+  else { CTU_T0(); unpark64(S, J); CTU_T1(J.W, 13); }
   return split_wins;
 }
 #endif

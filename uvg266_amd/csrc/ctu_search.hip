@@ -211,6 +211,10 @@ extern "C" int uvghip_ctu_plan_create_rows(int bitdepth, const uvghip_ctu_params
   if (p.wpp != 1 || p.depth_min < 1 || p.depth_max > 4 || p.depth_min > p.depth_max || p.rough_levels < 2 || p.rough_levels > 3 || p.qp < 0 || p.qp > 63 ||
       p.qp_c < 0 || p.qp_c > 63 || !(p.lambda > 0) || p.rd < 0 || p.rd > 1)
     return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_plan_create: configuration outside the supported subset");
+  // combine_intra_cus tries the first child's mode at EVERY depth without a search of its own (search.c:2082-2143); the kernel builds the
+  // candidate at depth 0 only, which is all there is with pu-depth-intra starting at 1 (tests/test_ctu_emulation.py, other ranges)
+  if (p.combine_intra_cus && p.depth_min > 1)
+    return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_plan_create: combine_intra_cus with pu-depth-intra starting below depth 1 is not supported");
   const int wc = (p.pic_w + 63) / 64, hc = (p.pic_h + 63) / 64, ctus = wc * hc;
   if (ctu_row0 < 0 || ctu_row1 > hc || ctu_row0 >= ctu_row1) return uvghip_set_error(hipErrorInvalidValue, "uvghip_ctu_plan_create_rows: CTU row range");
   const int total = wc * (ctu_row1 - ctu_row0) * n_pictures;
