@@ -325,6 +325,7 @@ template <typename PX> struct lds {
   // its chroma blocks by depth 2's between their evaluations; the modes (luma, chroma) of the request; per 32x32 transform unit the
   // flags, the SSDs and the bit counts (bits: chroma, bits_y: luma)
   int32_t req64, done64[2], m64[2];
+  int32_t creq, cdone[2];                           // the coder's pass by model (run_ctu): asked for; the flags / the chroma coefficients are done
   struct { int32_t cu, cv, ssd_u, ssd_v, cy, ssd_y; double bits, bits_y; } h64[4];
 #endif
   alignas(16) unsigned char arena[lds_cfg<PX>::slim ? (int)ARENA_BYTES_SLIM : (int)ARENA_BYTES];
@@ -3363,6 +3364,8 @@ template <typename PX> CTU_DEV void wait_eval(lds<PX> *S, int L)
   CTU_SYNC();
 #endif
 }
+enum { CODER_FLAGS = 1, CODER_LUMA = 2, CODER_CHROMA = 4, CODER_ALL = 7 };      // the coder's pass by model (below, at coder_pass)
+template <typename PX> CTU_DEV void coder_pass(lds<PX> *S, const job<PX> &J, int parts);
 #if defined(__HIPCC__)
 // waves 1..3: evaluate depth 4 - wave whenever asked, until told to stop (req < 0)
 template <typename PX> CTU_DEV void worker_loop(lds<PX> *S, const job<PX> &J)
@@ -3373,6 +3376,7 @@ template <typename PX> CTU_DEV void worker_loop(lds<PX> *S, const job<PX> &J)
   // wave has no evaluation to do
   const int steps64 = L == 1 ? 4 : (L == 2 ? 8 : 0);
   int n64 = 0;
+  bool coded = false;
   for (;;) {
     int r, h = hseen;
     bool step = false;
@@ -3381,6 +3385,16 @@ template <typename PX> CTU_DEV void worker_loop(lds<PX> *S, const job<PX> &J)
       if (r != seen) break;
       if (L == 3) { h = mb_load(&S->hreq); if (h != hseen) break; }        // depth 3's wave also takes the walk's Cb blocks (help_post)
       if (n64 < steps64 && mb_load(&S->req64)) { step = true; break; }
+      if (L >= 2 && !coded && mb_load(&S->creq)) {
+        // the search is over: this wave's part of the coder's pass (depth 3: the flags, depth 2: the chroma coefficients)
+        { CTU_T0();
+        coder_pass(S, J, L == 3 ? CODER_FLAGS : CODER_CHROMA);
+        CTU_T1(J.W, 8); }
+        CTU_SYNC();
+        LANE0 mb_store(&S->cdone[3 - L], 1);
+        coded = true;
+        continue;
+      }
       if (L == 3) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4);
     }
     if (r != seen) {
@@ -3525,71 +3539,83 @@ template <typename PX> CTU_DEV void search_ctu(lds<PX> *S, const job<PX> &J)
 
 // ====================================================================== the real coder's model adaptation + CTU in / out ======
 CTU_DEV int z_to_x(int z) { return (z & 1) | ((z >> 1) & 2) | ((z >> 2) & 4) | ((z >> 3) & 8); }
+// A context model is a state machine of its own: what it becomes depends on the bins coded with IT, in coding order, and on nothing
+// else; which model a bin uses depends on the syntax (levels, modes, flags, neighbours), never on another model's state.  So the pass
+// over the decided CTU splits by MODEL into three passes that each walk the CUs in coding order and touch disjoint entries of
+// S->coder: the flags (split, prediction modes, the three cbf), the luma coefficients (significance / greater-than / parity /
+// last position / group flags of colour type 0) and the chroma coefficients (the same of colour type 1, Cb before Cr).  Three waves
+// run them side by side (run_ctu); the host emulation runs them one after the other.  (enum CODER_*: above worker_loop)
 
 #if defined(CTU_LEAF4)
 // the real coder's walk over an 8x8 area of four 4x4 CUs (the shape most of a detailed CTU consists of): the area's 64 + 32 levels are
 // fetched once, a lane each; every block's bins go through coeff_bits4r from registers.  Same bins in the same order as coder_pass.
-template <typename PX> CTU_DEV void coder_area4(lds<PX> *S, const job<PX> &J, int lx, int ly)
+template <typename PX> CTU_DEV void coder_area4(lds<PX> *S, const job<PX> &J, int lx, int ly, int parts)
 {
   const params &P = J.P;
   const int lane = CTU_TID, r = lane & 15;
-  int lev_all, clev = 0;
+  int lev_all = 0, clev = 0;
   {
     const int k = lane >> 4;
-    lev_all = CTU_GLOAD(&J.coeff[(ly + (k >> 1) * 4 + (r >> 2)) * LCU + lx + (k & 1) * 4 + (r & 3)]);
-    if (lane < 32) clev = CTU_GLOAD(&J.coeff[4096 + k * 1024 + ((ly >> 1) + (r >> 2)) * LCU_C + (lx >> 1) + (r & 3)]);
+    if (parts & CODER_LUMA) lev_all = CTU_GLOAD(&J.coeff[(ly + (k >> 1) * 4 + (r >> 2)) * LCU + lx + (k & 1) * 4 + (r & 3)]);
+    if ((parts & CODER_CHROMA) && lane < 32) clev = CTU_GLOAD(&J.coeff[4096 + k * 1024 + ((ly >> 1) + (r >> 2)) * LCU_C + (lx >> 1) + (r & 3)]);
   }
   CTU_LDS uint32_t *const m = LDSP(uint32_t, S->coder);
   for (int k = 0; k < 4; ++k) {
     const int clx = lx + (k & 1) * 4, cly = ly + (k >> 1) * 4, x = J.x + clx, y = J.y + cly;
     const cu4 *c = cu_at(S, clx, cly);
     const int mode = __builtin_amdgcn_readfirstlane((int)c->mode), cb_y = __builtin_amdgcn_readfirstlane((int)c->cbf) & 1;
-    int mpm[6];
-    {
-      const cu4 *l, *a;
-      mpm_neighbours(S, x, y, clx, cly, 4, &l, &a);
-      int left_dir = 0, above_dir = 0;
-      if (l && l->type == CU_INTRA) left_dir = l->mode;
-      if (a && a->type == CU_INTRA && y % LCU != 0) above_dir = a->mode;
-      lf_mpm(__builtin_amdgcn_readfirstlane(left_dir), __builtin_amdgcn_readfirstlane(above_dir), mpm);
+    if (parts & CODER_FLAGS) {
+      int mpm[6];
+      {
+        const cu4 *l, *a;
+        mpm_neighbours(S, x, y, clx, cly, 4, &l, &a);
+        int left_dir = 0, above_dir = 0;
+        if (l && l->type == CU_INTRA) left_dir = l->mode;
+        if (a && a->type == CU_INTRA && y % LCU != 0) above_dir = a->mode;
+        lf_mpm(__builtin_amdgcn_readfirstlane(left_dir), __builtin_amdgcn_readfirstlane(above_dir), mpm);
+      }
+      LANE0 {
+        double dummy = 0;
+        if (k == 0)          // split flags of the enclosing quad-tree nodes that begin here (a 4x4 CU has none of its own)
+          for (int d = 0; (64 >> d) > 4; ++d) {
+            const int sz = 64 >> d;
+            if (!(lx & (sz - 1)) && !(ly & (sz - 1))) split_flag_bits(S, P, S->coder, 1, x, y, lx, ly, sz, 1, dummy);
+          }
+        lf_luma_mode_bits(S->coder, mpm, mode, dummy);
+        m_code(m, 1, M_CBF_LUMA + 0, cb_y, dummy);
+      }
+      WSYNC();
     }
-    LANE0 {
-      double dummy = 0;
-      if (k == 0)          // split flags of the enclosing quad-tree nodes that begin here (a 4x4 CU has none of its own)
-        for (int d = 0; (64 >> d) > 4; ++d) {
-          const int sz = 64 >> d;
-          if (!(lx & (sz - 1)) && !(ly & (sz - 1))) split_flag_bits(S, P, S->coder, 1, x, y, lx, ly, sz, 1, dummy);
-        }
-      lf_luma_mode_bits(S->coder, mpm, mode, dummy);
-      m_code(m, 1, M_CBF_LUMA + 0, cb_y, dummy);
-    }
-    WSYNC();
-    if (cb_y) (void)coeff_bits4r(S, m, 1, lf_shfl(lev_all, k * 16 + r), 0);
+    if ((parts & CODER_LUMA) && cb_y) (void)coeff_bits4r<PX, false>(S, m, 1, lf_shfl(lev_all, k * 16 + r), 0);
     if (k == 3) {
       // the area's chroma after its last luma CU: mode (the co-located luma CU is this one), cbfs of the area's first entry, levels
       const cu4 *a = cu_at(S, lx, ly);
       const int acbf = __builtin_amdgcn_readfirstlane((int)a->cbf), au = (acbf >> 1) & 1, av = (acbf >> 2) & 1;
-      LANE0 {
-        double dummy = 0;
-        chroma_mode_bits(S->coder, 1, c->mode_chroma, c->mode, dummy);
-        m_code(m, 1, M_CBF_CB + 0, au, dummy);
-        m_code(m, 1, M_CBF_CR + au, av, dummy);
+      if (parts & CODER_FLAGS) {
+        LANE0 {
+          double dummy = 0;
+          chroma_mode_bits(S->coder, 1, c->mode_chroma, c->mode, dummy);
+          m_code(m, 1, M_CBF_CB + 0, au, dummy);
+          m_code(m, 1, M_CBF_CR + au, av, dummy);
+        }
+        WSYNC();
       }
-      WSYNC();
-      if (au) (void)coeff_bits4r(S, m, 1, lf_shfl(clev, r), 1);
-      if (av) (void)coeff_bits4r(S, m, 1, lf_shfl(clev, 16 + r), 2);
+      if (parts & CODER_CHROMA) {
+        if (au) (void)coeff_bits4r<PX, false>(S, m, 1, lf_shfl(clev, r), 1);
+        if (av) (void)coeff_bits4r<PX, false>(S, m, 1, lf_shfl(clev, 16 + r), 2);
+      }
     }
   }
   CTU_SYNC();
 }
 #endif
 
-// uvg_encode_coding_tree (encode_coding_tree.c:1365-1727) over the decided CTU: only which models see which bins matters here.
-// The quad tree is walked in z-order over the 4x4 units: a CU starts where a unit is aligned to its CU's size.
-template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass(lds<PX> *S, const job<PX> &J)
+template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass(lds<PX> *S, const job<PX> &J, int parts)
 {
   wctx *const V = wv_of(S);
   const params &P = J.P;
+  // the chroma pass runs on depth 2's scratch: a 16x16 block is that depth's luma size, Cb and Cr take turns in its luma level array
+  int16_t *const lvu = parts == CODER_CHROMA ? V->lv0 : lv_of(V, 1), *const lvv = parts == CODER_CHROMA ? V->lv0 : lv_of(V, 2);
   for (int z = 0; z < 256; ++z) {
     const int lx = z_to_x(z) * 4, ly = z_to_x(z >> 1) * 4;
     const int x = J.x + lx, y = J.y + ly;
@@ -3599,7 +3625,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass(lds<PX> *S, const jo
     if ((lx & (n - 1)) || (ly & (n - 1))) continue;
 #if defined(CTU_LEAF4)
     if (n == 4) {              // (4x4 CUs come as whole 8x8 areas, the first of the four at the area's origin)
-      if (!(lx & 4) && !(ly & 4)) coder_area4(S, J, lx, ly);
+      if (!(lx & 4) && !(ly & 4)) coder_area4(S, J, lx, ly, parts);
       continue;
     }
 #endif
@@ -3608,26 +3634,17 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass(lds<PX> *S, const jo
     for (int tu = 0; tu < tus; ++tu) {
       const int tlx = lx + (tu & 1) * 32, tly = ly + (tu >> 1) * 32;
       const cu4 *t = cu_at(S, tlx, tly);
-      // levels of this transform unit (and, for the last 4x4 CU of an 8x8 area, of the area's chroma)
-      {
-        const int16_t *co = J.coeff + tly * LCU + tlx;
-        const int l2 = ilog2_dev(tn);
-        PAR_FOR(e, tn * tn) lv_of(V, 0)[e] = CTU_GLOAD(&co[(e >> l2) * LCU + (e & (tn - 1))]);
-        if (!sep || last4) {
-          const int cw = sep ? 4 : tn >> 1, cl2 = ilog2_dev(cw);
-          const int cbx = (sep ? (tlx & ~7) : tlx) >> 1, cby = (sep ? (tly & ~7) : tly) >> 1;
-          PAR_FOR(e, cw * cw) {
-            lv_of(V, 1)[e] = CTU_GLOAD(&J.coeff[4096 + (cby + (e >> cl2)) * LCU_C + cbx + (e & (cw - 1))]);
-            lv_of(V, 2)[e] = CTU_GLOAD(&J.coeff[5120 + (cby + (e >> cl2)) * LCU_C + cbx + (e & (cw - 1))]);
-          }
-        }
-      }
-      CTU_SYNC();
-      {
-        uint32_t *m = S->coder;
-        double dummy = 0;
-        const int cb_y = t->cbf & 1, cb_u = (t->cbf >> 1) & 1, cb_v = (t->cbf >> 2) & 1;
+      const int cb_y = t->cbf & 1, cb_u = (t->cbf >> 1) & 1, cb_v = (t->cbf >> 2) & 1;
+      // the chroma blocks of this transform unit (for the last 4x4 CU of an 8x8 area: the area's)
+      const int has_c = !sep || last4;
+      const int cw = sep ? 4 : tn >> 1, cl2 = ilog2_dev(cw);
+      const int cbx = (sep ? (tlx & ~7) : tlx) >> 1, cby = (sep ? (tly & ~7) : tly) >> 1;
+      const cu4 *a = sep ? cu_at(S, lx & ~7, ly & ~7) : t;       // (4x4 CUs: the flags of the area's first entry)
+      const int au = sep ? (a->cbf >> 1) & 1 : cb_u, av = sep ? (a->cbf >> 2) & 1 : cb_v;
+      uint32_t *m = S->coder;
+      if (parts & CODER_FLAGS) {
         LANE0 {
+          double dummy = 0;
           if (tu == 0) {
             // split flags of the enclosing quad-tree nodes that begin here, then this CU's own
             for (int d = 0; (64 >> d) > n; ++d) {
@@ -3643,24 +3660,32 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass(lds<PX> *S, const jo
             m_code(m, 1, M_CBF_CR + cb_u, cb_v, dummy);
           }
           m_code(m, 1, M_CBF_LUMA + 0, cb_y, dummy);      // luma_cbf_ctx stays 0: one transform unit per CU, or a CU that is not a TU
-        }
-        WSYNC();
-        if (cb_y) (void)coeff_bits(S, m, 1, lv_of(V, 0), tn, 0);
-        if (!sep) {
-          if (cb_u) (void)coeff_bits(S, m, 1, lv_of(V, 1), tn >> 1, 1);
-          if (cb_v) (void)coeff_bits(S, m, 1, lv_of(V, 2), tn >> 1, 2);
-        } else if (last4) {
-          // the area's chroma after its last luma CU: mode (the co-located luma CU is this one), cbfs of the area's first entry, levels
-          const cu4 *a = cu_at(S, lx & ~7, ly & ~7);
-          const int au = (a->cbf >> 1) & 1, av = (a->cbf >> 2) & 1;
-          LANE0 {
+          if (last4) {
+            // the area's chroma after its last luma CU: mode (the co-located luma CU is this one), cbfs of the area's first entry
             chroma_mode_bits(m, 1, c->mode_chroma, c->mode, dummy);
             m_code(m, 1, M_CBF_CB + 0, au, dummy);
             m_code(m, 1, M_CBF_CR + au, av, dummy);
           }
-          WSYNC();
-          if (au) (void)coeff_bits(S, m, 1, lv_of(V, 1), 4, 1);
-          if (av) (void)coeff_bits(S, m, 1, lv_of(V, 2), 4, 2);
+        }
+        WSYNC();
+      }
+      if ((parts & CODER_LUMA) && cb_y) {
+        const int16_t *co = J.coeff + tly * LCU + tlx;
+        const int l2 = ilog2_dev(tn);
+        PAR_FOR(e, tn * tn) lv_of(V, 0)[e] = CTU_GLOAD(&co[(e >> l2) * LCU + (e & (tn - 1))]);
+        CTU_SYNC();
+        (void)coeff_bits(S, m, 1, lv_of(V, 0), tn, 0);
+      }
+      if ((parts & CODER_CHROMA) && has_c) {
+        if (au) {
+          PAR_FOR(e, cw * cw) lvu[e] = CTU_GLOAD(&J.coeff[4096 + (cby + (e >> cl2)) * LCU_C + cbx + (e & (cw - 1))]);
+          CTU_SYNC();
+          (void)coeff_bits(S, m, 1, lvu, cw, 1);
+        }
+        if (av) {
+          PAR_FOR(e, cw * cw) lvv[e] = CTU_GLOAD(&J.coeff[5120 + (cby + (e >> cl2)) * LCU_C + cbx + (e & (cw - 1))]);
+          CTU_SYNC();
+          (void)coeff_bits(S, m, 1, lvv, cw, 2);
         }
       }
       CTU_SYNC();
@@ -3668,7 +3693,6 @@ template <typename PX> CTU_NOINLINE CTU_DEV void coder_pass(lds<PX> *S, const jo
   }
 }
 
-// init_lcu_t (search.c:2230-2330): neighbouring side information and samples, the source samples, the models
 template <typename PX> CTU_NOINLINE CTU_DEV void load_ctu(lds<PX> *S, const job<PX> &J)
 {
   const params &P = J.P;
@@ -3837,7 +3861,7 @@ template <typename PX> CTU_DEV void setup_waves(lds<PX> *S, scratch *W = nullptr
     S->req[k] = 0; S->done[k] = 0;
     if (k == 0) { S->hreq = 0; S->hdone = 0; }
 #if !defined(CTU_PB)
-    if (k == 0) { S->req64 = 0; S->done64[0] = 0; S->done64[1] = 0; }
+    if (k == 0) { S->req64 = 0; S->done64[0] = 0; S->done64[1] = 0; S->creq = 0; S->cdone[0] = 0; S->cdone[1] = 0; }
 #endif
   }
   BLK_SYNC();
@@ -3873,7 +3897,20 @@ template <typename PX> CTU_DEV void run_ctu(lds<PX> *S, const job<PX> &J)
     { CTU_T0();
     LANE0 S->vsel[CTU_WAVE] = 3;          // the depth-1 scratch for the coder's 32x32 blocks: the other waves are idle now
     CTU_SYNC();
-    coder_pass(S, J);
+#if defined(__HIPCC__)
+    // the coder's pass, split by model (CODER_*): the flags on depth 3's wave, the chroma coefficients on depth 2's, the luma
+    // coefficients here
+    LANE0 mb_store(&S->creq, 1);
+    { CTU_T0();
+    coder_pass(S, J, CODER_LUMA);
+    CTU_T1(J.W, 14); }        // (profile slot 14 of the walk's wave: its own part; slot 8: with the wait for the other two)
+    while (mb_load(&S->cdone[0]) == 0 || mb_load(&S->cdone[1]) == 0) __builtin_amdgcn_s_sleep(1);
+    CTU_SYNC();
+#else
+    coder_pass(S, J, CODER_LUMA);
+    LANE0 S->vsel[CTU_WAVE] = 0;
+    { const int me = g_emul_wave; g_emul_wave = 1; coder_pass(S, J, CODER_FLAGS); g_emul_wave = 2; coder_pass(S, J, CODER_CHROMA); g_emul_wave = me; }
+#endif
     CTU_T1(J.W, 8); }
 #if defined(__HIPCC__)
     LANE0 { for (int L = 1; L <= 3; ++L) mb_store(&S->req[L], -1); }

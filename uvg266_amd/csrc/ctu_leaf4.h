@@ -299,7 +299,9 @@ CTU_DEV void lf_luma_mode_bits(uint32_t *m_, const int (&p)[6], int mode, double
 // owners' registers in scan order, and the entropy-table lookups are taken out of the adaptation chain (a model's state after a bin
 // does not depend on the bin's cost): the sixteen steps of the sweep are pure register arithmetic, the sixteen lookups go out together.
 // Same bins, same adaptation, same sum as uvg_encode_coeff_nxn in count mode (encode_coding_tree-generic.c:53-323).
-template <typename PX> CTU_DEV double coeff_bits4r(lds<PX> *S, CTU_LDS uint32_t *m, int update, int lev, int color)
+// BITS = false: the models' adaptation only (the coder's pass: nobody reads the count) -- no entropy-table lookups, no Rice
+// parameters, no bypass bits, no sums.
+template <typename PX, bool BITS = true> CTU_DEV double coeff_bits4r(lds<PX> *S, CTU_LDS uint32_t *m, int update, int lev, int color)
 {
   const int lane = CTU_TID, r = lane & 15, px = r & 3, py = r >> 2, t = color ? 1 : 0;
   const int a = iabs_(lev);
@@ -325,7 +327,7 @@ template <typename PX> CTU_DEV double coeff_bits4r(lds<PX> *S, CTU_LDS uint32_t 
   CTU_LDS const uint8_t *const rate = LDSP(const uint8_t, kRate);
   const int rw = rate[model], prw = rate[pmodel];
   // ---- per position: contexts, Rice parameters, whether its sig flag is coded, the regular bins it spends ----
-  int ctx_sig, ofs = 0, r4, r0;
+  int ctx_sig, ofs = 0, r4 = 0, r0 = 0;
   {
     const int a1 = lf_nb<1>(a), a2 = lf_nb<2>(a), a5 = lf_nb<5>(a), a4 = lf_nb<4>(a), a8 = lf_nb<8>(a);
     int num_pos = 0, sum_abs = 0, sum = 0;
@@ -338,9 +340,11 @@ template <typename PX> CTU_DEV double coeff_bits4r(lds<PX> *S, CTU_LDS uint32_t 
     if (color == 0) ctx_sig += diag < 5 ? 4 : 0;
     if (t && ctx_sig > 7) ctx_sig = 7;
     if (sp != last) ofs = ((tsum < 4 ? tsum : 4) + 1) + (!diag ? (color == 0 ? 15 : 5) : color == 0 ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0);
-    int v4 = sum - 20, v0 = sum;
-    v4 = v4 < 31 ? v4 : 31; v0 = v0 < 31 ? v0 : 31;
-    r4 = go_rice_par((unsigned)(v4 > 0 ? v4 : 0)); r0 = go_rice_par((unsigned)(v0 > 0 ? v0 : 0));
+    if (BITS) {
+      int v4 = sum - 20, v0 = sum;
+      v4 = v4 < 31 ? v4 : 31; v0 = v0 < 31 ? v0 : 31;
+      r4 = go_rice_par((unsigned)(v4 > 0 ? v4 : 0)); r0 = go_rice_par((unsigned)(v0 > 0 ? v0 : 0));
+    }
   }
   const bool live = sp <= last;
   const int sig_coded = live && sp != last;
@@ -375,7 +379,7 @@ template <typename PX> CTU_DEV double coeff_bits4r(lds<PX> *S, CTU_LDS uint32_t 
     const bool hit = ((gates >> rsel) & 1u) && ((rj >> fsh) & fmask) == (uint32_t)k;
     const uint32_t bin = (bins >> rsel) & 1u;
     uint32_t s0 = st & 0xffffu, s1 = st >> 16;
-    idx[j] = (((s0 + s1) >> 8) << 1) ^ bin;
+    if (BITS) idx[j] = (((s0 + s1) >> 8) << 1) ^ bin;
     s0 -= (s0 >> r0w) & 0x7fe0u;
     s1 -= (s1 >> r1w) & 0x7ffeu;
     s0 += bin ? add0 : 0u;
@@ -399,6 +403,7 @@ template <typename PX> CTU_DEV double coeff_bits4r(lds<PX> *S, CTU_LDS uint32_t 
     if (pbin) { s0 += (0x7fffu >> p0w) & 0x7fe0u; s1 += (0x7fffu >> p1w) & 0x7ffeu; }
     if (phit && update) m[pmodel] = (s0 & 0xffffu) | (s1 << 16);
   }
+  if (!BITS) { WSYNC(); return 0.0; }
   // ---- the bins' costs, all lookups in flight together ----
   CTU_LDS const uint32_t *const ebits = LDSP(const uint32_t, tab_ebits());
   uint32_t acc = 0;
