@@ -100,6 +100,9 @@ __device__ __forceinline__ void cwrite(coder &c)                          // uvg
 }
 __device__ __forceinline__ void enc_bin(coder &c, row_state *R, int idx, int bin)      // uvg_cabac_encode_bin + CTX_UPDATE
 {
+#if defined(SLC_EXP_NO_BINS)
+  c.low += idx + bin; return;      // (timing experiment)
+#endif
   const uint32_t st = R->models[idx];
   uint32_t s0 = st & 0xffffu, s1 = st >> 16;
   const uint32_t state = (s0 + s1) >> 8;
@@ -213,6 +216,9 @@ __device__ inline void code_mvd(coder &c, row_state *R, int mvd_hor, int mvd_ver
 // uvg_encode_coeff_nxn on the levels staged in R->lv (n x n, raster); lane 0
 __device__ __forceinline__ void code_coeffs(coder &c, row_state *R, int n, int color)
 {
+#if defined(SLC_EXP_NO_COEFF)
+  return;      // (timing experiment: tools/dev/coder_time.py)
+#endif
   const int l2 = ilog2_dev(n), nn = n * n, cgw = n >> 2, t = color ? 1 : 0;
   const uint16_t *scan = R->scan + scan_base(l2);
   const int16_t *lv = R->lv;
