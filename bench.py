@@ -451,8 +451,8 @@ def alf_stage_timing(group, reps=2):
 def c2_clip(wl, device, frames=60, reps=2):
     """What BASELINE configs[1] itself would see: its 60-picture clip from HOST memory to the `.266` bytes of its pictures in HOST memory,
     wall clock -- upload of the source planes (pageable host memory, the default stream), one uvghip_loop_plan_run over the 60 pictures
-    (search -> filters -> slice data), then per picture the checksum of the output picture, the download of its rows and the NAL
-    assembly (uvghip_loop_plan_picture_nals: slice NAL + hash SEI).  60 pictures put ~660 CTUs in flight, below the device's 1024
+    (search -> filters -> slice data), then uvghip_loop_plan_group_nals: the checksums of the output pictures, ONE download of the group's rows
+    and the NAL assembly (slice NAL + hash SEI per picture).  60 pictures put ~660 CTUs in flight, below the device's 1024
     workgroup slots, and nothing overlaps the fill and drain of the single launch: this is the latency of ONE clip, the judged `value`
     is the throughput of many.  The plan and its buffers exist before the clock starts (an encoder keeps them).  Not part of `value`."""
     W, H, depth = wl["W"], wl["H"], wl["depth"]
@@ -468,14 +468,14 @@ def c2_clip(wl, device, frames=60, reps=2):
             for p, d in zip(yuv, dst):
                 d.copy_(torch.from_numpy(p), non_blocking=True)
         cs.run()
-        out = [cs.picture_nals(i, i) for i in range(frames)]
+        out = cs.group_nals(0)
         dt = time.perf_counter() - t0
         nbytes = sum(len(b) for b in out)
         best = dt if best is None or dt < best else best
     return {"value": round(frames / best, 2), "unit": "frames/s (one 60-picture clip, host memory to .266 bytes in host memory)", "frames": frames,
             "wall_ms": round(1e3 * best, 1), "bytes_out": int(nbytes), "upload_mb": round(frames * W * H * 1.5 * (1 if depth == 8 else 2) / 1e6, 1),
             "note": "one launch of 60 pictures: the wavefronts' fill and drain are not hidden by a second launch, 660 of 1024 workgroup slots busy at best; "
-                    "the NAL units are written per picture (checksum kernel, row download, host assembly)"}
+                    "the NAL units of the group come over in one download (uvghip_loop_plan_group_nals)"}
 
 
 def c4_clip(device, frames=60, with_cpu=True):
@@ -506,7 +506,7 @@ def c4_clip(device, frames=60, with_cpu=True):
             out = []
             for g, (cs, st) in enumerate(zip(loops, streams)):
                 with torch.cuda.stream(st):
-                    out += [cs.picture_nals(i, g * per + i) for i in range(per)]
+                    out += cs.group_nals(g * per)
             dt = time.perf_counter() - t0
             nbytes = sum(len(b) for b in out)
             best = dt if best is None or dt < best else best

@@ -1148,6 +1148,12 @@ UVGHIP_API int uvghip_write_idr_nals_alf(int poc, int qp_delta, int sao, const u
  * stream, into HOST memory -- uvghip_picture_checksum on its output picture, its rows brought to the host, uvghip_write_picture_nals.
  * Waits for the stream.  *len = bytes needed; an error if that exceeds cap. */
 UVGHIP_API int uvghip_loop_plan_picture_nals(uvghip_loop_plan_t *plan, int picture, int poc, uint8_t *out, size_t cap, size_t *len, void *stream);
+/* ... of ALL pictures of the group, as pictures first_poc, first_poc + 1, ... : what n calls of uvghip_loop_plan_picture_nals write, one
+ * after the other into `out` (lens[i] = bytes of picture i; HOST memory, n entries).  The checksums of all pictures first, their sums
+ * and row lengths in one copy, the rows gathered on the device and brought over in one copy: two waits for the stream instead of 2 n.
+ * (The encoder's bitstream writer appends a frame's NAL units when the frame is done, src/encoder_state-bitstream.c:1513-1607; with a group
+ * of frames in one launch they are all done together.) */
+UVGHIP_API int uvghip_loop_plan_group_nals(uvghip_loop_plan_t *plan, int first_poc, uint8_t *out, size_t cap, size_t *lens, void *stream);
 
 /* ------------------- (8) P / B pictures: candidate lists of the inter search ---------------------------------------------- */
 

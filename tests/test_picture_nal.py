@@ -155,6 +155,11 @@ def test_device_outputs_complete_a_multi_picture_stream(hip, name):
     stream = g["bitstream"].tobytes()
     at = stream.find(b"\x00\x00\x01\x00\x41")
     assert stream[:at] + mine == stream
+    # ... and the whole group in one call (uvghip_loop_plan_group_nals: one download), twice (the buffers it grew are reused)
+    for _ in range(2):
+        grp = cl.group_nals(0)
+        assert len(grp) == len(pics) and b"".join(grp) == mine
+    assert cl.group_nals(3) == [cl.picture_nals(i, 3 + i) for i in range(len(pics))]          # (other picture numbers)
 
 
 @pytest.mark.parametrize("name", ["ref_inter_136x72_10_qp22_4frames", "ref_inter_192x128_8_qp17_5frames", "ref_inter_264x136_8_qp32_9frames",

@@ -733,6 +733,22 @@ class ClosedLoop(CtuSearch):
                    "uvghip_loop_plan_picture_nals")
         return buf[:n.value].tobytes()
 
+    def group_nals(self, first_poc=0):
+        """uvghip_loop_plan_group_nals: after run(), the NAL units of every picture of the group as pictures first_poc, first_poc + 1, ...
+        -> list of bytes (what picture_nals(i, first_poc + i) returns for each i), with one download for the whole group."""
+        import ctypes
+        per = self.hc * (3 * 64 * int(self.P.pic_w)) * (1 if self.depth == 8 else 2) + 64 + 4 * self.hc
+        if getattr(self, "_nal_buf", None) is None or self._nal_buf.size < per * self.n:
+            self._nal_buf = np.empty(per * self.n, np.uint8)
+        lens = (ctypes.c_size_t * self.n)()
+        _lib.check(self.L.uvghip_loop_plan_group_nals(self.loop, first_poc, self._nal_buf.ctypes.data_as(ctypes.c_void_p), self._nal_buf.size, lens, _stream()),
+                   "uvghip_loop_plan_group_nals")
+        out, at = [], 0
+        for i in range(self.n):
+            out.append(self._nal_buf[at:at + lens[i]].tobytes())
+            at += lens[i]
+        return out
+
     def slice_data(self):
         """The rows' substreams the plan coded as the last thing of run(): (rows [n, n_rows, row_cap] uint8, row_bytes [n, n_rows] int32)
         as device views of the plan's buffers."""

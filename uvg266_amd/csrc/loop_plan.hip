@@ -31,6 +31,10 @@ struct uvghip_loop_plan {
   uvghip_ctu_params_t ctu_params;
   int fused;                              // the filters are ONE launch behind the search (uvghip_filter_pictures); `snap` holds the deblocked pictures
   void *filt_ws;
+  // uvghip_loop_plan_group_nals: the rows of the whole group gathered on the device and brought over in one copy (grown on demand)
+  uint8_t *pack_dev = nullptr, *pack_host = nullptr;
+  size_t pack_cap = 0;
+  unsigned long long *pack_base = nullptr;    // device: [n + 1] byte offsets of the pictures in the packed buffer, then [n] row pitches
 };
 
 namespace {
@@ -266,6 +270,93 @@ extern "C" int uvghip_loop_plan_picture_nals(uvghip_loop_plan_t *pl, int picture
   return uvghip_write_picture_nals(poc, 1, rows.data(), pitch, nb.data(), pl->hc, sums, out, cap, len);
 }
 
+// The NAL units of ALL pictures of the group after a run, as pictures first_poc, first_poc + 1, ... : what n calls of
+// uvghip_loop_plan_picture_nals write, one after the other into `out`, with two waits for the stream instead of 2 n and one download of the
+// rows instead of n * rows: the checksums of all pictures, then their sums and row lengths in one copy; the rows gathered on the device
+// (picture p at a 16-byte-aligned base, its rows at the picture's own pitch) into one buffer that comes over in one copy to pinned memory.
+namespace {
+__global__ void nal_layout_kernel(const int32_t *__restrict__ row_bytes, int n, int hc, unsigned long long *__restrict__ base)
+{
+  if (threadIdx.x || blockIdx.x) return;
+  unsigned long long at = 0;
+  unsigned long long *pitch = base + n + 1;
+  for (int p = 0; p < n; ++p) {
+    int m = 1;
+    for (int r = 0; r < hc; ++r) { const int b = row_bytes[(size_t)p * hc + r]; m = b > m ? b : m; }
+    const unsigned long long pt = ((unsigned long long)m + 15) & ~15ull;
+    base[p] = at; pitch[p] = pt;
+    at += pt * hc;
+  }
+  base[n] = at;
+}
+__global__ void __launch_bounds__(256) nal_gather_kernel(const uint8_t *__restrict__ rows, int row_cap, const int32_t *__restrict__ row_bytes, int n, int hc,
+                                                         const unsigned long long *__restrict__ base, uint8_t *__restrict__ packed)
+{
+  const int p = blockIdx.x / hc, r = blockIdx.x - p * hc;
+  const int nb = row_bytes[blockIdx.x];
+  if (nb <= 0 || nb > row_cap) return;
+  const uint4 *src = reinterpret_cast<const uint4 *>(rows + (size_t)blockIdx.x * row_cap);
+  uint4 *dst = reinterpret_cast<uint4 *>(packed + base[p] + (size_t)r * base[n + 1 + p]);
+  for (int i = threadIdx.x; i < (nb + 15) / 16; i += blockDim.x) dst[i] = src[i];
+}
+}  // namespace
+
+extern "C" int uvghip_loop_plan_group_nals(uvghip_loop_plan_t *pl, int first_poc, uint8_t *out, size_t cap, size_t *lens, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!pl || first_poc < 0 || !lens || (!out && cap)) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (pl->row_cap & 15) return uvghip_set_error(hipErrorInvalidValue, "uvghip_loop_plan_group_nals: the plan's row slots are not 16-byte multiples");
+  hipStream_t st = uvghip_stream(stream);
+  const int n = pl->n, hc = pl->hc;
+  for (int i = 0; i < n; ++i) {
+    const uvghip_loop_picture_t &q = pl->pics[i];
+    if (int rc = uvghip_picture_checksum(pl->bitdepth, q.out_y, q.out_stride, q.out_u, q.out_v, q.out_stride_c, pl->w, pl->h, pl->sums + 3 * (size_t)i, stream)) return rc;
+  }
+  if (!pl->pack_base) UVGHIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->pack_base), (size_t)(2 * n + 1) * sizeof(unsigned long long)));
+  hipLaunchKernelGGL(nal_layout_kernel, dim3(1), dim3(1), 0, st, pl->row_bytes, n, hc, pl->pack_base);
+  std::vector<uint32_t> sums((size_t)3 * n);
+  std::vector<int32_t> nb((size_t)n * hc);
+  UVGHIP_TRY(hipMemcpyAsync(sums.data(), pl->sums, sums.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  UVGHIP_TRY(hipMemcpyAsync(nb.data(), pl->row_bytes, nb.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  UVGHIP_TRY(hipStreamSynchronize(st));
+  // the same layout on the host
+  std::vector<size_t> base((size_t)n + 1), pitch(n);
+  size_t at = 0;
+  for (int p = 0; p < n; ++p) {
+    int m = 1;
+    for (int r = 0; r < hc; ++r) {
+      const int b = nb[(size_t)p * hc + r];
+      if (b <= 0 || b > pl->row_cap) return uvghip_set_error(hipErrorInvalidValue, "uvghip_loop_plan_group_nals: a row overflowed its slot (or the plan has not run)");
+      m = b > m ? b : m;
+    }
+    base[p] = at; pitch[p] = ((size_t)m + 15) & ~(size_t)15;
+    at += pitch[p] * hc;
+  }
+  base[n] = at;
+  if (at > pl->pack_cap) {
+    if (pl->pack_dev) { UVGHIP_TRY(hipFree(pl->pack_dev)); pl->pack_dev = nullptr; }
+    if (pl->pack_host) { UVGHIP_TRY(hipHostFree(pl->pack_host)); pl->pack_host = nullptr; }
+    pl->pack_cap = 0;
+    const size_t want = at + at / 4 + 4096;
+    UVGHIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->pack_dev), want));
+    UVGHIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pl->pack_host), want, hipHostMallocDefault));
+    pl->pack_cap = want;
+  }
+  hipLaunchKernelGGL(nal_gather_kernel, dim3(n * hc), dim3(256), 0, st, pl->rows, pl->row_cap, pl->row_bytes, n, hc, pl->pack_base, pl->pack_dev);
+  UVGHIP_TRY(hipGetLastError());
+  UVGHIP_TRY(hipMemcpyAsync(pl->pack_host, pl->pack_dev, at, hipMemcpyDeviceToHost, st));
+  UVGHIP_TRY(hipStreamSynchronize(st));
+  size_t used = 0;
+  for (int p = 0; p < n; ++p) {
+    size_t len = 0;
+    if (int rc = uvghip_write_picture_nals(first_poc + p, 1, pl->pack_host + base[p], pitch[p], nb.data() + (size_t)p * hc, hc, sums.data() + 3 * (size_t)p,
+                                           out ? out + used : nullptr, cap > used ? cap - used : 0, &len)) return rc;
+    lens[p] = len;
+    used += len;
+  }
+  return 0;
+}
+
 extern "C" int uvghip_loop_plan_results(const uvghip_loop_plan_t *pl, const int32_t **sao_info, const uint16_t **sao_models)
 {
   if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);
@@ -350,5 +441,8 @@ extern "C" void uvghip_loop_plan_destroy(uvghip_loop_plan_t *pl)
 {
   if (!pl) return;
   uvghip_ctu_plan_destroy(pl->search);
+  if (pl->pack_dev) (void)hipFree(pl->pack_dev);
+  if (pl->pack_host) (void)hipHostFree(pl->pack_host);
+  if (pl->pack_base) (void)hipFree(pl->pack_base);
   delete pl;
 }

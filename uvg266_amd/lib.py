@@ -262,6 +262,7 @@ SIGNATURES = {
     "uvghip_loop_plan_slice_data": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_encode_slice_rows": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "uvghip_loop_plan_picture_nals": (c_int, [c_vp, c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_vp]),
+    "uvghip_loop_plan_group_nals": (c_int, [c_vp, c_int, c_vp, ctypes.c_size_t, c_vp, c_vp]),
     "uvghip_loop_plan_alf_workspace_bytes": (ctypes.c_size_t, [c_vp]),
     "uvghip_loop_plan_alf_stage": (c_int, [c_vp, ALF_DECIDE_FN, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "uvghip_picture_checksum": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
