@@ -43,7 +43,9 @@ struct row_state {
   // arithmetic of context_get_sig_ctx_idx_abs / uvg_abs_sum per coefficient: sig context (4 bits, chroma's cap applied) | context
   // offset of the gt1 / parity / gt2 flags << 4 (5 bits) | Rice parameter of a remainder behind the context-coded flags << 9 |
   // Rice parameter of a bypass-coded position << 11
-  uint16_t ci_pos[1024];
+  // ... by SCAN position, with the position's level in the low half: the coding lane reads one word per position, in the order it
+  // visits them (the next one is in flight while the bins of this one are coded), instead of scan -> level, scan -> template
+  uint32_t ci_pos[1024];
 };
 // P / B slices: the CTU's motion for the AMVP predictors (the table uvg_inter_get_mv_cand_cua reads of the picture's cu array), the row's
 // history table, the picture's reference lists
@@ -221,7 +223,6 @@ __device__ __forceinline__ void code_coeffs(coder &c, row_state *R, int n, int c
 #endif
   const int l2 = ilog2_dev(n), nn = n * n, cgw = n >> 2, t = color ? 1 : 0;
   const uint16_t *scan = R->scan + scan_base(l2);
-  const int16_t *lv = R->lv;
   const int last = R->ci_last;                         // (stage() looked at the whole block with all lanes)
   if (last < 0) return;
   const unsigned long long sig_cg = R->ci_cg, sig_r = R->ci_r;      // per group, by scan index / by raster position: has a level
@@ -261,20 +262,22 @@ __device__ __forceinline__ void code_coeffs(coder &c, row_state *R, int n, int c
     const int infer_sig = (first_sig != last) ? ((g != 0) ? min_sub : -1) : first_sig;
     int num_nz = 0, next_sig;
     uint32_t signs = 0;
+    uint32_t ahead = R->ci_pos[first_sig];
     for (next_sig = first_sig; next_sig >= min_sub && reg_bins >= 4; next_sig--) {
-      const int blk = scan[next_sig];
-      const int s = lv[blk] != 0;
-      const int rec = R->ci_pos[blk];                       // (stage(): the position's context template, all lanes)
+      const uint32_t w = ahead;                            // (stage(): the position's level and context template, all lanes)
+      if (next_sig > 0) ahead = R->ci_pos[next_sig - 1];
+      const int level = (int)(int16_t)(w & 0xffffu), rec = (int)(w >> 16);
+      const int s = level != 0;
       if (num_nz || next_sig != infer_sig) {
         enc_bin(c, R, M_SIG + 12 * t + (rec & 15), s);
         reg_bins--;
       }
       if (s) {
         num_nz++;
-        signs = (signs << 1) | (lv[blk] < 0);
+        signs = (signs << 1) | (level < 0);
         // (the block's last position is coded before any template was looked at: offset 0, encode_coding_tree-generic.c:203-215)
         const int ofs = next_sig == last ? 0 : (rec >> 4) & 31;
-        int rem = iabs_((int)lv[blk]) - 1;
+        int rem = iabs_(level) - 1;
         const int gt1 = rem ? 1 : 0;
         enc_bin(c, R, M_GT1 + 21 * t + ofs, gt1);
         reg_bins--;
@@ -289,16 +292,17 @@ __device__ __forceinline__ void code_coeffs(coder &c, row_state *R, int n, int c
       }
     }
     for (int sp = first_sig; sp > next_sig; sp--) {               // Golomb-Rice remainders of the context-coded positions
-      const int blk = scan[sp];
-      const uint32_t a = (uint32_t)iabs_((int)lv[blk]);
-      if (a >= 4) enc_remain(c, (a - 4) >> 1, (uint32_t)((R->ci_pos[blk] >> 9) & 3));
+      const uint32_t w = R->ci_pos[sp];
+      const uint32_t a = (uint32_t)iabs_((int)(int16_t)(w & 0xffffu));
+      if (a >= 4) enc_remain(c, (a - 4) >> 1, (w >> (16 + 9)) & 3);
     }
     for (int sp = next_sig; sp >= min_sub; sp--) {                 // positions coded in bypass once the regular bins are spent
-      const int blk = scan[sp];
-      const uint32_t a = (uint32_t)iabs_((int)lv[blk]);
-      const uint32_t rice = (uint32_t)((R->ci_pos[blk] >> 11) & 3), pos0 = 1u << rice;
+      const uint32_t w = R->ci_pos[sp];
+      const int level = (int)(int16_t)(w & 0xffffu);
+      const uint32_t a = (uint32_t)iabs_(level);
+      const uint32_t rice = (w >> (16 + 11)) & 3, pos0 = 1u << rice;
       enc_remain(c, a == 0 ? pos0 : (a <= pos0 ? a - 1 : a), rice);
-      if (a) { num_nz++; signs = (signs << 1) | (lv[blk] < 0); }
+      if (a) { num_nz++; signs = (signs << 1) | (level < 0); }
     }
     enc_eps(c, signs, num_nz);
   }
@@ -395,7 +399,7 @@ __device__ __forceinline__ void stage(row_state *R, const int16_t *src, int stri
     else if (ctx_sig > 7) ctx_sig = 7;
     const int ofs = ((tsum < 4 ? tsum : 4) + 1) + (!diag ? (color == 0 ? 15 : 5) : color == 0 ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0);
     const int s4 = sum - 20 < 0 ? 0 : (sum - 20 < 31 ? sum - 20 : 31), s0 = sum < 31 ? sum : 31;
-    R->ci_pos[blk] = (uint16_t)(ctx_sig | ofs << 4 | go_rice_par((unsigned)s4) << 9 | go_rice_par((unsigned)s0) << 11);
+    R->ci_pos[sp] = (uint32_t)(uint16_t)R->lv[blk] | (uint32_t)(ctx_sig | ofs << 4 | go_rice_par((unsigned)s4) << 9 | go_rice_par((unsigned)s0) << 11) << 16;
   }
   __syncthreads();
 }
