@@ -283,6 +283,7 @@ struct pb_state {
   int32_t out4[4];
   int32_t ref_idx2[2];
   int32_t i0, i1, i2, i3;              // small hand-overs from lane 0 to the wave
+  int32_t early_tag;                   // 1 + the merge index whose luma levels the early-skip test left in the CU's coefficient target (0: none)
   double d0, d1;
 };
 #endif
@@ -2072,7 +2073,7 @@ template <typename PX> CTU_DEV int scaled_qp(const params &P, int color) { retur
 // predict + uvg_quantize_residual (quant-generic.c:460-612, RDOQ branch) of one transform block straight into D; its levels stay in
 // lv_of(V, color) and go to the CTU's coefficient array.  (x, y) / (lx, ly): luma position, n: luma size of the area.  -> has_coeffs
 // CTU_PB, flags: 1 the prediction is already in dst (a block of an inter CU), 2 no reconstruction (the early-skip test only wants
-// has_coeffs), 4 RDOQ prices "no luma coefficients" with the root cbf
+// has_coeffs), 4 RDOQ prices "no luma coefficients" with the root cbf, 8 the levels are in co already (reconstruction only)
 template <typename PX> CTU_NOINLINE CTU_DEV void rdoq_wave_ool(lds<PX> *S, scratch *W, const int16_t *coef_, int16_t *dst_, int n, int color, int cbf_u, int qp_scaled,
                                                            double lambda, int bitdepth)
 {
@@ -2102,13 +2103,27 @@ template <typename PX, bool OOL = false> CTU_INLINE1 CTU_DEV int recon_tu_inl(ld
   build_refs(S, J.P, color, x, y, lx, ly, n, cu_n);
   predict_block(S, mode, color, w, dst_, dp);
   CTU_T1(J.W, 1); }
+  const int qps = scaled_qp<PX>(J.P, color);
+#if defined(CTU_PB)
+  if (flags & 8) {
+    // the block's levels are in co already: an earlier call quantised this very residual (same prediction, same parameters -- the
+    // early-skip test of the merge candidate that became the CU, ctu_pb.h finish_inter); only the reconstruction is left to do
+    int nz = 0;
+    PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); const int16_t v = co[r * cp + q]; lv[e] = v; nz |= v != 0; }
+#if defined(__HIPCC__)
+    nz = __ballot(nz) != 0;
+#endif
+    LANE0 V->rq_i[1] = nz;
+    CTU_SYNC();
+  } else
+#endif
+  {
   { CTU_T0();
   PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); t0[e] = (int16_t)((int)Sp[r * sps + q] - (int)dst[r * dp + q]); }
   CTU_SYNC();
   fwd_pass(w, V->t0, V->t1, l2 - 1 + depth - 8);
   fwd_pass(w, V->t1, V->t0, l2 + 6);                     // (two buffers: the coefficients end up where the residual was)
   CTU_T1(J.W, 2); }
-  const int qps = scaled_qp<PX>(J.P, color);
   CTU_T0();
   {
     // chroma blocks: state->c_lambda as uvg_quantize_lcu_residual replaces it (transform.c:1575)
@@ -2118,6 +2133,7 @@ template <typename PX, bool OOL = false> CTU_INLINE1 CTU_DEV int recon_tu_inl(ld
   }
   CTU_SYNC();
   CTU_T1(J.W, 3);
+  }
   const int has = V->rq_i[1];
   PAR_FOR(e, w * w) { const int r = e >> l2, q = e & (w - 1); co[r * cp + q] = lv[e]; }
 #if defined(CTU_PB)

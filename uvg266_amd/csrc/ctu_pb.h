@@ -595,9 +595,10 @@ CTU_DEV bool same_merge(const icand::merge_cand &a, const icand::merge_cand &b)
 }
 
 // the residual of the CU's transform units against the prediction in T: uvg_quantize_lcu_residual (transform.c:1487-1603) for an inter
-// CU; -> the flags of up to four units (cbf4) and their union.  early: only the flags are wanted (no reconstruction).
+// CU; -> the flags of up to four units (cbf4) and their union.  early: only the flags are wanted (no reconstruction).  luma_done: the
+// luma levels of every unit are in T.ky already (the early-skip test of this very candidate quantised them): reconstruction only.
 template <typename PX> CTU_NOINLINE CTU_DEV int quantize_inter(lds<PX> *S, const job<PX> &J, int x, int y, int n, const cu_target<PX> &T, int luma, int chroma, int early,
-                                                              int32_t *cbf4)
+                                                              int32_t *cbf4, int luma_done = 0)
 {
   const int q = n > 32 ? 32 : n, nq = n / q;
   int any = 0;
@@ -607,7 +608,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int quantize_inter(lds<PX> *S, const
     int cbf = cbf4[i];
     if (luma) {
       cbf &= ~1;
-      cbf |= recon_tu(S, J, 0, tx, ty, tx & 63, ty & 63, q, 0, 0, T.ry + oy * T.rpy + ox, T.rpy, T.ky + oy * T.kpy + ox, T.kpy, q, fl);
+      cbf |= recon_tu(S, J, 0, tx, ty, tx & 63, ty & 63, q, 0, 0, T.ry + oy * T.rpy + ox, T.rpy, T.ky + oy * T.kpy + ox, T.kpy, q, fl | (luma_done ? 8 : 0));
     }
     if (chroma) {
       cbf &= ~6;
@@ -733,6 +734,7 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
   { PB_T0();
   if (B.tmvp && B.n_refs) prefetch_col(S, J, x, y, n);
   SERIAL {
+    Q.early_tag = 0;
     memset(&Q.cur, 0, sizeof Q.cur);                     // cur_pu: the CU's entry after search_cu's memset (type NOTSET)
     set_cand_ctx(S, x, y, n, N.split_tree);
     pb_tab tab = {S->pb.mot};
@@ -793,7 +795,11 @@ template <typename PX> CTU_NOINLINE CTU_DEV int search_pu_inter(lds<PX> *S, cons
         CTU_SYNC();
       } else pred_cu(S, J, x, y, n, &Q.cur.m, 1, 0, T.ry, T.rpy, T.ru, T.rv, T.rpc);
       int32_t cbf4[4] = {0, 0, 0, 0};
-      if (quantize_inter(S, J, x, y, n, T, 1, 0, 1, cbf4)) continue;
+      const int luma_any = quantize_inter(S, J, x, y, n, T, 1, 0, 1, cbf4);
+      // (the candidate's luma levels stay in T.ky: if it becomes the CU, finish_inter need not quantise the same residual again)
+      SERIAL Q.early_tag = merge_idx + 1;
+      CTU_SYNC();
+      if (luma_any) continue;
       pred_cu(S, J, x, y, n, &Q.cur.m, 0, 1, T.ry, T.rpy, T.ru, T.rv, T.rpc);
       if (quantize_inter(S, J, x, y, n, T, 0, 1, 1, cbf4)) continue;
       SERIAL {
@@ -1150,7 +1156,9 @@ template <typename PX> CTU_NOINLINE CTU_DEV void finish_inter(lds<PX> *S, const 
     }
     CTU_SYNC();
     pred_cu(S, J, x, y, n, &Q.cur.m, 1, 1, T.ry, T.rpy, T.ru, T.rv, T.rpc);
-    const int any = quantize_inter(S, J, x, y, n, T, 1, 1, 0, cbf4);
+    // the CU is the merge candidate the early-skip test quantised: same prediction, same residual, same RDOQ -- its luma levels are there
+    const int luma_done = Q.cur.merged && Q.early_tag == (int)Q.cur.merge_idx + 1;
+    const int any = quantize_inter(S, J, x, y, n, T, 1, 1, 0, cbf4, luma_done);
     if (n > 32) root_cbf = (any & 7) != 0;
     const int cbf = (cbf4[0] & 7) != 0 || root_cbf;
     SERIAL { if (Q.cur.merged && !cbf) { Q.cur.merged = 0; Q.cur.skipped = 1; } }
