@@ -32,7 +32,11 @@
 
 #if defined(__HIPCC__) && defined(CTU_PROFILE)
 #define PB_T0() const unsigned long long pb_t0__ = __builtin_amdgcn_s_memtime()
+#if defined(CTU_PROFILE_WALK)      // only the walk's wave counts the phases of eval_pb (slots < 14): they add up to its time
+#define PB_T1(W, slot) do { if (CTU_TID == 0 && ((slot) >= 14 || CTU_WAVE == 0)) (W)->prof_pb[slot] += __builtin_amdgcn_s_memtime() - pb_t0__; } while (0)
+#else
 #define PB_T1(W, slot) do { if (CTU_TID == 0) (W)->prof_pb[slot] += __builtin_amdgcn_s_memtime() - pb_t0__; } while (0)
+#endif
 #else
 #define PB_T0() ((void)0)
 #define PB_T1(W, slot) ((void)0)
