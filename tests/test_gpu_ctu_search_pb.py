@@ -90,6 +90,24 @@ def test_pb_ctu_search_equals_the_encoders_records(hip, name):
         assert H.compare_device_inter_picture(W, Hh, d, result_of(W, Hh, t)) == [], f"frame {fr}"
 
 
+@pytest.mark.parametrize("waves", [2, 3, 4])
+def test_every_wave_count_of_the_kernel_gives_the_same_pictures(hip, waves, monkeypatch):
+    """The kernel is one source built for one to four waves per CTU (a wave count asks for the LDS image up to its own fields:
+    pb_lds_bytes); a plain uvghip_ctu_search_pb launch runs the one-wave build, pictures in flight the four-wave one.  Every build, on
+    the goldens with the most varied tools, through the development override the library reads at launch."""
+    import torch
+    from uvg266_amd import api
+    monkeypatch.setenv("UVGHIP_PB_WAVES", str(waves))
+    for name in GOLDENS[:1] + [n for n in GOLDENS if "owf1" in n or "rd1" in n or "ra16" in n][:3]:
+        g = np.load(os.path.join(H.GOLDEN, name + ".npz"))
+        W, Hh, depth, pics, P = H.inter_pictures_from_golden(g)
+        descs, tens, recs = device_pictures(W, Hh, depth, pics, P)
+        ws = api.ctu_search_pb(descs, depth)
+        torch.cuda.synchronize()
+        for t, (fr, d) in zip(tens, recs):
+            assert H.compare_device_inter_picture(W, Hh, d, result_of(W, Hh, t)) == [], (name, f"frame {fr}")
+
+
 @pytest.mark.parametrize("name", GOLDENS)
 def test_device_search_then_device_coder_gives_the_encoders_slice_data(hip, name):
     """Both halves on the device, nothing of the encoder's in between: uvghip_ctu_search_pb's hand-over (side information, second table,

@@ -335,6 +335,8 @@ template <typename PX> struct lds {
   // the leaf wave of the two-wave build (ctu_pb.h post_leaves): on / off, the costs of the four 4x4 CUs of the area it was handed
   int32_t leaf_wave;
   double leaf_cost[4];
+  double leaf_limit;                   // the leaf wave stops when the costs of its 4x4 CUs exceed it (the walk lowers it when the 8x8 CU's cost is in);
+                                       // (in front of pbx: the two-wave launch asks for the image up to there, pb_lds_bytes)
   // the three-wave build (ctu_pb.h): the wave that evaluates the 32x32 / 16x16 CUs ahead of the walk has its own search state (of `pb`
   // it reads the shared tables only: mot, fl, hmvp_entry) and the 8x8 depth its own scratch; the one- and two-wave launches ask for
   // the image up to here (pb_lds_bytes)
@@ -346,7 +348,6 @@ template <typename PX> struct lds {
   alignas(16) int16_t b8_tmp[6 * 2 * 120];
   PX b8_pred[6 * 64];
   int32_t b8_satd[8];
-  double leaf_limit;                   // the leaf wave stops when the costs of its 4x4 CUs exceed it (the walk lowers it when the 8x8 CU's cost is in)
   // the four-wave build: 32x32 CUs on a wave of their own (search state and, for the 16x16 depth, scratch)
   pb_state pbx2;
   alignas(16) unsigned char arena16[arena_bytes(16)];
