@@ -28,10 +28,35 @@ enum { NM_ALF = 18, MA = NMODELS + 2 + NM_INTER };
 // one picture's ALF decisions as the coder needs them (uvghip_slice_alf_t with device pointers)
 struct alf_dev { int32_t alf_type, enabled[3], n_luma_aps, cc_enabled[2], cc_count[2], n_alts; const uint8_t *flags; const int16_t *set_idx; };
 
+// H.266 6.5.2: the up-right diagonal scans of the four square shapes (4x4 groups in diagonal order, the 16 positions of a group
+// likewise), at scan_base(log2 size): the same for every row of every picture -- a table of the code object, not 2.7 KB of every
+// workgroup's LDS (with them a row's image was 12.7 KB: three rows to the 40 KB a search workgroup leaves behind, now four)
+struct scan_table { uint16_t v[1360]; };
+constexpr scan_table make_scan_table()
+{
+  scan_table t = {};
+  int in[16] = {};
+  int q = 0;
+  for (int d = 0; d < 7; ++d) for (int x = 0; x <= d; ++x) { const int y = d - x; if (x < 4 && y < 4) in[q++] = y * 4 + x; }
+  for (int l2 = 2; l2 <= 5; ++l2) {
+    const int n = 1 << l2, cgw = n >> 2;
+    const int base = l2 == 5 ? 0 : l2 == 4 ? 1024 : l2 == 3 ? 1280 : 1344;          // ctu::scan_base
+    int g = 0;
+    for (int d = 0; d < 2 * cgw - 1; ++d)
+      for (int x = 0; x <= d; ++x) {
+        const int y = d - x;
+        if (x >= cgw || y >= cgw) continue;
+        for (int k = 0; k < 16; ++k) t.v[base + g * 16 + k] = (uint16_t)((y * 4 + (in[k] >> 2)) * n + x * 4 + (in[k] & 3));
+        ++g;
+      }
+  }
+  return t;
+}
+__device__ const scan_table k_scan = make_scan_table();
+
 struct row_state {
   uint32_t models[NMODELS + 2 + NM_INTER + NM_ALF];   // state0 | state1 << 16; [NMODELS] sao_merge_flag, [NMODELS + 1] sao_type_idx, the inter syntax, the ALF syntax
   uint8_t rate[NMODELS + 2 + NM_INTER + NM_ALF];
-  uint16_t scan[1360];                 // diagonal scans of 32, 16, 8, 4 (scan_base)
   int16_t lv[1024];                    // the levels of the transform block being coded, raster
   struct cui { uint8_t type, log2w, cbf, mode, mode_c, skipped, pad[2]; } cu[17 * 17];      // the CTU's side information + the row / column before it
   // what stage() finds out about the staged block with all lanes, so that the coding lane does not walk 1024 positions for it: the last
@@ -222,7 +247,7 @@ __device__ __forceinline__ void code_coeffs(coder &c, row_state *R, int n, int c
   return;      // (timing experiment: tools/dev/coder_time.py)
 #endif
   const int l2 = ilog2_dev(n), nn = n * n, cgw = n >> 2, t = color ? 1 : 0;
-  const uint16_t *scan = R->scan + scan_base(l2);
+  const uint16_t *scan = k_scan.v + scan_base(l2);
   const int last = R->ci_last;                         // (stage() looked at the whole block with all lanes)
   if (last < 0) return;
   const unsigned long long sig_cg = R->ci_cg, sig_r = R->ci_r;      // per group, by scan index / by raster position: has a level
@@ -353,7 +378,7 @@ __device__ __forceinline__ void stage(row_state *R, const int16_t *src, int stri
   for (int e = threadIdx.x; e < nn; e += blockDim.x) R->lv[e] = src[(e >> l2) * stride + (e & (n - 1))];
   __syncthreads();
   // (one wave per row: blockDim.x == 64)
-  const uint16_t *scan = R->scan + scan_base(l2);
+  const uint16_t *scan = k_scan.v + scan_base(l2);
   int last = -1;
   for (int sp = threadIdx.x; sp < nn; sp += 64) if (R->lv[scan[sp]]) last = sp;
   for (int o = 32; o >= 1; o >>= 1) { const int v = __shfl_xor(last, o, 64); last = v > last ? v : last; }
@@ -593,24 +618,6 @@ slice_rows_kernel(const pic_dev *__restrict__ pics, const pb_dev *__restrict__ p
     } else {
       const uint16_t *m = sao_models + ((size_t)pic * wc * hc + (size_t)(cy - 1) * wc) * 6 + 3 * i;
       R->models[NMODELS + i] = (uint32_t)m[0] | ((uint32_t)m[1] << 16);
-    }
-  }
-  if (lane0) {
-    // H.266 6.5.2: up-right diagonal scan of 4x4 groups, groups in diagonal order
-    int16_t *in = R->lv;                         // (free until the first block is staged)
-    int q = 0;
-    for (int d = 0; d < 7; ++d) for (int x = 0; x <= d; ++x) { const int y = d - x; if (x < 4 && y < 4) in[q++] = (int16_t)(y * 4 + x); }
-    for (int l2 = 2; l2 <= 5; ++l2) {
-      const int n = 1 << l2, cgw = n >> 2;
-      uint16_t *sc = R->scan + scan_base(l2);
-      int g = 0;
-      for (int d = 0; d < 2 * cgw - 1; ++d)
-        for (int x = 0; x <= d; ++x) {
-          const int y = d - x;
-          if (x >= cgw || y >= cgw) continue;
-          for (int k = 0; k < 16; ++k) sc[g * 16 + k] = (uint16_t)((y * 4 + (in[k] >> 2)) * n + x * 4 + (in[k] & 3));
-          ++g;
-        }
     }
   }
   __syncthreads();
