@@ -1366,6 +1366,18 @@ UVGHIP_API int uvghip_loop_plan_search_launch(uvghip_loop_plan_t *plan, void *st
 UVGHIP_API int uvghip_loop_plan_set_search_grid(uvghip_loop_plan_t *plan, int max_workgroups);
 UVGHIP_API const int32_t *uvghip_loop_plan_searched_flags(const uvghip_loop_plan_t *plan);
 UVGHIP_API int uvghip_loop_plan_run_coder(uvghip_loop_plan_t *plan, void *stream);
+/* ... and BESIDE the in-flight launch instead of behind it: the rows of the plan's pictures wait, CTU by CTU, for the flags that launch
+ * raises when a CTU's filters are done (final_flags: [picture][ctu] of the plan's pictures inside uvghip_loop_pb_inflight_final_flags of
+ * the call, i.e. + first_picture * ctus), so the I pictures' slice data is written while the P / B pictures are still searched.  Enqueue
+ * it behind uvghip_loop_plan_search_launch on the same stream (the search's outputs must be complete), and zero the flags of these
+ * pictures in that stream before the search launch (the in-flight call zeroes all of them again in its own stream before its kernel).
+ * uvghip_encode_slice_rows_behind is the same for a caller's own buffers (I slices, SAO on). */
+UVGHIP_API int uvghip_loop_plan_run_coder_behind(uvghip_loop_plan_t *plan, const int32_t *final_flags, void *stream);
+UVGHIP_API int uvghip_encode_slice_rows_behind(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, int n_pictures,
+                                               const int32_t *sao_info, const uint16_t *sao_models, const int32_t *final_flags, void *workspace, uint8_t *out,
+                                               int row_cap, int32_t *row_bytes, void *stream);
+UVGHIP_API const int32_t *uvghip_loop_pb_inflight_final_flags(int bitdepth, int n_pictures, int pic_w, int pic_h, const void *workspace);
+UVGHIP_API const int32_t *uvghip_ctu_search_pb_inflight_final_flags(int n_pictures, int pic_w, int pic_h, const void *workspace);
 UVGHIP_API int uvghip_ctu_plan_reset(uvghip_ctu_plan_t *plan, void *stream);
 UVGHIP_API int uvghip_ctu_plan_launch(uvghip_ctu_plan_t *plan, void *stream);
 UVGHIP_API int uvghip_ctu_plan_set_grid(uvghip_ctu_plan_t *plan, int max_workgroups);

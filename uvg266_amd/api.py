@@ -1305,6 +1305,13 @@ class LowDelayLoop:
         start = torch.cuda.Event()
         start.record(caller)
         A.wait_event(start); B.wait_event(start)
+        n = len(ent)
+        ctus = ((self.W + 63) // 64) * ((self.H + 63) // 64)
+        self.L.uvghip_loop_pb_inflight_final_flags.restype = ctypes.c_void_p
+        final = self.L.uvghip_loop_pb_inflight_final_flags(self.depth, n, self.W, self.H, _dev(ws))
+        off = final - ws.data_ptr()
+        with torch.cuda.stream(A):           # the I pictures' "final" flags: zero before their coder (behind the search, on A) can look at them
+            ws[off:off + n_ext * ctus * 4].zero_()
         for fl, loop, gm in groups:          # flags back to zero before the flight's kernel can look at them
             _lib.check(self.L.uvghip_loop_plan_search_reset(loop.loop, A.cuda_stream), "uvghip_loop_plan_search_reset")
         cleared = torch.cuda.Event()
@@ -1312,17 +1319,20 @@ class LowDelayLoop:
         B.wait_event(cleared)
         for fl, loop, gm in groups:
             _lib.check(self.L.uvghip_loop_plan_search_launch(loop.loop, A.cuda_stream), "uvghip_loop_plan_search_launch")
-        n = len(ent)
         _lib.check(self.L.uvghip_loop_pb_run_inflight_ext(self.depth, ctypes.byref(arr), n, self.sao_type, ric.ctypes.data, ctypes.byref(ext), grid_sum, _dev(ws), B.cuda_stream),
                    "uvghip_loop_pb_run_inflight_ext")
-        searched = torch.cuda.Event()
-        searched.record(A)
-        B.wait_event(searched)          # (the coder reads the search's levels and models: all there when the flight is done, this says so to the stream)
+        # the I pictures' slice data: behind their search on A, BESIDE the flight -- a row waits, CTU by CTU, for the flight's filter stage
+        # (uvghip_loop_plan_run_coder_behind); the I pictures are the first entries of the call, group after group
+        first = 0
         for fl, loop, gm in groups:
-            _lib.check(self.L.uvghip_loop_plan_run_coder(loop.loop, B.cuda_stream), "uvghip_loop_plan_run_coder")
+            _lib.check(self.L.uvghip_loop_plan_run_coder_behind(loop.loop, ctypes.c_void_p(final + first * ctus * 4), A.cuda_stream), "uvghip_loop_plan_run_coder_behind")
+            first += loop.n
             rows, nb = loop.slice_data()
             for j, g in enumerate(fl):
                 self.rows[g], self.row_bytes[g] = rows[j * self.n_seq:(j + 1) * self.n_seq], nb[j * self.n_seq:(j + 1) * self.n_seq]
+        coded = torch.cuda.Event()
+        coded.record(A)
+        B.wait_event(coded)
         c, d, cap, nr = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
         _lib.check(self.L.uvghip_loop_pb_inflight_results(self.depth, n, self.W, self.H, _dev(ws), None, None, ctypes.byref(c), ctypes.byref(d), ctypes.byref(cap), ctypes.byref(nr)),
                    "uvghip_loop_pb_inflight_results")

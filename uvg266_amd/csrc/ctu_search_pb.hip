@@ -257,6 +257,14 @@ ws_layout layout(int n_pictures, int pic_w, int pic_h)
 
 }  // namespace
 
+// where the in-flight launch raises a picture's per-CTU "final" flags (picture i at [i * ctus]): a consumer of the finished pictures that runs
+// beside the launch waits on them (uvghip_loop_plan_run_coder_behind).  The launch zeroes them in stream order before its kernel.
+extern "C" const int32_t *uvghip_ctu_search_pb_inflight_final_flags(int n_pictures, int pic_w, int pic_h, const void *workspace)
+{
+  if (n_pictures <= 0 || pic_w <= 0 || pic_h <= 0 || !workspace) return nullptr;
+  return reinterpret_cast<const int32_t *>(static_cast<const unsigned char *>(workspace) + layout(n_pictures, pic_w, pic_h).final_done);
+}
+
 #if defined(CTU_PROFILE)
 // development builds: where the scratch slots (whose tails hold the phase counters) sit in the workspace
 extern "C" __attribute__((visibility("default"))) size_t uvghip_ctu_search_pb_debug_scratch(int n_pictures, int pic_w, int pic_h, size_t *slot_bytes, int *n_slots)

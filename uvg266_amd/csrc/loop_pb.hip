@@ -216,6 +216,13 @@ extern "C" int uvghip_loop_pb_inflight_results(int bitdepth, int n_pictures, int
   return 0;
 }
 
+extern "C" const int32_t *uvghip_loop_pb_inflight_final_flags(int bitdepth, int n_pictures, int pic_w, int pic_h, const void *workspace)
+{
+  if ((bitdepth != 8 && bitdepth != 10) || n_pictures <= 0 || pic_w <= 0 || pic_h <= 0 || !workspace) return nullptr;
+  const flight_t L = flight_of(bitdepth, n_pictures, pic_w, pic_h);
+  return uvghip_ctu_search_pb_inflight_final_flags(n_pictures, pic_w, pic_h, static_cast<const unsigned char *>(workspace) + L.search);
+}
+
 extern "C" int uvghip_loop_pb_run_inflight(int bitdepth, const uvghip_loop_pb_picture_t *pictures, int n_pictures, int sao_type, const int32_t *ref_in_call, void *workspace,
                                            void *stream)
 {

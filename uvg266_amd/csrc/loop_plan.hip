@@ -233,6 +233,15 @@ extern "C" int uvghip_loop_plan_run_coder(uvghip_loop_plan_t *pl, void *stream)
   return uvghip_encode_slice_rows(pl->bitdepth, &pl->ctu_params, nullptr, pl->n, pl->sao_info, pl->sao_models, pl->coder_ws, pl->rows, pl->row_cap, pl->row_bytes, stream);
 }
 
+// ... beside the launch that is still filtering the plan's pictures (I pictures in the flight): the rows wait for that launch's per-CTU flags
+extern "C" int uvghip_loop_plan_run_coder_behind(uvghip_loop_plan_t *pl, const int32_t *final_flags, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!pl || !final_flags) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  return uvghip_encode_slice_rows_behind(pl->bitdepth, &pl->ctu_params, nullptr, pl->n, pl->sao_info, pl->sao_models, final_flags, pl->coder_ws, pl->rows, pl->row_cap,
+                                         pl->row_bytes, stream);
+}
+
 extern "C" int uvghip_loop_plan_slice_data(const uvghip_loop_plan_t *pl, const uint8_t **rows, const int32_t **row_bytes, int *row_cap, int *n_rows)
 {
   if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);

@@ -71,6 +71,7 @@ struct row_state {
   // ... by SCAN position, with the position's level in the low half: the coding lane reads one word per position, in the order it
   // visits them (the next one is in flight while the bins of this one are coded), instead of scan -> level, scan -> template
   uint32_t ci_pos[1024];
+  int32_t sao_l[34];                   // the CTU's SAO decision (fetched by the wave: a row that codes BEHIND the launch that decides it reads past the caches)
 };
 // P / B slices: the CTU's motion for the AMVP predictors (the table uvg_inter_get_mv_cand_cua reads of the picture's cu array), the row's
 // history table, the picture's reference lists
@@ -103,6 +104,15 @@ struct coder {                          // cabac_data_t (cabac.h:56-66) + the su
   int n, cap, zeros;
 };
 
+// a row coded beside the launch that finishes its pictures (wait_flags: that launch's per-CTU "final" flags): one lane waits for the CTU
+__device__ inline void wait_final(const int32_t *flag)
+{
+  int naps = 1;
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);
+    if (naps < 16) naps <<= 1;
+  }
+}
 __device__ __forceinline__ void put_byte(coder &c, uint32_t b)          // uvg_bitstream_put_byte: emulation prevention
 {
   b &= 0xff;
@@ -566,7 +576,8 @@ __device__ inline void alf_ctu(coder &c, row_state *R, const alf_dev &A, int k, 
 
 __global__ void __launch_bounds__(64)
 slice_rows_kernel(const pic_dev *__restrict__ pics, const pb_dev *__restrict__ pbs, const int32_t *__restrict__ sao, const uint16_t *__restrict__ sao_models,
-                  int W, int H, int qp, int bitdepth, uint8_t *__restrict__ out, int row_cap, int32_t *__restrict__ row_bytes, const alf_dev *__restrict__ alfs = nullptr)
+                  int W, int H, int qp, int bitdepth, uint8_t *__restrict__ out, int row_cap, int32_t *__restrict__ row_bytes, const alf_dev *__restrict__ alfs = nullptr,
+                  const int32_t *wait_flags = nullptr)
 {
   __shared__ row_state Rs;
   extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem[];          // row_state_pb for P / B pictures (none for I)
@@ -606,6 +617,10 @@ slice_rows_kernel(const pic_dev *__restrict__ pics, const pb_dev *__restrict__ p
       for (int i = 0; i < 8; ++i) { f.l[0][i] = PB->l[0][i]; f.l[1][i] = PB->l[1][i]; }
     }
   }
+  if (wait_flags && cy > 0 && sao_models) {
+    if (lane0) wait_final(wait_flags + (size_t)pic * wc * hc + (size_t)(cy - 1) * wc);
+    __syncthreads();
+  }
   if (threadIdx.x < 2) {
     const int i = threadIdx.x;
     R->rate[NMODELS + i] = k_ctx_init_sao[3][i];
@@ -617,7 +632,8 @@ slice_rows_kernel(const pic_dev *__restrict__ pics, const pb_dev *__restrict__ p
       R->models[NMODELS + i] = (uint32_t)((s << 8) & 0x7fe0) | ((uint32_t)((s << 8) & 0x7ffe) << 16);
     } else {
       const uint16_t *m = sao_models + ((size_t)pic * wc * hc + (size_t)(cy - 1) * wc) * 6 + 3 * i;
-      R->models[NMODELS + i] = (uint32_t)m[0] | ((uint32_t)m[1] << 16);
+      const uint32_t m0 = __hip_atomic_load(&m[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), m1 = __hip_atomic_load(&m[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      R->models[NMODELS + i] = m0 | (m1 << 16);
     }
   }
   __syncthreads();
@@ -641,6 +657,7 @@ slice_rows_kernel(const pic_dev *__restrict__ pics, const pb_dev *__restrict__ p
   for (int cx = 0; cx < wc; ++cx) {
     const int k = cy * wc + cx, x0 = cx * 64, y0 = cy * 64;
     const int16_t *co = D.coeff + (size_t)k * 6144;
+    if (wait_flags) { if (lane0) wait_final(wait_flags + (size_t)pic * wc * hc + k); }
     __syncthreads();
     for (int e = threadIdx.x; e < 17 * 17; e += blockDim.x) {       // the CTU's 16 x 16 units and one unit of border (left, above, corner)
       const int ux = e % 17 - 1, uy = e / 17 - 1, x = x0 + ux * 4, y = y0 + uy * 4;
@@ -665,8 +682,12 @@ slice_rows_kernel(const pic_dev *__restrict__ pics, const pb_dev *__restrict__ p
     }
     if (PB && lane0) Q->tab[17 * 17].type = 0;                      // the CTU above right: not a candidate under WPP
     __syncthreads();
+    if (sao) {
+      if (threadIdx.x < 34) R->sao_l[threadIdx.x] = __hip_atomic_load(sao + ((size_t)pic * wc * hc + k) * 34 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+    }
     if (lane0 && sao) {                                             // encode_sao
-      const int32_t *l = sao + ((size_t)pic * wc * hc + k) * 34, *ch = l + 17;
+      const int32_t *l = R->sao_l, *ch = l + 17;
       if (cx > 0) enc_bin(c, R, NMODELS, l[3]);
       if (cy > 0 && !l[3]) enc_bin(c, R, NMODELS, l[4]);
       if (!l[3] && !l[4]) { code_sao_color(c, R, l, 0, max_off); code_sao_color(c, R, ch, 1, max_off); code_sao_color(c, R, ch, 2, max_off); }
@@ -897,6 +918,28 @@ extern "C" int uvghip_encode_slice_rows(int bitdepth, const uvghip_ctu_params_t 
   hipStream_t st = uvghip_stream(stream);
   slice_rows_kernel<<<n_pictures * hc, 64, 0, st>>>(static_cast<const pic_dev *>(workspace), nullptr, sao_info, sao_models, W, H, params->qp, bitdepth, out,
                                                     row_cap, row_bytes);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// ... of pictures whose search is complete but whose in-loop filters (the SAO decisions the slice data carries) are being finished by ANOTHER
+// launch beside this one -- I pictures in the flight (uvghip_loop_pb_run_inflight_ext filters them CTU by CTU): final_flags are that
+// launch's per-CTU flags of these pictures ([picture][ctu], uvghip_loop_pb_inflight_final_flags), a row waits for each of its CTUs (and
+// for the first CTU of the row above: its SAO models).  The caller orders the flags' zeroing before this call's stream position.
+extern "C" int uvghip_encode_slice_rows_behind(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, int n_pictures,
+                                               const int32_t *sao_info, const uint16_t *sao_models, const int32_t *final_flags, void *workspace, uint8_t *out,
+                                               int row_cap, int32_t *row_bytes, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
+  if (!params || n_pictures <= 0 || !workspace || !out || row_cap <= 0 || !row_bytes || !sao_info || !sao_models || !final_flags)
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const int W = params->pic_w, H = params->pic_h, hc = (H + 63) / 64;
+  if (W <= 0 || H <= 0 || (W & 7) || (H & 7) || params->qp < 0 || params->qp > 63) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  hipStream_t st = uvghip_stream(stream);
+  if (pictures)
+    if (int rc = prepare_ordered(params, pictures, n_pictures, workspace, st)) return rc;
+  slice_rows_kernel<<<n_pictures * hc, 64, 0, st>>>(static_cast<const pic_dev *>(workspace), nullptr, sao_info, sao_models, W, H, params->qp, bitdepth, out,
+                                                    row_cap, row_bytes, nullptr, final_flags);
   UVGHIP_CHECK_LAUNCH();
 }
 

@@ -291,6 +291,10 @@ SIGNATURES = {
     "uvghip_loop_plan_set_search_grid": (c_int, [c_vp, c_int]),
     "uvghip_loop_plan_searched_flags": (c_vp, [c_vp]),
     "uvghip_loop_plan_run_coder": (c_int, [c_vp, c_vp]),
+    "uvghip_loop_plan_run_coder_behind": (c_int, [c_vp, c_vp, c_vp]),
+    "uvghip_encode_slice_rows_behind": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_loop_pb_inflight_final_flags": (c_vp, [c_int, c_int, c_int, c_int, c_vp]),
+    "uvghip_ctu_search_pb_inflight_final_flags": (c_vp, [c_int, c_int, c_int, c_vp]),
     "uvghip_ctu_plan_reset": (c_int, [c_vp, c_vp]),
     "uvghip_ctu_plan_launch": (c_int, [c_vp, c_vp]),
     "uvghip_ctu_plan_set_grid": (c_int, [c_vp, c_int]),
