@@ -1155,6 +1155,42 @@ UVGHIP_API int uvghip_loop_plan_picture_nals(uvghip_loop_plan_t *plan, int pictu
  * of frames in one launch they are all done together.) */
 UVGHIP_API int uvghip_loop_plan_group_nals(uvghip_loop_plan_t *plan, int first_poc, uint8_t *out, size_t cap, size_t *lens, void *stream);
 
+/* ------------------- (7b) tiles: the independent rectangles of a picture ---------------------------------------------------- */
+
+/* replaces: the encoder's TILE states for all-intra pictures under --tiles <cols>x<rows> --wpp (encoder_state_t of type
+ * ENCODER_STATE_TYPE_TILE, src/encoder_state-ctors_dtors.c: a sub-image of the frame, a cu_array view, a CABAC start and WPP rows per tile;
+ * the uniform grid and the tile scan of src/encoder.c:445-451, 480-510; the tile loop of encoder_state_encode, src/encoderstate.c:1221).
+ * In the reference a tile's edges are picture edges to the search AND to the in-loop filters (state->tile->frame everywhere;
+ * pps_loop_filter_across_tiles_enabled_flag = 0, src/encoder_state-bitstream.c:788), every tile starts from initialised context models,
+ * and the slice data is the tiles' substreams in tile raster order with all of them among the slice header's entry points (:977-1007).
+ * So a tile is a picture of its own size whose planes are views into the frame's: a tiles plan is one uvghip_loop_plan per tile SIZE (a
+ * uniform grid has at most four) that run beside each other -- the tiles of one picture are that many WPP wavefronts in flight.
+ *
+ * uvghip_tile_grid: HOST function.  tiles[cols * rows]: the grid in samples, raster order; first_ctu[cols * rows] (may be NULL): the
+ * tile-scan address (tiles_ctb_addr_rs_to_ts) of each tile's first CTU.  Refuses what the encoder refuses (more tiles than CTUs in a
+ * dimension, MAX_TILES_PER_DIM).
+ * uvghip_tiles_plan_create: pictures = the WHOLE pictures as for uvghip_loop_plan_create, params = the whole picture's; coeff / models
+ * hold a picture's CTUs in TILE-SCAN order (the order of the bitstream); cu in picture raster as ever (cu_stride >= 16 * CTUs per row).
+ * workspace: uvghip_tiles_workspace_bytes of device memory, in use until the plan is destroyed.
+ * uvghip_tiles_plan_run: search + filters + slice data of every tile of every picture; returns at once; the size classes run on the
+ * plan's own streams, forked from and joined to `stream`.
+ * uvghip_tiles_plan_tile: where tile `tile` (raster order) of picture `picture` lives -- its size class's loop plan and its picture index
+ * there (for uvghip_loop_plan_results / _slice_data), its rectangle, its first CTU's tile-scan address; any output pointer may be NULL.
+ * uvghip_tiles_plan_nals: after a run, the NAL units (slice NAL with the entry points of ALL substreams + hash SEI of the whole output
+ * picture) of pictures [first, first + count) as pictures first_poc, ... of the stream, one after the other into HOST memory (lens[i]
+ * bytes each); waits for the stream.  Behind the encoder's parameter sets (its PPS carries the grid, :768-791) they complete the .266 the
+ * encoder writes under --tiles, byte for byte (tests/test_gpu_tiles.py against tests/golden/ref_tiles_*.npz). */
+typedef struct uvghip_tiles_plan uvghip_tiles_plan_t;
+UVGHIP_API int uvghip_tile_grid(int pic_w, int pic_h, int cols, int rows, uvghip_rect_t *tiles, int32_t *first_ctu);
+UVGHIP_API size_t uvghip_tiles_workspace_bytes(int bitdepth, int n_pictures, int pic_w, int pic_h, int cols, int rows);
+UVGHIP_API int uvghip_tiles_plan_create(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_loop_picture_t *pictures, int n_pictures, int tile_cols, int tile_rows,
+                                        int sao_type, void *workspace, uvghip_tiles_plan_t **plan_out);
+UVGHIP_API int uvghip_tiles_plan_run(uvghip_tiles_plan_t *plan, void *stream);
+UVGHIP_API int uvghip_tiles_plan_layout(const uvghip_tiles_plan_t *plan, int *n_tiles, int *n_classes, int *n_substreams);
+UVGHIP_API int uvghip_tiles_plan_tile(const uvghip_tiles_plan_t *plan, int picture, int tile, uvghip_loop_plan_t **loop_plan, int *index, uvghip_rect_t *rect, int *first_ctu);
+UVGHIP_API int uvghip_tiles_plan_nals(uvghip_tiles_plan_t *plan, int first, int count, int first_poc, uint8_t *out, size_t cap, size_t *lens, void *stream);
+UVGHIP_API void uvghip_tiles_plan_destroy(uvghip_tiles_plan_t *plan);
+
 /* ------------------- (8) P / B pictures: candidate lists of the inter search ---------------------------------------------- */
 
 /* replaces: uvg_inter_get_merge_cand (src/inter.c:1989-2192) for n calls at once, one lane per call: the spatial candidates A0 / A1 /

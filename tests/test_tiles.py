@@ -1,0 +1,101 @@
+"""Tiles (--tiles <cols>x<rows> --wpp) on the CPU: the library's host function uvghip_tile_grid against the encoder's uniform grid, and the
+claim csrc/tiles.hip is built on -- a tile is a picture of its own (search, in-loop filters, context models, WPP rows), the slice data
+the tiles' substreams in tile raster order, the hash the whole picture's -- checked with the oracle's chain per tile against the files the
+real encoder wrote under --tiles (tests/golden/ref_tiles_*.npz, tools/refcheck/make_ctu_goldens.py::tiles)."""
+import ctypes
+import zlib
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+FULL = ["ref_tiles_264x136_8_qp27_2x2_1frames", "ref_tiles_192x192_8_qp37_1x3_1frames", "ref_tiles_320x192_8_qp22_5x1_1frames", "ref_tiles_416x240_10_qp32_3x2_2frames"]
+
+
+def uniform(n_ctus, parts):
+    return [(i + 1) * n_ctus // parts - i * n_ctus // parts for i in range(parts)]          # (src/encoder.c:445-451)
+
+
+def expected_grid(W, Hh, cols, rows):
+    wc, hc = (W + 63) // 64, (Hh + 63) // 64
+    rects, first, at, y0 = [], [], 0, 0
+    for th in uniform(hc, rows):
+        x0 = 0
+        for tw in uniform(wc, cols):
+            rects.append((x0 * 64, y0 * 64, min(tw * 64, W - x0 * 64), min(th * 64, Hh - y0 * 64)))
+            first.append(at)
+            at += tw * th
+            x0 += tw
+        y0 += th
+    return np.array(rects, np.int32), np.array(first, np.int32)
+
+
+@pytest.mark.parametrize("case", [(264, 136, 2, 2), (1920, 1080, 2, 2), (3840, 2160, 4, 2), (1920, 1080, 7, 5), (416, 240, 3, 2), (64, 64, 1, 1), (8, 8, 1, 1)])
+def test_tile_grid_is_the_encoders_uniform_grid(case):
+    from uvg266_amd import api
+    W, Hh, cols, rows = case
+    rects, first = api.tile_grid(W, Hh, cols, rows)
+    er, ef = expected_grid(W, Hh, cols, rows)
+    assert np.array_equal(rects, er) and np.array_equal(first, ef)
+    assert int((rects[:, 2] * rects[:, 3]).sum()) == W * Hh          # the tiles cover the picture exactly
+
+
+def test_tile_grid_refuses_what_the_encoder_refuses():
+    from uvg266_amd import lib
+    L = lib.load_library()
+    rects = np.zeros((64 * 64, 4), np.int32)
+    for W, Hh, cols, rows in [(264, 136, 6, 1), (264, 136, 1, 4), (264, 136, 0, 1), (4096, 4096, 48, 1), (0, 64, 1, 1)]:
+        assert L.uvghip_tile_grid(W, Hh, cols, rows, rects.ctypes.data, None) != 0
+    assert L.uvghip_tiles_workspace_bytes(8, 1, 264, 136, 6, 1) == 0
+
+
+def substreams(g, picture, n_sub):
+    off = g["row_off"]
+    return [g["row_bytes"][off[picture * n_sub + k]:off[picture * n_sub + k + 1]] for k in range(n_sub)]
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_a_tile_is_a_picture_of_its_own(orc, name):
+    """Every tile through the oracle's chain as a picture of the tile's size: its substreams are the encoder's, the pictures stitched
+    together are the picture the encoder returned, and slice NAL + hash SEI written by the library's host function from them complete the
+    encoder's .266."""
+    from uvg266_amd import api, lib
+    L = lib.load_library()
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, cols, rows = (int(a) for a in g["meta"])
+    rects, _ = api.tile_grid(W, Hh, cols, rows)
+    n_sub = int(sum((r[3] + 63) // 64 for r in rects))
+    stream = g["bitstream"].tobytes()
+    mine = b""
+    for poc, t in enumerate(g["ts"]):
+        y, u, v = H.varied_picture(W, Hh, int(t), depth)
+        assert zlib.crc32(y.tobytes() + u.tobytes() + v.tobytes()) == int(g["src_crc"][poc])
+        final = [np.zeros_like(y), np.zeros_like(u), np.zeros_like(v)]
+        rows_b = []
+        for tx, ty, tw, th in (tuple(int(a) for a in r) for r in rects):
+            sub = [np.ascontiguousarray(p[(ty >> c):(ty + th) >> c, (tx >> c):(tx + tw) >> c]) for p, c in ((y, 0), (u, 1), (v, 1))]
+            prm = H.search_params(tw, th, qp)
+            s = H.oracle_search_picture(orc, depth, prm, *sub)
+            f = H.oracle_sao_picture(orc, depth, tw, th, qp, prm.lam, tuple(sub), (s["rec_y"], s["rec_u"], s["rec_v"]), H.scu_from_cu(s["cu"], qp))
+            data, off, _ = H.oracle_encode_rows(orc, depth, prm, s, f["sao"])
+            rows_b += [data[off[r]:off[r + 1]] for r in range(len(off) - 1)]
+            for p, k, c in ((final[0], "final_y", 0), (final[1], "final_u", 1), (final[2], "final_v", 1)):
+                p[(ty >> c):(ty + th) >> c, (tx >> c):(tx + tw) >> c] = f[k]
+        assert len(rows_b) == n_sub
+        for k, (a, b) in enumerate(zip(rows_b, substreams(g, poc, n_sub))):
+            assert np.array_equal(a, b), f"substream {k} of picture {poc}"
+        assert np.array_equal(np.concatenate([p.reshape(-1) for p in final]), g["final"][poc]), "the picture the encoder returned"
+        sizes = np.array([len(r) for r in rows_b], np.int32)
+        packed = np.zeros((n_sub, int(sizes.max())), np.uint8)
+        for k, r in enumerate(rows_b):
+            packed[k, :len(r)] = r
+        sums = np.array([H.picture_checksum(p, depth) for p in final], np.uint32)
+        cap = int(sizes.sum()) + 64 + 4 * n_sub
+        out = np.zeros(cap, np.uint8)
+        n = ctypes.c_size_t(0)
+        assert L.uvghip_write_picture_nals(poc, 1, H.ptr(packed), packed.shape[1], H.ptr(sizes), n_sub, H.ptr(sums), H.ptr(out), cap, ctypes.byref(n)) == 0
+        mine += out[:n.value].tobytes()
+    at = stream.find(b"\x00\x00\x01\x00\x41")
+    assert at > 0 and stream[:at] + mine == stream          # parameter sets (the encoder's: its PPS carries the grid) + these bytes = the whole .266
+

@@ -251,6 +251,53 @@ def stream_alf(W, H, depth, qp, ts, crc_only=False):
           [sum(int(r[0][0]) == i for r in P) for i in range(len(ts))])
 
 
+def tiles(W, H, depth, qp, ts, cols, rows, crc_only=False):
+    """A -p 1 --tiles <cols>x<rows> --wpp stream (the source pictures: helpers.varied_picture of ts): the .266, every substream in the order
+    of the bitstream (per picture: tile after tile in raster order, a tile's WPP rows in order) and the pictures the encoder returned.
+    Records are tile-local (ctu_dump.c reads state->tile->frame), so the per-CTU items stay out: the .266 holds every coded decision, the
+    output pictures every filtered sample.  crc_only: lengths and CRCs instead of the bytes (BASELINE's sizes)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    px = np.uint8 if depth == 8 else np.uint16
+    tag = f"{W}x{H}_{depth}_qp{qp}_{cols}x{rows}_{len(ts)}frames"
+    yuv = f"/tmp/gold_tiles_{tag}.yuv"
+    crcs = []
+    with open(yuv, "wb") as f:
+        for t in ts:
+            y, u, v = helpers.varied_picture(W, H, t, depth)
+            crcs.append(zlib.crc32(y.tobytes() + u.tobytes() + v.tobytes()))
+            for p in (y, u, v):
+                f.write(p.astype(px).tobytes())
+    out = f"/tmp/gold_tiles_{tag}"
+    subprocess.check_call([os.path.join(ROOT, "tools/refcheck/ctu_dump.sh"), str(depth), yuv, str(W), str(H), str(len(ts)), out,
+                           "preset", "medium", "period", "1", "qp", str(qp), "tiles", f"{cols}x{rows}", "wpp", "1"], stderr=subprocess.DEVNULL)
+    recs = read_records(out + ".bin")
+    R = [r for n, r in recs if n == "row"]
+    F = [r for n, r in recs if n == "final"]
+    bs = open(out + ".266", "rb").read()
+    wc, hc = (W + 63) // 64, (H + 63) // 64
+    n_sub = sum(((i + 1) * hc // rows - i * hc // rows) for i in range(rows)) * cols
+    assert len(R) == n_sub * len(ts) and len(F) == len(ts)
+    # the records come in the order of the bitstream: the substreams follow each other inside every slice NAL
+    at = 0
+    for r in R:
+        at2 = bs.find(r[1].tobytes(), at)
+        assert at2 >= 0, "a substream is not where the order of the records says"
+        at = at2 + len(r[1])
+    head = bs.find(b"\x00\x00\x01\x00\x41")
+    assert head > 0
+    row_off = np.concatenate([[0], np.cumsum([len(r[1]) for r in R])]).astype(np.int64)
+    finals = [np.concatenate([f[1], f[2], f[3]]) for f in F]
+    more = dict(bitstream=np.frombuffer(bs, np.uint8), row_bytes=np.concatenate([r[1] for r in R]), final=np.stack(finals))
+    if crc_only:
+        more = dict(bitstream_head=np.frombuffer(bs[:head], np.uint8), bitstream_tail_len=np.int64(len(bs) - head), bitstream_tail_crc=np.uint32(zlib.crc32(bs[head:])),
+                    row_crc=np.array([zlib.crc32(r[1].tobytes()) for r in R], np.uint32), final_crc=np.array([zlib.crc32(f.tobytes()) for f in finals], np.uint32))
+        tag += "_crc"
+    np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_tiles_{tag}.npz"), meta=np.array([W, H, depth, qp, cols, rows], np.int32), ts=np.array(ts, np.int32),
+                        src_crc=np.array(crcs, np.uint32), row_off=row_off, **more)
+    print("wrote tiles", tag, len(bs), "bytes,", n_sub, "substreams per picture")
+
+
 def helpers_varied():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers
@@ -509,5 +556,11 @@ if __name__ == "__main__":
     inter(136, 200, 8, 27, 11, extra=("owf", "1"), suffix="_owf1", clip=3)             # frames in flight: the vectors restricted to what is final in the reference picture; content that rises ever faster
     inter(136, 72, 8, 27, 5, extra=("rd", "1"), suffix="_rd1", clip=2)                 # --preset slow = medium + rd 1 (a P / B CU never skips its intra search on a low inter cost); plateau content
     inter(136, 72, 8, 27, 33, extra=("gop", "16", "period", "16"), suffix="_ra16p16", clip=True)      # three intra periods of an open GOP: CRA pictures at POC 16 and 32, RASL pictures behind them
+    tiles(264, 136, 8, 27, (3,), 2, 2)                 # --tiles 2x2 --wpp: four tiles of four sizes (2 / 3 CTU columns, 1 / 2 CTU rows), partial CTUs at the picture's edges
+    tiles(416, 240, 10, 32, (2007, 11), 3, 2)          # ... 10 bit, two pictures of one stream, six tiles (2 / 2 / 3 columns: two sizes share a plan)
+    tiles(320, 192, 8, 22, (1004,), 5, 1)              # ... a row of one-CTU-wide tiles: every CTU starts its row's substream... and 1 x 3:
+    tiles(192, 192, 8, 37, (9,), 1, 3)                 # ... tiles one above the other, one WPP row each
+    tiles(1920, 1080, 8, 22, (0, 1), 2, 2, crc_only=True)      # BASELINE configs[1]'s picture in 2 x 2 tiles (bench.py tiles_clip), by CRC
+    tiles(3840, 2160, 10, 22, (0,), 4, 2, crc_only=True)       # ... configs[3]'s size and depth in 4 x 2 tiles: one tile per GPU of the node
     if not os.environ.get("GOLDENS_SKIP_CLIP120"):      # (ten minutes and 4 GB of records by itself)
         inter_crcs(1920, 1080, 8, 27, 120, extra=("owf", "1"), suffix="_owf1", clip=True)     # bench.py's c3_clip, picture by picture: BASELINE configs[2] as written, --owf 1 (frames in flight), crosses the second intra period at POC 64

@@ -872,6 +872,94 @@ class ClosedLoop(CtuSearch):
             CtuSearch.__del__(self)
 
 
+def tile_grid(pic_w, pic_h, cols, rows):
+    """uvghip_tile_grid (host function): the uniform grid of --tiles <cols>x<rows> -> (rects [cols * rows, 4] int32 (x, y, w, h in samples,
+    raster order of the tiles), first_ctu [cols * rows] int32: the tile-scan address of every tile's first CTU)."""
+    L = _lib.load_library()
+    rects = np.zeros((cols * rows, 4), np.int32)
+    first = np.zeros(cols * rows, np.int32)
+    _lib.check(L.uvghip_tile_grid(pic_w, pic_h, cols, rows, rects.ctypes.data, first.ctypes.data), "uvghip_tile_grid")
+    return rects, first
+
+
+class TiledLoop:
+    """uvghip_tiles_plan_*: all-intra pictures under --tiles <cols>x<rows> --wpp -- every tile an independent rectangle of the closed loop
+    (search, in-loop filters, slice data), the tiles of a picture beside each other on the device.  src: list of (y, u, v) whole-picture
+    device planes.  Outputs stay on the device: rec[i] / out[i] (whole pictures: before / after the in-loop filters), cu[i] (picture
+    raster), coeff[i] / models[i] (the CTUs in TILE-SCAN order: the order of the bitstream)."""
+
+    def __init__(self, params, src, tiles, sao_type=3):
+        import ctypes
+        self.P, self.n = params, len(src)
+        self.cols, self.rows = int(tiles[0]), int(tiles[1])
+        W, H = int(params.pic_w), int(params.pic_h)
+        self.wc, self.hc = (W + 63) // 64, (H + 63) // 64
+        dev = src[0][0].device
+        self.depth = _depth(src[0][0])
+        self.L = _lib.init(dev.index or 0)
+        self.src = src
+        self.rec = [tuple(torch.zeros_like(p) for p in s) for s in src]
+        self.out = [tuple(torch.zeros_like(p) for p in s) for s in src]
+        ctus = self.wc * self.hc
+        self.cu = [torch.zeros((self.hc * 16, self.wc * 16, 32), dtype=torch.uint8, device=dev) for _ in src]
+        self.coeff = [torch.zeros((ctus, 6144), dtype=torch.int16, device=dev) for _ in src]
+        self.models = [torch.zeros((ctus, 3, 257), dtype=torch.int32, device=dev) for _ in src]
+        lp = (_lib.LoopPicture * self.n)()
+        for i, (s, r, o) in enumerate(zip(src, self.rec, self.out)):
+            sp = _lib.CtuPicture(_dev(s[0]), _dev(s[1]), _dev(s[2]), s[0].stride(0), s[1].stride(0), _dev(r[0]), _dev(r[1]), _dev(r[2]),
+                                 r[0].stride(0), r[1].stride(0), _dev(self.cu[i]), self.wc * 16, 0, _dev(self.coeff[i]), _dev(self.models[i]))
+            lp[i] = _lib.LoopPicture(sp, _dev(o[0]), _dev(o[1]), _dev(o[2]), o[0].stride(0), o[1].stride(0))
+        self.pics = lp
+        nbytes = self.L.uvghip_tiles_workspace_bytes(self.depth, self.n, W, H, self.cols, self.rows)
+        if not nbytes:
+            raise ValueError("uvghip_tiles_workspace_bytes: the tile grid does not fit the picture")
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.plan = ctypes.c_void_p()
+        _lib.check(self.L.uvghip_tiles_plan_create(self.depth, ctypes.byref(self.P), lp, self.n, self.cols, self.rows, sao_type, _dev(self.ws), ctypes.byref(self.plan)),
+                   "uvghip_tiles_plan_create")
+        a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(self.L.uvghip_tiles_plan_layout(self.plan, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "uvghip_tiles_plan_layout")
+        self.n_tiles, self.n_classes, self.n_substreams = a.value, b.value, c.value
+
+    def run(self, stream=None):
+        """Enqueue search + filters + slice data of every tile of every picture (uvghip_tiles_plan_run); returns at once."""
+        _lib.check(self.L.uvghip_tiles_plan_run(self.plan, _stream() if stream is None else stream), "uvghip_tiles_plan_run")
+
+    def nals(self, first_poc=0, first=0, count=None):
+        """uvghip_tiles_plan_nals: after run(), slice NAL + hash SEI of pictures [first, first + count) as pictures first_poc, ... of the
+        stream -> list of bytes."""
+        import ctypes
+        count = self.n - first if count is None else count
+        per = self.hc * (3 * 64 * int(self.P.pic_w)) * (1 if self.depth == 8 else 2) + 64 + 4 * self.n_substreams      # (the row slots of the tiles of one CTU row add up to a picture row's)
+        if getattr(self, "_nal_buf", None) is None or self._nal_buf.size < per * count:
+            self._nal_buf = np.empty(per * count, np.uint8)
+        lens = (ctypes.c_size_t * count)()
+        _lib.check(self.L.uvghip_tiles_plan_nals(self.plan, first, count, first_poc, self._nal_buf.ctypes.data_as(ctypes.c_void_p), self._nal_buf.size, lens, _stream()),
+                   "uvghip_tiles_plan_nals")
+        out, at = [], 0
+        for i in range(count):
+            out.append(self._nal_buf[at:at + lens[i]].tobytes())
+            at += lens[i]
+        return out
+
+    def tile(self, picture, tile):
+        """uvghip_tiles_plan_tile -> (loop plan handle, picture index there, (x, y, w, h), first CTU in tile scan)."""
+        import ctypes
+        pl, idx, first = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int()
+        rect = np.zeros(4, np.int32)
+        _lib.check(self.L.uvghip_tiles_plan_tile(self.plan, picture, tile, ctypes.byref(pl), ctypes.byref(idx), rect.ctypes.data, ctypes.byref(first)), "uvghip_tiles_plan_tile")
+        return pl, idx.value, tuple(int(v) for v in rect), first.value
+
+    def __del__(self):
+        plan, self.plan = getattr(self, "plan", None), None
+        if plan:
+            try:
+                if torch is not None:          # (None at interpreter shutdown)
+                    torch.cuda.synchronize()
+            finally:
+                self.L.uvghip_tiles_plan_destroy(plan)
+
+
 def picture_checksum(y, u, v, stream=None):
     """uvghip_picture_checksum: the three plane sums of the decoded picture hash SEI (uvg_image_checksum) -> tensor [3] on the device
     (the uint32 values in an int32 tensor: .cpu().numpy().view(np.uint32))."""

@@ -1,0 +1,306 @@
+// uvghip_tiles_plan_*: all-intra pictures cut into TILES (--tiles CxR --wpp): the encoder's tile states (encoder_state_t of type
+// ENCODER_STATE_TYPE_TILE, src/encoder_state-ctors_dtors.c; every tile with its own sub-image of the frame, its own cu_array view,
+// its own CABAC start and its own WPP rows) as independent rectangles of the device's closed loop.
+//
+// What a tile is in the reference (all checked against runs of the encoder, tests/golden/ref_tiles_*.npz):
+//   * the search, the deblocking, the SAO decision and SAO itself see `state->tile->frame`, a sub-image: a tile's left / upper edge is
+//     a PICTURE edge to them (no neighbours, no references, no filtering across: pps_loop_filter_across_tiles_enabled_flag = 0,
+//     src/encoder_state-bitstream.c:788);
+//   * every tile starts from freshly initialised context models, its WPP rows synchronise inside the tile;
+//   * the slice data is the tiles' substreams in tile raster order, each tile's rows in order; the slice header's entry points list
+//     them all (encoder_state_entry_points_explore, :977-1007); everything else of the slice header is the one-tile header;
+//   * the decoded picture hash covers the whole picture.
+// So a tile IS a picture of its own size whose planes are views into the frame's (origin + the frame's stride), and the plan below is
+// host code only: one uvghip_loop_plan per tile SIZE (a uniform grid has at most four), holding that size's tiles of all pictures as its
+// "pictures"; the plans run beside each other on their own streams -- the tiles of ONE picture are that many WPP wavefronts in flight
+// (1080p in 2 x 2 tiles: four wavefronts of 29 diagonals instead of one of 62).
+#include "uvghip_common.h"
+#include <new>
+#include <vector>
+#include <cstring>
+
+struct uvghip_tiles_plan {
+  int bitdepth, n, w, h, cols, rows, sao_type;
+  std::vector<uvghip_rect_t> tiles;          // in samples, raster order of the tiles
+  std::vector<int> first_ctu;                // per tile: the tile-scan address of its first CTU (ctbAddrRsToTs of its corner)
+  struct size_class {
+    int w, h;
+    std::vector<int> ids;                    // the tiles of this size
+    uvghip_loop_plan_t *plan;
+    hipStream_t st;
+    hipEvent_t done;
+  };
+  std::vector<size_class> classes;
+  std::vector<int> cls_of, slot_of;          // per tile: its class and its index among the class's tiles
+  std::vector<uvghip_loop_picture_t> pics;
+  hipEvent_t fork;
+  uint32_t *sums;                            // device: [n][3]
+  uint8_t *host_rows;                        // pinned staging of the group's substreams (grown on demand)
+  size_t host_cap;
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// encoder.c:445-451: uniform spacing, column i is (i + 1) * W / n - i * W / n CTUs wide
+int grid(int pic_w, int pic_h, int cols, int rows, std::vector<uvghip_rect_t> &tiles, std::vector<int> &first_ctu)
+{
+  const int wc = (pic_w + 63) / 64, hc = (pic_h + 63) / 64;
+  if (cols < 1 || rows < 1 || cols > wc || rows > hc || cols >= 48 || rows >= 48) return 1;      // (MAX_TILES_PER_DIM, global.h:297 with cfg.c:314; the encoder refuses more tiles than CTUs, encoder.c:405-412)
+  tiles.resize((size_t)cols * rows);
+  first_ctu.resize((size_t)cols * rows);
+  int at = 0, y0 = 0;
+  for (int r = 0; r < rows; ++r) {
+    const int th = (r + 1) * hc / rows - r * hc / rows;
+    int x0 = 0;
+    for (int c = 0; c < cols; ++c) {
+      const int tw = (c + 1) * wc / cols - c * wc / cols;
+      uvghip_rect_t &t = tiles[(size_t)r * cols + c];
+      t.x = x0 * 64; t.y = y0 * 64;
+      t.w = (x0 + tw) * 64 > pic_w ? pic_w - x0 * 64 : tw * 64;
+      t.h = (y0 + th) * 64 > pic_h ? pic_h - y0 * 64 : th * 64;
+      first_ctu[(size_t)r * cols + c] = at;
+      at += tw * th;
+      x0 += tw;
+    }
+    y0 += th;
+  }
+  return 0;
+}
+
+struct class_key { int w, h, count; };
+void classes_of(const std::vector<uvghip_rect_t> &tiles, std::vector<class_key> &keys, std::vector<int> &cls_of, std::vector<int> &slot_of)
+{
+  cls_of.resize(tiles.size()); slot_of.resize(tiles.size());
+  for (size_t t = 0; t < tiles.size(); ++t) {
+    size_t k = 0;
+    while (k < keys.size() && (keys[k].w != tiles[t].w || keys[k].h != tiles[t].h)) ++k;
+    if (k == keys.size()) keys.push_back(class_key{tiles[t].w, tiles[t].h, 0});
+    cls_of[t] = (int)k; slot_of[t] = keys[k].count++;
+  }
+}
+
+void destroy(uvghip_tiles_plan *pl)
+{
+  for (auto &c : pl->classes) {
+    if (c.plan) uvghip_loop_plan_destroy(c.plan);
+    if (c.st) (void)hipStreamDestroy(c.st);
+    if (c.done) (void)hipEventDestroy(c.done);
+  }
+  if (pl->fork) (void)hipEventDestroy(pl->fork);
+  if (pl->host_rows) (void)hipHostFree(pl->host_rows);
+  delete pl;
+}
+
+}  // namespace
+
+// A HOST function (works without a device): the uniform tile grid of --tiles <cols>x<rows> (encoder.c:445-451, 480-510): tiles[cols * rows]
+// in samples, raster order; first_ctu[cols * rows] (may be NULL): the tile-scan address of every tile's first CTU.
+extern "C" int uvghip_tile_grid(int pic_w, int pic_h, int cols, int rows, uvghip_rect_t *tiles, int32_t *first_ctu)
+{
+  if (pic_w <= 0 || pic_h <= 0 || !tiles) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  std::vector<uvghip_rect_t> t;
+  std::vector<int> f;
+  if (grid(pic_w, pic_h, cols, rows, t, f)) return uvghip_set_error(hipErrorInvalidValue, "uvghip_tile_grid: more tiles than CTUs in a dimension (or none)");
+  for (size_t i = 0; i < t.size(); ++i) { tiles[i] = t[i]; if (first_ctu) first_ctu[i] = f[i]; }
+  return 0;
+}
+
+extern "C" size_t uvghip_tiles_workspace_bytes(int bitdepth, int n_pictures, int pic_w, int pic_h, int cols, int rows)
+{
+  if ((bitdepth != 8 && bitdepth != 10) || n_pictures <= 0 || pic_w <= 0 || pic_h <= 0) return 0;
+  std::vector<uvghip_rect_t> t;
+  std::vector<int> f, cls_of, slot_of;
+  if (grid(pic_w, pic_h, cols, rows, t, f)) return 0;
+  std::vector<class_key> keys;
+  classes_of(t, keys, cls_of, slot_of);
+  size_t at = align_up((size_t)n_pictures * 3 * sizeof(uint32_t), 256);
+  for (const class_key &k : keys) at += align_up(uvghip_loop_workspace_bytes(bitdepth, n_pictures * k.count, k.w, k.h), 256);
+  return at;
+}
+
+// pictures: the WHOLE pictures (planes with their strides; cu with cu_stride >= 16 * CTUs per picture row); coeff / models hold the CTUs in
+// TILE-SCAN order (the order of the bitstream: tile after tile, raster inside a tile).  params: the whole picture's (pic_w, pic_h).
+extern "C" int uvghip_tiles_plan_create(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_loop_picture_t *pictures, int n_pictures, int tile_cols, int tile_rows,
+                                        int sao_type, void *workspace, uvghip_tiles_plan_t **plan_out)
+{
+  UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
+  if (!params || !pictures || n_pictures <= 0 || !workspace || !plan_out) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  uvghip_tiles_plan *pl = new (std::nothrow) uvghip_tiles_plan;
+  if (!pl) return uvghip_set_error(hipErrorOutOfMemory, __func__);
+  pl->bitdepth = bitdepth; pl->n = n_pictures; pl->w = params->pic_w; pl->h = params->pic_h; pl->cols = tile_cols; pl->rows = tile_rows; pl->sao_type = sao_type;
+  pl->fork = nullptr; pl->host_rows = nullptr; pl->host_cap = 0;
+  if (grid(pl->w, pl->h, tile_cols, tile_rows, pl->tiles, pl->first_ctu)) { delete pl; return uvghip_set_error(hipErrorInvalidValue, "uvghip_tiles_plan_create: more tiles than CTUs in a dimension (or none)"); }
+  const int wc = (pl->w + 63) / 64;
+  for (int i = 0; i < n_pictures; ++i) {
+    const uvghip_ctu_picture_t &s = pictures[i].search;
+    if (!s.src_y || !s.src_u || !s.src_v || !s.rec_y || !s.rec_u || !s.rec_v || !s.cu || !s.coeff || !s.models || !pictures[i].out_y || !pictures[i].out_u || !pictures[i].out_v ||
+        s.src_stride < pl->w || s.rec_stride < pl->w || s.src_stride_c < pl->w / 2 || s.rec_stride_c < pl->w / 2 || s.cu_stride < wc * 16 || pictures[i].out_stride < pl->w ||
+        pictures[i].out_stride_c < pl->w / 2) { delete pl; return uvghip_set_error(hipErrorInvalidValue, "uvghip_tiles_plan_create: a picture's planes, tables or strides"); }
+  }
+  pl->pics.assign(pictures, pictures + n_pictures);
+  std::vector<class_key> keys;
+  classes_of(pl->tiles, keys, pl->cls_of, pl->slot_of);
+  pl->classes.resize(keys.size());
+  for (size_t k = 0; k < keys.size(); ++k) { pl->classes[k].w = keys[k].w; pl->classes[k].h = keys[k].h; pl->classes[k].plan = nullptr; pl->classes[k].st = nullptr; pl->classes[k].done = nullptr; }
+  for (size_t t = 0; t < pl->tiles.size(); ++t) pl->classes[pl->cls_of[t]].ids.push_back((int)t);
+  unsigned char *ws = static_cast<unsigned char *>(workspace);
+  pl->sums = reinterpret_cast<uint32_t *>(ws);
+  size_t at = align_up((size_t)n_pictures * 3 * sizeof(uint32_t), 256);
+  const size_t b = bitdepth == 8 ? 1 : 2;
+  for (auto &c : pl->classes) {
+    const int per = (int)c.ids.size();
+    std::vector<uvghip_loop_picture_t> sub((size_t)n_pictures * per);
+    for (int i = 0; i < n_pictures; ++i)
+      for (int j = 0; j < per; ++j) {
+        const uvghip_rect_t &t = pl->tiles[c.ids[j]];
+        uvghip_loop_picture_t q = pictures[i];
+        uvghip_ctu_picture_t &s = q.search;
+        auto luma = [&](const void *p, int stride) { return (void *)((unsigned char *)p + ((size_t)t.y * stride + t.x) * b); };
+        auto chroma = [&](const void *p, int stride) { return (void *)((unsigned char *)p + ((size_t)(t.y / 2) * stride + t.x / 2) * b); };
+        s.src_y = luma(s.src_y, s.src_stride); s.src_u = chroma(s.src_u, s.src_stride_c); s.src_v = chroma(s.src_v, s.src_stride_c);
+        s.rec_y = luma(s.rec_y, s.rec_stride); s.rec_u = chroma(s.rec_u, s.rec_stride_c); s.rec_v = chroma(s.rec_v, s.rec_stride_c);
+        q.out_y = luma(q.out_y, q.out_stride); q.out_u = chroma(q.out_u, q.out_stride_c); q.out_v = chroma(q.out_v, q.out_stride_c);
+        s.cu = s.cu + (size_t)(t.y / 4) * s.cu_stride + t.x / 4;
+        s.coeff = s.coeff + (size_t)pl->first_ctu[c.ids[j]] * 6144;
+        s.models = s.models + (size_t)pl->first_ctu[c.ids[j]] * 3 * UVGHIP_CTU_MODELS;
+        sub[(size_t)i * per + j] = q;
+      }
+    uvghip_ctu_params_t p = *params;
+    p.pic_w = c.w; p.pic_h = c.h;
+    if (int rc = uvghip_loop_plan_create(bitdepth, &p, sub.data(), n_pictures * per, sao_type, ws + at, &c.plan)) { destroy(pl); return rc; }
+    at += align_up(uvghip_loop_workspace_bytes(bitdepth, n_pictures * per, c.w, c.h), 256);
+    hipError_t e = hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c.done, hipEventDisableTiming);
+    if (e != hipSuccess) { destroy(pl); return uvghip_set_error(e, "uvghip_tiles_plan_create: streams"); }
+  }
+  hipError_t e = hipEventCreateWithFlags(&pl->fork, hipEventDisableTiming);
+  if (e != hipSuccess) { destroy(pl); return uvghip_set_error(e, "uvghip_tiles_plan_create: events"); }
+  *plan_out = pl;
+  return 0;
+}
+
+// Search + filters + slice data of every tile of every picture; returns at once.  The size classes run beside each other on the plan's own
+// streams, forked from and joined to `stream`: work enqueued on `stream` afterwards sees all of it.
+extern "C" int uvghip_tiles_plan_run(uvghip_tiles_plan_t *pl, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  hipStream_t st = uvghip_stream(stream);
+  if (pl->classes.size() == 1) return uvghip_loop_plan_run(pl->classes[0].plan, stream);
+  UVGHIP_TRY(hipEventRecord(pl->fork, st));
+  for (auto &c : pl->classes) {
+    UVGHIP_TRY(hipStreamWaitEvent(c.st, pl->fork, 0));
+    if (int rc = uvghip_loop_plan_run(c.plan, c.st)) return rc;
+    UVGHIP_TRY(hipEventRecord(c.done, c.st));
+  }
+  for (auto &c : pl->classes) UVGHIP_TRY(hipStreamWaitEvent(st, c.done, 0));
+  return 0;
+}
+
+extern "C" int uvghip_tiles_plan_layout(const uvghip_tiles_plan_t *pl, int *n_tiles, int *n_classes, int *n_substreams)
+{
+  if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (n_tiles) *n_tiles = (int)pl->tiles.size();
+  if (n_classes) *n_classes = (int)pl->classes.size();
+  if (n_substreams) {
+    int s = 0;
+    for (const uvghip_rect_t &t : pl->tiles) s += (t.h + 63) / 64;
+    *n_substreams = s;
+  }
+  return 0;
+}
+
+// Where tile `tile` (raster order) of picture `picture` lives: the loop plan of its size and its picture index there -- for
+// uvghip_loop_plan_results / _slice_data on a tile's own decisions and substreams.
+extern "C" int uvghip_tiles_plan_tile(const uvghip_tiles_plan_t *pl, int picture, int tile, uvghip_loop_plan_t **plan, int *index, uvghip_rect_t *rect, int *first_ctu)
+{
+  if (!pl || picture < 0 || picture >= pl->n || tile < 0 || tile >= (int)pl->tiles.size()) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const auto &c = pl->classes[pl->cls_of[tile]];
+  if (plan) *plan = c.plan;
+  if (index) *index = picture * (int)c.ids.size() + pl->slot_of[tile];
+  if (rect) *rect = pl->tiles[tile];
+  if (first_ctu) *first_ctu = pl->first_ctu[tile];
+  return 0;
+}
+
+// The NAL units of pictures [first, first + count) of the group after a run, as pictures first_poc, first_poc + 1, ... of the stream: per
+// picture the slice NAL -- the one-tile header, the entry points of ALL substreams, the tiles' rows in tile raster order -- and the hash SEI
+// of the whole output picture, one after the other into `out` (lens[i] bytes each).  Waits for the stream (the bytes are host memory):
+// twice for the whole range.  Behind the encoder's parameter sets (its PPS carries the tile grid, :768-791) these bytes complete the .266.
+extern "C" int uvghip_tiles_plan_nals(uvghip_tiles_plan_t *pl, int first, int count, int first_poc, uint8_t *out, size_t cap, size_t *lens, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!pl || first < 0 || count <= 0 || first + count > pl->n || first_poc < 0 || !lens || (!out && cap)) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  hipStream_t st = uvghip_stream(stream);
+  for (int i = first; i < first + count; ++i) {
+    const uvghip_loop_picture_t &q = pl->pics[i];
+    if (int rc = uvghip_picture_checksum(pl->bitdepth, q.out_y, q.out_stride, q.out_u, q.out_v, q.out_stride_c, pl->w, pl->h, pl->sums + 3 * (size_t)i, stream)) return rc;
+  }
+  std::vector<uint32_t> sums((size_t)3 * count);
+  UVGHIP_TRY(hipMemcpyAsync(sums.data(), pl->sums + 3 * (size_t)first, sums.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  // every class's row lengths of the range (a class's pictures are [picture][tile of the class]: the range is contiguous)
+  struct view { const uint8_t *rows; const int32_t *row_bytes; int row_cap, hc, per; std::vector<int32_t> nb; };
+  std::vector<view> v(pl->classes.size());
+  for (size_t k = 0; k < pl->classes.size(); ++k) {
+    if (int rc = uvghip_loop_plan_slice_data(pl->classes[k].plan, &v[k].rows, &v[k].row_bytes, &v[k].row_cap, &v[k].hc)) return rc;
+    v[k].per = (int)pl->classes[k].ids.size();
+    v[k].nb.resize((size_t)count * v[k].per * v[k].hc);
+    UVGHIP_TRY(hipMemcpyAsync(v[k].nb.data(), v[k].row_bytes + (size_t)first * v[k].per * v[k].hc, v[k].nb.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  }
+  UVGHIP_TRY(hipStreamSynchronize(st));
+  // a picture's substreams side by side at one pitch (the longest of the picture), pictures one after the other
+  int n_sub = 0;
+  for (const uvghip_rect_t &t : pl->tiles) n_sub += (t.h + 63) / 64;
+  std::vector<int32_t> nb((size_t)count * n_sub);
+  std::vector<size_t> base((size_t)count + 1), pitch(count);
+  size_t at = 0;
+  for (int i = 0; i < count; ++i) {
+    int s = 0, longest = 1;
+    for (size_t t = 0; t < pl->tiles.size(); ++t) {
+      const view &c = v[pl->cls_of[t]];
+      const int32_t *src = c.nb.data() + ((size_t)i * c.per + pl->slot_of[t]) * c.hc;
+      for (int r = 0; r < c.hc; ++r, ++s) {
+        if (src[r] <= 0 || src[r] > c.row_cap) return uvghip_set_error(hipErrorInvalidValue, "uvghip_tiles_plan_nals: a row overflowed its slot (or the plan has not run)");
+        nb[(size_t)i * n_sub + s] = src[r];
+        if (src[r] > longest) longest = src[r];
+      }
+    }
+    base[i] = at; pitch[i] = (size_t)longest;
+    at += pitch[i] * n_sub;
+  }
+  base[count] = at;
+  if (at > pl->host_cap) {
+    if (pl->host_rows) { UVGHIP_TRY(hipHostFree(pl->host_rows)); pl->host_rows = nullptr; pl->host_cap = 0; }
+    const size_t want = at + at / 4 + 4096;
+    UVGHIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pl->host_rows), want, hipHostMallocDefault));
+    pl->host_cap = want;
+  }
+  for (int i = 0; i < count; ++i) {
+    int s = 0;
+    for (size_t t = 0; t < pl->tiles.size(); ++t) {
+      const view &c = v[pl->cls_of[t]];
+      const size_t idx = (size_t)(first + i) * c.per + pl->slot_of[t];
+      for (int r = 0; r < c.hc; ++r, ++s)
+        UVGHIP_TRY(hipMemcpyAsync(pl->host_rows + base[i] + (size_t)s * pitch[i], c.rows + (idx * c.hc + r) * (size_t)c.row_cap, (size_t)nb[(size_t)i * n_sub + s],
+                                  hipMemcpyDeviceToHost, st));
+    }
+  }
+  UVGHIP_TRY(hipStreamSynchronize(st));
+  size_t used = 0;
+  for (int i = 0; i < count; ++i) {
+    size_t len = 0;
+    if (int rc = uvghip_write_picture_nals(first_poc + i, pl->sao_type != 0, pl->host_rows + base[i], pitch[i], nb.data() + (size_t)i * n_sub, n_sub, sums.data() + 3 * (size_t)i,
+                                           out ? out + used : nullptr, cap > used ? cap - used : 0, &len)) return rc;
+    lens[i] = len;
+    used += len;
+  }
+  return 0;
+}
+
+extern "C" void uvghip_tiles_plan_destroy(uvghip_tiles_plan_t *pl)
+{
+  if (pl) destroy(pl);
+}

@@ -263,6 +263,14 @@ SIGNATURES = {
     "uvghip_encode_slice_rows": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "uvghip_loop_plan_picture_nals": (c_int, [c_vp, c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_vp]),
     "uvghip_loop_plan_group_nals": (c_int, [c_vp, c_int, c_vp, ctypes.c_size_t, c_vp, c_vp]),
+    "uvghip_tile_grid": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "uvghip_tiles_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "uvghip_tiles_plan_create": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "uvghip_tiles_plan_run": (c_int, [c_vp, c_vp]),
+    "uvghip_tiles_plan_layout": (c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "uvghip_tiles_plan_tile": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "uvghip_tiles_plan_nals": (c_int, [c_vp, c_int, c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_vp]),
+    "uvghip_tiles_plan_destroy": (None, [c_vp]),
     "uvghip_loop_plan_alf_workspace_bytes": (ctypes.c_size_t, [c_vp]),
     "uvghip_loop_plan_alf_stage": (c_int, [c_vp, ALF_DECIDE_FN, c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "uvghip_picture_checksum": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
