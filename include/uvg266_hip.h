@@ -1077,6 +1077,11 @@ UVGHIP_API int uvghip_loop_plan_alf_stage(uvghip_loop_plan_t *plan, uvghip_alf_d
  * y >> 8) & 0xff, modulo 2^32.  sums: three uint32 in DEVICE memory (Y, U, V), zeroed and filled on the stream. */
 UVGHIP_API int uvghip_picture_checksum(int bitdepth, const void *plane_y, int stride_y, const void *plane_u, const void *plane_v,
                                        int stride_c, int width, int height, uint32_t *sums, void *stream);
+/* ... of the rectangle [x0, x0 + width) x [y0, y0 + height) (luma samples, even) of the picture whose planes are given, ADDED to sums (the
+ * caller zeroes them): a sample's term depends on the sample and its position in the picture only, so the sums of rectangles that tile the
+ * picture add up to uvghip_picture_checksum's -- tiles on several devices contribute with an all-reduce of three words. */
+UVGHIP_API int uvghip_picture_checksum_rect(int bitdepth, const void *plane_y, int stride_y, const void *plane_u, const void *plane_v,
+                                            int stride_c, int x0, int y0, int width, int height, uint32_t *sums, void *stream);
 
 /* replaces: for an IDR picture of an all-intra (-p 1) stream in the configuration of uvghip_ctu_plan_create (WPP, one slice, picture
  * header in the slice header): uvg_nal_write + uvg_encoder_state_write_bitstream_slice_header with the entry points
@@ -1190,6 +1195,22 @@ UVGHIP_API int uvghip_tiles_plan_layout(const uvghip_tiles_plan_t *plan, int *n_
 UVGHIP_API int uvghip_tiles_plan_tile(const uvghip_tiles_plan_t *plan, int picture, int tile, uvghip_loop_plan_t **loop_plan, int *index, uvghip_rect_t *rect, int *first_ctu);
 UVGHIP_API int uvghip_tiles_plan_nals(uvghip_tiles_plan_t *plan, int first, int count, int first_poc, uint8_t *out, size_t cap, size_t *lens, void *stream);
 UVGHIP_API void uvghip_tiles_plan_destroy(uvghip_tiles_plan_t *plan);
+/* The tiles of a picture over the devices of a node ("independent units exist at ... tiles").  Tiles share nothing -- no
+ * neighbour in the search, no sample in the filters --, so under the closed loop they are the one partition of ONE picture whose parts run
+ * side by side from the first CTU on (CTU-row bands wait for the band above), and the only exchange is at the picture's end: the substreams'
+ * lengths and bytes and three words of checksum go to whoever writes the NAL units.
+ * uvghip_tiles_plan_create_owned: owned[cols * rows] (raster order of the tiles; NULL = all): the tiles this device searches, filters and
+ * codes.  Pictures, tables and the layout of coeff / models are the whole picture's on every device; a device writes its tiles' parts.
+ * uvghip_tiles_plan_substreams: after a run, in HOST memory: lens[count][n_substreams] (uvghip_tiles_plan_layout) -- every substream's length
+ * in the order of the bitstream, 0 for the tiles of other devices --, the owned substreams' bytes one after the other in that order
+ * (*used bytes; an error beyond cap), sums[count][3] -- the owned tiles' terms of the output picture's checksum
+ * (uvghip_picture_checksum_rect).  Over the devices lengths and sums ADD UP (an all-reduce / a gather); uvghip_write_picture_nals then
+ * writes what uvghip_tiles_plan_nals writes on one device (tests/test_gpu_tiles.py with emulated ranks, tests/test_tiles.py with gloo). */
+UVGHIP_API size_t uvghip_tiles_workspace_bytes_owned(int bitdepth, int n_pictures, int pic_w, int pic_h, int cols, int rows, const uint8_t *owned);
+UVGHIP_API int uvghip_tiles_plan_create_owned(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_loop_picture_t *pictures, int n_pictures, int tile_cols,
+                                              int tile_rows, const uint8_t *owned, int sao_type, void *workspace, uvghip_tiles_plan_t **plan_out);
+UVGHIP_API int uvghip_tiles_plan_substreams(uvghip_tiles_plan_t *plan, int first, int count, int32_t *lens, uint8_t *bytes, size_t cap, size_t *used, uint32_t *sums,
+                                            void *stream);
 
 /* ------------------- (8) P / B pictures: candidate lists of the inter search ---------------------------------------------- */
 

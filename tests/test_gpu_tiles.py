@@ -121,3 +121,44 @@ def test_tiles_in_strided_planes_and_refusals(hip):
     assert stream[stream.find(b"\x00\x00\x01\x00\x41"):] == tl.nals()[0]
     with pytest.raises(ValueError):
         api.TiledLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), [tuple(src)], (6, 1))          # more tile columns than CTU columns
+
+
+@pytest.mark.parametrize("name,world", [("ref_tiles_264x136_8_qp27_2x2_1frames", 2), ("ref_tiles_416x240_10_qp32_3x2_2frames", 3), ("ref_tiles_320x192_8_qp22_5x1_1frames", 4),
+                                        ("ref_tiles_1920x1080_8_qp22_2x2_2frames_crc", 4), ("ref_tiles_3840x2160_10_qp22_4x2_1frames_crc", 8)])
+def test_tiles_over_emulated_ranks(hip, name, world):
+    """The tiles of a picture over the devices of a node, emulated on one: every "rank" has its own buffers and a plan of the tiles it owns
+    (uvghip_tiles_plan_create_owned), touches nothing outside them, and what the ranks contribute (uvghip_tiles_plan_substreams: lengths,
+    bytes, checksum terms) adds up to the encoder's NAL units (uvg266_amd.tiles.write_nals; the exchange itself: tests/test_tiles.py, gloo)."""
+    import torch
+    from uvg266_amd import api, tiles
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, cols, rows = (int(a) for a in g["meta"])
+    rects, _ = api.tile_grid(W, Hh, cols, rows)
+    owner = tiles.assign(rects, world)
+    src = []
+    for poc, t in enumerate(g["ts"]):
+        y, u, v = H.varied_picture(W, Hh, int(t), depth)
+        src.append(tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in (y, u, v)))
+    prm = H.search_params(W, Hh, qp)
+    parts = []
+    for rank in range(world):
+        tl = api.TiledLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), src, (cols, rows), owned=owner == rank)
+        for o in tl.out:
+            for p in o:
+                p.fill_(5)          # poison: a rank must not write outside its tiles
+        tl.run()
+        lens, data, sums = tl.substreams()
+        with pytest.raises(RuntimeError):
+            tl.nals()               # a part of the tiles cannot write the picture's NAL units by itself
+        for i in range(tl.n):
+            for t, (tx, ty, tw, th) in enumerate(tuple(int(a) for a in r) for r in rects):
+                if owner[t] != rank:
+                    assert all(bool((p[(ty >> c):(ty + th) >> c, (tx >> c):(tx + tw) >> c] == 5).all()) for p, c in zip(tl.out[i], (0, 1, 1))), "a tile of another rank was written"
+        parts.append((lens, data, sums))
+        del tl
+    nals = b"".join(tiles.write_nals(np.stack([p[0] for p in parts]), [p[1] for p in parts], np.stack([p[2] for p in parts])))
+    if "bitstream" in g.files:
+        stream = g["bitstream"].tobytes()
+        assert stream[stream.find(b"\x00\x00\x01\x00\x41"):] == nals
+    else:
+        assert len(nals) == int(g["bitstream_tail_len"]) and zlib.crc32(nals) == int(g["bitstream_tail_crc"])

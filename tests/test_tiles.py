@@ -99,3 +99,107 @@ def test_a_tile_is_a_picture_of_its_own(orc, name):
     at = stream.find(b"\x00\x00\x01\x00\x41")
     assert at > 0 and stream[:at] + mine == stream          # parameter sets (the encoder's: its PPS carries the grid) + these bytes = the whole .266
 
+
+
+# ---- the tiles of a picture over the ranks of a node (uvg266_amd/tiles.py) ---------------------------------------------------------------
+
+def test_assign_is_a_balanced_partition():
+    from uvg266_amd import api, tiles
+    for W, Hh, cols, rows in [(1920, 1080, 2, 2), (1920, 1080, 4, 2), (3840, 2160, 4, 2), (3840, 2160, 8, 4), (416, 240, 3, 2)]:
+        rects, _ = api.tile_grid(W, Hh, cols, rows)
+        for world in (1, 2, 3, 4, 8):
+            owner = tiles.assign(rects, world)
+            assert owner.min() >= 0 and owner.max() < world and len(owner) == cols * rows
+            counts = np.bincount(owner, minlength=world)
+            assert counts.max() - counts.min() <= 1 or cols * rows < world          # near-equal tiles: near-equal counts
+            assert np.array_equal(owner, tiles.assign(rects, world))                   # every rank computes the same table
+    rects, _ = api.tile_grid(3840, 2160, 4, 2)
+    assert sorted(tiles.assign(rects, 8)) == list(range(8))                           # configs[3]'s picture in 4 x 2 tiles: a tile per GPU
+
+
+def golden_contribution(g, rects, owner, rank):
+    """What a rank owning owner == rank would hand to tiles.gather_nals, cut out of the encoder's own run: its tiles' substreams and the
+    terms of its tiles' samples in the picture checksum (position-dependent: the mask takes the sample's place in the PICTURE)."""
+    W, Hh, depth = (int(a) for a in g["meta"][:3])
+    n_sub = int(sum((r[3] + 63) // 64 for r in rects))
+    count = len(g["ts"])
+    lens = np.zeros((count, n_sub), np.int32)
+    sums = np.zeros((count, 3), np.uint32)
+    data = []
+    off = g["row_off"]
+    for i in range(count):
+        planes = np.split(g["final"][i].astype(np.int64), [W * Hh, W * Hh + W * Hh // 4])
+        planes = [planes[0].reshape(Hh, W), planes[1].reshape(Hh // 2, W // 2), planes[2].reshape(Hh // 2, W // 2)]
+        s = 0
+        for t, (tx, ty, tw, th) in enumerate(tuple(int(a) for a in r) for r in rects):
+            for r in range((th + 63) // 64):
+                if owner[t] == rank:
+                    b = g["row_bytes"][off[i * n_sub + s]:off[i * n_sub + s + 1]]
+                    lens[i, s] = len(b)
+                    data.append(b)
+                s += 1
+            if owner[t] != rank:
+                continue
+            for c, p in enumerate(planes):
+                sh = 1 if c else 0
+                ys, xs = np.mgrid[ty >> sh:(ty + th) >> sh, tx >> sh:(tx + tw) >> sh]
+                m = (xs ^ ys ^ (xs >> 8) ^ (ys >> 8)) & 0xFF
+                v = p[ty >> sh:(ty + th) >> sh, tx >> sh:(tx + tw) >> sh]
+                term = ((v & 0xFF) ^ m).sum() + (((v >> 8) & 0xFF) ^ m).sum() * (depth > 8)
+                sums[i, c] = (int(sums[i, c]) + int(term)) & 0xFFFFFFFF
+    return lens, np.concatenate(data) if data else np.zeros(0, np.uint8), sums
+
+
+@pytest.mark.parametrize("name,world", [("ref_tiles_264x136_8_qp27_2x2_1frames", 2), ("ref_tiles_416x240_10_qp32_3x2_2frames", 3), ("ref_tiles_320x192_8_qp22_5x1_1frames", 4)])
+def test_write_nals_from_the_ranks_contributions(name, world):
+    """tiles.write_nals (no process group: the contributions side by side) = the encoder's bytes behind its parameter sets."""
+    from uvg266_amd import api, tiles
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, cols, rows = (int(a) for a in g["meta"])
+    rects, _ = api.tile_grid(W, Hh, cols, rows)
+    owner = tiles.assign(rects, world)
+    parts = [golden_contribution(g, rects, owner, r) for r in range(world)]
+    nals = tiles.write_nals(np.stack([p[0] for p in parts]), [p[1] for p in parts], np.stack([p[2] for p in parts]))
+    stream = g["bitstream"].tobytes()
+    at = stream.find(b"\x00\x00\x01\x00\x41")
+    assert stream[at:] == b"".join(nals)
+    with pytest.raises(ValueError):          # a substream nobody owns
+        tiles.write_nals(np.stack([p[0] for p in parts[1:]]), [p[1] for p in parts[1:]], np.stack([p[2] for p in parts[1:]]))
+
+
+def _tile_rank(rank, world, port, name, q):
+    import os
+    import torch.distributed as dist
+    from uvg266_amd import api, tiles
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, cols, rows = (int(a) for a in g["meta"])
+    rects, _ = api.tile_grid(W, Hh, cols, rows)
+    owner = tiles.assign(rects, world)
+    # (the device's part -- api.TiledLoop(owned=owner == rank).substreams() -- is played by the encoder's own record here: no GPU)
+    nals = tiles.gather_nals(golden_contribution(g, rects, owner, rank), first_poc=0, sao=True)
+    assert (nals is None) == (rank != 0)
+    if rank == 0:
+        q.put(b"".join(nals))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("ref_tiles_264x136_8_qp27_2x2_1frames", 2), ("ref_tiles_416x240_10_qp32_3x2_2frames", 3)])
+def test_tiles_over_gloo_ranks(name, world):
+    """2 and 3 processes, one per "GPU": every rank contributes its tiles, rank 0 ends up with the encoder's bytes."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_tile_rank, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    stream = H.ctu_golden(name)["bitstream"].tobytes()
+    assert stream[stream.find(b"\x00\x00\x01\x00\x41"):] == got

@@ -888,7 +888,9 @@ class TiledLoop:
     device planes.  Outputs stay on the device: rec[i] / out[i] (whole pictures: before / after the in-loop filters), cu[i] (picture
     raster), coeff[i] / models[i] (the CTUs in TILE-SCAN order: the order of the bitstream)."""
 
-    def __init__(self, params, src, tiles, sao_type=3):
+    def __init__(self, params, src, tiles, sao_type=3, owned=None):
+        """owned: per tile (raster order) whether THIS device searches, filters and codes it (uvghip_tiles_plan_create_owned: the tiles of a
+        picture over the devices of a node, uvg266_amd.tiles); None = all."""
         import ctypes
         self.P, self.n = params, len(src)
         self.cols, self.rows = int(tiles[0]), int(tiles[1])
@@ -898,25 +900,33 @@ class TiledLoop:
         self.depth = _depth(src[0][0])
         self.L = _lib.init(dev.index or 0)
         self.src = src
-        self.rec = [tuple(torch.zeros_like(p) for p in s) for s in src]
-        self.out = [tuple(torch.zeros_like(p) for p in s) for s in src]
+        self.rec = [tuple(torch.zeros(p.shape, dtype=p.dtype, device=dev) for p in s) for s in src]
+        self.out = [tuple(torch.zeros(p.shape, dtype=p.dtype, device=dev) for p in s) for s in src]
         ctus = self.wc * self.hc
         self.cu = [torch.zeros((self.hc * 16, self.wc * 16, 32), dtype=torch.uint8, device=dev) for _ in src]
         self.coeff = [torch.zeros((ctus, 6144), dtype=torch.int16, device=dev) for _ in src]
         self.models = [torch.zeros((ctus, 3, 257), dtype=torch.int32, device=dev) for _ in src]
         lp = (_lib.LoopPicture * self.n)()
+
+        def _plane(t):          # the source planes may be views into larger allocations: rows contiguous, any stride between them
+            assert t.is_cuda and t.dim() == 2 and t.stride(1) == 1, "device-resident plane with contiguous rows required"
+            return ctypes.c_void_p(t.data_ptr())
         for i, (s, r, o) in enumerate(zip(src, self.rec, self.out)):
-            sp = _lib.CtuPicture(_dev(s[0]), _dev(s[1]), _dev(s[2]), s[0].stride(0), s[1].stride(0), _dev(r[0]), _dev(r[1]), _dev(r[2]),
+            sp = _lib.CtuPicture(_plane(s[0]), _plane(s[1]), _plane(s[2]), s[0].stride(0), s[1].stride(0), _dev(r[0]), _dev(r[1]), _dev(r[2]),
                                  r[0].stride(0), r[1].stride(0), _dev(self.cu[i]), self.wc * 16, 0, _dev(self.coeff[i]), _dev(self.models[i]))
             lp[i] = _lib.LoopPicture(sp, _dev(o[0]), _dev(o[1]), _dev(o[2]), o[0].stride(0), o[1].stride(0))
         self.pics = lp
-        nbytes = self.L.uvghip_tiles_workspace_bytes(self.depth, self.n, W, H, self.cols, self.rows)
+        self.owned = None if owned is None else np.ascontiguousarray(np.asarray(owned) != 0, np.uint8)
+        if self.owned is not None and self.owned.size != self.cols * self.rows:
+            raise ValueError("owned: one entry per tile")
+        own = None if self.owned is None else self.owned.ctypes.data
+        nbytes = self.L.uvghip_tiles_workspace_bytes_owned(self.depth, self.n, W, H, self.cols, self.rows, own)
         if not nbytes:
-            raise ValueError("uvghip_tiles_workspace_bytes: the tile grid does not fit the picture")
+            raise ValueError("uvghip_tiles_workspace_bytes: the tile grid does not fit the picture (or no tile is owned)")
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self.plan = ctypes.c_void_p()
-        _lib.check(self.L.uvghip_tiles_plan_create(self.depth, ctypes.byref(self.P), lp, self.n, self.cols, self.rows, sao_type, _dev(self.ws), ctypes.byref(self.plan)),
-                   "uvghip_tiles_plan_create")
+        _lib.check(self.L.uvghip_tiles_plan_create_owned(self.depth, ctypes.byref(self.P), lp, self.n, self.cols, self.rows, own, sao_type, _dev(self.ws),
+                                                         ctypes.byref(self.plan)), "uvghip_tiles_plan_create_owned")
         a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _lib.check(self.L.uvghip_tiles_plan_layout(self.plan, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "uvghip_tiles_plan_layout")
         self.n_tiles, self.n_classes, self.n_substreams = a.value, b.value, c.value
@@ -941,6 +951,22 @@ class TiledLoop:
             out.append(self._nal_buf[at:at + lens[i]].tobytes())
             at += lens[i]
         return out
+
+    def substreams(self, first=0, count=None):
+        """uvghip_tiles_plan_substreams: what this device contributes to the NAL units of pictures [first, first + count) after run():
+        (lens [count, n_substreams] int32 -- 0 for the tiles of other devices --, the owned substreams' bytes in the order of the bitstream
+        (uint8), sums [count, 3] uint32: the owned tiles' terms of the output pictures' checksums).  Over the devices lengths and sums add up."""
+        import ctypes
+        count = self.n - first if count is None else count
+        lens = np.zeros((count, self.n_substreams), np.int32)
+        sums = np.zeros((count, 3), np.uint32)
+        cap = count * (self.hc * (3 * 64 * int(self.P.pic_w)) * (1 if self.depth == 8 else 2))
+        if getattr(self, "_sub_buf", None) is None or self._sub_buf.size < cap:
+            self._sub_buf = np.empty(cap, np.uint8)
+        used = ctypes.c_size_t(0)
+        _lib.check(self.L.uvghip_tiles_plan_substreams(self.plan, first, count, lens.ctypes.data, self._sub_buf.ctypes.data, self._sub_buf.size, ctypes.byref(used),
+                                                       sums.ctypes.data, _stream()), "uvghip_tiles_plan_substreams")
+        return lens, self._sub_buf[:used.value].copy(), sums
 
     def tile(self, picture, tile):
         """uvghip_tiles_plan_tile -> (loop plan handle, picture index there, (x, y, w, h), first CTU in tile scan)."""

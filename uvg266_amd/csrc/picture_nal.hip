@@ -17,12 +17,12 @@ namespace {
 
 // sum over the samples of (low byte ^ mask) [+ (high byte ^ mask)], mask = (x ^ y ^ x >> 8 ^ y >> 8) & 0xff, modulo 2^32
 template <typename PX>
-__global__ void __launch_bounds__(256) checksum_kernel(const PX *__restrict__ plane, int stride, int width, int height, uint32_t *__restrict__ sum)
+__global__ void __launch_bounds__(256) checksum_kernel(const PX *__restrict__ plane, int stride, int x0, int y0, int width, int height, uint32_t *__restrict__ sum)
 {
   uint32_t acc = 0;
   const size_t n = (size_t)width * height;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const int y = (int)(i / width), x = (int)(i - (size_t)y * width);
+    const int ry = (int)(i / width), y = y0 + ry, x = x0 + (int)(i - (size_t)ry * width);
     const uint32_t v = plane[(size_t)y * stride + x];
     const uint32_t mask = (uint32_t)((x & 0xff) ^ (y & 0xff) ^ (x >> 8) ^ (y >> 8)) & 0xffu;
     acc += (v & 0xffu) ^ mask;
@@ -173,13 +173,27 @@ extern "C" int uvghip_picture_checksum(int bitdepth, const void *plane_y, int st
     return uvghip_set_error(hipErrorInvalidValue, __func__);
   hipStream_t st = uvghip_stream(stream);
   UVGHIP_TRY(hipMemsetAsync(sums, 0, 3 * sizeof(uint32_t), st));
+  return uvghip_picture_checksum_rect(bitdepth, plane_y, stride_y, plane_u, plane_v, stride_c, 0, 0, width, height, sums, stream);
+}
+
+// ... of a rectangle of the picture, ADDED to sums: the checksum is a sum over samples of a function of the sample and its position in the
+// PICTURE, so the sums of rectangles that tile the picture add up to the picture's (tiles on several devices: an all-reduce of three words).
+extern "C" int uvghip_picture_checksum_rect(int bitdepth, const void *plane_y, int stride_y, const void *plane_u, const void *plane_v, int stride_c,
+                                            int x0, int y0, int width, int height, uint32_t *sums, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
+  if (!plane_y || !plane_u || !plane_v || !sums || width <= 0 || height <= 0 || x0 < 0 || y0 < 0 || ((width | height | x0 | y0) & 1) || stride_y < x0 + width ||
+      stride_c < (x0 + width) / 2)
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  hipStream_t st = uvghip_stream(stream);
   const void *planes[3] = {plane_y, plane_u, plane_v};
   for (int c = 0; c < 3; ++c) {
-    const int w = c ? width / 2 : width, h = c ? height / 2 : height, stride = c ? stride_c : stride_y;
+    const int w = c ? width / 2 : width, h = c ? height / 2 : height, stride = c ? stride_c : stride_y, ox = c ? x0 / 2 : x0, oy = c ? y0 / 2 : y0;
     const size_t n = (size_t)w * h;
     const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16) < 2048 ? (n + 256 * 16 - 1) / (256 * 16) : 2048);
-    if (bitdepth == 8) checksum_kernel<uint8_t><<<blocks, 256, 0, st>>>(static_cast<const uint8_t *>(planes[c]), stride, w, h, sums + c);
-    else checksum_kernel<uint16_t><<<blocks, 256, 0, st>>>(static_cast<const uint16_t *>(planes[c]), stride, w, h, sums + c);
+    if (bitdepth == 8) checksum_kernel<uint8_t><<<blocks, 256, 0, st>>>(static_cast<const uint8_t *>(planes[c]), stride, ox, oy, w, h, sums + c);
+    else checksum_kernel<uint16_t><<<blocks, 256, 0, st>>>(static_cast<const uint16_t *>(planes[c]), stride, ox, oy, w, h, sums + c);
   }
   UVGHIP_CHECK_LAUNCH();
 }

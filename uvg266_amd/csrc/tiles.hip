@@ -31,7 +31,9 @@ struct uvghip_tiles_plan {
     hipEvent_t done;
   };
   std::vector<size_class> classes;
-  std::vector<int> cls_of, slot_of;          // per tile: its class and its index among the class's tiles
+  std::vector<int> cls_of, slot_of;          // per tile: its class and its index among the class's tiles (-1: a tile another device owns)
+  std::vector<uint8_t> owned;                // per tile
+  bool all_owned;
   std::vector<uvghip_loop_picture_t> pics;
   hipEvent_t fork;
   uint32_t *sums;                            // device: [n][3]
@@ -70,10 +72,11 @@ int grid(int pic_w, int pic_h, int cols, int rows, std::vector<uvghip_rect_t> &t
 }
 
 struct class_key { int w, h, count; };
-void classes_of(const std::vector<uvghip_rect_t> &tiles, std::vector<class_key> &keys, std::vector<int> &cls_of, std::vector<int> &slot_of)
+void classes_of(const std::vector<uvghip_rect_t> &tiles, const uint8_t *owned, std::vector<class_key> &keys, std::vector<int> &cls_of, std::vector<int> &slot_of)
 {
-  cls_of.resize(tiles.size()); slot_of.resize(tiles.size());
+  cls_of.assign(tiles.size(), -1); slot_of.assign(tiles.size(), -1);
   for (size_t t = 0; t < tiles.size(); ++t) {
+    if (owned && !owned[t]) continue;
     size_t k = 0;
     while (k < keys.size() && (keys[k].w != tiles[t].w || keys[k].h != tiles[t].h)) ++k;
     if (k == keys.size()) keys.push_back(class_key{tiles[t].w, tiles[t].h, 0});
@@ -109,12 +112,18 @@ extern "C" int uvghip_tile_grid(int pic_w, int pic_h, int cols, int rows, uvghip
 
 extern "C" size_t uvghip_tiles_workspace_bytes(int bitdepth, int n_pictures, int pic_w, int pic_h, int cols, int rows)
 {
+  return uvghip_tiles_workspace_bytes_owned(bitdepth, n_pictures, pic_w, pic_h, cols, rows, nullptr);
+}
+
+extern "C" size_t uvghip_tiles_workspace_bytes_owned(int bitdepth, int n_pictures, int pic_w, int pic_h, int cols, int rows, const uint8_t *owned)
+{
   if ((bitdepth != 8 && bitdepth != 10) || n_pictures <= 0 || pic_w <= 0 || pic_h <= 0) return 0;
   std::vector<uvghip_rect_t> t;
   std::vector<int> f, cls_of, slot_of;
   if (grid(pic_w, pic_h, cols, rows, t, f)) return 0;
   std::vector<class_key> keys;
-  classes_of(t, keys, cls_of, slot_of);
+  classes_of(t, owned, keys, cls_of, slot_of);
+  if (keys.empty()) return 0;
   size_t at = align_up((size_t)n_pictures * 3 * sizeof(uint32_t), 256);
   for (const class_key &k : keys) at += align_up(uvghip_loop_workspace_bytes(bitdepth, n_pictures * k.count, k.w, k.h), 256);
   return at;
@@ -124,6 +133,16 @@ extern "C" size_t uvghip_tiles_workspace_bytes(int bitdepth, int n_pictures, int
 // TILE-SCAN order (the order of the bitstream: tile after tile, raster inside a tile).  params: the whole picture's (pic_w, pic_h).
 extern "C" int uvghip_tiles_plan_create(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_loop_picture_t *pictures, int n_pictures, int tile_cols, int tile_rows,
                                         int sao_type, void *workspace, uvghip_tiles_plan_t **plan_out)
+{
+  return uvghip_tiles_plan_create_owned(bitdepth, params, pictures, n_pictures, tile_cols, tile_rows, nullptr, sao_type, workspace, plan_out);
+}
+
+// ... of the tiles this device OWNS (owned[cols * rows], raster order; NULL = all): the tiles of a picture over the devices of a node.  Tiles
+// share nothing -- no halo in the search, none in the filters (pps_loop_filter_across_tiles_enabled_flag = 0) --, so the only exchange of an
+// all-intra picture is at its end: the substreams and the three words of the checksum (uvghip_tiles_plan_substreams) go to whoever writes
+// the NAL units.  The planes, tables and the workspace layout are those of the whole picture on every device; a device touches its tiles' parts.
+extern "C" int uvghip_tiles_plan_create_owned(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_loop_picture_t *pictures, int n_pictures, int tile_cols,
+                                              int tile_rows, const uint8_t *owned, int sao_type, void *workspace, uvghip_tiles_plan_t **plan_out)
 {
   UVGHIP_REQUIRE_READY();
   UVGHIP_REQUIRE_DEPTH(bitdepth);
@@ -142,10 +161,14 @@ extern "C" int uvghip_tiles_plan_create(int bitdepth, const uvghip_ctu_params_t 
   }
   pl->pics.assign(pictures, pictures + n_pictures);
   std::vector<class_key> keys;
-  classes_of(pl->tiles, keys, pl->cls_of, pl->slot_of);
+  pl->owned.assign(pl->tiles.size(), 1);
+  pl->all_owned = true;
+  if (owned) for (size_t t = 0; t < pl->tiles.size(); ++t) { pl->owned[t] = owned[t] != 0; pl->all_owned = pl->all_owned && owned[t]; }
+  classes_of(pl->tiles, pl->owned.data(), keys, pl->cls_of, pl->slot_of);
+  if (keys.empty()) { delete pl; return uvghip_set_error(hipErrorInvalidValue, "uvghip_tiles_plan_create_owned: this device owns no tile"); }
   pl->classes.resize(keys.size());
   for (size_t k = 0; k < keys.size(); ++k) { pl->classes[k].w = keys[k].w; pl->classes[k].h = keys[k].h; pl->classes[k].plan = nullptr; pl->classes[k].st = nullptr; pl->classes[k].done = nullptr; }
-  for (size_t t = 0; t < pl->tiles.size(); ++t) pl->classes[pl->cls_of[t]].ids.push_back((int)t);
+  for (size_t t = 0; t < pl->tiles.size(); ++t) if (pl->owned[t]) pl->classes[pl->cls_of[t]].ids.push_back((int)t);
   unsigned char *ws = static_cast<unsigned char *>(workspace);
   pl->sums = reinterpret_cast<uint32_t *>(ws);
   size_t at = align_up((size_t)n_pictures * 3 * sizeof(uint32_t), 256);
@@ -190,13 +213,18 @@ extern "C" int uvghip_tiles_plan_run(uvghip_tiles_plan_t *pl, void *stream)
   if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);
   hipStream_t st = uvghip_stream(stream);
   if (pl->classes.size() == 1) return uvghip_loop_plan_run(pl->classes[0].plan, stream);
+  // classes 1.. on the plan's own streams, class 0 on the caller's: a uniform grid's four classes then take four streams, what the
+  // runtime's hardware queues carry side by side by default (GPU_MAX_HW_QUEUES = 4; a fifth stream shares a queue with another and the
+  // two launches run one after the other: measured, 4 x 4 tiles of one 1080p picture 219 -> ms)
   UVGHIP_TRY(hipEventRecord(pl->fork, st));
-  for (auto &c : pl->classes) {
+  for (size_t k = 1; k < pl->classes.size(); ++k) {
+    auto &c = pl->classes[k];
     UVGHIP_TRY(hipStreamWaitEvent(c.st, pl->fork, 0));
     if (int rc = uvghip_loop_plan_run(c.plan, c.st)) return rc;
     UVGHIP_TRY(hipEventRecord(c.done, c.st));
   }
-  for (auto &c : pl->classes) UVGHIP_TRY(hipStreamWaitEvent(st, c.done, 0));
+  if (int rc = uvghip_loop_plan_run(pl->classes[0].plan, stream)) return rc;
+  for (size_t k = 1; k < pl->classes.size(); ++k) UVGHIP_TRY(hipStreamWaitEvent(st, pl->classes[k].done, 0));
   return 0;
 }
 
@@ -218,6 +246,7 @@ extern "C" int uvghip_tiles_plan_layout(const uvghip_tiles_plan_t *pl, int *n_ti
 extern "C" int uvghip_tiles_plan_tile(const uvghip_tiles_plan_t *pl, int picture, int tile, uvghip_loop_plan_t **plan, int *index, uvghip_rect_t *rect, int *first_ctu)
 {
   if (!pl || picture < 0 || picture >= pl->n || tile < 0 || tile >= (int)pl->tiles.size()) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (!pl->owned[tile]) return uvghip_set_error(hipErrorInvalidValue, "uvghip_tiles_plan_tile: a tile another device owns");
   const auto &c = pl->classes[pl->cls_of[tile]];
   if (plan) *plan = c.plan;
   if (index) *index = picture * (int)c.ids.size() + pl->slot_of[tile];
@@ -234,6 +263,7 @@ extern "C" int uvghip_tiles_plan_nals(uvghip_tiles_plan_t *pl, int first, int co
 {
   UVGHIP_REQUIRE_READY();
   if (!pl || first < 0 || count <= 0 || first + count > pl->n || first_poc < 0 || !lens || (!out && cap)) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (!pl->all_owned) return uvghip_set_error(hipErrorInvalidValue, "uvghip_tiles_plan_nals: the plan holds a part of the tiles (uvghip_tiles_plan_substreams + uvghip_write_picture_nals)");
   hipStream_t st = uvghip_stream(stream);
   for (int i = first; i < first + count; ++i) {
     const uvghip_loop_picture_t &q = pl->pics[i];
@@ -297,6 +327,62 @@ extern "C" int uvghip_tiles_plan_nals(uvghip_tiles_plan_t *pl, int first, int co
     lens[i] = len;
     used += len;
   }
+  return 0;
+}
+
+// What this device contributes to the NAL units of pictures [first, first + count) after a run, in HOST memory: lens[count][n_substreams] --
+// the length of every substream of the picture in the order of the bitstream, 0 for those of tiles another device owns --, the owned
+// substreams' bytes one after the other in that order (pictures one after the other; *used bytes, an error beyond cap), and
+// sums[count][3]: the checksum terms of the owned tiles of the output picture (uvghip_picture_checksum_rect).  Over all devices the lengths
+// and the sums ADD UP to the picture's (every substream has one owner); whoever has them all calls uvghip_write_picture_nals.  Waits for
+// the stream.
+extern "C" int uvghip_tiles_plan_substreams(uvghip_tiles_plan_t *pl, int first, int count, int32_t *lens, uint8_t *bytes, size_t cap, size_t *used, uint32_t *sums,
+                                            void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!pl || first < 0 || count <= 0 || first + count > pl->n || !lens || !used || !sums || (!bytes && cap)) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  hipStream_t st = uvghip_stream(stream);
+  UVGHIP_TRY(hipMemsetAsync(pl->sums + 3 * (size_t)first, 0, (size_t)count * 3 * sizeof(uint32_t), st));
+  for (int i = first; i < first + count; ++i) {
+    const uvghip_loop_picture_t &q = pl->pics[i];
+    for (size_t t = 0; t < pl->tiles.size(); ++t) {
+      if (!pl->owned[t]) continue;
+      const uvghip_rect_t &r = pl->tiles[t];
+      if (int rc = uvghip_picture_checksum_rect(pl->bitdepth, q.out_y, q.out_stride, q.out_u, q.out_v, q.out_stride_c, r.x, r.y, r.w, r.h, pl->sums + 3 * (size_t)i, stream)) return rc;
+    }
+  }
+  UVGHIP_TRY(hipMemcpyAsync(sums, pl->sums + 3 * (size_t)first, (size_t)count * 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  struct view { const uint8_t *rows; const int32_t *row_bytes; int row_cap, hc, per; std::vector<int32_t> nb; };
+  std::vector<view> v(pl->classes.size());
+  for (size_t k = 0; k < pl->classes.size(); ++k) {
+    if (int rc = uvghip_loop_plan_slice_data(pl->classes[k].plan, &v[k].rows, &v[k].row_bytes, &v[k].row_cap, &v[k].hc)) return rc;
+    v[k].per = (int)pl->classes[k].ids.size();
+    v[k].nb.resize((size_t)count * v[k].per * v[k].hc);
+    UVGHIP_TRY(hipMemcpyAsync(v[k].nb.data(), v[k].row_bytes + (size_t)first * v[k].per * v[k].hc, v[k].nb.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  }
+  UVGHIP_TRY(hipStreamSynchronize(st));
+  int n_sub = 0;
+  for (const uvghip_rect_t &t : pl->tiles) n_sub += (t.h + 63) / 64;
+  size_t at = 0;
+  for (int i = 0; i < count; ++i) {
+    int s = 0;
+    for (size_t t = 0; t < pl->tiles.size(); ++t) {
+      const int hc = (pl->tiles[t].h + 63) / 64;
+      if (!pl->owned[t]) { for (int r = 0; r < hc; ++r, ++s) lens[(size_t)i * n_sub + s] = 0; continue; }
+      const view &c = v[pl->cls_of[t]];
+      const int32_t *src = c.nb.data() + ((size_t)i * c.per + pl->slot_of[t]) * c.hc;
+      const size_t idx = (size_t)(first + i) * c.per + pl->slot_of[t];
+      for (int r = 0; r < c.hc; ++r, ++s) {
+        if (src[r] <= 0 || src[r] > c.row_cap) return uvghip_set_error(hipErrorInvalidValue, "uvghip_tiles_plan_substreams: a row overflowed its slot (or the plan has not run)");
+        lens[(size_t)i * n_sub + s] = src[r];
+        if (at + (size_t)src[r] <= cap) UVGHIP_TRY(hipMemcpyAsync(bytes + at, c.rows + (idx * c.hc + r) * (size_t)c.row_cap, (size_t)src[r], hipMemcpyDeviceToHost, st));
+        at += (size_t)src[r];
+      }
+    }
+  }
+  UVGHIP_TRY(hipStreamSynchronize(st));
+  *used = at;
+  if (at > cap) return uvghip_set_error(hipErrorInvalidValue, "uvghip_tiles_plan_substreams: the output buffer is too small (see *used)");
   return 0;
 }
 
