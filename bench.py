@@ -478,6 +478,67 @@ def c2_clip(wl, device, frames=60, reps=2):
                     "the NAL units of the group come over in one download (uvghip_loop_plan_group_nals)"}
 
 
+def tiles_clip(wl, device, frames=60, grid=(6, 4), with_cpu=True):
+    """BASELINE configs[1]'s 60-picture clip under --tiles <grid> --wpp (uvghip_tiles_plan_*: csrc/tiles.hip), host memory to `.266` bytes in
+    host memory like c2_clip, and ONE picture alone with and without tiles.  Tiles are the reference's independent rectangles (no neighbour in
+    the search, no sample in the filters, own context models): the stream is the one the reference writes with the same --tiles, not c2_clip's
+    -- the first two pictures' NAL units are held to its run (tests/golden/ref_tiles_1920x1080_8_qp22_6x4_2frames_crc.npz) inside this
+    line.  What tiles buy is latency: a 1080p picture is 62 WPP diagonals, in 6 x 4 tiles 24 wavefronts of 13 side by side."""
+    import zlib
+    W, H, depth = wl["W"], wl["H"], wl["depth"]
+    P = api.ctu_params(W, H, QP)
+    host = [tuple(np.ascontiguousarray(p) for p in layout.synthetic_yuv420(W, H, t, depth)) for t in range(frames)]
+    src = [tuple(torch.empty(p.shape, dtype=torch.uint8 if depth == 8 else torch.uint16, device=device) for p in yuv) for yuv in host]
+    tl = api.TiledLoop(P, src, grid)
+    best, out = None, None
+    for _ in range(3):                            # the first pass is the warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for yuv, dst in zip(host, src):
+            for p, d in zip(yuv, dst):
+                d.copy_(torch.from_numpy(p), non_blocking=True)
+        tl.run()
+        out = tl.nals(0)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    res = {"value": round(frames / best, 2), "unit": f"frames/s (one 60-picture clip under --tiles {grid[0]}x{grid[1]} --wpp, host memory to .266 bytes in host memory)",
+           "frames": frames, "wall_ms": round(1e3 * best, 1), "bytes_out": int(sum(len(b) for b in out)), "tiles": f"{grid[0]}x{grid[1]}", "size_classes": tl.n_classes,
+           "substreams_per_picture": tl.n_substreams, "parity_checked": False}
+    name = f"ref_tiles_{W}x{H}_{depth}_qp{QP}_{grid[0]}x{grid[1]}_2frames_crc"
+    g = None
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    if os.path.exists(path):
+        g = np.load(path)
+        two = out[0] + out[1]
+        ok = len(two) == int(g["bitstream_tail_len"]) and zlib.crc32(two) == int(g["bitstream_tail_crc"])
+        finals = [zlib.crc32(np.concatenate([p.cpu().numpy().reshape(-1) for p in tl.out[i]]).tobytes()) == int(g["final_crc"][i]) for i in range(2)]
+        res["parity_checked"] = bool(ok and all(finals))
+        res["parity"] = {"golden": name, "items": "slice NAL + hash SEI of pictures 0 and 1 (length + CRC-32) and the CRC-32 of their output pictures vs the reference encoder's run "
+                                                  "with the same --tiles"}
+    del tl
+    # one picture alone: the latency tiles are for
+    one = {}
+    for gr in ((1, 1), grid):
+        t1 = api.TiledLoop(P, src[:1], gr)
+        t1.run(); t1.nals(0)
+        b1 = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            t1.run()
+            t1.nals(0)
+            dt = time.perf_counter() - t0
+            b1 = dt if b1 is None or dt < b1 else b1
+        one["no_tiles" if gr == (1, 1) else f"tiles_{gr[0]}x{gr[1]}"] = round(1e3 * b1, 1)
+        del t1
+    res["one_picture_ms"] = one
+    res["note"] = ("the reference's tiles: independent rectangles, so the bytes differ from c2_clip's stream (the reference's with the same --tiles); one loop plan per tile size "
+                   "on its own stream, the tiles of a picture side by side on the device")
+    if with_cpu:
+        res["cpu_baseline"] = cpu_baseline_reference(wl, frames=frames, extra=("--tiles", f"{grid[0]}x{grid[1]}", "--wpp"))
+    return res
+
+
 def c4_clip(device, frames=60, with_cpu=True):
     """The 60-picture 3840x2160 10-bit clip of BASELINE configs[3]'s geometry, all-intra (-p 1 --preset medium at the bench's QP; the P / B
     + ALF combination of configs[3] as written is not built: DESIGN.md section 7), host memory to `.266` bytes in host memory as c2_clip:
@@ -948,7 +1009,7 @@ def closed_loop(wl, steps, warmup, in_flight, device, rank, world, dist, groups=
     return cls, F, elapsed, sum(m[0] for m in ms), sum(m[1] for m in ms)
 
 
-def cpu_baseline_reference(wl, frames=96):
+def cpu_baseline_reference(wl, frames=96, extra=()):
     """The reference encoder itself (oracle/_ref/uvg266_8: /root/reference built by oracle/build_ref.sh with plain gcc, AVX2 strategies
     and its own thread pool) on the GPU box's host cores: `frames` synthetic pictures of the workload, -p 1 --preset medium at the
     bench's QP, threads and frame parallelism at the encoder's defaults (auto).  A WHOLE encode (search, filters, bitstream): what the
@@ -969,7 +1030,7 @@ def cpu_baseline_reference(wl, frames=96):
             for t in range(frames):
                 for pl in layout.synthetic_yuv420(W, H, t, depth):
                     f.write(np.ascontiguousarray(pl).tobytes())
-        cmd = [exe, "-i", yuv, "--input-res", f"{W}x{H}", "-n", str(frames), "-p", "1", "--preset", "medium", "-q", str(QP), "-o", os.path.join(tmp, "out.266")]
+        cmd = [exe, "-i", yuv, "--input-res", f"{W}x{H}", "-n", str(frames), "-p", "1", "--preset", "medium", "-q", str(QP), "-o", os.path.join(tmp, "out.266")] + list(extra)
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
@@ -979,7 +1040,7 @@ def cpu_baseline_reference(wl, frames=96):
         if r.returncode != 0 or not os.path.getsize(os.path.join(tmp, "out.266")):
             return None
     return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "reference",
-            "sample": f"{frames} synthetic {W}x{H} {depth}-bit pictures through the reference encoder's CLI (-p 1 --preset medium -q {QP}, --threads / --owf auto "
+            "sample": f"{frames} synthetic {W}x{H} {depth}-bit pictures through the reference encoder's CLI (-p 1 --preset medium -q {QP}{''.join(' ' + e for e in extra)}, --threads / --owf auto "
                       f"on {cores} host threads, AVX2 strategies), wall time {dt:.1f} s incl. reading the input: a whole encode"}
 
 
@@ -1131,6 +1192,8 @@ def main():
     ap.add_argument("--only-c3-clip", action="store_true", help="time only extra_workloads.c3_clip and print it (development)")
     ap.add_argument("--ra-clip-frames", type=int, default=65, help="extra_workloads.ra_clip: coded pictures of the ONE random-access (--gop 16) clip that are timed (0: skip)")
     ap.add_argument("--no-c4-clip", dest="c4_clip", action="store_false", help="skip extra_workloads.c4_clip (the 60-picture 2160p 10-bit clip and its CPU baseline)")
+    ap.add_argument("--no-tiles-clip", dest="tiles_clip", action="store_false", help="skip extra_workloads.tiles_clip (the 60-picture clip under --tiles 6x4 --wpp and its CPU baseline)")
+    ap.add_argument("--only-tiles-clip", action="store_true", help="time only extra_workloads.tiles_clip and print it (development)")
     ap.add_argument("--only-c4-clip", action="store_true", help="time only extra_workloads.c4_clip and print it (development)")
     ap.add_argument("--only-2160p", action="store_true", help="time only extra_workloads.2160p10_closed_loop (with its ALF stage) and print it (development)")
     ap.add_argument("--only-ra-clip", action="store_true", help="time only extra_workloads.ra_clip and print it (development)")
@@ -1172,6 +1235,9 @@ def main():
         return
     if args.only_c4_clip:
         print(json.dumps({"c4_clip": c4_clip(device, with_cpu=not args.no_cpu_baseline)}), flush=True)
+        return
+    if args.only_tiles_clip:
+        print(json.dumps({"tiles_clip": tiles_clip(WORKLOADS["1080p8"], device, with_cpu=not args.no_cpu_baseline)}), flush=True)
         return
     if args.only_ra_clip:
         print(json.dumps({"ra_clip": ra_clip(device, frames=args.ra_clip_frames or 65, with_cpu=not args.no_cpu_baseline)}), flush=True)
@@ -1226,7 +1292,7 @@ def main():
             extra["alf_stage"] = alf_t
         if alf_t is not None and "ms_per_group" in alf_t and alf_t.get("parity_checked"):
             extra["value_with_alf_stage"] = round(ek * eF * world / (eel + ek * alf_t["ms_per_group"] * 1e-3), 3)        # (sequential: nothing of the stage overlaps the loop)
-    c3 = c3_loop = clip = c3_one = ra_one = c4_one = None
+    c3 = c3_loop = clip = c3_one = ra_one = c4_one = tiles_one = None
     if not args.no_extra and wl_name == "1080p8" and rank == 0:
         def side(fn, *a, **k):          # a side workload must not take the judged line down with it
             try:
@@ -1234,6 +1300,7 @@ def main():
             except (Exception, SystemExit) as e:          # noqa: BLE001
                 return {"error": f"{type(e).__name__}: {e}", "parity_checked": False}
         clip = side(c2_clip, wl, device)
+        tiles_one = side(tiles_clip, wl, device, with_cpu=not args.no_cpu_baseline) if args.tiles_clip else None
         c3 = side(inter_hot_path, device)
         c3_loop = side(low_delay_closed_loop, device, n_seq=args.c3_sequences)
         c4_one = side(c4_clip, device, with_cpu=not args.no_cpu_baseline) if args.c4_clip else None
@@ -1305,6 +1372,8 @@ def main():
                 out.setdefault("extra_workloads", {})["ra_clip"] = ra_one
             if clip is not None:
                 out.setdefault("extra_workloads", {})["c2_clip"] = clip
+            if tiles_one is not None:
+                out.setdefault("extra_workloads", {})["tiles_clip"] = tiles_one
             if c4_one is not None:
                 out.setdefault("extra_workloads", {})["c4_clip"] = c4_one
             if open_loop is not None:

@@ -561,6 +561,7 @@ if __name__ == "__main__":
     tiles(320, 192, 8, 22, (1004,), 5, 1)              # ... a row of one-CTU-wide tiles: every CTU starts its row's substream... and 1 x 3:
     tiles(192, 192, 8, 37, (9,), 1, 3)                 # ... tiles one above the other, one WPP row each
     tiles(1920, 1080, 8, 22, (0, 1), 2, 2, crc_only=True)      # BASELINE configs[1]'s picture in 2 x 2 tiles (bench.py tiles_clip), by CRC
+    tiles(1920, 1080, 8, 22, (0, 1), 6, 4, crc_only=True)      # ... bench.py's tiles_clip: 24 tiles of 5 x 4 / 5 x 5 CTUs
     tiles(3840, 2160, 10, 22, (0,), 4, 2, crc_only=True)       # ... configs[3]'s size and depth in 4 x 2 tiles: one tile per GPU of the node
     if not os.environ.get("GOLDENS_SKIP_CLIP120"):      # (ten minutes and 4 GB of records by itself)
         inter_crcs(1920, 1080, 8, 27, 120, extra=("owf", "1"), suffix="_owf1", clip=True)     # bench.py's c3_clip, picture by picture: BASELINE configs[2] as written, --owf 1 (frames in flight), crosses the second intra period at POC 64

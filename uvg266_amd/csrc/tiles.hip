@@ -215,7 +215,7 @@ extern "C" int uvghip_tiles_plan_run(uvghip_tiles_plan_t *pl, void *stream)
   if (pl->classes.size() == 1) return uvghip_loop_plan_run(pl->classes[0].plan, stream);
   // classes 1.. on the plan's own streams, class 0 on the caller's: a uniform grid's four classes then take four streams, what the
   // runtime's hardware queues carry side by side by default (GPU_MAX_HW_QUEUES = 4; a fifth stream shares a queue with another and the
-  // two launches run one after the other: measured, 4 x 4 tiles of one 1080p picture 219 -> ms)
+  // two launches run one after the other: measured, 4 x 4 tiles of one 1080p picture 219 -> 119 ms; uvg266_amd/__init__.py raises the default to 8)
   UVGHIP_TRY(hipEventRecord(pl->fork, st));
   for (size_t k = 1; k < pl->classes.size(); ++k) {
     auto &c = pl->classes[k];
