@@ -914,6 +914,58 @@ def cpu_baseline_low_delay(W, H, depth, qp, frames, gop="lp-g4d3t1"):
                       f"{cores} host threads, AVX2 strategies), wall time {dt:.1f} s incl. reading the input"}
 
 
+def tiles_sharded(device, rank, world, dist, n_pic=8, steps=3, grid=(4, 2)):
+    """ONE stream's pictures with every picture's TILES spread over the ranks (uvg266_amd/tiles.py): 3840x2160 10-bit under
+    --tiles 4x2 --wpp (a tile per GPU at 8 ranks), `n_pic` pictures per step.  A step = every rank's uvghip_tiles_plan_run over the tiles it
+    owns of all pictures -- no halo, nothing exchanged while it runs -- then tiles.gather_nals: two all-gathers (substream lengths +
+    checksum terms; the bytes) that leave the pictures' NAL units on rank 0.  Strong scaling: the pictures per step do not grow with the
+    ranks.  Picture 0's NAL units are held to the reference's run with the same --tiles.  Not part of `value`."""
+    import zlib
+    from uvg266_amd import tiles as T
+    wl = WORKLOADS["2160p10alf"]
+    W, H, depth = wl["W"], wl["H"], wl["depth"]
+    P = api.ctu_params(W, H, QP)
+    rects, _ = api.tile_grid(W, H, *grid)
+    owner = T.assign(rects, world)
+    src = [tuple(torch.from_numpy(np.ascontiguousarray(p)).to(device) for p in layout.synthetic_yuv420(W, H, t % 4, depth)) for t in range(n_pic)]
+    tl = api.TiledLoop(P, src, grid, owned=owner == rank)
+
+    def step():
+        tl.run()
+        part = tl.substreams()
+        if dist:
+            return T.gather_nals(part, 0, True), part
+        return T.write_nals(part[0][None], [part[1]], part[2][None], 0, True), part
+    nals, part = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        nals, part = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    out = {"value": round(steps * n_pic / elapsed, 2), "unit": "frames/s", "ranks": world, "scaling": "strong", "steps": steps, "pictures_per_step": n_pic,
+           "tiles": f"{grid[0]}x{grid[1]}", "tiles_of_rank0": int((owner == 0).sum()),
+           "comm_bytes_per_step_rank0": {"sent": int(part[0].nbytes + part[2].nbytes * 2 + 8 + len(part[1])), "collectives": "2 x all_gather (lengths + checksum terms; bytes)"},
+           "workload": f"{W}x{H} {depth}-bit, -p 1 --preset medium --tiles {grid[0]}x{grid[1]} --wpp at QP {QP}: every picture's tiles over {world} rank(s), "
+                       "search + in-loop filters + slice data per tile, NAL units gathered on rank 0",
+           "parity_checked": False}
+    if rank == 0:
+        path = os.path.join(ROOT, "tests", "golden", f"ref_tiles_{W}x{H}_{depth}_qp{QP}_{grid[0]}x{grid[1]}_1frames_crc.npz")
+        if os.path.exists(path):
+            g = np.load(path)
+            out["parity_checked"] = bool(len(nals[0]) == int(g["bitstream_tail_len"]) and zlib.crc32(nals[0]) == int(g["bitstream_tail_crc"]))
+            out["parity"] = "picture 0's slice NAL + hash SEI (length + CRC-32) vs the reference encoder's run with the same --tiles"
+    return out
+
+
 def search_rows(wl, device, rank, world, dist, transport, n_pic=64, steps=3):
     """The closed-loop CTU search with every picture sharded over the ranks by CTU rows (uvghip_ctu_plan_create_rows):
     a step = one launch of this rank's band of `n_pic` pictures, between the halo it receives from the band above (last reconstruction
@@ -1193,6 +1245,7 @@ def main():
     ap.add_argument("--ra-clip-frames", type=int, default=65, help="extra_workloads.ra_clip: coded pictures of the ONE random-access (--gop 16) clip that are timed (0: skip)")
     ap.add_argument("--no-c4-clip", dest="c4_clip", action="store_false", help="skip extra_workloads.c4_clip (the 60-picture 2160p 10-bit clip and its CPU baseline)")
     ap.add_argument("--no-tiles-clip", dest="tiles_clip", action="store_false", help="skip extra_workloads.tiles_clip (the 60-picture clip under --tiles 6x4 --wpp and its CPU baseline)")
+    ap.add_argument("--only-tiles-sharded", action="store_true", help="time only the tile-sharded 2160p 10-bit stream (every picture's tiles over the ranks; with one rank: all tiles here) and print it (development)")
     ap.add_argument("--only-tiles-clip", action="store_true", help="time only extra_workloads.tiles_clip and print it (development)")
     ap.add_argument("--only-c4-clip", action="store_true", help="time only extra_workloads.c4_clip and print it (development)")
     ap.add_argument("--only-2160p", action="store_true", help="time only extra_workloads.2160p10_closed_loop (with its ALF stage) and print it (development)")
@@ -1235,6 +1288,17 @@ def main():
         return
     if args.only_c4_clip:
         print(json.dumps({"c4_clip": c4_clip(device, with_cpu=not args.no_cpu_baseline)}), flush=True)
+        return
+    if args.only_tiles_sharded:
+        if world == 1 and os.environ.get("RANK") is not None:          # under torchrun with ONE rank: the collectives through RCCL all the same
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=device)
+        r = tiles_sharded(device, rank, world, dist)
+        if rank == 0:
+            print(json.dumps({"tiles_sharded": r}), flush=True)
+        if dist:
+            dist.destroy_process_group()
         return
     if args.only_tiles_clip:
         print(json.dumps({"tiles_clip": tiles_clip(WORKLOADS["1080p8"], device, with_cpu=not args.no_cpu_baseline)}), flush=True)
@@ -1415,6 +1479,11 @@ def main():
             except Exception as e:               # noqa: BLE001
                 rs = {"error": f"{type(e).__name__}: {e}"}
             row_sharded["closed_loop_search_rows"] = rs
+            try:
+                ts = tiles_sharded(device, rank, world, dist)
+            except Exception as e:               # noqa: BLE001
+                ts = {"error": f"{type(e).__name__}: {e}"}
+            row_sharded["tiles_sharded"] = ts
         except Exception as e:                   # noqa: BLE001 -- reported, not fatal: the judged line does not depend on it
             row_sharded = {"error": f"{type(e).__name__}: {e}", "rccl_ranks": world}
         dog.cancel()
