@@ -55,3 +55,26 @@ def test_cpp_host_program_writes_the_encoders_stream(hip, tmp_path):
     stream = g["bitstream"].tobytes()
     at = stream.find(b"\x00\x00\x01\x00\x41")
     assert stream[:at] + open(nals, "rb").read() == stream
+
+
+@pytest.mark.parametrize("name", ["ref_tiles_416x240_10_qp32_3x2_2frames", "ref_tiles_264x136_8_qp27_2x2_1frames"])
+def test_cpp_tiles_program_writes_the_encoders_stream_under_tiles(hip, tmp_path, name):
+    """examples/tiles: uvghip_tile_grid / uvghip_tiles_plan_* from C++ alone, from a .yuv: its NAL units behind the encoder's parameter sets
+    are the .266 the encoder wrote with the same --tiles."""
+    exe = os.path.join(H.ROOT, "examples", "tiles")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(H.ROOT, "examples")])
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, cols, rows = (int(a) for a in g["meta"])
+    yuv, nals = tmp_path / "in.yuv", tmp_path / "out.nals"
+    with open(yuv, "wb") as f:
+        for t in g["ts"]:
+            for plane in H.varied_picture(W, Hh, int(t), depth):
+                f.write(np.ascontiguousarray(plane).tobytes())
+    out = subprocess.check_output([exe, str(W), str(Hh), str(depth), str(qp), str(len(g["ts"])), str(cols), str(rows), str(yuv), str(nals)], text=True)
+    assert f"{cols * rows} tiles" in out
+    stream = g["bitstream"].tobytes()
+    at = stream.find(b"\x00\x00\x01\x00\x41")
+    assert stream[:at] + open(nals, "rb").read() == stream
+    crcs = [int(l.split()[-1], 16) for l in out.splitlines() if l.startswith("picture")]
+    assert crcs == [zlib.crc32(g["final"][i].tobytes()) for i in range(len(g["ts"]))]

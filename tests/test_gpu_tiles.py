@@ -162,3 +162,48 @@ def test_tiles_over_emulated_ranks(hip, name, world):
         assert stream[stream.find(b"\x00\x00\x01\x00\x41"):] == nals
     else:
         assert len(nals) == int(g["bitstream_tail_len"]) and zlib.crc32(nals) == int(g["bitstream_tail_crc"])
+
+
+@pytest.mark.parametrize("case", [(200, 136, 8, 32, 2, 1, 5), (328, 200, 10, 27, 3, 3, 1004), (448, 72, 8, 22, 7, 1, 2), (136, 264, 10, 37, 1, 4, 2003), (264, 264, 8, 17, 4, 4, 3),
+                                  (520, 136, 8, 27, 4, 2, 4011)])
+def test_other_grids_against_the_oracle(hip, orc, case):
+    """Grids, sizes and content the goldens do not hold (partial CTUs inside the last tiles, one-CTU tiles in both directions, 16 tiles of
+    one picture, noise and impulses): expected = the oracle's chain over every tile as a picture of its own -- the construction
+    tests/test_tiles.py holds to the reference's --tiles runs -- and the library's NAL writer over its rows."""
+    import torch
+    from uvg266_amd import api, lib
+    W, Hh, depth, qp, cols, rows, t = case
+    y, u, v = H.varied_picture(W, Hh, t, depth)
+    rects, first = api.tile_grid(W, Hh, cols, rows)
+    final = [np.zeros_like(y), np.zeros_like(u), np.zeros_like(v)]
+    want_rows, want_coeff = [], []
+    for tx, ty, tw, th in (tuple(int(a) for a in r) for r in rects):
+        sub = [np.ascontiguousarray(p[(ty >> c):(ty + th) >> c, (tx >> c):(tx + tw) >> c]) for p, c in ((y, 0), (u, 1), (v, 1))]
+        prm = H.search_params(tw, th, qp)
+        s = H.oracle_search_picture(orc, depth, prm, *sub)
+        f = H.oracle_sao_picture(orc, depth, tw, th, qp, prm.lam, tuple(sub), (s["rec_y"], s["rec_u"], s["rec_v"]), H.scu_from_cu(s["cu"], qp))
+        data, off, _ = H.oracle_encode_rows(orc, depth, prm, s, f["sao"])
+        want_rows += [data[off[r]:off[r + 1]] for r in range(len(off) - 1)]
+        want_coeff.append(s["coeff"])
+        for p, k, c in ((final[0], "final_y", 0), (final[1], "final_u", 1), (final[2], "final_v", 1)):
+            p[(ty >> c):(ty + th) >> c, (tx >> c):(tx + tw) >> c] = f[k]
+    prm = H.search_params(W, Hh, qp)
+    tl = api.TiledLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in (y, u, v))], (cols, rows))
+    tl.run()
+    nal = tl.nals()[0]
+    assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(tl.out[0], final)), "output picture"
+    got = tile_substreams(tl, 0)
+    assert len(got) == len(want_rows) and all(np.array_equal(a, b) for a, b in zip(got, want_rows)), "substreams"
+    assert np.array_equal(tl.coeff[0].cpu().numpy(), np.concatenate(want_coeff)), "levels in tile-scan order"          # (first_ctu: the tiles' CTUs one tile after the other)
+    assert [int(f) for f in first] == list(np.cumsum([0] + [len(c) for c in want_coeff[:-1]]))
+    sizes = np.array([len(r) for r in want_rows], np.int32)
+    packed = np.zeros((len(sizes), int(sizes.max())), np.uint8)
+    for k, r in enumerate(want_rows):
+        packed[k, :len(r)] = r
+    sums = np.array([H.picture_checksum(p, depth) for p in final], np.uint32)
+    cap = int(sizes.sum()) + 64 + 4 * len(sizes)
+    out = np.zeros(cap, np.uint8)
+    n = ctypes.c_size_t(0)
+    L = lib.load_library()
+    assert L.uvghip_write_picture_nals(0, 1, H.ptr(packed), packed.shape[1], H.ptr(sizes), len(sizes), H.ptr(sums), H.ptr(out), cap, ctypes.byref(n)) == 0
+    assert out[:n.value].tobytes() == nal
