@@ -39,6 +39,11 @@ struct uvghip_tiles_plan {
   uint32_t *sums;                            // device: [n][3]
   uint8_t *host_rows;                        // pinned staging of the group's substreams (grown on demand)
   size_t host_cap;
+  uint8_t *dev_rows;                         // the same bytes gathered on the device first: ONE download instead of one per substream
+  size_t dev_cap;
+  struct piece { const uint8_t *src; unsigned long long dst; unsigned long long len; };
+  piece *host_tab, *dev_tab;                 // the gather's table (pinned / device), grown on demand
+  size_t tab_cap;
 };
 
 namespace {
@@ -84,6 +89,55 @@ void classes_of(const std::vector<uvghip_rect_t> &tiles, const uint8_t *owned, s
   }
 }
 
+// a block per substream: its bytes from the size class's row slot to its place in the packed buffer
+__global__ void __launch_bounds__(256) tile_gather_kernel(const uvghip_tiles_plan::piece *__restrict__ tab, uint8_t *__restrict__ packed)
+{
+  const uvghip_tiles_plan::piece p = tab[blockIdx.x];
+  uint8_t *dst = packed + p.dst;
+  if ((((size_t)p.src | (size_t)dst) & 15) == 0) {
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(p.src);
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+    const unsigned long long n4 = p.len >> 4;
+    for (unsigned long long i = threadIdx.x; i < n4; i += blockDim.x) d4[i] = s4[i];
+    for (unsigned long long i = (n4 << 4) + threadIdx.x; i < p.len; i += blockDim.x) dst[i] = p.src[i];
+  } else {
+    for (unsigned long long i = threadIdx.x; i < p.len; i += blockDim.x) dst[i] = p.src[i];
+  }
+}
+
+// pieces (host vector) -> pl->host_rows[0, total): the table up, one gather launch, one download; the caller waits for the stream
+int gather_to_host(uvghip_tiles_plan *pl, const std::vector<uvghip_tiles_plan::piece> &pieces, size_t total, hipStream_t st)
+{
+  if (pieces.empty()) return 0;
+  if (total > pl->host_cap) {
+    if (pl->host_rows) { UVGHIP_TRY(hipHostFree(pl->host_rows)); pl->host_rows = nullptr; pl->host_cap = 0; }
+    const size_t want = total + total / 4 + 4096;
+    UVGHIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pl->host_rows), want, hipHostMallocDefault));
+    pl->host_cap = want;
+  }
+  if (total > pl->dev_cap) {
+    if (pl->dev_rows) { UVGHIP_TRY(hipFree(pl->dev_rows)); pl->dev_rows = nullptr; pl->dev_cap = 0; }
+    const size_t want = total + total / 4 + 4096;
+    UVGHIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->dev_rows), want));
+    pl->dev_cap = want;
+  }
+  if (pieces.size() > pl->tab_cap) {
+    if (pl->host_tab) { UVGHIP_TRY(hipHostFree(pl->host_tab)); pl->host_tab = nullptr; }
+    if (pl->dev_tab) { UVGHIP_TRY(hipFree(pl->dev_tab)); pl->dev_tab = nullptr; }
+    pl->tab_cap = 0;
+    const size_t want = pieces.size() + pieces.size() / 4 + 64;
+    UVGHIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pl->host_tab), want * sizeof(uvghip_tiles_plan::piece), hipHostMallocDefault));
+    UVGHIP_TRY(hipMalloc(reinterpret_cast<void **>(&pl->dev_tab), want * sizeof(uvghip_tiles_plan::piece)));
+    pl->tab_cap = want;
+  }
+  memcpy(pl->host_tab, pieces.data(), pieces.size() * sizeof(uvghip_tiles_plan::piece));          // (the previous call's table is no longer in use: every call ends with a wait)
+  UVGHIP_TRY(hipMemcpyAsync(pl->dev_tab, pl->host_tab, pieces.size() * sizeof(uvghip_tiles_plan::piece), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(tile_gather_kernel, dim3((unsigned)pieces.size()), dim3(256), 0, st, pl->dev_tab, pl->dev_rows);
+  UVGHIP_TRY(hipGetLastError());
+  UVGHIP_TRY(hipMemcpyAsync(pl->host_rows, pl->dev_rows, total, hipMemcpyDeviceToHost, st));
+  return 0;
+}
+
 void destroy(uvghip_tiles_plan *pl)
 {
   for (auto &c : pl->classes) {
@@ -93,6 +147,9 @@ void destroy(uvghip_tiles_plan *pl)
   }
   if (pl->fork) (void)hipEventDestroy(pl->fork);
   if (pl->host_rows) (void)hipHostFree(pl->host_rows);
+  if (pl->dev_rows) (void)hipFree(pl->dev_rows);
+  if (pl->host_tab) (void)hipHostFree(pl->host_tab);
+  if (pl->dev_tab) (void)hipFree(pl->dev_tab);
   delete pl;
 }
 
@@ -150,7 +207,7 @@ extern "C" int uvghip_tiles_plan_create_owned(int bitdepth, const uvghip_ctu_par
   uvghip_tiles_plan *pl = new (std::nothrow) uvghip_tiles_plan;
   if (!pl) return uvghip_set_error(hipErrorOutOfMemory, __func__);
   pl->bitdepth = bitdepth; pl->n = n_pictures; pl->w = params->pic_w; pl->h = params->pic_h; pl->cols = tile_cols; pl->rows = tile_rows; pl->sao_type = sao_type;
-  pl->fork = nullptr; pl->host_rows = nullptr; pl->host_cap = 0;
+  pl->fork = nullptr; pl->host_rows = nullptr; pl->host_cap = 0; pl->dev_rows = nullptr; pl->dev_cap = 0; pl->host_tab = nullptr; pl->dev_tab = nullptr; pl->tab_cap = 0;
   if (grid(pl->w, pl->h, tile_cols, tile_rows, pl->tiles, pl->first_ctu)) { delete pl; return uvghip_set_error(hipErrorInvalidValue, "uvghip_tiles_plan_create: more tiles than CTUs in a dimension (or none)"); }
   const int wc = (pl->w + 63) / 64;
   for (int i = 0; i < n_pictures; ++i) {
@@ -298,26 +355,23 @@ extern "C" int uvghip_tiles_plan_nals(uvghip_tiles_plan_t *pl, int first, int co
         if (src[r] > longest) longest = src[r];
       }
     }
-    base[i] = at; pitch[i] = (size_t)longest;
+    base[i] = at; pitch[i] = ((size_t)longest + 15) & ~(size_t)15;
     at += pitch[i] * n_sub;
   }
   base[count] = at;
-  if (at > pl->host_cap) {
-    if (pl->host_rows) { UVGHIP_TRY(hipHostFree(pl->host_rows)); pl->host_rows = nullptr; pl->host_cap = 0; }
-    const size_t want = at + at / 4 + 4096;
-    UVGHIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pl->host_rows), want, hipHostMallocDefault));
-    pl->host_cap = want;
-  }
+  std::vector<uvghip_tiles_plan::piece> pieces;
+  pieces.reserve((size_t)count * n_sub);
   for (int i = 0; i < count; ++i) {
     int s = 0;
     for (size_t t = 0; t < pl->tiles.size(); ++t) {
       const view &c = v[pl->cls_of[t]];
       const size_t idx = (size_t)(first + i) * c.per + pl->slot_of[t];
       for (int r = 0; r < c.hc; ++r, ++s)
-        UVGHIP_TRY(hipMemcpyAsync(pl->host_rows + base[i] + (size_t)s * pitch[i], c.rows + (idx * c.hc + r) * (size_t)c.row_cap, (size_t)nb[(size_t)i * n_sub + s],
-                                  hipMemcpyDeviceToHost, st));
+        pieces.push_back(uvghip_tiles_plan::piece{c.rows + (idx * c.hc + r) * (size_t)c.row_cap, (unsigned long long)(base[i] + (size_t)s * pitch[i]),
+                                                  (unsigned long long)nb[(size_t)i * n_sub + s]});
     }
   }
+  if (int rc = gather_to_host(pl, pieces, at, st)) return rc;
   UVGHIP_TRY(hipStreamSynchronize(st));
   size_t used = 0;
   for (int i = 0; i < count; ++i) {
@@ -364,6 +418,7 @@ extern "C" int uvghip_tiles_plan_substreams(uvghip_tiles_plan_t *pl, int first, 
   int n_sub = 0;
   for (const uvghip_rect_t &t : pl->tiles) n_sub += (t.h + 63) / 64;
   size_t at = 0;
+  std::vector<uvghip_tiles_plan::piece> pieces;
   for (int i = 0; i < count; ++i) {
     int s = 0;
     for (size_t t = 0; t < pl->tiles.size(); ++t) {
@@ -375,14 +430,16 @@ extern "C" int uvghip_tiles_plan_substreams(uvghip_tiles_plan_t *pl, int first, 
       for (int r = 0; r < c.hc; ++r, ++s) {
         if (src[r] <= 0 || src[r] > c.row_cap) return uvghip_set_error(hipErrorInvalidValue, "uvghip_tiles_plan_substreams: a row overflowed its slot (or the plan has not run)");
         lens[(size_t)i * n_sub + s] = src[r];
-        if (at + (size_t)src[r] <= cap) UVGHIP_TRY(hipMemcpyAsync(bytes + at, c.rows + (idx * c.hc + r) * (size_t)c.row_cap, (size_t)src[r], hipMemcpyDeviceToHost, st));
+        pieces.push_back(uvghip_tiles_plan::piece{c.rows + (idx * c.hc + r) * (size_t)c.row_cap, (unsigned long long)at, (unsigned long long)src[r]});
         at += (size_t)src[r];
       }
     }
   }
-  UVGHIP_TRY(hipStreamSynchronize(st));
   *used = at;
   if (at > cap) return uvghip_set_error(hipErrorInvalidValue, "uvghip_tiles_plan_substreams: the output buffer is too small (see *used)");
+  if (int rc = gather_to_host(pl, pieces, at, st)) return rc;
+  UVGHIP_TRY(hipStreamSynchronize(st));
+  if (at) memcpy(bytes, pl->host_rows, at);
   return 0;
 }
 
