@@ -472,7 +472,22 @@ def c2_clip(wl, device, frames=60, reps=2):
         dt = time.perf_counter() - t0
         nbytes = sum(len(b) for b in out)
         best = dt if best is None or dt < best else best
-    return {"value": round(frames / best, 2), "unit": "frames/s (one 60-picture clip, host memory to .266 bytes in host memory)", "frames": frames,
+    # one picture alone: the three launches one after the other / beside each other (uvghip_loop_plan_run_overlapped)
+    one = {}
+    c1 = api.ClosedLoop(P, src[:1])
+    for name, fn in (("run", c1.run), ("run_overlapped", c1.run_overlapped)):
+        fn(); c1.group_nals(0)
+        b1 = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            c1.group_nals(0)
+            dt = time.perf_counter() - t0
+            b1 = dt if b1 is None or dt < b1 else b1
+        one[name] = round(1e3 * b1, 1)
+    del c1
+    return {"value": round(frames / best, 2), "unit": "frames/s (one 60-picture clip, host memory to .266 bytes in host memory)", "frames": frames, "one_picture_ms": one,
             "wall_ms": round(1e3 * best, 1), "bytes_out": int(nbytes), "upload_mb": round(frames * W * H * 1.5 * (1 if depth == 8 else 2) / 1e6, 1),
             "note": "one launch of 60 pictures: the wavefronts' fill and drain are not hidden by a second launch, 660 of 1024 workgroup slots busy at best; "
                     "the NAL units of the group come over in one download (uvghip_loop_plan_group_nals)"}

@@ -965,6 +965,18 @@ UVGHIP_API size_t uvghip_loop_workspace_bytes(int bitdepth, int n_pictures, int 
 UVGHIP_API int uvghip_loop_plan_create(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_loop_picture_t *pictures,
                                        int n_pictures, int sao_type, void *workspace, uvghip_loop_plan_t **plan_out);
 UVGHIP_API int uvghip_loop_plan_run(uvghip_loop_plan_t *plan, void *stream);
+/* The same results with the three launches BESIDE each other instead of one after the other (the latency of ONE group: a clip, a picture):
+ * the search on `stream`, the filter stage on a stream of the plan's own behind the search's per-CTU flags
+ * (uvghip_filter_pictures_run_behind), the coder on another behind the filter stage's (uvghip_encode_slice_rows_behind) -- a CTU is
+ * filtered when it is searched and coded when it is filtered, as encoder_state_worker_encode_lcu_search / _bitstream do CTU by CTU
+ * (src/encoderstate.c:808-939), and the group's tail is one CTU's filter + its row's last bins instead of the whole filter and coder
+ * launches.  Forked from and joined to `stream`.  What runs beside the search is capped (128 persistent filter workgroups, 256 persistent
+ * coder waves that take row r of every picture, then row r + 1: UVGHIP_OVERLAP_FILTER_WGS / UVGHIP_OVERLAP_CODER_WAVES), because a waiting
+ * workgroup holds LDS the search cannot use.  For the latency of ONE small group: when the pictures' wavefronts can have more than 512 CTUs in
+ * progress (half the device's workgroup slots: more than 30 pictures of 1080p) the call IS uvghip_loop_plan_run -- beside a search that fills
+ * the device the overlap costs more search slots than the tail it hides (measured), and with several groups in flight
+ * (bench.py's judged line) launches overlap across groups anyway. */
+UVGHIP_API int uvghip_loop_plan_run_overlapped(uvghip_loop_plan_t *plan, void *stream);
 /* The two halves of uvghip_loop_plan_run on their own (a caller that wants events or other work between them). */
 UVGHIP_API int uvghip_loop_plan_run_search(uvghip_loop_plan_t *plan, void *stream);
 UVGHIP_API int uvghip_loop_plan_run_filters(uvghip_loop_plan_t *plan, void *stream);
@@ -1374,6 +1386,17 @@ UVGHIP_API size_t uvghip_filter_pictures_workspace_bytes(int n_pictures, int pic
 UVGHIP_API int uvghip_filter_pictures_prepare(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, const uvghip_pb_filter_t *filters,
                                               int n_pictures, int slice_type, void *workspace);
 UVGHIP_API int uvghip_filter_pictures_run(int bitdepth, int n_pictures, int pic_w, int pic_h, void *workspace, void *stream);
+/* ... BESIDE the search that feeds it instead of behind it: uvghip_filter_pictures_reset (ticket and flags to zero, in stream order), then on
+ * a stream that waits for the reset uvghip_filter_pictures_run_behind -- at most max_workgroups persistent workgroups that take CTU after CTU in
+ * wavefront order and wait for searched[picture][ctu] (the search plan's flags, uvghip_ctu_plan_done_flags) of each: a CTU is filtered as soon
+ * as it is searched (the order of encoder_state_worker_encode_lcu_search, src/encoderstate.c:808-853, CTU by CTU).  The search must have been
+ * LAUNCHED before this kernel (a waiting workgroup holds its slot; the cap keeps the device for the search).
+ * uvghip_filter_pictures_final_flags: the stage's own per-CTU flags [picture][ctu] (device memory) -- 1 when the CTU's SAO decision and its
+ * part of the output picture are published: what uvghip_encode_slice_rows_behind waits for. */
+UVGHIP_API int uvghip_filter_pictures_reset(int n_pictures, int pic_w, int pic_h, void *workspace, void *stream);
+UVGHIP_API int uvghip_filter_pictures_run_behind(int bitdepth, int n_pictures, int pic_w, int pic_h, void *workspace, const int32_t *searched, int max_workgroups,
+                                                 void *stream);
+UVGHIP_API const int32_t *uvghip_filter_pictures_final_flags(int n_pictures, int pic_w, int pic_h, const void *workspace);
 
 /* replaces, for a group of independent P / B pictures: the whole per-picture loop of the CTU worker (src/encoderstate.c:808-976) --
  * uvghip_ctu_search_pb, then per picture uvghip_deblock_frame_sao_snapshot on a copy of the reconstruction + uvghip_sao_stats_batch,
@@ -1433,6 +1456,12 @@ UVGHIP_API int uvghip_loop_plan_run_coder_behind(uvghip_loop_plan_t *plan, const
 UVGHIP_API int uvghip_encode_slice_rows_behind(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, int n_pictures,
                                                const int32_t *sao_info, const uint16_t *sao_models, const int32_t *final_flags, void *workspace, uint8_t *out,
                                                int row_cap, int32_t *row_bytes, void *stream);
+/* ... with at most max_waves rows in progress: persistent waves take row r of every picture, then row r + 1, from `ticket` (one int32 of DEVICE
+ * memory, zeroed by the caller in stream order before this call) -- for a coder that runs beside a search that is STILL RUNNING, where a
+ * waiting wave per row of a whole clip would hold the LDS the search needs (uvghip_loop_plan_run_overlapped). */
+UVGHIP_API int uvghip_encode_slice_rows_behind_capped(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, int n_pictures,
+                                                      const int32_t *sao_info, const uint16_t *sao_models, const int32_t *final_flags, int32_t *ticket, int max_waves,
+                                                      void *workspace, uint8_t *out, int row_cap, int32_t *row_bytes, void *stream);
 UVGHIP_API const int32_t *uvghip_loop_pb_inflight_final_flags(int bitdepth, int n_pictures, int pic_w, int pic_h, const void *workspace);
 UVGHIP_API const int32_t *uvghip_ctu_search_pb_inflight_final_flags(int n_pictures, int pic_w, int pic_h, const void *workspace);
 UVGHIP_API int uvghip_ctu_plan_reset(uvghip_ctu_plan_t *plan, void *stream);

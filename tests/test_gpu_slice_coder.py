@@ -89,3 +89,44 @@ def test_sweep_whole_loop_equals_the_oracle_chain(hip, orc):
         for a, k in zip(final, ("final_y", "final_u", "final_v")):
             assert np.array_equal(a, f[k]), (case, k)
         assert np.array_equal(np.concatenate([[0], np.cumsum(nb)]), off) and np.array_equal(got, want), case
+
+
+@pytest.mark.parametrize("name", ["ref_ctu_832x480_8_qp22", "ref_ctu_416x240_10_qp37", "ref_ctu_264x136_10_qp32", "ref_ctucrc_1920x1080_8_qp22", "ref_ctucrc_3840x2160_10_qp22"])
+def test_overlapped_run_equals_the_encoders(hip, name):
+    """uvghip_loop_plan_run_overlapped: the filter stage BESIDE the search (persistent workgroups behind its per-CTU flags), the coder behind the
+    filter stage's flags -- the same slice data, SAO decisions and output pictures as the three launches one after the other, several
+    pictures in the group, run after run (the flags are reset in stream order)."""
+    import torch
+    from uvg266_amd import api
+    g = H.ctu_golden(name)
+    W, Hh, depth, qp, y, u, v = H.golden_source(g)
+    prm = H.search_params(W, Hh, qp)
+    n = 3
+    src = [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in (y, u, v)) for _ in range(n)]
+    cl = api.ClosedLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), src)
+    cl.run()
+    torch.cuda.synchronize()
+    want_nals = cl.group_nals()
+    want_out = [[p.clone() for p in o] for o in cl.out]
+    want_info = [t.clone() for t in cl.sao_device()]
+    for rep in range(3):
+        out, nbytes = cl.slice_data()
+        out.zero_(); nbytes.zero_()
+        for o in cl.out:
+            for p in o:
+                p.zero_()
+        for i in range(n):          # nothing may come from the run before: the coder's rows start BEFORE the search has written their start models
+            cl.models[i].fill_(0x5a5a5a5a); cl.coeff[i].fill_(77); cl.cu[i].zero_()
+            for p in cl.rec[i]:
+                p.zero_()
+        cl.run_overlapped()
+        torch.cuda.synchronize()
+        assert cl.group_nals() == want_nals, f"NAL units, repetition {rep}"
+        assert all(torch.equal(a, b) for o, w in zip(cl.out, want_out) for a, b in zip(o, w)), "output pictures"
+        assert all(torch.equal(a, b) for a, b in zip(cl.sao_device(), want_info)), "SAO decisions / models"
+    nb = nbytes.cpu().numpy()[0]
+    rows = [out[0, r, :nb[r]].cpu().numpy() for r in range(len(nb))]
+    if "row_bytes" in g.files:
+        assert np.array_equal(np.concatenate(rows), g["row_bytes"])
+    else:
+        assert np.array_equal(np.array([zlib.crc32(r.tobytes()) for r in rows], np.uint32), g["row_crc"])

@@ -696,6 +696,11 @@ class ClosedLoop(CtuSearch):
         """Enqueue search + filters of all n pictures (uvghip_loop_plan_run); returns at once."""
         _lib.check(self.L.uvghip_loop_plan_run(self.loop, _stream() if stream is None else stream), "uvghip_loop_plan_run")
 
+    def run_overlapped(self, stream=None):
+        """uvghip_loop_plan_run_overlapped: the same results, the filter stage and the coder BESIDE the search (behind its per-CTU flags) instead
+        of after it -- the latency of one group; returns at once."""
+        _lib.check(self.L.uvghip_loop_plan_run_overlapped(self.loop, _stream() if stream is None else stream), "uvghip_loop_plan_run_overlapped")
+
     def run_search(self, stream=None):
         _lib.check(self.L.uvghip_loop_plan_run_search(self.loop, _stream() if stream is None else stream), "uvghip_loop_plan_run_search")
 

@@ -29,17 +29,23 @@ struct filter_args {
   const fpic_dev *pics;
   int32_t *ticket, *sao_done, *final_done;
   int wc, hc, n_pictures, W, H;
+  const int32_t *searched;      // BEHIND: [picture][ctu], the search's "done" flags (uvghip_ctu_plan_done_flags)
 };
 
-template <typename PX>
+// BEHIND: a small grid of persistent workgroups that take CTU after CTU and wait for the SEARCH's flag of each -- the filters of a group
+// BESIDE its search launch (uvghip_loop_plan_run_overlapped), a CTU filtered as soon as it is searched instead of after the last CTU of the
+// launch.  The grid is capped by the caller so that the search, launched first, keeps the device: a waiting workgroup holds its slot.
+template <typename PX, bool BEHIND>
 __global__ void __launch_bounds__(256) ctu_filter_kernel(filter_args A)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_ticket;
+  for (;;) {
   if (threadIdx.x == 0) s_ticket = atomicAdd(A.ticket, 1);
   __syncthreads();
   // ticket -> (diagonal cx + cy, picture, row): every CTU comes after its left and upper neighbour; pictures interleaved
   const int wc = A.wc, hc = A.hc, ctus = wc * hc;
+  if (BEHIND && s_ticket >= ctus * A.n_pictures) break;
   int t = s_ticket, d = 0;
   for (;; ++d) {
     const int lo = d - (wc - 1) > 0 ? d - (wc - 1) : 0, hi = d < hc - 1 ? d : hc - 1, cnt = (hi - lo + 1) * A.n_pictures;
@@ -55,7 +61,15 @@ __global__ void __launch_bounds__(256) ctu_filter_kernel(filter_args A)
   F.scu = D.scu; F.scu_stride = D.scu_stride;
   F.W = A.W; F.H = A.H; F.cx = cx; F.cy = cy; F.wc = wc; F.hc = hc;
   F.sao_done = A.sao_done + (size_t)pic * ctus; F.final_done = A.final_done + (size_t)pic * ctus;
+  if (BEHIND) {
+    // the CTU's own flag: its left / upper / upper-left neighbours, whose samples and side information the stage reads too, were searched before it
+    if (threadIdx.x == 0) { ctuf::wait_set(&A.searched[(size_t)pic * ctus + cy * wc + cx]); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+    __syncthreads();
+  }
   ctuf::filter_ctu<PX>(smem, D.F, F);
+  if (!BEHIND) break;
+  __syncthreads();          // the LDS image and s_ticket are free again
+  }
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -116,6 +130,43 @@ extern "C" int uvghip_filter_pictures_prepare(int bitdepth, const uvghip_ctu_par
   return 0;
 }
 
+// The run in two halves for a caller that lets the stage run BESIDE the search that feeds it (and a coder behind the stage's own flags):
+// reset -- ticket and flags to zero, in stream order -- then uvghip_filter_pictures_run_behind on a stream that waits for the reset: at most
+// max_workgroups persistent workgroups, each CTU waiting for searched[picture][ctu] (the search plan's flags).
+extern "C" int uvghip_filter_pictures_reset(int n_pictures, int pic_w, int pic_h, void *workspace, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (n_pictures <= 0 || pic_w <= 0 || pic_h <= 0 || !workspace) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  UVGHIP_TRY(hipMemsetAsync(workspace, 0, layout(n_pictures, pic_w, pic_h).pics, uvghip_stream(stream)));
+  return 0;
+}
+// ... the stage's per-CTU "final" flags [picture][ctu] (DEVICE memory): 1 when the CTU's part of the output picture and its SAO decision are published
+extern "C" const int32_t *uvghip_filter_pictures_final_flags(int n_pictures, int pic_w, int pic_h, const void *workspace)
+{
+  if (n_pictures <= 0 || pic_w <= 0 || pic_h <= 0 || !workspace) return nullptr;
+  return reinterpret_cast<const int32_t *>(static_cast<const unsigned char *>(workspace) + layout(n_pictures, pic_w, pic_h).final_done);
+}
+extern "C" int uvghip_filter_pictures_run_behind(int bitdepth, int n_pictures, int pic_w, int pic_h, void *workspace, const int32_t *searched, int max_workgroups, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
+  if (n_pictures <= 0 || pic_w <= 0 || pic_h <= 0 || !workspace || !searched || max_workgroups < 1) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const fl_layout L = layout(n_pictures, pic_w, pic_h);
+  unsigned char *ws = static_cast<unsigned char *>(workspace);
+  hipStream_t st = uvghip_stream(stream);
+  filter_args A;
+  A.pics = reinterpret_cast<const fpic_dev *>(ws + L.pics);
+  A.ticket = reinterpret_cast<int32_t *>(ws + L.ticket);
+  A.sao_done = reinterpret_cast<int32_t *>(ws + L.sao_done);
+  A.final_done = reinterpret_cast<int32_t *>(ws + L.final_done);
+  A.wc = (pic_w + 63) / 64; A.hc = (pic_h + 63) / 64; A.n_pictures = n_pictures; A.W = pic_w; A.H = pic_h;
+  A.searched = searched;
+  const int total = A.wc * A.hc * n_pictures, grid = total < max_workgroups ? total : max_workgroups;
+  if (bitdepth == 8) hipLaunchKernelGGL((ctu_filter_kernel<uint8_t, true>), dim3(grid), dim3(256), sizeof(ctuf::filt_lds<uint8_t>), st, A);
+  else hipLaunchKernelGGL((ctu_filter_kernel<uint16_t, true>), dim3(grid), dim3(256), sizeof(ctuf::filt_lds<uint16_t>), st, A);
+  UVGHIP_CHECK_LAUNCH();
+}
+
 extern "C" int uvghip_filter_pictures_run(int bitdepth, int n_pictures, int pic_w, int pic_h, void *workspace, void *stream)
 {
   UVGHIP_REQUIRE_READY();
@@ -126,13 +177,14 @@ extern "C" int uvghip_filter_pictures_run(int bitdepth, int n_pictures, int pic_
   hipStream_t st = uvghip_stream(stream);
   UVGHIP_TRY(hipMemsetAsync(ws, 0, L.pics, st));
   filter_args A;
+  A.searched = nullptr;
   A.pics = reinterpret_cast<const fpic_dev *>(ws + L.pics);
   A.ticket = reinterpret_cast<int32_t *>(ws + L.ticket);
   A.sao_done = reinterpret_cast<int32_t *>(ws + L.sao_done);
   A.final_done = reinterpret_cast<int32_t *>(ws + L.final_done);
   A.wc = (pic_w + 63) / 64; A.hc = (pic_h + 63) / 64; A.n_pictures = n_pictures; A.W = pic_w; A.H = pic_h;
   const int grid = A.wc * A.hc * n_pictures;
-  if (bitdepth == 8) hipLaunchKernelGGL(ctu_filter_kernel<uint8_t>, dim3(grid), dim3(256), sizeof(ctuf::filt_lds<uint8_t>), st, A);
-  else hipLaunchKernelGGL(ctu_filter_kernel<uint16_t>, dim3(grid), dim3(256), sizeof(ctuf::filt_lds<uint16_t>), st, A);
+  if (bitdepth == 8) hipLaunchKernelGGL((ctu_filter_kernel<uint8_t, false>), dim3(grid), dim3(256), sizeof(ctuf::filt_lds<uint8_t>), st, A);
+  else hipLaunchKernelGGL((ctu_filter_kernel<uint16_t, false>), dim3(grid), dim3(256), sizeof(ctuf::filt_lds<uint16_t>), st, A);
   UVGHIP_CHECK_LAUNCH();
 }

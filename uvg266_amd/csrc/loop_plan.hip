@@ -31,7 +31,11 @@ struct uvghip_loop_plan {
   uvghip_ctu_params_t ctu_params;
   int fused;                              // the filters are ONE launch behind the search (uvghip_filter_pictures); `snap` holds the deblocked pictures
   void *filt_ws;
+  int32_t *coder_ticket;                  // uvghip_loop_plan_run_overlapped: the persistent coder's row counter
   // uvghip_loop_plan_group_nals: the rows of the whole group gathered on the device and brought over in one copy (grown on demand)
+  // uvghip_loop_plan_run_overlapped: the filter stage and the coder on streams of the plan's own (created on first use)
+  hipStream_t side[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_side[2] = {nullptr, nullptr};
   uint8_t *pack_dev = nullptr, *pack_host = nullptr;
   size_t pack_cap = 0;
   unsigned long long *pack_base = nullptr;    // device: [n + 1] byte offsets of the pictures in the packed buffer, then [n] row pitches
@@ -41,7 +45,7 @@ namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-struct layout_t { size_t search, snap, rects_y, rects_c, edge[3], band[3], decide, info, models, params[3], coder, row_bytes, rows, sums, filt, total; int row_cap; };
+struct layout_t { size_t search, snap, rects_y, rects_c, edge[3], band[3], decide, info, models, params[3], coder, row_bytes, rows, sums, filt, tick, total; int row_cap; };
 
 layout_t layout_of(int bitdepth, int n, int w, int h)
 {
@@ -65,6 +69,7 @@ layout_t layout_of(int bitdepth, int n, int w, int h)
   L.rows = take((size_t)n * hc * L.row_cap);
   L.sums = take((size_t)n * 3 * sizeof(uint32_t));
   L.filt = take(uvghip_filter_pictures_workspace_bytes(n, w, h));
+  L.tick = take(256);
   L.total = at;
   return L;
 }
@@ -129,6 +134,7 @@ extern "C" int uvghip_loop_plan_create(int bitdepth, const uvghip_ctu_params_t *
     const char *e = getenv("UVGHIP_LOOP_UNFUSED");
     pl->fused = !(e && e[0] == '1');
     pl->filt_ws = ws + L.filt;
+    pl->coder_ticket = reinterpret_cast<int32_t *>(ws + L.tick);
     if (pl->fused) {
       std::vector<uvghip_pb_filter_t> fl(n_pictures);
       const size_t b = bitdepth == 8 ? 1 : 2, plane = (size_t)w * h * b;
@@ -165,6 +171,57 @@ extern "C" int uvghip_loop_plan_run(uvghip_loop_plan_t *pl, void *stream)
   if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);
   if (int rc = uvghip_ctu_plan_run(pl->search, stream)) return rc;
   return uvghip_loop_plan_run_filters(pl, stream);
+}
+
+extern "C" int uvghip_ctu_plan_reset(uvghip_ctu_plan_t *pl, void *stream);
+extern "C" int uvghip_ctu_plan_launch(uvghip_ctu_plan_t *pl, void *stream);
+extern "C" const int32_t *uvghip_ctu_plan_done_flags(const uvghip_ctu_plan_t *pl);
+extern "C" int uvghip_loop_plan_run_overlapped(uvghip_loop_plan_t *pl, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (!pl->fused) return uvghip_loop_plan_run(pl, stream);
+  // Beside a search that fills the device the stage's workgroups and the coder's waves displace search workgroups (a CU's 160 KB of LDS are four
+  // search workgroups exactly: one coder wave of 10 KB costs the CU a whole one) and the group gets SLOWER -- measured: 60 pictures of 1080p, up
+  // to 1020 CTUs in progress on 1024 slots, 543 -> 621 ms; 16 pictures 484 -> 415 ms, one picture 461 -> 396 ms.  So: only while the
+  // pictures' wavefronts leave half the device free.
+  {
+    const int wcx = (pl->w + 63) / 64;
+    if ((long long)pl->n * (wcx < pl->hc ? wcx : pl->hc) > 512 && !getenv("UVGHIP_OVERLAP_ALWAYS")) return uvghip_loop_plan_run(pl, stream);
+  }
+  // what runs beside the search is capped: a waiting filter workgroup or coder wave holds LDS a search workgroup cannot use (a coder wave 10 KB
+  // of a CU's 160 KB beside four search workgroups of 40 KB: one wave costs the CU a search workgroup)
+  static const int filter_cap = [] { const char *e = getenv("UVGHIP_OVERLAP_FILTER_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+  static const int coder_cap = [] { const char *e = getenv("UVGHIP_OVERLAP_CODER_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+  hipStream_t st = uvghip_stream(stream);
+  if (!pl->side[0]) {
+    for (int i = 0; i < 2; ++i) {
+      UVGHIP_TRY(hipStreamCreateWithFlags(&pl->side[i], hipStreamNonBlocking));
+      UVGHIP_TRY(hipEventCreateWithFlags(&pl->ev_side[i], hipEventDisableTiming));
+    }
+    UVGHIP_TRY(hipEventCreateWithFlags(&pl->ev_fork, hipEventDisableTiming));
+  }
+  // all flags to zero in `stream`, the side streams behind that; then the search, so that it is in the queue before anything waits for it
+  if (int rc = uvghip_ctu_plan_reset(pl->search, stream)) return rc;
+  if (int rc = uvghip_filter_pictures_reset(pl->n, pl->w, pl->h, pl->filt_ws, stream)) return rc;
+  UVGHIP_TRY(hipMemsetAsync(pl->coder_ticket, 0, sizeof(int32_t), st));
+  UVGHIP_TRY(hipEventRecord(pl->ev_fork, st));
+  if (int rc = uvghip_ctu_plan_launch(pl->search, stream)) return rc;
+  for (int i = 0; i < 2; ++i) UVGHIP_TRY(hipStreamWaitEvent(pl->side[i], pl->ev_fork, 0));
+  // the filter stage: as many persistent workgroups as the pictures' wavefronts can have CTUs in progress, at most an eighth of the device
+  const int wc = (pl->w + 63) / 64, per = wc < pl->hc ? wc : pl->hc;
+  long long g = (long long)per * pl->n;
+  if (g > filter_cap) g = filter_cap;
+  if (int rc = uvghip_filter_pictures_run_behind(pl->bitdepth, pl->n, pl->w, pl->h, pl->filt_ws, uvghip_ctu_plan_done_flags(pl->search), (int)g, pl->side[0])) return rc;
+  if (int rc = uvghip_encode_slice_rows_behind_capped(pl->bitdepth, &pl->ctu_params, nullptr, pl->n, pl->sao_info, pl->sao_models,
+                                                      uvghip_filter_pictures_final_flags(pl->n, pl->w, pl->h, pl->filt_ws), pl->coder_ticket, coder_cap, pl->coder_ws, pl->rows,
+                                                      pl->row_cap, pl->row_bytes, pl->side[1]))
+    return rc;
+  for (int i = 0; i < 2; ++i) {
+    UVGHIP_TRY(hipEventRecord(pl->ev_side[i], pl->side[i]));
+    UVGHIP_TRY(hipStreamWaitEvent(st, pl->ev_side[i], 0));
+  }
+  return 0;
 }
 
 extern "C" int uvghip_loop_plan_run_search(uvghip_loop_plan_t *pl, void *stream)
@@ -453,5 +510,10 @@ extern "C" void uvghip_loop_plan_destroy(uvghip_loop_plan_t *pl)
   if (pl->pack_dev) (void)hipFree(pl->pack_dev);
   if (pl->pack_host) (void)hipHostFree(pl->pack_host);
   if (pl->pack_base) (void)hipFree(pl->pack_base);
+  for (int i = 0; i < 2; ++i) {
+    if (pl->side[i]) (void)hipStreamDestroy(pl->side[i]);
+    if (pl->ev_side[i]) (void)hipEventDestroy(pl->ev_side[i]);
+  }
+  if (pl->ev_fork) (void)hipEventDestroy(pl->ev_fork);
   delete pl;
 }

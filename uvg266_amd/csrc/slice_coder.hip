@@ -574,21 +574,40 @@ __device__ inline void alf_ctu(coder &c, row_state *R, const alf_dev &A, int k, 
     }
 }
 
+// PERSIST: the launch is a capped number of waves that take row after row from a ticket counter -- row r of every picture, then row r + 1:
+// the order in which rows become codable behind a search that is still running (uvghip_encode_slice_rows_behind_capped) -- instead of a
+// wave per row: a waiting wave holds 10 KB of LDS a search workgroup cannot use.
+template <bool PERSIST = false>
 __global__ void __launch_bounds__(64)
 slice_rows_kernel(const pic_dev *__restrict__ pics, const pb_dev *__restrict__ pbs, const int32_t *__restrict__ sao, const uint16_t *__restrict__ sao_models,
                   int W, int H, int qp, int bitdepth, uint8_t *__restrict__ out, int row_cap, int32_t *__restrict__ row_bytes, const alf_dev *__restrict__ alfs = nullptr,
-                  const int32_t *wait_flags = nullptr)
+                  const int32_t *wait_flags = nullptr, int32_t *ticket = nullptr, int n_pictures = 0)
 {
   __shared__ row_state Rs;
+  __shared__ int s_job;
   extern __shared__ __attribute__((aligned(16))) unsigned char pb_smem[];          // row_state_pb for P / B pictures (none for I)
   row_state *R = &Rs;
   row_state_pb *Q = reinterpret_cast<row_state_pb *>(pb_smem);
   const int wc = (W + 63) / 64, hc = (H + 63) / 64;
-  const int pic = blockIdx.x / hc, cy = blockIdx.x - pic * hc;
+  for (;;) {
+  int job = blockIdx.x;
+  if (PERSIST) {
+    if (threadIdx.x == 0) s_job = atomicAdd(ticket, 1);
+    __syncthreads();
+    job = s_job;
+    if (job >= n_pictures * hc) break;
+  }
+  const int pic = PERSIST ? job % n_pictures : job / hc, cy = PERSIST ? job / n_pictures : job - pic * hc;
   const pic_dev D = pics[pic];
   const pb_dev *PB = pbs ? &pbs[pic] : nullptr;
   const int slice = PB ? PB->slice_type : 2, init_qp = PB ? PB->frame_qp : qp;
   const bool lane0 = threadIdx.x == 0;
+  // behind a launch that is still producing the pictures: the row's start -- the models behind the first CTU of the row above, its SAO
+  // models -- exists when that CTU is final (the search that wrote the models may itself still be running: uvghip_loop_plan_run_overlapped)
+  if (wait_flags && cy > 0) {
+    if (lane0) wait_final(wait_flags + (size_t)pic * wc * hc + (size_t)(cy - 1) * wc);
+    __syncthreads();
+  }
   // scans, window bytes, the row's start models
   for (int i = threadIdx.x; i < NMODELS; i += blockDim.x) {
     R->rate[i] = k_ctx_init[3][i];
@@ -616,10 +635,6 @@ slice_rows_kernel(const pic_dev *__restrict__ pics, const pb_dev *__restrict__ p
       f.l_size[0] = PB->l_size[0]; f.l_size[1] = PB->l_size[1];
       for (int i = 0; i < 8; ++i) { f.l[0][i] = PB->l[0][i]; f.l[1][i] = PB->l[1][i]; }
     }
-  }
-  if (wait_flags && cy > 0 && sao_models) {
-    if (lane0) wait_final(wait_flags + (size_t)pic * wc * hc + (size_t)(cy - 1) * wc);
-    __syncthreads();
   }
   if (threadIdx.x < 2) {
     const int i = threadIdx.x;
@@ -860,6 +875,9 @@ slice_rows_kernel(const pic_dev *__restrict__ pics, const pb_dev *__restrict__ p
     if (nacc) put_byte(c, acc << (8 - nacc));
     row_bytes[(size_t)pic * hc + cy] = c.n;            // (> row_cap: the buffer was too small, the row is truncated)
   }
+  if (!PERSIST) break;
+  __syncthreads();          // the row's state and s_job are free again
+  }
 }
 
 }  // namespace
@@ -916,7 +934,7 @@ extern "C" int uvghip_encode_slice_rows(int bitdepth, const uvghip_ctu_params_t 
   if (pictures)
     if (int rc = uvghip_slice_rows_prepare(params, pictures, n_pictures, workspace)) return rc;
   hipStream_t st = uvghip_stream(stream);
-  slice_rows_kernel<<<n_pictures * hc, 64, 0, st>>>(static_cast<const pic_dev *>(workspace), nullptr, sao_info, sao_models, W, H, params->qp, bitdepth, out,
+  slice_rows_kernel<false><<<n_pictures * hc, 64, 0, st>>>(static_cast<const pic_dev *>(workspace), nullptr, sao_info, sao_models, W, H, params->qp, bitdepth, out,
                                                     row_cap, row_bytes);
   UVGHIP_CHECK_LAUNCH();
 }
@@ -938,8 +956,30 @@ extern "C" int uvghip_encode_slice_rows_behind(int bitdepth, const uvghip_ctu_pa
   hipStream_t st = uvghip_stream(stream);
   if (pictures)
     if (int rc = prepare_ordered(params, pictures, n_pictures, workspace, st)) return rc;
-  slice_rows_kernel<<<n_pictures * hc, 64, 0, st>>>(static_cast<const pic_dev *>(workspace), nullptr, sao_info, sao_models, W, H, params->qp, bitdepth, out,
+  slice_rows_kernel<false><<<n_pictures * hc, 64, 0, st>>>(static_cast<const pic_dev *>(workspace), nullptr, sao_info, sao_models, W, H, params->qp, bitdepth, out,
                                                     row_cap, row_bytes, nullptr, final_flags);
+  UVGHIP_CHECK_LAUNCH();
+}
+
+// ... with at most max_waves rows in progress (persistent waves that take row r of every picture, then row r + 1, from `ticket`: one int32 of
+// DEVICE memory the caller zeroes in stream order before the launch): behind a search that is still RUNNING a waiting row must not hold what the
+// search needs -- a wave per row of a whole clip does (uvghip_loop_plan_run_overlapped).
+extern "C" int uvghip_encode_slice_rows_behind_capped(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_ctu_picture_t *pictures, int n_pictures,
+                                                      const int32_t *sao_info, const uint16_t *sao_models, const int32_t *final_flags, int32_t *ticket, int max_waves,
+                                                      void *workspace, uint8_t *out, int row_cap, int32_t *row_bytes, void *stream)
+{
+  UVGHIP_REQUIRE_READY();
+  UVGHIP_REQUIRE_DEPTH(bitdepth);
+  if (!params || n_pictures <= 0 || !workspace || !out || row_cap <= 0 || !row_bytes || !sao_info || !sao_models || !final_flags || !ticket || max_waves < 1)
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const int W = params->pic_w, H = params->pic_h, hc = (H + 63) / 64;
+  if (W <= 0 || H <= 0 || (W & 7) || (H & 7) || params->qp < 0 || params->qp > 63) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  hipStream_t st = uvghip_stream(stream);
+  if (pictures)
+    if (int rc = prepare_ordered(params, pictures, n_pictures, workspace, st)) return rc;
+  const int rows = n_pictures * hc, grid = rows < max_waves ? rows : max_waves;
+  slice_rows_kernel<true><<<grid, 64, 0, st>>>(static_cast<const pic_dev *>(workspace), nullptr, sao_info, sao_models, W, H, params->qp, bitdepth, out,
+                                               row_cap, row_bytes, nullptr, final_flags, ticket, n_pictures);
   UVGHIP_CHECK_LAUNCH();
 }
 
@@ -968,7 +1008,7 @@ extern "C" int uvghip_encode_slice_rows_alf(int bitdepth, const uvghip_ctu_param
   }
   unsigned char *aw = static_cast<unsigned char *>(workspace) + ((size_t)n_pictures * sizeof(pic_dev) + 255) / 256 * 256;
   if (int rc = uvghip_upload_ordered(aw, ad.data(), ad.size() * sizeof(alf_dev), st)) return rc;
-  slice_rows_kernel<<<n_pictures * hc, 64, 0, st>>>(static_cast<const pic_dev *>(workspace), nullptr, sao_info, sao_models, W, H, params->qp, bitdepth, out, row_cap, row_bytes,
+  slice_rows_kernel<false><<<n_pictures * hc, 64, 0, st>>>(static_cast<const pic_dev *>(workspace), nullptr, sao_info, sao_models, W, H, params->qp, bitdepth, out, row_cap, row_bytes,
                                                     reinterpret_cast<const alf_dev *>(aw));
   UVGHIP_CHECK_LAUNCH();
 }
@@ -998,7 +1038,7 @@ extern "C" int uvghip_encode_slice_rows_pb(int bitdepth, const uvghip_ctu_params
   }
   unsigned char *pbw = static_cast<unsigned char *>(workspace) + ((size_t)n_pictures * sizeof(pic_dev) + 255) / 256 * 256;
   if (int rc = uvghip_upload_ordered(pbw, pd.data(), pd.size() * sizeof(pb_dev), st)) return rc;
-  slice_rows_kernel<<<n_pictures * hc, 64, sizeof(row_state_pb), st>>>(static_cast<const pic_dev *>(workspace), reinterpret_cast<const pb_dev *>(pbw), sao_info, sao_models,
+  slice_rows_kernel<false><<<n_pictures * hc, 64, sizeof(row_state_pb), st>>>(static_cast<const pic_dev *>(workspace), reinterpret_cast<const pb_dev *>(pbw), sao_info, sao_models,
                                                                        W, H, params->qp, bitdepth, out, row_cap, row_bytes);
   UVGHIP_CHECK_LAUNCH();
 }

@@ -321,6 +321,11 @@ SIGNATURES = {
     "uvghip_loop_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
     "uvghip_loop_plan_create": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "uvghip_loop_plan_run": (c_int, [c_vp, c_vp]),
+    "uvghip_loop_plan_run_overlapped": (c_int, [c_vp, c_vp]),
+    "uvghip_encode_slice_rows_behind_capped": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_filter_pictures_reset": (c_int, [c_int, c_int, c_int, c_vp, c_vp]),
+    "uvghip_filter_pictures_run_behind": (c_int, [c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
+    "uvghip_filter_pictures_final_flags": (c_vp, [c_int, c_int, c_int, c_vp]),
     "uvghip_loop_plan_run_search": (c_int, [c_vp, c_vp]),
     "uvghip_loop_plan_run_filters": (c_int, [c_vp, c_vp]),
     "uvghip_loop_plan_results": (c_int, [c_vp, c_vp, c_vp]),
