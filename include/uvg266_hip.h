@@ -1218,6 +1218,15 @@ UVGHIP_API void uvghip_tiles_plan_destroy(uvghip_tiles_plan_t *plan);
  * (*used bytes; an error beyond cap), sums[count][3] -- the owned tiles' terms of the output picture's checksum
  * (uvghip_picture_checksum_rect).  Over the devices lengths and sums ADD UP (an all-reduce / a gather); uvghip_write_picture_nals then
  * writes what uvghip_tiles_plan_nals writes on one device (tests/test_gpu_tiles.py with emulated ranks, tests/test_tiles.py with gloo). */
+/* ... with the grid of --tiles-width-split / --tiles-height-split (src/encoder.c:452-478) instead of the uniform one: col_ctus[cols] / row_ctus[rows]
+ * = the columns' widths and the rows' heights in CTUs (encoder->tiles_col_width[] / tiles_row_height[]: the options' sample positions divided by
+ * 64, the last one the remainder); they must add up to the picture's CTU columns / rows.  owned as for _create_owned (NULL: all tiles). */
+UVGHIP_API int uvghip_tile_grid_split(int pic_w, int pic_h, const int32_t *col_ctus, int cols, const int32_t *row_ctus, int rows, uvghip_rect_t *tiles, int32_t *first_ctu);
+UVGHIP_API size_t uvghip_tiles_workspace_bytes_split(int bitdepth, int n_pictures, int pic_w, int pic_h, const int32_t *col_ctus, int cols, const int32_t *row_ctus, int rows,
+                                                     const uint8_t *owned);
+UVGHIP_API int uvghip_tiles_plan_create_split(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_loop_picture_t *pictures, int n_pictures, const int32_t *col_ctus,
+                                              int tile_cols, const int32_t *row_ctus, int tile_rows, const uint8_t *owned, int sao_type, void *workspace,
+                                              uvghip_tiles_plan_t **plan_out);
 UVGHIP_API size_t uvghip_tiles_workspace_bytes_owned(int bitdepth, int n_pictures, int pic_w, int pic_h, int cols, int rows, const uint8_t *owned);
 UVGHIP_API int uvghip_tiles_plan_create_owned(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_loop_picture_t *pictures, int n_pictures, int tile_cols,
                                               int tile_rows, const uint8_t *owned, int sao_type, void *workspace, uvghip_tiles_plan_t **plan_out);

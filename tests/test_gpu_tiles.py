@@ -11,7 +11,8 @@ import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-FULL = ["ref_tiles_264x136_8_qp27_2x2_1frames", "ref_tiles_192x192_8_qp37_1x3_1frames", "ref_tiles_320x192_8_qp22_5x1_1frames", "ref_tiles_416x240_10_qp32_3x2_2frames"]
+FULL = ["ref_tiles_264x136_8_qp27_2x2_1frames", "ref_tiles_192x192_8_qp37_1x3_1frames", "ref_tiles_320x192_8_qp22_5x1_1frames", "ref_tiles_416x240_10_qp32_3x2_2frames",
+        "ref_tiles_456x264_8_qp27_3x2_1frames_split"]          # (the last: --tiles-width-split / --tiles-height-split, columns of 1 / 4 / 3 CTUs)
 CRC = ["ref_tiles_1920x1080_8_qp22_2x2_2frames_crc", "ref_tiles_3840x2160_10_qp22_4x2_1frames_crc"]
 
 
@@ -25,7 +26,8 @@ def tiled_loop(g):
         assert zlib.crc32(y.tobytes() + u.tobytes() + v.tobytes()) == int(g["src_crc"][poc]), "synthetic generator drifted from the golden's source"
         src.append(tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in (y, u, v)))
     prm = H.search_params(W, Hh, qp)
-    return api.TiledLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), src, (cols, rows))
+    grid = (g["col_ctus"], g["row_ctus"]) if "col_ctus" in g.files else (cols, rows)
+    return api.TiledLoop(api.ctu_params(W, Hh, qp, lam=prm.lam), src, grid)
 
 
 def tile_substreams(tl, picture):

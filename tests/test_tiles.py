@@ -10,7 +10,13 @@ import pytest
 
 import helpers as H
 
-FULL = ["ref_tiles_264x136_8_qp27_2x2_1frames", "ref_tiles_192x192_8_qp37_1x3_1frames", "ref_tiles_320x192_8_qp22_5x1_1frames", "ref_tiles_416x240_10_qp32_3x2_2frames"]
+FULL = ["ref_tiles_264x136_8_qp27_2x2_1frames", "ref_tiles_192x192_8_qp37_1x3_1frames", "ref_tiles_320x192_8_qp22_5x1_1frames", "ref_tiles_416x240_10_qp32_3x2_2frames",
+        "ref_tiles_456x264_8_qp27_3x2_1frames_split"]
+
+
+def golden_grid(g):
+    """(cols, rows) of a uniform grid, or the columns' widths / rows' heights in CTUs of a --tiles-width-split / --tiles-height-split run."""
+    return (g["col_ctus"], g["row_ctus"]) if "col_ctus" in g.files else (int(g["meta"][4]), int(g["meta"][5]))
 
 
 def uniform(n_ctus, parts):
@@ -41,6 +47,22 @@ def test_tile_grid_is_the_encoders_uniform_grid(case):
     assert int((rects[:, 2] * rects[:, 3]).sum()) == W * Hh          # the tiles cover the picture exactly
 
 
+def test_tile_grid_from_explicit_splits():
+    """--tiles-width-split 64,320 --tiles-height-split 192 on 456x264 (encoder.c:452-478): columns of 1 / 4 / 3 CTUs (the last one cut by the
+    picture's edge: 456 = 7.125 CTUs), rows of 3 / 2."""
+    from uvg266_amd import api, lib
+    rects, first = api.tile_grid(456, 264, [1, 4, 3], [3, 2])
+    assert rects.tolist() == [[0, 0, 64, 192], [64, 0, 256, 192], [320, 0, 136, 192], [0, 192, 64, 72], [64, 192, 256, 72], [320, 192, 136, 72]]
+    assert first.tolist() == [0, 3, 15, 24, 26, 34]
+    L = lib.load_library()
+    out = np.zeros((64, 4), np.int32)
+    for cw, rh in [([1, 4, 2], [3, 2]), ([1, 4, 3], [3, 3]), ([0, 5, 3], [3, 2]), ([8], [5, 1])]:          # do not add up / an empty column
+        cw, rh = np.array(cw, np.int32), np.array(rh, np.int32)
+        assert L.uvghip_tile_grid_split(456, 264, cw.ctypes.data, len(cw), rh.ctypes.data, len(rh), out.ctypes.data, None) != 0
+    g = H.ctu_golden("ref_tiles_456x264_8_qp27_3x2_1frames_split")
+    assert g["col_ctus"].tolist() == [1, 4, 3] and g["row_ctus"].tolist() == [3, 2]
+
+
 def test_tile_grid_refuses_what_the_encoder_refuses():
     from uvg266_amd import lib
     L = lib.load_library()
@@ -64,7 +86,7 @@ def test_a_tile_is_a_picture_of_its_own(orc, name):
     L = lib.load_library()
     g = H.ctu_golden(name)
     W, Hh, depth, qp, cols, rows = (int(a) for a in g["meta"])
-    rects, _ = api.tile_grid(W, Hh, cols, rows)
+    rects, _ = api.tile_grid(W, Hh, *golden_grid(g))
     n_sub = int(sum((r[3] + 63) // 64 for r in rects))
     stream = g["bitstream"].tobytes()
     mine = b""

@@ -251,7 +251,7 @@ def stream_alf(W, H, depth, qp, ts, crc_only=False):
           [sum(int(r[0][0]) == i for r in P) for i in range(len(ts))])
 
 
-def tiles(W, H, depth, qp, ts, cols, rows, crc_only=False):
+def tiles(W, H, depth, qp, ts, cols, rows, crc_only=False, split=None):
     """A -p 1 --tiles <cols>x<rows> --wpp stream (the source pictures: helpers.varied_picture of ts): the .266, every substream in the order
     of the bitstream (per picture: tile after tile in raster order, a tile's WPP rows in order) and the pictures the encoder returned.
     Records are tile-local (ctu_dump.c reads state->tile->frame), so the per-CTU items stay out: the .266 holds every coded decision, the
@@ -259,7 +259,9 @@ def tiles(W, H, depth, qp, ts, cols, rows, crc_only=False):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers
     px = np.uint8 if depth == 8 else np.uint16
-    tag = f"{W}x{H}_{depth}_qp{qp}_{cols}x{rows}_{len(ts)}frames"
+    tag = f"{W}x{H}_{depth}_qp{qp}_{cols}x{rows}_{len(ts)}frames" + ("_split" if split else "")
+    # split = (column boundaries, row boundaries) in samples: --tiles-width-split / --tiles-height-split instead of the uniform grid
+    grid_opts = ["tiles", f"{cols}x{rows}"] if not split else ["tiles-width-split", ",".join(map(str, split[0])), "tiles-height-split", ",".join(map(str, split[1]))]
     yuv = f"/tmp/gold_tiles_{tag}.yuv"
     crcs = []
     with open(yuv, "wb") as f:
@@ -270,13 +272,13 @@ def tiles(W, H, depth, qp, ts, cols, rows, crc_only=False):
                 f.write(p.astype(px).tobytes())
     out = f"/tmp/gold_tiles_{tag}"
     subprocess.check_call([os.path.join(ROOT, "tools/refcheck/ctu_dump.sh"), str(depth), yuv, str(W), str(H), str(len(ts)), out,
-                           "preset", "medium", "period", "1", "qp", str(qp), "tiles", f"{cols}x{rows}", "wpp", "1"], stderr=subprocess.DEVNULL)
+                           "preset", "medium", "period", "1", "qp", str(qp)] + grid_opts + ["wpp", "1"], stderr=subprocess.DEVNULL)
     recs = read_records(out + ".bin")
     R = [r for n, r in recs if n == "row"]
     F = [r for n, r in recs if n == "final"]
     bs = open(out + ".266", "rb").read()
     wc, hc = (W + 63) // 64, (H + 63) // 64
-    n_sub = sum(((i + 1) * hc // rows - i * hc // rows) for i in range(rows)) * cols
+    n_sub = hc * cols          # every tile row's CTU rows, once per tile column
     assert len(R) == n_sub * len(ts) and len(F) == len(ts)
     # the records come in the order of the bitstream: the substreams follow each other inside every slice NAL
     at = 0
@@ -293,6 +295,9 @@ def tiles(W, H, depth, qp, ts, cols, rows, crc_only=False):
         more = dict(bitstream_head=np.frombuffer(bs[:head], np.uint8), bitstream_tail_len=np.int64(len(bs) - head), bitstream_tail_crc=np.uint32(zlib.crc32(bs[head:])),
                     row_crc=np.array([zlib.crc32(r[1].tobytes()) for r in R], np.uint32), final_crc=np.array([zlib.crc32(f.tobytes()) for f in finals], np.uint32))
         tag += "_crc"
+    if split:          # the columns' widths / rows' heights in CTUs (encoder.c:452-478)
+        edges = lambda b, n: np.diff([0] + [v // 64 for v in b] + [n]).astype(np.int32)
+        more.update(col_ctus=edges(split[0], wc), row_ctus=edges(split[1], hc))
     np.savez_compressed(os.path.join(ROOT, "tests/golden", f"ref_tiles_{tag}.npz"), meta=np.array([W, H, depth, qp, cols, rows], np.int32), ts=np.array(ts, np.int32),
                         src_crc=np.array(crcs, np.uint32), row_off=row_off, **more)
     print("wrote tiles", tag, len(bs), "bytes,", n_sub, "substreams per picture")
@@ -560,6 +565,7 @@ if __name__ == "__main__":
     tiles(416, 240, 10, 32, (2007, 11), 3, 2)          # ... 10 bit, two pictures of one stream, six tiles (2 / 2 / 3 columns: two sizes share a plan)
     tiles(320, 192, 8, 22, (1004,), 5, 1)              # ... a row of one-CTU-wide tiles: every CTU starts its row's substream... and 1 x 3:
     tiles(192, 192, 8, 37, (9,), 1, 3)                 # ... tiles one above the other, one WPP row each
+    tiles(456, 264, 8, 27, (1004,), 3, 2, split=((64, 320), (192,)))      # --tiles-width-split 64,320 --tiles-height-split 192: columns of 1 / 4 / 3 CTUs, rows of 3 / 2
     tiles(1920, 1080, 8, 22, (0, 1), 2, 2, crc_only=True)      # BASELINE configs[1]'s picture in 2 x 2 tiles (bench.py tiles_clip), by CRC
     tiles(1920, 1080, 8, 22, (0, 1), 6, 4, crc_only=True)      # ... bench.py's tiles_clip: 24 tiles of 5 x 4 / 5 x 5 CTUs
     tiles(3840, 2160, 10, 22, (0,), 4, 2, crc_only=True)       # ... configs[3]'s size and depth in 4 x 2 tiles: one tile per GPU of the node

@@ -879,8 +879,17 @@ class ClosedLoop(CtuSearch):
 
 def tile_grid(pic_w, pic_h, cols, rows):
     """uvghip_tile_grid (host function): the uniform grid of --tiles <cols>x<rows> -> (rects [cols * rows, 4] int32 (x, y, w, h in samples,
-    raster order of the tiles), first_ctu [cols * rows] int32: the tile-scan address of every tile's first CTU)."""
+    raster order of the tiles), first_ctu [cols * rows] int32: the tile-scan address of every tile's first CTU).  cols / rows may be
+    sequences instead: the columns' widths / the rows' heights in CTUs (uvghip_tile_grid_split: --tiles-width-split / --tiles-height-split)."""
     L = _lib.load_library()
+    if np.ndim(cols) or np.ndim(rows):
+        wc, hc = (pic_w + 63) // 64, (pic_h + 63) // 64
+        cw = np.ascontiguousarray(cols if np.ndim(cols) else [(i + 1) * wc // cols - i * wc // cols for i in range(cols)], np.int32)
+        rh = np.ascontiguousarray(rows if np.ndim(rows) else [(i + 1) * hc // rows - i * hc // rows for i in range(rows)], np.int32)
+        rects = np.zeros((len(cw) * len(rh), 4), np.int32)
+        first = np.zeros(len(cw) * len(rh), np.int32)
+        _lib.check(L.uvghip_tile_grid_split(pic_w, pic_h, cw.ctypes.data, len(cw), rh.ctypes.data, len(rh), rects.ctypes.data, first.ctypes.data), "uvghip_tile_grid_split")
+        return rects, first
     rects = np.zeros((cols * rows, 4), np.int32)
     first = np.zeros(cols * rows, np.int32)
     _lib.check(L.uvghip_tile_grid(pic_w, pic_h, cols, rows, rects.ctypes.data, first.ctypes.data), "uvghip_tile_grid")
@@ -898,9 +907,14 @@ class TiledLoop:
         picture over the devices of a node, uvg266_amd.tiles); None = all."""
         import ctypes
         self.P, self.n = params, len(src)
-        self.cols, self.rows = int(tiles[0]), int(tiles[1])
         W, H = int(params.pic_w), int(params.pic_h)
         self.wc, self.hc = (W + 63) // 64, (H + 63) // 64
+        # tiles = (cols, rows): the uniform grid of --tiles; either may be a sequence -- the columns' widths / the rows' heights in CTUs
+        # (--tiles-width-split / --tiles-height-split)
+        uni = lambda n, parts: [(i + 1) * n // parts - i * n // parts for i in range(parts)]
+        self.col_ctus = np.ascontiguousarray(tiles[0] if np.ndim(tiles[0]) else uni(self.wc, int(tiles[0])), np.int32)
+        self.row_ctus = np.ascontiguousarray(tiles[1] if np.ndim(tiles[1]) else uni(self.hc, int(tiles[1])), np.int32)
+        self.cols, self.rows = len(self.col_ctus), len(self.row_ctus)
         dev = src[0][0].device
         self.depth = _depth(src[0][0])
         self.L = _lib.init(dev.index or 0)
@@ -925,13 +939,13 @@ class TiledLoop:
         if self.owned is not None and self.owned.size != self.cols * self.rows:
             raise ValueError("owned: one entry per tile")
         own = None if self.owned is None else self.owned.ctypes.data
-        nbytes = self.L.uvghip_tiles_workspace_bytes_owned(self.depth, self.n, W, H, self.cols, self.rows, own)
+        nbytes = self.L.uvghip_tiles_workspace_bytes_split(self.depth, self.n, W, H, self.col_ctus.ctypes.data, self.cols, self.row_ctus.ctypes.data, self.rows, own)
         if not nbytes:
             raise ValueError("uvghip_tiles_workspace_bytes: the tile grid does not fit the picture (or no tile is owned)")
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self.plan = ctypes.c_void_p()
-        _lib.check(self.L.uvghip_tiles_plan_create_owned(self.depth, ctypes.byref(self.P), lp, self.n, self.cols, self.rows, own, sao_type, _dev(self.ws),
-                                                         ctypes.byref(self.plan)), "uvghip_tiles_plan_create_owned")
+        _lib.check(self.L.uvghip_tiles_plan_create_split(self.depth, ctypes.byref(self.P), lp, self.n, self.col_ctus.ctypes.data, self.cols, self.row_ctus.ctypes.data,
+                                                         self.rows, own, sao_type, _dev(self.ws), ctypes.byref(self.plan)), "uvghip_tiles_plan_create_split")
         a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _lib.check(self.L.uvghip_tiles_plan_layout(self.plan, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "uvghip_tiles_plan_layout")
         self.n_tiles, self.n_classes, self.n_substreams = a.value, b.value, c.value

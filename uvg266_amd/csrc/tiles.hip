@@ -50,19 +50,23 @@ namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// encoder.c:445-451: uniform spacing, column i is (i + 1) * W / n - i * W / n CTUs wide
-int grid(int pic_w, int pic_h, int cols, int rows, std::vector<uvghip_rect_t> &tiles, std::vector<int> &first_ctu)
+// the grid from the columns' widths and the rows' heights in CTUs (encoder->tiles_col_width / tiles_row_height)
+int grid_of(int pic_w, int pic_h, const std::vector<int> &colw, const std::vector<int> &rowh, std::vector<uvghip_rect_t> &tiles, std::vector<int> &first_ctu)
 {
-  const int wc = (pic_w + 63) / 64, hc = (pic_h + 63) / 64;
+  const int wc = (pic_w + 63) / 64, hc = (pic_h + 63) / 64, cols = (int)colw.size(), rows = (int)rowh.size();
   if (cols < 1 || rows < 1 || cols > wc || rows > hc || cols >= 48 || rows >= 48) return 1;      // (MAX_TILES_PER_DIM, global.h:297 with cfg.c:314; the encoder refuses more tiles than CTUs, encoder.c:405-412)
+  int sw = 0, sh = 0;
+  for (int v : colw) { if (v < 1) return 1; sw += v; }
+  for (int v : rowh) { if (v < 1) return 1; sh += v; }
+  if (sw != wc || sh != hc) return 1;
   tiles.resize((size_t)cols * rows);
   first_ctu.resize((size_t)cols * rows);
   int at = 0, y0 = 0;
   for (int r = 0; r < rows; ++r) {
-    const int th = (r + 1) * hc / rows - r * hc / rows;
+    const int th = rowh[r];
     int x0 = 0;
     for (int c = 0; c < cols; ++c) {
-      const int tw = (c + 1) * wc / cols - c * wc / cols;
+      const int tw = colw[c];
       uvghip_rect_t &t = tiles[(size_t)r * cols + c];
       t.x = x0 * 64; t.y = y0 * 64;
       t.w = (x0 + tw) * 64 > pic_w ? pic_w - x0 * 64 : tw * 64;
@@ -74,6 +78,21 @@ int grid(int pic_w, int pic_h, int cols, int rows, std::vector<uvghip_rect_t> &t
     y0 += th;
   }
   return 0;
+}
+
+// encoder.c:445-451: uniform spacing, column i is (i + 1) * W / n - i * W / n CTUs wide
+void uniform(int n_ctus, int parts, std::vector<int> &out)
+{
+  out.clear();
+  for (int i = 0; i < parts; ++i) out.push_back((i + 1) * n_ctus / parts - i * n_ctus / parts);
+}
+int grid(int pic_w, int pic_h, int cols, int rows, std::vector<uvghip_rect_t> &tiles, std::vector<int> &first_ctu)
+{
+  const int wc = (pic_w + 63) / 64, hc = (pic_h + 63) / 64;
+  if (cols < 1 || rows < 1 || cols > wc || rows > hc) return 1;
+  std::vector<int> colw, rowh;
+  uniform(wc, cols, colw); uniform(hc, rows, rowh);
+  return grid_of(pic_w, pic_h, colw, rowh, tiles, first_ctu);
 }
 
 struct class_key { int w, h, count; };
@@ -167,6 +186,19 @@ extern "C" int uvghip_tile_grid(int pic_w, int pic_h, int cols, int rows, uvghip
   return 0;
 }
 
+// ... of --tiles-width-split / --tiles-height-split (encoder.c:452-478): the columns' widths and the rows' heights in CTUs
+// (encoder->tiles_col_width[] / tiles_row_height[]; they must add up to the picture's).  HOST function.
+extern "C" int uvghip_tile_grid_split(int pic_w, int pic_h, const int32_t *col_ctus, int cols, const int32_t *row_ctus, int rows, uvghip_rect_t *tiles, int32_t *first_ctu)
+{
+  if (pic_w <= 0 || pic_h <= 0 || !tiles || !col_ctus || !row_ctus || cols < 1 || rows < 1) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  std::vector<uvghip_rect_t> t;
+  std::vector<int> f;
+  if (grid_of(pic_w, pic_h, std::vector<int>(col_ctus, col_ctus + cols), std::vector<int>(row_ctus, row_ctus + rows), t, f))
+    return uvghip_set_error(hipErrorInvalidValue, "uvghip_tile_grid_split: the columns / rows do not add up to the picture's CTUs (or an empty one, or too many)");
+  for (size_t i = 0; i < t.size(); ++i) { tiles[i] = t[i]; if (first_ctu) first_ctu[i] = f[i]; }
+  return 0;
+}
+
 extern "C" size_t uvghip_tiles_workspace_bytes(int bitdepth, int n_pictures, int pic_w, int pic_h, int cols, int rows)
 {
   return uvghip_tiles_workspace_bytes_owned(bitdepth, n_pictures, pic_w, pic_h, cols, rows, nullptr);
@@ -174,10 +206,20 @@ extern "C" size_t uvghip_tiles_workspace_bytes(int bitdepth, int n_pictures, int
 
 extern "C" size_t uvghip_tiles_workspace_bytes_owned(int bitdepth, int n_pictures, int pic_w, int pic_h, int cols, int rows, const uint8_t *owned)
 {
-  if ((bitdepth != 8 && bitdepth != 10) || n_pictures <= 0 || pic_w <= 0 || pic_h <= 0) return 0;
+  const int wc = (pic_w + 63) / 64, hc = (pic_h + 63) / 64;
+  if (pic_w <= 0 || pic_h <= 0 || cols < 1 || rows < 1 || cols > wc || rows > hc) return 0;
+  std::vector<int> colw, rowh;
+  uniform(wc, cols, colw); uniform(hc, rows, rowh);
+  return uvghip_tiles_workspace_bytes_split(bitdepth, n_pictures, pic_w, pic_h, colw.data(), cols, rowh.data(), rows, owned);
+}
+
+extern "C" size_t uvghip_tiles_workspace_bytes_split(int bitdepth, int n_pictures, int pic_w, int pic_h, const int32_t *col_ctus, int cols, const int32_t *row_ctus, int rows,
+                                                     const uint8_t *owned)
+{
+  if ((bitdepth != 8 && bitdepth != 10) || n_pictures <= 0 || pic_w <= 0 || pic_h <= 0 || !col_ctus || !row_ctus || cols < 1 || rows < 1) return 0;
   std::vector<uvghip_rect_t> t;
   std::vector<int> f, cls_of, slot_of;
-  if (grid(pic_w, pic_h, cols, rows, t, f)) return 0;
+  if (grid_of(pic_w, pic_h, std::vector<int>(col_ctus, col_ctus + cols), std::vector<int>(row_ctus, row_ctus + rows), t, f)) return 0;
   std::vector<class_key> keys;
   classes_of(t, owned, keys, cls_of, slot_of);
   if (keys.empty()) return 0;
@@ -201,14 +243,31 @@ extern "C" int uvghip_tiles_plan_create(int bitdepth, const uvghip_ctu_params_t 
 extern "C" int uvghip_tiles_plan_create_owned(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_loop_picture_t *pictures, int n_pictures, int tile_cols,
                                               int tile_rows, const uint8_t *owned, int sao_type, void *workspace, uvghip_tiles_plan_t **plan_out)
 {
+  if (!params) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const int wc = (params->pic_w + 63) / 64, hc = (params->pic_h + 63) / 64;
+  if (tile_cols < 1 || tile_rows < 1 || tile_cols > wc || tile_rows > hc)
+    return uvghip_set_error(hipErrorInvalidValue, "uvghip_tiles_plan_create: more tiles than CTUs in a dimension (or none)");
+  std::vector<int> colw, rowh;
+  uniform(wc, tile_cols, colw); uniform(hc, tile_rows, rowh);
+  return uvghip_tiles_plan_create_split(bitdepth, params, pictures, n_pictures, colw.data(), tile_cols, rowh.data(), tile_rows, owned, sao_type, workspace, plan_out);
+}
+
+// ... with the columns' widths and the rows' heights given in CTUs: --tiles-width-split / --tiles-height-split (encoder.c:452-478)
+extern "C" int uvghip_tiles_plan_create_split(int bitdepth, const uvghip_ctu_params_t *params, const uvghip_loop_picture_t *pictures, int n_pictures, const int32_t *col_ctus,
+                                              int tile_cols, const int32_t *row_ctus, int tile_rows, const uint8_t *owned, int sao_type, void *workspace,
+                                              uvghip_tiles_plan_t **plan_out)
+{
   UVGHIP_REQUIRE_READY();
   UVGHIP_REQUIRE_DEPTH(bitdepth);
-  if (!params || !pictures || n_pictures <= 0 || !workspace || !plan_out) return uvghip_set_error(hipErrorInvalidValue, __func__);
+  if (!params || !pictures || n_pictures <= 0 || !workspace || !plan_out || !col_ctus || !row_ctus || tile_cols < 1 || tile_rows < 1) return uvghip_set_error(hipErrorInvalidValue, __func__);
   uvghip_tiles_plan *pl = new (std::nothrow) uvghip_tiles_plan;
   if (!pl) return uvghip_set_error(hipErrorOutOfMemory, __func__);
   pl->bitdepth = bitdepth; pl->n = n_pictures; pl->w = params->pic_w; pl->h = params->pic_h; pl->cols = tile_cols; pl->rows = tile_rows; pl->sao_type = sao_type;
   pl->fork = nullptr; pl->host_rows = nullptr; pl->host_cap = 0; pl->dev_rows = nullptr; pl->dev_cap = 0; pl->host_tab = nullptr; pl->dev_tab = nullptr; pl->tab_cap = 0;
-  if (grid(pl->w, pl->h, tile_cols, tile_rows, pl->tiles, pl->first_ctu)) { delete pl; return uvghip_set_error(hipErrorInvalidValue, "uvghip_tiles_plan_create: more tiles than CTUs in a dimension (or none)"); }
+  if (grid_of(pl->w, pl->h, std::vector<int>(col_ctus, col_ctus + tile_cols), std::vector<int>(row_ctus, row_ctus + tile_rows), pl->tiles, pl->first_ctu)) {
+    delete pl;
+    return uvghip_set_error(hipErrorInvalidValue, "uvghip_tiles_plan_create: the tile columns / rows do not add up to the picture's CTUs (or an empty one, or too many)");
+  }
   const int wc = (pl->w + 63) / 64;
   for (int i = 0; i < n_pictures; ++i) {
     const uvghip_ctu_picture_t &s = pictures[i].search;

@@ -273,6 +273,9 @@ SIGNATURES = {
     "uvghip_tiles_plan_destroy": (None, [c_vp]),
     "uvghip_tiles_workspace_bytes_owned": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "uvghip_tiles_plan_create_owned": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_tile_grid_split": (c_int, [c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
+    "uvghip_tiles_workspace_bytes_split": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp]),
+    "uvghip_tiles_plan_create_split": (c_int, [c_int, c_vp, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_tiles_plan_substreams": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, ctypes.c_size_t, c_vp, c_vp, c_vp]),
     "uvghip_picture_checksum_rect": (c_int, [c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "uvghip_loop_plan_alf_workspace_bytes": (ctypes.c_size_t, [c_vp]),
