@@ -18,6 +18,7 @@
 #include <new>
 #include <vector>
 #include <cstring>
+#include <cstdlib>
 
 struct uvghip_tiles_plan {
   int bitdepth, n, w, h, cols, rows, sao_type;
@@ -328,7 +329,10 @@ extern "C" int uvghip_tiles_plan_run(uvghip_tiles_plan_t *pl, void *stream)
   UVGHIP_REQUIRE_READY();
   if (!pl) return uvghip_set_error(hipErrorInvalidValue, __func__);
   hipStream_t st = uvghip_stream(stream);
-  if (pl->classes.size() == 1) return uvghip_loop_plan_run(pl->classes[0].plan, stream);
+  // up to two size classes: each class's filters and coder BESIDE its search (uvghip_loop_plan_run_overlapped; it is the serial order by
+  // itself when the class's wavefronts fill the device) -- six streams in all, within what the runtime carries side by side
+  auto run_class = (pl->classes.size() <= 2 || getenv("UVGHIP_TILES_OVERLAP_ALL")) ? uvghip_loop_plan_run_overlapped : uvghip_loop_plan_run;
+  if (pl->classes.size() == 1) return run_class(pl->classes[0].plan, stream);
   // classes 1.. on the plan's own streams, class 0 on the caller's: a uniform grid's four classes then take four streams, what the
   // runtime's hardware queues carry side by side by default (GPU_MAX_HW_QUEUES = 4; a fifth stream shares a queue with another and the
   // two launches run one after the other: measured, 4 x 4 tiles of one 1080p picture 219 -> 119 ms; uvg266_amd/__init__.py raises the default to 8)
@@ -336,10 +340,10 @@ extern "C" int uvghip_tiles_plan_run(uvghip_tiles_plan_t *pl, void *stream)
   for (size_t k = 1; k < pl->classes.size(); ++k) {
     auto &c = pl->classes[k];
     UVGHIP_TRY(hipStreamWaitEvent(c.st, pl->fork, 0));
-    if (int rc = uvghip_loop_plan_run(c.plan, c.st)) return rc;
+    if (int rc = run_class(c.plan, c.st)) return rc;
     UVGHIP_TRY(hipEventRecord(c.done, c.st));
   }
-  if (int rc = uvghip_loop_plan_run(pl->classes[0].plan, stream)) return rc;
+  if (int rc = run_class(pl->classes[0].plan, stream)) return rc;
   for (size_t k = 1; k < pl->classes.size(); ++k) UVGHIP_TRY(hipStreamWaitEvent(st, pl->classes[k].done, 0));
   return 0;
 }
