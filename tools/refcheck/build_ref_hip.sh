@@ -3,7 +3,8 @@
 #   1. /root/reference/src is copied to a scratch directory under /tmp (never into the repository, nothing is written under
 #      /root/reference);
 #   2. INTEGRATION.md section 1 is applied by tools/refcheck/patch_ref_hip.py (one registration block per strategy group) and the
-#      section-2 shim (uvg266_amd/csrc/shim/strategies-hip-state.c) is copied to src/strategies/hip/;
+#      section-2 shim (uvg266_amd/csrc/shim/strategies-hip-state.c) is copied to src/strategies/hip/; so are section 10's frame-level
+#      hand-over (uvg266_amd/csrc/shim/frame-hip.c) and its two statements in uvg_encode_one_frame / the bitstream job;
 #   3. everything is compiled with oracle/build_ref.sh's flags + -DUVG_HAVE_HIP (+ -DDEBUG_STRATEGYSELECTOR for strategyselector.c so
 #      that the selector prints which strategy it chose per type) and linked against uvg266_amd/libuvg266hip.so.
 # Output: oracle/_ref/uvg266_{8,10}_hip (binaries only; git-ignored; they travel to the GPU box with the snapshot like oracle/_ref's
@@ -18,14 +19,14 @@ OUT="$ROOT/oracle/_ref"
 [ -f "$ROOT/uvg266_amd/libuvg266hip.so" ] || { echo "build_ref_hip.sh: build uvg266_amd/libuvg266hip.so first" >&2; exit 3; }
 "$ROOT/oracle/build_ref.sh" "$REF"                      # oracle/_ref/gen/version.h and the plain build beside it
 SUM=$( (cd "$REF" && find src -type f \( -name '*.c' -o -name '*.h' -o -name '*.in' \) | LC_ALL=C sort | xargs sha1sum; \
-        sha1sum "$HERE/patch_ref_hip.py" "$HERE/build_ref_hip.sh" "$ROOT/uvg266_amd/csrc/shim/strategies-hip-state.c" "$ROOT/include/uvg266_hip.h") | sha1sum | cut -d' ' -f1)
+        sha1sum "$HERE/patch_ref_hip.py" "$HERE/build_ref_hip.sh" "$ROOT/uvg266_amd/csrc/shim/strategies-hip-state.c" "$ROOT/uvg266_amd/csrc/shim/frame-hip.c" "$ROOT/include/uvg266_hip.h") | sha1sum | cut -d' ' -f1)
 if [ -f "$OUT/STAMP_HIP" ] && [ "$(cat "$OUT/STAMP_HIP")" = "$SUM" ] && [ -x "$OUT/uvg266_8_hip" ] && [ -x "$OUT/uvg266_10_hip" ]; then exit 0; fi
 SCR=$(mktemp -d /tmp/uvg266_hip_src.XXXXXX)
 trap 'rm -rf "$SCR"' EXIT
 cp -r "$REF/src" "$SCR/src"
 chmod -R u+w "$SCR/src"
 mkdir -p "$SCR/src/strategies/hip"
-cp "$ROOT/uvg266_amd/csrc/shim/strategies-hip-state.c" "$SCR/src/strategies/hip/"
+cp "$ROOT/uvg266_amd/csrc/shim/strategies-hip-state.c" "$ROOT/uvg266_amd/csrc/shim/frame-hip.c" "$SCR/src/strategies/hip/"
 python3 "$HERE/patch_ref_hip.py" "$SCR/src"
 CC=${CC:-gcc}
 BASE="-O3 -g0 -w -DNDEBUG -DUVG_DLL_EXPORTS -DUVG_HAVE_HIP -I$OUT/gen -I$SCR/src -I$SCR/src/extras -I$SCR/src/strategies -I$ROOT/include"

@@ -49,5 +49,38 @@ def main(src):
         print(f"patched {rel}")
 
 
+# the frame-level hand-over (uvg266_amd/csrc/shim/frame-hip.c).  Two statements.
+FRAME = [
+    ("encoderstate.c", r"void\s+uvg_encode_one_frame\s*\(", "  encoder_state_encode(state);\n",
+     "#if defined(UVG_HAVE_HIP)\n"
+     "  extern int uvg_hip_frame_enabled(const encoder_state_t *state);       /* strategies/hip/frame-hip.c */\n"
+     "  extern void uvg_hip_frame_begin(encoder_state_t *state);\n"
+     "  if (uvg_hip_frame_enabled(state)) uvg_hip_frame_begin(state); else\n"
+     "#endif\n"
+     "  encoder_state_encode(state);\n"),
+    ("encoder_state-bitstream.c", r"void\s+uvg_encoder_state_worker_write_bitstream\s*\(", "  uvg_encoder_state_write_bitstream((encoder_state_t *) opaque);\n",
+     "#if defined(UVG_HAVE_HIP)\n"
+     "  { extern void uvg_hip_frame_finish(encoder_state_t *state); uvg_hip_frame_finish((encoder_state_t *) opaque); }\n"
+     "#endif\n"
+     "  uvg_encoder_state_write_bitstream((encoder_state_t *) opaque);\n"),
+]
+
+
+def patch_frame(src):
+    for rel, fn, old, new in FRAME:
+        path = f"{src}/{rel}"
+        text = open(path).read()
+        m = re.search(fn, text)
+        if not m:
+            sys.exit(f"patch_ref_hip: {fn} not found in {rel}")
+        at = text.find(old, m.end())
+        if at < 0 or at - m.end() > 4000:
+            sys.exit(f"patch_ref_hip: `{old.strip()}` not found behind {fn} in {rel}")
+        text = text[:at] + new + text[at + len(old):]
+        open(path, "w").write(text)
+        print(f"patched {rel} (frame hand-over)")
+
+
 if __name__ == "__main__":
     main(sys.argv[1])
+    patch_frame(sys.argv[1])

@@ -1,0 +1,172 @@
+/* Frame-level half of the hip backend: an all-intra frame handed to the device's closed loop where the encoder would queue its
+ * per-CTU jobs.
+ *
+ * This file is compiled INSIDE the uvg266 source tree like strategies-hip-state.c (copy it to src/strategies/hip/; INTEGRATION.md
+ * section 10).  It sees encoder_state_t and does field extraction only: the frame's source planes and the frame-level QP / lambda in,
+ * the picture after the in-loop filters into frame->rec and every WPP row's substream into the row's leaf state out -- the samples,
+ * decisions and bins are libuvg266hip.so's (uvghip_frame_encoder_*, include/uvg266_hip.h section 7a).
+ *
+ * Two call sites, both applied by tools/refcheck/patch_ref_hip.py:
+ *   uvg_encode_one_frame (src/encoderstate.c:2051-2091): `if (uvg_hip_frame_enabled(state)) uvg_hip_frame_begin(state); else
+ *     encoder_state_encode(state);` -- behind encoder_state_init_new_frame, in front of the creation of the bitstream job;
+ *   uvg_encoder_state_worker_write_bitstream (src/encoder_state-bitstream.c:1609-1612): uvg_hip_frame_finish(state) in front of
+ *     uvg_encoder_state_write_bitstream -- the job waits for the device where it would have waited for the rows' jobs.
+ * Everything else of the frame is the encoder's own: parameter sets, slice header, entry points, the children's streams moved into
+ * the main stream, the hash SEI over frame->rec.
+ *
+ * UVG266_HIP_FRAME=1 asks for it.  A configuration the closed loop does not cover is an ERROR then, not a silent fall-back to
+ * the CPU search (the product path fails loudly): --preset medium / slow with -p 1 and --wpp is what is covered.
+ */
+#include "encoderstate.h"
+#include "encoder.h"
+#include "videoframe.h"
+#include "image.h"
+#include "bitstream.h"
+#include "rate_control.h"
+#include "uvg266_hip.h"
+
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define HIP_FRAME_SLOTS 64            /* main encoder states = frames in flight (--owf + 1) */
+
+static struct {
+  const encoder_state_t *state;
+  uvghip_frame_encoder_t *enc;
+  int begun;
+} hip_slots[HIP_FRAME_SLOTS];
+static pthread_mutex_t hip_slots_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static void hip_frame_die(const char *what)
+{
+  fprintf(stderr, "hip frame backend: %s (%s)\n", what, uvghip_last_error());
+  abort();
+}
+
+static int hip_slot_of(const encoder_state_t *state, int create)
+{
+  int at = -1;
+  pthread_mutex_lock(&hip_slots_lock);
+  for (int i = 0; i < HIP_FRAME_SLOTS && at < 0; ++i) if (hip_slots[i].state == state) at = i;
+  for (int i = 0; i < HIP_FRAME_SLOTS && at < 0 && create; ++i) {
+    if (!hip_slots[i].state) { hip_slots[i].state = state; hip_slots[i].enc = NULL; hip_slots[i].begun = 0; at = i; }
+  }
+  pthread_mutex_unlock(&hip_slots_lock);
+  return at;
+}
+
+/* the configuration uvghip_loop_plan_create's kernels were built for: what --preset medium / slow -p 1 --wpp sets (cfg.c's preset table) */
+static const char *hip_frame_unsupported(const encoder_state_t *state)
+{
+  const encoder_control_t *ctrl = state->encoder_control;
+  const uvg_config *c = &ctrl->cfg;
+  if (c->intra_period != 1) return "intra period != 1 (P / B pictures go through uvghip_loop_pb_run_inflight)";
+  if (!c->wpp) return "--no-wpp";
+  if (c->tiles_width_count > 1 || c->tiles_height_count > 1) return "tiles (uvghip_tiles_plan_*)";
+  if (c->slices) return "slices";
+  if (ctrl->chroma_format != UVG_CSP_420) return "chroma format";
+  if (c->rdo > 1) return "rd >= 2";
+  if (!c->rdoq_enable || c->rdoq_skip) return "rdoq off / rdoq-skip";
+  if (c->signhide_enable) return "signhide";
+  if (c->trskip_enable || c->chroma_trskip_enable) return "transform skip";
+  if (c->mts || c->lfnst || c->jccr || c->cclm || c->dual_tree || c->mip || c->mrl || c->isp || c->ibc || c->dep_quant) return "a VVC tool the medium preset leaves off";
+  if (c->alf_type || c->lmcs_enable) return "ALF / LMCS";
+  if (!c->sao_type || !c->deblock_enable || c->deblock_beta || c->deblock_tc) return "SAO off, deblocking off or with offsets";
+  if (c->cu_split_termination != UVG_CU_SPLIT_TERMINATION_ZERO) return "cu-split-termination";
+  if (c->full_intra_search || c->intra_rdo_et || c->fast_residual_cost_limit || c->lossless || c->implicit_rdpcm) return "an intra search option";
+  if (c->max_btt_depth[0] || c->ml_pu_depth_intra) return "multi-type tree / ml-pu-depth-intra";
+  if (c->target_bitrate > 0 || c->vaq || c->set_qp_in_cu || c->erp_aqp || c->scaling_list) return "rate control / adaptive QP / scaling lists";
+  if (state->tile->frame->source->roi.roi_array) return "roi";
+  if (ctrl->in.width % 8 || ctrl->in.height % 8) return "picture size not a multiple of 8";
+  return NULL;
+}
+
+int uvg_hip_frame_enabled(const encoder_state_t *state)
+{
+  const char *e = getenv("UVG266_HIP_FRAME");
+  if (!e || !*e || !strcmp(e, "0")) return 0;
+  const char *why = hip_frame_unsupported(state);
+  if (why) {
+    fprintf(stderr, "hip frame backend: UVG266_HIP_FRAME is set, but the closed loop does not cover this configuration: %s\n", why);
+    abort();
+  }
+  return 1;
+}
+
+/* the WPP rows' leaf states in the order the bitstream writer visits them (encoder_state_write_bitstream_children) */
+static int hip_collect_rows(encoder_state_t *state, encoder_state_t **rows, int cap, int n)
+{
+  if (state->is_leaf) {
+    if (state->type != ENCODER_STATE_TYPE_WAVEFRONT_ROW || n >= cap) return -1;
+    rows[n] = state;
+    return n + 1;
+  }
+  for (int i = 0; state->children[i].encoder_control; ++i) {
+    n = hip_collect_rows(&state->children[i], rows, cap, n);
+    if (n < 0) return n;
+  }
+  return n;
+}
+
+void uvg_hip_frame_begin(encoder_state_t *state)
+{
+  const encoder_control_t *ctrl = state->encoder_control;
+  encoder_state_t *rows[256];
+  const int n = hip_collect_rows(state, rows, 256, 0);
+  if (n != state->tile->frame->height_in_lcu) { fprintf(stderr, "hip frame backend: %d WPP rows for %d CTU rows\n", n, state->tile->frame->height_in_lcu); abort(); }
+
+  /* the frame-level parameters as every CTU of the frame would see them (no rate control, no ROI: checked above).  Derived on the MAIN
+   * state: a tile state's frame has no source picture before encoder_state_encode makes its sub-image (src/encoderstate.c:1232-1262) */
+  encoder_state_t *leaf = state;
+  vector2d_t origin = {0, 0};
+  uvg_set_lcu_lambda_and_qp(leaf, origin);                      /* src/rate_control.c:1097-1188 */
+  uvghip_ctu_params_t p;
+  memset(&p, 0, sizeof p);
+  p.pic_w = ctrl->in.width; p.pic_h = ctrl->in.height;
+  p.qp = leaf->qp; p.qp_c = ctrl->qp_map[0][leaf->qp];
+  p.depth_min = ctrl->cfg.pu_depth_intra.min[0]; p.depth_max = ctrl->cfg.pu_depth_intra.max[0];
+  p.wpp = ctrl->cfg.wpp; p.combine_intra_cus = ctrl->cfg.combine_intra_cus;
+  p.rough_levels = ctrl->cfg.intra_rough_search_levels; p.rd = ctrl->cfg.rdo;
+  p.lambda = leaf->lambda; p.lambda_sqrt = leaf->lambda_sqrt; p.c_lambda = leaf->c_lambda;
+  p.chroma_weight_u = leaf->chroma_weights[1]; p.chroma_weight_v = leaf->chroma_weights[2];
+  p.c_lambda_tu = uvg_calculate_chroma_lambda(leaf, false, 0);
+
+  const int at = hip_slot_of(state, 1);
+  if (at < 0) { fprintf(stderr, "hip frame backend: more than %d frames in flight\n", HIP_FRAME_SLOTS); abort(); }
+  if (!hip_slots[at].enc) {
+    if (uvghip_init(0) != 0) hip_frame_die("uvghip_init");
+    if (uvghip_frame_encoder_create(ctrl->bitdepth, &p, (int)ctrl->cfg.sao_type, &hip_slots[at].enc)) hip_frame_die("uvghip_frame_encoder_create");
+  }
+  const uvg_picture *src = state->tile->frame->source;
+  if (uvghip_frame_encoder_begin(hip_slots[at].enc, &p, src->y, src->u, src->v, src->stride, src->stride / 2)) hip_frame_die("uvghip_frame_encoder_begin");
+  hip_slots[at].begun = 1;
+}
+
+void uvg_hip_frame_finish(encoder_state_t *state)
+{
+  const int at = hip_slot_of(state, 0);
+  if (at < 0 || !hip_slots[at].begun) return;                   /* a frame the CPU encoded */
+  hip_slots[at].begun = 0;
+  uvg_picture *rec = state->tile->frame->rec;
+  const uint8_t *bytes;
+  const int32_t *row_bytes;
+  int n_rows;
+  if (uvghip_frame_encoder_finish(hip_slots[at].enc, rec->y, rec->u, rec->v, rec->stride, rec->stride / 2, &bytes, &row_bytes, &n_rows))
+    hip_frame_die("uvghip_frame_encoder_finish");
+  encoder_state_t *rows[256];
+  const int n = hip_collect_rows(state, rows, 256, 0);
+  if (n != n_rows) { fprintf(stderr, "hip frame backend: %d rows from the device for %d leaf states\n", n_rows, n); abort(); }
+  for (int r = 0; r < n; ++r) {
+    bitstream_t *s = &rows[r]->stream;
+    /* the row's bytes as the row's coder leaves them (uvg_bitstream_put_byte's emulation prevention already applied) */
+    uint8_t zeros = 0;
+    for (int i = 0; i < row_bytes[r]; ++i) {
+      uvg_bitstream_writebyte(s, bytes[i]);
+      zeros = bytes[i] == 0 ? zeros + 1 : 0;
+    }
+    s->zerocount = zeros;
+    bytes += row_bytes[r];
+  }
+}
