@@ -1180,24 +1180,27 @@ UVGHIP_API int uvghip_loop_plan_group_nals(uvghip_loop_plan_t *plan, int first_p
  * params below are what uvg_set_lcu_lambda_and_qp leaves in a leaf state, src/rate_control.c:1097-1188) and its own
  * uvg_encoder_state_worker_write_bitstream behind it: parameter sets, slice header with the entry points, the children's streams,
  * the hash SEI (src/encoder_state-bitstream.c:1513-1607).
- * One encoder object per frame in flight (the reference has one main encoder_state_t per --owf slot): device buffers for one picture,
- * a uvghip_loop_plan, a stream of its own.
- *   begin:  src_* = frame->source planes (HOST memory, strides in samples); stages them, enqueues upload + search + filters + slice data
- *           + the downloads and returns.  params may differ from picture to picture (QP, lambda); the size may not.
- *   finish: waits; out_* (HOST, strides in samples) receive the picture the encoder returns (frame->rec after deblocking and SAO);
- *           rows / row_bytes / n_rows: the substreams of the WPP rows one after the other in HOST memory owned by the object (valid
- *           until the next begin), row_bytes[r] bytes each -- what leaf state r holds in `stream` after its last CTU, emulation
- *           prevention included (append with uvg_bitstream_writebyte, not uvg_bitstream_put_byte).  May be called from another
- *           thread than begin (the bitstream job).
+ * One pool per encoder: n_slots = frames in flight (the reference has one main encoder_state_t per --owf slot: cfg.owf + 1), each slot
+ * the device buffers of one picture.  Frames that are begun collect in a GROUP; a group becomes ONE uvghip_loop_plan launch on a stream of
+ * its own when it holds group_max pictures, when a frame with other parameters arrives, or when one of its frames is asked for -- the
+ * pictures of a group share the device as the pictures of bench.py's launch do (separate launches of single pictures do not: beyond a
+ * handful of queues their waiting workgroups crowd each other out).
+ *   begin:  slot = the frame's slot (free: never used or finished); src_* = frame->source planes (HOST memory, strides in samples);
+ *           stages them, enqueues the upload and returns.  params may differ from picture to picture (QP, lambda); the size may not.
+ *   finish: launches the slot's group if it still collects, waits for it; out_* (HOST, strides in samples) receive the picture the
+ *           encoder returns (frame->rec after deblocking and SAO); rows / row_bytes / n_rows: the substreams of the WPP rows one after
+ *           the other in HOST memory owned by the pool (valid until the slot's next begin), row_bytes[r] bytes each -- what leaf state r
+ *           holds in `stream` after its last CTU, emulation prevention included (append with uvg_bitstream_writebyte, not
+ *           uvg_bitstream_put_byte).  May be called from another thread than begin (the bitstream job) and beside it.
  * Refuses what uvghip_loop_plan_create refuses (anything but --preset medium / slow -p 1 with SAO, qp_c != qp).
  * Reference-side caller: uvg266_amd/csrc/shim/frame-hip.c, applied by tools/refcheck/patch_ref_hip.py. */
-typedef struct uvghip_frame_encoder uvghip_frame_encoder_t;
-UVGHIP_API int uvghip_frame_encoder_create(int bitdepth, const uvghip_ctu_params_t *params, int sao_type, uvghip_frame_encoder_t **encoder_out);
-UVGHIP_API int uvghip_frame_encoder_begin(uvghip_frame_encoder_t *encoder, const uvghip_ctu_params_t *params, const void *src_y, const void *src_u,
-                                          const void *src_v, int src_stride, int src_stride_c);
-UVGHIP_API int uvghip_frame_encoder_finish(uvghip_frame_encoder_t *encoder, void *out_y, void *out_u, void *out_v, int out_stride, int out_stride_c,
-                                           const uint8_t **rows, const int32_t **row_bytes, int *n_rows);
-UVGHIP_API void uvghip_frame_encoder_destroy(uvghip_frame_encoder_t *encoder);
+typedef struct uvghip_frame_pool uvghip_frame_pool_t;
+UVGHIP_API int uvghip_frame_pool_create(int bitdepth, const uvghip_ctu_params_t *params, int sao_type, int n_slots, int group_max, uvghip_frame_pool_t **pool_out);
+UVGHIP_API int uvghip_frame_pool_begin(uvghip_frame_pool_t *pool, int slot, const uvghip_ctu_params_t *params, const void *src_y, const void *src_u,
+                                       const void *src_v, int src_stride, int src_stride_c);
+UVGHIP_API int uvghip_frame_pool_finish(uvghip_frame_pool_t *pool, int slot, void *out_y, void *out_u, void *out_v, int out_stride, int out_stride_c,
+                                        const uint8_t **rows, const int32_t **row_bytes, int *n_rows);
+UVGHIP_API void uvghip_frame_pool_destroy(uvghip_frame_pool_t *pool);
 
 /* ------------------- (7b) tiles: the independent rectangles of a picture ---------------------------------------------------- */
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The frame-level hand-over timed inside the reference encoder's own CLI (needs a GPU and oracle/_ref/uvg266_8{,_hip}):
 a 1920x1080 8-bit clip, -p 1 --preset medium (BASELINE configs[1]'s settings), once with the encoder's CPU search on all host threads
-(AVX2 strategies) and once with UVG266_HIP_FRAME=1 at several --owf (frames in flight = frame encoders, streams and plans on the device).
+(AVX2 strategies) and once with UVG266_HIP_FRAME=1 at several --owf (frames in flight = slots of the frame pool; groups of half of them per launch).
 Prints the CLI's wall time per run and whether the two files are the same file.  DEVELOPMENT TOOL (test infrastructure binaries).
 usage: frame_dropin_time.py [frames=32] [qp=22]"""
 import hashlib
@@ -34,7 +34,7 @@ def run(binary, yuv, out, args, env_extra):
 
 
 def main():
-    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     qp = int(sys.argv[2]) if len(sys.argv) > 2 else 22
     w, h = 1920, 1080
     with tempfile.TemporaryDirectory() as d:
@@ -48,7 +48,7 @@ def main():
         threads = os.cpu_count()
         want, dt, fps = run("uvg266_8", yuv, os.path.join(d, "cpu.266"), args + ["--threads", str(threads)], {})
         print(f"{frames} pictures {w}x{h} 8-bit qp {qp}: the encoder's CPU search, {threads} threads, --owf auto: {dt:.2f} s wall, the CLI's own FPS {fps}")
-        for owf in (0, 4, 16, 32):
+        for owf in (0, 3, 7, 15, 31, 63):
             got, dt, fps = run("uvg266_8_hip", yuv, os.path.join(d, f"hip{owf}.266"), args + ["--threads", "8", "--owf", str(owf)], {"UVG266_HIP_FRAME": "1"})
             print(f"  UVG266_HIP_FRAME=1 --owf {owf:2d}: {dt:.2f} s wall, the CLI's own FPS {fps}; the same file: {got == want}")
 

@@ -1,4 +1,4 @@
-// uvghip_frame_encoder_*: the closed loop for ONE all-intra picture handed over in HOST memory -- what uvg_encode_one_frame
+// uvghip_frame_pool_*: the closed loop for all-intra pictures handed over in HOST memory one by one -- what uvg_encode_one_frame
 // (src/encoderstate.c:2051-2091) gives a frame-level backend and what it wants back:
 //   in:   the source planes of state->tile->frame->source (uvg_picture: y / u / v, stride; src/uvg266.h:566-600) and the frame-level
 //         parameters the per-CTU worker would read (uvghip_ctu_params_t);
@@ -6,44 +6,48 @@
 //         src/encoder_state-bitstream.c:1420-1492) and the substream of every WPP row -- the bytes the row's leaf state would hold in
 //         `stream` when encoder_state_worker_encode_lcu_bitstream has coded its last CTU (src/encoderstate.c:862-976), emulation
 //         prevention included, ready for uvg_bitstream_move / the slice header's entry points (:977-1007, :1494-1511).
-// Host code only: device buffers for one picture, one uvghip_loop_plan (search -> deblocking -> SAO -> slice data), a stream of its own.
-// begin() stages the source, enqueues everything and returns; finish() waits and copies out -- between the two the encoder goes on
-// (with --owf N it begins the next frames: N encoders, N streams, N pictures' wavefronts on the device at once).
+// Host code only.  A SLOT is the device memory of one picture in flight (the encoder has cfg.owf + 1 main states); frames that are begun
+// collect in a GROUP, and a group is one uvghip_loop_plan launch (search -> deblocking -> SAO -> slice data of all its pictures) on a
+// stream of its own.  Why groups and not a launch per frame: measured inside the reference's CLI (profiles/r06_frame_dropin_time.txt),
+// five single-picture launches beside each other run 2.5 x as fast as one after the other, seventeen run 15 x SLOWER -- every launch puts
+// all its workgroups on the device at once, most of them waiting for their wavefront, and beyond the hardware queues the waiting ones of
+// one launch keep the running ones of another off the device.  Inside one launch the release order interleaves the pictures' wavefronts
+// (ctu_search.hip), which is what bench.py's 224-picture launches rely on.
 // The reference-side caller: csrc/shim/frame-hip.c, run by tests/test_gpu_dropin_frame.py.
 #include "uvghip_common.h"
+#include <mutex>
 #include <new>
+#include <vector>
 #include <cstring>
 #include <cstdlib>
 
-struct uvghip_frame_encoder {
-  int device, bitdepth, sao_type, w, h, wc, hc, row_cap;
-  uvghip_ctu_params_t P;
-  size_t b, ysz, csz, psz;
-  uint8_t *src, *rec, *out;                  // device: tight planes Y, U, V one after the other
-  void *cu, *coeff, *models, *ws;
-  uvghip_loop_plan_t *plan;
-  hipStream_t st;
-  uint8_t *host_src, *host_out;              // pinned staging of the source / the output picture
-  int32_t *host_row_bytes;                   // pinned [hc]
-  uint8_t *host_rows;                        // pinned: the rows' bytes one after the other (grown on demand)
-  size_t host_rows_cap;
-  const uint8_t *d_rows;
-  const int32_t *d_row_bytes;
-  bool busy;
-};
-
 namespace {
 
-void release(uvghip_frame_encoder *e)
-{
-  if (e->plan) uvghip_loop_plan_destroy(e->plan);
-  if (e->st) (void)hipStreamDestroy(e->st);
-  void *dev[] = {e->src, e->rec, e->out, e->cu, e->coeff, e->models, e->ws};
-  for (void *p : dev) if (p) (void)hipFree(p);
-  void *host[] = {e->host_src, e->host_out, e->host_row_bytes, e->host_rows};
-  for (void *p : host) if (p) (void)hipHostFree(p);
-  delete e;
-}
+enum { FREE = 0, PENDING = 1, LAUNCHED = 2 };
+constexpr int MAX_GROUPS = 8;
+
+struct slot_t {
+  uint8_t *src = nullptr, *rec = nullptr, *out = nullptr;      // device: tight planes Y, U, V one after the other
+  void *cu = nullptr, *coeff = nullptr, *models = nullptr;
+  uint8_t *host_src = nullptr, *host_out = nullptr;            // pinned staging of the source / the output picture
+  uint8_t *host_rows = nullptr;                                // pinned: the rows' bytes one after the other (grown on demand)
+  int32_t *host_row_bytes = nullptr;                           // pinned [hc]: this picture's row lengths, handed to the caller
+  size_t host_rows_cap = 0;
+  int state = FREE, group = -1, index = -1;
+};
+
+struct group_t {
+  uvghip_loop_plan_t *plan = nullptr;
+  void *ws = nullptr;
+  hipStream_t st = nullptr;
+  int32_t *host_row_bytes = nullptr;                           // pinned [group_max][hc]
+  std::vector<int> slots, planned;                             // the slots of this launch in plan order; those the plan was made for
+  uvghip_ctu_params_t P, planned_P;
+  const uint8_t *d_rows = nullptr;
+  const int32_t *d_row_bytes = nullptr;
+  int row_cap = 0, unfinished = 0;
+  bool launched = false, waited = false;
+};
 
 // rows of `bytes` bytes between a tight plane and a plane with a stride
 void copy_rows(uint8_t *dst, size_t dst_pitch, const uint8_t *src, size_t src_pitch, size_t bytes, int rows)
@@ -52,128 +56,228 @@ void copy_rows(uint8_t *dst, size_t dst_pitch, const uint8_t *src, size_t src_pi
   for (int y = 0; y < rows; ++y) memcpy(dst + y * dst_pitch, src + y * src_pitch, bytes);
 }
 
-int make_plan(uvghip_frame_encoder *e, const uvghip_ctu_params_t *p)
+}  // namespace
+
+struct uvghip_frame_pool {
+  std::mutex m;
+  int device = 0, bitdepth = 0, sao_type = 0, w = 0, h = 0, wc = 0, hc = 0, group_max = 1, open = -1;
+  size_t b = 1, ysz = 0, csz = 0, psz = 0;
+  std::vector<slot_t> slots;
+  group_t groups[MAX_GROUPS];
+};
+
+namespace {
+
+void release(uvghip_frame_pool *p)
 {
-  if (e->plan) { uvghip_loop_plan_destroy(e->plan); e->plan = nullptr; }
-  uvghip_loop_picture_t q;
+  for (group_t &g : p->groups) {
+    if (g.st) (void)hipStreamSynchronize(g.st);
+    if (g.plan) uvghip_loop_plan_destroy(g.plan);
+    if (g.st) (void)hipStreamDestroy(g.st);
+    if (g.ws) (void)hipFree(g.ws);
+    if (g.host_row_bytes) (void)hipHostFree(g.host_row_bytes);
+  }
+  for (slot_t &s : p->slots) {
+    void *dev[] = {s.src, s.rec, s.out, s.cu, s.coeff, s.models};
+    for (void *q : dev) if (q) (void)hipFree(q);
+    void *host[] = {s.host_src, s.host_out, s.host_rows, s.host_row_bytes};
+    for (void *q : host) if (q) (void)hipHostFree(q);
+  }
+  delete p;
+}
+
+// slot -> the loop plan's picture descriptor
+void describe(const uvghip_frame_pool *p, const slot_t &s, uvghip_loop_picture_t &q)
+{
   memset(&q, 0, sizeof q);
-  q.search.src_y = e->src; q.search.src_u = e->src + e->ysz; q.search.src_v = e->src + e->ysz + e->csz;
-  q.search.src_stride = e->w; q.search.src_stride_c = e->w / 2;
-  q.search.rec_y = e->rec; q.search.rec_u = e->rec + e->ysz; q.search.rec_v = e->rec + e->ysz + e->csz;
-  q.search.rec_stride = e->w; q.search.rec_stride_c = e->w / 2;
-  q.search.cu = static_cast<uvghip_scu_t *>(e->cu); q.search.cu_stride = e->wc * 16;
-  q.search.coeff = static_cast<int16_t *>(e->coeff); q.search.models = static_cast<uint32_t *>(e->models);
-  q.out_y = e->out; q.out_u = e->out + e->ysz; q.out_v = e->out + e->ysz + e->csz; q.out_stride = e->w; q.out_stride_c = e->w / 2;
-  if (int rc = uvghip_loop_plan_create(e->bitdepth, p, &q, 1, e->sao_type, e->ws, &e->plan)) return rc;
-  int n_rows = 0;
-  if (int rc = uvghip_loop_plan_slice_data(e->plan, &e->d_rows, &e->d_row_bytes, &e->row_cap, &n_rows)) return rc;
-  if (n_rows != e->hc) return uvghip_set_error(hipErrorInvalidValue, "uvghip_frame_encoder: the plan's rows are not the picture's CTU rows");
-  e->P = *p;
+  q.search.src_y = s.src; q.search.src_u = s.src + p->ysz; q.search.src_v = s.src + p->ysz + p->csz;
+  q.search.src_stride = p->w; q.search.src_stride_c = p->w / 2;
+  q.search.rec_y = s.rec; q.search.rec_u = s.rec + p->ysz; q.search.rec_v = s.rec + p->ysz + p->csz;
+  q.search.rec_stride = p->w; q.search.rec_stride_c = p->w / 2;
+  q.search.cu = static_cast<uvghip_scu_t *>(s.cu); q.search.cu_stride = p->wc * 16;
+  q.search.coeff = static_cast<int16_t *>(s.coeff); q.search.models = static_cast<uint32_t *>(s.models);
+  q.out_y = s.out; q.out_u = s.out + p->ysz; q.out_v = s.out + p->ysz + p->csz; q.out_stride = p->w; q.out_stride_c = p->w / 2;
+}
+
+// a group's stream, workspace (for group_max pictures) and row-length staging: made when the group object is first used, kept for good
+int ready_group(uvghip_frame_pool *p, group_t &g)
+{
+  if (g.st) return 0;
+  UVGHIP_TRY(hipMalloc(&g.ws, uvghip_loop_workspace_bytes(p->bitdepth, p->group_max, p->w, p->h)));
+  UVGHIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g.host_row_bytes), (size_t)p->group_max * p->hc * sizeof(int32_t), hipHostMallocDefault));
+  UVGHIP_TRY(hipStreamCreateWithFlags(&g.st, hipStreamNonBlocking));
+  return 0;
+}
+
+// the open group becomes one launch: plan (kept when the same slots with the same parameters come again), run, the downloads behind it
+int launch(uvghip_frame_pool *p, int gi)
+{
+  group_t &g = p->groups[gi];
+  const int k = (int)g.slots.size();
+  if (!g.plan || g.planned != g.slots || memcmp(&g.planned_P, &g.P, sizeof g.P)) {
+    if (g.plan) { uvghip_loop_plan_destroy(g.plan); g.plan = nullptr; }
+    std::vector<uvghip_loop_picture_t> pics(k);
+    for (int i = 0; i < k; ++i) describe(p, p->slots[g.slots[i]], pics[i]);
+    if (int rc = uvghip_loop_plan_create(p->bitdepth, &g.P, pics.data(), k, p->sao_type, g.ws, &g.plan)) return rc;
+    int n_rows = 0;
+    if (int rc = uvghip_loop_plan_slice_data(g.plan, &g.d_rows, &g.d_row_bytes, &g.row_cap, &n_rows)) return rc;
+    if (n_rows != p->hc) return uvghip_set_error(hipErrorInvalidValue, "uvghip_frame_pool: the plan's rows are not the picture's CTU rows");
+    g.planned = g.slots; g.planned_P = g.P;
+  }
+  if (int rc = uvghip_loop_plan_run(g.plan, g.st)) return rc;
+  for (int i = 0; i < k; ++i) {
+    slot_t &s = p->slots[g.slots[i]];
+    UVGHIP_TRY(hipMemcpyAsync(s.host_out, s.out, p->psz, hipMemcpyDeviceToHost, g.st));
+    s.state = LAUNCHED;
+  }
+  UVGHIP_TRY(hipMemcpyAsync(g.host_row_bytes, g.d_row_bytes, (size_t)k * p->hc * sizeof(int32_t), hipMemcpyDeviceToHost, g.st));
+  g.launched = true; g.waited = false; g.unfinished = k;
+  if (p->open == gi) p->open = -1;
   return 0;
 }
 
 }  // namespace
 
-extern "C" int uvghip_frame_encoder_create(int bitdepth, const uvghip_ctu_params_t *params, int sao_type, uvghip_frame_encoder_t **out)
+extern "C" int uvghip_frame_pool_create(int bitdepth, const uvghip_ctu_params_t *params, int sao_type, int n_slots, int group_max, uvghip_frame_pool_t **out)
 {
   UVGHIP_REQUIRE_READY();
   UVGHIP_REQUIRE_DEPTH(bitdepth);
-  if (!params || !out || params->pic_w <= 0 || params->pic_h <= 0 || (params->pic_w & 7) || (params->pic_h & 7))
+  if (!params || !out || params->pic_w <= 0 || params->pic_h <= 0 || (params->pic_w & 7) || (params->pic_h & 7) || n_slots < 1 || n_slots > 256 || group_max < 1)
     return uvghip_set_error(hipErrorInvalidValue, __func__);
-  uvghip_frame_encoder *e = new (std::nothrow) uvghip_frame_encoder();
-  if (!e) return uvghip_set_error(hipErrorOutOfMemory, __func__);
-  memset(static_cast<void *>(e), 0, sizeof *e);
-  e->bitdepth = bitdepth; e->sao_type = sao_type; e->w = params->pic_w; e->h = params->pic_h;
-  e->wc = (e->w + 63) / 64; e->hc = (e->h + 63) / 64;
-  e->b = bitdepth == 8 ? 1 : 2; e->ysz = (size_t)e->w * e->h * e->b; e->csz = e->ysz / 4; e->psz = e->ysz + 2 * e->csz;
-  const size_t ctus = (size_t)e->wc * e->hc, cu_bytes = (size_t)e->hc * 16 * e->wc * 16 * sizeof(uvghip_scu_t);
-  hipError_t err = hipGetDevice(&e->device);
-  auto dev = [&](void **p, size_t bytes, bool zero) {
-    if (err == hipSuccess) err = hipMalloc(p, bytes);
-    if (err == hipSuccess && zero) err = hipMemset(*p, 0, bytes);
+  uvghip_frame_pool *p = new (std::nothrow) uvghip_frame_pool();
+  if (!p) return uvghip_set_error(hipErrorOutOfMemory, __func__);
+  p->bitdepth = bitdepth; p->sao_type = sao_type; p->w = params->pic_w; p->h = params->pic_h;
+  p->wc = (p->w + 63) / 64; p->hc = (p->h + 63) / 64; p->group_max = group_max < n_slots ? group_max : n_slots;
+  p->b = bitdepth == 8 ? 1 : 2; p->ysz = (size_t)p->w * p->h * p->b; p->csz = p->ysz / 4; p->psz = p->ysz + 2 * p->csz;
+  const size_t ctus = (size_t)p->wc * p->hc, cu_bytes = (size_t)p->hc * 16 * p->wc * 16 * sizeof(uvghip_scu_t);
+  hipError_t err = hipGetDevice(&p->device);
+  p->slots.resize(n_slots);
+  auto dev = [&](void **q, size_t bytes, bool zero) {
+    if (err == hipSuccess) err = hipMalloc(q, bytes);
+    if (err == hipSuccess && zero) err = hipMemset(*q, 0, bytes);
   };
-  dev(reinterpret_cast<void **>(&e->src), e->psz, false);
-  dev(reinterpret_cast<void **>(&e->rec), e->psz, true);
-  dev(reinterpret_cast<void **>(&e->out), e->psz, false);
-  dev(&e->cu, cu_bytes, true);
-  dev(&e->coeff, ctus * 6144 * sizeof(int16_t), false);
-  dev(&e->models, ctus * 3 * UVGHIP_CTU_MODELS * sizeof(uint32_t), false);
-  dev(&e->ws, uvghip_loop_workspace_bytes(bitdepth, 1, e->w, e->h), false);
-  if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void **>(&e->host_src), e->psz, hipHostMallocDefault);
-  if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void **>(&e->host_out), e->psz, hipHostMallocDefault);
-  if (err == hipSuccess) err = hipHostMalloc(reinterpret_cast<void **>(&e->host_row_bytes), (size_t)e->hc * sizeof(int32_t), hipHostMallocDefault);
-  if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking);
-  if (err == hipSuccess) err = hipDeviceSynchronize();            // the memsets above ran on the null stream, e->st does not wait for it
-  if (err != hipSuccess) { release(e); return uvghip_set_error(err, __func__); }
-  if (int rc = make_plan(e, params)) { release(e); return rc; }      // refuses what the loop plan refuses (configuration, sao_type 0, qp_c != qp)
-  *out = e;
-  return 0;
-}
-
-extern "C" int uvghip_frame_encoder_begin(uvghip_frame_encoder_t *e, const uvghip_ctu_params_t *params, const void *src_y, const void *src_u, const void *src_v,
-                                          int src_stride, int src_stride_c)
-{
-  UVGHIP_REQUIRE_READY();
-  if (!e || !params || !src_y || !src_u || !src_v || src_stride < e->w || src_stride_c < e->w / 2) return uvghip_set_error(hipErrorInvalidValue, __func__);
-  if (e->busy) return uvghip_set_error(hipErrorNotReady, "uvghip_frame_encoder_begin: the previous picture has not been finished");
-  if (params->pic_w != e->w || params->pic_h != e->h) return uvghip_set_error(hipErrorInvalidValue, "uvghip_frame_encoder_begin: the picture size is the encoder's for good");
-  UVGHIP_TRY(hipSetDevice(e->device));
-  if (memcmp(params, &e->P, sizeof e->P)) {         // another QP / lambda than the last picture's: the plan binds them
-    if (int rc = make_plan(e, params)) return rc;
+  auto host = [&](void **q, size_t bytes) { if (err == hipSuccess) err = hipHostMalloc(q, bytes, hipHostMallocDefault); };
+  for (slot_t &s : p->slots) {
+    dev(reinterpret_cast<void **>(&s.src), p->psz, false);
+    dev(reinterpret_cast<void **>(&s.rec), p->psz, true);
+    dev(reinterpret_cast<void **>(&s.out), p->psz, false);
+    dev(&s.cu, cu_bytes, true);
+    dev(&s.coeff, ctus * 6144 * sizeof(int16_t), false);
+    dev(&s.models, ctus * 3 * UVGHIP_CTU_MODELS * sizeof(uint32_t), false);
+    host(reinterpret_cast<void **>(&s.host_src), p->psz);
+    host(reinterpret_cast<void **>(&s.host_out), p->psz);
+    host(reinterpret_cast<void **>(&s.host_row_bytes), (size_t)p->hc * sizeof(int32_t));
+    s.host_rows_cap = p->psz / 4 + 4096;                          // grown in finish() by the rare picture that needs more
+    host(reinterpret_cast<void **>(&s.host_rows), s.host_rows_cap);
   }
-  const size_t b = e->b;
-  copy_rows(e->host_src, e->w * b, static_cast<const uint8_t *>(src_y), src_stride * b, e->w * b, e->h);
-  copy_rows(e->host_src + e->ysz, e->w / 2 * b, static_cast<const uint8_t *>(src_u), src_stride_c * b, e->w / 2 * b, e->h / 2);
-  copy_rows(e->host_src + e->ysz + e->csz, e->w / 2 * b, static_cast<const uint8_t *>(src_v), src_stride_c * b, e->w / 2 * b, e->h / 2);
-  UVGHIP_TRY(hipMemcpyAsync(e->src, e->host_src, e->psz, hipMemcpyHostToDevice, e->st));
-  if (int rc = uvghip_loop_plan_run(e->plan, e->st)) return rc;
-  UVGHIP_TRY(hipMemcpyAsync(e->host_out, e->out, e->psz, hipMemcpyDeviceToHost, e->st));
-  UVGHIP_TRY(hipMemcpyAsync(e->host_row_bytes, e->d_row_bytes, (size_t)e->hc * sizeof(int32_t), hipMemcpyDeviceToHost, e->st));
-  e->busy = true;
+  if (err == hipSuccess) err = hipDeviceSynchronize();            // the memsets above ran on the null stream, the groups' streams do not wait for it
+  if (err != hipSuccess) { release(p); return uvghip_set_error(err, __func__); }
+  // a plan for one picture now: a configuration the loop plan refuses (sao_type 0, qp_c != qp, anything but the medium / slow settings) is
+  // refused here and not at the first frame's launch
+  int rc = ready_group(p, p->groups[0]);
+  if (!rc) {
+    uvghip_loop_picture_t q;
+    describe(p, p->slots[0], q);
+    uvghip_loop_plan_t *probe = nullptr;
+    rc = uvghip_loop_plan_create(bitdepth, params, &q, 1, sao_type, p->groups[0].ws, &probe);
+    if (!rc) uvghip_loop_plan_destroy(probe);
+  }
+  if (rc) { release(p); return rc; }
+  *out = p;
   return 0;
 }
 
-extern "C" int uvghip_frame_encoder_finish(uvghip_frame_encoder_t *e, void *out_y, void *out_u, void *out_v, int out_stride, int out_stride_c,
-                                           const uint8_t **rows, const int32_t **row_bytes, int *n_rows)
+extern "C" int uvghip_frame_pool_begin(uvghip_frame_pool_t *p, int slot, const uvghip_ctu_params_t *params, const void *src_y, const void *src_u, const void *src_v,
+                                       int src_stride, int src_stride_c)
 {
   UVGHIP_REQUIRE_READY();
-  if (!e || !out_y || !out_u || !out_v || out_stride < e->w || out_stride_c < e->w / 2 || !rows || !row_bytes || !n_rows)
+  if (!p || !params || !src_y || !src_u || !src_v || slot < 0 || slot >= (int)p->slots.size() || src_stride < p->w || src_stride_c < p->w / 2)
     return uvghip_set_error(hipErrorInvalidValue, __func__);
-  if (!e->busy) return uvghip_set_error(hipErrorNotReady, "uvghip_frame_encoder_finish: no picture has been begun");
-  UVGHIP_TRY(hipSetDevice(e->device));        // finish() may run on another thread than begin() (the encoder's bitstream job)
-  e->busy = false;
-  UVGHIP_TRY(hipStreamSynchronize(e->st));
+  if (params->pic_w != p->w || params->pic_h != p->h) return uvghip_set_error(hipErrorInvalidValue, "uvghip_frame_pool_begin: the picture size is the pool's for good");
+  UVGHIP_TRY(hipSetDevice(p->device));
+  slot_t &s = p->slots[slot];
+  {
+    std::lock_guard<std::mutex> lock(p->m);
+    if (s.state != FREE) return uvghip_set_error(hipErrorNotReady, "uvghip_frame_pool_begin: the slot's previous picture has not been finished");
+  }
+  // staged outside the lock: the slot is the caller's until it is PENDING
+  const size_t b = p->b;
+  copy_rows(s.host_src, p->w * b, static_cast<const uint8_t *>(src_y), src_stride * b, p->w * b, p->h);
+  copy_rows(s.host_src + p->ysz, p->w / 2 * b, static_cast<const uint8_t *>(src_u), src_stride_c * b, p->w / 2 * b, p->h / 2);
+  copy_rows(s.host_src + p->ysz + p->csz, p->w / 2 * b, static_cast<const uint8_t *>(src_v), src_stride_c * b, p->w / 2 * b, p->h / 2);
+  std::lock_guard<std::mutex> lock(p->m);
+  if (p->open >= 0 && memcmp(&p->groups[p->open].P, params, sizeof *params)) {       // another QP / lambda: a plan binds one set of parameters
+    if (int rc = launch(p, p->open)) return rc;
+  }
+  if (p->open < 0) {
+    for (int i = 0; i < MAX_GROUPS && p->open < 0; ++i) if (!p->groups[i].launched && p->groups[i].slots.empty()) p->open = i;
+    if (p->open < 0) return uvghip_set_error(hipErrorNotReady, "uvghip_frame_pool_begin: every group is in flight (finish frames in the order they were begun)");
+    if (int rc = ready_group(p, p->groups[p->open])) { p->open = -1; return rc; }
+    p->groups[p->open].P = *params;
+  }
+  group_t &g = p->groups[p->open];
+  UVGHIP_TRY(hipMemcpyAsync(s.src, s.host_src, p->psz, hipMemcpyHostToDevice, g.st));
+  s.state = PENDING; s.group = p->open; s.index = (int)g.slots.size();
+  g.slots.push_back(slot);
+  if ((int)g.slots.size() >= p->group_max) return launch(p, p->open);
+  return 0;
+}
+
+extern "C" int uvghip_frame_pool_finish(uvghip_frame_pool_t *p, int slot, void *out_y, void *out_u, void *out_v, int out_stride, int out_stride_c,
+                                        const uint8_t **rows, const int32_t **row_bytes, int *n_rows)
+{
+  UVGHIP_REQUIRE_READY();
+  if (!p || slot < 0 || slot >= (int)p->slots.size() || !out_y || !out_u || !out_v || out_stride < p->w || out_stride_c < p->w / 2 || !rows || !row_bytes || !n_rows)
+    return uvghip_set_error(hipErrorInvalidValue, __func__);
+  UVGHIP_TRY(hipSetDevice(p->device));        // finish() may run on another thread than begin() (the encoder's bitstream job)
+  slot_t &s = p->slots[slot];
+  std::unique_lock<std::mutex> lock(p->m);
+  if (s.state == FREE) return uvghip_set_error(hipErrorNotReady, "uvghip_frame_pool_finish: no picture has been begun in this slot");
+  if (s.state == PENDING) {
+    if (int rc = launch(p, s.group)) return rc;
+  }
+  group_t &g = p->groups[s.group];
+  const bool wait = !g.waited;
+  hipStream_t st = g.st;
+  lock.unlock();                              // begin() of the next frames goes on while this one waits
+  if (wait) UVGHIP_TRY(hipStreamSynchronize(st));
+  lock.lock();
+  g.waited = true;
   size_t total = 0;
-  for (int r = 0; r < e->hc; ++r) {
-    const int nb = e->host_row_bytes[r];
-    if (nb <= 0 || nb > e->row_cap) return uvghip_set_error(hipErrorInvalidValue, "uvghip_frame_encoder_finish: a row overflowed its slot");
+  for (int r = 0; r < p->hc; ++r) {
+    const int nb = g.host_row_bytes[(size_t)s.index * p->hc + r];
+    if (nb <= 0 || nb > g.row_cap) return uvghip_set_error(hipErrorInvalidValue, "uvghip_frame_pool_finish: a row overflowed its slot");
+    s.host_row_bytes[r] = nb;
     total += nb;
   }
-  if (total > e->host_rows_cap) {
-    if (e->host_rows) { UVGHIP_TRY(hipHostFree(e->host_rows)); e->host_rows = nullptr; e->host_rows_cap = 0; }
+  if (total > s.host_rows_cap) {
+    if (s.host_rows) { UVGHIP_TRY(hipHostFree(s.host_rows)); s.host_rows = nullptr; s.host_rows_cap = 0; }
     const size_t want = total + total / 2 + 4096;
-    UVGHIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->host_rows), want, hipHostMallocDefault));
-    e->host_rows_cap = want;
+    UVGHIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s.host_rows), want, hipHostMallocDefault));
+    s.host_rows_cap = want;
   }
   size_t at = 0;
-  for (int r = 0; r < e->hc; ++r) {
-    const int nb = e->host_row_bytes[r];
-    UVGHIP_TRY(hipMemcpyAsync(e->host_rows + at, e->d_rows + (size_t)r * e->row_cap, nb, hipMemcpyDeviceToHost, e->st));
+  for (int r = 0; r < p->hc; ++r) {
+    const int nb = s.host_row_bytes[r];
+    UVGHIP_TRY(hipMemcpyAsync(s.host_rows + at, g.d_rows + ((size_t)s.index * p->hc + r) * g.row_cap, nb, hipMemcpyDeviceToHost, st));
     at += nb;
   }
-  const size_t b = e->b;
-  copy_rows(static_cast<uint8_t *>(out_y), out_stride * b, e->host_out, e->w * b, e->w * b, e->h);
-  copy_rows(static_cast<uint8_t *>(out_u), out_stride_c * b, e->host_out + e->ysz, e->w / 2 * b, e->w / 2 * b, e->h / 2);
-  copy_rows(static_cast<uint8_t *>(out_v), out_stride_c * b, e->host_out + e->ysz + e->csz, e->w / 2 * b, e->w / 2 * b, e->h / 2);
-  UVGHIP_TRY(hipStreamSynchronize(e->st));
-  *rows = e->host_rows; *row_bytes = e->host_row_bytes; *n_rows = e->hc;
+  lock.unlock();
+  const size_t b = p->b;
+  copy_rows(static_cast<uint8_t *>(out_y), out_stride * b, s.host_out, p->w * b, p->w * b, p->h);
+  copy_rows(static_cast<uint8_t *>(out_u), out_stride_c * b, s.host_out + p->ysz, p->w / 2 * b, p->w / 2 * b, p->h / 2);
+  copy_rows(static_cast<uint8_t *>(out_v), out_stride_c * b, s.host_out + p->ysz + p->csz, p->w / 2 * b, p->w / 2 * b, p->h / 2);
+  UVGHIP_TRY(hipStreamSynchronize(st));       // the rows (the group's stream carries nothing else before all its frames are finished)
+  lock.lock();
+  s.state = FREE; s.group = -1; s.index = -1;
+  if (--g.unfinished == 0) { g.launched = false; g.slots.clear(); }
+  *rows = s.host_rows; *row_bytes = s.host_row_bytes; *n_rows = p->hc;
   return 0;
 }
 
-extern "C" void uvghip_frame_encoder_destroy(uvghip_frame_encoder_t *e)
+extern "C" void uvghip_frame_pool_destroy(uvghip_frame_pool_t *p)
 {
-  if (!e) return;
-  (void)hipSetDevice(e->device);
-  if (e->st) (void)hipStreamSynchronize(e->st);
-  release(e);
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  release(p);
 }

@@ -4,7 +4,7 @@
  * This file is compiled INSIDE the uvg266 source tree like strategies-hip-state.c (copy it to src/strategies/hip/; INTEGRATION.md
  * section 10).  It sees encoder_state_t and does field extraction only: the frame's source planes and the frame-level QP / lambda in,
  * the picture after the in-loop filters into frame->rec and every WPP row's substream into the row's leaf state out -- the samples,
- * decisions and bins are libuvg266hip.so's (uvghip_frame_encoder_*, include/uvg266_hip.h section 7a).
+ * decisions and bins are libuvg266hip.so's (uvghip_frame_pool_*, include/uvg266_hip.h section 7a).
  *
  * Two call sites, both applied by tools/refcheck/patch_ref_hip.py:
  *   uvg_encode_one_frame (src/encoderstate.c:2051-2091): `if (uvg_hip_frame_enabled(state)) uvg_hip_frame_begin(state); else
@@ -30,13 +30,13 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define HIP_FRAME_SLOTS 64            /* main encoder states = frames in flight (--owf + 1) */
+#define HIP_FRAME_SLOTS 256           /* main encoder states = frames in flight (cfg.owf + 1): the pool's slots */
 
 static struct {
   const encoder_state_t *state;
-  uvghip_frame_encoder_t *enc;
   int begun;
 } hip_slots[HIP_FRAME_SLOTS];
+static uvghip_frame_pool_t *hip_pool;
 static pthread_mutex_t hip_slots_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static void hip_frame_die(const char *what)
@@ -51,7 +51,7 @@ static int hip_slot_of(const encoder_state_t *state, int create)
   pthread_mutex_lock(&hip_slots_lock);
   for (int i = 0; i < HIP_FRAME_SLOTS && at < 0; ++i) if (hip_slots[i].state == state) at = i;
   for (int i = 0; i < HIP_FRAME_SLOTS && at < 0 && create; ++i) {
-    if (!hip_slots[i].state) { hip_slots[i].state = state; hip_slots[i].enc = NULL; hip_slots[i].begun = 0; at = i; }
+    if (!hip_slots[i].state) { hip_slots[i].state = state; hip_slots[i].begun = 0; at = i; }
   }
   pthread_mutex_unlock(&hip_slots_lock);
   return at;
@@ -133,14 +133,18 @@ void uvg_hip_frame_begin(encoder_state_t *state)
   p.chroma_weight_u = leaf->chroma_weights[1]; p.chroma_weight_v = leaf->chroma_weights[2];
   p.c_lambda_tu = uvg_calculate_chroma_lambda(leaf, false, 0);
 
+  const int n_slots = ctrl->cfg.owf + 1;                        /* the encoder's main states (src/encoder_state-ctors_dtors.c) */
   const int at = hip_slot_of(state, 1);
-  if (at < 0) { fprintf(stderr, "hip frame backend: more than %d frames in flight\n", HIP_FRAME_SLOTS); abort(); }
-  if (!hip_slots[at].enc) {
+  if (at < 0 || at >= n_slots) { fprintf(stderr, "hip frame backend: more main encoder states than --owf + 1 = %d\n", n_slots); abort(); }
+  if (!hip_pool) {                                              /* (uvg_encode_one_frame runs on the encoder's own thread only) */
+    /* frames collect in groups of half the frames in flight: two launches beside each other in the steady state (UVG266_HIP_FRAME_GROUP) */
+    const char *e = getenv("UVG266_HIP_FRAME_GROUP");
+    const int group = e && atoi(e) > 0 ? atoi(e) : (n_slots + 1) / 2;
     if (uvghip_init(0) != 0) hip_frame_die("uvghip_init");
-    if (uvghip_frame_encoder_create(ctrl->bitdepth, &p, (int)ctrl->cfg.sao_type, &hip_slots[at].enc)) hip_frame_die("uvghip_frame_encoder_create");
+    if (uvghip_frame_pool_create(ctrl->bitdepth, &p, (int)ctrl->cfg.sao_type, n_slots, group, &hip_pool)) hip_frame_die("uvghip_frame_pool_create");
   }
   const uvg_picture *src = state->tile->frame->source;
-  if (uvghip_frame_encoder_begin(hip_slots[at].enc, &p, src->y, src->u, src->v, src->stride, src->stride / 2)) hip_frame_die("uvghip_frame_encoder_begin");
+  if (uvghip_frame_pool_begin(hip_pool, at, &p, src->y, src->u, src->v, src->stride, src->stride / 2)) hip_frame_die("uvghip_frame_pool_begin");
   hip_slots[at].begun = 1;
 }
 
@@ -153,8 +157,8 @@ void uvg_hip_frame_finish(encoder_state_t *state)
   const uint8_t *bytes;
   const int32_t *row_bytes;
   int n_rows;
-  if (uvghip_frame_encoder_finish(hip_slots[at].enc, rec->y, rec->u, rec->v, rec->stride, rec->stride / 2, &bytes, &row_bytes, &n_rows))
-    hip_frame_die("uvghip_frame_encoder_finish");
+  if (uvghip_frame_pool_finish(hip_pool, at, rec->y, rec->u, rec->v, rec->stride, rec->stride / 2, &bytes, &row_bytes, &n_rows))
+    hip_frame_die("uvghip_frame_pool_finish");
   encoder_state_t *rows[256];
   const int n = hip_collect_rows(state, rows, 256, 0);
   if (n != n_rows) { fprintf(stderr, "hip frame backend: %d rows from the device for %d leaf states\n", n_rows, n); abort(); }

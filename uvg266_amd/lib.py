@@ -271,10 +271,10 @@ SIGNATURES = {
     "uvghip_tiles_plan_tile": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "uvghip_tiles_plan_nals": (c_int, [c_vp, c_int, c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_vp]),
     "uvghip_tiles_plan_destroy": (None, [c_vp]),
-    "uvghip_frame_encoder_create": (c_int, [c_int, c_vp, c_int, c_vp]),
-    "uvghip_frame_encoder_begin": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int]),
-    "uvghip_frame_encoder_finish": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
-    "uvghip_frame_encoder_destroy": (None, [c_vp]),
+    "uvghip_frame_pool_create": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_vp]),
+    "uvghip_frame_pool_begin": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int]),
+    "uvghip_frame_pool_finish": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
+    "uvghip_frame_pool_destroy": (None, [c_vp]),
     "uvghip_tiles_workspace_bytes_owned": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "uvghip_tiles_plan_create_owned": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "uvghip_tile_grid_split": (c_int, [c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp]),
