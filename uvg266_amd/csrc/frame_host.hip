@@ -15,7 +15,9 @@
 // (ctu_search.hip), which is what bench.py's 224-picture launches rely on.
 // The reference-side caller: csrc/shim/frame-hip.c, run by tests/test_gpu_dropin_frame.py.
 #include "uvghip_common.h"
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <vector>
 #include <cstring>
@@ -234,7 +236,19 @@ extern "C" int uvghip_frame_pool_finish(uvghip_frame_pool_t *p, int slot, void *
   std::unique_lock<std::mutex> lock(p->m);
   if (s.state == FREE) return uvghip_set_error(hipErrorNotReady, "uvghip_frame_pool_finish: no picture has been begun in this slot");
   if (s.state == PENDING) {
-    if (int rc = launch(p, s.group)) return rc;
+    // the frame is asked for while its group still collects.  The encoder's bitstream job for the FIRST frame of a clip becomes runnable the
+    // moment the frame is begun (nothing to wait for), with the encoder still reading the next frames: give the group a moment to grow --
+    // as long as frames keep arriving (a new one within 6 ms, 60 ms at most) -- instead of launching one picture alone (0.47 s for 1080p)
+    for (int quiet = 0, waited_ms = 0; s.state == PENDING && quiet < 3 && waited_ms < 60; waited_ms += 2) {
+      const size_t before = p->groups[s.group].slots.size();
+      lock.unlock();
+      std::this_thread::sleep_for(std::chrono::milliseconds(2));
+      lock.lock();
+      quiet = s.state == PENDING && p->groups[s.group].slots.size() == before ? quiet + 1 : 0;
+    }
+    if (s.state == PENDING) {                 // (begin() launches a group that fills up meanwhile)
+      if (int rc = launch(p, s.group)) return rc;
+    }
   }
   group_t &g = p->groups[s.group];
   const bool wait = !g.waited;
