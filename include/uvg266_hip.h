@@ -1196,6 +1196,12 @@ UVGHIP_API int uvghip_loop_plan_group_nals(uvghip_loop_plan_t *plan, int first_p
  * Reference-side caller: uvg266_amd/csrc/shim/frame-hip.c, applied by tools/refcheck/patch_ref_hip.py. */
 typedef struct uvghip_frame_pool uvghip_frame_pool_t;
 UVGHIP_API int uvghip_frame_pool_create(int bitdepth, const uvghip_ctu_params_t *params, int sao_type, int n_slots, int group_max, uvghip_frame_pool_t **pool_out);
+/* ... for frames cut into tiles (--tiles CxR --wpp, section 7b): col_ctus[cols] / row_ctus[rows] = encoder->tiles_col_width[] / tiles_row_height[] (in
+ * CTUs; the uniform grid and --tiles-width-split / --tiles-height-split alike).  A group is then one uvghip_tiles_plan launch; finish hands out
+ * the substreams of ALL tiles in the order of the bitstream (tile raster order, each tile's rows in order: the encoder's leaf states in the
+ * order encoder_state_write_bitstream_children visits them), n_rows = their number. */
+UVGHIP_API int uvghip_frame_pool_create_tiles(int bitdepth, const uvghip_ctu_params_t *params, int sao_type, int n_slots, int group_max, const int32_t *col_ctus, int cols,
+                                              const int32_t *row_ctus, int rows, uvghip_frame_pool_t **pool_out);
 UVGHIP_API int uvghip_frame_pool_begin(uvghip_frame_pool_t *pool, int slot, const uvghip_ctu_params_t *params, const void *src_y, const void *src_u,
                                        const void *src_v, int src_stride, int src_stride_c);
 UVGHIP_API int uvghip_frame_pool_finish(uvghip_frame_pool_t *pool, int slot, void *out_y, void *out_u, void *out_v, int out_stride, int out_stride_c,

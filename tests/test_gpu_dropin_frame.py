@@ -71,6 +71,19 @@ def test_all_intra_frames_through_the_closed_loop_write_the_encoders_own_file(tm
     assert both == want
 
 
+@pytest.mark.parametrize("depth,w,h,frames,qp,owf,tiles", [(8, 456, 264, 5, 27, 3, ["--tiles", "3x2"]), (10, 416, 240, 3, 32, 2, ["--tiles", "2x2"]),
+                                                           (8, 456, 264, 4, 27, 1, ["--tiles-width-split", "64,320", "--tiles-height-split", "192"])])
+def test_tiled_frames_through_the_closed_loop_write_the_encoders_own_file(tmp_path, depth, w, h, frames, qp, owf, tiles):
+    """--tiles CxR --wpp (and an explicit grid): a group is one tiles plan, the substreams of all tiles go to the tiles' WPP leaf states in
+    the order of the bitstream; the PPS with the grid, the slice header with all entry points and the hash SEI are the encoder's."""
+    yuv = clip(tmp_path, "in.yuv", w, h, frames, depth)
+    args = (["--input-res", f"{w}x{h}", "-n", str(frames), "-p", "1", "--preset", "medium", "-q", str(qp), "--owf", str(owf)] + tiles + ["--wpp"]
+            + (["--input-bitdepth", "10"] if depth == 10 else []))
+    want, _ = encode(need(os.path.join(REF, f"uvg266_{depth}")), yuv, str(tmp_path / "cpu.266"), {}, args + ["--no-cpuid"])
+    got, _ = encode(need(os.path.join(REF, f"uvg266_{depth}_hip")), yuv, str(tmp_path / "hip.266"), {"UVG266_HIP_FRAME": "1"}, args)
+    assert got == want
+
+
 def test_a_configuration_the_closed_loop_does_not_cover_is_refused_loudly(tmp_path):
     """UVG266_HIP_FRAME=1 with P / B pictures: the encoder stops with the reason instead of quietly searching on the CPU."""
     w, h = 264, 136

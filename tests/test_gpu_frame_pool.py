@@ -1,0 +1,69 @@
+"""uvghip_frame_pool_* over the C ABI (api.FramePool): pictures from host memory one by one, in groups -- every picture and every WPP row
+equals what the loop plan gives for the same picture on resident buffers (api.ClosedLoop, itself held to the reference encoder's records
+in tests/test_gpu_closed_loop.py / test_gpu_slice_coder.py), whatever the grouping: a full group, a group cut short by a finish, by
+another QP, slots reused out of order.  tests/test_gpu_dropin_frame.py runs the same entry points inside the reference encoder."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def loop_plan_result(params, yuv):
+    """One picture through api.ClosedLoop -> ((y, u, v) numpy, [row bytes])."""
+    import torch
+    from uvg266_amd import api
+    cl = api.ClosedLoop(params, [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in yuv)])
+    cl.run()
+    torch.cuda.synchronize()
+    rows, nb = cl.slice_data()
+    rows, nb = rows.cpu().numpy(), nb.cpu().numpy()
+    return tuple(t.cpu().numpy() for t in cl.out[0]), [rows[0, r, :nb[0, r]].tobytes() for r in range(nb.shape[1])]
+
+
+@pytest.mark.parametrize("depth,w,h", [(8, 264, 136), (10, 200, 136)])
+def test_pictures_through_the_pool_equal_the_loop_plans(hip, depth, w, h):
+    from uvg266_amd import api
+    pics = [H.varied_picture(w, h, t, depth) for t in range(7)]
+    qps = [27, 27, 27, 32, 32, 27, 22]                          # pictures 3 and 5 and 6 arrive with other parameters: their groups are cut
+    P = [api.ctu_params(w, h, q) for q in qps]
+    want = [loop_plan_result(P[i], pics[i]) for i in range(7)]
+    pool = api.FramePool(P[0], depth, n_slots=5, group_max=3)
+    slot_of = [0, 1, 2, 3, 4, 0, 2]                             # slots 0 and 2 are reused once their pictures are finished
+
+    def check(i, got):
+        (y, u, v), rows = got
+        for a, b in zip((y, u, v), want[i][0]):
+            assert np.array_equal(a, b), f"picture {i}"
+        assert rows == want[i][1], f"picture {i}: rows"
+
+    for i in range(5):
+        pool.begin(slot_of[i], P[i], pics[i])                   # 0 1 2 fill a group (launched by the third begin); 3 4 collect
+    check(0, pool.finish(0))
+    check(2, pool.finish(2))                                    # out of order inside a launched group
+    pool.begin(slot_of[5], P[5], pics[5])                       # QP 27 behind the open QP 32 group: that group is launched, 5 opens the next
+    pool.begin(slot_of[6], P[6], pics[6])                       # QP 22: 5's group is launched, 6 alone in the open one
+    check(6, pool.finish(slot_of[6]))                           # asked for while its group still collects: launched by finish
+    check(1, pool.finish(1))
+    check(3, pool.finish(3))
+    check(4, pool.finish(4))
+    check(5, pool.finish(slot_of[5]))
+
+
+def test_the_pool_refuses_misuse(hip):
+    from uvg266_amd import api, lib
+    w, h = 136, 72
+    P = api.ctu_params(w, h, 27)
+    pic = H.varied_picture(w, h, 0, 8)
+    pool = api.FramePool(P, 8, n_slots=2, group_max=2)
+    with pytest.raises(Exception, match="no picture has been begun"):
+        pool.finish(1)
+    pool.begin(0, P, pic)
+    with pytest.raises(Exception, match="has not been finished"):
+        pool.begin(0, P, pic)
+    with pytest.raises(Exception):
+        pool.begin(1, api.ctu_params(w + 8, h, 27), pic)        # the size is the pool's for good
+    pool.finish(0)
+    with pytest.raises(Exception):
+        api.FramePool(P, 8, n_slots=1, group_max=1, sao_type=0)  # what uvghip_loop_plan_create refuses is refused at creation

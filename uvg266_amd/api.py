@@ -671,6 +671,51 @@ class CtuSearch:
                 self.L.uvghip_ctu_plan_destroy(plan)
 
 
+class FramePool:
+    """uvghip_frame_pool_*: all-intra pictures from HOST memory one by one, as uvg_encode_one_frame hands them over
+    (src/encoderstate.c:2051-2091; csrc/frame_host.hip, csrc/shim/frame-hip.c): n_slots pictures in flight, the frames that are begun
+    before one is asked for share a launch of at most group_max pictures.  begin(slot, params, (y, u, v)) with numpy planes;
+    finish(slot) -> ((y, u, v) the picture after deblocking + SAO, [bytes of WPP row 0, row 1, ...])."""
+
+    def __init__(self, params, depth, n_slots, group_max, sao_type=3, device=0, tiles=None):
+        """tiles = (columns' widths, rows' heights) in CTUs: frames under --tiles (uvghip_frame_pool_create_tiles); finish() then returns the
+        substreams of all tiles in the order of the bitstream."""
+        import ctypes
+        self.L = _lib.init(device)
+        self.depth, self.w, self.h = depth, int(params.pic_w), int(params.pic_h)
+        self.pool = ctypes.c_void_p()
+        if tiles is None:
+            _lib.check(self.L.uvghip_frame_pool_create(depth, ctypes.byref(params), sao_type, n_slots, group_max, ctypes.byref(self.pool)), "uvghip_frame_pool_create")
+        else:
+            cols, rows = (np.ascontiguousarray(a, np.int32) for a in tiles)
+            _lib.check(self.L.uvghip_frame_pool_create_tiles(depth, ctypes.byref(params), sao_type, n_slots, group_max, cols.ctypes.data_as(ctypes.c_void_p), cols.size,
+                                                             rows.ctypes.data_as(ctypes.c_void_p), rows.size, ctypes.byref(self.pool)), "uvghip_frame_pool_create_tiles")
+
+    def begin(self, slot, params, yuv):
+        import ctypes
+        dt = np.uint8 if self.depth == 8 else np.uint16
+        y, u, v = (np.ascontiguousarray(p, dtype=dt) for p in yuv)
+        _lib.check(self.L.uvghip_frame_pool_begin(self.pool, slot, ctypes.byref(params), y.ctypes.data_as(ctypes.c_void_p), u.ctypes.data_as(ctypes.c_void_p),
+                                                  v.ctypes.data_as(ctypes.c_void_p), y.shape[1], u.shape[1]), "uvghip_frame_pool_begin")
+
+    def finish(self, slot):
+        import ctypes
+        dt = np.uint8 if self.depth == 8 else np.uint16
+        y, u, v = np.empty((self.h, self.w), dt), np.empty((self.h // 2, self.w // 2), dt), np.empty((self.h // 2, self.w // 2), dt)
+        rows, row_bytes, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int(0)
+        _lib.check(self.L.uvghip_frame_pool_finish(self.pool, slot, y.ctypes.data_as(ctypes.c_void_p), u.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p),
+                                                   self.w, self.w // 2, ctypes.byref(rows), ctypes.byref(row_bytes), ctypes.byref(n)), "uvghip_frame_pool_finish")
+        nb = np.ctypeslib.as_array(ctypes.cast(row_bytes, ctypes.POINTER(ctypes.c_int32)), (n.value,)).copy()
+        data = ctypes.string_at(rows.value, int(nb.sum()))
+        at = np.concatenate([[0], np.cumsum(nb)])
+        return (y, u, v), [data[at[r]:at[r + 1]] for r in range(n.value)]
+
+    def __del__(self):
+        pool, self.pool = getattr(self, "pool", None), None
+        if pool:
+            self.L.uvghip_frame_pool_destroy(pool)
+
+
 class ClosedLoop(CtuSearch):
     """uvghip_loop_plan_*: the search of CtuSearch followed by the in-loop filters on the reference's schedule, one call per
     group of pictures.  Adds out[i] = (y, u, v), the pictures after deblocking + SAO, and after a run sao_info ([n, ctus, 2, 17]

@@ -40,6 +40,10 @@ struct slot_t {
 
 struct group_t {
   uvghip_loop_plan_t *plan = nullptr;
+  uvghip_tiles_plan_t *tplan = nullptr;                        // a pool for tiled frames: the group's launch is a tiles plan
+  std::vector<int32_t> lens;                                   // tiled: [k][n_sub] substream lengths, the bytes of the group's pictures one
+  std::vector<uint8_t> bytes;                                  //        after the other, where each picture's begin
+  std::vector<size_t> pic_off;
   void *ws = nullptr;
   hipStream_t st = nullptr;
   int32_t *host_row_bytes = nullptr;                           // pinned [group_max][hc]
@@ -66,6 +70,9 @@ struct uvghip_frame_pool {
   size_t b = 1, ysz = 0, csz = 0, psz = 0;
   std::vector<slot_t> slots;
   group_t groups[MAX_GROUPS];
+  std::vector<int32_t> col_ctus, row_ctus;                     // tiled frames: the grid in CTUs (empty: one loop plan per group)
+  int n_sub = 0;                                               // substreams of a picture = leaf states of the encoder (hc without tiles)
+  bool tiled() const { return !col_ctus.empty(); }
 };
 
 namespace {
@@ -75,6 +82,7 @@ void release(uvghip_frame_pool *p)
   for (group_t &g : p->groups) {
     if (g.st) (void)hipStreamSynchronize(g.st);
     if (g.plan) uvghip_loop_plan_destroy(g.plan);
+    if (g.tplan) uvghip_tiles_plan_destroy(g.tplan);
     if (g.st) (void)hipStreamDestroy(g.st);
     if (g.ws) (void)hipFree(g.ws);
     if (g.host_row_bytes) (void)hipHostFree(g.host_row_bytes);
@@ -105,7 +113,11 @@ void describe(const uvghip_frame_pool *p, const slot_t &s, uvghip_loop_picture_t
 int ready_group(uvghip_frame_pool *p, group_t &g)
 {
   if (g.st) return 0;
-  UVGHIP_TRY(hipMalloc(&g.ws, uvghip_loop_workspace_bytes(p->bitdepth, p->group_max, p->w, p->h)));
+  const size_t ws = p->tiled() ? uvghip_tiles_workspace_bytes_split(p->bitdepth, p->group_max, p->w, p->h, p->col_ctus.data(), (int)p->col_ctus.size(), p->row_ctus.data(),
+                                                                    (int)p->row_ctus.size(), nullptr)
+                               : uvghip_loop_workspace_bytes(p->bitdepth, p->group_max, p->w, p->h);
+  if (!ws) return uvghip_set_error(hipErrorInvalidValue, "uvghip_frame_pool: no workspace size for this picture / grid");
+  UVGHIP_TRY(hipMalloc(&g.ws, ws));
   UVGHIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g.host_row_bytes), (size_t)p->group_max * p->hc * sizeof(int32_t), hipHostMallocDefault));
   UVGHIP_TRY(hipStreamCreateWithFlags(&g.st, hipStreamNonBlocking));
   return 0;
@@ -116,23 +128,32 @@ int launch(uvghip_frame_pool *p, int gi)
 {
   group_t &g = p->groups[gi];
   const int k = (int)g.slots.size();
-  if (!g.plan || g.planned != g.slots || memcmp(&g.planned_P, &g.P, sizeof g.P)) {
+  if ((!g.plan && !g.tplan) || g.planned != g.slots || memcmp(&g.planned_P, &g.P, sizeof g.P)) {
     if (g.plan) { uvghip_loop_plan_destroy(g.plan); g.plan = nullptr; }
+    if (g.tplan) { uvghip_tiles_plan_destroy(g.tplan); g.tplan = nullptr; }
     std::vector<uvghip_loop_picture_t> pics(k);
     for (int i = 0; i < k; ++i) describe(p, p->slots[g.slots[i]], pics[i]);
-    if (int rc = uvghip_loop_plan_create(p->bitdepth, &g.P, pics.data(), k, p->sao_type, g.ws, &g.plan)) return rc;
-    int n_rows = 0;
-    if (int rc = uvghip_loop_plan_slice_data(g.plan, &g.d_rows, &g.d_row_bytes, &g.row_cap, &n_rows)) return rc;
-    if (n_rows != p->hc) return uvghip_set_error(hipErrorInvalidValue, "uvghip_frame_pool: the plan's rows are not the picture's CTU rows");
+    if (p->tiled()) {
+      if (int rc = uvghip_tiles_plan_create_split(p->bitdepth, &g.P, pics.data(), k, p->col_ctus.data(), (int)p->col_ctus.size(), p->row_ctus.data(), (int)p->row_ctus.size(),
+                                                  nullptr, p->sao_type, g.ws, &g.tplan)) return rc;
+      int n_tiles = 0, n_classes = 0, n_sub = 0;
+      if (int rc = uvghip_tiles_plan_layout(g.tplan, &n_tiles, &n_classes, &n_sub)) return rc;
+      if (n_sub != p->n_sub) return uvghip_set_error(hipErrorInvalidValue, "uvghip_frame_pool: the tiles plan's substreams are not the grid's rows");
+    } else {
+      if (int rc = uvghip_loop_plan_create(p->bitdepth, &g.P, pics.data(), k, p->sao_type, g.ws, &g.plan)) return rc;
+      int n_rows = 0;
+      if (int rc = uvghip_loop_plan_slice_data(g.plan, &g.d_rows, &g.d_row_bytes, &g.row_cap, &n_rows)) return rc;
+      if (n_rows != p->hc) return uvghip_set_error(hipErrorInvalidValue, "uvghip_frame_pool: the plan's rows are not the picture's CTU rows");
+    }
     g.planned = g.slots; g.planned_P = g.P;
   }
-  if (int rc = uvghip_loop_plan_run(g.plan, g.st)) return rc;
+  if (int rc = p->tiled() ? uvghip_tiles_plan_run(g.tplan, g.st) : uvghip_loop_plan_run(g.plan, g.st)) return rc;
   for (int i = 0; i < k; ++i) {
     slot_t &s = p->slots[g.slots[i]];
     UVGHIP_TRY(hipMemcpyAsync(s.host_out, s.out, p->psz, hipMemcpyDeviceToHost, g.st));
     s.state = LAUNCHED;
   }
-  UVGHIP_TRY(hipMemcpyAsync(g.host_row_bytes, g.d_row_bytes, (size_t)k * p->hc * sizeof(int32_t), hipMemcpyDeviceToHost, g.st));
+  if (!p->tiled()) UVGHIP_TRY(hipMemcpyAsync(g.host_row_bytes, g.d_row_bytes, (size_t)k * p->hc * sizeof(int32_t), hipMemcpyDeviceToHost, g.st));
   g.launched = true; g.waited = false; g.unfinished = k;
   if (p->open == gi) p->open = -1;
   return 0;
@@ -142,15 +163,29 @@ int launch(uvghip_frame_pool *p, int gi)
 
 extern "C" int uvghip_frame_pool_create(int bitdepth, const uvghip_ctu_params_t *params, int sao_type, int n_slots, int group_max, uvghip_frame_pool_t **out)
 {
+  return uvghip_frame_pool_create_tiles(bitdepth, params, sao_type, n_slots, group_max, nullptr, 0, nullptr, 0, out);
+}
+
+extern "C" int uvghip_frame_pool_create_tiles(int bitdepth, const uvghip_ctu_params_t *params, int sao_type, int n_slots, int group_max, const int32_t *col_ctus, int cols,
+                                              const int32_t *row_ctus, int rows, uvghip_frame_pool_t **out)
+{
   UVGHIP_REQUIRE_READY();
   UVGHIP_REQUIRE_DEPTH(bitdepth);
   if (!params || !out || params->pic_w <= 0 || params->pic_h <= 0 || (params->pic_w & 7) || (params->pic_h & 7) || n_slots < 1 || n_slots > 256 || group_max < 1)
     return uvghip_set_error(hipErrorInvalidValue, __func__);
+  const bool tiled = cols * rows > 1;
+  if (tiled && (!col_ctus || !row_ctus || cols < 1 || rows < 1)) return uvghip_set_error(hipErrorInvalidValue, __func__);
   uvghip_frame_pool *p = new (std::nothrow) uvghip_frame_pool();
   if (!p) return uvghip_set_error(hipErrorOutOfMemory, __func__);
+  if (tiled) { p->col_ctus.assign(col_ctus, col_ctus + cols); p->row_ctus.assign(row_ctus, row_ctus + rows); }
   p->bitdepth = bitdepth; p->sao_type = sao_type; p->w = params->pic_w; p->h = params->pic_h;
   p->wc = (p->w + 63) / 64; p->hc = (p->h + 63) / 64; p->group_max = group_max < n_slots ? group_max : n_slots;
   p->b = bitdepth == 8 ? 1 : 2; p->ysz = (size_t)p->w * p->h * p->b; p->csz = p->ysz / 4; p->psz = p->ysz + 2 * p->csz;
+  p->n_sub = p->hc;
+  if (tiled) {                                                  // every tile's CTU rows (the grid itself is checked by the tiles plan)
+    p->n_sub = 0;
+    for (int r = 0; r < rows; ++r) p->n_sub += row_ctus[r] * cols;
+  }
   const size_t ctus = (size_t)p->wc * p->hc, cu_bytes = (size_t)p->hc * 16 * p->wc * 16 * sizeof(uvghip_scu_t);
   hipError_t err = hipGetDevice(&p->device);
   p->slots.resize(n_slots);
@@ -168,7 +203,7 @@ extern "C" int uvghip_frame_pool_create(int bitdepth, const uvghip_ctu_params_t 
     dev(&s.models, ctus * 3 * UVGHIP_CTU_MODELS * sizeof(uint32_t), false);
     host(reinterpret_cast<void **>(&s.host_src), p->psz);
     host(reinterpret_cast<void **>(&s.host_out), p->psz);
-    host(reinterpret_cast<void **>(&s.host_row_bytes), (size_t)p->hc * sizeof(int32_t));
+    host(reinterpret_cast<void **>(&s.host_row_bytes), (size_t)p->n_sub * sizeof(int32_t));
     s.host_rows_cap = p->psz / 4 + 4096;                          // grown in finish() by the rare picture that needs more
     host(reinterpret_cast<void **>(&s.host_rows), s.host_rows_cap);
   }
@@ -180,9 +215,15 @@ extern "C" int uvghip_frame_pool_create(int bitdepth, const uvghip_ctu_params_t 
   if (!rc) {
     uvghip_loop_picture_t q;
     describe(p, p->slots[0], q);
-    uvghip_loop_plan_t *probe = nullptr;
-    rc = uvghip_loop_plan_create(bitdepth, params, &q, 1, sao_type, p->groups[0].ws, &probe);
-    if (!rc) uvghip_loop_plan_destroy(probe);
+    if (tiled) {
+      uvghip_tiles_plan_t *probe = nullptr;
+      rc = uvghip_tiles_plan_create_split(bitdepth, params, &q, 1, col_ctus, cols, row_ctus, rows, nullptr, sao_type, p->groups[0].ws, &probe);
+      if (!rc) uvghip_tiles_plan_destroy(probe);
+    } else {
+      uvghip_loop_plan_t *probe = nullptr;
+      rc = uvghip_loop_plan_create(bitdepth, params, &q, 1, sao_type, p->groups[0].ws, &probe);
+      if (!rc) uvghip_loop_plan_destroy(probe);
+    }
   }
   if (rc) { release(p); return rc; }
   *out = p;
@@ -254,13 +295,30 @@ extern "C" int uvghip_frame_pool_finish(uvghip_frame_pool_t *p, int slot, void *
   const bool wait = !g.waited;
   hipStream_t st = g.st;
   lock.unlock();                              // begin() of the next frames goes on while this one waits
-  if (wait) UVGHIP_TRY(hipStreamSynchronize(st));
+  const bool tiled = p->tiled();
+  const int n_sub = p->n_sub;
+  if (wait && !tiled) UVGHIP_TRY(hipStreamSynchronize(st));
+  if (wait && tiled) {
+    // every substream of every picture of the group in one call (it waits for the stream): lengths, bytes in the order of the bitstream
+    const int k = (int)g.slots.size();
+    g.lens.resize((size_t)k * n_sub);
+    if (g.bytes.size() < (size_t)k * p->psz) g.bytes.resize((size_t)k * p->psz);
+    std::vector<uint32_t> sums((size_t)3 * k);
+    size_t used = 0;
+    if (int rc = uvghip_tiles_plan_substreams(g.tplan, 0, k, g.lens.data(), g.bytes.data(), g.bytes.size(), &used, sums.data(), st)) return rc;
+    g.pic_off.assign((size_t)k + 1, 0);
+    for (int i = 0; i < k; ++i) {
+      size_t n = 0;
+      for (int r = 0; r < n_sub; ++r) n += (size_t)g.lens[(size_t)i * n_sub + r];
+      g.pic_off[i + 1] = g.pic_off[i] + n;
+    }
+  }
   lock.lock();
   g.waited = true;
   size_t total = 0;
-  for (int r = 0; r < p->hc; ++r) {
-    const int nb = g.host_row_bytes[(size_t)s.index * p->hc + r];
-    if (nb <= 0 || nb > g.row_cap) return uvghip_set_error(hipErrorInvalidValue, "uvghip_frame_pool_finish: a row overflowed its slot");
+  for (int r = 0; r < n_sub; ++r) {
+    const int nb = tiled ? g.lens[(size_t)s.index * n_sub + r] : g.host_row_bytes[(size_t)s.index * p->hc + r];
+    if (nb <= 0 || (!tiled && nb > g.row_cap)) return uvghip_set_error(hipErrorInvalidValue, "uvghip_frame_pool_finish: a row overflowed its slot");
     s.host_row_bytes[r] = nb;
     total += nb;
   }
@@ -271,21 +329,22 @@ extern "C" int uvghip_frame_pool_finish(uvghip_frame_pool_t *p, int slot, void *
     s.host_rows_cap = want;
   }
   size_t at = 0;
-  for (int r = 0; r < p->hc; ++r) {
+  for (int r = 0; r < p->hc && !tiled; ++r) {
     const int nb = s.host_row_bytes[r];
     UVGHIP_TRY(hipMemcpyAsync(s.host_rows + at, g.d_rows + ((size_t)s.index * p->hc + r) * g.row_cap, nb, hipMemcpyDeviceToHost, st));
     at += nb;
   }
+  if (tiled) memcpy(s.host_rows, g.bytes.data() + g.pic_off[s.index], total);
   lock.unlock();
   const size_t b = p->b;
   copy_rows(static_cast<uint8_t *>(out_y), out_stride * b, s.host_out, p->w * b, p->w * b, p->h);
   copy_rows(static_cast<uint8_t *>(out_u), out_stride_c * b, s.host_out + p->ysz, p->w / 2 * b, p->w / 2 * b, p->h / 2);
   copy_rows(static_cast<uint8_t *>(out_v), out_stride_c * b, s.host_out + p->ysz + p->csz, p->w / 2 * b, p->w / 2 * b, p->h / 2);
-  UVGHIP_TRY(hipStreamSynchronize(st));       // the rows (the group's stream carries nothing else before all its frames are finished)
+  if (!tiled) UVGHIP_TRY(hipStreamSynchronize(st));       // the rows (the group's stream carries nothing else before all its frames are finished)
   lock.lock();
   s.state = FREE; s.group = -1; s.index = -1;
   if (--g.unfinished == 0) { g.launched = false; g.slots.clear(); }
-  *rows = s.host_rows; *row_bytes = s.host_row_bytes; *n_rows = p->hc;
+  *rows = s.host_rows; *row_bytes = s.host_row_bytes; *n_rows = n_sub;
   return 0;
 }
 

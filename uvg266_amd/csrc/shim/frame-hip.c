@@ -15,7 +15,7 @@
  * the main stream, the hash SEI over frame->rec.
  *
  * UVG266_HIP_FRAME=1 asks for it.  A configuration the closed loop does not cover is an ERROR then, not a silent fall-back to
- * the CPU search (the product path fails loudly): --preset medium / slow with -p 1 and --wpp is what is covered.
+ * the CPU search (the product path fails loudly): --preset medium / slow with -p 1 and --wpp is what is covered, with or without --tiles.
  */
 #include "encoderstate.h"
 #include "encoder.h"
@@ -64,7 +64,6 @@ static const char *hip_frame_unsupported(const encoder_state_t *state)
   const uvg_config *c = &ctrl->cfg;
   if (c->intra_period != 1) return "intra period != 1 (P / B pictures go through uvghip_loop_pb_run_inflight)";
   if (!c->wpp) return "--no-wpp";
-  if (c->tiles_width_count > 1 || c->tiles_height_count > 1) return "tiles (uvghip_tiles_plan_*)";
   if (c->slices) return "slices";
   if (ctrl->chroma_format != UVG_CSP_420) return "chroma format";
   if (c->rdo > 1) return "rd >= 2";
@@ -115,7 +114,7 @@ void uvg_hip_frame_begin(encoder_state_t *state)
   const encoder_control_t *ctrl = state->encoder_control;
   encoder_state_t *rows[256];
   const int n = hip_collect_rows(state, rows, 256, 0);
-  if (n != state->tile->frame->height_in_lcu) { fprintf(stderr, "hip frame backend: %d WPP rows for %d CTU rows\n", n, state->tile->frame->height_in_lcu); abort(); }
+  if (n < state->tile->frame->height_in_lcu) { fprintf(stderr, "hip frame backend: %d WPP rows for %d CTU rows\n", n, state->tile->frame->height_in_lcu); abort(); }
 
   /* the frame-level parameters as every CTU of the frame would see them (no rate control, no ROI: checked above).  Derived on the MAIN
    * state: a tile state's frame has no source picture before encoder_state_encode makes its sub-image (src/encoderstate.c:1232-1262) */
@@ -141,7 +140,10 @@ void uvg_hip_frame_begin(encoder_state_t *state)
     const char *e = getenv("UVG266_HIP_FRAME_GROUP");
     const int group = e && atoi(e) > 0 ? atoi(e) : (n_slots + 1) / 2;
     if (uvghip_init(0) != 0) hip_frame_die("uvghip_init");
-    if (uvghip_frame_pool_create(ctrl->bitdepth, &p, (int)ctrl->cfg.sao_type, n_slots, group, &hip_pool)) hip_frame_die("uvghip_frame_pool_create");
+    /* --tiles: the grid as the encoder derived it (encoder.c:445-478), in CTUs; every tile's WPP rows are leaf states of their own */
+    const int cols = ctrl->cfg.tiles_width_count, trows = ctrl->cfg.tiles_height_count;
+    if (uvghip_frame_pool_create_tiles(ctrl->bitdepth, &p, (int)ctrl->cfg.sao_type, n_slots, group, ctrl->tiles_col_width, cols, ctrl->tiles_row_height, trows, &hip_pool))
+      hip_frame_die("uvghip_frame_pool_create_tiles");
   }
   const uvg_picture *src = state->tile->frame->source;
   if (uvghip_frame_pool_begin(hip_pool, at, &p, src->y, src->u, src->v, src->stride, src->stride / 2)) hip_frame_die("uvghip_frame_pool_begin");

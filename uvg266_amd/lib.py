@@ -272,6 +272,7 @@ SIGNATURES = {
     "uvghip_tiles_plan_nals": (c_int, [c_vp, c_int, c_int, c_int, c_vp, ctypes.c_size_t, c_vp, c_vp]),
     "uvghip_tiles_plan_destroy": (None, [c_vp]),
     "uvghip_frame_pool_create": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_vp]),
+    "uvghip_frame_pool_create_tiles": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp]),
     "uvghip_frame_pool_begin": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int]),
     "uvghip_frame_pool_finish": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     "uvghip_frame_pool_destroy": (None, [c_vp]),
