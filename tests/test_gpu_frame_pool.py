@@ -67,3 +67,39 @@ def test_the_pool_refuses_misuse(hip):
     pool.finish(0)
     with pytest.raises(Exception):
         api.FramePool(P, 8, n_slots=1, group_max=1, sao_type=0)  # what uvghip_loop_plan_create refuses is refused at creation
+
+
+def test_the_pools_pictures_and_rows_complete_the_encoders_stream(hip):
+    """Anchored on the reference encoder's own file (tests/golden/ref_stream_192x128_8_qp27_3frames.npz): the three pictures through a pool
+    of two slots; the hash of each returned picture (uvghip_picture_checksum) and its rows through uvghip_write_picture_nals, behind the
+    encoder's parameter sets = the encoder's .266."""
+    import ctypes
+    import torch
+    from uvg266_amd import api, layout, lib
+    g = H.ctu_golden("ref_stream_192x128_8_qp27_3frames")
+    w, h, depth, qp = (int(a) for a in g["meta"])
+    P = api.ctu_params(w, h, qp)
+    pool = api.FramePool(P, depth, n_slots=2, group_max=2)
+    L = lib.init(0)
+    stream = g["bitstream"].tobytes()
+    out = stream[:stream.find(b"\x00\x00\x01\x00\x41")]
+    pics = [layout.synthetic_yuv420(w, h, int(t), depth) for t in g["ts"]]
+    pool.begin(0, P, pics[0])
+    pool.begin(1, P, pics[1])
+    done = [pool.finish(0)]
+    pool.begin(0, P, pics[2])
+    done += [pool.finish(1), pool.finish(0)]
+    for poc, ((y, u, v), rows) in enumerate(done):
+        sums = api.picture_checksum(*(torch.from_numpy(p).cuda() for p in (y, u, v))).cpu().numpy().view(np.uint32)
+        sizes = np.array([len(r) for r in rows], np.int32)
+        rows_2d = np.zeros((len(rows), int(sizes.max())), np.uint8)
+        for r, b in enumerate(rows):
+            rows_2d[r, :len(b)] = np.frombuffer(b, np.uint8)
+        cap = int(sizes.sum()) + 64 + 4 * len(sizes)
+        buf = np.zeros(cap, np.uint8)
+        n = ctypes.c_size_t(0)
+        ck = np.ascontiguousarray(sums, np.uint32)
+        lib.check(L.uvghip_write_picture_nals(poc, 1, H.ptr(rows_2d), rows_2d.shape[1], H.ptr(sizes), len(sizes), H.ptr(ck), H.ptr(buf), cap, ctypes.byref(n)),
+                  "uvghip_write_picture_nals")
+        out += buf[:n.value].tobytes()
+    assert out == stream

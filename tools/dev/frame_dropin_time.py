@@ -3,7 +3,7 @@
 a 1920x1080 8-bit clip, -p 1 --preset medium (BASELINE configs[1]'s settings), once with the encoder's CPU search on all host threads
 (AVX2 strategies) and once with UVG266_HIP_FRAME=1 at several --owf (frames in flight = slots of the frame pool; groups of half of them per launch).
 Prints the CLI's wall time per run and whether the two files are the same file.  DEVELOPMENT TOOL (test infrastructure binaries).
-usage: frame_dropin_time.py [frames=64] [qp=22] [width=1920 height=1080 depth=8] [owf,owf,...]"""
+usage: frame_dropin_time.py [frames=64] [qp=22] [width=1920 height=1080 depth=8] [owf,owf,...] [extra encoder options, e.g. --tiles 6x4 --wpp]"""
 import hashlib
 import os
 import subprocess
@@ -45,10 +45,10 @@ def main():
             for t in range(frames):
                 for plane in base[t % 4]:
                     f.write(np.ascontiguousarray(plane).tobytes())
-        args = ["--input-res", f"{w}x{h}", "-n", str(frames), "-p", "1", "--preset", "medium", "-q", str(qp)] + (["--input-bitdepth", "10"] if depth == 10 else [])
+        args = ["--input-res", f"{w}x{h}", "-n", str(frames), "-p", "1", "--preset", "medium", "-q", str(qp)] + (["--input-bitdepth", "10"] if depth == 10 else []) + sys.argv[7:]
         threads = os.cpu_count()
         want, dt, fps = run(f"uvg266_{depth}", yuv, os.path.join(d, "cpu.266"), args + ["--threads", str(threads)], {})
-        print(f"{frames} pictures {w}x{h} {depth}-bit qp {qp}: the encoder's CPU search, {threads} threads, --owf auto: {dt:.2f} s wall, the CLI's own FPS {fps}")
+        print(f"{frames} pictures {w}x{h} {depth}-bit qp {qp} {' '.join(sys.argv[7:])}: the encoder's CPU search, {threads} threads, --owf auto: {dt:.2f} s wall, the CLI's own FPS {fps}")
         for owf in owfs:
             got, dt, fps = run(f"uvg266_{depth}_hip", yuv, os.path.join(d, f"hip{owf}.266"), args + ["--threads", "8", "--owf", str(owf)], {"UVG266_HIP_FRAME": "1"})
             print(f"  UVG266_HIP_FRAME=1 --owf {owf:2d}: {dt:.2f} s wall, the CLI's own FPS {fps}; the same file: {got == want}")
