@@ -65,7 +65,8 @@ void copy_rows(uint8_t *dst, size_t dst_pitch, const uint8_t *src, size_t src_pi
 }  // namespace
 
 struct uvghip_frame_pool {
-  std::mutex m;
+  std::mutex m;                                                // the slots' and groups' states
+  std::mutex fin;                                              // finish() calls one at a time (a group's download is shared by its frames); begin() goes on beside them
   int device = 0, bitdepth = 0, sao_type = 0, w = 0, h = 0, wc = 0, hc = 0, group_max = 1, open = -1;
   size_t b = 1, ysz = 0, csz = 0, psz = 0;
   std::vector<slot_t> slots;
@@ -274,6 +275,7 @@ extern "C" int uvghip_frame_pool_finish(uvghip_frame_pool_t *p, int slot, void *
     return uvghip_set_error(hipErrorInvalidValue, __func__);
   UVGHIP_TRY(hipSetDevice(p->device));        // finish() may run on another thread than begin() (the encoder's bitstream job)
   slot_t &s = p->slots[slot];
+  std::lock_guard<std::mutex> serial(p->fin);
   std::unique_lock<std::mutex> lock(p->m);
   if (s.state == FREE) return uvghip_set_error(hipErrorNotReady, "uvghip_frame_pool_finish: no picture has been begun in this slot");
   if (s.state == PENDING) {
