@@ -72,7 +72,8 @@ def test_all_intra_frames_through_the_closed_loop_write_the_encoders_own_file(tm
 
 
 @pytest.mark.parametrize("depth,w,h,frames,qp,owf,tiles", [(8, 456, 264, 5, 27, 3, ["--tiles", "3x2"]), (10, 416, 240, 3, 32, 2, ["--tiles", "2x2"]),
-                                                           (8, 456, 264, 4, 27, 1, ["--tiles-width-split", "64,320", "--tiles-height-split", "192"])])
+                                                           (8, 456, 264, 4, 27, 1, ["--tiles-width-split", "64,320", "--tiles-height-split", "192"]),
+                                                           (8, 256, 4480, 2, 32, 1, ["--tiles", "4x2"])])      # 280 WPP leaf states (2160p in 8 x 4 tiles has 272)
 def test_tiled_frames_through_the_closed_loop_write_the_encoders_own_file(tmp_path, depth, w, h, frames, qp, owf, tiles):
     """--tiles CxR --wpp (and an explicit grid): a group is one tiles plan, the substreams of all tiles go to the tiles' WPP leaf states in
     the order of the bitstream; the PPS with the grid, the slice header with all entry points and the hash SEI are the encoder's."""

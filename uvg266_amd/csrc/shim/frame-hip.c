@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#define HIP_FRAME_LEAVES 8192         /* WPP leaf states of a frame: every tile's CTU rows (2160p in 8 x 4 tiles: 272) */
 #define HIP_FRAME_SLOTS 256           /* main encoder states = frames in flight (cfg.owf + 1): the pool's slots */
 
 static struct {
@@ -112,8 +113,8 @@ static int hip_collect_rows(encoder_state_t *state, encoder_state_t **rows, int 
 void uvg_hip_frame_begin(encoder_state_t *state)
 {
   const encoder_control_t *ctrl = state->encoder_control;
-  encoder_state_t *rows[256];
-  const int n = hip_collect_rows(state, rows, 256, 0);
+  encoder_state_t *rows[HIP_FRAME_LEAVES];
+  const int n = hip_collect_rows(state, rows, HIP_FRAME_LEAVES, 0);
   if (n < state->tile->frame->height_in_lcu) { fprintf(stderr, "hip frame backend: %d WPP rows for %d CTU rows\n", n, state->tile->frame->height_in_lcu); abort(); }
 
   /* the frame-level parameters as every CTU of the frame would see them (no rate control, no ROI: checked above).  Derived on the MAIN
@@ -161,8 +162,8 @@ void uvg_hip_frame_finish(encoder_state_t *state)
   int n_rows;
   if (uvghip_frame_pool_finish(hip_pool, at, rec->y, rec->u, rec->v, rec->stride, rec->stride / 2, &bytes, &row_bytes, &n_rows))
     hip_frame_die("uvghip_frame_pool_finish");
-  encoder_state_t *rows[256];
-  const int n = hip_collect_rows(state, rows, 256, 0);
+  encoder_state_t *rows[HIP_FRAME_LEAVES];
+  const int n = hip_collect_rows(state, rows, HIP_FRAME_LEAVES, 0);
   if (n != n_rows) { fprintf(stderr, "hip frame backend: %d rows from the device for %d leaf states\n", n_rows, n); abort(); }
   for (int r = 0; r < n; ++r) {
     bitstream_t *s = &rows[r]->stream;
