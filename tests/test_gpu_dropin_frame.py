@@ -71,6 +71,18 @@ def test_all_intra_frames_through_the_closed_loop_write_the_encoders_own_file(tm
     assert both == want
 
 
+@pytest.mark.parametrize("threads,owf", [(0, None), (0, 2), (16, None)])
+def test_the_encoders_own_scheduling_choices_do_not_matter(tmp_path, threads, owf):
+    """--threads 0 (no worker threads: the bitstream job runs on the thread that waits for it) and --owf auto (the encoder derives the frames in
+    flight from its thread count): begin() and finish() on one thread or two, the same file."""
+    w, h, frames = 264, 136, 7
+    yuv = clip(tmp_path, "in.yuv", w, h, frames, 8)
+    args = ["--input-res", f"{w}x{h}", "-n", str(frames), "-p", "1", "--preset", "medium", "-q", "27"] + ([] if owf is None else ["--owf", str(owf)])
+    want, _ = encode(need(os.path.join(REF, "uvg266_8")), yuv, str(tmp_path / "cpu.266"), {}, args + ["--no-cpuid"], threads=threads)
+    got, _ = encode(need(os.path.join(REF, "uvg266_8_hip")), yuv, str(tmp_path / "hip.266"), {"UVG266_HIP_FRAME": "1"}, args, threads=threads)
+    assert got == want
+
+
 @pytest.mark.parametrize("depth,w,h,frames,qp,owf,tiles", [(8, 456, 264, 5, 27, 3, ["--tiles", "3x2"]), (10, 416, 240, 3, 32, 2, ["--tiles", "2x2"]),
                                                            (8, 456, 264, 4, 27, 1, ["--tiles-width-split", "64,320", "--tiles-height-split", "192"]),
                                                            (8, 256, 4480, 2, 32, 1, ["--tiles", "4x2"])])      # 280 WPP leaf states (2160p in 8 x 4 tiles has 272)
