@@ -17,7 +17,9 @@ slice data of the encoder's .266, byte for byte); the parameter sets and NAL fra
 `value` = pictures/s of that closed loop.  The open-loop throughput of the same block kernels (every block size of every
 picture, no decisions: the previous rounds' headline) is reported under "open_loop"; "extra_workloads" holds the 2160p 10-bit closed
 loop and BASELINE configs[2] -- low-delay P / B sequences through the closed loop with the inter search on the device
-(c3_low_delay_closed_loop, parity-checked against the reference's own 1080p run) beside the open-loop motion search kernels.  --gpus N > 1: ranks take whole pictures (no data-path collective; "weak"); the CTU-row sharded filter
+(c3_low_delay_closed_loop, parity-checked against the reference's own 1080p run) beside the open-loop motion search kernels; and
+reference_cli_frame_handover: the reference encoder's own CLI (oracle/_ref/uvg266_8_hip) on cpu_baseline's pictures with its all-intra frames
+handed to uvghip_frame_pool_* (UVG266_HIP_FRAME=1), its .266 compared with the CPU run's.  --gpus N > 1: ranks take whole pictures (no data-path collective; "weak"); the CTU-row sharded filter
 chain over RCCL (uvghip_band_plan) is timed in the same run on 2160p10alf and reported under "row_sharded_rccl".
 """
 import argparse
@@ -1076,7 +1078,7 @@ def closed_loop(wl, steps, warmup, in_flight, device, rank, world, dist, groups=
     return cls, F, elapsed, sum(m[0] for m in ms), sum(m[1] for m in ms)
 
 
-def cpu_baseline_reference(wl, frames=96, extra=()):
+def cpu_baseline_reference(wl, frames=96, extra=(), dropin=None):
     """The reference encoder itself (oracle/_ref/uvg266_8: /root/reference built by oracle/build_ref.sh with plain gcc, AVX2 strategies
     and its own thread pool) on the GPU box's host cores: `frames` synthetic pictures of the workload, -p 1 --preset medium at the
     bench's QP, threads and frame parallelism at the encoder's defaults (auto).  A WHOLE encode (search, filters, bitstream): what the
@@ -1106,6 +1108,29 @@ def cpu_baseline_reference(wl, frames=96, extra=()):
         dt = time.perf_counter() - t0
         if r.returncode != 0 or not os.path.getsize(os.path.join(tmp, "out.266")):
             return None
+        if dropin is not None:
+            # the SAME encoder with the frame-level hand-over (oracle/_ref/uvg266_*_hip, UVG266_HIP_FRAME=1: DESIGN 4.19) on the same
+            # file: its all-intra frames go through uvghip_frame_pool_* on this GPU, everything else of the encode is its own code
+            try:
+                import hashlib
+                hip = exe + "_hip"
+                if os.access(hip, os.X_OK):
+                    out2 = os.path.join(tmp, "out_hip.266")
+                    cmd2 = [hip if c == exe else out2 if c == os.path.join(tmp, "out.266") else c for c in cmd] + ["--threads", "8", "--owf", "63"]
+                    env = dict(os.environ, UVG266_HIP_FRAME="1")
+                    t1 = time.perf_counter()
+                    r2 = subprocess.run(cmd2, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240, env=env)
+                    dt2 = time.perf_counter() - t1
+                    md5 = [hashlib.md5(open(f_, "rb").read()).hexdigest() for f_ in (os.path.join(tmp, "out.266"), out2)] if r2.returncode == 0 else None
+                    dropin.update({"value": round(frames / dt2, 3) if r2.returncode == 0 else None, "unit": "frames/s", "parity_checked": bool(md5 and md5[0] == md5[1]),
+                                   "workload": f"the reference encoder's own CLI on the same {frames} pictures with its all-intra frames handed to the device (UVG266_HIP_FRAME=1 "
+                                               f"--owf 63 --threads 8: uvg_encode_one_frame -> uvghip_frame_pool_begin, its bitstream job <- uvghip_frame_pool_finish); wall time of the "
+                                               f"process {dt2:.1f} s incl. reading the input, HIP start-up and the pool's creation; parity = the .266 is byte for byte the file of the CPU "
+                                               f"run beside it (cpu_baseline)"})
+                    if r2.returncode != 0:
+                        dropin["error"] = r2.stderr.decode(errors="replace")[-300:]
+            except Exception as e:      # a side line: never in the way of the baseline
+                dropin["error"] = repr(e)
     return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "reference",
             "sample": f"{frames} synthetic {W}x{H} {depth}-bit pictures through the reference encoder's CLI (-p 1 --preset medium -q {QP}{''.join(' ' + e for e in extra)}, --threads / --owf auto "
                       f"on {cores} host threads, AVX2 strategies), wall time {dt:.1f} s incl. reading the input: a whole encode"}
@@ -1460,7 +1485,10 @@ def main():
             if row_sharded is not None:
                 out["row_sharded_rccl"] = row_sharded
             if world == 1 and not args.no_cpu_baseline and wl_name == "1080p8":
-                out["cpu_baseline"] = cpu_baseline_reference(wl) or cpu_baseline_search(wl)
+                dropin = {}
+                out["cpu_baseline"] = cpu_baseline_reference(wl, dropin=dropin) or cpu_baseline_search(wl)
+                if dropin:
+                    out.setdefault("extra_workloads", {})["reference_cli_frame_handover"] = dropin
             print(json.dumps(out), flush=True)
 
     row_sharded = None
