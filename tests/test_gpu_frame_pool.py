@@ -103,3 +103,34 @@ def test_the_pools_pictures_and_rows_complete_the_encoders_stream(hip):
                   "uvghip_write_picture_nals")
         out += buf[:n.value].tobytes()
     assert out == stream
+
+
+@pytest.mark.parametrize("depth,w,h,grid", [(8, 264, 136, ([2, 3], [1, 2])), (10, 328, 200, ([3, 3], [2, 2]))])
+def test_tiled_pictures_through_the_pool_equal_the_tiles_plans(hip, depth, w, h, grid):
+    """uvghip_frame_pool_create_tiles: a group is one tiles plan -- the pictures and ALL tiles' substreams in the order of the bitstream equal
+    what api.TiledLoop gives for the same pictures on resident buffers (itself held to the reference's --tiles files, tests/test_gpu_tiles.py);
+    three pictures through two slots, the third alone in its group."""
+    import torch
+    from uvg266_amd import api
+    P = api.ctu_params(w, h, 27)
+    pics = [H.varied_picture(w, h, t, depth) for t in (2, 1003, 5)]
+
+    want = []
+    for yuv in pics:
+        tl = api.TiledLoop(P, [tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in yuv)], grid)
+        tl.run()
+        lens, data, _ = tl.substreams()
+        at = np.concatenate([[0], np.cumsum(lens[0])])
+        torch.cuda.synchronize()
+        want.append((tuple(t.cpu().numpy() for t in tl.out[0]),
+                     [data[at[r]:at[r + 1]].tobytes() for r in range(lens.shape[1])]))
+    pool = api.FramePool(P, depth, n_slots=2, group_max=2, tiles=grid)
+    pool.begin(0, P, pics[0])
+    pool.begin(1, P, pics[1])
+    got = [pool.finish(0)]
+    pool.begin(0, P, pics[2])
+    got += [pool.finish(1), pool.finish(0)]
+    for i, ((y, u, v), rows) in enumerate(got):
+        for a, b in zip((y, u, v), want[i][0]):
+            assert np.array_equal(a, b), f"picture {i}"
+        assert rows == want[i][1], f"picture {i}: substreams"
