@@ -49,7 +49,7 @@ def main(src):
         print(f"patched {rel}")
 
 
-# the frame-level hand-over (uvg266_amd/csrc/shim/frame-hip.c).  Two statements.
+# the frame-level hand-over (uvg266_amd/csrc/shim/frame-hip.c).  Two statements + the pool's release.
 FRAME = [
     ("encoderstate.c", r"void\s+uvg_encode_one_frame\s*\(", "  encoder_state_encode(state);\n",
      "#if defined(UVG_HAVE_HIP)\n"
@@ -63,6 +63,12 @@ FRAME = [
      "  { extern void uvg_hip_frame_finish(encoder_state_t *state); uvg_hip_frame_finish((encoder_state_t *) opaque); }\n"
      "#endif\n"
      "  uvg_encoder_state_write_bitstream((encoder_state_t *) opaque);\n"),
+    # the pool goes with the encoder instance: behind the stop of the thread queue (no bitstream job is running any more)
+    ("uvg266.c", r"static\s+void\s+uvg266_close\s*\(", "    if (encoder->states) {\n",
+     "#if defined(UVG_HAVE_HIP)\n"
+     "    { extern void uvg_hip_frame_close(const encoder_control_t *ctrl); uvg_hip_frame_close(encoder->control); }\n"
+     "#endif\n"
+     "    if (encoder->states) {\n"),
 ]
 
 

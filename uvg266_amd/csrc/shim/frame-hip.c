@@ -10,7 +10,8 @@
  *   uvg_encode_one_frame (src/encoderstate.c:2051-2091): `if (uvg_hip_frame_enabled(state)) uvg_hip_frame_begin(state); else
  *     encoder_state_encode(state);` -- behind encoder_state_init_new_frame, in front of the creation of the bitstream job;
  *   uvg_encoder_state_worker_write_bitstream (src/encoder_state-bitstream.c:1609-1612): uvg_hip_frame_finish(state) in front of
- *     uvg_encoder_state_write_bitstream -- the job waits for the device where it would have waited for the rows' jobs.
+ *     uvg_encoder_state_write_bitstream -- the job waits for the device where it would have waited for the rows' jobs;
+ *   (and uvg266_close, src/uvg266.c:56: uvg_hip_frame_close(encoder->control) releases the pool with the encoder instance.)
  * Everything else of the frame is the encoder's own: parameter sets, slice header, entry points, the children's streams moved into
  * the main stream, the hash SEI over frame->rec.
  *
@@ -38,6 +39,7 @@ static struct {
   int begun;
 } hip_slots[HIP_FRAME_SLOTS];
 static uvghip_frame_pool_t *hip_pool;
+static const encoder_control_t *hip_pool_ctrl;      /* the encoder instance the pool was made for */
 static pthread_mutex_t hip_slots_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static void hip_frame_die(const char *what)
@@ -136,6 +138,10 @@ void uvg_hip_frame_begin(encoder_state_t *state)
   const int n_slots = ctrl->cfg.owf + 1;                        /* the encoder's main states (src/encoder_state-ctors_dtors.c) */
   const int at = hip_slot_of(state, 1);
   if (at < 0 || at >= n_slots) { fprintf(stderr, "hip frame backend: more main encoder states than --owf + 1 = %d\n", n_slots); abort(); }
+  if (hip_pool && hip_pool_ctrl != ctrl) {
+    fprintf(stderr, "hip frame backend: a second encoder instance in this process (one frame pool at a time: close the first encoder)\n");
+    abort();
+  }
   if (!hip_pool) {                                              /* (uvg_encode_one_frame runs on the encoder's own thread only) */
     /* frames collect in groups of half the frames in flight: two launches beside each other in the steady state (UVG266_HIP_FRAME_GROUP) */
     const char *e = getenv("UVG266_HIP_FRAME_GROUP");
@@ -146,6 +152,7 @@ void uvg_hip_frame_begin(encoder_state_t *state)
     if (uvghip_frame_pool_create_tiles(ctrl->bitdepth, &p, (int)ctrl->cfg.sao_type, n_slots, group, ctrl->tiles_col_width, cols, ctrl->tiles_row_height, trows, &hip_pool))
       hip_frame_die("uvghip_frame_pool_create_tiles");
   }
+  hip_pool_ctrl = ctrl;
   const uvg_picture *src = state->tile->frame->source;
   if (uvghip_frame_pool_begin(hip_pool, at, &p, src->y, src->u, src->v, src->stride, src->stride / 2)) hip_frame_die("uvghip_frame_pool_begin");
   hip_slots[at].begun = 1;
@@ -193,4 +200,17 @@ void uvg_hip_frame_finish(encoder_state_t *state)
     hip_append(s, bytes, row_bytes[r]);
     bytes += row_bytes[r];
   }
+}
+
+/* Called by uvg266_close (src/uvg266.c:56-93) behind the stop of the thread queue: the pool and its device memory go with the encoder
+ * instance that used them; the next instance of the process makes its own. */
+void uvg_hip_frame_close(const encoder_control_t *ctrl)
+{
+  pthread_mutex_lock(&hip_slots_lock);
+  if (!hip_pool || hip_pool_ctrl != ctrl) { pthread_mutex_unlock(&hip_slots_lock); return; }
+  uvghip_frame_pool_destroy(hip_pool);
+  hip_pool = NULL;
+  hip_pool_ctrl = NULL;
+  memset(hip_slots, 0, sizeof hip_slots);
+  pthread_mutex_unlock(&hip_slots_lock);
 }
