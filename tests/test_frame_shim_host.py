@@ -21,3 +21,18 @@ def test_rows_appended_by_the_shim_leave_the_stream_as_the_encoders_own_writer_d
                            f"-I{H.ROOT}/include", os.path.join(H.ROOT, "tools", "refcheck", "rc_frame_append.c"), f"{REF}/src/bitstream.c", "-o", exe, "-lm", "-lpthread"])
     out = subprocess.check_output([exe], text=True)
     assert out.startswith("ok 400"), out
+
+
+def test_integration_md_shows_the_statements_the_build_applies():
+    """INTEGRATION.md section 1 / 10 are what tools/refcheck/patch_ref_hip.py writes into the scratch copy of the encoder: the registration block
+    of a strategy group and the three statements of the frame-level hand-over, text for text."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("patch_ref_hip", os.path.join(H.ROOT, "tools", "refcheck", "patch_ref_hip.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    doc = open(os.path.join(H.ROOT, "INTEGRATION.md")).read()
+    for rel, _fn, old, new in mod.FRAME:
+        added = new.replace(old, "") if new.endswith(old) else new
+        for line in added.strip().splitlines():
+            assert line.strip() in doc, (rel, line)
+        assert rel in doc
