@@ -95,6 +95,34 @@ def test_no_kernel_uses_scratch():
     assert kernels >= 60
 
 
+def test_the_ctu_kernels_scratch_does_not_grow():
+    """The two whole-CTU kernels are exempt from the rule above (scratch and spills to zero is NOT done) -- but not from a ceiling:
+    their scratch bytes per lane may only go down from what the round's final build has (the judged kernel 736 / 768 B at 8 / 10 bit, its
+    persistent form for the I pictures beside a flight 896 / 1728 B, the P / B kernel 1232 / 1008 B)."""
+    import glob
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "uvg266_amd", "csrc", "_build")
+    ceilings = [(r"ctu_search_kernelIhLb0", 736), (r"ctu_search_kernelItLb0", 768), (r"ctu_search_kernelIhLb1", 896), (r"ctu_search_kernelItLb1", 1728),
+                (r"ctu_search_pb_kernelIh", 1232), (r"ctu_search_pb_kernelIt", 1008)]
+    seen = 0
+    for f in ("ctu_search.usage", "ctu_search_pb.usage"):
+        path = os.path.join(root, f)
+        assert os.path.exists(path), "build with `python __graft_entry__.py` first"
+        name = None
+        for line in open(path):
+            line = line.strip()
+            if line.startswith("Function Name:"):
+                name = line.split(":", 1)[1].strip()
+            m = re.match(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+            if m and name:
+                for pat, top in ceilings:
+                    if pat in name:
+                        assert int(m.group(1)) <= top, f"{f}: {name}: {line} (ceiling {top})"
+                        seen += 1
+    assert seen >= 12
+
+
 def test_a_waves_role_is_not_read_off_the_hardware():
     """The CTU kernels give the waves of a workgroup roles (walker, depth 3 / 2 / 1).  A role derived from HW_REG_HW_ID was measurably
     faster and wrong: with several queues busy the scheduler saves waves and restores them on other SIMDs, and the role changed under
